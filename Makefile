@@ -1,0 +1,43 @@
+# Build everything in-tree.  `make` = scene generator + oracle (CPU) + HIP library (gfx950).
+#   libbrmi.so        HIP kernels + C ABI (include/brmi.h)           -> basicrenderer_amd/lib/
+#   libbrmi_scene.so  procedural scene generator (host only)          -> basicrenderer_amd/lib/
+#   liboracle.so      scalar CPU restatement of the reference shaders -> oracle/_build/   (tests only)
+ROCM      ?= /opt/rocm
+HIPCC     ?= $(ROCM)/bin/hipcc
+CXX       ?= g++
+LIBDIR    := basicrenderer_amd/lib
+ORCDIR    := oracle/_build
+
+# Strict IEEE arithmetic everywhere: no FMA contraction, no fast-math, correctly rounded div/sqrt.
+HIPFLAGS  := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math \
+             -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero -Iinclude -Wall
+ORCFLAGS  := -O2 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -fopenmp -Iinclude -Wall
+SCNFLAGS  := -O2 -std=c++17 -fPIC -shared -Iinclude -Wall
+
+HIP_SRCS  := $(wildcard basicrenderer_amd/csrc/*.hip)
+HIP_HDRS  := $(wildcard basicrenderer_amd/csrc/*.h) $(wildcard include/*.h)
+ORC_SRCS  := $(wildcard oracle/*.cpp)
+ORC_HDRS  := $(wildcard oracle/*.h) $(wildcard include/*.h)
+
+all: scene oracle hip
+
+scene: $(LIBDIR)/libbrmi_scene.so
+oracle: $(ORCDIR)/liboracle.so
+hip: $(LIBDIR)/libbrmi.so
+
+$(LIBDIR)/libbrmi_scene.so: basicrenderer_amd/csrc/scene/scene_gen.cpp include/brmi_scene.h include/brmi_types.h
+	@mkdir -p $(LIBDIR)
+	$(CXX) $(SCNFLAGS) $< -o $@
+
+$(ORCDIR)/liboracle.so: $(ORC_SRCS) $(ORC_HDRS)
+	@mkdir -p $(ORCDIR)
+	$(CXX) $(ORCFLAGS) $(ORC_SRCS) -o $@
+
+$(LIBDIR)/libbrmi.so: $(HIP_SRCS) $(HIP_HDRS)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) $(HIP_SRCS) -o $@
+
+clean:
+	rm -rf $(LIBDIR) $(ORCDIR)
+
+.PHONY: all scene oracle hip clean

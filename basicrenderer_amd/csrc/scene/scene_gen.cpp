@@ -1,0 +1,960 @@
+// scene_gen.cpp -- procedural scenes emitted directly in BasicRenderer's GPU data contract.
+//
+// Host-only (g++), no GPU code.  Produces, for a preset + seed:
+//   * page slabs: 256 KB page tiles, each `header | meshlet descriptors | positions (float3) |
+//     oct-snorm16 normals | triangle bytes`, the section order of BuildPackedTriangleMeshPageBlob
+//     (BR/src/Mesh/ClusterLODUtilities.cpp:2079-2311);
+//   * a cluster-LOD DAG per mesh (groups, segments, group page map) plus one 8-wide BVH per DAG
+//     depth hanging off a super-root, with the leaf/internal metric semantics the culling shaders
+//     assume (BR/src/Mesh/ClusterLODUtilities.cpp:4606-4900);
+//   * per-object / per-mesh / per-instance buffers, camera + culling camera
+//     (BR/src/Scene/Scene.cpp:509-535, BR/src/Managers/ViewManager.cpp:19-77), lights
+//     (BR/src/Scene/Scene.cpp:222-262), constant-factor materials.
+//
+// The LOD DAG is our own construction (regular-grid decimation of parametric patches): level-L
+// meshlets are 8x8-quad tiles sampled at stride 2^L, a group is a 4x4 block of meshlets, and the
+// four level-(L+1) meshlets that cover a level-L group all carry refinedGroup = that group.  It
+// is not the reference's meshoptimizer build, only a generator of valid input in its format.
+#include "brmi_scene.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+struct Pcg32 {
+    uint64_t state = 0x853c49e6748fea9bULL, inc = 0xda3e39cb94b95bdbULL;
+    explicit Pcg32(uint64_t seed, uint64_t seq = 1) {
+        state = 0; inc = (seq << 1u) | 1u; next(); state += seed; next();
+    }
+    uint32_t next() {
+        uint64_t old = state;
+        state = old * 6364136223846793005ULL + inc;
+        uint32_t xorshifted = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+        uint32_t rot = (uint32_t)(old >> 59u);
+        return (xorshifted >> rot) | (xorshifted << ((32u - rot) & 31u));
+    }
+    float uniform() { return (float)(next() >> 8) * (1.0f / 16777216.0f); }          // [0,1)
+    float range(float a, float b) { return a + (b - a) * uniform(); }
+    uint32_t below(uint32_t n) { return n ? next() % n : 0u; }
+};
+
+struct V3 { double x, y, z; };
+inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 operator*(V3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
+inline double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline double length(V3 a) { return std::sqrt(dot(a, a)); }
+inline V3 normalize(V3 a) { double l = length(a); return l > 0 ? a * (1.0 / l) : V3{0, 1, 0}; }
+
+struct Sphere { V3 c; double r; };
+Sphere enclose(const std::vector<Sphere>& s) {
+    if (s.empty()) return {{0, 0, 0}, 0};
+    V3 c{0, 0, 0};
+    for (auto& a : s) c = c + a.c;
+    c = c * (1.0 / (double)s.size());
+    double r = 0;
+    for (auto& a : s) r = std::max(r, length(a.c - c) + a.r);
+    return {c, r * (1.0 + 1e-5)};
+}
+
+struct M4 { double m[4][4]; };
+M4 identity() { M4 r{}; for (int i = 0; i < 4; i++) r.m[i][i] = 1; return r; }
+M4 mul(const M4& a, const M4& b) {
+    M4 r{};
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { double s = 0; for (int k = 0; k < 4; k++) s += a.m[i][k] * b.m[k][j]; r.m[i][j] = s; }
+    return r;
+}
+M4 inverse(const M4& a) {   // Gauss-Jordan in double
+    double aug[4][8];
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { aug[i][j] = a.m[i][j]; aug[i][j + 4] = (i == j) ? 1.0 : 0.0; }
+    for (int col = 0; col < 4; col++) {
+        int piv = col;
+        for (int r = col + 1; r < 4; r++) if (std::fabs(aug[r][col]) > std::fabs(aug[piv][col])) piv = r;
+        if (piv != col) for (int j = 0; j < 8; j++) std::swap(aug[piv][j], aug[col][j]);
+        double d = aug[col][col];
+        for (int j = 0; j < 8; j++) aug[col][j] /= d;
+        for (int r = 0; r < 4; r++) if (r != col) { double f = aug[r][col]; for (int j = 0; j < 8; j++) aug[r][j] -= f * aug[col][j]; }
+    }
+    M4 r{};
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) r.m[i][j] = aug[i][j + 4];
+    return r;
+}
+M4 transpose(const M4& a) { M4 r{}; for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) r.m[i][j] = a.m[j][i]; return r; }
+void store(float dst[4][4], const M4& a) { for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) dst[i][j] = (float)a.m[i][j]; }
+// row-vector convention: p' = p * M ; translation in row 3
+M4 translation(V3 t) { M4 r = identity(); r.m[3][0] = t.x; r.m[3][1] = t.y; r.m[3][2] = t.z; return r; }
+M4 scaling(double s) { M4 r = identity(); r.m[0][0] = r.m[1][1] = r.m[2][2] = s; return r; }
+M4 rotationY(double a) { M4 r = identity(); double c = std::cos(a), s = std::sin(a); r.m[0][0] = c; r.m[0][2] = -s; r.m[2][0] = s; r.m[2][2] = c; return r; }
+M4 rotationX(double a) { M4 r = identity(); double c = std::cos(a), s = std::sin(a); r.m[1][1] = c; r.m[1][2] = s; r.m[2][1] = -s; r.m[2][2] = c; return r; }
+M4 rotationZ(double a) { M4 r = identity(); double c = std::cos(a), s = std::sin(a); r.m[0][0] = c; r.m[0][1] = s; r.m[1][0] = -s; r.m[1][1] = c; return r; }
+V3 xformPoint(V3 p, const M4& m) {
+    return {p.x * m.m[0][0] + p.y * m.m[1][0] + p.z * m.m[2][0] + m.m[3][0],
+            p.x * m.m[0][1] + p.y * m.m[1][1] + p.z * m.m[2][1] + m.m[3][1],
+            p.x * m.m[0][2] + p.y * m.m[1][2] + p.z * m.m[2][2] + m.m[3][2]};
+}
+
+// smooth value noise -------------------------------------------------------------------------
+inline uint32_t hash3(int x, int y, uint32_t s) {
+    uint32_t h = (uint32_t)x * 0x8da6b343u ^ (uint32_t)y * 0xd8163841u ^ s * 0xcb1ab31fu;
+    h ^= h >> 13; h *= 0x5bd1e995u; h ^= h >> 15; h *= 0x27d4eb2du; h ^= h >> 13;
+    return h;
+}
+inline double lattice(int x, int y, uint32_t s) { return (double)(hash3(x, y, s) >> 8) * (2.0 / 16777216.0) - 1.0; }
+double valueNoise(double x, double y, uint32_t s) {
+    double fx = std::floor(x), fy = std::floor(y);
+    int ix = (int)fx, iy = (int)fy;
+    double tx = x - fx, ty = y - fy;
+    tx = tx * tx * (3 - 2 * tx); ty = ty * ty * (3 - 2 * ty);
+    double a = lattice(ix, iy, s), b = lattice(ix + 1, iy, s), c = lattice(ix, iy + 1, s), d = lattice(ix + 1, iy + 1, s);
+    return (a + (b - a) * tx) + ((c + (d - c) * tx) - (a + (b - a) * tx)) * ty;
+}
+double fbm(double x, double y, uint32_t s) {
+    return 0.6 * valueNoise(x, y, s) + 0.3 * valueNoise(2.03 * x, 2.03 * y, s + 17) + 0.1 * valueNoise(4.1 * x, 4.1 * y, s + 31);
+}
+
+// ---------------------------------------------------------------------------------------------
+enum PatchType { PATCH_PLANE = 0, PATCH_CYLINDER = 1, PATCH_ELLIPSOID = 2 };
+struct PatchDef {
+    int type = PATCH_PLANE;
+    V3 origin{0, 0, 0}, axisU{1, 0, 0}, axisV{0, 0, 1};   // plane: origin + u*U + v*V ; normal = U x V
+    V3 center{0, 0, 0}; double radiusX = 1, radiusY = 1, radiusZ = 1, height = 1;   // cylinder / ellipsoid
+    uint32_t nu0 = 1, nv0 = 1;          // meshlets per dimension at LOD 0
+    double noiseAmp = 0, noiseFreq = 4; uint32_t noiseSeed = 0;
+};
+
+V3 evalPatch(const PatchDef& p, double u, double v) {
+    double n = p.noiseAmp != 0 ? p.noiseAmp * fbm(u * p.noiseFreq, v * p.noiseFreq, p.noiseSeed) : 0.0;
+    if (p.type == PATCH_PLANE) {
+        V3 nrm = normalize(cross(p.axisU, p.axisV));
+        return p.origin + p.axisU * u + p.axisV * v + nrm * n;
+    } else if (p.type == PATCH_CYLINDER) {
+        // u sweeps the angle so that (dP/du x dP/dv) points outward with v along +Y
+        double th = -2.0 * M_PI * u;
+        double r = 1.0 + n;
+        return {p.center.x + p.radiusX * r * std::cos(th), p.center.y + p.height * v, p.center.z + p.radiusZ * r * std::sin(th)};
+    } else {
+        double th = -2.0 * M_PI * u;
+        double ph = M_PI * (0.04 + 0.92 * v) - 0.5 * M_PI;   // latitude, poles trimmed
+        double r = 1.0 + n;
+        return {p.center.x + p.radiusX * r * std::cos(ph) * std::cos(th), p.center.y + p.radiusY * r * std::sin(ph),
+                p.center.z + p.radiusZ * r * std::cos(ph) * std::sin(th)};
+    }
+}
+
+struct MeshDef {
+    std::vector<PatchDef> patches;
+    uint32_t lodLevels = 1;      // DAG depth count (1 = flat)
+    uint32_t material = 0;
+    bool skinned = false;
+};
+struct InstanceDef { uint32_t mesh; M4 model; bool reverseWinding = false; uint32_t skinSlot = 0xFFFFFFFFu; };
+
+uint32_t octEncode(V3 n) {
+    n = normalize(n);
+    double s = std::fabs(n.x) + std::fabs(n.y) + std::fabs(n.z);
+    double ox = n.x / s, oy = n.y / s;
+    if (n.z < 0) {
+        double tx = (1.0 - std::fabs(oy)) * (ox >= 0 ? 1.0 : -1.0);
+        double ty = (1.0 - std::fabs(ox)) * (oy >= 0 ? 1.0 : -1.0);
+        ox = tx; oy = ty;
+    }
+    int qx = (int)std::lround(std::max(-1.0, std::min(1.0, ox)) * 32767.0);
+    int qy = (int)std::lround(std::max(-1.0, std::min(1.0, oy)) * 32767.0);
+    return ((uint32_t)(uint16_t)(int16_t)qx) | (((uint32_t)(uint16_t)(int16_t)qy) << 16);
+}
+
+// per-meshlet build record
+struct MeshletBuild {
+    uint32_t level, patch, mi, mj;
+    int32_t  refinedGroup;        // mesh-local, -1 terminal
+    std::vector<float> pos;       // 81*3
+    std::vector<uint32_t> nrm;    // 81
+    std::vector<uint32_t> joints; // 81*8 (skinned only)
+    std::vector<float> weights;   // 81*8
+    Sphere bounds;
+};
+struct GroupBuild {
+    uint32_t level, patch, gi, gj;
+    std::vector<uint32_t> meshlets;    // indices into mesh meshlet list
+    Sphere bounds; double error = 0, maxParentError = FLT_MAX; int32_t parent = -1;
+    uint32_t firstSegment = 0, segmentCount = 0;
+};
+struct SegmentBuild { uint32_t group; int32_t refinedGroup; std::vector<uint32_t> meshlets; uint32_t pageIndex = 0, firstMeshletInPage = 0; Sphere cull; };
+
+}  // namespace
+
+struct brmi_scene {
+    brmi_scene_params params{};
+    std::vector<std::vector<uint8_t>> slabs;       // index 0 unused
+    std::vector<brmi_per_object> perObject;
+    std::vector<float> normalMatrices;             // 16 floats each
+    std::vector<brmi_per_mesh> perMesh;
+    std::vector<brmi_per_mesh_instance> perMeshInstance;
+    std::vector<brmi_mesh_instance_clod_offsets> clodOffsets;
+    std::vector<brmi_clod_mesh_metadata> meshMetadata;
+    std::vector<brmi_lod_node> nodes;
+    std::vector<brmi_lod_group> groups;
+    std::vector<brmi_lod_segment> segments;
+    std::vector<brmi_group_page_map_entry> pageMap;
+    std::vector<brmi_material_info> materials;
+    std::vector<brmi_openpbr_material_info> openpbr;
+    std::vector<brmi_light_info> lights;
+    std::vector<uint32_t> activeLights;
+    std::vector<brmi_camera> cameras;
+    std::vector<brmi_culling_camera> cullingCameras;
+    std::vector<brmi_view_raster_info> viewRasterInfo;
+    std::vector<brmi_per_frame> perFrame;
+    std::vector<uint32_t> activeDraws;
+    std::vector<float> skinningMatrices;
+    brmi_scene_stats stats{};
+    // page tile allocator
+    uint32_t curSlab = 0; uint32_t curSlabPages = 0;
+    static constexpr uint32_t kPagesPerSlab = 1024;   // 10-bit page index in the packed cluster
+};
+
+namespace {
+
+brmi_group_page_map_entry allocPage(brmi_scene& sc, const std::vector<uint8_t>& blob) {
+    if (sc.slabs.empty()) sc.slabs.emplace_back();   // slot 0 = "not resident"
+    if (sc.curSlab == 0 || sc.curSlabPages == brmi_scene::kPagesPerSlab) {
+        sc.slabs.emplace_back();
+        sc.curSlab = (uint32_t)sc.slabs.size() - 1;
+        sc.curSlabPages = 0;
+    }
+    auto& slab = sc.slabs[sc.curSlab];
+    uint32_t off = sc.curSlabPages * BRMI_PAGE_SIZE;
+    slab.resize((size_t)off + BRMI_PAGE_SIZE, 0);
+    std::memcpy(slab.data() + off, blob.data(), blob.size());
+    sc.curSlabPages++;
+    sc.stats.pages++;
+    return {sc.curSlab, off};
+}
+
+inline size_t align4(size_t v) { return (v + 3u) & ~size_t(3); }
+
+// Serialise meshlets [list] as one page blob (section order of BuildPackedTriangleMeshPageBlob).
+std::vector<uint8_t> buildPageBlob(const std::vector<const MeshletBuild*>& ms, bool skinned) {
+    const uint32_t M = (uint32_t)ms.size();
+    uint32_t totalVerts = 0, totalTris = 0;
+    for (auto* m : ms) { totalVerts += (uint32_t)m->nrm.size(); totalTris += 128; }
+    brmi_page_header h{};
+    h.meshletCount = M;
+    h.compressedPositionQuantExp = BRMI_POSITION_FORMAT_FLOAT3;
+    h.attributeMask = BRMI_PAGE_ATTRIBUTE_NORMAL | (skinned ? (BRMI_PAGE_ATTRIBUTE_JOINTS | BRMI_PAGE_ATTRIBUTE_WEIGHTS) : 0u);
+    h.uvSetCount = 0;
+    h.descriptorOffset = (uint32_t)align4(sizeof(brmi_page_header));
+    size_t cur = h.descriptorOffset + (size_t)M * sizeof(brmi_meshlet_descriptor);
+    h.uvDescriptorOffset = 0;
+    h.positionBitstreamOffset = (uint32_t)align4(cur);
+    cur = h.positionBitstreamOffset + (size_t)totalVerts * 12;
+    h.normalArrayOffset = (uint32_t)align4(cur);
+    cur = h.normalArrayOffset + (size_t)totalVerts * 4;
+    h.colorArrayOffset = 0;
+    if (skinned) {
+        h.jointArrayOffset = (uint32_t)align4(cur); cur = h.jointArrayOffset + (size_t)totalVerts * 32;
+        h.weightArrayOffset = (uint32_t)align4(cur); cur = h.weightArrayOffset + (size_t)totalVerts * 32;
+    }
+    h.uvBitstreamDirectoryOffset = 0;
+    h.boneIndexStreamOffset = (uint32_t)align4(cur);
+    size_t boneWords = 0;
+    if (skinned) boneWords = (size_t)M * 4;   // every skinned meshlet lists 4 bones
+    cur = h.boneIndexStreamOffset + boneWords * 4;
+    h.triangleStreamOffset = (uint32_t)align4(cur);
+    cur = h.triangleStreamOffset + (size_t)totalTris * 3;
+    std::vector<uint8_t> blob(align4(cur), 0);
+    std::memcpy(blob.data(), &h, sizeof(h));
+
+    uint32_t posCursor = 0, attrCursor = 0, triCursor = 0, boneCursor = 0;
+    for (uint32_t i = 0; i < M; i++) {
+        const MeshletBuild& m = *ms[i];
+        const uint32_t V = (uint32_t)m.nrm.size();
+        brmi_meshlet_descriptor d{};
+        d.positionBitOffset = posCursor;
+        d.vertexAttributeOffset = attrCursor;
+        d.triangleByteOffset = triCursor;
+        d.boneListOffset = boneCursor;
+        d.bitsAndVertexCount = V << 24;
+        d.triangleCountAndRefinedGroup = 128u | ((uint32_t)(m.refinedGroup + 1) << 16);
+        d.boneCount = skinned ? 4u : 0u;
+        d.bounds[0] = (float)m.bounds.c.x; d.bounds[1] = (float)m.bounds.c.y; d.bounds[2] = (float)m.bounds.c.z; d.bounds[3] = (float)m.bounds.r;
+        std::memcpy(blob.data() + h.descriptorOffset + (size_t)i * sizeof(d), &d, sizeof(d));
+        std::memcpy(blob.data() + h.positionBitstreamOffset + posCursor, m.pos.data(), (size_t)V * 12);
+        std::memcpy(blob.data() + h.normalArrayOffset + (size_t)attrCursor * 4, m.nrm.data(), (size_t)V * 4);
+        if (skinned) {
+            std::memcpy(blob.data() + h.jointArrayOffset + (size_t)attrCursor * 32, m.joints.data(), (size_t)V * 32);
+            std::memcpy(blob.data() + h.weightArrayOffset + (size_t)attrCursor * 32, m.weights.data(), (size_t)V * 32);
+            uint32_t bones[4] = {0, 1, 2, 3};
+            std::memcpy(blob.data() + h.boneIndexStreamOffset + (size_t)boneCursor * 4, bones, 16);
+            boneCursor += 4;
+        }
+        // 8x8 quads over a 9x9 vertex grid, two CCW triangles per quad (front = +normal side)
+        uint8_t* tri = blob.data() + h.triangleStreamOffset + triCursor;
+        for (uint32_t qj = 0; qj < 8; qj++) for (uint32_t qi = 0; qi < 8; qi++) {
+            uint8_t a = (uint8_t)(qj * 9 + qi), b = (uint8_t)(a + 1), c = (uint8_t)(a + 10), dd = (uint8_t)(a + 9);
+            // alternate the diagonal so neighbouring quads do not all share one direction
+            if (((qi + qj) & 1u) == 0) { *tri++ = a; *tri++ = b; *tri++ = c; *tri++ = a; *tri++ = c; *tri++ = dd; }
+            else                        { *tri++ = a; *tri++ = b; *tri++ = dd; *tri++ = b; *tri++ = c; *tri++ = dd; }
+        }
+        posCursor += V * 12; attrCursor += V; triCursor += 128 * 3;
+    }
+    return blob;
+}
+
+size_t meshletPageBytes(bool skinned) { return 64 + 81 * 12 + 81 * 4 + 384 + (skinned ? 81 * 64 + 16 : 0); }
+
+// Build one mesh: fills scene-global arrays, returns mesh metadata index.
+void buildMesh(brmi_scene& sc, const MeshDef& def, uint32_t meshIndex) {
+    const uint32_t levels = std::max(1u, std::min(def.lodLevels, 7u));
+    std::vector<MeshletBuild> meshlets;
+    std::vector<GroupBuild> groups;
+    // (level, patch) -> first group id and group-grid dims
+    struct LevelPatch { uint32_t firstGroup, gw, gh, firstMeshlet, mw, mh; };
+    std::vector<std::vector<LevelPatch>> lp(levels, std::vector<LevelPatch>(def.patches.size()));
+
+    for (uint32_t L = 0; L < levels; L++) {
+        for (size_t pi = 0; pi < def.patches.size(); pi++) {
+            const PatchDef& p = def.patches[pi];
+            const uint32_t mw = std::max(1u, p.nu0 >> L), mh = std::max(1u, p.nv0 >> L);
+            const uint32_t gw = (mw + 3) / 4, gh = (mh + 3) / 4;
+            const uint32_t NU = p.nu0 * 8, NV = p.nv0 * 8;       // LOD0 quads per dim
+            const uint32_t su = NU / (mw * 8), sv = NV / (mh * 8); // vertex stride in LOD0 grid units
+            lp[L][pi] = {(uint32_t)groups.size(), gw, gh, (uint32_t)meshlets.size(), mw, mh};
+            for (uint32_t gj = 0; gj < gh; gj++) for (uint32_t gi = 0; gi < gw; gi++) {
+                GroupBuild g{}; g.level = L; g.patch = (uint32_t)pi; g.gi = gi; g.gj = gj; groups.push_back(g);
+            }
+            for (uint32_t mj = 0; mj < mh; mj++) for (uint32_t mi = 0; mi < mw; mi++) {
+                MeshletBuild m{};
+                m.level = L; m.patch = (uint32_t)pi; m.mi = mi; m.mj = mj;
+                m.refinedGroup = -1;
+                if (L > 0) {
+                    const LevelPatch& prev = lp[L - 1][pi];
+                    uint32_t ci = std::min(2 * mi, prev.mw - 1) / 4, cj = std::min(2 * mj, prev.mh - 1) / 4;
+                    m.refinedGroup = (int32_t)(prev.firstGroup + cj * prev.gw + ci);
+                }
+                m.pos.resize(81 * 3); m.nrm.resize(81);
+                V3 lo{1e30, 1e30, 1e30}, hi{-1e30, -1e30, -1e30};
+                for (uint32_t lj = 0; lj < 9; lj++) for (uint32_t li = 0; li < 9; li++) {
+                    double u = (double)((mi * 8 + li) * su) / NU, v = (double)((mj * 8 + lj) * sv) / NV;
+                    V3 P = evalPatch(p, u, v);
+                    const double hu = 0.25 / NU, hv = 0.25 / NV;
+                    V3 du = evalPatch(p, u + hu, v) - evalPatch(p, u - hu, v);
+                    V3 dv = evalPatch(p, u, v + hv) - evalPatch(p, u, v - hv);
+                    V3 n = cross(du, dv);
+                    uint32_t k = lj * 9 + li;
+                    m.pos[k * 3 + 0] = (float)P.x; m.pos[k * 3 + 1] = (float)P.y; m.pos[k * 3 + 2] = (float)P.z;
+                    m.nrm[k] = octEncode(n);
+                    lo = {std::min(lo.x, P.x), std::min(lo.y, P.y), std::min(lo.z, P.z)};
+                    hi = {std::max(hi.x, P.x), std::max(hi.y, P.y), std::max(hi.z, P.z)};
+                }
+                V3 c = (lo + hi) * 0.5; double r = 0;
+                for (uint32_t k = 0; k < 81; k++) r = std::max(r, length(V3{m.pos[k * 3], m.pos[k * 3 + 1], m.pos[k * 3 + 2]} - c));
+                m.bounds = {c, r * (1.0 + 1e-5) + 1e-7};
+                if (def.skinned) {
+                    m.joints.assign(81 * 8, 0); m.weights.assign(81 * 8, 0.0f);
+                    for (uint32_t k = 0; k < 81; k++) {
+                        // 4 influences, weights from the vertex height; bones 0..3 (bounded by the skeleton size)
+                        float t = std::min(1.0f, std::max(0.0f, (m.pos[k * 3 + 1] - (float)lo.y) / (float)std::max(1e-6, hi.y - lo.y)));
+                        float w[4] = {(1 - t) * (1 - t), 2 * t * (1 - t) * 0.5f, 2 * t * (1 - t) * 0.5f, t * t};
+                        for (int q = 0; q < 4; q++) { m.joints[k * 8 + q] = (uint32_t)q; m.weights[k * 8 + q] = w[q]; }
+                    }
+                }
+                uint32_t gid = lp[L][pi].firstGroup + (mj / 4) * gw + (mi / 4);
+                groups[gid].meshlets.push_back((uint32_t)meshlets.size());
+                meshlets.push_back(std::move(m));
+            }
+        }
+    }
+    // group bounds (nested) and errors (monotone)
+    for (uint32_t L = 0; L < levels; L++) {
+        for (size_t pi = 0; pi < def.patches.size(); pi++) {
+            const LevelPatch& cur = lp[L][pi];
+            const PatchDef& p = def.patches[pi];
+            for (uint32_t gj = 0; gj < cur.gh; gj++) for (uint32_t gi = 0; gi < cur.gw; gi++) {
+                GroupBuild& g = groups[cur.firstGroup + gj * cur.gw + gi];
+                std::vector<Sphere> parts;
+                double childErr = 0;
+                if (L == 0) {
+                    for (uint32_t mi : g.meshlets) parts.push_back(meshlets[mi].bounds);
+                } else {
+                    // children = level L-1 groups referenced by this group's meshlets
+                    std::vector<int32_t> kids;
+                    for (uint32_t mi : g.meshlets) kids.push_back(meshlets[mi].refinedGroup);
+                    std::sort(kids.begin(), kids.end()); kids.erase(std::unique(kids.begin(), kids.end()), kids.end());
+                    for (int32_t k : kids) { parts.push_back(groups[k].bounds); childErr = std::max(childErr, groups[k].error); groups[k].parent = (int32_t)(&g - groups.data()); }
+                    for (uint32_t mi : g.meshlets) parts.push_back(meshlets[mi].bounds);
+                }
+                g.bounds = enclose(parts);
+                // own representation error: deviation of dropped level-(L-1) vertices from level-L edges
+                double dev = 0;
+                if (L > 0) {
+                    const uint32_t NU = p.nu0 * 8, NV = p.nv0 * 8;
+                    const uint32_t su = NU / (cur.mw * 8), sv = NV / (cur.mh * 8);
+                    for (uint32_t mi : g.meshlets) {
+                        const MeshletBuild& m = meshlets[mi];
+                        for (uint32_t lj = 0; lj < 8; lj++) for (uint32_t li = 0; li < 8; li++) {
+                            // midpoint of the quad vs. true surface
+                            double u = ((m.mi * 8 + li) * su + 0.5 * su) / NU, v = ((m.mj * 8 + lj) * sv + 0.5 * sv) / NV;
+                            V3 P = evalPatch(p, u, v);
+                            auto at = [&](uint32_t a, uint32_t b) { uint32_t k = b * 9 + a; return V3{m.pos[k * 3], m.pos[k * 3 + 1], m.pos[k * 3 + 2]}; };
+                            V3 Q = (at(li, lj) + at(li + 1, lj) + at(li, lj + 1) + at(li + 1, lj + 1)) * 0.25;
+                            dev = std::max(dev, length(P - Q));
+                        }
+                    }
+                }
+                g.error = (L == 0) ? 0.0 : std::max(childErr * 1.0001 + 1e-9, childErr + dev);
+            }
+        }
+    }
+    for (auto& g : groups) g.maxParentError = (g.parent >= 0) ? groups[g.parent].error : (double)FLT_MAX;
+
+    // segments: partition each group's meshlets by refinedGroup (stable)
+    std::vector<SegmentBuild> segs;
+    for (size_t gi = 0; gi < groups.size(); gi++) {
+        GroupBuild& g = groups[gi];
+        g.firstSegment = (uint32_t)segs.size();
+        std::vector<int32_t> keys;
+        for (uint32_t mi : g.meshlets) if (std::find(keys.begin(), keys.end(), meshlets[mi].refinedGroup) == keys.end()) keys.push_back(meshlets[mi].refinedGroup);
+        for (int32_t k : keys) {
+            SegmentBuild s{}; s.group = (uint32_t)gi; s.refinedGroup = k;
+            std::vector<Sphere> parts;
+            for (uint32_t mi : g.meshlets) if (meshlets[mi].refinedGroup == k) { s.meshlets.push_back(mi); parts.push_back(meshlets[mi].bounds); }
+            s.cull = enclose(parts);
+            segs.push_back(std::move(s));
+        }
+        g.segmentCount = (uint32_t)segs.size() - g.firstSegment;
+    }
+
+    // pages: pack segments sequentially
+    const uint32_t pageMapBase = (uint32_t)sc.pageMap.size();
+    {
+        std::vector<const MeshletBuild*> cur;
+        std::vector<size_t> curSegs;
+        size_t bytes = 64;
+        auto flush = [&]() {
+            if (cur.empty()) return;
+            auto blob = buildPageBlob(cur, def.skinned);
+            sc.pageMap.push_back(allocPage(sc, blob));
+            cur.clear(); curSegs.clear(); bytes = 64;
+        };
+        for (size_t si = 0; si < segs.size(); si++) {
+            size_t need = segs[si].meshlets.size() * meshletPageBytes(def.skinned) + 64;
+            if (bytes + need > BRMI_PAGE_SIZE) flush();
+            segs[si].pageIndex = (uint32_t)(sc.pageMap.size() - pageMapBase);
+            segs[si].firstMeshletInPage = (uint32_t)cur.size();
+            for (uint32_t mi : segs[si].meshlets) cur.push_back(&meshlets[mi]);
+            bytes += need;
+        }
+        flush();
+    }
+
+    // emit groups / segments
+    const uint32_t groupsBase = (uint32_t)sc.groups.size(), segmentsBase = (uint32_t)sc.segments.size();
+    uint32_t runningMeshlet = 0;
+    for (auto& g : groups) {
+        brmi_lod_group o{};
+        o.centerAndRadius[0] = (float)g.bounds.c.x; o.centerAndRadius[1] = (float)g.bounds.c.y; o.centerAndRadius[2] = (float)g.bounds.c.z; o.centerAndRadius[3] = (float)g.bounds.r;
+        o.error = (float)g.error;
+        o.firstMeshlet = runningMeshlet; o.meshletCount = (uint32_t)g.meshlets.size(); runningMeshlet += o.meshletCount;
+        o.depth = (int32_t)g.level;
+        o.firstSegment = g.firstSegment; o.segmentCount = g.segmentCount;
+        o.terminalSegmentCount = (g.level == 0) ? g.segmentCount : 0;
+        o.flags = 0; o.pageMapBase = 0; o.pageCount = 0;
+        o.parentGroupId = g.parent;
+        o.maxParentError = g.maxParentError >= (double)FLT_MAX ? FLT_MAX : (float)g.maxParentError;
+        o.representationError = (float)g.error;
+        sc.groups.push_back(o);
+    }
+    for (auto& s : segs) sc.segments.push_back({s.refinedGroup, s.firstMeshletInPage, (uint32_t)s.meshlets.size(), s.pageIndex});
+
+    // BVH: node 0 super-root, nodes 1..levels depth roots, then per-depth subtrees
+    struct BNode { brmi_lod_node n; std::vector<uint32_t> kids; Sphere cull, lod; double err; };
+    std::vector<BNode> bn(1 + levels);
+    uint32_t maxTreeDepth = 1;
+    auto setMetric = [](BNode& b) {
+        b.n.cullCenterAndRadius[0] = (float)b.cull.c.x; b.n.cullCenterAndRadius[1] = (float)b.cull.c.y; b.n.cullCenterAndRadius[2] = (float)b.cull.c.z; b.n.cullCenterAndRadius[3] = (float)b.cull.r;
+        b.n.lodCenterAndRadius[0] = (float)b.lod.c.x; b.n.lodCenterAndRadius[1] = (float)b.lod.c.y; b.n.lodCenterAndRadius[2] = (float)b.lod.c.z; b.n.lodCenterAndRadius[3] = (float)b.lod.r;
+        b.n.maxQuadricError = b.err >= (double)FLT_MAX ? FLT_MAX : (float)b.err;
+    };
+    for (uint32_t L = 0; L < levels; L++) {
+        // leaves of this depth
+        std::vector<BNode> level;
+        for (size_t si = 0; si < segs.size(); si++) {
+            const GroupBuild& g = groups[segs[si].group];
+            if (g.level != L) continue;
+            BNode b{}; b.n.isLeaf = BRMI_NODE_SEGMENT_LEAF; b.n.indexOrOffset = (uint32_t)si;
+            b.n.countMinusOne = (uint32_t)(segs[si].refinedGroup + 1); b.n.ownerGroupId = segs[si].group;
+            std::vector<Sphere> both{segs[si].cull};
+            b.cull = enclose(both); b.lod = g.bounds; b.err = g.maxParentError;
+            level.push_back(std::move(b));
+        }
+        // spatial order: Morton code of the cull centre inside the depth's bbox
+        V3 lo{1e30, 1e30, 1e30}, hi{-1e30, -1e30, -1e30};
+        for (auto& b : level) { lo = {std::min(lo.x, b.cull.c.x), std::min(lo.y, b.cull.c.y), std::min(lo.z, b.cull.c.z)}; hi = {std::max(hi.x, b.cull.c.x), std::max(hi.y, b.cull.c.y), std::max(hi.z, b.cull.c.z)}; }
+        auto morton = [&](const BNode& b) {
+            auto q = [](double v, double a, double c) { double t = c > a ? (v - a) / (c - a) : 0.0; return (uint32_t)std::min(1023.0, std::max(0.0, t * 1023.0)); };
+            auto spread = [](uint32_t v) { v &= 0x3FF; v = (v | (v << 16)) & 0x30000FF; v = (v | (v << 8)) & 0x300F00F; v = (v | (v << 4)) & 0x30C30C3; v = (v | (v << 2)) & 0x9249249; return v; };
+            return spread(q(b.cull.c.x, lo.x, hi.x)) | (spread(q(b.cull.c.y, lo.y, hi.y)) << 1) | (spread(q(b.cull.c.z, lo.z, hi.z)) << 2);
+        };
+        std::stable_sort(level.begin(), level.end(), [&](const BNode& a, const BNode& b) { return morton(a) < morton(b); });
+        // bottom-up: collapse 8 at a time; keep every tier so we can lay children out contiguously
+        std::vector<std::vector<BNode>> tiers; tiers.push_back(std::move(level));
+        while (tiers.back().size() > 1) {
+            auto& below = tiers.back();
+            std::vector<BNode> up;
+            for (size_t i = 0; i < below.size(); i += 8) {
+                BNode b{}; b.n.isLeaf = BRMI_NODE_INTERNAL;
+                std::vector<Sphere> cs, ls; double e = 0;
+                for (size_t k = i; k < std::min(below.size(), i + 8); k++) { b.kids.push_back((uint32_t)k); cs.push_back(below[k].cull); ls.push_back(below[k].lod); e = std::max(e, below[k].err); }
+                b.cull = enclose(cs); b.lod = enclose(ls); b.err = e;
+                up.push_back(std::move(b));
+            }
+            tiers.push_back(std::move(up));
+        }
+        maxTreeDepth = std::max(maxTreeDepth, (uint32_t)tiers.size() + 1);
+        // lay out top-down; tier T-1 is the depth root -> global slot 1+L
+        std::vector<std::vector<uint32_t>> slot(tiers.size());
+        for (size_t t = 0; t < tiers.size(); t++) slot[t].assign(tiers[t].size(), 0);
+        slot[tiers.size() - 1][0] = 1 + L;
+        for (size_t t = tiers.size(); t-- > 0;) {
+            for (size_t i = 0; i < tiers[t].size(); i++) {
+                BNode& b = tiers[t][i];
+                if (b.n.isLeaf == BRMI_NODE_INTERNAL) {
+                    uint32_t first = (uint32_t)bn.size();
+                    for (size_t k = 0; k < b.kids.size(); k++) { slot[t - 1][b.kids[k]] = first + (uint32_t)k; bn.emplace_back(); }
+                    b.n.indexOrOffset = first; b.n.countMinusOne = (uint32_t)b.kids.size() - 1; b.n.ownerGroupId = 0;
+                }
+                setMetric(b);
+                bn[slot[t][i]] = b;
+            }
+        }
+    }
+    {   // super-root
+        BNode& r = bn[0]; r.n.isLeaf = BRMI_NODE_INTERNAL; r.n.indexOrOffset = 1; r.n.countMinusOne = levels - 1;
+        std::vector<Sphere> cs, ls; for (uint32_t L = 0; L < levels; L++) { cs.push_back(bn[1 + L].cull); ls.push_back(bn[1 + L].lod); }
+        r.cull = enclose(cs); r.lod = enclose(ls); r.err = (double)FLT_MAX; setMetric(r);
+    }
+    const uint32_t nodesBase = (uint32_t)sc.nodes.size();
+    for (auto& b : bn) sc.nodes.push_back(b.n);
+
+    brmi_clod_mesh_metadata md{};
+    md.groupsBase = groupsBase; md.segmentsBase = segmentsBase; md.lodNodesBase = nodesBase; md.rootNode = 0;
+    md.pageMapBase = pageMapBase; md.lodLevelCount = levels; md.maxDepth = maxTreeDepth;
+    sc.meshMetadata.push_back(md);
+
+    brmi_per_mesh pm{};
+    pm.materialDataIndex = def.material; pm.rasterBucketIndex = 0;
+    pm.vertexFlags = (1u << 1) | (def.skinned ? BRMI_VERTEX_SKINNED : 0u);
+    pm.vertexByteSize = 24;
+    pm.boundingSphere[0] = bn[0].n.cullCenterAndRadius[0]; pm.boundingSphere[1] = bn[0].n.cullCenterAndRadius[1];
+    pm.boundingSphere[2] = bn[0].n.cullCenterAndRadius[2]; pm.boundingSphere[3] = bn[0].n.cullCenterAndRadius[3];
+    uint32_t lod0 = 0; for (auto& m : meshlets) lod0 += (m.level == 0);
+    pm.clodNumMeshlets = (uint32_t)meshlets.size(); pm.numMeshlets = lod0; pm.numVertices = lod0 * 81;
+    sc.perMesh.push_back(pm);
+
+    sc.stats.meshletsTotal += (uint32_t)meshlets.size(); sc.stats.meshletsLod0 += lod0;
+    sc.stats.uniqueTriangles += (uint64_t)lod0 * 128;
+    sc.stats.maxBvhDepth = std::max(sc.stats.maxBvhDepth, maxTreeDepth);
+    sc.stats.lodLevelsMax = std::max(sc.stats.lodLevelsMax, levels);
+    (void)meshIndex;
+}
+
+void addInstance(brmi_scene& sc, const InstanceDef& inst) {
+    brmi_per_object o{};
+    store(o.model, inst.model); store(o.prevModel, inst.model); store(o.modelInverse, inverse(inst.model));
+    o.normalMatrixBufferIndex = (uint32_t)sc.perObject.size();
+    o.objectFlags = inst.reverseWinding ? BRMI_OBJECT_FLAG_REVERSE_WINDING : 0u;
+    M4 nm = transpose(inverse(inst.model));
+    nm.m[0][3] = nm.m[1][3] = nm.m[2][3] = 0; nm.m[3][0] = nm.m[3][1] = nm.m[3][2] = 0; nm.m[3][3] = 1;
+    float nmf[4][4]; store(nmf, nm);
+    sc.normalMatrices.insert(sc.normalMatrices.end(), &nmf[0][0], &nmf[0][0] + 16);
+    brmi_per_mesh_instance mi{};
+    mi.perMeshBufferIndex = inst.mesh; mi.perObjectBufferIndex = (uint32_t)sc.perObject.size();
+    mi.skinningInstanceSlot = inst.skinSlot; mi.skinnedBoundsScale = 1.0f;
+    std::memcpy(mi.boundingSphere, sc.perMesh[inst.mesh].boundingSphere, 16);
+    sc.activeDraws.push_back((uint32_t)sc.perMeshInstance.size());
+    sc.perMeshInstance.push_back(mi);
+    sc.clodOffsets.push_back({inst.mesh});
+    sc.perObject.push_back(o);
+    sc.stats.instancedTriangles += (uint64_t)sc.perMesh[inst.mesh].numMeshlets * 128;
+    // scene bounds
+    const float* bs = sc.perMesh[inst.mesh].boundingSphere;
+    V3 c = xformPoint({bs[0], bs[1], bs[2]}, inst.model);
+    double sx = std::sqrt(inst.model.m[0][0] * inst.model.m[0][0] + inst.model.m[0][1] * inst.model.m[0][1] + inst.model.m[0][2] * inst.model.m[0][2]);
+    double r = bs[3] * sx;
+    for (int k = 0; k < 3; k++) {
+        double cv = k == 0 ? c.x : (k == 1 ? c.y : c.z);
+        sc.stats.sceneMin[k] = std::min(sc.stats.sceneMin[k], (float)(cv - r));
+        sc.stats.sceneMax[k] = std::max(sc.stats.sceneMax[k], (float)(cv + r));
+    }
+}
+
+void addMaterials(brmi_scene& sc, Pcg32& rng, uint32_t count) {
+    for (uint32_t i = 0; i < count; i++) {
+        brmi_material_info m{};
+        std::memset(&m, 0, sizeof(m));
+        m.materialFlags = 0;
+        bool metal = (i % 5) == 3;
+        bool emissive = (i % 11) == 7;
+        m.metallicFactor = metal ? 1.0f : 0.0f;
+        m.roughnessFactor = rng.range(0.25f, 0.9f);
+        m.ambientStrength = 1.0f; m.specularStrength = 1.0f; m.textureScale = 1.0f; m.alphaCutoff = 0.5f;
+        m.baseColorFactor[0] = rng.range(0.15f, 0.95f); m.baseColorFactor[1] = rng.range(0.15f, 0.95f); m.baseColorFactor[2] = rng.range(0.15f, 0.95f); m.baseColorFactor[3] = 1.0f;
+        if (emissive) { m.emissiveFactor[0] = rng.range(0.0f, 2.0f); m.emissiveFactor[1] = rng.range(0.0f, 2.0f); m.emissiveFactor[2] = rng.range(0.0f, 2.0f); }
+        m.emissiveFactor[3] = 1.0f;
+        m.compileFlagsID = 0; m.rasterBucketIndex = 0; m.openPBRMaterialDataIndex = i;
+        sc.materials.push_back(m);
+        brmi_openpbr_material_info o{};
+        std::memset(&o, 0, sizeof(o));
+        o.baseWeight = 1.0f; o.baseColor[0] = m.baseColorFactor[0]; o.baseColor[1] = m.baseColorFactor[1]; o.baseColor[2] = m.baseColorFactor[2];
+        o.baseDiffuseRoughness = (i % 3 == 0) ? rng.range(0.0f, 0.6f) : 0.0f;
+        o.baseMetalness = m.metallicFactor;
+        o.specularWeight = 1.0f; o.specularColor[0] = o.specularColor[1] = o.specularColor[2] = 1.0f;
+        o.specularRoughness = m.roughnessFactor; o.specularIor = 1.5f; o.specularAnisotropyRotationCosSin[0] = 1.0f;
+        o.coatWeight = 0.0f; o.coatColor[0] = o.coatColor[1] = o.coatColor[2] = 1.0f; o.coatRoughness = 0.0f; o.coatIor = 1.6f; o.coatDarkening = 1.0f;
+        o.coatAnisotropyRotationCosSin[0] = 1.0f;
+        o.fuzzWeight = 0.0f; o.fuzzColor[0] = o.fuzzColor[1] = o.fuzzColor[2] = 1.0f; o.fuzzRoughness = 0.5f;
+        o.transmissionColor[0] = o.transmissionColor[1] = o.transmissionColor[2] = 1.0f;
+        o.thinFilmIor = 1.4f; o.emissionLuminance = 0.0f; o.geometryOpacity = 1.0f;
+        sc.openpbr.push_back(o);
+    }
+}
+
+// BR/src/Utilities/MathUtils.cpp:36-69
+float calculateLightRadius(float intensity, float constant, float linear, float quadratic, float threshold = 0.3f) {
+    float a = quadratic, b = linear;
+    float c = constant - (intensity / threshold);
+    float d = 0.0f;
+    if (std::fabs(a) > 1e-6f) {
+        float disc = (float)(b * b - 4.0 * a * c);
+        d = disc < 0.0f ? 0.0f : (-b + std::sqrt(disc)) / (2.0f * a);
+    } else if (std::fabs(b) > 1e-6f) d = -c / b;
+    return d;
+}
+
+// BR/src/Scene/Scene.cpp:219-262
+void addLight(brmi_scene& sc, uint32_t type, V3 pos, V3 color, float intensity, V3 att, V3 dir) {
+    brmi_light_info l{};
+    std::memset(&l, 0, sizeof(l));
+    V3 an = normalize(att);
+    float maxRange = calculateLightRadius(intensity, (float)an.x, (float)an.y, (float)an.z);
+    l.type = type;
+    l.posWorldSpace[0] = (float)pos.x; l.posWorldSpace[1] = (float)pos.y; l.posWorldSpace[2] = (float)pos.z; l.posWorldSpace[3] = 0.0f;
+    V3 cn = normalize(color);
+    l.color[0] = (float)cn.x; l.color[1] = (float)cn.y; l.color[2] = (float)cn.z; l.color[3] = intensity;
+    l.attenuation[0] = (float)an.x; l.attenuation[1] = (float)an.y; l.attenuation[2] = (float)an.z; l.attenuation[3] = 0.0f;
+    V3 dn = (type == BRMI_LIGHT_POINT) ? V3{0, 0, 0} : normalize(dir);
+    l.dirWorldSpace[0] = (float)dn.x; l.dirWorldSpace[1] = (float)dn.y; l.dirWorldSpace[2] = (float)dn.z;
+    l.innerConeAngle = 1.0f; l.outerConeAngle = 1.0f;   // cos(0)
+    l.shadowViewInfoIndex = -1; l.nearPlane = 0.01f; l.farPlane = maxRange;
+    l.shadowMapIndex = -1; l.shadowSamplerIndex = -1; l.shadowCaster = 0;
+    l.maxRange = maxRange;
+    if (type == BRMI_LIGHT_POINT) { l.boundingSphere[0] = (float)pos.x; l.boundingSphere[1] = (float)pos.y; l.boundingSphere[2] = (float)pos.z; l.boundingSphere[3] = maxRange; }
+    sc.activeLights.push_back((uint32_t)sc.lights.size());
+    sc.lights.push_back(l);
+}
+
+// BR/src/Scene/Scene.cpp:509-535 (SetCamera) + ViewManager.cpp:19-77 (culling camera)
+void setCamera(brmi_scene& sc, V3 eye, double yaw, double pitch, double fovDeg, double zNear, double zFar) {
+    const uint32_t W = sc.params.width, H = sc.params.height;
+    const double fov = fovDeg * (M_PI / 180.0), aspect = (double)W / (double)H;
+    // camera world transform (row-vector): rotate then translate ; view = inverse
+    M4 world = mul(mul(rotationX(pitch), rotationY(yaw)), translation(eye));
+    M4 view = inverse(world);
+    // XMMatrixPerspectiveFovRH(fov, aspect, NearZ = zFar, FarZ = zNear): reversed Z
+    M4 proj{};
+    const double h = std::cos(0.5 * fov) / std::sin(0.5 * fov), w = h / aspect;
+    const double nearZ = zFar, farZ = zNear, fRange = farZ / (nearZ - farZ);
+    proj.m[0][0] = w; proj.m[1][1] = h; proj.m[2][2] = fRange; proj.m[2][3] = -1.0; proj.m[3][2] = fRange * nearZ;
+    brmi_camera c{};
+    std::memset(&c, 0, sizeof(c));
+    c.positionWorldSpace[0] = (float)eye.x; c.positionWorldSpace[1] = (float)eye.y; c.positionWorldSpace[2] = (float)eye.z; c.positionWorldSpace[3] = 1.0f;
+    store(c.view, view); store(c.viewInverse, world); store(c.projection, proj); store(c.projectionInverse, inverse(proj));
+    store(c.viewProjection, mul(view, proj)); store(c.prevView, view); store(c.prevJitteredProjection, proj);
+    store(c.prevUnjitteredProjection, proj); store(c.unjitteredProjection, proj);
+    // BR/src/Utilities/Utilities.cpp:1840-1868: near, far, left, right, bottom, top (view space, normalised)
+    const double t = std::tan(fov / 2.0);
+    double pl[6][4] = {{0, 0, -1, -zNear}, {0, 0, 1, zFar}, {1, 0, -t * aspect, 0}, {-1, 0, -t * aspect, 0}, {0, 1, -t, 0}, {0, -1, -t, 0}};
+    for (int i = 0; i < 6; i++) {
+        double len = std::sqrt(pl[i][0] * pl[i][0] + pl[i][1] * pl[i][1] + pl[i][2] * pl[i][2]);
+        for (int k = 0; k < 4; k++) c.clippingPlanes[i][k] = (float)(pl[i][k] / len);
+    }
+    c.fov = (float)fov; c.aspectRatio = (float)aspect; c.zNear = (float)zNear; c.zFar = (float)zFar;
+    c.depthBufferArrayIndex = -1; c.depthResX = W; c.depthResY = H;
+    uint32_t mips = 1; { uint32_t m = std::max(W, H); while (m > 1) { m >>= 1; mips++; } }
+    c.numDepthMips = mips; c.isOrtho = 0;
+    auto nextPow2 = [](uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; };
+    c.UVScaleToNextPowerOf2[0] = (float)W / (float)nextPow2(W); c.UVScaleToNextPowerOf2[1] = (float)H / (float)nextPow2(H);
+    sc.cameras.push_back(c);
+
+    brmi_culling_camera cc{};
+    std::memset(&cc, 0, sizeof(cc));
+    std::memcpy(cc.positionWorldSpace, c.positionWorldSpace, 16);
+    cc.projX = c.projection[0][0]; cc.projY = c.projection[1][1]; cc.zNear = c.zNear;
+    { float denom = (cc.projY * 0.5f) * (float)H; cc.errorOverDistanceThreshold = denom <= 0.0f ? FLT_MAX : 1.0f / denom; }
+    cc.isOrtho = 0;
+    for (int k = 0; k < 3; k++) { cc.viewRightWorld[k] = c.viewInverse[0][k]; cc.viewUpWorld[k] = c.viewInverse[1][k]; cc.viewForwardWorld[k] = -c.viewInverse[2][k]; }
+    std::memcpy(cc.viewProjection, c.viewProjection, 64);
+    for (int k = 0; k < 4; k++) cc.viewZ[k] = c.view[k][2];
+    std::memcpy(cc.viewInverse, c.viewInverse, 64); std::memcpy(cc.projectionInverse, c.projectionInverse, 64);
+    sc.cullingCameras.push_back(cc);
+
+    brmi_view_raster_info ri{};
+    ri.scissorMinX = 0; ri.scissorMinY = 0; ri.scissorMaxX = W; ri.scissorMaxY = H; ri.viewportScaleX = 1.0f; ri.viewportScaleY = 1.0f;
+    sc.viewRasterInfo.push_back(ri);
+}
+
+void finishFrame(brmi_scene& sc) {
+    brmi_per_frame f{};
+    std::memset(&f, 0, sizeof(f));
+    f.mainCameraIndex = 0; f.numLights = (uint32_t)sc.lights.size();
+    f.screenResX = sc.params.width; f.screenResY = sc.params.height;
+    f.lightClusterGridSizeX = 12; f.lightClusterGridSizeY = 12; f.lightClusterGridSizeZ = 24;   // BR/src/Renderer.cpp lightClusterSize
+    f.nearClusterCount = 4; f.clusterZSplitDepth = 6.0f;                                            // BR/src/Managers/Singletons/ResourceManager.cpp:73-74
+    sc.perFrame.push_back(f);
+    sc.stats.meshes = (uint32_t)sc.perMesh.size(); sc.stats.instances = (uint32_t)sc.perMeshInstance.size();
+    sc.stats.nodes = (uint32_t)sc.nodes.size(); sc.stats.groups = (uint32_t)sc.groups.size(); sc.stats.segments = (uint32_t)sc.segments.size();
+    sc.stats.lights = (uint32_t)sc.lights.size(); sc.stats.materials = (uint32_t)sc.materials.size();
+}
+
+PatchDef planePatch(V3 origin, V3 U, V3 V, uint32_t nu, uint32_t nv, double amp, double freq, uint32_t seed) {
+    PatchDef p; p.type = PATCH_PLANE; p.origin = origin; p.axisU = U; p.axisV = V; p.nu0 = nu; p.nv0 = nv; p.noiseAmp = amp; p.noiseFreq = freq; p.noiseSeed = seed; return p;
+}
+PatchDef cylinderPatch(V3 base, double r, double h, uint32_t nu, uint32_t nv, double amp, double freq, uint32_t seed) {
+    PatchDef p; p.type = PATCH_CYLINDER; p.center = base; p.radiusX = r; p.radiusZ = r; p.height = h; p.nu0 = nu; p.nv0 = nv; p.noiseAmp = amp; p.noiseFreq = freq; p.noiseSeed = seed; return p;
+}
+PatchDef ellipsoidPatch(V3 c, double rx, double ry, double rz, uint32_t nu, uint32_t nv, double amp, double freq, uint32_t seed) {
+    PatchDef p; p.type = PATCH_ELLIPSOID; p.center = c; p.radiusX = rx; p.radiusY = ry; p.radiusZ = rz; p.nu0 = nu; p.nv0 = nv; p.noiseAmp = amp; p.noiseFreq = freq; p.noiseSeed = seed; return p;
+}
+// closed box as 6 inward- or outward-facing plane patches
+void boxPatches(std::vector<PatchDef>& out, V3 lo, V3 hi, uint32_t n, double amp, uint32_t seed) {
+    V3 d = hi - lo;
+    out.push_back(planePatch({lo.x, hi.y, lo.z}, {0, 0, d.z}, {d.x, 0, 0}, n, n, amp, 3, seed + 0));          // top   (+Y)
+    out.push_back(planePatch({lo.x, lo.y, lo.z}, {d.x, 0, 0}, {0, 0, d.z}, n, n, amp, 3, seed + 1));          // bottom(-Y)
+    out.push_back(planePatch({lo.x, lo.y, hi.z}, {d.x, 0, 0}, {0, d.y, 0}, n, n, amp, 3, seed + 2));          // +Z
+    out.push_back(planePatch({hi.x, lo.y, lo.z}, {-d.x, 0, 0}, {0, d.y, 0}, n, n, amp, 3, seed + 3));         // -Z
+    out.push_back(planePatch({hi.x, lo.y, hi.z}, {0, 0, -d.z}, {0, d.y, 0}, n, n, amp, 3, seed + 4));         // +X
+    out.push_back(planePatch({lo.x, lo.y, lo.z}, {0, 0, d.z}, {0, d.y, 0}, n, n, amp, 3, seed + 5));          // -X
+}
+
+uint32_t roundPow2Mult(uint32_t v, uint32_t levels) { uint32_t q = 1u << (levels - 1); return std::max(q, (v + q - 1) / q * q); }
+
+// ---- presets ---------------------------------------------------------------------------------
+void presetTiny(brmi_scene& sc, Pcg32& rng) {
+    addMaterials(sc, rng, 4);
+    const uint32_t levels = sc.params.lodLevels ? sc.params.lodLevels : 1;
+    std::vector<MeshDef> meshes(3);
+    meshes[0].patches.push_back(planePatch({-2, 0, -2}, {0, 0, 4}, {4, 0, 0}, roundPow2Mult(2, levels), roundPow2Mult(2, levels), 0.15, 3, 11)); meshes[0].material = 0; meshes[0].lodLevels = levels;
+    meshes[1].patches.push_back(ellipsoidPatch({0, 0, 0}, 0.5, 0.5, 0.5, roundPow2Mult(2, levels), roundPow2Mult(1, levels), 0.05, 3, 12)); meshes[1].material = 1; meshes[1].lodLevels = levels;
+    meshes[2].patches.push_back(cylinderPatch({0, 0, 0}, 0.25, 1.5, roundPow2Mult(1, levels), roundPow2Mult(2, levels), 0.0, 3, 13)); meshes[2].material = 3; meshes[2].lodLevels = levels;
+    for (size_t i = 0; i < meshes.size(); i++) buildMesh(sc, meshes[i], (uint32_t)i);
+    addInstance(sc, {0, identity()});
+    addInstance(sc, {1, translation({0.3, 0.6, -0.4})});
+    addInstance(sc, {1, mul(scaling(0.6), translation({-1.0, 0.5, 0.5}))});
+    addInstance(sc, {2, translation({1.0, 0.0, -1.0})});
+    addInstance(sc, {2, mul(rotationZ(0.3), translation({-0.8, 0.0, -1.2}))});
+    addInstance(sc, {1, translation({0.0, 0.5, 30.0})});   // behind the camera: frustum-culled
+    setCamera(sc, {0.2, 1.2, 3.0}, 0.08, -0.28, 80.0, 0.1, 1000.0);
+    if (sc.params.withDirectionalLight) addLight(sc, BRMI_LIGHT_DIRECTIONAL, {0, 0, 0}, {1, 1, 1}, 10.0f, {1, 0, 0}, {0, -6, -1});
+    for (uint32_t i = 0; i < sc.params.numPointLights; i++)
+        addLight(sc, BRMI_LIGHT_POINT, {rng.range(-2, 2), rng.range(0.2f, 1.5f), rng.range(-2, 2)}, {rng.uniform(), rng.uniform(), rng.uniform()}, 3.0f, {0, 0, 1}, {0, 0, 0});
+}
+
+void presetSponza(brmi_scene& sc, Pcg32& rng) {
+    // atrium 40 (z) x 14 (x) x 10 (y); ~2048 LOD0 meshlets at sizeScale 1
+    addMaterials(sc, rng, 25);
+    const uint32_t levels = sc.params.lodLevels ? sc.params.lodLevels : 1;
+    const double s = std::sqrt(std::max(0.001f, sc.params.sizeScale));
+    auto dim = [&](double v) { return roundPow2Mult((uint32_t)std::max(1.0, std::round(v * s)), levels); };
+    std::vector<MeshDef> meshes;
+    auto addMesh = [&](std::vector<PatchDef> p, uint32_t mat) { MeshDef m; m.patches = std::move(p); m.material = mat; m.lodLevels = levels; meshes.push_back(std::move(m)); return (uint32_t)meshes.size() - 1; };
+    // floor faces +Y : U = +z, V = +x  => U x V = z x x = +y
+    uint32_t floor = addMesh({planePatch({-7, 0, -20}, {0, 0, 40}, {14, 0, 0}, dim(32), dim(16), 0.03, 24, 101)}, 0);
+    // ceiling faces -Y : U = +x, V = +z => x x z = -y
+    uint32_t ceil_ = addMesh({planePatch({-7, 10, -20}, {14, 0, 0}, {0, 0, 40}, dim(16), dim(16), 0.10, 10, 102)}, 1);
+    // left wall (x=-7) faces +X : U=+y? need U x V = +x : y x z = +x
+    uint32_t wallL = addMesh({planePatch({-7, 0, -20}, {0, 10, 0}, {0, 0, 40}, dim(8), dim(32), 0.08, 16, 103)}, 2);
+    // right wall (x=+7) faces -X : z x y = -x
+    uint32_t wallR = addMesh({planePatch({7, 0, -20}, {0, 0, 40}, {0, 10, 0}, dim(32), dim(8), 0.08, 16, 104)}, 4);
+    // far wall (z=-20) faces +Z : x x y = +z
+    uint32_t wallF = addMesh({planePatch({-7, 0, -20}, {14, 0, 0}, {0, 10, 0}, dim(8), dim(8), 0.12, 8, 105)}, 5);
+    // near wall (z=+20) faces -Z : y x x = -z
+    uint32_t wallN = addMesh({planePatch({-7, 0, 20}, {0, 10, 0}, {14, 0, 0}, dim(8), dim(8), 0.12, 8, 106)}, 6);
+    uint32_t column = addMesh({cylinderPatch({0, 0, 0}, 0.45, 8.0, dim(4), dim(8), 0.04, 6, 107)}, 8);
+    std::vector<PatchDef> bp; boxPatches(bp, {-0.5, 0, -0.5}, {0.5, 1, 0.5}, dim(1), 0.01, 300);
+    uint32_t box = addMesh(bp, 9);
+    uint32_t blob = addMesh({ellipsoidPatch({0, 0, 0}, 0.6, 0.6, 0.6, dim(4), dim(2), 0.08, 3, 108)}, 12);
+    for (size_t i = 0; i < meshes.size(); i++) buildMesh(sc, meshes[i], (uint32_t)i);
+    addInstance(sc, {floor, identity()}); addInstance(sc, {ceil_, identity()}); addInstance(sc, {wallL, identity()});
+    addInstance(sc, {wallR, identity()}); addInstance(sc, {wallF, identity()}); addInstance(sc, {wallN, identity()});
+    for (int i = 0; i < 8; i++) { double z = -17.5 + 5.0 * i; addInstance(sc, {column, translation({-4.5, 0, z})}); addInstance(sc, {column, translation({4.5, 0, z})}); }
+    for (int i = 0; i < 10; i++) {
+        double sc1 = rng.range(0.6f, 1.6f);
+        addInstance(sc, {box, mul(mul(scaling(sc1), rotationY(rng.range(0, 6.28f))), translation({rng.range(-3.5f, 3.5f), 0, rng.range(-18, 12)}))});
+    }
+    for (int i = 0; i < 6; i++) addInstance(sc, {blob, mul(scaling(rng.range(0.7f, 1.5f)), translation({rng.range(-3, 3), rng.range(1.0f, 5.0f), rng.range(-16, 8)}))});
+    setCamera(sc, {0.6, 1.7, 16.0}, 0.10, -0.04, 80.0, 0.1, 1000.0);
+    if (sc.params.withDirectionalLight) addLight(sc, BRMI_LIGHT_DIRECTIONAL, {0, 0, 0}, {1, 1, 1}, 10.0f, {1, 0, 0}, {0, -6, -1});
+    for (uint32_t i = 0; i < sc.params.numPointLights; i++)
+        addLight(sc, BRMI_LIGHT_POINT, {rng.range(-6.5f, 6.5f), rng.range(0.3f, 9.5f), rng.range(-19.5f, 19.5f)}, {rng.uniform(), rng.uniform(), rng.uniform()}, 3.0f, {0, 0, 1}, {0, 0, 0});
+}
+
+void presetStreet(brmi_scene& sc, Pcg32& rng, double triBudget, uint32_t nMeshes, uint32_t nInstances, uint32_t defaultLevels, bool foliage) {
+    addMaterials(sc, rng, 64);
+    const uint32_t maxLevels = sc.params.lodLevels ? sc.params.lodLevels : defaultLevels;
+    const double budgetMeshlets = triBudget * sc.params.sizeScale / 128.0;
+    std::vector<MeshDef> meshes;
+    auto lv = [&](uint32_t n0) { uint32_t l = 1; while (l < maxLevels && (n0 >> l) >= 1 && ((n0 >> l) << l) == n0) l++; return l; };
+    // big statics: ground + two facades (~13 % of the budget at sizeScale 1)
+    const double L = 120.0, Wd = 16.0, Hh = 24.0;
+    const double dimScale = std::sqrt(budgetMeshlets / 23437.5);
+    uint32_t gq = roundPow2Mult((uint32_t)std::max(1.0, std::round(16.0 * dimScale)), maxLevels);
+    { MeshDef m; m.patches.push_back(planePatch({-Wd, 0, -L}, {0, 0, 2 * L}, {2 * Wd, 0, 0}, gq * 4, gq, 0.05, 40, 201)); m.material = 0; m.lodLevels = lv(gq); meshes.push_back(m); }
+    uint32_t fq = gq;
+    { MeshDef m; m.patches.push_back(planePatch({-Wd, 0, -L}, {0, Hh, 0}, {0, 0, 2 * L}, fq, fq * 4, 0.35, 30, 202)); m.material = 1; m.lodLevels = lv(fq); meshes.push_back(m); }
+    { MeshDef m; m.patches.push_back(planePatch({Wd, 0, -L}, {0, 0, 2 * L}, {0, Hh, 0}, fq * 4, fq, 0.35, 30, 203)); m.material = 2; m.lodLevels = lv(fq); meshes.push_back(m); }
+    const uint32_t nStatics = (uint32_t)meshes.size();
+    // props: sizes drawn from a skewed distribution
+    const uint32_t nProps = std::max(1u, nMeshes - nStatics);
+    std::vector<uint32_t> propMeshlets(nProps);
+    for (uint32_t i = 0; i < nProps; i++) {
+        float u = rng.uniform();
+        uint32_t a = (u < 0.55f) ? 1u : (u < 0.85f ? 2u : (u < 0.97f ? 4u : 8u));   // meshlets per dim (nv); nu = 2a
+        if (foliage && (i % 3) == 0) a = 1;
+        if (maxLevels == 1) a = std::min(a, 4u);
+        MeshDef m;
+        uint32_t kind = foliage && (i % 3) == 0 ? 3u : (i % 3);
+        uint32_t seed = 400 + i;
+        if (kind == 0) m.patches.push_back(ellipsoidPatch({0, 0, 0}, rng.range(0.4f, 1.2f), rng.range(0.4f, 1.6f), rng.range(0.4f, 1.2f), 2 * a, a, rng.range(0.02f, 0.2f), 3, seed));
+        else if (kind == 1) m.patches.push_back(cylinderPatch({0, 0, 0}, rng.range(0.15f, 0.6f), rng.range(1.0f, 6.0f), a, 2 * a, rng.range(0.0f, 0.1f), 5, seed));
+        else if (kind == 2) { boxPatches(m.patches, {-0.7, 0, -0.5}, {0.7, rng.range(0.5f, 2.5f), 0.5}, std::max(1u, a / 2), 0.02, seed); }
+        else { // foliage card: two crossed double-sided-ish quads (two opposite-facing planes each)
+            double h = rng.range(0.8f, 2.5f), w = rng.range(0.5f, 1.5f);
+            m.patches.push_back(planePatch({-w, 0, 0}, {2 * w, 0, 0}, {0, h, 0}, a, a, 0.15, 4, seed));
+            m.patches.push_back(planePatch({w, 0, 0}, {-2 * w, 0, 0}, {0, h, 0}, a, a, 0.15, 4, seed + 1000));
+            m.patches.push_back(planePatch({0, 0, -w}, {0, 0, 2 * w}, {0, h, 0}, a, a, 0.15, 4, seed + 2000));
+            m.patches.push_back(planePatch({0, 0, w}, {0, 0, -2 * w}, {0, h, 0}, a, a, 0.15, 4, seed + 3000));
+        }
+        uint32_t minDim = 0xFFFFFFFFu; for (auto& p : m.patches) minDim = std::min(minDim, std::min(p.nu0, p.nv0));
+        m.lodLevels = lv(minDim);
+        m.material = 3 + rng.below(60);
+        uint32_t cnt = 0; for (auto& p : m.patches) cnt += p.nu0 * p.nv0;
+        propMeshlets[i] = cnt;
+        meshes.push_back(m);
+    }
+    for (size_t i = 0; i < meshes.size(); i++) buildMesh(sc, meshes[i], (uint32_t)i);
+    for (uint32_t i = 0; i < nStatics; i++) addInstance(sc, {i, identity()});
+    // instances: fill the remaining budget
+    double remaining = budgetMeshlets - (double)sc.stats.instancedTriangles / 128.0;
+    uint32_t made = 0;
+    const bool skinSome = sc.params.skinnedFraction1024 != 0; (void)skinSome;
+    while (made < nInstances && remaining > 0) {
+        uint32_t pi = rng.below(nProps);
+        double scl = rng.range(0.5f, 1.8f);
+        // 70 % on the street band, 30 % anywhere incl. behind the camera / behind facades
+        V3 pos;
+        if (rng.uniform() < 0.7f) pos = {rng.range((float)-Wd + 1, (float)Wd - 1), 0, rng.range((float)-L + 2, 20.0f)};
+        else pos = {rng.range((float)-Wd * 2.5f, (float)Wd * 2.5f), 0, rng.range((float)-L, (float)L)};
+        if (foliage) pos.y = rng.range(0.0f, 3.0f);
+        addInstance(sc, {nStatics + pi, mul(mul(scaling(scl), rotationY(rng.range(0, 6.2831f))), translation(pos))});
+        remaining -= propMeshlets[pi];
+        made++;
+    }
+    setCamera(sc, {0.8, 1.7, 28.0}, 0.06, -0.03, 80.0, 0.1, 1000.0);
+    if (sc.params.withDirectionalLight) addLight(sc, BRMI_LIGHT_DIRECTIONAL, {0, 0, 0}, {1, 1, 1}, 10.0f, {1, 0, 0}, {0, -6, -1});
+    for (uint32_t i = 0; i < sc.params.numPointLights; i++)
+        addLight(sc, BRMI_LIGHT_POINT, {rng.range((float)-Wd + 0.5f, (float)Wd - 0.5f), rng.range(0.3f, 6.0f), rng.range(-90.0f, 30.0f)}, {rng.uniform(), rng.uniform(), rng.uniform()}, 3.0f, {0, 0, 1}, {0, 0, 0});
+}
+
+void presetZorah(brmi_scene& sc, Pcg32& rng) {
+    addMaterials(sc, rng, 16);
+    const uint32_t levels = sc.params.lodLevels ? sc.params.lodLevels : 6;
+    // one detailed mesh (~100k tris at sizeScale 1: 32x24 = 768 meshlets) instanced on a huge grid
+    MeshDef m; uint32_t a = roundPow2Mult(16, levels);
+    m.patches.push_back(ellipsoidPatch({0, 1.0, 0}, 1.0, 1.0, 1.0, 2 * a, a, 0.25, 6, 900));
+    m.patches.push_back(cylinderPatch({0, -1.0, 0}, 0.6, 1.2, a, a, 0.05, 4, 901));
+    m.lodLevels = levels; m.material = 1;
+    buildMesh(sc, m, 0);
+    MeshDef g; g.patches.push_back(planePatch({-2000, -1.0, -4000}, {0, 0, 4200}, {4000, 0, 0}, roundPow2Mult(64, levels), roundPow2Mult(64, levels), 1.5, 200, 902)); g.lodLevels = levels; g.material = 0;
+    buildMesh(sc, g, 1);
+    addInstance(sc, {1, identity()});
+    const uint32_t n = (uint32_t)std::max(1.0, 100000.0 * sc.params.sizeScale);
+    const uint32_t side = (uint32_t)std::ceil(std::sqrt((double)n));
+    for (uint32_t i = 0; i < n; i++) {
+        double x = ((double)(i % side) - side / 2.0) * 3.2 + rng.range(-0.8f, 0.8f), z = -((double)(i / side)) * 3.2 + 10.0 + rng.range(-0.8f, 0.8f);
+        addInstance(sc, {0, mul(mul(scaling(rng.range(0.7f, 1.3f)), rotationY(rng.range(0, 6.2831f))), translation({x, 0.0, z}))});
+    }
+    setCamera(sc, {0.0, 6.0, 20.0}, 0.0, -0.12, 80.0, 0.1, 1000.0);
+    if (sc.params.withDirectionalLight) addLight(sc, BRMI_LIGHT_DIRECTIONAL, {0, 0, 0}, {1, 1, 1}, 10.0f, {1, 0, 0}, {0, -6, -1});
+    for (uint32_t i = 0; i < sc.params.numPointLights; i++)
+        addLight(sc, BRMI_LIGHT_POINT, {rng.range(-40, 40), rng.range(0.5f, 4.0f), rng.range(-120, 15)}, {rng.uniform(), rng.uniform(), rng.uniform()}, 3.0f, {0, 0, 1}, {0, 0, 0});
+}
+
+}  // namespace
+
+extern "C" {
+
+brmi_scene* brmi_scene_create(const brmi_scene_params* params) {
+    if (!params || params->width == 0 || params->height == 0) return nullptr;
+    brmi_scene* sc = new brmi_scene();
+    sc->params = *params;
+    if (sc->params.sizeScale <= 0.0f) sc->params.sizeScale = 1.0f;
+    for (int k = 0; k < 3; k++) { sc->stats.sceneMin[k] = 1e30f; sc->stats.sceneMax[k] = -1e30f; }
+    Pcg32 rng(0xB451C0DEull + params->seed, 54u + params->preset);
+    switch (params->preset) {
+        case BRMI_PRESET_TINY: presetTiny(*sc, rng); break;
+        case BRMI_PRESET_SPONZA: presetSponza(*sc, rng); break;
+        case BRMI_PRESET_BISTRO: presetStreet(*sc, rng, 3.0e6, 150, 2000, 5, false); break;
+        case BRMI_PRESET_SAN_MIGUEL: presetStreet(*sc, rng, 10.0e6, 220, 9000, 5, true); break;
+        case BRMI_PRESET_ZORAH: presetZorah(*sc, rng); break;
+        default: delete sc; return nullptr;
+    }
+    finishFrame(*sc);
+    return sc;
+}
+
+void brmi_scene_destroy(brmi_scene* scene) { delete scene; }
+
+int brmi_scene_array(const brmi_scene* s, uint32_t id, const void** ptr, uint64_t* bytes, uint32_t* count) {
+    if (!s || !ptr || !bytes || !count) return -1;
+#define ARR(vec, elem) do { *ptr = (vec).data(); *bytes = (uint64_t)(vec).size() * sizeof((vec)[0]); *count = (uint32_t)((vec).size() / (elem)); return 0; } while (0)
+    switch (id) {
+        case BRMI_ARR_PER_OBJECT: ARR(s->perObject, 1);
+        case BRMI_ARR_NORMAL_MATRICES: ARR(s->normalMatrices, 16);
+        case BRMI_ARR_PER_MESH: ARR(s->perMesh, 1);
+        case BRMI_ARR_PER_MESH_INSTANCE: ARR(s->perMeshInstance, 1);
+        case BRMI_ARR_CLOD_OFFSETS: ARR(s->clodOffsets, 1);
+        case BRMI_ARR_CLOD_MESH_METADATA: ARR(s->meshMetadata, 1);
+        case BRMI_ARR_LOD_NODES: ARR(s->nodes, 1);
+        case BRMI_ARR_LOD_GROUPS: ARR(s->groups, 1);
+        case BRMI_ARR_LOD_SEGMENTS: ARR(s->segments, 1);
+        case BRMI_ARR_GROUP_PAGE_MAP: ARR(s->pageMap, 1);
+        case BRMI_ARR_MATERIALS: ARR(s->materials, 1);
+        case BRMI_ARR_OPENPBR_MATERIALS: ARR(s->openpbr, 1);
+        case BRMI_ARR_LIGHTS: ARR(s->lights, 1);
+        case BRMI_ARR_ACTIVE_LIGHT_INDICES: ARR(s->activeLights, 1);
+        case BRMI_ARR_CAMERAS: ARR(s->cameras, 1);
+        case BRMI_ARR_CULLING_CAMERAS: ARR(s->cullingCameras, 1);
+        case BRMI_ARR_VIEW_RASTER_INFO: ARR(s->viewRasterInfo, 1);
+        case BRMI_ARR_PER_FRAME: ARR(s->perFrame, 1);
+        case BRMI_ARR_ACTIVE_DRAWS: ARR(s->activeDraws, 1);
+        case BRMI_ARR_SKINNING_MATRICES: ARR(s->skinningMatrices, 16);
+        default: return -1;
+    }
+#undef ARR
+}
+
+uint32_t brmi_scene_slab_count(const brmi_scene* s) { return s && !s->slabs.empty() ? (uint32_t)s->slabs.size() - 1 : 0; }
+int brmi_scene_slab(const brmi_scene* s, uint32_t i, const void** ptr, uint64_t* bytes) {
+    if (!s || i == 0 || i >= s->slabs.size()) return -1;
+    *ptr = s->slabs[i].data(); *bytes = s->slabs[i].size(); return 0;
+}
+void brmi_scene_get_stats(const brmi_scene* s, brmi_scene_stats* out) { if (s && out) *out = s->stats; }
+
+}  // extern "C"

@@ -1,0 +1,91 @@
+/*
+ * brmi_scene.h -- C ABI of the synthetic scene generator (libbrmi_scene.so, host only).
+ *
+ * The reference ships no assets (models/ and textures/ are git-ignored, .gitignore:17-18), so
+ * the benchmark frames are procedural stand-ins emitted directly in the reference's GPU data
+ * contract (include/brmi_types.h): 256 KB page slabs laid out like
+ * BuildPackedTriangleMeshPageBlob (BR/src/Mesh/ClusterLODUtilities.cpp:2079-2311), one 8-wide
+ * BVH per DAG depth under a super-root (ClusterLODUtilities.cpp:4606-4900), groups / segments /
+ * page map, per-object / per-mesh / per-instance buffers, cameras, lights and materials.
+ * Presets follow SURVEY.md section 8(d).
+ */
+#ifndef BRMI_SCENE_H
+#define BRMI_SCENE_H
+
+#include <stdint.h>
+#include "brmi_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum brmi_scene_preset {
+    BRMI_PRESET_TINY        = 0,  /* a handful of meshlets; unit tests */
+    BRMI_PRESET_SPONZA      = 1,  /* atrium, ~262k tris flat LOD, 1 directional (+N point) lights */
+    BRMI_PRESET_BISTRO      = 2,  /* street, ~3M tris, ~2000 instances of ~150 meshes, LOD DAG */
+    BRMI_PRESET_SAN_MIGUEL  = 3,  /* ~10M tris, high depth complexity */
+    BRMI_PRESET_ZORAH       = 4   /* massive instancing + deep LOD */
+};
+
+typedef struct brmi_scene_params {
+    uint32_t preset;
+    uint32_t seed;
+    uint32_t width, height;       /* render target size */
+    uint32_t numPointLights;
+    uint32_t withDirectionalLight;
+    uint32_t lodLevels;           /* 0 = preset default; 1 = flat */
+    float    sizeScale;           /* 1.0 = preset default triangle budget; <1 shrinks (tests) */
+    uint32_t skinnedFraction1024; /* fraction (x/1024) of instances that are skinned; 0 = none */
+    uint32_t reserved[7];
+} brmi_scene_params;
+
+/* Arrays a scene exposes.  Element layouts are the brmi_types.h structs. */
+enum brmi_scene_array {
+    BRMI_ARR_PER_OBJECT = 0,        /* brmi_per_object[] */
+    BRMI_ARR_NORMAL_MATRICES,       /* float[4][4][]  (Builtin::NormalMatrixBuffer) */
+    BRMI_ARR_PER_MESH,              /* brmi_per_mesh[] */
+    BRMI_ARR_PER_MESH_INSTANCE,     /* brmi_per_mesh_instance[] */
+    BRMI_ARR_CLOD_OFFSETS,          /* brmi_mesh_instance_clod_offsets[] (per mesh instance) */
+    BRMI_ARR_CLOD_MESH_METADATA,    /* brmi_clod_mesh_metadata[] */
+    BRMI_ARR_LOD_NODES,             /* brmi_lod_node[] */
+    BRMI_ARR_LOD_GROUPS,            /* brmi_lod_group[] */
+    BRMI_ARR_LOD_SEGMENTS,          /* brmi_lod_segment[] */
+    BRMI_ARR_GROUP_PAGE_MAP,        /* brmi_group_page_map_entry[] */
+    BRMI_ARR_MATERIALS,             /* brmi_material_info[] */
+    BRMI_ARR_OPENPBR_MATERIALS,     /* brmi_openpbr_material_info[] */
+    BRMI_ARR_LIGHTS,                /* brmi_light_info[] */
+    BRMI_ARR_ACTIVE_LIGHT_INDICES,  /* uint32_t[] */
+    BRMI_ARR_CAMERAS,               /* brmi_camera[] */
+    BRMI_ARR_CULLING_CAMERAS,       /* brmi_culling_camera[] */
+    BRMI_ARR_VIEW_RASTER_INFO,      /* brmi_view_raster_info[] */
+    BRMI_ARR_PER_FRAME,             /* brmi_per_frame[1] */
+    BRMI_ARR_ACTIVE_DRAWS,          /* uint32_t[] per-mesh-instance indices to cull (draw set) */
+    BRMI_ARR_SKINNING_MATRICES,     /* float[4][4][]: bone*invBind per (slot,joint); may be empty */
+    BRMI_ARR_COUNT
+};
+
+typedef struct brmi_scene brmi_scene;
+
+brmi_scene* brmi_scene_create(const brmi_scene_params* params);
+void        brmi_scene_destroy(brmi_scene* scene);
+
+/* Returns 0 on success.  `count` = element count. */
+int      brmi_scene_array(const brmi_scene* scene, uint32_t arrayId,
+                          const void** ptr, uint64_t* bytes, uint32_t* count);
+/* Page slabs: slab index s in [1, slabCount]; index 0 is the reference's "not resident". */
+uint32_t brmi_scene_slab_count(const brmi_scene* scene);
+int      brmi_scene_slab(const brmi_scene* scene, uint32_t slabIndex, const void** ptr, uint64_t* bytes);
+
+/* Summary numbers for reporting. */
+typedef struct brmi_scene_stats {
+    uint64_t uniqueTriangles, instancedTriangles;
+    uint32_t meshes, instances, meshletsTotal, meshletsLod0, pages, nodes, groups, segments;
+    uint32_t lights, materials, maxBvhDepth, lodLevelsMax;
+    float    sceneMin[3], sceneMax[3];
+} brmi_scene_stats;
+void brmi_scene_get_stats(const brmi_scene* scene, brmi_scene_stats* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
