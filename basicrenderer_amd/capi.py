@@ -1,0 +1,161 @@
+"""ctypes mirrors of include/brmi.h, include/brmi_scene.h and loaders for the in-tree libraries.
+
+Harness-side plumbing only: the product is libbrmi.so (HIP kernels behind the C ABI).  This module
+never imports anything from oracle/.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(_HERE, "lib")
+
+u32, u64, f32, vp = C.c_uint32, C.c_uint64, C.c_float, C.c_void_p
+
+
+class SceneParams(C.Structure):
+    _fields_ = [("preset", u32), ("seed", u32), ("width", u32), ("height", u32), ("numPointLights", u32),
+                ("withDirectionalLight", u32), ("lodLevels", u32), ("sizeScale", f32), ("skinnedFraction1024", u32),
+                ("reserved", u32 * 7)]
+
+
+class SceneStats(C.Structure):
+    _fields_ = [("uniqueTriangles", u64), ("instancedTriangles", u64)] + \
+               [(n, u32) for n in ("meshes instances meshletsTotal meshletsLod0 pages nodes groups segments "
+                                   "lights materials maxBvhDepth lodLevelsMax").split()] + \
+               [("sceneMin", f32 * 3), ("sceneMax", f32 * 3)]
+
+
+# order == enum brmi_scene_array
+SCENE_ARRAYS = ["perObject", "normalMatrices", "perMesh", "perMeshInstance", "clodOffsets", "meshMetadata", "lodNodes",
+                "lodGroups", "lodSegments", "groupPageMap", "materials", "openpbrMaterials", "lights",
+                "activeLightIndices", "cameras", "cullingCameras", "viewRasterInfo", "perFrame", "activeDraws",
+                "skinningMatrices", "lutOdE", "lutOdAvg", "lutImE", "lutImAvg", "lutFuzzLTC"]
+
+
+class SceneBuffers(C.Structure):
+    """brmi_scene_buffers (include/brmi.h).  Pointers are host or device addresses."""
+    _fields_ = [
+        ("slabs", vp), ("slabCount", u32),
+        ("perObject", vp), ("perObjectCount", u32),
+        ("normalMatrices", vp),
+        ("perMesh", vp), ("perMeshCount", u32),
+        ("perMeshInstance", vp), ("perMeshInstanceCount", u32),
+        ("clodOffsets", vp),
+        ("meshMetadata", vp), ("meshMetadataCount", u32),
+        ("lodNodes", vp), ("lodNodeCount", u32),
+        ("lodGroups", vp), ("lodGroupCount", u32),
+        ("lodSegments", vp), ("lodSegmentCount", u32),
+        ("groupPageMap", vp), ("groupPageMapCount", u32),
+        ("materials", vp), ("materialCount", u32),
+        ("openpbrMaterials", vp), ("openpbrMaterialCount", u32),
+        ("lights", vp), ("lightCount", u32),
+        ("activeLightIndices", vp),
+        ("cameras", vp), ("cameraCount", u32),
+        ("cullingCameras", vp),
+        ("viewRasterInfo", vp),
+        ("perFrame", vp),
+        ("activeDraws", vp), ("activeDrawCount", u32),
+        ("skinningMatrices", vp), ("skinningMatrixCount", u32),
+        ("lutOpaqueDielectricEnergyComplement", vp),
+        ("lutOpaqueDielectricAvgEnergyComplement", vp),
+        ("lutIdealMetalEnergyComplement", vp),
+        ("lutIdealMetalAvgEnergyComplement", vp),
+        ("lutFuzzLTC", vp),
+    ]
+
+
+class Config(C.Structure):
+    _fields_ = [("structSize", u32), ("width", u32), ("height", u32), ("maxVisibleClusters", u32),
+                ("maxTraversalRecords", u32), ("enableOcclusionCulling", u32), ("enableClusteredLighting", u32),
+                ("enablePunctualLights", u32), ("lightClusterSize", u32 * 3), ("phase2ExpansionFactor", u32),
+                ("collectPassStatistics", u32), ("maxBvhLevels", u32), ("bandY0", u32), ("bandY1", u32),
+                ("reserved", u32 * 8)]
+
+
+class ResourceDesc(C.Structure):
+    _fields_ = [("id", u32), ("name", C.c_char_p), ("bytes", u64), ("usage", u32), ("width", u32), ("height", u32),
+                ("bytesPerPixel", u32), ("tileW", u32), ("tileH", u32)]
+
+
+class ResourceBinding(C.Structure):
+    _fields_ = [("id", u32), ("ptr", vp), ("bytes", u64)]
+
+
+class FrameUpdate(C.Structure):
+    _fields_ = [("mainCameraHost", vp), ("perFrameHost", vp), ("frameIndex", u32)]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, u32) for n in ("instancesTested instancesVisible nodesVisited bucketRecords meshletsTested "
+                                   "visibleClusters visibleClustersPhase2 droppedRecords droppedClusters "
+                                   "lightPagesUsed").split()] + [("reserved", u32 * 6)]
+
+
+DECLARE_CB = C.CFUNCTYPE(None, vp, C.POINTER(ResourceDesc))
+
+RES_NAMES = ["VISIBILITY", "LINEAR_DEPTH", "GBUF_NORMALS", "GBUF_ALBEDO", "GBUF_COAT", "GBUF_EMISSIVE", "GBUF_FUZZ",
+             "GBUF_METALLIC_ROUGHNESS", "GBUF_MOTION_VECTORS", "HDR_COLOR", "VISIBLE_CLUSTERS", "LIGHT_CLUSTERS",
+             "LIGHT_PAGES", "HZB", "WORKSPACE"]
+RES = {n: i for i, n in enumerate(RES_NAMES)}
+STAGE_NAMES = ["clear", "cull", "raster", "depth_copy", "hzb", "cull2", "raster2", "gbuffer", "light_cluster", "shade"]
+
+_scene_lib = None
+_brmi_lib = None
+
+
+def scene_lib():
+    """libbrmi_scene.so: the host-side procedural scene generator."""
+    global _scene_lib
+    if _scene_lib is None:
+        path = os.path.join(LIB_DIR, "libbrmi_scene.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run `make scene` (or __graft_entry__.build())")
+        lib = C.CDLL(path)
+        lib.brmi_scene_create.restype = vp
+        lib.brmi_scene_create.argtypes = [C.POINTER(SceneParams)]
+        lib.brmi_scene_destroy.argtypes = [vp]
+        lib.brmi_scene_array.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(u64), C.POINTER(u32)]
+        lib.brmi_scene_slab_count.argtypes = [vp]
+        lib.brmi_scene_slab_count.restype = u32
+        lib.brmi_scene_slab.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(u64)]
+        lib.brmi_scene_get_stats.argtypes = [vp, C.POINTER(SceneStats)]
+        _scene_lib = lib
+    return _scene_lib
+
+
+BRMI_EXPORTS = ["brmi_abi_version", "brmi_default_config", "brmi_create", "brmi_declare", "brmi_set_scene", "brmi_setup",
+                "brmi_update", "brmi_execute", "brmi_destroy", "brmi_last_error", "brmi_clear_visibility", "brmi_cull",
+                "brmi_raster", "brmi_depth_copy", "brmi_build_hzb", "brmi_gbuffer", "brmi_light_clustering",
+                "brmi_shade", "brmi_read_counters", "brmi_stage_times", "brmi_algorithmic_bytes"]
+
+
+def brmi_lib():
+    """libbrmi.so: HIP kernels + C ABI.  Fails loudly when the extension has not been built."""
+    global _brmi_lib
+    if _brmi_lib is None:
+        path = os.path.join(LIB_DIR, "libbrmi.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: the HIP extension must be built (make hip); there is no CPU fallback")
+        lib = C.CDLL(path)
+        lib.brmi_abi_version.restype = u32
+        lib.brmi_default_config.argtypes = [C.POINTER(Config), u32, u32]
+        lib.brmi_default_config.restype = None
+        lib.brmi_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+        lib.brmi_declare.argtypes = [vp, DECLARE_CB, vp]
+        lib.brmi_set_scene.argtypes = [vp, C.POINTER(SceneBuffers)]
+        lib.brmi_setup.argtypes = [vp, C.POINTER(ResourceBinding), u32, vp]
+        lib.brmi_update.argtypes = [vp, C.POINTER(FrameUpdate), vp]
+        lib.brmi_execute.argtypes = [vp, vp]
+        lib.brmi_destroy.argtypes = [vp]
+        lib.brmi_destroy.restype = None
+        lib.brmi_last_error.argtypes = [vp]
+        lib.brmi_last_error.restype = C.c_char_p
+        for n in ("brmi_clear_visibility", "brmi_depth_copy", "brmi_build_hzb", "brmi_gbuffer", "brmi_light_clustering", "brmi_shade"):
+            getattr(lib, n).argtypes = [vp, vp]
+        lib.brmi_cull.argtypes = [vp, u32, vp]
+        lib.brmi_raster.argtypes = [vp, u32, vp]
+        lib.brmi_read_counters.argtypes = [vp, C.POINTER(Counters), vp]
+        lib.brmi_stage_times.argtypes = [vp, C.POINTER(f32)]
+        lib.brmi_algorithmic_bytes.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
+        _brmi_lib = lib
+    return _brmi_lib

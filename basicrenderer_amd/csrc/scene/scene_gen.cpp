@@ -172,7 +172,7 @@ uint32_t octEncode(V3 n) {
 
 // per-meshlet build record
 struct MeshletBuild {
-    uint32_t level, patch, mi, mj;
+    uint32_t level, patch, mi, mj, group;
     int32_t  refinedGroup;        // mesh-local, -1 terminal
     std::vector<float> pos;       // 81*3
     std::vector<uint32_t> nrm;    // 81
@@ -213,6 +213,7 @@ struct brmi_scene {
     std::vector<brmi_per_frame> perFrame;
     std::vector<uint32_t> activeDraws;
     std::vector<float> skinningMatrices;
+    std::vector<uint16_t> lutOdE, lutOdAvg, lutImE, lutImAvg; std::vector<float> lutLtc;
     brmi_scene_stats stats{};
     // page tile allocator
     uint32_t curSlab = 0; uint32_t curSlabPages = 0;
@@ -283,6 +284,7 @@ std::vector<uint8_t> buildPageBlob(const std::vector<const MeshletBuild*>& ms, b
         d.bitsAndVertexCount = V << 24;
         d.triangleCountAndRefinedGroup = 128u | ((uint32_t)(m.refinedGroup + 1) << 16);
         d.boneCount = skinned ? 4u : 0u;
+        d.sourceGroupLocalIndex = m.group;
         d.bounds[0] = (float)m.bounds.c.x; d.bounds[1] = (float)m.bounds.c.y; d.bounds[2] = (float)m.bounds.c.z; d.bounds[3] = (float)m.bounds.r;
         std::memcpy(blob.data() + h.descriptorOffset + (size_t)i * sizeof(d), &d, sizeof(d));
         std::memcpy(blob.data() + h.positionBitstreamOffset + posCursor, m.pos.data(), (size_t)V * 12);
@@ -366,6 +368,7 @@ void buildMesh(brmi_scene& sc, const MeshDef& def, uint32_t meshIndex) {
                     }
                 }
                 uint32_t gid = lp[L][pi].firstGroup + (mj / 4) * gw + (mi / 4);
+                m.group = gid;
                 groups[gid].meshlets.push_back((uint32_t)meshlets.size());
                 meshlets.push_back(std::move(m));
             }
@@ -723,6 +726,49 @@ void finishFrame(brmi_scene& sc) {
     sc.stats.lights = (uint32_t)sc.lights.size(); sc.stats.materials = (uint32_t)sc.materials.size();
 }
 
+
+// Stand-in OpenPBR lookup tables.  The reference includes them from adobe/openpbr-bsdf (absent
+// submodule; BR/src/Render/OpenPBRLookupResources.cpp:34-77), so these are synthetic but physically
+// plausible: energy complements derived from the MaterialX GGX directional-albedo fit
+// (BR/shaders/Include/PBR.hlsli:8-25) and its cosine-weighted averages.  Real tables drop in unchanged.
+double ggxDirAlbedo(double x, double y, double F0, double F90) {
+    const double c[9][4] = {{0.1003, 0.9345, 1.0, 1.0}, {-0.6303, -2.323, -1.765, 0.2281}, {9.748, 2.229, 8.263, 15.94}, {-2.038, -3.748, 11.53, -55.83},
+                            {29.34, 1.424, 28.96, 13.08}, {-8.245, -0.7684, -7.507, 41.26}, {-26.44, 1.436, -36.11, 54.9}, {19.99, 0.2913, 15.86, 300.2}, {-5.448, 0.6286, 33.37, -285.1}};
+    double r[4];
+    for (int i = 0; i < 4; i++) r[i] = c[0][i] + c[1][i] * x + c[2][i] * y + c[3][i] * x * y + c[4][i] * x * x + c[5][i] * y * y + c[6][i] * x * x * y + c[7][i] * x * y * y + c[8][i] * x * x * y * y;
+    double A = std::min(1.0, std::max(0.0, r[0] / r[2])), B = std::min(1.0, std::max(0.0, r[1] / r[3]));
+    return F0 * A + F90 * B;
+}
+void buildLuts(brmi_scene& sc) {
+    auto q = [](double v) { return (uint16_t)std::lround(std::min(1.0, std::max(0.0, v)) * 65535.0); };
+    const int N = 32;
+    sc.lutOdE.resize(N * N * N); sc.lutOdAvg.resize(N * N); sc.lutImE.resize(N * N); sc.lutImAvg.resize(N); sc.lutLtc.resize(N * N * 4);
+    auto iorOf = [&](int i) { if (i >= 16) return 1.0 + (i - 16) / 15.0 * 1.5; double fr = (15 - i) / 15.0; return 1.0 / (1.0 + fr * 1.5); };
+    for (int a = 0; a < N; a++) {
+        const double alpha = (a / 31.0) * (a / 31.0);
+        double avg = 0, wsum = 0;
+        for (int c = 0; c < N; c++) {
+            const double mu = c / 31.0;
+            const double comp = 1.0 - ggxDirAlbedo(mu, alpha, 1.0, 1.0);
+            sc.lutImE[a * N + c] = q(comp);
+        }
+        for (int k = 0; k < 256; k++) { double mu = (k + 0.5) / 256.0; avg += (1.0 - ggxDirAlbedo(mu, alpha, 1.0, 1.0)) * mu; wsum += mu; }
+        sc.lutImAvg[a] = q(avg / wsum);
+        for (int i = 0; i < N; i++) {
+            const double ior = iorOf(i), f = (ior - 1.0) / (ior + 1.0), F0 = f * f;
+            for (int c = 0; c < N; c++) sc.lutOdE[(i * N + a) * N + c] = q(1.0 - ggxDirAlbedo(c / 31.0, alpha, F0, 1.0));
+            double av = 0, ws = 0;
+            for (int k = 0; k < 256; k++) { double mu = (k + 0.5) / 256.0; av += (1.0 - ggxDirAlbedo(mu, alpha, F0, 1.0)) * mu; ws += mu; }
+            sc.lutOdAvg[i * N + a] = q(av / ws);
+        }
+    }
+    for (int r = 0; r < N; r++) for (int c = 0; c < N; c++) {
+        const double rough = r / 31.0, mu = c / 31.0;
+        float* t = &sc.lutLtc[(r * N + c) * 4];
+        t[0] = (float)(1.0 / (0.15 + 0.85 * rough)); t[1] = (float)(0.6 * (1.0 - mu) * (1.0 - 0.5 * rough)); t[2] = (float)(0.04 + 0.5 * rough * (1.0 - mu) * (1.0 - mu)); t[3] = 0.0f;
+    }
+}
+
 PatchDef planePatch(V3 origin, V3 U, V3 V, uint32_t nu, uint32_t nv, double amp, double freq, uint32_t seed) {
     PatchDef p; p.type = PATCH_PLANE; p.origin = origin; p.axisU = U; p.axisV = V; p.nu0 = nu; p.nv0 = nv; p.noiseAmp = amp; p.noiseFreq = freq; p.noiseSeed = seed; return p;
 }
@@ -915,6 +961,7 @@ brmi_scene* brmi_scene_create(const brmi_scene_params* params) {
         case BRMI_PRESET_ZORAH: presetZorah(*sc, rng); break;
         default: delete sc; return nullptr;
     }
+    buildLuts(*sc);
     finishFrame(*sc);
     return sc;
 }
@@ -945,6 +992,11 @@ int brmi_scene_array(const brmi_scene* s, uint32_t id, const void** ptr, uint64_
         case BRMI_ARR_PER_FRAME: ARR(s->perFrame, 1);
         case BRMI_ARR_ACTIVE_DRAWS: ARR(s->activeDraws, 1);
         case BRMI_ARR_SKINNING_MATRICES: ARR(s->skinningMatrices, 16);
+        case BRMI_ARR_LUT_OD_ENERGY: ARR(s->lutOdE, 1);
+        case BRMI_ARR_LUT_OD_AVG_ENERGY: ARR(s->lutOdAvg, 1);
+        case BRMI_ARR_LUT_IM_ENERGY: ARR(s->lutImE, 1);
+        case BRMI_ARR_LUT_IM_AVG_ENERGY: ARR(s->lutImAvg, 1);
+        case BRMI_ARR_LUT_FUZZ_LTC: ARR(s->lutLtc, 4);
         default: return -1;
     }
 #undef ARR

@@ -1,0 +1,117 @@
+"""Scene: numpy views over the arrays produced by libbrmi_scene.so, and their upload to HBM.
+
+The generator emits the reference's GPU data contract (include/brmi_types.h); this wrapper only
+moves bytes: host numpy views -> `SceneBuffers` with host pointers (for a CPU consumer) or with
+device pointers (torch uint8 tensors, for libbrmi.so).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+PRESETS = {"tiny": 0, "sponza": 1, "bistro": 2, "san_miguel": 3, "zorah": 4}
+
+# SceneBuffers field <- (scene array name, count field or None)
+_FIELD_MAP = [
+    ("perObject", "perObject", "perObjectCount"), ("normalMatrices", "normalMatrices", None),
+    ("perMesh", "perMesh", "perMeshCount"), ("perMeshInstance", "perMeshInstance", "perMeshInstanceCount"),
+    ("clodOffsets", "clodOffsets", None), ("meshMetadata", "meshMetadata", "meshMetadataCount"),
+    ("lodNodes", "lodNodes", "lodNodeCount"), ("lodGroups", "lodGroups", "lodGroupCount"),
+    ("lodSegments", "lodSegments", "lodSegmentCount"), ("groupPageMap", "groupPageMap", "groupPageMapCount"),
+    ("materials", "materials", "materialCount"), ("openpbrMaterials", "openpbrMaterials", "openpbrMaterialCount"),
+    ("lights", "lights", "lightCount"), ("activeLightIndices", "activeLightIndices", None),
+    ("cameras", "cameras", "cameraCount"), ("cullingCameras", "cullingCameras", None),
+    ("viewRasterInfo", "viewRasterInfo", None), ("perFrame", "perFrame", None),
+    ("activeDraws", "activeDraws", "activeDrawCount"), ("skinningMatrices", "skinningMatrices", "skinningMatrixCount"),
+    ("lutOpaqueDielectricEnergyComplement", "lutOdE", None), ("lutOpaqueDielectricAvgEnergyComplement", "lutOdAvg", None),
+    ("lutIdealMetalEnergyComplement", "lutImE", None), ("lutIdealMetalAvgEnergyComplement", "lutImAvg", None),
+    ("lutFuzzLTC", "lutFuzzLTC", None),
+]
+
+
+class Scene:
+    def __init__(self, preset="sponza", width=3840, height=2160, seed=0, point_lights=64, directional=True,
+                 lod_levels=0, size_scale=1.0):
+        lib = capi.scene_lib()
+        p = capi.SceneParams()
+        p.preset = PRESETS[preset] if isinstance(preset, str) else int(preset)
+        p.seed, p.width, p.height = seed, width, height
+        p.numPointLights, p.withDirectionalLight = point_lights, 1 if directional else 0
+        p.lodLevels, p.sizeScale = lod_levels, size_scale
+        self.preset, self.width, self.height = preset, width, height
+        self._lib = lib
+        self._h = lib.brmi_scene_create(C.byref(p))
+        if not self._h:
+            raise RuntimeError("brmi_scene_create failed")
+        self.arrays, self.counts = {}, {}
+        for i, name in enumerate(capi.SCENE_ARRAYS):
+            ptr, nbytes, count = capi.vp(), capi.u64(), capi.u32()
+            if lib.brmi_scene_array(self._h, i, C.byref(ptr), C.byref(nbytes), C.byref(count)) != 0:
+                raise RuntimeError(f"brmi_scene_array({name}) failed")
+            n = nbytes.value
+            if n:
+                buf = (C.c_uint8 * n).from_address(ptr.value)
+                self.arrays[name] = np.frombuffer(buf, dtype=np.uint8).copy()   # own the bytes
+            else:
+                self.arrays[name] = np.zeros(0, dtype=np.uint8)
+            self.counts[name] = count.value
+        self.slabs = [None]
+        for s in range(1, lib.brmi_scene_slab_count(self._h) + 1):
+            ptr, nbytes = capi.vp(), capi.u64()
+            lib.brmi_scene_slab(self._h, s, C.byref(ptr), C.byref(nbytes))
+            buf = (C.c_uint8 * nbytes.value).from_address(ptr.value)
+            self.slabs.append(np.frombuffer(buf, dtype=np.uint8).copy())
+        st = capi.SceneStats()
+        lib.brmi_scene_get_stats(self._h, C.byref(st))
+        self.stats = {n: (list(getattr(st, n)) if n.startswith("scene") else getattr(st, n)) for n, _ in capi.SceneStats._fields_}
+        lib.brmi_scene_destroy(self._h)
+        self._h = None
+        self._keep = []
+
+    # -- host ------------------------------------------------------------------------------------
+    def host_buffers(self):
+        """SceneBuffers whose pointers address this object's numpy arrays (CPU consumers)."""
+        sb = capi.SceneBuffers()
+        slab_ptrs = (capi.vp * len(self.slabs))()
+        for i, s in enumerate(self.slabs):
+            slab_ptrs[i] = s.ctypes.data if s is not None else None
+        self._keep.append(slab_ptrs)
+        sb.slabs, sb.slabCount = C.cast(slab_ptrs, capi.vp), len(self.slabs)
+        for field, arr, cnt in _FIELD_MAP:
+            a = self.arrays[arr]
+            setattr(sb, field, a.ctypes.data if a.size else None)
+            if cnt:
+                setattr(sb, cnt, self.counts[arr])
+        return sb
+
+    def camera_host(self):
+        return self.arrays["cameras"]
+
+    def per_frame_host(self):
+        return self.arrays["perFrame"]
+
+    # -- device ----------------------------------------------------------------------------------
+    def device_buffers(self, device="cuda"):
+        """Upload every array to HBM; returns (SceneBuffers with device pointers, list of tensors to keep alive)."""
+        import torch
+        keep = []
+        sb = capi.SceneBuffers()
+
+        def up(a):
+            if a is None or a.size == 0:
+                return None
+            t = torch.from_numpy(np.ascontiguousarray(a)).to(device)
+            keep.append(t)
+            return t.data_ptr()
+
+        ptrs = np.zeros(len(self.slabs), dtype=np.uint64)
+        for i, s in enumerate(self.slabs):
+            if s is not None:
+                ptrs[i] = up(s)
+        sb.slabs, sb.slabCount = up(ptrs.view(np.uint8)), len(self.slabs)
+        for field, arr, cnt in _FIELD_MAP:
+            setattr(sb, field, up(self.arrays[arr]))
+            if cnt:
+                setattr(sb, cnt, self.counts[arr])
+        return sb, keep

@@ -1,0 +1,192 @@
+/*
+ * brmi.h -- C ABI of libbrmi.so: the MI355X-native visibility-buffer path of BasicRenderer.
+ *
+ * Drop-in boundary.  In the reference this path lives behind OpenRenderGraph's pass interface
+ * (`ComputePass::{DeclareResourceUsages,Setup,Update,Execute,Cleanup}`, e.g.
+ * BR/include/Render/GraphExtensions/ClusterLOD/ClusterSoftwareRasterizationPass.h:16-54) and the
+ * graph extension that schedules the cull/raster chain
+ * (`IRenderGraphExtension`, BR/include/Render/GraphExtensions/CLodExtension.h:20-31;
+ * schedule BR/src/Render/GraphExtensions/CLodExtension.cpp:1411-2095).  Those interfaces hand
+ * shaders *descriptor indices*; this ABI hands kernels *device pointers* and a hipStream_t in
+ * place of the command list.  One `brmi_pass` object = the CLodExtension + VisUtil + light
+ * clustering + deferred shading passes of one view.  Failures are int status codes plus
+ * brmi_last_error() (the reference throws; BR/src/Renderer.cpp:2112-2122); fixed-capacity
+ * appends drop + count and never fault (BR/shaders/ClusterLOD/workGraphCulling.hlsl:3094-3112).
+ *
+ * No torch / C++ types cross this boundary: plain pointers, sizes and PODs only.
+ */
+#ifndef BRMI_H
+#define BRMI_H
+
+#include <stdint.h>
+#include "brmi_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BRMI_ABI_VERSION 1u
+
+typedef enum brmi_status {
+    BRMI_OK            = 0,
+    BRMI_ERR_INVALID   = -1,   /* bad argument / missing binding */
+    BRMI_ERR_HIP       = -2,   /* a HIP call failed; see brmi_last_error() */
+    BRMI_ERR_CAPACITY  = -3,   /* a declared resource is too small */
+    BRMI_ERR_STATE     = -4    /* phase called out of order (e.g. execute before setup) */
+} brmi_status;
+
+typedef struct brmi_pass brmi_pass;
+typedef void* brmi_stream;     /* hipStream_t; NULL = the default stream */
+
+/* ---- configuration: the SettingsManager keys this path reads ------------------------------ */
+/* defaults: BR/src/Renderer.cpp:1108-1237 ; BR/include/Renderer.h:157,216-221 */
+typedef struct brmi_config {
+    uint32_t structSize;               /* sizeof(brmi_config), for forward compatibility */
+    uint32_t width, height;            /* visibility / G-buffer / HDR target size */
+    uint32_t maxVisibleClusters;       /* CLodExtension maxClusters (Renderer.cpp:2494: 30,000,000) */
+    uint32_t maxTraversalRecords;      /* frontier + bucket capacity (reference shares maxClusters) */
+    uint32_t enableOcclusionCulling;   /* 2-phase HZB culling (Renderer.h:157 default true) */
+    uint32_t enableClusteredLighting;  /* PSO_CLUSTERED_LIGHTING (default true) */
+    uint32_t enablePunctualLights;     /* DeferredShadingPass root constant (default true) */
+    uint32_t lightClusterSize[3];      /* {12,12,24}  (Renderer.cpp:1154) */
+    uint32_t phase2ExpansionFactor;    /* meshlets per bucket record, CLodCommon.h:31 default 2 */
+    uint32_t collectPassStatistics;    /* per-stage hipEvent timing (Renderer.cpp:1133-1134) */
+    uint32_t maxBvhLevels;             /* level-loop bound; reference caps at 64 (HierarchicalDispatchCullingPass.cpp:57) */
+    uint32_t bandY0, bandY1;           /* rows [bandY0,bandY1) this GPU owns (multi-GPU tile split); 0,0 = all */
+    uint32_t reserved[8];
+} brmi_config;
+
+void brmi_default_config(brmi_config* cfg, uint32_t width, uint32_t height);
+
+/* ---- scene providers (IResourceProvider keys, BR/include/Renderer.h:284-323) ----------------
+ * Device pointers to the structured buffers the reference's managers own.  `slabs` is a device
+ * array of device pointers indexed by slabDescriptorIndex (entry 0 unused = "not resident").   */
+typedef struct brmi_scene_buffers {
+    const uint8_t* const*                  slabs;            uint32_t slabCount;        /* incl. entry 0 */
+    const brmi_per_object*                 perObject;        uint32_t perObjectCount;
+    const float*                           normalMatrices;   /* float[4][4] per object */
+    const brmi_per_mesh*                   perMesh;          uint32_t perMeshCount;
+    const brmi_per_mesh_instance*          perMeshInstance;  uint32_t perMeshInstanceCount;
+    const brmi_mesh_instance_clod_offsets* clodOffsets;
+    const brmi_clod_mesh_metadata*         meshMetadata;     uint32_t meshMetadataCount;
+    const brmi_lod_node*                   lodNodes;         uint32_t lodNodeCount;
+    const brmi_lod_group*                  lodGroups;        uint32_t lodGroupCount;
+    const brmi_lod_segment*                lodSegments;      uint32_t lodSegmentCount;
+    const brmi_group_page_map_entry*       groupPageMap;     uint32_t groupPageMapCount;
+    const brmi_material_info*              materials;        uint32_t materialCount;
+    const brmi_openpbr_material_info*      openpbrMaterials; uint32_t openpbrMaterialCount;
+    const brmi_light_info*                 lights;           uint32_t lightCount;
+    const uint32_t*                        activeLightIndices;
+    const brmi_camera*                     cameras;          uint32_t cameraCount;
+    const brmi_culling_camera*             cullingCameras;
+    const brmi_view_raster_info*           viewRasterInfo;
+    const brmi_per_frame*                  perFrame;
+    const uint32_t*                        activeDraws;      uint32_t activeDrawCount;  /* per-mesh-instance indices */
+    const float*                           skinningMatrices; uint32_t skinningMatrixCount; /* float[4][4]: bone*invBind */
+    /* OpenPBR lookup tables (BR/src/Render/OpenPBRLookupResources.cpp:34-77): R16_UNORM energy
+     * tables 32x32(x32) and the 32x32 float LTC table, injected by the caller. */
+    const uint16_t* lutOpaqueDielectricEnergyComplement;     /* [32 ior][32 alpha][32 cos] */
+    const uint16_t* lutOpaqueDielectricAvgEnergyComplement;  /* [32 ior][32 alpha] */
+    const uint16_t* lutIdealMetalEnergyComplement;           /* [32 alpha][32 cos] */
+    const uint16_t* lutIdealMetalAvgEnergyComplement;        /* [32 alpha] */
+    const float*    lutFuzzLTC;                               /* [32 rough][32 cos][4]: aInv,bInv,refl,0 */
+} brmi_scene_buffers;
+
+/* ---- graph resources the pass declares (DeclareResourceUsages) ---------------------------- */
+typedef enum brmi_resource_id {
+    BRMI_RES_VISIBILITY = 0,          /* Builtin::PrimaryCamera::VisibilityTexture  u64/px, tiled 8x8 */
+    BRMI_RES_LINEAR_DEPTH,            /* Builtin::PrimaryCamera::LinearDepthMap     f32/px, tiled */
+    BRMI_RES_GBUF_NORMALS,            /* Builtin::GBuffer::Normals            float4  */
+    BRMI_RES_GBUF_ALBEDO,             /* Builtin::GBuffer::Albedo             rgba8 unorm */
+    BRMI_RES_GBUF_COAT,               /* Builtin::GBuffer::Coat               rgba16f */
+    BRMI_RES_GBUF_EMISSIVE,           /* Builtin::GBuffer::Emissive           rgba16f */
+    BRMI_RES_GBUF_FUZZ,               /* Builtin::GBuffer::Fuzz               rgba16f */
+    BRMI_RES_GBUF_METALLIC_ROUGHNESS, /* Builtin::GBuffer::MetallicRoughness  rgba8 unorm */
+    BRMI_RES_GBUF_MOTION_VECTORS,     /* Builtin::GBuffer::MotionVectors      rg16f */
+    BRMI_RES_HDR_COLOR,               /* Builtin::Color::HDRColorTarget       rgba16f */
+    BRMI_RES_VISIBLE_CLUSTERS,        /* CLod visible-cluster buffer, 16 B records */
+    BRMI_RES_LIGHT_CLUSTERS,          /* Builtin::Light::ClusterBuffer */
+    BRMI_RES_LIGHT_PAGES,             /* Builtin::Light::PagesBuffer */
+    BRMI_RES_HZB,                     /* linear-depth mip chain for occlusion culling */
+    BRMI_RES_WORKSPACE,               /* frontiers, bucket records, bitmasks, counters, statistics */
+    BRMI_RES_COUNT
+} brmi_resource_id;
+
+typedef enum brmi_usage {
+    BRMI_USAGE_SHADER_RESOURCE  = 1u << 0,
+    BRMI_USAGE_UNORDERED_ACCESS = 1u << 1,
+    BRMI_USAGE_INTERNAL         = 1u << 2     /* no consumer outside this pass; may be aliased */
+} brmi_usage;
+
+typedef struct brmi_resource_desc {
+    uint32_t    id;             /* brmi_resource_id */
+    const char* name;           /* the reference's Builtin:: key this resource stands for */
+    uint64_t    bytes;          /* required size */
+    uint32_t    usage;          /* brmi_usage mask */
+    uint32_t    width, height;  /* logical size in pixels (0 for buffers) */
+    uint32_t    bytesPerPixel;
+    uint32_t    tileW, tileH;   /* storage tiling (8x8); pixel (x,y) lives at
+                                   ((y/tileH)*tilesX + x/tileW)*tileW*tileH + (y%tileH)*tileW + x%tileW */
+} brmi_resource_desc;
+
+typedef void (*brmi_declare_cb)(void* user, const brmi_resource_desc* desc);
+
+typedef struct brmi_resource_binding { uint32_t id; void* ptr; uint64_t bytes; } brmi_resource_binding;
+
+/* per-frame host data (UpdateExecutionContext) */
+typedef struct brmi_frame_update {
+    const brmi_camera*    mainCameraHost;   /* host copy of cameras[perFrame.mainCameraIndex] */
+    const brmi_per_frame* perFrameHost;     /* host copy of the per-frame constant buffer */
+    uint32_t              frameIndex;
+} brmi_frame_update;
+
+/* counters read back after a frame (the reference's GPU telemetry, CLodTelemetry.h) */
+typedef struct brmi_counters {
+    uint32_t instancesTested, instancesVisible;
+    uint32_t nodesVisited, bucketRecords;
+    uint32_t meshletsTested, visibleClusters, visibleClustersPhase2;
+    uint32_t droppedRecords, droppedClusters;
+    uint32_t lightPagesUsed;
+    uint32_t reserved[6];
+} brmi_counters;
+
+enum brmi_stage {
+    BRMI_STAGE_CLEAR = 0, BRMI_STAGE_CULL, BRMI_STAGE_RASTER, BRMI_STAGE_DEPTH_COPY, BRMI_STAGE_HZB,
+    BRMI_STAGE_CULL2, BRMI_STAGE_RASTER2, BRMI_STAGE_GBUFFER, BRMI_STAGE_LIGHT_CLUSTER, BRMI_STAGE_SHADE,
+    BRMI_STAGE_COUNT
+};
+
+/* ---- lifecycle (ComputePass phases) -------------------------------------------------------- */
+uint32_t    brmi_abi_version(void);
+int         brmi_create(const brmi_config* cfg, brmi_pass** out);
+int         brmi_declare(brmi_pass* pass, brmi_declare_cb cb, void* user);            /* DeclareResourceUsages */
+int         brmi_set_scene(brmi_pass* pass, const brmi_scene_buffers* scene);          /* provider resolution   */
+int         brmi_setup(brmi_pass* pass, const brmi_resource_binding* b, uint32_t n, brmi_stream stream); /* Setup */
+int         brmi_update(brmi_pass* pass, const brmi_frame_update* upd, brmi_stream stream);               /* Update */
+int         brmi_execute(brmi_pass* pass, brmi_stream stream);                          /* Execute: whole chain */
+void        brmi_destroy(brmi_pass* pass);                                               /* Cleanup */
+const char* brmi_last_error(const brmi_pass* pass);
+
+/* ---- stage-level entry points: one per compute pass the reference's graph schedules ---------
+ * (order of BR/src/Render/GraphExtensions/CLodExtension.cpp:1580-2088 and
+ *  BR/include/Render/RenderGraphBuildHelper.h:220-414) */
+int brmi_clear_visibility(brmi_pass* pass, brmi_stream stream);   /* ClearVisibilityBufferPass */
+int brmi_cull(brmi_pass* pass, uint32_t phase, brmi_stream stream);       /* HierarchicalCullingPass1/2 (K1-K3) */
+int brmi_raster(brmi_pass* pass, uint32_t phase, brmi_stream stream);     /* SoftwareRasterizeClustersPass1/2 (K5) */
+int brmi_depth_copy(brmi_pass* pass, brmi_stream stream);         /* LinearDepthCopyPass (K6) */
+int brmi_build_hzb(brmi_pass* pass, brmi_stream stream);          /* LinearDepthDownsamplePass */
+int brmi_gbuffer(brmi_pass* pass, brmi_stream stream);            /* MaterialHistogram..EvaluateMaterialGroups (K7,K8) */
+int brmi_light_clustering(brmi_pass* pass, brmi_stream stream);   /* ClusterGenerationPass + LightCullingPass (K9,K10) */
+int brmi_shade(brmi_pass* pass, brmi_stream stream);              /* DeferredShadingPass (K11) */
+
+/* ---- introspection ------------------------------------------------------------------------- */
+int brmi_read_counters(brmi_pass* pass, brmi_counters* out, brmi_stream stream);   /* synchronises */
+/* milliseconds per stage for the last execute (collectPassStatistics); synchronises */
+int brmi_stage_times(brmi_pass* pass, float* msOut /* [BRMI_STAGE_COUNT] */);
+/* algorithmic bytes of the last frame per SURVEY.md 8(d): 140*P + sum(144+12V+3T) + 64*M + 16*Mvis + 64*N */
+int brmi_algorithmic_bytes(brmi_pass* pass, uint64_t* perStage /* [BRMI_STAGE_COUNT] */, uint64_t* total);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BRMI_H */

@@ -61,6 +61,11 @@ enum brmi_scene_array {
     BRMI_ARR_PER_FRAME,             /* brmi_per_frame[1] */
     BRMI_ARR_ACTIVE_DRAWS,          /* uint32_t[] per-mesh-instance indices to cull (draw set) */
     BRMI_ARR_SKINNING_MATRICES,     /* float[4][4][]: bone*invBind per (slot,joint); may be empty */
+    BRMI_ARR_LUT_OD_ENERGY,         /* uint16[32][32][32]  opaque-dielectric energy complement (ior, alpha, cos) */
+    BRMI_ARR_LUT_OD_AVG_ENERGY,     /* uint16[32][32]      its cosine-weighted average (ior, alpha) */
+    BRMI_ARR_LUT_IM_ENERGY,         /* uint16[32][32]      ideal-metal energy complement (alpha, cos) */
+    BRMI_ARR_LUT_IM_AVG_ENERGY,     /* uint16[32]          its average (alpha) */
+    BRMI_ARR_LUT_FUZZ_LTC,          /* float[32][32][4]    fuzz LTC aInv, bInv, reflectance, 0 (rough, cos) */
     BRMI_ARR_COUNT
 };
 

@@ -1,0 +1,304 @@
+// orc_cull.cpp -- CPU restatement of the hierarchical culling chain (K1-K3).
+// TEST INFRASTRUCTURE ONLY (see orc_common.h).  PARITY UNPINNED.
+//
+// Follows:
+//   K1  PureComputeObjectCullCS            BR/shaders/ClusterLOD/computeCulling.hlsl:103-190
+//   K2  PureComputeTraverseFrontierCS      BR/shaders/ClusterLOD/computeCulling.hlsl:192-531
+//       CLodPrepareRenderableLeaf          BR/shaders/ClusterLOD/workGraphCulling.hlsl:1711-1784
+//       CLodRefinedChildSuppressesParent   BR/shaders/ClusterLOD/workGraphCulling.hlsl:1631-1700
+//       ProjectedGeometricError            BR/shaders/ClusterLOD/workGraphCulling.hlsl:1522-1541
+//   K3  ClusterCullBody                    BR/shaders/ClusterLOD/workGraphCulling.hlsl:2398-2760
+//       OcclusionCullingPerspectiveTexture2D  BR/shaders/Include/occlusionCulling.hlsli:165-212
+//       sphere_screen_extents              BR/shaders/Include/Misc/sphereScreenExtents.hlsli:14-31
+// Static frame: every group is resident (CLodGroupIsResident == true), streaming requests,
+// telemetry, VSM, voxel and Reyes branches are out of scope.
+//
+// The visible set is order-independent; the list is emitted in the canonical order
+// (instance index, mesh-local segment index, meshlet offset in segment) so that the cluster index
+// stored in the visibility key - and therefore equal-depth tie-breaking - is reproducible.
+#include <algorithm>
+#include <cfloat>
+#include <vector>
+
+#include "orc_common.h"
+
+namespace orc {
+
+struct HzbView {   // linear-depth mip chain (mip 0 = full resolution), row-major per mip
+    const float* data = nullptr; const uint64_t* mipOffsets = nullptr; uint32_t mipCount = 0; uint32_t width = 0, height = 0;
+};
+
+static float3 toViewSpace(float3 c, const mat4& model, const mat4& view) {
+    float4 w = mulPoint(c, model);
+    return xyz(mul(w, view));
+}
+static bool sphereOutsideFrustum(float3 c, float r, const float planes[6][4]) {
+    for (int i = 0; i < 6; i++) {
+        float d = dot(float3{planes[i][0], planes[i][1], planes[i][2]}, c) + planes[i][3];
+        if (d < -r) return true;
+    }
+    return false;
+}
+static float projectedGeometricError(float3 worldCenter, float worldRadius, float errMesh, float errScale, float3 camPos, float zNear, bool ortho) {
+    const float wsErr = errMesh * errScale;
+    if (ortho) return wsErr;
+    float dist = length(worldCenter - camPos);
+    float denom = fmax2(dist - worldRadius, zNear);
+    return wsErr / denom;
+}
+static bool refinedChildSuppressesParent(const brmi_scene_buffers& sc, uint32_t groupsBase, uint32_t childLocal, bool hasChild,
+                                         const mat4& model, float scale, const brmi_culling_camera& lodCam, bool ortho) {
+    if (!hasChild) return false;
+    const brmi_lod_group& g = sc.lodGroups[groupsBase + childLocal];
+    float3 c = xyz(mulPoint(float3{g.centerAndRadius[0], g.centerAndRadius[1], g.centerAndRadius[2]}, model));
+    float r = g.centerAndRadius[3] * scale;
+    float eod = projectedGeometricError(c, r, g.maxParentError, scale, float3{lodCam.positionWorldSpace[0], lodCam.positionWorldSpace[1], lodCam.positionWorldSpace[2]}, lodCam.zNear, ortho);
+    if (eod < lodCam.errorOverDistanceThreshold) return false;
+    return true;   // resident
+}
+
+// sphere_screen_extents + OcclusionCullingPerspectiveTexture2D (explicit-parameter overload)
+static bool occlusionCulled(const HzbView& hzb, const brmi_camera& cam, const mat4& proj, float3 centerVS, float sphereDepth, float radius) {
+    const float viewW = (float)cam.depthResX, viewH = (float)cam.depthResY, mips = (float)cam.numDepthMips;
+    float3 p = centerVS; p.y = -p.y;
+    float rad2 = radius * radius, d = p.z * radius;
+    float hv = std::sqrt(p.x * p.x + p.z * p.z - rad2);
+    float ha = p.x * hv, hb = p.x * radius, hc = p.z * hv;
+    float L = (ha - d) * proj.m[0][0] / (hc + hb);
+    float R = (ha + d) * proj.m[0][0] / (hc - hb);
+    float vv = std::sqrt(p.y * p.y + p.z * p.z - rad2);
+    float va = p.y * vv, vb = p.y * radius, vc = p.z * vv;
+    float B = (va - d) * proj.m[1][1] / (vc + vb);
+    float T = (va + d) * proj.m[1][1] / (vc - vb);
+    L = -L; R = -R;
+    // vUV = saturate(vLBRT.xwzy * (0.5,-0.5,0.5,-0.5) + 0.5)
+    float u0 = saturate(L * 0.5f + 0.5f), v0 = saturate(T * -0.5f + 0.5f), u1 = saturate(R * 0.5f + 0.5f), v1 = saturate(B * -0.5f + 0.5f);
+    float ax0 = u0 * viewW, ay0 = v0 * viewH, ax1 = u1 * viewW, ay1 = v1 * viewH;
+    float ex = ax1 - ax0, ey = ay1 - ay0;
+    float fMip = std::ceil(std::log2(fmax2(ex, ey)));
+    fMip = clampf(fMip, 0.0f, mips - 1.0f);
+    const float sx = cam.UVScaleToNextPowerOf2[0], sy = cam.UVScaleToNextPowerOf2[1];
+    float pu0 = u0 * sx, pv0 = v0 * sy, pu1 = u1 * sx, pv1 = v1 * sy;
+    const float ssx = fmax2(sx, 1e-6f), ssy = fmax2(sy, 1e-6f);
+    const uint32_t mip = (uint32_t)fMip;
+    uint32_t hzbW = (uint32_t)std::nearbyint(viewW / ssx), hzbH = (uint32_t)std::nearbyint(viewH / ssy);
+    hzbW = hzbW < 1 ? 1 : hzbW; hzbH = hzbH < 1 ? 1 : hzbH;
+    uint32_t mw = hzbW >> mip, mh = hzbH >> mip; mw = mw < 1 ? 1 : mw; mh = mh < 1 ? 1 : mh;
+    auto px = [&](float u, uint32_t res) { uint32_t v = (uint32_t)std::floor(u * (float)res); return v > res - 1 ? res - 1 : v; };
+    uint32_t x0 = px(pu0, mw), y0 = px(pv0, mh), x1 = px(pu1, mw), y1 = px(pv1, mh);
+    if (mip >= hzb.mipCount) return false;
+    const float* m = hzb.data + hzb.mipOffsets[mip];
+    float d0 = m[(uint64_t)y0 * mw + x0], d1 = m[(uint64_t)y0 * mw + x1], d2 = m[(uint64_t)y1 * mw + x1], d3 = m[(uint64_t)y1 * mw + x0];
+    float mx = fmax2(fmax2(d0, d1), fmax2(d2, d3));
+    return mx < sphereDepth - radius;
+}
+
+struct VisKey { uint32_t inst, seg, off; brmi_visible_cluster packed; };
+
+struct Bucket { uint32_t inst, group, seg, first, count, slab, pageOff, segFirst; bool replay; };
+struct NodeRec { uint32_t inst, node; bool allowRefine, replay; };
+
+}  // namespace orc
+
+using namespace orc;
+
+extern "C" {
+
+typedef struct orc_cull_params {
+    uint32_t phase;                 // 1 or 2
+    uint32_t enableOcclusion;       // test against `hzb`
+    uint32_t phase2ExpansionFactor;
+    uint32_t capacity;              // visible cluster capacity
+    const float* hzbData; const uint64_t* hzbMipOffsets; uint32_t hzbMipCount;
+    // phase 1 -> phase 2 hand-over (replay buffers), owned by the caller
+    uint32_t* replayNodes;   uint32_t replayNodeCapacity;   uint32_t* replayNodeCount;      // (inst,node) pairs
+    uint32_t* replayMeshlets; uint32_t replayMeshletCapacity; uint32_t* replayMeshletCount; // (inst,seg,localMeshlet,group) quads
+} orc_cull_params;
+
+// Returns the number of visible clusters written (canonical order).  `scene` holds HOST pointers.
+int orc_cull(const brmi_scene_buffers* scp, const orc_cull_params* prm, brmi_visible_cluster* out, uint32_t* outCount, brmi_counters* counters) {
+    const brmi_scene_buffers& sc = *scp;
+    const brmi_per_frame& pf = sc.perFrame[0];
+    const uint32_t viewId = pf.mainCameraIndex;
+    const brmi_camera& cam = sc.cameras[viewId];
+    const brmi_culling_camera& lodCam = sc.cullingCameras[viewId];
+    const bool ortho = cam.isOrtho != 0;
+    const mat4& view = M(cam.view);
+    HzbView hzb; hzb.data = prm->hzbData; hzb.mipOffsets = prm->hzbMipOffsets; hzb.mipCount = prm->hzbMipCount; hzb.width = cam.depthResX; hzb.height = cam.depthResY;
+    const bool occl = prm->enableOcclusion && hzb.data != nullptr && !ortho;
+    brmi_counters cnt{};
+    std::vector<NodeRec> frontier, next;
+    std::vector<Bucket> buckets;
+    std::vector<VisKey> visible;
+    uint32_t factor = prm->phase2ExpansionFactor; factor = factor < 1 ? 1 : (factor > 64 ? 64 : factor);
+    { uint32_t n = 1; for (uint32_t c = 2; c <= 64; c <<= 1) if (c <= factor) n = c; factor = n; }   // PureComputeNormalizePhase2ExpansionFactor
+
+    auto segOfLeaf = [&](const brmi_clod_mesh_metadata& md, const brmi_lod_node& n) -> const brmi_lod_segment& { return sc.lodSegments[md.segmentsBase + n.indexOrOffset]; };
+
+    if (prm->phase == 1) {
+        // K1: object cull, seed the root node of every surviving instance
+        for (uint32_t d = 0; d < sc.activeDrawCount; d++) {
+            const uint32_t ii = sc.activeDraws[d];
+            cnt.instancesTested++;
+            const brmi_per_mesh_instance& inst = sc.perMeshInstance[ii];
+            const mat4& model = M(sc.perObject[inst.perObjectBufferIndex].model);
+            float3 c = toViewSpace(float3{inst.boundingSphere[0], inst.boundingSphere[1], inst.boundingSphere[2]}, model, view);
+            float r = inst.boundingSphere[3] * maxAxisScale(model);
+            bool culled = false;
+            if (std::isnan(c.x) || std::isnan(c.y) || std::isnan(c.z) || std::isinf(c.x) || std::isinf(c.y) || std::isinf(c.z) || std::isnan(r) || std::isinf(r)) culled = true;
+            else culled = sphereOutsideFrustum(c, r, cam.clippingPlanes);
+            if (culled) continue;
+            cnt.instancesVisible++;
+            const brmi_clod_mesh_metadata& md = sc.meshMetadata[sc.clodOffsets[ii].clodMeshMetadataIndex];
+            frontier.push_back({ii, md.rootNode, true, false});
+        }
+    } else {
+        // phase 2: seed from the replay buffers (SeedPureComputeReplayNodesCS / ...ClustersCS)
+        for (uint32_t i = 0; i < *prm->replayNodeCount; i++) frontier.push_back({prm->replayNodes[2 * i], prm->replayNodes[2 * i + 1], true, true});
+        for (uint32_t i = 0; i < *prm->replayMeshletCount; i++) {
+            const uint32_t ii = prm->replayMeshlets[4 * i], segI = prm->replayMeshlets[4 * i + 1], lm = prm->replayMeshlets[4 * i + 2], grp = prm->replayMeshlets[4 * i + 3];
+            const brmi_clod_mesh_metadata& md = sc.meshMetadata[sc.clodOffsets[ii].clodMeshMetadataIndex];
+            const brmi_lod_segment& seg = sc.lodSegments[md.segmentsBase + segI];
+            const brmi_group_page_map_entry& pe = sc.groupPageMap[md.pageMapBase + seg.pageIndex];
+            buckets.push_back({ii, grp, segI, lm, 1, pe.slabDescriptorIndex, pe.slabByteOffset, seg.firstMeshletInPage, true});
+        }
+    }
+
+    // K2: level-synchronous BFS
+    uint32_t levels = 0;
+    while (!frontier.empty() && levels < 64) {
+        next.clear();
+        for (const NodeRec& rec : frontier) {
+            cnt.nodesVisited++;
+            const brmi_per_mesh_instance& inst = sc.perMeshInstance[rec.inst];
+            const brmi_clod_mesh_metadata& md = sc.meshMetadata[sc.clodOffsets[rec.inst].clodMeshMetadataIndex];
+            const brmi_per_mesh& pm = sc.perMesh[inst.perMeshBufferIndex];
+            const bool skinned = (pm.vertexFlags & BRMI_VERTEX_SKINNED) != 0;
+            const brmi_per_object& obj = sc.perObject[inst.perObjectBufferIndex];
+            const mat4& model = M(obj.model);
+            const brmi_lod_node& node = sc.lodNodes[md.lodNodesBase + rec.node];
+            const float scale = maxAxisScale(model);
+            float3 cullC = skinned ? float3{inst.boundingSphere[0], inst.boundingSphere[1], inst.boundingSphere[2]} : float3{node.cullCenterAndRadius[0], node.cullCenterAndRadius[1], node.cullCenterAndRadius[2]};
+            float cullR = skinned ? inst.boundingSphere[3] : node.cullCenterAndRadius[3];
+            float3 cVS = toViewSpace(cullC, model, view);
+            float rW = cullR * scale;
+            if (!rec.replay && sphereOutsideFrustum(cVS, rW, cam.clippingPlanes)) continue;
+            const float3 camPos{lodCam.positionWorldSpace[0], lodCam.positionWorldSpace[1], lodCam.positionWorldSpace[2]};
+            if (node.isLeaf != BRMI_NODE_INTERNAL) {
+                const brmi_lod_group& g = sc.lodGroups[md.groupsBase + node.ownerGroupId];
+                float3 gc = xyz(mulPoint(float3{g.centerAndRadius[0], g.centerAndRadius[1], g.centerAndRadius[2]}, model));
+                float gr = g.centerAndRadius[3] * scale;
+                float eod = projectedGeometricError(gc, gr, node.maxQuadricError, scale, camPos, lodCam.zNear, ortho);
+                if (!(rec.allowRefine && eod >= lodCam.errorOverDistanceThreshold)) continue;
+                if (refinedChildSuppressesParent(sc, md.groupsBase, node.countMinusOne - 1u, node.countMinusOne != 0u, model, scale, lodCam, ortho)) continue;
+                const brmi_lod_segment& seg = segOfLeaf(md, node);
+                if (seg.meshletCount == 0) continue;
+                const brmi_group_page_map_entry& pe = sc.groupPageMap[md.pageMapBase + seg.pageIndex];
+                if (pe.slabDescriptorIndex == 0) continue;
+                uint32_t base = seg.firstMeshletInPage, remaining = seg.meshletCount;
+                while (remaining > 0) {
+                    uint32_t chunk = remaining < factor ? remaining : factor;
+                    buckets.push_back({rec.inst, node.ownerGroupId, node.indexOrOffset, base, chunk, pe.slabDescriptorIndex, pe.slabByteOffset, seg.firstMeshletInPage, rec.replay});
+                    base += chunk; remaining -= chunk;
+                }
+                continue;
+            }
+            float3 lc = xyz(mulPoint(float3{node.lodCenterAndRadius[0], node.lodCenterAndRadius[1], node.lodCenterAndRadius[2]}, model));
+            float lr = node.lodCenterAndRadius[3] * scale;
+            float nodeEod = projectedGeometricError(lc, lr, node.maxQuadricError, scale, camPos, lodCam.zNear, ortho);
+            if (!(rec.allowRefine && nodeEod >= lodCam.errorOverDistanceThreshold)) continue;
+            if (occl) {
+                bool oc;
+                if (rec.replay) oc = occlusionCulled(hzb, cam, M(cam.projection), cVS, -cVS.z, rW);
+                else {
+                    const mat4& prevModel = M(obj.prevModel);
+                    float3 pc = toViewSpace(cullC, prevModel, M(cam.prevView));
+                    oc = occlusionCulled(hzb, cam, M(cam.prevUnjitteredProjection), pc, -pc.z, cullR * maxAxisScale(prevModel));
+                }
+                if (oc) {
+                    if (!rec.replay && prm->replayNodes && *prm->replayNodeCount < prm->replayNodeCapacity) {
+                        prm->replayNodes[2 * *prm->replayNodeCount] = rec.inst; prm->replayNodes[2 * *prm->replayNodeCount + 1] = rec.node; (*prm->replayNodeCount)++;
+                    }
+                    continue;
+                }
+            }
+            const uint32_t childCount = (node.countMinusOne + 1u) < BRMI_BVH_MAX_CHILDREN ? (node.countMinusOne + 1u) : BRMI_BVH_MAX_CHILDREN;
+            for (uint32_t k = 0; k < childCount; k++) {
+                const uint32_t childId = node.indexOrOffset + k;
+                const brmi_lod_node& ch = sc.lodNodes[md.lodNodesBase + childId];
+                float3 cc = skinned ? cullC : float3{ch.cullCenterAndRadius[0], ch.cullCenterAndRadius[1], ch.cullCenterAndRadius[2]};
+                float cr = skinned ? cullR : ch.cullCenterAndRadius[3];
+                float3 ccVS = toViewSpace(cc, model, view);
+                if (!rec.replay && sphereOutsideFrustum(ccVS, cr * scale, cam.clippingPlanes)) continue;
+                if (ch.isLeaf == BRMI_NODE_INTERNAL) {
+                    float3 wc = xyz(mulPoint(float3{ch.lodCenterAndRadius[0], ch.lodCenterAndRadius[1], ch.lodCenterAndRadius[2]}, model));
+                    float e = projectedGeometricError(wc, ch.lodCenterAndRadius[3] * scale, ch.maxQuadricError, scale, camPos, lodCam.zNear, ortho);
+                    if (e < lodCam.errorOverDistanceThreshold) continue;
+                }
+                next.push_back({rec.inst, childId, true, rec.replay});
+            }
+        }
+        frontier.swap(next);
+        levels++;
+    }
+
+    // K3: per-meshlet cull
+    cnt.bucketRecords = (uint32_t)buckets.size();
+    for (const Bucket& b : buckets) {
+        if (b.slab == 0) continue;
+        const brmi_per_mesh_instance& inst = sc.perMeshInstance[b.inst];
+        const brmi_clod_mesh_metadata& md = sc.meshMetadata[sc.clodOffsets[b.inst].clodMeshMetadataIndex];
+        const brmi_per_object& obj = sc.perObject[inst.perObjectBufferIndex];
+        const mat4& model = M(obj.model);
+        const float scale = maxAxisScale(model);
+        const uint8_t* slab = sc.slabs[b.slab];
+        const brmi_page_header* hdr = pageHeader(slab, b.pageOff);
+        const uint32_t groupId = b.group;
+        for (uint32_t m = 0; m < b.count; m++) {
+            const uint32_t lm = b.first + m;
+            cnt.meshletsTested++;
+            if (lm >= hdr->meshletCount) continue;
+            const brmi_meshlet_descriptor& desc = *meshletDesc(slab, b.pageOff, hdr->descriptorOffset, lm);
+            float3 bc{desc.bounds[0], desc.bounds[1], desc.bounds[2]};
+            float3 cVS = toViewSpace(bc, model, view);
+            float rW = desc.bounds[3] * scale;
+            bool survives = b.replay || !sphereOutsideFrustum(cVS, rW, cam.clippingPlanes);
+            if (survives) {
+                const int32_t refined = descRefinedGroup(desc);
+                if (refinedChildSuppressesParent(sc, md.groupsBase, (uint32_t)refined, refined >= 0, model, scale, lodCam, ortho)) survives = false;
+            }
+            if (survives && occl) {
+                bool oc;
+                if (b.replay) oc = occlusionCulled(hzb, cam, M(cam.projection), cVS, -cVS.z, rW);
+                else {
+                    const mat4& prevModel = M(obj.prevModel);
+                    float3 pc = toViewSpace(bc, prevModel, M(cam.prevView));
+                    oc = occlusionCulled(hzb, cam, M(cam.prevUnjitteredProjection), pc, -pc.z, desc.bounds[3] * maxAxisScale(prevModel));
+                }
+                if (oc) {
+                    if (!b.replay && prm->replayMeshlets && *prm->replayMeshletCount < prm->replayMeshletCapacity) {
+                        uint32_t k = *prm->replayMeshletCount;
+                        prm->replayMeshlets[4 * k] = b.inst; prm->replayMeshlets[4 * k + 1] = b.seg; prm->replayMeshlets[4 * k + 2] = lm; prm->replayMeshlets[4 * k + 3] = b.group; (*prm->replayMeshletCount)++;
+                    }
+                    survives = false;
+                }
+            }
+            if (!survives) continue;
+            visible.push_back({b.inst, b.seg, lm - b.segFirst, packVisibleCluster(viewId, b.inst, lm, groupId, b.slab, b.pageOff)});
+        }
+    }
+    std::sort(visible.begin(), visible.end(), [](const VisKey& a, const VisKey& b) {
+        if (a.inst != b.inst) return a.inst < b.inst;
+        if (a.seg != b.seg) return a.seg < b.seg;
+        return a.off < b.off;
+    });
+    uint32_t n = (uint32_t)visible.size();
+    if (n > prm->capacity) { cnt.droppedClusters = n - prm->capacity; n = prm->capacity; }
+    for (uint32_t i = 0; i < n; i++) out[i] = visible[i].packed;
+    *outCount = n;
+    if (prm->phase == 1) cnt.visibleClusters = n; else cnt.visibleClustersPhase2 = n;
+    if (counters) *counters = cnt;
+    return 0;
+}
+
+}  // extern "C"

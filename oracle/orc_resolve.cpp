@@ -1,0 +1,174 @@
+// orc_resolve.cpp -- CPU restatement of the G-buffer reconstruction from the visibility buffer (K8).
+// TEST INFRASTRUCTURE ONLY (see orc_common.h).  PARITY UNPINNED.
+//
+// Follows:
+//   EvaluateGBufferOptimized                    BR/shaders/gbuffer.hlsl:4-35
+//   ResolveClodCommonSampleFromVisKeyWithFace   BR/shaders/Include/clodResolveCommon.hlsli:1414-1721
+//   LoadMeshletResolveData_Wave                 BR/shaders/Include/clodResolveCommon.hlsli:716-809
+//   DecodeTriangleCompact                       BR/shaders/Include/clodResolveCommon.hlsli:1347-1378
+//   CalcFullBary / InterpolateWithDeriv         BR/shaders/Include/clodResolveCommon.hlsli:104-161
+//   UnpackSnorm16x2 / OctDecodeNormal           BR/shaders/Include/clodResolveCommon.hlsli:627-655
+//   ComputeClodMotionVector                     BR/shaders/Include/clodResolveCommon.hlsli:1380-1389
+//   SampleMaterialEvalFromUvCache               BR/shaders/Include/utilities.hlsli:1850-2075  (no PSO_*_TEXTURE define set)
+//   ResolveCanonicalOpenPBRSurface              BR/shaders/Include/utilities.hlsli:136-161
+// Scope: triangle clusters (no Reyes / voxel), constant-factor materials, no vertex colours.
+// G-buffer formats: BR/include/Render/RenderGraphBuildHelper.h:41-139, BR/src/Renderer.cpp:1618.
+#include "orc_common.h"
+
+namespace orc {
+
+struct Bary { float3 lambda, ddx, ddy; };
+
+static Bary calcFullBary(float4 pt0, float4 pt1, float4 pt2, float2 pixelNdc, float2 winSize) {
+    Bary r;
+    const float3 invW{rcp(pt0.w), rcp(pt1.w), rcp(pt2.w)};
+    const float2 ndc0{pt0.x * invW.x, pt0.y * invW.x}, ndc1{pt1.x * invW.y, pt1.y * invW.y}, ndc2{pt2.x * invW.z, pt2.y * invW.z};
+    const float2 a = ndc2 - ndc1, b = ndc0 - ndc1;
+    const float invDet = rcp(a.x * b.y - a.y * b.x);
+    r.ddx = float3{ndc1.y - ndc2.y, ndc2.y - ndc0.y, ndc0.y - ndc1.y} * invDet * invW;
+    r.ddy = float3{ndc2.x - ndc1.x, ndc0.x - ndc2.x, ndc1.x - ndc0.x} * invDet * invW;
+    float ddxSum = dot(r.ddx, float3{1, 1, 1});
+    float ddySum = dot(r.ddy, float3{1, 1, 1});
+    const float2 delta = pixelNdc - ndc0;
+    const float interpInvW = invW.x + delta.x * ddxSum + delta.y * ddySum;
+    const float interpW = rcp(interpInvW);
+    r.lambda.x = interpW * (invW.x + delta.x * r.ddx.x + delta.y * r.ddy.x);
+    r.lambda.y = interpW * (0.0f + delta.x * r.ddx.y + delta.y * r.ddy.y);
+    r.lambda.z = interpW * (0.0f + delta.x * r.ddx.z + delta.y * r.ddy.z);
+    r.ddx = r.ddx * (2.0f / winSize.x);
+    r.ddy = r.ddy * (2.0f / winSize.y);
+    ddxSum *= (2.0f / winSize.x);
+    ddySum *= (2.0f / winSize.y);
+    r.ddy = r.ddy * -1.0f;
+    ddySum *= -1.0f;
+    const float interpW_ddx = 1.0f / (interpInvW + ddxSum);
+    const float interpW_ddy = 1.0f / (interpInvW + ddySum);
+    r.ddx = interpW_ddx * (r.lambda * interpInvW + r.ddx) - r.lambda;
+    r.ddy = interpW_ddy * (r.lambda * interpInvW + r.ddy) - r.lambda;
+    return r;
+}
+static inline float interp(const Bary& b, float v0, float v1, float v2) { return dot(float3{v0, v1, v2}, b.lambda); }
+
+static float3 octDecodeNormal(uint32_t packed) {
+    const int32_t sp = (int32_t)packed;
+    const int32_t x = (int32_t)((uint32_t)sp << 16) >> 16, y = sp >> 16;
+    const float ex = fmax2(-1.0f, (float)x / 32767.0f), ey = fmax2(-1.0f, (float)y / 32767.0f);
+    float3 v{ex, ey, 1.0f - std::fabs(ex) - std::fabs(ey)};
+    if (v.z < 0.0f) {
+        const float fx = (1.0f - std::fabs(v.y)) * (v.x >= 0.0f ? 1.0f : -1.0f);
+        const float fy = (1.0f - std::fabs(v.x)) * (v.y >= 0.0f ? 1.0f : -1.0f);
+        v.x = fx; v.y = fy;
+    }
+    return normalize(v);
+}
+
+struct GBufferOut {
+    float* normals; uint32_t* albedo; uint64_t* coat; uint64_t* emissive; uint64_t* fuzz; uint32_t* metallicRoughness; uint32_t* motion;
+};
+
+static bool resolvePixel(const brmi_scene_buffers& sc, const brmi_visible_cluster* clusters, uint32_t clusterCount, uint64_t key,
+                         uint32_t px, uint32_t py, uint64_t idx, const GBufferOut& o) {
+    if (key == BRMI_VIS_EMPTY) return false;
+    const brmi_per_frame& pf = sc.perFrame[0];
+    const brmi_camera& cam = sc.cameras[pf.mainCameraIndex];
+    const uint32_t triId = (uint32_t)(key & 0x7Fu);
+    const uint32_t clusterIndex = (uint32_t)((key >> BRMI_VIS_TRI_BITS) & 0x3FFFFFFu);
+    if (clusterIndex >= clusterCount) return false;
+    const brmi_visible_cluster& pc = clusters[clusterIndex];
+    const uint32_t instanceID = vcInstanceID(pc), localMeshlet = vcLocalMeshlet(pc);
+    const brmi_per_mesh_instance& inst = sc.perMeshInstance[instanceID];
+    const brmi_per_mesh& mesh = sc.perMesh[inst.perMeshBufferIndex];
+    const uint8_t* slab = sc.slabs[vcSlabDescriptor(pc)];
+    const uint32_t pageOff = vcPageByteOffset(pc);
+    const brmi_page_header& hdr = *pageHeader(slab, pageOff);
+    const brmi_meshlet_descriptor& desc = *meshletDesc(slab, pageOff, hdr.descriptorOffset, localMeshlet);
+    if (triId >= descTriangleCount(desc)) return false;
+    uint32_t tri[3]; decodeTriangle(slab, pageOff + hdr.triangleStreamOffset, desc.triangleByteOffset, triId, tri);
+    const uint32_t posBase = pageOff + hdr.positionBitstreamOffset;
+    float3 p[3], n[3];
+    const bool skinned = (mesh.vertexFlags & BRMI_VERTEX_SKINNED) != 0;
+    for (int k = 0; k < 3; k++) {
+        p[k] = loadPosition(slab, hdr.compressedPositionQuantExp, posBase, desc.positionBitOffset, tri[k]);
+        n[k] = octDecodeNormal(load32(slab, pageOff + hdr.normalArrayOffset + (desc.vertexAttributeOffset + tri[k]) * 4u));
+        if (skinned) {   // ApplyClodSkinning
+            uint32_t joints[8] = {0, 0, 0, 0, 0, 0, 0, 0}; float weights[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (hdr.attributeMask & BRMI_PAGE_ATTRIBUTE_JOINTS) std::memcpy(joints, slab + pageOff + hdr.jointArrayOffset + (desc.vertexAttributeOffset + tri[k]) * 32u, 32);
+            if (hdr.attributeMask & BRMI_PAGE_ATTRIBUTE_WEIGHTS) std::memcpy(weights, slab + pageOff + hdr.weightArrayOffset + (desc.vertexAttributeOffset + tri[k]) * 32u, 32);
+            const mat4 skin = buildSkinMatrix(sc, inst.skinningInstanceSlot, joints, weights);
+            p[k] = xyz(mulPoint(p[k], skin));
+            n[k] = mul3(n[k], skin);
+        }
+    }
+    const brmi_per_object& obj = sc.perObject[inst.perObjectBufferIndex];
+    const brmi_material_info& mat = sc.materials[mesh.materialDataIndex];
+
+    const mat4 viewProj = mul(M(cam.view), M(cam.projection));
+    const mat4 objectToClip = mul(M(obj.model), viewProj);
+    const float4 clip0 = mulPoint(p[0], objectToClip), clip1 = mulPoint(p[1], objectToClip), clip2 = mulPoint(p[2], objectToClip);
+    const float2 winSize{(float)pf.screenResX, (float)pf.screenResY};
+    const float2 pixelUv{((float)px + 0.5f) / winSize.x, ((float)py + 0.5f) / winSize.y};
+    const float2 pixelNdc{pixelUv.x * 2.0f - 1.0f, (1.0f - pixelUv.y) * 2.0f - 1.0f};
+    const Bary bary = calcFullBary(clip0, clip1, clip2, pixelNdc, winSize);
+
+    const float3 posOS{interp(bary, p[0].x, p[1].x, p[2].x), interp(bary, p[0].y, p[1].y, p[2].y), interp(bary, p[0].z, p[1].z, p[2].z)};
+    const float3 worldPosition = xyz(mulPoint(posOS, M(obj.model)));
+    const float3 normalOS = normalize(float3{interp(bary, n[0].x, n[1].x, n[2].x), interp(bary, n[0].y, n[1].y, n[2].y), interp(bary, n[0].z, n[1].z, n[2].z)});
+    const mat4& normalMatrix = *reinterpret_cast<const mat4*>(sc.normalMatrices + (size_t)obj.normalMatrixBufferIndex * 16u);
+    const float3 worldNormal = normalize(mul3(normalOS, normalMatrix));
+
+    // SampleMaterialEvalFromUvCache with no texture permutation defines: factors only
+    const float3 vertexColor{1.0f, 1.0f, 1.0f};
+    const float3 baseColor = float3{mat.baseColorFactor[0], mat.baseColorFactor[1], mat.baseColorFactor[2]} * vertexColor;
+    const float metallic = mat.metallicFactor, roughness = mat.roughnessFactor, ao = 1.0f;
+    const float3 emissiveIn{mat.emissiveFactor[0], mat.emissiveFactor[1], mat.emissiveFactor[2]};
+    const brmi_openpbr_material_info& op = sc.openpbrMaterials[mat.openPBRMaterialDataIndex];
+    const float3 canonicalEmissive = float3{op.emissionColor[0], op.emissionColor[1], op.emissionColor[2]} * op.emissionLuminance;
+    const float3 coatColor = saturate(float3{op.coatColor[0], op.coatColor[1], op.coatColor[2]});
+    const float coatWeight = saturate(op.coatWeight), coatRoughness = saturate(op.coatRoughness);
+    const float3 fuzzColor = saturate(float3{op.fuzzColor[0], op.fuzzColor[1], op.fuzzColor[2]});
+    const float fuzzWeight = saturate(op.fuzzWeight), fuzzRoughness = saturate(op.fuzzRoughness);
+    const float3 emissive = dot(emissiveIn, emissiveIn) > 0.0f ? emissiveIn : canonicalEmissive;
+
+    // ComputeClodMotionVector
+    const mat4 unjVP = mul(M(cam.view), M(cam.unjitteredProjection));
+    const mat4 prevVP = mul(M(cam.prevView), M(cam.prevUnjitteredProjection));
+    const float4 clipCur = mulPoint(worldPosition, unjVP);
+    const float3 prevWorld = xyz(mulPoint(posOS, M(obj.prevModel)));
+    const float4 clipPrev = mulPoint(prevWorld, prevVP);
+    const float2 mv{clipCur.x / clipCur.w - clipPrev.x / clipPrev.w, clipCur.y / clipCur.w - clipPrev.y / clipPrev.w};
+
+    o.normals[idx * 4 + 0] = worldNormal.x; o.normals[idx * 4 + 1] = worldNormal.y; o.normals[idx * 4 + 2] = worldNormal.z;
+    o.normals[idx * 4 + 3] = (float)mat.openPBRMaterialDataIndex;
+    o.albedo[idx] = pack_unorm4(baseColor.x, baseColor.y, baseColor.z, ao);
+    o.coat[idx] = pack_half4(coatColor.x, coatColor.y, coatColor.z, coatWeight);
+    o.emissive[idx] = pack_half4(emissive.x, emissive.y, emissive.z, 0.0f);
+    o.fuzz[idx] = pack_half4(fuzzColor.x, fuzzColor.y, fuzzColor.z, fuzzRoughness);
+    o.metallicRoughness[idx] = pack_unorm4(metallic, roughness, coatRoughness, fuzzWeight);
+    o.motion[idx] = (uint32_t)f32_to_f16(mv.x) | ((uint32_t)f32_to_f16(mv.y) << 16);
+    return true;
+}
+
+}  // namespace orc
+
+using namespace orc;
+
+extern "C" {
+
+// All images are linear W x H.  Pixels without geometry are left untouched (the reference does not
+// write them); callers pass zero-initialised buffers.
+int orc_gbuffer(const brmi_scene_buffers* sc, const brmi_visible_cluster* clusters, uint32_t clusterCount, const uint64_t* vis,
+                uint32_t W, uint32_t H, uint32_t bandY0, uint32_t bandY1,
+                float* normals, uint32_t* albedo, uint64_t* coat, uint64_t* emissive, uint64_t* fuzz, uint32_t* metallicRoughness, uint32_t* motion,
+                int threads) {
+    GBufferOut o{normals, albedo, coat, emissive, fuzz, metallicRoughness, motion};
+    if (bandY1 == 0) { bandY0 = 0; bandY1 = H; }
+#pragma omp parallel for schedule(dynamic, 8) num_threads(threads > 0 ? threads : 1)
+    for (int64_t y = bandY0; y < (int64_t)bandY1; y++)
+        for (uint32_t x = 0; x < W; x++) {
+            const uint64_t idx = (uint64_t)y * W + x;
+            resolvePixel(*sc, clusters, clusterCount, vis[idx], x, (uint32_t)y, idx, o);
+        }
+    return 0;
+}
+
+}  // extern "C"

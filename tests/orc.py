@@ -1,0 +1,145 @@
+"""ctypes wrapper over oracle/_build/liboracle.so (TEST INFRASTRUCTURE: the CPU checker).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from basicrenderer_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_SO = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
+vp, u32, u64 = C.c_void_p, C.c_uint32, C.c_uint64
+
+
+class CullParams(C.Structure):
+    _fields_ = [("phase", u32), ("enableOcclusion", u32), ("phase2ExpansionFactor", u32), ("capacity", u32),
+                ("hzbData", vp), ("hzbMipOffsets", vp), ("hzbMipCount", u32),
+                ("replayNodes", vp), ("replayNodeCapacity", u32), ("replayNodeCount", vp),
+                ("replayMeshlets", vp), ("replayMeshletCapacity", u32), ("replayMeshletCount", vp)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(ORACLE_SO):
+            raise RuntimeError(f"{ORACLE_SO} missing: run `make oracle`")
+        _lib = C.CDLL(ORACLE_SO)
+    return _lib
+
+
+def P(a):
+    return a.ctypes.data_as(vp) if a is not None else None
+
+
+class OracleFrame:
+    """Runs the CPU restatement of the whole chain on a Scene; all images linear [H, W]."""
+
+    def __init__(self, scene, threads=None, capacity=1 << 22):
+        self.scene, self.W, self.H = scene, scene.width, scene.height
+        self.sb = scene.host_buffers()
+        self.threads = threads or os.cpu_count()
+        self.capacity = capacity
+        self.clusters = np.zeros((capacity, 4), dtype=np.uint32)
+        self.count = 0
+        self.counters = capi.Counters()
+
+    def cull(self, phase=1, occlusion=False, hzb=None, expansion=2):
+        prm = CullParams()
+        prm.phase, prm.enableOcclusion, prm.phase2ExpansionFactor, prm.capacity = phase, 1 if occlusion else 0, expansion, self.capacity
+        n = u32(0)
+        rc = lib().orc_cull(C.byref(self.sb), C.byref(prm), P(self.clusters), C.byref(n), C.byref(self.counters))
+        assert rc == 0
+        self.count = n.value
+        return self.clusters[: self.count]
+
+    def raster(self, band=(0, 0), first=0, count=None):
+        W, H = self.W, self.H
+        if not hasattr(self, "vis"):
+            self.vis = np.full((H, W), 0xFFFFFFFFFFFFFFFF, dtype=np.uint64)
+        cnt = self.count if count is None else count
+        lib().orc_raster(C.byref(self.sb), P(self.clusters), u32(first), u32(cnt), P(self.vis), u32(W), u32(H), u32(band[0]), u32(band[1]), C.c_int(self.threads))
+        return self.vis
+
+    def depth_copy(self):
+        self.depth = np.zeros((self.H, self.W), dtype=np.float32)
+        lib().orc_depth_copy(P(self.vis), P(self.depth), u64(self.W * self.H), C.c_int(self.threads))
+        return self.depth
+
+    def gbuffer(self, band=(0, 0)):
+        H, W = self.H, self.W
+        self.normals = np.zeros((H, W, 4), dtype=np.float32)
+        self.albedo = np.zeros((H, W), dtype=np.uint32)
+        self.coat = np.zeros((H, W), dtype=np.uint64)
+        self.emissive = np.zeros((H, W), dtype=np.uint64)
+        self.fuzz = np.zeros((H, W), dtype=np.uint64)
+        self.mr = np.zeros((H, W), dtype=np.uint32)
+        self.motion = np.zeros((H, W), dtype=np.uint32)
+        lib().orc_gbuffer(C.byref(self.sb), P(self.clusters), u32(self.count), P(self.vis), u32(W), u32(H), u32(band[0]), u32(band[1]),
+                          P(self.normals), P(self.albedo), P(self.coat), P(self.emissive), P(self.fuzz), P(self.mr), P(self.motion), C.c_int(self.threads))
+
+    def cluster_planes(self):
+        cam = self.scene.arrays["cameras"].view(np.float32)
+        pf = self.scene.arrays["perFrame"].view(np.uint32)
+        # brmi_camera: fov, aspect, zNear, zFar follow 16 + 9*64 + 96 bytes = 688 B -> float index 172
+        zNear, zFar = float(cam[174]), float(cam[175])
+        gz, nearSlices = int(pf[17]), int(pf[18])
+        zSplit = float(self.scene.arrays["perFrame"].view(np.float32)[19])
+        planes = np.zeros(2 * gz, dtype=np.float32)
+        lib().orc_cluster_planes(C.c_float(zNear), C.c_float(zFar), u32(gz), u32(nearSlices), C.c_float(zSplit), P(planes))
+        return planes
+
+    def light_cluster(self):
+        pf = self.scene.arrays["perFrame"].view(np.uint32)
+        gx, gy, gz = int(pf[15]), int(pf[16]), int(pf[17])
+        n = gx * gy * gz
+        self.pool = n * 10
+        self.light_clusters = np.zeros((n, 12), dtype=np.uint32)
+        self.light_pages = np.zeros((self.pool, 14), dtype=np.uint32)
+        used = u32(0)
+        self.planes = self.cluster_planes()
+        lib().orc_light_cluster(C.byref(self.sb), P(self.planes), P(self.light_clusters), P(self.light_pages), u32(self.pool), C.byref(used))
+        self.pages_used = used.value
+
+    def shade(self, band=(0, 0), punctual=True, clustered=True):
+        self.hdr = np.zeros((self.H, self.W), dtype=np.uint64)
+        lib().orc_shade(C.byref(self.sb), u32(self.W), u32(self.H), u32(band[0]), u32(band[1]), P(self.depth), P(self.normals), P(self.albedo), P(self.coat),
+                        P(self.emissive), P(self.fuzz), P(self.mr), P(self.light_clusters), P(self.light_pages), u32(self.pool),
+                        u32(1 if punctual else 0), u32(1 if clustered else 0), P(self.hdr), C.c_int(self.threads))
+        return self.hdr
+
+    def run(self):
+        self.cull()
+        self.raster()
+        self.depth_copy()
+        self.gbuffer()
+        self.light_cluster()
+        self.shade()
+        return self
+
+
+def hdr_to_float(hdr_u64):
+    """[H,W] uint64 (4 x f16) -> [H,W,4] float32"""
+    return hdr_u64.view(np.float16).reshape(hdr_u64.shape + (4,)).astype(np.float32)
+
+
+def canonical_ids(vis, clusters):
+    """Visibility keys -> canonical (instance, group, page, meshlet, tri) tuples packed in 2 x u64; empty stays ~0."""
+    empty = vis == np.uint64(0xFFFFFFFFFFFFFFFF)
+    tri = (vis & np.uint64(0x7F)).astype(np.uint64)
+    ci = ((vis >> np.uint64(7)) & np.uint64(0x3FFFFFF)).astype(np.int64)
+    ci = np.where(empty, 0, ci)
+    c = clusters[np.clip(ci, 0, max(len(clusters) - 1, 0))] if len(clusters) else np.zeros(vis.shape + (4,), dtype=np.uint32)
+    x, y, z = c[..., 0].astype(np.uint64), c[..., 1].astype(np.uint64), c[..., 2].astype(np.uint64)
+    a = (x << np.uint64(32)) | y                      # view|instance , meshlet|group_lo
+    b = (z << np.uint64(32)) | tri                    # group_hi|slab|page , tri
+    depth = vis >> np.uint64(33)
+    a = np.where(empty, np.uint64(0xFFFFFFFFFFFFFFFF), a)
+    b = np.where(empty, np.uint64(0xFFFFFFFFFFFFFFFF), b)
+    depth = np.where(empty, np.uint64(0xFFFFFFFFFFFFFFFF), depth)
+    return a, b, depth
