@@ -1,0 +1,400 @@
+// brmi_api.hip -- the C ABI of libbrmi.so (include/brmi.h): pass lifecycle and stage scheduling.
+//
+// Host side of the drop-in.  Mirrors the five phases of the reference's ComputePass /
+// IRenderGraphExtension (DeclareResourceUsages / Setup / Update / Execute / Cleanup) and the order
+// in which CLodExtension + RenderGraphBuildHelper schedule the chain
+// (BR/src/Render/GraphExtensions/CLodExtension.cpp:1580-2088, BR/include/Render/RenderGraphBuildHelper.h:220-414).
+// The library never allocates device memory: the graph (caller) owns every resource, exactly as
+// in the reference; kernels are enqueued on the caller's stream and nothing here synchronises
+// except the explicit read-back calls.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "brmi_device.h"
+#include "brmi_internal.h"
+
+namespace brmi {
+
+__global__ void k_debug_arith(const float* a, const float* b, float* outDiv, float* outSqrt, uint32_t* outHalf, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    outDiv[i] = a[i] / b[i];
+    outSqrt[i] = sqrtf(fabsf(a[i]));
+    outHalf[i] = f32_to_f16_bits(a[i]);
+}
+
+int fail(brmi_pass* p, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+    if (p) p->err = buf;
+    return code;
+}
+
+static uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+static const char* kResNames[BRMI_RES_COUNT] = {
+    "Builtin::PrimaryCamera::VisibilityTexture", "Builtin::PrimaryCamera::LinearDepthMap", "Builtin::GBuffer::Normals", "Builtin::GBuffer::Albedo",
+    "Builtin::GBuffer::Coat", "Builtin::GBuffer::Emissive", "Builtin::GBuffer::Fuzz", "Builtin::GBuffer::MetallicRoughness", "Builtin::GBuffer::MotionVectors",
+    "Builtin::Color::HDRColorTarget", "Builtin::CLod::VisibleClusters", "Builtin::Light::ClusterBuffer", "Builtin::Light::PagesBuffer",
+    "Builtin::PrimaryCamera::LinearDepthMap(mips)", "brmi::Workspace"};
+static const uint32_t kResBpp[BRMI_RES_COUNT] = {8, 4, 16, 4, 8, 8, 8, 4, 4, 8, 0, 0, 0, 4, 0};
+
+static void compute_sizes(brmi_pass* p) {
+    const brmi_config& c = p->cfg;
+    p->tilesX = (c.width + 7) / 8; p->tilesY = (c.height + 7) / 8;
+    p->paddedPixels = (uint64_t)p->tilesX * p->tilesY * 64;
+    p->bandY0 = c.bandY0; p->bandY1 = (c.bandY1 == 0 || c.bandY1 > c.height) ? c.height : c.bandY1;
+    if (p->bandY0 >= p->bandY1) p->bandY0 = 0;
+    { const uint32_t t0 = p->bandY0 / 8, t1 = (p->bandY1 + 7) / 8; p->bandFirstPixel = (uint64_t)t0 * p->tilesX * 64; p->bandPixelCount = (uint64_t)(t1 - t0) * p->tilesX * 64; }
+    p->numLightClusters = c.lightClusterSize[0] * c.lightClusterSize[1] * c.lightClusterSize[2];
+    p->lightPagePool = p->numLightClusters * BRMI_LIGHT_PAGES_PER_CLUSTER;
+    for (int i = 0; i < BRMI_RES_COUNT; i++) p->resNeed[i] = 0;
+    for (int i = BRMI_RES_VISIBILITY; i <= BRMI_RES_HDR_COLOR; i++) p->resNeed[i] = p->paddedPixels * kResBpp[i];
+    p->resNeed[BRMI_RES_VISIBLE_CLUSTERS] = (uint64_t)c.maxVisibleClusters * 16;
+    p->resNeed[BRMI_RES_LIGHT_CLUSTERS] = (uint64_t)p->numLightClusters * sizeof(brmi_light_cluster);
+    p->resNeed[BRMI_RES_LIGHT_PAGES] = (uint64_t)p->lightPagePool * sizeof(brmi_light_page);
+    // HZB: mip chain of the power-of-two padded linear depth (built only with occlusion culling)
+    p->hzbMipOffsets.clear(); p->hzbMipW.clear(); p->hzbMipH.clear();
+    uint64_t hzbFloats = 0;
+    if (c.enableOcclusionCulling) {
+        uint32_t w = 1, h = 1; while (w < c.width) w <<= 1; while (h < c.height) h <<= 1;
+        for (;;) { p->hzbMipOffsets.push_back(hzbFloats); p->hzbMipW.push_back(w); p->hzbMipH.push_back(h); hzbFloats += (uint64_t)w * h; if (w == 1 && h == 1) break; w = std::max(1u, w >> 1); h = std::max(1u, h >> 1); }
+    }
+    p->hzbMipCount = (uint32_t)p->hzbMipOffsets.size();
+    p->resNeed[BRMI_RES_HZB] = std::max<uint64_t>(16, hzbFloats * 4);
+    // workspace carve-up
+    Workspace& w = p->ws; uint64_t off = 0;
+    auto take = [&](uint64_t bytes) { uint64_t o = off; off = align_up(off + bytes, 256); return o; };
+    w.counters = take(256 * 4);
+    w.frontierA = take((uint64_t)c.maxTraversalRecords * sizeof(NodeRecord));
+    w.frontierB = take((uint64_t)c.maxTraversalRecords * sizeof(NodeRecord));
+    w.buckets = take((uint64_t)c.maxTraversalRecords * sizeof(BucketRecord));
+    w.tempVisible = take((uint64_t)c.maxVisibleClusters * sizeof(TempVisible));
+    w.bitmask1 = take((uint64_t)p->totalWords * 4);
+    w.bitmask2 = take((uint64_t)p->totalWords * 4);
+    w.wordPrefix = take((uint64_t)p->totalWords * 4);
+    w.blockSums = take((uint64_t)(p->scanBlocks + 1) * 4);
+    w.instanceBitBase = take((uint64_t)std::max<size_t>(1, p->hostInstanceBitBase.size()) * 4);
+    w.segPrefix = take((uint64_t)std::max<size_t>(1, p->hostSegPrefix.size()) * 4);
+    w.planes = take((uint64_t)2 * c.lightClusterSize[2] * 4);
+    w.replayNodes = take(16); w.replayBuckets = take(16);
+    w.total = off;
+    p->resNeed[BRMI_RES_WORKSPACE] = w.total;
+}
+
+template <typename T>
+static int read_back(brmi_pass* p, std::vector<T>& dst, const T* src, size_t n) {
+    dst.resize(n);
+    if (n == 0) return BRMI_OK;
+    if (!src) return fail(p, BRMI_ERR_INVALID, "scene buffer missing");
+    BRMI_HIP(p, hipMemcpy(dst.data(), src, n * sizeof(T), hipMemcpyDeviceToHost));
+    return BRMI_OK;
+}
+
+}  // namespace brmi
+
+using namespace brmi;
+
+extern "C" {
+
+uint32_t brmi_abi_version(void) { return BRMI_ABI_VERSION; }
+
+void brmi_default_config(brmi_config* cfg, uint32_t width, uint32_t height) {
+    if (!cfg) return;
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->structSize = sizeof(brmi_config);
+    cfg->width = width; cfg->height = height;
+    cfg->maxVisibleClusters = 1u << 22;       // reference: 30,000,000 (Renderer.cpp:2494); callers size it to the scene
+    cfg->maxTraversalRecords = 1u << 22;
+    cfg->enableOcclusionCulling = 0;          // 2-phase HZB chain: SURVEY.md 8f-2, not built in this round
+    cfg->enableClusteredLighting = 1;
+    cfg->enablePunctualLights = 1;
+    cfg->lightClusterSize[0] = 12; cfg->lightClusterSize[1] = 12; cfg->lightClusterSize[2] = 24;
+    cfg->phase2ExpansionFactor = 2;
+    cfg->collectPassStatistics = 0;
+    cfg->maxBvhLevels = 64;
+}
+
+int brmi_create(const brmi_config* cfg, brmi_pass** out) {
+    if (!cfg || !out || cfg->structSize != sizeof(brmi_config) || cfg->width == 0 || cfg->height == 0) return BRMI_ERR_INVALID;
+    if (cfg->maxVisibleClusters == 0 || cfg->maxVisibleClusters > (1u << 26) || cfg->maxTraversalRecords == 0) return BRMI_ERR_INVALID;
+    if (cfg->lightClusterSize[0] == 0 || cfg->lightClusterSize[1] == 0 || cfg->lightClusterSize[2] == 0) return BRMI_ERR_INVALID;
+    brmi_pass* p = new brmi_pass();
+    p->cfg = *cfg;
+    if (p->cfg.enableOcclusionCulling) { p->err = "enableOcclusionCulling: the phase-2 HZB chain is not built yet; running single-phase"; p->cfg.enableOcclusionCulling = 0; }
+    p->totalWords = 1; p->scanBlocks = 1;
+    compute_sizes(p);
+    *out = p;
+    return BRMI_OK;
+}
+
+void brmi_destroy(brmi_pass* p) {
+    if (!p) return;
+    if (p->eventsCreated) for (int i = 0; i < BRMI_STAGE_COUNT; i++) for (uint32_t k = 0; k < brmi_pass::kEventRing; k++) { (void)hipEventDestroy(p->evStart[i][k]); (void)hipEventDestroy(p->evStop[i][k]); }
+    delete p;
+}
+
+const char* brmi_last_error(const brmi_pass* p) { return p ? p->err.c_str() : "null pass"; }
+
+// Provider resolution.  Also derives the static rank tables of the deterministic visible-cluster
+// compaction (per-instance bit base, per-segment meshlet prefix) and the BVH level bound.
+int brmi_set_scene(brmi_pass* p, const brmi_scene_buffers* scene) {
+    if (!p || !scene) return BRMI_ERR_INVALID;
+    p->scene = *scene; p->haveScene = false; p->setupDone = false;
+    const brmi_scene_buffers& sc = p->scene;
+    if (!sc.slabs || !sc.perObject || !sc.perMesh || !sc.perMeshInstance || !sc.clodOffsets || !sc.meshMetadata || !sc.lodNodes || !sc.lodGroups ||
+        !sc.lodSegments || !sc.groupPageMap || !sc.materials || !sc.openpbrMaterials || !sc.cameras || !sc.cullingCameras || !sc.viewRasterInfo || !sc.perFrame ||
+        !sc.normalMatrices || (sc.activeDrawCount && !sc.activeDraws) || (sc.lightCount && (!sc.lights || !sc.activeLightIndices)))
+        return fail(p, BRMI_ERR_INVALID, "brmi_set_scene: a required scene buffer is null");
+    if (!sc.lutOpaqueDielectricEnergyComplement || !sc.lutOpaqueDielectricAvgEnergyComplement || !sc.lutIdealMetalEnergyComplement || !sc.lutIdealMetalAvgEnergyComplement || !sc.lutFuzzLTC)
+        return fail(p, BRMI_ERR_INVALID, "brmi_set_scene: OpenPBR lookup tables must be provided");
+    std::vector<brmi_clod_mesh_metadata> md; std::vector<brmi_mesh_instance_clod_offsets> offs; std::vector<brmi_lod_node> nodes; std::vector<brmi_lod_segment> segs;
+    int rc;
+    if ((rc = read_back(p, md, sc.meshMetadata, sc.meshMetadataCount))) return rc;
+    if ((rc = read_back(p, offs, sc.clodOffsets, sc.perMeshInstanceCount))) return rc;
+    if ((rc = read_back(p, nodes, sc.lodNodes, sc.lodNodeCount))) return rc;
+    if ((rc = read_back(p, segs, sc.lodSegments, sc.lodSegmentCount))) return rc;
+    // per mesh: walk the BVH, collect the segments its leaves reference, depth of the tree
+    p->hostSegPrefix.assign(segs.size(), 0);
+    std::vector<uint32_t> meshBits(md.size(), 0);
+    uint32_t maxDepth = 1;
+    std::vector<std::pair<uint32_t, uint32_t>> stack;
+    for (size_t m = 0; m < md.size(); m++) {
+        uint32_t segCount = 0;
+        stack.clear(); stack.push_back({md[m].rootNode, 1});
+        while (!stack.empty()) {
+            auto [n, d] = stack.back(); stack.pop_back();
+            if ((uint64_t)md[m].lodNodesBase + n >= nodes.size()) return fail(p, BRMI_ERR_INVALID, "mesh %zu: node %u out of range", m, n);
+            const brmi_lod_node& nd = nodes[md[m].lodNodesBase + n];
+            maxDepth = std::max(maxDepth, d);
+            if (nd.isLeaf != BRMI_NODE_INTERNAL) { segCount = std::max(segCount, nd.indexOrOffset + 1); continue; }
+            if (d > 64) return fail(p, BRMI_ERR_INVALID, "mesh %zu: BVH deeper than 64 levels", m);
+            const uint32_t cc = std::min(nd.countMinusOne + 1u, BRMI_BVH_MAX_CHILDREN);
+            for (uint32_t k = 0; k < cc; k++) stack.push_back({nd.indexOrOffset + k, d + 1});
+        }
+        uint64_t run = 0;
+        for (uint32_t s = 0; s < segCount; s++) {
+            const size_t gi = (size_t)md[m].segmentsBase + s;
+            if (gi >= segs.size()) return fail(p, BRMI_ERR_INVALID, "mesh %zu: segment %u out of range", m, s);
+            p->hostSegPrefix[gi] = (uint32_t)run; run += segs[gi].meshletCount;
+        }
+        if (run > 0xFFFFFFFFull) return fail(p, BRMI_ERR_CAPACITY, "mesh %zu has too many meshlets", m);
+        meshBits[m] = (uint32_t)run;
+    }
+    p->hostInstanceBitBase.assign(offs.size(), 0);
+    uint64_t bits = 0;
+    for (size_t i = 0; i < offs.size(); i++) {
+        if (offs[i].clodMeshMetadataIndex >= md.size()) return fail(p, BRMI_ERR_INVALID, "instance %zu: bad mesh metadata index", i);
+        p->hostInstanceBitBase[i] = (uint32_t)bits; bits += meshBits[offs[i].clodMeshMetadataIndex];
+        if (bits > 0xFFFFFFF0ull) return fail(p, BRMI_ERR_CAPACITY, "scene exceeds 2^32 (instance, meshlet) pairs");
+    }
+    p->totalBits = bits;
+    p->totalWords = (uint32_t)std::max<uint64_t>(1, (bits + 31) / 32);
+    p->scanBlocks = (p->totalWords + 2047u) / 2048u;
+    p->maxLevels = std::min(std::max(1u, maxDepth), std::max(1u, p->cfg.maxBvhLevels));
+    compute_sizes(p);
+    p->haveScene = true;
+    return BRMI_OK;
+}
+
+int brmi_declare(brmi_pass* p, brmi_declare_cb cb, void* user) {
+    if (!p || !cb) return BRMI_ERR_INVALID;
+    if (!p->haveScene) return fail(p, BRMI_ERR_STATE, "brmi_declare: call brmi_set_scene first (workspace size depends on the scene)");
+    for (uint32_t i = 0; i < BRMI_RES_COUNT; i++) {
+        brmi_resource_desc d{};
+        d.id = i; d.name = kResNames[i]; d.bytes = p->resNeed[i];
+        const bool image = i <= BRMI_RES_HDR_COLOR;
+        d.usage = BRMI_USAGE_UNORDERED_ACCESS | BRMI_USAGE_SHADER_RESOURCE | ((i == BRMI_RES_WORKSPACE || i == BRMI_RES_HZB) ? BRMI_USAGE_INTERNAL : 0u);
+        d.width = image ? p->cfg.width : 0; d.height = image ? p->cfg.height : 0; d.bytesPerPixel = kResBpp[i];
+        d.tileW = image ? 8 : 0; d.tileH = image ? 8 : 0;
+        cb(user, &d);
+    }
+    return BRMI_OK;
+}
+
+int brmi_setup(brmi_pass* p, const brmi_resource_binding* b, uint32_t n, brmi_stream stream) {
+    if (!p || (!b && n)) return BRMI_ERR_INVALID;
+    if (!p->haveScene) return fail(p, BRMI_ERR_STATE, "brmi_setup: call brmi_set_scene first");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    for (uint32_t i = 0; i < n; i++) {
+        if (b[i].id >= BRMI_RES_COUNT) return fail(p, BRMI_ERR_INVALID, "brmi_setup: unknown resource id %u", b[i].id);
+        p->res[b[i].id] = b[i].ptr; p->resBytes[b[i].id] = b[i].bytes;
+    }
+    for (uint32_t i = 0; i < BRMI_RES_COUNT; i++) {
+        if (!p->res[i]) return fail(p, BRMI_ERR_INVALID, "brmi_setup: resource %s not bound", kResNames[i]);
+        if (p->resBytes[i] < p->resNeed[i]) return fail(p, BRMI_ERR_CAPACITY, "brmi_setup: resource %s is %llu B, needs %llu B", kResNames[i], (unsigned long long)p->resBytes[i], (unsigned long long)p->resNeed[i]);
+        if ((reinterpret_cast<uintptr_t>(p->res[i]) & 15u) != 0) return fail(p, BRMI_ERR_INVALID, "brmi_setup: resource %s must be 16-byte aligned", kResNames[i]);
+    }
+    BRMI_HIP(p, hipMemsetAsync(p->res[BRMI_RES_WORKSPACE], 0, p->ws.total, s));
+    if (!p->hostInstanceBitBase.empty()) BRMI_HIP(p, hipMemcpyAsync(p->wsPtr<uint32_t>(p->ws.instanceBitBase), p->hostInstanceBitBase.data(), p->hostInstanceBitBase.size() * 4, hipMemcpyHostToDevice, s));
+    if (!p->hostSegPrefix.empty()) BRMI_HIP(p, hipMemcpyAsync(p->wsPtr<uint32_t>(p->ws.segPrefix), p->hostSegPrefix.data(), p->hostSegPrefix.size() * 4, hipMemcpyHostToDevice, s));
+    BRMI_HIP(p, hipStreamSynchronize(s));   // host vectors may be reused
+    if (p->cfg.collectPassStatistics && !p->eventsCreated) {
+        for (int i = 0; i < BRMI_STAGE_COUNT; i++) for (uint32_t k = 0; k < brmi_pass::kEventRing; k++) { BRMI_HIP(p, hipEventCreate(&p->evStart[i][k])); BRMI_HIP(p, hipEventCreate(&p->evStop[i][k])); }
+        p->eventsCreated = true;
+    }
+    p->setupDone = true;
+    return BRMI_OK;
+}
+
+// Per-frame host work.  The slice plane depths of the light-cluster grid are evaluated here with
+// logf/expf (clustering.hlsl:66-90 evaluates them per cluster on the GPU).
+int brmi_update(brmi_pass* p, const brmi_frame_update* u, brmi_stream stream) {
+    if (!p || !u || !u->mainCameraHost || !u->perFrameHost) return BRMI_ERR_INVALID;
+    if (!p->setupDone) return fail(p, BRMI_ERR_STATE, "brmi_update: call brmi_setup first");
+    p->camHost = *u->mainCameraHost; p->pfHost = *u->perFrameHost;
+    const brmi_per_frame& pf = p->pfHost;
+    if (pf.lightClusterGridSizeX != p->cfg.lightClusterSize[0] || pf.lightClusterGridSizeY != p->cfg.lightClusterSize[1] || pf.lightClusterGridSizeZ != p->cfg.lightClusterSize[2])
+        return fail(p, BRMI_ERR_INVALID, "brmi_update: per-frame light cluster grid differs from the configured lightClusterSize");
+    if (pf.screenResX != p->cfg.width || pf.screenResY != p->cfg.height) return fail(p, BRMI_ERR_INVALID, "brmi_update: per-frame screen size differs from the configured target size");
+    const float zNear = p->camHost.zNear, zFar = p->camHost.zFar, zSplit = pf.clusterZSplitDepth;
+    const uint32_t gz = pf.lightClusterGridSizeZ, nearSlices = pf.nearClusterCount;
+    p->planesHost.resize(2 * gz);
+    for (uint32_t sliceZ = 0; sliceZ < gz; sliceZ++) {
+        float pn, pfar;
+        if (sliceZ < nearSlices) {
+            const float sliceSize = (zSplit - zNear) / (float)nearSlices;
+            pn = -(zNear + (float)sliceZ * sliceSize);
+            pfar = -(zNear + (float)(sliceZ + 1) * sliceSize);
+        } else {
+            const float logStart = std::log(zSplit / zNear), logEnd = std::log(zFar / zNear);
+            const float t0 = (float)(sliceZ - nearSlices) / (float)(gz - nearSlices);
+            const float t1 = (float)(sliceZ + 1 - nearSlices) / (float)(gz - nearSlices);
+            pn = -zNear * std::exp(logStart + t0 * (logEnd - logStart));
+            pfar = -zNear * std::exp(logStart + t1 * (logEnd - logStart));
+        }
+        p->planesHost[2 * sliceZ] = pn; p->planesHost[2 * sliceZ + 1] = pfar;
+    }
+    {   // band planes of the screen-tile split, 2 px of slack (view space, through the eye)
+        const float projY = p->camHost.projection[1][1], H = (float)p->cfg.height;
+        const float T = 1.0f - 2.0f * ((float)p->bandY0 - 2.0f) / H, B = 1.0f - 2.0f * ((float)p->bandY1 + 2.0f) / H;
+        const float lt = std::sqrt(projY * projY + T * T), lb = std::sqrt(projY * projY + B * B);
+        p->bandPlaneTop[0] = 0.0f; p->bandPlaneTop[1] = -projY / lt; p->bandPlaneTop[2] = -T / lt;
+        p->bandPlaneBottom[0] = 0.0f; p->bandPlaneBottom[1] = projY / lb; p->bandPlaneBottom[2] = B / lb;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    BRMI_HIP(p, hipMemcpyAsync(p->wsPtr<float>(p->ws.planes), p->planesHost.data(), p->planesHost.size() * 4, hipMemcpyHostToDevice, s));
+    p->updated = true;
+    return BRMI_OK;
+}
+
+#define STAGE_BEGIN(p, st, s) do { if ((p)->eventsCreated) { (void)hipEventRecord((p)->evStart[st][(p)->evCount[st] % brmi_pass::kEventRing], (s)); } } while (0)
+#define STAGE_END(p, st, s) do { if ((p)->eventsCreated) { (void)hipEventRecord((p)->evStop[st][(p)->evCount[st] % brmi_pass::kEventRing], (s)); (p)->evCount[st]++; } } while (0)
+#define CHECK_READY(p) do { if (!(p)) return BRMI_ERR_INVALID; if (!(p)->setupDone || !(p)->updated) return brmi::fail((p), BRMI_ERR_STATE, "%s: setup/update not done", __func__); } while (0)
+
+int brmi_clear_visibility(brmi_pass* p, brmi_stream stream) {
+    CHECK_READY(p); hipStream_t s = static_cast<hipStream_t>(stream);
+    STAGE_BEGIN(p, BRMI_STAGE_CLEAR, s); int rc = launch_clear(p, s); STAGE_END(p, BRMI_STAGE_CLEAR, s); return rc;
+}
+int brmi_cull(brmi_pass* p, uint32_t phase, brmi_stream stream) {
+    CHECK_READY(p); hipStream_t s = static_cast<hipStream_t>(stream);
+    const int st = phase == 2 ? BRMI_STAGE_CULL2 : BRMI_STAGE_CULL;
+    STAGE_BEGIN(p, st, s); int rc = launch_cull(p, phase, s); STAGE_END(p, st, s); return rc;
+}
+int brmi_raster(brmi_pass* p, uint32_t phase, brmi_stream stream) {
+    CHECK_READY(p); hipStream_t s = static_cast<hipStream_t>(stream);
+    const int st = phase == 2 ? BRMI_STAGE_RASTER2 : BRMI_STAGE_RASTER;
+    STAGE_BEGIN(p, st, s); int rc = launch_raster(p, phase, s); STAGE_END(p, st, s); return rc;
+}
+int brmi_depth_copy(brmi_pass* p, brmi_stream stream) {
+    CHECK_READY(p); hipStream_t s = static_cast<hipStream_t>(stream);
+    STAGE_BEGIN(p, BRMI_STAGE_DEPTH_COPY, s); int rc = launch_depth_copy(p, s); STAGE_END(p, BRMI_STAGE_DEPTH_COPY, s); return rc;
+}
+int brmi_build_hzb(brmi_pass* p, brmi_stream stream) {
+    CHECK_READY(p); (void)stream;
+    return brmi::fail(p, BRMI_ERR_STATE, "brmi_build_hzb: the HZB chain (SURVEY.md 8f-2) is not built yet");
+}
+int brmi_gbuffer(brmi_pass* p, brmi_stream stream) {
+    CHECK_READY(p); hipStream_t s = static_cast<hipStream_t>(stream);
+    STAGE_BEGIN(p, BRMI_STAGE_GBUFFER, s); int rc = launch_gbuffer(p, s); STAGE_END(p, BRMI_STAGE_GBUFFER, s); return rc;
+}
+int brmi_light_clustering(brmi_pass* p, brmi_stream stream) {
+    CHECK_READY(p); hipStream_t s = static_cast<hipStream_t>(stream);
+    STAGE_BEGIN(p, BRMI_STAGE_LIGHT_CLUSTER, s); int rc = launch_light_clustering(p, s); STAGE_END(p, BRMI_STAGE_LIGHT_CLUSTER, s); return rc;
+}
+int brmi_shade(brmi_pass* p, brmi_stream stream) {
+    CHECK_READY(p); hipStream_t s = static_cast<hipStream_t>(stream);
+    STAGE_BEGIN(p, BRMI_STAGE_SHADE, s); int rc = launch_shade(p, s); STAGE_END(p, BRMI_STAGE_SHADE, s); return rc;
+}
+
+// The whole chain in graph order.  K6 is folded into the G-buffer kernel (one visibility read).
+int brmi_execute(brmi_pass* p, brmi_stream stream) {
+    CHECK_READY(p);
+    int rc;
+    if ((rc = brmi_clear_visibility(p, stream))) return rc;
+    if ((rc = brmi_cull(p, 1, stream))) return rc;
+    if ((rc = brmi_raster(p, 1, stream))) return rc;
+    if ((rc = brmi_gbuffer(p, stream))) return rc;
+    if ((rc = brmi_light_clustering(p, stream))) return rc;
+    if ((rc = brmi_shade(p, stream))) return rc;
+    return BRMI_OK;
+}
+
+int brmi_read_counters(brmi_pass* p, brmi_counters* out, brmi_stream stream) {
+    if (!p || !out) return BRMI_ERR_INVALID;
+    if (!p->setupDone) return brmi::fail(p, BRMI_ERR_STATE, "brmi_read_counters: setup not done");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    uint32_t c[CNT_WORDS];
+    BRMI_HIP(p, hipMemcpyAsync(c, p->counters(), sizeof(c), hipMemcpyDeviceToHost, s));
+    BRMI_HIP(p, hipStreamSynchronize(s));
+    std::memset(out, 0, sizeof(*out));
+    out->instancesTested = c[CNT_INSTANCES_TESTED]; out->instancesVisible = c[CNT_INSTANCES_VISIBLE];
+    out->nodesVisited = c[CNT_NODES_VISITED]; out->bucketRecords = c[CNT_BUCKETS]; out->meshletsTested = c[CNT_MESHLETS_TESTED];
+    out->visibleClusters = c[CNT_VISIBLE]; out->visibleClustersPhase2 = c[CNT_VISIBLE2];
+    out->droppedRecords = c[CNT_DROPPED_RECORDS]; out->droppedClusters = c[CNT_DROPPED_CLUSTERS]; out->lightPagesUsed = c[CNT_LIGHT_PAGES];
+    out->reserved[0] = c[CNT_SUM_VERTS_LO]; out->reserved[1] = c[CNT_SUM_VERTS_HI]; out->reserved[2] = c[CNT_SUM_TRIS_LO]; out->reserved[3] = c[CNT_SUM_TRIS_HI];
+    out->reserved[4] = c[CNT_RASTER_CLUSTERS];
+    return BRMI_OK;
+}
+
+int brmi_stage_times(brmi_pass* p, float* ms) {
+    if (!p || !ms) return BRMI_ERR_INVALID;
+    if (!p->eventsCreated) return brmi::fail(p, BRMI_ERR_STATE, "brmi_stage_times: collectPassStatistics is off");
+    // mean over the recordings since the previous call (at most the last kEventRing), then reset
+    for (int i = 0; i < BRMI_STAGE_COUNT; i++) {
+        ms[i] = 0.0f;
+        const uint32_t n = std::min(p->evCount[i], brmi_pass::kEventRing);
+        if (n == 0) continue;
+        double sum = 0.0;
+        for (uint32_t k = 0; k < n; k++) {
+            const uint32_t slot = (p->evCount[i] - 1 - k) % brmi_pass::kEventRing;
+            float t = 0.0f;
+            BRMI_HIP(p, hipEventSynchronize(p->evStop[i][slot]));
+            BRMI_HIP(p, hipEventElapsedTime(&t, p->evStart[i][slot], p->evStop[i][slot]));
+            sum += t;
+        }
+        ms[i] = (float)(sum / n);
+        p->evCount[i] = 0;
+    }
+    return BRMI_OK;
+}
+
+// bytes_frame = 140*P + sum_clusters(144 + 12V + 3T) + 64*M_tested + 16*M_visible + 64*N_nodes
+int brmi_algorithmic_bytes(brmi_pass* p, uint64_t* perStage, uint64_t* total) {
+    if (!p || !perStage || !total) return BRMI_ERR_INVALID;
+    brmi_counters c; int rc = brmi_read_counters(p, &c, nullptr); if (rc) return rc;
+    const uint64_t P = (uint64_t)p->cfg.width * (p->bandY1 - p->bandY0);
+    const uint64_t sumV = ((uint64_t)c.reserved[1] << 32) | c.reserved[0], sumT = ((uint64_t)c.reserved[3] << 32) | c.reserved[2], nClusters = c.reserved[4];
+    for (int i = 0; i < BRMI_STAGE_COUNT; i++) perStage[i] = 0;
+    perStage[BRMI_STAGE_CLEAR] = 8 * P;
+    perStage[BRMI_STAGE_CULL] = 64ull * c.meshletsTested + 16ull * (c.visibleClusters + c.visibleClustersPhase2) + 64ull * c.nodesVisited;
+    perStage[BRMI_STAGE_RASTER] = 8 * P + 144ull * nClusters + 12ull * sumV + 3ull * sumT;
+    perStage[BRMI_STAGE_GBUFFER] = (8 + 52 + 4) * P;
+    perStage[BRMI_STAGE_SHADE] = (4 + 48 + 8) * P;
+    *total = 0; for (int i = 0; i < BRMI_STAGE_COUNT; i++) *total += perStage[i];
+    return BRMI_OK;
+}
+
+int brmi_debug_arith(const float* a, const float* b, float* outDiv, float* outSqrt, uint32_t* outHalfBits, uint32_t n, brmi_stream stream) {
+    if (!a || !b || !outDiv || !outSqrt || !outHalfBits) return BRMI_ERR_INVALID;
+    if (n == 0) return BRMI_OK;
+    hipLaunchKernelGGL(k_debug_arith, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), a, b, outDiv, outSqrt, outHalfBits, n);
+    return hipGetLastError() == hipSuccess ? BRMI_OK : BRMI_ERR_HIP;
+}
+
+}  // extern "C"

@@ -1,0 +1,406 @@
+// brmi_cull.hip -- hierarchical culling (K1-K3) for gfx950.
+//
+// What it computes is the reference's chain
+//   PureComputeObjectCullCS / PureComputeTraverseFrontierCS   BR/shaders/ClusterLOD/computeCulling.hlsl:103-531
+//   ClusterCullBody                                           BR/shaders/ClusterLOD/workGraphCulling.hlsl:2398-3330
+// but not how the reference schedules it.  MI355X-first differences:
+//   * HIP has no ExecuteIndirect, and a dependent chain of tiny dispatches is latency-bound
+//     (SURVEY.md 8a-2).  Every level is a fixed-size grid-stride launch that reads its record
+//     count from HBM, so the whole chain is a static launch sequence (graph-capturable, no host
+//     round trip); empty levels retire in ~2 us.
+//   * The reference appends survivors with wave ballots into one buffer, so the cluster index
+//     that ends up in the visibility key depends on atomic ordering.  Here survivors set one bit
+//     in a per-(instance, segment, meshlet) bitmask, a popcount scan ranks the bits, and a scatter
+//     places each survivor at its rank: the visible-cluster list is identical run to run
+//     (canonical order: instance, segment, meshlet) with one atomic per wave, not per survivor.
+//   * Frontier / bucket appends are wave-aggregated (one atomic per wave64).
+#include "brmi_device.h"
+#include "brmi_internal.h"
+
+namespace brmi {
+
+struct CullArgs {
+    brmi_scene_buffers sc;
+    uint32_t* counters;
+    const uint32_t* instanceBitBase;
+    const uint32_t* segPrefix;
+    uint32_t recordCapacity, visibleCapacity, factor, phase;
+    // multi-GPU row band: two view-space planes through the eye bounding the band (1 = active)
+    uint32_t bandActive; float bandTop[3], bandBottom[3];
+};
+
+BRMI_DEV f3 to_view_space(f3 c, const m4& model, const m4& view) { return xyz(mul_vm(mul_point(c, model), view)); }
+
+BRMI_DEV bool sphere_outside_frustum(f3 c, float r, const float (*planes)[4]) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const float d = dot3(f3{planes[i][0], planes[i][1], planes[i][2]}, c) + planes[i][3];
+        if (d < -r) return true;
+    }
+    return false;
+}
+
+BRMI_DEV float projected_error(f3 worldCenter, float worldRadius, float errMesh, float errScale, f3 camPos, float zNear, bool ortho) {
+    const float wsErr = errMesh * errScale;
+    if (ortho) return wsErr;
+    const float dist = length3(worldCenter - camPos);
+    const float denom = max2(dist - worldRadius, zNear);
+    return wsErr / denom;
+}
+
+BRMI_DEV bool refined_child_suppresses(const brmi_scene_buffers& sc, uint32_t groupsBase, uint32_t childLocal, bool hasChild, const m4& model, float scale,
+                                       f3 camPos, float zNear, float threshold, bool ortho) {
+    if (!hasChild) return false;
+    const brmi_lod_group* g = sc.lodGroups + (groupsBase + childLocal);
+    const f3 c = xyz(mul_point(f3{g->centerAndRadius[0], g->centerAndRadius[1], g->centerAndRadius[2]}, model));
+    const float r = g->centerAndRadius[3] * scale;
+    const float eod = projected_error(c, r, g->maxParentError, scale, camPos, zNear, ortho);
+    return !(eod < threshold);   // resident: static frame
+}
+
+// K1 -------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_cull_instances(CullArgs a, NodeRecord* frontier0) {
+    const brmi_scene_buffers& sc = a.sc;
+    const uint32_t viewId = sc.perFrame->mainCameraIndex;
+    const brmi_camera* cam = sc.cameras + viewId;
+    const m4 view = load_m4(&cam->view[0][0]);
+    for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < ((sc.activeDrawCount + 63u) & ~63u); d += gridDim.x * blockDim.x) {
+        bool visible = false;
+        uint32_t ii = 0, root = 0;
+        if (d < sc.activeDrawCount) {
+            ii = sc.activeDraws[d];
+            const brmi_per_mesh_instance inst = sc.perMeshInstance[ii];
+            const m4 model = load_m4(&sc.perObject[inst.perObjectBufferIndex].model[0][0]);
+            const f3 c = to_view_space(f3{inst.boundingSphere[0], inst.boundingSphere[1], inst.boundingSphere[2]}, model, view);
+            const float r = inst.boundingSphere[3] * max_axis_scale(model);
+            const bool bad = isnan(c.x) || isnan(c.y) || isnan(c.z) || isinf(c.x) || isinf(c.y) || isinf(c.z) || isnan(r) || isinf(r);
+            visible = !bad && !sphere_outside_frustum(c, r, cam->clippingPlanes);
+            root = sc.meshMetadata[sc.clodOffsets[ii].clodMeshMetadataIndex].rootNode;
+            atomicAdd(&a.counters[CNT_INSTANCES_TESTED], 1u);
+            if (visible) atomicAdd(&a.counters[CNT_INSTANCES_VISIBLE], 1u);
+        }
+        const uint32_t slot = wave_append(&a.counters[CNT_FRONTIER0], visible);
+        if (visible) {
+            if (slot < a.recordCapacity) frontier0[slot] = NodeRecord{ii, (1u << 30) | (root & 0x3FFFFFFFu)};
+            else atomicAdd(&a.counters[CNT_DROPPED_RECORDS], 1u);
+        }
+    }
+}
+
+// K2: one BFS level ------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_traverse(CullArgs a, uint32_t level, const NodeRecord* frontierIn, NodeRecord* frontierOut, BucketRecord* buckets) {
+    const brmi_scene_buffers& sc = a.sc;
+    const uint32_t inputCount = min(a.counters[CNT_FRONTIER0 + level], a.recordCapacity);
+    const uint32_t viewId = sc.perFrame->mainCameraIndex;
+    const brmi_camera* cam = sc.cameras + viewId;
+    const brmi_culling_camera* lodCam = sc.cullingCameras + viewId;
+    const bool ortho = cam->isOrtho != 0;
+    const f3 camPos{lodCam->positionWorldSpace[0], lodCam->positionWorldSpace[1], lodCam->positionWorldSpace[2]};
+    const float zNear = lodCam->zNear, threshold = lodCam->errorOverDistanceThreshold;
+    const m4 view = load_m4(&cam->view[0][0]);
+    uint32_t* nextCount = &a.counters[CNT_FRONTIER0 + level + 1];
+    const uint32_t rounded = (inputCount + 63u) & ~63u;
+    for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < rounded; idx += gridDim.x * blockDim.x) {
+        const bool have = idx < inputCount;
+        // per-record state
+        bool isInternal = false, emitLeaf = false, replay = false;
+        uint32_t instIndex = 0, childBase = 0, childCount = 0, lodNodesBase = 0;
+        uint32_t segFirst = 0, segCount = 0, ownerGroup = 0, slabDesc = 0, slabOff = 0, firstBit = 0;
+        bool skinned = false;
+        m4 model{}; float scale = 0.0f;
+        f3 instC{0, 0, 0}; float instR = 0.0f;
+        if (have) {
+            const NodeRecord rec = frontierIn[idx];
+            instIndex = rec.instanceIndex;
+            replay = (rec.nodeIdPacked >> 31) != 0;
+            const bool allowRefine = ((rec.nodeIdPacked >> 30) & 1u) != 0;
+            const uint32_t nodeId = rec.nodeIdPacked & 0x3FFFFFFFu;
+            atomicAdd(&a.counters[CNT_NODES_VISITED], 1u);
+            const brmi_per_mesh_instance inst = sc.perMeshInstance[instIndex];
+            const brmi_clod_mesh_metadata md = sc.meshMetadata[sc.clodOffsets[instIndex].clodMeshMetadataIndex];
+            skinned = (sc.perMesh[inst.perMeshBufferIndex].vertexFlags & BRMI_VERTEX_SKINNED) != 0;
+            model = load_m4(&sc.perObject[inst.perObjectBufferIndex].model[0][0]);
+            scale = max_axis_scale(model);
+            instC = f3{inst.boundingSphere[0], inst.boundingSphere[1], inst.boundingSphere[2]}; instR = inst.boundingSphere[3];
+            lodNodesBase = md.lodNodesBase;
+            const brmi_lod_node node = sc.lodNodes[md.lodNodesBase + nodeId];
+            const f3 cullC = skinned ? instC : f3{node.cullCenterAndRadius[0], node.cullCenterAndRadius[1], node.cullCenterAndRadius[2]};
+            const float cullR = skinned ? instR : node.cullCenterAndRadius[3];
+            const f3 cVS = to_view_space(cullC, model, view);
+            const float rW = cullR * scale;
+            const bool culled = !replay && sphere_outside_frustum(cVS, rW, cam->clippingPlanes);
+            if (!culled) {
+                if (node.isLeaf != BRMI_NODE_INTERNAL) {
+                    const brmi_lod_group* g = sc.lodGroups + (md.groupsBase + node.ownerGroupId);
+                    const f3 gc = xyz(mul_point(f3{g->centerAndRadius[0], g->centerAndRadius[1], g->centerAndRadius[2]}, model));
+                    const float gr = g->centerAndRadius[3] * scale;
+                    const float eod = projected_error(gc, gr, node.maxQuadricError, scale, camPos, zNear, ortho);
+                    bool ok = allowRefine && (eod >= threshold);
+                    if (ok && refined_child_suppresses(sc, md.groupsBase, node.countMinusOne - 1u, node.countMinusOne != 0u, model, scale, camPos, zNear, threshold, ortho)) ok = false;
+                    if (ok) {
+                        const brmi_lod_segment seg = sc.lodSegments[md.segmentsBase + node.indexOrOffset];
+                        const brmi_group_page_map_entry pe = sc.groupPageMap[md.pageMapBase + seg.pageIndex];
+                        if (seg.meshletCount != 0u && pe.slabDescriptorIndex != 0u) {
+                            emitLeaf = true;
+                            segFirst = seg.firstMeshletInPage; segCount = seg.meshletCount; ownerGroup = node.ownerGroupId;
+                            slabDesc = pe.slabDescriptorIndex; slabOff = pe.slabByteOffset;
+                            firstBit = a.instanceBitBase[instIndex] + a.segPrefix[md.segmentsBase + node.indexOrOffset];
+                        }
+                    }
+                } else {
+                    const f3 lc = xyz(mul_point(f3{node.lodCenterAndRadius[0], node.lodCenterAndRadius[1], node.lodCenterAndRadius[2]}, model));
+                    const float lr = node.lodCenterAndRadius[3] * scale;
+                    const float nodeEod = projected_error(lc, lr, node.maxQuadricError, scale, camPos, zNear, ortho);
+                    if (allowRefine && (nodeEod >= threshold)) {
+                        isInternal = true;
+                        childBase = node.indexOrOffset;
+                        childCount = min(node.countMinusOne + 1u, BRMI_BVH_MAX_CHILDREN);
+                    }
+                }
+            }
+        }
+        // leaf: chunk the segment into bucket records of `factor` meshlets (computeCulling.hlsl:385-406)
+        // wave-cooperative emission: iterate chunk index k over the widest leaf in the wave
+        {
+            const uint32_t nChunks = emitLeaf ? (segCount + a.factor - 1u) / a.factor : 0u;
+            uint32_t waveMax = nChunks;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) waveMax = max(waveMax, (uint32_t)__shfl_xor((int)waveMax, o));
+            for (uint32_t k = 0; k < waveMax; k++) {
+                const bool emit = k < nChunks;
+                const uint32_t slot = wave_append(&a.counters[CNT_BUCKETS], emit);
+                if (emit) {
+                    if (slot < a.recordCapacity) {
+                        const uint32_t first = segFirst + k * a.factor;
+                        const uint32_t cnt = min(a.factor, segCount - k * a.factor);
+                        BucketRecord b;
+                        b.instanceIndex = instIndex; b.groupIdPacked = (replay ? 0x80000000u : 0u) | (ownerGroup & 0x7FFFFFFFu);
+                        b.meshletIndexAndCount = (cnt << 16) | (first & 0xFFFFu);
+                        b.pageSlabDescriptorIndex = slabDesc; b.pageSlabByteOffset = slabOff;
+                        b.firstBit = firstBit + k * a.factor; b.pad0 = 0; b.pad1 = 0;
+                        buckets[slot] = b;
+                    } else atomicAdd(&a.counters[CNT_DROPPED_RECORDS], 1u);
+                }
+            }
+        }
+        // internal: pre-filter children, append survivors to the next frontier (computeCulling.hlsl:477-530)
+        {
+            uint32_t waveMax = isInternal ? childCount : 0u;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) waveMax = max(waveMax, (uint32_t)__shfl_xor((int)waveMax, o));
+            for (uint32_t k = 0; k < waveMax; k++) {
+                bool emit = false;
+                uint32_t childId = 0;
+                if (isInternal && k < childCount) {
+                    childId = childBase + k;
+                    const brmi_lod_node* ch = sc.lodNodes + (lodNodesBase + childId);
+                    const f3 cc = skinned ? instC : f3{ch->cullCenterAndRadius[0], ch->cullCenterAndRadius[1], ch->cullCenterAndRadius[2]};
+                    const float cr = skinned ? instR : ch->cullCenterAndRadius[3];
+                    const f3 ccVS = to_view_space(cc, model, view);
+                    emit = replay || !sphere_outside_frustum(ccVS, cr * scale, cam->clippingPlanes);
+                    if (emit && ch->isLeaf == BRMI_NODE_INTERNAL) {
+                        const f3 wc = xyz(mul_point(f3{ch->lodCenterAndRadius[0], ch->lodCenterAndRadius[1], ch->lodCenterAndRadius[2]}, model));
+                        const float e = projected_error(wc, ch->lodCenterAndRadius[3] * scale, ch->maxQuadricError, scale, camPos, zNear, ortho);
+                        if (e < threshold) emit = false;
+                    }
+                }
+                const uint32_t slot = wave_append(nextCount, emit);
+                if (emit) {
+                    if (slot < a.recordCapacity) frontierOut[slot] = NodeRecord{instIndex, (replay ? 0x80000000u : 0u) | (1u << 30) | (childId & 0x3FFFFFFFu)};
+                    else atomicAdd(&a.counters[CNT_DROPPED_RECORDS], 1u);
+                }
+            }
+        }
+    }
+}
+
+// K3: per-meshlet cull ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_cull_clusters(CullArgs a, const BucketRecord* buckets, TempVisible* temp, uint32_t* bitmask) {
+    const brmi_scene_buffers& sc = a.sc;
+    const uint32_t bucketCount = min(a.counters[CNT_BUCKETS], a.recordCapacity);
+    const uint32_t viewId = sc.perFrame->mainCameraIndex;
+    const brmi_camera* cam = sc.cameras + viewId;
+    const brmi_culling_camera* lodCam = sc.cullingCameras + viewId;
+    const bool ortho = cam->isOrtho != 0;
+    const f3 camPos{lodCam->positionWorldSpace[0], lodCam->positionWorldSpace[1], lodCam->positionWorldSpace[2]};
+    const float zNear = lodCam->zNear, threshold = lodCam->errorOverDistanceThreshold;
+    const m4 view = load_m4(&cam->view[0][0]);
+    uint32_t* tempCount = &a.counters[a.phase == 2 ? CNT_TEMP_VISIBLE2 : CNT_TEMP_VISIBLE];
+    // one lane per (bucket, meshlet-in-bucket): `factor` lanes cooperate on a record
+    const uint64_t totalLanes = (uint64_t)bucketCount * a.factor;
+    const uint64_t rounded = (totalLanes + 63ull) & ~63ull;
+    for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < rounded; idx += (uint64_t)gridDim.x * blockDim.x) {
+        bool survives = false;
+        uint4 packed = make_uint4(0, 0, 0, 0);
+        uint32_t bit = 0;
+        if (idx < totalLanes) {
+            const uint32_t bi = (uint32_t)(idx / a.factor), m = (uint32_t)(idx % a.factor);
+            const BucketRecord b = buckets[bi];
+            const uint32_t count = b.meshletIndexAndCount >> 16, first = b.meshletIndexAndCount & 0xFFFFu;
+            if (m < count && b.pageSlabDescriptorIndex != 0u) {
+                atomicAdd(&a.counters[CNT_MESHLETS_TESTED], 1u);
+                const bool replay = (b.groupIdPacked >> 31) != 0;
+                const uint32_t lm = first + m;
+                const uint8_t* slab = sc.slabs[b.pageSlabDescriptorIndex];
+                const brmi_page_header* hdr = reinterpret_cast<const brmi_page_header*>(slab + b.pageSlabByteOffset);
+                if (lm < hdr->meshletCount) {
+                    const brmi_meshlet_descriptor* desc = reinterpret_cast<const brmi_meshlet_descriptor*>(slab + b.pageSlabByteOffset + hdr->descriptorOffset + lm * 64u);
+                    const float4 bounds = *reinterpret_cast<const float4*>(desc->bounds);
+                    const uint32_t triAndRefined = desc->triangleCountAndRefinedGroup;
+                    const brmi_per_mesh_instance inst = sc.perMeshInstance[b.instanceIndex];
+                    const brmi_clod_mesh_metadata* md = sc.meshMetadata + sc.clodOffsets[b.instanceIndex].clodMeshMetadataIndex;
+                    const m4 model = load_m4(&sc.perObject[inst.perObjectBufferIndex].model[0][0]);
+                    const float scale = max_axis_scale(model);
+                    const f3 cVS = to_view_space(f3{bounds.x, bounds.y, bounds.z}, model, view);
+                    const float rW = bounds.w * scale;
+                    survives = replay || !sphere_outside_frustum(cVS, rW, cam->clippingPlanes);
+                    if (survives) {
+                        const int refined = (int)(triAndRefined >> 16) - 1;
+                        if (refined_child_suppresses(sc, md->groupsBase, (uint32_t)refined, refined >= 0, model, scale, camPos, zNear, threshold, ortho)) survives = false;
+                    }
+                    if (survives && a.bandActive) {
+                        // tile-bounds test of the screen-tile split: conservative sphere vs the band's two planes
+                        if (dot3(f3{a.bandTop[0], a.bandTop[1], a.bandTop[2]}, cVS) < -rW || dot3(f3{a.bandBottom[0], a.bandBottom[1], a.bandBottom[2]}, cVS) < -rW) survives = false;
+                    }
+                    if (survives) {
+                        packed = pack_visible_cluster(viewId, b.instanceIndex, lm, b.groupIdPacked & 0x7FFFFFFFu, b.pageSlabDescriptorIndex, b.pageSlabByteOffset);
+                        bit = b.firstBit + m;
+                    }
+                }
+            }
+        }
+        const uint32_t slot = wave_append(tempCount, survives);
+        if (survives) {
+            if (slot < a.visibleCapacity) {
+                TempVisible t; t.packed = packed; t.bit = bit; t.pad0 = t.pad1 = t.pad2 = 0;
+                temp[slot] = t;
+                atomicOr(&bitmask[bit >> 5], 1u << (bit & 31u));
+            } else atomicAdd(&a.counters[CNT_DROPPED_CLUSTERS], 1u);
+        }
+    }
+}
+
+// rank = exclusive popcount scan over the bitmask ----------------------------------------------
+constexpr uint32_t SCAN_BLOCK_WORDS = 2048;   // words per workgroup (256 threads x 8)
+
+__global__ void __launch_bounds__(256) k_scan_reduce(const uint32_t* bitmask, uint32_t totalWords, uint32_t* blockSums) {
+    __shared__ uint32_t partial[4];
+    const uint32_t base = blockIdx.x * SCAN_BLOCK_WORDS;
+    uint32_t s = 0;
+    for (uint32_t i = threadIdx.x; i < SCAN_BLOCK_WORDS; i += 256) { const uint32_t w = base + i; if (w < totalWords) s += __popc(bitmask[w]); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor((int)s, o);
+    if ((threadIdx.x & 63u) == 0) partial[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) blockSums[blockIdx.x] = partial[0] + partial[1] + partial[2] + partial[3];
+}
+
+// single workgroup: exclusive scan of blockSums in place; total -> counters[outIndex] (clamped to capacity)
+__global__ void __launch_bounds__(1024) k_scan_blocks(uint32_t* blockSums, uint32_t nBlocks, uint32_t* counters, uint32_t outIndex, uint32_t capacity) {
+    __shared__ uint32_t waveTotals[16];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nBlocks; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < nBlocks ? blockSums[i] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o); if ((threadIdx.x & 63u) >= (uint32_t)o) incl += t; }
+        if ((threadIdx.x & 63u) == 63u) waveTotals[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        uint32_t waveBase = 0;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) waveBase += waveTotals[w];
+        const uint32_t c = carry;
+        if (i < nBlocks) blockSums[i] = c + waveBase + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = c + waveBase + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) counters[outIndex] = min(carry, capacity);
+}
+
+__global__ void __launch_bounds__(256) k_scan_words(const uint32_t* bitmask, uint32_t totalWords, const uint32_t* blockSums, uint32_t* wordPrefix) {
+    __shared__ uint32_t waveTotals[4];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = blockSums[blockIdx.x];
+    __syncthreads();
+    const uint32_t base = blockIdx.x * SCAN_BLOCK_WORDS;
+    for (uint32_t chunk = 0; chunk < SCAN_BLOCK_WORDS; chunk += 256) {
+        const uint32_t w = base + chunk + threadIdx.x;
+        const uint32_t v = w < totalWords ? __popc(bitmask[w]) : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o); if ((threadIdx.x & 63u) >= (uint32_t)o) incl += t; }
+        if ((threadIdx.x & 63u) == 63u) waveTotals[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        uint32_t waveBase = 0;
+        for (uint32_t k = 0; k < (threadIdx.x >> 6); k++) waveBase += waveTotals[k];
+        const uint32_t c = carry;
+        if (w < totalWords) wordPrefix[w] = c + waveBase + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 255) carry = c + waveBase + incl;
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256) k_scatter_visible(const TempVisible* temp, const uint32_t* counters, uint32_t tempCountIndex, const uint32_t* bitmask,
+                                                        const uint32_t* wordPrefix, uint4* visible, uint32_t baseIndexCounter, uint32_t capacity, uint32_t visibleCapacity) {
+    const uint32_t n = min(counters[tempCountIndex], visibleCapacity);
+    const uint32_t base = baseIndexCounter == 0xFFFFFFFFu ? 0u : counters[baseIndexCounter];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const TempVisible t = temp[i];
+        const uint32_t w = t.bit >> 5, b = t.bit & 31u;
+        const uint32_t rank = wordPrefix[w] + __popc(bitmask[w] & ((1u << b) - 1u));
+        const uint32_t dst = base + rank;
+        if (dst < capacity) visible[dst] = t.packed;
+    }
+}
+
+static inline uint32_t grid_for(uint64_t items, uint32_t block, uint32_t maxBlocks) {
+    uint64_t g = (items + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > maxBlocks) g = maxBlocks;
+    return (uint32_t)g;
+}
+
+int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
+    if (phase != 1) return fail(p, BRMI_ERR_INVALID, "brmi_cull: phase %u not available (occlusion phase 2 is not built yet)", phase);
+    CullArgs a;
+    a.sc = p->scene; a.counters = p->counters();
+    a.instanceBitBase = p->wsPtr<uint32_t>(p->ws.instanceBitBase); a.segPrefix = p->wsPtr<uint32_t>(p->ws.segPrefix);
+    a.recordCapacity = p->cfg.maxTraversalRecords; a.visibleCapacity = p->cfg.maxVisibleClusters;
+    uint32_t f = p->cfg.phase2ExpansionFactor; f = f < 1 ? 1 : (f > 64 ? 64 : f);
+    { uint32_t n = 1; for (uint32_t c = 2; c <= 64; c <<= 1) if (c <= f) n = c; f = n; }
+    a.factor = f; a.phase = phase;
+    a.bandActive = (p->bandY0 != 0 || p->bandY1 != p->cfg.height) ? 1u : 0u;
+    for (int k = 0; k < 3; k++) { a.bandTop[k] = p->bandPlaneTop[k]; a.bandBottom[k] = p->bandPlaneBottom[k]; }
+    NodeRecord* fa = p->wsPtr<NodeRecord>(p->ws.frontierA); NodeRecord* fb = p->wsPtr<NodeRecord>(p->ws.frontierB);
+    BucketRecord* buckets = p->wsPtr<BucketRecord>(p->ws.buckets);
+    TempVisible* temp = p->wsPtr<TempVisible>(p->ws.tempVisible);
+    uint32_t* bitmask = p->wsPtr<uint32_t>(p->ws.bitmask1);
+    uint32_t* wordPrefix = p->wsPtr<uint32_t>(p->ws.wordPrefix); uint32_t* blockSums = p->wsPtr<uint32_t>(p->ws.blockSums);
+
+    BRMI_HIP(p, hipMemsetAsync(p->counters(), 0, CNT_WORDS * sizeof(uint32_t), s));
+    BRMI_HIP(p, hipMemsetAsync(bitmask, 0, (size_t)p->totalWords * 4, s));
+    const uint32_t maxBlocks = 1024;
+    hipLaunchKernelGGL(k_cull_instances, dim3(grid_for(p->scene.activeDrawCount, 256, maxBlocks)), dim3(256), 0, s, a, fa);
+    BRMI_LAUNCH_CHECK(p, "k_cull_instances");
+    // frontier sizes are only known on the device: size the grids for the worst case that can matter
+    const uint32_t travGrid = grid_for(std::min<uint64_t>(p->cfg.maxTraversalRecords, (uint64_t)p->scene.lodNodeCount * 4 + 4096), 256, maxBlocks);
+    for (uint32_t level = 0; level < p->maxLevels; level++) {
+        hipLaunchKernelGGL(k_traverse, dim3(travGrid), dim3(256), 0, s, a, level, (level & 1u) ? fb : fa, (level & 1u) ? fa : fb, buckets);
+        BRMI_LAUNCH_CHECK(p, "k_traverse");
+    }
+    hipLaunchKernelGGL(k_cull_clusters, dim3(maxBlocks), dim3(256), 0, s, a, buckets, temp, bitmask);
+    BRMI_LAUNCH_CHECK(p, "k_cull_clusters");
+    hipLaunchKernelGGL(k_scan_reduce, dim3(p->scanBlocks), dim3(256), 0, s, bitmask, p->totalWords, blockSums);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, blockSums, p->scanBlocks, p->counters(), (uint32_t)CNT_VISIBLE, p->cfg.maxVisibleClusters);
+    hipLaunchKernelGGL(k_scan_words, dim3(p->scanBlocks), dim3(256), 0, s, bitmask, p->totalWords, blockSums, wordPrefix);
+    hipLaunchKernelGGL(k_scatter_visible, dim3(maxBlocks), dim3(256), 0, s, temp, p->counters(), (uint32_t)CNT_TEMP_VISIBLE, bitmask, wordPrefix,
+                       static_cast<uint4*>(p->res[BRMI_RES_VISIBLE_CLUSTERS]), 0xFFFFFFFFu, p->cfg.maxVisibleClusters, p->cfg.maxVisibleClusters);
+    BRMI_LAUNCH_CHECK(p, "compaction");
+    return BRMI_OK;
+}
+
+}  // namespace brmi

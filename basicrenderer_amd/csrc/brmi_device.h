@@ -1,0 +1,156 @@
+// brmi_device.h -- device-side arithmetic and data-access helpers shared by the HIP kernels.
+//
+// Arithmetic contract (the same specification the CPU checker is written against, implemented
+// here independently): IEEE-754 binary32, round-to-nearest-even, NO fused multiply-add (the
+// library is compiled with -ffp-contract=off), correctly rounded division and square root
+// (-fhip-fp32-correctly-rounded-divide-sqrt), denormals preserved.  HLSL semantics restated:
+//   mul(v, M)   row vector x row-major matrix, k accumulated 0..3 left to right
+//   dot(a, b)   ((a.x*b.x + a.y*b.y) + a.z*b.z) (+ a.w*b.w)
+//   rcp(x) = 1/x ; rsqrt(x) = 1/sqrt(x) ; normalize(v) = v * rsqrt(dot(v,v))
+#ifndef BRMI_DEVICE_H
+#define BRMI_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "brmi.h"
+
+#define BRMI_DEV __device__ __forceinline__
+
+namespace brmi {
+
+struct f2 { float x, y; };
+struct f3 { float x, y, z; };
+struct f4 { float x, y, z, w; };
+struct m4 { float m[4][4]; };
+
+BRMI_DEV uint32_t as_u32(float f) { return __float_as_uint(f); }
+BRMI_DEV float as_f32(uint32_t u) { return __uint_as_float(u); }
+
+BRMI_DEV f3 operator+(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+BRMI_DEV f3 operator-(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+BRMI_DEV f3 operator*(f3 a, f3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+BRMI_DEV f3 operator/(f3 a, f3 b) { return {a.x / b.x, a.y / b.y, a.z / b.z}; }
+BRMI_DEV f3 operator*(f3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+BRMI_DEV f3 operator*(float s, f3 a) { return {s * a.x, s * a.y, s * a.z}; }
+BRMI_DEV f3 operator/(f3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+BRMI_DEV f3 operator-(f3 a) { return {-a.x, -a.y, -a.z}; }
+BRMI_DEV f2 operator+(f2 a, f2 b) { return {a.x + b.x, a.y + b.y}; }
+BRMI_DEV f2 operator-(f2 a, f2 b) { return {a.x - b.x, a.y - b.y}; }
+
+BRMI_DEV float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+BRMI_DEV float dot4(f4 a, f4 b) { return ((a.x * b.x + a.y * b.y) + a.z * b.z) + a.w * b.w; }
+BRMI_DEV f3 cross3(f3 a, f3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+BRMI_DEV float rcpf(float x) { return 1.0f / x; }
+BRMI_DEV float rsqrtf_(float x) { return 1.0f / sqrtf(x); }
+BRMI_DEV float length3(f3 a) { return sqrtf(dot3(a, a)); }
+BRMI_DEV f3 normalize3(f3 a) { return a * rsqrtf_(dot3(a, a)); }
+BRMI_DEV float min2(float a, float b) { return a < b ? a : b; }
+BRMI_DEV float max2(float a, float b) { return a > b ? a : b; }
+BRMI_DEV float sat(float x) { return min2(max2(x, 0.0f), 1.0f); }
+BRMI_DEV f3 sat3(f3 v) { return {sat(v.x), sat(v.y), sat(v.z)}; }
+BRMI_DEV float clampf(float x, float a, float b) { return min2(max2(x, a), b); }
+BRMI_DEV float lerpf(float a, float b, float t) { return a + t * (b - a); }
+BRMI_DEV f3 lerp3(f3 a, f3 b, float t) { return {lerpf(a.x, b.x, t), lerpf(a.y, b.y, t), lerpf(a.z, b.z, t)}; }
+BRMI_DEV f3 min3v(f3 a, f3 b) { return {min2(a.x, b.x), min2(a.y, b.y), min2(a.z, b.z)}; }
+BRMI_DEV f3 max3v(f3 a, f3 b) { return {max2(a.x, b.x), max2(a.y, b.y), max2(a.z, b.z)}; }
+BRMI_DEV f3 xyz(f4 v) { return {v.x, v.y, v.z}; }
+
+BRMI_DEV f4 mul_vm(f4 v, const m4& a) {
+    f4 r;
+    r.x = ((v.x * a.m[0][0] + v.y * a.m[1][0]) + v.z * a.m[2][0]) + v.w * a.m[3][0];
+    r.y = ((v.x * a.m[0][1] + v.y * a.m[1][1]) + v.z * a.m[2][1]) + v.w * a.m[3][1];
+    r.z = ((v.x * a.m[0][2] + v.y * a.m[1][2]) + v.z * a.m[2][2]) + v.w * a.m[3][2];
+    r.w = ((v.x * a.m[0][3] + v.y * a.m[1][3]) + v.z * a.m[2][3]) + v.w * a.m[3][3];
+    return r;
+}
+BRMI_DEV f4 mul_point(f3 p, const m4& a) { return mul_vm(f4{p.x, p.y, p.z, 1.0f}, a); }
+BRMI_DEV f3 mul_v3m3(f3 v, const m4& a) {
+    return {(v.x * a.m[0][0] + v.y * a.m[1][0]) + v.z * a.m[2][0],
+            (v.x * a.m[0][1] + v.y * a.m[1][1]) + v.z * a.m[2][1],
+            (v.x * a.m[0][2] + v.y * a.m[1][2]) + v.z * a.m[2][2]};
+}
+BRMI_DEV m4 mul_mm(const m4& a, const m4& b) {
+    m4 r;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            r.m[i][j] = ((a.m[i][0] * b.m[0][j] + a.m[i][1] * b.m[1][j]) + a.m[i][2] * b.m[2][j]) + a.m[i][3] * b.m[3][j];
+    return r;
+}
+BRMI_DEV f4 mul_mcol(const m4& a, f4 v) {
+    return {((a.m[0][0] * v.x + a.m[0][1] * v.y) + a.m[0][2] * v.z) + a.m[0][3] * v.w,
+            ((a.m[1][0] * v.x + a.m[1][1] * v.y) + a.m[1][2] * v.z) + a.m[1][3] * v.w,
+            ((a.m[2][0] * v.x + a.m[2][1] * v.y) + a.m[2][2] * v.z) + a.m[2][3] * v.w,
+            ((a.m[3][0] * v.x + a.m[3][1] * v.y) + a.m[3][2] * v.z) + a.m[3][3] * v.w};
+}
+BRMI_DEV const m4& as_m4(const float (&a)[4][4]) { return *reinterpret_cast<const m4*>(&a[0][0]); }
+BRMI_DEV m4 load_m4(const float* p) {   // 64 B, 16 B aligned
+    m4 r;
+    const float4* q = reinterpret_cast<const float4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; i++) { float4 v = q[i]; r.m[i][0] = v.x; r.m[i][1] = v.y; r.m[i][2] = v.z; r.m[i][3] = v.w; }
+    return r;
+}
+BRMI_DEV float max_axis_scale(const m4& m) {   // MaxAxisScale_RowVector
+    f3 ax{m.m[0][0], m.m[0][1], m.m[0][2]}, ay{m.m[1][0], m.m[1][1], m.m[1][2]}, az{m.m[2][0], m.m[2][1], m.m[2][2]};
+    return max2(length3(ax), max2(length3(ay), length3(az)));
+}
+
+// float -> int with the saturating semantics of v_cvt_i32_f32, stated explicitly
+BRMI_DEV int to_int_sat(float f) {
+    if (!(f == f)) return 0;
+    if (f >= 2147483648.0f) return 2147483647;
+    if (f <= -2147483648.0f) return (-2147483647 - 1);
+    return (int)f;
+}
+
+// ---- packing ----------------------------------------------------------------------------------
+BRMI_DEV uint32_t f32_to_f16_bits(float f) { return (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)f); }   // v_cvt_f16_f32, RTNE
+BRMI_DEV float f16_bits_to_f32(uint32_t h) { return (float)__builtin_bit_cast(_Float16, (unsigned short)h); }
+BRMI_DEV uint64_t pack_half4(float a, float b, float c, float d) {
+    return (uint64_t)f32_to_f16_bits(a) | ((uint64_t)f32_to_f16_bits(b) << 16) | ((uint64_t)f32_to_f16_bits(c) << 32) | ((uint64_t)f32_to_f16_bits(d) << 48);
+}
+BRMI_DEV uint32_t unorm8(float x) { return (uint32_t)(sat(x) * 255.0f + 0.5f); }
+BRMI_DEV uint32_t pack_unorm4(float a, float b, float c, float d) { return unorm8(a) | (unorm8(b) << 8) | (unorm8(c) << 16) | (unorm8(d) << 24); }
+BRMI_DEV float unorm8_to_f32(uint32_t v) { return (float)(v & 0xFFu) / 255.0f; }
+
+// visibility key: 31 bits depth | 26 bits cluster | 7 bits triangle
+BRMI_DEV uint64_t pack_vis_key(float depth, uint32_t cluster, uint32_t tri) {
+    const uint64_t depthBits = as_u32(depth) >> 1;
+    return (depthBits << BRMI_VIS_META_BITS) | ((uint64_t)(cluster & 0x3FFFFFFu) << BRMI_VIS_TRI_BITS) | (uint64_t)(tri & 0x7Fu);
+}
+
+// packed visible cluster accessors
+BRMI_DEV uint32_t vc_view(const uint4& c) { return c.x & 0xFFu; }
+BRMI_DEV uint32_t vc_instance(const uint4& c) { return (c.x >> 8) & 0xFFFFFFu; }
+BRMI_DEV uint32_t vc_meshlet(const uint4& c) { return c.y & 0x3FFFu; }
+BRMI_DEV uint32_t vc_group(const uint4& c) { return ((c.y >> 14) & 0x3FFFFu) | ((c.z & 0x3u) << 18); }
+BRMI_DEV uint32_t vc_slab(const uint4& c) { return (c.z >> 2) & 0xFFFFFu; }
+BRMI_DEV uint32_t vc_page_offset(const uint4& c) { return ((c.z >> 22) & 0x3FFu) << 18; }
+BRMI_DEV uint4 pack_visible_cluster(uint32_t view, uint32_t inst, uint32_t meshlet, uint32_t group, uint32_t slab, uint32_t pageByteOffset) {
+    const uint32_t page = pageByteOffset >> 18;
+    return make_uint4((view & 0xFFu) | ((inst & 0xFFFFFFu) << 8), (meshlet & 0x3FFFu) | ((group & 0x3FFFFu) << 14),
+                      ((group >> 18) & 0x3u) | ((slab & 0xFFFFFu) << 2) | ((page & 0x3FFu) << 22), 0x1Fu);
+}
+
+// tiled 8x8 surface addressing: element index of pixel (x, y)
+BRMI_DEV uint32_t tiled_index(uint32_t x, uint32_t y, uint32_t tilesX) { return (((y >> 3) * tilesX + (x >> 3)) << 6) | ((y & 7u) << 3) | (x & 7u); }
+
+// wave64 helpers
+BRMI_DEV uint32_t lane_id() { return __lane_id(); }
+BRMI_DEV uint32_t lane_rank(uint64_t mask) { return __popcll(mask & ((1ull << lane_id()) - 1ull)); }
+// wave-aggregated append: one atomic per wave; returns the slot of this lane (valid when pred)
+BRMI_DEV uint32_t wave_append(uint32_t* counter, bool pred) {
+    const uint64_t mask = __ballot(pred);
+    if (mask == 0) return 0;
+    const uint32_t leader = __ffsll((unsigned long long)mask) - 1;
+    uint32_t base = 0;
+    if (lane_id() == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    return base + lane_rank(mask);
+}
+
+}  // namespace brmi
+#endif

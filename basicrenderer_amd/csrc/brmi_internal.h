@@ -1,0 +1,100 @@
+// brmi_internal.h -- host-side state of one brmi_pass and the workspace carve-up.
+#ifndef BRMI_INTERNAL_H
+#define BRMI_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "brmi.h"
+
+namespace brmi {
+
+// device-visible counters block (u32 words) at the head of the workspace
+enum CounterIndex : uint32_t {
+    CNT_BUCKETS = 0,          // bucket records appended by the traversal
+    CNT_TEMP_VISIBLE,         // survivors appended by the cluster cull (phase 1)
+    CNT_TEMP_VISIBLE2,        // survivors of phase 2
+    CNT_VISIBLE,              // phase-1 visible clusters after compaction (min(capacity))
+    CNT_VISIBLE2,             // phase-2 visible clusters after compaction
+    CNT_DROPPED_RECORDS,
+    CNT_DROPPED_CLUSTERS,
+    CNT_INSTANCES_TESTED,
+    CNT_INSTANCES_VISIBLE,
+    CNT_NODES_VISITED,
+    CNT_MESHLETS_TESTED,
+    CNT_LIGHT_PAGES,
+    CNT_REPLAY_NODES,
+    CNT_REPLAY_MESHLETS,
+    CNT_SUM_VERTS_LO, CNT_SUM_VERTS_HI,     // sum of vertex counts of rasterised clusters (u64)
+    CNT_SUM_TRIS_LO, CNT_SUM_TRIS_HI,
+    CNT_RASTER_CLUSTERS,
+    CNT_FRONTIER0 = 32,       // frontier sizes per BFS level: [CNT_FRONTIER0 + level]
+    CNT_WORDS = 32 + 72
+};
+
+// internal records (ours; the reference's 12 B / 24 B records plus the rank bookkeeping)
+struct NodeRecord { uint32_t instanceIndex, nodeIdPacked; };                       // 8 B (single view)
+struct BucketRecord {                                                                 // 32 B
+    uint32_t instanceIndex, groupIdPacked, meshletIndexAndCount, pageSlabDescriptorIndex;
+    uint32_t pageSlabByteOffset, firstBit, pad0, pad1;
+};
+struct TempVisible { uint4 packed; uint32_t bit, pad0, pad1, pad2; };                // 32 B
+
+struct Workspace {     // byte offsets into BRMI_RES_WORKSPACE
+    uint64_t counters, frontierA, frontierB, buckets, tempVisible, bitmask1, bitmask2, wordPrefix, blockSums,
+             instanceBitBase, segPrefix, planes, replayNodes, replayBuckets, total;
+};
+
+}  // namespace brmi
+
+struct brmi_pass {
+    brmi_config cfg{};
+    brmi_scene_buffers scene{};
+    bool haveScene = false, setupDone = false, updated = false;
+    void* res[BRMI_RES_COUNT] = {};
+    uint64_t resBytes[BRMI_RES_COUNT] = {};
+    uint64_t resNeed[BRMI_RES_COUNT] = {};
+    uint32_t tilesX = 0, tilesY = 0;
+    uint64_t paddedPixels = 0;
+    uint32_t bandY0 = 0, bandY1 = 0;
+    float bandPlaneTop[3] = {0, 0, 0}, bandPlaneBottom[3] = {0, 0, 0};
+    uint64_t bandFirstPixel = 0, bandPixelCount = 0;   // tiled index range covering the band's tile rows
+    uint32_t maxLevels = 1;
+    uint64_t totalBits = 0; uint32_t totalWords = 0, scanBlocks = 0;
+    uint32_t numLightClusters = 0, lightPagePool = 0;
+    uint32_t hzbMipCount = 0; std::vector<uint64_t> hzbMipOffsets; std::vector<uint32_t> hzbMipW, hzbMipH;
+    std::vector<uint32_t> hostInstanceBitBase, hostSegPrefix;
+    brmi::Workspace ws{};
+    brmi_camera camHost{};
+    brmi_per_frame pfHost{};
+    std::vector<float> planesHost;
+    static constexpr uint32_t kEventRing = 32;     // per-stage event pairs of the last kEventRing frames
+    hipEvent_t evStart[BRMI_STAGE_COUNT][kEventRing] = {}, evStop[BRMI_STAGE_COUNT][kEventRing] = {};
+    uint32_t evCount[BRMI_STAGE_COUNT] = {};       // recordings since the last brmi_stage_times()
+    bool eventsCreated = false;
+    std::string err;
+
+    template <typename T> T* wsPtr(uint64_t off) const { return reinterpret_cast<T*>(static_cast<uint8_t*>(res[BRMI_RES_WORKSPACE]) + off); }
+    uint32_t* counters() const { return wsPtr<uint32_t>(ws.counters); }
+};
+
+namespace brmi {
+
+int fail(brmi_pass* p, int code, const char* fmt, ...);
+#define BRMI_HIP(p, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return brmi::fail((p), BRMI_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); } while (0)
+#define BRMI_LAUNCH_CHECK(p, what) do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return brmi::fail((p), BRMI_ERR_HIP, "launch %s: %s", (what), hipGetErrorString(e_)); } while (0)
+
+// stage launchers (one translation unit each)
+int launch_clear(brmi_pass* p, hipStream_t s);
+int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s);
+int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s);
+int launch_depth_copy(brmi_pass* p, hipStream_t s);
+int launch_hzb(brmi_pass* p, hipStream_t s);
+int launch_gbuffer(brmi_pass* p, hipStream_t s);
+int launch_light_clustering(brmi_pass* p, hipStream_t s);
+int launch_shade(brmi_pass* p, hipStream_t s);
+
+}  // namespace brmi
+#endif

@@ -1,0 +1,610 @@
+// brmi_light.hip -- light clustering (K9 + K10) and clustered OpenPBR deferred shading (K11) for gfx950.
+//
+// Reference: BR/shaders/clustering.hlsl:31-107, BR/shaders/lightCulling.hlsl:40-126,
+// BR/shaders/deferred.hlsl:11-106, BR/shaders/Include/lighting.hlsli:81-196,391-661,
+// BR/shaders/Include/IBL.hlsli:94-672, BR/shaders/Include/PBR.hlsli:8-190,
+// BR/shaders/Include/utilities.hlsli:2590-2709.
+// MI355X-first differences:
+//   * K9 (1 thread per group, 3456 groups) and K10 (global atomic page allocator) fuse into one
+//     workgroup: AABBs, a counting pass, an LDS prefix scan that hands every cluster a contiguous,
+//     deterministic page range (= the allocation order of a serial run of the reference), and the
+//     fill pass.  Page contents and list order are exactly the reference's; page numbers no longer
+//     depend on atomic ordering.
+//   * slice plane depths come from the host (see brmi_update): log()/exp() results differ in the
+//     last bit between math libraries and would make light lists irreproducible.
+//   * K11 runs one lane per pixel in tile order (a wave = one 8x8 tile): all G-buffer reads and the
+//     HDR write are contiguous per wave.
+//   * OpenPBR lookup tables are injected R16_UNORM / float tables, bilinearly filtered in fp32.
+#include "brmi_device.h"
+#include "brmi_internal.h"
+
+namespace brmi {
+
+constexpr float PI_F = 3.1415926538f;
+constexpr float MEDIUMP_MAX = 65504.0f;
+
+// =================================== K9 + K10 ==================================================
+struct ClusterArgs {
+    brmi_scene_buffers sc;
+    const float* planes;          // near/far per slice, 2 * gridZ
+    brmi_light_cluster* clusters;
+    brmi_light_page* pages;
+    uint32_t poolSize;
+    uint32_t* counters;
+};
+
+BRMI_DEV bool light_hits_cluster(const brmi_light_info* l, const m4& view, f3 mn, f3 mx) {
+    if (l->type == BRMI_LIGHT_DIRECTIONAL) return true;
+    if (l->type != BRMI_LIGHT_POINT && l->type != BRMI_LIGHT_SPOT) return false;
+    const f3 center = xyz(mul_point(f3{l->boundingSphere[0], l->boundingSphere[1], l->boundingSphere[2]}, view));
+    const f3 closest = max3v(mn, min3v(center, mx));
+    const f3 d = closest - center;
+    return dot3(d, d) <= l->boundingSphere[3] * l->boundingSphere[3];
+}
+
+constexpr uint32_t MAX_CLUSTERS_LDS = 16384;
+
+__global__ void __launch_bounds__(1024) k_light_clustering(ClusterArgs a) {
+    __shared__ uint32_t pageBase[MAX_CLUSTERS_LDS];
+    __shared__ uint32_t waveTotals[16];
+    const brmi_scene_buffers& sc = a.sc;
+    const brmi_per_frame* pf = sc.perFrame;
+    const brmi_camera* cam = sc.cameras + pf->mainCameraIndex;
+    const uint32_t gx = pf->lightClusterGridSizeX, gy = pf->lightClusterGridSizeY, gz = pf->lightClusterGridSizeZ;
+    const uint32_t total = gx * gy * gz, lightCount = pf->numLights;
+    const float W = (float)pf->screenResX, H = (float)pf->screenResY;
+    const m4 invProj = load_m4(&cam->projectionInverse[0][0]);
+    const m4 view = load_m4(&cam->view[0][0]);
+    const float tsx = W / (float)gx, tsy = H / (float)gy;
+    const uint32_t perThread = (total + 1023u) / 1024u;
+    const uint32_t cBegin = threadIdx.x * perThread, cEnd = min(cBegin + perThread, total);
+
+    // pass 1: AABB (clustering.hlsl) + page demand of the serial allocator (lightCulling.hlsl:70-118)
+    uint32_t myPages = 0;
+    for (uint32_t idx = cBegin; idx < cEnd; idx++) {
+        const uint32_t x = idx % gx, y = (idx / gx) % gy, z = idx / (gx * gy);
+        f3 tileV[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const float sxp = ((float)x + (k ? 1.0f : 0.0f)) * tsx, syp = ((float)y + (k ? 1.0f : 0.0f)) * tsy;
+            const f4 ndc{2.0f * sxp / W - 1.0f, 2.0f * (H - syp - 1.0f) / H - 1.0f, 1.0f, 1.0f};
+            const f4 v = mul_vm(ndc, invProj);
+            tileV[k] = f3{v.x / v.w, v.y / v.w, v.z / v.w};
+        }
+        const float pn = a.planes[2 * z], pfar = a.planes[2 * z + 1];
+        f3 pts[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const f3 e = tileV[k & 1];
+            const float t = ((k & 2) ? pfar : pn) / e.z;
+            pts[k] = f3{t * e.x, t * e.y, t * e.z};
+        }
+        const f3 mn = min3v(min3v(pts[0], pts[1]), min3v(pts[2], pts[3])), mx = max3v(max3v(pts[0], pts[1]), max3v(pts[2], pts[3]));
+        brmi_light_cluster* c = a.clusters + idx;
+        *reinterpret_cast<float4*>(c->minPoint) = make_float4(mn.x, mn.y, mn.z, 0.0f);
+        *reinterpret_cast<float4*>(c->maxPoint) = make_float4(mx.x, mx.y, mx.z, 0.0f);
+        uint32_t pagesNeeded = 1, inPage = 0;
+        for (uint32_t i = 0; i < lightCount; i++) {
+            if (inPage >= BRMI_LIGHTS_PER_PAGE) { pagesNeeded++; inPage = 0; }
+            if (light_hits_cluster(sc.lights + sc.activeLightIndices[i], view, mn, mx)) inPage++;
+        }
+        pageBase[idx] = pagesNeeded;
+        myPages += pagesNeeded;
+    }
+    // block-wide exclusive scan of per-thread demand
+    uint32_t incl = myPages;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o); if ((threadIdx.x & 63u) >= (uint32_t)o) incl += t; }
+    if ((threadIdx.x & 63u) == 63u) waveTotals[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t base = incl - myPages;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) base += waveTotals[w];
+    if (threadIdx.x == 1023) a.counters[CNT_LIGHT_PAGES] = min(base + myPages, a.poolSize);
+
+    // pass 2: fill (same control flow as the reference, page numbers from the scan)
+    for (uint32_t idx = cBegin; idx < cEnd; idx++) {
+        brmi_light_cluster* c = a.clusters + idx;
+        const f3 mn{c->minPoint[0], c->minPoint[1], c->minPoint[2]}, mx{c->maxPoint[0], c->maxPoint[1], c->maxPoint[2]};
+        uint32_t next = base; base += pageBase[idx];
+        auto alloc = [&]() { const uint32_t i = next++; return i >= a.poolSize ? BRMI_LIGHT_PAGE_NULL : i; };
+        uint32_t page = alloc();
+        uint32_t numLights = 0, firstPage = page;
+        if (page != BRMI_LIGHT_PAGE_NULL) {
+            a.pages[page].ptrNextPage = BRMI_LIGHT_PAGE_NULL;
+            uint32_t inPage = 0;
+            for (uint32_t i = 0; i < lightCount; i++) {
+                if (inPage >= BRMI_LIGHTS_PER_PAGE) {
+                    a.pages[page].numLightsInPage = BRMI_LIGHTS_PER_PAGE;
+                    const uint32_t old = page;
+                    page = alloc();
+                    if (page == BRMI_LIGHT_PAGE_NULL) break;
+                    a.pages[page].ptrNextPage = old;
+                    firstPage = page;
+                    inPage = 0;
+                }
+                const uint32_t li = sc.activeLightIndices[i];
+                if (light_hits_cluster(sc.lights + li, view, mn, mx)) { a.pages[page].lightIndices[inPage] = li; inPage++; numLights++; }
+            }
+            if (page != BRMI_LIGHT_PAGE_NULL) a.pages[page].numLightsInPage = inPage;
+        }
+        c->numLights = numLights; c->ptrFirstPage = firstPage; c->pad[0] = 0; c->pad[1] = 0;
+    }
+}
+
+// =================================== K11 =======================================================
+struct Luts { const uint16_t* odE; const uint16_t* odAvg; const uint16_t* imE; const uint16_t* imAvg; const float* ltc; };
+
+BRMI_DEV float texel_u16(const uint16_t* t, uint32_t i) { return (float)t[i] / 65535.0f; }
+BRMI_DEV uint32_t clamp_texel(float f, uint32_t n) { int i = (int)f; i = i < 0 ? 0 : i; i = i > (int)n - 1 ? (int)n - 1 : i; return (uint32_t)i; }
+BRMI_DEV float sample_u16(const uint16_t* t, uint32_t W, uint32_t H, float u, float v) {
+    const float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
+    const float x0f = floorf(x), y0f = floorf(y);
+    const float fx = x - x0f, fy = y - y0f;
+    const uint32_t x0 = clamp_texel(x0f, W), x1 = clamp_texel(x0f + 1.0f, W), y0 = clamp_texel(y0f, H), y1 = clamp_texel(y0f + 1.0f, H);
+    const float r0 = lerpf(texel_u16(t, y0 * W + x0), texel_u16(t, y0 * W + x1), fx);
+    const float r1 = lerpf(texel_u16(t, y1 * W + x0), texel_u16(t, y1 * W + x1), fx);
+    return lerpf(r0, r1, fy);
+}
+BRMI_DEV f3 sample_ltc(const float* t, float u, float v) {
+    const float x = u * 32.0f - 0.5f, y = v * 32.0f - 0.5f;
+    const float x0f = floorf(x), y0f = floorf(y);
+    const float fx = x - x0f, fy = y - y0f;
+    const uint32_t x0 = clamp_texel(x0f, 32), x1 = clamp_texel(x0f + 1.0f, 32), y0 = clamp_texel(y0f, 32), y1 = clamp_texel(y0f + 1.0f, 32);
+    auto T = [&](uint32_t yy, uint32_t xx) { const float4 q = *reinterpret_cast<const float4*>(t + ((size_t)yy * 32u + xx) * 4u); return f3{q.x, q.y, q.z}; };
+    return lerp3(lerp3(T(y0, x0), T(y0, x1), fx), lerp3(T(y1, x0), T(y1, x1), fx), fy);
+}
+
+// ---- PBR.hlsli
+BRMI_DEV void ggx_dir_albedo_AB(float NdotV, float alpha, float& A, float& B) {
+    const float x = NdotV, y = alpha, x2 = x * x, y2 = y * y;
+    const float c0[4] = {0.1003f, 0.9345f, 1.0f, 1.0f}, c1[4] = {-0.6303f, -2.323f, -1.765f, 0.2281f}, c2[4] = {9.748f, 2.229f, 8.263f, 15.94f},
+                c3[4] = {-2.038f, -3.748f, 11.53f, -55.83f}, c4[4] = {29.34f, 1.424f, 28.96f, 13.08f}, c5[4] = {-8.245f, -0.7684f, -7.507f, 41.26f},
+                c6[4] = {-26.44f, 1.436f, -36.11f, 54.9f}, c7[4] = {19.99f, 0.2913f, 15.86f, 300.2f}, c8[4] = {-5.448f, 0.6286f, 33.37f, -285.1f};
+    float r[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        r[i] = c0[i] + c1[i] * x + c2[i] * y + c3[i] * x * y + c4[i] * x2 + c5[i] * y2 + c6[i] * x2 * y + c7[i] * x * y2 + c8[i] * x2 * y2;
+    A = clampf(r[0] / r[2], 0.0f, 1.0f); B = clampf(r[1] / r[3], 0.0f, 1.0f);
+}
+BRMI_DEV f3 ggx_energy_compensation(float NdotV, float alpha, f3 Fss) {
+    float A, B; ggx_dir_albedo_AB(NdotV, alpha, A, B);
+    const float Ess = (f3{1.0f, 1.0f, 1.0f} * A + f3{1.0f, 1.0f, 1.0f} * B).x;
+    return f3{1.0f, 1.0f, 1.0f} + Fss * (1.0f - Ess) / Ess;
+}
+BRMI_DEV f3 f_schlick(f3 f0, float f90, float VoH) {
+    const float pw = powf(1.0f - VoH, 5.0f);
+    return f0 + (f3{f90, f90, f90} - f0) * pw;
+}
+BRMI_DEV float v_smith_ggx(float roughness, float NoV, float NoL) {
+    const float a2 = roughness * roughness;
+    const float lambdaV = NoL * sqrtf((NoV - a2 * NoV) * NoV + a2);
+    const float lambdaL = NoV * sqrtf((NoL - a2 * NoL) * NoL + a2);
+    return min2(0.5f / (lambdaV + lambdaL), MEDIUMP_MAX);
+}
+BRMI_DEV float d_ggx(float roughness, float NoH) {
+    const float oneMinus = 1.0f - NoH * NoH;
+    const float aa = NoH * roughness;
+    const float k = roughness / (oneMinus + aa * aa);
+    return min2(k * k * (1.0f / PI_F), MEDIUMP_MAX);
+}
+BRMI_DEV f3 specular_lobe(float roughness, f3 f0, float NoV, float NoL, float NoH, float LoH) {
+    const float D = d_ggx(roughness, NoH), V = v_smith_ggx(roughness, NoV, NoL);
+    const float tmp = 50.0f * 0.33f;
+    const float f90 = sat(dot3(f0, f3{tmp, tmp, tmp}));
+    return (D * V) * f_schlick(f0, f90, LoH);
+}
+
+// ---- IBL.hlsli (OpenPBR)
+constexpr float TBL = 32.0f, TBL_M1 = 31.0f, IOR_MAX = 2.5f, INV_IOR_MAX = 1.0f / 2.5f;
+BRMI_DEV float fon_a() { return 0.5f - 2.0f / (3.0f * PI_F); }
+BRMI_DEV float fon_b() { return 2.0f / 3.0f - 28.0f / (15.0f * PI_F); }
+BRMI_DEV float ior_to_f0(float ior) { const float s = max2(ior, 1.0f); const float f = (s - 1.0f) / (s + 1.0f); return f * f; }
+BRMI_DEV float ior_to_index(float ior) {
+    const float safeIor = max2(ior, 1.0e-4f);
+    const float half = 0.5f * TBL, halfM1 = half - 1.0f, inv = 1.0f / (IOR_MAX - 1.0f);
+    if (safeIor < 1.0f) { const float invIor = 1.0f / safeIor; const float fr = (invIor - 1.0f) * inv; return halfM1 - fr * halfM1; }
+    const float fr = (safeIor - 1.0f) * inv;
+    return half + fr * halfM1;
+}
+BRMI_DEV float alpha_to_index(float alpha) { return sqrtf(sat(alpha)) * TBL_M1; }
+BRMI_DEV float cos_to_index(float c) { return sat(c) * TBL_M1; }
+BRMI_DEV float clamp_index(float e) { return clampf(e, 0.0f, TBL_M1); }
+BRMI_DEV float remap_index(float e) { const float inv = 1.0f / TBL; const float mn = 0.5f * inv, mx = 1.0f - mn; return clampf(mn + e * inv, mn, mx); }
+BRMI_DEV float extrapolate_ior(float tableValue, float ior) {
+    if (ior > IOR_MAX || ior < INV_IOR_MAX) {
+        const float f0Max = ior_to_f0(IOR_MAX);
+        const float invRange = 1.0f / (1.0f - f0Max);
+        const float f0 = ior_to_f0(max2(ior, 1.0e-4f));
+        const float progress = (f0 - f0Max) * invRange;
+        return (1.0f - progress) * tableValue;
+    }
+    return tableValue;
+}
+BRMI_DEV float fresnel_dielectric(float eta, float cosI) {
+    const float c = sat(cosI);
+    if (fabsf(eta - 1.0f) <= 1.0e-6f) return 0.0f;
+    const float s2 = max2(0.0f, 1.0f - c * c);
+    const float st2 = s2 / max2(eta * eta, 1.0e-6f);
+    if (st2 >= 1.0f) return 1.0f;
+    const float ct = sqrtf(max2(0.0f, 1.0f - st2));
+    const float eci = eta * c, ect = eta * ct;
+    const float rs = (c - ect) / max2(c + ect, 1.0e-6f);
+    const float rp = (ct - eci) / max2(ct + eci, 1.0e-6f);
+    return 0.5f * (rs * rs + rp * rp);
+}
+BRMI_DEV float lut_od_avg(const Luts& L, float ior, float alpha) {
+    const float ei = clamp_index(ior_to_index(ior)), ea = clamp_index(alpha_to_index(alpha));
+    return extrapolate_ior(sample_u16(L.odAvg, 32, 32, remap_index(ea), remap_index(ei)), ior);
+}
+BRMI_DEV float lut_od_e(const Luts& L, float ior, float alpha, float cosT) {
+    const float ei = clamp_index(ior_to_index(ior)), ea = clamp_index(alpha_to_index(alpha)), ec = clamp_index(cos_to_index(cosT));
+    const int s0 = (int)floorf(ei);
+    const int s1 = (s0 + 1) < 31 ? (s0 + 1) : 31;
+    const float st = ei - (float)s0;
+    const float u = remap_index(ec), v = remap_index(ea);
+    const float v0 = sample_u16(L.odE + (size_t)s0 * 1024u, 32, 32, u, v), v1 = sample_u16(L.odE + (size_t)s1 * 1024u, 32, 32, u, v);
+    return extrapolate_ior(lerpf(v0, v1, st), ior);
+}
+BRMI_DEV float lut_im_e(const Luts& L, float alpha, float cosT) {
+    const float ea = clamp_index(alpha_to_index(alpha)), ec = clamp_index(cos_to_index(cosT));
+    return sample_u16(L.imE, 32, 32, remap_index(ec), remap_index(ea));
+}
+BRMI_DEV float lut_im_avg(const Luts& L, float alpha) {
+    const float ea = clamp_index(alpha_to_index(alpha));
+    return sample_u16(L.imAvg, 32, 1, remap_index(ea), 0.5f);
+}
+BRMI_DEV f3 lut_fuzz_ltc(const Luts& L, float roughness, float cosT) {
+    const float u = sat(cosT) * (31.0f / 32.0f) + 0.5f / 32.0f, v = sat(roughness) * (31.0f / 32.0f) + 0.5f / 32.0f;
+    return sample_ltc(L.ltc, u, v);
+}
+BRMI_DEV float average_fresnel(float eta) {
+    const float s = max2(eta, 1.0e-4f);
+    if (s > 1.0f) return (s - 1.0f) / (4.08567f + 1.00071f * s);
+    const float s2 = s * s;
+    return 0.997118f + 0.1014f * s - 0.965241f * s2 - 0.130607f * s2 * s;
+}
+
+struct BaseState {
+    f3 weightedBaseColor, diffuseColor; float baseDiffuseRoughness, specularAlpha, weightedSpecularIor;
+    f3 dielectricSpecularF0; float dielectricSpecularWeight; f3 metalSpecularF0, metalAverageFresnel, metalMultipleScatterScale; float metalSpecularWeight;
+};
+struct CoatState { f3 tint; float presence, ior, roughness; f3 extraBaseLayerScale; };
+struct FuzzState { float roughness; f3 tint; float presence; f3 t, b, n, viewDirLocal; float viewReflected; };
+struct Frag {
+    f3 posWS, normalWS, viewWS, albedo, diffuseColor, emissive, dielectricSpecularF0, metalSpecularF0, metalAverageFresnel, coatColor, coatF0, fuzzColor;
+    float NdotV, roughness, baseDiffuseRoughness, specularAlpha, weightedSpecularIor, dielectricSpecularWeight, metalSpecularWeight, coatWeight, coatIor, coatDarkening, coatRoughness, fuzzWeight, fuzzRoughness;
+};
+
+BRMI_DEV BaseState make_base_state(const Frag& f) {
+    BaseState s;
+    s.weightedBaseColor = sat3(f.albedo); s.diffuseColor = f.diffuseColor; s.baseDiffuseRoughness = sat(f.baseDiffuseRoughness);
+    s.specularAlpha = sat(f.specularAlpha); s.weightedSpecularIor = max2(f.weightedSpecularIor, 1.0f);
+    s.dielectricSpecularF0 = sat3(f.dielectricSpecularF0); s.dielectricSpecularWeight = sat(f.dielectricSpecularWeight);
+    s.metalAverageFresnel = sat3(f.metalAverageFresnel); s.metalSpecularF0 = sat3(f.metalSpecularF0); s.metalSpecularWeight = sat(f.metalSpecularWeight);
+    s.metalMultipleScatterScale = s.metalSpecularWeight * s.metalAverageFresnel * s.metalAverageFresnel;
+    return s;
+}
+BRMI_DEV CoatState make_coat_state(const BaseState& b, const Frag& f) {
+    CoatState s;
+    s.tint = sat3(f.coatColor); s.presence = sat(f.coatWeight); s.ior = max2(f.coatIor, 1.0f); s.roughness = sat(f.coatRoughness);
+    // OpenPBRComputeCoatExtraBaseLayerScale
+    const float safeIor = max2(s.ior, 1.0f);
+    const float K_s = average_fresnel(safeIor);
+    const float K_r = 1.0f - (1.0f - K_s) / max2(safeIor * safeIor, 1.0e-4f);
+    const float ds = average_fresnel(b.weightedSpecularIor);
+    const float specBase = sat(b.dielectricSpecularWeight * ds + (1.0f - b.dielectricSpecularWeight));
+    const float effRough = lerpf(1.0f, sqrtf(sat(b.specularAlpha)), specBase);
+    const float K = lerpf(K_s, K_r, effRough);
+    const f3 fromMetal = b.metalSpecularWeight * b.metalAverageFresnel;
+    const f3 fromDiel = b.dielectricSpecularWeight * lerp3(b.weightedBaseColor, f3{1.0f, 1.0f, 1.0f}, ds);
+    const f3 E_b = sat3(fromMetal + fromDiel);
+    const f3 Delta = f3{1.0f - K, 1.0f - K, 1.0f - K} / max3v(f3{1.0f, 1.0f, 1.0f} - E_b * K, f3{1.0e-4f, 1.0e-4f, 1.0e-4f});
+    const float mod = sat(s.presence) * sat(f.coatDarkening);
+    s.extraBaseLayerScale = lerp3(f3{1.0f, 1.0f, 1.0f}, sat3(Delta), mod);
+    return s;
+}
+BRMI_DEV f3 coat_passage(const CoatState& s, float NdotX) {
+    const float c = sat(NdotX);
+    if (c <= 0.0f || min2(s.tint.x, min2(s.tint.y, s.tint.z)) >= 1.0f) return f3{1.0f, 1.0f, 1.0f};
+    const f3 t0{sqrtf(s.tint.x), sqrtf(s.tint.y), sqrtf(s.tint.z)};
+    const float eta = rcpf(s.ior);
+    const float rc = sqrtf(max2(0.0f, 1.0f - (1.0f - c * c) / max2(eta * eta, 1.0e-4f)));
+    const float ds = rcpf(max2(rc, 1.0e-4f));
+    const f3 tr{powf(t0.x, ds), powf(t0.y, ds), powf(t0.z, ds)};
+    return lerp3(f3{1.0f, 1.0f, 1.0f}, tr, s.presence);
+}
+BRMI_DEV float coat_reflected(const Luts& L, const CoatState& s, float NdotX) {
+    const float si = max2(s.ior, 1.0e-4f), sa = sat(s.roughness), sc = sat(NdotX);
+    const float refl = (sa <= 0.0f) ? fresnel_dielectric(si, sc) : 1.0f - lut_od_e(L, si, sa, sc);
+    return sat(s.presence * refl);
+}
+BRMI_DEV f3 coat_scale_incoming(const Luts& L, const CoatState& s, float NdotV) {
+    const float rp = coat_reflected(L, s, NdotV);
+    return coat_passage(s, NdotV) * f3{1.0f - rp, 1.0f - rp, 1.0f - rp} * s.extraBaseLayerScale;
+}
+BRMI_DEV f3 coat_scale_outgoing(const Luts& L, const CoatState& s, float NdotL) {
+    const float rp = coat_reflected(L, s, NdotL);
+    return coat_passage(s, NdotL) * f3{1.0f - rp, 1.0f - rp, 1.0f - rp};
+}
+BRMI_DEV float fuzz_dir_reflectance(const Luts& L, float r, float c) { return sat(lut_fuzz_ltc(L, r, c).z); }
+BRMI_DEV float fuzz_incoming_reflected(const Luts& L, float w, float r, float NdotV) { return sat(sat(w) * fuzz_dir_reflectance(L, r, NdotV)); }
+BRMI_DEV f3 to_local(const FuzzState& s, f3 d) { return f3{dot3(d, s.t), dot3(d, s.b), dot3(d, s.n)}; }
+BRMI_DEV FuzzState make_fuzz_state(const Luts& L, const Frag& f) {
+    FuzzState s;
+    s.roughness = sat(f.fuzzRoughness); s.tint = sat3(f.fuzzColor); s.presence = sat(f.fuzzWeight);
+    s.n = normalize3(f.normalWS);
+    const f3 v = normalize3(f.viewWS);
+    const f3 pv = v - s.n * dot3(v, s.n);
+    if (dot3(pv, pv) > 1.0e-6f) s.t = normalize3(pv);
+    else { const f3 helper = fabsf(s.n.z) < 0.999f ? f3{0.0f, 0.0f, 1.0f} : f3{0.0f, 1.0f, 0.0f}; s.t = normalize3(cross3(helper, s.n)); }
+    s.b = cross3(s.n, s.t);
+    s.viewDirLocal = to_local(s, v);
+    s.viewReflected = fuzz_incoming_reflected(L, s.presence, s.roughness, s.viewDirLocal.z);
+    return s;
+}
+BRMI_DEV f3 fuzz_sheen(const Luts& L, const FuzzState& s, f3 lightDir) {
+    const f3 ll = to_local(s, normalize3(lightDir));
+    if (s.viewDirLocal.z <= 0.0f || ll.z <= 0.0f) return f3{0.0f, 0.0f, 0.0f};
+    float phi = atan2f(s.viewDirLocal.y, s.viewDirLocal.x);
+    if (phi < 0.0f) phi += 2.0f * PI_F;
+    const float ang = -phi, sa = sinf(ang), ca = cosf(ang);
+    const f3 axis{0.0f, 0.0f, 1.0f};
+    const f3 ls = ll * ca + axis * dot3(ll, axis) * (1.0f - ca) + sa * cross3(axis, ll);
+    const f3 ltc = lut_fuzz_ltc(L, s.roughness, s.viewDirLocal.z);
+    const float aInv = ltc.x, bInv = ltc.y;
+    f3 wo{aInv * ls.x + bInv * ls.z, aInv * ls.y, ls.z};
+    const float len = length3(wo);
+    float e = 0.0f;
+    if (len > 0.0f) {
+        wo = wo / len;
+        const float det = aInv * aInv;
+        const float jac = det / max2(len * len * len, 1.0e-6f);
+        e = sat(wo.z) * (1.0f / PI_F) * jac;
+    }
+    return s.presence * ltc.z * s.tint * e;
+}
+BRMI_DEV float fon_dir_albedo(float mu, float roughness) {
+    const float m = sat(mu), mc = 1.0f - m;
+    const float g1 = 0.0571085289f, g2 = 0.491881867f, g3 = -0.332181442f, g4 = 0.0714429953f;
+    const float gOverPi = mc * (g1 + mc * (g2 + mc * (g3 + mc * g4)));
+    return (1.0f + roughness * gOverPi) / (1.0f + fon_a() * roughness);
+}
+BRMI_DEV f3 diffuse_eon(f3 albedo, float rough, float NdotV, float NdotL, float VdotL) {
+    const float muIn = sat(NdotV), muOut = sat(NdotL);
+    const float s = VdotL - muIn * muOut;
+    const float sOverT = s > 0.0f ? s / max2(max2(muIn, muOut), 1.0e-4f) : s;
+    const float A = 1.0f / (1.0f + fon_a() * rough);
+    const f3 single = albedo * (1.0f / PI_F) * A * (1.0f + rough * sOverT);
+    const float EOut = fon_dir_albedo(muOut, rough), EIn = fon_dir_albedo(muIn, rough);
+    const float avgE = A * (1.0f + fon_b() * rough);
+    const f3 msAlbedo = (albedo * albedo) * avgE / max3v(f3{1.0f, 1.0f, 1.0f} - albedo * (1.0f - avgE), f3{1.0e-4f, 1.0e-4f, 1.0e-4f});
+    const float k = max2(1.0e-4f, 1.0f - EOut) * max2(1.0e-4f, 1.0f - EIn) / max2(1.0e-4f, 1.0f - avgE);
+    const f3 multi = (msAlbedo * (1.0f / PI_F)) * f3{k, k, k};
+    return single + multi;
+}
+
+BRMI_DEV f3 light_contribution(const Luts& L, const Frag& f, f3 lightToFrag, f3 lightColor, float intensity, float attenuation, float spotAtt) {
+    const float NoV = sat(dot3(f.normalWS, f.viewWS)), NoL = sat(dot3(f.normalWS, lightToFrag));
+    const BaseState base = make_base_state(f);
+    const CoatState coat = make_coat_state(base, f);
+    const FuzzState fuzz = make_fuzz_state(L, f);
+    const f3 h = normalize3(lightToFrag + f.viewWS);
+    const float NoH = sat(dot3(f.normalWS, h)), LoH = sat(dot3(lightToFrag, h));
+    const float VdotL = dot3(f.viewWS, lightToFrag);
+    // EvaluateOpenPBRBaseLayerDirect
+    const float viewComp = lut_od_e(L, base.weightedSpecularIor, base.specularAlpha, sat(NoV));
+    const float avgComp = lut_od_avg(L, base.weightedSpecularIor, base.specularAlpha);
+    const float cachedView = max2(0.0f, viewComp / max2(avgComp, 1.0e-12f));
+    const float lightComp = lut_od_e(L, base.weightedSpecularIor, base.specularAlpha, sat(NoL));
+    const float diffuseEnergyComp = max2(0.0f, cachedView * lightComp);
+    const f3 diffuse = diffuse_eon(base.diffuseColor, base.baseDiffuseRoughness, NoV, NoL, VdotL) * diffuseEnergyComp;
+    const float mView = lut_im_e(L, base.specularAlpha, NoV), mLight = lut_im_e(L, base.specularAlpha, NoL), mAvg = lut_im_avg(L, base.specularAlpha);
+    const float mTab = mView * mLight / max2(mAvg, 1.0e-12f);
+    const float mScale = min2(mTab, rcpf(max2(NoL, 1.0e-4f))) * (1.0f / PI_F);
+    const f3 dielSpec = base.dielectricSpecularWeight * specular_lobe(base.specularAlpha, base.dielectricSpecularF0, NoV, NoL, NoH, LoH) *
+                        ggx_energy_compensation(NoV, base.specularAlpha, base.dielectricSpecularF0);
+    const f3 metalSpec = base.metalSpecularWeight * (specular_lobe(base.specularAlpha, base.metalSpecularF0, NoV, NoL, NoH, LoH) + base.metalMultipleScatterScale * mScale);
+    const f3 specular = dielSpec + metalSpec;
+    // layers
+    const f3 llocal = to_local(fuzz, normalize3(lightToFrag));
+    const float fuzzOut = (llocal.z <= 0.0f) ? 0.0f : sat(fuzz.presence * fuzz_dir_reflectance(L, fuzz.roughness, llocal.z));
+    const float fuzzScale = (1.0f - fuzz.viewReflected) * (1.0f - fuzzOut);
+    const f3 baseScale = coat_scale_incoming(L, coat, NoV) * coat_scale_outgoing(L, coat, NoL);
+    f3 coatFr{0.0f, 0.0f, 0.0f};
+    if (coat.presence > 0.0f) {
+        coatFr = specular_lobe(f.coatRoughness, f.coatF0, NoV, NoL, NoH, LoH);
+        coatFr = coatFr * (ggx_energy_compensation(NoV, f.coatRoughness, f.coatF0) * coat.presence);
+    }
+    const f3 fuzzFr = fuzz_sheen(L, fuzz, lightToFrag);
+    const f3 baseAtt = f3{fuzzScale, fuzzScale, fuzzScale} * baseScale;
+    const f3 brdf = (diffuse + specular) * baseAtt + coatFr * f3{fuzzScale, fuzzScale, fuzzScale} + fuzzFr;
+    return brdf * lightColor * intensity * attenuation * spotAtt * NoL;
+}
+
+struct ShadeArgs {
+    brmi_scene_buffers sc;
+    const float* depth; const float4* normals; const uint32_t* albedo; const unsigned long long* coat; const unsigned long long* emissive;
+    const unsigned long long* fuzz; const uint32_t* metallicRoughness;
+    const brmi_light_cluster* clusters; const brmi_light_page* pages; uint32_t poolSize;
+    unsigned long long* hdr;
+    uint32_t W, H, tilesX, bandY0, bandY1; uint64_t firstPixel, pixelCount;
+    uint32_t enablePunctual, clustered;
+};
+
+BRMI_DEV float half_at(unsigned long long v, int k) { return f16_bits_to_f32((uint32_t)(v >> (16 * k)) & 0xFFFFu); }
+
+__global__ void __launch_bounds__(256) k_shade(ShadeArgs a) {
+    const brmi_scene_buffers& sc = a.sc;
+    const brmi_per_frame* pf = sc.perFrame;
+    const brmi_camera* cam = sc.cameras + pf->mainCameraIndex;
+    const Luts L{sc.lutOpaqueDielectricEnergyComplement, sc.lutOpaqueDielectricAvgEnergyComplement, sc.lutIdealMetalEnergyComplement, sc.lutIdealMetalAvgEnergyComplement, sc.lutFuzzLTC};
+    const uint32_t gx = pf->lightClusterGridSizeX, gy = pf->lightClusterGridSizeY, gz = pf->lightClusterGridSizeZ;
+    const m4 invProj = load_m4(&cam->projectionInverse[0][0]), viewInv = load_m4(&cam->viewInverse[0][0]);
+    const f3 camPos{cam->positionWorldSpace[0], cam->positionWorldSpace[1], cam->positionWorldSpace[2]};
+    const float zNear = cam->zNear, zFar = cam->zFar, zSplit = pf->clusterZSplitDepth;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < a.pixelCount; j += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t i = a.firstPixel + j;
+        const uint32_t tile = (uint32_t)(i >> 6), within = (uint32_t)(i & 63u);
+        const uint32_t px = (tile % a.tilesX) * 8u + (within & 7u), py = (tile / a.tilesX) * 8u + (within >> 3);
+        if (px >= a.W || py >= a.H || py < a.bandY0 || py >= a.bandY1) continue;
+        const float d = a.depth[i];
+        if (as_u32(d) == BRMI_DEPTH_EMPTY_BITS) continue;
+        float uvx = ((float)px + 0.5f) / (float)pf->screenResX, uvy = ((float)py + 0.5f) / (float)pf->screenResY;
+        uvy = 1.0f - uvy;
+        const f4 clipPos{uvx * 2.0f - 1.0f, uvy * 2.0f - 1.0f, 1.0f, 1.0f};
+        const f4 viewPosH = mul_vm(clipPos, invProj);
+        const f3 posVS = xyz(viewPosH) * d;
+        const f3 posWS = xyz(mul_point(posVS, viewInv));
+        const f3 viewDir = normalize3(camPos - posWS);
+
+        // GetFragmentInfoScreenSpace + PopulateFragmentInfoFromOpenPBR
+        Frag f;
+        f.posWS = posWS; f.viewWS = viewDir;
+        const float4 ns = a.normals[i];
+        const f3 nrm{ns.x, ns.y, ns.z};
+        const uint32_t al = a.albedo[i], mr = a.metallicRoughness[i];
+        const unsigned long long cs = a.coat[i], es = a.emissive[i], fs = a.fuzz[i];
+        const f3 baseColor{unorm8_to_f32(al), unorm8_to_f32(al >> 8), unorm8_to_f32(al >> 16)};
+        const float metal = unorm8_to_f32(mr), pr = unorm8_to_f32(mr >> 8), coatR = unorm8_to_f32(mr >> 16), fuzzW = unorm8_to_f32(mr >> 24);
+        const float prc = clampf(pr, BRMI_MIN_PERCEPTUAL_ROUGHNESS, 1.0f);
+        f.roughness = prc * prc;
+        const float NdotVraw = dot3(nrm, viewDir);
+        f.normalWS = normalize3(nrm + max2(0.0f, -NdotVraw + BRMI_MIN_N_DOT_V) * viewDir);
+        f.NdotV = max2(BRMI_MIN_N_DOT_V, NdotVraw);
+        uint32_t opIndex = (uint32_t)(ns.w + 0.5f);
+        if (opIndex >= sc.openpbrMaterialCount) opIndex = 0;
+        const brmi_openpbr_material_info* op = sc.openpbrMaterials + opIndex;
+        const float baseWeight = sat(op->baseWeight), specularWeight = sat(op->specularWeight);
+        const f3 specularColor = sat3(f3{op->specularColor[0], op->specularColor[1], op->specularColor[2]});
+        const f3 weightedBaseColor = sat3(baseColor * baseWeight);
+        float weightedSpecularIor;
+        {
+            const float unscaledF0 = ior_to_f0(op->specularIor);
+            const float scaledF0 = min2(unscaledF0 * sat(specularWeight), 0.9999f);
+            const float safeF0 = min2(sat(scaledF0), 0.9999f);
+            const float sq = sqrtf(safeF0);
+            weightedSpecularIor = (1.0f + sq) / max2(1.0f - sq, 1.0e-4f);
+        }
+        const float dielF0Scalar = ior_to_f0(weightedSpecularIor);
+        f.dielectricSpecularF0 = sat3(specularColor * dielF0Scalar);
+        const float coatPR = clampf(coatR, BRMI_MIN_PERCEPTUAL_ROUGHNESS, 1.0f);
+        const float coatF0Scalar = ior_to_f0(op->coatIor);
+        f.dielectricSpecularWeight = sat(1.0f - metal);
+        f.metalSpecularWeight = sat(metal * specularWeight);
+        f.metalSpecularF0 = sat3(weightedBaseColor * specularColor);
+        {
+            const f3 safeF0 = sat3(weightedBaseColor), wmF0 = f3{1.0f, 1.0f, 1.0f} - safeF0;
+            const float cosMax = 1.0f / 7.0f, om = 1.0f - cosMax;
+            const float om5 = powf(om, 5.0f), om6 = powf(om, 6.0f);
+            const f3 wmF0b = f3{1.0f, 1.0f, 1.0f} - sat3(safeF0), wmTint = f3{1.0f, 1.0f, 1.0f} - sat3(specularColor);
+            const f3 num = (sat3(safeF0) + wmF0b * om5) * wmTint;
+            const float den = cosMax * om6;
+            const f3 b = num / max2(den, 1.0e-6f);
+            f.metalAverageFresnel = sat3(safeF0 + wmF0 * (1.0f / 21.0f) - b * (1.0f / 126.0f));
+        }
+        f.albedo = weightedBaseColor;
+        f.emissive = f3{half_at(es, 0), half_at(es, 1), half_at(es, 2)};
+        f.coatWeight = sat(half_at(cs, 3));
+        f.coatColor = sat3(f3{half_at(cs, 0), half_at(cs, 1), half_at(cs, 2)});
+        f.coatRoughness = coatPR * coatPR;
+        f.coatF0 = sat3(f.coatColor * coatF0Scalar);
+        f.coatIor = op->coatIor; f.coatDarkening = sat(op->coatDarkening);
+        f.fuzzWeight = sat(fuzzW); f.fuzzColor = sat3(f3{half_at(fs, 0), half_at(fs, 1), half_at(fs, 2)}); f.fuzzRoughness = sat(half_at(fs, 3));
+        f.baseDiffuseRoughness = sat(op->baseDiffuseRoughness);
+        f.specularAlpha = f.roughness; f.weightedSpecularIor = weightedSpecularIor;
+        f.diffuseColor = weightedBaseColor * (1.0f - metal);
+
+        f3 lighting{0.0f, 0.0f, 0.0f};
+        auto shadeLight = [&](uint32_t lightIndex) {
+            const brmi_light_info* l = sc.lights + lightIndex;
+            const uint32_t type = l->type;
+            f3 lightToFrag; float att, dist = 0.0f, spot = 1.0f;
+            const f3 lpos{l->posWorldSpace[0], l->posWorldSpace[1], l->posWorldSpace[2]};
+            if (type == BRMI_LIGHT_DIRECTIONAL) { lightToFrag = -f3{l->dirWorldSpace[0], l->dirWorldSpace[1], l->dirWorldSpace[2]}; att = 1.0f; }
+            else {
+                lightToFrag = normalize3(lpos - posWS);
+                dist = length3(lpos - posWS);
+                att = 1.0f / ((l->attenuation[0] + l->attenuation[1] * dist + l->attenuation[2] * dist * dist) + 0.0001f);
+            }
+            if (type == BRMI_LIGHT_SPOT) {
+                const f3 ld{l->dirWorldSpace[0], l->dirWorldSpace[1], l->dirWorldSpace[2]};
+                const float c = dot3(normalize3(ld), normalize3(-lightToFrag));
+                if (c > l->outerConeAngle) {
+                    if (c < l->innerConeAngle) { const float t = sat((c - l->outerConeAngle) / (l->innerConeAngle - l->outerConeAngle)); spot = t * t * (3.0f - 2.0f * t); }
+                    else spot = 1.0f;
+                } else spot = 0.0f;
+            }
+            if (type != BRMI_LIGHT_DIRECTIONAL && dist > l->maxRange) return;
+            const f3 c = light_contribution(L, f, lightToFrag, f3{l->color[0], l->color[1], l->color[2]}, l->color[3], att, spot);
+            lighting = lighting + (1.0f - 0.0f) * c;
+        };
+        if (a.enablePunctual) {
+            if (a.clustered) {
+                const float tsx = (float)pf->screenResX / (float)gx, tsy = (float)pf->screenResY / (float)gy;
+                const uint32_t tx = (uint32_t)((float)px / tsx), ty = (uint32_t)((float)py / tsy);
+                const float z = fabsf(posVS.z);
+                uint32_t sliceZ;
+                if (z < zSplit) { const float t = (z - zNear) / (zSplit - zNear); sliceZ = t > 0.0f ? (uint32_t)(t * (float)pf->nearClusterCount) : 0u; }
+                else {
+                    const float logStart = logf(zSplit / zNear), logEnd = logf(zFar / zNear), logZ = logf(z / zNear);
+                    const float u = (logZ - logStart) / (logEnd - logStart);
+                    sliceZ = pf->nearClusterCount + (u > 0.0f ? (uint32_t)(u * (float)(gz - pf->nearClusterCount)) : 0u);
+                }
+                const uint32_t ci = (uint32_t)((float)tx + (float)ty * (float)gx + (float)sliceZ * (float)gx * (float)gy);
+                if (ci < gx * gy * gz) {
+                    const brmi_light_cluster* cl = a.clusters + ci;
+                    const uint32_t count = cl->numLights;
+                    uint32_t page = cl->ptrFirstPage, remaining = count, visited = 0;
+                    const uint32_t maxPages = max(1u, (count + BRMI_LIGHTS_PER_PAGE - 1u) / BRMI_LIGHTS_PER_PAGE);
+                    while (page != BRMI_LIGHT_PAGE_NULL && page < a.poolSize && remaining > 0 && visited < maxPages) {
+                        const brmi_light_page* pg = a.pages + page;
+                        uint32_t n = min(pg->numLightsInPage, BRMI_LIGHTS_PER_PAGE);
+                        n = min(n, remaining);
+                        if (n == 0) break;
+                        for (uint32_t k = 0; k < n; k++) shadeLight(sc.activeLightIndices[pg->lightIndices[k]]);
+                        remaining -= n; page = pg->ptrNextPage; visited++;
+                    }
+                }
+            } else {
+                for (uint32_t k = 0; k < pf->numLights; k++) shadeLight(sc.activeLightIndices[k]);
+            }
+        }
+        {   // EvaluateOpenPBREmissive
+            const BaseState base = make_base_state(f);
+            const CoatState coatS = make_coat_state(base, f);
+            const float fuzzBase = 1.0f - fuzz_incoming_reflected(L, f.fuzzWeight, f.fuzzRoughness, f.NdotV);
+            const f3 coatT = coat_scale_incoming(L, coatS, f.NdotV);
+            lighting = lighting + f.emissive * f3{fuzzBase, fuzzBase, fuzzBase} * coatT;
+        }
+        a.hdr[i] = pack_half4(lighting.x, lighting.y, lighting.z, 1.0f);
+    }
+}
+
+int launch_light_clustering(brmi_pass* p, hipStream_t s) {
+    if (p->numLightClusters > MAX_CLUSTERS_LDS) return fail(p, BRMI_ERR_CAPACITY, "light cluster grid of %u clusters exceeds %u", p->numLightClusters, MAX_CLUSTERS_LDS);
+    ClusterArgs a;
+    a.sc = p->scene; a.planes = p->wsPtr<float>(p->ws.planes);
+    a.clusters = static_cast<brmi_light_cluster*>(p->res[BRMI_RES_LIGHT_CLUSTERS]); a.pages = static_cast<brmi_light_page*>(p->res[BRMI_RES_LIGHT_PAGES]);
+    a.poolSize = p->lightPagePool; a.counters = p->counters();
+    hipLaunchKernelGGL(k_light_clustering, dim3(1), dim3(1024), 0, s, a);
+    BRMI_LAUNCH_CHECK(p, "k_light_clustering");
+    return BRMI_OK;
+}
+
+int launch_shade(brmi_pass* p, hipStream_t s) {
+    ShadeArgs a;
+    a.sc = p->scene;
+    a.depth = static_cast<const float*>(p->res[BRMI_RES_LINEAR_DEPTH]); a.normals = static_cast<const float4*>(p->res[BRMI_RES_GBUF_NORMALS]);
+    a.albedo = static_cast<const uint32_t*>(p->res[BRMI_RES_GBUF_ALBEDO]); a.coat = static_cast<const unsigned long long*>(p->res[BRMI_RES_GBUF_COAT]);
+    a.emissive = static_cast<const unsigned long long*>(p->res[BRMI_RES_GBUF_EMISSIVE]); a.fuzz = static_cast<const unsigned long long*>(p->res[BRMI_RES_GBUF_FUZZ]);
+    a.metallicRoughness = static_cast<const uint32_t*>(p->res[BRMI_RES_GBUF_METALLIC_ROUGHNESS]);
+    a.clusters = static_cast<const brmi_light_cluster*>(p->res[BRMI_RES_LIGHT_CLUSTERS]); a.pages = static_cast<const brmi_light_page*>(p->res[BRMI_RES_LIGHT_PAGES]);
+    a.poolSize = p->lightPagePool; a.hdr = static_cast<unsigned long long*>(p->res[BRMI_RES_HDR_COLOR]);
+    a.W = p->cfg.width; a.H = p->cfg.height; a.tilesX = p->tilesX; a.bandY0 = p->bandY0; a.bandY1 = p->bandY1; a.firstPixel = p->bandFirstPixel; a.pixelCount = p->bandPixelCount;
+    a.enablePunctual = p->cfg.enablePunctualLights; a.clustered = p->cfg.enableClusteredLighting;
+    hipLaunchKernelGGL(k_shade, dim3(4096), dim3(256), 0, s, a);
+    BRMI_LAUNCH_CHECK(p, "k_shade");
+    return BRMI_OK;
+}
+
+}  // namespace brmi

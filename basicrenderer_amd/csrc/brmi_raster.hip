@@ -1,0 +1,219 @@
+// brmi_raster.hip -- visibility-buffer clear, software rasteriser (K5) and depth copy (K6) for gfx950.
+//
+// Computes what SWRasterCluster does (BR/shaders/ClusterLOD/softwareRaster.hlsl:290-612): vertices
+// of one meshlet to screen space, per-triangle edge-function setup, inclusive coverage at pixel
+// centres with incrementally stepped barycentrics, 64-bit min of (depth | cluster | triangle).
+// Scheduling is MI355X-first rather than the reference's one-128-thread-group-per-cluster indirect
+// dispatch per raster bucket:
+//   * persistent single-wave workgroups pull cluster indices from a device-side queue counter
+//     (cluster count lives in HBM; no indirect dispatch, no host read-back, natural load balance
+//     over clusters of very different pixel area);
+//   * wave64: lane = triangle, two passes over a 128-triangle meshlet.  The reference's
+//     WaveActiveAnyTrue(rectWidth > 4) vote (softwareRaster.hlsl:502) is evaluated per pass over the
+//     lanes that survived setup, which is exactly the wave composition of a 128-thread group on
+//     wave64 hardware;
+//   * the meshlet's screen-space vertices (<=128 x 12 B) are staged once in LDS;
+//   * the visibility surface is stored in 8x8 tiles (512 B = 4 cache lines) so the atomics of a
+//     meshlet footprint, and every later full-screen pass, touch whole lines.
+// Raster buckets (K4) collapse: with one PSO-free kernel there is nothing to sort by.
+#include "brmi_device.h"
+#include "brmi_internal.h"
+
+namespace brmi {
+
+struct RasterArgs {
+    brmi_scene_buffers sc;
+    const uint4* clusters;
+    uint32_t* counters;
+    uint32_t firstCounter, countCounter;   // counter indices: first cluster (0xFFFFFFFF = 0) and cluster count
+    uint32_t* queue;                        // work-queue head (zeroed before launch)
+    unsigned long long* vis;
+    uint32_t visW, visH, tilesX, bandY0, bandY1;
+};
+
+__global__ void __launch_bounds__(256) k_clear_vis(unsigned long long* vis, uint64_t n) {
+    // 16 B per lane per store (n is a multiple of 64)
+    ulonglong2* v2 = reinterpret_cast<ulonglong2*>(vis);
+    const uint64_t n2 = n >> 1;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (uint64_t)gridDim.x * blockDim.x) v2[i] = make_ulonglong2(BRMI_VIS_EMPTY, BRMI_VIS_EMPTY);
+}
+
+BRMI_DEV void clip_scanline(float value, float step, int& first, int& last, bool& has) {
+    if (!has) return;
+    if (step > 0.0f) { const int c = to_int_sat(ceilf(-value / step)); first = first > c ? first : c; }
+    else if (step < 0.0f) { const int f = to_int_sat(floorf(value / -step)); last = last < f ? last : f; }
+    else has = value >= 0.0f;
+    has = has && first <= last;
+}
+
+__global__ void __launch_bounds__(64) k_raster(RasterArgs a) {
+    __shared__ float sx[BRMI_MESHLET_MAX_VERTS], sy[BRMI_MESHLET_MAX_VERTS], sd[BRMI_MESHLET_MAX_VERTS];
+    const brmi_scene_buffers& sc = a.sc;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t first = a.firstCounter == 0xFFFFFFFFu ? 0u : a.counters[a.firstCounter];
+    const uint32_t count = a.counters[a.countCounter];
+    for (;;) {
+        uint32_t c = 0;
+        if (lane == 0) c = atomicAdd(a.queue, 1u);
+        c = __builtin_amdgcn_readfirstlane(c);
+        if (c >= count) break;
+        const uint32_t clusterIndex = first + c;
+        const uint4 pc = a.clusters[clusterIndex];
+        const uint32_t viewID = vc_view(pc), instanceID = vc_instance(pc), localMeshlet = vc_meshlet(pc);
+        const uint8_t* slab = sc.slabs[vc_slab(pc)];
+        const uint32_t pageOff = vc_page_offset(pc);
+        const brmi_page_header* hdr = reinterpret_cast<const brmi_page_header*>(slab + pageOff);
+        const brmi_meshlet_descriptor* desc = reinterpret_cast<const brmi_meshlet_descriptor*>(slab + pageOff + hdr->descriptorOffset + localMeshlet * 64u);
+        const uint32_t vertCount = min((desc->bitsAndVertexCount >> 24) & 0xFFu, BRMI_MESHLET_MAX_VERTS);
+        const uint32_t triCount = min(desc->triangleCountAndRefinedGroup & 0xFFFFu, BRMI_MESHLET_MAX_TRIS);
+        const brmi_per_mesh_instance* meshInst = sc.perMeshInstance + instanceID;
+        const brmi_per_object* obj = sc.perObject + meshInst->perObjectBufferIndex;
+        const brmi_culling_camera* cam = sc.cullingCameras + viewID;
+        const brmi_view_raster_info ri = sc.viewRasterInfo[viewID];
+        const float visWidth = (float)(ri.scissorMaxX - ri.scissorMinX), visHeight = (float)(ri.scissorMaxY - ri.scissorMinY);
+        const float sMinXf = (float)ri.scissorMinX, sMinYf = (float)ri.scissorMinY;
+        const m4 model = load_m4(&obj->model[0][0]);
+        const m4 mvp = mul_mm(model, load_m4(&cam->viewProjection[0][0]));
+        const f4 modelViewZ = mul_mcol(model, f4{cam->viewZ[0], cam->viewZ[1], cam->viewZ[2], cam->viewZ[3]});
+        const uint32_t posFormat = hdr->compressedPositionQuantExp;
+        const uint8_t* posBase = slab + pageOff + hdr->positionBitstreamOffset + desc->positionBitOffset;
+        const uint8_t* triBase = slab + pageOff + hdr->triangleStreamOffset + desc->triangleByteOffset;
+        const bool reverseWinding = (obj->objectFlags & BRMI_OBJECT_FLAG_REVERSE_WINDING) != 0;
+        if (lane == 0) {
+            atomicAdd(reinterpret_cast<unsigned long long*>(&a.counters[CNT_SUM_VERTS_LO]), (unsigned long long)vertCount);
+            atomicAdd(reinterpret_cast<unsigned long long*>(&a.counters[CNT_SUM_TRIS_LO]), (unsigned long long)triCount);
+            atomicAdd(&a.counters[CNT_RASTER_CLUSTERS], 1u);
+        }
+
+        // vertex stage -> LDS (softwareRaster.hlsl:339-387)
+        for (uint32_t v = lane; v < vertCount; v += 64) {
+            f3 lp{0.0f, 0.0f, 0.0f};
+            if (posFormat == BRMI_POSITION_FORMAT_FLOAT3) {
+                const float* pp = reinterpret_cast<const float*>(posBase + v * 12u);
+                lp = f3{pp[0], pp[1], pp[2]};
+            }
+            const f4 lp4{lp.x, lp.y, lp.z, 1.0f};
+            const f4 clip = mul_vm(lp4, mvp);
+            const float viewZ = dot4(lp4, modelViewZ);
+            const float invW = 1.0f / clip.w;
+            const float ndcx = clip.x * invW, ndcy = clip.y * invW;
+            sx[v] = (ndcx + 1.0f) * 0.5f * visWidth + sMinXf;
+            sy[v] = (1.0f - ndcy) * 0.5f * visHeight + sMinYf;
+            sd[v] = -viewZ;
+        }
+        __syncthreads();
+
+        // triangle stage: lane = triangle (softwareRaster.hlsl:416-611)
+        for (uint32_t waveBase = 0; waveBase < triCount; waveBase += 64) {
+            const uint32_t t = waveBase + lane;
+            bool active = t < triCount;
+            float d0 = 0, d1 = 0, d2 = 0, row_b0 = 0, row_b1 = 0, dx_b0 = 0, dx_b1 = 0, dy_b0 = 0, dy_b1 = 0;
+            int minX = 0, minY = 0, maxX = -1, maxY = -1;
+            if (active) {
+                uint32_t i0 = triBase[t * 3u], i1 = triBase[t * 3u + 1u], i2 = triBase[t * 3u + 2u];
+                if (reverseWinding) { const uint32_t tmp = i1; i1 = i2; i2 = tmp; }
+                const float s0x = sx[i0], s0y = sy[i0], s1x = sx[i1], s1y = sy[i1], s2x = sx[i2], s2y = sy[i2];
+                d0 = sd[i0]; d1 = sd[i1]; d2 = sd[i2];
+                if (d0 <= 0.0f || d1 <= 0.0f || d2 <= 0.0f) active = false;
+                const float e01x = s1x - s0x, e01y = s1y - s0y, e02x = s2x - s0x, e02y = s2y - s0y;
+                const float twiceArea = e01x * e02y - e01y * e02x;
+                if (twiceArea >= 0.0f) active = false;
+                if (active) {
+                    const float invTwiceArea = -1.0f / twiceArea;
+                    const float bbMinX = min2(min2(s0x, s1x), s2x), bbMinY = min2(min2(s0y, s1y), s2y);
+                    const float bbMaxX = max2(max2(s0x, s1x), s2x), bbMaxY = max2(max2(s0y, s1y), s2y);
+                    minX = to_int_sat(floorf(bbMinX)); minY = to_int_sat(floorf(bbMinY));
+                    maxX = to_int_sat(floorf(bbMaxX)); maxY = to_int_sat(floorf(bbMaxY));
+                    minX = max(minX, (int)ri.scissorMinX); minY = max(minY, (int)ri.scissorMinY);
+                    maxX = min(maxX, (int)ri.scissorMaxX - 1); maxY = min(maxY, (int)ri.scissorMaxY - 1);
+                    minX = max(minX, 0); minY = max(minY, 0);
+                    maxX = min(maxX, (int)a.visW - 1); maxY = min(maxY, (int)a.visH - 1);
+                    if (minX > maxX || minY > maxY) active = false;
+                    else {
+                        const float ox = (float)minX + 0.5f, oy = (float)minY + 0.5f;
+                        const float e12x = s2x - s1x, e12y = s2y - s1y, e20x = s0x - s2x, e20y = s0y - s2y;
+                        row_b0 = ((ox - s1x) * e12y - (oy - s1y) * e12x) * invTwiceArea;
+                        row_b1 = ((ox - s2x) * e20y - (oy - s2y) * e20x) * invTwiceArea;
+                        dx_b0 = e12y * invTwiceArea; dx_b1 = e20y * invTwiceArea;
+                        dy_b0 = -e12x * invTwiceArea; dy_b1 = -e20x * invTwiceArea;
+                    }
+                }
+            }
+            const int rectWidth = maxX - minX + 1;
+            const bool useScanlineRanges = __any(active && rectWidth > 4);
+            if (active) {
+                const float dx_b2 = -(dx_b0 + dx_b1);
+                float sb0 = row_b0, sb1 = row_b1;
+                for (int py = minY; py <= maxY; py++) {
+                    const bool rowInBand = (uint32_t)py >= a.bandY0 && (uint32_t)py < a.bandY1;
+                    const uint32_t rowBase = (((uint32_t)py >> 3) * a.tilesX << 6) | (((uint32_t)py & 7u) << 3);
+                    if (useScanlineRanges) {
+                        const float sb2 = 1.0f - sb0 - sb1;
+                        int firstOff = 0, lastOff = rectWidth - 1; bool has = true;
+                        clip_scanline(sb0, dx_b0, firstOff, lastOff, has);
+                        clip_scanline(sb1, dx_b1, firstOff, lastOff, has);
+                        clip_scanline(sb2, dx_b2, firstOff, lastOff, has);
+                        if (has && rowInBand) {
+                            float b0 = sb0 + (float)firstOff * dx_b0, b1 = sb1 + (float)firstOff * dx_b1;
+                            for (int px = minX + firstOff; px <= minX + lastOff; px++) {
+                                const float b2 = 1.0f - b0 - b1;
+                                const float depth = b0 * d0 + b1 * d1 + b2 * d2;
+                                atomicMin(&a.vis[rowBase + (((uint32_t)px >> 3) << 6) + ((uint32_t)px & 7u)], (unsigned long long)pack_vis_key(depth, clusterIndex, t));
+                                b0 += dx_b0; b1 += dx_b1;
+                            }
+                        }
+                    } else if (rowInBand) {
+                        float b0 = sb0, b1 = sb1;
+                        for (int px = minX; px <= maxX; px++) {
+                            const float b2 = 1.0f - b0 - b1;
+                            if (b0 >= 0.0f && b1 >= 0.0f && b2 >= 0.0f) {
+                                const float depth = b0 * d0 + b1 * d1 + b2 * d2;
+                                atomicMin(&a.vis[rowBase + (((uint32_t)px >> 3) << 6) + ((uint32_t)px & 7u)], (unsigned long long)pack_vis_key(depth, clusterIndex, t));
+                            }
+                            b0 += dx_b0; b1 += dx_b1;
+                        }
+                    }
+                    sb0 += dy_b0; sb1 += dy_b1;
+                }
+            }
+        }
+        __syncthreads();   // LDS is reused by the next cluster
+    }
+}
+
+// K6: linear depth from the visibility key (gbuffer.hlsl:114-161); one lane per pixel, tile order
+__global__ void __launch_bounds__(256) k_depth_copy(const unsigned long long* vis, float* depth, uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const unsigned long long k = vis[i];
+        depth[i] = (k == BRMI_VIS_EMPTY) ? as_f32(BRMI_DEPTH_EMPTY_BITS) : as_f32(((uint32_t)(k >> BRMI_VIS_META_BITS)) << 1);
+    }
+}
+
+int launch_clear(brmi_pass* p, hipStream_t s) {
+    hipLaunchKernelGGL(k_clear_vis, dim3(2048), dim3(256), 0, s, static_cast<unsigned long long*>(p->res[BRMI_RES_VISIBILITY]) + p->bandFirstPixel, p->bandPixelCount);
+    BRMI_LAUNCH_CHECK(p, "k_clear_vis");
+    return BRMI_OK;
+}
+
+int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
+    if (phase != 1) return fail(p, BRMI_ERR_INVALID, "brmi_raster: phase %u not available", phase);
+    RasterArgs a;
+    a.sc = p->scene; a.clusters = static_cast<const uint4*>(p->res[BRMI_RES_VISIBLE_CLUSTERS]); a.counters = p->counters();
+    a.firstCounter = 0xFFFFFFFFu; a.countCounter = CNT_VISIBLE;
+    a.queue = p->counters() + CNT_WORDS;   // one spare word after the counters block
+    a.vis = static_cast<unsigned long long*>(p->res[BRMI_RES_VISIBILITY]);
+    a.visW = p->cfg.width; a.visH = p->cfg.height; a.tilesX = p->tilesX; a.bandY0 = p->bandY0; a.bandY1 = p->bandY1;
+    BRMI_HIP(p, hipMemsetAsync(a.queue, 0, 4, s));
+    hipLaunchKernelGGL(k_raster, dim3(256 * 16), dim3(64), 0, s, a);
+    BRMI_LAUNCH_CHECK(p, "k_raster");
+    return BRMI_OK;
+}
+
+int launch_depth_copy(brmi_pass* p, hipStream_t s) {
+    hipLaunchKernelGGL(k_depth_copy, dim3(2048), dim3(256), 0, s, static_cast<const unsigned long long*>(p->res[BRMI_RES_VISIBILITY]) + p->bandFirstPixel,
+                       static_cast<float*>(p->res[BRMI_RES_LINEAR_DEPTH]) + p->bandFirstPixel, p->bandPixelCount);
+    BRMI_LAUNCH_CHECK(p, "k_depth_copy");
+    return BRMI_OK;
+}
+
+}  // namespace brmi

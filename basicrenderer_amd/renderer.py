@@ -1,0 +1,158 @@
+"""Harness over libbrmi.so: owns the HBM resources a render graph would own and drives the pass.
+
+PyTorch is plumbing here (device memory, streams, torch.distributed); every kernel is in
+libbrmi.so behind the C ABI of include/brmi.h.  There is no CPU fallback: if the HIP library is
+missing or no GPU is present this module raises.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+class BrmiError(RuntimeError):
+    pass
+
+
+def detile(flat, width, height, tile=8):
+    """Tiled 8x8 storage (numpy, leading dim = padded pixels) -> linear [H, W, ...]."""
+    tx, ty = (width + tile - 1) // tile, (height + tile - 1) // tile
+    rest = flat.shape[1:]
+    a = flat.reshape((ty, tx, tile, tile) + rest)
+    a = np.moveaxis(a, 2, 1).reshape((ty * tile, tx * tile) + rest)
+    return np.ascontiguousarray(a[:height, :width])
+
+
+class VisibilityRenderer:
+    """One brmi_pass (= CLodExtension + VisUtil + light clustering + deferred shading of one view)."""
+
+    def __init__(self, scene, device="cuda:0", max_clusters=None, occlusion=False, stats=False, band=(0, 0), **cfg_over):
+        import torch
+        if not torch.cuda.is_available():
+            raise BrmiError("no GPU: libbrmi.so needs an MI355X (there is no CPU fallback)")
+        self.torch = torch
+        self.lib = capi.brmi_lib()
+        self.scene, self.device = scene, torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.W, self.H = scene.width, scene.height
+        cfg = capi.Config()
+        self.lib.brmi_default_config(C.byref(cfg), self.W, self.H)
+        est = max(4096, 2 * scene.stats["meshletsTotal"] * max(1, scene.stats["instances"]) // max(1, scene.stats["meshes"]))
+        cfg.maxVisibleClusters = int(max_clusters or min(1 << 24, max(1 << 16, est)))
+        cfg.maxTraversalRecords = cfg.maxVisibleClusters
+        cfg.enableOcclusionCulling = 1 if occlusion else 0
+        cfg.collectPassStatistics = 1 if stats else 0
+        cfg.bandY0, cfg.bandY1 = band
+        for k, v in cfg_over.items():
+            setattr(cfg, k, v)
+        self.cfg = cfg
+        self._h = capi.vp()
+        self._check(self.lib.brmi_create(C.byref(cfg), C.byref(self._h)), "brmi_create", use_pass=False)
+        self.sb, self._scene_keep = scene.device_buffers(self.device)
+        self._check(self.lib.brmi_set_scene(self._h, C.byref(self.sb)), "brmi_set_scene")
+        self.descs = {}
+
+        def cb(_user, d):
+            d = d.contents
+            self.descs[d.id] = dict(name=d.name.decode(), bytes=d.bytes, width=d.width, height=d.height, bpp=d.bytesPerPixel)
+
+        self._cb = capi.DECLARE_CB(cb)
+        self._check(self.lib.brmi_declare(self._h, self._cb, None), "brmi_declare")
+        self.res = {}
+        binds = (capi.ResourceBinding * len(self.descs))()
+        for i, (rid, d) in enumerate(sorted(self.descs.items())):
+            t = torch.zeros(max(16, int(d["bytes"])), dtype=torch.uint8, device=self.device)
+            self.res[rid] = t
+            binds[i].id, binds[i].ptr, binds[i].bytes = rid, t.data_ptr(), t.numel()
+        self.stream = torch.cuda.current_stream(self.device)
+        self._check(self.lib.brmi_setup(self._h, binds, len(self.descs), self._s()), "brmi_setup")
+        self.update()
+
+    # ------------------------------------------------------------------------------------------
+    def _s(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _check(self, rc, what, use_pass=True):
+        if rc != 0:
+            msg = self.lib.brmi_last_error(self._h).decode() if use_pass and self._h else ""
+            raise BrmiError(f"{what} failed ({rc}): {msg}")
+
+    def update(self, frame_index=0):
+        cam, pf = self.scene.camera_host(), self.scene.per_frame_host()
+        upd = capi.FrameUpdate(cam.ctypes.data, pf.ctypes.data, frame_index)
+        self._check(self.lib.brmi_update(self._h, C.byref(upd), self._s()), "brmi_update")
+
+    def execute(self):
+        self._check(self.lib.brmi_execute(self._h, self._s()), "brmi_execute")
+
+    def stage(self, name, *args):
+        fn = getattr(self.lib, "brmi_" + name)
+        self._check(fn(self._h, *[capi.u32(a) for a in args], self._s()), "brmi_" + name)
+
+    def counters(self):
+        c = capi.Counters()
+        self._check(self.lib.brmi_read_counters(self._h, C.byref(c), self._s()), "brmi_read_counters")
+        return c
+
+    def stage_times(self):
+        ms = (capi.f32 * len(capi.STAGE_NAMES))()
+        self._check(self.lib.brmi_stage_times(self._h, ms), "brmi_stage_times")
+        return dict(zip(capi.STAGE_NAMES, [float(x) for x in ms]))
+
+    def algorithmic_bytes(self):
+        per = (capi.u64 * len(capi.STAGE_NAMES))()
+        total = capi.u64()
+        self._check(self.lib.brmi_algorithmic_bytes(self._h, per, C.byref(total)), "brmi_algorithmic_bytes")
+        return dict(zip(capi.STAGE_NAMES, [int(x) for x in per])), int(total.value)
+
+    # -- read-back (linear layout) ---------------------------------------------------------------
+    def _img(self, rid, dtype, comps=1):
+        self.torch.cuda.synchronize(self.device)
+        raw = self.res[capi.RES[rid]].cpu().numpy()
+        a = raw.view(dtype)
+        n = a.size // comps
+        a = a.reshape((n, comps)) if comps > 1 else a.reshape((n,))
+        return detile(a, self.W, self.H)
+
+    def visibility(self):
+        return self._img("VISIBILITY", np.uint64)
+
+    def depth(self):
+        return self._img("LINEAR_DEPTH", np.float32)
+
+    def hdr(self):
+        return self._img("HDR_COLOR", np.uint64)
+
+    def gbuffer(self):
+        return dict(normals=self._img("GBUF_NORMALS", np.float32, 4), albedo=self._img("GBUF_ALBEDO", np.uint32),
+                    coat=self._img("GBUF_COAT", np.uint64), emissive=self._img("GBUF_EMISSIVE", np.uint64),
+                    fuzz=self._img("GBUF_FUZZ", np.uint64), mr=self._img("GBUF_METALLIC_ROUGHNESS", np.uint32),
+                    motion=self._img("GBUF_MOTION_VECTORS", np.uint32))
+
+    def visible_clusters(self):
+        n = self.counters().visibleClusters
+        self.torch.cuda.synchronize(self.device)
+        raw = self.res[capi.RES["VISIBLE_CLUSTERS"]][: n * 16].cpu().numpy()
+        return raw.view(np.uint32).reshape(n, 4)
+
+    def light_clusters(self):
+        self.torch.cuda.synchronize(self.device)
+        c = self.res[capi.RES["LIGHT_CLUSTERS"]].cpu().numpy().view(np.uint32)
+        p = self.res[capi.RES["LIGHT_PAGES"]].cpu().numpy().view(np.uint32)
+        return c[: (c.size // 12) * 12].reshape(-1, 12), p[: (p.size // 14) * 14].reshape(-1, 14)
+
+    def hdr_tensor(self):
+        """The tiled HDR target as a torch uint8 view (for RCCL composition)."""
+        return self.res[capi.RES["HDR_COLOR"]]
+
+    def close(self):
+        if self._h:
+            self.lib.brmi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""bench.py -- shaded Mpixels/s of the visibility-buffer + clustered-resolve path on N MI355X.
+
+One "step" = one pass of the hot path over one synthetic frame already resident in HBM:
+clear -> cull -> software raster -> G-buffer(+depth) -> light clustering -> OpenPBR shade
+(-> RCCL all-gather of the HDR bands when N > 1).
+
+N = 1 : BASELINE.json configs[1], "Sponza 4K, visibility-buffer + clustered resolve, 1 dir + 64
+        point lights" (3840x2160).
+N > 1 : weak scaling by screen tile: every rank shades one 8.29 Mpixel row band (7680 x 1080) of a
+        7680 x (1080*N) frame of the same scene, geometry replicated, then the HDR bands are
+        all-gathered over xGMI so that every rank holds the composed image.
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (largest mean stage time):
+algorithmic bytes of SURVEY.md 8(d) / mean launch duration from HIP events on the execute stream.
+`cpu_baseline` times the CPU oracle (a port of the reference HLSL; test infrastructure) on one
+frame of the same workload, rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md)
+DOMINANT_KERNEL = {"raster": "k_raster", "gbuffer": "k_gbuffer", "shade": "k_shade", "cull": "k_traverse+k_cull_clusters", "clear": "k_clear_vis",
+                   "light_cluster": "k_light_clustering", "depth_copy": "k_depth_copy"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="sponza", choices=["sponza", "bistro", "san_miguel"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-scale", type=float, default=1.0, help="fraction of the frame height the CPU baseline renders")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from basicrenderer_amd import Scene
+    from basicrenderer_amd.renderer import VisibilityRenderer
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    n = world
+    assert n == args.gpus or world == 1, "--gpus must equal WORLD_SIZE"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+
+    lights = {"sponza": 64, "bistro": 256, "san_miguel": 256}[args.workload]
+    if n == 1:
+        W, H = 3840, 2160
+        band = (0, H)
+    else:
+        W, H = 7680, 1080 * n
+        band = (1080 * rank, 1080 * (rank + 1))
+    scene = Scene(args.workload, W, H, point_lights=lights, directional=True)
+    r = VisibilityRenderer(scene, device=dev, stats=True, band=band)
+
+    tilesX = (W + 7) // 8
+    band_bytes = ((band[1] - band[0]) // 8) * tilesX * 64 * 8
+    hdr = r.hdr_tensor()
+    my_band = hdr[(band[0] // 8) * tilesX * 64 * 8:][:band_bytes]
+    composed = torch.empty(band_bytes * n, dtype=torch.uint8, device=dev) if n > 1 else None
+
+    def step():
+        r.execute()
+        if n > 1:
+            dist.all_gather_into_tensor(composed, my_band)
+
+    for _ in range(args.warmup):
+        step()
+    r.stage_times()   # reset the event window
+    if n > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if n > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if n > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    stage_ms = r.stage_times()          # mean over the timed steps (HIP events on the execute stream)
+    per_stage_bytes, total_bytes = r.algorithmic_bytes()
+    c = r.counters()
+
+    if rank == 0:
+        shaded = W * (band[1] - band[0]) * n            # pixels dispatched per step, all ranks
+        ms_per_step = dt / args.steps * 1e3
+        value = shaded / 1e6 / (dt / args.steps)
+        dom = max(stage_ms, key=lambda k: stage_ms[k])
+        dom_s = stage_ms[dom] * 1e-3
+        achieved = per_stage_bytes[dom] / dom_s / 1e9 if dom_s > 0 else 0.0
+        frame_gbs = total_bytes / (dt / args.steps) / 1e9
+        out = {
+            "metric": "shaded Mpixels/s @4K (vis-buffer+resolve)", "value": round(value, 2), "unit": "Mpixels/s",
+            "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}-class procedural frame, {W}x{H}, 1 directional + {lights} point lights, "
+                                   f"{scene.stats['instancedTriangles']} instanced tris, {scene.stats['instances']} instances"
+                                   + (f", {n} row bands of 1080 rows + RCCL all-gather of HDR" if n > 1 else ""),
+                       "baseline_config": "configs[1]" if args.workload == "sponza" else "configs[2]",
+                       "pixels_per_gpu": W * (band[1] - band[0]), "visible_clusters_rank0": int(c.visibleClusters),
+                       "meshlets_tested_rank0": int(c.meshletsTested), "partition": f"row bands x{n}" if n > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": DOMINANT_KERNEL.get(dom, dom), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(per_stage_bytes[dom]), "launch_ms": round(stage_ms[dom], 4),
+                         "whole_frame": {"algorithmic_bytes": int(total_bytes), "achieved_GBps": round(frame_gbs, 2), "frac": round(frame_gbs / HBM_PEAK_GBS, 5)}},
+            "stage_ms": {k: round(v, 4) for k, v in stage_ms.items() if v > 0},
+        }
+        if n == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene, args.cpu_scale)
+        print(json.dumps(out), flush=True)
+    r.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(scene, scale):
+    """The CPU oracle (port of the reference HLSL) on the same frame, all host cores, one frame."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    cores = os.cpu_count() or 1
+    f = orc.OracleFrame(scene, threads=cores)
+    H = scene.height
+    rows = max(8, int(H * scale) // 8 * 8)
+    band = (0, rows) if rows < H else (0, 0)
+    t0 = time.perf_counter()
+    f.cull()
+    f.raster(band=band)
+    f.depth_copy()
+    f.gbuffer(band=band)
+    f.light_cluster()
+    f.shade(band=band)
+    dt = time.perf_counter() - t0
+    px = scene.width * (rows if rows < H else H)
+    return {"value": round(px / 1e6 / dt, 3), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+            "sample": f"1 frame, rows [0,{rows if rows < H else H}) of {scene.width}x{H} ({px} px), {dt:.1f} s, OpenMP over clusters / scanlines"}
+
+
+if __name__ == "__main__":
+    main()

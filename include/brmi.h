@@ -181,10 +181,16 @@ int brmi_shade(brmi_pass* pass, brmi_stream stream);              /* DeferredSha
 
 /* ---- introspection ------------------------------------------------------------------------- */
 int brmi_read_counters(brmi_pass* pass, brmi_counters* out, brmi_stream stream);   /* synchronises */
-/* milliseconds per stage for the last execute (collectPassStatistics); synchronises */
+/* mean milliseconds per stage over the frames executed since the previous call (at most the last 32;
+ * HIP events on the execute stream, collectPassStatistics); synchronises and resets the window */
 int brmi_stage_times(brmi_pass* pass, float* msOut /* [BRMI_STAGE_COUNT] */);
 /* algorithmic bytes of the last frame per SURVEY.md 8(d): 140*P + sum(144+12V+3T) + 64*M + 16*Mvis + 64*N */
 int brmi_algorithmic_bytes(brmi_pass* pass, uint64_t* perStage /* [BRMI_STAGE_COUNT] */, uint64_t* total);
+
+/* ---- diagnostics ---------------------------------------------------------------------------- */
+/* Evaluates the library's fp32 primitives on device data so a test can check the arithmetic contract
+ * (correctly rounded a/b and sqrt(a), round-to-nearest-even float->half) against IEEE on the host. */
+int brmi_debug_arith(const float* a, const float* b, float* outDiv, float* outSqrt, uint32_t* outHalfBits, uint32_t n, brmi_stream stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,58 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built():
+    """Build the CPU-side libraries on demand (the HIP library is built by __graft_entry__.build())."""
+    import subprocess
+    need = [os.path.join(ROOT, "basicrenderer_amd", "lib", "libbrmi_scene.so"), os.path.join(ROOT, "oracle", "_build", "liboracle.so")]
+    if not all(os.path.exists(p) for p in need):
+        subprocess.check_call(["make", "-C", ROOT, "scene", "oracle"], stdout=subprocess.DEVNULL)
+    yield
+
+
+SCENE_CASES = {
+    # name: (preset, W, H, kwargs)
+    "tiny": ("tiny", 256, 144, dict(point_lights=6)),
+    "tiny_lod": ("tiny", 320, 180, dict(point_lights=3, lod_levels=2)),
+    "sponza_small": ("sponza", 640, 360, dict(point_lights=64, size_scale=0.25)),
+    "bistro_small": ("bistro", 640, 360, dict(point_lights=256, size_scale=0.08)),
+}
+
+
+@pytest.fixture(scope="session")
+def scenes():
+    from basicrenderer_amd import Scene
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            preset, W, H, kw = SCENE_CASES[name]
+            cache[name] = Scene(preset, W, H, **kw)
+        return cache[name]
+
+    return get
+
+
+@pytest.fixture(scope="session")
+def oracle_frames(scenes):
+    import orc
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = orc.OracleFrame(scenes(name)).run()
+        return cache[name]
+
+    return get
