@@ -133,6 +133,10 @@ def brmi_lib():
     """libbrmi.so: HIP kernels + C ABI.  Fails loudly when the extension has not been built."""
     global _brmi_lib
     if _brmi_lib is None:
+        # One HIP runtime per process: PyTorch ships its own libamdhip64.so.7 / libhsa-runtime64 and owns
+        # the device memory we are handed, so it must be loaded first; libbrmi.so's NEEDED libamdhip64.so.7
+        # then resolves (by SONAME) to the copy already mapped instead of pulling in /opt/rocm's.
+        import torch  # noqa: F401
         path = os.path.join(LIB_DIR, "libbrmi.so")
         if not os.path.exists(path):
             raise RuntimeError(f"{path} is missing: the HIP extension must be built (make hip); there is no CPU fallback")
