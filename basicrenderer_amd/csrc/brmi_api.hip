@@ -83,6 +83,10 @@ static void compute_sizes(brmi_pass* p) {
     w.segPrefix = take((uint64_t)std::max<size_t>(1, p->hostSegPrefix.size()) * 4);
     w.planes = take((uint64_t)2 * c.lightClusterSize[2] * 4);
     w.replayNodes = take(16); w.replayBuckets = take(16);
+    w.lightVS = take((uint64_t)std::max(1u, p->scene.lightCount) * 16);
+    w.lightMeta = take((uint64_t)std::max(1u, p->scene.lightCount) * 4);
+    w.clusterPages = take((uint64_t)p->numLightClusters * 4);
+    w.bigTris = take((uint64_t)p->bigTriCapacity * 64);
     w.total = off;
     p->resNeed[BRMI_RES_WORKSPACE] = w.total;
 }

@@ -30,6 +30,7 @@ enum CounterIndex : uint32_t {
     CNT_SUM_VERTS_LO, CNT_SUM_VERTS_HI,     // sum of vertex counts of rasterised clusters (u64)
     CNT_SUM_TRIS_LO, CNT_SUM_TRIS_HI,
     CNT_RASTER_CLUSTERS,
+    CNT_BIG_TRIS,             // records in the big-triangle queue
     CNT_FRONTIER0 = 32,       // frontier sizes per BFS level: [CNT_FRONTIER0 + level]
     CNT_WORDS = 32 + 72
 };
@@ -44,7 +45,7 @@ struct TempVisible { uint4 packed; uint32_t bit, pad0, pad1, pad2; };           
 
 struct Workspace {     // byte offsets into BRMI_RES_WORKSPACE
     uint64_t counters, frontierA, frontierB, buckets, tempVisible, bitmask1, bitmask2, wordPrefix, blockSums,
-             instanceBitBase, segPrefix, planes, replayNodes, replayBuckets, total;
+             instanceBitBase, segPrefix, planes, replayNodes, replayBuckets, lightVS, lightMeta, clusterPages, bigTris, total;
 };
 
 }  // namespace brmi
@@ -64,6 +65,7 @@ struct brmi_pass {
     uint32_t maxLevels = 1;
     uint64_t totalBits = 0; uint32_t totalWords = 0, scanBlocks = 0;
     uint32_t numLightClusters = 0, lightPagePool = 0;
+    uint32_t bigTriCapacity = 1u << 18;
     uint32_t hzbMipCount = 0; std::vector<uint64_t> hzbMipOffsets; std::vector<uint32_t> hzbMipW, hzbMipH;
     std::vector<uint32_t> hostInstanceBitBase, hostSegPrefix;
     brmi::Workspace ws{};

@@ -5,16 +5,18 @@
 // BR/shaders/Include/IBL.hlsli:94-672, BR/shaders/Include/PBR.hlsli:8-190,
 // BR/shaders/Include/utilities.hlsli:2590-2709.
 // MI355X-first differences:
-//   * K9 (1 thread per group, 3456 groups) and K10 (global atomic page allocator) fuse into one
-//     workgroup: AABBs, a counting pass, an LDS prefix scan that hands every cluster a contiguous,
-//     deterministic page range (= the allocation order of a serial run of the reference), and the
-//     fill pass.  Page contents and list order are exactly the reference's; page numbers no longer
+//   * K9 (1 thread per group, 3456 groups) and K10 (global atomic page allocator) become: light
+//     spheres to view space once, one lane per cluster for AABB + page demand, a prefix scan that
+//     hands every cluster a contiguous, deterministic page range (= the allocation order of a
+//     serial run of the reference), and the fill pass.  Page contents and list order are exactly the reference's; page numbers no longer
 //     depend on atomic ordering.
 //   * slice plane depths come from the host (see brmi_update): log()/exp() results differ in the
 //     last bit between math libraries and would make light lists irreproducible.
 //   * K11 runs one lane per pixel in tile order (a wave = one 8x8 tile): all G-buffer reads and the
 //     HDR write are contiguous per wave.
 //   * OpenPBR lookup tables are injected R16_UNORM / float tables, bilinearly filtered in fp32.
+#include <algorithm>
+
 #include "brmi_device.h"
 #include "brmi_internal.h"
 
@@ -31,104 +33,133 @@ struct ClusterArgs {
     brmi_light_page* pages;
     uint32_t poolSize;
     uint32_t* counters;
+    float4* lightVS;              // per active light: view-space bounding sphere (xyz, r)
+    uint32_t* lightMeta;          // per active light: type | lightIndex << 2
+    uint32_t* clusterPages;       // per cluster: page demand, then (after the scan) first page
 };
 
-BRMI_DEV bool light_hits_cluster(const brmi_light_info* l, const m4& view, f3 mn, f3 mx) {
-    if (l->type == BRMI_LIGHT_DIRECTIONAL) return true;
-    if (l->type != BRMI_LIGHT_POINT && l->type != BRMI_LIGHT_SPOT) return false;
-    const f3 center = xyz(mul_point(f3{l->boundingSphere[0], l->boundingSphere[1], l->boundingSphere[2]}, view));
-    const f3 closest = max3v(mn, min3v(center, mx));
-    const f3 d = closest - center;
-    return dot3(d, d) <= l->boundingSphere[3] * l->boundingSphere[3];
+// view-space bounding spheres of the active lights, once per frame (testSphereAABB's transform, lightCulling.hlsl:15-21)
+__global__ void __launch_bounds__(64) k_lc_lights(ClusterArgs a) {
+    const brmi_scene_buffers& sc = a.sc;
+    const brmi_per_frame* pf = sc.perFrame;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pf->numLights) return;
+    const m4 view = load_m4(&sc.cameras[pf->mainCameraIndex].view[0][0]);
+    const uint32_t li = sc.activeLightIndices[i];
+    const brmi_light_info* l = sc.lights + li;
+    const f3 c = xyz(mul_point(f3{l->boundingSphere[0], l->boundingSphere[1], l->boundingSphere[2]}, view));
+    a.lightVS[i] = make_float4(c.x, c.y, c.z, l->boundingSphere[3]);
+    a.lightMeta[i] = (l->type & 3u) | (li << 2);
 }
 
-constexpr uint32_t MAX_CLUSTERS_LDS = 16384;
+BRMI_DEV bool light_hits_cluster(float4 sphere, uint32_t type, f3 mn, f3 mx) {
+    if (type == BRMI_LIGHT_DIRECTIONAL) return true;
+    if (type != BRMI_LIGHT_POINT && type != BRMI_LIGHT_SPOT) return false;
+    const f3 center{sphere.x, sphere.y, sphere.z};
+    const f3 closest = max3v(mn, min3v(center, mx));
+    const f3 d = closest - center;
+    return dot3(d, d) <= sphere.w * sphere.w;
+}
 
-__global__ void __launch_bounds__(1024) k_light_clustering(ClusterArgs a) {
-    __shared__ uint32_t pageBase[MAX_CLUSTERS_LDS];
-    __shared__ uint32_t waveTotals[16];
+// one lane per cluster: AABB (clustering.hlsl:31-107) + page demand of the serial allocator (lightCulling.hlsl:70-118)
+__global__ void __launch_bounds__(64) k_lc_count(ClusterArgs a) {
     const brmi_scene_buffers& sc = a.sc;
     const brmi_per_frame* pf = sc.perFrame;
     const brmi_camera* cam = sc.cameras + pf->mainCameraIndex;
     const uint32_t gx = pf->lightClusterGridSizeX, gy = pf->lightClusterGridSizeY, gz = pf->lightClusterGridSizeZ;
     const uint32_t total = gx * gy * gz, lightCount = pf->numLights;
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
     const float W = (float)pf->screenResX, H = (float)pf->screenResY;
     const m4 invProj = load_m4(&cam->projectionInverse[0][0]);
-    const m4 view = load_m4(&cam->view[0][0]);
     const float tsx = W / (float)gx, tsy = H / (float)gy;
-    const uint32_t perThread = (total + 1023u) / 1024u;
-    const uint32_t cBegin = threadIdx.x * perThread, cEnd = min(cBegin + perThread, total);
-
-    // pass 1: AABB (clustering.hlsl) + page demand of the serial allocator (lightCulling.hlsl:70-118)
-    uint32_t myPages = 0;
-    for (uint32_t idx = cBegin; idx < cEnd; idx++) {
-        const uint32_t x = idx % gx, y = (idx / gx) % gy, z = idx / (gx * gy);
-        f3 tileV[2];
+    const uint32_t x = idx % gx, y = (idx / gx) % gy, z = idx / (gx * gy);
+    f3 tileV[2];
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const float sxp = ((float)x + (k ? 1.0f : 0.0f)) * tsx, syp = ((float)y + (k ? 1.0f : 0.0f)) * tsy;
-            const f4 ndc{2.0f * sxp / W - 1.0f, 2.0f * (H - syp - 1.0f) / H - 1.0f, 1.0f, 1.0f};
-            const f4 v = mul_vm(ndc, invProj);
-            tileV[k] = f3{v.x / v.w, v.y / v.w, v.z / v.w};
-        }
-        const float pn = a.planes[2 * z], pfar = a.planes[2 * z + 1];
-        f3 pts[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const f3 e = tileV[k & 1];
-            const float t = ((k & 2) ? pfar : pn) / e.z;
-            pts[k] = f3{t * e.x, t * e.y, t * e.z};
-        }
-        const f3 mn = min3v(min3v(pts[0], pts[1]), min3v(pts[2], pts[3])), mx = max3v(max3v(pts[0], pts[1]), max3v(pts[2], pts[3]));
-        brmi_light_cluster* c = a.clusters + idx;
-        *reinterpret_cast<float4*>(c->minPoint) = make_float4(mn.x, mn.y, mn.z, 0.0f);
-        *reinterpret_cast<float4*>(c->maxPoint) = make_float4(mx.x, mx.y, mx.z, 0.0f);
-        uint32_t pagesNeeded = 1, inPage = 0;
-        for (uint32_t i = 0; i < lightCount; i++) {
-            if (inPage >= BRMI_LIGHTS_PER_PAGE) { pagesNeeded++; inPage = 0; }
-            if (light_hits_cluster(sc.lights + sc.activeLightIndices[i], view, mn, mx)) inPage++;
-        }
-        pageBase[idx] = pagesNeeded;
-        myPages += pagesNeeded;
+    for (int k = 0; k < 2; k++) {
+        const float sxp = ((float)x + (k ? 1.0f : 0.0f)) * tsx, syp = ((float)y + (k ? 1.0f : 0.0f)) * tsy;
+        const f4 ndc{2.0f * sxp / W - 1.0f, 2.0f * (H - syp - 1.0f) / H - 1.0f, 1.0f, 1.0f};
+        const f4 v = mul_vm(ndc, invProj);
+        tileV[k] = f3{v.x / v.w, v.y / v.w, v.z / v.w};
     }
-    // block-wide exclusive scan of per-thread demand
-    uint32_t incl = myPages;
+    const float pn = a.planes[2 * z], pfar = a.planes[2 * z + 1];
+    f3 pts[4];
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o); if ((threadIdx.x & 63u) >= (uint32_t)o) incl += t; }
-    if ((threadIdx.x & 63u) == 63u) waveTotals[threadIdx.x >> 6] = incl;
+    for (int k = 0; k < 4; k++) {
+        const f3 e = tileV[k & 1];
+        const float t = ((k & 2) ? pfar : pn) / e.z;
+        pts[k] = f3{t * e.x, t * e.y, t * e.z};
+    }
+    const f3 mn = min3v(min3v(pts[0], pts[1]), min3v(pts[2], pts[3])), mx = max3v(max3v(pts[0], pts[1]), max3v(pts[2], pts[3]));
+    brmi_light_cluster* c = a.clusters + idx;
+    *reinterpret_cast<float4*>(c->minPoint) = make_float4(mn.x, mn.y, mn.z, 0.0f);
+    *reinterpret_cast<float4*>(c->maxPoint) = make_float4(mx.x, mx.y, mx.z, 0.0f);
+    uint32_t pagesNeeded = 1, inPage = 0;
+    for (uint32_t i = 0; i < lightCount; i++) {
+        if (inPage >= BRMI_LIGHTS_PER_PAGE) { pagesNeeded++; inPage = 0; }
+        if (light_hits_cluster(a.lightVS[i], a.lightMeta[i] & 3u, mn, mx)) inPage++;
+    }
+    a.clusterPages[idx] = pagesNeeded;
+}
+
+// single workgroup: exclusive scan of the page demand in cluster order = the serial allocation order
+__global__ void __launch_bounds__(1024) k_lc_scan(ClusterArgs a) {
+    __shared__ uint32_t waveTotals[16];
+    __shared__ uint32_t carry;
+    const brmi_per_frame* pf = a.sc.perFrame;
+    const uint32_t total = pf->lightClusterGridSizeX * pf->lightClusterGridSizeY * pf->lightClusterGridSizeZ;
+    if (threadIdx.x == 0) carry = 0;
     __syncthreads();
-    uint32_t base = incl - myPages;
-    for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) base += waveTotals[w];
-    if (threadIdx.x == 1023) a.counters[CNT_LIGHT_PAGES] = min(base + myPages, a.poolSize);
-
-    // pass 2: fill (same control flow as the reference, page numbers from the scan)
-    for (uint32_t idx = cBegin; idx < cEnd; idx++) {
-        brmi_light_cluster* c = a.clusters + idx;
-        const f3 mn{c->minPoint[0], c->minPoint[1], c->minPoint[2]}, mx{c->maxPoint[0], c->maxPoint[1], c->maxPoint[2]};
-        uint32_t next = base; base += pageBase[idx];
-        auto alloc = [&]() { const uint32_t i = next++; return i >= a.poolSize ? BRMI_LIGHT_PAGE_NULL : i; };
-        uint32_t page = alloc();
-        uint32_t numLights = 0, firstPage = page;
-        if (page != BRMI_LIGHT_PAGE_NULL) {
-            a.pages[page].ptrNextPage = BRMI_LIGHT_PAGE_NULL;
-            uint32_t inPage = 0;
-            for (uint32_t i = 0; i < lightCount; i++) {
-                if (inPage >= BRMI_LIGHTS_PER_PAGE) {
-                    a.pages[page].numLightsInPage = BRMI_LIGHTS_PER_PAGE;
-                    const uint32_t old = page;
-                    page = alloc();
-                    if (page == BRMI_LIGHT_PAGE_NULL) break;
-                    a.pages[page].ptrNextPage = old;
-                    firstPage = page;
-                    inPage = 0;
-                }
-                const uint32_t li = sc.activeLightIndices[i];
-                if (light_hits_cluster(sc.lights + li, view, mn, mx)) { a.pages[page].lightIndices[inPage] = li; inPage++; numLights++; }
-            }
-            if (page != BRMI_LIGHT_PAGE_NULL) a.pages[page].numLightsInPage = inPage;
-        }
-        c->numLights = numLights; c->ptrFirstPage = firstPage; c->pad[0] = 0; c->pad[1] = 0;
+    for (uint32_t base = 0; base < total; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < total ? a.clusterPages[i] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o); if ((threadIdx.x & 63u) >= (uint32_t)o) incl += t; }
+        if ((threadIdx.x & 63u) == 63u) waveTotals[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        uint32_t waveBase = 0;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) waveBase += waveTotals[w];
+        const uint32_t c = carry;
+        if (i < total) a.clusterPages[i] = c + waveBase + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = c + waveBase + incl;
+        __syncthreads();
     }
+    if (threadIdx.x == 0) a.counters[CNT_LIGHT_PAGES] = min(carry, a.poolSize);
+}
+
+// fill: the reference's control flow per cluster, page numbers from the scan
+__global__ void __launch_bounds__(64) k_lc_fill(ClusterArgs a) {
+    const brmi_per_frame* pf = a.sc.perFrame;
+    const uint32_t total = pf->lightClusterGridSizeX * pf->lightClusterGridSizeY * pf->lightClusterGridSizeZ, lightCount = pf->numLights;
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    brmi_light_cluster* c = a.clusters + idx;
+    const f3 mn{c->minPoint[0], c->minPoint[1], c->minPoint[2]}, mx{c->maxPoint[0], c->maxPoint[1], c->maxPoint[2]};
+    uint32_t next = a.clusterPages[idx];
+    auto alloc = [&]() { const uint32_t i = next++; return i >= a.poolSize ? BRMI_LIGHT_PAGE_NULL : i; };
+    uint32_t page = alloc();
+    uint32_t numLights = 0, firstPage = page;
+    if (page != BRMI_LIGHT_PAGE_NULL) {
+        a.pages[page].ptrNextPage = BRMI_LIGHT_PAGE_NULL;
+        uint32_t inPage = 0;
+        for (uint32_t i = 0; i < lightCount; i++) {
+            if (inPage >= BRMI_LIGHTS_PER_PAGE) {
+                a.pages[page].numLightsInPage = BRMI_LIGHTS_PER_PAGE;
+                const uint32_t old = page;
+                page = alloc();
+                if (page == BRMI_LIGHT_PAGE_NULL) break;
+                a.pages[page].ptrNextPage = old;
+                firstPage = page;
+                inPage = 0;
+            }
+            const uint32_t meta = a.lightMeta[i];
+            if (light_hits_cluster(a.lightVS[i], meta & 3u, mn, mx)) { a.pages[page].lightIndices[inPage] = meta >> 2; inPage++; numLights++; }
+        }
+        if (page != BRMI_LIGHT_PAGE_NULL) a.pages[page].numLightsInPage = inPage;
+    }
+    c->numLights = numLights; c->ptrFirstPage = firstPage; c->pad[0] = 0; c->pad[1] = 0;
 }
 
 // =================================== K11 =======================================================
@@ -383,41 +414,102 @@ BRMI_DEV f3 diffuse_eon(f3 albedo, float rough, float NdotV, float NdotL, float 
     return single + multi;
 }
 
-BRMI_DEV f3 light_contribution(const Luts& L, const Frag& f, f3 lightToFrag, f3 lightColor, float intensity, float attenuation, float spotAtt) {
-    const float NoV = sat(dot3(f.normalWS, f.viewWS)), NoL = sat(dot3(f.normalWS, lightToFrag));
-    const BaseState base = make_base_state(f);
-    const CoatState coat = make_coat_state(base, f);
-    const FuzzState fuzz = make_fuzz_state(L, f);
+// Per-pixel part of calculateLightContributionPBR / EvaluateOpenPBRBaseLayerDirect.  The reference
+// re-derives all of this for every light; nothing here depends on the light, so it is evaluated once
+// per pixel with the same operations in the same order (bit-identical operands for the light loop).
+struct PixelCtx {
+    BaseState base;
+    float NoV;
+    bool plain;                 // coat and fuzz absent: their factors are exactly 1 / 0 and are skipped
+    CoatState coat; FuzzState fuzz;
+    f3 coatIn, coatComp;
+    float cachedView, mView, mAvgClamped;
+    f3 dielComp;
+    float f90Diel, f90Metal;
+    f3 eonSinglePre, eonMsPre; float eonEInTerm, eonDen;
+};
+
+BRMI_DEV PixelCtx make_pixel_ctx(const Luts& L, const Frag& f) {
+    PixelCtx c;
+    c.base = make_base_state(f);
+    c.NoV = sat(dot3(f.normalWS, f.viewWS));
+    c.plain = (sat(f.coatWeight) == 0.0f) && (sat(f.fuzzWeight) == 0.0f);
+    if (!c.plain) {
+        c.coat = make_coat_state(c.base, f);
+        c.fuzz = make_fuzz_state(L, f);
+        c.coatIn = coat_scale_incoming(L, c.coat, c.NoV);
+        c.coatComp = ggx_energy_compensation(c.NoV, f.coatRoughness, f.coatF0);
+    }
+    const BaseState& b = c.base;
+    const float viewComp = lut_od_e(L, b.weightedSpecularIor, b.specularAlpha, sat(c.NoV));
+    const float avgComp = lut_od_avg(L, b.weightedSpecularIor, b.specularAlpha);
+    c.cachedView = max2(0.0f, viewComp / max2(avgComp, 1.0e-12f));
+    c.mView = lut_im_e(L, b.specularAlpha, c.NoV);
+    c.mAvgClamped = max2(lut_im_avg(L, b.specularAlpha), 1.0e-12f);
+    c.dielComp = ggx_energy_compensation(c.NoV, b.specularAlpha, b.dielectricSpecularF0);
+    const float tmp = 50.0f * 0.33f;
+    c.f90Diel = sat(dot3(b.dielectricSpecularF0, f3{tmp, tmp, tmp}));
+    c.f90Metal = sat(dot3(b.metalSpecularF0, f3{tmp, tmp, tmp}));
+    // OpenPBRDiffuseEON, view-only factors
+    const float rough = b.baseDiffuseRoughness;
+    const float A = 1.0f / (1.0f + fon_a() * rough);
+    c.eonSinglePre = b.diffuseColor * (1.0f / PI_F) * A;
+    const float EIn = fon_dir_albedo(sat(c.NoV), rough);
+    const float avgE = A * (1.0f + fon_b() * rough);
+    const f3 msAlbedo = (b.diffuseColor * b.diffuseColor) * avgE / max3v(f3{1.0f, 1.0f, 1.0f} - b.diffuseColor * (1.0f - avgE), f3{1.0e-4f, 1.0e-4f, 1.0e-4f});
+    c.eonMsPre = msAlbedo * (1.0f / PI_F);
+    c.eonEInTerm = max2(1.0e-4f, 1.0f - EIn);
+    c.eonDen = max2(1.0e-4f, 1.0f - avgE);
+    return c;
+}
+
+BRMI_DEV f3 light_contribution(const Luts& L, const Frag& f, const PixelCtx& c, f3 lightToFrag, float NoL, f3 lightColor, float intensity, float attenuation, float spotAtt) {
+    const BaseState& base = c.base;
+    const float NoV = c.NoV;
     const f3 h = normalize3(lightToFrag + f.viewWS);
     const float NoH = sat(dot3(f.normalWS, h)), LoH = sat(dot3(lightToFrag, h));
     const float VdotL = dot3(f.viewWS, lightToFrag);
-    // EvaluateOpenPBRBaseLayerDirect
-    const float viewComp = lut_od_e(L, base.weightedSpecularIor, base.specularAlpha, sat(NoV));
-    const float avgComp = lut_od_avg(L, base.weightedSpecularIor, base.specularAlpha);
-    const float cachedView = max2(0.0f, viewComp / max2(avgComp, 1.0e-12f));
+    // diffuse: EON x dielectric energy compensation
     const float lightComp = lut_od_e(L, base.weightedSpecularIor, base.specularAlpha, sat(NoL));
-    const float diffuseEnergyComp = max2(0.0f, cachedView * lightComp);
-    const f3 diffuse = diffuse_eon(base.diffuseColor, base.baseDiffuseRoughness, NoV, NoL, VdotL) * diffuseEnergyComp;
-    const float mView = lut_im_e(L, base.specularAlpha, NoV), mLight = lut_im_e(L, base.specularAlpha, NoL), mAvg = lut_im_avg(L, base.specularAlpha);
-    const float mTab = mView * mLight / max2(mAvg, 1.0e-12f);
-    const float mScale = min2(mTab, rcpf(max2(NoL, 1.0e-4f))) * (1.0f / PI_F);
-    const f3 dielSpec = base.dielectricSpecularWeight * specular_lobe(base.specularAlpha, base.dielectricSpecularF0, NoV, NoL, NoH, LoH) *
-                        ggx_energy_compensation(NoV, base.specularAlpha, base.dielectricSpecularF0);
-    const f3 metalSpec = base.metalSpecularWeight * (specular_lobe(base.specularAlpha, base.metalSpecularF0, NoV, NoL, NoH, LoH) + base.metalMultipleScatterScale * mScale);
-    const f3 specular = dielSpec + metalSpec;
-    // layers
-    const f3 llocal = to_local(fuzz, normalize3(lightToFrag));
-    const float fuzzOut = (llocal.z <= 0.0f) ? 0.0f : sat(fuzz.presence * fuzz_dir_reflectance(L, fuzz.roughness, llocal.z));
-    const float fuzzScale = (1.0f - fuzz.viewReflected) * (1.0f - fuzzOut);
-    const f3 baseScale = coat_scale_incoming(L, coat, NoV) * coat_scale_outgoing(L, coat, NoL);
-    f3 coatFr{0.0f, 0.0f, 0.0f};
-    if (coat.presence > 0.0f) {
-        coatFr = specular_lobe(f.coatRoughness, f.coatF0, NoV, NoL, NoH, LoH);
-        coatFr = coatFr * (ggx_energy_compensation(NoV, f.coatRoughness, f.coatF0) * coat.presence);
+    const float diffuseEnergyComp = max2(0.0f, c.cachedView * lightComp);
+    f3 diffuse;
+    {
+        const float rough = base.baseDiffuseRoughness;
+        const float muIn = sat(NoV), muOut = sat(NoL);
+        const float sv = VdotL - muIn * muOut;
+        const float sOverT = sv > 0.0f ? sv / max2(max2(muIn, muOut), 1.0e-4f) : sv;
+        const f3 single = c.eonSinglePre * (1.0f + rough * sOverT);
+        const float EOut = fon_dir_albedo(muOut, rough);
+        const float k = max2(1.0e-4f, 1.0f - EOut) * c.eonEInTerm / c.eonDen;
+        diffuse = (single + c.eonMsPre * f3{k, k, k}) * diffuseEnergyComp;
     }
-    const f3 fuzzFr = fuzz_sheen(L, fuzz, lightToFrag);
-    const f3 baseAtt = f3{fuzzScale, fuzzScale, fuzzScale} * baseScale;
-    const f3 brdf = (diffuse + specular) * baseAtt + coatFr * f3{fuzzScale, fuzzScale, fuzzScale} + fuzzFr;
+    // specular: one D*V for both lobes (same roughness), one Schlick power
+    const float DV = d_ggx(base.specularAlpha, NoH) * v_smith_ggx(base.specularAlpha, NoV, NoL);
+    const float pw = __builtin_amdgcn_exp2f(5.0f * __builtin_amdgcn_logf(1.0f - LoH));   // pow(1 - LoH, 5) = exp2(5 log2 x), as DXC lowers it
+    const f3 Fd = base.dielectricSpecularF0 + (f3{c.f90Diel, c.f90Diel, c.f90Diel} - base.dielectricSpecularF0) * pw;
+    const f3 Fm = base.metalSpecularF0 + (f3{c.f90Metal, c.f90Metal, c.f90Metal} - base.metalSpecularF0) * pw;
+    const float mLight = lut_im_e(L, base.specularAlpha, NoL);
+    const float mTab = c.mView * mLight / c.mAvgClamped;
+    const float mScale = min2(mTab, rcpf(max2(NoL, 1.0e-4f))) * (1.0f / PI_F);
+    const f3 dielSpec = base.dielectricSpecularWeight * (DV * Fd) * c.dielComp;
+    const f3 metalSpec = base.metalSpecularWeight * (DV * Fm + base.metalMultipleScatterScale * mScale);
+    const f3 specular = dielSpec + metalSpec;
+    f3 brdf;
+    if (c.plain) brdf = diffuse + specular;
+    else {
+        const f3 llocal = to_local(c.fuzz, normalize3(lightToFrag));
+        const float fuzzOut = (llocal.z <= 0.0f) ? 0.0f : sat(c.fuzz.presence * fuzz_dir_reflectance(L, c.fuzz.roughness, llocal.z));
+        const float fuzzScale = (1.0f - c.fuzz.viewReflected) * (1.0f - fuzzOut);
+        const f3 baseScale = c.coatIn * coat_scale_outgoing(L, c.coat, NoL);
+        f3 coatFr{0.0f, 0.0f, 0.0f};
+        if (c.coat.presence > 0.0f) {
+            coatFr = specular_lobe(f.coatRoughness, f.coatF0, NoV, NoL, NoH, LoH);
+            coatFr = coatFr * (c.coatComp * c.coat.presence);
+        }
+        const f3 fuzzFr = fuzz_sheen(L, c.fuzz, lightToFrag);
+        const f3 baseAtt = f3{fuzzScale, fuzzScale, fuzzScale} * baseScale;
+        brdf = (diffuse + specular) * baseAtt + coatFr * f3{fuzzScale, fuzzScale, fuzzScale} + fuzzFr;
+    }
     return brdf * lightColor * intensity * attenuation * spotAtt * NoL;
 }
 
@@ -442,6 +534,12 @@ __global__ void __launch_bounds__(256) k_shade(ShadeArgs a) {
     const m4 invProj = load_m4(&cam->projectionInverse[0][0]), viewInv = load_m4(&cam->viewInverse[0][0]);
     const f3 camPos{cam->positionWorldSpace[0], cam->positionWorldSpace[1], cam->positionWorldSpace[2]};
     const float zNear = cam->zNear, zFar = cam->zFar, zSplit = pf->clusterZSplitDepth;
+    const float resX = (float)pf->screenResX, resY = (float)pf->screenResY;
+    const float tsx = resX / (float)gx, tsy = resY / (float)gy;
+    const float logStart = logf(zSplit / zNear), logEnd = logf(zFar / zNear);
+    const uint32_t nearSlices = pf->nearClusterCount, numLights = pf->numLights;
+    const float om = 1.0f - 1.0f / 7.0f;
+    const float om5 = powf(om, 5.0f), om6 = powf(om, 6.0f);
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < a.pixelCount; j += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t i = a.firstPixel + j;
         const uint32_t tile = (uint32_t)(i >> 6), within = (uint32_t)(i & 63u);
@@ -449,7 +547,7 @@ __global__ void __launch_bounds__(256) k_shade(ShadeArgs a) {
         if (px >= a.W || py >= a.H || py < a.bandY0 || py >= a.bandY1) continue;
         const float d = a.depth[i];
         if (as_u32(d) == BRMI_DEPTH_EMPTY_BITS) continue;
-        float uvx = ((float)px + 0.5f) / (float)pf->screenResX, uvy = ((float)py + 0.5f) / (float)pf->screenResY;
+        float uvx = ((float)px + 0.5f) / resX, uvy = ((float)py + 0.5f) / resY;
         uvy = 1.0f - uvy;
         const f4 clipPos{uvx * 2.0f - 1.0f, uvy * 2.0f - 1.0f, 1.0f, 1.0f};
         const f4 viewPosH = mul_vm(clipPos, invProj);
@@ -494,8 +592,7 @@ __global__ void __launch_bounds__(256) k_shade(ShadeArgs a) {
         f.metalSpecularF0 = sat3(weightedBaseColor * specularColor);
         {
             const f3 safeF0 = sat3(weightedBaseColor), wmF0 = f3{1.0f, 1.0f, 1.0f} - safeF0;
-            const float cosMax = 1.0f / 7.0f, om = 1.0f - cosMax;
-            const float om5 = powf(om, 5.0f), om6 = powf(om, 6.0f);
+            const float cosMax = 1.0f / 7.0f;
             const f3 wmF0b = f3{1.0f, 1.0f, 1.0f} - sat3(safeF0), wmTint = f3{1.0f, 1.0f, 1.0f} - sat3(specularColor);
             const f3 num = (sat3(safeF0) + wmF0b * om5) * wmTint;
             const float den = cosMax * om6;
@@ -514,41 +611,44 @@ __global__ void __launch_bounds__(256) k_shade(ShadeArgs a) {
         f.specularAlpha = f.roughness; f.weightedSpecularIor = weightedSpecularIor;
         f.diffuseColor = weightedBaseColor * (1.0f - metal);
 
+        const PixelCtx ctx = make_pixel_ctx(L, f);
         f3 lighting{0.0f, 0.0f, 0.0f};
         auto shadeLight = [&](uint32_t lightIndex) {
             const brmi_light_info* l = sc.lights + lightIndex;
             const uint32_t type = l->type;
             f3 lightToFrag; float att, dist = 0.0f, spot = 1.0f;
-            const f3 lpos{l->posWorldSpace[0], l->posWorldSpace[1], l->posWorldSpace[2]};
             if (type == BRMI_LIGHT_DIRECTIONAL) { lightToFrag = -f3{l->dirWorldSpace[0], l->dirWorldSpace[1], l->dirWorldSpace[2]}; att = 1.0f; }
             else {
-                lightToFrag = normalize3(lpos - posWS);
-                dist = length3(lpos - posWS);
+                const f3 toL = f3{l->posWorldSpace[0], l->posWorldSpace[1], l->posWorldSpace[2]} - posWS;
+                dist = length3(toL);
+                if (dist > l->maxRange) return;                      // lighting.hlsli:614-617
+                lightToFrag = normalize3(toL);
                 att = 1.0f / ((l->attenuation[0] + l->attenuation[1] * dist + l->attenuation[2] * dist * dist) + 0.0001f);
             }
+            // a light at or below the horizon contributes brdf * ... * 0 = +-0 (the BRDF is finite): adding it is the identity, so skip it
+            const float NoL = sat(dot3(f.normalWS, lightToFrag));
+            if (NoL == 0.0f) return;
             if (type == BRMI_LIGHT_SPOT) {
                 const f3 ld{l->dirWorldSpace[0], l->dirWorldSpace[1], l->dirWorldSpace[2]};
-                const float c = dot3(normalize3(ld), normalize3(-lightToFrag));
-                if (c > l->outerConeAngle) {
-                    if (c < l->innerConeAngle) { const float t = sat((c - l->outerConeAngle) / (l->innerConeAngle - l->outerConeAngle)); spot = t * t * (3.0f - 2.0f * t); }
+                const float cc = dot3(normalize3(ld), normalize3(-lightToFrag));
+                if (cc > l->outerConeAngle) {
+                    if (cc < l->innerConeAngle) { const float t = sat((cc - l->outerConeAngle) / (l->innerConeAngle - l->outerConeAngle)); spot = t * t * (3.0f - 2.0f * t); }
                     else spot = 1.0f;
-                } else spot = 0.0f;
+                } else return;                                        // spot = 0: contribution is +-0
             }
-            if (type != BRMI_LIGHT_DIRECTIONAL && dist > l->maxRange) return;
-            const f3 c = light_contribution(L, f, lightToFrag, f3{l->color[0], l->color[1], l->color[2]}, l->color[3], att, spot);
-            lighting = lighting + (1.0f - 0.0f) * c;
+            const f3 c = light_contribution(L, f, ctx, lightToFrag, NoL, f3{l->color[0], l->color[1], l->color[2]}, l->color[3], att, spot);
+            lighting = lighting + c;
         };
         if (a.enablePunctual) {
             if (a.clustered) {
-                const float tsx = (float)pf->screenResX / (float)gx, tsy = (float)pf->screenResY / (float)gy;
                 const uint32_t tx = (uint32_t)((float)px / tsx), ty = (uint32_t)((float)py / tsy);
                 const float z = fabsf(posVS.z);
                 uint32_t sliceZ;
-                if (z < zSplit) { const float t = (z - zNear) / (zSplit - zNear); sliceZ = t > 0.0f ? (uint32_t)(t * (float)pf->nearClusterCount) : 0u; }
+                if (z < zSplit) { const float t = (z - zNear) / (zSplit - zNear); sliceZ = t > 0.0f ? (uint32_t)(t * (float)nearSlices) : 0u; }
                 else {
-                    const float logStart = logf(zSplit / zNear), logEnd = logf(zFar / zNear), logZ = logf(z / zNear);
+                    const float logZ = logf(z / zNear);
                     const float u = (logZ - logStart) / (logEnd - logStart);
-                    sliceZ = pf->nearClusterCount + (u > 0.0f ? (uint32_t)(u * (float)(gz - pf->nearClusterCount)) : 0u);
+                    sliceZ = nearSlices + (u > 0.0f ? (uint32_t)(u * (float)(gz - nearSlices)) : 0u);
                 }
                 const uint32_t ci = (uint32_t)((float)tx + (float)ty * (float)gx + (float)sliceZ * (float)gx * (float)gy);
                 if (ci < gx * gy * gz) {
@@ -566,14 +666,14 @@ __global__ void __launch_bounds__(256) k_shade(ShadeArgs a) {
                     }
                 }
             } else {
-                for (uint32_t k = 0; k < pf->numLights; k++) shadeLight(sc.activeLightIndices[k]);
+                for (uint32_t k = 0; k < numLights; k++) shadeLight(sc.activeLightIndices[k]);
             }
         }
-        {   // EvaluateOpenPBREmissive
-            const BaseState base = make_base_state(f);
-            const CoatState coatS = make_coat_state(base, f);
+        // EvaluateOpenPBREmissive
+        if (ctx.plain) lighting = lighting + f.emissive;
+        else {
             const float fuzzBase = 1.0f - fuzz_incoming_reflected(L, f.fuzzWeight, f.fuzzRoughness, f.NdotV);
-            const f3 coatT = coat_scale_incoming(L, coatS, f.NdotV);
+            const f3 coatT = coat_scale_incoming(L, ctx.coat, f.NdotV);
             lighting = lighting + f.emissive * f3{fuzzBase, fuzzBase, fuzzBase} * coatT;
         }
         a.hdr[i] = pack_half4(lighting.x, lighting.y, lighting.z, 1.0f);
@@ -581,13 +681,18 @@ __global__ void __launch_bounds__(256) k_shade(ShadeArgs a) {
 }
 
 int launch_light_clustering(brmi_pass* p, hipStream_t s) {
-    if (p->numLightClusters > MAX_CLUSTERS_LDS) return fail(p, BRMI_ERR_CAPACITY, "light cluster grid of %u clusters exceeds %u", p->numLightClusters, MAX_CLUSTERS_LDS);
     ClusterArgs a;
     a.sc = p->scene; a.planes = p->wsPtr<float>(p->ws.planes);
     a.clusters = static_cast<brmi_light_cluster*>(p->res[BRMI_RES_LIGHT_CLUSTERS]); a.pages = static_cast<brmi_light_page*>(p->res[BRMI_RES_LIGHT_PAGES]);
     a.poolSize = p->lightPagePool; a.counters = p->counters();
-    hipLaunchKernelGGL(k_light_clustering, dim3(1), dim3(1024), 0, s, a);
-    BRMI_LAUNCH_CHECK(p, "k_light_clustering");
+    a.lightVS = p->wsPtr<float4>(p->ws.lightVS); a.lightMeta = p->wsPtr<uint32_t>(p->ws.lightMeta); a.clusterPages = p->wsPtr<uint32_t>(p->ws.clusterPages);
+    if (p->pfHost.numLights > p->scene.lightCount) return fail(p, BRMI_ERR_INVALID, "perFrame.numLights (%u) exceeds the light buffer (%u)", p->pfHost.numLights, p->scene.lightCount);
+    const uint32_t nl = std::max(1u, p->pfHost.numLights), nc = p->numLightClusters;
+    hipLaunchKernelGGL(k_lc_lights, dim3((nl + 63) / 64), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_lc_count, dim3((nc + 63) / 64), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_lc_scan, dim3(1), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(k_lc_fill, dim3((nc + 63) / 64), dim3(64), 0, s, a);
+    BRMI_LAUNCH_CHECK(p, "light clustering");
     return BRMI_OK;
 }
 

@@ -21,7 +21,19 @@
 
 namespace brmi {
 
+// A triangle whose clamped bounding box exceeds BIG_TRI_AREA pixels is not walked by its lane: the lane
+// emits one record per 64-row chunk (carrying the exactly stepped scanline start of the chunk) and
+// k_raster_big walks those rows one lane per row.  Same arithmetic per pixel, different lane mapping.
+struct BigTriRecord {        // 64 B
+    uint32_t clusterIndex, triAndFlags;      // tri | useScanlineRanges << 8 | rowCount << 16
+    int32_t  minX, rectWidth, rowStart;
+    float    sb0, sb1, dx_b0, dx_b1, dy_b0, dy_b1, d0, d1, d2;
+    uint32_t pad0, pad1;
+};
+constexpr int BIG_TRI_AREA = 1024;
+
 struct RasterArgs {
+    BigTriRecord* bigTris; uint32_t bigTriCapacity;
     brmi_scene_buffers sc;
     const uint4* clusters;
     uint32_t* counters;
@@ -44,6 +56,38 @@ BRMI_DEV void clip_scanline(float value, float step, int& first, int& last, bool
     else if (step < 0.0f) { const int f = to_int_sat(floorf(value / -step)); last = last < f ? last : f; }
     else has = value >= 0.0f;
     has = has && first <= last;
+}
+
+// One scanline of one triangle (softwareRaster.hlsl:506-609), barycentrics at the row start given.
+BRMI_DEV void raster_row(unsigned long long* vis, uint32_t tilesX, int py, int minX, int rectWidth, bool useScanlineRanges, float sb0, float sb1,
+                         float dx_b0, float dx_b1, float dx_b2, float d0, float d1, float d2, uint32_t clusterIndex, uint32_t t) {
+    const uint32_t rowBase = (((uint32_t)py >> 3) * tilesX << 6) | (((uint32_t)py & 7u) << 3);
+    if (useScanlineRanges) {
+        const float sb2 = 1.0f - sb0 - sb1;
+        int firstOff = 0, lastOff = rectWidth - 1; bool has = true;
+        clip_scanline(sb0, dx_b0, firstOff, lastOff, has);
+        clip_scanline(sb1, dx_b1, firstOff, lastOff, has);
+        clip_scanline(sb2, dx_b2, firstOff, lastOff, has);
+        if (has) {
+            float b0 = sb0 + (float)firstOff * dx_b0, b1 = sb1 + (float)firstOff * dx_b1;
+            for (int px = minX + firstOff; px <= minX + lastOff; px++) {
+                const float b2 = 1.0f - b0 - b1;
+                const float depth = b0 * d0 + b1 * d1 + b2 * d2;
+                atomicMin(&vis[rowBase + (((uint32_t)px >> 3) << 6) + ((uint32_t)px & 7u)], (unsigned long long)pack_vis_key(depth, clusterIndex, t));
+                b0 += dx_b0; b1 += dx_b1;
+            }
+        }
+    } else {
+        float b0 = sb0, b1 = sb1;
+        for (int px = minX; px < minX + rectWidth; px++) {
+            const float b2 = 1.0f - b0 - b1;
+            if (b0 >= 0.0f && b1 >= 0.0f && b2 >= 0.0f) {
+                const float depth = b0 * d0 + b1 * d1 + b2 * d2;
+                atomicMin(&vis[rowBase + (((uint32_t)px >> 3) << 6) + ((uint32_t)px & 7u)], (unsigned long long)pack_vis_key(depth, clusterIndex, t));
+            }
+            b0 += dx_b0; b1 += dx_b1;
+        }
+    }
 }
 
 __global__ void __launch_bounds__(64) k_raster(RasterArgs a) {
@@ -144,40 +188,56 @@ __global__ void __launch_bounds__(64) k_raster(RasterArgs a) {
             if (active) {
                 const float dx_b2 = -(dx_b0 + dx_b1);
                 float sb0 = row_b0, sb1 = row_b1;
-                for (int py = minY; py <= maxY; py++) {
-                    const bool rowInBand = (uint32_t)py >= a.bandY0 && (uint32_t)py < a.bandY1;
-                    const uint32_t rowBase = (((uint32_t)py >> 3) * a.tilesX << 6) | (((uint32_t)py & 7u) << 3);
-                    if (useScanlineRanges) {
-                        const float sb2 = 1.0f - sb0 - sb1;
-                        int firstOff = 0, lastOff = rectWidth - 1; bool has = true;
-                        clip_scanline(sb0, dx_b0, firstOff, lastOff, has);
-                        clip_scanline(sb1, dx_b1, firstOff, lastOff, has);
-                        clip_scanline(sb2, dx_b2, firstOff, lastOff, has);
-                        if (has && rowInBand) {
-                            float b0 = sb0 + (float)firstOff * dx_b0, b1 = sb1 + (float)firstOff * dx_b1;
-                            for (int px = minX + firstOff; px <= minX + lastOff; px++) {
-                                const float b2 = 1.0f - b0 - b1;
-                                const float depth = b0 * d0 + b1 * d1 + b2 * d2;
-                                atomicMin(&a.vis[rowBase + (((uint32_t)px >> 3) << 6) + ((uint32_t)px & 7u)], (unsigned long long)pack_vis_key(depth, clusterIndex, t));
-                                b0 += dx_b0; b1 += dx_b1;
-                            }
+                const int rows = maxY - minY + 1;
+                int py = minY;
+                if (rows * rectWidth > BIG_TRI_AREA) {
+                    // hand the triangle to k_raster_big in chunks of 64 rows; the lane only steps the row starts
+                    while (py <= maxY) {
+                        const int n = min(64, maxY - py + 1);
+                        const bool touchesBand = (uint32_t)(py + n) > a.bandY0 && (uint32_t)py < a.bandY1;
+                        if (touchesBand) {
+                            const uint32_t slot = atomicAdd(&a.counters[CNT_BIG_TRIS], 1u);
+                            if (slot >= a.bigTriCapacity) { atomicSub(&a.counters[CNT_BIG_TRIS], 1u); break; }   // queue full: walk the rest here
+                            BigTriRecord r;
+                            r.clusterIndex = clusterIndex; r.triAndFlags = t | (useScanlineRanges ? 0x100u : 0u) | ((uint32_t)n << 16);
+                            r.minX = minX; r.rectWidth = rectWidth; r.rowStart = py;
+                            r.sb0 = sb0; r.sb1 = sb1; r.dx_b0 = dx_b0; r.dx_b1 = dx_b1; r.dy_b0 = dy_b0; r.dy_b1 = dy_b1; r.d0 = d0; r.d1 = d1; r.d2 = d2; r.pad0 = 0; r.pad1 = 0;
+                            a.bigTris[slot] = r;
                         }
-                    } else if (rowInBand) {
-                        float b0 = sb0, b1 = sb1;
-                        for (int px = minX; px <= maxX; px++) {
-                            const float b2 = 1.0f - b0 - b1;
-                            if (b0 >= 0.0f && b1 >= 0.0f && b2 >= 0.0f) {
-                                const float depth = b0 * d0 + b1 * d1 + b2 * d2;
-                                atomicMin(&a.vis[rowBase + (((uint32_t)px >> 3) << 6) + ((uint32_t)px & 7u)], (unsigned long long)pack_vis_key(depth, clusterIndex, t));
-                            }
-                            b0 += dx_b0; b1 += dx_b1;
-                        }
+                        for (int k = 0; k < n; k++) { sb0 += dy_b0; sb1 += dy_b1; }
+                        py += n;
                     }
+                }
+                for (; py <= maxY; py++) {
+                    if ((uint32_t)py >= a.bandY0 && (uint32_t)py < a.bandY1)
+                        raster_row(a.vis, a.tilesX, py, minX, rectWidth, useScanlineRanges, sb0, sb1, dx_b0, dx_b1, dx_b2, d0, d1, d2, clusterIndex, t);
                     sb0 += dy_b0; sb1 += dy_b1;
                 }
             }
         }
         __syncthreads();   // LDS is reused by the next cluster
+    }
+}
+
+// one wave per record, one lane per row: the lane steps to its row exactly as the serial loop would
+__global__ void __launch_bounds__(64) k_raster_big(RasterArgs a) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t count = min(a.counters[CNT_BIG_TRIS], a.bigTriCapacity);
+    for (;;) {
+        uint32_t ri = 0;
+        if (lane == 0) ri = atomicAdd(a.queue + 1, 1u);
+        ri = __builtin_amdgcn_readfirstlane(ri);
+        if (ri >= count) break;
+        const BigTriRecord r = a.bigTris[ri];
+        const uint32_t n = r.triAndFlags >> 16;
+        if (lane < n) {
+            float sb0 = r.sb0, sb1 = r.sb1;
+            for (uint32_t k = 0; k < lane; k++) { sb0 += r.dy_b0; sb1 += r.dy_b1; }
+            const int py = r.rowStart + (int)lane;
+            if ((uint32_t)py >= a.bandY0 && (uint32_t)py < a.bandY1)
+                raster_row(a.vis, a.tilesX, py, r.minX, r.rectWidth, (r.triAndFlags & 0x100u) != 0, sb0, sb1, r.dx_b0, r.dx_b1, -(r.dx_b0 + r.dx_b1), r.d0, r.d1, r.d2,
+                           r.clusterIndex, r.triAndFlags & 0x7Fu);
+        }
     }
 }
 
@@ -203,9 +263,12 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
     a.queue = p->counters() + CNT_WORDS;   // one spare word after the counters block
     a.vis = static_cast<unsigned long long*>(p->res[BRMI_RES_VISIBILITY]);
     a.visW = p->cfg.width; a.visH = p->cfg.height; a.tilesX = p->tilesX; a.bandY0 = p->bandY0; a.bandY1 = p->bandY1;
-    BRMI_HIP(p, hipMemsetAsync(a.queue, 0, 4, s));
+    a.bigTris = p->wsPtr<BigTriRecord>(p->ws.bigTris); a.bigTriCapacity = p->bigTriCapacity;
+    BRMI_HIP(p, hipMemsetAsync(a.queue, 0, 8, s));
     hipLaunchKernelGGL(k_raster, dim3(256 * 16), dim3(64), 0, s, a);
     BRMI_LAUNCH_CHECK(p, "k_raster");
+    hipLaunchKernelGGL(k_raster_big, dim3(256 * 16), dim3(64), 0, s, a);
+    BRMI_LAUNCH_CHECK(p, "k_raster_big");
     return BRMI_OK;
 }
 
