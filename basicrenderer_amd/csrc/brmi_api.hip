@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "brmi_device.h"
@@ -87,6 +88,9 @@ static void compute_sizes(brmi_pass* p) {
     w.lightMeta = take((uint64_t)std::max(1u, p->scene.lightCount) * 4);
     w.clusterPages = take((uint64_t)p->numLightClusters * 4);
     w.bigTris = take((uint64_t)p->bigTriCapacity * 64);
+    w.frameConst = take(3 * 64);
+    w.objConst = take((uint64_t)std::max(1u, p->scene.perObjectCount) * 36 * 4);
+    w.lutF = take((uint64_t)(32768 + 1024 + 1024 + 32 + 256) * 4);
     w.total = off;
     p->resNeed[BRMI_RES_WORKSPACE] = w.total;
 }
@@ -132,6 +136,7 @@ int brmi_create(const brmi_config* cfg, brmi_pass** out) {
     p->cfg = *cfg;
     if (p->cfg.enableOcclusionCulling) { p->err = "enableOcclusionCulling: the phase-2 HZB chain is not built yet; running single-phase"; p->cfg.enableOcclusionCulling = 0; }
     p->totalWords = 1; p->scanBlocks = 1;
+    if (const char* e = std::getenv("BRMI_RASTER_MODE")) p->rasterMode = std::atoi(e);
     compute_sizes(p);
     *out = p;
     return BRMI_OK;
@@ -237,6 +242,7 @@ int brmi_setup(brmi_pass* p, const brmi_resource_binding* b, uint32_t n, brmi_st
     BRMI_HIP(p, hipMemsetAsync(p->res[BRMI_RES_WORKSPACE], 0, p->ws.total, s));
     if (!p->hostInstanceBitBase.empty()) BRMI_HIP(p, hipMemcpyAsync(p->wsPtr<uint32_t>(p->ws.instanceBitBase), p->hostInstanceBitBase.data(), p->hostInstanceBitBase.size() * 4, hipMemcpyHostToDevice, s));
     if (!p->hostSegPrefix.empty()) BRMI_HIP(p, hipMemcpyAsync(p->wsPtr<uint32_t>(p->ws.segPrefix), p->hostSegPrefix.data(), p->hostSegPrefix.size() * 4, hipMemcpyHostToDevice, s));
+    { int rc = launch_expand_luts(p, s); if (rc) return rc; }
     BRMI_HIP(p, hipStreamSynchronize(s));   // host vectors may be reused
     if (p->cfg.collectPassStatistics && !p->eventsCreated) {
         for (int i = 0; i < BRMI_STAGE_COUNT; i++) for (uint32_t k = 0; k < brmi_pass::kEventRing; k++) { BRMI_HIP(p, hipEventCreate(&p->evStart[i][k])); BRMI_HIP(p, hipEventCreate(&p->evStop[i][k])); }

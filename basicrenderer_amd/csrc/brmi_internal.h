@@ -45,7 +45,7 @@ struct TempVisible { uint4 packed; uint32_t bit, pad0, pad1, pad2; };           
 
 struct Workspace {     // byte offsets into BRMI_RES_WORKSPACE
     uint64_t counters, frontierA, frontierB, buckets, tempVisible, bitmask1, bitmask2, wordPrefix, blockSums,
-             instanceBitBase, segPrefix, planes, replayNodes, replayBuckets, lightVS, lightMeta, clusterPages, bigTris, total;
+             instanceBitBase, segPrefix, planes, replayNodes, replayBuckets, lightVS, lightMeta, clusterPages, bigTris, lutF, frameConst, objConst, total;
 };
 
 }  // namespace brmi
@@ -66,6 +66,7 @@ struct brmi_pass {
     uint64_t totalBits = 0; uint32_t totalWords = 0, scanBlocks = 0;
     uint32_t numLightClusters = 0, lightPagePool = 0;
     uint32_t bigTriCapacity = 1u << 18;
+    int rasterMode = 0;          // BRMI_RASTER_MODE: 0 atomic min (product), 3 read-then-atomic; 1/2 are bandwidth experiments
     uint32_t hzbMipCount = 0; std::vector<uint64_t> hzbMipOffsets; std::vector<uint32_t> hzbMipW, hzbMipH;
     std::vector<uint32_t> hostInstanceBitBase, hostSegPrefix;
     brmi::Workspace ws{};
@@ -96,6 +97,7 @@ int launch_depth_copy(brmi_pass* p, hipStream_t s);
 int launch_hzb(brmi_pass* p, hipStream_t s);
 int launch_gbuffer(brmi_pass* p, hipStream_t s);
 int launch_light_clustering(brmi_pass* p, hipStream_t s);
+int launch_expand_luts(brmi_pass* p, hipStream_t s);
 int launch_shade(brmi_pass* p, hipStream_t s);
 
 }  // namespace brmi

@@ -68,8 +68,11 @@ __global__ void __launch_bounds__(64) k_lc_count(ClusterArgs a) {
     const brmi_camera* cam = sc.cameras + pf->mainCameraIndex;
     const uint32_t gx = pf->lightClusterGridSizeX, gy = pf->lightClusterGridSizeY, gz = pf->lightClusterGridSizeZ;
     const uint32_t total = gx * gy * gz, lightCount = pf->numLights;
-    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
+    __shared__ float4 shSphere[64];
+    __shared__ uint32_t shType[64];
+    const uint32_t idxRaw = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = idxRaw < total;
+    const uint32_t idx = valid ? idxRaw : total - 1;
     const float W = (float)pf->screenResX, H = (float)pf->screenResY;
     const m4 invProj = load_m4(&cam->projectionInverse[0][0]);
     const float tsx = W / (float)gx, tsy = H / (float)gy;
@@ -92,14 +95,22 @@ __global__ void __launch_bounds__(64) k_lc_count(ClusterArgs a) {
     }
     const f3 mn = min3v(min3v(pts[0], pts[1]), min3v(pts[2], pts[3])), mx = max3v(max3v(pts[0], pts[1]), max3v(pts[2], pts[3]));
     brmi_light_cluster* c = a.clusters + idx;
-    *reinterpret_cast<float4*>(c->minPoint) = make_float4(mn.x, mn.y, mn.z, 0.0f);
-    *reinterpret_cast<float4*>(c->maxPoint) = make_float4(mx.x, mx.y, mx.z, 0.0f);
-    uint32_t pagesNeeded = 1, inPage = 0;
-    for (uint32_t i = 0; i < lightCount; i++) {
-        if (inPage >= BRMI_LIGHTS_PER_PAGE) { pagesNeeded++; inPage = 0; }
-        if (light_hits_cluster(a.lightVS[i], a.lightMeta[i] & 3u, mn, mx)) inPage++;
+    if (valid) {
+        *reinterpret_cast<float4*>(c->minPoint) = make_float4(mn.x, mn.y, mn.z, 0.0f);
+        *reinterpret_cast<float4*>(c->maxPoint) = make_float4(mx.x, mx.y, mx.z, 0.0f);
     }
-    a.clusterPages[idx] = pagesNeeded;
+    uint32_t pagesNeeded = 1, inPage = 0;
+    for (uint32_t base = 0; base < lightCount; base += 64) {      // lights staged through LDS, 64 at a time
+        if (base + threadIdx.x < lightCount) { shSphere[threadIdx.x] = a.lightVS[base + threadIdx.x]; shType[threadIdx.x] = a.lightMeta[base + threadIdx.x] & 3u; }
+        __syncthreads();
+        const uint32_t n = min(64u, lightCount - base);
+        for (uint32_t k = 0; k < n; k++) {
+            if (inPage >= BRMI_LIGHTS_PER_PAGE) { pagesNeeded++; inPage = 0; }
+            if (light_hits_cluster(shSphere[k], shType[k], mn, mx)) inPage++;
+        }
+        __syncthreads();
+    }
+    if (valid) a.clusterPages[idx] = pagesNeeded;
 }
 
 // single workgroup: exclusive scan of the page demand in cluster order = the serial allocation order
@@ -133,41 +144,52 @@ __global__ void __launch_bounds__(1024) k_lc_scan(ClusterArgs a) {
 __global__ void __launch_bounds__(64) k_lc_fill(ClusterArgs a) {
     const brmi_per_frame* pf = a.sc.perFrame;
     const uint32_t total = pf->lightClusterGridSizeX * pf->lightClusterGridSizeY * pf->lightClusterGridSizeZ, lightCount = pf->numLights;
-    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
+    __shared__ float4 shSphere[64];
+    __shared__ uint32_t shMeta[64];
+    const uint32_t idxRaw = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = idxRaw < total;
+    const uint32_t idx = valid ? idxRaw : total - 1;
     brmi_light_cluster* c = a.clusters + idx;
     const f3 mn{c->minPoint[0], c->minPoint[1], c->minPoint[2]}, mx{c->maxPoint[0], c->maxPoint[1], c->maxPoint[2]};
     uint32_t next = a.clusterPages[idx];
     auto alloc = [&]() { const uint32_t i = next++; return i >= a.poolSize ? BRMI_LIGHT_PAGE_NULL : i; };
-    uint32_t page = alloc();
-    uint32_t numLights = 0, firstPage = page;
-    if (page != BRMI_LIGHT_PAGE_NULL) {
-        a.pages[page].ptrNextPage = BRMI_LIGHT_PAGE_NULL;
-        uint32_t inPage = 0;
-        for (uint32_t i = 0; i < lightCount; i++) {
+    uint32_t page = valid ? alloc() : BRMI_LIGHT_PAGE_NULL;
+    uint32_t numLights = 0, firstPage = page, inPage = 0;
+    bool open = page != BRMI_LIGHT_PAGE_NULL;      // false once the allocator ran dry (the reference's `break`)
+    if (open) a.pages[page].ptrNextPage = BRMI_LIGHT_PAGE_NULL;
+    for (uint32_t base = 0; base < lightCount; base += 64) {
+        if (base + threadIdx.x < lightCount) { shSphere[threadIdx.x] = a.lightVS[base + threadIdx.x]; shMeta[threadIdx.x] = a.lightMeta[base + threadIdx.x]; }
+        __syncthreads();
+        const uint32_t n = min(64u, lightCount - base);
+        for (uint32_t k = 0; k < n && open; k++) {
             if (inPage >= BRMI_LIGHTS_PER_PAGE) {
                 a.pages[page].numLightsInPage = BRMI_LIGHTS_PER_PAGE;
                 const uint32_t old = page;
                 page = alloc();
-                if (page == BRMI_LIGHT_PAGE_NULL) break;
+                if (page == BRMI_LIGHT_PAGE_NULL) { open = false; break; }
                 a.pages[page].ptrNextPage = old;
                 firstPage = page;
                 inPage = 0;
             }
-            const uint32_t meta = a.lightMeta[i];
-            if (light_hits_cluster(a.lightVS[i], meta & 3u, mn, mx)) { a.pages[page].lightIndices[inPage] = meta >> 2; inPage++; numLights++; }
+            const uint32_t meta = shMeta[k];
+            if (light_hits_cluster(shSphere[k], meta & 3u, mn, mx)) { a.pages[page].lightIndices[inPage] = meta >> 2; inPage++; numLights++; }
         }
-        if (page != BRMI_LIGHT_PAGE_NULL) a.pages[page].numLightsInPage = inPage;
+        __syncthreads();
     }
-    c->numLights = numLights; c->ptrFirstPage = firstPage; c->pad[0] = 0; c->pad[1] = 0;
+    if (valid) {
+        if (page != BRMI_LIGHT_PAGE_NULL) a.pages[page].numLightsInPage = inPage;
+        c->numLights = numLights; c->ptrFirstPage = firstPage; c->pad[0] = 0; c->pad[1] = 0;
+    }
 }
 
 // =================================== K11 =======================================================
-struct Luts { const uint16_t* odE; const uint16_t* odAvg; const uint16_t* imE; const uint16_t* imAvg; const float* ltc; };
+// The R16_UNORM tables are expanded once (k_expand_luts: texel / 65535.0f, the UNORM decode) so the
+// per-sample cost is four loads, not four correctly rounded divisions.  unorm8[] is the same for /255.
+struct Luts { const float* odE; const float* odAvg; const float* imE; const float* imAvg; const float* ltc; const float* unorm8; };
 
-BRMI_DEV float texel_u16(const uint16_t* t, uint32_t i) { return (float)t[i] / 65535.0f; }
+BRMI_DEV float texel_u16(const float* t, uint32_t i) { return t[i]; }
 BRMI_DEV uint32_t clamp_texel(float f, uint32_t n) { int i = (int)f; i = i < 0 ? 0 : i; i = i > (int)n - 1 ? (int)n - 1 : i; return (uint32_t)i; }
-BRMI_DEV float sample_u16(const uint16_t* t, uint32_t W, uint32_t H, float u, float v) {
+BRMI_DEV float sample_u16(const float* t, uint32_t W, uint32_t H, float u, float v) {
     const float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
     const float x0f = floorf(x), y0f = floorf(y);
     const float fx = x - x0f, fy = y - y0f;
@@ -521,6 +543,7 @@ struct ShadeArgs {
     unsigned long long* hdr;
     uint32_t W, H, tilesX, bandY0, bandY1; uint64_t firstPixel, pixelCount;
     uint32_t enablePunctual, clustered;
+    const float* lutF;   // expanded tables: odE[32768] odAvg[1024] imE[1024] imAvg[32] unorm8[256]
 };
 
 BRMI_DEV float half_at(unsigned long long v, int k) { return f16_bits_to_f32((uint32_t)(v >> (16 * k)) & 0xFFFFu); }
@@ -529,7 +552,7 @@ __global__ void __launch_bounds__(256) k_shade(ShadeArgs a) {
     const brmi_scene_buffers& sc = a.sc;
     const brmi_per_frame* pf = sc.perFrame;
     const brmi_camera* cam = sc.cameras + pf->mainCameraIndex;
-    const Luts L{sc.lutOpaqueDielectricEnergyComplement, sc.lutOpaqueDielectricAvgEnergyComplement, sc.lutIdealMetalEnergyComplement, sc.lutIdealMetalAvgEnergyComplement, sc.lutFuzzLTC};
+    const Luts L{a.lutF, a.lutF + 32768, a.lutF + 32768 + 1024, a.lutF + 32768 + 2048, sc.lutFuzzLTC, a.lutF + 32768 + 2048 + 32};
     const uint32_t gx = pf->lightClusterGridSizeX, gy = pf->lightClusterGridSizeY, gz = pf->lightClusterGridSizeZ;
     const m4 invProj = load_m4(&cam->projectionInverse[0][0]), viewInv = load_m4(&cam->viewInverse[0][0]);
     const f3 camPos{cam->positionWorldSpace[0], cam->positionWorldSpace[1], cam->positionWorldSpace[2]};
@@ -562,8 +585,8 @@ __global__ void __launch_bounds__(256) k_shade(ShadeArgs a) {
         const f3 nrm{ns.x, ns.y, ns.z};
         const uint32_t al = a.albedo[i], mr = a.metallicRoughness[i];
         const unsigned long long cs = a.coat[i], es = a.emissive[i], fs = a.fuzz[i];
-        const f3 baseColor{unorm8_to_f32(al), unorm8_to_f32(al >> 8), unorm8_to_f32(al >> 16)};
-        const float metal = unorm8_to_f32(mr), pr = unorm8_to_f32(mr >> 8), coatR = unorm8_to_f32(mr >> 16), fuzzW = unorm8_to_f32(mr >> 24);
+        const f3 baseColor{L.unorm8[al & 0xFFu], L.unorm8[(al >> 8) & 0xFFu], L.unorm8[(al >> 16) & 0xFFu]};
+        const float metal = L.unorm8[mr & 0xFFu], pr = L.unorm8[(mr >> 8) & 0xFFu], coatR = L.unorm8[(mr >> 16) & 0xFFu], fuzzW = L.unorm8[mr >> 24];
         const float prc = clampf(pr, BRMI_MIN_PERCEPTUAL_ROUGHNESS, 1.0f);
         f.roughness = prc * prc;
         const float NdotVraw = dot3(nrm, viewDir);
@@ -680,6 +703,23 @@ __global__ void __launch_bounds__(256) k_shade(ShadeArgs a) {
     }
 }
 
+__global__ void __launch_bounds__(256) k_expand_luts(const uint16_t* odE, const uint16_t* odAvg, const uint16_t* imE, const uint16_t* imAvg, float* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 32768u) out[i] = (float)odE[i] / 65535.0f;
+    else if (i < 32768u + 1024u) out[i] = (float)odAvg[i - 32768u] / 65535.0f;
+    else if (i < 32768u + 2048u) out[i] = (float)imE[i - 32768u - 1024u] / 65535.0f;
+    else if (i < 32768u + 2048u + 32u) out[i] = (float)imAvg[i - 32768u - 2048u] / 65535.0f;
+    else if (i < 32768u + 2048u + 32u + 256u) out[i] = (float)(i - (32768u + 2048u + 32u)) / 255.0f;
+}
+
+int launch_expand_luts(brmi_pass* p, hipStream_t s) {
+    const brmi_scene_buffers& sc = p->scene;
+    hipLaunchKernelGGL(k_expand_luts, dim3((35104 + 255) / 256), dim3(256), 0, s, sc.lutOpaqueDielectricEnergyComplement, sc.lutOpaqueDielectricAvgEnergyComplement,
+                       sc.lutIdealMetalEnergyComplement, sc.lutIdealMetalAvgEnergyComplement, p->wsPtr<float>(p->ws.lutF));
+    BRMI_LAUNCH_CHECK(p, "k_expand_luts");
+    return BRMI_OK;
+}
+
 int launch_light_clustering(brmi_pass* p, hipStream_t s) {
     ClusterArgs a;
     a.sc = p->scene; a.planes = p->wsPtr<float>(p->ws.planes);
@@ -707,6 +747,7 @@ int launch_shade(brmi_pass* p, hipStream_t s) {
     a.poolSize = p->lightPagePool; a.hdr = static_cast<unsigned long long*>(p->res[BRMI_RES_HDR_COLOR]);
     a.W = p->cfg.width; a.H = p->cfg.height; a.tilesX = p->tilesX; a.bandY0 = p->bandY0; a.bandY1 = p->bandY1; a.firstPixel = p->bandFirstPixel; a.pixelCount = p->bandPixelCount;
     a.enablePunctual = p->cfg.enablePunctualLights; a.clustered = p->cfg.enableClusteredLighting;
+    a.lutF = p->wsPtr<float>(p->ws.lutF);
     hipLaunchKernelGGL(k_shade, dim3(4096), dim3(256), 0, s, a);
     BRMI_LAUNCH_CHECK(p, "k_shade");
     return BRMI_OK;

@@ -34,6 +34,7 @@ constexpr int BIG_TRI_AREA = 1024;
 
 struct RasterArgs {
     BigTriRecord* bigTris; uint32_t bigTriCapacity;
+    const float* objConst;   // per object: MVP (16), objectToClip (16), modelViewZ (4)
     brmi_scene_buffers sc;
     const uint4* clusters;
     uint32_t* counters;
@@ -58,8 +59,20 @@ BRMI_DEV void clip_scanline(float value, float step, int& first, int& last, bool
     has = has && first <= last;
 }
 
+// Visibility write.  MODE 0 is the product path (64-bit atomic min).  MODE 3 reads the key first and skips the
+// atomic when it cannot win (the stored key only ever decreases, so a stale read is merely conservative).
+// MODEs 1 (plain store) and 2 (no write) exist for bandwidth experiments only and give wrong images.
+template <int MODE>
+BRMI_DEV void emit_key(unsigned long long* addr, unsigned long long key, unsigned long long& sink) {
+    if (MODE == 0) atomicMin(addr, key);
+    else if (MODE == 1) *addr = key;
+    else if (MODE == 2) sink ^= key;
+    else { if (key < __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(addr, key); }
+}
+
 // One scanline of one triangle (softwareRaster.hlsl:506-609), barycentrics at the row start given.
-BRMI_DEV void raster_row(unsigned long long* vis, uint32_t tilesX, int py, int minX, int rectWidth, bool useScanlineRanges, float sb0, float sb1,
+template <int MODE>
+BRMI_DEV void raster_row(unsigned long long& sink, unsigned long long* vis, uint32_t tilesX, int py, int minX, int rectWidth, bool useScanlineRanges, float sb0, float sb1,
                          float dx_b0, float dx_b1, float dx_b2, float d0, float d1, float d2, uint32_t clusterIndex, uint32_t t) {
     const uint32_t rowBase = (((uint32_t)py >> 3) * tilesX << 6) | (((uint32_t)py & 7u) << 3);
     if (useScanlineRanges) {
@@ -73,7 +86,7 @@ BRMI_DEV void raster_row(unsigned long long* vis, uint32_t tilesX, int py, int m
             for (int px = minX + firstOff; px <= minX + lastOff; px++) {
                 const float b2 = 1.0f - b0 - b1;
                 const float depth = b0 * d0 + b1 * d1 + b2 * d2;
-                atomicMin(&vis[rowBase + (((uint32_t)px >> 3) << 6) + ((uint32_t)px & 7u)], (unsigned long long)pack_vis_key(depth, clusterIndex, t));
+                emit_key<MODE>(&vis[rowBase + (((uint32_t)px >> 3) << 6) + ((uint32_t)px & 7u)], (unsigned long long)pack_vis_key(depth, clusterIndex, t), sink);
                 b0 += dx_b0; b1 += dx_b1;
             }
         }
@@ -83,14 +96,16 @@ BRMI_DEV void raster_row(unsigned long long* vis, uint32_t tilesX, int py, int m
             const float b2 = 1.0f - b0 - b1;
             if (b0 >= 0.0f && b1 >= 0.0f && b2 >= 0.0f) {
                 const float depth = b0 * d0 + b1 * d1 + b2 * d2;
-                atomicMin(&vis[rowBase + (((uint32_t)px >> 3) << 6) + ((uint32_t)px & 7u)], (unsigned long long)pack_vis_key(depth, clusterIndex, t));
+                emit_key<MODE>(&vis[rowBase + (((uint32_t)px >> 3) << 6) + ((uint32_t)px & 7u)], (unsigned long long)pack_vis_key(depth, clusterIndex, t), sink);
             }
             b0 += dx_b0; b1 += dx_b1;
         }
     }
 }
 
+template <int MODE>
 __global__ void __launch_bounds__(64) k_raster(RasterArgs a) {
+    unsigned long long sink = 0;
     __shared__ float sx[BRMI_MESHLET_MAX_VERTS], sy[BRMI_MESHLET_MAX_VERTS], sd[BRMI_MESHLET_MAX_VERTS];
     const brmi_scene_buffers& sc = a.sc;
     const uint32_t lane = threadIdx.x;
@@ -112,13 +127,12 @@ __global__ void __launch_bounds__(64) k_raster(RasterArgs a) {
         const uint32_t triCount = min(desc->triangleCountAndRefinedGroup & 0xFFFFu, BRMI_MESHLET_MAX_TRIS);
         const brmi_per_mesh_instance* meshInst = sc.perMeshInstance + instanceID;
         const brmi_per_object* obj = sc.perObject + meshInst->perObjectBufferIndex;
-        const brmi_culling_camera* cam = sc.cullingCameras + viewID;
         const brmi_view_raster_info ri = sc.viewRasterInfo[viewID];
         const float visWidth = (float)(ri.scissorMaxX - ri.scissorMinX), visHeight = (float)(ri.scissorMaxY - ri.scissorMinY);
         const float sMinXf = (float)ri.scissorMinX, sMinYf = (float)ri.scissorMinY;
-        const m4 model = load_m4(&obj->model[0][0]);
-        const m4 mvp = mul_mm(model, load_m4(&cam->viewProjection[0][0]));
-        const f4 modelViewZ = mul_mcol(model, f4{cam->viewZ[0], cam->viewZ[1], cam->viewZ[2], cam->viewZ[3]});
+        const float* oc = a.objConst + (size_t)meshInst->perObjectBufferIndex * 36u;
+        const m4 mvp = load_m4(oc);
+        const f4 modelViewZ{oc[32], oc[33], oc[34], oc[35]};
         const uint32_t posFormat = hdr->compressedPositionQuantExp;
         const uint8_t* posBase = slab + pageOff + hdr->positionBitstreamOffset + desc->positionBitOffset;
         const uint8_t* triBase = slab + pageOff + hdr->triangleStreamOffset + desc->triangleByteOffset;
@@ -210,17 +224,20 @@ __global__ void __launch_bounds__(64) k_raster(RasterArgs a) {
                 }
                 for (; py <= maxY; py++) {
                     if ((uint32_t)py >= a.bandY0 && (uint32_t)py < a.bandY1)
-                        raster_row(a.vis, a.tilesX, py, minX, rectWidth, useScanlineRanges, sb0, sb1, dx_b0, dx_b1, dx_b2, d0, d1, d2, clusterIndex, t);
+                        raster_row<MODE>(sink, a.vis, a.tilesX, py, minX, rectWidth, useScanlineRanges, sb0, sb1, dx_b0, dx_b1, dx_b2, d0, d1, d2, clusterIndex, t);
                     sb0 += dy_b0; sb1 += dy_b1;
                 }
             }
         }
         __syncthreads();   // LDS is reused by the next cluster
     }
+    if (MODE == 2 && sink == 0x123456789ull) a.vis[0] = sink;
 }
 
 // one wave per record, one lane per row: the lane steps to its row exactly as the serial loop would
+template <int MODE>
 __global__ void __launch_bounds__(64) k_raster_big(RasterArgs a) {
+    unsigned long long sink = 0;
     const uint32_t lane = threadIdx.x;
     const uint32_t count = min(a.counters[CNT_BIG_TRIS], a.bigTriCapacity);
     for (;;) {
@@ -235,10 +252,11 @@ __global__ void __launch_bounds__(64) k_raster_big(RasterArgs a) {
             for (uint32_t k = 0; k < lane; k++) { sb0 += r.dy_b0; sb1 += r.dy_b1; }
             const int py = r.rowStart + (int)lane;
             if ((uint32_t)py >= a.bandY0 && (uint32_t)py < a.bandY1)
-                raster_row(a.vis, a.tilesX, py, r.minX, r.rectWidth, (r.triAndFlags & 0x100u) != 0, sb0, sb1, r.dx_b0, r.dx_b1, -(r.dx_b0 + r.dx_b1), r.d0, r.d1, r.d2,
+                raster_row<MODE>(sink, a.vis, a.tilesX, py, r.minX, r.rectWidth, (r.triAndFlags & 0x100u) != 0, sb0, sb1, r.dx_b0, r.dx_b1, -(r.dx_b0 + r.dx_b1), r.d0, r.d1, r.d2,
                            r.clusterIndex, r.triAndFlags & 0x7Fu);
         }
     }
+    if (MODE == 2 && sink == 0x123456789ull) a.vis[0] = sink;
 }
 
 // K6: linear depth from the visibility key (gbuffer.hlsl:114-161); one lane per pixel, tile order
@@ -264,11 +282,15 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
     a.vis = static_cast<unsigned long long*>(p->res[BRMI_RES_VISIBILITY]);
     a.visW = p->cfg.width; a.visH = p->cfg.height; a.tilesX = p->tilesX; a.bandY0 = p->bandY0; a.bandY1 = p->bandY1;
     a.bigTris = p->wsPtr<BigTriRecord>(p->ws.bigTris); a.bigTriCapacity = p->bigTriCapacity;
+    a.objConst = p->wsPtr<float>(p->ws.objConst);
     BRMI_HIP(p, hipMemsetAsync(a.queue, 0, 8, s));
-    hipLaunchKernelGGL(k_raster, dim3(256 * 16), dim3(64), 0, s, a);
+    switch (p->rasterMode) {
+#define BRMI_RASTER_LAUNCH(M) case M: hipLaunchKernelGGL(k_raster<M>, dim3(256 * 16), dim3(64), 0, s, a); hipLaunchKernelGGL(k_raster_big<M>, dim3(256 * 16), dim3(64), 0, s, a); break;
+        BRMI_RASTER_LAUNCH(1) BRMI_RASTER_LAUNCH(2) BRMI_RASTER_LAUNCH(3)
+        default: hipLaunchKernelGGL(k_raster<0>, dim3(256 * 16), dim3(64), 0, s, a); hipLaunchKernelGGL(k_raster_big<0>, dim3(256 * 16), dim3(64), 0, s, a); break;
+#undef BRMI_RASTER_LAUNCH
+    }
     BRMI_LAUNCH_CHECK(p, "k_raster");
-    hipLaunchKernelGGL(k_raster_big, dim3(256 * 16), dim3(64), 0, s, a);
-    BRMI_LAUNCH_CHECK(p, "k_raster_big");
     return BRMI_OK;
 }
 

@@ -26,6 +26,7 @@ struct GBufferArgs {
     uint32_t* metallicRoughness; uint32_t* motion; float* depth;
     uint32_t W, H, tilesX, bandY0, bandY1; uint64_t firstPixel, pixelCount;
     uint32_t clusterCapacity;
+    const m4* frameConst; const float* objConst;
 };
 
 struct Bary { f3 lambda; };
@@ -69,10 +70,8 @@ __global__ void __launch_bounds__(256) k_gbuffer(GBufferArgs a) {
     const brmi_camera* cam = sc.cameras + pf->mainCameraIndex;
     const uint32_t clusterCount = min(a.counters[CNT_VISIBLE] + a.counters[CNT_VISIBLE2], a.clusterCapacity);
     // view-projection products are frame constants; every lane derives them the way the shader does
-    const m4 viewM = load_m4(&cam->view[0][0]);
-    const m4 viewProj = mul_mm(viewM, load_m4(&cam->projection[0][0]));
-    const m4 unjVP = mul_mm(viewM, load_m4(&cam->unjitteredProjection[0][0]));
-    const m4 prevVP = mul_mm(load_m4(&cam->prevView[0][0]), load_m4(&cam->prevUnjitteredProjection[0][0]));
+    const m4 unjVP = a.frameConst[1], prevVP = a.frameConst[2];
+    (void)cam;
     const float winX = (float)pf->screenResX, winY = (float)pf->screenResY;
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < a.pixelCount; j += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t i = a.firstPixel + j;
@@ -110,7 +109,7 @@ __global__ void __launch_bounds__(256) k_gbuffer(GBufferArgs a) {
         const brmi_per_object* obj = sc.perObject + inst.perObjectBufferIndex;
         const brmi_material_info* mat = sc.materials + mesh->materialDataIndex;
         const m4 model = load_m4(&obj->model[0][0]);
-        const m4 objectToClip = mul_mm(model, viewProj);
+        const m4 objectToClip = load_m4(a.objConst + (size_t)inst.perObjectBufferIndex * 36u + 16u);
         const f4 clip0 = mul_point(p[0], objectToClip), clip1 = mul_point(p[1], objectToClip), clip2 = mul_point(p[2], objectToClip);
         const float uvx = ((float)px + 0.5f) / winX, uvy = ((float)py + 0.5f) / winY;
         const float ndcX = uvx * 2.0f - 1.0f, ndcY = (1.0f - uvy) * 2.0f - 1.0f;
@@ -160,6 +159,7 @@ int launch_gbuffer(brmi_pass* p, hipStream_t s) {
     a.motion = static_cast<uint32_t*>(p->res[BRMI_RES_GBUF_MOTION_VECTORS]); a.depth = static_cast<float*>(p->res[BRMI_RES_LINEAR_DEPTH]);
     a.W = p->cfg.width; a.H = p->cfg.height; a.tilesX = p->tilesX; a.bandY0 = p->bandY0; a.bandY1 = p->bandY1; a.firstPixel = p->bandFirstPixel; a.pixelCount = p->bandPixelCount;
     a.clusterCapacity = p->cfg.maxVisibleClusters;
+    a.frameConst = p->wsPtr<m4>(p->ws.frameConst); a.objConst = p->wsPtr<float>(p->ws.objConst);
     hipLaunchKernelGGL(k_gbuffer, dim3(4096), dim3(256), 0, s, a);
     BRMI_LAUNCH_CHECK(p, "k_gbuffer");
     return BRMI_OK;
