@@ -89,6 +89,7 @@ static void compute_sizes(brmi_pass* p) {
     w.clusterPages = take((uint64_t)p->numLightClusters * 4);
     w.bigTris = take((uint64_t)p->bigTriCapacity * 64);
     w.frameConst = take(3 * 64);
+    w.matConst = take((uint64_t)std::max(1u, p->scene.openpbrMaterialCount) * 48);
     w.objConst = take((uint64_t)std::max(1u, p->scene.perObjectCount) * 36 * 4);
     w.lutF = take((uint64_t)(32768 + 1024 + 1024 + 32 + 256) * 4);
     w.total = off;
@@ -137,6 +138,7 @@ int brmi_create(const brmi_config* cfg, brmi_pass** out) {
     if (p->cfg.enableOcclusionCulling) { p->err = "enableOcclusionCulling: the phase-2 HZB chain is not built yet; running single-phase"; p->cfg.enableOcclusionCulling = 0; }
     p->totalWords = 1; p->scanBlocks = 1;
     if (const char* e = std::getenv("BRMI_RASTER_MODE")) p->rasterMode = std::atoi(e);
+    if (const char* e = std::getenv("BRMI_BIG_TRI_AREA")) p->bigTriArea = std::max(1, std::atoi(e));
     compute_sizes(p);
     *out = p;
     return BRMI_OK;
@@ -358,7 +360,7 @@ int brmi_read_counters(brmi_pass* p, brmi_counters* out, brmi_stream stream) {
     out->visibleClusters = c[CNT_VISIBLE]; out->visibleClustersPhase2 = c[CNT_VISIBLE2];
     out->droppedRecords = c[CNT_DROPPED_RECORDS]; out->droppedClusters = c[CNT_DROPPED_CLUSTERS]; out->lightPagesUsed = c[CNT_LIGHT_PAGES];
     out->reserved[0] = c[CNT_SUM_VERTS_LO]; out->reserved[1] = c[CNT_SUM_VERTS_HI]; out->reserved[2] = c[CNT_SUM_TRIS_LO]; out->reserved[3] = c[CNT_SUM_TRIS_HI];
-    out->reserved[4] = c[CNT_RASTER_CLUSTERS];
+    out->reserved[4] = c[CNT_RASTER_CLUSTERS]; out->reserved[5] = c[CNT_BIG_TRIS];
     return BRMI_OK;
 }
 

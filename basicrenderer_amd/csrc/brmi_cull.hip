@@ -375,16 +375,40 @@ __global__ void __launch_bounds__(256) k_scan_words(const uint32_t* bitmask, uin
     }
 }
 
-__global__ void __launch_bounds__(256) k_scatter_visible(const TempVisible* temp, const uint32_t* counters, uint32_t tempCountIndex, const uint32_t* bitmask,
-                                                        const uint32_t* wordPrefix, uint4* visible, uint32_t baseIndexCounter, uint32_t capacity, uint32_t visibleCapacity) {
+// Places every survivor at its rank.  Also accumulates the vertex / triangle totals of the clusters that will be
+// rasterised (statistics for the algorithmic-byte count), one atomic per wave: a per-cluster atomic on three
+// shared words would serialise the whole rasteriser (~90 same-address atomics per microsecond).
+__global__ void __launch_bounds__(256) k_scatter_visible(const TempVisible* temp, uint32_t* counters, uint32_t tempCountIndex, const uint32_t* bitmask,
+                                                        const uint32_t* wordPrefix, uint4* visible, uint32_t baseIndexCounter, uint32_t capacity, uint32_t visibleCapacity,
+                                                        const uint8_t* const* slabs) {
     const uint32_t n = min(counters[tempCountIndex], visibleCapacity);
     const uint32_t base = baseIndexCounter == 0xFFFFFFFFu ? 0u : counters[baseIndexCounter];
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const TempVisible t = temp[i];
-        const uint32_t w = t.bit >> 5, b = t.bit & 31u;
-        const uint32_t rank = wordPrefix[w] + __popc(bitmask[w] & ((1u << b) - 1u));
-        const uint32_t dst = base + rank;
-        if (dst < capacity) visible[dst] = t.packed;
+    const uint32_t rounded = (n + 63u) & ~63u;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += gridDim.x * blockDim.x) {
+        uint32_t verts = 0, tris = 0, placed = 0;
+        if (i < n) {
+            const TempVisible t = temp[i];
+            const uint32_t w = t.bit >> 5, b = t.bit & 31u;
+            const uint32_t rank = wordPrefix[w] + __popc(bitmask[w] & ((1u << b) - 1u));
+            const uint32_t dst = base + rank;
+            if (dst < capacity) {
+                visible[dst] = t.packed;
+                const uint8_t* slab = slabs[vc_slab(t.packed)];
+                const uint32_t pageOff = vc_page_offset(t.packed);
+                const brmi_page_header* hdr = reinterpret_cast<const brmi_page_header*>(slab + pageOff);
+                const brmi_meshlet_descriptor* desc = reinterpret_cast<const brmi_meshlet_descriptor*>(slab + pageOff + hdr->descriptorOffset + vc_meshlet(t.packed) * 64u);
+                verts = min((desc->bitsAndVertexCount >> 24) & 0xFFu, BRMI_MESHLET_MAX_VERTS);
+                tris = min(desc->triangleCountAndRefinedGroup & 0xFFFFu, BRMI_MESHLET_MAX_TRIS);
+                placed = 1;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { verts += (uint32_t)__shfl_xor((int)verts, o); tris += (uint32_t)__shfl_xor((int)tris, o); placed += (uint32_t)__shfl_xor((int)placed, o); }
+        if ((threadIdx.x & 63u) == 0 && placed != 0) {
+            atomicAdd(reinterpret_cast<unsigned long long*>(&counters[CNT_SUM_VERTS_LO]), (unsigned long long)verts);
+            atomicAdd(reinterpret_cast<unsigned long long*>(&counters[CNT_SUM_TRIS_LO]), (unsigned long long)tris);
+            atomicAdd(&counters[CNT_RASTER_CLUSTERS], placed);
+        }
     }
 }
 
@@ -430,7 +454,7 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, blockSums, p->scanBlocks, p->counters(), (uint32_t)CNT_VISIBLE, p->cfg.maxVisibleClusters);
     hipLaunchKernelGGL(k_scan_words, dim3(p->scanBlocks), dim3(256), 0, s, bitmask, p->totalWords, blockSums, wordPrefix);
     hipLaunchKernelGGL(k_scatter_visible, dim3(maxBlocks), dim3(256), 0, s, temp, p->counters(), (uint32_t)CNT_TEMP_VISIBLE, bitmask, wordPrefix,
-                       static_cast<uint4*>(p->res[BRMI_RES_VISIBLE_CLUSTERS]), 0xFFFFFFFFu, p->cfg.maxVisibleClusters, p->cfg.maxVisibleClusters);
+                       static_cast<uint4*>(p->res[BRMI_RES_VISIBLE_CLUSTERS]), 0xFFFFFFFFu, p->cfg.maxVisibleClusters, p->cfg.maxVisibleClusters, p->scene.slabs);
     BRMI_LAUNCH_CHECK(p, "compaction");
     return BRMI_OK;
 }

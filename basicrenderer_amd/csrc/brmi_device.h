@@ -135,8 +135,8 @@ BRMI_DEV uint4 pack_visible_cluster(uint32_t view, uint32_t inst, uint32_t meshl
                       ((group >> 18) & 0x3u) | ((slab & 0xFFFFFu) << 2) | ((page & 0x3FFu) << 22), 0x1Fu);
 }
 
-// tiled 8x8 surface addressing: element index of pixel (x, y)
-BRMI_DEV uint32_t tiled_index(uint32_t x, uint32_t y, uint32_t tilesX) { return (((y >> 3) * tilesX + (x >> 3)) << 6) | ((y & 7u) << 3) | (x & 7u); }
+// tiled 8x8 surface addressing, column-major inside the tile: element index of pixel (x, y)
+BRMI_DEV uint32_t tiled_index(uint32_t x, uint32_t y, uint32_t tilesX) { return (((y >> 3) * tilesX + (x >> 3)) << 6) | ((x & 7u) << 3) | (y & 7u); }
 
 // wave64 helpers
 BRMI_DEV uint32_t lane_id() { return __lane_id(); }

@@ -30,7 +30,8 @@ enum CounterIndex : uint32_t {
     CNT_SUM_VERTS_LO, CNT_SUM_VERTS_HI,     // sum of vertex counts of rasterised clusters (u64)
     CNT_SUM_TRIS_LO, CNT_SUM_TRIS_HI,
     CNT_RASTER_CLUSTERS,
-    CNT_BIG_TRIS,             // records in the big-triangle queue
+    CNT_BIG_TRIS,             // narrow records in the big-triangle queue (bottom-up)
+    CNT_BIG_TRIS_WIDE,        // wide records (top-down)
     CNT_FRONTIER0 = 32,       // frontier sizes per BFS level: [CNT_FRONTIER0 + level]
     CNT_WORDS = 32 + 72
 };
@@ -45,7 +46,7 @@ struct TempVisible { uint4 packed; uint32_t bit, pad0, pad1, pad2; };           
 
 struct Workspace {     // byte offsets into BRMI_RES_WORKSPACE
     uint64_t counters, frontierA, frontierB, buckets, tempVisible, bitmask1, bitmask2, wordPrefix, blockSums,
-             instanceBitBase, segPrefix, planes, replayNodes, replayBuckets, lightVS, lightMeta, clusterPages, bigTris, lutF, frameConst, objConst, total;
+             instanceBitBase, segPrefix, planes, replayNodes, replayBuckets, lightVS, lightMeta, clusterPages, bigTris, lutF, frameConst, objConst, matConst, total;
 };
 
 }  // namespace brmi
@@ -65,7 +66,8 @@ struct brmi_pass {
     uint32_t maxLevels = 1;
     uint64_t totalBits = 0; uint32_t totalWords = 0, scanBlocks = 0;
     uint32_t numLightClusters = 0, lightPagePool = 0;
-    uint32_t bigTriCapacity = 1u << 18;
+    uint32_t bigTriCapacity = 1u << 20;
+    int bigTriArea = 128;
     int rasterMode = 0;          // BRMI_RASTER_MODE: 0 atomic min (product), 3 read-then-atomic; 1/2 are bandwidth experiments
     uint32_t hzbMipCount = 0; std::vector<uint64_t> hzbMipOffsets; std::vector<uint32_t> hzbMipW, hzbMipH;
     std::vector<uint32_t> hostInstanceBitBase, hostSegPrefix;

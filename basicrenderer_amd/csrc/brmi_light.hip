@@ -310,6 +310,36 @@ BRMI_DEV f3 lut_fuzz_ltc(const Luts& L, float roughness, float cosT) {
     const float u = sat(cosT) * (31.0f / 32.0f) + 0.5f / 32.0f, v = sat(roughness) * (31.0f / 32.0f) + 0.5f / 32.0f;
     return sample_ltc(L.ltc, u, v);
 }
+// Bilinear fetch with the row (v) part prepared once: identical arithmetic to sample_u16, split in two.
+struct LutRows { const float* r0; const float* r1; float fy; };
+BRMI_DEV LutRows prep_rows(const float* t, uint32_t H, float v) {
+    const float y = v * (float)H - 0.5f;
+    const float y0f = floorf(y);
+    return LutRows{t + clamp_texel(y0f, H) * 32u, t + clamp_texel(y0f + 1.0f, H) * 32u, y - y0f};
+}
+BRMI_DEV float sample_rows(const LutRows& r, float u) {
+    const float x = u * 32.0f - 0.5f;
+    const float x0f = floorf(x);
+    const float fx = x - x0f;
+    const uint32_t x0 = clamp_texel(x0f, 32), x1 = clamp_texel(x0f + 1.0f, 32);
+    return lerpf(lerpf(r.r0[x0], r.r0[x1], fx), lerpf(r.r1[x0], r.r1[x1], fx), r.fy);
+}
+// lut_od_e with (ior, alpha) prepared
+struct OdPrep { LutRows s0, s1; float st, ior; };
+BRMI_DEV OdPrep prep_od_e(const Luts& L, float ior, float alpha) {
+    const float ei = clamp_index(ior_to_index(ior)), ea = clamp_index(alpha_to_index(alpha));
+    const int s0 = (int)floorf(ei);
+    const int s1 = (s0 + 1) < 31 ? (s0 + 1) : 31;
+    const float v = remap_index(ea);
+    return OdPrep{prep_rows(L.odE + (size_t)s0 * 1024u, 32, v), prep_rows(L.odE + (size_t)s1 * 1024u, 32, v), ei - (float)s0, ior};
+}
+BRMI_DEV float sample_od_e(const OdPrep& p, float cosT) {
+    const float u = remap_index(clamp_index(cos_to_index(cosT)));
+    return extrapolate_ior(lerpf(sample_rows(p.s0, u), sample_rows(p.s1, u), p.st), p.ior);
+}
+BRMI_DEV LutRows prep_im_e(const Luts& L, float alpha) { return prep_rows(L.imE, 32, remap_index(clamp_index(alpha_to_index(alpha)))); }
+BRMI_DEV float sample_im_e(const LutRows& r, float cosT) { return sample_rows(r, remap_index(clamp_index(cos_to_index(cosT)))); }
+
 BRMI_DEV float average_fresnel(float eta) {
     const float s = max2(eta, 1.0e-4f);
     if (s > 1.0f) return (s - 1.0f) / (4.08567f + 1.00071f * s);
@@ -449,6 +479,7 @@ struct PixelCtx {
     f3 dielComp;
     float f90Diel, f90Metal;
     f3 eonSinglePre, eonMsPre; float eonEInTerm, eonDen;
+    OdPrep od; LutRows im;
 };
 
 BRMI_DEV PixelCtx make_pixel_ctx(const Luts& L, const Frag& f) {
@@ -463,10 +494,12 @@ BRMI_DEV PixelCtx make_pixel_ctx(const Luts& L, const Frag& f) {
         c.coatComp = ggx_energy_compensation(c.NoV, f.coatRoughness, f.coatF0);
     }
     const BaseState& b = c.base;
-    const float viewComp = lut_od_e(L, b.weightedSpecularIor, b.specularAlpha, sat(c.NoV));
+    c.od = prep_od_e(L, b.weightedSpecularIor, b.specularAlpha);
+    c.im = prep_im_e(L, b.specularAlpha);
+    const float viewComp = sample_od_e(c.od, sat(c.NoV));
     const float avgComp = lut_od_avg(L, b.weightedSpecularIor, b.specularAlpha);
     c.cachedView = max2(0.0f, viewComp / max2(avgComp, 1.0e-12f));
-    c.mView = lut_im_e(L, b.specularAlpha, c.NoV);
+    c.mView = sample_im_e(c.im, c.NoV);
     c.mAvgClamped = max2(lut_im_avg(L, b.specularAlpha), 1.0e-12f);
     c.dielComp = ggx_energy_compensation(c.NoV, b.specularAlpha, b.dielectricSpecularF0);
     const float tmp = 50.0f * 0.33f;
@@ -492,7 +525,7 @@ BRMI_DEV f3 light_contribution(const Luts& L, const Frag& f, const PixelCtx& c, 
     const float NoH = sat(dot3(f.normalWS, h)), LoH = sat(dot3(lightToFrag, h));
     const float VdotL = dot3(f.viewWS, lightToFrag);
     // diffuse: EON x dielectric energy compensation
-    const float lightComp = lut_od_e(L, base.weightedSpecularIor, base.specularAlpha, sat(NoL));
+    const float lightComp = sample_od_e(c.od, sat(NoL));
     const float diffuseEnergyComp = max2(0.0f, c.cachedView * lightComp);
     f3 diffuse;
     {
@@ -510,7 +543,7 @@ BRMI_DEV f3 light_contribution(const Luts& L, const Frag& f, const PixelCtx& c, 
     const float pw = __builtin_amdgcn_exp2f(5.0f * __builtin_amdgcn_logf(1.0f - LoH));   // pow(1 - LoH, 5) = exp2(5 log2 x), as DXC lowers it
     const f3 Fd = base.dielectricSpecularF0 + (f3{c.f90Diel, c.f90Diel, c.f90Diel} - base.dielectricSpecularF0) * pw;
     const f3 Fm = base.metalSpecularF0 + (f3{c.f90Metal, c.f90Metal, c.f90Metal} - base.metalSpecularF0) * pw;
-    const float mLight = lut_im_e(L, base.specularAlpha, NoL);
+    const float mLight = sample_im_e(c.im, NoL);
     const float mTab = c.mView * mLight / c.mAvgClamped;
     const float mScale = min2(mTab, rcpf(max2(NoL, 1.0e-4f))) * (1.0f / PI_F);
     const f3 dielSpec = base.dielectricSpecularWeight * (DV * Fd) * c.dielComp;
@@ -535,6 +568,27 @@ BRMI_DEV f3 light_contribution(const Luts& L, const Frag& f, const PixelCtx& c, 
     return brdf * lightColor * intensity * attenuation * spotAtt * NoL;
 }
 
+// Per-material part of PopulateFragmentInfoFromOpenPBR (utilities.hlsli:2590-2637): depends only on the
+// OpenPBR material record, so it is evaluated once per material per frame instead of once per pixel.
+struct MatConst { float baseWeight, specularWeight, specR, specG, specB, weightedSpecularIor, dielF0Scalar, coatF0Scalar, coatIor, coatDarkening, baseDiffuseRoughness, pad; };
+__global__ void __launch_bounds__(64) k_material_constants(brmi_scene_buffers sc, MatConst* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= sc.openpbrMaterialCount) return;
+    const brmi_openpbr_material_info* op = sc.openpbrMaterials + i;
+    MatConst m;
+    m.baseWeight = sat(op->baseWeight); m.specularWeight = sat(op->specularWeight);
+    m.specR = sat(op->specularColor[0]); m.specG = sat(op->specularColor[1]); m.specB = sat(op->specularColor[2]);
+    const float unscaledF0 = ior_to_f0(op->specularIor);
+    const float scaledF0 = min2(unscaledF0 * sat(m.specularWeight), 0.9999f);
+    const float safeF0 = min2(sat(scaledF0), 0.9999f);
+    const float sq = sqrtf(safeF0);
+    m.weightedSpecularIor = (1.0f + sq) / max2(1.0f - sq, 1.0e-4f);
+    m.dielF0Scalar = ior_to_f0(m.weightedSpecularIor);
+    m.coatF0Scalar = ior_to_f0(op->coatIor);
+    m.coatIor = op->coatIor; m.coatDarkening = sat(op->coatDarkening); m.baseDiffuseRoughness = sat(op->baseDiffuseRoughness); m.pad = 0.0f;
+    out[i] = m;
+}
+
 struct ShadeArgs {
     brmi_scene_buffers sc;
     const float* depth; const float4* normals; const uint32_t* albedo; const unsigned long long* coat; const unsigned long long* emissive;
@@ -544,6 +598,7 @@ struct ShadeArgs {
     uint32_t W, H, tilesX, bandY0, bandY1; uint64_t firstPixel, pixelCount;
     uint32_t enablePunctual, clustered;
     const float* lutF;   // expanded tables: odE[32768] odAvg[1024] imE[1024] imAvg[32] unorm8[256]
+    const MatConst* matConst;
 };
 
 BRMI_DEV float half_at(unsigned long long v, int k) { return f16_bits_to_f32((uint32_t)(v >> (16 * k)) & 0xFFFFu); }
@@ -566,7 +621,7 @@ __global__ void __launch_bounds__(256) k_shade(ShadeArgs a) {
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < a.pixelCount; j += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t i = a.firstPixel + j;
         const uint32_t tile = (uint32_t)(i >> 6), within = (uint32_t)(i & 63u);
-        const uint32_t px = (tile % a.tilesX) * 8u + (within & 7u), py = (tile / a.tilesX) * 8u + (within >> 3);
+        const uint32_t px = (tile % a.tilesX) * 8u + (within >> 3), py = (tile / a.tilesX) * 8u + (within & 7u);
         if (px >= a.W || py >= a.H || py < a.bandY0 || py >= a.bandY1) continue;
         const float d = a.depth[i];
         if (as_u32(d) == BRMI_DEPTH_EMPTY_BITS) continue;
@@ -594,22 +649,14 @@ __global__ void __launch_bounds__(256) k_shade(ShadeArgs a) {
         f.NdotV = max2(BRMI_MIN_N_DOT_V, NdotVraw);
         uint32_t opIndex = (uint32_t)(ns.w + 0.5f);
         if (opIndex >= sc.openpbrMaterialCount) opIndex = 0;
-        const brmi_openpbr_material_info* op = sc.openpbrMaterials + opIndex;
-        const float baseWeight = sat(op->baseWeight), specularWeight = sat(op->specularWeight);
-        const f3 specularColor = sat3(f3{op->specularColor[0], op->specularColor[1], op->specularColor[2]});
+        const MatConst mc = a.matConst[opIndex];
+        const float baseWeight = mc.baseWeight, specularWeight = mc.specularWeight;
+        const f3 specularColor{mc.specR, mc.specG, mc.specB};
         const f3 weightedBaseColor = sat3(baseColor * baseWeight);
-        float weightedSpecularIor;
-        {
-            const float unscaledF0 = ior_to_f0(op->specularIor);
-            const float scaledF0 = min2(unscaledF0 * sat(specularWeight), 0.9999f);
-            const float safeF0 = min2(sat(scaledF0), 0.9999f);
-            const float sq = sqrtf(safeF0);
-            weightedSpecularIor = (1.0f + sq) / max2(1.0f - sq, 1.0e-4f);
-        }
-        const float dielF0Scalar = ior_to_f0(weightedSpecularIor);
-        f.dielectricSpecularF0 = sat3(specularColor * dielF0Scalar);
+        const float weightedSpecularIor = mc.weightedSpecularIor;
+        f.dielectricSpecularF0 = sat3(specularColor * mc.dielF0Scalar);
         const float coatPR = clampf(coatR, BRMI_MIN_PERCEPTUAL_ROUGHNESS, 1.0f);
-        const float coatF0Scalar = ior_to_f0(op->coatIor);
+        const float coatF0Scalar = mc.coatF0Scalar;
         f.dielectricSpecularWeight = sat(1.0f - metal);
         f.metalSpecularWeight = sat(metal * specularWeight);
         f.metalSpecularF0 = sat3(weightedBaseColor * specularColor);
@@ -628,9 +675,9 @@ __global__ void __launch_bounds__(256) k_shade(ShadeArgs a) {
         f.coatColor = sat3(f3{half_at(cs, 0), half_at(cs, 1), half_at(cs, 2)});
         f.coatRoughness = coatPR * coatPR;
         f.coatF0 = sat3(f.coatColor * coatF0Scalar);
-        f.coatIor = op->coatIor; f.coatDarkening = sat(op->coatDarkening);
+        f.coatIor = mc.coatIor; f.coatDarkening = mc.coatDarkening;
         f.fuzzWeight = sat(fuzzW); f.fuzzColor = sat3(f3{half_at(fs, 0), half_at(fs, 1), half_at(fs, 2)}); f.fuzzRoughness = sat(half_at(fs, 3));
-        f.baseDiffuseRoughness = sat(op->baseDiffuseRoughness);
+        f.baseDiffuseRoughness = mc.baseDiffuseRoughness;
         f.specularAlpha = f.roughness; f.weightedSpecularIor = weightedSpecularIor;
         f.diffuseColor = weightedBaseColor * (1.0f - metal);
 
@@ -748,6 +795,8 @@ int launch_shade(brmi_pass* p, hipStream_t s) {
     a.W = p->cfg.width; a.H = p->cfg.height; a.tilesX = p->tilesX; a.bandY0 = p->bandY0; a.bandY1 = p->bandY1; a.firstPixel = p->bandFirstPixel; a.pixelCount = p->bandPixelCount;
     a.enablePunctual = p->cfg.enablePunctualLights; a.clustered = p->cfg.enableClusteredLighting;
     a.lutF = p->wsPtr<float>(p->ws.lutF);
+    a.matConst = p->wsPtr<MatConst>(p->ws.matConst);
+    hipLaunchKernelGGL(k_material_constants, dim3((std::max(1u, p->scene.openpbrMaterialCount) + 63) / 64), dim3(64), 0, s, p->scene, p->wsPtr<MatConst>(p->ws.matConst));
     hipLaunchKernelGGL(k_shade, dim3(4096), dim3(256), 0, s, a);
     BRMI_LAUNCH_CHECK(p, "k_shade");
     return BRMI_OK;

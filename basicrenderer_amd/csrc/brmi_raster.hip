@@ -30,11 +30,13 @@ struct BigTriRecord {        // 64 B
     float    sb0, sb1, dx_b0, dx_b1, dy_b0, dy_b1, d0, d1, d2;
     uint32_t pad0, pad1;
 };
-constexpr int BIG_TRI_AREA = 1024;
+constexpr int RASTER_SEG = 256;        // longest run of pixels one lane walks in the row-parallel kernel
+constexpr int REC_ROWS = 16;           // rows per big-triangle record: k_raster_big runs four records per wave64
 
 struct RasterArgs {
     BigTriRecord* bigTris; uint32_t bigTriCapacity;
     const float* objConst;   // per object: MVP (16), objectToClip (16), modelViewZ (4)
+    int bigTriArea;          // clamped-bbox pixels above which a triangle goes to the row-parallel kernel
     brmi_scene_buffers sc;
     const uint4* clusters;
     uint32_t* counters;
@@ -71,10 +73,14 @@ BRMI_DEV void emit_key(unsigned long long* addr, unsigned long long key, unsigne
 }
 
 // One scanline of one triangle (softwareRaster.hlsl:506-609), barycentrics at the row start given.
+// `seg` >= 0 restricts the walk to the seg-th run of RASTER_SEG pixels after the row's first covered pixel;
+// the barycentrics are still stepped pixel by pixel from the row start, so every value is the one the
+// serial loop produces.  Surfaces are 8x8 tiles stored column-major inside the tile (8 vertically adjacent
+// pixels are one contiguous 64 B run: lanes that own neighbouring rows hit the same cache line).
 template <int MODE>
 BRMI_DEV void raster_row(unsigned long long& sink, unsigned long long* vis, uint32_t tilesX, int py, int minX, int rectWidth, bool useScanlineRanges, float sb0, float sb1,
-                         float dx_b0, float dx_b1, float dx_b2, float d0, float d1, float d2, uint32_t clusterIndex, uint32_t t) {
-    const uint32_t rowBase = (((uint32_t)py >> 3) * tilesX << 6) | (((uint32_t)py & 7u) << 3);
+                         float dx_b0, float dx_b1, float dx_b2, float d0, float d1, float d2, uint32_t clusterIndex, uint32_t t, int seg) {
+    const uint32_t rowBase = (((uint32_t)py >> 3) * tilesX << 6) | ((uint32_t)py & 7u);
     if (useScanlineRanges) {
         const float sb2 = 1.0f - sb0 - sb1;
         int firstOff = 0, lastOff = rectWidth - 1; bool has = true;
@@ -83,20 +89,28 @@ BRMI_DEV void raster_row(unsigned long long& sink, unsigned long long* vis, uint
         clip_scanline(sb2, dx_b2, firstOff, lastOff, has);
         if (has) {
             float b0 = sb0 + (float)firstOff * dx_b0, b1 = sb1 + (float)firstOff * dx_b1;
-            for (int px = minX + firstOff; px <= minX + lastOff; px++) {
+            int x0 = minX + firstOff, x1 = minX + lastOff;
+            if (seg >= 0) {
+                const int skip = seg * RASTER_SEG;
+                if (skip > lastOff - firstOff) return;
+                for (int k = 0; k < skip; k++) { b0 += dx_b0; b1 += dx_b1; }
+                x0 += skip; x1 = min(x1, x0 + RASTER_SEG - 1);
+            }
+            for (int px = x0; px <= x1; px++) {
                 const float b2 = 1.0f - b0 - b1;
                 const float depth = b0 * d0 + b1 * d1 + b2 * d2;
-                emit_key<MODE>(&vis[rowBase + (((uint32_t)px >> 3) << 6) + ((uint32_t)px & 7u)], (unsigned long long)pack_vis_key(depth, clusterIndex, t), sink);
+                emit_key<MODE>(&vis[rowBase + (((uint32_t)px >> 3) << 6) + (((uint32_t)px & 7u) << 3)], (unsigned long long)pack_vis_key(depth, clusterIndex, t), sink);
                 b0 += dx_b0; b1 += dx_b1;
             }
         }
     } else {
+        if (seg > 0) return;      // narrow boxes (width <= 4) are never segmented
         float b0 = sb0, b1 = sb1;
         for (int px = minX; px < minX + rectWidth; px++) {
             const float b2 = 1.0f - b0 - b1;
             if (b0 >= 0.0f && b1 >= 0.0f && b2 >= 0.0f) {
                 const float depth = b0 * d0 + b1 * d1 + b2 * d2;
-                emit_key<MODE>(&vis[rowBase + (((uint32_t)px >> 3) << 6) + ((uint32_t)px & 7u)], (unsigned long long)pack_vis_key(depth, clusterIndex, t), sink);
+                emit_key<MODE>(&vis[rowBase + (((uint32_t)px >> 3) << 6) + (((uint32_t)px & 7u) << 3)], (unsigned long long)pack_vis_key(depth, clusterIndex, t), sink);
             }
             b0 += dx_b0; b1 += dx_b1;
         }
@@ -111,11 +125,9 @@ __global__ void __launch_bounds__(64) k_raster(RasterArgs a) {
     const uint32_t lane = threadIdx.x;
     const uint32_t first = a.firstCounter == 0xFFFFFFFFu ? 0u : a.counters[a.firstCounter];
     const uint32_t count = a.counters[a.countCounter];
-    for (;;) {
-        uint32_t c = 0;
-        if (lane == 0) c = atomicAdd(a.queue, 1u);
-        c = __builtin_amdgcn_readfirstlane(c);
-        if (c >= count) break;
+    // static round-robin over clusters: a shared queue head saturates at ~90 dequeues/us (MI355X_MICROARCH.md, row
+    // "dequeue"), which is slower than the work itself once big triangles are handed off
+    for (uint32_t c = blockIdx.x; c < count; c += gridDim.x) {
         const uint32_t clusterIndex = first + c;
         const uint4 pc = a.clusters[clusterIndex];
         const uint32_t viewID = vc_view(pc), instanceID = vc_instance(pc), localMeshlet = vc_meshlet(pc);
@@ -137,11 +149,6 @@ __global__ void __launch_bounds__(64) k_raster(RasterArgs a) {
         const uint8_t* posBase = slab + pageOff + hdr->positionBitstreamOffset + desc->positionBitOffset;
         const uint8_t* triBase = slab + pageOff + hdr->triangleStreamOffset + desc->triangleByteOffset;
         const bool reverseWinding = (obj->objectFlags & BRMI_OBJECT_FLAG_REVERSE_WINDING) != 0;
-        if (lane == 0) {
-            atomicAdd(reinterpret_cast<unsigned long long*>(&a.counters[CNT_SUM_VERTS_LO]), (unsigned long long)vertCount);
-            atomicAdd(reinterpret_cast<unsigned long long*>(&a.counters[CNT_SUM_TRIS_LO]), (unsigned long long)triCount);
-            atomicAdd(&a.counters[CNT_RASTER_CLUSTERS], 1u);
-        }
 
         // vertex stage -> LDS (softwareRaster.hlsl:339-387)
         for (uint32_t v = lane; v < vertCount; v += 64) {
@@ -199,33 +206,62 @@ __global__ void __launch_bounds__(64) k_raster(RasterArgs a) {
             }
             const int rectWidth = maxX - minX + 1;
             const bool useScanlineRanges = __any(active && rectWidth > 4);
+            // classify: big triangles are handed to k_raster_big as 16-row records; records of boxes wider than
+            // RASTER_SEG go to the "wide" end of the queue (walked by a whole wave, 4 lanes per row)
+            const int rows = maxY - minY + 1;
+            bool big = active && rows * rectWidth > a.bigTriArea;
+            const bool wide = rectWidth > RASTER_SEG;
+            uint32_t nrec = 0;
+            if (big) {
+                for (int py = minY; py <= maxY; py += REC_ROWS) {
+                    const int n = min(REC_ROWS, maxY - py + 1);
+                    if ((uint32_t)(py + n) > a.bandY0 && (uint32_t)py < a.bandY1) nrec++;
+                }
+            }
+            // one reservation per wave and per queue end
+            uint32_t inclN = (big && !wide) ? nrec : 0u, inclW = (big && wide) ? nrec : 0u;
+            const uint32_t mineN = inclN, mineW = inclW;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t vn = (uint32_t)__shfl_up((int)inclN, o), vw = (uint32_t)__shfl_up((int)inclW, o);
+                if (lane >= (uint32_t)o) { inclN += vn; inclW += vw; }
+            }
+            const uint32_t totalN = (uint32_t)__shfl((int)inclN, 63), totalW = (uint32_t)__shfl((int)inclW, 63);
+            uint32_t slot = 0;
+            if (totalN + totalW != 0) {
+                uint32_t baseN = 0, baseW = 0;
+                if (lane == 0) { baseN = atomicAdd(&a.counters[CNT_BIG_TRIS], totalN); baseW = atomicAdd(&a.counters[CNT_BIG_TRIS_WIDE], totalW); }
+                baseN = (uint32_t)__shfl((int)baseN, 0); baseW = (uint32_t)__shfl((int)baseW, 0);
+                if ((uint64_t)baseN + totalN + baseW + totalW > a.bigTriCapacity) {      // queue full: give the slots back and walk everything here
+                    if (lane == 0) { atomicSub(&a.counters[CNT_BIG_TRIS], totalN); atomicSub(&a.counters[CNT_BIG_TRIS_WIDE], totalW); }
+                    big = false;
+                }
+                // narrow records grow from the bottom, wide records from the top of the same array
+                slot = wide ? (a.bigTriCapacity - 1u - (baseW + inclW - mineW)) : (baseN + inclN - mineN);
+            }
             if (active) {
                 const float dx_b2 = -(dx_b0 + dx_b1);
                 float sb0 = row_b0, sb1 = row_b1;
-                const int rows = maxY - minY + 1;
-                int py = minY;
-                if (rows * rectWidth > BIG_TRI_AREA) {
-                    // hand the triangle to k_raster_big in chunks of 64 rows; the lane only steps the row starts
-                    while (py <= maxY) {
-                        const int n = min(64, maxY - py + 1);
-                        const bool touchesBand = (uint32_t)(py + n) > a.bandY0 && (uint32_t)py < a.bandY1;
-                        if (touchesBand) {
-                            const uint32_t slot = atomicAdd(&a.counters[CNT_BIG_TRIS], 1u);
-                            if (slot >= a.bigTriCapacity) { atomicSub(&a.counters[CNT_BIG_TRIS], 1u); break; }   // queue full: walk the rest here
+                if (big) {
+                    for (int py = minY; py <= maxY; py += REC_ROWS) {
+                        const int n = min(REC_ROWS, maxY - py + 1);
+                        if ((uint32_t)(py + n) > a.bandY0 && (uint32_t)py < a.bandY1) {
                             BigTriRecord r;
-                            r.clusterIndex = clusterIndex; r.triAndFlags = t | (useScanlineRanges ? 0x100u : 0u) | ((uint32_t)n << 16);
+                            r.clusterIndex = clusterIndex;
                             r.minX = minX; r.rectWidth = rectWidth; r.rowStart = py;
                             r.sb0 = sb0; r.sb1 = sb1; r.dx_b0 = dx_b0; r.dx_b1 = dx_b1; r.dy_b0 = dy_b0; r.dy_b1 = dy_b1; r.d0 = d0; r.d1 = d1; r.d2 = d2; r.pad0 = 0; r.pad1 = 0;
+                            r.triAndFlags = t | (useScanlineRanges ? 0x100u : 0u) | ((uint32_t)n << 16);
                             a.bigTris[slot] = r;
+                            slot = wide ? slot - 1u : slot + 1u;
                         }
                         for (int k = 0; k < n; k++) { sb0 += dy_b0; sb1 += dy_b1; }
-                        py += n;
                     }
-                }
-                for (; py <= maxY; py++) {
-                    if ((uint32_t)py >= a.bandY0 && (uint32_t)py < a.bandY1)
-                        raster_row<MODE>(sink, a.vis, a.tilesX, py, minX, rectWidth, useScanlineRanges, sb0, sb1, dx_b0, dx_b1, dx_b2, d0, d1, d2, clusterIndex, t);
-                    sb0 += dy_b0; sb1 += dy_b1;
+                } else {
+                    for (int py = minY; py <= maxY; py++) {
+                        if ((uint32_t)py >= a.bandY0 && (uint32_t)py < a.bandY1)
+                            raster_row<MODE>(sink, a.vis, a.tilesX, py, minX, rectWidth, useScanlineRanges, sb0, sb1, dx_b0, dx_b1, dx_b2, d0, d1, d2, clusterIndex, t, -1);
+                        sb0 += dy_b0; sb1 += dy_b1;
+                    }
                 }
             }
         }
@@ -234,26 +270,43 @@ __global__ void __launch_bounds__(64) k_raster(RasterArgs a) {
     if (MODE == 2 && sink == 0x123456789ull) a.vis[0] = sink;
 }
 
-// one wave per record, one lane per row: the lane steps to its row exactly as the serial loop would
+// Row-parallel walk of the queued 16-row records; records are taken round-robin (no shared queue head).
+//   narrow records (box width <= RASTER_SEG): four per wave64, 16 lanes = 16 rows each;
+//   wide records: one per wave64, 4 lanes per row, lane `phase` walks pixel runs phase, phase+4, ... of RASTER_SEG.
+// Every lane steps to its row / run exactly as the serial loop would.
 template <int MODE>
 __global__ void __launch_bounds__(64) k_raster_big(RasterArgs a) {
     unsigned long long sink = 0;
-    const uint32_t lane = threadIdx.x;
-    const uint32_t count = min(a.counters[CNT_BIG_TRIS], a.bigTriCapacity);
-    for (;;) {
-        uint32_t ri = 0;
-        if (lane == 0) ri = atomicAdd(a.queue + 1, 1u);
-        ri = __builtin_amdgcn_readfirstlane(ri);
-        if (ri >= count) break;
+    const uint32_t lane = threadIdx.x, sub = lane >> 4, row = lane & 15u;
+    const uint32_t nNarrow = min(a.counters[CNT_BIG_TRIS], a.bigTriCapacity);
+    const uint32_t nWide = min(a.counters[CNT_BIG_TRIS_WIDE], a.bigTriCapacity - nNarrow);
+    for (uint32_t base = blockIdx.x * 4u; base < nNarrow; base += gridDim.x * 4u) {
+        const uint32_t ri = base + sub;
+        if (ri >= nNarrow) continue;
         const BigTriRecord r = a.bigTris[ri];
-        const uint32_t n = r.triAndFlags >> 16;
-        if (lane < n) {
+        const uint32_t n = (r.triAndFlags >> 16) & 0xFFu;
+        if (row < n) {
             float sb0 = r.sb0, sb1 = r.sb1;
-            for (uint32_t k = 0; k < lane; k++) { sb0 += r.dy_b0; sb1 += r.dy_b1; }
-            const int py = r.rowStart + (int)lane;
+            for (uint32_t k = 0; k < row; k++) { sb0 += r.dy_b0; sb1 += r.dy_b1; }
+            const int py = r.rowStart + (int)row;
             if ((uint32_t)py >= a.bandY0 && (uint32_t)py < a.bandY1)
                 raster_row<MODE>(sink, a.vis, a.tilesX, py, r.minX, r.rectWidth, (r.triAndFlags & 0x100u) != 0, sb0, sb1, r.dx_b0, r.dx_b1, -(r.dx_b0 + r.dx_b1), r.d0, r.d1, r.d2,
-                           r.clusterIndex, r.triAndFlags & 0x7Fu);
+                                 r.clusterIndex, r.triAndFlags & 0x7Fu, -1);
+        }
+    }
+    for (uint32_t wi = blockIdx.x; wi < nWide; wi += gridDim.x) {
+        const BigTriRecord r = a.bigTris[a.bigTriCapacity - 1u - wi];
+        const uint32_t n = (r.triAndFlags >> 16) & 0xFFu;
+        if (row < n) {
+            float sb0 = r.sb0, sb1 = r.sb1;
+            for (uint32_t k = 0; k < row; k++) { sb0 += r.dy_b0; sb1 += r.dy_b1; }
+            const int py = r.rowStart + (int)row;
+            if ((uint32_t)py >= a.bandY0 && (uint32_t)py < a.bandY1) {
+                const int segs = (r.rectWidth + RASTER_SEG - 1) / RASTER_SEG;
+                for (int sg = (int)sub; sg < segs; sg += 4)
+                    raster_row<MODE>(sink, a.vis, a.tilesX, py, r.minX, r.rectWidth, (r.triAndFlags & 0x100u) != 0, sb0, sb1, r.dx_b0, r.dx_b1, -(r.dx_b0 + r.dx_b1), r.d0, r.d1, r.d2,
+                                     r.clusterIndex, r.triAndFlags & 0x7Fu, sg);
+            }
         }
     }
     if (MODE == 2 && sink == 0x123456789ull) a.vis[0] = sink;
@@ -283,11 +336,11 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
     a.visW = p->cfg.width; a.visH = p->cfg.height; a.tilesX = p->tilesX; a.bandY0 = p->bandY0; a.bandY1 = p->bandY1;
     a.bigTris = p->wsPtr<BigTriRecord>(p->ws.bigTris); a.bigTriCapacity = p->bigTriCapacity;
     a.objConst = p->wsPtr<float>(p->ws.objConst);
-    BRMI_HIP(p, hipMemsetAsync(a.queue, 0, 8, s));
+    a.bigTriArea = p->bigTriArea;
     switch (p->rasterMode) {
-#define BRMI_RASTER_LAUNCH(M) case M: hipLaunchKernelGGL(k_raster<M>, dim3(256 * 16), dim3(64), 0, s, a); hipLaunchKernelGGL(k_raster_big<M>, dim3(256 * 16), dim3(64), 0, s, a); break;
+#define BRMI_RASTER_LAUNCH(M) case M: hipLaunchKernelGGL(k_raster<M>, dim3(256 * 16), dim3(64), 0, s, a); hipLaunchKernelGGL(k_raster_big<M>, dim3(256 * 32), dim3(64), 0, s, a); break;
         BRMI_RASTER_LAUNCH(1) BRMI_RASTER_LAUNCH(2) BRMI_RASTER_LAUNCH(3)
-        default: hipLaunchKernelGGL(k_raster<0>, dim3(256 * 16), dim3(64), 0, s, a); hipLaunchKernelGGL(k_raster_big<0>, dim3(256 * 16), dim3(64), 0, s, a); break;
+        default: hipLaunchKernelGGL(k_raster<0>, dim3(256 * 16), dim3(64), 0, s, a); hipLaunchKernelGGL(k_raster_big<0>, dim3(256 * 32), dim3(64), 0, s, a); break;
 #undef BRMI_RASTER_LAUNCH
     }
     BRMI_LAUNCH_CHECK(p, "k_raster");

@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(256) k_gbuffer(GBufferArgs a) {
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < a.pixelCount; j += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t i = a.firstPixel + j;
         const uint32_t tile = (uint32_t)(i >> 6), within = (uint32_t)(i & 63u);
-        const uint32_t px = (tile % a.tilesX) * 8u + (within & 7u), py = (tile / a.tilesX) * 8u + (within >> 3);
+        const uint32_t px = (tile % a.tilesX) * 8u + (within >> 3), py = (tile / a.tilesX) * 8u + (within & 7u);
         if (px >= a.W || py >= a.H || py < a.bandY0 || py >= a.bandY1) continue;
         const unsigned long long key = a.vis[i];
         if (a.depth) a.depth[i] = (key == BRMI_VIS_EMPTY) ? as_f32(BRMI_DEPTH_EMPTY_BITS) : as_f32(((uint32_t)(key >> BRMI_VIS_META_BITS)) << 1);

@@ -16,11 +16,11 @@ class BrmiError(RuntimeError):
 
 
 def detile(flat, width, height, tile=8):
-    """Tiled 8x8 storage (numpy, leading dim = padded pixels) -> linear [H, W, ...]."""
+    """Tiled 8x8 storage, column-major inside a tile (numpy, leading dim = padded pixels) -> linear [H, W, ...]."""
     tx, ty = (width + tile - 1) // tile, (height + tile - 1) // tile
     rest = flat.shape[1:]
-    a = flat.reshape((ty, tx, tile, tile) + rest)
-    a = np.moveaxis(a, 2, 1).reshape((ty * tile, tx * tile) + rest)
+    a = flat.reshape((ty, tx, tile, tile) + rest)            # [tileY, tileX, xInTile, yInTile]
+    a = np.transpose(a, (0, 3, 1, 2) + tuple(range(4, 4 + len(rest)))).reshape((ty * tile, tx * tile) + rest)
     return np.ascontiguousarray(a[:height, :width])
 
 

@@ -125,8 +125,8 @@ typedef struct brmi_resource_desc {
     uint32_t    usage;          /* brmi_usage mask */
     uint32_t    width, height;  /* logical size in pixels (0 for buffers) */
     uint32_t    bytesPerPixel;
-    uint32_t    tileW, tileH;   /* storage tiling (8x8); pixel (x,y) lives at
-                                   ((y/tileH)*tilesX + x/tileW)*tileW*tileH + (y%tileH)*tileW + x%tileW */
+    uint32_t    tileW, tileH;   /* storage tiling (8x8, column-major inside a tile); pixel (x,y) lives at
+                                   ((y/tileH)*tilesX + x/tileW)*tileW*tileH + (x%tileW)*tileH + y%tileH */
 } brmi_resource_desc;
 
 typedef void (*brmi_declare_cb)(void* user, const brmi_resource_desc* desc);
