@@ -91,6 +91,7 @@ static void compute_sizes(brmi_pass* p) {
     w.frameConst = take(3 * 64);
     w.matConst = take((uint64_t)std::max(1u, p->scene.openpbrMaterialCount) * 48);
     w.objConst = take((uint64_t)std::max(1u, p->scene.perObjectCount) * 36 * 4);
+    w.deferredPixels = take(p->bandPixelCount * 4);
     w.lutF = take((uint64_t)(32768 + 1024 + 1024 + 32 + 256) * 4);
     w.total = off;
     p->resNeed[BRMI_RES_WORKSPACE] = w.total;

@@ -32,6 +32,7 @@ enum CounterIndex : uint32_t {
     CNT_RASTER_CLUSTERS,
     CNT_BIG_TRIS,             // narrow records in the big-triangle queue (bottom-up)
     CNT_BIG_TRIS_WIDE,        // wide records (top-down)
+    CNT_DEFERRED_PIXELS,      // pixels the specialised shading kernel left to the general one
     CNT_FRONTIER0 = 32,       // frontier sizes per BFS level: [CNT_FRONTIER0 + level]
     CNT_WORDS = 32 + 72
 };
@@ -46,7 +47,7 @@ struct TempVisible { uint4 packed; uint32_t bit, pad0, pad1, pad2; };           
 
 struct Workspace {     // byte offsets into BRMI_RES_WORKSPACE
     uint64_t counters, frontierA, frontierB, buckets, tempVisible, bitmask1, bitmask2, wordPrefix, blockSums,
-             instanceBitBase, segPrefix, planes, replayNodes, replayBuckets, lightVS, lightMeta, clusterPages, bigTris, lutF, frameConst, objConst, matConst, total;
+             instanceBitBase, segPrefix, planes, replayNodes, replayBuckets, lightVS, lightMeta, clusterPages, bigTris, lutF, frameConst, objConst, matConst, deferredPixels, total;
 };
 
 }  // namespace brmi

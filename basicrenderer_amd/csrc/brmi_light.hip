@@ -207,6 +207,15 @@ BRMI_DEV f3 sample_ltc(const float* t, float u, float v) {
     return lerp3(lerp3(T(y0, x0), T(y0, x1), fx), lerp3(T(y1, x0), T(y1, x1), fx), fy);
 }
 
+// K11 is checked to 1 fp16 ULP, not bit for bit: outside the direction vectors (N, V, L, H stay on IEEE
+// division / sqrt, 1 - NoH^2 amplifies their error) the BRDF algebra uses the hardware reciprocal and
+// square root (1 ULP, what HLSL `/`, rcp and sqrt compile to on a GPU) instead of the ~11-instruction
+// correctly rounded expansions.
+BRMI_DEV float qdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+BRMI_DEV float qrcp(float b) { return __builtin_amdgcn_rcpf(b); }
+BRMI_DEV float qsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+BRMI_DEV f3 qdiv3(f3 a, f3 b) { return f3{qdiv(a.x, b.x), qdiv(a.y, b.y), qdiv(a.z, b.z)}; }
+
 // ---- PBR.hlsli
 BRMI_DEV void ggx_dir_albedo_AB(float NdotV, float alpha, float& A, float& B) {
     const float x = NdotV, y = alpha, x2 = x * x, y2 = y * y;
@@ -217,12 +226,12 @@ BRMI_DEV void ggx_dir_albedo_AB(float NdotV, float alpha, float& A, float& B) {
 #pragma unroll
     for (int i = 0; i < 4; i++)
         r[i] = c0[i] + c1[i] * x + c2[i] * y + c3[i] * x * y + c4[i] * x2 + c5[i] * y2 + c6[i] * x2 * y + c7[i] * x * y2 + c8[i] * x2 * y2;
-    A = clampf(r[0] / r[2], 0.0f, 1.0f); B = clampf(r[1] / r[3], 0.0f, 1.0f);
+    A = clampf(qdiv(r[0], r[2]), 0.0f, 1.0f); B = clampf(qdiv(r[1], r[3]), 0.0f, 1.0f);
 }
 BRMI_DEV f3 ggx_energy_compensation(float NdotV, float alpha, f3 Fss) {
     float A, B; ggx_dir_albedo_AB(NdotV, alpha, A, B);
     const float Ess = (f3{1.0f, 1.0f, 1.0f} * A + f3{1.0f, 1.0f, 1.0f} * B).x;
-    return f3{1.0f, 1.0f, 1.0f} + Fss * (1.0f - Ess) / Ess;
+    return f3{1.0f, 1.0f, 1.0f} + Fss * (1.0f - Ess) * qrcp(Ess);
 }
 BRMI_DEV f3 f_schlick(f3 f0, float f90, float VoH) {
     const float pw = powf(1.0f - VoH, 5.0f);
@@ -230,14 +239,14 @@ BRMI_DEV f3 f_schlick(f3 f0, float f90, float VoH) {
 }
 BRMI_DEV float v_smith_ggx(float roughness, float NoV, float NoL) {
     const float a2 = roughness * roughness;
-    const float lambdaV = NoL * sqrtf((NoV - a2 * NoV) * NoV + a2);
-    const float lambdaL = NoV * sqrtf((NoL - a2 * NoL) * NoL + a2);
-    return min2(0.5f / (lambdaV + lambdaL), MEDIUMP_MAX);
+    const float lambdaV = NoL * qsqrt((NoV - a2 * NoV) * NoV + a2);
+    const float lambdaL = NoV * qsqrt((NoL - a2 * NoL) * NoL + a2);
+    return min2(qdiv(0.5f, lambdaV + lambdaL), MEDIUMP_MAX);
 }
 BRMI_DEV float d_ggx(float roughness, float NoH) {
     const float oneMinus = 1.0f - NoH * NoH;
     const float aa = NoH * roughness;
-    const float k = roughness / (oneMinus + aa * aa);
+    const float k = qdiv(roughness, oneMinus + aa * aa);
     return min2(k * k * (1.0f / PI_F), MEDIUMP_MAX);
 }
 BRMI_DEV f3 specular_lobe(float roughness, f3 f0, float NoV, float NoL, float NoH, float LoH) {
@@ -259,7 +268,7 @@ BRMI_DEV float ior_to_index(float ior) {
     const float fr = (safeIor - 1.0f) * inv;
     return half + fr * halfM1;
 }
-BRMI_DEV float alpha_to_index(float alpha) { return sqrtf(sat(alpha)) * TBL_M1; }
+BRMI_DEV float alpha_to_index(float alpha) { return qsqrt(sat(alpha)) * TBL_M1; }
 BRMI_DEV float cos_to_index(float c) { return sat(c) * TBL_M1; }
 BRMI_DEV float clamp_index(float e) { return clampf(e, 0.0f, TBL_M1); }
 BRMI_DEV float remap_index(float e) { const float inv = 1.0f / TBL; const float mn = 0.5f * inv, mx = 1.0f - mn; return clampf(mn + e * inv, mn, mx); }
@@ -450,7 +459,7 @@ BRMI_DEV float fon_dir_albedo(float mu, float roughness) {
     const float m = sat(mu), mc = 1.0f - m;
     const float g1 = 0.0571085289f, g2 = 0.491881867f, g3 = -0.332181442f, g4 = 0.0714429953f;
     const float gOverPi = mc * (g1 + mc * (g2 + mc * (g3 + mc * g4)));
-    return (1.0f + roughness * gOverPi) / (1.0f + fon_a() * roughness);
+    return qdiv(1.0f + roughness * gOverPi, 1.0f + fon_a() * roughness);
 }
 BRMI_DEV f3 diffuse_eon(f3 albedo, float rough, float NdotV, float NdotL, float VdotL) {
     const float muIn = sat(NdotV), muOut = sat(NdotL);
@@ -482,12 +491,13 @@ struct PixelCtx {
     OdPrep od; LutRows im;
 };
 
+template <bool GENERAL>
 BRMI_DEV PixelCtx make_pixel_ctx(const Luts& L, const Frag& f) {
     PixelCtx c;
     c.base = make_base_state(f);
     c.NoV = sat(dot3(f.normalWS, f.viewWS));
-    c.plain = (sat(f.coatWeight) == 0.0f) && (sat(f.fuzzWeight) == 0.0f);
-    if (!c.plain) {
+    c.plain = !GENERAL || ((sat(f.coatWeight) == 0.0f) && (sat(f.fuzzWeight) == 0.0f));
+    if (GENERAL && !c.plain) {
         c.coat = make_coat_state(c.base, f);
         c.fuzz = make_fuzz_state(L, f);
         c.coatIn = coat_scale_incoming(L, c.coat, c.NoV);
@@ -498,7 +508,7 @@ BRMI_DEV PixelCtx make_pixel_ctx(const Luts& L, const Frag& f) {
     c.im = prep_im_e(L, b.specularAlpha);
     const float viewComp = sample_od_e(c.od, sat(c.NoV));
     const float avgComp = lut_od_avg(L, b.weightedSpecularIor, b.specularAlpha);
-    c.cachedView = max2(0.0f, viewComp / max2(avgComp, 1.0e-12f));
+    c.cachedView = max2(0.0f, qdiv(viewComp, max2(avgComp, 1.0e-12f)));
     c.mView = sample_im_e(c.im, c.NoV);
     c.mAvgClamped = max2(lut_im_avg(L, b.specularAlpha), 1.0e-12f);
     c.dielComp = ggx_energy_compensation(c.NoV, b.specularAlpha, b.dielectricSpecularF0);
@@ -507,17 +517,18 @@ BRMI_DEV PixelCtx make_pixel_ctx(const Luts& L, const Frag& f) {
     c.f90Metal = sat(dot3(b.metalSpecularF0, f3{tmp, tmp, tmp}));
     // OpenPBRDiffuseEON, view-only factors
     const float rough = b.baseDiffuseRoughness;
-    const float A = 1.0f / (1.0f + fon_a() * rough);
+    const float A = qrcp(1.0f + fon_a() * rough);
     c.eonSinglePre = b.diffuseColor * (1.0f / PI_F) * A;
     const float EIn = fon_dir_albedo(sat(c.NoV), rough);
     const float avgE = A * (1.0f + fon_b() * rough);
-    const f3 msAlbedo = (b.diffuseColor * b.diffuseColor) * avgE / max3v(f3{1.0f, 1.0f, 1.0f} - b.diffuseColor * (1.0f - avgE), f3{1.0e-4f, 1.0e-4f, 1.0e-4f});
+    const f3 msAlbedo = qdiv3((b.diffuseColor * b.diffuseColor) * avgE, max3v(f3{1.0f, 1.0f, 1.0f} - b.diffuseColor * (1.0f - avgE), f3{1.0e-4f, 1.0e-4f, 1.0e-4f}));
     c.eonMsPre = msAlbedo * (1.0f / PI_F);
     c.eonEInTerm = max2(1.0e-4f, 1.0f - EIn);
     c.eonDen = max2(1.0e-4f, 1.0f - avgE);
     return c;
 }
 
+template <bool GENERAL>
 BRMI_DEV f3 light_contribution(const Luts& L, const Frag& f, const PixelCtx& c, f3 lightToFrag, float NoL, f3 lightColor, float intensity, float attenuation, float spotAtt) {
     const BaseState& base = c.base;
     const float NoV = c.NoV;
@@ -532,10 +543,10 @@ BRMI_DEV f3 light_contribution(const Luts& L, const Frag& f, const PixelCtx& c, 
         const float rough = base.baseDiffuseRoughness;
         const float muIn = sat(NoV), muOut = sat(NoL);
         const float sv = VdotL - muIn * muOut;
-        const float sOverT = sv > 0.0f ? sv / max2(max2(muIn, muOut), 1.0e-4f) : sv;
+        const float sOverT = sv > 0.0f ? qdiv(sv, max2(max2(muIn, muOut), 1.0e-4f)) : sv;
         const f3 single = c.eonSinglePre * (1.0f + rough * sOverT);
         const float EOut = fon_dir_albedo(muOut, rough);
-        const float k = max2(1.0e-4f, 1.0f - EOut) * c.eonEInTerm / c.eonDen;
+        const float k = qdiv(max2(1.0e-4f, 1.0f - EOut) * c.eonEInTerm, c.eonDen);
         diffuse = (single + c.eonMsPre * f3{k, k, k}) * diffuseEnergyComp;
     }
     // specular: one D*V for both lobes (same roughness), one Schlick power
@@ -544,13 +555,13 @@ BRMI_DEV f3 light_contribution(const Luts& L, const Frag& f, const PixelCtx& c, 
     const f3 Fd = base.dielectricSpecularF0 + (f3{c.f90Diel, c.f90Diel, c.f90Diel} - base.dielectricSpecularF0) * pw;
     const f3 Fm = base.metalSpecularF0 + (f3{c.f90Metal, c.f90Metal, c.f90Metal} - base.metalSpecularF0) * pw;
     const float mLight = sample_im_e(c.im, NoL);
-    const float mTab = c.mView * mLight / c.mAvgClamped;
-    const float mScale = min2(mTab, rcpf(max2(NoL, 1.0e-4f))) * (1.0f / PI_F);
+    const float mTab = qdiv(c.mView * mLight, c.mAvgClamped);
+    const float mScale = min2(mTab, qrcp(max2(NoL, 1.0e-4f))) * (1.0f / PI_F);
     const f3 dielSpec = base.dielectricSpecularWeight * (DV * Fd) * c.dielComp;
     const f3 metalSpec = base.metalSpecularWeight * (DV * Fm + base.metalMultipleScatterScale * mScale);
     const f3 specular = dielSpec + metalSpec;
     f3 brdf;
-    if (c.plain) brdf = diffuse + specular;
+    if (!GENERAL || c.plain) brdf = diffuse + specular;
     else {
         const f3 llocal = to_local(c.fuzz, normalize3(lightToFrag));
         const float fuzzOut = (llocal.z <= 0.0f) ? 0.0f : sat(c.fuzz.presence * fuzz_dir_reflectance(L, c.fuzz.roughness, llocal.z));
@@ -599,32 +610,49 @@ struct ShadeArgs {
     uint32_t enablePunctual, clustered;
     const float* lutF;   // expanded tables: odE[32768] odAvg[1024] imE[1024] imAvg[32] unorm8[256]
     const MatConst* matConst;
+    uint32_t* counters; uint32_t* deferred;   // pixels (band-relative tiled index) left to the general kernel
 };
 
 BRMI_DEV float half_at(unsigned long long v, int k) { return f16_bits_to_f32((uint32_t)(v >> (16 * k)) & 0xFFFFu); }
 
-__global__ void __launch_bounds__(256) k_shade(ShadeArgs a) {
+// Frame constants of the shading pass (uniform; evaluated by every lane like the shader does).
+struct ShadeFrame {
+    Luts L; uint32_t gx, gy, gz, nearSlices, numLights; m4 invProj, viewInv; f3 camPos;
+    float zNear, zFar, zSplit, resX, resY, tsx, tsy, logStart, logEnd, om5, om6;
+};
+BRMI_DEV ShadeFrame make_shade_frame(const ShadeArgs& a) {
     const brmi_scene_buffers& sc = a.sc;
     const brmi_per_frame* pf = sc.perFrame;
     const brmi_camera* cam = sc.cameras + pf->mainCameraIndex;
-    const Luts L{a.lutF, a.lutF + 32768, a.lutF + 32768 + 1024, a.lutF + 32768 + 2048, sc.lutFuzzLTC, a.lutF + 32768 + 2048 + 32};
-    const uint32_t gx = pf->lightClusterGridSizeX, gy = pf->lightClusterGridSizeY, gz = pf->lightClusterGridSizeZ;
-    const m4 invProj = load_m4(&cam->projectionInverse[0][0]), viewInv = load_m4(&cam->viewInverse[0][0]);
-    const f3 camPos{cam->positionWorldSpace[0], cam->positionWorldSpace[1], cam->positionWorldSpace[2]};
-    const float zNear = cam->zNear, zFar = cam->zFar, zSplit = pf->clusterZSplitDepth;
-    const float resX = (float)pf->screenResX, resY = (float)pf->screenResY;
-    const float tsx = resX / (float)gx, tsy = resY / (float)gy;
-    const float logStart = logf(zSplit / zNear), logEnd = logf(zFar / zNear);
-    const uint32_t nearSlices = pf->nearClusterCount, numLights = pf->numLights;
+    ShadeFrame k;
+    k.L = Luts{a.lutF, a.lutF + 32768, a.lutF + 32768 + 1024, a.lutF + 32768 + 2048, sc.lutFuzzLTC, a.lutF + 32768 + 2048 + 32};
+    k.gx = pf->lightClusterGridSizeX; k.gy = pf->lightClusterGridSizeY; k.gz = pf->lightClusterGridSizeZ;
+    k.invProj = load_m4(&cam->projectionInverse[0][0]); k.viewInv = load_m4(&cam->viewInverse[0][0]);
+    k.camPos = f3{cam->positionWorldSpace[0], cam->positionWorldSpace[1], cam->positionWorldSpace[2]};
+    k.zNear = cam->zNear; k.zFar = cam->zFar; k.zSplit = pf->clusterZSplitDepth;
+    k.resX = (float)pf->screenResX; k.resY = (float)pf->screenResY;
+    k.tsx = k.resX / (float)k.gx; k.tsy = k.resY / (float)k.gy;
+    k.logStart = logf(k.zSplit / k.zNear); k.logEnd = logf(k.zFar / k.zNear);
+    k.nearSlices = pf->nearClusterCount; k.numLights = pf->numLights;
     const float om = 1.0f - 1.0f / 7.0f;
-    const float om5 = powf(om, 5.0f), om6 = powf(om, 6.0f);
-    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < a.pixelCount; j += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t i = a.firstPixel + j;
-        const uint32_t tile = (uint32_t)(i >> 6), within = (uint32_t)(i & 63u);
-        const uint32_t px = (tile % a.tilesX) * 8u + (within >> 3), py = (tile / a.tilesX) * 8u + (within & 7u);
-        if (px >= a.W || py >= a.H || py < a.bandY0 || py >= a.bandY1) continue;
+    k.om5 = powf(om, 5.0f); k.om6 = powf(om, 6.0f);
+    return k;
+}
+
+// One pixel of DeferredCSMain.  GENERAL = false is the specialisation for pixels without coat and fuzz (their
+// layer factors are exactly 1 / 0); it returns false for any other pixel, which is then shaded by the GENERAL
+// kernel from a deferred list -- the same idea as the reference's per-material-permutation pixel lists
+// (VisUtil.hlsl), applied to register pressure: the specialised kernel needs half the VGPRs.
+template <bool GENERAL>
+BRMI_DEV bool shade_pixel(const ShadeArgs& a, const ShadeFrame& k, uint64_t i, uint32_t px, uint32_t py) {
+    const brmi_scene_buffers& sc = a.sc;
+    const Luts& L = k.L;
+    const uint32_t gx = k.gx, gy = k.gy, gz = k.gz, nearSlices = k.nearSlices, numLights = k.numLights;
+    const m4& invProj = k.invProj; const m4& viewInv = k.viewInv; const f3 camPos = k.camPos;
+    const float zNear = k.zNear, zSplit = k.zSplit, resX = k.resX, resY = k.resY, tsx = k.tsx, tsy = k.tsy, logStart = k.logStart, logEnd = k.logEnd, om5 = k.om5, om6 = k.om6;
+    (void)gy;
         const float d = a.depth[i];
-        if (as_u32(d) == BRMI_DEPTH_EMPTY_BITS) continue;
+        if (as_u32(d) == BRMI_DEPTH_EMPTY_BITS) return true;
         float uvx = ((float)px + 0.5f) / resX, uvy = ((float)py + 0.5f) / resY;
         uvy = 1.0f - uvy;
         const f4 clipPos{uvx * 2.0f - 1.0f, uvy * 2.0f - 1.0f, 1.0f, 1.0f};
@@ -666,7 +694,7 @@ __global__ void __launch_bounds__(256) k_shade(ShadeArgs a) {
             const f3 wmF0b = f3{1.0f, 1.0f, 1.0f} - sat3(safeF0), wmTint = f3{1.0f, 1.0f, 1.0f} - sat3(specularColor);
             const f3 num = (sat3(safeF0) + wmF0b * om5) * wmTint;
             const float den = cosMax * om6;
-            const f3 b = num / max2(den, 1.0e-6f);
+            const f3 b = num * qrcp(max2(den, 1.0e-6f));
             f.metalAverageFresnel = sat3(safeF0 + wmF0 * (1.0f / 21.0f) - b * (1.0f / 126.0f));
         }
         f.albedo = weightedBaseColor;
@@ -681,7 +709,8 @@ __global__ void __launch_bounds__(256) k_shade(ShadeArgs a) {
         f.specularAlpha = f.roughness; f.weightedSpecularIor = weightedSpecularIor;
         f.diffuseColor = weightedBaseColor * (1.0f - metal);
 
-        const PixelCtx ctx = make_pixel_ctx(L, f);
+        if (!GENERAL && !((f.coatWeight == 0.0f) && (f.fuzzWeight == 0.0f))) return false;   // defer to the general kernel
+        const PixelCtx ctx = make_pixel_ctx<GENERAL>(L, f);
         f3 lighting{0.0f, 0.0f, 0.0f};
         auto shadeLight = [&](uint32_t lightIndex) {
             const brmi_light_info* l = sc.lights + lightIndex;
@@ -693,7 +722,7 @@ __global__ void __launch_bounds__(256) k_shade(ShadeArgs a) {
                 dist = length3(toL);
                 if (dist > l->maxRange) return;                      // lighting.hlsli:614-617
                 lightToFrag = normalize3(toL);
-                att = 1.0f / ((l->attenuation[0] + l->attenuation[1] * dist + l->attenuation[2] * dist * dist) + 0.0001f);
+                att = qrcp((l->attenuation[0] + l->attenuation[1] * dist + l->attenuation[2] * dist * dist) + 0.0001f);
             }
             // a light at or below the horizon contributes brdf * ... * 0 = +-0 (the BRDF is finite): adding it is the identity, so skip it
             const float NoL = sat(dot3(f.normalWS, lightToFrag));
@@ -706,7 +735,7 @@ __global__ void __launch_bounds__(256) k_shade(ShadeArgs a) {
                     else spot = 1.0f;
                 } else return;                                        // spot = 0: contribution is +-0
             }
-            const f3 c = light_contribution(L, f, ctx, lightToFrag, NoL, f3{l->color[0], l->color[1], l->color[2]}, l->color[3], att, spot);
+            const f3 c = light_contribution<GENERAL>(L, f, ctx, lightToFrag, NoL, f3{l->color[0], l->color[1], l->color[2]}, l->color[3], att, spot);
             lighting = lighting + c;
         };
         if (a.enablePunctual) {
@@ -740,13 +769,37 @@ __global__ void __launch_bounds__(256) k_shade(ShadeArgs a) {
             }
         }
         // EvaluateOpenPBREmissive
-        if (ctx.plain) lighting = lighting + f.emissive;
+        if (!GENERAL || ctx.plain) lighting = lighting + f.emissive;
         else {
             const float fuzzBase = 1.0f - fuzz_incoming_reflected(L, f.fuzzWeight, f.fuzzRoughness, f.NdotV);
             const f3 coatT = coat_scale_incoming(L, ctx.coat, f.NdotV);
             lighting = lighting + f.emissive * f3{fuzzBase, fuzzBase, fuzzBase} * coatT;
         }
         a.hdr[i] = pack_half4(lighting.x, lighting.y, lighting.z, 1.0f);
+        return true;
+}
+
+template <bool GENERAL>
+__global__ void __launch_bounds__(256) k_shade(ShadeArgs a) {
+    const ShadeFrame k = make_shade_frame(a);
+    if (!GENERAL) {
+        for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < ((a.pixelCount + 63ull) & ~63ull); j += (uint64_t)gridDim.x * blockDim.x) {
+            const uint64_t i = a.firstPixel + j;
+            const uint32_t tile = (uint32_t)(i >> 6), within = (uint32_t)(i & 63u);
+            const uint32_t px = (tile % a.tilesX) * 8u + (within >> 3), py = (tile / a.tilesX) * 8u + (within & 7u);
+            bool done = true;
+            if (j < a.pixelCount && px < a.W && py < a.H && py >= a.bandY0 && py < a.bandY1) done = shade_pixel<false>(a, k, i, px, py);
+            const uint32_t slot = wave_append(&a.counters[CNT_DEFERRED_PIXELS], !done);
+            if (!done) a.deferred[slot] = (uint32_t)j;
+        }
+    } else {
+        const uint32_t n = a.counters[CNT_DEFERRED_PIXELS];
+        for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
+            const uint64_t i = a.firstPixel + a.deferred[q];
+            const uint32_t tile = (uint32_t)(i >> 6), within = (uint32_t)(i & 63u);
+            const uint32_t px = (tile % a.tilesX) * 8u + (within >> 3), py = (tile / a.tilesX) * 8u + (within & 7u);
+            shade_pixel<true>(a, k, i, px, py);
+        }
     }
 }
 
@@ -797,7 +850,10 @@ int launch_shade(brmi_pass* p, hipStream_t s) {
     a.lutF = p->wsPtr<float>(p->ws.lutF);
     a.matConst = p->wsPtr<MatConst>(p->ws.matConst);
     hipLaunchKernelGGL(k_material_constants, dim3((std::max(1u, p->scene.openpbrMaterialCount) + 63) / 64), dim3(64), 0, s, p->scene, p->wsPtr<MatConst>(p->ws.matConst));
-    hipLaunchKernelGGL(k_shade, dim3(4096), dim3(256), 0, s, a);
+    a.counters = p->counters(); a.deferred = p->wsPtr<uint32_t>(p->ws.deferredPixels);
+    BRMI_HIP(p, hipMemsetAsync(&p->counters()[CNT_DEFERRED_PIXELS], 0, 4, s));
+    hipLaunchKernelGGL(k_shade<false>, dim3(4096), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_shade<true>, dim3(2048), dim3(256), 0, s, a);
     BRMI_LAUNCH_CHECK(p, "k_shade");
     return BRMI_OK;
 }

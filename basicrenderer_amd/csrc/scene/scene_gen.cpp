@@ -624,6 +624,15 @@ void addMaterials(brmi_scene& sc, Pcg32& rng, uint32_t count) {
         o.coatAnisotropyRotationCosSin[0] = 1.0f;
         o.fuzzWeight = 0.0f; o.fuzzColor[0] = o.fuzzColor[1] = o.fuzzColor[2] = 1.0f; o.fuzzRoughness = 0.5f;
         o.transmissionColor[0] = o.transmissionColor[1] = o.transmissionColor[2] = 1.0f;
+        if ((sc.params.materialFeatures & 1u) && (i % 3) == 1) {
+            o.coatWeight = rng.range(0.3f, 1.0f); o.coatRoughness = rng.range(0.0f, 0.4f); o.coatDarkening = rng.range(0.0f, 1.0f);
+            o.coatColor[0] = rng.range(0.6f, 1.0f); o.coatColor[1] = rng.range(0.6f, 1.0f); o.coatColor[2] = rng.range(0.6f, 1.0f);
+            if (i % 2) o.coatRoughness = 0.0f;
+        }
+        if ((sc.params.materialFeatures & 2u) && (i % 3) == 2) {
+            o.fuzzWeight = rng.range(0.2f, 1.0f); o.fuzzRoughness = rng.range(0.1f, 0.9f);
+            o.fuzzColor[0] = rng.range(0.3f, 1.0f); o.fuzzColor[1] = rng.range(0.3f, 1.0f); o.fuzzColor[2] = rng.range(0.3f, 1.0f);
+        }
         o.thinFilmIor = 1.4f; o.emissionLuminance = 0.0f; o.geometryOpacity = 1.0f;
         sc.openpbr.push_back(o);
     }

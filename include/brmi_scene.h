@@ -36,7 +36,8 @@ typedef struct brmi_scene_params {
     uint32_t lodLevels;           /* 0 = preset default; 1 = flat */
     float    sizeScale;           /* 1.0 = preset default triangle budget; <1 shrinks (tests) */
     uint32_t skinnedFraction1024; /* fraction (x/1024) of instances that are skinned; 0 = none */
-    uint32_t reserved[7];
+    uint32_t materialFeatures;    /* bit 0: some materials carry an OpenPBR coat, bit 1: some carry fuzz (default: neither) */
+    uint32_t reserved[6];
 } brmi_scene_params;
 
 /* Arrays a scene exposes.  Element layouts are the brmi_types.h structs. */

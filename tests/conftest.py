@@ -26,6 +26,8 @@ SCENE_CASES = {
     # name: (preset, W, H, kwargs)
     "tiny": ("tiny", 256, 144, dict(point_lights=6)),
     "tiny_lod": ("tiny", 320, 180, dict(point_lights=3, lod_levels=2)),
+    "tiny_coat_fuzz": ("tiny", 256, 144, dict(point_lights=6, material_features=3)),
+    "sponza_coat_fuzz": ("sponza", 480, 270, dict(point_lights=32, size_scale=0.15, material_features=3)),
     "sponza_small": ("sponza", 640, 360, dict(point_lights=64, size_scale=0.25)),
     "bistro_small": ("bistro", 640, 360, dict(point_lights=256, size_scale=0.08)),
 }
