@@ -9,7 +9,8 @@ LIBDIR    := basicrenderer_amd/lib
 ORCDIR    := oracle/_build
 
 # Strict IEEE arithmetic everywhere: no FMA contraction, no fast-math, correctly rounded div/sqrt.
-HIPFLAGS  := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math \
+EXTRA     ?=
+HIPFLAGS  := $(EXTRA) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math \
              -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero -Iinclude -Wall
 ORCFLAGS  := -O2 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -fopenmp -Iinclude -Wall
 SCNFLAGS  := -O2 -std=c++17 -fPIC -shared -Iinclude -Wall

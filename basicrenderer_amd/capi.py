@@ -137,7 +137,7 @@ def brmi_lib():
         # the device memory we are handed, so it must be loaded first; libbrmi.so's NEEDED libamdhip64.so.7
         # then resolves (by SONAME) to the copy already mapped instead of pulling in /opt/rocm's.
         import torch  # noqa: F401
-        path = os.path.join(LIB_DIR, "libbrmi.so")
+        path = os.environ.get("BRMI_LIB_PATH") or os.path.join(LIB_DIR, "libbrmi.so")   # override: A/B builds of the same ABI
         if not os.path.exists(path):
             raise RuntimeError(f"{path} is missing: the HIP extension must be built (make hip); there is no CPU fallback")
         lib = C.CDLL(path)

@@ -1,0 +1,45 @@
+"""Screen-tile partition of a frame over the GPUs of one node and its RCCL composition.
+
+Geometry, materials and lights are replicated; rank r owns the row band [r*Hb, (r+1)*Hb) of the frame
+(Hb a multiple of the 8-row surface tile, so a band is one contiguous byte range of every tiled surface).
+The lit HDR bands are composed with ONE all-gather (equal counts) so that every rank ends up with the
+full image -- the only data-path collective of the path.
+"""
+TILE = 8
+BAND_ROWS = 1080          # rows per rank for N > 1 (7680 x 1080 = one 4K frame worth of pixels)
+
+
+def frame_size(n_gpus):
+    """Weak scaling: every rank shades 8,294,400 pixels.  N = 1 is the 4K frame of BASELINE.json."""
+    return (3840, 2160) if n_gpus == 1 else (7680, BAND_ROWS * n_gpus)
+
+
+def band_of(rank, n_gpus, height):
+    if n_gpus == 1:
+        return (0, height)
+    rows = height // n_gpus
+    if rows % TILE or rows * n_gpus != height:
+        raise ValueError(f"height {height} does not split into {n_gpus} bands of whole 8-row tiles")
+    return (rank * rows, (rank + 1) * rows)
+
+
+def band_byte_range(band, width, bytes_per_pixel):
+    """Byte range of a row band inside a tiled (8x8) surface."""
+    tiles_x = (width + TILE - 1) // TILE
+    if band[0] % TILE or band[1] % TILE:
+        raise ValueError("band must be tile aligned")
+    row_bytes = tiles_x * TILE * TILE * bytes_per_pixel
+    return (band[0] // TILE) * row_bytes, (band[1] // TILE) * row_bytes
+
+
+def compose_bands(surface_u8, band, width, bytes_per_pixel, out=None, group=None):
+    """All-gather the caller's band of a tiled surface (flat uint8 tensor); returns the composed surface."""
+    import torch
+    import torch.distributed as dist
+    lo, hi = band_byte_range(band, width, bytes_per_pixel)
+    mine = surface_u8[lo:hi]
+    n = dist.get_world_size(group)
+    if out is None:
+        out = torch.empty((hi - lo) * n, dtype=torch.uint8, device=surface_u8.device)
+    dist.all_gather_into_tensor(out, mine, group=group)
+    return out

@@ -139,6 +139,9 @@ BRMI_DEV uint4 pack_visible_cluster(uint32_t view, uint32_t inst, uint32_t meshl
 BRMI_DEV uint32_t tiled_index(uint32_t x, uint32_t y, uint32_t tilesX) { return (((y >> 3) * tilesX + (x >> 3)) << 6) | ((x & 7u) << 3) | (y & 7u); }
 
 // wave64 helpers
+// force a wave-uniform value into an SGPR (frame constants loaded through a pointer otherwise occupy VGPRs)
+BRMI_DEV float uni(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x))); }
+BRMI_DEV m4 uni_m4(const m4& a) { m4 r; for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) r.m[i][j] = uni(a.m[i][j]); return r; }
 BRMI_DEV uint32_t lane_id() { return __lane_id(); }
 BRMI_DEV uint32_t lane_rank(uint64_t mask) { return __popcll(mask & ((1ull << lane_id()) - 1ull)); }
 // wave-aggregated append: one atomic per wave; returns the slot of this lane (valid when pred)

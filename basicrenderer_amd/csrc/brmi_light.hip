@@ -627,15 +627,16 @@ BRMI_DEV ShadeFrame make_shade_frame(const ShadeArgs& a) {
     ShadeFrame k;
     k.L = Luts{a.lutF, a.lutF + 32768, a.lutF + 32768 + 1024, a.lutF + 32768 + 2048, sc.lutFuzzLTC, a.lutF + 32768 + 2048 + 32};
     k.gx = pf->lightClusterGridSizeX; k.gy = pf->lightClusterGridSizeY; k.gz = pf->lightClusterGridSizeZ;
-    k.invProj = load_m4(&cam->projectionInverse[0][0]); k.viewInv = load_m4(&cam->viewInverse[0][0]);
-    k.camPos = f3{cam->positionWorldSpace[0], cam->positionWorldSpace[1], cam->positionWorldSpace[2]};
-    k.zNear = cam->zNear; k.zFar = cam->zFar; k.zSplit = pf->clusterZSplitDepth;
-    k.resX = (float)pf->screenResX; k.resY = (float)pf->screenResY;
+    k.invProj = uni_m4(load_m4(&cam->projectionInverse[0][0])); k.viewInv = uni_m4(load_m4(&cam->viewInverse[0][0]));
+    k.camPos = f3{uni(cam->positionWorldSpace[0]), uni(cam->positionWorldSpace[1]), uni(cam->positionWorldSpace[2])};
+    k.zNear = uni(cam->zNear); k.zFar = uni(cam->zFar); k.zSplit = uni(pf->clusterZSplitDepth);
+    k.resX = uni((float)pf->screenResX); k.resY = uni((float)pf->screenResY);
     k.tsx = k.resX / (float)k.gx; k.tsy = k.resY / (float)k.gy;
-    k.logStart = logf(k.zSplit / k.zNear); k.logEnd = logf(k.zFar / k.zNear);
+    k.tsx = uni(k.tsx); k.tsy = uni(k.tsy);
+    k.logStart = uni(logf(k.zSplit / k.zNear)); k.logEnd = uni(logf(k.zFar / k.zNear));
     k.nearSlices = pf->nearClusterCount; k.numLights = pf->numLights;
     const float om = 1.0f - 1.0f / 7.0f;
-    k.om5 = powf(om, 5.0f); k.om6 = powf(om, 6.0f);
+    k.om5 = uni(powf(om, 5.0f)); k.om6 = uni(powf(om, 6.0f));
     return k;
 }
 
@@ -779,8 +780,11 @@ BRMI_DEV bool shade_pixel(const ShadeArgs& a, const ShadeFrame& k, uint64_t i, u
         return true;
 }
 
+#ifndef BRMI_SHADE_WAVES
+#define BRMI_SHADE_WAVES 1
+#endif
 template <bool GENERAL>
-__global__ void __launch_bounds__(256) k_shade(ShadeArgs a) {
+__global__ void __launch_bounds__(256, BRMI_SHADE_WAVES) k_shade(ShadeArgs a) {
     const ShadeFrame k = make_shade_frame(a);
     if (!GENERAL) {
         for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < ((a.pixelCount + 63ull) & ~63ull); j += (uint64_t)gridDim.x * blockDim.x) {

@@ -70,9 +70,9 @@ __global__ void __launch_bounds__(256) k_gbuffer(GBufferArgs a) {
     const brmi_camera* cam = sc.cameras + pf->mainCameraIndex;
     const uint32_t clusterCount = min(a.counters[CNT_VISIBLE] + a.counters[CNT_VISIBLE2], a.clusterCapacity);
     // view-projection products are frame constants; every lane derives them the way the shader does
-    const m4 unjVP = a.frameConst[1], prevVP = a.frameConst[2];
+    const m4 unjVP = uni_m4(a.frameConst[1]), prevVP = uni_m4(a.frameConst[2]);
     (void)cam;
-    const float winX = (float)pf->screenResX, winY = (float)pf->screenResY;
+    const float winX = uni((float)pf->screenResX), winY = uni((float)pf->screenResY);
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < a.pixelCount; j += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t i = a.firstPixel + j;
         const uint32_t tile = (uint32_t)(i >> 6), within = (uint32_t)(i & 63u);

@@ -24,6 +24,18 @@ def detile(flat, width, height, tile=8):
     return np.ascontiguousarray(a[:height, :width])
 
 
+def tile(img, tile=8):
+    """Linear [H, W, ...] -> tiled 8x8 storage (column-major inside a tile), padded to whole tiles; inverse of detile."""
+    height, width = img.shape[:2]
+    tx, ty = (width + tile - 1) // tile, (height + tile - 1) // tile
+    rest = img.shape[2:]
+    pad = np.zeros((ty * tile, tx * tile) + rest, dtype=img.dtype)
+    pad[:height, :width] = img
+    a = pad.reshape((ty, tile, tx, tile) + rest)                      # [tileY, yInTile, tileX, xInTile]
+    a = np.transpose(a, (0, 2, 3, 1) + tuple(range(4, 4 + len(rest))))
+    return np.ascontiguousarray(a).reshape((ty * tx * tile * tile,) + rest)
+
+
 class VisibilityRenderer:
     """One brmi_pass (= CLodExtension + VisUtil + light clustering + deferred shading of one view)."""
 

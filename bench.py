@@ -43,7 +43,7 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    from basicrenderer_amd import Scene
+    from basicrenderer_amd import Scene, compose
     from basicrenderer_amd.renderer import VisibilityRenderer
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -58,25 +58,19 @@ def main():
     dev = torch.device(f"cuda:{local_rank}")
 
     lights = {"sponza": 64, "bistro": 256, "san_miguel": 256}[args.workload]
-    if n == 1:
-        W, H = 3840, 2160
-        band = (0, H)
-    else:
-        W, H = 7680, 1080 * n
-        band = (1080 * rank, 1080 * (rank + 1))
+    W, H = compose.frame_size(n)
+    band = compose.band_of(rank, n, H)
     scene = Scene(args.workload, W, H, point_lights=lights, directional=True)
     r = VisibilityRenderer(scene, device=dev, stats=True, band=band)
 
-    tilesX = (W + 7) // 8
-    band_bytes = ((band[1] - band[0]) // 8) * tilesX * 64 * 8
     hdr = r.hdr_tensor()
-    my_band = hdr[(band[0] // 8) * tilesX * 64 * 8:][:band_bytes]
-    composed = torch.empty(band_bytes * n, dtype=torch.uint8, device=dev) if n > 1 else None
+    lo, hi = compose.band_byte_range(band, W, 8)
+    composed = torch.empty((hi - lo) * n, dtype=torch.uint8, device=dev) if n > 1 else None
 
     def step():
         r.execute()
         if n > 1:
-            dist.all_gather_into_tensor(composed, my_band)
+            compose.compose_bands(hdr, band, W, 8, out=composed)
 
     for _ in range(args.warmup):
         step()

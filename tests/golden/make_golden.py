@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/*.npz from the CPU oracle.
+
+The reference (panthuncia/BasicRenderer) holds no golden vectors, images or known-answer tests for the
+visibility-buffer path, and neither its HLSL nor its DX12 host code can run in this
+environment, so these fixtures are outputs of OUR restatement (oracle/) on seeded procedural scenes.  They pin
+the oracle against regressions and give the GPU tests a second, frozen reference; they do not pin the oracle to
+the reference ("parity unpinned").
+
+Usage:  python tests/golden/make_golden.py        (from the repository root, after `make scene oracle`)
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+GOLDEN_CASES = {
+    # name: (preset, W, H, Scene kwargs)
+    "golden_tiny": ("tiny", 160, 90, dict(point_lights=5, seed=3)),
+    "golden_tiny_lod_coat_fuzz": ("tiny", 160, 90, dict(point_lights=4, seed=5, lod_levels=2, material_features=3)),
+    "golden_sponza": ("sponza", 192, 108, dict(point_lights=24, seed=1, size_scale=0.05)),
+}
+
+
+def render(name):
+    import orc
+    from basicrenderer_amd import Scene
+    preset, W, H, kw = GOLDEN_CASES[name]
+    sc = Scene(preset, W, H, **kw)
+    f = orc.OracleFrame(sc, threads=1).run()
+    c = f.counters
+    return dict(
+        clusters=f.clusters[: f.count].copy(), vis=f.vis, depth=f.depth.view(np.uint32), normals=f.normals.view(np.uint32), albedo=f.albedo, coat=f.coat,
+        emissive=f.emissive, fuzz=f.fuzz, mr=f.mr, motion=f.motion, hdr=f.hdr, light_clusters=f.light_clusters, light_pages=f.light_pages[: f.pages_used],
+        counters=np.array([c.instancesTested, c.instancesVisible, c.nodesVisited, c.bucketRecords, c.meshletsTested, c.visibleClusters], dtype=np.uint32))
+
+
+if __name__ == "__main__":
+    out = os.path.dirname(os.path.abspath(__file__))
+    for name in GOLDEN_CASES:
+        data = render(name)
+        path = os.path.join(out, name + ".npz")
+        np.savez_compressed(path, **data)
+        print(name, os.path.getsize(path), "bytes;", int((data["vis"] != np.uint64(0xFFFFFFFFFFFFFFFF)).sum()), "covered px;", len(data["clusters"]), "clusters")

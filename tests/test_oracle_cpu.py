@@ -1,0 +1,250 @@
+"""CPU suite (`-m "not gpu"`): the oracle against its golden fixtures and domain properties, host logic,
+and the C-ABI surface of libbrmi.so (load + exported symbols only; no kernel runs without a GPU)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMPTY = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _golden(name):
+    return np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+
+
+@pytest.mark.parametrize("name", ["golden_tiny", "golden_tiny_lod_coat_fuzz", "golden_sponza"])
+def test_oracle_reproduces_golden_fixtures(name):
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden
+    got, want = make_golden.render(name), _golden(name)
+    for key in want.files:
+        assert np.array_equal(got[key], want[key]), f"{name}: {key} differs from the committed fixture"
+
+
+def test_oracle_is_thread_count_invariant(scenes):
+    import orc
+    sc = scenes("tiny_lod")
+    a = orc.OracleFrame(sc, threads=1).run()
+    b = orc.OracleFrame(sc, threads=8).run()
+    assert np.array_equal(a.vis, b.vis) and np.array_equal(a.hdr, b.hdr) and np.array_equal(a.normals.view(np.uint32), b.normals.view(np.uint32))
+
+
+def test_oracle_band_split_composes(scenes):
+    """Rows rendered band by band equal the full frame (the screen-tile partition is exact)."""
+    import orc
+    sc = scenes("tiny")
+    full = orc.OracleFrame(sc).run()
+    parts = orc.OracleFrame(sc)
+    parts.cull()
+    for band in [(0, 40), (40, 96), (96, sc.height)]:
+        parts.raster(band=band)
+    assert np.array_equal(parts.vis, full.vis)
+    parts.depth_copy(); parts.light_cluster()
+    hdr = np.zeros_like(full.hdr)
+    for band in [(0, 40), (40, 96), (96, sc.height)]:
+        parts.gbuffer(band=band)
+        hdr[band[0]:band[1]] = parts.shade(band=band)[band[0]:band[1]]
+    assert np.array_equal(hdr, full.hdr)
+
+
+def test_visibility_key_layout():
+    import orc
+    lib = orc.lib()
+    lib.orc_pack_vis_key.restype = C.c_uint64
+    lib.orc_pack_vis_key.argtypes = [C.c_float, C.c_uint32, C.c_uint32]
+    k = lib.orc_pack_vis_key(1.5, 0x2ABCDEF, 0x55)
+    assert k & 0x7F == 0x55 and (k >> 7) & 0x3FFFFFF == 0x2ABCDEF
+    assert (k >> 33) == (np.float32(1.5).view(np.uint32) >> 1)
+    # the key orders by depth first: nearer (smaller positive float) < farther, whatever the payload
+    near, far = lib.orc_pack_vis_key(0.999, 0x3FFFFFF, 0x7F), lib.orc_pack_vis_key(1.001, 0, 0)
+    assert near < far
+    # equal depth: lower cluster index wins, then lower triangle id
+    assert lib.orc_pack_vis_key(2.0, 3, 9) < lib.orc_pack_vis_key(2.0, 4, 0) < lib.orc_pack_vis_key(2.0, 4, 1)
+
+
+def test_half_and_unorm_conversions_match_numpy():
+    import orc
+    lib = orc.lib()
+    rng = np.random.default_rng(11)
+    x = np.concatenate([rng.standard_normal(200000).astype(np.float32) * np.exp(rng.uniform(-18, 12, 200000)).astype(np.float32),
+                        np.array([0, -0.0, 65504, 65520, 1e-8, 6e-8, 6.1e-5, np.inf, -np.inf, 1.0, 0.33325195], dtype=np.float32)])
+    out = np.zeros(x.size, dtype=np.uint16)
+    lib.orc_f32_to_f16(orc.P(x), orc.P(out), C.c_uint64(x.size))
+    with np.errstate(over="ignore"):
+        assert np.array_equal(out, x.astype(np.float16).view(np.uint16))
+    back = np.zeros(65536, dtype=np.float32)
+    allh = np.arange(65536, dtype=np.uint16)
+    lib.orc_f16_to_f32(orc.P(allh), orc.P(back), C.c_uint64(65536))
+    ref = allh.view(np.float16).astype(np.float32)
+    ok = ~np.isnan(ref)
+    assert np.array_equal(back[ok].view(np.uint32), ref[ok].view(np.uint32)) and np.isnan(back[~ok]).all()
+    u = rng.uniform(-0.2, 1.2, 100000).astype(np.float32)
+    q = np.zeros(u.size, dtype=np.uint32)
+    lib.orc_unorm8(orc.P(u), orc.P(q), C.c_uint64(u.size))
+    assert np.array_equal(q, (np.clip(u, 0, 1) * np.float32(255) + np.float32(0.5)).astype(np.uint32))
+
+
+def test_lod_cut_never_draws_a_group_and_its_refinement(scenes):
+    """The two-condition LOD cut: a visible cluster that refines group r excludes every cluster of group r (same instance)."""
+    import orc
+    sc = scenes("bistro_small")
+    f = orc.OracleFrame(sc)
+    cl = f.cull()
+    assert f.count > 0 and sc.stats["lodLevelsMax"] > 1
+    inst = cl[:, 0] >> 8
+    group = ((cl[:, 1] >> 14) & 0x3FFFF) | ((cl[:, 2] & 3) << 18)
+    visible = set(zip(inst.tolist(), group.tolist()))
+    sb = sc.arrays
+    md = sb["meshMetadata"].view(np.uint32).reshape(-1, 10)
+    off = sb["clodOffsets"].view(np.uint32)
+    groups = sb["lodGroups"].view(np.uint32).reshape(-1, 19)
+    depths = set()
+    for i, g in visible:
+        gb = md[off[i], 0]
+        depth = int(groups[gb + g, 7])
+        depths.add(depth)
+    # a coarser group may be visible through OTHER segments; what must never happen is a visible meshlet whose own
+    # refined (finer) group is visible too
+    slabs = sc.slabs
+    for row in cl[:: max(1, len(cl) // 400)]:
+        i = int(row[0] >> 8); lm = int(row[1] & 0x3FFF); slab = slabs[int((row[2] >> 2) & 0xFFFFF)]; page = int((row[2] >> 22) & 0x3FF) << 18
+        hdr = slab[page:page + 64].view(np.uint32)
+        desc = slab[page + hdr[4] + lm * 64: page + hdr[4] + lm * 64 + 64].view(np.uint32)
+        refined = int(desc[8] >> 16) - 1
+        if refined >= 0:
+            assert (i, refined) not in visible, "a cluster and the group it was simplified from are both visible"
+    assert len(depths) > 1, "the test scene should exercise more than one LOD depth"
+
+
+def test_frustum_culls_the_instance_behind_the_camera(scenes):
+    import orc
+    f = orc.OracleFrame(scenes("tiny"))
+    f.cull()
+    assert f.counters.instancesTested == 6 and f.counters.instancesVisible == 5
+
+
+def test_light_lists_are_conservative_and_ordered(oracle_frames, scenes):
+    f, sc = oracle_frames("sponza_small"), scenes("sponza_small")
+    lights = sc.arrays["lights"].view(np.float32).reshape(-1, 32)
+    cam_view = sc.arrays["cameras"].view(np.float32)[4:20].reshape(4, 4)
+    total = 0
+    for ci in range(0, len(f.light_clusters), 7):
+        c = f.light_clusters[ci]
+        n, page = int(c[8]), int(c[9])
+        mn, mx = c[0:3].view(np.float32), c[4:7].view(np.float32)
+        got = []
+        while page != 0xFFFFFFFF and len(got) < n:
+            pg = f.light_pages[page]
+            got.extend(pg[2:2 + int(pg[1])].tolist())
+            page = int(pg[0])
+        assert len(got) == n
+        # within the walk order (newest page first) indices ascend inside a page and every listed light touches the AABB
+        for li in got:
+            L = lights[li]
+            if int(L[0].view(np.uint32)) == 2:
+                continue
+            center = np.append(L[25:28], 1.0).astype(np.float32) @ cam_view
+            closest = np.maximum(mn, np.minimum(center[:3], mx))
+            assert np.sum((closest - center[:3]) ** 2) <= L[28] ** 2 * (1 + 1e-5) + 1e-6
+        total += n
+    assert total > 0
+
+
+def test_detile_inverts_the_tiled_layout():
+    from basicrenderer_amd.renderer import detile
+    W, H = 37, 21
+    tx, ty = (W + 7) // 8, (H + 7) // 8
+    flat = np.zeros(tx * ty * 64, dtype=np.int64)
+    for y in range(ty * 8):
+        for x in range(tx * 8):
+            flat[((y >> 3) * tx + (x >> 3)) * 64 + (x & 7) * 8 + (y & 7)] = y * 1000 + x       # brmi.h tiling formula
+    img = detile(flat, W, H)
+    yy, xx = np.mgrid[0:H, 0:W]
+    assert np.array_equal(img, yy * 1000 + xx)
+    from basicrenderer_amd.renderer import tile
+    assert np.array_equal(detile(tile(img), W, H), img)
+    rgba = np.random.default_rng(0).integers(0, 255, (H, W, 4), dtype=np.uint8)
+    assert np.array_equal(detile(tile(rgba), W, H), rgba)
+
+
+def test_compose_band_ranges():
+    from basicrenderer_amd import compose
+    assert compose.frame_size(1) == (3840, 2160) and compose.frame_size(8) == (7680, 8640)
+    for n in (1, 2, 4, 8):
+        W, H = compose.frame_size(n)
+        bands = [compose.band_of(r, n, H) for r in range(n)]
+        assert bands[0][0] == 0 and bands[-1][1] == H and all(b[1] - b[0] == H // n for b in bands)
+        assert all(W * (b[1] - b[0]) == 3840 * 2160 for b in bands)          # weak scaling: fixed pixels per rank
+        rng = [compose.band_byte_range(b, W, 8) for b in bands]
+        assert all(rng[i][1] == rng[i + 1][0] for i in range(n - 1))
+    with pytest.raises(ValueError):
+        compose.band_of(0, 7, 2160)
+
+
+def _decls(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(brmi_[a-z0-9_]+)\s*\(", txt)) - {"brmi_declare_cb"})
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """include/brmi.h is the drop-in boundary: every function it declares must be exported by libbrmi.so."""
+    from basicrenderer_amd import capi
+    lib = capi.brmi_lib()
+    names = _decls("brmi.h")
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"libbrmi.so does not export {n}"
+    assert sorted(names) == sorted(capi.BRMI_EXPORTS)
+    slib = capi.scene_lib()
+    for n in _decls("brmi_scene.h"):
+        assert hasattr(slib, n), f"libbrmi_scene.so does not export {n}"
+    assert lib.brmi_abi_version() == 1
+
+
+def test_c_abi_rejects_bad_calls_without_a_gpu():
+    from basicrenderer_amd import capi
+    lib = capi.brmi_lib()
+    cfg = capi.Config()
+    lib.brmi_default_config(C.byref(cfg), 1920, 1080)
+    assert cfg.structSize == C.sizeof(capi.Config) and cfg.lightClusterSize[2] == 24 and cfg.phase2ExpansionFactor == 2
+    h = capi.vp()
+    cfg.structSize = 12
+    assert lib.brmi_create(C.byref(cfg), C.byref(h)) == -1
+    lib.brmi_default_config(C.byref(cfg), 1920, 1080)
+    assert lib.brmi_create(C.byref(cfg), C.byref(h)) == 0
+    assert lib.brmi_execute(h, None) == -4 and lib.brmi_cull(h, 1, None) == -4
+    assert lib.brmi_set_scene(h, None) == -1
+    lib.brmi_destroy(h)
+
+
+def test_struct_sizes_match_the_reference_layouts():
+    """The ctypes mirrors and the C structs agree with the sizes the reference uploads."""
+    from basicrenderer_amd import Scene
+    sc = Scene("tiny", 64, 64, point_lights=1)
+    per = {"perObject": 208, "perMesh": 64, "perMeshInstance": 32, "lodNodes": 64, "lodGroups": 76, "lodSegments": 16, "groupPageMap": 8,
+           "cameras": 736, "cullingCameras": 304, "viewRasterInfo": 48, "perFrame": 104, "lights": 128, "materials": 276, "openpbrMaterials": 400,
+           "meshMetadata": 40}
+    for name, size in per.items():
+        assert sc.arrays[name].size == sc.counts[name] * size, name
+    for s in sc.slabs[1:]:
+        assert s.size % (256 * 1024) == 0
+
+
+def test_product_path_never_touches_the_oracle():
+    """Only tests/, smoke() and bench.py's cpu_baseline leg may use oracle/."""
+    pkg = os.path.join(ROOT, "basicrenderer_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp", ".hpp")):
+                txt = open(os.path.join(dirpath, fn), errors="ignore").read()
+                for m in re.finditer(r"^\s*(?:#\s*include|import|from)\b.*$", txt, flags=re.M):
+                    assert "orc" not in m.group(0).split("#")[0].replace("force", "") or "include" not in m.group(0) and "import orc" not in m.group(0), f"{fn}: {m.group(0)}"
+                assert "liboracle" not in txt and "oracle/_build" not in txt, fn
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    head, _, tail = bench.partition("def cpu_baseline")
+    assert "import orc" not in head and "import orc" in tail
