@@ -20,7 +20,7 @@ HIP_HDRS  := $(wildcard basicrenderer_amd/csrc/*.h) $(wildcard include/*.h)
 ORC_SRCS  := $(wildcard oracle/*.cpp)
 ORC_HDRS  := $(wildcard oracle/*.h) $(wildcard include/*.h)
 
-all: scene oracle hip
+all: scene oracle hip host_example
 
 scene: $(LIBDIR)/libbrmi_scene.so
 oracle: $(ORCDIR)/liboracle.so
@@ -38,7 +38,12 @@ $(LIBDIR)/libbrmi.so: $(HIP_SRCS) $(HIP_HDRS)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) $(HIP_SRCS) -o $@
 
+# C++ host driving the passes through basicrenderer_amd/host/brmi_passes.hpp (links both libraries)
+host_example: $(LIBDIR)/brmi_host_frame
+$(LIBDIR)/brmi_host_frame: examples/host_frame.cpp basicrenderer_amd/host/brmi_passes.hpp $(LIBDIR)/libbrmi.so $(LIBDIR)/libbrmi_scene.so
+	$(HIPCC) -O2 -std=c++17 -Iinclude examples/host_frame.cpp -L$(LIBDIR) -lbrmi -lbrmi_scene -Wl,-rpath,'$$ORIGIN' -o $@
+
 clean:
 	rm -rf $(LIBDIR) $(ORCDIR)
 
-.PHONY: all scene oracle hip clean
+.PHONY: all scene oracle hip host_example clean

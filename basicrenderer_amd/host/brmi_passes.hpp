@@ -1,0 +1,142 @@
+// brmi_passes.hpp -- C++ host mirror of the reference's pass interface for the visibility-buffer path.
+//
+// The reference schedules this path as OpenRenderGraph passes: subclasses of `ComputePass` with
+//   DeclareResourceUsages(ComputePassBuilder*) / Setup() / Update(const UpdateExecutionContext&) /
+//   Execute(PassExecutionContext&) / Cleanup()
+// (e.g. BR/include/Render/GraphExtensions/ClusterLOD/ClusterSoftwareRasterizationPass.h:16-54,
+//  BR/include/RenderPasses/DeferredShadingPass.h:11-121) spliced into the graph by
+// `CLodExtension::GatherStructuralPasses` (BR/src/Render/GraphExtensions/CLodExtension.cpp:1411-2095)
+// and `RenderGraphBuildHelper` (BR/include/Render/RenderGraphBuildHelper.h:220-414).
+//
+// OpenRenderGraph / BasicRHI sources are absent from the reference checkout (empty submodules), so the
+// minimal surface those classes need is restated here under the same names and phase semantics; every
+// pass forwards to the C ABI of libbrmi.so (include/brmi.h).  A maintainer with the real graph derives
+// these classes from the real `ComputePass` instead of `brmi::host::ComputePass` and nothing else changes
+// (INTEGRATION.md).  Failures throw std::runtime_error, as the reference's passes do
+// (BR/src/Renderer.cpp:2112-2122).
+#pragma once
+
+#include <cstdint>
+#include <functional>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "brmi.h"
+
+namespace brmi::host {
+
+struct PassReturn {};                                   // reference: Execute() returns PassReturn{}
+struct UpdateExecutionContext { const brmi_camera* mainCamera; const brmi_per_frame* perFrame; uint32_t frameIndex; };
+struct PassExecutionContext { brmi_stream commandList; uint32_t frameIndex; float deltaTime; };   // commandList -> hipStream_t
+
+// what DeclareResourceUsages reports: the reference's builder verbs, by Builtin:: resource name
+struct ComputePassBuilder {
+    std::vector<std::string> shaderResources, unorderedAccess;
+    ComputePassBuilder& WithShaderResource(std::string n) { shaderResources.push_back(std::move(n)); return *this; }
+    ComputePassBuilder& WithUnorderedAccess(std::string n) { unorderedAccess.push_back(std::move(n)); return *this; }
+};
+
+// One shared brmi_pass per view; the individual passes are views on its stages (the reference shares the
+// same buffers between these passes through the resource registry).
+class PassState {
+public:
+    explicit PassState(const brmi_config& cfg) { check(brmi_create(&cfg, &pass_), "brmi_create"); }
+    ~PassState() { brmi_destroy(pass_); }
+    PassState(const PassState&) = delete;
+    PassState& operator=(const PassState&) = delete;
+    brmi_pass* get() const { return pass_; }
+    void check(int rc, const char* what) const {
+        if (rc != BRMI_OK) throw std::runtime_error(std::string(what) + ": " + (pass_ ? brmi_last_error(pass_) : "invalid argument"));
+    }
+    void SetScene(const brmi_scene_buffers& sc) { check(brmi_set_scene(pass_, &sc), "brmi_set_scene"); }
+    std::vector<brmi_resource_desc> Declare() {
+        std::vector<brmi_resource_desc> out;
+        check(brmi_declare(pass_, [](void* u, const brmi_resource_desc* d) { static_cast<std::vector<brmi_resource_desc>*>(u)->push_back(*d); }, &out), "brmi_declare");
+        return out;
+    }
+    void Bind(const std::vector<brmi_resource_binding>& b, brmi_stream s) { check(brmi_setup(pass_, b.data(), (uint32_t)b.size(), s), "brmi_setup"); }
+    void Update(const UpdateExecutionContext& u, brmi_stream s) {
+        brmi_frame_update f{u.mainCamera, u.perFrame, u.frameIndex};
+        check(brmi_update(pass_, &f, s), "brmi_update");
+    }
+private:
+    brmi_pass* pass_ = nullptr;
+};
+
+class ComputePass {
+public:
+    explicit ComputePass(std::shared_ptr<PassState> st, std::string name) : state(std::move(st)), name_(std::move(name)) {}
+    virtual ~ComputePass() = default;
+    virtual void DeclareResourceUsages(ComputePassBuilder* builder) = 0;
+    virtual void Setup() {}
+    virtual void Update(const UpdateExecutionContext&) {}
+    virtual PassReturn Execute(PassExecutionContext& ctx) = 0;
+    virtual void Cleanup() {}
+    const std::string& Name() const { return name_; }
+protected:
+    std::shared_ptr<PassState> state;
+    std::string name_;
+};
+
+#define BRMI_STAGE_PASS(CLASS, NAME, CALL, SRVS, UAVS)                                                        \
+    class CLASS final : public ComputePass {                                                                  \
+    public:                                                                                                   \
+        explicit CLASS(std::shared_ptr<PassState> st) : ComputePass(std::move(st), NAME) {}                   \
+        void DeclareResourceUsages(ComputePassBuilder* b) override {                                          \
+            for (const char* s : std::vector<const char*> SRVS) b->WithShaderResource(s);                     \
+            for (const char* u : std::vector<const char*> UAVS) b->WithUnorderedAccess(u);                    \
+        }                                                                                                     \
+        PassReturn Execute(PassExecutionContext& ctx) override { state->check(CALL, NAME); return {}; }       \
+    };
+
+// reference: ClearVisibilityBufferPass (BR/include/RenderPasses/ClearVisibilityBufferPass.h)
+BRMI_STAGE_PASS(ClearVisibilityBufferPass, "ClearVisibilityBufferPass", brmi_clear_visibility(state->get(), ctx.commandList),
+                ({}), ({"Builtin::PrimaryCamera::VisibilityTexture"}))
+// reference: HierarchicalDispatchCullingPass phase 1 (BR/src/Render/GraphExtensions/ClusterLOD/HierarchicalDispatchCullingPass.cpp:496-1114)
+BRMI_STAGE_PASS(HierarchicalCullingPass1, "HierarchicalCullingPass1", brmi_cull(state->get(), 1, ctx.commandList),
+                ({"Builtin::PerMeshInstanceBuffer", "Builtin::PerObjectBuffer", "Builtin::CameraBuffer", "Builtin::CullingCameraBuffer", "Builtin::CLod::Nodes",
+                  "Builtin::CLod::Groups", "Builtin::CLod::Segments", "Builtin::CLod::GroupPageMap", "Builtin::CLod::MeshMetadata", "Builtin::CLod::Offsets"}),
+                ({"Builtin::CLod::VisibleClusters", "brmi::Workspace"}))
+// reference: ClusterSoftwareRasterizationPass (BR/src/Render/GraphExtensions/ClusterLOD/ClusterSoftwareRasterizationPass.cpp:154-207);
+// the raster-bucket histogram / scan / compaction passes (RasterBucket*Pass) collapse into it
+BRMI_STAGE_PASS(SoftwareRasterizeClustersPass1, "SoftwareRasterizeClustersPass1", brmi_raster(state->get(), 1, ctx.commandList),
+                ({"Builtin::CLod::VisibleClusters", "Builtin::PerMeshInstanceBuffer", "Builtin::PerObjectBuffer", "Builtin::CullingCameraBuffer", "CLod page slabs"}),
+                ({"Builtin::PrimaryCamera::VisibilityTexture"}))
+// reference: PerViewLinearDepthCopyPass (BR/src/Render/GraphExtensions/ClusterLOD/PerViewLinearDepthCopyPass.cpp)
+BRMI_STAGE_PASS(LinearDepthCopyPass1, "LinearDepthCopyPass1", brmi_depth_copy(state->get(), ctx.commandList),
+                ({"Builtin::PrimaryCamera::VisibilityTexture"}), ({"Builtin::PrimaryCamera::LinearDepthMap"}))
+// reference: MaterialHistogram .. EvaluateMaterialGroups (BR/include/RenderPasses/VisUtil/*.h; parameter list at EvaluateMaterialGroupsPass.h:68-111)
+BRMI_STAGE_PASS(EvaluateMaterialGroupsPass, "EvaluateMaterialGroupsPass", brmi_gbuffer(state->get(), ctx.commandList),
+                ({"Builtin::PrimaryCamera::VisibilityTexture", "Builtin::CLod::VisibleClusters", "Builtin::PerMaterialDataBuffer", "Builtin::PerMaterialOpenPBRDataBuffer",
+                  "Builtin::NormalMatrixBuffer", "CLod page slabs"}),
+                ({"Builtin::GBuffer::Normals", "Builtin::GBuffer::Albedo", "Builtin::GBuffer::Coat", "Builtin::GBuffer::Emissive", "Builtin::GBuffer::Fuzz",
+                  "Builtin::GBuffer::MetallicRoughness", "Builtin::GBuffer::MotionVectors", "Builtin::PrimaryCamera::LinearDepthMap"}))
+// reference: ClusterGenerationPass + LightCullingPass (BR/include/RenderPasses/ClusterGenerationPass.h:41-42, LightCullingPass.h:49-51)
+BRMI_STAGE_PASS(LightCullingPass, "LightCullingPass", brmi_light_clustering(state->get(), ctx.commandList),
+                ({"Builtin::Light::InfoBuffer", "Builtin::Light::ActiveLightIndices", "Builtin::CameraBuffer"}),
+                ({"Builtin::Light::ClusterBuffer", "Builtin::Light::PagesBuffer"}))
+// reference: DeferredShadingPass (BR/include/RenderPasses/DeferredShadingPass.h:77-107)
+BRMI_STAGE_PASS(DeferredShadingPass, "DeferredShadingPass", brmi_shade(state->get(), ctx.commandList),
+                ({"Builtin::GBuffer::Normals", "Builtin::GBuffer::Albedo", "Builtin::GBuffer::Coat", "Builtin::GBuffer::Emissive", "Builtin::GBuffer::Fuzz",
+                  "Builtin::GBuffer::MetallicRoughness", "Builtin::PrimaryCamera::LinearDepthMap", "Builtin::Light::ClusterBuffer", "Builtin::Light::PagesBuffer",
+                  "Builtin::OpenPBR::*"}),
+                ({"Builtin::Color::HDRColorTarget"}))
+#undef BRMI_STAGE_PASS
+
+// reference: CLodExtension (IRenderGraphExtension) -- returns the passes in the order the reference graph runs them
+class BrmiGraphExtension {
+public:
+    explicit BrmiGraphExtension(std::shared_ptr<PassState> st) : state_(std::move(st)) {}
+    // GatherStructuralPasses: cull/raster chain spliced before "MaterialHistogramPass" (CLodExtension.cpp:1704,1910)
+    std::vector<std::shared_ptr<ComputePass>> GatherStructuralPasses() const {
+        return {std::make_shared<ClearVisibilityBufferPass>(state_), std::make_shared<HierarchicalCullingPass1>(state_),
+                std::make_shared<SoftwareRasterizeClustersPass1>(state_), std::make_shared<EvaluateMaterialGroupsPass>(state_),
+                std::make_shared<LightCullingPass>(state_), std::make_shared<DeferredShadingPass>(state_)};
+    }
+private:
+    std::shared_ptr<PassState> state_;
+};
+
+}  // namespace brmi::host

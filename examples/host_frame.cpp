@@ -1,0 +1,112 @@
+// host_frame.cpp -- a C++ host driving the path exactly as a render graph would: providers resolved to device
+// buffers, resources declared by the pass and allocated by the "graph" (here: hipMalloc), passes gathered from the
+// extension and executed in order on one stream.  Prints the frame's checksums as one JSON line.
+//
+//   build:  make host_example        run:  basicrenderer_amd/lib/brmi_host_frame [preset W H lights]
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../basicrenderer_amd/host/brmi_passes.hpp"
+#include "brmi_scene.h"
+
+#define HIPCHK(x) do { hipError_t e = (x); if (e != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); std::exit(2); } } while (0)
+
+static uint64_t fnv1a(const void* p, size_t n) {
+    const uint8_t* b = static_cast<const uint8_t*>(p); uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; }
+    return h;
+}
+
+template <typename T> static const T* upload(const brmi_scene* sc, uint32_t id, uint32_t* count, std::vector<void*>& keep) {
+    const void* p; uint64_t bytes; uint32_t n;
+    if (brmi_scene_array(sc, id, &p, &bytes, &n) != 0) std::exit(3);
+    if (count) *count = n;
+    if (bytes == 0) return nullptr;
+    void* d; HIPCHK(hipMalloc(&d, bytes)); HIPCHK(hipMemcpy(d, p, bytes, hipMemcpyHostToDevice)); keep.push_back(d);
+    return static_cast<const T*>(d);
+}
+
+int main(int argc, char** argv) {
+    using namespace brmi::host;
+    brmi_scene_params prm{};
+    prm.preset = argc > 1 ? (uint32_t)std::atoi(argv[1]) : BRMI_PRESET_TINY;
+    prm.width = argc > 2 ? (uint32_t)std::atoi(argv[2]) : 256; prm.height = argc > 3 ? (uint32_t)std::atoi(argv[3]) : 144;
+    prm.numPointLights = argc > 4 ? (uint32_t)std::atoi(argv[4]) : 6; prm.withDirectionalLight = 1; prm.sizeScale = 1.0f;
+    brmi_scene* scene = brmi_scene_create(&prm);
+    if (!scene) return 1;
+    std::vector<void*> keep;
+    brmi_scene_buffers sb{};
+    // slabs: device array of device pointers, entry 0 = "not resident"
+    const uint32_t nslabs = brmi_scene_slab_count(scene);
+    std::vector<const uint8_t*> slabPtrs(nslabs + 1, nullptr);
+    for (uint32_t s = 1; s <= nslabs; s++) {
+        const void* p; uint64_t bytes; brmi_scene_slab(scene, s, &p, &bytes);
+        void* d; HIPCHK(hipMalloc(&d, bytes)); HIPCHK(hipMemcpy(d, p, bytes, hipMemcpyHostToDevice)); keep.push_back(d); slabPtrs[s] = static_cast<const uint8_t*>(d);
+    }
+    { void* d; HIPCHK(hipMalloc(&d, slabPtrs.size() * 8)); HIPCHK(hipMemcpy(d, slabPtrs.data(), slabPtrs.size() * 8, hipMemcpyHostToDevice)); keep.push_back(d);
+      sb.slabs = static_cast<const uint8_t* const*>(d); sb.slabCount = nslabs + 1; }
+    sb.perObject = upload<brmi_per_object>(scene, BRMI_ARR_PER_OBJECT, &sb.perObjectCount, keep);
+    sb.normalMatrices = upload<float>(scene, BRMI_ARR_NORMAL_MATRICES, nullptr, keep);
+    sb.perMesh = upload<brmi_per_mesh>(scene, BRMI_ARR_PER_MESH, &sb.perMeshCount, keep);
+    sb.perMeshInstance = upload<brmi_per_mesh_instance>(scene, BRMI_ARR_PER_MESH_INSTANCE, &sb.perMeshInstanceCount, keep);
+    sb.clodOffsets = upload<brmi_mesh_instance_clod_offsets>(scene, BRMI_ARR_CLOD_OFFSETS, nullptr, keep);
+    sb.meshMetadata = upload<brmi_clod_mesh_metadata>(scene, BRMI_ARR_CLOD_MESH_METADATA, &sb.meshMetadataCount, keep);
+    sb.lodNodes = upload<brmi_lod_node>(scene, BRMI_ARR_LOD_NODES, &sb.lodNodeCount, keep);
+    sb.lodGroups = upload<brmi_lod_group>(scene, BRMI_ARR_LOD_GROUPS, &sb.lodGroupCount, keep);
+    sb.lodSegments = upload<brmi_lod_segment>(scene, BRMI_ARR_LOD_SEGMENTS, &sb.lodSegmentCount, keep);
+    sb.groupPageMap = upload<brmi_group_page_map_entry>(scene, BRMI_ARR_GROUP_PAGE_MAP, &sb.groupPageMapCount, keep);
+    sb.materials = upload<brmi_material_info>(scene, BRMI_ARR_MATERIALS, &sb.materialCount, keep);
+    sb.openpbrMaterials = upload<brmi_openpbr_material_info>(scene, BRMI_ARR_OPENPBR_MATERIALS, &sb.openpbrMaterialCount, keep);
+    sb.lights = upload<brmi_light_info>(scene, BRMI_ARR_LIGHTS, &sb.lightCount, keep);
+    sb.activeLightIndices = upload<uint32_t>(scene, BRMI_ARR_ACTIVE_LIGHT_INDICES, nullptr, keep);
+    sb.cameras = upload<brmi_camera>(scene, BRMI_ARR_CAMERAS, &sb.cameraCount, keep);
+    sb.cullingCameras = upload<brmi_culling_camera>(scene, BRMI_ARR_CULLING_CAMERAS, nullptr, keep);
+    sb.viewRasterInfo = upload<brmi_view_raster_info>(scene, BRMI_ARR_VIEW_RASTER_INFO, nullptr, keep);
+    sb.perFrame = upload<brmi_per_frame>(scene, BRMI_ARR_PER_FRAME, nullptr, keep);
+    sb.activeDraws = upload<uint32_t>(scene, BRMI_ARR_ACTIVE_DRAWS, &sb.activeDrawCount, keep);
+    sb.skinningMatrices = upload<float>(scene, BRMI_ARR_SKINNING_MATRICES, &sb.skinningMatrixCount, keep);
+    sb.lutOpaqueDielectricEnergyComplement = upload<uint16_t>(scene, BRMI_ARR_LUT_OD_ENERGY, nullptr, keep);
+    sb.lutOpaqueDielectricAvgEnergyComplement = upload<uint16_t>(scene, BRMI_ARR_LUT_OD_AVG_ENERGY, nullptr, keep);
+    sb.lutIdealMetalEnergyComplement = upload<uint16_t>(scene, BRMI_ARR_LUT_IM_ENERGY, nullptr, keep);
+    sb.lutIdealMetalAvgEnergyComplement = upload<uint16_t>(scene, BRMI_ARR_LUT_IM_AVG_ENERGY, nullptr, keep);
+    sb.lutFuzzLTC = upload<float>(scene, BRMI_ARR_LUT_FUZZ_LTC, nullptr, keep);
+
+    hipStream_t stream; HIPCHK(hipStreamCreate(&stream));
+    try {
+        brmi_config cfg; brmi_default_config(&cfg, prm.width, prm.height);
+        cfg.maxVisibleClusters = 1u << 16; cfg.maxTraversalRecords = 1u << 16;
+        auto state = std::make_shared<PassState>(cfg);
+        state->SetScene(sb);
+        // the graph owns the memory of every declared resource
+        std::vector<brmi_resource_binding> binds;
+        std::vector<uint64_t> sizes(BRMI_RES_COUNT, 0);
+        for (const brmi_resource_desc& d : state->Declare()) {
+            void* p; const uint64_t bytes = d.bytes < 16 ? 16 : d.bytes;
+            HIPCHK(hipMalloc(&p, bytes)); HIPCHK(hipMemset(p, 0, bytes)); keep.push_back(p);
+            binds.push_back({d.id, p, bytes}); sizes[d.id] = d.bytes;
+        }
+        state->Bind(binds, stream);
+        BrmiGraphExtension ext(state);
+        auto passes = ext.GatherStructuralPasses();
+        ComputePassBuilder builder;
+        for (auto& p : passes) { p->DeclareResourceUsages(&builder); p->Setup(); }
+        const void* camHost; const void* pfHost; uint64_t b; uint32_t n;
+        brmi_scene_array(scene, BRMI_ARR_CAMERAS, &camHost, &b, &n); brmi_scene_array(scene, BRMI_ARR_PER_FRAME, &pfHost, &b, &n);
+        state->Update({static_cast<const brmi_camera*>(camHost), static_cast<const brmi_per_frame*>(pfHost), 0}, stream);
+        PassExecutionContext ctx{stream, 0, 0.0f};
+        for (auto& p : passes) p->Execute(ctx);
+        HIPCHK(hipStreamSynchronize(stream));
+        brmi_counters c; state->check(brmi_read_counters(state->get(), &c, stream), "brmi_read_counters");
+        auto checksum = [&](uint32_t id) { std::vector<uint8_t> h(sizes[id]); for (auto& bd : binds) if (bd.id == id) HIPCHK(hipMemcpy(h.data(), bd.ptr, sizes[id], hipMemcpyDeviceToHost)); return fnv1a(h.data(), h.size()); };
+        std::printf("{\"passes\": %zu, \"srv\": %zu, \"uav\": %zu, \"visible_clusters\": %u, \"vis_fnv\": \"%016llx\", \"hdr_fnv\": \"%016llx\", \"normals_fnv\": \"%016llx\"}\n",
+                    passes.size(), builder.shaderResources.size(), builder.unorderedAccess.size(), c.visibleClusters,
+                    (unsigned long long)checksum(BRMI_RES_VISIBILITY), (unsigned long long)checksum(BRMI_RES_HDR_COLOR), (unsigned long long)checksum(BRMI_RES_GBUF_NORMALS));
+    } catch (const std::exception& e) { std::fprintf(stderr, "error: %s\n", e.what()); return 4; }
+    for (void* p : keep) (void)hipFree(p);
+    brmi_scene_destroy(scene);
+    return 0;
+}

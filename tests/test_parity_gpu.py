@@ -213,3 +213,35 @@ def test_full_size_4k_properties(preset, lights):
     inst = cl[:, 0] >> np.uint64(8)
     assert (np.diff(inst.astype(np.int64)) >= 0).all()
     r.close()
+
+
+def test_cpp_host_passes_reproduce_the_python_frame(scenes):
+    """The C++ host mirror (basicrenderer_amd/host/brmi_passes.hpp) driving the stage-level C ABI gives the same bytes."""
+    import hashlib
+    import json
+    import os
+    import subprocess
+    from basicrenderer_amd import capi
+    from basicrenderer_amd.renderer import VisibilityRenderer
+    exe = os.path.join(capi.LIB_DIR, "brmi_host_frame")
+    if not os.path.exists(exe):
+        pytest.skip("brmi_host_frame not built (make host_example)")
+    out = subprocess.run([exe, "0", "256", "144", "6"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    got = json.loads(out.stdout.strip().splitlines()[-1])
+    assert got["passes"] == 6 and got["srv"] > 20 and got["uav"] > 10
+
+    def fnv(buf):
+        h = 1469598103934665603
+        for b in buf.tobytes():
+            h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return f"{h:016x}"
+
+    r = VisibilityRenderer(scenes("tiny"))
+    r.execute()
+    assert got["visible_clusters"] == r.counters().visibleClusters
+    r.torch.cuda.synchronize()
+    for key, rid in (("vis_fnv", "VISIBILITY"), ("hdr_fnv", "HDR_COLOR"), ("normals_fnv", "GBUF_NORMALS")):
+        raw = r.res[capi.RES[rid]].cpu().numpy()[: r.descs[capi.RES[rid]]["bytes"]]
+        assert fnv(raw) == got[key], key
+    r.close()
