@@ -15,7 +15,7 @@ u32, u64, f32, vp = C.c_uint32, C.c_uint64, C.c_float, C.c_void_p
 class SceneParams(C.Structure):
     _fields_ = [("preset", u32), ("seed", u32), ("width", u32), ("height", u32), ("numPointLights", u32),
                 ("withDirectionalLight", u32), ("lodLevels", u32), ("sizeScale", f32), ("skinnedFraction1024", u32),
-                ("materialFeatures", u32), ("reserved", u32 * 6)]
+                ("materialFeatures", u32), ("cameraStep", u32), ("reserved", u32 * 5)]
 
 
 class SceneStats(C.Structure):
@@ -88,7 +88,7 @@ class FrameUpdate(C.Structure):
 class Counters(C.Structure):
     _fields_ = [(n, u32) for n in ("instancesTested instancesVisible nodesVisited bucketRecords meshletsTested "
                                    "visibleClusters visibleClustersPhase2 droppedRecords droppedClusters "
-                                   "lightPagesUsed").split()] + [("reserved", u32 * 6)]
+                                   "lightPagesUsed replayNodes replayMeshlets").split()] + [("reserved", u32 * 6)]
 
 
 DECLARE_CB = C.CFUNCTYPE(None, vp, C.POINTER(ResourceDesc))
@@ -125,7 +125,7 @@ def scene_lib():
 
 BRMI_EXPORTS = ["brmi_abi_version", "brmi_default_config", "brmi_create", "brmi_declare", "brmi_set_scene", "brmi_setup",
                 "brmi_update", "brmi_execute", "brmi_destroy", "brmi_last_error", "brmi_clear_visibility", "brmi_cull",
-                "brmi_raster", "brmi_depth_copy", "brmi_build_hzb", "brmi_gbuffer", "brmi_light_clustering",
+                "brmi_raster", "brmi_depth_copy", "brmi_build_hzb", "brmi_invalidate_hzb", "brmi_gbuffer", "brmi_light_clustering",
                 "brmi_shade", "brmi_read_counters", "brmi_stage_times", "brmi_algorithmic_bytes", "brmi_debug_arith"]
 
 
@@ -156,6 +156,7 @@ def brmi_lib():
         lib.brmi_last_error.restype = C.c_char_p
         for n in ("brmi_clear_visibility", "brmi_depth_copy", "brmi_build_hzb", "brmi_gbuffer", "brmi_light_clustering", "brmi_shade"):
             getattr(lib, n).argtypes = [vp, vp]
+        lib.brmi_invalidate_hzb.argtypes = [vp]
         lib.brmi_cull.argtypes = [vp, u32, vp]
         lib.brmi_raster.argtypes = [vp, u32, vp]
         lib.brmi_read_counters.argtypes = [vp, C.POINTER(Counters), vp]

@@ -64,7 +64,12 @@ static void compute_sizes(brmi_pass* p) {
     uint64_t hzbFloats = 0;
     if (c.enableOcclusionCulling) {
         uint32_t w = 1, h = 1; while (w < c.width) w <<= 1; while (h < c.height) h <<= 1;
-        for (;;) { p->hzbMipOffsets.push_back(hzbFloats); p->hzbMipW.push_back(w); p->hzbMipH.push_back(h); hzbFloats += (uint64_t)w * h; if (w == 1 && h == 1) break; w = std::max(1u, w >> 1); h = std::max(1u, h >> 1); }
+        for (uint32_t mip = 0;; mip++) {      // mip 0 is the depth map itself: no storage
+            p->hzbMipOffsets.push_back(hzbFloats); p->hzbMipW.push_back(w); p->hzbMipH.push_back(h);
+            if (mip > 0) hzbFloats += (uint64_t)w * h;
+            if (w == 1 && h == 1) break;
+            w = std::max(1u, w >> 1); h = std::max(1u, h >> 1);
+        }
     }
     p->hzbMipCount = (uint32_t)p->hzbMipOffsets.size();
     p->resNeed[BRMI_RES_HZB] = std::max<uint64_t>(16, hzbFloats * 4);
@@ -83,7 +88,10 @@ static void compute_sizes(brmi_pass* p) {
     w.instanceBitBase = take((uint64_t)std::max<size_t>(1, p->hostInstanceBitBase.size()) * 4);
     w.segPrefix = take((uint64_t)std::max<size_t>(1, p->hostSegPrefix.size()) * 4);
     w.planes = take((uint64_t)2 * c.lightClusterSize[2] * 4);
-    w.replayNodes = take(16); w.replayBuckets = take(16);
+    // phase-1 -> phase-2 hand-over (reference: clodStructs.hlsli:629-652); the replay bucket array doubles as the
+    // phase-2 bucket array, so it has the full record capacity
+    w.replayNodes = take(c.enableOcclusionCulling ? (uint64_t)c.maxTraversalRecords * sizeof(NodeRecord) : 16);
+    w.replayBuckets = take(c.enableOcclusionCulling ? (uint64_t)c.maxTraversalRecords * sizeof(BucketRecord) : 16);
     w.lightVS = take((uint64_t)std::max(1u, p->scene.lightCount) * 16);
     w.lightMeta = take((uint64_t)std::max(1u, p->scene.lightCount) * 4);
     w.clusterPages = take((uint64_t)p->numLightClusters * 4);
@@ -108,6 +116,15 @@ static int read_back(brmi_pass* p, std::vector<T>& dst, const T* src, size_t n) 
 
 }  // namespace brmi
 
+brmi::HzbDesc brmi_pass::hzbDesc() const {
+    brmi::HzbDesc d{};
+    d.depth = static_cast<const float*>(res[BRMI_RES_LINEAR_DEPTH]); d.mips = static_cast<float*>(res[BRMI_RES_HZB]);
+    d.width = cfg.width; d.height = cfg.height; d.tilesX = tilesX; d.mipCount = hzbMipCount;
+    d.paddedW = hzbMipCount ? hzbMipW[0] : 1; d.paddedH = hzbMipCount ? hzbMipH[0] : 1;
+    for (uint32_t i = 0; i < brmi::kMaxHzbMips; i++) d.mipOffset[i] = i < hzbMipCount ? (uint32_t)hzbMipOffsets[i] : 0u;
+    return d;
+}
+
 using namespace brmi;
 
 extern "C" {
@@ -121,7 +138,7 @@ void brmi_default_config(brmi_config* cfg, uint32_t width, uint32_t height) {
     cfg->width = width; cfg->height = height;
     cfg->maxVisibleClusters = 1u << 22;       // reference: 30,000,000 (Renderer.cpp:2494); callers size it to the scene
     cfg->maxTraversalRecords = 1u << 22;
-    cfg->enableOcclusionCulling = 0;          // 2-phase HZB chain: SURVEY.md 8f-2, not built in this round
+    cfg->enableOcclusionCulling = 0;          // opt-in: 2-phase HZB occlusion culling (needs a previous frame to pay off)
     cfg->enableClusteredLighting = 1;
     cfg->enablePunctualLights = 1;
     cfg->lightClusterSize[0] = 12; cfg->lightClusterSize[1] = 12; cfg->lightClusterSize[2] = 24;
@@ -136,7 +153,6 @@ int brmi_create(const brmi_config* cfg, brmi_pass** out) {
     if (cfg->lightClusterSize[0] == 0 || cfg->lightClusterSize[1] == 0 || cfg->lightClusterSize[2] == 0) return BRMI_ERR_INVALID;
     brmi_pass* p = new brmi_pass();
     p->cfg = *cfg;
-    if (p->cfg.enableOcclusionCulling) { p->err = "enableOcclusionCulling: the phase-2 HZB chain is not built yet; running single-phase"; p->cfg.enableOcclusionCulling = 0; }
     p->totalWords = 1; p->scanBlocks = 1;
     if (const char* e = std::getenv("BRMI_RASTER_MODE")) p->rasterMode = std::atoi(e);
     if (const char* e = std::getenv("BRMI_BIG_TRI_AREA")) p->bigTriArea = std::max(1, std::atoi(e));
@@ -319,8 +335,16 @@ int brmi_depth_copy(brmi_pass* p, brmi_stream stream) {
     STAGE_BEGIN(p, BRMI_STAGE_DEPTH_COPY, s); int rc = launch_depth_copy(p, s); STAGE_END(p, BRMI_STAGE_DEPTH_COPY, s); return rc;
 }
 int brmi_build_hzb(brmi_pass* p, brmi_stream stream) {
-    CHECK_READY(p); (void)stream;
-    return brmi::fail(p, BRMI_ERR_STATE, "brmi_build_hzb: the HZB chain (SURVEY.md 8f-2) is not built yet");
+    CHECK_READY(p); hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!p->cfg.enableOcclusionCulling) return brmi::fail(p, BRMI_ERR_STATE, "brmi_build_hzb: the pass was created without enableOcclusionCulling");
+    STAGE_BEGIN(p, BRMI_STAGE_HZB, s); int rc = launch_hzb(p, s); STAGE_END(p, BRMI_STAGE_HZB, s);
+    if (rc == BRMI_OK) p->hzbValid = true;
+    return rc;
+}
+int brmi_invalidate_hzb(brmi_pass* p) {
+    if (!p) return BRMI_ERR_INVALID;
+    p->hzbValid = false;
+    return BRMI_OK;
 }
 int brmi_gbuffer(brmi_pass* p, brmi_stream stream) {
     CHECK_READY(p); hipStream_t s = static_cast<hipStream_t>(stream);
@@ -342,7 +366,16 @@ int brmi_execute(brmi_pass* p, brmi_stream stream) {
     if ((rc = brmi_clear_visibility(p, stream))) return rc;
     if ((rc = brmi_cull(p, 1, stream))) return rc;
     if ((rc = brmi_raster(p, 1, stream))) return rc;
+    if (p->cfg.enableOcclusionCulling) {
+        // reference graph: LinearDepthCopyPass1 -> LinearDepthDownsamplePass1 -> HierarchicalCullingPass2 -> ...RasterizeClustersPass2
+        // -> LinearDepthCopyPass2 -> LinearDepthDownsamplePass2 (CLodExtension.cpp:1920-2088)
+        if ((rc = brmi_depth_copy(p, stream))) return rc;
+        if ((rc = brmi_build_hzb(p, stream))) return rc;
+        if ((rc = brmi_cull(p, 2, stream))) return rc;
+        if ((rc = brmi_raster(p, 2, stream))) return rc;
+    }
     if ((rc = brmi_gbuffer(p, stream))) return rc;
+    if (p->cfg.enableOcclusionCulling && (rc = brmi_build_hzb(p, stream))) return rc;   // the G-buffer kernel wrote the final depth
     if ((rc = brmi_light_clustering(p, stream))) return rc;
     if ((rc = brmi_shade(p, stream))) return rc;
     return BRMI_OK;
@@ -362,6 +395,7 @@ int brmi_read_counters(brmi_pass* p, brmi_counters* out, brmi_stream stream) {
     out->droppedRecords = c[CNT_DROPPED_RECORDS]; out->droppedClusters = c[CNT_DROPPED_CLUSTERS]; out->lightPagesUsed = c[CNT_LIGHT_PAGES];
     out->reserved[0] = c[CNT_SUM_VERTS_LO]; out->reserved[1] = c[CNT_SUM_VERTS_HI]; out->reserved[2] = c[CNT_SUM_TRIS_LO]; out->reserved[3] = c[CNT_SUM_TRIS_HI];
     out->reserved[4] = c[CNT_RASTER_CLUSTERS]; out->reserved[5] = c[CNT_BIG_TRIS];
+    out->replayNodes = c[CNT_REPLAY_NODES]; out->replayMeshlets = c[CNT_REPLAY_MESHLETS];
     return BRMI_OK;
 }
 

@@ -25,6 +25,12 @@ struct CullArgs {
     const uint32_t* instanceBitBase;
     const uint32_t* segPrefix;
     uint32_t recordCapacity, visibleCapacity, factor, phase;
+    // occlusion culling: phase 1 tests against the previous frame's chain with the previous transforms and appends what it
+    // rejects to the replay buffers; phase 2 re-tests those against the chain of the depth phase 1 just rasterised
+    uint32_t occlusion;
+    uint32_t frontier0Counter, bucketCounter;   // counter words of the level-0 frontier and of the bucket array in use
+    NodeRecord* replayNodes; BucketRecord* replayBuckets;
+    HzbDesc hzb;
     // multi-GPU row band: two view-space planes through the eye bounding the band (1 = active)
     uint32_t bandActive; float bandTop[3], bandBottom[3];
 };
@@ -56,6 +62,61 @@ BRMI_DEV bool refined_child_suppresses(const brmi_scene_buffers& sc, uint32_t gr
     const float r = g->centerAndRadius[3] * scale;
     const float eod = projected_error(c, r, g->maxParentError, scale, camPos, zNear, ortho);
     return !(eod < threshold);   // resident: static frame
+}
+
+// ceil(log2(x)) clamped to [0, maxMip], evaluated on the float's bits (the oracle's definition: stable next to powers of two)
+BRMI_DEV uint32_t ceil_log2_clamped(float x, uint32_t maxMip) {
+    if (!(x > 1.0f)) return 0u;
+    const uint32_t u = __float_as_uint(x);
+    const uint32_t m = ((u >> 23) & 0xFFu) - 127u + ((u & 0x7FFFFFu) ? 1u : 0u);
+    return m < maxMip ? m : maxMip;
+}
+
+BRMI_DEV float hzb_load(const HzbDesc& h, uint32_t mip, uint32_t x, uint32_t y, uint32_t mipW) {
+    if (mip == 0u) return (x < h.width && y < h.height) ? h.depth[tiled_index(x, y, h.tilesX)] : __uint_as_float(BRMI_DEPTH_EMPTY_BITS);
+    return h.mips[h.mipOffset[mip] + (size_t)y * mipW + x];
+}
+
+// sphere_screen_extents (Misc/sphereScreenExtents.hlsli:14-31) + OcclusionCullingPerspectiveTexture2D
+// (occlusionCulling.hlsli:165-212): screen rectangle of the sphere -> mip whose texels cover it -> four point loads.
+BRMI_DEV bool occlusion_culled(const HzbDesc& hzb, const brmi_camera* cam, float p00, float p11, f3 centerVS, float sphereDepth, float radius) {
+    const float viewW = (float)cam->depthResX, viewH = (float)cam->depthResY;
+    const float px = centerVS.x, py = -centerVS.y, pz = centerVS.z;
+    const float rad2 = radius * radius, d = pz * radius;
+    const float hv = sqrtf(px * px + pz * pz - rad2);
+    const float ha = px * hv, hb = px * radius, hc = pz * hv;
+    float L = (ha - d) * p00 / (hc + hb);
+    float R = (ha + d) * p00 / (hc - hb);
+    const float vv = sqrtf(py * py + pz * pz - rad2);
+    const float va = py * vv, vb = py * radius, vc = pz * vv;
+    const float B = (va - d) * p11 / (vc + vb);
+    const float T = (va + d) * p11 / (vc - vb);
+    L = -L; R = -R;
+    const float u0 = sat(L * 0.5f + 0.5f), v0 = sat(T * -0.5f + 0.5f), u1 = sat(R * 0.5f + 0.5f), v1 = sat(B * -0.5f + 0.5f);
+    const float ax0 = u0 * viewW, ay0 = v0 * viewH, ax1 = u1 * viewW, ay1 = v1 * viewH;
+    const float ex = ax1 - ax0, ey = ay1 - ay0;
+    const uint32_t mip = ceil_log2_clamped(max2(ex, ey), cam->numDepthMips - 1u);
+    const float sx = cam->UVScaleToNextPowerOf2[0], sy = cam->UVScaleToNextPowerOf2[1];
+    const float pu0 = u0 * sx, pv0 = v0 * sy, pu1 = u1 * sx, pv1 = v1 * sy;
+    const float ssx = max2(sx, 1e-6f), ssy = max2(sy, 1e-6f);
+    uint32_t hzbW = (uint32_t)rintf(viewW / ssx), hzbH = (uint32_t)rintf(viewH / ssy);
+    hzbW = max(hzbW, 1u); hzbH = max(hzbH, 1u);
+    const uint32_t mw = max(hzbW >> mip, 1u), mh = max(hzbH >> mip, 1u);
+    const uint32_t x0 = min((uint32_t)floorf(pu0 * (float)mw), mw - 1u), y0 = min((uint32_t)floorf(pv0 * (float)mh), mh - 1u);
+    const uint32_t x1 = min((uint32_t)floorf(pu1 * (float)mw), mw - 1u), y1 = min((uint32_t)floorf(pv1 * (float)mh), mh - 1u);
+    if (mip >= hzb.mipCount) return false;
+    const float d0 = hzb_load(hzb, mip, x0, y0, mw), d1 = hzb_load(hzb, mip, x1, y0, mw), d2 = hzb_load(hzb, mip, x1, y1, mw), d3 = hzb_load(hzb, mip, x0, y1, mw);
+    const float mx = max2(max2(d0, d1), max2(d2, d3));
+    return mx < sphereDepth - radius;
+}
+
+// phase 1: previous frame's transforms (the chain is the previous frame's depth); phase 2 / replay: current ones
+BRMI_DEV bool occlusion_test(const CullArgs& a, const brmi_camera* cam, bool replay, f3 localCenter, float localRadius, f3 currentVS, float currentRadius,
+                             const brmi_per_object* obj) {
+    if (replay) return occlusion_culled(a.hzb, cam, cam->projection[0][0], cam->projection[1][1], currentVS, -currentVS.z, currentRadius);
+    const m4 prevModel = load_m4(&obj->prevModel[0][0]);
+    const f3 pc = to_view_space(localCenter, prevModel, load_m4(&cam->prevView[0][0]));
+    return occlusion_culled(a.hzb, cam, cam->prevUnjitteredProjection[0][0], cam->prevUnjitteredProjection[1][1], pc, -pc.z, localRadius * max_axis_scale(prevModel));
 }
 
 // Frame / object constants ------------------------------------------------------------------------
@@ -121,7 +182,7 @@ __global__ void __launch_bounds__(256) k_cull_instances(CullArgs a, NodeRecord* 
 // K2: one BFS level ------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_traverse(CullArgs a, uint32_t level, const NodeRecord* frontierIn, NodeRecord* frontierOut, BucketRecord* buckets) {
     const brmi_scene_buffers& sc = a.sc;
-    const uint32_t inputCount = min(a.counters[CNT_FRONTIER0 + level], a.recordCapacity);
+    const uint32_t inputCount = min(a.counters[level == 0 ? a.frontier0Counter : CNT_FRONTIER0 + level], a.recordCapacity);
     const uint32_t viewId = sc.perFrame->mainCameraIndex;
     const brmi_camera* cam = sc.cameras + viewId;
     const brmi_culling_camera* lodCam = sc.cullingCameras + viewId;
@@ -134,7 +195,8 @@ __global__ void __launch_bounds__(256) k_traverse(CullArgs a, uint32_t level, co
     for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < rounded; idx += gridDim.x * blockDim.x) {
         const bool have = idx < inputCount;
         // per-record state
-        bool isInternal = false, emitLeaf = false, replay = false;
+        bool isInternal = false, emitLeaf = false, replay = false, occluded = false;
+        uint32_t occludedNode = 0;
         uint32_t instIndex = 0, childBase = 0, childCount = 0, lodNodesBase = 0;
         uint32_t segFirst = 0, segCount = 0, ownerGroup = 0, slabDesc = 0, slabOff = 0, firstBit = 0;
         bool skinned = false;
@@ -183,11 +245,22 @@ __global__ void __launch_bounds__(256) k_traverse(CullArgs a, uint32_t level, co
                     const float lr = node.lodCenterAndRadius[3] * scale;
                     const float nodeEod = projected_error(lc, lr, node.maxQuadricError, scale, camPos, zNear, ortho);
                     if (allowRefine && (nodeEod >= threshold)) {
-                        isInternal = true;
-                        childBase = node.indexOrOffset;
-                        childCount = min(node.countMinusOne + 1u, BRMI_BVH_MAX_CHILDREN);
+                        if (a.occlusion && occlusion_test(a, cam, replay, cullC, cullR, cVS, rW, sc.perObject + inst.perObjectBufferIndex)) {
+                            occluded = !replay; occludedNode = nodeId;     // a node rejected in phase 2 is simply dropped
+                        } else {
+                            isInternal = true;
+                            childBase = node.indexOrOffset;
+                            childCount = min(node.countMinusOne + 1u, BRMI_BVH_MAX_CHILDREN);
+                        }
                     }
                 }
+            }
+        }
+        if (a.occlusion && a.phase == 1u) {   // hand the rejected node to phase 2 (workGraphCulling.hlsl:3094-3112: drop + count when full)
+            const uint32_t slot = wave_append(&a.counters[CNT_REPLAY_NODES], occluded);
+            if (occluded) {
+                if (slot < a.recordCapacity) a.replayNodes[slot] = NodeRecord{instIndex, 0x80000000u | (1u << 30) | (occludedNode & 0x3FFFFFFFu)};
+                else atomicAdd(&a.counters[CNT_DROPPED_RECORDS], 1u);
             }
         }
         // leaf: chunk the segment into bucket records of `factor` meshlets (computeCulling.hlsl:385-406)
@@ -199,7 +272,7 @@ __global__ void __launch_bounds__(256) k_traverse(CullArgs a, uint32_t level, co
             for (int o = 32; o > 0; o >>= 1) waveMax = max(waveMax, (uint32_t)__shfl_xor((int)waveMax, o));
             for (uint32_t k = 0; k < waveMax; k++) {
                 const bool emit = k < nChunks;
-                const uint32_t slot = wave_append(&a.counters[CNT_BUCKETS], emit);
+                const uint32_t slot = wave_append(&a.counters[a.bucketCounter], emit);
                 if (emit) {
                     if (slot < a.recordCapacity) {
                         const uint32_t first = segFirst + k * a.factor;
@@ -248,7 +321,7 @@ __global__ void __launch_bounds__(256) k_traverse(CullArgs a, uint32_t level, co
 // K3: per-meshlet cull ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_cull_clusters(CullArgs a, const BucketRecord* buckets, TempVisible* temp, uint32_t* bitmask) {
     const brmi_scene_buffers& sc = a.sc;
-    const uint32_t bucketCount = min(a.counters[CNT_BUCKETS], a.recordCapacity);
+    const uint32_t bucketCount = min(a.counters[a.bucketCounter], a.recordCapacity);
     const uint32_t viewId = sc.perFrame->mainCameraIndex;
     const brmi_camera* cam = sc.cameras + viewId;
     const brmi_culling_camera* lodCam = sc.cullingCameras + viewId;
@@ -261,9 +334,10 @@ __global__ void __launch_bounds__(256) k_cull_clusters(CullArgs a, const BucketR
     const uint64_t totalLanes = (uint64_t)bucketCount * a.factor;
     const uint64_t rounded = (totalLanes + 63ull) & ~63ull;
     for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < rounded; idx += (uint64_t)gridDim.x * blockDim.x) {
-        bool survives = false;
+        bool survives = false, occluded = false;
         uint4 packed = make_uint4(0, 0, 0, 0);
         uint32_t bit = 0;
+        BucketRecord again{};
         if (idx < totalLanes) {
             const uint32_t bi = (uint32_t)(idx / a.factor), m = (uint32_t)(idx % a.factor);
             const BucketRecord b = buckets[bi];
@@ -293,11 +367,27 @@ __global__ void __launch_bounds__(256) k_cull_clusters(CullArgs a, const BucketR
                         // tile-bounds test of the screen-tile split: conservative sphere vs the band's two planes
                         if (dot3(f3{a.bandTop[0], a.bandTop[1], a.bandTop[2]}, cVS) < -rW || dot3(f3{a.bandBottom[0], a.bandBottom[1], a.bandBottom[2]}, cVS) < -rW) survives = false;
                     }
+                    if (survives && a.occlusion &&
+                        occlusion_test(a, cam, replay, f3{bounds.x, bounds.y, bounds.z}, bounds.w, cVS, rW, sc.perObject + inst.perObjectBufferIndex)) {
+                        survives = false;
+                        if (!replay) {
+                            occluded = true;
+                            again = b; again.groupIdPacked = 0x80000000u | (b.groupIdPacked & 0x7FFFFFFFu);
+                            again.meshletIndexAndCount = (1u << 16) | (lm & 0xFFFFu); again.firstBit = b.firstBit + m;
+                        }
+                    }
                     if (survives) {
                         packed = pack_visible_cluster(viewId, b.instanceIndex, lm, b.groupIdPacked & 0x7FFFFFFFu, b.pageSlabDescriptorIndex, b.pageSlabByteOffset);
                         bit = b.firstBit + m;
                     }
                 }
+            }
+        }
+        if (a.occlusion && a.phase == 1u) {
+            const uint32_t rs = wave_append(&a.counters[CNT_REPLAY_MESHLETS], occluded);
+            if (occluded) {
+                if (rs < a.recordCapacity) a.replayBuckets[rs] = again;
+                else atomicAdd(&a.counters[CNT_DROPPED_RECORDS], 1u);
             }
         }
         const uint32_t slot = wave_append(tempCount, survives);
@@ -327,7 +417,7 @@ __global__ void __launch_bounds__(256) k_scan_reduce(const uint32_t* bitmask, ui
 }
 
 // single workgroup: exclusive scan of blockSums in place; total -> counters[outIndex] (clamped to capacity)
-__global__ void __launch_bounds__(1024) k_scan_blocks(uint32_t* blockSums, uint32_t nBlocks, uint32_t* counters, uint32_t outIndex, uint32_t capacity) {
+__global__ void __launch_bounds__(1024) k_scan_blocks(uint32_t* blockSums, uint32_t nBlocks, uint32_t* counters, uint32_t outIndex, uint32_t capacity, uint32_t usedIndex) {
     __shared__ uint32_t waveTotals[16];
     __shared__ uint32_t carry;
     if (threadIdx.x == 0) carry = 0;
@@ -348,7 +438,7 @@ __global__ void __launch_bounds__(1024) k_scan_blocks(uint32_t* blockSums, uint3
         if (threadIdx.x == 1023) carry = c + waveBase + incl;
         __syncthreads();
     }
-    if (threadIdx.x == 0) counters[outIndex] = min(carry, capacity);
+    if (threadIdx.x == 0) counters[outIndex] = min(carry, capacity - (usedIndex == 0xFFFFFFFFu ? 0u : min(counters[usedIndex], capacity)));
 }
 
 __global__ void __launch_bounds__(256) k_scan_words(const uint32_t* bitmask, uint32_t totalWords, const uint32_t* blockSums, uint32_t* wordPrefix) {
@@ -419,8 +509,18 @@ static inline uint32_t grid_for(uint64_t items, uint32_t block, uint32_t maxBloc
     return (uint32_t)g;
 }
 
+// phase 2 starts from the replay buffers: the replayed meshlets become the first bucket records, the replayed nodes the
+// level-0 frontier; per-level frontier counters start from zero
+__global__ void k_seed_phase2(uint32_t* counters, uint32_t capacity) {
+    const uint32_t t = threadIdx.x;
+    if (t == 0) { counters[CNT_REPLAY_NODES] = min(counters[CNT_REPLAY_NODES], capacity); counters[CNT_BUCKETS] = min(counters[CNT_REPLAY_MESHLETS], capacity); counters[CNT_TEMP_VISIBLE2] = 0; counters[CNT_VISIBLE2] = 0; }
+    if (t < CNT_WORDS - CNT_FRONTIER0) counters[CNT_FRONTIER0 + t] = 0;
+}
+
 int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
-    if (phase != 1) return fail(p, BRMI_ERR_INVALID, "brmi_cull: phase %u not available (occlusion phase 2 is not built yet)", phase);
+    if (phase != 1 && phase != 2) return fail(p, BRMI_ERR_INVALID, "brmi_cull: phase %u (1 or 2)", phase);
+    if (phase == 2 && !p->cfg.enableOcclusionCulling) return fail(p, BRMI_ERR_STATE, "brmi_cull: phase 2 needs a pass created with enableOcclusionCulling");
+    if (phase == 2 && !p->hzbValid) return fail(p, BRMI_ERR_STATE, "brmi_cull: phase 2 needs brmi_build_hzb on the phase-1 depth first");
     CullArgs a;
     a.sc = p->scene; a.counters = p->counters();
     a.instanceBitBase = p->wsPtr<uint32_t>(p->ws.instanceBitBase); a.segPrefix = p->wsPtr<uint32_t>(p->ws.segPrefix);
@@ -430,31 +530,45 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
     a.factor = f; a.phase = phase;
     a.bandActive = (p->bandY0 != 0 || p->bandY1 != p->cfg.height) ? 1u : 0u;
     for (int k = 0; k < 3; k++) { a.bandTop[k] = p->bandPlaneTop[k]; a.bandBottom[k] = p->bandPlaneBottom[k]; }
+    a.occlusion = (p->cfg.enableOcclusionCulling && p->hzbValid && p->camHost.isOrtho == 0) ? 1u : 0u;
+    a.replayNodes = p->wsPtr<NodeRecord>(p->ws.replayNodes); a.replayBuckets = p->wsPtr<BucketRecord>(p->ws.replayBuckets);
+    a.hzb = p->hzbDesc();
+    a.frontier0Counter = phase == 1 ? (uint32_t)CNT_FRONTIER0 : (uint32_t)CNT_REPLAY_NODES;
+    a.bucketCounter = CNT_BUCKETS;   // phase 2: seeded with the replayed meshlets, the bucket array is the replay buffer itself
     NodeRecord* fa = p->wsPtr<NodeRecord>(p->ws.frontierA); NodeRecord* fb = p->wsPtr<NodeRecord>(p->ws.frontierB);
-    BucketRecord* buckets = p->wsPtr<BucketRecord>(p->ws.buckets);
+    BucketRecord* buckets = phase == 1 ? p->wsPtr<BucketRecord>(p->ws.buckets) : a.replayBuckets;
     TempVisible* temp = p->wsPtr<TempVisible>(p->ws.tempVisible);
-    uint32_t* bitmask = p->wsPtr<uint32_t>(p->ws.bitmask1);
+    uint32_t* bitmask = p->wsPtr<uint32_t>(phase == 1 ? p->ws.bitmask1 : p->ws.bitmask2);
     uint32_t* wordPrefix = p->wsPtr<uint32_t>(p->ws.wordPrefix); uint32_t* blockSums = p->wsPtr<uint32_t>(p->ws.blockSums);
 
-    BRMI_HIP(p, hipMemsetAsync(p->counters(), 0, CNT_WORDS * sizeof(uint32_t), s));
-    BRMI_HIP(p, hipMemsetAsync(bitmask, 0, (size_t)p->totalWords * 4, s));
     const uint32_t maxBlocks = 1024;
-    hipLaunchKernelGGL(k_object_constants, dim3((std::max(1u, p->scene.perObjectCount) + 63) / 64), dim3(64), 0, s, p->scene, p->wsPtr<m4>(p->ws.frameConst), p->wsPtr<float>(p->ws.objConst));
-    hipLaunchKernelGGL(k_cull_instances, dim3(grid_for(p->scene.activeDrawCount, 256, maxBlocks)), dim3(256), 0, s, a, fa);
-    BRMI_LAUNCH_CHECK(p, "k_cull_instances");
+    if (phase == 1) {
+        BRMI_HIP(p, hipMemsetAsync(p->counters(), 0, CNT_WORDS * sizeof(uint32_t), s));
+        BRMI_HIP(p, hipMemsetAsync(bitmask, 0, (size_t)p->totalWords * 4, s));
+        hipLaunchKernelGGL(k_object_constants, dim3((std::max(1u, p->scene.perObjectCount) + 63) / 64), dim3(64), 0, s, p->scene, p->wsPtr<m4>(p->ws.frameConst), p->wsPtr<float>(p->ws.objConst));
+        hipLaunchKernelGGL(k_cull_instances, dim3(grid_for(p->scene.activeDrawCount, 256, maxBlocks)), dim3(256), 0, s, a, fa);
+        BRMI_LAUNCH_CHECK(p, "k_cull_instances");
+    } else {
+        BRMI_HIP(p, hipMemsetAsync(bitmask, 0, (size_t)p->totalWords * 4, s));
+        hipLaunchKernelGGL(k_seed_phase2, dim3(1), dim3(128), 0, s, p->counters(), a.recordCapacity);
+    }
     // frontier sizes are only known on the device: size the grids for the worst case that can matter
     const uint32_t travGrid = grid_for(std::min<uint64_t>(p->cfg.maxTraversalRecords, (uint64_t)p->scene.lodNodeCount * 4 + 4096), 256, maxBlocks);
     for (uint32_t level = 0; level < p->maxLevels; level++) {
-        hipLaunchKernelGGL(k_traverse, dim3(travGrid), dim3(256), 0, s, a, level, (level & 1u) ? fb : fa, (level & 1u) ? fa : fb, buckets);
+        // phase 2 reads level 0 from the replay buffer and then ping-pongs like phase 1 (level 0 writes fb)
+        const NodeRecord* in = level == 0 ? (phase == 1 ? fa : a.replayNodes) : ((level & 1u) ? fb : fa);
+        hipLaunchKernelGGL(k_traverse, dim3(travGrid), dim3(256), 0, s, a, level, in, (level & 1u) ? fa : fb, buckets);
         BRMI_LAUNCH_CHECK(p, "k_traverse");
     }
     hipLaunchKernelGGL(k_cull_clusters, dim3(maxBlocks), dim3(256), 0, s, a, buckets, temp, bitmask);
     BRMI_LAUNCH_CHECK(p, "k_cull_clusters");
     hipLaunchKernelGGL(k_scan_reduce, dim3(p->scanBlocks), dim3(256), 0, s, bitmask, p->totalWords, blockSums);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, blockSums, p->scanBlocks, p->counters(), (uint32_t)CNT_VISIBLE, p->cfg.maxVisibleClusters);
+    // phase 2 appends behind the phase-1 clusters: its capacity is what phase 1 left
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, blockSums, p->scanBlocks, p->counters(), (uint32_t)(phase == 1 ? CNT_VISIBLE : CNT_VISIBLE2),
+                       p->cfg.maxVisibleClusters, phase == 1 ? 0xFFFFFFFFu : (uint32_t)CNT_VISIBLE);
     hipLaunchKernelGGL(k_scan_words, dim3(p->scanBlocks), dim3(256), 0, s, bitmask, p->totalWords, blockSums, wordPrefix);
-    hipLaunchKernelGGL(k_scatter_visible, dim3(maxBlocks), dim3(256), 0, s, temp, p->counters(), (uint32_t)CNT_TEMP_VISIBLE, bitmask, wordPrefix,
-                       static_cast<uint4*>(p->res[BRMI_RES_VISIBLE_CLUSTERS]), 0xFFFFFFFFu, p->cfg.maxVisibleClusters, p->cfg.maxVisibleClusters, p->scene.slabs);
+    hipLaunchKernelGGL(k_scatter_visible, dim3(maxBlocks), dim3(256), 0, s, temp, p->counters(), (uint32_t)(phase == 1 ? CNT_TEMP_VISIBLE : CNT_TEMP_VISIBLE2), bitmask, wordPrefix,
+                       static_cast<uint4*>(p->res[BRMI_RES_VISIBLE_CLUSTERS]), phase == 1 ? 0xFFFFFFFFu : (uint32_t)CNT_VISIBLE, p->cfg.maxVisibleClusters, p->cfg.maxVisibleClusters, p->scene.slabs);
     BRMI_LAUNCH_CHECK(p, "compaction");
     return BRMI_OK;
 }

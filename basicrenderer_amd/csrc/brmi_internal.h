@@ -45,6 +45,15 @@ struct BucketRecord {                                                           
 };
 struct TempVisible { uint4 packed; uint32_t bit, pad0, pad1, pad2; };                // 32 B
 
+// Linear-depth mip chain as the occlusion test sees it.  Mip 0 is the tiled LinearDepthMap itself (texels outside
+// width x height read as "empty"), mips >= 1 are row-major arrays inside BRMI_RES_HZB at mipOffset[mip] floats.
+constexpr uint32_t kMaxHzbMips = 16;
+struct HzbDesc {
+    const float* depth; float* mips;
+    uint32_t width, height, tilesX, mipCount, paddedW, paddedH;
+    uint32_t mipOffset[kMaxHzbMips];
+};
+
 struct Workspace {     // byte offsets into BRMI_RES_WORKSPACE
     uint64_t counters, frontierA, frontierB, buckets, tempVisible, bitmask1, bitmask2, wordPrefix, blockSums,
              instanceBitBase, segPrefix, planes, replayNodes, replayBuckets, lightVS, lightMeta, clusterPages, bigTris, lutF, frameConst, objConst, matConst, deferredPixels, total;
@@ -70,7 +79,9 @@ struct brmi_pass {
     uint32_t bigTriCapacity = 1u << 20;
     int bigTriArea = 128;
     int rasterMode = 0;          // BRMI_RASTER_MODE: 0 atomic min (product), 3 read-then-atomic; 1/2 are bandwidth experiments
-    uint32_t hzbMipCount = 0; std::vector<uint64_t> hzbMipOffsets; std::vector<uint32_t> hzbMipW, hzbMipH;
+    uint32_t hzbMipCount = 0; std::vector<uint64_t> hzbMipOffsets; std::vector<uint32_t> hzbMipW, hzbMipH;   // [mip]; offsets in floats, mip 0 unused
+    bool hzbValid = false;       // a chain built from a finished frame exists (phase 1 of the next frame tests against it)
+    brmi::HzbDesc hzbDesc() const;
     std::vector<uint32_t> hostInstanceBitBase, hostSegPrefix;
     brmi::Workspace ws{};
     brmi_camera camHost{};

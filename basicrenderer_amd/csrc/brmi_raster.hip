@@ -327,10 +327,16 @@ int launch_clear(brmi_pass* p, hipStream_t s) {
 }
 
 int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
-    if (phase != 1) return fail(p, BRMI_ERR_INVALID, "brmi_raster: phase %u not available", phase);
+    if (phase != 1 && phase != 2) return fail(p, BRMI_ERR_INVALID, "brmi_raster: phase %u (1 or 2)", phase);
+    if (phase == 2 && !p->cfg.enableOcclusionCulling) return fail(p, BRMI_ERR_STATE, "brmi_raster: phase 2 needs a pass created with enableOcclusionCulling");
     RasterArgs a;
     a.sc = p->scene; a.clusters = static_cast<const uint4*>(p->res[BRMI_RES_VISIBLE_CLUSTERS]); a.counters = p->counters();
     a.firstCounter = 0xFFFFFFFFu; a.countCounter = CNT_VISIBLE;
+    if (phase == 2) {   // clusters [visible1, visible1 + visible2); the big-triangle queue starts empty again
+        a.firstCounter = CNT_VISIBLE; a.countCounter = CNT_VISIBLE2;
+        static_assert(CNT_BIG_TRIS_WIDE == CNT_BIG_TRIS + 1, "queue counters are cleared together");
+        BRMI_HIP(p, hipMemsetAsync(p->counters() + CNT_BIG_TRIS, 0, 2 * sizeof(uint32_t), s));
+    }
     a.queue = p->counters() + CNT_WORDS;   // one spare word after the counters block
     a.vis = static_cast<unsigned long long*>(p->res[BRMI_RES_VISIBILITY]);
     a.visW = p->cfg.width; a.visH = p->cfg.height; a.tilesX = p->tilesX; a.bandY0 = p->bandY0; a.bandY1 = p->bandY1;

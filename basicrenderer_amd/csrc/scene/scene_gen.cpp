@@ -677,8 +677,17 @@ void setCamera(brmi_scene& sc, V3 eye, double yaw, double pitch, double fovDeg, 
     const uint32_t W = sc.params.width, H = sc.params.height;
     const double fov = fovDeg * (M_PI / 180.0), aspect = (double)W / (double)H;
     // camera world transform (row-vector): rotate then translate ; view = inverse
-    M4 world = mul(mul(rotationX(pitch), rotationY(yaw)), translation(eye));
+    // camera path for multi-frame tests: every step strafes, advances and turns a little; prevView = view of the previous step
+    auto worldAt = [&](uint32_t step) {
+        const double k = (double)step;
+        const V3 e{eye.x + 0.35 * k, eye.y + 0.05 * k, eye.z - 0.6 * k};
+        return mul(mul(rotationX(pitch), rotationY(yaw + 0.07 * k)), translation(e));
+    };
+    const uint32_t step = sc.params.cameraStep;
+    { const double k = (double)step; eye = V3{eye.x + 0.35 * k, eye.y + 0.05 * k, eye.z - 0.6 * k}; }
+    M4 world = worldAt(step);
     M4 view = inverse(world);
+    M4 prevView = step > 0 ? inverse(worldAt(step - 1)) : view;
     // XMMatrixPerspectiveFovRH(fov, aspect, NearZ = zFar, FarZ = zNear): reversed Z
     M4 proj{};
     const double h = std::cos(0.5 * fov) / std::sin(0.5 * fov), w = h / aspect;
@@ -688,7 +697,7 @@ void setCamera(brmi_scene& sc, V3 eye, double yaw, double pitch, double fovDeg, 
     std::memset(&c, 0, sizeof(c));
     c.positionWorldSpace[0] = (float)eye.x; c.positionWorldSpace[1] = (float)eye.y; c.positionWorldSpace[2] = (float)eye.z; c.positionWorldSpace[3] = 1.0f;
     store(c.view, view); store(c.viewInverse, world); store(c.projection, proj); store(c.projectionInverse, inverse(proj));
-    store(c.viewProjection, mul(view, proj)); store(c.prevView, view); store(c.prevJitteredProjection, proj);
+    store(c.viewProjection, mul(view, proj)); store(c.prevView, prevView); store(c.prevJitteredProjection, proj);
     store(c.prevUnjitteredProjection, proj); store(c.unjitteredProjection, proj);
     // BR/src/Utilities/Utilities.cpp:1840-1868: near, far, left, right, bottom, top (view space, normalised)
     const double t = std::tan(fov / 2.0);

@@ -90,8 +90,17 @@ class VisibilityRenderer:
             msg = self.lib.brmi_last_error(self._h).decode() if use_pass and self._h else ""
             raise BrmiError(f"{what} failed ({rc}): {msg}")
 
+    def set_camera_from(self, other, frame_index=0):
+        """Next frame's camera: copy `other`'s camera / culling-camera buffers (same geometry, another camera step) into
+        the device buffers the pass reads -- what the reference's CameraManager does between frames -- then brmi_update."""
+        for name in ("cameras", "cullingCameras"):
+            self.scene.device_arrays[name].copy_(self.torch.from_numpy(other.arrays[name]).to(self.device))
+        self._cam_scene = other
+        self.update(frame_index)
+
     def update(self, frame_index=0):
-        cam, pf = self.scene.camera_host(), self.scene.per_frame_host()
+        src = getattr(self, "_cam_scene", self.scene)
+        cam, pf = src.camera_host(), src.per_frame_host()
         upd = capi.FrameUpdate(cam.ctypes.data, pf.ctypes.data, frame_index)
         self._check(self.lib.brmi_update(self._h, C.byref(upd), self._s()), "brmi_update")
 
@@ -143,10 +152,27 @@ class VisibilityRenderer:
                     motion=self._img("GBUF_MOTION_VECTORS", np.uint32))
 
     def visible_clusters(self):
-        n = self.counters().visibleClusters
+        c = self.counters()
+        n = c.visibleClusters + c.visibleClustersPhase2
         self.torch.cuda.synchronize(self.device)
         raw = self.res[capi.RES["VISIBLE_CLUSTERS"]][: n * 16].cpu().numpy()
         return raw.view(np.uint32).reshape(n, 4)
+
+    def invalidate_hzb(self):
+        self._check(self.lib.brmi_invalidate_hzb(self._h), "brmi_invalidate_hzb")
+
+    def hzb_mips(self):
+        """Mips >= 1 of the linear-depth chain as row-major arrays (mip 0 is depth() padded to a power of two)."""
+        self.torch.cuda.synchronize(self.device)
+        raw = self.res[capi.RES["HZB"]].cpu().numpy().view(np.float32)
+        pw, ph = 1 << (self.W - 1).bit_length(), 1 << (self.H - 1).bit_length()
+        out, off, mip = [], 0, 1
+        while pw > 1 or ph > 1:
+            pw, ph = max(1, pw >> 1), max(1, ph >> 1)
+            out.append(raw[off: off + pw * ph].reshape(ph, pw))
+            off += pw * ph
+            mip += 1
+        return out
 
     def light_clusters(self):
         self.torch.cuda.synchronize(self.device)

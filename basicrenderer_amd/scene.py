@@ -32,7 +32,7 @@ _FIELD_MAP = [
 
 class Scene:
     def __init__(self, preset="sponza", width=3840, height=2160, seed=0, point_lights=64, directional=True,
-                 lod_levels=0, size_scale=1.0, material_features=0):
+                 lod_levels=0, size_scale=1.0, material_features=0, camera_step=0):
         lib = capi.scene_lib()
         p = capi.SceneParams()
         p.preset = PRESETS[preset] if isinstance(preset, str) else int(preset)
@@ -40,6 +40,7 @@ class Scene:
         p.numPointLights, p.withDirectionalLight = point_lights, 1 if directional else 0
         p.lodLevels, p.sizeScale = lod_levels, size_scale
         p.materialFeatures = material_features
+        p.cameraStep = camera_step
         self.preset, self.width, self.height = preset, width, height
         self._lib = lib
         self._h = lib.brmi_scene_create(C.byref(p))
@@ -111,8 +112,12 @@ class Scene:
             if s is not None:
                 ptrs[i] = up(s)
         sb.slabs, sb.slabCount = up(ptrs.view(np.uint8)), len(self.slabs)
+        self.device_arrays = {}
         for field, arr, cnt in _FIELD_MAP:
+            n = len(keep)
             setattr(sb, field, up(self.arrays[arr]))
+            if len(keep) > n:
+                self.device_arrays[arr] = keep[-1]      # the camera manager's role in tests: rewrite a buffer in place
             if cnt:
                 setattr(sb, cnt, self.counts[arr])
         return sb, keep

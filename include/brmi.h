@@ -147,6 +147,7 @@ typedef struct brmi_counters {
     uint32_t meshletsTested, visibleClusters, visibleClustersPhase2;
     uint32_t droppedRecords, droppedClusters;
     uint32_t lightPagesUsed;
+    uint32_t replayNodes, replayMeshlets;   /* occluded in phase 1, re-tested in phase 2 */
     uint32_t reserved[6];
 } brmi_counters;
 
@@ -174,7 +175,9 @@ int brmi_clear_visibility(brmi_pass* pass, brmi_stream stream);   /* ClearVisibi
 int brmi_cull(brmi_pass* pass, uint32_t phase, brmi_stream stream);       /* HierarchicalCullingPass1/2 (K1-K3) */
 int brmi_raster(brmi_pass* pass, uint32_t phase, brmi_stream stream);     /* SoftwareRasterizeClustersPass1/2 (K5) */
 int brmi_depth_copy(brmi_pass* pass, brmi_stream stream);         /* LinearDepthCopyPass (K6) */
-int brmi_build_hzb(brmi_pass* pass, brmi_stream stream);          /* LinearDepthDownsamplePass */
+int brmi_build_hzb(brmi_pass* pass, brmi_stream stream);          /* LinearDepthDownsamplePass (SPD max-reduce; BR/shaders/downsample.hlsl) */
+/* Drops the previous frame's depth chain (camera cut, resize): the next phase 1 runs without occlusion tests. */
+int brmi_invalidate_hzb(brmi_pass* pass);
 int brmi_gbuffer(brmi_pass* pass, brmi_stream stream);            /* MaterialHistogram..EvaluateMaterialGroups (K7,K8) */
 int brmi_light_clustering(brmi_pass* pass, brmi_stream stream);   /* ClusterGenerationPass + LightCullingPass (K9,K10) */
 int brmi_shade(brmi_pass* pass, brmi_stream stream);              /* DeferredShadingPass (K11) */

@@ -37,7 +37,8 @@ typedef struct brmi_scene_params {
     float    sizeScale;           /* 1.0 = preset default triangle budget; <1 shrinks (tests) */
     uint32_t skinnedFraction1024; /* fraction (x/1024) of instances that are skinned; 0 = none */
     uint32_t materialFeatures;    /* bit 0: some materials carry an OpenPBR coat, bit 1: some carry fuzz (default: neither) */
-    uint32_t reserved[6];
+    uint32_t cameraStep;          /* frame number on the preset's camera path (0 = start); prevView is the view of step - 1 */
+    uint32_t reserved[5];
 } brmi_scene_params;
 
 /* Arrays a scene exposes.  Element layouts are the brmi_types.h structs. */

@@ -57,6 +57,16 @@ static bool refinedChildSuppressesParent(const brmi_scene_buffers& sc, uint32_t 
     return true;   // resident
 }
 
+// ceil(log2(x)) clamped to [0, maxMip], evaluated exactly on the float's bits.  The shader calls log2(), whose
+// last-bit behaviour next to powers of two differs between GPUs and libm; the exact value is the stable definition.
+static uint32_t ceilLog2Clamped(float x, uint32_t maxMip) {
+    if (!(x > 1.0f)) return 0;                       // log2 <= 0 (and NaN / -inf) clamp to mip 0
+    const uint32_t u = asuint(x);
+    const int e = (int)((u >> 23) & 0xFFu) - 127;
+    const uint32_t m = (uint32_t)e + ((u & 0x7FFFFFu) ? 1u : 0u);
+    return m < maxMip ? m : maxMip;
+}
+
 // sphere_screen_extents + OcclusionCullingPerspectiveTexture2D (explicit-parameter overload)
 static bool occlusionCulled(const HzbView& hzb, const brmi_camera& cam, const mat4& proj, float3 centerVS, float sphereDepth, float radius) {
     const float viewW = (float)cam.depthResX, viewH = (float)cam.depthResY, mips = (float)cam.numDepthMips;
@@ -75,12 +85,10 @@ static bool occlusionCulled(const HzbView& hzb, const brmi_camera& cam, const ma
     float u0 = saturate(L * 0.5f + 0.5f), v0 = saturate(T * -0.5f + 0.5f), u1 = saturate(R * 0.5f + 0.5f), v1 = saturate(B * -0.5f + 0.5f);
     float ax0 = u0 * viewW, ay0 = v0 * viewH, ax1 = u1 * viewW, ay1 = v1 * viewH;
     float ex = ax1 - ax0, ey = ay1 - ay0;
-    float fMip = std::ceil(std::log2(fmax2(ex, ey)));
-    fMip = clampf(fMip, 0.0f, mips - 1.0f);
+    const uint32_t mip = ceilLog2Clamped(fmax2(ex, ey), (uint32_t)mips - 1u);
     const float sx = cam.UVScaleToNextPowerOf2[0], sy = cam.UVScaleToNextPowerOf2[1];
     float pu0 = u0 * sx, pv0 = v0 * sy, pu1 = u1 * sx, pv1 = v1 * sy;
     const float ssx = fmax2(sx, 1e-6f), ssy = fmax2(sy, 1e-6f);
-    const uint32_t mip = (uint32_t)fMip;
     uint32_t hzbW = (uint32_t)std::nearbyint(viewW / ssx), hzbH = (uint32_t)std::nearbyint(viewH / ssy);
     hzbW = hzbW < 1 ? 1 : hzbW; hzbH = hzbH < 1 ? 1 : hzbH;
     uint32_t mw = hzbW >> mip, mh = hzbH >> mip; mw = mw < 1 ? 1 : mw; mh = mh < 1 ? 1 : mh;
@@ -114,6 +122,34 @@ typedef struct orc_cull_params {
     uint32_t* replayNodes;   uint32_t replayNodeCapacity;   uint32_t* replayNodeCount;      // (inst,node) pairs
     uint32_t* replayMeshlets; uint32_t replayMeshletCapacity; uint32_t* replayMeshletCount; // (inst,seg,localMeshlet,group) quads
 } orc_cull_params;
+
+// Linear-depth mip chain used by the occlusion test: mip 0 = the depth map padded to the next power of two
+// (padding = "empty", 0x7F7FFFFF, so it never occludes), each further mip the max of 2x2 texels
+// (SpdReduce4 in BR/shaders/downsample.hlsl:108-112).  Returns the float count written.
+uint64_t orc_build_hzb(const float* depth, uint32_t W, uint32_t H, float* out, uint64_t* mipOffsets, uint32_t* mipCountOut) {
+    uint32_t pw = 1, ph = 1; while (pw < W) pw <<= 1; while (ph < H) ph <<= 1;
+    uint64_t off = 0; uint32_t mip = 0; uint32_t w = pw, h = ph;
+    const float empty = asfloat(BRMI_DEPTH_EMPTY_BITS);
+    for (;;) {
+        mipOffsets[mip] = off;
+        float* dst = out + off;
+        if (mip == 0) {
+            for (uint32_t y = 0; y < h; y++) for (uint32_t x = 0; x < w; x++) dst[(uint64_t)y * w + x] = (x < W && y < H) ? depth[(uint64_t)y * W + x] : empty;
+        } else {
+            const float* src = out + mipOffsets[mip - 1];
+            uint32_t sw = pw >> (mip - 1), sh = ph >> (mip - 1); sw = sw < 1 ? 1 : sw; sh = sh < 1 ? 1 : sh;
+            for (uint32_t y = 0; y < h; y++) for (uint32_t x = 0; x < w; x++) {
+                const uint32_t x0 = x * 2 < sw ? x * 2 : sw - 1, x1 = x * 2 + 1 < sw ? x * 2 + 1 : sw - 1, y0 = y * 2 < sh ? y * 2 : sh - 1, y1 = y * 2 + 1 < sh ? y * 2 + 1 : sh - 1;
+                dst[(uint64_t)y * w + x] = fmax2(fmax2(src[(uint64_t)y0 * sw + x0], src[(uint64_t)y0 * sw + x1]), fmax2(src[(uint64_t)y1 * sw + x0], src[(uint64_t)y1 * sw + x1]));
+            }
+        }
+        off += (uint64_t)w * h; mip++;
+        if (w == 1 && h == 1) break;
+        w = w > 1 ? w >> 1 : 1; h = h > 1 ? h >> 1 : 1;
+    }
+    *mipCountOut = mip;
+    return off;
+}
 
 // Returns the number of visible clusters written (canonical order).  `scene` holds HOST pointers.
 int orc_cull(const brmi_scene_buffers* scp, const orc_cull_params* prm, brmi_visible_cluster* out, uint32_t* outCount, brmi_counters* counters) {

@@ -50,13 +50,59 @@ class OracleFrame:
         self.counters = capi.Counters()
 
     def cull(self, phase=1, occlusion=False, hzb=None, expansion=2):
+        """phase 1: clusters [0, n1).  phase 2: replays what phase 1 found occluded and appends its survivors at [n1, n1+n2).
+        `hzb` = (data, mipOffsets, mipCount) from build_hzb(); phase 1 tests against the previous frame's chain."""
         prm = CullParams()
-        prm.phase, prm.enableOcclusion, prm.phase2ExpansionFactor, prm.capacity = phase, 1 if occlusion else 0, expansion, self.capacity
+        prm.phase, prm.enableOcclusion, prm.phase2ExpansionFactor = phase, 1 if (occlusion and hzb is not None) else 0, expansion
+        if not hasattr(self, "replay_nodes"):
+            cap = 1 << 20
+            self.replay_nodes, self.replay_meshlets = np.zeros((cap, 2), dtype=np.uint32), np.zeros((cap, 4), dtype=np.uint32)
+            self.n_replay_nodes, self.n_replay_meshlets = u32(0), u32(0)
+        if phase == 1:
+            self.n_replay_nodes.value = 0
+            self.n_replay_meshlets.value = 0
+            self.count = 0
+        if hzb is not None:
+            prm.hzbData, prm.hzbMipOffsets, prm.hzbMipCount = P(hzb[0]), P(hzb[1]), hzb[2]
+        prm.replayNodes, prm.replayNodeCapacity, prm.replayNodeCount = P(self.replay_nodes), len(self.replay_nodes), C.addressof(self.n_replay_nodes)
+        prm.replayMeshlets, prm.replayMeshletCapacity, prm.replayMeshletCount = P(self.replay_meshlets), len(self.replay_meshlets), C.addressof(self.n_replay_meshlets)
+        first = 0 if phase == 1 else self.count
+        prm.capacity = self.capacity - first
         n = u32(0)
-        rc = lib().orc_cull(C.byref(self.sb), C.byref(prm), P(self.clusters), C.byref(n), C.byref(self.counters))
+        cnt = capi.Counters()
+        rc = lib().orc_cull(C.byref(self.sb), C.byref(prm), P(self.clusters[first:]), C.byref(n), C.byref(cnt))
         assert rc == 0
-        self.count = n.value
+        if phase == 1:
+            self.counters, self.count1 = cnt, n.value
+        else:
+            self.counters2, self.count2 = cnt, n.value
+        self.count = first + n.value
         return self.clusters[: self.count]
+
+    def build_hzb(self):
+        """Mip chain (mip 0 = depth padded to a power of two) of the current linear depth map."""
+        pw, ph = 1 << (self.W - 1).bit_length(), 1 << (self.H - 1).bit_length()
+        data = np.zeros(pw * ph * 2, dtype=np.float32)
+        offs = np.zeros(32, dtype=np.uint64)
+        n = u32(0)
+        lib().orc_build_hzb.restype = u64
+        lib().orc_build_hzb(P(self.depth), u32(self.W), u32(self.H), P(data), P(offs), C.byref(n))
+        self.hzb = (data, offs, n.value)
+        return self.hzb
+
+    def run_occlusion(self, prev_hzb=None):
+        """One frame of the 2-phase chain: cull1 (vs previous HZB) -> raster1 -> depth -> HZB -> cull2 -> raster2 -> depth -> HZB."""
+        if hasattr(self, "vis"):
+            del self.vis
+        self.cull(phase=1, occlusion=True, hzb=prev_hzb)
+        self.raster()
+        self.depth_copy()
+        mid = self.build_hzb()
+        n1 = self.count
+        self.cull(phase=2, occlusion=True, hzb=mid)
+        self.raster(first=n1, count=self.count - n1)
+        self.depth_copy()
+        return self.build_hzb()
 
     def raster(self, band=(0, 0), first=0, count=None):
         W, H = self.W, self.H

@@ -245,3 +245,116 @@ def test_cpp_host_passes_reproduce_the_python_frame(scenes):
         raw = r.res[capi.RES[rid]].cpu().numpy()[: r.descs[capi.RES[rid]]["bytes"]]
         assert fnv(raw) == got[key], key
     r.close()
+
+
+# ---- 2-phase HZB occlusion culling -----------------------------------------------------------
+OCCLUSION_CASES = {
+    # name: (preset, W, H, kwargs) -- rendered for camera steps 0, 1, 2 so that phase 1 tests against a reprojected chain
+    "sponza": ("sponza", 640, 360, dict(point_lights=8, size_scale=0.25)),
+    "bistro": ("bistro", 640, 360, dict(point_lights=8, size_scale=0.3)),
+    "tiny_odd": ("tiny", 200, 120, dict(point_lights=2)),          # non-power-of-two, non-tile-multiple target
+}
+
+
+@pytest.fixture(scope="module")
+def occlusion_runs():
+    """GPU and oracle driven through the same three frames of a camera path with occlusion culling on."""
+    import orc
+    from basicrenderer_amd import Scene
+    from basicrenderer_amd.renderer import VisibilityRenderer
+    cache = {}
+
+    def get(name):
+        if name in cache:
+            return cache[name]
+        preset, W, H, kw = OCCLUSION_CASES[name]
+        frames, hz, r = [], None, None
+        for step in range(3):
+            sc = Scene(preset, W, H, camera_step=step, **kw)
+            if r is None:
+                r = VisibilityRenderer(sc, occlusion=True, stats=True)
+            else:
+                r.set_camera_from(sc, frame_index=step)
+            r.execute()
+            o = orc.OracleFrame(sc)
+            prev = hz
+            hz = o.run_occlusion(prev)
+            ref = orc.OracleFrame(sc)                  # the same frame without occlusion culling
+            ref.cull(); ref.raster()
+            frames.append(dict(scene=sc, oracle=o, ref=ref, counters=r.counters(), clusters=r.visible_clusters().copy(), vis=r.visibility(), depth=r.depth(),
+                               hzb=[m.copy() for m in r.hzb_mips()], hdr=r.hdr(), had_prev=prev is not None))
+        r.close()
+        cache[name] = frames
+        return frames
+
+    return get
+
+
+@pytest.mark.parametrize("name", list(OCCLUSION_CASES))
+def test_occlusion_two_phase_cluster_lists_exact(name, occlusion_runs):
+    frames = occlusion_runs(name)
+    replayed = 0
+    for i, f in enumerate(frames):
+        o, c = f["oracle"], f["counters"]
+        assert c.droppedRecords == 0 and c.droppedClusters == 0
+        assert (c.visibleClusters, c.visibleClustersPhase2) == (o.count1, o.count2), f"frame {i}"
+        assert (c.replayNodes, c.replayMeshlets) == (o.n_replay_nodes.value, o.n_replay_meshlets.value), f"frame {i}"
+        assert c.nodesVisited == o.counters.nodesVisited + o.counters2.nodesVisited
+        assert c.meshletsTested == o.counters.meshletsTested + o.counters2.meshletsTested
+        assert np.array_equal(f["clusters"], o.clusters[: o.count]), f"frame {i}"
+        replayed += c.replayNodes + c.replayMeshlets
+        if i == 0:
+            assert c.replayNodes == 0 and c.replayMeshlets == 0      # no previous chain: phase 1 runs untested
+    if name != "tiny_odd":
+        assert replayed > 0, "the case does not exercise the replay path"
+
+
+@pytest.mark.parametrize("name", list(OCCLUSION_CASES))
+def test_occlusion_hzb_chain_bit_exact(name, occlusion_runs):
+    for f in occlusion_runs(name):
+        o = f["oracle"]
+        data, offs, n = o.hzb
+        pw, ph = 1 << (o.W - 1).bit_length(), 1 << (o.H - 1).bit_length()
+        assert len(f["hzb"]) == n - 1
+        assert np.array_equal(f["depth"].view(np.uint32), o.depth.view(np.uint32))
+        for mip in range(1, n):
+            w, h = max(1, pw >> mip), max(1, ph >> mip)
+            ref = data[int(offs[mip]): int(offs[mip]) + w * h].reshape(h, w)
+            assert np.array_equal(f["hzb"][mip - 1].view(np.uint32), ref.view(np.uint32)), f"mip {mip}"
+
+
+@pytest.mark.parametrize("name", list(OCCLUSION_CASES))
+def test_occlusion_does_not_change_the_image(name, occlusion_runs):
+    """Occlusion culling is conservative: same triangles win every pixel as without it (cluster indices differ, identities don't)."""
+    import orc
+    for i, f in enumerate(occlusion_runs(name)):
+        o, ref = f["oracle"], f["ref"]
+        assert np.array_equal(f["vis"], o.vis), f"frame {i}: visibility keys differ from the oracle's 2-phase frame"
+        got = orc.canonical_ids(f["vis"], f["clusters"])
+        want = orc.canonical_ids(ref.vis, ref.clusters[: ref.count])
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b), f"frame {i}"
+
+
+def test_occlusion_static_camera_culls_hidden_clusters_at_4k():
+    """Bistro-class street at full size: the second frame must rasterise fewer clusters and produce the same HDR bytes."""
+    from basicrenderer_amd import Scene
+    from basicrenderer_amd.renderer import VisibilityRenderer
+    sc = Scene("bistro", 3840, 2160, point_lights=256)
+    base = VisibilityRenderer(sc, stats=True)
+    base.execute()
+    hdr0, n0 = base.hdr(), base.counters().visibleClusters
+    base.close()
+    r = VisibilityRenderer(sc, occlusion=True, stats=True)
+    r.execute()
+    c = r.counters()
+    assert c.visibleClusters == n0 and c.visibleClustersPhase2 == 0
+    assert np.array_equal(r.hdr(), hdr0)
+    r.execute()
+    c = r.counters()
+    assert c.visibleClusters + c.visibleClustersPhase2 < n0 * 0.8, (c.visibleClusters, c.visibleClustersPhase2, n0)
+    assert np.array_equal(r.hdr(), hdr0)
+    r.invalidate_hzb()
+    r.execute()
+    assert r.counters().visibleClusters == n0
+    r.close()
