@@ -431,6 +431,12 @@ int brmi_algorithmic_bytes(brmi_pass* p, uint64_t* perStage, uint64_t* total) {
     perStage[BRMI_STAGE_CLEAR] = 8 * P;
     perStage[BRMI_STAGE_CULL] = 64ull * c.meshletsTested + 16ull * (c.visibleClusters + c.visibleClustersPhase2) + 64ull * c.nodesVisited;
     perStage[BRMI_STAGE_RASTER] = 8 * P + 144ull * nClusters + 12ull * sumV + 3ull * sumT;
+    if (p->cfg.enableOcclusionCulling) {
+        // depth copy: 8 B key in, 4 B depth out; chain: every depth texel read once, 1/3 of that written, built twice per frame;
+        // phase-2 cull / raster traffic is counted in the cull / raster rows (their counters accumulate over both phases)
+        perStage[BRMI_STAGE_DEPTH_COPY] = 12 * P;
+        perStage[BRMI_STAGE_HZB] = 2 * (4 * P + 4 * P / 3);
+    }
     perStage[BRMI_STAGE_GBUFFER] = (8 + 52 + 4) * P;
     perStage[BRMI_STAGE_SHADE] = (4 + 48 + 8) * P;
     *total = 0; for (int i = 0; i < BRMI_STAGE_COUNT; i++) *total += perStage[i];

@@ -644,15 +644,32 @@ BRMI_DEV ShadeFrame make_shade_frame(const ShadeArgs& a) {
 // layer factors are exactly 1 / 0); it returns false for any other pixel, which is then shaded by the GENERAL
 // kernel from a deferred list -- the same idea as the reference's per-material-permutation pixel lists
 // (VisUtil.hlsl), applied to register pressure: the specialised kernel needs half the VGPRs.
+// the G-buffer words of one pixel, as stored
+struct RawPixel { float d; float4 ns; uint32_t al, mr; unsigned long long cs, es, fs; };
+BRMI_DEV RawPixel load_raw_pixel(const ShadeArgs& a, uint64_t i) {
+    RawPixel r;
+    r.d = a.depth[i]; r.ns = a.normals[i]; r.al = a.albedo[i]; r.mr = a.metallicRoughness[i]; r.cs = a.coat[i]; r.es = a.emissive[i]; r.fs = a.fuzz[i];
+    return r;
+}
+BRMI_DEV RawPixel empty_raw_pixel() { RawPixel r{}; r.d = as_f32(BRMI_DEPTH_EMPTY_BITS); return r; }
+
+// what the specialised kernel keeps in flight for the next tile: coat / fuzz words reduced to the coat weight
+BRMI_DEV RawPixel load_raw_pixel_plain(const ShadeArgs& a, uint64_t i) {
+    RawPixel r;
+    r.d = a.depth[i]; r.ns = a.normals[i]; r.al = a.albedo[i]; r.mr = a.metallicRoughness[i]; r.es = a.emissive[i];
+    r.cs = (unsigned long long)reinterpret_cast<const uint16_t*>(a.coat)[i * 4u + 3u] << 48; r.fs = 0ull;   // coat weight only (a plain pixel has no other coat / fuzz input)
+    return r;
+}
+
 template <bool GENERAL>
-BRMI_DEV bool shade_pixel(const ShadeArgs& a, const ShadeFrame& k, uint64_t i, uint32_t px, uint32_t py) {
+BRMI_DEV bool shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const RawPixel& raw, uint64_t i, uint32_t px, uint32_t py) {
     const brmi_scene_buffers& sc = a.sc;
     const Luts& L = k.L;
     const uint32_t gx = k.gx, gy = k.gy, gz = k.gz, nearSlices = k.nearSlices, numLights = k.numLights;
     const m4& invProj = k.invProj; const m4& viewInv = k.viewInv; const f3 camPos = k.camPos;
     const float zNear = k.zNear, zSplit = k.zSplit, resX = k.resX, resY = k.resY, tsx = k.tsx, tsy = k.tsy, logStart = k.logStart, logEnd = k.logEnd, om5 = k.om5, om6 = k.om6;
     (void)gy;
-        const float d = a.depth[i];
+        const float d = raw.d;
         if (as_u32(d) == BRMI_DEPTH_EMPTY_BITS) return true;
         float uvx = ((float)px + 0.5f) / resX, uvy = ((float)py + 0.5f) / resY;
         uvy = 1.0f - uvy;
@@ -665,10 +682,10 @@ BRMI_DEV bool shade_pixel(const ShadeArgs& a, const ShadeFrame& k, uint64_t i, u
         // GetFragmentInfoScreenSpace + PopulateFragmentInfoFromOpenPBR
         Frag f;
         f.posWS = posWS; f.viewWS = viewDir;
-        const float4 ns = a.normals[i];
+        const float4 ns = raw.ns;
         const f3 nrm{ns.x, ns.y, ns.z};
-        const uint32_t al = a.albedo[i], mr = a.metallicRoughness[i];
-        const unsigned long long cs = a.coat[i], es = a.emissive[i], fs = a.fuzz[i];
+        const uint32_t al = raw.al, mr = raw.mr;
+        const unsigned long long cs = raw.cs, es = raw.es, fs = raw.fs;
         const f3 baseColor{L.unorm8[al & 0xFFu], L.unorm8[(al >> 8) & 0xFFu], L.unorm8[(al >> 16) & 0xFFu]};
         const float metal = L.unorm8[mr & 0xFFu], pr = L.unorm8[(mr >> 8) & 0xFFu], coatR = L.unorm8[(mr >> 16) & 0xFFu], fuzzW = L.unorm8[mr >> 24];
         const float prc = clampf(pr, BRMI_MIN_PERCEPTUAL_ROUGHNESS, 1.0f);
@@ -780,21 +797,33 @@ BRMI_DEV bool shade_pixel(const ShadeArgs& a, const ShadeFrame& k, uint64_t i, u
         return true;
 }
 
+// the specialised kernel must keep 3 waves per SIMD (<= 168 VGPRs); the general one is rare and may use the whole file
 #ifndef BRMI_SHADE_WAVES
-#define BRMI_SHADE_WAVES 1
+#define BRMI_SHADE_WAVES 3
 #endif
 template <bool GENERAL>
-__global__ void __launch_bounds__(256, BRMI_SHADE_WAVES) k_shade(ShadeArgs a) {
+__global__ void __launch_bounds__(256, GENERAL ? 1 : BRMI_SHADE_WAVES) k_shade(ShadeArgs a) {
     const ShadeFrame k = make_shade_frame(a);
     if (!GENERAL) {
-        for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < ((a.pixelCount + 63ull) & ~63ull); j += (uint64_t)gridDim.x * blockDim.x) {
+        // software pipeline: the G-buffer words of the next tile are requested before the current one is shaded, so
+        // their HBM latency overlaps ~1000 VALU instructions instead of stalling the wave at the top of every iteration
+        const uint64_t end = (a.pixelCount + 63ull) & ~63ull, stride = (uint64_t)gridDim.x * blockDim.x;
+        auto fetch = [&](uint64_t j, uint32_t& px, uint32_t& py) {
             const uint64_t i = a.firstPixel + j;
             const uint32_t tile = (uint32_t)(i >> 6), within = (uint32_t)(i & 63u);
-            const uint32_t px = (tile % a.tilesX) * 8u + (within >> 3), py = (tile / a.tilesX) * 8u + (within & 7u);
-            bool done = true;
-            if (j < a.pixelCount && px < a.W && py < a.H && py >= a.bandY0 && py < a.bandY1) done = shade_pixel<false>(a, k, i, px, py);
+            px = (tile % a.tilesX) * 8u + (within >> 3); py = (tile / a.tilesX) * 8u + (within & 7u);
+            return (j < a.pixelCount && px < a.W && py < a.H && py >= a.bandY0 && py < a.bandY1) ? load_raw_pixel_plain(a, i) : empty_raw_pixel();
+        };
+        uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        uint32_t px = 0, py = 0;
+        RawPixel cur = j < end ? fetch(j, px, py) : empty_raw_pixel();
+        for (; j < end; j += stride) {
+            uint32_t npx = 0, npy = 0;
+            const RawPixel nxt = (j + stride < end) ? fetch(j + stride, npx, npy) : empty_raw_pixel();
+            const bool done = shade_pixel<false>(a, k, cur, a.firstPixel + j, px, py);
             const uint32_t slot = wave_append(&a.counters[CNT_DEFERRED_PIXELS], !done);
             if (!done) a.deferred[slot] = (uint32_t)j;
+            cur = nxt; px = npx; py = npy;
         }
     } else {
         const uint32_t n = a.counters[CNT_DEFERRED_PIXELS];
@@ -802,7 +831,7 @@ __global__ void __launch_bounds__(256, BRMI_SHADE_WAVES) k_shade(ShadeArgs a) {
             const uint64_t i = a.firstPixel + a.deferred[q];
             const uint32_t tile = (uint32_t)(i >> 6), within = (uint32_t)(i & 63u);
             const uint32_t px = (tile % a.tilesX) * 8u + (within >> 3), py = (tile / a.tilesX) * 8u + (within & 7u);
-            shade_pixel<true>(a, k, i, px, py);
+            shade_pixel<true>(a, k, load_raw_pixel(a, i), i, px, py);
         }
     }
 }

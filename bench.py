@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md)
 DOMINANT_KERNEL = {"raster": "k_raster", "gbuffer": "k_gbuffer", "shade": "k_shade", "cull": "k_traverse+k_cull_clusters", "clear": "k_clear_vis",
-                   "light_cluster": "k_light_clustering", "depth_copy": "k_depth_copy"}
+                   "light_cluster": "k_light_clustering", "depth_copy": "k_depth_copy", "hzb": "k_hzb_head", "cull2": "k_traverse+k_cull_clusters", "raster2": "k_raster"}
 
 
 def main():
@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="sponza", choices=["sponza", "bistro", "san_miguel"])
+    ap.add_argument("--occlusion", type=int, default=1, choices=[0, 1],
+                    help="2-phase HZB occlusion culling (reference default: on, BR/include/Renderer.h:220); timed frames are steady state")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scale", type=float, default=1.0, help="fraction of the frame height the CPU baseline renders")
     args = ap.parse_args()
@@ -61,7 +63,7 @@ def main():
     W, H = compose.frame_size(n)
     band = compose.band_of(rank, n, H)
     scene = Scene(args.workload, W, H, point_lights=lights, directional=True)
-    r = VisibilityRenderer(scene, device=dev, stats=True, band=band)
+    r = VisibilityRenderer(scene, device=dev, stats=True, band=band, occlusion=bool(args.occlusion))
 
     hdr = r.hdr_tensor()
     lo, hi = compose.band_byte_range(band, W, 8)
@@ -111,6 +113,7 @@ def main():
                                    + (f", {n} row bands of 1080 rows + RCCL all-gather of HDR" if n > 1 else ""),
                        "baseline_config": "configs[1]" if args.workload == "sponza" else "configs[2]",
                        "pixels_per_gpu": W * (band[1] - band[0]), "visible_clusters_rank0": int(c.visibleClusters),
+                       "occlusion_culling": bool(args.occlusion), "visible_clusters_phase2_rank0": int(c.visibleClustersPhase2),
                        "meshlets_tested_rank0": int(c.meshletsTested), "partition": f"row bands x{n}" if n > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": DOMINANT_KERNEL.get(dom, dom), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
