@@ -144,6 +144,9 @@ BRMI_DEV float uni(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_
 BRMI_DEV m4 uni_m4(const m4& a) { m4 r; for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) r.m[i][j] = uni(a.m[i][j]); return r; }
 BRMI_DEV uint32_t lane_id() { return __lane_id(); }
 BRMI_DEV uint32_t lane_rank(uint64_t mask) { return __popcll(mask & ((1ull << lane_id()) - 1ull)); }
+// Read-only data produced by an earlier kernel, viewed through the constant address space: with a wave-uniform address
+// the compiler then selects scalar (s_load) instead of vector loads.
+template <typename T> BRMI_DEV const __attribute__((address_space(4))) T* kconst(const T* p) { return (const __attribute__((address_space(4))) T*)p; }
 // wave-aggregated append: one atomic per wave; returns the slot of this lane (valid when pred)
 BRMI_DEV uint32_t wave_append(uint32_t* counter, bool pred) {
     const uint64_t mask = __ballot(pred);

@@ -731,7 +731,7 @@ BRMI_DEV bool shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const RawPixe
         const PixelCtx ctx = make_pixel_ctx<GENERAL>(L, f);
         f3 lighting{0.0f, 0.0f, 0.0f};
         auto shadeLight = [&](uint32_t lightIndex) {
-            const brmi_light_info* l = sc.lights + lightIndex;
+            const auto* l = kconst(sc.lights) + lightIndex;      // wave-uniform in the clustered path: scalar loads
             const uint32_t type = l->type;
             f3 lightToFrag; float att, dist = 0.0f, spot = 1.0f;
             if (type == BRMI_LIGHT_DIRECTIONAL) { lightToFrag = -f3{l->dirWorldSpace[0], l->dirWorldSpace[1], l->dirWorldSpace[2]}; att = 1.0f; }
@@ -769,17 +769,32 @@ BRMI_DEV bool shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const RawPixe
                 }
                 const uint32_t ci = (uint32_t)((float)tx + (float)ty * (float)gx + (float)sliceZ * (float)gx * (float)gy);
                 if (ci < gx * gy * gz) {
-                    const brmi_light_cluster* cl = a.clusters + ci;
-                    const uint32_t count = cl->numLights;
-                    uint32_t page = cl->ptrFirstPage, remaining = count, visited = 0;
-                    const uint32_t maxPages = max(1u, (count + BRMI_LIGHTS_PER_PAGE - 1u) / BRMI_LIGHTS_PER_PAGE);
-                    while (page != BRMI_LIGHT_PAGE_NULL && page < a.poolSize && remaining > 0 && visited < maxPages) {
-                        const brmi_light_page* pg = a.pages + page;
-                        uint32_t n = min(pg->numLightsInPage, BRMI_LIGHTS_PER_PAGE);
-                        n = min(n, remaining);
-                        if (n == 0) break;
-                        for (uint32_t k = 0; k < n; k++) shadeLight(sc.activeLightIndices[pg->lightIndices[k]]);
-                        remaining -= n; page = pg->ptrNextPage; visited++;
+                    // Waterfall over the distinct clusters of the wave (an 8x8 tile usually sits in one): with the cluster
+                    // index in an SGPR the cluster record, its pages, the index indirections and the light records are all
+                    // scalar loads -- no vector-memory latency and no VGPRs for light parameters inside the loop.
+                    // The lane set of a cluster comes from a ballot (not from `ci == uci` directly) so that value numbering
+                    // cannot substitute the per-lane `ci` for the scalar `uci`, and `uci` depends on the loop-carried mask so
+                    // that it cannot be hoisted.
+                    uint64_t pending = __ballot(1);
+                    while (pending != 0ull) {
+                        const uint32_t lead = (uint32_t)__ffsll((unsigned long long)pending) - 1u;
+                        const uint32_t uci = (uint32_t)__builtin_amdgcn_readlane((int)ci, (int)lead);
+                        const uint64_t same = __ballot(ci == uci);
+                        pending &= ~same;
+                        if ((same >> lane_id()) & 1ull) {
+                            const auto* cl = kconst(a.clusters) + uci;
+                            const uint32_t count = cl->numLights;
+                            uint32_t page = cl->ptrFirstPage, remaining = count, visited = 0;
+                            const uint32_t maxPages = max(1u, (count + BRMI_LIGHTS_PER_PAGE - 1u) / BRMI_LIGHTS_PER_PAGE);
+                            while (page != BRMI_LIGHT_PAGE_NULL && page < a.poolSize && remaining > 0 && visited < maxPages) {
+                                const auto* pg = kconst(a.pages) + page;
+                                uint32_t n = min(pg->numLightsInPage, BRMI_LIGHTS_PER_PAGE);
+                                n = min(n, remaining);
+                                if (n == 0) break;
+                                for (uint32_t k = 0; k < n; k++) shadeLight(kconst(sc.activeLightIndices)[pg->lightIndices[k]]);
+                                remaining -= n; page = pg->ptrNextPage; visited++;
+                            }
+                        }
                     }
                 }
             } else {
