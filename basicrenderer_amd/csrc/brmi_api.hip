@@ -95,7 +95,9 @@ static void compute_sizes(brmi_pass* p) {
     w.lightVS = take((uint64_t)std::max(1u, p->scene.lightCount) * 16);
     w.lightMeta = take((uint64_t)std::max(1u, p->scene.lightCount) * 4);
     w.clusterPages = take((uint64_t)p->numLightClusters * 4);
-    w.bigTris = take((uint64_t)p->bigTriCapacity * 64);
+    p->binsX = (c.width + 255) / 256; p->binsY = (c.height + 15) / 16;
+    w.binCounts = take((uint64_t)p->binsX * p->binsY * 4);
+    w.binRecords = take((uint64_t)p->binsX * p->binsY * p->binCapacity * 64);
     w.frameConst = take(3 * 64);
     w.matConst = take((uint64_t)std::max(1u, p->scene.openpbrMaterialCount) * 48);
     w.objConst = take((uint64_t)std::max(1u, p->scene.perObjectCount) * 36 * 4);
@@ -154,7 +156,7 @@ int brmi_create(const brmi_config* cfg, brmi_pass** out) {
     brmi_pass* p = new brmi_pass();
     p->cfg = *cfg;
     p->totalWords = 1; p->scanBlocks = 1;
-    if (const char* e = std::getenv("BRMI_RASTER_MODE")) p->rasterMode = std::atoi(e);
+    if (const char* e = std::getenv("BRMI_BIN_CAPACITY")) p->binCapacity = (uint32_t)std::max(1, std::atoi(e));
     if (const char* e = std::getenv("BRMI_BIG_TRI_AREA")) p->bigTriArea = std::max(1, std::atoi(e));
     compute_sizes(p);
     *out = p;
@@ -394,7 +396,7 @@ int brmi_read_counters(brmi_pass* p, brmi_counters* out, brmi_stream stream) {
     out->visibleClusters = c[CNT_VISIBLE]; out->visibleClustersPhase2 = c[CNT_VISIBLE2];
     out->droppedRecords = c[CNT_DROPPED_RECORDS]; out->droppedClusters = c[CNT_DROPPED_CLUSTERS]; out->lightPagesUsed = c[CNT_LIGHT_PAGES];
     out->reserved[0] = c[CNT_SUM_VERTS_LO]; out->reserved[1] = c[CNT_SUM_VERTS_HI]; out->reserved[2] = c[CNT_SUM_TRIS_LO]; out->reserved[3] = c[CNT_SUM_TRIS_HI];
-    out->reserved[4] = c[CNT_RASTER_CLUSTERS]; out->reserved[5] = c[CNT_BIG_TRIS];
+    out->reserved[4] = c[CNT_RASTER_CLUSTERS]; out->reserved[5] = c[CNT_BIN_OVERFLOW];
     out->replayNodes = c[CNT_REPLAY_NODES]; out->replayMeshlets = c[CNT_REPLAY_MESHLETS];
     return BRMI_OK;
 }

@@ -30,8 +30,8 @@ enum CounterIndex : uint32_t {
     CNT_SUM_VERTS_LO, CNT_SUM_VERTS_HI,     // sum of vertex counts of rasterised clusters (u64)
     CNT_SUM_TRIS_LO, CNT_SUM_TRIS_HI,
     CNT_RASTER_CLUSTERS,
-    CNT_BIG_TRIS,             // narrow records in the big-triangle queue (bottom-up)
-    CNT_BIG_TRIS_WIDE,        // wide records (top-down)
+    CNT_BIN_OVERFLOW,         // raster records that found their screen bin full (rasterised in place with global atomics)
+    CNT_UNUSED0,
     CNT_DEFERRED_PIXELS,      // pixels the specialised shading kernel left to the general one
     CNT_FRONTIER0 = 32,       // frontier sizes per BFS level: [CNT_FRONTIER0 + level]
     CNT_WORDS = 32 + 72
@@ -56,7 +56,7 @@ struct HzbDesc {
 
 struct Workspace {     // byte offsets into BRMI_RES_WORKSPACE
     uint64_t counters, frontierA, frontierB, buckets, tempVisible, bitmask1, bitmask2, wordPrefix, blockSums,
-             instanceBitBase, segPrefix, planes, replayNodes, replayBuckets, lightVS, lightMeta, clusterPages, bigTris, lutF, frameConst, objConst, matConst, deferredPixels, total;
+             instanceBitBase, segPrefix, planes, replayNodes, replayBuckets, lightVS, lightMeta, clusterPages, binCounts, binRecords, lutF, frameConst, objConst, matConst, deferredPixels, total;
 };
 
 }  // namespace brmi
@@ -76,9 +76,8 @@ struct brmi_pass {
     uint32_t maxLevels = 1;
     uint64_t totalBits = 0; uint32_t totalWords = 0, scanBlocks = 0;
     uint32_t numLightClusters = 0, lightPagePool = 0;
-    uint32_t bigTriCapacity = 1u << 20;
-    int bigTriArea = 128;
-    int rasterMode = 0;          // BRMI_RASTER_MODE: 0 atomic min (product), 3 read-then-atomic; 1/2 are bandwidth experiments
+    uint32_t binsX = 0, binsY = 0, binCapacity = 1024;   // raster bins: 256 px x 16 rows, binCapacity records of 64 B each (BRMI_BIN_CAPACITY)
+    int bigTriArea = 128;        // clamped-bbox pixels above which a triangle is binned (BRMI_BIG_TRI_AREA)
     uint32_t hzbMipCount = 0; std::vector<uint64_t> hzbMipOffsets; std::vector<uint32_t> hzbMipW, hzbMipH;   // [mip]; offsets in floats, mip 0 unused
     bool hzbValid = false;       // a chain built from a finished frame exists (phase 1 of the next frame tests against it)
     brmi::HzbDesc hzbDesc() const;

@@ -5,43 +5,49 @@
 // centres with incrementally stepped barycentrics, 64-bit min of (depth | cluster | triangle).
 // Scheduling is MI355X-first rather than the reference's one-128-thread-group-per-cluster indirect
 // dispatch per raster bucket:
-//   * persistent single-wave workgroups pull cluster indices from a device-side queue counter
-//     (cluster count lives in HBM; no indirect dispatch, no host read-back, natural load balance
-//     over clusters of very different pixel area);
-//   * wave64: lane = triangle, two passes over a 128-triangle meshlet.  The reference's
-//     WaveActiveAnyTrue(rectWidth > 4) vote (softwareRaster.hlsl:502) is evaluated per pass over the
-//     lanes that survived setup, which is exactly the wave composition of a 128-thread group on
-//     wave64 hardware;
-//   * the meshlet's screen-space vertices (<=128 x 12 B) are staged once in LDS;
-//   * the visibility surface is stored in 8x8 tiles (512 B = 4 cache lines) so the atomics of a
-//     meshlet footprint, and every later full-screen pass, touch whole lines.
+//   * k_raster: one wave64 per cluster (static round-robin; cluster count lives in HBM: no indirect
+//     dispatch, no host read-back).  lane = triangle, two passes over a 128-triangle meshlet.  The
+//     reference's WaveActiveAnyTrue(rectWidth > 4) vote (softwareRaster.hlsl:502) is evaluated per pass
+//     over the lanes that survived setup, which is exactly the wave composition of a 128-thread group on
+//     wave64 hardware.  The meshlet's screen-space vertices (<= 128 x 12 B) are staged once in LDS.
+//     Triangles with a small clamped bounding box are walked by their lane with global 64-bit atomic-min.
+//   * Sort-middle for everything larger: 64-bit global atomics are element-serialised in L2 (~100 G/s on
+//     MI355X, measured), so a frame with 3x overdraw of large triangles spends its time there.  Larger
+//     triangles are cut into records of <= 16 rows and appended to screen bins (256 px x 16 rows).
+//     k_raster_bins gives every bin to one workgroup: it walks the records one lane per row with LDS
+//     atomic-min into a 32 KB tile of keys and merges the tile into the visibility buffer once, with plain
+//     coalesced 64 B loads / stores (the bin is exclusively owned; k_raster has finished).
+//   * Per-pixel arithmetic is untouched by the re-scheduling: a lane that enters a row in the middle
+//     (bin strip) steps the barycentrics pixel by pixel from the row start exactly as the serial loop does.
+//   * the visibility surface is stored in 8x8 tiles (512 B = 4 cache lines), column-major inside the tile, so
+//     lanes that own neighbouring rows hit the same cache line and every later full-screen pass touches
+//     whole lines.
 // Raster buckets (K4) collapse: with one PSO-free kernel there is nothing to sort by.
 #include "brmi_device.h"
 #include "brmi_internal.h"
 
 namespace brmi {
 
-// A triangle whose clamped bounding box exceeds BIG_TRI_AREA pixels is not walked by its lane: the lane
-// emits one record per 64-row chunk (carrying the exactly stepped scanline start of the chunk) and
-// k_raster_big walks those rows one lane per row.  Same arithmetic per pixel, different lane mapping.
-struct BigTriRecord {        // 64 B
+// One record = up to BIN_ROWS rows of one triangle inside one bin band; it is appended to every bin strip its box overlaps.
+struct BinRecord {           // 64 B
     uint32_t clusterIndex, triAndFlags;      // tri | useScanlineRanges << 8 | rowCount << 16
     int32_t  minX, rectWidth, rowStart;
-    float    sb0, sb1, dx_b0, dx_b1, dy_b0, dy_b1, d0, d1, d2;
+    float    sb0, sb1, dx_b0, dx_b1, dy_b0, dy_b1, d0, d1, d2;   // barycentrics at (minX, rowStart), their steps, vertex depths
     uint32_t pad0, pad1;
 };
-constexpr int RASTER_SEG = 256;        // longest run of pixels one lane walks in the row-parallel kernel
-constexpr int REC_ROWS = 16;           // rows per big-triangle record: k_raster_big runs four records per wave64
+static_assert(sizeof(BinRecord) == 64, "one cache line");
+constexpr int BIN_W = 256, BIN_ROWS = 16;          // bin = 4096 keys = 32 KB of LDS
+constexpr int BIN_W_SHIFT = 8, BIN_ROWS_SHIFT = 4;
+constexpr int COOP_ENTRIES = 8;                     // triangles with more bin entries than this are emitted by the whole wave
 
 struct RasterArgs {
-    BigTriRecord* bigTris; uint32_t bigTriCapacity;
+    BinRecord* binRecords; uint32_t* binCounts; uint32_t binCapacity, binsX, binsY;
     const float* objConst;   // per object: MVP (16), objectToClip (16), modelViewZ (4)
-    int bigTriArea;          // clamped-bbox pixels above which a triangle goes to the row-parallel kernel
+    int bigTriArea;          // clamped-bbox pixels above which a triangle is binned
     brmi_scene_buffers sc;
     const uint4* clusters;
     uint32_t* counters;
     uint32_t firstCounter, countCounter;   // counter indices: first cluster (0xFFFFFFFF = 0) and cluster count
-    uint32_t* queue;                        // work-queue head (zeroed before launch)
     unsigned long long* vis;
     uint32_t visW, visH, tilesX, bandY0, bandY1;
 };
@@ -61,26 +67,24 @@ BRMI_DEV void clip_scanline(float value, float step, int& first, int& last, bool
     has = has && first <= last;
 }
 
-// Visibility write.  MODE 0 is the product path (64-bit atomic min).  MODE 3 reads the key first and skips the
-// atomic when it cannot win (the stored key only ever decreases, so a stale read is merely conservative).
-// MODEs 1 (plain store) and 2 (no write) exist for bandwidth experiments only and give wrong images.
-template <int MODE>
-BRMI_DEV void emit_key(unsigned long long* addr, unsigned long long key, unsigned long long& sink) {
-    if (MODE == 0) atomicMin(addr, key);
-    else if (MODE == 1) *addr = key;
-    else if (MODE == 2) sink ^= key;
-    else { if (key < __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(addr, key); }
-}
+// Where a key goes: the visibility buffer (tiled, 64-bit atomic min in L2) or the LDS tile of a bin.
+struct GlobalSink {
+    unsigned long long* vis; uint32_t tilesX;
+    BRMI_DEV void operator()(int px, int py, unsigned long long key) const {
+        atomicMin(&vis[tiled_index((uint32_t)px, (uint32_t)py, tilesX)], key);
+    }
+};
+struct LdsSink {
+    unsigned long long* tile; int x0, y0;       // tile[(px - x0) * BIN_ROWS + (py - y0)]
+    BRMI_DEV void operator()(int px, int py, unsigned long long key) const { atomicMin(&tile[(px - x0) * BIN_ROWS + (py - y0)], key); }
+};
 
-// One scanline of one triangle (softwareRaster.hlsl:506-609), barycentrics at the row start given.
-// `seg` >= 0 restricts the walk to the seg-th run of RASTER_SEG pixels after the row's first covered pixel;
-// the barycentrics are still stepped pixel by pixel from the row start, so every value is the one the
-// serial loop produces.  Surfaces are 8x8 tiles stored column-major inside the tile (8 vertically adjacent
-// pixels are one contiguous 64 B run: lanes that own neighbouring rows hit the same cache line).
-template <int MODE>
-BRMI_DEV void raster_row(unsigned long long& sink, unsigned long long* vis, uint32_t tilesX, int py, int minX, int rectWidth, bool useScanlineRanges, float sb0, float sb1,
-                         float dx_b0, float dx_b1, float dx_b2, float d0, float d1, float d2, uint32_t clusterIndex, uint32_t t, int seg) {
-    const uint32_t rowBase = (((uint32_t)py >> 3) * tilesX << 6) | ((uint32_t)py & 7u);
+// One scanline of one triangle (softwareRaster.hlsl:506-609), barycentrics at the row start given, restricted to
+// pixels clipX0..clipX1.  The barycentrics are stepped pixel by pixel from the row's first pixel even when the walk
+// starts further right, so every value is the one the serial loop produces.
+template <typename Sink>
+BRMI_DEV void raster_row(const Sink& sink, int py, int minX, int rectWidth, bool useScanlineRanges, float sb0, float sb1,
+                         float dx_b0, float dx_b1, float dx_b2, float d0, float d1, float d2, uint32_t clusterIndex, uint32_t t, int clipX0, int clipX1) {
     if (useScanlineRanges) {
         const float sb2 = 1.0f - sb0 - sb1;
         int firstOff = 0, lastOff = rectWidth - 1; bool has = true;
@@ -89,42 +93,57 @@ BRMI_DEV void raster_row(unsigned long long& sink, unsigned long long* vis, uint
         clip_scanline(sb2, dx_b2, firstOff, lastOff, has);
         if (has) {
             float b0 = sb0 + (float)firstOff * dx_b0, b1 = sb1 + (float)firstOff * dx_b1;
-            int x0 = minX + firstOff, x1 = minX + lastOff;
-            if (seg >= 0) {
-                const int skip = seg * RASTER_SEG;
-                if (skip > lastOff - firstOff) return;
-                for (int k = 0; k < skip; k++) { b0 += dx_b0; b1 += dx_b1; }
-                x0 += skip; x1 = min(x1, x0 + RASTER_SEG - 1);
-            }
+            int x0 = minX + firstOff;
+            const int x1 = min(minX + lastOff, clipX1);
+            if (x0 < clipX0) { for (int k = clipX0 - x0; k > 0; k--) { b0 += dx_b0; b1 += dx_b1; } x0 = clipX0; }
             for (int px = x0; px <= x1; px++) {
                 const float b2 = 1.0f - b0 - b1;
                 const float depth = b0 * d0 + b1 * d1 + b2 * d2;
-                emit_key<MODE>(&vis[rowBase + (((uint32_t)px >> 3) << 6) + (((uint32_t)px & 7u) << 3)], (unsigned long long)pack_vis_key(depth, clusterIndex, t), sink);
+                sink(px, py, (unsigned long long)pack_vis_key(depth, clusterIndex, t));
                 b0 += dx_b0; b1 += dx_b1;
             }
         }
     } else {
-        if (seg > 0) return;      // narrow boxes (width <= 4) are never segmented
         float b0 = sb0, b1 = sb1;
-        for (int px = minX; px < minX + rectWidth; px++) {
+        int x0 = minX;
+        const int x1 = min(minX + rectWidth - 1, clipX1);
+        if (x0 < clipX0) { for (int k = clipX0 - x0; k > 0; k--) { b0 += dx_b0; b1 += dx_b1; } x0 = clipX0; }
+        for (int px = x0; px <= x1; px++) {
             const float b2 = 1.0f - b0 - b1;
             if (b0 >= 0.0f && b1 >= 0.0f && b2 >= 0.0f) {
                 const float depth = b0 * d0 + b1 * d1 + b2 * d2;
-                emit_key<MODE>(&vis[rowBase + (((uint32_t)px >> 3) << 6) + (((uint32_t)px & 7u) << 3)], (unsigned long long)pack_vis_key(depth, clusterIndex, t), sink);
+                sink(px, py, (unsigned long long)pack_vis_key(depth, clusterIndex, t));
             }
             b0 += dx_b0; b1 += dx_b1;
         }
     }
 }
 
-template <int MODE>
+// Appends one record to one bin; when the bin is full its rows are rasterised here with global atomics (counted).
+BRMI_DEV void bin_append(const RasterArgs& a, const BinRecord& r, uint32_t strip, uint32_t band) {
+    const uint32_t bin = band * a.binsX + strip;
+    const uint32_t slot = atomicAdd(&a.binCounts[bin], 1u);
+    if (slot < a.binCapacity) { a.binRecords[(size_t)bin * a.binCapacity + slot] = r; return; }
+    atomicAdd(&a.counters[CNT_BIN_OVERFLOW], 1u);
+    const GlobalSink sink{a.vis, a.tilesX};
+    float sb0 = r.sb0, sb1 = r.sb1;
+    const int n = (int)((r.triAndFlags >> 16) & 0xFFu);
+    for (int k = 0; k < n; k++) {
+        const int py = r.rowStart + k;
+        if ((uint32_t)py >= a.bandY0 && (uint32_t)py < a.bandY1)
+            raster_row(sink, py, r.minX, r.rectWidth, (r.triAndFlags & 0x100u) != 0, sb0, sb1, r.dx_b0, r.dx_b1, -(r.dx_b0 + r.dx_b1), r.d0, r.d1, r.d2, r.clusterIndex, r.triAndFlags & 0x7Fu,
+                       (int)(strip << BIN_W_SHIFT), (int)(strip << BIN_W_SHIFT) + BIN_W - 1);
+        sb0 += r.dy_b0; sb1 += r.dy_b1;
+    }
+}
+
 __global__ void __launch_bounds__(64) k_raster(RasterArgs a) {
-    unsigned long long sink = 0;
     __shared__ float sx[BRMI_MESHLET_MAX_VERTS], sy[BRMI_MESHLET_MAX_VERTS], sd[BRMI_MESHLET_MAX_VERTS];
     const brmi_scene_buffers& sc = a.sc;
     const uint32_t lane = threadIdx.x;
     const uint32_t first = a.firstCounter == 0xFFFFFFFFu ? 0u : a.counters[a.firstCounter];
     const uint32_t count = a.counters[a.countCounter];
+    const GlobalSink gsink{a.vis, a.tilesX};
     // static round-robin over clusters: a shared queue head saturates at ~90 dequeues/us (MI355X_MICROARCH.md, row
     // "dequeue"), which is slower than the work itself once big triangles are handed off
     for (uint32_t c = blockIdx.x; c < count; c += gridDim.x) {
@@ -206,110 +225,115 @@ __global__ void __launch_bounds__(64) k_raster(RasterArgs a) {
             }
             const int rectWidth = maxX - minX + 1;
             const bool useScanlineRanges = __any(active && rectWidth > 4);
-            // classify: big triangles are handed to k_raster_big as 16-row records; records of boxes wider than
-            // RASTER_SEG go to the "wide" end of the queue (walked by a whole wave, 4 lanes per row)
             const int rows = maxY - minY + 1;
-            bool big = active && rows * rectWidth > a.bigTriArea;
-            const bool wide = rectWidth > RASTER_SEG;
-            uint32_t nrec = 0;
-            if (big) {
-                for (int py = minY; py <= maxY; py += REC_ROWS) {
-                    const int n = min(REC_ROWS, maxY - py + 1);
-                    if ((uint32_t)(py + n) > a.bandY0 && (uint32_t)py < a.bandY1) nrec++;
-                }
-            }
-            // one reservation per wave and per queue end
-            uint32_t inclN = (big && !wide) ? nrec : 0u, inclW = (big && wide) ? nrec : 0u;
-            const uint32_t mineN = inclN, mineW = inclW;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t vn = (uint32_t)__shfl_up((int)inclN, o), vw = (uint32_t)__shfl_up((int)inclW, o);
-                if (lane >= (uint32_t)o) { inclN += vn; inclW += vw; }
-            }
-            const uint32_t totalN = (uint32_t)__shfl((int)inclN, 63), totalW = (uint32_t)__shfl((int)inclW, 63);
-            uint32_t slot = 0;
-            if (totalN + totalW != 0) {
-                uint32_t baseN = 0, baseW = 0;
-                if (lane == 0) { baseN = atomicAdd(&a.counters[CNT_BIG_TRIS], totalN); baseW = atomicAdd(&a.counters[CNT_BIG_TRIS_WIDE], totalW); }
-                baseN = (uint32_t)__shfl((int)baseN, 0); baseW = (uint32_t)__shfl((int)baseW, 0);
-                if ((uint64_t)baseN + totalN + baseW + totalW > a.bigTriCapacity) {      // queue full: give the slots back and walk everything here
-                    if (lane == 0) { atomicSub(&a.counters[CNT_BIG_TRIS], totalN); atomicSub(&a.counters[CNT_BIG_TRIS_WIDE], totalW); }
-                    big = false;
-                }
-                // narrow records grow from the bottom, wide records from the top of the same array
-                slot = wide ? (a.bigTriCapacity - 1u - (baseW + inclW - mineW)) : (baseN + inclN - mineN);
-            }
-            if (active) {
+            const bool big = active && rows * rectWidth > a.bigTriArea;
+            // bins the box overlaps (rows clipped to this GPU's band)
+            const int yLo = max(minY, (int)a.bandY0), yHi = min(maxY, (int)a.bandY1 - 1);
+            const int band0 = yLo >> BIN_ROWS_SHIFT, band1 = yHi >> BIN_ROWS_SHIFT, strip0 = minX >> BIN_W_SHIFT, strip1 = maxX >> BIN_W_SHIFT;
+            const int nStrips = strip1 - strip0 + 1;
+            const int entries = (big && yLo <= yHi) ? (band1 - band0 + 1) * nStrips : 0;
+            const uint32_t flags = t | (useScanlineRanges ? 0x100u : 0u);
+            if (active && !big) {
+                // small box: walked by its lane, global atomics
                 const float dx_b2 = -(dx_b0 + dx_b1);
                 float sb0 = row_b0, sb1 = row_b1;
-                if (big) {
-                    for (int py = minY; py <= maxY; py += REC_ROWS) {
-                        const int n = min(REC_ROWS, maxY - py + 1);
-                        if ((uint32_t)(py + n) > a.bandY0 && (uint32_t)py < a.bandY1) {
-                            BigTriRecord r;
-                            r.clusterIndex = clusterIndex;
-                            r.minX = minX; r.rectWidth = rectWidth; r.rowStart = py;
-                            r.sb0 = sb0; r.sb1 = sb1; r.dx_b0 = dx_b0; r.dx_b1 = dx_b1; r.dy_b0 = dy_b0; r.dy_b1 = dy_b1; r.d0 = d0; r.d1 = d1; r.d2 = d2; r.pad0 = 0; r.pad1 = 0;
-                            r.triAndFlags = t | (useScanlineRanges ? 0x100u : 0u) | ((uint32_t)n << 16);
-                            a.bigTris[slot] = r;
-                            slot = wide ? slot - 1u : slot + 1u;
-                        }
-                        for (int k = 0; k < n; k++) { sb0 += dy_b0; sb1 += dy_b1; }
-                    }
-                } else {
-                    for (int py = minY; py <= maxY; py++) {
-                        if ((uint32_t)py >= a.bandY0 && (uint32_t)py < a.bandY1)
-                            raster_row<MODE>(sink, a.vis, a.tilesX, py, minX, rectWidth, useScanlineRanges, sb0, sb1, dx_b0, dx_b1, dx_b2, d0, d1, d2, clusterIndex, t, -1);
-                        sb0 += dy_b0; sb1 += dy_b1;
-                    }
+                for (int py = minY; py <= maxY; py++) {
+                    if ((uint32_t)py >= a.bandY0 && (uint32_t)py < a.bandY1)
+                        raster_row(gsink, py, minX, rectWidth, useScanlineRanges, sb0, sb1, dx_b0, dx_b1, dx_b2, d0, d1, d2, clusterIndex, t, minX, maxX);
+                    sb0 += dy_b0; sb1 += dy_b1;
+                }
+            } else if (entries > 0 && entries <= COOP_ENTRIES) {
+                // a few bins: the lane appends its own records, stepping the row start band by band
+                float sb0 = row_b0, sb1 = row_b1;
+                int py = minY;
+                for (; py < yLo; py++) { sb0 += dy_b0; sb1 += dy_b1; }
+                while (py <= yHi) {
+                    const int band = py >> BIN_ROWS_SHIFT;
+                    const int n = min(((band + 1) << BIN_ROWS_SHIFT), yHi + 1) - py;
+                    BinRecord r;
+                    r.clusterIndex = clusterIndex; r.triAndFlags = flags | ((uint32_t)n << 16);
+                    r.minX = minX; r.rectWidth = rectWidth; r.rowStart = py;
+                    r.sb0 = sb0; r.sb1 = sb1; r.dx_b0 = dx_b0; r.dx_b1 = dx_b1; r.dy_b0 = dy_b0; r.dy_b1 = dy_b1; r.d0 = d0; r.d1 = d1; r.d2 = d2; r.pad0 = 0; r.pad1 = 0;
+                    for (int st = strip0; st <= strip1; st++) bin_append(a, r, (uint32_t)st, (uint32_t)band);
+                    for (int k = 0; k < n; k++) { sb0 += dy_b0; sb1 += dy_b1; }
+                    py += n;
+                }
+            }
+            // many bins: the whole wave emits the triangle.  lane L owns bands band0 + L, band0 + L + 64, ...: it steps the row
+            // start down to each of them (the same additions the serial loop makes) and appends the band's record to every strip.
+            uint64_t coop = __ballot(entries > COOP_ENTRIES);
+            while (coop != 0ull) {
+                const int src = __ffsll((unsigned long long)coop) - 1;
+                coop &= coop - 1ull;
+                const float c_sb0 = __shfl(row_b0, src), c_sb1 = __shfl(row_b1, src), c_dx0 = __shfl(dx_b0, src), c_dx1 = __shfl(dx_b1, src);
+                const float c_dy0 = __shfl(dy_b0, src), c_dy1 = __shfl(dy_b1, src), c_d0 = __shfl(d0, src), c_d1 = __shfl(d1, src), c_d2 = __shfl(d2, src);
+                const int c_minX = __shfl(minX, src), c_minY = __shfl(minY, src), c_w = __shfl(rectWidth, src), c_yLo = __shfl(yLo, src), c_yHi = __shfl(yHi, src);
+                const int c_band0 = __shfl(band0, src), c_band1 = __shfl(band1, src), c_strip0 = __shfl(strip0, src), c_strip1 = __shfl(strip1, src);
+                const uint32_t c_flags = (uint32_t)__shfl((int)flags, src);
+                float sb0 = c_sb0, sb1 = c_sb1;
+                int py = c_minY;
+                for (int band = c_band0 + (int)lane; band <= c_band1; band += 64) {
+                    const int start = max(band << BIN_ROWS_SHIFT, c_yLo);
+                    for (; py < start; py++) { sb0 += c_dy0; sb1 += c_dy1; }
+                    const int n = min(((band + 1) << BIN_ROWS_SHIFT), c_yHi + 1) - start;
+                    BinRecord r;
+                    r.clusterIndex = clusterIndex; r.triAndFlags = c_flags | ((uint32_t)n << 16);
+                    r.minX = c_minX; r.rectWidth = c_w; r.rowStart = start;
+                    r.sb0 = sb0; r.sb1 = sb1; r.dx_b0 = c_dx0; r.dx_b1 = c_dx1; r.dy_b0 = c_dy0; r.dy_b1 = c_dy1; r.d0 = c_d0; r.d1 = c_d1; r.d2 = c_d2; r.pad0 = 0; r.pad1 = 0;
+                    for (int st = c_strip0; st <= c_strip1; st++) bin_append(a, r, (uint32_t)st, (uint32_t)band);
                 }
             }
         }
         __syncthreads();   // LDS is reused by the next cluster
     }
-    if (MODE == 2 && sink == 0x123456789ull) a.vis[0] = sink;
 }
 
-// Row-parallel walk of the queued 16-row records; records are taken round-robin (no shared queue head).
-//   narrow records (box width <= RASTER_SEG): four per wave64, 16 lanes = 16 rows each;
-//   wide records: one per wave64, 4 lanes per row, lane `phase` walks pixel runs phase, phase+4, ... of RASTER_SEG.
-// Every lane steps to its row / run exactly as the serial loop would.
-template <int MODE>
-__global__ void __launch_bounds__(64) k_raster_big(RasterArgs a) {
-    unsigned long long sink = 0;
-    const uint32_t lane = threadIdx.x, sub = lane >> 4, row = lane & 15u;
-    const uint32_t nNarrow = min(a.counters[CNT_BIG_TRIS], a.bigTriCapacity);
-    const uint32_t nWide = min(a.counters[CNT_BIG_TRIS_WIDE], a.bigTriCapacity - nNarrow);
-    for (uint32_t base = blockIdx.x * 4u; base < nNarrow; base += gridDim.x * 4u) {
+// One workgroup per bin: the bin's records are walked one lane per row (16 records at a time) with LDS atomic-min into a tile
+// of keys; the tile is then merged into the visibility buffer in 64 B pieces (8 vertically adjacent pixels of a tile column).
+__global__ void __launch_bounds__(256) k_raster_bins(RasterArgs a) {
+    __shared__ unsigned long long tile[BIN_W * BIN_ROWS];
+    const uint32_t strip = blockIdx.x, band = blockIdx.y, bin = band * a.binsX + strip;
+    const uint32_t n = min(a.binCounts[bin], a.binCapacity);
+    if (n == 0) return;
+    for (uint32_t i = threadIdx.x; i < BIN_W * BIN_ROWS; i += 256) tile[i] = BRMI_VIS_EMPTY;
+    __syncthreads();
+    const int x0 = (int)(strip << BIN_W_SHIFT), y0 = (int)(band << BIN_ROWS_SHIFT);
+    const LdsSink sink{tile, x0, y0};
+    const BinRecord* recs = a.binRecords + (size_t)bin * a.binCapacity;
+    const uint32_t sub = threadIdx.x >> 4, row = threadIdx.x & 15u;
+    for (uint32_t base = 0; base < n; base += 16) {
         const uint32_t ri = base + sub;
-        if (ri >= nNarrow) continue;
-        const BigTriRecord r = a.bigTris[ri];
-        const uint32_t n = (r.triAndFlags >> 16) & 0xFFu;
-        if (row < n) {
+        if (ri >= n) continue;
+        const BinRecord r = recs[ri];
+        const uint32_t rows = (r.triAndFlags >> 16) & 0xFFu;
+        if (row < rows) {
             float sb0 = r.sb0, sb1 = r.sb1;
             for (uint32_t k = 0; k < row; k++) { sb0 += r.dy_b0; sb1 += r.dy_b1; }
             const int py = r.rowStart + (int)row;
             if ((uint32_t)py >= a.bandY0 && (uint32_t)py < a.bandY1)
-                raster_row<MODE>(sink, a.vis, a.tilesX, py, r.minX, r.rectWidth, (r.triAndFlags & 0x100u) != 0, sb0, sb1, r.dx_b0, r.dx_b1, -(r.dx_b0 + r.dx_b1), r.d0, r.d1, r.d2,
-                                 r.clusterIndex, r.triAndFlags & 0x7Fu, -1);
+                raster_row(sink, py, r.minX, r.rectWidth, (r.triAndFlags & 0x100u) != 0, sb0, sb1, r.dx_b0, r.dx_b1, -(r.dx_b0 + r.dx_b1), r.d0, r.d1, r.d2, r.clusterIndex, r.triAndFlags & 0x7Fu,
+                           x0, x0 + BIN_W - 1);
         }
     }
-    for (uint32_t wi = blockIdx.x; wi < nWide; wi += gridDim.x) {
-        const BigTriRecord r = a.bigTris[a.bigTriCapacity - 1u - wi];
-        const uint32_t n = (r.triAndFlags >> 16) & 0xFFu;
-        if (row < n) {
-            float sb0 = r.sb0, sb1 = r.sb1;
-            for (uint32_t k = 0; k < row; k++) { sb0 += r.dy_b0; sb1 += r.dy_b1; }
-            const int py = r.rowStart + (int)row;
-            if ((uint32_t)py >= a.bandY0 && (uint32_t)py < a.bandY1) {
-                const int segs = (r.rectWidth + RASTER_SEG - 1) / RASTER_SEG;
-                for (int sg = (int)sub; sg < segs; sg += 4)
-                    raster_row<MODE>(sink, a.vis, a.tilesX, py, r.minX, r.rectWidth, (r.triAndFlags & 0x100u) != 0, sb0, sb1, r.dx_b0, r.dx_b1, -(r.dx_b0 + r.dx_b1), r.d0, r.d1, r.d2,
-                                     r.clusterIndex, r.triAndFlags & 0x7Fu, sg);
-            }
+    __syncthreads();
+    // merge: item = (column x, upper / lower 8 rows) = 8 keys = 64 B, contiguous in the tile and in the 8x8-tiled surface
+    for (uint32_t item = threadIdx.x; item < BIN_W * 2; item += 256) {
+        const uint32_t half = item >> 8 /* BIN_W items per half */, xl = item & (BIN_W - 1);
+        const ulonglong2* src = reinterpret_cast<const ulonglong2*>(&tile[xl * BIN_ROWS + half * 8u]);
+        ulonglong2 k[4];
+        bool any = false;
+#pragma unroll
+        for (int q = 0; q < 4; q++) { k[q] = src[q]; any = any || k[q].x != BRMI_VIS_EMPTY || k[q].y != BRMI_VIS_EMPTY; }
+        if (!any) continue;      // untouched (this also covers columns / rows beyond the target size)
+        const uint32_t px = (uint32_t)x0 + xl, py = (uint32_t)y0 + half * 8u;
+        ulonglong2* dst = reinterpret_cast<ulonglong2*>(&a.vis[(((py >> 3) * a.tilesX + (px >> 3)) << 6) | ((px & 7u) << 3)]);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const ulonglong2 g = dst[q];
+            const ulonglong2 m = make_ulonglong2(g.x < k[q].x ? g.x : k[q].x, g.y < k[q].y ? g.y : k[q].y);
+            if (m.x != g.x || m.y != g.y) dst[q] = m;
         }
     }
-    if (MODE == 2 && sink == 0x123456789ull) a.vis[0] = sink;
 }
 
 // K6: linear depth from the visibility key (gbuffer.hlsl:114-161); one lane per pixel, tile order
@@ -332,23 +356,16 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
     RasterArgs a;
     a.sc = p->scene; a.clusters = static_cast<const uint4*>(p->res[BRMI_RES_VISIBLE_CLUSTERS]); a.counters = p->counters();
     a.firstCounter = 0xFFFFFFFFu; a.countCounter = CNT_VISIBLE;
-    if (phase == 2) {   // clusters [visible1, visible1 + visible2); the big-triangle queue starts empty again
-        a.firstCounter = CNT_VISIBLE; a.countCounter = CNT_VISIBLE2;
-        static_assert(CNT_BIG_TRIS_WIDE == CNT_BIG_TRIS + 1, "queue counters are cleared together");
-        BRMI_HIP(p, hipMemsetAsync(p->counters() + CNT_BIG_TRIS, 0, 2 * sizeof(uint32_t), s));
-    }
-    a.queue = p->counters() + CNT_WORDS;   // one spare word after the counters block
+    if (phase == 2) { a.firstCounter = CNT_VISIBLE; a.countCounter = CNT_VISIBLE2; }   // clusters [visible1, visible1 + visible2)
     a.vis = static_cast<unsigned long long*>(p->res[BRMI_RES_VISIBILITY]);
     a.visW = p->cfg.width; a.visH = p->cfg.height; a.tilesX = p->tilesX; a.bandY0 = p->bandY0; a.bandY1 = p->bandY1;
-    a.bigTris = p->wsPtr<BigTriRecord>(p->ws.bigTris); a.bigTriCapacity = p->bigTriCapacity;
+    a.binRecords = p->wsPtr<BinRecord>(p->ws.binRecords); a.binCounts = p->wsPtr<uint32_t>(p->ws.binCounts);
+    a.binCapacity = p->binCapacity; a.binsX = p->binsX; a.binsY = p->binsY;
     a.objConst = p->wsPtr<float>(p->ws.objConst);
     a.bigTriArea = p->bigTriArea;
-    switch (p->rasterMode) {
-#define BRMI_RASTER_LAUNCH(M) case M: hipLaunchKernelGGL(k_raster<M>, dim3(256 * 16), dim3(64), 0, s, a); hipLaunchKernelGGL(k_raster_big<M>, dim3(256 * 32), dim3(64), 0, s, a); break;
-        BRMI_RASTER_LAUNCH(1) BRMI_RASTER_LAUNCH(2) BRMI_RASTER_LAUNCH(3)
-        default: hipLaunchKernelGGL(k_raster<0>, dim3(256 * 16), dim3(64), 0, s, a); hipLaunchKernelGGL(k_raster_big<0>, dim3(256 * 32), dim3(64), 0, s, a); break;
-#undef BRMI_RASTER_LAUNCH
-    }
+    BRMI_HIP(p, hipMemsetAsync(a.binCounts, 0, (size_t)p->binsX * p->binsY * sizeof(uint32_t), s));
+    hipLaunchKernelGGL(k_raster, dim3(256 * 16), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_raster_bins, dim3(p->binsX, p->binsY), dim3(256), 0, s, a);
     BRMI_LAUNCH_CHECK(p, "k_raster");
     return BRMI_OK;
 }
