@@ -156,6 +156,7 @@ int brmi_create(const brmi_config* cfg, brmi_pass** out) {
     brmi_pass* p = new brmi_pass();
     p->cfg = *cfg;
     p->totalWords = 1; p->scanBlocks = 1;
+    if (const char* e = std::getenv("BRMI_RASTER_DEBUG")) p->rasterDebug = std::atoi(e);
     if (const char* e = std::getenv("BRMI_BIN_CAPACITY")) p->binCapacity = (uint32_t)std::max(1, std::atoi(e));
     if (const char* e = std::getenv("BRMI_BIG_TRI_AREA")) p->bigTriArea = std::max(1, std::atoi(e));
     compute_sizes(p);

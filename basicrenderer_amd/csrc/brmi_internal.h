@@ -77,6 +77,7 @@ struct brmi_pass {
     uint64_t totalBits = 0; uint32_t totalWords = 0, scanBlocks = 0;
     uint32_t numLightClusters = 0, lightPagePool = 0;
     uint32_t binsX = 0, binsY = 0, binCapacity = 1024;   // raster bins: 256 px x 16 rows, binCapacity records of 64 B each (BRMI_BIN_CAPACITY)
+    int rasterDebug = 0;         // BRMI_RASTER_DEBUG (experiments; non-zero gives wrong images)
     int bigTriArea = 128;        // clamped-bbox pixels above which a triangle is binned (BRMI_BIG_TRI_AREA)
     uint32_t hzbMipCount = 0; std::vector<uint64_t> hzbMipOffsets; std::vector<uint32_t> hzbMipW, hzbMipH;   // [mip]; offsets in floats, mip 0 unused
     bool hzbValid = false;       // a chain built from a finished frame exists (phase 1 of the next frame tests against it)

@@ -38,12 +38,14 @@ struct BinRecord {           // 64 B
 static_assert(sizeof(BinRecord) == 64, "one cache line");
 constexpr int BIN_W = 256, BIN_ROWS = 16;          // bin = 4096 keys = 32 KB of LDS
 constexpr int BIN_W_SHIFT = 8, BIN_ROWS_SHIFT = 4;
-constexpr int COOP_ENTRIES = 8;                     // triangles with more bin entries than this are emitted by the whole wave
+constexpr int BIN_WINDOW = 1024;                    // bins a wave can count in LDS at once (cells of its bin bounding box)
+constexpr int COOP_ENTRIES = 64;                    // triangles with more bin entries than this are emitted by the whole wave
 
 struct RasterArgs {
     BinRecord* binRecords; uint32_t* binCounts; uint32_t binCapacity, binsX, binsY;
     const float* objConst;   // per object: MVP (16), objectToClip (16), modelViewZ (4)
     int bigTriArea;          // clamped-bbox pixels above which a triangle is binned
+    int debugFlags;          // experiments only (BRMI_RASTER_DEBUG): 1 = skip the direct walk, 2 = skip bin emission, 4 = skip the bin pass
     brmi_scene_buffers sc;
     const uint4* clusters;
     uint32_t* counters;
@@ -119,10 +121,9 @@ BRMI_DEV void raster_row(const Sink& sink, int py, int minX, int rectWidth, bool
     }
 }
 
-// Appends one record to one bin; when the bin is full its rows are rasterised here with global atomics (counted).
-BRMI_DEV void bin_append(const RasterArgs& a, const BinRecord& r, uint32_t strip, uint32_t band) {
+// Stores one record at a reserved slot of a bin; when the bin is full its rows are rasterised here with global atomics (counted).
+BRMI_DEV void bin_store(const RasterArgs& a, const BinRecord& r, uint32_t strip, uint32_t band, uint32_t slot) {
     const uint32_t bin = band * a.binsX + strip;
-    const uint32_t slot = atomicAdd(&a.binCounts[bin], 1u);
     if (slot < a.binCapacity) { a.binRecords[(size_t)bin * a.binCapacity + slot] = r; return; }
     atomicAdd(&a.counters[CNT_BIN_OVERFLOW], 1u);
     const GlobalSink sink{a.vis, a.tilesX};
@@ -136,9 +137,13 @@ BRMI_DEV void bin_append(const RasterArgs& a, const BinRecord& r, uint32_t strip
         sb0 += r.dy_b0; sb1 += r.dy_b1;
     }
 }
+BRMI_DEV void bin_append(const RasterArgs& a, const BinRecord& r, uint32_t strip, uint32_t band) {
+    bin_store(a, r, strip, band, atomicAdd(&a.binCounts[band * a.binsX + strip], 1u));
+}
 
 __global__ void __launch_bounds__(64) k_raster(RasterArgs a) {
     __shared__ float sx[BRMI_MESHLET_MAX_VERTS], sy[BRMI_MESHLET_MAX_VERTS], sd[BRMI_MESHLET_MAX_VERTS];
+    __shared__ uint32_t binBase[BIN_WINDOW];
     const brmi_scene_buffers& sc = a.sc;
     const uint32_t lane = threadIdx.x;
     const uint32_t first = a.firstCounter == 0xFFFFFFFFu ? 0u : a.counters[a.firstCounter];
@@ -233,7 +238,7 @@ __global__ void __launch_bounds__(64) k_raster(RasterArgs a) {
             const int nStrips = strip1 - strip0 + 1;
             const int entries = (big && yLo <= yHi) ? (band1 - band0 + 1) * nStrips : 0;
             const uint32_t flags = t | (useScanlineRanges ? 0x100u : 0u);
-            if (active && !big) {
+            if (active && !big && !(a.debugFlags & 1)) {
                 // small box: walked by its lane, global atomics
                 const float dx_b2 = -(dx_b0 + dx_b1);
                 float sb0 = row_b0, sb1 = row_b1;
@@ -242,26 +247,57 @@ __global__ void __launch_bounds__(64) k_raster(RasterArgs a) {
                         raster_row(gsink, py, minX, rectWidth, useScanlineRanges, sb0, sb1, dx_b0, dx_b1, dx_b2, d0, d1, d2, clusterIndex, t, minX, maxX);
                     sb0 += dy_b0; sb1 += dy_b1;
                 }
-            } else if (entries > 0 && entries <= COOP_ENTRIES) {
-                // a few bins: the lane appends its own records, stepping the row start band by band
-                float sb0 = row_b0, sb1 = row_b1;
-                int py = minY;
-                for (; py < yLo; py++) { sb0 += dy_b0; sb1 += dy_b1; }
-                while (py <= yHi) {
-                    const int band = py >> BIN_ROWS_SHIFT;
-                    const int n = min(((band + 1) << BIN_ROWS_SHIFT), yHi + 1) - py;
-                    BinRecord r;
-                    r.clusterIndex = clusterIndex; r.triAndFlags = flags | ((uint32_t)n << 16);
-                    r.minX = minX; r.rectWidth = rectWidth; r.rowStart = py;
-                    r.sb0 = sb0; r.sb1 = sb1; r.dx_b0 = dx_b0; r.dx_b1 = dx_b1; r.dy_b0 = dy_b0; r.dy_b1 = dy_b1; r.d0 = d0; r.d1 = d1; r.d2 = d2; r.pad0 = 0; r.pad1 = 0;
-                    for (int st = strip0; st <= strip1; st++) bin_append(a, r, (uint32_t)st, (uint32_t)band);
-                    for (int k = 0; k < n; k++) { sb0 += dy_b0; sb1 += dy_b1; }
-                    py += n;
+            }
+            // A few bins per triangle: every lane appends its own records.  A slot in a bin costs an atomic with return on the
+            // bin's counter (~2 us round trip, and the triangles of a meshlet hit the same few bins), so the wave first counts
+            // its records per bin in an LDS window over the bins it touches, reserves each bin's run with ONE global atomic,
+            // and then hands out the slots from LDS.
+            const bool few = entries > 0 && entries <= COOP_ENTRIES && !(a.debugFlags & 2);
+            if (__any(few)) {
+                int wb0 = few ? band0 : 0x7FFFFFFF, wb1 = few ? band1 : -1, ws0 = few ? strip0 : 0x7FFFFFFF, ws1 = few ? strip1 : -1;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    wb0 = min(wb0, __shfl_xor(wb0, o)); wb1 = max(wb1, __shfl_xor(wb1, o));
+                    ws0 = min(ws0, __shfl_xor(ws0, o)); ws1 = max(ws1, __shfl_xor(ws1, o));
                 }
+                const int winW = ws1 - ws0 + 1, cells = (wb1 - wb0 + 1) * winW;
+                const bool windowed = cells <= BIN_WINDOW;      // wave-uniform
+                if (windowed) {
+                    for (int cI = (int)lane; cI < cells; cI += 64) binBase[cI] = 0u;
+                    __syncthreads();
+                    if (few) for (int band = band0; band <= band1; band++) for (int st = strip0; st <= strip1; st++) atomicAdd(&binBase[(band - wb0) * winW + (st - ws0)], 1u);
+                    __syncthreads();
+                    for (int cI = (int)lane; cI < cells; cI += 64) {
+                        const uint32_t nrec = binBase[cI];
+                        if (nrec != 0u) binBase[cI] = atomicAdd(&a.binCounts[(uint32_t)(wb0 + cI / winW) * a.binsX + (uint32_t)(ws0 + cI % winW)], nrec);
+                    }
+                    __syncthreads();
+                }
+                if (few) {
+                    // step the row start band by band (the additions of the serial loop) and append one record per band and strip
+                    float sb0 = row_b0, sb1 = row_b1;
+                    int py = minY;
+                    for (; py < yLo; py++) { sb0 += dy_b0; sb1 += dy_b1; }
+                    while (py <= yHi) {
+                        const int band = py >> BIN_ROWS_SHIFT;
+                        const int n = min(((band + 1) << BIN_ROWS_SHIFT), yHi + 1) - py;
+                        BinRecord r;
+                        r.clusterIndex = clusterIndex; r.triAndFlags = flags | ((uint32_t)n << 16);
+                        r.minX = minX; r.rectWidth = rectWidth; r.rowStart = py;
+                        r.sb0 = sb0; r.sb1 = sb1; r.dx_b0 = dx_b0; r.dx_b1 = dx_b1; r.dy_b0 = dy_b0; r.dy_b1 = dy_b1; r.d0 = d0; r.d1 = d1; r.d2 = d2; r.pad0 = 0; r.pad1 = 0;
+                        for (int st = strip0; st <= strip1; st++) {
+                            if (windowed) bin_store(a, r, (uint32_t)st, (uint32_t)band, atomicAdd(&binBase[(band - wb0) * winW + (st - ws0)], 1u));
+                            else bin_append(a, r, (uint32_t)st, (uint32_t)band);
+                        }
+                        for (int k = 0; k < n; k++) { sb0 += dy_b0; sb1 += dy_b1; }
+                        py += n;
+                    }
+                }
+                if (windowed) __syncthreads();    // binBase is reused by the next batch
             }
             // many bins: the whole wave emits the triangle.  lane L owns bands band0 + L, band0 + L + 64, ...: it steps the row
             // start down to each of them (the same additions the serial loop makes) and appends the band's record to every strip.
-            uint64_t coop = __ballot(entries > COOP_ENTRIES);
+            uint64_t coop = __ballot(entries > COOP_ENTRIES && !(a.debugFlags & 2));
             while (coop != 0ull) {
                 const int src = __ffsll((unsigned long long)coop) - 1;
                 coop &= coop - 1ull;
@@ -362,10 +398,10 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
     a.binRecords = p->wsPtr<BinRecord>(p->ws.binRecords); a.binCounts = p->wsPtr<uint32_t>(p->ws.binCounts);
     a.binCapacity = p->binCapacity; a.binsX = p->binsX; a.binsY = p->binsY;
     a.objConst = p->wsPtr<float>(p->ws.objConst);
-    a.bigTriArea = p->bigTriArea;
+    a.bigTriArea = p->bigTriArea; a.debugFlags = p->rasterDebug;
     BRMI_HIP(p, hipMemsetAsync(a.binCounts, 0, (size_t)p->binsX * p->binsY * sizeof(uint32_t), s));
     hipLaunchKernelGGL(k_raster, dim3(256 * 16), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(k_raster_bins, dim3(p->binsX, p->binsY), dim3(256), 0, s, a);
+    if (!(p->rasterDebug & 4)) hipLaunchKernelGGL(k_raster_bins, dim3(p->binsX, p->binsY), dim3(256), 0, s, a);
     BRMI_LAUNCH_CHECK(p, "k_raster");
     return BRMI_OK;
 }
