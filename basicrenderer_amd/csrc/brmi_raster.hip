@@ -144,6 +144,9 @@ BRMI_DEV void bin_append(const RasterArgs& a, const BinRecord& r, uint32_t strip
 __global__ void __launch_bounds__(64) k_raster(RasterArgs a) {
     __shared__ float sx[BRMI_MESHLET_MAX_VERTS], sy[BRMI_MESHLET_MAX_VERTS], sd[BRMI_MESHLET_MAX_VERTS];
     __shared__ uint32_t binBase[BIN_WINDOW];
+    __shared__ float tpF[9][64];
+    __shared__ int tpI[4][64];
+    __shared__ uint32_t rowOff[65];
     const brmi_scene_buffers& sc = a.sc;
     const uint32_t lane = threadIdx.x;
     const uint32_t first = a.firstCounter == 0xFFFFFFFFu ? 0u : a.counters[a.firstCounter];
@@ -238,14 +241,36 @@ __global__ void __launch_bounds__(64) k_raster(RasterArgs a) {
             const int nStrips = strip1 - strip0 + 1;
             const int entries = (big && yLo <= yHi) ? (band1 - band0 + 1) * nStrips : 0;
             const uint32_t flags = t | (useScanlineRanges ? 0x100u : 0u);
-            if (active && !big && !(a.debugFlags & 1)) {
-                // small box: walked by its lane, global atomics
-                const float dx_b2 = -(dx_b0 + dx_b1);
-                float sb0 = row_b0, sb1 = row_b1;
-                for (int py = minY; py <= maxY; py++) {
-                    if ((uint32_t)py >= a.bandY0 && (uint32_t)py < a.bandY1)
-                        raster_row(gsink, py, minX, rectWidth, useScanlineRanges, sb0, sb1, dx_b0, dx_b1, dx_b2, d0, d1, d2, clusterIndex, t, minX, maxX);
-                    sb0 += dy_b0; sb1 += dy_b1;
+            // Small boxes: global atomics.  lane = triangle leaves most lanes idle (culled triangles, boxes of very different
+            // size), so the rows of the batch's small triangles are re-dealt to the lanes: an exclusive scan of the row counts,
+            // the setup of every triangle parked in LDS, then lane k takes rows k, k + 64, ... of the concatenated row list.
+            {
+                const bool small = active && !big && !(a.debugFlags & 1) && yLo <= yHi;
+                const uint32_t myRows = small ? (uint32_t)(yHi - yLo + 1) : 0u;
+                uint32_t incl = myRows;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o); if (lane >= (uint32_t)o) incl += v; }
+                const uint32_t totalRows = (uint32_t)__shfl((int)incl, 63);
+                if (totalRows != 0u) {
+                    rowOff[lane] = incl - myRows;
+                    if (lane == 63) rowOff[64] = totalRows;
+                    tpF[0][lane] = row_b0; tpF[1][lane] = row_b1; tpF[2][lane] = dx_b0; tpF[3][lane] = dx_b1; tpF[4][lane] = dy_b0; tpF[5][lane] = dy_b1;
+                    tpF[6][lane] = d0; tpF[7][lane] = d1; tpF[8][lane] = d2;
+                    tpI[0][lane] = minX; tpI[1][lane] = rectWidth; tpI[2][lane] = minY; tpI[3][lane] = yLo;
+                    __syncthreads();
+                    for (uint32_t task = lane; task < totalRows; task += 64) {
+                        uint32_t tri = 0;
+#pragma unroll
+                        for (uint32_t step = 32; step > 0; step >>= 1) if (rowOff[tri + step] <= task) tri += step;
+                        const int t_minX = tpI[0][tri], t_w = tpI[1][tri], t_minY = tpI[2][tri];
+                        const int py = tpI[3][tri] + (int)(task - rowOff[tri]);
+                        const float t_dx0 = tpF[2][tri], t_dx1 = tpF[3][tri], t_dy0 = tpF[4][tri], t_dy1 = tpF[5][tri];
+                        float sb0 = tpF[0][tri], sb1 = tpF[1][tri];
+                        for (int k = py - t_minY; k > 0; k--) { sb0 += t_dy0; sb1 += t_dy1; }      // the serial loop's row stepping
+                        raster_row(gsink, py, t_minX, t_w, useScanlineRanges, sb0, sb1, t_dx0, t_dx1, -(t_dx0 + t_dx1), tpF[6][tri], tpF[7][tri], tpF[8][tri], clusterIndex, waveBase + tri,
+                                   t_minX, t_minX + t_w - 1);
+                    }
+                    __syncthreads();
                 }
             }
             // A few bins per triangle: every lane appends its own records.  A slot in a bin costs an atomic with return on the
@@ -326,18 +351,21 @@ __global__ void __launch_bounds__(64) k_raster(RasterArgs a) {
 
 // One workgroup per bin: the bin's records are walked one lane per row (16 records at a time) with LDS atomic-min into a tile
 // of keys; the tile is then merged into the visibility buffer in 64 B pieces (8 vertically adjacent pixels of a tile column).
-__global__ void __launch_bounds__(256) k_raster_bins(RasterArgs a) {
+#ifndef BRMI_BIN_THREADS
+#define BRMI_BIN_THREADS 512
+#endif
+__global__ void __launch_bounds__(BRMI_BIN_THREADS) k_raster_bins(RasterArgs a) {
     __shared__ unsigned long long tile[BIN_W * BIN_ROWS];
     const uint32_t strip = blockIdx.x, band = blockIdx.y, bin = band * a.binsX + strip;
     const uint32_t n = min(a.binCounts[bin], a.binCapacity);
     if (n == 0) return;
-    for (uint32_t i = threadIdx.x; i < BIN_W * BIN_ROWS; i += 256) tile[i] = BRMI_VIS_EMPTY;
+    for (uint32_t i = threadIdx.x; i < BIN_W * BIN_ROWS; i += BRMI_BIN_THREADS) tile[i] = BRMI_VIS_EMPTY;
     __syncthreads();
     const int x0 = (int)(strip << BIN_W_SHIFT), y0 = (int)(band << BIN_ROWS_SHIFT);
     const LdsSink sink{tile, x0, y0};
     const BinRecord* recs = a.binRecords + (size_t)bin * a.binCapacity;
     const uint32_t sub = threadIdx.x >> 4, row = threadIdx.x & 15u;
-    for (uint32_t base = 0; base < n; base += 16) {
+    for (uint32_t base = 0; base < n; base += BRMI_BIN_THREADS / 16) {
         const uint32_t ri = base + sub;
         if (ri >= n) continue;
         const BinRecord r = recs[ri];
@@ -353,7 +381,7 @@ __global__ void __launch_bounds__(256) k_raster_bins(RasterArgs a) {
     }
     __syncthreads();
     // merge: item = (column x, upper / lower 8 rows) = 8 keys = 64 B, contiguous in the tile and in the 8x8-tiled surface
-    for (uint32_t item = threadIdx.x; item < BIN_W * 2; item += 256) {
+    for (uint32_t item = threadIdx.x; item < BIN_W * 2; item += BRMI_BIN_THREADS) {
         const uint32_t half = item >> 8 /* BIN_W items per half */, xl = item & (BIN_W - 1);
         const ulonglong2* src = reinterpret_cast<const ulonglong2*>(&tile[xl * BIN_ROWS + half * 8u]);
         ulonglong2 k[4];
@@ -401,7 +429,7 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
     a.bigTriArea = p->bigTriArea; a.debugFlags = p->rasterDebug;
     BRMI_HIP(p, hipMemsetAsync(a.binCounts, 0, (size_t)p->binsX * p->binsY * sizeof(uint32_t), s));
     hipLaunchKernelGGL(k_raster, dim3(256 * 16), dim3(64), 0, s, a);
-    if (!(p->rasterDebug & 4)) hipLaunchKernelGGL(k_raster_bins, dim3(p->binsX, p->binsY), dim3(256), 0, s, a);
+    if (!(p->rasterDebug & 4)) hipLaunchKernelGGL(k_raster_bins, dim3(p->binsX, p->binsY), dim3(BRMI_BIN_THREADS), 0, s, a);
     BRMI_LAUNCH_CHECK(p, "k_raster");
     return BRMI_OK;
 }
