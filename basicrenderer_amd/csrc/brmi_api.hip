@@ -98,6 +98,7 @@ static void compute_sizes(brmi_pass* p) {
     p->binsX = (c.width + 255) / 256; p->binsY = (c.height + 15) / 16;
     w.binCounts = take((uint64_t)p->binsX * p->binsY * 4);
     w.binRecords = take((uint64_t)p->binsX * p->binsY * p->binCapacity * 64);
+    w.clusterSetup = take((uint64_t)c.maxVisibleClusters * sizeof(ClusterSetup));
     w.frameConst = take(3 * 64);
     w.matConst = take((uint64_t)std::max(1u, p->scene.openpbrMaterialCount) * 48);
     w.objConst = take((uint64_t)std::max(1u, p->scene.perObjectCount) * 36 * 4);
@@ -156,6 +157,7 @@ int brmi_create(const brmi_config* cfg, brmi_pass** out) {
     brmi_pass* p = new brmi_pass();
     p->cfg = *cfg;
     p->totalWords = 1; p->scanBlocks = 1;
+    if (const char* e = std::getenv("BRMI_RASTER_GRID")) p->rasterGrid = (uint32_t)std::max(64, std::atoi(e));
     if (const char* e = std::getenv("BRMI_RASTER_DEBUG")) p->rasterDebug = std::atoi(e);
     if (const char* e = std::getenv("BRMI_BIN_CAPACITY")) p->binCapacity = (uint32_t)std::max(1, std::atoi(e));
     if (const char* e = std::getenv("BRMI_BIG_TRI_AREA")) p->bigTriArea = std::max(1, std::atoi(e));

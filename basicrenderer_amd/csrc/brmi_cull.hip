@@ -470,7 +470,8 @@ __global__ void __launch_bounds__(256) k_scan_words(const uint32_t* bitmask, uin
 // shared words would serialise the whole rasteriser (~90 same-address atomics per microsecond).
 __global__ void __launch_bounds__(256) k_scatter_visible(const TempVisible* temp, uint32_t* counters, uint32_t tempCountIndex, const uint32_t* bitmask,
                                                         const uint32_t* wordPrefix, uint4* visible, uint32_t baseIndexCounter, uint32_t capacity, uint32_t visibleCapacity,
-                                                        const uint8_t* const* slabs) {
+                                                        brmi_scene_buffers sc, ClusterSetup* setup) {
+    const uint8_t* const* slabs = sc.slabs;
     const uint32_t n = min(counters[tempCountIndex], visibleCapacity);
     const uint32_t base = baseIndexCounter == 0xFFFFFFFFu ? 0u : counters[baseIndexCounter];
     const uint32_t rounded = (n + 63u) & ~63u;
@@ -490,6 +491,19 @@ __global__ void __launch_bounds__(256) k_scatter_visible(const TempVisible* temp
                 verts = min((desc->bitsAndVertexCount >> 24) & 0xFFu, BRMI_MESHLET_MAX_VERTS);
                 tris = min(desc->triangleCountAndRefinedGroup & 0xFFFFu, BRMI_MESHLET_MAX_TRIS);
                 placed = 1;
+                // resolve the cluster for the rasteriser and the G-buffer pass
+                const uint32_t instanceIndex = vc_instance(t.packed);
+                const brmi_per_mesh_instance inst = sc.perMeshInstance[instanceIndex];
+                const brmi_per_object* obj = sc.perObject + inst.perObjectBufferIndex;
+                ClusterSetup cs;
+                cs.posBase = slab + pageOff + hdr->positionBitstreamOffset + desc->positionBitOffset;
+                cs.triBase = slab + pageOff + hdr->triangleStreamOffset + desc->triangleByteOffset;
+                cs.nrmBase = slab + pageOff + hdr->normalArrayOffset + desc->vertexAttributeOffset * 4u;
+                cs.counts = verts | (tris << 8) | ((hdr->compressedPositionQuantExp & 0xFFu) << 16) | (((obj->objectFlags & BRMI_OBJECT_FLAG_REVERSE_WINDING) != 0 ? 1u : 0u) << 24);
+                cs.perObjectIndex = inst.perObjectBufferIndex; cs.instanceIndex = instanceIndex; cs.viewId = vc_view(t.packed);
+                cs.materialDataIndex = sc.perMesh[inst.perMeshBufferIndex].materialDataIndex; cs.normalMatrixIndex = obj->normalMatrixBufferIndex;
+                cs.pad[0] = cs.pad[1] = cs.pad[2] = cs.pad[3] = 0u;
+                setup[dst] = cs;
             }
         }
 #pragma unroll
@@ -568,7 +582,7 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
                        p->cfg.maxVisibleClusters, phase == 1 ? 0xFFFFFFFFu : (uint32_t)CNT_VISIBLE);
     hipLaunchKernelGGL(k_scan_words, dim3(p->scanBlocks), dim3(256), 0, s, bitmask, p->totalWords, blockSums, wordPrefix);
     hipLaunchKernelGGL(k_scatter_visible, dim3(maxBlocks), dim3(256), 0, s, temp, p->counters(), (uint32_t)(phase == 1 ? CNT_TEMP_VISIBLE : CNT_TEMP_VISIBLE2), bitmask, wordPrefix,
-                       static_cast<uint4*>(p->res[BRMI_RES_VISIBLE_CLUSTERS]), phase == 1 ? 0xFFFFFFFFu : (uint32_t)CNT_VISIBLE, p->cfg.maxVisibleClusters, p->cfg.maxVisibleClusters, p->scene.slabs);
+                       static_cast<uint4*>(p->res[BRMI_RES_VISIBLE_CLUSTERS]), phase == 1 ? 0xFFFFFFFFu : (uint32_t)CNT_VISIBLE, p->cfg.maxVisibleClusters, p->cfg.maxVisibleClusters, p->scene, p->wsPtr<ClusterSetup>(p->ws.clusterSetup));
     BRMI_LAUNCH_CHECK(p, "compaction");
     return BRMI_OK;
 }

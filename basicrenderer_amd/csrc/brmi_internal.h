@@ -45,6 +45,17 @@ struct BucketRecord {                                                           
 };
 struct TempVisible { uint4 packed; uint32_t bit, pad0, pad1, pad2; };                // 32 B
 
+// Everything the rasteriser and the G-buffer pass need to start on a visible cluster, resolved once by the compaction
+// kernel (one lane per cluster, all in flight): the per-cluster chain cluster -> slab -> page header -> meshlet descriptor
+// -> instance -> mesh / object is 6 dependent HBM round trips when every consumer walks it itself.
+struct ClusterSetup {                 // 64 B
+    const uint8_t* posBase; const uint8_t* triBase; const uint8_t* nrmBase;
+    uint32_t counts;                  // vertCount | triCount << 8 | positionFormat << 16 | reverseWinding << 24
+    uint32_t perObjectIndex, instanceIndex, viewId, materialDataIndex, normalMatrixIndex;
+    uint32_t pad[4];
+};
+static_assert(sizeof(ClusterSetup) == 64, "one cache line");
+
 // Linear-depth mip chain as the occlusion test sees it.  Mip 0 is the tiled LinearDepthMap itself (texels outside
 // width x height read as "empty"), mips >= 1 are row-major arrays inside BRMI_RES_HZB at mipOffset[mip] floats.
 constexpr uint32_t kMaxHzbMips = 16;
@@ -56,7 +67,7 @@ struct HzbDesc {
 
 struct Workspace {     // byte offsets into BRMI_RES_WORKSPACE
     uint64_t counters, frontierA, frontierB, buckets, tempVisible, bitmask1, bitmask2, wordPrefix, blockSums,
-             instanceBitBase, segPrefix, planes, replayNodes, replayBuckets, lightVS, lightMeta, clusterPages, binCounts, binRecords, lutF, frameConst, objConst, matConst, deferredPixels, total;
+             instanceBitBase, segPrefix, planes, replayNodes, replayBuckets, lightVS, lightMeta, clusterPages, binCounts, binRecords, clusterSetup, lutF, frameConst, objConst, matConst, deferredPixels, total;
 };
 
 }  // namespace brmi
@@ -77,6 +88,7 @@ struct brmi_pass {
     uint64_t totalBits = 0; uint32_t totalWords = 0, scanBlocks = 0;
     uint32_t numLightClusters = 0, lightPagePool = 0;
     uint32_t binsX = 0, binsY = 0, binCapacity = 1024;   // raster bins: 256 px x 16 rows, binCapacity records of 64 B each (BRMI_BIN_CAPACITY)
+    uint32_t rasterGrid = 4096;  // single-wave workgroups of k_raster (BRMI_RASTER_GRID)
     int rasterDebug = 0;         // BRMI_RASTER_DEBUG (experiments; non-zero gives wrong images)
     int bigTriArea = 128;        // clamped-bbox pixels above which a triangle is binned (BRMI_BIG_TRI_AREA)
     uint32_t hzbMipCount = 0; std::vector<uint64_t> hzbMipOffsets; std::vector<uint32_t> hzbMipW, hzbMipH;   // [mip]; offsets in floats, mip 0 unused

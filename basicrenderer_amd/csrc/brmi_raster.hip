@@ -45,9 +45,9 @@ struct RasterArgs {
     BinRecord* binRecords; uint32_t* binCounts; uint32_t binCapacity, binsX, binsY;
     const float* objConst;   // per object: MVP (16), objectToClip (16), modelViewZ (4)
     int bigTriArea;          // clamped-bbox pixels above which a triangle is binned
-    int debugFlags;          // experiments only (BRMI_RASTER_DEBUG): 1 = skip the direct walk, 2 = skip bin emission, 4 = skip the bin pass
+    int debugFlags;          // experiments only (BRMI_RASTER_DEBUG): 1 = skip the direct walk, 2 = skip bin emission, 4 = skip the bin pass, 8 = direct walk without the atomic
     brmi_scene_buffers sc;
-    const uint4* clusters;
+    const uint4* clusters; const ClusterSetup* setup;
     uint32_t* counters;
     uint32_t firstCounter, countCounter;   // counter indices: first cluster (0xFFFFFFFF = 0) and cluster count
     unsigned long long* vis;
@@ -71,8 +71,9 @@ BRMI_DEV void clip_scanline(float value, float step, int& first, int& last, bool
 
 // Where a key goes: the visibility buffer (tiled, 64-bit atomic min in L2) or the LDS tile of a bin.
 struct GlobalSink {
-    unsigned long long* vis; uint32_t tilesX;
+    unsigned long long* vis; uint32_t tilesX; int dbg;
     BRMI_DEV void operator()(int px, int py, unsigned long long key) const {
+        if (dbg & 8) { if (key == 0x1234567ull) vis[0] = key; return; }
         atomicMin(&vis[tiled_index((uint32_t)px, (uint32_t)py, tilesX)], key);
     }
 };
@@ -126,7 +127,7 @@ BRMI_DEV void bin_store(const RasterArgs& a, const BinRecord& r, uint32_t strip,
     const uint32_t bin = band * a.binsX + strip;
     if (slot < a.binCapacity) { a.binRecords[(size_t)bin * a.binCapacity + slot] = r; return; }
     atomicAdd(&a.counters[CNT_BIN_OVERFLOW], 1u);
-    const GlobalSink sink{a.vis, a.tilesX};
+    const GlobalSink sink{a.vis, a.tilesX, 0};
     float sb0 = r.sb0, sb1 = r.sb1;
     const int n = (int)((r.triAndFlags >> 16) & 0xFFu);
     for (int k = 0; k < n; k++) {
@@ -151,31 +152,22 @@ __global__ void __launch_bounds__(64) k_raster(RasterArgs a) {
     const uint32_t lane = threadIdx.x;
     const uint32_t first = a.firstCounter == 0xFFFFFFFFu ? 0u : a.counters[a.firstCounter];
     const uint32_t count = a.counters[a.countCounter];
-    const GlobalSink gsink{a.vis, a.tilesX};
+    const GlobalSink gsink{a.vis, a.tilesX, a.debugFlags};
     // static round-robin over clusters: a shared queue head saturates at ~90 dequeues/us (MI355X_MICROARCH.md, row
     // "dequeue"), which is slower than the work itself once big triangles are handed off
     for (uint32_t c = blockIdx.x; c < count; c += gridDim.x) {
         const uint32_t clusterIndex = first + c;
-        const uint4 pc = a.clusters[clusterIndex];
-        const uint32_t viewID = vc_view(pc), instanceID = vc_instance(pc), localMeshlet = vc_meshlet(pc);
-        const uint8_t* slab = sc.slabs[vc_slab(pc)];
-        const uint32_t pageOff = vc_page_offset(pc);
-        const brmi_page_header* hdr = reinterpret_cast<const brmi_page_header*>(slab + pageOff);
-        const brmi_meshlet_descriptor* desc = reinterpret_cast<const brmi_meshlet_descriptor*>(slab + pageOff + hdr->descriptorOffset + localMeshlet * 64u);
-        const uint32_t vertCount = min((desc->bitsAndVertexCount >> 24) & 0xFFu, BRMI_MESHLET_MAX_VERTS);
-        const uint32_t triCount = min(desc->triangleCountAndRefinedGroup & 0xFFFFu, BRMI_MESHLET_MAX_TRIS);
-        const brmi_per_mesh_instance* meshInst = sc.perMeshInstance + instanceID;
-        const brmi_per_object* obj = sc.perObject + meshInst->perObjectBufferIndex;
-        const brmi_view_raster_info ri = sc.viewRasterInfo[viewID];
+        const ClusterSetup cs = a.setup[clusterIndex];        // resolved by the compaction kernel: one hop instead of six
+        const uint32_t vertCount = cs.counts & 0xFFu, triCount = (cs.counts >> 8) & 0xFFu, posFormat = (cs.counts >> 16) & 0xFFu;
+        const bool reverseWinding = (cs.counts >> 24) != 0u;
+        const brmi_view_raster_info ri = sc.viewRasterInfo[cs.viewId];
         const float visWidth = (float)(ri.scissorMaxX - ri.scissorMinX), visHeight = (float)(ri.scissorMaxY - ri.scissorMinY);
         const float sMinXf = (float)ri.scissorMinX, sMinYf = (float)ri.scissorMinY;
-        const float* oc = a.objConst + (size_t)meshInst->perObjectBufferIndex * 36u;
+        const float* oc = a.objConst + (size_t)cs.perObjectIndex * 36u;
         const m4 mvp = load_m4(oc);
         const f4 modelViewZ{oc[32], oc[33], oc[34], oc[35]};
-        const uint32_t posFormat = hdr->compressedPositionQuantExp;
-        const uint8_t* posBase = slab + pageOff + hdr->positionBitstreamOffset + desc->positionBitOffset;
-        const uint8_t* triBase = slab + pageOff + hdr->triangleStreamOffset + desc->triangleByteOffset;
-        const bool reverseWinding = (obj->objectFlags & BRMI_OBJECT_FLAG_REVERSE_WINDING) != 0;
+        const uint8_t* posBase = cs.posBase;
+        const uint8_t* triBase = cs.triBase;
 
         // vertex stage -> LDS (softwareRaster.hlsl:339-387)
         for (uint32_t v = lane; v < vertCount; v += 64) {
@@ -419,6 +411,7 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
     if (phase == 2 && !p->cfg.enableOcclusionCulling) return fail(p, BRMI_ERR_STATE, "brmi_raster: phase 2 needs a pass created with enableOcclusionCulling");
     RasterArgs a;
     a.sc = p->scene; a.clusters = static_cast<const uint4*>(p->res[BRMI_RES_VISIBLE_CLUSTERS]); a.counters = p->counters();
+    a.setup = p->wsPtr<ClusterSetup>(p->ws.clusterSetup);
     a.firstCounter = 0xFFFFFFFFu; a.countCounter = CNT_VISIBLE;
     if (phase == 2) { a.firstCounter = CNT_VISIBLE; a.countCounter = CNT_VISIBLE2; }   // clusters [visible1, visible1 + visible2)
     a.vis = static_cast<unsigned long long*>(p->res[BRMI_RES_VISIBILITY]);
@@ -428,7 +421,7 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
     a.objConst = p->wsPtr<float>(p->ws.objConst);
     a.bigTriArea = p->bigTriArea; a.debugFlags = p->rasterDebug;
     BRMI_HIP(p, hipMemsetAsync(a.binCounts, 0, (size_t)p->binsX * p->binsY * sizeof(uint32_t), s));
-    hipLaunchKernelGGL(k_raster, dim3(256 * 16), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_raster, dim3(p->rasterGrid), dim3(64), 0, s, a);
     if (!(p->rasterDebug & 4)) hipLaunchKernelGGL(k_raster_bins, dim3(p->binsX, p->binsY), dim3(BRMI_BIN_THREADS), 0, s, a);
     BRMI_LAUNCH_CHECK(p, "k_raster");
     return BRMI_OK;
