@@ -99,6 +99,11 @@ static void compute_sizes(brmi_pass* p) {
     w.binCounts = take((uint64_t)p->binsX * p->binsY * 4);
     w.binRecords = take((uint64_t)p->binsX * p->binsY * p->binCapacity * 64);
     w.clusterSetup = take((uint64_t)c.maxVisibleClusters * sizeof(ClusterSetup));
+    // resolve arena: full tables for up to 65536 clusters (more when they are not full); clusters beyond it are resolved per pixel
+    p->resolveCapacity = (uint32_t)std::min<uint64_t>((uint64_t)c.maxVisibleClusters, 65536ull) * BRMI_MESHLET_MAX_TRIS;
+    w.resolveVerts = take((uint64_t)p->resolveCapacity * sizeof(ResolveVertex));
+    w.resolveTris = take((uint64_t)p->resolveCapacity * sizeof(ResolveTriangle));
+    w.matWords = take((uint64_t)std::max(1u, p->scene.materialCount) * sizeof(MaterialWords));
     w.frameConst = take(3 * 64);
     w.matConst = take((uint64_t)std::max(1u, p->scene.openpbrMaterialCount) * 48);
     w.objConst = take((uint64_t)std::max(1u, p->scene.perObjectCount) * 36 * 4);

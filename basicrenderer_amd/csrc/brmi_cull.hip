@@ -470,48 +470,68 @@ __global__ void __launch_bounds__(256) k_scan_words(const uint32_t* bitmask, uin
 // shared words would serialise the whole rasteriser (~90 same-address atomics per microsecond).
 __global__ void __launch_bounds__(256) k_scatter_visible(const TempVisible* temp, uint32_t* counters, uint32_t tempCountIndex, const uint32_t* bitmask,
                                                         const uint32_t* wordPrefix, uint4* visible, uint32_t baseIndexCounter, uint32_t capacity, uint32_t visibleCapacity,
-                                                        brmi_scene_buffers sc, ClusterSetup* setup) {
+                                                        brmi_scene_buffers sc, ClusterSetup* setup, uint32_t resolveCapacity) {
     const uint8_t* const* slabs = sc.slabs;
     const uint32_t n = min(counters[tempCountIndex], visibleCapacity);
     const uint32_t base = baseIndexCounter == 0xFFFFFFFFu ? 0u : counters[baseIndexCounter];
     const uint32_t rounded = (n + 63u) & ~63u;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += gridDim.x * blockDim.x) {
-        uint32_t verts = 0, tris = 0, placed = 0;
+        uint32_t verts = 0, tris = 0, placed = 0, dst = 0;
+        TempVisible t{};
+        const uint8_t* slab = nullptr; uint32_t pageOff = 0;
+        const brmi_page_header* hdr = nullptr; const brmi_meshlet_descriptor* desc = nullptr;
         if (i < n) {
-            const TempVisible t = temp[i];
+            t = temp[i];
             const uint32_t w = t.bit >> 5, b = t.bit & 31u;
             const uint32_t rank = wordPrefix[w] + __popc(bitmask[w] & ((1u << b) - 1u));
-            const uint32_t dst = base + rank;
+            dst = base + rank;
             if (dst < capacity) {
                 visible[dst] = t.packed;
-                const uint8_t* slab = slabs[vc_slab(t.packed)];
-                const uint32_t pageOff = vc_page_offset(t.packed);
-                const brmi_page_header* hdr = reinterpret_cast<const brmi_page_header*>(slab + pageOff);
-                const brmi_meshlet_descriptor* desc = reinterpret_cast<const brmi_meshlet_descriptor*>(slab + pageOff + hdr->descriptorOffset + vc_meshlet(t.packed) * 64u);
+                slab = slabs[vc_slab(t.packed)];
+                pageOff = vc_page_offset(t.packed);
+                hdr = reinterpret_cast<const brmi_page_header*>(slab + pageOff);
+                desc = reinterpret_cast<const brmi_meshlet_descriptor*>(slab + pageOff + hdr->descriptorOffset + vc_meshlet(t.packed) * 64u);
                 verts = min((desc->bitsAndVertexCount >> 24) & 0xFFu, BRMI_MESHLET_MAX_VERTS);
                 tris = min(desc->triangleCountAndRefinedGroup & 0xFFFFu, BRMI_MESHLET_MAX_TRIS);
                 placed = 1;
-                // resolve the cluster for the rasteriser and the G-buffer pass
-                const uint32_t instanceIndex = vc_instance(t.packed);
-                const brmi_per_mesh_instance inst = sc.perMeshInstance[instanceIndex];
-                const brmi_per_object* obj = sc.perObject + inst.perObjectBufferIndex;
-                ClusterSetup cs;
-                cs.posBase = slab + pageOff + hdr->positionBitstreamOffset + desc->positionBitOffset;
-                cs.triBase = slab + pageOff + hdr->triangleStreamOffset + desc->triangleByteOffset;
-                cs.nrmBase = slab + pageOff + hdr->normalArrayOffset + desc->vertexAttributeOffset * 4u;
-                cs.counts = verts | (tris << 8) | ((hdr->compressedPositionQuantExp & 0xFFu) << 16) | (((obj->objectFlags & BRMI_OBJECT_FLAG_REVERSE_WINDING) != 0 ? 1u : 0u) << 24);
-                cs.perObjectIndex = inst.perObjectBufferIndex; cs.instanceIndex = instanceIndex; cs.viewId = vc_view(t.packed);
-                cs.materialDataIndex = sc.perMesh[inst.perMeshBufferIndex].materialDataIndex; cs.normalMatrixIndex = obj->normalMatrixBufferIndex;
-                cs.pad[0] = cs.pad[1] = cs.pad[2] = cs.pad[3] = 0u;
-                setup[dst] = cs;
             }
         }
+        // wave totals (statistics) double as the reservation of the cluster's tables in the resolve arena: the value the
+        // atomic returns is the wave's base, an exclusive scan over the lanes gives every cluster its offset
+        uint32_t inclV = verts, inclT = tris;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { verts += (uint32_t)__shfl_xor((int)verts, o); tris += (uint32_t)__shfl_xor((int)tris, o); placed += (uint32_t)__shfl_xor((int)placed, o); }
-        if ((threadIdx.x & 63u) == 0 && placed != 0) {
-            atomicAdd(reinterpret_cast<unsigned long long*>(&counters[CNT_SUM_VERTS_LO]), (unsigned long long)verts);
-            atomicAdd(reinterpret_cast<unsigned long long*>(&counters[CNT_SUM_TRIS_LO]), (unsigned long long)tris);
-            atomicAdd(&counters[CNT_RASTER_CLUSTERS], placed);
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = (uint32_t)__shfl_up((int)inclV, o), tt = (uint32_t)__shfl_up((int)inclT, o);
+            if ((threadIdx.x & 63u) >= (uint32_t)o) { inclV += v; inclT += tt; }
+        }
+        const uint32_t totV = (uint32_t)__shfl((int)inclV, 63), totT = (uint32_t)__shfl((int)inclT, 63);
+        const uint64_t anyPlaced = __ballot(placed != 0);
+        unsigned long long baseV = 0, baseT = 0;
+        if (anyPlaced != 0ull) {
+            if ((threadIdx.x & 63u) == 0) {
+                baseV = atomicAdd(reinterpret_cast<unsigned long long*>(&counters[CNT_SUM_VERTS_LO]), (unsigned long long)totV);
+                baseT = atomicAdd(reinterpret_cast<unsigned long long*>(&counters[CNT_SUM_TRIS_LO]), (unsigned long long)totT);
+                atomicAdd(&counters[CNT_RASTER_CLUSTERS], (uint32_t)__popcll(anyPlaced));
+            }
+            baseV = __shfl((unsigned long long)baseV, 0); baseT = __shfl((unsigned long long)baseT, 0);
+        }
+        if (placed) {
+            // resolve the cluster for the rasteriser and the G-buffer pass
+            const uint32_t instanceIndex = vc_instance(t.packed);
+            const brmi_per_mesh_instance inst = sc.perMeshInstance[instanceIndex];
+            const brmi_per_object* obj = sc.perObject + inst.perObjectBufferIndex;
+            ClusterSetup cs;
+            cs.posBase = slab + pageOff + hdr->positionBitstreamOffset + desc->positionBitOffset;
+            cs.triBase = slab + pageOff + hdr->triangleStreamOffset + desc->triangleByteOffset;
+            cs.nrmBase = slab + pageOff + hdr->normalArrayOffset + desc->vertexAttributeOffset * 4u;
+            cs.counts = verts | (tris << 8) | ((hdr->compressedPositionQuantExp & 0xFFu) << 16) | (((obj->objectFlags & BRMI_OBJECT_FLAG_REVERSE_WINDING) != 0 ? 1u : 0u) << 24);
+            cs.perObjectIndex = inst.perObjectBufferIndex; cs.instanceIndex = instanceIndex; cs.viewId = vc_view(t.packed);
+            cs.materialDataIndex = sc.perMesh[inst.perMeshBufferIndex].materialDataIndex; cs.normalMatrixIndex = obj->normalMatrixBufferIndex;
+            const unsigned long long v0 = baseV + (inclV - verts), t0 = baseT + (inclT - tris);
+            const bool fits = v0 + verts <= resolveCapacity && t0 + tris <= resolveCapacity;
+            cs.vertBase = fits ? (uint32_t)v0 : BRMI_ARENA_NONE; cs.triBase32 = fits ? (uint32_t)t0 : BRMI_ARENA_NONE;
+            cs.pad[0] = cs.pad[1] = 0u;
+            setup[dst] = cs;
         }
     }
 }
@@ -582,7 +602,7 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
                        p->cfg.maxVisibleClusters, phase == 1 ? 0xFFFFFFFFu : (uint32_t)CNT_VISIBLE);
     hipLaunchKernelGGL(k_scan_words, dim3(p->scanBlocks), dim3(256), 0, s, bitmask, p->totalWords, blockSums, wordPrefix);
     hipLaunchKernelGGL(k_scatter_visible, dim3(maxBlocks), dim3(256), 0, s, temp, p->counters(), (uint32_t)(phase == 1 ? CNT_TEMP_VISIBLE : CNT_TEMP_VISIBLE2), bitmask, wordPrefix,
-                       static_cast<uint4*>(p->res[BRMI_RES_VISIBLE_CLUSTERS]), phase == 1 ? 0xFFFFFFFFu : (uint32_t)CNT_VISIBLE, p->cfg.maxVisibleClusters, p->cfg.maxVisibleClusters, p->scene, p->wsPtr<ClusterSetup>(p->ws.clusterSetup));
+                       static_cast<uint4*>(p->res[BRMI_RES_VISIBLE_CLUSTERS]), phase == 1 ? 0xFFFFFFFFu : (uint32_t)CNT_VISIBLE, p->cfg.maxVisibleClusters, p->cfg.maxVisibleClusters, p->scene, p->wsPtr<ClusterSetup>(p->ws.clusterSetup), p->resolveCapacity);
     BRMI_LAUNCH_CHECK(p, "compaction");
     return BRMI_OK;
 }

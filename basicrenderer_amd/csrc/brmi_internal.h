@@ -52,8 +52,15 @@ struct ClusterSetup {                 // 64 B
     const uint8_t* posBase; const uint8_t* triBase; const uint8_t* nrmBase;
     uint32_t counts;                  // vertCount | triCount << 8 | positionFormat << 16 | reverseWinding << 24
     uint32_t perObjectIndex, instanceIndex, viewId, materialDataIndex, normalMatrixIndex;
-    uint32_t pad[4];
+    uint32_t vertBase, triBase32;     // first ResolveVertex / ResolveTriangle of the cluster in the resolve arena (BRMI_ARENA_NONE: none)
+    uint32_t pad[2];
 };
+constexpr uint32_t BRMI_ARENA_NONE = 0xFFFFFFFFu;
+// resolve arena: per-vertex and per-triangle tables of the visible clusters (brmi_resolve.hip)
+struct ResolveVertex { float px, py, pz, nx, ny, nz; };                                   // 24 B: object-space position, decoded normal
+struct ResolveTriangle { float n0x, n0y, invW0, ddx[3], ddy[3], ddxSum, ddySum; uint32_t indices; };   // 48 B: triangle part of CalcFullBary
+struct MaterialWords { uint32_t albedo, metallicRoughness; unsigned long long coat, emissive, fuzz; float opIndexF; uint32_t pad; };   // 40 B
+static_assert(sizeof(ResolveVertex) == 24 && sizeof(ResolveTriangle) == 48 && sizeof(MaterialWords) == 40, "table layouts");
 static_assert(sizeof(ClusterSetup) == 64, "one cache line");
 
 // Linear-depth mip chain as the occlusion test sees it.  Mip 0 is the tiled LinearDepthMap itself (texels outside
@@ -67,7 +74,7 @@ struct HzbDesc {
 
 struct Workspace {     // byte offsets into BRMI_RES_WORKSPACE
     uint64_t counters, frontierA, frontierB, buckets, tempVisible, bitmask1, bitmask2, wordPrefix, blockSums,
-             instanceBitBase, segPrefix, planes, replayNodes, replayBuckets, lightVS, lightMeta, clusterPages, binCounts, binRecords, clusterSetup, lutF, frameConst, objConst, matConst, deferredPixels, total;
+             instanceBitBase, segPrefix, planes, replayNodes, replayBuckets, lightVS, lightMeta, clusterPages, binCounts, binRecords, clusterSetup, resolveVerts, resolveTris, matWords, lutF, frameConst, objConst, matConst, deferredPixels, total;
 };
 
 }  // namespace brmi
@@ -88,6 +95,7 @@ struct brmi_pass {
     uint64_t totalBits = 0; uint32_t totalWords = 0, scanBlocks = 0;
     uint32_t numLightClusters = 0, lightPagePool = 0;
     uint32_t binsX = 0, binsY = 0, binCapacity = 1024;   // raster bins: 256 px x 16 rows, binCapacity records of 64 B each (BRMI_BIN_CAPACITY)
+    uint32_t resolveCapacity = 0;   // vertices (and triangles) the resolve arena holds
     uint32_t rasterGrid = 4096;  // single-wave workgroups of k_raster (BRMI_RASTER_GRID)
     int rasterDebug = 0;         // BRMI_RASTER_DEBUG (experiments; non-zero gives wrong images)
     int bigTriArea = 128;        // clamped-bbox pixels above which a triangle is binned (BRMI_BIG_TRI_AREA)

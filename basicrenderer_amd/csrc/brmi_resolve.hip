@@ -27,29 +27,9 @@ struct GBufferArgs {
     uint32_t W, H, tilesX, bandY0, bandY1; uint64_t firstPixel, pixelCount;
     uint32_t clusterCapacity;
     const m4* frameConst; const float* objConst;
+    const ClusterSetup* setup; ResolveVertex* verts; ResolveTriangle* tris; uint32_t vertCapacity, triCapacity;
+    MaterialWords* matWords;
 };
-
-struct Bary { f3 lambda; };
-
-// CalcFullBary: only lambda is consumed when no texture / normal map is bound
-BRMI_DEV f3 calc_bary_lambda(f4 pt0, f4 pt1, f4 pt2, float ndcX, float ndcY) {
-    const f3 invW{rcpf(pt0.w), rcpf(pt1.w), rcpf(pt2.w)};
-    const float n0x = pt0.x * invW.x, n0y = pt0.y * invW.x, n1x = pt1.x * invW.y, n1y = pt1.y * invW.y, n2x = pt2.x * invW.z, n2y = pt2.y * invW.z;
-    const float ax = n2x - n1x, ay = n2y - n1y, bx = n0x - n1x, by = n0y - n1y;
-    const float invDet = rcpf(ax * by - ay * bx);
-    const f3 ddx = f3{n1y - n2y, n2y - n0y, n0y - n1y} * invDet * invW;
-    const f3 ddy = f3{n2x - n1x, n0x - n2x, n1x - n0x} * invDet * invW;
-    const float ddxSum = dot3(ddx, f3{1.0f, 1.0f, 1.0f});
-    const float ddySum = dot3(ddy, f3{1.0f, 1.0f, 1.0f});
-    const float dx = ndcX - n0x, dy = ndcY - n0y;
-    const float interpInvW = invW.x + dx * ddxSum + dy * ddySum;
-    const float interpW = rcpf(interpInvW);
-    f3 l;
-    l.x = interpW * (invW.x + dx * ddx.x + dy * ddy.x);
-    l.y = interpW * (0.0f + dx * ddx.y + dy * ddy.y);
-    l.z = interpW * (0.0f + dx * ddx.z + dy * ddy.z);
-    return l;
-}
 
 BRMI_DEV f3 oct_decode_normal(uint32_t packed) {
     const int sp = (int)packed;
@@ -64,88 +44,202 @@ BRMI_DEV f3 oct_decode_normal(uint32_t packed) {
     return normalize3(v);
 }
 
+// The constant-factor material of SampleMaterialEvalFromUvCache (no texture permutations) only depends on the material
+// record: its five packed G-buffer words are evaluated once per material per frame instead of once per pixel.
+__global__ void __launch_bounds__(64) k_material_words(brmi_scene_buffers sc, MaterialWords* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= sc.materialCount) return;
+    const brmi_material_info* mat = sc.materials + i;
+    const f3 baseColor = f3{mat->baseColorFactor[0], mat->baseColorFactor[1], mat->baseColorFactor[2]} * f3{1.0f, 1.0f, 1.0f};
+    const float metallic = mat->metallicFactor, roughness = mat->roughnessFactor, ao = 1.0f;
+    const f3 emissiveIn{mat->emissiveFactor[0], mat->emissiveFactor[1], mat->emissiveFactor[2]};
+    const uint32_t opIndex = mat->openPBRMaterialDataIndex;
+    const brmi_openpbr_material_info* op = sc.openpbrMaterials + opIndex;
+    const f3 canonicalEmissive = f3{op->emissionColor[0], op->emissionColor[1], op->emissionColor[2]} * op->emissionLuminance;
+    const f3 coatColor = sat3(f3{op->coatColor[0], op->coatColor[1], op->coatColor[2]});
+    const float coatWeight = sat(op->coatWeight), coatRoughness = sat(op->coatRoughness);
+    const f3 fuzzColor = sat3(f3{op->fuzzColor[0], op->fuzzColor[1], op->fuzzColor[2]});
+    const float fuzzWeight = sat(op->fuzzWeight), fuzzRoughness = sat(op->fuzzRoughness);
+    const f3 emissive = dot3(emissiveIn, emissiveIn) > 0.0f ? emissiveIn : canonicalEmissive;
+    MaterialWords w;
+    w.albedo = pack_unorm4(baseColor.x, baseColor.y, baseColor.z, ao);
+    w.metallicRoughness = pack_unorm4(metallic, roughness, coatRoughness, fuzzWeight);
+    w.coat = pack_half4(coatColor.x, coatColor.y, coatColor.z, coatWeight);
+    w.emissive = pack_half4(emissive.x, emissive.y, emissive.z, 0.0f);
+    w.fuzz = pack_half4(fuzzColor.x, fuzzColor.y, fuzzColor.z, fuzzRoughness);
+    w.opIndexF = (float)opIndex; w.pad = 0u;
+    out[i] = w;
+}
+
+// Per-cluster resolve tables, one wave64 per visible cluster.  Everything CalcFullBary (clodResolveCommon.hlsli:104-143)
+// derives from the triangle alone -- the three projected vertices, 1/w, the screen-space derivatives of the barycentrics --
+// and the decoded vertex normals are evaluated once per triangle / vertex here with the shader's operation order; the pixel
+// pass then only evaluates the part that depends on the pixel.  (The reference shader recomputes all of it per pixel.)
+__global__ void __launch_bounds__(64) k_resolve_setup(GBufferArgs a) {
+    __shared__ float cx[BRMI_MESHLET_MAX_VERTS], cy[BRMI_MESHLET_MAX_VERTS], cw[BRMI_MESHLET_MAX_VERTS];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t clusterCount = min(a.counters[CNT_VISIBLE] + a.counters[CNT_VISIBLE2], a.clusterCapacity);
+    for (uint32_t c = blockIdx.x; c < clusterCount; c += gridDim.x) {
+        const ClusterSetup cs = a.setup[c];
+        if (cs.vertBase == BRMI_ARENA_NONE) continue;          // arena full: the pixel pass walks this cluster's data itself
+        const uint32_t vertCount = cs.counts & 0xFFu, triCount = (cs.counts >> 8) & 0xFFu, posFormat = (cs.counts >> 16) & 0xFFu;
+        const m4 objectToClip = load_m4(a.objConst + (size_t)cs.perObjectIndex * 36u + 16u);
+        for (uint32_t v = lane; v < vertCount; v += 64) {
+            f3 p{0.0f, 0.0f, 0.0f};
+            if (posFormat == BRMI_POSITION_FORMAT_FLOAT3) { const float* pp = reinterpret_cast<const float*>(cs.posBase + v * 12u); p = f3{pp[0], pp[1], pp[2]}; }
+            const f3 n = oct_decode_normal(*reinterpret_cast<const uint32_t*>(cs.nrmBase + v * 4u));
+            const f4 clip = mul_point(p, objectToClip);
+            cx[v] = clip.x; cy[v] = clip.y; cw[v] = clip.w;
+            a.verts[cs.vertBase + v] = ResolveVertex{p.x, p.y, p.z, n.x, n.y, n.z};
+        }
+        __syncthreads();
+        for (uint32_t t = lane; t < triCount; t += 64) {
+            const uint8_t* tb = cs.triBase + t * 3u;
+            const uint32_t i0 = tb[0], i1 = tb[1], i2 = tb[2];
+            // CalcFullBary, triangle part
+            const f3 invW{rcpf(cw[i0]), rcpf(cw[i1]), rcpf(cw[i2])};
+            const float n0x = cx[i0] * invW.x, n0y = cy[i0] * invW.x, n1x = cx[i1] * invW.y, n1y = cy[i1] * invW.y, n2x = cx[i2] * invW.z, n2y = cy[i2] * invW.z;
+            const float ax = n2x - n1x, ay = n2y - n1y, bx = n0x - n1x, by = n0y - n1y;
+            const float invDet = rcpf(ax * by - ay * bx);
+            const f3 ddx = f3{n1y - n2y, n2y - n0y, n0y - n1y} * invDet * invW;
+            const f3 ddy = f3{n2x - n1x, n0x - n2x, n1x - n0x} * invDet * invW;
+            ResolveTriangle r;
+            r.n0x = n0x; r.n0y = n0y; r.invW0 = invW.x;
+            r.ddx[0] = ddx.x; r.ddx[1] = ddx.y; r.ddx[2] = ddx.z; r.ddy[0] = ddy.x; r.ddy[1] = ddy.y; r.ddy[2] = ddy.z;
+            r.ddxSum = dot3(ddx, f3{1.0f, 1.0f, 1.0f}); r.ddySum = dot3(ddy, f3{1.0f, 1.0f, 1.0f});
+            r.indices = i0 | (i1 << 8) | (i2 << 16);
+            a.tris[cs.triBase32 + t] = r;
+        }
+        __syncthreads();
+    }
+}
+
+// CalcFullBary, pixel part: only lambda is consumed when no texture / normal map is bound
+BRMI_DEV f3 bary_lambda(const ResolveTriangle& r, float ndcX, float ndcY) {
+    const float dx = ndcX - r.n0x, dy = ndcY - r.n0y;
+    const float interpInvW = r.invW0 + dx * r.ddxSum + dy * r.ddySum;
+    const float interpW = rcpf(interpInvW);
+    f3 l;
+    l.x = interpW * (r.invW0 + dx * r.ddx[0] + dy * r.ddy[0]);
+    l.y = interpW * (0.0f + dx * r.ddx[1] + dy * r.ddy[1]);
+    l.z = interpW * (0.0f + dx * r.ddx[2] + dy * r.ddy[2]);
+    return l;
+}
+
+// triangle + vertex tables of one pixel when its cluster has no arena space: the chain the setup kernel walks, per pixel
+BRMI_DEV void resolve_tables_inline(const GBufferArgs& a, const ClusterSetup& cs, uint32_t triId, ResolveTriangle& r, f3 p[3], f3 n[3]) {
+    const uint8_t* tb = cs.triBase + triId * 3u;
+    const uint32_t ti[3] = {tb[0], tb[1], tb[2]};
+    const m4 objectToClip = load_m4(a.objConst + (size_t)cs.perObjectIndex * 36u + 16u);
+    f4 clip[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        if (((cs.counts >> 16) & 0xFFu) == BRMI_POSITION_FORMAT_FLOAT3) { const float* pp = reinterpret_cast<const float*>(cs.posBase + ti[k] * 12u); p[k] = f3{pp[0], pp[1], pp[2]}; }
+        else p[k] = f3{0.0f, 0.0f, 0.0f};
+        n[k] = oct_decode_normal(*reinterpret_cast<const uint32_t*>(cs.nrmBase + ti[k] * 4u));
+        clip[k] = mul_point(p[k], objectToClip);
+    }
+    const f3 invW{rcpf(clip[0].w), rcpf(clip[1].w), rcpf(clip[2].w)};
+    const float n0x = clip[0].x * invW.x, n0y = clip[0].y * invW.x, n1x = clip[1].x * invW.y, n1y = clip[1].y * invW.y, n2x = clip[2].x * invW.z, n2y = clip[2].y * invW.z;
+    const float ax = n2x - n1x, ay = n2y - n1y, bx = n0x - n1x, by = n0y - n1y;
+    const float invDet = rcpf(ax * by - ay * bx);
+    const f3 ddx = f3{n1y - n2y, n2y - n0y, n0y - n1y} * invDet * invW;
+    const f3 ddy = f3{n2x - n1x, n0x - n2x, n1x - n0x} * invDet * invW;
+    r.n0x = n0x; r.n0y = n0y; r.invW0 = invW.x;
+    r.ddx[0] = ddx.x; r.ddx[1] = ddx.y; r.ddx[2] = ddx.z; r.ddy[0] = ddy.x; r.ddy[1] = ddy.y; r.ddy[2] = ddy.z;
+    r.ddxSum = dot3(ddx, f3{1.0f, 1.0f, 1.0f}); r.ddySum = dot3(ddy, f3{1.0f, 1.0f, 1.0f});
+    r.indices = ti[0] | (ti[1] << 8) | (ti[2] << 16);
+}
+
+template <typename M> BRMI_DEV m4 load_m4_any(const M* p) {     // p: float in the global or the constant address space
+    m4 r;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) r.m[i][j] = p[i * 4 + j];
+    return r;
+}
+
+constexpr int RESOLVE_WATERFALL = 4;     // distinct mesh instances per 8x8 tile handled with scalar loads before falling back
+
 __global__ void __launch_bounds__(256) k_gbuffer(GBufferArgs a) {
     const brmi_scene_buffers& sc = a.sc;
     const brmi_per_frame* pf = sc.perFrame;
-    const brmi_camera* cam = sc.cameras + pf->mainCameraIndex;
     const uint32_t clusterCount = min(a.counters[CNT_VISIBLE] + a.counters[CNT_VISIBLE2], a.clusterCapacity);
     // view-projection products are frame constants; every lane derives them the way the shader does
     const m4 unjVP = uni_m4(a.frameConst[1]), prevVP = uni_m4(a.frameConst[2]);
-    (void)cam;
     const float winX = uni((float)pf->screenResX), winY = uni((float)pf->screenResY);
-    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < a.pixelCount; j += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t end = (a.pixelCount + 63ull) & ~63ull;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < end; j += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t i = a.firstPixel + j;
         const uint32_t tile = (uint32_t)(i >> 6), within = (uint32_t)(i & 63u);
         const uint32_t px = (tile % a.tilesX) * 8u + (within >> 3), py = (tile / a.tilesX) * 8u + (within & 7u);
-        if (px >= a.W || py >= a.H || py < a.bandY0 || py >= a.bandY1) continue;
-        const unsigned long long key = a.vis[i];
-        if (a.depth) a.depth[i] = (key == BRMI_VIS_EMPTY) ? as_f32(BRMI_DEPTH_EMPTY_BITS) : as_f32(((uint32_t)(key >> BRMI_VIS_META_BITS)) << 1);
-        if (key == BRMI_VIS_EMPTY) continue;
+        bool valid = j < a.pixelCount && px < a.W && py < a.H && py >= a.bandY0 && py < a.bandY1;
+        unsigned long long key = BRMI_VIS_EMPTY;
+        if (valid) {
+            key = a.vis[i];
+            if (a.depth) a.depth[i] = (key == BRMI_VIS_EMPTY) ? as_f32(BRMI_DEPTH_EMPTY_BITS) : as_f32(((uint32_t)(key >> BRMI_VIS_META_BITS)) << 1);
+        }
         const uint32_t triId = (uint32_t)(key & 0x7Full);
         const uint32_t clusterIndex = (uint32_t)((key >> BRMI_VIS_TRI_BITS) & 0x3FFFFFFull);
-        if (clusterIndex >= clusterCount) continue;
-        const uint4 pc = a.clusters[clusterIndex];
-        const uint32_t instanceID = vc_instance(pc), localMeshlet = vc_meshlet(pc);
-        const brmi_per_mesh_instance inst = sc.perMeshInstance[instanceID];
-        const brmi_per_mesh* mesh = sc.perMesh + inst.perMeshBufferIndex;
-        const uint8_t* slab = sc.slabs[vc_slab(pc)];
-        const uint32_t pageOff = vc_page_offset(pc);
-        const brmi_page_header* hdr = reinterpret_cast<const brmi_page_header*>(slab + pageOff);
-        const brmi_meshlet_descriptor* desc = reinterpret_cast<const brmi_meshlet_descriptor*>(slab + pageOff + hdr->descriptorOffset + localMeshlet * 64u);
-        if (triId >= (desc->triangleCountAndRefinedGroup & 0xFFFFu)) continue;
-        const uint8_t* tb = slab + pageOff + hdr->triangleStreamOffset + desc->triangleByteOffset + triId * 3u;
-        const uint32_t ti[3] = {tb[0], tb[1], tb[2]};
-        const uint8_t* posBase = slab + pageOff + hdr->positionBitstreamOffset + desc->positionBitOffset;
-        const uint8_t* nrmBase = slab + pageOff + hdr->normalArrayOffset + desc->vertexAttributeOffset * 4u;
-        f3 p[3], n[3];
+        valid = valid && key != BRMI_VIS_EMPTY && clusterIndex < clusterCount;
+        ClusterSetup cs{};
+        if (valid) { cs = a.setup[clusterIndex]; valid = triId < ((cs.counts >> 8) & 0xFFu); }
+        // per-pixel part of the tables
+        ResolveTriangle r{}; f3 p[3] = {}, n[3] = {};
+        if (valid) {
+            if (cs.vertBase != BRMI_ARENA_NONE) {
+                r = a.tris[cs.triBase32 + triId];
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            if (hdr->compressedPositionQuantExp == BRMI_POSITION_FORMAT_FLOAT3) {
-                const float* pp = reinterpret_cast<const float*>(posBase + ti[k] * 12u);
-                p[k] = f3{pp[0], pp[1], pp[2]};
-            } else p[k] = f3{0.0f, 0.0f, 0.0f};
-            n[k] = oct_decode_normal(*reinterpret_cast<const uint32_t*>(nrmBase + ti[k] * 4u));
+                for (int k = 0; k < 3; k++) {
+                    const ResolveVertex v = a.verts[cs.vertBase + ((r.indices >> (8 * k)) & 0xFFu)];
+                    p[k] = f3{v.px, v.py, v.pz}; n[k] = f3{v.nx, v.ny, v.nz};
+                }
+            } else resolve_tables_inline(a, cs, triId, r, p, n);
         }
-        const brmi_per_object* obj = sc.perObject + inst.perObjectBufferIndex;
-        const brmi_material_info* mat = sc.materials + mesh->materialDataIndex;
-        const m4 model = load_m4(&obj->model[0][0]);
-        const m4 objectToClip = load_m4(a.objConst + (size_t)inst.perObjectBufferIndex * 36u + 16u);
-        const f4 clip0 = mul_point(p[0], objectToClip), clip1 = mul_point(p[1], objectToClip), clip2 = mul_point(p[2], objectToClip);
         const float uvx = ((float)px + 0.5f) / winX, uvy = ((float)py + 0.5f) / winY;
         const float ndcX = uvx * 2.0f - 1.0f, ndcY = (1.0f - uvy) * 2.0f - 1.0f;
-        const f3 l = calc_bary_lambda(clip0, clip1, clip2, ndcX, ndcY);
+        const f3 l = bary_lambda(r, ndcX, ndcY);
         const f3 posOS{dot3(f3{p[0].x, p[1].x, p[2].x}, l), dot3(f3{p[0].y, p[1].y, p[2].y}, l), dot3(f3{p[0].z, p[1].z, p[2].z}, l)};
-        const f3 worldPosition = xyz(mul_point(posOS, model));
         const f3 normalOS = normalize3(f3{dot3(f3{n[0].x, n[1].x, n[2].x}, l), dot3(f3{n[0].y, n[1].y, n[2].y}, l), dot3(f3{n[0].z, n[1].z, n[2].z}, l)});
-        const m4 normalMatrix = load_m4(sc.normalMatrices + (size_t)obj->normalMatrixBufferIndex * 16u);
-        const f3 worldNormal = normalize3(mul_v3m3(normalOS, normalMatrix));
 
-        // constant-factor material (SampleMaterialEvalFromUvCache without texture permutations)
-        const f3 baseColor = f3{mat->baseColorFactor[0], mat->baseColorFactor[1], mat->baseColorFactor[2]} * f3{1.0f, 1.0f, 1.0f};
-        const float metallic = mat->metallicFactor, roughness = mat->roughnessFactor, ao = 1.0f;
-        const f3 emissiveIn{mat->emissiveFactor[0], mat->emissiveFactor[1], mat->emissiveFactor[2]};
-        const uint32_t opIndex = mat->openPBRMaterialDataIndex;
-        const brmi_openpbr_material_info* op = sc.openpbrMaterials + opIndex;
-        const f3 canonicalEmissive = f3{op->emissionColor[0], op->emissionColor[1], op->emissionColor[2]} * op->emissionLuminance;
-        const f3 coatColor = sat3(f3{op->coatColor[0], op->coatColor[1], op->coatColor[2]});
-        const float coatWeight = sat(op->coatWeight), coatRoughness = sat(op->coatRoughness);
-        const f3 fuzzColor = sat3(f3{op->fuzzColor[0], op->fuzzColor[1], op->fuzzColor[2]});
-        const float fuzzWeight = sat(op->fuzzWeight), fuzzRoughness = sat(op->fuzzRoughness);
-        const f3 emissive = dot3(emissiveIn, emissiveIn) > 0.0f ? emissiveIn : canonicalEmissive;
-
-        // ComputeClodMotionVector
-        const f4 clipCur = mul_point(worldPosition, unjVP);
-        const f3 prevWorld = xyz(mul_point(posOS, load_m4(&obj->prevModel[0][0])));
-        const f4 clipPrev = mul_point(prevWorld, prevVP);
-        const float mvx = clipCur.x / clipCur.w - clipPrev.x / clipPrev.w, mvy = clipCur.y / clipCur.w - clipPrev.y / clipPrev.w;
-
-        a.normals[i] = make_float4(worldNormal.x, worldNormal.y, worldNormal.z, (float)opIndex);
-        a.albedo[i] = pack_unorm4(baseColor.x, baseColor.y, baseColor.z, ao);
-        a.coat[i] = pack_half4(coatColor.x, coatColor.y, coatColor.z, coatWeight);
-        a.emissive[i] = pack_half4(emissive.x, emissive.y, emissive.z, 0.0f);
-        a.fuzz[i] = pack_half4(fuzzColor.x, fuzzColor.y, fuzzColor.z, fuzzRoughness);
-        a.metallicRoughness[i] = pack_unorm4(metallic, roughness, coatRoughness, fuzzWeight);
-        a.motion[i] = f32_to_f16_bits(mvx) | (f32_to_f16_bits(mvy) << 16);
+        // object / material part: model, previous model, normal matrix and the material's packed words.  `obj`, `nm`, `mw`
+        // are either scalar (constant address space, wave-uniform index) or per-lane pointers.
+        auto finish = [&](auto obj, auto nm, auto mw) {
+            const m4 model = load_m4_any(&obj->model[0][0]);
+            const f3 worldPosition = xyz(mul_point(posOS, model));
+            const m4 normalMatrix = load_m4_any(nm);
+            const f3 worldNormal = normalize3(mul_v3m3(normalOS, normalMatrix));
+            // ComputeClodMotionVector
+            const f4 clipCur = mul_point(worldPosition, unjVP);
+            const f3 prevWorld = xyz(mul_point(posOS, load_m4_any(&obj->prevModel[0][0])));
+            const f4 clipPrev = mul_point(prevWorld, prevVP);
+            const float mvx = clipCur.x / clipCur.w - clipPrev.x / clipPrev.w, mvy = clipCur.y / clipCur.w - clipPrev.y / clipPrev.w;
+            a.normals[i] = make_float4(worldNormal.x, worldNormal.y, worldNormal.z, mw->opIndexF);
+            a.albedo[i] = mw->albedo;
+            a.coat[i] = mw->coat;
+            a.emissive[i] = mw->emissive;
+            a.fuzz[i] = mw->fuzz;
+            a.metallicRoughness[i] = mw->metallicRoughness;
+            a.motion[i] = f32_to_f16_bits(mvx) | (f32_to_f16_bits(mvy) << 16);
+        };
+        // waterfall over the distinct mesh instances of the tile (usually one or two)
+        uint64_t pending = __ballot(valid);
+        for (int it = 0; pending != 0ull; it++) {
+            if (it == RESOLVE_WATERFALL) {      // a tile of many small instances: per-lane loads for the rest
+                if ((pending >> lane_id()) & 1ull)
+                    finish(sc.perObject + cs.perObjectIndex, sc.normalMatrices + (size_t)cs.normalMatrixIndex * 16u, a.matWords + cs.materialDataIndex);
+                break;
+            }
+            const int lead = __ffsll((unsigned long long)pending) - 1;
+            const uint32_t uInst = (uint32_t)__builtin_amdgcn_readlane((int)cs.instanceIndex, lead);
+            const uint32_t uObj = (uint32_t)__builtin_amdgcn_readlane((int)cs.perObjectIndex, lead);
+            const uint32_t uNm = (uint32_t)__builtin_amdgcn_readlane((int)cs.normalMatrixIndex, lead);
+            const uint32_t uMat = (uint32_t)__builtin_amdgcn_readlane((int)cs.materialDataIndex, lead);
+            const uint64_t same = __ballot(valid && cs.instanceIndex == uInst);
+            pending &= ~same;
+            if ((same >> lane_id()) & 1ull) finish(kconst(sc.perObject) + uObj, kconst(sc.normalMatrices) + (size_t)uNm * 16u, kconst(a.matWords) + uMat);
+        }
     }
 }
 
@@ -160,6 +254,11 @@ int launch_gbuffer(brmi_pass* p, hipStream_t s) {
     a.W = p->cfg.width; a.H = p->cfg.height; a.tilesX = p->tilesX; a.bandY0 = p->bandY0; a.bandY1 = p->bandY1; a.firstPixel = p->bandFirstPixel; a.pixelCount = p->bandPixelCount;
     a.clusterCapacity = p->cfg.maxVisibleClusters;
     a.frameConst = p->wsPtr<m4>(p->ws.frameConst); a.objConst = p->wsPtr<float>(p->ws.objConst);
+    a.setup = p->wsPtr<ClusterSetup>(p->ws.clusterSetup); a.verts = p->wsPtr<ResolveVertex>(p->ws.resolveVerts); a.tris = p->wsPtr<ResolveTriangle>(p->ws.resolveTris);
+    a.vertCapacity = p->resolveCapacity; a.triCapacity = p->resolveCapacity;
+    a.matWords = p->wsPtr<MaterialWords>(p->ws.matWords);
+    hipLaunchKernelGGL(k_material_words, dim3((std::max(1u, p->scene.materialCount) + 63) / 64), dim3(64), 0, s, p->scene, a.matWords);
+    hipLaunchKernelGGL(k_resolve_setup, dim3(4096), dim3(64), 0, s, a);
     hipLaunchKernelGGL(k_gbuffer, dim3(4096), dim3(256), 0, s, a);
     BRMI_LAUNCH_CHECK(p, "k_gbuffer");
     return BRMI_OK;
