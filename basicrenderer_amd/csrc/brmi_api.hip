@@ -103,6 +103,7 @@ static void compute_sizes(brmi_pass* p) {
     p->resolveCapacity = (uint32_t)std::min<uint64_t>((uint64_t)c.maxVisibleClusters, 65536ull) * BRMI_MESHLET_MAX_TRIS;
     w.resolveVerts = take((uint64_t)p->resolveCapacity * sizeof(ResolveVertex));
     w.resolveTris = take((uint64_t)p->resolveCapacity * sizeof(ResolveTriangle));
+    w.shadeTables = take(((uint64_t)2 * c.width + 2 * c.height + 64) * 4);
     w.matWords = take((uint64_t)std::max(1u, p->scene.materialCount) * sizeof(MaterialWords));
     w.frameConst = take(3 * 64);
     w.matConst = take((uint64_t)std::max(1u, p->scene.openpbrMaterialCount) * 48);

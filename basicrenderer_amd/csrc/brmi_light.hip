@@ -532,7 +532,7 @@ template <bool GENERAL>
 BRMI_DEV f3 light_contribution(const Luts& L, const Frag& f, const PixelCtx& c, f3 lightToFrag, float NoL, f3 lightColor, float intensity, float attenuation, float spotAtt) {
     const BaseState& base = c.base;
     const float NoV = c.NoV;
-    const f3 h = normalize3(lightToFrag + f.viewWS);
+    const f3 h = normalize3(lightToFrag + f.viewWS);       // N, V, L, H stay correctly rounded: 1 - NoH^2 amplifies their error at low roughness
     const float NoH = sat(dot3(f.normalWS, h)), LoH = sat(dot3(lightToFrag, h));
     const float VdotL = dot3(f.viewWS, lightToFrag);
     // diffuse: EON x dielectric energy compensation
@@ -600,7 +600,52 @@ __global__ void __launch_bounds__(64) k_material_constants(brmi_scene_buffers sc
     out[i] = m;
 }
 
+// Per-frame tables of the shading pass.  Everything here is what the shader computes per pixel from px, py or view depth
+// alone, evaluated once per column / row / slice with the shader's own (correctly rounded) arithmetic:
+//   uvx[px] = (px + 0.5) / resX     tileX[px] = (uint)(px / (resX / gx))       (lighting.hlsli cluster lookup)
+//   uvy[py], tileY[py] likewise
+//   sliceStart[s] = smallest view depth whose cluster slice is >= s (the slice formula is monotone in depth), s = 1..gz;
+//   sliceStart[0] = 0, sliceStart[gz + 1] = +inf.
+struct ShadeTables { float* uvx; uint32_t* tileX; float* uvy; uint32_t* tileY; float* sliceStart; };
+
+BRMI_DEV uint32_t cluster_slice_exact(float z, float zNear, float zSplit, float logStart, float logEnd, uint32_t nearSlices, uint32_t gz) {
+    if (z < zSplit) { const float t = (z - zNear) / (zSplit - zNear); return t > 0.0f ? (uint32_t)(t * (float)nearSlices) : 0u; }
+    const float logZ = logf(z / zNear);
+    const float u = (logZ - logStart) / (logEnd - logStart);
+    return nearSlices + (u > 0.0f ? (uint32_t)(u * (float)(gz - nearSlices)) : 0u);
+}
+
+__global__ void __launch_bounds__(256) k_shade_tables(brmi_scene_buffers sc, ShadeTables t, uint32_t W, uint32_t H) {
+    const brmi_per_frame* pf = sc.perFrame;
+    const brmi_camera* cam = sc.cameras + pf->mainCameraIndex;
+    const float resX = (float)pf->screenResX, resY = (float)pf->screenResY;
+    const uint32_t gx = pf->lightClusterGridSizeX, gy = pf->lightClusterGridSizeY, gz = pf->lightClusterGridSizeZ;
+    const float tsx = resX / (float)gx, tsy = resY / (float)gy;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < W) { t.uvx[i] = ((float)i + 0.5f) / resX; t.tileX[i] = (uint32_t)((float)i / tsx); }
+    if (i < H) { t.uvy[i] = ((float)i + 0.5f) / resY; t.tileY[i] = (uint32_t)((float)i / tsy); }
+    if (i <= gz + 1u) {
+        float b = 0.0f;
+        if (i == gz + 1u) b = __uint_as_float(0x7F800000u);
+        else if (i > 0u) {
+            const float zNear = cam->zNear, zFar = cam->zFar, zSplit = pf->clusterZSplitDepth;
+            const float logStart = logf(zSplit / zNear), logEnd = logf(zFar / zNear);
+            // bisection over the positive floats: lo fails, hi passes.  The search stops at 1e30 (z / zNear must stay finite for
+            // the float -> uint conversion of the formula to be defined); a slice that starts beyond it starts at +inf.
+            uint32_t lo = 0u, hi = __float_as_uint(1.0e30f);
+            if (cluster_slice_exact(1.0e30f, zNear, zSplit, logStart, logEnd, pf->nearClusterCount, gz) < i) lo = hi = 0x7F800000u;
+            while (hi - lo > 1u) {
+                const uint32_t mid = lo + ((hi - lo) >> 1);
+                if (cluster_slice_exact(__uint_as_float(mid), zNear, zSplit, logStart, logEnd, pf->nearClusterCount, gz) >= i) hi = mid; else lo = mid;
+            }
+            b = __uint_as_float(hi);
+        }
+        t.sliceStart[i] = b;
+    }
+}
+
 struct ShadeArgs {
+    ShadeTables tables;
     brmi_scene_buffers sc;
     const float* depth; const float4* normals; const uint32_t* albedo; const unsigned long long* coat; const unsigned long long* emissive;
     const unsigned long long* fuzz; const uint32_t* metallicRoughness;
@@ -619,6 +664,7 @@ BRMI_DEV float half_at(unsigned long long v, int k) { return f16_bits_to_f32((ui
 struct ShadeFrame {
     Luts L; uint32_t gx, gy, gz, nearSlices, numLights; m4 invProj, viewInv; f3 camPos;
     float zNear, zFar, zSplit, resX, resY, tsx, tsy, logStart, logEnd, om5, om6;
+    float nearScale, farScale, log2Near;     // fast estimate of the cluster slice (corrected against the exact slice starts)
 };
 BRMI_DEV ShadeFrame make_shade_frame(const ShadeArgs& a) {
     const brmi_scene_buffers& sc = a.sc;
@@ -637,6 +683,9 @@ BRMI_DEV ShadeFrame make_shade_frame(const ShadeArgs& a) {
     k.nearSlices = pf->nearClusterCount; k.numLights = pf->numLights;
     const float om = 1.0f - 1.0f / 7.0f;
     k.om5 = uni(powf(om, 5.0f)); k.om6 = uni(powf(om, 6.0f));
+    k.nearScale = uni((float)k.nearSlices / (k.zSplit - k.zNear));
+    k.farScale = uni((float)(k.gz - k.nearSlices) / (k.logEnd - k.logStart));
+    k.log2Near = uni(log2f(k.zNear));
     return k;
 }
 
@@ -662,16 +711,16 @@ BRMI_DEV RawPixel load_raw_pixel_plain(const ShadeArgs& a, uint64_t i) {
 }
 
 template <bool GENERAL>
-BRMI_DEV bool shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const RawPixel& raw, uint64_t i, uint32_t px, uint32_t py) {
+BRMI_DEV bool shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const float* sliceStart, const RawPixel& raw, uint64_t i, uint32_t px, uint32_t py) {
     const brmi_scene_buffers& sc = a.sc;
     const Luts& L = k.L;
     const uint32_t gx = k.gx, gy = k.gy, gz = k.gz, nearSlices = k.nearSlices, numLights = k.numLights;
     const m4& invProj = k.invProj; const m4& viewInv = k.viewInv; const f3 camPos = k.camPos;
-    const float zNear = k.zNear, zSplit = k.zSplit, resX = k.resX, resY = k.resY, tsx = k.tsx, tsy = k.tsy, logStart = k.logStart, logEnd = k.logEnd, om5 = k.om5, om6 = k.om6;
+    const float zNear = k.zNear, zSplit = k.zSplit, logStart = k.logStart, om5 = k.om5, om6 = k.om6;
     (void)gy;
         const float d = raw.d;
         if (as_u32(d) == BRMI_DEPTH_EMPTY_BITS) return true;
-        float uvx = ((float)px + 0.5f) / resX, uvy = ((float)py + 0.5f) / resY;
+        float uvx = a.tables.uvx[px], uvy = a.tables.uvy[py];
         uvy = 1.0f - uvy;
         const f4 clipPos{uvx * 2.0f - 1.0f, uvy * 2.0f - 1.0f, 1.0f, 1.0f};
         const f4 viewPosH = mul_vm(clipPos, invProj);
@@ -758,14 +807,19 @@ BRMI_DEV bool shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const RawPixe
         };
         if (a.enablePunctual) {
             if (a.clustered) {
-                const uint32_t tx = (uint32_t)((float)px / tsx), ty = (uint32_t)((float)py / tsy);
+                const uint32_t tx = a.tables.tileX[px], ty = a.tables.tileY[py];
                 const float z = fabsf(posVS.z);
+                // slice: a hardware-log estimate (within one slice of the shader's formula), corrected against the exact first
+                // depth of that slice and of the next one -- the value of the formula without its two divisions and logf
                 uint32_t sliceZ;
-                if (z < zSplit) { const float t = (z - zNear) / (zSplit - zNear); sliceZ = t > 0.0f ? (uint32_t)(t * (float)nearSlices) : 0u; }
-                else {
-                    const float logZ = logf(z / zNear);
-                    const float u = (logZ - logStart) / (logEnd - logStart);
-                    sliceZ = nearSlices + (u > 0.0f ? (uint32_t)(u * (float)(gz - nearSlices)) : 0u);
+                {
+                    const float est = z < zSplit ? (z - zNear) * k.nearScale
+                                                 : (float)nearSlices + ((__builtin_amdgcn_logf(z) - k.log2Near) * 0.69314718f - logStart) * k.farScale;
+                    int e = (int)min2(max2(est, 0.0f), (float)gz);
+                    const float lo = sliceStart[e], hi = sliceStart[e + 1];
+                    e += (z >= hi) ? 1 : 0; e -= (z < lo) ? 1 : 0;
+                    sliceZ = (uint32_t)e;
+
                 }
                 const uint32_t ci = (uint32_t)((float)tx + (float)ty * (float)gx + (float)sliceZ * (float)gx * (float)gy);
                 if (ci < gx * gy * gz) {
@@ -819,6 +873,9 @@ BRMI_DEV bool shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const RawPixe
 template <bool GENERAL>
 __global__ void __launch_bounds__(256, GENERAL ? 1 : BRMI_SHADE_WAVES) k_shade(ShadeArgs a) {
     const ShadeFrame k = make_shade_frame(a);
+    __shared__ float sliceStart[64];
+    if (threadIdx.x < 64) sliceStart[threadIdx.x] = threadIdx.x <= k.gz + 1u ? a.tables.sliceStart[threadIdx.x] : __uint_as_float(0x7F800000u);
+    __syncthreads();
     if (!GENERAL) {
         // software pipeline: the G-buffer words of the next tile are requested before the current one is shaded, so
         // their HBM latency overlaps ~1000 VALU instructions instead of stalling the wave at the top of every iteration
@@ -835,7 +892,7 @@ __global__ void __launch_bounds__(256, GENERAL ? 1 : BRMI_SHADE_WAVES) k_shade(S
         for (; j < end; j += stride) {
             uint32_t npx = 0, npy = 0;
             const RawPixel nxt = (j + stride < end) ? fetch(j + stride, npx, npy) : empty_raw_pixel();
-            const bool done = shade_pixel<false>(a, k, cur, a.firstPixel + j, px, py);
+            const bool done = shade_pixel<false>(a, k, sliceStart, cur, a.firstPixel + j, px, py);
             const uint32_t slot = wave_append(&a.counters[CNT_DEFERRED_PIXELS], !done);
             if (!done) a.deferred[slot] = (uint32_t)j;
             cur = nxt; px = npx; py = npy;
@@ -846,7 +903,7 @@ __global__ void __launch_bounds__(256, GENERAL ? 1 : BRMI_SHADE_WAVES) k_shade(S
             const uint64_t i = a.firstPixel + a.deferred[q];
             const uint32_t tile = (uint32_t)(i >> 6), within = (uint32_t)(i & 63u);
             const uint32_t px = (tile % a.tilesX) * 8u + (within >> 3), py = (tile / a.tilesX) * 8u + (within & 7u);
-            shade_pixel<true>(a, k, load_raw_pixel(a, i), i, px, py);
+            shade_pixel<true>(a, k, sliceStart, load_raw_pixel(a, i), i, px, py);
         }
     }
 }
@@ -897,6 +954,12 @@ int launch_shade(brmi_pass* p, hipStream_t s) {
     a.enablePunctual = p->cfg.enablePunctualLights; a.clustered = p->cfg.enableClusteredLighting;
     a.lutF = p->wsPtr<float>(p->ws.lutF);
     a.matConst = p->wsPtr<MatConst>(p->ws.matConst);
+    {
+        uint32_t* tb = p->wsPtr<uint32_t>(p->ws.shadeTables);
+        const uint32_t W = p->cfg.width, H = p->cfg.height;
+        a.tables = ShadeTables{reinterpret_cast<float*>(tb), tb + W, reinterpret_cast<float*>(tb + 2 * W), tb + 2 * W + H, reinterpret_cast<float*>(tb + 2 * W + 2 * H)};
+        hipLaunchKernelGGL(k_shade_tables, dim3((std::max(std::max(W, H), 64u) + 255) / 256), dim3(256), 0, s, p->scene, a.tables, W, H);
+    }
     hipLaunchKernelGGL(k_material_constants, dim3((std::max(1u, p->scene.openpbrMaterialCount) + 63) / 64), dim3(64), 0, s, p->scene, p->wsPtr<MatConst>(p->ws.matConst));
     a.counters = p->counters(); a.deferred = p->wsPtr<uint32_t>(p->ws.deferredPixels);
     BRMI_HIP(p, hipMemsetAsync(&p->counters()[CNT_DEFERRED_PIXELS], 0, 4, s));
