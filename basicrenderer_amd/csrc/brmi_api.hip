@@ -128,7 +128,7 @@ static int read_back(brmi_pass* p, std::vector<T>& dst, const T* src, size_t n) 
 brmi::HzbDesc brmi_pass::hzbDesc() const {
     brmi::HzbDesc d{};
     d.depth = static_cast<const float*>(res[BRMI_RES_LINEAR_DEPTH]); d.mips = static_cast<float*>(res[BRMI_RES_HZB]);
-    d.width = cfg.width; d.height = cfg.height; d.tilesX = tilesX; d.mipCount = hzbMipCount;
+    d.width = cfg.width; d.height = cfg.height; d.tilesX = tilesX; d.mipCount = hzbMipCount; d.rowLo = bandY0; d.rowHi = bandY1;
     d.paddedW = hzbMipCount ? hzbMipW[0] : 1; d.paddedH = hzbMipCount ? hzbMipH[0] : 1;
     for (uint32_t i = 0; i < brmi::kMaxHzbMips; i++) d.mipOffset[i] = i < hzbMipCount ? (uint32_t)hzbMipOffsets[i] : 0u;
     return d;
@@ -323,8 +323,8 @@ int brmi_update(brmi_pass* p, const brmi_frame_update* u, brmi_stream stream) {
     return BRMI_OK;
 }
 
-#define STAGE_BEGIN(p, st, s) do { if ((p)->eventsCreated) { (void)hipEventRecord((p)->evStart[st][(p)->evCount[st] % brmi_pass::kEventRing], (s)); } } while (0)
-#define STAGE_END(p, st, s) do { if ((p)->eventsCreated) { (void)hipEventRecord((p)->evStop[st][(p)->evCount[st] % brmi_pass::kEventRing], (s)); (p)->evCount[st]++; } } while (0)
+#define STAGE_BEGIN(p, st, s) do { if ((p)->eventsCreated && (((p)->timedStages >> (st)) & 1u)) { (void)hipEventRecord((p)->evStart[st][(p)->evCount[st] % brmi_pass::kEventRing], (s)); } } while (0)
+#define STAGE_END(p, st, s) do { if ((p)->eventsCreated && (((p)->timedStages >> (st)) & 1u)) { (void)hipEventRecord((p)->evStop[st][(p)->evCount[st] % brmi_pass::kEventRing], (s)); (p)->evCount[st]++; } } while (0)
 #define CHECK_READY(p) do { if (!(p)) return BRMI_ERR_INVALID; if (!(p)->setupDone || !(p)->updated) return brmi::fail((p), BRMI_ERR_STATE, "%s: setup/update not done", __func__); } while (0)
 
 int brmi_clear_visibility(brmi_pass* p, brmi_stream stream) {
@@ -348,7 +348,15 @@ int brmi_depth_copy(brmi_pass* p, brmi_stream stream) {
 int brmi_build_hzb(brmi_pass* p, brmi_stream stream) {
     CHECK_READY(p); hipStream_t s = static_cast<hipStream_t>(stream);
     if (!p->cfg.enableOcclusionCulling) return brmi::fail(p, BRMI_ERR_STATE, "brmi_build_hzb: the pass was created without enableOcclusionCulling");
-    STAGE_BEGIN(p, BRMI_STAGE_HZB, s); int rc = launch_hzb(p, s); STAGE_END(p, BRMI_STAGE_HZB, s);
+    STAGE_BEGIN(p, BRMI_STAGE_HZB, s); int rc = launch_hzb(p, s, false, false); STAGE_END(p, BRMI_STAGE_HZB, s);
+    if (rc == BRMI_OK) p->hzbValid = true;
+    return rc;
+}
+// brmi_execute's variants: (1) LinearDepthCopyPass1 + LinearDepthDownsamplePass1 in one kernel (the chain is built straight
+// from the visibility keys, the depth map is written on the way); (2) LinearDepthDownsamplePass2 skipped on the device when
+// phase 2 rasterised nothing, because the final depth then equals the phase-1 depth the chain was just built from.
+static int build_hzb_fused(brmi_pass* p, hipStream_t s, bool fromVisibility, bool onlyIfPhase2Drew) {
+    STAGE_BEGIN(p, BRMI_STAGE_HZB, s); int rc = launch_hzb(p, s, fromVisibility, onlyIfPhase2Drew); STAGE_END(p, BRMI_STAGE_HZB, s);
     if (rc == BRMI_OK) p->hzbValid = true;
     return rc;
 }
@@ -380,13 +388,12 @@ int brmi_execute(brmi_pass* p, brmi_stream stream) {
     if (p->cfg.enableOcclusionCulling) {
         // reference graph: LinearDepthCopyPass1 -> LinearDepthDownsamplePass1 -> HierarchicalCullingPass2 -> ...RasterizeClustersPass2
         // -> LinearDepthCopyPass2 -> LinearDepthDownsamplePass2 (CLodExtension.cpp:1920-2088)
-        if ((rc = brmi_depth_copy(p, stream))) return rc;
-        if ((rc = brmi_build_hzb(p, stream))) return rc;
+        if ((rc = build_hzb_fused(p, static_cast<hipStream_t>(stream), true, false))) return rc;
         if ((rc = brmi_cull(p, 2, stream))) return rc;
         if ((rc = brmi_raster(p, 2, stream))) return rc;
     }
     if ((rc = brmi_gbuffer(p, stream))) return rc;
-    if (p->cfg.enableOcclusionCulling && (rc = brmi_build_hzb(p, stream))) return rc;   // the G-buffer kernel wrote the final depth
+    if (p->cfg.enableOcclusionCulling && (rc = build_hzb_fused(p, static_cast<hipStream_t>(stream), false, true))) return rc;   // the G-buffer kernel wrote the final depth
     if ((rc = brmi_light_clustering(p, stream))) return rc;
     if ((rc = brmi_shade(p, stream))) return rc;
     return BRMI_OK;
@@ -407,6 +414,12 @@ int brmi_read_counters(brmi_pass* p, brmi_counters* out, brmi_stream stream) {
     out->reserved[0] = c[CNT_SUM_VERTS_LO]; out->reserved[1] = c[CNT_SUM_VERTS_HI]; out->reserved[2] = c[CNT_SUM_TRIS_LO]; out->reserved[3] = c[CNT_SUM_TRIS_HI];
     out->reserved[4] = c[CNT_RASTER_CLUSTERS]; out->reserved[5] = c[CNT_BIN_OVERFLOW];
     out->replayNodes = c[CNT_REPLAY_NODES]; out->replayMeshlets = c[CNT_REPLAY_MESHLETS];
+    return BRMI_OK;
+}
+
+int brmi_set_timed_stages(brmi_pass* p, uint32_t stageMask) {
+    if (!p) return BRMI_ERR_INVALID;
+    p->timedStages = stageMask;
     return BRMI_OK;
 }
 

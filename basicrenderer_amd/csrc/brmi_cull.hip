@@ -73,7 +73,7 @@ BRMI_DEV uint32_t ceil_log2_clamped(float x, uint32_t maxMip) {
 }
 
 BRMI_DEV float hzb_load(const HzbDesc& h, uint32_t mip, uint32_t x, uint32_t y, uint32_t mipW) {
-    if (mip == 0u) return (x < h.width && y < h.height) ? h.depth[tiled_index(x, y, h.tilesX)] : __uint_as_float(BRMI_DEPTH_EMPTY_BITS);
+    if (mip == 0u) return (x < h.width && y >= h.rowLo && y < h.rowHi) ? h.depth[tiled_index(x, y, h.tilesX)] : __uint_as_float(BRMI_DEPTH_EMPTY_BITS);
     return h.mips[h.mipOffset[mip] + (size_t)y * mipW + x];
 }
 

@@ -12,11 +12,16 @@
 namespace brmi {
 
 BRMI_DEV float hzb_depth_texel(const HzbDesc& h, uint32_t x, uint32_t y) {
-    return (x < h.width && y < h.height) ? h.depth[tiled_index(x, y, h.tilesX)] : __uint_as_float(BRMI_DEPTH_EMPTY_BITS);
+    return (x < h.width && y >= h.rowLo && y < h.rowHi) ? h.depth[tiled_index(x, y, h.tilesX)] : __uint_as_float(BRMI_DEPTH_EMPTY_BITS);
 }
+BRMI_DEV float key_depth(unsigned long long k) { return (k == BRMI_VIS_EMPTY) ? as_f32(BRMI_DEPTH_EMPTY_BITS) : as_f32(((uint32_t)(k >> BRMI_VIS_META_BITS)) << 1); }
 
 // mips 1..5 from the depth map: block = 16 x 16 texels of mip 1 (requires paddedW, paddedH >= 32)
-__global__ void __launch_bounds__(256) k_hzb_head(HzbDesc h) {
+// FROM_VIS: the source is the visibility buffer; the linear depth of the four texels (K6, gbuffer.hlsl:114-161) is written to
+// the depth map on the way.  `skipUnless` (may be null): the launch does nothing when that counter is zero.
+template <bool FROM_VIS>
+__global__ void __launch_bounds__(256) k_hzb_head(HzbDesc h, const unsigned long long* vis, float* depthOut, const uint32_t* skipUnless) {
+    if (skipUnless && *skipUnless == 0u) return;
     __shared__ float lvl[16 * 16];
     const uint32_t tx = threadIdx.x >> 4, ty = threadIdx.x & 15u;             // ty fastest: follows the column-major tile layout
     const uint32_t bx = blockIdx.x, by = blockIdx.y;
@@ -24,7 +29,28 @@ __global__ void __launch_bounds__(256) k_hzb_head(HzbDesc h) {
     float v;
     {
         const uint32_t x0 = x1 * 2u, y0 = y1 * 2u;
-        if (x0 + 1u < h.width && y0 + 1u < h.height) {
+        if (FROM_VIS) {
+            // rows y0, y0 + 1 of a column are adjacent in the tile: one 16 B key load and one 8 B depth store per column
+            float d[2][2];
+#pragma unroll
+            for (uint32_t c = 0; c < 2; c++) {
+                const uint32_t x = x0 + c;
+                if (x < h.width && y0 >= h.rowLo && y0 + 1u < h.rowHi) {       // (bands are multiples of 8 rows: both rows inside or both outside)
+                    const uint32_t ti = tiled_index(x, y0, h.tilesX);
+                    const ulonglong2 k2 = *reinterpret_cast<const ulonglong2*>(vis + ti);
+                    d[c][0] = key_depth(k2.x); d[c][1] = key_depth(k2.y);
+                    *reinterpret_cast<float2*>(depthOut + ti) = make_float2(d[c][0], d[c][1]);
+                } else {
+                    for (uint32_t r = 0; r < 2; r++) {
+                        const uint32_t y = y0 + r;
+                        const bool in = x < h.width && y >= h.rowLo && y < h.rowHi;
+                        d[c][r] = in ? key_depth(vis[tiled_index(x, y, h.tilesX)]) : __uint_as_float(BRMI_DEPTH_EMPTY_BITS);
+                        if (in) depthOut[tiled_index(x, y, h.tilesX)] = d[c][r];
+                    }
+                }
+            }
+            v = max2(max2(d[0][0], d[1][0]), max2(d[0][1], d[1][1]));
+        } else if (x0 + 1u < h.width && y0 >= h.rowLo && y0 + 1u < h.rowHi) {
             // both rows of a column are adjacent in the tile: one 8-byte load per column
             const float2 c0 = *reinterpret_cast<const float2*>(h.depth + tiled_index(x0, y0, h.tilesX));
             const float2 c1 = *reinterpret_cast<const float2*>(h.depth + tiled_index(x0 + 1u, y0, h.tilesX));
@@ -59,7 +85,8 @@ __global__ void __launch_bounds__(256) k_hzb_head(HzbDesc h) {
 
 // mips firstMip..last, one workgroup, level by level (source texels clamped to the source extent: a dimension that
 // reached 1 stays 1)
-__global__ void __launch_bounds__(1024) k_hzb_tail(HzbDesc h, uint32_t firstMip) {
+__global__ void __launch_bounds__(1024) k_hzb_tail(HzbDesc h, uint32_t firstMip, const uint32_t* skipUnless) {
+    if (skipUnless && *skipUnless == 0u) return;
     for (uint32_t mip = firstMip; mip < h.mipCount; mip++) {
         const uint32_t sw = max(1u, h.paddedW >> (mip - 1u)), sh = max(1u, h.paddedH >> (mip - 1u));
         const uint32_t w = max(1u, h.paddedW >> mip), hh = max(1u, h.paddedH >> mip);
@@ -77,15 +104,20 @@ __global__ void __launch_bounds__(1024) k_hzb_tail(HzbDesc h, uint32_t firstMip)
     }
 }
 
-int launch_hzb(brmi_pass* p, hipStream_t s) {
-    if (p->hzbMipCount < 2) return BRMI_OK;     // 1 x 1 target: mip 0 is all there is
+int launch_hzb(brmi_pass* p, hipStream_t s, bool fromVisibility, bool onlyIfPhase2Drew) {
     const HzbDesc h = p->hzbDesc();
+    const bool head = h.paddedW >= 32 && h.paddedH >= 32;
+    if (fromVisibility && !head) { int rc = launch_depth_copy(p, s); if (rc) return rc; fromVisibility = false; }   // tiny targets: unfused
+    if (p->hzbMipCount < 2) return BRMI_OK;     // 1 x 1 target: mip 0 is all there is
+    const uint32_t* skip = onlyIfPhase2Drew ? p->counters() + CNT_VISIBLE2 : nullptr;
     uint32_t first = 1;
-    if (h.paddedW >= 32 && h.paddedH >= 32) {
-        hipLaunchKernelGGL(k_hzb_head, dim3(h.paddedW / 32, h.paddedH / 32), dim3(256), 0, s, h);
+    if (head) {
+        const dim3 grid(h.paddedW / 32, h.paddedH / 32);
+        if (fromVisibility) hipLaunchKernelGGL(k_hzb_head<true>, grid, dim3(256), 0, s, h, static_cast<const unsigned long long*>(p->res[BRMI_RES_VISIBILITY]), static_cast<float*>(p->res[BRMI_RES_LINEAR_DEPTH]), skip);
+        else hipLaunchKernelGGL(k_hzb_head<false>, grid, dim3(256), 0, s, h, (const unsigned long long*)nullptr, (float*)nullptr, skip);
         first = 6;
     }
-    if (first < h.mipCount) hipLaunchKernelGGL(k_hzb_tail, dim3(1), dim3(1024), 0, s, h, first);
+    if (first < h.mipCount) hipLaunchKernelGGL(k_hzb_tail, dim3(1), dim3(1024), 0, s, h, first, skip);
     BRMI_LAUNCH_CHECK(p, "k_hzb");
     return BRMI_OK;
 }

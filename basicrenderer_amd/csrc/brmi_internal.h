@@ -69,6 +69,7 @@ constexpr uint32_t kMaxHzbMips = 16;
 struct HzbDesc {
     const float* depth; float* mips;
     uint32_t width, height, tilesX, mipCount, paddedW, paddedH;
+    uint32_t rowLo, rowHi;          // rows this GPU renders (multi-GPU band); every other row reads as empty
     uint32_t mipOffset[kMaxHzbMips];
 };
 
@@ -111,6 +112,7 @@ struct brmi_pass {
     hipEvent_t evStart[BRMI_STAGE_COUNT][kEventRing] = {}, evStop[BRMI_STAGE_COUNT][kEventRing] = {};
     uint32_t evCount[BRMI_STAGE_COUNT] = {};       // recordings since the last brmi_stage_times()
     bool eventsCreated = false;
+    uint32_t timedStages = 0xFFFFFFFFu;            // brmi_set_timed_stages
     std::string err;
 
     template <typename T> T* wsPtr(uint64_t off) const { return reinterpret_cast<T*>(static_cast<uint8_t*>(res[BRMI_RES_WORKSPACE]) + off); }
@@ -128,7 +130,7 @@ int launch_clear(brmi_pass* p, hipStream_t s);
 int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s);
 int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s);
 int launch_depth_copy(brmi_pass* p, hipStream_t s);
-int launch_hzb(brmi_pass* p, hipStream_t s);
+int launch_hzb(brmi_pass* p, hipStream_t s, bool fromVisibility, bool onlyIfPhase2Drew);
 int launch_gbuffer(brmi_pass* p, hipStream_t s);
 int launch_light_clustering(brmi_pass* p, hipStream_t s);
 int launch_expand_luts(brmi_pass* p, hipStream_t s);

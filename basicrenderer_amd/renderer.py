@@ -121,6 +121,11 @@ class VisibilityRenderer:
         self._check(self.lib.brmi_stage_times(self._h, ms), "brmi_stage_times")
         return dict(zip(capi.STAGE_NAMES, [float(x) for x in ms]))
 
+    def set_timed_stages(self, names=None):
+        """Record HIP events only around the named stages (None = all)."""
+        mask = 0xFFFFFFFF if names is None else sum(1 << capi.STAGE_NAMES.index(n) for n in names)
+        self._check(self.lib.brmi_set_timed_stages(self._h, mask), "brmi_set_timed_stages")
+
     def algorithmic_bytes(self):
         per = (capi.u64 * len(capi.STAGE_NAMES))()
         total = capi.u64()
