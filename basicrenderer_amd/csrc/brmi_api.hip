@@ -76,7 +76,7 @@ static void compute_sizes(brmi_pass* p) {
     // workspace carve-up
     Workspace& w = p->ws; uint64_t off = 0;
     auto take = [&](uint64_t bytes) { uint64_t o = off; off = align_up(off + bytes, 256); return o; };
-    w.counters = take(256 * 4);
+    w.counters = take((uint64_t)(CNT_WORDS + 64) * 4);
     w.frontierA = take((uint64_t)c.maxTraversalRecords * sizeof(NodeRecord));
     w.frontierB = take((uint64_t)c.maxTraversalRecords * sizeof(NodeRecord));
     w.buckets = take((uint64_t)c.maxTraversalRecords * sizeof(BucketRecord));
@@ -163,6 +163,7 @@ int brmi_create(const brmi_config* cfg, brmi_pass** out) {
     brmi_pass* p = new brmi_pass();
     p->cfg = *cfg;
     p->totalWords = 1; p->scanBlocks = 1;
+    if (const char* e = std::getenv("BRMI_CULL_LEVEL_KERNELS")) p->forceLevelKernels = std::atoi(e) != 0;
     if (const char* e = std::getenv("BRMI_RASTER_GRID")) p->rasterGrid = (uint32_t)std::max(64, std::atoi(e));
     if (const char* e = std::getenv("BRMI_RASTER_DEBUG")) p->rasterDebug = std::atoi(e);
     if (const char* e = std::getenv("BRMI_BIN_CAPACITY")) p->binCapacity = (uint32_t)std::max(1, std::atoi(e));
@@ -202,15 +203,19 @@ int brmi_set_scene(brmi_pass* p, const brmi_scene_buffers* scene) {
     p->hostSegPrefix.assign(segs.size(), 0);
     std::vector<uint32_t> meshBits(md.size(), 0);
     uint32_t maxDepth = 1;
+    p->maxLevelWidth = 1;
+    std::vector<uint32_t> levelWidth;
     std::vector<std::pair<uint32_t, uint32_t>> stack;
     for (size_t m = 0; m < md.size(); m++) {
         uint32_t segCount = 0;
+        levelWidth.assign(66, 0);
         stack.clear(); stack.push_back({md[m].rootNode, 1});
         while (!stack.empty()) {
             auto [n, d] = stack.back(); stack.pop_back();
             if ((uint64_t)md[m].lodNodesBase + n >= nodes.size()) return fail(p, BRMI_ERR_INVALID, "mesh %zu: node %u out of range", m, n);
             const brmi_lod_node& nd = nodes[md[m].lodNodesBase + n];
             maxDepth = std::max(maxDepth, d);
+            if (d < levelWidth.size()) p->maxLevelWidth = std::max(p->maxLevelWidth, ++levelWidth[d]);
             if (nd.isLeaf != BRMI_NODE_INTERNAL) { segCount = std::max(segCount, nd.indexOrOffset + 1); continue; }
             if (d > 64) return fail(p, BRMI_ERR_INVALID, "mesh %zu: BVH deeper than 64 levels", m);
             const uint32_t cc = std::min(nd.countMinusOne + 1u, BRMI_BVH_MAX_CHILDREN);
@@ -408,7 +413,11 @@ int brmi_read_counters(brmi_pass* p, brmi_counters* out, brmi_stream stream) {
     BRMI_HIP(p, hipStreamSynchronize(s));
     std::memset(out, 0, sizeof(*out));
     out->instancesTested = c[CNT_INSTANCES_TESTED]; out->instancesVisible = c[CNT_INSTANCES_VISIBLE];
-    out->nodesVisited = c[CNT_NODES_VISITED]; out->bucketRecords = c[CNT_BUCKETS]; out->meshletsTested = c[CNT_MESHLETS_TESTED];
+    out->nodesVisited = c[CNT_NODES_VISITED];
+    for (uint32_t st = 0; st < CNT_STRIPE_COUNT; st++) {
+        const uint32_t* sp = c + CNT_STRIPES + st * CNT_STRIPE_WORDS;
+        out->instancesTested += sp[0]; out->instancesVisible += sp[1]; out->nodesVisited += sp[2];
+    } out->bucketRecords = c[CNT_BUCKETS]; out->meshletsTested = c[CNT_MESHLETS_TESTED];
     out->visibleClusters = c[CNT_VISIBLE]; out->visibleClustersPhase2 = c[CNT_VISIBLE2];
     out->droppedRecords = c[CNT_DROPPED_RECORDS]; out->droppedClusters = c[CNT_DROPPED_CLUSTERS]; out->lightPagesUsed = c[CNT_LIGHT_PAGES];
     out->reserved[0] = c[CNT_SUM_VERTS_LO]; out->reserved[1] = c[CNT_SUM_VERTS_HI]; out->reserved[2] = c[CNT_SUM_TRIS_LO]; out->reserved[3] = c[CNT_SUM_TRIS_HI];

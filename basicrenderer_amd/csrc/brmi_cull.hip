@@ -318,6 +318,225 @@ __global__ void __launch_bounds__(256) k_traverse(CullArgs a, uint32_t level, co
     }
 }
 
+// K1 + K2 in one launch: one wave64 per draw (phase 1) or per replayed node (phase 2) walks that instance's BVH breadth-first
+// with the frontier in LDS.  Instances are independent, so the level-by-level kernel sequence above -- one launch and ~8
+// dependent HBM round trips per level for every instance -- becomes one launch in which the per-instance state (instance,
+// mesh metadata, model matrix) is fetched once and a level costs node -> group / segment -> page map.  Used when every mesh's
+// BVH level fits the LDS frontier (brmi_set_scene checks); same tests, same operation order as k_cull_instances / k_traverse.
+constexpr uint32_t HIER_CAP = 1024;
+constexpr uint32_t HIER_STAGE = 512;      // bucket records staged in LDS (16 KB)
+template <bool REPLAY>
+__global__ void __launch_bounds__(64) k_cull_hierarchy(CullArgs a, BucketRecord* buckets) {
+    __shared__ uint32_t frontier[2][HIER_CAP];
+    __shared__ uint32_t counts[2];
+    __shared__ uint32_t childOff[65], childFirst[64];
+    __shared__ BucketRecord stage[HIER_STAGE];     // bucket records of the instance being walked: one global reservation per flush
+    const brmi_scene_buffers& sc = a.sc;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t viewId = sc.perFrame->mainCameraIndex;
+    const brmi_camera* cam = sc.cameras + viewId;
+    const brmi_culling_camera* lodCam = sc.cullingCameras + viewId;
+    const bool ortho = cam->isOrtho != 0;
+    const f3 camPos{lodCam->positionWorldSpace[0], lodCam->positionWorldSpace[1], lodCam->positionWorldSpace[2]};
+    const float zNear = lodCam->zNear, threshold = lodCam->errorOverDistanceThreshold;
+    const m4 view = load_m4(&cam->view[0][0]);
+    const uint32_t seeds = REPLAY ? min(a.counters[CNT_REPLAY_NODES], a.recordCapacity) : sc.activeDrawCount;
+    uint32_t nTested = 0, nVisible = 0, nNodes = 0;
+    uint32_t staged = 0;                            // wave-uniform
+    auto flush = [&]() {
+        if (staged == 0u) return;
+        uint32_t baseSlot = 0;
+        if (lane == 0) baseSlot = atomicAdd(&a.counters[a.bucketCounter], staged);
+        baseSlot = (uint32_t)__shfl((int)baseSlot, 0);
+        __syncthreads();
+        for (uint32_t k = lane; k < staged; k += 64u) {
+            if (baseSlot + k < a.recordCapacity) buckets[baseSlot + k] = stage[k];
+            else atomicAdd(&a.counters[CNT_DROPPED_RECORDS], 1u);
+        }
+        __syncthreads();
+        staged = 0u;
+    };
+    for (uint32_t seed = blockIdx.x; seed < seeds; seed += gridDim.x) {
+        uint32_t instIndex, startNode;
+        if (REPLAY) { const NodeRecord rec = a.replayNodes[seed]; instIndex = rec.instanceIndex; startNode = rec.nodeIdPacked & 0x3FFFFFFFu; }
+        else instIndex = sc.activeDraws[seed];
+        const brmi_per_mesh_instance inst = sc.perMeshInstance[instIndex];
+        const brmi_clod_mesh_metadata md = sc.meshMetadata[sc.clodOffsets[instIndex].clodMeshMetadataIndex];
+        const brmi_per_object* obj = sc.perObject + inst.perObjectBufferIndex;
+        const m4 model = load_m4(&obj->model[0][0]);
+        const float scale = max_axis_scale(model);
+        const f3 instC{inst.boundingSphere[0], inst.boundingSphere[1], inst.boundingSphere[2]}; const float instR = inst.boundingSphere[3];
+        if (!REPLAY) {
+            // K1 (PureComputeObjectCullCS)
+            const f3 c = to_view_space(instC, model, view);
+            const float r = instR * scale;
+            const bool bad = isnan(c.x) || isnan(c.y) || isnan(c.z) || isinf(c.x) || isinf(c.y) || isinf(c.z) || isnan(r) || isinf(r);
+            const bool visible = !bad && !sphere_outside_frustum(c, r, cam->clippingPlanes);
+            nTested++;
+            if (!visible) continue;
+            nVisible++;
+            startNode = md.rootNode;
+        }
+        const bool skinned = (sc.perMesh[inst.perMeshBufferIndex].vertexFlags & BRMI_VERTEX_SKINNED) != 0;
+        const uint32_t bitBase = a.instanceBitBase[instIndex];
+        __syncthreads();
+        if (lane == 0) { frontier[0][0] = startNode; counts[0] = 1u; counts[1] = 0u; }
+        __syncthreads();
+        for (uint32_t level = 0; level < 64u; level++) {
+            const uint32_t cur = level & 1u, nxt = cur ^ 1u;
+            const uint32_t n = min(counts[cur], HIER_CAP);
+            if (n == 0u) break;
+            for (uint32_t base = 0; base < n; base += 64u) {
+                const bool have = base + lane < n;
+                bool isInternal = false, emitLeaf = false, occluded = false;
+                uint32_t nodeId = 0, childBase = 0, childCount = 0, segFirst = 0, segCount = 0, ownerGroup = 0, slabDesc = 0, slabOff = 0, firstBit = 0;
+                if (have) {
+                    nodeId = frontier[cur][base + lane];
+                    nNodes++;
+                    const brmi_lod_node node = sc.lodNodes[md.lodNodesBase + nodeId];
+                    const f3 cullC = skinned ? instC : f3{node.cullCenterAndRadius[0], node.cullCenterAndRadius[1], node.cullCenterAndRadius[2]};
+                    const float cullR = skinned ? instR : node.cullCenterAndRadius[3];
+                    const f3 cVS = to_view_space(cullC, model, view);
+                    const float rW = cullR * scale;
+                    const bool culled = !REPLAY && sphere_outside_frustum(cVS, rW, cam->clippingPlanes);
+                    if (!culled) {
+                        if (node.isLeaf != BRMI_NODE_INTERNAL) {
+                            const brmi_lod_group* g = sc.lodGroups + (md.groupsBase + node.ownerGroupId);
+                            const f3 gc = xyz(mul_point(f3{g->centerAndRadius[0], g->centerAndRadius[1], g->centerAndRadius[2]}, model));
+                            const float gr = g->centerAndRadius[3] * scale;
+                            const float eod = projected_error(gc, gr, node.maxQuadricError, scale, camPos, zNear, ortho);
+                            bool ok = eod >= threshold;
+                            if (ok && refined_child_suppresses(sc, md.groupsBase, node.countMinusOne - 1u, node.countMinusOne != 0u, model, scale, camPos, zNear, threshold, ortho)) ok = false;
+                            if (ok) {
+                                const brmi_lod_segment seg = sc.lodSegments[md.segmentsBase + node.indexOrOffset];
+                                const brmi_group_page_map_entry pe = sc.groupPageMap[md.pageMapBase + seg.pageIndex];
+                                if (seg.meshletCount != 0u && pe.slabDescriptorIndex != 0u) {
+                                    emitLeaf = true;
+                                    segFirst = seg.firstMeshletInPage; segCount = seg.meshletCount; ownerGroup = node.ownerGroupId;
+                                    slabDesc = pe.slabDescriptorIndex; slabOff = pe.slabByteOffset;
+                                    firstBit = bitBase + a.segPrefix[md.segmentsBase + node.indexOrOffset];
+                                }
+                            }
+                        } else {
+                            const f3 lc = xyz(mul_point(f3{node.lodCenterAndRadius[0], node.lodCenterAndRadius[1], node.lodCenterAndRadius[2]}, model));
+                            const float lr = node.lodCenterAndRadius[3] * scale;
+                            const float nodeEod = projected_error(lc, lr, node.maxQuadricError, scale, camPos, zNear, ortho);
+                            if (nodeEod >= threshold) {
+                                if (a.occlusion && occlusion_test(a, cam, REPLAY, cullC, cullR, cVS, rW, obj)) occluded = !REPLAY;
+                                else { isInternal = true; childBase = node.indexOrOffset; childCount = min(node.countMinusOne + 1u, BRMI_BVH_MAX_CHILDREN); }
+                            }
+                        }
+                    }
+                }
+                if (!REPLAY && a.occlusion) {
+                    const uint32_t slot = wave_append(&a.counters[CNT_REPLAY_NODES], occluded);
+                    if (occluded) {
+                        if (slot < a.recordCapacity) a.replayNodes[slot] = NodeRecord{instIndex, 0x80000000u | (1u << 30) | (nodeId & 0x3FFFFFFFu)};
+                        else atomicAdd(&a.counters[CNT_DROPPED_RECORDS], 1u);
+                    }
+                }
+                {   // leaf: bucket records of `factor` meshlets (computeCulling.hlsl:385-406).  One reservation for the whole wave
+                    // (an atomic with return per chunk would put ~2 us of latency on every chunk of this single-wave workgroup).
+                    const uint32_t nChunks = emitLeaf ? (segCount + a.factor - 1u) / a.factor : 0u;
+                    uint32_t incl = nChunks;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o); if (lane >= (uint32_t)o) incl += v; }
+                    const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+                    if (total != 0u) {
+                        if (staged + total > HIER_STAGE) flush();
+                        if (total <= HIER_STAGE) {
+                            const uint32_t baseSlot = staged + (incl - nChunks);
+                            for (uint32_t k = 0; k < nChunks; k++) {
+                                const uint32_t first = segFirst + k * a.factor;
+                                const uint32_t cnt = min(a.factor, segCount - k * a.factor);
+                                BucketRecord b;
+                                b.instanceIndex = instIndex; b.groupIdPacked = (REPLAY ? 0x80000000u : 0u) | (ownerGroup & 0x7FFFFFFFu);
+                                b.meshletIndexAndCount = (cnt << 16) | (first & 0xFFFFu);
+                                b.pageSlabDescriptorIndex = slabDesc; b.pageSlabByteOffset = slabOff;
+                                b.firstBit = firstBit + k * a.factor; b.pad0 = 0; b.pad1 = 0;
+                                stage[baseSlot + k] = b;
+                            }
+                            staged += total;
+                        } else {
+                            // more chunks in one step than the stage holds (very large segments): straight to the global array
+                            uint32_t baseSlot = 0;
+                            if (lane == 0) baseSlot = atomicAdd(&a.counters[a.bucketCounter], total);
+                            baseSlot = (uint32_t)__shfl((int)baseSlot, 0) + (incl - nChunks);
+                            for (uint32_t k = 0; k < nChunks; k++) {
+                                const uint32_t slot = baseSlot + k;
+                                if (slot < a.recordCapacity) {
+                                    const uint32_t first = segFirst + k * a.factor;
+                                    const uint32_t cnt = min(a.factor, segCount - k * a.factor);
+                                    BucketRecord b;
+                                    b.instanceIndex = instIndex; b.groupIdPacked = (REPLAY ? 0x80000000u : 0u) | (ownerGroup & 0x7FFFFFFFu);
+                                    b.meshletIndexAndCount = (cnt << 16) | (first & 0xFFFFu);
+                                    b.pageSlabDescriptorIndex = slabDesc; b.pageSlabByteOffset = slabOff;
+                                    b.firstBit = firstBit + k * a.factor; b.pad0 = 0; b.pad1 = 0;
+                                    buckets[slot] = b;
+                                } else atomicAdd(&a.counters[CNT_DROPPED_RECORDS], 1u);
+                            }
+                        }
+                    }
+                }
+                {   // internal: pre-filter the children, survivors go to the next level's frontier (computeCulling.hlsl:477-530).
+                    // The children of all nodes of this step are dealt to the lanes (exclusive scan of the child counts), so their
+                    // node records are fetched side by side instead of one dependent round trip per child index.
+                    const uint32_t myChildren = isInternal ? childCount : 0u;
+                    uint32_t incl = myChildren;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o); if (lane >= (uint32_t)o) incl += v; }
+                    const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+                    if (total != 0u) {
+                        childOff[lane] = incl - myChildren; childFirst[lane] = childBase;
+                        if (lane == 63) childOff[64] = total;
+                        __syncthreads();
+                        for (uint32_t task = lane; task < ((total + 63u) & ~63u); task += 64u) {
+                            bool emit = false;
+                            uint32_t childId = 0;
+                            if (task < total) {
+                                uint32_t parent = 0;
+#pragma unroll
+                                for (uint32_t step = 32; step > 0; step >>= 1) if (childOff[parent + step] <= task) parent += step;
+                                childId = childFirst[parent] + (task - childOff[parent]);
+                                const brmi_lod_node* ch = sc.lodNodes + (md.lodNodesBase + childId);
+                                const f3 cc = skinned ? instC : f3{ch->cullCenterAndRadius[0], ch->cullCenterAndRadius[1], ch->cullCenterAndRadius[2]};
+                                const float cr = skinned ? instR : ch->cullCenterAndRadius[3];
+                                const f3 ccVS = to_view_space(cc, model, view);
+                                emit = REPLAY || !sphere_outside_frustum(ccVS, cr * scale, cam->clippingPlanes);
+                                if (emit && ch->isLeaf == BRMI_NODE_INTERNAL) {
+                                    const f3 wc = xyz(mul_point(f3{ch->lodCenterAndRadius[0], ch->lodCenterAndRadius[1], ch->lodCenterAndRadius[2]}, model));
+                                    const float e = projected_error(wc, ch->lodCenterAndRadius[3] * scale, ch->maxQuadricError, scale, camPos, zNear, ortho);
+                                    if (e < threshold) emit = false;
+                                }
+                            }
+                            const uint32_t slot = wave_append(&counts[nxt], emit);
+                            if (emit) {
+                                if (slot < HIER_CAP) frontier[nxt][slot] = childId;
+                                else atomicAdd(&a.counters[CNT_DROPPED_RECORDS], 1u);
+                            }
+                        }
+                        __syncthreads();
+                    }
+                }
+            }
+            __syncthreads();
+            if (lane == 0) counts[cur] = 0u;
+            __syncthreads();
+        }
+    }
+    flush();
+    // statistics: one atomic per wave and counter, on one of 64 stripes (every stripe has its own 128 B line: thousands of
+    // same-line atomics serialise at ~90 per microsecond); brmi_read_counters adds the stripes up
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nNodes += (uint32_t)__shfl_xor((int)nNodes, o);
+    if (lane == 0) {
+        uint32_t* stripe = a.counters + CNT_STRIPES + (blockIdx.x & (CNT_STRIPE_COUNT - 1u)) * CNT_STRIPE_WORDS;
+        if (nTested) atomicAdd(&stripe[0], nTested);
+        if (nVisible) atomicAdd(&stripe[1], nVisible);
+        if (nNodes) atomicAdd(&stripe[2], nNodes);
+    }
+}
+
 // K3: per-meshlet cull ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_cull_clusters(CullArgs a, const BucketRecord* buckets, TempVisible* temp, uint32_t* bitmask) {
     const brmi_scene_buffers& sc = a.sc;
@@ -548,7 +767,7 @@ static inline uint32_t grid_for(uint64_t items, uint32_t block, uint32_t maxBloc
 __global__ void k_seed_phase2(uint32_t* counters, uint32_t capacity) {
     const uint32_t t = threadIdx.x;
     if (t == 0) { counters[CNT_REPLAY_NODES] = min(counters[CNT_REPLAY_NODES], capacity); counters[CNT_BUCKETS] = min(counters[CNT_REPLAY_MESHLETS], capacity); counters[CNT_TEMP_VISIBLE2] = 0; counters[CNT_VISIBLE2] = 0; }
-    if (t < CNT_WORDS - CNT_FRONTIER0) counters[CNT_FRONTIER0 + t] = 0;
+    if (t < CNT_STRIPES - CNT_FRONTIER0) counters[CNT_FRONTIER0 + t] = 0;
 }
 
 int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
@@ -576,19 +795,22 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
     uint32_t* wordPrefix = p->wsPtr<uint32_t>(p->ws.wordPrefix); uint32_t* blockSums = p->wsPtr<uint32_t>(p->ws.blockSums);
 
     const uint32_t maxBlocks = 1024;
+    const bool hierarchy = p->maxLevelWidth <= HIER_CAP && !p->forceLevelKernels;
     if (phase == 1) {
         BRMI_HIP(p, hipMemsetAsync(p->counters(), 0, CNT_WORDS * sizeof(uint32_t), s));
         BRMI_HIP(p, hipMemsetAsync(bitmask, 0, (size_t)p->totalWords * 4, s));
         hipLaunchKernelGGL(k_object_constants, dim3((std::max(1u, p->scene.perObjectCount) + 63) / 64), dim3(64), 0, s, p->scene, p->wsPtr<m4>(p->ws.frameConst), p->wsPtr<float>(p->ws.objConst));
-        hipLaunchKernelGGL(k_cull_instances, dim3(grid_for(p->scene.activeDrawCount, 256, maxBlocks)), dim3(256), 0, s, a, fa);
+        if (hierarchy) hipLaunchKernelGGL(k_cull_hierarchy<false>, dim3(std::min(std::max(1u, p->scene.activeDrawCount), 8192u)), dim3(64), 0, s, a, buckets);
+        else hipLaunchKernelGGL(k_cull_instances, dim3(grid_for(p->scene.activeDrawCount, 256, maxBlocks)), dim3(256), 0, s, a, fa);
         BRMI_LAUNCH_CHECK(p, "k_cull_instances");
     } else {
         BRMI_HIP(p, hipMemsetAsync(bitmask, 0, (size_t)p->totalWords * 4, s));
         hipLaunchKernelGGL(k_seed_phase2, dim3(1), dim3(128), 0, s, p->counters(), a.recordCapacity);
+        if (hierarchy) hipLaunchKernelGGL(k_cull_hierarchy<true>, dim3(2048), dim3(64), 0, s, a, buckets);
     }
     // frontier sizes are only known on the device: size the grids for the worst case that can matter
     const uint32_t travGrid = grid_for(std::min<uint64_t>(p->cfg.maxTraversalRecords, (uint64_t)p->scene.lodNodeCount * 4 + 4096), 256, maxBlocks);
-    for (uint32_t level = 0; level < p->maxLevels; level++) {
+    for (uint32_t level = 0; level < p->maxLevels && !hierarchy; level++) {
         // phase 2 reads level 0 from the replay buffer and then ping-pongs like phase 1 (level 0 writes fb)
         const NodeRecord* in = level == 0 ? (phase == 1 ? fa : a.replayNodes) : ((level & 1u) ? fb : fa);
         hipLaunchKernelGGL(k_traverse, dim3(travGrid), dim3(256), 0, s, a, level, in, (level & 1u) ? fa : fb, buckets);

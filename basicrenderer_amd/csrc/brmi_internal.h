@@ -34,7 +34,9 @@ enum CounterIndex : uint32_t {
     CNT_UNUSED0,
     CNT_DEFERRED_PIXELS,      // pixels the specialised shading kernel left to the general one
     CNT_FRONTIER0 = 32,       // frontier sizes per BFS level: [CNT_FRONTIER0 + level]
-    CNT_WORDS = 32 + 72
+    CNT_STRIPES = 128,        // 64 stripes x 32 words: per-stripe {instances tested, instances visible, nodes visited}
+    CNT_STRIPE_COUNT = 64, CNT_STRIPE_WORDS = 32,
+    CNT_WORDS = 128 + 64 * 32
 };
 
 // internal records (ours; the reference's 12 B / 24 B records plus the rank bookkeeping)
@@ -93,6 +95,8 @@ struct brmi_pass {
     float bandPlaneTop[3] = {0, 0, 0}, bandPlaneBottom[3] = {0, 0, 0};
     uint64_t bandFirstPixel = 0, bandPixelCount = 0;   // tiled index range covering the band's tile rows
     uint32_t maxLevels = 1;
+    uint32_t maxLevelWidth = 0;      // widest BVH level of any mesh (decides between the per-instance and the per-level traversal)
+    bool forceLevelKernels = false;  // BRMI_CULL_LEVEL_KERNELS=1: always use the per-level kernels (tests, very wide hierarchies)
     uint64_t totalBits = 0; uint32_t totalWords = 0, scanBlocks = 0;
     uint32_t numLightClusters = 0, lightPagePool = 0;
     uint32_t binsX = 0, binsY = 0, binCapacity = 1024;   // raster bins: 256 px x 16 rows, binCapacity records of 64 B each (BRMI_BIN_CAPACITY)
