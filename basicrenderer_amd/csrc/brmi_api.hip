@@ -95,6 +95,9 @@ static void compute_sizes(brmi_pass* p) {
     w.lightVS = take((uint64_t)std::max(1u, p->scene.lightCount) * 16);
     w.lightMeta = take((uint64_t)std::max(1u, p->scene.lightCount) * 4);
     w.clusterPages = take((uint64_t)p->numLightClusters * 4);
+    w.clusterHits = take((uint64_t)p->numLightClusters * 4);
+    w.pageTotal = take(16);
+    w.lightHitMasks = take((uint64_t)p->numLightClusters * ((std::max(1u, p->scene.lightCount) + 63u) / 64u) * 8);
     p->binsX = (c.width + 255) / 256; p->binsY = (c.height + 15) / 16;
     w.binCounts = take((uint64_t)p->binsX * p->binsY * 4);
     w.binRecords = take((uint64_t)p->binsX * p->binsY * p->binCapacity * 64);

@@ -36,6 +36,9 @@ struct ClusterArgs {
     float4* lightVS;              // per active light: view-space bounding sphere (xyz, r)
     uint32_t* lightMeta;          // per active light: type | lightIndex << 2
     uint32_t* clusterPages;       // per cluster: page demand, then (after the scan) first page
+    uint32_t* clusterHits;        // per cluster: lights that touch it
+    uint32_t* pageTotal;          // [0]: pages demanded by all clusters (unclamped)
+    uint64_t* hitMasks; uint32_t maskWords;   // per cluster: one bit per light of the list
 };
 
 // view-space bounding spheres of the active lights, once per frame (testSphereAABB's transform, lightCulling.hlsl:15-21)
@@ -61,18 +64,19 @@ BRMI_DEV bool light_hits_cluster(float4 sphere, uint32_t type, f3 mn, f3 mx) {
     return dot3(d, d) <= sphere.w * sphere.w;
 }
 
-// one lane per cluster: AABB (clustering.hlsl:31-107) + page demand of the serial allocator (lightCulling.hlsl:70-118)
-__global__ void __launch_bounds__(64) k_lc_count(ClusterArgs a) {
+// One wave64 per cluster, one lane per light: AABB (clustering.hlsl:31-107), the lights that touch it as bit masks, and the
+// page demand of the reference's serial allocator (lightCulling.hlsl:70-118) in closed form.  The serial loop opens a new page
+// whenever it reaches a light (hit or not) with 12 entries in the current page, so with T hits in total it allocates
+// 1 + T / 12 pages, minus one when the page filled exactly at the last light of the list.
+__global__ void __launch_bounds__(256) k_lc_count(ClusterArgs a) {
     const brmi_scene_buffers& sc = a.sc;
     const brmi_per_frame* pf = sc.perFrame;
     const brmi_camera* cam = sc.cameras + pf->mainCameraIndex;
     const uint32_t gx = pf->lightClusterGridSizeX, gy = pf->lightClusterGridSizeY, gz = pf->lightClusterGridSizeZ;
     const uint32_t total = gx * gy * gz, lightCount = pf->numLights;
-    __shared__ float4 shSphere[64];
-    __shared__ uint32_t shType[64];
-    const uint32_t idxRaw = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = idxRaw < total;
-    const uint32_t idx = valid ? idxRaw : total - 1;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t idx = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (idx >= total) return;
     const float W = (float)pf->screenResX, H = (float)pf->screenResY;
     const m4 invProj = load_m4(&cam->projectionInverse[0][0]);
     const float tsx = W / (float)gx, tsy = H / (float)gy;
@@ -95,22 +99,27 @@ __global__ void __launch_bounds__(64) k_lc_count(ClusterArgs a) {
     }
     const f3 mn = min3v(min3v(pts[0], pts[1]), min3v(pts[2], pts[3])), mx = max3v(max3v(pts[0], pts[1]), max3v(pts[2], pts[3]));
     brmi_light_cluster* c = a.clusters + idx;
-    if (valid) {
+    if (lane == 0) {
         *reinterpret_cast<float4*>(c->minPoint) = make_float4(mn.x, mn.y, mn.z, 0.0f);
         *reinterpret_cast<float4*>(c->maxPoint) = make_float4(mx.x, mx.y, mx.z, 0.0f);
     }
-    uint32_t pagesNeeded = 1, inPage = 0;
-    for (uint32_t base = 0; base < lightCount; base += 64) {      // lights staged through LDS, 64 at a time
-        if (base + threadIdx.x < lightCount) { shSphere[threadIdx.x] = a.lightVS[base + threadIdx.x]; shType[threadIdx.x] = a.lightMeta[base + threadIdx.x] & 3u; }
-        __syncthreads();
-        const uint32_t n = min(64u, lightCount - base);
-        for (uint32_t k = 0; k < n; k++) {
-            if (inPage >= BRMI_LIGHTS_PER_PAGE) { pagesNeeded++; inPage = 0; }
-            if (light_hits_cluster(shSphere[k], shType[k], mn, mx)) inPage++;
-        }
-        __syncthreads();
+    uint32_t hits = 0;                  // wave-uniform
+    int lastHit = -1;                   // position in the light list of the last hit
+    uint64_t* masks = a.hitMasks + (size_t)idx * a.maskWords;
+    for (uint32_t base = 0, w = 0; base < lightCount; base += 64, w++) {
+        const uint32_t li = base + lane;
+        bool hit = false;
+        if (li < lightCount) hit = light_hits_cluster(a.lightVS[li], a.lightMeta[li] & 3u, mn, mx);
+        const uint64_t m = __ballot(hit);
+        if (lane == 0) masks[w] = m;
+        if (m != 0ull) { hits += (uint32_t)__popcll(m); lastHit = (int)base + 63 - __clzll((long long)m); }
     }
-    if (valid) a.clusterPages[idx] = pagesNeeded;
+    if (lane == 0) {
+        uint32_t pagesNeeded = 1u + hits / BRMI_LIGHTS_PER_PAGE;
+        if (hits != 0u && hits % BRMI_LIGHTS_PER_PAGE == 0u && lastHit == (int)lightCount - 1) pagesNeeded--;
+        a.clusterPages[idx] = pagesNeeded;
+        a.clusterHits[idx] = hits;
+    }
 }
 
 // single workgroup: exclusive scan of the page demand in cluster order = the serial allocation order
@@ -137,48 +146,44 @@ __global__ void __launch_bounds__(1024) k_lc_scan(ClusterArgs a) {
         if (threadIdx.x == 1023) carry = c + waveBase + incl;
         __syncthreads();
     }
-    if (threadIdx.x == 0) a.counters[CNT_LIGHT_PAGES] = min(carry, a.poolSize);
+    if (threadIdx.x == 0) { a.counters[CNT_LIGHT_PAGES] = min(carry, a.poolSize); a.pageTotal[0] = carry; }
 }
 
-// fill: the reference's control flow per cluster, page numbers from the scan
-__global__ void __launch_bounds__(64) k_lc_fill(ClusterArgs a) {
+// fill, one wave64 per cluster: hit j of the cluster (in light-list order, from the bit masks) goes to entry j % 12 of the
+// cluster's page j / 12; pages come from the scan, are chained newest -> oldest like the serial allocator chains them, and
+// stop where the pool ends (the reference's `break`: the cluster then keeps its full pages only).
+__global__ void __launch_bounds__(256) k_lc_fill(ClusterArgs a) {
     const brmi_per_frame* pf = a.sc.perFrame;
     const uint32_t total = pf->lightClusterGridSizeX * pf->lightClusterGridSizeY * pf->lightClusterGridSizeZ, lightCount = pf->numLights;
-    __shared__ float4 shSphere[64];
-    __shared__ uint32_t shMeta[64];
-    const uint32_t idxRaw = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = idxRaw < total;
-    const uint32_t idx = valid ? idxRaw : total - 1;
-    brmi_light_cluster* c = a.clusters + idx;
-    const f3 mn{c->minPoint[0], c->minPoint[1], c->minPoint[2]}, mx{c->maxPoint[0], c->maxPoint[1], c->maxPoint[2]};
-    uint32_t next = a.clusterPages[idx];
-    auto alloc = [&]() { const uint32_t i = next++; return i >= a.poolSize ? BRMI_LIGHT_PAGE_NULL : i; };
-    uint32_t page = valid ? alloc() : BRMI_LIGHT_PAGE_NULL;
-    uint32_t numLights = 0, firstPage = page, inPage = 0;
-    bool open = page != BRMI_LIGHT_PAGE_NULL;      // false once the allocator ran dry (the reference's `break`)
-    if (open) a.pages[page].ptrNextPage = BRMI_LIGHT_PAGE_NULL;
-    for (uint32_t base = 0; base < lightCount; base += 64) {
-        if (base + threadIdx.x < lightCount) { shSphere[threadIdx.x] = a.lightVS[base + threadIdx.x]; shMeta[threadIdx.x] = a.lightMeta[base + threadIdx.x]; }
-        __syncthreads();
-        const uint32_t n = min(64u, lightCount - base);
-        for (uint32_t k = 0; k < n && open; k++) {
-            if (inPage >= BRMI_LIGHTS_PER_PAGE) {
-                a.pages[page].numLightsInPage = BRMI_LIGHTS_PER_PAGE;
-                const uint32_t old = page;
-                page = alloc();
-                if (page == BRMI_LIGHT_PAGE_NULL) { open = false; break; }
-                a.pages[page].ptrNextPage = old;
-                firstPage = page;
-                inPage = 0;
-            }
-            const uint32_t meta = shMeta[k];
-            if (light_hits_cluster(shSphere[k], meta & 3u, mn, mx)) { a.pages[page].lightIndices[inPage] = meta >> 2; inPage++; numLights++; }
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t idx = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (idx >= total) return;
+    const uint32_t base = a.clusterPages[idx];                                 // first page (exclusive scan of the demand)
+    const uint32_t hits = a.clusterHits[idx];
+    const uint32_t demand = (idx + 1u < total ? a.clusterPages[idx + 1u] : a.pageTotal[0]) - base;
+    const uint32_t valid = base >= a.poolSize ? 0u : min(demand, a.poolSize - base);   // pages that exist
+    const uint64_t* masks = a.hitMasks + (size_t)idx * a.maskWords;
+    uint32_t before = 0;
+    for (uint32_t lb = 0, w = 0; lb < lightCount; lb += 64, w++) {
+        const uint64_t m = masks[w];
+        if ((m >> lane) & 1ull) {
+            const uint32_t j = before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            const uint32_t pg = j / BRMI_LIGHTS_PER_PAGE;
+            if (pg < valid) a.pages[base + pg].lightIndices[j % BRMI_LIGHTS_PER_PAGE] = a.lightMeta[lb + lane] >> 2;
         }
-        __syncthreads();
+        before += (uint32_t)__popcll(m);
     }
-    if (valid) {
-        if (page != BRMI_LIGHT_PAGE_NULL) a.pages[page].numLightsInPage = inPage;
-        c->numLights = numLights; c->ptrFirstPage = firstPage; c->pad[0] = 0; c->pad[1] = 0;
+    for (uint32_t pg = lane; pg < valid; pg += 64) {
+        brmi_light_page* p = a.pages + base + pg;
+        p->ptrNextPage = pg == 0u ? BRMI_LIGHT_PAGE_NULL : base + pg - 1u;
+        // every page but the newest is full; with the pool exhausted all surviving pages are full
+        p->numLightsInPage = (valid < demand || pg + 1u < demand) ? BRMI_LIGHTS_PER_PAGE : hits - BRMI_LIGHTS_PER_PAGE * (demand - 1u);
+    }
+    if (lane == 0) {
+        brmi_light_cluster* c = a.clusters + idx;
+        c->numLights = valid < demand ? BRMI_LIGHTS_PER_PAGE * valid : hits;
+        c->ptrFirstPage = valid == 0u ? BRMI_LIGHT_PAGE_NULL : base + valid - 1u;
+        c->pad[0] = 0; c->pad[1] = 0;
     }
 }
 
@@ -934,9 +939,11 @@ int launch_light_clustering(brmi_pass* p, hipStream_t s) {
     if (p->pfHost.numLights > p->scene.lightCount) return fail(p, BRMI_ERR_INVALID, "perFrame.numLights (%u) exceeds the light buffer (%u)", p->pfHost.numLights, p->scene.lightCount);
     const uint32_t nl = std::max(1u, p->pfHost.numLights), nc = p->numLightClusters;
     hipLaunchKernelGGL(k_lc_lights, dim3((nl + 63) / 64), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(k_lc_count, dim3((nc + 63) / 64), dim3(64), 0, s, a);
+    a.clusterHits = p->wsPtr<uint32_t>(p->ws.clusterHits); a.pageTotal = p->wsPtr<uint32_t>(p->ws.pageTotal);
+    a.hitMasks = p->wsPtr<uint64_t>(p->ws.lightHitMasks); a.maskWords = (std::max(1u, p->scene.lightCount) + 63u) / 64u;
+    hipLaunchKernelGGL(k_lc_count, dim3((nc + 3) / 4), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_lc_scan, dim3(1), dim3(1024), 0, s, a);
-    hipLaunchKernelGGL(k_lc_fill, dim3((nc + 63) / 64), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_lc_fill, dim3((nc + 3) / 4), dim3(256), 0, s, a);
     BRMI_LAUNCH_CHECK(p, "light clustering");
     return BRMI_OK;
 }
