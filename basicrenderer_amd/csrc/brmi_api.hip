@@ -76,13 +76,15 @@ static void compute_sizes(brmi_pass* p) {
     // workspace carve-up
     Workspace& w = p->ws; uint64_t off = 0;
     auto take = [&](uint64_t bytes) { uint64_t o = off; off = align_up(off + bytes, 256); return o; };
+    // counters and both bitmasks are adjacent: one fill clears them at the start of a frame
     w.counters = take((uint64_t)(CNT_WORDS + 64) * 4);
+    w.bitmask1 = take((uint64_t)p->totalWords * 4);
+    w.bitmask2 = take((uint64_t)p->totalWords * 4);
+    w.frameClearBytes = off - w.counters;
     w.frontierA = take((uint64_t)c.maxTraversalRecords * sizeof(NodeRecord));
     w.frontierB = take((uint64_t)c.maxTraversalRecords * sizeof(NodeRecord));
     w.buckets = take((uint64_t)c.maxTraversalRecords * sizeof(BucketRecord));
     w.tempVisible = take((uint64_t)c.maxVisibleClusters * sizeof(TempVisible));
-    w.bitmask1 = take((uint64_t)p->totalWords * 4);
-    w.bitmask2 = take((uint64_t)p->totalWords * 4);
     w.wordPrefix = take((uint64_t)p->totalWords * 4);
     w.blockSums = take((uint64_t)(p->scanBlocks + 1) * 4);
     w.instanceBitBase = take((uint64_t)std::max<size_t>(1, p->hostInstanceBitBase.size()) * 4);

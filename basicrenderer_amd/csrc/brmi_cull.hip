@@ -660,6 +660,27 @@ __global__ void __launch_bounds__(1024) k_scan_blocks(uint32_t* blockSums, uint3
     if (threadIdx.x == 0) counters[outIndex] = min(carry, capacity - (usedIndex == 0xFFFFFFFFu ? 0u : min(counters[usedIndex], capacity)));
 }
 
+// Small scenes (<= RANK_FUSED_WORDS bitmask words): the three scan launches as one workgroup.  Thread t owns a contiguous span
+// of words: popcount sum, block scan of the 1024 sums, then the per-word prefixes of its span.
+constexpr uint32_t RANK_FUSED_WORDS = 1u << 17;
+__global__ void __launch_bounds__(1024) k_rank_fused(const uint32_t* bitmask, uint32_t totalWords, uint32_t* wordPrefix, uint32_t* counters, uint32_t outIndex, uint32_t capacity, uint32_t usedIndex) {
+    __shared__ uint32_t waveTotals[16];
+    const uint32_t span = (totalWords + 1023u) / 1024u;
+    const uint32_t w0 = threadIdx.x * span, w1 = min(w0 + span, totalWords);
+    uint32_t sum = 0;
+    for (uint32_t w = w0; w < w1; w++) sum += __popc(bitmask[w]);
+    uint32_t incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o); if ((threadIdx.x & 63u) >= (uint32_t)o) incl += t; }
+    if ((threadIdx.x & 63u) == 63u) waveTotals[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t waveBase = 0, all = 0;
+    for (uint32_t w = 0; w < 16; w++) { if (w < (threadIdx.x >> 6)) waveBase += waveTotals[w]; all += waveTotals[w]; }
+    uint32_t run = waveBase + incl - sum;
+    for (uint32_t w = w0; w < w1; w++) { wordPrefix[w] = run; run += __popc(bitmask[w]); }
+    if (threadIdx.x == 0) counters[outIndex] = min(all, capacity - (usedIndex == 0xFFFFFFFFu ? 0u : min(counters[usedIndex], capacity)));
+}
+
 __global__ void __launch_bounds__(256) k_scan_words(const uint32_t* bitmask, uint32_t totalWords, const uint32_t* blockSums, uint32_t* wordPrefix) {
     __shared__ uint32_t waveTotals[4];
     __shared__ uint32_t carry;
@@ -797,14 +818,12 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
     const uint32_t maxBlocks = 1024;
     const bool hierarchy = p->maxLevelWidth <= HIER_CAP && !p->forceLevelKernels;
     if (phase == 1) {
-        BRMI_HIP(p, hipMemsetAsync(p->counters(), 0, CNT_WORDS * sizeof(uint32_t), s));
-        BRMI_HIP(p, hipMemsetAsync(bitmask, 0, (size_t)p->totalWords * 4, s));
+        BRMI_HIP(p, hipMemsetAsync(p->counters(), 0, p->ws.frameClearBytes, s));      // counters + both survivor bitmasks
         hipLaunchKernelGGL(k_object_constants, dim3((std::max(1u, p->scene.perObjectCount) + 63) / 64), dim3(64), 0, s, p->scene, p->wsPtr<m4>(p->ws.frameConst), p->wsPtr<float>(p->ws.objConst));
         if (hierarchy) hipLaunchKernelGGL(k_cull_hierarchy<false>, dim3(std::min(std::max(1u, p->scene.activeDrawCount), 8192u)), dim3(64), 0, s, a, buckets);
         else hipLaunchKernelGGL(k_cull_instances, dim3(grid_for(p->scene.activeDrawCount, 256, maxBlocks)), dim3(256), 0, s, a, fa);
         BRMI_LAUNCH_CHECK(p, "k_cull_instances");
     } else {
-        BRMI_HIP(p, hipMemsetAsync(bitmask, 0, (size_t)p->totalWords * 4, s));
         hipLaunchKernelGGL(k_seed_phase2, dim3(1), dim3(128), 0, s, p->counters(), a.recordCapacity);
         if (hierarchy) hipLaunchKernelGGL(k_cull_hierarchy<true>, dim3(2048), dim3(64), 0, s, a, buckets);
     }
@@ -818,11 +837,15 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
     }
     hipLaunchKernelGGL(k_cull_clusters, dim3(maxBlocks), dim3(256), 0, s, a, buckets, temp, bitmask);
     BRMI_LAUNCH_CHECK(p, "k_cull_clusters");
-    hipLaunchKernelGGL(k_scan_reduce, dim3(p->scanBlocks), dim3(256), 0, s, bitmask, p->totalWords, blockSums);
     // phase 2 appends behind the phase-1 clusters: its capacity is what phase 1 left
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, blockSums, p->scanBlocks, p->counters(), (uint32_t)(phase == 1 ? CNT_VISIBLE : CNT_VISIBLE2),
-                       p->cfg.maxVisibleClusters, phase == 1 ? 0xFFFFFFFFu : (uint32_t)CNT_VISIBLE);
-    hipLaunchKernelGGL(k_scan_words, dim3(p->scanBlocks), dim3(256), 0, s, bitmask, p->totalWords, blockSums, wordPrefix);
+    const uint32_t outIndex = phase == 1 ? CNT_VISIBLE : CNT_VISIBLE2, usedIndex = phase == 1 ? 0xFFFFFFFFu : (uint32_t)CNT_VISIBLE;
+    if (p->totalWords <= RANK_FUSED_WORDS && !p->forceLevelKernels) {
+        hipLaunchKernelGGL(k_rank_fused, dim3(1), dim3(1024), 0, s, bitmask, p->totalWords, wordPrefix, p->counters(), outIndex, p->cfg.maxVisibleClusters, usedIndex);
+    } else {
+        hipLaunchKernelGGL(k_scan_reduce, dim3(p->scanBlocks), dim3(256), 0, s, bitmask, p->totalWords, blockSums);
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, blockSums, p->scanBlocks, p->counters(), outIndex, p->cfg.maxVisibleClusters, usedIndex);
+        hipLaunchKernelGGL(k_scan_words, dim3(p->scanBlocks), dim3(256), 0, s, bitmask, p->totalWords, blockSums, wordPrefix);
+    }
     hipLaunchKernelGGL(k_scatter_visible, dim3(maxBlocks), dim3(256), 0, s, temp, p->counters(), (uint32_t)(phase == 1 ? CNT_TEMP_VISIBLE : CNT_TEMP_VISIBLE2), bitmask, wordPrefix,
                        static_cast<uint4*>(p->res[BRMI_RES_VISIBLE_CLUSTERS]), phase == 1 ? 0xFFFFFFFFu : (uint32_t)CNT_VISIBLE, p->cfg.maxVisibleClusters, p->cfg.maxVisibleClusters, p->scene, p->wsPtr<ClusterSetup>(p->ws.clusterSetup), p->resolveCapacity);
     BRMI_LAUNCH_CHECK(p, "compaction");

@@ -77,7 +77,7 @@ struct HzbDesc {
 
 struct Workspace {     // byte offsets into BRMI_RES_WORKSPACE
     uint64_t counters, frontierA, frontierB, buckets, tempVisible, bitmask1, bitmask2, wordPrefix, blockSums,
-             instanceBitBase, segPrefix, planes, replayNodes, replayBuckets, lightVS, lightMeta, clusterPages, clusterHits, pageTotal, lightHitMasks, binCounts, binRecords, clusterSetup, resolveVerts, resolveTris, matWords, shadeTables, lutF, frameConst, objConst, matConst, deferredPixels, total;
+             instanceBitBase, segPrefix, planes, replayNodes, replayBuckets, lightVS, lightMeta, clusterPages, clusterHits, pageTotal, lightHitMasks, binCounts, binRecords, clusterSetup, resolveVerts, resolveTris, matWords, shadeTables, lutF, frameConst, objConst, matConst, deferredPixels, frameClearBytes, total;
 };
 
 }  // namespace brmi

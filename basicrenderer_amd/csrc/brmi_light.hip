@@ -587,8 +587,9 @@ BRMI_DEV f3 light_contribution(const Luts& L, const Frag& f, const PixelCtx& c, 
 // Per-material part of PopulateFragmentInfoFromOpenPBR (utilities.hlsli:2590-2637): depends only on the
 // OpenPBR material record, so it is evaluated once per material per frame instead of once per pixel.
 struct MatConst { float baseWeight, specularWeight, specR, specG, specB, weightedSpecularIor, dielF0Scalar, coatF0Scalar, coatIor, coatDarkening, baseDiffuseRoughness, pad; };
-__global__ void __launch_bounds__(64) k_material_constants(brmi_scene_buffers sc, MatConst* out) {
+__global__ void __launch_bounds__(64) k_material_constants(brmi_scene_buffers sc, MatConst* out, uint32_t* counters) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) counters[CNT_DEFERRED_PIXELS] = 0u;      // the deferred-pixel list of the shading kernels starts empty
     if (i >= sc.openpbrMaterialCount) return;
     const brmi_openpbr_material_info* op = sc.openpbrMaterials + i;
     MatConst m;
@@ -967,9 +968,8 @@ int launch_shade(brmi_pass* p, hipStream_t s) {
         a.tables = ShadeTables{reinterpret_cast<float*>(tb), tb + W, reinterpret_cast<float*>(tb + 2 * W), tb + 2 * W + H, reinterpret_cast<float*>(tb + 2 * W + 2 * H)};
         hipLaunchKernelGGL(k_shade_tables, dim3((std::max(std::max(W, H), 64u) + 255) / 256), dim3(256), 0, s, p->scene, a.tables, W, H);
     }
-    hipLaunchKernelGGL(k_material_constants, dim3((std::max(1u, p->scene.openpbrMaterialCount) + 63) / 64), dim3(64), 0, s, p->scene, p->wsPtr<MatConst>(p->ws.matConst));
+    hipLaunchKernelGGL(k_material_constants, dim3((std::max(1u, p->scene.openpbrMaterialCount) + 63) / 64), dim3(64), 0, s, p->scene, p->wsPtr<MatConst>(p->ws.matConst), p->counters());
     a.counters = p->counters(); a.deferred = p->wsPtr<uint32_t>(p->ws.deferredPixels);
-    BRMI_HIP(p, hipMemsetAsync(&p->counters()[CNT_DEFERRED_PIXELS], 0, 4, s));
     hipLaunchKernelGGL(k_shade<false>, dim3(4096), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_shade<true>, dim3(2048), dim3(256), 0, s, a);
     BRMI_LAUNCH_CHECK(p, "k_shade");

@@ -351,6 +351,8 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS) k_raster_bins(RasterArgs a) 
     const uint32_t strip = blockIdx.x, band = blockIdx.y, bin = band * a.binsX + strip;
     const uint32_t n = min(a.binCounts[bin], a.binCapacity);
     if (n == 0) return;
+    __syncthreads();                                    // every thread has read the count
+    if (threadIdx.x == 0) a.binCounts[bin] = 0u;      // self-cleaning: the bins are empty again when this launch retires
     for (uint32_t i = threadIdx.x; i < BIN_W * BIN_ROWS; i += BRMI_BIN_THREADS) tile[i] = BRMI_VIS_EMPTY;
     __syncthreads();
     const int x0 = (int)(strip << BIN_W_SHIFT), y0 = (int)(band << BIN_ROWS_SHIFT);
@@ -420,7 +422,6 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
     a.binCapacity = p->binCapacity; a.binsX = p->binsX; a.binsY = p->binsY;
     a.objConst = p->wsPtr<float>(p->ws.objConst);
     a.bigTriArea = p->bigTriArea; a.debugFlags = p->rasterDebug;
-    BRMI_HIP(p, hipMemsetAsync(a.binCounts, 0, (size_t)p->binsX * p->binsY * sizeof(uint32_t), s));
     hipLaunchKernelGGL(k_raster, dim3(p->rasterGrid), dim3(64), 0, s, a);
     if (!(p->rasterDebug & 4)) hipLaunchKernelGGL(k_raster_bins, dim3(p->binsX, p->binsY), dim3(BRMI_BIN_THREADS), 0, s, a);
     BRMI_LAUNCH_CHECK(p, "k_raster");
