@@ -106,6 +106,7 @@ static void compute_sizes(brmi_pass* p) {
     w.clusterSetup = take((uint64_t)c.maxVisibleClusters * sizeof(ClusterSetup));
     // resolve arena: full tables for up to 65536 clusters (more when they are not full); clusters beyond it are resolved per pixel
     p->resolveCapacity = (uint32_t)std::min<uint64_t>((uint64_t)c.maxVisibleClusters, 65536ull) * BRMI_MESHLET_MAX_TRIS;
+    if (const char* e = std::getenv("BRMI_RESOLVE_CAPACITY")) p->resolveCapacity = (uint32_t)std::max(1, std::atoi(e));   // tests: force the per-pixel fallback
     w.resolveVerts = take((uint64_t)p->resolveCapacity * sizeof(ResolveVertex));
     w.resolveTris = take((uint64_t)p->resolveCapacity * sizeof(ResolveTriangle));
     w.shadeTables = take(((uint64_t)2 * c.width + 2 * c.height + 64) * 4);
