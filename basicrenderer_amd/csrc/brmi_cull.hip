@@ -537,6 +537,32 @@ __global__ void __launch_bounds__(64) k_cull_hierarchy(CullArgs a, BucketRecord*
     }
 }
 
+// ComputeSkinnedMeshletBounds (workGraphCulling.hlsl:1405-1467): the meshlet sphere moved by every bone the meshlet lists,
+// merged pairwise into one enclosing sphere
+BRMI_DEV float4 skinned_meshlet_bounds(const brmi_scene_buffers& sc, const brmi_meshlet_descriptor* desc, const brmi_page_header* hdr, const uint8_t* page, uint32_t slot, float4 staticBounds) {
+    const uint32_t boneCount = desc->boneCount;
+    if (slot == 0xFFFFFFFFu || boneCount == 0u || sc.skinningMatrices == nullptr) return staticBounds;
+    const uint32_t* boneList = reinterpret_cast<const uint32_t*>(page + hdr->boneIndexStreamOffset + desc->boneListOffset * 4u);
+    const f3 c0{staticBounds.x, staticBounds.y, staticBounds.z};
+    f3 mc{0.0f, 0.0f, 0.0f}; float mr = 0.0f; bool init = false;
+    for (uint32_t b = 0; b < boneCount; b++) {
+        const m4 m = load_bone_skin_matrix(sc.skinningMatrices, slot, boneList[b]);
+        const f3 tc = xyz(mul_point(c0, m));
+        const float tr = staticBounds.w * max_axis_scale(m);
+        if (!init) { mc = tc; mr = tr; init = true; continue; }
+        const f3 delta = tc - mc;
+        const float dist = length3(delta);
+        if (dist + tr <= mr) continue;
+        if (dist + mr <= tr) { mc = tc; mr = tr; continue; }
+        const float newRadius = 0.5f * (dist + mr + tr);
+        const float t = (newRadius - mr) / max2(dist, 1e-12f);
+        mc = mc + delta * t;
+        mr = newRadius;
+    }
+    if (!init) return staticBounds;
+    return make_float4(mc.x, mc.y, mc.z, mr * (1.0f + 1e-5f));
+}
+
 // K3: per-meshlet cull ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_cull_clusters(CullArgs a, const BucketRecord* buckets, TempVisible* temp, uint32_t* bitmask) {
     const brmi_scene_buffers& sc = a.sc;
@@ -569,9 +595,11 @@ __global__ void __launch_bounds__(256) k_cull_clusters(CullArgs a, const BucketR
                 const brmi_page_header* hdr = reinterpret_cast<const brmi_page_header*>(slab + b.pageSlabByteOffset);
                 if (lm < hdr->meshletCount) {
                     const brmi_meshlet_descriptor* desc = reinterpret_cast<const brmi_meshlet_descriptor*>(slab + b.pageSlabByteOffset + hdr->descriptorOffset + lm * 64u);
-                    const float4 bounds = *reinterpret_cast<const float4*>(desc->bounds);
+                    float4 bounds = *reinterpret_cast<const float4*>(desc->bounds);
                     const uint32_t triAndRefined = desc->triangleCountAndRefinedGroup;
                     const brmi_per_mesh_instance inst = sc.perMeshInstance[b.instanceIndex];
+                    if ((sc.perMesh[inst.perMeshBufferIndex].vertexFlags & BRMI_VERTEX_SKINNED) != 0u)
+                        bounds = skinned_meshlet_bounds(sc, desc, hdr, slab + b.pageSlabByteOffset, inst.skinningInstanceSlot, bounds);
                     const brmi_clod_mesh_metadata* md = sc.meshMetadata + sc.clodOffsets[b.instanceIndex].clodMeshMetadataIndex;
                     const m4 model = load_m4(&sc.perObject[inst.perObjectBufferIndex].model[0][0]);
                     const float scale = max_axis_scale(model);
@@ -764,13 +792,17 @@ __global__ void __launch_bounds__(256) k_scatter_visible(const TempVisible* temp
             cs.posBase = slab + pageOff + hdr->positionBitstreamOffset + desc->positionBitOffset;
             cs.triBase = slab + pageOff + hdr->triangleStreamOffset + desc->triangleByteOffset;
             cs.nrmBase = slab + pageOff + hdr->normalArrayOffset + desc->vertexAttributeOffset * 4u;
-            cs.counts = verts | (tris << 8) | ((hdr->compressedPositionQuantExp & 0xFFu) << 16) | (((obj->objectFlags & BRMI_OBJECT_FLAG_REVERSE_WINDING) != 0 ? 1u : 0u) << 24);
+            const brmi_per_mesh* pm = sc.perMesh + inst.perMeshBufferIndex;
+            cs.counts = verts | (tris << 8) | ((hdr->compressedPositionQuantExp & 0xFFu) << 16) | (((obj->objectFlags & BRMI_OBJECT_FLAG_REVERSE_WINDING) != 0 ? 1u : 0u) << 24)
+                      | ((pm->vertexFlags & BRMI_VERTEX_SKINNED) ? BRMI_CS_SKINNED : 0u) | ((hdr->attributeMask & BRMI_PAGE_ATTRIBUTE_JOINTS) ? BRMI_CS_JOINTS : 0u)
+                      | ((hdr->attributeMask & BRMI_PAGE_ATTRIBUTE_WEIGHTS) ? BRMI_CS_WEIGHTS : 0u);
+            cs.jointDelta = (int32_t)(hdr->jointArrayOffset + desc->vertexAttributeOffset * 32u) - (int32_t)(hdr->normalArrayOffset + desc->vertexAttributeOffset * 4u);
+            cs.weightDelta = (int32_t)(hdr->weightArrayOffset + desc->vertexAttributeOffset * 32u) - (int32_t)(hdr->normalArrayOffset + desc->vertexAttributeOffset * 4u);
             cs.perObjectIndex = inst.perObjectBufferIndex; cs.instanceIndex = instanceIndex; cs.viewId = vc_view(t.packed);
-            cs.materialDataIndex = sc.perMesh[inst.perMeshBufferIndex].materialDataIndex; cs.normalMatrixIndex = obj->normalMatrixBufferIndex;
+            cs.materialDataIndex = pm->materialDataIndex; cs.normalMatrixIndex = obj->normalMatrixBufferIndex;
             const unsigned long long v0 = baseV + (inclV - verts), t0 = baseT + (inclT - tris);
             const bool fits = v0 + verts <= resolveCapacity && t0 + tris <= resolveCapacity;
             cs.vertBase = fits ? (uint32_t)v0 : BRMI_ARENA_NONE; cs.triBase32 = fits ? (uint32_t)t0 : BRMI_ARENA_NONE;
-            cs.pad[0] = cs.pad[1] = 0u;
             setup[dst] = cs;
         }
     }

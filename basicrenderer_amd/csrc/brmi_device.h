@@ -144,6 +144,43 @@ BRMI_DEV float uni(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_
 BRMI_DEV m4 uni_m4(const m4& a) { m4 r; for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) r.m[i][j] = uni(a.m[i][j]); return r; }
 BRMI_DEV uint32_t lane_id() { return __lane_id(); }
 BRMI_DEV uint32_t lane_rank(uint64_t mask) { return __popcll(mask & ((1ull << lane_id()) - 1ull)); }
+// ---- skinning (BR/shaders/Include/skinningCommon.hlsli:23-88) -------------------------------------------------------------
+// `skinningMatrices` holds bone * inverseBind per (slot, joint), 64 joints per slot; LoadBoneSkinMatrix is its transpose.
+BRMI_DEV m4 load_bone_skin_matrix(const float* skinningMatrices, uint32_t slot, uint32_t joint) {
+    const m4 prod = load_m4(skinningMatrices + ((size_t)slot * 64u + joint) * 16u);
+    m4 r;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) r.m[i][j] = prod.m[j][i];
+    return r;
+}
+// BuildSkinMatrix: w0*M0 + w1*M1 + ... + w7*M7, left to right
+BRMI_DEV m4 build_skin_matrix(const float* skinningMatrices, uint32_t slot, const uint32_t* joints, const float* weights) {
+    m4 r;
+    if (slot == 0xFFFFFFFFu || skinningMatrices == nullptr) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) r.m[i][j] = (i == j) ? 1.0f : 0.0f;
+        return r;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const m4 b = load_bone_skin_matrix(skinningMatrices, slot, joints[k]);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) { const float t = weights[k] * b.m[i][j]; r.m[i][j] = (k == 0) ? t : r.m[i][j] + t; }
+    }
+    return r;
+}
+// joints / weights of one vertex (8 x u32, 8 x f32); missing arrays read as zero
+BRMI_DEV void load_skin_influences(const uint8_t* jointPtr, const uint8_t* weightPtr, uint32_t joints[8], float weights[8]) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) { joints[k] = jointPtr ? reinterpret_cast<const uint32_t*>(jointPtr)[k] : 0u; weights[k] = weightPtr ? reinterpret_cast<const float*>(weightPtr)[k] : 0.0f; }
+}
+
 // Read-only data produced by an earlier kernel, viewed through the constant address space: with a wave-uniform address
 // the compiler then selects scalar (s_load) instead of vector loads.
 template <typename T> BRMI_DEV const __attribute__((address_space(4))) T* kconst(const T* p) { return (const __attribute__((address_space(4))) T*)p; }

@@ -52,11 +52,13 @@ struct TempVisible { uint4 packed; uint32_t bit, pad0, pad1, pad2; };           
 // -> instance -> mesh / object is 6 dependent HBM round trips when every consumer walks it itself.
 struct ClusterSetup {                 // 64 B
     const uint8_t* posBase; const uint8_t* triBase; const uint8_t* nrmBase;
-    uint32_t counts;                  // vertCount | triCount << 8 | positionFormat << 16 | reverseWinding << 24
+    uint32_t counts;                  // vertCount | triCount << 8 | positionFormat << 16 | reverseWinding << 24 | skinned mesh << 25 |
+                                      // page has joints << 26 | page has weights << 27
     uint32_t perObjectIndex, instanceIndex, viewId, materialDataIndex, normalMatrixIndex;
     uint32_t vertBase, triBase32;     // first ResolveVertex / ResolveTriangle of the cluster in the resolve arena (BRMI_ARENA_NONE: none)
-    uint32_t pad[2];
+    int32_t jointDelta, weightDelta;  // byte offsets of the cluster's joint / weight arrays (32 B per vertex) relative to nrmBase
 };
+constexpr uint32_t BRMI_CS_SKINNED = 1u << 25, BRMI_CS_JOINTS = 1u << 26, BRMI_CS_WEIGHTS = 1u << 27;
 constexpr uint32_t BRMI_ARENA_NONE = 0xFFFFFFFFu;
 // resolve arena: per-vertex and per-triangle tables of the visible clusters (brmi_resolve.hip)
 struct ResolveVertex { float px, py, pz, nx, ny, nz; };                                   // 24 B: object-space position, decoded normal

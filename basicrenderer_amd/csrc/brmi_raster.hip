@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(64) k_raster(RasterArgs a) {
         const uint32_t clusterIndex = first + c;
         const ClusterSetup cs = a.setup[clusterIndex];        // resolved by the compaction kernel: one hop instead of six
         const uint32_t vertCount = cs.counts & 0xFFu, triCount = (cs.counts >> 8) & 0xFFu, posFormat = (cs.counts >> 16) & 0xFFu;
-        const bool reverseWinding = (cs.counts >> 24) != 0u;
+        const bool reverseWinding = ((cs.counts >> 24) & 1u) != 0u;
         const brmi_view_raster_info ri = sc.viewRasterInfo[cs.viewId];
         const float visWidth = (float)(ri.scissorMaxX - ri.scissorMinX), visHeight = (float)(ri.scissorMaxY - ri.scissorMinY);
         const float sMinXf = (float)ri.scissorMinX, sMinYf = (float)ri.scissorMinY;
@@ -168,6 +168,9 @@ __global__ void __launch_bounds__(64) k_raster(RasterArgs a) {
         const f4 modelViewZ{oc[32], oc[33], oc[34], oc[35]};
         const uint8_t* posBase = cs.posBase;
         const uint8_t* triBase = cs.triBase;
+        // compute skinning, folded into the vertex fetch (softwareRaster.hlsl:349-360)
+        const bool skinVerts = (cs.counts & (BRMI_CS_SKINNED | BRMI_CS_JOINTS)) == (BRMI_CS_SKINNED | BRMI_CS_JOINTS);
+        const uint32_t skinSlot = skinVerts ? sc.perMeshInstance[cs.instanceIndex].skinningInstanceSlot : 0xFFFFFFFFu;
 
         // vertex stage -> LDS (softwareRaster.hlsl:339-387)
         for (uint32_t v = lane; v < vertCount; v += 64) {
@@ -175,6 +178,11 @@ __global__ void __launch_bounds__(64) k_raster(RasterArgs a) {
             if (posFormat == BRMI_POSITION_FORMAT_FLOAT3) {
                 const float* pp = reinterpret_cast<const float*>(posBase + v * 12u);
                 lp = f3{pp[0], pp[1], pp[2]};
+            }
+            if (skinVerts) {
+                uint32_t joints[8]; float weights[8];
+                load_skin_influences(cs.nrmBase + cs.jointDelta + v * 32u, (cs.counts & BRMI_CS_WEIGHTS) ? cs.nrmBase + cs.weightDelta + v * 32u : nullptr, joints, weights);
+                lp = xyz(mul_point(lp, build_skin_matrix(sc.skinningMatrices, skinSlot, joints, weights)));
             }
             const f4 lp4{lp.x, lp.y, lp.z, 1.0f};
             const f4 clip = mul_vm(lp4, mvp);

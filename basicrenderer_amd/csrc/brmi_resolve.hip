@@ -84,10 +84,18 @@ __global__ void __launch_bounds__(64) k_resolve_setup(GBufferArgs a) {
         if (cs.vertBase == BRMI_ARENA_NONE) continue;          // arena full: the pixel pass walks this cluster's data itself
         const uint32_t vertCount = cs.counts & 0xFFu, triCount = (cs.counts >> 8) & 0xFFu, posFormat = (cs.counts >> 16) & 0xFFu;
         const m4 objectToClip = load_m4(a.objConst + (size_t)cs.perObjectIndex * 36u + 16u);
+        const bool skinned = (cs.counts & BRMI_CS_SKINNED) != 0u;
+        const uint32_t skinSlot = skinned ? a.sc.perMeshInstance[cs.instanceIndex].skinningInstanceSlot : 0xFFFFFFFFu;
         for (uint32_t v = lane; v < vertCount; v += 64) {
             f3 p{0.0f, 0.0f, 0.0f};
             if (posFormat == BRMI_POSITION_FORMAT_FLOAT3) { const float* pp = reinterpret_cast<const float*>(cs.posBase + v * 12u); p = f3{pp[0], pp[1], pp[2]}; }
-            const f3 n = oct_decode_normal(*reinterpret_cast<const uint32_t*>(cs.nrmBase + v * 4u));
+            f3 n = oct_decode_normal(*reinterpret_cast<const uint32_t*>(cs.nrmBase + v * 4u));
+            if (skinned) {      // ApplyClodSkinning (clodResolveCommon.hlsli:702-714): once per vertex here, not once per pixel and corner
+                uint32_t joints[8]; float weights[8];
+                load_skin_influences((cs.counts & BRMI_CS_JOINTS) ? cs.nrmBase + cs.jointDelta + v * 32u : nullptr, (cs.counts & BRMI_CS_WEIGHTS) ? cs.nrmBase + cs.weightDelta + v * 32u : nullptr, joints, weights);
+                const m4 skin = build_skin_matrix(a.sc.skinningMatrices, skinSlot, joints, weights);
+                p = xyz(mul_point(p, skin)); n = mul_v3m3(n, skin);
+            }
             const f4 clip = mul_point(p, objectToClip);
             cx[v] = clip.x; cy[v] = clip.y; cw[v] = clip.w;
             a.verts[cs.vertBase + v] = ResolveVertex{p.x, p.y, p.z, n.x, n.y, n.z};
@@ -131,12 +139,20 @@ BRMI_DEV void resolve_tables_inline(const GBufferArgs& a, const ClusterSetup& cs
     const uint8_t* tb = cs.triBase + triId * 3u;
     const uint32_t ti[3] = {tb[0], tb[1], tb[2]};
     const m4 objectToClip = load_m4(a.objConst + (size_t)cs.perObjectIndex * 36u + 16u);
+    const bool skinned = (cs.counts & BRMI_CS_SKINNED) != 0u;
+    const uint32_t skinSlot = skinned ? a.sc.perMeshInstance[cs.instanceIndex].skinningInstanceSlot : 0xFFFFFFFFu;
     f4 clip[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         if (((cs.counts >> 16) & 0xFFu) == BRMI_POSITION_FORMAT_FLOAT3) { const float* pp = reinterpret_cast<const float*>(cs.posBase + ti[k] * 12u); p[k] = f3{pp[0], pp[1], pp[2]}; }
         else p[k] = f3{0.0f, 0.0f, 0.0f};
         n[k] = oct_decode_normal(*reinterpret_cast<const uint32_t*>(cs.nrmBase + ti[k] * 4u));
+        if (skinned) {
+            uint32_t joints[8]; float weights[8];
+            load_skin_influences((cs.counts & BRMI_CS_JOINTS) ? cs.nrmBase + cs.jointDelta + ti[k] * 32u : nullptr, (cs.counts & BRMI_CS_WEIGHTS) ? cs.nrmBase + cs.weightDelta + ti[k] * 32u : nullptr, joints, weights);
+            const m4 skin = build_skin_matrix(a.sc.skinningMatrices, skinSlot, joints, weights);
+            p[k] = xyz(mul_point(p[k], skin)); n[k] = mul_v3m3(n[k], skin);
+        }
         clip[k] = mul_point(p[k], objectToClip);
     }
     const f3 invW{rcpf(clip[0].w), rcpf(clip[1].w), rcpf(clip[2].w)};

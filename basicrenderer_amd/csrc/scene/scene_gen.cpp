@@ -809,6 +809,21 @@ void boxPatches(std::vector<PatchDef>& out, V3 lo, V3 hi, uint32_t n, double amp
 
 uint32_t roundPow2Mult(uint32_t v, uint32_t levels) { uint32_t q = 1u << (levels - 1); return std::max(q, (v + q - 1) / q * q); }
 
+// A skinning instance slot: 64 joint matrices (bone * inverseBind products, what LoadBoneSkinMatrix multiplies out per
+// use; skinningCommon.hlsli:23-48).  Joints 0..3 are the ones the generated meshes reference: a bend along +Y.
+uint32_t addSkinSlot(brmi_scene& sc, Pcg32& rng, double amount) {
+    const uint32_t slot = (uint32_t)(sc.skinningMatrices.size() / (64 * 16));
+    for (uint32_t j = 0; j < 64; j++) {
+        const double k = (double)(j & 3) / 3.0;
+        // stored as the column-vector product; the shader transposes it into the row-vector skin matrix
+        M4 rowVec = mul(mul(rotationZ(amount * 0.6 * k + rng.range(-0.02f, 0.02f)), rotationX(amount * 0.25 * k)), translation({0.15 * amount * k, 0.05 * k, 0.0}));
+        M4 stored = transpose(rowVec);
+        float f[4][4]; store(f, stored);
+        sc.skinningMatrices.insert(sc.skinningMatrices.end(), &f[0][0], &f[0][0] + 16);
+    }
+    return slot;
+}
+
 // ---- presets ---------------------------------------------------------------------------------
 void presetTiny(brmi_scene& sc, Pcg32& rng) {
     addMaterials(sc, rng, 4);
@@ -817,12 +832,14 @@ void presetTiny(brmi_scene& sc, Pcg32& rng) {
     meshes[0].patches.push_back(planePatch({-2, 0, -2}, {0, 0, 4}, {4, 0, 0}, roundPow2Mult(2, levels), roundPow2Mult(2, levels), 0.15, 3, 11)); meshes[0].material = 0; meshes[0].lodLevels = levels;
     meshes[1].patches.push_back(ellipsoidPatch({0, 0, 0}, 0.5, 0.5, 0.5, roundPow2Mult(2, levels), roundPow2Mult(1, levels), 0.05, 3, 12)); meshes[1].material = 1; meshes[1].lodLevels = levels;
     meshes[2].patches.push_back(cylinderPatch({0, 0, 0}, 0.25, 1.5, roundPow2Mult(1, levels), roundPow2Mult(2, levels), 0.0, 3, 13)); meshes[2].material = 3; meshes[2].lodLevels = levels;
+    const bool skin = sc.params.skinnedFraction1024 != 0;
+    if (skin) { meshes.push_back(meshes[1]); meshes.back().skinned = true; meshes.push_back(meshes[2]); meshes.back().skinned = true; }   // meshes 3, 4
     for (size_t i = 0; i < meshes.size(); i++) buildMesh(sc, meshes[i], (uint32_t)i);
     addInstance(sc, {0, identity()});
     addInstance(sc, {1, translation({0.3, 0.6, -0.4})});
-    addInstance(sc, {1, mul(scaling(0.6), translation({-1.0, 0.5, 0.5}))});
+    addInstance(sc, {skin ? 3u : 1u, mul(scaling(0.6), translation({-1.0, 0.5, 0.5})), false, skin ? addSkinSlot(sc, rng, 1.0) : 0xFFFFFFFFu});
     addInstance(sc, {2, translation({1.0, 0.0, -1.0})});
-    addInstance(sc, {2, mul(rotationZ(0.3), translation({-0.8, 0.0, -1.2}))});
+    addInstance(sc, {skin ? 4u : 2u, mul(rotationZ(0.3), translation({-0.8, 0.0, -1.2})), false, skin ? addSkinSlot(sc, rng, 1.6) : 0xFFFFFFFFu});
     addInstance(sc, {1, translation({0.0, 0.5, 30.0})});   // behind the camera: frustum-culled
     setCamera(sc, {0.2, 1.2, 3.0}, 0.08, -0.28, 80.0, 0.1, 1000.0);
     if (sc.params.withDirectionalLight) addLight(sc, BRMI_LIGHT_DIRECTIONAL, {0, 0, 0}, {1, 1, 1}, 10.0f, {1, 0, 0}, {0, -6, -1});
@@ -910,6 +927,7 @@ void presetStreet(brmi_scene& sc, Pcg32& rng, double triBudget, uint32_t nMeshes
         m.material = 3 + rng.below(60);
         uint32_t cnt = 0; for (auto& p : m.patches) cnt += p.nu0 * p.nv0;
         propMeshlets[i] = cnt;
+        m.skinned = ((i * 2654435761u) >> 22) < sc.params.skinnedFraction1024;     // hash of the prop index: does not disturb the scene's random stream
         meshes.push_back(m);
     }
     for (size_t i = 0; i < meshes.size(); i++) buildMesh(sc, meshes[i], (uint32_t)i);
@@ -917,7 +935,7 @@ void presetStreet(brmi_scene& sc, Pcg32& rng, double triBudget, uint32_t nMeshes
     // instances: fill the remaining budget
     double remaining = budgetMeshlets - (double)sc.stats.instancedTriangles / 128.0;
     uint32_t made = 0;
-    const bool skinSome = sc.params.skinnedFraction1024 != 0; (void)skinSome;
+    Pcg32 skinRng(sc.params.seed * 977u + 5u, 77u);
     while (made < nInstances && remaining > 0) {
         uint32_t pi = rng.below(nProps);
         double scl = rng.range(0.5f, 1.8f);
@@ -926,7 +944,8 @@ void presetStreet(brmi_scene& sc, Pcg32& rng, double triBudget, uint32_t nMeshes
         if (rng.uniform() < 0.7f) pos = {rng.range((float)-Wd + 1, (float)Wd - 1), 0, rng.range((float)-L + 2, 20.0f)};
         else pos = {rng.range((float)-Wd * 2.5f, (float)Wd * 2.5f), 0, rng.range((float)-L, (float)L)};
         if (foliage) pos.y = rng.range(0.0f, 3.0f);
-        addInstance(sc, {nStatics + pi, mul(mul(scaling(scl), rotationY(rng.range(0, 6.2831f))), translation(pos))});
+        const M4 xf = mul(mul(scaling(scl), rotationY(rng.range(0, 6.2831f))), translation(pos));
+        addInstance(sc, {nStatics + pi, xf, false, meshes[nStatics + pi].skinned ? addSkinSlot(sc, skinRng, skinRng.range(0.3f, 1.5f)) : 0xFFFFFFFFu});
         remaining -= propMeshlets[pi];
         made++;
     }

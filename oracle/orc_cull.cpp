@@ -18,6 +18,7 @@
 // stored in the visibility key - and therefore equal-depth tie-breaking - is reproducible.
 #include <algorithm>
 #include <cfloat>
+#include <cstring>
 #include <vector>
 
 #include "orc_common.h"
@@ -99,6 +100,34 @@ static bool occlusionCulled(const HzbView& hzb, const brmi_camera& cam, const ma
     float d0 = m[(uint64_t)y0 * mw + x0], d1 = m[(uint64_t)y0 * mw + x1], d2 = m[(uint64_t)y1 * mw + x1], d3 = m[(uint64_t)y1 * mw + x0];
     float mx = fmax2(fmax2(d0, d1), fmax2(d2, d3));
     return mx < sphereDepth - radius;
+}
+
+// ComputeSkinnedMeshletBounds (workGraphCulling.hlsl:1405-1467): the meshlet sphere moved by every bone the meshlet lists,
+// merged pairwise into one enclosing sphere
+static void skinnedMeshletBounds(const brmi_scene_buffers& sc, const brmi_meshlet_descriptor& desc, const brmi_page_header& hdr, const uint8_t* slab, uint32_t pageOff,
+                                 uint32_t slot, float3& center, float& radius) {
+    if (slot == 0xFFFFFFFFu || desc.boneCount == 0u || sc.skinningMatrices == nullptr) return;
+    const uint32_t boneListBase = pageOff + hdr.boneIndexStreamOffset + desc.boneListOffset * 4u;
+    const float3 c0 = center; const float r0 = radius;
+    float3 mc{0, 0, 0}; float mr = 0.0f; bool init = false;
+    for (uint32_t b = 0; b < desc.boneCount; b++) {
+        uint32_t joint; std::memcpy(&joint, slab + boneListBase + b * 4u, 4);
+        const float* prod = sc.skinningMatrices + ((size_t)slot * 64u + joint) * 16u;
+        mat4 m; for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) m.m[i][j] = prod[j * 4 + i];     // LoadBoneSkinMatrix: transpose(bone * invBind)
+        const float3 tc = xyz(mulPoint(c0, m));
+        const float tr = r0 * maxAxisScale(m);
+        if (!init) { mc = tc; mr = tr; init = true; continue; }
+        const float3 delta = tc - mc;
+        const float dist = length(delta);
+        if (dist + tr <= mr) continue;
+        if (dist + mr <= tr) { mc = tc; mr = tr; continue; }
+        const float newRadius = 0.5f * (dist + mr + tr);
+        const float t = (newRadius - mr) / fmax2(dist, 1e-12f);
+        mc = mc + delta * t;
+        mr = newRadius;
+    }
+    if (!init) return;
+    center = mc; radius = mr * (1.0f + 1e-5f);
 }
 
 struct VisKey { uint32_t inst, seg, off; brmi_visible_cluster packed; };
@@ -296,8 +325,10 @@ int orc_cull(const brmi_scene_buffers* scp, const orc_cull_params* prm, brmi_vis
             if (lm >= hdr->meshletCount) continue;
             const brmi_meshlet_descriptor& desc = *meshletDesc(slab, b.pageOff, hdr->descriptorOffset, lm);
             float3 bc{desc.bounds[0], desc.bounds[1], desc.bounds[2]};
+            float br = desc.bounds[3];
+            if (sc.perMesh[inst.perMeshBufferIndex].vertexFlags & BRMI_VERTEX_SKINNED) skinnedMeshletBounds(sc, desc, *hdr, slab, b.pageOff, inst.skinningInstanceSlot, bc, br);
             float3 cVS = toViewSpace(bc, model, view);
-            float rW = desc.bounds[3] * scale;
+            float rW = br * scale;
             bool survives = b.replay || !sphereOutsideFrustum(cVS, rW, cam.clippingPlanes);
             if (survives) {
                 const int32_t refined = descRefinedGroup(desc);
@@ -309,7 +340,7 @@ int orc_cull(const brmi_scene_buffers* scp, const orc_cull_params* prm, brmi_vis
                 else {
                     const mat4& prevModel = M(obj.prevModel);
                     float3 pc = toViewSpace(bc, prevModel, M(cam.prevView));
-                    oc = occlusionCulled(hzb, cam, M(cam.prevUnjitteredProjection), pc, -pc.z, desc.bounds[3] * maxAxisScale(prevModel));
+                    oc = occlusionCulled(hzb, cam, M(cam.prevUnjitteredProjection), pc, -pc.z, br * maxAxisScale(prevModel));
                 }
                 if (oc) {
                     if (!b.replay && prm->replayMeshlets && *prm->replayMeshletCount < prm->replayMeshletCapacity) {

@@ -30,6 +30,9 @@ SCENE_CASES = {
     "sponza_coat_fuzz": ("sponza", 480, 270, dict(point_lights=32, size_scale=0.15, material_features=3)),
     "sponza_small": ("sponza", 640, 360, dict(point_lights=64, size_scale=0.25)),
     "bistro_small": ("bistro", 640, 360, dict(point_lights=256, size_scale=0.08)),
+    # compute skinning: bone-merged meshlet bounds in the cull, skinned vertices in raster and resolve
+    "tiny_skinned": ("tiny", 256, 144, dict(point_lights=4, skinned_fraction=1.0, lod_levels=2)),
+    "bistro_skinned": ("bistro", 640, 360, dict(point_lights=32, size_scale=0.3, skinned_fraction=0.3)),
 }
 
 
