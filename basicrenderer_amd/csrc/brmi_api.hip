@@ -104,8 +104,9 @@ static void compute_sizes(brmi_pass* p) {
     w.binCounts = take((uint64_t)p->binsX * p->binsY * 4);
     w.binRecords = take((uint64_t)p->binsX * p->binsY * p->binCapacity * 64);
     w.clusterSetup = take((uint64_t)c.maxVisibleClusters * sizeof(ClusterSetup));
-    // resolve arena: full tables for up to 65536 clusters (more when they are not full); clusters beyond it are resolved per pixel
-    p->resolveCapacity = (uint32_t)std::min<uint64_t>((uint64_t)c.maxVisibleClusters, 65536ull) * BRMI_MESHLET_MAX_TRIS;
+    // resolve arena: full tables (72 B per vertex + triangle slot) for up to 2^20 clusters = 9.7 GB of the 288; a configuration
+    // that allows more visible clusters keeps the per-pixel path for the clusters that do not fit
+    p->resolveCapacity = (uint32_t)std::min<uint64_t>((uint64_t)c.maxVisibleClusters, 1ull << 20) * BRMI_MESHLET_MAX_TRIS;
     if (const char* e = std::getenv("BRMI_RESOLVE_CAPACITY")) p->resolveCapacity = (uint32_t)std::max(1, std::atoi(e));   // tests: force the per-pixel fallback
     w.resolveVerts = take((uint64_t)p->resolveCapacity * sizeof(ResolveVertex));
     w.resolveTris = take((uint64_t)p->resolveCapacity * sizeof(ResolveTriangle));

@@ -178,6 +178,9 @@ template <typename M> BRMI_DEV m4 load_m4_any(const M* p) {     // p: float in t
 
 constexpr int RESOLVE_WATERFALL = 4;     // distinct mesh instances per 8x8 tile handled with scalar loads before falling back
 
+// INLINE_TABLES: the arena may be too small for the frame, keep the per-pixel table path (it doubles the register count, so
+// the host only picks this variant when the arena cannot hold every cluster the configuration allows).
+template <bool INLINE_TABLES>
 __global__ void __launch_bounds__(256) k_gbuffer(GBufferArgs a) {
     const brmi_scene_buffers& sc = a.sc;
     const brmi_per_frame* pf = sc.perFrame;
@@ -211,7 +214,8 @@ __global__ void __launch_bounds__(256) k_gbuffer(GBufferArgs a) {
                     const ResolveVertex v = a.verts[cs.vertBase + ((r.indices >> (8 * k)) & 0xFFu)];
                     p[k] = f3{v.px, v.py, v.pz}; n[k] = f3{v.nx, v.ny, v.nz};
                 }
-            } else resolve_tables_inline(a, cs, triId, r, p, n);
+            } else if (INLINE_TABLES) resolve_tables_inline(a, cs, triId, r, p, n);
+            else valid = false;      // cannot happen: the arena holds every cluster of this configuration
         }
         const float uvx = ((float)px + 0.5f) / winX, uvy = ((float)py + 0.5f) / winY;
         const float ndcX = uvx * 2.0f - 1.0f, ndcY = (1.0f - uvy) * 2.0f - 1.0f;
@@ -275,7 +279,8 @@ int launch_gbuffer(brmi_pass* p, hipStream_t s) {
     a.matWords = p->wsPtr<MaterialWords>(p->ws.matWords);
     hipLaunchKernelGGL(k_material_words, dim3((std::max(1u, p->scene.materialCount) + 63) / 64), dim3(64), 0, s, p->scene, a.matWords);
     hipLaunchKernelGGL(k_resolve_setup, dim3(4096), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(k_gbuffer, dim3(4096), dim3(256), 0, s, a);
+    if ((uint64_t)p->resolveCapacity >= (uint64_t)p->cfg.maxVisibleClusters * BRMI_MESHLET_MAX_TRIS) hipLaunchKernelGGL(k_gbuffer<false>, dim3(4096), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_gbuffer<true>, dim3(4096), dim3(256), 0, s, a);
     BRMI_LAUNCH_CHECK(p, "k_gbuffer");
     return BRMI_OK;
 }

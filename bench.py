@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md)
+PROFILE_TAG = {"sponza": "r01_sponza4k", "bistro": "r01_bistro4k"}   # profiles/<tag>_traffic.json (tools/profile.sh)
 DOMINANT_KERNEL = {"raster": "k_raster", "gbuffer": "k_gbuffer", "shade": "k_shade", "cull": "k_traverse+k_cull_clusters", "clear": "k_clear_vis",
                    "light_cluster": "k_light_clustering", "depth_copy": "k_depth_copy", "hzb": "k_hzb_head", "cull2": "k_traverse+k_cull_clusters", "raster2": "k_raster"}
 
@@ -113,6 +114,16 @@ def main():
         dom_s = stage_ms[dom] * 1e-3
         achieved = per_stage_bytes[dom] / dom_s / 1e9 if dom_s > 0 else 0.0
         frame_gbs = total_bytes / (dt / args.steps) / 1e9
+        # HBM-side bytes of the dominant kernel per launch, from the committed rocprofv3 --pmc passes of this same command
+        # (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE; tools/profile.sh).  null when no profile of this workload / kernel is committed.
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", PROFILE_TAG.get(args.workload, "") + "_traffic.json")))
+            kname = "k_shade<false>" if dom == "shade" else DOMINANT_KERNEL.get(dom, dom)
+            if n == 1 and kname in tj:
+                traffic = tj[kname]["hbm_bytes_per_launch"]
+        except (OSError, ValueError):
+            pass
         out = {
             "metric": "shaded Mpixels/s @4K (vis-buffer+resolve)", "value": round(value, 2), "unit": "Mpixels/s",
             "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -125,7 +136,7 @@ def main():
                        "occlusion_culling": bool(args.occlusion), "visible_clusters_phase2_rank0": int(c.visibleClustersPhase2),
                        "meshlets_tested_rank0": int(c.meshletsTested), "partition": f"row bands x{n}" if n > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": DOMINANT_KERNEL.get(dom, dom), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(per_stage_bytes[dom]), "launch_ms": round(stage_ms[dom], 4),
                          "whole_frame": {"algorithmic_bytes": int(total_bytes), "achieved_GBps": round(frame_gbs, 2), "frac": round(frame_gbs / HBM_PEAK_GBS, 5)}},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items() if v > 0},
