@@ -107,6 +107,16 @@ BRMI_STAGE_PASS(SoftwareRasterizeClustersPass1, "SoftwareRasterizeClustersPass1"
 // reference: PerViewLinearDepthCopyPass (BR/src/Render/GraphExtensions/ClusterLOD/PerViewLinearDepthCopyPass.cpp)
 BRMI_STAGE_PASS(LinearDepthCopyPass1, "LinearDepthCopyPass1", brmi_depth_copy(state->get(), ctx.commandList),
                 ({"Builtin::PrimaryCamera::VisibilityTexture"}), ({"Builtin::PrimaryCamera::LinearDepthMap"}))
+// reference: linear-depth downsample (FidelityFX SPD, BR/include/RenderPasses/FidelityFX/Downsample.h; scheduled at CLodExtension.cpp:1920-1949)
+BRMI_STAGE_PASS(LinearDepthDownsamplePass, "LinearDepthDownsamplePass", brmi_build_hzb(state->get(), ctx.commandList),
+                ({"Builtin::PrimaryCamera::LinearDepthMap"}), ({"Builtin::PrimaryCamera::LinearDepthMap(mips)"}))
+// reference: phase 2 of the occlusion chain (CLodExtension.cpp:2002-2088): replays what phase 1 found occluded
+BRMI_STAGE_PASS(HierarchicalCullingPass2, "HierarchicalCullingPass2", brmi_cull(state->get(), 2, ctx.commandList),
+                ({"Builtin::PrimaryCamera::LinearDepthMap(mips)", "Builtin::PerMeshInstanceBuffer", "Builtin::PerObjectBuffer", "Builtin::CameraBuffer", "brmi::Workspace"}),
+                ({"Builtin::CLod::VisibleClusters", "brmi::Workspace"}))
+BRMI_STAGE_PASS(SoftwareRasterizeClustersPass2, "SoftwareRasterizeClustersPass2", brmi_raster(state->get(), 2, ctx.commandList),
+                ({"Builtin::CLod::VisibleClusters", "Builtin::PerMeshInstanceBuffer", "Builtin::PerObjectBuffer", "Builtin::CullingCameraBuffer", "CLod page slabs"}),
+                ({"Builtin::PrimaryCamera::VisibilityTexture"}))
 // reference: MaterialHistogram .. EvaluateMaterialGroups (BR/include/RenderPasses/VisUtil/*.h; parameter list at EvaluateMaterialGroupsPass.h:68-111)
 BRMI_STAGE_PASS(EvaluateMaterialGroupsPass, "EvaluateMaterialGroupsPass", brmi_gbuffer(state->get(), ctx.commandList),
                 ({"Builtin::PrimaryCamera::VisibilityTexture", "Builtin::CLod::VisibleClusters", "Builtin::PerMaterialDataBuffer", "Builtin::PerMaterialOpenPBRDataBuffer",
@@ -128,15 +138,25 @@ BRMI_STAGE_PASS(DeferredShadingPass, "DeferredShadingPass", brmi_shade(state->ge
 // reference: CLodExtension (IRenderGraphExtension) -- returns the passes in the order the reference graph runs them
 class BrmiGraphExtension {
 public:
-    explicit BrmiGraphExtension(std::shared_ptr<PassState> st) : state_(std::move(st)) {}
-    // GatherStructuralPasses: cull/raster chain spliced before "MaterialHistogramPass" (CLodExtension.cpp:1704,1910)
+    explicit BrmiGraphExtension(std::shared_ptr<PassState> st, bool occlusionCulling = false) : state_(std::move(st)), occlusion_(occlusionCulling) {}
+    // GatherStructuralPasses: cull/raster chain spliced before "MaterialHistogramPass" (CLodExtension.cpp:1704,1910); with
+    // enableOcclusionCulling the depth copy / downsample / phase-2 passes follow phase 1 and the chain is rebuilt from the final
+    // depth for the next frame (CLodExtension.cpp:1920-2088)
     std::vector<std::shared_ptr<ComputePass>> GatherStructuralPasses() const {
-        return {std::make_shared<ClearVisibilityBufferPass>(state_), std::make_shared<HierarchicalCullingPass1>(state_),
-                std::make_shared<SoftwareRasterizeClustersPass1>(state_), std::make_shared<EvaluateMaterialGroupsPass>(state_),
-                std::make_shared<LightCullingPass>(state_), std::make_shared<DeferredShadingPass>(state_)};
+        std::vector<std::shared_ptr<ComputePass>> p{std::make_shared<ClearVisibilityBufferPass>(state_), std::make_shared<HierarchicalCullingPass1>(state_),
+                                                    std::make_shared<SoftwareRasterizeClustersPass1>(state_)};
+        if (occlusion_) {
+            p.push_back(std::make_shared<LinearDepthCopyPass1>(state_)); p.push_back(std::make_shared<LinearDepthDownsamplePass>(state_));
+            p.push_back(std::make_shared<HierarchicalCullingPass2>(state_)); p.push_back(std::make_shared<SoftwareRasterizeClustersPass2>(state_));
+        }
+        p.push_back(std::make_shared<EvaluateMaterialGroupsPass>(state_));
+        if (occlusion_) p.push_back(std::make_shared<LinearDepthDownsamplePass>(state_));
+        p.push_back(std::make_shared<LightCullingPass>(state_)); p.push_back(std::make_shared<DeferredShadingPass>(state_));
+        return p;
     }
 private:
     std::shared_ptr<PassState> state_;
+    bool occlusion_ = false;
 };
 
 }  // namespace brmi::host

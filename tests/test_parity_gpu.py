@@ -246,6 +246,24 @@ def test_cpp_host_passes_reproduce_the_python_frame(scenes):
         assert fnv(raw) == got[key], key
     r.close()
 
+    # occlusion culling: the reference graph's unfused pass sequence (depth copy, downsample, phase 2, downsample) through the
+    # stage entry points against brmi_execute's fused one, two frames of a Sponza-class scene
+    from basicrenderer_amd import Scene
+    out = subprocess.run([exe, "1", "640", "360", "8", "1", "2"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    got = json.loads(out.stdout.strip().splitlines()[-1])
+    assert got["passes"] == 11 and got["replayed"] > 0
+    r = VisibilityRenderer(Scene("sponza", 640, 360, point_lights=8), occlusion=True, max_clusters=1 << 16)
+    r.execute()
+    r.execute()
+    c = r.counters()
+    assert (got["visible_clusters"], got["visible_clusters_phase2"]) == (c.visibleClusters, c.visibleClustersPhase2)
+    r.torch.cuda.synchronize()
+    for key, rid in (("vis_fnv", "VISIBILITY"), ("hdr_fnv", "HDR_COLOR"), ("normals_fnv", "GBUF_NORMALS")):
+        raw = r.res[capi.RES[rid]].cpu().numpy()[: r.descs[capi.RES[rid]]["bytes"]]
+        assert fnv(raw) == got[key], key
+    r.close()
+
 
 # ---- 2-phase HZB occlusion culling -----------------------------------------------------------
 OCCLUSION_CASES = {
