@@ -170,6 +170,28 @@ def test_band_split_composes_to_full_frame(scenes, gpu_frames):
         r.close()
 
 
+def test_band_split_with_occlusion_culling_composes_to_full_frame():
+    """The multi-GPU bench default: row bands with 2-phase occlusion culling on, two frames (the second one tests against the
+    band's own depth chain; rows of other ranks read as empty).  Lit bytes of every band equal the full frame without occlusion."""
+    from basicrenderer_amd import Scene
+    from basicrenderer_amd.renderer import VisibilityRenderer
+    sc = Scene("bistro", 640, 360, point_lights=16, size_scale=0.3)
+    full = VisibilityRenderer(sc)
+    full.execute()
+    fh, n_full = full.hdr(), full.counters().visibleClusters
+    full.close()
+    for y0, y1 in ((0, 120), (120, 240), (240, 360)):
+        r = VisibilityRenderer(sc, band=(y0, y1), occlusion=True, stats=True)
+        r.execute()
+        assert np.array_equal(r.hdr()[y0:y1], fh[y0:y1]), "frame 0"
+        r.execute()
+        c = r.counters()
+        assert np.array_equal(r.hdr()[y0:y1], fh[y0:y1]), "frame 1"
+        assert c.visibleClusters + c.visibleClustersPhase2 < n_full
+        assert c.droppedRecords == 0 and c.droppedClusters == 0
+        r.close()
+
+
 def test_error_paths(scenes):
     from basicrenderer_amd import capi
     lib = capi.brmi_lib()
