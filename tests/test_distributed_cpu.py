@@ -31,6 +31,18 @@ def _worker(rank, world, port, W, H, out_path):
     f.cull(); f.raster(band=band); f.depth_copy(); f.gbuffer(band=band); f.light_cluster(); f.shade(band=band)
     surface = torch.from_numpy(tile(f.hdr).view(np.uint8).copy())
     composed = compose.compose_bands(surface, band, W, 8)
+    # the pipelined composer bench.py uses: three frames whose band content changes, every composed frame must be complete
+    live = surface.clone()
+    composer = compose.BandComposer(live, band, W, 8, depth=2)
+    lo, hi = compose.band_byte_range(band, W, 8)
+    for frame in range(3):
+        live[lo:hi] = surface[lo:hi] ^ frame                      # "render" frame k into the target
+        slot = composer.submit()
+        live[lo:hi] = 0xEE                                         # the next frame overwrites the target while the gather is in flight
+        composer.work[slot].wait()
+        want = compose.compose_bands(surface ^ frame, band, W, 8)
+        assert torch.equal(composer.out[slot], want), f"pipelined composition of frame {frame}"
+    assert torch.equal(composer.finish(), compose.compose_bands(surface ^ 2, band, W, 8))
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)                      # the max-over-ranks timing reduction of bench.py
     assert t.item() == world
