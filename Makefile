@@ -13,7 +13,7 @@ EXTRA     ?=
 HIPFLAGS  := $(EXTRA) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math \
              -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero -Iinclude -Wall
 ORCFLAGS  := -O2 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -fopenmp -Iinclude -Wall
-SCNFLAGS  := -O2 -std=c++17 -fPIC -shared -Iinclude -Wall
+SCNFLAGS  := -O2 -std=c++17 -fPIC -shared -Iinclude -Wall -ldl
 
 HIP_SRCS  := $(wildcard basicrenderer_amd/csrc/*.hip)
 HIP_HDRS  := $(wildcard basicrenderer_amd/csrc/*.h) $(wildcard include/*.h)

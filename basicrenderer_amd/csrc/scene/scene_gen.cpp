@@ -22,6 +22,8 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <dlfcn.h>
+#include <string>
 #include <vector>
 
 namespace {
@@ -176,9 +178,12 @@ struct MeshletBuild {
     int32_t  refinedGroup;        // mesh-local, -1 terminal
     std::vector<float> pos;       // 81*3
     std::vector<uint32_t> nrm;    // 81
-    std::vector<uint32_t> joints; // 81*8 (skinned only)
-    std::vector<float> weights;   // 81*8
+    std::vector<uint32_t> joints; // V*8 (skinned only)
+    std::vector<float> weights;   // V*8
+    std::vector<uint8_t> tris;    // 3 local indices per triangle; empty = the implicit 8x8-quad grid over 9x9 vertices
     Sphere bounds;
+    uint32_t vertCount() const { return (uint32_t)nrm.size(); }
+    uint32_t triCount() const { return tris.empty() ? 128u : (uint32_t)(tris.size() / 3); }
 };
 struct GroupBuild {
     uint32_t level, patch, gi, gj;
@@ -215,6 +220,8 @@ struct brmi_scene {
     std::vector<float> skinningMatrices;
     std::vector<uint16_t> lutOdE, lutOdAvg, lutImE, lutImAvg; std::vector<float> lutLtc;
     brmi_scene_stats stats{};
+    std::vector<uint64_t> meshLod0Triangles;        // per mesh: triangles of its finest level
+    bool failed = false;                            // a mesh could not be built (reference LOD builder missing)
     // page tile allocator
     uint32_t curSlab = 0; uint32_t curSlabPages = 0;
     static constexpr uint32_t kPagesPerSlab = 1024;   // 10-bit page index in the packed cluster
@@ -244,7 +251,7 @@ inline size_t align4(size_t v) { return (v + 3u) & ~size_t(3); }
 std::vector<uint8_t> buildPageBlob(const std::vector<const MeshletBuild*>& ms, bool skinned) {
     const uint32_t M = (uint32_t)ms.size();
     uint32_t totalVerts = 0, totalTris = 0;
-    for (auto* m : ms) { totalVerts += (uint32_t)m->nrm.size(); totalTris += 128; }
+    for (auto* m : ms) { totalVerts += m->vertCount(); totalTris += m->triCount(); }
     brmi_page_header h{};
     h.meshletCount = M;
     h.compressedPositionQuantExp = BRMI_POSITION_FORMAT_FLOAT3;
@@ -282,7 +289,7 @@ std::vector<uint8_t> buildPageBlob(const std::vector<const MeshletBuild*>& ms, b
         d.triangleByteOffset = triCursor;
         d.boneListOffset = boneCursor;
         d.bitsAndVertexCount = V << 24;
-        d.triangleCountAndRefinedGroup = 128u | ((uint32_t)(m.refinedGroup + 1) << 16);
+        d.triangleCountAndRefinedGroup = m.triCount() | ((uint32_t)(m.refinedGroup + 1) << 16);
         d.boneCount = skinned ? 4u : 0u;
         d.sourceGroupLocalIndex = m.group;
         d.bounds[0] = (float)m.bounds.c.x; d.bounds[1] = (float)m.bounds.c.y; d.bounds[2] = (float)m.bounds.c.z; d.bounds[3] = (float)m.bounds.r;
@@ -296,26 +303,25 @@ std::vector<uint8_t> buildPageBlob(const std::vector<const MeshletBuild*>& ms, b
             std::memcpy(blob.data() + h.boneIndexStreamOffset + (size_t)boneCursor * 4, bones, 16);
             boneCursor += 4;
         }
-        // 8x8 quads over a 9x9 vertex grid, two CCW triangles per quad (front = +normal side)
+        // 8x8 quads over a 9x9 vertex grid, two CCW triangles per quad (front = +normal side); or the meshlet's own triangle list
         uint8_t* tri = blob.data() + h.triangleStreamOffset + triCursor;
-        for (uint32_t qj = 0; qj < 8; qj++) for (uint32_t qi = 0; qi < 8; qi++) {
+        if (!m.tris.empty()) std::memcpy(tri, m.tris.data(), m.tris.size());
+        else for (uint32_t qj = 0; qj < 8; qj++) for (uint32_t qi = 0; qi < 8; qi++) {
             uint8_t a = (uint8_t)(qj * 9 + qi), b = (uint8_t)(a + 1), c = (uint8_t)(a + 10), dd = (uint8_t)(a + 9);
             // alternate the diagonal so neighbouring quads do not all share one direction
             if (((qi + qj) & 1u) == 0) { *tri++ = a; *tri++ = b; *tri++ = c; *tri++ = a; *tri++ = c; *tri++ = dd; }
             else                        { *tri++ = a; *tri++ = b; *tri++ = dd; *tri++ = b; *tri++ = c; *tri++ = dd; }
         }
-        posCursor += V * 12; attrCursor += V; triCursor += 128 * 3;
+        posCursor += V * 12; attrCursor += V; triCursor += m.triCount() * 3;
     }
     return blob;
 }
 
-size_t meshletPageBytes(bool skinned) { return 64 + 81 * 12 + 81 * 4 + 384 + (skinned ? 81 * 64 + 16 : 0); }
+size_t meshletPageBytes(const MeshletBuild& m, bool skinned) { return 64 + (size_t)m.vertCount() * 16 + (size_t)m.triCount() * 3 + 4 + (skinned ? (size_t)m.vertCount() * 64 + 16 : 0); }
 
-// Build one mesh: fills scene-global arrays, returns mesh metadata index.
-void buildMesh(brmi_scene& sc, const MeshDef& def, uint32_t meshIndex) {
+// Built-in LOD DAG: a quadtree over the patch grids (level-L meshlets are 8x8 quads with stride 2^L, groups are 4x4 meshlets).
+uint32_t buildQuadtreeDag(const MeshDef& def, std::vector<MeshletBuild>& meshlets, std::vector<GroupBuild>& groups) {
     const uint32_t levels = std::max(1u, std::min(def.lodLevels, 7u));
-    std::vector<MeshletBuild> meshlets;
-    std::vector<GroupBuild> groups;
     // (level, patch) -> first group id and group-grid dims
     struct LevelPatch { uint32_t firstGroup, gw, gh, firstMeshlet, mw, mh; };
     std::vector<std::vector<LevelPatch>> lp(levels, std::vector<LevelPatch>(def.patches.size()));
@@ -416,6 +422,126 @@ void buildMesh(brmi_scene& sc, const MeshDef& def, uint32_t meshIndex) {
         }
     }
     for (auto& g : groups) g.maxParentError = (g.parent >= 0) ? groups[g.parent].error : (double)FLT_MAX;
+    return levels;
+}
+
+// ---- the reference's own LOD builder (oracle/_ref/libclodref.so: meshoptimizer 1.0 + the reference's clusterlod.h) ------------
+struct ClodGroupOut { int32_t depth; float center[3], radius, error; uint32_t firstCluster, clusterCount; };
+struct ClodClusterOut { int32_t group, refined; float center[3], radius, error; uint32_t vertexCount, triangleCount, firstVertex, firstTriangleByte; };
+struct ClodRefApi {
+    void* handle = nullptr;
+    void* (*build)(const float*, size_t, const uint32_t*, size_t, const float*) = nullptr;
+    void (*counts)(const void*, uint32_t*, uint32_t*, uint32_t*, uint32_t*) = nullptr;
+    void (*copy)(const void*, void*, void*, uint32_t*, uint8_t*) = nullptr;
+    void (*release)(void*) = nullptr;
+};
+ClodRefApi* clodRef() {
+    static ClodRefApi api; static bool tried = false;
+    if (tried) return api.handle ? &api : nullptr;
+    tried = true;
+    std::string path;
+    if (const char* e = std::getenv("BRMI_CLODREF_LIB")) path = e;
+    else {
+        Dl_info info{};
+        if (dladdr((void*)&clodRef, &info) && info.dli_fname) {      // <repo>/basicrenderer_amd/lib/libbrmi_scene.so -> <repo>/oracle/_ref/libclodref.so
+            path = info.dli_fname;
+            for (int up = 0; up < 3; up++) { const size_t k = path.find_last_of('/'); if (k == std::string::npos) break; path.resize(k); }
+            path += "/oracle/_ref/libclodref.so";
+        }
+    }
+    api.handle = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!api.handle) { std::fprintf(stderr, "brmi_scene: cannot load the reference LOD builder (%s): %s\n", path.c_str(), dlerror()); return nullptr; }
+    api.build = (decltype(api.build))dlsym(api.handle, "clodref_build"); api.counts = (decltype(api.counts))dlsym(api.handle, "clodref_counts");
+    api.copy = (decltype(api.copy))dlsym(api.handle, "clodref_copy"); api.release = (decltype(api.release))dlsym(api.handle, "clodref_free");
+    if (!api.build || !api.counts || !api.copy || !api.release) { api.handle = nullptr; return nullptr; }
+    return &api;
+}
+
+// LOD DAG from clodBuild: the patches are tessellated at their LOD0 resolution into one indexed mesh, the reference's builder
+// clusters / groups / simplifies it, and its output is mapped onto the build records:
+//   group  -> LOD group: bounds and error of `clodGroup::simplified` (the test "is this group's simplification too coarse", rule 1,
+//             and through `refined` rule 2 of clusterlod.h)
+//   cluster -> meshlet with its own vertex / triangle counts, `refined` = refinedGroup
+// Returns the number of DAG depths, 0 on failure.
+uint32_t buildClusterLodDag(const MeshDef& def, std::vector<MeshletBuild>& meshlets, std::vector<GroupBuild>& groups) {
+    ClodRefApi* api = clodRef();
+    if (!api) return 0;
+    std::vector<float> pos, nrm; std::vector<uint32_t> idx;
+    for (const PatchDef& p : def.patches) {
+        const uint32_t NU = p.nu0 * 8, NV = p.nv0 * 8, base = (uint32_t)(pos.size() / 3);
+        for (uint32_t j = 0; j <= NV; j++) for (uint32_t i = 0; i <= NU; i++) {
+            const double u = (double)i / NU, v = (double)j / NV;
+            const V3 P = evalPatch(p, u, v);
+            const double hu = 0.25 / NU, hv = 0.25 / NV;
+            const V3 n = normalize(cross(evalPatch(p, u + hu, v) - evalPatch(p, u - hu, v), evalPatch(p, u, v + hv) - evalPatch(p, u, v - hv)));
+            pos.push_back((float)P.x); pos.push_back((float)P.y); pos.push_back((float)P.z);
+            nrm.push_back((float)n.x); nrm.push_back((float)n.y); nrm.push_back((float)n.z);
+        }
+        for (uint32_t qj = 0; qj < NV; qj++) for (uint32_t qi = 0; qi < NU; qi++) {
+            const uint32_t a = base + qj * (NU + 1) + qi, b = a + 1, c = a + NU + 2, d = a + NU + 1;
+            if (((qi + qj) & 1u) == 0) { idx.insert(idx.end(), {a, b, c, a, c, d}); } else { idx.insert(idx.end(), {a, b, d, b, c, d}); }
+        }
+    }
+    void* res = api->build(pos.data(), pos.size() / 3, idx.data(), idx.size(), nrm.data());
+    if (!res) return 0;
+    uint32_t nG = 0, nC = 0, nV = 0, nT = 0;
+    api->counts(res, &nG, &nC, &nV, &nT);
+    std::vector<ClodGroupOut> g(nG); std::vector<ClodClusterOut> c(nC); std::vector<uint32_t> vref(nV); std::vector<uint8_t> tri(nT);
+    api->copy(res, g.data(), c.data(), vref.data(), tri.data());
+    api->release(res);
+    uint32_t levels = 1;
+    groups.resize(nG);
+    for (uint32_t gi = 0; gi < nG; gi++) {
+        GroupBuild& o = groups[gi];
+        o.level = (uint32_t)std::max(0, g[gi].depth); o.patch = 0; o.gi = gi; o.gj = 0;
+        o.bounds = {V3{g[gi].center[0], g[gi].center[1], g[gi].center[2]}, (double)g[gi].radius};
+        o.maxParentError = g[gi].error >= FLT_MAX ? (double)FLT_MAX : (double)g[gi].error;
+        o.error = 0; o.parent = -1;
+        levels = std::max(levels, o.level + 1);
+    }
+    meshlets.reserve(nC);
+    for (uint32_t ci = 0; ci < nC; ci++) {
+        const ClodClusterOut& k = c[ci];
+        MeshletBuild m{};
+        m.level = groups[k.group].level; m.patch = 0; m.mi = ci; m.mj = 0; m.group = (uint32_t)k.group; m.refinedGroup = k.refined;
+        const uint32_t V = k.vertexCount, T = k.triangleCount;
+        m.pos.resize((size_t)V * 3); m.nrm.resize(V);
+        V3 lo{1e30, 1e30, 1e30}, hi{-1e30, -1e30, -1e30};
+        for (uint32_t v = 0; v < V; v++) {
+            const uint32_t src = vref[k.firstVertex + v];
+            for (int q = 0; q < 3; q++) m.pos[v * 3 + q] = pos[(size_t)src * 3 + q];
+            m.nrm[v] = octEncode(V3{nrm[(size_t)src * 3], nrm[(size_t)src * 3 + 1], nrm[(size_t)src * 3 + 2]});
+            lo = {std::min(lo.x, (double)m.pos[v * 3]), std::min(lo.y, (double)m.pos[v * 3 + 1]), std::min(lo.z, (double)m.pos[v * 3 + 2])};
+            hi = {std::max(hi.x, (double)m.pos[v * 3]), std::max(hi.y, (double)m.pos[v * 3 + 1]), std::max(hi.z, (double)m.pos[v * 3 + 2])};
+        }
+        m.tris.assign(tri.begin() + k.firstTriangleByte, tri.begin() + k.firstTriangleByte + (size_t)T * 3);
+        // the builder's sphere (optimize_bounds), widened if float rounding left a vertex outside
+        const V3 cc{k.center[0], k.center[1], k.center[2]};
+        double r = k.radius;
+        for (uint32_t v = 0; v < V; v++) r = std::max(r, length(V3{m.pos[v * 3], m.pos[v * 3 + 1], m.pos[v * 3 + 2]} - cc));
+        m.bounds = {cc, r * (1.0 + 1e-5) + 1e-7};
+        if (def.skinned) {
+            m.joints.assign((size_t)V * 8, 0); m.weights.assign((size_t)V * 8, 0.0f);
+            for (uint32_t v = 0; v < V; v++) {
+                float t = std::min(1.0f, std::max(0.0f, (m.pos[v * 3 + 1] - (float)lo.y) / (float)std::max(1e-6, hi.y - lo.y)));
+                float w[4] = {(1 - t) * (1 - t), 2 * t * (1 - t) * 0.5f, 2 * t * (1 - t) * 0.5f, t * t};
+                for (int q = 0; q < 4; q++) { m.joints[(size_t)v * 8 + q] = (uint32_t)q; m.weights[(size_t)v * 8 + q] = w[q]; }
+            }
+        }
+        groups[k.group].meshlets.push_back((uint32_t)meshlets.size());
+        groups[k.group].error = std::max(groups[k.group].error, (double)k.error);
+        if (k.refined >= 0 && groups[k.refined].parent < 0) groups[k.refined].parent = k.group;
+        meshlets.push_back(std::move(m));
+    }
+    return levels;
+}
+
+// Build one mesh: LOD DAG (built-in quadtree or the reference's builder), then segments, pages, groups and the 8-wide BVH.
+bool buildMesh(brmi_scene& sc, const MeshDef& def, uint32_t meshIndex) {
+    std::vector<MeshletBuild> meshlets;
+    std::vector<GroupBuild> groups;
+    const uint32_t levels = sc.params.lodBuilder == BRMI_LOD_BUILDER_CLUSTERLOD ? buildClusterLodDag(def, meshlets, groups) : buildQuadtreeDag(def, meshlets, groups);
+    if (levels == 0) { sc.failed = true; return false; }
 
     // segments: partition each group's meshlets by refinedGroup (stable)
     std::vector<SegmentBuild> segs;
@@ -425,11 +551,16 @@ void buildMesh(brmi_scene& sc, const MeshDef& def, uint32_t meshIndex) {
         std::vector<int32_t> keys;
         for (uint32_t mi : g.meshlets) if (std::find(keys.begin(), keys.end(), meshlets[mi].refinedGroup) == keys.end()) keys.push_back(meshlets[mi].refinedGroup);
         for (int32_t k : keys) {
+            // one segment per (group, refined group); a segment that would not fit a 256 KB page is cut into several
             SegmentBuild s{}; s.group = (uint32_t)gi; s.refinedGroup = k;
-            std::vector<Sphere> parts;
-            for (uint32_t mi : g.meshlets) if (meshlets[mi].refinedGroup == k) { s.meshlets.push_back(mi); parts.push_back(meshlets[mi].bounds); }
-            s.cull = enclose(parts);
-            segs.push_back(std::move(s));
+            std::vector<Sphere> parts; size_t bytes = 0;
+            auto close = [&]() { if (s.meshlets.empty()) return; s.cull = enclose(parts); segs.push_back(s); s.meshlets.clear(); parts.clear(); bytes = 0; };
+            for (uint32_t mi : g.meshlets) if (meshlets[mi].refinedGroup == k) {
+                const size_t need = meshletPageBytes(meshlets[mi], def.skinned);
+                if (bytes + need + 256 > BRMI_PAGE_SIZE) close();
+                s.meshlets.push_back(mi); parts.push_back(meshlets[mi].bounds); bytes += need;
+            }
+            close();
         }
         g.segmentCount = (uint32_t)segs.size() - g.firstSegment;
     }
@@ -447,7 +578,7 @@ void buildMesh(brmi_scene& sc, const MeshDef& def, uint32_t meshIndex) {
             cur.clear(); curSegs.clear(); bytes = 64;
         };
         for (size_t si = 0; si < segs.size(); si++) {
-            size_t need = segs[si].meshlets.size() * meshletPageBytes(def.skinned) + 64;
+            size_t need = 64; for (uint32_t mi : segs[si].meshlets) need += meshletPageBytes(meshlets[mi], def.skinned);
             if (bytes + need > BRMI_PAGE_SIZE) flush();
             segs[si].pageIndex = (uint32_t)(sc.pageMap.size() - pageMapBase);
             segs[si].firstMeshletInPage = (uint32_t)cur.size();
@@ -557,15 +688,18 @@ void buildMesh(brmi_scene& sc, const MeshDef& def, uint32_t meshIndex) {
     pm.vertexByteSize = 24;
     pm.boundingSphere[0] = bn[0].n.cullCenterAndRadius[0]; pm.boundingSphere[1] = bn[0].n.cullCenterAndRadius[1];
     pm.boundingSphere[2] = bn[0].n.cullCenterAndRadius[2]; pm.boundingSphere[3] = bn[0].n.cullCenterAndRadius[3];
-    uint32_t lod0 = 0; for (auto& m : meshlets) lod0 += (m.level == 0);
-    pm.clodNumMeshlets = (uint32_t)meshlets.size(); pm.numMeshlets = lod0; pm.numVertices = lod0 * 81;
+    uint32_t lod0 = 0, lod0Verts = 0; uint64_t lod0Tris = 0;
+    for (auto& m : meshlets) if (m.level == 0) { lod0++; lod0Verts += m.vertCount(); lod0Tris += m.triCount(); }
+    pm.clodNumMeshlets = (uint32_t)meshlets.size(); pm.numMeshlets = lod0; pm.numVertices = lod0Verts;
     sc.perMesh.push_back(pm);
+    sc.meshLod0Triangles.push_back(lod0Tris);
 
     sc.stats.meshletsTotal += (uint32_t)meshlets.size(); sc.stats.meshletsLod0 += lod0;
-    sc.stats.uniqueTriangles += (uint64_t)lod0 * 128;
+    sc.stats.uniqueTriangles += lod0Tris;
     sc.stats.maxBvhDepth = std::max(sc.stats.maxBvhDepth, maxTreeDepth);
     sc.stats.lodLevelsMax = std::max(sc.stats.lodLevelsMax, levels);
     (void)meshIndex;
+    return true;
 }
 
 void addInstance(brmi_scene& sc, const InstanceDef& inst) {
@@ -585,7 +719,7 @@ void addInstance(brmi_scene& sc, const InstanceDef& inst) {
     sc.perMeshInstance.push_back(mi);
     sc.clodOffsets.push_back({inst.mesh});
     sc.perObject.push_back(o);
-    sc.stats.instancedTriangles += (uint64_t)sc.perMesh[inst.mesh].numMeshlets * 128;
+    sc.stats.instancedTriangles += sc.meshLod0Triangles[inst.mesh];
     // scene bounds
     const float* bs = sc.perMesh[inst.mesh].boundingSphere;
     V3 c = xformPoint({bs[0], bs[1], bs[2]}, inst.model);
@@ -988,6 +1122,7 @@ brmi_scene* brmi_scene_create(const brmi_scene_params* params) {
     brmi_scene* sc = new brmi_scene();
     sc->params = *params;
     if (sc->params.sizeScale <= 0.0f) sc->params.sizeScale = 1.0f;
+    if (sc->params.lodBuilder == BRMI_LOD_BUILDER_CLUSTERLOD && !clodRef()) { delete sc; return nullptr; }
     for (int k = 0; k < 3; k++) { sc->stats.sceneMin[k] = 1e30f; sc->stats.sceneMax[k] = -1e30f; }
     Pcg32 rng(0xB451C0DEull + params->seed, 54u + params->preset);
     switch (params->preset) {
@@ -998,6 +1133,7 @@ brmi_scene* brmi_scene_create(const brmi_scene_params* params) {
         case BRMI_PRESET_ZORAH: presetZorah(*sc, rng); break;
         default: delete sc; return nullptr;
     }
+    if (sc->failed) { delete sc; return nullptr; }
     buildLuts(*sc);
     finishFrame(*sc);
     return sc;

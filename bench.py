@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--workload", default="sponza", choices=["sponza", "bistro", "san_miguel"])
     ap.add_argument("--occlusion", type=int, default=1, choices=[0, 1],
                     help="2-phase HZB occlusion culling (reference default: on, BR/include/Renderer.h:220); timed frames are steady state")
+    ap.add_argument("--lod-builder", default="quadtree", choices=["quadtree", "clusterlod"],
+                    help="clusterlod: mesh LOD DAGs from the reference's own builder (oracle/_ref/libclodref.so) instead of the generator's quadtree")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scale", type=float, default=1.0, help="fraction of the frame height the CPU baseline renders")
     args = ap.parse_args()
@@ -63,7 +65,7 @@ def main():
     lights = {"sponza": 64, "bistro": 256, "san_miguel": 256}[args.workload]
     W, H = compose.frame_size(n)
     band = compose.band_of(rank, n, H)
-    scene = Scene(args.workload, W, H, point_lights=lights, directional=True)
+    scene = Scene(args.workload, W, H, point_lights=lights, directional=True, lod_builder=args.lod_builder)
     r = VisibilityRenderer(scene, device=dev, stats=True, band=band, occlusion=bool(args.occlusion))
 
     hdr = r.hdr_tensor()
@@ -134,6 +136,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}-class procedural frame, {W}x{H}, 1 directional + {lights} point lights, "
                                    f"{scene.stats['instancedTriangles']} instanced tris, {scene.stats['instances']} instances"
+                                   + (", LOD DAG built by the reference's clusterlod.h" if args.lod_builder == "clusterlod" else "")
                                    + (f", {n} row bands of 1080 rows + RCCL all-gather of HDR (pipelined one frame deep)" if n > 1 else ""),
                        "baseline_config": "configs[1]" if args.workload == "sponza" else "configs[2]",
                        "pixels_per_gpu": W * (band[1] - band[0]), "visible_clusters_rank0": int(c.visibleClusters),

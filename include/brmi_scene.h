@@ -27,6 +27,12 @@ enum brmi_scene_preset {
     BRMI_PRESET_ZORAH       = 4   /* massive instancing + deep LOD */
 };
 
+/* Who builds the cluster-LOD DAG of every mesh.  QUADTREE: the generator's own regular DAG (81-vertex / 128-triangle grid
+ * meshlets).  CLUSTERLOD: the reference's builder -- vendored meshoptimizer + the reference's clusterlod.h, compiled from the
+ * reference checkout into oracle/_ref/libclodref.so (oracle/ref/Makefile) and loaded at run time (BRMI_CLODREF_LIB overrides the
+ * path); meshlets then have irregular vertex / triangle counts and groups of up to ~512 clusters, like the reference's assets. */
+enum brmi_lod_builder { BRMI_LOD_BUILDER_QUADTREE = 0, BRMI_LOD_BUILDER_CLUSTERLOD = 1 };
+
 typedef struct brmi_scene_params {
     uint32_t preset;
     uint32_t seed;
@@ -38,7 +44,8 @@ typedef struct brmi_scene_params {
     uint32_t skinnedFraction1024; /* fraction (x/1024) of instances that are skinned; 0 = none */
     uint32_t materialFeatures;    /* bit 0: some materials carry an OpenPBR coat, bit 1: some carry fuzz (default: neither) */
     uint32_t cameraStep;          /* frame number on the preset's camera path (0 = start); prevView is the view of step - 1 */
-    uint32_t reserved[5];
+    uint32_t lodBuilder;          /* enum brmi_lod_builder */
+    uint32_t reserved[4];
 } brmi_scene_params;
 
 /* Arrays a scene exposes.  Element layouts are the brmi_types.h structs. */

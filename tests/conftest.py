@@ -19,7 +19,16 @@ def _built():
     need = [os.path.join(ROOT, "basicrenderer_amd", "lib", "libbrmi_scene.so"), os.path.join(ROOT, "oracle", "_build", "liboracle.so")]
     if not all(os.path.exists(p) for p in need):
         subprocess.check_call(["make", "-C", ROOT, "scene", "oracle"], stdout=subprocess.DEVNULL)
+    # the reference's LOD builder is compiled from the reference checkout where that exists (this container); the built
+    # library travels to the GPU box with the snapshot
+    ref = os.path.join(ROOT, "oracle", "_ref", "libclodref.so")
+    if not os.path.exists(ref) and os.path.isdir("/root/reference"):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle", "ref")], stdout=subprocess.DEVNULL)
     yield
+
+
+def have_clodref():
+    return os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libclodref.so"))
 
 
 SCENE_CASES = {
@@ -33,6 +42,10 @@ SCENE_CASES = {
     # compute skinning: bone-merged meshlet bounds in the cull, skinned vertices in raster and resolve
     "tiny_skinned": ("tiny", 256, 144, dict(point_lights=4, skinned_fraction=1.0, lod_levels=2)),
     "bistro_skinned": ("bistro", 640, 360, dict(point_lights=32, size_scale=0.3, skinned_fraction=0.3)),
+    # LOD DAG from the reference's own builder (meshoptimizer + clusterlod.h, oracle/_ref): irregular meshlets, ~400-cluster groups
+    "tiny_clod": ("tiny", 256, 144, dict(point_lights=4, lod_builder="clusterlod")),
+    "sponza_clod": ("sponza", 640, 360, dict(point_lights=32, size_scale=0.25, lod_builder="clusterlod")),
+    "bistro_clod_skinned": ("bistro", 640, 360, dict(point_lights=32, size_scale=0.3, skinned_fraction=0.3, lod_builder="clusterlod")),
 }
 
 

@@ -142,10 +142,15 @@ def test_half_and_unorm_conversions_match_numpy():
     assert np.array_equal(q, (np.clip(u, 0, 1) * np.float32(255) + np.float32(0.5)).astype(np.uint32))
 
 
-def test_lod_cut_never_draws_a_group_and_its_refinement(scenes):
-    """The two-condition LOD cut: a visible cluster that refines group r excludes every cluster of group r (same instance)."""
+@pytest.mark.parametrize("case", ["bistro_small", "sponza_clod"])
+def test_lod_cut_never_draws_a_group_and_its_refinement(case, scenes):
+    """The two-condition LOD cut: a visible cluster that refines group r excludes every cluster of group r (same instance).
+    `sponza_clod`: the DAG comes from the reference's own builder (clusterlod.h rules 1 and 2)."""
     import orc
-    sc = scenes("bistro_small")
+    from conftest import have_clodref
+    if case.endswith("_clod") and not have_clodref():
+        pytest.skip("oracle/_ref/libclodref.so not built (needs the reference checkout)")
+    sc = scenes(case)
     f = orc.OracleFrame(sc)
     cl = f.cull()
     assert f.count > 0 and sc.stats["lodLevelsMax"] > 1
@@ -172,6 +177,39 @@ def test_lod_cut_never_draws_a_group_and_its_refinement(scenes):
         if refined >= 0:
             assert (i, refined) not in visible, "a cluster and the group it was simplified from are both visible"
     assert len(depths) > 1, "the test scene should exercise more than one LOD depth"
+
+
+def test_reference_lod_builder_output_is_well_formed_and_covers_the_surface(scenes):
+    """Meshes built by the reference's clodBuild (oracle/_ref): meshlets within the 128 / 128 limits, local indices in range,
+    and the finest cut (depth 0) tiles the same triangle count the tessellation produced; the rendered coverage of the scene is
+    the same as with the built-in quadtree DAG up to LOD error."""
+    import orc
+    from conftest import have_clodref
+    from basicrenderer_amd import Scene
+    if not have_clodref():
+        pytest.skip("oracle/_ref/libclodref.so not built (needs the reference checkout)")
+    sc = scenes("sponza_clod")
+    lod0_tris = 0
+    for slab in sc.slabs[1:]:
+        for page in range(0, len(slab), 1 << 18):
+            hdr = slab[page:page + 64].view(np.uint32)
+            n = int(hdr[0])
+            for lm in range(n):
+                d = slab[page + hdr[4] + lm * 64: page + hdr[4] + lm * 64 + 64].view(np.uint32)
+                V, T = int(d[7] >> 24), int(d[8] & 0xFFFF)
+                assert 3 <= V <= 128 and 1 <= T <= 128
+                tri = slab[page + hdr[12] + int(d[2]): page + hdr[12] + int(d[2]) + 3 * T]
+                assert tri.max() < V
+                if int(d[8] >> 16) == 0:
+                    lod0_tris += T
+    # sponza at size_scale 0.25: every patch is tessellated into 2 * (8 nu) * (8 nv) triangles
+    assert lod0_tris == sc.stats["uniqueTriangles"] and lod0_tris > 10000
+    a = orc.OracleFrame(sc)
+    a.cull(); a.raster()
+    b = orc.OracleFrame(Scene("sponza", 640, 360, point_lights=32, size_scale=0.25))
+    b.cull(); b.raster()
+    ca, cb = a.vis != EMPTY, b.vis != EMPTY
+    assert (ca != cb).mean() < 0.002          # same silhouettes
 
 
 def test_frustum_culls_the_instance_behind_the_camera(scenes):
