@@ -103,6 +103,7 @@ static void compute_sizes(brmi_pass* p) {
     p->binsX = (c.width + 255) / 256; p->binsY = (c.height + 15) / 16;
     w.binCounts = take((uint64_t)p->binsX * p->binsY * 4);
     w.binRecords = take((uint64_t)p->binsX * p->binsY * p->binCapacity * 64);
+    w.binOverflow = take((uint64_t)CNT_STRIPE_COUNT * p->binOverflowPerStripe * 64);
     w.clusterSetup = take((uint64_t)c.maxVisibleClusters * sizeof(ClusterSetup));
     // resolve arena: full tables (72 B per vertex + triangle slot) for up to 2^20 clusters = 9.7 GB of the 288; a configuration
     // that allows more visible clusters keeps the per-pixel path for the clusters that do not fit
@@ -173,6 +174,7 @@ int brmi_create(const brmi_config* cfg, brmi_pass** out) {
     if (const char* e = std::getenv("BRMI_CULL_LEVEL_KERNELS")) p->forceLevelKernels = std::atoi(e) != 0;
     if (const char* e = std::getenv("BRMI_RASTER_GRID")) p->rasterGrid = (uint32_t)std::max(64, std::atoi(e));
     if (const char* e = std::getenv("BRMI_RASTER_DEBUG")) p->rasterDebug = std::atoi(e);
+    if (const char* e = std::getenv("BRMI_BIN_OVERFLOW")) p->binOverflowPerStripe = (uint32_t)std::max(0, std::atoi(e));
     if (const char* e = std::getenv("BRMI_BIN_CAPACITY")) p->binCapacity = (uint32_t)std::max(1, std::atoi(e));
     if (const char* e = std::getenv("BRMI_BIG_TRI_AREA")) p->bigTriArea = std::max(1, std::atoi(e));
     compute_sizes(p);
@@ -421,14 +423,16 @@ int brmi_read_counters(brmi_pass* p, brmi_counters* out, brmi_stream stream) {
     std::memset(out, 0, sizeof(*out));
     out->instancesTested = c[CNT_INSTANCES_TESTED]; out->instancesVisible = c[CNT_INSTANCES_VISIBLE];
     out->nodesVisited = c[CNT_NODES_VISITED];
+    uint32_t overflowQueued = 0;
     for (uint32_t st = 0; st < CNT_STRIPE_COUNT; st++) {
         const uint32_t* sp = c + CNT_STRIPES + st * CNT_STRIPE_WORDS;
         out->instancesTested += sp[0]; out->instancesVisible += sp[1]; out->nodesVisited += sp[2];
+        overflowQueued += sp[STRIPE_OVERFLOW];
     } out->bucketRecords = c[CNT_BUCKETS]; out->meshletsTested = c[CNT_MESHLETS_TESTED];
     out->visibleClusters = c[CNT_VISIBLE]; out->visibleClustersPhase2 = c[CNT_VISIBLE2];
     out->droppedRecords = c[CNT_DROPPED_RECORDS]; out->droppedClusters = c[CNT_DROPPED_CLUSTERS]; out->lightPagesUsed = c[CNT_LIGHT_PAGES];
     out->reserved[0] = c[CNT_SUM_VERTS_LO]; out->reserved[1] = c[CNT_SUM_VERTS_HI]; out->reserved[2] = c[CNT_SUM_TRIS_LO]; out->reserved[3] = c[CNT_SUM_TRIS_HI];
-    out->reserved[4] = c[CNT_RASTER_CLUSTERS]; out->reserved[5] = c[CNT_BIN_OVERFLOW];
+    out->reserved[4] = c[CNT_RASTER_CLUSTERS]; out->reserved[5] = c[CNT_BIN_OVERFLOW] + overflowQueued;
     out->replayNodes = c[CNT_REPLAY_NODES]; out->replayMeshlets = c[CNT_REPLAY_MESHLETS];
     return BRMI_OK;
 }

@@ -821,6 +821,11 @@ __global__ void k_seed_phase2(uint32_t* counters, uint32_t capacity) {
     const uint32_t t = threadIdx.x;
     if (t == 0) { counters[CNT_REPLAY_NODES] = min(counters[CNT_REPLAY_NODES], capacity); counters[CNT_BUCKETS] = min(counters[CNT_REPLAY_MESHLETS], capacity); counters[CNT_TEMP_VISIBLE2] = 0; counters[CNT_VISIBLE2] = 0; }
     if (t < CNT_STRIPES - CNT_FRONTIER0) counters[CNT_FRONTIER0 + t] = 0;
+    if (t < CNT_STRIPE_COUNT) {      // raster overflow queues of phase 1: count them, then empty them for phase 2
+        uint32_t* q = &counters[CNT_STRIPES + t * CNT_STRIPE_WORDS + STRIPE_OVERFLOW];
+        if (*q) atomicAdd(&counters[CNT_BIN_OVERFLOW], *q);
+        *q = 0u;
+    }
 }
 
 int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {

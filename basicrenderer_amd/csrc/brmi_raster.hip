@@ -43,6 +43,7 @@ constexpr int COOP_ENTRIES = 64;                    // triangles with more bin e
 
 struct RasterArgs {
     BinRecord* binRecords; uint32_t* binCounts; uint32_t binCapacity, binsX, binsY;
+    BinRecord* overflow; uint32_t overflowPerStripe;     // 64 striped queues of records whose bin was full (pad0 = strip)
     const float* objConst;   // per object: MVP (16), objectToClip (16), modelViewZ (4)
     int bigTriArea;          // clamped-bbox pixels above which a triangle is binned
     int debugFlags;          // experiments only (BRMI_RASTER_DEBUG): 1 = skip the direct walk, 2 = skip bin emission, 4 = skip the bin pass, 8 = direct walk without the atomic
@@ -123,20 +124,29 @@ BRMI_DEV void raster_row(const Sink& sink, int py, int minX, int rectWidth, bool
 }
 
 // Stores one record at a reserved slot of a bin; when the bin is full its rows are rasterised here with global atomics (counted).
-BRMI_DEV void bin_store(const RasterArgs& a, const BinRecord& r, uint32_t strip, uint32_t band, uint32_t slot) {
-    const uint32_t bin = band * a.binsX + strip;
-    if (slot < a.binCapacity) { a.binRecords[(size_t)bin * a.binCapacity + slot] = r; return; }
-    atomicAdd(&a.counters[CNT_BIN_OVERFLOW], 1u);
+BRMI_DEV void raster_record_global(const RasterArgs& a, const BinRecord& r, uint32_t strip, uint32_t firstRow, uint32_t rowStep) {
     const GlobalSink sink{a.vis, a.tilesX, 0};
+    const uint32_t n = (r.triAndFlags >> 16) & 0xFFu;
     float sb0 = r.sb0, sb1 = r.sb1;
-    const int n = (int)((r.triAndFlags >> 16) & 0xFFu);
-    for (int k = 0; k < n; k++) {
-        const int py = r.rowStart + k;
+    uint32_t k = 0;
+    for (uint32_t row = firstRow; row < n; row += rowStep) {
+        for (; k < row; k++) { sb0 += r.dy_b0; sb1 += r.dy_b1; }
+        const int py = r.rowStart + (int)row;
         if ((uint32_t)py >= a.bandY0 && (uint32_t)py < a.bandY1)
             raster_row(sink, py, r.minX, r.rectWidth, (r.triAndFlags & 0x100u) != 0, sb0, sb1, r.dx_b0, r.dx_b1, -(r.dx_b0 + r.dx_b1), r.d0, r.d1, r.d2, r.clusterIndex, r.triAndFlags & 0x7Fu,
                        (int)(strip << BIN_W_SHIFT), (int)(strip << BIN_W_SHIFT) + BIN_W - 1);
-        sb0 += r.dy_b0; sb1 += r.dy_b1;
     }
+}
+
+// Stores one record at a reserved slot of a bin.  A full bin sends the record to the overflow queue of the wave's stripe
+// (k_raster_overflow walks those row-parallel with global atomics); a full queue rasterises it right here.
+BRMI_DEV void bin_store(const RasterArgs& a, const BinRecord& r, uint32_t strip, uint32_t band, uint32_t slot) {
+    const uint32_t bin = band * a.binsX + strip;
+    if (slot < a.binCapacity) { a.binRecords[(size_t)bin * a.binCapacity + slot] = r; return; }
+    const uint32_t stripe = blockIdx.x & (CNT_STRIPE_COUNT - 1u);
+    const uint32_t q = atomicAdd(&a.counters[CNT_STRIPES + stripe * CNT_STRIPE_WORDS + STRIPE_OVERFLOW], 1u);
+    if (q < a.overflowPerStripe) { BinRecord o = r; o.pad0 = strip; a.overflow[(size_t)stripe * a.overflowPerStripe + q] = o; return; }
+    raster_record_global(a, r, strip, 0u, 1u);
 }
 BRMI_DEV void bin_append(const RasterArgs& a, const BinRecord& r, uint32_t strip, uint32_t band) {
     bin_store(a, r, strip, band, atomicAdd(&a.binCounts[band * a.binsX + strip], 1u));
@@ -402,6 +412,27 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS) k_raster_bins(RasterArgs a) 
     }
 }
 
+// Records that did not fit their bin: four per wave64, one lane per row, global 64-bit atomics (the bins' merge is a plain
+// read-modify-write, so this runs after k_raster_bins).  The queue lengths are cleared with the frame's counters and, between the
+// two raster phases, by k_seed_phase2.
+__global__ void __launch_bounds__(64) k_raster_overflow(RasterArgs a) {
+    const uint32_t lane = threadIdx.x, sub = lane >> 4, row = lane & 15u;
+    // lane = stripe: all 64 queue lengths with one load; nearly every frame has none
+    const uint32_t mine = min(a.counters[CNT_STRIPES + lane * CNT_STRIPE_WORDS + STRIPE_OVERFLOW], a.overflowPerStripe);
+    uint64_t busy = __ballot(mine != 0u);
+    while (busy != 0ull) {
+        const uint32_t stripe = (uint32_t)__ffsll((unsigned long long)busy) - 1u;
+        busy &= busy - 1ull;
+        const uint32_t n = (uint32_t)__shfl((int)mine, (int)stripe);
+        for (uint32_t base = blockIdx.x * 4u; base < n; base += gridDim.x * 4u) {
+            const uint32_t ri = base + sub;
+            if (ri >= n) continue;
+            const BinRecord r = a.overflow[(size_t)stripe * a.overflowPerStripe + ri];
+            raster_record_global(a, r, r.pad0, row, 16u);
+        }
+    }
+}
+
 // K6: linear depth from the visibility key (gbuffer.hlsl:114-161); one lane per pixel, tile order
 __global__ void __launch_bounds__(256) k_depth_copy(const unsigned long long* vis, float* depth, uint64_t n) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -428,10 +459,12 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
     a.visW = p->cfg.width; a.visH = p->cfg.height; a.tilesX = p->tilesX; a.bandY0 = p->bandY0; a.bandY1 = p->bandY1;
     a.binRecords = p->wsPtr<BinRecord>(p->ws.binRecords); a.binCounts = p->wsPtr<uint32_t>(p->ws.binCounts);
     a.binCapacity = p->binCapacity; a.binsX = p->binsX; a.binsY = p->binsY;
+    a.overflow = p->wsPtr<BinRecord>(p->ws.binOverflow); a.overflowPerStripe = p->binOverflowPerStripe;
     a.objConst = p->wsPtr<float>(p->ws.objConst);
     a.bigTriArea = p->bigTriArea; a.debugFlags = p->rasterDebug;
     hipLaunchKernelGGL(k_raster, dim3(p->rasterGrid), dim3(64), 0, s, a);
     if (!(p->rasterDebug & 4)) hipLaunchKernelGGL(k_raster_bins, dim3(p->binsX, p->binsY), dim3(BRMI_BIN_THREADS), 0, s, a);
+    hipLaunchKernelGGL(k_raster_overflow, dim3(1024), dim3(64), 0, s, a);
     BRMI_LAUNCH_CHECK(p, "k_raster");
     return BRMI_OK;
 }
