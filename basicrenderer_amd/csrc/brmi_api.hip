@@ -81,6 +81,7 @@ static void compute_sizes(brmi_pass* p) {
     w.bitmask1 = take((uint64_t)p->totalWords * 4);
     w.bitmask2 = take((uint64_t)p->totalWords * 4);
     w.frameClearBytes = off - w.counters;
+    w.usedClusters = take((uint64_t)c.maxVisibleClusters);     // one byte per visible cluster, zeroed by the compaction kernel
     w.frontierA = take((uint64_t)c.maxTraversalRecords * sizeof(NodeRecord));
     w.frontierB = take((uint64_t)c.maxTraversalRecords * sizeof(NodeRecord));
     w.buckets = take((uint64_t)c.maxTraversalRecords * sizeof(BucketRecord));

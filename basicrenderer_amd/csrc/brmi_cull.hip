@@ -323,9 +323,10 @@ __global__ void __launch_bounds__(256) k_traverse(CullArgs a, uint32_t level, co
 // dependent HBM round trips per level for every instance -- becomes one launch in which the per-instance state (instance,
 // mesh metadata, model matrix) is fetched once and a level costs node -> group / segment -> page map.  Used when every mesh's
 // BVH level fits the LDS frontier (brmi_set_scene checks); same tests, same operation order as k_cull_instances / k_traverse.
-constexpr uint32_t HIER_CAP = 1024;
-constexpr uint32_t HIER_STAGE = 512;      // bucket records staged in LDS (16 KB)
-template <bool REPLAY>
+constexpr uint32_t HIER_CAP_MAX = 1024;   // widest BVH level the LDS frontier variants cover
+// HIER_CAP nodes per frontier, HIER_STAGE bucket records staged in LDS: (256, 128) = 6 KB keeps ~20 workgroups per CU in flight
+// (scenes of many small instances), (1024, 512) = 24 KB covers wide hierarchies.
+template <bool REPLAY, uint32_t HIER_CAP, uint32_t HIER_STAGE>
 __global__ void __launch_bounds__(64) k_cull_hierarchy(CullArgs a, BucketRecord* buckets) {
     __shared__ uint32_t frontier[2][HIER_CAP];
     __shared__ uint32_t counts[2];
@@ -738,7 +739,7 @@ __global__ void __launch_bounds__(256) k_scan_words(const uint32_t* bitmask, uin
 // shared words would serialise the whole rasteriser (~90 same-address atomics per microsecond).
 __global__ void __launch_bounds__(256) k_scatter_visible(const TempVisible* temp, uint32_t* counters, uint32_t tempCountIndex, const uint32_t* bitmask,
                                                         const uint32_t* wordPrefix, uint4* visible, uint32_t baseIndexCounter, uint32_t capacity, uint32_t visibleCapacity,
-                                                        brmi_scene_buffers sc, ClusterSetup* setup, uint32_t resolveCapacity) {
+                                                        brmi_scene_buffers sc, ClusterSetup* setup, uint32_t resolveCapacity, uint8_t* used) {
     const uint8_t* const* slabs = sc.slabs;
     const uint32_t n = min(counters[tempCountIndex], visibleCapacity);
     const uint32_t base = baseIndexCounter == 0xFFFFFFFFu ? 0u : counters[baseIndexCounter];
@@ -804,6 +805,7 @@ __global__ void __launch_bounds__(256) k_scatter_visible(const TempVisible* temp
             const bool fits = v0 + verts <= resolveCapacity && t0 + tris <= resolveCapacity;
             cs.vertBase = fits ? (uint32_t)v0 : BRMI_ARENA_NONE; cs.triBase32 = fits ? (uint32_t)t0 : BRMI_ARENA_NONE;
             setup[dst] = cs;
+            used[dst] = 0;        // "owns a pixel" flag of the G-buffer pass
         }
     }
 }
@@ -853,16 +855,20 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
     uint32_t* wordPrefix = p->wsPtr<uint32_t>(p->ws.wordPrefix); uint32_t* blockSums = p->wsPtr<uint32_t>(p->ws.blockSums);
 
     const uint32_t maxBlocks = 1024;
-    const bool hierarchy = p->maxLevelWidth <= HIER_CAP && !p->forceLevelKernels;
+    const bool hierarchy = p->maxLevelWidth <= HIER_CAP_MAX && !p->forceLevelKernels;
+    const bool smallHier = p->maxLevelWidth <= 256u;
     if (phase == 1) {
         BRMI_HIP(p, hipMemsetAsync(p->counters(), 0, p->ws.frameClearBytes, s));      // counters + both survivor bitmasks
         hipLaunchKernelGGL(k_object_constants, dim3((std::max(1u, p->scene.perObjectCount) + 63) / 64), dim3(64), 0, s, p->scene, p->wsPtr<m4>(p->ws.frameConst), p->wsPtr<float>(p->ws.objConst));
-        if (hierarchy) hipLaunchKernelGGL(k_cull_hierarchy<false>, dim3(std::min(std::max(1u, p->scene.activeDrawCount), 8192u)), dim3(64), 0, s, a, buckets);
+        const dim3 hgrid(std::min(std::max(1u, p->scene.activeDrawCount), 16384u));
+        if (hierarchy && smallHier) hipLaunchKernelGGL((k_cull_hierarchy<false, 256, 128>), hgrid, dim3(64), 0, s, a, buckets);
+        else if (hierarchy) hipLaunchKernelGGL((k_cull_hierarchy<false, 1024, 512>), hgrid, dim3(64), 0, s, a, buckets);
         else hipLaunchKernelGGL(k_cull_instances, dim3(grid_for(p->scene.activeDrawCount, 256, maxBlocks)), dim3(256), 0, s, a, fa);
         BRMI_LAUNCH_CHECK(p, "k_cull_instances");
     } else {
         hipLaunchKernelGGL(k_seed_phase2, dim3(1), dim3(128), 0, s, p->counters(), a.recordCapacity);
-        if (hierarchy) hipLaunchKernelGGL(k_cull_hierarchy<true>, dim3(2048), dim3(64), 0, s, a, buckets);
+        if (hierarchy && smallHier) hipLaunchKernelGGL((k_cull_hierarchy<true, 256, 128>), dim3(2048), dim3(64), 0, s, a, buckets);
+        else if (hierarchy) hipLaunchKernelGGL((k_cull_hierarchy<true, 1024, 512>), dim3(2048), dim3(64), 0, s, a, buckets);
     }
     // frontier sizes are only known on the device: size the grids for the worst case that can matter
     const uint32_t travGrid = grid_for(std::min<uint64_t>(p->cfg.maxTraversalRecords, (uint64_t)p->scene.lodNodeCount * 4 + 4096), 256, maxBlocks);
@@ -884,7 +890,7 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
         hipLaunchKernelGGL(k_scan_words, dim3(p->scanBlocks), dim3(256), 0, s, bitmask, p->totalWords, blockSums, wordPrefix);
     }
     hipLaunchKernelGGL(k_scatter_visible, dim3(maxBlocks), dim3(256), 0, s, temp, p->counters(), (uint32_t)(phase == 1 ? CNT_TEMP_VISIBLE : CNT_TEMP_VISIBLE2), bitmask, wordPrefix,
-                       static_cast<uint4*>(p->res[BRMI_RES_VISIBLE_CLUSTERS]), phase == 1 ? 0xFFFFFFFFu : (uint32_t)CNT_VISIBLE, p->cfg.maxVisibleClusters, p->cfg.maxVisibleClusters, p->scene, p->wsPtr<ClusterSetup>(p->ws.clusterSetup), p->resolveCapacity);
+                       static_cast<uint4*>(p->res[BRMI_RES_VISIBLE_CLUSTERS]), phase == 1 ? 0xFFFFFFFFu : (uint32_t)CNT_VISIBLE, p->cfg.maxVisibleClusters, p->cfg.maxVisibleClusters, p->scene, p->wsPtr<ClusterSetup>(p->ws.clusterSetup), p->resolveCapacity, p->wsPtr<uint8_t>(p->ws.usedClusters));
     BRMI_LAUNCH_CHECK(p, "compaction");
     return BRMI_OK;
 }

@@ -38,7 +38,7 @@ struct BinRecord {           // 64 B
 static_assert(sizeof(BinRecord) == 64, "one cache line");
 constexpr int BIN_W = 256, BIN_ROWS = 16;          // bin = 4096 keys = 32 KB of LDS
 constexpr int BIN_W_SHIFT = 8, BIN_ROWS_SHIFT = 4;
-constexpr int BIN_WINDOW = 1024;                    // bins a wave can count in LDS at once (cells of its bin bounding box)
+constexpr int BIN_WINDOW = 256;                     // bins a wave can count in LDS at once (cells of its bin bounding box)
 constexpr int COOP_ENTRIES = 64;                    // triangles with more bin entries than this are emitted by the whole wave
 
 struct RasterArgs {
@@ -152,7 +152,10 @@ BRMI_DEV void bin_append(const RasterArgs& a, const BinRecord& r, uint32_t strip
     bin_store(a, r, strip, band, atomicAdd(&a.binCounts[band * a.binsX + strip], 1u));
 }
 
-__global__ void __launch_bounds__(64) k_raster(RasterArgs a) {
+#ifndef BRMI_RASTER_WAVES
+#define BRMI_RASTER_WAVES 1
+#endif
+__global__ void __launch_bounds__(64, BRMI_RASTER_WAVES) k_raster(RasterArgs a) {
     __shared__ float sx[BRMI_MESHLET_MAX_VERTS], sy[BRMI_MESHLET_MAX_VERTS], sd[BRMI_MESHLET_MAX_VERTS];
     __shared__ uint32_t binBase[BIN_WINDOW];
     __shared__ float tpF[9][64];

@@ -29,6 +29,7 @@ struct GBufferArgs {
     const m4* frameConst; const float* objConst;
     const ClusterSetup* setup; ResolveVertex* verts; ResolveTriangle* tris; uint32_t vertCapacity, triCapacity;
     MaterialWords* matWords;
+    const uint8_t* used;           // per visible cluster: owns a pixel (valid when counters[CNT_RESOLVE_MARKED])
 };
 
 BRMI_DEV f3 oct_decode_normal(uint32_t packed) {
@@ -71,6 +72,26 @@ __global__ void __launch_bounds__(64) k_material_words(brmi_scene_buffers sc, Ma
     out[i] = w;
 }
 
+// Scenes of pixel-sized triangles (Zorah-class) have far more triangles in their visible clusters than pixels on screen; setting
+// up every triangle of every visible cluster would cost more than it saves.  When the frame is of that kind (decided on the
+// device from the counters) this pass marks the clusters that own at least one pixel, and the setup kernel skips the rest.
+__global__ void __launch_bounds__(256) k_mark_used_clusters(GBufferArgs a, uint8_t* used, uint32_t* counters) {
+    const uint32_t clusterCount = min(a.counters[CNT_VISIBLE] + a.counters[CNT_VISIBLE2], a.clusterCapacity);
+    const uint64_t tris = ((uint64_t)a.counters[CNT_SUM_TRIS_HI] << 32) | a.counters[CNT_SUM_TRIS_LO];
+    if (tris * 2ull <= a.pixelCount) return;                 // wave-uniform: few triangles per pixel, set up everything
+    if (blockIdx.x == 0 && threadIdx.x == 0) counters[CNT_RESOLVE_MARKED] = 1u;
+    const uint64_t end = (a.pixelCount + 63ull) & ~63ull;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < end; j += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t i = a.firstPixel + j;
+        const unsigned long long key = j < a.pixelCount ? a.vis[i] : BRMI_VIS_EMPTY;
+        const uint32_t cid = (uint32_t)((key >> BRMI_VIS_TRI_BITS) & 0x3FFFFFFull);
+        // one byte per cluster, plain stores (every writer stores 1; the compaction kernel zeroed the flags): a bit mask would need
+        // atomics on words shared by 32 clusters.  One store per run of equal ids along the tile's column-major order.
+        const uint32_t prev = (uint32_t)__shfl_up((int)cid, 1);
+        if (key != BRMI_VIS_EMPTY && cid < clusterCount && (lane_id() == 0u || cid != prev)) used[cid] = 1;
+    }
+}
+
 // Per-cluster resolve tables, one wave64 per visible cluster.  Everything CalcFullBary (clodResolveCommon.hlsli:104-143)
 // derives from the triangle alone -- the three projected vertices, 1/w, the screen-space derivatives of the barycentrics --
 // and the decoded vertex normals are evaluated once per triangle / vertex here with the shader's operation order; the pixel
@@ -79,7 +100,9 @@ __global__ void __launch_bounds__(64) k_resolve_setup(GBufferArgs a) {
     __shared__ float cx[BRMI_MESHLET_MAX_VERTS], cy[BRMI_MESHLET_MAX_VERTS], cw[BRMI_MESHLET_MAX_VERTS];
     const uint32_t lane = threadIdx.x;
     const uint32_t clusterCount = min(a.counters[CNT_VISIBLE] + a.counters[CNT_VISIBLE2], a.clusterCapacity);
+    const bool marked = a.counters[CNT_RESOLVE_MARKED] != 0u;
     for (uint32_t c = blockIdx.x; c < clusterCount; c += gridDim.x) {
+        if (marked && a.used[c] == 0) continue;      // no pixel shows this cluster
         const ClusterSetup cs = a.setup[c];
         if (cs.vertBase == BRMI_ARENA_NONE) continue;          // arena full: the pixel pass walks this cluster's data itself
         const uint32_t vertCount = cs.counts & 0xFFu, triCount = (cs.counts >> 8) & 0xFFu, posFormat = (cs.counts >> 16) & 0xFFu;
@@ -278,7 +301,9 @@ int launch_gbuffer(brmi_pass* p, hipStream_t s) {
     a.vertCapacity = p->resolveCapacity; a.triCapacity = p->resolveCapacity;
     a.matWords = p->wsPtr<MaterialWords>(p->ws.matWords);
     hipLaunchKernelGGL(k_material_words, dim3((std::max(1u, p->scene.materialCount) + 63) / 64), dim3(64), 0, s, p->scene, a.matWords);
-    hipLaunchKernelGGL(k_resolve_setup, dim3(4096), dim3(64), 0, s, a);
+    a.used = p->wsPtr<uint8_t>(p->ws.usedClusters);
+    hipLaunchKernelGGL(k_mark_used_clusters, dim3(2048), dim3(256), 0, s, a, p->wsPtr<uint8_t>(p->ws.usedClusters), p->counters());
+    hipLaunchKernelGGL(k_resolve_setup, dim3(8192), dim3(64), 0, s, a);
     if ((uint64_t)p->resolveCapacity >= (uint64_t)p->cfg.maxVisibleClusters * BRMI_MESHLET_MAX_TRIS) hipLaunchKernelGGL(k_gbuffer<false>, dim3(4096), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(k_gbuffer<true>, dim3(4096), dim3(256), 0, s, a);
     BRMI_LAUNCH_CHECK(p, "k_gbuffer");
