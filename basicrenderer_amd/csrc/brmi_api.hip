@@ -90,6 +90,7 @@ static void compute_sizes(brmi_pass* p) {
     w.blockSums = take((uint64_t)(p->scanBlocks + 1) * 4);
     w.instanceBitBase = take((uint64_t)std::max<size_t>(1, p->hostInstanceBitBase.size()) * 4);
     w.segPrefix = take((uint64_t)std::max<size_t>(1, p->hostSegPrefix.size()) * 4);
+    w.meshLevelWidth = take((uint64_t)std::max<size_t>(1, p->hostMeshLevelWidth.size()) * 4);
     w.planes = take((uint64_t)2 * c.lightClusterSize[2] * 4);
     // phase-1 -> phase-2 hand-over (reference: clodStructs.hlsli:629-652); the replay bucket array doubles as the
     // phase-2 bucket array, so it has the full record capacity
@@ -213,7 +214,7 @@ int brmi_set_scene(brmi_pass* p, const brmi_scene_buffers* scene) {
     p->hostSegPrefix.assign(segs.size(), 0);
     std::vector<uint32_t> meshBits(md.size(), 0);
     uint32_t maxDepth = 1;
-    p->maxLevelWidth = 1;
+    p->maxLevelWidth = 1; p->minLevelWidth = 0xFFFFFFFFu; p->hostMeshLevelWidth.assign(md.size(), 1u);
     std::vector<uint32_t> levelWidth;
     std::vector<std::pair<uint32_t, uint32_t>> stack;
     for (size_t m = 0; m < md.size(); m++) {
@@ -225,7 +226,7 @@ int brmi_set_scene(brmi_pass* p, const brmi_scene_buffers* scene) {
             if ((uint64_t)md[m].lodNodesBase + n >= nodes.size()) return fail(p, BRMI_ERR_INVALID, "mesh %zu: node %u out of range", m, n);
             const brmi_lod_node& nd = nodes[md[m].lodNodesBase + n];
             maxDepth = std::max(maxDepth, d);
-            if (d < levelWidth.size()) p->maxLevelWidth = std::max(p->maxLevelWidth, ++levelWidth[d]);
+            if (d < levelWidth.size()) p->hostMeshLevelWidth[m] = std::max(p->hostMeshLevelWidth[m], ++levelWidth[d]);
             if (nd.isLeaf != BRMI_NODE_INTERNAL) { segCount = std::max(segCount, nd.indexOrOffset + 1); continue; }
             if (d > 64) return fail(p, BRMI_ERR_INVALID, "mesh %zu: BVH deeper than 64 levels", m);
             const uint32_t cc = std::min(nd.countMinusOne + 1u, BRMI_BVH_MAX_CHILDREN);
@@ -239,6 +240,7 @@ int brmi_set_scene(brmi_pass* p, const brmi_scene_buffers* scene) {
         }
         if (run > 0xFFFFFFFFull) return fail(p, BRMI_ERR_CAPACITY, "mesh %zu has too many meshlets", m);
         meshBits[m] = (uint32_t)run;
+        p->maxLevelWidth = std::max(p->maxLevelWidth, p->hostMeshLevelWidth[m]); p->minLevelWidth = std::min(p->minLevelWidth, p->hostMeshLevelWidth[m]);
     }
     p->hostInstanceBitBase.assign(offs.size(), 0);
     uint64_t bits = 0;
@@ -287,6 +289,7 @@ int brmi_setup(brmi_pass* p, const brmi_resource_binding* b, uint32_t n, brmi_st
     BRMI_HIP(p, hipMemsetAsync(p->res[BRMI_RES_WORKSPACE], 0, p->ws.total, s));
     if (!p->hostInstanceBitBase.empty()) BRMI_HIP(p, hipMemcpyAsync(p->wsPtr<uint32_t>(p->ws.instanceBitBase), p->hostInstanceBitBase.data(), p->hostInstanceBitBase.size() * 4, hipMemcpyHostToDevice, s));
     if (!p->hostSegPrefix.empty()) BRMI_HIP(p, hipMemcpyAsync(p->wsPtr<uint32_t>(p->ws.segPrefix), p->hostSegPrefix.data(), p->hostSegPrefix.size() * 4, hipMemcpyHostToDevice, s));
+    if (!p->hostMeshLevelWidth.empty()) BRMI_HIP(p, hipMemcpyAsync(p->wsPtr<uint32_t>(p->ws.meshLevelWidth), p->hostMeshLevelWidth.data(), p->hostMeshLevelWidth.size() * 4, hipMemcpyHostToDevice, s));
     { int rc = launch_expand_luts(p, s); if (rc) return rc; }
     BRMI_HIP(p, hipStreamSynchronize(s));   // host vectors may be reused
     if (p->cfg.collectPassStatistics && !p->eventsCreated) {

@@ -325,9 +325,9 @@ __global__ void __launch_bounds__(256) k_traverse(CullArgs a, uint32_t level, co
 // BVH level fits the LDS frontier (brmi_set_scene checks); same tests, same operation order as k_cull_instances / k_traverse.
 constexpr uint32_t HIER_CAP_MAX = 1024;   // widest BVH level the LDS frontier variants cover
 // HIER_CAP nodes per frontier, HIER_STAGE bucket records staged in LDS: (256, 128) = 6 KB keeps ~20 workgroups per CU in flight
-// (scenes of many small instances), (1024, 512) = 24 KB covers wide hierarchies.
+// (scenes of many small instances), (1024, 128) = 12 KB covers wide hierarchies.
 template <bool REPLAY, uint32_t HIER_CAP, uint32_t HIER_STAGE>
-__global__ void __launch_bounds__(64) k_cull_hierarchy(CullArgs a, BucketRecord* buckets) {
+__global__ void __launch_bounds__(64) k_cull_hierarchy(CullArgs a, BucketRecord* buckets, const uint32_t* meshLevelWidth, uint32_t widthLo, uint32_t widthHi) {
     __shared__ uint32_t frontier[2][HIER_CAP];
     __shared__ uint32_t counts[2];
     __shared__ uint32_t childOff[65], childFirst[64];
@@ -362,7 +362,12 @@ __global__ void __launch_bounds__(64) k_cull_hierarchy(CullArgs a, BucketRecord*
         if (REPLAY) { const NodeRecord rec = a.replayNodes[seed]; instIndex = rec.instanceIndex; startNode = rec.nodeIdPacked & 0x3FFFFFFFu; }
         else instIndex = sc.activeDraws[seed];
         const brmi_per_mesh_instance inst = sc.perMeshInstance[instIndex];
-        const brmi_clod_mesh_metadata md = sc.meshMetadata[sc.clodOffsets[instIndex].clodMeshMetadataIndex];
+        const uint32_t mdIndex = sc.clodOffsets[instIndex].clodMeshMetadataIndex;
+        {   // this launch handles the meshes whose widest BVH level fits its LDS frontier class
+            const uint32_t width = meshLevelWidth[mdIndex];
+            if (width < widthLo || width > widthHi) continue;
+        }
+        const brmi_clod_mesh_metadata md = sc.meshMetadata[mdIndex];
         const brmi_per_object* obj = sc.perObject + inst.perObjectBufferIndex;
         const m4 model = load_m4(&obj->model[0][0]);
         const float scale = max_axis_scale(model);
@@ -856,19 +861,21 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
 
     const uint32_t maxBlocks = 1024;
     const bool hierarchy = p->maxLevelWidth <= HIER_CAP_MAX && !p->forceLevelKernels;
-    const bool smallHier = p->maxLevelWidth <= 256u;
+    const uint32_t* meshWidth = p->wsPtr<uint32_t>(p->ws.meshLevelWidth);
     if (phase == 1) {
         BRMI_HIP(p, hipMemsetAsync(p->counters(), 0, p->ws.frameClearBytes, s));      // counters + both survivor bitmasks
         hipLaunchKernelGGL(k_object_constants, dim3((std::max(1u, p->scene.perObjectCount) + 63) / 64), dim3(64), 0, s, p->scene, p->wsPtr<m4>(p->ws.frameConst), p->wsPtr<float>(p->ws.objConst));
         const dim3 hgrid(std::min(std::max(1u, p->scene.activeDrawCount), 16384u));
-        if (hierarchy && smallHier) hipLaunchKernelGGL((k_cull_hierarchy<false, 256, 128>), hgrid, dim3(64), 0, s, a, buckets);
-        else if (hierarchy) hipLaunchKernelGGL((k_cull_hierarchy<false, 1024, 512>), hgrid, dim3(64), 0, s, a, buckets);
-        else hipLaunchKernelGGL(k_cull_instances, dim3(grid_for(p->scene.activeDrawCount, 256, maxBlocks)), dim3(256), 0, s, a, fa);
+        if (hierarchy) {
+            // narrow meshes (most instances) with the 6 KB variant, wide ones with the 24 KB variant; each launch skips the other class
+            if (p->minLevelWidth <= 256u) hipLaunchKernelGGL((k_cull_hierarchy<false, 256, 128>), hgrid, dim3(64), 0, s, a, buckets, meshWidth, 0u, 256u);
+            if (p->maxLevelWidth > 256u) hipLaunchKernelGGL((k_cull_hierarchy<false, 1024, 128>), hgrid, dim3(64), 0, s, a, buckets, meshWidth, 257u, HIER_CAP_MAX);
+        } else hipLaunchKernelGGL(k_cull_instances, dim3(grid_for(p->scene.activeDrawCount, 256, maxBlocks)), dim3(256), 0, s, a, fa);
         BRMI_LAUNCH_CHECK(p, "k_cull_instances");
     } else {
         hipLaunchKernelGGL(k_seed_phase2, dim3(1), dim3(128), 0, s, p->counters(), a.recordCapacity);
-        if (hierarchy && smallHier) hipLaunchKernelGGL((k_cull_hierarchy<true, 256, 128>), dim3(2048), dim3(64), 0, s, a, buckets);
-        else if (hierarchy) hipLaunchKernelGGL((k_cull_hierarchy<true, 1024, 512>), dim3(2048), dim3(64), 0, s, a, buckets);
+        if (hierarchy && p->minLevelWidth <= 256u) hipLaunchKernelGGL((k_cull_hierarchy<true, 256, 128>), dim3(2048), dim3(64), 0, s, a, buckets, meshWidth, 0u, 256u);
+        if (hierarchy && p->maxLevelWidth > 256u) hipLaunchKernelGGL((k_cull_hierarchy<true, 1024, 128>), dim3(2048), dim3(64), 0, s, a, buckets, meshWidth, 257u, HIER_CAP_MAX);
     }
     // frontier sizes are only known on the device: size the grids for the worst case that can matter
     const uint32_t travGrid = grid_for(std::min<uint64_t>(p->cfg.maxTraversalRecords, (uint64_t)p->scene.lodNodeCount * 4 + 4096), 256, maxBlocks);

@@ -81,7 +81,7 @@ struct HzbDesc {
 
 struct Workspace {     // byte offsets into BRMI_RES_WORKSPACE
     uint64_t counters, frontierA, frontierB, buckets, tempVisible, bitmask1, bitmask2, wordPrefix, blockSums,
-             instanceBitBase, segPrefix, planes, replayNodes, replayBuckets, lightVS, lightMeta, clusterPages, clusterHits, pageTotal, lightHitMasks, binCounts, binRecords, binOverflow, clusterSetup, resolveVerts, resolveTris, matWords, shadeTables, lutF, frameConst, objConst, matConst, deferredPixels, usedClusters, frameClearBytes, total;
+             instanceBitBase, segPrefix, meshLevelWidth, planes, replayNodes, replayBuckets, lightVS, lightMeta, clusterPages, clusterHits, pageTotal, lightHitMasks, binCounts, binRecords, binOverflow, clusterSetup, resolveVerts, resolveTris, matWords, shadeTables, lutF, frameConst, objConst, matConst, deferredPixels, usedClusters, frameClearBytes, total;
 };
 
 }  // namespace brmi
@@ -99,6 +99,8 @@ struct brmi_pass {
     float bandPlaneTop[3] = {0, 0, 0}, bandPlaneBottom[3] = {0, 0, 0};
     uint64_t bandFirstPixel = 0, bandPixelCount = 0;   // tiled index range covering the band's tile rows
     uint32_t maxLevels = 1;
+    uint32_t minLevelWidth = 0;      // narrowest such width over the meshes
+    std::vector<uint32_t> hostMeshLevelWidth;   // per mesh metadata entry
     uint32_t maxLevelWidth = 0;      // widest BVH level of any mesh (decides between the per-instance and the per-level traversal)
     bool forceLevelKernels = false;  // BRMI_CULL_LEVEL_KERNELS=1: always use the per-level kernels (tests, very wide hierarchies)
     uint64_t totalBits = 0; uint32_t totalWords = 0, scanBlocks = 0;
