@@ -211,17 +211,26 @@ __global__ void __launch_bounds__(256) k_gbuffer(GBufferArgs a) {
     // view-projection products are frame constants; every lane derives them the way the shader does
     const m4 unjVP = uni_m4(a.frameConst[1]), prevVP = uni_m4(a.frameConst[2]);
     const float winX = uni((float)pf->screenResX), winY = uni((float)pf->screenResY);
-    const uint64_t end = (a.pixelCount + 63ull) & ~63ull;
-    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < end; j += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t end = (a.pixelCount + 63ull) & ~63ull, stride = (uint64_t)gridDim.x * blockDim.x;
+    // software pipeline: the key and the cluster record of the next tile are requested while this one is resolved (the chain
+    // key -> cluster -> triangle -> vertices is four dependent loads)
+    auto pixel_of = [&](uint64_t j, uint32_t& px, uint32_t& py) {
         const uint64_t i = a.firstPixel + j;
         const uint32_t tile = (uint32_t)(i >> 6), within = (uint32_t)(i & 63u);
-        const uint32_t px = (tile % a.tilesX) * 8u + (within >> 3), py = (tile / a.tilesX) * 8u + (within & 7u);
-        bool valid = j < a.pixelCount && px < a.W && py < a.H && py >= a.bandY0 && py < a.bandY1;
-        unsigned long long key = BRMI_VIS_EMPTY;
-        if (valid) {
-            key = a.vis[i];
-            if (a.depth) a.depth[i] = (key == BRMI_VIS_EMPTY) ? as_f32(BRMI_DEPTH_EMPTY_BITS) : as_f32(((uint32_t)(key >> BRMI_VIS_META_BITS)) << 1);
-        }
+        px = (tile % a.tilesX) * 8u + (within >> 3); py = (tile / a.tilesX) * 8u + (within & 7u);
+        return j < a.pixelCount && px < a.W && py < a.H && py >= a.bandY0 && py < a.bandY1;
+    };
+    uint64_t j0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t npx = 0, npy = 0;
+    bool nvalid = j0 < end && pixel_of(j0, npx, npy);
+    unsigned long long nkey = nvalid ? a.vis[a.firstPixel + j0] : BRMI_VIS_EMPTY;
+    for (uint64_t j = j0; j < end; j += stride) {
+        const uint64_t i = a.firstPixel + j;
+        const uint32_t px = npx, py = npy;
+        bool valid = nvalid;
+        const unsigned long long key = nkey;
+        if (j + stride < end) { nvalid = pixel_of(j + stride, npx, npy); nkey = nvalid ? a.vis[a.firstPixel + j + stride] : BRMI_VIS_EMPTY; }
+        if (valid && a.depth) a.depth[i] = (key == BRMI_VIS_EMPTY) ? as_f32(BRMI_DEPTH_EMPTY_BITS) : as_f32(((uint32_t)(key >> BRMI_VIS_META_BITS)) << 1);
         const uint32_t triId = (uint32_t)(key & 0x7Full);
         const uint32_t clusterIndex = (uint32_t)((key >> BRMI_VIS_TRI_BITS) & 0x3FFFFFFull);
         valid = valid && key != BRMI_VIS_EMPTY && clusterIndex < clusterCount;
