@@ -255,6 +255,7 @@ int brmi_set_scene(brmi_pass* p, const brmi_scene_buffers* scene) {
     p->maxLevels = std::min(std::max(1u, maxDepth), std::max(1u, p->cfg.maxBvhLevels));
     compute_sizes(p);
     p->haveScene = true;
+    p->updateSerial++;
     return BRMI_OK;
 }
 
@@ -297,6 +298,7 @@ int brmi_setup(brmi_pass* p, const brmi_resource_binding* b, uint32_t n, brmi_st
         p->eventsCreated = true;
     }
     p->setupDone = true;
+    p->constantsSerial = 0;      // the workspace was cleared: the frame constants have to be evaluated again
     return BRMI_OK;
 }
 
@@ -338,6 +340,7 @@ int brmi_update(brmi_pass* p, const brmi_frame_update* u, brmi_stream stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     BRMI_HIP(p, hipMemcpyAsync(p->wsPtr<float>(p->ws.planes), p->planesHost.data(), p->planesHost.size() * 4, hipMemcpyHostToDevice, s));
     p->updated = true;
+    p->updateSerial++;       // the per-frame constants are re-evaluated by the next stage call
     return BRMI_OK;
 }
 

@@ -119,37 +119,6 @@ BRMI_DEV bool occlusion_test(const CullArgs& a, const brmi_camera* cam, bool rep
     return occlusion_culled(a.hzb, cam, cam->prevUnjitteredProjection[0][0], cam->prevUnjitteredProjection[1][1], pc, -pc.z, localRadius * max_axis_scale(prevModel));
 }
 
-// Frame / object constants ------------------------------------------------------------------------
-// The reference shaders rebuild these matrix products in every thread (softwareRaster.hlsl:336-337,
-// clodResolveCommon.hlsli:1531-1535,1697-1702).  They only depend on the camera and the object, so they
-// are evaluated once per frame / once per object with the same operation order and read back later.
-//   frameConst[0] = mul(view, projection)           frameConst[1] = mul(view, unjitteredProjection)
-//   frameConst[2] = mul(prevView, prevUnjitteredProjection)
-//   objConst[o]   = { mul(model, cullCam.viewProjection), mul(model, frameConst[0]), mul(model, cullCam.viewZ) }
-__global__ void __launch_bounds__(64) k_object_constants(brmi_scene_buffers sc, m4* frameConst, float* objConst) {
-    const uint32_t viewId = sc.perFrame->mainCameraIndex;
-    const brmi_camera* cam = sc.cameras + viewId;
-    const brmi_culling_camera* cc = sc.cullingCameras + viewId;
-    const m4 viewM = load_m4(&cam->view[0][0]);
-    const m4 viewProj = mul_mm(viewM, load_m4(&cam->projection[0][0]));
-    const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
-    if (o == 0) {
-        frameConst[0] = viewProj;
-        frameConst[1] = mul_mm(viewM, load_m4(&cam->unjitteredProjection[0][0]));
-        frameConst[2] = mul_mm(load_m4(&cam->prevView[0][0]), load_m4(&cam->prevUnjitteredProjection[0][0]));
-    }
-    if (o >= sc.perObjectCount) return;
-    const m4 model = load_m4(&sc.perObject[o].model[0][0]);
-    m4* dst = reinterpret_cast<m4*>(objConst + (size_t)o * 36u);
-    const m4 mvp = mul_mm(model, load_m4(&cc->viewProjection[0][0]));
-    const m4 otc = mul_mm(model, viewProj);
-    const f4 mvz = mul_mcol(model, f4{cc->viewZ[0], cc->viewZ[1], cc->viewZ[2], cc->viewZ[3]});
-    float* d = objConst + (size_t)o * 36u;
-    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { d[i * 4 + j] = mvp.m[i][j]; d[16 + i * 4 + j] = otc.m[i][j]; }
-    d[32] = mvz.x; d[33] = mvz.y; d[34] = mvz.z; d[35] = mvz.w;
-    (void)dst;
-}
-
 // K1 -------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_cull_instances(CullArgs a, NodeRecord* frontier0) {
     const brmi_scene_buffers& sc = a.sc;
@@ -836,6 +805,7 @@ __global__ void k_seed_phase2(uint32_t* counters, uint32_t capacity) {
 }
 
 int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
+    if (int rc = ensure_frame_constants(p, s)) return rc;
     if (phase != 1 && phase != 2) return fail(p, BRMI_ERR_INVALID, "brmi_cull: phase %u (1 or 2)", phase);
     if (phase == 2 && !p->cfg.enableOcclusionCulling) return fail(p, BRMI_ERR_STATE, "brmi_cull: phase 2 needs a pass created with enableOcclusionCulling");
     if (phase == 2 && !p->hzbValid) return fail(p, BRMI_ERR_STATE, "brmi_cull: phase 2 needs brmi_build_hzb on the phase-1 depth first");
@@ -864,7 +834,6 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
     const uint32_t* meshWidth = p->wsPtr<uint32_t>(p->ws.meshLevelWidth);
     if (phase == 1) {
         BRMI_HIP(p, hipMemsetAsync(p->counters(), 0, p->ws.frameClearBytes, s));      // counters + both survivor bitmasks
-        hipLaunchKernelGGL(k_object_constants, dim3((std::max(1u, p->scene.perObjectCount) + 63) / 64), dim3(64), 0, s, p->scene, p->wsPtr<m4>(p->ws.frameConst), p->wsPtr<float>(p->ws.objConst));
         const dim3 hgrid(std::min(std::max(1u, p->scene.activeDrawCount), 16384u));
         if (hierarchy) {
             // narrow meshes (most instances) with the 6 KB variant, wide ones with the 24 KB variant; each launch skips the other class

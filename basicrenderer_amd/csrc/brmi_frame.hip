@@ -1,0 +1,180 @@
+// brmi_frame.hip -- per-frame constants of the whole path in ONE launch.
+//
+// The reference's shaders rebuild these values in every thread; they only depend on the camera, the objects, the materials and
+// the lights, so they are evaluated once per brmi_update with the shaders' operation order and read back by the stages.  They
+// used to be five small kernels in three stages; a kernel that does a few hundred threads of work still costs ~5 us on MI355X,
+// so the five jobs share one launch, each taking a range of workgroups:
+//   object constants      frameConst[0..2], objConst[o] = {model * cullCam.viewProjection, model * (view * projection), model * viewZ}
+//   material words        the five packed G-buffer words of every constant-factor material
+//   material constants    per-material part of PopulateFragmentInfoFromOpenPBR
+//   shade tables          uv / cluster tile per column and row, first depth of every cluster slice
+//   light spheres         view-space bounding sphere of every active light
+#include "brmi_device.h"
+#include "brmi_internal.h"
+
+namespace brmi {
+
+// Frame / object constants ------------------------------------------------------------------------
+// The reference shaders rebuild these matrix products in every thread (softwareRaster.hlsl:336-337,
+// clodResolveCommon.hlsli:1531-1535,1697-1702).  They only depend on the camera and the object, so they
+// are evaluated once per frame / once per object with the same operation order and read back later.
+//   frameConst[0] = mul(view, projection)           frameConst[1] = mul(view, unjitteredProjection)
+//   frameConst[2] = mul(prevView, prevUnjitteredProjection)
+//   objConst[o]   = { mul(model, cullCam.viewProjection), mul(model, frameConst[0]), mul(model, cullCam.viewZ) }
+BRMI_DEV void job_object_constants(const brmi_scene_buffers& sc, m4* frameConst, float* objConst, uint32_t o) {
+    const uint32_t viewId = sc.perFrame->mainCameraIndex;
+    const brmi_camera* cam = sc.cameras + viewId;
+    const brmi_culling_camera* cc = sc.cullingCameras + viewId;
+    const m4 viewM = load_m4(&cam->view[0][0]);
+    const m4 viewProj = mul_mm(viewM, load_m4(&cam->projection[0][0]));
+    if (o == 0) {
+        frameConst[0] = viewProj;
+        frameConst[1] = mul_mm(viewM, load_m4(&cam->unjitteredProjection[0][0]));
+        frameConst[2] = mul_mm(load_m4(&cam->prevView[0][0]), load_m4(&cam->prevUnjitteredProjection[0][0]));
+    }
+    if (o >= sc.perObjectCount) return;
+    const m4 model = load_m4(&sc.perObject[o].model[0][0]);
+    m4* dst = reinterpret_cast<m4*>(objConst + (size_t)o * 36u);
+    const m4 mvp = mul_mm(model, load_m4(&cc->viewProjection[0][0]));
+    const m4 otc = mul_mm(model, viewProj);
+    const f4 mvz = mul_mcol(model, f4{cc->viewZ[0], cc->viewZ[1], cc->viewZ[2], cc->viewZ[3]});
+    float* d = objConst + (size_t)o * 36u;
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { d[i * 4 + j] = mvp.m[i][j]; d[16 + i * 4 + j] = otc.m[i][j]; }
+    d[32] = mvz.x; d[33] = mvz.y; d[34] = mvz.z; d[35] = mvz.w;
+    (void)dst;
+}
+
+// The constant-factor material of SampleMaterialEvalFromUvCache (no texture permutations) only depends on the material
+// record: its five packed G-buffer words are evaluated once per material per frame instead of once per pixel.
+BRMI_DEV void job_material_words(const brmi_scene_buffers& sc, MaterialWords* out, uint32_t i) {
+    if (i >= sc.materialCount) return;
+    const brmi_material_info* mat = sc.materials + i;
+    const f3 baseColor = f3{mat->baseColorFactor[0], mat->baseColorFactor[1], mat->baseColorFactor[2]} * f3{1.0f, 1.0f, 1.0f};
+    const float metallic = mat->metallicFactor, roughness = mat->roughnessFactor, ao = 1.0f;
+    const f3 emissiveIn{mat->emissiveFactor[0], mat->emissiveFactor[1], mat->emissiveFactor[2]};
+    const uint32_t opIndex = mat->openPBRMaterialDataIndex;
+    const brmi_openpbr_material_info* op = sc.openpbrMaterials + opIndex;
+    const f3 canonicalEmissive = f3{op->emissionColor[0], op->emissionColor[1], op->emissionColor[2]} * op->emissionLuminance;
+    const f3 coatColor = sat3(f3{op->coatColor[0], op->coatColor[1], op->coatColor[2]});
+    const float coatWeight = sat(op->coatWeight), coatRoughness = sat(op->coatRoughness);
+    const f3 fuzzColor = sat3(f3{op->fuzzColor[0], op->fuzzColor[1], op->fuzzColor[2]});
+    const float fuzzWeight = sat(op->fuzzWeight), fuzzRoughness = sat(op->fuzzRoughness);
+    const f3 emissive = dot3(emissiveIn, emissiveIn) > 0.0f ? emissiveIn : canonicalEmissive;
+    MaterialWords w;
+    w.albedo = pack_unorm4(baseColor.x, baseColor.y, baseColor.z, ao);
+    w.metallicRoughness = pack_unorm4(metallic, roughness, coatRoughness, fuzzWeight);
+    w.coat = pack_half4(coatColor.x, coatColor.y, coatColor.z, coatWeight);
+    w.emissive = pack_half4(emissive.x, emissive.y, emissive.z, 0.0f);
+    w.fuzz = pack_half4(fuzzColor.x, fuzzColor.y, fuzzColor.z, fuzzRoughness);
+    w.opIndexF = (float)opIndex; w.pad = 0u;
+    out[i] = w;
+}
+
+// view-space bounding spheres of the active lights, once per frame (testSphereAABB's transform, lightCulling.hlsl:15-21)
+BRMI_DEV void job_light_spheres(const brmi_scene_buffers& sc, float4* lightVS, uint32_t* lightMeta, uint32_t i) {
+    const brmi_per_frame* pf = sc.perFrame;
+    if (i >= pf->numLights) return;
+    const m4 view = load_m4(&sc.cameras[pf->mainCameraIndex].view[0][0]);
+    const uint32_t li = sc.activeLightIndices[i];
+    const brmi_light_info* l = sc.lights + li;
+    const f3 c = xyz(mul_point(f3{l->boundingSphere[0], l->boundingSphere[1], l->boundingSphere[2]}, view));
+    lightVS[i] = make_float4(c.x, c.y, c.z, l->boundingSphere[3]);
+    lightMeta[i] = (l->type & 3u) | (li << 2);
+}
+
+// Per-material part of PopulateFragmentInfoFromOpenPBR (utilities.hlsli:2590-2637): depends only on the
+// OpenPBR material record, so it is evaluated once per material per frame instead of once per pixel.
+BRMI_DEV void job_material_constants(const brmi_scene_buffers& sc, MatConst* out, uint32_t i) {
+    if (i >= sc.openpbrMaterialCount) return;
+    const brmi_openpbr_material_info* op = sc.openpbrMaterials + i;
+    MatConst m;
+    m.baseWeight = sat(op->baseWeight); m.specularWeight = sat(op->specularWeight);
+    m.specR = sat(op->specularColor[0]); m.specG = sat(op->specularColor[1]); m.specB = sat(op->specularColor[2]);
+    const float unscaledF0 = ior_to_f0(op->specularIor);
+    const float scaledF0 = min2(unscaledF0 * sat(m.specularWeight), 0.9999f);
+    const float safeF0 = min2(sat(scaledF0), 0.9999f);
+    const float sq = sqrtf(safeF0);
+    m.weightedSpecularIor = (1.0f + sq) / max2(1.0f - sq, 1.0e-4f);
+    m.dielF0Scalar = ior_to_f0(m.weightedSpecularIor);
+    m.coatF0Scalar = ior_to_f0(op->coatIor);
+    m.coatIor = op->coatIor; m.coatDarkening = sat(op->coatDarkening); m.baseDiffuseRoughness = sat(op->baseDiffuseRoughness); m.pad = 0.0f;
+    out[i] = m;
+}
+
+// Per-frame tables of the shading pass.  Everything here is what the shader computes per pixel from px, py or view depth
+// alone, evaluated once per column / row / slice with the shader's own (correctly rounded) arithmetic:
+//   uvx[px] = (px + 0.5) / resX     tileX[px] = (uint)(px / (resX / gx))       (lighting.hlsli cluster lookup)
+//   uvy[py], tileY[py] likewise
+//   sliceStart[s] = smallest view depth whose cluster slice is >= s (the slice formula is monotone in depth), s = 1..gz;
+//   sliceStart[0] = 0, sliceStart[gz + 1] = +inf.
+BRMI_DEV void job_shade_tables(const brmi_scene_buffers& sc, ShadeTables t, uint32_t W, uint32_t H, uint32_t i) {
+    const brmi_per_frame* pf = sc.perFrame;
+    const brmi_camera* cam = sc.cameras + pf->mainCameraIndex;
+    const float resX = (float)pf->screenResX, resY = (float)pf->screenResY;
+    const uint32_t gx = pf->lightClusterGridSizeX, gy = pf->lightClusterGridSizeY, gz = pf->lightClusterGridSizeZ;
+    const float tsx = resX / (float)gx, tsy = resY / (float)gy;
+    if (i < W) { t.uvx[i] = ((float)i + 0.5f) / resX; t.tileX[i] = (uint32_t)((float)i / tsx); }
+    if (i < H) { t.uvy[i] = ((float)i + 0.5f) / resY; t.tileY[i] = (uint32_t)((float)i / tsy); }
+    if (i <= gz + 1u) {
+        float b = 0.0f;
+        if (i == gz + 1u) b = __uint_as_float(0x7F800000u);
+        else if (i > 0u) {
+            const float zNear = cam->zNear, zFar = cam->zFar, zSplit = pf->clusterZSplitDepth;
+            const float logStart = logf(zSplit / zNear), logEnd = logf(zFar / zNear);
+            // bisection over the positive floats: lo fails, hi passes.  The search stops at 1e30 (z / zNear must stay finite for
+            // the float -> uint conversion of the formula to be defined); a slice that starts beyond it starts at +inf.
+            uint32_t lo = 0u, hi = __float_as_uint(1.0e30f);
+            if (cluster_slice_exact(1.0e30f, zNear, zSplit, logStart, logEnd, pf->nearClusterCount, gz) < i) lo = hi = 0x7F800000u;
+            while (hi - lo > 1u) {
+                const uint32_t mid = lo + ((hi - lo) >> 1);
+                if (cluster_slice_exact(__uint_as_float(mid), zNear, zSplit, logStart, logEnd, pf->nearClusterCount, gz) >= i) hi = mid; else lo = mid;
+            }
+            b = __uint_as_float(hi);
+        }
+        t.sliceStart[i] = b;
+    }
+}
+
+struct FrameJobs {
+    brmi_scene_buffers sc;
+    m4* frameConst; float* objConst; MaterialWords* matWords; MatConst* matConst; ShadeTables tables; float4* lightVS; uint32_t* lightMeta;
+    uint32_t W, H;
+    uint32_t firstBlock[6];      // block ranges of the five jobs
+};
+
+__global__ void __launch_bounds__(64) k_frame_constants(FrameJobs j) {
+    const uint32_t b = blockIdx.x;
+    if (b < j.firstBlock[1]) job_object_constants(j.sc, j.frameConst, j.objConst, (b - j.firstBlock[0]) * 64u + threadIdx.x);
+    else if (b < j.firstBlock[2]) job_material_words(j.sc, j.matWords, (b - j.firstBlock[1]) * 64u + threadIdx.x);
+    else if (b < j.firstBlock[3]) job_material_constants(j.sc, j.matConst, (b - j.firstBlock[2]) * 64u + threadIdx.x);
+    else if (b < j.firstBlock[4]) job_shade_tables(j.sc, j.tables, j.W, j.H, (b - j.firstBlock[3]) * 64u + threadIdx.x);
+    else job_light_spheres(j.sc, j.lightVS, j.lightMeta, (b - j.firstBlock[4]) * 64u + threadIdx.x);
+}
+
+ShadeTables shade_tables_of(const brmi_pass* p) {
+    uint32_t* tb = p->wsPtr<uint32_t>(p->ws.shadeTables);
+    const uint32_t W = p->cfg.width, H = p->cfg.height;
+    return ShadeTables{reinterpret_cast<float*>(tb), tb + W, reinterpret_cast<float*>(tb + 2 * W), tb + 2 * W + H, reinterpret_cast<float*>(tb + 2 * W + 2 * H)};
+}
+
+// Launches the constants kernel if brmi_update / brmi_set_scene happened since the last time (every stage calls this first).
+int ensure_frame_constants(brmi_pass* p, hipStream_t s) {
+    if (p->constantsSerial == p->updateSerial) return BRMI_OK;
+    if (p->pfHost.numLights > p->scene.lightCount) return fail(p, BRMI_ERR_INVALID, "perFrame.numLights (%u) exceeds the light buffer (%u)", p->pfHost.numLights, p->scene.lightCount);
+    FrameJobs j;
+    j.sc = p->scene; j.frameConst = p->wsPtr<m4>(p->ws.frameConst); j.objConst = p->wsPtr<float>(p->ws.objConst);
+    j.matWords = p->wsPtr<MaterialWords>(p->ws.matWords); j.matConst = p->wsPtr<MatConst>(p->ws.matConst); j.tables = shade_tables_of(p);
+    j.lightVS = p->wsPtr<float4>(p->ws.lightVS); j.lightMeta = p->wsPtr<uint32_t>(p->ws.lightMeta);
+    j.W = p->cfg.width; j.H = p->cfg.height;
+    auto blocks = [](uint32_t n) { return (std::max(1u, n) + 63u) / 64u; };
+    const uint32_t counts[5] = {blocks(p->scene.perObjectCount), blocks(p->scene.materialCount), blocks(p->scene.openpbrMaterialCount),
+                                blocks(std::max(std::max(j.W, j.H), 64u)), blocks(p->pfHost.numLights)};
+    j.firstBlock[0] = 0;
+    for (int k = 0; k < 5; k++) j.firstBlock[k + 1] = j.firstBlock[k] + counts[k];
+    hipLaunchKernelGGL(k_frame_constants, dim3(j.firstBlock[5]), dim3(64), 0, s, j);
+    BRMI_LAUNCH_CHECK(p, "k_frame_constants");
+    p->constantsSerial = p->updateSerial;
+    return BRMI_OK;
+}
+
+}  // namespace brmi

@@ -31,7 +31,7 @@ enum CounterIndex : uint32_t {
     CNT_SUM_TRIS_LO, CNT_SUM_TRIS_HI,
     CNT_RASTER_CLUSTERS,
     CNT_BIN_OVERFLOW,         // raster records that found their screen bin full (rasterised in place with global atomics)
-    CNT_UNUSED0,
+    CNT_DEFERRED_PIXELS_B,    // second deferred-pixel counter: shading calls alternate, each clears the other one for the next call
     CNT_DEFERRED_PIXELS,      // pixels the specialised shading kernel left to the general one
     CNT_RESOLVE_MARKED,       // the G-buffer pass marked the clusters that own a pixel (frames with more triangles than pixels)
     CNT_FRONTIER0 = 32,       // frontier sizes per BFS level: [CNT_FRONTIER0 + level]
@@ -61,6 +61,9 @@ struct ClusterSetup {                 // 64 B
     int32_t jointDelta, weightDelta;  // byte offsets of the cluster's joint / weight arrays (32 B per vertex) relative to nrmBase
 };
 constexpr uint32_t BRMI_CS_SKINNED = 1u << 25, BRMI_CS_JOINTS = 1u << 26, BRMI_CS_WEIGHTS = 1u << 27;
+// per-frame tables and per-material constants of the shading pass (brmi_frame.hip fills them, brmi_light.hip reads them)
+struct ShadeTables { float* uvx; uint32_t* tileX; float* uvy; uint32_t* tileY; float* sliceStart; };
+struct MatConst { float baseWeight, specularWeight, specR, specG, specB, weightedSpecularIor, dielF0Scalar, coatF0Scalar, coatIor, coatDarkening, baseDiffuseRoughness, pad; };
 constexpr uint32_t BRMI_ARENA_NONE = 0xFFFFFFFFu;
 // resolve arena: per-vertex and per-triangle tables of the visible clusters (brmi_resolve.hip)
 struct ResolveVertex { float px, py, pz, nx, ny, nz; };                                   // 24 B: object-space position, decoded normal
@@ -122,6 +125,8 @@ struct brmi_pass {
     static constexpr uint32_t kEventRing = 32;     // per-stage event pairs of the last kEventRing frames
     hipEvent_t evStart[BRMI_STAGE_COUNT][kEventRing] = {}, evStop[BRMI_STAGE_COUNT][kEventRing] = {};
     uint32_t evCount[BRMI_STAGE_COUNT] = {};       // recordings since the last brmi_stage_times()
+    uint32_t updateSerial = 1, constantsSerial = 0;  // brmi_update / brmi_set_scene bump updateSerial; the frame constants follow
+    uint32_t shadeSerial = 0;                        // parity selects the deferred-pixel counter of a shading call
     bool eventsCreated = false;
     uint32_t timedStages = 0xFFFFFFFFu;            // brmi_set_timed_stages
     std::string err;
@@ -137,6 +142,8 @@ int fail(brmi_pass* p, int code, const char* fmt, ...);
 #define BRMI_LAUNCH_CHECK(p, what) do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return brmi::fail((p), BRMI_ERR_HIP, "launch %s: %s", (what), hipGetErrorString(e_)); } while (0)
 
 // stage launchers (one translation unit each)
+int ensure_frame_constants(brmi_pass* p, hipStream_t s);
+ShadeTables shade_tables_of(const brmi_pass* p);
 int launch_clear(brmi_pass* p, hipStream_t s);
 int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s);
 int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s);

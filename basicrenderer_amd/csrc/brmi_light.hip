@@ -41,20 +41,6 @@ struct ClusterArgs {
     uint64_t* hitMasks; uint32_t maskWords;   // per cluster: one bit per light of the list
 };
 
-// view-space bounding spheres of the active lights, once per frame (testSphereAABB's transform, lightCulling.hlsl:15-21)
-__global__ void __launch_bounds__(64) k_lc_lights(ClusterArgs a) {
-    const brmi_scene_buffers& sc = a.sc;
-    const brmi_per_frame* pf = sc.perFrame;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= pf->numLights) return;
-    const m4 view = load_m4(&sc.cameras[pf->mainCameraIndex].view[0][0]);
-    const uint32_t li = sc.activeLightIndices[i];
-    const brmi_light_info* l = sc.lights + li;
-    const f3 c = xyz(mul_point(f3{l->boundingSphere[0], l->boundingSphere[1], l->boundingSphere[2]}, view));
-    a.lightVS[i] = make_float4(c.x, c.y, c.z, l->boundingSphere[3]);
-    a.lightMeta[i] = (l->type & 3u) | (li << 2);
-}
-
 BRMI_DEV bool light_hits_cluster(float4 sphere, uint32_t type, f3 mn, f3 mx) {
     if (type == BRMI_LIGHT_DIRECTIONAL) return true;
     if (type != BRMI_LIGHT_POINT && type != BRMI_LIGHT_SPOT) return false;
@@ -265,7 +251,6 @@ BRMI_DEV f3 specular_lobe(float roughness, f3 f0, float NoV, float NoL, float No
 constexpr float TBL = 32.0f, TBL_M1 = 31.0f, IOR_MAX = 2.5f, INV_IOR_MAX = 1.0f / 2.5f;
 BRMI_DEV float fon_a() { return 0.5f - 2.0f / (3.0f * PI_F); }
 BRMI_DEV float fon_b() { return 2.0f / 3.0f - 28.0f / (15.0f * PI_F); }
-BRMI_DEV float ior_to_f0(float ior) { const float s = max2(ior, 1.0f); const float f = (s - 1.0f) / (s + 1.0f); return f * f; }
 BRMI_DEV float ior_to_index(float ior) {
     const float safeIor = max2(ior, 1.0e-4f);
     const float half = 0.5f * TBL, halfM1 = half - 1.0f, inv = 1.0f / (IOR_MAX - 1.0f);
@@ -584,72 +569,6 @@ BRMI_DEV f3 light_contribution(const Luts& L, const Frag& f, const PixelCtx& c, 
     return brdf * lightColor * intensity * attenuation * spotAtt * NoL;
 }
 
-// Per-material part of PopulateFragmentInfoFromOpenPBR (utilities.hlsli:2590-2637): depends only on the
-// OpenPBR material record, so it is evaluated once per material per frame instead of once per pixel.
-struct MatConst { float baseWeight, specularWeight, specR, specG, specB, weightedSpecularIor, dielF0Scalar, coatF0Scalar, coatIor, coatDarkening, baseDiffuseRoughness, pad; };
-__global__ void __launch_bounds__(64) k_material_constants(brmi_scene_buffers sc, MatConst* out, uint32_t* counters) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) counters[CNT_DEFERRED_PIXELS] = 0u;      // the deferred-pixel list of the shading kernels starts empty
-    if (i >= sc.openpbrMaterialCount) return;
-    const brmi_openpbr_material_info* op = sc.openpbrMaterials + i;
-    MatConst m;
-    m.baseWeight = sat(op->baseWeight); m.specularWeight = sat(op->specularWeight);
-    m.specR = sat(op->specularColor[0]); m.specG = sat(op->specularColor[1]); m.specB = sat(op->specularColor[2]);
-    const float unscaledF0 = ior_to_f0(op->specularIor);
-    const float scaledF0 = min2(unscaledF0 * sat(m.specularWeight), 0.9999f);
-    const float safeF0 = min2(sat(scaledF0), 0.9999f);
-    const float sq = sqrtf(safeF0);
-    m.weightedSpecularIor = (1.0f + sq) / max2(1.0f - sq, 1.0e-4f);
-    m.dielF0Scalar = ior_to_f0(m.weightedSpecularIor);
-    m.coatF0Scalar = ior_to_f0(op->coatIor);
-    m.coatIor = op->coatIor; m.coatDarkening = sat(op->coatDarkening); m.baseDiffuseRoughness = sat(op->baseDiffuseRoughness); m.pad = 0.0f;
-    out[i] = m;
-}
-
-// Per-frame tables of the shading pass.  Everything here is what the shader computes per pixel from px, py or view depth
-// alone, evaluated once per column / row / slice with the shader's own (correctly rounded) arithmetic:
-//   uvx[px] = (px + 0.5) / resX     tileX[px] = (uint)(px / (resX / gx))       (lighting.hlsli cluster lookup)
-//   uvy[py], tileY[py] likewise
-//   sliceStart[s] = smallest view depth whose cluster slice is >= s (the slice formula is monotone in depth), s = 1..gz;
-//   sliceStart[0] = 0, sliceStart[gz + 1] = +inf.
-struct ShadeTables { float* uvx; uint32_t* tileX; float* uvy; uint32_t* tileY; float* sliceStart; };
-
-BRMI_DEV uint32_t cluster_slice_exact(float z, float zNear, float zSplit, float logStart, float logEnd, uint32_t nearSlices, uint32_t gz) {
-    if (z < zSplit) { const float t = (z - zNear) / (zSplit - zNear); return t > 0.0f ? (uint32_t)(t * (float)nearSlices) : 0u; }
-    const float logZ = logf(z / zNear);
-    const float u = (logZ - logStart) / (logEnd - logStart);
-    return nearSlices + (u > 0.0f ? (uint32_t)(u * (float)(gz - nearSlices)) : 0u);
-}
-
-__global__ void __launch_bounds__(256) k_shade_tables(brmi_scene_buffers sc, ShadeTables t, uint32_t W, uint32_t H) {
-    const brmi_per_frame* pf = sc.perFrame;
-    const brmi_camera* cam = sc.cameras + pf->mainCameraIndex;
-    const float resX = (float)pf->screenResX, resY = (float)pf->screenResY;
-    const uint32_t gx = pf->lightClusterGridSizeX, gy = pf->lightClusterGridSizeY, gz = pf->lightClusterGridSizeZ;
-    const float tsx = resX / (float)gx, tsy = resY / (float)gy;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < W) { t.uvx[i] = ((float)i + 0.5f) / resX; t.tileX[i] = (uint32_t)((float)i / tsx); }
-    if (i < H) { t.uvy[i] = ((float)i + 0.5f) / resY; t.tileY[i] = (uint32_t)((float)i / tsy); }
-    if (i <= gz + 1u) {
-        float b = 0.0f;
-        if (i == gz + 1u) b = __uint_as_float(0x7F800000u);
-        else if (i > 0u) {
-            const float zNear = cam->zNear, zFar = cam->zFar, zSplit = pf->clusterZSplitDepth;
-            const float logStart = logf(zSplit / zNear), logEnd = logf(zFar / zNear);
-            // bisection over the positive floats: lo fails, hi passes.  The search stops at 1e30 (z / zNear must stay finite for
-            // the float -> uint conversion of the formula to be defined); a slice that starts beyond it starts at +inf.
-            uint32_t lo = 0u, hi = __float_as_uint(1.0e30f);
-            if (cluster_slice_exact(1.0e30f, zNear, zSplit, logStart, logEnd, pf->nearClusterCount, gz) < i) lo = hi = 0x7F800000u;
-            while (hi - lo > 1u) {
-                const uint32_t mid = lo + ((hi - lo) >> 1);
-                if (cluster_slice_exact(__uint_as_float(mid), zNear, zSplit, logStart, logEnd, pf->nearClusterCount, gz) >= i) hi = mid; else lo = mid;
-            }
-            b = __uint_as_float(hi);
-        }
-        t.sliceStart[i] = b;
-    }
-}
-
 struct ShadeArgs {
     ShadeTables tables;
     brmi_scene_buffers sc;
@@ -662,6 +581,7 @@ struct ShadeArgs {
     const float* lutF;   // expanded tables: odE[32768] odAvg[1024] imE[1024] imAvg[32] unorm8[256]
     const MatConst* matConst;
     uint32_t* counters; uint32_t* deferred;   // pixels (band-relative tiled index) left to the general kernel
+    uint32_t deferredCounter, nextDeferredCounter;   // counter word of this call's deferred list / of the next call's (cleared here)
 };
 
 BRMI_DEV float half_at(unsigned long long v, int k) { return f16_bits_to_f32((uint32_t)(v >> (16 * k)) & 0xFFFFu); }
@@ -899,12 +819,13 @@ __global__ void __launch_bounds__(256, GENERAL ? 1 : BRMI_SHADE_WAVES) k_shade(S
             uint32_t npx = 0, npy = 0;
             const RawPixel nxt = (j + stride < end) ? fetch(j + stride, npx, npy) : empty_raw_pixel();
             const bool done = shade_pixel<false>(a, k, sliceStart, cur, a.firstPixel + j, px, py);
-            const uint32_t slot = wave_append(&a.counters[CNT_DEFERRED_PIXELS], !done);
+            const uint32_t slot = wave_append(&a.counters[a.deferredCounter], !done);
             if (!done) a.deferred[slot] = (uint32_t)j;
             cur = nxt; px = npx; py = npy;
         }
     } else {
-        const uint32_t n = a.counters[CNT_DEFERRED_PIXELS];
+        const uint32_t n = a.counters[a.deferredCounter];
+        if (blockIdx.x == 0 && threadIdx.x == 0) a.counters[a.nextDeferredCounter] = 0u;      // the next shading call starts with an empty list
         for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
             const uint64_t i = a.firstPixel + a.deferred[q];
             const uint32_t tile = (uint32_t)(i >> 6), within = (uint32_t)(i & 63u);
@@ -932,14 +853,13 @@ int launch_expand_luts(brmi_pass* p, hipStream_t s) {
 }
 
 int launch_light_clustering(brmi_pass* p, hipStream_t s) {
+    if (int rc = ensure_frame_constants(p, s)) return rc;
     ClusterArgs a;
     a.sc = p->scene; a.planes = p->wsPtr<float>(p->ws.planes);
     a.clusters = static_cast<brmi_light_cluster*>(p->res[BRMI_RES_LIGHT_CLUSTERS]); a.pages = static_cast<brmi_light_page*>(p->res[BRMI_RES_LIGHT_PAGES]);
     a.poolSize = p->lightPagePool; a.counters = p->counters();
     a.lightVS = p->wsPtr<float4>(p->ws.lightVS); a.lightMeta = p->wsPtr<uint32_t>(p->ws.lightMeta); a.clusterPages = p->wsPtr<uint32_t>(p->ws.clusterPages);
-    if (p->pfHost.numLights > p->scene.lightCount) return fail(p, BRMI_ERR_INVALID, "perFrame.numLights (%u) exceeds the light buffer (%u)", p->pfHost.numLights, p->scene.lightCount);
-    const uint32_t nl = std::max(1u, p->pfHost.numLights), nc = p->numLightClusters;
-    hipLaunchKernelGGL(k_lc_lights, dim3((nl + 63) / 64), dim3(64), 0, s, a);
+    const uint32_t nc = p->numLightClusters;
     a.clusterHits = p->wsPtr<uint32_t>(p->ws.clusterHits); a.pageTotal = p->wsPtr<uint32_t>(p->ws.pageTotal);
     a.hitMasks = p->wsPtr<uint64_t>(p->ws.lightHitMasks); a.maskWords = (std::max(1u, p->scene.lightCount) + 63u) / 64u;
     hipLaunchKernelGGL(k_lc_count, dim3((nc + 3) / 4), dim3(256), 0, s, a);
@@ -950,6 +870,7 @@ int launch_light_clustering(brmi_pass* p, hipStream_t s) {
 }
 
 int launch_shade(brmi_pass* p, hipStream_t s) {
+    if (int rc = ensure_frame_constants(p, s)) return rc;
     ShadeArgs a;
     a.sc = p->scene;
     a.depth = static_cast<const float*>(p->res[BRMI_RES_LINEAR_DEPTH]); a.normals = static_cast<const float4*>(p->res[BRMI_RES_GBUF_NORMALS]);
@@ -962,14 +883,11 @@ int launch_shade(brmi_pass* p, hipStream_t s) {
     a.enablePunctual = p->cfg.enablePunctualLights; a.clustered = p->cfg.enableClusteredLighting;
     a.lutF = p->wsPtr<float>(p->ws.lutF);
     a.matConst = p->wsPtr<MatConst>(p->ws.matConst);
-    {
-        uint32_t* tb = p->wsPtr<uint32_t>(p->ws.shadeTables);
-        const uint32_t W = p->cfg.width, H = p->cfg.height;
-        a.tables = ShadeTables{reinterpret_cast<float*>(tb), tb + W, reinterpret_cast<float*>(tb + 2 * W), tb + 2 * W + H, reinterpret_cast<float*>(tb + 2 * W + 2 * H)};
-        hipLaunchKernelGGL(k_shade_tables, dim3((std::max(std::max(W, H), 64u) + 255) / 256), dim3(256), 0, s, p->scene, a.tables, W, H);
-    }
-    hipLaunchKernelGGL(k_material_constants, dim3((std::max(1u, p->scene.openpbrMaterialCount) + 63) / 64), dim3(64), 0, s, p->scene, p->wsPtr<MatConst>(p->ws.matConst), p->counters());
+    a.tables = shade_tables_of(p);
     a.counters = p->counters(); a.deferred = p->wsPtr<uint32_t>(p->ws.deferredPixels);
+    a.deferredCounter = (p->shadeSerial & 1u) ? CNT_DEFERRED_PIXELS_B : CNT_DEFERRED_PIXELS;
+    a.nextDeferredCounter = (p->shadeSerial & 1u) ? CNT_DEFERRED_PIXELS : CNT_DEFERRED_PIXELS_B;
+    p->shadeSerial++;
     hipLaunchKernelGGL(k_shade<false>, dim3(4096), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_shade<true>, dim3(2048), dim3(256), 0, s, a);
     BRMI_LAUNCH_CHECK(p, "k_shade");

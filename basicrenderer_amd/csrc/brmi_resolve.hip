@@ -45,33 +45,6 @@ BRMI_DEV f3 oct_decode_normal(uint32_t packed) {
     return normalize3(v);
 }
 
-// The constant-factor material of SampleMaterialEvalFromUvCache (no texture permutations) only depends on the material
-// record: its five packed G-buffer words are evaluated once per material per frame instead of once per pixel.
-__global__ void __launch_bounds__(64) k_material_words(brmi_scene_buffers sc, MaterialWords* out) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= sc.materialCount) return;
-    const brmi_material_info* mat = sc.materials + i;
-    const f3 baseColor = f3{mat->baseColorFactor[0], mat->baseColorFactor[1], mat->baseColorFactor[2]} * f3{1.0f, 1.0f, 1.0f};
-    const float metallic = mat->metallicFactor, roughness = mat->roughnessFactor, ao = 1.0f;
-    const f3 emissiveIn{mat->emissiveFactor[0], mat->emissiveFactor[1], mat->emissiveFactor[2]};
-    const uint32_t opIndex = mat->openPBRMaterialDataIndex;
-    const brmi_openpbr_material_info* op = sc.openpbrMaterials + opIndex;
-    const f3 canonicalEmissive = f3{op->emissionColor[0], op->emissionColor[1], op->emissionColor[2]} * op->emissionLuminance;
-    const f3 coatColor = sat3(f3{op->coatColor[0], op->coatColor[1], op->coatColor[2]});
-    const float coatWeight = sat(op->coatWeight), coatRoughness = sat(op->coatRoughness);
-    const f3 fuzzColor = sat3(f3{op->fuzzColor[0], op->fuzzColor[1], op->fuzzColor[2]});
-    const float fuzzWeight = sat(op->fuzzWeight), fuzzRoughness = sat(op->fuzzRoughness);
-    const f3 emissive = dot3(emissiveIn, emissiveIn) > 0.0f ? emissiveIn : canonicalEmissive;
-    MaterialWords w;
-    w.albedo = pack_unorm4(baseColor.x, baseColor.y, baseColor.z, ao);
-    w.metallicRoughness = pack_unorm4(metallic, roughness, coatRoughness, fuzzWeight);
-    w.coat = pack_half4(coatColor.x, coatColor.y, coatColor.z, coatWeight);
-    w.emissive = pack_half4(emissive.x, emissive.y, emissive.z, 0.0f);
-    w.fuzz = pack_half4(fuzzColor.x, fuzzColor.y, fuzzColor.z, fuzzRoughness);
-    w.opIndexF = (float)opIndex; w.pad = 0u;
-    out[i] = w;
-}
-
 // Scenes of pixel-sized triangles (Zorah-class) have far more triangles in their visible clusters than pixels on screen; setting
 // up every triangle of every visible cluster would cost more than it saves.  When the frame is of that kind (decided on the
 // device from the counters) this pass marks the clusters that own at least one pixel, and the setup kernel skips the rest.
@@ -296,6 +269,7 @@ __global__ void __launch_bounds__(256) k_gbuffer(GBufferArgs a) {
 }
 
 int launch_gbuffer(brmi_pass* p, hipStream_t s) {
+    if (int rc = ensure_frame_constants(p, s)) return rc;
     GBufferArgs a;
     a.sc = p->scene; a.clusters = static_cast<const uint4*>(p->res[BRMI_RES_VISIBLE_CLUSTERS]); a.counters = p->counters();
     a.vis = static_cast<const unsigned long long*>(p->res[BRMI_RES_VISIBILITY]);
@@ -309,7 +283,6 @@ int launch_gbuffer(brmi_pass* p, hipStream_t s) {
     a.setup = p->wsPtr<ClusterSetup>(p->ws.clusterSetup); a.verts = p->wsPtr<ResolveVertex>(p->ws.resolveVerts); a.tris = p->wsPtr<ResolveTriangle>(p->ws.resolveTris);
     a.vertCapacity = p->resolveCapacity; a.triCapacity = p->resolveCapacity;
     a.matWords = p->wsPtr<MaterialWords>(p->ws.matWords);
-    hipLaunchKernelGGL(k_material_words, dim3((std::max(1u, p->scene.materialCount) + 63) / 64), dim3(64), 0, s, p->scene, a.matWords);
     a.used = p->wsPtr<uint8_t>(p->ws.usedClusters);
     hipLaunchKernelGGL(k_mark_used_clusters, dim3(2048), dim3(256), 0, s, a, p->wsPtr<uint8_t>(p->ws.usedClusters), p->counters());
     hipLaunchKernelGGL(k_resolve_setup, dim3(8192), dim3(64), 0, s, a);

@@ -73,6 +73,7 @@ def main():
     composer = compose.BandComposer(hdr, band, W, 8) if n > 1 else None     # all-gather of frame k overlaps the rendering of frame k + 1
 
     def step():
+        r.update()                      # the per-frame Update phase (camera / per-frame constants), as the reference's passes run it every frame
         r.execute()
         if composer:
             composer.submit()
