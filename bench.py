@@ -41,6 +41,7 @@ def main():
                     help="2-phase HZB occlusion culling (reference default: on, BR/include/Renderer.h:220); timed frames are steady state")
     ap.add_argument("--lod-builder", default="quadtree", choices=["quadtree", "clusterlod"],
                     help="clusterlod: mesh LOD DAGs from the reference's own builder (oracle/_ref/libclodref.so) instead of the generator's quadtree")
+    ap.add_argument("--force-compose", action="store_true", help="run the RCCL band composition even with one rank (checks the collective path on a single GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scale", type=float, default=1.0, help="fraction of the frame height the CPU baseline renders")
     args = ap.parse_args()
@@ -54,9 +55,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or args.force_compose:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
     n = world
     assert n == args.gpus or world == 1, "--gpus must equal WORLD_SIZE"
     torch.cuda.set_device(local_rank)
@@ -70,7 +73,7 @@ def main():
 
     hdr = r.hdr_tensor()
     lo, hi = compose.band_byte_range(band, W, 8)
-    composer = compose.BandComposer(hdr, band, W, 8) if n > 1 else None     # all-gather of frame k overlaps the rendering of frame k + 1
+    composer = compose.BandComposer(hdr, band, W, 8) if (n > 1 or args.force_compose) else None     # all-gather of frame k overlaps the rendering of frame k + 1
 
     def step():
         r.update()                      # the per-frame Update phase (camera / per-frame constants), as the reference's passes run it every frame
@@ -154,7 +157,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(scene, args.cpu_scale)
         print(json.dumps(out), flush=True)
     r.close()
-    if world > 1:
+    if world > 1 or args.force_compose:
         dist.destroy_process_group()
 
 
