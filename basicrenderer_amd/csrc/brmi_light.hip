@@ -889,7 +889,7 @@ int launch_shade(brmi_pass* p, hipStream_t s) {
     a.nextDeferredCounter = (p->shadeSerial & 1u) ? CNT_DEFERRED_PIXELS : CNT_DEFERRED_PIXELS_B;
     p->shadeSerial++;
     hipLaunchKernelGGL(k_shade<false>, dim3(4096), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_shade<true>, dim3(2048), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_shade<true>, dim3(512), dim3(256), 0, s, a);
     BRMI_LAUNCH_CHECK(p, "k_shade");
     return BRMI_OK;
 }

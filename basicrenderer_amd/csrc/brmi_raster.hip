@@ -467,7 +467,7 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
     a.bigTriArea = p->bigTriArea; a.debugFlags = p->rasterDebug;
     hipLaunchKernelGGL(k_raster, dim3(p->rasterGrid), dim3(64), 0, s, a);
     if (!(p->rasterDebug & 4)) hipLaunchKernelGGL(k_raster_bins, dim3(p->binsX, p->binsY), dim3(BRMI_BIN_THREADS), 0, s, a);
-    hipLaunchKernelGGL(k_raster_overflow, dim3(1024), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_raster_overflow, dim3(512), dim3(64), 0, s, a);
     BRMI_LAUNCH_CHECK(p, "k_raster");
     return BRMI_OK;
 }
