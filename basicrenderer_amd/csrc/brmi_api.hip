@@ -288,6 +288,9 @@ int brmi_setup(brmi_pass* p, const brmi_resource_binding* b, uint32_t n, brmi_st
         if ((reinterpret_cast<uintptr_t>(p->res[i]) & 15u) != 0) return fail(p, BRMI_ERR_INVALID, "brmi_setup: resource %s must be 16-byte aligned", kResNames[i]);
     }
     BRMI_HIP(p, hipMemsetAsync(p->res[BRMI_RES_WORKSPACE], 0, p->ws.total, s));
+    // the depth chain starts out "empty" everywhere; a multi-GPU band only ever rewrites the texels its rows reach
+    if (p->cfg.enableOcclusionCulling && p->resNeed[BRMI_RES_HZB] >= 4) BRMI_HIP(p, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p->res[BRMI_RES_HZB]), (int)BRMI_DEPTH_EMPTY_BITS, p->resNeed[BRMI_RES_HZB] / 4, s));
+    p->hzbValid = false;
     if (!p->hostInstanceBitBase.empty()) BRMI_HIP(p, hipMemcpyAsync(p->wsPtr<uint32_t>(p->ws.instanceBitBase), p->hostInstanceBitBase.data(), p->hostInstanceBitBase.size() * 4, hipMemcpyHostToDevice, s));
     if (!p->hostSegPrefix.empty()) BRMI_HIP(p, hipMemcpyAsync(p->wsPtr<uint32_t>(p->ws.segPrefix), p->hostSegPrefix.data(), p->hostSegPrefix.size() * 4, hipMemcpyHostToDevice, s));
     if (!p->hostMeshLevelWidth.empty()) BRMI_HIP(p, hipMemcpyAsync(p->wsPtr<uint32_t>(p->ws.meshLevelWidth), p->hostMeshLevelWidth.data(), p->hostMeshLevelWidth.size() * 4, hipMemcpyHostToDevice, s));

@@ -20,11 +20,11 @@ BRMI_DEV float key_depth(unsigned long long k) { return (k == BRMI_VIS_EMPTY) ? 
 // FROM_VIS: the source is the visibility buffer; the linear depth of the four texels (K6, gbuffer.hlsl:114-161) is written to
 // the depth map on the way.  `skipUnless` (may be null): the launch does nothing when that counter is zero.
 template <bool FROM_VIS>
-__global__ void __launch_bounds__(256) k_hzb_head(HzbDesc h, const unsigned long long* vis, float* depthOut, const uint32_t* skipUnless) {
+__global__ void __launch_bounds__(256) k_hzb_head(HzbDesc h, const unsigned long long* vis, float* depthOut, const uint32_t* skipUnless, uint32_t blockRow0) {
     if (skipUnless && *skipUnless == 0u) return;
     __shared__ float lvl[16 * 16];
     const uint32_t tx = threadIdx.x >> 4, ty = threadIdx.x & 15u;             // ty fastest: follows the column-major tile layout
-    const uint32_t bx = blockIdx.x, by = blockIdx.y;
+    const uint32_t bx = blockIdx.x, by = blockIdx.y + blockRow0;      // only the 32-row strips that touch this GPU's band are launched
     const uint32_t x1 = bx * 16u + tx, y1 = by * 16u + ty;                    // mip-1 texel
     float v;
     {
@@ -112,9 +112,11 @@ int launch_hzb(brmi_pass* p, hipStream_t s, bool fromVisibility, bool onlyIfPhas
     const uint32_t* skip = onlyIfPhase2Drew ? p->counters() + CNT_VISIBLE2 : nullptr;
     uint32_t first = 1;
     if (head) {
-        const dim3 grid(h.paddedW / 32, h.paddedH / 32);
-        if (fromVisibility) hipLaunchKernelGGL(k_hzb_head<true>, grid, dim3(256), 0, s, h, static_cast<const unsigned long long*>(p->res[BRMI_RES_VISIBILITY]), static_cast<float*>(p->res[BRMI_RES_LINEAR_DEPTH]), skip);
-        else hipLaunchKernelGGL(k_hzb_head<false>, grid, dim3(256), 0, s, h, (const unsigned long long*)nullptr, (float*)nullptr, skip);
+        // texels of mips 1-5 outside the band's 32-row strips never change: brmi_setup filled the chain with "empty"
+        const uint32_t row0 = h.rowLo / 32u, row1 = std::min((h.rowHi + 31u) / 32u, h.paddedH / 32u);
+        const dim3 grid(h.paddedW / 32, std::max(1u, row1 - row0));
+        if (fromVisibility) hipLaunchKernelGGL(k_hzb_head<true>, grid, dim3(256), 0, s, h, static_cast<const unsigned long long*>(p->res[BRMI_RES_VISIBILITY]), static_cast<float*>(p->res[BRMI_RES_LINEAR_DEPTH]), skip, row0);
+        else hipLaunchKernelGGL(k_hzb_head<false>, grid, dim3(256), 0, s, h, (const unsigned long long*)nullptr, (float*)nullptr, skip, row0);
         first = 6;
     }
     if (first < h.mipCount) hipLaunchKernelGGL(k_hzb_tail, dim3(1), dim3(1024), 0, s, h, first, skip);

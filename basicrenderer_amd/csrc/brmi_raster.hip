@@ -254,6 +254,10 @@ __global__ void __launch_bounds__(64, BRMI_RASTER_WAVES) k_raster(RasterArgs a) 
             const int nStrips = strip1 - strip0 + 1;
             const int entries = (big && yLo <= yHi) ? (band1 - band0 + 1) * nStrips : 0;
             const uint32_t flags = t | (useScanlineRanges ? 0x100u : 0u);
+            // row start at the first row of this GPU's band: the serial loop's additions from the box top, made once per triangle with
+            // all lanes stepping side by side (a lower band of a multi-GPU frame starts thousands of rows below the top of a large box)
+            float band_b0 = row_b0, band_b1 = row_b1;
+            if (entries > 0) for (int y = minY; y < yLo; y++) { band_b0 += dy_b0; band_b1 += dy_b1; }
             // Small boxes: global atomics.  lane = triangle leaves most lanes idle (culled triangles, boxes of very different
             // size), so the rows of the batch's small triangles are re-dealt to the lanes: an exclusive scan of the row counts,
             // the setup of every triangle parked in LDS, then lane k takes rows k, k + 64, ... of the concatenated row list.
@@ -313,9 +317,8 @@ __global__ void __launch_bounds__(64, BRMI_RASTER_WAVES) k_raster(RasterArgs a) 
                 }
                 if (few) {
                     // step the row start band by band (the additions of the serial loop) and append one record per band and strip
-                    float sb0 = row_b0, sb1 = row_b1;
-                    int py = minY;
-                    for (; py < yLo; py++) { sb0 += dy_b0; sb1 += dy_b1; }
+                    float sb0 = band_b0, sb1 = band_b1;
+                    int py = yLo;
                     while (py <= yHi) {
                         const int band = py >> BIN_ROWS_SHIFT;
                         const int n = min(((band + 1) << BIN_ROWS_SHIFT), yHi + 1) - py;
@@ -339,13 +342,13 @@ __global__ void __launch_bounds__(64, BRMI_RASTER_WAVES) k_raster(RasterArgs a) 
             while (coop != 0ull) {
                 const int src = __ffsll((unsigned long long)coop) - 1;
                 coop &= coop - 1ull;
-                const float c_sb0 = __shfl(row_b0, src), c_sb1 = __shfl(row_b1, src), c_dx0 = __shfl(dx_b0, src), c_dx1 = __shfl(dx_b1, src);
+                const float c_sb0 = __shfl(band_b0, src), c_sb1 = __shfl(band_b1, src), c_dx0 = __shfl(dx_b0, src), c_dx1 = __shfl(dx_b1, src);
                 const float c_dy0 = __shfl(dy_b0, src), c_dy1 = __shfl(dy_b1, src), c_d0 = __shfl(d0, src), c_d1 = __shfl(d1, src), c_d2 = __shfl(d2, src);
-                const int c_minX = __shfl(minX, src), c_minY = __shfl(minY, src), c_w = __shfl(rectWidth, src), c_yLo = __shfl(yLo, src), c_yHi = __shfl(yHi, src);
+                const int c_minX = __shfl(minX, src), c_w = __shfl(rectWidth, src), c_yLo = __shfl(yLo, src), c_yHi = __shfl(yHi, src);
                 const int c_band0 = __shfl(band0, src), c_band1 = __shfl(band1, src), c_strip0 = __shfl(strip0, src), c_strip1 = __shfl(strip1, src);
                 const uint32_t c_flags = (uint32_t)__shfl((int)flags, src);
                 float sb0 = c_sb0, sb1 = c_sb1;
-                int py = c_minY;
+                int py = c_yLo;
                 for (int band = c_band0 + (int)lane; band <= c_band1; band += 64) {
                     const int start = max(band << BIN_ROWS_SHIFT, c_yLo);
                     for (; py < start; py++) { sb0 += c_dy0; sb1 += c_dy1; }
@@ -354,7 +357,15 @@ __global__ void __launch_bounds__(64, BRMI_RASTER_WAVES) k_raster(RasterArgs a) 
                     r.clusterIndex = clusterIndex; r.triAndFlags = c_flags | ((uint32_t)n << 16);
                     r.minX = c_minX; r.rectWidth = c_w; r.rowStart = start;
                     r.sb0 = sb0; r.sb1 = sb1; r.dx_b0 = c_dx0; r.dx_b1 = c_dx1; r.dy_b0 = c_dy0; r.dy_b1 = c_dy1; r.d0 = c_d0; r.d1 = c_d1; r.d2 = c_d2; r.pad0 = 0; r.pad1 = 0;
-                    for (int st = c_strip0; st <= c_strip1; st++) bin_append(a, r, (uint32_t)st, (uint32_t)band);
+                    // all the band's bin slots are requested before the first one is used: the atomics overlap instead of costing one
+                    // round trip per strip (a full-width triangle touches 15-30 strips)
+                    for (int st0 = c_strip0; st0 <= c_strip1; st0 += 8) {
+                        uint32_t slots[8];
+#pragma unroll
+                        for (int k = 0; k < 8; k++) slots[k] = (st0 + k <= c_strip1) ? atomicAdd(&a.binCounts[(uint32_t)band * a.binsX + (uint32_t)(st0 + k)], 1u) : 0u;
+#pragma unroll
+                        for (int k = 0; k < 8; k++) if (st0 + k <= c_strip1) bin_store(a, r, (uint32_t)(st0 + k), (uint32_t)band, slots[k]);
+                    }
                 }
             }
         }
