@@ -475,3 +475,50 @@ def test_per_level_traversal_kernels_match(name, scenes, oracle_frames):
     assert np.array_equal(r.visible_clusters(), o.clusters[: o.count])
     assert np.array_equal(r.visibility(), o.vis)
     r.close()
+
+
+# ---- seeded sweep over odd sizes and option mixes ---------------------------------------------------------------------
+SWEEP = [
+    # (preset, W, H, Scene kwargs, renderer kwargs)
+    ("tiny", 333, 187, dict(seed=11, point_lights=5, lod_levels=3, material_features=1), dict()),
+    ("tiny", 97, 61, dict(seed=12, point_lights=1, directional=False, skinned_fraction=1.0), dict(occlusion=True)),
+    ("sponza", 517, 293, dict(seed=13, point_lights=40, size_scale=0.12, lod_levels=2, material_features=2), dict(occlusion=True)),
+    ("sponza", 1000, 96, dict(seed=14, point_lights=7, size_scale=0.08), dict()),
+    ("bistro", 408, 600, dict(seed=15, point_lights=90, size_scale=0.25, skinned_fraction=0.5, material_features=3), dict(occlusion=True)),
+    ("zorah", 640, 360, dict(seed=16, point_lights=12, size_scale=0.004, skinned_fraction=0.0), dict()),
+]
+
+
+@pytest.mark.parametrize("case", range(len(SWEEP)))
+def test_seeded_sweep_whole_frame(case):
+    """Odd target sizes (not multiples of the 8x8 tile, the 16-row band or the 256-pixel strip), other seeds, every option
+    mix: the whole frame against the oracle -- cluster list, keys, depth, normals exact, HDR within one fp16 ULP."""
+    import orc
+    from basicrenderer_amd import Scene
+    from basicrenderer_amd.renderer import VisibilityRenderer
+    preset, W, H, skw, rkw = SWEEP[case]
+    sc = Scene(preset, W, H, **skw)
+    r = VisibilityRenderer(sc, stats=True, **rkw)
+    o = orc.OracleFrame(sc)
+    if rkw.get("occlusion"):
+        hz = None
+        for _ in range(2):
+            r.execute()
+            hz = o.run_occlusion(hz)
+        o.gbuffer(); o.light_cluster(); o.shade()
+    else:
+        r.execute()
+        o.run()
+    c = r.counters()
+    assert c.droppedRecords == 0 and c.droppedClusters == 0
+    assert np.array_equal(r.visible_clusters(), o.clusters[: o.count])
+    assert np.array_equal(r.visibility(), o.vis)
+    assert np.array_equal(r.depth().view(np.uint32), o.depth.view(np.uint32))
+    covered = o.vis != np.uint64(0xFFFFFFFFFFFFFFFF)
+    g = r.gbuffer()
+    assert np.array_equal(g["normals"][covered].view(np.uint32), o.normals[covered].view(np.uint32))
+    assert np.array_equal(g["motion"][covered], o.motion[covered])
+    a = r.hdr().view(np.uint16).reshape(H, W, 4)[covered]
+    b = o.hdr.view(np.uint16).reshape(H, W, 4)[covered]
+    assert _half_ulp_distance(a, b).max() <= 1
+    r.close()

@@ -1,0 +1,29 @@
+#!/bin/bash
+# Builds the scene generator and the CPU oracle with AddressSanitizer + UBSan and runs two occlusion frames of three scenes
+# (GPU sanitizers are not available on the pool; the CPU side is what can be checked this way).
+set -e
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+OUT=${TMPDIR:-/tmp}/brmi_asan
+mkdir -p $OUT
+g++ -O1 -g -std=c++17 -fPIC -shared -I$ROOT/include -fsanitize=address,undefined -fno-omit-frame-pointer $ROOT/basicrenderer_amd/csrc/scene/scene_gen.cpp -o $OUT/libbrmi_scene.so -ldl
+g++ -O1 -g -std=c++17 -fPIC -shared -I$ROOT/include -I$ROOT/oracle -ffp-contract=off -fopenmp -fsanitize=address,undefined -fno-omit-frame-pointer $ROOT/oracle/*.cpp -o $OUT/liboracle.so
+cat > $OUT/run.py <<PY
+import sys
+sys.path.insert(0, "$ROOT"); sys.path.insert(0, "$ROOT/tests")
+import basicrenderer_amd.capi as capi
+capi.LIB_DIR = "$OUT"
+import orc
+orc.ORACLE_SO = "$OUT/liboracle.so"
+from basicrenderer_amd import Scene
+import os
+cases = [dict(preset="tiny", width=200, height=120, point_lights=3, skinned_fraction=1.0, lod_levels=2),
+         dict(preset="sponza", width=320, height=180, point_lights=16, size_scale=0.1, material_features=3)]
+if os.path.exists("$ROOT/oracle/_ref/libclodref.so"):
+    cases.append(dict(preset="bistro", width=320, height=180, point_lights=16, size_scale=0.2, skinned_fraction=0.3, lod_builder="clusterlod"))
+for kw in cases:
+    o = orc.OracleFrame(Scene(**kw), threads=2)
+    hz = o.run_occlusion(None); hz = o.run_occlusion(hz)
+    o.gbuffer(); o.light_cluster(); o.shade()
+    print(kw["preset"], "clean,", o.count, "clusters")
+PY
+BRMI_CLODREF_LIB=$ROOT/oracle/_ref/libclodref.so ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD=$(g++ -print-file-name=libasan.so):$(g++ -print-file-name=libubsan.so) python3 $OUT/run.py
