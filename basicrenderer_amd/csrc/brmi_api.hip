@@ -54,6 +54,7 @@ static void compute_sizes(brmi_pass* p) {
     { const uint32_t t0 = p->bandY0 / 8, t1 = (p->bandY1 + 7) / 8; p->bandFirstPixel = (uint64_t)t0 * p->tilesX * 64; p->bandPixelCount = (uint64_t)(t1 - t0) * p->tilesX * 64; }
     p->numLightClusters = c.lightClusterSize[0] * c.lightClusterSize[1] * c.lightClusterSize[2];
     p->lightPagePool = p->numLightClusters * BRMI_LIGHT_PAGES_PER_CLUSTER;
+    if (const char* e = std::getenv("BRMI_LIGHT_PAGE_POOL")) p->lightPagePool = (uint32_t)std::max(1, std::atoi(e));   // tests: exhaust the page pool
     for (int i = 0; i < BRMI_RES_COUNT; i++) p->resNeed[i] = 0;
     for (int i = BRMI_RES_VISIBILITY; i <= BRMI_RES_HDR_COLOR; i++) p->resNeed[i] = p->paddedPixels * kResBpp[i];
     p->resNeed[BRMI_RES_VISIBLE_CLUSTERS] = (uint64_t)c.maxVisibleClusters * 16;

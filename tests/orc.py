@@ -140,11 +140,11 @@ class OracleFrame:
         lib().orc_cluster_planes(C.c_float(zNear), C.c_float(zFar), u32(gz), u32(nearSlices), C.c_float(zSplit), P(planes))
         return planes
 
-    def light_cluster(self):
+    def light_cluster(self, pool=None):
         pf = self.scene.arrays["perFrame"].view(np.uint32)
         gx, gy, gz = int(pf[15]), int(pf[16]), int(pf[17])
         n = gx * gy * gz
-        self.pool = n * 10
+        self.pool = pool or n * 10
         self.light_clusters = np.zeros((n, 12), dtype=np.uint32)
         self.light_pages = np.zeros((self.pool, 14), dtype=np.uint32)
         used = u32(0)

@@ -109,6 +109,31 @@ def test_light_lists_exact(name, gpu_frames, oracle_frames):
         assert np.array_equal(gp[pg, : 2 + n], o.light_pages[pg, : 2 + n]), f"page {pg}"
 
 
+@pytest.mark.parametrize("pool", [5000, 3456 + 40, 700])
+def test_light_page_pool_exhaustion_matches_the_serial_allocator(pool, scenes):
+    """With fewer pages than the clusters ask for, the reference's allocator runs dry part-way through a cluster (`break`): the
+    cluster keeps its full pages only.  Same clusters, same pages, same lit image as the oracle's serial loop."""
+    import orc
+    from basicrenderer_amd.renderer import VisibilityRenderer
+    sc = scenes("sponza_small")                       # 64 point lights: clusters with several pages
+    with _Env(BRMI_LIGHT_PAGE_POOL=pool):
+        r = VisibilityRenderer(sc, stats=True)
+    r.execute()
+    o = orc.OracleFrame(sc)
+    o.cull(); o.raster(); o.depth_copy(); o.gbuffer(); o.light_cluster(pool=pool); o.shade()
+    gc, gp = r.light_clusters()
+    assert np.array_equal(gc[:, :10], o.light_clusters[:, :10])
+    assert r.counters().lightPagesUsed == o.pages_used
+    for pg in range(o.pages_used):
+        n = int(o.light_pages[pg, 1])
+        assert np.array_equal(gp[pg, : 2 + n], o.light_pages[pg, : 2 + n]), f"page {pg}"
+    covered = o.vis != np.uint64(0xFFFFFFFFFFFFFFFF)
+    a = r.hdr().view(np.uint16).reshape(o.H, o.W, 4)[covered]
+    b = o.hdr.view(np.uint16).reshape(o.H, o.W, 4)[covered]
+    assert _half_ulp_distance(a, b).max() <= 1
+    r.close()
+
+
 def _half_ulp_distance(a_bits, b_bits):
     def key(h):
         h = h.astype(np.int32)
