@@ -161,28 +161,11 @@ def main():
         dist.destroy_process_group()
 
 
-def effective_cores():
-    """Host cores this process may actually use: the affinity mask, capped by the cgroup CPU quota of the container."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        if quota != "max":
-            n = min(n, max(1, int(quota) // int(period)))
-    except (OSError, ValueError):
-        try:
-            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-            if q > 0:
-                n = min(n, max(1, q // per))
-        except (OSError, ValueError):
-            pass
-    return n
-
-
 def cpu_baseline(scene, scale):
     """The CPU oracle (port of the reference HLSL) on the same frame, all host cores, one frame."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc
-    cores = effective_cores()
+    cores = orc.effective_cores()
     f = orc.OracleFrame(scene, threads=cores)
     H = scene.height
     rows = max(8, int(H * scale) // 8 * 8)

@@ -33,6 +33,23 @@ def lib():
     return _lib
 
 
+def effective_cores():
+    """Host cores this process may actually use: the affinity mask, capped by the cgroup CPU quota of the container."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def P(a):
     return a.ctypes.data_as(vp) if a is not None else None
 
@@ -43,7 +60,7 @@ class OracleFrame:
     def __init__(self, scene, threads=None, capacity=1 << 22):
         self.scene, self.W, self.H = scene, scene.width, scene.height
         self.sb = scene.host_buffers()
-        self.threads = threads or os.cpu_count()
+        self.threads = threads or effective_cores()
         self.capacity = capacity
         self.clusters = np.zeros((capacity, 4), dtype=np.uint32)
         self.count = 0
