@@ -310,18 +310,19 @@ BRMI_DEV f3 lut_fuzz_ltc(const Luts& L, float roughness, float cosT) {
     return sample_ltc(L.ltc, u, v);
 }
 // Bilinear fetch with the row (v) part prepared once: identical arithmetic to sample_u16, split in two.
-struct LutRows { const float* r0; const float* r1; float fy; };
-BRMI_DEV LutRows prep_rows(const float* t, uint32_t H, float v) {
+// Rows are 32-bit offsets into the expanded-table buffer (one SGPR base + VGPR offset per load) rather than 64-bit pointers.
+struct LutRows { uint32_t r0, r1; float fy; };
+BRMI_DEV LutRows prep_rows(uint32_t tableOffset, uint32_t H, float v) {
     const float y = v * (float)H - 0.5f;
     const float y0f = floorf(y);
-    return LutRows{t + clamp_texel(y0f, H) * 32u, t + clamp_texel(y0f + 1.0f, H) * 32u, y - y0f};
+    return LutRows{tableOffset + clamp_texel(y0f, H) * 32u, tableOffset + clamp_texel(y0f + 1.0f, H) * 32u, y - y0f};
 }
-BRMI_DEV float sample_rows(const LutRows& r, float u) {
+BRMI_DEV float sample_rows(const float* lut, const LutRows& r, float u) {
     const float x = u * 32.0f - 0.5f;
     const float x0f = floorf(x);
     const float fx = x - x0f;
     const uint32_t x0 = clamp_texel(x0f, 32), x1 = clamp_texel(x0f + 1.0f, 32);
-    return lerpf(lerpf(r.r0[x0], r.r0[x1], fx), lerpf(r.r1[x0], r.r1[x1], fx), r.fy);
+    return lerpf(lerpf(lut[r.r0 + x0], lut[r.r0 + x1], fx), lerpf(lut[r.r1 + x0], lut[r.r1 + x1], fx), r.fy);
 }
 // lut_od_e with (ior, alpha) prepared
 struct OdPrep { LutRows s0, s1; float st, ior; };
@@ -330,14 +331,14 @@ BRMI_DEV OdPrep prep_od_e(const Luts& L, float ior, float alpha) {
     const int s0 = (int)floorf(ei);
     const int s1 = (s0 + 1) < 31 ? (s0 + 1) : 31;
     const float v = remap_index(ea);
-    return OdPrep{prep_rows(L.odE + (size_t)s0 * 1024u, 32, v), prep_rows(L.odE + (size_t)s1 * 1024u, 32, v), ei - (float)s0, ior};
+    return OdPrep{prep_rows((uint32_t)s0 * 1024u, 32, v), prep_rows((uint32_t)s1 * 1024u, 32, v), ei - (float)s0, ior};      // odE starts the buffer
 }
-BRMI_DEV float sample_od_e(const OdPrep& p, float cosT) {
+BRMI_DEV float sample_od_e(const Luts& L, const OdPrep& p, float cosT) {
     const float u = remap_index(clamp_index(cos_to_index(cosT)));
-    return extrapolate_ior(lerpf(sample_rows(p.s0, u), sample_rows(p.s1, u), p.st), p.ior);
+    return extrapolate_ior(lerpf(sample_rows(L.odE, p.s0, u), sample_rows(L.odE, p.s1, u), p.st), p.ior);
 }
-BRMI_DEV LutRows prep_im_e(const Luts& L, float alpha) { return prep_rows(L.imE, 32, remap_index(clamp_index(alpha_to_index(alpha)))); }
-BRMI_DEV float sample_im_e(const LutRows& r, float cosT) { return sample_rows(r, remap_index(clamp_index(cos_to_index(cosT)))); }
+BRMI_DEV LutRows prep_im_e(const Luts& L, float alpha) { return prep_rows((uint32_t)(L.imE - L.odE), 32, remap_index(clamp_index(alpha_to_index(alpha)))); }
+BRMI_DEV float sample_im_e(const Luts& L, const LutRows& r, float cosT) { return sample_rows(L.odE, r, remap_index(clamp_index(cos_to_index(cosT)))); }
 
 BRMI_DEV float average_fresnel(float eta) {
     const float s = max2(eta, 1.0e-4f);
@@ -496,10 +497,10 @@ BRMI_DEV PixelCtx make_pixel_ctx(const Luts& L, const Frag& f) {
     const BaseState& b = c.base;
     c.od = prep_od_e(L, b.weightedSpecularIor, b.specularAlpha);
     c.im = prep_im_e(L, b.specularAlpha);
-    const float viewComp = sample_od_e(c.od, sat(c.NoV));
+    const float viewComp = sample_od_e(L, c.od, sat(c.NoV));
     const float avgComp = lut_od_avg(L, b.weightedSpecularIor, b.specularAlpha);
     c.cachedView = max2(0.0f, qdiv(viewComp, max2(avgComp, 1.0e-12f)));
-    c.mView = sample_im_e(c.im, c.NoV);
+    c.mView = sample_im_e(L, c.im, c.NoV);
     c.mAvgClamped = max2(lut_im_avg(L, b.specularAlpha), 1.0e-12f);
     c.dielComp = ggx_energy_compensation(c.NoV, b.specularAlpha, b.dielectricSpecularF0);
     const float tmp = 50.0f * 0.33f;
@@ -526,7 +527,7 @@ BRMI_DEV f3 light_contribution(const Luts& L, const Frag& f, const PixelCtx& c, 
     const float NoH = sat(dot3(f.normalWS, h)), LoH = sat(dot3(lightToFrag, h));
     const float VdotL = dot3(f.viewWS, lightToFrag);
     // diffuse: EON x dielectric energy compensation
-    const float lightComp = sample_od_e(c.od, sat(NoL));
+    const float lightComp = sample_od_e(L, c.od, sat(NoL));
     const float diffuseEnergyComp = max2(0.0f, c.cachedView * lightComp);
     f3 diffuse;
     {
@@ -544,7 +545,7 @@ BRMI_DEV f3 light_contribution(const Luts& L, const Frag& f, const PixelCtx& c, 
     const float pw = __builtin_amdgcn_exp2f(5.0f * __builtin_amdgcn_logf(1.0f - LoH));   // pow(1 - LoH, 5) = exp2(5 log2 x), as DXC lowers it
     const f3 Fd = base.dielectricSpecularF0 + (f3{c.f90Diel, c.f90Diel, c.f90Diel} - base.dielectricSpecularF0) * pw;
     const f3 Fm = base.metalSpecularF0 + (f3{c.f90Metal, c.f90Metal, c.f90Metal} - base.metalSpecularF0) * pw;
-    const float mLight = sample_im_e(c.im, NoL);
+    const float mLight = sample_im_e(L, c.im, NoL);
     const float mTab = qdiv(c.mView * mLight, c.mAvgClamped);
     const float mScale = min2(mTab, qrcp(max2(NoL, 1.0e-4f))) * (1.0f / PI_F);
     const f3 dielSpec = base.dielectricSpecularWeight * (DV * Fd) * c.dielComp;
