@@ -177,7 +177,10 @@ constexpr int RESOLVE_WATERFALL = 4;     // distinct mesh instances per 8x8 tile
 // INLINE_TABLES: the arena may be too small for the frame, keep the per-pixel table path (it doubles the register count, so
 // the host only picks this variant when the arena cannot hold every cluster the configuration allows).
 template <bool INLINE_TABLES>
-__global__ void __launch_bounds__(256) k_gbuffer(GBufferArgs a) {
+#ifndef BRMI_GB_WAVES
+#define BRMI_GB_WAVES 6
+#endif
+__global__ void __launch_bounds__(256, INLINE_TABLES ? 1 : BRMI_GB_WAVES) k_gbuffer(GBufferArgs a) {
     const brmi_scene_buffers& sc = a.sc;
     const brmi_per_frame* pf = sc.perFrame;
     const uint32_t clusterCount = min(a.counters[CNT_VISIBLE] + a.counters[CNT_VISIBLE2], a.clusterCapacity);
