@@ -119,7 +119,8 @@ static void compute_sizes(brmi_pass* p) {
     w.frameConst = take(3 * 64);
     w.matConst = take((uint64_t)std::max(1u, p->scene.openpbrMaterialCount) * 48);
     w.objConst = take((uint64_t)std::max(1u, p->scene.perObjectCount) * 36 * 4);
-    w.deferredPixels = take(p->bandPixelCount * 4);
+    p->deferredStripeCapacity = (uint32_t)(((p->bandPixelCount / 4096 + CNT_STRIPE_COUNT) / CNT_STRIPE_COUNT) * 4096);   // 64-tile runs of a stripe x 4096 pixels
+    w.deferredPixels = take((uint64_t)CNT_STRIPE_COUNT * p->deferredStripeCapacity * 4);
     w.lutF = take((uint64_t)(32768 + 1024 + 1024 + 32 + 256) * 4);
     w.total = off;
     p->resNeed[BRMI_RES_WORKSPACE] = w.total;

@@ -37,6 +37,7 @@ enum CounterIndex : uint32_t {
     CNT_FRONTIER0 = 32,       // frontier sizes per BFS level: [CNT_FRONTIER0 + level]
     CNT_STRIPES = 128,        // 64 stripes x 32 words: per-stripe {instances tested, instances visible, nodes visited}
     CNT_STRIPE_COUNT = 64, CNT_STRIPE_WORDS = 32,
+    STRIPE_DEFERRED_A = 4, STRIPE_DEFERRED_B = 5,   // words of a stripe: deferred-pixel list lengths of alternating shading calls
     STRIPE_OVERFLOW = 3,      // word of a stripe: records in the stripe's raster overflow queue
     CNT_WORDS = 128 + 64 * 32
 };
@@ -110,6 +111,7 @@ struct brmi_pass {
     uint32_t numLightClusters = 0, lightPagePool = 0;
     uint32_t binOverflowPerStripe = 1u << 14;       // 64 stripes x 16384 records x 64 B = 64 MB
     uint32_t binsX = 0, binsY = 0, binCapacity = 2048;   // raster bins: 256 px x 16 rows, binCapacity records of 64 B each (BRMI_BIN_CAPACITY)
+    uint32_t deferredStripeCapacity = 0;   // entries per deferred-pixel stripe
     uint32_t resolveCapacity = 0;   // vertices (and triangles) the resolve arena holds
     uint32_t rasterGrid = 4096;  // single-wave workgroups of k_raster (BRMI_RASTER_GRID)
     int rasterDebug = 0;         // BRMI_RASTER_DEBUG (experiments; non-zero gives wrong images)

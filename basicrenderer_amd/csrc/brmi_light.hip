@@ -339,7 +339,6 @@ BRMI_DEV float sample_od_e(const Luts& L, const OdPrep& p, float cosT) {
 }
 BRMI_DEV LutRows prep_im_e(const Luts& L, float alpha) { return prep_rows((uint32_t)(L.imE - L.odE), 32, remap_index(clamp_index(alpha_to_index(alpha)))); }
 BRMI_DEV float sample_im_e(const Luts& L, const LutRows& r, float cosT) { return sample_rows(L.odE, r, remap_index(clamp_index(cos_to_index(cosT)))); }
-
 BRMI_DEV float average_fresnel(float eta) {
     const float s = max2(eta, 1.0e-4f);
     if (s > 1.0f) return (s - 1.0f) / (4.08567f + 1.00071f * s);
@@ -351,8 +350,8 @@ struct BaseState {
     f3 weightedBaseColor, diffuseColor; float baseDiffuseRoughness, specularAlpha, weightedSpecularIor;
     f3 dielectricSpecularF0; float dielectricSpecularWeight; f3 metalSpecularF0, metalAverageFresnel, metalMultipleScatterScale; float metalSpecularWeight;
 };
-struct CoatState { f3 tint; float presence, ior, roughness; f3 extraBaseLayerScale; };
-struct FuzzState { float roughness; f3 tint; float presence; f3 t, b, n, viewDirLocal; float viewReflected; };
+struct CoatState { f3 tint; float presence, ior, roughness; f3 extraBaseLayerScale; f3 t0, lt0; float eta; };   // t0 = sqrt(tint), lt0 = log2(t0), eta = 1 / ior: light-independent parts of coat_passage
+struct FuzzState { float roughness; f3 tint; float presence; f3 t, b, n, viewDirLocal; float viewReflected; float sa, ca; f3 ltcView; };   // sa, ca, ltcView: light-independent parts of fuzz_sheen
 struct Frag {
     f3 posWS, normalWS, viewWS, albedo, diffuseColor, emissive, dielectricSpecularF0, metalSpecularF0, metalAverageFresnel, coatColor, coatF0, fuzzColor;
     float NdotV, roughness, baseDiffuseRoughness, specularAlpha, weightedSpecularIor, dielectricSpecularWeight, metalSpecularWeight, coatWeight, coatIor, coatDarkening, coatRoughness, fuzzWeight, fuzzRoughness;
@@ -384,16 +383,18 @@ BRMI_DEV CoatState make_coat_state(const BaseState& b, const Frag& f) {
     const f3 Delta = f3{1.0f - K, 1.0f - K, 1.0f - K} / max3v(f3{1.0f, 1.0f, 1.0f} - E_b * K, f3{1.0e-4f, 1.0e-4f, 1.0e-4f});
     const float mod = sat(s.presence) * sat(f.coatDarkening);
     s.extraBaseLayerScale = lerp3(f3{1.0f, 1.0f, 1.0f}, sat3(Delta), mod);
+    s.t0 = f3{sqrtf(s.tint.x), sqrtf(s.tint.y), sqrtf(s.tint.z)}; s.eta = rcpf(s.ior);
+    s.lt0 = f3{__builtin_amdgcn_logf(s.t0.x), __builtin_amdgcn_logf(s.t0.y), __builtin_amdgcn_logf(s.t0.z)};
     return s;
 }
 BRMI_DEV f3 coat_passage(const CoatState& s, float NdotX) {
     const float c = sat(NdotX);
     if (c <= 0.0f || min2(s.tint.x, min2(s.tint.y, s.tint.z)) >= 1.0f) return f3{1.0f, 1.0f, 1.0f};
-    const f3 t0{sqrtf(s.tint.x), sqrtf(s.tint.y), sqrtf(s.tint.z)};
-    const float eta = rcpf(s.ior);
+    const float eta = s.eta;
     const float rc = sqrtf(max2(0.0f, 1.0f - (1.0f - c * c) / max2(eta * eta, 1.0e-4f)));
     const float ds = rcpf(max2(rc, 1.0e-4f));
-    const f3 tr{powf(t0.x, ds), powf(t0.y, ds), powf(t0.z, ds)};
+    // pow(x, y) = exp2(y * log2 x), as DXC lowers it (tolerance-level, like the Schlick power); log2(t0) is hoisted with t0
+    const f3 tr{__builtin_amdgcn_exp2f(ds * s.lt0.x), __builtin_amdgcn_exp2f(ds * s.lt0.y), __builtin_amdgcn_exp2f(ds * s.lt0.z)};
     return lerp3(f3{1.0f, 1.0f, 1.0f}, tr, s.presence);
 }
 BRMI_DEV float coat_reflected(const Luts& L, const CoatState& s, float NdotX) {
@@ -409,6 +410,18 @@ BRMI_DEV f3 coat_scale_outgoing(const Luts& L, const CoatState& s, float NdotL) 
     const float rp = coat_reflected(L, s, NdotL);
     return coat_passage(s, NdotL) * f3{1.0f - rp, 1.0f - rp, 1.0f - rp};
 }
+// coat_reflected / coat_scale_outgoing with the coat's (ior, roughness) table rows prepared once per pixel
+BRMI_DEV OdPrep prep_coat_od(const Luts& L, const CoatState& s) { return prep_od_e(L, max2(s.ior, 1.0e-4f), sat(s.roughness)); }
+BRMI_DEV float coat_reflected_prepared(const Luts& L, const CoatState& s, const OdPrep& od, float NdotX) {
+    const float si = max2(s.ior, 1.0e-4f), sa = sat(s.roughness), sc = sat(NdotX);
+    const float refl = (sa <= 0.0f) ? fresnel_dielectric(si, sc) : 1.0f - sample_od_e(L, od, sc);
+    return sat(s.presence * refl);
+}
+BRMI_DEV f3 coat_scale_outgoing_prepared(const Luts& L, const CoatState& s, const OdPrep& od, float NdotL) {
+    const float rp = coat_reflected_prepared(L, s, od, NdotL);
+    return coat_passage(s, NdotL) * f3{1.0f - rp, 1.0f - rp, 1.0f - rp};
+}
+
 BRMI_DEV float fuzz_dir_reflectance(const Luts& L, float r, float c) { return sat(lut_fuzz_ltc(L, r, c).z); }
 BRMI_DEV float fuzz_incoming_reflected(const Luts& L, float w, float r, float NdotV) { return sat(sat(w) * fuzz_dir_reflectance(L, r, NdotV)); }
 BRMI_DEV f3 to_local(const FuzzState& s, f3 d) { return f3{dot3(d, s.t), dot3(d, s.b), dot3(d, s.n)}; }
@@ -423,17 +436,20 @@ BRMI_DEV FuzzState make_fuzz_state(const Luts& L, const Frag& f) {
     s.b = cross3(s.n, s.t);
     s.viewDirLocal = to_local(s, v);
     s.viewReflected = fuzz_incoming_reflected(L, s.presence, s.roughness, s.viewDirLocal.z);
-    return s;
-}
-BRMI_DEV f3 fuzz_sheen(const Luts& L, const FuzzState& s, f3 lightDir) {
-    const f3 ll = to_local(s, normalize3(lightDir));
-    if (s.viewDirLocal.z <= 0.0f || ll.z <= 0.0f) return f3{0.0f, 0.0f, 0.0f};
     float phi = atan2f(s.viewDirLocal.y, s.viewDirLocal.x);
     if (phi < 0.0f) phi += 2.0f * PI_F;
-    const float ang = -phi, sa = sinf(ang), ca = cosf(ang);
+    const float ang = -phi;
+    s.sa = sinf(ang); s.ca = cosf(ang);
+    s.ltcView = lut_fuzz_ltc(L, s.roughness, s.viewDirLocal.z);
+    return s;
+}
+// `ll` = the light direction in the fuzz frame (to_local(s, normalize(lightDir)), which the caller has already)
+BRMI_DEV f3 fuzz_sheen(const FuzzState& s, f3 ll) {
+    if (s.viewDirLocal.z <= 0.0f || ll.z <= 0.0f) return f3{0.0f, 0.0f, 0.0f};
+    const float sa = s.sa, ca = s.ca;
     const f3 axis{0.0f, 0.0f, 1.0f};
     const f3 ls = ll * ca + axis * dot3(ll, axis) * (1.0f - ca) + sa * cross3(axis, ll);
-    const f3 ltc = lut_fuzz_ltc(L, s.roughness, s.viewDirLocal.z);
+    const f3 ltc = s.ltcView;
     const float aInv = ltc.x, bInv = ltc.y;
     f3 wo{aInv * ls.x + bInv * ls.z, aInv * ls.y, ls.z};
     const float len = length3(wo);
@@ -480,6 +496,7 @@ struct PixelCtx {
     float f90Diel, f90Metal;
     f3 eonSinglePre, eonMsPre; float eonEInTerm, eonDen;
     OdPrep od; LutRows im;
+    OdPrep coatOd;              // GENERAL: rows of the coat's (ior, roughness)
 };
 
 template <bool GENERAL>
@@ -492,6 +509,7 @@ BRMI_DEV PixelCtx make_pixel_ctx(const Luts& L, const Frag& f) {
         c.coat = make_coat_state(c.base, f);
         c.fuzz = make_fuzz_state(L, f);
         c.coatIn = coat_scale_incoming(L, c.coat, c.NoV);
+        c.coatOd = prep_coat_od(L, c.coat);
         c.coatComp = ggx_energy_compensation(c.NoV, f.coatRoughness, f.coatF0);
     }
     const BaseState& b = c.base;
@@ -557,13 +575,13 @@ BRMI_DEV f3 light_contribution(const Luts& L, const Frag& f, const PixelCtx& c, 
         const f3 llocal = to_local(c.fuzz, normalize3(lightToFrag));
         const float fuzzOut = (llocal.z <= 0.0f) ? 0.0f : sat(c.fuzz.presence * fuzz_dir_reflectance(L, c.fuzz.roughness, llocal.z));
         const float fuzzScale = (1.0f - c.fuzz.viewReflected) * (1.0f - fuzzOut);
-        const f3 baseScale = c.coatIn * coat_scale_outgoing(L, c.coat, NoL);
+        const f3 baseScale = c.coatIn * coat_scale_outgoing_prepared(L, c.coat, c.coatOd, NoL);
         f3 coatFr{0.0f, 0.0f, 0.0f};
         if (c.coat.presence > 0.0f) {
             coatFr = specular_lobe(f.coatRoughness, f.coatF0, NoV, NoL, NoH, LoH);
             coatFr = coatFr * (c.coatComp * c.coat.presence);
         }
-        const f3 fuzzFr = fuzz_sheen(L, c.fuzz, lightToFrag);
+        const f3 fuzzFr = fuzz_sheen(c.fuzz, llocal);
         const f3 baseAtt = f3{fuzzScale, fuzzScale, fuzzScale} * baseScale;
         brdf = (diffuse + specular) * baseAtt + coatFr * f3{fuzzScale, fuzzScale, fuzzScale} + fuzzFr;
     }
@@ -582,7 +600,11 @@ struct ShadeArgs {
     const float* lutF;   // expanded tables: odE[32768] odAvg[1024] imE[1024] imAvg[32] unorm8[256]
     const MatConst* matConst;
     uint32_t* counters; uint32_t* deferred;   // pixels (band-relative tiled index) left to the general kernel
-    uint32_t deferredCounter, nextDeferredCounter;   // counter word of this call's deferred list / of the next call's (cleared here)
+    // The deferred pixels go to 64 striped lists (tile t appends to stripe (t / 64) % 64, so no stripe can exceed its share): one
+    // list with one counter would take an atomic with return per tile on a single address (~90 per microsecond on MI355X;
+    // 130 k tiles = 1.4 ms when most pixels carry coat or fuzz).
+    uint32_t deferredWord, nextDeferredWord;   // word inside a stripe: this call's list length / the next call's (cleared here)
+    uint32_t stripeCapacity;
 };
 
 BRMI_DEV float half_at(unsigned long long v, int k) { return f16_bits_to_f32((uint32_t)(v >> (16 * k)) & 0xFFFFu); }
@@ -820,15 +842,30 @@ __global__ void __launch_bounds__(256, GENERAL ? 1 : BRMI_SHADE_WAVES) k_shade(S
             uint32_t npx = 0, npy = 0;
             const RawPixel nxt = (j + stride < end) ? fetch(j + stride, npx, npy) : empty_raw_pixel();
             const bool done = shade_pixel<false>(a, k, sliceStart, cur, a.firstPixel + j, px, py);
-            const uint32_t slot = wave_append(&a.counters[a.deferredCounter], !done);
-            if (!done) a.deferred[slot] = (uint32_t)j;
+            const uint32_t stripe = (uint32_t)(j >> 12) & (CNT_STRIPE_COUNT - 1u);     // wave-uniform; runs of 64 neighbouring tiles share a stripe (locality of the list)
+            const uint32_t slot = wave_append(&a.counters[CNT_STRIPES + stripe * CNT_STRIPE_WORDS + a.deferredWord], !done);
+            if (!done) a.deferred[(size_t)stripe * a.stripeCapacity + slot] = (uint32_t)j;
             cur = nxt; px = npx; py = npy;
         }
     } else {
-        const uint32_t n = a.counters[a.deferredCounter];
-        if (blockIdx.x == 0 && threadIdx.x == 0) a.counters[a.nextDeferredCounter] = 0u;      // the next shading call starts with an empty list
-        for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
-            const uint64_t i = a.firstPixel + a.deferred[q];
+        if (blockIdx.x == 0 && threadIdx.x < CNT_STRIPE_COUNT) a.counters[CNT_STRIPES + threadIdx.x * CNT_STRIPE_WORDS + a.nextDeferredWord] = 0u;   // the next shading call starts with empty lists
+        // the 64 lists as one index space: their lengths are read side by side and scanned, a work item finds its stripe by search
+        __shared__ uint32_t stripeStart[CNT_STRIPE_COUNT + 1];
+        if (threadIdx.x < 64u) {
+            const uint32_t n = min(a.counters[CNT_STRIPES + threadIdx.x * CNT_STRIPE_WORDS + a.deferredWord], a.stripeCapacity);
+            uint32_t incl = n;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o); if (threadIdx.x >= (uint32_t)o) incl += v; }
+            stripeStart[threadIdx.x] = incl - n;
+            if (threadIdx.x == 63u) stripeStart[64] = incl;
+        }
+        __syncthreads();
+        const uint32_t total = stripeStart[64];
+        for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += gridDim.x * blockDim.x) {
+            uint32_t stripe = 0;
+#pragma unroll
+            for (uint32_t step = 32; step > 0; step >>= 1) if (stripeStart[stripe + step] <= q) stripe += step;
+            const uint64_t i = a.firstPixel + a.deferred[(size_t)stripe * a.stripeCapacity + (q - stripeStart[stripe])];
             const uint32_t tile = (uint32_t)(i >> 6), within = (uint32_t)(i & 63u);
             const uint32_t px = (tile % a.tilesX) * 8u + (within >> 3), py = (tile / a.tilesX) * 8u + (within & 7u);
             shade_pixel<true>(a, k, sliceStart, load_raw_pixel(a, i), i, px, py);
@@ -886,8 +923,9 @@ int launch_shade(brmi_pass* p, hipStream_t s) {
     a.matConst = p->wsPtr<MatConst>(p->ws.matConst);
     a.tables = shade_tables_of(p);
     a.counters = p->counters(); a.deferred = p->wsPtr<uint32_t>(p->ws.deferredPixels);
-    a.deferredCounter = (p->shadeSerial & 1u) ? CNT_DEFERRED_PIXELS_B : CNT_DEFERRED_PIXELS;
-    a.nextDeferredCounter = (p->shadeSerial & 1u) ? CNT_DEFERRED_PIXELS : CNT_DEFERRED_PIXELS_B;
+    a.deferredWord = (p->shadeSerial & 1u) ? STRIPE_DEFERRED_B : STRIPE_DEFERRED_A;
+    a.nextDeferredWord = (p->shadeSerial & 1u) ? STRIPE_DEFERRED_A : STRIPE_DEFERRED_B;
+    a.stripeCapacity = p->deferredStripeCapacity;
     p->shadeSerial++;
     hipLaunchKernelGGL(k_shade<false>, dim3(4096), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_shade<true>, dim3(512), dim3(256), 0, s, a);
