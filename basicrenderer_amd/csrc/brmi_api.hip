@@ -120,7 +120,7 @@ static void compute_sizes(brmi_pass* p) {
     w.matConst = take((uint64_t)std::max(1u, p->scene.openpbrMaterialCount) * 48);
     w.objConst = take((uint64_t)std::max(1u, p->scene.perObjectCount) * 36 * 4);
     p->deferredStripeCapacity = (uint32_t)(((p->bandPixelCount / 4096 + CNT_STRIPE_COUNT) / CNT_STRIPE_COUNT) * 4096);   // 64-tile runs of a stripe x 4096 pixels
-    w.deferredPixels = take((uint64_t)CNT_STRIPE_COUNT * p->deferredStripeCapacity * 4);
+    w.deferredPixels = take((uint64_t)3 * CNT_STRIPE_COUNT * p->deferredStripeCapacity * 4);      // one set of striped lists per layered class
     w.lutF = take((uint64_t)(32768 + 1024 + 1024 + 32 + 256) * 4);
     w.total = off;
     p->resNeed[BRMI_RES_WORKSPACE] = w.total;
@@ -212,6 +212,12 @@ int brmi_set_scene(brmi_pass* p, const brmi_scene_buffers* scene) {
     if ((rc = read_back(p, offs, sc.clodOffsets, sc.perMeshInstanceCount))) return rc;
     if ((rc = read_back(p, nodes, sc.lodNodes, sc.lodNodeCount))) return rc;
     if ((rc = read_back(p, segs, sc.lodSegments, sc.lodSegmentCount))) return rc;
+    {   // which layered shading variants the scene can need (materials edited on the device later: call brmi_set_scene again)
+        std::vector<brmi_openpbr_material_info> op;
+        if ((rc = read_back(p, op, sc.openpbrMaterials, sc.openpbrMaterialCount))) return rc;
+        p->sceneHasCoat = p->sceneHasFuzz = false;
+        for (const auto& m : op) { if (m.coatWeight > 0.0f) p->sceneHasCoat = true; if (m.fuzzWeight > 0.0f) p->sceneHasFuzz = true; }
+    }
     // per mesh: walk the BVH, collect the segments its leaves reference, depth of the tree
     p->hostSegPrefix.assign(segs.size(), 0);
     std::vector<uint32_t> meshBits(md.size(), 0);

@@ -37,7 +37,7 @@ enum CounterIndex : uint32_t {
     CNT_FRONTIER0 = 32,       // frontier sizes per BFS level: [CNT_FRONTIER0 + level]
     CNT_STRIPES = 128,        // 64 stripes x 32 words: per-stripe {instances tested, instances visible, nodes visited}
     CNT_STRIPE_COUNT = 64, CNT_STRIPE_WORDS = 32,
-    STRIPE_DEFERRED_A = 4, STRIPE_DEFERRED_B = 5,   // words of a stripe: deferred-pixel list lengths of alternating shading calls
+    STRIPE_DEFERRED_A = 4, STRIPE_DEFERRED_B = 8,   // words of a stripe: deferred-pixel list lengths (3 classes each) of alternating shading calls
     STRIPE_OVERFLOW = 3,      // word of a stripe: records in the stripe's raster overflow queue
     CNT_WORDS = 128 + 64 * 32
 };
@@ -106,6 +106,7 @@ struct brmi_pass {
     uint32_t minLevelWidth = 0;      // narrowest such width over the meshes
     std::vector<uint32_t> hostMeshLevelWidth;   // per mesh metadata entry
     uint32_t maxLevelWidth = 0;      // widest BVH level of any mesh (decides between the per-instance and the per-level traversal)
+    bool sceneHasCoat = true, sceneHasFuzz = true;   // some OpenPBR material has a coat / fuzz layer (brmi_set_scene)
     bool forceLevelKernels = false;  // BRMI_CULL_LEVEL_KERNELS=1: always use the per-level kernels (tests, very wide hierarchies)
     uint64_t totalBits = 0; uint32_t totalWords = 0, scanBlocks = 0;
     uint32_t numLightClusters = 0, lightPagePool = 0;

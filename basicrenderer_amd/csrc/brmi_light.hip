@@ -488,7 +488,6 @@ BRMI_DEV f3 diffuse_eon(f3 albedo, float rough, float NdotV, float NdotL, float 
 struct PixelCtx {
     BaseState base;
     float NoV;
-    bool plain;                 // coat and fuzz absent: their factors are exactly 1 / 0 and are skipped
     CoatState coat; FuzzState fuzz;
     f3 coatIn, coatComp;
     float cachedView, mView, mAvgClamped;
@@ -499,19 +498,20 @@ struct PixelCtx {
     OdPrep coatOd;              // GENERAL: rows of the coat's (ior, roughness)
 };
 
-template <bool GENERAL>
+template <int MODE>
 BRMI_DEV PixelCtx make_pixel_ctx(const Luts& L, const Frag& f) {
     PixelCtx c;
     c.base = make_base_state(f);
     c.NoV = sat(dot3(f.normalWS, f.viewWS));
-    c.plain = !GENERAL || ((sat(f.coatWeight) == 0.0f) && (sat(f.fuzzWeight) == 0.0f));
-    if (GENERAL && !c.plain) {
+    // MODE bit 0: the pixel has a coat, bit 1: it has fuzz.  A layer that is absent has factors of exactly 1 / 0, so the
+    // variants without it skip its terms without changing a bit of the result.
+    if (MODE & 1) {
         c.coat = make_coat_state(c.base, f);
-        c.fuzz = make_fuzz_state(L, f);
         c.coatIn = coat_scale_incoming(L, c.coat, c.NoV);
         c.coatOd = prep_coat_od(L, c.coat);
         c.coatComp = ggx_energy_compensation(c.NoV, f.coatRoughness, f.coatF0);
     }
+    if (MODE & 2) c.fuzz = make_fuzz_state(L, f);
     const BaseState& b = c.base;
     c.od = prep_od_e(L, b.weightedSpecularIor, b.specularAlpha);
     c.im = prep_im_e(L, b.specularAlpha);
@@ -537,7 +537,7 @@ BRMI_DEV PixelCtx make_pixel_ctx(const Luts& L, const Frag& f) {
     return c;
 }
 
-template <bool GENERAL>
+template <int MODE>
 BRMI_DEV f3 light_contribution(const Luts& L, const Frag& f, const PixelCtx& c, f3 lightToFrag, float NoL, f3 lightColor, float intensity, float attenuation, float spotAtt) {
     const BaseState& base = c.base;
     const float NoV = c.NoV;
@@ -570,18 +570,24 @@ BRMI_DEV f3 light_contribution(const Luts& L, const Frag& f, const PixelCtx& c, 
     const f3 metalSpec = base.metalSpecularWeight * (DV * Fm + base.metalMultipleScatterScale * mScale);
     const f3 specular = dielSpec + metalSpec;
     f3 brdf;
-    if (!GENERAL || c.plain) brdf = diffuse + specular;
+    if (MODE == 0) brdf = diffuse + specular;
     else {
-        const f3 llocal = to_local(c.fuzz, normalize3(lightToFrag));
-        const float fuzzOut = (llocal.z <= 0.0f) ? 0.0f : sat(c.fuzz.presence * fuzz_dir_reflectance(L, c.fuzz.roughness, llocal.z));
-        const float fuzzScale = (1.0f - c.fuzz.viewReflected) * (1.0f - fuzzOut);
-        const f3 baseScale = c.coatIn * coat_scale_outgoing_prepared(L, c.coat, c.coatOd, NoL);
-        f3 coatFr{0.0f, 0.0f, 0.0f};
-        if (c.coat.presence > 0.0f) {
-            coatFr = specular_lobe(f.coatRoughness, f.coatF0, NoV, NoL, NoH, LoH);
-            coatFr = coatFr * (c.coatComp * c.coat.presence);
+        float fuzzScale = 1.0f;
+        f3 fuzzFr{0.0f, 0.0f, 0.0f};
+        if (MODE & 2) {
+            const f3 llocal = to_local(c.fuzz, normalize3(lightToFrag));
+            const float fuzzOut = (llocal.z <= 0.0f) ? 0.0f : sat(c.fuzz.presence * fuzz_dir_reflectance(L, c.fuzz.roughness, llocal.z));
+            fuzzScale = (1.0f - c.fuzz.viewReflected) * (1.0f - fuzzOut);
+            fuzzFr = fuzz_sheen(c.fuzz, llocal);
         }
-        const f3 fuzzFr = fuzz_sheen(c.fuzz, llocal);
+        f3 baseScale{1.0f, 1.0f, 1.0f}, coatFr{0.0f, 0.0f, 0.0f};
+        if (MODE & 1) {
+            baseScale = c.coatIn * coat_scale_outgoing_prepared(L, c.coat, c.coatOd, NoL);
+            if (c.coat.presence > 0.0f) {
+                coatFr = specular_lobe(f.coatRoughness, f.coatF0, NoV, NoL, NoH, LoH);
+                coatFr = coatFr * (c.coatComp * c.coat.presence);
+            }
+        }
         const f3 baseAtt = f3{fuzzScale, fuzzScale, fuzzScale} * baseScale;
         brdf = (diffuse + specular) * baseAtt + coatFr * f3{fuzzScale, fuzzScale, fuzzScale} + fuzzFr;
     }
@@ -659,8 +665,9 @@ BRMI_DEV RawPixel load_raw_pixel_plain(const ShadeArgs& a, uint64_t i) {
     return r;
 }
 
-template <bool GENERAL>
-BRMI_DEV bool shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const float* sliceStart, const RawPixel& raw, uint64_t i, uint32_t px, uint32_t py) {
+// Returns 0 when the pixel is done, else the class (1 coat, 2 fuzz, 3 both) of the variant that has to shade it.
+template <int MODE>
+BRMI_DEV uint32_t shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const float* sliceStart, const RawPixel& raw, uint64_t i, uint32_t px, uint32_t py) {
     const brmi_scene_buffers& sc = a.sc;
     const Luts& L = k.L;
     const uint32_t gx = k.gx, gy = k.gy, gz = k.gz, nearSlices = k.nearSlices, numLights = k.numLights;
@@ -668,7 +675,7 @@ BRMI_DEV bool shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const float* 
     const float zNear = k.zNear, zSplit = k.zSplit, logStart = k.logStart, om5 = k.om5, om6 = k.om6;
     (void)gy;
         const float d = raw.d;
-        if (as_u32(d) == BRMI_DEPTH_EMPTY_BITS) return true;
+        if (as_u32(d) == BRMI_DEPTH_EMPTY_BITS) return 0u;
         float uvx = a.tables.uvx[px], uvy = a.tables.uvy[py];
         uvy = 1.0f - uvy;
         const f4 clipPos{uvx * 2.0f - 1.0f, uvy * 2.0f - 1.0f, 1.0f, 1.0f};
@@ -725,8 +732,9 @@ BRMI_DEV bool shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const float* 
         f.specularAlpha = f.roughness; f.weightedSpecularIor = weightedSpecularIor;
         f.diffuseColor = weightedBaseColor * (1.0f - metal);
 
-        if (!GENERAL && !((f.coatWeight == 0.0f) && (f.fuzzWeight == 0.0f))) return false;   // defer to the general kernel
-        const PixelCtx ctx = make_pixel_ctx<GENERAL>(L, f);
+        const uint32_t cls = (f.coatWeight != 0.0f ? 1u : 0u) | (f.fuzzWeight != 0.0f ? 2u : 0u);
+        if (cls != (uint32_t)MODE) return MODE == 0 ? cls : 0u;      // MODE 0 defers; the layered variants only see their own class
+        const PixelCtx ctx = make_pixel_ctx<MODE>(L, f);
         f3 lighting{0.0f, 0.0f, 0.0f};
         auto shadeLight = [&](uint32_t lightIndex) {
             const auto* l = kconst(sc.lights) + lightIndex;      // wave-uniform in the clustered path: scalar loads
@@ -751,7 +759,7 @@ BRMI_DEV bool shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const float* 
                     else spot = 1.0f;
                 } else return;                                        // spot = 0: contribution is +-0
             }
-            const f3 c = light_contribution<GENERAL>(L, f, ctx, lightToFrag, NoL, f3{l->color[0], l->color[1], l->color[2]}, l->color[3], att, spot);
+            const f3 c = light_contribution<MODE>(L, f, ctx, lightToFrag, NoL, f3{l->color[0], l->color[1], l->color[2]}, l->color[3], att, spot);
             lighting = lighting + c;
         };
         if (a.enablePunctual) {
@@ -805,27 +813,27 @@ BRMI_DEV bool shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const float* 
             }
         }
         // EvaluateOpenPBREmissive
-        if (!GENERAL || ctx.plain) lighting = lighting + f.emissive;
+        if (MODE == 0) lighting = lighting + f.emissive;
         else {
-            const float fuzzBase = 1.0f - fuzz_incoming_reflected(L, f.fuzzWeight, f.fuzzRoughness, f.NdotV);
-            const f3 coatT = coat_scale_incoming(L, ctx.coat, f.NdotV);
+            const float fuzzBase = (MODE & 2) ? 1.0f - fuzz_incoming_reflected(L, f.fuzzWeight, f.fuzzRoughness, f.NdotV) : 1.0f;
+            const f3 coatT = (MODE & 1) ? coat_scale_incoming(L, ctx.coat, f.NdotV) : f3{1.0f, 1.0f, 1.0f};
             lighting = lighting + f.emissive * f3{fuzzBase, fuzzBase, fuzzBase} * coatT;
         }
         a.hdr[i] = pack_half4(lighting.x, lighting.y, lighting.z, 1.0f);
-        return true;
+        return 0u;
 }
 
 // the specialised kernel must keep 3 waves per SIMD (<= 168 VGPRs); the general one is rare and may use the whole file
 #ifndef BRMI_SHADE_WAVES
 #define BRMI_SHADE_WAVES 3
 #endif
-template <bool GENERAL>
-__global__ void __launch_bounds__(256, GENERAL ? 1 : BRMI_SHADE_WAVES) k_shade(ShadeArgs a) {
+template <int MODE>
+__global__ void __launch_bounds__(256, MODE != 0 ? 1 : BRMI_SHADE_WAVES) k_shade(ShadeArgs a) {
     const ShadeFrame k = make_shade_frame(a);
     __shared__ float sliceStart[64];
     if (threadIdx.x < 64) sliceStart[threadIdx.x] = threadIdx.x <= k.gz + 1u ? a.tables.sliceStart[threadIdx.x] : __uint_as_float(0x7F800000u);
     __syncthreads();
-    if (!GENERAL) {
+    if (MODE == 0) {
         // software pipeline: the G-buffer words of the next tile are requested before the current one is shaded, so
         // their HBM latency overlaps ~1000 VALU instructions instead of stalling the wave at the top of every iteration
         const uint64_t end = (a.pixelCount + 63ull) & ~63ull, stride = (uint64_t)gridDim.x * blockDim.x;
@@ -841,18 +849,25 @@ __global__ void __launch_bounds__(256, GENERAL ? 1 : BRMI_SHADE_WAVES) k_shade(S
         for (; j < end; j += stride) {
             uint32_t npx = 0, npy = 0;
             const RawPixel nxt = (j + stride < end) ? fetch(j + stride, npx, npy) : empty_raw_pixel();
-            const bool done = shade_pixel<false>(a, k, sliceStart, cur, a.firstPixel + j, px, py);
+            const uint32_t cls = shade_pixel<0>(a, k, sliceStart, cur, a.firstPixel + j, px, py);
+            const bool done = cls == 0u;
             const uint32_t stripe = (uint32_t)(j >> 12) & (CNT_STRIPE_COUNT - 1u);     // wave-uniform; runs of 64 neighbouring tiles share a stripe (locality of the list)
-            const uint32_t slot = wave_append(&a.counters[CNT_STRIPES + stripe * CNT_STRIPE_WORDS + a.deferredWord], !done);
-            if (!done) a.deferred[(size_t)stripe * a.stripeCapacity + slot] = (uint32_t)j;
+            if (__any(!done)) {
+                // one list per class (coat, fuzz, both) so that every layered variant walks a dense list
+#pragma unroll
+                for (uint32_t c = 1; c <= 3; c++) {
+                    const uint32_t slot = wave_append(&a.counters[CNT_STRIPES + stripe * CNT_STRIPE_WORDS + a.deferredWord + (c - 1u)], cls == c);
+                    if (cls == c && slot < a.stripeCapacity) a.deferred[((size_t)(c - 1u) * CNT_STRIPE_COUNT + stripe) * a.stripeCapacity + slot] = (uint32_t)j;
+                }
+            }
             cur = nxt; px = npx; py = npy;
         }
     } else {
-        if (blockIdx.x == 0 && threadIdx.x < CNT_STRIPE_COUNT) a.counters[CNT_STRIPES + threadIdx.x * CNT_STRIPE_WORDS + a.nextDeferredWord] = 0u;   // the next shading call starts with empty lists
+        if (blockIdx.x == 0 && threadIdx.x < CNT_STRIPE_COUNT) a.counters[CNT_STRIPES + threadIdx.x * CNT_STRIPE_WORDS + a.nextDeferredWord + (uint32_t)(MODE - 1)] = 0u;   // the next shading call starts with empty lists
         // the 64 lists as one index space: their lengths are read side by side and scanned, a work item finds its stripe by search
         __shared__ uint32_t stripeStart[CNT_STRIPE_COUNT + 1];
         if (threadIdx.x < 64u) {
-            const uint32_t n = min(a.counters[CNT_STRIPES + threadIdx.x * CNT_STRIPE_WORDS + a.deferredWord], a.stripeCapacity);
+            const uint32_t n = min(a.counters[CNT_STRIPES + threadIdx.x * CNT_STRIPE_WORDS + a.deferredWord + (uint32_t)(MODE - 1)], a.stripeCapacity);
             uint32_t incl = n;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o); if (threadIdx.x >= (uint32_t)o) incl += v; }
@@ -865,10 +880,10 @@ __global__ void __launch_bounds__(256, GENERAL ? 1 : BRMI_SHADE_WAVES) k_shade(S
             uint32_t stripe = 0;
 #pragma unroll
             for (uint32_t step = 32; step > 0; step >>= 1) if (stripeStart[stripe + step] <= q) stripe += step;
-            const uint64_t i = a.firstPixel + a.deferred[(size_t)stripe * a.stripeCapacity + (q - stripeStart[stripe])];
+            const uint64_t i = a.firstPixel + a.deferred[((size_t)(MODE - 1) * CNT_STRIPE_COUNT + stripe) * a.stripeCapacity + (q - stripeStart[stripe])];
             const uint32_t tile = (uint32_t)(i >> 6), within = (uint32_t)(i & 63u);
             const uint32_t px = (tile % a.tilesX) * 8u + (within >> 3), py = (tile / a.tilesX) * 8u + (within & 7u);
-            shade_pixel<true>(a, k, sliceStart, load_raw_pixel(a, i), i, px, py);
+            shade_pixel<MODE>(a, k, sliceStart, load_raw_pixel(a, i), i, px, py);
         }
     }
 }
@@ -927,8 +942,11 @@ int launch_shade(brmi_pass* p, hipStream_t s) {
     a.nextDeferredWord = (p->shadeSerial & 1u) ? STRIPE_DEFERRED_A : STRIPE_DEFERRED_B;
     a.stripeCapacity = p->deferredStripeCapacity;
     p->shadeSerial++;
-    hipLaunchKernelGGL(k_shade<false>, dim3(4096), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_shade<true>, dim3(512), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_shade<0>, dim3(4096), dim3(256), 0, s, a);
+    // deferred pixels by class: coat, fuzz, both -- only the variants some material of the scene can need
+    if (p->sceneHasCoat) hipLaunchKernelGGL(k_shade<1>, dim3(512), dim3(256), 0, s, a);
+    if (p->sceneHasFuzz) hipLaunchKernelGGL(k_shade<2>, dim3(512), dim3(256), 0, s, a);
+    if (p->sceneHasCoat && p->sceneHasFuzz) hipLaunchKernelGGL(k_shade<3>, dim3(512), dim3(256), 0, s, a);
     BRMI_LAUNCH_CHECK(p, "k_shade");
     return BRMI_OK;
 }
