@@ -15,7 +15,7 @@ u32, u64, f32, vp = C.c_uint32, C.c_uint64, C.c_float, C.c_void_p
 class SceneParams(C.Structure):
     _fields_ = [("preset", u32), ("seed", u32), ("width", u32), ("height", u32), ("numPointLights", u32),
                 ("withDirectionalLight", u32), ("lodLevels", u32), ("sizeScale", f32), ("skinnedFraction1024", u32),
-                ("materialFeatures", u32), ("cameraStep", u32), ("lodBuilder", u32), ("reserved", u32 * 4)]
+                ("materialFeatures", u32), ("cameraStep", u32), ("lodBuilder", u32), ("spotLightEvery", u32), ("reserved", u32 * 3)]
 
 
 class SceneStats(C.Structure):

@@ -786,6 +786,15 @@ float calculateLightRadius(float intensity, float constant, float linear, float 
 
 // BR/src/Scene/Scene.cpp:219-262
 void addLight(brmi_scene& sc, uint32_t type, V3 pos, V3 color, float intensity, V3 att, V3 dir) {
+    // spot lights on request: every spotLightEvery-th point light becomes a spot aimed roughly at the scene floor
+    // (BR/src/Scene/Scene.cpp:220-262: cone angles stored as cosines, bounding sphere of the cone from MathUtils.cpp:70-82)
+    double innerAngle = 0.0, outerAngle = 0.0;
+    if (type == BRMI_LIGHT_POINT && sc.params.spotLightEvery != 0 && (sc.lights.size() % sc.params.spotLightEvery) == 0) {
+        type = BRMI_LIGHT_SPOT;
+        const double k = (double)(sc.lights.size() % 7) / 7.0;
+        dir = V3{0.6 * std::cos(6.2831 * k), -1.0, 0.6 * std::sin(6.2831 * k)};
+        innerAngle = 0.35 + 0.2 * k; outerAngle = innerAngle + 0.25;
+    }
     brmi_light_info l{};
     std::memset(&l, 0, sizeof(l));
     V3 an = normalize(att);
@@ -797,11 +806,16 @@ void addLight(brmi_scene& sc, uint32_t type, V3 pos, V3 color, float intensity, 
     l.attenuation[0] = (float)an.x; l.attenuation[1] = (float)an.y; l.attenuation[2] = (float)an.z; l.attenuation[3] = 0.0f;
     V3 dn = (type == BRMI_LIGHT_POINT) ? V3{0, 0, 0} : normalize(dir);
     l.dirWorldSpace[0] = (float)dn.x; l.dirWorldSpace[1] = (float)dn.y; l.dirWorldSpace[2] = (float)dn.z;
-    l.innerConeAngle = 1.0f; l.outerConeAngle = 1.0f;   // cos(0)
+    l.innerConeAngle = (float)std::cos(innerAngle); l.outerConeAngle = (float)std::cos(outerAngle);   // cos(0) = 1 for non-spot lights
     l.shadowViewInfoIndex = -1; l.nearPlane = 0.01f; l.farPlane = maxRange;
     l.shadowMapIndex = -1; l.shadowSamplerIndex = -1; l.shadowCaster = 0;
     l.maxRange = maxRange;
     if (type == BRMI_LIGHT_POINT) { l.boundingSphere[0] = (float)pos.x; l.boundingSphere[1] = (float)pos.y; l.boundingSphere[2] = (float)pos.z; l.boundingSphere[3] = maxRange; }
+    if (type == BRMI_LIGHT_SPOT) {      // ComputeConeBoundingSphere(origin, direction, height = maxRange, halfAngle = outer)
+        const float r = maxRange * std::tan((float)outerAngle);
+        const V3 c = pos + dn * (0.5 * (double)maxRange);
+        l.boundingSphere[0] = (float)c.x; l.boundingSphere[1] = (float)c.y; l.boundingSphere[2] = (float)c.z; l.boundingSphere[3] = std::sqrt(maxRange * maxRange + r * r);
+    }
     sc.activeLights.push_back((uint32_t)sc.lights.size());
     sc.lights.push_back(l);
 }

@@ -32,7 +32,7 @@ _FIELD_MAP = [
 
 class Scene:
     def __init__(self, preset="sponza", width=3840, height=2160, seed=0, point_lights=64, directional=True,
-                 lod_levels=0, size_scale=1.0, material_features=0, camera_step=0, skinned_fraction=0.0, lod_builder="quadtree"):
+                 lod_levels=0, size_scale=1.0, material_features=0, camera_step=0, skinned_fraction=0.0, lod_builder="quadtree", spot_every=0):
         lib = capi.scene_lib()
         p = capi.SceneParams()
         p.preset = PRESETS[preset] if isinstance(preset, str) else int(preset)
@@ -41,6 +41,7 @@ class Scene:
         p.lodLevels, p.sizeScale = lod_levels, size_scale
         p.materialFeatures = material_features
         p.cameraStep = camera_step
+        p.spotLightEvery = spot_every
         p.lodBuilder = {"quadtree": 0, "clusterlod": 1}[lod_builder]
         p.skinnedFraction1024 = int(round(skinned_fraction * 1024))
         self.preset, self.width, self.height = preset, width, height

@@ -45,7 +45,8 @@ typedef struct brmi_scene_params {
     uint32_t materialFeatures;    /* bit 0: some materials carry an OpenPBR coat, bit 1: some carry fuzz (default: neither) */
     uint32_t cameraStep;          /* frame number on the preset's camera path (0 = start); prevView is the view of step - 1 */
     uint32_t lodBuilder;          /* enum brmi_lod_builder */
-    uint32_t reserved[4];
+    uint32_t spotLightEvery;      /* k > 0: every k-th punctual light is a spot light (0 = point lights only) */
+    uint32_t reserved[3];
 } brmi_scene_params;
 
 /* Arrays a scene exposes.  Element layouts are the brmi_types.h structs. */
