@@ -702,7 +702,15 @@ bool buildMesh(brmi_scene& sc, const MeshDef& def, uint32_t meshIndex) {
     return true;
 }
 
-void addInstance(brmi_scene& sc, const InstanceDef& inst) {
+void addInstance(brmi_scene& sc, const InstanceDef& instIn) {
+    InstanceDef inst = instIn;
+    // materialFeatures bit 2: every third instance (not the first: usually the ground) is mirrored in its local x axis and drawn with
+    // reversed winding (negative-determinant transforms, BRMI_OBJECT_FLAG_REVERSE_WINDING)
+    if ((sc.params.materialFeatures & 4u) && sc.perMeshInstance.size() % 3u == 2u) {
+        M4 mirror = identity(); mirror.m[0][0] = -1.0;
+        inst.model = mul(mirror, inst.model);
+        inst.reverseWinding = !inst.reverseWinding;
+    }
     brmi_per_object o{};
     store(o.model, inst.model); store(o.prevModel, inst.model); store(o.modelInverse, inverse(inst.model));
     o.normalMatrixBufferIndex = (uint32_t)sc.perObject.size();

@@ -42,7 +42,7 @@ typedef struct brmi_scene_params {
     uint32_t lodLevels;           /* 0 = preset default; 1 = flat */
     float    sizeScale;           /* 1.0 = preset default triangle budget; <1 shrinks (tests) */
     uint32_t skinnedFraction1024; /* fraction (x/1024) of instances that are skinned; 0 = none */
-    uint32_t materialFeatures;    /* bit 0: some materials carry an OpenPBR coat, bit 1: some carry fuzz (default: neither) */
+    uint32_t materialFeatures;    /* bit 0: some materials carry an OpenPBR coat, bit 1: some carry fuzz, bit 2: every third instance is mirrored and drawn with reversed winding (default: none) */
     uint32_t cameraStep;          /* frame number on the preset's camera path (0 = start); prevView is the view of step - 1 */
     uint32_t lodBuilder;          /* enum brmi_lod_builder */
     uint32_t spotLightEvery;      /* k > 0: every k-th punctual light is a spot light (0 = point lights only) */

@@ -45,6 +45,8 @@ SCENE_CASES = {
     # LOD DAG from the reference's own builder (meshoptimizer + clusterlod.h, oracle/_ref): irregular meshlets, ~400-cluster groups
     # spot lights (cone attenuation in the shader, cone bounding spheres in the light clustering)
     "sponza_spots": ("sponza", 640, 360, dict(point_lights=48, size_scale=0.25, spot_every=2, material_features=1)),
+    # mirrored instances drawn with reversed winding
+    "bistro_mirrored": ("bistro", 640, 360, dict(point_lights=16, size_scale=0.3, material_features=4)),
     "tiny_clod": ("tiny", 256, 144, dict(point_lights=4, lod_builder="clusterlod")),
     "sponza_clod": ("sponza", 640, 360, dict(point_lights=32, size_scale=0.25, lod_builder="clusterlod")),
     "bistro_clod_skinned": ("bistro", 640, 360, dict(point_lights=32, size_scale=0.3, skinned_fraction=0.3, lod_builder="clusterlod")),

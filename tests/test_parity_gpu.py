@@ -12,7 +12,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["tiny", "tiny_lod", "tiny_coat_fuzz", "sponza_coat_fuzz", "sponza_small", "bistro_small", "tiny_skinned", "bistro_skinned", "tiny_clod", "sponza_clod", "bistro_clod_skinned", "sponza_spots"]
+CASES = ["tiny", "tiny_lod", "tiny_coat_fuzz", "sponza_coat_fuzz", "sponza_small", "bistro_small", "tiny_skinned", "bistro_skinned", "tiny_clod", "sponza_clod", "bistro_clod_skinned", "sponza_spots", "bistro_mirrored"]
 
 
 @pytest.fixture(scope="module")
