@@ -414,7 +414,10 @@ int brmi_shade(brmi_pass* p, brmi_stream stream) {
 int brmi_execute(brmi_pass* p, brmi_stream stream) {
     CHECK_READY(p);
     int rc;
-    if ((rc = brmi_clear_visibility(p, stream))) return rc;
+    p->fuseFrameClear = true;
+    rc = brmi_clear_visibility(p, stream);
+    p->fuseFrameClear = false;
+    if (rc) return rc;
     if ((rc = brmi_cull(p, 1, stream))) return rc;
     if ((rc = brmi_raster(p, 1, stream))) return rc;
     if (p->cfg.enableOcclusionCulling) {

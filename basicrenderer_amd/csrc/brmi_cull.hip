@@ -833,7 +833,8 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
     const bool hierarchy = p->maxLevelWidth <= HIER_CAP_MAX && !p->forceLevelKernels;
     const uint32_t* meshWidth = p->wsPtr<uint32_t>(p->ws.meshLevelWidth);
     if (phase == 1) {
-        BRMI_HIP(p, hipMemsetAsync(p->counters(), 0, p->ws.frameClearBytes, s));      // counters + both survivor bitmasks
+        if (!p->frameStateCleared) BRMI_HIP(p, hipMemsetAsync(p->counters(), 0, p->ws.frameClearBytes, s));      // counters + both survivor bitmasks
+        p->frameStateCleared = false;
         const dim3 hgrid(std::min(std::max(1u, p->scene.activeDrawCount), 16384u));
         if (hierarchy) {
             // narrow meshes (most instances) with the 6 KB variant, wide ones with the 24 KB variant; each launch skips the other class

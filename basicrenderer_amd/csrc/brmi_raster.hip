@@ -55,11 +55,14 @@ struct RasterArgs {
     uint32_t visW, visH, tilesX, bandY0, bandY1;
 };
 
-__global__ void __launch_bounds__(256) k_clear_vis(unsigned long long* vis, uint64_t n) {
+// `frameState` (may be null): the counters + survivor bitmasks block that the culling pass clears at the start of a frame; brmi_execute
+// has this kernel clear it too, one launch instead of a kernel and a fill.
+__global__ void __launch_bounds__(256) k_clear_vis(unsigned long long* vis, uint64_t n, uint4* frameState, uint64_t frameState16) {
     // 16 B per lane per store (n is a multiple of 64)
     ulonglong2* v2 = reinterpret_cast<ulonglong2*>(vis);
     const uint64_t n2 = n >> 1;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (uint64_t)gridDim.x * blockDim.x) v2[i] = make_ulonglong2(BRMI_VIS_EMPTY, BRMI_VIS_EMPTY);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < frameState16; i += (uint64_t)gridDim.x * blockDim.x) frameState[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 BRMI_DEV void clip_scanline(float value, float step, int& first, int& last, bool& has) {
@@ -456,7 +459,11 @@ __global__ void __launch_bounds__(256) k_depth_copy(const unsigned long long* vi
 }
 
 int launch_clear(brmi_pass* p, hipStream_t s) {
-    hipLaunchKernelGGL(k_clear_vis, dim3(2048), dim3(256), 0, s, static_cast<unsigned long long*>(p->res[BRMI_RES_VISIBILITY]) + p->bandFirstPixel, p->bandPixelCount);
+    // inside brmi_execute the culling pass follows immediately: take its frame clear along (frameClearBytes is a multiple of 256)
+    uint4* frameState = p->fuseFrameClear ? p->wsPtr<uint4>(p->ws.counters) : nullptr;
+    hipLaunchKernelGGL(k_clear_vis, dim3(2048), dim3(256), 0, s, static_cast<unsigned long long*>(p->res[BRMI_RES_VISIBILITY]) + p->bandFirstPixel, p->bandPixelCount,
+                       frameState, frameState ? p->ws.frameClearBytes / 16 : 0ull);
+    p->frameStateCleared = p->fuseFrameClear;
     BRMI_LAUNCH_CHECK(p, "k_clear_vis");
     return BRMI_OK;
 }
