@@ -29,7 +29,8 @@ class SceneStats(C.Structure):
 SCENE_ARRAYS = ["perObject", "normalMatrices", "perMesh", "perMeshInstance", "clodOffsets", "meshMetadata", "lodNodes",
                 "lodGroups", "lodSegments", "groupPageMap", "materials", "openpbrMaterials", "lights",
                 "activeLightIndices", "cameras", "cullingCameras", "viewRasterInfo", "perFrame", "activeDraws",
-                "skinningMatrices", "lutOdE", "lutOdAvg", "lutImE", "lutImAvg", "lutFuzzLTC"]
+                "skinningMatrices", "lutOdE", "lutOdAvg", "lutImE", "lutImAvg", "lutFuzzLTC",
+                "textureDescs", "texels", "samplerDescs", "srgbToLinear"]
 
 
 class SceneBuffers(C.Structure):
@@ -61,6 +62,9 @@ class SceneBuffers(C.Structure):
         ("lutIdealMetalEnergyComplement", vp),
         ("lutIdealMetalAvgEnergyComplement", vp),
         ("lutFuzzLTC", vp),
+        ("textures", vp), ("textureCount", u32),
+        ("samplers", vp), ("samplerCount", u32),
+        ("srgbToLinear", vp),
     ]
 
 

@@ -122,6 +122,13 @@ static void compute_sizes(brmi_pass* p) {
     p->deferredStripeCapacity = (uint32_t)(((p->bandPixelCount / 4096 + CNT_STRIPE_COUNT) / CNT_STRIPE_COUNT) * 4096);   // 64-tile runs of a stripe x 4096 pixels
     w.deferredPixels = take((uint64_t)3 * CNT_STRIPE_COUNT * p->deferredStripeCapacity * 4);      // one set of striped lists per layered class
     w.lutF = take((uint64_t)(32768 + 1024 + 1024 + 32 + 256) * 4);
+    // textured / alpha-tested scenes only: where each visible cluster's UV set lives, the texcoords of the resolve arena's vertices,
+    // and the alpha-test operands that travel with binned triangles
+    const bool uvs = p->sceneHasTextures || p->sceneHasAlphaTest;
+    w.clusterUv = take(uvs ? (uint64_t)c.maxVisibleClusters * 16 : 16);
+    w.resolveUVs = take(p->sceneHasTextures ? (uint64_t)p->resolveCapacity * 8 : 16);
+    w.binAlpha = take(p->sceneHasAlphaTest ? (uint64_t)p->binsX * p->binsY * p->binCapacity * 48 : 16);
+    w.overflowAlpha = take(p->sceneHasAlphaTest ? (uint64_t)CNT_STRIPE_COUNT * p->binOverflowPerStripe * 48 : 16);
     w.total = off;
     p->resNeed[BRMI_RES_WORKSPACE] = w.total;
 }
@@ -217,6 +224,26 @@ int brmi_set_scene(brmi_pass* p, const brmi_scene_buffers* scene) {
         if ((rc = read_back(p, op, sc.openpbrMaterials, sc.openpbrMaterialCount))) return rc;
         p->sceneHasCoat = p->sceneHasFuzz = false;
         for (const auto& m : op) { if (m.coatWeight > 0.0f) p->sceneHasCoat = true; if (m.fuzzWeight > 0.0f) p->sceneHasFuzz = true; }
+        // texture slots: the alpha-test variants of the rasteriser and the texture-sampling variant of the G-buffer pass are only
+        // launched for scenes that need them
+        std::vector<brmi_material_info> mats;
+        if ((rc = read_back(p, mats, sc.materials, sc.materialCount))) return rc;
+        p->sceneHasAlphaTest = p->sceneHasTextures = false;
+        for (size_t i = 0; i < mats.size(); i++) {
+            const brmi_material_info& m = mats[i];
+            if (m.materialFlags & (1u << 9)) return fail(p, BRMI_ERR_INVALID, "material %zu: MATERIAL_PARALLAX (height maps) is not supported by this path", i);
+            if (m.materialFlags & BRMI_MATERIAL_ALPHA_TEST) p->sceneHasAlphaTest = true;
+            if (m.materialFlags & BRMI_MATERIAL_ANY_TEXTURE) {
+                p->sceneHasTextures = true;
+                const uint32_t f = m.materialFlags;
+                if (((f & BRMI_MATERIAL_BASE_COLOR_TEXTURE) && m.baseColorUvSetIndex) || ((f & BRMI_MATERIAL_NORMAL_MAP) && m.normalUvSetIndex) || ((f & BRMI_MATERIAL_METALLIC_TEXTURE) && m.metallicUvSetIndex) ||
+                    ((f & BRMI_MATERIAL_ROUGHNESS_TEXTURE) && m.roughnessUvSetIndex) || ((f & BRMI_MATERIAL_EMISSIVE_TEXTURE) && m.emissiveUvSetIndex) || ((f & BRMI_MATERIAL_AO_TEXTURE) && m.aoUvSetIndex) ||
+                    ((f & BRMI_MATERIAL_OPACITY_TEXTURE) && m.opacityUvSetIndex))
+                    return fail(p, BRMI_ERR_INVALID, "material %zu: texture slots must use UV set 0 (only set 0 is decoded on this path)", i);
+            }
+        }
+        if (p->sceneHasTextures && (!sc.textures || !sc.samplers || !sc.srgbToLinear || sc.textureCount == 0 || sc.samplerCount == 0))
+            return fail(p, BRMI_ERR_INVALID, "brmi_set_scene: materials sample textures but the texture / sampler tables or the sRGB decode table are missing");
     }
     // per mesh: walk the BVH, collect the segments its leaves reference, depth of the tree
     p->hostSegPrefix.assign(segs.size(), 0);

@@ -5,9 +5,11 @@
 //   ClusterCullBody                                           BR/shaders/ClusterLOD/workGraphCulling.hlsl:2398-3330
 // but not how the reference schedules it.  MI355X-first differences:
 //   * HIP has no ExecuteIndirect, and a dependent chain of tiny dispatches is latency-bound
-//     (SURVEY.md 8a-2).  Every level is a fixed-size grid-stride launch that reads its record
-//     count from HBM, so the whole chain is a static launch sequence (graph-capturable, no host
-//     round trip); empty levels retire in ~2 us.
+//     (SURVEY.md 8a-2).  The default path walks each instance's BVH inside ONE launch with the
+//     frontier in LDS (k_cull_hierarchy: one wave64 per draw / replayed node).  Hierarchies whose
+//     widest level exceeds the LDS frontier fall back to one fixed-size grid-stride launch per
+//     level that reads its record count from HBM (k_cull_instances / k_traverse); either way the
+//     chain is a static launch sequence with no host round trip.
 //   * The reference appends survivors with wave ballots into one buffer, so the cluster index
 //     that ends up in the visibility key depends on atomic ordering.  Here survivors set one bit
 //     in a per-(instance, segment, meshlet) bitmask, a popcount scan ranks the bits, and a scatter
@@ -16,6 +18,7 @@
 //   * Frontier / bucket appends are wave-aggregated (one atomic per wave64).
 #include "brmi_device.h"
 #include "brmi_internal.h"
+#include "brmi_texture.h"
 
 namespace brmi {
 
@@ -713,7 +716,7 @@ __global__ void __launch_bounds__(256) k_scan_words(const uint32_t* bitmask, uin
 // shared words would serialise the whole rasteriser (~90 same-address atomics per microsecond).
 __global__ void __launch_bounds__(256) k_scatter_visible(const TempVisible* temp, uint32_t* counters, uint32_t tempCountIndex, const uint32_t* bitmask,
                                                         const uint32_t* wordPrefix, uint4* visible, uint32_t baseIndexCounter, uint32_t capacity, uint32_t visibleCapacity,
-                                                        brmi_scene_buffers sc, ClusterSetup* setup, uint32_t resolveCapacity, uint8_t* used) {
+                                                        brmi_scene_buffers sc, ClusterSetup* setup, uint32_t resolveCapacity, uint8_t* used, ClusterUv* clusterUv) {
     const uint8_t* const* slabs = sc.slabs;
     const uint32_t n = min(counters[tempCountIndex], visibleCapacity);
     const uint32_t base = baseIndexCounter == 0xFFFFFFFFu ? 0u : counters[baseIndexCounter];
@@ -771,6 +774,16 @@ __global__ void __launch_bounds__(256) k_scatter_visible(const TempVisible* temp
             cs.counts = verts | (tris << 8) | ((hdr->compressedPositionQuantExp & 0xFFu) << 16) | (((obj->objectFlags & BRMI_OBJECT_FLAG_REVERSE_WINDING) != 0 ? 1u : 0u) << 24)
                       | ((pm->vertexFlags & BRMI_VERTEX_SKINNED) ? BRMI_CS_SKINNED : 0u) | ((hdr->attributeMask & BRMI_PAGE_ATTRIBUTE_JOINTS) ? BRMI_CS_JOINTS : 0u)
                       | ((hdr->attributeMask & BRMI_PAGE_ATTRIBUTE_WEIGHTS) ? BRMI_CS_WEIGHTS : 0u);
+            if (clusterUv) {      // scenes with textured / alpha-tested materials: UV set 0 of the meshlet and the material's class
+                const uint32_t mflags = sc.materials[pm->materialDataIndex].materialFlags;
+                cs.counts |= ((mflags & BRMI_MATERIAL_ALPHA_TEST) ? BRMI_CS_ALPHA : 0u) | ((mflags & BRMI_MATERIAL_ANY_TEXTURE) ? BRMI_CS_TEXTURED : 0u);
+                ClusterUv cu{nullptr, nullptr};
+                if (hdr->uvSetCount != 0u) {
+                    cu.desc = slab + pageOff + hdr->uvDescriptorOffset + (vc_meshlet(t.packed) * hdr->uvSetCount) * 32u;
+                    cu.stream = slab + pageOff + *reinterpret_cast<const uint32_t*>(slab + pageOff + hdr->uvBitstreamDirectoryOffset);
+                }
+                clusterUv[dst] = cu;
+            }
             cs.jointDelta = (int32_t)(hdr->jointArrayOffset + desc->vertexAttributeOffset * 32u) - (int32_t)(hdr->normalArrayOffset + desc->vertexAttributeOffset * 4u);
             cs.weightDelta = (int32_t)(hdr->weightArrayOffset + desc->vertexAttributeOffset * 32u) - (int32_t)(hdr->normalArrayOffset + desc->vertexAttributeOffset * 4u);
             cs.perObjectIndex = inst.perObjectBufferIndex; cs.instanceIndex = instanceIndex; cs.viewId = vc_view(t.packed);
@@ -869,7 +882,8 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
         hipLaunchKernelGGL(k_scan_words, dim3(p->scanBlocks), dim3(256), 0, s, bitmask, p->totalWords, blockSums, wordPrefix);
     }
     hipLaunchKernelGGL(k_scatter_visible, dim3(smallGrid), dim3(256), 0, s, temp, p->counters(), (uint32_t)(phase == 1 ? CNT_TEMP_VISIBLE : CNT_TEMP_VISIBLE2), bitmask, wordPrefix,
-                       static_cast<uint4*>(p->res[BRMI_RES_VISIBLE_CLUSTERS]), phase == 1 ? 0xFFFFFFFFu : (uint32_t)CNT_VISIBLE, p->cfg.maxVisibleClusters, p->cfg.maxVisibleClusters, p->scene, p->wsPtr<ClusterSetup>(p->ws.clusterSetup), p->resolveCapacity, p->wsPtr<uint8_t>(p->ws.usedClusters));
+                       static_cast<uint4*>(p->res[BRMI_RES_VISIBLE_CLUSTERS]), phase == 1 ? 0xFFFFFFFFu : (uint32_t)CNT_VISIBLE, p->cfg.maxVisibleClusters, p->cfg.maxVisibleClusters, p->scene, p->wsPtr<ClusterSetup>(p->ws.clusterSetup), p->resolveCapacity, p->wsPtr<uint8_t>(p->ws.usedClusters),
+                       (p->sceneHasTextures || p->sceneHasAlphaTest) ? p->wsPtr<ClusterUv>(p->ws.clusterUv) : nullptr);
     BRMI_LAUNCH_CHECK(p, "compaction");
     return BRMI_OK;
 }

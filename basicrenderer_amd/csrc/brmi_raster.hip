@@ -25,6 +25,7 @@
 // Raster buckets (K4) collapse: with one PSO-free kernel there is nothing to sort by.
 #include "brmi_device.h"
 #include "brmi_internal.h"
+#include "brmi_texture.h"
 
 namespace brmi {
 
@@ -33,9 +34,13 @@ struct BinRecord {           // 64 B
     uint32_t clusterIndex, triAndFlags;      // tri | useScanlineRanges << 8 | rowCount << 16
     int32_t  minX, rectWidth, rowStart;
     float    sb0, sb1, dx_b0, dx_b1, dy_b0, dy_b1, d0, d1, d2;   // barycentrics at (minX, rowStart), their steps, vertex depths
-    uint32_t pad0, pad1;
+    uint32_t pad0, pad1;                      // pad0: strip (overflow queue only); pad1 != 0: alpha tested, its AlphaRecord sits at the same index of the side array
 };
 static_assert(sizeof(BinRecord) == 64, "one cache line");
+// what the alpha test of a binned triangle needs besides the record (softwareRaster.hlsl:525-540): only written / read for
+// clusters whose material is alpha tested, in scenes that have such materials
+struct AlphaRecord { AlphaTri tri; uint32_t materialDataIndex, pad[2]; };     // 48 B
+static_assert(sizeof(AlphaRecord) == 48, "AlphaRecord layout");
 constexpr int BIN_W = 256, BIN_ROWS = 16;          // bin = 4096 keys = 32 KB of LDS
 constexpr int BIN_W_SHIFT = 8, BIN_ROWS_SHIFT = 4;
 constexpr int BIN_WINDOW = 256;                     // bins a wave can count in LDS at once (cells of its bin bounding box)
@@ -44,6 +49,8 @@ constexpr int COOP_ENTRIES = 64;                    // triangles with more bin e
 struct RasterArgs {
     BinRecord* binRecords; uint32_t* binCounts; uint32_t binCapacity, binsX, binsY;
     BinRecord* overflow; uint32_t overflowPerStripe;     // 64 striped queues of records whose bin was full (pad0 = strip)
+    AlphaRecord* binAlpha; AlphaRecord* overflowAlpha;   // side arrays of binRecords / overflow (alpha-tested scenes only)
+    const ClusterUv* clusterUv;
     const float* objConst;   // per object: MVP (16), objectToClip (16), modelViewZ (4)
     int bigTriArea;          // clamped-bbox pixels above which a triangle is binned
     int debugFlags;          // experiments only (BRMI_RASTER_DEBUG): 1 = skip the direct walk, 2 = skip bin emission, 4 = skip the bin pass, 8 = direct walk without the atomic
@@ -86,11 +93,18 @@ struct LdsSink {
     BRMI_DEV void operator()(int px, int py, unsigned long long key) const { atomicMin(&tile[(px - x0) * BIN_ROWS + (py - y0)], key); }
 };
 
+// The per-pixel alpha test: nothing for the plain kernels, SWAlphaTestFailed on the pixel's texcoord for an alpha-tested record.
+struct NoAlpha { BRMI_DEV bool operator()(float, float, float) const { return false; } };
+struct TexAlpha {
+    const brmi_scene_buffers* sc; AlphaMaterial mat; AlphaTri tri; bool enabled;
+    BRMI_DEV bool operator()(float b0, float b1, float b2) const { return enabled && alpha_test_failed(*sc, mat, pixel_texcoord(tri, b0, b1, b2)); }
+};
+
 // One scanline of one triangle (softwareRaster.hlsl:506-609), barycentrics at the row start given, restricted to
 // pixels clipX0..clipX1.  The barycentrics are stepped pixel by pixel from the row's first pixel even when the walk
 // starts further right, so every value is the one the serial loop produces.
-template <typename Sink>
-BRMI_DEV void raster_row(const Sink& sink, int py, int minX, int rectWidth, bool useScanlineRanges, float sb0, float sb1,
+template <typename Sink, typename Alpha>
+BRMI_DEV void raster_row(const Sink& sink, const Alpha& alphaFails, int py, int minX, int rectWidth, bool useScanlineRanges, float sb0, float sb1,
                          float dx_b0, float dx_b1, float dx_b2, float d0, float d1, float d2, uint32_t clusterIndex, uint32_t t, int clipX0, int clipX1) {
     if (useScanlineRanges) {
         const float sb2 = 1.0f - sb0 - sb1;
@@ -105,8 +119,10 @@ BRMI_DEV void raster_row(const Sink& sink, int py, int minX, int rectWidth, bool
             if (x0 < clipX0) { for (int k = clipX0 - x0; k > 0; k--) { b0 += dx_b0; b1 += dx_b1; } x0 = clipX0; }
             for (int px = x0; px <= x1; px++) {
                 const float b2 = 1.0f - b0 - b1;
-                const float depth = b0 * d0 + b1 * d1 + b2 * d2;
-                sink(px, py, (unsigned long long)pack_vis_key(depth, clusterIndex, t));
+                if (!alphaFails(b0, b1, b2)) {
+                    const float depth = b0 * d0 + b1 * d1 + b2 * d2;
+                    sink(px, py, (unsigned long long)pack_vis_key(depth, clusterIndex, t));
+                }
                 b0 += dx_b0; b1 += dx_b1;
             }
         }
@@ -117,7 +133,7 @@ BRMI_DEV void raster_row(const Sink& sink, int py, int minX, int rectWidth, bool
         if (x0 < clipX0) { for (int k = clipX0 - x0; k > 0; k--) { b0 += dx_b0; b1 += dx_b1; } x0 = clipX0; }
         for (int px = x0; px <= x1; px++) {
             const float b2 = 1.0f - b0 - b1;
-            if (b0 >= 0.0f && b1 >= 0.0f && b2 >= 0.0f) {
+            if (b0 >= 0.0f && b1 >= 0.0f && b2 >= 0.0f && !alphaFails(b0, b1, b2)) {
                 const float depth = b0 * d0 + b1 * d1 + b2 * d2;
                 sink(px, py, (unsigned long long)pack_vis_key(depth, clusterIndex, t));
             }
@@ -127,7 +143,8 @@ BRMI_DEV void raster_row(const Sink& sink, int py, int minX, int rectWidth, bool
 }
 
 // Stores one record at a reserved slot of a bin; when the bin is full its rows are rasterised here with global atomics (counted).
-BRMI_DEV void raster_record_global(const RasterArgs& a, const BinRecord& r, uint32_t strip, uint32_t firstRow, uint32_t rowStep) {
+template <typename Alpha>
+BRMI_DEV void raster_record_global(const RasterArgs& a, const BinRecord& r, const Alpha& alpha, uint32_t strip, uint32_t firstRow, uint32_t rowStep) {
     const GlobalSink sink{a.vis, a.tilesX, 0};
     const uint32_t n = (r.triAndFlags >> 16) & 0xFFu;
     float sb0 = r.sb0, sb1 = r.sb1;
@@ -136,30 +153,47 @@ BRMI_DEV void raster_record_global(const RasterArgs& a, const BinRecord& r, uint
         for (; k < row; k++) { sb0 += r.dy_b0; sb1 += r.dy_b1; }
         const int py = r.rowStart + (int)row;
         if ((uint32_t)py >= a.bandY0 && (uint32_t)py < a.bandY1)
-            raster_row(sink, py, r.minX, r.rectWidth, (r.triAndFlags & 0x100u) != 0, sb0, sb1, r.dx_b0, r.dx_b1, -(r.dx_b0 + r.dx_b1), r.d0, r.d1, r.d2, r.clusterIndex, r.triAndFlags & 0x7Fu,
+            raster_row(sink, alpha, py, r.minX, r.rectWidth, (r.triAndFlags & 0x100u) != 0, sb0, sb1, r.dx_b0, r.dx_b1, -(r.dx_b0 + r.dx_b1), r.d0, r.d1, r.d2, r.clusterIndex, r.triAndFlags & 0x7Fu,
                        (int)(strip << BIN_W_SHIFT), (int)(strip << BIN_W_SHIFT) + BIN_W - 1);
     }
 }
+BRMI_DEV TexAlpha tex_alpha_of(const RasterArgs& a, const AlphaRecord& ar) { return TexAlpha{&a.sc, load_alpha_material(a.sc, ar.materialDataIndex), ar.tri, true}; }
 
 // Stores one record at a reserved slot of a bin.  A full bin sends the record to the overflow queue of the wave's stripe
 // (k_raster_overflow walks those row-parallel with global atomics); a full queue rasterises it right here.
-BRMI_DEV void bin_store(const RasterArgs& a, const BinRecord& r, uint32_t strip, uint32_t band, uint32_t slot) {
+// r.pad1 != 0: the record is alpha tested and its AlphaRecord `ar` travels with it.
+BRMI_DEV void bin_store(const RasterArgs& a, const BinRecord& r, const AlphaRecord& ar, uint32_t strip, uint32_t band, uint32_t slot) {
+    const bool alpha = r.pad1 != 0u;
     const uint32_t bin = band * a.binsX + strip;
-    if (slot < a.binCapacity) { a.binRecords[(size_t)bin * a.binCapacity + slot] = r; return; }
+    if (slot < a.binCapacity) {
+        a.binRecords[(size_t)bin * a.binCapacity + slot] = r;
+        if (alpha) a.binAlpha[(size_t)bin * a.binCapacity + slot] = ar;
+        return;
+    }
     const uint32_t stripe = blockIdx.x & (CNT_STRIPE_COUNT - 1u);
     const uint32_t q = atomicAdd(&a.counters[CNT_STRIPES + stripe * CNT_STRIPE_WORDS + STRIPE_OVERFLOW], 1u);
-    if (q < a.overflowPerStripe) { BinRecord o = r; o.pad0 = strip; a.overflow[(size_t)stripe * a.overflowPerStripe + q] = o; return; }
-    raster_record_global(a, r, strip, 0u, 1u);
+    if (q < a.overflowPerStripe) {
+        BinRecord o = r; o.pad0 = strip; a.overflow[(size_t)stripe * a.overflowPerStripe + q] = o;
+        if (alpha) a.overflowAlpha[(size_t)stripe * a.overflowPerStripe + q] = ar;
+        return;
+    }
+    if (alpha) raster_record_global(a, r, tex_alpha_of(a, ar), strip, 0u, 1u);
+    else raster_record_global(a, r, NoAlpha{}, strip, 0u, 1u);
 }
-BRMI_DEV void bin_append(const RasterArgs& a, const BinRecord& r, uint32_t strip, uint32_t band) {
-    bin_store(a, r, strip, band, atomicAdd(&a.binCounts[band * a.binsX + strip], 1u));
+BRMI_DEV void bin_append(const RasterArgs& a, const BinRecord& r, const AlphaRecord& ar, uint32_t strip, uint32_t band) {
+    bin_store(a, r, ar, strip, band, atomicAdd(&a.binCounts[band * a.binsX + strip], 1u));
 }
 
 #ifndef BRMI_RASTER_WAVES
 #define BRMI_RASTER_WAVES 1
 #endif
+// ALPHA: the scene has alpha-tested materials; clusters of such a material (BRMI_CS_ALPHA) also stage 1/w and the texcoord of their
+// vertices and test every covered pixel.  Scenes without them run the plain instantiation (no extra registers or LDS).
+template <bool ALPHA>
 __global__ void __launch_bounds__(64, BRMI_RASTER_WAVES) k_raster(RasterArgs a) {
     __shared__ float sx[BRMI_MESHLET_MAX_VERTS], sy[BRMI_MESHLET_MAX_VERTS], sd[BRMI_MESHLET_MAX_VERTS];
+    __shared__ float siw[ALPHA ? BRMI_MESHLET_MAX_VERTS : 1], su[ALPHA ? BRMI_MESHLET_MAX_VERTS : 1], sv[ALPHA ? BRMI_MESHLET_MAX_VERTS : 1];
+    __shared__ float tpA[ALPHA ? 9 : 1][64];
     __shared__ uint32_t binBase[BIN_WINDOW];
     __shared__ float tpF[9][64];
     __shared__ int tpI[4][64];
@@ -187,6 +221,10 @@ __global__ void __launch_bounds__(64, BRMI_RASTER_WAVES) k_raster(RasterArgs a) 
         // compute skinning, folded into the vertex fetch (softwareRaster.hlsl:349-360)
         const bool skinVerts = (cs.counts & (BRMI_CS_SKINNED | BRMI_CS_JOINTS)) == (BRMI_CS_SKINNED | BRMI_CS_JOINTS);
         const uint32_t skinSlot = skinVerts ? sc.perMeshInstance[cs.instanceIndex].skinningInstanceSlot : 0xFFFFFFFFu;
+        const bool alphaCluster = ALPHA && (cs.counts & BRMI_CS_ALPHA) != 0u;
+        ClusterUv cu{nullptr, nullptr};
+        AlphaMaterial amat{};
+        if (alphaCluster) { cu = a.clusterUv[clusterIndex]; amat = load_alpha_material(sc, cs.materialDataIndex); }
 
         // vertex stage -> LDS (softwareRaster.hlsl:339-387)
         for (uint32_t v = lane; v < vertCount; v += 64) {
@@ -208,6 +246,7 @@ __global__ void __launch_bounds__(64, BRMI_RASTER_WAVES) k_raster(RasterArgs a) 
             sx[v] = (ndcx + 1.0f) * 0.5f * visWidth + sMinXf;
             sy[v] = (1.0f - ndcy) * 0.5f * visHeight + sMinYf;
             sd[v] = -viewZ;
+            if (alphaCluster) { const f2 uv = decode_uv(cu, v); siw[v] = invW; su[v] = uv.x; sv[v] = uv.y; }
         }
         __syncthreads();
 
@@ -217,9 +256,11 @@ __global__ void __launch_bounds__(64, BRMI_RASTER_WAVES) k_raster(RasterArgs a) 
             bool active = t < triCount;
             float d0 = 0, d1 = 0, d2 = 0, row_b0 = 0, row_b1 = 0, dx_b0 = 0, dx_b1 = 0, dy_b0 = 0, dy_b1 = 0;
             int minX = 0, minY = 0, maxX = -1, maxY = -1;
+            AlphaRecord arec{};
             if (active) {
                 uint32_t i0 = triBase[t * 3u], i1 = triBase[t * 3u + 1u], i2 = triBase[t * 3u + 2u];
                 if (reverseWinding) { const uint32_t tmp = i1; i1 = i2; i2 = tmp; }
+                if (alphaCluster) { arec.tri = AlphaTri{siw[i0], siw[i1], siw[i2], f2{su[i0], sv[i0]}, f2{su[i1], sv[i1]}, f2{su[i2], sv[i2]}}; arec.materialDataIndex = cs.materialDataIndex; }
                 const float s0x = sx[i0], s0y = sy[i0], s1x = sx[i1], s1y = sy[i1], s2x = sx[i2], s2y = sy[i2];
                 d0 = sd[i0]; d1 = sd[i1]; d2 = sd[i2];
                 if (d0 <= 0.0f || d1 <= 0.0f || d2 <= 0.0f) active = false;
@@ -277,6 +318,10 @@ __global__ void __launch_bounds__(64, BRMI_RASTER_WAVES) k_raster(RasterArgs a) 
                     tpF[0][lane] = row_b0; tpF[1][lane] = row_b1; tpF[2][lane] = dx_b0; tpF[3][lane] = dx_b1; tpF[4][lane] = dy_b0; tpF[5][lane] = dy_b1;
                     tpF[6][lane] = d0; tpF[7][lane] = d1; tpF[8][lane] = d2;
                     tpI[0][lane] = minX; tpI[1][lane] = rectWidth; tpI[2][lane] = minY; tpI[3][lane] = yLo;
+                    if (alphaCluster) {
+                        tpA[0][lane] = arec.tri.invW0; tpA[1][lane] = arec.tri.invW1; tpA[2][lane] = arec.tri.invW2;
+                        tpA[3][lane] = arec.tri.uv0.x; tpA[4][lane] = arec.tri.uv0.y; tpA[5][lane] = arec.tri.uv1.x; tpA[6][lane] = arec.tri.uv1.y; tpA[7][lane] = arec.tri.uv2.x; tpA[8][lane] = arec.tri.uv2.y;
+                    }
                     __syncthreads();
                     for (uint32_t task = lane; task < totalRows; task += 64) {
                         uint32_t tri = 0;
@@ -287,7 +332,12 @@ __global__ void __launch_bounds__(64, BRMI_RASTER_WAVES) k_raster(RasterArgs a) 
                         const float t_dx0 = tpF[2][tri], t_dx1 = tpF[3][tri], t_dy0 = tpF[4][tri], t_dy1 = tpF[5][tri];
                         float sb0 = tpF[0][tri], sb1 = tpF[1][tri];
                         for (int k = py - t_minY; k > 0; k--) { sb0 += t_dy0; sb1 += t_dy1; }      // the serial loop's row stepping
-                        raster_row(gsink, py, t_minX, t_w, useScanlineRanges, sb0, sb1, t_dx0, t_dx1, -(t_dx0 + t_dx1), tpF[6][tri], tpF[7][tri], tpF[8][tri], clusterIndex, waveBase + tri,
+                        if (alphaCluster) {
+                            const TexAlpha ta{&a.sc, amat, AlphaTri{tpA[0][tri], tpA[1][tri], tpA[2][tri], f2{tpA[3][tri], tpA[4][tri]}, f2{tpA[5][tri], tpA[6][tri]}, f2{tpA[7][tri], tpA[8][tri]}}, true};
+                            raster_row(gsink, ta, py, t_minX, t_w, useScanlineRanges, sb0, sb1, t_dx0, t_dx1, -(t_dx0 + t_dx1), tpF[6][tri], tpF[7][tri], tpF[8][tri], clusterIndex, waveBase + tri,
+                                       t_minX, t_minX + t_w - 1);
+                        } else
+                        raster_row(gsink, NoAlpha{}, py, t_minX, t_w, useScanlineRanges, sb0, sb1, t_dx0, t_dx1, -(t_dx0 + t_dx1), tpF[6][tri], tpF[7][tri], tpF[8][tri], clusterIndex, waveBase + tri,
                                    t_minX, t_minX + t_w - 1);
                     }
                     __syncthreads();
@@ -328,10 +378,10 @@ __global__ void __launch_bounds__(64, BRMI_RASTER_WAVES) k_raster(RasterArgs a) 
                         BinRecord r;
                         r.clusterIndex = clusterIndex; r.triAndFlags = flags | ((uint32_t)n << 16);
                         r.minX = minX; r.rectWidth = rectWidth; r.rowStart = py;
-                        r.sb0 = sb0; r.sb1 = sb1; r.dx_b0 = dx_b0; r.dx_b1 = dx_b1; r.dy_b0 = dy_b0; r.dy_b1 = dy_b1; r.d0 = d0; r.d1 = d1; r.d2 = d2; r.pad0 = 0; r.pad1 = 0;
+                        r.sb0 = sb0; r.sb1 = sb1; r.dx_b0 = dx_b0; r.dx_b1 = dx_b1; r.dy_b0 = dy_b0; r.dy_b1 = dy_b1; r.d0 = d0; r.d1 = d1; r.d2 = d2; r.pad0 = 0; r.pad1 = alphaCluster ? 1u : 0u;
                         for (int st = strip0; st <= strip1; st++) {
-                            if (windowed) bin_store(a, r, (uint32_t)st, (uint32_t)band, atomicAdd(&binBase[(band - wb0) * winW + (st - ws0)], 1u));
-                            else bin_append(a, r, (uint32_t)st, (uint32_t)band);
+                            if (windowed) bin_store(a, r, arec, (uint32_t)st, (uint32_t)band, atomicAdd(&binBase[(band - wb0) * winW + (st - ws0)], 1u));
+                            else bin_append(a, r, arec, (uint32_t)st, (uint32_t)band);
                         }
                         for (int k = 0; k < n; k++) { sb0 += dy_b0; sb1 += dy_b1; }
                         py += n;
@@ -350,6 +400,12 @@ __global__ void __launch_bounds__(64, BRMI_RASTER_WAVES) k_raster(RasterArgs a) 
                 const int c_minX = __shfl(minX, src), c_w = __shfl(rectWidth, src), c_yLo = __shfl(yLo, src), c_yHi = __shfl(yHi, src);
                 const int c_band0 = __shfl(band0, src), c_band1 = __shfl(band1, src), c_strip0 = __shfl(strip0, src), c_strip1 = __shfl(strip1, src);
                 const uint32_t c_flags = (uint32_t)__shfl((int)flags, src);
+                AlphaRecord c_arec{};
+                if (alphaCluster) {
+                    c_arec.tri = AlphaTri{__shfl(arec.tri.invW0, src), __shfl(arec.tri.invW1, src), __shfl(arec.tri.invW2, src), f2{__shfl(arec.tri.uv0.x, src), __shfl(arec.tri.uv0.y, src)},
+                                          f2{__shfl(arec.tri.uv1.x, src), __shfl(arec.tri.uv1.y, src)}, f2{__shfl(arec.tri.uv2.x, src), __shfl(arec.tri.uv2.y, src)}};
+                    c_arec.materialDataIndex = cs.materialDataIndex;
+                }
                 float sb0 = c_sb0, sb1 = c_sb1;
                 int py = c_yLo;
                 for (int band = c_band0 + (int)lane; band <= c_band1; band += 64) {
@@ -359,7 +415,7 @@ __global__ void __launch_bounds__(64, BRMI_RASTER_WAVES) k_raster(RasterArgs a) 
                     BinRecord r;
                     r.clusterIndex = clusterIndex; r.triAndFlags = c_flags | ((uint32_t)n << 16);
                     r.minX = c_minX; r.rectWidth = c_w; r.rowStart = start;
-                    r.sb0 = sb0; r.sb1 = sb1; r.dx_b0 = c_dx0; r.dx_b1 = c_dx1; r.dy_b0 = c_dy0; r.dy_b1 = c_dy1; r.d0 = c_d0; r.d1 = c_d1; r.d2 = c_d2; r.pad0 = 0; r.pad1 = 0;
+                    r.sb0 = sb0; r.sb1 = sb1; r.dx_b0 = c_dx0; r.dx_b1 = c_dx1; r.dy_b0 = c_dy0; r.dy_b1 = c_dy1; r.d0 = c_d0; r.d1 = c_d1; r.d2 = c_d2; r.pad0 = 0; r.pad1 = alphaCluster ? 1u : 0u;
                     // all the band's bin slots are requested before the first one is used: the atomics overlap instead of costing one
                     // round trip per strip (a full-width triangle touches 15-30 strips)
                     for (int st0 = c_strip0; st0 <= c_strip1; st0 += 8) {
@@ -367,7 +423,7 @@ __global__ void __launch_bounds__(64, BRMI_RASTER_WAVES) k_raster(RasterArgs a) 
 #pragma unroll
                         for (int k = 0; k < 8; k++) slots[k] = (st0 + k <= c_strip1) ? atomicAdd(&a.binCounts[(uint32_t)band * a.binsX + (uint32_t)(st0 + k)], 1u) : 0u;
 #pragma unroll
-                        for (int k = 0; k < 8; k++) if (st0 + k <= c_strip1) bin_store(a, r, (uint32_t)(st0 + k), (uint32_t)band, slots[k]);
+                        for (int k = 0; k < 8; k++) if (st0 + k <= c_strip1) bin_store(a, r, c_arec, (uint32_t)(st0 + k), (uint32_t)band, slots[k]);
                     }
                 }
             }
@@ -381,6 +437,7 @@ __global__ void __launch_bounds__(64, BRMI_RASTER_WAVES) k_raster(RasterArgs a) 
 #ifndef BRMI_BIN_THREADS
 #define BRMI_BIN_THREADS 512
 #endif
+template <bool ALPHA>
 __global__ void __launch_bounds__(BRMI_BIN_THREADS) k_raster_bins(RasterArgs a) {
     __shared__ unsigned long long tile[BIN_W * BIN_ROWS];
     const uint32_t strip = blockIdx.x, band = blockIdx.y, bin = band * a.binsX + strip;
@@ -403,9 +460,14 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS) k_raster_bins(RasterArgs a) 
             float sb0 = r.sb0, sb1 = r.sb1;
             for (uint32_t k = 0; k < row; k++) { sb0 += r.dy_b0; sb1 += r.dy_b1; }
             const int py = r.rowStart + (int)row;
-            if ((uint32_t)py >= a.bandY0 && (uint32_t)py < a.bandY1)
-                raster_row(sink, py, r.minX, r.rectWidth, (r.triAndFlags & 0x100u) != 0, sb0, sb1, r.dx_b0, r.dx_b1, -(r.dx_b0 + r.dx_b1), r.d0, r.d1, r.d2, r.clusterIndex, r.triAndFlags & 0x7Fu,
+            if ((uint32_t)py >= a.bandY0 && (uint32_t)py < a.bandY1) {
+                if (ALPHA && r.pad1 != 0u)
+                    raster_row(sink, tex_alpha_of(a, a.binAlpha[(size_t)bin * a.binCapacity + ri]), py, r.minX, r.rectWidth, (r.triAndFlags & 0x100u) != 0, sb0, sb1, r.dx_b0, r.dx_b1, -(r.dx_b0 + r.dx_b1),
+                               r.d0, r.d1, r.d2, r.clusterIndex, r.triAndFlags & 0x7Fu, x0, x0 + BIN_W - 1);
+                else
+                raster_row(sink, NoAlpha{}, py, r.minX, r.rectWidth, (r.triAndFlags & 0x100u) != 0, sb0, sb1, r.dx_b0, r.dx_b1, -(r.dx_b0 + r.dx_b1), r.d0, r.d1, r.d2, r.clusterIndex, r.triAndFlags & 0x7Fu,
                            x0, x0 + BIN_W - 1);
+            }
         }
     }
     __syncthreads();
@@ -432,6 +494,7 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS) k_raster_bins(RasterArgs a) 
 // Records that did not fit their bin: four per wave64, one lane per row, global 64-bit atomics (the bins' merge is a plain
 // read-modify-write, so this runs after k_raster_bins).  The queue lengths are cleared with the frame's counters and, between the
 // two raster phases, by k_seed_phase2.
+template <bool ALPHA>
 __global__ void __launch_bounds__(64) k_raster_overflow(RasterArgs a) {
     const uint32_t lane = threadIdx.x, sub = lane >> 4, row = lane & 15u;
     // lane = stripe: all 64 queue lengths with one load; nearly every frame has none
@@ -445,7 +508,8 @@ __global__ void __launch_bounds__(64) k_raster_overflow(RasterArgs a) {
             const uint32_t ri = base + sub;
             if (ri >= n) continue;
             const BinRecord r = a.overflow[(size_t)stripe * a.overflowPerStripe + ri];
-            raster_record_global(a, r, r.pad0, row, 16u);
+            if (ALPHA && r.pad1 != 0u) raster_record_global(a, r, tex_alpha_of(a, a.overflowAlpha[(size_t)stripe * a.overflowPerStripe + ri]), r.pad0, row, 16u);
+            else raster_record_global(a, r, NoAlpha{}, r.pad0, row, 16u);
         }
     }
 }
@@ -483,9 +547,17 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
     a.overflow = p->wsPtr<BinRecord>(p->ws.binOverflow); a.overflowPerStripe = p->binOverflowPerStripe;
     a.objConst = p->wsPtr<float>(p->ws.objConst);
     a.bigTriArea = p->bigTriArea; a.debugFlags = p->rasterDebug;
-    hipLaunchKernelGGL(k_raster, dim3(p->rasterGrid), dim3(64), 0, s, a);
-    if (!(p->rasterDebug & 4)) hipLaunchKernelGGL(k_raster_bins, dim3(p->binsX, p->binsY), dim3(BRMI_BIN_THREADS), 0, s, a);
-    hipLaunchKernelGGL(k_raster_overflow, dim3(512), dim3(64), 0, s, a);
+    a.binAlpha = p->wsPtr<AlphaRecord>(p->ws.binAlpha); a.overflowAlpha = p->wsPtr<AlphaRecord>(p->ws.overflowAlpha);
+    a.clusterUv = p->wsPtr<ClusterUv>(p->ws.clusterUv);
+    if (p->sceneHasAlphaTest) {
+        hipLaunchKernelGGL(k_raster<true>, dim3(p->rasterGrid), dim3(64), 0, s, a);
+        if (!(p->rasterDebug & 4)) hipLaunchKernelGGL(k_raster_bins<true>, dim3(p->binsX, p->binsY), dim3(BRMI_BIN_THREADS), 0, s, a);
+        hipLaunchKernelGGL(k_raster_overflow<true>, dim3(512), dim3(64), 0, s, a);
+    } else {
+        hipLaunchKernelGGL(k_raster<false>, dim3(p->rasterGrid), dim3(64), 0, s, a);
+        if (!(p->rasterDebug & 4)) hipLaunchKernelGGL(k_raster_bins<false>, dim3(p->binsX, p->binsY), dim3(BRMI_BIN_THREADS), 0, s, a);
+        hipLaunchKernelGGL(k_raster_overflow<false>, dim3(512), dim3(64), 0, s, a);
+    }
     BRMI_LAUNCH_CHECK(p, "k_raster");
     return BRMI_OK;
 }

@@ -14,6 +14,7 @@
 //     or written by the wave is one contiguous 256 B..1 KB segment.
 #include "brmi_device.h"
 #include "brmi_internal.h"
+#include "brmi_texture.h"
 
 namespace brmi {
 
@@ -30,6 +31,7 @@ struct GBufferArgs {
     const ClusterSetup* setup; ResolveVertex* verts; ResolveTriangle* tris; uint32_t vertCapacity, triCapacity;
     MaterialWords* matWords;
     const uint8_t* used;           // per visible cluster: owns a pixel (valid when counters[CNT_RESOLVE_MARKED])
+    const ClusterUv* clusterUv; float2* uvs;      // textured scenes: UV set 0 of every visible cluster, decoded texcoords of the arena's vertices
 };
 
 BRMI_DEV f3 oct_decode_normal(uint32_t packed) {
@@ -95,6 +97,7 @@ __global__ void __launch_bounds__(64) k_resolve_setup(GBufferArgs a) {
             const f4 clip = mul_point(p, objectToClip);
             cx[v] = clip.x; cy[v] = clip.y; cw[v] = clip.w;
             a.verts[cs.vertBase + v] = ResolveVertex{p.x, p.y, p.z, n.x, n.y, n.z};
+            if (a.uvs && (cs.counts & BRMI_CS_TEXTURED)) { const f2 uv = decode_uv(a.clusterUv[c], v); a.uvs[cs.vertBase + v] = make_float2(uv.x, uv.y); }
         }
         __syncthreads();
         for (uint32_t t = lane; t < triCount; t += 64) {
@@ -129,6 +132,23 @@ BRMI_DEV f3 bary_lambda(const ResolveTriangle& r, float ndcX, float ndcY) {
     l.z = interpW * (0.0f + dx * r.ddx[2] + dy * r.ddy[2]);
     return l;
 }
+
+// CalcFullBary, the rest of the pixel part (clodResolveCommon.hlsli:128-141): screen-space derivatives of the barycentrics
+struct BaryDeriv { f3 ddx, ddy; };
+BRMI_DEV BaryDeriv bary_derivatives(const ResolveTriangle& r, f3 lambda, float ndcX, float ndcY, float winX, float winY) {
+    const float dx = ndcX - r.n0x, dy = ndcY - r.n0y;
+    const float interpInvW = r.invW0 + dx * r.ddxSum + dy * r.ddySum;
+    const float sx = 2.0f / winX, sy = 2.0f / winY;
+    const f3 ddx = f3{r.ddx[0], r.ddx[1], r.ddx[2]} * sx;
+    const f3 ddy = (f3{r.ddy[0], r.ddy[1], r.ddy[2]} * sy) * -1.0f;
+    const float ddxSum = r.ddxSum * sx, ddySum = (r.ddySum * sy) * -1.0f;
+    const float interpW_ddx = 1.0f / (interpInvW + ddxSum), interpW_ddy = 1.0f / (interpInvW + ddySum);
+    BaryDeriv d;
+    d.ddx = interpW_ddx * (lambda * interpInvW + ddx) - lambda;
+    d.ddy = interpW_ddy * (lambda * interpInvW + ddy) - lambda;
+    return d;
+}
+BRMI_DEV float swizzle4(f4 v, uint32_t idx) { return idx == 0u ? v.x : idx == 1u ? v.y : idx == 2u ? v.z : v.w; }
 
 // triangle + vertex tables of one pixel when its cluster has no arena space: the chain the setup kernel walks, per pixel
 BRMI_DEV void resolve_tables_inline(const GBufferArgs& a, const ClusterSetup& cs, uint32_t triId, ResolveTriangle& r, f3 p[3], f3 n[3]) {
@@ -176,11 +196,13 @@ constexpr int RESOLVE_WATERFALL = 4;     // distinct mesh instances per 8x8 tile
 
 // INLINE_TABLES: the arena may be too small for the frame, keep the per-pixel table path (it doubles the register count, so
 // the host only picks this variant when the arena cannot hold every cluster the configuration allows).
-template <bool INLINE_TABLES>
+// TEXTURED: some material of the scene samples textures (SampleMaterialEvalFromUvCache with its PSO_*_TEXTURE branches, evaluated
+// per pixel from the material's flags); scenes of constant-factor materials run the lean instantiation.
 #ifndef BRMI_GB_WAVES
 #define BRMI_GB_WAVES 6
 #endif
-__global__ void __launch_bounds__(256, INLINE_TABLES ? 1 : BRMI_GB_WAVES) k_gbuffer(GBufferArgs a) {
+template <bool INLINE_TABLES, bool TEXTURED>
+__global__ void __launch_bounds__(256, (INLINE_TABLES || TEXTURED) ? 1 : BRMI_GB_WAVES) k_gbuffer(GBufferArgs a) {
     const brmi_scene_buffers& sc = a.sc;
     const brmi_per_frame* pf = sc.perFrame;
     const uint32_t clusterCount = min(a.counters[CNT_VISIBLE] + a.counters[CNT_VISIBLE2], a.clusterCapacity);
@@ -213,17 +235,26 @@ __global__ void __launch_bounds__(256, INLINE_TABLES ? 1 : BRMI_GB_WAVES) k_gbuf
         ClusterSetup cs{};
         if (valid) { cs = a.setup[clusterIndex]; valid = triId < ((cs.counts >> 8) & 0xFFu); }
         // per-pixel part of the tables
-        ResolveTriangle r{}; f3 p[3] = {}, n[3] = {};
+        ResolveTriangle r{}; f3 p[3] = {}, n[3] = {}; f2 tc[3] = {};
         if (valid) {
+            const bool wantUv = TEXTURED && (cs.counts & BRMI_CS_TEXTURED) != 0u;
             if (cs.vertBase != BRMI_ARENA_NONE) {
                 r = a.tris[cs.triBase32 + triId];
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
-                    const ResolveVertex v = a.verts[cs.vertBase + ((r.indices >> (8 * k)) & 0xFFu)];
+                    const uint32_t vi = cs.vertBase + ((r.indices >> (8 * k)) & 0xFFu);
+                    const ResolveVertex v = a.verts[vi];
                     p[k] = f3{v.px, v.py, v.pz}; n[k] = f3{v.nx, v.ny, v.nz};
+                    if (wantUv) { const float2 u = a.uvs[vi]; tc[k] = f2{u.x, u.y}; }
                 }
-            } else if (INLINE_TABLES) resolve_tables_inline(a, cs, triId, r, p, n);
-            else valid = false;      // cannot happen: the arena holds every cluster of this configuration
+            } else if (INLINE_TABLES) {
+                resolve_tables_inline(a, cs, triId, r, p, n);
+                if (wantUv) {
+                    const ClusterUv cu = a.clusterUv[clusterIndex];
+#pragma unroll
+                    for (int k = 0; k < 3; k++) tc[k] = decode_uv(cu, (r.indices >> (8 * k)) & 0xFFu);
+                }
+            } else valid = false;      // cannot happen: the arena holds every cluster of this configuration
         }
         const float uvx = ((float)px + 0.5f) / winX, uvy = ((float)py + 0.5f) / winY;
         const float ndcX = uvx * 2.0f - 1.0f, ndcY = (1.0f - uvy) * 2.0f - 1.0f;
@@ -233,7 +264,7 @@ __global__ void __launch_bounds__(256, INLINE_TABLES ? 1 : BRMI_GB_WAVES) k_gbuf
 
         // object / material part: model, previous model, normal matrix and the material's packed words.  `obj`, `nm`, `mw`
         // are either scalar (constant address space, wave-uniform index) or per-lane pointers.
-        auto finish = [&](auto obj, auto nm, auto mw) {
+        auto finish = [&](auto obj, auto nm, auto mw, auto mat) {
             const m4 model = load_m4_any(&obj->model[0][0]);
             const f3 worldPosition = xyz(mul_point(posOS, model));
             const m4 normalMatrix = load_m4_any(nm);
@@ -243,12 +274,61 @@ __global__ void __launch_bounds__(256, INLINE_TABLES ? 1 : BRMI_GB_WAVES) k_gbuf
             const f3 prevWorld = xyz(mul_point(posOS, load_m4_any(&obj->prevModel[0][0])));
             const f4 clipPrev = mul_point(prevWorld, prevVP);
             const float mvx = clipCur.x / clipCur.w - clipPrev.x / clipPrev.w, mvy = clipCur.y / clipCur.w - clipPrev.y / clipPrev.w;
-            a.normals[i] = make_float4(worldNormal.x, worldNormal.y, worldNormal.z, mw->opIndexF);
-            a.albedo[i] = mw->albedo;
+            uint32_t albedoW = mw->albedo, mrW = mw->metallicRoughness;
+            unsigned long long emissiveW = mw->emissive;
+            f3 normalWS = worldNormal;
+            if (TEXTURED) {
+                const uint32_t flags = mat->materialFlags;
+                if (flags & BRMI_MATERIAL_ANY_TEXTURE) {
+                    // BuildClodMaterialUvData for UV set 0 + SampleMaterialEvalFromUvCache (utilities.hlsli:1850-2075)
+                    const BaryDeriv bd = bary_derivatives(r, l, ndcX, ndcY, winX, winY);
+                    const f3 us{tc[0].x, tc[1].x, tc[2].x}, vs{tc[0].y, tc[1].y, tc[2].y};
+                    const f2 uv{dot3(us, l), dot3(vs, l)}, dUVdx{dot3(us, bd.ddx), dot3(vs, bd.ddx)}, dUVdy{dot3(us, bd.ddy), dot3(vs, bd.ddy)};
+                    f4 baseColor{mat->baseColorFactor[0], mat->baseColorFactor[1], mat->baseColorFactor[2], mat->baseColorFactor[3]};
+                    if (flags & BRMI_MATERIAL_BASE_COLOR_TEXTURE) {
+                        const f4 t = sample_grad(sc, mat->baseColorTextureIndex, mat->baseColorSamplerIndex, uv, dUVdx, dUVdy);
+                        baseColor = f4{baseColor.x * t.x, baseColor.y * t.y, baseColor.z * t.z, baseColor.w * t.w};
+                    }
+                    float metallic = mat->metallicFactor, roughness = mat->roughnessFactor;
+                    if (flags & BRMI_MATERIAL_METALLIC_TEXTURE) metallic = swizzle4(sample_grad(sc, mat->metallicTextureIndex, mat->metallicSamplerIndex, uv, dUVdx, dUVdy), mat->metallicChannel) * mat->metallicFactor;
+                    if (flags & BRMI_MATERIAL_ROUGHNESS_TEXTURE) roughness = swizzle4(sample_grad(sc, mat->roughnessTextureIndex, mat->roughnessSamplerIndex, uv, dUVdx, dUVdy), mat->roughnessChannel) * mat->roughnessFactor;
+                    if (flags & BRMI_MATERIAL_NORMAL_MAP) {
+                        // dpdx / dpdy through the model's 3x3 (clodResolveCommon.hlsli:1607-1624), cotangent_frame_from_derivs (utilities.hlsli:323-336)
+                        const f3 pxs{p[0].x, p[1].x, p[2].x}, pys{p[0].y, p[1].y, p[2].y}, pzs{p[0].z, p[1].z, p[2].z};
+                        const f3 dpdx = mul_v3m3(f3{dot3(pxs, bd.ddx), dot3(pys, bd.ddx), dot3(pzs, bd.ddx)}, model);
+                        const f3 dpdy = mul_v3m3(f3{dot3(pxs, bd.ddy), dot3(pys, bd.ddy), dot3(pzs, bd.ddy)}, model);
+                        const f3 dp2perp = cross3(dpdy, worldNormal), dp1perp = cross3(worldNormal, dpdx);
+                        const f3 T = dp2perp * dUVdx.x + dp1perp * dUVdy.x, B = dp2perp * dUVdx.y + dp1perp * dUVdy.y;
+                        const float invmax = rsqrtf_(max2(dot3(T, T), dot3(B, B)));
+                        const f3 Tn = T * invmax, Bn = B * invmax;
+                        const f4 t = sample_grad(sc, mat->normalTextureIndex, mat->normalSamplerIndex, uv, dUVdx, dUVdy);
+                        f3 tn = normalize3(f3{t.x, t.y, t.z} * 2.0f - f3{1.0f, 1.0f, 1.0f});
+                        if (flags & BRMI_MATERIAL_NEGATE_NORMALS) tn = -tn;
+                        if (flags & BRMI_MATERIAL_INVERT_NORMAL_GREEN) tn.y = -tn.y;
+                        normalWS = normalize3(f3{(tn.x * Tn.x + tn.y * Bn.x) + tn.z * worldNormal.x, (tn.x * Tn.y + tn.y * Bn.y) + tn.z * worldNormal.y, (tn.x * Tn.z + tn.y * Bn.z) + tn.z * worldNormal.z});
+                    }
+                    float ao = 1.0f;
+                    if (flags & BRMI_MATERIAL_AO_TEXTURE) ao = swizzle4(sample_grad(sc, mat->aoMapIndex, mat->aoSamplerIndex, uv, dUVdx, dUVdy), mat->aoChannel);
+                    f3 emissiveIn{mat->emissiveFactor[0], mat->emissiveFactor[1], mat->emissiveFactor[2]};
+                    if (flags & BRMI_MATERIAL_EMISSIVE_TEXTURE) {
+                        const f4 t = sample_grad(sc, mat->emissiveTextureIndex, mat->emissiveSamplerIndex, uv, dUVdx, dUVdy);
+                        emissiveIn = f3{swizzle4(t, mat->emissiveChannels[0]), swizzle4(t, mat->emissiveChannels[1]), swizzle4(t, mat->emissiveChannels[2])} * emissiveIn;
+                        // ResolveCanonicalOpenPBRSurface: an all-zero sampled emissive falls back to the OpenPBR record's
+                        const uint32_t opIndex = mat->openPBRMaterialDataIndex;
+                        const f3 canonical = f3{sc.openpbrMaterials[opIndex].emissionColor[0], sc.openpbrMaterials[opIndex].emissionColor[1], sc.openpbrMaterials[opIndex].emissionColor[2]} * sc.openpbrMaterials[opIndex].emissionLuminance;
+                        const f3 e = dot3(emissiveIn, emissiveIn) > 0.0f ? emissiveIn : canonical;
+                        emissiveW = pack_half4(e.x, e.y, e.z, 0.0f);
+                    }
+                    albedoW = pack_unorm4(baseColor.x, baseColor.y, baseColor.z, ao);
+                    mrW = (pack_unorm4(metallic, roughness, 0.0f, 0.0f) & 0xFFFFu) | (mrW & 0xFFFF0000u);       // coat roughness / fuzz weight stay the material's
+                }
+            }
+            a.normals[i] = make_float4(normalWS.x, normalWS.y, normalWS.z, mw->opIndexF);
+            a.albedo[i] = albedoW;
             a.coat[i] = mw->coat;
-            a.emissive[i] = mw->emissive;
+            a.emissive[i] = emissiveW;
             a.fuzz[i] = mw->fuzz;
-            a.metallicRoughness[i] = mw->metallicRoughness;
+            a.metallicRoughness[i] = mrW;
             a.motion[i] = f32_to_f16_bits(mvx) | (f32_to_f16_bits(mvy) << 16);
         };
         // waterfall over the distinct mesh instances of the tile (usually one or two)
@@ -256,7 +336,7 @@ __global__ void __launch_bounds__(256, INLINE_TABLES ? 1 : BRMI_GB_WAVES) k_gbuf
         for (int it = 0; pending != 0ull; it++) {
             if (it == RESOLVE_WATERFALL) {      // a tile of many small instances: per-lane loads for the rest
                 if ((pending >> lane_id()) & 1ull)
-                    finish(sc.perObject + cs.perObjectIndex, sc.normalMatrices + (size_t)cs.normalMatrixIndex * 16u, a.matWords + cs.materialDataIndex);
+                    finish(sc.perObject + cs.perObjectIndex, sc.normalMatrices + (size_t)cs.normalMatrixIndex * 16u, a.matWords + cs.materialDataIndex, sc.materials + cs.materialDataIndex);
                 break;
             }
             const int lead = __ffsll((unsigned long long)pending) - 1;
@@ -266,7 +346,7 @@ __global__ void __launch_bounds__(256, INLINE_TABLES ? 1 : BRMI_GB_WAVES) k_gbuf
             const uint32_t uMat = (uint32_t)__builtin_amdgcn_readlane((int)cs.materialDataIndex, lead);
             const uint64_t same = __ballot(valid && cs.instanceIndex == uInst);
             pending &= ~same;
-            if ((same >> lane_id()) & 1ull) finish(kconst(sc.perObject) + uObj, kconst(sc.normalMatrices) + (size_t)uNm * 16u, kconst(a.matWords) + uMat);
+            if ((same >> lane_id()) & 1ull) finish(kconst(sc.perObject) + uObj, kconst(sc.normalMatrices) + (size_t)uNm * 16u, kconst(a.matWords) + uMat, kconst(sc.materials) + uMat);
         }
     }
 }
@@ -287,10 +367,18 @@ int launch_gbuffer(brmi_pass* p, hipStream_t s) {
     a.vertCapacity = p->resolveCapacity; a.triCapacity = p->resolveCapacity;
     a.matWords = p->wsPtr<MaterialWords>(p->ws.matWords);
     a.used = p->wsPtr<uint8_t>(p->ws.usedClusters);
+    a.clusterUv = p->sceneHasTextures ? p->wsPtr<ClusterUv>(p->ws.clusterUv) : nullptr;
+    a.uvs = p->sceneHasTextures ? p->wsPtr<float2>(p->ws.resolveUVs) : nullptr;
     hipLaunchKernelGGL(k_mark_used_clusters, dim3(2048), dim3(256), 0, s, a, p->wsPtr<uint8_t>(p->ws.usedClusters), p->counters());
     hipLaunchKernelGGL(k_resolve_setup, dim3(8192), dim3(64), 0, s, a);
-    if ((uint64_t)p->resolveCapacity >= (uint64_t)p->cfg.maxVisibleClusters * BRMI_MESHLET_MAX_TRIS) hipLaunchKernelGGL(k_gbuffer<false>, dim3(4096), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(k_gbuffer<true>, dim3(4096), dim3(256), 0, s, a);
+    const bool lean = (uint64_t)p->resolveCapacity >= (uint64_t)p->cfg.maxVisibleClusters * BRMI_MESHLET_MAX_TRIS;
+    if (p->sceneHasTextures) {
+        if (lean) hipLaunchKernelGGL((k_gbuffer<false, true>), dim3(4096), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_gbuffer<true, true>), dim3(4096), dim3(256), 0, s, a);
+    } else {
+        if (lean) hipLaunchKernelGGL((k_gbuffer<false, false>), dim3(4096), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_gbuffer<true, false>), dim3(4096), dim3(256), 0, s, a);
+    }
     BRMI_LAUNCH_CHECK(p, "k_gbuffer");
     return BRMI_OK;
 }

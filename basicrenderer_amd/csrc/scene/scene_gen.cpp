@@ -178,6 +178,7 @@ struct MeshletBuild {
     int32_t  refinedGroup;        // mesh-local, -1 terminal
     std::vector<float> pos;       // 81*3
     std::vector<uint32_t> nrm;    // 81
+    std::vector<float> uv;        // V*2 (meshes with a UV set only)
     std::vector<uint32_t> joints; // V*8 (skinned only)
     std::vector<float> weights;   // V*8
     std::vector<uint8_t> tris;    // 3 local indices per triangle; empty = the implicit 8x8-quad grid over 9x9 vertices
@@ -219,6 +220,10 @@ struct brmi_scene {
     std::vector<uint32_t> activeDraws;
     std::vector<float> skinningMatrices;
     std::vector<uint16_t> lutOdE, lutOdAvg, lutImE, lutImAvg; std::vector<float> lutLtc;
+    std::vector<brmi_texture_desc> textureDescs;   // texels = byte offset into `texels`
+    std::vector<uint8_t> texels;
+    std::vector<brmi_sampler_desc> samplerDescs;
+    std::vector<float> srgbToLinear;
     brmi_scene_stats stats{};
     std::vector<uint64_t> meshLod0Triangles;        // per mesh: triangles of its finest level
     bool failed = false;                            // a mesh could not be built (reference LOD builder missing)
@@ -248,7 +253,24 @@ brmi_group_page_map_entry allocPage(brmi_scene& sc, const std::vector<uint8_t>& 
 inline size_t align4(size_t v) { return (v + 3u) & ~size_t(3); }
 
 // Serialise meshlets [list] as one page blob (section order of BuildPackedTriangleMeshPageBlob).
-std::vector<uint8_t> buildPageBlob(const std::vector<const MeshletBuild*>& ms, bool skinned) {
+// QuantizeUvOffset / BitsNeededForRange / AppendBits (BR/src/Mesh/ClusterLODUtilities.cpp:58-110,508-517)
+uint32_t quantizeUvOffset(float value) {
+    const long long scaled = std::llround((double)value * (double)BRMI_UV_QUANTIZATION_SCALE);
+    return (uint32_t)std::max(0ll, std::min(scaled, 0xFFFFFFFFll));
+}
+uint32_t bitsNeededForRange(uint32_t range) { uint32_t b = 0; while (range) { b++; range >>= 1; } return b ? b : 1u; }
+void appendBits(std::vector<uint32_t>& words, uint64_t& cursor, uint32_t value, uint32_t bitCount) {
+    if (bitCount == 0) return;
+    const size_t needWords = (size_t)((cursor + bitCount + 31ull) / 32ull);
+    if (words.size() < needWords) words.resize(needWords, 0u);
+    const uint64_t off = cursor & 31ull, wi = cursor >> 5, mask = bitCount >= 32u ? 0xFFFFFFFFull : ((1ull << bitCount) - 1ull);
+    const uint64_t v = (uint64_t)value & mask;
+    words[(size_t)wi] |= (uint32_t)(v << off);
+    if (off + bitCount > 32u) words[(size_t)wi + 1] |= (uint32_t)(v >> (32u - off));
+    cursor += bitCount;
+}
+
+std::vector<uint8_t> buildPageBlob(const std::vector<const MeshletBuild*>& ms, bool skinned, bool hasUv) {
     const uint32_t M = (uint32_t)ms.size();
     uint32_t totalVerts = 0, totalTris = 0;
     for (auto* m : ms) { totalVerts += m->vertCount(); totalTris += m->triCount(); }
@@ -256,10 +278,35 @@ std::vector<uint8_t> buildPageBlob(const std::vector<const MeshletBuild*>& ms, b
     h.meshletCount = M;
     h.compressedPositionQuantExp = BRMI_POSITION_FORMAT_FLOAT3;
     h.attributeMask = BRMI_PAGE_ATTRIBUTE_NORMAL | (skinned ? (BRMI_PAGE_ATTRIBUTE_JOINTS | BRMI_PAGE_ATTRIBUTE_WEIGHTS) : 0u);
-    h.uvSetCount = 0;
+    h.uvSetCount = hasUv ? 1u : 0u;
     h.descriptorOffset = (uint32_t)align4(sizeof(brmi_page_header));
     size_t cur = h.descriptorOffset + (size_t)M * sizeof(brmi_meshlet_descriptor);
     h.uvDescriptorOffset = 0;
+    // UV set 0: per-meshlet descriptor (min, 1/65535 scale, bit widths) + one bitstream per set (ClusterLODUtilities.cpp:1267-1308,1712-1742)
+    std::vector<brmi_meshlet_uv_descriptor> uvDescs;
+    std::vector<uint32_t> uvWords;
+    if (hasUv) {
+        h.uvDescriptorOffset = (uint32_t)align4(cur);
+        cur = h.uvDescriptorOffset + (size_t)M * sizeof(brmi_meshlet_uv_descriptor);
+        uint64_t bitCursor = 0;
+        for (auto* m : ms) {
+            const uint32_t V = m->vertCount();
+            float minU = FLT_MAX, minV = FLT_MAX, maxU = -FLT_MAX, maxV = -FLT_MAX;
+            for (uint32_t v = 0; v < V; v++) { minU = std::min(minU, m->uv[v * 2]); maxU = std::max(maxU, m->uv[v * 2]); minV = std::min(minV, m->uv[v * 2 + 1]); maxV = std::max(maxV, m->uv[v * 2 + 1]); }
+            if (V == 0) minU = minV = maxU = maxV = 0.0f;
+            brmi_meshlet_uv_descriptor d{};
+            d.uvBitOffset = (uint32_t)bitCursor;
+            d.uvMinU = minU; d.uvMinV = minV; d.uvScaleU = 1.0f / BRMI_UV_QUANTIZATION_SCALE; d.uvScaleV = 1.0f / BRMI_UV_QUANTIZATION_SCALE;
+            const uint32_t bitsU = bitsNeededForRange(quantizeUvOffset(std::max(0.0f, maxU - minU))), bitsV = bitsNeededForRange(quantizeUvOffset(std::max(0.0f, maxV - minV)));
+            d.uvBits = (bitsU & 0xFFu) | ((bitsV & 0xFFu) << 8);
+            const uint32_t maxEncU = bitsU >= 32u ? 0xFFFFFFFFu : ((1u << bitsU) - 1u), maxEncV = bitsV >= 32u ? 0xFFFFFFFFu : ((1u << bitsV) - 1u);
+            for (uint32_t v = 0; v < V; v++) {
+                appendBits(uvWords, bitCursor, std::min(maxEncU, quantizeUvOffset(std::max(0.0f, m->uv[v * 2] - minU))), bitsU);
+                appendBits(uvWords, bitCursor, std::min(maxEncV, quantizeUvOffset(std::max(0.0f, m->uv[v * 2 + 1] - minV))), bitsV);
+            }
+            uvDescs.push_back(d);
+        }
+    }
     h.positionBitstreamOffset = (uint32_t)align4(cur);
     cur = h.positionBitstreamOffset + (size_t)totalVerts * 12;
     h.normalArrayOffset = (uint32_t)align4(cur);
@@ -270,6 +317,12 @@ std::vector<uint8_t> buildPageBlob(const std::vector<const MeshletBuild*>& ms, b
         h.weightArrayOffset = (uint32_t)align4(cur); cur = h.weightArrayOffset + (size_t)totalVerts * 32;
     }
     h.uvBitstreamDirectoryOffset = 0;
+    uint32_t uvBitstreamOffset = 0;
+    if (hasUv) {
+        h.uvBitstreamDirectoryOffset = (uint32_t)align4(cur);
+        uvBitstreamOffset = (uint32_t)align4(h.uvBitstreamDirectoryOffset + 4u);      // one directory entry per UV set
+        cur = uvBitstreamOffset + uvWords.size() * 4 + 4;                               // + one word: a 32-bit read may straddle the end
+    }
     h.boneIndexStreamOffset = (uint32_t)align4(cur);
     size_t boneWords = 0;
     if (skinned) boneWords = (size_t)M * 4;   // every skinned meshlet lists 4 bones
@@ -278,6 +331,11 @@ std::vector<uint8_t> buildPageBlob(const std::vector<const MeshletBuild*>& ms, b
     cur = h.triangleStreamOffset + (size_t)totalTris * 3;
     std::vector<uint8_t> blob(align4(cur), 0);
     std::memcpy(blob.data(), &h, sizeof(h));
+    if (hasUv) {
+        std::memcpy(blob.data() + h.uvDescriptorOffset, uvDescs.data(), uvDescs.size() * sizeof(brmi_meshlet_uv_descriptor));
+        std::memcpy(blob.data() + h.uvBitstreamDirectoryOffset, &uvBitstreamOffset, 4);
+        if (!uvWords.empty()) std::memcpy(blob.data() + uvBitstreamOffset, uvWords.data(), uvWords.size() * 4);
+    }
 
     uint32_t posCursor = 0, attrCursor = 0, triCursor = 0, boneCursor = 0;
     for (uint32_t i = 0; i < M; i++) {
@@ -317,10 +375,12 @@ std::vector<uint8_t> buildPageBlob(const std::vector<const MeshletBuild*>& ms, b
     return blob;
 }
 
-size_t meshletPageBytes(const MeshletBuild& m, bool skinned) { return 64 + (size_t)m.vertCount() * 16 + (size_t)m.triCount() * 3 + 4 + (skinned ? (size_t)m.vertCount() * 64 + 16 : 0); }
+size_t meshletPageBytes(const MeshletBuild& m, bool skinned, bool hasUv) {
+    return 64 + (size_t)m.vertCount() * 16 + (size_t)m.triCount() * 3 + 4 + (skinned ? (size_t)m.vertCount() * 64 + 16 : 0) + (hasUv ? 32 + (size_t)m.vertCount() * 8 + 8 : 0);
+}
 
 // Built-in LOD DAG: a quadtree over the patch grids (level-L meshlets are 8x8 quads with stride 2^L, groups are 4x4 meshlets).
-uint32_t buildQuadtreeDag(const MeshDef& def, std::vector<MeshletBuild>& meshlets, std::vector<GroupBuild>& groups) {
+uint32_t buildQuadtreeDag(const MeshDef& def, bool hasUv, std::vector<MeshletBuild>& meshlets, std::vector<GroupBuild>& groups) {
     const uint32_t levels = std::max(1u, std::min(def.lodLevels, 7u));
     // (level, patch) -> first group id and group-grid dims
     struct LevelPatch { uint32_t firstGroup, gw, gh, firstMeshlet, mw, mh; };
@@ -347,6 +407,7 @@ uint32_t buildQuadtreeDag(const MeshDef& def, std::vector<MeshletBuild>& meshlet
                     m.refinedGroup = (int32_t)(prev.firstGroup + cj * prev.gw + ci);
                 }
                 m.pos.resize(81 * 3); m.nrm.resize(81);
+                if (hasUv) m.uv.resize(81 * 2);
                 V3 lo{1e30, 1e30, 1e30}, hi{-1e30, -1e30, -1e30};
                 for (uint32_t lj = 0; lj < 9; lj++) for (uint32_t li = 0; li < 9; li++) {
                     double u = (double)((mi * 8 + li) * su) / NU, v = (double)((mj * 8 + lj) * sv) / NV;
@@ -358,6 +419,7 @@ uint32_t buildQuadtreeDag(const MeshDef& def, std::vector<MeshletBuild>& meshlet
                     uint32_t k = lj * 9 + li;
                     m.pos[k * 3 + 0] = (float)P.x; m.pos[k * 3 + 1] = (float)P.y; m.pos[k * 3 + 2] = (float)P.z;
                     m.nrm[k] = octEncode(n);
+                    if (hasUv) { m.uv[k * 2] = (float)(u * p.nu0); m.uv[k * 2 + 1] = (float)(v * p.nv0); }   // one texture repeat per LOD-0 meshlet
                     lo = {std::min(lo.x, P.x), std::min(lo.y, P.y), std::min(lo.z, P.z)};
                     hi = {std::max(hi.x, P.x), std::max(hi.y, P.y), std::max(hi.z, P.z)};
                 }
@@ -463,10 +525,10 @@ ClodRefApi* clodRef() {
 //             and through `refined` rule 2 of clusterlod.h)
 //   cluster -> meshlet with its own vertex / triangle counts, `refined` = refinedGroup
 // Returns the number of DAG depths, 0 on failure.
-uint32_t buildClusterLodDag(const MeshDef& def, std::vector<MeshletBuild>& meshlets, std::vector<GroupBuild>& groups) {
+uint32_t buildClusterLodDag(const MeshDef& def, bool hasUv, std::vector<MeshletBuild>& meshlets, std::vector<GroupBuild>& groups) {
     ClodRefApi* api = clodRef();
     if (!api) return 0;
-    std::vector<float> pos, nrm; std::vector<uint32_t> idx;
+    std::vector<float> pos, nrm, uvs; std::vector<uint32_t> idx;
     for (const PatchDef& p : def.patches) {
         const uint32_t NU = p.nu0 * 8, NV = p.nv0 * 8, base = (uint32_t)(pos.size() / 3);
         for (uint32_t j = 0; j <= NV; j++) for (uint32_t i = 0; i <= NU; i++) {
@@ -476,6 +538,7 @@ uint32_t buildClusterLodDag(const MeshDef& def, std::vector<MeshletBuild>& meshl
             const V3 n = normalize(cross(evalPatch(p, u + hu, v) - evalPatch(p, u - hu, v), evalPatch(p, u, v + hv) - evalPatch(p, u, v - hv)));
             pos.push_back((float)P.x); pos.push_back((float)P.y); pos.push_back((float)P.z);
             nrm.push_back((float)n.x); nrm.push_back((float)n.y); nrm.push_back((float)n.z);
+            uvs.push_back((float)(u * p.nu0)); uvs.push_back((float)(v * p.nv0));
         }
         for (uint32_t qj = 0; qj < NV; qj++) for (uint32_t qi = 0; qi < NU; qi++) {
             const uint32_t a = base + qj * (NU + 1) + qi, b = a + 1, c = a + NU + 2, d = a + NU + 1;
@@ -506,9 +569,11 @@ uint32_t buildClusterLodDag(const MeshDef& def, std::vector<MeshletBuild>& meshl
         m.level = groups[k.group].level; m.patch = 0; m.mi = ci; m.mj = 0; m.group = (uint32_t)k.group; m.refinedGroup = k.refined;
         const uint32_t V = k.vertexCount, T = k.triangleCount;
         m.pos.resize((size_t)V * 3); m.nrm.resize(V);
+        if (hasUv) m.uv.resize((size_t)V * 2);
         V3 lo{1e30, 1e30, 1e30}, hi{-1e30, -1e30, -1e30};
         for (uint32_t v = 0; v < V; v++) {
             const uint32_t src = vref[k.firstVertex + v];
+            if (hasUv) { m.uv[(size_t)v * 2] = uvs[(size_t)src * 2]; m.uv[(size_t)v * 2 + 1] = uvs[(size_t)src * 2 + 1]; }
             for (int q = 0; q < 3; q++) m.pos[v * 3 + q] = pos[(size_t)src * 3 + q];
             m.nrm[v] = octEncode(V3{nrm[(size_t)src * 3], nrm[(size_t)src * 3 + 1], nrm[(size_t)src * 3 + 2]});
             lo = {std::min(lo.x, (double)m.pos[v * 3]), std::min(lo.y, (double)m.pos[v * 3 + 1]), std::min(lo.z, (double)m.pos[v * 3 + 2])};
@@ -540,7 +605,8 @@ uint32_t buildClusterLodDag(const MeshDef& def, std::vector<MeshletBuild>& meshl
 bool buildMesh(brmi_scene& sc, const MeshDef& def, uint32_t meshIndex) {
     std::vector<MeshletBuild> meshlets;
     std::vector<GroupBuild> groups;
-    const uint32_t levels = sc.params.lodBuilder == BRMI_LOD_BUILDER_CLUSTERLOD ? buildClusterLodDag(def, meshlets, groups) : buildQuadtreeDag(def, meshlets, groups);
+    const bool hasUv = (sc.params.materialFeatures & 24u) != 0u;
+    const uint32_t levels = sc.params.lodBuilder == BRMI_LOD_BUILDER_CLUSTERLOD ? buildClusterLodDag(def, hasUv, meshlets, groups) : buildQuadtreeDag(def, hasUv, meshlets, groups);
     if (levels == 0) { sc.failed = true; return false; }
 
     // segments: partition each group's meshlets by refinedGroup (stable)
@@ -556,7 +622,7 @@ bool buildMesh(brmi_scene& sc, const MeshDef& def, uint32_t meshIndex) {
             std::vector<Sphere> parts; size_t bytes = 0;
             auto close = [&]() { if (s.meshlets.empty()) return; s.cull = enclose(parts); segs.push_back(s); s.meshlets.clear(); parts.clear(); bytes = 0; };
             for (uint32_t mi : g.meshlets) if (meshlets[mi].refinedGroup == k) {
-                const size_t need = meshletPageBytes(meshlets[mi], def.skinned);
+                const size_t need = meshletPageBytes(meshlets[mi], def.skinned, hasUv);
                 if (bytes + need + 256 > BRMI_PAGE_SIZE) close();
                 s.meshlets.push_back(mi); parts.push_back(meshlets[mi].bounds); bytes += need;
             }
@@ -573,12 +639,12 @@ bool buildMesh(brmi_scene& sc, const MeshDef& def, uint32_t meshIndex) {
         size_t bytes = 64;
         auto flush = [&]() {
             if (cur.empty()) return;
-            auto blob = buildPageBlob(cur, def.skinned);
+            auto blob = buildPageBlob(cur, def.skinned, hasUv);
             sc.pageMap.push_back(allocPage(sc, blob));
             cur.clear(); curSegs.clear(); bytes = 64;
         };
         for (size_t si = 0; si < segs.size(); si++) {
-            size_t need = 64; for (uint32_t mi : segs[si].meshlets) need += meshletPageBytes(meshlets[mi], def.skinned);
+            size_t need = 64; for (uint32_t mi : segs[si].meshlets) need += meshletPageBytes(meshlets[mi], def.skinned, hasUv);
             if (bytes + need > BRMI_PAGE_SIZE) flush();
             segs[si].pageIndex = (uint32_t)(sc.pageMap.size() - pageMapBase);
             segs[si].firstMeshletInPage = (uint32_t)cur.size();
@@ -740,7 +806,84 @@ void addInstance(brmi_scene& sc, const InstanceDef& instIn) {
     }
 }
 
+// ---- procedural textures (materialFeatures bits 3 / 4) ----------------------------------------------------------------
+// RGBA8 with a full box-filtered mip chain.  kind 0: base colour (sRGB) with an alpha mask of round holes; 1: occlusion (R) /
+// roughness (G) / metallic (B), linear; 2: tangent-space normal map; 3: emissive (sRGB) sparse dots; 4: opacity (A) stripes.
+uint32_t addTexture(brmi_scene& sc, uint32_t kind, uint32_t size, uint32_t seed) {
+    brmi_texture_desc d{};
+    d.texels = reinterpret_cast<const uint8_t*>((uintptr_t)sc.texels.size());
+    d.width = size; d.height = size; d.format = (kind == 0 || kind == 3) ? BRMI_TEXTURE_FORMAT_RGBA8_UNORM_SRGB : BRMI_TEXTURE_FORMAT_RGBA8_UNORM;
+    std::vector<float> lvl((size_t)size * size * 4);
+    auto q8 = [](double x) { return (uint8_t)std::lround(std::max(0.0, std::min(1.0, x)) * 255.0); };
+    for (uint32_t y = 0; y < size; y++) for (uint32_t x = 0; x < size; x++) {
+        const double u = (x + 0.5) / size, v = (y + 0.5) / size;
+        float* t = &lvl[((size_t)y * size + x) * 4];
+        const double n = fbm(u * 8.0, v * 8.0, seed), n2 = fbm(u * 16.0 + 3.0, v * 16.0 + 7.0, seed ^ 0x9E37u);
+        if (kind == 0) {
+            const bool brick = (((int)(v * 8.0) & 1) ? std::fmod(u * 4.0 + 0.5, 1.0) : std::fmod(u * 4.0, 1.0)) < 0.06 || std::fmod(v * 8.0, 1.0) < 0.1;
+            const double base = brick ? 0.35 : 0.75;
+            t[0] = (float)(base + 0.25 * n); t[1] = (float)(base * 0.9 + 0.2 * n2); t[2] = (float)(base * 0.8 + 0.15 * n);
+            // alpha: 4x4 round holes with a soft edge (the cutoff of an alpha-tested material cuts through the gradient)
+            const double cx = std::fmod(u * 4.0, 1.0) - 0.5, cy = std::fmod(v * 4.0, 1.0) - 0.5, r = std::sqrt(cx * cx + cy * cy);
+            t[3] = (float)std::max(0.0, std::min(1.0, (r - 0.22) * 10.0 + 0.5));
+        } else if (kind == 1) {
+            t[0] = (float)(0.6 + 0.4 * n); t[1] = (float)(0.2 + 0.8 * n2); t[2] = (float)((std::fmod(u * 6.0, 1.0) < 0.5) == (std::fmod(v * 6.0, 1.0) < 0.5) ? 0.9 : 0.05); t[3] = 1.0f;
+        } else if (kind == 2) {
+            const double e = 1.0 / size;
+            const double hx = fbm((u + e) * 8.0, v * 8.0, seed) - fbm((u - e) * 8.0, v * 8.0, seed), hy = fbm(u * 8.0, (v + e) * 8.0, seed) - fbm(u * 8.0, (v - e) * 8.0, seed);
+            V3 nn = normalize(V3{-hx * 24.0, -hy * 24.0, 1.0});
+            t[0] = (float)(nn.x * 0.5 + 0.5); t[1] = (float)(nn.y * 0.5 + 0.5); t[2] = (float)(nn.z * 0.5 + 0.5); t[3] = 1.0f;
+        } else if (kind == 3) {
+            const double cx = std::fmod(u * 6.0, 1.0) - 0.5, cy = std::fmod(v * 6.0, 1.0) - 0.5;
+            const double g = std::max(0.0, 1.0 - std::sqrt(cx * cx + cy * cy) * 5.0);
+            t[0] = (float)g; t[1] = (float)(g * (0.4 + 0.6 * n)); t[2] = (float)(g * 0.3); t[3] = 1.0f;
+        } else {
+            t[0] = t[1] = t[2] = 1.0f;
+            t[3] = (float)std::max(0.0, std::min(1.0, (std::fabs(std::fmod(u * 5.0 + v * 2.0, 1.0) - 0.5) - 0.15) * 8.0 + 0.5));
+        }
+    }
+    uint32_t w = size, offsetTexels = 0, level = 0;
+    for (;;) {
+        d.mipOffset[level] = offsetTexels;
+        for (size_t k = 0; k < (size_t)w * w * 4; k++) sc.texels.push_back(q8(lvl[k]));
+        offsetTexels += w * w; level++;
+        if (w == 1) break;
+        const uint32_t h2 = w / 2;
+        std::vector<float> nxt((size_t)h2 * h2 * 4);
+        for (uint32_t y = 0; y < h2; y++) for (uint32_t x = 0; x < h2; x++) for (int c = 0; c < 4; c++)
+            nxt[((size_t)y * h2 + x) * 4 + c] = 0.25f * (lvl[((size_t)(2 * y) * w + 2 * x) * 4 + c] + lvl[((size_t)(2 * y) * w + 2 * x + 1) * 4 + c] +
+                                                        lvl[((size_t)(2 * y + 1) * w + 2 * x) * 4 + c] + lvl[((size_t)(2 * y + 1) * w + 2 * x + 1) * 4 + c]);
+        lvl.swap(nxt); w = h2;
+    }
+    d.mipCount = level;
+    sc.textureDescs.push_back(d);
+    return (uint32_t)sc.textureDescs.size() - 1;
+}
+
+struct TextureSet { std::vector<uint32_t> base, orm, normal, emissive, opacity; };
+TextureSet addTextures(brmi_scene& sc) {
+    // samplers: the reference's default (Sampler.cpp:20-40: trilinear, wrap), a clamp / mirror one, linear with nearest mip, all point
+    sc.samplerDescs.push_back({BRMI_ADDRESS_WRAP, BRMI_ADDRESS_WRAP, BRMI_FILTER_LINEAR, BRMI_FILTER_LINEAR, BRMI_FILTER_LINEAR, 0.0f, 0.0f, FLT_MAX});
+    sc.samplerDescs.push_back({BRMI_ADDRESS_CLAMP, BRMI_ADDRESS_MIRROR, BRMI_FILTER_LINEAR, BRMI_FILTER_LINEAR, BRMI_FILTER_LINEAR, 0.0f, 0.0f, FLT_MAX});
+    sc.samplerDescs.push_back({BRMI_ADDRESS_WRAP, BRMI_ADDRESS_WRAP, BRMI_FILTER_LINEAR, BRMI_FILTER_LINEAR, BRMI_FILTER_POINT, 0.5f, 0.0f, 6.0f});
+    sc.samplerDescs.push_back({BRMI_ADDRESS_MIRROR, BRMI_ADDRESS_WRAP, BRMI_FILTER_POINT, BRMI_FILTER_POINT, BRMI_FILTER_POINT, 0.0f, 1.0f, FLT_MAX});
+    sc.srgbToLinear.resize(256);
+    for (int c = 0; c < 256; c++) { const double x = c / 255.0; sc.srgbToLinear[c] = (float)(x <= 0.04045 ? x / 12.92 : std::pow((x + 0.055) / 1.055, 2.4)); }
+    TextureSet t;
+    const uint32_t seed = 0x7E57u + sc.params.seed;
+    const uint32_t sizes[4] = {256, 128, 512, 64};
+    for (uint32_t k = 0; k < 4; k++) t.base.push_back(addTexture(sc, 0, sizes[k], seed + k));
+    for (uint32_t k = 0; k < 2; k++) t.orm.push_back(addTexture(sc, 1, sizes[k], seed + 16 + k));
+    for (uint32_t k = 0; k < 2; k++) t.normal.push_back(addTexture(sc, 2, sizes[k], seed + 32 + k));
+    t.emissive.push_back(addTexture(sc, 3, 128, seed + 48));
+    t.opacity.push_back(addTexture(sc, 4, 128, seed + 64));
+    return t;
+}
+
 void addMaterials(brmi_scene& sc, Pcg32& rng, uint32_t count) {
+    const bool textured = (sc.params.materialFeatures & 24u) != 0u, alphaTested = (sc.params.materialFeatures & 16u) != 0u;
+    TextureSet tex;
+    if (textured) tex = addTextures(sc);
     for (uint32_t i = 0; i < count; i++) {
         brmi_material_info m{};
         std::memset(&m, 0, sizeof(m));
@@ -754,6 +897,35 @@ void addMaterials(brmi_scene& sc, Pcg32& rng, uint32_t count) {
         if (emissive) { m.emissiveFactor[0] = rng.range(0.0f, 2.0f); m.emissiveFactor[1] = rng.range(0.0f, 2.0f); m.emissiveFactor[2] = rng.range(0.0f, 2.0f); }
         m.emissiveFactor[3] = 1.0f;
         m.compileFlagsID = 0; m.rasterBucketIndex = 0; m.openPBRMaterialDataIndex = i;
+        m.baseColorChannels[0] = 0; m.baseColorChannels[1] = 1; m.baseColorChannels[2] = 2; m.baseColorChannels[3] = 3;
+        m.normalChannels[0] = 0; m.normalChannels[1] = 1; m.normalChannels[2] = 2;
+        m.emissiveChannels[0] = 0; m.emissiveChannels[1] = 1; m.emissiveChannels[2] = 2;
+        if (textured && (i % 4) != 3) {           // every fourth material stays constant-factor
+            m.materialFlags |= BRMI_MATERIAL_TEXTURED | BRMI_MATERIAL_BASE_COLOR_TEXTURE;
+            m.baseColorTextureIndex = tex.base[i % tex.base.size()]; m.baseColorSamplerIndex = (i / 4) % 4u;
+            m.baseColorFactor[0] = m.baseColorFactor[0] * 0.5f + 0.5f; m.baseColorFactor[1] = m.baseColorFactor[1] * 0.5f + 0.5f; m.baseColorFactor[2] = m.baseColorFactor[2] * 0.5f + 0.5f;
+            if ((i % 2) == 0) {                  // glTF packing: occlusion R, roughness G, metallic B of one texture
+                m.materialFlags |= BRMI_MATERIAL_METALLIC_TEXTURE | BRMI_MATERIAL_ROUGHNESS_TEXTURE;
+                m.metallicTextureIndex = m.roughnessTextureIndex = tex.orm[(i / 2) % tex.orm.size()];
+                m.metallicSamplerIndex = m.roughnessSamplerIndex = 0; m.metallicChannel = 2; m.roughnessChannel = 1;
+                m.metallicFactor = 1.0f; m.roughnessFactor = 1.0f;
+                if ((i % 3) == 0) { m.materialFlags |= BRMI_MATERIAL_AO_TEXTURE; m.aoMapIndex = m.metallicTextureIndex; m.aoSamplerIndex = 0; m.aoChannel = 0; }
+            }
+            if ((i % 3) != 1) {
+                m.materialFlags |= BRMI_MATERIAL_NORMAL_MAP; m.normalTextureIndex = tex.normal[i % tex.normal.size()]; m.normalSamplerIndex = (i % 5) == 0 ? 1u : 0u;
+                if ((i % 7) == 2) m.materialFlags |= BRMI_MATERIAL_INVERT_NORMAL_GREEN;
+            }
+            if ((i % 5) == 2) {
+                m.materialFlags |= BRMI_MATERIAL_EMISSIVE_TEXTURE; m.emissiveTextureIndex = tex.emissive[0]; m.emissiveSamplerIndex = 0;
+                m.emissiveFactor[0] = 1.5f; m.emissiveFactor[1] = 1.0f; m.emissiveFactor[2] = 0.5f;
+            }
+        }
+        if (alphaTested && (i % 3) == 0) {
+            m.materialFlags |= BRMI_MATERIAL_ALPHA_TEST | BRMI_MATERIAL_TEXTURED | BRMI_MATERIAL_BASE_COLOR_TEXTURE;
+            m.baseColorTextureIndex = tex.base[i % tex.base.size()]; m.baseColorSamplerIndex = (i / 3) % 3u;     // linear-filtered samplers cut through the soft edge
+            m.alphaCutoff = 0.35f + 0.05f * (float)(i % 5);
+            if ((i % 2) == 0) { m.materialFlags |= BRMI_MATERIAL_OPACITY_TEXTURE; m.opacityTextureIndex = tex.opacity[0]; m.opacitySamplerIndex = 0; }
+        }
         sc.materials.push_back(m);
         brmi_openpbr_material_info o{};
         std::memset(&o, 0, sizeof(o));
@@ -1192,6 +1364,10 @@ int brmi_scene_array(const brmi_scene* s, uint32_t id, const void** ptr, uint64_
         case BRMI_ARR_LUT_IM_ENERGY: ARR(s->lutImE, 1);
         case BRMI_ARR_LUT_IM_AVG_ENERGY: ARR(s->lutImAvg, 1);
         case BRMI_ARR_LUT_FUZZ_LTC: ARR(s->lutLtc, 4);
+        case BRMI_ARR_TEXTURE_DESCS: ARR(s->textureDescs, 1);
+        case BRMI_ARR_TEXELS: ARR(s->texels, 1);
+        case BRMI_ARR_SAMPLER_DESCS: ARR(s->samplerDescs, 1);
+        case BRMI_ARR_SRGB_TO_LINEAR: ARR(s->srgbToLinear, 1);
         default: return -1;
     }
 #undef ARR

@@ -27,7 +27,9 @@ _FIELD_MAP = [
     ("lutOpaqueDielectricEnergyComplement", "lutOdE", None), ("lutOpaqueDielectricAvgEnergyComplement", "lutOdAvg", None),
     ("lutIdealMetalEnergyComplement", "lutImE", None), ("lutIdealMetalAvgEnergyComplement", "lutImAvg", None),
     ("lutFuzzLTC", "lutFuzzLTC", None),
+    ("samplers", "samplerDescs", "samplerCount"), ("srgbToLinear", "srgbToLinear", None),
 ]
+TEXTURE_DESC_BYTES = 96      # brmi_texture_desc; its first 8 bytes are the texel pointer (generator output: byte offset into `texels`)
 
 
 class Scene:
@@ -88,7 +90,17 @@ class Scene:
             setattr(sb, field, a.ctypes.data if a.size else None)
             if cnt:
                 setattr(sb, cnt, self.counts[arr])
+        if self.counts["textureDescs"]:
+            descs = self._relocated_texture_descs(self.arrays["texels"].ctypes.data)
+            self._keep.append(descs)
+            sb.textures, sb.textureCount = descs.ctypes.data, self.counts["textureDescs"]
         return sb
+
+    def _relocated_texture_descs(self, texel_base):
+        descs = self.arrays["textureDescs"].copy()
+        ptrs = descs.view(np.uint64).reshape(-1, TEXTURE_DESC_BYTES // 8)[:, 0]
+        ptrs += np.uint64(texel_base)
+        return descs
 
     def camera_host(self):
         return self.arrays["cameras"]
@@ -123,4 +135,6 @@ class Scene:
                 self.device_arrays[arr] = keep[-1]      # the camera manager's role in tests: rewrite a buffer in place
             if cnt:
                 setattr(sb, cnt, self.counts[arr])
+        if self.counts["textureDescs"]:
+            sb.textures, sb.textureCount = up(self._relocated_texture_descs(up(self.arrays["texels"]))), self.counts["textureDescs"]
         return sb, keep

@@ -90,6 +90,12 @@ typedef struct brmi_scene_buffers {
     const uint16_t* lutIdealMetalEnergyComplement;           /* [32 alpha][32 cos] */
     const uint16_t* lutIdealMetalAvgEnergyComplement;        /* [32 alpha] */
     const float*    lutFuzzLTC;                               /* [32 rough][32 cos][4]: aInv,bInv,refl,0 */
+    /* material textures (the descriptor-heap slots MaterialInfo indexes); all may be null / 0 for a scene of
+     * constant-factor materials.  srgbToLinear: float[256], the sRGB decode of an 8-bit code (injected like the LUTs:
+     * pow() differs between math libraries). */
+    const brmi_texture_desc* textures;     uint32_t textureCount;
+    const brmi_sampler_desc* samplers;     uint32_t samplerCount;
+    const float*             srgbToLinear;
 } brmi_scene_buffers;
 
 /* ---- graph resources the pass declares (DeclareResourceUsages) ---------------------------- */

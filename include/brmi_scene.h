@@ -42,7 +42,9 @@ typedef struct brmi_scene_params {
     uint32_t lodLevels;           /* 0 = preset default; 1 = flat */
     float    sizeScale;           /* 1.0 = preset default triangle budget; <1 shrinks (tests) */
     uint32_t skinnedFraction1024; /* fraction (x/1024) of instances that are skinned; 0 = none */
-    uint32_t materialFeatures;    /* bit 0: some materials carry an OpenPBR coat, bit 1: some carry fuzz, bit 2: every third instance is mirrored and drawn with reversed winding (default: none) */
+    uint32_t materialFeatures;    /* bit 0: some materials carry an OpenPBR coat, bit 1: some carry fuzz, bit 2: every third instance is mirrored and drawn with reversed winding,
+                                     bit 3: meshes carry a UV set and most materials sample textures (base colour, metallic / roughness, emissive, AO, normal map),
+                                     bit 4: every third material is alpha tested against its base-colour / opacity texture (implies bit 3) (default: none) */
     uint32_t cameraStep;          /* frame number on the preset's camera path (0 = start); prevView is the view of step - 1 */
     uint32_t lodBuilder;          /* enum brmi_lod_builder */
     uint32_t spotLightEvery;      /* k > 0: every k-th punctual light is a spot light (0 = point lights only) */
@@ -76,6 +78,10 @@ enum brmi_scene_array {
     BRMI_ARR_LUT_IM_ENERGY,         /* uint16[32][32]      ideal-metal energy complement (alpha, cos) */
     BRMI_ARR_LUT_IM_AVG_ENERGY,     /* uint16[32]          its average (alpha) */
     BRMI_ARR_LUT_FUZZ_LTC,          /* float[32][32][4]    fuzz LTC aInv, bInv, reflectance, 0 (rough, cos) */
+    BRMI_ARR_TEXTURE_DESCS,         /* brmi_texture_desc[]; `texels` holds the BYTE OFFSET into BRMI_ARR_TEXELS: add the base after upload */
+    BRMI_ARR_TEXELS,                /* uint8[]             RGBA8 texels of every texture, mip chains packed */
+    BRMI_ARR_SAMPLER_DESCS,         /* brmi_sampler_desc[] */
+    BRMI_ARR_SRGB_TO_LINEAR,        /* float[256] */
     BRMI_ARR_COUNT
 };
 

@@ -55,8 +55,24 @@ extern "C" {
 #define BRMI_OBJECT_FLAG_REVERSE_WINDING (1u << 0)
 #define BRMI_VERTEX_SKINNED           (1u << 3)
 /* BR/shaders/Include/materialFlags.hlsli (subset the path reads) */
-#define BRMI_MATERIAL_ALPHA_TEST      (1u << 13)
-#define BRMI_MATERIAL_DOUBLE_SIDED     (1u << 8)
+#define BRMI_MATERIAL_TEXTURED             (1u << 0)
+#define BRMI_MATERIAL_BASE_COLOR_TEXTURE   (1u << 1)
+#define BRMI_MATERIAL_NORMAL_MAP           (1u << 2)
+#define BRMI_MATERIAL_AO_TEXTURE           (1u << 3)
+#define BRMI_MATERIAL_EMISSIVE_TEXTURE     (1u << 4)
+#define BRMI_MATERIAL_METALLIC_TEXTURE     (1u << 6)
+#define BRMI_MATERIAL_ROUGHNESS_TEXTURE    (1u << 7)
+#define BRMI_MATERIAL_DOUBLE_SIDED         (1u << 8)
+#define BRMI_MATERIAL_NEGATE_NORMALS       (1u << 10)
+#define BRMI_MATERIAL_INVERT_NORMAL_GREEN  (1u << 11)
+#define BRMI_MATERIAL_OPACITY_TEXTURE      (1u << 12)
+#define BRMI_MATERIAL_ALPHA_TEST           (1u << 13)
+/* every material texture slot the path samples (parallax / height maps and the OpenPBR coat / fuzz textures are not) */
+#define BRMI_MATERIAL_ANY_TEXTURE (BRMI_MATERIAL_BASE_COLOR_TEXTURE | BRMI_MATERIAL_NORMAL_MAP | BRMI_MATERIAL_AO_TEXTURE | \
+                                   BRMI_MATERIAL_EMISSIVE_TEXTURE | BRMI_MATERIAL_METALLIC_TEXTURE | BRMI_MATERIAL_ROUGHNESS_TEXTURE | \
+                                   BRMI_MATERIAL_OPACITY_TEXTURE)
+/* page attribute: the page carries UV sets (CLodPageHeader::uvSetCount > 0) */
+#define BRMI_UV_QUANTIZATION_SCALE    65535.0f      /* BR/src/Mesh/ClusterLODUtilities.cpp:45-46 */
 /* BR/shaders/Include/constants.hlsli:9-12 */
 #define BRMI_MIN_PERCEPTUAL_ROUGHNESS 0.06f
 #define BRMI_MIN_N_DOT_V              1e-4f
@@ -365,6 +381,32 @@ typedef struct brmi_openpbr_material_info {
     uint32_t geometryThinWalled, pad0, pad1, pad2;
     uint32_t textureBindings[38];   /* coat/fuzz texture+sampler indices, channels, uv sets, streaming ids */
 } brmi_openpbr_material_info;               /* 400 B */
+
+/* ---- textures and samplers ---------------------------------------------------------------
+ * What a bindless descriptor-heap slot stands for on this boundary: `MaterialInfo::*TextureIndex` indexes
+ * brmi_scene_buffers::textures, `*SamplerIndex` indexes brmi_scene_buffers::samplers.  Texels are RGBA8, row-major,
+ * the mip chain tightly packed (level l starts mipOffset[l] texels after `texels`, size max(1, w >> l) x max(1, h >> l)).
+ * The sampler is evaluated in software (DESIGN.md "software sampler"): rhi::SamplerDesc fields of
+ * BR/src/Resources/Sampler.cpp:20-40 / BR/src/Import/GlTFLoader.cpp:856-885 that an isotropic filter reads. */
+#define BRMI_TEXTURE_FORMAT_RGBA8_UNORM       0u
+#define BRMI_TEXTURE_FORMAT_RGBA8_UNORM_SRGB  1u     /* rgb decoded through brmi_scene_buffers::srgbToLinear before filtering */
+#define BRMI_TEXTURE_MAX_MIPS                 16u
+typedef struct brmi_texture_desc {
+    const uint8_t* texels;                  /* device pointer (scene generator output: byte offset into BRMI_ARR_TEXELS) */
+    uint32_t width, height, mipCount, format;
+    uint32_t mipOffset[BRMI_TEXTURE_MAX_MIPS];
+    uint32_t reserved[2];
+} brmi_texture_desc;                        /* 96 B */
+#define BRMI_ADDRESS_WRAP    0u
+#define BRMI_ADDRESS_MIRROR  1u
+#define BRMI_ADDRESS_CLAMP   2u
+#define BRMI_FILTER_POINT    0u
+#define BRMI_FILTER_LINEAR   1u
+typedef struct brmi_sampler_desc {
+    uint32_t addressU, addressV;
+    uint32_t minFilter, magFilter, mipFilter;
+    float    mipLodBias, minLod, maxLod;
+} brmi_sampler_desc;                        /* 32 B */
 
 /* ---- path-internal records --------------------------------------------------------------- */
 /* 16-byte packed visible cluster, BR/shaders/Include/visibleClusterPacking.hlsli:83-122,220-235

@@ -7,6 +7,8 @@
 //   SWRasterClipScanlineConstraint  BR/shaders/ClusterLOD/softwareRaster.hlsl:262-288
 //   PackVisKey / UnpackVisKey       BR/shaders/Include/visibilityPacking.hlsli:11-37
 //   PerViewPrimaryDepthCopyCS       BR/shaders/gbuffer.hlsl:114-161
+//   SWAlphaTestFailed, per-pixel perspective-correct texcoord   BR/shaders/ClusterLOD/softwareRaster.hlsl:135-172,525-540,574-589
+//     (CLOD_SW_RASTER_DYNAMIC_ALPHA_TEST: the test runs for materials flagged MATERIAL_ALPHA_TEST; rcp = 1/x, orc_common.h)
 //
 // Wave semantics: the reference picks its scan strategy with WaveActiveAnyTrue(rectWidth > 4)
 // (softwareRaster.hlsl:502), so the result depends on which triangles share a wave.  CDNA is
@@ -17,6 +19,7 @@
 #include <vector>
 
 #include "orc_common.h"
+#include "orc_texture.h"
 
 namespace orc {
 
@@ -50,6 +53,7 @@ struct TriLane {
     float d0, d1, d2;
     int minX, minY, maxX, maxY, rectWidth;
     float row_b0, row_b1, dx_b0, dx_b1, dy_b0, dy_b1, dx_b2;
+    float invW0, invW1, invW2; float2 uv0, uv1, uv2;
 };
 
 void rasterCluster(const brmi_scene_buffers& sc, const brmi_visible_cluster& pc, uint32_t clusterIndex, uint64_t* vis, uint32_t visW, uint32_t visH,
@@ -74,6 +78,17 @@ void rasterCluster(const brmi_scene_buffers& sc, const brmi_visible_cluster& pc,
     const bool skinned = (mesh.vertexFlags & BRMI_VERTEX_SKINNED) != 0;
 
     float2 gsScreen[BRMI_MESHLET_MAX_VERTS]; float gsDepth[BRMI_MESHLET_MAX_VERTS];
+    float gsInvW[BRMI_MESHLET_MAX_VERTS]; float2 gsTexcoord[BRMI_MESHLET_MAX_VERTS];
+    const uint32_t materialDataIndex = mesh.materialDataIndex;
+    const bool alphaTest = (sc.materials[materialDataIndex].materialFlags & BRMI_MATERIAL_ALPHA_TEST) != 0u;
+    // softwareRaster.hlsl:525-540: texcoord at the pixel from the stepped barycentrics, then SWAlphaTestFailed
+    auto pixelFails = [&](const TriLane& L, float b0, float b1, float b2) {
+        if (!alphaTest) return false;
+        const float pc0 = b0 * L.invW0, pc1 = b1 * L.invW1, pc2 = b2 * L.invW2;
+        const float invSum = rcp(pc0 + pc1 + pc2);
+        const float2 texcoord = (L.uv0 * pc0 + L.uv1 * pc1 + L.uv2 * pc2) * invSum;
+        return alphaTestFailed(sc, texcoord, materialDataIndex);
+    };
     for (uint32_t v = 0; v < vertCount && v < BRMI_MESHLET_MAX_VERTS; v++) {
         float3 lp = loadPosition(slab, hdr.compressedPositionQuantExp, posBase, desc.positionBitOffset, v);
         if (skinned && (hdr.attributeMask & BRMI_PAGE_ATTRIBUTE_JOINTS)) {
@@ -91,6 +106,8 @@ void rasterCluster(const brmi_scene_buffers& sc, const brmi_visible_cluster& pc,
         gsScreen[v].x = (ndcx + 1.0f) * 0.5f * visWidth + sMinXf;
         gsScreen[v].y = (1.0f - ndcy) * 0.5f * visHeight + sMinYf;
         gsDepth[v] = -viewZ;
+        gsInvW[v] = invW;
+        gsTexcoord[v] = decodeCompressedUV(slab, pageOff, hdr, localMeshlet, 0u, v);
     }
     const bool reverseWinding = (obj.objectFlags & BRMI_OBJECT_FLAG_REVERSE_WINDING) != 0;
     const uint32_t triBase = pageOff + hdr.triangleStreamOffset;
@@ -128,6 +145,8 @@ void rasterCluster(const brmi_scene_buffers& sc, const brmi_visible_cluster& pc,
             L.dy_b0 = -e12.x * invTwiceArea; L.dy_b1 = -e20.x * invTwiceArea;
             L.dx_b2 = -(L.dx_b0 + L.dx_b1);
             L.d0 = d0; L.d1 = d1; L.d2 = d2;
+            L.invW0 = gsInvW[tri[0]]; L.invW1 = gsInvW[tri[1]]; L.invW2 = gsInvW[tri[2]];
+            L.uv0 = gsTexcoord[tri[0]]; L.uv1 = gsTexcoord[tri[1]]; L.uv2 = gsTexcoord[tri[2]];
             L.minX = minX; L.minY = minY; L.maxX = maxX; L.maxY = maxY; L.rectWidth = maxX - minX + 1;
             L.active = true;
             any = any || (L.rectWidth > 4);
@@ -150,8 +169,10 @@ void rasterCluster(const brmi_scene_buffers& sc, const brmi_visible_cluster& pc,
                         float b0 = sb0 + (float)first * L.dx_b0, b1 = sb1 + (float)first * L.dx_b1;
                         for (int px = L.minX + first; px <= L.minX + last; px++) {
                             const float b2 = 1.0f - b0 - b1;
-                            const float depth = b0 * L.d0 + b1 * L.d1 + b2 * L.d2;
-                            atomicMinU64(&vis[(uint64_t)py * visW + (uint32_t)px], packVisKey(depth, clusterIndex, t));
+                            if (!pixelFails(L, b0, b1, b2)) {
+                                const float depth = b0 * L.d0 + b1 * L.d1 + b2 * L.d2;
+                                atomicMinU64(&vis[(uint64_t)py * visW + (uint32_t)px], packVisKey(depth, clusterIndex, t));
+                            }
                             b0 += L.dx_b0; b1 += L.dx_b1;
                         }
                     }
@@ -159,7 +180,7 @@ void rasterCluster(const brmi_scene_buffers& sc, const brmi_visible_cluster& pc,
                     float b0 = sb0, b1 = sb1;
                     for (int px = L.minX; px <= L.maxX; px++) {
                         const float b2 = 1.0f - b0 - b1;
-                        if (b0 >= 0.0f && b1 >= 0.0f && b2 >= 0.0f) {
+                        if (b0 >= 0.0f && b1 >= 0.0f && b2 >= 0.0f && !pixelFails(L, b0, b1, b2)) {
                             const float depth = b0 * L.d0 + b1 * L.d1 + b2 * L.d2;
                             atomicMinU64(&vis[(uint64_t)py * visW + (uint32_t)px], packVisKey(depth, clusterIndex, t));
                         }

@@ -9,11 +9,17 @@
 //   CalcFullBary / InterpolateWithDeriv         BR/shaders/Include/clodResolveCommon.hlsli:104-161
 //   UnpackSnorm16x2 / OctDecodeNormal           BR/shaders/Include/clodResolveCommon.hlsli:627-655
 //   ComputeClodMotionVector                     BR/shaders/Include/clodResolveCommon.hlsli:1380-1389
-//   SampleMaterialEvalFromUvCache               BR/shaders/Include/utilities.hlsli:1850-2075  (no PSO_*_TEXTURE define set)
+//   SampleMaterialEvalFromUvCache               BR/shaders/Include/utilities.hlsli:1850-2075
+//   BuildClodMaterialUvData / AppendClodMaterialUvSample   BR/shaders/Include/clodResolveCommon.hlsli:271-430
+//   cotangent_frame_from_derivs / BuildMaterialTBN          BR/shaders/Include/utilities.hlsli:323-336,1278-1287
 //   ResolveCanonicalOpenPBRSurface              BR/shaders/Include/utilities.hlsli:136-161
-// Scope: triangle clusters (no Reyes / voxel), constant-factor materials, no vertex colours.
+// Scope: triangle clusters (no Reyes / voxel), no vertex colours.  Material texture slots: base colour, opacity, metallic,
+// roughness, normal map, AO, emissive, each through the software sampler of orc_texture.h; no parallax / height map, no OpenPBR
+// coat / fuzz textures, no texture streaming feedback.  A slot's UV set index below MATERIAL_MAX_UNIQUE_UV_SETS (8) is decoded
+// as that set (a set the page does not carry decodes to (0, 0)); any other index uses set 0.
 // G-buffer formats: BR/include/Render/RenderGraphBuildHelper.h:41-139, BR/src/Renderer.cpp:1618.
 #include "orc_common.h"
+#include "orc_texture.h"
 
 namespace orc {
 
@@ -48,6 +54,10 @@ static Bary calcFullBary(float4 pt0, float4 pt1, float4 pt2, float2 pixelNdc, fl
     return r;
 }
 static inline float interp(const Bary& b, float v0, float v1, float v2) { return dot(float3{v0, v1, v2}, b.lambda); }
+// InterpolateWithDeriv: value, d/dx, d/dy
+static inline float3 interpDeriv(const Bary& b, float v0, float v1, float v2) { const float3 m{v0, v1, v2}; return {dot(m, b.lambda), dot(m, b.ddx), dot(m, b.ddy)}; }
+struct UvSample { float2 uv, dUVdx, dUVdy; };
+static inline float swizzle(float4 v, uint32_t idx) { return idx == 0 ? v.x : idx == 1 ? v.y : idx == 2 ? v.z : v.w; }
 
 static float3 octDecodeNormal(uint32_t packed) {
     const int32_t sp = (int32_t)packed;
@@ -116,11 +126,55 @@ static bool resolvePixel(const brmi_scene_buffers& sc, const brmi_visible_cluste
     const mat4& normalMatrix = *reinterpret_cast<const mat4*>(sc.normalMatrices + (size_t)obj.normalMatrixBufferIndex * 16u);
     const float3 worldNormal = normalize(mul3(normalOS, normalMatrix));
 
-    // SampleMaterialEvalFromUvCache with no texture permutation defines: factors only
+    // SampleMaterialEvalFromUvCache: factors x the texture slots the material enables
+    const uint32_t flags = mat.materialFlags;
+    auto uvOf = [&](uint32_t uvSetIndex) {       // AppendClodMaterialUvSample
+        const uint32_t set = uvSetIndex < 8u ? uvSetIndex : 0u;
+        const float2 a = decodeCompressedUV(slab, pageOff, hdr, localMeshlet, set, tri[0]), b = decodeCompressedUV(slab, pageOff, hdr, localMeshlet, set, tri[1]),
+                     c = decodeCompressedUV(slab, pageOff, hdr, localMeshlet, set, tri[2]);
+        const float3 iu = interpDeriv(bary, a.x, b.x, c.x), iv = interpDeriv(bary, a.y, b.y, c.y);
+        return UvSample{{iu.x, iv.x}, {iu.y, iv.y}, {iu.z, iv.z}};
+    };
+    auto sample = [&](uint32_t textureIndex, uint32_t samplerIndex, uint32_t uvSetIndex) {
+        const UvSample u = uvOf(uvSetIndex);
+        return sampleGrad(sc, textureIndex, samplerIndex, u.uv, u.dUVdx, u.dUVdy);
+    };
     const float3 vertexColor{1.0f, 1.0f, 1.0f};
-    const float3 baseColor = float3{mat.baseColorFactor[0], mat.baseColorFactor[1], mat.baseColorFactor[2]} * vertexColor;
-    const float metallic = mat.metallicFactor, roughness = mat.roughnessFactor, ao = 1.0f;
-    const float3 emissiveIn{mat.emissiveFactor[0], mat.emissiveFactor[1], mat.emissiveFactor[2]};
+    float4 baseColor4{mat.baseColorFactor[0], mat.baseColorFactor[1], mat.baseColorFactor[2], mat.baseColorFactor[3]};
+    if (flags & BRMI_MATERIAL_BASE_COLOR_TEXTURE) {
+        const float4 t = sample(mat.baseColorTextureIndex, mat.baseColorSamplerIndex, mat.baseColorUvSetIndex);
+        baseColor4 = float4{baseColor4.x * t.x, baseColor4.y * t.y, baseColor4.z * t.z, baseColor4.w * t.w};
+    }
+    if (flags & BRMI_MATERIAL_OPACITY_TEXTURE) baseColor4.w *= sample(mat.opacityTextureIndex, mat.opacitySamplerIndex, mat.opacityUvSetIndex).w;
+    float metallic = mat.metallicFactor, roughness = mat.roughnessFactor;
+    if (flags & BRMI_MATERIAL_METALLIC_TEXTURE) metallic = swizzle(sample(mat.metallicTextureIndex, mat.metallicSamplerIndex, mat.metallicUvSetIndex), mat.metallicChannel) * mat.metallicFactor;
+    if (flags & BRMI_MATERIAL_ROUGHNESS_TEXTURE) roughness = swizzle(sample(mat.roughnessTextureIndex, mat.roughnessSamplerIndex, mat.roughnessUvSetIndex), mat.roughnessChannel) * mat.roughnessFactor;
+    float3 normalWS = worldNormal;
+    if (flags & BRMI_MATERIAL_NORMAL_MAP) {
+        // dpdx / dpdy of the object-space position through the model's 3x3 (clodResolveCommon.hlsli:1607-1624)
+        const float3 ipx = interpDeriv(bary, p[0].x, p[1].x, p[2].x), ipy = interpDeriv(bary, p[0].y, p[1].y, p[2].y), ipz = interpDeriv(bary, p[0].z, p[1].z, p[2].z);
+        const float3 dpdx = mul3(float3{ipx.y, ipy.y, ipz.y}, M(obj.model)), dpdy = mul3(float3{ipx.z, ipy.z, ipz.z}, M(obj.model));
+        const UvSample u = uvOf(mat.normalUvSetIndex);
+        // cotangent_frame_from_derivs
+        const float3 dp2perp = cross(dpdy, worldNormal), dp1perp = cross(worldNormal, dpdx);
+        const float3 T = dp2perp * u.dUVdx.x + dp1perp * u.dUVdy.x, B = dp2perp * u.dUVdx.y + dp1perp * u.dUVdy.y;
+        const float invmax = rsqrt(fmax2(dot(T, T), dot(B, B)));
+        const float3 Tn = T * invmax, Bn = B * invmax;
+        const float4 t = sampleGrad(sc, mat.normalTextureIndex, mat.normalSamplerIndex, u.uv, u.dUVdx, u.dUVdy);
+        float3 tn = normalize(float3{t.x, t.y, t.z} * 2.0f - float3{1.0f, 1.0f, 1.0f});
+        if (flags & BRMI_MATERIAL_NEGATE_NORMALS) tn = -tn;
+        if (flags & BRMI_MATERIAL_INVERT_NORMAL_GREEN) tn.y = -tn.y;
+        // mul(tangentSpaceNormal, float3x3(T, B, N)): rows of the frame
+        normalWS = normalize(float3{(tn.x * Tn.x + tn.y * Bn.x) + tn.z * worldNormal.x, (tn.x * Tn.y + tn.y * Bn.y) + tn.z * worldNormal.y, (tn.x * Tn.z + tn.y * Bn.z) + tn.z * worldNormal.z});
+    }
+    float ao = 1.0f;
+    if (flags & BRMI_MATERIAL_AO_TEXTURE) ao = swizzle(sample(mat.aoMapIndex, mat.aoSamplerIndex, mat.aoUvSetIndex), mat.aoChannel);
+    float3 emissiveIn{mat.emissiveFactor[0], mat.emissiveFactor[1], mat.emissiveFactor[2]};
+    if (flags & BRMI_MATERIAL_EMISSIVE_TEXTURE) {
+        const float4 t = sample(mat.emissiveTextureIndex, mat.emissiveSamplerIndex, mat.emissiveUvSetIndex);
+        emissiveIn = float3{swizzle(t, mat.emissiveChannels[0]), swizzle(t, mat.emissiveChannels[1]), swizzle(t, mat.emissiveChannels[2])} * emissiveIn;
+    }
+    const float3 baseColor = float3{baseColor4.x, baseColor4.y, baseColor4.z} * vertexColor;
     const brmi_openpbr_material_info& op = sc.openpbrMaterials[mat.openPBRMaterialDataIndex];
     const float3 canonicalEmissive = float3{op.emissionColor[0], op.emissionColor[1], op.emissionColor[2]} * op.emissionLuminance;
     const float3 coatColor = saturate(float3{op.coatColor[0], op.coatColor[1], op.coatColor[2]});
@@ -137,7 +191,7 @@ static bool resolvePixel(const brmi_scene_buffers& sc, const brmi_visible_cluste
     const float4 clipPrev = mulPoint(prevWorld, prevVP);
     const float2 mv{clipCur.x / clipCur.w - clipPrev.x / clipPrev.w, clipCur.y / clipCur.w - clipPrev.y / clipPrev.w};
 
-    o.normals[idx * 4 + 0] = worldNormal.x; o.normals[idx * 4 + 1] = worldNormal.y; o.normals[idx * 4 + 2] = worldNormal.z;
+    o.normals[idx * 4 + 0] = normalWS.x; o.normals[idx * 4 + 1] = normalWS.y; o.normals[idx * 4 + 2] = normalWS.z;
     o.normals[idx * 4 + 3] = (float)mat.openPBRMaterialDataIndex;
     o.albedo[idx] = pack_unorm4(baseColor.x, baseColor.y, baseColor.z, ao);
     o.coat[idx] = pack_half4(coatColor.x, coatColor.y, coatColor.z, coatWeight);

@@ -47,9 +47,17 @@ SCENE_CASES = {
     "sponza_spots": ("sponza", 640, 360, dict(point_lights=48, size_scale=0.25, spot_every=2, material_features=1)),
     # mirrored instances drawn with reversed winding
     "bistro_mirrored": ("bistro", 640, 360, dict(point_lights=16, size_scale=0.3, material_features=4)),
+    # UV streams + material textures through the software sampler (base colour, metallic / roughness, AO, emissive, normal map)
+    "tiny_textured": ("tiny", 256, 144, dict(point_lights=6, lod_levels=2, material_features=8)),
+    "sponza_textured": ("sponza", 640, 360, dict(point_lights=32, size_scale=0.25, material_features=8 | 3)),
+    # alpha-tested materials: per-pixel texcoord + SampleLevel in the rasteriser (direct, binned and overflow paths)
+    "tiny_alpha": ("tiny", 256, 144, dict(point_lights=6, lod_levels=2, material_features=24)),
+    "sponza_alpha": ("sponza", 640, 360, dict(point_lights=32, size_scale=0.25, material_features=24)),
+    "bistro_alpha_skinned": ("bistro", 640, 360, dict(point_lights=32, size_scale=0.3, material_features=24 | 4, skinned_fraction=0.3)),
     "tiny_clod": ("tiny", 256, 144, dict(point_lights=4, lod_builder="clusterlod")),
     "sponza_clod": ("sponza", 640, 360, dict(point_lights=32, size_scale=0.25, lod_builder="clusterlod")),
     "bistro_clod_skinned": ("bistro", 640, 360, dict(point_lights=32, size_scale=0.3, skinned_fraction=0.3, lod_builder="clusterlod")),
+    "sponza_clod_alpha": ("sponza", 640, 360, dict(point_lights=16, size_scale=0.25, lod_builder="clusterlod", material_features=24)),
 }
 
 

@@ -12,7 +12,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["tiny", "tiny_lod", "tiny_coat_fuzz", "sponza_coat_fuzz", "sponza_small", "bistro_small", "tiny_skinned", "bistro_skinned", "tiny_clod", "sponza_clod", "bistro_clod_skinned", "sponza_spots", "bistro_mirrored"]
+CASES = ["tiny", "tiny_lod", "tiny_coat_fuzz", "sponza_coat_fuzz", "sponza_small", "bistro_small", "tiny_skinned", "bistro_skinned", "tiny_clod", "sponza_clod", "bistro_clod_skinned", "sponza_spots", "bistro_mirrored",
+         "tiny_textured", "sponza_textured", "tiny_alpha", "sponza_alpha", "bistro_alpha_skinned", "sponza_clod_alpha"]
 
 
 @pytest.fixture(scope="module")
@@ -461,13 +462,41 @@ def test_full_raster_bins_fall_back_to_global_atomics(name, queue, scenes, oracl
 
 
 @pytest.mark.parametrize("area", [1, 1 << 30])
-def test_raster_threshold_does_not_change_the_image(area, scenes, oracle_frames):
-    """Everything binned / nothing binned: the two code paths produce the same keys."""
+@pytest.mark.parametrize("name", ["sponza_small", "sponza_alpha"])
+def test_raster_threshold_does_not_change_the_image(name, area, scenes, oracle_frames):
+    """Everything binned / nothing binned: the two code paths produce the same keys (alpha-tested triangles included)."""
     from basicrenderer_amd.renderer import VisibilityRenderer
     with _Env(BRMI_BIG_TRI_AREA=area):
-        r = VisibilityRenderer(scenes("sponza_small"), stats=True)
+        r = VisibilityRenderer(scenes(name), stats=True)
     r.execute()
-    assert np.array_equal(r.visibility(), oracle_frames("sponza_small").vis)
+    assert np.array_equal(r.visibility(), oracle_frames(name).vis)
+    r.close()
+
+
+@pytest.mark.parametrize("queue", [16384, 2, 0])
+def test_alpha_tested_records_survive_bin_overflow(queue, scenes, oracle_frames):
+    """The alpha-test operands travel with a record into the overflow queue and into the in-place fallback."""
+    from basicrenderer_amd.renderer import VisibilityRenderer
+    with _Env(BRMI_BIN_CAPACITY=3, BRMI_BIN_OVERFLOW=queue):
+        r = VisibilityRenderer(scenes("sponza_alpha"), stats=True)
+    r.execute()
+    assert queue == 0 or r.counters().reserved[5] > 0, "the case does not overflow any bin"
+    assert np.array_equal(r.visibility(), oracle_frames("sponza_alpha").vis)
+    r.close()
+
+
+def test_textured_resolve_without_arena_space_matches(scenes, oracle_frames):
+    """Textured clusters outside the resolve arena decode their texcoords per pixel: same G-buffer bytes."""
+    from basicrenderer_amd.renderer import VisibilityRenderer
+    o = oracle_frames("sponza_textured")
+    with _Env(BRMI_RESOLVE_CAPACITY=5000):
+        r = VisibilityRenderer(scenes("sponza_textured"), stats=True)
+    r.execute()
+    g = r.gbuffer()
+    covered = o.vis != np.uint64(0xFFFFFFFFFFFFFFFF)
+    assert np.array_equal(g["normals"][covered].view(np.uint32), o.normals[covered].view(np.uint32))
+    for k, ref in (("albedo", o.albedo), ("mr", o.mr), ("emissive", o.emissive)):
+        assert np.array_equal(g[k][covered], ref[covered]), k
     r.close()
 
 
@@ -511,6 +540,8 @@ SWEEP = [
     ("sponza", 1000, 96, dict(seed=14, point_lights=7, size_scale=0.08), dict()),
     ("bistro", 408, 600, dict(seed=15, point_lights=90, size_scale=0.25, skinned_fraction=0.5, material_features=3), dict(occlusion=True)),
     ("zorah", 640, 360, dict(seed=16, point_lights=12, size_scale=0.004, skinned_fraction=0.0), dict()),
+    ("sponza", 451, 333, dict(seed=17, point_lights=20, size_scale=0.12, lod_levels=3, material_features=24 | 3), dict(occlusion=True)),
+    ("san_miguel", 640, 360, dict(seed=18, point_lights=24, size_scale=0.02, material_features=24), dict(occlusion=True)),
 ]
 
 
