@@ -129,6 +129,7 @@ static void compute_sizes(brmi_pass* p) {
     w.resolveUVs = take(p->sceneHasTextures ? (uint64_t)p->resolveCapacity * 8 : 16);
     w.binAlpha = take(p->sceneHasAlphaTest ? (uint64_t)p->binsX * p->binsY * p->binCapacity * 48 : 16);
     w.overflowAlpha = take(p->sceneHasAlphaTest ? (uint64_t)CNT_STRIPE_COUNT * p->binOverflowPerStripe * 48 : 16);
+    w.alphaMats = take(p->sceneHasAlphaTest ? (uint64_t)std::max(1u, p->scene.materialCount) * 128 : 16);
     w.total = off;
     p->resNeed[BRMI_RES_WORKSPACE] = w.total;
 }
@@ -187,7 +188,8 @@ int brmi_create(const brmi_config* cfg, brmi_pass** out) {
     if (const char* e = std::getenv("BRMI_RASTER_DEBUG")) p->rasterDebug = std::atoi(e);
     if (const char* e = std::getenv("BRMI_BIN_OVERFLOW")) p->binOverflowPerStripe = (uint32_t)std::max(0, std::atoi(e));
     if (const char* e = std::getenv("BRMI_BIN_CAPACITY")) p->binCapacity = (uint32_t)std::max(1, std::atoi(e));
-    if (const char* e = std::getenv("BRMI_BIG_TRI_AREA")) p->bigTriArea = std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("BRMI_BIG_TRI_AREA")) p->bigTriArea = p->bigTriAreaAlpha = std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("BRMI_BIG_TRI_AREA_ALPHA")) p->bigTriAreaAlpha = std::max(1, std::atoi(e));
     compute_sizes(p);
     *out = p;
     return BRMI_OK;

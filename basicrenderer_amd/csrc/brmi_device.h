@@ -193,6 +193,9 @@ BRMI_DEV uint32_t cluster_slice_exact(float z, float zNear, float zSplit, float 
 // Read-only data produced by an earlier kernel, viewed through the constant address space: with a wave-uniform address
 // the compiler then selects scalar (s_load) instead of vector loads.
 template <typename T> BRMI_DEV const __attribute__((address_space(4))) T* kconst(const T* p) { return (const __attribute__((address_space(4))) T*)p; }
+// `p` in the address space of `like`: tables indexed by fields of a record take the scalar path when the record does
+template <typename L, typename T> BRMI_DEV const T* as_space_of(const L*, const T* p) { return p; }
+template <typename L, typename T> BRMI_DEV const __attribute__((address_space(4))) T* as_space_of(const __attribute__((address_space(4))) L*, const T* p) { return kconst(p); }
 // wave-aggregated append: one atomic per wave; returns the slot of this lane (valid when pred)
 BRMI_DEV uint32_t wave_append(uint32_t* counter, bool pred) {
     const uint64_t mask = __ballot(pred);

@@ -11,6 +11,7 @@
 //   light spheres         view-space bounding sphere of every active light
 #include "brmi_device.h"
 #include "brmi_internal.h"
+#include "brmi_texture.h"
 
 namespace brmi {
 
@@ -46,9 +47,11 @@ BRMI_DEV void job_object_constants(const brmi_scene_buffers& sc, m4* frameConst,
 
 // The constant-factor material of SampleMaterialEvalFromUvCache (no texture permutations) only depends on the material
 // record: its five packed G-buffer words are evaluated once per material per frame instead of once per pixel.
-BRMI_DEV void job_material_words(const brmi_scene_buffers& sc, MaterialWords* out, uint32_t i) {
+BRMI_DEV void job_material_words(const brmi_scene_buffers& sc, MaterialWords* out, AlphaMaterial* alphaMats, uint32_t i) {
     if (i >= sc.materialCount) return;
     const brmi_material_info* mat = sc.materials + i;
+    // the rasteriser's alpha test: texture bindings and SampleLevel(.., 0)'s level choice, resolved once per material
+    if (alphaMats && (mat->materialFlags & BRMI_MATERIAL_ALPHA_TEST)) alphaMats[i] = load_alpha_material(mat, sc.textures, sc.textureCount, sc.samplers, sc.samplerCount);
     const f3 baseColor = f3{mat->baseColorFactor[0], mat->baseColorFactor[1], mat->baseColorFactor[2]} * f3{1.0f, 1.0f, 1.0f};
     const float metallic = mat->metallicFactor, roughness = mat->roughnessFactor, ao = 1.0f;
     const f3 emissiveIn{mat->emissiveFactor[0], mat->emissiveFactor[1], mat->emissiveFactor[2]};
@@ -138,6 +141,7 @@ BRMI_DEV void job_shade_tables(const brmi_scene_buffers& sc, ShadeTables t, uint
 struct FrameJobs {
     brmi_scene_buffers sc;
     m4* frameConst; float* objConst; MaterialWords* matWords; MatConst* matConst; ShadeTables tables; float4* lightVS; uint32_t* lightMeta;
+    AlphaMaterial* alphaMats;
     uint32_t W, H;
     uint32_t firstBlock[6];      // block ranges of the five jobs
 };
@@ -145,7 +149,7 @@ struct FrameJobs {
 __global__ void __launch_bounds__(64) k_frame_constants(FrameJobs j) {
     const uint32_t b = blockIdx.x;
     if (b < j.firstBlock[1]) job_object_constants(j.sc, j.frameConst, j.objConst, (b - j.firstBlock[0]) * 64u + threadIdx.x);
-    else if (b < j.firstBlock[2]) job_material_words(j.sc, j.matWords, (b - j.firstBlock[1]) * 64u + threadIdx.x);
+    else if (b < j.firstBlock[2]) job_material_words(j.sc, j.matWords, j.alphaMats, (b - j.firstBlock[1]) * 64u + threadIdx.x);
     else if (b < j.firstBlock[3]) job_material_constants(j.sc, j.matConst, (b - j.firstBlock[2]) * 64u + threadIdx.x);
     else if (b < j.firstBlock[4]) job_shade_tables(j.sc, j.tables, j.W, j.H, (b - j.firstBlock[3]) * 64u + threadIdx.x);
     else job_light_spheres(j.sc, j.lightVS, j.lightMeta, (b - j.firstBlock[4]) * 64u + threadIdx.x);
@@ -165,6 +169,7 @@ int ensure_frame_constants(brmi_pass* p, hipStream_t s) {
     j.sc = p->scene; j.frameConst = p->wsPtr<m4>(p->ws.frameConst); j.objConst = p->wsPtr<float>(p->ws.objConst);
     j.matWords = p->wsPtr<MaterialWords>(p->ws.matWords); j.matConst = p->wsPtr<MatConst>(p->ws.matConst); j.tables = shade_tables_of(p);
     j.lightVS = p->wsPtr<float4>(p->ws.lightVS); j.lightMeta = p->wsPtr<uint32_t>(p->ws.lightMeta);
+    j.alphaMats = p->sceneHasAlphaTest ? p->wsPtr<AlphaMaterial>(p->ws.alphaMats) : nullptr;
     j.W = p->cfg.width; j.H = p->cfg.height;
     auto blocks = [](uint32_t n) { return (std::max(1u, n) + 63u) / 64u; };
     const uint32_t counts[5] = {blocks(p->scene.perObjectCount), blocks(p->scene.materialCount), blocks(p->scene.openpbrMaterialCount),

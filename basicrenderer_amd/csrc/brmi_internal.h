@@ -87,7 +87,7 @@ struct HzbDesc {
 struct Workspace {     // byte offsets into BRMI_RES_WORKSPACE
     uint64_t counters, frontierA, frontierB, buckets, tempVisible, bitmask1, bitmask2, wordPrefix, blockSums,
              instanceBitBase, segPrefix, meshLevelWidth, planes, replayNodes, replayBuckets, lightVS, lightMeta, clusterPages, clusterHits, pageTotal, lightHitMasks, binCounts, binRecords, binOverflow, clusterSetup, resolveVerts, resolveTris, matWords, shadeTables, lutF, frameConst, objConst, matConst, deferredPixels, usedClusters,
-             clusterUv, binAlpha, overflowAlpha, resolveUVs, frameClearBytes, total;
+             clusterUv, binAlpha, overflowAlpha, resolveUVs, alphaMats, frameClearBytes, total;
 };
 
 }  // namespace brmi
@@ -120,7 +120,7 @@ struct brmi_pass {
     uint32_t resolveCapacity = 0;   // vertices (and triangles) the resolve arena holds
     uint32_t rasterGrid = 4096;  // single-wave workgroups of k_raster (BRMI_RASTER_GRID)
     int rasterDebug = 0;         // BRMI_RASTER_DEBUG (experiments; non-zero gives wrong images)
-    int bigTriArea = 128;        // clamped-bbox pixels above which a triangle is binned (BRMI_BIG_TRI_AREA)
+    int bigTriArea = 128, bigTriAreaAlpha = 32;        // clamped-bbox pixels above which a triangle is binned (BRMI_BIG_TRI_AREA)
     uint32_t hzbMipCount = 0; std::vector<uint64_t> hzbMipOffsets; std::vector<uint32_t> hzbMipW, hzbMipH;   // [mip]; offsets in floats, mip 0 unused
     bool hzbValid = false;       // a chain built from a finished frame exists (phase 1 of the next frame tests against it)
     brmi::HzbDesc hzbDesc() const;

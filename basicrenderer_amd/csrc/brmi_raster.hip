@@ -51,8 +51,10 @@ struct RasterArgs {
     BinRecord* overflow; uint32_t overflowPerStripe;     // 64 striped queues of records whose bin was full (pad0 = strip)
     AlphaRecord* binAlpha; AlphaRecord* overflowAlpha;   // side arrays of binRecords / overflow (alpha-tested scenes only)
     const ClusterUv* clusterUv;
+    const AlphaMaterial* alphaMats;                      // per material: the alpha test's texture bindings resolved (k_frame_constants)
     const float* objConst;   // per object: MVP (16), objectToClip (16), modelViewZ (4)
     int bigTriArea;          // clamped-bbox pixels above which a triangle is binned
+    int bigTriAreaAlpha;     // the same for alpha-tested clusters: their pixels are far cheaper in a bin (LDS early-out, more lanes in flight)
     int debugFlags;          // experiments only (BRMI_RASTER_DEBUG): 1 = skip the direct walk, 2 = skip bin emission, 4 = skip the bin pass, 8 = direct walk without the atomic
     brmi_scene_buffers sc;
     const uint4* clusters; const ClusterSetup* setup;
@@ -82,23 +84,42 @@ BRMI_DEV void clip_scanline(float value, float step, int& first, int& last, bool
 
 // Where a key goes: the visibility buffer (tiled, 64-bit atomic min in L2) or the LDS tile of a bin.
 struct GlobalSink {
+    static constexpr bool kPeekCheap = false;
     unsigned long long* vis; uint32_t tilesX; int dbg;
     BRMI_DEV void operator()(int px, int py, unsigned long long key) const {
         if (dbg & 8) { if (key == 0x1234567ull) vis[0] = key; return; }
         atomicMin(&vis[tiled_index((uint32_t)px, (uint32_t)py, tilesX)], key);
     }
+    BRMI_DEV unsigned long long peek(int px, int py) const { return __builtin_nontemporal_load(&vis[tiled_index((uint32_t)px, (uint32_t)py, tilesX)]); }
 };
 struct LdsSink {
+    static constexpr bool kPeekCheap = true;
     unsigned long long* tile; int x0, y0;       // tile[(px - x0) * BIN_ROWS + (py - y0)]
     BRMI_DEV void operator()(int px, int py, unsigned long long key) const { atomicMin(&tile[(px - x0) * BIN_ROWS + (py - y0)], key); }
+    BRMI_DEV unsigned long long peek(int px, int py) const { return *(volatile const unsigned long long*)&tile[(px - x0) * BIN_ROWS + (py - y0)]; }
 };
 
 // The per-pixel alpha test: nothing for the plain kernels, SWAlphaTestFailed on the pixel's texcoord for an alpha-tested record.
-struct NoAlpha { BRMI_DEV bool operator()(float, float, float) const { return false; } };
+// kEarlyZ: a key that cannot win the pixel's 64-bit min is dropped before the (expensive) test -- the test's outcome could not
+// change the buffer either way.
+struct NoAlpha { static constexpr bool kEarlyZ = false; BRMI_DEV bool operator()(float, float, float) const { return false; } };
 struct TexAlpha {
-    const brmi_scene_buffers* sc; AlphaMaterial mat; AlphaTri tri; bool enabled;
-    BRMI_DEV bool operator()(float b0, float b1, float b2) const { return enabled && alpha_test_failed(*sc, mat, pixel_texcoord(tri, b0, b1, b2)); }
+    static constexpr bool kEarlyZ = true;
+    const float* unorm; AlphaMaterial mat; AlphaTri tri;
+    BRMI_DEV bool operator()(float b0, float b1, float b2) const { return alpha_test_failed(unorm, mat, pixel_texcoord(tri, b0, b1, b2)); }
 };
+
+// An alpha-tested pixel.  LDS tile: look first (a few cycles), sample only if the key can still win.  Visibility buffer in HBM: the
+// look is as slow as the texel fetches, so both are requested together and the pixel costs one memory round trip, not two.
+template <typename Sink, typename Alpha>
+BRMI_DEV void emit_tested(const Sink& sink, const Alpha& alphaFails, int px, int py, unsigned long long key, float b0, float b1, float b2) {
+    if (Sink::kPeekCheap) { if (key < sink.peek(px, py) && !alphaFails(b0, b1, b2)) sink(px, py, key); }
+    else {
+        const unsigned long long cur = sink.peek(px, py);
+        const bool fails = alphaFails(b0, b1, b2);
+        if (key < cur && !fails) sink(px, py, key);
+    }
+}
 
 // One scanline of one triangle (softwareRaster.hlsl:506-609), barycentrics at the row start given, restricted to
 // pixels clipX0..clipX1.  The barycentrics are stepped pixel by pixel from the row's first pixel even when the walk
@@ -119,10 +140,10 @@ BRMI_DEV void raster_row(const Sink& sink, const Alpha& alphaFails, int py, int 
             if (x0 < clipX0) { for (int k = clipX0 - x0; k > 0; k--) { b0 += dx_b0; b1 += dx_b1; } x0 = clipX0; }
             for (int px = x0; px <= x1; px++) {
                 const float b2 = 1.0f - b0 - b1;
-                if (!alphaFails(b0, b1, b2)) {
-                    const float depth = b0 * d0 + b1 * d1 + b2 * d2;
-                    sink(px, py, (unsigned long long)pack_vis_key(depth, clusterIndex, t));
-                }
+                const float depth = b0 * d0 + b1 * d1 + b2 * d2;
+                const unsigned long long key = (unsigned long long)pack_vis_key(depth, clusterIndex, t);
+                if (Alpha::kEarlyZ) emit_tested(sink, alphaFails, px, py, key, b0, b1, b2);
+                else sink(px, py, key);
                 b0 += dx_b0; b1 += dx_b1;
             }
         }
@@ -133,9 +154,11 @@ BRMI_DEV void raster_row(const Sink& sink, const Alpha& alphaFails, int py, int 
         if (x0 < clipX0) { for (int k = clipX0 - x0; k > 0; k--) { b0 += dx_b0; b1 += dx_b1; } x0 = clipX0; }
         for (int px = x0; px <= x1; px++) {
             const float b2 = 1.0f - b0 - b1;
-            if (b0 >= 0.0f && b1 >= 0.0f && b2 >= 0.0f && !alphaFails(b0, b1, b2)) {
+            if (b0 >= 0.0f && b1 >= 0.0f && b2 >= 0.0f) {
                 const float depth = b0 * d0 + b1 * d1 + b2 * d2;
-                sink(px, py, (unsigned long long)pack_vis_key(depth, clusterIndex, t));
+                const unsigned long long key = (unsigned long long)pack_vis_key(depth, clusterIndex, t);
+                if (Alpha::kEarlyZ) emit_tested(sink, alphaFails, px, py, key, b0, b1, b2);
+                else sink(px, py, key);
             }
             b0 += dx_b0; b1 += dx_b1;
         }
@@ -157,12 +180,12 @@ BRMI_DEV void raster_record_global(const RasterArgs& a, const BinRecord& r, cons
                        (int)(strip << BIN_W_SHIFT), (int)(strip << BIN_W_SHIFT) + BIN_W - 1);
     }
 }
-BRMI_DEV TexAlpha tex_alpha_of(const RasterArgs& a, const AlphaRecord& ar) { return TexAlpha{&a.sc, load_alpha_material(a.sc, ar.materialDataIndex), ar.tri, true}; }
+BRMI_DEV TexAlpha tex_alpha_of(const RasterArgs& a, const float* unorm, const AlphaRecord& ar) { return TexAlpha{unorm, a.alphaMats[ar.materialDataIndex], ar.tri}; }
 
 // Stores one record at a reserved slot of a bin.  A full bin sends the record to the overflow queue of the wave's stripe
 // (k_raster_overflow walks those row-parallel with global atomics); a full queue rasterises it right here.
 // r.pad1 != 0: the record is alpha tested and its AlphaRecord `ar` travels with it.
-BRMI_DEV void bin_store(const RasterArgs& a, const BinRecord& r, const AlphaRecord& ar, uint32_t strip, uint32_t band, uint32_t slot) {
+BRMI_DEV void bin_store(const RasterArgs& a, const float* unorm, const BinRecord& r, const AlphaRecord& ar, uint32_t strip, uint32_t band, uint32_t slot) {
     const bool alpha = r.pad1 != 0u;
     const uint32_t bin = band * a.binsX + strip;
     if (slot < a.binCapacity) {
@@ -177,11 +200,11 @@ BRMI_DEV void bin_store(const RasterArgs& a, const BinRecord& r, const AlphaReco
         if (alpha) a.overflowAlpha[(size_t)stripe * a.overflowPerStripe + q] = ar;
         return;
     }
-    if (alpha) raster_record_global(a, r, tex_alpha_of(a, ar), strip, 0u, 1u);
+    if (alpha) raster_record_global(a, r, tex_alpha_of(a, unorm, ar), strip, 0u, 1u);
     else raster_record_global(a, r, NoAlpha{}, strip, 0u, 1u);
 }
-BRMI_DEV void bin_append(const RasterArgs& a, const BinRecord& r, const AlphaRecord& ar, uint32_t strip, uint32_t band) {
-    bin_store(a, r, ar, strip, band, atomicAdd(&a.binCounts[band * a.binsX + strip], 1u));
+BRMI_DEV void bin_append(const RasterArgs& a, const float* unorm, const BinRecord& r, const AlphaRecord& ar, uint32_t strip, uint32_t band) {
+    bin_store(a, unorm, r, ar, strip, band, atomicAdd(&a.binCounts[band * a.binsX + strip], 1u));
 }
 
 #ifndef BRMI_RASTER_WAVES
@@ -189,11 +212,16 @@ BRMI_DEV void bin_append(const RasterArgs& a, const BinRecord& r, const AlphaRec
 #endif
 // ALPHA: the scene has alpha-tested materials; clusters of such a material (BRMI_CS_ALPHA) also stage 1/w and the texcoord of their
 // vertices and test every covered pixel.  Scenes without them run the plain instantiation (no extra registers or LDS).
+#ifndef BRMI_RASTER_ALPHA_WAVES
+#define BRMI_RASTER_ALPHA_WAVES 2
+#endif
 template <bool ALPHA>
-__global__ void __launch_bounds__(64, BRMI_RASTER_WAVES) k_raster(RasterArgs a) {
+__global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RASTER_WAVES) k_raster(RasterArgs a) {
     __shared__ float sx[BRMI_MESHLET_MAX_VERTS], sy[BRMI_MESHLET_MAX_VERTS], sd[BRMI_MESHLET_MAX_VERTS];
     __shared__ float siw[ALPHA ? BRMI_MESHLET_MAX_VERTS : 1], su[ALPHA ? BRMI_MESHLET_MAX_VERTS : 1], sv[ALPHA ? BRMI_MESHLET_MAX_VERTS : 1];
     __shared__ float tpA[ALPHA ? 9 : 1][64];
+    __shared__ float unormT[ALPHA ? 256 : 1];      // code / 255.0f
+    if (ALPHA) { for (uint32_t i = threadIdx.x; i < 256u; i += 64u) unormT[i] = (float)i / 255.0f; __syncthreads(); }
     __shared__ uint32_t binBase[BIN_WINDOW];
     __shared__ float tpF[9][64];
     __shared__ int tpI[4][64];
@@ -224,7 +252,7 @@ __global__ void __launch_bounds__(64, BRMI_RASTER_WAVES) k_raster(RasterArgs a) 
         const bool alphaCluster = ALPHA && (cs.counts & BRMI_CS_ALPHA) != 0u;
         ClusterUv cu{nullptr, nullptr};
         AlphaMaterial amat{};
-        if (alphaCluster) { cu = a.clusterUv[clusterIndex]; amat = load_alpha_material(sc, cs.materialDataIndex); }
+        if (alphaCluster) { cu = a.clusterUv[clusterIndex]; amat = a.alphaMats[cs.materialDataIndex]; }
 
         // vertex stage -> LDS (softwareRaster.hlsl:339-387)
         for (uint32_t v = lane; v < vertCount; v += 64) {
@@ -291,7 +319,7 @@ __global__ void __launch_bounds__(64, BRMI_RASTER_WAVES) k_raster(RasterArgs a) 
             const int rectWidth = maxX - minX + 1;
             const bool useScanlineRanges = __any(active && rectWidth > 4);
             const int rows = maxY - minY + 1;
-            const bool big = active && rows * rectWidth > a.bigTriArea;
+            const bool big = active && rows * rectWidth > (alphaCluster ? a.bigTriAreaAlpha : a.bigTriArea);
             // bins the box overlaps (rows clipped to this GPU's band)
             const int yLo = max(minY, (int)a.bandY0), yHi = min(maxY, (int)a.bandY1 - 1);
             const int band0 = yLo >> BIN_ROWS_SHIFT, band1 = yHi >> BIN_ROWS_SHIFT, strip0 = minX >> BIN_W_SHIFT, strip1 = maxX >> BIN_W_SHIFT;
@@ -333,7 +361,7 @@ __global__ void __launch_bounds__(64, BRMI_RASTER_WAVES) k_raster(RasterArgs a) 
                         float sb0 = tpF[0][tri], sb1 = tpF[1][tri];
                         for (int k = py - t_minY; k > 0; k--) { sb0 += t_dy0; sb1 += t_dy1; }      // the serial loop's row stepping
                         if (alphaCluster) {
-                            const TexAlpha ta{&a.sc, amat, AlphaTri{tpA[0][tri], tpA[1][tri], tpA[2][tri], f2{tpA[3][tri], tpA[4][tri]}, f2{tpA[5][tri], tpA[6][tri]}, f2{tpA[7][tri], tpA[8][tri]}}, true};
+                            const TexAlpha ta{unormT, amat, AlphaTri{tpA[0][tri], tpA[1][tri], tpA[2][tri], f2{tpA[3][tri], tpA[4][tri]}, f2{tpA[5][tri], tpA[6][tri]}, f2{tpA[7][tri], tpA[8][tri]}}};
                             raster_row(gsink, ta, py, t_minX, t_w, useScanlineRanges, sb0, sb1, t_dx0, t_dx1, -(t_dx0 + t_dx1), tpF[6][tri], tpF[7][tri], tpF[8][tri], clusterIndex, waveBase + tri,
                                        t_minX, t_minX + t_w - 1);
                         } else
@@ -380,8 +408,8 @@ __global__ void __launch_bounds__(64, BRMI_RASTER_WAVES) k_raster(RasterArgs a) 
                         r.minX = minX; r.rectWidth = rectWidth; r.rowStart = py;
                         r.sb0 = sb0; r.sb1 = sb1; r.dx_b0 = dx_b0; r.dx_b1 = dx_b1; r.dy_b0 = dy_b0; r.dy_b1 = dy_b1; r.d0 = d0; r.d1 = d1; r.d2 = d2; r.pad0 = 0; r.pad1 = alphaCluster ? 1u : 0u;
                         for (int st = strip0; st <= strip1; st++) {
-                            if (windowed) bin_store(a, r, arec, (uint32_t)st, (uint32_t)band, atomicAdd(&binBase[(band - wb0) * winW + (st - ws0)], 1u));
-                            else bin_append(a, r, arec, (uint32_t)st, (uint32_t)band);
+                            if (windowed) bin_store(a, unormT, r, arec, (uint32_t)st, (uint32_t)band, atomicAdd(&binBase[(band - wb0) * winW + (st - ws0)], 1u));
+                            else bin_append(a, unormT, r, arec, (uint32_t)st, (uint32_t)band);
                         }
                         for (int k = 0; k < n; k++) { sb0 += dy_b0; sb1 += dy_b1; }
                         py += n;
@@ -423,7 +451,7 @@ __global__ void __launch_bounds__(64, BRMI_RASTER_WAVES) k_raster(RasterArgs a) 
 #pragma unroll
                         for (int k = 0; k < 8; k++) slots[k] = (st0 + k <= c_strip1) ? atomicAdd(&a.binCounts[(uint32_t)band * a.binsX + (uint32_t)(st0 + k)], 1u) : 0u;
 #pragma unroll
-                        for (int k = 0; k < 8; k++) if (st0 + k <= c_strip1) bin_store(a, r, c_arec, (uint32_t)(st0 + k), (uint32_t)band, slots[k]);
+                        for (int k = 0; k < 8; k++) if (st0 + k <= c_strip1) bin_store(a, unormT, r, c_arec, (uint32_t)(st0 + k), (uint32_t)band, slots[k]);
                     }
                 }
             }
@@ -438,11 +466,15 @@ __global__ void __launch_bounds__(64, BRMI_RASTER_WAVES) k_raster(RasterArgs a) 
 #define BRMI_BIN_THREADS 512
 #endif
 template <bool ALPHA>
-__global__ void __launch_bounds__(BRMI_BIN_THREADS) k_raster_bins(RasterArgs a) {
+__global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? 4 : 1) k_raster_bins(RasterArgs a) {
     __shared__ unsigned long long tile[BIN_W * BIN_ROWS];
+    __shared__ float unormT[ALPHA ? 256 : 1];
+    __shared__ uint16_t alphaList[ALPHA ? 4096 : 1];      // indices of the bin's alpha-tested records (first 4096; later ones take the row path)
+    __shared__ uint32_t alphaCount;
     const uint32_t strip = blockIdx.x, band = blockIdx.y, bin = band * a.binsX + strip;
     const uint32_t n = min(a.binCounts[bin], a.binCapacity);
     if (n == 0) return;
+    if (ALPHA) { for (uint32_t i = threadIdx.x; i < 256u; i += BRMI_BIN_THREADS) unormT[i] = (float)i / 255.0f; if (threadIdx.x == 0) alphaCount = 0u; }
     __syncthreads();                                    // every thread has read the count
     if (threadIdx.x == 0) a.binCounts[bin] = 0u;      // self-cleaning: the bins are empty again when this launch retires
     for (uint32_t i = threadIdx.x; i < BIN_W * BIN_ROWS; i += BRMI_BIN_THREADS) tile[i] = BRMI_VIS_EMPTY;
@@ -456,18 +488,48 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS) k_raster_bins(RasterArgs a) 
         if (ri >= n) continue;
         const BinRecord r = recs[ri];
         const uint32_t rows = (r.triAndFlags >> 16) & 0xFFu;
-        if (row < rows) {
+        bool deferred = false;
+        // alpha tested and wide inside this bin: listed for the segment pass below (a narrow record keeps the 16-lane row walk)
+        if (ALPHA && r.pad1 != 0u && min(r.minX + r.rectWidth - 1, x0 + BIN_W - 1) - max(r.minX, x0) >= 48) {
+            uint32_t slot = 0;
+            if (row == 0u) slot = atomicAdd(&alphaCount, 1u);
+            slot = (uint32_t)__shfl((int)slot, (int)(lane_id() & 48u));
+            deferred = slot < 4096u && ri < 65536u;
+            if (deferred && row == 0u) alphaList[slot] = (uint16_t)ri;
+        }
+        if (row < rows && !deferred) {
             float sb0 = r.sb0, sb1 = r.sb1;
             for (uint32_t k = 0; k < row; k++) { sb0 += r.dy_b0; sb1 += r.dy_b1; }
             const int py = r.rowStart + (int)row;
-            if ((uint32_t)py >= a.bandY0 && (uint32_t)py < a.bandY1) {
-                if (ALPHA && r.pad1 != 0u)
-                    raster_row(sink, tex_alpha_of(a, a.binAlpha[(size_t)bin * a.binCapacity + ri]), py, r.minX, r.rectWidth, (r.triAndFlags & 0x100u) != 0, sb0, sb1, r.dx_b0, r.dx_b1, -(r.dx_b0 + r.dx_b1),
-                               r.d0, r.d1, r.d2, r.clusterIndex, r.triAndFlags & 0x7Fu, x0, x0 + BIN_W - 1);
-                else
+            if ((uint32_t)py >= a.bandY0 && (uint32_t)py < a.bandY1 && ALPHA && r.pad1 != 0u)
+                raster_row(sink, tex_alpha_of(a, unormT, a.binAlpha[(size_t)bin * a.binCapacity + ri]), py, r.minX, r.rectWidth, (r.triAndFlags & 0x100u) != 0, sb0, sb1, r.dx_b0, r.dx_b1, -(r.dx_b0 + r.dx_b1),
+                           r.d0, r.d1, r.d2, r.clusterIndex, r.triAndFlags & 0x7Fu, x0, x0 + BIN_W - 1);
+            else if ((uint32_t)py >= a.bandY0 && (uint32_t)py < a.bandY1)
                 raster_row(sink, NoAlpha{}, py, r.minX, r.rectWidth, (r.triAndFlags & 0x100u) != 0, sb0, sb1, r.dx_b0, r.dx_b1, -(r.dx_b0 + r.dx_b1), r.d0, r.d1, r.d2, r.clusterIndex, r.triAndFlags & 0x7Fu,
                            x0, x0 + BIN_W - 1);
-            }
+        }
+    }
+    if (ALPHA) {
+        // Alpha-tested records after the opaque ones (more keys to reject untested).  A pixel of theirs costs a dependent chain of
+        // texel fetches, and a bin often holds only a handful of such records (two floor triangles): one lane per row would walk
+        // 256 pixels serially.  Lane = (row, 32-pixel segment): 128 lanes per record, four records at a time; a segment's
+        // barycentrics are stepped from the row start like every clipped walk.
+        __syncthreads();
+        const uint32_t rsub = threadIdx.x >> 7, seg = (threadIdx.x >> 4) & 7u;
+        const uint32_t listed = min(alphaCount, 4096u);
+        for (uint32_t base = 0; base < listed; base += BRMI_BIN_THREADS / 128) {
+            if (base + rsub >= listed) continue;
+            const uint32_t ri = alphaList[base + rsub];
+            const BinRecord r = recs[ri];
+            const uint32_t rows = (r.triAndFlags >> 16) & 0xFFu;
+            const int sx0 = x0 + (int)(seg << 5), sx1 = sx0 + 31;
+            if (row >= rows || r.minX > sx1 || r.minX + r.rectWidth - 1 < sx0) continue;
+            float sb0 = r.sb0, sb1 = r.sb1;
+            for (uint32_t k = 0; k < row; k++) { sb0 += r.dy_b0; sb1 += r.dy_b1; }
+            const int py = r.rowStart + (int)row;
+            if ((uint32_t)py >= a.bandY0 && (uint32_t)py < a.bandY1)
+                raster_row(sink, tex_alpha_of(a, unormT, a.binAlpha[(size_t)bin * a.binCapacity + ri]), py, r.minX, r.rectWidth, (r.triAndFlags & 0x100u) != 0, sb0, sb1, r.dx_b0, r.dx_b1, -(r.dx_b0 + r.dx_b1),
+                           r.d0, r.d1, r.d2, r.clusterIndex, r.triAndFlags & 0x7Fu, sx0, sx1);
         }
     }
     __syncthreads();
@@ -497,6 +559,8 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS) k_raster_bins(RasterArgs a) 
 template <bool ALPHA>
 __global__ void __launch_bounds__(64) k_raster_overflow(RasterArgs a) {
     const uint32_t lane = threadIdx.x, sub = lane >> 4, row = lane & 15u;
+    __shared__ float unormT[ALPHA ? 256 : 1];
+    if (ALPHA) { for (uint32_t i = threadIdx.x; i < 256u; i += 64u) unormT[i] = (float)i / 255.0f; __syncthreads(); }
     // lane = stripe: all 64 queue lengths with one load; nearly every frame has none
     const uint32_t mine = min(a.counters[CNT_STRIPES + lane * CNT_STRIPE_WORDS + STRIPE_OVERFLOW], a.overflowPerStripe);
     uint64_t busy = __ballot(mine != 0u);
@@ -508,7 +572,7 @@ __global__ void __launch_bounds__(64) k_raster_overflow(RasterArgs a) {
             const uint32_t ri = base + sub;
             if (ri >= n) continue;
             const BinRecord r = a.overflow[(size_t)stripe * a.overflowPerStripe + ri];
-            if (ALPHA && r.pad1 != 0u) raster_record_global(a, r, tex_alpha_of(a, a.overflowAlpha[(size_t)stripe * a.overflowPerStripe + ri]), r.pad0, row, 16u);
+            if (ALPHA && r.pad1 != 0u) raster_record_global(a, r, tex_alpha_of(a, unormT, a.overflowAlpha[(size_t)stripe * a.overflowPerStripe + ri]), r.pad0, row, 16u);
             else raster_record_global(a, r, NoAlpha{}, r.pad0, row, 16u);
         }
     }
@@ -546,9 +610,11 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
     a.binCapacity = p->binCapacity; a.binsX = p->binsX; a.binsY = p->binsY;
     a.overflow = p->wsPtr<BinRecord>(p->ws.binOverflow); a.overflowPerStripe = p->binOverflowPerStripe;
     a.objConst = p->wsPtr<float>(p->ws.objConst);
-    a.bigTriArea = p->bigTriArea; a.debugFlags = p->rasterDebug;
+    a.bigTriArea = p->bigTriArea; a.bigTriAreaAlpha = p->bigTriAreaAlpha; a.debugFlags = p->rasterDebug;
     a.binAlpha = p->wsPtr<AlphaRecord>(p->ws.binAlpha); a.overflowAlpha = p->wsPtr<AlphaRecord>(p->ws.overflowAlpha);
     a.clusterUv = p->wsPtr<ClusterUv>(p->ws.clusterUv);
+    a.alphaMats = p->wsPtr<AlphaMaterial>(p->ws.alphaMats);
+    if (p->sceneHasAlphaTest) if (int rc = ensure_frame_constants(p, s)) return rc;
     if (p->sceneHasAlphaTest) {
         hipLaunchKernelGGL(k_raster<true>, dim3(p->rasterGrid), dim3(64), 0, s, a);
         if (!(p->rasterDebug & 4)) hipLaunchKernelGGL(k_raster_bins<true>, dim3(p->binsX, p->binsY), dim3(BRMI_BIN_THREADS), 0, s, a);

@@ -202,8 +202,14 @@ constexpr int RESOLVE_WATERFALL = 4;     // distinct mesh instances per 8x8 tile
 #define BRMI_GB_WAVES 6
 #endif
 template <bool INLINE_TABLES, bool TEXTURED>
-__global__ void __launch_bounds__(256, (INLINE_TABLES || TEXTURED) ? 1 : BRMI_GB_WAVES) k_gbuffer(GBufferArgs a) {
+#ifndef BRMI_GBT_WAVES
+#define BRMI_GBT_WAVES 3
+#endif
+__global__ void __launch_bounds__(256, INLINE_TABLES ? 1 : (TEXTURED ? BRMI_GBT_WAVES : BRMI_GB_WAVES)) k_gbuffer(GBufferArgs a) {
     const brmi_scene_buffers& sc = a.sc;
+    __shared__ float texelTables[TEXTURED ? 512 : 1];          // code -> float: unorm, sRGB decode
+    if (TEXTURED) { stage_texel_tables(texelTables, sc.srgbToLinear, threadIdx.x, 256u); __syncthreads(); }
+    TexelTables tb; tb.t = texelTables;
     const brmi_per_frame* pf = sc.perFrame;
     const uint32_t clusterCount = min(a.counters[CNT_VISIBLE] + a.counters[CNT_VISIBLE2], a.clusterCapacity);
     // view-projection products are frame constants; every lane derives them the way the shader does
@@ -284,14 +290,38 @@ __global__ void __launch_bounds__(256, (INLINE_TABLES || TEXTURED) ? 1 : BRMI_GB
                     const BaryDeriv bd = bary_derivatives(r, l, ndcX, ndcY, winX, winY);
                     const f3 us{tc[0].x, tc[1].x, tc[2].x}, vs{tc[0].y, tc[1].y, tc[2].y};
                     const f2 uv{dot3(us, l), dot3(vs, l)}, dUVdx{dot3(us, bd.ddx), dot3(vs, bd.ddx)}, dUVdy{dot3(us, bd.ddy), dot3(vs, bd.ddy)};
-                    f4 baseColor{mat->baseColorFactor[0], mat->baseColorFactor[1], mat->baseColorFactor[2], mat->baseColorFactor[3]};
-                    if (flags & BRMI_MATERIAL_BASE_COLOR_TEXTURE) {
-                        const f4 t = sample_grad(sc, mat->baseColorTextureIndex, mat->baseColorSamplerIndex, uv, dUVdx, dUVdy);
-                        baseColor = f4{baseColor.x * t.x, baseColor.y * t.y, baseColor.z * t.z, baseColor.w * t.w};
+                    // texture / sampler tables in the address space of the material pointer: scalar loads on the waterfall path
+                    auto texturesP = as_space_of(mat, sc.textures); auto samplersP = as_space_of(mat, sc.samplers);
+                    auto bind = [&](uint32_t ti, uint32_t si) { return bind_texture(texturesP, sc.textureCount, samplersP, sc.samplerCount, ti, si); };
+                    // One loop over the texture slots (one copy of the sampler code).  Metallic, roughness and occlusion usually are
+                    // channels of ONE texture (glTF packing): a slot bound like the previous one reuses its fetch.
+                    f4 sBase{1.0f, 1.0f, 1.0f, 1.0f}, sMetal{}, sRough{}, sAo{}, sNormal{}, sEmis{};
+                    {
+                        TexBinding prev{}; f4 prevSample{};
+#pragma nounroll
+                        for (uint32_t slot = 0; slot < 6u; slot++) {
+                            uint32_t bit, ti, si;
+                            switch (slot) {
+                                case 0: bit = BRMI_MATERIAL_BASE_COLOR_TEXTURE; ti = mat->baseColorTextureIndex; si = mat->baseColorSamplerIndex; break;
+                                case 1: bit = BRMI_MATERIAL_METALLIC_TEXTURE; ti = mat->metallicTextureIndex; si = mat->metallicSamplerIndex; break;
+                                case 2: bit = BRMI_MATERIAL_ROUGHNESS_TEXTURE; ti = mat->roughnessTextureIndex; si = mat->roughnessSamplerIndex; break;
+                                case 3: bit = BRMI_MATERIAL_AO_TEXTURE; ti = mat->aoMapIndex; si = mat->aoSamplerIndex; break;
+                                case 4: bit = BRMI_MATERIAL_NORMAL_MAP; ti = mat->normalTextureIndex; si = mat->normalSamplerIndex; break;
+                                default: bit = BRMI_MATERIAL_EMISSIVE_TEXTURE; ti = mat->emissiveTextureIndex; si = mat->emissiveSamplerIndex; break;
+                            }
+                            if (!(flags & bit)) continue;
+                            const TexBinding bnd = bind(ti, si);
+                            const f4 t = same_binding(prev, bnd) ? prevSample : sample_grad(tb, bnd, uv, dUVdx, dUVdy);
+                            prev = bnd; prevSample = t;
+                            if (slot == 0u) sBase = t; else if (slot == 1u) sMetal = t; else if (slot == 2u) sRough = t; else if (slot == 3u) sAo = t; else if (slot == 4u) sNormal = t; else sEmis = t;
+                        }
                     }
-                    float metallic = mat->metallicFactor, roughness = mat->roughnessFactor;
-                    if (flags & BRMI_MATERIAL_METALLIC_TEXTURE) metallic = swizzle4(sample_grad(sc, mat->metallicTextureIndex, mat->metallicSamplerIndex, uv, dUVdx, dUVdy), mat->metallicChannel) * mat->metallicFactor;
-                    if (flags & BRMI_MATERIAL_ROUGHNESS_TEXTURE) roughness = swizzle4(sample_grad(sc, mat->roughnessTextureIndex, mat->roughnessSamplerIndex, uv, dUVdx, dUVdy), mat->roughnessChannel) * mat->roughnessFactor;
+                    f4 baseColor{mat->baseColorFactor[0], mat->baseColorFactor[1], mat->baseColorFactor[2], mat->baseColorFactor[3]};
+                    if (flags & BRMI_MATERIAL_BASE_COLOR_TEXTURE) baseColor = f4{baseColor.x * sBase.x, baseColor.y * sBase.y, baseColor.z * sBase.z, baseColor.w * sBase.w};
+                    float metallic = mat->metallicFactor, roughness = mat->roughnessFactor, ao = 1.0f;
+                    if (flags & BRMI_MATERIAL_METALLIC_TEXTURE) metallic = swizzle4(sMetal, mat->metallicChannel) * mat->metallicFactor;
+                    if (flags & BRMI_MATERIAL_ROUGHNESS_TEXTURE) roughness = swizzle4(sRough, mat->roughnessChannel) * mat->roughnessFactor;
+                    if (flags & BRMI_MATERIAL_AO_TEXTURE) ao = swizzle4(sAo, mat->aoChannel);
                     if (flags & BRMI_MATERIAL_NORMAL_MAP) {
                         // dpdx / dpdy through the model's 3x3 (clodResolveCommon.hlsli:1607-1624), cotangent_frame_from_derivs (utilities.hlsli:323-336)
                         const f3 pxs{p[0].x, p[1].x, p[2].x}, pys{p[0].y, p[1].y, p[2].y}, pzs{p[0].z, p[1].z, p[2].z};
@@ -301,21 +331,19 @@ __global__ void __launch_bounds__(256, (INLINE_TABLES || TEXTURED) ? 1 : BRMI_GB
                         const f3 T = dp2perp * dUVdx.x + dp1perp * dUVdy.x, B = dp2perp * dUVdx.y + dp1perp * dUVdy.y;
                         const float invmax = rsqrtf_(max2(dot3(T, T), dot3(B, B)));
                         const f3 Tn = T * invmax, Bn = B * invmax;
-                        const f4 t = sample_grad(sc, mat->normalTextureIndex, mat->normalSamplerIndex, uv, dUVdx, dUVdy);
+                        const f4 t = sNormal;
                         f3 tn = normalize3(f3{t.x, t.y, t.z} * 2.0f - f3{1.0f, 1.0f, 1.0f});
                         if (flags & BRMI_MATERIAL_NEGATE_NORMALS) tn = -tn;
                         if (flags & BRMI_MATERIAL_INVERT_NORMAL_GREEN) tn.y = -tn.y;
                         normalWS = normalize3(f3{(tn.x * Tn.x + tn.y * Bn.x) + tn.z * worldNormal.x, (tn.x * Tn.y + tn.y * Bn.y) + tn.z * worldNormal.y, (tn.x * Tn.z + tn.y * Bn.z) + tn.z * worldNormal.z});
                     }
-                    float ao = 1.0f;
-                    if (flags & BRMI_MATERIAL_AO_TEXTURE) ao = swizzle4(sample_grad(sc, mat->aoMapIndex, mat->aoSamplerIndex, uv, dUVdx, dUVdy), mat->aoChannel);
                     f3 emissiveIn{mat->emissiveFactor[0], mat->emissiveFactor[1], mat->emissiveFactor[2]};
                     if (flags & BRMI_MATERIAL_EMISSIVE_TEXTURE) {
-                        const f4 t = sample_grad(sc, mat->emissiveTextureIndex, mat->emissiveSamplerIndex, uv, dUVdx, dUVdy);
+                        const f4 t = sEmis;
                         emissiveIn = f3{swizzle4(t, mat->emissiveChannels[0]), swizzle4(t, mat->emissiveChannels[1]), swizzle4(t, mat->emissiveChannels[2])} * emissiveIn;
                         // ResolveCanonicalOpenPBRSurface: an all-zero sampled emissive falls back to the OpenPBR record's
-                        const uint32_t opIndex = mat->openPBRMaterialDataIndex;
-                        const f3 canonical = f3{sc.openpbrMaterials[opIndex].emissionColor[0], sc.openpbrMaterials[opIndex].emissionColor[1], sc.openpbrMaterials[opIndex].emissionColor[2]} * sc.openpbrMaterials[opIndex].emissionLuminance;
+                        const auto* op = as_space_of(mat, sc.openpbrMaterials) + mat->openPBRMaterialDataIndex;
+                        const f3 canonical = f3{op->emissionColor[0], op->emissionColor[1], op->emissionColor[2]} * op->emissionLuminance;
                         const f3 e = dot3(emissiveIn, emissiveIn) > 0.0f ? emissiveIn : canonical;
                         emissiveW = pack_half4(e.x, e.y, e.z, 0.0f);
                     }

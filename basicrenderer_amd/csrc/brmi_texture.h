@@ -44,62 +44,99 @@ BRMI_DEV f2 decode_uv(const ClusterUv& cu, uint32_t vertex) {
 }
 
 BRMI_DEV int floor_to_int(float f) { return to_int_sat(floorf(f)); }
+// n > 0.  Power-of-two sizes (nearly every texture) wrap / mirror with a mask; the result is the same as the general modulo.
 BRMI_DEV int address_texel(int i, int n, uint32_t mode) {
     if (mode == BRMI_ADDRESS_CLAMP) return i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
+    const bool pow2 = (n & (n - 1)) == 0;
     if (mode == BRMI_ADDRESS_MIRROR) {
         const int p = 2 * n;
-        int t = i % p; if (t < 0) t += p;
+        int t;
+        if (pow2) t = i & (p - 1); else { t = i % p; if (t < 0) t += p; }
         return t < n ? t : p - 1 - t;
     }
+    if (pow2) return i & (n - 1);
     int t = i % n; if (t < 0) t += n;
     return t;
 }
 BRMI_DEV f4 lerp4(f4 a, f4 b, float t) { return {a.x + t * (b.x - a.x), a.y + t * (b.y - a.y), a.z + t * (b.z - a.z), a.w + t * (b.w - a.w)}; }
 
-struct TexView { const uint32_t* texels; uint32_t width, height, mipCount; bool srgb; const uint32_t* mipOffset; const float* srgbToLinear; };
-BRMI_DEV f4 fetch_texel(const TexView& tx, uint32_t level, int x, int y) {
-    const uint32_t w = tx.width >> level ? tx.width >> level : 1u;
-    const uint32_t c = tx.texels[(size_t)tx.mipOffset[level] + (size_t)y * w + (size_t)x];
+// code -> float tables: unorm[c] = c / 255.0f, srgb[c] = the injected sRGB decode.  Kernels stage both in LDS (512 floats):
+// a texel costs four table reads instead of four correctly rounded divisions / three global gathers.
+struct TexelTables { const float* t; };        // [0, 256) unorm, [256, 512) sRGB decode
+BRMI_DEV void stage_texel_tables(float* lds512, const float* srgbToLinear, uint32_t tid, uint32_t nthreads) {
+    for (uint32_t i = tid; i < 256u; i += nthreads) { lds512[i] = (float)i / 255.0f; lds512[256u + i] = srgbToLinear ? srgbToLinear[i] : 0.0f; }
+}
+
+// one texture slot as the sampler sees it: descriptor and sampler state, fetched once per material (scalar loads when the
+// material index is wave-uniform: pass the tables through kconst())
+struct TexBinding { const uint32_t* texels; const uint32_t* mipOffset; uint32_t width, height, mipCount; bool srgb, bound; brmi_sampler_desc sm; };
+template <typename TexPtr, typename SampPtr>
+BRMI_DEV TexBinding bind_texture(TexPtr textures, uint32_t textureCount, SampPtr samplers, uint32_t samplerCount, uint32_t textureIndex, uint32_t samplerIndex) {
+    TexBinding b{};
+    b.bound = textureIndex < textureCount && samplerIndex < samplerCount;
+    if (!b.bound) return b;
+    const auto* td = textures + textureIndex;
+    const auto* sd = samplers + samplerIndex;
+    b.texels = reinterpret_cast<const uint32_t*>(td->texels); b.mipOffset = (const uint32_t*)td->mipOffset;
+    b.width = td->width; b.height = td->height; b.mipCount = td->mipCount; b.srgb = td->format == BRMI_TEXTURE_FORMAT_RGBA8_UNORM_SRGB;
+    b.sm.addressU = sd->addressU; b.sm.addressV = sd->addressV; b.sm.minFilter = sd->minFilter; b.sm.magFilter = sd->magFilter; b.sm.mipFilter = sd->mipFilter;
+    b.sm.mipLodBias = sd->mipLodBias; b.sm.minLod = sd->minLod; b.sm.maxLod = sd->maxLod;
+    return b;
+}
+BRMI_DEV bool same_binding(const TexBinding& a, const TexBinding& b) {
+    return a.bound && b.bound && a.texels == b.texels && a.sm.addressU == b.sm.addressU && a.sm.addressV == b.sm.addressV && a.sm.minFilter == b.sm.minFilter && a.sm.magFilter == b.sm.magFilter &&
+           a.sm.mipFilter == b.sm.mipFilter && a.sm.mipLodBias == b.sm.mipLodBias && a.sm.minLod == b.sm.minLod && a.sm.maxLod == b.sm.maxLod;
+}
+
+// texel memory is HBM: say so, a pointer read out of a descriptor is otherwise loaded through the flat path
+typedef const __attribute__((address_space(1))) uint32_t* GlobalTexels;
+BRMI_DEV GlobalTexels as_global(const uint32_t* p) { return (GlobalTexels)p; }
+BRMI_DEV f4 fetch_texel(const TexelTables& tb, const uint32_t* levelBase, int w, bool srgb, int x, int y) {
+    const uint32_t c = as_global(levelBase)[(size_t)y * (size_t)w + (size_t)x];
     f4 r;
-    if (tx.srgb) { r.x = tx.srgbToLinear[c & 0xFFu]; r.y = tx.srgbToLinear[(c >> 8) & 0xFFu]; r.z = tx.srgbToLinear[(c >> 16) & 0xFFu]; }
-    else { r.x = (float)(c & 0xFFu) / 255.0f; r.y = (float)((c >> 8) & 0xFFu) / 255.0f; r.z = (float)((c >> 16) & 0xFFu) / 255.0f; }
-    r.w = (float)(c >> 24) / 255.0f;
+    const uint32_t o = srgb ? 256u : 0u;      // an offset, not a second pointer: the reads stay LDS reads
+    r.x = tb.t[o + (c & 0xFFu)]; r.y = tb.t[o + ((c >> 8) & 0xFFu)]; r.z = tb.t[o + ((c >> 16) & 0xFFu)];
+    r.w = tb.t[c >> 24];
     return r;
 }
 
-BRMI_DEV f4 sample_level_filtered(const TexView& tx, const brmi_sampler_desc& sm, uint32_t level, f2 uv, uint32_t filter) {
+BRMI_DEV f4 sample_level_filtered(const TexelTables& tb, const TexBinding& tx, uint32_t level, f2 uv, uint32_t filter) {
     const int w = (int)(tx.width >> level ? tx.width >> level : 1u), h = (int)(tx.height >> level ? tx.height >> level : 1u);
+    const uint32_t* base = tx.texels + as_global(tx.mipOffset)[level];
     if (filter == BRMI_FILTER_POINT)
-        return fetch_texel(tx, level, address_texel(floor_to_int(uv.x * (float)w), w, sm.addressU), address_texel(floor_to_int(uv.y * (float)h), h, sm.addressV));
+        return fetch_texel(tb, base, w, tx.srgb, address_texel(floor_to_int(uv.x * (float)w), w, tx.sm.addressU), address_texel(floor_to_int(uv.y * (float)h), h, tx.sm.addressV));
     const float fx = uv.x * (float)w - 0.5f, fy = uv.y * (float)h - 0.5f;
     const float tx_ = fx - floorf(fx), ty_ = fy - floorf(fy);
     const int x0 = floor_to_int(fx), y0 = floor_to_int(fy);
-    const int xa = address_texel(x0, w, sm.addressU), xb = address_texel(x0 == 0x7FFFFFFF ? x0 : x0 + 1, w, sm.addressU);
-    const int ya = address_texel(y0, h, sm.addressV), yb = address_texel(y0 == 0x7FFFFFFF ? y0 : y0 + 1, h, sm.addressV);
-    const f4 t00 = fetch_texel(tx, level, xa, ya), t10 = fetch_texel(tx, level, xb, ya), t01 = fetch_texel(tx, level, xa, yb), t11 = fetch_texel(tx, level, xb, yb);
+    const int xa = address_texel(x0, w, tx.sm.addressU), xb = address_texel(x0 == 0x7FFFFFFF ? x0 : x0 + 1, w, tx.sm.addressU);
+    const int ya = address_texel(y0, h, tx.sm.addressV), yb = address_texel(y0 == 0x7FFFFFFF ? y0 : y0 + 1, h, tx.sm.addressV);
+    const f4 t00 = fetch_texel(tb, base, w, tx.srgb, xa, ya), t10 = fetch_texel(tb, base, w, tx.srgb, xb, ya), t01 = fetch_texel(tb, base, w, tx.srgb, xa, yb), t11 = fetch_texel(tb, base, w, tx.srgb, xb, yb);
     return lerp4(lerp4(t00, t10, tx_), lerp4(t01, t11, tx_), ty_);
 }
 
 // Texture2D::SampleLevel.  An unbound slot reads as opaque white.
-BRMI_DEV f4 sample_level(const brmi_scene_buffers& sc, uint32_t textureIndex, uint32_t samplerIndex, f2 uv, float lodIn) {
-    if (textureIndex >= sc.textureCount || samplerIndex >= sc.samplerCount) return {1.0f, 1.0f, 1.0f, 1.0f};
-    const brmi_texture_desc* td = sc.textures + textureIndex;
-    const brmi_sampler_desc sm = sc.samplers[samplerIndex];
-    const TexView tx{reinterpret_cast<const uint32_t*>(td->texels), td->width, td->height, td->mipCount, td->format == BRMI_TEXTURE_FORMAT_RGBA8_UNORM_SRGB, td->mipOffset, sc.srgbToLinear};
-    float lod = min2(max2(lodIn + sm.mipLodBias, sm.minLod), sm.maxLod);
+BRMI_DEV f4 sample_level(const TexelTables& tb, const TexBinding& tx, f2 uv, float lodIn) {
+    if (!tx.bound) return {1.0f, 1.0f, 1.0f, 1.0f};
+    float lod = min2(max2(lodIn + tx.sm.mipLodBias, tx.sm.minLod), tx.sm.maxLod);
     lod = min2(max2(lod, 0.0f), (float)(tx.mipCount - 1u));
-    const uint32_t filter = lod <= 0.0f ? sm.magFilter : sm.minFilter;
-    if (sm.mipFilter == BRMI_FILTER_POINT) {
+    const uint32_t filter = lod <= 0.0f ? tx.sm.magFilter : tx.sm.minFilter;
+    if (tx.sm.mipFilter == BRMI_FILTER_POINT) {
         uint32_t level = (uint32_t)floor_to_int(lod + 0.5f);
         if (level > tx.mipCount - 1u) level = tx.mipCount - 1u;
-        return sample_level_filtered(tx, sm, level, uv, filter);
+        return sample_level_filtered(tb, tx, level, uv, filter);
     }
     const uint32_t l0 = (uint32_t)floor_to_int(lod);
     const float frac = lod - floorf(lod);
-    const f4 a = sample_level_filtered(tx, sm, l0, uv, filter);
-    if (frac == 0.0f) return a;
     const uint32_t l1 = l0 + 1u > tx.mipCount - 1u ? tx.mipCount - 1u : l0 + 1u;
-    return lerp4(a, sample_level_filtered(tx, sm, l1, uv, filter), frac);
+    // one copy of the filter code for both levels (the kernels inline this several times)
+    f4 acc{};
+#pragma nounroll
+    for (uint32_t k = 0; k < 2u; k++) {
+        if (k == 1u && frac == 0.0f) break;                   // a + 0 * (b - a)
+        const f4 v = sample_level_filtered(tb, tx, k ? l1 : l0, uv, filter);
+        acc = k ? lerp4(acc, v, frac) : v;
+    }
+    return acc;
 }
 
 BRMI_DEV float log2_poly(float x) {
@@ -110,28 +147,71 @@ BRMI_DEV float log2_poly(float x) {
     return (float)e + p;
 }
 // Texture2D::SampleGrad
-BRMI_DEV f4 sample_grad(const brmi_scene_buffers& sc, uint32_t textureIndex, uint32_t samplerIndex, f2 uv, f2 dUVdx, f2 dUVdy) {
-    if (textureIndex >= sc.textureCount || samplerIndex >= sc.samplerCount) return {1.0f, 1.0f, 1.0f, 1.0f};
-    const float W = (float)sc.textures[textureIndex].width, H = (float)sc.textures[textureIndex].height;
+BRMI_DEV f4 sample_grad(const TexelTables& tb, const TexBinding& tx, f2 uv, f2 dUVdx, f2 dUVdy) {
+    if (!tx.bound) return {1.0f, 1.0f, 1.0f, 1.0f};
+    const float W = (float)tx.width, H = (float)tx.height;
     const float dxx = dUVdx.x * W, dxy = dUVdx.y * H, dyx = dUVdy.x * W, dyy = dUVdy.y * H;
     const float rho2 = max2(dxx * dxx + dxy * dxy, dyx * dyx + dyy * dyy);
     float lod;
     if (!(rho2 >= 1.17549435e-38f)) lod = -127.0f;
     else if (rho2 > 3.0e38f) lod = 128.0f;
     else lod = 0.5f * log2_poly(rho2);
-    return sample_level(sc, textureIndex, samplerIndex, uv, lod);
+    return sample_level(tb, tx, uv, lod);
 }
 
-// SWAlphaTestFailed (CLOD_SW_RASTER_DYNAMIC_ALPHA_TEST); the caller has already checked MATERIAL_ALPHA_TEST
-struct AlphaMaterial { uint32_t flags, baseTex, baseSamp, opTex, opSamp; float alphaFactor, cutoff; };
-BRMI_DEV AlphaMaterial load_alpha_material(const brmi_scene_buffers& sc, uint32_t materialDataIndex) {
-    const brmi_material_info* m = sc.materials + materialDataIndex;
-    return {m->materialFlags, m->baseColorTextureIndex, m->baseColorSamplerIndex, m->opacityTextureIndex, m->opacitySamplerIndex, m->baseColorFactor[3], m->alphaCutoff};
+// SWAlphaTestFailed (CLOD_SW_RASTER_DYNAMIC_ALPHA_TEST).  Everything that depends on the material alone -- the two texture
+// bindings, SampleLevel(.., 0)'s level choice -- is resolved once per cluster / record, not per pixel.
+struct AlphaLevel { const uint32_t* base; int w, h; };
+struct AlphaTex { AlphaLevel l0, l1; float frac; uint32_t filter, addressU, addressV; bool used; };
+struct AlphaMaterial { AlphaTex baseColor, opacity; float alphaFactor, cutoff; };
+static_assert(sizeof(AlphaMaterial) <= 128, "the per-material table reserves 128 B per entry");
+BRMI_DEV AlphaTex alpha_tex_of(const TexBinding& tx, bool enabled) {
+    AlphaTex t{};
+    t.used = enabled && tx.bound;
+    if (!t.used) return t;
+    float lod = min2(max2(0.0f + tx.sm.mipLodBias, tx.sm.minLod), tx.sm.maxLod);
+    lod = min2(max2(lod, 0.0f), (float)(tx.mipCount - 1u));
+    t.filter = lod <= 0.0f ? tx.sm.magFilter : tx.sm.minFilter; t.addressU = tx.sm.addressU; t.addressV = tx.sm.addressV;
+    uint32_t a, b;
+    if (tx.sm.mipFilter == BRMI_FILTER_POINT) { a = (uint32_t)floor_to_int(lod + 0.5f); if (a > tx.mipCount - 1u) a = tx.mipCount - 1u; b = a; t.frac = 0.0f; }
+    else { a = (uint32_t)floor_to_int(lod); t.frac = lod - floorf(lod); b = a + 1u > tx.mipCount - 1u ? tx.mipCount - 1u : a + 1u; }
+    t.l0 = AlphaLevel{tx.texels + as_global(tx.mipOffset)[a], (int)(tx.width >> a ? tx.width >> a : 1u), (int)(tx.height >> a ? tx.height >> a : 1u)};
+    t.l1 = AlphaLevel{tx.texels + as_global(tx.mipOffset)[b], (int)(tx.width >> b ? tx.width >> b : 1u), (int)(tx.height >> b ? tx.height >> b : 1u)};
+    return t;
 }
-BRMI_DEV bool alpha_test_failed(const brmi_scene_buffers& sc, const AlphaMaterial& m, f2 uv) {
+template <typename MatPtr, typename TexPtr, typename SampPtr>
+BRMI_DEV AlphaMaterial load_alpha_material(MatPtr m, TexPtr textures, uint32_t textureCount, SampPtr samplers, uint32_t samplerCount) {
+    AlphaMaterial r;
+    const uint32_t flags = m->materialFlags;
+    r.alphaFactor = m->baseColorFactor[3]; r.cutoff = m->alphaCutoff;
+    r.baseColor = alpha_tex_of(bind_texture(textures, textureCount, samplers, samplerCount, m->baseColorTextureIndex, m->baseColorSamplerIndex), (flags & BRMI_MATERIAL_BASE_COLOR_TEXTURE) != 0u);
+    r.opacity = alpha_tex_of(bind_texture(textures, textureCount, samplers, samplerCount, m->opacityTextureIndex, m->opacitySamplerIndex), (flags & BRMI_MATERIAL_OPACITY_TEXTURE) != 0u);
+    // a slot whose flag is set but whose descriptor is out of range reads as opaque white: alpha *= 1
+    return r;
+}
+BRMI_DEV float alpha_level(const float* unorm, const AlphaLevel& L, const AlphaTex& t, f2 uv) {
+    if (t.filter == BRMI_FILTER_POINT)
+        return unorm[as_global(L.base)[(size_t)address_texel(floor_to_int(uv.y * (float)L.h), L.h, t.addressV) * (size_t)L.w + (size_t)address_texel(floor_to_int(uv.x * (float)L.w), L.w, t.addressU)] >> 24];
+    const float fx = uv.x * (float)L.w - 0.5f, fy = uv.y * (float)L.h - 0.5f;
+    const float tx_ = fx - floorf(fx), ty_ = fy - floorf(fy);
+    const int x0 = floor_to_int(fx), y0 = floor_to_int(fy);
+    const int xa = address_texel(x0, L.w, t.addressU), xb = address_texel(x0 == 0x7FFFFFFF ? x0 : x0 + 1, L.w, t.addressU);
+    const int ya = address_texel(y0, L.h, t.addressV), yb = address_texel(y0 == 0x7FFFFFFF ? y0 : y0 + 1, L.h, t.addressV);
+    GlobalTexels g = as_global(L.base);
+    const uint32_t c00 = g[(size_t)ya * (size_t)L.w + (size_t)xa], c10 = g[(size_t)ya * (size_t)L.w + (size_t)xb], c01 = g[(size_t)yb * (size_t)L.w + (size_t)xa], c11 = g[(size_t)yb * (size_t)L.w + (size_t)xb];
+    const float a00 = unorm[c00 >> 24], a10 = unorm[c10 >> 24], a01 = unorm[c01 >> 24], a11 = unorm[c11 >> 24];
+    const float top = a00 + tx_ * (a10 - a00), bot = a01 + tx_ * (a11 - a01);
+    return top + ty_ * (bot - top);
+}
+BRMI_DEV float alpha_sample(const float* unorm, const AlphaTex& t, f2 uv) {
+    const float a = alpha_level(unorm, t.l0, t, uv);
+    if (t.frac == 0.0f) return a;
+    return a + t.frac * (alpha_level(unorm, t.l1, t, uv) - a);
+}
+BRMI_DEV bool alpha_test_failed(const float* unorm, const AlphaMaterial& m, f2 uv) {
     float alpha = m.alphaFactor;
-    if (m.flags & BRMI_MATERIAL_BASE_COLOR_TEXTURE) alpha *= sample_level(sc, m.baseTex, m.baseSamp, uv, 0.0f).w;
-    if (m.flags & BRMI_MATERIAL_OPACITY_TEXTURE) alpha *= sample_level(sc, m.opTex, m.opSamp, uv, 0.0f).w;
+    if (m.baseColor.used) alpha *= alpha_sample(unorm, m.baseColor, uv);
+    if (m.opacity.used) alpha *= alpha_sample(unorm, m.opacity, uv);
     return alpha < m.cutoff;
 }
 // the texcoord of a pixel from the stepped barycentrics (softwareRaster.hlsl:526-531)

@@ -41,6 +41,8 @@ def main():
                     help="2-phase HZB occlusion culling (reference default: on, BR/include/Renderer.h:220); timed frames are steady state")
     ap.add_argument("--lod-builder", default="quadtree", choices=["quadtree", "clusterlod"],
                     help="clusterlod: mesh LOD DAGs from the reference's own builder (oracle/_ref/libclodref.so) instead of the generator's quadtree")
+    ap.add_argument("--material-features", type=int, default=0,
+                    help="scene generator feature bits (brmi_scene.h): 1 coat, 2 fuzz, 4 mirrored instances, 8 texture-sampled materials, 16 alpha-tested materials; 0 = BASELINE.json's constant-factor configuration")
     ap.add_argument("--force-compose", action="store_true", help="run the RCCL band composition even with one rank (checks the collective path on a single GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scale", type=float, default=1.0, help="fraction of the frame height the CPU baseline renders")
@@ -68,7 +70,7 @@ def main():
     lights = {"sponza": 64, "bistro": 256, "san_miguel": 256}[args.workload]
     W, H = compose.frame_size(n)
     band = compose.band_of(rank, n, H)
-    scene = Scene(args.workload, W, H, point_lights=lights, directional=True, lod_builder=args.lod_builder)
+    scene = Scene(args.workload, W, H, point_lights=lights, directional=True, lod_builder=args.lod_builder, material_features=args.material_features)
     r = VisibilityRenderer(scene, device=dev, stats=True, band=band, occlusion=bool(args.occlusion))
 
     hdr = r.hdr_tensor()
@@ -141,6 +143,7 @@ def main():
             "config": {"workload": f"{args.workload}-class procedural frame, {W}x{H}, 1 directional + {lights} point lights, "
                                    f"{scene.stats['instancedTriangles']} instanced tris, {scene.stats['instances']} instances"
                                    + (", LOD DAG built by the reference's clusterlod.h" if args.lod_builder == "clusterlod" else "")
+                                   + (f", material features {args.material_features} (8 = texture-sampled, 16 = alpha-tested materials)" if args.material_features else "")
                                    + (f", {n} row bands of 1080 rows + RCCL all-gather of HDR (pipelined one frame deep)" if n > 1 else ""),
                        "baseline_config": "configs[1]" if args.workload == "sponza" else "configs[2]",
                        "pixels_per_gpu": W * (band[1] - band[0]), "visible_clusters_rank0": int(c.visibleClusters),
