@@ -102,7 +102,8 @@ BRMI_STAGE_PASS(HierarchicalCullingPass1, "HierarchicalCullingPass1", brmi_cull(
 // reference: ClusterSoftwareRasterizationPass (BR/src/Render/GraphExtensions/ClusterLOD/ClusterSoftwareRasterizationPass.cpp:154-207);
 // the raster-bucket histogram / scan / compaction passes (RasterBucket*Pass) collapse into it
 BRMI_STAGE_PASS(SoftwareRasterizeClustersPass1, "SoftwareRasterizeClustersPass1", brmi_raster(state->get(), 1, ctx.commandList),
-                ({"Builtin::CLod::VisibleClusters", "Builtin::PerMeshInstanceBuffer", "Builtin::PerObjectBuffer", "Builtin::CullingCameraBuffer", "CLod page slabs"}),
+                ({"Builtin::CLod::VisibleClusters", "Builtin::PerMeshInstanceBuffer", "Builtin::PerObjectBuffer", "Builtin::CullingCameraBuffer", "CLod page slabs",
+                  "Builtin::PerMaterialDataBuffer", "material textures + samplers (alpha test)"}),
                 ({"Builtin::PrimaryCamera::VisibilityTexture"}))
 // reference: PerViewLinearDepthCopyPass (BR/src/Render/GraphExtensions/ClusterLOD/PerViewLinearDepthCopyPass.cpp)
 BRMI_STAGE_PASS(LinearDepthCopyPass1, "LinearDepthCopyPass1", brmi_depth_copy(state->get(), ctx.commandList),
@@ -115,12 +116,13 @@ BRMI_STAGE_PASS(HierarchicalCullingPass2, "HierarchicalCullingPass2", brmi_cull(
                 ({"Builtin::PrimaryCamera::LinearDepthMap(mips)", "Builtin::PerMeshInstanceBuffer", "Builtin::PerObjectBuffer", "Builtin::CameraBuffer", "brmi::Workspace"}),
                 ({"Builtin::CLod::VisibleClusters", "brmi::Workspace"}))
 BRMI_STAGE_PASS(SoftwareRasterizeClustersPass2, "SoftwareRasterizeClustersPass2", brmi_raster(state->get(), 2, ctx.commandList),
-                ({"Builtin::CLod::VisibleClusters", "Builtin::PerMeshInstanceBuffer", "Builtin::PerObjectBuffer", "Builtin::CullingCameraBuffer", "CLod page slabs"}),
+                ({"Builtin::CLod::VisibleClusters", "Builtin::PerMeshInstanceBuffer", "Builtin::PerObjectBuffer", "Builtin::CullingCameraBuffer", "CLod page slabs",
+                  "Builtin::PerMaterialDataBuffer", "material textures + samplers (alpha test)"}),
                 ({"Builtin::PrimaryCamera::VisibilityTexture"}))
 // reference: MaterialHistogram .. EvaluateMaterialGroups (BR/include/RenderPasses/VisUtil/*.h; parameter list at EvaluateMaterialGroupsPass.h:68-111)
 BRMI_STAGE_PASS(EvaluateMaterialGroupsPass, "EvaluateMaterialGroupsPass", brmi_gbuffer(state->get(), ctx.commandList),
                 ({"Builtin::PrimaryCamera::VisibilityTexture", "Builtin::CLod::VisibleClusters", "Builtin::PerMaterialDataBuffer", "Builtin::PerMaterialOpenPBRDataBuffer",
-                  "Builtin::NormalMatrixBuffer", "CLod page slabs"}),
+                  "Builtin::NormalMatrixBuffer", "CLod page slabs", "material textures + samplers"}),
                 ({"Builtin::GBuffer::Normals", "Builtin::GBuffer::Albedo", "Builtin::GBuffer::Coat", "Builtin::GBuffer::Emissive", "Builtin::GBuffer::Fuzz",
                   "Builtin::GBuffer::MetallicRoughness", "Builtin::GBuffer::MotionVectors", "Builtin::PrimaryCamera::LinearDepthMap"}))
 // reference: ClusterGenerationPass + LightCullingPass (BR/include/RenderPasses/ClusterGenerationPass.h:41-42, LightCullingPass.h:49-51)

@@ -2,7 +2,7 @@
 // buffers, resources declared by the pass and allocated by the "graph" (here: hipMalloc), passes gathered from the
 // extension and executed in order on one stream.  Prints the frame's checksums as one JSON line.
 //
-//   build:  make host_example        run:  basicrenderer_amd/lib/brmi_host_frame [preset W H lights]
+//   build:  make host_example        run:  basicrenderer_amd/lib/brmi_host_frame [preset W H lights occlusion frames materialFeatures lodLevels]
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -39,6 +39,8 @@ int main(int argc, char** argv) {
     prm.numPointLights = argc > 4 ? (uint32_t)std::atoi(argv[4]) : 6; prm.withDirectionalLight = 1; prm.sizeScale = 1.0f;
     const bool occlusion = argc > 5 && std::atoi(argv[5]) != 0;      // 2-phase HZB occlusion culling: the unfused pass sequence of the reference graph
     const int frames = argc > 6 ? std::max(1, std::atoi(argv[6])) : 1;
+    prm.materialFeatures = argc > 7 ? (uint32_t)std::atoi(argv[7]) : 0u;        // brmi_scene.h: 8 = texture-sampled, 16 = alpha-tested materials
+    prm.lodLevels = argc > 8 ? (uint32_t)std::atoi(argv[8]) : 0u;
     brmi_scene* scene = brmi_scene_create(&prm);
     if (!scene) return 1;
     std::vector<void*> keep;
@@ -77,6 +79,19 @@ int main(int argc, char** argv) {
     sb.lutIdealMetalEnergyComplement = upload<uint16_t>(scene, BRMI_ARR_LUT_IM_ENERGY, nullptr, keep);
     sb.lutIdealMetalAvgEnergyComplement = upload<uint16_t>(scene, BRMI_ARR_LUT_IM_AVG_ENERGY, nullptr, keep);
     sb.lutFuzzLTC = upload<float>(scene, BRMI_ARR_LUT_FUZZ_LTC, nullptr, keep);
+    {   // material textures: the generator's descriptors hold byte offsets into the texel array; the host relocates them to device pointers
+        const void* hp; uint64_t bytes; uint32_t n;
+        brmi_scene_array(scene, BRMI_ARR_TEXTURE_DESCS, &hp, &bytes, &n);
+        if (n) {
+            const uint8_t* texels = upload<uint8_t>(scene, BRMI_ARR_TEXELS, nullptr, keep);
+            std::vector<brmi_texture_desc> descs(static_cast<const brmi_texture_desc*>(hp), static_cast<const brmi_texture_desc*>(hp) + n);
+            for (auto& d : descs) d.texels = texels + reinterpret_cast<uintptr_t>(d.texels);
+            void* dd; HIPCHK(hipMalloc(&dd, bytes)); HIPCHK(hipMemcpy(dd, descs.data(), bytes, hipMemcpyHostToDevice)); keep.push_back(dd);
+            sb.textures = static_cast<const brmi_texture_desc*>(dd); sb.textureCount = n;
+            sb.samplers = upload<brmi_sampler_desc>(scene, BRMI_ARR_SAMPLER_DESCS, &sb.samplerCount, keep);
+            sb.srgbToLinear = upload<float>(scene, BRMI_ARR_SRGB_TO_LINEAR, nullptr, keep);
+        }
+    }
 
     hipStream_t stream; HIPCHK(hipStreamCreate(&stream));
     try {

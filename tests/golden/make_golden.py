@@ -25,6 +25,8 @@ GOLDEN_CASES = {
     "golden_sponza": ("sponza", 192, 108, dict(point_lights=24, seed=1, size_scale=0.05)),
     # compute skinning + the 2-phase occlusion chain: second frame of a camera path (phase 1 tests against frame 0's chain)
     "golden_tiny_skinned_occlusion": ("tiny", 160, 90, dict(point_lights=3, seed=7, lod_levels=2, skinned_fraction=1.0)),
+    # UV streams, alpha-tested rasterisation and texture-sampled materials through the software sampler
+    "golden_tiny_textured_alpha": ("tiny", 160, 90, dict(point_lights=4, seed=9, lod_levels=2, material_features=24)),
 }
 
 
@@ -52,7 +54,7 @@ def render(name):
 
 if __name__ == "__main__":
     out = os.path.dirname(os.path.abspath(__file__))
-    for name in GOLDEN_CASES:
+    for name in (sys.argv[1:] or GOLDEN_CASES):
         data = render(name)
         path = os.path.join(out, name + ".npz")
         np.savez_compressed(path, **data)

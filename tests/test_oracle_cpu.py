@@ -15,7 +15,7 @@ def _golden(name):
     return np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
 
 
-@pytest.mark.parametrize("name", ["golden_tiny", "golden_tiny_lod_coat_fuzz", "golden_sponza", "golden_tiny_skinned_occlusion"])
+@pytest.mark.parametrize("name", ["golden_tiny", "golden_tiny_lod_coat_fuzz", "golden_sponza", "golden_tiny_skinned_occlusion", "golden_tiny_textured_alpha"])
 def test_oracle_reproduces_golden_fixtures(name):
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
@@ -23,6 +23,188 @@ def test_oracle_reproduces_golden_fixtures(name):
     got, want = make_golden.render(name), _golden(name)
     for key in want.files:
         assert np.array_equal(got[key], want[key]), f"{name}: {key} differs from the committed fixture"
+
+
+# ---- UV streams, software sampler, alpha test (oracle/orc_texture.h) -----------------------------------------------------
+class _TexScene:
+    """A textured scene plus numpy views of its texture / sampler tables for independent restatements."""
+
+    def __init__(self, **kw):
+        import orc
+        from basicrenderer_amd import Scene
+        self.scene = Scene("tiny", 160, 90, point_lights=2, lod_levels=2, material_features=24, **kw)
+        self.sb = self.scene.host_buffers()
+        self.lib = orc.lib()
+        d = self.scene.arrays["textureDescs"].view(np.uint32).reshape(-1, 24)
+        self.tex = [dict(offset=int(r[0]) | (int(r[1]) << 32), w=int(r[2]), h=int(r[3]), mips=int(r[4]), srgb=int(r[5]) == 1, mip_offset=[int(x) for x in r[6:22]]) for r in d]
+        self.samp = self.scene.arrays["samplerDescs"].view(np.uint32).reshape(-1, 8)
+        self.texels = self.scene.arrays["texels"]
+        self.srgb = self.scene.arrays["srgbToLinear"].view(np.float32)
+
+    def level(self, t, l):
+        tx = self.tex[t]
+        w, h = max(1, tx["w"] >> l), max(1, tx["h"] >> l)
+        raw = self.texels[tx["offset"] + tx["mip_offset"][l] * 4: tx["offset"] + (tx["mip_offset"][l] + w * h) * 4].reshape(h, w, 4)
+        out = raw.astype(np.float64) / 255.0
+        if tx["srgb"]:
+            out[..., :3] = self.srgb[raw[..., :3]].astype(np.float64)
+        return out
+
+    def sample_level(self, t, s, uv, lod):
+        uv = np.ascontiguousarray(uv, dtype=np.float32); lod = np.ascontiguousarray(lod, dtype=np.float32)
+        out = np.zeros((len(uv), 4), dtype=np.float32)
+        self.lib.orc_sample_level(C.byref(self.sb), C.c_uint32(t), C.c_uint32(s), uv.ctypes.data_as(C.c_void_p), lod.ctypes.data_as(C.c_void_p), C.c_uint64(len(uv)), out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def sample_grad(self, t, s, uv, ddx, ddy):
+        uv, ddx, ddy = (np.ascontiguousarray(a, dtype=np.float32) for a in (uv, ddx, ddy))
+        out = np.zeros((len(uv), 4), dtype=np.float32)
+        self.lib.orc_sample_grad(C.byref(self.sb), C.c_uint32(t), C.c_uint32(s), uv.ctypes.data_as(C.c_void_p), ddx.ctypes.data_as(C.c_void_p), ddy.ctypes.data_as(C.c_void_p), C.c_uint64(len(uv)), out.ctypes.data_as(C.c_void_p))
+        return out
+
+
+@pytest.fixture(scope="module")
+def texscene():
+    return _TexScene()
+
+
+def _address(i, n, mode):
+    if mode == 2:
+        return np.clip(i, 0, n - 1)
+    if mode == 1:
+        t = np.mod(i, 2 * n)
+        return np.where(t < n, t, 2 * n - 1 - t)
+    return np.mod(i, n)
+
+
+def test_sampler_matches_a_float64_restatement_of_the_d3d_filter(texscene):
+    """SampleLevel at fixed levels, every sampler (wrap / clamp+mirror / nearest-mip / all point), against bilinear / point
+    filtering written independently in float64."""
+    ts = texscene
+    rng = np.random.default_rng(5)
+    for t in (0, 2, 4, 8):                     # sRGB base colour 256 and 512, linear ORM, linear alpha stripes
+        for s in range(4):
+            au, av, minf, magf, mipf = (int(x) for x in ts.samp[s][:5])
+            bias, lo, hi = ts.samp[s][5:8].view(np.float32)
+            for l in (0, 1, 3):
+                uv = rng.uniform(-2.5, 3.5, (400, 2)).astype(np.float32)
+                got = ts.sample_level(t, s, uv, np.full(400, l - bias, dtype=np.float32))
+                lod = float(np.clip(np.float32(l - bias) + bias, lo, hi))
+                lod = min(max(lod, 0.0), ts.tex[t]["mips"] - 1)
+                if mipf == 0:
+                    levels, frac = [int(np.floor(lod + 0.5))], 0.0
+                else:
+                    levels, frac = [int(np.floor(lod)), min(int(np.floor(lod)) + 1, ts.tex[t]["mips"] - 1)], lod - np.floor(lod)
+                filt = magf if lod <= 0 else minf
+                acc = []
+                for lv in levels:
+                    img = ts.level(t, lv)
+                    h, w = img.shape[:2]
+                    if filt == 0:
+                        x = _address(np.floor(uv[:, 0].astype(np.float64) * w).astype(np.int64), w, au); y = _address(np.floor(uv[:, 1].astype(np.float64) * h).astype(np.int64), h, av)
+                        acc.append(img[y, x])
+                    else:
+                        fx = uv[:, 0].astype(np.float64) * w - 0.5; fy = uv[:, 1].astype(np.float64) * h - 0.5
+                        x0 = np.floor(fx).astype(np.int64); y0 = np.floor(fy).astype(np.int64)
+                        tx = (fx - x0)[:, None]; ty = (fy - y0)[:, None]
+                        xa, xb, ya, yb = _address(x0, w, au), _address(x0 + 1, w, au), _address(y0, h, av), _address(y0 + 1, h, av)
+                        top = img[ya, xa] * (1 - tx) + img[ya, xb] * tx; bot = img[yb, xa] * (1 - tx) + img[yb, xb] * tx
+                        acc.append(top * (1 - ty) + bot * ty)
+                want = acc[0] if len(acc) == 1 or frac == 0 else acc[0] * (1 - frac) + acc[1] * frac
+                # fp32 rounding of the texel coordinate can move a sample across a texel boundary (point filter): allow a handful
+                bad = np.abs(got - want).max(axis=1) > 3e-4      # u * w is rounded to fp32 (ulp 1.2e-4 at 1800 texels) before the weights are taken
+                assert bad.sum() <= (8 if filt == 0 else 0), (t, s, l, int(bad.sum()), float(np.abs(got - want).max()))
+
+
+def test_sampler_returns_the_texel_at_texel_centres_and_wraps(texscene):
+    ts = texscene
+    img = ts.level(0, 0)
+    h, w = img.shape[:2]
+    ys, xs = np.meshgrid(np.arange(0, h, 7), np.arange(0, w, 5), indexing="ij")
+    uv = np.stack([(xs.ravel() + 0.5) / w, (ys.ravel() + 0.5) / h], 1).astype(np.float32)
+    for s in (0, 3):          # linear and point: both return the texel itself at its centre
+        got = ts.sample_level(0, s, uv, np.full(len(uv), -8.0, dtype=np.float32) if s == 0 else np.full(len(uv), -8.0, dtype=np.float32))
+        lv = 0 if s == 0 else 1                                   # sampler 3 has minLod = 1
+        ref = ts.level(0, lv)
+        if lv == 0:
+            assert np.array_equal(got, ref[ys.ravel(), xs.ravel()].astype(np.float32))
+    # wrap: whole-number shifts of a coordinate that stays exactly representable give the same bits
+    uv = (np.arange(64)[:, None] / 64.0 + np.array([[0.0078125, 0.01171875]])).astype(np.float32)
+    a = ts.sample_level(0, 0, uv, np.zeros(64, dtype=np.float32))
+    b = ts.sample_level(0, 0, uv + np.float32(2.0), np.zeros(64, dtype=np.float32))
+    assert np.array_equal(a, b)
+
+
+def test_sample_grad_picks_the_level_of_the_footprint(texscene):
+    """A footprint of exactly 2^k texels selects level k exactly (the LOD polynomial is exact at powers of two); in between the
+    result is the blend of the two levels at the fraction log2 gives, and the polynomial stays within 7e-5 of log2."""
+    ts = texscene
+    rng = np.random.default_rng(6)
+    uv = rng.uniform(0, 1, (200, 2)).astype(np.float32)
+    W = ts.tex[0]["w"]
+    for k in range(0, 6):
+        ddx = np.tile(np.array([[2.0 ** k / W, 0.0]], dtype=np.float32), (200, 1)); ddy = np.tile(np.array([[0.0, 0.5 / W]], dtype=np.float32), (200, 1))
+        assert np.array_equal(ts.sample_grad(0, 0, uv, ddx, ddy), ts.sample_level(0, 0, uv, np.full(200, float(k), dtype=np.float32)))
+    x = np.exp(rng.uniform(-40, 40, 100000)).astype(np.float32)
+    out = np.zeros_like(x)
+    ts.lib.orc_log2_poly(x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.c_uint64(len(x)))
+    assert np.abs(out.astype(np.float64) - np.log2(x.astype(np.float64))).max() < 7e-5
+    assert (np.diff(out[np.argsort(x)]) >= 0).all()                 # monotone: a larger footprint never picks a finer level
+    # zero footprint = magnification: the finest level through the mag filter
+    z = np.zeros((200, 2), dtype=np.float32)
+    assert np.array_equal(ts.sample_grad(0, 0, uv, z, z), ts.sample_level(0, 0, uv, np.zeros(200, dtype=np.float32)))
+
+
+def test_uv_streams_decode_like_a_bignum_restatement_of_the_packer(texscene):
+    """SWDecodeCompressedUV against an independent decode (Python integers over the raw page bytes) for every visible cluster; the
+    quantisation the generator applies is the reference's (min + q / 65535, bits = bit length of the quantised range)."""
+    import orc
+    ts = texscene
+    f = orc.OracleFrame(ts.scene)
+    f.cull()
+    assert f.count > 0
+    out = np.zeros((128, 2), dtype=np.float32)
+    for ci in range(f.count):
+        c = f.clusters[ci]
+        n = ts.lib.orc_cluster_uvs(C.byref(ts.sb), c.ctypes.data_as(C.c_void_p), C.c_uint32(0), out.ctypes.data_as(C.c_void_p))
+        slab = ts.scene.slabs[(int(c[2]) >> 2) & 0xFFFFF]
+        page = ((int(c[2]) >> 22) & 0x3FF) << 18
+        hdr = slab[page: page + 64].view(np.uint32)
+        uv_sets, uv_desc_off, uv_dir_off, meshlet = int(hdr[3]), int(hdr[5]), int(hdr[11]), int(c[1]) & 0x3FFF
+        assert uv_sets == 1
+        d = slab[page + uv_desc_off + meshlet * 32: page + uv_desc_off + meshlet * 32 + 32]
+        bit_off = int(d[:4].view(np.uint32)[0]); mn_u, mn_v, sc_u, sc_v = d[4:20].view(np.float32); bits = int(d[20:24].view(np.uint32)[0])
+        bu, bv = bits & 0xFF, (bits >> 8) & 0xFF
+        assert 1 <= bu <= 20 and 1 <= bv <= 20 and sc_u == np.float32(1.0 / 65535.0)
+        stream = page + int(slab[page + uv_dir_off: page + uv_dir_off + 4].view(np.uint32)[0])
+        big = int.from_bytes(slab[stream: stream + ((bit_off + n * (bu + bv) + 63) // 8)].tobytes(), "little")
+        for v in range(n):
+            cur = bit_off + v * (bu + bv)
+            eu = (big >> cur) & ((1 << bu) - 1); ev = (big >> (cur + bu)) & ((1 << bv) - 1)
+            assert out[v, 0] == np.float32(mn_u + np.float32(eu) * sc_u) and out[v, 1] == np.float32(mn_v + np.float32(ev) * sc_v)
+        assert eu <= (1 << bu) - 1
+
+
+def test_alpha_test_cuts_holes_and_only_in_alpha_tested_materials(texscene):
+    """The alpha-tested frame covers fewer pixels than the same scene without the flag; every surviving key of an alpha-tested
+    cluster passes SWAlphaTestFailed at ITS pixel when re-evaluated, and materials without the flag never fail."""
+    import orc
+    from basicrenderer_amd import Scene
+    ts = texscene
+    f = orc.OracleFrame(ts.scene).run()
+    g = orc.OracleFrame(Scene("tiny", 160, 90, point_lights=2, lod_levels=2, material_features=8)).run()
+    assert 0 < (f.vis != EMPTY).sum() < (g.vis != EMPTY).sum()
+    mats = ts.scene.arrays["materials"].view(np.uint32).reshape(-1, 69)
+    uv = np.random.default_rng(3).uniform(-1, 2, (2000, 2)).astype(np.float32)
+    res = np.zeros(2000, dtype=np.uint8)
+    some_fail = False
+    for m in range(len(mats)):
+        ts.lib.orc_alpha_test_failed(C.byref(ts.sb), C.c_uint32(m), uv.ctypes.data_as(C.c_void_p), C.c_uint64(2000), res.ctypes.data_as(C.c_void_p))
+        if mats[m, 0] & (1 << 13):
+            some_fail = some_fail or (0 < res.sum() < 2000)
+        else:
+            assert res.sum() == 0
+    assert some_fail
 
 
 def test_hzb_chain_is_a_max_pyramid_of_the_padded_depth():

@@ -97,6 +97,34 @@ def test_depth_and_gbuffer_bit_exact(name, gpu_frames, oracle_frames):
         assert not bad.any(), f"{key}: {int(bad.sum())} of {bad.size} values differ"
 
 
+@pytest.mark.parametrize("name", ["golden_tiny", "golden_tiny_lod_coat_fuzz", "golden_sponza", "golden_tiny_textured_alpha"])
+def test_gpu_reproduces_the_committed_golden_fixtures(name):
+    """The frozen fixtures under tests/golden/ (inputs regenerated from the seed, expected outputs committed): a reference that does
+    not move with the oracle's source."""
+    import os
+    import sys
+    from basicrenderer_amd import Scene
+    from basicrenderer_amd.renderer import VisibilityRenderer
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tests", "golden"))
+    import make_golden
+    want = np.load(os.path.join(root, "tests", "golden", name + ".npz"))
+    preset, W, H, kw = make_golden.GOLDEN_CASES[name]
+    r = VisibilityRenderer(Scene(preset, W, H, **kw), stats=True)
+    r.execute()
+    assert np.array_equal(r.visible_clusters(), want["clusters"])
+    assert np.array_equal(r.visibility(), want["vis"])
+    covered = want["vis"] != np.uint64(0xFFFFFFFFFFFFFFFF)
+    g = r.gbuffer()
+    assert np.array_equal(r.depth().view(np.uint32), want["depth"])
+    assert np.array_equal(g["normals"].view(np.uint32)[covered], want["normals"][covered])
+    for k in ("albedo", "coat", "emissive", "fuzz", "mr", "motion"):
+        assert np.array_equal(g[k][covered], want[k][covered]), k
+    a, b = r.hdr().view(np.uint16).astype(np.int32), want["hdr"].view(np.uint16).astype(np.int32)
+    assert np.abs(a - b).max() <= 1
+    r.close()
+
+
 @pytest.mark.parametrize("name", CASES)
 def test_light_lists_exact(name, gpu_frames, oracle_frames):
     g, o = gpu_frames(name), oracle_frames(name)
@@ -292,6 +320,19 @@ def test_cpp_host_passes_reproduce_the_python_frame(scenes):
     for key, rid in (("vis_fnv", "VISIBILITY"), ("hdr_fnv", "HDR_COLOR"), ("normals_fnv", "GBUF_NORMALS")):
         raw = r.res[capi.RES[rid]].cpu().numpy()[: r.descs[capi.RES[rid]]["bytes"]]
         assert fnv(raw) == got[key], key
+    r.close()
+
+    # texture-sampled and alpha-tested materials through the C++ host (texture descriptors relocated by the host)
+    from basicrenderer_amd import Scene
+    out = subprocess.run([exe, "0", "256", "144", "6", "0", "1", "24", "2"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    got = json.loads(out.stdout.strip().splitlines()[-1])
+    r = VisibilityRenderer(Scene("tiny", 256, 144, point_lights=6, lod_levels=2, material_features=24))
+    r.execute()
+    r.torch.cuda.synchronize()
+    for key, rid in (("vis_fnv", "VISIBILITY"), ("hdr_fnv", "HDR_COLOR"), ("normals_fnv", "GBUF_NORMALS")):
+        raw = r.res[capi.RES[rid]].cpu().numpy()[: r.descs[capi.RES[rid]]["bytes"]]
+        assert fnv(raw) == got[key], "textured: " + key
     r.close()
 
     # occlusion culling: the reference graph's unfused pass sequence (depth copy, downsample, phase 2, downsample) through the
