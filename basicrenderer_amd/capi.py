@@ -117,6 +117,9 @@ def scene_lib():
         lib = C.CDLL(path)
         lib.brmi_scene_create.restype = vp
         lib.brmi_scene_create.argtypes = [C.POINTER(SceneParams)]
+        lib.brmi_scene_create_from_cache.restype = vp
+        lib.brmi_scene_create_from_cache.argtypes = [C.POINTER(SceneParams), C.c_char_p]
+        lib.brmi_scene_export_cache.argtypes = [vp, C.c_char_p]
         lib.brmi_scene_destroy.argtypes = [vp]
         lib.brmi_scene_array.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(u64), C.POINTER(u32)]
         lib.brmi_scene_slab_count.argtypes = [vp]

@@ -512,17 +512,16 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? 4 : 1) k_raster_bins
     if (ALPHA) {
         // Alpha-tested records after the opaque ones (more keys to reject untested).  A pixel of theirs costs a dependent chain of
         // texel fetches, and a bin often holds only a handful of such records (two floor triangles): one lane per row would walk
-        // 256 pixels serially.  Lane = (row, 32-pixel segment): 128 lanes per record, four records at a time; a segment's
-        // barycentrics are stepped from the row start like every clipped walk.
+        // 256 pixels serially.  Lane = (row, 8-pixel segment): the whole workgroup walks one record at a time, every lane at most 8
+        // dependent fetches deep; a segment's barycentrics are stepped from the row start like every clipped walk.
         __syncthreads();
-        const uint32_t rsub = threadIdx.x >> 7, seg = (threadIdx.x >> 4) & 7u;
+        const uint32_t seg = threadIdx.x >> 4;
         const uint32_t listed = min(alphaCount, 4096u);
-        for (uint32_t base = 0; base < listed; base += BRMI_BIN_THREADS / 128) {
-            if (base + rsub >= listed) continue;
-            const uint32_t ri = alphaList[base + rsub];
+        for (uint32_t li = 0; li < listed; li++) {
+            const uint32_t ri = alphaList[li];
             const BinRecord r = recs[ri];
             const uint32_t rows = (r.triAndFlags >> 16) & 0xFFu;
-            const int sx0 = x0 + (int)(seg << 5), sx1 = sx0 + 31;
+            const int sx0 = x0 + (int)(seg << 3), sx1 = sx0 + 7;
             if (row >= rows || r.minX > sx1 || r.minX + r.rectWidth - 1 < sx0) continue;
             float sb0 = r.sb0, sb1 = r.sb1;
             for (uint32_t k = 0; k < row; k++) { sb0 += r.dy_b0; sb1 += r.dy_b1; }

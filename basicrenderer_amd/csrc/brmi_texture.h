@@ -91,52 +91,56 @@ BRMI_DEV bool same_binding(const TexBinding& a, const TexBinding& b) {
 // texel memory is HBM: say so, a pointer read out of a descriptor is otherwise loaded through the flat path
 typedef const __attribute__((address_space(1))) uint32_t* GlobalTexels;
 BRMI_DEV GlobalTexels as_global(const uint32_t* p) { return (GlobalTexels)p; }
-BRMI_DEV f4 fetch_texel(const TexelTables& tb, const uint32_t* levelBase, int w, bool srgb, int x, int y) {
-    const uint32_t c = as_global(levelBase)[(size_t)y * (size_t)w + (size_t)x];
-    f4 r;
-    const uint32_t o = srgb ? 256u : 0u;      // an offset, not a second pointer: the reads stay LDS reads
-    r.x = tb.t[o + (c & 0xFFu)]; r.y = tb.t[o + ((c >> 8) & 0xFFu)]; r.z = tb.t[o + ((c >> 16) & 0xFFu)];
-    r.w = tb.t[c >> 24];
-    return r;
-}
-
-BRMI_DEV f4 sample_level_filtered(const TexelTables& tb, const TexBinding& tx, uint32_t level, f2 uv, uint32_t filter) {
+// The 2x2 (or single-texel) footprint of one level: addresses and weights first, the four texel words requested together.
+struct Footprint { uint32_t c00, c10, c01, c11; float tx, ty; };
+BRMI_DEV Footprint fetch_footprint(const TexBinding& tx, uint32_t levelOffset, uint32_t level, f2 uv, uint32_t filter) {
     const int w = (int)(tx.width >> level ? tx.width >> level : 1u), h = (int)(tx.height >> level ? tx.height >> level : 1u);
-    const uint32_t* base = tx.texels + as_global(tx.mipOffset)[level];
-    if (filter == BRMI_FILTER_POINT)
-        return fetch_texel(tb, base, w, tx.srgb, address_texel(floor_to_int(uv.x * (float)w), w, tx.sm.addressU), address_texel(floor_to_int(uv.y * (float)h), h, tx.sm.addressV));
+    GlobalTexels base = as_global(tx.texels + levelOffset);
+    Footprint f;
+    if (filter == BRMI_FILTER_POINT) {
+        const int x = address_texel(floor_to_int(uv.x * (float)w), w, tx.sm.addressU), y = address_texel(floor_to_int(uv.y * (float)h), h, tx.sm.addressV);
+        f.c00 = f.c10 = f.c01 = f.c11 = base[(size_t)y * (size_t)w + (size_t)x]; f.tx = 0.0f; f.ty = 0.0f;      // a + 0 * (a - a) = a
+        return f;
+    }
     const float fx = uv.x * (float)w - 0.5f, fy = uv.y * (float)h - 0.5f;
-    const float tx_ = fx - floorf(fx), ty_ = fy - floorf(fy);
+    f.tx = fx - floorf(fx); f.ty = fy - floorf(fy);
     const int x0 = floor_to_int(fx), y0 = floor_to_int(fy);
     const int xa = address_texel(x0, w, tx.sm.addressU), xb = address_texel(x0 == 0x7FFFFFFF ? x0 : x0 + 1, w, tx.sm.addressU);
     const int ya = address_texel(y0, h, tx.sm.addressV), yb = address_texel(y0 == 0x7FFFFFFF ? y0 : y0 + 1, h, tx.sm.addressV);
-    const f4 t00 = fetch_texel(tb, base, w, tx.srgb, xa, ya), t10 = fetch_texel(tb, base, w, tx.srgb, xb, ya), t01 = fetch_texel(tb, base, w, tx.srgb, xa, yb), t11 = fetch_texel(tb, base, w, tx.srgb, xb, yb);
-    return lerp4(lerp4(t00, t10, tx_), lerp4(t01, t11, tx_), ty_);
+    f.c00 = base[(size_t)ya * (size_t)w + (size_t)xa]; f.c10 = base[(size_t)ya * (size_t)w + (size_t)xb];
+    f.c01 = base[(size_t)yb * (size_t)w + (size_t)xa]; f.c11 = base[(size_t)yb * (size_t)w + (size_t)xb];
+    return f;
+}
+BRMI_DEV f4 decode_texel(const TexelTables& tb, uint32_t c, bool srgb) {
+    const uint32_t o = srgb ? 256u : 0u;      // an offset, not a second pointer: the reads stay LDS reads
+    return {tb.t[o + (c & 0xFFu)], tb.t[o + ((c >> 8) & 0xFFu)], tb.t[o + ((c >> 16) & 0xFFu)], tb.t[c >> 24]};
+}
+BRMI_DEV f4 filter_footprint(const TexelTables& tb, const Footprint& f, bool srgb) {
+    return lerp4(lerp4(decode_texel(tb, f.c00, srgb), decode_texel(tb, f.c10, srgb), f.tx), lerp4(decode_texel(tb, f.c01, srgb), decode_texel(tb, f.c11, srgb), f.tx), f.ty);
 }
 
-// Texture2D::SampleLevel.  An unbound slot reads as opaque white.
+// Texture2D::SampleLevel.  An unbound slot reads as opaque white.  Both mip offsets are requested together, then both footprints:
+// two memory round trips per sample instead of four.  (When no lane of the wave blends levels the second footprint is skipped.)
 BRMI_DEV f4 sample_level(const TexelTables& tb, const TexBinding& tx, f2 uv, float lodIn) {
     if (!tx.bound) return {1.0f, 1.0f, 1.0f, 1.0f};
     float lod = min2(max2(lodIn + tx.sm.mipLodBias, tx.sm.minLod), tx.sm.maxLod);
     lod = min2(max2(lod, 0.0f), (float)(tx.mipCount - 1u));
     const uint32_t filter = lod <= 0.0f ? tx.sm.magFilter : tx.sm.minFilter;
+    uint32_t l0, l1; float frac;
     if (tx.sm.mipFilter == BRMI_FILTER_POINT) {
-        uint32_t level = (uint32_t)floor_to_int(lod + 0.5f);
-        if (level > tx.mipCount - 1u) level = tx.mipCount - 1u;
-        return sample_level_filtered(tb, tx, level, uv, filter);
+        l0 = (uint32_t)floor_to_int(lod + 0.5f);
+        if (l0 > tx.mipCount - 1u) l0 = tx.mipCount - 1u;
+        l1 = l0; frac = 0.0f;
+    } else {
+        l0 = (uint32_t)floor_to_int(lod); frac = lod - floorf(lod);
+        l1 = l0 + 1u > tx.mipCount - 1u ? tx.mipCount - 1u : l0 + 1u;
     }
-    const uint32_t l0 = (uint32_t)floor_to_int(lod);
-    const float frac = lod - floorf(lod);
-    const uint32_t l1 = l0 + 1u > tx.mipCount - 1u ? tx.mipCount - 1u : l0 + 1u;
-    // one copy of the filter code for both levels (the kernels inline this several times)
-    f4 acc{};
-#pragma nounroll
-    for (uint32_t k = 0; k < 2u; k++) {
-        if (k == 1u && frac == 0.0f) break;                   // a + 0 * (b - a)
-        const f4 v = sample_level_filtered(tb, tx, k ? l1 : l0, uv, filter);
-        acc = k ? lerp4(acc, v, frac) : v;
-    }
-    return acc;
+    const uint32_t off0 = as_global(tx.mipOffset)[l0], off1 = as_global(tx.mipOffset)[l1];
+    const Footprint f0 = fetch_footprint(tx, off0, l0, uv, filter);
+    if (!__any(frac != 0.0f)) return filter_footprint(tb, f0, tx.srgb);       // a + 0 * (b - a) for every lane
+    const Footprint f1 = fetch_footprint(tx, off1, l1, uv, filter);
+    const f4 a = filter_footprint(tb, f0, tx.srgb);
+    return frac == 0.0f ? a : lerp4(a, filter_footprint(tb, f1, tx.srgb), frac);
 }
 
 BRMI_DEV float log2_poly(float x) {

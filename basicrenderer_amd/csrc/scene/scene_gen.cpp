@@ -24,6 +24,8 @@
 #include <cstring>
 #include <dlfcn.h>
 #include <string>
+#include <fstream>
+#include <string>
 #include <vector>
 
 namespace {
@@ -227,6 +229,11 @@ struct brmi_scene {
     brmi_scene_stats stats{};
     std::vector<uint64_t> meshLod0Triangles;        // per mesh: triangles of its finest level
     bool failed = false;                            // a mesh could not be built (reference LOD builder missing)
+    // CLodCache (de)serialisation: what the cache stores per mesh beyond the GPU arrays, and where meshes come from
+    struct MeshCacheInfo { uint32_t groupCount = 0, segmentCount = 0, nodeCount = 0, pageCount = 0, maxTraversalDepth = 0;
+                           std::vector<float> segmentBounds; std::vector<uint32_t> lodNodeRanges; };   // xyzr per segment; (offset, count) per depth
+    std::vector<MeshCacheInfo> meshCache;
+    std::string cacheDir;                           // non-empty: buildMesh loads mesh i from <cacheDir>/mesh_<i>.clodbin + .clodmeta
     // page tile allocator
     uint32_t curSlab = 0; uint32_t curSlabPages = 0;
     static constexpr uint32_t kPagesPerSlab = 1024;   // 10-bit page index in the packed cluster
@@ -602,7 +609,10 @@ uint32_t buildClusterLodDag(const MeshDef& def, bool hasUv, std::vector<MeshletB
 }
 
 // Build one mesh: LOD DAG (built-in quadtree or the reference's builder), then segments, pages, groups and the 8-wide BVH.
+bool loadCachedMesh(brmi_scene& sc, const MeshDef& def, uint32_t meshIndex);
+
 bool buildMesh(brmi_scene& sc, const MeshDef& def, uint32_t meshIndex) {
+    if (!sc.cacheDir.empty()) { if (!loadCachedMesh(sc, def, meshIndex)) { sc.failed = true; return false; } return true; }
     std::vector<MeshletBuild> meshlets;
     std::vector<GroupBuild> groups;
     const bool hasUv = (sc.params.materialFeatures & 24u) != 0u;
@@ -672,6 +682,9 @@ bool buildMesh(brmi_scene& sc, const MeshDef& def, uint32_t meshIndex) {
         sc.groups.push_back(o);
     }
     for (auto& s : segs) sc.segments.push_back({s.refinedGroup, s.firstMeshletInPage, (uint32_t)s.meshlets.size(), s.pageIndex});
+    brmi_scene::MeshCacheInfo ci;
+    ci.groupCount = (uint32_t)groups.size(); ci.segmentCount = (uint32_t)segs.size(); ci.pageCount = (uint32_t)sc.pageMap.size() - pageMapBase;
+    for (auto& sg : segs) { ci.segmentBounds.push_back((float)sg.cull.c.x); ci.segmentBounds.push_back((float)sg.cull.c.y); ci.segmentBounds.push_back((float)sg.cull.c.z); ci.segmentBounds.push_back((float)sg.cull.r); }
 
     // BVH: node 0 super-root, nodes 1..levels depth roots, then per-depth subtrees
     struct BNode { brmi_lod_node n; std::vector<uint32_t> kids; Sphere cull, lod; double err; };
@@ -683,6 +696,7 @@ bool buildMesh(brmi_scene& sc, const MeshDef& def, uint32_t meshIndex) {
         b.n.maxQuadricError = b.err >= (double)FLT_MAX ? FLT_MAX : (float)b.err;
     };
     for (uint32_t L = 0; L < levels; L++) {
+        ci.lodNodeRanges.push_back((uint32_t)bn.size());      // nodes of depth L (besides its root at slot 1 + L) start here
         // leaves of this depth
         std::vector<BNode> level;
         for (size_t si = 0; si < segs.size(); si++) {
@@ -718,6 +732,7 @@ bool buildMesh(brmi_scene& sc, const MeshDef& def, uint32_t meshIndex) {
             tiers.push_back(std::move(up));
         }
         maxTreeDepth = std::max(maxTreeDepth, (uint32_t)tiers.size() + 1);
+        struct Finish { std::vector<uint32_t>& r; std::vector<BNode>& b; ~Finish() { r.push_back((uint32_t)b.size() - r.back()); } } finish{ci.lodNodeRanges, bn};
         // lay out top-down; tier T-1 is the depth root -> global slot 1+L
         std::vector<std::vector<uint32_t>> slot(tiers.size());
         for (size_t t = 0; t < tiers.size(); t++) slot[t].assign(tiers[t].size(), 0);
@@ -742,6 +757,8 @@ bool buildMesh(brmi_scene& sc, const MeshDef& def, uint32_t meshIndex) {
     }
     const uint32_t nodesBase = (uint32_t)sc.nodes.size();
     for (auto& b : bn) sc.nodes.push_back(b.n);
+    ci.nodeCount = (uint32_t)bn.size(); ci.maxTraversalDepth = maxTreeDepth;
+    sc.meshCache.push_back(std::move(ci));
 
     brmi_clod_mesh_metadata md{};
     md.groupsBase = groupsBase; md.segmentsBase = segmentsBase; md.lodNodesBase = nodesBase; md.rootNode = 0;
@@ -765,6 +782,209 @@ bool buildMesh(brmi_scene& sc, const MeshDef& def, uint32_t meshIndex) {
     sc.stats.maxBvhDepth = std::max(sc.stats.maxBvhDepth, maxTreeDepth);
     sc.stats.lodLevelsMax = std::max(sc.stats.lodLevelsMax, levels);
     (void)meshIndex;
+    return true;
+}
+
+// ---- CLodCache: the reference's on-disk form of one mesh's cluster-LOD data ----------------------------------------------------
+// container  "<name>.clodbin": ContainerHeader {magic 'CLOD', version 4, reserved, pageCount}, a directory of pageCount
+//            ClusterLODGroupDiskLocator {u64 blobOffset, u32 blobSizeBytes, u32 reserved}, then the page blobs
+//            (SaveContainerPayload / OpenContainerFile, BR/src/Import/CLodCache.cpp:252-259,309-374,1000-1020);
+// metadata   the byte blob of SerializeMetadata (CLodCache.cpp:171-211), schema 47: POD vectors are u64 count + elements, strings
+//            u64 length + bytes.  The reference stores this blob as the `clodBlob` uchar-array attribute of a USD crate file
+//            (CLodCache.cpp:528-560), which needs OpenUSD to open; here the blob is a plain file ("<name>.clodmeta").
+constexpr uint32_t kClodContainerMagic = 0x444F4C43u, kClodContainerVersion = 4u, kClodSchemaVersion = 47u;
+struct ClodDiskLocator { uint64_t blobOffset; uint32_t blobSizeBytes, reserved; };
+struct ClodNodeRange { uint32_t offset, count; };
+
+struct MeshCacheData {
+    std::vector<brmi_lod_group> groups; std::vector<brmi_lod_segment> segments; std::vector<float> segmentBounds; float objectSphere[4] = {0, 0, 0, 0};
+    std::vector<uint32_t> groupPageReferences, groupPageReferenceOffsets;
+    uint32_t trianglePageCount = 0;
+    std::vector<brmi_lod_node> nodes; std::vector<ClodNodeRange> lodNodeRanges; std::vector<uint32_t> lodLevelRoots;
+    uint32_t maxDepth = 0, maxTraversalDepth = 0;
+    std::vector<std::vector<uint8_t>> pages;
+    uint64_t buildConfigHash = 0; std::string sourceIdentifier, primPath, subsetName, containerFileName;
+};
+
+template <typename T> void putPod(std::vector<uint8_t>& o, const T& v) { const uint8_t* p = reinterpret_cast<const uint8_t*>(&v); o.insert(o.end(), p, p + sizeof(T)); }
+template <typename T> void putVec(std::vector<uint8_t>& o, const std::vector<T>& v) { putPod(o, (uint64_t)v.size()); if (!v.empty()) { const uint8_t* p = reinterpret_cast<const uint8_t*>(v.data()); o.insert(o.end(), p, p + sizeof(T) * v.size()); } }
+void putStr(std::vector<uint8_t>& o, const std::string& v) { putPod(o, (uint64_t)v.size()); o.insert(o.end(), v.begin(), v.end()); }
+template <typename T> bool getPod(const std::vector<uint8_t>& in, size_t& off, T& v) { if (off + sizeof(T) > in.size()) return false; std::memcpy(&v, in.data() + off, sizeof(T)); off += sizeof(T); return true; }
+template <typename T> bool getVec(const std::vector<uint8_t>& in, size_t& off, std::vector<T>& v) {
+    uint64_t n = 0; if (!getPod(in, off, n)) return false;
+    if (n > (in.size() - off) / sizeof(T)) return false;
+    v.resize((size_t)n); if (n) std::memcpy(v.data(), in.data() + off, sizeof(T) * (size_t)n); off += sizeof(T) * (size_t)n; return true;
+}
+bool getStr(const std::vector<uint8_t>& in, size_t& off, std::string& v) { uint64_t n = 0; if (!getPod(in, off, n) || n > in.size() - off) return false; v.assign(reinterpret_cast<const char*>(in.data() + off), (size_t)n); off += (size_t)n; return true; }
+
+std::vector<uint8_t> serializeClodMetadata(const MeshCacheData& d, const std::vector<ClodDiskLocator>& pageLocators) {
+    std::vector<uint8_t> o;
+    putPod(o, kClodSchemaVersion); putPod(o, d.buildConfigHash);
+    putVec(o, d.groups); putVec(o, d.segments);
+    putPod(o, (uint64_t)(d.segmentBounds.size() / 4)); { const uint8_t* p = reinterpret_cast<const uint8_t*>(d.segmentBounds.data()); o.insert(o.end(), p, p + d.segmentBounds.size() * 4); }
+    o.insert(o.end(), reinterpret_cast<const uint8_t*>(d.objectSphere), reinterpret_cast<const uint8_t*>(d.objectSphere) + 16);
+    putPod(o, (uint8_t)0);                                            // no inline group chunks
+    putVec(o, std::vector<ClodDiskLocator>{});                        // groupDiskLocators (per-group files: the pre-container layout)
+    putVec(o, pageLocators);
+    putVec(o, d.groupPageReferences); putVec(o, d.groupPageReferenceOffsets);
+    putPod(o, d.trianglePageCount); putPod(o, d.trianglePageCount /* voxelPageBase */); putPod(o, (uint32_t)0 /* voxelPageCount */);
+    putStr(o, d.sourceIdentifier); putStr(o, d.primPath); putStr(o, d.subsetName); putPod(o, d.buildConfigHash); putStr(o, d.containerFileName);
+    putVec(o, d.nodes); putVec(o, d.lodNodeRanges); putVec(o, d.lodLevelRoots);
+    putPod(o, d.maxDepth); putPod(o, d.maxTraversalDepth);
+    return o;
+}
+bool deserializeClodMetadata(const std::vector<uint8_t>& in, MeshCacheData& d, std::vector<ClodDiskLocator>& pageLocators) {
+    size_t off = 0; uint32_t schema = 0, voxelBase = 0, voxelCount = 0; uint8_t inlineChunks = 0; uint64_t hash2 = 0;
+    std::vector<ClodDiskLocator> groupLocators;
+    struct Chunk { uint32_t w[5]; }; std::vector<Chunk> chunks;
+    struct S4 { float v[4]; }; std::vector<S4> sb;
+    if (!getPod(in, off, schema) || schema != kClodSchemaVersion) return false;
+    if (!getPod(in, off, d.buildConfigHash) || !getVec(in, off, d.groups) || !getVec(in, off, d.segments) || !getVec(in, off, sb)) return false;
+    d.segmentBounds.resize(sb.size() * 4); if (!sb.empty()) std::memcpy(d.segmentBounds.data(), sb.data(), sb.size() * 16);
+    if (off + 16 > in.size()) return false;
+    std::memcpy(d.objectSphere, in.data() + off, 16); off += 16;
+    if (!getPod(in, off, inlineChunks)) return false;
+    if (inlineChunks && !getVec(in, off, chunks)) return false;
+    if (!getVec(in, off, groupLocators) || !getVec(in, off, pageLocators) || !getVec(in, off, d.groupPageReferences) || !getVec(in, off, d.groupPageReferenceOffsets)) return false;
+    if (!getPod(in, off, d.trianglePageCount) || !getPod(in, off, voxelBase) || !getPod(in, off, voxelCount)) return false;
+    if (!getStr(in, off, d.sourceIdentifier) || !getStr(in, off, d.primPath) || !getStr(in, off, d.subsetName) || !getPod(in, off, hash2) || !getStr(in, off, d.containerFileName)) return false;
+    if (!getVec(in, off, d.nodes) || !getVec(in, off, d.lodNodeRanges) || !getVec(in, off, d.lodLevelRoots) || !getPod(in, off, d.maxDepth) || !getPod(in, off, d.maxTraversalDepth)) return false;
+    return off == in.size() && voxelCount == 0;                      // voxel-LOD pages are not part of this path
+}
+
+bool writeWholeFile(const std::string& path, const std::vector<uint8_t>& bytes) { std::ofstream f(path, std::ios::binary | std::ios::trunc); if (!f) return false; f.write(reinterpret_cast<const char*>(bytes.data()), (std::streamsize)bytes.size()); return f.good(); }
+bool readWholeFile(const std::string& path, std::vector<uint8_t>& bytes) {
+    std::ifstream f(path, std::ios::binary | std::ios::ate); if (!f) return false;
+    const std::streamoff n = f.tellg(); if (n < 0) return false;
+    bytes.resize((size_t)n); f.seekg(0); if (n) f.read(reinterpret_cast<char*>(bytes.data()), n); return f.good() || n == 0;
+}
+
+// mesh `m` of a generated scene in the cache's terms (everything mesh-local, as the builder emits it)
+MeshCacheData collectMeshCache(const brmi_scene& sc, uint32_t m) {
+    MeshCacheData d;
+    const brmi_clod_mesh_metadata& md = sc.meshMetadata[m];
+    const brmi_scene::MeshCacheInfo& ci = sc.meshCache[m];
+    d.groups.assign(sc.groups.begin() + md.groupsBase, sc.groups.begin() + md.groupsBase + ci.groupCount);
+    d.segments.assign(sc.segments.begin() + md.segmentsBase, sc.segments.begin() + md.segmentsBase + ci.segmentCount);
+    d.segmentBounds = ci.segmentBounds;
+    std::memcpy(d.objectSphere, sc.perMesh[m].boundingSphere, 16);
+    d.nodes.assign(sc.nodes.begin() + md.lodNodesBase, sc.nodes.begin() + md.lodNodesBase + ci.nodeCount);
+    for (size_t k = 0; k + 1 < ci.lodNodeRanges.size(); k += 2) d.lodNodeRanges.push_back({ci.lodNodeRanges[k], ci.lodNodeRanges[k + 1]});
+    for (uint32_t L = 0; L < md.lodLevelCount; L++) d.lodLevelRoots.push_back(1 + L);       // ClusterLODUtilities.cpp:4677-4679
+    d.maxDepth = md.lodLevelCount ? md.lodLevelCount - 1 : 0; d.maxTraversalDepth = ci.maxTraversalDepth;
+    d.trianglePageCount = ci.pageCount;
+    for (uint32_t pg = 0; pg < ci.pageCount; pg++) {
+        const brmi_group_page_map_entry& e = sc.pageMap[md.pageMapBase + pg];
+        const uint8_t* base = sc.slabs[e.slabDescriptorIndex].data() + e.slabByteOffset;
+        // the blob proper: up to the end of the triangle stream, the last section (BuildPackedTriangleMeshPageBlob's order)
+        const brmi_page_header* h = reinterpret_cast<const brmi_page_header*>(base);
+        size_t triBytes = 0;
+        for (uint32_t q = 0; q < h->meshletCount; q++) { brmi_meshlet_descriptor ds; std::memcpy(&ds, base + h->descriptorOffset + (size_t)q * 64u, 64); triBytes += (size_t)(ds.triangleCountAndRefinedGroup & 0xFFFFu) * 3u; }
+        d.pages.emplace_back(base, base + std::min<size_t>(BRMI_PAGE_SIZE, align4(h->triangleStreamOffset + triBytes)));
+    }
+    d.groupPageReferenceOffsets.push_back(0);
+    for (const brmi_lod_group& g : d.groups) {                         // pages a group's segments live in
+        std::vector<uint32_t> pages;
+        for (uint32_t k = 0; k < g.segmentCount; k++) { const uint32_t pi = d.segments[g.firstSegment + k].pageIndex; if (std::find(pages.begin(), pages.end(), pi) == pages.end()) pages.push_back(pi); }
+        d.groupPageReferences.insert(d.groupPageReferences.end(), pages.begin(), pages.end());
+        d.groupPageReferenceOffsets.push_back((uint32_t)d.groupPageReferences.size());
+    }
+    d.sourceIdentifier = "brmi_scene"; d.primPath = "/mesh_" + std::to_string(m); d.subsetName = ""; d.containerFileName = "mesh_" + std::to_string(m) + ".clodbin";
+    d.buildConfigHash = 0x62726D69ull;
+    return d;
+}
+
+bool saveMeshCache(const MeshCacheData& d, const std::string& dir, uint32_t m) {
+    std::vector<ClodDiskLocator> loc(d.pages.size());
+    std::vector<uint8_t> file;
+    const uint32_t header[4] = {kClodContainerMagic, kClodContainerVersion, 0u, (uint32_t)d.pages.size()};
+    putPod(file, header);
+    const size_t dirOff = file.size();
+    file.resize(file.size() + loc.size() * sizeof(ClodDiskLocator), 0);
+    for (size_t i = 0; i < d.pages.size(); i++) { loc[i] = {(uint64_t)file.size(), (uint32_t)d.pages[i].size(), 0u}; file.insert(file.end(), d.pages[i].begin(), d.pages[i].end()); }
+    if (!loc.empty()) std::memcpy(file.data() + dirOff, loc.data(), loc.size() * sizeof(ClodDiskLocator));
+    const std::string stem = dir + "/mesh_" + std::to_string(m);
+    return writeWholeFile(stem + ".clodbin", file) && writeWholeFile(stem + ".clodmeta", serializeClodMetadata(d, loc));
+}
+
+bool loadMeshCache(const std::string& dir, uint32_t m, MeshCacheData& d) {
+    const std::string stem = dir + "/mesh_" + std::to_string(m);
+    std::vector<uint8_t> meta, file; std::vector<ClodDiskLocator> metaLoc;
+    if (!readWholeFile(stem + ".clodmeta", meta) || !deserializeClodMetadata(meta, d, metaLoc)) return false;
+    if (!readWholeFile(stem + ".clodbin", file) || file.size() < 16) return false;
+    uint32_t header[4]; std::memcpy(header, file.data(), 16);
+    if (header[0] != kClodContainerMagic || header[1] != kClodContainerVersion) return false;           // OpenContainerFile, CLodCache.cpp:1014
+    const uint32_t pageCount = header[3];
+    if (file.size() < 16 + (size_t)pageCount * sizeof(ClodDiskLocator) || metaLoc.size() != pageCount) return false;
+    std::vector<ClodDiskLocator> loc(pageCount);
+    if (pageCount) std::memcpy(loc.data(), file.data() + 16, (size_t)pageCount * sizeof(ClodDiskLocator));
+    for (uint32_t i = 0; i < pageCount; i++) {
+        if (loc[i].blobOffset != metaLoc[i].blobOffset || loc[i].blobSizeBytes != metaLoc[i].blobSizeBytes) return false;     // directory and metadata agree
+        if (loc[i].blobOffset > file.size() || loc[i].blobSizeBytes > file.size() - loc[i].blobOffset || loc[i].blobSizeBytes > BRMI_PAGE_SIZE) return false;
+        d.pages.emplace_back(file.begin() + (size_t)loc[i].blobOffset, file.begin() + (size_t)loc[i].blobOffset + loc[i].blobSizeBytes);
+    }
+    // the structure the kernels index without checks: validate every cross reference once, here
+    if (d.trianglePageCount != pageCount || d.nodes.empty() || d.groupPageReferenceOffsets.size() != d.groups.size() + 1) return false;
+    for (const brmi_lod_segment& sg : d.segments) if (sg.pageIndex >= pageCount || sg.refinedGroup >= (int32_t)d.groups.size()) return false;
+    for (const brmi_lod_group& g : d.groups) if ((uint64_t)g.firstSegment + g.segmentCount > d.segments.size()) return false;
+    for (const brmi_lod_node& n : d.nodes) {
+        if (n.isLeaf == BRMI_NODE_INTERNAL) { if ((uint64_t)n.indexOrOffset + n.countMinusOne + 1 > d.nodes.size() || n.countMinusOne + 1 > BRMI_BVH_MAX_CHILDREN) return false; }
+        else if (n.indexOrOffset >= d.segments.size() || n.ownerGroupId >= d.groups.size()) return false;
+    }
+    for (size_t si = 0; si < d.segments.size(); si++) {
+        const std::vector<uint8_t>& pg = d.pages[d.segments[si].pageIndex];
+        if (pg.size() < sizeof(brmi_page_header)) return false;
+        const brmi_page_header* h = reinterpret_cast<const brmi_page_header*>(pg.data());
+        if ((uint64_t)d.segments[si].firstMeshletInPage + d.segments[si].meshletCount > h->meshletCount || (uint64_t)h->descriptorOffset + (uint64_t)h->meshletCount * 64u > pg.size()) return false;
+    }
+    return true;
+}
+
+// buildMesh's emission from cached data: the same appends, with the material / skinning flags of the mesh definition
+bool loadCachedMesh(brmi_scene& sc, const MeshDef& def, uint32_t meshIndex) {
+    MeshCacheData d;
+    if (!loadMeshCache(sc.cacheDir, meshIndex, d)) return false;
+    const uint32_t pageMapBase = (uint32_t)sc.pageMap.size(), groupsBase = (uint32_t)sc.groups.size(), segmentsBase = (uint32_t)sc.segments.size(), nodesBase = (uint32_t)sc.nodes.size();
+    for (auto& pg : d.pages) sc.pageMap.push_back(allocPage(sc, pg));
+    sc.groups.insert(sc.groups.end(), d.groups.begin(), d.groups.end());
+    sc.segments.insert(sc.segments.end(), d.segments.begin(), d.segments.end());
+    sc.nodes.insert(sc.nodes.end(), d.nodes.begin(), d.nodes.end());
+    const uint32_t levels = (uint32_t)d.lodLevelRoots.size();
+    brmi_scene::MeshCacheInfo ci;
+    ci.groupCount = (uint32_t)d.groups.size(); ci.segmentCount = (uint32_t)d.segments.size(); ci.nodeCount = (uint32_t)d.nodes.size(); ci.pageCount = (uint32_t)d.pages.size();
+    ci.maxTraversalDepth = d.maxTraversalDepth; ci.segmentBounds = d.segmentBounds;
+    for (const ClodNodeRange& r : d.lodNodeRanges) { ci.lodNodeRanges.push_back(r.offset); ci.lodNodeRanges.push_back(r.count); }
+    sc.meshCache.push_back(std::move(ci));
+    brmi_clod_mesh_metadata md{};
+    md.groupsBase = groupsBase; md.segmentsBase = segmentsBase; md.lodNodesBase = nodesBase; md.rootNode = 0;
+    md.pageMapBase = pageMapBase; md.lodLevelCount = levels; md.maxDepth = d.maxTraversalDepth;
+    sc.meshMetadata.push_back(md);
+    // meshlet statistics of the finest level from the pages themselves
+    uint32_t total = 0, lod0 = 0, lod0Verts = 0; uint64_t lod0Tris = 0;
+    for (const brmi_lod_group& g : d.groups) {
+        total += g.meshletCount;
+        if (g.depth != 0) continue;
+        for (uint32_t k = 0; k < g.segmentCount; k++) {
+            const brmi_lod_segment& sg = d.segments[g.firstSegment + k];
+            const std::vector<uint8_t>& pg = d.pages[sg.pageIndex];
+            const brmi_page_header* h = reinterpret_cast<const brmi_page_header*>(pg.data());
+            for (uint32_t q = 0; q < sg.meshletCount; q++) {
+                brmi_meshlet_descriptor ds; std::memcpy(&ds, pg.data() + h->descriptorOffset + (size_t)(sg.firstMeshletInPage + q) * 64u, 64);
+                lod0++; lod0Verts += (ds.bitsAndVertexCount >> 24) & 0xFFu; lod0Tris += ds.triangleCountAndRefinedGroup & 0xFFFFu;
+            }
+        }
+    }
+    brmi_per_mesh pm{};
+    pm.materialDataIndex = def.material; pm.rasterBucketIndex = 0;
+    pm.vertexFlags = (1u << 1) | (def.skinned ? BRMI_VERTEX_SKINNED : 0u);
+    pm.vertexByteSize = 24;
+    std::memcpy(pm.boundingSphere, d.objectSphere, 16);
+    pm.clodNumMeshlets = total; pm.numMeshlets = lod0; pm.numVertices = lod0Verts;
+    sc.perMesh.push_back(pm);
+    sc.meshLod0Triangles.push_back(lod0Tris);
+    sc.stats.meshletsTotal += total; sc.stats.meshletsLod0 += lod0; sc.stats.uniqueTriangles += lod0Tris;
+    sc.stats.maxBvhDepth = std::max(sc.stats.maxBvhDepth, d.maxTraversalDepth);
+    sc.stats.lodLevelsMax = std::max(sc.stats.lodLevelsMax, levels);
     return true;
 }
 
@@ -1311,10 +1531,11 @@ void presetZorah(brmi_scene& sc, Pcg32& rng) {
 
 extern "C" {
 
-brmi_scene* brmi_scene_create(const brmi_scene_params* params) {
+static brmi_scene* createScene(const brmi_scene_params* params, const char* cacheDir) {
     if (!params || params->width == 0 || params->height == 0) return nullptr;
     brmi_scene* sc = new brmi_scene();
     sc->params = *params;
+    if (cacheDir) sc->cacheDir = cacheDir;
     if (sc->params.sizeScale <= 0.0f) sc->params.sizeScale = 1.0f;
     if (sc->params.lodBuilder == BRMI_LOD_BUILDER_CLUSTERLOD && !clodRef()) { delete sc; return nullptr; }
     for (int k = 0; k < 3; k++) { sc->stats.sceneMin[k] = 1e30f; sc->stats.sceneMax[k] = -1e30f; }
@@ -1332,8 +1553,20 @@ brmi_scene* brmi_scene_create(const brmi_scene_params* params) {
     finishFrame(*sc);
     return sc;
 }
+brmi_scene* brmi_scene_create(const brmi_scene_params* params) { return createScene(params, nullptr); }
 
 void brmi_scene_destroy(brmi_scene* scene) { delete scene; }
+
+int brmi_scene_export_cache(const brmi_scene* s, const char* directory) {
+    if (!s || !directory || s->meshCache.size() != s->meshMetadata.size()) return -1;
+    for (uint32_t m = 0; m < (uint32_t)s->meshMetadata.size(); m++) if (!saveMeshCache(collectMeshCache(*s, m), directory, m)) return -2;
+    return (int)s->meshMetadata.size();
+}
+
+brmi_scene* brmi_scene_create_from_cache(const brmi_scene_params* params, const char* directory) {
+    if (!directory || !*directory) return nullptr;
+    return createScene(params, directory);
+}
 
 int brmi_scene_array(const brmi_scene* s, uint32_t id, const void** ptr, uint64_t* bytes, uint32_t* count) {
     if (!s || !ptr || !bytes || !count) return -1;

@@ -88,6 +88,18 @@ enum brmi_scene_array {
 typedef struct brmi_scene brmi_scene;
 
 brmi_scene* brmi_scene_create(const brmi_scene_params* params);
+
+/* CLodCache: the reference's on-disk form of a mesh's cluster-LOD data (BR/src/Import/CLodCache.cpp).
+ *   <dir>/mesh_<i>.clodbin   container v4: {magic 'CLOD', version 4, reserved, pageCount}, pageCount locators {u64 offset, u32 size,
+ *                            u32 reserved}, the page blobs (SaveContainerPayload :309-374; checked like OpenContainerFile :1000-1020)
+ *   <dir>/mesh_<i>.clodmeta  the metadata blob of SerializeMetadata (:171-211, schema 47): groups, segments, segment bounds, object
+ *                            sphere, page locators, group -> page references, BVH nodes, per-depth node ranges and roots.
+ *                            (The reference keeps this blob in the `clodBlob` attribute of a USD crate file; extracting it needs OpenUSD.)
+ * brmi_scene_export_cache writes every mesh of a scene (returns the mesh count, < 0 on error).  brmi_scene_create_from_cache
+ * builds the preset's scene but takes each mesh from the cache instead of building it: every cross reference of the loaded data is
+ * validated (the kernels index it unchecked); NULL on a missing, truncated or inconsistent file. */
+int         brmi_scene_export_cache(const brmi_scene* scene, const char* directory);
+brmi_scene* brmi_scene_create_from_cache(const brmi_scene_params* params, const char* directory);
 void        brmi_scene_destroy(brmi_scene* scene);
 
 /* Returns 0 on success.  `count` = element count. */

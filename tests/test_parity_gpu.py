@@ -196,16 +196,18 @@ def test_idempotent_and_deterministic(scenes):
     r.close()
 
 
-def test_band_split_composes_to_full_frame(scenes, gpu_frames):
-    """Multi-GPU partition property on one GPU: rendering row bands separately reproduces the full frame.
+@pytest.mark.parametrize("case", ["sponza_small", "sponza_alpha"])
+def test_band_split_composes_to_full_frame(case, scenes, gpu_frames):
+    """Multi-GPU partition property on one GPU: rendering row bands separately reproduces the full frame (also with alpha-tested
+    and texture-sampled materials: an alpha record is cut per band like any other).
 
     A band pass also culls clusters against its band, so cluster *indices* differ from the full-frame
     list; canonical ids (instance, group, page, meshlet, tri), depth bits and the lit HDR bytes must not.
     """
     import orc
     from basicrenderer_amd.renderer import VisibilityRenderer
-    sc = scenes("sponza_small")
-    full = gpu_frames("sponza_small")
+    sc = scenes(case)
+    full = gpu_frames(case)
     fa, fb, fd = orc.canonical_ids(full.visibility(), full.visible_clusters())
     fh = full.hdr()
     H = sc.height
