@@ -124,8 +124,9 @@ static void compute_sizes(brmi_pass* p) {
     w.lutF = take((uint64_t)(32768 + 1024 + 1024 + 32 + 256) * 4);
     // textured / alpha-tested scenes only: where each visible cluster's UV set lives, the texcoords of the resolve arena's vertices,
     // and the alpha-test operands that travel with binned triangles
-    const bool uvs = p->sceneHasTextures || p->sceneHasAlphaTest;
-    w.clusterUv = take(uvs ? (uint64_t)c.maxVisibleClusters * 16 : 16);
+    const bool uvs = p->sceneHasTextures || p->sceneHasAlphaTest || p->sceneHasVertexColors;
+    w.clusterUv = take(uvs ? (uint64_t)c.maxVisibleClusters * 32 : 16);
+    w.resolveColors = take(p->sceneHasVertexColors ? (uint64_t)p->resolveCapacity * 4 : 16);
     w.resolveUVs = take(p->sceneHasTextures ? (uint64_t)p->resolveCapacity * 8 : 16);
     w.binAlpha = take(p->sceneHasAlphaTest ? (uint64_t)p->binsX * p->binsY * p->binCapacity * 48 : 16);
     w.overflowAlpha = take(p->sceneHasAlphaTest ? (uint64_t)CNT_STRIPE_COUNT * p->binOverflowPerStripe * 48 : 16);
@@ -244,6 +245,10 @@ int brmi_set_scene(brmi_pass* p, const brmi_scene_buffers* scene) {
                     return fail(p, BRMI_ERR_INVALID, "material %zu: texture slots must use UV set 0 (only set 0 is decoded on this path)", i);
             }
         }
+        std::vector<brmi_per_mesh> pms;
+        if ((rc = read_back(p, pms, sc.perMesh, sc.perMeshCount))) return rc;
+        p->sceneHasVertexColors = false;
+        for (const auto& pm : pms) if (pm.vertexFlags & 1u) p->sceneHasVertexColors = true;       // VERTEX_COLORS (BR/include/Mesh/VertexFlags.h)
         if (p->sceneHasTextures && (!sc.textures || !sc.samplers || !sc.srgbToLinear || sc.textureCount == 0 || sc.samplerCount == 0))
             return fail(p, BRMI_ERR_INVALID, "brmi_set_scene: materials sample textures but the texture / sampler tables or the sRGB decode table are missing");
     }

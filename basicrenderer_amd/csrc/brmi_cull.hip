@@ -777,7 +777,8 @@ __global__ void __launch_bounds__(256) k_scatter_visible(const TempVisible* temp
             if (clusterUv) {      // scenes with textured / alpha-tested materials: UV set 0 of the meshlet and the material's class
                 const uint32_t mflags = sc.materials[pm->materialDataIndex].materialFlags;
                 cs.counts |= ((mflags & BRMI_MATERIAL_ALPHA_TEST) ? BRMI_CS_ALPHA : 0u) | ((mflags & BRMI_MATERIAL_ANY_TEXTURE) ? BRMI_CS_TEXTURED : 0u);
-                ClusterUv cu{nullptr, nullptr};
+                ClusterUv cu{nullptr, nullptr, nullptr, 0ull};
+                if (hdr->attributeMask & BRMI_PAGE_ATTRIBUTE_COLOR) { cs.counts |= BRMI_CS_COLOR; cu.color = slab + pageOff + hdr->colorArrayOffset + desc->vertexAttributeOffset * 4u; }
                 if (hdr->uvSetCount != 0u) {
                     cu.desc = slab + pageOff + hdr->uvDescriptorOffset + (vc_meshlet(t.packed) * hdr->uvSetCount) * 32u;
                     cu.stream = slab + pageOff + *reinterpret_cast<const uint32_t*>(slab + pageOff + hdr->uvBitstreamDirectoryOffset);
@@ -883,7 +884,7 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
     }
     hipLaunchKernelGGL(k_scatter_visible, dim3(smallGrid), dim3(256), 0, s, temp, p->counters(), (uint32_t)(phase == 1 ? CNT_TEMP_VISIBLE : CNT_TEMP_VISIBLE2), bitmask, wordPrefix,
                        static_cast<uint4*>(p->res[BRMI_RES_VISIBLE_CLUSTERS]), phase == 1 ? 0xFFFFFFFFu : (uint32_t)CNT_VISIBLE, p->cfg.maxVisibleClusters, p->cfg.maxVisibleClusters, p->scene, p->wsPtr<ClusterSetup>(p->ws.clusterSetup), p->resolveCapacity, p->wsPtr<uint8_t>(p->ws.usedClusters),
-                       (p->sceneHasTextures || p->sceneHasAlphaTest) ? p->wsPtr<ClusterUv>(p->ws.clusterUv) : nullptr);
+                       (p->sceneHasTextures || p->sceneHasAlphaTest || p->sceneHasVertexColors) ? p->wsPtr<ClusterUv>(p->ws.clusterUv) : nullptr);
     BRMI_LAUNCH_CHECK(p, "compaction");
     return BRMI_OK;
 }

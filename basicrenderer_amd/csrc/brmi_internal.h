@@ -62,7 +62,7 @@ struct ClusterSetup {                 // 64 B
     int32_t jointDelta, weightDelta;  // byte offsets of the cluster's joint / weight arrays (32 B per vertex) relative to nrmBase
 };
 constexpr uint32_t BRMI_CS_SKINNED = 1u << 25, BRMI_CS_JOINTS = 1u << 26, BRMI_CS_WEIGHTS = 1u << 27;
-constexpr uint32_t BRMI_CS_ALPHA = 1u << 28, BRMI_CS_TEXTURED = 1u << 29;    // the cluster's material is alpha tested / samples textures
+constexpr uint32_t BRMI_CS_ALPHA = 1u << 28, BRMI_CS_TEXTURED = 1u << 29, BRMI_CS_COLOR = 1u << 30;    // the cluster's material is alpha tested / samples textures
 // per-frame tables and per-material constants of the shading pass (brmi_frame.hip fills them, brmi_light.hip reads them)
 struct ShadeTables { float* uvx; uint32_t* tileX; float* uvy; uint32_t* tileY; float* sliceStart; };
 struct MatConst { float baseWeight, specularWeight, specR, specG, specB, weightedSpecularIor, dielF0Scalar, coatF0Scalar, coatIor, coatDarkening, baseDiffuseRoughness, pad; };
@@ -87,7 +87,7 @@ struct HzbDesc {
 struct Workspace {     // byte offsets into BRMI_RES_WORKSPACE
     uint64_t counters, frontierA, frontierB, buckets, tempVisible, bitmask1, bitmask2, wordPrefix, blockSums,
              instanceBitBase, segPrefix, meshLevelWidth, planes, replayNodes, replayBuckets, lightVS, lightMeta, clusterPages, clusterHits, pageTotal, lightHitMasks, binCounts, binRecords, binOverflow, clusterSetup, resolveVerts, resolveTris, matWords, shadeTables, lutF, frameConst, objConst, matConst, deferredPixels, usedClusters,
-             clusterUv, binAlpha, overflowAlpha, resolveUVs, alphaMats, frameClearBytes, total;
+             clusterUv, binAlpha, overflowAlpha, resolveUVs, resolveColors, alphaMats, frameClearBytes, total;
 };
 
 }  // namespace brmi
@@ -108,6 +108,7 @@ struct brmi_pass {
     uint32_t minLevelWidth = 0;      // narrowest such width over the meshes
     std::vector<uint32_t> hostMeshLevelWidth;   // per mesh metadata entry
     uint32_t maxLevelWidth = 0;      // widest BVH level of any mesh (decides between the per-instance and the per-level traversal)
+    bool sceneHasVertexColors = false;                           // some mesh's pages carry vertex colours (perMesh.vertexFlags bit 0)
     bool sceneHasAlphaTest = false, sceneHasTextures = false;   // some material is alpha tested / samples a texture (brmi_set_scene)
     bool sceneHasCoat = true, sceneHasFuzz = true;   // some OpenPBR material has a coat / fuzz layer (brmi_set_scene)
     bool fuseFrameClear = false, frameStateCleared = false;   // brmi_execute: the visibility clear also clears the culling pass's frame state

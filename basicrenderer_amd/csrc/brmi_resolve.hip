@@ -32,6 +32,7 @@ struct GBufferArgs {
     MaterialWords* matWords;
     const uint8_t* used;           // per visible cluster: owns a pixel (valid when counters[CNT_RESOLVE_MARKED])
     const ClusterUv* clusterUv; float2* uvs;      // textured scenes: UV set 0 of every visible cluster, decoded texcoords of the arena's vertices
+    uint32_t* colors;                             // scenes with vertex colours: the RGBA8 colour of the arena's vertices
 };
 
 BRMI_DEV f3 oct_decode_normal(uint32_t packed) {
@@ -98,6 +99,7 @@ __global__ void __launch_bounds__(64) k_resolve_setup(GBufferArgs a) {
             cx[v] = clip.x; cy[v] = clip.y; cw[v] = clip.w;
             a.verts[cs.vertBase + v] = ResolveVertex{p.x, p.y, p.z, n.x, n.y, n.z};
             if (a.uvs && (cs.counts & BRMI_CS_TEXTURED)) { const f2 uv = decode_uv(a.clusterUv[c], v); a.uvs[cs.vertBase + v] = make_float2(uv.x, uv.y); }
+            if (a.colors && (cs.counts & BRMI_CS_COLOR)) a.colors[cs.vertBase + v] = reinterpret_cast<const uint32_t*>(a.clusterUv[c].color)[v];
         }
         __syncthreads();
         for (uint32_t t = lane; t < triCount; t += 64) {
@@ -241,9 +243,9 @@ __global__ void __launch_bounds__(256, INLINE_TABLES ? 1 : (TEXTURED ? BRMI_GBT_
         ClusterSetup cs{};
         if (valid) { cs = a.setup[clusterIndex]; valid = triId < ((cs.counts >> 8) & 0xFFu); }
         // per-pixel part of the tables
-        ResolveTriangle r{}; f3 p[3] = {}, n[3] = {}; f2 tc[3] = {};
+        ResolveTriangle r{}; f3 p[3] = {}, n[3] = {}; f2 tc[3] = {}; uint32_t vc[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
         if (valid) {
-            const bool wantUv = TEXTURED && (cs.counts & BRMI_CS_TEXTURED) != 0u;
+            const bool wantUv = TEXTURED && (cs.counts & BRMI_CS_TEXTURED) != 0u, wantColor = TEXTURED && (cs.counts & BRMI_CS_COLOR) != 0u;
             if (cs.vertBase != BRMI_ARENA_NONE) {
                 r = a.tris[cs.triBase32 + triId];
 #pragma unroll
@@ -252,6 +254,7 @@ __global__ void __launch_bounds__(256, INLINE_TABLES ? 1 : (TEXTURED ? BRMI_GBT_
                     const ResolveVertex v = a.verts[vi];
                     p[k] = f3{v.px, v.py, v.pz}; n[k] = f3{v.nx, v.ny, v.nz};
                     if (wantUv) { const float2 u = a.uvs[vi]; tc[k] = f2{u.x, u.y}; }
+                    if (wantColor) vc[k] = a.colors[vi];
                 }
             } else if (INLINE_TABLES) {
                 resolve_tables_inline(a, cs, triId, r, p, n);
@@ -259,6 +262,11 @@ __global__ void __launch_bounds__(256, INLINE_TABLES ? 1 : (TEXTURED ? BRMI_GBT_
                     const ClusterUv cu = a.clusterUv[clusterIndex];
 #pragma unroll
                     for (int k = 0; k < 3; k++) tc[k] = decode_uv(cu, (r.indices >> (8 * k)) & 0xFFu);
+                }
+                if (wantColor) {
+                    const uint32_t* col = reinterpret_cast<const uint32_t*>(a.clusterUv[clusterIndex].color);
+#pragma unroll
+                    for (int k = 0; k < 3; k++) vc[k] = col[(r.indices >> (8 * k)) & 0xFFu];
                 }
             } else valid = false;      // cannot happen: the arena holds every cluster of this configuration
         }
@@ -285,6 +293,13 @@ __global__ void __launch_bounds__(256, INLINE_TABLES ? 1 : (TEXTURED ? BRMI_GBT_
             f3 normalWS = worldNormal;
             if (TEXTURED) {
                 const uint32_t flags = mat->materialFlags;
+                // DecodeCompressedColor + interpolation (clodResolveCommon.hlsli:657-667,1641-1648); white where the page has no colours
+                const bool colored = (cs.counts & BRMI_CS_COLOR) != 0u;
+                f3 vertexColor{1.0f, 1.0f, 1.0f};
+                if (colored) vertexColor = f3{dot3(f3{tb.t[vc[0] & 0xFFu], tb.t[vc[1] & 0xFFu], tb.t[vc[2] & 0xFFu]}, l), dot3(f3{tb.t[(vc[0] >> 8) & 0xFFu], tb.t[(vc[1] >> 8) & 0xFFu], tb.t[(vc[2] >> 8) & 0xFFu]}, l),
+                                              dot3(f3{tb.t[(vc[0] >> 16) & 0xFFu], tb.t[(vc[1] >> 16) & 0xFFu], tb.t[(vc[2] >> 16) & 0xFFu]}, l)};
+                if (!(flags & BRMI_MATERIAL_ANY_TEXTURE) && colored)
+                    albedoW = pack_unorm4(mat->baseColorFactor[0] * vertexColor.x, mat->baseColorFactor[1] * vertexColor.y, mat->baseColorFactor[2] * vertexColor.z, 1.0f);
                 if (flags & BRMI_MATERIAL_ANY_TEXTURE) {
                     // BuildClodMaterialUvData for UV set 0 + SampleMaterialEvalFromUvCache (utilities.hlsli:1850-2075)
                     const BaryDeriv bd = bary_derivatives(r, l, ndcX, ndcY, winX, winY);
@@ -347,7 +362,7 @@ __global__ void __launch_bounds__(256, INLINE_TABLES ? 1 : (TEXTURED ? BRMI_GBT_
                         const f3 e = dot3(emissiveIn, emissiveIn) > 0.0f ? emissiveIn : canonical;
                         emissiveW = pack_half4(e.x, e.y, e.z, 0.0f);
                     }
-                    albedoW = pack_unorm4(baseColor.x, baseColor.y, baseColor.z, ao);
+                    albedoW = pack_unorm4(baseColor.x * vertexColor.x, baseColor.y * vertexColor.y, baseColor.z * vertexColor.z, ao);
                     mrW = (pack_unorm4(metallic, roughness, 0.0f, 0.0f) & 0xFFFFu) | (mrW & 0xFFFF0000u);       // coat roughness / fuzz weight stay the material's
                 }
             }
@@ -397,10 +412,12 @@ int launch_gbuffer(brmi_pass* p, hipStream_t s) {
     a.used = p->wsPtr<uint8_t>(p->ws.usedClusters);
     a.clusterUv = p->sceneHasTextures ? p->wsPtr<ClusterUv>(p->ws.clusterUv) : nullptr;
     a.uvs = p->sceneHasTextures ? p->wsPtr<float2>(p->ws.resolveUVs) : nullptr;
+    a.colors = p->sceneHasVertexColors ? p->wsPtr<uint32_t>(p->ws.resolveColors) : nullptr;
+    if (p->sceneHasVertexColors) a.clusterUv = p->wsPtr<ClusterUv>(p->ws.clusterUv);
     hipLaunchKernelGGL(k_mark_used_clusters, dim3(2048), dim3(256), 0, s, a, p->wsPtr<uint8_t>(p->ws.usedClusters), p->counters());
     hipLaunchKernelGGL(k_resolve_setup, dim3(8192), dim3(64), 0, s, a);
     const bool lean = (uint64_t)p->resolveCapacity >= (uint64_t)p->cfg.maxVisibleClusters * BRMI_MESHLET_MAX_TRIS;
-    if (p->sceneHasTextures) {
+    if (p->sceneHasTextures || p->sceneHasVertexColors) {
         if (lean) hipLaunchKernelGGL((k_gbuffer<false, true>), dim3(4096), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((k_gbuffer<true, true>), dim3(4096), dim3(256), 0, s, a);
     } else {

@@ -18,8 +18,8 @@
 
 namespace brmi {
 
-// where UV set 0 of a visible cluster lives (written by the compaction kernel next to ClusterSetup); desc == nullptr: the page has no UV set
-struct ClusterUv { const uint8_t* desc; const uint8_t* stream; };
+// where UV set 0 and the vertex colours of a visible cluster live (written by the compaction kernel next to ClusterSetup); desc == nullptr: the page has no UV set
+struct ClusterUv { const uint8_t* desc; const uint8_t* stream; const uint8_t* color; uint64_t pad; };      // color: the meshlet's RGBA8 vertex colours (nullptr: none)
 
 BRMI_DEV uint32_t read_packed_bits32(const uint8_t* stream, uint32_t startBit, uint32_t bitCount) {
     if (bitCount == 0u) return 0u;

@@ -181,6 +181,7 @@ struct MeshletBuild {
     std::vector<float> pos;       // 81*3
     std::vector<uint32_t> nrm;    // 81
     std::vector<float> uv;        // V*2 (meshes with a UV set only)
+    std::vector<uint32_t> color;  // V RGBA8 (materialFeatures bit 5 only)
     std::vector<uint32_t> joints; // V*8 (skinned only)
     std::vector<float> weights;   // V*8
     std::vector<uint8_t> tris;    // 3 local indices per triangle; empty = the implicit 8x8-quad grid over 9x9 vertices
@@ -278,13 +279,14 @@ void appendBits(std::vector<uint32_t>& words, uint64_t& cursor, uint32_t value, 
 }
 
 std::vector<uint8_t> buildPageBlob(const std::vector<const MeshletBuild*>& ms, bool skinned, bool hasUv) {
+    const bool hasColor = !ms.empty() && !ms[0]->color.empty();
     const uint32_t M = (uint32_t)ms.size();
     uint32_t totalVerts = 0, totalTris = 0;
     for (auto* m : ms) { totalVerts += m->vertCount(); totalTris += m->triCount(); }
     brmi_page_header h{};
     h.meshletCount = M;
     h.compressedPositionQuantExp = BRMI_POSITION_FORMAT_FLOAT3;
-    h.attributeMask = BRMI_PAGE_ATTRIBUTE_NORMAL | (skinned ? (BRMI_PAGE_ATTRIBUTE_JOINTS | BRMI_PAGE_ATTRIBUTE_WEIGHTS) : 0u);
+    h.attributeMask = BRMI_PAGE_ATTRIBUTE_NORMAL | (skinned ? (BRMI_PAGE_ATTRIBUTE_JOINTS | BRMI_PAGE_ATTRIBUTE_WEIGHTS) : 0u) | (hasColor ? BRMI_PAGE_ATTRIBUTE_COLOR : 0u);
     h.uvSetCount = hasUv ? 1u : 0u;
     h.descriptorOffset = (uint32_t)align4(sizeof(brmi_page_header));
     size_t cur = h.descriptorOffset + (size_t)M * sizeof(brmi_meshlet_descriptor);
@@ -319,6 +321,7 @@ std::vector<uint8_t> buildPageBlob(const std::vector<const MeshletBuild*>& ms, b
     h.normalArrayOffset = (uint32_t)align4(cur);
     cur = h.normalArrayOffset + (size_t)totalVerts * 4;
     h.colorArrayOffset = 0;
+    if (hasColor) { h.colorArrayOffset = (uint32_t)align4(cur); cur = h.colorArrayOffset + (size_t)totalVerts * 4; }
     if (skinned) {
         h.jointArrayOffset = (uint32_t)align4(cur); cur = h.jointArrayOffset + (size_t)totalVerts * 32;
         h.weightArrayOffset = (uint32_t)align4(cur); cur = h.weightArrayOffset + (size_t)totalVerts * 32;
@@ -361,6 +364,7 @@ std::vector<uint8_t> buildPageBlob(const std::vector<const MeshletBuild*>& ms, b
         std::memcpy(blob.data() + h.descriptorOffset + (size_t)i * sizeof(d), &d, sizeof(d));
         std::memcpy(blob.data() + h.positionBitstreamOffset + posCursor, m.pos.data(), (size_t)V * 12);
         std::memcpy(blob.data() + h.normalArrayOffset + (size_t)attrCursor * 4, m.nrm.data(), (size_t)V * 4);
+        if (hasColor) std::memcpy(blob.data() + h.colorArrayOffset + (size_t)attrCursor * 4, m.color.data(), (size_t)V * 4);
         if (skinned) {
             std::memcpy(blob.data() + h.jointArrayOffset + (size_t)attrCursor * 32, m.joints.data(), (size_t)V * 32);
             std::memcpy(blob.data() + h.weightArrayOffset + (size_t)attrCursor * 32, m.weights.data(), (size_t)V * 32);
@@ -383,11 +387,18 @@ std::vector<uint8_t> buildPageBlob(const std::vector<const MeshletBuild*>& ms, b
 }
 
 size_t meshletPageBytes(const MeshletBuild& m, bool skinned, bool hasUv) {
-    return 64 + (size_t)m.vertCount() * 16 + (size_t)m.triCount() * 3 + 4 + (skinned ? (size_t)m.vertCount() * 64 + 16 : 0) + (hasUv ? 32 + (size_t)m.vertCount() * 8 + 8 : 0);
+    return 64 + (size_t)m.vertCount() * 16 + (size_t)m.triCount() * 3 + 4 + (skinned ? (size_t)m.vertCount() * 64 + 16 : 0) + (hasUv ? 32 + (size_t)m.vertCount() * 8 + 8 : 0) + (m.color.empty() ? 0 : (size_t)m.vertCount() * 4 + 4);
 }
 
 // Built-in LOD DAG: a quadtree over the patch grids (level-L meshlets are 8x8 quads with stride 2^L, groups are 4x4 meshlets).
-uint32_t buildQuadtreeDag(const MeshDef& def, bool hasUv, std::vector<MeshletBuild>& meshlets, std::vector<GroupBuild>& groups) {
+// PackColorUnorm8 (ClusterLODUtilities.cpp:495-506) of a smooth procedural tint
+uint32_t vertexColorOf(double a, double b, uint32_t seed) {
+    auto q = [](double x) { return (uint32_t)std::lround(std::max(0.0, std::min(1.0, x)) * 255.0); };
+    const double n0 = valueNoise(a * 1.7, b * 1.7, seed ^ 0xC0105u), n1 = valueNoise(a * 2.3 + 5.0, b * 2.3, seed ^ 0xC0106u);
+    return q(0.55 + 0.45 * n0) | (q(0.55 + 0.45 * n1) << 8) | (q(0.75 + 0.25 * n0 * n1) << 16) | (0xFFu << 24);
+}
+
+uint32_t buildQuadtreeDag(const MeshDef& def, bool hasUv, bool hasColor, std::vector<MeshletBuild>& meshlets, std::vector<GroupBuild>& groups) {
     const uint32_t levels = std::max(1u, std::min(def.lodLevels, 7u));
     // (level, patch) -> first group id and group-grid dims
     struct LevelPatch { uint32_t firstGroup, gw, gh, firstMeshlet, mw, mh; };
@@ -427,6 +438,7 @@ uint32_t buildQuadtreeDag(const MeshDef& def, bool hasUv, std::vector<MeshletBui
                     m.pos[k * 3 + 0] = (float)P.x; m.pos[k * 3 + 1] = (float)P.y; m.pos[k * 3 + 2] = (float)P.z;
                     m.nrm[k] = octEncode(n);
                     if (hasUv) { m.uv[k * 2] = (float)(u * p.nu0); m.uv[k * 2 + 1] = (float)(v * p.nv0); }   // one texture repeat per LOD-0 meshlet
+                    if (hasColor) m.color.push_back(vertexColorOf(u * p.nu0, v * p.nv0, p.noiseSeed));
                     lo = {std::min(lo.x, P.x), std::min(lo.y, P.y), std::min(lo.z, P.z)};
                     hi = {std::max(hi.x, P.x), std::max(hi.y, P.y), std::max(hi.z, P.z)};
                 }
@@ -532,10 +544,10 @@ ClodRefApi* clodRef() {
 //             and through `refined` rule 2 of clusterlod.h)
 //   cluster -> meshlet with its own vertex / triangle counts, `refined` = refinedGroup
 // Returns the number of DAG depths, 0 on failure.
-uint32_t buildClusterLodDag(const MeshDef& def, bool hasUv, std::vector<MeshletBuild>& meshlets, std::vector<GroupBuild>& groups) {
+uint32_t buildClusterLodDag(const MeshDef& def, bool hasUv, bool hasColor, std::vector<MeshletBuild>& meshlets, std::vector<GroupBuild>& groups) {
     ClodRefApi* api = clodRef();
     if (!api) return 0;
-    std::vector<float> pos, nrm, uvs; std::vector<uint32_t> idx;
+    std::vector<float> pos, nrm, uvs; std::vector<uint32_t> idx, colors;
     for (const PatchDef& p : def.patches) {
         const uint32_t NU = p.nu0 * 8, NV = p.nv0 * 8, base = (uint32_t)(pos.size() / 3);
         for (uint32_t j = 0; j <= NV; j++) for (uint32_t i = 0; i <= NU; i++) {
@@ -546,6 +558,7 @@ uint32_t buildClusterLodDag(const MeshDef& def, bool hasUv, std::vector<MeshletB
             pos.push_back((float)P.x); pos.push_back((float)P.y); pos.push_back((float)P.z);
             nrm.push_back((float)n.x); nrm.push_back((float)n.y); nrm.push_back((float)n.z);
             uvs.push_back((float)(u * p.nu0)); uvs.push_back((float)(v * p.nv0));
+            colors.push_back(vertexColorOf(u * p.nu0, v * p.nv0, p.noiseSeed));
         }
         for (uint32_t qj = 0; qj < NV; qj++) for (uint32_t qi = 0; qi < NU; qi++) {
             const uint32_t a = base + qj * (NU + 1) + qi, b = a + 1, c = a + NU + 2, d = a + NU + 1;
@@ -581,6 +594,7 @@ uint32_t buildClusterLodDag(const MeshDef& def, bool hasUv, std::vector<MeshletB
         for (uint32_t v = 0; v < V; v++) {
             const uint32_t src = vref[k.firstVertex + v];
             if (hasUv) { m.uv[(size_t)v * 2] = uvs[(size_t)src * 2]; m.uv[(size_t)v * 2 + 1] = uvs[(size_t)src * 2 + 1]; }
+            if (hasColor) m.color.push_back(colors[src]);
             for (int q = 0; q < 3; q++) m.pos[v * 3 + q] = pos[(size_t)src * 3 + q];
             m.nrm[v] = octEncode(V3{nrm[(size_t)src * 3], nrm[(size_t)src * 3 + 1], nrm[(size_t)src * 3 + 2]});
             lo = {std::min(lo.x, (double)m.pos[v * 3]), std::min(lo.y, (double)m.pos[v * 3 + 1]), std::min(lo.z, (double)m.pos[v * 3 + 2])};
@@ -615,8 +629,8 @@ bool buildMesh(brmi_scene& sc, const MeshDef& def, uint32_t meshIndex) {
     if (!sc.cacheDir.empty()) { if (!loadCachedMesh(sc, def, meshIndex)) { sc.failed = true; return false; } return true; }
     std::vector<MeshletBuild> meshlets;
     std::vector<GroupBuild> groups;
-    const bool hasUv = (sc.params.materialFeatures & 24u) != 0u;
-    const uint32_t levels = sc.params.lodBuilder == BRMI_LOD_BUILDER_CLUSTERLOD ? buildClusterLodDag(def, hasUv, meshlets, groups) : buildQuadtreeDag(def, hasUv, meshlets, groups);
+    const bool hasUv = (sc.params.materialFeatures & 24u) != 0u, hasColor = (sc.params.materialFeatures & 32u) != 0u;
+    const uint32_t levels = sc.params.lodBuilder == BRMI_LOD_BUILDER_CLUSTERLOD ? buildClusterLodDag(def, hasUv, hasColor, meshlets, groups) : buildQuadtreeDag(def, hasUv, hasColor, meshlets, groups);
     if (levels == 0) { sc.failed = true; return false; }
 
     // segments: partition each group's meshlets by refinedGroup (stable)
@@ -767,7 +781,7 @@ bool buildMesh(brmi_scene& sc, const MeshDef& def, uint32_t meshIndex) {
 
     brmi_per_mesh pm{};
     pm.materialDataIndex = def.material; pm.rasterBucketIndex = 0;
-    pm.vertexFlags = (1u << 1) | (def.skinned ? BRMI_VERTEX_SKINNED : 0u);
+    pm.vertexFlags = (1u << 1) | (def.skinned ? BRMI_VERTEX_SKINNED : 0u) | (hasColor ? 1u : 0u) | (hasUv ? (1u << 2) : 0u);
     pm.vertexByteSize = 24;
     pm.boundingSphere[0] = bn[0].n.cullCenterAndRadius[0]; pm.boundingSphere[1] = bn[0].n.cullCenterAndRadius[1];
     pm.boundingSphere[2] = bn[0].n.cullCenterAndRadius[2]; pm.boundingSphere[3] = bn[0].n.cullCenterAndRadius[3];
@@ -924,7 +938,7 @@ bool loadMeshCache(const std::string& dir, uint32_t m, MeshCacheData& d) {
         d.pages.emplace_back(file.begin() + (size_t)loc[i].blobOffset, file.begin() + (size_t)loc[i].blobOffset + loc[i].blobSizeBytes);
     }
     // the structure the kernels index without checks: validate every cross reference once, here
-    if (d.trianglePageCount != pageCount || d.nodes.empty() || d.groupPageReferenceOffsets.size() != d.groups.size() + 1) return false;
+    if (pageCount == 0 || d.trianglePageCount != pageCount || d.nodes.empty() || d.groupPageReferenceOffsets.size() != d.groups.size() + 1) return false;
     for (const brmi_lod_segment& sg : d.segments) if (sg.pageIndex >= pageCount || sg.refinedGroup >= (int32_t)d.groups.size()) return false;
     for (const brmi_lod_group& g : d.groups) if ((uint64_t)g.firstSegment + g.segmentCount > d.segments.size()) return false;
     for (const brmi_lod_node& n : d.nodes) {
@@ -976,7 +990,8 @@ bool loadCachedMesh(brmi_scene& sc, const MeshDef& def, uint32_t meshIndex) {
     }
     brmi_per_mesh pm{};
     pm.materialDataIndex = def.material; pm.rasterBucketIndex = 0;
-    pm.vertexFlags = (1u << 1) | (def.skinned ? BRMI_VERTEX_SKINNED : 0u);
+    const brmi_page_header* h0 = reinterpret_cast<const brmi_page_header*>(d.pages[0].data());
+    pm.vertexFlags = (1u << 1) | (def.skinned ? BRMI_VERTEX_SKINNED : 0u) | ((h0->attributeMask & BRMI_PAGE_ATTRIBUTE_COLOR) ? 1u : 0u) | (h0->uvSetCount ? (1u << 2) : 0u);
     pm.vertexByteSize = 24;
     std::memcpy(pm.boundingSphere, d.objectSphere, 16);
     pm.clodNumMeshlets = total; pm.numMeshlets = lod0; pm.numVertices = lod0Verts;

@@ -13,7 +13,7 @@
 //   BuildClodMaterialUvData / AppendClodMaterialUvSample   BR/shaders/Include/clodResolveCommon.hlsli:271-430
 //   cotangent_frame_from_derivs / BuildMaterialTBN          BR/shaders/Include/utilities.hlsli:323-336,1278-1287
 //   ResolveCanonicalOpenPBRSurface              BR/shaders/Include/utilities.hlsli:136-161
-// Scope: triangle clusters (no Reyes / voxel), no vertex colours.  Material texture slots: base colour, opacity, metallic,
+// Scope: triangle clusters (no Reyes / voxel).  Vertex colours (CLOD_PAGE_ATTRIBUTE_COLOR) tint the base colour.  Material texture slots: base colour, opacity, metallic,
 // roughness, normal map, AO, emissive, each through the software sampler of orc_texture.h; no parallax / height map, no OpenPBR
 // coat / fuzz textures, no texture streaming feedback.  A slot's UV set index below MATERIAL_MAX_UNIQUE_UV_SETS (8) is decoded
 // as that set (a set the page does not carry decodes to (0, 0)); any other index uses set 0.
@@ -139,7 +139,16 @@ static bool resolvePixel(const brmi_scene_buffers& sc, const brmi_visible_cluste
         const UvSample u = uvOf(uvSetIndex);
         return sampleGrad(sc, textureIndex, samplerIndex, u.uv, u.dUVdx, u.dUVdy);
     };
-    const float3 vertexColor{1.0f, 1.0f, 1.0f};
+    // DecodeCompressedColor + the vertexColor interpolation (clodResolveCommon.hlsli:657-667,1521-1531,1641-1648)
+    float3 vertexColor{1.0f, 1.0f, 1.0f};
+    if (hdr.attributeMask & BRMI_PAGE_ATTRIBUTE_COLOR) {
+        float3 c[3];
+        for (int k = 0; k < 3; k++) {
+            const uint32_t packed = load32(slab, pageOff + hdr.colorArrayOffset + (desc.vertexAttributeOffset + tri[k]) * 4u);
+            c[k] = float3{(float)(packed & 0xFFu) / 255.0f, (float)((packed >> 8) & 0xFFu) / 255.0f, (float)((packed >> 16) & 0xFFu) / 255.0f};
+        }
+        vertexColor = float3{interp(bary, c[0].x, c[1].x, c[2].x), interp(bary, c[0].y, c[1].y, c[2].y), interp(bary, c[0].z, c[1].z, c[2].z)};
+    }
     float4 baseColor4{mat.baseColorFactor[0], mat.baseColorFactor[1], mat.baseColorFactor[2], mat.baseColorFactor[3]};
     if (flags & BRMI_MATERIAL_BASE_COLOR_TEXTURE) {
         const float4 t = sample(mat.baseColorTextureIndex, mat.baseColorSamplerIndex, mat.baseColorUvSetIndex);

@@ -54,6 +54,9 @@ SCENE_CASES = {
     "tiny_alpha": ("tiny", 256, 144, dict(point_lights=6, lod_levels=2, material_features=24)),
     "sponza_alpha": ("sponza", 640, 360, dict(point_lights=32, size_scale=0.25, material_features=24)),
     "bistro_alpha_skinned": ("bistro", 640, 360, dict(point_lights=32, size_scale=0.3, material_features=24 | 4, skinned_fraction=0.3)),
+    # RGBA8 vertex colours in the pages tint the base colour (constant-factor and textured materials)
+    "tiny_vcolor": ("tiny", 256, 144, dict(point_lights=6, lod_levels=2, material_features=32)),
+    "sponza_vcolor_textured": ("sponza", 640, 360, dict(point_lights=32, size_scale=0.25, material_features=32 | 24 | 3)),
     "tiny_clod": ("tiny", 256, 144, dict(point_lights=4, lod_builder="clusterlod")),
     "sponza_clod": ("sponza", 640, 360, dict(point_lights=32, size_scale=0.25, lod_builder="clusterlod")),
     "bistro_clod_skinned": ("bistro", 640, 360, dict(point_lights=32, size_scale=0.3, skinned_fraction=0.3, lod_builder="clusterlod")),

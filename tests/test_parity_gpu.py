@@ -13,7 +13,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 CASES = ["tiny", "tiny_lod", "tiny_coat_fuzz", "sponza_coat_fuzz", "sponza_small", "bistro_small", "tiny_skinned", "bistro_skinned", "tiny_clod", "sponza_clod", "bistro_clod_skinned", "sponza_spots", "bistro_mirrored",
-         "tiny_textured", "sponza_textured", "tiny_alpha", "sponza_alpha", "bistro_alpha_skinned", "sponza_clod_alpha"]
+         "tiny_textured", "sponza_textured", "tiny_alpha", "sponza_alpha", "bistro_alpha_skinned", "sponza_clod_alpha", "tiny_vcolor", "sponza_vcolor_textured"]
 
 
 @pytest.fixture(scope="module")
@@ -529,11 +529,11 @@ def test_alpha_tested_records_survive_bin_overflow(queue, scenes, oracle_frames)
 
 
 def test_textured_resolve_without_arena_space_matches(scenes, oracle_frames):
-    """Textured clusters outside the resolve arena decode their texcoords per pixel: same G-buffer bytes."""
+    """Textured / vertex-coloured clusters outside the resolve arena decode their texcoords and colours per pixel: same G-buffer bytes."""
     from basicrenderer_amd.renderer import VisibilityRenderer
-    o = oracle_frames("sponza_textured")
+    o = oracle_frames("sponza_vcolor_textured")
     with _Env(BRMI_RESOLVE_CAPACITY=5000):
-        r = VisibilityRenderer(scenes("sponza_textured"), stats=True)
+        r = VisibilityRenderer(scenes("sponza_vcolor_textured"), stats=True)
     r.execute()
     g = r.gbuffer()
     covered = o.vis != np.uint64(0xFFFFFFFFFFFFFFFF)
@@ -585,6 +585,7 @@ SWEEP = [
     ("zorah", 640, 360, dict(seed=16, point_lights=12, size_scale=0.004, skinned_fraction=0.0), dict()),
     ("sponza", 451, 333, dict(seed=17, point_lights=20, size_scale=0.12, lod_levels=3, material_features=24 | 3), dict(occlusion=True)),
     ("san_miguel", 640, 360, dict(seed=18, point_lights=24, size_scale=0.02, material_features=24), dict(occlusion=True)),
+    ("bistro", 500, 281, dict(seed=19, point_lights=30, size_scale=0.2, material_features=32 | 8 | 4, skinned_fraction=0.2), dict(occlusion=True)),
 ]
 
 
