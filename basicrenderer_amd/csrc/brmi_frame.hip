@@ -123,7 +123,7 @@ BRMI_DEV void job_shade_tables(const brmi_scene_buffers& sc, ShadeTables t, uint
         if (i == gz + 1u) b = __uint_as_float(0x7F800000u);
         else if (i > 0u) {
             const float zNear = cam->zNear, zFar = cam->zFar, zSplit = pf->clusterZSplitDepth;
-            const float logStart = logf(zSplit / zNear), logEnd = logf(zFar / zNear);
+            const float logStart = log_cr(zSplit / zNear), logEnd = log_cr(zFar / zNear);
             // bisection over the positive floats: lo fails, hi passes.  The search stops at 1e30 (z / zNear must stay finite for
             // the float -> uint conversion of the formula to be defined); a slice that starts beyond it starts at +inf.
             uint32_t lo = 0u, hi = __float_as_uint(1.0e30f);

@@ -634,7 +634,7 @@ BRMI_DEV ShadeFrame make_shade_frame(const ShadeArgs& a) {
     k.resX = uni((float)pf->screenResX); k.resY = uni((float)pf->screenResY);
     k.tsx = k.resX / (float)k.gx; k.tsy = k.resY / (float)k.gy;
     k.tsx = uni(k.tsx); k.tsy = uni(k.tsy);
-    k.logStart = uni(logf(k.zSplit / k.zNear)); k.logEnd = uni(logf(k.zFar / k.zNear));
+    k.logStart = uni(logf(k.zSplit / k.zNear)); k.logEnd = uni(logf(k.zFar / k.zNear));      // only feed the slice ESTIMATE below (the exact slice starts come from the table)
     k.nearSlices = pf->nearClusterCount; k.numLights = pf->numLights;
     const float om = 1.0f - 1.0f / 7.0f;
     k.om5 = uni(powf(om, 5.0f)); k.om6 = uni(powf(om, 6.0f));

@@ -23,7 +23,8 @@
 // One deliberate relocation: the 25 slice plane depths of the cluster grid use log()/exp()
 // (clustering.hlsl:77-90), whose last-bit results differ between GPU and CPU math libraries and
 // would make AABBs - hence light lists - irreproducible.  They are computed once on the host with
-// logf/expf (orc_cluster_planes) and consumed by both sides.
+// logf/expf (orc_cluster_planes) and consumed by both sides.  The per-pixel slice lookup of ComputeClusterID
+// (lighting.hlsli:166-196) evaluates its log() as the correctly rounded fp32 logarithm for the same reason.
 #include <cmath>
 #include <vector>
 
@@ -567,7 +568,10 @@ int orc_shade(const brmi_scene_buffers* scp, uint32_t W, uint32_t H, uint32_t ba
                     uint32_t sliceZ;
                     if (z < pf.clusterZSplitDepth) { const float t = (z - cam.zNear) / (pf.clusterZSplitDepth - cam.zNear); sliceZ = t > 0.0f ? (uint32_t)(t * (float)pf.nearClusterCount) : 0u; }
                     else {
-                        const float logStart = std::log(pf.clusterZSplitDepth / cam.zNear), logEnd = std::log(cam.zFar / cam.zNear), logZ = std::log(z / cam.zNear);
+                        // log() = the correctly rounded fp32 logarithm (through double on both sides): a pixel whose depth sits within an
+                        // ulp of a slice boundary must land in the same slice on CPU and GPU, and their float logf differ in the last bit
+                        auto logCR = [](float x) { return (float)std::log((double)x); };
+                        const float logStart = logCR(pf.clusterZSplitDepth / cam.zNear), logEnd = logCR(cam.zFar / cam.zNear), logZ = logCR(z / cam.zNear);
                         const float u = (logZ - logStart) / (logEnd - logStart);
                         sliceZ = pf.nearClusterCount + (u > 0.0f ? (uint32_t)(u * (float)(gz - pf.nearClusterCount)) : 0u);
                     }

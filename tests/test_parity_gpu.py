@@ -321,6 +321,72 @@ def test_full_size_4k_properties(preset, lights):
     r.close()
 
 
+@pytest.mark.parametrize("preset,W,H,lights,kw", [("sponza", 1920, 1080, 0, dict()),                 # BASELINE.json configs[0]: 1080p, one directional light
+                                                  ("sponza", 3840, 2160, 64, dict()),                # configs[1]: the bench workload
+                                                  ("bistro", 3840, 2160, 256, dict()),               # configs[2]
+                                                  ("san_miguel", 3840, 2160, 256, dict(material_features=24))])   # configs[3] with its alpha-tested materials
+def test_full_size_frames_against_the_oracle(preset, W, H, lights, kw):
+    """BASELINE.json's configurations at their full size, whole frame against the CPU oracle (it renders a 4K frame in well under a
+    second per stage on the box's cores): cluster list, visibility keys, depth, every G-buffer plane exact; HDR within one fp16 ULP."""
+    import orc
+    from basicrenderer_amd import Scene
+    from basicrenderer_amd.renderer import VisibilityRenderer
+    sc = Scene(preset, W, H, point_lights=lights, **kw)
+    r = VisibilityRenderer(sc, stats=True)
+    r.execute()
+    o = orc.OracleFrame(sc).run()
+    c = r.counters()
+    assert c.droppedRecords == 0 and c.droppedClusters == 0
+    assert np.array_equal(r.visible_clusters(), o.clusters[: o.count])
+    vis = r.visibility()
+    assert np.array_equal(vis, o.vis), f"{int((vis != o.vis).sum())} keys differ"
+    covered = o.vis != np.uint64(0xFFFFFFFFFFFFFFFF)
+    assert np.array_equal(r.depth().view(np.uint32), o.depth.view(np.uint32))
+    g = r.gbuffer()
+    assert np.array_equal(g["normals"].view(np.uint32)[covered], o.normals.view(np.uint32)[covered])
+    for k, ref in (("albedo", o.albedo), ("mr", o.mr), ("motion", o.motion), ("coat", o.coat), ("emissive", o.emissive), ("fuzz", o.fuzz)):
+        assert np.array_equal(g[k][covered], ref[covered]), k
+    a, b = r.hdr().view(np.uint16).astype(np.int32), o.hdr.view(np.uint16).astype(np.int32)
+    assert np.abs(a - b).max() <= 1
+    r.close()
+
+
+@pytest.mark.parametrize("preset,lights,kw", [("sponza", 64, dict()), ("bistro", 256, dict()), ("san_miguel", 256, dict(material_features=24))])
+def test_full_size_camera_path_with_occlusion_against_the_oracle(preset, lights, kw):
+    """Three 4K frames of the camera path with 2-phase occlusion culling on (the bench default), every frame against the oracle's
+    2-phase frame: both phases' cluster lists, keys, depth, G-buffer exact, HDR within one fp16 ULP on covered pixels (pixels without
+    geometry are not written -- DeferredCSMain returns -- so they keep the previous frame's value)."""
+    import orc
+    from basicrenderer_amd import Scene
+    from basicrenderer_amd.renderer import VisibilityRenderer
+    hz, r = None, None
+    for step in range(3):
+        sc = Scene(preset, 3840, 2160, point_lights=lights, camera_step=step, **kw)
+        if r is None:
+            r = VisibilityRenderer(sc, occlusion=True, stats=True)
+        else:
+            r.set_camera_from(sc, frame_index=step)
+        r.execute()
+        o = orc.OracleFrame(sc)
+        hz = o.run_occlusion(hz)
+        o.gbuffer(); o.light_cluster(); o.shade()
+        c = r.counters()
+        assert c.droppedRecords == 0 and c.droppedClusters == 0
+        assert (c.visibleClusters, c.visibleClustersPhase2) == (o.count1, o.count2), f"frame {step}"
+        assert np.array_equal(r.visible_clusters(), o.clusters[: o.count]), f"frame {step}"
+        assert np.array_equal(r.visibility(), o.vis), f"frame {step}"
+        covered = o.vis != np.uint64(0xFFFFFFFFFFFFFFFF)
+        g = r.gbuffer()
+        assert np.array_equal(g["normals"].view(np.uint32)[covered], o.normals.view(np.uint32)[covered]), f"frame {step}"
+        for k, ref in (("albedo", o.albedo), ("mr", o.mr), ("motion", o.motion), ("emissive", o.emissive)):
+            assert np.array_equal(g[k][covered], ref[covered]), f"frame {step}: {k}"
+        a, b = r.hdr().view(np.uint16).astype(np.int32).reshape(2160, 3840, 4)[covered], o.hdr.view(np.uint16).astype(np.int32).reshape(2160, 3840, 4)[covered]
+        assert np.abs(a - b).max() <= 1, f"frame {step}"
+        if step > 0 and preset != "sponza":
+            assert o.count2 > 0, "the path does not exercise phase 2"
+    r.close()
+
+
 def test_cpp_host_passes_reproduce_the_python_frame(scenes):
     """The C++ host mirror (basicrenderer_amd/host/brmi_passes.hpp) driving the stage-level C ABI gives the same bytes."""
     import hashlib
