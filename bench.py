@@ -131,9 +131,12 @@ def main():
         traffic = None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", PROFILE_TAG.get(args.workload, "") + "_traffic.json")))
-            kname = "k_shade<false>" if dom == "shade" else DOMINANT_KERNEL.get(dom, dom)
-            if n == 1 and kname in tj:
-                traffic = tj[kname]["hbm_bytes_per_launch"]
+            # the stage's dominant kernel; template instantiations ("k_shade<0>", "k_raster<true>") are matched by base name and the
+            # one that takes the most time per launch is used
+            base = DOMINANT_KERNEL.get(dom, dom).split("<")[0]
+            cands = [k for k in tj if k.split("<")[0] == base]
+            if n == 1 and cands:
+                traffic = tj[max(cands, key=lambda k: tj[k].get("avg_us", 0.0))]["hbm_bytes_per_launch"]
         except (OSError, ValueError):
             pass
         out = {
