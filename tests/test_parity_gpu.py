@@ -324,7 +324,8 @@ def test_full_size_4k_properties(preset, lights):
 @pytest.mark.parametrize("preset,W,H,lights,kw", [("sponza", 1920, 1080, 0, dict()),                 # BASELINE.json configs[0]: 1080p, one directional light
                                                   ("sponza", 3840, 2160, 64, dict()),                # configs[1]: the bench workload
                                                   ("bistro", 3840, 2160, 256, dict()),               # configs[2]
-                                                  ("san_miguel", 3840, 2160, 256, dict(material_features=24))])   # configs[3] with its alpha-tested materials
+                                                  ("san_miguel", 3840, 2160, 256, dict(material_features=24)),    # configs[3] with its alpha-tested materials
+                                                  ("zorah", 7680, 4320, 64, dict(skinned_fraction=0.01))])        # configs[4]: 8K, 100 k instances, 1 % skinned
 def test_full_size_frames_against_the_oracle(preset, W, H, lights, kw):
     """BASELINE.json's configurations at their full size, whole frame against the CPU oracle (it renders a 4K frame in well under a
     second per stage on the box's cores): cluster list, visibility keys, depth, every G-buffer plane exact; HDR within one fp16 ULP."""
@@ -385,6 +386,32 @@ def test_full_size_camera_path_with_occlusion_against_the_oracle(preset, lights,
         if step > 0 and preset != "sponza":
             assert o.count2 > 0, "the path does not exercise phase 2"
     r.close()
+
+
+@pytest.mark.parametrize("preset,lights,n", [("sponza", 64, 2), ("bistro", 256, 4)])
+def test_full_size_band_split_against_the_oracle(preset, lights, n):
+    """The multi-GPU bench's partition at its real size on one GPU: the 7680 x (1080 n) frame rendered band by band (occlusion
+    culling on, two frames each) equals the oracle's full frame on every band: triangle identities, depth, lit bytes."""
+    import orc
+    from basicrenderer_amd import Scene, compose
+    from basicrenderer_amd.renderer import VisibilityRenderer
+    W, H = compose.frame_size(n)
+    sc = Scene(preset, W, H, point_lights=lights)
+    o = orc.OracleFrame(sc).run()
+    fa, fb, fd = orc.canonical_ids(o.vis, o.clusters[: o.count])
+    oh = o.hdr.view(np.uint16).astype(np.int32).reshape(H, W, 4)
+    for rank in range(n):
+        y0, y1 = compose.band_of(rank, n, H)
+        r = VisibilityRenderer(sc, band=(y0, y1), occlusion=True, stats=True)
+        r.execute(); r.execute()
+        c = r.counters()
+        assert c.droppedRecords == 0 and c.droppedClusters == 0
+        a, b, d = orc.canonical_ids(r.visibility(), r.visible_clusters())
+        assert np.array_equal(a[y0:y1], fa[y0:y1]) and np.array_equal(b[y0:y1], fb[y0:y1]) and np.array_equal(d[y0:y1], fd[y0:y1]), f"rank {rank}"
+        covered = (o.vis != np.uint64(0xFFFFFFFFFFFFFFFF))[y0:y1]
+        gh = r.hdr().view(np.uint16).astype(np.int32).reshape(H, W, 4)
+        assert np.abs(gh[y0:y1][covered] - oh[y0:y1][covered]).max() <= 1, f"rank {rank}"
+        r.close()
 
 
 def test_cpp_host_passes_reproduce_the_python_frame(scenes):
