@@ -122,6 +122,7 @@ static void compute_sizes(brmi_pass* p) {
     p->deferredStripeCapacity = (uint32_t)(((p->bandPixelCount / 4096 + CNT_STRIPE_COUNT) / CNT_STRIPE_COUNT) * 4096);   // 64-tile runs of a stripe x 4096 pixels
     w.deferredPixels = take((uint64_t)3 * CNT_STRIPE_COUNT * p->deferredStripeCapacity * 4);      // one set of striped lists per layered class
     w.lutF = take((uint64_t)(32768 + 1024 + 1024 + 32 + 256) * 4);
+    w.shadeMat = take((uint64_t)std::max(1u, p->scene.openpbrMaterialCount) * 256 * 64);      // (OpenPBR material, roughness code) table of the shading pass
     // textured / alpha-tested scenes only: where each visible cluster's UV set lives, the texcoords of the resolve arena's vertices,
     // and the alpha-test operands that travel with binned triangles
     const bool uvs = p->sceneHasTextures || p->sceneHasAlphaTest || p->sceneHasVertexColors;

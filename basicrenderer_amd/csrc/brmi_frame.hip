@@ -12,6 +12,7 @@
 #include "brmi_device.h"
 #include "brmi_internal.h"
 #include "brmi_texture.h"
+#include "brmi_shade_math.h"
 
 namespace brmi {
 
@@ -87,9 +88,7 @@ BRMI_DEV void job_light_spheres(const brmi_scene_buffers& sc, float4* lightVS, u
 
 // Per-material part of PopulateFragmentInfoFromOpenPBR (utilities.hlsli:2590-2637): depends only on the
 // OpenPBR material record, so it is evaluated once per material per frame instead of once per pixel.
-BRMI_DEV void job_material_constants(const brmi_scene_buffers& sc, MatConst* out, uint32_t i) {
-    if (i >= sc.openpbrMaterialCount) return;
-    const brmi_openpbr_material_info* op = sc.openpbrMaterials + i;
+BRMI_DEV MatConst material_constants_of(const brmi_openpbr_material_info* op) {
     MatConst m;
     m.baseWeight = sat(op->baseWeight); m.specularWeight = sat(op->specularWeight);
     m.specR = sat(op->specularColor[0]); m.specG = sat(op->specularColor[1]); m.specB = sat(op->specularColor[2]);
@@ -101,7 +100,26 @@ BRMI_DEV void job_material_constants(const brmi_scene_buffers& sc, MatConst* out
     m.dielF0Scalar = ior_to_f0(m.weightedSpecularIor);
     m.coatF0Scalar = ior_to_f0(op->coatIor);
     m.coatIor = op->coatIor; m.coatDarkening = sat(op->coatDarkening); m.baseDiffuseRoughness = sat(op->baseDiffuseRoughness); m.pad = 0.0f;
-    out[i] = m;
+    return m;
+}
+BRMI_DEV void job_material_constants(const brmi_scene_buffers& sc, MatConst* out, uint32_t i) {
+    if (i >= sc.openpbrMaterialCount) return;
+    out[i] = material_constants_of(sc.openpbrMaterials + i);
+}
+// (material, roughness code) -> the light-independent table part of make_pixel_ctx (brmi_shade_math.h): the same functions the shader
+// called per pixel, evaluated once per pair
+BRMI_DEV void job_shade_material_table(const brmi_scene_buffers& sc, const float* lutF, ShadeMaterialEntry* out, uint32_t i) {
+    const uint32_t m = i >> 8, code = i & 255u;
+    if (m >= sc.openpbrMaterialCount) return;
+    const Luts L{lutF, lutF + 32768, lutF + 32768 + 1024, lutF + 32768 + 2048, sc.lutFuzzLTC, lutF + 32768 + 2048 + 32};
+    const MatConst mc = material_constants_of(sc.openpbrMaterials + m);
+    const float prc = clampf(L.unorm8[code], BRMI_MIN_PERCEPTUAL_ROUGHNESS, 1.0f);
+    const float alpha = sat(prc * prc), ior = max2(mc.weightedSpecularIor, 1.0f);        // BaseState::specularAlpha / weightedSpecularIor
+    ShadeMaterialEntry e;
+    e.od = prep_od_e(L, ior, alpha); e.im = prep_im_e(L, alpha);
+    e.avgComp = lut_od_avg(L, ior, alpha); e.mAvgClamped = max2(lut_im_avg(L, alpha), 1.0e-12f);
+    e.pad[0] = e.pad[1] = e.pad[2] = 0u;
+    out[i] = e;
 }
 
 // Per-frame tables of the shading pass.  Everything here is what the shader computes per pixel from px, py or view depth
@@ -142,8 +160,9 @@ struct FrameJobs {
     brmi_scene_buffers sc;
     m4* frameConst; float* objConst; MaterialWords* matWords; MatConst* matConst; ShadeTables tables; float4* lightVS; uint32_t* lightMeta;
     AlphaMaterial* alphaMats;
+    const float* lutF; ShadeMaterialEntry* shadeMat;
     uint32_t W, H;
-    uint32_t firstBlock[6];      // block ranges of the five jobs
+    uint32_t firstBlock[7];      // block ranges of the six jobs
 };
 
 __global__ void __launch_bounds__(64) k_frame_constants(FrameJobs j) {
@@ -152,7 +171,8 @@ __global__ void __launch_bounds__(64) k_frame_constants(FrameJobs j) {
     else if (b < j.firstBlock[2]) job_material_words(j.sc, j.matWords, j.alphaMats, (b - j.firstBlock[1]) * 64u + threadIdx.x);
     else if (b < j.firstBlock[3]) job_material_constants(j.sc, j.matConst, (b - j.firstBlock[2]) * 64u + threadIdx.x);
     else if (b < j.firstBlock[4]) job_shade_tables(j.sc, j.tables, j.W, j.H, (b - j.firstBlock[3]) * 64u + threadIdx.x);
-    else job_light_spheres(j.sc, j.lightVS, j.lightMeta, (b - j.firstBlock[4]) * 64u + threadIdx.x);
+    else if (b < j.firstBlock[5]) job_light_spheres(j.sc, j.lightVS, j.lightMeta, (b - j.firstBlock[4]) * 64u + threadIdx.x);
+    else job_shade_material_table(j.sc, j.lutF, j.shadeMat, (b - j.firstBlock[5]) * 64u + threadIdx.x);
 }
 
 ShadeTables shade_tables_of(const brmi_pass* p) {
@@ -172,11 +192,15 @@ int ensure_frame_constants(brmi_pass* p, hipStream_t s) {
     j.alphaMats = p->sceneHasAlphaTest ? p->wsPtr<AlphaMaterial>(p->ws.alphaMats) : nullptr;
     j.W = p->cfg.width; j.H = p->cfg.height;
     auto blocks = [](uint32_t n) { return (std::max(1u, n) + 63u) / 64u; };
-    const uint32_t counts[5] = {blocks(p->scene.perObjectCount), blocks(p->scene.materialCount), blocks(p->scene.openpbrMaterialCount),
-                                blocks(std::max(std::max(j.W, j.H), 64u)), blocks(p->pfHost.numLights)};
+    j.lutF = p->wsPtr<float>(p->ws.lutF); j.shadeMat = p->wsPtr<ShadeMaterialEntry>(p->ws.shadeMat);
+    const uint32_t counts[6] = {blocks(p->scene.perObjectCount), blocks(p->scene.materialCount), blocks(p->scene.openpbrMaterialCount),
+                                blocks(std::max(std::max(j.W, j.H), 64u)), blocks(p->pfHost.numLights),
+                                // the (material, roughness) table only depends on the OpenPBR records and the lookup tables: built with the first
+                                // frame after brmi_setup (OpenPBR records edited on the device later: brmi_set_scene + brmi_setup again)
+                                p->constantsSerial == 0 ? blocks(std::max(1u, p->scene.openpbrMaterialCount) * 256u) : 0u};
     j.firstBlock[0] = 0;
-    for (int k = 0; k < 5; k++) j.firstBlock[k + 1] = j.firstBlock[k] + counts[k];
-    hipLaunchKernelGGL(k_frame_constants, dim3(j.firstBlock[5]), dim3(64), 0, s, j);
+    for (int k = 0; k < 6; k++) j.firstBlock[k + 1] = j.firstBlock[k] + counts[k];
+    hipLaunchKernelGGL(k_frame_constants, dim3(j.firstBlock[6]), dim3(64), 0, s, j);
     BRMI_LAUNCH_CHECK(p, "k_frame_constants");
     p->constantsSerial = p->updateSerial;
     return BRMI_OK;

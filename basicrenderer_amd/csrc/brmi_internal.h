@@ -87,7 +87,7 @@ struct HzbDesc {
 struct Workspace {     // byte offsets into BRMI_RES_WORKSPACE
     uint64_t counters, frontierA, frontierB, buckets, tempVisible, bitmask1, bitmask2, wordPrefix, blockSums,
              instanceBitBase, segPrefix, meshLevelWidth, planes, replayNodes, replayBuckets, lightVS, lightMeta, clusterPages, clusterHits, pageTotal, lightHitMasks, binCounts, binRecords, binOverflow, clusterSetup, resolveVerts, resolveTris, matWords, shadeTables, lutF, frameConst, objConst, matConst, deferredPixels, usedClusters,
-             clusterUv, binAlpha, overflowAlpha, resolveUVs, resolveColors, alphaMats, frameClearBytes, total;
+             clusterUv, binAlpha, overflowAlpha, resolveUVs, resolveColors, alphaMats, shadeMat, frameClearBytes, total;
 };
 
 }  // namespace brmi

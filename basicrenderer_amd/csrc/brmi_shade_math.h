@@ -1,0 +1,193 @@
+// brmi_shade_math.h -- GGX / OpenPBR lookup-table arithmetic shared by the shading kernel and the per-frame table builder.
+// Reference: BR/shaders/Include/PBR.hlsli:8-190, BR/shaders/Include/IBL.hlsli:94-672 (see brmi_light.hip for the per-function map).
+#ifndef BRMI_SHADE_MATH_H
+#define BRMI_SHADE_MATH_H
+
+#include "brmi_device.h"
+
+namespace brmi {
+
+constexpr float PI_F = 3.1415926538f;
+constexpr float MEDIUMP_MAX = 65504.0f;
+
+// The R16_UNORM tables are expanded once (k_expand_luts: texel / 65535.0f, the UNORM decode) so the
+// per-sample cost is four loads, not four correctly rounded divisions.  unorm8[] is the same for /255.
+struct Luts { const float* odE; const float* odAvg; const float* imE; const float* imAvg; const float* ltc; const float* unorm8; };
+
+BRMI_DEV float texel_u16(const float* t, uint32_t i) { return t[i]; }
+BRMI_DEV uint32_t clamp_texel(float f, uint32_t n) { int i = (int)f; i = i < 0 ? 0 : i; i = i > (int)n - 1 ? (int)n - 1 : i; return (uint32_t)i; }
+BRMI_DEV float sample_u16(const float* t, uint32_t W, uint32_t H, float u, float v) {
+    const float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
+    const float x0f = floorf(x), y0f = floorf(y);
+    const float fx = x - x0f, fy = y - y0f;
+    const uint32_t x0 = clamp_texel(x0f, W), x1 = clamp_texel(x0f + 1.0f, W), y0 = clamp_texel(y0f, H), y1 = clamp_texel(y0f + 1.0f, H);
+    const float r0 = lerpf(texel_u16(t, y0 * W + x0), texel_u16(t, y0 * W + x1), fx);
+    const float r1 = lerpf(texel_u16(t, y1 * W + x0), texel_u16(t, y1 * W + x1), fx);
+    return lerpf(r0, r1, fy);
+}
+BRMI_DEV f3 sample_ltc(const float* t, float u, float v) {
+    const float x = u * 32.0f - 0.5f, y = v * 32.0f - 0.5f;
+    const float x0f = floorf(x), y0f = floorf(y);
+    const float fx = x - x0f, fy = y - y0f;
+    const uint32_t x0 = clamp_texel(x0f, 32), x1 = clamp_texel(x0f + 1.0f, 32), y0 = clamp_texel(y0f, 32), y1 = clamp_texel(y0f + 1.0f, 32);
+    auto T = [&](uint32_t yy, uint32_t xx) { const float4 q = *reinterpret_cast<const float4*>(t + ((size_t)yy * 32u + xx) * 4u); return f3{q.x, q.y, q.z}; };
+    return lerp3(lerp3(T(y0, x0), T(y0, x1), fx), lerp3(T(y1, x0), T(y1, x1), fx), fy);
+}
+
+// K11 is checked to 1 fp16 ULP, not bit for bit: outside the direction vectors (N, V, L, H stay on IEEE
+// division / sqrt, 1 - NoH^2 amplifies their error) the BRDF algebra uses the hardware reciprocal and
+// square root (1 ULP, what HLSL `/`, rcp and sqrt compile to on a GPU) instead of the ~11-instruction
+// correctly rounded expansions.
+BRMI_DEV float qdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+BRMI_DEV float qrcp(float b) { return __builtin_amdgcn_rcpf(b); }
+BRMI_DEV float qsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+BRMI_DEV f3 qdiv3(f3 a, f3 b) { return f3{qdiv(a.x, b.x), qdiv(a.y, b.y), qdiv(a.z, b.z)}; }
+
+// ---- PBR.hlsli
+BRMI_DEV void ggx_dir_albedo_AB(float NdotV, float alpha, float& A, float& B) {
+    const float x = NdotV, y = alpha, x2 = x * x, y2 = y * y;
+    const float c0[4] = {0.1003f, 0.9345f, 1.0f, 1.0f}, c1[4] = {-0.6303f, -2.323f, -1.765f, 0.2281f}, c2[4] = {9.748f, 2.229f, 8.263f, 15.94f},
+                c3[4] = {-2.038f, -3.748f, 11.53f, -55.83f}, c4[4] = {29.34f, 1.424f, 28.96f, 13.08f}, c5[4] = {-8.245f, -0.7684f, -7.507f, 41.26f},
+                c6[4] = {-26.44f, 1.436f, -36.11f, 54.9f}, c7[4] = {19.99f, 0.2913f, 15.86f, 300.2f}, c8[4] = {-5.448f, 0.6286f, 33.37f, -285.1f};
+    float r[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        r[i] = c0[i] + c1[i] * x + c2[i] * y + c3[i] * x * y + c4[i] * x2 + c5[i] * y2 + c6[i] * x2 * y + c7[i] * x * y2 + c8[i] * x2 * y2;
+    A = clampf(qdiv(r[0], r[2]), 0.0f, 1.0f); B = clampf(qdiv(r[1], r[3]), 0.0f, 1.0f);
+}
+BRMI_DEV f3 ggx_energy_compensation(float NdotV, float alpha, f3 Fss) {
+    float A, B; ggx_dir_albedo_AB(NdotV, alpha, A, B);
+    const float Ess = (f3{1.0f, 1.0f, 1.0f} * A + f3{1.0f, 1.0f, 1.0f} * B).x;
+    return f3{1.0f, 1.0f, 1.0f} + Fss * (1.0f - Ess) * qrcp(Ess);
+}
+BRMI_DEV f3 f_schlick(f3 f0, float f90, float VoH) {
+    const float pw = powf(1.0f - VoH, 5.0f);
+    return f0 + (f3{f90, f90, f90} - f0) * pw;
+}
+BRMI_DEV float v_smith_ggx(float roughness, float NoV, float NoL) {
+    const float a2 = roughness * roughness;
+    const float lambdaV = NoL * qsqrt((NoV - a2 * NoV) * NoV + a2);
+    const float lambdaL = NoV * qsqrt((NoL - a2 * NoL) * NoL + a2);
+    return min2(qdiv(0.5f, lambdaV + lambdaL), MEDIUMP_MAX);
+}
+BRMI_DEV float d_ggx(float roughness, float NoH) {
+    const float oneMinus = 1.0f - NoH * NoH;
+    const float aa = NoH * roughness;
+    const float k = qdiv(roughness, oneMinus + aa * aa);
+    return min2(k * k * (1.0f / PI_F), MEDIUMP_MAX);
+}
+BRMI_DEV f3 specular_lobe(float roughness, f3 f0, float NoV, float NoL, float NoH, float LoH) {
+    const float D = d_ggx(roughness, NoH), V = v_smith_ggx(roughness, NoV, NoL);
+    const float tmp = 50.0f * 0.33f;
+    const float f90 = sat(dot3(f0, f3{tmp, tmp, tmp}));
+    return (D * V) * f_schlick(f0, f90, LoH);
+}
+
+// ---- IBL.hlsli (OpenPBR)
+constexpr float TBL = 32.0f, TBL_M1 = 31.0f, IOR_MAX = 2.5f, INV_IOR_MAX = 1.0f / 2.5f;
+BRMI_DEV float fon_a() { return 0.5f - 2.0f / (3.0f * PI_F); }
+BRMI_DEV float fon_b() { return 2.0f / 3.0f - 28.0f / (15.0f * PI_F); }
+BRMI_DEV float ior_to_index(float ior) {
+    const float safeIor = max2(ior, 1.0e-4f);
+    const float half = 0.5f * TBL, halfM1 = half - 1.0f, inv = 1.0f / (IOR_MAX - 1.0f);
+    if (safeIor < 1.0f) { const float invIor = 1.0f / safeIor; const float fr = (invIor - 1.0f) * inv; return halfM1 - fr * halfM1; }
+    const float fr = (safeIor - 1.0f) * inv;
+    return half + fr * halfM1;
+}
+BRMI_DEV float alpha_to_index(float alpha) { return qsqrt(sat(alpha)) * TBL_M1; }
+BRMI_DEV float cos_to_index(float c) { return sat(c) * TBL_M1; }
+BRMI_DEV float clamp_index(float e) { return clampf(e, 0.0f, TBL_M1); }
+BRMI_DEV float remap_index(float e) { const float inv = 1.0f / TBL; const float mn = 0.5f * inv, mx = 1.0f - mn; return clampf(mn + e * inv, mn, mx); }
+BRMI_DEV float extrapolate_ior(float tableValue, float ior) {
+    if (ior > IOR_MAX || ior < INV_IOR_MAX) {
+        const float f0Max = ior_to_f0(IOR_MAX);
+        const float invRange = 1.0f / (1.0f - f0Max);
+        const float f0 = ior_to_f0(max2(ior, 1.0e-4f));
+        const float progress = (f0 - f0Max) * invRange;
+        return (1.0f - progress) * tableValue;
+    }
+    return tableValue;
+}
+BRMI_DEV float fresnel_dielectric(float eta, float cosI) {
+    const float c = sat(cosI);
+    if (fabsf(eta - 1.0f) <= 1.0e-6f) return 0.0f;
+    const float s2 = max2(0.0f, 1.0f - c * c);
+    const float st2 = s2 / max2(eta * eta, 1.0e-6f);
+    if (st2 >= 1.0f) return 1.0f;
+    const float ct = sqrtf(max2(0.0f, 1.0f - st2));
+    const float eci = eta * c, ect = eta * ct;
+    const float rs = (c - ect) / max2(c + ect, 1.0e-6f);
+    const float rp = (ct - eci) / max2(ct + eci, 1.0e-6f);
+    return 0.5f * (rs * rs + rp * rp);
+}
+BRMI_DEV float lut_od_avg(const Luts& L, float ior, float alpha) {
+    const float ei = clamp_index(ior_to_index(ior)), ea = clamp_index(alpha_to_index(alpha));
+    return extrapolate_ior(sample_u16(L.odAvg, 32, 32, remap_index(ea), remap_index(ei)), ior);
+}
+BRMI_DEV float lut_od_e(const Luts& L, float ior, float alpha, float cosT) {
+    const float ei = clamp_index(ior_to_index(ior)), ea = clamp_index(alpha_to_index(alpha)), ec = clamp_index(cos_to_index(cosT));
+    const int s0 = (int)floorf(ei);
+    const int s1 = (s0 + 1) < 31 ? (s0 + 1) : 31;
+    const float st = ei - (float)s0;
+    const float u = remap_index(ec), v = remap_index(ea);
+    const float v0 = sample_u16(L.odE + (size_t)s0 * 1024u, 32, 32, u, v), v1 = sample_u16(L.odE + (size_t)s1 * 1024u, 32, 32, u, v);
+    return extrapolate_ior(lerpf(v0, v1, st), ior);
+}
+BRMI_DEV float lut_im_e(const Luts& L, float alpha, float cosT) {
+    const float ea = clamp_index(alpha_to_index(alpha)), ec = clamp_index(cos_to_index(cosT));
+    return sample_u16(L.imE, 32, 32, remap_index(ec), remap_index(ea));
+}
+BRMI_DEV float lut_im_avg(const Luts& L, float alpha) {
+    const float ea = clamp_index(alpha_to_index(alpha));
+    return sample_u16(L.imAvg, 32, 1, remap_index(ea), 0.5f);
+}
+BRMI_DEV f3 lut_fuzz_ltc(const Luts& L, float roughness, float cosT) {
+    const float u = sat(cosT) * (31.0f / 32.0f) + 0.5f / 32.0f, v = sat(roughness) * (31.0f / 32.0f) + 0.5f / 32.0f;
+    return sample_ltc(L.ltc, u, v);
+}
+// Bilinear fetch with the row (v) part prepared once: identical arithmetic to sample_u16, split in two.
+// Rows are 32-bit offsets into the expanded-table buffer (one SGPR base + VGPR offset per load) rather than 64-bit pointers.
+struct LutRows { uint32_t r0, r1; float fy; };
+BRMI_DEV LutRows prep_rows(uint32_t tableOffset, uint32_t H, float v) {
+    const float y = v * (float)H - 0.5f;
+    const float y0f = floorf(y);
+    return LutRows{tableOffset + clamp_texel(y0f, H) * 32u, tableOffset + clamp_texel(y0f + 1.0f, H) * 32u, y - y0f};
+}
+BRMI_DEV float sample_rows(const float* lut, const LutRows& r, float u) {
+    const float x = u * 32.0f - 0.5f;
+    const float x0f = floorf(x);
+    const float fx = x - x0f;
+    const uint32_t x0 = clamp_texel(x0f, 32), x1 = clamp_texel(x0f + 1.0f, 32);
+    return lerpf(lerpf(lut[r.r0 + x0], lut[r.r0 + x1], fx), lerpf(lut[r.r1 + x0], lut[r.r1 + x1], fx), r.fy);
+}
+// lut_od_e with (ior, alpha) prepared
+struct OdPrep { LutRows s0, s1; float st, ior; };
+BRMI_DEV OdPrep prep_od_e(const Luts& L, float ior, float alpha) {
+    const float ei = clamp_index(ior_to_index(ior)), ea = clamp_index(alpha_to_index(alpha));
+    const int s0 = (int)floorf(ei);
+    const int s1 = (s0 + 1) < 31 ? (s0 + 1) : 31;
+    const float v = remap_index(ea);
+    return OdPrep{prep_rows((uint32_t)s0 * 1024u, 32, v), prep_rows((uint32_t)s1 * 1024u, 32, v), ei - (float)s0, ior};      // odE starts the buffer
+}
+BRMI_DEV float sample_od_e(const Luts& L, const OdPrep& p, float cosT) {
+    const float u = remap_index(clamp_index(cos_to_index(cosT)));
+    return extrapolate_ior(lerpf(sample_rows(L.odE, p.s0, u), sample_rows(L.odE, p.s1, u), p.st), p.ior);
+}
+BRMI_DEV LutRows prep_im_e(const Luts& L, float alpha) { return prep_rows((uint32_t)(L.imE - L.odE), 32, remap_index(clamp_index(alpha_to_index(alpha)))); }
+BRMI_DEV float sample_im_e(const Luts& L, const LutRows& r, float cosT) { return sample_rows(L.odE, r, remap_index(clamp_index(cos_to_index(cosT)))); }
+BRMI_DEV float average_fresnel(float eta) {
+    const float s = max2(eta, 1.0e-4f);
+    if (s > 1.0f) return (s - 1.0f) / (4.08567f + 1.00071f * s);
+    const float s2 = s * s;
+    return 0.997118f + 0.1014f * s - 0.965241f * s2 - 0.130607f * s2 * s;
+}
+
+
+// What make_pixel_ctx needs from (OpenPBR material, 8-bit perceptual roughness code) alone: the prepared rows of the opaque-dielectric
+// and ideal-metal energy tables and the two table averages.  Built once per frame for every (material, code) pair with the functions
+// above (k_frame_constants), read with four 16 B loads per pixel instead of ~140 instructions and 8 table fetches.
+struct ShadeMaterialEntry { OdPrep od; LutRows im; float avgComp, mAvgClamped; uint32_t pad[3]; };
+static_assert(sizeof(ShadeMaterialEntry) == 64, "one cache line");
+
+}  // namespace brmi
+#endif
