@@ -253,6 +253,46 @@ int brmi_set_scene(brmi_pass* p, const brmi_scene_buffers* scene) {
         if (p->sceneHasTextures && (!sc.textures || !sc.samplers || !sc.srgbToLinear || sc.textureCount == 0 || sc.samplerCount == 0))
             return fail(p, BRMI_ERR_INVALID, "brmi_set_scene: materials sample textures but the texture / sampler tables or the sRGB decode table are missing");
     }
+    {   // Cross references the kernels follow unchecked: validated once here, on the host copies (a bad index is an error message, not a
+        // GPU fault).  Page contents (headers, descriptors, streams inside the slabs) are NOT walked: they are the builder's contract.
+        std::vector<brmi_per_mesh_instance> insts; std::vector<uint32_t> draws; std::vector<brmi_per_mesh> pms; std::vector<brmi_material_info> mats;
+        std::vector<brmi_group_page_map_entry> pmap; std::vector<brmi_lod_group> groups; std::vector<brmi_per_object> objs;
+        if ((rc = read_back(p, insts, sc.perMeshInstance, sc.perMeshInstanceCount))) return rc;
+        if ((rc = read_back(p, draws, sc.activeDraws, sc.activeDrawCount))) return rc;
+        if ((rc = read_back(p, pms, sc.perMesh, sc.perMeshCount))) return rc;
+        if ((rc = read_back(p, mats, sc.materials, sc.materialCount))) return rc;
+        if ((rc = read_back(p, pmap, sc.groupPageMap, sc.groupPageMapCount))) return rc;
+        if ((rc = read_back(p, groups, sc.lodGroups, sc.lodGroupCount))) return rc;
+        if ((rc = read_back(p, objs, sc.perObject, sc.perObjectCount))) return rc;
+        for (size_t i = 0; i < draws.size(); i++) if (draws[i] >= insts.size()) return fail(p, BRMI_ERR_INVALID, "activeDraws[%zu] = %u: no such mesh instance", i, draws[i]);
+        for (size_t i = 0; i < insts.size(); i++) {
+            if (insts[i].perMeshBufferIndex >= pms.size()) return fail(p, BRMI_ERR_INVALID, "mesh instance %zu: perMeshBufferIndex %u out of range", i, insts[i].perMeshBufferIndex);
+            if (insts[i].perObjectBufferIndex >= sc.perObjectCount) return fail(p, BRMI_ERR_INVALID, "mesh instance %zu: perObjectBufferIndex %u out of range", i, insts[i].perObjectBufferIndex);
+            if ((pms[insts[i].perMeshBufferIndex].vertexFlags & BRMI_VERTEX_SKINNED) && insts[i].skinningInstanceSlot != 0xFFFFFFFFu &&
+                ((uint64_t)insts[i].skinningInstanceSlot + 1u) * 64u > sc.skinningMatrixCount)
+                return fail(p, BRMI_ERR_INVALID, "mesh instance %zu: skinning slot %u lies outside the skinning matrix buffer", i, insts[i].skinningInstanceSlot);
+        }
+        for (size_t i = 0; i < pms.size(); i++) if (pms[i].materialDataIndex >= mats.size()) return fail(p, BRMI_ERR_INVALID, "mesh %zu: materialDataIndex %u out of range", i, pms[i].materialDataIndex);
+        for (size_t i = 0; i < mats.size(); i++) if (mats[i].openPBRMaterialDataIndex >= sc.openpbrMaterialCount) return fail(p, BRMI_ERR_INVALID, "material %zu: openPBRMaterialDataIndex %u out of range", i, mats[i].openPBRMaterialDataIndex);
+        for (size_t i = 0; i < pmap.size(); i++) {
+            if (pmap[i].slabDescriptorIndex >= sc.slabCount) return fail(p, BRMI_ERR_INVALID, "page map entry %zu: slab %u out of range", i, pmap[i].slabDescriptorIndex);
+            if (pmap[i].slabByteOffset % BRMI_PAGE_SIZE) return fail(p, BRMI_ERR_INVALID, "page map entry %zu: offset %u is not a page boundary", i, pmap[i].slabByteOffset);
+        }
+        for (size_t m = 0; m < md.size(); m++) if (md[m].groupsBase > groups.size() || md[m].segmentsBase > segs.size() || md[m].pageMapBase > pmap.size()) return fail(p, BRMI_ERR_INVALID, "mesh metadata %zu: base index out of range", m);
+        for (size_t i = 0; i < offs.size(); i++) if (offs[i].clodMeshMetadataIndex >= md.size()) return fail(p, BRMI_ERR_INVALID, "instance %zu: bad mesh metadata index", i);
+        // segments -> pages and refined groups, relative to the mesh that owns them (a mesh's segments end where the next mesh's begin)
+        std::vector<uint32_t> order(md.size());
+        for (size_t m = 0; m < md.size(); m++) order[m] = (uint32_t)m;
+        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return md[a].segmentsBase < md[b].segmentsBase; });
+        for (size_t k = 0; k < order.size(); k++) {
+            const brmi_clod_mesh_metadata& mm = md[order[k]];
+            const size_t segEnd = k + 1 < order.size() ? md[order[k + 1]].segmentsBase : segs.size();
+            for (size_t si = mm.segmentsBase; si < segEnd; si++) {
+                if ((uint64_t)mm.pageMapBase + segs[si].pageIndex >= pmap.size()) return fail(p, BRMI_ERR_INVALID, "segment %zu: page %u lies outside the group page map", si, segs[si].pageIndex);
+                if (segs[si].refinedGroup >= 0 && (uint64_t)mm.groupsBase + (uint32_t)segs[si].refinedGroup >= groups.size()) return fail(p, BRMI_ERR_INVALID, "segment %zu: refined group %d out of range", si, segs[si].refinedGroup);
+            }
+        }
+    }
     // per mesh: walk the BVH, collect the segments its leaves reference, depth of the tree
     p->hostSegPrefix.assign(segs.size(), 0);
     std::vector<uint32_t> meshBits(md.size(), 0);
