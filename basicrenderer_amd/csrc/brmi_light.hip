@@ -489,8 +489,11 @@ BRMI_DEV RawPixel empty_raw_pixel() { RawPixel r{}; r.d = as_f32(BRMI_DEPTH_EMPT
 // what the specialised kernel keeps in flight for the next tile: coat / fuzz words reduced to the coat weight
 BRMI_DEV RawPixel load_raw_pixel_plain(const ShadeArgs& a, uint64_t i) {
     RawPixel r;
-    r.d = a.depth[i]; r.ns = a.normals[i]; r.al = a.albedo[i]; r.mr = a.metallicRoughness[i]; r.es = a.emissive[i];
-    r.cs = (unsigned long long)reinterpret_cast<const uint16_t*>(a.coat)[i * 4u + 3u] << 48; r.fs = 0ull;   // coat weight only (a plain pixel has no other coat / fuzz input)
+    // read once: streaming loads
+    r.d = __builtin_nontemporal_load(&a.depth[i]);
+    r.ns = make_float4(__builtin_nontemporal_load(&a.normals[i].x), __builtin_nontemporal_load(&a.normals[i].y), __builtin_nontemporal_load(&a.normals[i].z), __builtin_nontemporal_load(&a.normals[i].w));
+    r.al = __builtin_nontemporal_load(&a.albedo[i]); r.mr = __builtin_nontemporal_load(&a.metallicRoughness[i]); r.es = __builtin_nontemporal_load(&a.emissive[i]);
+    r.cs = (unsigned long long)__builtin_nontemporal_load(&reinterpret_cast<const uint16_t*>(a.coat)[i * 4u + 3u]) << 48; r.fs = 0ull;   // coat weight only (a plain pixel has no other coat / fuzz input)
     return r;
 }
 
@@ -648,7 +651,7 @@ BRMI_DEV uint32_t shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const flo
             const f3 coatT = (MODE & 1) ? coat_scale_incoming(L, ctx.coat, f.NdotV) : f3{1.0f, 1.0f, 1.0f};
             lighting = lighting + f.emissive * f3{fuzzBase, fuzzBase, fuzzBase} * coatT;
         }
-        a.hdr[i] = pack_half4(lighting.x, lighting.y, lighting.z, 1.0f);
+        __builtin_nontemporal_store((unsigned long long)pack_half4(lighting.x, lighting.y, lighting.z, 1.0f), &a.hdr[i]);
         return 0u;
 }
 

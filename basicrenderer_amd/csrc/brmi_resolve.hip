@@ -229,14 +229,14 @@ __global__ void __launch_bounds__(256, INLINE_TABLES ? 1 : (TEXTURED ? BRMI_GBT_
     uint64_t j0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t npx = 0, npy = 0;
     bool nvalid = j0 < end && pixel_of(j0, npx, npy);
-    unsigned long long nkey = nvalid ? a.vis[a.firstPixel + j0] : BRMI_VIS_EMPTY;
+    unsigned long long nkey = nvalid ? __builtin_nontemporal_load(&a.vis[a.firstPixel + j0]) : BRMI_VIS_EMPTY;
     for (uint64_t j = j0; j < end; j += stride) {
         const uint64_t i = a.firstPixel + j;
         const uint32_t px = npx, py = npy;
         bool valid = nvalid;
         const unsigned long long key = nkey;
-        if (j + stride < end) { nvalid = pixel_of(j + stride, npx, npy); nkey = nvalid ? a.vis[a.firstPixel + j + stride] : BRMI_VIS_EMPTY; }
-        if (valid && a.depth) a.depth[i] = (key == BRMI_VIS_EMPTY) ? as_f32(BRMI_DEPTH_EMPTY_BITS) : as_f32(((uint32_t)(key >> BRMI_VIS_META_BITS)) << 1);
+        if (j + stride < end) { nvalid = pixel_of(j + stride, npx, npy); nkey = nvalid ? __builtin_nontemporal_load(&a.vis[a.firstPixel + j + stride]) : BRMI_VIS_EMPTY; }
+        if (valid && a.depth) __builtin_nontemporal_store((key == BRMI_VIS_EMPTY) ? as_f32(BRMI_DEPTH_EMPTY_BITS) : as_f32(((uint32_t)(key >> BRMI_VIS_META_BITS)) << 1), &a.depth[i]);
         const uint32_t triId = (uint32_t)(key & 0x7Full);
         const uint32_t clusterIndex = (uint32_t)((key >> BRMI_VIS_TRI_BITS) & 0x3FFFFFFull);
         valid = valid && key != BRMI_VIS_EMPTY && clusterIndex < clusterCount;
@@ -366,13 +366,16 @@ __global__ void __launch_bounds__(256, INLINE_TABLES ? 1 : (TEXTURED ? BRMI_GBT_
                     mrW = (pack_unorm4(metallic, roughness, 0.0f, 0.0f) & 0xFFFFu) | (mrW & 0xFFFF0000u);       // coat roughness / fuzz weight stay the material's
                 }
             }
-            a.normals[i] = make_float4(normalWS.x, normalWS.y, normalWS.z, mw->opIndexF);
-            a.albedo[i] = albedoW;
-            a.coat[i] = mw->coat;
-            a.emissive[i] = emissiveW;
-            a.fuzz[i] = mw->fuzz;
-            a.metallicRoughness[i] = mrW;
-            a.motion[i] = f32_to_f16_bits(mvx) | (f32_to_f16_bits(mvy) << 16);
+            // streaming stores: 52 B per pixel written once and read once by the shading pass; keeping them out of the caches
+            // leaves L2 / the memory-side cache to the vertex tables, the keys and the shading pass's own reads (0.149 -> 0.123 ms,
+            // and 0.339 -> 0.324 ms for k_shade)
+            { float4 nv = make_float4(normalWS.x, normalWS.y, normalWS.z, mw->opIndexF); __builtin_nontemporal_store(nv.x, &a.normals[i].x); __builtin_nontemporal_store(nv.y, &a.normals[i].y); __builtin_nontemporal_store(nv.z, &a.normals[i].z); __builtin_nontemporal_store(nv.w, &a.normals[i].w); }
+            __builtin_nontemporal_store(albedoW, &a.albedo[i]);
+            __builtin_nontemporal_store((unsigned long long)mw->coat, &a.coat[i]);
+            __builtin_nontemporal_store(emissiveW, &a.emissive[i]);
+            __builtin_nontemporal_store((unsigned long long)mw->fuzz, &a.fuzz[i]);
+            __builtin_nontemporal_store(mrW, &a.metallicRoughness[i]);
+            __builtin_nontemporal_store((uint32_t)(f32_to_f16_bits(mvx) | (f32_to_f16_bits(mvy) << 16)), &a.motion[i]);
         };
         // waterfall over the distinct mesh instances of the tile (usually one or two)
         uint64_t pending = __ballot(valid);
