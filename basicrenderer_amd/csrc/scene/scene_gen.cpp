@@ -1183,6 +1183,10 @@ void addMaterials(brmi_scene& sc, Pcg32& rng, uint32_t count) {
             o.fuzzColor[0] = rng.range(0.3f, 1.0f); o.fuzzColor[1] = rng.range(0.3f, 1.0f); o.fuzzColor[2] = rng.range(0.3f, 1.0f);
         }
         o.thinFilmIor = 1.4f; o.emissionLuminance = 0.0f; o.geometryOpacity = 1.0f;
+        // coat / fuzz texture + sampler indices (words 0-11 of the binding tail): OPENPBR_INVALID_TEXTURE_INDEX = no texture (utilities.hlsli:641-646);
+        // colour channels 0,1,2,3 as the reference's defaults
+        for (int k = 0; k < 12; k++) o.textureBindings[k] = 0xFFFFFFFFu;
+        for (int k = 0; k < 4; k++) { o.textureBindings[12 + k] = (uint32_t)k; o.textureBindings[19 + k] = (uint32_t)k; }
         sc.openpbr.push_back(o);
     }
 }

@@ -379,7 +379,9 @@ typedef struct brmi_openpbr_material_info {
     float    emissionColor[3];
     float    geometryOpacity;
     uint32_t geometryThinWalled, pad0, pad1, pad2;
-    uint32_t textureBindings[38];   /* coat/fuzz texture+sampler indices, channels, uv sets, streaming ids */
+    uint32_t textureBindings[38];   /* [0..11] coat colour / weight / roughness, fuzz colour / weight / roughness: (texture, sampler) index pairs,
+                                       0xFFFFFFFF = none (OPENPBR_INVALID_TEXTURE_INDEX, utilities.hlsli:641); [12..18] coat colour channels x4, weight
+                                       channel, roughness channel, pad; [19..25] the same for fuzz; [26..31] UV set per slot; [32..37] streaming ids */
 } brmi_openpbr_material_info;               /* 400 B */
 
 /* ---- textures and samplers ---------------------------------------------------------------

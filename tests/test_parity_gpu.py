@@ -320,6 +320,11 @@ def test_unsupported_material_bindings_are_refused():
     m[0, 0] |= 1 << 9                                                # MATERIAL_PARALLAX
     with pytest.raises(BrmiError, match="PARALLAX"):
         VisibilityRenderer(sc)
+    sc = scene()
+    op = sc.arrays["openpbrMaterials"].view(np.uint32).reshape(-1, 100)
+    op[0, 62:64] = 0                                                 # coatColorTextureIndex / SamplerIndex = 0: a bound OpenPBR layer texture
+    with pytest.raises(BrmiError, match="OpenPBR layer textures"):
+        VisibilityRenderer(sc)
     VisibilityRenderer(scene()).close()                              # the untouched scene is accepted
 
 
