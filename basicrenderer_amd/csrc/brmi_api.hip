@@ -227,21 +227,23 @@ int brmi_set_scene(brmi_pass* p, const brmi_scene_buffers* scene) {
         std::vector<brmi_openpbr_material_info> op;
         if ((rc = read_back(p, op, sc.openpbrMaterials, sc.openpbrMaterialCount))) return rc;
         p->sceneHasCoat = p->sceneHasFuzz = false;
+        bool layerTextures = false;
         for (size_t i = 0; i < op.size(); i++) {
             const auto& m = op[i];
             if (m.coatWeight > 0.0f) p->sceneHasCoat = true;
             if (m.fuzzWeight > 0.0f) p->sceneHasFuzz = true;
-            // HasOpenPBRTexture (utilities.hlsli:643-646): a coat / fuzz slot with a valid texture AND sampler index is sampled by the reference;
-            // this path evaluates those six slots from their factors only, so such a material is refused rather than rendered differently
+            // HasOpenPBRTexture (utilities.hlsli:643-646): a coat / fuzz slot with a valid texture AND sampler index is sampled
             for (int k = 0; k < 6; k++)
-                if (m.textureBindings[2 * k] != 0xFFFFFFFFu && m.textureBindings[2 * k + 1] != 0xFFFFFFFFu)
-                    return fail(p, BRMI_ERR_INVALID, "OpenPBR material %zu: coat / fuzz texture slot %d is bound (texture %u); OpenPBR layer textures are not supported by this path", i, k, m.textureBindings[2 * k]);
+                if (m.textureBindings[2 * k] != 0xFFFFFFFFu && m.textureBindings[2 * k + 1] != 0xFFFFFFFFu) {
+                    layerTextures = true;
+                    if (m.textureBindings[26 + k] != 0u) return fail(p, BRMI_ERR_INVALID, "OpenPBR material %zu: coat / fuzz texture slot %d must use UV set 0 (only set 0 is decoded on this path)", i, k);
+                }
         }
         // texture slots: the alpha-test variants of the rasteriser and the texture-sampling variant of the G-buffer pass are only
         // launched for scenes that need them
         std::vector<brmi_material_info> mats;
         if ((rc = read_back(p, mats, sc.materials, sc.materialCount))) return rc;
-        p->sceneHasAlphaTest = p->sceneHasTextures = false;
+        p->sceneHasAlphaTest = false; p->sceneHasTextures = layerTextures;
         for (size_t i = 0; i < mats.size(); i++) {
             const brmi_material_info& m = mats[i];
             if (m.materialFlags & (1u << 9)) return fail(p, BRMI_ERR_INVALID, "material %zu: MATERIAL_PARALLAX (height maps) is not supported by this path", i);

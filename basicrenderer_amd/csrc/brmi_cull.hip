@@ -776,7 +776,8 @@ __global__ void __launch_bounds__(256) k_scatter_visible(const TempVisible* temp
                       | ((hdr->attributeMask & BRMI_PAGE_ATTRIBUTE_WEIGHTS) ? BRMI_CS_WEIGHTS : 0u);
             if (clusterUv) {      // scenes with textured / alpha-tested materials: UV set 0 of the meshlet and the material's class
                 const uint32_t mflags = sc.materials[pm->materialDataIndex].materialFlags;
-                cs.counts |= ((mflags & BRMI_MATERIAL_ALPHA_TEST) ? BRMI_CS_ALPHA : 0u) | ((mflags & BRMI_MATERIAL_ANY_TEXTURE) ? BRMI_CS_TEXTURED : 0u);
+                const bool layerTextures = openpbr_has_textures(sc.openpbrMaterials + sc.materials[pm->materialDataIndex].openPBRMaterialDataIndex);
+                cs.counts |= ((mflags & BRMI_MATERIAL_ALPHA_TEST) ? BRMI_CS_ALPHA : 0u) | (((mflags & BRMI_MATERIAL_ANY_TEXTURE) || layerTextures) ? BRMI_CS_TEXTURED : 0u);
                 ClusterUv cu{nullptr, nullptr, nullptr, 0ull};
                 if (hdr->attributeMask & BRMI_PAGE_ATTRIBUTE_COLOR) { cs.counts |= BRMI_CS_COLOR; cu.color = slab + pageOff + hdr->colorArrayOffset + desc->vertexAttributeOffset * 4u; }
                 if (hdr->uvSetCount != 0u) {

@@ -196,6 +196,13 @@ BRMI_DEV uint32_t cluster_slice_exact(float z, float zNear, float zSplit, float 
 // Read-only data produced by an earlier kernel, viewed through the constant address space: with a wave-uniform address
 // the compiler then selects scalar (s_load) instead of vector loads.
 template <typename T> BRMI_DEV const __attribute__((address_space(4))) T* kconst(const T* p) { return (const __attribute__((address_space(4))) T*)p; }
+// HasOpenPBRTexture (utilities.hlsli:643-646) for any of the six coat / fuzz slots of an OpenPBR record
+template <typename Op> BRMI_DEV bool openpbr_has_textures(Op op) {
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < 6; k++) any = any || (op->textureBindings[2 * k] != 0xFFFFFFFFu && op->textureBindings[2 * k + 1] != 0xFFFFFFFFu);
+    return any;
+}
 // `p` in the address space of `like`: tables indexed by fields of a record take the scalar path when the record does
 template <typename L, typename T> BRMI_DEV const T* as_space_of(const L*, const T* p) { return p; }
 template <typename L, typename T> BRMI_DEV const __attribute__((address_space(4))) T* as_space_of(const __attribute__((address_space(4))) L*, const T* p) { return kconst(p); }

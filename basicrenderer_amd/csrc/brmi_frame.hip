@@ -70,7 +70,7 @@ BRMI_DEV void job_material_words(const brmi_scene_buffers& sc, MaterialWords* ou
     w.coat = pack_half4(coatColor.x, coatColor.y, coatColor.z, coatWeight);
     w.emissive = pack_half4(emissive.x, emissive.y, emissive.z, 0.0f);
     w.fuzz = pack_half4(fuzzColor.x, fuzzColor.y, fuzzColor.z, fuzzRoughness);
-    w.opIndexF = (float)opIndex; w.pad = 0u;
+    w.opIndexF = (float)opIndex; w.pad = openpbr_has_textures(op) ? 1u : 0u;        // bit 0: the OpenPBR record binds coat / fuzz textures
     out[i] = w;
 }
 

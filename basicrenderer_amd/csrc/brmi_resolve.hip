@@ -289,7 +289,7 @@ __global__ void __launch_bounds__(256, INLINE_TABLES ? 1 : (TEXTURED ? BRMI_GBT_
             const f4 clipPrev = mul_point(prevWorld, prevVP);
             const float mvx = clipCur.x / clipCur.w - clipPrev.x / clipPrev.w, mvy = clipCur.y / clipCur.w - clipPrev.y / clipPrev.w;
             uint32_t albedoW = mw->albedo, mrW = mw->metallicRoughness;
-            unsigned long long emissiveW = mw->emissive;
+            unsigned long long emissiveW = mw->emissive, coatW = mw->coat, fuzzW = mw->fuzz;
             f3 normalWS = worldNormal;
             if (TEXTURED) {
                 const uint32_t flags = mat->materialFlags;
@@ -300,7 +300,8 @@ __global__ void __launch_bounds__(256, INLINE_TABLES ? 1 : (TEXTURED ? BRMI_GBT_
                                               dot3(f3{tb.t[(vc[0] >> 16) & 0xFFu], tb.t[(vc[1] >> 16) & 0xFFu], tb.t[(vc[2] >> 16) & 0xFFu]}, l)};
                 if (!(flags & BRMI_MATERIAL_ANY_TEXTURE) && colored)
                     albedoW = pack_unorm4(mat->baseColorFactor[0] * vertexColor.x, mat->baseColorFactor[1] * vertexColor.y, mat->baseColorFactor[2] * vertexColor.z, 1.0f);
-                if (flags & BRMI_MATERIAL_ANY_TEXTURE) {
+                const bool layerTex = (mw->pad & 1u) != 0u;
+                if ((flags & BRMI_MATERIAL_ANY_TEXTURE) || layerTex) {
                     // BuildClodMaterialUvData for UV set 0 + SampleMaterialEvalFromUvCache (utilities.hlsli:1850-2075)
                     const BaryDeriv bd = bary_derivatives(r, l, ndcX, ndcY, winX, winY);
                     const f3 us{tc[0].x, tc[1].x, tc[2].x}, vs{tc[0].y, tc[1].y, tc[2].y};
@@ -311,11 +312,19 @@ __global__ void __launch_bounds__(256, INLINE_TABLES ? 1 : (TEXTURED ? BRMI_GBT_
                     // One loop over the texture slots (one copy of the sampler code).  Metallic, roughness and occlusion usually are
                     // channels of ONE texture (glTF packing): a slot bound like the previous one reuses its fetch.
                     f4 sBase{1.0f, 1.0f, 1.0f, 1.0f}, sMetal{}, sRough{}, sAo{}, sNormal{}, sEmis{};
+                    const f4 one4{1.0f, 1.0f, 1.0f, 1.0f};
+                    f4 sL0 = one4, sL1 = one4, sL2 = one4, sL3 = one4, sL4 = one4, sL5 = one4;     // coat colour / weight / roughness, fuzz colour / weight / roughness
+                    const auto* opRec = as_space_of(mat, sc.openpbrMaterials) + mat->openPBRMaterialDataIndex;
                     {
                         TexBinding prev{}; f4 prevSample{};
 #pragma nounroll
-                        for (uint32_t slot = 0; slot < 6u; slot++) {
+                        for (uint32_t slot = 0; slot < (layerTex ? 12u : 6u); slot++) {
                             uint32_t bit, ti, si;
+                            if (slot >= 6u) {       // ApplyOpenPBRTextureSampling (utilities.hlsli:720-846): bound when both indices are valid
+                                ti = opRec->textureBindings[2u * (slot - 6u)]; si = opRec->textureBindings[2u * (slot - 6u) + 1u];
+                                if (ti == 0xFFFFFFFFu || si == 0xFFFFFFFFu) continue;
+                                bit = 0u;
+                            } else
                             switch (slot) {
                                 case 0: bit = BRMI_MATERIAL_BASE_COLOR_TEXTURE; ti = mat->baseColorTextureIndex; si = mat->baseColorSamplerIndex; break;
                                 case 1: bit = BRMI_MATERIAL_METALLIC_TEXTURE; ti = mat->metallicTextureIndex; si = mat->metallicSamplerIndex; break;
@@ -324,11 +333,12 @@ __global__ void __launch_bounds__(256, INLINE_TABLES ? 1 : (TEXTURED ? BRMI_GBT_
                                 case 4: bit = BRMI_MATERIAL_NORMAL_MAP; ti = mat->normalTextureIndex; si = mat->normalSamplerIndex; break;
                                 default: bit = BRMI_MATERIAL_EMISSIVE_TEXTURE; ti = mat->emissiveTextureIndex; si = mat->emissiveSamplerIndex; break;
                             }
-                            if (!(flags & bit)) continue;
+                            if (slot < 6u && !(flags & bit)) continue;
                             const TexBinding bnd = bind(ti, si);
                             const f4 t = same_binding(prev, bnd) ? prevSample : sample_grad(tb, bnd, uv, dUVdx, dUVdy);
                             prev = bnd; prevSample = t;
-                            if (slot == 0u) sBase = t; else if (slot == 1u) sMetal = t; else if (slot == 2u) sRough = t; else if (slot == 3u) sAo = t; else if (slot == 4u) sNormal = t; else sEmis = t;
+                            if (slot == 0u) sBase = t; else if (slot == 1u) sMetal = t; else if (slot == 2u) sRough = t; else if (slot == 3u) sAo = t; else if (slot == 4u) sNormal = t; else if (slot == 5u) sEmis = t;
+                            else if (slot == 6u) sL0 = t; else if (slot == 7u) sL1 = t; else if (slot == 8u) sL2 = t; else if (slot == 9u) sL3 = t; else if (slot == 10u) sL4 = t; else sL5 = t;
                         }
                     }
                     f4 baseColor{mat->baseColorFactor[0], mat->baseColorFactor[1], mat->baseColorFactor[2], mat->baseColorFactor[3]};
@@ -364,6 +374,17 @@ __global__ void __launch_bounds__(256, INLINE_TABLES ? 1 : (TEXTURED ? BRMI_GBT_
                     }
                     albedoW = pack_unorm4(baseColor.x * vertexColor.x, baseColor.y * vertexColor.y, baseColor.z * vertexColor.z, ao);
                     mrW = (pack_unorm4(metallic, roughness, 0.0f, 0.0f) & 0xFFFFu) | (mrW & 0xFFFF0000u);       // coat roughness / fuzz weight stay the material's
+                    if (layerTex) {
+                        // surface.x = saturate(record.x) [ResolveCanonicalOpenPBRSurface]; x *= sample (1 when the slot is unbound); x = saturate(x)
+                        auto tbw = [&](uint32_t w) { return opRec->textureBindings[w]; };
+                        const f3 cc = sat3(sat3(f3{opRec->coatColor[0], opRec->coatColor[1], opRec->coatColor[2]}) * f3{swizzle4(sL0, tbw(12)), swizzle4(sL0, tbw(13)), swizzle4(sL0, tbw(14))});
+                        const float cw = sat(sat(opRec->coatWeight) * swizzle4(sL1, tbw(16))), cr = sat(sat(opRec->coatRoughness) * swizzle4(sL2, tbw(17)));
+                        const f3 fc = sat3(sat3(f3{opRec->fuzzColor[0], opRec->fuzzColor[1], opRec->fuzzColor[2]}) * f3{swizzle4(sL3, tbw(19)), swizzle4(sL3, tbw(20)), swizzle4(sL3, tbw(21))});
+                        const float fw = sat(sat(opRec->fuzzWeight) * swizzle4(sL4, tbw(23))), fr = sat(sat(opRec->fuzzRoughness) * swizzle4(sL5, tbw(24)));
+                        coatW = pack_half4(cc.x, cc.y, cc.z, cw);
+                        fuzzW = pack_half4(fc.x, fc.y, fc.z, fr);
+                        mrW = (mrW & 0xFFFFu) | (pack_unorm4(0.0f, 0.0f, cr, fw) & 0xFFFF0000u);
+                    }
                 }
             }
             // streaming stores: 52 B per pixel written once and read once by the shading pass; keeping them out of the caches
@@ -371,9 +392,9 @@ __global__ void __launch_bounds__(256, INLINE_TABLES ? 1 : (TEXTURED ? BRMI_GBT_
             // and 0.339 -> 0.324 ms for k_shade)
             { float4 nv = make_float4(normalWS.x, normalWS.y, normalWS.z, mw->opIndexF); __builtin_nontemporal_store(nv.x, &a.normals[i].x); __builtin_nontemporal_store(nv.y, &a.normals[i].y); __builtin_nontemporal_store(nv.z, &a.normals[i].z); __builtin_nontemporal_store(nv.w, &a.normals[i].w); }
             __builtin_nontemporal_store(albedoW, &a.albedo[i]);
-            __builtin_nontemporal_store((unsigned long long)mw->coat, &a.coat[i]);
+            __builtin_nontemporal_store(coatW, &a.coat[i]);
             __builtin_nontemporal_store(emissiveW, &a.emissive[i]);
-            __builtin_nontemporal_store((unsigned long long)mw->fuzz, &a.fuzz[i]);
+            __builtin_nontemporal_store(fuzzW, &a.fuzz[i]);
             __builtin_nontemporal_store(mrW, &a.metallicRoughness[i]);
             __builtin_nontemporal_store((uint32_t)(f32_to_f16_bits(mvx) | (f32_to_f16_bits(mvy) << 16)), &a.motion[i]);
         };

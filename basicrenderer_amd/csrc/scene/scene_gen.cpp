@@ -1187,6 +1187,19 @@ void addMaterials(brmi_scene& sc, Pcg32& rng, uint32_t count) {
         // colour channels 0,1,2,3 as the reference's defaults
         for (int k = 0; k < 12; k++) o.textureBindings[k] = 0xFFFFFFFFu;
         for (int k = 0; k < 4; k++) { o.textureBindings[12 + k] = (uint32_t)k; o.textureBindings[19 + k] = (uint32_t)k; }
+        // materialFeatures bit 6 (with bit 3 for the UVs): layered materials also texture their coat / fuzz parameters
+        if ((sc.params.materialFeatures & 64u) && textured) {
+            if (o.coatWeight > 0.0f) {
+                o.textureBindings[0] = tex.base[(i + 1) % tex.base.size()]; o.textureBindings[1] = 0;                 // coat colour (sRGB)
+                o.textureBindings[2] = tex.orm[i % tex.orm.size()]; o.textureBindings[3] = 0; o.textureBindings[16] = 0;      // coat weight: R of the ORM texture
+                if (i % 2) { o.textureBindings[4] = tex.orm[(i + 1) % tex.orm.size()]; o.textureBindings[5] = 2; o.textureBindings[17] = 1; o.coatRoughness = 0.6f; }   // coat roughness: G
+            }
+            if (o.fuzzWeight > 0.0f) {
+                o.textureBindings[6] = tex.base[(i + 2) % tex.base.size()]; o.textureBindings[7] = 1; o.textureBindings[19] = 2; o.textureBindings[21] = 0;   // fuzz colour, b / g / r
+                o.textureBindings[8] = tex.orm[i % tex.orm.size()]; o.textureBindings[9] = 0; o.textureBindings[23] = 1;      // fuzz weight: G
+                o.textureBindings[10] = tex.orm[i % tex.orm.size()]; o.textureBindings[11] = 0; o.textureBindings[24] = 0;    // fuzz roughness: R (same binding: one fetch)
+            }
+        }
         sc.openpbr.push_back(o);
     }
 }

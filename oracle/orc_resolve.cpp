@@ -14,8 +14,8 @@
 //   cotangent_frame_from_derivs / BuildMaterialTBN          BR/shaders/Include/utilities.hlsli:323-336,1278-1287
 //   ResolveCanonicalOpenPBRSurface              BR/shaders/Include/utilities.hlsli:136-161
 // Scope: triangle clusters (no Reyes / voxel).  Vertex colours (CLOD_PAGE_ATTRIBUTE_COLOR) tint the base colour.  Material texture slots: base colour, opacity, metallic,
-// roughness, normal map, AO, emissive, each through the software sampler of orc_texture.h; no parallax / height map, no OpenPBR
-// coat / fuzz textures, no texture streaming feedback.  A slot's UV set index below MATERIAL_MAX_UNIQUE_UV_SETS (8) is decoded
+// roughness, normal map, AO, emissive and the six OpenPBR coat / fuzz slots, each through the software sampler of orc_texture.h; no
+// parallax / height map, no texture streaming feedback.  A slot's UV set index below MATERIAL_MAX_UNIQUE_UV_SETS (8) is decoded
 // as that set (a set the page does not carry decodes to (0, 0)); any other index uses set 0.
 // G-buffer formats: BR/include/Render/RenderGraphBuildHelper.h:41-139, BR/src/Renderer.cpp:1618.
 #include "orc_common.h"
@@ -186,10 +186,23 @@ static bool resolvePixel(const brmi_scene_buffers& sc, const brmi_visible_cluste
     const float3 baseColor = float3{baseColor4.x, baseColor4.y, baseColor4.z} * vertexColor;
     const brmi_openpbr_material_info& op = sc.openpbrMaterials[mat.openPBRMaterialDataIndex];
     const float3 canonicalEmissive = float3{op.emissionColor[0], op.emissionColor[1], op.emissionColor[2]} * op.emissionLuminance;
-    const float3 coatColor = saturate(float3{op.coatColor[0], op.coatColor[1], op.coatColor[2]});
-    const float coatWeight = saturate(op.coatWeight), coatRoughness = saturate(op.coatRoughness);
-    const float3 fuzzColor = saturate(float3{op.fuzzColor[0], op.fuzzColor[1], op.fuzzColor[2]});
-    const float fuzzWeight = saturate(op.fuzzWeight), fuzzRoughness = saturate(op.fuzzRoughness);
+    float3 coatColor = saturate(float3{op.coatColor[0], op.coatColor[1], op.coatColor[2]});
+    float coatWeight = saturate(op.coatWeight), coatRoughness = saturate(op.coatRoughness);
+    float3 fuzzColor = saturate(float3{op.fuzzColor[0], op.fuzzColor[1], op.fuzzColor[2]});
+    float fuzzWeight = saturate(op.fuzzWeight), fuzzRoughness = saturate(op.fuzzRoughness);
+    {   // ApplyOpenPBRTextureSampling (utilities.hlsli:720-846): the six coat / fuzz slots, bound when texture AND sampler index are valid
+        const uint32_t* tb = op.textureBindings;      // layout: include/brmi_types.h
+        auto bound = [&](int k) { return tb[2 * k] != 0xFFFFFFFFu && tb[2 * k + 1] != 0xFFFFFFFFu; };
+        auto fetch = [&](int k) { return sample(tb[2 * k], tb[2 * k + 1], tb[26 + k]); };
+        if (bound(0)) { const float4 t = fetch(0); coatColor = coatColor * float3{swizzle(t, tb[12]), swizzle(t, tb[13]), swizzle(t, tb[14])}; }
+        if (bound(1)) coatWeight *= swizzle(fetch(1), tb[16]);
+        if (bound(2)) coatRoughness *= swizzle(fetch(2), tb[17]);
+        if (bound(3)) { const float4 t = fetch(3); fuzzColor = fuzzColor * float3{swizzle(t, tb[19]), swizzle(t, tb[20]), swizzle(t, tb[21])}; }
+        if (bound(4)) fuzzWeight *= swizzle(fetch(4), tb[23]);
+        if (bound(5)) fuzzRoughness *= swizzle(fetch(5), tb[24]);
+        coatColor = saturate(coatColor); coatWeight = saturate(coatWeight); coatRoughness = saturate(coatRoughness);
+        fuzzColor = saturate(fuzzColor); fuzzWeight = saturate(fuzzWeight); fuzzRoughness = saturate(fuzzRoughness);
+    }
     const float3 emissive = dot(emissiveIn, emissiveIn) > 0.0f ? emissiveIn : canonicalEmissive;
 
     // ComputeClodMotionVector

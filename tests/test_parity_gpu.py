@@ -13,7 +13,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 CASES = ["tiny", "tiny_lod", "tiny_coat_fuzz", "sponza_coat_fuzz", "sponza_small", "bistro_small", "tiny_skinned", "bistro_skinned", "tiny_clod", "sponza_clod", "bistro_clod_skinned", "sponza_spots", "bistro_mirrored",
-         "tiny_textured", "sponza_textured", "tiny_alpha", "sponza_alpha", "bistro_alpha_skinned", "sponza_clod_alpha", "tiny_vcolor", "sponza_vcolor_textured"]
+         "tiny_textured", "sponza_textured", "tiny_alpha", "sponza_alpha", "bistro_alpha_skinned", "sponza_clod_alpha", "tiny_vcolor", "sponza_vcolor_textured", "sponza_layer_textures", "tiny_layer_textures_only"]
 
 
 @pytest.fixture(scope="module")
@@ -322,8 +322,9 @@ def test_unsupported_material_bindings_are_refused():
         VisibilityRenderer(sc)
     sc = scene()
     op = sc.arrays["openpbrMaterials"].view(np.uint32).reshape(-1, 100)
-    op[0, 62:64] = 0                                                 # coatColorTextureIndex / SamplerIndex = 0: a bound OpenPBR layer texture
-    with pytest.raises(BrmiError, match="OpenPBR layer textures"):
+    op[0, 62:64] = 0                                                 # coatColorTextureIndex / SamplerIndex = 0: a bound OpenPBR layer texture ...
+    op[0, 62 + 26] = 2                                               # ... on UV set 2
+    with pytest.raises(BrmiError, match="UV set 0"):
         VisibilityRenderer(sc)
     VisibilityRenderer(scene()).close()                              # the untouched scene is accepted
 
