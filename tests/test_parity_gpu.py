@@ -184,6 +184,29 @@ def test_hdr_within_one_half_ulp(name, gpu_frames, oracle_frames):
     assert (a[covered][:, :3] != 0).any()
 
 
+@pytest.mark.parametrize("name", ["sponza_small", "tiny_coat_fuzz", "sponza_alpha"])
+def test_lighting_toggles_match_the_oracle(name, scenes, oracle_frames):
+    """DeferredShadingPass's two switches: without PSO_CLUSTERED_LIGHTING every active light is walked per pixel (same image up to the
+    summation order of the light list), without punctual lights only the emissive term is left."""
+    import orc
+    from basicrenderer_amd.renderer import VisibilityRenderer
+    o = oracle_frames(name)
+    covered = o.vis != np.uint64(0xFFFFFFFFFFFFFFFF)
+    for kw, okw in ((dict(enableClusteredLighting=0), dict(clustered=False)), (dict(enablePunctualLights=0), dict(punctual=False))):
+        r = VisibilityRenderer(scenes(name), stats=True, **kw)
+        r.execute()
+        ref = orc.OracleFrame(scenes(name)).run()
+        ref.shade(**okw)
+        assert np.array_equal(r.visibility(), o.vis)
+        a = r.hdr().view(np.uint16).astype(np.int32).reshape(o.H, o.W, 4)[covered]
+        b = ref.hdr.view(np.uint16).astype(np.int32).reshape(o.H, o.W, 4)[covered]
+        assert np.abs(a - b).max() <= 1, str(kw)
+        if "enablePunctualLights" in kw:
+            lit = oracle_frames(name).hdr.view(np.uint16).reshape(o.H, o.W, 4)[covered]
+            assert (ref.hdr.view(np.uint16).reshape(o.H, o.W, 4)[covered][:, :3].astype(np.int64).sum() < lit[:, :3].astype(np.int64).sum())
+        r.close()
+
+
 def test_idempotent_and_deterministic(scenes):
     """Two executions of the same frame give identical bytes (no order dependence left in any stage)."""
     from basicrenderer_amd.renderer import VisibilityRenderer
