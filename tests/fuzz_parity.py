@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Randomised differential sweep: libbrmi.so against the CPU oracle on many small seeded frames (run on the GPU box:
+`gpurun -- python tests/fuzz_parity.py [count] [seed]`).  Every frame: random preset / size / lights / LOD depth / material feature mix /
+skinning / LOD builder / occlusion culling with a camera path / row band; cluster lists, keys, depth, G-buffer exact, HDR <= 1 fp16 ULP on
+covered pixels.  TEST INFRASTRUCTURE: imports the oracle."""
+import os, sys, time, random
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import orc
+from conftest import have_clodref
+from basicrenderer_amd import Scene
+from basicrenderer_amd.renderer import VisibilityRenderer
+EMPTY = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def compare(r, o, band, tag):
+    bad = []
+    y0, y1 = band if band != (0, 0) else (0, o.H)
+    if band == (0, 0):
+        if not np.array_equal(r.visible_clusters(), o.clusters[: o.count]): bad.append("clusters")
+        if not np.array_equal(r.visibility(), o.vis): bad.append("vis")
+        cov = o.vis != EMPTY
+        g = r.gbuffer()
+        if not np.array_equal(r.depth().view(np.uint32), o.depth.view(np.uint32)): bad.append("depth")
+        if not np.array_equal(g["normals"].view(np.uint32)[cov], o.normals.view(np.uint32)[cov]): bad.append("normals")
+        for k, ref in (("albedo", o.albedo), ("mr", o.mr), ("motion", o.motion), ("coat", o.coat), ("emissive", o.emissive), ("fuzz", o.fuzz)):
+            if not np.array_equal(g[k][cov], ref[cov]): bad.append(k)
+    else:
+        a, b, d = orc.canonical_ids(r.visibility(), r.visible_clusters()); fa, fb, fd = orc.canonical_ids(o.vis, o.clusters[: o.count])
+        if not (np.array_equal(a[y0:y1], fa[y0:y1]) and np.array_equal(b[y0:y1], fb[y0:y1]) and np.array_equal(d[y0:y1], fd[y0:y1])): bad.append("band ids")
+        cov = o.vis != EMPTY
+    hd = np.abs(r.hdr().view(np.uint16).astype(np.int32).reshape(o.H, o.W, 4) - o.hdr.view(np.uint16).astype(np.int32).reshape(o.H, o.W, 4))[y0:y1][cov[y0:y1]]
+    if hd.size and hd.max() > 1: bad.append(f"hdr {hd.max()}")
+    c = r.counters()
+    if c.droppedRecords or c.droppedClusters: bad.append("dropped")
+    return bad
+
+
+def main():
+    count = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    fails, t0 = 0, time.time()
+    for it in range(count):
+        preset = rng.choice(["tiny", "tiny", "sponza", "bistro", "san_miguel", "zorah"])
+        W, H = rng.randrange(64, 900), rng.randrange(48, 520)
+        mf = rng.choice([0, 0, 3, 8, 24, 27, 32, 59, 63, 127, 4, 96 | 11])
+        kw = dict(seed=rng.randrange(1, 1 << 20), point_lights=rng.choice([0, 1, 7, 40, 150]), directional=rng.random() < 0.8, material_features=mf,
+                  lod_levels=rng.choice([0, 1, 2, 3]), skinned_fraction=rng.choice([0.0, 0.0, 0.3, 1.0]), spot_every=rng.choice([0, 0, 2, 3]),
+                  size_scale={"tiny": 1.0, "sponza": rng.choice([0.05, 0.2]), "bistro": rng.choice([0.05, 0.2]), "san_miguel": 0.02, "zorah": 0.003}[preset])
+        if have_clodref() and preset in ("tiny", "sponza") and rng.random() < 0.2: kw["lod_builder"] = "clusterlod"
+        occlusion = rng.random() < 0.5
+        band = (0, 0)
+        if not occlusion and rng.random() < 0.25 and H >= 64:
+            y0 = 8 * rng.randrange(0, H // 16); band = (y0, min(H, y0 + 8 * rng.randrange(1, max(2, (H - y0) // 8 + 1))))
+        tag = f"#{it} {preset} {W}x{H} mf={mf} " + " ".join(f"{k}={v}" for k, v in kw.items() if k not in ("material_features",)) + (" occ" if occlusion else "") + (f" band={band}" if band != (0, 0) else "")
+        try:
+            bad = []
+            if occlusion:
+                hz, r = None, None
+                for step in range(rng.choice([2, 3])):
+                    sc = Scene(preset, W, H, camera_step=step, **kw)
+                    if r is None: r = VisibilityRenderer(sc, occlusion=True, stats=True)
+                    else: r.set_camera_from(sc, frame_index=step)
+                    r.execute()
+                    o = orc.OracleFrame(sc); hz = o.run_occlusion(hz); o.gbuffer(); o.light_cluster(); o.shade()
+                    c = r.counters()
+                    if (c.visibleClusters, c.visibleClustersPhase2) != (o.count1, o.count2): bad.append(f"step{step} counts")
+                    bad += [f"step{step} {b}" for b in compare(r, o, (0, 0), tag)]
+                r.close()
+            else:
+                sc = Scene(preset, W, H, **kw)
+                r = VisibilityRenderer(sc, stats=True, band=band); r.execute()
+                o = orc.OracleFrame(sc).run()
+                bad = compare(r, o, band, tag)
+                r.close()
+        except Exception as e:      # noqa: BLE001
+            bad = ["EXCEPTION " + repr(e)]
+        if bad:
+            fails += 1
+            print("MISMATCH", tag, "->", " ".join(bad), flush=True)
+        elif it % 25 == 0:
+            print("ok", tag, f"({time.time() - t0:.0f}s)", flush=True)
+    print(f"{count} frames, {fails} failing, {time.time() - t0:.0f}s")
+
+
+if __name__ == "__main__":
+    main()
