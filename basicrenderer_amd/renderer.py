@@ -191,8 +191,14 @@ class VisibilityRenderer:
 
     def close(self):
         if self._h:
+            self.torch.cuda.synchronize(self.device)
             self.lib.brmi_destroy(self._h)
             self._h = None
+            # every byte the pass used is caller-owned: drop the resource tensors and the uploaded scene with the pass
+            self.res = {}
+            self._scene_keep = []
+            if hasattr(self.scene, "device_arrays"):
+                self.scene.device_arrays = {}
 
     def __del__(self):
         try:

@@ -109,7 +109,8 @@ typedef enum brmi_resource_id {
     BRMI_RES_GBUF_FUZZ,               /* Builtin::GBuffer::Fuzz               rgba16f */
     BRMI_RES_GBUF_METALLIC_ROUGHNESS, /* Builtin::GBuffer::MetallicRoughness  rgba8 unorm */
     BRMI_RES_GBUF_MOTION_VECTORS,     /* Builtin::GBuffer::MotionVectors      rg16f */
-    BRMI_RES_HDR_COLOR,               /* Builtin::Color::HDRColorTarget       rgba16f */
+    BRMI_RES_HDR_COLOR,               /* Builtin::Color::HDRColorTarget       rgba16f; like the G-buffer planes, pixels without geometry are NOT
+                                         written (DeferredCSMain returns, BR/shaders/deferred.hlsl:33-37): the graph clears / the sky pass fills them */
     BRMI_RES_VISIBLE_CLUSTERS,        /* CLod visible-cluster buffer, 16 B records */
     BRMI_RES_LIGHT_CLUSTERS,          /* Builtin::Light::ClusterBuffer */
     BRMI_RES_LIGHT_PAGES,             /* Builtin::Light::PagesBuffer */

@@ -76,9 +76,14 @@ def main():
                 r.close()
         except Exception as e:      # noqa: BLE001
             bad = ["EXCEPTION " + repr(e)]
+        r = o = sc = None
+        if it % 20 == 19:
+            import gc
+            import torch
+            gc.collect(); torch.cuda.empty_cache()
         if bad:
             fails += 1
-            print("MISMATCH", tag, "->", " ".join(bad), flush=True)
+            print("MISMATCH", tag, "->", " ".join(bad)[:300], flush=True)
         elif it % 25 == 0:
             print("ok", tag, f"({time.time() - t0:.0f}s)", flush=True)
     print(f"{count} frames, {fails} failing, {time.time() - t0:.0f}s")
