@@ -469,7 +469,14 @@ template <bool ALPHA>
 __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? 4 : 1) k_raster_bins(RasterArgs a) {
     __shared__ unsigned long long tile[BIN_W * BIN_ROWS];
     __shared__ float unormT[ALPHA ? 256 : 1];
-    __shared__ uint16_t alphaList[ALPHA ? 4096 : 1];      // indices of the bin's alpha-tested records (first 4096; later ones take the row path)
+#ifndef BRMI_ALPHA_SEG_SHIFT
+#define BRMI_ALPHA_SEG_SHIFT 3
+#endif
+    constexpr int ALPHA_SEG_SHIFT = BRMI_ALPHA_SEG_SHIFT;     // pixels per task = 1 << shift
+    constexpr uint32_t ALPHA_LIST = 4096;                 // alpha-tested records a bin hands to the task pass (later ones take the row path)
+    __shared__ uint16_t alphaList[ALPHA ? ALPHA_LIST : 1];
+    __shared__ uint32_t taskStart[ALPHA ? ALPHA_LIST + 1 : 1];      // exclusive prefix of the listed records' task counts
+    __shared__ uint32_t scanPart[ALPHA ? BRMI_BIN_THREADS : 1];
     __shared__ uint32_t alphaCount;
     const uint32_t strip = blockIdx.x, band = blockIdx.y, bin = band * a.binsX + strip;
     const uint32_t n = min(a.binCounts[bin], a.binCapacity);
@@ -489,12 +496,11 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? 4 : 1) k_raster_bins
         const BinRecord r = recs[ri];
         const uint32_t rows = (r.triAndFlags >> 16) & 0xFFu;
         bool deferred = false;
-        // alpha tested and wide inside this bin: listed for the segment pass below (a narrow record keeps the 16-lane row walk)
-        if (ALPHA && r.pad1 != 0u && min(r.minX + r.rectWidth - 1, x0 + BIN_W - 1) - max(r.minX, x0) >= 48) {
+        if (ALPHA && r.pad1 != 0u) {      // alpha tested: listed for the task pass below
             uint32_t slot = 0;
             if (row == 0u) slot = atomicAdd(&alphaCount, 1u);
             slot = (uint32_t)__shfl((int)slot, (int)(lane_id() & 48u));
-            deferred = slot < 4096u && ri < 65536u;
+            deferred = slot < ALPHA_LIST && ri < 65536u;
             if (deferred && row == 0u) alphaList[slot] = (uint16_t)ri;
         }
         if (row < rows && !deferred) {
@@ -510,22 +516,49 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? 4 : 1) k_raster_bins
         }
     }
     if (ALPHA) {
-        // Alpha-tested records after the opaque ones (more keys to reject untested).  A pixel of theirs costs a dependent chain of
-        // texel fetches, and a bin often holds only a handful of such records (two floor triangles): one lane per row would walk
-        // 256 pixels serially.  Lane = (row, 8-pixel segment): the whole workgroup walks one record at a time, every lane at most 8
-        // dependent fetches deep; a segment's barycentrics are stepped from the row start like every clipped walk.
+        // Alpha-tested records after the opaque ones (more keys to reject untested).  A pixel of theirs costs a texcoord, a dependent
+        // texel fetch and the filter, and the records of a bin are anything from two floor triangles that span it to hundreds of
+        // 10-pixel slivers: with one lane per record row most lanes idle or walk long rows alone.  The rows are cut into 8-pixel
+        // segments and ALL segments of the bin's alpha records form one task list (prefix sum over the records' segment counts in
+        // LDS, a task finds its record by bisection) dealt round-robin to the 512 lanes; a segment's barycentrics are stepped from
+        // the row start like every clipped walk, so the keys are those of the serial loop.
         __syncthreads();
-        const uint32_t seg = threadIdx.x >> 4;
-        const uint32_t listed = min(alphaCount, 4096u);
-        for (uint32_t li = 0; li < listed; li++) {
-            const uint32_t ri = alphaList[li];
+        const uint32_t listed = min(alphaCount, ALPHA_LIST);
+        auto tasks_of = [&](const BinRecord& r) {
+            const int bx0 = max(r.minX, x0), bx1 = min(r.minX + r.rectWidth - 1, x0 + BIN_W - 1);
+            return bx1 < bx0 ? 0u : ((r.triAndFlags >> 16) & 0xFFu) * (uint32_t)(((bx1 - bx0) >> ALPHA_SEG_SHIFT) + 1);
+        };
+        // exclusive scan of the task counts: 8 consecutive records per thread, then a scan of the 512 partial sums
+        constexpr uint32_t PER = ALPHA_LIST / BRMI_BIN_THREADS;
+        uint32_t mine[PER]; uint32_t sum = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) { const uint32_t j = threadIdx.x * PER + k; mine[k] = j < listed ? tasks_of(recs[alphaList[j]]) : 0u; sum += mine[k]; }
+        scanPart[threadIdx.x] = sum;
+        __syncthreads();
+        for (uint32_t o = 1; o < BRMI_BIN_THREADS; o <<= 1) {
+            const uint32_t v = threadIdx.x >= o ? scanPart[threadIdx.x - o] : 0u;
+            __syncthreads();
+            scanPart[threadIdx.x] += v;
+            __syncthreads();
+        }
+        uint32_t run = scanPart[threadIdx.x] - sum;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) { const uint32_t j = threadIdx.x * PER + k; if (j <= listed) taskStart[j] = run; run += mine[k]; }
+        __syncthreads();
+        const uint32_t total = listed ? taskStart[listed] : 0u;
+        for (uint32_t task = threadIdx.x; task < total; task += BRMI_BIN_THREADS) {
+            uint32_t j = 0;
+#pragma unroll
+            for (uint32_t step = ALPHA_LIST / 2; step > 0; step >>= 1) if (j + step <= listed && taskStart[j + step] <= task) j += step;
+            const uint32_t ri = alphaList[j];
             const BinRecord r = recs[ri];
-            const uint32_t rows = (r.triAndFlags >> 16) & 0xFFu;
-            const int sx0 = x0 + (int)(seg << 3), sx1 = sx0 + 7;
-            if (row >= rows || r.minX > sx1 || r.minX + r.rectWidth - 1 < sx0) continue;
+            const int bx0 = max(r.minX, x0), bx1 = min(r.minX + r.rectWidth - 1, x0 + BIN_W - 1);
+            const uint32_t nseg = (uint32_t)(((bx1 - bx0) >> ALPHA_SEG_SHIFT) + 1), local = task - taskStart[j];
+            const uint32_t trow = local / nseg, tseg = local - trow * nseg;
+            const int sx0 = bx0 + (int)(tseg << ALPHA_SEG_SHIFT), sx1 = min(sx0 + (1 << ALPHA_SEG_SHIFT) - 1, bx1);
             float sb0 = r.sb0, sb1 = r.sb1;
-            for (uint32_t k = 0; k < row; k++) { sb0 += r.dy_b0; sb1 += r.dy_b1; }
-            const int py = r.rowStart + (int)row;
+            for (uint32_t k = 0; k < trow; k++) { sb0 += r.dy_b0; sb1 += r.dy_b1; }
+            const int py = r.rowStart + (int)trow;
             if ((uint32_t)py >= a.bandY0 && (uint32_t)py < a.bandY1)
                 raster_row(sink, tex_alpha_of(a, unormT, a.binAlpha[(size_t)bin * a.binCapacity + ri]), py, r.minX, r.rectWidth, (r.triAndFlags & 0x100u) != 0, sb0, sb1, r.dx_b0, r.dx_b1, -(r.dx_b0 + r.dx_b1),
                            r.d0, r.d1, r.d2, r.clusterIndex, r.triAndFlags & 0x7Fu, sx0, sx1);
