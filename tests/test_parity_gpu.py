@@ -97,7 +97,7 @@ def test_depth_and_gbuffer_bit_exact(name, gpu_frames, oracle_frames):
         assert not bad.any(), f"{key}: {int(bad.sum())} of {bad.size} values differ"
 
 
-@pytest.mark.parametrize("name", ["golden_tiny", "golden_tiny_lod_coat_fuzz", "golden_sponza", "golden_tiny_textured_alpha"])
+@pytest.mark.parametrize("name", ["golden_tiny", "golden_tiny_lod_coat_fuzz", "golden_sponza", "golden_tiny_textured_alpha", "golden_sponza_all_features"])
 def test_gpu_reproduces_the_committed_golden_fixtures(name):
     """The frozen fixtures under tests/golden/ (inputs regenerated from the seed, expected outputs committed): a reference that does
     not move with the oracle's source."""
