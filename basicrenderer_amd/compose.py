@@ -45,6 +45,12 @@ def compose_bands(surface_u8, band, width, bytes_per_pixel, out=None, group=None
     return out
 
 
+def rgb_of(surface_u8):
+    """The three colour channels of a (tiled) RGBA16F byte surface as a strided [pixels, 3] int16 view (fp16 bit patterns)."""
+    import torch
+    return surface_u8.view(torch.int16).view(-1, 4)[:, :3]
+
+
 class BandComposer:
     """Pipelined composition for a frame loop: the all-gather of frame k runs on the collective stream while frame k+1 is rendered.
 
@@ -52,17 +58,30 @@ class BandComposer:
     serialised behind the frame it would halve the throughput.  `submit()` copies the caller's band to one of `depth` staging
     buffers (the HDR target is overwritten by the next frame) and starts the all-gather asynchronously; a staging buffer is
     reused only after its collective has finished.  `finish()` waits for everything and returns the last composed surface.
+
+    `transport="rgb16f"` (RGBA16F lit target only) gathers the three colour channels and delivers the composed image as RGB16F, 6 B
+    per pixel instead of 8: the lit target's alpha is the constant 1.0 of an opaque frame, and the gather -- not the rendering -- is
+    what bounds the frame rate from two GPUs on.  `out[i]` is then a [pixels, 3] int16 tensor of fp16 bit
+    patterns in the same (tiled, band after band) pixel order; the staging copy drops the alpha on the way.
     """
 
-    def __init__(self, surface_u8, band, width, bytes_per_pixel, depth=2, group=None):
+    def __init__(self, surface_u8, band, width, bytes_per_pixel, depth=2, group=None, transport="surface"):
         import torch
         import torch.distributed as dist
+        if transport not in ("surface", "rgb16f") or (transport == "rgb16f" and bytes_per_pixel != 8):
+            raise ValueError("transport must be 'surface' or, for an RGBA16F surface, 'rgb16f'")
         lo, hi = band_byte_range(band, width, bytes_per_pixel)
-        self.dist, self.group, self.depth = dist, group, depth
-        self.src = surface_u8[lo:hi]
+        self.dist, self.group, self.depth, self.transport = dist, group, depth, transport
         n = dist.get_world_size(group)
-        self.stage = [torch.empty_like(self.src) for _ in range(depth)]
-        self.out = [torch.empty((hi - lo) * n, dtype=torch.uint8, device=surface_u8.device) for _ in range(depth)]
+        if transport == "rgb16f":
+            self.src = rgb_of(surface_u8[lo:hi])                                       # strided view: copy_ compacts it
+            pixels = (hi - lo) // 8
+            self.stage = [torch.empty((pixels, 3), dtype=torch.int16, device=surface_u8.device) for _ in range(depth)]
+            self.out = [torch.empty((pixels * n, 3), dtype=torch.int16, device=surface_u8.device) for _ in range(depth)]
+        else:
+            self.src = surface_u8[lo:hi]
+            self.stage = [torch.empty_like(self.src) for _ in range(depth)]
+            self.out = [torch.empty((hi - lo) * n, dtype=torch.uint8, device=surface_u8.device) for _ in range(depth)]
         self.work = [None] * depth
         self.frames = 0
 
@@ -71,7 +90,9 @@ class BandComposer:
         if self.work[i] is not None:
             self.work[i].wait()
         self.stage[i].copy_(self.src)
-        self.work[i] = self.dist.all_gather_into_tensor(self.out[i], self.stage[i], group=self.group, async_op=True)
+        import torch
+        # the collective sees bytes (RCCL has no 16-bit integer type, and nothing is reduced)
+        self.work[i] = self.dist.all_gather_into_tensor(self.out[i].view(-1).view(torch.uint8), self.stage[i].view(-1).view(torch.uint8), group=self.group, async_op=True)
         self.frames += 1
         return i
 

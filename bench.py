@@ -43,6 +43,8 @@ def main():
                     help="clusterlod: mesh LOD DAGs from the reference's own builder (oracle/_ref/libclodref.so) instead of the generator's quadtree")
     ap.add_argument("--material-features", type=int, default=0,
                     help="scene generator feature bits (brmi_scene.h): 1 coat, 2 fuzz, 4 mirrored instances, 8 texture-sampled materials, 16 alpha-tested materials; 0 = BASELINE.json's constant-factor configuration")
+    ap.add_argument("--transport", default="rgb16f", choices=["rgb16f", "surface"],
+                    help="what the band composition gathers: the colour channels as RGB16F (default; the composed image has no alpha plane) or the RGBA16F surface bytes")
     ap.add_argument("--force-compose", action="store_true", help="run the RCCL band composition even with one rank (checks the collective path on a single GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scale", type=float, default=1.0, help="fraction of the frame height the CPU baseline renders")
@@ -75,7 +77,8 @@ def main():
 
     hdr = r.hdr_tensor()
     lo, hi = compose.band_byte_range(band, W, 8)
-    composer = compose.BandComposer(hdr, band, W, 8) if (n > 1 or args.force_compose) else None     # all-gather of frame k overlaps the rendering of frame k + 1
+    # all-gather of frame k overlaps the rendering of frame k + 1; the colour channels travel (RGB16F, 6 B/px): the lit target's alpha is constant
+    composer = compose.BandComposer(hdr, band, W, 8, transport=args.transport) if (n > 1 or args.force_compose) else None
 
     def step():
         r.update()                      # the per-frame Update phase (camera / per-frame constants), as the reference's passes run it every frame
@@ -147,7 +150,7 @@ def main():
                                    f"{scene.stats['instancedTriangles']} instanced tris, {scene.stats['instances']} instances"
                                    + (", LOD DAG built by the reference's clusterlod.h" if args.lod_builder == "clusterlod" else "")
                                    + (f", material features {args.material_features} (8 = texture-sampled, 16 = alpha-tested materials)" if args.material_features else "")
-                                   + (f", {n} row bands of 1080 rows + RCCL all-gather of HDR (pipelined one frame deep)" if n > 1 else ""),
+                                   + (f", {n} row bands of 1080 rows + RCCL all-gather of HDR ({args.transport}, pipelined one frame deep)" if n > 1 else ""),
                        "baseline_config": "configs[1]" if args.workload == "sponza" else "configs[2]",
                        "pixels_per_gpu": W * (band[1] - band[0]), "visible_clusters_rank0": int(c.visibleClusters),
                        "occlusion_culling": bool(args.occlusion), "visible_clusters_phase2_rank0": int(c.visibleClustersPhase2),
@@ -161,10 +164,19 @@ def main():
         }
         if n == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, args.cpu_scale)
-        print(json.dumps(out), flush=True)
+        result_line = json.dumps(out)
+    else:
+        result_line = None
     r.close()
     if world > 1 or args.force_compose:
+        # RCCL writes a version banner to the C stdout buffer; pushed out here, on every rank, so that rank 0's JSON is the last line
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        dist.barrier()                       # every rank has flushed before rank 0 prints
         dist.destroy_process_group()
+        ctypes.CDLL(None).fflush(None)
+    if result_line is not None:
+        print(result_line, flush=True)
 
 
 def cpu_baseline(scene, scale):

@@ -43,6 +43,16 @@ def _worker(rank, world, port, W, H, out_path):
         want = compose.compose_bands(surface ^ frame, band, W, 8)
         assert torch.equal(composer.out[slot], want), f"pipelined composition of frame {frame}"
     assert torch.equal(composer.finish(), compose.compose_bands(surface ^ 2, band, W, 8))
+    # colour-only transport (bench.py's choice for N > 1): the composed RGB16F image is the colour channels of the composed surface
+    rgb = compose.BandComposer(live, band, W, 8, depth=2, transport="rgb16f")
+    for frame in range(3):
+        live[lo:hi] = surface[lo:hi] ^ frame
+        slot = rgb.submit()
+        live[lo:hi] = 0xEE
+        rgb.work[slot].wait()
+        want = compose.rgb_of(compose.compose_bands(surface ^ frame, band, W, 8))
+        assert rgb.out[slot].shape == want.shape and torch.equal(rgb.out[slot], want), f"rgb transport, frame {frame}"
+    assert torch.equal(rgb.finish(), compose.rgb_of(compose.compose_bands(surface ^ 2, band, W, 8)))
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)                      # the max-over-ranks timing reduction of bench.py
     assert t.item() == world
