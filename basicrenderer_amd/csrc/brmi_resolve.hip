@@ -316,7 +316,7 @@ __global__ void __launch_bounds__(256, INLINE_TABLES ? 1 : (TEXTURED ? BRMI_GBT_
                     f4 sL0 = one4, sL1 = one4, sL2 = one4, sL3 = one4, sL4 = one4, sL5 = one4;     // coat colour / weight / roughness, fuzz colour / weight / roughness
                     const auto* opRec = as_space_of(mat, sc.openpbrMaterials) + mat->openPBRMaterialDataIndex;
                     {
-                        TexBinding prev{}; f4 prevSample{};
+                        uint32_t prevTi = 0xFFFFFFFFu, prevSi = 0xFFFFFFFFu; f4 prevSample{};      // same (texture, sampler) pair as the previous slot: same fetch
 #pragma nounroll
                         for (uint32_t slot = 0; slot < (layerTex ? 12u : 6u); slot++) {
                             uint32_t bit, ti, si;
@@ -334,9 +334,9 @@ __global__ void __launch_bounds__(256, INLINE_TABLES ? 1 : (TEXTURED ? BRMI_GBT_
                                 default: bit = BRMI_MATERIAL_EMISSIVE_TEXTURE; ti = mat->emissiveTextureIndex; si = mat->emissiveSamplerIndex; break;
                             }
                             if (slot < 6u && !(flags & bit)) continue;
-                            const TexBinding bnd = bind(ti, si);
-                            const f4 t = same_binding(prev, bnd) ? prevSample : sample_grad(tb, bnd, uv, dUVdx, dUVdy);
-                            prev = bnd; prevSample = t;
+                            f4 t = prevSample;
+                            if (ti != prevTi || si != prevSi || ti >= sc.textureCount || si >= sc.samplerCount) t = sample_grad(tb, bind(ti, si), uv, dUVdx, dUVdy);
+                            prevTi = ti; prevSi = si; prevSample = t;
                             if (slot == 0u) sBase = t; else if (slot == 1u) sMetal = t; else if (slot == 2u) sRough = t; else if (slot == 3u) sAo = t; else if (slot == 4u) sNormal = t; else if (slot == 5u) sEmis = t;
                             else if (slot == 6u) sL0 = t; else if (slot == 7u) sL1 = t; else if (slot == 8u) sL2 = t; else if (slot == 9u) sL3 = t; else if (slot == 10u) sL4 = t; else sL5 = t;
                         }
