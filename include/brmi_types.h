@@ -394,7 +394,7 @@ typedef struct brmi_openpbr_material_info {
 #define BRMI_TEXTURE_FORMAT_RGBA8_UNORM_SRGB  1u     /* rgb decoded through brmi_scene_buffers::srgbToLinear before filtering */
 #define BRMI_TEXTURE_MAX_MIPS                 16u
 typedef struct brmi_texture_desc {
-    const uint8_t* texels;                  /* device pointer (scene generator output: byte offset into BRMI_ARR_TEXELS) */
+    const uint8_t* texels;                  /* device pointer, 4-byte aligned (scene generator output: byte offset into BRMI_ARR_TEXELS) */
     uint32_t width, height, mipCount, format;
     uint32_t mipOffset[BRMI_TEXTURE_MAX_MIPS];
     uint32_t reserved[2];

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised differential sweep: libbrmi.so against the CPU oracle on many small seeded frames (run on the GPU box:
-`gpurun -- python tests/fuzz_parity.py [count] [seed]`).  Every frame: random preset / size / lights / LOD depth / material feature mix /
+`gpurun -- python tests/fuzz_parity.py [count] [seed] [size multiplier]`).  Every frame: random preset / size / lights / LOD depth / material feature mix /
 skinning / LOD builder / occlusion culling with a camera path / row band; cluster lists, keys, depth, G-buffer exact, HDR <= 1 fp16 ULP on
 covered pixels.  TEST INFRASTRUCTURE: imports the oracle."""
 import os, sys, time, random
@@ -43,7 +43,8 @@ def main():
     fails, t0 = 0, time.time()
     for it in range(count):
         preset = rng.choice(["tiny", "tiny", "sponza", "bistro", "san_miguel", "zorah"])
-        W, H = rng.randrange(64, 900), rng.randrange(48, 520)
+        big = int(sys.argv[3]) if len(sys.argv) > 3 else 1          # optional third argument: size multiplier (4 = up to 3600 x 2080)
+        W, H = rng.randrange(64, 900 * big), rng.randrange(48, 520 * big)
         mf = rng.choice([0, 0, 3, 8, 24, 27, 32, 59, 63, 127, 4, 96 | 11])
         kw = dict(seed=rng.randrange(1, 1 << 20), point_lights=rng.choice([0, 1, 7, 40, 150]), directional=rng.random() < 0.8, material_features=mf,
                   lod_levels=rng.choice([0, 1, 2, 3]), skinned_fraction=rng.choice([0.0, 0.0, 0.3, 1.0]), spot_every=rng.choice([0, 0, 2, 3]),
