@@ -134,8 +134,8 @@ BRMI_DEV void job_shade_tables(const brmi_scene_buffers& sc, ShadeTables t, uint
     const float resX = (float)pf->screenResX, resY = (float)pf->screenResY;
     const uint32_t gx = pf->lightClusterGridSizeX, gy = pf->lightClusterGridSizeY, gz = pf->lightClusterGridSizeZ;
     const float tsx = resX / (float)gx, tsy = resY / (float)gy;
-    if (i < W) { t.uvx[i] = ((float)i + 0.5f) / resX; t.tileX[i] = (uint32_t)((float)i / tsx); }
-    if (i < H) { t.uvy[i] = ((float)i + 0.5f) / resY; t.tileY[i] = (uint32_t)((float)i / tsy); }
+    if (i < W) t.x[i] = AxisEntry{((float)i + 0.5f) / resX, (uint32_t)((float)i / tsx)};
+    if (i < H) t.y[i] = AxisEntry{((float)i + 0.5f) / resY, (uint32_t)((float)i / tsy)};
     if (i <= gz + 1u) {
         float b = 0.0f;
         if (i == gz + 1u) b = __uint_as_float(0x7F800000u);
@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(64) k_frame_constants(FrameJobs j) {
 ShadeTables shade_tables_of(const brmi_pass* p) {
     uint32_t* tb = p->wsPtr<uint32_t>(p->ws.shadeTables);
     const uint32_t W = p->cfg.width, H = p->cfg.height;
-    return ShadeTables{reinterpret_cast<float*>(tb), tb + W, reinterpret_cast<float*>(tb + 2 * W), tb + 2 * W + H, reinterpret_cast<float*>(tb + 2 * W + 2 * H)};
+    return ShadeTables{reinterpret_cast<AxisEntry*>(tb), reinterpret_cast<AxisEntry*>(tb + 2 * W), reinterpret_cast<float*>(tb + 2 * W + 2 * H)};
 }
 
 // Launches the constants kernel if brmi_update / brmi_set_scene happened since the last time (every stage calls this first).

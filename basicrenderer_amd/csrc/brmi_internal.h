@@ -64,7 +64,8 @@ struct ClusterSetup {                 // 64 B
 constexpr uint32_t BRMI_CS_SKINNED = 1u << 25, BRMI_CS_JOINTS = 1u << 26, BRMI_CS_WEIGHTS = 1u << 27;
 constexpr uint32_t BRMI_CS_ALPHA = 1u << 28, BRMI_CS_TEXTURED = 1u << 29, BRMI_CS_COLOR = 1u << 30;    // the cluster's material is alpha tested / samples textures
 // per-frame tables and per-material constants of the shading pass (brmi_frame.hip fills them, brmi_light.hip reads them)
-struct ShadeTables { float* uvx; uint32_t* tileX; float* uvy; uint32_t* tileY; float* sliceStart; };
+struct AxisEntry { float uv; uint32_t tile; };       // per column / row: (i + 0.5) / res and the light-cluster tile index
+struct ShadeTables { AxisEntry* x; AxisEntry* y; float* sliceStart; };
 struct MatConst { float baseWeight, specularWeight, specR, specG, specB, weightedSpecularIor, dielF0Scalar, coatF0Scalar, coatIor, coatDarkening, baseDiffuseRoughness, pad; };
 constexpr uint32_t BRMI_ARENA_NONE = 0xFFFFFFFFu;
 // resolve arena: per-vertex and per-triangle tables of the visible clusters (brmi_resolve.hip)

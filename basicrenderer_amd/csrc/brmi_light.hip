@@ -508,7 +508,8 @@ BRMI_DEV uint32_t shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const flo
     (void)gy;
         const float d = raw.d;
         if (as_u32(d) == BRMI_DEPTH_EMPTY_BITS) return 0u;
-        float uvx = a.tables.uvx[px], uvy = a.tables.uvy[py];
+        const AxisEntry ax = a.tables.x[px], ay = a.tables.y[py];
+        float uvx = ax.uv, uvy = ay.uv;
         uvy = 1.0f - uvy;
         const f4 clipPos{uvx * 2.0f - 1.0f, uvy * 2.0f - 1.0f, 1.0f, 1.0f};
         const f4 viewPosH = mul_vm(clipPos, invProj);
@@ -596,7 +597,7 @@ BRMI_DEV uint32_t shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const flo
         };
         if (a.enablePunctual) {
             if (a.clustered) {
-                const uint32_t tx = a.tables.tileX[px], ty = a.tables.tileY[py];
+                const uint32_t tx = ax.tile, ty = ay.tile;
                 const float z = fabsf(posVS.z);
                 // slice: a hardware-log estimate (within one slice of the shader's formula), corrected against the exact first
                 // depth of that slice and of the next one -- the value of the formula without its two divisions and logf
