@@ -433,6 +433,7 @@ struct ShadeArgs {
     uint32_t enablePunctual, clustered;
     const float* lutF;   // expanded tables: odE[32768] odAvg[1024] imE[1024] imAvg[32] unorm8[256]
     const MatConst* matConst;
+    uint32_t sceneHasCoat;                  // 0: no OpenPBR record has a coat weight > 0, the coat plane's weight is 0 everywhere
     const ShadeMaterialEntry* shadeMat;     // (OpenPBR material, roughness code) -> prepared table rows and averages (k_frame_constants)
     uint32_t* counters; uint32_t* deferred;   // pixels (band-relative tiled index) left to the general kernel
     // The deferred pixels go to 64 striped lists (tile t appends to stripe (t / 64) % 64, so no stripe can exceed its share): one
@@ -493,7 +494,8 @@ BRMI_DEV RawPixel load_raw_pixel_plain(const ShadeArgs& a, uint64_t i) {
     r.d = __builtin_nontemporal_load(&a.depth[i]);
     r.ns = make_float4(__builtin_nontemporal_load(&a.normals[i].x), __builtin_nontemporal_load(&a.normals[i].y), __builtin_nontemporal_load(&a.normals[i].z), __builtin_nontemporal_load(&a.normals[i].w));
     r.al = __builtin_nontemporal_load(&a.albedo[i]); r.mr = __builtin_nontemporal_load(&a.metallicRoughness[i]); r.es = __builtin_nontemporal_load(&a.emissive[i]);
-    r.cs = (unsigned long long)__builtin_nontemporal_load(&reinterpret_cast<const uint16_t*>(a.coat)[i * 4u + 3u]) << 48; r.fs = 0ull;   // coat weight only (a plain pixel has no other coat / fuzz input)
+    // the coat plane is only looked at for its weight, and only when some material of the scene has a coat at all (brmi_set_scene)
+    r.cs = a.sceneHasCoat ? (unsigned long long)__builtin_nontemporal_load(&reinterpret_cast<const uint16_t*>(a.coat)[i * 4u + 3u]) << 48 : 0ull; r.fs = 0ull;   // coat weight only (a plain pixel has no other coat / fuzz input)
     return r;
 }
 
@@ -770,6 +772,7 @@ int launch_shade(brmi_pass* p, hipStream_t s) {
     a.lutF = p->wsPtr<float>(p->ws.lutF);
     a.matConst = p->wsPtr<MatConst>(p->ws.matConst);
     a.shadeMat = p->wsPtr<ShadeMaterialEntry>(p->ws.shadeMat);
+    a.sceneHasCoat = p->sceneHasCoat ? 1u : 0u;
     a.tables = shade_tables_of(p);
     a.counters = p->counters(); a.deferred = p->wsPtr<uint32_t>(p->ws.deferredPixels);
     a.deferredWord = (p->shadeSerial & 1u) ? STRIPE_DEFERRED_B : STRIPE_DEFERRED_A;
