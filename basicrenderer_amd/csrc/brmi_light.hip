@@ -501,7 +501,7 @@ BRMI_DEV RawPixel load_raw_pixel_plain(const ShadeArgs& a, uint64_t i) {
 
 // Returns 0 when the pixel is done, else the class (1 coat, 2 fuzz, 3 both) of the variant that has to shade it.
 template <int MODE>
-BRMI_DEV uint32_t shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const float* sliceStart, const RawPixel& raw, uint64_t i, uint32_t px, uint32_t py) {
+BRMI_DEV uint32_t shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const float* sliceStart, const float* unorm8, const RawPixel& raw, uint64_t i, uint32_t px, uint32_t py) {
     const brmi_scene_buffers& sc = a.sc;
     const Luts& L = k.L;
     const uint32_t gx = k.gx, gy = k.gy, gz = k.gz, nearSlices = k.nearSlices, numLights = k.numLights;
@@ -526,8 +526,9 @@ BRMI_DEV uint32_t shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const flo
         const f3 nrm{ns.x, ns.y, ns.z};
         const uint32_t al = raw.al, mr = raw.mr;
         const unsigned long long cs = raw.cs, es = raw.es, fs = raw.fs;
-        const f3 baseColor{L.unorm8[al & 0xFFu], L.unorm8[(al >> 8) & 0xFFu], L.unorm8[(al >> 16) & 0xFFu]};
-        const float metal = L.unorm8[mr & 0xFFu], pr = L.unorm8[(mr >> 8) & 0xFFu], coatR = L.unorm8[(mr >> 16) & 0xFFu], fuzzW = L.unorm8[mr >> 24];
+        // code / 255 from the LDS copy of the table: seven reads per pixel that do not go through the vector-memory path
+        const f3 baseColor{unorm8[al & 0xFFu], unorm8[(al >> 8) & 0xFFu], unorm8[(al >> 16) & 0xFFu]};
+        const float metal = unorm8[mr & 0xFFu], pr = unorm8[(mr >> 8) & 0xFFu], coatR = unorm8[(mr >> 16) & 0xFFu], fuzzW = unorm8[mr >> 24];
         const float prc = clampf(pr, BRMI_MIN_PERCEPTUAL_ROUGHNESS, 1.0f);
         f.roughness = prc * prc;
         const float NdotVraw = dot3(nrm, viewDir);
@@ -666,6 +667,8 @@ template <int MODE>
 __global__ void __launch_bounds__(256, MODE != 0 ? 1 : BRMI_SHADE_WAVES) k_shade(ShadeArgs a) {
     const ShadeFrame k = make_shade_frame(a);
     __shared__ float sliceStart[64];
+    __shared__ float unormT[256];
+    unormT[threadIdx.x] = k.L.unorm8[threadIdx.x];       // blockDim.x == 256
     if (threadIdx.x < 64) sliceStart[threadIdx.x] = threadIdx.x <= k.gz + 1u ? a.tables.sliceStart[threadIdx.x] : __uint_as_float(0x7F800000u);
     __syncthreads();
     if (MODE == 0) {
@@ -684,7 +687,7 @@ __global__ void __launch_bounds__(256, MODE != 0 ? 1 : BRMI_SHADE_WAVES) k_shade
         for (; j < end; j += stride) {
             uint32_t npx = 0, npy = 0;
             const RawPixel nxt = (j + stride < end) ? fetch(j + stride, npx, npy) : empty_raw_pixel();
-            const uint32_t cls = shade_pixel<0>(a, k, sliceStart, cur, a.firstPixel + j, px, py);
+            const uint32_t cls = shade_pixel<0>(a, k, sliceStart, unormT, cur, a.firstPixel + j, px, py);
             const bool done = cls == 0u;
             const uint32_t stripe = (uint32_t)(j >> 12) & (CNT_STRIPE_COUNT - 1u);     // wave-uniform; runs of 64 neighbouring tiles share a stripe (locality of the list)
             if (__any(!done)) {
@@ -718,7 +721,7 @@ __global__ void __launch_bounds__(256, MODE != 0 ? 1 : BRMI_SHADE_WAVES) k_shade
             const uint64_t i = a.firstPixel + a.deferred[((size_t)(MODE - 1) * CNT_STRIPE_COUNT + stripe) * a.stripeCapacity + (q - stripeStart[stripe])];
             const uint32_t tile = (uint32_t)(i >> 6), within = (uint32_t)(i & 63u);
             const uint32_t px = (tile % a.tilesX) * 8u + (within >> 3), py = (tile / a.tilesX) * 8u + (within & 7u);
-            shade_pixel<MODE>(a, k, sliceStart, load_raw_pixel(a, i), i, px, py);
+            shade_pixel<MODE>(a, k, sliceStart, unormT, load_raw_pixel(a, i), i, px, py);
         }
     }
 }
