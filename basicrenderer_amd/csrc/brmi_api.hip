@@ -243,11 +243,13 @@ int brmi_set_scene(brmi_pass* p, const brmi_scene_buffers* scene) {
         // launched for scenes that need them
         std::vector<brmi_material_info> mats;
         if ((rc = read_back(p, mats, sc.materials, sc.materialCount))) return rc;
-        p->sceneHasAlphaTest = false; p->sceneHasTextures = layerTextures;
+        p->sceneHasAlphaTest = false; p->sceneHasTextures = layerTextures; p->sceneHasParallax = false;
         for (size_t i = 0; i < mats.size(); i++) {
             const brmi_material_info& m = mats[i];
-            if (m.materialFlags & (1u << 9)) return fail(p, BRMI_ERR_INVALID, "material %zu: MATERIAL_PARALLAX (height maps) is not supported by this path", i);
+            if ((m.materialFlags & BRMI_MATERIAL_PARALLAX) && m.heightUvSetIndex)
+                return fail(p, BRMI_ERR_INVALID, "material %zu: the height map must use UV set 0 (only set 0 is decoded on this path)", i);
             if (m.materialFlags & BRMI_MATERIAL_ALPHA_TEST) p->sceneHasAlphaTest = true;
+            if (m.materialFlags & BRMI_MATERIAL_PARALLAX) p->sceneHasParallax = true;
             if (m.materialFlags & BRMI_MATERIAL_ANY_TEXTURE) {
                 p->sceneHasTextures = true;
                 const uint32_t f = m.materialFlags;

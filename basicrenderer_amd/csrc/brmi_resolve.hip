@@ -150,6 +150,50 @@ BRMI_DEV BaryDeriv bary_derivatives(const ResolveTriangle& r, f3 lambda, float n
     d.ddy = interpW_ddy * (lambda * interpInvW + ddy) - lambda;
     return d;
 }
+// getContactRefinementParallaxCoordsAndHeight (parallax.hlsli:46-120; oracle: parallaxCoords in orc_resolve.cpp).  16 coarse steps
+// along the tangent-space view ray, one refinement pass after the first hit, a secant between the last two points; p1 / p2 /
+// parallaxAmount start as zero where the HLSL leaves them uninitialised.
+BRMI_DEV float wrap1(float x) { const float y = x + 1.0f; return y - floorf(y); }
+BRMI_DEV f2 parallax_coords(const TexelTables& tb, const TexBinding& height, f3 T, f3 B, f3 N, f2 uv, f3 viewDirWS, float heightmapScale, f2 dUVdx, f2 dUVdy) {
+    uv.y = 1.0f - uv.y;
+    const f3 viewDir = normalize3(f3{dot3(T, viewDirWS), dot3(B, viewDirWS), dot3(N, viewDirWS)});
+    const float maxHeight = heightmapScale, minHeight = maxHeight * 0.5f;
+    int numSteps = 16;
+    const float viewCorrection = (-viewDir.z) + 2.0f;
+    float stepSize = 1.0f / 17.0f;
+    f2 stepOffset{viewDir.x * maxHeight * stepSize, viewDir.y * maxHeight * stepSize};
+    f2 lastOffset{wrap1(viewDir.x * minHeight + uv.x), wrap1(viewDir.y * minHeight + uv.y)};
+    float lastRayDepth = 1.0f, lastHeight = 1.0f;
+    f2 p1{0.0f, 0.0f}, p2{0.0f, 0.0f};
+    bool refine = false;
+#pragma nounroll
+    while (numSteps > 0) {
+        const f2 candidateOffset{wrap1(lastOffset.x - stepOffset.x), wrap1(lastOffset.y - stepOffset.y)};
+        const float currentRayDepth = lastRayDepth - stepSize;
+        const float currentHeight = viewCorrection * sample_grad(tb, height, candidateOffset, dUVdx, dUVdy).x;
+        if (currentHeight > currentRayDepth) {
+            p1 = f2{currentRayDepth, currentHeight};
+            p2 = f2{lastRayDepth, lastHeight};
+            if (refine) break;
+            refine = true;
+            lastRayDepth = p2.x;
+            stepSize = stepSize / (float)numSteps;
+            stepOffset = f2{stepOffset.x / (float)numSteps, stepOffset.y / (float)numSteps};
+            continue;
+        }
+        lastOffset = candidateOffset;
+        lastRayDepth = currentRayDepth;
+        lastHeight = currentHeight;
+        numSteps -= 1;
+    }
+    const float diff1 = p1.x - p1.y, diff2 = p2.x - p2.y;
+    const float denominator = diff2 - diff1;
+    float parallaxAmount = 0.0f;
+    if (denominator != 0.0f) parallaxAmount = (p1.x * diff2 - p2.x * diff1) / denominator;
+    const float offset = ((1.0f - parallaxAmount) * -maxHeight) + minHeight;
+    return f2{viewDir.x * offset + uv.x, viewDir.y * offset + uv.y};
+}
+
 BRMI_DEV float swizzle4(f4 v, uint32_t idx) { return idx == 0u ? v.x : idx == 1u ? v.y : idx == 2u ? v.z : v.w; }
 
 // triangle + vertex tables of one pixel when its cluster has no arena space: the chain the setup kernel walks, per pixel
@@ -203,7 +247,7 @@ constexpr int RESOLVE_WATERFALL = 4;     // distinct mesh instances per 8x8 tile
 #ifndef BRMI_GB_WAVES
 #define BRMI_GB_WAVES 6
 #endif
-template <bool INLINE_TABLES, bool TEXTURED>
+template <bool INLINE_TABLES, bool TEXTURED, bool PARALLAX = false>
 #ifndef BRMI_GBT_WAVES
 #define BRMI_GBT_WAVES 3
 #endif
@@ -305,10 +349,29 @@ __global__ void __launch_bounds__(256, INLINE_TABLES ? 1 : (TEXTURED ? BRMI_GBT_
                     // BuildClodMaterialUvData for UV set 0 + SampleMaterialEvalFromUvCache (utilities.hlsli:1850-2075)
                     const BaryDeriv bd = bary_derivatives(r, l, ndcX, ndcY, winX, winY);
                     const f3 us{tc[0].x, tc[1].x, tc[2].x}, vs{tc[0].y, tc[1].y, tc[2].y};
-                    const f2 uv{dot3(us, l), dot3(vs, l)}, dUVdx{dot3(us, bd.ddx), dot3(vs, bd.ddx)}, dUVdy{dot3(us, bd.ddy), dot3(vs, bd.ddy)};
+                    f2 uv{dot3(us, l), dot3(vs, l)};
+                    const f2 dUVdx{dot3(us, bd.ddx), dot3(vs, bd.ddx)}, dUVdy{dot3(us, bd.ddy), dot3(vs, bd.ddy)};
                     // texture / sampler tables in the address space of the material pointer: scalar loads on the waterfall path
                     auto texturesP = as_space_of(mat, sc.textures); auto samplersP = as_space_of(mat, sc.samplers);
                     auto bind = [&](uint32_t ti, uint32_t si) { return bind_texture(texturesP, sc.textureCount, samplersP, sc.samplerCount, ti, si); };
+                    f3 Tn{}, Bn{};
+                    auto cotangent_frame = [&]() {
+                        // dpdx / dpdy through the model's 3x3 (clodResolveCommon.hlsli:1607-1624), cotangent_frame_from_derivs (utilities.hlsli:323-336)
+                        const f3 pxs{p[0].x, p[1].x, p[2].x}, pys{p[0].y, p[1].y, p[2].y}, pzs{p[0].z, p[1].z, p[2].z};
+                        const f3 dpdx = mul_v3m3(f3{dot3(pxs, bd.ddx), dot3(pys, bd.ddx), dot3(pzs, bd.ddx)}, model);
+                        const f3 dpdy = mul_v3m3(f3{dot3(pxs, bd.ddy), dot3(pys, bd.ddy), dot3(pzs, bd.ddy)}, model);
+                        const f3 dp2perp = cross3(dpdy, worldNormal), dp1perp = cross3(worldNormal, dpdx);
+                        const f3 T = dp2perp * dUVdx.x + dp1perp * dUVdy.x, B = dp2perp * dUVdx.y + dp1perp * dUVdy.y;
+                        const float invmax = rsqrtf_(max2(dot3(T, T), dot3(B, B)));
+                        Tn = T * invmax; Bn = B * invmax;
+                    };
+                    // with parallax the frame is needed before the fetches; without, building it next to its only use keeps six registers free over them
+                    if (PARALLAX && (flags & (BRMI_MATERIAL_NORMAL_MAP | BRMI_MATERIAL_PARALLAX))) cotangent_frame();
+                    if (PARALLAX && (flags & BRMI_MATERIAL_PARALLAX)) {       // PSO_PARALLAX (utilities.hlsli:1869-1897): every slot shares UV set 0, so all of them move
+                        const brmi_camera* cam = sc.cameras + sc.perFrame->mainCameraIndex;
+                        const f3 camPos{cam->positionWorldSpace[0], cam->positionWorldSpace[1], cam->positionWorldSpace[2]};
+                        uv = parallax_coords(tb, bind(mat->heightMapIndex, mat->heightSamplerIndex), Tn, Bn, worldNormal, uv, normalize3(camPos - worldPosition), mat->heightMapScale, dUVdx, dUVdy);
+                    }
                     // One loop over the texture slots (one copy of the sampler code).  Metallic, roughness and occlusion usually are
                     // channels of ONE texture (glTF packing): a slot bound like the previous one reuses its fetch.
                     f4 sBase{1.0f, 1.0f, 1.0f, 1.0f}, sMetal{}, sRough{}, sAo{}, sNormal{}, sEmis{};
@@ -348,14 +411,7 @@ __global__ void __launch_bounds__(256, INLINE_TABLES ? 1 : (TEXTURED ? BRMI_GBT_
                     if (flags & BRMI_MATERIAL_ROUGHNESS_TEXTURE) roughness = swizzle4(sRough, mat->roughnessChannel) * mat->roughnessFactor;
                     if (flags & BRMI_MATERIAL_AO_TEXTURE) ao = swizzle4(sAo, mat->aoChannel);
                     if (flags & BRMI_MATERIAL_NORMAL_MAP) {
-                        // dpdx / dpdy through the model's 3x3 (clodResolveCommon.hlsli:1607-1624), cotangent_frame_from_derivs (utilities.hlsli:323-336)
-                        const f3 pxs{p[0].x, p[1].x, p[2].x}, pys{p[0].y, p[1].y, p[2].y}, pzs{p[0].z, p[1].z, p[2].z};
-                        const f3 dpdx = mul_v3m3(f3{dot3(pxs, bd.ddx), dot3(pys, bd.ddx), dot3(pzs, bd.ddx)}, model);
-                        const f3 dpdy = mul_v3m3(f3{dot3(pxs, bd.ddy), dot3(pys, bd.ddy), dot3(pzs, bd.ddy)}, model);
-                        const f3 dp2perp = cross3(dpdy, worldNormal), dp1perp = cross3(worldNormal, dpdx);
-                        const f3 T = dp2perp * dUVdx.x + dp1perp * dUVdy.x, B = dp2perp * dUVdx.y + dp1perp * dUVdy.y;
-                        const float invmax = rsqrtf_(max2(dot3(T, T), dot3(B, B)));
-                        const f3 Tn = T * invmax, Bn = B * invmax;
+                        if (!PARALLAX) cotangent_frame();
                         const f4 t = sNormal;
                         f3 tn = normalize3(f3{t.x, t.y, t.z} * 2.0f - f3{1.0f, 1.0f, 1.0f});
                         if (flags & BRMI_MATERIAL_NEGATE_NORMALS) tn = -tn;
@@ -442,7 +498,10 @@ int launch_gbuffer(brmi_pass* p, hipStream_t s) {
     hipLaunchKernelGGL(k_resolve_setup, dim3(8192), dim3(64), 0, s, a);
     const bool lean = (uint64_t)p->resolveCapacity >= (uint64_t)p->cfg.maxVisibleClusters * BRMI_MESHLET_MAX_TRIS;
     if (p->sceneHasTextures || p->sceneHasVertexColors) {
-        if (lean) hipLaunchKernelGGL((k_gbuffer<false, true>), dim3(4096), dim3(256), 0, s, a);
+        if (p->sceneHasParallax) {      // its own variant: the ray march costs the others registers they would spill
+            if (lean) hipLaunchKernelGGL((k_gbuffer<false, true, true>), dim3(4096), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((k_gbuffer<true, true, true>), dim3(4096), dim3(256), 0, s, a);
+        } else if (lean) hipLaunchKernelGGL((k_gbuffer<false, true>), dim3(4096), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((k_gbuffer<true, true>), dim3(4096), dim3(256), 0, s, a);
     } else {
         if (lean) hipLaunchKernelGGL((k_gbuffer<false, false>), dim3(4096), dim3(256), 0, s, a);

@@ -1043,7 +1043,8 @@ void addInstance(brmi_scene& sc, const InstanceDef& instIn) {
 
 // ---- procedural textures (materialFeatures bits 3 / 4) ----------------------------------------------------------------
 // RGBA8 with a full box-filtered mip chain.  kind 0: base colour (sRGB) with an alpha mask of round holes; 1: occlusion (R) /
-// roughness (G) / metallic (B), linear; 2: tangent-space normal map; 3: emissive (sRGB) sparse dots; 4: opacity (A) stripes.
+// roughness (G) / metallic (B), linear; 2: tangent-space normal map; 3: emissive (sRGB) sparse dots; 4: opacity (A) stripes;
+// 5: height map (R): bricks above their mortar, fbm on top; 6: the same a twentieth as tall (view rays mostly never dip below it).
 uint32_t addTexture(brmi_scene& sc, uint32_t kind, uint32_t size, uint32_t seed) {
     brmi_texture_desc d{};
     d.texels = reinterpret_cast<const uint8_t*>((uintptr_t)sc.texels.size());
@@ -1072,6 +1073,10 @@ uint32_t addTexture(brmi_scene& sc, uint32_t kind, uint32_t size, uint32_t seed)
             const double cx = std::fmod(u * 6.0, 1.0) - 0.5, cy = std::fmod(v * 6.0, 1.0) - 0.5;
             const double g = std::max(0.0, 1.0 - std::sqrt(cx * cx + cy * cy) * 5.0);
             t[0] = (float)g; t[1] = (float)(g * (0.4 + 0.6 * n)); t[2] = (float)(g * 0.3); t[3] = 1.0f;
+        } else if (kind == 5 || kind == 6) {
+            const bool mortar = (((int)(v * 8.0) & 1) ? std::fmod(u * 4.0 + 0.5, 1.0) : std::fmod(u * 4.0, 1.0)) < 0.06 || std::fmod(v * 8.0, 1.0) < 0.1;
+            const double h = (mortar ? 0.15 : 0.7) + 0.3 * n;
+            t[0] = t[1] = t[2] = (float)(kind == 6 ? h * 0.05 : h); t[3] = 1.0f;
         } else {
             t[0] = t[1] = t[2] = 1.0f;
             t[3] = (float)std::max(0.0, std::min(1.0, (std::fabs(std::fmod(u * 5.0 + v * 2.0, 1.0) - 0.5) - 0.15) * 8.0 + 0.5));
@@ -1095,7 +1100,7 @@ uint32_t addTexture(brmi_scene& sc, uint32_t kind, uint32_t size, uint32_t seed)
     return (uint32_t)sc.textureDescs.size() - 1;
 }
 
-struct TextureSet { std::vector<uint32_t> base, orm, normal, emissive, opacity; };
+struct TextureSet { std::vector<uint32_t> base, orm, normal, emissive, opacity, height; };
 TextureSet addTextures(brmi_scene& sc) {
     // samplers: the reference's default (Sampler.cpp:20-40: trilinear, wrap), a clamp / mirror one, linear with nearest mip, all point
     sc.samplerDescs.push_back({BRMI_ADDRESS_WRAP, BRMI_ADDRESS_WRAP, BRMI_FILTER_LINEAR, BRMI_FILTER_LINEAR, BRMI_FILTER_LINEAR, 0.0f, 0.0f, FLT_MAX});
@@ -1112,6 +1117,7 @@ TextureSet addTextures(brmi_scene& sc) {
     for (uint32_t k = 0; k < 2; k++) t.normal.push_back(addTexture(sc, 2, sizes[k], seed + 32 + k));
     t.emissive.push_back(addTexture(sc, 3, 128, seed + 48));
     t.opacity.push_back(addTexture(sc, 4, 128, seed + 64));
+    if (sc.params.materialFeatures & 128u) { t.height.push_back(addTexture(sc, 5, 256, seed + 80)); t.height.push_back(addTexture(sc, 5, 128, seed + 81)); t.height.push_back(addTexture(sc, 6, 64, seed + 82)); }
     return t;
 }
 
@@ -1154,6 +1160,12 @@ void addMaterials(brmi_scene& sc, Pcg32& rng, uint32_t count) {
                 m.materialFlags |= BRMI_MATERIAL_EMISSIVE_TEXTURE; m.emissiveTextureIndex = tex.emissive[0]; m.emissiveSamplerIndex = 0;
                 m.emissiveFactor[0] = 1.5f; m.emissiveFactor[1] = 1.0f; m.emissiveFactor[2] = 0.5f;
             }
+        }
+        // materialFeatures bit 7 (with bit 3): parallax on about half of the textured materials, with and without a normal map
+        if ((sc.params.materialFeatures & 128u) && (m.materialFlags & BRMI_MATERIAL_TEXTURED) && ((i % 2) == 1 || (i % 6) == 0)) {
+            m.materialFlags |= BRMI_MATERIAL_PARALLAX;
+            m.heightMapIndex = tex.height[i % tex.height.size()]; m.heightSamplerIndex = (i % 4) == 1 ? 2u : 0u;
+            m.heightMapScale = 0.02f + 0.01f * (float)(i % 7);
         }
         if (alphaTested && (i % 3) == 0) {
             m.materialFlags |= BRMI_MATERIAL_ALPHA_TEST | BRMI_MATERIAL_TEXTURED | BRMI_MATERIAL_BASE_COLOR_TEXTURE;

@@ -46,7 +46,8 @@ typedef struct brmi_scene_params {
                                      bit 3: meshes carry a UV set and most materials sample textures (base colour, metallic / roughness, emissive, AO, normal map),
                                      bit 4: every third material is alpha tested against its base-colour / opacity texture (implies bit 3),
                                      bit 5: pages carry RGBA8 vertex colours (CLOD_PAGE_ATTRIBUTE_COLOR) that tint the base colour,
-                                     bit 6: coat / fuzz materials (bits 0 / 1) also bind OpenPBR layer textures (needs bit 3) (default: none) */
+                                     bit 6: coat / fuzz materials (bits 0 / 1) also bind OpenPBR layer textures (needs bit 3),
+                                     bit 7: about half of the textured materials (bit 3) carry a height map with MATERIAL_PARALLAX (default: none) */
     uint32_t cameraStep;          /* frame number on the preset's camera path (0 = start); prevView is the view of step - 1 */
     uint32_t lodBuilder;          /* enum brmi_lod_builder */
     uint32_t spotLightEvery;      /* k > 0: every k-th punctual light is a spot light (0 = point lights only) */

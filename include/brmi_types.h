@@ -63,11 +63,12 @@ extern "C" {
 #define BRMI_MATERIAL_METALLIC_TEXTURE     (1u << 6)
 #define BRMI_MATERIAL_ROUGHNESS_TEXTURE    (1u << 7)
 #define BRMI_MATERIAL_DOUBLE_SIDED         (1u << 8)
+#define BRMI_MATERIAL_PARALLAX             (1u << 9)    /* contact-refinement parallax of the height map: moves the texcoord of the slots below */
 #define BRMI_MATERIAL_NEGATE_NORMALS       (1u << 10)
 #define BRMI_MATERIAL_INVERT_NORMAL_GREEN  (1u << 11)
 #define BRMI_MATERIAL_OPACITY_TEXTURE      (1u << 12)
 #define BRMI_MATERIAL_ALPHA_TEST           (1u << 13)
-/* every material texture slot the path samples (parallax / height maps and the OpenPBR coat / fuzz textures are not) */
+/* every material texture slot whose sample reaches the G-buffer (the height map only moves their texcoord; the OpenPBR coat / fuzz slots live in textureBindings) */
 #define BRMI_MATERIAL_ANY_TEXTURE (BRMI_MATERIAL_BASE_COLOR_TEXTURE | BRMI_MATERIAL_NORMAL_MAP | BRMI_MATERIAL_AO_TEXTURE | \
                                    BRMI_MATERIAL_EMISSIVE_TEXTURE | BRMI_MATERIAL_METALLIC_TEXTURE | BRMI_MATERIAL_ROUGHNESS_TEXTURE | \
                                    BRMI_MATERIAL_OPACITY_TEXTURE)

@@ -13,9 +13,11 @@
 //   BuildClodMaterialUvData / AppendClodMaterialUvSample   BR/shaders/Include/clodResolveCommon.hlsli:271-430
 //   cotangent_frame_from_derivs / BuildMaterialTBN          BR/shaders/Include/utilities.hlsli:323-336,1278-1287
 //   ResolveCanonicalOpenPBRSurface              BR/shaders/Include/utilities.hlsli:136-161
+//   getContactRefinementParallaxCoordsAndHeight BR/shaders/Include/parallax.hlsli:39-120 (call: utilities.hlsli:1869-1897)
 // Scope: triangle clusters (no Reyes / voxel).  Vertex colours (CLOD_PAGE_ATTRIBUTE_COLOR) tint the base colour.  Material texture slots: base colour, opacity, metallic,
-// roughness, normal map, AO, emissive and the six OpenPBR coat / fuzz slots, each through the software sampler of orc_texture.h; no
-// parallax / height map, no texture streaming feedback.  A slot's UV set index below MATERIAL_MAX_UNIQUE_UV_SETS (8) is decoded
+// roughness, normal map, AO, emissive and the six OpenPBR coat / fuzz slots, each through the software sampler of orc_texture.h;
+// contact-refinement parallax (MATERIAL_PARALLAX) moves the texcoord of every slot that shares the height map's UV set; no texture
+// streaming feedback.  A slot's UV set index below MATERIAL_MAX_UNIQUE_UV_SETS (8) is decoded
 // as that set (a set the page does not carry decodes to (0, 0)); any other index uses set 0.
 // G-buffer formats: BR/include/Render/RenderGraphBuildHelper.h:41-139, BR/src/Renderer.cpp:1618.
 #include "orc_common.h"
@@ -70,6 +72,51 @@ static float3 octDecodeNormal(uint32_t packed) {
         v.x = fx; v.y = fy;
     }
     return normalize(v);
+}
+
+// getContactRefinementParallaxCoordsAndHeight (parallax.hlsli:46-120): 16 coarse steps along the tangent-space view ray, on the first
+// hit one refinement pass with the step divided by the steps left, then a secant between the last two points.  T, B, N are the rows
+// of the cotangent frame.  The HLSL reads p1 / p2 / parallaxAmount uninitialised when the ray never dips below the height field or
+// the secant is degenerate; here both start as zero (p1 = p2 = 0 gives parallaxAmount = 0), which is what DXC's undef lowers to.
+static inline float wrap1(float x) { const float y = x + 1.0f; return y - std::floor(y); }      // WrapFloat2: frac(input + 1.0)
+static float2 parallaxCoords(const brmi_scene_buffers& sc, uint32_t heightMapIndex, uint32_t heightSamplerIndex, float3 T, float3 B, float3 N,
+                             float2 uv, float3 viewDirWS, float heightmapScale, float2 dUVdx, float2 dUVdy) {
+    uv.y = 1.0f - uv.y;
+    const float3 viewDir = normalize(float3{dot(T, viewDirWS), dot(B, viewDirWS), dot(N, viewDirWS)});     // mul(TBN, viewDir)
+    const float maxHeight = heightmapScale, minHeight = maxHeight * 0.5f;
+    int numSteps = 16;
+    const float viewCorrection = (-viewDir.z) + 2.0f;
+    float stepSize = 1.0f / ((float)numSteps + 1.0f);
+    float2 stepOffset{viewDir.x * maxHeight * stepSize, viewDir.y * maxHeight * stepSize};
+    float2 lastOffset{wrap1(viewDir.x * minHeight + uv.x), wrap1(viewDir.y * minHeight + uv.y)};
+    float lastRayDepth = 1.0f, lastHeight = 1.0f;
+    float2 p1{0.0f, 0.0f}, p2{0.0f, 0.0f};
+    bool refine = false;
+    while (numSteps > 0) {
+        const float2 candidateOffset{wrap1(lastOffset.x - stepOffset.x), wrap1(lastOffset.y - stepOffset.y)};
+        const float currentRayDepth = lastRayDepth - stepSize;
+        const float currentHeight = viewCorrection * sampleGrad(sc, heightMapIndex, heightSamplerIndex, candidateOffset, dUVdx, dUVdy).x;      // Texture2D<float>
+        if (currentHeight > currentRayDepth) {
+            p1 = float2{currentRayDepth, currentHeight};
+            p2 = float2{lastRayDepth, lastHeight};
+            if (refine) { lastHeight = currentHeight; break; }
+            refine = true;
+            lastRayDepth = p2.x;
+            stepSize /= (float)numSteps;
+            stepOffset.x /= (float)numSteps; stepOffset.y /= (float)numSteps;
+            continue;
+        }
+        lastOffset = candidateOffset;
+        lastRayDepth = currentRayDepth;
+        lastHeight = currentHeight;
+        numSteps -= 1;
+    }
+    const float diff1 = p1.x - p1.y, diff2 = p2.x - p2.y;
+    const float denominator = diff2 - diff1;
+    float parallaxAmount = 0.0f;
+    if (denominator != 0.0f) parallaxAmount = (p1.x * diff2 - p2.x * diff1) / denominator;
+    const float offset = ((1.0f - parallaxAmount) * -maxHeight) + minHeight;
+    return float2{viewDir.x * offset + uv.x, viewDir.y * offset + uv.y};
 }
 
 struct GBufferOut {
@@ -135,8 +182,35 @@ static bool resolvePixel(const brmi_scene_buffers& sc, const brmi_visible_cluste
         const float3 iu = interpDeriv(bary, a.x, b.x, c.x), iv = interpDeriv(bary, a.y, b.y, c.y);
         return UvSample{{iu.x, iv.x}, {iu.y, iv.y}, {iu.z, iv.z}};
     };
+    // the cotangent frame of the normal map / parallax (BuildMaterialUvBindings: the normal slot's UVs, else the height slot's)
+    float3 Tn{}, Bn{};
+    auto resolvedSet = [](uint32_t uvSetIndex) { return uvSetIndex < 8u ? uvSetIndex : 0u; };
+    if (flags & (BRMI_MATERIAL_NORMAL_MAP | BRMI_MATERIAL_PARALLAX)) {
+        // dpdx / dpdy of the object-space position through the model's 3x3 (clodResolveCommon.hlsli:1607-1624)
+        const float3 ipx = interpDeriv(bary, p[0].x, p[1].x, p[2].x), ipy = interpDeriv(bary, p[0].y, p[1].y, p[2].y), ipz = interpDeriv(bary, p[0].z, p[1].z, p[2].z);
+        const float3 dpdx = mul3(float3{ipx.y, ipy.y, ipz.y}, M(obj.model)), dpdy = mul3(float3{ipx.z, ipy.z, ipz.z}, M(obj.model));
+        const UvSample u = uvOf((flags & BRMI_MATERIAL_NORMAL_MAP) ? mat.normalUvSetIndex : mat.heightUvSetIndex);
+        // cotangent_frame_from_derivs
+        const float3 dp2perp = cross(dpdy, worldNormal), dp1perp = cross(worldNormal, dpdx);
+        const float3 T = dp2perp * u.dUVdx.x + dp1perp * u.dUVdy.x, B = dp2perp * u.dUVdx.y + dp1perp * u.dUVdy.y;
+        const float invmax = rsqrt(fmax2(dot(T, T), dot(B, B)));
+        Tn = T * invmax; Bn = B * invmax;
+    }
+    // PSO_PARALLAX (utilities.hlsli:1869-1897): every slot whose UV cache entry is the height map's samples at the displaced texcoord
+    bool hasParallaxUv = false; float2 parallaxUv{};
+    if (flags & BRMI_MATERIAL_PARALLAX) {
+        const UvSample h = uvOf(mat.heightUvSetIndex);
+        const float3 camPos{cam.positionWorldSpace[0], cam.positionWorldSpace[1], cam.positionWorldSpace[2]};
+        parallaxUv = parallaxCoords(sc, mat.heightMapIndex, mat.heightSamplerIndex, Tn, Bn, worldNormal, h.uv, normalize(camPos - worldPosition), mat.heightMapScale, h.dUVdx, h.dUVdy);
+        hasParallaxUv = true;
+    }
+    auto uvOfSlot = [&](uint32_t uvSetIndex) {      // ResolveMaterialUvSample: the parallax result keeps the height map's gradients
+        UvSample u = uvOf(uvSetIndex);
+        if (hasParallaxUv && resolvedSet(uvSetIndex) == resolvedSet(mat.heightUvSetIndex)) u.uv = parallaxUv;
+        return u;
+    };
     auto sample = [&](uint32_t textureIndex, uint32_t samplerIndex, uint32_t uvSetIndex) {
-        const UvSample u = uvOf(uvSetIndex);
+        const UvSample u = uvOfSlot(uvSetIndex);
         return sampleGrad(sc, textureIndex, samplerIndex, u.uv, u.dUVdx, u.dUVdy);
     };
     // DecodeCompressedColor + the vertexColor interpolation (clodResolveCommon.hlsli:657-667,1521-1531,1641-1648)
@@ -160,15 +234,7 @@ static bool resolvePixel(const brmi_scene_buffers& sc, const brmi_visible_cluste
     if (flags & BRMI_MATERIAL_ROUGHNESS_TEXTURE) roughness = swizzle(sample(mat.roughnessTextureIndex, mat.roughnessSamplerIndex, mat.roughnessUvSetIndex), mat.roughnessChannel) * mat.roughnessFactor;
     float3 normalWS = worldNormal;
     if (flags & BRMI_MATERIAL_NORMAL_MAP) {
-        // dpdx / dpdy of the object-space position through the model's 3x3 (clodResolveCommon.hlsli:1607-1624)
-        const float3 ipx = interpDeriv(bary, p[0].x, p[1].x, p[2].x), ipy = interpDeriv(bary, p[0].y, p[1].y, p[2].y), ipz = interpDeriv(bary, p[0].z, p[1].z, p[2].z);
-        const float3 dpdx = mul3(float3{ipx.y, ipy.y, ipz.y}, M(obj.model)), dpdy = mul3(float3{ipx.z, ipy.z, ipz.z}, M(obj.model));
-        const UvSample u = uvOf(mat.normalUvSetIndex);
-        // cotangent_frame_from_derivs
-        const float3 dp2perp = cross(dpdy, worldNormal), dp1perp = cross(worldNormal, dpdx);
-        const float3 T = dp2perp * u.dUVdx.x + dp1perp * u.dUVdy.x, B = dp2perp * u.dUVdx.y + dp1perp * u.dUVdy.y;
-        const float invmax = rsqrt(fmax2(dot(T, T), dot(B, B)));
-        const float3 Tn = T * invmax, Bn = B * invmax;
+        const UvSample u = uvOfSlot(mat.normalUvSetIndex);
         const float4 t = sampleGrad(sc, mat.normalTextureIndex, mat.normalSamplerIndex, u.uv, u.dUVdx, u.dUVdy);
         float3 tn = normalize(float3{t.x, t.y, t.z} * 2.0f - float3{1.0f, 1.0f, 1.0f});
         if (flags & BRMI_MATERIAL_NEGATE_NORMALS) tn = -tn;
@@ -229,6 +295,18 @@ static bool resolvePixel(const brmi_scene_buffers& sc, const brmi_visible_cluste
 using namespace orc;
 
 extern "C" {
+
+// parallaxCoords on its own, one call per sample (tests): frame rows T / B / N, texcoord, world-space view direction, gradients
+int orc_parallax_coords(const brmi_scene_buffers* sc, uint32_t heightMapIndex, uint32_t heightSamplerIndex, float heightmapScale, const float* T, const float* B, const float* N,
+                        const float* uv, const float* viewDir, const float* dUVdx, const float* dUVdy, uint64_t n, float* out) {
+    for (uint64_t i = 0; i < n; i++) {
+        const float2 r = parallaxCoords(*sc, heightMapIndex, heightSamplerIndex, float3{T[i * 3], T[i * 3 + 1], T[i * 3 + 2]}, float3{B[i * 3], B[i * 3 + 1], B[i * 3 + 2]},
+                                        float3{N[i * 3], N[i * 3 + 1], N[i * 3 + 2]}, float2{uv[i * 2], uv[i * 2 + 1]}, float3{viewDir[i * 3], viewDir[i * 3 + 1], viewDir[i * 3 + 2]},
+                                        heightmapScale, float2{dUVdx[i * 2], dUVdx[i * 2 + 1]}, float2{dUVdy[i * 2], dUVdy[i * 2 + 1]});
+        out[i * 2] = r.x; out[i * 2 + 1] = r.y;
+    }
+    return 0;
+}
 
 // All images are linear W x H.  Pixels without geometry are left untouched (the reference does not
 // write them); callers pass zero-initialised buffers.

@@ -60,6 +60,9 @@ SCENE_CASES = {
     # OpenPBR coat / fuzz texture slots (ApplyOpenPBRTextureSampling) on layered materials
     "sponza_layer_textures": ("sponza", 640, 360, dict(point_lights=32, size_scale=0.25, material_features=64 | 8 | 3)),
     "tiny_layer_textures_only": ("tiny", 256, 144, dict(point_lights=4, lod_levels=2, material_features=64 | 16 | 3 | 32)),
+    # contact-refinement parallax: the height map moves the texcoord of every slot (with / without a normal map, rays that never hit)
+    "tiny_parallax": ("tiny", 256, 144, dict(point_lights=6, lod_levels=2, material_features=128 | 8)),
+    "sponza_parallax_all": ("sponza", 640, 360, dict(point_lights=32, size_scale=0.25, material_features=128 | 64 | 32 | 24 | 3)),
     "tiny_clod": ("tiny", 256, 144, dict(point_lights=4, lod_builder="clusterlod")),
     "sponza_clod": ("sponza", 640, 360, dict(point_lights=32, size_scale=0.25, lod_builder="clusterlod")),
     "bistro_clod_skinned": ("bistro", 640, 360, dict(point_lights=32, size_scale=0.3, skinned_fraction=0.3, lod_builder="clusterlod")),

@@ -116,6 +116,86 @@ def test_sampler_matches_a_float64_restatement_of_the_d3d_filter(texscene):
                 assert bad.sum() <= (8 if filt == 0 else 0), (t, s, l, int(bad.sum()), float(np.abs(got - want).max()))
 
 
+def test_parallax_march_matches_a_stepwise_restatement():
+    """getContactRefinementParallaxCoordsAndHeight (parallax.hlsli:46-120): the oracle's march against the same march written out
+    step by step here on numpy float32 scalars (heights through orc_sample_grad), plus its fixed points: scale 0 returns the
+    v-flipped texcoord untouched, an unbound height map (reads 1) hits on the first step."""
+    import orc
+    from basicrenderer_amd import Scene
+    scene = Scene("tiny", 160, 90, point_lights=2, lod_levels=2, material_features=128 | 8)
+    sb = scene.host_buffers(); lib = orc.lib()
+    n_tex = scene.counts["textureDescs"]
+    f32 = np.float32
+    rng = np.random.default_rng(11)
+    n = 160
+    N = rng.standard_normal((n, 3)); N /= np.linalg.norm(N, axis=1, keepdims=True)
+    T = np.cross(N, rng.standard_normal((n, 3))); T /= np.linalg.norm(T, axis=1, keepdims=True)
+    B = np.cross(N, T)
+    V = N * rng.uniform(0.15, 1.0, (n, 1)) + T * rng.uniform(-1, 1, (n, 1)) + B * rng.uniform(-1, 1, (n, 1)); V /= np.linalg.norm(V, axis=1, keepdims=True)
+    T, B, N, V = (np.ascontiguousarray(a, dtype=f32) for a in (T, B, N, V))
+    uv = rng.uniform(-1.5, 2.5, (n, 2)).astype(f32)
+    ddx = (rng.uniform(-1, 1, (n, 2)) * 0.004).astype(f32); ddy = (rng.uniform(-1, 1, (n, 2)) * 0.004).astype(f32)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+
+    def oracle(tex, samp, scale):
+        out = np.zeros((n, 2), dtype=f32)
+        lib.orc_parallax_coords(C.byref(sb), C.c_uint32(tex), C.c_uint32(samp), C.c_float(scale), P(T), P(B), P(N), P(uv), P(V), P(ddx), P(ddy), C.c_uint64(n), P(out))
+        return out
+
+    def height(tex, samp, i, u, v):
+        o = np.zeros((1, 4), dtype=f32); q = np.array([[u, v]], dtype=f32)
+        lib.orc_sample_grad(C.byref(sb), C.c_uint32(tex), C.c_uint32(samp), P(q), P(ddx[i:i + 1].copy()), P(ddy[i:i + 1].copy()), C.c_uint64(1), P(o))
+        return o[0, 0]
+
+    def wrap1(x):
+        y = f32(x + f32(1.0)); return f32(y - np.floor(y))
+
+    def march(tex, samp, scale, i):
+        u, v = uv[i, 0], f32(f32(1.0) - uv[i, 1])
+        d = np.array([f32(f32(T[i, 0] * V[i, 0] + T[i, 1] * V[i, 1]) + T[i, 2] * V[i, 2]), f32(f32(B[i, 0] * V[i, 0] + B[i, 1] * V[i, 1]) + B[i, 2] * V[i, 2]),
+                      f32(f32(N[i, 0] * V[i, 0] + N[i, 1] * V[i, 1]) + N[i, 2] * V[i, 2])], dtype=f32)
+        inv = f32(f32(1.0) / np.sqrt(f32(f32(d[0] * d[0] + d[1] * d[1]) + d[2] * d[2])))        # normalize = v * rsqrt(dot(v, v)), rsqrt = 1 / sqrt
+        d = (d * inv).astype(f32)
+        max_h = f32(scale); min_h = f32(max_h * f32(0.5))
+        steps = 16; corr = f32(-d[2] + f32(2.0)); step = f32(f32(1.0) / f32(17.0))
+        so = [f32(f32(d[0] * max_h) * step), f32(f32(d[1] * max_h) * step)]
+        last = [wrap1(f32(d[0] * min_h) + u), wrap1(f32(d[1] * min_h) + v)]
+        last_depth, last_height = f32(1.0), f32(1.0)
+        p1, p2, refine, fetches = (f32(0), f32(0)), (f32(0), f32(0)), False, 0
+        while steps > 0:
+            cand = [wrap1(last[0] - so[0]), wrap1(last[1] - so[1])]
+            depth = f32(last_depth - step)
+            h = f32(corr * height(tex, samp, i, cand[0], cand[1])); fetches += 1
+            if h > depth:
+                p1, p2 = (depth, h), (last_depth, last_height)
+                if refine:
+                    break
+                refine = True; last_depth = p2[0]; step = f32(step / f32(steps)); so = [f32(so[0] / f32(steps)), f32(so[1] / f32(steps))]
+                continue
+            last, last_depth, last_height = cand, depth, h
+            steps -= 1
+        d1, d2 = f32(p1[0] - p1[1]), f32(p2[0] - p2[1]); den = f32(d2 - d1)
+        amount = f32(f32(f32(p1[0] * d2) - f32(p2[0] * d1)) / den) if den != 0 else f32(0)
+        off = f32(f32(f32(f32(1.0) - amount) * f32(-max_h)) + min_h)
+        return np.array([f32(f32(d[0] * off) + u), f32(f32(d[1] * off) + v)], dtype=f32), fetches, steps == 0
+
+    with np.errstate(all="ignore"):
+        missed = 0
+        for tex, samp, scale in ((n_tex - 3, 0, 0.05), (n_tex - 2, 2, 0.08), (n_tex - 1, 0, 0.04)):       # the 256 and 128 height maps, the shallow one
+            got = oracle(tex, samp, scale)
+            assert np.isfinite(got).all()
+            for i in range(0, n, 4):
+                want, fetches, ran_out = march(tex, samp, scale, i)
+                missed += ran_out
+                assert 1 <= fetches <= 32
+                assert np.array_equal(got[i], want), (tex, i, got[i], want)
+        assert missed > 0                               # the shallow map: some rays never dip below the height field (p1 = p2 = 0 path)
+    flipped = np.stack([uv[:, 0], f32(1.0) - uv[:, 1]], 1)
+    assert np.array_equal(oracle(n_tex - 3, 0, 0.0), flipped)
+    # an unbound height map reads 1: hit on the first coarse step and again on the first refined one -> a fixed secant, still finite
+    assert np.isfinite(oracle(0xFFFFFFFF, 0, 0.05)).all()
+
+
 def test_sampler_returns_the_texel_at_texel_centres_and_wraps(texscene):
     ts = texscene
     img = ts.level(0, 0)

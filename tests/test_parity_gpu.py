@@ -13,7 +13,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 CASES = ["tiny", "tiny_lod", "tiny_coat_fuzz", "sponza_coat_fuzz", "sponza_small", "bistro_small", "tiny_skinned", "bistro_skinned", "tiny_clod", "sponza_clod", "bistro_clod_skinned", "sponza_spots", "bistro_mirrored",
-         "tiny_textured", "sponza_textured", "tiny_alpha", "sponza_alpha", "bistro_alpha_skinned", "sponza_clod_alpha", "tiny_vcolor", "sponza_vcolor_textured", "sponza_layer_textures", "tiny_layer_textures_only"]
+         "tiny_textured", "sponza_textured", "tiny_alpha", "sponza_alpha", "bistro_alpha_skinned", "sponza_clod_alpha", "tiny_vcolor", "sponza_vcolor_textured", "sponza_layer_textures", "tiny_layer_textures_only", "tiny_parallax", "sponza_parallax_all"]
 
 
 @pytest.fixture(scope="module")
@@ -320,7 +320,7 @@ def test_dangling_scene_indices_are_refused():
 
 def test_unsupported_material_bindings_are_refused():
     """What this path does not decode is rejected by brmi_set_scene with a message, never rendered wrong: a missing texture table,
-    a texture slot on a UV set other than 0, parallax (height-map) materials."""
+    a texture slot (or the parallax height map) on a UV set other than 0."""
     from basicrenderer_amd import Scene
     from basicrenderer_amd.renderer import VisibilityRenderer, BrmiError
     mat_words = 276 // 4
@@ -340,8 +340,9 @@ def test_unsupported_material_bindings_are_refused():
         VisibilityRenderer(sc)
     sc = scene()
     m = sc.arrays["materials"].view(np.uint32).reshape(-1, mat_words)
-    m[0, 0] |= 1 << 9                                                # MATERIAL_PARALLAX
-    with pytest.raises(BrmiError, match="PARALLAX"):
+    m[textured, 0] |= 1 << 9                                         # MATERIAL_PARALLAX ...
+    m[textured, 58] = 3                                              # ... with heightUvSetIndex (word 58) = 3
+    with pytest.raises(BrmiError, match="height map must use UV set 0"):
         VisibilityRenderer(sc)
     sc = scene()
     op = sc.arrays["openpbrMaterials"].view(np.uint32).reshape(-1, 100)

@@ -19,8 +19,8 @@ import os
 cases = [dict(preset="tiny", width=200, height=120, point_lights=3, skinned_fraction=1.0, lod_levels=2),
          dict(preset="sponza", width=320, height=180, point_lights=16, size_scale=0.1, material_features=3),
          # UV streams, alpha test, texture-sampled materials (every sampler state), vertex colours, OpenPBR layer textures; cache round trip
-         dict(preset="sponza", width=333, height=187, point_lights=8, size_scale=0.1, material_features=127, lod_levels=2, export_cache="$OUT/cache"),
-         dict(preset="sponza", width=333, height=187, point_lights=8, size_scale=0.1, material_features=127, lod_levels=2, cache_dir="$OUT/cache")]
+         dict(preset="sponza", width=333, height=187, point_lights=8, size_scale=0.1, material_features=255, lod_levels=2, export_cache="$OUT/cache"),
+         dict(preset="sponza", width=333, height=187, point_lights=8, size_scale=0.1, material_features=255, lod_levels=2, cache_dir="$OUT/cache")]
 if os.path.exists("$ROOT/oracle/_ref/libclodref.so"):
     cases.append(dict(preset="bistro", width=320, height=180, point_lights=16, size_scale=0.2, skinned_fraction=0.3, lod_builder="clusterlod"))
 for kw in cases:
