@@ -15,7 +15,7 @@ def _golden(name):
     return np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
 
 
-@pytest.mark.parametrize("name", ["golden_tiny", "golden_tiny_lod_coat_fuzz", "golden_sponza", "golden_tiny_skinned_occlusion", "golden_tiny_textured_alpha", "golden_sponza_all_features"])
+@pytest.mark.parametrize("name", ["golden_tiny", "golden_tiny_lod_coat_fuzz", "golden_sponza", "golden_tiny_skinned_occlusion", "golden_tiny_textured_alpha", "golden_sponza_all_features", "golden_tiny_parallax"])
 def test_oracle_reproduces_golden_fixtures(name):
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))

@@ -97,7 +97,7 @@ def test_depth_and_gbuffer_bit_exact(name, gpu_frames, oracle_frames):
         assert not bad.any(), f"{key}: {int(bad.sum())} of {bad.size} values differ"
 
 
-@pytest.mark.parametrize("name", ["golden_tiny", "golden_tiny_lod_coat_fuzz", "golden_sponza", "golden_tiny_textured_alpha", "golden_sponza_all_features"])
+@pytest.mark.parametrize("name", ["golden_tiny", "golden_tiny_lod_coat_fuzz", "golden_sponza", "golden_tiny_textured_alpha", "golden_sponza_all_features", "golden_tiny_parallax"])
 def test_gpu_reproduces_the_committed_golden_fixtures(name):
     """The frozen fixtures under tests/golden/ (inputs regenerated from the seed, expected outputs committed): a reference that does
     not move with the oracle's source."""
@@ -387,6 +387,7 @@ def test_full_size_4k_properties(preset, lights):
                                                   ("sponza", 3840, 2160, 64, dict()),                # configs[1]: the bench workload
                                                   ("bistro", 3840, 2160, 256, dict()),               # configs[2]
                                                   ("san_miguel", 3840, 2160, 256, dict(material_features=24)),    # configs[3] with its alpha-tested materials
+                                                  ("sponza", 3840, 2160, 64, dict(material_features=255, spot_every=3)),   # every material feature incl. parallax, at 4K
                                                   ("zorah", 7680, 4320, 64, dict(skinned_fraction=0.01))])        # configs[4]: 8K, 100 k instances, 1 % skinned
 def test_full_size_frames_against_the_oracle(preset, W, H, lights, kw):
     """BASELINE.json's configurations at their full size, whole frame against the CPU oracle (it renders a 4K frame in well under a
