@@ -46,6 +46,9 @@ def frames():
         cases.append((f"sponza4k seed{seed} mf63", dict(preset="sponza", width=3840, height=2160, point_lights=64, seed=seed, material_features=63, spot_every=3)))
         cases.append((f"bistro4k seed{seed} mf59 skinned", dict(preset="bistro", width=3840, height=2160, point_lights=256, seed=seed, material_features=59, skinned_fraction=0.3)))
         cases.append((f"sanmiguel4k seed{seed} mf24", dict(preset="san_miguel", width=3840, height=2160, point_lights=256, seed=seed, material_features=24)))
+    for seed in range(1, 4):
+        cases.append((f"bistro4k seed{seed} mf255 parallax", dict(preset="bistro", width=3840, height=2160, point_lights=256, seed=seed, material_features=255)))
+        cases.append((f"sanmiguel4k seed{seed} mf152 parallax alpha", dict(preset="san_miguel", width=3840, height=2160, point_lights=128, seed=seed, material_features=128 | 24)))
     cases.append(("sponza8k", dict(preset="sponza", width=7680, height=4320, point_lights=64)))
     cases.append(("bistro4k clod", dict(preset="bistro", width=3840, height=2160, point_lights=256, lod_builder="clusterlod", material_features=24)))
     cases.append(("zorah4k", dict(preset="zorah", width=3840, height=2160, point_lights=64, size_scale=0.02)))
