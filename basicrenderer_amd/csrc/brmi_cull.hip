@@ -793,6 +793,7 @@ __global__ void __launch_bounds__(256) k_scatter_visible(const TempVisible* temp
             const unsigned long long v0 = baseV + (inclV - verts), t0 = baseT + (inclT - tris);
             const bool fits = v0 + verts <= resolveCapacity && t0 + tris <= resolveCapacity;
             cs.vertBase = fits ? (uint32_t)v0 : BRMI_ARENA_NONE; cs.triBase32 = fits ? (uint32_t)t0 : BRMI_ARENA_NONE;
+            if (!fits) atomicOr(&counters[CNT_RESOLVE_SPILL], 1u);      // selects the G-buffer kernel variant (brmi_gbuffer)
             setup[dst] = cs;
             used[dst] = 0;        // "owns a pixel" flag of the G-buffer pass
         }

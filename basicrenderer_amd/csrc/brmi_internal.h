@@ -33,6 +33,7 @@ enum CounterIndex : uint32_t {
     CNT_BIN_OVERFLOW,         // raster records that found their screen bin full (rasterised in place with global atomics)
     CNT_DEFERRED_PIXELS_B,    // second deferred-pixel counter: shading calls alternate, each clears the other one for the next call
     CNT_DEFERRED_PIXELS,      // pixels the specialised shading kernel left to the general one
+    CNT_RESOLVE_SPILL,        // some visible cluster found the resolve arena full (its pixels decode their vertices in place)
     CNT_RESOLVE_MARKED,       // the G-buffer pass marked the clusters that own a pixel (frames with more triangles than pixels)
     CNT_FRONTIER0 = 32,       // frontier sizes per BFS level: [CNT_FRONTIER0 + level]
     CNT_STRIPES = 128,        // 64 stripes x 32 words: per-stripe {instances tested, instances visible, nodes visited}
