@@ -26,7 +26,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md)
-PROFILE_TAG = {"sponza": "r01_sponza4k", "bistro": "r01_bistro4k"}   # profiles/<tag>_traffic.json (tools/profile.sh)
+# profiles/<tag>_traffic.json (tools/profile.sh), keyed by (workload, material feature bits): traffic of another configuration is not this one's
+PROFILE_TAG = {("sponza", 0): "r01_sponza4k", ("bistro", 0): "r01_bistro4k", ("san_miguel", 0): "r01_sanmiguel4k",
+               ("san_miguel", 24): "r01_sanmiguel4k_alpha_tex", ("sponza", 136): "r01_sponza4k_parallax"}
 DOMINANT_KERNEL = {"raster": "k_raster", "gbuffer": "k_gbuffer", "shade": "k_shade", "cull": "k_traverse+k_cull_clusters", "clear": "k_clear_vis",
                    "light_cluster": "k_light_clustering", "depth_copy": "k_depth_copy", "hzb": "k_hzb_head", "cull2": "k_traverse+k_cull_clusters", "raster2": "k_raster"}
 
@@ -133,7 +135,7 @@ def main():
         # (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE; tools/profile.sh).  null when no profile of this workload / kernel is committed.
         traffic = None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", PROFILE_TAG.get(args.workload, "") + "_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", PROFILE_TAG.get((args.workload, args.material_features), "none") + "_traffic.json")))
             # the stage's dominant kernel; template instantiations ("k_shade<0>", "k_raster<true>") are matched by base name and the
             # one that takes the most time per launch is used
             base = DOMINANT_KERNEL.get(dom, dom).split("<")[0]
@@ -151,7 +153,7 @@ def main():
                                    + (", LOD DAG built by the reference's clusterlod.h" if args.lod_builder == "clusterlod" else "")
                                    + (f", material features {args.material_features} (8 = texture-sampled, 16 = alpha-tested materials)" if args.material_features else "")
                                    + (f", {n} row bands of 1080 rows + RCCL all-gather of HDR ({args.transport}, pipelined one frame deep)" if n > 1 else ""),
-                       "baseline_config": "configs[1]" if args.workload == "sponza" else "configs[2]",
+                       "baseline_config": {"sponza": "configs[1]", "bistro": "configs[2]", "san_miguel": "configs[3]"}[args.workload],
                        "pixels_per_gpu": W * (band[1] - band[0]), "visible_clusters_rank0": int(c.visibleClusters),
                        "occlusion_culling": bool(args.occlusion), "visible_clusters_phase2_rank0": int(c.visibleClustersPhase2),
                        "meshlets_tested_rank0": int(c.meshletsTested), "partition": f"row bands x{n}" if n > 1 else "single GPU"},
