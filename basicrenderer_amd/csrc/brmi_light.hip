@@ -390,12 +390,18 @@ BRMI_DEV f3 light_contribution(const Luts& L, const Frag& f, const PixelCtx& c, 
     const float DV = d_ggx(base.specularAlpha, NoH) * v_smith_ggx(base.specularAlpha, NoV, NoL);
     const float pw = __builtin_amdgcn_exp2f(5.0f * __builtin_amdgcn_logf(1.0f - LoH));   // pow(1 - LoH, 5) = exp2(5 log2 x), as DXC lowers it
     const f3 Fd = base.dielectricSpecularF0 + (f3{c.f90Diel, c.f90Diel, c.f90Diel} - base.dielectricSpecularF0) * pw;
-    const f3 Fm = base.metalSpecularF0 + (f3{c.f90Metal, c.f90Metal, c.f90Metal} - base.metalSpecularF0) * pw;
-    const float mLight = sample_im_e(L, c.im, NoL);
-    const float mTab = qdiv(c.mView * mLight, c.mAvgClamped);
-    const float mScale = min2(mTab, qrcp(max2(NoL, 1.0e-4f))) * (1.0f / PI_F);
     const f3 dielSpec = base.dielectricSpecularWeight * (DV * Fd) * c.dielComp;
-    const f3 metalSpec = base.metalSpecularWeight * (DV * Fm + base.metalMultipleScatterScale * mScale);
+    // A dielectric pixel (metal weight 0) has metalSpec = 0 * (finite) = +-0, and dielSpec + (+-0) = dielSpec up to the sign of a zero
+    // that the sums into `lighting` (which starts at +0) cannot carry: the metal lobe -- table fetch, Fresnel, multiple-scatter term --
+    // is skipped for it.  A non-finite D*V keeps the full expression (0 * inf is NaN, not 0).
+    f3 metalSpec{0.0f, 0.0f, 0.0f};
+    if (!(base.metalSpecularWeight == 0.0f && fabsf(DV) <= 3.4028234e38f)) {
+        const f3 Fm = base.metalSpecularF0 + (f3{c.f90Metal, c.f90Metal, c.f90Metal} - base.metalSpecularF0) * pw;
+        const float mLight = sample_im_e(L, c.im, NoL);
+        const float mTab = qdiv(c.mView * mLight, c.mAvgClamped);
+        const float mScale = min2(mTab, qrcp(max2(NoL, 1.0e-4f))) * (1.0f / PI_F);
+        metalSpec = base.metalSpecularWeight * (DV * Fm + base.metalMultipleScatterScale * mScale);
+    }
     const f3 specular = dielSpec + metalSpec;
     f3 brdf;
     if (MODE == 0) brdf = diffuse + specular;
