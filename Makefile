@@ -13,7 +13,7 @@ EXTRA     ?=
 HIPFLAGS  := $(EXTRA) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math \
              -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero -Iinclude -Wall
 ORCFLAGS  := -O2 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -fopenmp -Iinclude -Wall
-SCNFLAGS  := -O2 -std=c++17 -fPIC -shared -Iinclude -Wall -ldl
+SCNFLAGS  := -O2 -std=c++17 -fPIC -shared -Iinclude -Wall -fopenmp
 
 HIP_SRCS  := $(wildcard basicrenderer_amd/csrc/*.hip)
 HIP_HDRS  := $(wildcard basicrenderer_amd/csrc/*.h) $(wildcard include/*.h)
@@ -26,9 +26,10 @@ scene: $(LIBDIR)/libbrmi_scene.so
 oracle: $(ORCDIR)/liboracle.so
 hip: $(LIBDIR)/libbrmi.so
 
-$(LIBDIR)/libbrmi_scene.so: basicrenderer_amd/csrc/scene/scene_gen.cpp include/brmi_scene.h include/brmi_types.h
+SCN_SRCS  := basicrenderer_amd/csrc/scene/scene_gen.cpp basicrenderer_amd/csrc/scene/lod_builder.cpp
+$(LIBDIR)/libbrmi_scene.so: $(SCN_SRCS) include/brmi_scene.h include/brmi_types.h
 	@mkdir -p $(LIBDIR)
-	$(CXX) $(SCNFLAGS) $< -o $@
+	$(CXX) $(SCNFLAGS) $(SCN_SRCS) -o $@
 
 $(ORCDIR)/liboracle.so: $(ORC_SRCS) $(ORC_HDRS)
 	@mkdir -p $(ORCDIR)

@@ -15,7 +15,25 @@ u32, u64, f32, vp = C.c_uint32, C.c_uint64, C.c_float, C.c_void_p
 class SceneParams(C.Structure):
     _fields_ = [("preset", u32), ("seed", u32), ("width", u32), ("height", u32), ("numPointLights", u32),
                 ("withDirectionalLight", u32), ("lodLevels", u32), ("sizeScale", f32), ("skinnedFraction1024", u32),
-                ("materialFeatures", u32), ("cameraStep", u32), ("lodBuilder", u32), ("spotLightEvery", u32), ("reserved", u32 * 3)]
+                ("materialFeatures", u32), ("cameraStep", u32), ("lodBuilder", u32), ("spotLightEvery", u32), ("detail", f32), ("reserved", u32 * 2)]
+
+
+class DagGroup(C.Structure):
+    _fields_ = [("depth", C.c_int32), ("center", f32 * 3), ("radius", f32), ("error", f32), ("firstCluster", u32), ("clusterCount", u32)]
+
+
+class DagCluster(C.Structure):
+    _fields_ = [("group", C.c_int32), ("refined", C.c_int32), ("center", f32 * 3), ("radius", f32), ("error", f32),
+                ("vertexCount", u32), ("triangleCount", u32), ("firstVertex", u32), ("firstTriangleByte", u32)]
+
+
+class Dag(C.Structure):
+    """brmi_dag (include/brmi_scene.h): a cluster-LOD DAG as flat arrays."""
+    _fields_ = [("groups", C.POINTER(DagGroup)), ("groupCount", u32), ("clusters", C.POINTER(DagCluster)), ("clusterCount", u32),
+                ("vertexRefs", C.POINTER(u32)), ("vertexRefCount", u32), ("triangles", C.POINTER(C.c_uint8)), ("triangleBytes", u32), ("owner", vp)]
+
+
+LOD_BUILDERS = {"quadtree": 0, "external": 1, "own": 2}
 
 
 class SceneStats(C.Structure):
@@ -117,6 +135,11 @@ def scene_lib():
         lib = C.CDLL(path)
         lib.brmi_scene_create.restype = vp
         lib.brmi_scene_create.argtypes = [C.POINTER(SceneParams)]
+        lib.brmi_scene_create_with_dag_builder.restype = vp
+        lib.brmi_scene_create_with_dag_builder.argtypes = [C.POINTER(SceneParams), vp, vp, vp]
+        lib.brmi_lod_build.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.POINTER(Dag)]
+        lib.brmi_lod_release.argtypes = [vp, C.POINTER(Dag)]
+        lib.brmi_lod_release.restype = None
         lib.brmi_scene_create_from_cache.restype = vp
         lib.brmi_scene_create_from_cache.argtypes = [C.POINTER(SceneParams), C.c_char_p]
         lib.brmi_scene_export_cache.argtypes = [vp, C.c_char_p]

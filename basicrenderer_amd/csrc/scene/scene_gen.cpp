@@ -11,10 +11,10 @@
 //     (BR/src/Scene/Scene.cpp:509-535, BR/src/Managers/ViewManager.cpp:19-77), lights
 //     (BR/src/Scene/Scene.cpp:222-262), constant-factor materials.
 //
-// The LOD DAG is our own construction (regular-grid decimation of parametric patches): level-L
-// meshlets are 8x8-quad tiles sampled at stride 2^L, a group is a 4x4 block of meshlets, and the
-// four level-(L+1) meshlets that cover a level-L group all carry refinedGroup = that group.  It
-// is not the reference's meshoptimizer build, only a generator of valid input in its format.
+// LOD DAGs come from one of three builders (brmi_scene.h, enum brmi_lod_builder): the built-in quadtree (regular-grid decimation of
+// parametric patches: level-L meshlets are 8x8-quad tiles sampled at stride 2^L, a group is a 4x4 block of meshlets, the four
+// level-(L+1) meshlets that cover a level-L group carry refinedGroup = that group), this library's cluster-LOD builder
+// (lod_builder.cpp), or a builder the caller hands in.  This file never loads another library.
 #include "brmi_scene.h"
 
 #include <algorithm>
@@ -22,7 +22,6 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
-#include <dlfcn.h>
 #include <string>
 #include <fstream>
 #include <string>
@@ -131,10 +130,14 @@ struct PatchDef {
     V3 center{0, 0, 0}; double radiusX = 1, radiusY = 1, radiusZ = 1, height = 1;   // cylinder / ellipsoid
     uint32_t nu0 = 1, nv0 = 1;          // meshlets per dimension at LOD 0
     double noiseAmp = 0, noiseFreq = 4; uint32_t noiseSeed = 0;
+    double detail = 1;                  // brmi_scene_params::detail: > 1 scales the relief and adds two finer octaves of it
 };
 
 V3 evalPatch(const PatchDef& p, double u, double v) {
     double n = p.noiseAmp != 0 ? p.noiseAmp * fbm(u * p.noiseFreq, v * p.noiseFreq, p.noiseSeed) : 0.0;
+    if (p.detail > 1.0 && p.noiseAmp != 0)      // amplitude ~ wavelength: every LOD level keeps an error comparable to its edge length
+        n = p.noiseAmp * p.detail * (fbm(u * p.noiseFreq, v * p.noiseFreq, p.noiseSeed) + 0.4 * fbm(u * p.noiseFreq * 4.0, v * p.noiseFreq * 4.0, p.noiseSeed + 101u) +
+                                     0.16 * fbm(u * p.noiseFreq * 16.0, v * p.noiseFreq * 16.0, p.noiseSeed + 202u));
     if (p.type == PATCH_PLANE) {
         V3 nrm = normalize(cross(p.axisU, p.axisV));
         return p.origin + p.axisU * u + p.axisV * v + nrm * n;
@@ -229,7 +232,8 @@ struct brmi_scene {
     std::vector<float> srgbToLinear;
     brmi_scene_stats stats{};
     std::vector<uint64_t> meshLod0Triangles;        // per mesh: triangles of its finest level
-    bool failed = false;                            // a mesh could not be built (reference LOD builder missing)
+    bool failed = false;                            // a mesh could not be built (the DAG builder failed or returned an inconsistent DAG)
+    brmi_dag_build_fn dagBuild = nullptr; brmi_dag_release_fn dagRelease = nullptr; void* dagUser = nullptr;   // lodBuilder EXTERNAL / OWN
     // CLodCache (de)serialisation: what the cache stores per mesh beyond the GPU arrays, and where meshes come from
     struct MeshCacheInfo { uint32_t groupCount = 0, segmentCount = 0, nodeCount = 0, pageCount = 0, maxTraversalDepth = 0;
                            std::vector<float> segmentBounds; std::vector<uint32_t> lodNodeRanges; };   // xyzr per segment; (offset, count) per depth
@@ -506,47 +510,14 @@ uint32_t buildQuadtreeDag(const MeshDef& def, bool hasUv, bool hasColor, std::ve
     return levels;
 }
 
-// ---- the reference's own LOD builder (oracle/_ref/libclodref.so: meshoptimizer 1.0 + the reference's clusterlod.h) ------------
-struct ClodGroupOut { int32_t depth; float center[3], radius, error; uint32_t firstCluster, clusterCount; };
-struct ClodClusterOut { int32_t group, refined; float center[3], radius, error; uint32_t vertexCount, triangleCount, firstVertex, firstTriangleByte; };
-struct ClodRefApi {
-    void* handle = nullptr;
-    void* (*build)(const float*, size_t, const uint32_t*, size_t, const float*) = nullptr;
-    void (*counts)(const void*, uint32_t*, uint32_t*, uint32_t*, uint32_t*) = nullptr;
-    void (*copy)(const void*, void*, void*, uint32_t*, uint8_t*) = nullptr;
-    void (*release)(void*) = nullptr;
-};
-ClodRefApi* clodRef() {
-    static ClodRefApi api; static bool tried = false;
-    if (tried) return api.handle ? &api : nullptr;
-    tried = true;
-    std::string path;
-    if (const char* e = std::getenv("BRMI_CLODREF_LIB")) path = e;
-    else {
-        Dl_info info{};
-        if (dladdr((void*)&clodRef, &info) && info.dli_fname) {      // <repo>/basicrenderer_amd/lib/libbrmi_scene.so -> <repo>/oracle/_ref/libclodref.so
-            path = info.dli_fname;
-            for (int up = 0; up < 3; up++) { const size_t k = path.find_last_of('/'); if (k == std::string::npos) break; path.resize(k); }
-            path += "/oracle/_ref/libclodref.so";
-        }
-    }
-    api.handle = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
-    if (!api.handle) { std::fprintf(stderr, "brmi_scene: cannot load the reference LOD builder (%s): %s\n", path.c_str(), dlerror()); return nullptr; }
-    api.build = (decltype(api.build))dlsym(api.handle, "clodref_build"); api.counts = (decltype(api.counts))dlsym(api.handle, "clodref_counts");
-    api.copy = (decltype(api.copy))dlsym(api.handle, "clodref_copy"); api.release = (decltype(api.release))dlsym(api.handle, "clodref_free");
-    if (!api.build || !api.counts || !api.copy || !api.release) { api.handle = nullptr; return nullptr; }
-    return &api;
-}
-
-// LOD DAG from clodBuild: the patches are tessellated at their LOD0 resolution into one indexed mesh, the reference's builder
-// clusters / groups / simplifies it, and its output is mapped onto the build records:
+// LOD DAG from a cluster-LOD builder (lod_builder.cpp, or the caller's): the patches are tessellated at their LOD0 resolution into one
+// indexed mesh, the builder clusters / groups / simplifies it, and its output (a brmi_dag) is mapped onto the build records:
 //   group  -> LOD group: bounds and error of `clodGroup::simplified` (the test "is this group's simplification too coarse", rule 1,
 //             and through `refined` rule 2 of clusterlod.h)
 //   cluster -> meshlet with its own vertex / triangle counts, `refined` = refinedGroup
 // Returns the number of DAG depths, 0 on failure.
-uint32_t buildClusterLodDag(const MeshDef& def, bool hasUv, bool hasColor, std::vector<MeshletBuild>& meshlets, std::vector<GroupBuild>& groups) {
-    ClodRefApi* api = clodRef();
-    if (!api) return 0;
+uint32_t buildClusterLodDag(const brmi_scene& sc, const MeshDef& def, bool hasUv, bool hasColor, std::vector<MeshletBuild>& meshlets, std::vector<GroupBuild>& groups) {
+    if (!sc.dagBuild) return 0;
     std::vector<float> pos, nrm, uvs; std::vector<uint32_t> idx, colors;
     for (const PatchDef& p : def.patches) {
         const uint32_t NU = p.nu0 * 8, NV = p.nv0 * 8, base = (uint32_t)(pos.size() / 3);
@@ -565,13 +536,20 @@ uint32_t buildClusterLodDag(const MeshDef& def, bool hasUv, bool hasColor, std::
             if (((qi + qj) & 1u) == 0) { idx.insert(idx.end(), {a, b, c, a, c, d}); } else { idx.insert(idx.end(), {a, b, d, b, c, d}); }
         }
     }
-    void* res = api->build(pos.data(), pos.size() / 3, idx.data(), idx.size(), nrm.data());
-    if (!res) return 0;
-    uint32_t nG = 0, nC = 0, nV = 0, nT = 0;
-    api->counts(res, &nG, &nC, &nV, &nT);
-    std::vector<ClodGroupOut> g(nG); std::vector<ClodClusterOut> c(nC); std::vector<uint32_t> vref(nV); std::vector<uint8_t> tri(nT);
-    api->copy(res, g.data(), c.data(), vref.data(), tri.data());
-    api->release(res);
+    brmi_dag dag{};
+    if (sc.dagBuild(sc.dagUser, pos.data(), pos.size() / 3, idx.data(), idx.size(), nrm.data(), &dag) != 0) return 0;
+    struct Release { const brmi_scene& sc; brmi_dag& d; ~Release() { if (sc.dagRelease) sc.dagRelease(sc.dagUser, &d); } } release{sc, dag};
+    const uint32_t nG = dag.groupCount, nC = dag.clusterCount;
+    const brmi_dag_group* g = dag.groups; const brmi_dag_cluster* c = dag.clusters; const uint32_t* vref = dag.vertexRefs; const uint8_t* tri = dag.triangles;
+    // the kernels index what follows unchecked: refuse a DAG whose cross references or limits are off
+    if (nG == 0 || nC == 0 || !g || !c || !vref || !tri) return 0;
+    for (uint32_t ci = 0; ci < nC; ci++) {
+        const brmi_dag_cluster& k = c[ci];
+        if (k.group < 0 || (uint32_t)k.group >= nG || k.refined >= (int32_t)nG || k.vertexCount == 0 || k.vertexCount > BRMI_MESHLET_MAX_VERTS || k.triangleCount == 0 || k.triangleCount > BRMI_MESHLET_MAX_TRIS ||
+            (uint64_t)k.firstVertex + k.vertexCount > dag.vertexRefCount || (uint64_t)k.firstTriangleByte + (uint64_t)k.triangleCount * 3u > dag.triangleBytes) return 0;
+        for (uint32_t v = 0; v < k.vertexCount; v++) if (vref[k.firstVertex + v] >= pos.size() / 3) return 0;
+        for (uint32_t t = 0; t < k.triangleCount * 3u; t++) if (tri[k.firstTriangleByte + t] >= k.vertexCount) return 0;
+    }
     uint32_t levels = 1;
     groups.resize(nG);
     for (uint32_t gi = 0; gi < nG; gi++) {
@@ -584,7 +562,7 @@ uint32_t buildClusterLodDag(const MeshDef& def, bool hasUv, bool hasColor, std::
     }
     meshlets.reserve(nC);
     for (uint32_t ci = 0; ci < nC; ci++) {
-        const ClodClusterOut& k = c[ci];
+        const brmi_dag_cluster& k = c[ci];
         MeshletBuild m{};
         m.level = groups[k.group].level; m.patch = 0; m.mi = ci; m.mj = 0; m.group = (uint32_t)k.group; m.refinedGroup = k.refined;
         const uint32_t V = k.vertexCount, T = k.triangleCount;
@@ -600,7 +578,7 @@ uint32_t buildClusterLodDag(const MeshDef& def, bool hasUv, bool hasColor, std::
             lo = {std::min(lo.x, (double)m.pos[v * 3]), std::min(lo.y, (double)m.pos[v * 3 + 1]), std::min(lo.z, (double)m.pos[v * 3 + 2])};
             hi = {std::max(hi.x, (double)m.pos[v * 3]), std::max(hi.y, (double)m.pos[v * 3 + 1]), std::max(hi.z, (double)m.pos[v * 3 + 2])};
         }
-        m.tris.assign(tri.begin() + k.firstTriangleByte, tri.begin() + k.firstTriangleByte + (size_t)T * 3);
+        m.tris.assign(tri + k.firstTriangleByte, tri + k.firstTriangleByte + (size_t)T * 3);
         // the builder's sphere (optimize_bounds), widened if float rounding left a vertex outside
         const V3 cc{k.center[0], k.center[1], k.center[2]};
         double r = k.radius;
@@ -625,12 +603,14 @@ uint32_t buildClusterLodDag(const MeshDef& def, bool hasUv, bool hasColor, std::
 // Build one mesh: LOD DAG (built-in quadtree or the reference's builder), then segments, pages, groups and the 8-wide BVH.
 bool loadCachedMesh(brmi_scene& sc, const MeshDef& def, uint32_t meshIndex);
 
-bool buildMesh(brmi_scene& sc, const MeshDef& def, uint32_t meshIndex) {
+bool buildMesh(brmi_scene& sc, const MeshDef& defIn, uint32_t meshIndex) {
+    MeshDef def = defIn;
+    for (PatchDef& pd : def.patches) pd.detail = sc.params.detail;
     if (!sc.cacheDir.empty()) { if (!loadCachedMesh(sc, def, meshIndex)) { sc.failed = true; return false; } return true; }
     std::vector<MeshletBuild> meshlets;
     std::vector<GroupBuild> groups;
     const bool hasUv = (sc.params.materialFeatures & 24u) != 0u, hasColor = (sc.params.materialFeatures & 32u) != 0u;
-    const uint32_t levels = sc.params.lodBuilder == BRMI_LOD_BUILDER_CLUSTERLOD ? buildClusterLodDag(def, hasUv, hasColor, meshlets, groups) : buildQuadtreeDag(def, hasUv, hasColor, meshlets, groups);
+    const uint32_t levels = sc.params.lodBuilder != BRMI_LOD_BUILDER_QUADTREE ? buildClusterLodDag(sc, def, hasUv, hasColor, meshlets, groups) : buildQuadtreeDag(def, hasUv, hasColor, meshlets, groups);
     if (levels == 0) { sc.failed = true; return false; }
 
     // segments: partition each group's meshlets by refinedGroup (stable)
@@ -1575,13 +1555,16 @@ void presetZorah(brmi_scene& sc, Pcg32& rng) {
 
 extern "C" {
 
-static brmi_scene* createScene(const brmi_scene_params* params, const char* cacheDir) {
+static brmi_scene* createScene(const brmi_scene_params* params, const char* cacheDir, brmi_dag_build_fn build = nullptr, brmi_dag_release_fn release = nullptr, void* user = nullptr) {
     if (!params || params->width == 0 || params->height == 0) return nullptr;
     brmi_scene* sc = new brmi_scene();
     sc->params = *params;
     if (cacheDir) sc->cacheDir = cacheDir;
     if (sc->params.sizeScale <= 0.0f) sc->params.sizeScale = 1.0f;
-    if (sc->params.lodBuilder == BRMI_LOD_BUILDER_CLUSTERLOD && !clodRef()) { delete sc; return nullptr; }
+    if (!(sc->params.detail > 1.0f)) sc->params.detail = 1.0f;
+    if (sc->params.lodBuilder == BRMI_LOD_BUILDER_OWN) { sc->dagBuild = brmi_lod_build; sc->dagRelease = brmi_lod_release; }
+    else if (sc->params.lodBuilder == BRMI_LOD_BUILDER_EXTERNAL) { sc->dagBuild = build; sc->dagRelease = release; sc->dagUser = user; }
+    if (sc->params.lodBuilder > BRMI_LOD_BUILDER_OWN || (sc->params.lodBuilder == BRMI_LOD_BUILDER_EXTERNAL && !build && !cacheDir)) { delete sc; return nullptr; }
     for (int k = 0; k < 3; k++) { sc->stats.sceneMin[k] = 1e30f; sc->stats.sceneMax[k] = -1e30f; }
     Pcg32 rng(0xB451C0DEull + params->seed, 54u + params->preset);
     switch (params->preset) {
@@ -1598,6 +1581,10 @@ static brmi_scene* createScene(const brmi_scene_params* params, const char* cach
     return sc;
 }
 brmi_scene* brmi_scene_create(const brmi_scene_params* params) { return createScene(params, nullptr); }
+brmi_scene* brmi_scene_create_with_dag_builder(const brmi_scene_params* params, brmi_dag_build_fn build, brmi_dag_release_fn release, void* user) {
+    if (!params || params->lodBuilder != BRMI_LOD_BUILDER_EXTERNAL || !build) return nullptr;
+    return createScene(params, nullptr, build, release, user);
+}
 
 void brmi_scene_destroy(brmi_scene* scene) { delete scene; }
 

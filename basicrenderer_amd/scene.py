@@ -34,7 +34,10 @@ TEXTURE_DESC_BYTES = 96      # brmi_texture_desc; its first 8 bytes are the texe
 
 class Scene:
     def __init__(self, preset="sponza", width=3840, height=2160, seed=0, point_lights=64, directional=True,
-                 lod_levels=0, size_scale=1.0, material_features=0, camera_step=0, skinned_fraction=0.0, lod_builder="quadtree", spot_every=0, cache_dir=None, export_cache=None):
+                 lod_levels=0, size_scale=1.0, material_features=0, camera_step=0, skinned_fraction=0.0, lod_builder="quadtree", spot_every=0, cache_dir=None, export_cache=None,
+                 detail=1.0, dag_builder=None):
+        """lod_builder: "quadtree" (regular grid DAG) or "own" (the library's cluster-LOD builder); dag_builder = (build_fn, release_fn)
+        addresses of a caller-supplied builder with the brmi_dag_build_fn / brmi_dag_release_fn signatures (lod_builder becomes "external")."""
         lib = capi.scene_lib()
         p = capi.SceneParams()
         p.preset = PRESETS[preset] if isinstance(preset, str) else int(preset)
@@ -44,16 +47,24 @@ class Scene:
         p.materialFeatures = material_features
         p.cameraStep = camera_step
         p.spotLightEvery = spot_every
-        p.lodBuilder = {"quadtree": 0, "clusterlod": 1}[lod_builder]
+        if dag_builder is not None:
+            lod_builder = "external"
+        p.lodBuilder = capi.LOD_BUILDERS[lod_builder]
+        p.detail = detail
         p.skinnedFraction1024 = int(round(skinned_fraction * 1024))
         self.preset, self.width, self.height = preset, width, height
         self._lib = lib
         # cache_dir: take every mesh from CLodCache files (include/brmi_scene.h) instead of building it; export_cache: write them
-        self._h = lib.brmi_scene_create_from_cache(C.byref(p), str(cache_dir).encode()) if cache_dir else lib.brmi_scene_create(C.byref(p))
+        if cache_dir:
+            self._h = lib.brmi_scene_create_from_cache(C.byref(p), str(cache_dir).encode())
+        elif dag_builder is not None:
+            self._h = lib.brmi_scene_create_with_dag_builder(C.byref(p), dag_builder[0], dag_builder[1], None)
+        else:
+            self._h = lib.brmi_scene_create(C.byref(p))
         if not self._h and cache_dir:
             raise RuntimeError(f"brmi_scene_create_from_cache({cache_dir}) failed: a cache file is missing, truncated or inconsistent")
         if not self._h:
-            raise RuntimeError("brmi_scene_create failed" + (": the reference LOD builder oracle/_ref/libclodref.so is missing (make -C oracle/ref)" if lod_builder == "clusterlod" else ""))
+            raise RuntimeError(f"brmi_scene_create failed (lod_builder={lod_builder})")
         if export_cache:
             if lib.brmi_scene_export_cache(self._h, str(export_cache).encode()) < 0:
                 raise RuntimeError(f"brmi_scene_export_cache({export_cache}) failed")

@@ -41,8 +41,8 @@ def main():
     ap.add_argument("--workload", default="sponza", choices=["sponza", "bistro", "san_miguel"])
     ap.add_argument("--occlusion", type=int, default=1, choices=[0, 1],
                     help="2-phase HZB occlusion culling (reference default: on, BR/include/Renderer.h:220); timed frames are steady state")
-    ap.add_argument("--lod-builder", default="quadtree", choices=["quadtree", "clusterlod"],
-                    help="clusterlod: mesh LOD DAGs from the reference's own builder (oracle/_ref/libclodref.so) instead of the generator's quadtree")
+    ap.add_argument("--lod-builder", default="quadtree", choices=["quadtree", "own"],
+                    help="own: mesh LOD DAGs from the library's cluster-LOD builder (irregular meshlets, ~384-cluster groups) instead of the generator's quadtree")
     ap.add_argument("--material-features", type=int, default=0,
                     help="scene generator feature bits (brmi_scene.h): 1 coat, 2 fuzz, 4 mirrored instances, 8 texture-sampled materials, 16 alpha-tested materials, 32 vertex colours, 64 OpenPBR layer textures, 128 parallax; 0 = BASELINE.json's constant-factor configuration")
     ap.add_argument("--transport", default="rgb16f", choices=["rgb16f", "surface"],
@@ -150,7 +150,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}-class procedural frame, {W}x{H}, 1 directional + {lights} point lights, "
                                    f"{scene.stats['instancedTriangles']} instanced tris, {scene.stats['instances']} instances"
-                                   + (", LOD DAG built by the reference's clusterlod.h" if args.lod_builder == "clusterlod" else "")
+                                   + (", LOD DAGs from the library's cluster-LOD builder" if args.lod_builder == "own" else "")
                                    + (f", material features {args.material_features} (8 = texture-sampled, 16 = alpha-tested materials)" if args.material_features else "")
                                    + (f", {n} row bands of 1080 rows + RCCL all-gather of HDR ({args.transport}, pipelined one frame deep)" if n > 1 else ""),
                        "baseline_config": {"sponza": "configs[1]", "bistro": "configs[2]", "san_miguel": "configs[3]"}[args.workload],

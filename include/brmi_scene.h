@@ -12,6 +12,7 @@
 #ifndef BRMI_SCENE_H
 #define BRMI_SCENE_H
 
+#include <stddef.h>
 #include <stdint.h>
 #include "brmi_types.h"
 
@@ -27,11 +28,32 @@ enum brmi_scene_preset {
     BRMI_PRESET_ZORAH       = 4   /* massive instancing + deep LOD */
 };
 
-/* Who builds the cluster-LOD DAG of every mesh.  QUADTREE: the generator's own regular DAG (81-vertex / 128-triangle grid
- * meshlets).  CLUSTERLOD: the reference's builder -- vendored meshoptimizer + the reference's clusterlod.h, compiled from the
- * reference checkout into oracle/_ref/libclodref.so (oracle/ref/Makefile) and loaded at run time (BRMI_CLODREF_LIB overrides the
- * path); meshlets then have irregular vertex / triangle counts and groups of up to ~512 clusters, like the reference's assets. */
-enum brmi_lod_builder { BRMI_LOD_BUILDER_QUADTREE = 0, BRMI_LOD_BUILDER_CLUSTERLOD = 1 };
+/* Who builds the cluster-LOD DAG of every mesh.
+ *   QUADTREE  the generator's regular DAG (81-vertex / 128-triangle grid meshlets, 4x4-meshlet groups).
+ *   EXTERNAL  a builder handed in by the caller (brmi_scene_create_with_dag_builder): the generator tessellates each mesh into one
+ *             indexed triangle list and maps the DAG it gets back onto pages / groups / BVH.  The tests use this entry to run the
+ *             scenes through the reference's own clodBuild (tests/clodref_bridge.py); libbrmi_scene.so itself never loads it.
+ *   OWN       this library's cluster-LOD builder (basicrenderer_amd/csrc/scene/lod_builder.cpp, brmi_lod_build below): irregular
+ *             meshlets, ~384-cluster groups, QEM simplification with locked group boundaries -- SURVEY.md section 8, row f-1. */
+enum brmi_lod_builder { BRMI_LOD_BUILDER_QUADTREE = 0, BRMI_LOD_BUILDER_EXTERNAL = 1, BRMI_LOD_BUILDER_OWN = 2 };
+
+/* A cluster-LOD DAG as flat arrays (what clusterlod.h's clodBuild reports through its callback, BR/include/ThirdParty/meshoptimizer/
+ * clusterlod.h:118-160).  group.{center,radius,error} is clodGroup::simplified -- the sphere and error the two rendering rules test
+ * (FLT_MAX error = terminal group); cluster.{center,radius} bounds the cluster's own geometry, cluster.error is the error of the
+ * group whose simplification produced it, cluster.refined that group's index (-1 = input geometry).  vertexRefs lists, per cluster,
+ * the input-mesh vertex of every local vertex; triangles holds 3 local indices per triangle. */
+typedef struct brmi_dag_group   { int32_t depth; float center[3], radius, error; uint32_t firstCluster, clusterCount; } brmi_dag_group;
+typedef struct brmi_dag_cluster { int32_t group, refined; float center[3], radius, error; uint32_t vertexCount, triangleCount, firstVertex, firstTriangleByte; } brmi_dag_cluster;
+typedef struct brmi_dag {
+    const brmi_dag_group* groups;     uint32_t groupCount;
+    const brmi_dag_cluster* clusters; uint32_t clusterCount;
+    const uint32_t* vertexRefs;       uint32_t vertexRefCount;
+    const uint8_t* triangles;         uint32_t triangleBytes;
+    void* owner;                      /* the builder's bookkeeping; released by its release function */
+} brmi_dag;
+/* positions: float3 per vertex; indices: 3 per triangle; normals: float3 per vertex or NULL.  Returns 0 on success. */
+typedef int  (*brmi_dag_build_fn)(void* user, const float* positions, size_t vertexCount, const uint32_t* indices, size_t indexCount, const float* normals, brmi_dag* out);
+typedef void (*brmi_dag_release_fn)(void* user, brmi_dag* dag);
 
 typedef struct brmi_scene_params {
     uint32_t preset;
@@ -51,7 +73,9 @@ typedef struct brmi_scene_params {
     uint32_t cameraStep;          /* frame number on the preset's camera path (0 = start); prevView is the view of step - 1 */
     uint32_t lodBuilder;          /* enum brmi_lod_builder */
     uint32_t spotLightEvery;      /* k > 0: every k-th punctual light is a spot light (0 = point lights only) */
-    uint32_t reserved[3];
+    float    detail;              /* geometric detail of the street presets: 0 / 1 = the smooth default surfaces; d > 1 multiplies the relief amplitude by d and
+                                     adds two octaves of it at 4x / 16x the frequency, so that the LOD error test keeps fine clusters (1-4 px triangles at 4K) */
+    uint32_t reserved[2];
 } brmi_scene_params;
 
 /* Arrays a scene exposes.  Element layouts are the brmi_types.h structs. */
@@ -91,6 +115,14 @@ enum brmi_scene_array {
 typedef struct brmi_scene brmi_scene;
 
 brmi_scene* brmi_scene_create(const brmi_scene_params* params);
+/* lodBuilder = EXTERNAL: `build` is called once per mesh, `release` (may be NULL) once its DAG has been consumed. */
+brmi_scene* brmi_scene_create_with_dag_builder(const brmi_scene_params* params, brmi_dag_build_fn build, brmi_dag_release_fn release, void* user);
+
+/* This library's cluster-LOD builder, with the brmi_dag_build_fn / brmi_dag_release_fn signatures (user is ignored).
+ * Limits 128 vertices / 128 triangles per cluster, groups of ~384 clusters with <= 8 refined groups each, target ratio 0.5, stuck
+ * threshold 0.85, error merge max(1.5 x previous, current): the settings of BR/src/Mesh/ClusterLODUtilities.cpp:5426-5458. */
+int  brmi_lod_build(void* user, const float* positions, size_t vertexCount, const uint32_t* indices, size_t indexCount, const float* normals, brmi_dag* out);
+void brmi_lod_release(void* user, brmi_dag* dag);
 
 /* CLodCache: the reference's on-disk form of a mesh's cluster-LOD data (BR/src/Import/CLodCache.cpp).
  *   <dir>/mesh_<i>.clodbin   container v4: {magic 'CLOD', version 4, reserved, pageCount}, pageCount locators {u64 offset, u32 size,

@@ -1,5 +1,6 @@
 // clodref.cpp -- thin C ABI over the reference's own cluster-LOD builder.
-// TEST / DATA-GENERATION INFRASTRUCTURE: only the scene generator and the tests use it; never the product path.
+// TEST INFRASTRUCTURE: loaded by tests/clodref_bridge.py only, which hands clodref_dag_build / clodref_dag_release to
+// brmi_scene_create_with_dag_builder as the caller-supplied DAG builder.  Nothing under basicrenderer_amd/ loads it.
 //
 // What is compiled here is the reference's code where it lies under /root/reference (nothing is copied):
 //   ThirdParty/meshoptimizer/src/*.cpp                        vendored meshoptimizer 1.0
@@ -11,6 +12,7 @@
 #include <cstring>
 #include <vector>
 
+#include "brmi_scene.h"      // brmi_dag: the flat DAG arrays the scene generator consumes (this repository's header)
 #include "meshoptimizer.h"
 #define CLUSTERLOD_IMPLEMENTATION
 #include "clusterlod.h"
@@ -88,6 +90,20 @@ void clodref_copy(const clodref_result* r, void* groups, void* clusters, uint32_
     std::memcpy(triangles, res->triangles.data(), res->triangles.size());
 }
 void clodref_free(clodref_result* r) { delete reinterpret_cast<Result*>(r); }
+
+// the same build with the brmi_dag_build_fn / brmi_dag_release_fn signatures (GroupOut / ClusterOut are brmi_dag_group / brmi_dag_cluster)
+static_assert(sizeof(GroupOut) == sizeof(brmi_dag_group) && sizeof(ClusterOut) == sizeof(brmi_dag_cluster), "DAG record layouts");
+int clodref_dag_build(void*, const float* positions, size_t vertexCount, const uint32_t* indices, size_t indexCount, const float* normals, brmi_dag* out) {
+    Result* res = reinterpret_cast<Result*>(clodref_build(positions, vertexCount, indices, indexCount, normals));
+    if (!res || !out) return -1;
+    out->groups = reinterpret_cast<const brmi_dag_group*>(res->groups.data()); out->groupCount = (uint32_t)res->groups.size();
+    out->clusters = reinterpret_cast<const brmi_dag_cluster*>(res->clusters.data()); out->clusterCount = (uint32_t)res->clusters.size();
+    out->vertexRefs = res->vertices.data(); out->vertexRefCount = (uint32_t)res->vertices.size();
+    out->triangles = res->triangles.data(); out->triangleBytes = (uint32_t)res->triangles.size();
+    out->owner = res;
+    return 0;
+}
+void clodref_dag_release(void*, brmi_dag* dag) { if (dag) { delete reinterpret_cast<Result*>(dag->owner); std::memset(dag, 0, sizeof(*dag)); } }
 uint32_t clodref_meshoptimizer_version(void) { return MESHOPTIMIZER_VERSION; }
 
 }  // extern "C"

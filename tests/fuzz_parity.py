@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import orc
 from conftest import have_clodref
-from basicrenderer_amd import Scene
+from conftest import Scene
 from basicrenderer_amd.renderer import VisibilityRenderer
 EMPTY = np.uint64(0xFFFFFFFFFFFFFFFF)
 

@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))   # li
 
 def frames():
     import numpy as np, orc
-    from basicrenderer_amd import Scene
+    from conftest import Scene
     from basicrenderer_amd.renderer import VisibilityRenderer
     EMPTY = np.uint64(0xFFFFFFFFFFFFFFFF)
     def check(tag, sc):
@@ -62,7 +62,7 @@ def frames():
 
 def occlusion():
     import numpy as np, orc
-    from basicrenderer_amd import Scene
+    from conftest import Scene
     from basicrenderer_amd.renderer import VisibilityRenderer
     EMPTY = np.uint64(0xFFFFFFFFFFFFFFFF)
     ok = True
@@ -102,7 +102,7 @@ def occlusion():
 
 def bands():
     import numpy as np, orc
-    from basicrenderer_amd import Scene
+    from conftest import Scene
     from basicrenderer_amd.renderer import VisibilityRenderer
     from basicrenderer_amd import compose
     EMPTY = np.uint64(0xFFFFFFFFFFFFFFFF)

@@ -31,7 +31,7 @@ class _TexScene:
 
     def __init__(self, **kw):
         import orc
-        from basicrenderer_amd import Scene
+        from conftest import Scene
         self.scene = Scene("tiny", 160, 90, point_lights=2, lod_levels=2, material_features=24, **kw)
         self.sb = self.scene.host_buffers()
         self.lib = orc.lib()
@@ -121,7 +121,7 @@ def test_parallax_march_matches_a_stepwise_restatement():
     step by step here on numpy float32 scalars (heights through orc_sample_grad), plus its fixed points: scale 0 returns the
     v-flipped texcoord untouched, an unbound height map (reads 1) hits on the first step."""
     import orc
-    from basicrenderer_amd import Scene
+    from conftest import Scene
     scene = Scene("tiny", 160, 90, point_lights=2, lod_levels=2, material_features=128 | 8)
     sb = scene.host_buffers(); lib = orc.lib()
     n_tex = scene.counts["textureDescs"]
@@ -269,7 +269,7 @@ def test_alpha_test_cuts_holes_and_only_in_alpha_tested_materials(texscene):
     """The alpha-tested frame covers fewer pixels than the same scene without the flag; every surviving key of an alpha-tested
     cluster passes SWAlphaTestFailed at ITS pixel when re-evaluated, and materials without the flag never fail."""
     import orc
-    from basicrenderer_amd import Scene
+    from conftest import Scene
     ts = texscene
     f = orc.OracleFrame(ts.scene).run()
     g = orc.OracleFrame(Scene("tiny", 160, 90, point_lights=2, lod_levels=2, material_features=8)).run()
@@ -295,7 +295,7 @@ def test_clod_cache_round_trip_reproduces_the_scene_byte_for_byte(preset, kw, tm
     every slab byte is the same, so everything downstream (oracle, kernels) is too."""
     import struct
     from conftest import have_clodref
-    from basicrenderer_amd import Scene
+    from conftest import Scene
     if kw.get("lod_builder") == "clusterlod" and not have_clodref():
         pytest.skip("oracle/_ref/libclodref.so not built")
     a = Scene(preset, 320, 180, point_lights=4, export_cache=tmp_path, **kw)
@@ -324,7 +324,7 @@ def test_clod_cache_rejects_damaged_files(tmp_path):
     """Truncated, mislabelled or internally inconsistent cache files are refused, never loaded."""
     import shutil
     import struct
-    from basicrenderer_amd import Scene
+    from conftest import Scene
     good = tmp_path / "good"; good.mkdir()
     Scene("tiny", 128, 72, point_lights=1, lod_levels=2, export_cache=good)
 
@@ -360,7 +360,7 @@ def test_clod_cache_rejects_damaged_files(tmp_path):
 def test_hzb_chain_is_a_max_pyramid_of_the_padded_depth():
     """orc_build_hzb against a numpy restatement: pad to a power of two with 'empty', 2x2 max per level."""
     import orc
-    from basicrenderer_amd import Scene
+    from conftest import Scene
     f = orc.OracleFrame(Scene("tiny", 200, 120, point_lights=1), threads=2)
     f.cull(); f.raster(); f.depth_copy()
     data, offs, n = f.build_hzb()
@@ -383,7 +383,7 @@ def test_hzb_chain_is_a_max_pyramid_of_the_padded_depth():
 def test_occlusion_culling_is_conservative_along_a_camera_path(preset, kw):
     """2-phase culling against a reprojected previous-frame chain never changes which triangle wins a pixel."""
     import orc
-    from basicrenderer_amd import Scene
+    from conftest import Scene
     hz, replayed = None, 0
     for step in range(3):
         sc = Scene(preset, 480, 270, point_lights=4, camera_step=step, **kw)
@@ -400,7 +400,7 @@ def test_occlusion_culling_is_conservative_along_a_camera_path(preset, kw):
 
 def test_skinning_moves_geometry_and_only_skinned_instances(scenes):
     import orc
-    from basicrenderer_amd import Scene
+    from conftest import Scene
     plain = orc.OracleFrame(Scene("tiny", 256, 144, point_lights=2)).run()
     skinned = orc.OracleFrame(Scene("tiny", 256, 144, point_lights=2, skinned_fraction=1.0)).run()
     changed = plain.vis != skinned.vis
@@ -474,7 +474,7 @@ def test_half_and_unorm_conversions_match_numpy():
     assert np.array_equal(q, (np.clip(u, 0, 1) * np.float32(255) + np.float32(0.5)).astype(np.uint32))
 
 
-@pytest.mark.parametrize("case", ["bistro_small", "sponza_clod"])
+@pytest.mark.parametrize("case", ["bistro_small", "sponza_clod", "sponza_ownlod", "bistro_ownlod_skinned"])
 def test_lod_cut_never_draws_a_group_and_its_refinement(case, scenes):
     """The two-condition LOD cut: a visible cluster that refines group r excludes every cluster of group r (same instance).
     `sponza_clod`: the DAG comes from the reference's own builder (clusterlod.h rules 1 and 2)."""
@@ -511,16 +511,17 @@ def test_lod_cut_never_draws_a_group_and_its_refinement(case, scenes):
     assert len(depths) > 1, "the test scene should exercise more than one LOD depth"
 
 
-def test_reference_lod_builder_output_is_well_formed_and_covers_the_surface(scenes):
-    """Meshes built by the reference's clodBuild (oracle/_ref): meshlets within the 128 / 128 limits, local indices in range,
-    and the finest cut (depth 0) tiles the same triangle count the tessellation produced; the rendered coverage of the scene is
-    the same as with the built-in quadtree DAG up to LOD error."""
+@pytest.mark.parametrize("case", ["sponza_clod", "sponza_ownlod"])
+def test_lod_builder_output_is_well_formed_and_covers_the_surface(case, scenes):
+    """Meshes built by the reference's clodBuild (oracle/_ref) and by this library's own builder (lod_builder.cpp): meshlets within
+    the 128 / 128 limits, local indices in range, and the finest cut (depth 0) tiles the same triangle count the tessellation
+    produced; the rendered coverage of the scene is the same as with the built-in quadtree DAG up to LOD error."""
     import orc
     from conftest import have_clodref
-    from basicrenderer_amd import Scene
-    if not have_clodref():
+    from conftest import Scene
+    if case.endswith("_clod") and not have_clodref():
         pytest.skip("oracle/_ref/libclodref.so not built (needs the reference checkout)")
-    sc = scenes("sponza_clod")
+    sc = scenes(case)
     lod0_tris = 0
     for slab in sc.slabs[1:]:
         for page in range(0, len(slab), 1 << 18):
@@ -542,6 +543,130 @@ def test_reference_lod_builder_output_is_well_formed_and_covers_the_surface(scen
     b.cull(); b.raster()
     ca, cb = a.vis != EMPTY, b.vis != EMPTY
     assert (ca != cb).mean() < 0.002          # same silhouettes
+
+
+def _dag_of(build, release, P, I):
+    """Runs a brmi_dag_build_fn on (positions, indices); returns (groups[depth, error, firstCluster, clusterCount, radius, center xyz], clusters[group, refined, V, T, error, radius, center xyz], vertexRefs, triangles)."""
+    from basicrenderer_amd import capi
+    d = capi.Dag()
+    assert build(None, P.ctypes.data, len(P), I.ctypes.data, len(I), None, C.byref(d)) == 0
+    g = np.array([(x.depth, x.error, x.firstCluster, x.clusterCount, x.radius, *x.center) for x in (d.groups[i] for i in range(d.groupCount))], dtype=np.float64)
+    c = np.array([(x.group, x.refined, x.vertexCount, x.triangleCount, x.error, x.radius, *x.center, x.firstVertex, x.firstTriangleByte) for x in (d.clusters[i] for i in range(d.clusterCount))], dtype=np.float64)
+    refs = np.ctypeslib.as_array(d.vertexRefs, (d.vertexRefCount,)).copy()
+    tris = np.ctypeslib.as_array(d.triangles, (d.triangleBytes,)).copy()
+    release(None, C.byref(d))
+    return g, c, refs, tris
+
+
+def _relief_grid(nu, nv, kind):
+    u, v = np.meshgrid(np.linspace(0, 1, nu + 1), np.linspace(0, 1, nv + 1))
+    h = 0.05 * (np.sin(u * 9) * np.cos(v * 7) + 0.3 * np.sin(u * 37 + 1) * np.sin(v * 41))
+    if kind == "plane":
+        P = np.stack([u * 4, h, v * 4], -1)
+    else:                              # closed in u (seam of coincident vertices), open at the trimmed poles
+        th, ph, r = -2 * np.pi * u, np.pi * (0.04 + 0.92 * v) - np.pi / 2, 1 + h
+        P = np.stack([r * np.cos(ph) * np.cos(th), r * np.sin(ph), r * np.cos(ph) * np.sin(th)], -1)
+        P[:, -1] = P[:, 0]
+    a = (np.arange(nv)[:, None] * (nu + 1) + np.arange(nu)[None, :]).ravel()
+    even = ((np.arange(nv)[:, None] + np.arange(nu)[None, :]) % 2 == 0).ravel()
+    b, c, d = a + 1, a + nu + 2, a + nu + 1
+    I = np.where(even[:, None], np.stack([a, b, c, a, c, d], 1), np.stack([a, b, d, b, c, d], 1)).astype(np.uint32).ravel()
+    return np.ascontiguousarray(P.reshape(-1, 3), dtype=np.float32), I
+
+
+@pytest.mark.parametrize("shape", [("plane", 64, 64), ("plane", 200, 136), ("ball", 128, 64), ("plane", 384, 384)])
+def test_own_lod_builder_dag_is_valid_and_tracks_the_reference_builder(shape):
+    """brmi_lod_build (lod_builder.cpp, row f-1) against the reference's clodBuild (oracle/_ref) on the same meshes: the limits of
+    ClusterLODUtilities.cpp:5426-5458 hold (128 vertices / 128 triangles, > 64 triangles per cluster of a level that has more than
+    128, <= 8 refined groups per group), errors are monotone up the DAG with the 1.5x merge rule, every level halves the
+    triangle count, depth-0 clusters partition the input triangles, the simplification keeps every original border vertex of a
+    plane's outline corners -- and depth count, cluster count and error range stay inside a stated band of the reference's."""
+    from conftest import have_clodref
+    from basicrenderer_amd import capi
+    kind, nu, nv = shape
+    P, I = _relief_grid(nu, nv, kind)
+    lib = capi.scene_lib()
+    g, c, refs, tris = _dag_of(lib.brmi_lod_build, lib.brmi_lod_release, P, I)
+    grp = c[:, 0].astype(int)
+    assert c[:, 2].max() <= 128 and c[:, 3].max() <= 128 and c[:, 2].min() >= 3
+    depth_of_cluster = g[grp, 0].astype(int)
+    T0 = len(I) // 3
+    assert c[depth_of_cluster == 0, 3].sum() == T0 and (c[depth_of_cluster == 0, 1] == -1).all()
+    # depth-0 clusters partition the input triangles (as vertex-index triples)
+    seen = set()
+    for k in np.nonzero(depth_of_cluster == 0)[0]:
+        fv, ft, V, T = int(c[k, 9]), int(c[k, 10]), int(c[k, 2]), int(c[k, 3])
+        local = tris[ft: ft + 3 * T].reshape(-1, 3).astype(np.int64)
+        assert local.max() < V
+        for t in refs[fv + local]:
+            seen.add(tuple(int(x) for x in t))
+    assert seen == set(tuple(int(x) for x in t) for t in I.reshape(-1, 3))
+    depths = int(g[:, 0].max()) + 1
+    for L in range(depths):
+        m = depth_of_cluster == L
+        if c[m, 3].sum() > 128:
+            assert c[m, 3].min() > 64, f"level {L}: a cluster with <= 64 triangles"
+        if L:
+            prev = c[depth_of_cluster == L - 1, 3].sum()
+            # only what the non-terminal groups of level L-1 released moves up; half of it, within the simplifier's slack
+            assert c[m, 3].sum() <= 0.55 * prev + 64
+    # errors: a cluster carries its source group's error; its own group merges max(1.5 x previous, own)
+    own_err = g[grp, 1]
+    assert (c[:, 4] <= own_err).all()
+    fin = g[:, 1] < 1e30
+    for gi in np.nonzero(fin)[0]:
+        members = c[grp == gi]
+        assert g[gi, 1] >= 1.5 * members[:, 4].max() * (1 - 1e-6)
+        assert len(set(members[:, 1].astype(int).tolist())) <= 8 and len(members) <= 512
+    assert (~fin).sum() >= 1                       # the coarsest group is terminal
+    # LOD spheres nest: a group's sphere contains the spheres of the groups its clusters refine
+    for gi in range(len(g)):
+        for r in set(c[grp == gi, 1].astype(int).tolist()) - {-1}:
+            dist = np.linalg.norm(g[gi, 5:8] - g[r, 5:8])
+            assert dist + g[r, 4] <= g[gi, 4] * (1 + 1e-4) + 1e-5
+    if not have_clodref():
+        return
+    import clodref_bridge
+    ref = clodref_bridge.lib()
+    ref.clodref_dag_build.argtypes = lib.brmi_lod_build.argtypes
+    ref.clodref_dag_release.argtypes = lib.brmi_lod_release.argtypes
+    rg, rc, _, _ = _dag_of(ref.clodref_dag_build, ref.clodref_dag_release, P, I)
+    assert abs((int(rg[:, 0].max()) + 1) - depths) <= 1
+    assert 0.9 <= len(c) / len(rc) <= 1.1                       # cluster counts within 10 %
+    rfin = rg[:, 1] < 1e30
+    assert 0.25 <= g[fin, 1].max() / rg[rfin, 1].max() <= 4.0    # same error scale (geometry-only vs attribute-aware quadrics)
+
+
+def test_own_lod_builder_keeps_seams_closed_and_is_deterministic():
+    """A closed-in-u surface has a seam of coincident vertices with different indices: after every level the simplified clusters
+    still meet along it (every seam edge of a cut is matched by an edge with the same two positions on the other side), and two
+    builds of the same mesh are byte-identical."""
+    from basicrenderer_amd import capi
+    lib = capi.scene_lib()
+    P, I = _relief_grid(96, 48, "ball")
+    g, c, refs, tris = _dag_of(lib.brmi_lod_build, lib.brmi_lod_release, P, I)
+    g2, c2, refs2, tris2 = _dag_of(lib.brmi_lod_build, lib.brmi_lod_release, P, I)
+    assert np.array_equal(g, g2) and np.array_equal(c, c2) and np.array_equal(refs, refs2) and np.array_equal(tris, tris2)
+    grp = c[:, 0].astype(int)
+    poskey = {i: P[i].tobytes() for i in range(len(P))}
+    for L in range(int(g[:, 0].max()) + 1):
+        # the cut "all clusters produced at depth L" (refined groups of depth L-1, or the input for L = 0) is a closed surface up to its true borders
+        m = np.nonzero((g[grp, 0] == L))[0]
+        edges = {}
+        for k in m:
+            fv, ft, T = int(c[k, 9]), int(c[k, 10]), int(c[k, 3])
+            for t in refs[fv + tris[ft: ft + 3 * T].reshape(-1, 3).astype(np.int64)]:
+                for a, b in ((t[0], t[1]), (t[1], t[2]), (t[2], t[0])):
+                    e = tuple(sorted((poskey[int(a)], poskey[int(b)])))
+                    edges[e] = edges.get(e, 0) + 1
+        open_edges = [e for e, n in edges.items() if n == 1]
+        # the ball is open only at the two trimmed poles: every open edge lies on the first or last row of the grid
+        rows = {P[j * 97:(j + 1) * 97].tobytes() for j in (0, 48)}
+        pole = set()
+        for j in (0, 48):
+            pole |= {P[j * 97 + i].tobytes() for i in range(97)}
+        assert all(e[0] in pole and e[1] in pole for e in open_edges), f"depth {L}: crack away from the poles"
+        assert all(n <= 2 for n in edges.values())
 
 
 def test_frustum_culls_the_instance_behind_the_camera(scenes):
@@ -648,7 +773,7 @@ def test_c_abi_rejects_bad_calls_without_a_gpu():
 
 def test_struct_sizes_match_the_reference_layouts():
     """The ctypes mirrors and the C structs agree with the sizes the reference uploads."""
-    from basicrenderer_amd import Scene
+    from conftest import Scene
     sc = Scene("tiny", 64, 64, point_lights=1)
     per = {"perObject": 208, "perMesh": 64, "perMeshInstance": 32, "lodNodes": 64, "lodGroups": 76, "lodSegments": 16, "groupPageMap": 8,
            "cameras": 736, "cullingCameras": 304, "viewRasterInfo": 48, "perFrame": 104, "lights": 128, "materials": 276, "openpbrMaterials": 400,
@@ -669,6 +794,12 @@ def test_product_path_never_touches_the_oracle():
                 for m in re.finditer(r"^\s*(?:#\s*include|import|from)\b.*$", txt, flags=re.M):
                     assert "orc" not in m.group(0).split("#")[0].replace("force", "") or "include" not in m.group(0) and "import orc" not in m.group(0), f"{fn}: {m.group(0)}"
                 assert "liboracle" not in txt and "oracle/_build" not in txt, fn
+                # nor anything built from the reference checkout (oracle/_ref), nor a run-time loader that could pull it in
+                low = txt.lower()
+                for word in ("oracle/_ref", "clodref", "dlopen", "dlsym", "dlfcn"):
+                    assert word not in low, f"{fn}: mentions {word}"
     bench = open(os.path.join(ROOT, "bench.py")).read()
     head, _, tail = bench.partition("def cpu_baseline")
     assert "import orc" not in head and "import orc" in tail
+    for word in ("oracle/_ref", "clodref", "oracle/_build", "liboracle"):
+        assert word not in head.lower(), f"bench.py (measured path) mentions {word}"

@@ -12,7 +12,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["tiny", "tiny_lod", "tiny_coat_fuzz", "sponza_coat_fuzz", "sponza_small", "bistro_small", "tiny_skinned", "bistro_skinned", "tiny_clod", "sponza_clod", "bistro_clod_skinned", "sponza_spots", "bistro_mirrored",
+CASES = ["tiny", "tiny_lod", "tiny_coat_fuzz", "sponza_coat_fuzz", "sponza_small", "bistro_small", "tiny_skinned", "bistro_skinned", "tiny_clod", "sponza_clod", "bistro_clod_skinned", "tiny_ownlod", "sponza_ownlod", "bistro_ownlod_skinned", "sponza_ownlod_alpha", "sponza_spots", "bistro_mirrored",
          "tiny_textured", "sponza_textured", "tiny_alpha", "sponza_alpha", "bistro_alpha_skinned", "sponza_clod_alpha", "tiny_vcolor", "sponza_vcolor_textured", "sponza_layer_textures", "tiny_layer_textures_only", "tiny_parallax", "sponza_parallax_all"]
 
 
@@ -103,7 +103,7 @@ def test_gpu_reproduces_the_committed_golden_fixtures(name):
     not move with the oracle's source."""
     import os
     import sys
-    from basicrenderer_amd import Scene
+    from conftest import Scene
     from basicrenderer_amd.renderer import VisibilityRenderer
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "tests", "golden"))
@@ -252,7 +252,7 @@ def test_band_split_composes_to_full_frame(case, scenes, gpu_frames):
 def test_band_split_with_occlusion_culling_composes_to_full_frame():
     """The multi-GPU bench default: row bands with 2-phase occlusion culling on, two frames (the second one tests against the
     band's own depth chain; rows of other ranks read as empty).  Lit bytes of every band equal the full frame without occlusion."""
-    from basicrenderer_amd import Scene
+    from conftest import Scene
     from basicrenderer_amd.renderer import VisibilityRenderer
     sc = Scene("bistro", 640, 360, point_lights=16, size_scale=0.3)
     full = VisibilityRenderer(sc)
@@ -288,7 +288,7 @@ def test_error_paths(scenes):
 
 def test_dangling_scene_indices_are_refused():
     """brmi_set_scene validates the cross references the kernels follow unchecked: a dangling index is an error, not a GPU fault."""
-    from basicrenderer_amd import Scene
+    from conftest import Scene
     from basicrenderer_amd.renderer import VisibilityRenderer, BrmiError
 
     def scene():
@@ -321,7 +321,7 @@ def test_dangling_scene_indices_are_refused():
 def test_unsupported_material_bindings_are_refused():
     """What this path does not decode is rejected by brmi_set_scene with a message, never rendered wrong: a missing texture table,
     a texture slot (or the parallax height map) on a UV set other than 0."""
-    from basicrenderer_amd import Scene
+    from conftest import Scene
     from basicrenderer_amd.renderer import VisibilityRenderer, BrmiError
     mat_words = 276 // 4
 
@@ -356,7 +356,7 @@ def test_unsupported_material_bindings_are_refused():
 @pytest.mark.parametrize("preset,lights", [("sponza", 64), ("bistro", 256)])
 def test_full_size_4k_properties(preset, lights):
     """BASELINE.json sizes: size-independent properties (no oracle run at 4K in the test budget)."""
-    from basicrenderer_amd import Scene
+    from conftest import Scene
     from basicrenderer_amd.renderer import VisibilityRenderer
     sc = Scene(preset, 3840, 2160, point_lights=lights)
     r = VisibilityRenderer(sc, stats=True)
@@ -393,7 +393,7 @@ def test_full_size_frames_against_the_oracle(preset, W, H, lights, kw):
     """BASELINE.json's configurations at their full size, whole frame against the CPU oracle (it renders a 4K frame in well under a
     second per stage on the box's cores): cluster list, visibility keys, depth, every G-buffer plane exact; HDR within one fp16 ULP."""
     import orc
-    from basicrenderer_amd import Scene
+    from conftest import Scene
     from basicrenderer_amd.renderer import VisibilityRenderer
     sc = Scene(preset, W, H, point_lights=lights, **kw)
     r = VisibilityRenderer(sc, stats=True)
@@ -421,7 +421,7 @@ def test_full_size_camera_path_with_occlusion_against_the_oracle(preset, lights,
     2-phase frame: both phases' cluster lists, keys, depth, G-buffer exact, HDR within one fp16 ULP on covered pixels (pixels without
     geometry are not written -- DeferredCSMain returns -- so they keep the previous frame's value)."""
     import orc
-    from basicrenderer_amd import Scene
+    from conftest import Scene
     from basicrenderer_amd.renderer import VisibilityRenderer
     hz, r = None, None
     for step in range(3):
@@ -456,7 +456,8 @@ def test_full_size_band_split_against_the_oracle(preset, lights, n):
     """The multi-GPU bench's partition at its real size on one GPU: the 7680 x (1080 n) frame rendered band by band (occlusion
     culling on, two frames each) equals the oracle's full frame on every band: triangle identities, depth, lit bytes."""
     import orc
-    from basicrenderer_amd import Scene, compose
+    from basicrenderer_amd import compose
+    from conftest import Scene
     from basicrenderer_amd.renderer import VisibilityRenderer
     W, H = compose.frame_size(n)
     sc = Scene(preset, W, H, point_lights=lights)
@@ -509,7 +510,7 @@ def test_cpp_host_passes_reproduce_the_python_frame(scenes):
     r.close()
 
     # texture-sampled and alpha-tested materials through the C++ host (texture descriptors relocated by the host)
-    from basicrenderer_amd import Scene
+    from conftest import Scene
     out = subprocess.run([exe, "0", "256", "144", "6", "0", "1", "24", "2"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     got = json.loads(out.stdout.strip().splitlines()[-1])
@@ -523,7 +524,7 @@ def test_cpp_host_passes_reproduce_the_python_frame(scenes):
 
     # occlusion culling: the reference graph's unfused pass sequence (depth copy, downsample, phase 2, downsample) through the
     # stage entry points against brmi_execute's fused one, two frames of a Sponza-class scene
-    from basicrenderer_amd import Scene
+    from conftest import Scene
     out = subprocess.run([exe, "1", "640", "360", "8", "1", "2"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     got = json.loads(out.stdout.strip().splitlines()[-1])
@@ -553,7 +554,7 @@ OCCLUSION_CASES = {
 def occlusion_runs():
     """GPU and oracle driven through the same three frames of a camera path with occlusion culling on."""
     import orc
-    from basicrenderer_amd import Scene
+    from conftest import Scene
     from basicrenderer_amd.renderer import VisibilityRenderer
     cache = {}
 
@@ -631,7 +632,7 @@ def test_occlusion_does_not_change_the_image(name, occlusion_runs):
 
 def test_occlusion_static_camera_culls_hidden_clusters_at_4k():
     """Bistro-class street at full size: the second frame must rasterise fewer clusters and produce the same HDR bytes."""
-    from basicrenderer_amd import Scene
+    from conftest import Scene
     from basicrenderer_amd.renderer import VisibilityRenderer
     sc = Scene("bistro", 3840, 2160, point_lights=256)
     base = VisibilityRenderer(sc, stats=True)
@@ -778,7 +779,7 @@ def test_seeded_sweep_whole_frame(case):
     """Odd target sizes (not multiples of the 8x8 tile, the 16-row band or the 256-pixel strip), other seeds, every option
     mix: the whole frame against the oracle -- cluster list, keys, depth, normals exact, HDR within one fp16 ULP."""
     import orc
-    from basicrenderer_amd import Scene
+    from conftest import Scene
     from basicrenderer_amd.renderer import VisibilityRenderer
     preset, W, H, skw, rkw = SWEEP[case]
     sc = Scene(preset, W, H, **skw)
