@@ -122,7 +122,11 @@ static void compute_sizes(brmi_pass* p) {
     p->deferredStripeCapacity = (uint32_t)(((p->bandPixelCount / 4096 + CNT_STRIPE_COUNT) / CNT_STRIPE_COUNT) * 4096);   // 64-tile runs of a stripe x 4096 pixels
     w.deferredPixels = take((uint64_t)3 * CNT_STRIPE_COUNT * p->deferredStripeCapacity * 4);      // one set of striped lists per layered class
     w.lutF = take((uint64_t)(32768 + 1024 + 1024 + 32 + 256) * 4);
-    w.shadeMat = take((uint64_t)std::max(1u, p->scene.openpbrMaterialCount) * 256 * 64);      // (OpenPBR material, roughness code) table of the shading pass
+    w.shadeRows = take((uint64_t)std::max(1u, p->scene.openpbrMaterialCount) * 256 * 256);    // (OpenPBR material, roughness code) -> folded energy-table rows of the shading pass
+    w.shadeAvgs = take((uint64_t)std::max(1u, p->scene.openpbrMaterialCount) * 256 * 8);
+    w.shadeLights = take((uint64_t)std::max(1u, p->scene.lightCount) * 80);                     // the shading pass's 80 B record per active light
+    w.clusterList = take((uint64_t)p->numLightClusters * 8);                                    // per light cluster: first entry / length of its flat light list
+    w.listEntries = take((uint64_t)p->lightPagePool * BRMI_LIGHTS_PER_PAGE * 4 + 256);        // the page contents once more, in the order the page walk visits them
     // textured / alpha-tested scenes only: where each visible cluster's UV set lives, the texcoords of the resolve arena's vertices,
     // and the alpha-test operands that travel with binned triangles
     const bool uvs = p->sceneHasTextures || p->sceneHasAlphaTest || p->sceneHasVertexColors;

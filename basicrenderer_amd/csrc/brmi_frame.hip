@@ -75,7 +75,9 @@ BRMI_DEV void job_material_words(const brmi_scene_buffers& sc, MaterialWords* ou
 }
 
 // view-space bounding spheres of the active lights, once per frame (testSphereAABB's transform, lightCulling.hlsl:15-21)
-BRMI_DEV void job_light_spheres(const brmi_scene_buffers& sc, float4* lightVS, uint32_t* lightMeta, uint32_t i) {
+// ... and the shading pass's record of the light (brmi_light.hip, ShadeLight): what getLightParametersForFragment reads, 80 B, indexed
+// by the position in the active-light list.  normalize(dirWorldSpace) of a spot light is per light, not per pixel (lighting.hlsli:640).
+BRMI_DEV void job_light_spheres(const brmi_scene_buffers& sc, float4* lightVS, uint32_t* lightMeta, float4* shadeLights, uint32_t i) {
     const brmi_per_frame* pf = sc.perFrame;
     if (i >= pf->numLights) return;
     const m4 view = load_m4(&sc.cameras[pf->mainCameraIndex].view[0][0]);
@@ -84,6 +86,17 @@ BRMI_DEV void job_light_spheres(const brmi_scene_buffers& sc, float4* lightVS, u
     const f3 c = xyz(mul_point(f3{l->boundingSphere[0], l->boundingSphere[1], l->boundingSphere[2]}, view));
     lightVS[i] = make_float4(c.x, c.y, c.z, l->boundingSphere[3]);
     lightMeta[i] = (l->type & 3u) | (li << 2);
+    float4* r = shadeLights + (size_t)i * 5u;
+    const f3 dir{l->dirWorldSpace[0], l->dirWorldSpace[1], l->dirWorldSpace[2]};
+    if (l->type == BRMI_LIGHT_DIRECTIONAL) r[0] = make_float4(-dir.x, -dir.y, -dir.z, 0.0f);     // lightToFrag
+    else r[0] = make_float4(l->posWorldSpace[0], l->posWorldSpace[1], l->posWorldSpace[2], l->maxRange);
+    // dist > maxRange certainly holds once dist^2 exceeds this bound (sqrt is monotone and correctly rounded; 1e-6 covers the products' rounding)
+    const float mr = as_f32(as_u32(fabsf(l->maxRange)) + 1u);
+    r[1] = make_float4(l->attenuation[0], l->attenuation[1], l->attenuation[2], (mr * mr) * 1.000001f);
+    r[2] = make_float4(l->color[0], l->color[1], l->color[2], l->color[3]);
+    const f3 sd = l->type == BRMI_LIGHT_SPOT ? normalize3(dir) : f3{0.0f, 0.0f, 0.0f};
+    r[3] = make_float4(sd.x, sd.y, sd.z, l->outerConeAngle);
+    r[4] = make_float4(l->innerConeAngle, as_f32(l->type), 0.0f, 0.0f);
 }
 
 // Per-material part of PopulateFragmentInfoFromOpenPBR (utilities.hlsli:2590-2637): depends only on the
@@ -108,18 +121,14 @@ BRMI_DEV void job_material_constants(const brmi_scene_buffers& sc, MatConst* out
 }
 // (material, roughness code) -> the light-independent table part of make_pixel_ctx (brmi_shade_math.h): the same functions the shader
 // called per pixel, evaluated once per pair
-BRMI_DEV void job_shade_material_table(const brmi_scene_buffers& sc, const float* lutF, ShadeMaterialEntry* out, uint32_t i) {
+BRMI_DEV void job_shade_material_table(const brmi_scene_buffers& sc, const float* lutF, ShadeRows* rows, ShadeAverages* avgs, uint32_t i) {
     const uint32_t m = i >> 8, code = i & 255u;
     if (m >= sc.openpbrMaterialCount) return;
     const Luts L{lutF, lutF + 32768, lutF + 32768 + 1024, lutF + 32768 + 2048, sc.lutFuzzLTC, lutF + 32768 + 2048 + 32};
     const MatConst mc = material_constants_of(sc.openpbrMaterials + m);
     const float prc = clampf(L.unorm8[code], BRMI_MIN_PERCEPTUAL_ROUGHNESS, 1.0f);
     const float alpha = sat(prc * prc), ior = max2(mc.weightedSpecularIor, 1.0f);        // BaseState::specularAlpha / weightedSpecularIor
-    ShadeMaterialEntry e;
-    e.od = prep_od_e(L, ior, alpha); e.im = prep_im_e(L, alpha);
-    e.avgComp = lut_od_avg(L, ior, alpha); e.mAvgClamped = max2(lut_im_avg(L, alpha), 1.0e-12f);
-    e.pad[0] = e.pad[1] = e.pad[2] = 0u;
-    out[i] = e;
+    build_shade_rows(L, ior, alpha, rows[i], avgs[i]);
 }
 
 // Per-frame tables of the shading pass.  Everything here is what the shader computes per pixel from px, py or view depth
@@ -158,9 +167,9 @@ BRMI_DEV void job_shade_tables(const brmi_scene_buffers& sc, ShadeTables t, uint
 
 struct FrameJobs {
     brmi_scene_buffers sc;
-    m4* frameConst; float* objConst; MaterialWords* matWords; MatConst* matConst; ShadeTables tables; float4* lightVS; uint32_t* lightMeta;
+    m4* frameConst; float* objConst; MaterialWords* matWords; MatConst* matConst; ShadeTables tables; float4* lightVS; uint32_t* lightMeta; float4* shadeLights;
     AlphaMaterial* alphaMats;
-    const float* lutF; ShadeMaterialEntry* shadeMat;
+    const float* lutF; ShadeRows* shadeRows; ShadeAverages* shadeAvgs;
     uint32_t W, H;
     uint32_t firstBlock[7];      // block ranges of the six jobs
 };
@@ -171,8 +180,8 @@ __global__ void __launch_bounds__(64) k_frame_constants(FrameJobs j) {
     else if (b < j.firstBlock[2]) job_material_words(j.sc, j.matWords, j.alphaMats, (b - j.firstBlock[1]) * 64u + threadIdx.x);
     else if (b < j.firstBlock[3]) job_material_constants(j.sc, j.matConst, (b - j.firstBlock[2]) * 64u + threadIdx.x);
     else if (b < j.firstBlock[4]) job_shade_tables(j.sc, j.tables, j.W, j.H, (b - j.firstBlock[3]) * 64u + threadIdx.x);
-    else if (b < j.firstBlock[5]) job_light_spheres(j.sc, j.lightVS, j.lightMeta, (b - j.firstBlock[4]) * 64u + threadIdx.x);
-    else job_shade_material_table(j.sc, j.lutF, j.shadeMat, (b - j.firstBlock[5]) * 64u + threadIdx.x);
+    else if (b < j.firstBlock[5]) job_light_spheres(j.sc, j.lightVS, j.lightMeta, j.shadeLights, (b - j.firstBlock[4]) * 64u + threadIdx.x);
+    else job_shade_material_table(j.sc, j.lutF, j.shadeRows, j.shadeAvgs, (b - j.firstBlock[5]) * 64u + threadIdx.x);
 }
 
 ShadeTables shade_tables_of(const brmi_pass* p) {
@@ -188,11 +197,11 @@ int ensure_frame_constants(brmi_pass* p, hipStream_t s) {
     FrameJobs j;
     j.sc = p->scene; j.frameConst = p->wsPtr<m4>(p->ws.frameConst); j.objConst = p->wsPtr<float>(p->ws.objConst);
     j.matWords = p->wsPtr<MaterialWords>(p->ws.matWords); j.matConst = p->wsPtr<MatConst>(p->ws.matConst); j.tables = shade_tables_of(p);
-    j.lightVS = p->wsPtr<float4>(p->ws.lightVS); j.lightMeta = p->wsPtr<uint32_t>(p->ws.lightMeta);
+    j.lightVS = p->wsPtr<float4>(p->ws.lightVS); j.lightMeta = p->wsPtr<uint32_t>(p->ws.lightMeta); j.shadeLights = p->wsPtr<float4>(p->ws.shadeLights);
     j.alphaMats = p->sceneHasAlphaTest ? p->wsPtr<AlphaMaterial>(p->ws.alphaMats) : nullptr;
     j.W = p->cfg.width; j.H = p->cfg.height;
     auto blocks = [](uint32_t n) { return (std::max(1u, n) + 63u) / 64u; };
-    j.lutF = p->wsPtr<float>(p->ws.lutF); j.shadeMat = p->wsPtr<ShadeMaterialEntry>(p->ws.shadeMat);
+    j.lutF = p->wsPtr<float>(p->ws.lutF); j.shadeRows = p->wsPtr<ShadeRows>(p->ws.shadeRows); j.shadeAvgs = p->wsPtr<ShadeAverages>(p->ws.shadeAvgs);
     const uint32_t counts[6] = {blocks(p->scene.perObjectCount), blocks(p->scene.materialCount), blocks(p->scene.openpbrMaterialCount),
                                 blocks(std::max(std::max(j.W, j.H), 64u)), blocks(p->pfHost.numLights),
                                 // the (material, roughness) table only depends on the OpenPBR records and the lookup tables: built with the first

@@ -35,6 +35,7 @@ enum CounterIndex : uint32_t {
     CNT_DEFERRED_PIXELS,      // pixels the specialised shading kernel left to the general one
     CNT_RESOLVE_SPILL,        // some visible cluster found the resolve arena full (its pixels decode their vertices in place)
     CNT_RESOLVE_MARKED,       // the G-buffer pass marked the clusters that own a pixel (frames with more triangles than pixels)
+    CNT_DEFERRED_DROPPED,     // layered pixels that found their deferred-list stripe full (impossible by construction; counted anyway)
     CNT_FRONTIER0 = 32,       // frontier sizes per BFS level: [CNT_FRONTIER0 + level]
     CNT_STRIPES = 128,        // 64 stripes x 32 words: per-stripe {instances tested, instances visible, nodes visited}
     CNT_STRIPE_COUNT = 64, CNT_STRIPE_WORDS = 32,
@@ -89,7 +90,7 @@ struct HzbDesc {
 struct Workspace {     // byte offsets into BRMI_RES_WORKSPACE
     uint64_t counters, frontierA, frontierB, buckets, tempVisible, bitmask1, bitmask2, wordPrefix, blockSums,
              instanceBitBase, segPrefix, meshLevelWidth, planes, replayNodes, replayBuckets, lightVS, lightMeta, clusterPages, clusterHits, pageTotal, lightHitMasks, binCounts, binRecords, binOverflow, clusterSetup, resolveVerts, resolveTris, matWords, shadeTables, lutF, frameConst, objConst, matConst, deferredPixels, usedClusters,
-             clusterUv, binAlpha, overflowAlpha, resolveUVs, resolveColors, alphaMats, shadeMat, frameClearBytes, total;
+             clusterUv, binAlpha, overflowAlpha, resolveUVs, resolveColors, alphaMats, shadeRows, shadeAvgs, shadeLights, clusterList, listEntries, frameClearBytes, total;
 };
 
 }  // namespace brmi

@@ -38,6 +38,9 @@ struct ClusterArgs {
     uint32_t* clusterHits;        // per cluster: lights that touch it
     uint32_t* pageTotal;          // [0]: pages demanded by all clusters (unclamped)
     uint64_t* hitMasks; uint32_t maskWords;   // per cluster: one bit per light of the list
+    // the same lists once more for the shading pass, flat: clusterList[c] = {first entry, length}, entries = positions in the active-light
+    // list in the order the page walk of the reference visits them (newest page first)
+    uint2* clusterList; uint32_t* listEntries;
 };
 
 BRMI_DEV bool light_hits_cluster(float4 sphere, uint32_t type, f3 mn, f3 mx) {
@@ -148,13 +151,19 @@ __global__ void __launch_bounds__(256) k_lc_fill(ClusterArgs a) {
     const uint32_t demand = (idx + 1u < total ? a.clusterPages[idx + 1u] : a.pageTotal[0]) - base;
     const uint32_t valid = base >= a.poolSize ? 0u : min(demand, a.poolSize - base);   // pages that exist
     const uint64_t* masks = a.hitMasks + (size_t)idx * a.maskWords;
+    // the walk starts at the newest page (base + valid - 1), the only one that may be partly filled
+    const uint32_t newestCount = (valid < demand || valid == 0u) ? BRMI_LIGHTS_PER_PAGE : hits - BRMI_LIGHTS_PER_PAGE * (demand - 1u);
+    const uint32_t listBase = base * BRMI_LIGHTS_PER_PAGE;
     uint32_t before = 0;
     for (uint32_t lb = 0, w = 0; lb < lightCount; lb += 64, w++) {
         const uint64_t m = masks[w];
         if ((m >> lane) & 1ull) {
             const uint32_t j = before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            const uint32_t pg = j / BRMI_LIGHTS_PER_PAGE;
-            if (pg < valid) a.pages[base + pg].lightIndices[j % BRMI_LIGHTS_PER_PAGE] = a.lightMeta[lb + lane] >> 2;
+            const uint32_t pg = j / BRMI_LIGHTS_PER_PAGE, e = j % BRMI_LIGHTS_PER_PAGE;
+            if (pg < valid) {
+                a.pages[base + pg].lightIndices[e] = a.lightMeta[lb + lane] >> 2;
+                a.listEntries[listBase + (pg + 1u == valid ? e : newestCount + BRMI_LIGHTS_PER_PAGE * (valid - 2u - pg) + e)] = lb + lane;
+            }
         }
         before += (uint32_t)__popcll(m);
     }
@@ -169,6 +178,9 @@ __global__ void __launch_bounds__(256) k_lc_fill(ClusterArgs a) {
         c->numLights = valid < demand ? BRMI_LIGHTS_PER_PAGE * valid : hits;
         c->ptrFirstPage = valid == 0u ? BRMI_LIGHT_PAGE_NULL : base + valid - 1u;
         c->pad[0] = 0; c->pad[1] = 0;
+        // The reference's walk (lighting.hlsli:625-655) stops at a page with no lights in it: a cluster whose newest page was opened by a
+        // light that then missed (12, 24, ... hits and more lights behind the last one) shades NO light at all.  Reproduced as it is.
+        a.clusterList[idx] = make_uint2(listBase, (valid == 0u || newestCount == 0u) ? 0u : c->numLights);
     }
 }
 
@@ -309,6 +321,85 @@ BRMI_DEV f3 diffuse_eon(f3 albedo, float rough, float NdotV, float NdotL, float 
     return single + multi;
 }
 
+// The shading pass's record of a light (k_frame_constants), five float4 indexed by the position in the active-light list.
+//   [0] point / spot: world position, maxRange       directional: lightToFrag (= -direction), 0
+//   [1] attenuation polynomial, conservative upper bound of maxRange^2
+//   [2] colour, intensity        [3] spot: normalize(direction), cos(outer)        [4] cos(inner), type bits
+struct ShadeLightLanes { float4 r0, r1, r2, r3, r4; };      // one light per lane
+
+struct ShadeArgs {
+    ShadeTables tables;
+    const brmi_per_frame* perFrame; const brmi_camera* cameras; uint32_t openpbrMaterialCount; const float* lutFuzzLTC;
+    const float* depth; const float4* normals; const uint32_t* albedo; const unsigned long long* coat; const unsigned long long* emissive;
+    const unsigned long long* fuzz; const uint32_t* metallicRoughness;
+    const float4* shadeLights; const uint2* clusterList; const uint32_t* listEntries;
+    unsigned long long* hdr;
+    uint32_t W, H, tilesX, bandY0, bandY1; uint64_t firstPixel, pixelCount;
+    uint32_t enablePunctual, clustered;
+    const float* lutF;   // expanded tables: odE[32768] odAvg[1024] imE[1024] imAvg[32] unorm8[256]
+    const MatConst* matConst;
+    uint32_t sceneHasCoat;                  // 0: no OpenPBR record has a coat weight > 0, the coat plane's weight is 0 everywhere
+    const ShadeRows* shadeRows; const ShadeAverages* shadeAvgs;     // (OpenPBR material, roughness code) -> folded table rows and averages (k_frame_constants)
+    uint32_t* counters; uint32_t* deferred;   // pixels (band-relative tiled index) left to the general kernel
+    // The deferred pixels go to 64 striped lists (tile t appends to stripe (t / 64) % 64, so no stripe can exceed its share): one
+    // list with one counter would take an atomic with return per tile on a single address (~90 per microsecond on MI355X;
+    // 130 k tiles = 1.4 ms when most pixels carry coat or fuzz).
+    uint32_t deferredWord, nextDeferredWord;   // word inside a stripe: this call's list length / the next call's (cleared here)
+    uint32_t stripeCapacity;
+};
+
+BRMI_DEV float half_at(unsigned long long v, int k) { return f16_bits_to_f32((uint32_t)(v >> (16 * k)) & 0xFFFFu); }
+BRMI_DEV float bcast(float v, uint32_t lane) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), (int)lane)); }
+
+// Frame constants of the shading pass (uniform; evaluated by every lane like the shader does).
+struct ShadeFrame {
+    Luts L; uint32_t gx, gy, gz, nearSlices, numLights; m4 invProj, viewInv; f3 camPos;
+    float zNear, zFar, zSplit, resX, resY, tsx, tsy, logStart, logEnd, om5, om6;
+    float nearScale, farScale, log2Near;     // fast estimate of the cluster slice (corrected against the exact slice starts)
+};
+BRMI_DEV ShadeFrame make_shade_frame(const ShadeArgs& a) {
+    const brmi_per_frame* pf = a.perFrame;
+    const brmi_camera* cam = a.cameras + pf->mainCameraIndex;
+    ShadeFrame k;
+    k.L = Luts{a.lutF, a.lutF + 32768, a.lutF + 32768 + 1024, a.lutF + 32768 + 2048, a.lutFuzzLTC, a.lutF + 32768 + 2048 + 32};
+    k.gx = pf->lightClusterGridSizeX; k.gy = pf->lightClusterGridSizeY; k.gz = pf->lightClusterGridSizeZ;
+    k.invProj = uni_m4(load_m4(&cam->projectionInverse[0][0])); k.viewInv = uni_m4(load_m4(&cam->viewInverse[0][0]));
+    k.camPos = f3{uni(cam->positionWorldSpace[0]), uni(cam->positionWorldSpace[1]), uni(cam->positionWorldSpace[2])};
+    k.zNear = uni(cam->zNear); k.zFar = uni(cam->zFar); k.zSplit = uni(pf->clusterZSplitDepth);
+    k.resX = uni((float)pf->screenResX); k.resY = uni((float)pf->screenResY);
+    k.tsx = k.resX / (float)k.gx; k.tsy = k.resY / (float)k.gy;
+    k.tsx = uni(k.tsx); k.tsy = uni(k.tsy);
+    k.logStart = uni(logf(k.zSplit / k.zNear)); k.logEnd = uni(logf(k.zFar / k.zNear));      // only feed the slice ESTIMATE below (the exact slice starts come from the table)
+    k.nearSlices = pf->nearClusterCount; k.numLights = pf->numLights;
+    const float om = 1.0f - 1.0f / 7.0f;
+    k.om5 = uni(powf(om, 5.0f)); k.om6 = uni(powf(om, 6.0f));
+    k.nearScale = uni((float)k.nearSlices / (k.zSplit - k.zNear));
+    k.farScale = uni((float)(k.gz - k.nearSlices) / (k.logEnd - k.logStart));
+    k.log2Near = uni(log2f(k.zNear));
+    return k;
+}
+
+// the G-buffer words of one pixel, as stored
+struct RawPixel { float d; float4 ns; uint32_t al, mr; unsigned long long cs, es, fs; };
+BRMI_DEV RawPixel load_raw_pixel(const ShadeArgs& a, uint64_t i) {
+    RawPixel r;
+    r.d = a.depth[i]; r.ns = a.normals[i]; r.al = a.albedo[i]; r.mr = a.metallicRoughness[i]; r.cs = a.coat[i]; r.es = a.emissive[i]; r.fs = a.fuzz[i];
+    return r;
+}
+BRMI_DEV RawPixel empty_raw_pixel() { RawPixel r{}; r.d = as_f32(BRMI_DEPTH_EMPTY_BITS); return r; }
+
+// what the specialised kernel keeps in flight for the next tile: coat / fuzz words reduced to the coat weight
+BRMI_DEV RawPixel load_raw_pixel_plain(const ShadeArgs& a, uint64_t i) {
+    RawPixel r;
+    // read once: streaming loads
+    r.d = __builtin_nontemporal_load(&a.depth[i]);
+    r.ns = make_float4(__builtin_nontemporal_load(&a.normals[i].x), __builtin_nontemporal_load(&a.normals[i].y), __builtin_nontemporal_load(&a.normals[i].z), __builtin_nontemporal_load(&a.normals[i].w));
+    r.al = __builtin_nontemporal_load(&a.albedo[i]); r.mr = __builtin_nontemporal_load(&a.metallicRoughness[i]); r.es = __builtin_nontemporal_load(&a.emissive[i]);
+    // the coat plane is only looked at for its weight, and only when some material of the scene has a coat at all (brmi_set_scene)
+    r.cs = a.sceneHasCoat ? (unsigned long long)__builtin_nontemporal_load(&reinterpret_cast<const uint16_t*>(a.coat)[i * 4u + 3u]) << 48 : 0ull; r.fs = 0ull;   // coat weight only (a plain pixel has no other coat / fuzz input)
+    return r;
+}
+
 // Per-pixel part of calculateLightContributionPBR / EvaluateOpenPBRBaseLayerDirect.  The reference
 // re-derives all of this for every light; nothing here depends on the light, so it is evaluated once
 // per pixel with the same operations in the same order (bit-identical operands for the light loop).
@@ -321,12 +412,12 @@ struct PixelCtx {
     f3 dielComp;
     float f90Diel, f90Metal;
     f3 eonSinglePre, eonMsPre; float eonEInTerm, eonDen;
-    OdPrep od; LutRows im;
+    const float* odRow; const float* imRow;     // folded rows of the pixel's (material, roughness code)
     OdPrep coatOd;              // GENERAL: rows of the coat's (ior, roughness)
 };
 
 template <int MODE>
-BRMI_DEV PixelCtx make_pixel_ctx(const Luts& L, const Frag& f, const ShadeMaterialEntry& me) {
+BRMI_DEV PixelCtx make_pixel_ctx(const Luts& L, const Frag& f, const ShadeRows* rows, const ShadeAverages avg) {
     PixelCtx c;
     c.base = make_base_state(f);
     c.NoV = sat(dot3(f.normalWS, f.viewWS));
@@ -340,40 +431,39 @@ BRMI_DEV PixelCtx make_pixel_ctx(const Luts& L, const Frag& f, const ShadeMateri
     }
     if (MODE & 2) c.fuzz = make_fuzz_state(L, f);
     const BaseState& b = c.base;
-    // the (material, roughness code) part -- prep_od_e, prep_im_e, lut_od_avg, lut_im_avg -- comes from the per-frame table
-    c.od = me.od;
-    c.im = me.im;
-    const float viewComp = sample_od_e(L, c.od, sat(c.NoV));
-    const float avgComp = me.avgComp;
-    c.cachedView = max2(0.0f, qdiv(viewComp, max2(avgComp, 1.0e-12f)));
-    c.mView = sample_im_e(L, c.im, c.NoV);
-    c.mAvgClamped = me.mAvgClamped;
+    c.odRow = rows->od; c.imRow = rows->im;
+    const float viewComp = sample_folded_row(c.odRow, sat(c.NoV));
+    c.cachedView = max2(0.0f, qdiv(viewComp, max2(avg.avgComp, 1.0e-12f)));
+    c.mView = sample_folded_row(c.imRow, c.NoV);
+    c.mAvgClamped = avg.mAvgClamped;
     c.dielComp = ggx_energy_compensation(c.NoV, b.specularAlpha, b.dielectricSpecularF0);
     const float tmp = 50.0f * 0.33f;
     c.f90Diel = sat(dot3(b.dielectricSpecularF0, f3{tmp, tmp, tmp}));
     c.f90Metal = sat(dot3(b.metalSpecularF0, f3{tmp, tmp, tmp}));
-    // OpenPBRDiffuseEON, view-only factors
-    const float rough = b.baseDiffuseRoughness;
-    const float A = qrcp(1.0f + fon_a() * rough);
-    c.eonSinglePre = b.diffuseColor * (1.0f / PI_F) * A;
-    const float EIn = fon_dir_albedo(sat(c.NoV), rough);
-    const float avgE = A * (1.0f + fon_b() * rough);
-    const f3 msAlbedo = qdiv3((b.diffuseColor * b.diffuseColor) * avgE, max3v(f3{1.0f, 1.0f, 1.0f} - b.diffuseColor * (1.0f - avgE), f3{1.0e-4f, 1.0e-4f, 1.0e-4f}));
-    c.eonMsPre = msAlbedo * (1.0f / PI_F);
-    c.eonEInTerm = max2(1.0e-4f, 1.0f - EIn);
-    c.eonDen = max2(1.0e-4f, 1.0f - avgE);
+    {   // OpenPBRDiffuseEON, view-only factors
+        BRMI_FP_FAST
+        const float rough = b.baseDiffuseRoughness;
+        const float A = qrcp(1.0f + fon_a() * rough);
+        c.eonSinglePre = b.diffuseColor * (1.0f / PI_F) * A;
+        const float EIn = fon_dir_albedo(sat(c.NoV), rough);
+        const float avgE = A * (1.0f + fon_b() * rough);
+        const f3 msAlbedo = qdiv3((b.diffuseColor * b.diffuseColor) * avgE, max3v(f3{1.0f, 1.0f, 1.0f} - b.diffuseColor * (1.0f - avgE), f3{1.0e-4f, 1.0e-4f, 1.0e-4f}));
+        c.eonMsPre = msAlbedo * (1.0f / PI_F);
+        c.eonEInTerm = max2(1.0e-4f, 1.0f - EIn);
+        c.eonDen = max2(1.0e-4f, 1.0f - avgE);
+    }
     return c;
 }
 
+// `h` = normalize(L + V), NoH, LoH come from the caller (correctly rounded, contraction off: 1 - NoH^2 amplifies their error at low
+// roughness); everything in here holds the HDR tolerance and may fuse.
 template <int MODE>
-BRMI_DEV f3 light_contribution(const Luts& L, const Frag& f, const PixelCtx& c, f3 lightToFrag, float NoL, f3 lightColor, float intensity, float attenuation, float spotAtt) {
+BRMI_DEV f3 light_contribution(const Luts& L, const Frag& f, const PixelCtx& c, f3 lightToFrag, float NoL, float NoH, float LoH, float VdotL, float D, f3 lightColor, float intensity, float attenuation, float spotAtt) {
+    BRMI_FP_FAST
     const BaseState& base = c.base;
     const float NoV = c.NoV;
-    const f3 h = normalize3(lightToFrag + f.viewWS);       // N, V, L, H stay correctly rounded: 1 - NoH^2 amplifies their error at low roughness
-    const float NoH = sat(dot3(f.normalWS, h)), LoH = sat(dot3(lightToFrag, h));
-    const float VdotL = dot3(f.viewWS, lightToFrag);
     // diffuse: EON x dielectric energy compensation
-    const float lightComp = sample_od_e(L, c.od, sat(NoL));
+    const float lightComp = sample_folded_row(c.odRow, sat(NoL));
     const float diffuseEnergyComp = max2(0.0f, c.cachedView * lightComp);
     f3 diffuse;
     {
@@ -387,7 +477,7 @@ BRMI_DEV f3 light_contribution(const Luts& L, const Frag& f, const PixelCtx& c, 
         diffuse = (single + c.eonMsPre * f3{k, k, k}) * diffuseEnergyComp;
     }
     // specular: one D*V for both lobes (same roughness), one Schlick power
-    const float DV = d_ggx(base.specularAlpha, NoH) * v_smith_ggx(base.specularAlpha, NoV, NoL);
+    const float DV = D * v_smith_ggx(base.specularAlpha, NoV, NoL);
     const float pw = __builtin_amdgcn_exp2f(5.0f * __builtin_amdgcn_logf(1.0f - LoH));   // pow(1 - LoH, 5) = exp2(5 log2 x), as DXC lowers it
     const f3 Fd = base.dielectricSpecularF0 + (f3{c.f90Diel, c.f90Diel, c.f90Diel} - base.dielectricSpecularF0) * pw;
     const f3 dielSpec = base.dielectricSpecularWeight * (DV * Fd) * c.dielComp;
@@ -397,7 +487,7 @@ BRMI_DEV f3 light_contribution(const Luts& L, const Frag& f, const PixelCtx& c, 
     f3 metalSpec{0.0f, 0.0f, 0.0f};
     if (!(base.metalSpecularWeight == 0.0f && fabsf(DV) <= 3.4028234e38f)) {
         const f3 Fm = base.metalSpecularF0 + (f3{c.f90Metal, c.f90Metal, c.f90Metal} - base.metalSpecularF0) * pw;
-        const float mLight = sample_im_e(L, c.im, NoL);
+        const float mLight = sample_folded_row(c.imRow, NoL);
         const float mTab = qdiv(c.mView * mLight, c.mAvgClamped);
         const float mScale = min2(mTab, qrcp(max2(NoL, 1.0e-4f))) * (1.0f / PI_F);
         metalSpec = base.metalSpecularWeight * (DV * Fm + base.metalMultipleScatterScale * mScale);
@@ -428,105 +518,36 @@ BRMI_DEV f3 light_contribution(const Luts& L, const Frag& f, const PixelCtx& c, 
     return brdf * lightColor * intensity * attenuation * spotAtt * NoL;
 }
 
-struct ShadeArgs {
-    ShadeTables tables;
-    brmi_scene_buffers sc;
-    const float* depth; const float4* normals; const uint32_t* albedo; const unsigned long long* coat; const unsigned long long* emissive;
-    const unsigned long long* fuzz; const uint32_t* metallicRoughness;
-    const brmi_light_cluster* clusters; const brmi_light_page* pages; uint32_t poolSize;
-    unsigned long long* hdr;
-    uint32_t W, H, tilesX, bandY0, bandY1; uint64_t firstPixel, pixelCount;
-    uint32_t enablePunctual, clustered;
-    const float* lutF;   // expanded tables: odE[32768] odAvg[1024] imE[1024] imAvg[32] unorm8[256]
-    const MatConst* matConst;
-    uint32_t sceneHasCoat;                  // 0: no OpenPBR record has a coat weight > 0, the coat plane's weight is 0 everywhere
-    const ShadeMaterialEntry* shadeMat;     // (OpenPBR material, roughness code) -> prepared table rows and averages (k_frame_constants)
-    uint32_t* counters; uint32_t* deferred;   // pixels (band-relative tiled index) left to the general kernel
-    // The deferred pixels go to 64 striped lists (tile t appends to stripe (t / 64) % 64, so no stripe can exceed its share): one
-    // list with one counter would take an atomic with return per tile on a single address (~90 per microsecond on MI355X;
-    // 130 k tiles = 1.4 ms when most pixels carry coat or fuzz).
-    uint32_t deferredWord, nextDeferredWord;   // word inside a stripe: this call's list length / the next call's (cleared here)
-    uint32_t stripeCapacity;
-};
-
-BRMI_DEV float half_at(unsigned long long v, int k) { return f16_bits_to_f32((uint32_t)(v >> (16 * k)) & 0xFFFFu); }
-
-// Frame constants of the shading pass (uniform; evaluated by every lane like the shader does).
-struct ShadeFrame {
-    Luts L; uint32_t gx, gy, gz, nearSlices, numLights; m4 invProj, viewInv; f3 camPos;
-    float zNear, zFar, zSplit, resX, resY, tsx, tsy, logStart, logEnd, om5, om6;
-    float nearScale, farScale, log2Near;     // fast estimate of the cluster slice (corrected against the exact slice starts)
-};
-BRMI_DEV ShadeFrame make_shade_frame(const ShadeArgs& a) {
-    const brmi_scene_buffers& sc = a.sc;
-    const brmi_per_frame* pf = sc.perFrame;
-    const brmi_camera* cam = sc.cameras + pf->mainCameraIndex;
-    ShadeFrame k;
-    k.L = Luts{a.lutF, a.lutF + 32768, a.lutF + 32768 + 1024, a.lutF + 32768 + 2048, sc.lutFuzzLTC, a.lutF + 32768 + 2048 + 32};
-    k.gx = pf->lightClusterGridSizeX; k.gy = pf->lightClusterGridSizeY; k.gz = pf->lightClusterGridSizeZ;
-    k.invProj = uni_m4(load_m4(&cam->projectionInverse[0][0])); k.viewInv = uni_m4(load_m4(&cam->viewInverse[0][0]));
-    k.camPos = f3{uni(cam->positionWorldSpace[0]), uni(cam->positionWorldSpace[1]), uni(cam->positionWorldSpace[2])};
-    k.zNear = uni(cam->zNear); k.zFar = uni(cam->zFar); k.zSplit = uni(pf->clusterZSplitDepth);
-    k.resX = uni((float)pf->screenResX); k.resY = uni((float)pf->screenResY);
-    k.tsx = k.resX / (float)k.gx; k.tsy = k.resY / (float)k.gy;
-    k.tsx = uni(k.tsx); k.tsy = uni(k.tsy);
-    k.logStart = uni(logf(k.zSplit / k.zNear)); k.logEnd = uni(logf(k.zFar / k.zNear));      // only feed the slice ESTIMATE below (the exact slice starts come from the table)
-    k.nearSlices = pf->nearClusterCount; k.numLights = pf->numLights;
-    const float om = 1.0f - 1.0f / 7.0f;
-    k.om5 = uni(powf(om, 5.0f)); k.om6 = uni(powf(om, 6.0f));
-    k.nearScale = uni((float)k.nearSlices / (k.zSplit - k.zNear));
-    k.farScale = uni((float)(k.gz - k.nearSlices) / (k.logEnd - k.logStart));
-    k.log2Near = uni(log2f(k.zNear));
-    return k;
-}
-
-// One pixel of DeferredCSMain.  GENERAL = false is the specialisation for pixels without coat and fuzz (their
-// layer factors are exactly 1 / 0); it returns false for any other pixel, which is then shaded by the GENERAL
-// kernel from a deferred list -- the same idea as the reference's per-material-permutation pixel lists
-// (VisUtil.hlsl), applied to register pressure: the specialised kernel needs half the VGPRs.
-// the G-buffer words of one pixel, as stored
-struct RawPixel { float d; float4 ns; uint32_t al, mr; unsigned long long cs, es, fs; };
-BRMI_DEV RawPixel load_raw_pixel(const ShadeArgs& a, uint64_t i) {
-    RawPixel r;
-    r.d = a.depth[i]; r.ns = a.normals[i]; r.al = a.albedo[i]; r.mr = a.metallicRoughness[i]; r.cs = a.coat[i]; r.es = a.emissive[i]; r.fs = a.fuzz[i];
-    return r;
-}
-BRMI_DEV RawPixel empty_raw_pixel() { RawPixel r{}; r.d = as_f32(BRMI_DEPTH_EMPTY_BITS); return r; }
-
-// what the specialised kernel keeps in flight for the next tile: coat / fuzz words reduced to the coat weight
-BRMI_DEV RawPixel load_raw_pixel_plain(const ShadeArgs& a, uint64_t i) {
-    RawPixel r;
-    // read once: streaming loads
-    r.d = __builtin_nontemporal_load(&a.depth[i]);
-    r.ns = make_float4(__builtin_nontemporal_load(&a.normals[i].x), __builtin_nontemporal_load(&a.normals[i].y), __builtin_nontemporal_load(&a.normals[i].z), __builtin_nontemporal_load(&a.normals[i].w));
-    r.al = __builtin_nontemporal_load(&a.albedo[i]); r.mr = __builtin_nontemporal_load(&a.metallicRoughness[i]); r.es = __builtin_nontemporal_load(&a.emissive[i]);
-    // the coat plane is only looked at for its weight, and only when some material of the scene has a coat at all (brmi_set_scene)
-    r.cs = a.sceneHasCoat ? (unsigned long long)__builtin_nontemporal_load(&reinterpret_cast<const uint16_t*>(a.coat)[i * 4u + 3u]) << 48 : 0ull; r.fs = 0ull;   // coat weight only (a plain pixel has no other coat / fuzz input)
-    return r;
-}
-
-// Returns 0 when the pixel is done, else the class (1 coat, 2 fuzz, 3 both) of the variant that has to shade it.
+// One pixel per lane of DeferredCSMain (deferred.hlsl:11-106).  Every lane of the wave runs through here together -- `live` lanes
+// shade, the others (no geometry, outside the band, another material class) only lend a hand where the wave works as a team:
+//   * the lights of a cluster are STAGED one per lane (a lane loads the 80 B record of one light of the list: all records of a
+//     cluster arrive in one memory round trip, whatever the list length) and then broadcast light by light with v_readlane, so the
+//     light loop has no memory access of its own (the per-light chain page -> index -> record was five dependent scalar loads);
+//   * the broadcast is two-stage: position and range first, then a conservative reject on squared distance and facing (no lane of
+//     the tile can receive anything from the light: skip it before the correctly rounded sqrt / divide and the rest of the record).
+// MODE = class of pixel this instantiation shades (0 plain, 1 coat, 2 fuzz, 3 both: a layer that is absent has factors of exactly
+// 1 / 0, so the plain variant needs half the registers -- the same idea as the reference's per-material-permutation pixel lists).
+// Returns, for a live lane whose class is not MODE, that class (MODE 0 defers such pixels); 0 otherwise.
 template <int MODE>
-BRMI_DEV uint32_t shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const float* sliceStart, const float* unorm8, const RawPixel& raw, uint64_t i, uint32_t px, uint32_t py) {
-    const brmi_scene_buffers& sc = a.sc;
+BRMI_DEV uint32_t shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const float* sliceStart, const float* unorm8, const RawPixel& raw, bool live, uint64_t i, uint32_t px, uint32_t py) {
     const Luts& L = k.L;
-    const uint32_t gx = k.gx, gy = k.gy, gz = k.gz, nearSlices = k.nearSlices, numLights = k.numLights;
-    const m4& invProj = k.invProj; const m4& viewInv = k.viewInv; const f3 camPos = k.camPos;
-    const float zNear = k.zNear, zSplit = k.zSplit, logStart = k.logStart, om5 = k.om5, om6 = k.om6;
-    (void)gy;
+    const uint32_t gx = k.gx, gy = k.gy, gz = k.gz, nearSlices = k.nearSlices;
+    live = live && as_u32(raw.d) != BRMI_DEPTH_EMPTY_BITS;
+    Frag f{}; PixelCtx ctx{}; f3 posWS{0.0f, 0.0f, 0.0f};
+    uint32_t ci = 0xFFFFFFFFu, cls = 0u;
+    if (live) {
+        const m4& invProj = k.invProj; const m4& viewInv = k.viewInv;
         const float d = raw.d;
-        if (as_u32(d) == BRMI_DEPTH_EMPTY_BITS) return 0u;
         const AxisEntry ax = a.tables.x[px], ay = a.tables.y[py];
         float uvx = ax.uv, uvy = ay.uv;
         uvy = 1.0f - uvy;
         const f4 clipPos{uvx * 2.0f - 1.0f, uvy * 2.0f - 1.0f, 1.0f, 1.0f};
         const f4 viewPosH = mul_vm(clipPos, invProj);
         const f3 posVS = xyz(viewPosH) * d;
-        const f3 posWS = xyz(mul_point(posVS, viewInv));
-        const f3 viewDir = normalize3(camPos - posWS);
+        posWS = xyz(mul_point(posVS, viewInv));
+        const f3 viewDir = normalize3(k.camPos - posWS);
 
         // GetFragmentInfoScreenSpace + PopulateFragmentInfoFromOpenPBR
-        Frag f;
         f.posWS = posWS; f.viewWS = viewDir;
         const float4 ns = raw.ns;
         const f3 nrm{ns.x, ns.y, ns.z};
@@ -541,15 +562,13 @@ BRMI_DEV uint32_t shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const flo
         f.normalWS = normalize3(nrm + max2(0.0f, -NdotVraw + BRMI_MIN_N_DOT_V) * viewDir);
         f.NdotV = max2(BRMI_MIN_N_DOT_V, NdotVraw);
         uint32_t opIndex = (uint32_t)(ns.w + 0.5f);
-        if (opIndex >= sc.openpbrMaterialCount) opIndex = 0;
+        if (opIndex >= a.openpbrMaterialCount) opIndex = 0;
         const MatConst mc = a.matConst[opIndex];
         const float baseWeight = mc.baseWeight, specularWeight = mc.specularWeight;
         const f3 specularColor{mc.specR, mc.specG, mc.specB};
         const f3 weightedBaseColor = sat3(baseColor * baseWeight);
-        const float weightedSpecularIor = mc.weightedSpecularIor;
         f.dielectricSpecularF0 = sat3(specularColor * mc.dielF0Scalar);
         const float coatPR = clampf(coatR, BRMI_MIN_PERCEPTUAL_ROUGHNESS, 1.0f);
-        const float coatF0Scalar = mc.coatF0Scalar;
         f.dielectricSpecularWeight = sat(1.0f - metal);
         f.metalSpecularWeight = sat(metal * specularWeight);
         f.metalSpecularF0 = sat3(weightedBaseColor * specularColor);
@@ -557,8 +576,8 @@ BRMI_DEV uint32_t shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const flo
             const f3 safeF0 = sat3(weightedBaseColor), wmF0 = f3{1.0f, 1.0f, 1.0f} - safeF0;
             const float cosMax = 1.0f / 7.0f;
             const f3 wmF0b = f3{1.0f, 1.0f, 1.0f} - sat3(safeF0), wmTint = f3{1.0f, 1.0f, 1.0f} - sat3(specularColor);
-            const f3 num = (sat3(safeF0) + wmF0b * om5) * wmTint;
-            const float den = cosMax * om6;
+            const f3 num = (sat3(safeF0) + wmF0b * k.om5) * wmTint;
+            const float den = cosMax * k.om6;
             const f3 b = num * qrcp(max2(den, 1.0e-6f));
             f.metalAverageFresnel = sat3(safeF0 + wmF0 * (1.0f / 21.0f) - b * (1.0f / 126.0f));
         }
@@ -567,93 +586,94 @@ BRMI_DEV uint32_t shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const flo
         f.coatWeight = sat(half_at(cs, 3));
         f.coatColor = sat3(f3{half_at(cs, 0), half_at(cs, 1), half_at(cs, 2)});
         f.coatRoughness = coatPR * coatPR;
-        f.coatF0 = sat3(f.coatColor * coatF0Scalar);
+        f.coatF0 = sat3(f.coatColor * mc.coatF0Scalar);
         f.coatIor = mc.coatIor; f.coatDarkening = mc.coatDarkening;
         f.fuzzWeight = sat(fuzzW); f.fuzzColor = sat3(f3{half_at(fs, 0), half_at(fs, 1), half_at(fs, 2)}); f.fuzzRoughness = sat(half_at(fs, 3));
         f.baseDiffuseRoughness = mc.baseDiffuseRoughness;
-        f.specularAlpha = f.roughness; f.weightedSpecularIor = weightedSpecularIor;
+        f.specularAlpha = f.roughness; f.weightedSpecularIor = mc.weightedSpecularIor;
         f.diffuseColor = weightedBaseColor * (1.0f - metal);
 
-        const uint32_t cls = (f.coatWeight != 0.0f ? 1u : 0u) | (f.fuzzWeight != 0.0f ? 2u : 0u);
-        if (cls != (uint32_t)MODE) return MODE == 0 ? cls : 0u;      // MODE 0 defers; the layered variants only see their own class
-        const PixelCtx ctx = make_pixel_ctx<MODE>(L, f, a.shadeMat[opIndex * 256u + ((mr >> 8) & 0xFFu)]);
-        f3 lighting{0.0f, 0.0f, 0.0f};
-        auto shadeLight = [&](uint32_t lightIndex) {
-            const auto* l = kconst(sc.lights) + lightIndex;      // wave-uniform in the clustered path: scalar loads
-            const uint32_t type = l->type;
-            f3 lightToFrag; float att, dist = 0.0f, spot = 1.0f;
-            if (type == BRMI_LIGHT_DIRECTIONAL) { lightToFrag = -f3{l->dirWorldSpace[0], l->dirWorldSpace[1], l->dirWorldSpace[2]}; att = 1.0f; }
-            else {
-                const f3 toL = f3{l->posWorldSpace[0], l->posWorldSpace[1], l->posWorldSpace[2]} - posWS;
-                dist = length3(toL);
-                if (dist > l->maxRange) return;                      // lighting.hlsli:614-617
-                lightToFrag = normalize3(toL);
-                att = qrcp((l->attenuation[0] + l->attenuation[1] * dist + l->attenuation[2] * dist * dist) + 0.0001f);
-            }
-            // a light at or below the horizon contributes brdf * ... * 0 = +-0 (the BRDF is finite): adding it is the identity, so skip it
-            const float NoL = sat(dot3(f.normalWS, lightToFrag));
-            if (NoL == 0.0f) return;
-            if (type == BRMI_LIGHT_SPOT) {
-                const f3 ld{l->dirWorldSpace[0], l->dirWorldSpace[1], l->dirWorldSpace[2]};
-                const float cc = dot3(normalize3(ld), normalize3(-lightToFrag));
-                if (cc > l->outerConeAngle) {
-                    if (cc < l->innerConeAngle) { const float t = sat((cc - l->outerConeAngle) / (l->innerConeAngle - l->outerConeAngle)); spot = t * t * (3.0f - 2.0f * t); }
-                    else spot = 1.0f;
-                } else return;                                        // spot = 0: contribution is +-0
-            }
-            const f3 c = light_contribution<MODE>(L, f, ctx, lightToFrag, NoL, f3{l->color[0], l->color[1], l->color[2]}, l->color[3], att, spot);
-            lighting = lighting + c;
-        };
-        if (a.enablePunctual) {
+        cls = (f.coatWeight != 0.0f ? 1u : 0u) | (f.fuzzWeight != 0.0f ? 2u : 0u);
+        if (cls != (uint32_t)MODE) live = false;             // MODE 0 defers it; the layered variants only see their own class
+        else {
+            cls = 0u;
+            const uint32_t entry = opIndex * 256u + ((mr >> 8) & 0xFFu);
+            ctx = make_pixel_ctx<MODE>(L, f, a.shadeRows + entry, a.shadeAvgs[entry]);
             if (a.clustered) {
-                const uint32_t tx = ax.tile, ty = ay.tile;
                 const float z = fabsf(posVS.z);
                 // slice: a hardware-log estimate (within one slice of the shader's formula), corrected against the exact first
                 // depth of that slice and of the next one -- the value of the formula without its two divisions and logf
-                uint32_t sliceZ;
-                {
-                    const float est = z < zSplit ? (z - zNear) * k.nearScale
-                                                 : (float)nearSlices + ((__builtin_amdgcn_logf(z) - k.log2Near) * 0.69314718f - logStart) * k.farScale;
-                    int e = (int)min2(max2(est, 0.0f), (float)gz);
-                    const float lo = sliceStart[e], hi = sliceStart[e + 1];
-                    e += (z >= hi) ? 1 : 0; e -= (z < lo) ? 1 : 0;
-                    sliceZ = (uint32_t)e;
-
+                const float est = z < k.zSplit ? (z - k.zNear) * k.nearScale
+                                               : (float)nearSlices + ((__builtin_amdgcn_logf(z) - k.log2Near) * 0.69314718f - k.logStart) * k.farScale;
+                int e = (int)min2(max2(est, 0.0f), (float)gz);
+                const float lo = sliceStart[e], hi = sliceStart[e + 1];
+                e += (z >= hi) ? 1 : 0; e -= (z < lo) ? 1 : 0;
+                ci = (uint32_t)((float)ax.tile + (float)ay.tile * (float)gx + (float)(uint32_t)e * (float)gx * (float)gy);
+                if (ci >= gx * gy * gz) ci = 0xFFFFFFFFu;
+            } else ci = 0u;
+        }
+    }
+    f3 lighting{0.0f, 0.0f, 0.0f};
+    if (a.enablePunctual) {
+        // Waterfall over the distinct clusters of the wave (an 8x8 tile usually sits in one).  The loop and the staging run with every
+        // lane of the wave; only the light loop proper is restricted to the lanes of the cluster.  The lane set comes from a ballot and
+        // `uci` depends on the loop-carried mask, so neither can be replaced by the per-lane `ci`.
+        uint64_t pending = __ballot(live && ci != 0xFFFFFFFFu);
+        while (pending != 0ull) {
+            const uint32_t lead = (uint32_t)__ffsll((unsigned long long)pending) - 1u;
+            const uint32_t uci = (uint32_t)__builtin_amdgcn_readlane((int)ci, (int)lead);
+            const uint64_t same = __ballot(live && ci == uci);
+            pending &= ~same;
+            const bool mine = (same >> lane_id()) & 1ull;
+            uint32_t listBase = 0u, listCount = k.numLights;         // no clustering: the whole active list, in order
+            if (a.clustered) { const auto* cl = kconst(reinterpret_cast<const uint32_t*>(a.clusterList)) + 2u * (size_t)uci; listBase = cl[0]; listCount = cl[1]; }
+            for (uint32_t c0 = 0; c0 < listCount; c0 += 64u) {
+                const uint32_t n = min(64u, listCount - c0);
+                ShadeLightLanes s{};
+                if (lane_id() < n) {
+                    const uint32_t li = a.clustered ? a.listEntries[listBase + c0 + lane_id()] : c0 + lane_id();
+                    const float4* rec = a.shadeLights + (size_t)li * 5u;
+                    s.r0 = rec[0]; s.r1 = rec[1]; s.r2 = rec[2]; s.r3 = rec[3]; s.r4 = rec[4];
                 }
-                const uint32_t ci = (uint32_t)((float)tx + (float)ty * (float)gx + (float)sliceZ * (float)gx * (float)gy);
-                if (ci < gx * gy * gz) {
-                    // Waterfall over the distinct clusters of the wave (an 8x8 tile usually sits in one): with the cluster
-                    // index in an SGPR the cluster record, its pages, the index indirections and the light records are all
-                    // scalar loads -- no vector-memory latency and no VGPRs for light parameters inside the loop.
-                    // The lane set of a cluster comes from a ballot (not from `ci == uci` directly) so that value numbering
-                    // cannot substitute the per-lane `ci` for the scalar `uci`, and `uci` depends on the loop-carried mask so
-                    // that it cannot be hoisted.
-                    uint64_t pending = __ballot(1);
-                    while (pending != 0ull) {
-                        const uint32_t lead = (uint32_t)__ffsll((unsigned long long)pending) - 1u;
-                        const uint32_t uci = (uint32_t)__builtin_amdgcn_readlane((int)ci, (int)lead);
-                        const uint64_t same = __ballot(ci == uci);
-                        pending &= ~same;
-                        if ((same >> lane_id()) & 1ull) {
-                            const auto* cl = kconst(a.clusters) + uci;
-                            const uint32_t count = cl->numLights;
-                            uint32_t page = cl->ptrFirstPage, remaining = count, visited = 0;
-                            const uint32_t maxPages = max(1u, (count + BRMI_LIGHTS_PER_PAGE - 1u) / BRMI_LIGHTS_PER_PAGE);
-                            while (page != BRMI_LIGHT_PAGE_NULL && page < a.poolSize && remaining > 0 && visited < maxPages) {
-                                const auto* pg = kconst(a.pages) + page;
-                                uint32_t n = min(pg->numLightsInPage, BRMI_LIGHTS_PER_PAGE);
-                                n = min(n, remaining);
-                                if (n == 0) break;
-                                for (uint32_t k = 0; k < n; k++) shadeLight(kconst(sc.activeLightIndices)[pg->lightIndices[k]]);
-                                remaining -= n; page = pg->ptrNextPage; visited++;
-                            }
-                        }
+                if (mine) for (uint32_t q = 0; q < n; q++) {
+                    const uint32_t type = as_u32(bcast(s.r4.y, q));
+                    const f3 lp{bcast(s.r0.x, q), bcast(s.r0.y, q), bcast(s.r0.z, q)};
+                    f3 lightToFrag; float att = 1.0f, spot = 1.0f;
+                    if (type == BRMI_LIGHT_DIRECTIONAL) lightToFrag = lp;
+                    else {
+                        const float maxRange = bcast(s.r0.w, q), range2Hi = bcast(s.r1.w, q);
+                        const f3 toL = lp - posWS;
+                        const float d2 = dot3(toL, toL);
+                        // conservative rejects (exactly the lanes dropped here would be dropped below): beyond the range, or facing away
+                        // by more than any rounding of normalize() can undo
+                        if (d2 > range2Hi || dot3(f.normalWS, toL) < -1.0e-5f * qsqrt(d2)) continue;
+                        const float dist = sqrtf(d2);
+                        if (dist > maxRange) continue;                      // lighting.hlsli:614-617
+                        lightToFrag = toL * rcpf(dist);                      // normalize(toL) = toL * (1 / sqrt(dot))
+                        const float a0 = bcast(s.r1.x, q), a1 = bcast(s.r1.y, q), a2 = bcast(s.r1.z, q);
+                        att = qrcp((a0 + a1 * dist + a2 * dist * dist) + 0.0001f);
                     }
+                    // a light at or below the horizon contributes brdf * ... * 0 = +-0 (the BRDF is finite): adding it is the identity, so skip it
+                    const float NoL = sat(dot3(f.normalWS, lightToFrag));
+                    if (NoL == 0.0f) continue;
+                    if (type == BRMI_LIGHT_SPOT) {
+                        const f3 sd{bcast(s.r3.x, q), bcast(s.r3.y, q), bcast(s.r3.z, q)};
+                        const float outer = bcast(s.r3.w, q), inner = bcast(s.r4.x, q);
+                        const float cc = dot3(sd, normalize3(-lightToFrag));
+                        if (!(cc > outer)) continue;                        // spot = 0: contribution is +-0
+                        if (cc < inner) { const float t = sat((cc - outer) / (inner - outer)); spot = t * t * (3.0f - 2.0f * t); }
+                    }
+                    const f3 h = normalize3(lightToFrag + f.viewWS);        // N, V, L, H stay correctly rounded
+                    const float NoH = sat(dot3(f.normalWS, h)), LoH = sat(dot3(lightToFrag, h));
+                    const float VdotL = dot3(f.viewWS, lightToFrag);
+                    const float D = d_ggx(ctx.base.specularAlpha, NoH);
+                    const f3 col{bcast(s.r2.x, q), bcast(s.r2.y, q), bcast(s.r2.z, q)};
+                    lighting = lighting + light_contribution<MODE>(L, f, ctx, lightToFrag, NoL, NoH, LoH, VdotL, D, col, bcast(s.r2.w, q), att, spot);
                 }
-            } else {
-                for (uint32_t k = 0; k < numLights; k++) shadeLight(sc.activeLightIndices[k]);
             }
         }
+    }
+    if (live) {
         // EvaluateOpenPBREmissive
         if (MODE == 0) lighting = lighting + f.emissive;
         else {
@@ -662,7 +682,8 @@ BRMI_DEV uint32_t shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const flo
             lighting = lighting + f.emissive * f3{fuzzBase, fuzzBase, fuzzBase} * coatT;
         }
         __builtin_nontemporal_store((unsigned long long)pack_half4(lighting.x, lighting.y, lighting.z, 1.0f), &a.hdr[i]);
-        return 0u;
+    }
+    return cls;
 }
 
 // the specialised kernel must keep 3 waves per SIMD (<= 168 VGPRs); the general one is rare and may use the whole file
@@ -679,32 +700,35 @@ __global__ void __launch_bounds__(256, MODE != 0 ? 1 : BRMI_SHADE_WAVES) k_shade
     __syncthreads();
     if (MODE == 0) {
         // software pipeline: the G-buffer words of the next tile are requested before the current one is shaded, so
-        // their HBM latency overlaps ~1000 VALU instructions instead of stalling the wave at the top of every iteration
+        // their HBM latency overlaps the shading of this one instead of stalling the wave at the top of every iteration
         const uint64_t end = (a.pixelCount + 63ull) & ~63ull, stride = (uint64_t)gridDim.x * blockDim.x;
-        auto fetch = [&](uint64_t j, uint32_t& px, uint32_t& py) {
+        auto fetch = [&](uint64_t j, uint32_t& px, uint32_t& py, bool& ok) {
             const uint64_t i = a.firstPixel + j;
             const uint32_t tile = (uint32_t)(i >> 6), within = (uint32_t)(i & 63u);
             px = (tile % a.tilesX) * 8u + (within >> 3); py = (tile / a.tilesX) * 8u + (within & 7u);
-            return (j < a.pixelCount && px < a.W && py < a.H && py >= a.bandY0 && py < a.bandY1) ? load_raw_pixel_plain(a, i) : empty_raw_pixel();
+            ok = j < a.pixelCount && px < a.W && py < a.H && py >= a.bandY0 && py < a.bandY1;
+            return ok ? load_raw_pixel_plain(a, i) : empty_raw_pixel();
         };
-        uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-        uint32_t px = 0, py = 0;
-        RawPixel cur = j < end ? fetch(j, px, py) : empty_raw_pixel();
+        uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;      // `end` and `stride` are multiples of 64: the loop is wave-uniform
+        uint32_t px = 0, py = 0; bool ok = false;
+        RawPixel cur = j < end ? fetch(j, px, py, ok) : empty_raw_pixel();
         for (; j < end; j += stride) {
-            uint32_t npx = 0, npy = 0;
-            const RawPixel nxt = (j + stride < end) ? fetch(j + stride, npx, npy) : empty_raw_pixel();
-            const uint32_t cls = shade_pixel<0>(a, k, sliceStart, unormT, cur, a.firstPixel + j, px, py);
-            const bool done = cls == 0u;
+            uint32_t npx = 0, npy = 0; bool nok = false;
+            const RawPixel nxt = (j + stride < end) ? fetch(j + stride, npx, npy, nok) : empty_raw_pixel();
+            const uint32_t cls = shade_pixel<0>(a, k, sliceStart, unormT, cur, ok, a.firstPixel + j, px, py);
             const uint32_t stripe = (uint32_t)(j >> 12) & (CNT_STRIPE_COUNT - 1u);     // wave-uniform; runs of 64 neighbouring tiles share a stripe (locality of the list)
-            if (__any(!done)) {
+            if (__any(cls != 0u)) {
                 // one list per class (coat, fuzz, both) so that every layered variant walks a dense list
 #pragma unroll
                 for (uint32_t c = 1; c <= 3; c++) {
                     const uint32_t slot = wave_append(&a.counters[CNT_STRIPES + stripe * CNT_STRIPE_WORDS + a.deferredWord + (c - 1u)], cls == c);
-                    if (cls == c && slot < a.stripeCapacity) a.deferred[((size_t)(c - 1u) * CNT_STRIPE_COUNT + stripe) * a.stripeCapacity + slot] = (uint32_t)j;
+                    if (cls == c) {
+                        if (slot < a.stripeCapacity) a.deferred[((size_t)(c - 1u) * CNT_STRIPE_COUNT + stripe) * a.stripeCapacity + slot] = (uint32_t)j;
+                        else atomicAdd(&a.counters[CNT_DEFERRED_DROPPED], 1u);          // cannot happen by construction (a stripe holds its share of the band); counted like every other drop
+                    }
                 }
             }
-            cur = nxt; px = npx; py = npy;
+            cur = nxt; px = npx; py = npy; ok = nok;
         }
     } else {
         if (blockIdx.x == 0 && threadIdx.x < CNT_STRIPE_COUNT) a.counters[CNT_STRIPES + threadIdx.x * CNT_STRIPE_WORDS + a.nextDeferredWord + (uint32_t)(MODE - 1)] = 0u;   // the next shading call starts with empty lists
@@ -720,14 +744,22 @@ __global__ void __launch_bounds__(256, MODE != 0 ? 1 : BRMI_SHADE_WAVES) k_shade
         }
         __syncthreads();
         const uint32_t total = stripeStart[64];
-        for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += gridDim.x * blockDim.x) {
-            uint32_t stripe = 0;
+        // wave-uniform loop (q0 is the same for the 64 lanes of a wave): the lanes past the end of the list stay in step with the others
+        for (uint32_t q0 = blockIdx.x * blockDim.x; q0 < total; q0 += gridDim.x * blockDim.x) {
+            const uint32_t q = q0 + threadIdx.x;
+            const bool ok = q < total;
+            uint64_t i = a.firstPixel; uint32_t px = 0, py = 0;
+            RawPixel raw = empty_raw_pixel();
+            if (ok) {
+                uint32_t stripe = 0;
 #pragma unroll
-            for (uint32_t step = 32; step > 0; step >>= 1) if (stripeStart[stripe + step] <= q) stripe += step;
-            const uint64_t i = a.firstPixel + a.deferred[((size_t)(MODE - 1) * CNT_STRIPE_COUNT + stripe) * a.stripeCapacity + (q - stripeStart[stripe])];
-            const uint32_t tile = (uint32_t)(i >> 6), within = (uint32_t)(i & 63u);
-            const uint32_t px = (tile % a.tilesX) * 8u + (within >> 3), py = (tile / a.tilesX) * 8u + (within & 7u);
-            shade_pixel<MODE>(a, k, sliceStart, unormT, load_raw_pixel(a, i), i, px, py);
+                for (uint32_t step = 32; step > 0; step >>= 1) if (stripeStart[stripe + step] <= q) stripe += step;
+                i = a.firstPixel + a.deferred[((size_t)(MODE - 1) * CNT_STRIPE_COUNT + stripe) * a.stripeCapacity + (q - stripeStart[stripe])];
+                const uint32_t tile = (uint32_t)(i >> 6), within = (uint32_t)(i & 63u);
+                px = (tile % a.tilesX) * 8u + (within >> 3); py = (tile / a.tilesX) * 8u + (within & 7u);
+                raw = load_raw_pixel(a, i);
+            }
+            shade_pixel<MODE>(a, k, sliceStart, unormT, raw, ok, i, px, py);
         }
     }
 }
@@ -759,6 +791,7 @@ int launch_light_clustering(brmi_pass* p, hipStream_t s) {
     const uint32_t nc = p->numLightClusters;
     a.clusterHits = p->wsPtr<uint32_t>(p->ws.clusterHits); a.pageTotal = p->wsPtr<uint32_t>(p->ws.pageTotal);
     a.hitMasks = p->wsPtr<uint64_t>(p->ws.lightHitMasks); a.maskWords = (std::max(1u, p->scene.lightCount) + 63u) / 64u;
+    a.clusterList = p->wsPtr<uint2>(p->ws.clusterList); a.listEntries = p->wsPtr<uint32_t>(p->ws.listEntries);
     hipLaunchKernelGGL(k_lc_count, dim3((nc + 3) / 4), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_lc_scan, dim3(1), dim3(1024), 0, s, a);
     hipLaunchKernelGGL(k_lc_fill, dim3((nc + 3) / 4), dim3(256), 0, s, a);
@@ -769,18 +802,18 @@ int launch_light_clustering(brmi_pass* p, hipStream_t s) {
 int launch_shade(brmi_pass* p, hipStream_t s) {
     if (int rc = ensure_frame_constants(p, s)) return rc;
     ShadeArgs a;
-    a.sc = p->scene;
+    a.perFrame = p->scene.perFrame; a.cameras = p->scene.cameras; a.openpbrMaterialCount = p->scene.openpbrMaterialCount; a.lutFuzzLTC = p->scene.lutFuzzLTC;
+    a.shadeLights = p->wsPtr<float4>(p->ws.shadeLights); a.clusterList = p->wsPtr<uint2>(p->ws.clusterList); a.listEntries = p->wsPtr<uint32_t>(p->ws.listEntries);
     a.depth = static_cast<const float*>(p->res[BRMI_RES_LINEAR_DEPTH]); a.normals = static_cast<const float4*>(p->res[BRMI_RES_GBUF_NORMALS]);
     a.albedo = static_cast<const uint32_t*>(p->res[BRMI_RES_GBUF_ALBEDO]); a.coat = static_cast<const unsigned long long*>(p->res[BRMI_RES_GBUF_COAT]);
     a.emissive = static_cast<const unsigned long long*>(p->res[BRMI_RES_GBUF_EMISSIVE]); a.fuzz = static_cast<const unsigned long long*>(p->res[BRMI_RES_GBUF_FUZZ]);
     a.metallicRoughness = static_cast<const uint32_t*>(p->res[BRMI_RES_GBUF_METALLIC_ROUGHNESS]);
-    a.clusters = static_cast<const brmi_light_cluster*>(p->res[BRMI_RES_LIGHT_CLUSTERS]); a.pages = static_cast<const brmi_light_page*>(p->res[BRMI_RES_LIGHT_PAGES]);
-    a.poolSize = p->lightPagePool; a.hdr = static_cast<unsigned long long*>(p->res[BRMI_RES_HDR_COLOR]);
+    a.hdr = static_cast<unsigned long long*>(p->res[BRMI_RES_HDR_COLOR]);
     a.W = p->cfg.width; a.H = p->cfg.height; a.tilesX = p->tilesX; a.bandY0 = p->bandY0; a.bandY1 = p->bandY1; a.firstPixel = p->bandFirstPixel; a.pixelCount = p->bandPixelCount;
     a.enablePunctual = p->cfg.enablePunctualLights; a.clustered = p->cfg.enableClusteredLighting;
     a.lutF = p->wsPtr<float>(p->ws.lutF);
     a.matConst = p->wsPtr<MatConst>(p->ws.matConst);
-    a.shadeMat = p->wsPtr<ShadeMaterialEntry>(p->ws.shadeMat);
+    a.shadeRows = p->wsPtr<ShadeRows>(p->ws.shadeRows); a.shadeAvgs = p->wsPtr<ShadeAverages>(p->ws.shadeAvgs);
     a.sceneHasCoat = p->sceneHasCoat ? 1u : 0u;
     a.tables = shade_tables_of(p);
     a.counters = p->counters(); a.deferred = p->wsPtr<uint32_t>(p->ws.deferredPixels);

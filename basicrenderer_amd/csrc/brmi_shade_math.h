@@ -44,7 +44,11 @@ BRMI_DEV float qsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 BRMI_DEV f3 qdiv3(f3 a, f3 b) { return f3{qdiv(a.x, b.x), qdiv(a.y, b.y), qdiv(a.z, b.z)}; }
 
 // ---- PBR.hlsli
+// BRMI_FP_FAST: a block of BRDF algebra whose result only has to hold the HDR tolerance (1 fp16 ULP) may contract a * b + c into an
+// FMA (one rounding instead of two).  Never used on N, V, L, H or on 1 - NoH^2 (d_ggx), whose error the highlight amplifies.
+#define BRMI_FP_FAST _Pragma("clang fp contract(fast)")
 BRMI_DEV void ggx_dir_albedo_AB(float NdotV, float alpha, float& A, float& B) {
+    BRMI_FP_FAST
     const float x = NdotV, y = alpha, x2 = x * x, y2 = y * y;
     const float c0[4] = {0.1003f, 0.9345f, 1.0f, 1.0f}, c1[4] = {-0.6303f, -2.323f, -1.765f, 0.2281f}, c2[4] = {9.748f, 2.229f, 8.263f, 15.94f},
                 c3[4] = {-2.038f, -3.748f, 11.53f, -55.83f}, c4[4] = {29.34f, 1.424f, 28.96f, 13.08f}, c5[4] = {-8.245f, -0.7684f, -7.507f, 41.26f},
@@ -56,6 +60,7 @@ BRMI_DEV void ggx_dir_albedo_AB(float NdotV, float alpha, float& A, float& B) {
     A = clampf(qdiv(r[0], r[2]), 0.0f, 1.0f); B = clampf(qdiv(r[1], r[3]), 0.0f, 1.0f);
 }
 BRMI_DEV f3 ggx_energy_compensation(float NdotV, float alpha, f3 Fss) {
+    BRMI_FP_FAST
     float A, B; ggx_dir_albedo_AB(NdotV, alpha, A, B);
     const float Ess = (f3{1.0f, 1.0f, 1.0f} * A + f3{1.0f, 1.0f, 1.0f} * B).x;
     return f3{1.0f, 1.0f, 1.0f} + Fss * (1.0f - Ess) * qrcp(Ess);
@@ -65,6 +70,7 @@ BRMI_DEV f3 f_schlick(f3 f0, float f90, float VoH) {
     return f0 + (f3{f90, f90, f90} - f0) * pw;
 }
 BRMI_DEV float v_smith_ggx(float roughness, float NoV, float NoL) {
+    BRMI_FP_FAST
     const float a2 = roughness * roughness;
     const float lambdaV = NoL * qsqrt((NoV - a2 * NoV) * NoV + a2);
     const float lambdaL = NoV * qsqrt((NoL - a2 * NoL) * NoL + a2);
@@ -183,11 +189,37 @@ BRMI_DEV float average_fresnel(float eta) {
 }
 
 
-// What make_pixel_ctx needs from (OpenPBR material, 8-bit perceptual roughness code) alone: the prepared rows of the opaque-dielectric
-// and ideal-metal energy tables and the two table averages.  Built once per frame for every (material, code) pair with the functions
-// above (k_frame_constants), read with four 16 B loads per pixel instead of ~140 instructions and 8 table fetches.
-struct ShadeMaterialEntry { OdPrep od; LutRows im; float avgComp, mAvgClamped; uint32_t pad[3]; };
-static_assert(sizeof(ShadeMaterialEntry) == 64, "one cache line");
+// What the shading pass needs from (OpenPBR material, 8-bit perceptual roughness code) alone.  For such a pair the opaque-dielectric
+// energy complement is a function of the cosine only: lut_od_e's bilinear fetch in each of the two IOR slices, the lerp between the
+// slices and the IOR extrapolation are all linear in the texels, so they are folded ONCE per pair into a row of 32 values
+//     odRow[x] = extrapolate_ior(lerp(lerp(s0.row0[x], s0.row1[x], fy), lerp(s1.row0[x], s1.row1[x], fy), st), ior)
+// and a sample is one lerp between two neighbours of that row (2 loads + ~12 instructions instead of 8 loads + ~45); likewise the
+// ideal-metal complement (imRow, a function of the roughness code alone).  The column index and weight are computed exactly as
+// sample_rows computes them; what changes is the order in which the (multilinear) interpolation is associated, i.e. fp32 rounding in
+// the last bits -- tolerance-level, like the hardware rcp in the BRDF algebra.  Built by k_frame_constants with the first frame after
+// brmi_setup.
+struct ShadeRows { float od[32]; float im[32]; };                    // 256 B per (material, code)
+struct ShadeAverages { float avgComp, mAvgClamped; };              // lut_od_avg / max(lut_im_avg, 1e-12) of the pair
+static_assert(sizeof(ShadeRows) == 256 && sizeof(ShadeAverages) == 8, "table layouts");
+BRMI_DEV void build_shade_rows(const Luts& L, float ior, float alpha, ShadeRows& r, ShadeAverages& a) {
+    const OdPrep od = prep_od_e(L, ior, alpha);
+    const LutRows im = prep_im_e(L, alpha);
+    for (uint32_t x = 0; x < 32u; x++) {
+        const float v0 = lerpf(L.odE[od.s0.r0 + x], L.odE[od.s0.r1 + x], od.s0.fy), v1 = lerpf(L.odE[od.s1.r0 + x], L.odE[od.s1.r1 + x], od.s1.fy);
+        r.od[x] = extrapolate_ior(lerpf(v0, v1, od.st), ior);
+        r.im[x] = lerpf(L.odE[im.r0 + x], L.odE[im.r1 + x], im.fy);
+    }
+    a.avgComp = lut_od_avg(L, ior, alpha); a.mAvgClamped = max2(lut_im_avg(L, alpha), 1.0e-12f);
+}
+// one sample of a folded row: column and weight as in sample_rows
+BRMI_DEV float sample_folded_row(const float* row, float cosT) {
+    const float u = remap_index(clamp_index(cos_to_index(cosT)));
+    const float x = u * 32.0f - 0.5f;
+    const float x0f = floorf(x);
+    const float fx = x - x0f;
+    const uint32_t x0 = clamp_texel(x0f, 32), x1 = clamp_texel(x0f + 1.0f, 32);
+    return lerpf(row[x0], row[x1], fx);
+}
 
 }  // namespace brmi
 #endif

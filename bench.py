@@ -51,10 +51,21 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scale", type=float, default=1.0, help="fraction of the frame height the CPU baseline renders")
     args = ap.parse_args()
+    if args.gpus < 1:
+        fail_line(args, "--gpus must be >= 1")
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        # No launcher around us: start the N ranks ourselves -- as a CHILD torchrun, before this process has touched the GPU -- and
+        # exit with its code.  (Never an exec from a process that initialised HIP, and never a silent fall-back to one rank.)
+        sys.exit(self_launch(args))
+    if world_env is not None and int(world_env) != args.gpus:
+        fail_line(args, f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world_env} ranks")
 
     import numpy as np
     import torch
     import torch.distributed as dist
+    if torch.cuda.device_count() < args.gpus:
+        fail_line(args, f"--gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible")
     from basicrenderer_amd import Scene, compose
     from basicrenderer_amd.renderer import VisibilityRenderer
 
@@ -67,7 +78,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
     n = world
-    assert n == args.gpus or world == 1, "--gpus must equal WORLD_SIZE"
+    assert n == args.gpus
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
 
@@ -179,6 +190,27 @@ def main():
         ctypes.CDLL(None).fflush(None)
     if result_line is not None:
         print(result_line, flush=True)
+
+
+def fail_line(args, why):
+    """An N-GPU request that cannot be honoured is an error line and a non-zero exit, never a 1-GPU number."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(json.dumps({"metric": "shaded Mpixels/s @4K (vis-buffer+resolve)", "value": None, "unit": "Mpixels/s", "n_gpus": args.gpus,
+                          "steps": args.steps, "warmup": args.warmup, "error": why}), flush=True)
+    sys.exit(2)
+
+
+def self_launch(args):
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def cpu_baseline(scene, scale):
