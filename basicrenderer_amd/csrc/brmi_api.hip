@@ -29,6 +29,16 @@ __global__ void k_debug_arith(const float* a, const float* b, float* outDiv, flo
     outHalf[i] = f32_to_f16_bits(a[i]);
 }
 
+__global__ void k_debug_arith_in_range(const float* a, float* outRcp, float* outSqrt, float* outNorm, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = a[i];
+    outRcp[i] = in_range_pow63(x) ? rcp_rn_in_range(x) : 1.0f / x;
+    outSqrt[i] = in_range_pow63(x) ? sqrt_rn_in_range(x) : sqrtf(x);
+    float len; const f3 v = normalize3_len(f3{x, 1.0f, 0.5f}, x, len);      // the guarded pair on the same operand
+    outNorm[i] = v.y;                                                        // = 1 / sqrt(x)
+}
+
 int fail(brmi_pass* p, int code, const char* fmt, ...) {
     char buf[512];
     va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
@@ -117,14 +127,15 @@ static void compute_sizes(brmi_pass* p) {
     w.shadeTables = take(((uint64_t)2 * c.width + 2 * c.height + 64) * 4);
     w.matWords = take((uint64_t)std::max(1u, p->scene.materialCount) * sizeof(MaterialWords));
     w.frameConst = take(3 * 64);
-    w.matConst = take((uint64_t)std::max(1u, p->scene.openpbrMaterialCount) * 48);
+    w.matConst = take((uint64_t)std::max(1u, p->scene.openpbrMaterialCount) * sizeof(MatConst));
     w.objConst = take((uint64_t)std::max(1u, p->scene.perObjectCount) * 36 * 4);
     p->deferredStripeCapacity = (uint32_t)(((p->bandPixelCount / 4096 + CNT_STRIPE_COUNT) / CNT_STRIPE_COUNT) * 4096);   // 64-tile runs of a stripe x 4096 pixels
     w.deferredPixels = take((uint64_t)3 * CNT_STRIPE_COUNT * p->deferredStripeCapacity * 4);      // one set of striped lists per layered class
     w.lutF = take((uint64_t)(32768 + 1024 + 1024 + 32 + 256) * 4);
     w.shadeRows = take((uint64_t)std::max(1u, p->scene.openpbrMaterialCount) * 256 * 256);    // (OpenPBR material, roughness code) -> folded energy-table rows of the shading pass
     w.shadeAvgs = take((uint64_t)std::max(1u, p->scene.openpbrMaterialCount) * 256 * 8);
-    w.shadeLights = take((uint64_t)std::max(1u, p->scene.lightCount) * 80);                     // the shading pass's 80 B record per active light
+    w.ggxQuads = take(256 * 48);                                                                  // roughness code -> the GGX albedo fit as quadratics in N.V
+    w.shadeLights = take((uint64_t)std::max(1u, p->scene.lightCount) * 64);                     // the shading pass's 64 B record per active light
     w.clusterList = take((uint64_t)p->numLightClusters * 8);                                    // per light cluster: first entry / length of its flat light list
     w.listEntries = take((uint64_t)p->lightPagePool * BRMI_LIGHTS_PER_PAGE * 4 + 256);        // the page contents once more, in the order the page walk visits them
     // textured / alpha-tested scenes only: where each visible cluster's UV set lives, the texcoords of the resolve arena's vertices,
@@ -604,6 +615,13 @@ int brmi_debug_arith(const float* a, const float* b, float* outDiv, float* outSq
     if (!a || !b || !outDiv || !outSqrt || !outHalfBits) return BRMI_ERR_INVALID;
     if (n == 0) return BRMI_OK;
     hipLaunchKernelGGL(k_debug_arith, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), a, b, outDiv, outSqrt, outHalfBits, n);
+    return hipGetLastError() == hipSuccess ? BRMI_OK : BRMI_ERR_HIP;
+}
+
+int brmi_debug_arith_in_range(const float* a, float* outRcp, float* outSqrt, float* outRsqrt, uint32_t n, brmi_stream stream) {
+    if (!a || !outRcp || !outSqrt || !outRsqrt) return BRMI_ERR_INVALID;
+    if (n == 0) return BRMI_OK;
+    hipLaunchKernelGGL(k_debug_arith_in_range, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), a, outRcp, outSqrt, outRsqrt, n);
     return hipGetLastError() == hipSuccess ? BRMI_OK : BRMI_ERR_HIP;
 }
 

@@ -45,6 +45,34 @@ BRMI_DEV float rcpf(float x) { return 1.0f / x; }
 BRMI_DEV float rsqrtf_(float x) { return 1.0f / sqrtf(x); }
 BRMI_DEV float length3(f3 a) { return sqrtf(dot3(a, a)); }
 BRMI_DEV f3 normalize3(f3 a) { return a * rsqrtf_(dot3(a, a)); }
+// Correctly rounded sqrt(x) and 1 / x for x well inside the normal range, 2^-63 <= x < 2^63.  The compiler's expansions of sqrtf and of
+// the division carry an input-scaling prologue and a fix-up epilogue for subnormal / huge / special operands (7 of 16 and 4 of 11
+// instructions); for an in-range operand those are the identity, and what is left -- restated here operation by operation -- is the
+// hardware estimate plus the same FMA corrections, so the results are bit-identical to the IEEE ones.  The vectors of the shading pass
+// (eye and light distances of a scene in metres) always take this path; anything else falls back to the general form.
+BRMI_DEV bool in_range_pow63(float x) { return (as_u32(x) - 0x20000000u) < 0x3F000000u; }     // positive, finite, 2^-63 <= x < 2^63
+BRMI_DEV float sqrt_rn_in_range(float x) {
+    const float y = __builtin_amdgcn_sqrtf(x);
+    const float yDown = as_f32(as_u32(y) - 1u), yUp = as_f32(as_u32(y) + 1u);
+    const float eDown = __builtin_fmaf(-yDown, y, x), eUp = __builtin_fmaf(-yUp, y, x);
+    float r = eDown <= 0.0f ? yDown : y;
+    r = eUp > 0.0f ? yUp : r;
+    return r;
+}
+BRMI_DEV float rcp_rn_in_range(float x) {
+    const float r0 = __builtin_amdgcn_rcpf(x);
+    const float r1 = __builtin_fmaf(__builtin_fmaf(-x, r0, 1.0f), r0, r0);
+    const float q = __builtin_fmaf(__builtin_fmaf(-x, r1, 1.0f), r1, r1);
+    return __builtin_fmaf(__builtin_fmaf(-x, q, 1.0f), r1, q);
+}
+// length and normalize with the two helpers: `len` = sqrt(dot(a, a)), returns a * (1 / len), as normalize3 / length3 compute them
+BRMI_DEV f3 normalize3_len(f3 a, float d2, float& len) {
+    float inv;
+    if (in_range_pow63(d2)) { len = sqrt_rn_in_range(d2); inv = rcp_rn_in_range(len); }
+    else { len = sqrtf(d2); inv = 1.0f / len; }
+    return a * inv;
+}
+BRMI_DEV f3 normalize3_q(f3 a) { float len; return normalize3_len(a, dot3(a, a), len); }
 BRMI_DEV float min2(float a, float b) { return a < b ? a : b; }
 BRMI_DEV float max2(float a, float b) { return a > b ? a : b; }
 BRMI_DEV float sat(float x) { return min2(max2(x, 0.0f), 1.0f); }

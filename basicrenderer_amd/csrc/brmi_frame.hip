@@ -75,8 +75,8 @@ BRMI_DEV void job_material_words(const brmi_scene_buffers& sc, MaterialWords* ou
 }
 
 // view-space bounding spheres of the active lights, once per frame (testSphereAABB's transform, lightCulling.hlsl:15-21)
-// ... and the shading pass's record of the light (brmi_light.hip, ShadeLight): what getLightParametersForFragment reads, 80 B, indexed
-// by the position in the active-light list.  normalize(dirWorldSpace) of a spot light is per light, not per pixel (lighting.hlsli:640).
+// ... and the shading pass's record of the light (brmi_light.hip, ShadeLightLanes): what getLightParametersForFragment reads, 64 B, indexed
+// (four float4) by the position in the active-light list.  normalize(dirWorldSpace) of a spot light is per light, not per pixel (lighting.hlsli:640).
 BRMI_DEV void job_light_spheres(const brmi_scene_buffers& sc, float4* lightVS, uint32_t* lightMeta, float4* shadeLights, uint32_t i) {
     const brmi_per_frame* pf = sc.perFrame;
     if (i >= pf->numLights) return;
@@ -86,17 +86,18 @@ BRMI_DEV void job_light_spheres(const brmi_scene_buffers& sc, float4* lightVS, u
     const f3 c = xyz(mul_point(f3{l->boundingSphere[0], l->boundingSphere[1], l->boundingSphere[2]}, view));
     lightVS[i] = make_float4(c.x, c.y, c.z, l->boundingSphere[3]);
     lightMeta[i] = (l->type & 3u) | (li << 2);
-    float4* r = shadeLights + (size_t)i * 5u;
+    float4* r = shadeLights + (size_t)i * 4u;
     const f3 dir{l->dirWorldSpace[0], l->dirWorldSpace[1], l->dirWorldSpace[2]};
-    if (l->type == BRMI_LIGHT_DIRECTIONAL) r[0] = make_float4(-dir.x, -dir.y, -dir.z, 0.0f);     // lightToFrag
-    else r[0] = make_float4(l->posWorldSpace[0], l->posWorldSpace[1], l->posWorldSpace[2], l->maxRange);
-    // dist > maxRange certainly holds once dist^2 exceeds this bound (sqrt is monotone and correctly rounded; 1e-6 covers the products' rounding)
-    const float mr = as_f32(as_u32(fabsf(l->maxRange)) + 1u);
-    r[1] = make_float4(l->attenuation[0], l->attenuation[1], l->attenuation[2], (mr * mr) * 1.000001f);
-    r[2] = make_float4(l->color[0], l->color[1], l->color[2], l->color[3]);
-    const f3 sd = l->type == BRMI_LIGHT_SPOT ? normalize3(dir) : f3{0.0f, 0.0f, 0.0f};
-    r[3] = make_float4(sd.x, sd.y, sd.z, l->outerConeAngle);
-    r[4] = make_float4(l->innerConeAngle, as_f32(l->type), 0.0f, 0.0f);
+    if (l->type == BRMI_LIGHT_DIRECTIONAL) r[0] = make_float4(-dir.x, -dir.y, -dir.z, -1.0f);     // lightToFrag; a negative range marks the type
+    else r[0] = make_float4(l->posWorldSpace[0], l->posWorldSpace[1], l->posWorldSpace[2], max2(l->maxRange, 0.0f));
+    // dist > maxRange certainly holds once dist^2 exceeds this bound (sqrt is monotone and correctly rounded; 1e-6 covers the products' rounding);
+    // a negative range rejects every pixel
+    const float mr = as_f32(as_u32(max2(l->maxRange, 0.0f)) + 1u);
+    r[1] = make_float4(l->attenuation[0], l->attenuation[1], l->attenuation[2], l->maxRange < 0.0f ? -1.0f : (mr * mr) * 1.000001f);
+    r[2] = make_float4(l->color[0] * l->color[3], l->color[1] * l->color[3], l->color[2] * l->color[3], l->innerConeAngle);
+    const bool spotL = l->type == BRMI_LIGHT_SPOT;
+    const f3 sd = spotL ? normalize3(dir) : f3{0.0f, 0.0f, 0.0f};
+    r[3] = make_float4(sd.x, sd.y, sd.z, spotL ? max2(l->outerConeAngle, -1.0f) : -2.0f);
 }
 
 // Per-material part of PopulateFragmentInfoFromOpenPBR (utilities.hlsli:2590-2637): depends only on the
@@ -113,6 +114,18 @@ BRMI_DEV MatConst material_constants_of(const brmi_openpbr_material_info* op) {
     m.dielF0Scalar = ior_to_f0(m.weightedSpecularIor);
     m.coatF0Scalar = ior_to_f0(op->coatIor);
     m.coatIor = op->coatIor; m.coatDarkening = sat(op->coatDarkening); m.baseDiffuseRoughness = sat(op->baseDiffuseRoughness); m.pad = 0.0f;
+    {   // OpenPBRDiffuseEON, the part that only depends on the material's diffuse roughness (IBL.hlsli:94-131)
+        const float rough = m.baseDiffuseRoughness;
+        const float A = qrcp(1.0f + fon_a() * rough);
+        const float g[4] = {0.0571085289f, 0.491881867f, -0.332181442f, 0.0714429953f};
+        m.fonA = A;
+        for (int k = 0; k < 4; k++) m.fonK[k] = A * rough * g[k];
+        m.eonSingleScale = (1.0f / PI_F) * A;
+        m.eonAvgE = A * (1.0f + fon_b() * rough);
+        m.eonOneMinusAvgE = 1.0f - m.eonAvgE;
+        m.eonInvDen = qrcp(max2(1.0e-4f, 1.0f - m.eonAvgE));
+        m.pad2[0] = m.pad2[1] = m.pad2[2] = 0.0f;
+    }
     return m;
 }
 BRMI_DEV void job_material_constants(const brmi_scene_buffers& sc, MatConst* out, uint32_t i) {
@@ -121,10 +134,11 @@ BRMI_DEV void job_material_constants(const brmi_scene_buffers& sc, MatConst* out
 }
 // (material, roughness code) -> the light-independent table part of make_pixel_ctx (brmi_shade_math.h): the same functions the shader
 // called per pixel, evaluated once per pair
-BRMI_DEV void job_shade_material_table(const brmi_scene_buffers& sc, const float* lutF, ShadeRows* rows, ShadeAverages* avgs, uint32_t i) {
+BRMI_DEV void job_shade_material_table(const brmi_scene_buffers& sc, const float* lutF, ShadeRows* rows, ShadeAverages* avgs, GgxQuad* quads, uint32_t i) {
     const uint32_t m = i >> 8, code = i & 255u;
-    if (m >= sc.openpbrMaterialCount) return;
     const Luts L{lutF, lutF + 32768, lutF + 32768 + 1024, lutF + 32768 + 2048, sc.lutFuzzLTC, lutF + 32768 + 2048 + 32};
+    if (m == 0u) { const float pc = clampf(L.unorm8[code], BRMI_MIN_PERCEPTUAL_ROUGHNESS, 1.0f); quads[code] = ggx_quad_of(pc * pc); }   // f.roughness / f.coatRoughness of the code
+    if (m >= sc.openpbrMaterialCount) return;
     const MatConst mc = material_constants_of(sc.openpbrMaterials + m);
     const float prc = clampf(L.unorm8[code], BRMI_MIN_PERCEPTUAL_ROUGHNESS, 1.0f);
     const float alpha = sat(prc * prc), ior = max2(mc.weightedSpecularIor, 1.0f);        // BaseState::specularAlpha / weightedSpecularIor
@@ -169,7 +183,7 @@ struct FrameJobs {
     brmi_scene_buffers sc;
     m4* frameConst; float* objConst; MaterialWords* matWords; MatConst* matConst; ShadeTables tables; float4* lightVS; uint32_t* lightMeta; float4* shadeLights;
     AlphaMaterial* alphaMats;
-    const float* lutF; ShadeRows* shadeRows; ShadeAverages* shadeAvgs;
+    const float* lutF; ShadeRows* shadeRows; ShadeAverages* shadeAvgs; GgxQuad* ggxQuads;
     uint32_t W, H;
     uint32_t firstBlock[7];      // block ranges of the six jobs
 };
@@ -181,7 +195,7 @@ __global__ void __launch_bounds__(64) k_frame_constants(FrameJobs j) {
     else if (b < j.firstBlock[3]) job_material_constants(j.sc, j.matConst, (b - j.firstBlock[2]) * 64u + threadIdx.x);
     else if (b < j.firstBlock[4]) job_shade_tables(j.sc, j.tables, j.W, j.H, (b - j.firstBlock[3]) * 64u + threadIdx.x);
     else if (b < j.firstBlock[5]) job_light_spheres(j.sc, j.lightVS, j.lightMeta, j.shadeLights, (b - j.firstBlock[4]) * 64u + threadIdx.x);
-    else job_shade_material_table(j.sc, j.lutF, j.shadeRows, j.shadeAvgs, (b - j.firstBlock[5]) * 64u + threadIdx.x);
+    else job_shade_material_table(j.sc, j.lutF, j.shadeRows, j.shadeAvgs, j.ggxQuads, (b - j.firstBlock[5]) * 64u + threadIdx.x);
 }
 
 ShadeTables shade_tables_of(const brmi_pass* p) {
@@ -201,7 +215,7 @@ int ensure_frame_constants(brmi_pass* p, hipStream_t s) {
     j.alphaMats = p->sceneHasAlphaTest ? p->wsPtr<AlphaMaterial>(p->ws.alphaMats) : nullptr;
     j.W = p->cfg.width; j.H = p->cfg.height;
     auto blocks = [](uint32_t n) { return (std::max(1u, n) + 63u) / 64u; };
-    j.lutF = p->wsPtr<float>(p->ws.lutF); j.shadeRows = p->wsPtr<ShadeRows>(p->ws.shadeRows); j.shadeAvgs = p->wsPtr<ShadeAverages>(p->ws.shadeAvgs);
+    j.lutF = p->wsPtr<float>(p->ws.lutF); j.shadeRows = p->wsPtr<ShadeRows>(p->ws.shadeRows); j.shadeAvgs = p->wsPtr<ShadeAverages>(p->ws.shadeAvgs); j.ggxQuads = p->wsPtr<GgxQuad>(p->ws.ggxQuads);
     const uint32_t counts[6] = {blocks(p->scene.perObjectCount), blocks(p->scene.materialCount), blocks(p->scene.openpbrMaterialCount),
                                 blocks(std::max(std::max(j.W, j.H), 64u)), blocks(p->pfHost.numLights),
                                 // the (material, roughness) table only depends on the OpenPBR records and the lookup tables: built with the first

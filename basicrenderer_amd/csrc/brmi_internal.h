@@ -68,7 +68,13 @@ constexpr uint32_t BRMI_CS_ALPHA = 1u << 28, BRMI_CS_TEXTURED = 1u << 29, BRMI_C
 // per-frame tables and per-material constants of the shading pass (brmi_frame.hip fills them, brmi_light.hip reads them)
 struct AxisEntry { float uv; uint32_t tile; };       // per column / row: (i + 0.5) / res and the light-cluster tile index
 struct ShadeTables { AxisEntry* x; AxisEntry* y; float* sliceStart; };
-struct MatConst { float baseWeight, specularWeight, specR, specG, specB, weightedSpecularIor, dielF0Scalar, coatF0Scalar, coatIor, coatDarkening, baseDiffuseRoughness, pad; };
+struct MatConst {
+    float baseWeight, specularWeight, specR, specG, specB, weightedSpecularIor, dielF0Scalar, coatF0Scalar, coatIor, coatDarkening, baseDiffuseRoughness, pad;
+    // OpenPBRDiffuseEON with the material's diffuse roughness folded in (tolerance-level re-association, brmi_light.hip):
+    // fon_dir_albedo(mu) = fonA + mc (fonK[0] + mc (fonK[1] + mc (fonK[2] + mc fonK[3]))), mc = 1 - mu
+    float fonA, fonK[4], eonSingleScale /* A / pi */, eonAvgE, eonOneMinusAvgE, eonInvDen /* 1 / max(1e-4, 1 - avgE) */, pad2[3];
+};
+static_assert(sizeof(MatConst) == 96, "six float4");
 constexpr uint32_t BRMI_ARENA_NONE = 0xFFFFFFFFu;
 // resolve arena: per-vertex and per-triangle tables of the visible clusters (brmi_resolve.hip)
 struct ResolveVertex { float px, py, pz, nx, ny, nz; };                                   // 24 B: object-space position, decoded normal
@@ -90,7 +96,7 @@ struct HzbDesc {
 struct Workspace {     // byte offsets into BRMI_RES_WORKSPACE
     uint64_t counters, frontierA, frontierB, buckets, tempVisible, bitmask1, bitmask2, wordPrefix, blockSums,
              instanceBitBase, segPrefix, meshLevelWidth, planes, replayNodes, replayBuckets, lightVS, lightMeta, clusterPages, clusterHits, pageTotal, lightHitMasks, binCounts, binRecords, binOverflow, clusterSetup, resolveVerts, resolveTris, matWords, shadeTables, lutF, frameConst, objConst, matConst, deferredPixels, usedClusters,
-             clusterUv, binAlpha, overflowAlpha, resolveUVs, resolveColors, alphaMats, shadeRows, shadeAvgs, shadeLights, clusterList, listEntries, frameClearBytes, total;
+             clusterUv, binAlpha, overflowAlpha, resolveUVs, resolveColors, alphaMats, shadeRows, shadeAvgs, ggxQuads, shadeLights, clusterList, listEntries, frameClearBytes, total;
 };
 
 }  // namespace brmi

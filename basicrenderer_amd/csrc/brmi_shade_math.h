@@ -38,6 +38,9 @@ BRMI_DEV f3 sample_ltc(const float* t, float u, float v) {
 // division / sqrt, 1 - NoH^2 amplifies their error) the BRDF algebra uses the hardware reciprocal and
 // square root (1 ULP, what HLSL `/`, rcp and sqrt compile to on a GPU) instead of the ~11-instruction
 // correctly rounded expansions.
+// saturate as one v_med3_f32 (the shading pass only: for finite x the value of min(max(x, 0), 1); the sign of a zero result is not pinned)
+BRMI_DEV float satq(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
+BRMI_DEV f3 satq3(f3 v) { return f3{satq(v.x), satq(v.y), satq(v.z)}; }
 BRMI_DEV float qdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 BRMI_DEV float qrcp(float b) { return __builtin_amdgcn_rcpf(b); }
 BRMI_DEV float qsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
@@ -58,6 +61,29 @@ BRMI_DEV void ggx_dir_albedo_AB(float NdotV, float alpha, float& A, float& B) {
     for (int i = 0; i < 4; i++)
         r[i] = c0[i] + c1[i] * x + c2[i] * y + c3[i] * x * y + c4[i] * x2 + c5[i] * y2 + c6[i] * x2 * y + c7[i] * x * y2 + c8[i] * x2 * y2;
     A = clampf(qdiv(r[0], r[2]), 0.0f, 1.0f); B = clampf(qdiv(r[1], r[3]), 0.0f, 1.0f);
+}
+// For a fixed alpha the fit's four polynomials are quadratics in x = N.V: r[i](x) = q0[i] + x (q1[i] + x q2[i]).  alpha only depends on
+// the 8-bit roughness code of the G-buffer, so the 12 coefficients are tabulated per code (k_frame_constants) and a pixel evaluates
+// 8 FMAs instead of the 36-term form (tolerance-level: the same polynomial, associated differently).
+struct GgxQuad { float q0[4], q1[4], q2[4]; };
+static_assert(sizeof(GgxQuad) == 48, "three float4");
+BRMI_DEV GgxQuad ggx_quad_of(float alpha) {
+    const float y = alpha, y2 = y * y;
+    const float c0[4] = {0.1003f, 0.9345f, 1.0f, 1.0f}, c1[4] = {-0.6303f, -2.323f, -1.765f, 0.2281f}, c2[4] = {9.748f, 2.229f, 8.263f, 15.94f},
+                c3[4] = {-2.038f, -3.748f, 11.53f, -55.83f}, c4[4] = {29.34f, 1.424f, 28.96f, 13.08f}, c5[4] = {-8.245f, -0.7684f, -7.507f, 41.26f},
+                c6[4] = {-26.44f, 1.436f, -36.11f, 54.9f}, c7[4] = {19.99f, 0.2913f, 15.86f, 300.2f}, c8[4] = {-5.448f, 0.6286f, 33.37f, -285.1f};
+    GgxQuad g;
+    for (int i = 0; i < 4; i++) { g.q0[i] = c0[i] + c2[i] * y + c5[i] * y2; g.q1[i] = c1[i] + c3[i] * y + c7[i] * y2; g.q2[i] = c4[i] + c6[i] * y + c8[i] * y2; }
+    return g;
+}
+BRMI_DEV f3 ggx_energy_compensation_q(const GgxQuad& g, float x, f3 Fss) {
+    BRMI_FP_FAST
+    float r[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) r[i] = g.q0[i] + x * (g.q1[i] + x * g.q2[i]);
+    const float A = clampf(qdiv(r[0], r[2]), 0.0f, 1.0f), B = clampf(qdiv(r[1], r[3]), 0.0f, 1.0f);
+    const float Ess = A + B;
+    return f3{1.0f, 1.0f, 1.0f} + Fss * ((1.0f - Ess) * qrcp(Ess));
 }
 BRMI_DEV f3 ggx_energy_compensation(float NdotV, float alpha, f3 Fss) {
     BRMI_FP_FAST

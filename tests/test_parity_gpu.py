@@ -63,6 +63,31 @@ def test_arithmetic_contract():
         assert np.array_equal(oh.cpu().numpy().astype(np.uint16), a.astype(np.float16).view(np.uint16))
 
 
+def test_in_range_sqrt_and_reciprocal_are_the_ieee_results():
+    """The shading pass computes its vector lengths and normalisations with the scaling-free forms of sqrt and 1 / x (brmi_device.h).
+    Bit for bit the IEEE results on 4 M operands: dense around 1, across the whole in-range span, at its edges, and outside it (where the
+    general form takes over)."""
+    import torch
+    from basicrenderer_amd import capi
+    lib = capi.brmi_lib()
+    rng = np.random.default_rng(11)
+    n = 1 << 22
+    a = np.exp2(rng.uniform(-70, 70, n)).astype(np.float32)
+    a[: n // 4] = rng.uniform(0.25, 4.0, n // 4).astype(np.float32)
+    edge = np.float32(2.0) ** np.array([-63, 63, -64, 62], dtype=np.float32)
+    a[-64:] = np.array([np.nextafter(e, np.float32(s)) for e in edge for s in (0, np.inf)] * 8, dtype=np.float32)
+    a[-80:-64] = np.array([0.0, np.inf, 1e-45, 1e-40, 3e38, 1.0, 4.0, 2.0 ** -126] * 2, dtype=np.float32)
+    ta = torch.from_numpy(a).cuda()
+    orc_, osq, ors = torch.empty_like(ta), torch.empty_like(ta), torch.empty_like(ta)
+    assert lib.brmi_debug_arith_in_range(ta.data_ptr(), orc_.data_ptr(), osq.data_ptr(), ors.data_ptr(), n, None) == 0
+    torch.cuda.synchronize()
+    with np.errstate(all="ignore"):
+        sq = np.sqrt(a)
+        assert np.array_equal(orc_.cpu().numpy().view(np.uint32), (np.float32(1) / a).view(np.uint32))
+        assert np.array_equal(osq.cpu().numpy().view(np.uint32), sq.view(np.uint32))
+        assert np.array_equal(ors.cpu().numpy().view(np.uint32), (np.float32(1) * (np.float32(1) / sq)).view(np.uint32))
+
+
 @pytest.mark.parametrize("name", CASES)
 def test_cull_visible_clusters_exact(name, gpu_frames, oracle_frames):
     g, o = gpu_frames(name), oracle_frames(name)
