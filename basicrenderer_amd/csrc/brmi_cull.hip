@@ -36,6 +36,9 @@ struct CullArgs {
     HzbDesc hzb;
     // multi-GPU row band: two view-space planes through the eye bounding the band (1 = active)
     uint32_t bandActive; float bandTop[3], bandBottom[3];
+    // mixed traversal: meshes whose widest BVH level fits the LDS frontier are walked by k_cull_hierarchy (one wave per instance, one launch),
+    // the few wider ones by the level-per-launch kernels (all lanes of the chip on one level); the latter skip instances narrower than this
+    const uint32_t* meshLevelWidth; uint32_t levelKernelsWidthLo;
 };
 
 BRMI_DEV f3 to_view_space(f3 c, const m4& model, const m4& view) { return xyz(mul_vm(mul_point(c, model), view)); }
@@ -131,7 +134,7 @@ __global__ void __launch_bounds__(256) k_cull_instances(CullArgs a, NodeRecord* 
     for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < ((sc.activeDrawCount + 63u) & ~63u); d += gridDim.x * blockDim.x) {
         bool visible = false;
         uint32_t ii = 0, root = 0;
-        if (d < sc.activeDrawCount) {
+        if (d < sc.activeDrawCount && (a.levelKernelsWidthLo == 0u || a.meshLevelWidth[sc.clodOffsets[sc.activeDraws[d]].clodMeshMetadataIndex] >= a.levelKernelsWidthLo)) {
             ii = sc.activeDraws[d];
             const brmi_per_mesh_instance inst = sc.perMeshInstance[ii];
             const m4 model = load_m4(&sc.perObject[inst.perObjectBufferIndex].model[0][0]);
@@ -165,7 +168,10 @@ __global__ void __launch_bounds__(256) k_traverse(CullArgs a, uint32_t level, co
     uint32_t* nextCount = &a.counters[CNT_FRONTIER0 + level + 1];
     const uint32_t rounded = (inputCount + 63u) & ~63u;
     for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < rounded; idx += gridDim.x * blockDim.x) {
-        const bool have = idx < inputCount;
+        bool have = idx < inputCount;
+        // phase 2 of a mixed traversal: the replay buffer also holds nodes of the narrow instances, which k_cull_hierarchy<true> walks
+        if (have && level == 0u && a.phase == 2u && a.levelKernelsWidthLo != 0u &&
+            a.meshLevelWidth[sc.clodOffsets[frontierIn[idx].instanceIndex].clodMeshMetadataIndex] < a.levelKernelsWidthLo) have = false;
         // per-record state
         bool isInternal = false, emitLeaf = false, replay = false, occluded = false;
         uint32_t occludedNode = 0;
@@ -297,7 +303,9 @@ __global__ void __launch_bounds__(256) k_traverse(CullArgs a, uint32_t level, co
 // BVH level fits the LDS frontier (brmi_set_scene checks); same tests, same operation order as k_cull_instances / k_traverse.
 constexpr uint32_t HIER_CAP_MAX = 1024;   // widest BVH level the LDS frontier variants cover
 // HIER_CAP nodes per frontier, HIER_STAGE bucket records staged in LDS: (256, 128) = 6 KB keeps ~20 workgroups per CU in flight
-// (scenes of many small instances), (1024, 128) = 12 KB covers wide hierarchies.
+// (scenes of many small instances), (1024, 128) = 12 KB covers wide hierarchies.  Meshes wider than that (a street's ground and facades
+// tessellated to pixel-sized triangles: 1,600 leaf segments on one level) go through the level-per-launch kernels, which put every
+// lane of the chip on one level -- a single wave walking such a mesh alone took 0.4 ms (tried with a 4096-node variant).
 template <bool REPLAY, uint32_t HIER_CAP, uint32_t HIER_STAGE>
 __global__ void __launch_bounds__(64) k_cull_hierarchy(CullArgs a, BucketRecord* buckets, const uint32_t* meshLevelWidth, uint32_t widthLo, uint32_t widthHi) {
     __shared__ uint32_t frontier[2][HIER_CAP];
@@ -846,8 +854,11 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
     uint32_t* wordPrefix = p->wsPtr<uint32_t>(p->ws.wordPrefix); uint32_t* blockSums = p->wsPtr<uint32_t>(p->ws.blockSums);
 
     const uint32_t maxBlocks = 1024;
-    const bool hierarchy = p->maxLevelWidth <= HIER_CAP_MAX && !p->forceLevelKernels;
+    // one launch of k_cull_hierarchy for the meshes that fit its LDS frontier, the level kernels for the rest (or for everything: tests)
+    const bool hierarchy = p->minLevelWidth <= HIER_CAP_MAX && !p->forceLevelKernels;
+    const bool levelKernels = p->maxLevelWidth > HIER_CAP_MAX || p->forceLevelKernels;
     const uint32_t* meshWidth = p->wsPtr<uint32_t>(p->ws.meshLevelWidth);
+    a.meshLevelWidth = meshWidth; a.levelKernelsWidthLo = (hierarchy && levelKernels) ? HIER_CAP_MAX + 1u : 0u;
     if (phase == 1) {
         if (!p->frameStateCleared) BRMI_HIP(p, hipMemsetAsync(p->counters(), 0, p->ws.frameClearBytes, s));      // counters + both survivor bitmasks
         p->frameStateCleared = false;
@@ -856,7 +867,8 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
             // narrow meshes (most instances) with the 6 KB variant, wide ones with the 24 KB variant; each launch skips the other class
             if (p->minLevelWidth <= 256u) hipLaunchKernelGGL((k_cull_hierarchy<false, 256, 128>), hgrid, dim3(64), 0, s, a, buckets, meshWidth, 0u, 256u);
             if (p->maxLevelWidth > 256u) hipLaunchKernelGGL((k_cull_hierarchy<false, 1024, 128>), hgrid, dim3(64), 0, s, a, buckets, meshWidth, 257u, HIER_CAP_MAX);
-        } else hipLaunchKernelGGL(k_cull_instances, dim3(grid_for(p->scene.activeDrawCount, 256, maxBlocks)), dim3(256), 0, s, a, fa);
+        }
+        if (levelKernels) hipLaunchKernelGGL(k_cull_instances, dim3(grid_for(p->scene.activeDrawCount, 256, maxBlocks)), dim3(256), 0, s, a, fa);
         BRMI_LAUNCH_CHECK(p, "k_cull_instances");
     } else {
         hipLaunchKernelGGL(k_seed_phase2, dim3(1), dim3(128), 0, s, p->counters(), a.recordCapacity);
@@ -865,7 +877,7 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
     }
     // frontier sizes are only known on the device: size the grids for the worst case that can matter
     const uint32_t travGrid = grid_for(std::min<uint64_t>(p->cfg.maxTraversalRecords, (uint64_t)p->scene.lodNodeCount * 4 + 4096), 256, maxBlocks);
-    for (uint32_t level = 0; level < p->maxLevels && !hierarchy; level++) {
+    for (uint32_t level = 0; level < p->maxLevels && levelKernels; level++) {
         // phase 2 reads level 0 from the replay buffer and then ping-pongs like phase 1 (level 0 writes fb)
         const NodeRecord* in = level == 0 ? (phase == 1 ? fa : a.replayNodes) : ((level & 1u) ? fb : fa);
         hipLaunchKernelGGL(k_traverse, dim3(travGrid), dim3(256), 0, s, a, level, in, (level & 1u) ? fa : fb, buckets);

@@ -23,6 +23,8 @@
 //     lanes that own neighbouring rows hit the same cache line and every later full-screen pass touches
 //     whole lines.
 // Raster buckets (K4) collapse: with one PSO-free kernel there is nothing to sort by.
+#include <algorithm>
+
 #include "brmi_device.h"
 #include "brmi_internal.h"
 #include "brmi_texture.h"
@@ -43,6 +45,7 @@ struct AlphaRecord { AlphaTri tri; uint32_t materialDataIndex, pad[2]; };     //
 static_assert(sizeof(AlphaRecord) == 48, "AlphaRecord layout");
 constexpr int BIN_W = 256, BIN_ROWS = 16;          // bin = 4096 keys = 32 KB of LDS
 constexpr int BIN_W_SHIFT = 8, BIN_ROWS_SHIFT = 4;
+constexpr uint32_t BIN_SLICE = 1024;               // records of a bin one workgroup of k_raster_bins walks
 constexpr int BIN_WINDOW = 256;                     // bins a wave can count in LDS at once (cells of its bin bounding box)
 constexpr int COOP_ENTRIES = 64;                    // triangles with more bin entries than this are emitted by the whole wave
 
@@ -478,19 +481,26 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? 4 : 1) k_raster_bins
     __shared__ uint32_t taskStart[ALPHA ? ALPHA_LIST + 1 : 1];      // exclusive prefix of the listed records' task counts
     __shared__ uint32_t scanPart[ALPHA ? BRMI_BIN_THREADS : 1];
     __shared__ uint32_t alphaCount;
+    // A bin with many records (the near field of a dense frame: thousands of slivers on one strip of ground) is cut into slices of
+    // BIN_SLICE records, one workgroup each (blockIdx.z): the kernel ends with its slowest workgroup, and one bin with 8,000 records
+    // used to be that workgroup.  The slices of a bin merge into the visibility buffer with atomic-min; a bin that fits one slice keeps
+    // the plain read-modify-write merge (it owns its pixels).  The counts are cleared by k_raster_overflow, which runs next.
     const uint32_t strip = blockIdx.x, band = blockIdx.y, bin = band * a.binsX + strip;
-    const uint32_t n = min(a.binCounts[bin], a.binCapacity);
-    if (n == 0) return;
-    if (ALPHA) { for (uint32_t i = threadIdx.x; i < 256u; i += BRMI_BIN_THREADS) unormT[i] = (float)i / 255.0f; if (threadIdx.x == 0) alphaCount = 0u; }
-    __syncthreads();                                    // every thread has read the count
-    if (threadIdx.x == 0) a.binCounts[bin] = 0u;      // self-cleaning: the bins are empty again when this launch retires
+    const uint32_t nAll = min(a.binCounts[bin], a.binCapacity);
+    const bool shared = nAll > BIN_SLICE;               // other workgroups (or later slices of this one) write this bin's pixels too
+    if (ALPHA) for (uint32_t i = threadIdx.x; i < 256u; i += BRMI_BIN_THREADS) unormT[i] = (float)i / 255.0f;
+    // slice blockIdx.z, then every gridDim.z-th one (phase 2, which rarely draws anything, is launched with one slice per bin)
+    for (uint32_t first = blockIdx.z * BIN_SLICE; first < nAll; first += gridDim.z * BIN_SLICE) {
+    const uint32_t n = min(nAll, first + BIN_SLICE);
+    __syncthreads();                                    // the previous slice's merge has read the tile
+    if (ALPHA && threadIdx.x == 0) alphaCount = 0u;
     for (uint32_t i = threadIdx.x; i < BIN_W * BIN_ROWS; i += BRMI_BIN_THREADS) tile[i] = BRMI_VIS_EMPTY;
     __syncthreads();
     const int x0 = (int)(strip << BIN_W_SHIFT), y0 = (int)(band << BIN_ROWS_SHIFT);
     const LdsSink sink{tile, x0, y0};
     const BinRecord* recs = a.binRecords + (size_t)bin * a.binCapacity;
     const uint32_t sub = threadIdx.x >> 4, row = threadIdx.x & 15u;
-    for (uint32_t base = 0; base < n; base += BRMI_BIN_THREADS / 16) {
+    for (uint32_t base = first; base < n; base += BRMI_BIN_THREADS / 16) {
         const uint32_t ri = base + sub;
         if (ri >= n) continue;
         const BinRecord r = recs[ri];
@@ -500,8 +510,8 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? 4 : 1) k_raster_bins
             uint32_t slot = 0;
             if (row == 0u) slot = atomicAdd(&alphaCount, 1u);
             slot = (uint32_t)__shfl((int)slot, (int)(lane_id() & 48u));
-            deferred = slot < ALPHA_LIST && ri < 65536u;
-            if (deferred && row == 0u) alphaList[slot] = (uint16_t)ri;
+            deferred = slot < ALPHA_LIST;                 // ri - first < BIN_SLICE <= 65536: fits the 16-bit list entry
+            if (deferred && row == 0u) alphaList[slot] = (uint16_t)(ri - first);
         }
         if (row < rows && !deferred) {
             float sb0 = r.sb0, sb1 = r.sb1;
@@ -532,7 +542,7 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? 4 : 1) k_raster_bins
         constexpr uint32_t PER = ALPHA_LIST / BRMI_BIN_THREADS;
         uint32_t mine[PER]; uint32_t sum = 0;
 #pragma unroll
-        for (uint32_t k = 0; k < PER; k++) { const uint32_t j = threadIdx.x * PER + k; mine[k] = j < listed ? tasks_of(recs[alphaList[j]]) : 0u; sum += mine[k]; }
+        for (uint32_t k = 0; k < PER; k++) { const uint32_t j = threadIdx.x * PER + k; mine[k] = j < listed ? tasks_of(recs[first + alphaList[j]]) : 0u; sum += mine[k]; }
         scanPart[threadIdx.x] = sum;
         __syncthreads();
         for (uint32_t o = 1; o < BRMI_BIN_THREADS; o <<= 1) {
@@ -544,13 +554,14 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? 4 : 1) k_raster_bins
         uint32_t run = scanPart[threadIdx.x] - sum;
 #pragma unroll
         for (uint32_t k = 0; k < PER; k++) { const uint32_t j = threadIdx.x * PER + k; if (j <= listed) taskStart[j] = run; run += mine[k]; }
+        if (threadIdx.x == BRMI_BIN_THREADS - 1u && listed == ALPHA_LIST) taskStart[ALPHA_LIST] = run;      // j never reaches ALPHA_LIST in the loop above
         __syncthreads();
         const uint32_t total = listed ? taskStart[listed] : 0u;
         for (uint32_t task = threadIdx.x; task < total; task += BRMI_BIN_THREADS) {
             uint32_t j = 0;
 #pragma unroll
             for (uint32_t step = ALPHA_LIST / 2; step > 0; step >>= 1) if (j + step <= listed && taskStart[j + step] <= task) j += step;
-            const uint32_t ri = alphaList[j];
+            const uint32_t ri = first + alphaList[j];
             const BinRecord r = recs[ri];
             const int bx0 = max(r.minX, x0), bx1 = min(r.minX + r.rectWidth - 1, x0 + BIN_W - 1);
             const uint32_t nseg = (uint32_t)(((bx1 - bx0) >> ALPHA_SEG_SHIFT) + 1), local = task - taskStart[j];
@@ -576,6 +587,12 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? 4 : 1) k_raster_bins
         if (!any) continue;      // untouched (this also covers columns / rows beyond the target size)
         const uint32_t px = (uint32_t)x0 + xl, py = (uint32_t)y0 + half * 8u;
         ulonglong2* dst = reinterpret_cast<ulonglong2*>(&a.vis[(((py >> 3) * a.tilesX + (px >> 3)) << 6) | ((px & 7u) << 3)]);
+        if (shared) {
+            unsigned long long* d1 = reinterpret_cast<unsigned long long*>(dst);
+#pragma unroll
+            for (int q = 0; q < 4; q++) { if (k[q].x != BRMI_VIS_EMPTY) atomicMin(&d1[2 * q], k[q].x); if (k[q].y != BRMI_VIS_EMPTY) atomicMin(&d1[2 * q + 1], k[q].y); }
+            continue;
+        }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const ulonglong2 g = dst[q];
@@ -583,6 +600,7 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? 4 : 1) k_raster_bins
             if (m.x != g.x || m.y != g.y) dst[q] = m;
         }
     }
+    }   // slices
 }
 
 // Records that did not fit their bin: four per wave64, one lane per row, global 64-bit atomics (the bins' merge is a plain
@@ -593,6 +611,8 @@ __global__ void __launch_bounds__(64) k_raster_overflow(RasterArgs a) {
     const uint32_t lane = threadIdx.x, sub = lane >> 4, row = lane & 15u;
     __shared__ float unormT[ALPHA ? 256 : 1];
     if (ALPHA) { for (uint32_t i = threadIdx.x; i < 256u; i += 64u) unormT[i] = (float)i / 255.0f; __syncthreads(); }
+    // the bins are empty again when this launch retires (k_raster_bins has finished; its slices all read the counts)
+    for (uint32_t i = blockIdx.x * 64u + lane; i < a.binsX * a.binsY; i += gridDim.x * 64u) a.binCounts[i] = 0u;
     // lane = stripe: all 64 queue lengths with one load; nearly every frame has none
     const uint32_t mine = min(a.counters[CNT_STRIPES + lane * CNT_STRIPE_WORDS + STRIPE_OVERFLOW], a.overflowPerStripe);
     uint64_t busy = __ballot(mine != 0u);
@@ -647,13 +667,14 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
     a.clusterUv = p->wsPtr<ClusterUv>(p->ws.clusterUv);
     a.alphaMats = p->wsPtr<AlphaMaterial>(p->ws.alphaMats);
     if (p->sceneHasAlphaTest) if (int rc = ensure_frame_constants(p, s)) return rc;
+    const uint32_t slices = phase == 2 ? 1u : std::min(16u, (p->binCapacity + BIN_SLICE - 1u) / BIN_SLICE);
     if (p->sceneHasAlphaTest) {
         hipLaunchKernelGGL(k_raster<true>, dim3(p->rasterGrid), dim3(64), 0, s, a);
-        if (!(p->rasterDebug & 4)) hipLaunchKernelGGL(k_raster_bins<true>, dim3(p->binsX, p->binsY), dim3(BRMI_BIN_THREADS), 0, s, a);
+        if (!(p->rasterDebug & 4)) hipLaunchKernelGGL(k_raster_bins<true>, dim3(p->binsX, p->binsY, slices), dim3(BRMI_BIN_THREADS), 0, s, a);
         hipLaunchKernelGGL(k_raster_overflow<true>, dim3(512), dim3(64), 0, s, a);
     } else {
         hipLaunchKernelGGL(k_raster<false>, dim3(p->rasterGrid), dim3(64), 0, s, a);
-        if (!(p->rasterDebug & 4)) hipLaunchKernelGGL(k_raster_bins<false>, dim3(p->binsX, p->binsY), dim3(BRMI_BIN_THREADS), 0, s, a);
+        if (!(p->rasterDebug & 4)) hipLaunchKernelGGL(k_raster_bins<false>, dim3(p->binsX, p->binsY, slices), dim3(BRMI_BIN_THREADS), 0, s, a);
         hipLaunchKernelGGL(k_raster_overflow<false>, dim3(512), dim3(64), 0, s, a);
     }
     BRMI_LAUNCH_CHECK(p, "k_raster");

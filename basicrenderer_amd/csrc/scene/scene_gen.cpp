@@ -135,9 +135,12 @@ struct PatchDef {
 
 V3 evalPatch(const PatchDef& p, double u, double v) {
     double n = p.noiseAmp != 0 ? p.noiseAmp * fbm(u * p.noiseFreq, v * p.noiseFreq, p.noiseSeed) : 0.0;
-    if (p.detail > 1.0 && p.noiseAmp != 0)      // amplitude ~ wavelength: every LOD level keeps an error comparable to its edge length
-        n = p.noiseAmp * p.detail * (fbm(u * p.noiseFreq, v * p.noiseFreq, p.noiseSeed) + 0.4 * fbm(u * p.noiseFreq * 4.0, v * p.noiseFreq * 4.0, p.noiseSeed + 101u) +
-                                     0.16 * fbm(u * p.noiseFreq * 16.0, v * p.noiseFreq * 16.0, p.noiseSeed + 202u));
+    if (p.detail > 1.0 && p.noiseAmp != 0) {
+        // roughness at every scale: seven more octaves, each half the wavelength and half the amplitude of the one before, so that the
+        // simplification error of a LOD level stays proportional to its edge length and the 1-pixel error test keeps pixel-sized triangles
+        double a = p.noiseAmp * (p.detail - 1.0) * 0.25, f = p.noiseFreq;
+        for (uint32_t k = 1; k <= 7u; k++) { a *= 0.5; f *= 2.0; n += a * valueNoise(u * f, v * f, p.noiseSeed + 101u * k); }
+    }
     if (p.type == PATCH_PLANE) {
         V3 nrm = normalize(cross(p.axisU, p.axisV));
         return p.origin + p.axisU * u + p.axisV * v + nrm * n;
@@ -1473,7 +1476,9 @@ void presetStreet(brmi_scene& sc, Pcg32& rng, double triBudget, uint32_t nMeshes
     { MeshDef m; m.patches.push_back(planePatch({-Wd, 0, -L}, {0, Hh, 0}, {0, 0, 2 * L}, fq, fq * 4, 0.35, 30, 202)); m.material = 1; m.lodLevels = lv(fq); meshes.push_back(m); }
     { MeshDef m; m.patches.push_back(planePatch({Wd, 0, -L}, {0, 0, 2 * L}, {0, Hh, 0}, fq * 4, fq, 0.35, 30, 203)); m.material = 2; m.lodLevels = lv(fq); meshes.push_back(m); }
     const uint32_t nStatics = (uint32_t)meshes.size();
-    // props: sizes drawn from a skewed distribution
+    // props: sizes drawn from a skewed distribution.  The instance count is capped, so a budget beyond sizeScale 4 goes into the props'
+    // tessellation (a power of two per dimension: the LOD levels halve it): the dense workloads put their triangles where the camera looks
+    uint32_t propTess = 1; while (sc.params.sizeScale >= 4.0f * (float)(propTess * propTess)) propTess *= 2u;
     const uint32_t nProps = std::max(1u, nMeshes - nStatics);
     std::vector<uint32_t> propMeshlets(nProps);
     for (uint32_t i = 0; i < nProps; i++) {
@@ -1481,6 +1486,7 @@ void presetStreet(brmi_scene& sc, Pcg32& rng, double triBudget, uint32_t nMeshes
         uint32_t a = (u < 0.55f) ? 1u : (u < 0.85f ? 2u : (u < 0.97f ? 4u : 8u));   // meshlets per dim (nv); nu = 2a
         if (foliage && (i % 3) == 0) a = 1;
         if (maxLevels == 1) a = std::min(a, 4u);
+        a *= propTess;
         MeshDef m;
         uint32_t kind = foliage && (i % 3) == 0 ? 3u : (i % 3);
         uint32_t seed = 400 + i;

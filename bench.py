@@ -25,6 +25,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+WORKLOADS = {"sponza": ("sponza", {}), "bistro": ("bistro", {}), "san_miguel": ("san_miguel", {}), "bistro_dense": ("bistro", dict(size_scale=20.0, detail=96.0))}
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md)
 # profiles/<tag>_traffic.json (tools/profile.sh), keyed by (workload, material feature bits): traffic of another configuration is not this one's
 PROFILE_TAG = {("sponza", 0): "r01_sponza4k", ("bistro", 0): "r01_bistro4k", ("san_miguel", 0): "r01_sanmiguel4k",
@@ -38,7 +39,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="sponza", choices=["sponza", "bistro", "san_miguel"])
+    ap.add_argument("--workload", default="sponza", choices=["sponza", "bistro", "san_miguel", "bistro_dense"],
+                    help="bistro_dense: the Bistro-class street with 20x the triangle budget and fractal relief, so that the 1 px LOD test keeps pixel-sized "
+                         "triangles: > 20 k visible clusters, > 150 k meshlets tested per 4K frame (SURVEY.md 8 a-3's regime)")
     ap.add_argument("--occlusion", type=int, default=1, choices=[0, 1],
                     help="2-phase HZB occlusion culling (reference default: on, BR/include/Renderer.h:220); timed frames are steady state")
     ap.add_argument("--lod-builder", default="quadtree", choices=["quadtree", "own"],
@@ -82,10 +85,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
 
-    lights = {"sponza": 64, "bistro": 256, "san_miguel": 256}[args.workload]
+    lights = {"sponza": 64, "bistro": 256, "san_miguel": 256, "bistro_dense": 256}[args.workload]
+    preset, scene_kw = WORKLOADS[args.workload]
     W, H = compose.frame_size(n)
     band = compose.band_of(rank, n, H)
-    scene = Scene(args.workload, W, H, point_lights=lights, directional=True, lod_builder=args.lod_builder, material_features=args.material_features)
+    scene = Scene(preset, W, H, point_lights=lights, directional=True, lod_builder=args.lod_builder, material_features=args.material_features, **scene_kw)
     r = VisibilityRenderer(scene, device=dev, stats=True, band=band, occlusion=bool(args.occlusion))
 
     hdr = r.hdr_tensor()
@@ -164,7 +168,7 @@ def main():
                                    + (", LOD DAGs from the library's cluster-LOD builder" if args.lod_builder == "own" else "")
                                    + (f", material features {args.material_features} (8 = texture-sampled, 16 = alpha-tested materials)" if args.material_features else "")
                                    + (f", {n} row bands of 1080 rows + RCCL all-gather of HDR ({args.transport}, pipelined one frame deep)" if n > 1 else ""),
-                       "baseline_config": {"sponza": "configs[1]", "bistro": "configs[2]", "san_miguel": "configs[3]"}[args.workload],
+                       "baseline_config": {"sponza": "configs[1]", "bistro": "configs[2]", "san_miguel": "configs[3]", "bistro_dense": "configs[2], dense geometry"}[args.workload],
                        "pixels_per_gpu": W * (band[1] - band[0]), "visible_clusters_rank0": int(c.visibleClusters),
                        "occlusion_culling": bool(args.occlusion), "visible_clusters_phase2_rank0": int(c.visibleClustersPhase2),
                        "meshlets_tested_rank0": int(c.meshletsTested), "partition": f"row bands x{n}" if n > 1 else "single GPU"},

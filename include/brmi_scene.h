@@ -73,8 +73,9 @@ typedef struct brmi_scene_params {
     uint32_t cameraStep;          /* frame number on the preset's camera path (0 = start); prevView is the view of step - 1 */
     uint32_t lodBuilder;          /* enum brmi_lod_builder */
     uint32_t spotLightEvery;      /* k > 0: every k-th punctual light is a spot light (0 = point lights only) */
-    float    detail;              /* geometric detail of the street presets: 0 / 1 = the smooth default surfaces; d > 1 multiplies the relief amplitude by d and
-                                     adds two octaves of it at 4x / 16x the frequency, so that the LOD error test keeps fine clusters (1-4 px triangles at 4K) */
+    float    detail;              /* geometric detail: 0 / 1 = the smooth default surfaces; d > 1 adds seven octaves of relief below the base one, each half the
+                                     wavelength and half the amplitude of the one before (first amplitude (d - 1) / 8 of the base), so that every LOD level keeps an
+                                     error proportional to its edge length and the 1 px error test selects pixel-sized triangles */
     uint32_t reserved[2];
 } brmi_scene_params;
 

@@ -413,7 +413,9 @@ def test_full_size_4k_properties(preset, lights):
                                                   ("bistro", 3840, 2160, 256, dict()),               # configs[2]
                                                   ("san_miguel", 3840, 2160, 256, dict(material_features=24)),    # configs[3] with its alpha-tested materials
                                                   ("sponza", 3840, 2160, 64, dict(material_features=255, spot_every=3)),   # every material feature incl. parallax, at 4K
-                                                  ("zorah", 7680, 4320, 64, dict(skinned_fraction=0.01))])        # configs[4]: 8K, 100 k instances, 1 % skinned
+                                                  ("zorah", 7680, 4320, 64, dict(skinned_fraction=0.01)),         # configs[4]: 8K, 100 k instances, 1 % skinned
+                                                  ("bistro", 3840, 2160, 256, dict(size_scale=20.0, detail=96.0)),   # bench.py --workload bistro_dense: pixel-sized triangles, wide + narrow BVHs (mixed traversal)
+                                                  ("bistro", 3840, 2160, 256, dict(size_scale=3.0, detail=8.0, lod_builder="own"))])   # configs[2] through the library's own cluster-LOD builder
 def test_full_size_frames_against_the_oracle(preset, W, H, lights, kw):
     """BASELINE.json's configurations at their full size, whole frame against the CPU oracle (it renders a 4K frame in well under a
     second per stage on the box's cores): cluster list, visibility keys, depth, every G-buffer plane exact; HDR within one fp16 ULP."""
@@ -440,7 +442,8 @@ def test_full_size_frames_against_the_oracle(preset, W, H, lights, kw):
     r.close()
 
 
-@pytest.mark.parametrize("preset,lights,kw", [("sponza", 64, dict()), ("bistro", 256, dict()), ("san_miguel", 256, dict(material_features=24))])
+@pytest.mark.parametrize("preset,lights,kw", [("sponza", 64, dict()), ("bistro", 256, dict()), ("san_miguel", 256, dict(material_features=24)),
+                                              ("bistro", 256, dict(size_scale=20.0, detail=96.0))])      # the dense workload: 2-phase occlusion over the mixed traversal
 def test_full_size_camera_path_with_occlusion_against_the_oracle(preset, lights, kw):
     """Three 4K frames of the camera path with 2-phase occlusion culling on (the bench default), every frame against the oracle's
     2-phase frame: both phases' cluster lists, keys, depth, G-buffer exact, HDR within one fp16 ULP on covered pixels (pixels without
