@@ -5,11 +5,13 @@ One "step" = one pass of the hot path over one synthetic frame already resident 
 clear -> cull -> software raster -> G-buffer(+depth) -> light clustering -> OpenPBR shade
 (-> RCCL all-gather of the HDR bands when N > 1).
 
-N = 1 : BASELINE.json configs[1], "Sponza 4K, visibility-buffer + clustered resolve, 1 dir + 64
-        point lights" (3840x2160).
+N = 1 : BASELINE.json configs[2], "Bistro 4K, meshlet cull + vis-buffer raster, 256 point lights" (3840x2160) -- the frame the
+        north star's one numeric target is stated on (>= 60 fps).  The same run then measures configs[1] ("Sponza 4K,
+        visibility-buffer + clustered resolve, 1 dir + 64 point lights") and reports it as `configs1` inside the line.
 N > 1 : weak scaling by screen tile: every rank shades one 8.29 Mpixel row band (7680 x 1080) of a
         7680 x (1080*N) frame of the same scene, geometry replicated, then the HDR bands are
-        all-gathered over xGMI so that every rank holds the composed image.
+        all-gathered over xGMI so that every rank holds the composed image.  Without a launcher around it
+        (no WORLD_SIZE) `--gpus N` starts its own N ranks; it never reports a 1-GPU number for an N-GPU request.
 
 Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (largest mean stage time):
 algorithmic bytes of SURVEY.md 8(d) / mean launch duration from HIP events on the execute stream.
@@ -27,9 +29,10 @@ sys.path.insert(0, ROOT)
 
 WORKLOADS = {"sponza": ("sponza", {}), "bistro": ("bistro", {}), "san_miguel": ("san_miguel", {}), "bistro_dense": ("bistro", dict(size_scale=20.0, detail=96.0))}
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md)
+VALU_PEAK_WAVE_INSTS = 1.2288e12   # wave64 VALU instructions per second: 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles (MI355X_MICROARCH.md, cycle constants)
 # profiles/<tag>_traffic.json (tools/profile.sh), keyed by (workload, material feature bits): traffic of another configuration is not this one's
-PROFILE_TAG = {("sponza", 0): "r01_sponza4k", ("bistro", 0): "r01_bistro4k", ("san_miguel", 0): "r01_sanmiguel4k",
-               ("san_miguel", 24): "r01_sanmiguel4k_alpha_tex", ("sponza", 136): "r01_sponza4k_parallax"}
+PROFILE_TAG = {("sponza", 0): "r02_sponza4k", ("bistro", 0): "r02_bistro4k", ("san_miguel", 0): "r02_sanmiguel4k", ("bistro_dense", 0): "r02_bistro4k_dense",
+               ("san_miguel", 24): "r02_sanmiguel4k_alpha_tex", ("sponza", 136): "r02_sponza4k_parallax"}
 DOMINANT_KERNEL = {"raster": "k_raster", "gbuffer": "k_gbuffer", "shade": "k_shade", "cull": "k_traverse+k_cull_clusters", "clear": "k_clear_vis",
                    "light_cluster": "k_light_clustering", "depth_copy": "k_depth_copy", "hzb": "k_hzb_head", "cull2": "k_traverse+k_cull_clusters", "raster2": "k_raster"}
 
@@ -37,11 +40,13 @@ DOMINANT_KERNEL = {"raster": "k_raster", "gbuffer": "k_gbuffer", "shade": "k_sha
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="sponza", choices=["sponza", "bistro", "san_miguel", "bistro_dense"],
-                    help="bistro_dense: the Bistro-class street with 20x the triangle budget and fractal relief, so that the 1 px LOD test keeps pixel-sized "
-                         "triangles: > 20 k visible clusters, > 150 k meshlets tested per 4K frame (SURVEY.md 8 a-3's regime)")
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="bistro", choices=list(WORKLOADS),
+                    help="bistro (default) = BASELINE.json configs[2], the north star's target frame; sponza = configs[1]; san_miguel = configs[3]; "
+                         "bistro_dense: the Bistro-class street with 20x the triangle budget and fractal relief, so that the 1 px LOD test keeps "
+                         "pixel-sized triangles: > 20 k visible clusters, > 150 k meshlets tested per 4K frame (SURVEY.md 8 a-3's regime)")
+    ap.add_argument("--no-second", action="store_true", help="N = 1 only: do not add the configs[1] (Sponza) measurement as `configs1` to the line")
     ap.add_argument("--occlusion", type=int, default=1, choices=[0, 1],
                     help="2-phase HZB occlusion culling (reference default: on, BR/include/Renderer.h:220); timed frames are steady state")
     ap.add_argument("--lod-builder", default="quadtree", choices=["quadtree", "own"],
@@ -64,13 +69,10 @@ def main():
     if world_env is not None and int(world_env) != args.gpus:
         fail_line(args, f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world_env} ranks")
 
-    import numpy as np
     import torch
     import torch.distributed as dist
     if torch.cuda.device_count() < args.gpus:
         fail_line(args, f"--gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible")
-    from basicrenderer_amd import Scene, compose
-    from basicrenderer_amd.renderer import VisibilityRenderer
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -80,20 +82,42 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
-    n = world
-    assert n == args.gpus
+    assert world == args.gpus
     torch.cuda.set_device(local_rank)
-    dev = torch.device(f"cuda:{local_rank}")
 
-    lights = {"sponza": 64, "bistro": 256, "san_miguel": 256, "bistro_dense": 256}[args.workload]
-    preset, scene_kw = WORKLOADS[args.workload]
+    out = measure(args, args.workload, world, rank, local_rank, cpu=(world == 1 and not args.no_cpu_baseline))
+    if world == 1 and not args.no_second and args.workload != "sponza":
+        # the metric string's own wording ("vis-buffer+resolve") is configs[1]: measured by the same run, reported beside the target frame
+        second = measure(args, "sponza", world, rank, local_rank, cpu=False)
+        if out is not None:
+            out["configs1"] = {k: second[k] for k in ("value", "unit", "ms_per_step", "config", "roofline", "stage_ms")}
+    result_line = json.dumps(out) if out is not None else None
+    if world > 1 or args.force_compose:
+        # RCCL writes a version banner to the C stdout buffer; pushed out here, on every rank, so that rank 0's JSON is the last line
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        dist.barrier()                       # every rank has flushed before rank 0 prints
+        dist.destroy_process_group()
+        ctypes.CDLL(None).fflush(None)
+    if result_line is not None:
+        print(result_line, flush=True)
+
+
+def measure(args, workload, n, rank, local_rank, cpu):
+    """K timed steps of one workload on this rank's GPU (all ranks call it together); rank 0 returns the result object."""
+    import torch
+    import torch.distributed as dist
+    from basicrenderer_amd import Scene, compose
+    from basicrenderer_amd.renderer import VisibilityRenderer
+    dev = torch.device(f"cuda:{local_rank}")
+    lights = {"sponza": 64, "bistro": 256, "san_miguel": 256, "bistro_dense": 256}[workload]
+    preset, scene_kw = WORKLOADS[workload]
     W, H = compose.frame_size(n)
     band = compose.band_of(rank, n, H)
     scene = Scene(preset, W, H, point_lights=lights, directional=True, lod_builder=args.lod_builder, material_features=args.material_features, **scene_kw)
     r = VisibilityRenderer(scene, device=dev, stats=True, band=band, occlusion=bool(args.occlusion))
 
     hdr = r.hdr_tensor()
-    lo, hi = compose.band_byte_range(band, W, 8)
     # all-gather of frame k overlaps the rendering of frame k + 1; the colour channels travel (RGB16F, 6 B/px): the lit target's alpha is constant
     composer = compose.BandComposer(hdr, band, W, 8, transport=args.transport) if (n > 1 or args.force_compose) else None
 
@@ -132,12 +156,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
-    stage_ms = r.stage_times()          # mean over the timed steps (HIP events on the execute stream); dominant stage only
+    stage_ms = r.stage_times()          # mean over the last timed steps (HIP events on the execute stream); dominant stage only
     if warm_ms:
         stage_ms = {k: (stage_ms[k] if k == dom_stage else warm_ms[k]) for k in warm_ms}
     per_stage_bytes, total_bytes = r.algorithmic_bytes()
     c = r.counters()
-
+    out = None
     if rank == 0:
         shaded = W * (band[1] - band[0]) * n            # pixels dispatched per step, all ranks
         ms_per_step = dt / args.steps * 1e3
@@ -146,54 +170,52 @@ def main():
         dom_s = stage_ms[dom] * 1e-3
         achieved = per_stage_bytes[dom] / dom_s / 1e9 if dom_s > 0 else 0.0
         frame_gbs = total_bytes / (dt / args.steps) / 1e9
-        # HBM-side bytes of the dominant kernel per launch, from the committed rocprofv3 --pmc passes of this same command
-        # (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE; tools/profile.sh).  null when no profile of this workload / kernel is committed.
-        traffic = None
+        # From the committed rocprofv3 passes of this same command (tools/profile.sh): HBM-side bytes of the dominant kernel per launch
+        # (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE) and its VALU instruction count (SQ_INSTS_VALU).  null when no profile of this
+        # workload / kernel is committed.
+        traffic, valu = None, None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", PROFILE_TAG.get((args.workload, args.material_features), "none") + "_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", PROFILE_TAG.get((workload, args.material_features), "none") + "_traffic.json")))
             # the stage's dominant kernel; template instantiations ("k_shade<0>", "k_raster<true>") are matched by base name and the
             # one that takes the most time per launch is used
             base = DOMINANT_KERNEL.get(dom, dom).split("<")[0]
             cands = [k for k in tj if k.split("<")[0] == base]
             if n == 1 and cands:
-                traffic = tj[max(cands, key=lambda k: tj[k].get("avg_us", 0.0))]["hbm_bytes_per_launch"]
-        except (OSError, ValueError):
+                rec = tj[max(cands, key=lambda k: tj[k].get("avg_us", 0.0))]
+                traffic = rec["hbm_bytes_per_launch"]
+                if rec.get("valu_wave_insts_per_launch"):
+                    wi = rec["valu_wave_insts_per_launch"]
+                    # the microarchitecture guide's issue peak: one wave64 VALU instruction per 2 cycles per SIMD, 1024 SIMDs, 2.4 GHz
+                    valu = {"wave_insts": int(wi), "insts_per_px": round(wi * 64.0 / (W * (band[1] - band[0])), 1), "peak_wave_insts_per_s": VALU_PEAK_WAVE_INSTS,
+                            "frac": round(wi / dom_s / VALU_PEAK_WAVE_INSTS, 5), "source": "SQ_INSTS_VALU of the committed profile / this run's launch time"}
+        except (OSError, ValueError, KeyError):
             pass
+        hbm_frac = achieved / HBM_PEAK_GBS
         out = {
             "metric": "shaded Mpixels/s @4K (vis-buffer+resolve)", "value": round(value, 2), "unit": "Mpixels/s",
             "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}-class procedural frame, {W}x{H}, 1 directional + {lights} point lights, "
+            "config": {"workload": f"{workload}-class procedural frame, {W}x{H}, 1 directional + {lights} point lights, "
                                    f"{scene.stats['instancedTriangles']} instanced tris, {scene.stats['instances']} instances"
                                    + (", LOD DAGs from the library's cluster-LOD builder" if args.lod_builder == "own" else "")
                                    + (f", material features {args.material_features} (8 = texture-sampled, 16 = alpha-tested materials)" if args.material_features else "")
                                    + (f", {n} row bands of 1080 rows + RCCL all-gather of HDR ({args.transport}, pipelined one frame deep)" if n > 1 else ""),
-                       "baseline_config": {"sponza": "configs[1]", "bistro": "configs[2]", "san_miguel": "configs[3]", "bistro_dense": "configs[2], dense geometry"}[args.workload],
+                       "baseline_config": {"sponza": "configs[1]", "bistro": "configs[2]", "san_miguel": "configs[3]", "bistro_dense": "configs[2], dense geometry"}[workload],
+                       "fps": round(1e3 / ms_per_step, 1),
                        "pixels_per_gpu": W * (band[1] - band[0]), "visible_clusters_rank0": int(c.visibleClusters),
                        "occlusion_culling": bool(args.occlusion), "visible_clusters_phase2_rank0": int(c.visibleClustersPhase2),
                        "meshlets_tested_rank0": int(c.meshletsTested), "partition": f"row bands x{n}" if n > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": DOMINANT_KERNEL.get(dom, dom), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+            "roofline": {"bound": "valu" if (valu and valu["frac"] > hbm_frac) else "hbm", "kernel": DOMINANT_KERNEL.get(dom, dom), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(hbm_frac, 5), "traffic": traffic, "valu": valu,
                          "algorithmic_bytes_per_launch": int(per_stage_bytes[dom]), "launch_ms": round(stage_ms[dom], 4),
                          "whole_frame": {"algorithmic_bytes": int(total_bytes), "achieved_GBps": round(frame_gbs, 2), "frac": round(frame_gbs / HBM_PEAK_GBS, 5)}},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items() if v > 0},
             "stage_ms_note": f"'{dom}' from HIP events inside the timed region; the other stages from 10 untimed frames before it",
         }
-        if n == 1 and not args.no_cpu_baseline:
+        if cpu:
             out["cpu_baseline"] = cpu_baseline(scene, args.cpu_scale)
-        result_line = json.dumps(out)
-    else:
-        result_line = None
     r.close()
-    if world > 1 or args.force_compose:
-        # RCCL writes a version banner to the C stdout buffer; pushed out here, on every rank, so that rank 0's JSON is the last line
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
-        dist.barrier()                       # every rank has flushed before rank 0 prints
-        dist.destroy_process_group()
-        ctypes.CDLL(None).fflush(None)
-    if result_line is not None:
-        print(result_line, flush=True)
+    return out
 
 
 def fail_line(args, why):

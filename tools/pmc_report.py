@@ -42,6 +42,7 @@ for k in sorted(sq, key=lambda k: -float(st.get(k, {"TotalDurationNs": 0})["Tota
     print(f"{name[:44]:44s} {avg:8.1f} {st.get(k, {}).get('Calls', '?'):>6s} {s['SQ_WAVES'] / c:7.0f} {s['SQ_INSTS_VALU'] / max(s['SQ_WAVES'], 1):9.0f} "
           f"{100 * s['SQ_ACTIVE_INST_VALU'] / wc:6.1f} {100 * s['SQ_WAIT_ANY'] / wc:6.1f} {100 * s['SQ_WAIT_INST_ANY'] / wc:6.1f} {fetch_kib / 1024:13.2f} {write_kib / 1024:9.2f}")
     traffic[name] = {"avg_us": round(avg, 2), "fetch_size_kib_raw": round(fetch_kib, 1), "write_size_kib": round(write_kib, 1),
-                     "hbm_bytes_per_launch": int(2 * fetch_kib * 1024 + write_kib * 1024)}
+                     "hbm_bytes_per_launch": int(2 * fetch_kib * 1024 + write_kib * 1024),
+                     "valu_wave_insts_per_launch": int(s["SQ_INSTS_VALU"] / max(c, 1)), "waves_per_launch": int(s["SQ_WAVES"] / max(c, 1))}
 if traffic_out:
     json.dump(traffic, open(traffic_out, "w"), indent=1, sort_keys=True)
