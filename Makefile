@@ -1,6 +1,7 @@
 # Build everything in-tree.  `make` = scene generator + oracle (CPU) + HIP library (gfx950).
 #   libbrmi.so        HIP kernels + C ABI (include/brmi.h)           -> basicrenderer_amd/lib/
 #   libbrmi_scene.so  procedural scene generator (host only)          -> basicrenderer_amd/lib/
+#   libbrmi_compose.so  RCCL composition of the row-band partition (include/brmi_compose.h) -> basicrenderer_amd/lib/
 #   liboracle.so      scalar CPU restatement of the reference shaders -> oracle/_build/   (tests only)
 ROCM      ?= /opt/rocm
 HIPCC     ?= $(ROCM)/bin/hipcc
@@ -20,11 +21,12 @@ HIP_HDRS  := $(wildcard basicrenderer_amd/csrc/*.h) $(wildcard include/*.h)
 ORC_SRCS  := $(wildcard oracle/*.cpp)
 ORC_HDRS  := $(wildcard oracle/*.h) $(wildcard include/*.h)
 
-all: scene oracle hip host_example
+all: scene oracle hip compose host_example
 
 scene: $(LIBDIR)/libbrmi_scene.so
 oracle: $(ORCDIR)/liboracle.so
 hip: $(LIBDIR)/libbrmi.so
+compose: $(LIBDIR)/libbrmi_compose.so
 
 SCN_SRCS  := basicrenderer_amd/csrc/scene/scene_gen.cpp basicrenderer_amd/csrc/scene/lod_builder.cpp
 $(LIBDIR)/libbrmi_scene.so: $(SCN_SRCS) include/brmi_scene.h include/brmi_types.h
@@ -39,6 +41,11 @@ $(LIBDIR)/libbrmi.so: $(HIP_SRCS) $(HIP_HDRS)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) $(HIP_SRCS) -o $@
 
+# multi-GPU composition: the only library that links RCCL (include/brmi_compose.h)
+$(LIBDIR)/libbrmi_compose.so: basicrenderer_amd/csrc/compose/brmi_compose.hip include/brmi_compose.h
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(EXTRA) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Iinclude -I$(ROCM)/include -Wall $< -L$(ROCM)/lib -lrccl -o $@
+
 # C++ host driving the passes through basicrenderer_amd/host/brmi_passes.hpp (links both libraries)
 host_example: $(LIBDIR)/brmi_host_frame
 $(LIBDIR)/brmi_host_frame: examples/host_frame.cpp basicrenderer_amd/host/brmi_passes.hpp $(LIBDIR)/libbrmi.so $(LIBDIR)/libbrmi_scene.so
@@ -47,4 +54,4 @@ $(LIBDIR)/brmi_host_frame: examples/host_frame.cpp basicrenderer_amd/host/brmi_p
 clean:
 	rm -rf $(LIBDIR) $(ORCDIR)
 
-.PHONY: all scene oracle hip host_example clean
+.PHONY: all scene oracle hip compose host_example clean

@@ -113,6 +113,48 @@ class Counters(C.Structure):
                                    "lightPagesUsed replayNodes replayMeshlets").split()] + [("reserved", u32 * 6)]
 
 
+class ComposeConfig(C.Structure):
+    """brmi_compose_config (include/brmi_compose.h)."""
+    _fields_ = [("structSize", u32), ("width", u32), ("bandY0", u32), ("bandY1", u32), ("bytesPerPixel", u32), ("transport", u32), ("depth", u32),
+                ("rank", u32), ("nRanks", u32), ("device", C.c_int32), ("reserved", u32 * 6)]
+
+
+COMPOSE_EXPORTS = ["brmi_compose_unique_id", "brmi_compose_create", "brmi_compose_staging_bytes", "brmi_compose_output_bytes", "brmi_compose_bind",
+                   "brmi_compose_submit", "brmi_compose_finish", "brmi_compose_destroy", "brmi_compose_last_error"]
+_compose_lib = None
+
+
+def compose_lib():
+    """libbrmi_compose.so: RCCL composition of the row-band partition behind a C ABI.  torch is imported first so that its RCCL / HIP
+    runtime (same SONAMEs) are the ones the process uses."""
+    global _compose_lib
+    if _compose_lib is None:
+        import torch  # noqa: F401
+        path = os.path.join(LIB_DIR, "libbrmi_compose.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run `make compose` (or __graft_entry__.build())")
+        try:      # torch ships librccl.so without the .1 suffix: map it under its SONAME before the library asks for it
+            C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+        lib = C.CDLL(path)
+        lib.brmi_compose_unique_id.argtypes = [vp]
+        lib.brmi_compose_create.argtypes = [C.POINTER(ComposeConfig), C.c_char_p, C.POINTER(vp)]
+        lib.brmi_compose_staging_bytes.argtypes = [vp]
+        lib.brmi_compose_staging_bytes.restype = u64
+        lib.brmi_compose_output_bytes.argtypes = [vp]
+        lib.brmi_compose_output_bytes.restype = u64
+        lib.brmi_compose_bind.argtypes = [vp, vp, u64, vp, u64]
+        lib.brmi_compose_submit.argtypes = [vp, vp, vp]
+        lib.brmi_compose_finish.argtypes = [vp, vp, C.POINTER(vp)]
+        lib.brmi_compose_destroy.argtypes = [vp]
+        lib.brmi_compose_destroy.restype = None
+        lib.brmi_compose_last_error.argtypes = [vp]
+        lib.brmi_compose_last_error.restype = C.c_char_p
+        _compose_lib = lib
+    return _compose_lib
+
+
 DECLARE_CB = C.CFUNCTYPE(None, vp, C.POINTER(ResourceDesc))
 
 RES_NAMES = ["VISIBILITY", "LINEAR_DEPTH", "GBUF_NORMALS", "GBUF_ALBEDO", "GBUF_COAT", "GBUF_EMISSIVE", "GBUF_FUZZ",

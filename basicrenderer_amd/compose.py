@@ -102,3 +102,76 @@ class BandComposer:
                 w.wait()
         self.work = [None] * self.depth
         return self.out[(self.frames - 1) % self.depth] if self.frames else None
+
+
+class NativeBandComposer:
+    """BandComposer's pipeline behind the C ABI of libbrmi_compose.so (include/brmi_compose.h): the staging copy, the RCCL all-gather on
+    the composer's own stream and the event ordering all live in C++; this class only owns the buffers (the library allocates nothing)
+    and hands the ncclUniqueId from rank 0 to the others over torch.distributed.  `out[i]` / finish() as BandComposer."""
+
+    def __init__(self, surface_u8, band, width, bytes_per_pixel, depth=2, group=None, transport="surface", rank=None, world=None):
+        import ctypes as C
+        import torch
+        import torch.distributed as dist
+        from . import capi
+        self.torch, self.C, self.lib = torch, C, capi.compose_lib()
+        dev = surface_u8.device
+        rank = dist.get_rank(group) if rank is None else rank
+        world = dist.get_world_size(group) if world is None else world
+        ident = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            buf = (C.c_uint8 * 128)()
+            if self.lib.brmi_compose_unique_id(buf) != 0:
+                raise RuntimeError("brmi_compose_unique_id failed")
+            ident = torch.tensor(list(buf), dtype=torch.uint8)
+        if world > 1:
+            ident = ident.to(dev) if dist.get_backend(group) == "nccl" else ident
+            dist.broadcast(ident, src=0, group=group)
+        ident = bytes(ident.cpu().tolist())
+        cfg = capi.ComposeConfig()
+        cfg.structSize = C.sizeof(capi.ComposeConfig)
+        cfg.width, cfg.bandY0, cfg.bandY1, cfg.bytesPerPixel = width, band[0], band[1], bytes_per_pixel
+        cfg.transport = {"surface": 0, "rgb16f": 1}[transport]
+        cfg.depth, cfg.rank, cfg.nRanks, cfg.device = depth, rank, world, dev.index or 0
+        self._h = capi.vp()
+        rc = self.lib.brmi_compose_create(C.byref(cfg), ident, C.byref(self._h))
+        if rc != 0:
+            msg = self.lib.brmi_compose_last_error(self._h).decode() if self._h else ""
+            raise RuntimeError(f"brmi_compose_create failed ({rc}): {msg}")
+        sb, ob = self.lib.brmi_compose_staging_bytes(self._h), self.lib.brmi_compose_output_bytes(self._h)
+        self.stage = torch.empty(sb * depth, dtype=torch.uint8, device=dev)
+        self.outbuf = torch.empty(ob * depth, dtype=torch.uint8, device=dev)
+        self._check(self.lib.brmi_compose_bind(self._h, self.stage.data_ptr(), self.stage.numel(), self.outbuf.data_ptr(), self.outbuf.numel()), "brmi_compose_bind")
+        view = (lambda t: t.view(torch.int16).view(-1, 3)) if transport == "rgb16f" else (lambda t: t)
+        self.out = [view(self.outbuf[i * ob:(i + 1) * ob]) for i in range(depth)]
+        self.surface, self.depth, self.frames, self.dev = surface_u8, depth, 0, dev
+
+    def _check(self, rc, what):
+        if rc < 0:
+            raise RuntimeError(f"{what} failed ({rc}): {self.lib.brmi_compose_last_error(self._h).decode()}")
+        return rc
+
+    def _stream(self):
+        return self.C.c_void_p(self.torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def submit(self):
+        slot = self._check(self.lib.brmi_compose_submit(self._h, self.surface.data_ptr(), self._stream()), "brmi_compose_submit")
+        self.frames += 1
+        return slot
+
+    def finish(self):
+        ptr = self.C.c_void_p()
+        self._check(self.lib.brmi_compose_finish(self._h, self._stream(), self.C.byref(ptr)), "brmi_compose_finish")
+        return self.out[(self.frames - 1) % self.depth] if self.frames else None
+
+    def close(self):
+        if self._h:
+            self.torch.cuda.synchronize(self.dev)
+            self.lib.brmi_compose_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -55,6 +55,8 @@ def main():
                     help="scene generator feature bits (brmi_scene.h): 1 coat, 2 fuzz, 4 mirrored instances, 8 texture-sampled materials, 16 alpha-tested materials, 32 vertex colours, 64 OpenPBR layer textures, 128 parallax; 0 = BASELINE.json's constant-factor configuration")
     ap.add_argument("--transport", default="rgb16f", choices=["rgb16f", "surface"],
                     help="what the band composition gathers: the colour channels as RGB16F (default; the composed image has no alpha plane) or the RGBA16F surface bytes")
+    ap.add_argument("--composer", default="native", choices=["native", "torch"],
+                    help="who runs the all-gather: libbrmi_compose.so (RCCL called from C++ behind include/brmi_compose.h; default) or torch.distributed")
     ap.add_argument("--force-compose", action="store_true", help="run the RCCL band composition even with one rank (checks the collective path on a single GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scale", type=float, default=1.0, help="fraction of the frame height the CPU baseline renders")
@@ -119,7 +121,10 @@ def measure(args, workload, n, rank, local_rank, cpu):
 
     hdr = r.hdr_tensor()
     # all-gather of frame k overlaps the rendering of frame k + 1; the colour channels travel (RGB16F, 6 B/px): the lit target's alpha is constant
-    composer = compose.BandComposer(hdr, band, W, 8, transport=args.transport) if (n > 1 or args.force_compose) else None
+    composer = None
+    if n > 1 or args.force_compose:
+        cls = compose.NativeBandComposer if args.composer == "native" else compose.BandComposer
+        composer = cls(hdr, band, W, 8, transport=args.transport)
 
     def step():
         r.update()                      # the per-frame Update phase (camera / per-frame constants), as the reference's passes run it every frame
@@ -199,7 +204,7 @@ def measure(args, workload, n, rank, local_rank, cpu):
                                    f"{scene.stats['instancedTriangles']} instanced tris, {scene.stats['instances']} instances"
                                    + (", LOD DAGs from the library's cluster-LOD builder" if args.lod_builder == "own" else "")
                                    + (f", material features {args.material_features} (8 = texture-sampled, 16 = alpha-tested materials)" if args.material_features else "")
-                                   + (f", {n} row bands of 1080 rows + RCCL all-gather of HDR ({args.transport}, pipelined one frame deep)" if n > 1 else ""),
+                                   + (f", {n} row bands of 1080 rows + RCCL all-gather of HDR ({args.transport}, pipelined one frame deep, {'libbrmi_compose.so' if args.composer == 'native' else 'torch.distributed'})" if composer else ""),
                        "baseline_config": {"sponza": "configs[1]", "bistro": "configs[2]", "san_miguel": "configs[3]", "bistro_dense": "configs[2], dense geometry"}[workload],
                        "fps": round(1e3 / ms_per_step, 1),
                        "pixels_per_gpu": W * (band[1] - band[0]), "visible_clusters_rank0": int(c.visibleClusters),

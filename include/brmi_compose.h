@@ -1,0 +1,64 @@
+/*
+ * brmi_compose.h -- C ABI of libbrmi_compose.so: composition of the screen-tile partition over the GPUs of one node.
+ *
+ * SURVEY.md section 8(e) / BASELINE.json north_star: the frame is split into row bands, every GPU renders its band with libbrmi.so and the
+ * lit HDR bands are composed with ONE RCCL all-gather over xGMI so that every rank holds the whole image.  The reference has no
+ * multi-GPU path; the interface follows the pass interface of include/brmi.h (a stream in place of the command list, caller-owned
+ * device memory, status codes + last-error string).  This library is the only place that links RCCL; libbrmi.so does not.
+ *
+ * Pipelining: submit() copies the band out of the lit target (which the next frame overwrites) into one of `depth` staging
+ * buffers on the render stream and starts the all-gather on the composer's own stream; the collective of frame k overlaps the
+ * rendering of frame k + 1.  A staging / output buffer is reused only after its collective has finished (stream-ordered, no host
+ * synchronisation).  finish() makes a stream wait for everything in flight and names the newest composed image.
+ */
+#ifndef BRMI_COMPOSE_H
+#define BRMI_COMPOSE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BRMI_COMPOSE_ID_BYTES 128u          /* sizeof(ncclUniqueId) */
+
+typedef enum brmi_compose_transport {
+    BRMI_TRANSPORT_SURFACE = 0,             /* the band's bytes as they are in the tiled surface */
+    BRMI_TRANSPORT_RGB16F  = 1              /* RGBA16F surface only: the three colour channels, 6 B per pixel (the lit target's alpha is the constant 1) */
+} brmi_compose_transport;
+
+typedef struct brmi_compose_config {
+    uint32_t structSize;                    /* sizeof(brmi_compose_config) */
+    uint32_t width;                         /* frame width in pixels (the tiled surface is ceil(width / 8) tiles wide) */
+    uint32_t bandY0, bandY1;                /* rows this rank owns; multiples of 8, the same height on every rank */
+    uint32_t bytesPerPixel;                 /* of the surface (8 for the RGBA16F lit target) */
+    uint32_t transport;                     /* brmi_compose_transport */
+    uint32_t depth;                         /* staging / output buffers in flight (>= 1; 2 overlaps one frame) */
+    uint32_t rank, nRanks;
+    int32_t  device;                        /* HIP device of this rank */
+    uint32_t reserved[6];
+} brmi_compose_config;
+
+typedef struct brmi_composer brmi_composer;
+typedef void* brmi_compose_stream;          /* hipStream_t */
+
+/* Rank 0 creates the id; the host hands the bytes to every rank over any channel it has (MPI, a socket, torch.distributed). */
+int brmi_compose_unique_id(uint8_t id[BRMI_COMPOSE_ID_BYTES]);
+/* Collective: every rank calls it with the same id (ncclCommInitRank). */
+int brmi_compose_create(const brmi_compose_config* cfg, const uint8_t id[BRMI_COMPOSE_ID_BYTES], brmi_composer** out);
+/* Bytes of ONE staging buffer (this rank's band in transport form) and of ONE output buffer (all bands); the caller binds
+ * `depth` of each, contiguous. */
+uint64_t brmi_compose_staging_bytes(const brmi_composer* c);
+uint64_t brmi_compose_output_bytes(const brmi_composer* c);
+int brmi_compose_bind(brmi_composer* c, void* staging, uint64_t stagingBytes, void* output, uint64_t outputBytes);
+/* `surface`: base of the tiled surface (the whole frame's allocation).  Returns the buffer slot used (>= 0) or a negative status. */
+int brmi_compose_submit(brmi_composer* c, const void* surface, brmi_compose_stream renderStream);
+/* `stream` waits for every collective in flight; *composed = the output buffer of the newest frame (NULL before the first submit). */
+int brmi_compose_finish(brmi_composer* c, brmi_compose_stream stream, void** composed);
+void brmi_compose_destroy(brmi_composer* c);
+const char* brmi_compose_last_error(const brmi_composer* c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BRMI_COMPOSE_H */

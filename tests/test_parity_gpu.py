@@ -479,8 +479,10 @@ def test_full_size_camera_path_with_occlusion_against_the_oracle(preset, lights,
     r.close()
 
 
-@pytest.mark.parametrize("preset,lights,n", [("sponza", 64, 2), ("bistro", 256, 4)])
-def test_full_size_band_split_against_the_oracle(preset, lights, n):
+@pytest.mark.parametrize("preset,lights,n,kw", [("sponza", 64, 2, dict()), ("bistro", 256, 4, dict()),
+                                                ("bistro", 256, 8, dict()),                                  # the 8-GPU partition: 7680 x 8640, eight bands
+                                                ("san_miguel", 256, 8, dict(material_features=24))])         # BASELINE.json configs[3] with its alpha-tested materials
+def test_full_size_band_split_against_the_oracle(preset, lights, n, kw):
     """The multi-GPU bench's partition at its real size on one GPU: the 7680 x (1080 n) frame rendered band by band (occlusion
     culling on, two frames each) equals the oracle's full frame on every band: triangle identities, depth, lit bytes."""
     import orc
@@ -488,7 +490,7 @@ def test_full_size_band_split_against_the_oracle(preset, lights, n):
     from conftest import Scene
     from basicrenderer_amd.renderer import VisibilityRenderer
     W, H = compose.frame_size(n)
-    sc = Scene(preset, W, H, point_lights=lights)
+    sc = Scene(preset, W, H, point_lights=lights, **kw)
     o = orc.OracleFrame(sc).run()
     fa, fb, fd = orc.canonical_ids(o.vis, o.clusters[: o.count])
     oh = o.hdr.view(np.uint16).astype(np.int32).reshape(H, W, 4)
@@ -504,6 +506,40 @@ def test_full_size_band_split_against_the_oracle(preset, lights, n):
         gh = r.hdr().view(np.uint16).astype(np.int32).reshape(H, W, 4)
         assert np.abs(gh[y0:y1][covered] - oh[y0:y1][covered]).max() <= 1, f"rank {rank}"
         r.close()
+
+
+@pytest.mark.parametrize("transport", ["surface", "rgb16f"])
+def test_native_composer_gathers_the_band_bytes(transport, scenes):
+    """libbrmi_compose.so (RCCL called from C++, include/brmi_compose.h) with one rank: three pipelined submits of a row band of the lit
+    target, two buffers in flight; the composed image is the band's bytes (RGB16F transport: its three colour channels), and a frame
+    submitted after the target changed composes the new bytes (the staging copy is ordered behind the rendering stream)."""
+    import torch
+    from basicrenderer_amd import compose
+    from basicrenderer_amd.renderer import VisibilityRenderer
+    sc = scenes("sponza_small")
+    r = VisibilityRenderer(sc, stats=True)
+    r.execute()
+    hdr = r.hdr_tensor()
+    band = (120, 240)
+    comp = compose.NativeBandComposer(hdr, band, sc.width, 8, depth=2, transport=transport, rank=0, world=1)
+    lo, hi = compose.band_byte_range(band, sc.width, 8)
+
+    def expect():
+        b = hdr[lo:hi].clone()
+        return compose.rgb_of(b).contiguous() if transport == "rgb16f" else b
+
+    for k in range(3):
+        comp.submit()
+    out = comp.finish()
+    torch.cuda.synchronize()
+    assert torch.equal(out.reshape(-1), expect().reshape(-1))
+    hdr[lo:hi] = torch.randint(0, 255, (hi - lo,), dtype=torch.uint8, device=hdr.device)      # "the next frame"
+    comp.submit()
+    out = comp.finish()
+    torch.cuda.synchronize()
+    assert torch.equal(out.reshape(-1), expect().reshape(-1))
+    comp.close()
+    r.close()
 
 
 def test_cpp_host_passes_reproduce_the_python_frame(scenes):
