@@ -197,6 +197,7 @@ int brmi_create(const brmi_config* cfg, brmi_pass** out) {
     if (!cfg || !out || cfg->structSize != sizeof(brmi_config) || cfg->width == 0 || cfg->height == 0) return BRMI_ERR_INVALID;
     if (cfg->maxVisibleClusters == 0 || cfg->maxVisibleClusters > (1u << 26) || cfg->maxTraversalRecords == 0) return BRMI_ERR_INVALID;
     if (cfg->lightClusterSize[0] == 0 || cfg->lightClusterSize[1] == 0 || cfg->lightClusterSize[2] == 0) return BRMI_ERR_INVALID;
+    if (cfg->lightClusterSize[2] > 62u) return BRMI_ERR_INVALID;      // the slice-start table (workspace and the shading pass's LDS copy) holds 64 entries: gz + 2
     brmi_pass* p = new brmi_pass();
     p->cfg = *cfg;
     p->totalWords = 1; p->scanBlocks = 1;
@@ -517,6 +518,7 @@ int brmi_shade(brmi_pass* p, brmi_stream stream) {
 int brmi_execute(brmi_pass* p, brmi_stream stream) {
     CHECK_READY(p);
     int rc;
+    p->executesSinceTimes++;
     p->fuseFrameClear = true;
     rc = brmi_clear_visibility(p, stream);
     p->fuseFrameClear = false;
@@ -570,10 +572,13 @@ int brmi_set_timed_stages(brmi_pass* p, uint32_t stageMask) {
 int brmi_stage_times(brmi_pass* p, float* ms) {
     if (!p || !ms) return BRMI_ERR_INVALID;
     if (!p->eventsCreated) return brmi::fail(p, BRMI_ERR_STATE, "brmi_stage_times: collectPassStatistics is off");
-    // mean over the recordings since the previous call (at most the last kEventRing), then reset
+    // mean PER FRAME over the recordings since the previous call (at most the last kEventRing), then reset.  brmi_execute records the
+    // depth-chain stage twice per frame (before phase 2 and after the G-buffer pass): its two recordings are one frame's cost.
     for (int i = 0; i < BRMI_STAGE_COUNT; i++) {
         ms[i] = 0.0f;
-        const uint32_t n = std::min(p->evCount[i], brmi_pass::kEventRing);
+        const uint32_t perFrame = (i == BRMI_STAGE_HZB && p->executesSinceTimes != 0u && p->evCount[i] == 2u * p->executesSinceTimes) ? 2u : 1u;
+        uint32_t n = std::min(p->evCount[i], brmi_pass::kEventRing);
+        n -= n % perFrame;
         if (n == 0) continue;
         double sum = 0.0;
         for (uint32_t k = 0; k < n; k++) {
@@ -583,15 +588,18 @@ int brmi_stage_times(brmi_pass* p, float* ms) {
             BRMI_HIP(p, hipEventElapsedTime(&t, p->evStart[i][slot], p->evStop[i][slot]));
             sum += t;
         }
-        ms[i] = (float)(sum / n);
+        ms[i] = (float)(sum / (n / perFrame));
         p->evCount[i] = 0;
     }
+    p->executesSinceTimes = 0;
     return BRMI_OK;
 }
 
 // bytes_frame = 140*P + sum_clusters(144 + 12V + 3T) + 64*M_tested + 16*M_visible + 64*N_nodes
 int brmi_algorithmic_bytes(brmi_pass* p, uint64_t* perStage, uint64_t* total) {
     if (!p || !perStage || !total) return BRMI_ERR_INVALID;
+    // a read-back call: waits for whatever stream the frame was executed on (a non-blocking stream does not order with the NULL stream)
+    BRMI_HIP(p, hipDeviceSynchronize());
     brmi_counters c; int rc = brmi_read_counters(p, &c, nullptr); if (rc) return rc;
     const uint64_t P = (uint64_t)p->cfg.width * (p->bandY1 - p->bandY0);
     const uint64_t sumV = ((uint64_t)c.reserved[1] << 32) | c.reserved[0], sumT = ((uint64_t)c.reserved[3] << 32) | c.reserved[2], nClusters = c.reserved[4];

@@ -840,7 +840,11 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
     uint32_t f = p->cfg.phase2ExpansionFactor; f = f < 1 ? 1 : (f > 64 ? 64 : f);
     { uint32_t n = 1; for (uint32_t c = 2; c <= 64; c <<= 1) if (c <= f) n = c; f = n; }
     a.factor = f; a.phase = phase;
-    a.bandActive = (p->bandY0 != 0 || p->bandY1 != p->cfg.height) ? 1u : 0u;
+    // the band test's two planes through the eye only bound a row band under a symmetric perspective projection: an orthographic or
+    // off-centre camera keeps the frustum test alone (the rasteriser's row filter still confines the band; nothing is lost but the early cull)
+    const bool symmetricPerspective = p->camHost.isOrtho == 0 && p->camHost.projection[2][0] == 0.0f && p->camHost.projection[2][1] == 0.0f &&
+                                      p->camHost.projection[3][0] == 0.0f && p->camHost.projection[3][1] == 0.0f;
+    a.bandActive = ((p->bandY0 != 0 || p->bandY1 != p->cfg.height) && symmetricPerspective) ? 1u : 0u;
     for (int k = 0; k < 3; k++) { a.bandTop[k] = p->bandPlaneTop[k]; a.bandBottom[k] = p->bandPlaneBottom[k]; }
     a.occlusion = (p->cfg.enableOcclusionCulling && p->hzbValid && p->camHost.isOrtho == 0) ? 1u : 0u;
     a.replayNodes = p->wsPtr<NodeRecord>(p->ws.replayNodes); a.replayBuckets = p->wsPtr<BucketRecord>(p->ws.replayBuckets);

@@ -142,6 +142,7 @@ struct brmi_pass {
     static constexpr uint32_t kEventRing = 32;     // per-stage event pairs of the last kEventRing frames
     hipEvent_t evStart[BRMI_STAGE_COUNT][kEventRing] = {}, evStop[BRMI_STAGE_COUNT][kEventRing] = {};
     uint32_t evCount[BRMI_STAGE_COUNT] = {};       // recordings since the last brmi_stage_times()
+    uint32_t executesSinceTimes = 0;               // brmi_execute calls since then (a stage recorded twice per frame reports its per-frame cost)
     uint32_t updateSerial = 1, constantsSerial = 0;  // brmi_update / brmi_set_scene bump updateSerial; the frame constants follow
     uint32_t shadeSerial = 0;                        // parity selects the deferred-pixel counter of a shading call
     bool eventsCreated = false;

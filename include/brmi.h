@@ -191,13 +191,15 @@ int brmi_shade(brmi_pass* pass, brmi_stream stream);              /* DeferredSha
 
 /* ---- introspection ------------------------------------------------------------------------- */
 int brmi_read_counters(brmi_pass* pass, brmi_counters* out, brmi_stream stream);   /* synchronises */
-/* mean milliseconds per stage over the frames executed since the previous call (at most the last 32;
+/* mean milliseconds per stage AND FRAME over the frames executed since the previous call (at most the last 32; the depth-chain stage, which
+ * brmi_execute runs twice per frame, reports the sum of its two builds;
  * HIP events on the execute stream, collectPassStatistics); synchronises and resets the window */
 int brmi_stage_times(brmi_pass* pass, float* msOut /* [BRMI_STAGE_COUNT] */);
 /* Restricts the event pairs to the stages whose bit (1 << brmi_stage) is set; every event pair is a barrier on the stream,
  * so a benchmark times all stages once and then only the one it reports on.  Default: all stages. */
 int brmi_set_timed_stages(brmi_pass* pass, uint32_t stageMask);
-/* algorithmic bytes of the last frame per SURVEY.md 8(d): 140*P + sum(144+12V+3T) + 64*M + 16*Mvis + 64*N */
+/* algorithmic bytes of the last frame per SURVEY.md 8(d): 140*P + sum(144+12V+3T) + 64*M + 16*Mvis + 64*N.  A read-back call: waits for
+ * the device (whatever stream the frame ran on) before it reads the frame's counters. */
 int brmi_algorithmic_bytes(brmi_pass* pass, uint64_t* perStage /* [BRMI_STAGE_COUNT] */, uint64_t* total);
 
 /* ---- diagnostics ---------------------------------------------------------------------------- */

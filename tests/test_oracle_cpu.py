@@ -320,6 +320,46 @@ def test_clod_cache_round_trip_reproduces_the_scene_byte_for_byte(preset, kw, tm
     assert struct.unpack_from("<I", meta, 0)[0] == 47
 
 
+def test_scene_loads_a_clod_cache_it_did_not_write():
+    """tests/golden/clodcache_tiny/ was written by tests/golden/make_clod_cache.py -- plain struct.pack in the reference's field order
+    (CLodCache.cpp:171-211,252-259; page blobs per ClusterLODUtilities.cpp:2079-2311), no call into this repository's libraries.  The reader
+    takes the committed files (and the generator still reproduces them byte for byte); the loaded scene carries exactly those pages,
+    groups, segments and BVH nodes, and the oracle renders it."""
+    import struct
+    import sys
+    import orc
+    from basicrenderer_amd import Scene
+    gold = os.path.join(ROOT, "tests", "golden")
+    sys.path.insert(0, gold)
+    import make_clod_cache as mk
+    cache = os.path.join(gold, "clodcache_tiny")
+    built = [mk.build_mesh(kind, i) for i, kind in enumerate(["plane", "dome", "cylinder"])]
+    for i, (container, meta, info) in enumerate(built):
+        assert open(os.path.join(cache, f"mesh_{i}.clodbin"), "rb").read() == container
+        assert open(os.path.join(cache, f"mesh_{i}.clodmeta"), "rb").read() == meta
+    sc = Scene("tiny", 256, 144, point_lights=4, cache_dir=cache)
+    assert sc.stats["meshes"] == 3 and sc.stats["meshletsTotal"] == sum(b[2]["meshlets"] for b in built) == 200
+    assert sc.stats["pages"] == 4 and sc.stats["uniqueTriangles"] == 25600 and sc.stats["lodLevelsMax"] == 1
+    # the page map points at the writer's blobs, byte for byte (mesh 0 needs two pages)
+    pm = sc.arrays["groupPageMap"].view(np.uint32).reshape(-1, 2)
+    page = 0
+    for container, _, info in built:
+        n = struct.unpack_from("<I", container, 12)[0]
+        assert n == info["pages"]
+        for k in range(n):
+            off, size, _ = struct.unpack_from("<QII", container, 16 + 16 * k)
+            slab, base = sc.slabs[int(pm[page, 0])], int(pm[page, 1])
+            assert bytes(slab[base: base + size]) == container[off: off + size]
+            page += 1
+    # groups / segments / nodes as serialised
+    assert sc.counts["lodGroups"] == 15 and sc.counts["lodSegments"] == 15 and sc.counts["lodNodes"] == 21
+    nodes = sc.arrays["lodNodes"].view(np.uint32).reshape(-1, 16)
+    assert nodes[0, 0] == 0 and nodes[0, 1] == 1 and nodes[0, 2] == 0                 # super-root -> the one depth root
+    assert (nodes[:, 0] == 2).sum() == 15                                            # one segment leaf per group
+    f = orc.OracleFrame(sc).run()
+    assert f.count > 100 and (f.vis != EMPTY).sum() > 5000
+
+
 def test_clod_cache_rejects_damaged_files(tmp_path):
     """Truncated, mislabelled or internally inconsistent cache files are refused, never loaded."""
     import shutil

@@ -508,6 +508,38 @@ def test_full_size_band_split_against_the_oracle(preset, lights, n, kw):
         r.close()
 
 
+def test_frame_from_an_independently_written_clod_cache_matches_the_oracle():
+    """the scene is loaded from tests/golden/clodcache_tiny/ -- CLodCache v4 containers + schema-47 metadata blobs written
+    by an independent Python script in the reference's field order (tests/golden/make_clod_cache.py), a mesh of two pages among them --
+    and rendered: cluster list, visibility keys, depth, G-buffer exact against the oracle, HDR within one fp16 ULP."""
+    import os
+    import orc
+    from basicrenderer_amd import Scene
+    from basicrenderer_amd.renderer import VisibilityRenderer
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sc = Scene("tiny", 640, 360, point_lights=6, cache_dir=os.path.join(root, "tests", "golden", "clodcache_tiny"))
+    r = VisibilityRenderer(sc, stats=True, occlusion=True)
+    o = orc.OracleFrame(sc)
+    hz = None
+    for _ in range(2):
+        r.execute()
+        hz = o.run_occlusion(hz)
+    o.gbuffer(); o.light_cluster(); o.shade()
+    assert o.count > 100
+    assert np.array_equal(r.visible_clusters(), o.clusters[: o.count])
+    assert np.array_equal(r.visibility(), o.vis)
+    covered = o.vis != np.uint64(0xFFFFFFFFFFFFFFFF)
+    assert covered.sum() > 20000
+    assert np.array_equal(r.depth().view(np.uint32), o.depth.view(np.uint32))
+    g = r.gbuffer()
+    assert np.array_equal(g["normals"].view(np.uint32)[covered], o.normals.view(np.uint32)[covered])
+    for k, ref in (("albedo", o.albedo), ("mr", o.mr), ("emissive", o.emissive)):
+        assert np.array_equal(g[k][covered], ref[covered]), k
+    a, b = r.hdr().view(np.uint16).astype(np.int32), o.hdr.view(np.uint16).astype(np.int32)
+    assert np.abs(a - b).max() <= 1
+    r.close()
+
+
 @pytest.mark.parametrize("transport", ["surface", "rgb16f"])
 def test_native_composer_gathers_the_band_bytes(transport, scenes):
     """libbrmi_compose.so (RCCL called from C++, include/brmi_compose.h) with one rank: three pipelined submits of a row band of the lit
