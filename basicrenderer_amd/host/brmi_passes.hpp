@@ -31,11 +31,19 @@ struct PassReturn {};                                   // reference: Execute() 
 struct UpdateExecutionContext { const brmi_camera* mainCamera; const brmi_per_frame* perFrame; uint32_t frameIndex; };
 struct PassExecutionContext { brmi_stream commandList; uint32_t frameIndex; float deltaTime; };   // commandList -> hipStream_t
 
-// what DeclareResourceUsages reports: the reference's builder verbs, by Builtin:: resource name
+// what DeclareResourceUsages reports: the reference's four builder verbs (census over the reference's passes: WithShaderResource 159,
+// WithUnorderedAccess 143, WithConstantBuffer 55, WithIndirectArguments 23 uses), by Builtin:: resource name
 struct ComputePassBuilder {
-    std::vector<std::string> shaderResources, unorderedAccess;
+    std::vector<std::string> shaderResources, unorderedAccess, indirectArguments, constantBuffers;
     ComputePassBuilder& WithShaderResource(std::string n) { shaderResources.push_back(std::move(n)); return *this; }
     ComputePassBuilder& WithUnorderedAccess(std::string n) { unorderedAccess.push_back(std::move(n)); return *this; }
+    // the reference's ExecuteIndirect argument / count buffers: here the counters of the workspace that size the device-side loops
+    ComputePassBuilder& WithIndirectArguments(std::string n) { indirectArguments.push_back(std::move(n)); return *this; }
+    ComputePassBuilder& WithConstantBuffer(std::string n) { constantBuffers.push_back(std::move(n)); return *this; }
+    bool Mentions(const std::string& n) const {
+        for (const auto* v : {&shaderResources, &unorderedAccess, &indirectArguments, &constantBuffers}) for (const auto& e : *v) if (e == n) return true;
+        return false;
+    }
 };
 
 // One shared brmi_pass per view; the individual passes are views on its stages (the reference shares the
@@ -87,6 +95,8 @@ protected:
         void DeclareResourceUsages(ComputePassBuilder* b) override {                                          \
             for (const char* s : std::vector<const char*> SRVS) b->WithShaderResource(s);                     \
             for (const char* u : std::vector<const char*> UAVS) b->WithUnorderedAccess(u);                    \
+            b->WithConstantBuffer("Builtin::PerFrameBuffer");                                                 \
+            b->WithIndirectArguments("brmi::Workspace");   /* cluster / record counts read on the device */   \
         }                                                                                                     \
         PassReturn Execute(PassExecutionContext& ctx) override { state->check(CALL, NAME); return {}; }       \
     };
@@ -137,13 +147,81 @@ BRMI_STAGE_PASS(DeferredShadingPass, "DeferredShadingPass", brmi_shade(state->ge
                 ({"Builtin::Color::HDRColorTarget"}))
 #undef BRMI_STAGE_PASS
 
-// reference: CLodExtension (IRenderGraphExtension) -- returns the passes in the order the reference graph runs them
-class BrmiGraphExtension {
+// ---- the extension interface (BR/include/Render/GraphExtensions/CLodExtension.h:20-31) ------------------------------------------
+// Stand-ins for the graph-side types the five hooks take (OpenRenderGraph is an empty submodule in the reference checkout).
+struct ResourceRegistry;                                 // opaque: the graph's name -> backing map
+// what the extension needs from the graph: memory for a declared resource (the graph owns backing memory, aliasing and barriers:
+// BR/src/Renderer.cpp:2536-2571) and the stream the frame is recorded on
+struct RenderGraph {
+    std::function<void*(const brmi_resource_desc&)> allocate;      // RegisterResource + backing
+    brmi_stream stream = nullptr;
+    ResourceRegistry* registry = nullptr;
+};
+struct ExternalInsertPoint {
+    enum Kind { Begin, End, After, Before, Between } kind = End;
+    std::string anchor, anchor2;
+    static ExternalInsertPoint AtBegin() { return {Begin, "", ""}; }
+    static ExternalInsertPoint AtEnd() { return {End, "", ""}; }
+    static ExternalInsertPoint AfterPass(std::string a) { return {After, std::move(a), ""}; }
+    static ExternalInsertPoint BeforePass(std::string a) { return {Before, std::move(a), ""}; }
+    static ExternalInsertPoint BetweenPasses(std::string a, std::string b) { return {Between, std::move(a), std::move(b)}; }
+};
+struct ExternalPassDesc {                                // ExternalPassDesc::Compute(name, pass).At(point)
+    std::string name; std::shared_ptr<ComputePass> pass; ExternalInsertPoint where; std::vector<std::string> alsoBefore;
+    static ExternalPassDesc Compute(std::string n, std::shared_ptr<ComputePass> p) { ExternalPassDesc d; d.name = std::move(n); d.pass = std::move(p); return d; }
+    ExternalPassDesc& At(ExternalInsertPoint p) { where = std::move(p); return *this; }
+    ExternalPassDesc& AlsoBefore(std::string n) { alsoBefore.push_back(std::move(n)); return *this; }
+};
+class IRenderGraphExtension {
+public:
+    virtual ~IRenderGraphExtension() = default;
+    virtual void PrepareForBuild(RenderGraph& rg) = 0;
+    virtual void Initialize(RenderGraph& rg) = 0;
+    virtual void OnRegistryReset(ResourceRegistry* reg) = 0;
+    virtual void GatherStructuralPasses(RenderGraph& rg, std::vector<ExternalPassDesc>& outPasses) = 0;
+    virtual void GatherFramePasses(RenderGraph& rg, std::vector<ExternalPassDesc>& outPasses) = 0;
+};
+
+// reference: CLodExtension -- the five hooks over one shared brmi_pass
+class BrmiGraphExtension final : public IRenderGraphExtension {
 public:
     explicit BrmiGraphExtension(std::shared_ptr<PassState> st, bool occlusionCulling = false) : state_(std::move(st)), occlusion_(occlusionCulling) {}
+    // PrepareForBuild (CLodExtension.cpp: capacity / settings refresh before the graph is compiled): what the pass will ask the graph for
+    void PrepareForBuild(RenderGraph&) override { declared_ = state_->Declare(); }
+    // Initialize (InitializeCoreResources + RegisterResource): the graph allocates every declared resource, the pass binds them
+    void Initialize(RenderGraph& rg) override {
+        if (declared_.empty()) declared_ = state_->Declare();
+        bindings_.clear();
+        for (const brmi_resource_desc& d : declared_) {
+            brmi_resource_desc padded = d; if (padded.bytes < 16) padded.bytes = 16;
+            void* p = rg.allocate ? rg.allocate(padded) : nullptr;
+            if (!p) throw std::runtime_error(std::string("BrmiGraphExtension::Initialize: the graph returned no backing for ") + d.name);
+            bindings_.push_back({d.id, p, padded.bytes});
+        }
+        state_->Bind(bindings_, rg.stream);
+        bound_ = true;
+    }
+    // OnRegistryReset: the graph dropped its backings (resize, device reset): nothing may be executed until Initialize ran again
+    void OnRegistryReset(ResourceRegistry*) override { bound_ = false; bindings_.clear(); brmi_invalidate_hzb(state_->get()); }
     // GatherStructuralPasses: cull/raster chain spliced before "MaterialHistogramPass" (CLodExtension.cpp:1704,1910); with
     // enableOcclusionCulling the depth copy / downsample / phase-2 passes follow phase 1 and the chain is rebuilt from the final
     // depth for the next frame (CLodExtension.cpp:1920-2088)
+    void GatherStructuralPasses(RenderGraph&, std::vector<ExternalPassDesc>& out) override {
+        if (!bound_) throw std::runtime_error("BrmiGraphExtension::GatherStructuralPasses: Initialize has not run since the last registry reset");
+        std::string prev;
+        for (auto& p : GatherStructuralPasses()) {
+            ExternalPassDesc d = ExternalPassDesc::Compute(p->Name(), p);
+            d.At(prev.empty() ? ExternalInsertPoint::AtBegin() : ExternalInsertPoint::AfterPass(prev));
+            if (p->Name() == "SoftwareRasterizeClustersPass1" || p->Name() == "SoftwareRasterizeClustersPass2") d.AlsoBefore("MaterialHistogramPass");
+            prev = p->Name();
+            out.push_back(std::move(d));
+        }
+    }
+    // GatherFramePasses: the reference adds its per-frame streaming / telemetry passes here; this path has none (everything resident)
+    void GatherFramePasses(RenderGraph&, std::vector<ExternalPassDesc>&) override {}
+    const std::vector<brmi_resource_desc>& Declared() const { return declared_; }
+    const std::vector<brmi_resource_binding>& Bindings() const { return bindings_; }
+    // the plain pass list (order = the order the reference graph runs them)
     std::vector<std::shared_ptr<ComputePass>> GatherStructuralPasses() const {
         std::vector<std::shared_ptr<ComputePass>> p{std::make_shared<ClearVisibilityBufferPass>(state_), std::make_shared<HierarchicalCullingPass1>(state_),
                                                     std::make_shared<SoftwareRasterizeClustersPass1>(state_)};
@@ -158,7 +236,9 @@ public:
     }
 private:
     std::shared_ptr<PassState> state_;
-    bool occlusion_ = false;
+    bool occlusion_ = false, bound_ = false;
+    std::vector<brmi_resource_desc> declared_;
+    std::vector<brmi_resource_binding> bindings_;
 };
 
 }  // namespace brmi::host

@@ -219,6 +219,7 @@ def measure(args, workload, n, rank, local_rank, cpu):
         }
         if cpu:
             out["cpu_baseline"] = cpu_baseline(scene, args.cpu_scale)
+            out["configs0"] = cpu_forward_baseline()
     r.close()
     return out
 
@@ -271,6 +272,27 @@ def cpu_baseline(scene, scale):
     return {"value": round(px / 1e6 / dt, 3), "unit": "Mpixels/s", "cores": cores, "kind": "port",
             "sample": f"{len(times)} frames ({sum(times):.1f} s), median {dt:.2f} s per frame of rows [0,{rows if rows < H else H}) of {scene.width}x{H} ({px} px); "
                       f"cull, raster, G-buffer, light clustering, shade; OpenMP over clusters / scanlines"}
+
+
+def cpu_forward_baseline():
+    """BASELINE.json configs[0] -- "Sponza static frame, 1080p, 1 directional light, forward PBR -- CPU scalar raster reference (no GPU)": the
+    CPU oracle's forward entry (lighting from the unquantised material inputs, shaders.hlsl:221-229) on all host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    from basicrenderer_amd import Scene
+    sc = Scene("sponza", 1920, 1080, point_lights=0, directional=True)
+    cores = orc.effective_cores()
+    f = orc.OracleFrame(sc, threads=cores)
+    times = []
+    while len(times) < 2 or (sum(times) < 4.0 and len(times) < 16):
+        if hasattr(f, "vis"):
+            del f.vis
+        t0 = time.perf_counter()
+        f.cull(); f.raster(); f.depth_copy(); f.gbuffer(forward=True); f.light_cluster(); f.shade(forward=True)
+        times.append(time.perf_counter() - t0)
+    dt = sorted(times)[len(times) // 2]
+    return {"value": round(1920 * 1080 / 1e6 / dt, 3), "unit": "Mpixels/s", "cores": cores, "kind": "port", "baseline_config": "configs[0]",
+            "sample": f"{len(times)} frames ({sum(times):.1f} s), median {dt:.3f} s per 1920x1080 frame, 1 directional light, forward PBR: cull, raster, material resolve, forward lighting"}
 
 
 if __name__ == "__main__":

@@ -99,19 +99,33 @@ int main(int argc, char** argv) {
         cfg.maxVisibleClusters = 1u << 16; cfg.maxTraversalRecords = 1u << 16; cfg.enableOcclusionCulling = occlusion ? 1u : 0u;
         auto state = std::make_shared<PassState>(cfg);
         state->SetScene(sb);
-        // the graph owns the memory of every declared resource
-        std::vector<brmi_resource_binding> binds;
+        // the five hooks of the reference's IRenderGraphExtension, in the order the graph calls them; the "graph" owns the memory of
+        // every declared resource (here: hipMalloc)
         std::vector<uint64_t> sizes(BRMI_RES_COUNT, 0);
-        for (const brmi_resource_desc& d : state->Declare()) {
-            void* p; const uint64_t bytes = d.bytes < 16 ? 16 : d.bytes;
-            HIPCHK(hipMalloc(&p, bytes)); HIPCHK(hipMemset(p, 0, bytes)); keep.push_back(p);
-            binds.push_back({d.id, p, bytes}); sizes[d.id] = d.bytes;
-        }
-        state->Bind(binds, stream);
+        RenderGraph rg;
+        rg.stream = stream;
+        rg.allocate = [&](const brmi_resource_desc& d) { void* p = nullptr; HIPCHK(hipMalloc(&p, d.bytes)); HIPCHK(hipMemset(p, 0, d.bytes)); keep.push_back(p); return p; };
         BrmiGraphExtension ext(state, occlusion);
-        auto passes = ext.GatherStructuralPasses();
+        ext.PrepareForBuild(rg);
+        for (const brmi_resource_desc& d : ext.Declared()) sizes[d.id] = d.bytes;
+        ext.Initialize(rg);
+        ext.OnRegistryReset(rg.registry);           // a registry reset (resize): the passes are unusable until Initialize ran again
+        bool refused = false;
+        { std::vector<ExternalPassDesc> none; try { ext.GatherStructuralPasses(rg, none); } catch (const std::runtime_error&) { refused = true; } }
+        if (!refused) throw std::runtime_error("GatherStructuralPasses ran on a reset registry");
+        ext.Initialize(rg);
+        const std::vector<brmi_resource_binding> binds = ext.Bindings();
+        std::vector<ExternalPassDesc> descs, framePasses;
+        ext.GatherStructuralPasses(rg, descs);
+        ext.GatherFramePasses(rg, framePasses);
+        std::vector<std::shared_ptr<ComputePass>> passes;
+        for (auto& d : descs) passes.push_back(d.pass);
         ComputePassBuilder builder;
         for (auto& p : passes) { p->DeclareResourceUsages(&builder); p->Setup(); }
+        // every resource the C ABI declares is named by some pass of the chain (the HZB chain only with occlusion culling: its passes are not scheduled without)
+        for (const brmi_resource_desc& d : ext.Declared())
+            if (!builder.Mentions(d.name) && !(d.id == BRMI_RES_HZB && !occlusion) && !(d.id == BRMI_RES_LINEAR_DEPTH && false))
+                throw std::runtime_error(std::string("no pass declares ") + d.name);
         const void* camHost; const void* pfHost; uint64_t b; uint32_t n;
         brmi_scene_array(scene, BRMI_ARR_CAMERAS, &camHost, &b, &n); brmi_scene_array(scene, BRMI_ARR_PER_FRAME, &pfHost, &b, &n);
         state->Update({static_cast<const brmi_camera*>(camHost), static_cast<const brmi_per_frame*>(pfHost), 0}, stream);
@@ -122,8 +136,8 @@ int main(int argc, char** argv) {
         HIPCHK(hipStreamSynchronize(stream));
         brmi_counters c; state->check(brmi_read_counters(state->get(), &c, stream), "brmi_read_counters");
         auto checksum = [&](uint32_t id) { std::vector<uint8_t> h(sizes[id]); for (auto& bd : binds) if (bd.id == id) HIPCHK(hipMemcpy(h.data(), bd.ptr, sizes[id], hipMemcpyDeviceToHost)); return fnv1a(h.data(), h.size()); };
-        std::printf("{\"passes\": %zu, \"srv\": %zu, \"uav\": %zu, \"visible_clusters\": %u, \"visible_clusters_phase2\": %u, \"replayed\": %u, \"vis_fnv\": \"%016llx\", \"hdr_fnv\": \"%016llx\", \"normals_fnv\": \"%016llx\"}\n",
-                    passes.size(), builder.shaderResources.size(), builder.unorderedAccess.size(), c.visibleClusters, c.visibleClustersPhase2, c.replayNodes + c.replayMeshlets,
+        std::printf("{\"passes\": %zu, \"frame_passes\": %zu, \"srv\": %zu, \"uav\": %zu, \"cbv\": %zu, \"indirect\": %zu, \"visible_clusters\": %u, \"visible_clusters_phase2\": %u, \"replayed\": %u, \"vis_fnv\": \"%016llx\", \"hdr_fnv\": \"%016llx\", \"normals_fnv\": \"%016llx\"}\n",
+                    passes.size(), framePasses.size(), builder.shaderResources.size(), builder.unorderedAccess.size(), builder.constantBuffers.size(), builder.indirectArguments.size(), c.visibleClusters, c.visibleClustersPhase2, c.replayNodes + c.replayMeshlets,
                     (unsigned long long)checksum(BRMI_RES_VISIBILITY), (unsigned long long)checksum(BRMI_RES_HDR_COLOR), (unsigned long long)checksum(BRMI_RES_GBUF_NORMALS));
     } catch (const std::exception& e) { std::fprintf(stderr, "error: %s\n", e.what()); return 4; }
     for (void* p : keep) (void)hipFree(p);

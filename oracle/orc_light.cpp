@@ -454,10 +454,24 @@ int orc_light_cluster(const brmi_scene_buffers* scp, const float* planesNearFar,
 }
 
 // K11.  Inputs are the linear G-buffer images written by orc_gbuffer + orc_depth_copy.
+// orc_shade_forward: the FORWARD variant of the same lighting (BASELINE.json configs[0], "forward PBR"; shaders.hlsl:221-229 PSMain ->
+// GetFragmentInfoDirect, utilities.hlsli:2791-2807): `forwardInputs` (orc_gbuffer_forward) carries the material inputs before the G-buffer's
+// quantisation and the interpolated world position, which replace the decoded G-buffer words and the position reconstructed from depth; the
+// normal is the same fp32 value either way.  Null = the deferred path.
+int orc_shade_forward(const brmi_scene_buffers* scp, uint32_t W, uint32_t H, uint32_t bandY0, uint32_t bandY1, const float* depth,
+              const float* normals, const uint32_t* albedo, const uint64_t* coat, const uint64_t* emissive, const uint64_t* fuzz, const uint32_t* metallicRoughness,
+              const brmi_light_cluster* clusters, const brmi_light_page* pages, uint32_t poolSize,
+              uint32_t enablePunctual, uint32_t clusteredLighting, uint64_t* hdr, const float* forwardInputs, int threads);
 int orc_shade(const brmi_scene_buffers* scp, uint32_t W, uint32_t H, uint32_t bandY0, uint32_t bandY1, const float* depth,
               const float* normals, const uint32_t* albedo, const uint64_t* coat, const uint64_t* emissive, const uint64_t* fuzz, const uint32_t* metallicRoughness,
               const brmi_light_cluster* clusters, const brmi_light_page* pages, uint32_t poolSize,
               uint32_t enablePunctual, uint32_t clusteredLighting, uint64_t* hdr, int threads) {
+    return orc_shade_forward(scp, W, H, bandY0, bandY1, depth, normals, albedo, coat, emissive, fuzz, metallicRoughness, clusters, pages, poolSize, enablePunctual, clusteredLighting, hdr, nullptr, threads);
+}
+int orc_shade_forward(const brmi_scene_buffers* scp, uint32_t W, uint32_t H, uint32_t bandY0, uint32_t bandY1, const float* depth,
+              const float* normals, const uint32_t* albedo, const uint64_t* coat, const uint64_t* emissive, const uint64_t* fuzz, const uint32_t* metallicRoughness,
+              const brmi_light_cluster* clusters, const brmi_light_page* pages, uint32_t poolSize,
+              uint32_t enablePunctual, uint32_t clusteredLighting, uint64_t* hdr, const float* forwardInputs, int threads) {
     const brmi_scene_buffers& sc = *scp;
     const brmi_per_frame& pf = sc.perFrame[0];
     const brmi_camera& cam = sc.cameras[pf.mainCameraIndex];
@@ -475,8 +489,10 @@ int orc_shade(const brmi_scene_buffers* scp, uint32_t W, uint32_t H, uint32_t ba
             const float linearZ = d;
             const float4 clipPos{uvx * 2.0f - 1.0f, uvy * 2.0f - 1.0f, 1.0f, 1.0f};
             const float4 viewPosH = mul(clipPos, M(cam.projectionInverse));
-            const float3 posVS = xyz(viewPosH) * linearZ;
-            const float3 posWS = xyz(mulPoint(posVS, M(cam.viewInverse)));
+            float3 posVS = xyz(viewPosH) * linearZ;
+            float3 posWS = xyz(mulPoint(posVS, M(cam.viewInverse)));
+            const float* fwd = forwardInputs ? forwardInputs + idx * 24u : nullptr;
+            if (fwd) { posWS = float3{fwd[20], fwd[21], fwd[22]}; posVS = xyz(mulPoint(posWS, M(cam.view))); }      // input.positionWorldSpace / positionViewSpace of the forward PSInput
             const float3 viewDir = normalize(float3{cam.positionWorldSpace[0], cam.positionWorldSpace[1], cam.positionWorldSpace[2]} - posWS);
 
             // GetFragmentInfoScreenSpace
@@ -485,10 +501,16 @@ int orc_shade(const brmi_scene_buffers* scp, uint32_t W, uint32_t H, uint32_t ba
             const float3 nrm{normals[idx * 4], normals[idx * 4 + 1], normals[idx * 4 + 2]};
             const float nw = normals[idx * 4 + 3];
             const uint32_t al = albedo[idx], mr = metallicRoughness[idx];
-            const float3 baseColor{unorm8_to_float(al), unorm8_to_float(al >> 8), unorm8_to_float(al >> 16)};
+            const float3 baseColor = fwd ? float3{fwd[0], fwd[1], fwd[2]} : float3{unorm8_to_float(al), unorm8_to_float(al >> 8), unorm8_to_float(al >> 16)};
             auto H4 = [](uint64_t v, int k) { return f16_to_f32((uint16_t)(v >> (16 * k))); };
             const uint64_t cs = coat[idx], es = emissive[idx], fs = fuzz[idx];
-            const float metal = unorm8_to_float(mr), pr = unorm8_to_float(mr >> 8), coatR = unorm8_to_float(mr >> 16), fuzzW = unorm8_to_float(mr >> 24);
+            // the three fp16 planes: decoded words (deferred) or the unquantised inputs (forward)
+            const float3 emissiveIn = fwd ? float3{fwd[12], fwd[13], fwd[14]} : float3{H4(es, 0), H4(es, 1), H4(es, 2)};
+            const float3 coatColorIn = fwd ? float3{fwd[8], fwd[9], fwd[10]} : float3{H4(cs, 0), H4(cs, 1), H4(cs, 2)};
+            const float coatWeightIn = fwd ? fwd[11] : H4(cs, 3);
+            const float3 fuzzColorIn = fwd ? float3{fwd[16], fwd[17], fwd[18]} : float3{H4(fs, 0), H4(fs, 1), H4(fs, 2)};
+            const float fuzzRoughnessIn = fwd ? fwd[19] : H4(fs, 3);
+            const float metal = fwd ? fwd[4] : unorm8_to_float(mr), pr = fwd ? fwd[5] : unorm8_to_float(mr >> 8), coatR = fwd ? fwd[6] : unorm8_to_float(mr >> 16), fuzzW = fwd ? fwd[7] : unorm8_to_float(mr >> 24);
             const float prc = clampf(pr, BRMI_MIN_PERCEPTUAL_ROUGHNESS, 1.0f);
             f.roughness = prc * prc;
             float NdotV = dot(nrm, viewDir);
@@ -526,13 +548,13 @@ int orc_shade(const brmi_scene_buffers* scp, uint32_t W, uint32_t H, uint32_t ba
                 f.metalAverageFresnel = saturate(safeF0 + wmF0 * (1.0f / 21.0f) - b * (1.0f / 126.0f));
             }
             f.albedo = weightedBaseColor;
-            f.emissive = float3{H4(es, 0), H4(es, 1), H4(es, 2)};
-            f.coatWeight = saturate(H4(cs, 3));
-            f.coatColor = saturate(float3{H4(cs, 0), H4(cs, 1), H4(cs, 2)});
+            f.emissive = emissiveIn;
+            f.coatWeight = saturate(coatWeightIn);
+            f.coatColor = saturate(coatColorIn);
             f.coatRoughness = coatPR * coatPR;
             f.coatF0 = saturate(f.coatColor * coatF0Scalar);
             f.coatIor = op.coatIor; f.coatDarkening = saturate(op.coatDarkening);
-            f.fuzzWeight = saturate(fuzzW); f.fuzzColor = saturate(float3{H4(fs, 0), H4(fs, 1), H4(fs, 2)}); f.fuzzRoughness = saturate(H4(fs, 3));
+            f.fuzzWeight = saturate(fuzzW); f.fuzzColor = saturate(fuzzColorIn); f.fuzzRoughness = saturate(fuzzRoughnessIn);
             f.baseDiffuseRoughness = saturate(op.baseDiffuseRoughness);
             f.specularAlpha = f.roughness; f.weightedSpecularIor = weightedSpecularIor;
             f.dielectricSpecularF0 = dielF0;

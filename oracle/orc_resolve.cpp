@@ -121,6 +121,10 @@ static float2 parallaxCoords(const brmi_scene_buffers& sc, uint32_t heightMapInd
 
 struct GBufferOut {
     float* normals; uint32_t* albedo; uint64_t* coat; uint64_t* emissive; uint64_t* fuzz; uint32_t* metallicRoughness; uint32_t* motion;
+    // forward shading (shaders.hlsl:221-229, GetFragmentInfoDirect utilities.hlsli:2791-2807): the material inputs BEFORE the G-buffer's
+    // UNORM8 / fp16 quantisation and the interpolated world position, 24 floats per pixel: base colour rgb + ao | metallic, roughness, coat
+    // roughness, fuzz weight | coat colour rgb + weight | emissive rgb + 0 | fuzz colour rgb + roughness | world position xyz + 1
+    float* forwardInputs = nullptr;
 };
 
 static bool resolvePixel(const brmi_scene_buffers& sc, const brmi_visible_cluster* clusters, uint32_t clusterCount, uint64_t key,
@@ -287,6 +291,12 @@ static bool resolvePixel(const brmi_scene_buffers& sc, const brmi_visible_cluste
     o.fuzz[idx] = pack_half4(fuzzColor.x, fuzzColor.y, fuzzColor.z, fuzzRoughness);
     o.metallicRoughness[idx] = pack_unorm4(metallic, roughness, coatRoughness, fuzzWeight);
     o.motion[idx] = (uint32_t)f32_to_f16(mv.x) | ((uint32_t)f32_to_f16(mv.y) << 16);
+    if (o.forwardInputs) {
+        float* r = o.forwardInputs + idx * 24u;
+        const float v[24] = {baseColor.x, baseColor.y, baseColor.z, ao, metallic, roughness, coatRoughness, fuzzWeight, coatColor.x, coatColor.y, coatColor.z, coatWeight,
+                             emissive.x, emissive.y, emissive.z, 0.0f, fuzzColor.x, fuzzColor.y, fuzzColor.z, fuzzRoughness, worldPosition.x, worldPosition.y, worldPosition.z, 1.0f};
+        for (int k = 0; k < 24; k++) r[k] = v[k];
+    }
     return true;
 }
 
@@ -310,11 +320,22 @@ int orc_parallax_coords(const brmi_scene_buffers* sc, uint32_t heightMapIndex, u
 
 // All images are linear W x H.  Pixels without geometry are left untouched (the reference does not
 // write them); callers pass zero-initialised buffers.
+int orc_gbuffer_forward(const brmi_scene_buffers* sc, const brmi_visible_cluster* clusters, uint32_t clusterCount, const uint64_t* vis,
+                        uint32_t W, uint32_t H, uint32_t bandY0, uint32_t bandY1,
+                        float* normals, uint32_t* albedo, uint64_t* coat, uint64_t* emissive, uint64_t* fuzz, uint32_t* metallicRoughness, uint32_t* motion,
+                        float* forwardInputs /* may be null: 24 floats per pixel, see GBufferOut */, int threads);
 int orc_gbuffer(const brmi_scene_buffers* sc, const brmi_visible_cluster* clusters, uint32_t clusterCount, const uint64_t* vis,
                 uint32_t W, uint32_t H, uint32_t bandY0, uint32_t bandY1,
                 float* normals, uint32_t* albedo, uint64_t* coat, uint64_t* emissive, uint64_t* fuzz, uint32_t* metallicRoughness, uint32_t* motion,
                 int threads) {
+    return orc_gbuffer_forward(sc, clusters, clusterCount, vis, W, H, bandY0, bandY1, normals, albedo, coat, emissive, fuzz, metallicRoughness, motion, nullptr, threads);
+}
+int orc_gbuffer_forward(const brmi_scene_buffers* sc, const brmi_visible_cluster* clusters, uint32_t clusterCount, const uint64_t* vis,
+                        uint32_t W, uint32_t H, uint32_t bandY0, uint32_t bandY1,
+                        float* normals, uint32_t* albedo, uint64_t* coat, uint64_t* emissive, uint64_t* fuzz, uint32_t* metallicRoughness, uint32_t* motion,
+                        float* forwardInputs, int threads) {
     GBufferOut o{normals, albedo, coat, emissive, fuzz, metallicRoughness, motion};
+    o.forwardInputs = forwardInputs;
     if (bandY1 == 0) { bandY0 = 0; bandY1 = H; }
 #pragma omp parallel for schedule(dynamic, 8) num_threads(threads > 0 ? threads : 1)
     for (int64_t y = bandY0; y < (int64_t)bandY1; y++)

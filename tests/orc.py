@@ -134,7 +134,8 @@ class OracleFrame:
         lib().orc_depth_copy(P(self.vis), P(self.depth), u64(self.W * self.H), C.c_int(self.threads))
         return self.depth
 
-    def gbuffer(self, band=(0, 0)):
+    def gbuffer(self, band=(0, 0), forward=False):
+        """forward=True also keeps the unquantised material inputs + interpolated world position (24 floats per pixel) for shade(forward=True)."""
         H, W = self.H, self.W
         self.normals = np.zeros((H, W, 4), dtype=np.float32)
         self.albedo = np.zeros((H, W), dtype=np.uint32)
@@ -143,8 +144,10 @@ class OracleFrame:
         self.fuzz = np.zeros((H, W), dtype=np.uint64)
         self.mr = np.zeros((H, W), dtype=np.uint32)
         self.motion = np.zeros((H, W), dtype=np.uint32)
-        lib().orc_gbuffer(C.byref(self.sb), P(self.clusters), u32(self.count), P(self.vis), u32(W), u32(H), u32(band[0]), u32(band[1]),
-                          P(self.normals), P(self.albedo), P(self.coat), P(self.emissive), P(self.fuzz), P(self.mr), P(self.motion), C.c_int(self.threads))
+        self.forward_inputs = np.zeros((H, W, 24), dtype=np.float32) if forward else None
+        lib().orc_gbuffer_forward(C.byref(self.sb), P(self.clusters), u32(self.count), P(self.vis), u32(W), u32(H), u32(band[0]), u32(band[1]),
+                                  P(self.normals), P(self.albedo), P(self.coat), P(self.emissive), P(self.fuzz), P(self.mr), P(self.motion),
+                                  P(self.forward_inputs) if forward else None, C.c_int(self.threads))
 
     def cluster_planes(self):
         cam = self.scene.arrays["cameras"].view(np.float32)
@@ -169,11 +172,12 @@ class OracleFrame:
         lib().orc_light_cluster(C.byref(self.sb), P(self.planes), P(self.light_clusters), P(self.light_pages), u32(self.pool), C.byref(used))
         self.pages_used = used.value
 
-    def shade(self, band=(0, 0), punctual=True, clustered=True):
+    def shade(self, band=(0, 0), punctual=True, clustered=True, forward=False):
+        """forward=True: BASELINE.json configs[0]'s "forward PBR" -- the same lighting from the unquantised material inputs (gbuffer(forward=True))."""
         self.hdr = np.zeros((self.H, self.W), dtype=np.uint64)
-        lib().orc_shade(C.byref(self.sb), u32(self.W), u32(self.H), u32(band[0]), u32(band[1]), P(self.depth), P(self.normals), P(self.albedo), P(self.coat),
-                        P(self.emissive), P(self.fuzz), P(self.mr), P(self.light_clusters), P(self.light_pages), u32(self.pool),
-                        u32(1 if punctual else 0), u32(1 if clustered else 0), P(self.hdr), C.c_int(self.threads))
+        lib().orc_shade_forward(C.byref(self.sb), u32(self.W), u32(self.H), u32(band[0]), u32(band[1]), P(self.depth), P(self.normals), P(self.albedo), P(self.coat),
+                                P(self.emissive), P(self.fuzz), P(self.mr), P(self.light_clusters), P(self.light_pages), u32(self.pool),
+                                u32(1 if punctual else 0), u32(1 if clustered else 0), P(self.hdr), P(self.forward_inputs) if forward else None, C.c_int(self.threads))
         return self.hdr
 
     def run(self):

@@ -709,6 +709,43 @@ def test_own_lod_builder_keeps_seams_closed_and_is_deterministic():
         assert all(n <= 2 for n in edges.values())
 
 
+def test_forward_pbr_is_the_deferred_lighting_without_the_gbuffer_quantisation():
+    """BASELINE.json configs[0] names a FORWARD PBR frame (shaders.hlsl:221-229 -> GetFragmentInfoDirect, utilities.hlsli:2791): the same
+    lightFragment fed with the material inputs before their UNORM8 / fp16 round trip and with the interpolated world position.  The
+    oracle's forward entry differs from its deferred one by exactly that: close everywhere (the G-buffer holds 8 bits per material
+    channel), not identical, and identical where the inputs survive the round trip (forward inputs replaced by the decoded words)."""
+    import orc
+    from basicrenderer_amd import Scene
+    sc = Scene("sponza", 480, 270, point_lights=8, size_scale=0.1)
+    f = orc.OracleFrame(sc)
+    f.cull(); f.raster(); f.depth_copy(); f.gbuffer(forward=True); f.light_cluster()
+    deferred = f.shade().copy()
+    forward = f.shade(forward=True).copy()
+    covered = f.vis != EMPTY
+    a = deferred.view(np.float16).reshape(f.H, f.W, 4)[covered][:, :3].astype(np.float64)
+    b = forward.view(np.float16).reshape(f.H, f.W, 4)[covered][:, :3].astype(np.float64)
+    assert not np.array_equal(a, b)
+    rel = np.abs(a - b) / np.maximum(np.abs(a), 1e-3)
+    assert np.percentile(rel, 99) < 0.03 and np.median(rel) < 0.005
+    # feeding the decoded G-buffer words (and the depth-reconstructed position's neighbour: the interpolated one) back in must give the
+    # deferred image again up to the position's rounding
+    fi = f.forward_inputs
+    al, mr = f.albedo, f.mr
+    for k in range(3):
+        fi[..., k] = ((al >> (8 * k)) & 0xFF).astype(np.float32) / np.float32(255)
+    for k in range(4):
+        fi[..., 4 + k] = ((mr >> (8 * k)) & 0xFF).astype(np.float32) / np.float32(255)
+    h = lambda plane, k: ((plane >> np.uint64(16 * k)) & np.uint64(0xFFFF)).astype(np.uint16).view(np.float16).astype(np.float32)
+    for k in range(4):
+        fi[..., 8 + k] = h(f.coat, k); fi[..., 16 + k] = h(f.fuzz, k)
+    for k in range(3):
+        fi[..., 12 + k] = h(f.emissive, k)
+    again = f.shade(forward=True)
+    c = again.view(np.float16).reshape(f.H, f.W, 4)[covered][:, :3].astype(np.float64)
+    rel2 = np.abs(a - c) / np.maximum(np.abs(a), 1e-3)
+    assert np.percentile(rel2, 99) < 1e-2 and np.median(rel2) < 1e-3 and np.percentile(rel2, 99) < np.percentile(rel, 99)
+
+
 def test_frustum_culls_the_instance_behind_the_camera(scenes):
     import orc
     f = orc.OracleFrame(scenes("tiny"))
