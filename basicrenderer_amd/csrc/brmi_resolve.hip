@@ -155,6 +155,12 @@ BRMI_DEV BaryDeriv bary_derivatives(const ResolveTriangle& r, f3 lambda, float n
 // along the tangent-space view ray, one refinement pass after the first hit, a secant between the last two points; p1 / p2 /
 // parallaxAmount start as zero where the HLSL leaves them uninitialised.
 BRMI_DEV float wrap1(float x) { const float y = x + 1.0f; return y - floorf(y); }
+// Steps of the march whose fetches are issued together.  1 = the HLSL's loop as it is.  Larger batches were tried to overlap the fetches'
+// latency (Sponza 4K, parallax on half of the textured materials: G-buffer 1.31 ms at 1, 1.42 at 2, 1.53 at 4, 1.90 at 8): the steps behind
+// the first hit of a batch are wasted work and the pass is bound by its instruction count (texel addressing, decode, filter), not by latency.
+#ifndef PARALLAX_BATCH
+#define PARALLAX_BATCH 1
+#endif
 BRMI_DEV f2 parallax_coords(const TexelTables& tb, const TexBinding& height, f3 T, f3 B, f3 N, f2 uv, f3 viewDirWS, float heightmapScale, f2 dUVdx, f2 dUVdy) {
     uv.y = 1.0f - uv.y;
     const f3 viewDir = normalize3(f3{dot3(T, viewDirWS), dot3(B, viewDirWS), dot3(N, viewDirWS)});
@@ -167,25 +173,44 @@ BRMI_DEV f2 parallax_coords(const TexelTables& tb, const TexBinding& height, f3 
     float lastRayDepth = 1.0f, lastHeight = 1.0f;
     f2 p1{0.0f, 0.0f}, p2{0.0f, 0.0f};
     bool refine = false;
+    // Every fetch of the march uses the pixel's gradients: the level of detail, the filter and the two mip levels are settled once.
+    // The march itself is the HLSL's loop evaluated PARALLAX_BATCH steps at a time: the ray offsets of the next steps do not depend on the
+    // heights (only the decision where to stop does), so their fetches are issued together -- one memory round trip per batch instead of
+    // one per step -- and then examined in order; a step behind the first hit of its batch was fetched for nothing and changes nothing.
+    const bool bound = height.bound;
+    const LevelSetup ls = bound ? prepare_level(height, grad_lod(height, dUVdx, dUVdy)) : LevelSetup{};
+    bool done = false;
 #pragma nounroll
-    while (numSteps > 0) {
-        const f2 candidateOffset{wrap1(lastOffset.x - stepOffset.x), wrap1(lastOffset.y - stepOffset.y)};
-        const float currentRayDepth = lastRayDepth - stepSize;
-        const float currentHeight = viewCorrection * sample_grad(tb, height, candidateOffset, dUVdx, dUVdy).x;
-        if (currentHeight > currentRayDepth) {
-            p1 = f2{currentRayDepth, currentHeight};
-            p2 = f2{lastRayDepth, lastHeight};
-            if (refine) break;
-            refine = true;
-            lastRayDepth = p2.x;
-            stepSize = stepSize / (float)numSteps;
-            stepOffset = f2{stepOffset.x / (float)numSteps, stepOffset.y / (float)numSteps};
-            continue;
+    while (numSteps > 0 && !done) {
+        const int n = numSteps < PARALLAX_BATCH ? numSteps : PARALLAX_BATCH;
+        f2 cand[PARALLAX_BATCH]; float depthAt[PARALLAX_BATCH], heightAt[PARALLAX_BATCH];
+        f2 o = lastOffset; float dpt = lastRayDepth;
+#pragma unroll
+        for (int i = 0; i < PARALLAX_BATCH; i++) {
+            o = f2{wrap1(o.x - stepOffset.x), wrap1(o.y - stepOffset.y)}; dpt = dpt - stepSize;
+            cand[i] = o; depthAt[i] = dpt;
         }
-        lastOffset = candidateOffset;
-        lastRayDepth = currentRayDepth;
-        lastHeight = currentHeight;
-        numSteps -= 1;
+#pragma unroll
+        for (int i = 0; i < PARALLAX_BATCH; i++) heightAt[i] = (i < n) ? viewCorrection * (bound ? sample_prepared(tb, height, ls, cand[i]).x : 1.0f) : 0.0f;
+#pragma unroll
+        for (int i = 0; i < PARALLAX_BATCH; i++) {
+            if (i >= n || done) continue;
+            const float currentRayDepth = depthAt[i], currentHeight = heightAt[i];
+            if (currentHeight > currentRayDepth) {
+                p1 = f2{currentRayDepth, currentHeight};
+                p2 = f2{lastRayDepth, lastHeight};
+                if (refine) { done = true; continue; }
+                refine = true;
+                lastRayDepth = p2.x;
+                stepSize = stepSize / (float)numSteps;
+                stepOffset = f2{stepOffset.x / (float)numSteps, stepOffset.y / (float)numSteps};
+                break;                                   // the rest of the batch was laid out with the coarse step: start over from here
+            }
+            lastOffset = cand[i];
+            lastRayDepth = currentRayDepth;
+            lastHeight = currentHeight;
+            numSteps -= 1;
+        }
     }
     const float diff1 = p1.x - p1.y, diff2 = p2.x - p2.y;
     const float denominator = diff2 - diff1;
@@ -252,7 +277,13 @@ template <bool INLINE_TABLES, bool TEXTURED, bool PARALLAX = false>
 #ifndef BRMI_GBT_WAVES
 #define BRMI_GBT_WAVES 3
 #endif
-__global__ void __launch_bounds__(256, INLINE_TABLES ? 1 : (TEXTURED ? BRMI_GBT_WAVES : BRMI_GB_WAVES)) k_gbuffer(GBufferArgs a) {
+// the parallax variant: three waves per SIMD with 47 registers of the ray march's state in scratch (160 B per lane) is faster than two
+// waves without scratch (1.39 against 1.47 ms, Sponza 4K with parallax on half of the textured materials): the march is bound by its
+// instruction stream and needs the third wave more than it minds the scratch traffic
+#ifndef BRMI_GBP_WAVES
+#define BRMI_GBP_WAVES 3
+#endif
+__global__ void __launch_bounds__(256, INLINE_TABLES ? 1 : (PARALLAX ? BRMI_GBP_WAVES : (TEXTURED ? BRMI_GBT_WAVES : BRMI_GB_WAVES))) k_gbuffer(GBufferArgs a) {
     const brmi_scene_buffers& sc = a.sc;
     if (a.variantSelect != 0u && (a.counters[CNT_RESOLVE_SPILL] != 0u) != (a.variantSelect == 2u)) return;     // the other variant's frame
     __shared__ float texelTables[TEXTURED ? 512 : 1];          // code -> float: unorm, sRGB decode

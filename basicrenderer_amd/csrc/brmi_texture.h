@@ -121,26 +121,35 @@ BRMI_DEV f4 filter_footprint(const TexelTables& tb, const Footprint& f, bool srg
 
 // Texture2D::SampleLevel.  An unbound slot reads as opaque white.  Both mip offsets are requested together, then both footprints:
 // two memory round trips per sample instead of four.  (When no lane of the wave blends levels the second footprint is skipped.)
-BRMI_DEV f4 sample_level(const TexelTables& tb, const TexBinding& tx, f2 uv, float lodIn) {
-    if (!tx.bound) return {1.0f, 1.0f, 1.0f, 1.0f};
+// The part that depends on the level of detail alone -- clamps, filter choice, the two mip levels and their offsets -- is a LevelSetup:
+// a caller that samples one texture many times at one LOD (the parallax march: 32 fetches with the pixel's gradients) prepares it once.
+struct LevelSetup { uint32_t l0, l1, off0, off1, filter; float frac; };
+BRMI_DEV LevelSetup prepare_level(const TexBinding& tx, float lodIn) {
+    LevelSetup s;
     float lod = min2(max2(lodIn + tx.sm.mipLodBias, tx.sm.minLod), tx.sm.maxLod);
     lod = min2(max2(lod, 0.0f), (float)(tx.mipCount - 1u));
-    const uint32_t filter = lod <= 0.0f ? tx.sm.magFilter : tx.sm.minFilter;
-    uint32_t l0, l1; float frac;
+    s.filter = lod <= 0.0f ? tx.sm.magFilter : tx.sm.minFilter;
     if (tx.sm.mipFilter == BRMI_FILTER_POINT) {
-        l0 = (uint32_t)floor_to_int(lod + 0.5f);
-        if (l0 > tx.mipCount - 1u) l0 = tx.mipCount - 1u;
-        l1 = l0; frac = 0.0f;
+        s.l0 = (uint32_t)floor_to_int(lod + 0.5f);
+        if (s.l0 > tx.mipCount - 1u) s.l0 = tx.mipCount - 1u;
+        s.l1 = s.l0; s.frac = 0.0f;
     } else {
-        l0 = (uint32_t)floor_to_int(lod); frac = lod - floorf(lod);
-        l1 = l0 + 1u > tx.mipCount - 1u ? tx.mipCount - 1u : l0 + 1u;
+        s.l0 = (uint32_t)floor_to_int(lod); s.frac = lod - floorf(lod);
+        s.l1 = s.l0 + 1u > tx.mipCount - 1u ? tx.mipCount - 1u : s.l0 + 1u;
     }
-    const uint32_t off0 = as_global(tx.mipOffset)[l0], off1 = as_global(tx.mipOffset)[l1];
-    const Footprint f0 = fetch_footprint(tx, off0, l0, uv, filter);
-    if (!__any(frac != 0.0f)) return filter_footprint(tb, f0, tx.srgb);       // a + 0 * (b - a) for every lane
-    const Footprint f1 = fetch_footprint(tx, off1, l1, uv, filter);
+    s.off0 = as_global(tx.mipOffset)[s.l0]; s.off1 = as_global(tx.mipOffset)[s.l1];
+    return s;
+}
+BRMI_DEV f4 sample_prepared(const TexelTables& tb, const TexBinding& tx, const LevelSetup& s, f2 uv) {
+    const Footprint f0 = fetch_footprint(tx, s.off0, s.l0, uv, s.filter);
+    if (!__any(s.frac != 0.0f)) return filter_footprint(tb, f0, tx.srgb);       // a + 0 * (b - a) for every lane
+    const Footprint f1 = fetch_footprint(tx, s.off1, s.l1, uv, s.filter);
     const f4 a = filter_footprint(tb, f0, tx.srgb);
-    return frac == 0.0f ? a : lerp4(a, filter_footprint(tb, f1, tx.srgb), frac);
+    return s.frac == 0.0f ? a : lerp4(a, filter_footprint(tb, f1, tx.srgb), s.frac);
+}
+BRMI_DEV f4 sample_level(const TexelTables& tb, const TexBinding& tx, f2 uv, float lodIn) {
+    if (!tx.bound) return {1.0f, 1.0f, 1.0f, 1.0f};
+    return sample_prepared(tb, tx, prepare_level(tx, lodIn), uv);
 }
 
 BRMI_DEV float log2_poly(float x) {
@@ -150,17 +159,18 @@ BRMI_DEV float log2_poly(float x) {
     const float p = t * (1.442609190940857f + t * (-0.7168022990226746f + t * (0.44070422649383545f + t * (-0.2247820496559143f + t * 0.05827096104621887f))));
     return (float)e + p;
 }
-// Texture2D::SampleGrad
-BRMI_DEV f4 sample_grad(const TexelTables& tb, const TexBinding& tx, f2 uv, f2 dUVdx, f2 dUVdy) {
-    if (!tx.bound) return {1.0f, 1.0f, 1.0f, 1.0f};
+// Texture2D::SampleGrad: the level of detail of a gradient pair, then SampleLevel
+BRMI_DEV float grad_lod(const TexBinding& tx, f2 dUVdx, f2 dUVdy) {
     const float W = (float)tx.width, H = (float)tx.height;
     const float dxx = dUVdx.x * W, dxy = dUVdx.y * H, dyx = dUVdy.x * W, dyy = dUVdy.y * H;
     const float rho2 = max2(dxx * dxx + dxy * dxy, dyx * dyx + dyy * dyy);
-    float lod;
-    if (!(rho2 >= 1.17549435e-38f)) lod = -127.0f;
-    else if (rho2 > 3.0e38f) lod = 128.0f;
-    else lod = 0.5f * log2_poly(rho2);
-    return sample_level(tb, tx, uv, lod);
+    if (!(rho2 >= 1.17549435e-38f)) return -127.0f;
+    if (rho2 > 3.0e38f) return 128.0f;
+    return 0.5f * log2_poly(rho2);
+}
+BRMI_DEV f4 sample_grad(const TexelTables& tb, const TexBinding& tx, f2 uv, f2 dUVdx, f2 dUVdy) {
+    if (!tx.bound) return {1.0f, 1.0f, 1.0f, 1.0f};
+    return sample_level(tb, tx, uv, grad_lod(tx, dUVdx, dUVdy));
 }
 
 // SWAlphaTestFailed (CLOD_SW_RASTER_DYNAMIC_ALPHA_TEST).  Everything that depends on the material alone -- the two texture
