@@ -143,7 +143,7 @@ static void compute_sizes(brmi_pass* p) {
     const bool uvs = p->sceneHasTextures || p->sceneHasAlphaTest || p->sceneHasVertexColors;
     w.clusterUv = take(uvs ? (uint64_t)c.maxVisibleClusters * 32 : 16);
     w.resolveColors = take(p->sceneHasVertexColors ? (uint64_t)p->resolveCapacity * 4 : 16);
-    w.resolveUVs = take(p->sceneHasTextures ? (uint64_t)p->resolveCapacity * 8 : 16);
+    w.resolveUVs = take(p->sceneHasTextures ? (uint64_t)p->resolveCapacity * 8 * p->sceneUvSets : 16);
     w.binAlpha = take(p->sceneHasAlphaTest ? (uint64_t)p->binsX * p->binsY * p->binCapacity * 48 : 16);
     w.overflowAlpha = take(p->sceneHasAlphaTest ? (uint64_t)CNT_STRIPE_COUNT * p->binOverflowPerStripe * 48 : 16);
     w.alphaMats = take(p->sceneHasAlphaTest ? (uint64_t)std::max(1u, p->scene.materialCount) * 128 : 16);
@@ -244,6 +244,9 @@ int brmi_set_scene(brmi_pass* p, const brmi_scene_buffers* scene) {
         if ((rc = read_back(p, op, sc.openpbrMaterials, sc.openpbrMaterialCount))) return rc;
         p->sceneHasCoat = p->sceneHasFuzz = false;
         bool layerTextures = false;
+        // UV sets the G-buffer pass must decode: 1 + the highest set an enabled texture slot names (AppendClodMaterialUvSample: an index >= 8 reads set 0)
+        uint32_t uvSets = 1;
+        auto names_set = [&](uint32_t setIndex) { if (setIndex < 8u && setIndex + 1u > uvSets) uvSets = setIndex + 1u; };
         for (size_t i = 0; i < op.size(); i++) {
             const auto& m = op[i];
             if (m.coatWeight > 0.0f) p->sceneHasCoat = true;
@@ -252,7 +255,7 @@ int brmi_set_scene(brmi_pass* p, const brmi_scene_buffers* scene) {
             for (int k = 0; k < 6; k++)
                 if (m.textureBindings[2 * k] != 0xFFFFFFFFu && m.textureBindings[2 * k + 1] != 0xFFFFFFFFu) {
                     layerTextures = true;
-                    if (m.textureBindings[26 + k] != 0u) return fail(p, BRMI_ERR_INVALID, "OpenPBR material %zu: coat / fuzz texture slot %d must use UV set 0 (only set 0 is decoded on this path)", i, k);
+                    names_set(m.textureBindings[26 + k]);
                 }
         }
         // texture slots: the alpha-test variants of the rasteriser and the texture-sampling variant of the G-buffer pass are only
@@ -262,19 +265,22 @@ int brmi_set_scene(brmi_pass* p, const brmi_scene_buffers* scene) {
         p->sceneHasAlphaTest = false; p->sceneHasTextures = layerTextures; p->sceneHasParallax = false;
         for (size_t i = 0; i < mats.size(); i++) {
             const brmi_material_info& m = mats[i];
-            if ((m.materialFlags & BRMI_MATERIAL_PARALLAX) && m.heightUvSetIndex)
-                return fail(p, BRMI_ERR_INVALID, "material %zu: the height map must use UV set 0 (only set 0 is decoded on this path)", i);
+            if (m.materialFlags & BRMI_MATERIAL_PARALLAX) names_set(m.heightUvSetIndex);
             if (m.materialFlags & BRMI_MATERIAL_ALPHA_TEST) p->sceneHasAlphaTest = true;
             if (m.materialFlags & BRMI_MATERIAL_PARALLAX) p->sceneHasParallax = true;
             if (m.materialFlags & BRMI_MATERIAL_ANY_TEXTURE) {
                 p->sceneHasTextures = true;
                 const uint32_t f = m.materialFlags;
-                if (((f & BRMI_MATERIAL_BASE_COLOR_TEXTURE) && m.baseColorUvSetIndex) || ((f & BRMI_MATERIAL_NORMAL_MAP) && m.normalUvSetIndex) || ((f & BRMI_MATERIAL_METALLIC_TEXTURE) && m.metallicUvSetIndex) ||
-                    ((f & BRMI_MATERIAL_ROUGHNESS_TEXTURE) && m.roughnessUvSetIndex) || ((f & BRMI_MATERIAL_EMISSIVE_TEXTURE) && m.emissiveUvSetIndex) || ((f & BRMI_MATERIAL_AO_TEXTURE) && m.aoUvSetIndex) ||
-                    ((f & BRMI_MATERIAL_OPACITY_TEXTURE) && m.opacityUvSetIndex))
-                    return fail(p, BRMI_ERR_INVALID, "material %zu: texture slots must use UV set 0 (only set 0 is decoded on this path)", i);
+                if (f & BRMI_MATERIAL_BASE_COLOR_TEXTURE) names_set(m.baseColorUvSetIndex);
+                if (f & BRMI_MATERIAL_NORMAL_MAP) names_set(m.normalUvSetIndex);
+                if (f & BRMI_MATERIAL_METALLIC_TEXTURE) names_set(m.metallicUvSetIndex);
+                if (f & BRMI_MATERIAL_ROUGHNESS_TEXTURE) names_set(m.roughnessUvSetIndex);
+                if (f & BRMI_MATERIAL_EMISSIVE_TEXTURE) names_set(m.emissiveUvSetIndex);
+                if (f & BRMI_MATERIAL_AO_TEXTURE) names_set(m.aoUvSetIndex);
+                // the opacity slot only feeds the alpha channel, which the G-buffer does not store; the rasteriser's alpha test reads UV set 0 as the reference's does
             }
         }
+        p->sceneUvSets = uvSets;
         std::vector<brmi_per_mesh> pms;
         if ((rc = read_back(p, pms, sc.perMesh, sc.perMeshCount))) return rc;
         p->sceneHasVertexColors = false;

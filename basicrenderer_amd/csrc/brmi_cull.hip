@@ -786,11 +786,13 @@ __global__ void __launch_bounds__(256) k_scatter_visible(const TempVisible* temp
                 const uint32_t mflags = sc.materials[pm->materialDataIndex].materialFlags;
                 const bool layerTextures = openpbr_has_textures(sc.openpbrMaterials + sc.materials[pm->materialDataIndex].openPBRMaterialDataIndex);
                 cs.counts |= ((mflags & BRMI_MATERIAL_ALPHA_TEST) ? BRMI_CS_ALPHA : 0u) | (((mflags & BRMI_MATERIAL_ANY_TEXTURE) || layerTextures) ? BRMI_CS_TEXTURED : 0u);
-                ClusterUv cu{nullptr, nullptr, nullptr, 0ull};
+                ClusterUv cu{nullptr, nullptr, nullptr, 0, 0u};
                 if (hdr->attributeMask & BRMI_PAGE_ATTRIBUTE_COLOR) { cs.counts |= BRMI_CS_COLOR; cu.color = slab + pageOff + hdr->colorArrayOffset + desc->vertexAttributeOffset * 4u; }
                 if (hdr->uvSetCount != 0u) {
                     cu.desc = slab + pageOff + hdr->uvDescriptorOffset + (vc_meshlet(t.packed) * hdr->uvSetCount) * 32u;
                     cu.stream = slab + pageOff + *reinterpret_cast<const uint32_t*>(slab + pageOff + hdr->uvBitstreamDirectoryOffset);
+                    cu.directory = (int32_t)hdr->uvBitstreamDirectoryOffset - (int32_t)(hdr->uvDescriptorOffset + (vc_meshlet(t.packed) * hdr->uvSetCount) * 32u);
+                    cu.setCount = hdr->uvSetCount;
                 }
                 clusterUv[dst] = cu;
             }

@@ -31,7 +31,8 @@ struct GBufferArgs {
     const ClusterSetup* setup; ResolveVertex* verts; ResolveTriangle* tris; uint32_t vertCapacity, triCapacity;
     MaterialWords* matWords;
     const uint8_t* used;           // per visible cluster: owns a pixel (valid when counters[CNT_RESOLVE_MARKED])
-    const ClusterUv* clusterUv; float2* uvs;      // textured scenes: UV set 0 of every visible cluster, decoded texcoords of the arena's vertices
+    const ClusterUv* clusterUv; float2* uvs;      // textured scenes: where the UV sets of every visible cluster live, decoded texcoords of the arena's vertices
+    uint32_t uvSets;                              // sets the materials of the scene address (1 unless one names a set > 0): uvs holds [set][vertCapacity]
     uint32_t* colors;                             // scenes with vertex colours: the RGBA8 colour of the arena's vertices
     uint32_t variantSelect;        // 0: run; 1: run only when no cluster spilled out of the arena; 2: only when one did (counters[CNT_RESOLVE_SPILL])
 };
@@ -99,7 +100,8 @@ __global__ void __launch_bounds__(64) k_resolve_setup(GBufferArgs a) {
             const f4 clip = mul_point(p, objectToClip);
             cx[v] = clip.x; cy[v] = clip.y; cw[v] = clip.w;
             a.verts[cs.vertBase + v] = ResolveVertex{p.x, p.y, p.z, n.x, n.y, n.z};
-            if (a.uvs && (cs.counts & BRMI_CS_TEXTURED)) { const f2 uv = decode_uv(a.clusterUv[c], v); a.uvs[cs.vertBase + v] = make_float2(uv.x, uv.y); }
+            if (a.uvs && (cs.counts & BRMI_CS_TEXTURED))
+                for (uint32_t set = 0; set < a.uvSets; set++) { const f2 uv = decode_uv_set(a.clusterUv[c], set, v); a.uvs[(size_t)set * a.vertCapacity + cs.vertBase + v] = make_float2(uv.x, uv.y); }
             if (a.colors && (cs.counts & BRMI_CS_COLOR)) a.colors[cs.vertBase + v] = reinterpret_cast<const uint32_t*>(a.clusterUv[c].color)[v];
         }
         __syncthreads();
@@ -273,7 +275,8 @@ constexpr int RESOLVE_WATERFALL = 4;     // distinct mesh instances per 8x8 tile
 #ifndef BRMI_GB_WAVES
 #define BRMI_GB_WAVES 6
 #endif
-template <bool INLINE_TABLES, bool TEXTURED, bool PARALLAX = false>
+// MULTI_UV: some texture slot of the scene names a UV set > 0 (brmi_set_scene); the common single-set scenes run the variant without the set switching
+template <bool INLINE_TABLES, bool TEXTURED, bool PARALLAX = false, bool MULTI_UV = false>
 #ifndef BRMI_GBT_WAVES
 #define BRMI_GBT_WAVES 3
 #endif
@@ -347,6 +350,15 @@ __global__ void __launch_bounds__(256, INLINE_TABLES ? 1 : (PARALLAX ? BRMI_GBP_
                 }
             } else valid = false;      // cannot happen: the arena holds every cluster of this configuration
         }
+        // the corners' texcoords of a set > 0 (rare: fetched only by the slots that name one)
+        auto corner_uvs = [&](uint32_t set, f2 (&o)[3]) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const uint32_t local = (r.indices >> (8 * k)) & 0xFFu;
+                if (cs.vertBase != BRMI_ARENA_NONE) { const float2 u = set < a.uvSets ? a.uvs[(size_t)set * a.vertCapacity + cs.vertBase + local] : make_float2(0.0f, 0.0f); o[k] = f2{u.x, u.y}; }
+                else o[k] = decode_uv_set(a.clusterUv[clusterIndex], set, local);
+            }
+        };
         const float uvx = ((float)px + 0.5f) / winX, uvy = ((float)py + 0.5f) / winY;
         const float ndcX = uvx * 2.0f - 1.0f, ndcY = (1.0f - uvy) * 2.0f - 1.0f;
         const f3 l = bary_lambda(r, ndcX, ndcY);
@@ -379,11 +391,25 @@ __global__ void __launch_bounds__(256, INLINE_TABLES ? 1 : (PARALLAX ? BRMI_GBP_
                     albedoW = pack_unorm4(mat->baseColorFactor[0] * vertexColor.x, mat->baseColorFactor[1] * vertexColor.y, mat->baseColorFactor[2] * vertexColor.z, 1.0f);
                 const bool layerTex = (mw->pad & 1u) != 0u;
                 if ((flags & BRMI_MATERIAL_ANY_TEXTURE) || layerTex) {
-                    // BuildClodMaterialUvData for UV set 0 + SampleMaterialEvalFromUvCache (utilities.hlsli:1850-2075)
+                    // BuildClodMaterialUvData + SampleMaterialEvalFromUvCache (utilities.hlsli:1850-2075).  uv / dUVdx / dUVdy are the texcoord and
+                    // gradients of `curSet`; use_set() switches them to the set a slot names (AppendClodMaterialUvSample: indices >= 8 mean set 0).
                     const BaryDeriv bd = bary_derivatives(r, l, ndcX, ndcY, winX, winY);
-                    const f3 us{tc[0].x, tc[1].x, tc[2].x}, vs{tc[0].y, tc[1].y, tc[2].y};
-                    f2 uv{dot3(us, l), dot3(vs, l)};
-                    const f2 dUVdx{dot3(us, bd.ddx), dot3(vs, bd.ddx)}, dUVdy{dot3(us, bd.ddy), dot3(vs, bd.ddy)};
+                    f2 uv, dUVdx, dUVdy;
+                    uint32_t curSet = 0u, parallaxSet = 0xFFFFFFFFu; f2 parallaxUv{};
+                    auto interpolate = [&](const f2 (&c)[3]) {
+                        const f3 us{c[0].x, c[1].x, c[2].x}, vs{c[0].y, c[1].y, c[2].y};
+                        uv = f2{dot3(us, l), dot3(vs, l)};
+                        dUVdx = f2{dot3(us, bd.ddx), dot3(vs, bd.ddx)}; dUVdy = f2{dot3(us, bd.ddy), dot3(vs, bd.ddy)};
+                    };
+                    auto use_set = [&](uint32_t setIndex) {
+                        if (!MULTI_UV) return;
+                        const uint32_t set = setIndex < 8u ? setIndex : 0u;
+                        if (set == curSet) return;
+                        curSet = set;
+                        if (set == 0u) interpolate(tc); else { f2 c[3]; corner_uvs(set, c); interpolate(c); }
+                        if (PARALLAX && set == parallaxSet) uv = parallaxUv;      // ResolveMaterialUvSample: the displaced texcoord, the set's own gradients
+                    };
+                    interpolate(tc);
                     // texture / sampler tables in the address space of the material pointer: scalar loads on the waterfall path
                     auto texturesP = as_space_of(mat, sc.textures); auto samplersP = as_space_of(mat, sc.samplers);
                     auto bind = [&](uint32_t ti, uint32_t si) { return bind_texture(texturesP, sc.textureCount, samplersP, sc.samplerCount, ti, si); };
@@ -398,12 +424,15 @@ __global__ void __launch_bounds__(256, INLINE_TABLES ? 1 : (PARALLAX ? BRMI_GBP_
                         const float invmax = rsqrtf_(max2(dot3(T, T), dot3(B, B)));
                         Tn = T * invmax; Bn = B * invmax;
                     };
-                    // with parallax the frame is needed before the fetches; without, building it next to its only use keeps six registers free over them
-                    if (PARALLAX && (flags & (BRMI_MATERIAL_NORMAL_MAP | BRMI_MATERIAL_PARALLAX))) cotangent_frame();
-                    if (PARALLAX && (flags & BRMI_MATERIAL_PARALLAX)) {       // PSO_PARALLAX (utilities.hlsli:1869-1897): every slot shares UV set 0, so all of them move
+                    // with parallax the frame is needed before the fetches; without, building it next to its only use keeps six registers free over them.
+                    // BuildMaterialUvBindings: the frame follows the normal slot's UV set, else the height slot's
+                    if (PARALLAX && (flags & (BRMI_MATERIAL_NORMAL_MAP | BRMI_MATERIAL_PARALLAX))) { use_set((flags & BRMI_MATERIAL_NORMAL_MAP) ? mat->normalUvSetIndex : mat->heightUvSetIndex); cotangent_frame(); }
+                    if (PARALLAX && (flags & BRMI_MATERIAL_PARALLAX)) {       // PSO_PARALLAX (utilities.hlsli:1869-1897): every slot on the height map's UV set moves with it
                         const brmi_camera* cam = sc.cameras + sc.perFrame->mainCameraIndex;
                         const f3 camPos{cam->positionWorldSpace[0], cam->positionWorldSpace[1], cam->positionWorldSpace[2]};
-                        uv = parallax_coords(tb, bind(mat->heightMapIndex, mat->heightSamplerIndex), Tn, Bn, worldNormal, uv, normalize3(camPos - worldPosition), mat->heightMapScale, dUVdx, dUVdy);
+                        use_set(mat->heightUvSetIndex);
+                        parallaxUv = parallax_coords(tb, bind(mat->heightMapIndex, mat->heightSamplerIndex), Tn, Bn, worldNormal, uv, normalize3(camPos - worldPosition), mat->heightMapScale, dUVdx, dUVdy);
+                        parallaxSet = curSet; uv = parallaxUv;
                     }
                     // One loop over the texture slots (one copy of the sampler code).  Metallic, roughness and occlusion usually are
                     // channels of ONE texture (glTF packing): a slot bound like the previous one reuses its fetch.
@@ -412,27 +441,28 @@ __global__ void __launch_bounds__(256, INLINE_TABLES ? 1 : (PARALLAX ? BRMI_GBP_
                     f4 sL0 = one4, sL1 = one4, sL2 = one4, sL3 = one4, sL4 = one4, sL5 = one4;     // coat colour / weight / roughness, fuzz colour / weight / roughness
                     const auto* opRec = as_space_of(mat, sc.openpbrMaterials) + mat->openPBRMaterialDataIndex;
                     {
-                        uint32_t prevTi = 0xFFFFFFFFu, prevSi = 0xFFFFFFFFu; f4 prevSample{};      // same (texture, sampler) pair as the previous slot: same fetch
+                        uint32_t prevTi = 0xFFFFFFFFu, prevSi = 0xFFFFFFFFu, prevSet = 0xFFFFFFFFu; f4 prevSample{};      // same (texture, sampler, UV set) as the previous slot: same fetch
 #pragma nounroll
                         for (uint32_t slot = 0; slot < (layerTex ? 12u : 6u); slot++) {
-                            uint32_t bit, ti, si;
+                            uint32_t bit, ti, si, set;
                             if (slot >= 6u) {       // ApplyOpenPBRTextureSampling (utilities.hlsli:720-846): bound when both indices are valid
-                                ti = opRec->textureBindings[2u * (slot - 6u)]; si = opRec->textureBindings[2u * (slot - 6u) + 1u];
+                                ti = opRec->textureBindings[2u * (slot - 6u)]; si = opRec->textureBindings[2u * (slot - 6u) + 1u]; set = opRec->textureBindings[26u + (slot - 6u)];
                                 if (ti == 0xFFFFFFFFu || si == 0xFFFFFFFFu) continue;
                                 bit = 0u;
                             } else
                             switch (slot) {
-                                case 0: bit = BRMI_MATERIAL_BASE_COLOR_TEXTURE; ti = mat->baseColorTextureIndex; si = mat->baseColorSamplerIndex; break;
-                                case 1: bit = BRMI_MATERIAL_METALLIC_TEXTURE; ti = mat->metallicTextureIndex; si = mat->metallicSamplerIndex; break;
-                                case 2: bit = BRMI_MATERIAL_ROUGHNESS_TEXTURE; ti = mat->roughnessTextureIndex; si = mat->roughnessSamplerIndex; break;
-                                case 3: bit = BRMI_MATERIAL_AO_TEXTURE; ti = mat->aoMapIndex; si = mat->aoSamplerIndex; break;
-                                case 4: bit = BRMI_MATERIAL_NORMAL_MAP; ti = mat->normalTextureIndex; si = mat->normalSamplerIndex; break;
-                                default: bit = BRMI_MATERIAL_EMISSIVE_TEXTURE; ti = mat->emissiveTextureIndex; si = mat->emissiveSamplerIndex; break;
+                                case 0: bit = BRMI_MATERIAL_BASE_COLOR_TEXTURE; ti = mat->baseColorTextureIndex; si = mat->baseColorSamplerIndex; set = mat->baseColorUvSetIndex; break;
+                                case 1: bit = BRMI_MATERIAL_METALLIC_TEXTURE; ti = mat->metallicTextureIndex; si = mat->metallicSamplerIndex; set = mat->metallicUvSetIndex; break;
+                                case 2: bit = BRMI_MATERIAL_ROUGHNESS_TEXTURE; ti = mat->roughnessTextureIndex; si = mat->roughnessSamplerIndex; set = mat->roughnessUvSetIndex; break;
+                                case 3: bit = BRMI_MATERIAL_AO_TEXTURE; ti = mat->aoMapIndex; si = mat->aoSamplerIndex; set = mat->aoUvSetIndex; break;
+                                case 4: bit = BRMI_MATERIAL_NORMAL_MAP; ti = mat->normalTextureIndex; si = mat->normalSamplerIndex; set = mat->normalUvSetIndex; break;
+                                default: bit = BRMI_MATERIAL_EMISSIVE_TEXTURE; ti = mat->emissiveTextureIndex; si = mat->emissiveSamplerIndex; set = mat->emissiveUvSetIndex; break;
                             }
                             if (slot < 6u && !(flags & bit)) continue;
+                            use_set(set);
                             f4 t = prevSample;
-                            if (ti != prevTi || si != prevSi || ti >= sc.textureCount || si >= sc.samplerCount) t = sample_grad(tb, bind(ti, si), uv, dUVdx, dUVdy);
-                            prevTi = ti; prevSi = si; prevSample = t;
+                            if (ti != prevTi || si != prevSi || (MULTI_UV && curSet != prevSet) || ti >= sc.textureCount || si >= sc.samplerCount) t = sample_grad(tb, bind(ti, si), uv, dUVdx, dUVdy);
+                            prevTi = ti; prevSi = si; prevSet = curSet; prevSample = t;
                             if (slot == 0u) sBase = t; else if (slot == 1u) sMetal = t; else if (slot == 2u) sRough = t; else if (slot == 3u) sAo = t; else if (slot == 4u) sNormal = t; else if (slot == 5u) sEmis = t;
                             else if (slot == 6u) sL0 = t; else if (slot == 7u) sL1 = t; else if (slot == 8u) sL2 = t; else if (slot == 9u) sL3 = t; else if (slot == 10u) sL4 = t; else sL5 = t;
                         }
@@ -444,7 +474,7 @@ __global__ void __launch_bounds__(256, INLINE_TABLES ? 1 : (PARALLAX ? BRMI_GBP_
                     if (flags & BRMI_MATERIAL_ROUGHNESS_TEXTURE) roughness = swizzle4(sRough, mat->roughnessChannel) * mat->roughnessFactor;
                     if (flags & BRMI_MATERIAL_AO_TEXTURE) ao = swizzle4(sAo, mat->aoChannel);
                     if (flags & BRMI_MATERIAL_NORMAL_MAP) {
-                        if (!PARALLAX) cotangent_frame();
+                        if (!PARALLAX) { use_set(mat->normalUvSetIndex); cotangent_frame(); }
                         const f4 t = sNormal;
                         f3 tn = normalize3(f3{t.x, t.y, t.z} * 2.0f - f3{1.0f, 1.0f, 1.0f});
                         if (flags & BRMI_MATERIAL_NEGATE_NORMALS) tn = -tn;
@@ -524,7 +554,7 @@ int launch_gbuffer(brmi_pass* p, hipStream_t s) {
     a.matWords = p->wsPtr<MaterialWords>(p->ws.matWords);
     a.used = p->wsPtr<uint8_t>(p->ws.usedClusters);
     a.clusterUv = p->sceneHasTextures ? p->wsPtr<ClusterUv>(p->ws.clusterUv) : nullptr;
-    a.uvs = p->sceneHasTextures ? p->wsPtr<float2>(p->ws.resolveUVs) : nullptr;
+    a.uvs = p->sceneHasTextures ? p->wsPtr<float2>(p->ws.resolveUVs) : nullptr; a.uvSets = p->sceneUvSets;
     a.colors = p->sceneHasVertexColors ? p->wsPtr<uint32_t>(p->ws.resolveColors) : nullptr;
     if (p->sceneHasVertexColors) a.clusterUv = p->wsPtr<ClusterUv>(p->ws.clusterUv);
     hipLaunchKernelGGL(k_mark_used_clusters, dim3(2048), dim3(256), 0, s, a, p->wsPtr<uint8_t>(p->ws.usedClusters), p->counters());
@@ -539,7 +569,9 @@ int launch_gbuffer(brmi_pass* p, hipStream_t s) {
         if (!lean) { a.variantSelect = 2u; hipLaunchKernelGGL(fallbackKernel, dim3(4096), dim3(256), 0, s, a); }
     };
     if (p->sceneHasTextures || p->sceneHasVertexColors) {
-        if (p->sceneHasParallax) launch(k_gbuffer<false, true, true>, k_gbuffer<true, true, true>);      // its own variant: the ray march costs the others registers they would spill
+        const bool multiUv = p->sceneUvSets > 1;
+        if (p->sceneHasParallax) { if (multiUv) launch(k_gbuffer<false, true, true, true>, k_gbuffer<true, true, true, true>); else launch(k_gbuffer<false, true, true>, k_gbuffer<true, true, true>); }   // its own variant: the ray march costs the others registers they would spill
+        else if (multiUv) launch(k_gbuffer<false, true, false, true>, k_gbuffer<true, true, false, true>);
         else launch(k_gbuffer<false, true>, k_gbuffer<true, true>);
     } else launch(k_gbuffer<false, false>, k_gbuffer<true, false>);
     BRMI_LAUNCH_CHECK(p, "k_gbuffer");

@@ -18,8 +18,10 @@
 
 namespace brmi {
 
-// where UV set 0 and the vertex colours of a visible cluster live (written by the compaction kernel next to ClusterSetup); desc == nullptr: the page has no UV set
-struct ClusterUv { const uint8_t* desc; const uint8_t* stream; const uint8_t* color; uint64_t pad; };      // color: the meshlet's RGBA8 vertex colours (nullptr: none)
+// where the UV sets and the vertex colours of a visible cluster live (written by the compaction kernel next to ClusterSetup); desc == nullptr: the page has no UV set.
+// desc / stream address set 0 (the set of the rasteriser's alpha test and of nearly every material); the others are reached through the page's bitstream
+// directory: `directory` = its offset from desc, `setCount` = CLodPageHeader::uvSetCount.
+struct ClusterUv { const uint8_t* desc; const uint8_t* stream; const uint8_t* color; int32_t directory; uint32_t setCount; };      // color: the meshlet's RGBA8 vertex colours (nullptr: none)
 
 BRMI_DEV uint32_t read_packed_bits32(const uint8_t* stream, uint32_t startBit, uint32_t bitCount) {
     if (bitCount == 0u) return 0u;
@@ -41,6 +43,18 @@ BRMI_DEV f2 decode_uv(const ClusterUv& cu, uint32_t vertex) {
     cursor += bitsU;
     const uint32_t ev = read_packed_bits32(cu.stream, cursor, bitsV);
     return {as_f32(d0.y) + (float)eu * as_f32(d0.w), as_f32(d0.z) + (float)ev * as_f32(d1.x)};
+}
+
+// DecodeCompressedUV for any set (clodResolveCommon.hlsli:612-655): descriptors are [meshlet][set], one bitstream per set behind the directory; a set the
+// page does not carry reads (0, 0)
+BRMI_DEV f2 decode_uv_set(const ClusterUv& cu, uint32_t set, uint32_t vertex) {
+    if (set == 0u) return decode_uv(cu, vertex);
+    if (cu.desc == nullptr || set >= cu.setCount) return {0.0f, 0.0f};
+    const uint32_t* dir = reinterpret_cast<const uint32_t*>(cu.desc + cu.directory);
+    ClusterUv s = cu;
+    s.desc = cu.desc + set * 32u;
+    s.stream = cu.stream - dir[0] + dir[set];
+    return decode_uv(s, vertex);
 }
 
 BRMI_DEV int floor_to_int(float f) { return to_int_sat(floorf(f)); }

@@ -285,7 +285,16 @@ void appendBits(std::vector<uint32_t>& words, uint64_t& cursor, uint32_t value, 
     cursor += bitCount;
 }
 
-std::vector<uint8_t> buildPageBlob(const std::vector<const MeshletBuild*>& ms, bool skinned, bool hasUv) {
+// UV set k > 0 of a vertex: an affine image of set 0 (a different scale, skew and offset per set, so every set has its own gradients and descriptor ranges)
+inline void derivedUv(uint32_t set, float u, float v, float& ou, float& ov) {
+    if (set == 0u) { ou = u; ov = v; return; }
+    const float k = (float)set;
+    ou = (0.37f + 0.05f * k) * u + 0.21f * v + 0.11f * k;
+    ov = -0.19f * u + (0.43f + 0.03f * k) * v + 0.30f;
+}
+
+std::vector<uint8_t> buildPageBlob(const std::vector<const MeshletBuild*>& ms, bool skinned, uint32_t uvSets) {
+    const bool hasUv = uvSets != 0u;
     const bool hasColor = !ms.empty() && !ms[0]->color.empty();
     const uint32_t M = (uint32_t)ms.size();
     uint32_t totalVerts = 0, totalTris = 0;
@@ -294,33 +303,38 @@ std::vector<uint8_t> buildPageBlob(const std::vector<const MeshletBuild*>& ms, b
     h.meshletCount = M;
     h.compressedPositionQuantExp = BRMI_POSITION_FORMAT_FLOAT3;
     h.attributeMask = BRMI_PAGE_ATTRIBUTE_NORMAL | (skinned ? (BRMI_PAGE_ATTRIBUTE_JOINTS | BRMI_PAGE_ATTRIBUTE_WEIGHTS) : 0u) | (hasColor ? BRMI_PAGE_ATTRIBUTE_COLOR : 0u);
-    h.uvSetCount = hasUv ? 1u : 0u;
+    h.uvSetCount = uvSets;
     h.descriptorOffset = (uint32_t)align4(sizeof(brmi_page_header));
     size_t cur = h.descriptorOffset + (size_t)M * sizeof(brmi_meshlet_descriptor);
     h.uvDescriptorOffset = 0;
-    // UV set 0: per-meshlet descriptor (min, 1/65535 scale, bit widths) + one bitstream per set (ClusterLODUtilities.cpp:1267-1308,1712-1742)
-    std::vector<brmi_meshlet_uv_descriptor> uvDescs;
-    std::vector<uint32_t> uvWords;
+    // UV sets: descriptors [meshlet][set] (min, 1/65535 scale, bit widths) + one bitstream per set behind a directory (ClusterLODUtilities.cpp:1267-1308,1712-1742)
+    std::vector<brmi_meshlet_uv_descriptor> uvDescs((size_t)M * uvSets);
+    std::vector<std::vector<uint32_t>> uvWords(uvSets);
     if (hasUv) {
         h.uvDescriptorOffset = (uint32_t)align4(cur);
-        cur = h.uvDescriptorOffset + (size_t)M * sizeof(brmi_meshlet_uv_descriptor);
-        uint64_t bitCursor = 0;
-        for (auto* m : ms) {
-            const uint32_t V = m->vertCount();
-            float minU = FLT_MAX, minV = FLT_MAX, maxU = -FLT_MAX, maxV = -FLT_MAX;
-            for (uint32_t v = 0; v < V; v++) { minU = std::min(minU, m->uv[v * 2]); maxU = std::max(maxU, m->uv[v * 2]); minV = std::min(minV, m->uv[v * 2 + 1]); maxV = std::max(maxV, m->uv[v * 2 + 1]); }
-            if (V == 0) minU = minV = maxU = maxV = 0.0f;
-            brmi_meshlet_uv_descriptor d{};
-            d.uvBitOffset = (uint32_t)bitCursor;
-            d.uvMinU = minU; d.uvMinV = minV; d.uvScaleU = 1.0f / BRMI_UV_QUANTIZATION_SCALE; d.uvScaleV = 1.0f / BRMI_UV_QUANTIZATION_SCALE;
-            const uint32_t bitsU = bitsNeededForRange(quantizeUvOffset(std::max(0.0f, maxU - minU))), bitsV = bitsNeededForRange(quantizeUvOffset(std::max(0.0f, maxV - minV)));
-            d.uvBits = (bitsU & 0xFFu) | ((bitsV & 0xFFu) << 8);
-            const uint32_t maxEncU = bitsU >= 32u ? 0xFFFFFFFFu : ((1u << bitsU) - 1u), maxEncV = bitsV >= 32u ? 0xFFFFFFFFu : ((1u << bitsV) - 1u);
-            for (uint32_t v = 0; v < V; v++) {
-                appendBits(uvWords, bitCursor, std::min(maxEncU, quantizeUvOffset(std::max(0.0f, m->uv[v * 2] - minU))), bitsU);
-                appendBits(uvWords, bitCursor, std::min(maxEncV, quantizeUvOffset(std::max(0.0f, m->uv[v * 2 + 1] - minV))), bitsV);
+        cur = h.uvDescriptorOffset + (size_t)M * uvSets * sizeof(brmi_meshlet_uv_descriptor);
+        for (uint32_t set = 0; set < uvSets; set++) {
+            uint64_t bitCursor = 0;
+            for (uint32_t mi = 0; mi < M; mi++) {
+                const MeshletBuild* m = ms[mi];
+                const uint32_t V = m->vertCount();
+                std::vector<float> uv((size_t)V * 2);
+                for (uint32_t v = 0; v < V; v++) derivedUv(set, m->uv[v * 2], m->uv[v * 2 + 1], uv[v * 2], uv[v * 2 + 1]);
+                float minU = FLT_MAX, minV = FLT_MAX, maxU = -FLT_MAX, maxV = -FLT_MAX;
+                for (uint32_t v = 0; v < V; v++) { minU = std::min(minU, uv[v * 2]); maxU = std::max(maxU, uv[v * 2]); minV = std::min(minV, uv[v * 2 + 1]); maxV = std::max(maxV, uv[v * 2 + 1]); }
+                if (V == 0) minU = minV = maxU = maxV = 0.0f;
+                brmi_meshlet_uv_descriptor d{};
+                d.uvBitOffset = (uint32_t)bitCursor;
+                d.uvMinU = minU; d.uvMinV = minV; d.uvScaleU = 1.0f / BRMI_UV_QUANTIZATION_SCALE; d.uvScaleV = 1.0f / BRMI_UV_QUANTIZATION_SCALE;
+                const uint32_t bitsU = bitsNeededForRange(quantizeUvOffset(std::max(0.0f, maxU - minU))), bitsV = bitsNeededForRange(quantizeUvOffset(std::max(0.0f, maxV - minV)));
+                d.uvBits = (bitsU & 0xFFu) | ((bitsV & 0xFFu) << 8);
+                const uint32_t maxEncU = bitsU >= 32u ? 0xFFFFFFFFu : ((1u << bitsU) - 1u), maxEncV = bitsV >= 32u ? 0xFFFFFFFFu : ((1u << bitsV) - 1u);
+                for (uint32_t v = 0; v < V; v++) {
+                    appendBits(uvWords[set], bitCursor, std::min(maxEncU, quantizeUvOffset(std::max(0.0f, uv[v * 2] - minU))), bitsU);
+                    appendBits(uvWords[set], bitCursor, std::min(maxEncV, quantizeUvOffset(std::max(0.0f, uv[v * 2 + 1] - minV))), bitsV);
+                }
+                uvDescs[(size_t)mi * uvSets + set] = d;
             }
-            uvDescs.push_back(d);
         }
     }
     h.positionBitstreamOffset = (uint32_t)align4(cur);
@@ -334,11 +348,11 @@ std::vector<uint8_t> buildPageBlob(const std::vector<const MeshletBuild*>& ms, b
         h.weightArrayOffset = (uint32_t)align4(cur); cur = h.weightArrayOffset + (size_t)totalVerts * 32;
     }
     h.uvBitstreamDirectoryOffset = 0;
-    uint32_t uvBitstreamOffset = 0;
+    std::vector<uint32_t> uvBitstreamOffset(uvSets, 0u);
     if (hasUv) {
         h.uvBitstreamDirectoryOffset = (uint32_t)align4(cur);
-        uvBitstreamOffset = (uint32_t)align4(h.uvBitstreamDirectoryOffset + 4u);      // one directory entry per UV set
-        cur = uvBitstreamOffset + uvWords.size() * 4 + 4;                               // + one word: a 32-bit read may straddle the end
+        cur = align4(h.uvBitstreamDirectoryOffset + 4u * uvSets);                      // one directory entry per UV set
+        for (uint32_t set = 0; set < uvSets; set++) { uvBitstreamOffset[set] = (uint32_t)cur; cur += uvWords[set].size() * 4 + 4; }     // + one word: a 32-bit read may straddle the end
     }
     h.boneIndexStreamOffset = (uint32_t)align4(cur);
     size_t boneWords = 0;
@@ -350,8 +364,8 @@ std::vector<uint8_t> buildPageBlob(const std::vector<const MeshletBuild*>& ms, b
     std::memcpy(blob.data(), &h, sizeof(h));
     if (hasUv) {
         std::memcpy(blob.data() + h.uvDescriptorOffset, uvDescs.data(), uvDescs.size() * sizeof(brmi_meshlet_uv_descriptor));
-        std::memcpy(blob.data() + h.uvBitstreamDirectoryOffset, &uvBitstreamOffset, 4);
-        if (!uvWords.empty()) std::memcpy(blob.data() + uvBitstreamOffset, uvWords.data(), uvWords.size() * 4);
+        std::memcpy(blob.data() + h.uvBitstreamDirectoryOffset, uvBitstreamOffset.data(), uvBitstreamOffset.size() * 4);
+        for (uint32_t set = 0; set < uvSets; set++) if (!uvWords[set].empty()) std::memcpy(blob.data() + uvBitstreamOffset[set], uvWords[set].data(), uvWords[set].size() * 4);
     }
 
     uint32_t posCursor = 0, attrCursor = 0, triCursor = 0, boneCursor = 0;
@@ -393,8 +407,8 @@ std::vector<uint8_t> buildPageBlob(const std::vector<const MeshletBuild*>& ms, b
     return blob;
 }
 
-size_t meshletPageBytes(const MeshletBuild& m, bool skinned, bool hasUv) {
-    return 64 + (size_t)m.vertCount() * 16 + (size_t)m.triCount() * 3 + 4 + (skinned ? (size_t)m.vertCount() * 64 + 16 : 0) + (hasUv ? 32 + (size_t)m.vertCount() * 8 + 8 : 0) + (m.color.empty() ? 0 : (size_t)m.vertCount() * 4 + 4);
+size_t meshletPageBytes(const MeshletBuild& m, bool skinned, uint32_t uvSets) {
+    return 64 + (size_t)m.vertCount() * 16 + (size_t)m.triCount() * 3 + 4 + (skinned ? (size_t)m.vertCount() * 64 + 16 : 0) + (size_t)uvSets * (32 + (size_t)m.vertCount() * 8 + 8) + (m.color.empty() ? 0 : (size_t)m.vertCount() * 4 + 4);
 }
 
 // Built-in LOD DAG: a quadtree over the patch grids (level-L meshlets are 8x8 quads with stride 2^L, groups are 4x4 meshlets).
@@ -613,6 +627,7 @@ bool buildMesh(brmi_scene& sc, const MeshDef& defIn, uint32_t meshIndex) {
     std::vector<MeshletBuild> meshlets;
     std::vector<GroupBuild> groups;
     const bool hasUv = (sc.params.materialFeatures & 24u) != 0u, hasColor = (sc.params.materialFeatures & 32u) != 0u;
+    const uint32_t uvSets = hasUv ? ((sc.params.materialFeatures & 256u) ? 3u : 1u) : 0u;       // materialFeatures bit 8: pages carry three UV sets
     const uint32_t levels = sc.params.lodBuilder != BRMI_LOD_BUILDER_QUADTREE ? buildClusterLodDag(sc, def, hasUv, hasColor, meshlets, groups) : buildQuadtreeDag(def, hasUv, hasColor, meshlets, groups);
     if (levels == 0) { sc.failed = true; return false; }
 
@@ -629,7 +644,7 @@ bool buildMesh(brmi_scene& sc, const MeshDef& defIn, uint32_t meshIndex) {
             std::vector<Sphere> parts; size_t bytes = 0;
             auto close = [&]() { if (s.meshlets.empty()) return; s.cull = enclose(parts); segs.push_back(s); s.meshlets.clear(); parts.clear(); bytes = 0; };
             for (uint32_t mi : g.meshlets) if (meshlets[mi].refinedGroup == k) {
-                const size_t need = meshletPageBytes(meshlets[mi], def.skinned, hasUv);
+                const size_t need = meshletPageBytes(meshlets[mi], def.skinned, uvSets);
                 if (bytes + need + 256 > BRMI_PAGE_SIZE) close();
                 s.meshlets.push_back(mi); parts.push_back(meshlets[mi].bounds); bytes += need;
             }
@@ -646,12 +661,12 @@ bool buildMesh(brmi_scene& sc, const MeshDef& defIn, uint32_t meshIndex) {
         size_t bytes = 64;
         auto flush = [&]() {
             if (cur.empty()) return;
-            auto blob = buildPageBlob(cur, def.skinned, hasUv);
+            auto blob = buildPageBlob(cur, def.skinned, uvSets);
             sc.pageMap.push_back(allocPage(sc, blob));
             cur.clear(); curSegs.clear(); bytes = 64;
         };
         for (size_t si = 0; si < segs.size(); si++) {
-            size_t need = 64; for (uint32_t mi : segs[si].meshlets) need += meshletPageBytes(meshlets[mi], def.skinned, hasUv);
+            size_t need = 64; for (uint32_t mi : segs[si].meshlets) need += meshletPageBytes(meshlets[mi], def.skinned, uvSets);
             if (bytes + need > BRMI_PAGE_SIZE) flush();
             segs[si].pageIndex = (uint32_t)(sc.pageMap.size() - pageMapBase);
             segs[si].firstMeshletInPage = (uint32_t)cur.size();
@@ -1150,6 +1165,17 @@ void addMaterials(brmi_scene& sc, Pcg32& rng, uint32_t count) {
             m.heightMapIndex = tex.height[i % tex.height.size()]; m.heightSamplerIndex = (i % 4) == 1 ? 2u : 0u;
             m.heightMapScale = 0.02f + 0.01f * (float)(i % 7);
         }
+        // materialFeatures bit 8 (with bit 3): texture slots spread over the pages' three UV sets -- packed slots sharing a set, the normal map (and with it
+        // the tangent frame) on its own set, the height map on a set only some slots share, an index past the page's sets (reads (0, 0)) and one >= 8 (reads set 0)
+        if ((sc.params.materialFeatures & 256u) && (m.materialFlags & BRMI_MATERIAL_TEXTURED)) {
+            switch (i % 5) {
+                case 0: m.aoUvSetIndex = 1; m.metallicUvSetIndex = 1; m.roughnessUvSetIndex = 1; m.emissiveUvSetIndex = 2; break;
+                case 1: m.normalUvSetIndex = 1; m.heightUvSetIndex = 1; m.baseColorUvSetIndex = 1; break;
+                case 2: m.baseColorUvSetIndex = 2; m.emissiveUvSetIndex = 1; m.normalUvSetIndex = 2; break;
+                case 3: m.heightUvSetIndex = 2; m.baseColorUvSetIndex = 2; m.metallicUvSetIndex = 1; m.roughnessUvSetIndex = 2; break;
+                default: m.baseColorUvSetIndex = 9; m.metallicUvSetIndex = 3; m.roughnessUvSetIndex = 3; m.aoUvSetIndex = 1; break;
+            }
+        }
         if (alphaTested && (i % 3) == 0) {
             m.materialFlags |= BRMI_MATERIAL_ALPHA_TEST | BRMI_MATERIAL_TEXTURED | BRMI_MATERIAL_BASE_COLOR_TEXTURE;
             m.baseColorTextureIndex = tex.base[i % tex.base.size()]; m.baseColorSamplerIndex = (i / 3) % 3u;     // linear-filtered samplers cut through the soft edge
@@ -1194,6 +1220,9 @@ void addMaterials(brmi_scene& sc, Pcg32& rng, uint32_t count) {
                 o.textureBindings[8] = tex.orm[i % tex.orm.size()]; o.textureBindings[9] = 0; o.textureBindings[23] = 1;      // fuzz weight: G
                 o.textureBindings[10] = tex.orm[i % tex.orm.size()]; o.textureBindings[11] = 0; o.textureBindings[24] = 0;    // fuzz roughness: R (same binding: one fetch)
             }
+        }
+        if ((sc.params.materialFeatures & 256u) && textured) {      // bit 8: the coat weight and fuzz colour slots on other UV sets (textureBindings[26..31] = the slots' set indices)
+            o.textureBindings[26 + 1] = 1; o.textureBindings[26 + 3] = 2; if (i % 2) o.textureBindings[26 + 5] = 1;
         }
         sc.openpbr.push_back(o);
     }

@@ -69,7 +69,8 @@ typedef struct brmi_scene_params {
                                      bit 4: every third material is alpha tested against its base-colour / opacity texture (implies bit 3),
                                      bit 5: pages carry RGBA8 vertex colours (CLOD_PAGE_ATTRIBUTE_COLOR) that tint the base colour,
                                      bit 6: coat / fuzz materials (bits 0 / 1) also bind OpenPBR layer textures (needs bit 3),
-                                     bit 7: about half of the textured materials (bit 3) carry a height map with MATERIAL_PARALLAX (default: none) */
+                                     bit 7: about half of the textured materials (bit 3) carry a height map with MATERIAL_PARALLAX (default: none),
+                                     bit 8: pages carry three UV sets and the materials' texture slots (bit 3, with 6 / 7 also the layer and height slots) are spread over them */
     uint32_t cameraStep;          /* frame number on the preset's camera path (0 = start); prevView is the view of step - 1 */
     uint32_t lodBuilder;          /* enum brmi_lod_builder */
     uint32_t spotLightEvery;      /* k > 0: every k-th punctual light is a spot light (0 = point lights only) */

@@ -31,6 +31,8 @@ GOLDEN_CASES = {
     "golden_sponza_all_features": ("sponza", 192, 108, dict(point_lights=12, seed=4, size_scale=0.05, lod_levels=2, material_features=127, spot_every=3)),
     # contact-refinement parallax (height maps, with and without a normal map, rays that never hit) on top of textures + layer textures
     "golden_tiny_parallax": ("tiny", 160, 90, dict(point_lights=4, seed=13, lod_levels=2, material_features=128 | 64 | 8 | 3)),
+    # three UV sets per page, texture slots (material, OpenPBR layer and height slots) spread over them
+    "golden_tiny_uv_sets": ("tiny", 160, 90, dict(point_lights=4, seed=17, lod_levels=2, material_features=256 | 128 | 64 | 16 | 8 | 3)),
 }
 
 

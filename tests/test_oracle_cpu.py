@@ -15,7 +15,7 @@ def _golden(name):
     return np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
 
 
-@pytest.mark.parametrize("name", ["golden_tiny", "golden_tiny_lod_coat_fuzz", "golden_sponza", "golden_tiny_skinned_occlusion", "golden_tiny_textured_alpha", "golden_sponza_all_features", "golden_tiny_parallax"])
+@pytest.mark.parametrize("name", ["golden_tiny", "golden_tiny_lod_coat_fuzz", "golden_sponza", "golden_tiny_skinned_occlusion", "golden_tiny_textured_alpha", "golden_sponza_all_features", "golden_tiny_parallax", "golden_tiny_uv_sets"])
 def test_oracle_reproduces_golden_fixtures(name):
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
@@ -235,34 +235,61 @@ def test_sample_grad_picks_the_level_of_the_footprint(texscene):
     assert np.array_equal(ts.sample_grad(0, 0, uv, z, z), ts.sample_level(0, 0, uv, np.zeros(200, dtype=np.float32)))
 
 
-def test_uv_streams_decode_like_a_bignum_restatement_of_the_packer(texscene):
-    """SWDecodeCompressedUV against an independent decode (Python integers over the raw page bytes) for every visible cluster; the
-    quantisation the generator applies is the reference's (min + q / 65535, bits = bit length of the quantised range)."""
+def _check_uv_streams(ts, sets):
     import orc
-    ts = texscene
     f = orc.OracleFrame(ts.scene)
     f.cull()
     assert f.count > 0
-    out = np.zeros((128, 2), dtype=np.float32)
+    out = np.zeros((sets + 1, 128, 2), dtype=np.float32)
     for ci in range(f.count):
         c = f.clusters[ci]
-        n = ts.lib.orc_cluster_uvs(C.byref(ts.sb), c.ctypes.data_as(C.c_void_p), C.c_uint32(0), out.ctypes.data_as(C.c_void_p))
         slab = ts.scene.slabs[(int(c[2]) >> 2) & 0xFFFFF]
         page = ((int(c[2]) >> 22) & 0x3FF) << 18
         hdr = slab[page: page + 64].view(np.uint32)
         uv_sets, uv_desc_off, uv_dir_off, meshlet = int(hdr[3]), int(hdr[5]), int(hdr[11]), int(c[1]) & 0x3FFF
-        assert uv_sets == 1
-        d = slab[page + uv_desc_off + meshlet * 32: page + uv_desc_off + meshlet * 32 + 32]
-        bit_off = int(d[:4].view(np.uint32)[0]); mn_u, mn_v, sc_u, sc_v = d[4:20].view(np.float32); bits = int(d[20:24].view(np.uint32)[0])
-        bu, bv = bits & 0xFF, (bits >> 8) & 0xFF
-        assert 1 <= bu <= 20 and 1 <= bv <= 20 and sc_u == np.float32(1.0 / 65535.0)
-        stream = page + int(slab[page + uv_dir_off: page + uv_dir_off + 4].view(np.uint32)[0])
-        big = int.from_bytes(slab[stream: stream + ((bit_off + n * (bu + bv) + 63) // 8)].tobytes(), "little")
-        for v in range(n):
-            cur = bit_off + v * (bu + bv)
-            eu = (big >> cur) & ((1 << bu) - 1); ev = (big >> (cur + bu)) & ((1 << bv) - 1)
-            assert out[v, 0] == np.float32(mn_u + np.float32(eu) * sc_u) and out[v, 1] == np.float32(mn_v + np.float32(ev) * sc_v)
-        assert eu <= (1 << bu) - 1
+        assert uv_sets == sets
+        for s in range(sets + 1):
+            n = ts.lib.orc_cluster_uvs(C.byref(ts.sb), c.ctypes.data_as(C.c_void_p), C.c_uint32(s), out[s].ctypes.data_as(C.c_void_p))
+            if s == sets:                          # a set the page does not carry reads (0, 0)
+                assert not out[s, :n].any()
+                continue
+            d0 = page + uv_desc_off + (meshlet * sets + s) * 32              # descriptors are [meshlet][set]
+            d = slab[d0: d0 + 32]
+            bit_off = int(d[:4].view(np.uint32)[0]); mn_u, mn_v, sc_u, sc_v = d[4:20].view(np.float32); bits = int(d[20:24].view(np.uint32)[0])
+            bu, bv = bits & 0xFF, (bits >> 8) & 0xFF
+            assert 1 <= bu <= 20 and 1 <= bv <= 20 and sc_u == np.float32(1.0 / 65535.0)
+            stream = page + int(slab[page + uv_dir_off + 4 * s: page + uv_dir_off + 4 * s + 4].view(np.uint32)[0])       # one bitstream per set behind the directory
+            big = int.from_bytes(slab[stream: stream + ((bit_off + n * (bu + bv) + 63) // 8)].tobytes(), "little")
+            for v in range(n):
+                cur = bit_off + v * (bu + bv)
+                eu = (big >> cur) & ((1 << bu) - 1); ev = (big >> (cur + bu)) & ((1 << bv) - 1)
+                assert out[s, v, 0] == np.float32(mn_u + np.float32(eu) * sc_u) and out[s, v, 1] == np.float32(mn_v + np.float32(ev) * sc_v)
+            assert eu <= (1 << bu) - 1
+        # the generator's sets 1.. are affine images of set 0: every set decodes to ITS texcoords (up to two quantisation steps)
+        for s in range(1, sets):
+            k = np.float32(s)
+            eu = (0.37 + 0.05 * k) * out[0, :n, 0] + 0.21 * out[0, :n, 1] + 0.11 * k
+            ev = -0.19 * out[0, :n, 0] + (0.43 + 0.03 * k) * out[0, :n, 1] + 0.30
+            assert np.abs(out[s, :n, 0] - eu).max() < 4.0 / 65535.0 and np.abs(out[s, :n, 1] - ev).max() < 4.0 / 65535.0
+
+
+def test_uv_streams_decode_like_a_bignum_restatement_of_the_packer(texscene):
+    """SWDecodeCompressedUV against an independent decode (Python integers over the raw page bytes) for every visible cluster; the
+    quantisation the generator applies is the reference's (min + q / 65535, bits = bit length of the quantised range)."""
+    _check_uv_streams(texscene, 1)
+
+
+def test_every_uv_set_of_a_page_decodes_through_its_own_descriptor_and_stream():
+    """Pages with three UV sets (descriptors [meshlet][set], one bitstream per set behind the directory; clodResolveCommon.hlsli:612-655): each set against the
+    independent decode, and a set index past the page's count reads (0, 0)."""
+    class TS:
+        pass
+    import orc
+    from conftest import Scene
+    ts = TS()
+    ts.scene = Scene("tiny", 160, 90, point_lights=2, lod_levels=2, material_features=256 | 24)
+    ts.sb = ts.scene.host_buffers(); ts.lib = orc.lib()
+    _check_uv_streams(ts, 3)
 
 
 def test_alpha_test_cuts_holes_and_only_in_alpha_tested_materials(texscene):

@@ -122,7 +122,7 @@ def test_depth_and_gbuffer_bit_exact(name, gpu_frames, oracle_frames):
         assert not bad.any(), f"{key}: {int(bad.sum())} of {bad.size} values differ"
 
 
-@pytest.mark.parametrize("name", ["golden_tiny", "golden_tiny_lod_coat_fuzz", "golden_sponza", "golden_tiny_textured_alpha", "golden_sponza_all_features", "golden_tiny_parallax"])
+@pytest.mark.parametrize("name", ["golden_tiny", "golden_tiny_lod_coat_fuzz", "golden_sponza", "golden_tiny_textured_alpha", "golden_sponza_all_features", "golden_tiny_parallax", "golden_tiny_uv_sets"])
 def test_gpu_reproduces_the_committed_golden_fixtures(name):
     """The frozen fixtures under tests/golden/ (inputs regenerated from the seed, expected outputs committed): a reference that does
     not move with the oracle's source."""
@@ -343,39 +343,44 @@ def test_dangling_scene_indices_are_refused():
     VisibilityRenderer(scene()).close()
 
 
-def test_unsupported_material_bindings_are_refused():
-    """What this path does not decode is rejected by brmi_set_scene with a message, never rendered wrong: a missing texture table,
-    a texture slot (or the parallax height map) on a UV set other than 0."""
+def test_missing_texture_table_is_refused():
+    """Materials that sample textures without a texture table are rejected by brmi_set_scene with a message, never rendered wrong."""
     from conftest import Scene
     from basicrenderer_amd.renderer import VisibilityRenderer, BrmiError
-    mat_words = 276 // 4
-
-    def scene():
-        return Scene("tiny", 128, 72, point_lights=1, lod_levels=2, material_features=8)
-
-    sc = scene()
-    sc.counts["textureDescs"] = 0                                   # materials sample textures, no table
+    sc = Scene("tiny", 128, 72, point_lights=1, lod_levels=2, material_features=8)
+    sc.counts["textureDescs"] = 0
     with pytest.raises(BrmiError, match="texture"):
         VisibilityRenderer(sc)
-    sc = scene()
+    VisibilityRenderer(Scene("tiny", 128, 72, point_lights=1, lod_levels=2, material_features=8)).close()
+
+
+def test_texture_slots_on_other_uv_sets_match_the_oracle():
+    """A caller's materials naming UV sets the pages do and do not carry (AppendClodMaterialUvSample / BuildMaterialUvBindings, utilities.hlsli:1850-1897): the
+    pages here hold ONE set, so a slot on set 1..7 samples texcoord (0, 0) with zero gradients, an index >= 8 reads set 0, and a height map on its own set displaces
+    only the slots that share it -- G-buffer exact against the oracle on the edited scene."""
+    import orc
+    from conftest import Scene
+    from basicrenderer_amd.renderer import VisibilityRenderer
+    mat_words = 276 // 4
+    sc = Scene("tiny", 160, 90, point_lights=3, lod_levels=2, material_features=128 | 64 | 8 | 3)
     m = sc.arrays["materials"].view(np.uint32).reshape(-1, mat_words)
-    textured = np.nonzero(m[:, 0] & 2)[0][0]
-    m[textured, 52] = 1                                              # baseColorUvSetIndex (word 52 of MaterialInfo)
-    with pytest.raises(BrmiError, match="UV set 0"):
-        VisibilityRenderer(sc)
-    sc = scene()
-    m = sc.arrays["materials"].view(np.uint32).reshape(-1, mat_words)
-    m[textured, 0] |= 1 << 9                                         # MATERIAL_PARALLAX ...
-    m[textured, 58] = 3                                              # ... with heightUvSetIndex (word 58) = 3
-    with pytest.raises(BrmiError, match="height map must use UV set 0"):
-        VisibilityRenderer(sc)
-    sc = scene()
+    textured = np.nonzero(m[:, 0] & 2)[0]
+    m[textured[0::3], 52] = 1                                         # baseColorUvSetIndex (word 52 of MaterialInfo): a set the pages lack
+    m[textured[1::3], 52] = 11                                        # >= 8: set 0
+    m[textured[1::3], 56] = 2                                         # emissiveUvSetIndex
+    m[textured[2::3], 58] = 3                                         # heightUvSetIndex: parallax (where enabled) moves no other slot
     op = sc.arrays["openpbrMaterials"].view(np.uint32).reshape(-1, 100)
-    op[0, 62:64] = 0                                                 # coatColorTextureIndex / SamplerIndex = 0: a bound OpenPBR layer texture ...
-    op[0, 62 + 26] = 2                                               # ... on UV set 2
-    with pytest.raises(BrmiError, match="UV set 0"):
-        VisibilityRenderer(sc)
-    VisibilityRenderer(scene()).close()                              # the untouched scene is accepted
+    op[:, 62 + 26 + 1] = 2                                            # coat weight slot on set 2
+    r = VisibilityRenderer(sc)
+    r.execute()
+    o = orc.OracleFrame(sc).run()
+    covered = o.vis != np.uint64(0xFFFFFFFFFFFFFFFF)
+    assert np.array_equal(r.visibility(), o.vis)
+    g = r.gbuffer()
+    for name, want in (("normals", o.normals), ("albedo", o.albedo), ("mr", o.mr), ("emissive", o.emissive), ("coat", o.coat), ("fuzz", o.fuzz)):
+        got = g[name][covered]
+        assert np.array_equal(got.view(np.uint8), want[covered].view(np.uint8)), name
+    r.close()
 
 
 @pytest.mark.parametrize("preset,lights", [("sponza", 64), ("bistro", 256)])
@@ -867,6 +872,9 @@ SWEEP = [
     ("sponza", 451, 333, dict(seed=17, point_lights=20, size_scale=0.12, lod_levels=3, material_features=24 | 3), dict(occlusion=True)),
     ("san_miguel", 640, 360, dict(seed=18, point_lights=24, size_scale=0.02, material_features=24), dict(occlusion=True)),
     ("bistro", 500, 281, dict(seed=19, point_lights=30, size_scale=0.2, material_features=32 | 8 | 4, skinned_fraction=0.2), dict(occlusion=True)),
+    # three UV sets per page, slots spread over them: with layer textures + parallax + alpha test, and on the mesh builder's clusters
+    ("sponza", 451, 333, dict(seed=20, point_lights=20, size_scale=0.12, lod_levels=3, material_features=256 | 128 | 64 | 24 | 3), dict(occlusion=True)),
+    ("bistro", 640, 360, dict(seed=21, point_lights=30, size_scale=0.1, material_features=256 | 32 | 8, lod_builder="own"), dict()),
 ]
 
 
