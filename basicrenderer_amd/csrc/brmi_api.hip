@@ -451,6 +451,33 @@ int brmi_update(brmi_pass* p, const brmi_frame_update* u, brmi_stream stream) {
         }
         p->planesHost[2 * sliceZ] = pn; p->planesHost[2 * sliceZ + 1] = pfar;
     }
+    // sliceStart[s] = smallest view depth whose cluster slice (ComputeClusterID, lighting.hlsli:166-196) is >= s: the formula is monotone in
+    // depth, so the shading pass finds a pixel's slice by comparing against this table instead of two divisions and a logarithm.  Bisection
+    // over the positive floats with the shader's own formula; `log` is the correctly rounded fp32 logarithm (through fp64).  Re-evaluated
+    // only when the depth range or the grid changes.
+    if (p->sliceStartHost.empty() || p->sliceKey[0] != zNear || p->sliceKey[1] != zFar || p->sliceKey[2] != zSplit || p->sliceKeyN[0] != nearSlices || p->sliceKeyN[1] != gz) {
+        auto log_cr = [](float x) { return (float)std::log((double)x); };
+        const float logStart = log_cr(zSplit / zNear), logEnd = log_cr(zFar / zNear);
+        auto slice_of = [&](float z) -> uint32_t {
+            if (z < zSplit) { const float t = (z - zNear) / (zSplit - zNear); return t > 0.0f ? (uint32_t)std::min(t * (float)nearSlices, 4294967040.0f) : 0u; }
+            const float logZ = log_cr(z / zNear);
+            const float u = (logZ - logStart) / (logEnd - logStart);
+            return nearSlices + (u > 0.0f ? (uint32_t)std::min(u * (float)(gz - nearSlices), 4294967040.0f) : 0u);
+        };
+        auto bits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+        auto flt = [](uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; };
+        p->sliceStartHost.assign(gz + 2, 0.0f);
+        p->sliceStartHost[gz + 1] = flt(0x7F800000u);
+        for (uint32_t i = 1; i <= gz; i++) {
+            // lo fails, hi passes.  The search stops at 1e30 (z / zNear must stay finite for the float -> uint conversion of the formula to
+            // be defined); a slice that starts beyond it starts at +inf.
+            uint32_t lo = 0u, hi = bits(1.0e30f);
+            if (slice_of(1.0e30f) < i) lo = hi = 0x7F800000u;
+            while (hi - lo > 1u) { const uint32_t mid = lo + ((hi - lo) >> 1); if (slice_of(flt(mid)) >= i) hi = mid; else lo = mid; }
+            p->sliceStartHost[i] = flt(hi);
+        }
+        p->sliceKey[0] = zNear; p->sliceKey[1] = zFar; p->sliceKey[2] = zSplit; p->sliceKeyN[0] = nearSlices; p->sliceKeyN[1] = gz;
+    }
     {   // band planes of the screen-tile split, 2 px of slack (view space, through the eye)
         const float projY = p->camHost.projection[1][1], H = (float)p->cfg.height;
         const float T = 1.0f - 2.0f * ((float)p->bandY0 - 2.0f) / H, B = 1.0f - 2.0f * ((float)p->bandY1 + 2.0f) / H;
@@ -458,8 +485,7 @@ int brmi_update(brmi_pass* p, const brmi_frame_update* u, brmi_stream stream) {
         p->bandPlaneTop[0] = 0.0f; p->bandPlaneTop[1] = -projY / lt; p->bandPlaneTop[2] = -T / lt;
         p->bandPlaneBottom[0] = 0.0f; p->bandPlaneBottom[1] = projY / lb; p->bandPlaneBottom[2] = B / lb;
     }
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    BRMI_HIP(p, hipMemcpyAsync(p->wsPtr<float>(p->ws.planes), p->planesHost.data(), p->planesHost.size() * 4, hipMemcpyHostToDevice, s));
+    (void)stream;      // nothing is uploaded: the slice planes are kernel arguments of the light clustering, everything else is derived on the device
     p->updated = true;
     p->updateSerial++;       // the per-frame constants are re-evaluated by the next stage call
     return BRMI_OK;
@@ -534,7 +560,10 @@ int brmi_execute(brmi_pass* p, brmi_stream stream) {
     if (p->cfg.enableOcclusionCulling) {
         // reference graph: LinearDepthCopyPass1 -> LinearDepthDownsamplePass1 -> HierarchicalCullingPass2 -> ...RasterizeClustersPass2
         // -> LinearDepthCopyPass2 -> LinearDepthDownsamplePass2 (CLodExtension.cpp:1920-2088)
-        if ((rc = build_hzb_fused(p, static_cast<hipStream_t>(stream), true, false))) return rc;
+        p->seedInHzbTail = true;
+        rc = build_hzb_fused(p, static_cast<hipStream_t>(stream), true, false);
+        p->seedInHzbTail = false;
+        if (rc) return rc;
         if ((rc = brmi_cull(p, 2, stream))) return rc;
         if ((rc = brmi_raster(p, 2, stream))) return rc;
     }

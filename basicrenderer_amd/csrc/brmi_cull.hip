@@ -722,13 +722,39 @@ __global__ void __launch_bounds__(256) k_scan_words(const uint32_t* bitmask, uin
 // Places every survivor at its rank.  Also accumulates the vertex / triangle totals of the clusters that will be
 // rasterised (statistics for the algorithmic-byte count), one atomic per wave: a per-cluster atomic on three
 // shared words would serialise the whole rasteriser (~90 same-address atomics per microsecond).
+// LOCAL_RANK (survivor bitmasks of <= LOCAL_RANK_WORDS words: every BASELINE-class scene): no rank kernel runs before this one; every
+// workgroup that has survivors to place scans the popcounts itself into LDS (a few thousand L2-resident words), workgroup 0 publishes the
+// total.  One ~5 us launch less per culling phase.
+constexpr uint32_t LOCAL_RANK_WORDS = 8192;
+struct LocalRank { uint32_t totalWords, outIndex, usedIndex; };
+template <bool LOCAL_RANK>
 __global__ void __launch_bounds__(256) k_scatter_visible(const TempVisible* temp, uint32_t* counters, uint32_t tempCountIndex, const uint32_t* bitmask,
                                                         const uint32_t* wordPrefix, uint4* visible, uint32_t baseIndexCounter, uint32_t capacity, uint32_t visibleCapacity,
-                                                        brmi_scene_buffers sc, ClusterSetup* setup, uint32_t resolveCapacity, uint8_t* used, ClusterUv* clusterUv) {
+                                                        brmi_scene_buffers sc, ClusterSetup* setup, uint32_t resolveCapacity, uint8_t* used, ClusterUv* clusterUv, LocalRank lr) {
     const uint8_t* const* slabs = sc.slabs;
     const uint32_t n = min(counters[tempCountIndex], visibleCapacity);
     const uint32_t base = baseIndexCounter == 0xFFFFFFFFu ? 0u : counters[baseIndexCounter];
     const uint32_t rounded = (n + 63u) & ~63u;
+    __shared__ uint32_t prefixLds[LOCAL_RANK ? LOCAL_RANK_WORDS : 1];
+    __shared__ uint32_t waveTotals[4];
+    if (LOCAL_RANK) {
+        if (blockIdx.x != 0u && blockIdx.x * blockDim.x >= rounded) return;       // nothing to place here (workgroup 0 always publishes the total)
+        const uint32_t span = (lr.totalWords + 255u) / 256u;
+        const uint32_t w0 = threadIdx.x * span, w1 = min(w0 + span, lr.totalWords);
+        uint32_t sum = 0;
+        for (uint32_t w = w0; w < w1; w++) sum += __popc(bitmask[w]);
+        uint32_t incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o); if ((threadIdx.x & 63u) >= (uint32_t)o) incl += t; }
+        if ((threadIdx.x & 63u) == 63u) waveTotals[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        uint32_t waveBase = 0, all = 0;
+        for (uint32_t w = 0; w < 4; w++) { if (w < (threadIdx.x >> 6)) waveBase += waveTotals[w]; all += waveTotals[w]; }
+        uint32_t run = waveBase + incl - sum;
+        for (uint32_t w = w0; w < w1; w++) { prefixLds[w] = run; run += __popc(bitmask[w]); }
+        if (blockIdx.x == 0u && threadIdx.x == 0u) counters[lr.outIndex] = min(all, capacity - (lr.usedIndex == 0xFFFFFFFFu ? 0u : min(counters[lr.usedIndex], capacity)));
+        __syncthreads();
+    }
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += gridDim.x * blockDim.x) {
         uint32_t verts = 0, tris = 0, placed = 0, dst = 0;
         TempVisible t{};
@@ -737,7 +763,7 @@ __global__ void __launch_bounds__(256) k_scatter_visible(const TempVisible* temp
         if (i < n) {
             t = temp[i];
             const uint32_t w = t.bit >> 5, b = t.bit & 31u;
-            const uint32_t rank = wordPrefix[w] + __popc(bitmask[w] & ((1u << b) - 1u));
+            const uint32_t rank = (LOCAL_RANK ? prefixLds[w] : wordPrefix[w]) + __popc(bitmask[w] & ((1u << b) - 1u));
             dst = base + rank;
             if (dst < capacity) {
                 visible[dst] = t.packed;
@@ -819,16 +845,7 @@ static inline uint32_t grid_for(uint64_t items, uint32_t block, uint32_t maxBloc
 
 // phase 2 starts from the replay buffers: the replayed meshlets become the first bucket records, the replayed nodes the
 // level-0 frontier; per-level frontier counters start from zero
-__global__ void k_seed_phase2(uint32_t* counters, uint32_t capacity) {
-    const uint32_t t = threadIdx.x;
-    if (t == 0) { counters[CNT_REPLAY_NODES] = min(counters[CNT_REPLAY_NODES], capacity); counters[CNT_BUCKETS] = min(counters[CNT_REPLAY_MESHLETS], capacity); counters[CNT_TEMP_VISIBLE2] = 0; counters[CNT_VISIBLE2] = 0; }
-    if (t < CNT_STRIPES - CNT_FRONTIER0) counters[CNT_FRONTIER0 + t] = 0;
-    if (t < CNT_STRIPE_COUNT) {      // raster overflow queues of phase 1: count them, then empty them for phase 2
-        uint32_t* q = &counters[CNT_STRIPES + t * CNT_STRIPE_WORDS + STRIPE_OVERFLOW];
-        if (*q) atomicAdd(&counters[CNT_BIN_OVERFLOW], *q);
-        *q = 0u;
-    }
-}
+__global__ void k_seed_phase2(uint32_t* counters, uint32_t capacity) { seed_phase2(counters, capacity, threadIdx.x); }
 
 int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
     if (int rc = ensure_frame_constants(p, s)) return rc;
@@ -877,7 +894,9 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
         if (levelKernels) hipLaunchKernelGGL(k_cull_instances, dim3(grid_for(p->scene.activeDrawCount, 256, maxBlocks)), dim3(256), 0, s, a, fa);
         BRMI_LAUNCH_CHECK(p, "k_cull_instances");
     } else {
-        hipLaunchKernelGGL(k_seed_phase2, dim3(1), dim3(128), 0, s, p->counters(), a.recordCapacity);
+        // brmi_execute seeds in the tail of the depth-chain build that precedes this call (one launch less)
+        if (!p->phase2Seeded) hipLaunchKernelGGL(k_seed_phase2, dim3(1), dim3(128), 0, s, p->counters(), a.recordCapacity);
+        p->phase2Seeded = false;
         if (hierarchy && p->minLevelWidth <= 256u) hipLaunchKernelGGL((k_cull_hierarchy<true, 256, 128>), dim3(2048), dim3(64), 0, s, a, buckets, meshWidth, 0u, 256u);
         if (hierarchy && p->maxLevelWidth > 256u) hipLaunchKernelGGL((k_cull_hierarchy<true, 1024, 128>), dim3(2048), dim3(64), 0, s, a, buckets, meshWidth, 257u, HIER_CAP_MAX);
     }
@@ -895,16 +914,22 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
     BRMI_LAUNCH_CHECK(p, "k_cull_clusters");
     // phase 2 appends behind the phase-1 clusters: its capacity is what phase 1 left
     const uint32_t outIndex = phase == 1 ? CNT_VISIBLE : CNT_VISIBLE2, usedIndex = phase == 1 ? 0xFFFFFFFFu : (uint32_t)CNT_VISIBLE;
-    if (p->totalWords <= RANK_FUSED_WORDS && !p->forceLevelKernels) {
+    const bool localRank = p->totalWords <= LOCAL_RANK_WORDS && !p->forceLevelKernels;
+    if (localRank) {
+        // ranked inside the scatter kernel
+    } else if (p->totalWords <= RANK_FUSED_WORDS && !p->forceLevelKernels) {
         hipLaunchKernelGGL(k_rank_fused, dim3(1), dim3(1024), 0, s, bitmask, p->totalWords, wordPrefix, p->counters(), outIndex, p->cfg.maxVisibleClusters, usedIndex);
     } else {
         hipLaunchKernelGGL(k_scan_reduce, dim3(p->scanBlocks), dim3(256), 0, s, bitmask, p->totalWords, blockSums);
         hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, blockSums, p->scanBlocks, p->counters(), outIndex, p->cfg.maxVisibleClusters, usedIndex);
         hipLaunchKernelGGL(k_scan_words, dim3(p->scanBlocks), dim3(256), 0, s, bitmask, p->totalWords, blockSums, wordPrefix);
     }
-    hipLaunchKernelGGL(k_scatter_visible, dim3(smallGrid), dim3(256), 0, s, temp, p->counters(), (uint32_t)(phase == 1 ? CNT_TEMP_VISIBLE : CNT_TEMP_VISIBLE2), bitmask, wordPrefix,
-                       static_cast<uint4*>(p->res[BRMI_RES_VISIBLE_CLUSTERS]), phase == 1 ? 0xFFFFFFFFu : (uint32_t)CNT_VISIBLE, p->cfg.maxVisibleClusters, p->cfg.maxVisibleClusters, p->scene, p->wsPtr<ClusterSetup>(p->ws.clusterSetup), p->resolveCapacity, p->wsPtr<uint8_t>(p->ws.usedClusters),
-                       (p->sceneHasTextures || p->sceneHasAlphaTest || p->sceneHasVertexColors) ? p->wsPtr<ClusterUv>(p->ws.clusterUv) : nullptr);
+    auto scatter = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(smallGrid), dim3(256), 0, s, temp, p->counters(), (uint32_t)(phase == 1 ? CNT_TEMP_VISIBLE : CNT_TEMP_VISIBLE2), bitmask, wordPrefix,
+                           static_cast<uint4*>(p->res[BRMI_RES_VISIBLE_CLUSTERS]), phase == 1 ? 0xFFFFFFFFu : (uint32_t)CNT_VISIBLE, p->cfg.maxVisibleClusters, p->cfg.maxVisibleClusters, p->scene, p->wsPtr<ClusterSetup>(p->ws.clusterSetup), p->resolveCapacity, p->wsPtr<uint8_t>(p->ws.usedClusters),
+                           (p->sceneHasTextures || p->sceneHasAlphaTest || p->sceneHasVertexColors) ? p->wsPtr<ClusterUv>(p->ws.clusterUv) : nullptr, LocalRank{p->totalWords, outIndex, usedIndex});
+    };
+    if (localRank) scatter(k_scatter_visible<true>); else scatter(k_scatter_visible<false>);
     BRMI_LAUNCH_CHECK(p, "compaction");
     return BRMI_OK;
 }

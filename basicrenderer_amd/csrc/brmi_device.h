@@ -210,17 +210,6 @@ BRMI_DEV void load_skin_influences(const uint8_t* jointPtr, const uint8_t* weigh
 }
 
 BRMI_DEV float ior_to_f0(float ior) { const float s = max2(ior, 1.0f); const float f = (s - 1.0f) / (s + 1.0f); return f * f; }
-// The correctly rounded fp32 logarithm (through fp64): GPU and CPU logf differ in the last bit, and a depth within an ulp of a
-// slice boundary has to land in the same light-cluster slice on both.  Only used where tables are built, never per pixel.
-BRMI_DEV float log_cr(float x) { return (float)log((double)x); }
-// cluster slice of a view depth, exactly as the deferred shader evaluates it (lighting.hlsli cluster lookup)
-BRMI_DEV uint32_t cluster_slice_exact(float z, float zNear, float zSplit, float logStart, float logEnd, uint32_t nearSlices, uint32_t gz) {
-    if (z < zSplit) { const float t = (z - zNear) / (zSplit - zNear); return t > 0.0f ? (uint32_t)(t * (float)nearSlices) : 0u; }
-    const float logZ = log_cr(z / zNear);
-    const float u = (logZ - logStart) / (logEnd - logStart);
-    return nearSlices + (u > 0.0f ? (uint32_t)(u * (float)(gz - nearSlices)) : 0u);
-}
-
 // Read-only data produced by an earlier kernel, viewed through the constant address space: with a wave-uniform address
 // the compiler then selects scalar (s_load) instead of vector loads.
 template <typename T> BRMI_DEV const __attribute__((address_space(4))) T* kconst(const T* p) { return (const __attribute__((address_space(4))) T*)p; }

@@ -151,32 +151,16 @@ BRMI_DEV void job_shade_material_table(const brmi_scene_buffers& sc, const float
 //   uvy[py], tileY[py] likewise
 //   sliceStart[s] = smallest view depth whose cluster slice is >= s (the slice formula is monotone in depth), s = 1..gz;
 //   sliceStart[0] = 0, sliceStart[gz + 1] = +inf.
-BRMI_DEV void job_shade_tables(const brmi_scene_buffers& sc, ShadeTables t, uint32_t W, uint32_t H, uint32_t i) {
+// The slice starts are evaluated on the host (brmi_update: they depend on the camera's depth range and the grid alone, a bisection of ~30
+// dependent fp64 logarithms per slice that was this kernel's critical path) and travel as kernel arguments.
+BRMI_DEV void job_shade_tables(const brmi_scene_buffers& sc, ShadeTables t, uint32_t W, uint32_t H, const float* sliceStart, uint32_t i) {
     const brmi_per_frame* pf = sc.perFrame;
-    const brmi_camera* cam = sc.cameras + pf->mainCameraIndex;
     const float resX = (float)pf->screenResX, resY = (float)pf->screenResY;
     const uint32_t gx = pf->lightClusterGridSizeX, gy = pf->lightClusterGridSizeY, gz = pf->lightClusterGridSizeZ;
     const float tsx = resX / (float)gx, tsy = resY / (float)gy;
     if (i < W) t.x[i] = AxisEntry{((float)i + 0.5f) / resX, (uint32_t)((float)i / tsx)};
     if (i < H) t.y[i] = AxisEntry{((float)i + 0.5f) / resY, (uint32_t)((float)i / tsy)};
-    if (i <= gz + 1u) {
-        float b = 0.0f;
-        if (i == gz + 1u) b = __uint_as_float(0x7F800000u);
-        else if (i > 0u) {
-            const float zNear = cam->zNear, zFar = cam->zFar, zSplit = pf->clusterZSplitDepth;
-            const float logStart = log_cr(zSplit / zNear), logEnd = log_cr(zFar / zNear);
-            // bisection over the positive floats: lo fails, hi passes.  The search stops at 1e30 (z / zNear must stay finite for
-            // the float -> uint conversion of the formula to be defined); a slice that starts beyond it starts at +inf.
-            uint32_t lo = 0u, hi = __float_as_uint(1.0e30f);
-            if (cluster_slice_exact(1.0e30f, zNear, zSplit, logStart, logEnd, pf->nearClusterCount, gz) < i) lo = hi = 0x7F800000u;
-            while (hi - lo > 1u) {
-                const uint32_t mid = lo + ((hi - lo) >> 1);
-                if (cluster_slice_exact(__uint_as_float(mid), zNear, zSplit, logStart, logEnd, pf->nearClusterCount, gz) >= i) hi = mid; else lo = mid;
-            }
-            b = __uint_as_float(hi);
-        }
-        t.sliceStart[i] = b;
-    }
+    if (i <= gz + 1u) t.sliceStart[i] = sliceStart[i];
 }
 
 struct FrameJobs {
@@ -185,6 +169,7 @@ struct FrameJobs {
     AlphaMaterial* alphaMats;
     const float* lutF; ShadeRows* shadeRows; ShadeAverages* shadeAvgs; GgxQuad* ggxQuads;
     uint32_t W, H;
+    float sliceStart[64];        // first view depth of every light-cluster slice (brmi_update), [0] = 0, [gz + 1] = +inf
     uint32_t firstBlock[7];      // block ranges of the six jobs
 };
 
@@ -193,7 +178,7 @@ __global__ void __launch_bounds__(64) k_frame_constants(FrameJobs j) {
     if (b < j.firstBlock[1]) job_object_constants(j.sc, j.frameConst, j.objConst, (b - j.firstBlock[0]) * 64u + threadIdx.x);
     else if (b < j.firstBlock[2]) job_material_words(j.sc, j.matWords, j.alphaMats, (b - j.firstBlock[1]) * 64u + threadIdx.x);
     else if (b < j.firstBlock[3]) job_material_constants(j.sc, j.matConst, (b - j.firstBlock[2]) * 64u + threadIdx.x);
-    else if (b < j.firstBlock[4]) job_shade_tables(j.sc, j.tables, j.W, j.H, (b - j.firstBlock[3]) * 64u + threadIdx.x);
+    else if (b < j.firstBlock[4]) job_shade_tables(j.sc, j.tables, j.W, j.H, j.sliceStart, (b - j.firstBlock[3]) * 64u + threadIdx.x);
     else if (b < j.firstBlock[5]) job_light_spheres(j.sc, j.lightVS, j.lightMeta, j.shadeLights, (b - j.firstBlock[4]) * 64u + threadIdx.x);
     else job_shade_material_table(j.sc, j.lutF, j.shadeRows, j.shadeAvgs, j.ggxQuads, (b - j.firstBlock[5]) * 64u + threadIdx.x);
 }
@@ -214,6 +199,7 @@ int ensure_frame_constants(brmi_pass* p, hipStream_t s) {
     j.lightVS = p->wsPtr<float4>(p->ws.lightVS); j.lightMeta = p->wsPtr<uint32_t>(p->ws.lightMeta); j.shadeLights = p->wsPtr<float4>(p->ws.shadeLights);
     j.alphaMats = p->sceneHasAlphaTest ? p->wsPtr<AlphaMaterial>(p->ws.alphaMats) : nullptr;
     j.W = p->cfg.width; j.H = p->cfg.height;
+    for (uint32_t k = 0; k < 64; k++) j.sliceStart[k] = k < p->sliceStartHost.size() ? p->sliceStartHost[k] : 0.0f;
     auto blocks = [](uint32_t n) { return (std::max(1u, n) + 63u) / 64u; };
     j.lutF = p->wsPtr<float>(p->ws.lutF); j.shadeRows = p->wsPtr<ShadeRows>(p->ws.shadeRows); j.shadeAvgs = p->wsPtr<ShadeAverages>(p->ws.shadeAvgs); j.ggxQuads = p->wsPtr<GgxQuad>(p->ws.ggxQuads);
     const uint32_t counts[6] = {blocks(p->scene.perObjectCount), blocks(p->scene.materialCount), blocks(p->scene.openpbrMaterialCount),

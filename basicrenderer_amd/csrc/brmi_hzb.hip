@@ -16,9 +16,32 @@ BRMI_DEV float hzb_depth_texel(const HzbDesc& h, uint32_t x, uint32_t y) {
 }
 BRMI_DEV float key_depth(unsigned long long k) { return (k == BRMI_VIS_EMPTY) ? as_f32(BRMI_DEPTH_EMPTY_BITS) : as_f32(((uint32_t)(k >> BRMI_VIS_META_BITS)) << 1); }
 
+// mips firstMip..last, one workgroup, level by level (source texels clamped to the source extent: a dimension that
+// reached 1 stays 1)
+BRMI_DEV void hzb_tail_levels(const HzbDesc& h, uint32_t firstMip, uint32_t threads) {
+    for (uint32_t mip = firstMip; mip < h.mipCount; mip++) {
+        const uint32_t sw = max(1u, h.paddedW >> (mip - 1u)), sh = max(1u, h.paddedH >> (mip - 1u));
+        const uint32_t w = max(1u, h.paddedW >> mip), hh = max(1u, h.paddedH >> mip);
+        const float* src = h.mips + h.mipOffset[mip - 1u];
+        float* dst = h.mips + h.mipOffset[mip];
+        for (uint32_t i = threadIdx.x; i < w * hh; i += threads) {
+            const uint32_t x = i % w, y = i / w;
+            const uint32_t x0 = min(2u * x, sw - 1u), x1 = min(2u * x + 1u, sw - 1u), y0 = min(2u * y, sh - 1u), y1 = min(2u * y + 1u, sh - 1u);
+            float a, b, c, d;
+            if (mip == 1u) { a = hzb_depth_texel(h, x0, y0); b = hzb_depth_texel(h, x1, y0); c = hzb_depth_texel(h, x0, y1); d = hzb_depth_texel(h, x1, y1); }
+            else { a = src[(size_t)y0 * sw + x0]; b = src[(size_t)y0 * sw + x1]; c = src[(size_t)y1 * sw + x0]; d = src[(size_t)y1 * sw + x1]; }
+            dst[i] = max2(max2(a, b), max2(c, d));
+        }
+        __syncthreads();   // also orders this block's global writes before the next level's reads
+    }
+}
+
 // mips 1..5 from the depth map: block = 16 x 16 texels of mip 1 (requires paddedW, paddedH >= 32)
 // FROM_VIS: the source is the visibility buffer; the linear depth of the four texels (K6, gbuffer.hlsl:114-161) is written to
 // the depth map on the way.  `skipUnless` (may be null): the launch does nothing when that counter is zero.
+// (FidelityFX SPD's single-pass scheme -- the last workgroup to finish builds the tail -- was tried: every workgroup needs a device-scope fence
+// before it takes its ticket, which on this part writes back the XCD's L2; 4,352 of them turned a 20 us kernel into 1.1 ms.  The tail stays
+// a launch of its own.)
 template <bool FROM_VIS>
 __global__ void __launch_bounds__(256) k_hzb_head(HzbDesc h, const unsigned long long* vis, float* depthOut, const uint32_t* skipUnless, uint32_t blockRow0) {
     if (skipUnless && *skipUnless == 0u) return;
@@ -83,25 +106,11 @@ __global__ void __launch_bounds__(256) k_hzb_head(HzbDesc h, const unsigned long
     }
 }
 
-// mips firstMip..last, one workgroup, level by level (source texels clamped to the source extent: a dimension that
-// reached 1 stays 1)
-__global__ void __launch_bounds__(1024) k_hzb_tail(HzbDesc h, uint32_t firstMip, const uint32_t* skipUnless) {
+// `seedCounters` (brmi_execute's phase-1 build only): the block also does k_seed_phase2's work for the culling pass that follows.
+__global__ void __launch_bounds__(1024) k_hzb_tail(HzbDesc h, uint32_t firstMip, const uint32_t* skipUnless, uint32_t* seedCounters, uint32_t seedCapacity) {
     if (skipUnless && *skipUnless == 0u) return;
-    for (uint32_t mip = firstMip; mip < h.mipCount; mip++) {
-        const uint32_t sw = max(1u, h.paddedW >> (mip - 1u)), sh = max(1u, h.paddedH >> (mip - 1u));
-        const uint32_t w = max(1u, h.paddedW >> mip), hh = max(1u, h.paddedH >> mip);
-        const float* src = h.mips + h.mipOffset[mip - 1u];
-        float* dst = h.mips + h.mipOffset[mip];
-        for (uint32_t i = threadIdx.x; i < w * hh; i += 1024u) {
-            const uint32_t x = i % w, y = i / w;
-            const uint32_t x0 = min(2u * x, sw - 1u), x1 = min(2u * x + 1u, sw - 1u), y0 = min(2u * y, sh - 1u), y1 = min(2u * y + 1u, sh - 1u);
-            float a, b, c, d;
-            if (mip == 1u) { a = hzb_depth_texel(h, x0, y0); b = hzb_depth_texel(h, x1, y0); c = hzb_depth_texel(h, x0, y1); d = hzb_depth_texel(h, x1, y1); }
-            else { a = src[(size_t)y0 * sw + x0]; b = src[(size_t)y0 * sw + x1]; c = src[(size_t)y1 * sw + x0]; d = src[(size_t)y1 * sw + x1]; }
-            dst[i] = max2(max2(a, b), max2(c, d));
-        }
-        __syncthreads();   // also orders this block's global writes before the next level's reads
-    }
+    if (seedCounters) seed_phase2(seedCounters, seedCapacity, threadIdx.x);
+    hzb_tail_levels(h, firstMip, 1024u);
 }
 
 int launch_hzb(brmi_pass* p, hipStream_t s, bool fromVisibility, bool onlyIfPhase2Drew) {
@@ -119,7 +128,11 @@ int launch_hzb(brmi_pass* p, hipStream_t s, bool fromVisibility, bool onlyIfPhas
         else hipLaunchKernelGGL(k_hzb_head<false>, grid, dim3(256), 0, s, h, (const unsigned long long*)nullptr, (float*)nullptr, skip, row0);
         first = 6;
     }
-    if (first < h.mipCount) hipLaunchKernelGGL(k_hzb_tail, dim3(1), dim3(1024), 0, s, h, first, skip);
+    if (first < h.mipCount) {
+        const bool seed = p->seedInHzbTail && !onlyIfPhase2Drew;
+        hipLaunchKernelGGL(k_hzb_tail, dim3(1), dim3(1024), 0, s, h, first, skip, seed ? p->counters() : nullptr, p->cfg.maxTraversalRecords);
+        if (seed) p->phase2Seeded = true;
+    }
     BRMI_LAUNCH_CHECK(p, "k_hzb");
     return BRMI_OK;
 }

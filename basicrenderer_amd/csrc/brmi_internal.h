@@ -44,6 +44,18 @@ enum CounterIndex : uint32_t {
     CNT_WORDS = 128 + 64 * 32
 };
 
+// Phase 2 starts from the replay buffers: the replayed meshlets become the first bucket records, the replayed nodes the level-0 frontier;
+// per-level frontier counters start from zero; the raster overflow queues of phase 1 are counted and emptied.  Thread t of (at least) 128.
+__device__ inline void seed_phase2(uint32_t* counters, uint32_t capacity, uint32_t t) {
+    if (t == 0) { counters[CNT_REPLAY_NODES] = min(counters[CNT_REPLAY_NODES], capacity); counters[CNT_BUCKETS] = min(counters[CNT_REPLAY_MESHLETS], capacity); counters[CNT_TEMP_VISIBLE2] = 0; counters[CNT_VISIBLE2] = 0; }
+    if (t < CNT_STRIPES - CNT_FRONTIER0) counters[CNT_FRONTIER0 + t] = 0;
+    if (t < CNT_STRIPE_COUNT) {
+        uint32_t* q = &counters[CNT_STRIPES + t * CNT_STRIPE_WORDS + STRIPE_OVERFLOW];
+        if (*q) atomicAdd(&counters[CNT_BIN_OVERFLOW], *q);
+        *q = 0u;
+    }
+}
+
 // internal records (ours; the reference's 12 B / 24 B records plus the rank bookkeeping)
 struct NodeRecord { uint32_t instanceIndex, nodeIdPacked; };                       // 8 B (single view)
 struct BucketRecord {                                                                 // 32 B
@@ -121,6 +133,8 @@ struct brmi_pass {
     uint32_t sceneUvSets = 1;      // UV sets the texture slots of the scene's materials name (brmi_set_scene)
     bool sceneHasAlphaTest = false, sceneHasTextures = false, sceneHasParallax = false;   // some material is alpha tested / samples a texture (brmi_set_scene)
     bool sceneHasCoat = true, sceneHasFuzz = true;   // some OpenPBR material has a coat / fuzz layer (brmi_set_scene)
+    std::vector<float> sliceStartHost; float sliceKey[3] = {0, 0, 0}; uint32_t sliceKeyN[2] = {0, 0};   // slice starts of the light-cluster grid and the inputs they were made from
+    bool seedInHzbTail = false, phase2Seeded = false;           // brmi_execute: the tail of the phase-1 depth-chain build also seeds phase 2 (k_seed_phase2's work)
     bool fuseFrameClear = false, frameStateCleared = false;   // brmi_execute: the visibility clear also clears the culling pass's frame state
     bool forceLevelKernels = false;  // BRMI_CULL_LEVEL_KERNELS=1: always use the per-level kernels (tests, very wide hierarchies)
     uint64_t totalBits = 0; uint32_t totalWords = 0, scanBlocks = 0;

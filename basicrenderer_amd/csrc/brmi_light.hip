@@ -27,14 +27,14 @@ namespace brmi {
 // =================================== K9 + K10 ==================================================
 struct ClusterArgs {
     brmi_scene_buffers sc;
-    const float* planes;          // near/far per slice, 2 * gridZ
+    float planes[2 * 62];         // near/far per slice, 2 * gridZ (brmi_update evaluates them on the host; they travel as kernel arguments, not through a copy)
     brmi_light_cluster* clusters;
     brmi_light_page* pages;
     uint32_t poolSize;
     uint32_t* counters;
     float4* lightVS;              // per active light: view-space bounding sphere (xyz, r)
     uint32_t* lightMeta;          // per active light: type | lightIndex << 2
-    uint32_t* clusterPages;       // per cluster: page demand, then (after the scan) first page
+    uint32_t* clusterPages;       // per cluster: page demand
     uint32_t* clusterHits;        // per cluster: lights that touch it
     uint32_t* pageTotal;          // [0]: pages demanded by all clusters (unclamped)
     uint64_t* hitMasks; uint32_t maskWords;   // per cluster: one bit per light of the list
@@ -110,45 +110,30 @@ __global__ void __launch_bounds__(256) k_lc_count(ClusterArgs a) {
     }
 }
 
-// single workgroup: exclusive scan of the page demand in cluster order = the serial allocation order
-__global__ void __launch_bounds__(1024) k_lc_scan(ClusterArgs a) {
-    __shared__ uint32_t waveTotals[16];
-    __shared__ uint32_t carry;
-    const brmi_per_frame* pf = a.sc.perFrame;
-    const uint32_t total = pf->lightClusterGridSizeX * pf->lightClusterGridSizeY * pf->lightClusterGridSizeZ;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < total; base += 1024) {
-        const uint32_t i = base + threadIdx.x;
-        const uint32_t v = i < total ? a.clusterPages[i] : 0u;
-        uint32_t incl = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o); if ((threadIdx.x & 63u) >= (uint32_t)o) incl += t; }
-        if ((threadIdx.x & 63u) == 63u) waveTotals[threadIdx.x >> 6] = incl;
-        __syncthreads();
-        uint32_t waveBase = 0;
-        for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) waveBase += waveTotals[w];
-        const uint32_t c = carry;
-        if (i < total) a.clusterPages[i] = c + waveBase + incl - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry = c + waveBase + incl;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) { a.counters[CNT_LIGHT_PAGES] = min(carry, a.poolSize); a.pageTotal[0] = carry; }
-}
-
 // fill, one wave64 per cluster: hit j of the cluster (in light-list order, from the bit masks) goes to entry j % 12 of the
 // cluster's page j / 12; pages come from the scan, are chained newest -> oldest like the serial allocator chains them, and
 // stop where the pool ends (the reference's `break`: the cluster then keeps its full pages only).
+// The first page of a cluster is the exclusive prefix of the page demand in cluster order = the serial allocation order.  Every workgroup
+// sums the demand of the clusters before its own four (a few thousand L2-resident words over 256 threads) instead of a scan kernel of
+// its own between count and fill: one ~6 us launch less per frame.
 __global__ void __launch_bounds__(256) k_lc_fill(ClusterArgs a) {
+    __shared__ uint32_t waveSum[4], waveDemand[4];
     const brmi_per_frame* pf = a.sc.perFrame;
     const uint32_t total = pf->lightClusterGridSizeX * pf->lightClusterGridSizeY * pf->lightClusterGridSizeZ, lightCount = pf->numLights;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t idx = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t idx0 = blockIdx.x * 4u, idx = idx0 + wave;
+    uint32_t part = 0;
+    for (uint32_t i = threadIdx.x; i < min(idx0, total); i += 256u) part += a.clusterPages[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += (uint32_t)__shfl_xor((int)part, o);
+    const uint32_t demand = idx < total ? a.clusterPages[idx] : 0u;
+    if (lane == 0) { waveSum[wave] = part; waveDemand[wave] = demand; }
+    __syncthreads();
+    uint32_t base = waveSum[0] + waveSum[1] + waveSum[2] + waveSum[3];         // first page of this wave's cluster
+    for (uint32_t w = 0; w < wave; w++) base += waveDemand[w];
+    if (idx + 1u == total && lane == 0) { a.counters[CNT_LIGHT_PAGES] = min(base + demand, a.poolSize); a.pageTotal[0] = base + demand; }
     if (idx >= total) return;
-    const uint32_t base = a.clusterPages[idx];                                 // first page (exclusive scan of the demand)
     const uint32_t hits = a.clusterHits[idx];
-    const uint32_t demand = (idx + 1u < total ? a.clusterPages[idx + 1u] : a.pageTotal[0]) - base;
     const uint32_t valid = base >= a.poolSize ? 0u : min(demand, a.poolSize - base);   // pages that exist
     const uint64_t* masks = a.hitMasks + (size_t)idx * a.maskWords;
     // the walk starts at the newest page (base + valid - 1), the only one that may be partly filled
@@ -842,7 +827,8 @@ int launch_expand_luts(brmi_pass* p, hipStream_t s) {
 int launch_light_clustering(brmi_pass* p, hipStream_t s) {
     if (int rc = ensure_frame_constants(p, s)) return rc;
     ClusterArgs a;
-    a.sc = p->scene; a.planes = p->wsPtr<float>(p->ws.planes);
+    a.sc = p->scene;
+    for (size_t k = 0; k < p->planesHost.size() && k < 2 * 62; k++) a.planes[k] = p->planesHost[k];
     a.clusters = static_cast<brmi_light_cluster*>(p->res[BRMI_RES_LIGHT_CLUSTERS]); a.pages = static_cast<brmi_light_page*>(p->res[BRMI_RES_LIGHT_PAGES]);
     a.poolSize = p->lightPagePool; a.counters = p->counters();
     a.lightVS = p->wsPtr<float4>(p->ws.lightVS); a.lightMeta = p->wsPtr<uint32_t>(p->ws.lightMeta); a.clusterPages = p->wsPtr<uint32_t>(p->ws.clusterPages);
@@ -851,7 +837,6 @@ int launch_light_clustering(brmi_pass* p, hipStream_t s) {
     a.hitMasks = p->wsPtr<uint64_t>(p->ws.lightHitMasks); a.maskWords = (std::max(1u, p->scene.lightCount) + 63u) / 64u;
     a.clusterList = p->wsPtr<uint2>(p->ws.clusterList); a.listEntries = p->wsPtr<uint32_t>(p->ws.listEntries);
     hipLaunchKernelGGL(k_lc_count, dim3((nc + 3) / 4), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_lc_scan, dim3(1), dim3(1024), 0, s, a);
     hipLaunchKernelGGL(k_lc_fill, dim3((nc + 3) / 4), dim3(256), 0, s, a);
     BRMI_LAUNCH_CHECK(p, "light clustering");
     return BRMI_OK;

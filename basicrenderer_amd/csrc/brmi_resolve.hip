@@ -557,7 +557,10 @@ int launch_gbuffer(brmi_pass* p, hipStream_t s) {
     a.uvs = p->sceneHasTextures ? p->wsPtr<float2>(p->ws.resolveUVs) : nullptr; a.uvSets = p->sceneUvSets;
     a.colors = p->sceneHasVertexColors ? p->wsPtr<uint32_t>(p->ws.resolveColors) : nullptr;
     if (p->sceneHasVertexColors) a.clusterUv = p->wsPtr<ClusterUv>(p->ws.clusterUv);
-    hipLaunchKernelGGL(k_mark_used_clusters, dim3(2048), dim3(256), 0, s, a, p->wsPtr<uint8_t>(p->ws.usedClusters), p->counters());
+    // the marking pass only acts on frames with more than half a triangle per pixel; no cut through the scene's DAGs has more triangles than all
+    // its meshlets together (totalBits: one survivor bit per meshlet of every instance), so most scenes can never be such a frame
+    if ((uint64_t)p->totalBits * BRMI_MESHLET_MAX_TRIS * 2ull > p->bandPixelCount)
+        hipLaunchKernelGGL(k_mark_used_clusters, dim3(2048), dim3(256), 0, s, a, p->wsPtr<uint8_t>(p->ws.usedClusters), p->counters());
     hipLaunchKernelGGL(k_resolve_setup, dim3(8192), dim3(64), 0, s, a);
     const bool lean = (uint64_t)p->resolveCapacity >= (uint64_t)p->cfg.maxVisibleClusters * BRMI_MESHLET_MAX_TRIS;
     // `lean`: the arena holds every visible cluster even at 128 vertices / triangles each.  Otherwise whether one spilled is only
