@@ -143,7 +143,7 @@ struct brmi_pass {
     uint32_t binsX = 0, binsY = 0, binCapacity = 8192;   // raster bins: 256 px x 16 rows, binCapacity records of 64 B each (BRMI_BIN_CAPACITY): 1 GB at 4K, walked in slices of 1024
     uint32_t deferredStripeCapacity = 0;   // entries per deferred-pixel stripe
     uint32_t resolveCapacity = 0;   // vertices (and triangles) the resolve arena holds
-    uint32_t rasterGrid = 4096;  // single-wave workgroups of k_raster (BRMI_RASTER_GRID)
+    uint32_t rasterGrid = 8192;  // single-wave workgroups of k_raster (BRMI_RASTER_GRID)
     int rasterDebug = 0;         // BRMI_RASTER_DEBUG (experiments; non-zero gives wrong images)
     int bigTriArea = 64, bigTriAreaAlpha = 32;        // clamped-bbox pixels above which a triangle is binned (BRMI_BIG_TRI_AREA)
     uint32_t hzbMipCount = 0; std::vector<uint64_t> hzbMipOffsets; std::vector<uint32_t> hzbMipW, hzbMipH;   // [mip]; offsets in floats, mip 0 unused

@@ -58,6 +58,7 @@ struct RasterArgs {
     const float* objConst;   // per object: MVP (16), objectToClip (16), modelViewZ (4)
     int bigTriArea;          // clamped-bbox pixels above which a triangle is binned
     int bigTriAreaAlpha;     // the same for alpha-tested clusters: their pixels are far cheaper in a bin (LDS early-out, more lanes in flight)
+    uint32_t binMinSlice;    // fewest records a slice of a bin holds (BRMI_BIN_MIN_SLICE)
     int debugFlags;          // experiments only (BRMI_RASTER_DEBUG): 1 = skip the direct walk, 2 = skip bin emission, 4 = skip the bin pass, 8 = direct walk without the atomic
     brmi_scene_buffers sc;
     const uint4* clusters; const ClusterSetup* setup;
@@ -236,10 +237,23 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
     const GlobalSink gsink{a.vis, a.tilesX, a.debugFlags};
     // static round-robin over clusters: a shared queue head saturates at ~90 dequeues/us (MI355X_MICROARCH.md, row
     // "dequeue"), which is slower than the work itself once big triangles are handed off
-    for (uint32_t c = blockIdx.x; c < count; c += gridDim.x) {
+    // Frames with far fewer clusters than the grid has waves (every BASELINE-class frame: ~2 k clusters on 1024 SIMDs) are bound by a
+    // cluster's serial chain (fetch, setup, rows, bin reservation -- twice), not by throughput: there a cluster is dealt to 2, 4 or 8 waves.
+    // Each wave transforms the vertices, takes ONE of the two 64-triangle passes (softwareRaster.hlsl:502 votes per wave of 64 triangles,
+    // so the passes are independent), sets up all 64 triangles of it (the vote needs them) and emits only its share of them.  Keys are
+    // order-free, so the result is the same.
+    uint32_t split = 1u;
+    if (!(a.debugFlags & 0x40000000u)) { while (split < 8u && count * split * 2u <= gridDim.x) split *= 2u; }
+    const uint32_t parts = max(split >> 1, 1u), lanesPerPart = 64u / parts;      // shares of a pass
+    const uint32_t items = count * split;
+    for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
+        const uint32_t c = item / split, sub = item % split;
         const uint32_t clusterIndex = first + c;
         const ClusterSetup cs = a.setup[clusterIndex];        // resolved by the compaction kernel: one hop instead of six
         const uint32_t vertCount = cs.counts & 0xFFu, triCount = (cs.counts >> 8) & 0xFFu, posFormat = (cs.counts >> 16) & 0xFFu;
+        const uint32_t passLo = split > 1u ? (sub / parts) * 64u : 0u, passHi = split > 1u ? min(passLo + 64u, triCount) : triCount;
+        const uint32_t part = sub % parts;
+        if (passLo + part * lanesPerPart >= triCount) continue;      // (wave-uniform) no triangle of this share exists
         const bool reverseWinding = ((cs.counts >> 24) & 1u) != 0u;
         const brmi_view_raster_info ri = sc.viewRasterInfo[cs.viewId];
         const float visWidth = (float)(ri.scissorMaxX - ri.scissorMinX), visHeight = (float)(ri.scissorMaxY - ri.scissorMinY);
@@ -282,7 +296,7 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
         __syncthreads();
 
         // triangle stage: lane = triangle (softwareRaster.hlsl:416-611)
-        for (uint32_t waveBase = 0; waveBase < triCount; waveBase += 64) {
+        for (uint32_t waveBase = passLo; waveBase < passHi; waveBase += 64) {
             const uint32_t t = waveBase + lane;
             bool active = t < triCount;
             float d0 = 0, d1 = 0, d2 = 0, row_b0 = 0, row_b1 = 0, dx_b0 = 0, dx_b1 = 0, dy_b0 = 0, dy_b1 = 0;
@@ -321,6 +335,7 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
             }
             const int rectWidth = maxX - minX + 1;
             const bool useScanlineRanges = __any(active && rectWidth > 4);
+            if (parts > 1u && lane / lanesPerPart != part) active = false;      // another wave's share of the pass
             const int rows = maxY - minY + 1;
             const bool big = active && rows * rectWidth > (alphaCluster ? a.bigTriAreaAlpha : a.bigTriArea);
             // bins the box overlaps (rows clipped to this GPU's band)
@@ -487,11 +502,13 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? 4 : 1) k_raster_bins
     // the plain read-modify-write merge (it owns its pixels).  The counts are cleared by k_raster_overflow, which runs next.
     const uint32_t strip = blockIdx.x, band = blockIdx.y, bin = band * a.binsX + strip;
     const uint32_t nAll = min(a.binCounts[bin], a.binCapacity);
-    const bool shared = nAll > BIN_SLICE;               // other workgroups (or later slices of this one) write this bin's pixels too
+    // the slices of a bin share its records evenly (a multiple of the 32 records one step walks, at least binMinSlice of them)
+    const uint32_t sliceSize = max(a.binMinSlice, ((nAll + gridDim.z - 1u) / gridDim.z + 31u) & ~31u);
+    const bool shared = nAll > sliceSize;               // other workgroups (or later slices of this one) write this bin's pixels too
     if (ALPHA) for (uint32_t i = threadIdx.x; i < 256u; i += BRMI_BIN_THREADS) unormT[i] = (float)i / 255.0f;
     // slice blockIdx.z, then every gridDim.z-th one (phase 2, which rarely draws anything, is launched with one slice per bin)
-    for (uint32_t first = blockIdx.z * BIN_SLICE; first < nAll; first += gridDim.z * BIN_SLICE) {
-    const uint32_t n = min(nAll, first + BIN_SLICE);
+    for (uint32_t first = blockIdx.z * sliceSize; first < nAll; first += gridDim.z * sliceSize) {
+    const uint32_t n = min(nAll, first + sliceSize);
     __syncthreads();                                    // the previous slice's merge has read the tile
     if (ALPHA && threadIdx.x == 0) alphaCount = 0u;
     for (uint32_t i = threadIdx.x; i < BIN_W * BIN_ROWS; i += BRMI_BIN_THREADS) tile[i] = BRMI_VIS_EMPTY;
@@ -663,6 +680,8 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
     a.overflow = p->wsPtr<BinRecord>(p->ws.binOverflow); a.overflowPerStripe = p->binOverflowPerStripe;
     a.objConst = p->wsPtr<float>(p->ws.objConst);
     a.bigTriArea = p->bigTriArea; a.bigTriAreaAlpha = p->bigTriAreaAlpha; a.debugFlags = p->rasterDebug;
+    static const uint32_t minSlice = [] { const char* e = std::getenv("BRMI_BIN_MIN_SLICE"); return e ? (uint32_t)std::max(32, std::atoi(e)) : 1024u; }();
+    a.binMinSlice = minSlice;
     a.binAlpha = p->wsPtr<AlphaRecord>(p->ws.binAlpha); a.overflowAlpha = p->wsPtr<AlphaRecord>(p->ws.overflowAlpha);
     a.clusterUv = p->wsPtr<ClusterUv>(p->ws.clusterUv);
     a.alphaMats = p->wsPtr<AlphaMaterial>(p->ws.alphaMats);
