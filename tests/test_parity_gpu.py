@@ -6,6 +6,7 @@ channel for the lit HDR target (pow / log differ in the last bits between GPU an
 libraries; BASELINE.json north_star tolerance).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -352,6 +353,25 @@ def test_missing_texture_table_is_refused():
     with pytest.raises(BrmiError, match="texture"):
         VisibilityRenderer(sc)
     VisibilityRenderer(Scene("tiny", 128, 72, point_lights=1, lod_levels=2, material_features=8)).close()
+
+
+def test_alpha_test_on_odd_sized_single_level_textures_matches_the_oracle():
+    """Every texture re-declared 100 x 60 with one level (not a power of two: the general modulo of wrap / mirror addressing, partial edge
+    footprints): the rasteriser's alpha test and the G-buffer's sampler stay exact against the oracle."""
+    import orc
+    from conftest import Scene
+    from basicrenderer_amd.renderer import VisibilityRenderer
+    sc = Scene("tiny", 160, 90, point_lights=2, lod_levels=2, material_features=24, seed=23)
+    d = sc.arrays["textureDescs"].view(np.uint32).reshape(-1, 24)
+    d[:, 2] = 100; d[:, 3] = 60; d[:, 4] = 1                      # width, height, mipCount
+    o = orc.OracleFrame(sc).run()
+    covered = o.vis != np.uint64(0xFFFFFFFFFFFFFFFF)
+    assert 0 < covered.sum() < covered.size
+    r = VisibilityRenderer(sc)
+    r.execute()
+    assert np.array_equal(r.visibility(), o.vis)
+    assert np.array_equal(r.gbuffer()["albedo"][covered], o.albedo[covered])
+    r.close()
 
 
 def test_texture_slots_on_other_uv_sets_match_the_oracle():
