@@ -551,11 +551,24 @@ int brmi_execute(brmi_pass* p, brmi_stream stream) {
     CHECK_READY(p);
     int rc;
     p->executesSinceTimes++;
+    // When the phase-1 traversal is the one-launch LDS walk and the frame constants are due anyway, the frame needs no clear launch: the
+    // constants kernel zeroes the culling state and the walk's launch carries the visibility clear (brmi_cull.hip, SideClear).
+    static const bool rideEnv = [] { const char* e = std::getenv("BRMI_CLEAR_RIDES"); return !e || std::atoi(e) != 0; }();
+    const bool rides = rideEnv && p->constantsSerial != p->updateSerial && p->minLevelWidth <= 256u && !p->forceLevelKernels && p->scene.activeDrawCount != 0u;
+    p->lightGridDone = false;
+    if (rides) {
+        p->clearFrameStateWithConstants = true; p->clearVisibilityWithTraversal = true;
+        rc = brmi_cull(p, 1, stream);
+        p->clearFrameStateWithConstants = false;
+        if (rc == BRMI_OK && p->clearVisibilityWithTraversal) { p->clearVisibilityWithTraversal = false; return brmi::fail(p, BRMI_ERR_STATE, "brmi_execute: the traversal did not carry the visibility clear"); }
+        if (rc) { p->clearVisibilityWithTraversal = false; return rc; }
+    } else {
     p->fuseFrameClear = true;
     rc = brmi_clear_visibility(p, stream);
     p->fuseFrameClear = false;
     if (rc) return rc;
     if ((rc = brmi_cull(p, 1, stream))) return rc;
+    }
     if ((rc = brmi_raster(p, 1, stream))) return rc;
     if (p->cfg.enableOcclusionCulling) {
         // reference graph: LinearDepthCopyPass1 -> LinearDepthDownsamplePass1 -> HierarchicalCullingPass2 -> ...RasterizeClustersPass2
@@ -569,7 +582,8 @@ int brmi_execute(brmi_pass* p, brmi_stream stream) {
     }
     if ((rc = brmi_gbuffer(p, stream))) return rc;
     if (p->cfg.enableOcclusionCulling && (rc = build_hzb_fused(p, static_cast<hipStream_t>(stream), false, true))) return rc;   // the G-buffer kernel wrote the final depth
-    if ((rc = brmi_light_clustering(p, stream))) return rc;
+    if (p->lightGridDone) p->lightGridDone = false;      // the culling pass's launches carried it
+    else if ((rc = brmi_light_clustering(p, stream))) return rc;
     if ((rc = brmi_shade(p, stream))) return rc;
     return BRMI_OK;
 }

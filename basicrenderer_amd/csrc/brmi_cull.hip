@@ -16,8 +16,10 @@
 //     places each survivor at its rank: the visible-cluster list is identical run to run
 //     (canonical order: instance, segment, meshlet) with one atomic per wave, not per survivor.
 //   * Frontier / bucket appends are wave-aggregated (one atomic per wave64).
+#include <type_traits>
 #include "brmi_device.h"
 #include "brmi_internal.h"
+#include "brmi_lightgrid.h"
 #include "brmi_texture.h"
 
 namespace brmi {
@@ -306,8 +308,24 @@ constexpr uint32_t HIER_CAP_MAX = 1024;   // widest BVH level the LDS frontier v
 // (scenes of many small instances), (1024, 128) = 12 KB covers wide hierarchies.  Meshes wider than that (a street's ground and facades
 // tessellated to pixel-sized triangles: 1,600 leaf segments on one level) go through the level-per-launch kernels, which put every
 // lane of the chip on one level -- a single wave walking such a mesh alone took 0.4 ms (tried with a 4096-node variant).
-template <bool REPLAY, uint32_t HIER_CAP, uint32_t HIER_STAGE>
-__global__ void __launch_bounds__(64) k_cull_hierarchy(CullArgs a, BucketRecord* buckets, const uint32_t* meshLevelWidth, uint32_t widthLo, uint32_t widthHi) {
+// SIDE (brmi_execute, phase 1): the launch carries extra workgroups behind the traversal's that clear the visibility buffer.  The walk is a
+// chain of dependent loads on ~1.3 waves per SIMD; the 66 MB of stores disappear in its shadow instead of costing a launch of their own.
+// Behind those, one workgroup per light cluster runs the first half of the light clustering (AABB + hit masks + page demand: it depends on
+// the frame constants alone); the second half rides on k_cull_clusters.  Frame: three launches and ~25 us less.
+struct NoSide {};
+struct SideJobs { ulonglong2* vis2; uint64_t n2; uint32_t walkBlocks, clearBlocks; ClusterArgs lc; };
+template <bool REPLAY, uint32_t HIER_CAP, uint32_t HIER_STAGE, bool SIDE = false>
+__global__ void __launch_bounds__(64) k_cull_hierarchy(CullArgs a, BucketRecord* buckets, const uint32_t* meshLevelWidth, uint32_t widthLo, uint32_t widthHi, typename std::conditional<SIDE, SideJobs, NoSide>::type sj) {
+    uint32_t walkBlocks = gridDim.x;
+    if constexpr (SIDE) {
+        walkBlocks = sj.walkBlocks;
+        if (blockIdx.x >= sj.walkBlocks + sj.clearBlocks) { lc_count_wave(sj.lc, blockIdx.x - sj.walkBlocks - sj.clearBlocks, threadIdx.x); return; }
+        if (blockIdx.x >= sj.walkBlocks) {
+            const uint64_t stride = (uint64_t)sj.clearBlocks * 64u;
+            for (uint64_t i = (uint64_t)(blockIdx.x - sj.walkBlocks) * 64u + threadIdx.x; i < sj.n2; i += stride) sj.vis2[i] = make_ulonglong2(BRMI_VIS_EMPTY, BRMI_VIS_EMPTY);
+            return;
+        }
+    }
     __shared__ uint32_t frontier[2][HIER_CAP];
     __shared__ uint32_t counts[2];
     __shared__ uint32_t childOff[65], childFirst[64];
@@ -337,7 +355,7 @@ __global__ void __launch_bounds__(64) k_cull_hierarchy(CullArgs a, BucketRecord*
         __syncthreads();
         staged = 0u;
     };
-    for (uint32_t seed = blockIdx.x; seed < seeds; seed += gridDim.x) {
+    for (uint32_t seed = blockIdx.x; seed < seeds; seed += walkBlocks) {
         uint32_t instIndex, startNode;
         if (REPLAY) { const NodeRecord rec = a.replayNodes[seed]; instIndex = rec.instanceIndex; startNode = rec.nodeIdPacked & 0x3FFFFFFFu; }
         else instIndex = sc.activeDraws[seed];
@@ -550,7 +568,15 @@ BRMI_DEV float4 skinned_meshlet_bounds(const brmi_scene_buffers& sc, const brmi_
 }
 
 // K3: per-meshlet cull ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_cull_clusters(CullArgs a, const BucketRecord* buckets, TempVisible* temp, uint32_t* bitmask) {
+// SIDE: workgroups behind the first `mainBlocks` run the second half of the light clustering (page prefix + fill; four clusters each)
+struct LcRide { uint32_t mainBlocks; ClusterArgs lc; };
+template <bool SIDE>
+__global__ void __launch_bounds__(256) k_cull_clusters(CullArgs a, const BucketRecord* buckets, TempVisible* temp, uint32_t* bitmask, typename std::conditional<SIDE, LcRide, NoSide>::type ride) {
+    uint32_t mainBlocks = gridDim.x;
+    if constexpr (SIDE) {
+        mainBlocks = ride.mainBlocks;
+        if (blockIdx.x >= ride.mainBlocks) { lc_fill_block(ride.lc, blockIdx.x - ride.mainBlocks, threadIdx.x); return; }
+    }
     const brmi_scene_buffers& sc = a.sc;
     const uint32_t bucketCount = min(a.counters[a.bucketCounter], a.recordCapacity);
     const uint32_t viewId = sc.perFrame->mainCameraIndex;
@@ -564,7 +590,7 @@ __global__ void __launch_bounds__(256) k_cull_clusters(CullArgs a, const BucketR
     // one lane per (bucket, meshlet-in-bucket): `factor` lanes cooperate on a record
     const uint64_t totalLanes = (uint64_t)bucketCount * a.factor;
     const uint64_t rounded = (totalLanes + 63ull) & ~63ull;
-    for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < rounded; idx += (uint64_t)gridDim.x * blockDim.x) {
+    for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < rounded; idx += (uint64_t)mainBlocks * blockDim.x) {
         bool survives = false, occluded = false;
         uint4 packed = make_uint4(0, 0, 0, 0);
         uint32_t bit = 0;
@@ -877,6 +903,7 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
     uint32_t* wordPrefix = p->wsPtr<uint32_t>(p->ws.wordPrefix); uint32_t* blockSums = p->wsPtr<uint32_t>(p->ws.blockSums);
 
     const uint32_t maxBlocks = 1024;
+    bool lightGridRides = false;      // this call's launches carry the light clustering (brmi_execute)
     // one launch of k_cull_hierarchy for the meshes that fit its LDS frontier, the level kernels for the rest (or for everything: tests)
     const bool hierarchy = p->minLevelWidth <= HIER_CAP_MAX && !p->forceLevelKernels;
     const bool levelKernels = p->maxLevelWidth > HIER_CAP_MAX || p->forceLevelKernels;
@@ -888,8 +915,15 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
         const dim3 hgrid(std::min(std::max(1u, p->scene.activeDrawCount), 16384u));
         if (hierarchy) {
             // narrow meshes (most instances) with the 6 KB variant, wide ones with the 24 KB variant; each launch skips the other class
-            if (p->minLevelWidth <= 256u) hipLaunchKernelGGL((k_cull_hierarchy<false, 256, 128>), hgrid, dim3(64), 0, s, a, buckets, meshWidth, 0u, 256u);
-            if (p->maxLevelWidth > 256u) hipLaunchKernelGGL((k_cull_hierarchy<false, 1024, 128>), hgrid, dim3(64), 0, s, a, buckets, meshWidth, 257u, HIER_CAP_MAX);
+            const NoSide none{};
+            if (p->minLevelWidth <= 256u) {
+                if (p->clearVisibilityWithTraversal) {
+                    SideJobs sj{reinterpret_cast<ulonglong2*>(static_cast<unsigned long long*>(p->res[BRMI_RES_VISIBILITY]) + p->bandFirstPixel), p->bandPixelCount >> 1, hgrid.x, 8192u, cluster_args_of(p)};
+                    hipLaunchKernelGGL((k_cull_hierarchy<false, 256, 128, true>), dim3(hgrid.x + sj.clearBlocks + p->numLightClusters), dim3(64), 0, s, a, buckets, meshWidth, 0u, 256u, sj);
+                    p->clearVisibilityWithTraversal = false; lightGridRides = true;
+                } else hipLaunchKernelGGL((k_cull_hierarchy<false, 256, 128>), hgrid, dim3(64), 0, s, a, buckets, meshWidth, 0u, 256u, none);
+            }
+            if (p->maxLevelWidth > 256u) hipLaunchKernelGGL((k_cull_hierarchy<false, 1024, 128>), hgrid, dim3(64), 0, s, a, buckets, meshWidth, 257u, HIER_CAP_MAX, none);
         }
         if (levelKernels) hipLaunchKernelGGL(k_cull_instances, dim3(grid_for(p->scene.activeDrawCount, 256, maxBlocks)), dim3(256), 0, s, a, fa);
         BRMI_LAUNCH_CHECK(p, "k_cull_instances");
@@ -897,8 +931,9 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
         // brmi_execute seeds in the tail of the depth-chain build that precedes this call (one launch less)
         if (!p->phase2Seeded) hipLaunchKernelGGL(k_seed_phase2, dim3(1), dim3(128), 0, s, p->counters(), a.recordCapacity);
         p->phase2Seeded = false;
-        if (hierarchy && p->minLevelWidth <= 256u) hipLaunchKernelGGL((k_cull_hierarchy<true, 256, 128>), dim3(2048), dim3(64), 0, s, a, buckets, meshWidth, 0u, 256u);
-        if (hierarchy && p->maxLevelWidth > 256u) hipLaunchKernelGGL((k_cull_hierarchy<true, 1024, 128>), dim3(2048), dim3(64), 0, s, a, buckets, meshWidth, 257u, HIER_CAP_MAX);
+        const NoSide none{};
+        if (hierarchy && p->minLevelWidth <= 256u) hipLaunchKernelGGL((k_cull_hierarchy<true, 256, 128>), dim3(2048), dim3(64), 0, s, a, buckets, meshWidth, 0u, 256u, none);
+        if (hierarchy && p->maxLevelWidth > 256u) hipLaunchKernelGGL((k_cull_hierarchy<true, 1024, 128>), dim3(2048), dim3(64), 0, s, a, buckets, meshWidth, 257u, HIER_CAP_MAX, none);
     }
     // frontier sizes are only known on the device: size the grids for the worst case that can matter
     const uint32_t travGrid = grid_for(std::min<uint64_t>(p->cfg.maxTraversalRecords, (uint64_t)p->scene.lodNodeCount * 4 + 4096), 256, maxBlocks);
@@ -910,7 +945,10 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
     }
     // grid-stride kernels that usually find little to do: a few hundred workgroups retire in ~3 us, a thousand in ~6
     const uint32_t smallGrid = phase == 1 ? 512u : 128u;
-    hipLaunchKernelGGL(k_cull_clusters, dim3(smallGrid), dim3(256), 0, s, a, buckets, temp, bitmask);
+    if (lightGridRides) {
+        hipLaunchKernelGGL(k_cull_clusters<true>, dim3(smallGrid + (p->numLightClusters + 3u) / 4u), dim3(256), 0, s, a, buckets, temp, bitmask, LcRide{smallGrid, cluster_args_of(p)});
+        p->lightGridDone = true;
+    } else hipLaunchKernelGGL(k_cull_clusters<false>, dim3(smallGrid), dim3(256), 0, s, a, buckets, temp, bitmask, NoSide{});
     BRMI_LAUNCH_CHECK(p, "k_cull_clusters");
     // phase 2 appends behind the phase-1 clusters: its capacity is what phase 1 left
     const uint32_t outIndex = phase == 1 ? CNT_VISIBLE : CNT_VISIBLE2, usedIndex = phase == 1 ? 0xFFFFFFFFu : (uint32_t)CNT_VISIBLE;

@@ -170,7 +170,8 @@ struct FrameJobs {
     const float* lutF; ShadeRows* shadeRows; ShadeAverages* shadeAvgs; GgxQuad* ggxQuads;
     uint32_t W, H;
     float sliceStart[64];        // first view depth of every light-cluster slice (brmi_update), [0] = 0, [gz + 1] = +inf
-    uint32_t firstBlock[7];      // block ranges of the six jobs
+    uint4* frameState; uint64_t frameState16;      // brmi_execute: the culling pass's counters + survivor bitmasks, zeroed here (job 7)
+    uint32_t firstBlock[8];      // block ranges of the seven jobs
 };
 
 __global__ void __launch_bounds__(64) k_frame_constants(FrameJobs j) {
@@ -180,7 +181,8 @@ __global__ void __launch_bounds__(64) k_frame_constants(FrameJobs j) {
     else if (b < j.firstBlock[3]) job_material_constants(j.sc, j.matConst, (b - j.firstBlock[2]) * 64u + threadIdx.x);
     else if (b < j.firstBlock[4]) job_shade_tables(j.sc, j.tables, j.W, j.H, j.sliceStart, (b - j.firstBlock[3]) * 64u + threadIdx.x);
     else if (b < j.firstBlock[5]) job_light_spheres(j.sc, j.lightVS, j.lightMeta, j.shadeLights, (b - j.firstBlock[4]) * 64u + threadIdx.x);
-    else job_shade_material_table(j.sc, j.lutF, j.shadeRows, j.shadeAvgs, j.ggxQuads, (b - j.firstBlock[5]) * 64u + threadIdx.x);
+    else if (b < j.firstBlock[6]) job_shade_material_table(j.sc, j.lutF, j.shadeRows, j.shadeAvgs, j.ggxQuads, (b - j.firstBlock[5]) * 64u + threadIdx.x);
+    else for (uint64_t i = (uint64_t)(b - j.firstBlock[6]) * 64u + threadIdx.x; i < j.frameState16; i += (uint64_t)(j.firstBlock[7] - j.firstBlock[6]) * 64u) j.frameState[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 ShadeTables shade_tables_of(const brmi_pass* p) {
@@ -209,8 +211,12 @@ int ensure_frame_constants(brmi_pass* p, hipStream_t s) {
                                 p->constantsSerial == 0 ? blocks(std::max(1u, p->scene.openpbrMaterialCount) * 256u) : 0u};
     j.firstBlock[0] = 0;
     for (int k = 0; k < 6; k++) j.firstBlock[k + 1] = j.firstBlock[k] + counts[k];
-    hipLaunchKernelGGL(k_frame_constants, dim3(j.firstBlock[6]), dim3(64), 0, s, j);
+    // brmi_execute without a clear launch of its own (the visibility clear rides on the traversal kernel): the frame state is zeroed here
+    j.frameState = p->wsPtr<uint4>(p->ws.counters); j.frameState16 = p->clearFrameStateWithConstants ? p->ws.frameClearBytes / 16 : 0ull;
+    j.firstBlock[7] = j.firstBlock[6] + (uint32_t)std::min<uint64_t>((j.frameState16 + 511u) / 512u, 4096u);
+    hipLaunchKernelGGL(k_frame_constants, dim3(j.firstBlock[7]), dim3(64), 0, s, j);
     BRMI_LAUNCH_CHECK(p, "k_frame_constants");
+    if (p->clearFrameStateWithConstants) p->frameStateCleared = true;
     p->constantsSerial = p->updateSerial;
     return BRMI_OK;
 }
