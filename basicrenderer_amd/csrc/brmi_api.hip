@@ -580,14 +580,8 @@ int brmi_execute(brmi_pass* p, brmi_stream stream) {
         if ((rc = brmi_cull(p, 2, stream))) return rc;
         if ((rc = brmi_raster(p, 2, stream))) return rc;
     }
-    // the chain for the next frame's phase 1 must include what phase 2 drew: rebuilt (only then) from the final keys by workgroups that ride on
-    // the G-buffer and shading launches; BRMI_HZB_RIDES=0: two launches of its own after the G-buffer pass (the kernel wrote the final depth)
-    static const bool hzbRideEnv = [] { const char* e = std::getenv("BRMI_HZB_RIDES"); return !e || std::atoi(e) != 0; }();
-    p->hzbRebuildRides = p->cfg.enableOcclusionCulling && hzbRideEnv; p->hzbHeadRode = false;
-    rc = brmi_gbuffer(p, stream);
-    p->hzbRebuildRides = false;
-    if (rc) return rc;
-    if (p->cfg.enableOcclusionCulling && !p->hzbHeadRode && (rc = build_hzb_fused(p, static_cast<hipStream_t>(stream), false, true))) return rc;
+    if ((rc = brmi_gbuffer(p, stream))) return rc;
+    if (p->cfg.enableOcclusionCulling && (rc = build_hzb_fused(p, static_cast<hipStream_t>(stream), false, true))) return rc;   // the G-buffer kernel wrote the final depth
     if (p->lightGridDone) p->lightGridDone = false;      // the culling pass's launches carried it
     else if ((rc = brmi_light_clustering(p, stream))) return rc;
     if ((rc = brmi_shade(p, stream))) return rc;

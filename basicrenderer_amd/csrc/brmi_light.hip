@@ -21,7 +21,6 @@
 #include "brmi_internal.h"
 #include "brmi_shade_math.h"
 #include "brmi_lightgrid.h"
-#include "brmi_hzb.h"
 
 namespace brmi {
 
@@ -194,7 +193,6 @@ struct ShadeArgs {
     // 130 k tiles = 1.4 ms when most pixels carry coat or fuzz).
     uint32_t deferredWord, nextDeferredWord;   // word inside a stripe: this call's list length / the next call's (cleared here)
     uint32_t stripeCapacity;
-    HzbRide hzbRide;      // brmi_execute: one workgroup behind the first mainBlocks of k_shade<0> finishes the depth chain's rebuild (mips 6..)
 };
 
 BRMI_DEV float half_at(unsigned long long v, int k) { return f16_bits_to_f32((uint32_t)(v >> (16 * k)) & 0xFFFFu); }
@@ -585,10 +583,6 @@ BRMI_DEV uint32_t shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const flo
 #endif
 template <int MODE>
 __global__ void __launch_bounds__(256, MODE != 0 ? 1 : BRMI_SHADE_WAVES) k_shade(ShadeArgs a) {
-    if (MODE == 0 && a.hzbRide.on && blockIdx.x >= a.hzbRide.mainBlocks) {      // the tail of the depth chain's rebuild after phase 2 rides here (brmi_hzb.h)
-        if (*a.hzbRide.skipUnless != 0u) hzb_tail_levels(a.hzbRide.h, a.hzbRide.firstTailMip, 256u);
-        return;
-    }
     const ShadeFrame k = make_shade_frame(a);
     __shared__ float sliceStart[64];
     __shared__ float unormT[256];
@@ -606,7 +600,7 @@ __global__ void __launch_bounds__(256, MODE != 0 ? 1 : BRMI_SHADE_WAVES) k_shade
         // lane only adds its own constant offset (no per-lane 64-bit address math, no integer division per pixel).  Software pipeline: the
         // G-buffer words of the next tile are requested before the current one is shaded.
         const uint32_t lane = threadIdx.x & 63u;
-        const uint32_t wavesInGrid = (a.hzbRide.on ? a.hzbRide.mainBlocks : gridDim.x) * (blockDim.x >> 6);
+        const uint32_t wavesInGrid = gridDim.x * (blockDim.x >> 6);
         const uint32_t tileCount = (uint32_t)((a.pixelCount + 63ull) >> 6), firstTile = (uint32_t)(a.firstPixel >> 6);
         uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
         uint32_t tx = (firstTile + t) % a.tilesX, ty = (firstTile + t) / a.tilesX;
@@ -736,14 +730,7 @@ int launch_shade(brmi_pass* p, hipStream_t s) {
     a.nextDeferredWord = (p->shadeSerial & 1u) ? STRIPE_DEFERRED_A : STRIPE_DEFERRED_B;
     a.stripeCapacity = p->deferredStripeCapacity;
     p->shadeSerial++;
-    a.hzbRide = HzbRide{};
-    if (p->hzbHeadRode) {      // the G-buffer launch carried the head of the rebuild: the tail follows here
-        const HzbDesc h = p->hzbDesc();
-        if (6u < h.mipCount) a.hzbRide = HzbRide{h, p->counters() + CNT_VISIBLE2, 4096u, 0u, 0u, 6u, 1u};
-        p->hzbHeadRode = false;
-    }
-    hipLaunchKernelGGL(k_shade<0>, dim3(4096 + a.hzbRide.on), dim3(256), 0, s, a);
-    a.hzbRide.on = 0u;
+    hipLaunchKernelGGL(k_shade<0>, dim3(4096), dim3(256), 0, s, a);
     // deferred pixels by class: coat, fuzz, both -- only the variants some material of the scene can need
     if (p->sceneHasCoat) hipLaunchKernelGGL(k_shade<1>, dim3(512), dim3(256), 0, s, a);
     if (p->sceneHasFuzz) hipLaunchKernelGGL(k_shade<2>, dim3(512), dim3(256), 0, s, a);

@@ -14,7 +14,6 @@
 //     or written by the wave is one contiguous 256 B..1 KB segment.
 #include "brmi_device.h"
 #include "brmi_internal.h"
-#include "brmi_hzb.h"
 #include "brmi_texture.h"
 
 namespace brmi {
@@ -35,7 +34,6 @@ struct GBufferArgs {
     const ClusterUv* clusterUv; float2* uvs;      // textured scenes: where the UV sets of every visible cluster live, decoded texcoords of the arena's vertices
     uint32_t uvSets;                              // sets the materials of the scene address (1 unless one names a set > 0): uvs holds [set][vertCapacity]
     uint32_t* colors;                             // scenes with vertex colours: the RGBA8 colour of the arena's vertices
-    HzbRide hzbRide;               // brmi_execute: workgroups behind the first mainBlocks rebuild mips 1-5 of the depth chain if phase 2 drew anything
     uint32_t variantSelect;        // 0: run; 1: run only when no cluster spilled out of the arena; 2: only when one did (counters[CNT_RESOLVE_SPILL])
 };
 
@@ -289,12 +287,6 @@ template <bool INLINE_TABLES, bool TEXTURED, bool PARALLAX = false, bool MULTI_U
 #define BRMI_GBP_WAVES 3
 #endif
 __global__ void __launch_bounds__(256, INLINE_TABLES ? 1 : (PARALLAX ? BRMI_GBP_WAVES : (TEXTURED ? BRMI_GBT_WAVES : BRMI_GB_WAVES))) k_gbuffer(GBufferArgs a) {
-    if (a.hzbRide.on && blockIdx.x >= a.hzbRide.mainBlocks) {      // the depth chain's rebuild after phase 2 rides here (brmi_hzb.h)
-        if (*a.hzbRide.skipUnless == 0u) return;
-        const uint32_t vb = blockIdx.x - a.hzbRide.mainBlocks;
-        hzb_head_block<true, false>(a.hzbRide.h, a.vis, nullptr, vb % a.hzbRide.gridX, vb / a.hzbRide.gridX + a.hzbRide.row0, threadIdx.x);
-        return;
-    }
     const brmi_scene_buffers& sc = a.sc;
     if (a.variantSelect != 0u && (a.counters[CNT_RESOLVE_SPILL] != 0u) != (a.variantSelect == 2u)) return;     // the other variant's frame
     __shared__ float texelTables[TEXTURED ? 512 : 1];          // code -> float: unorm, sRGB decode
@@ -305,7 +297,7 @@ __global__ void __launch_bounds__(256, INLINE_TABLES ? 1 : (PARALLAX ? BRMI_GBP_
     // view-projection products are frame constants; every lane derives them the way the shader does
     const m4 unjVP = uni_m4(a.frameConst[1]), prevVP = uni_m4(a.frameConst[2]);
     const float winX = uni((float)pf->screenResX), winY = uni((float)pf->screenResY);
-    const uint64_t end = (a.pixelCount + 63ull) & ~63ull, stride = (uint64_t)(a.hzbRide.on ? a.hzbRide.mainBlocks : gridDim.x) * blockDim.x;
+    const uint64_t end = (a.pixelCount + 63ull) & ~63ull, stride = (uint64_t)gridDim.x * blockDim.x;
     // software pipeline: the key and the cluster record of the next tile are requested while this one is resolved (the chain
     // key -> cluster -> triangle -> vertices is four dependent loads)
     auto pixel_of = [&](uint64_t j, uint32_t& px, uint32_t& py) {
@@ -574,22 +566,9 @@ int launch_gbuffer(brmi_pass* p, hipStream_t s) {
     // `lean`: the arena holds every visible cluster even at 128 vertices / triangles each.  Otherwise whether one spilled is only
     // known on the device: both variants are launched and each leaves at once when the frame is the other one's (a ~5 us empty
     // launch against the two-waves-per-SIMD fallback variant on frames that do not need it: San-Miguel-class 4K 1.04 -> 0.98 ms).
-    // brmi_execute with occlusion culling: the chain's rebuild after phase 2 rides on this launch (head) and on the shading kernel's (tail)
-    a.hzbRide = HzbRide{};
-    uint32_t rideBlocks = 0;
-    if (p->hzbRebuildRides) {
-        const HzbDesc h = p->hzbDesc();
-        if (h.paddedW >= 32 && h.paddedH >= 32 && p->hzbMipCount >= 2) {
-            const uint32_t row0 = h.rowLo / 32u, row1 = std::min((h.rowHi + 31u) / 32u, h.paddedH / 32u);
-            a.hzbRide = HzbRide{h, p->counters() + CNT_VISIBLE2, 4096u, h.paddedW / 32u, row0, 6u, 1u};
-            rideBlocks = (h.paddedW / 32u) * std::max(1u, row1 - row0);
-            p->hzbHeadRode = true;
-        }
-    }
     auto launch = [&](auto leanKernel, auto fallbackKernel) {
         a.variantSelect = lean ? 0u : 1u;
-        hipLaunchKernelGGL(leanKernel, dim3(4096 + rideBlocks), dim3(256), 0, s, a);
-        a.hzbRide.on = 0u;
+        hipLaunchKernelGGL(leanKernel, dim3(4096), dim3(256), 0, s, a);
         if (!lean) { a.variantSelect = 2u; hipLaunchKernelGGL(fallbackKernel, dim3(4096), dim3(256), 0, s, a); }
     };
     if (p->sceneHasTextures || p->sceneHasVertexColors) {
