@@ -554,7 +554,7 @@ int brmi_execute(brmi_pass* p, brmi_stream stream) {
     // When the phase-1 traversal is the one-launch LDS walk and the frame constants are due anyway, the frame needs no clear launch: the
     // constants kernel zeroes the culling state and the walk's launch carries the visibility clear (brmi_cull.hip, SideClear).
     static const bool rideEnv = [] { const char* e = std::getenv("BRMI_CLEAR_RIDES"); return !e || std::atoi(e) != 0; }();
-    const bool rides = rideEnv && p->constantsSerial != p->updateSerial && p->minLevelWidth <= 256u && !p->forceLevelKernels && p->scene.activeDrawCount != 0u;
+    const bool rides = rideEnv && p->constantsSerial != p->updateSerial && p->minLevelWidth <= 1024u /* the one-launch walk runs (brmi_cull.hip: HIER_CAP_MAX) */ && !p->forceLevelKernels && p->scene.activeDrawCount != 0u;
     p->lightGridDone = false;
     if (rides) {
         p->clearFrameStateWithConstants = true; p->clearVisibilityWithTraversal = true;

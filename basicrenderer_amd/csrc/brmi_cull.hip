@@ -914,16 +914,18 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
         p->frameStateCleared = false;
         const dim3 hgrid(std::min(std::max(1u, p->scene.activeDrawCount), 16384u));
         if (hierarchy) {
-            // narrow meshes (most instances) with the 6 KB variant, wide ones with the 24 KB variant; each launch skips the other class
-            const NoSide none{};
-            if (p->minLevelWidth <= 256u) {
-                if (p->clearVisibilityWithTraversal) {
-                    SideJobs sj{reinterpret_cast<ulonglong2*>(static_cast<unsigned long long*>(p->res[BRMI_RES_VISIBILITY]) + p->bandFirstPixel), p->bandPixelCount >> 1, hgrid.x, 8192u, cluster_args_of(p)};
-                    hipLaunchKernelGGL((k_cull_hierarchy<false, 256, 128, true>), dim3(hgrid.x + sj.clearBlocks + p->numLightClusters), dim3(64), 0, s, a, buckets, meshWidth, 0u, 256u, sj);
-                    p->clearVisibilityWithTraversal = false; lightGridRides = true;
-                } else hipLaunchKernelGGL((k_cull_hierarchy<false, 256, 128>), hgrid, dim3(64), 0, s, a, buckets, meshWidth, 0u, 256u, none);
-            }
-            if (p->maxLevelWidth > 256u) hipLaunchKernelGGL((k_cull_hierarchy<false, 1024, 128>), hgrid, dim3(64), 0, s, a, buckets, meshWidth, 257u, HIER_CAP_MAX, none);
+            // ONE launch: the 6 KB-frontier variant when every mesh is narrow (<= 256 nodes per level), else the 24 KB variant for all meshes up
+            // to 1024 (two launches, one per class, ran one after the other: San-Miguel-class cull 178 -> 140 us with one)
+            const bool wide = p->maxLevelWidth > 256u;
+            const uint32_t widthHi = wide ? HIER_CAP_MAX : 256u;
+            if (p->clearVisibilityWithTraversal) {
+                SideJobs sj{reinterpret_cast<ulonglong2*>(static_cast<unsigned long long*>(p->res[BRMI_RES_VISIBILITY]) + p->bandFirstPixel), p->bandPixelCount >> 1, hgrid.x, 8192u, cluster_args_of(p)};
+                const dim3 grid(hgrid.x + sj.clearBlocks + p->numLightClusters);
+                if (wide) hipLaunchKernelGGL((k_cull_hierarchy<false, 1024, 128, true>), grid, dim3(64), 0, s, a, buckets, meshWidth, 0u, widthHi, sj);
+                else hipLaunchKernelGGL((k_cull_hierarchy<false, 256, 128, true>), grid, dim3(64), 0, s, a, buckets, meshWidth, 0u, widthHi, sj);
+                p->clearVisibilityWithTraversal = false; lightGridRides = true;
+            } else if (wide) hipLaunchKernelGGL((k_cull_hierarchy<false, 1024, 128>), hgrid, dim3(64), 0, s, a, buckets, meshWidth, 0u, widthHi, NoSide{});
+            else hipLaunchKernelGGL((k_cull_hierarchy<false, 256, 128>), hgrid, dim3(64), 0, s, a, buckets, meshWidth, 0u, widthHi, NoSide{});
         }
         if (levelKernels) hipLaunchKernelGGL(k_cull_instances, dim3(grid_for(p->scene.activeDrawCount, 256, maxBlocks)), dim3(256), 0, s, a, fa);
         BRMI_LAUNCH_CHECK(p, "k_cull_instances");
@@ -932,8 +934,8 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
         if (!p->phase2Seeded) hipLaunchKernelGGL(k_seed_phase2, dim3(1), dim3(128), 0, s, p->counters(), a.recordCapacity);
         p->phase2Seeded = false;
         const NoSide none{};
-        if (hierarchy && p->minLevelWidth <= 256u) hipLaunchKernelGGL((k_cull_hierarchy<true, 256, 128>), dim3(2048), dim3(64), 0, s, a, buckets, meshWidth, 0u, 256u, none);
-        if (hierarchy && p->maxLevelWidth > 256u) hipLaunchKernelGGL((k_cull_hierarchy<true, 1024, 128>), dim3(2048), dim3(64), 0, s, a, buckets, meshWidth, 257u, HIER_CAP_MAX, none);
+        if (hierarchy && p->maxLevelWidth <= 256u) hipLaunchKernelGGL((k_cull_hierarchy<true, 256, 128>), dim3(2048), dim3(64), 0, s, a, buckets, meshWidth, 0u, 256u, none);
+        else if (hierarchy) hipLaunchKernelGGL((k_cull_hierarchy<true, 1024, 128>), dim3(2048), dim3(64), 0, s, a, buckets, meshWidth, 0u, HIER_CAP_MAX, none);
     }
     // frontier sizes are only known on the device: size the grids for the worst case that can matter
     const uint32_t travGrid = grid_for(std::min<uint64_t>(p->cfg.maxTraversalRecords, (uint64_t)p->scene.lodNodeCount * 4 + 4096), 256, maxBlocks);
