@@ -203,6 +203,7 @@ int brmi_create(const brmi_config* cfg, brmi_pass** out) {
     p->totalWords = 1; p->scanBlocks = 1;
     if (const char* e = std::getenv("BRMI_CULL_LEVEL_KERNELS")) p->forceLevelKernels = std::atoi(e) != 0;
     if (const char* e = std::getenv("BRMI_RASTER_GRID")) p->rasterGrid = (uint32_t)std::max(64, std::atoi(e));
+    if (const char* e = std::getenv("BRMI_FUSE_SHADE")) p->fuseShadeOptIn = std::atoi(e) != 0;
     if (const char* e = std::getenv("BRMI_RASTER_DEBUG")) p->rasterDebug = std::atoi(e);
     if (const char* e = std::getenv("BRMI_BIN_OVERFLOW")) p->binOverflowPerStripe = (uint32_t)std::max(0, std::atoi(e));
     if (const char* e = std::getenv("BRMI_BIN_CAPACITY")) p->binCapacity = (uint32_t)std::min(65536, std::max(1, std::atoi(e)));   // 16-bit record indices inside a bin slice's alpha list; 65536 x 64 B x bins is far beyond any frame
@@ -580,10 +581,20 @@ int brmi_execute(brmi_pass* p, brmi_stream stream) {
         if ((rc = brmi_cull(p, 2, stream))) return rc;
         if ((rc = brmi_raster(p, 2, stream))) return rc;
     }
-    if ((rc = brmi_gbuffer(p, stream))) return rc;
+    // BRMI_FUSE_SHADE=1 (off by default): one pass over the pixels for G-buffer + shading where the G-buffer kernel is the lean one
+    // (brmi_resolve.hip: k_gbuffer_shade); the light lists must exist by then.  Measured: 338 us against 103 + 236 us for the two kernels on
+    // the Bistro-class 4K frame -- both are bound by VALU issue (the G-buffer kernel at six waves per SIMD as well), so not reading the
+    // 48 B per pixel back buys 6 us of the frame.  Kept as a tested variant, not as the default: the two-kernel frame is what the profiles describe.
+    const bool fuseEnv = p->fuseShadeOptIn;
+    bool lightsDone = p->lightGridDone;      // the culling pass's launches carried the light clustering
+    p->lightGridDone = false;
+    if (fuseEnv && !lightsDone) { if ((rc = brmi_light_clustering(p, stream))) return rc; lightsDone = true; }
+    p->fuseShadeIntoGBuffer = fuseEnv; p->plainPixelsShaded = false;
+    rc = brmi_gbuffer(p, stream);
+    p->fuseShadeIntoGBuffer = false;
+    if (rc) return rc;
     if (p->cfg.enableOcclusionCulling && (rc = build_hzb_fused(p, static_cast<hipStream_t>(stream), false, true))) return rc;   // the G-buffer kernel wrote the final depth
-    if (p->lightGridDone) p->lightGridDone = false;      // the culling pass's launches carried it
-    else if ((rc = brmi_light_clustering(p, stream))) return rc;
+    if (!lightsDone && (rc = brmi_light_clustering(p, stream))) return rc;
     if ((rc = brmi_shade(p, stream))) return rc;
     return BRMI_OK;
 }
