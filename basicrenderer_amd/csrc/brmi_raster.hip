@@ -211,8 +211,10 @@ BRMI_DEV void bin_append(const RasterArgs& a, const float* unorm, const BinRecor
     bin_store(a, unorm, r, ar, strip, band, atomicAdd(&a.binCounts[band * a.binsX + strip], 1u));
 }
 
+// three waves per SIMD (<= 168 VGPRs; the unconstrained kernel takes 181 and runs two): Bistro raster 122 -> 115 us, San Miguel 192 -> 182 us;
+// four (<= 128 VGPRs) spills and loses it again
 #ifndef BRMI_RASTER_WAVES
-#define BRMI_RASTER_WAVES 1
+#define BRMI_RASTER_WAVES 3
 #endif
 // ALPHA: the scene has alpha-tested materials; clusters of such a material (BRMI_CS_ALPHA) also stage 1/w and the texcoord of their
 // vertices and test every covered pixel.  Scenes without them run the plain instantiation (no extra registers or LDS).
