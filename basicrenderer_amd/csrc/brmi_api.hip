@@ -334,6 +334,7 @@ int brmi_set_scene(brmi_pass* p, const brmi_scene_buffers* scene) {
     std::vector<uint32_t> meshBits(md.size(), 0);
     uint32_t maxDepth = 1;
     p->maxLevelWidth = 1; p->minLevelWidth = 0xFFFFFFFFu; p->hostMeshLevelWidth.assign(md.size(), 1u);
+    p->spillLevels = 0;
     std::vector<uint32_t> levelWidth;
     std::vector<std::pair<uint32_t, uint32_t>> stack;
     for (size_t m = 0; m < md.size(); m++) {
@@ -360,6 +361,13 @@ int brmi_set_scene(brmi_pass* p, const brmi_scene_buffers* scene) {
         if (run > 0xFFFFFFFFull) return fail(p, BRMI_ERR_CAPACITY, "mesh %zu has too many meshlets", m);
         meshBits[m] = (uint32_t)run;
         p->maxLevelWidth = std::max(p->maxLevelWidth, p->hostMeshLevelWidth[m]); p->minLevelWidth = std::min(p->minLevelWidth, p->hostMeshLevelWidth[m]);
+        if (p->hostMeshLevelWidth[m] > 1024u) {
+            // a mesh too wide for the LDS walk: the walk hands its frontier to the level kernels at the first level that holds more than 128 nodes
+            // (brmi_cull.hip, spill mode) -- never above the first level that CAN hold that many; what is left below bounds the level launches
+            uint32_t depth = 1, first = 0;
+            for (uint32_t d = 1; d < levelWidth.size(); d++) { if (levelWidth[d]) depth = d; if (!first && levelWidth[d] > 128u) first = d; }
+            if (first) p->spillLevels = std::max(p->spillLevels, depth - first + 1u);
+        }
     }
     p->hostInstanceBitBase.assign(offs.size(), 0);
     uint64_t bits = 0;

@@ -315,7 +315,11 @@ constexpr uint32_t HIER_CAP_MAX = 1024;   // widest BVH level the LDS frontier v
 struct NoSide {};
 struct SideJobs { ulonglong2* vis2; uint64_t n2; uint32_t walkBlocks, clearBlocks; ClusterArgs lc; };
 template <bool REPLAY, uint32_t HIER_CAP, uint32_t HIER_STAGE, bool SIDE = false>
-__global__ void __launch_bounds__(64) k_cull_hierarchy(CullArgs a, BucketRecord* buckets, const uint32_t* meshLevelWidth, uint32_t widthLo, uint32_t widthHi, typename std::conditional<SIDE, SideJobs, NoSide>::type sj) {
+// Spill mode (meshes wider than `spillAbove` nodes per level): the walk keeps such an instance only while its frontier is small enough for the
+// next level to fit the LDS frontier whatever the fan-out (<= HIER_CAP / 8 nodes) and then appends the frontier to `spillOut`, the level-0 input
+// of the level kernels.  The top levels of a wide hierarchy hold a handful of nodes each; as level launches they cost 12 us apiece.
+__global__ void __launch_bounds__(64) k_cull_hierarchy(CullArgs a, BucketRecord* buckets, const uint32_t* meshLevelWidth, uint32_t widthLo, uint32_t widthHi, uint32_t spillAbove, NodeRecord* spillOut,
+                                                    typename std::conditional<SIDE, SideJobs, NoSide>::type sj) {
     uint32_t walkBlocks = gridDim.x;
     if constexpr (SIDE) {
         walkBlocks = sj.walkBlocks;
@@ -361,10 +365,10 @@ __global__ void __launch_bounds__(64) k_cull_hierarchy(CullArgs a, BucketRecord*
         else instIndex = sc.activeDraws[seed];
         const brmi_per_mesh_instance inst = sc.perMeshInstance[instIndex];
         const uint32_t mdIndex = sc.clodOffsets[instIndex].clodMeshMetadataIndex;
-        {   // this launch handles the meshes whose widest BVH level fits its LDS frontier class
-            const uint32_t width = meshLevelWidth[mdIndex];
-            if (width < widthLo || width > widthHi) continue;
-        }
+        // this launch handles the meshes whose widest BVH level fits its LDS frontier class, and the top of wider ones
+        const uint32_t width = meshLevelWidth[mdIndex];
+        if (width < widthLo || width > widthHi) continue;
+        const bool spill = width > spillAbove;
         const brmi_clod_mesh_metadata md = sc.meshMetadata[mdIndex];
         const brmi_per_object* obj = sc.perObject + inst.perObjectBufferIndex;
         const m4 model = load_m4(&obj->model[0][0]);
@@ -390,6 +394,16 @@ __global__ void __launch_bounds__(64) k_cull_hierarchy(CullArgs a, BucketRecord*
             const uint32_t cur = level & 1u, nxt = cur ^ 1u;
             const uint32_t n = min(counts[cur], HIER_CAP);
             if (n == 0u) break;
+            if (spill && n > HIER_CAP / BRMI_BVH_MAX_CHILDREN) {      // the level after this one may not fit: the level kernels take over from here
+                uint32_t baseSlot = 0;
+                if (lane == 0) baseSlot = atomicAdd(&a.counters[CNT_FRONTIER0], n);
+                baseSlot = (uint32_t)__shfl((int)baseSlot, 0);
+                for (uint32_t k = lane; k < n; k += 64u) {
+                    if (baseSlot + k < a.recordCapacity) spillOut[baseSlot + k] = NodeRecord{instIndex, (REPLAY ? 0x80000000u : 0u) | (1u << 30) | (frontier[cur][k] & 0x3FFFFFFFu)};
+                    else atomicAdd(&a.counters[CNT_DROPPED_RECORDS], 1u);
+                }
+                break;
+            }
             for (uint32_t base = 0; base < n; base += 64u) {
                 const bool have = base + lane < n;
                 bool isInternal = false, emitLeaf = false, occluded = false;
@@ -908,7 +922,11 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
     const bool hierarchy = p->minLevelWidth <= HIER_CAP_MAX && !p->forceLevelKernels;
     const bool levelKernels = p->maxLevelWidth > HIER_CAP_MAX || p->forceLevelKernels;
     const uint32_t* meshWidth = p->wsPtr<uint32_t>(p->ws.meshLevelWidth);
-    a.meshLevelWidth = meshWidth; a.levelKernelsWidthLo = (hierarchy && levelKernels) ? HIER_CAP_MAX + 1u : 0u;
+    // meshes of both kinds: the one-launch walk also starts the wide ones and hands their frontiers to the level kernels (spill mode)
+    const bool spillMode = hierarchy && levelKernels;
+    a.meshLevelWidth = meshWidth; a.levelKernelsWidthLo = 0u;
+    if (spillMode) a.frontier0Counter = CNT_FRONTIER0;
+    const uint32_t widthAll = spillMode ? 0xFFFFFFFFu : 0u, spillAbove = spillMode ? HIER_CAP_MAX : 0xFFFFFFFFu;
     if (phase == 1) {
         if (!p->frameStateCleared) BRMI_HIP(p, hipMemsetAsync(p->counters(), 0, p->ws.frameClearBytes, s));      // counters + both survivor bitmasks
         p->frameStateCleared = false;
@@ -917,31 +935,32 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
             // ONE launch: the 6 KB-frontier variant when every mesh is narrow (<= 256 nodes per level), else the 24 KB variant for all meshes up
             // to 1024 (two launches, one per class, ran one after the other: San-Miguel-class cull 178 -> 140 us with one)
             const bool wide = p->maxLevelWidth > 256u;
-            const uint32_t widthHi = wide ? HIER_CAP_MAX : 256u;
+            const uint32_t widthHi = spillMode ? widthAll : (wide ? HIER_CAP_MAX : 256u);
             if (p->clearVisibilityWithTraversal) {
                 SideJobs sj{reinterpret_cast<ulonglong2*>(static_cast<unsigned long long*>(p->res[BRMI_RES_VISIBILITY]) + p->bandFirstPixel), p->bandPixelCount >> 1, hgrid.x, 8192u, cluster_args_of(p)};
                 const dim3 grid(hgrid.x + sj.clearBlocks + p->numLightClusters);
-                if (wide) hipLaunchKernelGGL((k_cull_hierarchy<false, 1024, 128, true>), grid, dim3(64), 0, s, a, buckets, meshWidth, 0u, widthHi, sj);
-                else hipLaunchKernelGGL((k_cull_hierarchy<false, 256, 128, true>), grid, dim3(64), 0, s, a, buckets, meshWidth, 0u, widthHi, sj);
+                if (wide) hipLaunchKernelGGL((k_cull_hierarchy<false, 1024, 128, true>), grid, dim3(64), 0, s, a, buckets, meshWidth, 0u, widthHi, spillAbove, fa, sj);
+                else hipLaunchKernelGGL((k_cull_hierarchy<false, 256, 128, true>), grid, dim3(64), 0, s, a, buckets, meshWidth, 0u, widthHi, spillAbove, fa, sj);
                 p->clearVisibilityWithTraversal = false; lightGridRides = true;
-            } else if (wide) hipLaunchKernelGGL((k_cull_hierarchy<false, 1024, 128>), hgrid, dim3(64), 0, s, a, buckets, meshWidth, 0u, widthHi, NoSide{});
-            else hipLaunchKernelGGL((k_cull_hierarchy<false, 256, 128>), hgrid, dim3(64), 0, s, a, buckets, meshWidth, 0u, widthHi, NoSide{});
+            } else if (wide) hipLaunchKernelGGL((k_cull_hierarchy<false, 1024, 128>), hgrid, dim3(64), 0, s, a, buckets, meshWidth, 0u, widthHi, spillAbove, fa, NoSide{});
+            else hipLaunchKernelGGL((k_cull_hierarchy<false, 256, 128>), hgrid, dim3(64), 0, s, a, buckets, meshWidth, 0u, widthHi, spillAbove, fa, NoSide{});
         }
-        if (levelKernels) hipLaunchKernelGGL(k_cull_instances, dim3(grid_for(p->scene.activeDrawCount, 256, maxBlocks)), dim3(256), 0, s, a, fa);
+        if (levelKernels && !spillMode) hipLaunchKernelGGL(k_cull_instances, dim3(grid_for(p->scene.activeDrawCount, 256, maxBlocks)), dim3(256), 0, s, a, fa);
         BRMI_LAUNCH_CHECK(p, "k_cull_instances");
     } else {
         // brmi_execute seeds in the tail of the depth-chain build that precedes this call (one launch less)
         if (!p->phase2Seeded) hipLaunchKernelGGL(k_seed_phase2, dim3(1), dim3(128), 0, s, p->counters(), a.recordCapacity);
         p->phase2Seeded = false;
         const NoSide none{};
-        if (hierarchy && p->maxLevelWidth <= 256u) hipLaunchKernelGGL((k_cull_hierarchy<true, 256, 128>), dim3(2048), dim3(64), 0, s, a, buckets, meshWidth, 0u, 256u, none);
-        else if (hierarchy) hipLaunchKernelGGL((k_cull_hierarchy<true, 1024, 128>), dim3(2048), dim3(64), 0, s, a, buckets, meshWidth, 0u, HIER_CAP_MAX, none);
+        if (hierarchy && p->maxLevelWidth <= 256u) hipLaunchKernelGGL((k_cull_hierarchy<true, 256, 128>), dim3(2048), dim3(64), 0, s, a, buckets, meshWidth, 0u, 256u, spillAbove, fa, none);
+        else if (hierarchy) hipLaunchKernelGGL((k_cull_hierarchy<true, 1024, 128>), dim3(2048), dim3(64), 0, s, a, buckets, meshWidth, 0u, spillMode ? widthAll : HIER_CAP_MAX, spillAbove, fa, none);
     }
     // frontier sizes are only known on the device: size the grids for the worst case that can matter
     const uint32_t travGrid = grid_for(std::min<uint64_t>(p->cfg.maxTraversalRecords, (uint64_t)p->scene.lodNodeCount * 4 + 4096), 256, maxBlocks);
-    for (uint32_t level = 0; level < p->maxLevels && levelKernels; level++) {
-        // phase 2 reads level 0 from the replay buffer and then ping-pongs like phase 1 (level 0 writes fb)
-        const NodeRecord* in = level == 0 ? (phase == 1 ? fa : a.replayNodes) : ((level & 1u) ? fb : fa);
+    const uint32_t levelLaunches = spillMode ? std::min(p->maxLevels, std::max(1u, p->spillLevels)) : p->maxLevels;
+    for (uint32_t level = 0; level < levelLaunches && levelKernels; level++) {
+        // without the walk in front (forced level kernels) phase 2 reads level 0 from the replay buffer; then ping-pong like phase 1 (level 0 writes fb)
+        const NodeRecord* in = level == 0 ? ((phase == 1 || spillMode) ? fa : a.replayNodes) : ((level & 1u) ? fb : fa);
         hipLaunchKernelGGL(k_traverse, dim3(travGrid), dim3(256), 0, s, a, level, in, (level & 1u) ? fa : fb, buckets);
         BRMI_LAUNCH_CHECK(p, "k_traverse");
     }

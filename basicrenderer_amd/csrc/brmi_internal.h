@@ -126,6 +126,7 @@ struct brmi_pass {
     float bandPlaneTop[3] = {0, 0, 0}, bandPlaneBottom[3] = {0, 0, 0};
     uint64_t bandFirstPixel = 0, bandPixelCount = 0;   // tiled index range covering the band's tile rows
     uint32_t maxLevels = 1;
+    uint32_t spillLevels = 0;        // level-kernel launches the widest meshes still need below the point where the LDS walk hands them over
     uint32_t minLevelWidth = 0;      // narrowest such width over the meshes
     std::vector<uint32_t> hostMeshLevelWidth;   // per mesh metadata entry
     uint32_t maxLevelWidth = 0;      // widest BVH level of any mesh (decides between the per-instance and the per-level traversal)
