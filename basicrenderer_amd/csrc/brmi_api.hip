@@ -623,6 +623,7 @@ int brmi_read_counters(brmi_pass* p, brmi_counters* out, brmi_stream stream) {
         out->instancesTested += sp[0]; out->instancesVisible += sp[1]; out->nodesVisited += sp[2];
         overflowQueued += sp[STRIPE_OVERFLOW];
     } out->bucketRecords = c[CNT_BUCKETS]; out->meshletsTested = c[CNT_MESHLETS_TESTED];
+    for (uint32_t st = 0; st < CNT_STRIPE_COUNT; st++) out->meshletsTested += c[CNT_STRIPES + st * CNT_STRIPE_WORDS + STRIPE_MESHLETS_TESTED];
     out->visibleClusters = c[CNT_VISIBLE]; out->visibleClustersPhase2 = c[CNT_VISIBLE2];
     out->droppedRecords = c[CNT_DROPPED_RECORDS]; out->droppedClusters = c[CNT_DROPPED_CLUSTERS]; out->lightPagesUsed = c[CNT_LIGHT_PAGES];
     out->reserved[0] = c[CNT_SUM_VERTS_LO]; out->reserved[1] = c[CNT_SUM_VERTS_HI]; out->reserved[2] = c[CNT_SUM_TRIS_LO]; out->reserved[3] = c[CNT_SUM_TRIS_HI];

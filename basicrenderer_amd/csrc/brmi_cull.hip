@@ -188,7 +188,6 @@ __global__ void __launch_bounds__(256) k_traverse(CullArgs a, uint32_t level, co
             replay = (rec.nodeIdPacked >> 31) != 0;
             const bool allowRefine = ((rec.nodeIdPacked >> 30) & 1u) != 0;
             const uint32_t nodeId = rec.nodeIdPacked & 0x3FFFFFFFu;
-            atomicAdd(&a.counters[CNT_NODES_VISITED], 1u);
             const brmi_per_mesh_instance inst = sc.perMeshInstance[instIndex];
             const brmi_clod_mesh_metadata md = sc.meshMetadata[sc.clodOffsets[instIndex].clodMeshMetadataIndex];
             skinned = (sc.perMesh[inst.perMeshBufferIndex].vertexFlags & BRMI_VERTEX_SKINNED) != 0;
@@ -235,6 +234,10 @@ __global__ void __launch_bounds__(256) k_traverse(CullArgs a, uint32_t level, co
                     }
                 }
             }
+        }
+        {   // statistics: one atomic per wave on one of 64 stripes
+            const uint64_t hm = __ballot(have);
+            if (hm != 0ull && (threadIdx.x & 63u) == 0u) atomicAdd(&a.counters[CNT_STRIPES + (blockIdx.x & (CNT_STRIPE_COUNT - 1u)) * CNT_STRIPE_WORDS + 2u], (uint32_t)__popcll(hm));
         }
         if (a.occlusion && a.phase == 1u) {   // hand the rejected node to phase 2 (workGraphCulling.hlsl:3094-3112: drop + count when full)
             const uint32_t slot = wave_append(&a.counters[CNT_REPLAY_NODES], occluded);
@@ -605,7 +608,7 @@ __global__ void __launch_bounds__(256) k_cull_clusters(CullArgs a, const BucketR
     const uint64_t totalLanes = (uint64_t)bucketCount * a.factor;
     const uint64_t rounded = (totalLanes + 63ull) & ~63ull;
     for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < rounded; idx += (uint64_t)mainBlocks * blockDim.x) {
-        bool survives = false, occluded = false;
+        bool survives = false, occluded = false, tested = false;
         uint4 packed = make_uint4(0, 0, 0, 0);
         uint32_t bit = 0;
         BucketRecord again{};
@@ -614,7 +617,7 @@ __global__ void __launch_bounds__(256) k_cull_clusters(CullArgs a, const BucketR
             const BucketRecord b = buckets[bi];
             const uint32_t count = b.meshletIndexAndCount >> 16, first = b.meshletIndexAndCount & 0xFFFFu;
             if (m < count && b.pageSlabDescriptorIndex != 0u) {
-                atomicAdd(&a.counters[CNT_MESHLETS_TESTED], 1u);
+                tested = true;
                 const bool replay = (b.groupIdPacked >> 31) != 0;
                 const uint32_t lm = first + m;
                 const uint8_t* slab = sc.slabs[b.pageSlabDescriptorIndex];
@@ -655,6 +658,10 @@ __global__ void __launch_bounds__(256) k_cull_clusters(CullArgs a, const BucketR
                     }
                 }
             }
+        }
+        {   // statistics: one atomic per wave on one of 64 stripes
+            const uint64_t tm = __ballot(tested);
+            if (tm != 0ull && (threadIdx.x & 63u) == 0u) atomicAdd(&a.counters[CNT_STRIPES + (blockIdx.x & (CNT_STRIPE_COUNT - 1u)) * CNT_STRIPE_WORDS + STRIPE_MESHLETS_TESTED], (uint32_t)__popcll(tm));
         }
         if (a.occlusion && a.phase == 1u) {
             const uint32_t rs = wave_append(&a.counters[CNT_REPLAY_MESHLETS], occluded);

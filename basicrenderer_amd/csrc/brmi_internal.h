@@ -13,10 +13,7 @@ namespace brmi {
 
 // device-visible counters block (u32 words) at the head of the workspace
 enum CounterIndex : uint32_t {
-    CNT_BUCKETS = 0,          // bucket records appended by the traversal
-    CNT_TEMP_VISIBLE,         // survivors appended by the cluster cull (phase 1)
-    CNT_TEMP_VISIBLE2,        // survivors of phase 2
-    CNT_VISIBLE,              // phase-1 visible clusters after compaction (min(capacity))
+    CNT_VISIBLE = 3,          // phase-1 visible clusters after compaction (min(capacity))
     CNT_VISIBLE2,             // phase-2 visible clusters after compaction
     CNT_DROPPED_RECORDS,
     CNT_DROPPED_CLUSTERS,
@@ -25,9 +22,7 @@ enum CounterIndex : uint32_t {
     CNT_NODES_VISITED,
     CNT_MESHLETS_TESTED,
     CNT_LIGHT_PAGES,
-    CNT_REPLAY_NODES,
-    CNT_REPLAY_MESHLETS,
-    CNT_SUM_VERTS_LO, CNT_SUM_VERTS_HI,     // sum of vertex counts of rasterised clusters (u64)
+    CNT_SUM_VERTS_LO = 14, CNT_SUM_VERTS_HI,     // sum of vertex counts of rasterised clusters (u64)
     CNT_SUM_TRIS_LO, CNT_SUM_TRIS_HI,
     CNT_RASTER_CLUSTERS,
     CNT_BIN_OVERFLOW,         // raster records that found their screen bin full (rasterised in place with global atomics)
@@ -41,7 +36,15 @@ enum CounterIndex : uint32_t {
     CNT_STRIPE_COUNT = 64, CNT_STRIPE_WORDS = 32,
     STRIPE_DEFERRED_A = 4, STRIPE_DEFERRED_B = 8,   // words of a stripe: deferred-pixel list lengths (3 classes each) of alternating shading calls
     STRIPE_OVERFLOW = 3,      // word of a stripe: records in the stripe's raster overflow queue
-    CNT_WORDS = 128 + 64 * 32
+    STRIPE_MESHLETS_TESTED = 12,   // word of a stripe: meshlets the cluster cull looked at (statistics; one shared word cost a same-line atomic per wave)
+    // the append counters every wave of the culling kernels hits (atomics with return) each on a 128 B line of its own: on one line they
+    // serialise against each other and against the statistics (~100 wave-level atomics per microsecond and line)
+    CNT_BUCKETS = 128 + 64 * 32,            // bucket records appended by the traversal
+    CNT_TEMP_VISIBLE = CNT_BUCKETS + 32,    // survivors appended by the cluster cull (phase 1)
+    CNT_TEMP_VISIBLE2 = CNT_BUCKETS + 64,   // survivors of phase 2
+    CNT_REPLAY_NODES = CNT_BUCKETS + 96,
+    CNT_REPLAY_MESHLETS = CNT_BUCKETS + 128,
+    CNT_WORDS = CNT_BUCKETS + 160
 };
 
 // Phase 2 starts from the replay buffers: the replayed meshlets become the first bucket records, the replayed nodes the level-0 frontier;
