@@ -748,12 +748,12 @@ __global__ void __launch_bounds__(256) k_scan_words(const uint32_t* bitmask, uin
 // Places every survivor at its rank.  Also accumulates the vertex / triangle totals of the clusters that will be
 // rasterised (statistics for the algorithmic-byte count), one atomic per wave: a per-cluster atomic on three
 // shared words would serialise the whole rasteriser (~90 same-address atomics per microsecond).
-// LOCAL_RANK (survivor bitmasks of <= LOCAL_RANK_WORDS words): no rank kernel runs before this one; every workgroup that has survivors to
-// place scans the popcounts itself -- one LDS prefix per group of 2^groupShift words (<= LOCAL_RANK_GROUPS groups), the words of a survivor's
-// own group are counted on demand -- and workgroup 0 publishes the total.  One launch less per culling phase (5 us; 21 us where a single
-// workgroup used to scan the dense frame's 25 k words).
-constexpr uint32_t LOCAL_RANK_GROUPS = 8192, LOCAL_RANK_WORDS = LOCAL_RANK_GROUPS << 4;
-struct LocalRank { uint32_t totalWords, outIndex, usedIndex, groupShift; };
+// LOCAL_RANK (survivor bitmasks of <= LOCAL_RANK_WORDS words: every BASELINE-class scene): no rank kernel runs before this one; every
+// workgroup that has survivors to place scans the popcounts itself into LDS (a few thousand L2-resident words), workgroup 0 publishes the
+// total.  One ~5 us launch less per culling phase.  Larger bitmasks take the three scan launches (a variant with one LDS prefix per group
+// of words up to 2^17 words was measured on the dense frame's 25 k words: 55 us per phase against 27).
+constexpr uint32_t LOCAL_RANK_WORDS = 8192;
+struct LocalRank { uint32_t totalWords, outIndex, usedIndex; };
 template <bool LOCAL_RANK>
 __global__ void __launch_bounds__(256) k_scatter_visible(const TempVisible* temp, uint32_t* counters, uint32_t tempCountIndex, const uint32_t* bitmask,
                                                         const uint32_t* wordPrefix, uint4* visible, uint32_t baseIndexCounter, uint32_t capacity, uint32_t visibleCapacity,
@@ -762,14 +762,12 @@ __global__ void __launch_bounds__(256) k_scatter_visible(const TempVisible* temp
     const uint32_t n = min(counters[tempCountIndex], visibleCapacity);
     const uint32_t base = baseIndexCounter == 0xFFFFFFFFu ? 0u : counters[baseIndexCounter];
     const uint32_t rounded = (n + 63u) & ~63u;
-    __shared__ uint32_t prefixLds[LOCAL_RANK ? LOCAL_RANK_GROUPS : 1];
+    __shared__ uint32_t prefixLds[LOCAL_RANK ? LOCAL_RANK_WORDS : 1];
     __shared__ uint32_t waveTotals[4];
     if (LOCAL_RANK) {
         if (blockIdx.x != 0u && blockIdx.x * blockDim.x >= rounded) return;       // nothing to place here (workgroup 0 always publishes the total)
-        const uint32_t groups = (lr.totalWords + (1u << lr.groupShift) - 1u) >> lr.groupShift;
-        const uint32_t gspan = (groups + 255u) / 256u;                         // whole groups per thread
-        const uint32_t g0 = threadIdx.x * gspan, g1 = min(g0 + gspan, groups);
-        const uint32_t w0 = g0 << lr.groupShift, w1 = min(g1 << lr.groupShift, lr.totalWords);
+        const uint32_t span = (lr.totalWords + 255u) / 256u;
+        const uint32_t w0 = threadIdx.x * span, w1 = min(w0 + span, lr.totalWords);
         uint32_t sum = 0;
         for (uint32_t w = w0; w < w1; w++) sum += __popc(bitmask[w]);
         uint32_t incl = sum;
@@ -780,7 +778,7 @@ __global__ void __launch_bounds__(256) k_scatter_visible(const TempVisible* temp
         uint32_t waveBase = 0, all = 0;
         for (uint32_t w = 0; w < 4; w++) { if (w < (threadIdx.x >> 6)) waveBase += waveTotals[w]; all += waveTotals[w]; }
         uint32_t run = waveBase + incl - sum;
-        for (uint32_t w = w0; w < w1; w++) { if ((w & ((1u << lr.groupShift) - 1u)) == 0u) prefixLds[w >> lr.groupShift] = run; run += __popc(bitmask[w]); }
+        for (uint32_t w = w0; w < w1; w++) { prefixLds[w] = run; run += __popc(bitmask[w]); }
         if (blockIdx.x == 0u && threadIdx.x == 0u) counters[lr.outIndex] = min(all, capacity - (lr.usedIndex == 0xFFFFFFFFu ? 0u : min(counters[lr.usedIndex], capacity)));
         __syncthreads();
     }
@@ -792,9 +790,7 @@ __global__ void __launch_bounds__(256) k_scatter_visible(const TempVisible* temp
         if (i < n) {
             t = temp[i];
             const uint32_t w = t.bit >> 5, b = t.bit & 31u;
-            uint32_t rank = __popc(bitmask[w] & ((1u << b) - 1u));
-            if (LOCAL_RANK) { rank += prefixLds[w >> lr.groupShift]; for (uint32_t v = (w >> lr.groupShift) << lr.groupShift; v < w; v++) rank += __popc(bitmask[v]); }
-            else rank += wordPrefix[w];
+            const uint32_t rank = (LOCAL_RANK ? prefixLds[w] : wordPrefix[w]) + __popc(bitmask[w] & ((1u << b) - 1u));
             dst = base + rank;
             if (dst < capacity) {
                 visible[dst] = t.packed;
@@ -964,9 +960,9 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
     BRMI_LAUNCH_CHECK(p, "k_cull_clusters");
     // phase 2 appends behind the phase-1 clusters: its capacity is what phase 1 left
     const uint32_t outIndex = phase == 1 ? CNT_VISIBLE : CNT_VISIBLE2, usedIndex = phase == 1 ? 0xFFFFFFFFu : (uint32_t)CNT_VISIBLE;
+    // every workgroup of the scatter scanning the bitmask itself pays off while the bitmask is small (BASELINE-class scenes: ~1-4 k words);
+    // from 8 k words on the three scan launches are faster (dense frame, 25 k words: 27 us against 55 us per phase)
     const bool localRank = p->totalWords <= LOCAL_RANK_WORDS && !p->forceLevelKernels;
-    uint32_t groupShift = 0;
-    while (((p->totalWords + (1u << groupShift) - 1u) >> groupShift) > LOCAL_RANK_GROUPS) groupShift++;
     if (localRank) {
         // ranked inside the scatter kernel
     } else {
@@ -977,7 +973,7 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
     auto scatter = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(smallGrid), dim3(256), 0, s, temp, p->counters(), (uint32_t)(phase == 1 ? CNT_TEMP_VISIBLE : CNT_TEMP_VISIBLE2), bitmask, wordPrefix,
                            static_cast<uint4*>(p->res[BRMI_RES_VISIBLE_CLUSTERS]), phase == 1 ? 0xFFFFFFFFu : (uint32_t)CNT_VISIBLE, p->cfg.maxVisibleClusters, p->cfg.maxVisibleClusters, p->scene, p->wsPtr<ClusterSetup>(p->ws.clusterSetup), p->resolveCapacity, p->wsPtr<uint8_t>(p->ws.usedClusters),
-                           (p->sceneHasTextures || p->sceneHasAlphaTest || p->sceneHasVertexColors) ? p->wsPtr<ClusterUv>(p->ws.clusterUv) : nullptr, LocalRank{p->totalWords, outIndex, usedIndex, groupShift});
+                           (p->sceneHasTextures || p->sceneHasAlphaTest || p->sceneHasVertexColors) ? p->wsPtr<ClusterUv>(p->ws.clusterUv) : nullptr, LocalRank{p->totalWords, outIndex, usedIndex});
     };
     if (localRank) scatter(k_scatter_visible<true>); else scatter(k_scatter_visible<false>);
     BRMI_LAUNCH_CHECK(p, "compaction");
