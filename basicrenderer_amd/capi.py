@@ -18,6 +18,19 @@ class SceneParams(C.Structure):
                 ("materialFeatures", u32), ("cameraStep", u32), ("lodBuilder", u32), ("spotLightEvery", u32), ("detail", f32), ("reserved", u32 * 2)]
 
 
+class MeshInput(C.Structure):
+    _fields_ = [("positions", vp), ("normals", vp), ("uvs", vp), ("colors", vp), ("vertexCount", C.c_size_t), ("indices", vp), ("indexCount", C.c_size_t),
+                ("material", u32), ("reserved", u32 * 3)]
+
+
+class InstanceInput(C.Structure):
+    _fields_ = [("mesh", u32), ("reverseWinding", u32), ("model", (f32 * 4) * 4)]
+
+
+class ViewInput(C.Structure):
+    _fields_ = [("eye", f32 * 3), ("yaw", f32), ("pitch", f32), ("fovYDegrees", f32), ("zNear", f32), ("zFar", f32)]
+
+
 class DagGroup(C.Structure):
     _fields_ = [("depth", C.c_int32), ("center", f32 * 3), ("radius", f32), ("error", f32), ("firstCluster", u32), ("clusterCount", u32)]
 
@@ -179,6 +192,8 @@ def scene_lib():
         lib.brmi_scene_create.argtypes = [C.POINTER(SceneParams)]
         lib.brmi_scene_create_with_dag_builder.restype = vp
         lib.brmi_scene_create_with_dag_builder.argtypes = [C.POINTER(SceneParams), vp, vp, vp]
+        lib.brmi_scene_create_from_meshes.restype = vp
+        lib.brmi_scene_create_from_meshes.argtypes = [C.POINTER(SceneParams), C.POINTER(MeshInput), u32, C.POINTER(InstanceInput), u32, C.POINTER(ViewInput), vp, vp, vp]
         lib.brmi_lod_build.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.POINTER(Dag)]
         lib.brmi_lod_release.argtypes = [vp, C.POINTER(Dag)]
         lib.brmi_lod_release.restype = None

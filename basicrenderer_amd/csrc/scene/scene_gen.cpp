@@ -159,6 +159,7 @@ V3 evalPatch(const PatchDef& p, double u, double v) {
 }
 
 struct MeshDef {
+    const brmi_mesh_input* user = nullptr;      // the caller's mesh (brmi_scene_create_from_meshes) instead of patches
     std::vector<PatchDef> patches;
     uint32_t lodLevels = 1;      // DAG depth count (1 = flat)
     uint32_t material = 0;
@@ -536,6 +537,29 @@ uint32_t buildQuadtreeDag(const MeshDef& def, bool hasUv, bool hasColor, std::ve
 uint32_t buildClusterLodDag(const brmi_scene& sc, const MeshDef& def, bool hasUv, bool hasColor, std::vector<MeshletBuild>& meshlets, std::vector<GroupBuild>& groups) {
     if (!sc.dagBuild) return 0;
     std::vector<float> pos, nrm, uvs; std::vector<uint32_t> idx, colors;
+    if (def.user) {
+        const brmi_mesh_input& u = *def.user;
+        const size_t V = u.vertexCount;
+        pos.assign(u.positions, u.positions + V * 3); idx.assign(u.indices, u.indices + u.indexCount);
+        if (u.normals) nrm.assign(u.normals, u.normals + V * 3);
+        else {      // area-weighted vertex normals
+            std::vector<V3> acc(V, V3{0, 0, 0});
+            for (size_t t = 0; t + 2 < idx.size(); t += 3) {
+                const uint32_t a = idx[t], b = idx[t + 1], c = idx[t + 2];
+                const V3 pa{pos[a * 3], pos[a * 3 + 1], pos[a * 3 + 2]}, pb{pos[b * 3], pos[b * 3 + 1], pos[b * 3 + 2]}, pc{pos[c * 3], pos[c * 3 + 1], pos[c * 3 + 2]};
+                const V3 n = cross(pb - pa, pc - pa);
+                acc[a] = acc[a] + n; acc[b] = acc[b] + n; acc[c] = acc[c] + n;
+            }
+            nrm.resize(V * 3);
+            for (size_t v = 0; v < V; v++) {
+                const double l = std::sqrt(dot(acc[v], acc[v]));
+                const V3 n = l > 0 ? acc[v] * (1.0 / l) : V3{0, 1, 0};
+                nrm[v * 3] = (float)n.x; nrm[v * 3 + 1] = (float)n.y; nrm[v * 3 + 2] = (float)n.z;
+            }
+        }
+        if (u.uvs) uvs.assign(u.uvs, u.uvs + V * 2); else uvs.assign(V * 2, 0.0f);
+        if (u.colors) colors.assign(u.colors, u.colors + V); else colors.assign(V, 0xFFFFFFFFu);
+    }
     for (const PatchDef& p : def.patches) {
         const uint32_t NU = p.nu0 * 8, NV = p.nv0 * 8, base = (uint32_t)(pos.size() / 3);
         for (uint32_t j = 0; j <= NV; j++) for (uint32_t i = 0; i <= NU; i++) {
@@ -1616,6 +1640,53 @@ static brmi_scene* createScene(const brmi_scene_params* params, const char* cach
     return sc;
 }
 brmi_scene* brmi_scene_create(const brmi_scene_params* params) { return createScene(params, nullptr); }
+
+brmi_scene* brmi_scene_create_from_meshes(const brmi_scene_params* params, const brmi_mesh_input* meshes, uint32_t meshCount, const brmi_instance_input* instances, uint32_t instanceCount,
+                                          const brmi_view_input* view, brmi_dag_build_fn build, brmi_dag_release_fn release, void* user) {
+    if (!params || params->width == 0 || params->height == 0 || !meshes || meshCount == 0 || !instances || instanceCount == 0 || !view) return nullptr;
+    if (!(view->zNear > 0.0f) || !(view->zFar > view->zNear) || !(view->fovYDegrees > 0.0f) || !(view->fovYDegrees < 180.0f)) return nullptr;
+    uint32_t materialCount = 1;
+    for (uint32_t m = 0; m < meshCount; m++) {
+        const brmi_mesh_input& u = meshes[m];
+        if (!u.positions || !u.indices || u.vertexCount == 0 || u.indexCount < 3 || u.indexCount % 3 != 0 || u.vertexCount > 0x7FFFFFFFull || u.material > 4095u) return nullptr;
+        for (size_t i = 0; i < u.indexCount; i++) if (u.indices[i] >= u.vertexCount) return nullptr;
+        for (size_t i = 0; i < u.vertexCount * 3; i++) if (!std::isfinite(u.positions[i])) return nullptr;
+        materialCount = std::max(materialCount, u.material + 1u);
+    }
+    for (uint32_t i = 0; i < instanceCount; i++) {
+        if (instances[i].mesh >= meshCount) return nullptr;
+        for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) if (!std::isfinite(instances[i].model[r][c])) return nullptr;
+    }
+    brmi_scene* sc = new brmi_scene();
+    sc->params = *params;
+    if (sc->params.sizeScale <= 0.0f) sc->params.sizeScale = 1.0f;
+    sc->params.detail = 1.0f;
+    if (sc->params.lodBuilder == BRMI_LOD_BUILDER_EXTERNAL && build) { sc->dagBuild = build; sc->dagRelease = release; sc->dagUser = user; }
+    else { sc->params.lodBuilder = BRMI_LOD_BUILDER_OWN; sc->dagBuild = brmi_lod_build; sc->dagRelease = brmi_lod_release; }      // (the quadtree builder only knows the procedural patches)
+    for (int k = 0; k < 3; k++) { sc->stats.sceneMin[k] = 1e30f; sc->stats.sceneMax[k] = -1e30f; }
+    Pcg32 rng(0xB451C0DEull + params->seed, 54u + 77u);
+    addMaterials(*sc, rng, materialCount);
+    for (uint32_t m = 0; m < meshCount && !sc->failed; m++) {
+        MeshDef def; def.user = &meshes[m]; def.material = meshes[m].material; def.lodLevels = sc->params.lodLevels ? sc->params.lodLevels : 1;
+        buildMesh(*sc, def, m);
+    }
+    if (sc->failed) { delete sc; return nullptr; }
+    for (uint32_t i = 0; i < instanceCount; i++) {
+        M4 model{};
+        for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) model.m[r][c] = instances[i].model[r][c];
+        addInstance(*sc, {instances[i].mesh, model, instances[i].reverseWinding != 0});
+    }
+    setCamera(*sc, V3{view->eye[0], view->eye[1], view->eye[2]}, view->yaw, view->pitch, view->fovYDegrees, view->zNear, view->zFar);
+    const V3 lo{sc->stats.sceneMin[0], sc->stats.sceneMin[1], sc->stats.sceneMin[2]}, hi{sc->stats.sceneMax[0], sc->stats.sceneMax[1], sc->stats.sceneMax[2]};
+    const double extent = std::max(1e-3, std::max(hi.x - lo.x, std::max(hi.y - lo.y, hi.z - lo.z)));
+    if (sc->params.withDirectionalLight) addLight(*sc, BRMI_LIGHT_DIRECTIONAL, {0, 0, 0}, {1, 1, 1}, 10.0f, {1, 0, 0}, {-0.3, -1.0, -0.4});
+    for (uint32_t i = 0; i < sc->params.numPointLights; i++)
+        addLight(*sc, BRMI_LIGHT_POINT, {rng.range((float)lo.x, (float)hi.x), rng.range((float)lo.y, (float)hi.y), rng.range((float)lo.z, (float)hi.z)}, {rng.uniform(), rng.uniform(), rng.uniform()},
+                 (float)(3.0 * extent * extent / 16.0), {0, 0, 1}, {0, 0, 0});
+    buildLuts(*sc);
+    finishFrame(*sc);
+    return sc;
+}
 brmi_scene* brmi_scene_create_with_dag_builder(const brmi_scene_params* params, brmi_dag_build_fn build, brmi_dag_release_fn release, void* user) {
     if (!params || params->lodBuilder != BRMI_LOD_BUILDER_EXTERNAL || !build) return nullptr;
     return createScene(params, nullptr, build, release, user);

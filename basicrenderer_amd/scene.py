@@ -35,9 +35,13 @@ TEXTURE_DESC_BYTES = 96      # brmi_texture_desc; its first 8 bytes are the texe
 class Scene:
     def __init__(self, preset="sponza", width=3840, height=2160, seed=0, point_lights=64, directional=True,
                  lod_levels=0, size_scale=1.0, material_features=0, camera_step=0, skinned_fraction=0.0, lod_builder="quadtree", spot_every=0, cache_dir=None, export_cache=None,
-                 detail=1.0, dag_builder=None):
+                 detail=1.0, dag_builder=None, meshes=None, instances=None, view=None):
         """lod_builder: "quadtree" (regular grid DAG) or "own" (the library's cluster-LOD builder); dag_builder = (build_fn, release_fn)
-        addresses of a caller-supplied builder with the brmi_dag_build_fn / brmi_dag_release_fn signatures (lod_builder becomes "external")."""
+        addresses of a caller-supplied builder with the brmi_dag_build_fn / brmi_dag_release_fn signatures (lod_builder becomes "external").
+
+        meshes / instances / view: a scene of the CALLER's geometry (brmi_scene_create_from_meshes) instead of a preset.  meshes = list of
+        dicts {positions [V,3] f32, indices [T*3] u32, normals / uvs / colors optional, material}; instances = list of (mesh index, 4x4
+        row-vector model matrix[, reverse_winding]); view = dict(eye, yaw, pitch, fov, near, far)."""
         lib = capi.scene_lib()
         p = capi.SceneParams()
         p.preset = PRESETS[preset] if isinstance(preset, str) else int(preset)
@@ -55,7 +59,36 @@ class Scene:
         self.preset, self.width, self.height = preset, width, height
         self._lib = lib
         # cache_dir: take every mesh from CLodCache files (include/brmi_scene.h) instead of building it; export_cache: write them
-        if cache_dir:
+        if meshes is not None:
+            if lod_builder == "quadtree":
+                p.lodBuilder = capi.LOD_BUILDERS["own"]
+            keep = []
+            mi = (capi.MeshInput * len(meshes))()
+            for k, m in enumerate(meshes):
+                pos = np.ascontiguousarray(m["positions"], dtype=np.float32).reshape(-1, 3); idx = np.ascontiguousarray(m["indices"], dtype=np.uint32).ravel()
+                keep += [pos, idx]
+                mi[k].positions, mi[k].vertexCount, mi[k].indices, mi[k].indexCount = pos.ctypes.data, len(pos), idx.ctypes.data, len(idx)
+                for key, dt, comps in (("normals", np.float32, 3), ("uvs", np.float32, 2), ("colors", np.uint32, 1)):
+                    if m.get(key) is not None:
+                        a = np.ascontiguousarray(m[key], dtype=dt).reshape(len(pos), comps); keep.append(a)
+                        setattr(mi[k], key, a.ctypes.data)
+                mi[k].material = int(m.get("material", 0))
+            ii = (capi.InstanceInput * len(instances))()
+            for k, inst in enumerate(instances):
+                ii[k].mesh, ii[k].reverseWinding = int(inst[0]), int(bool(inst[2])) if len(inst) > 2 else 0
+                mm = np.asarray(inst[1], dtype=np.float32).reshape(4, 4)
+                for r in range(4):
+                    for c in range(4):
+                        ii[k].model[r][c] = float(mm[r, c])
+            vi = capi.ViewInput()
+            vi.eye[0], vi.eye[1], vi.eye[2] = (float(x) for x in view["eye"])
+            vi.yaw, vi.pitch, vi.fovYDegrees, vi.zNear, vi.zFar = float(view.get("yaw", 0.0)), float(view.get("pitch", 0.0)), float(view.get("fov", 60.0)), float(view.get("near", 0.1)), float(view.get("far", 1000.0))
+            b = dag_builder if dag_builder is not None else (None, None)
+            self._h = lib.brmi_scene_create_from_meshes(C.byref(p), mi, len(meshes), ii, len(instances), C.byref(vi), b[0], b[1], None)
+            if not self._h:
+                raise RuntimeError("brmi_scene_create_from_meshes failed: bad mesh / instance input")
+            del keep
+        elif cache_dir:
             self._h = lib.brmi_scene_create_from_cache(C.byref(p), str(cache_dir).encode())
         elif dag_builder is not None:
             self._h = lib.brmi_scene_create_with_dag_builder(C.byref(p), dag_builder[0], dag_builder[1], None)

@@ -120,6 +120,30 @@ brmi_scene* brmi_scene_create(const brmi_scene_params* params);
 /* lodBuilder = EXTERNAL: `build` is called once per mesh, `release` (may be NULL) once its DAG has been consumed. */
 brmi_scene* brmi_scene_create_with_dag_builder(const brmi_scene_params* params, brmi_dag_build_fn build, brmi_dag_release_fn release, void* user);
 
+/* A scene of the CALLER's meshes (row f-1: real content instead of the procedural stand-ins): every mesh goes through the cluster-LOD
+ * builder (this library's, or `build` when lodBuilder = EXTERNAL) and the page / BVH packer; materials (params->materialFeatures), lights
+ * (one directional + params->numPointLights inside the scene's bounds) and the lookup tables are the procedural ones.  params->preset is
+ * ignored.  NULL on bad input (indices out of range, non-finite positions, no triangles, an instance naming a missing mesh). */
+typedef struct brmi_mesh_input {
+    const float*    positions;      /* vertexCount x 3 */
+    const float*    normals;        /* vertexCount x 3, or NULL: area-weighted vertex normals are derived */
+    const float*    uvs;            /* vertexCount x 2, or NULL: (0, 0) where the scene's materials want texcoords */
+    const uint32_t* colors;         /* vertexCount x RGBA8, or NULL: white where materialFeatures bit 5 asks for vertex colours */
+    size_t          vertexCount;
+    const uint32_t* indices;        /* triangle list */
+    size_t          indexCount;
+    uint32_t        material;       /* the mesh's material (materials 0 .. max over the meshes are generated) */
+    uint32_t        reserved[3];
+} brmi_mesh_input;
+typedef struct brmi_instance_input {
+    uint32_t mesh, reverseWinding;
+    float    model[4][4];           /* row-vector convention, as the reference's PerObjectCB: p' = p * M, translation in row 3 */
+} brmi_instance_input;
+typedef struct brmi_view_input { float eye[3], yaw, pitch, fovYDegrees, zNear, zFar; } brmi_view_input;   /* yaw about +y, pitch about the camera's x; looking down -z at 0, 0 */
+brmi_scene* brmi_scene_create_from_meshes(const brmi_scene_params* params, const brmi_mesh_input* meshes, uint32_t meshCount,
+                                          const brmi_instance_input* instances, uint32_t instanceCount, const brmi_view_input* view,
+                                          brmi_dag_build_fn build, brmi_dag_release_fn release, void* user);
+
 /* This library's cluster-LOD builder, with the brmi_dag_build_fn / brmi_dag_release_fn signatures (user is ignored).
  * Limits 128 vertices / 128 triangles per cluster, groups of ~384 clusters with <= 8 refined groups each, target ratio 0.5, stuck
  * threshold 0.85, error merge max(1.5 x previous, current): the settings of BR/src/Mesh/ClusterLODUtilities.cpp:5426-5458. */

@@ -1,6 +1,7 @@
 import os
 import sys
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -111,3 +112,39 @@ def oracle_frames(scenes):
         return cache[name]
 
     return get
+
+
+def caller_mesh_scene(width=480, height=270, **kw):
+    """A scene of meshes this file makes up (not the generator's patches) through brmi_scene_create_from_meshes: a torus with a UV seam, an
+    open height field without normals (derived by the library) and a fan of large triangles; two instances of the torus, one mirrored."""
+    from basicrenderer_amd import Scene as RawScene
+
+    def torus(nu=96, nv=48, R=1.0, r=0.4):
+        u = np.linspace(0, 2 * np.pi, nu, endpoint=False); v = np.linspace(0, 2 * np.pi, nv, endpoint=False)
+        U, V = np.meshgrid(u, v, indexing="ij")
+        P = np.stack([(R + r * np.cos(V)) * np.cos(U), r * np.sin(V), (R + r * np.cos(V)) * np.sin(U)], -1).reshape(-1, 3)
+        N = np.stack([np.cos(V) * np.cos(U), np.sin(V), np.cos(V) * np.sin(U)], -1).reshape(-1, 3)
+        uv = np.stack([U / (2 * np.pi) * 4, V / (2 * np.pi) * 2], -1).reshape(-1, 2)
+        i, j = np.meshgrid(np.arange(nu), np.arange(nv), indexing="ij")
+        a = (i * nv + j).ravel(); b = (((i + 1) % nu) * nv + j).ravel(); c = (((i + 1) % nu) * nv + (j + 1) % nv).ravel(); d = (i * nv + (j + 1) % nv).ravel()
+        return dict(positions=P.astype(np.float32), normals=N.astype(np.float32), uvs=uv.astype(np.float32), indices=np.stack([a, c, b, a, d, c], 1).ravel().astype(np.uint32), material=0)
+
+    def field(n=80):
+        x, z = np.meshgrid(np.linspace(-4, 4, n + 1), np.linspace(-4, 4, n + 1), indexing="ij")
+        y = -0.8 + 0.15 * np.sin(x * 2.1) * np.cos(z * 1.7) + 0.04 * np.sin(x * 9.0 + z * 7.0)
+        P = np.stack([x, y, z], -1).reshape(-1, 3)
+        i, j = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+        a = (i * (n + 1) + j).ravel(); b = a + (n + 1); c = b + 1; d = a + 1
+        return dict(positions=P.astype(np.float32), indices=np.stack([a, d, c, a, c, b], 1).ravel().astype(np.uint32), uvs=(P[:, [0, 2]] * 0.5).astype(np.float32), material=1)
+
+    def fan():
+        P = np.array([[0, 3.0, -6.0]] + [[8 * np.cos(t), 3.0 + 4 * np.sin(t), -6.0] for t in np.linspace(0, 2 * np.pi, 13)[:-1]], dtype=np.float32)
+        I = np.array([[0, k + 1, (k + 1) % 12 + 1] for k in range(12)], dtype=np.uint32).ravel()
+        return dict(positions=P, indices=I, material=2)
+
+    eye = np.eye(4, dtype=np.float32)
+    moved = eye.copy(); moved[3, :3] = [2.4, 0.2, -0.8]
+    mirrored = np.diag([-0.7, 0.7, 0.7, 1.0]).astype(np.float32); mirrored[3, :3] = [-2.2, 0.4, 0.3]
+    kw.setdefault("point_lights", 6)
+    return RawScene(width=width, height=height, meshes=[torus(), field(), fan()],
+                    instances=[(0, eye), (0, moved), (0, mirrored, True), (1, eye), (2, eye)], view=dict(eye=(0.5, 1.6, 4.5), yaw=0.05, pitch=-0.3, fov=65, near=0.1, far=200), **kw)

@@ -612,6 +612,43 @@ def test_lod_builder_output_is_well_formed_and_covers_the_surface(case, scenes):
     assert (ca != cb).mean() < 0.002          # same silhouettes
 
 
+def test_scene_of_caller_meshes_packs_their_triangles_exactly():
+    """brmi_scene_create_from_meshes (row f-1: real content through the builder and the page packer): the depth-0 clusters of every mesh hold
+    exactly the caller's triangles (positions are FLOAT3 pages: bit-exact), coarser levels exist, the oracle renders the scene, and bad input
+    is refused."""
+    import orc
+    from conftest import caller_mesh_scene
+    from basicrenderer_amd import Scene as RawScene
+    sc = caller_mesh_scene(material_features=8)
+    assert sc.stats["meshes"] == 3 and sc.stats["instances"] == 5 and sc.stats["lodLevelsMax"] >= 3
+    assert sc.stats["uniqueTriangles"] == 96 * 48 * 2 + 80 * 80 * 2 + 12
+    lod0 = set()
+    for slab in sc.slabs[1:]:
+        for page in range(0, len(slab), 1 << 18):
+            hdr = slab[page:page + 64].view(np.uint32)
+            for lm in range(int(hdr[0])):
+                d = slab[page + hdr[4] + lm * 64: page + hdr[4] + lm * 64 + 64].view(np.uint32)
+                V, T = int(d[7] >> 24), int(d[8] & 0xFFFF)
+                if int(d[8] >> 16) != 0:
+                    continue                                   # refines a group: not the finest level
+                pos = slab[page + hdr[6] + int(d[0]): page + hdr[6] + int(d[0]) + V * 12].view(np.float32).reshape(V, 3)
+                tri = slab[page + hdr[12] + int(d[2]): page + hdr[12] + int(d[2]) + 3 * T].reshape(T, 3)
+                for t in tri:
+                    lod0.add(tuple(sorted(tuple(pos[k].tobytes() for k in t))))
+    assert len(lod0) == sc.stats["uniqueTriangles"]             # every input triangle once, no other
+    f = orc.OracleFrame(sc).run()
+    covered = f.vis != EMPTY
+    assert 0.5 < covered.mean() < 1.0 and f.count > 20
+    hdr = f.hdr.view(np.float16).astype(np.float32)
+    assert not np.isnan(hdr).any() and hdr[np.isfinite(hdr)].max() > 0.1      # (a highlight next to a light may overflow fp16 to +inf, as in the reference's R16G16B16A16_FLOAT target)
+    tri = dict(positions=np.zeros((3, 3), np.float32), indices=np.array([0, 1, 5], np.uint32))
+    with pytest.raises(RuntimeError):
+        RawScene(width=64, height=64, meshes=[tri], instances=[(0, np.eye(4))], view=dict(eye=(0, 0, 3)))      # index out of range
+    tri["indices"] = np.array([0, 1, 2], np.uint32)
+    with pytest.raises(RuntimeError):
+        RawScene(width=64, height=64, meshes=[tri], instances=[(1, np.eye(4))], view=dict(eye=(0, 0, 3)))      # instance of a missing mesh
+
+
 def _dag_of(build, release, P, I):
     """Runs a brmi_dag_build_fn on (positions, indices); returns (groups[depth, error, firstCluster, clusterCount, radius, center xyz], clusters[group, refined, V, T, error, radius, center xyz], vertexRefs, triangles)."""
     from basicrenderer_amd import capi

@@ -355,6 +355,37 @@ def test_missing_texture_table_is_refused():
     VisibilityRenderer(Scene("tiny", 128, 72, point_lights=1, lod_levels=2, material_features=8)).close()
 
 
+@pytest.mark.parametrize("features,occlusion", [(0, False), (24 | 3, True)])
+def test_scene_of_caller_meshes_matches_the_oracle(features, occlusion):
+    """Row f-1 end to end: meshes made up by the test (a torus with a UV seam, a height field without normals, a fan of screen-sized
+    triangles; a mirrored instance) go through brmi_scene_create_from_meshes -- the library's LOD builder and page packer -- and the frame
+    matches the oracle: cluster list, keys, depth and G-buffer exact, HDR within one fp16 ULP."""
+    import orc
+    from conftest import caller_mesh_scene
+    from basicrenderer_amd.renderer import VisibilityRenderer
+    sc = caller_mesh_scene(material_features=features)
+    r = VisibilityRenderer(sc, stats=True, occlusion=occlusion)
+    o = orc.OracleFrame(sc)
+    if occlusion:
+        hz = None
+        for _ in range(2):
+            r.execute(); hz = o.run_occlusion(hz)
+        o.gbuffer(); o.light_cluster(); o.shade()
+    else:
+        r.execute(); o.run()
+    c = r.counters()
+    assert c.droppedRecords == 0 and c.droppedClusters == 0 and o.count > 20
+    assert np.array_equal(r.visible_clusters(), o.clusters[: o.count])
+    assert np.array_equal(r.visibility(), o.vis)
+    assert np.array_equal(r.depth().view(np.uint32), o.depth.view(np.uint32))
+    covered = o.vis != np.uint64(0xFFFFFFFFFFFFFFFF)
+    g = r.gbuffer()
+    assert np.array_equal(g["normals"][covered].view(np.uint32), o.normals[covered].view(np.uint32)) and np.array_equal(g["albedo"][covered], o.albedo[covered])
+    a, b = r.hdr().view(np.uint16).astype(np.int32), o.hdr.view(np.uint16).astype(np.int32)
+    assert np.abs(a - b).max() <= 1
+    r.close()
+
+
 def test_fused_gbuffer_and_shading_kernel_matches_the_oracle(monkeypatch):
     """BRMI_FUSE_SHADE=1: brmi_execute shades the plain pixels inside the G-buffer kernel (k_gbuffer_shade) from the words it has just stored;
     layered pixels still go through the per-class lists.  Same G-buffer bytes, HDR within one fp16 ULP of the oracle -- and of the two-kernel frame."""
