@@ -649,6 +649,30 @@ def test_scene_of_caller_meshes_packs_their_triangles_exactly():
         RawScene(width=64, height=64, meshes=[tri], instances=[(1, np.eye(4))], view=dict(eye=(0, 0, 3)))      # instance of a missing mesh
 
 
+def test_obj_loader_feeds_the_scene_builder(tmp_path):
+    """basicrenderer_amd.obj (harness): a cube with texcoords, negative indices, a quad and an n-gon face, two materials -> two meshes with
+    fan-triangulated faces, seam vertices kept apart, v flipped; the scene built from them renders in the oracle."""
+    import orc
+    from basicrenderer_amd import Scene as RawScene
+    from basicrenderer_amd.obj import frame_view, load_obj
+    lines = ["# cube", "v -1 -1 -1", "v 1 -1 -1", "v 1 1 -1", "v -1 1 -1", "v -1 -1 1", "v 1 -1 1", "v 1 1 1", "v -1 1 1",
+             "vt 0 0", "vt 1 0", "vt 1 1", "vt 0 1", "vn 0 0 1", "vn 0 0 -1",
+             "usemtl front", "f 5/1/1 6/2/1 7/3/1 8/4/1", "usemtl rest", "f 2/1/2 1/2/2 4/3/2 3/4/2",
+             "f 1/1 2/2 6/3 5/4", "f -6/1 -5/2 -1/3 -2/4", "f 4/1 8/2 7/3", "f 4/1 7/3 3/4", "f 1/1 5/2 8/3 4/4"]
+    path = tmp_path / "cube.obj"
+    path.write_text("\n".join(lines) + "\n")
+    meshes = load_obj(str(path))
+    assert [m["name"] for m in meshes] == ["front", "rest"] and [m["material"] for m in meshes] == [0, 1]
+    assert len(meshes[0]["indices"]) == 6 and len(meshes[1]["indices"]) == 3 * (2 + 2 + 2 + 1 + 1 + 2)
+    assert "normals" in meshes[0] and "normals" not in meshes[1] and "uvs" in meshes[1]
+    assert np.array_equal(meshes[0]["uvs"], np.array([[0, 1], [1, 1], [1, 0], [0, 0]], dtype=np.float32))      # v flipped
+    assert np.array_equal(meshes[0]["positions"][0], [-1, -1, 1])
+    sc = RawScene(width=160, height=90, point_lights=2, meshes=meshes, instances=[(0, np.eye(4)), (1, np.eye(4))], view=frame_view(meshes))
+    assert sc.stats["uniqueTriangles"] == 12
+    f = orc.OracleFrame(sc).run()
+    assert (f.vis != EMPTY).mean() > 0.05
+
+
 def _dag_of(build, release, P, I):
     """Runs a brmi_dag_build_fn on (positions, indices); returns (groups[depth, error, firstCluster, clusterCount, radius, center xyz], clusters[group, refined, V, T, error, radius, center xyz], vertexRefs, triangles)."""
     from basicrenderer_amd import capi
