@@ -40,7 +40,7 @@ DOMINANT_KERNEL = {"raster": "k_raster", "gbuffer": "k_gbuffer", "shade": "k_sha
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="bistro", choices=list(WORKLOADS),
                     help="bistro (default) = BASELINE.json configs[2], the north star's target frame; sponza = configs[1]; san_miguel = configs[3]; "
