@@ -45,7 +45,7 @@ def main():
         preset = rng.choice(["tiny", "tiny", "sponza", "bistro", "san_miguel", "zorah"])
         big = int(sys.argv[3]) if len(sys.argv) > 3 else 1          # optional third argument: size multiplier (4 = up to 3600 x 2080)
         W, H = rng.randrange(64, 900 * big), rng.randrange(48, 520 * big)
-        mf = rng.choice([0, 0, 3, 8, 24, 27, 32, 59, 63, 127, 4, 96 | 11, 128 | 8, 255, 128 | 91])
+        mf = rng.choice([0, 0, 3, 8, 24, 27, 32, 59, 63, 127, 4, 96 | 11, 128 | 8, 255, 128 | 91, 256 | 8, 256 | 27, 511, 256 | 128 | 64 | 11])
         kw = dict(seed=rng.randrange(1, 1 << 20), point_lights=rng.choice([0, 1, 7, 40, 150]), directional=rng.random() < 0.8, material_features=mf,
                   lod_levels=rng.choice([0, 1, 2, 3]), skinned_fraction=rng.choice([0.0, 0.0, 0.3, 1.0]), spot_every=rng.choice([0, 0, 2, 3]),
                   size_scale={"tiny": 1.0, "sponza": rng.choice([0.05, 0.2]), "bistro": rng.choice([0.05, 0.2]), "san_miguel": 0.02, "zorah": 0.003}[preset])
