@@ -29,6 +29,11 @@ int orc_sample_grad(const brmi_scene_buffers* sc, uint32_t textureIndex, uint32_
     }
     return 0;
 }
+uint32_t clusterSlice(float z, float zNear, float zFar, float zSplit, uint32_t nearSlices, uint32_t gz);      // orc_light.cpp
+int orc_cluster_slice(const float* z, uint64_t n, float zNear, float zFar, float zSplit, uint32_t nearSlices, uint32_t gz, uint32_t* out) {
+    for (uint64_t i = 0; i < n; i++) out[i] = clusterSlice(z[i], zNear, zFar, zSplit, nearSlices, gz);
+    return 0;
+}
 int orc_log2_poly(const float* in, float* out, uint64_t n) { for (uint64_t i = 0; i < n; i++) out[i] = log2Poly(in[i]); return 0; }
 // decoded UV set `uvSet` of every vertex of a visible cluster's meshlet; returns the vertex count
 int orc_cluster_uvs(const brmi_scene_buffers* sc, const brmi_visible_cluster* cluster, uint32_t uvSet, float* out) {

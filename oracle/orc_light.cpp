@@ -366,6 +366,17 @@ using namespace orc;
 
 extern "C" {
 
+// ComputeClusterID's slice of a view depth (lighting.hlsli:166-196).  log() = the correctly rounded fp32 logarithm (through double on both
+// sides): a pixel whose depth sits within an ulp of a slice boundary must land in the same slice on CPU and GPU, and their float logf
+// differ in the last bit.  (tests/test_oracle_cpu.py holds it against an arbitrary-precision restatement.)
+uint32_t clusterSlice(float z, float zNear, float zFar, float zSplit, uint32_t nearSlices, uint32_t gz) {
+    if (z < zSplit) { const float t = (z - zNear) / (zSplit - zNear); return t > 0.0f ? (uint32_t)(t * (float)nearSlices) : 0u; }
+    auto logCR = [](float x) { return (float)std::log((double)x); };
+    const float logStart = logCR(zSplit / zNear), logEnd = logCR(zFar / zNear), logZ = logCR(z / zNear);
+    const float u = (logZ - logStart) / (logEnd - logStart);
+    return nearSlices + (u > 0.0f ? (uint32_t)(u * (float)(gz - nearSlices)) : 0u);
+}
+
 // Slice plane depths (view space, negative): planes[s] = near plane of slice s, planes[s+1] = far plane.
 // clustering.hlsl:66-90.  Written with logf/expf on the host; `planes` has gridZ+1 pairs? No: one array
 // of 2*gridZ floats (near, far per slice) because the two expressions are not bit-identical.
@@ -587,16 +598,7 @@ int orc_shade_forward(const brmi_scene_buffers* scp, uint32_t W, uint32_t H, uin
                     const float tsx = (float)pf.screenResX / (float)gx, tsy = (float)pf.screenResY / (float)gy;
                     const uint32_t tx = (uint32_t)((float)px / tsx), ty = (uint32_t)((float)py / tsy);
                     const float z = std::fabs(posVS.z);
-                    uint32_t sliceZ;
-                    if (z < pf.clusterZSplitDepth) { const float t = (z - cam.zNear) / (pf.clusterZSplitDepth - cam.zNear); sliceZ = t > 0.0f ? (uint32_t)(t * (float)pf.nearClusterCount) : 0u; }
-                    else {
-                        // log() = the correctly rounded fp32 logarithm (through double on both sides): a pixel whose depth sits within an
-                        // ulp of a slice boundary must land in the same slice on CPU and GPU, and their float logf differ in the last bit
-                        auto logCR = [](float x) { return (float)std::log((double)x); };
-                        const float logStart = logCR(pf.clusterZSplitDepth / cam.zNear), logEnd = logCR(cam.zFar / cam.zNear), logZ = logCR(z / cam.zNear);
-                        const float u = (logZ - logStart) / (logEnd - logStart);
-                        sliceZ = pf.nearClusterCount + (u > 0.0f ? (uint32_t)(u * (float)(gz - pf.nearClusterCount)) : 0u);
-                    }
+                    const uint32_t sliceZ = clusterSlice(z, cam.zNear, cam.zFar, pf.clusterZSplitDepth, pf.nearClusterCount, gz);
                     const uint32_t ci = (uint32_t)((float)tx + (float)ty * (float)gx + (float)sliceZ * (float)gx * (float)gy);
                     if (ci < gx * gy * gz) {
                         const brmi_light_cluster& cl = clusters[ci];

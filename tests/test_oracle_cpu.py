@@ -649,6 +649,56 @@ def test_scene_of_caller_meshes_packs_their_triangles_exactly():
         RawScene(width=64, height=64, meshes=[tri], instances=[(1, np.eye(4))], view=dict(eye=(0, 0, 3)))      # instance of a missing mesh
 
 
+def test_cluster_slice_lookup_against_an_arbitrary_precision_restatement():
+    """ComputeClusterID's slice (lighting.hlsli:166-196) as the oracle evaluates it -- fp32 operations around a logarithm defined as the
+    CORRECTLY ROUNDED fp32 log -- against a restatement whose logarithm comes from 60-digit decimal arithmetic rounded once to fp32 (no libm on
+    the path): random depths, depths next to every slice boundary, and the table of slice starts the shading pass uses must be the exact
+    thresholds of that function."""
+    import decimal
+    import orc
+    lib = orc.lib()
+    lib.orc_cluster_slice.argtypes = [C.c_void_p, C.c_uint64, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.c_void_p]
+    f32 = np.float32
+    decimal.getcontext().prec = 60
+
+    def log_cr(x):                     # ln of the fp32 number x, rounded ONCE to fp32
+        d = decimal.Decimal(float(x)).ln()
+        lo = f32(float(d))             # float(d): correctly rounded to double; a second rounding to fp32 can only differ on a tie, checked below
+        near = [f32(np.nextafter(lo, f32(-np.inf))), lo, f32(np.nextafter(lo, f32(np.inf)))]
+        return min(near, key=lambda c: abs(decimal.Decimal(float(c)) - d))
+
+    def slice_ref(z, zn, zf, zs, ns, gz):
+        z, zn, zf, zs = f32(z), f32(zn), f32(zf), f32(zs)
+        if z < zs:
+            t = f32(f32(z - zn) / f32(zs - zn))
+            return int(f32(t * f32(ns))) if t > 0 else 0
+        ls, le, lz = log_cr(f32(zs / zn)), log_cr(f32(zf / zn)), log_cr(f32(z / zn))
+        u = f32(f32(lz - ls) / f32(le - ls))
+        return ns + (int(f32(u * f32(gz - ns))) if u > 0 else 0)
+
+    rng = np.random.default_rng(11)
+    for zn, zf, zs, ns, gz in ((0.1, 1000.0, 10.0, 8, 24), (0.05, 250.0, 4.0, 4, 16), (1.0, 5000.0, 30.0, 10, 32)):
+        z = np.concatenate([np.exp(rng.uniform(np.log(zn), np.log(zf), 600)).astype(f32), np.array([zn, zs, zf], dtype=f32)])
+        # the exact slice thresholds by bisection on the reference function, and their neighbours
+        starts = []
+        for s_ in range(1, gz):
+            lo, hi = f32(zn).view(np.uint32).item(), f32(zf * 2).view(np.uint32).item()
+            while hi - lo > 1:
+                mid = (lo + hi) // 2
+                if slice_ref(np.uint32(mid).view(f32), zn, zf, zs, ns, gz) >= s_:
+                    hi = mid
+                else:
+                    lo = mid
+            starts.append(hi)
+        edge = np.array([b + d for b in starts for d in (-2, -1, 0, 1)], dtype=np.uint32).view(f32)
+        z = np.concatenate([z, edge])
+        out = np.zeros(len(z), dtype=np.uint32)
+        lib.orc_cluster_slice(z.ctypes.data, len(z), zn, zf, zs, ns, gz, out.ctypes.data)
+        want = np.array([slice_ref(v, zn, zf, zs, ns, gz) for v in z], dtype=np.uint32)
+        assert np.array_equal(out, want), np.nonzero(out != want)[0][:5]
+        assert (np.diff(out[np.argsort(z, kind="stable")].astype(np.int64)) >= 0).all()        # monotone in depth: thresholds exist
+
+
 def test_obj_loader_feeds_the_scene_builder(tmp_path):
     """basicrenderer_amd.obj (harness): a cube with texcoords, negative indices, a quad and an n-gon face, two materials -> two meshes with
     fan-triangulated faces, seam vertices kept apart, v flipped; the scene built from them renders in the oracle."""
