@@ -204,6 +204,7 @@ int brmi_create(const brmi_config* cfg, brmi_pass** out) {
     if (const char* e = std::getenv("BRMI_CULL_LEVEL_KERNELS")) p->forceLevelKernels = std::atoi(e) != 0;
     if (const char* e = std::getenv("BRMI_RASTER_GRID")) p->rasterGrid = (uint32_t)std::max(64, std::atoi(e));
     if (const char* e = std::getenv("BRMI_FUSE_SHADE")) p->fuseShadeOptIn = std::atoi(e) != 0;
+    if (const char* e = std::getenv("BRMI_SPILL_WIDTH")) p->spillWidth = (uint32_t)std::min(1024, std::max(128, std::atoi(e)));
     if (const char* e = std::getenv("BRMI_RASTER_DEBUG")) p->rasterDebug = std::atoi(e);
     if (const char* e = std::getenv("BRMI_BIN_OVERFLOW")) p->binOverflowPerStripe = (uint32_t)std::max(0, std::atoi(e));
     if (const char* e = std::getenv("BRMI_BIN_CAPACITY")) p->binCapacity = (uint32_t)std::min(65536, std::max(1, std::atoi(e)));   // 16-bit record indices inside a bin slice's alpha list; 65536 x 64 B x bins is far beyond any frame
@@ -361,7 +362,7 @@ int brmi_set_scene(brmi_pass* p, const brmi_scene_buffers* scene) {
         if (run > 0xFFFFFFFFull) return fail(p, BRMI_ERR_CAPACITY, "mesh %zu has too many meshlets", m);
         meshBits[m] = (uint32_t)run;
         p->maxLevelWidth = std::max(p->maxLevelWidth, p->hostMeshLevelWidth[m]); p->minLevelWidth = std::min(p->minLevelWidth, p->hostMeshLevelWidth[m]);
-        if (p->hostMeshLevelWidth[m] > 1024u) {
+        if (p->hostMeshLevelWidth[m] > p->spillWidth) {
             // a mesh too wide for the LDS walk: the walk hands its frontier to the level kernels at the first level that holds more than 128 nodes
             // (brmi_cull.hip, spill mode) -- never above the first level that CAN hold that many; what is left below bounds the level launches
             uint32_t depth = 1, first = 0;

@@ -306,6 +306,9 @@ __global__ void __launch_bounds__(256) k_traverse(CullArgs a, uint32_t level, co
 // dependent HBM round trips per level for every instance -- becomes one launch in which the per-instance state (instance,
 // mesh metadata, model matrix) is fetched once and a level costs node -> group / segment -> page map.  Used when every mesh's
 // BVH level fits the LDS frontier (brmi_set_scene checks); same tests, same operation order as k_cull_instances / k_traverse.
+#ifndef BRMI_HIER_STAGE_WIDE
+#define BRMI_HIER_STAGE_WIDE 128
+#endif
 constexpr uint32_t HIER_CAP_MAX = 1024;   // widest BVH level the LDS frontier variants cover
 // HIER_CAP nodes per frontier, HIER_STAGE bucket records staged in LDS: (256, 128) = 6 KB keeps ~20 workgroups per CU in flight
 // (scenes of many small instances), (1024, 128) = 12 KB covers wide hierarchies.  Meshes wider than that (a street's ground and facades
@@ -907,13 +910,13 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
     bool lightGridRides = false;      // this call's launches carry the light clustering (brmi_execute)
     // one launch of k_cull_hierarchy for the meshes that fit its LDS frontier, the level kernels for the rest (or for everything: tests)
     const bool hierarchy = p->minLevelWidth <= HIER_CAP_MAX && !p->forceLevelKernels;
-    const bool levelKernels = p->maxLevelWidth > HIER_CAP_MAX || p->forceLevelKernels;
+    const bool levelKernels = p->maxLevelWidth > p->spillWidth || p->forceLevelKernels;
     const uint32_t* meshWidth = p->wsPtr<uint32_t>(p->ws.meshLevelWidth);
     // meshes of both kinds: the one-launch walk also starts the wide ones and hands their frontiers to the level kernels (spill mode)
     const bool spillMode = hierarchy && levelKernels;
     a.meshLevelWidth = meshWidth; a.levelKernelsWidthLo = 0u;
     if (spillMode) a.frontier0Counter = CNT_FRONTIER0;
-    const uint32_t widthAll = spillMode ? 0xFFFFFFFFu : 0u, spillAbove = spillMode ? HIER_CAP_MAX : 0xFFFFFFFFu;
+    const uint32_t widthAll = spillMode ? 0xFFFFFFFFu : 0u, spillAbove = spillMode ? p->spillWidth : 0xFFFFFFFFu;
     if (phase == 1) {
         if (!p->frameStateCleared) BRMI_HIP(p, hipMemsetAsync(p->counters(), 0, p->ws.frameClearBytes, s));      // counters + both survivor bitmasks
         p->frameStateCleared = false;
@@ -926,10 +929,10 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
             if (p->clearVisibilityWithTraversal) {
                 SideJobs sj{reinterpret_cast<ulonglong2*>(static_cast<unsigned long long*>(p->res[BRMI_RES_VISIBILITY]) + p->bandFirstPixel), p->bandPixelCount >> 1, hgrid.x, 8192u, cluster_args_of(p)};
                 const dim3 grid(hgrid.x + sj.clearBlocks + p->numLightClusters);
-                if (wide) hipLaunchKernelGGL((k_cull_hierarchy<false, 1024, 128, true>), grid, dim3(64), 0, s, a, buckets, meshWidth, 0u, widthHi, spillAbove, fa, sj);
+                if (wide) hipLaunchKernelGGL((k_cull_hierarchy<false, 1024, BRMI_HIER_STAGE_WIDE, true>), grid, dim3(64), 0, s, a, buckets, meshWidth, 0u, widthHi, spillAbove, fa, sj);
                 else hipLaunchKernelGGL((k_cull_hierarchy<false, 256, 128, true>), grid, dim3(64), 0, s, a, buckets, meshWidth, 0u, widthHi, spillAbove, fa, sj);
                 p->clearVisibilityWithTraversal = false; lightGridRides = true;
-            } else if (wide) hipLaunchKernelGGL((k_cull_hierarchy<false, 1024, 128>), hgrid, dim3(64), 0, s, a, buckets, meshWidth, 0u, widthHi, spillAbove, fa, NoSide{});
+            } else if (wide) hipLaunchKernelGGL((k_cull_hierarchy<false, 1024, BRMI_HIER_STAGE_WIDE>), hgrid, dim3(64), 0, s, a, buckets, meshWidth, 0u, widthHi, spillAbove, fa, NoSide{});
             else hipLaunchKernelGGL((k_cull_hierarchy<false, 256, 128>), hgrid, dim3(64), 0, s, a, buckets, meshWidth, 0u, widthHi, spillAbove, fa, NoSide{});
         }
         if (levelKernels && !spillMode) hipLaunchKernelGGL(k_cull_instances, dim3(grid_for(p->scene.activeDrawCount, 256, maxBlocks)), dim3(256), 0, s, a, fa);
@@ -940,7 +943,7 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
         p->phase2Seeded = false;
         const NoSide none{};
         if (hierarchy && p->maxLevelWidth <= 256u) hipLaunchKernelGGL((k_cull_hierarchy<true, 256, 128>), dim3(2048), dim3(64), 0, s, a, buckets, meshWidth, 0u, 256u, spillAbove, fa, none);
-        else if (hierarchy) hipLaunchKernelGGL((k_cull_hierarchy<true, 1024, 128>), dim3(2048), dim3(64), 0, s, a, buckets, meshWidth, 0u, spillMode ? widthAll : HIER_CAP_MAX, spillAbove, fa, none);
+        else if (hierarchy) hipLaunchKernelGGL((k_cull_hierarchy<true, 1024, BRMI_HIER_STAGE_WIDE>), dim3(2048), dim3(64), 0, s, a, buckets, meshWidth, 0u, spillMode ? widthAll : HIER_CAP_MAX, spillAbove, fa, none);
     }
     // frontier sizes are only known on the device: size the grids for the worst case that can matter
     const uint32_t travGrid = grid_for(std::min<uint64_t>(p->cfg.maxTraversalRecords, (uint64_t)p->scene.lodNodeCount * 4 + 4096), 256, maxBlocks);

@@ -129,6 +129,7 @@ struct brmi_pass {
     float bandPlaneTop[3] = {0, 0, 0}, bandPlaneBottom[3] = {0, 0, 0};
     uint64_t bandFirstPixel = 0, bandPixelCount = 0;   // tiled index range covering the band's tile rows
     uint32_t maxLevels = 1;
+    uint32_t spillWidth = 1024;      // meshes with a BVH level wider than this go to the level kernels below their top (<= the widest LDS frontier; BRMI_SPILL_WIDTH)
     uint32_t spillLevels = 0;        // level-kernel launches the widest meshes still need below the point where the LDS walk hands them over
     uint32_t minLevelWidth = 0;      // narrowest such width over the meshes
     std::vector<uint32_t> hostMeshLevelWidth;   // per mesh metadata entry
