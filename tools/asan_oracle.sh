@@ -5,7 +5,7 @@ set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=${TMPDIR:-/tmp}/brmi_asan
 mkdir -p $OUT $OUT/cache
-g++ -O1 -g -std=c++17 -fPIC -shared -I$ROOT/include -fsanitize=address,undefined -fno-omit-frame-pointer $ROOT/basicrenderer_amd/csrc/scene/scene_gen.cpp -o $OUT/libbrmi_scene.so -ldl
+g++ -O1 -g -std=c++17 -fPIC -shared -I$ROOT/include -fsanitize=address,undefined -fno-omit-frame-pointer $ROOT/basicrenderer_amd/csrc/scene/scene_gen.cpp $ROOT/basicrenderer_amd/csrc/scene/lod_builder.cpp -fopenmp -o $OUT/libbrmi_scene.so
 g++ -O1 -g -std=c++17 -fPIC -shared -I$ROOT/include -I$ROOT/oracle -ffp-contract=off -fopenmp -fsanitize=address,undefined -fno-omit-frame-pointer $ROOT/oracle/*.cpp -o $OUT/liboracle.so
 cat > $OUT/run.py <<PY
 import sys
@@ -21,12 +21,15 @@ cases = [dict(preset="tiny", width=200, height=120, point_lights=3, skinned_frac
          # UV streams, alpha test, texture-sampled materials (every sampler state), vertex colours, OpenPBR layer textures; cache round trip
          dict(preset="sponza", width=333, height=187, point_lights=8, size_scale=0.1, material_features=255, lod_levels=2, export_cache="$OUT/cache"),
          dict(preset="sponza", width=333, height=187, point_lights=8, size_scale=0.1, material_features=255, lod_levels=2, cache_dir="$OUT/cache")]
-if os.path.exists("$ROOT/oracle/_ref/libclodref.so"):
-    cases.append(dict(preset="bistro", width=320, height=180, point_lights=16, size_scale=0.2, skinned_fraction=0.3, lod_builder="clusterlod"))
-for kw in cases:
-    o = orc.OracleFrame(Scene(**kw), threads=2)
+# the library's own LOD builder, three UV sets, and a scene of caller meshes through brmi_scene_create_from_meshes
+cases.append(dict(preset="bistro", width=320, height=180, point_lights=16, size_scale=0.2, skinned_fraction=0.3, lod_builder="own", material_features=256 | 24))
+from conftest import caller_mesh_scene
+for kw in cases + [None]:
+    sc = Scene(**kw) if kw is not None else caller_mesh_scene(material_features=24)
+    kw = kw or dict(preset="caller meshes")
+    o = orc.OracleFrame(sc, threads=2)
     hz = o.run_occlusion(None); hz = o.run_occlusion(hz)
     o.gbuffer(); o.light_cluster(); o.shade()
     print(kw["preset"], "clean,", o.count, "clusters")
 PY
-BRMI_CLODREF_LIB=$ROOT/oracle/_ref/libclodref.so ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD=$(g++ -print-file-name=libasan.so):$(g++ -print-file-name=libubsan.so) python3 $OUT/run.py
+ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD=$(g++ -print-file-name=libasan.so):$(g++ -print-file-name=libubsan.so) python3 $OUT/run.py
