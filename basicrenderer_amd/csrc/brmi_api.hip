@@ -348,7 +348,12 @@ int brmi_set_scene(brmi_pass* p, const brmi_scene_buffers* scene) {
             const brmi_lod_node& nd = nodes[md[m].lodNodesBase + n];
             maxDepth = std::max(maxDepth, d);
             if (d < levelWidth.size()) p->hostMeshLevelWidth[m] = std::max(p->hostMeshLevelWidth[m], ++levelWidth[d]);
-            if (nd.isLeaf != BRMI_NODE_INTERNAL) { segCount = std::max(segCount, nd.indexOrOffset + 1); continue; }
+            if (nd.isLeaf != BRMI_NODE_INTERNAL) {
+                // a leaf names its group and (countMinusOne - 1) the group that refines it: the traversal reads both records unchecked
+                if ((uint64_t)md[m].groupsBase + nd.ownerGroupId >= sc.lodGroupCount) return fail(p, BRMI_ERR_INVALID, "mesh %zu: leaf node %u names group %u, which does not exist", m, n, nd.ownerGroupId);
+                if (nd.countMinusOne != 0u && (uint64_t)md[m].groupsBase + (nd.countMinusOne - 1u) >= sc.lodGroupCount) return fail(p, BRMI_ERR_INVALID, "mesh %zu: leaf node %u names refined group %u, which does not exist", m, n, nd.countMinusOne - 1u);
+                segCount = std::max(segCount, nd.indexOrOffset + 1); continue;
+            }
             if (d > 64) return fail(p, BRMI_ERR_INVALID, "mesh %zu: BVH deeper than 64 levels", m);
             const uint32_t cc = std::min(nd.countMinusOne + 1u, BRMI_BVH_MAX_CHILDREN);
             for (uint32_t k = 0; k < cc; k++) stack.push_back({nd.indexOrOffset + k, d + 1});
