@@ -336,6 +336,13 @@ def test_dangling_scene_indices_are_refused():
         a[elem, word] = value
         with pytest.raises(BrmiError, match=msg):
             VisibilityRenderer(sc)
+    for word, value, msg in ((3, 1 << 24, "names group"), (2, 1 << 24, "refined group")):       # a leaf node's ownerGroupId / refinedGroup + 1
+        sc = scene()
+        nodes = sc.arrays["lodNodes"].view(np.uint32).reshape(-1, 16)
+        leaf = np.nonzero(nodes[:, 0] == 2)[0][0]
+        nodes[leaf, word] = value
+        with pytest.raises(BrmiError, match=msg):
+            VisibilityRenderer(sc)
     m = scene()
     mats = m.arrays["materials"].view(np.uint32).reshape(-1, 69)
     mats[0, 60] = 9999                                                # openPBRMaterialDataIndex (word 60 of MaterialInfo)
