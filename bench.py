@@ -121,10 +121,28 @@ def measure(args, workload, n, rank, local_rank, cpu):
 
     hdr = r.hdr_tensor()
     # all-gather of frame k overlaps the rendering of frame k + 1; the colour channels travel (RGB16F, 6 B/px): the lit target's alpha is constant
-    composer = None
+    composer, composer_used = None, args.composer
     if n > 1 or args.force_compose:
-        cls = compose.NativeBandComposer if args.composer == "native" else compose.BandComposer
-        composer = cls(hdr, band, W, 8, transport=args.transport)
+        composer_used = args.composer
+        if args.composer == "native":
+            # libbrmi_compose.so issues the collective itself; if its communicator cannot be set up on some rank (it has only ever run on one
+            # GPU in development), every rank falls back to the torch.distributed composer together rather than losing the N > 1 line
+            failed, why = 0, ""
+            try:
+                composer = compose.NativeBandComposer(hdr, band, W, 8, transport=args.transport)
+            except Exception as e:      # noqa: BLE001
+                failed, why = 1, f"{type(e).__name__}: {e}"
+            if n > 1:
+                flag = torch.tensor([failed], device=dev, dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                failed = int(flag.item())
+            if failed:
+                if composer is not None:
+                    composer.close()
+                composer = compose.BandComposer(hdr, band, W, 8, transport=args.transport)
+                composer_used = "torch (native composer failed" + (f": {why}" if why else " on another rank") + ")"
+        else:
+            composer = compose.BandComposer(hdr, band, W, 8, transport=args.transport)
 
     def step():
         r.update()                      # the per-frame Update phase (camera / per-frame constants), as the reference's passes run it every frame
@@ -204,7 +222,7 @@ def measure(args, workload, n, rank, local_rank, cpu):
                                    f"{scene.stats['instancedTriangles']} instanced tris, {scene.stats['instances']} instances"
                                    + (", LOD DAGs from the library's cluster-LOD builder" if args.lod_builder == "own" else "")
                                    + (f", material features {args.material_features} (8 = texture-sampled, 16 = alpha-tested materials)" if args.material_features else "")
-                                   + (f", {n} row bands of 1080 rows + RCCL all-gather of HDR ({args.transport}, pipelined one frame deep, {'libbrmi_compose.so' if args.composer == 'native' else 'torch.distributed'})" if composer else ""),
+                                   + (f", {n} row bands of 1080 rows + RCCL all-gather of HDR ({args.transport}, pipelined one frame deep, {'libbrmi_compose.so' if composer_used == 'native' else ('torch.distributed' if composer_used == 'torch' else composer_used)})" if composer else ""),
                        "baseline_config": {"sponza": "configs[1]", "bistro": "configs[2]", "san_miguel": "configs[3]", "bistro_dense": "configs[2], dense geometry"}[workload],
                        "fps": round(1e3 / ms_per_step, 1),
                        "pixels_per_gpu": W * (band[1] - band[0]), "visible_clusters_rank0": int(c.visibleClusters),
