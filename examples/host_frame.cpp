@@ -41,7 +41,28 @@ int main(int argc, char** argv) {
     const int frames = argc > 6 ? std::max(1, std::atoi(argv[6])) : 1;
     prm.materialFeatures = argc > 7 ? (uint32_t)std::atoi(argv[7]) : 0u;        // brmi_scene.h: 8 = texture-sampled, 16 = alpha-tested materials
     prm.lodLevels = argc > 8 ? (uint32_t)std::atoi(argv[8]) : 0u;
-    brmi_scene* scene = brmi_scene_create(&prm);
+    brmi_scene* scene = nullptr;
+    if (prm.preset == 100u) {
+        // preset 100: not a preset -- the host's OWN geometry through brmi_scene_create_from_meshes (row f-1).  A height field whose coordinates
+        // are exact binary fractions (the Python test builds the same arrays), drawn twice; normals are left to the library.
+        const uint32_t n = 48;
+        std::vector<float> pos, uv; std::vector<uint32_t> idx;
+        for (uint32_t i = 0; i <= n; i++) for (uint32_t j = 0; j <= n; j++) {
+            pos.push_back((float)i * 0.125f - 3.0f); pos.push_back((float)((i * 7u + j * 13u) % 16u) / 64.0f - 0.5f); pos.push_back((float)j * 0.125f - 3.0f);
+            uv.push_back((float)i / 8.0f); uv.push_back((float)j / 8.0f);
+        }
+        for (uint32_t i = 0; i < n; i++) for (uint32_t j = 0; j < n; j++) {
+            const uint32_t a = i * (n + 1) + j, b = a + (n + 1), c = b + 1, d = a + 1;
+            const uint32_t q[6] = {a, d, c, a, c, b};
+            idx.insert(idx.end(), q, q + 6);
+        }
+        brmi_mesh_input mesh{}; mesh.positions = pos.data(); mesh.uvs = uv.data(); mesh.vertexCount = pos.size() / 3; mesh.indices = idx.data(); mesh.indexCount = idx.size(); mesh.material = 0;
+        brmi_instance_input inst[2] = {};
+        for (int k = 0; k < 2; k++) { inst[k].mesh = 0; for (int r = 0; r < 4; r++) inst[k].model[r][r] = 1.0f; }
+        inst[1].model[3][0] = 1.5f; inst[1].model[3][1] = 0.75f; inst[1].model[3][2] = -2.0f;
+        brmi_view_input view{}; view.eye[0] = 0.25f; view.eye[1] = 1.5f; view.eye[2] = 4.0f; view.yaw = 0.0f; view.pitch = -0.25f; view.fovYDegrees = 60.0f; view.zNear = 0.125f; view.zFar = 256.0f;
+        scene = brmi_scene_create_from_meshes(&prm, &mesh, 1, inst, 2, &view, nullptr, nullptr, nullptr);
+    } else scene = brmi_scene_create(&prm);
     if (!scene) return 1;
     std::vector<void*> keep;
     brmi_scene_buffers sb{};

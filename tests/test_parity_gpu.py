@@ -723,6 +723,31 @@ def test_cpp_host_passes_reproduce_the_python_frame(scenes):
         assert fnv(raw) == got[key], key
     r.close()
 
+    # the host's own geometry through brmi_scene_create_from_meshes, from C++ (preset 100 of the example) and from Python: the same arrays
+    # (coordinates are exact binary fractions), the same bytes
+    from basicrenderer_amd import Scene as RawScene
+    out = subprocess.run([exe, "100", "320", "180", "4", "0", "1", "8"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    got = json.loads(out.stdout.strip().splitlines()[-1])
+    n = 48
+    ii, jj = np.meshgrid(np.arange(n + 1), np.arange(n + 1), indexing="ij")
+    P = np.stack([ii * 0.125 - 3.0, ((ii * 7 + jj * 13) % 16) / 64.0 - 0.5, jj * 0.125 - 3.0], -1).reshape(-1, 3).astype(np.float32)
+    uv = np.stack([ii / 8.0, jj / 8.0], -1).reshape(-1, 2).astype(np.float32)
+    qi, qj = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    a = (qi * (n + 1) + qj).ravel(); b = a + (n + 1); c = b + 1; d = a + 1
+    I = np.stack([a, d, c, a, c, b], 1).ravel().astype(np.uint32)
+    moved = np.eye(4, dtype=np.float32); moved[3, :3] = [1.5, 0.75, -2.0]
+    sc = RawScene(width=320, height=180, point_lights=4, material_features=8, meshes=[dict(positions=P, uvs=uv, indices=I, material=0)],
+                  instances=[(0, np.eye(4, dtype=np.float32)), (0, moved)], view=dict(eye=(0.25, 1.5, 4.0), yaw=0.0, pitch=-0.25, fov=60.0, near=0.125, far=256.0))
+    r = VisibilityRenderer(sc)
+    r.execute()
+    assert got["visible_clusters"] == r.counters().visibleClusters and got["visible_clusters"] > 10
+    r.torch.cuda.synchronize()
+    for key, rid in (("vis_fnv", "VISIBILITY"), ("hdr_fnv", "HDR_COLOR"), ("normals_fnv", "GBUF_NORMALS")):
+        raw = r.res[capi.RES[rid]].cpu().numpy()[: r.descs[capi.RES[rid]]["bytes"]]
+        assert fnv(raw) == got[key], key
+    r.close()
+
 
 # ---- 2-phase HZB occlusion culling -----------------------------------------------------------
 OCCLUSION_CASES = {
