@@ -485,15 +485,24 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
 #ifndef BRMI_BIN_THREADS
 #define BRMI_BIN_THREADS 512
 #endif
+// The alpha-tested variant is bound by the latency of its per-pixel texel fetches: it wants as many resident workgroups as the
+// register file and the LDS allow.  BRMI_ALPHA_LIST sizes two LDS arrays; at 4096 entries the workgroup needs 43 KB and only three
+// fit a CU, at 2048 it needs 31 KB and four do (profiles/r02_experiments.md).
+#ifndef BRMI_BIN_ALPHA_WAVES
+#define BRMI_BIN_ALPHA_WAVES 4
+#endif
+#ifndef BRMI_ALPHA_LIST
+#define BRMI_ALPHA_LIST 2048
+#endif
 template <bool ALPHA>
-__global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? 4 : 1) k_raster_bins(RasterArgs a) {
+__global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES : 1) k_raster_bins(RasterArgs a) {
     __shared__ unsigned long long tile[BIN_W * BIN_ROWS];
     __shared__ float unormT[ALPHA ? 256 : 1];
 #ifndef BRMI_ALPHA_SEG_SHIFT
 #define BRMI_ALPHA_SEG_SHIFT 3
 #endif
     constexpr int ALPHA_SEG_SHIFT = BRMI_ALPHA_SEG_SHIFT;     // pixels per task = 1 << shift
-    constexpr uint32_t ALPHA_LIST = 4096;                 // alpha-tested records a bin hands to the task pass (later ones take the row path)
+    constexpr uint32_t ALPHA_LIST = BRMI_ALPHA_LIST;      // alpha-tested records a bin hands to the task pass (later ones take the row path)
     __shared__ uint16_t alphaList[ALPHA ? ALPHA_LIST : 1];
     __shared__ uint32_t taskStart[ALPHA ? ALPHA_LIST + 1 : 1];      // exclusive prefix of the listed records' task counts
     __shared__ uint32_t scanPart[ALPHA ? BRMI_BIN_THREADS : 1];
