@@ -212,7 +212,7 @@ def scene_lib():
 
 BRMI_EXPORTS = ["brmi_abi_version", "brmi_default_config", "brmi_create", "brmi_declare", "brmi_set_scene", "brmi_setup",
                 "brmi_update", "brmi_execute", "brmi_destroy", "brmi_last_error", "brmi_clear_visibility", "brmi_cull",
-                "brmi_raster", "brmi_depth_copy", "brmi_build_hzb", "brmi_invalidate_hzb", "brmi_gbuffer", "brmi_light_clustering",
+                "brmi_raster", "brmi_depth_copy", "brmi_build_hzb", "brmi_invalidate_hzb", "brmi_set_history_source", "brmi_gbuffer", "brmi_light_clustering",
                 "brmi_shade", "brmi_read_counters", "brmi_stage_times", "brmi_set_timed_stages", "brmi_algorithmic_bytes", "brmi_debug_arith", "brmi_debug_arith_in_range"]
 
 
@@ -244,6 +244,7 @@ def brmi_lib():
         for n in ("brmi_clear_visibility", "brmi_depth_copy", "brmi_build_hzb", "brmi_gbuffer", "brmi_light_clustering", "brmi_shade"):
             getattr(lib, n).argtypes = [vp, vp]
         lib.brmi_invalidate_hzb.argtypes = [vp]
+        lib.brmi_set_history_source.argtypes = [vp, vp]
         lib.brmi_cull.argtypes = [vp, u32, vp]
         lib.brmi_raster.argtypes = [vp, u32, vp]
         lib.brmi_read_counters.argtypes = [vp, C.POINTER(Counters), vp]

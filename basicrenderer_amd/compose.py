@@ -72,6 +72,7 @@ class BandComposer:
             raise ValueError("transport must be 'surface' or, for an RGBA16F surface, 'rgb16f'")
         lo, hi = band_byte_range(band, width, bytes_per_pixel)
         self.dist, self.group, self.depth, self.transport = dist, group, depth, transport
+        self.byte_range, self.surface_ptr = (lo, hi), surface_u8.data_ptr()
         n = dist.get_world_size(group)
         if transport == "rgb16f":
             self.src = rgb_of(surface_u8[lo:hi])                                       # strided view: copy_ compacts it
@@ -85,11 +86,16 @@ class BandComposer:
         self.work = [None] * depth
         self.frames = 0
 
-    def submit(self):
+    def submit(self, surface_u8=None):
+        """`surface_u8`: the frame's surface when it is not the one given at construction (two passes in flight alternate their targets)."""
         i = self.frames % self.depth
         if self.work[i] is not None:
             self.work[i].wait()
-        self.stage[i].copy_(self.src)
+        src = self.src
+        if surface_u8 is not None and surface_u8.data_ptr() != self.surface_ptr:
+            lo, hi = self.byte_range
+            src = rgb_of(surface_u8[lo:hi]) if self.transport == "rgb16f" else surface_u8[lo:hi]
+        self.stage[i].copy_(src)
         import torch
         # the collective sees bytes (RCCL has no 16-bit integer type, and nothing is reduced)
         self.work[i] = self.dist.all_gather_into_tensor(self.out[i].view(-1).view(torch.uint8), self.stage[i].view(-1).view(torch.uint8), group=self.group, async_op=True)
@@ -154,8 +160,8 @@ class NativeBandComposer:
     def _stream(self):
         return self.C.c_void_p(self.torch.cuda.current_stream(self.dev).cuda_stream)
 
-    def submit(self):
-        slot = self._check(self.lib.brmi_compose_submit(self._h, self.surface.data_ptr(), self._stream()), "brmi_compose_submit")
+    def submit(self, surface_u8=None):
+        slot = self._check(self.lib.brmi_compose_submit(self._h, (self.surface if surface_u8 is None else surface_u8).data_ptr(), self._stream()), "brmi_compose_submit")
         self.frames += 1
         return slot
 

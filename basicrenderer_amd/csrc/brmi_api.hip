@@ -218,6 +218,9 @@ int brmi_create(const brmi_config* cfg, brmi_pass** out) {
 void brmi_destroy(brmi_pass* p) {
     if (!p) return;
     if (p->eventsCreated) for (int i = 0; i < BRMI_STAGE_COUNT; i++) for (uint32_t k = 0; k < brmi_pass::kEventRing; k++) { (void)hipEventDestroy(p->evStart[i][k]); (void)hipEventDestroy(p->evStop[i][k]); }
+    (void)brmi_set_history_source(p, nullptr);
+    for (brmi_pass* user : p->historyUsers) user->history = nullptr;
+    if (p->chainReady) (void)hipEventDestroy(p->chainReady);
     delete p;
 }
 
@@ -548,6 +551,22 @@ int brmi_invalidate_hzb(brmi_pass* p) {
     p->hzbValid = false;
     return BRMI_OK;
 }
+int brmi_set_history_source(brmi_pass* p, brmi_pass* source) {
+    if (!p) return BRMI_ERR_INVALID;
+    if (source == p) source = nullptr;
+    if (source) {
+        if (!p->setupDone || !source->setupDone) return brmi::fail(p, BRMI_ERR_STATE, "brmi_set_history_source: both passes need brmi_setup first");
+        if (!p->cfg.enableOcclusionCulling || !source->cfg.enableOcclusionCulling) return brmi::fail(p, BRMI_ERR_STATE, "brmi_set_history_source: both passes need enableOcclusionCulling (there is no history otherwise)");
+        if (p->cfg.width != source->cfg.width || p->cfg.height != source->cfg.height || p->bandY0 != source->bandY0 || p->bandY1 != source->bandY1)
+            return brmi::fail(p, BRMI_ERR_INVALID, "brmi_set_history_source: the passes differ in size or band (%ux%u rows %u-%u against %ux%u rows %u-%u)", p->cfg.width, p->cfg.height, p->bandY0, p->bandY1,
+                              source->cfg.width, source->cfg.height, source->bandY0, source->bandY1);
+        if (!source->chainReady) BRMI_HIP(p, hipEventCreateWithFlags(&source->chainReady, hipEventDisableTiming));
+    }
+    if (p->history) { auto& u = p->history->historyUsers; u.erase(std::remove(u.begin(), u.end(), p), u.end()); }
+    p->history = source;
+    if (source) source->historyUsers.push_back(p);
+    return BRMI_OK;
+}
 int brmi_gbuffer(brmi_pass* p, brmi_stream stream) {
     CHECK_READY(p); hipStream_t s = static_cast<hipStream_t>(stream);
     STAGE_BEGIN(p, BRMI_STAGE_GBUFFER, s); int rc = launch_gbuffer(p, s); STAGE_END(p, BRMI_STAGE_GBUFFER, s); return rc;
@@ -566,6 +585,8 @@ int brmi_execute(brmi_pass* p, brmi_stream stream) {
     CHECK_READY(p);
     int rc;
     p->executesSinceTimes++;
+    // frames in flight: this frame's phase 1 reads the chain the source pass built for the frame before, possibly on another stream
+    if (p->history && p->history->chainRecorded) BRMI_HIP(p, hipStreamWaitEvent(static_cast<hipStream_t>(stream), p->history->chainReady, 0));
     // When the phase-1 traversal is the one-launch LDS walk and the frame constants are due anyway, the frame needs no clear launch: the
     // constants kernel zeroes the culling state and the walk's launch carries the visibility clear (brmi_cull.hip, SideClear).
     static const bool rideEnv = [] { const char* e = std::getenv("BRMI_CLEAR_RIDES"); return !e || std::atoi(e) != 0; }();
@@ -594,6 +615,11 @@ int brmi_execute(brmi_pass* p, brmi_stream stream) {
         if (rc) return rc;
         if ((rc = brmi_cull(p, 2, stream))) return rc;
         if ((rc = brmi_raster(p, 2, stream))) return rc;
+        // LinearDepthCopyPass2 + LinearDepthDownsamplePass2 straight from the final visibility keys, skipped on the device when phase 2 drew
+        // nothing: the depth map and the chain are final BEFORE the G-buffer kernel (which then skips its depth store), so a pass that
+        // renders the next frame on another stream (brmi_set_history_source) can start while this frame is resolved and shaded.
+        if ((rc = build_hzb_fused(p, static_cast<hipStream_t>(stream), true, true))) return rc;
+        if (!p->historyUsers.empty()) { BRMI_HIP(p, hipEventRecord(p->chainReady, static_cast<hipStream_t>(stream))); p->chainRecorded = true; }
     }
     // BRMI_FUSE_SHADE=1 (off by default): one pass over the pixels for G-buffer + shading where the G-buffer kernel is the lean one
     // (brmi_resolve.hip: k_gbuffer_shade); the light lists must exist by then.  Measured: 338 us against 103 + 236 us for the two kernels on
@@ -604,10 +630,10 @@ int brmi_execute(brmi_pass* p, brmi_stream stream) {
     p->lightGridDone = false;
     if (fuseEnv && !lightsDone) { if ((rc = brmi_light_clustering(p, stream))) return rc; lightsDone = true; }
     p->fuseShadeIntoGBuffer = fuseEnv; p->plainPixelsShaded = false;
+    p->depthFinal = p->cfg.enableOcclusionCulling != 0;
     rc = brmi_gbuffer(p, stream);
-    p->fuseShadeIntoGBuffer = false;
+    p->fuseShadeIntoGBuffer = false; p->depthFinal = false;
     if (rc) return rc;
-    if (p->cfg.enableOcclusionCulling && (rc = build_hzb_fused(p, static_cast<hipStream_t>(stream), false, true))) return rc;   // the G-buffer kernel wrote the final depth
     if (!lightsDone && (rc = brmi_light_clustering(p, stream))) return rc;
     if ((rc = brmi_shade(p, stream))) return rc;
     return BRMI_OK;

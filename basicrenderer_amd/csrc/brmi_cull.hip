@@ -895,9 +895,10 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
                                       p->camHost.projection[3][0] == 0.0f && p->camHost.projection[3][1] == 0.0f;
     a.bandActive = ((p->bandY0 != 0 || p->bandY1 != p->cfg.height) && symmetricPerspective) ? 1u : 0u;
     for (int k = 0; k < 3; k++) { a.bandTop[k] = p->bandPlaneTop[k]; a.bandBottom[k] = p->bandPlaneBottom[k]; }
-    a.occlusion = (p->cfg.enableOcclusionCulling && p->hzbValid && p->camHost.isOrtho == 0) ? 1u : 0u;
+    const brmi_pass* chain = p->chainOwner(phase);      // frames in flight: phase 1 reads the chain of the pass that rendered the frame before
+    a.occlusion = (p->cfg.enableOcclusionCulling && chain->hzbValid && p->camHost.isOrtho == 0) ? 1u : 0u;
     a.replayNodes = p->wsPtr<NodeRecord>(p->ws.replayNodes); a.replayBuckets = p->wsPtr<BucketRecord>(p->ws.replayBuckets);
-    a.hzb = p->hzbDesc();
+    a.hzb = chain->hzbDesc();
     a.frontier0Counter = phase == 1 ? (uint32_t)CNT_FRONTIER0 : (uint32_t)CNT_REPLAY_NODES;
     a.bucketCounter = CNT_BUCKETS;   // phase 2: seeded with the replayed meshlets, the bucket array is the replay buffer itself
     NodeRecord* fa = p->wsPtr<NodeRecord>(p->ws.frontierA); NodeRecord* fb = p->wsPtr<NodeRecord>(p->ws.frontierB);

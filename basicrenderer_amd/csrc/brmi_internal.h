@@ -157,6 +157,12 @@ struct brmi_pass {
     int bigTriArea = 64, bigTriAreaAlpha = 32;        // clamped-bbox pixels above which a triangle is binned (BRMI_BIG_TRI_AREA)
     uint32_t hzbMipCount = 0; std::vector<uint64_t> hzbMipOffsets; std::vector<uint32_t> hzbMipW, hzbMipH;   // [mip]; offsets in floats, mip 0 unused
     bool hzbValid = false;       // a chain built from a finished frame exists (phase 1 of the next frame tests against it)
+    brmi_pass* history = nullptr;    // brmi_set_history_source: the pass whose chain phase 1 tests against (frames in flight); null = this pass's own
+    hipEvent_t chainReady = nullptr; // recorded by brmi_execute after the frame's last chain build when another pass may be reading it
+    bool chainRecorded = false;
+    std::vector<brmi_pass*> historyUsers;   // passes whose `history` is this pass (unlinked when it is destroyed)
+    bool depthFinal = false;         // brmi_execute: the depth map is final before the G-buffer kernel runs (it skips its depth store)
+    const brmi_pass* chainOwner(uint32_t phase) const { return (phase == 1 && history) ? history : this; }
     brmi::HzbDesc hzbDesc() const;
     std::vector<uint32_t> hostInstanceBitBase, hostSegPrefix;
     brmi::Workspace ws{};

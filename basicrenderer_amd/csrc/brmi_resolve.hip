@@ -594,7 +594,7 @@ int launch_gbuffer(brmi_pass* p, hipStream_t s) {
     a.normals = static_cast<float4*>(p->res[BRMI_RES_GBUF_NORMALS]); a.albedo = static_cast<uint32_t*>(p->res[BRMI_RES_GBUF_ALBEDO]);
     a.coat = static_cast<unsigned long long*>(p->res[BRMI_RES_GBUF_COAT]); a.emissive = static_cast<unsigned long long*>(p->res[BRMI_RES_GBUF_EMISSIVE]);
     a.fuzz = static_cast<unsigned long long*>(p->res[BRMI_RES_GBUF_FUZZ]); a.metallicRoughness = static_cast<uint32_t*>(p->res[BRMI_RES_GBUF_METALLIC_ROUGHNESS]);
-    a.motion = static_cast<uint32_t*>(p->res[BRMI_RES_GBUF_MOTION_VECTORS]); a.depth = static_cast<float*>(p->res[BRMI_RES_LINEAR_DEPTH]);
+    a.motion = static_cast<uint32_t*>(p->res[BRMI_RES_GBUF_MOTION_VECTORS]); a.depth = p->depthFinal ? nullptr : static_cast<float*>(p->res[BRMI_RES_LINEAR_DEPTH]);
     a.W = p->cfg.width; a.H = p->cfg.height; a.tilesX = p->tilesX; a.bandY0 = p->bandY0; a.bandY1 = p->bandY1; a.firstPixel = p->bandFirstPixel; a.pixelCount = p->bandPixelCount;
     a.clusterCapacity = p->cfg.maxVisibleClusters;
     a.frameConst = p->wsPtr<m4>(p->ws.frameConst); a.objConst = p->wsPtr<float>(p->ws.objConst);

@@ -62,6 +62,7 @@ class VisibilityRenderer:
         self._h = capi.vp()
         self._check(self.lib.brmi_create(C.byref(cfg), C.byref(self._h)), "brmi_create", use_pass=False)
         self.sb, self._scene_keep = scene.device_buffers(self.device)
+        self.device_arrays = dict(scene.device_arrays)      # this pass's own copies (two passes in flight each have their camera buffers)
         self._check(self.lib.brmi_set_scene(self._h, C.byref(self.sb)), "brmi_set_scene")
         self.descs = {}
 
@@ -94,7 +95,7 @@ class VisibilityRenderer:
         """Next frame's camera: copy `other`'s camera / culling-camera buffers (same geometry, another camera step) into
         the device buffers the pass reads -- what the reference's CameraManager does between frames -- then brmi_update."""
         for name in ("cameras", "cullingCameras"):
-            self.scene.device_arrays[name].copy_(self.torch.from_numpy(other.arrays[name]).to(self.device))
+            self.device_arrays[name].copy_(self.torch.from_numpy(other.arrays[name]).to(self.device))
         self._cam_scene = other
         self.update(frame_index)
 
@@ -166,6 +167,10 @@ class VisibilityRenderer:
     def invalidate_hzb(self):
         self._check(self.lib.brmi_invalidate_hzb(self._h), "brmi_invalidate_hzb")
 
+    def set_history_source(self, other):
+        """Frames in flight: phase 1 tests against the depth chain `other` built for the frame before (None unlinks)."""
+        self._check(self.lib.brmi_set_history_source(self._h, other._h if other is not None else None), "brmi_set_history_source")
+
     def hzb_mips(self):
         """Mips >= 1 of the linear-depth chain as row-major arrays (mip 0 is depth() padded to a power of two)."""
         self.torch.cuda.synchronize(self.device)
@@ -197,6 +202,7 @@ class VisibilityRenderer:
             # every byte the pass used is caller-owned: drop the resource tensors and the uploaded scene with the pass
             self.res = {}
             self._scene_keep = []
+            self.device_arrays = {}
             if hasattr(self.scene, "device_arrays"):
                 self.scene.device_arrays = {}
 

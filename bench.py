@@ -58,6 +58,11 @@ def main():
     ap.add_argument("--composer", default="native", choices=["native", "torch"],
                     help="who runs the all-gather: libbrmi_compose.so (RCCL called from C++ behind include/brmi_compose.h; default) or torch.distributed")
     ap.add_argument("--force-compose", action="store_true", help="run the RCCL band composition even with one rank (checks the collective path on a single GPU)")
+    ap.add_argument("--frames-in-flight", type=int, default=2, choices=[1, 2],
+                    help="2 (default): two passes with their own resources render alternate frames on two streams (brmi_set_history_source; the "
+                         "reference's numFramesInFlight) -- frame k+1's culling and rasterisation, which are latency-bound and leave most of the chip idle, "
+                         "overlap frame k's G-buffer and shading.  1: one pass, one stream, frames back to back.  Every frame does all of its work either way; "
+                         "the roofline block is measured on serial frames (a kernel's duration while it shares the CUs with another frame is not its own)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scale", type=float, default=1.0, help="fraction of the frame height the CPU baseline renders")
     args = ap.parse_args()
@@ -118,6 +123,15 @@ def measure(args, workload, n, rank, local_rank, cpu):
     band = compose.band_of(rank, n, H)
     scene = Scene(preset, W, H, point_lights=lights, directional=True, lod_builder=args.lod_builder, material_features=args.material_features, **scene_kw)
     r = VisibilityRenderer(scene, device=dev, stats=True, band=band, occlusion=bool(args.occlusion))
+    fif = args.frames_in_flight
+    passes, streams = [r], [torch.cuda.current_stream(dev)]
+    if fif == 2:
+        # the second pass has its own resources and scene upload (its camera buffers are its own); phase 1 of each tests against the chain
+        # the other built for the frame before
+        passes.append(VisibilityRenderer(scene, device=dev, stats=False, band=band, occlusion=bool(args.occlusion)))
+        if args.occlusion:
+            passes[0].set_history_source(passes[1]); passes[1].set_history_source(passes[0])
+        streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
 
     hdr = r.hdr_tensor()
     # all-gather of frame k overlaps the rendering of frame k + 1; the colour channels travel (RGB16F, 6 B/px): the lit target's alpha is constant
@@ -144,11 +158,24 @@ def measure(args, workload, n, rank, local_rank, cpu):
         else:
             composer = compose.BandComposer(hdr, band, W, 8, transport=args.transport)
 
-    def step():
-        r.update()                      # the per-frame Update phase (camera / per-frame constants), as the reference's passes run it every frame
-        r.execute()
-        if composer:
-            composer.submit()
+    frame_no = [0]
+
+    def step(serial=False):
+        k = 0 if serial else frame_no[0] % len(passes)
+        p = passes[k]
+        with torch.cuda.stream(streams[k]):
+            p.update()                  # the per-frame Update phase (camera / per-frame constants), as the reference's passes run it every frame
+            p.execute()
+            if composer:
+                composer.submit(p.hdr_tensor())
+        frame_no[0] += 1
+
+    def serial_frames(count):
+        """`count` frames of pass 0 alone with nothing else on the GPU (per-stage HIP events mean a kernel's own duration only then)."""
+        torch.cuda.synchronize()
+        for _ in range(count):
+            step(serial=True)
+        torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -156,12 +183,13 @@ def measure(args, workload, n, rank, local_rank, cpu):
     # event pair is a barrier on the stream, ten pairs per frame cost ~5 %), whose mean launch duration feeds `roofline`.
     if composer:
         composer.finish()
+    torch.cuda.synchronize()
     r.stage_times()                       # drop the warm-up window (first-frame effects)
-    for _ in range(10):                   # untimed: per-stage profile of the steady state, all stages
-        step()
+    serial_frames(10)                     # untimed: per-stage profile of the steady state, all stages
     warm_ms = r.stage_times()
     dom_stage = max(warm_ms, key=lambda k: warm_ms[k])
     r.set_timed_stages([dom_stage])
+    frame_no[0] = 0
     if n > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -180,6 +208,12 @@ def measure(args, workload, n, rank, local_rank, cpu):
     dt = float(t.item())
 
     stage_ms = r.stage_times()          # mean over the last timed steps (HIP events on the execute stream); dominant stage only
+    in_flight_ms = None
+    if fif == 2:
+        # the dominant kernel shared the CUs with the other pass's frame during the timed region: its own duration comes from serial frames
+        in_flight_ms = stage_ms[dom_stage]
+        serial_frames(min(args.steps, 200))
+        stage_ms = r.stage_times()
     if warm_ms:
         stage_ms = {k: (stage_ms[k] if k == dom_stage else warm_ms[k]) for k in warm_ms}
     per_stage_bytes, total_bytes = r.algorithmic_bytes()
@@ -227,18 +261,25 @@ def measure(args, workload, n, rank, local_rank, cpu):
                        "fps": round(1e3 / ms_per_step, 1),
                        "pixels_per_gpu": W * (band[1] - band[0]), "visible_clusters_rank0": int(c.visibleClusters),
                        "occlusion_culling": bool(args.occlusion), "visible_clusters_phase2_rank0": int(c.visibleClustersPhase2),
-                       "meshlets_tested_rank0": int(c.meshletsTested), "partition": f"row bands x{n}" if n > 1 else "single GPU"},
+                       "meshlets_tested_rank0": int(c.meshletsTested), "partition": f"row bands x{n}" if n > 1 else "single GPU",
+                       "frames_in_flight": fif},
             "roofline": {"bound": "valu" if (valu and valu["frac"] > hbm_frac) else "hbm", "kernel": DOMINANT_KERNEL.get(dom, dom), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(hbm_frac, 5), "traffic": traffic, "valu": valu,
                          "algorithmic_bytes_per_launch": int(per_stage_bytes[dom]), "launch_ms": round(stage_ms[dom], 4),
                          "whole_frame": {"algorithmic_bytes": int(total_bytes), "achieved_GBps": round(frame_gbs, 2), "frac": round(frame_gbs / HBM_PEAK_GBS, 5)}},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items() if v > 0},
-            "stage_ms_note": f"'{dom}' from HIP events inside the timed region; the other stages from 10 untimed frames before it",
+            "stage_ms_note": (f"'{dom}' from HIP events inside the timed region; the other stages from 10 untimed frames before it" if fif == 1 else
+                              f"serial frames of one pass (nothing else on the GPU): '{dom}' over {min(args.steps, 200)} frames after the timed region, the other stages over 10 frames "
+                              f"before it; inside the timed region, sharing the CUs with the other pass's frame, '{dom}' took {in_flight_ms:.4f} ms per launch"),
         }
+        if fif == 2:
+            out["roofline"]["launch_ms_in_flight"] = round(in_flight_ms, 4)
+            out["frame_latency_ms"] = round(sum(stage_ms.values()), 4)
         if cpu:
             out["cpu_baseline"] = cpu_baseline(scene, args.cpu_scale)
             out["configs0"] = cpu_forward_baseline()
-    r.close()
+    for p in passes:
+        p.close()
     return out
 
 

@@ -185,6 +185,13 @@ int brmi_depth_copy(brmi_pass* pass, brmi_stream stream);         /* LinearDepth
 int brmi_build_hzb(brmi_pass* pass, brmi_stream stream);          /* LinearDepthDownsamplePass (SPD max-reduce; BR/shaders/downsample.hlsl) */
 /* Drops the previous frame's depth chain (camera cut, resize): the next phase 1 runs without occlusion tests. */
 int brmi_invalidate_hzb(brmi_pass* pass);
+/* Frames in flight (the reference's `numFramesInFlight`, CLodStreamingSystem.cpp:956): two passes with their own resources render
+ * alternate frames on two streams; phase 1 of a pass then tests against the depth chain the OTHER pass built for the frame before
+ * (`source`), not against its own, which is two frames old.  Both passes must have the same size and band, and each the other as
+ * its source.  brmi_execute orders the two streams itself: a frame starts when the source's chain of the frame before is complete
+ * (one event wait), everything after the source's chain build -- its G-buffer and shading -- overlaps this pass's culling and
+ * rasterisation.  The images are those of one pass rendering the same frames in order.  NULL unlinks. */
+int brmi_set_history_source(brmi_pass* pass, brmi_pass* source);
 int brmi_gbuffer(brmi_pass* pass, brmi_stream stream);            /* MaterialHistogram..EvaluateMaterialGroups (K7,K8) */
 int brmi_light_clustering(brmi_pass* pass, brmi_stream stream);   /* ClusterGenerationPass + LightCullingPass (K9,K10) */
 int brmi_shade(brmi_pass* pass, brmi_stream stream);              /* DeferredShadingPass (K11) */

@@ -838,6 +838,77 @@ def test_occlusion_does_not_change_the_image(name, occlusion_runs):
             assert np.array_equal(a, b), f"frame {i}"
 
 
+@pytest.mark.parametrize("name", ["bistro", "tiny_odd"])
+def test_two_frames_in_flight_render_the_frames_of_one_pass(name):
+    """brmi_set_history_source: two passes alternate the frames of a camera path on two streams, each testing phase 1 against the chain
+    the other built for the frame before.  No host synchronisation between the frames -- the passes' own event orders the streams --
+    and every frame's keys, depth, chain, cluster list and HDR bytes are those of one pass rendering the path in order."""
+    import torch
+    from conftest import Scene
+    from basicrenderer_amd import capi
+    from basicrenderer_amd.renderer import VisibilityRenderer
+    preset, W, H, kw = OCCLUSION_CASES[name]
+    steps = 6
+    scenes = [Scene(preset, W, H, camera_step=s, **kw) for s in range(steps)]
+    keep = ("VISIBILITY", "LINEAR_DEPTH", "HZB", "HDR_COLOR", "VISIBLE_CLUSTERS", "GBUF_NORMALS")
+    serial = []
+    one = VisibilityRenderer(scenes[0], occlusion=True)
+    for s in range(steps):
+        if s:
+            one.set_camera_from(scenes[s], frame_index=s)
+        one.execute()
+        c = one.counters()
+        serial.append(({k: one.res[capi.RES[k]].clone() for k in keep}, (c.visibleClusters, c.visibleClustersPhase2, c.replayNodes, c.replayMeshlets)))
+    one.close()
+    assert sum(c[2] + c[3] for _, c in serial) > 0 or name == "tiny_odd", "the path does not exercise the replay buffers"
+    passes = [VisibilityRenderer(Scene(preset, W, H, camera_step=0, **kw), occlusion=True) for _ in range(2)]
+    passes[0].set_history_source(passes[1]); passes[1].set_history_source(passes[0])
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    got = []
+    for s in range(steps):
+        r = passes[s & 1]
+        with torch.cuda.stream(streams[s & 1]):
+            r.set_camera_from(scenes[s], frame_index=s)
+            r.execute()
+            got.append({k: r.res[capi.RES[k]].clone() for k in keep})      # same stream: ordered after the frame, no host wait
+    torch.cuda.synchronize()
+    drawn_frames = 0
+    for s in range(steps):
+        want, counts = serial[s]
+        for k in ("VISIBILITY", "LINEAR_DEPTH", "HZB"):
+            assert torch.equal(got[s][k], want[k]), f"frame {s}: {k} differs from the one-pass frame"
+        n = (counts[0] + counts[1]) * 16
+        assert torch.equal(got[s]["VISIBLE_CLUSTERS"][:n], want["VISIBLE_CLUSTERS"][:n]), f"frame {s}: cluster list"
+        # pixels no triangle covers are not written by the resolve / shading kernels (they keep what an earlier frame of the SAME pass left)
+        drawn = (want["VISIBILITY"].view(torch.int64) != -1)
+        drawn_frames += int(drawn.any())
+        for k, bpp in (("HDR_COLOR", 8), ("GBUF_NORMALS", 16)):
+            a, b = got[s][k].view(-1, bpp)[: drawn.numel()], want[k].view(-1, bpp)[: drawn.numel()]
+            assert torch.equal(a[drawn], b[drawn]), f"frame {s}: {k} differs from the one-pass frame"
+    assert drawn_frames >= 3
+    # a pass that loses its source falls back to its own (two frames old) chain; destroying in either order is safe
+    passes[0].close()
+    passes[1].execute()
+    passes[1].close()
+
+
+def test_history_source_is_validated():
+    from conftest import Scene
+    from basicrenderer_amd.renderer import VisibilityRenderer, BrmiError
+    a = VisibilityRenderer(Scene("tiny", 200, 120, point_lights=2), occlusion=True)
+    b = VisibilityRenderer(Scene("tiny", 208, 120, point_lights=2), occlusion=True)
+    c = VisibilityRenderer(Scene("tiny", 200, 120, point_lights=2), occlusion=False)
+    with pytest.raises(BrmiError, match="differ in size"):
+        a.set_history_source(b)
+    with pytest.raises(BrmiError, match="enableOcclusionCulling"):
+        a.set_history_source(c)
+    a.set_history_source(a)            # a pass is always its own source
+    a.set_history_source(None)
+    for r in (a, b, c):
+        r.close()
+
+
 def test_occlusion_static_camera_culls_hidden_clusters_at_4k():
     """Bistro-class street at full size: the second frame must rasterise fewer clusters and produce the same HDR bytes."""
     from conftest import Scene
