@@ -211,7 +211,7 @@ def scene_lib():
 
 
 BRMI_EXPORTS = ["brmi_abi_version", "brmi_default_config", "brmi_create", "brmi_declare", "brmi_set_scene", "brmi_setup",
-                "brmi_update", "brmi_execute", "brmi_destroy", "brmi_last_error", "brmi_clear_visibility", "brmi_cull",
+                "brmi_update", "brmi_execute", "brmi_execute_split", "brmi_destroy", "brmi_last_error", "brmi_clear_visibility", "brmi_cull",
                 "brmi_raster", "brmi_depth_copy", "brmi_build_hzb", "brmi_invalidate_hzb", "brmi_set_history_source", "brmi_gbuffer", "brmi_light_clustering",
                 "brmi_shade", "brmi_read_counters", "brmi_stage_times", "brmi_set_timed_stages", "brmi_algorithmic_bytes", "brmi_debug_arith", "brmi_debug_arith_in_range"]
 
@@ -237,6 +237,7 @@ def brmi_lib():
         lib.brmi_setup.argtypes = [vp, C.POINTER(ResourceBinding), u32, vp]
         lib.brmi_update.argtypes = [vp, C.POINTER(FrameUpdate), vp]
         lib.brmi_execute.argtypes = [vp, vp]
+        lib.brmi_execute_split.argtypes = [vp, vp, vp]
         lib.brmi_destroy.argtypes = [vp]
         lib.brmi_destroy.restype = None
         lib.brmi_last_error.argtypes = [vp]

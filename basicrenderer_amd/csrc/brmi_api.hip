@@ -221,6 +221,8 @@ void brmi_destroy(brmi_pass* p) {
     (void)brmi_set_history_source(p, nullptr);
     for (brmi_pass* user : p->historyUsers) user->history = nullptr;
     if (p->chainReady) (void)hipEventDestroy(p->chainReady);
+    if (p->geometryDone) (void)hipEventDestroy(p->geometryDone);
+    if (p->frameDone) (void)hipEventDestroy(p->frameDone);
     delete p;
 }
 
@@ -549,6 +551,7 @@ static int build_hzb_fused(brmi_pass* p, hipStream_t s, bool fromVisibility, boo
 int brmi_invalidate_hzb(brmi_pass* p) {
     if (!p) return BRMI_ERR_INVALID;
     p->hzbValid = false;
+    if (p->history) p->history->hzbValid = false;      // the chain the next phase 1 would test against is the source's
     return BRMI_OK;
 }
 int brmi_set_history_source(brmi_pass* p, brmi_pass* source) {
@@ -560,7 +563,6 @@ int brmi_set_history_source(brmi_pass* p, brmi_pass* source) {
         if (p->cfg.width != source->cfg.width || p->cfg.height != source->cfg.height || p->bandY0 != source->bandY0 || p->bandY1 != source->bandY1)
             return brmi::fail(p, BRMI_ERR_INVALID, "brmi_set_history_source: the passes differ in size or band (%ux%u rows %u-%u against %ux%u rows %u-%u)", p->cfg.width, p->cfg.height, p->bandY0, p->bandY1,
                               source->cfg.width, source->cfg.height, source->bandY0, source->bandY1);
-        if (!source->chainReady) BRMI_HIP(p, hipEventCreateWithFlags(&source->chainReady, hipEventDisableTiming));
     }
     if (p->history) { auto& u = p->history->historyUsers; u.erase(std::remove(u.begin(), u.end(), p), u.end()); }
     p->history = source;
@@ -581,12 +583,24 @@ int brmi_shade(brmi_pass* p, brmi_stream stream) {
 }
 
 // The whole chain in graph order.  K6 is folded into the G-buffer kernel (one visibility read).
-int brmi_execute(brmi_pass* p, brmi_stream stream) {
+int brmi_execute(brmi_pass* p, brmi_stream stream) { return brmi_execute_split(p, stream, stream); }
+
+// Geometry half (culling, rasterisation, depth chain: latency-bound launches that leave most of the chip idle) on `stream`, resolve +
+// shading half (VALU-bound, fills the chip) on `shadeStream`.  With two linked passes alternating frames on the SAME two streams -- the
+// geometry stream created with a higher priority -- frame k+1's geometry runs beside frame k's shading and gets CU slots first.
+int brmi_execute_split(brmi_pass* p, brmi_stream stream, brmi_stream shadeStream) {
     CHECK_READY(p);
     int rc;
     p->executesSinceTimes++;
+    const bool split = shadeStream != stream;
+    // this pass's previous frame may still be resolving / shading on the other stream: its visibility buffer and tables are about to be rewritten
+    if (p->frameDoneRecorded) BRMI_HIP(p, hipStreamWaitEvent(static_cast<hipStream_t>(stream), p->frameDone, 0));
+    p->frameDoneRecorded = false;
     // frames in flight: this frame's phase 1 reads the chain the source pass built for the frame before, possibly on another stream
     if (p->history && p->history->chainRecorded) BRMI_HIP(p, hipStreamWaitEvent(static_cast<hipStream_t>(stream), p->history->chainReady, 0));
+    // ... and this frame rewrites the chain a pass that has THIS one as its source may still be reading in its phase 1 (the same event:
+    // it is recorded after that pass's culling)
+    for (brmi_pass* user : p->historyUsers) if (user != p->history && user->chainRecorded) BRMI_HIP(p, hipStreamWaitEvent(static_cast<hipStream_t>(stream), user->chainReady, 0));
     // When the phase-1 traversal is the one-launch LDS walk and the frame constants are due anyway, the frame needs no clear launch: the
     // constants kernel zeroes the culling state and the walk's launch carries the visibility clear (brmi_cull.hip, SideClear).
     static const bool rideEnv = [] { const char* e = std::getenv("BRMI_CLEAR_RIDES"); return !e || std::atoi(e) != 0; }();
@@ -619,12 +633,21 @@ int brmi_execute(brmi_pass* p, brmi_stream stream) {
         // nothing: the depth map and the chain are final BEFORE the G-buffer kernel (which then skips its depth store), so a pass that
         // renders the next frame on another stream (brmi_set_history_source) can start while this frame is resolved and shaded.
         if ((rc = build_hzb_fused(p, static_cast<hipStream_t>(stream), true, true))) return rc;
-        if (!p->historyUsers.empty()) { BRMI_HIP(p, hipEventRecord(p->chainReady, static_cast<hipStream_t>(stream))); p->chainRecorded = true; }
+        // recorded every frame (a pass may be linked to this one later, from another stream)
+        if (!p->chainReady) BRMI_HIP(p, hipEventCreateWithFlags(&p->chainReady, hipEventDisableTiming));
+        BRMI_HIP(p, hipEventRecord(p->chainReady, static_cast<hipStream_t>(stream))); p->chainRecorded = true;
     }
     // BRMI_FUSE_SHADE=1 (off by default): one pass over the pixels for G-buffer + shading where the G-buffer kernel is the lean one
     // (brmi_resolve.hip: k_gbuffer_shade); the light lists must exist by then.  Measured: 338 us against 103 + 236 us for the two kernels on
     // the Bistro-class 4K frame -- both are bound by VALU issue (the G-buffer kernel at six waves per SIMD as well), so not reading the
     // 48 B per pixel back buys 6 us of the frame.  Kept as a tested variant, not as the default: the two-kernel frame is what the profiles describe.
+    if (split) {
+        if (!p->geometryDone) BRMI_HIP(p, hipEventCreateWithFlags(&p->geometryDone, hipEventDisableTiming));
+        if (!p->frameDone) BRMI_HIP(p, hipEventCreateWithFlags(&p->frameDone, hipEventDisableTiming));
+        BRMI_HIP(p, hipEventRecord(p->geometryDone, static_cast<hipStream_t>(stream)));
+        BRMI_HIP(p, hipStreamWaitEvent(static_cast<hipStream_t>(shadeStream), p->geometryDone, 0));
+        stream = shadeStream;
+    }
     const bool fuseEnv = p->fuseShadeOptIn;
     bool lightsDone = p->lightGridDone;      // the culling pass's launches carried the light clustering
     p->lightGridDone = false;
@@ -636,6 +659,7 @@ int brmi_execute(brmi_pass* p, brmi_stream stream) {
     if (rc) return rc;
     if (!lightsDone && (rc = brmi_light_clustering(p, stream))) return rc;
     if ((rc = brmi_shade(p, stream))) return rc;
+    if (split) { BRMI_HIP(p, hipEventRecord(p->frameDone, static_cast<hipStream_t>(stream))); p->frameDoneRecorded = true; }
     return BRMI_OK;
 }
 

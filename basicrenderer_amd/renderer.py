@@ -105,8 +105,12 @@ class VisibilityRenderer:
         upd = capi.FrameUpdate(cam.ctypes.data, pf.ctypes.data, frame_index)
         self._check(self.lib.brmi_update(self._h, C.byref(upd), self._s()), "brmi_update")
 
-    def execute(self):
-        self._check(self.lib.brmi_execute(self._h, self._s()), "brmi_execute")
+    def execute(self, shading_stream=None):
+        """The whole frame on the current stream; with `shading_stream` (a torch stream) the resolve + shading half goes there."""
+        if shading_stream is None:
+            self._check(self.lib.brmi_execute(self._h, self._s()), "brmi_execute")
+        else:
+            self._check(self.lib.brmi_execute_split(self._h, self._s(), C.c_void_p(shading_stream.cuda_stream)), "brmi_execute_split")
 
     def stage(self, name, *args):
         fn = getattr(self.lib, "brmi_" + name)

@@ -124,14 +124,21 @@ def measure(args, workload, n, rank, local_rank, cpu):
     scene = Scene(preset, W, H, point_lights=lights, directional=True, lod_builder=args.lod_builder, material_features=args.material_features, **scene_kw)
     r = VisibilityRenderer(scene, device=dev, stats=True, band=band, occlusion=bool(args.occlusion))
     fif = args.frames_in_flight
-    passes, streams = [r], [torch.cuda.current_stream(dev)]
+    passes, streams, shade_streams = [r], [torch.cuda.current_stream(dev)], [None, None]
     if fif == 2:
         # the second pass has its own resources and scene upload (its camera buffers are its own); phase 1 of each tests against the chain
         # the other built for the frame before
         passes.append(VisibilityRenderer(scene, device=dev, stats=False, band=band, occlusion=bool(args.occlusion)))
         if args.occlusion:
             passes[0].set_history_source(passes[1]); passes[1].set_history_source(passes[0])
-        streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+        mode = os.environ.get("BRMI_BENCH_STREAMS", "split")
+        if mode == "split":
+            # both passes use the same pair: a geometry stream (higher priority: its launches are latency-bound and want CU slots the moment
+            # they are ready) and a shading stream
+            geometry, shading = torch.cuda.Stream(dev, priority=-1), torch.cuda.Stream(dev, priority=0)
+            streams, shade_streams = [geometry, geometry], [shading, shading]
+        else:
+            streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]        # one stream per pass, whole frames
 
     hdr = r.hdr_tensor()
     # all-gather of frame k overlaps the rendering of frame k + 1; the colour channels travel (RGB16F, 6 B/px): the lit target's alpha is constant
@@ -165,8 +172,9 @@ def measure(args, workload, n, rank, local_rank, cpu):
         p = passes[k]
         with torch.cuda.stream(streams[k]):
             p.update()                  # the per-frame Update phase (camera / per-frame constants), as the reference's passes run it every frame
-            p.execute()
-            if composer:
+            p.execute(None if serial else shade_streams[k])
+        if composer:
+            with torch.cuda.stream(streams[k] if serial or shade_streams[k] is None else shade_streams[k]):
                 composer.submit(p.hdr_tensor())
         frame_no[0] += 1
 

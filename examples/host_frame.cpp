@@ -2,7 +2,9 @@
 // buffers, resources declared by the pass and allocated by the "graph" (here: hipMalloc), passes gathered from the
 // extension and executed in order on one stream.  Prints the frame's checksums as one JSON line.
 //
-//   build:  make host_example        run:  basicrenderer_amd/lib/brmi_host_frame [preset W H lights occlusion frames materialFeatures lodLevels]
+//   build:  make host_example        run:  basicrenderer_amd/lib/brmi_host_frame [preset W H lights occlusion frames materialFeatures lodLevels framesInFlight]
+// framesInFlight = 2 (needs occlusion = 1): after the graph-driven frames, the same frames again through two linked passes that alternate on a
+// geometry stream and a shading stream (brmi_set_history_source + brmi_execute_split); the line then reports the last of THOSE frames.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -41,6 +43,7 @@ int main(int argc, char** argv) {
     const int frames = argc > 6 ? std::max(1, std::atoi(argv[6])) : 1;
     prm.materialFeatures = argc > 7 ? (uint32_t)std::atoi(argv[7]) : 0u;        // brmi_scene.h: 8 = texture-sampled, 16 = alpha-tested materials
     prm.lodLevels = argc > 8 ? (uint32_t)std::atoi(argv[8]) : 0u;
+    const int framesInFlight = argc > 9 ? std::atoi(argv[9]) : 1;
     brmi_scene* scene = nullptr;
     if (prm.preset == 100u) {
         // preset 100: not a preset -- the host's OWN geometry through brmi_scene_create_from_meshes (row f-1).  A height field whose coordinates
@@ -155,8 +158,33 @@ int main(int argc, char** argv) {
             for (auto& p : passes) p->Execute(ctx);
         }
         HIPCHK(hipStreamSynchronize(stream));
-        brmi_counters c; state->check(brmi_read_counters(state->get(), &c, stream), "brmi_read_counters");
-        auto checksum = [&](uint32_t id) { std::vector<uint8_t> h(sizes[id]); for (auto& bd : binds) if (bd.id == id) HIPCHK(hipMemcpy(h.data(), bd.ptr, sizes[id], hipMemcpyDeviceToHost)); return fnv1a(h.data(), h.size()); };
+        std::vector<brmi_resource_binding> lastBinds = binds;
+        std::shared_ptr<PassState> last = state;
+        std::shared_ptr<PassState> second;
+        if (framesInFlight == 2) {
+            if (!occlusion) throw std::runtime_error("framesInFlight = 2 needs occlusion = 1 (there is no history to share otherwise)");
+            // the second pass owns a full set of resources; its phase 1 reads the first pass's depth chain and vice versa
+            second = std::make_shared<PassState>(cfg);
+            second->SetScene(sb);
+            std::vector<brmi_resource_binding> binds2;
+            for (const brmi_resource_desc& d : second->Declare()) binds2.push_back(brmi_resource_binding{d.id, rg.allocate(d), d.bytes});
+            second->Bind(binds2, stream);
+            second->Update({static_cast<const brmi_camera*>(camHost), static_cast<const brmi_per_frame*>(pfHost), 0}, stream);
+            state->check(brmi_invalidate_hzb(state->get()), "brmi_invalidate_hzb");       // start the sequence over: frame 0 has no history
+            state->check(brmi_set_history_source(state->get(), second->get()), "brmi_set_history_source");
+            second->check(brmi_set_history_source(second->get(), state->get()), "brmi_set_history_source");
+            int least = 0, greatest = 0; HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            hipStream_t geometry, shading;
+            HIPCHK(hipStreamCreateWithPriority(&geometry, hipStreamNonBlocking, greatest)); HIPCHK(hipStreamCreateWithPriority(&shading, hipStreamNonBlocking, least));
+            HIPCHK(hipStreamSynchronize(stream));
+            PassState* pair[2] = {state.get(), second.get()};
+            for (int f = 0; f < frames; f++) pair[f & 1]->check(brmi_execute_split(pair[f & 1]->get(), geometry, shading), "brmi_execute_split");
+            HIPCHK(hipStreamSynchronize(shading)); HIPCHK(hipStreamSynchronize(geometry));
+            HIPCHK(hipStreamDestroy(geometry)); HIPCHK(hipStreamDestroy(shading));
+            if ((frames - 1) & 1) { last = second; lastBinds = binds2; }
+        }
+        brmi_counters c; last->check(brmi_read_counters(last->get(), &c, stream), "brmi_read_counters");
+        auto checksum = [&](uint32_t id) { std::vector<uint8_t> h(sizes[id]); for (auto& bd : lastBinds) if (bd.id == id) HIPCHK(hipMemcpy(h.data(), bd.ptr, sizes[id], hipMemcpyDeviceToHost)); return fnv1a(h.data(), h.size()); };
         std::printf("{\"passes\": %zu, \"frame_passes\": %zu, \"srv\": %zu, \"uav\": %zu, \"cbv\": %zu, \"indirect\": %zu, \"visible_clusters\": %u, \"visible_clusters_phase2\": %u, \"replayed\": %u, \"vis_fnv\": \"%016llx\", \"hdr_fnv\": \"%016llx\", \"normals_fnv\": \"%016llx\"}\n",
                     passes.size(), framePasses.size(), builder.shaderResources.size(), builder.unorderedAccess.size(), builder.constantBuffers.size(), builder.indirectArguments.size(), c.visibleClusters, c.visibleClustersPhase2, c.replayNodes + c.replayMeshlets,
                     (unsigned long long)checksum(BRMI_RES_VISIBILITY), (unsigned long long)checksum(BRMI_RES_HDR_COLOR), (unsigned long long)checksum(BRMI_RES_GBUF_NORMALS));

@@ -172,6 +172,12 @@ int         brmi_set_scene(brmi_pass* pass, const brmi_scene_buffers* scene);   
 int         brmi_setup(brmi_pass* pass, const brmi_resource_binding* b, uint32_t n, brmi_stream stream); /* Setup */
 int         brmi_update(brmi_pass* pass, const brmi_frame_update* upd, brmi_stream stream);               /* Update */
 int         brmi_execute(brmi_pass* pass, brmi_stream stream);                          /* Execute: whole chain */
+/* The same frame on two streams (the reference schedules its passes on a graphics and an async-compute queue): culling, rasterisation
+ * and the depth chain on `geometryStream`, G-buffer, light lists (when the culling launches did not carry them) and shading on
+ * `shadingStream`; events order the two halves and the pass's next frame.  Outputs are ready when `shadingStream` is.  With
+ * brmi_set_history_source and two passes alternating frames on the SAME pair of streams, frame k+1's geometry half -- latency-bound
+ * launches that leave most of the chip idle -- runs beside frame k's shading half; give `geometryStream` the higher priority. */
+int         brmi_execute_split(brmi_pass* pass, brmi_stream geometryStream, brmi_stream shadingStream);
 void        brmi_destroy(brmi_pass* pass);                                               /* Cleanup */
 const char* brmi_last_error(const brmi_pass* pass);
 
@@ -187,8 +193,8 @@ int brmi_build_hzb(brmi_pass* pass, brmi_stream stream);          /* LinearDepth
 int brmi_invalidate_hzb(brmi_pass* pass);
 /* Frames in flight (the reference's `numFramesInFlight`, CLodStreamingSystem.cpp:956): two passes with their own resources render
  * alternate frames on two streams; phase 1 of a pass then tests against the depth chain the OTHER pass built for the frame before
- * (`source`), not against its own, which is two frames old.  Both passes must have the same size and band, and each the other as
- * its source.  brmi_execute orders the two streams itself: a frame starts when the source's chain of the frame before is complete
+ * (`source`), not against its own, which is two frames old.  Both passes must have the same size and band; for two frames in
+ * flight each is the other's source.  brmi_execute orders the streams itself: a frame starts when the source's chain of the frame before is complete
  * (one event wait), everything after the source's chain build -- its G-buffer and shading -- overlaps this pass's culling and
  * rasterisation.  The images are those of one pass rendering the same frames in order.  NULL unlinks. */
 int brmi_set_history_source(brmi_pass* pass, brmi_pass* source);

@@ -53,6 +53,18 @@ def _worker(rank, world, port, W, H, out_path):
         want = compose.rgb_of(compose.compose_bands(surface ^ frame, band, W, 8))
         assert rgb.out[slot].shape == want.shape and torch.equal(rgb.out[slot], want), f"rgb transport, frame {frame}"
     assert torch.equal(rgb.finish(), compose.rgb_of(compose.compose_bands(surface ^ 2, band, W, 8)))
+    # two frames in flight (bench.py's default): the frames alternate between the targets of two passes, one composer gathers both
+    targets = [surface.clone(), surface.clone()]
+    for transport in ("surface", "rgb16f"):
+        both = compose.BandComposer(targets[0], band, W, 8, depth=2, transport=transport)
+        for frame in range(4):
+            tgt = targets[frame & 1]
+            tgt[lo:hi] = surface[lo:hi] ^ (frame + 7)
+            slot = both.submit(tgt)
+            both.work[slot].wait()
+            want = compose.compose_bands(surface ^ (frame + 7), band, W, 8)
+            assert torch.equal(both.out[slot], compose.rgb_of(want) if transport == "rgb16f" else want), f"alternating targets, {transport}, frame {frame}"
+        both.finish()
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)                      # the max-over-ranks timing reduction of bench.py
     assert t.item() == world

@@ -529,21 +529,27 @@ def test_full_size_frames_against_the_oracle(preset, W, H, lights, kw):
     r.close()
 
 
-@pytest.mark.parametrize("preset,lights,kw", [("sponza", 64, dict()), ("bistro", 256, dict()), ("san_miguel", 256, dict(material_features=24)),
-                                              ("bistro", 256, dict(size_scale=20.0, detail=96.0))])      # the dense workload: 2-phase occlusion over the mixed traversal
-def test_full_size_camera_path_with_occlusion_against_the_oracle(preset, lights, kw):
+@pytest.mark.parametrize("preset,lights,kw,in_flight", [("sponza", 64, dict(), 1), ("bistro", 256, dict(), 1), ("san_miguel", 256, dict(material_features=24), 1),
+                                                        ("bistro", 256, dict(size_scale=20.0, detail=96.0), 1),      # the dense workload: 2-phase occlusion over the mixed traversal
+                                                        ("bistro", 256, dict(), 2)])                                 # the bench default: two passes render alternate frames
+def test_full_size_camera_path_with_occlusion_against_the_oracle(preset, lights, kw, in_flight):
     """Three 4K frames of the camera path with 2-phase occlusion culling on (the bench default), every frame against the oracle's
     2-phase frame: both phases' cluster lists, keys, depth, G-buffer exact, HDR within one fp16 ULP on covered pixels (pixels without
-    geometry are not written -- DeferredCSMain returns -- so they keep the previous frame's value)."""
+    geometry are not written -- DeferredCSMain returns -- so they keep the previous frame's value).  in_flight = 2: the frames
+    alternate between two linked passes (brmi_set_history_source), each testing phase 1 against the other's depth chain."""
     import orc
     from conftest import Scene
     from basicrenderer_amd.renderer import VisibilityRenderer
-    hz, r = None, None
+    hz, passes = None, []
     for step in range(3):
         sc = Scene(preset, 3840, 2160, point_lights=lights, camera_step=step, **kw)
-        if r is None:
-            r = VisibilityRenderer(sc, occlusion=True, stats=True)
+        if len(passes) < in_flight:
+            passes.append(VisibilityRenderer(sc, occlusion=True, stats=True))
+            if len(passes) == 2:
+                passes[0].set_history_source(passes[1]); passes[1].set_history_source(passes[0])
+            r = passes[-1]
         else:
+            r = passes[step % in_flight]
             r.set_camera_from(sc, frame_index=step)
         r.execute()
         o = orc.OracleFrame(sc)
@@ -563,7 +569,8 @@ def test_full_size_camera_path_with_occlusion_against_the_oracle(preset, lights,
         assert np.abs(a - b).max() <= 1, f"frame {step}"
         if step > 0 and preset != "sponza":
             assert o.count2 > 0, "the path does not exercise phase 2"
-    r.close()
+    for r in passes:
+        r.close()
 
 
 @pytest.mark.parametrize("preset,lights,n,kw", [("sponza", 64, 2, dict()), ("bistro", 256, 4, dict()),
@@ -722,6 +729,13 @@ def test_cpp_host_passes_reproduce_the_python_frame(scenes):
         raw = r.res[capi.RES[rid]].cpu().numpy()[: r.descs[capi.RES[rid]]["bytes"]]
         assert fnv(raw) == got[key], key
     r.close()
+    # ... and the same two frames through two linked passes in flight on a geometry and a shading stream (brmi_set_history_source +
+    # brmi_execute_split called from C++): frame 1 comes from the second pass, with the same bytes
+    out = subprocess.run([exe, "1", "640", "360", "8", "1", "2", "0", "0", "2"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    pair = json.loads(out.stdout.strip().splitlines()[-1])
+    for key in ("visible_clusters", "visible_clusters_phase2", "replayed", "vis_fnv", "hdr_fnv", "normals_fnv"):
+        assert pair[key] == got[key], "two frames in flight: " + key
 
     # the host's own geometry through brmi_scene_create_from_meshes, from C++ (preset 100 of the example) and from Python: the same arrays
     # (coordinates are exact binary fractions), the same bytes
@@ -838,11 +852,12 @@ def test_occlusion_does_not_change_the_image(name, occlusion_runs):
             assert np.array_equal(a, b), f"frame {i}"
 
 
-@pytest.mark.parametrize("name", ["bistro", "tiny_odd"])
-def test_two_frames_in_flight_render_the_frames_of_one_pass(name):
+@pytest.mark.parametrize("name,split", [("bistro", False), ("tiny_odd", False), ("bistro", True), ("sponza", True)])
+def test_two_frames_in_flight_render_the_frames_of_one_pass(name, split):
     """brmi_set_history_source: two passes alternate the frames of a camera path on two streams, each testing phase 1 against the chain
-    the other built for the frame before.  No host synchronisation between the frames -- the passes' own event orders the streams --
-    and every frame's keys, depth, chain, cluster list and HDR bytes are those of one pass rendering the path in order."""
+    the other built for the frame before.  No host synchronisation between the frames -- the passes' own events order the streams --
+    and every frame's keys, depth, chain, cluster list and HDR bytes are those of one pass rendering the path in order.
+    split: brmi_execute_split, both passes on one geometry stream (high priority) and one shading stream."""
     import torch
     from conftest import Scene
     from basicrenderer_amd import capi
@@ -863,15 +878,16 @@ def test_two_frames_in_flight_render_the_frames_of_one_pass(name):
     assert sum(c[2] + c[3] for _, c in serial) > 0 or name == "tiny_odd", "the path does not exercise the replay buffers"
     passes = [VisibilityRenderer(Scene(preset, W, H, camera_step=0, **kw), occlusion=True) for _ in range(2)]
     passes[0].set_history_source(passes[1]); passes[1].set_history_source(passes[0])
-    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    streams = [torch.cuda.Stream(priority=-1), torch.cuda.Stream()]
     torch.cuda.synchronize()
     got = []
     for s in range(steps):
         r = passes[s & 1]
-        with torch.cuda.stream(streams[s & 1]):
+        with torch.cuda.stream(streams[0] if split else streams[s & 1]):
             r.set_camera_from(scenes[s], frame_index=s)
-            r.execute()
-            got.append({k: r.res[capi.RES[k]].clone() for k in keep})      # same stream: ordered after the frame, no host wait
+            r.execute(streams[1] if split else None)
+        with torch.cuda.stream(streams[1] if split else streams[s & 1]):
+            got.append({k: r.res[capi.RES[k]].clone() for k in keep})      # the stream the frame ends on: ordered after it, no host wait
     torch.cuda.synchronize()
     drawn_frames = 0
     for s in range(steps):
