@@ -78,7 +78,9 @@ int brmi_compose_create(const brmi_compose_config* cfg, const uint8_t id[BRMI_CO
     CHECK_HIP(c, hipSetDevice(cfg->device));
     ncclUniqueId u; std::memcpy(&u, id, sizeof(u));
     CHECK_NCCL(c, ncclCommInitRank(&c->comm, (int)cfg->nRanks, u, (int)cfg->rank));
-    CHECK_HIP(c, hipStreamCreateWithFlags(&c->collStream, hipStreamNonBlocking));
+    // highest priority: from two GPUs on the gather bounds the frame rate, and with two frames in flight the render
+    // streams keep every CU busy -- the collective's few workgroups must not queue behind them
+    { int least = 0, greatest = 0; CHECK_HIP(c, hipDeviceGetStreamPriorityRange(&least, &greatest)); CHECK_HIP(c, hipStreamCreateWithPriority(&c->collStream, hipStreamNonBlocking, greatest)); }
     c->staged.resize(cfg->depth); c->done.resize(cfg->depth); c->inFlight.assign(cfg->depth, false);
     for (uint32_t i = 0; i < cfg->depth; i++) { CHECK_HIP(c, hipEventCreateWithFlags(&c->staged[i], hipEventDisableTiming)); CHECK_HIP(c, hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming)); }
     return 0;
