@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Render a Wavefront OBJ through the whole path on an MI355X and write the lit frame as a PNG (Reinhard + sRGB).
+"""Render a Wavefront OBJ or a glTF 2.0 file (.gltf / .glb) through the whole path on an MI355X and write the lit frame as a PNG
+(Reinhard + sRGB).
 
-    python examples/render_obj.py model.obj out.png [--size 1920x1080] [--lights 32] [--features 0]
+    python examples/render_obj.py model.obj|scene.glb out.png [--size 1920x1080] [--lights 32] [--features 0]
 """
 import argparse
 import os
@@ -34,9 +35,14 @@ def main():
     from basicrenderer_amd.obj import frame_view, load_obj
     from basicrenderer_amd.renderer import VisibilityRenderer
     w, h = (int(x) for x in a.size.lower().split("x"))
-    meshes = load_obj(a.obj)
-    sc = Scene(width=w, height=h, point_lights=a.lights, material_features=a.features, meshes=meshes, instances=[(k, np.eye(4, dtype=np.float32)) for k in range(len(meshes))],
-               view=frame_view(meshes))
+    if a.obj.lower().endswith((".gltf", ".glb")):
+        from basicrenderer_amd import gltf
+        meshes, instances = gltf.load_gltf(a.obj)
+        view = gltf.frame_view(meshes, instances)
+    else:
+        meshes = load_obj(a.obj)
+        instances, view = [(k, np.eye(4, dtype=np.float32)) for k in range(len(meshes))], frame_view(meshes)
+    sc = Scene(width=w, height=h, point_lights=a.lights, material_features=a.features, meshes=meshes, instances=instances, view=view)
     r = VisibilityRenderer(sc, occlusion=True)
     r.execute(); r.execute()
     hdr = r.hdr().view(np.float16).reshape(h, w, 4)[..., :3].astype(np.float32)

@@ -723,6 +723,80 @@ def test_obj_loader_feeds_the_scene_builder(tmp_path):
     assert (f.vis != EMPTY).mean() > 0.05
 
 
+def _tiny_gltf(tmp_path, container):
+    """A two-mesh glTF written by hand: float positions, normalised uint16 texcoords interleaved with padding (byteStride), uint16 and absent
+    indices, a LINES primitive, a node hierarchy with TRS and a matrix node.  container: 'glb', 'gltf-uri' (external .bin), 'gltf-data'."""
+    import base64, json, struct
+    quad = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]], dtype=np.float32)
+    tri = np.array([[0, 0, 0], [2, 0, 0], [0, 2, 0], [0, 0, 0], [0, 2, 0], [-2, 0, 0]], dtype=np.float32)       # two triangles, no indices
+    uv16 = np.array([[0, 0], [65535, 0], [65535, 65535], [0, 65535]], dtype=np.uint16)
+    inter = b"".join(uv16[i].tobytes() + b"\xAB\xCD\xEF\x01" for i in range(4))                               # stride 8: 4 B of texcoord + 4 B of something else
+    idx = np.array([0, 1, 2, 0, 2, 3], dtype=np.uint16)
+    nrm = np.tile(np.array([[0, 0, 1]], dtype=np.float32), (4, 1))
+    parts, views = [], []
+    for blob, stride in ((quad.tobytes(), None), (inter, 8), (idx.tobytes(), None), (nrm.tobytes(), None), (tri.tobytes(), None)):
+        off = sum(len(p) for p in parts)
+        v = dict(buffer=0, byteOffset=off, byteLength=len(blob))
+        if stride:
+            v["byteStride"] = stride
+        views.append(v)
+        parts.append(blob + b"\0" * (-len(blob) % 4))
+    binary = b"".join(parts)
+    doc = dict(asset=dict(version="2.0"), buffers=[dict(byteLength=len(binary))], bufferViews=views,
+               accessors=[dict(bufferView=0, componentType=5126, count=4, type="VEC3"), dict(bufferView=1, componentType=5123, normalized=True, count=4, type="VEC2"),
+                          dict(bufferView=2, componentType=5123, count=6, type="SCALAR"), dict(bufferView=3, componentType=5126, count=4, type="VEC3"),
+                          dict(bufferView=4, componentType=5126, count=6, type="VEC3")],
+               materials=[dict(name="a"), dict(name="b")],
+               meshes=[dict(name="quad", primitives=[dict(attributes=dict(POSITION=0, TEXCOORD_0=1, NORMAL=3), indices=2, material=1), dict(attributes=dict(POSITION=0), mode=1)]),
+                       dict(name="tris", primitives=[dict(attributes=dict(POSITION=4))])],
+               nodes=[dict(name="root", translation=[10, 0, 0], children=[1]),
+                      dict(name="child", mesh=0, scale=[2, 2, 2], rotation=[0, 0, float(np.sin(np.pi / 4)), float(np.cos(np.pi / 4))], translation=[0, 5, 0]),   # 90 degrees about z
+                      dict(name="other", mesh=1, matrix=[1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, -3, 0, 4, 1]), dict(name="unused", mesh=0)],
+               scenes=[dict(nodes=[0, 2])], scene=0)
+    if container == "glb":
+        js = json.dumps(doc).encode(); js += b" " * (-len(js) % 4)
+        path = tmp_path / "tiny.glb"
+        path.write_bytes(struct.pack("<4sII", b"glTF", 2, 12 + 8 + len(js) + 8 + len(binary)) + struct.pack("<I4s", len(js), b"JSON") + js + struct.pack("<I4s", len(binary), b"BIN\0") + binary)
+    else:
+        if container == "gltf-uri":
+            (tmp_path / "tiny.bin").write_bytes(binary); doc["buffers"][0]["uri"] = "tiny.bin"
+        else:
+            doc["buffers"][0]["uri"] = "data:application/octet-stream;base64," + base64.b64encode(binary).decode()
+        path = tmp_path / "tiny.gltf"
+        path.write_text(json.dumps(doc))
+    return str(path), quad, tri
+
+
+@pytest.mark.parametrize("container", ["glb", "gltf-uri", "gltf-data"])
+def test_gltf_loader_feeds_the_scene_builder(tmp_path, container):
+    """basicrenderer_amd.gltf (harness): accessors (strided, normalised, indexed and not), the three containers, node transforms in the
+    path's row-vector convention; the scene built from a file renders in the oracle."""
+    import orc
+    from basicrenderer_amd import Scene as RawScene
+    from basicrenderer_amd.gltf import GltfError, frame_view, load_gltf
+    path, quad, tri = _tiny_gltf(tmp_path, container)
+    meshes, instances = load_gltf(path)
+    assert [m["name"] for m in meshes] == ["quad.0", "tris.0"] and [m["material"] for m in meshes] == [1, 2]          # the LINES primitive is skipped; no material -> one past the last
+    assert np.array_equal(meshes[0]["positions"], quad) and np.array_equal(meshes[0]["indices"], [0, 1, 2, 0, 2, 3]) and meshes[0]["indices"].dtype == np.uint32
+    assert np.array_equal(meshes[0]["uvs"], np.array([[0, 0], [1, 0], [1, 1], [0, 1]], dtype=np.float32)) and "normals" in meshes[0]
+    assert np.array_equal(meshes[1]["positions"], tri) and np.array_equal(meshes[1]["indices"], np.arange(6)) and "uvs" not in meshes[1]
+    assert [k for k, _ in instances] == [0, 1]                                                                       # the node outside the scene is not instanced
+    # child: scale 2, rotate 90 degrees about z, move up 5, then the root's +10 in x: (1, 0, 0) -> (0, 2, 0) -> (0, 7, 0) -> (10, 7, 0)
+    p = np.array([1.0, 0.0, 0.0, 1.0], dtype=np.float32) @ instances[0][1]
+    assert np.allclose(p[:3], [10, 7, 0], atol=1e-5) and instances[0][1].dtype == np.float32
+    assert np.allclose(np.array([0, 0, 0, 1.0]) @ instances[1][1], [-3, 0, 4, 1])
+    sc = RawScene(width=160, height=90, point_lights=2, meshes=meshes, instances=instances, view=frame_view(meshes, instances))
+    assert sc.stats["uniqueTriangles"] == 4 and sc.stats["instances"] == 2
+    f = orc.OracleFrame(sc).run()
+    assert (f.vis != EMPTY).mean() > 0.004           # three small shapes 13 units apart
+    if container == "glb":
+        data = open(path, "rb").read()
+        bad = tmp_path / "bad.glb"
+        bad.write_bytes(data[:-40])
+        with pytest.raises(GltfError, match="truncated"):
+            load_gltf(str(bad))
+
+
 def _dag_of(build, release, P, I):
     """Runs a brmi_dag_build_fn on (positions, indices); returns (groups[depth, error, firstCluster, clusterCount, radius, center xyz], clusters[group, refined, V, T, error, radius, center xyz], vertexRefs, triangles)."""
     from basicrenderer_amd import capi
