@@ -393,6 +393,26 @@ def test_scene_of_caller_meshes_matches_the_oracle(features, occlusion):
     r.close()
 
 
+def test_gltf_file_renders_like_the_oracle(tmp_path):
+    """A glTF file (the hand-written one of the CPU suite: strided normalised texcoords, node hierarchy) through the loader, the LOD
+    builder and the whole path with texture-sampled materials: keys, depth exact, HDR within one fp16 ULP."""
+    import orc
+    from test_oracle_cpu import _tiny_gltf
+    from basicrenderer_amd import Scene as RawScene
+    from basicrenderer_amd.gltf import frame_view, load_gltf
+    from basicrenderer_amd.renderer import VisibilityRenderer
+    meshes, instances = load_gltf(_tiny_gltf(tmp_path, "glb")[0])
+    sc = RawScene(width=320, height=180, point_lights=3, material_features=8, meshes=meshes, instances=instances, view=frame_view(meshes, instances))
+    r = VisibilityRenderer(sc)
+    r.execute()
+    o = orc.OracleFrame(sc).run()
+    assert (o.vis != np.uint64(0xFFFFFFFFFFFFFFFF)).sum() > 100
+    assert np.array_equal(r.visibility(), o.vis) and np.array_equal(r.depth().view(np.uint32), o.depth.view(np.uint32))
+    a, b = r.hdr().view(np.uint16).astype(np.int32), o.hdr.view(np.uint16).astype(np.int32)
+    assert np.abs(a - b).max() <= 1
+    r.close()
+
+
 def test_fused_gbuffer_and_shading_kernel_matches_the_oracle(monkeypatch):
     """BRMI_FUSE_SHADE=1: brmi_execute shades the plain pixels inside the G-buffer kernel (k_gbuffer_shade) from the words it has just stored;
     layered pixels still go through the per-class lists.  Same G-buffer bytes, HDR within one fp16 ULP of the oracle -- and of the two-kernel frame."""
