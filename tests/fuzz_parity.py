@@ -57,7 +57,34 @@ def main():
         tag = f"#{it} {preset} {W}x{H} mf={mf} " + " ".join(f"{k}={v}" for k, v in kw.items() if k not in ("material_features",)) + (" occ" if occlusion else "") + (f" band={band}" if band != (0, 0) else "")
         try:
             bad = []
-            if occlusion:
+            if occlusion and rng.random() < 0.4:
+                # two frames in flight: linked passes alternate the frames on a geometry and a shading stream with no host synchronisation in
+                # between; the last two frames (one per pass) are then compared with the oracle's sequential frames
+                import torch
+                steps = rng.choice([2, 3, 4, 5])
+                tag += f" in-flight x{steps}"
+                scenes = [Scene(preset, W, H, camera_step=s, **kw) for s in range(steps)]
+                passes = [VisibilityRenderer(scenes[0], occlusion=True, stats=True), VisibilityRenderer(Scene(preset, W, H, camera_step=0, **kw), occlusion=True, stats=True)]
+                passes[0].set_history_source(passes[1]); passes[1].set_history_source(passes[0])
+                geometry, shading = torch.cuda.Stream(priority=-1), torch.cuda.Stream()
+                torch.cuda.synchronize()
+                for s in range(steps):
+                    with torch.cuda.stream(geometry):
+                        passes[s & 1].set_camera_from(scenes[s], frame_index=s)
+                        passes[s & 1].execute(shading)
+                torch.cuda.synchronize()
+                hz, oracles = None, []
+                for s in range(steps):
+                    o = orc.OracleFrame(scenes[s]); hz = o.run_occlusion(hz)
+                    if s >= steps - 2: o.gbuffer(); o.light_cluster(); o.shade()
+                    oracles.append(o)
+                for s in (steps - 2, steps - 1):
+                    c = passes[s & 1].counters()
+                    if (c.visibleClusters, c.visibleClustersPhase2) != (oracles[s].count1, oracles[s].count2): bad.append(f"step{s} counts")
+                    bad += [f"step{s} {b}" for b in compare(passes[s & 1], oracles[s], (0, 0), tag)]
+                for p in passes: p.close()
+                passes = oracles = scenes = None
+            elif occlusion:
                 hz, r = None, None
                 for step in range(rng.choice([2, 3])):
                     sc = Scene(preset, W, H, camera_step=step, **kw)
