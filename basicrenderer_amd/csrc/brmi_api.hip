@@ -593,6 +593,7 @@ int brmi_execute_split(brmi_pass* p, brmi_stream stream, brmi_stream shadeStream
     int rc;
     p->executesSinceTimes++;
     const bool split = shadeStream != stream;
+    p->resolveSetupDone = false;
     // this pass's previous frame may still be resolving / shading on the other stream: its visibility buffer and tables are about to be rewritten
     if (p->frameDoneRecorded) BRMI_HIP(p, hipStreamWaitEvent(static_cast<hipStream_t>(stream), p->frameDone, 0));
     p->frameDoneRecorded = false;
@@ -642,6 +643,8 @@ int brmi_execute_split(brmi_pass* p, brmi_stream stream, brmi_stream shadeStream
     // the Bistro-class 4K frame -- both are bound by VALU issue (the G-buffer kernel at six waves per SIMD as well), so not reading the
     // 48 B per pixel back buys 6 us of the frame.  Kept as a tested variant, not as the default: the two-kernel frame is what the profiles describe.
     if (split) {
+        if ((rc = launch_resolve_setup(p, static_cast<hipStream_t>(stream)))) return rc;
+        p->resolveSetupDone = true;
         if (!p->geometryDone) BRMI_HIP(p, hipEventCreateWithFlags(&p->geometryDone, hipEventDisableTiming));
         if (!p->frameDone) BRMI_HIP(p, hipEventCreateWithFlags(&p->frameDone, hipEventDisableTiming));
         BRMI_HIP(p, hipEventRecord(p->geometryDone, static_cast<hipStream_t>(stream)));

@@ -163,6 +163,7 @@ struct brmi_pass {
     hipEvent_t geometryDone = nullptr, frameDone = nullptr;   // brmi_execute_split: geometry half -> shading half, and the frame's end on the shading stream
     bool frameDoneRecorded = false;
     std::vector<brmi_pass*> historyUsers;   // passes whose `history` is this pass (unlinked when it is destroyed)
+    bool resolveSetupDone = false;   // brmi_execute_split: the per-cluster tables were made on the geometry stream
     bool depthFinal = false;         // brmi_execute: the depth map is final before the G-buffer kernel runs (it skips its depth store)
     const brmi_pass* chainOwner(uint32_t phase) const { return (phase == 1 && history) ? history : this; }
     brmi::HzbDesc hzbDesc() const;
@@ -200,6 +201,7 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s);
 int launch_depth_copy(brmi_pass* p, hipStream_t s);
 int launch_hzb(brmi_pass* p, hipStream_t s, bool fromVisibility, bool onlyIfPhase2Drew);
 int launch_gbuffer(brmi_pass* p, hipStream_t s);
+int launch_resolve_setup(brmi_pass* p, hipStream_t s);
 int launch_light_clustering(brmi_pass* p, hipStream_t s);
 int launch_expand_luts(brmi_pass* p, hipStream_t s);
 int launch_shade(brmi_pass* p, hipStream_t s);

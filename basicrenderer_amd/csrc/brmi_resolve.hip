@@ -586,8 +586,7 @@ __global__ void __launch_bounds__(256, BRMI_FUSED_WAVES) k_gbuffer_shade(GBuffer
     gbuffer_body<false, false, false, false>(a, ShadeEpilogue{sh, k, sliceStart, unormT, camK});
 }
 
-int launch_gbuffer(brmi_pass* p, hipStream_t s) {
-    if (int rc = ensure_frame_constants(p, s)) return rc;
+static GBufferArgs gbuffer_args_of(brmi_pass* p) {
     GBufferArgs a;
     a.sc = p->scene; a.clusters = static_cast<const uint4*>(p->res[BRMI_RES_VISIBLE_CLUSTERS]); a.counters = p->counters();
     a.vis = static_cast<const unsigned long long*>(p->res[BRMI_RES_VISIBILITY]);
@@ -606,11 +605,28 @@ int launch_gbuffer(brmi_pass* p, hipStream_t s) {
     a.uvs = p->sceneHasTextures ? p->wsPtr<float2>(p->ws.resolveUVs) : nullptr; a.uvSets = p->sceneUvSets;
     a.colors = p->sceneHasVertexColors ? p->wsPtr<uint32_t>(p->ws.resolveColors) : nullptr;
     if (p->sceneHasVertexColors) a.clusterUv = p->wsPtr<ClusterUv>(p->ws.clusterUv);
+    return a;
+}
+
+// The per-cluster tables of the pixel pass.  Part of brmi_gbuffer; brmi_execute_split runs it at the end of the geometry half instead (it
+// needs the final cluster list and keys only), so that the shading half starts with the pixel pass.
+int launch_resolve_setup(brmi_pass* p, hipStream_t s) {
+    if (int rc = ensure_frame_constants(p, s)) return rc;
+    const GBufferArgs a = gbuffer_args_of(p);
     // the marking pass only acts on frames with more than half a triangle per pixel; no cut through the scene's DAGs has more triangles than all
     // its meshlets together (totalBits: one survivor bit per meshlet of every instance), so most scenes can never be such a frame
     if ((uint64_t)p->totalBits * BRMI_MESHLET_MAX_TRIS * 2ull > p->bandPixelCount)
         hipLaunchKernelGGL(k_mark_used_clusters, dim3(2048), dim3(256), 0, s, a, p->wsPtr<uint8_t>(p->ws.usedClusters), p->counters());
     hipLaunchKernelGGL(k_resolve_setup, dim3(8192), dim3(64), 0, s, a);
+    BRMI_LAUNCH_CHECK(p, "k_resolve_setup");
+    return BRMI_OK;
+}
+
+int launch_gbuffer(brmi_pass* p, hipStream_t s) {
+    if (int rc = ensure_frame_constants(p, s)) return rc;
+    if (p->resolveSetupDone) p->resolveSetupDone = false;
+    else if (int rc = launch_resolve_setup(p, s)) return rc;
+    GBufferArgs a = gbuffer_args_of(p);
     const bool lean = (uint64_t)p->resolveCapacity >= (uint64_t)p->cfg.maxVisibleClusters * BRMI_MESHLET_MAX_TRIS;
     // `lean`: the arena holds every visible cluster even at 128 vertices / triangles each.  Otherwise whether one spilled is only
     // known on the device: both variants are launched and each leaves at once when the frame is the other one's (a ~5 us empty
