@@ -929,6 +929,42 @@ def test_two_frames_in_flight_render_the_frames_of_one_pass(name, split):
     passes[1].close()
 
 
+def test_split_streams_without_occlusion_culling_match_the_serial_frame():
+    """brmi_execute_split on a pass without a depth chain (no history to link): two passes alternate four frames of a camera path on one
+    geometry / shading stream pair, light clustering included; the drawn pixels are those of brmi_execute."""
+    import torch
+    from conftest import Scene
+    from basicrenderer_amd import capi
+    from basicrenderer_amd.renderer import VisibilityRenderer
+    scenes = [Scene("sponza", 640, 360, point_lights=8, size_scale=0.25, camera_step=s, material_features=27) for s in range(4)]
+    one = VisibilityRenderer(scenes[0])
+    want = []
+    for s in range(4):
+        if s:
+            one.set_camera_from(scenes[s], frame_index=s)
+        one.execute()
+        want.append({k: one.res[capi.RES[k]].clone() for k in ("VISIBILITY", "HDR_COLOR", "GBUF_ALBEDO")})
+    one.close()
+    pair = [VisibilityRenderer(Scene("sponza", 640, 360, point_lights=8, size_scale=0.25, material_features=27)) for _ in range(2)]
+    geometry, shading = torch.cuda.Stream(priority=-1), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    got = []
+    for s in range(4):
+        with torch.cuda.stream(geometry):
+            pair[s & 1].set_camera_from(scenes[s], frame_index=s)
+            pair[s & 1].execute(shading)
+        with torch.cuda.stream(shading):
+            got.append({k: pair[s & 1].res[capi.RES[k]].clone() for k in want[s]})
+    torch.cuda.synchronize()
+    for s in range(4):
+        drawn = want[s]["VISIBILITY"].view(torch.int64) != -1
+        assert drawn.any() and torch.equal(got[s]["VISIBILITY"], want[s]["VISIBILITY"]), f"frame {s}"
+        for k, bpp in (("HDR_COLOR", 8), ("GBUF_ALBEDO", 4)):
+            assert torch.equal(got[s][k].view(-1, bpp)[: drawn.numel()][drawn], want[s][k].view(-1, bpp)[: drawn.numel()][drawn]), f"frame {s}: {k}"
+    for r in pair:
+        r.close()
+
+
 def test_history_source_is_validated():
     from conftest import Scene
     from basicrenderer_amd.renderer import VisibilityRenderer, BrmiError
