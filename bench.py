@@ -58,10 +58,12 @@ def main():
     ap.add_argument("--composer", default="native", choices=["native", "torch"],
                     help="who runs the all-gather: libbrmi_compose.so (RCCL called from C++ behind include/brmi_compose.h; default) or torch.distributed")
     ap.add_argument("--force-compose", action="store_true", help="run the RCCL band composition even with one rank (checks the collective path on a single GPU)")
-    ap.add_argument("--frames-in-flight", type=int, default=2, choices=[1, 2],
-                    help="2 (default): two passes with their own resources render alternate frames on two streams (brmi_set_history_source; the "
-                         "reference's numFramesInFlight) -- frame k+1's culling and rasterisation, which are latency-bound and leave most of the chip idle, "
-                         "overlap frame k's G-buffer and shading.  1: one pass, one stream, frames back to back.  Every frame does all of its work either way; "
+    ap.add_argument("--frames-in-flight", type=int, default=2, choices=[1, 2, 3],
+                    help="2 (default) or 3 (the reference's numFramesInFlight default, Renderer.h:110): that many passes with their own resources render the frames "
+                         "in turn on a geometry stream and a shading stream (brmi_set_history_source + brmi_execute_split) -- frame k+1's culling and rasterisation, "
+                         "which are latency-bound and leave most of the chip idle, overlap frame k's G-buffer and shading; a third pass gains 3 %% on the Bistro-class "
+                         "frame and loses 7 %% on the Sponza-class one.  1: one pass, one stream, frames back to back.  "
+                         "Every frame does all of its work either way; "
                          "the roofline block is measured on serial frames (a kernel's duration while it shares the CUs with another frame is not its own)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scale", type=float, default=1.0, help="fraction of the frame height the CPU baseline renders")
@@ -125,20 +127,22 @@ def measure(args, workload, n, rank, local_rank, cpu):
     r = VisibilityRenderer(scene, device=dev, stats=True, band=band, occlusion=bool(args.occlusion))
     fif = args.frames_in_flight
     passes, streams, shade_streams = [r], [torch.cuda.current_stream(dev)], [None, None]
-    if fif == 2:
+    if fif >= 2:
         # the second pass has its own resources and scene upload (its camera buffers are its own); phase 1 of each tests against the chain
         # the other built for the frame before
-        passes.append(VisibilityRenderer(scene, device=dev, stats=False, band=band, occlusion=bool(args.occlusion)))
+        for _ in range(fif - 1):
+            passes.append(VisibilityRenderer(scene, device=dev, stats=False, band=band, occlusion=bool(args.occlusion)))
         if args.occlusion:
-            passes[0].set_history_source(passes[1]); passes[1].set_history_source(passes[0])
+            for k in range(fif):
+                passes[k].set_history_source(passes[(k - 1) % fif])        # the pass that renders the frame before
         mode = os.environ.get("BRMI_BENCH_STREAMS", "split")
         if mode == "split":
             # both passes use the same pair: a geometry stream (higher priority: its launches are latency-bound and want CU slots the moment
             # they are ready) and a shading stream
             geometry, shading = torch.cuda.Stream(dev, priority=-1), torch.cuda.Stream(dev, priority=0)
-            streams, shade_streams = [geometry, geometry], [shading, shading]
+            streams, shade_streams = [geometry] * fif, [shading] * fif
         else:
-            streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]        # one stream per pass, whole frames
+            streams, shade_streams = [torch.cuda.Stream(dev) for _ in range(fif)], [None] * fif        # one stream per pass, whole frames
 
     hdr = r.hdr_tensor()
     # all-gather of frame k overlaps the rendering of frame k + 1; the colour channels travel (RGB16F, 6 B/px): the lit target's alpha is constant
@@ -219,7 +223,7 @@ def measure(args, workload, n, rank, local_rank, cpu):
 
     stage_ms = r.stage_times()          # mean over the last timed steps (HIP events on the execute stream); dominant stage only
     in_flight_ms = None
-    if fif == 2:
+    if fif >= 2:
         # the dominant kernel shared the CUs with the other pass's frame during the timed region: its own duration comes from serial frames
         in_flight_ms = stage_ms[dom_stage]
         serial_ms = serial_frames(min(args.steps, 200))
@@ -282,7 +286,7 @@ def measure(args, workload, n, rank, local_rank, cpu):
                               f"serial frames of one pass (nothing else on the GPU): '{dom}' over {min(args.steps, 200)} frames after the timed region, the other stages over 10 frames "
                               f"before it; inside the timed region, sharing the CUs with the other pass's frame, '{dom}' took {in_flight_ms:.4f} ms per launch"),
         }
-        if fif == 2:
+        if fif >= 2:
             out["roofline"]["launch_ms_in_flight"] = round(in_flight_ms, 4)
             out["serial_frame_ms"] = round(serial_ms, 4)      # one pass, one stream, frames back to back (what --frames-in-flight 1 times)
         if cpu:

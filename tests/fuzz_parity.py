@@ -62,16 +62,17 @@ def main():
                 # between; the last two frames (one per pass) are then compared with the oracle's sequential frames
                 import torch
                 steps = rng.choice([2, 3, 4, 5])
-                tag += f" in-flight x{steps}"
+                ring = rng.choice([2, 3])
+                tag += f" in-flight x{steps} ring {ring}"
                 scenes = [Scene(preset, W, H, camera_step=s, **kw) for s in range(steps)]
-                passes = [VisibilityRenderer(scenes[0], occlusion=True, stats=True), VisibilityRenderer(Scene(preset, W, H, camera_step=0, **kw), occlusion=True, stats=True)]
-                passes[0].set_history_source(passes[1]); passes[1].set_history_source(passes[0])
+                passes = [VisibilityRenderer(Scene(preset, W, H, camera_step=0, **kw), occlusion=True, stats=True) for _ in range(ring)]
+                for k in range(ring): passes[k].set_history_source(passes[(k - 1) % ring])
                 geometry, shading = torch.cuda.Stream(priority=-1), torch.cuda.Stream()
                 torch.cuda.synchronize()
                 for s in range(steps):
                     with torch.cuda.stream(geometry):
-                        passes[s & 1].set_camera_from(scenes[s], frame_index=s)
-                        passes[s & 1].execute(shading)
+                        passes[s % ring].set_camera_from(scenes[s], frame_index=s)
+                        passes[s % ring].execute(shading)
                 torch.cuda.synchronize()
                 hz, oracles = None, []
                 for s in range(steps):
@@ -79,9 +80,9 @@ def main():
                     if s >= steps - 2: o.gbuffer(); o.light_cluster(); o.shade()
                     oracles.append(o)
                 for s in (steps - 2, steps - 1):
-                    c = passes[s & 1].counters()
+                    c = passes[s % ring].counters()
                     if (c.visibleClusters, c.visibleClustersPhase2) != (oracles[s].count1, oracles[s].count2): bad.append(f"step{s} counts")
-                    bad += [f"step{s} {b}" for b in compare(passes[s & 1], oracles[s], (0, 0), tag)]
+                    bad += [f"step{s} {b}" for b in compare(passes[s % ring], oracles[s], (0, 0), tag)]
                 for p in passes: p.close()
                 passes = oracles = scenes = None
             elif occlusion:

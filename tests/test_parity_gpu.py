@@ -872,18 +872,19 @@ def test_occlusion_does_not_change_the_image(name, occlusion_runs):
             assert np.array_equal(a, b), f"frame {i}"
 
 
-@pytest.mark.parametrize("name,split", [("bistro", False), ("tiny_odd", False), ("bistro", True), ("sponza", True)])
-def test_two_frames_in_flight_render_the_frames_of_one_pass(name, split):
+@pytest.mark.parametrize("name,split,n", [("bistro", False, 2), ("tiny_odd", False, 2), ("bistro", True, 2), ("sponza", True, 2), ("bistro", True, 3), ("sponza", False, 3)])
+def test_two_frames_in_flight_render_the_frames_of_one_pass(name, split, n):
     """brmi_set_history_source: two passes alternate the frames of a camera path on two streams, each testing phase 1 against the chain
     the other built for the frame before.  No host synchronisation between the frames -- the passes' own events order the streams --
     and every frame's keys, depth, chain, cluster list and HDR bytes are those of one pass rendering the path in order.
-    split: brmi_execute_split, both passes on one geometry stream (high priority) and one shading stream."""
+    split: brmi_execute_split, all passes on one geometry stream (high priority) and one shading stream.  n = 3: a ring of three passes
+    (the reference's default numFramesInFlight, Renderer.h:110), each reading the chain of the pass that rendered the frame before."""
     import torch
     from conftest import Scene
     from basicrenderer_amd import capi
     from basicrenderer_amd.renderer import VisibilityRenderer
     preset, W, H, kw = OCCLUSION_CASES[name]
-    steps = 6
+    steps = 7
     scenes = [Scene(preset, W, H, camera_step=s, **kw) for s in range(steps)]
     keep = ("VISIBILITY", "LINEAR_DEPTH", "HZB", "HDR_COLOR", "VISIBLE_CLUSTERS", "GBUF_NORMALS")
     serial = []
@@ -896,17 +897,18 @@ def test_two_frames_in_flight_render_the_frames_of_one_pass(name, split):
         serial.append(({k: one.res[capi.RES[k]].clone() for k in keep}, (c.visibleClusters, c.visibleClustersPhase2, c.replayNodes, c.replayMeshlets)))
     one.close()
     assert sum(c[2] + c[3] for _, c in serial) > 0 or name == "tiny_odd", "the path does not exercise the replay buffers"
-    passes = [VisibilityRenderer(Scene(preset, W, H, camera_step=0, **kw), occlusion=True) for _ in range(2)]
-    passes[0].set_history_source(passes[1]); passes[1].set_history_source(passes[0])
-    streams = [torch.cuda.Stream(priority=-1), torch.cuda.Stream()]
+    passes = [VisibilityRenderer(Scene(preset, W, H, camera_step=0, **kw), occlusion=True) for _ in range(n)]
+    for k in range(n):
+        passes[k].set_history_source(passes[(k - 1) % n])
+    streams = [torch.cuda.Stream(priority=-1), torch.cuda.Stream(), torch.cuda.Stream()]
     torch.cuda.synchronize()
     got = []
     for s in range(steps):
-        r = passes[s & 1]
-        with torch.cuda.stream(streams[0] if split else streams[s & 1]):
+        r = passes[s % n]
+        with torch.cuda.stream(streams[0] if split else streams[s % n]):
             r.set_camera_from(scenes[s], frame_index=s)
             r.execute(streams[1] if split else None)
-        with torch.cuda.stream(streams[1] if split else streams[s & 1]):
+        with torch.cuda.stream(streams[1] if split else streams[s % n]):
             got.append({k: r.res[capi.RES[k]].clone() for k in keep})      # the stream the frame ends on: ordered after it, no host wait
     torch.cuda.synchronize()
     drawn_frames = 0
@@ -926,7 +928,8 @@ def test_two_frames_in_flight_render_the_frames_of_one_pass(name, split):
     # a pass that loses its source falls back to its own (two frames old) chain; destroying in either order is safe
     passes[0].close()
     passes[1].execute()
-    passes[1].close()
+    for r in passes[1:]:
+        r.close()
 
 
 def test_split_streams_without_occlusion_culling_match_the_serial_frame():
