@@ -277,14 +277,17 @@ constexpr int RESOLVE_WATERFALL = 4;     // distinct mesh instances per 8x8 tile
 #define BRMI_GB_WAVES 6
 #endif
 // MULTI_UV: some texture slot of the scene names a UV set > 0 (brmi_set_scene); the common single-set scenes run the variant without the set switching
+// Waves per SIMD of the textured variants, re-measured on the build without packed pairs (Sponza 4K, G-buffer stage): single-set textured
+// 3 / 4 waves 572 / 555 us; parallax 2 / 3 / 4 waves 1009 / 1055 / 1047 us; the MULTI_UV variants need their registers (three sets: 720 us at
+// 3 waves against 752 at 4; with parallax 1387 at 3 against 1639 at 2)
 #ifndef BRMI_GBT_WAVES
-#define BRMI_GBT_WAVES 3
+#define BRMI_GBT_WAVES 4
 #endif
-// the parallax variant: three waves per SIMD with 47 registers of the ray march's state in scratch (160 B per lane) is faster than two
-// waves without scratch (1.39 against 1.47 ms, Sponza 4K with parallax on half of the textured materials): the march is bound by its
-// instruction stream and needs the third wave more than it minds the scratch traffic
 #ifndef BRMI_GBP_WAVES
-#define BRMI_GBP_WAVES 3
+#define BRMI_GBP_WAVES 2
+#endif
+#ifndef BRMI_GBM_WAVES
+#define BRMI_GBM_WAVES 3
 #endif
 // Epi: what happens to a pixel's G-buffer words besides being stored.  `pixel()` is called once per lane and tile, in converged control flow,
 // after the tile's waterfall: nothing for the plain kernels, the whole deferred shading of the pixel for the fused one (k_gbuffer_shade).
@@ -567,7 +570,7 @@ BRMI_DEV void gbuffer_body(const GBufferArgs& a, const Epi& epi) {
     }
 }
 template <bool INLINE_TABLES, bool TEXTURED, bool PARALLAX = false, bool MULTI_UV = false>
-__global__ void __launch_bounds__(256, INLINE_TABLES ? 1 : (PARALLAX ? BRMI_GBP_WAVES : (TEXTURED ? BRMI_GBT_WAVES : BRMI_GB_WAVES))) k_gbuffer(GBufferArgs a) {
+__global__ void __launch_bounds__(256, INLINE_TABLES ? 1 : (MULTI_UV ? BRMI_GBM_WAVES : (PARALLAX ? BRMI_GBP_WAVES : (TEXTURED ? BRMI_GBT_WAVES : BRMI_GB_WAVES)))) k_gbuffer(GBufferArgs a) {
     gbuffer_body<INLINE_TABLES, TEXTURED, PARALLAX, MULTI_UV>(a, NoEpilogue{});
 }
 
