@@ -137,10 +137,10 @@ def measure(args, workload, n, rank, local_rank, cpu):
                 passes[k].set_history_source(passes[(k - 1) % fif])        # the pass that renders the frame before
         mode = os.environ.get("BRMI_BENCH_STREAMS", "split")
         if mode == "split":
-            # both passes use the same pair: a geometry stream (higher priority: its launches are latency-bound and want CU slots the moment
-            # they are ready) and a shading stream
+            # the passes share a geometry stream (higher priority: its launches are latency-bound and want CU slots the moment they are ready)
             geometry, shading = torch.cuda.Stream(dev, priority=-1), torch.cuda.Stream(dev, priority=0)
-            streams, shade_streams = [geometry] * fif, [shading] * fif
+            # a shading stream per pass: a frame's pixel pass may start on the tail of the frame before's k_shade (-1 % against one shared stream)
+            streams, shade_streams = [geometry] * fif, [shading] + [torch.cuda.Stream(dev, priority=0) for _ in range(fif - 1)]
         else:
             streams, shade_streams = [torch.cuda.Stream(dev) for _ in range(fif)], [None] * fif        # one stream per pass, whole frames
 
