@@ -175,8 +175,9 @@ int         brmi_execute(brmi_pass* pass, brmi_stream stream);                  
 /* The same frame on two streams (the reference schedules its passes on a graphics and an async-compute queue): culling, rasterisation
  * and the depth chain on `geometryStream`, G-buffer, light lists (when the culling launches did not carry them) and shading on
  * `shadingStream`; events order the two halves and the pass's next frame.  Outputs are ready when `shadingStream` is.  With
- * brmi_set_history_source and two passes alternating frames on the SAME pair of streams, frame k+1's geometry half -- latency-bound
- * launches that leave most of the chip idle -- runs beside frame k's shading half; give `geometryStream` the higher priority. */
+ * brmi_set_history_source and two passes alternating frames on the same geometry stream (the shading stream may be shared or one per
+ * pass), frame k+1's geometry half -- latency-bound launches that leave most of the chip idle -- runs beside frame k's shading half;
+ * give `geometryStream` the higher priority. */
 int         brmi_execute_split(brmi_pass* pass, brmi_stream geometryStream, brmi_stream shadingStream);
 void        brmi_destroy(brmi_pass* pass);                                               /* Cleanup */
 const char* brmi_last_error(const brmi_pass* pass);
