@@ -126,6 +126,7 @@ static void compute_sizes(brmi_pass* p) {
     w.resolveTris = take((uint64_t)p->resolveCapacity * sizeof(ResolveTriangle));
     w.shadeTables = take(((uint64_t)2 * c.width + 2 * c.height + 64) * 4);
     w.matWords = take((uint64_t)std::max(1u, p->scene.materialCount) * sizeof(MaterialWords));
+    w.layerUniform = take(sizeof(LayerUniform));
     w.frameConst = take(3 * 64);
     w.matConst = take((uint64_t)std::max(1u, p->scene.openpbrMaterialCount) * sizeof(MatConst));
     w.objConst = take((uint64_t)std::max(1u, p->scene.perObjectCount) * 36 * 4);
@@ -191,6 +192,7 @@ void brmi_default_config(brmi_config* cfg, uint32_t width, uint32_t height) {
     cfg->phase2ExpansionFactor = 2;
     cfg->collectPassStatistics = 0;
     cfg->maxBvhLevels = 64;
+    cfg->keepUniformLayerPlanes = 1;
 }
 
 int brmi_create(const brmi_config* cfg, brmi_pass** out) {
@@ -439,6 +441,7 @@ int brmi_setup(brmi_pass* p, const brmi_resource_binding* b, uint32_t n, brmi_st
         p->eventsCreated = true;
     }
     p->setupDone = true;
+    p->layerPlanesDirty = true;      // new (or re-bound) G-buffer planes: the uniform coat / fuzz words have to be filled in again
     p->constantsSerial = 0;      // the workspace was cleared: the frame constants have to be evaluated again
     return BRMI_OK;
 }

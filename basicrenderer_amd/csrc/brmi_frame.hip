@@ -74,6 +74,44 @@ BRMI_DEV void job_material_words(const brmi_scene_buffers& sc, MaterialWords* ou
     out[i] = w;
 }
 
+// Do all materials of the scene store the same coat / fuzz word?  (One wave; the words are those of job_material_words, and a record that
+// binds coat / fuzz textures makes its plane per-pixel.)  The G-buffer kernels skip a plane's stores while it holds that word everywhere.
+BRMI_DEV void job_layer_uniform(const brmi_scene_buffers& sc, LayerUniform* out, uint32_t lane) {
+    unsigned long long coat0 = 0ull, fuzz0 = 0ull;
+    bool coatSame = true, fuzzSame = true;
+    auto words = [&](uint32_t i, unsigned long long& c, unsigned long long& f, bool& tex) {
+        const brmi_openpbr_material_info* op = sc.openpbrMaterials + sc.materials[i].openPBRMaterialDataIndex;
+        const f3 coatColor = sat3(f3{op->coatColor[0], op->coatColor[1], op->coatColor[2]});
+        const f3 fuzzColor = sat3(f3{op->fuzzColor[0], op->fuzzColor[1], op->fuzzColor[2]});
+        c = pack_half4(coatColor.x, coatColor.y, coatColor.z, sat(op->coatWeight));
+        f = pack_half4(fuzzColor.x, fuzzColor.y, fuzzColor.z, sat(op->fuzzRoughness));
+        tex = openpbr_has_textures(op);
+    };
+    bool tex0 = false;
+    if (sc.materialCount != 0u) words(0u, coat0, fuzz0, tex0);
+    coatSame = fuzzSame = sc.materialCount != 0u && !tex0;
+    for (uint32_t i = lane; i < sc.materialCount; i += 64u) {
+        unsigned long long c, f; bool tex;
+        words(i, c, f, tex);
+        coatSame = coatSame && !tex && c == coat0;
+        fuzzSame = fuzzSame && !tex && f == fuzz0;
+    }
+    coatSame = __all(coatSame); fuzzSame = __all(fuzzSame);
+    if (lane == 0u) { out->coatWord = coat0; out->fuzzWord = fuzz0; out->coatUniform = coatSame ? 1u : 0u; out->fuzzUniform = fuzzSame ? 1u : 0u; }
+}
+
+// After brmi_setup (new plane memory): a uniform plane is filled with its word once; `filled` is what lets the G-buffer kernels skip it.
+__global__ void __launch_bounds__(256) k_fill_layer_planes(LayerUniform* L, unsigned long long* coat, unsigned long long* fuzz, uint64_t n) {
+    const bool doCoat = L->coatUniform != 0u, doFuzz = L->fuzzUniform != 0u;
+    const unsigned long long cw = L->coatWord, fw = L->fuzzWord;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        if (doCoat) coat[i] = cw;
+        if (doFuzz) fuzz[i] = fw;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) { L->coatFilled = doCoat ? 1u : 0u; L->fuzzFilled = doFuzz ? 1u : 0u; L->coatFilledWord = cw; L->fuzzFilledWord = fw; }
+}
+
 // view-space bounding spheres of the active lights, once per frame (testSphereAABB's transform, lightCulling.hlsl:15-21)
 // ... and the shading pass's record of the light (brmi_light.hip, ShadeLightLanes): what getLightParametersForFragment reads, 64 B, indexed
 // (four float4) by the position in the active-light list.  normalize(dirWorldSpace) of a spot light is per light, not per pixel (lighting.hlsli:640).
@@ -166,7 +204,7 @@ BRMI_DEV void job_shade_tables(const brmi_scene_buffers& sc, ShadeTables t, uint
 struct FrameJobs {
     brmi_scene_buffers sc;
     m4* frameConst; float* objConst; MaterialWords* matWords; MatConst* matConst; ShadeTables tables; float4* lightVS; uint32_t* lightMeta; float4* shadeLights;
-    AlphaMaterial* alphaMats;
+    AlphaMaterial* alphaMats; LayerUniform* layer;
     const float* lutF; ShadeRows* shadeRows; ShadeAverages* shadeAvgs; GgxQuad* ggxQuads;
     uint32_t W, H;
     float sliceStart[64];        // first view depth of every light-cluster slice (brmi_update), [0] = 0, [gz + 1] = +inf
@@ -182,7 +220,8 @@ __global__ void __launch_bounds__(64) k_frame_constants(FrameJobs j) {
     else if (b < j.firstBlock[4]) job_shade_tables(j.sc, j.tables, j.W, j.H, j.sliceStart, (b - j.firstBlock[3]) * 64u + threadIdx.x);
     else if (b < j.firstBlock[5]) job_light_spheres(j.sc, j.lightVS, j.lightMeta, j.shadeLights, (b - j.firstBlock[4]) * 64u + threadIdx.x);
     else if (b < j.firstBlock[6]) job_shade_material_table(j.sc, j.lutF, j.shadeRows, j.shadeAvgs, j.ggxQuads, (b - j.firstBlock[5]) * 64u + threadIdx.x);
-    else for (uint64_t i = (uint64_t)(b - j.firstBlock[6]) * 64u + threadIdx.x; i < j.frameState16; i += (uint64_t)(j.firstBlock[7] - j.firstBlock[6]) * 64u) j.frameState[i] = make_uint4(0u, 0u, 0u, 0u);
+    else if (b < j.firstBlock[7]) { for (uint64_t i = (uint64_t)(b - j.firstBlock[6]) * 64u + threadIdx.x; i < j.frameState16; i += (uint64_t)(j.firstBlock[7] - j.firstBlock[6]) * 64u) j.frameState[i] = make_uint4(0u, 0u, 0u, 0u); }
+    else job_layer_uniform(j.sc, j.layer, threadIdx.x);
 }
 
 ShadeTables shade_tables_of(const brmi_pass* p) {
@@ -200,6 +239,7 @@ int ensure_frame_constants(brmi_pass* p, hipStream_t s) {
     j.matWords = p->wsPtr<MaterialWords>(p->ws.matWords); j.matConst = p->wsPtr<MatConst>(p->ws.matConst); j.tables = shade_tables_of(p);
     j.lightVS = p->wsPtr<float4>(p->ws.lightVS); j.lightMeta = p->wsPtr<uint32_t>(p->ws.lightMeta); j.shadeLights = p->wsPtr<float4>(p->ws.shadeLights);
     j.alphaMats = p->sceneHasAlphaTest ? p->wsPtr<AlphaMaterial>(p->ws.alphaMats) : nullptr;
+    j.layer = p->wsPtr<LayerUniform>(p->ws.layerUniform);
     j.W = p->cfg.width; j.H = p->cfg.height;
     for (uint32_t k = 0; k < 64; k++) j.sliceStart[k] = k < p->sliceStartHost.size() ? p->sliceStartHost[k] : 0.0f;
     auto blocks = [](uint32_t n) { return (std::max(1u, n) + 63u) / 64u; };
@@ -214,8 +254,22 @@ int ensure_frame_constants(brmi_pass* p, hipStream_t s) {
     // brmi_execute without a clear launch of its own (the visibility clear rides on the traversal kernel): the frame state is zeroed here
     j.frameState = p->wsPtr<uint4>(p->ws.counters); j.frameState16 = p->clearFrameStateWithConstants ? p->ws.frameClearBytes / 16 : 0ull;
     j.firstBlock[7] = j.firstBlock[6] + (uint32_t)std::min<uint64_t>((j.frameState16 + 511u) / 512u, 4096u);
-    hipLaunchKernelGGL(k_frame_constants, dim3(j.firstBlock[7]), dim3(64), 0, s, j);
+    hipLaunchKernelGGL(k_frame_constants, dim3(j.firstBlock[7] + 1u), dim3(64), 0, s, j);       // + the layer-uniformity job's block
     BRMI_LAUNCH_CHECK(p, "k_frame_constants");
+    if (p->layerPlanesDirty) {
+        // first constants after brmi_setup: planes whose word is the same for every material are filled once (the G-buffer kernels then skip them)
+        if (p->cfg.keepUniformLayerPlanes) {
+            hipLaunchKernelGGL(k_fill_layer_planes, dim3(2048), dim3(256), 0, s, j.layer, static_cast<unsigned long long*>(p->res[BRMI_RES_GBUF_COAT]), static_cast<unsigned long long*>(p->res[BRMI_RES_GBUF_FUZZ]),
+                               std::min(p->resBytes[BRMI_RES_GBUF_COAT], p->resBytes[BRMI_RES_GBUF_FUZZ]) / 8u);
+            BRMI_LAUNCH_CHECK(p, "k_fill_layer_planes");
+            // once per brmi_setup: the host picks the G-buffer kernel's instantiation from the answer
+            LayerUniform lu;
+            BRMI_HIP(p, hipMemcpyAsync(&lu, j.layer, sizeof(lu), hipMemcpyDeviceToHost, s));
+            BRMI_HIP(p, hipStreamSynchronize(s));
+            p->layerPlanesUniform = lu.coatUniform != 0u && lu.fuzzUniform != 0u && lu.coatFilled != 0u && lu.fuzzFilled != 0u;
+        } else p->layerPlanesUniform = false;
+        p->layerPlanesDirty = false;
+    }
     if (p->clearFrameStateWithConstants) p->frameStateCleared = true;
     p->constantsSerial = p->updateSerial;
     return BRMI_OK;

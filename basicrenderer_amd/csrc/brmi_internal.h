@@ -108,10 +108,14 @@ struct HzbDesc {
     uint32_t mipOffset[kMaxHzbMips];
 };
 
+// Scenes whose materials all pack to the same coat (fuzz) G-buffer word: the word and whether the plane currently holds it everywhere
+// (brmi_frame.hip: job_layer_uniform, k_fill_layer_planes; brmi_resolve.hip skips the plane's stores)
+struct LayerUniform { unsigned long long coatWord, fuzzWord, coatFilledWord, fuzzFilledWord; uint32_t coatUniform, fuzzUniform, coatFilled, fuzzFilled; };
+
 struct Workspace {     // byte offsets into BRMI_RES_WORKSPACE
     uint64_t counters, frontierA, frontierB, buckets, tempVisible, bitmask1, bitmask2, wordPrefix, blockSums,
              instanceBitBase, segPrefix, meshLevelWidth, planes, replayNodes, replayBuckets, lightVS, lightMeta, clusterPages, clusterHits, pageTotal, lightHitMasks, binCounts, binRecords, binOverflow, clusterSetup, resolveVerts, resolveTris, matWords, shadeTables, lutF, frameConst, objConst, matConst, deferredPixels, usedClusters,
-             clusterUv, binAlpha, overflowAlpha, resolveUVs, resolveColors, alphaMats, shadeRows, shadeAvgs, ggxQuads, shadeLights, clusterList, listEntries, frameClearBytes, total;
+             clusterUv, binAlpha, overflowAlpha, resolveUVs, resolveColors, alphaMats, shadeRows, shadeAvgs, ggxQuads, shadeLights, clusterList, listEntries, layerUniform, frameClearBytes, total;
 };
 
 }  // namespace brmi
@@ -163,6 +167,8 @@ struct brmi_pass {
     hipEvent_t geometryDone = nullptr, frameDone = nullptr;   // brmi_execute_split: geometry half -> shading half, and the frame's end on the shading stream
     bool frameDoneRecorded = false;
     std::vector<brmi_pass*> historyUsers;   // passes whose `history` is this pass (unlinked when it is destroyed)
+    bool layerPlanesDirty = false;   // brmi_setup: the next constants launch is followed by k_fill_layer_planes
+    bool layerPlanesUniform = false; // ... which found one coat and one fuzz word for the whole scene and filled both planes (read back once)
     bool resolveSetupDone = false;   // brmi_execute_split: the per-cluster tables were made on the geometry stream
     bool depthFinal = false;         // brmi_execute: the depth map is final before the G-buffer kernel runs (it skips its depth store)
     const brmi_pass* chainOwner(uint32_t phase) const { return (phase == 1 && history) ? history : this; }

@@ -314,7 +314,7 @@ struct ShadeEpilogue {
         shade_defer(sh, (uint32_t)(tileBase >> 6) - (uint32_t)(sh.firstPixel >> 6), cls, lane);
     }
 };
-template <bool INLINE_TABLES, bool TEXTURED, bool PARALLAX, bool MULTI_UV, class Epi>
+template <bool INLINE_TABLES, bool TEXTURED, bool PARALLAX, bool MULTI_UV, bool SLIM, class Epi>
 BRMI_DEV void gbuffer_body(const GBufferArgs& a, const Epi& epi) {
     const brmi_scene_buffers& sc = a.sc;
     if (a.variantSelect != 0u && (a.counters[CNT_RESOLVE_SPILL] != 0u) != (a.variantSelect == 2u)) return;     // the other variant's frame
@@ -323,6 +323,10 @@ BRMI_DEV void gbuffer_body(const GBufferArgs& a, const Epi& epi) {
     TexelTables tb; tb.t = texelTables;
     const brmi_per_frame* pf = sc.perFrame;
     const uint32_t clusterCount = min(a.counters[CNT_VISIBLE] + a.counters[CNT_VISIBLE2], a.clusterCapacity);
+    // SLIM (chosen by the host, brmi_execute only): the depth map is final already, and the coat and fuzz planes hold the one word every
+    // material of the scene stores (filled once after brmi_setup) -- 20 of 56 B per pixel are not stored.  Compile-time: the same skips as
+    // run-time branches made the kernel slower than storing everything (107 against 103 us; without the stores: 93)
+    constexpr bool skipCoat = SLIM, skipFuzz = SLIM;
     // view-projection products are frame constants; every lane derives them the way the shader does
     const m4 unjVP = uni_m4(a.frameConst[1]), prevVP = uni_m4(a.frameConst[2]);
     const float winX = uni((float)pf->screenResX), winY = uni((float)pf->screenResY);
@@ -347,7 +351,7 @@ BRMI_DEV void gbuffer_body(const GBufferArgs& a, const Epi& epi) {
         const unsigned long long key = nkey;
         float4 outN = make_float4(0.0f, 0.0f, 0.0f, 0.0f); uint32_t outAl = 0u, outMr = 0u; unsigned long long outCoat = 0ull, outEmis = 0ull;      // the pixel's words, for the epilogue
         if (j + stride < end) { nvalid = pixel_of(j + stride, npx, npy); nkey = nvalid ? __builtin_nontemporal_load(&a.vis[a.firstPixel + j + stride]) : BRMI_VIS_EMPTY; }
-        if (valid && a.depth) __builtin_nontemporal_store((key == BRMI_VIS_EMPTY) ? as_f32(BRMI_DEPTH_EMPTY_BITS) : as_f32(((uint32_t)(key >> BRMI_VIS_META_BITS)) << 1), &a.depth[i]);
+        if (!SLIM && valid && a.depth) __builtin_nontemporal_store((key == BRMI_VIS_EMPTY) ? as_f32(BRMI_DEPTH_EMPTY_BITS) : as_f32(((uint32_t)(key >> BRMI_VIS_META_BITS)) << 1), &a.depth[i]);
         const uint32_t triId = (uint32_t)(key & 0x7Full);
         const uint32_t clusterIndex = (uint32_t)((key >> BRMI_VIS_TRI_BITS) & 0x3FFFFFFull);
         valid = valid && key != BRMI_VIS_EMPTY && clusterIndex < clusterCount;
@@ -542,9 +546,9 @@ BRMI_DEV void gbuffer_body(const GBufferArgs& a, const Epi& epi) {
             // and 0.339 -> 0.324 ms for k_shade)
             { float4 nv = make_float4(normalWS.x, normalWS.y, normalWS.z, mw->opIndexF); __builtin_nontemporal_store(nv.x, &a.normals[i].x); __builtin_nontemporal_store(nv.y, &a.normals[i].y); __builtin_nontemporal_store(nv.z, &a.normals[i].z); __builtin_nontemporal_store(nv.w, &a.normals[i].w); }
             __builtin_nontemporal_store(albedoW, &a.albedo[i]);
-            __builtin_nontemporal_store(coatW, &a.coat[i]);
+            if (!skipCoat) __builtin_nontemporal_store(coatW, &a.coat[i]);
             __builtin_nontemporal_store(emissiveW, &a.emissive[i]);
-            __builtin_nontemporal_store(fuzzW, &a.fuzz[i]);
+            if (!skipFuzz) __builtin_nontemporal_store(fuzzW, &a.fuzz[i]);
             __builtin_nontemporal_store(mrW, &a.metallicRoughness[i]);
             __builtin_nontemporal_store((uint32_t)(f32_to_f16_bits(mvx) | (f32_to_f16_bits(mvy) << 16)), &a.motion[i]);
             if (Epi::kWanted) { outN = make_float4(normalWS.x, normalWS.y, normalWS.z, mw->opIndexF); outAl = albedoW; outMr = mrW; outCoat = coatW; outEmis = emissiveW; }
@@ -569,9 +573,9 @@ BRMI_DEV void gbuffer_body(const GBufferArgs& a, const Epi& epi) {
         if (Epi::kWanted) epi.pixel(inBand, key, valid, px, py, i, outN, outAl, outMr, outCoat, outEmis);
     }
 }
-template <bool INLINE_TABLES, bool TEXTURED, bool PARALLAX = false, bool MULTI_UV = false>
+template <bool INLINE_TABLES, bool TEXTURED, bool PARALLAX = false, bool MULTI_UV = false, bool SLIM = false>
 __global__ void __launch_bounds__(256, INLINE_TABLES ? 1 : (MULTI_UV ? BRMI_GBM_WAVES : (PARALLAX ? BRMI_GBP_WAVES : (TEXTURED ? BRMI_GBT_WAVES : BRMI_GB_WAVES)))) k_gbuffer(GBufferArgs a) {
-    gbuffer_body<INLINE_TABLES, TEXTURED, PARALLAX, MULTI_UV>(a, NoEpilogue{});
+    gbuffer_body<INLINE_TABLES, TEXTURED, PARALLAX, MULTI_UV, SLIM>(a, NoEpilogue{});
 }
 
 // G-buffer + deferred shading of the plain pixels in one pass over the frame (brmi_execute, scenes of constant-factor materials whose visible
@@ -586,7 +590,7 @@ __global__ void __launch_bounds__(256, BRMI_FUSED_WAVES) k_gbuffer_shade(GBuffer
     __shared__ float unormT[256];
     __shared__ float4 camK[9];
     shade_stage_lds(sh, k, sliceStart, unormT, camK);
-    gbuffer_body<false, false, false, false>(a, ShadeEpilogue{sh, k, sliceStart, unormT, camK});
+    gbuffer_body<false, false, false, false, false>(a, ShadeEpilogue{sh, k, sliceStart, unormT, camK});
 }
 
 static GBufferArgs gbuffer_args_of(brmi_pass* p) {
@@ -630,6 +634,9 @@ int launch_gbuffer(brmi_pass* p, hipStream_t s) {
     if (p->resolveSetupDone) p->resolveSetupDone = false;
     else if (int rc = launch_resolve_setup(p, s)) return rc;
     GBufferArgs a = gbuffer_args_of(p);
+    // inside brmi_execute with occlusion culling the depth map is final; with the layer planes holding the scene's one coat / fuzz word the
+    // slim instantiations leave 20 B per pixel unwritten.  The fallback variant (arena overflow) writes everything: same values.
+    const bool slim = p->depthFinal && p->layerPlanesUniform;
     const bool lean = (uint64_t)p->resolveCapacity >= (uint64_t)p->cfg.maxVisibleClusters * BRMI_MESHLET_MAX_TRIS;
     // `lean`: the arena holds every visible cluster even at 128 vertices / triangles each.  Otherwise whether one spilled is only
     // known on the device: both variants are launched and each leaves at once when the frame is the other one's (a ~5 us empty
@@ -648,10 +655,15 @@ int launch_gbuffer(brmi_pass* p, hipStream_t s) {
     }
     if (p->sceneHasTextures || p->sceneHasVertexColors) {
         const bool multiUv = p->sceneUvSets > 1;
-        if (p->sceneHasParallax) { if (multiUv) launch(k_gbuffer<false, true, true, true>, k_gbuffer<true, true, true, true>); else launch(k_gbuffer<false, true, true>, k_gbuffer<true, true, true>); }   // its own variant: the ray march costs the others registers they would spill
-        else if (multiUv) launch(k_gbuffer<false, true, false, true>, k_gbuffer<true, true, false, true>);
+        if (p->sceneHasParallax) {      // its own variants: the ray march costs the others registers they would spill
+            if (multiUv) { if (slim) launch(k_gbuffer<false, true, true, true, true>, k_gbuffer<true, true, true, true>); else launch(k_gbuffer<false, true, true, true>, k_gbuffer<true, true, true, true>); }
+            else if (slim) launch(k_gbuffer<false, true, true, false, true>, k_gbuffer<true, true, true>);
+            else launch(k_gbuffer<false, true, true>, k_gbuffer<true, true, true>);
+        } else if (multiUv) { if (slim) launch(k_gbuffer<false, true, false, true, true>, k_gbuffer<true, true, false, true>); else launch(k_gbuffer<false, true, false, true>, k_gbuffer<true, true, false, true>); }
+        else if (slim) launch(k_gbuffer<false, true, false, false, true>, k_gbuffer<true, true>);
         else launch(k_gbuffer<false, true>, k_gbuffer<true, true>);
-    } else launch(k_gbuffer<false, false>, k_gbuffer<true, false>);
+    } else if (slim) launch(k_gbuffer<false, false, false, false, true>, k_gbuffer<true, false>);
+    else launch(k_gbuffer<false, false>, k_gbuffer<true, false>);
     BRMI_LAUNCH_CHECK(p, "k_gbuffer");
     return BRMI_OK;
 }
