@@ -601,10 +601,12 @@ int brmi_execute_split(brmi_pass* p, brmi_stream stream, brmi_stream shadeStream
     if (p->frameDoneRecorded) BRMI_HIP(p, hipStreamWaitEvent(static_cast<hipStream_t>(stream), p->frameDone, 0));
     p->frameDoneRecorded = false;
     // frames in flight: this frame's phase 1 reads the chain the source pass built for the frame before, possibly on another stream
-    if (p->history && p->history->chainRecorded) BRMI_HIP(p, hipStreamWaitEvent(static_cast<hipStream_t>(stream), p->history->chainReady, 0));
+    // (recorded on this very stream -- the passes of a ring share their geometry stream --: stream order already says so, and every wait
+    // is a barrier packet worth a few us on the geometry half's critical path)
+    if (p->history && p->history->chainRecorded && p->history->chainStream != stream) BRMI_HIP(p, hipStreamWaitEvent(static_cast<hipStream_t>(stream), p->history->chainReady, 0));
     // ... and this frame rewrites the chain a pass that has THIS one as its source may still be reading in its phase 1 (the same event:
     // it is recorded after that pass's culling)
-    for (brmi_pass* user : p->historyUsers) if (user != p->history && user->chainRecorded) BRMI_HIP(p, hipStreamWaitEvent(static_cast<hipStream_t>(stream), user->chainReady, 0));
+    for (brmi_pass* user : p->historyUsers) if (user != p->history && user->chainRecorded && user->chainStream != stream) BRMI_HIP(p, hipStreamWaitEvent(static_cast<hipStream_t>(stream), user->chainReady, 0));
     // When the phase-1 traversal is the one-launch LDS walk and the frame constants are due anyway, the frame needs no clear launch: the
     // constants kernel zeroes the culling state and the walk's launch carries the visibility clear (brmi_cull.hip, SideClear).
     static const bool rideEnv = [] { const char* e = std::getenv("BRMI_CLEAR_RIDES"); return !e || std::atoi(e) != 0; }();
@@ -639,7 +641,7 @@ int brmi_execute_split(brmi_pass* p, brmi_stream stream, brmi_stream shadeStream
         if ((rc = build_hzb_fused(p, static_cast<hipStream_t>(stream), true, true))) return rc;
         // recorded every frame (a pass may be linked to this one later, from another stream)
         if (!p->chainReady) BRMI_HIP(p, hipEventCreateWithFlags(&p->chainReady, hipEventDisableTiming));
-        BRMI_HIP(p, hipEventRecord(p->chainReady, static_cast<hipStream_t>(stream))); p->chainRecorded = true;
+        BRMI_HIP(p, hipEventRecord(p->chainReady, static_cast<hipStream_t>(stream))); p->chainRecorded = true; p->chainStream = stream;
     }
     // BRMI_FUSE_SHADE=1 (off by default): one pass over the pixels for G-buffer + shading where the G-buffer kernel is the lean one
     // (brmi_resolve.hip: k_gbuffer_shade); the light lists must exist by then.  Measured: 338 us against 103 + 236 us for the two kernels on

@@ -164,6 +164,7 @@ struct brmi_pass {
     brmi_pass* history = nullptr;    // brmi_set_history_source: the pass whose chain phase 1 tests against (frames in flight); null = this pass's own
     hipEvent_t chainReady = nullptr; // recorded by brmi_execute after the frame's last chain build when another pass may be reading it
     bool chainRecorded = false;
+    brmi_stream chainStream = nullptr;   // the stream chainReady was last recorded on
     hipEvent_t geometryDone = nullptr, frameDone = nullptr;   // brmi_execute_split: geometry half -> shading half, and the frame's end on the shading stream
     bool frameDoneRecorded = false;
     std::vector<brmi_pass*> historyUsers;   // passes whose `history` is this pass (unlinked when it is destroyed)
