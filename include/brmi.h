@@ -175,7 +175,7 @@ int         brmi_set_scene(brmi_pass* pass, const brmi_scene_buffers* scene);   
 int         brmi_setup(brmi_pass* pass, const brmi_resource_binding* b, uint32_t n, brmi_stream stream); /* Setup */
 int         brmi_update(brmi_pass* pass, const brmi_frame_update* upd, brmi_stream stream);               /* Update */
 int         brmi_execute(brmi_pass* pass, brmi_stream stream);                          /* Execute: whole chain */
-/* The same frame on two streams (the reference schedules its passes on a graphics and an async-compute queue): culling, rasterisation
+/* The same frame on two streams (the reference's graph owns a graphics, a compute and a copy queue and passes state a preference: `QueueKind`, `PreferQueue`; DeviceManager.cpp:178): culling, rasterisation
  * and the depth chain on `geometryStream`, G-buffer, light lists (when the culling launches did not carry them) and shading on
  * `shadingStream`; events order the two halves and the pass's next frame.  Outputs are ready when `shadingStream` is.  With
  * brmi_set_history_source and two passes alternating frames on the same geometry stream (the shading stream may be shared or one per
