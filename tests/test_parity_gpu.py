@@ -968,6 +968,37 @@ def test_split_streams_without_occlusion_culling_match_the_serial_frame():
         r.close()
 
 
+@pytest.mark.parametrize("occlusion", [False, True])
+def test_uniform_layer_planes_are_filled_once_and_skipped(occlusion):
+    """brmi_config::keepUniformLayerPlanes: a scene without coated / fuzzy materials stores one coat word and one fuzz word; the planes are
+    filled with them after brmi_setup (pixels no triangle covers read the word too) and, inside brmi_execute with occlusion culling, the slim
+    G-buffer instantiation leaves them alone.  Covered pixels are byte-identical with the flag off; a scene WITH layered materials is not touched."""
+    from conftest import Scene
+    from basicrenderer_amd.renderer import VisibilityRenderer
+    sc = Scene("sponza", 640, 360, point_lights=8, size_scale=0.25)
+    on, off = VisibilityRenderer(sc, occlusion=occlusion), VisibilityRenderer(sc, occlusion=occlusion, keepUniformLayerPlanes=0)
+    for r in (on, off):
+        r.execute(); r.execute()
+    vis = on.visibility()
+    covered = vis != np.uint64(0xFFFFFFFFFFFFFFFF)
+    assert covered.any() and (~covered).any() and np.array_equal(vis, off.visibility())
+    g_on, g_off = on.gbuffer(), off.gbuffer()
+    for k in g_on:
+        assert np.array_equal(g_on[k][covered], g_off[k][covered]), k
+    assert np.array_equal(on.hdr()[covered], off.hdr()[covered])
+    for k in ("coat", "fuzz"):
+        word = np.unique(g_on[k][covered])
+        assert word.size == 1 and (g_on[k] == word[0]).all(), k          # one word, everywhere
+        assert (g_off[k][~covered] == 0).all(), k                        # flag off: nobody wrote the uncovered pixels
+    on.close(); off.close()
+    layered = VisibilityRenderer(Scene("sponza", 640, 360, point_lights=8, size_scale=0.25, material_features=3), occlusion=occlusion)
+    layered.execute()
+    g = layered.gbuffer()
+    cov = layered.visibility() != np.uint64(0xFFFFFFFFFFFFFFFF)
+    assert np.unique(g["coat"][cov]).size > 1 and (g["coat"][~cov] == 0).all()
+    layered.close()
+
+
 def test_history_source_is_validated():
     from conftest import Scene
     from basicrenderer_amd.renderer import VisibilityRenderer, BrmiError
