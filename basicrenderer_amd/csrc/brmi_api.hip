@@ -192,7 +192,7 @@ void brmi_default_config(brmi_config* cfg, uint32_t width, uint32_t height) {
     cfg->phase2ExpansionFactor = 2;
     cfg->collectPassStatistics = 0;
     cfg->maxBvhLevels = 64;
-    cfg->keepUniformLayerPlanes = 1;
+    cfg->keepUniformLayerPlanes = 0;          // opt-in: every plane is written every frame unless the host says the planes are its to keep
 }
 
 int brmi_create(const brmi_config* cfg, brmi_pass** out) {

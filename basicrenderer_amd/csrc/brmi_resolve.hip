@@ -314,7 +314,7 @@ struct ShadeEpilogue {
         shade_defer(sh, (uint32_t)(tileBase >> 6) - (uint32_t)(sh.firstPixel >> 6), cls, lane);
     }
 };
-template <bool INLINE_TABLES, bool TEXTURED, bool PARALLAX, bool MULTI_UV, bool SLIM, class Epi>
+template <bool INLINE_TABLES, bool TEXTURED, bool PARALLAX, bool MULTI_UV, int SLIM, class Epi>
 BRMI_DEV void gbuffer_body(const GBufferArgs& a, const Epi& epi) {
     const brmi_scene_buffers& sc = a.sc;
     if (a.variantSelect != 0u && (a.counters[CNT_RESOLVE_SPILL] != 0u) != (a.variantSelect == 2u)) return;     // the other variant's frame
@@ -323,10 +323,11 @@ BRMI_DEV void gbuffer_body(const GBufferArgs& a, const Epi& epi) {
     TexelTables tb; tb.t = texelTables;
     const brmi_per_frame* pf = sc.perFrame;
     const uint32_t clusterCount = min(a.counters[CNT_VISIBLE] + a.counters[CNT_VISIBLE2], a.clusterCapacity);
-    // SLIM (chosen by the host, brmi_execute only): the depth map is final already, and the coat and fuzz planes hold the one word every
-    // material of the scene stores (filled once after brmi_setup) -- 20 of 56 B per pixel are not stored.  Compile-time: the same skips as
-    // run-time branches made the kernel slower than storing everything (107 against 103 us; without the stores: 93)
-    constexpr bool skipCoat = SLIM, skipFuzz = SLIM;
+    // SLIM (chosen by the host, brmi_execute only): 1 = the depth map is final already (the chain build wrote it from the keys); 2 = also the
+    // coat and fuzz planes hold the one word every material of the scene stores (brmi_config::keepUniformLayerPlanes: filled once after
+    // brmi_setup) -- 20 of 56 B per pixel are not stored.  Compile-time: the same skips as run-time branches made the kernel slower than
+    // storing everything (107 against 103 us; without the stores: 93)
+    constexpr bool skipCoat = SLIM == 2, skipFuzz = SLIM == 2;
     // view-projection products are frame constants; every lane derives them the way the shader does
     const m4 unjVP = uni_m4(a.frameConst[1]), prevVP = uni_m4(a.frameConst[2]);
     const float winX = uni((float)pf->screenResX), winY = uni((float)pf->screenResY);
@@ -351,7 +352,7 @@ BRMI_DEV void gbuffer_body(const GBufferArgs& a, const Epi& epi) {
         const unsigned long long key = nkey;
         float4 outN = make_float4(0.0f, 0.0f, 0.0f, 0.0f); uint32_t outAl = 0u, outMr = 0u; unsigned long long outCoat = 0ull, outEmis = 0ull;      // the pixel's words, for the epilogue
         if (j + stride < end) { nvalid = pixel_of(j + stride, npx, npy); nkey = nvalid ? __builtin_nontemporal_load(&a.vis[a.firstPixel + j + stride]) : BRMI_VIS_EMPTY; }
-        if (!SLIM && valid && a.depth) __builtin_nontemporal_store((key == BRMI_VIS_EMPTY) ? as_f32(BRMI_DEPTH_EMPTY_BITS) : as_f32(((uint32_t)(key >> BRMI_VIS_META_BITS)) << 1), &a.depth[i]);
+        if (SLIM == 0 && valid && a.depth) __builtin_nontemporal_store((key == BRMI_VIS_EMPTY) ? as_f32(BRMI_DEPTH_EMPTY_BITS) : as_f32(((uint32_t)(key >> BRMI_VIS_META_BITS)) << 1), &a.depth[i]);
         const uint32_t triId = (uint32_t)(key & 0x7Full);
         const uint32_t clusterIndex = (uint32_t)((key >> BRMI_VIS_TRI_BITS) & 0x3FFFFFFull);
         valid = valid && key != BRMI_VIS_EMPTY && clusterIndex < clusterCount;
@@ -573,7 +574,7 @@ BRMI_DEV void gbuffer_body(const GBufferArgs& a, const Epi& epi) {
         if (Epi::kWanted) epi.pixel(inBand, key, valid, px, py, i, outN, outAl, outMr, outCoat, outEmis);
     }
 }
-template <bool INLINE_TABLES, bool TEXTURED, bool PARALLAX = false, bool MULTI_UV = false, bool SLIM = false>
+template <bool INLINE_TABLES, bool TEXTURED, bool PARALLAX = false, bool MULTI_UV = false, int SLIM = 0>
 __global__ void __launch_bounds__(256, INLINE_TABLES ? 1 : (MULTI_UV ? BRMI_GBM_WAVES : (PARALLAX ? BRMI_GBP_WAVES : (TEXTURED ? BRMI_GBT_WAVES : BRMI_GB_WAVES)))) k_gbuffer(GBufferArgs a) {
     gbuffer_body<INLINE_TABLES, TEXTURED, PARALLAX, MULTI_UV, SLIM>(a, NoEpilogue{});
 }
@@ -590,7 +591,7 @@ __global__ void __launch_bounds__(256, BRMI_FUSED_WAVES) k_gbuffer_shade(GBuffer
     __shared__ float unormT[256];
     __shared__ float4 camK[9];
     shade_stage_lds(sh, k, sliceStart, unormT, camK);
-    gbuffer_body<false, false, false, false, false>(a, ShadeEpilogue{sh, k, sliceStart, unormT, camK});
+    gbuffer_body<false, false, false, false, 0>(a, ShadeEpilogue{sh, k, sliceStart, unormT, camK});
 }
 
 static GBufferArgs gbuffer_args_of(brmi_pass* p) {
@@ -636,7 +637,7 @@ int launch_gbuffer(brmi_pass* p, hipStream_t s) {
     GBufferArgs a = gbuffer_args_of(p);
     // inside brmi_execute with occlusion culling the depth map is final; with the layer planes holding the scene's one coat / fuzz word the
     // slim instantiations leave 20 B per pixel unwritten.  The fallback variant (arena overflow) writes everything: same values.
-    const bool slim = p->depthFinal && p->layerPlanesUniform;
+    const int slim = p->depthFinal ? (p->layerPlanesUniform ? 2 : 1) : 0;
     const bool lean = (uint64_t)p->resolveCapacity >= (uint64_t)p->cfg.maxVisibleClusters * BRMI_MESHLET_MAX_TRIS;
     // `lean`: the arena holds every visible cluster even at 128 vertices / triangles each.  Otherwise whether one spilled is only
     // known on the device: both variants are launched and each leaves at once when the frame is the other one's (a ~5 us empty
@@ -658,15 +659,14 @@ int launch_gbuffer(brmi_pass* p, hipStream_t s) {
     }
     if (p->sceneHasTextures || p->sceneHasVertexColors) {
         const bool multiUv = p->sceneUvSets > 1;
-        if (p->sceneHasParallax) {      // its own variants: the ray march costs the others registers they would spill
-            if (multiUv) { if (slim) launch(k_gbuffer<false, true, true, true, true>, k_gbuffer<true, true, true, true>); else launch(k_gbuffer<false, true, true, true>, k_gbuffer<true, true, true, true>); }
-            else if (slim) launch(k_gbuffer<false, true, true, false, true>, k_gbuffer<true, true, true>);
-            else launch(k_gbuffer<false, true, true>, k_gbuffer<true, true, true>);
-        } else if (multiUv) { if (slim) launch(k_gbuffer<false, true, false, true, true>, k_gbuffer<true, true, false, true>); else launch(k_gbuffer<false, true, false, true>, k_gbuffer<true, true, false, true>); }
-        else if (slim) launch(k_gbuffer<false, true, false, false, true>, k_gbuffer<true, true>);
-        else launch(k_gbuffer<false, true>, k_gbuffer<true, true>);
-    } else if (slim) launch(k_gbuffer<false, false, false, false, true>, k_gbuffer<true, false>);
-    else launch(k_gbuffer<false, false>, k_gbuffer<true, false>);
+        // (SLIM: 0 / 1 / 2 as decided above)
+#define BRMI_GB_LAUNCH(T, P, M) do { if (slim == 2) launch(k_gbuffer<false, T, P, M, 2>, k_gbuffer<true, T, P, M>); else if (slim == 1) launch(k_gbuffer<false, T, P, M, 1>, k_gbuffer<true, T, P, M>); \
+                                     else launch(k_gbuffer<false, T, P, M>, k_gbuffer<true, T, P, M>); } while (0)
+        if (p->sceneHasParallax) { if (multiUv) BRMI_GB_LAUNCH(true, true, true); else BRMI_GB_LAUNCH(true, true, false); }      // its own variants: the ray march costs the others registers they would spill
+        else if (multiUv) BRMI_GB_LAUNCH(true, false, true);
+        else BRMI_GB_LAUNCH(true, false, false);
+    } else BRMI_GB_LAUNCH(false, false, false);
+#undef BRMI_GB_LAUNCH
     BRMI_LAUNCH_CHECK(p, "k_gbuffer");
     return BRMI_OK;
 }

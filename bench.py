@@ -65,6 +65,9 @@ def main():
                          "frame and loses 7 %% on the Sponza-class one.  1: one pass, one stream, frames back to back.  "
                          "Every frame does all of its work either way; "
                          "the roofline block is measured on serial frames (a kernel's duration while it shares the CUs with another frame is not its own)")
+    ap.add_argument("--keep-uniform-layer-planes", type=int, default=0, choices=[0, 1],
+                    help="brmi_config::keepUniformLayerPlanes: 1 = the coat / fuzz G-buffer planes of a scene whose materials all store the same word are filled "
+                         "once and not rewritten (G-buffer kernel 93 -> 84 us).  Default 0: every frame writes every plane")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scale", type=float, default=1.0, help="fraction of the frame height the CPU baseline renders")
     args = ap.parse_args()
@@ -124,14 +127,14 @@ def measure(args, workload, n, rank, local_rank, cpu):
     W, H = compose.frame_size(n)
     band = compose.band_of(rank, n, H)
     scene = Scene(preset, W, H, point_lights=lights, directional=True, lod_builder=args.lod_builder, material_features=args.material_features, **scene_kw)
-    r = VisibilityRenderer(scene, device=dev, stats=True, band=band, occlusion=bool(args.occlusion))
+    r = VisibilityRenderer(scene, device=dev, stats=True, band=band, occlusion=bool(args.occlusion), keepUniformLayerPlanes=args.keep_uniform_layer_planes)
     fif = args.frames_in_flight
     passes, streams, shade_streams = [r], [torch.cuda.current_stream(dev)], [None, None]
     if fif >= 2:
         # the second pass has its own resources and scene upload (its camera buffers are its own); phase 1 of each tests against the chain
         # the other built for the frame before
         for _ in range(fif - 1):
-            passes.append(VisibilityRenderer(scene, device=dev, stats=False, band=band, occlusion=bool(args.occlusion)))
+            passes.append(VisibilityRenderer(scene, device=dev, stats=False, band=band, occlusion=bool(args.occlusion), keepUniformLayerPlanes=args.keep_uniform_layer_planes))
         if args.occlusion:
             for k in range(fif):
                 passes[k].set_history_source(passes[(k - 1) % fif])        # the pass that renders the frame before

@@ -53,9 +53,10 @@ typedef struct brmi_config {
     uint32_t collectPassStatistics;    /* per-stage hipEvent timing (Renderer.cpp:1133-1134) */
     uint32_t maxBvhLevels;             /* level-loop bound; reference caps at 64 (HierarchicalDispatchCullingPass.cpp:57) */
     uint32_t bandY0, bandY1;           /* rows [bandY0,bandY1) this GPU owns (multi-GPU tile split); 0,0 = all */
-    uint32_t keepUniformLayerPlanes;   /* default 1: when every material of the scene packs to the same coat (fuzz) G-buffer word and binds no coat / fuzz
-                                          texture, the plane is filled with that word once after brmi_setup and the per-frame stores to it are skipped
-                                          (16 of 52 B per pixel).  Set 0 if anything else writes, clears or aliases GBUF_COAT / GBUF_FUZZ between frames. */
+    uint32_t keepUniformLayerPlanes;   /* default 0 (every plane is written every frame).  1: when every material of the scene packs to the same coat
+                                          (fuzz) G-buffer word and binds no coat / fuzz texture, the plane is filled with that word once after brmi_setup
+                                          and brmi_execute skips the per-frame stores to it (16 of 52 B per pixel).  Only for hosts that neither write,
+                                          clear nor alias GBUF_COAT / GBUF_FUZZ between frames. */
     uint32_t reserved[7];
 } brmi_config;
 

@@ -970,13 +970,13 @@ def test_split_streams_without_occlusion_culling_match_the_serial_frame():
 
 @pytest.mark.parametrize("occlusion", [False, True])
 def test_uniform_layer_planes_are_filled_once_and_skipped(occlusion):
-    """brmi_config::keepUniformLayerPlanes: a scene without coated / fuzzy materials stores one coat word and one fuzz word; the planes are
+    """brmi_config::keepUniformLayerPlanes = 1 (opt-in): a scene without coated / fuzzy materials stores one coat word and one fuzz word; the planes are
     filled with them after brmi_setup (pixels no triangle covers read the word too) and, inside brmi_execute with occlusion culling, the slim
     G-buffer instantiation leaves them alone.  Covered pixels are byte-identical with the flag off; a scene WITH layered materials is not touched."""
     from conftest import Scene
     from basicrenderer_amd.renderer import VisibilityRenderer
     sc = Scene("sponza", 640, 360, point_lights=8, size_scale=0.25)
-    on, off = VisibilityRenderer(sc, occlusion=occlusion), VisibilityRenderer(sc, occlusion=occlusion, keepUniformLayerPlanes=0)
+    on, off = VisibilityRenderer(sc, occlusion=occlusion, keepUniformLayerPlanes=1), VisibilityRenderer(sc, occlusion=occlusion)
     for r in (on, off):
         r.execute(); r.execute()
     vis = on.visibility()
@@ -991,7 +991,7 @@ def test_uniform_layer_planes_are_filled_once_and_skipped(occlusion):
         assert word.size == 1 and (g_on[k] == word[0]).all(), k          # one word, everywhere
         assert (g_off[k][~covered] == 0).all(), k                        # flag off: nobody wrote the uncovered pixels
     on.close(); off.close()
-    layered = VisibilityRenderer(Scene("sponza", 640, 360, point_lights=8, size_scale=0.25, material_features=3), occlusion=occlusion)
+    layered = VisibilityRenderer(Scene("sponza", 640, 360, point_lights=8, size_scale=0.25, material_features=3), occlusion=occlusion, keepUniformLayerPlanes=1)
     layered.execute()
     g = layered.gbuffer()
     cov = layered.visibility() != np.uint64(0xFFFFFFFFFFFFFFFF)
