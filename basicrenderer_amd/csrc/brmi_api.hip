@@ -596,7 +596,7 @@ int brmi_execute_split(brmi_pass* p, brmi_stream stream, brmi_stream shadeStream
     int rc;
     p->executesSinceTimes++;
     const bool split = shadeStream != stream;
-    p->resolveSetupDone = false;
+    p->resolveSetupDone = false; p->depthFinal = false;      // (a frame that failed half-way must not leave its shortcuts to the stage entry points)
     // this pass's previous frame may still be resolving / shading on the other stream: its visibility buffer and tables are about to be rewritten
     if (p->frameDoneRecorded) BRMI_HIP(p, hipStreamWaitEvent(static_cast<hipStream_t>(stream), p->frameDone, 0));
     p->frameDoneRecorded = false;
