@@ -15,7 +15,7 @@ u32, u64, f32, vp = C.c_uint32, C.c_uint64, C.c_float, C.c_void_p
 class SceneParams(C.Structure):
     _fields_ = [("preset", u32), ("seed", u32), ("width", u32), ("height", u32), ("numPointLights", u32),
                 ("withDirectionalLight", u32), ("lodLevels", u32), ("sizeScale", f32), ("skinnedFraction1024", u32),
-                ("materialFeatures", u32), ("cameraStep", u32), ("lodBuilder", u32), ("spotLightEvery", u32), ("detail", f32), ("reserved", u32 * 2)]
+                ("materialFeatures", u32), ("cameraStep", u32), ("lodBuilder", u32), ("spotLightEvery", u32), ("detail", f32), ("uniqueTriangleBudget", u32), ("reliefSlope", f32)]
 
 
 class MeshInput(C.Structure):
@@ -206,6 +206,7 @@ def scene_lib():
         lib.brmi_scene_slab_count.restype = u32
         lib.brmi_scene_slab.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(u64)]
         lib.brmi_scene_get_stats.argtypes = [vp, C.POINTER(SceneStats)]
+        lib.brmi_scene_camera_at.argtypes = [C.POINTER(SceneParams), C.c_double, C.c_double, vp, vp]
         _scene_lib = lib
     return _scene_lib
 

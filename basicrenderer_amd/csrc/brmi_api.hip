@@ -128,6 +128,7 @@ static void compute_sizes(brmi_pass* p) {
     w.matWords = take((uint64_t)std::max(1u, p->scene.materialCount) * sizeof(MaterialWords));
     w.layerUniform = take(sizeof(LayerUniform));
     w.frameConst = take(3 * 64);
+    w.frameSnapshot = take(sizeof(FrameSnapshot));
     w.matConst = take((uint64_t)std::max(1u, p->scene.openpbrMaterialCount) * sizeof(MatConst));
     w.objConst = take((uint64_t)std::max(1u, p->scene.perObjectCount) * 36 * 4);
     p->deferredStripeCapacity = (uint32_t)(((p->bandPixelCount / 4096 + CNT_STRIPE_COUNT) / CNT_STRIPE_COUNT) * 4096);   // 64-tile runs of a stripe x 4096 pixels
@@ -518,12 +519,30 @@ int brmi_update(brmi_pass* p, const brmi_frame_update* u, brmi_stream stream) {
 #define STAGE_END(p, st, s) do { if ((p)->eventsCreated && (((p)->timedStages >> (st)) & 1u)) { (void)hipEventRecord((p)->evStop[st][(p)->evCount[st] % brmi_pass::kEventRing], (s)); (p)->evCount[st]++; } } while (0)
 #define CHECK_READY(p) do { if (!(p)) return BRMI_ERR_INVALID; if (!(p)->setupDone || !(p)->updated) return brmi::fail((p), BRMI_ERR_STATE, "%s: setup/update not done", __func__); } while (0)
 
+// What a frame's first launch has to wait for when frames are in flight (brmi_execute_split, and the stage entry points that start a frame:
+// a graph that schedules the stages itself after a split frame gets the same ordering).  No-ops when nothing was recorded.
+static int wait_for_frames_in_flight(brmi_pass* p, brmi_stream stream) {
+    // this pass's previous frame may still be resolving / shading on the other stream: its visibility buffer and tables are about to be rewritten
+    if (p->frameDoneRecorded) BRMI_HIP(p, hipStreamWaitEvent(static_cast<hipStream_t>(stream), p->frameDone, 0));
+    p->frameDoneRecorded = false;
+    // frames in flight: this frame's phase 1 reads the chain the source pass built for the frame before, possibly on another stream
+    // (recorded on this very stream -- the passes of a ring share their geometry stream --: stream order already says so, and every wait
+    // is a barrier packet worth a few us on the geometry half's critical path)
+    if (p->history && p->history->chainRecorded && p->history->chainStream != stream) BRMI_HIP(p, hipStreamWaitEvent(static_cast<hipStream_t>(stream), p->history->chainReady, 0));
+    // ... and this frame rewrites the chain a pass that has THIS one as its source may still be reading in its phase 1 (the same event:
+    // it is recorded after that pass's culling)
+    for (brmi_pass* user : p->historyUsers) if (user != p->history && user->chainRecorded && user->chainStream != stream) BRMI_HIP(p, hipStreamWaitEvent(static_cast<hipStream_t>(stream), user->chainReady, 0));
+    return BRMI_OK;
+}
+
 int brmi_clear_visibility(brmi_pass* p, brmi_stream stream) {
     CHECK_READY(p); hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int w = wait_for_frames_in_flight(p, stream)) return w;
     STAGE_BEGIN(p, BRMI_STAGE_CLEAR, s); int rc = launch_clear(p, s); STAGE_END(p, BRMI_STAGE_CLEAR, s); return rc;
 }
 int brmi_cull(brmi_pass* p, uint32_t phase, brmi_stream stream) {
     CHECK_READY(p); hipStream_t s = static_cast<hipStream_t>(stream);
+    if (phase == 1) if (int w = wait_for_frames_in_flight(p, stream)) return w;
     const int st = phase == 2 ? BRMI_STAGE_CULL2 : BRMI_STAGE_CULL;
     STAGE_BEGIN(p, st, s); int rc = launch_cull(p, phase, s); STAGE_END(p, st, s); return rc;
 }
@@ -597,16 +616,7 @@ int brmi_execute_split(brmi_pass* p, brmi_stream stream, brmi_stream shadeStream
     p->executesSinceTimes++;
     const bool split = shadeStream != stream;
     p->resolveSetupDone = false; p->depthFinal = false;      // (a frame that failed half-way must not leave its shortcuts to the stage entry points)
-    // this pass's previous frame may still be resolving / shading on the other stream: its visibility buffer and tables are about to be rewritten
-    if (p->frameDoneRecorded) BRMI_HIP(p, hipStreamWaitEvent(static_cast<hipStream_t>(stream), p->frameDone, 0));
-    p->frameDoneRecorded = false;
-    // frames in flight: this frame's phase 1 reads the chain the source pass built for the frame before, possibly on another stream
-    // (recorded on this very stream -- the passes of a ring share their geometry stream --: stream order already says so, and every wait
-    // is a barrier packet worth a few us on the geometry half's critical path)
-    if (p->history && p->history->chainRecorded && p->history->chainStream != stream) BRMI_HIP(p, hipStreamWaitEvent(static_cast<hipStream_t>(stream), p->history->chainReady, 0));
-    // ... and this frame rewrites the chain a pass that has THIS one as its source may still be reading in its phase 1 (the same event:
-    // it is recorded after that pass's culling)
-    for (brmi_pass* user : p->historyUsers) if (user != p->history && user->chainRecorded && user->chainStream != stream) BRMI_HIP(p, hipStreamWaitEvent(static_cast<hipStream_t>(stream), user->chainReady, 0));
+    if ((rc = wait_for_frames_in_flight(p, stream))) return rc;
     // When the phase-1 traversal is the one-launch LDS walk and the frame constants are due anyway, the frame needs no clear launch: the
     // constants kernel zeroes the culling state and the walk's launch carries the visibility clear (brmi_cull.hip, SideClear).
     static const bool rideEnv = [] { const char* e = std::getenv("BRMI_CLEAR_RIDES"); return !e || std::atoi(e) != 0; }();

@@ -23,8 +23,14 @@ namespace brmi {
 //   frameConst[0] = mul(view, projection)           frameConst[1] = mul(view, unjitteredProjection)
 //   frameConst[2] = mul(prevView, prevUnjitteredProjection)
 //   objConst[o]   = { mul(model, cullCam.viewProjection), mul(model, frameConst[0]), mul(model, cullCam.viewZ) }
-BRMI_DEV void job_object_constants(const brmi_scene_buffers& sc, m4* frameConst, float* objConst, uint32_t o) {
+BRMI_DEV void job_object_constants(const brmi_scene_buffers& sc, m4* frameConst, float* objConst, FrameSnapshot* snap, uint32_t o) {
     const uint32_t viewId = sc.perFrame->mainCameraIndex;
+    if (o < 64u) {      // the job's first workgroup: the camera and the per-frame record the shading half will read (FrameSnapshot)
+        const uint32_t* pfSrc = reinterpret_cast<const uint32_t*>(sc.perFrame); uint32_t* pfDst = reinterpret_cast<uint32_t*>(&snap->perFrame);
+        for (uint32_t i = o; i < sizeof(brmi_per_frame) / 4u; i += 64u) pfDst[i] = (i == offsetof(brmi_per_frame, mainCameraIndex) / 4u) ? 0u : pfSrc[i];
+        const uint32_t* cSrc = reinterpret_cast<const uint32_t*>(sc.cameras + viewId); uint32_t* cDst = reinterpret_cast<uint32_t*>(&snap->camera);
+        for (uint32_t i = o; i < sizeof(brmi_camera) / 4u; i += 64u) cDst[i] = cSrc[i];
+    }
     const brmi_camera* cam = sc.cameras + viewId;
     const brmi_culling_camera* cc = sc.cullingCameras + viewId;
     const m4 viewM = load_m4(&cam->view[0][0]);
@@ -203,7 +209,7 @@ BRMI_DEV void job_shade_tables(const brmi_scene_buffers& sc, ShadeTables t, uint
 
 struct FrameJobs {
     brmi_scene_buffers sc;
-    m4* frameConst; float* objConst; MaterialWords* matWords; MatConst* matConst; ShadeTables tables; float4* lightVS; uint32_t* lightMeta; float4* shadeLights;
+    m4* frameConst; FrameSnapshot* snapshot; float* objConst; MaterialWords* matWords; MatConst* matConst; ShadeTables tables; float4* lightVS; uint32_t* lightMeta; float4* shadeLights;
     AlphaMaterial* alphaMats; LayerUniform* layer;
     const float* lutF; ShadeRows* shadeRows; ShadeAverages* shadeAvgs; GgxQuad* ggxQuads;
     uint32_t W, H;
@@ -214,7 +220,7 @@ struct FrameJobs {
 
 __global__ void __launch_bounds__(64) k_frame_constants(FrameJobs j) {
     const uint32_t b = blockIdx.x;
-    if (b < j.firstBlock[1]) job_object_constants(j.sc, j.frameConst, j.objConst, (b - j.firstBlock[0]) * 64u + threadIdx.x);
+    if (b < j.firstBlock[1]) job_object_constants(j.sc, j.frameConst, j.objConst, j.snapshot, (b - j.firstBlock[0]) * 64u + threadIdx.x);
     else if (b < j.firstBlock[2]) job_material_words(j.sc, j.matWords, j.alphaMats, (b - j.firstBlock[1]) * 64u + threadIdx.x);
     else if (b < j.firstBlock[3]) job_material_constants(j.sc, j.matConst, (b - j.firstBlock[2]) * 64u + threadIdx.x);
     else if (b < j.firstBlock[4]) job_shade_tables(j.sc, j.tables, j.W, j.H, j.sliceStart, (b - j.firstBlock[3]) * 64u + threadIdx.x);
@@ -230,12 +236,19 @@ ShadeTables shade_tables_of(const brmi_pass* p) {
     return ShadeTables{reinterpret_cast<AxisEntry*>(tb), reinterpret_cast<AxisEntry*>(tb + 2 * W), reinterpret_cast<float*>(tb + 2 * W + 2 * H)};
 }
 
+brmi_scene_buffers shading_scene_of(const brmi_pass* p) {
+    brmi_scene_buffers sc = p->scene;
+    FrameSnapshot* snap = p->wsPtr<FrameSnapshot>(p->ws.frameSnapshot);
+    sc.perFrame = &snap->perFrame; sc.cameras = &snap->camera; sc.cameraCount = 1u;
+    return sc;
+}
+
 // Launches the constants kernel if brmi_update / brmi_set_scene happened since the last time (every stage calls this first).
 int ensure_frame_constants(brmi_pass* p, hipStream_t s) {
     if (p->constantsSerial == p->updateSerial) return BRMI_OK;
     if (p->pfHost.numLights > p->scene.lightCount) return fail(p, BRMI_ERR_INVALID, "perFrame.numLights (%u) exceeds the light buffer (%u)", p->pfHost.numLights, p->scene.lightCount);
     FrameJobs j;
-    j.sc = p->scene; j.frameConst = p->wsPtr<m4>(p->ws.frameConst); j.objConst = p->wsPtr<float>(p->ws.objConst);
+    j.sc = p->scene; j.frameConst = p->wsPtr<m4>(p->ws.frameConst); j.snapshot = p->wsPtr<FrameSnapshot>(p->ws.frameSnapshot); j.objConst = p->wsPtr<float>(p->ws.objConst);
     j.matWords = p->wsPtr<MaterialWords>(p->ws.matWords); j.matConst = p->wsPtr<MatConst>(p->ws.matConst); j.tables = shade_tables_of(p);
     j.lightVS = p->wsPtr<float4>(p->ws.lightVS); j.lightMeta = p->wsPtr<uint32_t>(p->ws.lightMeta); j.shadeLights = p->wsPtr<float4>(p->ws.shadeLights);
     j.alphaMats = p->sceneHasAlphaTest ? p->wsPtr<AlphaMaterial>(p->ws.alphaMats) : nullptr;

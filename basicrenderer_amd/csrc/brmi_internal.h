@@ -110,12 +110,18 @@ struct HzbDesc {
 
 // Scenes whose materials all pack to the same coat (fuzz) G-buffer word: the word and whether the plane currently holds it everywhere
 // (brmi_frame.hip: job_layer_uniform, k_fill_layer_planes; brmi_resolve.hip skips the plane's stores)
+// The frame's main camera and per-frame record as the constants kernel found them (brmi_frame.hip).  The resolve + shading half of a frame reads
+// THESE, never the caller's buffers: with frames in flight the host rewrites its camera buffer for frame k + n while frame k is still being
+// shaded on the other stream; the constants kernel of the pass's next frame runs behind the frameDone wait, so the copy is stable for as
+// long as anything reads it.  perFrame.mainCameraIndex of the copy is 0 (the copy holds that one camera).
+struct FrameSnapshot { brmi_per_frame perFrame; brmi_camera camera; };
+
 struct LayerUniform { unsigned long long coatWord, fuzzWord, coatFilledWord, fuzzFilledWord; uint32_t coatUniform, fuzzUniform, coatFilled, fuzzFilled; };
 
 struct Workspace {     // byte offsets into BRMI_RES_WORKSPACE
     uint64_t counters, frontierA, frontierB, buckets, tempVisible, bitmask1, bitmask2, wordPrefix, blockSums,
              instanceBitBase, segPrefix, meshLevelWidth, planes, replayNodes, replayBuckets, lightVS, lightMeta, clusterPages, clusterHits, pageTotal, lightHitMasks, binCounts, binRecords, binOverflow, clusterSetup, resolveVerts, resolveTris, matWords, shadeTables, lutF, frameConst, objConst, matConst, deferredPixels, usedClusters,
-             clusterUv, binAlpha, overflowAlpha, resolveUVs, resolveColors, alphaMats, shadeRows, shadeAvgs, ggxQuads, shadeLights, clusterList, listEntries, layerUniform, frameClearBytes, total;
+             frameSnapshot, clusterUv, binAlpha, overflowAlpha, resolveUVs, resolveColors, alphaMats, shadeRows, shadeAvgs, ggxQuads, shadeLights, clusterList, listEntries, layerUniform, frameClearBytes, total;
 };
 
 }  // namespace brmi
@@ -201,6 +207,7 @@ int fail(brmi_pass* p, int code, const char* fmt, ...);
 
 // stage launchers (one translation unit each)
 int ensure_frame_constants(brmi_pass* p, hipStream_t s);
+brmi_scene_buffers shading_scene_of(const brmi_pass* p);      // p->scene with cameras / perFrame pointing at the pass's FrameSnapshot
 ShadeTables shade_tables_of(const brmi_pass* p);
 int launch_clear(brmi_pass* p, hipStream_t s);
 int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s);

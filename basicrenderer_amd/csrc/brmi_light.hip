@@ -136,7 +136,8 @@ ClusterArgs cluster_args_of(brmi_pass* p) {
 
 int launch_light_clustering(brmi_pass* p, hipStream_t s) {
     if (int rc = ensure_frame_constants(p, s)) return rc;
-    const ClusterArgs a = cluster_args_of(p);
+    ClusterArgs a = cluster_args_of(p);
+    a.sc = shading_scene_of(p);      // may run on the shading stream of a split frame: the frame's own camera (FrameSnapshot), not the caller's buffer
     const uint32_t nc = p->numLightClusters;
     hipLaunchKernelGGL(k_lc_count, dim3((nc + 3) / 4), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_lc_fill, dim3((nc + 3) / 4), dim3(256), 0, s, a);
@@ -146,7 +147,8 @@ int launch_light_clustering(brmi_pass* p, hipStream_t s) {
 
 ShadeArgs shade_args_of(brmi_pass* p) {
     ShadeArgs a;
-    a.perFrame = p->scene.perFrame; a.cameras = p->scene.cameras; a.openpbrMaterialCount = p->scene.openpbrMaterialCount; a.lutFuzzLTC = p->scene.lutFuzzLTC;
+    { const brmi_scene_buffers ssc = shading_scene_of(p); a.perFrame = ssc.perFrame; a.cameras = ssc.cameras; }
+    a.openpbrMaterialCount = p->scene.openpbrMaterialCount; a.lutFuzzLTC = p->scene.lutFuzzLTC;
     a.shadeLights = p->wsPtr<float4>(p->ws.shadeLights); a.clusterList = p->wsPtr<uint2>(p->ws.clusterList); a.listEntries = p->wsPtr<uint32_t>(p->ws.listEntries);
     a.depth = static_cast<const float*>(p->res[BRMI_RES_LINEAR_DEPTH]); a.normals = static_cast<const float4*>(p->res[BRMI_RES_GBUF_NORMALS]);
     a.albedo = static_cast<const uint32_t*>(p->res[BRMI_RES_GBUF_ALBEDO]); a.coat = static_cast<const unsigned long long*>(p->res[BRMI_RES_GBUF_COAT]);

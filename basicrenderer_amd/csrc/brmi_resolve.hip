@@ -596,7 +596,8 @@ __global__ void __launch_bounds__(256, BRMI_FUSED_WAVES) k_gbuffer_shade(GBuffer
 
 static GBufferArgs gbuffer_args_of(brmi_pass* p) {
     GBufferArgs a;
-    a.sc = p->scene; a.clusters = static_cast<const uint4*>(p->res[BRMI_RES_VISIBLE_CLUSTERS]); a.counters = p->counters();
+    a.sc = shading_scene_of(p);      // the frame's camera / per-frame record as the constants kernel saw them (FrameSnapshot)
+    a.clusters = static_cast<const uint4*>(p->res[BRMI_RES_VISIBLE_CLUSTERS]); a.counters = p->counters();
     a.vis = static_cast<const unsigned long long*>(p->res[BRMI_RES_VISIBILITY]);
     a.normals = static_cast<float4*>(p->res[BRMI_RES_GBUF_NORMALS]); a.albedo = static_cast<uint32_t*>(p->res[BRMI_RES_GBUF_ALBEDO]);
     a.coat = static_cast<unsigned long long*>(p->res[BRMI_RES_GBUF_COAT]); a.emissive = static_cast<unsigned long long*>(p->res[BRMI_RES_GBUF_EMISSIVE]);

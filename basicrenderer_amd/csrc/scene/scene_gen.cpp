@@ -131,7 +131,16 @@ struct PatchDef {
     uint32_t nu0 = 1, nv0 = 1;          // meshlets per dimension at LOD 0
     double noiseAmp = 0, noiseFreq = 4; uint32_t noiseSeed = 0;
     double detail = 1;                  // brmi_scene_params::detail: > 1 scales the relief and adds two finer octaves of it
+    double reliefSlope = 0;             // brmi_scene_params::reliefSlope: > 0 adds seven octaves whose amplitude is this fraction of their own wavelength
 };
+
+// shortest world-space wavelength of the patch's base noise octave, and the world length one unit of the noise displaces
+inline void patchNoiseScale(const PatchDef& p, double& wavelength, double& unit) {
+    const double f = p.noiseFreq > 0 ? p.noiseFreq : 1.0;
+    if (p.type == PATCH_PLANE) { wavelength = std::min(length(p.axisU), length(p.axisV)) / f; unit = 1.0; }
+    else if (p.type == PATCH_CYLINDER) { const double r = std::min(p.radiusX, p.radiusZ); wavelength = std::min(2.0 * M_PI * r, p.height) / f; unit = r; }
+    else { const double r = std::min(p.radiusX, std::min(p.radiusY, p.radiusZ)); wavelength = M_PI * r / f; unit = r; }
+}
 
 V3 evalPatch(const PatchDef& p, double u, double v) {
     double n = p.noiseAmp != 0 ? p.noiseAmp * fbm(u * p.noiseFreq, v * p.noiseFreq, p.noiseSeed) : 0.0;
@@ -139,6 +148,13 @@ V3 evalPatch(const PatchDef& p, double u, double v) {
         // roughness at every scale: seven more octaves, each half the wavelength and half the amplitude of the one before, so that the
         // simplification error of a LOD level stays proportional to its edge length and the 1-pixel error test keeps pixel-sized triangles
         double a = p.noiseAmp * (p.detail - 1.0) * 0.25, f = p.noiseFreq;
+        for (uint32_t k = 1; k <= 7u; k++) { a *= 0.5; f *= 2.0; n += a * valueNoise(u * f, v * f, p.noiseSeed + 101u * k); }
+    }
+    if (p.reliefSlope > 0.0) {
+        // the same roughness at every scale, stated in world units and the same for every patch: octave k (wavelength / 2^k) displaces by
+        // reliefSlope x its own wavelength, so a LOD level's simplification error is that fraction of its edge length whatever the patch
+        double wl, unit; patchNoiseScale(p, wl, unit);
+        double a = p.reliefSlope * wl / unit, f = p.noiseFreq > 0 ? p.noiseFreq : 1.0;
         for (uint32_t k = 1; k <= 7u; k++) { a *= 0.5; f *= 2.0; n += a * valueNoise(u * f, v * f, p.noiseSeed + 101u * k); }
     }
     if (p.type == PATCH_PLANE) {
@@ -164,6 +180,7 @@ struct MeshDef {
     uint32_t lodLevels = 1;      // DAG depth count (1 = flat)
     uint32_t material = 0;
     bool skinned = false;
+    double reliefScale = 1.0;    // share of brmi_scene_params::reliefSlope this mesh takes (a street's ground is paved, not a mountain range)
 };
 struct InstanceDef { uint32_t mesh; M4 model; bool reverseWinding = false; uint32_t skinSlot = 0xFFFFFFFFu; };
 
@@ -646,7 +663,7 @@ bool loadCachedMesh(brmi_scene& sc, const MeshDef& def, uint32_t meshIndex);
 
 bool buildMesh(brmi_scene& sc, const MeshDef& defIn, uint32_t meshIndex) {
     MeshDef def = defIn;
-    for (PatchDef& pd : def.patches) pd.detail = sc.params.detail;
+    for (PatchDef& pd : def.patches) { pd.detail = sc.params.detail; pd.reliefSlope = sc.params.reliefSlope > 0.0f ? sc.params.reliefSlope * def.reliefScale : 0.0; }
     if (!sc.cacheDir.empty()) { if (!loadCachedMesh(sc, def, meshIndex)) { sc.failed = true; return false; } return true; }
     std::vector<MeshletBuild> meshlets;
     std::vector<GroupBuild> groups;
@@ -1301,27 +1318,25 @@ void addLight(brmi_scene& sc, uint32_t type, V3 pos, V3 color, float intensity, 
 }
 
 // BR/src/Scene/Scene.cpp:509-535 (SetCamera) + ViewManager.cpp:19-77 (culling camera)
-void setCamera(brmi_scene& sc, V3 eye, double yaw, double pitch, double fovDeg, double zNear, double zFar) {
-    const uint32_t W = sc.params.width, H = sc.params.height;
+// `step` / `prevStep`: position on the camera path (whole numbers = the test frames; brmi_scene_camera_at walks it in fractions)
+void makeCamera(uint32_t W, uint32_t H, V3 eye, double yaw, double pitch, double fovDeg, double zNear, double zFar, double step, double prevStep,
+                brmi_camera& c, brmi_culling_camera& cc) {
     const double fov = fovDeg * (M_PI / 180.0), aspect = (double)W / (double)H;
     // camera world transform (row-vector): rotate then translate ; view = inverse
     // camera path for multi-frame tests: every step strafes, advances and turns a little; prevView = view of the previous step
-    auto worldAt = [&](uint32_t step) {
-        const double k = (double)step;
+    auto worldAt = [&](double k) {
         const V3 e{eye.x + 0.35 * k, eye.y + 0.05 * k, eye.z - 0.6 * k};
         return mul(mul(rotationX(pitch), rotationY(yaw + 0.07 * k)), translation(e));
     };
-    const uint32_t step = sc.params.cameraStep;
-    { const double k = (double)step; eye = V3{eye.x + 0.35 * k, eye.y + 0.05 * k, eye.z - 0.6 * k}; }
     M4 world = worldAt(step);
+    { const double k = step; eye = V3{eye.x + 0.35 * k, eye.y + 0.05 * k, eye.z - 0.6 * k}; }
     M4 view = inverse(world);
-    M4 prevView = step > 0 ? inverse(worldAt(step - 1)) : view;
+    M4 prevView = prevStep != step ? inverse(worldAt(prevStep)) : view;
     // XMMatrixPerspectiveFovRH(fov, aspect, NearZ = zFar, FarZ = zNear): reversed Z
     M4 proj{};
     const double h = std::cos(0.5 * fov) / std::sin(0.5 * fov), w = h / aspect;
     const double nearZ = zFar, farZ = zNear, fRange = farZ / (nearZ - farZ);
     proj.m[0][0] = w; proj.m[1][1] = h; proj.m[2][2] = fRange; proj.m[2][3] = -1.0; proj.m[3][2] = fRange * nearZ;
-    brmi_camera c{};
     std::memset(&c, 0, sizeof(c));
     c.positionWorldSpace[0] = (float)eye.x; c.positionWorldSpace[1] = (float)eye.y; c.positionWorldSpace[2] = (float)eye.z; c.positionWorldSpace[3] = 1.0f;
     store(c.view, view); store(c.viewInverse, world); store(c.projection, proj); store(c.projectionInverse, inverse(proj));
@@ -1340,9 +1355,6 @@ void setCamera(brmi_scene& sc, V3 eye, double yaw, double pitch, double fovDeg, 
     c.numDepthMips = mips; c.isOrtho = 0;
     auto nextPow2 = [](uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; };
     c.UVScaleToNextPowerOf2[0] = (float)W / (float)nextPow2(W); c.UVScaleToNextPowerOf2[1] = (float)H / (float)nextPow2(H);
-    sc.cameras.push_back(c);
-
-    brmi_culling_camera cc{};
     std::memset(&cc, 0, sizeof(cc));
     std::memcpy(cc.positionWorldSpace, c.positionWorldSpace, 16);
     cc.projX = c.projection[0][0]; cc.projY = c.projection[1][1]; cc.zNear = c.zNear;
@@ -1352,12 +1364,31 @@ void setCamera(brmi_scene& sc, V3 eye, double yaw, double pitch, double fovDeg, 
     std::memcpy(cc.viewProjection, c.viewProjection, 64);
     for (int k = 0; k < 4; k++) cc.viewZ[k] = c.view[k][2];
     std::memcpy(cc.viewInverse, c.viewInverse, 64); std::memcpy(cc.projectionInverse, c.projectionInverse, 64);
-    sc.cullingCameras.push_back(cc);
+}
 
+void setCamera(brmi_scene& sc, V3 eye, double yaw, double pitch, double fovDeg, double zNear, double zFar) {
+    const uint32_t W = sc.params.width, H = sc.params.height;
+    brmi_camera c{}; brmi_culling_camera cc{};
+    const uint32_t step = sc.params.cameraStep;
+    makeCamera(W, H, eye, yaw, pitch, fovDeg, zNear, zFar, (double)step, step > 0 ? (double)(step - 1) : (double)step, c, cc);
+    sc.cameras.push_back(c);
+    sc.cullingCameras.push_back(cc);
     brmi_view_raster_info ri{};
     ri.scissorMinX = 0; ri.scissorMinY = 0; ri.scissorMaxX = W; ri.scissorMaxY = H; ri.viewportScaleX = 1.0f; ri.viewportScaleY = 1.0f;
     sc.viewRasterInfo.push_back(ri);
 }
+
+// where each preset's camera path starts (eye, yaw, pitch); field of view 80 degrees, zNear 0.1, zFar 1000 (BasicRenderer.cpp:417-428)
+bool presetCameraBase(uint32_t preset, V3& eye, double& yaw, double& pitch) {
+    switch (preset) {
+        case BRMI_PRESET_TINY: eye = {0.2, 1.2, 3.0}; yaw = 0.08; pitch = -0.28; return true;
+        case BRMI_PRESET_SPONZA: eye = {0.6, 1.7, 16.0}; yaw = 0.10; pitch = -0.04; return true;
+        case BRMI_PRESET_BISTRO: case BRMI_PRESET_SAN_MIGUEL: eye = {0.8, 1.7, 28.0}; yaw = 0.06; pitch = -0.03; return true;
+        case BRMI_PRESET_ZORAH: eye = {0.0, 6.0, 20.0}; yaw = 0.0; pitch = -0.12; return true;
+        default: return false;
+    }
+}
+void setPresetCamera(brmi_scene& sc) { V3 eye{0, 0, 0}; double yaw = 0, pitch = 0; presetCameraBase(sc.params.preset, eye, yaw, pitch); setCamera(sc, eye, yaw, pitch, 80.0, 0.1, 1000.0); }
 
 void finishFrame(brmi_scene& sc) {
     brmi_per_frame f{};
@@ -1469,7 +1500,7 @@ void presetTiny(brmi_scene& sc, Pcg32& rng) {
     addInstance(sc, {2, translation({1.0, 0.0, -1.0})});
     addInstance(sc, {skin ? 4u : 2u, mul(rotationZ(0.3), translation({-0.8, 0.0, -1.2})), false, skin ? addSkinSlot(sc, rng, 1.6) : 0xFFFFFFFFu});
     addInstance(sc, {1, translation({0.0, 0.5, 30.0})});   // behind the camera: frustum-culled
-    setCamera(sc, {0.2, 1.2, 3.0}, 0.08, -0.28, 80.0, 0.1, 1000.0);
+    setPresetCamera(sc);
     if (sc.params.withDirectionalLight) addLight(sc, BRMI_LIGHT_DIRECTIONAL, {0, 0, 0}, {1, 1, 1}, 10.0f, {1, 0, 0}, {0, -6, -1});
     for (uint32_t i = 0; i < sc.params.numPointLights; i++)
         addLight(sc, BRMI_LIGHT_POINT, {rng.range(-2, 2), rng.range(0.2f, 1.5f), rng.range(-2, 2)}, {rng.uniform(), rng.uniform(), rng.uniform()}, 3.0f, {0, 0, 1}, {0, 0, 0});
@@ -1508,7 +1539,7 @@ void presetSponza(brmi_scene& sc, Pcg32& rng) {
         addInstance(sc, {box, mul(mul(scaling(sc1), rotationY(rng.range(0, 6.28f))), translation({rng.range(-3.5f, 3.5f), 0, rng.range(-18, 12)}))});
     }
     for (int i = 0; i < 6; i++) addInstance(sc, {blob, mul(scaling(rng.range(0.7f, 1.5f)), translation({rng.range(-3, 3), rng.range(1.0f, 5.0f), rng.range(-16, 8)}))});
-    setCamera(sc, {0.6, 1.7, 16.0}, 0.10, -0.04, 80.0, 0.1, 1000.0);
+    setPresetCamera(sc);
     if (sc.params.withDirectionalLight) addLight(sc, BRMI_LIGHT_DIRECTIONAL, {0, 0, 0}, {1, 1, 1}, 10.0f, {1, 0, 0}, {0, -6, -1});
     for (uint32_t i = 0; i < sc.params.numPointLights; i++)
         addLight(sc, BRMI_LIGHT_POINT, {rng.range(-6.5f, 6.5f), rng.range(0.3f, 9.5f), rng.range(-19.5f, 19.5f)}, {rng.uniform(), rng.uniform(), rng.uniform()}, 3.0f, {0, 0, 1}, {0, 0, 0});
@@ -1522,16 +1553,30 @@ void presetStreet(brmi_scene& sc, Pcg32& rng, double triBudget, uint32_t nMeshes
     auto lv = [&](uint32_t n0) { uint32_t l = 1; while (l < maxLevels && (n0 >> l) >= 1 && ((n0 >> l) << l) == n0) l++; return l; };
     // big statics: ground + two facades (~13 % of the budget at sizeScale 1)
     const double L = 120.0, Wd = 16.0, Hh = 24.0;
-    const double dimScale = std::sqrt(budgetMeshlets / 23437.5);
+    // params.uniqueTriangleBudget: `triBudget` counts the triangles of the MESHES ("~3.0 M tris, ~2,000 instances of ~150 meshes" --
+    // 150 meshes of 20 k triangles, each drawn a dozen times; only then can a frame test the 60-80 k meshlets row a-3 speaks of), and every one
+    // of the nInstances is placed.  Statics and props get twice the tessellation per dimension of the instanced-budget scene: 4.4 x its 0.67 M
+    // unique triangles.  0 (rounds 1-2, the golden fixtures): the budget counts instanced triangles and caps the instance count.
+    const bool uniqueBudget = sc.params.uniqueTriangleBudget != 0u;
+    const double dimScale = std::sqrt(budgetMeshlets / 23437.5) * (uniqueBudget ? 2.0 : 1.0);
     uint32_t gq = roundPow2Mult((uint32_t)std::max(1.0, std::round(16.0 * dimScale)), maxLevels);
-    { MeshDef m; m.patches.push_back(planePatch({-Wd, 0, -L}, {0, 0, 2 * L}, {2 * Wd, 0, 0}, gq * 4, gq, 0.05, 40, 201)); m.material = 0; m.lodLevels = lv(gq); meshes.push_back(m); }
+    { MeshDef m; m.patches.push_back(planePatch({-Wd, 0, -L}, {0, 0, 2 * L}, {2 * Wd, 0, 0}, gq * 4, gq, 0.05, 40, 201)); m.material = 0; m.lodLevels = lv(gq); m.reliefScale = 0.15; meshes.push_back(m); }
     uint32_t fq = gq;
+    // Facades.  Instanced budget: two 240 m walls of their own.  Unique budget: a street front is a row of houses built from the same parts -- two
+    // 30 m facade modules (the second turned round serves the other side of the street), eight of them per side, each tessellated twice as
+    // finely per metre as the single wall could afford: 5 cm triangles where the wall had 10 x 23 cm ones.
+    const uint32_t kModules = 8;
+    if (!uniqueBudget) {
     { MeshDef m; m.patches.push_back(planePatch({-Wd, 0, -L}, {0, Hh, 0}, {0, 0, 2 * L}, fq, fq * 4, 0.35, 30, 202)); m.material = 1; m.lodLevels = lv(fq); meshes.push_back(m); }
     { MeshDef m; m.patches.push_back(planePatch({Wd, 0, -L}, {0, 0, 2 * L}, {0, Hh, 0}, fq * 4, fq, 0.35, 30, 203)); m.material = 2; m.lodLevels = lv(fq); meshes.push_back(m); }
+    } else {
+        for (uint32_t k = 0; k < 2u; k++) { MeshDef m; m.patches.push_back(planePatch({-Wd, 0, 0}, {0, Hh, 0}, {0, 0, 2 * L / kModules}, fq * 2, fq * 2, 0.35, 4, 202 + k)); m.material = 1 + k; m.lodLevels = lv(fq * 2); meshes.push_back(m); }
+    }
     const uint32_t nStatics = (uint32_t)meshes.size();
     // props: sizes drawn from a skewed distribution.  The instance count is capped, so a budget beyond sizeScale 4 goes into the props'
     // tessellation (a power of two per dimension: the LOD levels halve it): the dense workloads put their triangles where the camera looks
     uint32_t propTess = 1; while (sc.params.sizeScale >= 4.0f * (float)(propTess * propTess)) propTess *= 2u;
+    if (uniqueBudget) propTess *= 2u;
     const uint32_t nProps = std::max(1u, nMeshes - nStatics);
     std::vector<uint32_t> propMeshlets(nProps);
     for (uint32_t i = 0; i < nProps; i++) {
@@ -1562,12 +1607,20 @@ void presetStreet(brmi_scene& sc, Pcg32& rng, double triBudget, uint32_t nMeshes
         meshes.push_back(m);
     }
     for (size_t i = 0; i < meshes.size(); i++) buildMesh(sc, meshes[i], (uint32_t)i);
-    for (uint32_t i = 0; i < nStatics; i++) addInstance(sc, {i, identity()});
+    if (!uniqueBudget) for (uint32_t i = 0; i < nStatics; i++) addInstance(sc, {i, identity()});
+    else {
+        addInstance(sc, {0, identity()});
+        for (uint32_t k = 0; k < kModules; k++) {
+            const double z0 = -L + 2 * L / kModules * k;
+            addInstance(sc, {1 + (k & 1u), translation({0, 0, z0})});                                                   // x = -Wd, facing +x
+            addInstance(sc, {2 - (k & 1u), mul(rotationY(M_PI), translation({0, 0, z0 + 2 * L / kModules}))});          // turned round: x = +Wd, facing -x
+        }
+    }
     // instances: fill the remaining budget
     double remaining = budgetMeshlets - (double)sc.stats.instancedTriangles / 128.0;
     uint32_t made = 0;
     Pcg32 skinRng(sc.params.seed * 977u + 5u, 77u);
-    while (made < nInstances && remaining > 0) {
+    while (made < nInstances && (remaining > 0 || uniqueBudget)) {
         uint32_t pi = rng.below(nProps);
         double scl = rng.range(0.5f, 1.8f);
         // 70 % on the street band, 30 % anywhere incl. behind the camera / behind facades
@@ -1575,12 +1628,14 @@ void presetStreet(brmi_scene& sc, Pcg32& rng, double triBudget, uint32_t nMeshes
         if (rng.uniform() < 0.7f) pos = {rng.range((float)-Wd + 1, (float)Wd - 1), 0, rng.range((float)-L + 2, 20.0f)};
         else pos = {rng.range((float)-Wd * 2.5f, (float)Wd * 2.5f), 0, rng.range((float)-L, (float)L)};
         if (foliage) pos.y = rng.range(0.0f, 3.0f);
+        // a street has a carriageway: nothing stands within 3.5 m of the camera's path (x = 0.8, z from 34 down to 4), or the frame is one prop's back
+        if (uniqueBudget && std::fabs(pos.x - 0.8) < 3.5 && pos.z > 4.0) continue;
         const M4 xf = mul(mul(scaling(scl), rotationY(rng.range(0, 6.2831f))), translation(pos));
         addInstance(sc, {nStatics + pi, xf, false, meshes[nStatics + pi].skinned ? addSkinSlot(sc, skinRng, skinRng.range(0.3f, 1.5f)) : 0xFFFFFFFFu});
         remaining -= propMeshlets[pi];
         made++;
     }
-    setCamera(sc, {0.8, 1.7, 28.0}, 0.06, -0.03, 80.0, 0.1, 1000.0);
+    setPresetCamera(sc);
     if (sc.params.withDirectionalLight) addLight(sc, BRMI_LIGHT_DIRECTIONAL, {0, 0, 0}, {1, 1, 1}, 10.0f, {1, 0, 0}, {0, -6, -1});
     for (uint32_t i = 0; i < sc.params.numPointLights; i++)
         addLight(sc, BRMI_LIGHT_POINT, {rng.range((float)-Wd + 0.5f, (float)Wd - 0.5f), rng.range(0.3f, 6.0f), rng.range(-90.0f, 30.0f)}, {rng.uniform(), rng.uniform(), rng.uniform()}, 3.0f, {0, 0, 1}, {0, 0, 0});
@@ -1604,7 +1659,7 @@ void presetZorah(brmi_scene& sc, Pcg32& rng) {
         double x = ((double)(i % side) - side / 2.0) * 3.2 + rng.range(-0.8f, 0.8f), z = -((double)(i / side)) * 3.2 + 10.0 + rng.range(-0.8f, 0.8f);
         addInstance(sc, {0, mul(mul(scaling(rng.range(0.7f, 1.3f)), rotationY(rng.range(0, 6.2831f))), translation({x, 0.0, z}))});
     }
-    setCamera(sc, {0.0, 6.0, 20.0}, 0.0, -0.12, 80.0, 0.1, 1000.0);
+    setPresetCamera(sc);
     if (sc.params.withDirectionalLight) addLight(sc, BRMI_LIGHT_DIRECTIONAL, {0, 0, 0}, {1, 1, 1}, 10.0f, {1, 0, 0}, {0, -6, -1});
     for (uint32_t i = 0; i < sc.params.numPointLights; i++)
         addLight(sc, BRMI_LIGHT_POINT, {rng.range(-40, 40), rng.range(0.5f, 4.0f), rng.range(-120, 15)}, {rng.uniform(), rng.uniform(), rng.uniform()}, 3.0f, {0, 0, 1}, {0, 0, 0});
@@ -1640,6 +1695,14 @@ static brmi_scene* createScene(const brmi_scene_params* params, const char* cach
     return sc;
 }
 brmi_scene* brmi_scene_create(const brmi_scene_params* params) { return createScene(params, nullptr); }
+
+int brmi_scene_camera_at(const brmi_scene_params* params, double step, double prevStep, brmi_camera* camera, brmi_culling_camera* cullingCamera) {
+    if (!params || !camera || !cullingCamera || params->width == 0 || params->height == 0 || !(step >= 0.0) || !(prevStep >= 0.0)) return -1;
+    V3 eye; double yaw, pitch;
+    if (!presetCameraBase(params->preset, eye, yaw, pitch)) return -1;
+    makeCamera(params->width, params->height, eye, yaw, pitch, 80.0, 0.1, 1000.0, step, prevStep, *camera, *cullingCamera);
+    return 0;
+}
 
 brmi_scene* brmi_scene_create_from_meshes(const brmi_scene_params* params, const brmi_mesh_input* meshes, uint32_t meshCount, const brmi_instance_input* instances, uint32_t instanceCount,
                                           const brmi_view_input* view, brmi_dag_build_fn build, brmi_dag_release_fn release, void* user) {

@@ -97,9 +97,23 @@ class VisibilityRenderer:
         for name in ("cameras", "cullingCameras"):
             self.device_arrays[name].copy_(self.torch.from_numpy(other.arrays[name]).to(self.device))
         self._cam_scene = other
+        self._cam_bytes = None
         self.update(frame_index)
 
+    def set_camera_device(self, cameras_dev, culling_cameras_dev, cameras_host, frame_index=0):
+        """Next frame's camera from buffers already in HBM (uint8 tensors with the bytes of Scene.camera_at): two device-to-device copies on the
+        current stream into this pass's camera buffers, then brmi_update with the host copy of the same camera."""
+        self.device_arrays["cameras"].copy_(cameras_dev, non_blocking=True)
+        self.device_arrays["cullingCameras"].copy_(culling_cameras_dev, non_blocking=True)
+        upd = capi.FrameUpdate(cameras_host.ctypes.data, self.scene.per_frame_host().ctypes.data, frame_index)
+        self._check(self.lib.brmi_update(self._h, C.byref(upd), self._s()), "brmi_update")
+        self._cam_bytes = cameras_host      # update() of a later frame repeats this camera
+
     def update(self, frame_index=0):
+        if getattr(self, "_cam_bytes", None) is not None:
+            upd = capi.FrameUpdate(self._cam_bytes.ctypes.data, self.scene.per_frame_host().ctypes.data, frame_index)
+            self._check(self.lib.brmi_update(self._h, C.byref(upd), self._s()), "brmi_update")
+            return
         src = getattr(self, "_cam_scene", self.scene)
         cam, pf = src.camera_host(), src.per_frame_host()
         upd = capi.FrameUpdate(cam.ctypes.data, pf.ctypes.data, frame_index)

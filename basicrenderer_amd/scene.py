@@ -35,7 +35,7 @@ TEXTURE_DESC_BYTES = 96      # brmi_texture_desc; its first 8 bytes are the texe
 class Scene:
     def __init__(self, preset="sponza", width=3840, height=2160, seed=0, point_lights=64, directional=True,
                  lod_levels=0, size_scale=1.0, material_features=0, camera_step=0, skinned_fraction=0.0, lod_builder="quadtree", spot_every=0, cache_dir=None, export_cache=None,
-                 detail=1.0, dag_builder=None, meshes=None, instances=None, view=None):
+                 detail=1.0, unique_budget=False, relief_slope=0.0, dag_builder=None, meshes=None, instances=None, view=None):
         """lod_builder: "quadtree" (regular grid DAG) or "own" (the library's cluster-LOD builder); dag_builder = (build_fn, release_fn)
         addresses of a caller-supplied builder with the brmi_dag_build_fn / brmi_dag_release_fn signatures (lod_builder becomes "external").
 
@@ -55,9 +55,12 @@ class Scene:
             lod_builder = "external"
         p.lodBuilder = capi.LOD_BUILDERS[lod_builder]
         p.detail = detail
+        p.uniqueTriangleBudget = 1 if unique_budget else 0
+        p.reliefSlope = relief_slope
         p.skinnedFraction1024 = int(round(skinned_fraction * 1024))
         self.preset, self.width, self.height = preset, width, height
         self._lib = lib
+        self._params = p
         # cache_dir: take every mesh from CLodCache files (include/brmi_scene.h) instead of building it; export_cache: write them
         if meshes is not None:
             if lod_builder == "quadtree":
@@ -154,6 +157,14 @@ class Scene:
 
     def camera_host(self):
         return self.arrays["cameras"]
+
+    def camera_at(self, step, prev_step=None):
+        """(cameras, cullingCameras) byte arrays of the preset's camera at `step` of its path (brmi_scene_camera_at; fractions allowed) --
+        what the reference's CameraManager writes between frames; the scene itself is not rebuilt."""
+        cam, cull = np.zeros(len(self.arrays["cameras"]), dtype=np.uint8), np.zeros(len(self.arrays["cullingCameras"]), dtype=np.uint8)
+        if self._lib.brmi_scene_camera_at(C.byref(self._params), float(step), float(step if prev_step is None else prev_step), cam.ctypes.data, cull.ctypes.data) != 0:
+            raise RuntimeError("brmi_scene_camera_at failed: this scene has no preset camera path")
+        return cam, cull
 
     def per_frame_host(self):
         return self.arrays["perFrame"]

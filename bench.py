@@ -27,12 +27,26 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-WORKLOADS = {"sponza": ("sponza", {}), "bistro": ("bistro", {}), "san_miguel": ("san_miguel", {}), "bistro_dense": ("bistro", dict(size_scale=20.0, detail=96.0))}
+# workload -> (scene preset, Scene keyword arguments, default material feature bits)
+#   bistro        BASELINE.json configs[2] as SURVEY.md 8(d) states it: ~3.0 M triangles in ~150 meshes, ~2,000 instances, every mesh through the
+#                 library's cluster-LOD builder; surfaces carry relief at every scale (reliefSlope) so that the builder's errors keep fine levels alive
+#   bistro_r2     the frame rounds 1-2 timed under that name: 3.0 M INSTANCED triangles, quadtree DAGs, smooth surfaces (2 k visible clusters)
+#   bistro_dense  the r2 street with 20 x the triangle budget and fractal relief: > 20 k visible clusters, > 150 k meshlets tested per frame
+#   san_miguel    configs[3]: 30 % of the materials alpha tested, most of them texture sampled (material features 24), as SURVEY.md 8(d) config 4 says
+WORKLOADS = {"sponza": ("sponza", {}, 0),
+             "bistro": ("bistro", dict(unique_budget=True, lod_builder="own", relief_slope=1.5), 0),
+             "bistro_r2": ("bistro", {}, 0),
+             "san_miguel": ("san_miguel", {}, 24),
+             "bistro_dense": ("bistro", dict(size_scale=20.0, detail=96.0), 0)}
+LIGHTS = {"sponza": 64, "bistro": 256, "bistro_r2": 256, "san_miguel": 256, "bistro_dense": 256}
+BASELINE_CONFIG = {"sponza": "configs[1]", "bistro": "configs[2]", "bistro_r2": "configs[2], the instanced-budget frame of rounds 1-2", "san_miguel": "configs[3]",
+                   "bistro_dense": "configs[2], dense geometry"}
+PATH_STEP = 0.02        # --camera-path: position on the preset's camera path advances by this much per frame (one unit = 0.35 m sideways, 0.6 m ahead, 4 degrees)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md)
 VALU_PEAK_WAVE_INSTS = 1.2288e12   # wave64 VALU instructions per second: 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles (MI355X_MICROARCH.md, cycle constants)
 # profiles/<tag>_traffic.json (tools/profile.sh), keyed by (workload, material feature bits): traffic of another configuration is not this one's
-PROFILE_TAG = {("sponza", 0): "r02_sponza4k", ("bistro", 0): "r02_bistro4k", ("san_miguel", 0): "r02_sanmiguel4k", ("bistro_dense", 0): "r02_bistro4k_dense",
-               ("san_miguel", 24): "r02_sanmiguel4k_alpha_tex", ("sponza", 136): "r02_sponza4k_parallax"}
+PROFILE_TAG = {("sponza", 0): "r03_sponza4k", ("bistro", 0): "r03_bistro4k", ("bistro_r2", 0): "r02_bistro4k", ("san_miguel", 0): "r02_sanmiguel4k", ("bistro_dense", 0): "r03_bistro4k_dense",
+               ("san_miguel", 24): "r03_sanmiguel4k", ("sponza", 136): "r02_sponza4k_parallax"}
 DOMINANT_KERNEL = {"raster": "k_raster", "gbuffer": "k_gbuffer", "shade": "k_shade", "cull": "k_traverse+k_cull_clusters", "clear": "k_clear_vis",
                    "light_cluster": "k_light_clustering", "depth_copy": "k_depth_copy", "hzb": "k_hzb_head", "cull2": "k_traverse+k_cull_clusters", "raster2": "k_raster"}
 
@@ -47,12 +61,17 @@ def main():
                          "bistro_dense: the Bistro-class street with 20x the triangle budget and fractal relief, so that the 1 px LOD test keeps "
                          "pixel-sized triangles: > 20 k visible clusters, > 150 k meshlets tested per 4K frame (SURVEY.md 8 a-3's regime)")
     ap.add_argument("--no-second", action="store_true", help="N = 1 only: do not add the configs[1] (Sponza) measurement as `configs1` to the line")
+    ap.add_argument("--no-dense", action="store_true", help="N = 1 only: do not add the dense-geometry measurement (bistro_dense) as `dense` to the line")
+    ap.add_argument("--camera-path", type=int, default=200,
+                    help="N = 1 only: after the static-camera region, K frames along the preset's camera path (a new camera every frame, so that phase 2 of the "
+                         "occlusion chain has work) reported as `path`; 0 skips it")
+    ap.add_argument("--repeats", type=int, default=0, help="timed regions of --steps frames each; the median is reported.  0 = 5 when --steps < 200, else 1")
     ap.add_argument("--occlusion", type=int, default=1, choices=[0, 1],
                     help="2-phase HZB occlusion culling (reference default: on, BR/include/Renderer.h:220); timed frames are steady state")
-    ap.add_argument("--lod-builder", default="quadtree", choices=["quadtree", "own"],
-                    help="own: mesh LOD DAGs from the library's cluster-LOD builder (irregular meshlets, ~384-cluster groups) instead of the generator's quadtree")
-    ap.add_argument("--material-features", type=int, default=0,
-                    help="scene generator feature bits (brmi_scene.h): 1 coat, 2 fuzz, 4 mirrored instances, 8 texture-sampled materials, 16 alpha-tested materials, 32 vertex colours, 64 OpenPBR layer textures, 128 parallax; 0 = BASELINE.json's constant-factor configuration")
+    ap.add_argument("--lod-builder", default=None, choices=["quadtree", "own"],
+                    help="own: mesh LOD DAGs from the library's cluster-LOD builder (irregular meshlets, ~384-cluster groups) instead of the generator's quadtree; default: the workload's (bistro: own)")
+    ap.add_argument("--material-features", type=int, default=None,
+                    help="default: the workload's (san_miguel: 24, else 0).  scene generator feature bits (brmi_scene.h): 1 coat, 2 fuzz, 4 mirrored instances, 8 texture-sampled materials, 16 alpha-tested materials, 32 vertex colours, 64 OpenPBR layer textures, 128 parallax; 0 = BASELINE.json's constant-factor configuration")
     ap.add_argument("--transport", default="rgb16f", choices=["rgb16f", "surface"],
                     help="what the band composition gathers: the colour channels as RGB16F (default; the composed image has no alpha plane) or the RGBA16F surface bytes")
     ap.add_argument("--composer", default="native", choices=["native", "torch"],
@@ -100,9 +119,14 @@ def main():
     out = measure(args, args.workload, world, rank, local_rank, cpu=(world == 1 and not args.no_cpu_baseline))
     if world == 1 and not args.no_second and args.workload != "sponza":
         # the metric string's own wording ("vis-buffer+resolve") is configs[1]: measured by the same run, reported beside the target frame
-        second = measure(args, "sponza", world, rank, local_rank, cpu=False)
+        second = measure(args, "sponza", world, rank, local_rank, cpu=False, path=False)
         if out is not None:
-            out["configs1"] = {k: second[k] for k in ("value", "unit", "ms_per_step", "config", "roofline", "stage_ms")}
+            out["configs1"] = {k: second[k] for k in ("value", "unit", "ms_per_step", "ms_per_step_minmax", "config", "roofline", "stage_ms") if k in second}
+    if world == 1 and not args.no_dense and args.workload != "bistro_dense":
+        # SURVEY.md 8 a-3 / a-5's regime (tens of thousands of visible clusters, pixel-sized triangles) under the same clock as the headline
+        dense = measure(args, "bistro_dense", world, rank, local_rank, cpu=False, path=False)
+        if out is not None:
+            out["dense"] = {k: dense[k] for k in ("value", "unit", "ms_per_step", "ms_per_step_minmax", "config", "roofline", "stage_ms", "serial_frame_ms") if k in dense}
     result_line = json.dumps(out) if out is not None else None
     if world > 1 or args.force_compose:
         # RCCL writes a version banner to the C stdout buffer; pushed out here, on every rank, so that rank 0's JSON is the last line
@@ -115,18 +139,23 @@ def main():
         print(result_line, flush=True)
 
 
-def measure(args, workload, n, rank, local_rank, cpu):
+def measure(args, workload, n, rank, local_rank, cpu, path=True):
     """K timed steps of one workload on this rank's GPU (all ranks call it together); rank 0 returns the result object."""
     import torch
     import torch.distributed as dist
     from basicrenderer_amd import Scene, compose
     from basicrenderer_amd.renderer import VisibilityRenderer
     dev = torch.device(f"cuda:{local_rank}")
-    lights = {"sponza": 64, "bistro": 256, "san_miguel": 256, "bistro_dense": 256}[workload]
-    preset, scene_kw = WORKLOADS[workload]
+    lights = LIGHTS[workload]
+    preset, scene_kw, default_features = WORKLOADS[workload]
+    scene_kw = dict(scene_kw)
+    features = default_features if args.material_features is None else args.material_features
+    if args.lod_builder is not None:
+        scene_kw["lod_builder"] = args.lod_builder
+    lod_builder = scene_kw.get("lod_builder", "quadtree")
     W, H = compose.frame_size(n)
     band = compose.band_of(rank, n, H)
-    scene = Scene(preset, W, H, point_lights=lights, directional=True, lod_builder=args.lod_builder, material_features=args.material_features, **scene_kw)
+    scene = Scene(preset, W, H, point_lights=lights, directional=True, material_features=features, **scene_kw)
     r = VisibilityRenderer(scene, device=dev, stats=True, band=band, occlusion=bool(args.occlusion), keepUniformLayerPlanes=args.keep_uniform_layer_planes)
     fif = args.frames_in_flight
     passes, streams, shade_streams = [r], [torch.cuda.current_stream(dev)], [None, None]
@@ -206,23 +235,30 @@ def measure(args, workload, n, rank, local_rank, cpu):
     warm_ms = r.stage_times()
     dom_stage = max(warm_ms, key=lambda k: warm_ms[k])
     r.set_timed_stages([dom_stage])
-    frame_no[0] = 0
-    if n > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    if composer:
-        composer.finish()               # the last frames' collectives are inside the timed region
-    torch.cuda.synchronize()
-    if n > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if n > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    # The timed region: EXACTLY --steps frames between a barrier + synchronize on both sides, MAX over ranks.  A short region (the driver's
+    # 20 steps are 9 ms) is one noisy sample, so it is repeated (--repeats; 5 when --steps < 200) and the MEDIAN region is reported, the
+    # spread beside it (`ms_per_step_minmax`); `steps` stays the per-region count.
+    repeats = args.repeats if args.repeats > 0 else (5 if args.steps < 200 else 1)
+    regions = []
+    for _ in range(repeats):
+        frame_no[0] = 0
+        if n > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        if composer:
+            composer.finish()               # the last frames' collectives are inside the timed region
+        torch.cuda.synchronize()
+        if n > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if n > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        regions.append(float(t.item()))
+    dt = sorted(regions)[len(regions) // 2]
 
     stage_ms = r.stage_times()          # mean over the last timed steps (HIP events on the execute stream); dominant stage only
     in_flight_ms = None
@@ -235,6 +271,9 @@ def measure(args, workload, n, rank, local_rank, cpu):
         stage_ms = {k: (stage_ms[k] if k == dom_stage else warm_ms[k]) for k in warm_ms}
     per_stage_bytes, total_bytes = r.algorithmic_bytes()
     c = r.counters()
+    path_out = None
+    if path and n == 1 and args.camera_path > 0 and args.occlusion:
+        path_out = camera_path(args, scene, passes, streams, shade_streams, r, dev)
     out = None
     if rank == 0:
         shaded = W * (band[1] - band[0]) * n            # pixels dispatched per step, all ranks
@@ -249,7 +288,7 @@ def measure(args, workload, n, rank, local_rank, cpu):
         # workload / kernel is committed.
         traffic, valu = None, None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", PROFILE_TAG.get((workload, args.material_features), "none") + "_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", PROFILE_TAG.get((workload, features), "none") + "_traffic.json")))
             # the stage's dominant kernel; template instantiations ("k_shade<0>", "k_raster<true>") are matched by base name and the
             # one that takes the most time per launch is used
             base = DOMINANT_KERNEL.get(dom, dom).split("<")[0]
@@ -268,13 +307,16 @@ def measure(args, workload, n, rank, local_rank, cpu):
         out = {
             "metric": "shaded Mpixels/s @4K (vis-buffer+resolve)", "value": round(value, 2), "unit": "Mpixels/s",
             "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "repeats": repeats, "ms_per_step_minmax": [round(min(regions) / args.steps * 1e3, 4), round(max(regions) / args.steps * 1e3, 4)],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{workload}-class procedural frame, {W}x{H}, 1 directional + {lights} point lights, "
                                    f"{scene.stats['instancedTriangles']} instanced tris, {scene.stats['instances']} instances"
-                                   + (", LOD DAGs from the library's cluster-LOD builder" if args.lod_builder == "own" else "")
-                                   + (f", material features {args.material_features} (8 = texture-sampled, 16 = alpha-tested materials)" if args.material_features else "")
+                                   + f" ({scene.stats['uniqueTriangles']} in {scene.stats['meshes']} meshes)"
+                                   + (", LOD DAGs from the library's cluster-LOD builder" if lod_builder == "own" else "")
+                                   + (f", relief slope {scene_kw['relief_slope']}" if scene_kw.get("relief_slope") else "")
+                                   + (f", material features {features} (8 = texture-sampled, 16 = alpha-tested materials)" if features else "")
                                    + (f", {n} row bands of 1080 rows + RCCL all-gather of HDR ({args.transport}, pipelined one frame deep, {'libbrmi_compose.so' if composer_used == 'native' else ('torch.distributed' if composer_used == 'torch' else composer_used)})" if composer else ""),
-                       "baseline_config": {"sponza": "configs[1]", "bistro": "configs[2]", "san_miguel": "configs[3]", "bistro_dense": "configs[2], dense geometry"}[workload],
+                       "baseline_config": BASELINE_CONFIG[workload],
                        "fps": round(1e3 / ms_per_step, 1),
                        "pixels_per_gpu": W * (band[1] - band[0]), "visible_clusters_rank0": int(c.visibleClusters),
                        "occlusion_culling": bool(args.occlusion), "visible_clusters_phase2_rank0": int(c.visibleClustersPhase2),
@@ -292,12 +334,70 @@ def measure(args, workload, n, rank, local_rank, cpu):
         if fif >= 2:
             out["roofline"]["launch_ms_in_flight"] = round(in_flight_ms, 4)
             out["serial_frame_ms"] = round(serial_ms, 4)      # one pass, one stream, frames back to back (what --frames-in-flight 1 times)
+        if path_out is not None:
+            out["path"] = path_out
         if cpu:
             out["cpu_baseline"] = cpu_baseline(scene, args.cpu_scale)
             out["configs0"] = cpu_forward_baseline()
     for p in passes:
         p.close()
     return out
+
+
+def camera_path(args, scene, passes, streams, shade_streams, r, dev):
+    """K frames along the preset's camera path, a new camera every frame (what the reference's CameraManager does between frames): the previous
+    frame's depth chain no longer matches, phase 1 rejects what it should not, and phase 2 of the occlusion chain (replay, cull, rasterise,
+    second chain build) has work -- the static-camera region times it finding nothing.  Same arrangement as the timed region (frames in flight);
+    the cameras are resident in HBM before the clock starts, each frame copies its own into the pass's camera buffers on the geometry stream."""
+    import numpy as np
+    import torch
+    K = args.camera_path
+    cams = [scene.camera_at(PATH_STEP * (k + 1), PATH_STEP * k) for k in range(K)]
+    cam_dev = [(torch.from_numpy(c).to(dev), torch.from_numpy(cc).to(dev)) for c, cc in cams]
+    fif = len(passes)
+
+    def frame(k, serial=False):
+        i = 0 if serial else k % fif
+        p = passes[i]
+        with torch.cuda.stream(streams[i]):
+            p.set_camera_device(cam_dev[k][0], cam_dev[k][1], cams[k][0])
+            p.execute(None if serial else shade_streams[i])
+
+    for k in range(min(K, 8)):          # leave the static camera: the first frames of a path see the largest jump
+        frame(k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(K):
+        frame(k)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # the same path once more, one pass, with a counter read-back per frame (untimed): how much work phase 2 had, and the stage times
+    r.set_timed_stages(None)
+    r.stage_times()
+    phase1, phase2, replayed = [], [], []
+    if fif >= 2:
+        passes[0].set_history_source(None)      # one pass alone tests against its own chain of the frame before
+    for k in range(K):
+        frame(k, serial=True)
+        if k >= K - 32:
+            c = r.counters()
+            phase1.append(int(c.visibleClusters)); phase2.append(int(c.visibleClustersPhase2)); replayed.append(int(c.replayNodes) + int(c.replayMeshlets))
+    stage_ms = r.stage_times()
+    if fif >= 2:
+        passes[0].set_history_source(passes[-1])
+    # back to the static camera for whatever is measured next
+    base = scene.camera_at(0.0)
+    for i, p in enumerate(passes):
+        with torch.cuda.stream(streams[i]):
+            p.set_camera_device(torch.from_numpy(base[0]).to(dev), torch.from_numpy(base[1]).to(dev), base[0])
+    torch.cuda.synchronize()
+    px = scene.width * scene.height
+    return {"frames": K, "ms_per_step": round(dt / K * 1e3, 4), "value": round(px / 1e6 / (dt / K), 2), "unit": "Mpixels/s",
+            "camera": f"{PATH_STEP} path units per frame ({0.35 * PATH_STEP:.4f} m sideways, {0.6 * PATH_STEP:.4f} m ahead, {0.07 * PATH_STEP * 57.2958:.3f} degrees of yaw)",
+            "visible_clusters_phase1_mean": round(float(np.mean(phase1)), 1), "visible_clusters_phase2_mean": round(float(np.mean(phase2)), 1),
+            "replayed_records_mean": round(float(np.mean(replayed)), 1), "frames_in_flight": fif,
+            "stage_ms": {k: round(v, 4) for k, v in stage_ms.items() if v > 0},
+            "stage_ms_note": "serial frames of one pass over the same path (last 32 frames); ms_per_step is the in-flight arrangement of the timed region"}
 
 
 def fail_line(args, why):

@@ -165,9 +165,17 @@ int main(int argc, char** argv) {
             if (!occlusion) throw std::runtime_error("framesInFlight = 2 needs occlusion = 1 (there is no history to share otherwise)");
             // the second pass owns a full set of resources; its phase 1 reads the first pass's depth chain and vice versa
             second = std::make_shared<PassState>(cfg);
-            second->SetScene(sb);
+            // per-frame inputs are per pass (include/brmi.h, brmi_execute_split): the second pass gets its own camera, culling camera, raster
+            // info and per-frame record; geometry, materials and lights are read-only and shared
+            brmi_scene_buffers sb2 = sb;
+            sb2.cameras = upload<brmi_camera>(scene, BRMI_ARR_CAMERAS, &sb2.cameraCount, keep);
+            sb2.cullingCameras = upload<brmi_culling_camera>(scene, BRMI_ARR_CULLING_CAMERAS, nullptr, keep);
+            sb2.viewRasterInfo = upload<brmi_view_raster_info>(scene, BRMI_ARR_VIEW_RASTER_INFO, nullptr, keep);
+            sb2.perFrame = upload<brmi_per_frame>(scene, BRMI_ARR_PER_FRAME, nullptr, keep);
+            second->SetScene(sb2);
             std::vector<brmi_resource_binding> binds2;
-            for (const brmi_resource_desc& d : second->Declare()) binds2.push_back(brmi_resource_binding{d.id, rg.allocate(d), d.bytes});
+            // at least 16 bytes each, like BrmiGraphExtension::Initialize's bindings
+            for (const brmi_resource_desc& d : second->Declare()) { brmi_resource_desc pd = d; if (pd.bytes < 16) pd.bytes = 16; binds2.push_back(brmi_resource_binding{d.id, rg.allocate(pd), pd.bytes}); }
             second->Bind(binds2, stream);
             second->Update({static_cast<const brmi_camera*>(camHost), static_cast<const brmi_per_frame*>(pfHost), 0}, stream);
             state->check(brmi_invalidate_hzb(state->get()), "brmi_invalidate_hzb");       // start the sequence over: frame 0 has no history

@@ -181,7 +181,15 @@ int         brmi_execute(brmi_pass* pass, brmi_stream stream);                  
  * `shadingStream`; events order the two halves and the pass's next frame.  Outputs are ready when `shadingStream` is.  With
  * brmi_set_history_source and two passes alternating frames on the same geometry stream (the shading stream may be shared or one per
  * pass), frame k+1's geometry half -- latency-bound launches that leave most of the chip idle -- runs beside frame k's shading half;
- * give `geometryStream` the higher priority. */
+ * give `geometryStream` the higher priority.
+ * Per-frame inputs with frames in flight: the resolve + shading half reads the camera and the per-frame record from a copy the frame's
+ * first launch makes in the pass's workspace, so the caller may rewrite `cameras`, `cullingCameras`, `viewRasterInfo` and `perFrame` for the
+ * pass's NEXT frame as soon as this call has returned -- ON `geometryStream`, before the brmi_update of that frame (stream order then puts
+ * the write behind this frame's geometry half and in front of the next frame's).  Passes that render frames in turn must not share these
+ * buffers (each pass binds its own: brmi_set_scene), and buffers every frame reads but none owns (lights, materials, objects, geometry)
+ * may only change while no frame that reads them is in flight.
+ * The stage entry points that start a frame (brmi_clear_visibility, brmi_cull(1)) issue the same waits as this call, so a graph that runs
+ * the stages itself after a split frame is ordered behind that frame's shading half. */
 int         brmi_execute_split(brmi_pass* pass, brmi_stream geometryStream, brmi_stream shadingStream);
 void        brmi_destroy(brmi_pass* pass);                                               /* Cleanup */
 const char* brmi_last_error(const brmi_pass* pass);

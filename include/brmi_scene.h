@@ -77,7 +77,12 @@ typedef struct brmi_scene_params {
     float    detail;              /* geometric detail: 0 / 1 = the smooth default surfaces; d > 1 adds seven octaves of relief below the base one, each half the
                                      wavelength and half the amplitude of the one before (first amplitude (d - 1) / 8 of the base), so that every LOD level keeps an
                                      error proportional to its edge length and the 1 px error test selects pixel-sized triangles */
-    uint32_t reserved[2];
+    uint32_t uniqueTriangleBudget;/* street presets: 1 = the preset's triangle budget counts the triangles of the meshes (Bistro-class: ~3 M in 150 meshes) and all of
+                                     its instances are placed (~2,000: ~19 M instanced triangles, SURVEY.md 8(d) config 3 / row a-3's meshlet counts);
+                                     0 = the budget counts instanced triangles and caps the instance count (the frames of rounds 1-2 and the golden fixtures) */
+    float    reliefSlope;         /* > 0: seven octaves of relief below every patch's base wavelength, octave k displacing by reliefSlope x its own wavelength
+                                     (world units, the same for every patch; `detail` scales each patch's own amplitude instead).  A LOD level's error is then
+                                     that fraction of its edge length, and the 1 px error test selects triangles of ~1 / reliefSlope pixels per edge */
 } brmi_scene_params;
 
 /* Arrays a scene exposes.  Element layouts are the brmi_types.h structs. */
@@ -117,6 +122,10 @@ enum brmi_scene_array {
 typedef struct brmi_scene brmi_scene;
 
 brmi_scene* brmi_scene_create(const brmi_scene_params* params);
+/* The preset's camera anywhere on its path, without building the scene: what a CameraManager hands the passes between frames.  `step` is a
+ * position on the path (cameraStep k of brmi_scene_params is step = k: the same bytes), `prevStep` the position of the frame before (prevView).
+ * Only params->preset / width / height are read.  Returns 0, or -1 on a bad argument. */
+int brmi_scene_camera_at(const brmi_scene_params* params, double step, double prevStep, brmi_camera* camera, brmi_culling_camera* cullingCamera);
 /* lodBuilder = EXTERNAL: `build` is called once per mesh, `release` (may be NULL) once its DAG has been consumed. */
 brmi_scene* brmi_scene_create_with_dag_builder(const brmi_scene_params* params, brmi_dag_build_fn build, brmi_dag_release_fn release, void* user);
 
