@@ -39,9 +39,16 @@ $(ORCDIR)/liboracle.so: $(ORC_SRCS) $(ORC_HDRS)
 	@mkdir -p $(ORCDIR)
 	$(CXX) $(ORCFLAGS) $(ORC_SRCS) -o $@
 
-$(LIBDIR)/libbrmi.so: $(HIP_SRCS) $(HIP_HDRS) Makefile
+# one object per translation unit (build/, git-ignored): an edit recompiles its own file only, and `make -j` compiles them side by side
+OBJDIR    := build/hip
+HIP_OBJS  := $(patsubst basicrenderer_amd/csrc/%.hip,$(OBJDIR)/%.o,$(HIP_SRCS))
+HIPCFLAGS := $(filter-out -shared,$(HIPFLAGS))
+$(OBJDIR)/%.o: basicrenderer_amd/csrc/%.hip $(HIP_HDRS) Makefile
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPCFLAGS) -c $< -o $@
+$(LIBDIR)/libbrmi.so: $(HIP_OBJS)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) $(HIP_SRCS) -o $@
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(HIP_OBJS) -o $@
 
 # multi-GPU composition: the only library that links RCCL (include/brmi_compose.h)
 $(LIBDIR)/libbrmi_compose.so: basicrenderer_amd/csrc/compose/brmi_compose.hip include/brmi_compose.h
@@ -54,6 +61,6 @@ $(LIBDIR)/brmi_host_frame: examples/host_frame.cpp basicrenderer_amd/host/brmi_p
 	$(HIPCC) -O2 -std=c++17 -Iinclude examples/host_frame.cpp -L$(LIBDIR) -lbrmi -lbrmi_scene -Wl,-rpath,'$$ORIGIN' -o $@
 
 clean:
-	rm -rf $(LIBDIR) $(ORCDIR)
+	rm -rf $(LIBDIR) $(ORCDIR) build
 
 .PHONY: all scene oracle hip compose host_example clean

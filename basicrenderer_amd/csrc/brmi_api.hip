@@ -117,6 +117,13 @@ static void compute_sizes(brmi_pass* p) {
     w.binCounts = take((uint64_t)p->binsX * p->binsY * 4);
     w.binRecords = take((uint64_t)p->binsX * p->binsY * p->binCapacity * 64);
     w.binOverflow = take((uint64_t)CNT_STRIPE_COUNT * p->binOverflowPerStripe * 64);
+    raster_tile_grid(c.width, c.height, &p->rtilesX, &p->rtilesY);
+    w.tileCounts = take((uint64_t)p->rtilesX * p->rtilesY * 4);
+    w.tileLists = take((uint64_t)p->rtilesX * p->rtilesY * p->tileCapacity * 16);
+    p->xvertClusters = (uint32_t)std::min<uint64_t>(c.maxVisibleClusters, 1ull << 21);
+    if (const char* e = std::getenv("BRMI_XVERT_CLUSTERS")) p->xvertClusters = (uint32_t)std::max(0, std::atoi(e));   // tests: clusters beyond the cache take the overflow path
+    w.xverts = take((uint64_t)std::max(1u, p->xvertClusters) * 3 * BRMI_MESHLET_MAX_VERTS * 4);
+    w.tileOverflow = take((uint64_t)p->tileOverflowCapacity * 8);
     w.clusterSetup = take((uint64_t)c.maxVisibleClusters * sizeof(ClusterSetup));
     // resolve arena: full tables (72 B per vertex + triangle slot) for up to 2^20 clusters = 9.7 GB of the 288; a configuration
     // that allows more visible clusters keeps the per-pixel path for the clusters that do not fit
@@ -212,6 +219,10 @@ int brmi_create(const brmi_config* cfg, brmi_pass** out) {
     if (const char* e = std::getenv("BRMI_BIN_OVERFLOW")) p->binOverflowPerStripe = (uint32_t)std::max(0, std::atoi(e));
     if (const char* e = std::getenv("BRMI_BIN_CAPACITY")) p->binCapacity = (uint32_t)std::min(65536, std::max(1, std::atoi(e)));   // 16-bit record indices inside a bin slice's alpha list; 65536 x 64 B x bins is far beyond any frame
     if (const char* e = std::getenv("BRMI_BIG_TRI_AREA")) p->bigTriArea = p->bigTriAreaAlpha = std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("BRMI_TILE_CAPACITY")) p->tileCapacity = (uint32_t)std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("BRMI_TILE_SLICE")) p->tileMinSlice = (uint32_t)std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("BRMI_TILE_OVERFLOW")) p->tileOverflowCapacity = (uint32_t)std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("BRMI_RASTER_MODE")) p->rasterTiles = std::string(e) == "tiles";
     if (const char* e = std::getenv("BRMI_BIG_TRI_AREA_ALPHA")) p->bigTriAreaAlpha = std::max(1, std::atoi(e));
     compute_sizes(p);
     *out = p;
@@ -759,6 +770,13 @@ int brmi_algorithmic_bytes(brmi_pass* p, uint64_t* perStage, uint64_t* total) {
     perStage[BRMI_STAGE_GBUFFER] = (8 + 52 + 4) * P;
     perStage[BRMI_STAGE_SHADE] = (4 + 48 + 8) * P;
     *total = 0; for (int i = 0; i < BRMI_STAGE_COUNT; i++) *total += perStage[i];
+    return BRMI_OK;
+}
+
+int brmi_debug_read_bin_records(brmi_pass* p, void* dst, uint64_t bytes) {
+    if (!p || !dst || !p->setupDone) return BRMI_ERR_INVALID;
+    BRMI_HIP(p, hipDeviceSynchronize());
+    BRMI_HIP(p, hipMemcpy(dst, p->wsPtr<uint8_t>(p->ws.binRecords), bytes, hipMemcpyDeviceToHost));
     return BRMI_OK;
 }
 

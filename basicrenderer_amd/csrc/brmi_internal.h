@@ -31,6 +31,7 @@ enum CounterIndex : uint32_t {
     CNT_RESOLVE_SPILL,        // some visible cluster found the resolve arena full (its pixels decode their vertices in place)
     CNT_RESOLVE_MARKED,       // the G-buffer pass marked the clusters that own a pixel (frames with more triangles than pixels)
     CNT_DEFERRED_DROPPED,     // layered pixels that found their deferred-list stripe full (impossible by construction; counted anyway)
+    CNT_TILE_OVERFLOW,        // (cluster, tile) pairs of the tile rasteriser that found the tile's list full (folded into CNT_BIN_OVERFLOW per phase)
     CNT_FRONTIER0 = 32,       // frontier sizes per BFS level: [CNT_FRONTIER0 + level]
     CNT_STRIPES = 128,        // 64 stripes x 32 words: per-stripe {instances tested, instances visible, nodes visited}
     CNT_STRIPE_COUNT = 64, CNT_STRIPE_WORDS = 32,
@@ -121,7 +122,7 @@ struct LayerUniform { unsigned long long coatWord, fuzzWord, coatFilledWord, fuz
 struct Workspace {     // byte offsets into BRMI_RES_WORKSPACE
     uint64_t counters, frontierA, frontierB, buckets, tempVisible, bitmask1, bitmask2, wordPrefix, blockSums,
              instanceBitBase, segPrefix, meshLevelWidth, planes, replayNodes, replayBuckets, lightVS, lightMeta, clusterPages, clusterHits, pageTotal, lightHitMasks, binCounts, binRecords, binOverflow, clusterSetup, resolveVerts, resolveTris, matWords, shadeTables, lutF, frameConst, objConst, matConst, deferredPixels, usedClusters,
-             frameSnapshot, clusterUv, binAlpha, overflowAlpha, resolveUVs, resolveColors, alphaMats, shadeRows, shadeAvgs, ggxQuads, shadeLights, clusterList, listEntries, layerUniform, frameClearBytes, total;
+             frameSnapshot, tileCounts, tileLists, tileOverflow, xverts, clusterUv, binAlpha, overflowAlpha, resolveUVs, resolveColors, alphaMats, shadeRows, shadeAvgs, ggxQuads, shadeLights, clusterList, listEntries, layerUniform, frameClearBytes, total;
 };
 
 }  // namespace brmi
@@ -160,6 +161,9 @@ struct brmi_pass {
     uint32_t numLightClusters = 0, lightPagePool = 0;
     uint32_t binOverflowPerStripe = 1u << 14;       // 64 stripes x 16384 records x 64 B = 64 MB
     uint32_t binsX = 0, binsY = 0, binCapacity = 8192;   // raster bins: 256 px x 16 rows, binCapacity records of 64 B each (BRMI_BIN_CAPACITY): 1 GB at 4K, walked in slices of 1024
+    bool rasterTiles = false;     // BRMI_RASTER_MODE=tiles (opaque scenes): cluster-granular sort-middle (k_raster_tile_lists / k_raster_tiles) instead of the triangle bins -- bit-exact, a fifth of the HBM traffic, 20-40 % slower (profiles/r03_experiments.md)
+    uint32_t rtilesX = 0, rtilesY = 0, tileCapacity = 1024, tileOverflowCapacity = 1u << 20, tileMinSlice = 128;
+    uint32_t xvertClusters = 0;   // clusters the screen-vertex cache holds (1.5 KB each): min(maxVisibleClusters, 2^21); BRMI_XVERT_CLUSTERS   // 64 x 64 px raster tiles, cluster indices per tile list (BRMI_TILE_CAPACITY)
     uint32_t deferredStripeCapacity = 0;   // entries per deferred-pixel stripe
     uint32_t resolveCapacity = 0;   // vertices (and triangles) the resolve arena holds
     uint32_t rasterGrid = 8192;  // single-wave workgroups of k_raster (BRMI_RASTER_GRID)
@@ -212,6 +216,7 @@ ShadeTables shade_tables_of(const brmi_pass* p);
 int launch_clear(brmi_pass* p, hipStream_t s);
 int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s);
 int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s);
+void raster_tile_grid(uint32_t width, uint32_t height, uint32_t* tilesX, uint32_t* tilesY);      // tiles of the cluster-granular rasteriser (brmi_raster.hip)
 int launch_depth_copy(brmi_pass* p, hipStream_t s);
 int launch_hzb(brmi_pass* p, hipStream_t s, bool fromVisibility, bool onlyIfPhase2Drew);
 int launch_gbuffer(brmi_pass* p, hipStream_t s);

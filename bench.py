@@ -47,6 +47,7 @@ VALU_PEAK_WAVE_INSTS = 1.2288e12   # wave64 VALU instructions per second: 256 CU
 # profiles/<tag>_traffic.json (tools/profile.sh), keyed by (workload, material feature bits): traffic of another configuration is not this one's
 PROFILE_TAG = {("sponza", 0): "r03_sponza4k", ("bistro", 0): "r03_bistro4k", ("bistro_r2", 0): "r02_bistro4k", ("san_miguel", 0): "r02_sanmiguel4k", ("bistro_dense", 0): "r03_bistro4k_dense",
                ("san_miguel", 24): "r03_sanmiguel4k", ("sponza", 136): "r02_sponza4k_parallax"}
+_STREAM_CACHE = {}
 DOMINANT_KERNEL = {"raster": "k_raster", "gbuffer": "k_gbuffer", "shade": "k_shade", "cull": "k_traverse+k_cull_clusters", "clear": "k_clear_vis",
                    "light_cluster": "k_light_clustering", "depth_copy": "k_depth_copy", "hzb": "k_hzb_head", "cull2": "k_traverse+k_cull_clusters", "raster2": "k_raster"}
 
@@ -170,11 +171,20 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True):
         mode = os.environ.get("BRMI_BENCH_STREAMS", "split")
         if mode == "split":
             # the passes share a geometry stream (higher priority: its launches are latency-bound and want CU slots the moment they are ready)
-            geometry, shading = torch.cuda.Stream(dev, priority=-1), torch.cuda.Stream(dev, priority=0)
-            # a shading stream per pass: a frame's pixel pass may start on the tail of the frame before's k_shade (-1 % against one shared stream)
-            streams, shade_streams = [geometry] * fif, [shading] + [torch.cuda.Stream(dev, priority=0) for _ in range(fif - 1)]
+            # the streams are made once per process and shared by every workload measured in it: HIP maps streams onto a few hardware queues,
+            # and a second set of streams created for the third workload of a run landed on the queues of the first (geometry and shading
+            # halves serialised: the dense frame took 1.84 ms in flight against 0.97 ms measured on its own)
+            key = (str(dev), fif, "split")
+            if key not in _STREAM_CACHE:
+                geometry, shading = torch.cuda.Stream(dev, priority=-1), torch.cuda.Stream(dev, priority=0)
+                # a shading stream per pass: a frame's pixel pass may start on the tail of the frame before's k_shade (-1 % against one shared stream)
+                _STREAM_CACHE[key] = ([geometry] * fif, [shading] + [torch.cuda.Stream(dev, priority=0) for _ in range(fif - 1)])
+            streams, shade_streams = _STREAM_CACHE[key]
         else:
-            streams, shade_streams = [torch.cuda.Stream(dev) for _ in range(fif)], [None] * fif        # one stream per pass, whole frames
+            key = (str(dev), fif, "whole")
+            if key not in _STREAM_CACHE:
+                _STREAM_CACHE[key] = ([torch.cuda.Stream(dev) for _ in range(fif)], [None] * fif)        # one stream per pass, whole frames
+            streams, shade_streams = _STREAM_CACHE[key]
 
     hdr = r.hdr_tensor()
     # all-gather of frame k overlaps the rendering of frame k + 1; the colour channels travel (RGB16F, 6 B/px): the lit target's alpha is constant

@@ -233,6 +233,9 @@ int brmi_algorithmic_bytes(brmi_pass* pass, uint64_t* perStage /* [BRMI_STAGE_CO
  * (correctly rounded a/b and sqrt(a), round-to-nearest-even float->half) against IEEE on the host. */
 int brmi_debug_arith(const float* a, const float* b, float* outDiv, float* outSqrt, uint32_t* outHalfBits, uint32_t n, brmi_stream stream);
 
+/* Experiments only: the first `bytes` of the raster bin-record region of the workspace (instrumented builds park per-workgroup time stamps there). */
+int brmi_debug_read_bin_records(brmi_pass* pass, void* dst, uint64_t bytes);
+
 /* The shading pass's in-range forms of 1 / a, sqrt(a) and 1 / sqrt(a) (brmi_device.h: the IEEE expansions without their scaling prologue and
  * fix-up epilogue for 2^-63 <= a < 2^63, the general form elsewhere): a test compares them bit for bit with the host's IEEE results. */
 int brmi_debug_arith_in_range(const float* a, float* outRcp, float* outSqrt, float* outRsqrt, uint32_t n, brmi_stream stream);
