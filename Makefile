@@ -60,7 +60,13 @@ host_example: $(LIBDIR)/brmi_host_frame
 $(LIBDIR)/brmi_host_frame: examples/host_frame.cpp basicrenderer_amd/host/brmi_passes.hpp $(LIBDIR)/libbrmi.so $(LIBDIR)/libbrmi_scene.so
 	$(HIPCC) -O2 -std=c++17 -Iinclude examples/host_frame.cpp -L$(LIBDIR) -lbrmi -lbrmi_scene -Wl,-rpath,'$$ORIGIN' -o $@
 
+# tools/valu_issue_probe.hip: what a SIMD issues per cycle (profiles/r03_valu_issue_probe.txt is its output on an MI355X)
+probe: build/valu_issue_probe
+build/valu_issue_probe: tools/valu_issue_probe.hip
+	@mkdir -p build
+	$(HIPCC) --offload-arch=gfx950 -O2 $< -o $@
+
 clean:
 	rm -rf $(LIBDIR) $(ORCDIR) build
 
-.PHONY: all scene oracle hip compose host_example clean
+.PHONY: all scene oracle hip compose host_example probe clean

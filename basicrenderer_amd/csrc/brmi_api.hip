@@ -124,6 +124,7 @@ static void compute_sizes(brmi_pass* p) {
     if (const char* e = std::getenv("BRMI_XVERT_CLUSTERS")) p->xvertClusters = (uint32_t)std::max(0, std::atoi(e));   // tests: clusters beyond the cache take the overflow path
     w.xverts = take((uint64_t)std::max(1u, p->xvertClusters) * 3 * BRMI_MESHLET_MAX_VERTS * 4);
     w.tileOverflow = take((uint64_t)p->tileOverflowCapacity * 8);
+    w.debugStamps = take(4096);      // instrumented builds (-DBRMI_TILE_STAMPS) park per-phase cycle sums here
     w.clusterSetup = take((uint64_t)c.maxVisibleClusters * sizeof(ClusterSetup));
     // resolve arena: full tables (72 B per vertex + triangle slot) for up to 2^20 clusters = 9.7 GB of the 288; a configuration
     // that allows more visible clusters keeps the per-pixel path for the clusters that do not fit
@@ -776,7 +777,9 @@ int brmi_algorithmic_bytes(brmi_pass* p, uint64_t* perStage, uint64_t* total) {
 int brmi_debug_read_bin_records(brmi_pass* p, void* dst, uint64_t bytes) {
     if (!p || !dst || !p->setupDone) return BRMI_ERR_INVALID;
     BRMI_HIP(p, hipDeviceSynchronize());
-    BRMI_HIP(p, hipMemcpy(dst, p->wsPtr<uint8_t>(p->ws.binRecords), bytes, hipMemcpyDeviceToHost));
+    // (bytes with bit 63 set: the stamp region instead, where instrumented builds of k_raster park their phase sums)
+    const bool overflowRegion = (bytes >> 63) != 0; bytes &= ~(1ull << 63);
+    BRMI_HIP(p, hipMemcpy(dst, overflowRegion ? p->wsPtr<uint8_t>(p->ws.debugStamps) : p->wsPtr<uint8_t>(p->ws.binRecords), bytes, hipMemcpyDeviceToHost));
     return BRMI_OK;
 }
 

@@ -213,6 +213,17 @@ BRMI_DEV float ior_to_f0(float ior) { const float s = max2(ior, 1.0f); const flo
 // Read-only data produced by an earlier kernel, viewed through the constant address space: with a wave-uniform address
 // the compiler then selects scalar (s_load) instead of vector loads.
 template <typename T> BRMI_DEV const __attribute__((address_space(4))) T* kconst(const T* p) { return (const __attribute__((address_space(4))) T*)p; }
+// A whole record through the constant address space (word by word: the compiler merges the words into s_load_dwordxN when the address is
+// wave-uniform).  For records an EARLIER kernel wrote or the host uploaded -- the scalar cache is not coherent with this launch's own stores.
+template <typename T> BRMI_DEV T load_uniform(const T* p) {
+    static_assert(sizeof(T) % 4 == 0, "whole dwords");
+    T r;
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&r);
+    const __attribute__((address_space(4))) uint32_t* src = (const __attribute__((address_space(4))) uint32_t*)p;
+#pragma unroll
+    for (uint32_t i = 0; i < sizeof(T) / 4; i++) dst[i] = src[i];
+    return r;
+}
 // HasOpenPBRTexture (utilities.hlsli:643-646) for any of the six coat / fuzz slots of an OpenPBR record
 template <typename Op> BRMI_DEV bool openpbr_has_textures(Op op) {
     bool any = false;

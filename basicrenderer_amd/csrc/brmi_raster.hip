@@ -68,6 +68,7 @@ struct RasterArgs {
     uint32_t visW, visH, tilesX, bandY0, bandY1;
     // cluster-granular sort-middle (k_raster_tile_lists / k_raster_tiles): per 64 x 64 px screen tile a list of visible-cluster indices
     uint32_t* tileCounts; struct TileEntry* tileLists; uint32_t tileCapacity, rtilesX, rtilesY, tileMinSlice;
+    unsigned long long* debugStamps;                     // instrumented builds only
     float* xverts; uint32_t xvertClusters;               // screen-vertex cache: 384 floats per visible cluster, for clusters [0, xvertClusters)
     uint2* tileOverflow; uint32_t tileOverflowCapacity;      // (cluster, tile) pairs that found their list full
 };
@@ -248,8 +249,10 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
     __shared__ uint32_t rowOff[65];
     const brmi_scene_buffers& sc = a.sc;
     const uint32_t lane = threadIdx.x;
-    const uint32_t first = a.firstCounter == 0xFFFFFFFFu ? 0u : a.counters[a.firstCounter];
-    const uint32_t count = a.counters[a.countCounter];
+    // wave-uniform by construction; said so to the compiler, which then fetches a cluster's records with scalar loads (one s_load per record
+    // instead of a chain of vector loads with a wait after each: the fetch was 11-29 % of the kernel's wave-cycles, measured with phase stamps)
+    const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.firstCounter == 0xFFFFFFFFu ? 0u : a.counters[a.firstCounter]));
+    const uint32_t count = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.counters[a.countCounter]);
     const GlobalSink gsink{a.vis, a.tilesX, a.debugFlags};
     // static round-robin over clusters: a shared queue head saturates at ~90 dequeues/us (MI355X_MICROARCH.md, row
     // "dequeue"), which is slower than the work itself once big triangles are handed off
@@ -262,23 +265,42 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
     if (!(a.debugFlags & 0x40000000u)) { while (split < 8u && count * split * 2u <= gridDim.x) split *= 2u; }
     const uint32_t parts = max(split >> 1, 1u), lanesPerPart = 64u / parts;      // shares of a pass
     const uint32_t items = count * split;
+#ifdef BRMI_TILE_STAMPS
+    unsigned long long kph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, kprev = __builtin_amdgcn_s_memtime();
+#define KSTAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); kph[k] += now_ - kprev; kprev = now_; } while (0)
+#else
+#define KSTAMP(k) do { } while (0)
+#endif
     for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
+        KSTAMP(7);
         const uint32_t c = item / split, sub = item % split;
         const uint32_t clusterIndex = first + c;
-        const ClusterSetup cs = a.setup[clusterIndex];        // resolved by the compaction kernel: one hop instead of six
+        const ClusterSetup cs = load_uniform(&a.setup[clusterIndex]);        // resolved by the compaction kernel: one hop instead of six
         const uint32_t vertCount = cs.counts & 0xFFu, triCount = (cs.counts >> 8) & 0xFFu, posFormat = (cs.counts >> 16) & 0xFFu;
         const uint32_t passLo = split > 1u ? (sub / parts) * 64u : 0u, passHi = split > 1u ? min(passLo + 64u, triCount) : triCount;
         const uint32_t part = sub % parts;
         if (passLo + part * lanesPerPart >= triCount) continue;      // (wave-uniform) no triangle of this share exists
         const bool reverseWinding = ((cs.counts >> 24) & 1u) != 0u;
-        const brmi_view_raster_info ri = sc.viewRasterInfo[cs.viewId];
+        const brmi_view_raster_info ri = load_uniform(&sc.viewRasterInfo[cs.viewId]);
         const float visWidth = (float)(ri.scissorMaxX - ri.scissorMinX), visHeight = (float)(ri.scissorMaxY - ri.scissorMinY);
         const float sMinXf = (float)ri.scissorMinX, sMinYf = (float)ri.scissorMinY;
-        const float* oc = a.objConst + (size_t)cs.perObjectIndex * 36u;
-        const m4 mvp = load_m4(oc);
+        const auto oc = kconst(a.objConst + (size_t)cs.perObjectIndex * 36u);
+        m4 mvp;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) mvp.m[i][j] = oc[i * 4 + j];
         const f4 modelViewZ{oc[32], oc[33], oc[34], oc[35]};
         const uint8_t* posBase = cs.posBase;
         const uint8_t* triBase = cs.triBase;
+        // the index bytes of both passes are requested before the vertex stage: behind the barrier they were a round trip of their own in
+        // front of every pass's setup (15-27 % of the kernel's wave-cycles)
+        uint32_t pi0[2] = {0u, 0u}, pi1[2] = {0u, 0u}, pi2[2] = {0u, 0u};
+#pragma unroll
+        for (uint32_t k = 0; k < 2u; k++) {
+            const uint32_t t = passLo + k * 64u + lane;
+            if (passLo + k * 64u < passHi && t < triCount) { pi0[k] = triBase[t * 3u]; pi1[k] = triBase[t * 3u + 1u]; pi2[k] = triBase[t * 3u + 2u]; }
+        }
         // compute skinning, folded into the vertex fetch (softwareRaster.hlsl:349-360)
         const bool skinVerts = (cs.counts & (BRMI_CS_SKINNED | BRMI_CS_JOINTS)) == (BRMI_CS_SKINNED | BRMI_CS_JOINTS);
         const uint32_t skinSlot = skinVerts ? sc.perMeshInstance[cs.instanceIndex].skinningInstanceSlot : 0xFFFFFFFFu;
@@ -287,6 +309,8 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
         AlphaMaterial amat{};
         if (alphaCluster) { cu = a.clusterUv[clusterIndex]; amat = a.alphaMats[cs.materialDataIndex]; }
 
+        if (a.debugFlags & 0x100) { const float probe_ = mvp.m[0][0] + modelViewZ.x + visWidth; if (probe_ == 1234.5f) a.counters[CNT_DROPPED_CLUSTERS] = 1u; }   // (instrumented runs: the cluster's records have arrived)
+        KSTAMP(0);
         // vertex stage -> LDS (softwareRaster.hlsl:339-387)
         for (uint32_t v = lane; v < vertCount; v += 64) {
             f3 lp{0.0f, 0.0f, 0.0f};
@@ -310,6 +334,7 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
             if (alphaCluster) { const f2 uv = decode_uv(cu, v); siw[v] = invW; su[v] = uv.x; sv[v] = uv.y; }
         }
         __syncthreads();
+        KSTAMP(1);
 
         // triangle stage: lane = triangle (softwareRaster.hlsl:416-611)
         for (uint32_t waveBase = passLo; waveBase < passHi; waveBase += 64) {
@@ -319,7 +344,8 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
             int minX = 0, minY = 0, maxX = -1, maxY = -1;
             AlphaRecord arec{};
             if (active) {
-                uint32_t i0 = triBase[t * 3u], i1 = triBase[t * 3u + 1u], i2 = triBase[t * 3u + 2u];
+                const uint32_t pk = (waveBase - passLo) >> 6;
+                uint32_t i0 = pk ? pi0[1] : pi0[0], i1 = pk ? pi1[1] : pi1[0], i2 = pk ? pi2[1] : pi2[0];
                 if (reverseWinding) { const uint32_t tmp = i1; i1 = i2; i2 = tmp; }
                 if (alphaCluster) { arec.tri = AlphaTri{siw[i0], siw[i1], siw[i2], f2{su[i0], sv[i0]}, f2{su[i1], sv[i1]}, f2{su[i2], sv[i2]}}; arec.materialDataIndex = cs.materialDataIndex; }
                 const float s0x = sx[i0], s0y = sy[i0], s1x = sx[i1], s1y = sy[i1], s2x = sx[i2], s2y = sy[i2];
@@ -364,6 +390,7 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
             // all lanes stepping side by side (a lower band of a multi-GPU frame starts thousands of rows below the top of a large box)
             float band_b0 = row_b0, band_b1 = row_b1;
             if (entries > 0) for (int y = minY; y < yLo; y++) { band_b0 += dy_b0; band_b1 += dy_b1; }
+            KSTAMP(2);
             // Small boxes: global atomics.  lane = triangle leaves most lanes idle (culled triangles, boxes of very different
             // size), so the rows of the batch's small triangles are re-dealt to the lanes: an exclusive scan of the row counts,
             // the setup of every triangle parked in LDS, then lane k takes rows k, k + 64, ... of the concatenated row list.
@@ -405,6 +432,7 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
                     __syncthreads();
                 }
             }
+            KSTAMP(3);
             // A few bins per triangle: every lane appends its own records.  A slot in a bin costs an atomic with return on the
             // bin's counter (~2 us round trip, and the triangles of a meshlet hit the same few bins), so the wave first counts
             // its records per bin in an LDS window over the bins it touches, reserves each bin's run with ONE global atomic,
@@ -451,6 +479,7 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
                 }
                 if (windowed) __syncthreads();    // binBase is reused by the next batch
             }
+            KSTAMP(4);
             // many bins: the whole wave emits the triangle.  lane L owns bands band0 + L, band0 + L + 64, ...: it steps the row
             // start down to each of them (the same additions the serial loop makes) and appends the band's record to every strip.
             uint64_t coop = __ballot(entries > COOP_ENTRIES && !(a.debugFlags & 2));
@@ -489,9 +518,13 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
                     }
                 }
             }
+            KSTAMP(5);
         }
         __syncthreads();   // LDS is reused by the next cluster
     }
+#ifdef BRMI_TILE_STAMPS
+    if (lane < 8u && (a.debugFlags & 0x100)) { unsigned long long v = 0; for (int k = 0; k < 8; k++) if (lane == (uint32_t)k) v = kph[k]; atomicAdd(a.debugStamps + 16u + lane, v); }
+#endif
 }
 
 // One workgroup per bin: the bin's records are walked one lane per row (16 records at a time) with LDS atomic-min into a tile
@@ -1093,7 +1126,7 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
     a.alphaMats = p->wsPtr<AlphaMaterial>(p->ws.alphaMats);
     if (p->sceneHasAlphaTest) if (int rc = ensure_frame_constants(p, s)) return rc;
     a.tileCounts = p->wsPtr<uint32_t>(p->ws.tileCounts); a.tileLists = p->wsPtr<TileEntry>(p->ws.tileLists); a.tileCapacity = p->tileCapacity;
-    a.xverts = p->wsPtr<float>(p->ws.xverts); a.xvertClusters = p->xvertClusters;
+    a.xverts = p->wsPtr<float>(p->ws.xverts); a.xvertClusters = p->xvertClusters; a.debugStamps = p->wsPtr<unsigned long long>(p->ws.debugStamps);
     a.rtilesX = p->rtilesX; a.rtilesY = p->rtilesY; a.tileOverflow = p->wsPtr<uint2>(p->ws.tileOverflow); a.tileOverflowCapacity = p->tileOverflowCapacity;
     if (p->rasterTiles && !p->sceneHasAlphaTest) {
         // cluster-granular sort-middle: lists, tiles (only the tile rows of this GPU's band), overflow pairs + list reset

@@ -44,6 +44,10 @@ BASELINE_CONFIG = {"sponza": "configs[1]", "bistro": "configs[2]", "bistro_r2": 
 PATH_STEP = 0.02        # --camera-path: position on the preset's camera path advances by this much per frame (one unit = 0.35 m sideways, 0.6 m ahead, 4 degrees)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md)
 VALU_PEAK_WAVE_INSTS = 1.2288e12   # wave64 VALU instructions per second: 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles (MI355X_MICROARCH.md, cycle constants)
+# ... and what tools/valu_issue_probe.hip measured on the box (profiles/r03_valu_issue_probe.txt): independent v_fma / v_mul / v_mov streams at 2-4 waves
+# per SIMD issue one wave64 instruction per 2.3-2.5 cycles per SIMD at the 2.2-2.4 GHz the chip holds (0.93-1.06 T/s); three-source selects /
+# medians one per 4.2 cycles, v_rcp / v_exp / v_sqrt one per 8.2 cycles (0.30 T/s)
+VALU_PEAK_MEASURED = 0.96e12
 # profiles/<tag>_traffic.json (tools/profile.sh), keyed by (workload, material feature bits): traffic of another configuration is not this one's
 PROFILE_TAG = {("sponza", 0): "r03_sponza4k", ("bistro", 0): "r03_bistro4k", ("bistro_r2", 0): "r02_bistro4k", ("san_miguel", 0): "r02_sanmiguel4k", ("bistro_dense", 0): "r03_bistro4k_dense",
                ("san_miguel", 24): "r03_sanmiguel4k", ("sponza", 136): "r02_sponza4k_parallax"}
@@ -310,7 +314,9 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True):
                     wi = rec["valu_wave_insts_per_launch"]
                     # the microarchitecture guide's issue peak: one wave64 VALU instruction per 2 cycles per SIMD, 1024 SIMDs, 2.4 GHz
                     valu = {"wave_insts": int(wi), "insts_per_px": round(wi * 64.0 / (W * (band[1] - band[0])), 1), "peak_wave_insts_per_s": VALU_PEAK_WAVE_INSTS,
-                            "frac": round(wi / dom_s / VALU_PEAK_WAVE_INSTS, 5), "source": "SQ_INSTS_VALU of the committed profile / this run's launch time"}
+                            "frac": round(wi / dom_s / VALU_PEAK_WAVE_INSTS, 5), "peak_measured_wave_insts_per_s": VALU_PEAK_MEASURED,
+                            "frac_of_measured_peak": round(wi / dom_s / VALU_PEAK_MEASURED, 5),
+                            "source": "SQ_INSTS_VALU of the committed profile / this run's launch time; measured peak: tools/valu_issue_probe.hip (full-rate instructions)"}
         except (OSError, ValueError, KeyError):
             pass
         hbm_frac = achieved / HBM_PEAK_GBS
