@@ -56,8 +56,11 @@ struct TriLane {
     float invW0, invW1, invW2; float2 uv0, uv1, uv2;
 };
 
+// voteMode: how WaveActiveAnyTrue(rectWidth > 4) (softwareRaster.hlsl:502) is evaluated.  0 = over the 64 triangles of a wave64 (the
+// restatement's choice); 1 = over 32-triangle groups, as wave32 hardware would (NVIDIA, RDNA); 2 = always true;
+// 3 = always false.  Modes 1-3 exist to MEASURE how much of the image depends on that choice (tests/test_oracle_cpu.py).
 void rasterCluster(const brmi_scene_buffers& sc, const brmi_visible_cluster& pc, uint32_t clusterIndex, uint64_t* vis, uint32_t visW, uint32_t visH,
-                   uint32_t bandY0, uint32_t bandY1) {
+                   uint32_t bandY0, uint32_t bandY1, int voteMode = 0) {
     const uint32_t viewID = vcViewID(pc), instanceID = vcInstanceID(pc), localMeshlet = vcLocalMeshlet(pc);
     const uint8_t* slab = sc.slabs[vcSlabDescriptor(pc)];
     const uint32_t pageOff = vcPageByteOffset(pc);
@@ -151,10 +154,13 @@ void rasterCluster(const brmi_scene_buffers& sc, const brmi_visible_cluster& pc,
             L.active = true;
             any = any || (L.rectWidth > 4);
         }
-        const bool useScanlineRanges = any;   // WaveActiveAnyTrue over the lanes still active
+        bool anyHalf[2] = {false, false};
+        for (uint32_t l = 0; l < 64; l++) if (lanes[l].active && lanes[l].rectWidth > 4) anyHalf[l >> 5] = true;
         for (uint32_t l = 0; l < 64; l++) {
             const TriLane& L = lanes[l];
             if (!L.active) continue;
+            // WaveActiveAnyTrue over the lanes still active
+            const bool useScanlineRanges = voteMode == 0 ? any : voteMode == 1 ? anyHalf[l >> 5] : voteMode == 2;
             const uint32_t t = waveBase + l;
             float sb0 = L.row_b0, sb1 = L.row_b1;
             for (int py = L.minY; py <= L.maxY; py++) {
@@ -206,6 +212,14 @@ int orc_raster(const brmi_scene_buffers* sc, const brmi_visible_cluster* cluster
     if (bandY1 == 0) { bandY0 = 0; bandY1 = H; }
 #pragma omp parallel for schedule(dynamic, 16) num_threads(threads > 0 ? threads : 1)
     for (int64_t i = 0; i < (int64_t)count; i++) rasterCluster(*sc, clusters[first + i], first + (uint32_t)i, vis, W, H, bandY0, bandY1);
+    return 0;
+}
+
+// the same with the wave vote evaluated another way (rasterCluster: voteMode) -- measurement only
+int orc_raster_vote(const brmi_scene_buffers* sc, const brmi_visible_cluster* clusters, uint32_t first, uint32_t count,
+                    uint64_t* vis, uint32_t W, uint32_t H, int voteMode, int threads) {
+#pragma omp parallel for schedule(dynamic, 16) num_threads(threads > 0 ? threads : 1)
+    for (int64_t i = 0; i < (int64_t)count; i++) rasterCluster(*sc, clusters[first + i], first + (uint32_t)i, vis, W, H, 0, H, voteMode);
     return 0;
 }
 

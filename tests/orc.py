@@ -129,6 +129,13 @@ class OracleFrame:
         lib().orc_raster(C.byref(self.sb), P(self.clusters), u32(first), u32(cnt), P(self.vis), u32(W), u32(H), u32(band[0]), u32(band[1]), C.c_int(self.threads))
         return self.vis
 
+    def raster_vote(self, vote_mode):
+        """The visibility image with the rasteriser's wave vote (softwareRaster.hlsl:502) evaluated another way: 0 wave64 (= raster()), 1 over
+        32-triangle groups (wave32 hardware), 2 always scanline ranges, 3 never.  Measurement only; self.vis is untouched."""
+        vis = np.full((self.H, self.W), 0xFFFFFFFFFFFFFFFF, dtype=np.uint64)
+        lib().orc_raster_vote(C.byref(self.sb), P(self.clusters), u32(0), u32(self.count), P(vis), u32(self.W), u32(self.H), C.c_int(vote_mode), C.c_int(self.threads))
+        return vis
+
     def depth_copy(self):
         self.depth = np.zeros((self.H, self.W), dtype=np.float32)
         lib().orc_depth_copy(P(self.vis), P(self.depth), u64(self.W * self.H), C.c_int(self.threads))
