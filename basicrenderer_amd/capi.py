@@ -129,11 +129,13 @@ class Counters(C.Structure):
 class ComposeConfig(C.Structure):
     """brmi_compose_config (include/brmi_compose.h)."""
     _fields_ = [("structSize", u32), ("width", u32), ("bandY0", u32), ("bandY1", u32), ("bytesPerPixel", u32), ("transport", u32), ("depth", u32),
-                ("rank", u32), ("nRanks", u32), ("device", C.c_int32), ("reserved", u32 * 6)]
+                ("rank", u32), ("nRanks", u32), ("device", C.c_int32), ("path", u32), ("waitTimeoutMs", u32), ("reserved", u32 * 4)]
 
 
 COMPOSE_EXPORTS = ["brmi_compose_unique_id", "brmi_compose_create", "brmi_compose_staging_bytes", "brmi_compose_output_bytes", "brmi_compose_bind",
-                   "brmi_compose_submit", "brmi_compose_finish", "brmi_compose_destroy", "brmi_compose_last_error"]
+                   "brmi_compose_submit", "brmi_compose_finish", "brmi_compose_destroy", "brmi_compose_last_error",
+                   "brmi_compose_alloc_shared", "brmi_compose_export", "brmi_compose_import", "brmi_compose_last_wait_status"]
+COMPOSE_HANDLE_BYTES = 160
 _compose_lib = None
 
 
@@ -161,6 +163,10 @@ def compose_lib():
         lib.brmi_compose_submit.argtypes = [vp, vp, vp]
         lib.brmi_compose_finish.argtypes = [vp, vp, C.POINTER(vp)]
         lib.brmi_compose_destroy.argtypes = [vp]
+        lib.brmi_compose_alloc_shared.argtypes = [vp]
+        lib.brmi_compose_export.argtypes = [vp, C.c_char_p]
+        lib.brmi_compose_import.argtypes = [vp, C.c_char_p, u32]
+        lib.brmi_compose_last_wait_status.argtypes = [vp]
         lib.brmi_compose_destroy.restype = None
         lib.brmi_compose_last_error.argtypes = [vp]
         lib.brmi_compose_last_error.restype = C.c_char_p

@@ -181,3 +181,91 @@ class NativeBandComposer:
             self.close()
         except Exception:
             pass
+
+
+class _DevicePointer:
+    """A device allocation owned by somebody else (here: libbrmi_compose.so's shared buffers) as a torch tensor, through the array interface."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 3, "strides": None}
+
+
+class PeerBandComposer:
+    """The same pipeline without a collective (include/brmi_compose.h, BRMI_COMPOSE_PEER_WRITE): every rank maps every other rank's output
+    buffers (hipIpcMemHandle) and a kernel on the render stream stores the band into all of them; flag words say when a band has landed.
+    `exchange(handle_bytes) -> [handle bytes of every rank, in rank order]` is the host's channel for the one-time handle exchange (the
+    default uses torch.distributed.all_gather_object; a test with two processes and no process group passes its own).
+    `out[i]` / finish() as BandComposer; finish() makes the current stream wait for the peers' bands of the newest frame."""
+
+    def __init__(self, surface_u8, band, width, bytes_per_pixel, depth=2, group=None, transport="surface", rank=None, world=None, exchange=None, timeout_ms=2000):
+        import ctypes as C
+        import torch
+        from . import capi
+        self.torch, self.C, self.lib = torch, C, capi.compose_lib()
+        dev = surface_u8.device
+        if rank is None or world is None:
+            import torch.distributed as dist
+            rank, world = dist.get_rank(group), dist.get_world_size(group)
+        cfg = capi.ComposeConfig()
+        cfg.structSize = C.sizeof(capi.ComposeConfig)
+        cfg.width, cfg.bandY0, cfg.bandY1, cfg.bytesPerPixel = width, band[0], band[1], bytes_per_pixel
+        cfg.transport = {"surface": 0, "rgb16f": 1}[transport]
+        cfg.depth, cfg.rank, cfg.nRanks, cfg.device = depth, rank, world, dev.index or 0
+        cfg.path, cfg.waitTimeoutMs = 1, timeout_ms
+        self._h = capi.vp()
+        rc = self.lib.brmi_compose_create(C.byref(cfg), bytes(128), C.byref(self._h))
+        if rc != 0:
+            raise RuntimeError(f"brmi_compose_create (peer write) failed ({rc})")
+        self._check(self.lib.brmi_compose_alloc_shared(self._h), "brmi_compose_alloc_shared")
+        mine = C.create_string_buffer(capi.COMPOSE_HANDLE_BYTES)
+        self._check(self.lib.brmi_compose_export(self._h, mine), "brmi_compose_export")
+        if exchange is None:
+            import torch.distributed as dist
+
+            def exchange(b):
+                got = [None] * world
+                dist.all_gather_object(got, b, group=group)
+                return got
+        handles = exchange(mine.raw) if world > 1 else [mine.raw]
+        self._check(self.lib.brmi_compose_import(self._h, b"".join(handles), world), "brmi_compose_import")
+        ob = self.lib.brmi_compose_output_bytes(self._h)
+        self.surface, self.depth, self.frames, self.dev, self._ob, self.transport = surface_u8, depth, 0, dev, ob, transport
+        self.out = [None] * depth
+
+    def _check(self, rc, what):
+        if rc < 0:
+            raise RuntimeError(f"{what} failed ({rc}): {self.lib.brmi_compose_last_error(self._h).decode()}")
+        return rc
+
+    def _stream(self):
+        return self.C.c_void_p(self.torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def submit(self, surface_u8=None):
+        slot = self._check(self.lib.brmi_compose_submit(self._h, (self.surface if surface_u8 is None else surface_u8).data_ptr(), self._stream()), "brmi_compose_submit")
+        self.frames += 1
+        return slot
+
+    def finish(self):
+        ptr = self.C.c_void_p()
+        self._check(self.lib.brmi_compose_finish(self._h, self._stream(), self.C.byref(ptr)), "brmi_compose_finish")
+        if not self.frames:
+            return None
+        t = self.torch.as_tensor(_DevicePointer(ptr.value, self._ob), device=self.dev)
+        return t.view(self.torch.int16).view(-1, 3) if self.transport == "rgb16f" else t
+
+    def wait_status(self):
+        """0, or raises once a wait for a peer timed out (synchronises)."""
+        self.torch.cuda.synchronize(self.dev)
+        return self._check(self.lib.brmi_compose_last_wait_status(self._h), "peer wait")
+
+    def close(self):
+        if self._h:
+            self.torch.cuda.synchronize(self.dev)
+            self.lib.brmi_compose_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -219,7 +219,7 @@ int brmi_create(const brmi_config* cfg, brmi_pass** out) {
     if (const char* e = std::getenv("BRMI_RASTER_DEBUG")) p->rasterDebug = std::atoi(e);
     if (const char* e = std::getenv("BRMI_BIN_OVERFLOW")) p->binOverflowPerStripe = (uint32_t)std::max(0, std::atoi(e));
     if (const char* e = std::getenv("BRMI_BIN_CAPACITY")) p->binCapacity = (uint32_t)std::min(65536, std::max(1, std::atoi(e)));   // 16-bit record indices inside a bin slice's alpha list; 65536 x 64 B x bins is far beyond any frame
-    if (const char* e = std::getenv("BRMI_BIG_TRI_AREA")) p->bigTriArea = p->bigTriAreaAlpha = std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("BRMI_BIG_TRI_AREA")) p->bigTriArea = p->bigTriAreaAlpha = p->bigTriAreaDense = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("BRMI_TILE_CAPACITY")) p->tileCapacity = (uint32_t)std::max(1, std::atoi(e));
     if (const char* e = std::getenv("BRMI_TILE_SLICE")) p->tileMinSlice = (uint32_t)std::max(1, std::atoi(e));
     if (const char* e = std::getenv("BRMI_TILE_OVERFLOW")) p->tileOverflowCapacity = (uint32_t)std::max(1, std::atoi(e));

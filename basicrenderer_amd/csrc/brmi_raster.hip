@@ -57,6 +57,7 @@ struct RasterArgs {
     const AlphaMaterial* alphaMats;                      // per material: the alpha test's texture bindings resolved (k_frame_constants)
     const float* objConst;   // per object: MVP (16), objectToClip (16), modelViewZ (4)
     int bigTriArea;          // clamped-bbox pixels above which a triangle is binned
+    int bigTriAreaDense; uint32_t denseClusterCount;     // ... on frames with at least this many visible clusters
     int bigTriAreaAlpha;     // the same for alpha-tested clusters: their pixels are far cheaper in a bin (LDS early-out, more lanes in flight)
     uint32_t binMinSlice;    // fewest records a slice of a bin holds (BRMI_BIN_MIN_SLICE)
     int debugFlags;          // experiments only (BRMI_RASTER_DEBUG): 1 = skip the direct walk, 2 = skip bin emission, 4 = skip the bin pass, 8 = direct walk without the atomic
@@ -379,7 +380,9 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
             const bool useScanlineRanges = __any(active && rectWidth > 4);
             if (parts > 1u && lane / lanesPerPart != part) active = false;      // another wave's share of the pass
             const int rows = maxY - minY + 1;
-            const bool big = active && rows * rectWidth > (alphaCluster ? a.bigTriAreaAlpha : a.bigTriArea);
+            // frames of many small clusters bin from 32 px on (the row re-deal's global atomics are what their waves wait for: 34-35 % of the
+            // kernel's wave-cycles, phase stamps); frames of few large clusters keep 64 (measured both ways, profiles/r03_experiments.md)
+            const bool big = active && rows * rectWidth > (alphaCluster ? a.bigTriAreaAlpha : (count >= a.denseClusterCount ? a.bigTriAreaDense : a.bigTriArea));
             // bins the box overlaps (rows clipped to this GPU's band)
             const int yLo = max(minY, (int)a.bandY0), yHi = min(maxY, (int)a.bandY1 - 1);
             const int band0 = yLo >> BIN_ROWS_SHIFT, band1 = yHi >> BIN_ROWS_SHIFT, strip0 = minX >> BIN_W_SHIFT, strip1 = maxX >> BIN_W_SHIFT;
@@ -1119,6 +1122,7 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
     a.overflow = p->wsPtr<BinRecord>(p->ws.binOverflow); a.overflowPerStripe = p->binOverflowPerStripe;
     a.objConst = p->wsPtr<float>(p->ws.objConst);
     a.bigTriArea = p->bigTriArea; a.bigTriAreaAlpha = p->bigTriAreaAlpha; a.debugFlags = p->rasterDebug;
+    a.bigTriAreaDense = p->bigTriAreaDense; a.denseClusterCount = p->denseClusterCount;
     static const uint32_t minSlice = [] { const char* e = std::getenv("BRMI_BIN_MIN_SLICE"); return e ? (uint32_t)std::max(32, std::atoi(e)) : 1024u; }();
     a.binMinSlice = minSlice;
     a.binAlpha = p->wsPtr<AlphaRecord>(p->ws.binAlpha); a.overflowAlpha = p->wsPtr<AlphaRecord>(p->ws.overflowAlpha);

@@ -16,8 +16,22 @@
 
 static_assert(sizeof(ncclUniqueId) == BRMI_COMPOSE_ID_BYTES, "ncclUniqueId size");
 
+// peer-write path: what a rank exports, and how a rank sees a peer
+struct PeerHandle { hipIpcMemHandle_t output, flags; uint64_t outputBytes; uint32_t rank, pad; };
+static_assert(sizeof(PeerHandle) <= BRMI_COMPOSE_HANDLE_BYTES, "BRMI_COMPOSE_HANDLE_BYTES");
+constexpr uint32_t kMaxRanks = 16;
+// flag words of one rank (in its own memory, written by its peers with system-scope stores): landed[slot][writer] = newest frame whose band
+// the writer has stored into this rank's output[slot]; submitted[reader] = newest frame that reader has submitted itself (it no longer
+// needs frame - depth); status = 0 or the frame a wait gave up on
+struct FlagBlock { uint32_t landed[8][kMaxRanks]; uint32_t submitted[kMaxRanks]; uint32_t status; uint32_t pad[15]; };
+struct PeerTable { uint8_t* output[kMaxRanks]; FlagBlock* flags[kMaxRanks]; };
+
 struct brmi_composer {
     brmi_compose_config cfg{};
+    bool peerWrite = false, ownsShared = false, imported = false;
+    FlagBlock* flags = nullptr;                 // this rank's (device memory)
+    PeerTable peers{};                          // [rank] -> mapped pointers ([own rank] = own buffers)
+    std::vector<void*> opened;                  // hipIpcOpenMemHandle results, closed on destroy
     ncclComm_t comm = nullptr;
     hipStream_t collStream = nullptr;
     std::vector<hipEvent_t> staged, done;       // per slot: staging copy finished (render stream) / collective finished (collective stream)
@@ -50,6 +64,46 @@ __global__ void __launch_bounds__(256) k_pack_rgb16f(const uint4* src, uint2* ds
     }
 }
 
+// ---- peer-write path -----------------------------------------------------------------------------------------------------------------
+// waits (one wave, system-scope loads, s_sleep between polls) until every word of `words[0..n)` except [skip] is >= `want`; gives up after
+// `timeoutTicks` of the 100 MHz clock and latches `want` into *status
+__global__ void k_wait_flags(const uint32_t* words, uint32_t n, uint32_t skip, uint32_t want, uint32_t* status, unsigned long long timeoutTicks) {
+    const uint32_t lane = threadIdx.x;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    bool ok = lane >= n || lane == skip;
+    while (!__all(ok)) {
+        if (!ok) ok = (int32_t)(__hip_atomic_load(&words[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - want) >= 0;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > timeoutTicks) { if (lane == 0) __hip_atomic_store(status, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+        __builtin_amdgcn_s_sleep(32);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");      // system scope: the bands behind the flags
+}
+// the band into every rank's image (own copy included).  RGB = drop the alpha on the way: four pixels (32 B) in, 24 B out per thread and peer.
+template <bool RGB>
+__global__ void __launch_bounds__(256) k_peer_write(const uint4* src, PeerTable peers, uint32_t nRanks, uint64_t slotOffset, uint64_t bandOffsetOut, uint64_t units) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < units; i += (uint64_t)gridDim.x * blockDim.x) {
+        if (RGB) {
+            const uint4 a = src[2 * i], b = src[2 * i + 1];
+            const uint32_t r0g0 = a.x, b0 = a.y & 0xFFFFu, r1g1 = a.z, b1 = a.w & 0xFFFFu, r2g2 = b.x, b2 = b.y & 0xFFFFu, r3g3 = b.z, b3 = b.w & 0xFFFFu;
+            const uint2 o0 = make_uint2(r0g0, b0 | (r1g1 << 16)), o1 = make_uint2((r1g1 >> 16) | (b1 << 16), r2g2), o2 = make_uint2(b2 | (r3g3 << 16), (r3g3 >> 16) | (b3 << 16));
+            for (uint32_t p = 0; p < nRanks; p++) { uint2* d = reinterpret_cast<uint2*>(peers.output[p] + slotOffset + bandOffsetOut) + 3 * i; d[0] = o0; d[1] = o1; d[2] = o2; }
+        } else {
+            const uint4 v = src[i];
+            for (uint32_t p = 0; p < nRanks; p++) reinterpret_cast<uint4*>(peers.output[p] + slotOffset + bandOffsetOut)[i] = v;
+        }
+    }
+}
+// after k_peer_write has retired (a kernel boundary makes its stores visible system-wide): "my band of `frame` has landed in your slot"
+__global__ void k_signal_landed(PeerTable peers, uint32_t nRanks, uint32_t rank, uint32_t slot, uint32_t frame) {
+    const uint32_t p = threadIdx.x;
+    if (p < nRanks) __hip_atomic_store(&peers.flags[p]->landed[slot][rank], frame, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// at the head of a submit: "I am at frame `frame`: whatever you hold for me of frame - depth may be overwritten"
+__global__ void k_signal_submitted(PeerTable peers, uint32_t nRanks, uint32_t rank, uint32_t frame) {
+    const uint32_t p = threadIdx.x;
+    if (p < nRanks) __hip_atomic_store(&peers.flags[p]->submitted[rank], frame, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 }  // namespace
 
 extern "C" {
@@ -67,8 +121,10 @@ int brmi_compose_create(const brmi_compose_config* cfg, const uint8_t id[BRMI_CO
     if (cfg->nRanks == 0 || cfg->rank >= cfg->nRanks || cfg->depth == 0 || cfg->depth > 8 || cfg->width == 0 || cfg->bytesPerPixel == 0) return -1;
     if (cfg->bandY0 % 8u || cfg->bandY1 % 8u || cfg->bandY1 <= cfg->bandY0) return -1;
     if (cfg->transport > BRMI_TRANSPORT_RGB16F || (cfg->transport == BRMI_TRANSPORT_RGB16F && cfg->bytesPerPixel != 8)) return -1;
+    if (cfg->path > BRMI_COMPOSE_PEER_WRITE || (cfg->path == BRMI_COMPOSE_PEER_WRITE && cfg->nRanks > kMaxRanks)) return -1;
     brmi_composer* c = new brmi_composer();
     c->cfg = *cfg;
+    c->peerWrite = cfg->path == BRMI_COMPOSE_PEER_WRITE;
     const uint64_t tilesX = (cfg->width + 7u) / 8u, rowBytes = tilesX * 64u * cfg->bytesPerPixel;      // one 8-row tile row of the surface
     c->bandOffset = (uint64_t)(cfg->bandY0 / 8u) * rowBytes; c->bandBytes = (uint64_t)((cfg->bandY1 - cfg->bandY0) / 8u) * rowBytes;
     c->pixels = c->bandBytes / cfg->bytesPerPixel;
@@ -76,8 +132,10 @@ int brmi_compose_create(const brmi_compose_config* cfg, const uint8_t id[BRMI_CO
     c->outputBytes = c->stagingBytes * cfg->nRanks;
     *out = c;
     CHECK_HIP(c, hipSetDevice(cfg->device));
-    ncclUniqueId u; std::memcpy(&u, id, sizeof(u));
-    CHECK_NCCL(c, ncclCommInitRank(&c->comm, (int)cfg->nRanks, u, (int)cfg->rank));
+    if (!c->peerWrite) {
+        ncclUniqueId u; std::memcpy(&u, id, sizeof(u));
+        CHECK_NCCL(c, ncclCommInitRank(&c->comm, (int)cfg->nRanks, u, (int)cfg->rank));
+    }
     // highest priority: from two GPUs on the gather bounds the frame rate, and with two frames in flight the render
     // streams keep every CU busy -- the collective's few workgroups must not queue behind them
     { int least = 0, greatest = 0; CHECK_HIP(c, hipDeviceGetStreamPriorityRange(&least, &greatest)); CHECK_HIP(c, hipStreamCreateWithPriority(&c->collStream, hipStreamNonBlocking, greatest)); }
@@ -89,8 +147,59 @@ int brmi_compose_create(const brmi_compose_config* cfg, const uint8_t id[BRMI_CO
 uint64_t brmi_compose_staging_bytes(const brmi_composer* c) { return c ? c->stagingBytes : 0; }
 uint64_t brmi_compose_output_bytes(const brmi_composer* c) { return c ? c->outputBytes : 0; }
 
+int brmi_compose_alloc_shared(brmi_composer* c) {
+    if (!c) return -1;
+    if (!c->peerWrite) return fail(c, -4, "brmi_compose_alloc_shared: the composer was created for the all-gather path");
+    if (c->output) return fail(c, -4, "brmi_compose_alloc_shared: buffers are bound already");
+    void* out = nullptr; void* fl = nullptr;
+    CHECK_HIP(c, hipMalloc(&out, c->outputBytes * c->cfg.depth));
+    CHECK_HIP(c, hipMalloc(&fl, sizeof(FlagBlock)));
+    CHECK_HIP(c, hipMemset(fl, 0, sizeof(FlagBlock)));
+    CHECK_HIP(c, hipDeviceSynchronize());
+    c->output = static_cast<uint8_t*>(out); c->flags = static_cast<FlagBlock*>(fl); c->ownsShared = true;
+    c->staging = c->output;      // (unused on this path: the band goes straight from the surface into the images)
+    c->peers.output[c->cfg.rank] = c->output; c->peers.flags[c->cfg.rank] = c->flags;
+    return 0;
+}
+
+int brmi_compose_export(brmi_composer* c, uint8_t handle[BRMI_COMPOSE_HANDLE_BYTES]) {
+    if (!c || !handle) return -1;
+    if (!c->peerWrite || !c->output || !c->flags) return fail(c, -4, "brmi_compose_export: peer-write composer with shared buffers (brmi_compose_alloc_shared) needed");
+    PeerHandle h{};
+    CHECK_HIP(c, hipIpcGetMemHandle(&h.output, c->output));
+    CHECK_HIP(c, hipIpcGetMemHandle(&h.flags, c->flags));
+    h.outputBytes = c->outputBytes * c->cfg.depth; h.rank = c->cfg.rank;
+    std::memset(handle, 0, BRMI_COMPOSE_HANDLE_BYTES); std::memcpy(handle, &h, sizeof(h));
+    return 0;
+}
+
+int brmi_compose_import(brmi_composer* c, const uint8_t* handles, uint32_t count) {
+    if (!c || !handles) return -1;
+    if (!c->peerWrite || !c->output) return fail(c, -4, "brmi_compose_import: export first");
+    if (count != c->cfg.nRanks) return fail(c, -1, "brmi_compose_import: %u handles for %u ranks", count, c->cfg.nRanks);
+    for (uint32_t r = 0; r < count; r++) {
+        if (r == c->cfg.rank) continue;
+        PeerHandle h; std::memcpy(&h, handles + (size_t)r * BRMI_COMPOSE_HANDLE_BYTES, sizeof(h));
+        if (h.rank != r || h.outputBytes != c->outputBytes * c->cfg.depth) return fail(c, -1, "brmi_compose_import: entry %u is rank %u with %llu B (expected %llu)", r, h.rank, (unsigned long long)h.outputBytes, (unsigned long long)(c->outputBytes * c->cfg.depth));
+        void* po = nullptr; void* pf = nullptr;
+        CHECK_HIP(c, hipIpcOpenMemHandle(&po, h.output, hipIpcMemLazyEnablePeerAccess)); c->opened.push_back(po);
+        CHECK_HIP(c, hipIpcOpenMemHandle(&pf, h.flags, hipIpcMemLazyEnablePeerAccess)); c->opened.push_back(pf);
+        c->peers.output[r] = static_cast<uint8_t*>(po); c->peers.flags[r] = static_cast<FlagBlock*>(pf);
+    }
+    c->imported = true;
+    return 0;
+}
+
+int brmi_compose_last_wait_status(brmi_composer* c) {
+    if (!c || !c->flags) return -1;
+    uint32_t st = 0;
+    CHECK_HIP(c, hipMemcpy(&st, &c->flags->status, 4, hipMemcpyDeviceToHost));
+    return st ? fail(c, -6, "a wait for a peer's band of frame %u timed out", st) : 0;
+}
+
 int brmi_compose_bind(brmi_composer* c, void* staging, uint64_t stagingBytes, void* output, uint64_t outputBytes) {
     if (!c || !staging || !output) return -1;
+    if (c->peerWrite) return fail(c, -4, "brmi_compose_bind: the peer-write path shares its buffers with other processes: brmi_compose_alloc_shared");
     if (stagingBytes < c->stagingBytes * c->cfg.depth || outputBytes < c->outputBytes * c->cfg.depth) return fail(c, -3, "brmi_compose_bind: %u buffers of %llu B (staging) and %llu B (output) are needed",
                                                                                                                       c->cfg.depth, (unsigned long long)c->stagingBytes, (unsigned long long)c->outputBytes);
     if ((reinterpret_cast<uintptr_t>(staging) | reinterpret_cast<uintptr_t>(output)) & 15u) return fail(c, -1, "brmi_compose_bind: buffers must be 16-byte aligned");
@@ -103,6 +212,28 @@ int brmi_compose_submit(brmi_composer* c, const void* surface, brmi_compose_stre
     if (!c->staging) return fail(c, -4, "brmi_compose_submit: call brmi_compose_bind first");
     hipStream_t rs = static_cast<hipStream_t>(renderStream);
     const uint32_t slot = (uint32_t)(c->frames % c->cfg.depth);
+    if (c->peerWrite) {
+        if (!c->imported && c->cfg.nRanks > 1) return fail(c, -4, "brmi_compose_submit: call brmi_compose_import first");
+        const uint32_t frame = (uint32_t)(c->frames + 1u), n = c->cfg.nRanks;
+        const unsigned long long ticks = (unsigned long long)(c->cfg.waitTimeoutMs ? c->cfg.waitTimeoutMs : 2000u) * 100000ull;
+        const uint8_t* band = static_cast<const uint8_t*>(surface) + c->bandOffset;
+        // 1. every peer learns that this rank is at `frame` (its copies of frame - depth are free); 2. this rank waits until every peer is
+        // there too, i.e. until the slot it is about to overwrite in THEIR images is free; 3. the band; 4. "landed"
+        hipLaunchKernelGGL(k_signal_submitted, dim3(1), dim3(64), 0, rs, c->peers, n, c->cfg.rank, frame);
+        if (n > 1) hipLaunchKernelGGL(k_wait_flags, dim3(1), dim3(64), 0, rs, c->flags->submitted, n, c->cfg.rank, frame, &c->flags->status, ticks);
+        const uint64_t slotOffset = (uint64_t)slot * c->outputBytes, bandOut = (uint64_t)c->cfg.rank * c->stagingBytes;
+        if (c->cfg.transport == BRMI_TRANSPORT_RGB16F) {
+            const uint64_t quads = c->pixels / 4u;
+            hipLaunchKernelGGL(k_peer_write<true>, dim3((unsigned)std::min<uint64_t>(4096, (quads + 255) / 256)), dim3(256), 0, rs, reinterpret_cast<const uint4*>(band), c->peers, n, slotOffset, bandOut, quads);
+        } else {
+            const uint64_t vecs = c->bandBytes / 16u;
+            hipLaunchKernelGGL(k_peer_write<false>, dim3((unsigned)std::min<uint64_t>(4096, (vecs + 255) / 256)), dim3(256), 0, rs, reinterpret_cast<const uint4*>(band), c->peers, n, slotOffset, bandOut, vecs);
+        }
+        hipLaunchKernelGGL(k_signal_landed, dim3(1), dim3(64), 0, rs, c->peers, n, c->cfg.rank, slot, frame);
+        CHECK_HIP(c, hipGetLastError());
+        c->frames++;
+        return (int)slot;
+    }
     uint8_t* st = c->staging + (uint64_t)slot * c->stagingBytes; uint8_t* dst = c->output + (uint64_t)slot * c->outputBytes;
     const uint8_t* band = static_cast<const uint8_t*>(surface) + c->bandOffset;
     if (c->inFlight[slot]) CHECK_HIP(c, hipStreamWaitEvent(rs, c->done[slot], 0));       // the slot's previous collective has read the staging buffer
@@ -123,6 +254,17 @@ int brmi_compose_submit(brmi_composer* c, const void* surface, brmi_compose_stre
 int brmi_compose_finish(brmi_composer* c, brmi_compose_stream stream, void** composed) {
     if (!c) return -1;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (c->peerWrite) {
+        if (c->frames && c->cfg.nRanks > 1) {
+            const uint32_t slot = (uint32_t)((c->frames - 1) % c->cfg.depth);
+            const unsigned long long ticks = (unsigned long long)(c->cfg.waitTimeoutMs ? c->cfg.waitTimeoutMs : 2000u) * 100000ull;
+            // (its own band was stored by a kernel already on the rank's render stream; the caller orders `stream` behind that one as with the all-gather)
+            hipLaunchKernelGGL(k_wait_flags, dim3(1), dim3(64), 0, s, c->flags->landed[slot], c->cfg.nRanks, c->cfg.rank, (uint32_t)c->frames, &c->flags->status, ticks);
+            CHECK_HIP(c, hipGetLastError());
+        }
+        if (composed) *composed = c->frames ? c->output + (uint64_t)((c->frames - 1) % c->cfg.depth) * c->outputBytes : nullptr;
+        return 0;
+    }
     for (uint32_t i = 0; i < c->cfg.depth; i++) if (c->inFlight[i]) { CHECK_HIP(c, hipStreamWaitEvent(s, c->done[i], 0)); c->inFlight[i] = false; }
     if (composed) *composed = c->frames ? c->output + (uint64_t)((c->frames - 1) % c->cfg.depth) * c->outputBytes : nullptr;
     return 0;
@@ -133,6 +275,8 @@ void brmi_compose_destroy(brmi_composer* c) {
     if (c->collStream) (void)hipStreamSynchronize(c->collStream);
     for (hipEvent_t e : c->staged) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->done) if (e) (void)hipEventDestroy(e);
+    for (void* p : c->opened) (void)hipIpcCloseMemHandle(p);
+    if (c->ownsShared) { (void)hipDeviceSynchronize(); (void)hipFree(c->output); (void)hipFree(c->flags); }
     if (c->comm) (void)ncclCommDestroy(c->comm);
     if (c->collStream) (void)hipStreamDestroy(c->collStream);
     delete c;

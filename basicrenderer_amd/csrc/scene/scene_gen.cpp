@@ -1328,8 +1328,10 @@ void makeCamera(uint32_t W, uint32_t H, V3 eye, double yaw, double pitch, double
         const V3 e{eye.x + 0.35 * k, eye.y + 0.05 * k, eye.z - 0.6 * k};
         return mul(mul(rotationX(pitch), rotationY(yaw + 0.07 * k)), translation(e));
     };
-    M4 world = worldAt(step);
+    // (the eye moves first and the view matrices start from the moved eye: the path of the matrices is twice as long as that of
+    // positionWorldSpace.  Kept as rounds 1-2 had it: the golden fixtures are frames of this path)
     { const double k = step; eye = V3{eye.x + 0.35 * k, eye.y + 0.05 * k, eye.z - 0.6 * k}; }
+    M4 world = worldAt(step);
     M4 view = inverse(world);
     M4 prevView = prevStep != step ? inverse(worldAt(prevStep)) : view;
     // XMMatrixPerspectiveFovRH(fov, aspect, NearZ = zFar, FarZ = zNear): reversed Z

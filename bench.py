@@ -79,8 +79,9 @@ def main():
                     help="default: the workload's (san_miguel: 24, else 0).  scene generator feature bits (brmi_scene.h): 1 coat, 2 fuzz, 4 mirrored instances, 8 texture-sampled materials, 16 alpha-tested materials, 32 vertex colours, 64 OpenPBR layer textures, 128 parallax; 0 = BASELINE.json's constant-factor configuration")
     ap.add_argument("--transport", default="rgb16f", choices=["rgb16f", "surface"],
                     help="what the band composition gathers: the colour channels as RGB16F (default; the composed image has no alpha plane) or the RGBA16F surface bytes")
-    ap.add_argument("--composer", default="native", choices=["native", "torch"],
-                    help="who runs the all-gather: libbrmi_compose.so (RCCL called from C++ behind include/brmi_compose.h; default) or torch.distributed")
+    ap.add_argument("--composer", default="native", choices=["native", "peer", "torch"],
+                    help="who composes the bands: libbrmi_compose.so with one RCCL all-gather per frame (native; default), libbrmi_compose.so's peer-write path "
+                         "(peer: hipIpc-mapped output buffers, every rank stores its band into every other rank's image, no collective), or torch.distributed")
     ap.add_argument("--force-compose", action="store_true", help="run the RCCL band composition even with one rank (checks the collective path on a single GPU)")
     ap.add_argument("--frames-in-flight", type=int, default=2, choices=[1, 2, 3],
                     help="2 (default) or 3 (the reference's numFramesInFlight default, Renderer.h:110): that many passes with their own resources render the frames "
@@ -195,23 +196,40 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True):
     composer, composer_used = None, args.composer
     if n > 1 or args.force_compose:
         composer_used = args.composer
-        if args.composer == "native":
-            # libbrmi_compose.so issues the collective itself; if its communicator cannot be set up on some rank (it has only ever run on one
-            # GPU in development), every rank falls back to the torch.distributed composer together rather than losing the N > 1 line
+        if args.composer in ("native", "peer"):
+            # libbrmi_compose.so issues the composition itself.  Whether it can is decided WITHOUT a collective first -- load the library, make
+            # a unique id (RCCL path) -- and agreed on by all ranks (one all_reduce): ncclCommInitRank is collective, so a rank that cannot
+            # even load the library would leave the others blocked inside it.  Creation proper follows only when every rank said yes; any
+            # failure there (peer path: mapping a peer's buffers) is again agreed on before the timed region, and all ranks fall back to the
+            # torch.distributed composer together.
+            import ctypes as C
+            from basicrenderer_amd import capi
             failed, why = 0, ""
             try:
-                composer = compose.NativeBandComposer(hdr, band, W, 8, transport=args.transport)
+                lib = capi.compose_lib()
+                if args.composer == "native" and rank == 0 and lib.brmi_compose_unique_id((C.c_uint8 * 128)()) != 0:
+                    raise RuntimeError("brmi_compose_unique_id failed")
             except Exception as e:      # noqa: BLE001
                 failed, why = 1, f"{type(e).__name__}: {e}"
-            if n > 1:
-                flag = torch.tensor([failed], device=dev, dtype=torch.int32)
-                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-                failed = int(flag.item())
+
+            def agree(flag):
+                if n > 1:
+                    t = torch.tensor([flag], device=dev, dtype=torch.int32)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    return int(t.item())
+                return flag
+            failed = agree(failed)
+            if not failed:
+                try:
+                    composer = (compose.PeerBandComposer if args.composer == "peer" else compose.NativeBandComposer)(hdr, band, W, 8, transport=args.transport)
+                except Exception as e:      # noqa: BLE001
+                    failed, why = 1, f"{type(e).__name__}: {e}"
+                failed = agree(failed)
             if failed:
                 if composer is not None:
                     composer.close()
                 composer = compose.BandComposer(hdr, band, W, 8, transport=args.transport)
-                composer_used = "torch (native composer failed" + (f": {why}" if why else " on another rank") + ")"
+                composer_used = "torch (" + args.composer + " composer failed" + (f": {why}" if why else " on another rank") + ")"
         else:
             composer = compose.BandComposer(hdr, band, W, 8, transport=args.transport)
 
@@ -331,7 +349,7 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True):
                                    + (", LOD DAGs from the library's cluster-LOD builder" if lod_builder == "own" else "")
                                    + (f", relief slope {scene_kw['relief_slope']}" if scene_kw.get("relief_slope") else "")
                                    + (f", material features {features} (8 = texture-sampled, 16 = alpha-tested materials)" if features else "")
-                                   + (f", {n} row bands of 1080 rows + RCCL all-gather of HDR ({args.transport}, pipelined one frame deep, {'libbrmi_compose.so' if composer_used == 'native' else ('torch.distributed' if composer_used == 'torch' else composer_used)})" if composer else ""),
+                                   + (f", {n} row bands of 1080 rows + RCCL all-gather of HDR ({args.transport}, pipelined one frame deep, {'libbrmi_compose.so' if composer_used == 'native' else ('libbrmi_compose.so peer write' if composer_used == 'peer' else ('torch.distributed' if composer_used == 'torch' else composer_used))})" if composer else ""),
                        "baseline_config": BASELINE_CONFIG[workload],
                        "fps": round(1e3 / ms_per_step, 1),
                        "pixels_per_gpu": W * (band[1] - band[0]), "visible_clusters_rank0": int(c.visibleClusters),

@@ -27,6 +27,18 @@ typedef enum brmi_compose_transport {
     BRMI_TRANSPORT_RGB16F  = 1              /* RGBA16F surface only: the three colour channels, 6 B per pixel (the lit target's alpha is the constant 1) */
 } brmi_compose_transport;
 
+/* How the bands travel.
+ *   ALLGATHER   one ncclAllGather per frame on the composer's own stream (RCCL builds rings over the xGMI mesh).
+ *   PEER_WRITE  no collective and no RCCL: every rank maps every other rank's output buffers (hipIpcMemHandle, exchanged once by the host
+ *               like the unique id) and a kernel on the render stream stores its band straight into each peer's image, at the band's
+ *               place -- N - 1 independent store streams over N - 1 different xGMI links, no staging copy, no ring hops (DESIGN.md
+ *               section 6).  A frame number per (slot, writer) says a band has landed; a writer waits for the reader's own submit of the
+ *               frame before it overwrites the slot (the image of frame f stays valid until the rank submits frame f + depth, as with
+ *               the all-gather).  Setup: create -> alloc_shared (or bind memory that is the base of a hipMalloc allocation) -> export ->
+ *               [host moves the handles] -> import -> submit / finish as before. */
+typedef enum brmi_compose_path { BRMI_COMPOSE_ALLGATHER = 0, BRMI_COMPOSE_PEER_WRITE = 1 } brmi_compose_path;
+#define BRMI_COMPOSE_HANDLE_BYTES 160u      /* two hipIpcMemHandle_t (output buffers, flag words) + the buffer size + the rank */
+
 typedef struct brmi_compose_config {
     uint32_t structSize;                    /* sizeof(brmi_compose_config) */
     uint32_t width;                         /* frame width in pixels (the tiled surface is ceil(width / 8) tiles wide) */
@@ -36,7 +48,9 @@ typedef struct brmi_compose_config {
     uint32_t depth;                         /* staging / output buffers in flight (>= 1; 2 overlaps one frame) */
     uint32_t rank, nRanks;
     int32_t  device;                        /* HIP device of this rank */
-    uint32_t reserved[6];
+    uint32_t path;                          /* brmi_compose_path (0 = the all-gather) */
+    uint32_t waitTimeoutMs;                 /* PEER_WRITE: a wait for a peer's flag gives up after this long and latches an error (0 = 2000 ms) */
+    uint32_t reserved[4];
 } brmi_compose_config;
 
 typedef struct brmi_composer brmi_composer;
@@ -51,6 +65,13 @@ int brmi_compose_create(const brmi_compose_config* cfg, const uint8_t id[BRMI_CO
 uint64_t brmi_compose_staging_bytes(const brmi_composer* c);
 uint64_t brmi_compose_output_bytes(const brmi_composer* c);
 int brmi_compose_bind(brmi_composer* c, void* staging, uint64_t stagingBytes, void* output, uint64_t outputBytes);
+/* PEER_WRITE only.  alloc_shared: `depth` output buffers + the flag words as allocations of their own (what hipIpcGetMemHandle wants), owned
+ * by the composer and bound; export: this rank's handles; import: every rank's handles (nRanks x BRMI_COMPOSE_HANDLE_BYTES, rank order; the
+ * rank's own entry is ignored).  last_wait_status: 0, or -6 once a wait for a peer timed out (the composed images are not to be trusted). */
+int brmi_compose_alloc_shared(brmi_composer* c);
+int brmi_compose_export(brmi_composer* c, uint8_t handle[BRMI_COMPOSE_HANDLE_BYTES]);
+int brmi_compose_import(brmi_composer* c, const uint8_t* handles, uint32_t count);
+int brmi_compose_last_wait_status(brmi_composer* c);
 /* `surface`: base of the tiled surface (the whole frame's allocation).  Returns the buffer slot used (>= 0) or a negative status. */
 int brmi_compose_submit(brmi_composer* c, const void* surface, brmi_compose_stream renderStream);
 /* `stream` waits for every collective in flight; *composed = the output buffer of the newest frame (NULL before the first submit). */

@@ -1,0 +1,63 @@
+"""One rank of the two-process peer-write composition test (tests/test_parity_gpu.py).  Started as a fresh child process per rank (no exec
+after GPU initialisation): both ranks live on cuda:0, exchange their hipIpcMemHandles through files in a scratch directory and compose
+`frames` frames of a synthetic RGBA16F surface whose bytes depend on (rank, frame).  Writes the composed image of the last frame to
+<dir>/composed_<rank>.npy; the parent checks it against the bytes both ranks must have contributed."""
+import os
+import sys
+import time
+
+import numpy as np
+
+
+def surface_bytes(rank, frame, nbytes):
+    """The rank's whole tiled surface for a frame (deterministic, different per rank and frame)."""
+    rng = np.random.Generator(np.random.PCG64(1234 + 1000 * frame + rank))
+    return rng.integers(0, 256, nbytes, dtype=np.uint8)
+
+
+def main():
+    root, scratch, rank, world, transport, frames = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5], int(sys.argv[6])
+    sys.path.insert(0, root)
+    import torch
+    from basicrenderer_amd import compose
+    dev = torch.device("cuda:0")
+    W, rows = 256, 32 * world
+    band = (rank * 32, (rank + 1) * 32)
+    nbytes = (W // 8) * (rows // 8) * 64 * 8
+    surf = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+
+    def exchange(mine):
+        with open(os.path.join(scratch, f"handle_{rank}.tmp"), "wb") as f:
+            f.write(mine)
+        os.replace(os.path.join(scratch, f"handle_{rank}.tmp"), os.path.join(scratch, f"handle_{rank}.bin"))
+        out = []
+        for r in range(world):
+            path, t0 = os.path.join(scratch, f"handle_{r}.bin"), time.time()
+            while not os.path.exists(path):
+                if time.time() - t0 > 60:
+                    raise RuntimeError(f"rank {r} never exported its handles")
+                time.sleep(0.01)
+            out.append(open(path, "rb").read())
+        return out
+
+    comp = compose.PeerBandComposer(surf, band, W, 8, depth=2, transport=transport, rank=rank, world=world, exchange=exchange, timeout_ms=20000)
+    last = None
+    for f in range(frames):
+        surf.copy_(torch.from_numpy(surface_bytes(rank, f, nbytes)).to(dev))
+        if rank == 1 and f == 1:
+            time.sleep(0.3)      # one rank late: the other one's wait kernels really wait
+        comp.submit()
+        last = comp.finish()
+        torch.cuda.synchronize()
+    comp.wait_status()
+    np.save(os.path.join(scratch, f"composed_{rank}.npy"), last.cpu().numpy())
+    # both ranks keep their buffers mapped until the other one is done reading
+    open(os.path.join(scratch, f"done_{rank}"), "w").close()
+    t0 = time.time()
+    while not all(os.path.exists(os.path.join(scratch, f"done_{r}")) for r in range(world)) and time.time() - t0 < 60:
+        time.sleep(0.01)
+    comp.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 CASES = ["tiny", "tiny_lod", "tiny_coat_fuzz", "sponza_coat_fuzz", "sponza_small", "bistro_small", "tiny_skinned", "bistro_skinned", "tiny_clod", "sponza_clod", "bistro_clod_skinned", "tiny_ownlod", "sponza_ownlod", "bistro_ownlod_skinned", "sponza_ownlod_alpha", "sponza_spots", "bistro_mirrored",
          "tiny_textured", "sponza_textured", "tiny_alpha", "sponza_alpha", "bistro_alpha_skinned", "sponza_clod_alpha", "tiny_vcolor", "sponza_vcolor_textured", "sponza_layer_textures", "tiny_layer_textures_only", "tiny_parallax", "sponza_parallax_all"]
@@ -652,6 +653,35 @@ def test_frame_from_an_independently_written_clod_cache_matches_the_oracle():
     a, b = r.hdr().view(np.uint16).astype(np.int32), o.hdr.view(np.uint16).astype(np.int32)
     assert np.abs(a - b).max() <= 1
     r.close()
+
+
+@pytest.mark.parametrize("transport", ["surface", "rgb16f"])
+def test_peer_write_composer_with_two_processes_on_one_gpu(transport, tmp_path):
+    """The peer-write transport of libbrmi_compose.so (BRMI_COMPOSE_PEER_WRITE: no RCCL, hipIpcMemHandle-mapped output buffers, flag words) with
+    TWO PROCESSES on one GPU -- a fresh child per rank, handles exchanged through files.  Three pipelined frames whose surface bytes depend on
+    (rank, frame); rank 1 is late for one of them.  Every rank's composed image of the last frame must hold both ranks' bands of THAT
+    frame (RGB16F transport: their colour channels), byte for byte."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import peer_compose_worker as w
+    world, frames = 2, 3
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "peer_compose_worker.py"), ROOT, str(tmp_path), str(r), str(world), transport, str(frames)],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    outs = [p.communicate(timeout=300)[0].decode(errors="replace") for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    W, rows = 256, 32 * world
+    nbytes = (W // 8) * (rows // 8) * 64 * 8
+    band_bytes = nbytes // world
+    want = []
+    for r in range(world):
+        b = w.surface_bytes(r, frames - 1, nbytes)[r * band_bytes:(r + 1) * band_bytes]
+        want.append(b.view(np.int16).reshape(-1, 4)[:, :3].copy() if transport == "rgb16f" else b)
+    want = np.concatenate(want)
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), f"composed_{r}.npy"))
+        assert np.array_equal(got, want), f"rank {r}: composed image differs"
 
 
 @pytest.mark.parametrize("transport", ["surface", "rgb16f"])
