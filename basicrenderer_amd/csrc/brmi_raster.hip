@@ -84,6 +84,13 @@ __global__ void __launch_bounds__(256) k_clear_vis(unsigned long long* vis, uint
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < frameState16; i += (uint64_t)gridDim.x * blockDim.x) frameState[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
+// LDS visibility inside ONE wave (waves of one workgroup that run different amounts of work: no workgroup barrier between their steps)
+BRMI_DEV void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 BRMI_DEV void clip_scanline(float value, float step, int& first, int& last, bool& has) {
     if (!has) return;
     if (step > 0.0f) { const int c = to_int_sat(ceilf(-value / step)); first = first > c ? first : c; }
@@ -563,6 +570,12 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES
     // the plain read-modify-write merge (it owns its pixels).  The counts are cleared by k_raster_overflow, which runs next.
     const uint32_t strip = blockIdx.x, band = blockIdx.y, bin = band * a.binsX + strip;
     const uint32_t nAll = min(a.binCounts[bin], a.binCapacity);
+#ifdef BRMI_TILE_STAMPS
+    unsigned long long bph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bprev = __builtin_amdgcn_s_memtime();
+#define BSTAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); bph[k] += now_ - bprev; bprev = now_; } while (0)
+#else
+#define BSTAMP(k) do { } while (0)
+#endif
     // the slices of a bin share its records evenly (a multiple of the 32 records one step walks, at least binMinSlice of them)
     const uint32_t sliceSize = max(a.binMinSlice, ((nAll + gridDim.z - 1u) / gridDim.z + 31u) & ~31u);
     const bool shared = nAll > sliceSize;               // other workgroups (or later slices of this one) write this bin's pixels too
@@ -574,14 +587,23 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES
     if (ALPHA && threadIdx.x == 0) alphaCount = 0u;
     for (uint32_t i = threadIdx.x; i < BIN_W * BIN_ROWS; i += BRMI_BIN_THREADS) tile[i] = BRMI_VIS_EMPTY;
     __syncthreads();
+    BSTAMP(0);
     const int x0 = (int)(strip << BIN_W_SHIFT), y0 = (int)(band << BIN_ROWS_SHIFT);
     const LdsSink sink{tile, x0, y0};
     const BinRecord* recs = a.binRecords + (size_t)bin * a.binCapacity;
     const uint32_t sub = threadIdx.x >> 4, row = threadIdx.x & 15u;
+    // the record of the NEXT step is requested before this step's rows are walked: the records come from HBM (the launch before wrote 86 MiB of
+    // them on a dense frame), a step's load is a round trip of its own, and a slice is 32 steps -- the record walk was 75 % of this kernel's
+    // wave-cycles (phase stamps).  (Lane = record with the rows re-dealt to the lanes -- an owner byte per row in LDS, the record's fields
+    // fetched from the owning lane with ds_bpermute -- walks a dense frame's 3-6-row records 8 % faster on its own, but needs 78 VGPRs
+    // instead of 46: beside three k_shade waves per SIMD the kernel then finds no room, and the frame with two in flight got 18 % slower.)
+    BinRecord pending{};
+    if (first + sub < n) pending = recs[first + sub];
     for (uint32_t base = first; base < n; base += BRMI_BIN_THREADS / 16) {
         const uint32_t ri = base + sub;
+        const BinRecord r = pending;
+        if (ri + BRMI_BIN_THREADS / 16 < n) pending = recs[ri + BRMI_BIN_THREADS / 16];
         if (ri >= n) continue;
-        const BinRecord r = recs[ri];
         const uint32_t rows = (r.triAndFlags >> 16) & 0xFFu;
         bool deferred = false;
         if (ALPHA && r.pad1 != 0u) {      // alpha tested: listed for the task pass below
@@ -603,6 +625,7 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES
                            x0, x0 + BIN_W - 1);
         }
     }
+    BSTAMP(1);
     if (ALPHA) {
         // Alpha-tested records after the opaque ones (more keys to reject untested).  A pixel of theirs costs a texcoord, a dependent
         // texel fetch and the filter, and the records of a bin are anything from two floor triangles that span it to hundreds of
@@ -635,6 +658,7 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES
         if (threadIdx.x == BRMI_BIN_THREADS - 1u && listed == ALPHA_LIST) taskStart[ALPHA_LIST] = run;      // j never reaches ALPHA_LIST in the loop above
         __syncthreads();
         const uint32_t total = listed ? taskStart[listed] : 0u;
+        BSTAMP(2);
         for (uint32_t task = threadIdx.x; task < total; task += BRMI_BIN_THREADS) {
             uint32_t j = 0;
 #pragma unroll
@@ -652,8 +676,10 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES
                 raster_row(sink, tex_alpha_of(a, unormT, a.binAlpha[(size_t)bin * a.binCapacity + ri]), py, r.minX, r.rectWidth, (r.triAndFlags & 0x100u) != 0, sb0, sb1, r.dx_b0, r.dx_b1, -(r.dx_b0 + r.dx_b1),
                            r.d0, r.d1, r.d2, r.clusterIndex, r.triAndFlags & 0x7Fu, sx0, sx1);
         }
+        BSTAMP(3);
     }
     __syncthreads();
+    BSTAMP(4);
     // merge: item = (column x, upper / lower 8 rows) = 8 keys = 64 B, contiguous in the tile and in the 8x8-tiled surface
     for (uint32_t item = threadIdx.x; item < BIN_W * 2; item += BRMI_BIN_THREADS) {
         const uint32_t half = item >> 8 /* BIN_W items per half */, xl = item & (BIN_W - 1);
@@ -678,7 +704,11 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES
             if (m.x != g.x || m.y != g.y) dst[q] = m;
         }
     }
+    BSTAMP(5);
     }   // slices
+#ifdef BRMI_TILE_STAMPS
+    if ((threadIdx.x & 63u) < 8u && (a.debugFlags & 0x200)) { unsigned long long v = 0; for (int k = 0; k < 8; k++) if ((threadIdx.x & 63u) == (uint32_t)k) v = bph[k]; atomicAdd(a.debugStamps + 32u + (threadIdx.x & 63u), v); }
+#endif
 }
 
 // Records that did not fit their bin: four per wave64, one lane per row, global 64-bit atomics (the bins' merge is a plain
@@ -744,12 +774,6 @@ static_assert(RT_W * RT_H == 4096 && RT_H >= 8, "4096 keys per tile, whole 8-row
 constexpr uint32_t RT_THREADS = 512, RT_WAVES = RT_THREADS / 64;
 constexpr uint32_t RT_MAX_SLICE = 64u * RT_WAVES;
 
-// LDS visibility inside ONE wave (the waves of a tile workgroup run different entries: no workgroup barrier inside an entry)
-BRMI_DEV void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 struct WaveStage {           // one wave's staging area
     float sx[BRMI_MESHLET_MAX_VERTS], sy[BRMI_MESHLET_MAX_VERTS], sd[BRMI_MESHLET_MAX_VERTS];

@@ -349,7 +349,7 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True):
                                    + (", LOD DAGs from the library's cluster-LOD builder" if lod_builder == "own" else "")
                                    + (f", relief slope {scene_kw['relief_slope']}" if scene_kw.get("relief_slope") else "")
                                    + (f", material features {features} (8 = texture-sampled, 16 = alpha-tested materials)" if features else "")
-                                   + (f", {n} row bands of 1080 rows + RCCL all-gather of HDR ({args.transport}, pipelined one frame deep, {'libbrmi_compose.so' if composer_used == 'native' else ('libbrmi_compose.so peer write' if composer_used == 'peer' else ('torch.distributed' if composer_used == 'torch' else composer_used))})" if composer else ""),
+                                   + (f", {n} row bands of 1080 rows + composition of HDR on every rank ({args.transport}, pipelined one frame deep, {'libbrmi_compose.so: one RCCL all-gather per frame' if composer_used == 'native' else ('libbrmi_compose.so: peer writes over hipIpc-mapped images, no collective' if composer_used == 'peer' else ('torch.distributed' if composer_used == 'torch' else composer_used))})" if composer else ""),
                        "baseline_config": BASELINE_CONFIG[workload],
                        "fps": round(1e3 / ms_per_step, 1),
                        "pixels_per_gpu": W * (band[1] - band[0]), "visible_clusters_rank0": int(c.visibleClusters),
