@@ -147,7 +147,8 @@ static void compute_sizes(brmi_pass* p) {
     w.ggxQuads = take(256 * 48);                                                                  // roughness code -> the GGX albedo fit as quadratics in N.V
     w.shadeLights = take((uint64_t)std::max(1u, p->scene.lightCount) * 64);                     // the shading pass's 64 B record per active light
     w.clusterList = take((uint64_t)p->numLightClusters * 8);                                    // per light cluster: first entry / length of its flat light list
-    w.listEntries = take((uint64_t)p->lightPagePool * BRMI_LIGHTS_PER_PAGE * 4 + 256);        // the page contents once more, in the order the page walk visits them
+    w.listEntries = take((uint64_t)p->lightPagePool * BRMI_LIGHTS_PER_PAGE * 4 + 256);
+    w.listRecords = take((uint64_t)p->lightPagePool * BRMI_LIGHTS_PER_PAGE * 64 + 4096);      // ... and the lights' 64 B shading records in the same order        // the page contents once more, in the order the page walk visits them
     // textured / alpha-tested scenes only: where each visible cluster's UV set lives, the texcoords of the resolve arena's vertices,
     // and the alpha-test operands that travel with binned triangles
     const bool uvs = p->sceneHasTextures || p->sceneHasAlphaTest || p->sceneHasVertexColors;

@@ -122,7 +122,7 @@ struct LayerUniform { unsigned long long coatWord, fuzzWord, coatFilledWord, fuz
 struct Workspace {     // byte offsets into BRMI_RES_WORKSPACE
     uint64_t counters, frontierA, frontierB, buckets, tempVisible, bitmask1, bitmask2, wordPrefix, blockSums,
              instanceBitBase, segPrefix, meshLevelWidth, planes, replayNodes, replayBuckets, lightVS, lightMeta, clusterPages, clusterHits, pageTotal, lightHitMasks, binCounts, binRecords, binOverflow, clusterSetup, resolveVerts, resolveTris, matWords, shadeTables, lutF, frameConst, objConst, matConst, deferredPixels, usedClusters,
-             frameSnapshot, tileCounts, tileLists, tileOverflow, xverts, debugStamps, clusterUv, binAlpha, overflowAlpha, resolveUVs, resolveColors, alphaMats, shadeRows, shadeAvgs, ggxQuads, shadeLights, clusterList, listEntries, layerUniform, frameClearBytes, total;
+             frameSnapshot, tileCounts, tileLists, tileOverflow, xverts, debugStamps, clusterUv, binAlpha, overflowAlpha, resolveUVs, resolveColors, alphaMats, shadeRows, shadeAvgs, ggxQuads, shadeLights, clusterList, listEntries, listRecords, layerUniform, frameClearBytes, total;
 };
 
 }  // namespace brmi

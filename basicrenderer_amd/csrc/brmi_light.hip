@@ -131,6 +131,7 @@ ClusterArgs cluster_args_of(brmi_pass* p) {
     a.clusterHits = p->wsPtr<uint32_t>(p->ws.clusterHits); a.pageTotal = p->wsPtr<uint32_t>(p->ws.pageTotal);
     a.hitMasks = p->wsPtr<uint64_t>(p->ws.lightHitMasks); a.maskWords = (std::max(1u, p->scene.lightCount) + 63u) / 64u;
     a.clusterList = p->wsPtr<uint2>(p->ws.clusterList); a.listEntries = p->wsPtr<uint32_t>(p->ws.listEntries);
+    a.shadeLights = p->wsPtr<float4>(p->ws.shadeLights); a.listRecords = p->wsPtr<float4>(p->ws.listRecords);
     return a;
 }
 
@@ -150,6 +151,7 @@ ShadeArgs shade_args_of(brmi_pass* p) {
     { const brmi_scene_buffers ssc = shading_scene_of(p); a.perFrame = ssc.perFrame; a.cameras = ssc.cameras; }
     a.openpbrMaterialCount = p->scene.openpbrMaterialCount; a.lutFuzzLTC = p->scene.lutFuzzLTC;
     a.shadeLights = p->wsPtr<float4>(p->ws.shadeLights); a.clusterList = p->wsPtr<uint2>(p->ws.clusterList); a.listEntries = p->wsPtr<uint32_t>(p->ws.listEntries);
+    a.listRecords = p->wsPtr<float4>(p->ws.listRecords);
     a.depth = static_cast<const float*>(p->res[BRMI_RES_LINEAR_DEPTH]); a.normals = static_cast<const float4*>(p->res[BRMI_RES_GBUF_NORMALS]);
     a.albedo = static_cast<const uint32_t*>(p->res[BRMI_RES_GBUF_ALBEDO]); a.coat = static_cast<const unsigned long long*>(p->res[BRMI_RES_GBUF_COAT]);
     a.emissive = static_cast<const unsigned long long*>(p->res[BRMI_RES_GBUF_EMISSIVE]); a.fuzz = static_cast<const unsigned long long*>(p->res[BRMI_RES_GBUF_FUZZ]);

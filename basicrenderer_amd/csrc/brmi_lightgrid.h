@@ -24,6 +24,7 @@ struct ClusterArgs {
     // the same lists once more for the shading pass, flat: clusterList[c] = {first entry, length}, entries = positions in the active-light
     // list in the order the page walk of the reference visits them (newest page first)
     uint2* clusterList; uint32_t* listEntries;
+    const float4* shadeLights; float4* listRecords;      // the shading pass's 64 B light records, and a copy of them in list order (one hop less per tile)
 };
 
 BRMI_DEV bool light_hits_cluster(float4 sphere, uint32_t type, f3 mn, f3 mx) {
@@ -129,7 +130,12 @@ BRMI_DEV void lc_fill_block(const ClusterArgs& a, uint32_t vblock, uint32_t tid)
             const uint32_t pg = j / BRMI_LIGHTS_PER_PAGE, e = j % BRMI_LIGHTS_PER_PAGE;
             if (pg < valid) {
                 a.pages[base + pg].lightIndices[e] = a.lightMeta[lb + lane] >> 2;
-                a.listEntries[listBase + (pg + 1u == valid ? e : newestCount + BRMI_LIGHTS_PER_PAGE * (valid - 2u - pg) + e)] = lb + lane;
+                const uint32_t pos = listBase + (pg + 1u == valid ? e : newestCount + BRMI_LIGHTS_PER_PAGE * (valid - 2u - pg) + e);
+                a.listEntries[pos] = lb + lane;
+                // the light's shading record beside its list entry: k_shade stages a cluster's lights with ONE dependent load (list position
+                // -> record) instead of two (-> light index -> record); the chain is on every tile's critical path
+                const float4* src = a.shadeLights + (size_t)(lb + lane) * 4u; float4* dst = a.listRecords + (size_t)pos * 4u;
+                dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
             }
         }
         before += (uint32_t)__popcll(m);

@@ -157,7 +157,7 @@ struct ShadeArgs {
     const brmi_per_frame* perFrame; const brmi_camera* cameras; uint32_t openpbrMaterialCount; const float* lutFuzzLTC;
     const float* depth; const float4* normals; const uint32_t* albedo; const unsigned long long* coat; const unsigned long long* emissive;
     const unsigned long long* fuzz; const uint32_t* metallicRoughness;
-    const float4* shadeLights; const uint2* clusterList; const uint32_t* listEntries;
+    const float4* shadeLights; const uint2* clusterList; const uint32_t* listEntries; const float4* listRecords;
     unsigned long long* hdr;
     uint32_t W, H, tilesX, bandY0, bandY1; uint64_t firstPixel, pixelCount;
     uint32_t enablePunctual, clustered;
@@ -371,8 +371,8 @@ BRMI_DEV f3 light_contribution(const Luts& L, const Frag& f, const PixelCtx& c, 
 BRMI_DEV ShadeLightLanes stage_lights(const ShadeArgs& a, uint32_t listBase, uint32_t c0, uint32_t n) {
     ShadeLightLanes s;               // lanes >= n are never broadcast from
     if (lane_id() < n) {
-        const uint32_t li = a.clustered ? a.listEntries[listBase + c0 + lane_id()] : c0 + lane_id();
-        const float4* rec = a.shadeLights + (size_t)li * 4u;
+        // clustered: the records lie in list order (k_lc_fill copies them there); else the active-light list itself, in order
+        const float4* rec = a.clustered ? a.listRecords + (size_t)(listBase + c0 + lane_id()) * 4u : a.shadeLights + (size_t)(c0 + lane_id()) * 4u;
         s.r0 = rec[0]; s.r1 = rec[1]; s.r2 = rec[2]; s.r3 = rec[3];
     }
     return s;
@@ -453,7 +453,11 @@ BRMI_DEV uint32_t shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const flo
         f.NdotV = max2(BRMI_MIN_N_DOT_V, NdotVraw);
         uint32_t opIndex = (uint32_t)(ns.w + 0.5f);
         if (opIndex >= a.openpbrMaterialCount) opIndex = 0;
+#ifdef BRMI_ABLATE_MATCONST
+        const MatConst mc = a.matConst[0];      // (experiment: one wave-uniform record instead of a gather per pixel; wrong image for mixed scenes)
+#else
         const MatConst mc = a.matConst[opIndex];
+#endif
         const float baseWeight = mc.baseWeight, specularWeight = mc.specularWeight;
         const f3 specularColor{mc.specR, mc.specG, mc.specB};
         const f3 weightedBaseColor = satq3(baseColor * baseWeight);

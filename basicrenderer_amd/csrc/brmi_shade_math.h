@@ -239,6 +239,9 @@ BRMI_DEV void build_shade_rows(const Luts& L, float ior, float alpha, ShadeRows&
 }
 // one sample of a folded row: column and weight as in sample_rows
 BRMI_DEV float sample_folded_row(const float* row, float cosT) {
+#ifdef BRMI_ABLATE_ROWS
+    return cosT * 0.5f;      // (experiment: the table gathers gone; wrong image)
+#endif
     const float u = remap_index(clamp_index(cos_to_index(cosT)));
     const float x = u * 32.0f - 0.5f;
     const float x0f = floorf(x);
