@@ -104,7 +104,7 @@ class Config(C.Structure):
                 ("maxTraversalRecords", u32), ("enableOcclusionCulling", u32), ("enableClusteredLighting", u32),
                 ("enablePunctualLights", u32), ("lightClusterSize", u32 * 3), ("phase2ExpansionFactor", u32),
                 ("collectPassStatistics", u32), ("maxBvhLevels", u32), ("bandY0", u32), ("bandY1", u32),
-                ("keepUniformLayerPlanes", u32), ("reserved", u32 * 7)]
+                ("keepUniformLayerPlanes", u32), ("stripeRows", u32), ("stripeCount", u32), ("stripeIndex", u32), ("fullHeight", u32), ("reserved", u32 * 3)]
 
 
 class ResourceDesc(C.Structure):

@@ -9,9 +9,29 @@ TILE = 8
 BAND_ROWS = 1080          # rows per rank for N > 1 (7680 x 1080 = one 4K frame worth of pixels)
 
 
-def frame_size(n_gpus):
-    """Weak scaling: every rank shades 8,294,400 pixels.  N = 1 is the 4K frame of BASELINE.json."""
-    return (3840, 2160) if n_gpus == 1 else (7680, BAND_ROWS * n_gpus)
+STRIPE_BAND_ROWS = 1088   # rows per rank with the interleaved partition: chunks are multiples of the 16-row raster bin, and 1080 has no such divisor
+STRIPE_ROWS = 64          # default chunk height: the fastest of 16 / 32 / 64 / 272 / 544 at N = 8 (profiles/r03_rank_balance.md)
+
+
+def frame_size(n_gpus, partition="bands"):
+    """Weak scaling: every rank shades one 4K frame's worth of pixels (8,294,400 with row bands, 8,355,840 with the interleaved
+    partition).  N = 1 is the 4K frame of BASELINE.json."""
+    if n_gpus == 1:
+        return (3840, 2160)
+    return (7680, (STRIPE_BAND_ROWS if partition == "stripes" else BAND_ROWS) * n_gpus)
+
+
+def stripe_frame_rows(rank, n_gpus, height, rows=STRIPE_ROWS):
+    """Rows of the frame a rank owns under the interleaved partition, in the order of its compact surfaces (include/brmi.h,
+    brmi_config::stripe*): chunks of `rows` rows, `n_gpus` chunks to a group, one chunk per group and rank, the order inside a group
+    running back and forth from group to group."""
+    import numpy as np
+    if rows % 16 or height % (rows * n_gpus):
+        raise ValueError(f"height {height} does not split into groups of {n_gpus} chunks of {rows} rows (a multiple of 16)")
+    v = np.arange(height // n_gpus)
+    g = v // rows
+    slot = np.where(g % 2 == 1, n_gpus - 1 - rank, rank)
+    return (g * n_gpus + slot) * rows + v % rows
 
 
 def band_of(rank, n_gpus, height):

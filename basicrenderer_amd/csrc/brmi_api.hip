@@ -61,6 +61,7 @@ static void compute_sizes(brmi_pass* p) {
     p->paddedPixels = (uint64_t)p->tilesX * p->tilesY * 64;
     p->bandY0 = c.bandY0; p->bandY1 = (c.bandY1 == 0 || c.bandY1 > c.height) ? c.height : c.bandY1;
     if (p->bandY0 >= p->bandY1) p->bandY0 = 0;
+    p->stripes = c.stripeCount > 1u ? StripeMap{c.stripeRows, c.stripeCount, c.stripeIndex, c.fullHeight} : StripeMap{0u, 0u, 0u, c.height};
     { const uint32_t t0 = p->bandY0 / 8, t1 = (p->bandY1 + 7) / 8; p->bandFirstPixel = (uint64_t)t0 * p->tilesX * 64; p->bandPixelCount = (uint64_t)(t1 - t0) * p->tilesX * 64; }
     p->numLightClusters = c.lightClusterSize[0] * c.lightClusterSize[1] * c.lightClusterSize[2];
     p->lightPagePool = p->numLightClusters * BRMI_LIGHT_PAGES_PER_CLUSTER;
@@ -176,7 +177,7 @@ static int read_back(brmi_pass* p, std::vector<T>& dst, const T* src, size_t n) 
 brmi::HzbDesc brmi_pass::hzbDesc() const {
     brmi::HzbDesc d{};
     d.depth = static_cast<const float*>(res[BRMI_RES_LINEAR_DEPTH]); d.mips = static_cast<float*>(res[BRMI_RES_HZB]);
-    d.width = cfg.width; d.height = cfg.height; d.tilesX = tilesX; d.mipCount = hzbMipCount; d.rowLo = bandY0; d.rowHi = bandY1;
+    d.width = cfg.width; d.height = cfg.height; d.tilesX = tilesX; d.mipCount = hzbMipCount; d.rowLo = bandY0; d.rowHi = bandY1; d.stripes = stripes;
     d.paddedW = hzbMipCount ? hzbMipW[0] : 1; d.paddedH = hzbMipCount ? hzbMipH[0] : 1;
     for (uint32_t i = 0; i < brmi::kMaxHzbMips; i++) d.mipOffset[i] = i < hzbMipCount ? (uint32_t)hzbMipOffsets[i] : 0u;
     return d;
@@ -209,7 +210,11 @@ int brmi_create(const brmi_config* cfg, brmi_pass** out) {
     if (!cfg || !out || cfg->structSize != sizeof(brmi_config) || cfg->width == 0 || cfg->height == 0) return BRMI_ERR_INVALID;
     if (cfg->maxVisibleClusters == 0 || cfg->maxVisibleClusters > (1u << 26) || cfg->maxTraversalRecords == 0) return BRMI_ERR_INVALID;
     if (cfg->lightClusterSize[0] == 0 || cfg->lightClusterSize[1] == 0 || cfg->lightClusterSize[2] == 0) return BRMI_ERR_INVALID;
-    if (cfg->lightClusterSize[2] > 62u) return BRMI_ERR_INVALID;      // the slice-start table (workspace and the shading pass's LDS copy) holds 64 entries: gz + 2
+    if (cfg->lightClusterSize[2] > 62u) return BRMI_ERR_INVALID;
+    if (cfg->stripeCount > 1u) {      // interleaved partition: whole chunks of 16-row bin bands, the same number on every GPU, no band on top
+        if (cfg->stripeRows == 0u || cfg->stripeRows % 16u || cfg->stripeIndex >= cfg->stripeCount || cfg->bandY0 != 0u || (cfg->bandY1 != 0u && cfg->bandY1 != cfg->height)) return BRMI_ERR_INVALID;
+        if (cfg->fullHeight == 0u || cfg->fullHeight % (cfg->stripeRows * cfg->stripeCount) || cfg->height != cfg->fullHeight / cfg->stripeCount) return BRMI_ERR_INVALID;
+    }      // the slice-start table (workspace and the shading pass's LDS copy) holds 64 entries: gz + 2
     brmi_pass* p = new brmi_pass();
     p->cfg = *cfg;
     p->totalWords = 1; p->scanBlocks = 1;
@@ -469,7 +474,7 @@ int brmi_update(brmi_pass* p, const brmi_frame_update* u, brmi_stream stream) {
     const brmi_per_frame& pf = p->pfHost;
     if (pf.lightClusterGridSizeX != p->cfg.lightClusterSize[0] || pf.lightClusterGridSizeY != p->cfg.lightClusterSize[1] || pf.lightClusterGridSizeZ != p->cfg.lightClusterSize[2])
         return fail(p, BRMI_ERR_INVALID, "brmi_update: per-frame light cluster grid differs from the configured lightClusterSize");
-    if (pf.screenResX != p->cfg.width || pf.screenResY != p->cfg.height) return fail(p, BRMI_ERR_INVALID, "brmi_update: per-frame screen size differs from the configured target size");
+    if (pf.screenResX != p->cfg.width || pf.screenResY != p->frameHeight()) return fail(p, BRMI_ERR_INVALID, "brmi_update: per-frame screen size differs from the configured target size");
     const float zNear = p->camHost.zNear, zFar = p->camHost.zFar, zSplit = pf.clusterZSplitDepth;
     const uint32_t gz = pf.lightClusterGridSizeZ, nearSlices = pf.nearClusterCount;
     p->planesHost.resize(2 * gz);
@@ -516,7 +521,7 @@ int brmi_update(brmi_pass* p, const brmi_frame_update* u, brmi_stream stream) {
         p->sliceKey[0] = zNear; p->sliceKey[1] = zFar; p->sliceKey[2] = zSplit; p->sliceKeyN[0] = nearSlices; p->sliceKeyN[1] = gz;
     }
     {   // band planes of the screen-tile split, 2 px of slack (view space, through the eye)
-        const float projY = p->camHost.projection[1][1], H = (float)p->cfg.height;
+        const float projY = p->camHost.projection[1][1], H = (float)p->frameHeight();
         const float T = 1.0f - 2.0f * ((float)p->bandY0 - 2.0f) / H, B = 1.0f - 2.0f * ((float)p->bandY1 + 2.0f) / H;
         const float lt = std::sqrt(projY * projY + T * T), lb = std::sqrt(projY * projY + B * B);
         p->bandPlaneTop[0] = 0.0f; p->bandPlaneTop[1] = -projY / lt; p->bandPlaneTop[2] = -T / lt;

@@ -38,6 +38,7 @@ struct CullArgs {
     HzbDesc hzb;
     // multi-GPU row band: two view-space planes through the eye bounding the band (1 = active)
     uint32_t bandActive; float bandTop[3], bandBottom[3];
+    StripeMap stripes;      // interleaved partition: ownership test of the cluster cull
     // mixed traversal: meshes whose widest BVH level fits the LDS frontier are walked by k_cull_hierarchy (one wave per instance, one launch),
     // the few wider ones by the level-per-launch kernels (all lanes of the chip on one level); the latter skip instances narrower than this
     const uint32_t* meshLevelWidth; uint32_t levelKernelsWidthLo;
@@ -110,8 +111,25 @@ BRMI_DEV bool occlusion_culled(const HzbDesc& hzb, const brmi_camera* cam, float
     uint32_t hzbW = (uint32_t)rintf(viewW / ssx), hzbH = (uint32_t)rintf(viewH / ssy);
     hzbW = max(hzbW, 1u); hzbH = max(hzbH, 1u);
     const uint32_t mw = max(hzbW >> mip, 1u), mh = max(hzbH >> mip, 1u);
-    const uint32_t x0 = min((uint32_t)floorf(pu0 * (float)mw), mw - 1u), y0 = min((uint32_t)floorf(pv0 * (float)mh), mh - 1u);
-    const uint32_t x1 = min((uint32_t)floorf(pu1 * (float)mw), mw - 1u), y1 = min((uint32_t)floorf(pv1 * (float)mh), mh - 1u);
+    uint32_t x0 = min((uint32_t)floorf(pu0 * (float)mw), mw - 1u), y0 = min((uint32_t)floorf(pv0 * (float)mh), mh - 1u);
+    uint32_t x1 = min((uint32_t)floorf(pu1 * (float)mw), mw - 1u), y1 = min((uint32_t)floorf(pv1 * (float)mh), mh - 1u);
+    if (stripe_on(hzb.stripes)) {
+        // Interleaved partition (no counterpart in the reference): the chain is built from this GPU's compact depth surface, so the rectangle's
+        // frame rows are mapped onto the surface rows this GPU owns among them -- consecutive surface rows -- and the mip is chosen from THAT
+        // extent; a rectangle of extent <= 2^mip spans at most two texels per axis, so the four corner texels cover it.  A rectangle that
+        // holds none of this GPU's rows says nothing here (the ownership test of the cluster cull drops such clusters for good).
+        const uint32_t H = hzb.stripes.fullHeight;
+        const uint32_t r0 = min((uint32_t)floorf(ay0), H - 1u), r1 = min((uint32_t)floorf(ay1), H - 1u);
+        const uint32_t f = stripe_first_owned(hzb.stripes, r0), l = stripe_last_owned(hzb.stripes, r1);
+        if (l == 0xFFFFFFFFu || f > l) return false;
+        const uint32_t vy0 = stripe_vrow(hzb.stripes, f), vy1 = stripe_vrow(hzb.stripes, l);
+        const uint32_t smip = ceil_log2_clamped(max2(fabsf(ex) + 1.0f, (float)(vy1 - vy0 + 1u)), hzb.mipCount - 1u);      // (|ex|: the reference's horizontal extents come out swapped; here the test has to be conservative)
+        const uint32_t smw = max(hzb.paddedW >> smip, 1u), smh = max(hzb.paddedH >> smip, 1u);
+        const uint32_t px0 = min((uint32_t)floorf(min2(ax0, ax1)), hzb.width - 1u), px1 = min((uint32_t)floorf(max2(ax0, ax1)), hzb.width - 1u);
+        x0 = min(px0 >> smip, smw - 1u); x1 = min(px1 >> smip, smw - 1u); y0 = min(vy0 >> smip, smh - 1u); y1 = min(vy1 >> smip, smh - 1u);
+        const float e0 = hzb_load(hzb, smip, x0, y0, smw), e1 = hzb_load(hzb, smip, x1, y0, smw), e2 = hzb_load(hzb, smip, x1, y1, smw), e3 = hzb_load(hzb, smip, x0, y1, smw);
+        return max2(max2(e0, e1), max2(e2, e3)) < sphereDepth - radius;
+    }
     if (mip >= hzb.mipCount) return false;
     const float d0 = hzb_load(hzb, mip, x0, y0, mw), d1 = hzb_load(hzb, mip, x1, y0, mw), d2 = hzb_load(hzb, mip, x1, y1, mw), d3 = hzb_load(hzb, mip, x0, y1, mw);
     const float mx = max2(max2(d0, d1), max2(d2, d3));
@@ -125,6 +143,23 @@ BRMI_DEV bool occlusion_test(const CullArgs& a, const brmi_camera* cam, bool rep
     const m4 prevModel = load_m4(&obj->prevModel[0][0]);
     const f3 pc = to_view_space(localCenter, prevModel, load_m4(&cam->prevView[0][0]));
     return occlusion_culled(a.hzb, cam, cam->prevUnjitteredProjection[0][0], cam->prevUnjitteredProjection[1][1], pc, -pc.z, localRadius * max_axis_scale(prevModel));
+}
+
+// Interleaved partition: does the sphere's screen rectangle (the vertical extents of sphere_screen_extents, two rows of slack) hold a row
+// this GPU owns?  Spheres that reach the near plane are kept (the extents are not defined there).
+BRMI_DEV bool stripe_rejects(const StripeMap& m, const brmi_camera* cam, f3 centerVS, float radius) {
+    const float pz = centerVS.z;
+    if (!(-pz - radius > cam->zNear)) return false;
+    const float py = -centerVS.y, p11 = cam->projection[1][1];
+    const float rad2 = radius * radius, d = pz * radius;
+    const float vv = sqrtf(py * py + pz * pz - rad2);
+    const float va = py * vv, vb = py * radius, vc = pz * vv;
+    const float B = (va - d) * p11 / (vc + vb), T = (va + d) * p11 / (vc - vb);
+    const float v0 = sat(T * -0.5f + 0.5f), v1 = sat(B * -0.5f + 0.5f);
+    if (!(v0 <= v1)) return false;
+    const float H = (float)m.fullHeight;
+    const int r0 = max(to_int_sat(floorf(v0 * H)) - 2, 0), r1 = min(to_int_sat(floorf(v1 * H)) + 2, (int)m.fullHeight - 1);
+    return stripe_first_owned(m, (uint32_t)r0) > (uint32_t)r1;
 }
 
 // K1 -------------------------------------------------------------------------------------------
@@ -646,6 +681,7 @@ __global__ void __launch_bounds__(256) k_cull_clusters(CullArgs a, const BucketR
                         // tile-bounds test of the screen-tile split: conservative sphere vs the band's two planes
                         if (dot3(f3{a.bandTop[0], a.bandTop[1], a.bandTop[2]}, cVS) < -rW || dot3(f3{a.bandBottom[0], a.bandBottom[1], a.bandBottom[2]}, cVS) < -rW) survives = false;
                     }
+                    if (survives && stripe_on(a.stripes) && stripe_rejects(a.stripes, cam, cVS, rW)) survives = false;      // no row of this GPU's: dropped, not replayed
                     if (survives && a.occlusion &&
                         occlusion_test(a, cam, replay, f3{bounds.x, bounds.y, bounds.z}, bounds.w, cVS, rW, sc.perObject + inst.perObjectBufferIndex)) {
                         survives = false;
@@ -895,6 +931,7 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
                                       p->camHost.projection[3][0] == 0.0f && p->camHost.projection[3][1] == 0.0f;
     a.bandActive = ((p->bandY0 != 0 || p->bandY1 != p->cfg.height) && symmetricPerspective) ? 1u : 0u;
     for (int k = 0; k < 3; k++) { a.bandTop[k] = p->bandPlaneTop[k]; a.bandBottom[k] = p->bandPlaneBottom[k]; }
+    a.stripes = p->stripes;
     const brmi_pass* chain = p->chainOwner(phase);      // frames in flight: phase 1 reads the chain of the pass that rendered the frame before
     a.occlusion = (p->cfg.enableOcclusionCulling && chain->hzbValid && p->camHost.isOrtho == 0) ? 1u : 0u;
     a.replayNodes = p->wsPtr<NodeRecord>(p->ws.replayNodes); a.replayBuckets = p->wsPtr<BucketRecord>(p->ws.replayBuckets);

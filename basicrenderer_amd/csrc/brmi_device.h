@@ -166,6 +166,46 @@ BRMI_DEV uint4 pack_visible_cluster(uint32_t view, uint32_t inst, uint32_t meshl
 // tiled 8x8 surface addressing, column-major inside the tile: element index of pixel (x, y)
 BRMI_DEV uint32_t tiled_index(uint32_t x, uint32_t y, uint32_t tilesX) { return (((y >> 3) * tilesX + (x >> 3)) << 6) | ((x & 7u) << 3) | (y & 7u); }
 
+// ---- interleaved screen partition (brmi_config::stripe*): rows of the frame <-> rows of this GPU's compact surfaces -----------------------
+// The frame is cut into chunks of `rows` rows; `count` consecutive chunks form a group, every GPU owns one chunk of every group: chunk
+// `index` in even groups, chunk count - 1 - index in odd ones (the order runs back and forth, so a vertical gradient of the frame's cost --
+// sky at the top, the horizon's detail in the middle -- does not favour one GPU in every group: measured max / min over 8 ranks 1.16 -> see
+// DESIGN.md section 6).
+struct StripeMap { uint32_t rows, count, index, fullHeight; };      // count <= 1: the identity (fullHeight = the surface height)
+BRMI_DEV bool stripe_on(const StripeMap& m) { return m.count > 1u; }
+BRMI_DEV uint32_t stripe_slot(const StripeMap& m, uint32_t group) { return (group & 1u) ? m.count - 1u - m.index : m.index; }      // this GPU's chunk inside a group
+BRMI_DEV bool stripe_owns(const StripeMap& m, uint32_t py) {
+    if (m.count <= 1u) return true;
+    const uint32_t c = py / m.rows, g = c / m.count;
+    return c - g * m.count == stripe_slot(m, g);
+}
+BRMI_DEV uint32_t stripe_vrow(const StripeMap& m, uint32_t py) {      // surface row of an owned frame row
+    if (m.count <= 1u) return py;
+    const uint32_t c = py / m.rows;
+    return (c / m.count) * m.rows + (py - c * m.rows);
+}
+BRMI_DEV uint32_t stripe_rrow(const StripeMap& m, uint32_t v) {       // frame row of a surface row
+    if (m.count <= 1u) return v;
+    const uint32_t g = v / m.rows;
+    return (g * m.count + stripe_slot(m, g)) * m.rows + (v - g * m.rows);
+}
+// first owned frame row >= y / last owned frame row <= y (0xFFFFFFFF: none)
+BRMI_DEV uint32_t stripe_first_owned(const StripeMap& m, uint32_t y) {
+    if (m.count <= 1u) return y;
+    const uint32_t c = y / m.rows, g = c / m.count, mine = g * m.count + stripe_slot(m, g);
+    if (c == mine) return y;
+    if (c < mine) return mine * m.rows;
+    return ((g + 1u) * m.count + stripe_slot(m, g + 1u)) * m.rows;
+}
+BRMI_DEV uint32_t stripe_last_owned(const StripeMap& m, uint32_t y) {
+    if (m.count <= 1u) return y;
+    const uint32_t c = y / m.rows, g = c / m.count, mine = g * m.count + stripe_slot(m, g);
+    if (c == mine) return y;
+    if (c > mine) return mine * m.rows + m.rows - 1u;
+    if (g == 0u) return 0xFFFFFFFFu;
+    return ((g - 1u) * m.count + stripe_slot(m, g - 1u)) * m.rows + m.rows - 1u;
+}
+
 // wave64 helpers
 // force a wave-uniform value into an SGPR (frame constants loaded through a pointer otherwise occupy VGPRs)
 BRMI_DEV float uni(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x))); }

@@ -197,13 +197,14 @@ BRMI_DEV void job_shade_material_table(const brmi_scene_buffers& sc, const float
 //   sliceStart[0] = 0, sliceStart[gz + 1] = +inf.
 // The slice starts are evaluated on the host (brmi_update: they depend on the camera's depth range and the grid alone, a bisection of ~30
 // dependent fp64 logarithms per slice that was this kernel's critical path) and travel as kernel arguments.
-BRMI_DEV void job_shade_tables(const brmi_scene_buffers& sc, ShadeTables t, uint32_t W, uint32_t H, const float* sliceStart, uint32_t i) {
+BRMI_DEV void job_shade_tables(const brmi_scene_buffers& sc, ShadeTables t, uint32_t W, uint32_t H, const StripeMap& stripes, const float* sliceStart, uint32_t i) {
     const brmi_per_frame* pf = sc.perFrame;
     const float resX = (float)pf->screenResX, resY = (float)pf->screenResY;
     const uint32_t gx = pf->lightClusterGridSizeX, gy = pf->lightClusterGridSizeY, gz = pf->lightClusterGridSizeZ;
     const float tsx = resX / (float)gx, tsy = resY / (float)gy;
     if (i < W) t.x[i] = AxisEntry{((float)i + 0.5f) / resX, (uint32_t)((float)i / tsx)};
-    if (i < H) t.y[i] = AxisEntry{((float)i + 0.5f) / resY, (uint32_t)((float)i / tsy)};
+    // (interleaved partition: the table is indexed by the surface row, its entries are those of the frame row behind it)
+    if (i < H) { const float fy = (float)stripe_rrow(stripes, i); t.y[i] = AxisEntry{(fy + 0.5f) / resY, (uint32_t)(fy / tsy)}; }
     if (i <= gz + 1u) t.sliceStart[i] = sliceStart[i];
 }
 
@@ -212,7 +213,7 @@ struct FrameJobs {
     m4* frameConst; FrameSnapshot* snapshot; float* objConst; MaterialWords* matWords; MatConst* matConst; ShadeTables tables; float4* lightVS; uint32_t* lightMeta; float4* shadeLights;
     AlphaMaterial* alphaMats; LayerUniform* layer;
     const float* lutF; ShadeRows* shadeRows; ShadeAverages* shadeAvgs; GgxQuad* ggxQuads;
-    uint32_t W, H;
+    uint32_t W, H; StripeMap stripes;
     float sliceStart[64];        // first view depth of every light-cluster slice (brmi_update), [0] = 0, [gz + 1] = +inf
     uint4* frameState; uint64_t frameState16;      // brmi_execute: the culling pass's counters + survivor bitmasks, zeroed here (job 7)
     uint32_t firstBlock[8];      // block ranges of the seven jobs
@@ -223,7 +224,7 @@ __global__ void __launch_bounds__(64) k_frame_constants(FrameJobs j) {
     if (b < j.firstBlock[1]) job_object_constants(j.sc, j.frameConst, j.objConst, j.snapshot, (b - j.firstBlock[0]) * 64u + threadIdx.x);
     else if (b < j.firstBlock[2]) job_material_words(j.sc, j.matWords, j.alphaMats, (b - j.firstBlock[1]) * 64u + threadIdx.x);
     else if (b < j.firstBlock[3]) job_material_constants(j.sc, j.matConst, (b - j.firstBlock[2]) * 64u + threadIdx.x);
-    else if (b < j.firstBlock[4]) job_shade_tables(j.sc, j.tables, j.W, j.H, j.sliceStart, (b - j.firstBlock[3]) * 64u + threadIdx.x);
+    else if (b < j.firstBlock[4]) job_shade_tables(j.sc, j.tables, j.W, j.H, j.stripes, j.sliceStart, (b - j.firstBlock[3]) * 64u + threadIdx.x);
     else if (b < j.firstBlock[5]) job_light_spheres(j.sc, j.lightVS, j.lightMeta, j.shadeLights, (b - j.firstBlock[4]) * 64u + threadIdx.x);
     else if (b < j.firstBlock[6]) job_shade_material_table(j.sc, j.lutF, j.shadeRows, j.shadeAvgs, j.ggxQuads, (b - j.firstBlock[5]) * 64u + threadIdx.x);
     else if (b < j.firstBlock[7]) { for (uint64_t i = (uint64_t)(b - j.firstBlock[6]) * 64u + threadIdx.x; i < j.frameState16; i += (uint64_t)(j.firstBlock[7] - j.firstBlock[6]) * 64u) j.frameState[i] = make_uint4(0u, 0u, 0u, 0u); }
@@ -253,7 +254,7 @@ int ensure_frame_constants(brmi_pass* p, hipStream_t s) {
     j.lightVS = p->wsPtr<float4>(p->ws.lightVS); j.lightMeta = p->wsPtr<uint32_t>(p->ws.lightMeta); j.shadeLights = p->wsPtr<float4>(p->ws.shadeLights);
     j.alphaMats = p->sceneHasAlphaTest ? p->wsPtr<AlphaMaterial>(p->ws.alphaMats) : nullptr;
     j.layer = p->wsPtr<LayerUniform>(p->ws.layerUniform);
-    j.W = p->cfg.width; j.H = p->cfg.height;
+    j.W = p->cfg.width; j.H = p->cfg.height; j.stripes = p->stripes;
     for (uint32_t k = 0; k < 64; k++) j.sliceStart[k] = k < p->sliceStartHost.size() ? p->sliceStartHost[k] : 0.0f;
     auto blocks = [](uint32_t n) { return (std::max(1u, n) + 63u) / 64u; };
     j.lutF = p->wsPtr<float>(p->ws.lutF); j.shadeRows = p->wsPtr<ShadeRows>(p->ws.shadeRows); j.shadeAvgs = p->wsPtr<ShadeAverages>(p->ws.shadeAvgs); j.ggxQuads = p->wsPtr<GgxQuad>(p->ws.ggxQuads);

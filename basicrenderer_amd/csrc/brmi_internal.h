@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "brmi.h"
+#include "brmi_device.h"
 
 namespace brmi {
 
@@ -106,6 +107,7 @@ struct HzbDesc {
     const float* depth; float* mips;
     uint32_t width, height, tilesX, mipCount, paddedW, paddedH;
     uint32_t rowLo, rowHi;          // rows this GPU renders (multi-GPU band); every other row reads as empty
+    StripeMap stripes;              // interleaved partition: the chain lives in surface rows, the occlusion test maps the frame's rows onto them
     uint32_t mipOffset[kMaxHzbMips];
 };
 
@@ -137,6 +139,8 @@ struct brmi_pass {
     uint32_t tilesX = 0, tilesY = 0;
     uint64_t paddedPixels = 0;
     uint32_t bandY0 = 0, bandY1 = 0;
+    brmi::StripeMap stripes{0, 0, 0, 0};     // brmi_config::stripe*: count > 1 = interleaved partition, surfaces hold the owned rows only
+    uint32_t frameHeight() const { return stripes.count > 1u ? stripes.fullHeight : cfg.height; }   // rows of the frame the cameras describe
     float bandPlaneTop[3] = {0, 0, 0}, bandPlaneBottom[3] = {0, 0, 0};
     uint64_t bandFirstPixel = 0, bandPixelCount = 0;   // tiled index range covering the band's tile rows
     uint32_t maxLevels = 1;

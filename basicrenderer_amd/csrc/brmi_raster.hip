@@ -66,7 +66,9 @@ struct RasterArgs {
     uint32_t* counters;
     uint32_t firstCounter, countCounter;   // counter indices: first cluster (0xFFFFFFFF = 0) and cluster count
     unsigned long long* vis;
-    uint32_t visW, visH, tilesX, bandY0, bandY1;
+    uint32_t visW, visH, tilesX, bandY0, bandY1;      // visW x visH: the FRAME (scissor clamp); bandY0 / bandY1: rows of the surface this GPU renders (records live in surface rows)
+    uint32_t rowLo, rowHi;                            // frame rows k_raster looks at: the band, or the whole frame with the interleaved partition ...
+    StripeMap stripes;                                // ... whose ownership test and frame row -> surface row mapping this is
     // cluster-granular sort-middle (k_raster_tile_lists / k_raster_tiles): per 64 x 64 px screen tile a list of visible-cluster indices
     uint32_t* tileCounts; struct TileEntry* tileLists; uint32_t tileCapacity, rtilesX, rtilesY, tileMinSlice;
     unsigned long long* debugStamps;                     // instrumented builds only
@@ -391,8 +393,13 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
             // kernel's wave-cycles, phase stamps); frames of few large clusters keep 64 (measured both ways, profiles/r03_experiments.md)
             const bool big = active && rows * rectWidth > (alphaCluster ? a.bigTriAreaAlpha : (count >= a.denseClusterCount ? a.bigTriAreaDense : a.bigTriArea));
             // bins the box overlaps (rows clipped to this GPU's band)
-            const int yLo = max(minY, (int)a.bandY0), yHi = min(maxY, (int)a.bandY1 - 1);
+            const int yLo = max(minY, (int)a.rowLo), yHi = min(maxY, (int)a.rowHi - 1);
             const int band0 = yLo >> BIN_ROWS_SHIFT, band1 = yHi >> BIN_ROWS_SHIFT, strip0 = minX >> BIN_W_SHIFT, strip1 = maxX >> BIN_W_SHIFT;
+            // interleaved partition: a 16-row bin band of the frame is owned whole or not at all (chunks are multiples of 16 rows); an owned
+            // one is bin band `vband` of this GPU's surfaces
+            const bool striped = stripe_on(a.stripes);
+            auto owns_band = [&](int band) { return !striped || stripe_owns(a.stripes, (uint32_t)band << BIN_ROWS_SHIFT); };
+            auto vband = [&](int band) { return striped ? stripe_vrow(a.stripes, (uint32_t)band << BIN_ROWS_SHIFT) >> BIN_ROWS_SHIFT : (uint32_t)band; };
             const int nStrips = strip1 - strip0 + 1;
             const int entries = (big && yLo <= yHi) ? (band1 - band0 + 1) * nStrips : 0;
             const uint32_t flags = t | (useScanlineRanges ? 0x100u : 0u);
@@ -406,7 +413,10 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
             // the setup of every triangle parked in LDS, then lane k takes rows k, k + 64, ... of the concatenated row list.
             {
                 const bool small = active && !big && !(a.debugFlags & 1) && yLo <= yHi;
-                const uint32_t myRows = small ? (uint32_t)(yHi - yLo + 1) : 0u;
+                uint32_t myRows = small ? (uint32_t)(yHi - yLo + 1) : 0u;
+                // interleaved partition: a box inside one chunk (nearly all small boxes) is owned whole or dropped here; one that straddles a
+                // chunk boundary keeps its rows and the row tasks test each
+                if (striped && myRows != 0u && (uint32_t)yLo / a.stripes.rows == (uint32_t)yHi / a.stripes.rows && !stripe_owns(a.stripes, (uint32_t)yLo)) myRows = 0u;
                 uint32_t incl = myRows;
 #pragma unroll
                 for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o); if (lane >= (uint32_t)o) incl += v; }
@@ -430,13 +440,15 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
                         const int py = tpI[3][tri] + (int)(task - rowOff[tri]);
                         const float t_dx0 = tpF[2][tri], t_dx1 = tpF[3][tri], t_dy0 = tpF[4][tri], t_dy1 = tpF[5][tri];
                         float sb0 = tpF[0][tri], sb1 = tpF[1][tri];
+                        if (striped && !stripe_owns(a.stripes, (uint32_t)py)) continue;      // another GPU's row
                         for (int k = py - t_minY; k > 0; k--) { sb0 += t_dy0; sb1 += t_dy1; }      // the serial loop's row stepping
+                        const int spy = striped ? (int)stripe_vrow(a.stripes, (uint32_t)py) : py;      // the row of this GPU's surface
                         if (alphaCluster) {
                             const TexAlpha ta{unormT, amat, AlphaTri{tpA[0][tri], tpA[1][tri], tpA[2][tri], f2{tpA[3][tri], tpA[4][tri]}, f2{tpA[5][tri], tpA[6][tri]}, f2{tpA[7][tri], tpA[8][tri]}}};
-                            raster_row(gsink, ta, py, t_minX, t_w, useScanlineRanges, sb0, sb1, t_dx0, t_dx1, -(t_dx0 + t_dx1), tpF[6][tri], tpF[7][tri], tpF[8][tri], clusterIndex, waveBase + tri,
+                            raster_row(gsink, ta, spy, t_minX, t_w, useScanlineRanges, sb0, sb1, t_dx0, t_dx1, -(t_dx0 + t_dx1), tpF[6][tri], tpF[7][tri], tpF[8][tri], clusterIndex, waveBase + tri,
                                        t_minX, t_minX + t_w - 1);
                         } else
-                        raster_row(gsink, NoAlpha{}, py, t_minX, t_w, useScanlineRanges, sb0, sb1, t_dx0, t_dx1, -(t_dx0 + t_dx1), tpF[6][tri], tpF[7][tri], tpF[8][tri], clusterIndex, waveBase + tri,
+                        raster_row(gsink, NoAlpha{}, spy, t_minX, t_w, useScanlineRanges, sb0, sb1, t_dx0, t_dx1, -(t_dx0 + t_dx1), tpF[6][tri], tpF[7][tri], tpF[8][tri], clusterIndex, waveBase + tri,
                                    t_minX, t_minX + t_w - 1);
                     }
                     __syncthreads();
@@ -460,11 +472,11 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
                 if (windowed) {
                     for (int cI = (int)lane; cI < cells; cI += 64) binBase[cI] = 0u;
                     __syncthreads();
-                    if (few) for (int band = band0; band <= band1; band++) for (int st = strip0; st <= strip1; st++) atomicAdd(&binBase[(band - wb0) * winW + (st - ws0)], 1u);
+                    if (few) for (int band = band0; band <= band1; band++) if (owns_band(band)) for (int st = strip0; st <= strip1; st++) atomicAdd(&binBase[(band - wb0) * winW + (st - ws0)], 1u);
                     __syncthreads();
                     for (int cI = (int)lane; cI < cells; cI += 64) {
                         const uint32_t nrec = binBase[cI];
-                        if (nrec != 0u) binBase[cI] = atomicAdd(&a.binCounts[(uint32_t)(wb0 + cI / winW) * a.binsX + (uint32_t)(ws0 + cI % winW)], nrec);
+                        if (nrec != 0u) binBase[cI] = atomicAdd(&a.binCounts[vband(wb0 + cI / winW) * a.binsX + (uint32_t)(ws0 + cI % winW)], nrec);
                     }
                     __syncthreads();
                 }
@@ -477,11 +489,11 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
                         const int n = min(((band + 1) << BIN_ROWS_SHIFT), yHi + 1) - py;
                         BinRecord r;
                         r.clusterIndex = clusterIndex; r.triAndFlags = flags | ((uint32_t)n << 16);
-                        r.minX = minX; r.rectWidth = rectWidth; r.rowStart = py;
+                        r.minX = minX; r.rectWidth = rectWidth; r.rowStart = striped ? (int)stripe_vrow(a.stripes, (uint32_t)py) : py;      // (an owned band's rows are consecutive surface rows)
                         r.sb0 = sb0; r.sb1 = sb1; r.dx_b0 = dx_b0; r.dx_b1 = dx_b1; r.dy_b0 = dy_b0; r.dy_b1 = dy_b1; r.d0 = d0; r.d1 = d1; r.d2 = d2; r.pad0 = 0; r.pad1 = alphaCluster ? 1u : 0u;
-                        for (int st = strip0; st <= strip1; st++) {
-                            if (windowed) bin_store(a, unormT, r, arec, (uint32_t)st, (uint32_t)band, atomicAdd(&binBase[(band - wb0) * winW + (st - ws0)], 1u));
-                            else bin_append(a, unormT, r, arec, (uint32_t)st, (uint32_t)band);
+                        if (owns_band(band)) for (int st = strip0; st <= strip1; st++) {
+                            if (windowed) bin_store(a, unormT, r, arec, (uint32_t)st, vband(band), atomicAdd(&binBase[(band - wb0) * winW + (st - ws0)], 1u));
+                            else bin_append(a, unormT, r, arec, (uint32_t)st, vband(band));
                         }
                         for (int k = 0; k < n; k++) { sb0 += dy_b0; sb1 += dy_b1; }
                         py += n;
@@ -510,21 +522,23 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
                 float sb0 = c_sb0, sb1 = c_sb1;
                 int py = c_yLo;
                 for (int band = c_band0 + (int)lane; band <= c_band1; band += 64) {
+                    if (!owns_band(band)) continue;      // (the stepping below catches up from the last band this lane emitted)
                     const int start = max(band << BIN_ROWS_SHIFT, c_yLo);
                     for (; py < start; py++) { sb0 += c_dy0; sb1 += c_dy1; }
                     const int n = min(((band + 1) << BIN_ROWS_SHIFT), c_yHi + 1) - start;
                     BinRecord r;
                     r.clusterIndex = clusterIndex; r.triAndFlags = c_flags | ((uint32_t)n << 16);
-                    r.minX = c_minX; r.rectWidth = c_w; r.rowStart = start;
+                    r.minX = c_minX; r.rectWidth = c_w; r.rowStart = striped ? (int)stripe_vrow(a.stripes, (uint32_t)start) : start;
+                    const uint32_t vb = vband(band);
                     r.sb0 = sb0; r.sb1 = sb1; r.dx_b0 = c_dx0; r.dx_b1 = c_dx1; r.dy_b0 = c_dy0; r.dy_b1 = c_dy1; r.d0 = c_d0; r.d1 = c_d1; r.d2 = c_d2; r.pad0 = 0; r.pad1 = alphaCluster ? 1u : 0u;
                     // all the band's bin slots are requested before the first one is used: the atomics overlap instead of costing one
                     // round trip per strip (a full-width triangle touches 15-30 strips)
                     for (int st0 = c_strip0; st0 <= c_strip1; st0 += 8) {
                         uint32_t slots[8];
 #pragma unroll
-                        for (int k = 0; k < 8; k++) slots[k] = (st0 + k <= c_strip1) ? atomicAdd(&a.binCounts[(uint32_t)band * a.binsX + (uint32_t)(st0 + k)], 1u) : 0u;
+                        for (int k = 0; k < 8; k++) slots[k] = (st0 + k <= c_strip1) ? atomicAdd(&a.binCounts[vb * a.binsX + (uint32_t)(st0 + k)], 1u) : 0u;
 #pragma unroll
-                        for (int k = 0; k < 8; k++) if (st0 + k <= c_strip1) bin_store(a, unormT, r, c_arec, (uint32_t)(st0 + k), (uint32_t)band, slots[k]);
+                        for (int k = 0; k < 8; k++) if (st0 + k <= c_strip1) bin_store(a, unormT, r, c_arec, (uint32_t)(st0 + k), vb, slots[k]);
                     }
                 }
             }
@@ -1131,6 +1145,8 @@ int launch_clear(brmi_pass* p, hipStream_t s) {
 
 void raster_tile_grid(uint32_t width, uint32_t height, uint32_t* tilesX, uint32_t* tilesY) { *tilesX = (width + RT_W - 1) / RT_W; *tilesY = (height + RT_H - 1) / RT_H; }
 
+static bool stripe_count_on(const brmi_pass* p) { return p->stripes.count > 1u; }
+
 int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
     if (phase != 1 && phase != 2) return fail(p, BRMI_ERR_INVALID, "brmi_raster: phase %u (1 or 2)", phase);
     if (phase == 2 && !p->cfg.enableOcclusionCulling) return fail(p, BRMI_ERR_STATE, "brmi_raster: phase 2 needs a pass created with enableOcclusionCulling");
@@ -1140,7 +1156,8 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
     a.firstCounter = 0xFFFFFFFFu; a.countCounter = CNT_VISIBLE;
     if (phase == 2) { a.firstCounter = CNT_VISIBLE; a.countCounter = CNT_VISIBLE2; }   // clusters [visible1, visible1 + visible2)
     a.vis = static_cast<unsigned long long*>(p->res[BRMI_RES_VISIBILITY]);
-    a.visW = p->cfg.width; a.visH = p->cfg.height; a.tilesX = p->tilesX; a.bandY0 = p->bandY0; a.bandY1 = p->bandY1;
+    a.visW = p->cfg.width; a.visH = p->frameHeight(); a.tilesX = p->tilesX; a.bandY0 = p->bandY0; a.bandY1 = p->bandY1;
+    a.stripes = p->stripes; a.rowLo = stripe_count_on(p) ? 0u : p->bandY0; a.rowHi = stripe_count_on(p) ? p->frameHeight() : p->bandY1;
     a.binRecords = p->wsPtr<BinRecord>(p->ws.binRecords); a.binCounts = p->wsPtr<uint32_t>(p->ws.binCounts);
     a.binCapacity = p->binCapacity; a.binsX = p->binsX; a.binsY = p->binsY;
     a.overflow = p->wsPtr<BinRecord>(p->ws.binOverflow); a.overflowPerStripe = p->binOverflowPerStripe;
@@ -1156,7 +1173,7 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
     a.tileCounts = p->wsPtr<uint32_t>(p->ws.tileCounts); a.tileLists = p->wsPtr<TileEntry>(p->ws.tileLists); a.tileCapacity = p->tileCapacity;
     a.xverts = p->wsPtr<float>(p->ws.xverts); a.xvertClusters = p->xvertClusters; a.debugStamps = p->wsPtr<unsigned long long>(p->ws.debugStamps);
     a.rtilesX = p->rtilesX; a.rtilesY = p->rtilesY; a.tileOverflow = p->wsPtr<uint2>(p->ws.tileOverflow); a.tileOverflowCapacity = p->tileOverflowCapacity;
-    if (p->rasterTiles && !p->sceneHasAlphaTest) {
+    if (p->rasterTiles && !p->sceneHasAlphaTest && !stripe_count_on(p)) {      // (the tile path knows bands only)
         // cluster-granular sort-middle: lists, tiles (only the tile rows of this GPU's band), overflow pairs + list reset
         const uint32_t row0 = p->bandY0 >> RT_H_SHIFT, row1 = (p->bandY1 - 1u) >> RT_H_SHIFT;
         a.tileMinSlice = p->tileMinSlice;

@@ -27,6 +27,7 @@ struct GBufferArgs {
     float4* normals; uint32_t* albedo; unsigned long long* coat; unsigned long long* emissive; unsigned long long* fuzz;
     uint32_t* metallicRoughness; uint32_t* motion; float* depth;
     uint32_t W, H, tilesX, bandY0, bandY1; uint64_t firstPixel, pixelCount;
+    StripeMap stripes;      // interleaved partition: surface row -> frame row
     uint32_t clusterCapacity;
     const m4* frameConst; const float* objConst;
     const ClusterSetup* setup; ResolveVertex* verts; ResolveTriangle* tris; uint32_t vertCapacity, triCapacity;
@@ -395,7 +396,7 @@ BRMI_DEV void gbuffer_body(const GBufferArgs& a, const Epi& epi) {
                 else o[k] = decode_uv_set(a.clusterUv[clusterIndex], set, local);
             }
         };
-        const float uvx = ((float)px + 0.5f) / winX, uvy = ((float)py + 0.5f) / winY;
+        const float uvx = ((float)px + 0.5f) / winX, uvy = ((float)stripe_rrow(a.stripes, py) + 0.5f) / winY;      // the pixel's row in the FRAME
         const float ndcX = uvx * 2.0f - 1.0f, ndcY = (1.0f - uvy) * 2.0f - 1.0f;
         const f3 l = bary_lambda(r, ndcX, ndcY);
         const f3 posOS{dot3(f3{p[0].x, p[1].x, p[2].x}, l), dot3(f3{p[0].y, p[1].y, p[2].y}, l), dot3(f3{p[0].z, p[1].z, p[2].z}, l)};
@@ -604,6 +605,7 @@ static GBufferArgs gbuffer_args_of(brmi_pass* p) {
     a.fuzz = static_cast<unsigned long long*>(p->res[BRMI_RES_GBUF_FUZZ]); a.metallicRoughness = static_cast<uint32_t*>(p->res[BRMI_RES_GBUF_METALLIC_ROUGHNESS]);
     a.motion = static_cast<uint32_t*>(p->res[BRMI_RES_GBUF_MOTION_VECTORS]); a.depth = p->depthFinal ? nullptr : static_cast<float*>(p->res[BRMI_RES_LINEAR_DEPTH]);
     a.W = p->cfg.width; a.H = p->cfg.height; a.tilesX = p->tilesX; a.bandY0 = p->bandY0; a.bandY1 = p->bandY1; a.firstPixel = p->bandFirstPixel; a.pixelCount = p->bandPixelCount;
+    a.stripes = p->stripes;
     a.clusterCapacity = p->cfg.maxVisibleClusters;
     a.frameConst = p->wsPtr<m4>(p->ws.frameConst); a.objConst = p->wsPtr<float>(p->ws.objConst);
     a.setup = p->wsPtr<ClusterSetup>(p->ws.clusterSetup); a.verts = p->wsPtr<ResolveVertex>(p->ws.resolveVerts); a.tris = p->wsPtr<ResolveTriangle>(p->ws.resolveTris);

@@ -39,7 +39,10 @@ def tile(img, tile=8):
 class VisibilityRenderer:
     """One brmi_pass (= CLodExtension + VisUtil + light clustering + deferred shading of one view)."""
 
-    def __init__(self, scene, device="cuda:0", max_clusters=None, occlusion=False, stats=False, band=(0, 0), **cfg_over):
+    def __init__(self, scene, device="cuda:0", max_clusters=None, occlusion=False, stats=False, band=(0, 0), stripes=None, **cfg_over):
+        """stripes = (rows, count, index): the interleaved screen partition (brmi_config::stripe*): this pass owns the chunks of `rows` rows
+        with index = `index` (mod `count`) of the scene's frame and renders them into compact surfaces of height / count rows; read-backs
+        return those compact images, `frame_rows()` says which rows of the frame they are."""
         import torch
         if not torch.cuda.is_available():
             raise BrmiError("no GPU: libbrmi.so needs an MI355X (there is no CPU fallback)")
@@ -48,8 +51,16 @@ class VisibilityRenderer:
         self.scene, self.device = scene, torch.device(device)
         torch.cuda.set_device(self.device)
         self.W, self.H = scene.width, scene.height
+        self.stripes = stripes
+        if stripes is not None:
+            rows, count, index = stripes
+            if scene.height % (rows * count):
+                raise ValueError(f"{scene.height} rows do not split into chunks of {rows} rows for {count} GPUs")
+            self.H = scene.height // count          # the compact surfaces
         cfg = capi.Config()
         self.lib.brmi_default_config(C.byref(cfg), self.W, self.H)
+        if stripes is not None:
+            cfg.stripeRows, cfg.stripeCount, cfg.stripeIndex, cfg.fullHeight = stripes[0], stripes[1], stripes[2], scene.height
         est = max(4096, 2 * scene.stats["meshletsTotal"] * max(1, scene.stats["instances"]) // max(1, scene.stats["meshes"]))
         cfg.maxVisibleClusters = int(max_clusters or min(1 << 24, max(1 << 16, est)))
         cfg.maxTraversalRecords = cfg.maxVisibleClusters
@@ -90,6 +101,14 @@ class VisibilityRenderer:
         if rc != 0:
             msg = self.lib.brmi_last_error(self._h).decode() if use_pass and self._h else ""
             raise BrmiError(f"{what} failed ({rc}): {msg}")
+
+    def frame_rows(self):
+        """Row of the scene's frame behind every row of this pass's surfaces (the identity without `stripes`)."""
+        if self.stripes is None:
+            return np.arange(self.H)
+        from . import compose
+        rows, count, index = self.stripes
+        return compose.stripe_frame_rows(index, count, self.scene.height, rows)
 
     def set_camera_from(self, other, frame_index=0):
         """Next frame's camera: copy `other`'s camera / culling-camera buffers (same geometry, another camera step) into

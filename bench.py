@@ -77,6 +77,11 @@ def main():
                     help="own: mesh LOD DAGs from the library's cluster-LOD builder (irregular meshlets, ~384-cluster groups) instead of the generator's quadtree; default: the workload's (bistro: own)")
     ap.add_argument("--material-features", type=int, default=None,
                     help="default: the workload's (san_miguel: 24, else 0).  scene generator feature bits (brmi_scene.h): 1 coat, 2 fuzz, 4 mirrored instances, 8 texture-sampled materials, 16 alpha-tested materials, 32 vertex colours, 64 OpenPBR layer textures, 128 parallax; 0 = BASELINE.json's constant-factor configuration")
+    ap.add_argument("--partition", default="stripes", choices=["stripes", "bands"],
+                    help="N > 1: how the frame is split.  stripes (default): the interleaved partition of SURVEY.md 8(e) -- chunks of --stripe-rows rows, one "
+                         "chunk of every group of N per rank, compact surfaces (brmi_config::stripe*); measured at N = 8 on one GPU the slowest rank takes "
+                         "0.78 ms per frame against 1.62 ms with contiguous bands (profiles/r03_rank_balance.md).  bands: one contiguous band of 1080 rows per rank")
+    ap.add_argument("--stripe-rows", type=int, default=64, help="chunk height of the interleaved partition (a multiple of 16 that divides 1088: 16, 32, 64, 272, 544)")
     ap.add_argument("--transport", default="rgb16f", choices=["rgb16f", "surface"],
                     help="what the band composition gathers: the colour channels as RGB16F (default; the composed image has no alpha plane) or the RGBA16F surface bytes")
     ap.add_argument("--composer", default="native", choices=["native", "peer", "torch"],
@@ -93,11 +98,23 @@ def main():
     ap.add_argument("--keep-uniform-layer-planes", type=int, default=0, choices=[0, 1],
                     help="brmi_config::keepUniformLayerPlanes: 1 = the coat / fuzz G-buffer planes of a scene whose materials all store the same word are filled "
                          "once and not rewritten (G-buffer kernel 93 -> 84 us).  Default 0: every frame writes every plane")
+    ap.add_argument("--emulate-rank", type=int, default=None,
+                    help="testing on ONE GPU: render rank R's share of the --gpus N frame alone (same partition, frame size and passes as the N-GPU run; "
+                         "no process group; the composer, if forced, gathers this rank's share only).  The line says so and is not an N-GPU number")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scale", type=float, default=1.0, help="fraction of the frame height the CPU baseline renders")
     args = ap.parse_args()
     if args.gpus < 1:
         fail_line(args, "--gpus must be >= 1")
+    if args.emulate_rank is not None:
+        if not (0 <= args.emulate_rank < args.gpus):
+            fail_line(args, f"--emulate-rank {args.emulate_rank} of --gpus {args.gpus}")
+        import torch
+        torch.cuda.set_device(0)
+        out = measure(args, args.workload, args.gpus, args.emulate_rank, 0, cpu=False, path=False, emulated=True)
+        out["emulated"] = f"rank {args.emulate_rank} of {args.gpus} alone on one GPU: value counts all {args.gpus} ranks' pixels over THIS rank's time; not an N-GPU measurement"
+        print(json.dumps(out), flush=True)
+        return
     world_env = os.environ.get("WORLD_SIZE")
     if world_env is None and args.gpus > 1:
         # No launcher around us: start the N ranks ourselves -- as a CHILD torchrun, before this process has touched the GPU -- and
@@ -145,7 +162,7 @@ def main():
         print(result_line, flush=True)
 
 
-def measure(args, workload, n, rank, local_rank, cpu, path=True):
+def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False):
     """K timed steps of one workload on this rank's GPU (all ranks call it together); rank 0 returns the result object."""
     import torch
     import torch.distributed as dist
@@ -159,17 +176,25 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True):
     if args.lod_builder is not None:
         scene_kw["lod_builder"] = args.lod_builder
     lod_builder = scene_kw.get("lod_builder", "quadtree")
-    W, H = compose.frame_size(n)
-    band = compose.band_of(rank, n, H)
+    multi = n > 1 and not emulated          # a process group exists
+    striped = n > 1 and args.partition == "stripes"
+    W, H = compose.frame_size(n, args.partition)
+    if striped:
+        compose.stripe_frame_rows(rank, n, H, args.stripe_rows)      # (raises on a chunk height that does not fit)
+        band = (0, H // n)                                             # the rank's compact surfaces hold its rows only: the composer takes all of them
+        part = dict(stripes=(args.stripe_rows, n, rank))
+    else:
+        band = compose.band_of(rank, n, H)
+        part = dict(band=band)
     scene = Scene(preset, W, H, point_lights=lights, directional=True, material_features=features, **scene_kw)
-    r = VisibilityRenderer(scene, device=dev, stats=True, band=band, occlusion=bool(args.occlusion), keepUniformLayerPlanes=args.keep_uniform_layer_planes)
+    r = VisibilityRenderer(scene, device=dev, stats=True, occlusion=bool(args.occlusion), keepUniformLayerPlanes=args.keep_uniform_layer_planes, **part)
     fif = args.frames_in_flight
     passes, streams, shade_streams = [r], [torch.cuda.current_stream(dev)], [None, None]
     if fif >= 2:
         # the second pass has its own resources and scene upload (its camera buffers are its own); phase 1 of each tests against the chain
         # the other built for the frame before
         for _ in range(fif - 1):
-            passes.append(VisibilityRenderer(scene, device=dev, stats=False, band=band, occlusion=bool(args.occlusion), keepUniformLayerPlanes=args.keep_uniform_layer_planes))
+            passes.append(VisibilityRenderer(scene, device=dev, stats=False, occlusion=bool(args.occlusion), keepUniformLayerPlanes=args.keep_uniform_layer_planes, **part))
         if args.occlusion:
             for k in range(fif):
                 passes[k].set_history_source(passes[(k - 1) % fif])        # the pass that renders the frame before
@@ -194,7 +219,7 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True):
     hdr = r.hdr_tensor()
     # all-gather of frame k overlaps the rendering of frame k + 1; the colour channels travel (RGB16F, 6 B/px): the lit target's alpha is constant
     composer, composer_used = None, args.composer
-    if n > 1 or args.force_compose:
+    if multi or args.force_compose:
         composer_used = args.composer
         if args.composer in ("native", "peer"):
             # libbrmi_compose.so issues the composition itself.  Whether it can is decided WITHOUT a collective first -- load the library, make
@@ -213,7 +238,7 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True):
                 failed, why = 1, f"{type(e).__name__}: {e}"
 
             def agree(flag):
-                if n > 1:
+                if multi:
                     t = torch.tensor([flag], device=dev, dtype=torch.int32)
                     dist.all_reduce(t, op=dist.ReduceOp.MAX)
                     return int(t.item())
@@ -221,7 +246,7 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True):
             failed = agree(failed)
             if not failed:
                 try:
-                    composer = (compose.PeerBandComposer if args.composer == "peer" else compose.NativeBandComposer)(hdr, band, W, 8, transport=args.transport)
+                    composer = (compose.PeerBandComposer if args.composer == "peer" else compose.NativeBandComposer)(hdr, band, W, 8, transport=args.transport, **(dict(rank=0, world=1) if emulated else {}))
                 except Exception as e:      # noqa: BLE001
                     failed, why = 1, f"{type(e).__name__}: {e}"
                 failed = agree(failed)
@@ -274,7 +299,7 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True):
     regions = []
     for _ in range(repeats):
         frame_no[0] = 0
-        if n > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -283,11 +308,11 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True):
         if composer:
             composer.finish()               # the last frames' collectives are inside the timed region
         torch.cuda.synchronize()
-        if n > 1:
+        if multi:
             dist.barrier()
         dt = time.perf_counter() - t0
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        if n > 1:
+        if multi:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         regions.append(float(t.item()))
     dt = sorted(regions)[len(regions) // 2]
@@ -307,7 +332,7 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True):
     if path and n == 1 and args.camera_path > 0 and args.occlusion:
         path_out = camera_path(args, scene, passes, streams, shade_streams, r, dev)
     out = None
-    if rank == 0:
+    if rank == 0 or emulated:
         shaded = W * (band[1] - band[0]) * n            # pixels dispatched per step, all ranks
         ms_per_step = dt / args.steps * 1e3
         value = shaded / 1e6 / (dt / args.steps)
@@ -356,12 +381,12 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True):
                                    + (", LOD DAGs from the library's cluster-LOD builder" if lod_builder == "own" else "")
                                    + (f", relief slope {scene_kw['relief_slope']}" if scene_kw.get("relief_slope") else "")
                                    + (f", material features {features} (8 = texture-sampled, 16 = alpha-tested materials)" if features else "")
-                                   + (f", {n} row bands of 1080 rows + composition of HDR on every rank ({args.transport}, pipelined one frame deep, {'libbrmi_compose.so: one RCCL all-gather per frame' if composer_used == 'native' else ('libbrmi_compose.so: peer writes over hipIpc-mapped images, no collective' if composer_used == 'peer' else ('torch.distributed' if composer_used == 'torch' else composer_used))})" if composer else ""),
+                                   + ((f", interleaved partition: chunks of {args.stripe_rows} rows, one per group of {n} and rank, {band[1]} rows per rank in compact surfaces" if striped else f", {n} row bands of 1080 rows") + f" + composition of HDR on every rank ({args.transport}, pipelined one frame deep, {'libbrmi_compose.so: one RCCL all-gather per frame' if composer_used == 'native' else ('libbrmi_compose.so: peer writes over hipIpc-mapped images, no collective' if composer_used == 'peer' else ('torch.distributed' if composer_used == 'torch' else composer_used))})" if composer else ""),
                        "baseline_config": BASELINE_CONFIG[workload],
                        "fps": round(1e3 / ms_per_step, 1),
                        "pixels_per_gpu": W * (band[1] - band[0]), "visible_clusters_rank0": int(c.visibleClusters),
                        "occlusion_culling": bool(args.occlusion), "visible_clusters_phase2_rank0": int(c.visibleClustersPhase2),
-                       "meshlets_tested_rank0": int(c.meshletsTested), "partition": f"row bands x{n}" if n > 1 else "single GPU",
+                       "meshlets_tested_rank0": int(c.meshletsTested), "partition": (f"interleaved chunks of {args.stripe_rows} rows x{n}" if striped else f"row bands x{n}") if n > 1 else "single GPU",
                        "frames_in_flight": fif},
             "roofline": {"bound": "valu" if (valu and valu["frac"] > hbm_frac) else "hbm", "kernel": {"raster": "k_raster + k_raster_bins (+ k_raster_overflow), both occlusion phases"}.get(dom, DOMINANT_KERNEL.get(dom, dom)), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(hbm_frac, 5), "traffic": traffic, "valu": valu,

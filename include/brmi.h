@@ -57,7 +57,15 @@ typedef struct brmi_config {
                                           (fuzz) G-buffer word and binds no coat / fuzz texture, the plane is filled with that word once after brmi_setup
                                           and brmi_execute skips the per-frame stores to it (16 of 52 B per pixel).  Only for hosts that neither write,
                                           clear nor alias GBUF_COAT / GBUF_FUZZ between frames. */
-    uint32_t reserved[7];
+    /* Interleaved screen partition, round 3.  stripeCount > 1: a frame `fullHeight` rows high is cut into chunks of `stripeRows`
+     * rows (a multiple of 16), stripeCount consecutive chunks form a group, and this GPU owns one chunk of every group -- chunk stripeIndex of
+     * the even groups, chunk stripeCount - 1 - stripeIndex of the odd ones (back and forth, so that a vertical cost gradient does not favour
+     * one GPU) -- and renders them into COMPACT surfaces: `height` is then the number of rows it owns (fullHeight / stripeCount; fullHeight a
+     * multiple of stripeRows * stripeCount), and row v of every surface is row (g * stripeCount + slot(g)) * stripeRows + v % stripeRows of the
+     * frame, g = v / stripeRows.  Cameras, lights and perFrame.screenResY describe the FULL frame.  bandY0 / bandY1 stay 0.
+     * 0 / 1: off (the contiguous band of bandY0 / bandY1, or the whole frame). */
+    uint32_t stripeRows, stripeCount, stripeIndex, fullHeight;
+    uint32_t reserved[3];
 } brmi_config;
 
 void brmi_default_config(brmi_config* cfg, uint32_t width, uint32_t height);

@@ -22,7 +22,7 @@ def _worker(rank, world, port, W, H, out_path):
     import torch.distributed as dist
     import orc
     from basicrenderer_amd import Scene, compose
-    from basicrenderer_amd.renderer import tile
+    from basicrenderer_amd.renderer import detile, tile
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sc = Scene("tiny", W, H, point_lights=4, seed=2)            # every rank builds the same (replicated) scene
@@ -65,6 +65,18 @@ def _worker(rank, world, port, W, H, out_path):
             want = compose.compose_bands(surface ^ (frame + 7), band, W, 8)
             assert torch.equal(both.out[slot], compose.rgb_of(want) if transport == "rgb16f" else want), f"alternating targets, {transport}, frame {frame}"
         both.finish()
+    # the interleaved partition (bench.py's default for N > 1): every rank holds its rows in a COMPACT surface (chunks of 16 rows, back and
+    # forth inside the groups); the composer gathers the compact surfaces rank after rank, and stripe_frame_rows says where the rows go
+    full_frame = orc.OracleFrame(sc, threads=2).run().hdr
+    mine = compose.stripe_frame_rows(rank, world, H, 16)
+    compact = torch.from_numpy(tile(np.ascontiguousarray(full_frame[mine])).view(np.uint8).copy())
+    gathered = compose.compose_bands(compact, (0, H // world), W, 8)
+    per_rank = gathered.numel() // world
+    rebuilt = np.zeros_like(full_frame)
+    for rk in range(world):
+        part = gathered[rk * per_rank:(rk + 1) * per_rank].numpy().view(np.uint64)
+        rebuilt[compose.stripe_frame_rows(rk, world, H, 16)] = detile(part, W, H // world)
+    assert np.array_equal(rebuilt, full_frame), "interleaved partition: the gathered compact surfaces do not rebuild the frame"
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)                      # the max-over-ranks timing reduction of bench.py
     assert t.item() == world
@@ -87,3 +99,27 @@ def test_two_rank_band_composition_matches_single_process(tmp_path):
     full = orc.OracleFrame(Scene("tiny", W, H, point_lights=4, seed=2)).run()
     assert np.array_equal(detile(composed, W, H), full.hdr)
     assert (full.hdr != 0).any()
+
+
+def test_interleaved_partition_is_a_partition_of_the_rows():
+    """stripe_frame_rows (the Python statement of brmi_config::stripe*): over the ranks every row of the frame appears exactly once, a rank's rows
+    come in whole chunks, and the chunk a rank owns inside a group runs back and forth from group to group."""
+    sys.path.insert(0, ROOT)
+    from basicrenderer_amd import compose
+    for n, H, rows in ((8, 1088 * 8, 64), (4, 1088 * 4, 16), (2, 64, 16), (3, 288, 32)):
+        seen = np.zeros(H, dtype=int)
+        for r in range(n):
+            fr = compose.stripe_frame_rows(r, n, H, rows)
+            assert len(fr) == H // n
+            seen[fr] += 1
+            chunks = fr.reshape(-1, rows)
+            assert (np.diff(chunks, axis=1) == 1).all() and (chunks[:, 0] % rows == 0).all()
+            slots = (chunks[:, 0] // rows) % n
+            assert (slots[0::2] == r).all() and (slots[1::2] == n - 1 - r).all()
+        assert (seen == 1).all()
+    for bad in ((8, 1080 * 8, 64), (2, 64, 8)):
+        try:
+            compose.stripe_frame_rows(0, *bad)
+            raise AssertionError("accepted a chunk height that does not fit")
+        except ValueError:
+            pass

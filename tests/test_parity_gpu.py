@@ -276,6 +276,71 @@ def test_band_split_composes_to_full_frame(case, scenes, gpu_frames):
         r.close()
 
 
+@pytest.mark.parametrize("preset,W,H,kw,rows,count", [
+    ("sponza", 640, 384, dict(point_lights=32, size_scale=0.25), 16, 3),
+    ("sponza", 640, 384, dict(point_lights=32, size_scale=0.25), 16, 8),
+    ("sponza", 640, 384, dict(point_lights=16, size_scale=0.25, material_features=24), 32, 2),
+    ("bistro", 640, 384, dict(point_lights=32, size_scale=0.1), 64, 3),
+    ("tiny", 256, 144, dict(point_lights=4, skinned_fraction=1.0, lod_levels=2), 16, 3),
+])
+def test_interleaved_stripes_compose_to_full_frame(preset, W, H, kw, rows, count):
+    """The interleaved screen partition (brmi_config::stripe*; SURVEY.md 8e): GPU r owns the chunks of `rows` rows with index r (mod count) and
+    renders them into COMPACT surfaces (height / count rows).  Rendering every rank's share on one GPU and putting the rows back where they
+    belong reproduces the full frame: canonical ids, depth bits, lit HDR bytes -- also for triangles that straddle chunk boundaries, binned
+    triangles cut per 16-row band, alpha-tested and skinned clusters."""
+    import orc
+    from basicrenderer_amd import Scene
+    from basicrenderer_amd.renderer import VisibilityRenderer
+    sc = Scene(preset, W, H, **kw)
+    full = VisibilityRenderer(sc)
+    full.execute()
+    fa, fb, fd = orc.canonical_ids(full.visibility(), full.visible_clusters())
+    fh, fdepth = full.hdr(), full.depth().view(np.uint32)
+    covered = np.zeros(H, dtype=bool)
+    for index in range(count):
+        r = VisibilityRenderer(sc, stripes=(rows, count, index))
+        r.execute()
+        fr = r.frame_rows()
+        assert len(fr) == H // count and not covered[fr].any()
+        covered[fr] = True
+        a, b, d = orc.canonical_ids(r.visibility(), r.visible_clusters())
+        assert np.array_equal(a, fa[fr]) and np.array_equal(b, fb[fr]) and np.array_equal(d, fd[fr]), f"rank {index}: visibility differs"
+        assert np.array_equal(r.hdr(), fh[fr]), f"rank {index}: HDR differs"
+        assert np.array_equal(r.depth().view(np.uint32), fdepth[fr]), f"rank {index}: depth differs"
+        r.close()
+    assert covered.all()
+    full.close()
+
+
+def test_interleaved_stripes_with_occlusion_culling_compose_to_full_frame():
+    """The same with 2-phase occlusion culling along a camera path: every rank keeps a depth chain of ITS rows only (the occlusion test maps a
+    cluster's frame rows onto the surface rows the rank owns among them) and drops clusters that touch none of its rows; three frames, the
+    rows of the last one equal the full frame's."""
+    import orc
+    from basicrenderer_amd import Scene
+    from basicrenderer_amd.renderer import VisibilityRenderer
+    W, H, count, rows = 640, 384, 4, 32
+    frames = [Scene("bistro", W, H, point_lights=32, size_scale=0.3, camera_step=k) for k in range(3)]
+    full = VisibilityRenderer(frames[0], occlusion=True)
+    ranks = [VisibilityRenderer(frames[0], occlusion=True, stripes=(rows, count, i)) for i in range(count)]
+    for k in range(3):
+        for r in [full] + ranks:
+            if k:
+                r.set_camera_from(frames[k], frame_index=k)
+            r.execute()
+    fa, fb, fd = orc.canonical_ids(full.visibility(), full.visible_clusters())
+    fh = full.hdr()
+    for i, r in enumerate(ranks):
+        fr = r.frame_rows()
+        a, b, d = orc.canonical_ids(r.visibility(), r.visible_clusters())
+        assert np.array_equal(a, fa[fr]) and np.array_equal(b, fb[fr]) and np.array_equal(d, fd[fr]), f"rank {i}: visibility differs"
+        assert np.array_equal(r.hdr(), fh[fr]), f"rank {i}: HDR differs"
+        c = r.counters()
+        assert c.visibleClusters + c.visibleClustersPhase2 < full.counters().visibleClusters + full.counters().visibleClustersPhase2 + 1
+        r.close()
+    full.close()
+
+
 def test_band_split_with_occlusion_culling_composes_to_full_frame():
     """The multi-GPU bench default: row bands with 2-phase occlusion culling on, two frames (the second one tests against the
     band's own depth chain; rows of other ranks read as empty).  Lit bytes of every band equal the full frame without occlusion."""

@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""tools/rank_balance.py -- how evenly the screen partition of `bench.py --gpus N` loads the ranks, measured on ONE GPU.
+
+Every rank of the N-GPU frame (7680 x 1080 N, weak scaling) is rendered in turn on this GPU, without the composition, in the bench's
+arrangement (two frames in flight), and its ms per frame is reported.  `--chunks K` gives a rank K contiguous chunks instead of one band --
+rank r owns chunks r, r + N, ..., each 1080 / K rows -- rendered by K pass rings side by side on their own stream pairs: the interleaved
+assignment of SURVEY.md 8(e) at the granularity that keeps the geometry half proportional to 1 / N.  Prints one JSON
+line: per-rank times, max / min, and the visible clusters each rank rasterises.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ranks", type=int, default=8)
+    ap.add_argument("--chunks", type=int, default=1)
+    ap.add_argument("--stripe-rows", type=int, default=0, help="> 0: the in-kernel interleaved partition (brmi_config::stripe*) with chunks of this many rows, one pass ring per rank, "
+                                                                "on a frame of 1088 rows per rank (1080 has no multiple of 16 among its divisors)")
+    ap.add_argument("--workload", default="bistro")
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--frames-in-flight", type=int, default=2)
+    ap.add_argument("--only", type=int, nargs="*", help="ranks to measure (default: all)")
+    args = ap.parse_args()
+    import torch
+    import bench
+    from basicrenderer_amd import Scene, compose
+    from basicrenderer_amd.renderer import VisibilityRenderer
+    dev = torch.device("cuda:0")
+    n, K, fif = args.ranks, args.chunks, args.frames_in_flight
+    W, H = compose.frame_size(n)
+    if args.stripe_rows:
+        H = 1088 * n
+    preset, kw, features = bench.WORKLOADS[args.workload]
+    scene = Scene(preset, W, H, point_lights=bench.LIGHTS[args.workload], directional=True, material_features=features, **kw)
+    rows = H // (n * K)
+    if not args.stripe_rows and (rows % 8 or rows * n * K != H):
+        raise SystemExit(f"{H} rows do not split into {n} x {K} chunks of whole 8-row tiles")
+    # stream pairs made once (HIP maps streams onto a few hardware queues): one geometry stream and `fif` shading streams per chunk
+    geo = [torch.cuda.Stream(dev, priority=-1) for _ in range(K)]
+    shade = [[torch.cuda.Stream(dev, priority=0) for _ in range(fif)] for _ in range(K)]
+    out = {"ranks": n, "stripe_rows": args.stripe_rows, "chunks_per_rank": K, "rows_per_chunk": rows, "frame": [W, H], "workload": args.workload, "frames_in_flight": fif, "per_rank": []}
+    for r in (args.only if args.only else range(n)):
+        rings = []
+        for k in range(K):
+            c = r + k * n
+            band = (c * rows, (c + 1) * rows)
+            if args.stripe_rows:
+                ring = [VisibilityRenderer(scene, device=dev, stats=(j == 0), stripes=(args.stripe_rows, n, r), occlusion=True) for j in range(fif)]
+            else:
+                ring = [VisibilityRenderer(scene, device=dev, stats=(j == 0), band=band, occlusion=True) for j in range(fif)]
+            for j in range(fif):
+                ring[j].set_history_source(ring[(j - 1) % fif])
+            rings.append(ring)
+
+        def frame(i):
+            for k, ring in enumerate(rings):
+                p = ring[i % fif]
+                with torch.cuda.stream(geo[k]):
+                    p.update()
+                    p.execute(shade[k][i % fif])
+
+        for i in range(10):
+            frame(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            frame(i)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / args.steps * 1e3
+        vis = sum(int(ring[0].counters().visibleClusters) for ring in rings)
+        out["per_rank"].append({"rank": r, "ms_per_frame": round(ms, 4), "visible_clusters": vis})
+        for ring in rings:
+            for p in ring:
+                p.close()
+        torch.cuda.empty_cache()
+    t = [x["ms_per_frame"] for x in out["per_rank"]]
+    out["max_over_min"] = round(max(t) / min(t), 3)
+    out["max_ms"], out["min_ms"], out["mean_ms"] = max(t), min(t), round(sum(t) / len(t), 4)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
