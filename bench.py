@@ -8,10 +8,12 @@ clear -> cull -> software raster -> G-buffer(+depth) -> light clustering -> Open
 N = 1 : BASELINE.json configs[2], "Bistro 4K, meshlet cull + vis-buffer raster, 256 point lights" (3840x2160) -- the frame the
         north star's one numeric target is stated on (>= 60 fps).  The same run then measures configs[1] ("Sponza 4K,
         visibility-buffer + clustered resolve, 1 dir + 64 point lights") and reports it as `configs1` inside the line.
-N > 1 : weak scaling by screen tile: every rank shades one 8.29 Mpixel row band (7680 x 1080) of a
-        7680 x (1080*N) frame of the same scene, geometry replicated, then the HDR bands are
-        all-gathered over xGMI so that every rank holds the composed image.  Without a launcher around it
-        (no WORLD_SIZE) `--gpus N` starts its own N ranks; it never reports a 1-GPU number for an N-GPU request.
+N > 1 : weak scaling by screen tile: the frame is 7680 x 1088 N (7680 x 1080 N with --partition bands), geometry replicated; every rank shades
+        one 4K frame's worth of pixels -- by default the chunks of 64 rows the interleaved partition deals it (brmi_config::stripe*: one chunk
+        of every group of N, compact surfaces; the slowest of 8 ranks takes 0.78 ms per frame against 1.62 ms with contiguous bands, measured
+        rank by rank on one GPU) -- and the HDR shares are composed so that every rank holds all of them (one RCCL all-gather per frame, or
+        --composer peer: stores into hipIpc-mapped images, no collective).  Without a launcher around it (no WORLD_SIZE) `--gpus N` starts its
+        own N ranks; it never reports a 1-GPU number for an N-GPU request.  `--emulate-rank R` renders one rank's share alone on one GPU.
 
 Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (largest mean stage time):
 algorithmic bytes of SURVEY.md 8(d) / mean launch duration from HIP events on the execute stream.
