@@ -1027,6 +1027,53 @@ def test_two_frames_in_flight_render_the_frames_of_one_pass(name, split, n):
         r.close()
 
 
+def test_two_frames_in_flight_at_4k_with_a_camera_that_moves_every_frame():
+    """The size at which the round-2 hazard would show: at 4K the shading half of frame k (0.35 ms) outlives the geometry half of frame k + 1, and
+    the host writes the next camera into the pass's camera buffers while frame k may still be shading.  Six frames of the Bistro-class camera
+    path (a new camera every frame, written on the geometry stream as brmi.h says, no host wait anywhere) through two linked passes on a
+    geometry and a shading stream; every frame's keys, depth and -- the part that reads the camera on the shading stream -- HDR bytes are those
+    of one pass rendering the path serially.  (The shading half reads the frame's own snapshot of the camera, not the caller's buffer.)"""
+    import torch
+    from basicrenderer_amd import Scene, capi
+    from basicrenderer_amd.renderer import VisibilityRenderer
+    sc = Scene("bistro", 3840, 2160, point_lights=64)
+    steps = 6
+    cams = [sc.camera_at(0.5 * (k + 1), 0.5 * k) for k in range(steps)]      # half a path unit per frame: 17 cm sideways, 30 cm ahead, 2 degrees
+    dev = torch.device("cuda:0")
+    cam_dev = [(torch.from_numpy(c).to(dev), torch.from_numpy(cc).to(dev)) for c, cc in cams]
+    keep = ("VISIBILITY", "LINEAR_DEPTH", "HDR_COLOR")
+    one = VisibilityRenderer(sc, occlusion=True)
+    serial = []
+    for k in range(steps):
+        one.set_camera_device(cam_dev[k][0], cam_dev[k][1], cams[k][0], frame_index=k)
+        one.execute()
+        torch.cuda.synchronize()
+        serial.append({n: one.res[capi.RES[n]].clone() for n in keep})
+    one.close()
+    assert not torch.equal(serial[0]["HDR_COLOR"], serial[steps - 1]["HDR_COLOR"]), "the camera does not move"
+    passes = [VisibilityRenderer(sc, occlusion=True) for _ in range(2)]
+    passes[0].set_history_source(passes[1]); passes[1].set_history_source(passes[0])
+    geometry, shading = torch.cuda.Stream(priority=-1), [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    got = []
+    for k in range(steps):
+        p = passes[k & 1]
+        with torch.cuda.stream(geometry):
+            p.set_camera_device(cam_dev[k][0], cam_dev[k][1], cams[k][0], frame_index=k)
+            p.execute(shading[k & 1])
+        with torch.cuda.stream(shading[k & 1]):
+            got.append({n: p.res[capi.RES[n]].clone() for n in keep})
+    torch.cuda.synchronize()
+    for k in range(steps):
+        for n in ("VISIBILITY", "LINEAR_DEPTH"):
+            assert torch.equal(got[k][n], serial[k][n]), f"frame {k}: {n} differs from the serial frame"
+        drawn = serial[k]["VISIBILITY"].view(torch.int64) != -1
+        a, b = got[k]["HDR_COLOR"].view(-1, 8)[: drawn.numel()], serial[k]["HDR_COLOR"].view(-1, 8)[: drawn.numel()]
+        assert torch.equal(a[drawn], b[drawn]), f"frame {k}: HDR differs from the serial frame (a later frame's camera reached its shading half?)"
+    for p in passes:
+        p.close()
+
+
 def test_split_streams_without_occlusion_culling_match_the_serial_frame():
     """brmi_execute_split on a pass without a depth chain (no history to link): two passes alternate four frames of a camera path on one
     geometry / shading stream pair, light clustering included; the drawn pixels are those of brmi_execute."""
