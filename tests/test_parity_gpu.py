@@ -588,7 +588,8 @@ def test_full_size_4k_properties(preset, lights):
                                                   ("sponza", 3840, 2160, 64, dict(material_features=255, spot_every=3)),   # every material feature incl. parallax, at 4K
                                                   ("zorah", 7680, 4320, 64, dict(skinned_fraction=0.01)),         # configs[4]: 8K, 100 k instances, 1 % skinned
                                                   ("bistro", 3840, 2160, 256, dict(size_scale=20.0, detail=96.0)),   # bench.py --workload bistro_dense: pixel-sized triangles, wide + narrow BVHs (mixed traversal)
-                                                  ("bistro", 3840, 2160, 256, dict(size_scale=3.0, detail=8.0, lod_builder="own"))])   # configs[2] through the library's own cluster-LOD builder
+                                                  ("bistro", 3840, 2160, 256, dict(size_scale=3.0, detail=8.0, lod_builder="own")),   # configs[2] through the library's own cluster-LOD builder
+                                                  ("bistro", 3840, 2160, 256, dict(unique_budget=True, lod_builder="own", relief_slope=1.5))])   # round 3's bench default: 2.6 M triangles in 150 meshes, 2,017 instances, 10 k visible clusters
 def test_full_size_frames_against_the_oracle(preset, W, H, lights, kw):
     """BASELINE.json's configurations at their full size, whole frame against the CPU oracle (it renders a 4K frame in well under a
     second per stage on the box's cores): cluster list, visibility keys, depth, every G-buffer plane exact; HDR within one fp16 ULP."""
@@ -617,7 +618,8 @@ def test_full_size_frames_against_the_oracle(preset, W, H, lights, kw):
 
 @pytest.mark.parametrize("preset,lights,kw,in_flight", [("sponza", 64, dict(), 1), ("bistro", 256, dict(), 1), ("san_miguel", 256, dict(material_features=24), 1),
                                                         ("bistro", 256, dict(size_scale=20.0, detail=96.0), 1),      # the dense workload: 2-phase occlusion over the mixed traversal
-                                                        ("bistro", 256, dict(), 2)])                                 # the bench default: two passes render alternate frames
+                                                        ("bistro", 256, dict(), 2),                                  # two passes render alternate frames
+                                                        ("bistro", 256, dict(unique_budget=True, lod_builder="own", relief_slope=1.5), 2)])   # the bench default of round 3, as the bench runs it
 def test_full_size_camera_path_with_occlusion_against_the_oracle(preset, lights, kw, in_flight):
     """Three 4K frames of the camera path with 2-phase occlusion culling on (the bench default), every frame against the oracle's
     2-phase frame: both phases' cluster lists, keys, depth, G-buffer exact, HDR within one fp16 ULP on covered pixels (pixels without
@@ -686,6 +688,57 @@ def test_full_size_band_split_against_the_oracle(preset, lights, n, kw):
         gh = r.hdr().view(np.uint16).astype(np.int32).reshape(H, W, 4)
         assert np.abs(gh[y0:y1][covered] - oh[y0:y1][covered]).max() <= 1, f"rank {rank}"
         r.close()
+
+
+@pytest.mark.parametrize("preset,lights,n,rows,kw", [("bistro", 256, 4, 64, dict(unique_budget=True, lod_builder="own", relief_slope=1.5)),   # the bench's N = 4 frame, its default chunk height
+                                                     ("bistro", 256, 8, 16, dict()),                                                          # the finest interleave, eight ranks
+                                                     ("san_miguel", 256, 2, 272, dict(material_features=24))])                                # alpha-tested clusters across chunk boundaries
+def test_full_size_interleaved_partition_against_the_oracle(preset, lights, n, rows, kw):
+    """bench.py --gpus N's default partition at its real size on one GPU: the 7680 x (1088 N) frame, every rank's interleaved share (compact
+    surfaces, occlusion culling on, two frames each) against the oracle's full frame: triangle identities, depth and lit bytes of the rows
+    the rank owns."""
+    import orc
+    from basicrenderer_amd import compose
+    from conftest import Scene
+    from basicrenderer_amd.renderer import VisibilityRenderer
+    W, H = compose.frame_size(n, "stripes")
+    sc = Scene(preset, W, H, point_lights=lights, **kw)
+    o = orc.OracleFrame(sc).run()
+    fa, fb, fd = orc.canonical_ids(o.vis, o.clusters[: o.count])
+    oh = o.hdr.view(np.uint16).astype(np.int32).reshape(H, W, 4)
+    for rank in range(n):
+        r = VisibilityRenderer(sc, stripes=(rows, n, rank), occlusion=True, stats=True)
+        r.execute(); r.execute()
+        c = r.counters()
+        assert c.droppedRecords == 0 and c.droppedClusters == 0
+        fr = r.frame_rows()
+        a, b, d = orc.canonical_ids(r.visibility(), r.visible_clusters())
+        assert np.array_equal(a, fa[fr]) and np.array_equal(b, fb[fr]) and np.array_equal(d, fd[fr]), f"rank {rank}"
+        covered = (o.vis != np.uint64(0xFFFFFFFFFFFFFFFF))[fr]
+        gh = r.hdr().view(np.uint16).astype(np.int32).reshape(H // n, W, 4)
+        assert np.abs(gh[covered] - oh[fr][covered]).max() <= 1, f"rank {rank}"
+        r.close()
+
+
+@pytest.mark.parametrize("preset,lights,kw", [("bistro", 256, dict(unique_budget=True, lod_builder="own", relief_slope=1.5)), ("bistro", 256, dict(size_scale=20.0, detail=96.0)), ("sponza", 64, dict())])
+def test_full_size_tile_rasteriser_draws_the_oracles_keys(preset, lights, kw):
+    """BRMI_RASTER_MODE=tiles (the cluster-granular rasteriser, opt-in) on the 4K bench frames: cluster list, keys and depth are the oracle's."""
+    import orc
+    from conftest import Scene
+    from basicrenderer_amd.renderer import VisibilityRenderer
+    sc = Scene(preset, 3840, 2160, point_lights=lights, **kw)
+    with _Env(BRMI_RASTER_MODE="tiles"):
+        r = VisibilityRenderer(sc, stats=True)
+    r.execute()
+    o = orc.OracleFrame(sc)
+    o.cull(); o.raster(); o.depth_copy()
+    c = r.counters()
+    assert c.droppedRecords == 0 and c.droppedClusters == 0
+    assert np.array_equal(r.visible_clusters(), o.clusters[: o.count])
+    vis = r.visibility()
+    assert np.array_equal(vis, o.vis), f"{int((vis != o.vis).sum())} keys differ"
+    assert np.array_equal(r.depth().view(np.uint32), o.depth.view(np.uint32))
+    r.close()
 
 
 def test_frame_from_an_independently_written_clod_cache_matches_the_oracle():
