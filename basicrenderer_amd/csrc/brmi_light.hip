@@ -16,6 +16,7 @@
 //     HDR write are contiguous per wave.
 //   * OpenPBR lookup tables are injected R16_UNORM / float tables, bilinearly filtered in fp32.
 #include <algorithm>
+#include <cstdlib>
 
 #include "brmi_device.h"
 #include "brmi_internal.h"
@@ -180,7 +181,10 @@ int launch_shade(brmi_pass* p, hipStream_t s) {
     // 8192 workgroups of four waves, four tiles per wave at 4K: against 4096 (eight tiles per wave) the kernel's tail is shorter (233 -> 226 us)
     // and, with another frame's geometry half in flight beside it, slots come free twice as often for that half's high-priority launches
     // (Bistro 4K, two frames in flight: 0.436 -> 0.413 ms per frame; 16384: 0.425, 2048: 0.49)
-    else hipLaunchKernelGGL(k_shade<0>, dim3(8192), dim3(256), 0, s, a);
+    else {
+        static const uint32_t pad = [] { const char* e = std::getenv("BRMI_SHADE_LDS_PAD"); return e ? (uint32_t)std::atoi(e) : 0u; }();   // (experiment: unused dynamic LDS caps the kernel's occupancy)
+        hipLaunchKernelGGL(k_shade<0>, dim3(8192), dim3(256), pad, s, a);
+    }
     // deferred pixels by class: coat, fuzz, both -- only the variants some material of the scene can need
     if (p->sceneHasCoat) hipLaunchKernelGGL(k_shade<1>, dim3(512), dim3(256), 0, s, a);
     if (p->sceneHasFuzz) hipLaunchKernelGGL(k_shade<2>, dim3(512), dim3(256), 0, s, a);

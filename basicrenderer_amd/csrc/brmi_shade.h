@@ -151,6 +151,10 @@ BRMI_DEV f3 diffuse_eon(f3 albedo, float rough, float NdotV, float NdotL, float 
 //   [1] attenuation polynomial, conservative upper bound of maxRange^2
 //   [2] colour x intensity, cos(inner)        [3] spot: normalize(direction), cos(outer); any other light: 0, -2
 struct ShadeLightLanes { float4 r0, r1, r2, r3; };      // one light per lane
+struct ShadeLightRecord { float r0[4], r1[4], r2[4], r3[4]; };   // the same record as plain words (scalar loads)
+#ifndef BRMI_SHADE_SCALAR_LIGHTS
+#define BRMI_SHADE_SCALAR_LIGHTS 1
+#endif
 
 struct ShadeArgs {
     ShadeTables tables;
@@ -504,6 +508,47 @@ BRMI_DEV uint32_t shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const flo
         const uint64_t same = __ballot(live && ci == uci);
         pending &= ~same;
         const bool mine = (same >> lane_id()) & 1ull;
+#if BRMI_SHADE_SCALAR_LIGHTS
+        // The records of a cluster's lights lie in list order (k_lc_fill), so light q of the list is ONE wave-uniform 64 B record: a scalar
+        // load brings it into SGPRs -- no staging registers (16 VGPRs) and no v_readlane per field.
+        const float4* recBase = a.clustered ? a.listRecords + (size_t)listBase * 4u : a.shadeLights;
+        if (mine) for (uint32_t q = 0; q < listCount; q++) {
+            // one s_load_dwordx16 (as sixteen separate words the compiler fetched the record in four dependent pieces)
+            typedef float f32x16 __attribute__((ext_vector_type(16)));
+            const f32x16 w = *reinterpret_cast<const __attribute__((address_space(4))) f32x16*>(kconst(recBase + (size_t)q * 4u));
+            const ShadeLightRecord lr{{w[0], w[1], w[2], w[3]}, {w[4], w[5], w[6], w[7]}, {w[8], w[9], w[10], w[11]}, {w[12], w[13], w[14], w[15]}};
+            const f3 lp{lr.r0[0], lr.r0[1], lr.r0[2]};
+            const float maxRange = lr.r0[3];
+            f3 lightToFrag; float att = 1.0f, spot = 1.0f;
+            if (maxRange < 0.0f) lightToFrag = lp;           // directional
+            else {
+                const float range2Hi = lr.r1[3];
+                const f3 toL = lp - posWS;
+                const float d2 = dot3(toL, toL);
+                if (d2 > range2Hi || dot3(f.normalWS, toL) < -1.0e-5f * qsqrt(d2)) continue;
+                float dist;
+                lightToFrag = normalize3_len(toL, d2, dist);
+                if (dist > maxRange) continue;
+                att = qrcp((lr.r1[0] + lr.r1[1] * dist + lr.r1[2] * dist * dist) + 0.0001f);
+            }
+            const float NoL = satq(dot3(f.normalWS, lightToFrag));
+            if (NoL == 0.0f) continue;
+            const float outer = lr.r3[3];
+            if (outer > -1.5f) {                                    // spot light
+                const f3 sd{lr.r3[0], lr.r3[1], lr.r3[2]};
+                const float inner = lr.r2[3];
+                const float cc = dot3(sd, normalize3_q(-lightToFrag));
+                if (!(cc > outer)) continue;
+                if (cc < inner) { const float t = satq((cc - outer) / (inner - outer)); spot = t * t * (3.0f - 2.0f * t); }
+            }
+            const f3 h = normalize3_q(lightToFrag + f.viewWS);
+            const float NoH = satq(dot3(f.normalWS, h)), LoH = satq(dot3(lightToFrag, h));
+            const float VdotL = dot3(f.viewWS, lightToFrag);
+            const float D = d_ggx(ctx.base.specularAlpha, NoH);
+            const f3 col{lr.r2[0], lr.r2[1], lr.r2[2]};
+            lighting = lighting + light_contribution<MODE>(L, f, ctx, lightToFrag, NoL, NoH, LoH, VdotL, D, col, att, spot);
+        }
+#else
         for (uint32_t c0 = 0; c0 < listCount; c0 += 64u) {
             const uint32_t n = min(64u, listCount - c0);
             if (!staged) s = stage_lights(a, listBase, c0, n);
@@ -545,6 +590,7 @@ BRMI_DEV uint32_t shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const flo
                 lighting = lighting + light_contribution<MODE>(L, f, ctx, lightToFrag, NoL, NoH, LoH, VdotL, D, col, att, spot);
             }
         }
+#endif
         staged = false;
     }
     if (live) {

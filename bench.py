@@ -208,9 +208,10 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False)
             # halves serialised: the dense frame took 1.84 ms in flight against 0.97 ms measured on its own)
             key = (str(dev), fif, "split")
             if key not in _STREAM_CACHE:
-                geometry, shading = torch.cuda.Stream(dev, priority=-1), torch.cuda.Stream(dev, priority=0)
+                gp, sp = (int(v) for v in os.environ.get("BRMI_BENCH_PRIORITIES", "-1,0").split(","))     # (experiments)
+                geometry, shading = torch.cuda.Stream(dev, priority=gp), torch.cuda.Stream(dev, priority=sp)
                 # a shading stream per pass: a frame's pixel pass may start on the tail of the frame before's k_shade (-1 % against one shared stream)
-                _STREAM_CACHE[key] = ([geometry] * fif, [shading] + [torch.cuda.Stream(dev, priority=0) for _ in range(fif - 1)])
+                _STREAM_CACHE[key] = ([geometry] * fif, [shading] + [torch.cuda.Stream(dev, priority=sp) for _ in range(fif - 1)])
             streams, shade_streams = _STREAM_CACHE[key]
         else:
             key = (str(dev), fif, "whole")
