@@ -118,6 +118,14 @@ static void compute_sizes(brmi_pass* p) {
     w.binCounts = take((uint64_t)p->binsX * p->binsY * 4);
     w.binRecords = take((uint64_t)p->binsX * p->binsY * p->binCapacity * 64);
     w.binOverflow = take((uint64_t)CNT_STRIPE_COUNT * p->binOverflowPerStripe * 64);
+    // the plan of a k_raster_bins launch: header, three words per bin, the (bin, slice) items; scratch tiles of 32 KB for the slices of bins
+    // that several workgroups walk (2048 tiles = 64 MB: a 4K frame whose every bin is full would want 16 k; bins beyond merge with atomics)
+    p->binItemCapacity = p->binsX * p->binsY * std::max(1u, (p->binCapacity + 31u) / 32u > 256u ? 256u : (p->binCapacity + 31u) / 32u);
+    p->binItemCapacity = std::min<uint32_t>(p->binItemCapacity, 1u << 22);
+    if (const char* e = std::getenv("BRMI_BIN_SCRATCH_TILES")) p->binScratchTiles = (uint32_t)std::max(0, std::atoi(e));
+    w.binPlan = take((uint64_t)(16 + 3 * p->binsX * p->binsY) * 4);
+    w.binItems = take((uint64_t)p->binItemCapacity * 4);
+    w.binScratch = take((uint64_t)std::max(1u, p->binScratchTiles) * 4096 * 8);
     raster_tile_grid(c.width, c.height, &p->rtilesX, &p->rtilesY);
     w.tileCounts = take((uint64_t)p->rtilesX * p->rtilesY * 4);
     w.tileLists = take((uint64_t)p->rtilesX * p->rtilesY * p->tileCapacity * 16);
@@ -125,7 +133,7 @@ static void compute_sizes(brmi_pass* p) {
     if (const char* e = std::getenv("BRMI_XVERT_CLUSTERS")) p->xvertClusters = (uint32_t)std::max(0, std::atoi(e));   // tests: clusters beyond the cache take the overflow path
     w.xverts = take((uint64_t)std::max(1u, p->xvertClusters) * 3 * BRMI_MESHLET_MAX_VERTS * 4);
     w.tileOverflow = take((uint64_t)p->tileOverflowCapacity * 8);
-    w.debugStamps = take(4096);      // instrumented builds (-DBRMI_TILE_STAMPS) park per-phase cycle sums here
+    w.debugStamps = take(4096 + 1024 * 1024);      // instrumented builds (-DBRMI_TILE_STAMPS) park per-phase cycle sums here
     w.clusterSetup = take((uint64_t)c.maxVisibleClusters * sizeof(ClusterSetup));
     // resolve arena: full tables (72 B per vertex + triangle slot) for up to 2^20 clusters = 9.7 GB of the 288; a configuration
     // that allows more visible clusters keeps the per-pixel path for the clusters that do not fit
@@ -785,6 +793,7 @@ int brmi_debug_read_bin_records(brmi_pass* p, void* dst, uint64_t bytes) {
     BRMI_HIP(p, hipDeviceSynchronize());
     // (bytes with bit 63 set: the stamp region instead, where instrumented builds of k_raster park their phase sums)
     const bool overflowRegion = (bytes >> 63) != 0; bytes &= ~(1ull << 63);
+    if ((bytes >> 62) & 1ull) { bytes &= ~(1ull << 62); BRMI_HIP(p, hipMemset(p->wsPtr<uint8_t>(p->ws.binRecords), 0, bytes)); return BRMI_OK; }   // (bit 62: zero the records instead, so that a following frame's records can be told from older ones)
     BRMI_HIP(p, hipMemcpy(dst, overflowRegion ? p->wsPtr<uint8_t>(p->ws.debugStamps) : p->wsPtr<uint8_t>(p->ws.binRecords), bytes, hipMemcpyDeviceToHost));
     return BRMI_OK;
 }

@@ -123,7 +123,7 @@ struct LayerUniform { unsigned long long coatWord, fuzzWord, coatFilledWord, fuz
 
 struct Workspace {     // byte offsets into BRMI_RES_WORKSPACE
     uint64_t counters, frontierA, frontierB, buckets, tempVisible, bitmask1, bitmask2, wordPrefix, blockSums,
-             instanceBitBase, segPrefix, meshLevelWidth, planes, replayNodes, replayBuckets, lightVS, lightMeta, clusterPages, clusterHits, pageTotal, lightHitMasks, binCounts, binRecords, binOverflow, clusterSetup, resolveVerts, resolveTris, matWords, shadeTables, lutF, frameConst, objConst, matConst, deferredPixels, usedClusters,
+             instanceBitBase, segPrefix, meshLevelWidth, planes, replayNodes, replayBuckets, lightVS, lightMeta, clusterPages, clusterHits, pageTotal, lightHitMasks, binCounts, binRecords, binOverflow, binPlan, binItems, binScratch, clusterSetup, resolveVerts, resolveTris, matWords, shadeTables, lutF, frameConst, objConst, matConst, deferredPixels, usedClusters,
              frameSnapshot, tileCounts, tileLists, tileOverflow, xverts, debugStamps, clusterUv, binAlpha, overflowAlpha, resolveUVs, resolveColors, alphaMats, shadeRows, shadeAvgs, ggxQuads, shadeLights, clusterList, listEntries, listRecords, layerUniform, frameClearBytes, total;
 };
 
@@ -164,6 +164,7 @@ struct brmi_pass {
     uint64_t totalBits = 0; uint32_t totalWords = 0, scanBlocks = 0;
     uint32_t numLightClusters = 0, lightPagePool = 0;
     uint32_t binOverflowPerStripe = 1u << 14;       // 64 stripes x 16384 records x 64 B = 64 MB
+    uint32_t binScratchTiles = 2048, binItemCapacity = 0;   // k_raster_bins: scratch tiles for bins several workgroups share (BRMI_BIN_SCRATCH_TILES), work items
     uint32_t binsX = 0, binsY = 0, binCapacity = 8192;   // raster bins: 256 px x 16 rows, binCapacity records of 64 B each (BRMI_BIN_CAPACITY): 1 GB at 4K, walked in slices of 1024
     bool rasterTiles = false;     // BRMI_RASTER_MODE=tiles (opaque scenes): cluster-granular sort-middle (k_raster_tile_lists / k_raster_tiles) instead of the triangle bins -- bit-exact, a fifth of the HBM traffic, 20-40 % slower (profiles/r03_experiments.md)
     uint32_t rtilesX = 0, rtilesY = 0, tileCapacity = 1024, tileOverflowCapacity = 1u << 20, tileMinSlice = 128;

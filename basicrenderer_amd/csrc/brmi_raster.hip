@@ -59,7 +59,10 @@ struct RasterArgs {
     int bigTriArea;          // clamped-bbox pixels above which a triangle is binned
     int bigTriAreaDense; uint32_t denseClusterCount;     // ... on frames with at least this many visible clusters
     int bigTriAreaAlpha;     // the same for alpha-tested clusters: their pixels are far cheaper in a bin (LDS early-out, more lanes in flight)
-    uint32_t binMinSlice;    // fewest records a slice of a bin holds (BRMI_BIN_MIN_SLICE)
+    uint32_t binMinSlice;    // most records one workgroup walks alone: a bin with more is cut into slices (BRMI_BIN_MIN_SLICE)
+    uint32_t binSharedSlice; // records per slice of such a bin (BRMI_BIN_SHARED_SLICE)
+    // the plan of a k_raster_bins launch (plan_bins): header {itemCount, ticket}, per bin {records, first scratch tile, slices done}, the work items
+    uint32_t* binPlan; uint32_t* binItems; unsigned long long* binScratch; uint32_t binScratchTiles, binItemCapacity;
     int debugFlags;          // experiments only (BRMI_RASTER_DEBUG): 1 = skip the direct walk, 2 = skip bin emission, 4 = skip the bin pass, 8 = direct walk without the atomic
     brmi_scene_buffers sc;
     const uint4* clusters; const ClusterSetup* setup;
@@ -93,12 +96,15 @@ BRMI_DEV void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// ClipScanlineRange (softwareRaster.hlsl:262-288).  The shader divides -value / step for a rising edge and value / -step for a falling one; IEEE
+// division is sign-symmetric, so both are the same number: ONE correctly rounded division per edge whatever the lanes' signs (as two branches a
+// wave whose lanes disagree about the sign ran both: six divisions per row, half of what a binned row of average length costs).
 BRMI_DEV void clip_scanline(float value, float step, int& first, int& last, bool& has) {
-    if (!has) return;
-    if (step > 0.0f) { const int c = to_int_sat(ceilf(-value / step)); first = first > c ? first : c; }
-    else if (step < 0.0f) { const int f = to_int_sat(floorf(value / -step)); last = last < f ? last : f; }
-    else has = value >= 0.0f;
-    has = has && first <= last;
+    const float q = -value / step;                               // step == 0: not used
+    const int c = to_int_sat(ceilf(q)), f = to_int_sat(floorf(q));
+    if (step > 0.0f) first = first > c ? first : c;
+    if (step < 0.0f) last = last < f ? last : f;
+    has = has && (step != 0.0f || value >= 0.0f) && first <= last;
 }
 
 // Where a key goes: the visibility buffer (tiled, 64-bit atomic min in L2) or the LDS tile of a bin.
@@ -556,6 +562,16 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
 #ifndef BRMI_BIN_THREADS
 #define BRMI_BIN_THREADS 512
 #endif
+#ifndef BRMI_BIN_PRIORITY
+#define BRMI_BIN_PRIORITY 0
+#endif
+#ifndef BRMI_BIN_SORT
+#define BRMI_BIN_SORT 1
+#endif
+#ifndef BRMI_BIN_SORT_MIN
+#define BRMI_BIN_SORT_MIN 96u
+#endif
+constexpr uint32_t BIN_ORDER_CAP = 1024;       // longest slice the walk order is built for (longer ones: BRMI_BIN_CAPACITY above 8192) walk in arrival order
 // The alpha-tested variant is bound by the latency of its per-pixel texel fetches: it wants as many resident workgroups as the
 // register file and the LDS allow.  BRMI_ALPHA_LIST sizes two LDS arrays; at 4096 entries the workgroup needs 43 KB and only three
 // fit a CU, at 2048 it needs 31 KB and four do (profiles/r02_experiments.md).
@@ -578,26 +594,51 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES
     __shared__ uint32_t taskStart[ALPHA ? ALPHA_LIST + 1 : 1];      // exclusive prefix of the listed records' task counts
     __shared__ uint32_t scanPart[ALPHA ? BRMI_BIN_THREADS : 1];
     __shared__ uint32_t alphaCount;
-    // A bin with many records (the near field of a dense frame: thousands of slivers on one strip of ground) is cut into slices of
-    // BIN_SLICE records, one workgroup each (blockIdx.z): the kernel ends with its slowest workgroup, and one bin with 8,000 records
-    // used to be that workgroup.  The slices of a bin merge into the visibility buffer with atomic-min; a bin that fits one slice keeps
-    // the plain read-modify-write merge (it owns its pixels).  The counts are cleared by k_raster_overflow, which runs next.
-    const uint32_t strip = blockIdx.x, band = blockIdx.y, bin = band * a.binsX + strip;
-    const uint32_t nAll = min(a.binCounts[bin], a.binCapacity);
+    __shared__ uint16_t order[ALPHA ? 1 : BIN_ORDER_CAP];       // the slice's records in walk order (opaque scenes)
+    __shared__ uint32_t classCount[18], classBase[19];
+    // The launch is a pool of workgroups that take work items -- (bin, slice) pairs, longest first -- from the list plan_bins wrote (the launch
+    // before: k_raster_overflow).  A bin with up to binMinSlice records is one item and keeps the plain read-modify-write merge (it owns its
+    // pixels).  A bin with more (the near field of a dense frame: thousands of slivers on one strip of ground; one workgroup walked such a bin
+    // for 400 us while 250 CUs idled) is cut into slices; every slice parks its tile of keys in a scratch tile, and the slice that finishes
+    // last folds the others' tiles into its own and merges once, plainly -- no per-key atomics (as atomic-min merges, eight keys of a 64 B line
+    // from several slices at a time, slices shorter than 1024 records LOST: raster 0.22 -> 0.25 -> 0.29 ms at 512 / 256).
+    // Why a list: a grid of (bins x slices) workgroups started in grid order; a slice of 1024 records that started 30 us into the launch ended
+    // it at 126 us while the balanced load was 56 us, and 14,000 of the 16,200 workgroups found nothing (scratch/bins_timeline.py).
+    __shared__ uint32_t curItem, doneBefore;
+    const uint32_t itemCount = min(a.binPlan[0], a.binItemCapacity), nBins = a.binsX * a.binsY;
+    const uint32_t* binN = a.binPlan + 16, * binSlot = binN + nBins; uint32_t* binDone = a.binPlan + 16 + 2u * nBins;
 #ifdef BRMI_TILE_STAMPS
     unsigned long long bph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bprev = __builtin_amdgcn_s_memtime();
+    unsigned long long wWait = 0, wWalk = 0, wPrev = 0;
 #define BSTAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); bph[k] += now_ - bprev; bprev = now_; } while (0)
 #else
 #define BSTAMP(k) do { } while (0)
 #endif
-    // the slices of a bin share its records evenly (a multiple of the 32 records one step walks, at least binMinSlice of them)
-    const uint32_t sliceSize = max(a.binMinSlice, ((nAll + gridDim.z - 1u) / gridDim.z + 31u) & ~31u);
-    const bool shared = nAll > sliceSize;               // other workgroups (or later slices of this one) write this bin's pixels too
     if (ALPHA) for (uint32_t i = threadIdx.x; i < 256u; i += BRMI_BIN_THREADS) unormT[i] = (float)i / 255.0f;
-    // slice blockIdx.z, then every gridDim.z-th one (phase 2, which rarely draws anything, is launched with one slice per bin)
-    for (uint32_t first = blockIdx.z * sliceSize; first < nAll; first += gridDim.z * sliceSize) {
-    const uint32_t n = min(nAll, first + sliceSize);
-    __syncthreads();                                    // the previous slice's merge has read the tile
+    // Items are handed out by ticket, in list order.  An atomic with return on one address serves ~90 per microsecond, so a thousand workgroups
+    // asking at once would wait up to 11 us for their first item: the first half of the pool starts on the item of its own index instead.  (Not
+    // the whole pool: workgroups that find no room on a CU at first -- the other frame's shading pass is resident -- would sit on the long items
+    // of their index until the resident ones run out of tickets, and end the launch with them.)
+    const uint32_t staticItems = gridDim.x / 2u;
+    uint32_t itemIndex = blockIdx.x;
+    if (blockIdx.x >= staticItems) {
+        if (threadIdx.x == 0) curItem = staticItems + atomicAdd(&a.binPlan[1], 1u);
+        __syncthreads();
+        itemIndex = curItem;
+    }
+    for (; itemIndex < itemCount; ) {
+#ifdef BRMI_TILE_STAMPS
+    const unsigned long long wgStart = __builtin_amdgcn_s_memrealtime();      // 100 MHz, the same clock on every CU: a timeline of the launch's items
+#endif
+    const uint32_t item = a.binItems[itemIndex];
+    const uint32_t bin = item & 0xFFFFu, slice = (item >> 16) & 0xFFu, sliceCount = (item >> 24) + 1u;
+    const uint32_t strip = bin % a.binsX, band = bin / a.binsX;
+    const uint32_t nAll = binN[bin];
+    // the slices of a bin share its records evenly (a multiple of the 32 records one step walks)
+    const uint32_t sliceSize = sliceCount == 1u ? nAll : ((nAll + sliceCount - 1u) / sliceCount + 31u) & ~31u;
+    const bool shared = sliceCount > 1u;                // other workgroups walk records of this bin too
+    const uint32_t first = slice * sliceSize;
+    const uint32_t n = max(first, min(nAll, first + sliceSize));      // (the plan's slices are never empty: sliceSize <= binSharedSlice, a multiple of 32)
     if (ALPHA && threadIdx.x == 0) alphaCount = 0u;
     for (uint32_t i = threadIdx.x; i < BIN_W * BIN_ROWS; i += BRMI_BIN_THREADS) tile[i] = BRMI_VIS_EMPTY;
     __syncthreads();
@@ -605,19 +646,65 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES
     const int x0 = (int)(strip << BIN_W_SHIFT), y0 = (int)(band << BIN_ROWS_SHIFT);
     const LdsSink sink{tile, x0, y0};
     const BinRecord* recs = a.binRecords + (size_t)bin * a.binCapacity;
-    const uint32_t sub = threadIdx.x >> 4, row = threadIdx.x & 15u;
+    // ---- order of the walk.  A wave walks its records in lockstep: a step lasts as long as its longest row, and a record with r rows keeps
+    // r of its lanes busy.  The records of a bin arrive in no order (mean 6 rows, widths from 2 to 256 px: timeline and model in
+    // profiles/r03_experiments.md -- the slowest wave of a 1024-record slice stepped 1,300 pixels where 300 would do with every lane busy, and
+    // the launch ends with those slices).  So the slice is counting-sorted by (rows <= 4 / <= 8 / <= 16, log2 of the pixels a row steps): a
+    // record gets 4, 8 or 16 lanes, and the records a wave takes together are about equally wide.  Keys are order-free (64-bit min).
+    constexpr uint32_t WIDTH_CLASSES = 6, SORT_CLASSES = 3 * WIDTH_CLASSES;
+    const uint32_t m = n - first;
+    const bool sorted = BRMI_BIN_SORT && !ALPHA && m >= BRMI_BIN_SORT_MIN && m <= BIN_ORDER_CAP;
+    if (sorted) {
+        if (threadIdx.x < SORT_CLASSES) classCount[threadIdx.x] = 0u;
+        __syncthreads();
+        uint32_t key[BIN_ORDER_CAP / BRMI_BIN_THREADS], slot[BIN_ORDER_CAP / BRMI_BIN_THREADS];
+#pragma unroll
+        for (uint32_t k = 0; k < BIN_ORDER_CAP / BRMI_BIN_THREADS; k++) {
+            const uint32_t i = threadIdx.x + k * BRMI_BIN_THREADS;
+            key[k] = 0xFFFFFFFFu;
+            if (i < m) {
+                const BinRecord* r = recs + first + i;
+                const uint32_t rows = (r->triAndFlags >> 16) & 0xFFu;
+                const int steps = min(r->minX + r->rectWidth, x0 + BIN_W) - r->minX;          // pixels a row's lane steps and walks
+                const uint32_t wc = steps <= 8 ? 0u : min(WIDTH_CLASSES - 1u, 29u - (uint32_t)__clz((uint32_t)(steps - 1)));      // <= 8, 16, 32, 64, 128, more
+                key[k] = (rows <= 4u ? 0u : rows <= 8u ? 1u : 2u) * WIDTH_CLASSES + wc;
+                slot[k] = atomicAdd(&classCount[key[k]], 1u);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t run = 0;
+            for (uint32_t c = 0; c < SORT_CLASSES; c++) { classBase[c] = run; run += classCount[c]; }
+            classBase[SORT_CLASSES] = run;
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < BIN_ORDER_CAP / BRMI_BIN_THREADS; k++) if (key[k] != 0xFFFFFFFFu) order[classBase[key[k]] + slot[k]] = (uint16_t)(threadIdx.x + k * BRMI_BIN_THREADS);
+        __syncthreads();
+    }
     // the record of the NEXT step is requested before this step's rows are walked: the records come from HBM (the launch before wrote 86 MiB of
     // them on a dense frame), a step's load is a round trip of its own, and a slice is 32 steps -- the record walk was 75 % of this kernel's
     // wave-cycles (phase stamps).  (Lane = record with the rows re-dealt to the lanes -- an owner byte per row in LDS, the record's fields
     // fetched from the owning lane with ds_bpermute -- walks a dense frame's 3-6-row records 8 % faster on its own, but needs 78 VGPRs
     // instead of 46: beside three k_shade waves per SIMD the kernel then finds no room, and the frame with two in flight got 18 % slower.)
-    BinRecord pending{};
-    if (first + sub < n) pending = recs[first + sub];
-    for (uint32_t base = first; base < n; base += BRMI_BIN_THREADS / 16) {
-        const uint32_t ri = base + sub;
+    for (uint32_t rc = sorted ? 0u : 2u; rc < 3u; rc++) {
+    const uint32_t sh = 2u + rc;                                          // 4, 8 or 16 lanes per record
+    const uint32_t sub = threadIdx.x >> sh, row = threadIdx.x & ((1u << sh) - 1u), per = BRMI_BIN_THREADS >> sh;
+    const uint32_t cs = sorted ? classBase[rc * WIDTH_CLASSES] : 0u, ce = sorted ? classBase[(rc + 1u) * WIDTH_CLASSES] : m;
+    auto record_at = [&](uint32_t idx) { return first + (sorted ? (uint32_t)order[idx] : idx); };
+    BinRecord pending{}; uint32_t riPending = 0;
+    if (cs + sub < ce) { riPending = record_at(cs + sub); pending = recs[riPending]; }
+#ifdef BRMI_TILE_STAMPS
+    wPrev = __builtin_amdgcn_s_memtime();
+#endif
+    for (uint32_t base = cs; base < ce; base += per) {
+        const uint32_t idx = base + sub, ri = riPending;
         const BinRecord r = pending;
-        if (ri + BRMI_BIN_THREADS / 16 < n) pending = recs[ri + BRMI_BIN_THREADS / 16];
-        if (ri >= n) continue;
+#ifdef BRMI_TILE_STAMPS
+        { uint32_t probe_ = r.clusterIndex; asm volatile("" :: "v"(probe_)); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); wWait += now_ - wPrev; wPrev = now_; }     // the record has arrived
+#endif
+        if (idx + per < ce) { riPending = record_at(idx + per); pending = recs[riPending]; }
+        if (idx >= ce) continue;
         const uint32_t rows = (r.triAndFlags >> 16) & 0xFFu;
         bool deferred = false;
         if (ALPHA && r.pad1 != 0u) {      // alpha tested: listed for the task pass below
@@ -638,7 +725,11 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES
                 raster_row(sink, NoAlpha{}, py, r.minX, r.rectWidth, (r.triAndFlags & 0x100u) != 0, sb0, sb1, r.dx_b0, r.dx_b1, -(r.dx_b0 + r.dx_b1), r.d0, r.d1, r.d2, r.clusterIndex, r.triAndFlags & 0x7Fu,
                            x0, x0 + BIN_W - 1);
         }
+#ifdef BRMI_TILE_STAMPS
+        { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); wWalk += now_ - wPrev; wPrev = now_; }
+#endif
     }
+    }   // row classes
     BSTAMP(1);
     if (ALPHA) {
         // Alpha-tested records after the opaque ones (more keys to reject untested).  A pixel of theirs costs a texcoord, a dependent
@@ -694,9 +785,46 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES
     }
     __syncthreads();
     BSTAMP(4);
+    // ---- a slice of a shared bin: park the tile; the slice that arrives last folds the others in and goes on to merge
+    bool atomicMerge = false, fold = true;
+    if (shared) {
+        const uint32_t slot = binSlot[bin];
+        if (slot == 0xFFFFFFFFu) atomicMerge = true;      // more shared bins than scratch tiles (counted by the plan): the keys go to L2 one by one
+        else {
+            // agent-scope stores / loads (write through / read around the XCD's L2: the folding workgroup may sit on another XCD)
+            unsigned long long* mine = a.binScratch + ((size_t)slot + slice) * (BIN_W * BIN_ROWS);
+            for (uint32_t i = threadIdx.x; i < BIN_W * BIN_ROWS; i += BRMI_BIN_THREADS) __hip_atomic_store(&mine[i], tile[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // every wave's stores have left (vmcnt), the workgroup has met, then the counter: the order the hand-off needs.  (Agent-scope
+            // release / acquire fences instead write back and invalidate the XCD's whole L2 per slice: raster 0.22 -> 0.45 ms.)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) doneBefore = __hip_atomic_fetch_add(&binDone[bin], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            fold = doneBefore + 1u == sliceCount;          // else another slice folds and merges
+            if (fold) {
+            // (a thread's eight keys of a tile are requested together: the fold is a memory round trip per tile, not per key)
+            const unsigned long long* tiles = a.binScratch + (size_t)slot * (BIN_W * BIN_ROWS);
+            unsigned long long best[BIN_W * BIN_ROWS / BRMI_BIN_THREADS];
+#pragma unroll
+            for (uint32_t k = 0; k < BIN_W * BIN_ROWS / BRMI_BIN_THREADS; k++) best[k] = tile[threadIdx.x + k * BRMI_BIN_THREADS];
+            for (uint32_t z = 0; z < sliceCount; z++) {
+                if (z == slice) continue;
+                unsigned long long o[BIN_W * BIN_ROWS / BRMI_BIN_THREADS];
+#pragma unroll
+                for (uint32_t k = 0; k < BIN_W * BIN_ROWS / BRMI_BIN_THREADS; k++) o[k] = __hip_atomic_load(&tiles[(size_t)z * (BIN_W * BIN_ROWS) + threadIdx.x + k * BRMI_BIN_THREADS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (uint32_t k = 0; k < BIN_W * BIN_ROWS / BRMI_BIN_THREADS; k++) best[k] = o[k] < best[k] ? o[k] : best[k];
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < BIN_W * BIN_ROWS / BRMI_BIN_THREADS; k++) tile[threadIdx.x + k * BRMI_BIN_THREADS] = best[k];
+            if (threadIdx.x == 0) __hip_atomic_store(&binDone[bin], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            }
+        }
+    }
     // merge: item = (column x, upper / lower 8 rows) = 8 keys = 64 B, contiguous in the tile and in the 8x8-tiled surface
-    for (uint32_t item = threadIdx.x; item < BIN_W * 2; item += BRMI_BIN_THREADS) {
-        const uint32_t half = item >> 8 /* BIN_W items per half */, xl = item & (BIN_W - 1);
+    for (uint32_t item2 = threadIdx.x; fold && item2 < BIN_W * 2; item2 += BRMI_BIN_THREADS) {
+        const uint32_t half = item2 >> 8 /* BIN_W items per half */, xl = item2 & (BIN_W - 1);
         const ulonglong2* src = reinterpret_cast<const ulonglong2*>(&tile[xl * BIN_ROWS + half * 8u]);
         ulonglong2 k[4];
         bool any = false;
@@ -705,7 +833,7 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES
         if (!any) continue;      // untouched (this also covers columns / rows beyond the target size)
         const uint32_t px = (uint32_t)x0 + xl, py = (uint32_t)y0 + half * 8u;
         ulonglong2* dst = reinterpret_cast<ulonglong2*>(&a.vis[(((py >> 3) * a.tilesX + (px >> 3)) << 6) | ((px & 7u) << 3)]);
-        if (shared) {
+        if (atomicMerge) {
             unsigned long long* d1 = reinterpret_cast<unsigned long long*>(dst);
 #pragma unroll
             for (int q = 0; q < 4; q++) { if (k[q].x != BRMI_VIS_EMPTY) atomicMin(&d1[2 * q], k[q].x); if (k[q].y != BRMI_VIS_EMPTY) atomicMin(&d1[2 * q + 1], k[q].y); }
@@ -714,27 +842,77 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const ulonglong2 g = dst[q];
-            const ulonglong2 m = make_ulonglong2(g.x < k[q].x ? g.x : k[q].x, g.y < k[q].y ? g.y : k[q].y);
-            if (m.x != g.x || m.y != g.y) dst[q] = m;
+            const ulonglong2 m2 = make_ulonglong2(g.x < k[q].x ? g.x : k[q].x, g.y < k[q].y ? g.y : k[q].y);
+            if (m2.x != g.x || m2.y != g.y) dst[q] = m2;
         }
     }
     BSTAMP(5);
-    }   // slices
+#ifdef BRMI_TILE_STAMPS
+    if (threadIdx.x == 0 && (a.debugFlags & 0x400)) {       // timeline: one entry per work item
+        unsigned long long* w = a.debugStamps + 64u + 4u * (size_t)itemIndex;
+        w[0] = wgStart; w[1] = __builtin_amdgcn_s_memrealtime(); w[2] = (unsigned long long)(n - first) | ((unsigned long long)item << 32); w[3] = wWalk;
+    }
+#endif
+    __syncthreads();                                    // the merge has read the tile (and everyone has read curItem)
+    if (threadIdx.x == 0) curItem = staticItems + atomicAdd(&a.binPlan[1], 1u);
+    __syncthreads();
+    itemIndex = curItem;
+    }   // work items
 #ifdef BRMI_TILE_STAMPS
     if ((threadIdx.x & 63u) < 8u && (a.debugFlags & 0x200)) { unsigned long long v = 0; for (int k = 0; k < 8; k++) if ((threadIdx.x & 63u) == (uint32_t)k) v = bph[k]; atomicAdd(a.debugStamps + 32u + (threadIdx.x & 63u), v); }
 #endif
 }
 
-// Records that did not fit their bin: four per wave64, one lane per row, global 64-bit atomics (the bins' merge is a plain
-// read-modify-write, so this runs after k_raster_bins).  The queue lengths are cleared with the frame's counters and, between the
-// two raster phases, by k_seed_phase2.
+// The plan of the k_raster_bins launch that follows (the last workgroup of k_raster_overflow): every bin's record count is taken (and cleared
+// for the next frame), bins with more than binMinSlice records are cut into slices of at most binSharedSlice and get scratch tiles, and the
+// (bin, slice) items are counting-sorted by length, longest first -- the pool of workgroups then ends its launch with short items.
+BRMI_DEV void plan_bins(const RasterArgs& a) {
+    __shared__ uint32_t classCount[16], classBase[16], tileRun;
+    const uint32_t nBins = a.binsX * a.binsY;
+    uint32_t* binN = a.binPlan + 16, * binSlot = binN + nBins, * binDone = binSlot + nBins;
+    if (threadIdx.x < 16u) classCount[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) tileRun = 0u;
+    __syncthreads();
+    auto slices_of = [&](uint32_t n) { return n == 0u ? 0u : n <= a.binMinSlice ? 1u : min((n + a.binSharedSlice - 1u) / a.binSharedSlice, 256u); };
+    auto class_of = [&](uint32_t n, uint32_t sc) { const uint32_t len = (n + sc - 1u) / sc; return 31u - (uint32_t)__clz(len); };      // log2 of the slice length (< 16: a slice holds < 65536 records)
+    for (uint32_t b0 = 0; b0 < nBins; b0 += 8u * blockDim.x) {
+        uint32_t n[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; k++) { const uint32_t b = b0 + k * blockDim.x + threadIdx.x; n[k] = b < nBins ? min(a.binCounts[b], a.binCapacity) : 0u; }      // eight loads in flight
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; k++) {
+            const uint32_t b = b0 + k * blockDim.x + threadIdx.x;
+            if (b >= nBins) continue;
+            const uint32_t sc = slices_of(n[k]);
+            a.binCounts[b] = 0u; binN[b] = n[k]; binDone[b] = 0u;
+            uint32_t slot = 0xFFFFFFFFu;
+            if (sc > 1u) { const uint32_t base = atomicAdd(&tileRun, sc); if (base + sc <= a.binScratchTiles) slot = base; }      // (any order: a tile range per shared bin)
+            binSlot[b] = slot;
+            if (sc != 0u) atomicAdd(&classCount[class_of(n[k], sc)], sc);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t run = 0; for (int c = 15; c >= 0; c--) { classBase[c] = run; run += classCount[c]; } a.binPlan[0] = run; a.binPlan[1] = 0u; a.binPlan[2] = tileRun; }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nBins; b += blockDim.x) {
+        const uint32_t n = binN[b], sc = slices_of(n);
+        if (sc == 0u) continue;
+        const uint32_t at = atomicAdd(&classBase[class_of(n, sc)], sc);
+        for (uint32_t z = 0; z < sc; z++) if (at + z < a.binItemCapacity) a.binItems[at + z] = b | (z << 16) | ((sc - 1u) << 24);
+    }
+}
+
+// Records that did not fit their bin: four per wave64, one lane per row, global 64-bit atomics.  Runs BEFORE k_raster_bins (whose plain
+// read-modify-write merges then see these keys like k_raster's own); its last workgroup writes that launch's plan.  The queue lengths are
+// cleared with the frame's counters and, between the two raster phases, by k_seed_phase2.
 template <bool ALPHA>
-__global__ void __launch_bounds__(64) k_raster_overflow(RasterArgs a) {
-    const uint32_t lane = threadIdx.x, sub = lane >> 4, row = lane & 15u;
+__global__ void __launch_bounds__(256) k_raster_overflow(RasterArgs a) {
+    if (blockIdx.x == gridDim.x - 1u) { plan_bins(a); return; }
+    // a wave = four records at a time, one lane per row
+    const uint32_t lane = threadIdx.x & 63u, sub = lane >> 4, row = lane & 15u;
+    const uint32_t walker = blockIdx.x * 4u + (threadIdx.x >> 6), walkers = (gridDim.x - 1u) * 4u;
     __shared__ float unormT[ALPHA ? 256 : 1];
-    if (ALPHA) { for (uint32_t i = threadIdx.x; i < 256u; i += 64u) unormT[i] = (float)i / 255.0f; __syncthreads(); }
-    // the bins are empty again when this launch retires (k_raster_bins has finished; its slices all read the counts)
-    for (uint32_t i = blockIdx.x * 64u + lane; i < a.binsX * a.binsY; i += gridDim.x * 64u) a.binCounts[i] = 0u;
+    if (ALPHA) { unormT[threadIdx.x] = (float)threadIdx.x / 255.0f; __syncthreads(); }
     // lane = stripe: all 64 queue lengths with one load; nearly every frame has none
     const uint32_t mine = min(a.counters[CNT_STRIPES + lane * CNT_STRIPE_WORDS + STRIPE_OVERFLOW], a.overflowPerStripe);
     uint64_t busy = __ballot(mine != 0u);
@@ -742,7 +920,7 @@ __global__ void __launch_bounds__(64) k_raster_overflow(RasterArgs a) {
         const uint32_t stripe = (uint32_t)__ffsll((unsigned long long)busy) - 1u;
         busy &= busy - 1ull;
         const uint32_t n = (uint32_t)__shfl((int)mine, (int)stripe);
-        for (uint32_t base = blockIdx.x * 4u; base < n; base += gridDim.x * 4u) {
+        for (uint32_t base = walker * 4u; base < n; base += walkers * 4u) {
             const uint32_t ri = base + sub;
             if (ri >= n) continue;
             const BinRecord r = a.overflow[(size_t)stripe * a.overflowPerStripe + ri];
@@ -1166,6 +1344,10 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
     a.bigTriAreaDense = p->bigTriAreaDense; a.denseClusterCount = p->denseClusterCount;
     static const uint32_t minSlice = [] { const char* e = std::getenv("BRMI_BIN_MIN_SLICE"); return e ? (uint32_t)std::max(32, std::atoi(e)) : 1024u; }();
     a.binMinSlice = minSlice;
+    static const uint32_t sharedSlice = [] { const char* e = std::getenv("BRMI_BIN_SHARED_SLICE"); return e ? (uint32_t)std::max(32, std::atoi(e)) : 512u; }();
+    a.binSharedSlice = std::min(sharedSlice, minSlice) & ~31u;        // a multiple of the 32 records a step walks: no slice of the plan is empty
+    a.binPlan = p->wsPtr<uint32_t>(p->ws.binPlan); a.binItems = p->wsPtr<uint32_t>(p->ws.binItems); a.binScratch = p->wsPtr<unsigned long long>(p->ws.binScratch);
+    a.binScratchTiles = p->binScratchTiles; a.binItemCapacity = p->binItemCapacity;
     a.binAlpha = p->wsPtr<AlphaRecord>(p->ws.binAlpha); a.overflowAlpha = p->wsPtr<AlphaRecord>(p->ws.overflowAlpha);
     a.clusterUv = p->wsPtr<ClusterUv>(p->ws.clusterUv);
     a.alphaMats = p->wsPtr<AlphaMaterial>(p->ws.alphaMats);
@@ -1185,19 +1367,21 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
         BRMI_LAUNCH_CHECK(p, "k_raster_tiles");
         return BRMI_OK;
     }
-    const uint32_t slices = phase == 2 ? 1u : std::min(16u, (p->binCapacity + BIN_SLICE - 1u) / BIN_SLICE);
+    // the pool of k_raster_bins: four 512-thread workgroups per CU is what the LDS holds; phase 2 rarely has an item at all
+    static const uint32_t binGrid = [] { const char* e = std::getenv("BRMI_BIN_GRID"); return e ? (uint32_t)std::max(1, std::atoi(e)) : 1024u; }();
+    const dim3 bgrid(phase == 2 ? std::min(binGrid, 256u) : binGrid);
     // phase 2 rarely has more than a handful of clusters: 2048 workgroups (the kernel strides; two waves per SIMD) start and retire a little
     // faster than 8192 that find nothing (-3 us per frame)
     static const uint32_t grid2 = [] { const char* e = std::getenv("BRMI_RASTER_GRID2"); return e ? (uint32_t)std::max(64, std::atoi(e)) : 2048u; }();
     const dim3 rgrid(phase == 2 ? std::min(p->rasterGrid, grid2) : p->rasterGrid);
     if (p->sceneHasAlphaTest) {
         hipLaunchKernelGGL(k_raster<true>, rgrid, dim3(64), 0, s, a);
-        if (!(p->rasterDebug & 4)) hipLaunchKernelGGL(k_raster_bins<true>, dim3(p->binsX, p->binsY, slices), dim3(BRMI_BIN_THREADS), 0, s, a);
-        hipLaunchKernelGGL(k_raster_overflow<true>, dim3(512), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(k_raster_overflow<true>, dim3(129), dim3(256), 0, s, a);
+        if (!(p->rasterDebug & 4)) hipLaunchKernelGGL(k_raster_bins<true>, bgrid, dim3(BRMI_BIN_THREADS), 0, s, a);
     } else {
         hipLaunchKernelGGL(k_raster<false>, rgrid, dim3(64), 0, s, a);
-        if (!(p->rasterDebug & 4)) hipLaunchKernelGGL(k_raster_bins<false>, dim3(p->binsX, p->binsY, slices), dim3(BRMI_BIN_THREADS), 0, s, a);
-        hipLaunchKernelGGL(k_raster_overflow<false>, dim3(512), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(k_raster_overflow<false>, dim3(129), dim3(256), 0, s, a);
+        if (!(p->rasterDebug & 4)) hipLaunchKernelGGL(k_raster_bins<false>, bgrid, dim3(BRMI_BIN_THREADS), 0, s, a);
     }
     BRMI_LAUNCH_CHECK(p, "k_raster");
     return BRMI_OK;

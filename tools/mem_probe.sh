@@ -15,7 +15,7 @@ for set in "GRBM_GUI_ACTIVE TA_TA_BUSY_sum TA_BUSY_avr TA_BUSY_max" \
            "TD_TD_BUSY_sum TD_TC_STALL_sum TD_LOAD_WAVEFRONT_sum" \
            "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_FLAT SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_WAVES"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --kernel-trace -d $O/m$i -o p --output-format csv -- python3 bench.py --no-cpu-baseline --no-second --no-dense --camera-path 0 --steps 5 --warmup 2 "$@" > $O/m$i.log 2>&1
+  timeout 300 rocprofv3 --pmc $set --kernel-trace -d $O/m$i -o p --output-format csv -- python3 bench.py --no-cpu-baseline --no-second --no-dense --camera-path 0 --steps 5 --warmup 2 "$@" > $O/m$i.log 2>&1
 done
 python3 - $O <<'PY' > $O/mem.txt
 import csv, sys, collections, glob

@@ -5,9 +5,9 @@ TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp
 O=$ROOT/gpurun_out/$TAG; mkdir -p $O
 cd $ROOT
-python3 bench.py --no-cpu-baseline --no-second --steps 100 "$@" > $O/bench.json 2> $O/bench.err
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_BUSY_CYCLES --kernel-trace -d $O/p1 -o p --output-format csv -- python3 bench.py --no-cpu-baseline --steps 5 --warmup 2 "$@" > $O/p1.log 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_TRANS --kernel-trace -d $O/p2 -o p --output-format csv -- python3 bench.py --no-cpu-baseline --steps 5 --warmup 2 "$@" > $O/p2.log 2>&1
+python3 bench.py --no-cpu-baseline --no-second --no-dense --camera-path 0 --steps 100 "$@" > $O/bench.json 2> $O/bench.err
+timeout 400 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_BUSY_CYCLES --kernel-trace -d $O/p1 -o p --output-format csv -- python3 bench.py --no-cpu-baseline --no-second --no-dense --camera-path 0 --steps 5 --warmup 2 "$@" > $O/p1.log 2>&1
+timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_TRANS --kernel-trace -d $O/p2 -o p --output-format csv -- python3 bench.py --no-cpu-baseline --no-second --no-dense --camera-path 0 --steps 5 --warmup 2 "$@" > $O/p2.log 2>&1
 python3 - $O <<'PY' > $O/sq.txt
 import csv, sys, collections, glob
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); disp = collections.defaultdict(lambda: collections.defaultdict(set))
