@@ -174,7 +174,7 @@ struct brmi_pass {
     uint32_t rasterGrid = 8192;  // single-wave workgroups of k_raster (BRMI_RASTER_GRID)
     int rasterDebug = 0;         // BRMI_RASTER_DEBUG (experiments; non-zero gives wrong images)
     int bigTriAreaDense = 32; uint32_t denseClusterCount = 6144;   // frames with that many visible clusters bin from this area on (BRMI_BIG_TRI_AREA sets both)
-    int bigTriArea = 64, bigTriAreaAlpha = 32;        // clamped-bbox pixels above which a triangle is binned (BRMI_BIG_TRI_AREA)
+    int bigTriArea = 32, bigTriAreaAlpha = 32;        // clamped-bbox pixels above which a triangle is binned (BRMI_BIG_TRI_AREA; 64 until the bins kernel walked sorted slices: Sponza-class raster 0.096 -> 0.090 ms at 32)
     uint32_t hzbMipCount = 0; std::vector<uint64_t> hzbMipOffsets; std::vector<uint32_t> hzbMipW, hzbMipH;   // [mip]; offsets in floats, mip 0 unused
     bool hzbValid = false;       // a chain built from a finished frame exists (phase 1 of the next frame tests against it)
     brmi_pass* history = nullptr;    // brmi_set_history_source: the pass whose chain phase 1 tests against (frames in flight); null = this pass's own

@@ -254,6 +254,8 @@ BRMI_DEV void bin_append(const RasterArgs& a, const float* unorm, const BinRecor
 #endif
 template <bool ALPHA>
 __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RASTER_WAVES) k_raster(RasterArgs a) {
+    // (one wave per workgroup: LDS hand-offs between its lanes need wave_lds_sync() only.  __syncthreads() also waits for every global store
+    // and atomic the wave has in flight -- the record stores and the small boxes' atomic-mins: a memory round trip per hand-off.)
     __shared__ float sx[BRMI_MESHLET_MAX_VERTS], sy[BRMI_MESHLET_MAX_VERTS], sd[BRMI_MESHLET_MAX_VERTS];
     __shared__ float siw[ALPHA ? BRMI_MESHLET_MAX_VERTS : 1], su[ALPHA ? BRMI_MESHLET_MAX_VERTS : 1], sv[ALPHA ? BRMI_MESHLET_MAX_VERTS : 1];
     __shared__ float tpA[ALPHA ? 9 : 1][64];
@@ -349,7 +351,7 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
             sd[v] = -viewZ;
             if (alphaCluster) { const f2 uv = decode_uv(cu, v); siw[v] = invW; su[v] = uv.x; sv[v] = uv.y; }
         }
-        __syncthreads();
+        wave_lds_sync();
         KSTAMP(1);
 
         // triangle stage: lane = triangle (softwareRaster.hlsl:416-611)
@@ -413,6 +415,38 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
             // all lanes stepping side by side (a lower band of a multi-GPU frame starts thousands of rows below the top of a large box)
             float band_b0 = row_b0, band_b1 = row_b1;
             if (entries > 0) for (int y = minY; y < yLo; y++) { band_b0 += dy_b0; band_b1 += dy_b1; }
+            // A few bins per triangle: every lane appends its own records (below, after the small boxes).  A slot in a bin costs an atomic with
+            // return on the bin's counter (~2 us round trip, and the triangles of a meshlet hit the same few bins), so the wave first counts
+            // its records per bin in an LDS window over the bins it touches and reserves each bin's run with ONE global atomic -- requested
+            // HERE, before the small boxes are walked, and used after them: the round trip was 44 % of this kernel's wave-cycles when the
+            // wave sat through it (phase stamps, Bistro-class frame).
+            const bool few = entries > 0 && entries <= COOP_ENTRIES && !(a.debugFlags & 2);
+            const bool anyFew = __any(few);
+            int wb0 = 0, ws0 = 0, winW = 1, cells = 0; bool windowed = false;
+            uint32_t resvCount[BIN_WINDOW / 64] = {}, resvBase[BIN_WINDOW / 64] = {};
+            if (anyFew) {
+                int wb1 = few ? band1 : -1, ws1 = few ? strip1 : -1;
+                wb0 = few ? band0 : 0x7FFFFFFF; ws0 = few ? strip0 : 0x7FFFFFFF;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    wb0 = min(wb0, __shfl_xor(wb0, o)); wb1 = max(wb1, __shfl_xor(wb1, o));
+                    ws0 = min(ws0, __shfl_xor(ws0, o)); ws1 = max(ws1, __shfl_xor(ws1, o));
+                }
+                winW = ws1 - ws0 + 1; cells = (wb1 - wb0 + 1) * winW;
+                windowed = cells <= BIN_WINDOW;      // wave-uniform
+                if (windowed) {
+                    for (int cI = (int)lane; cI < cells; cI += 64) binBase[cI] = 0u;
+                    wave_lds_sync();
+                    if (few) for (int band = band0; band <= band1; band++) if (owns_band(band)) for (int st = strip0; st <= strip1; st++) atomicAdd(&binBase[(band - wb0) * winW + (st - ws0)], 1u);
+                    wave_lds_sync();
+#pragma unroll
+                    for (int k = 0; k < BIN_WINDOW / 64; k++) {
+                        const int cI = (int)lane + 64 * k;
+                        resvCount[k] = cI < cells ? binBase[cI] : 0u;
+                        if (resvCount[k] != 0u) resvBase[k] = atomicAdd(&a.binCounts[vband(wb0 + cI / winW) * a.binsX + (uint32_t)(ws0 + cI % winW)], resvCount[k]);
+                    }
+                }
+            }
             KSTAMP(2);
             // Small boxes: global atomics.  lane = triangle leaves most lanes idle (culled triangles, boxes of very different
             // size), so the rows of the batch's small triangles are re-dealt to the lanes: an exclusive scan of the row counts,
@@ -437,7 +471,7 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
                         tpA[0][lane] = arec.tri.invW0; tpA[1][lane] = arec.tri.invW1; tpA[2][lane] = arec.tri.invW2;
                         tpA[3][lane] = arec.tri.uv0.x; tpA[4][lane] = arec.tri.uv0.y; tpA[5][lane] = arec.tri.uv1.x; tpA[6][lane] = arec.tri.uv1.y; tpA[7][lane] = arec.tri.uv2.x; tpA[8][lane] = arec.tri.uv2.y;
                     }
-                    __syncthreads();
+                    wave_lds_sync();
                     for (uint32_t task = lane; task < totalRows; task += 64) {
                         uint32_t tri = 0;
 #pragma unroll
@@ -457,34 +491,17 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
                         raster_row(gsink, NoAlpha{}, spy, t_minX, t_w, useScanlineRanges, sb0, sb1, t_dx0, t_dx1, -(t_dx0 + t_dx1), tpF[6][tri], tpF[7][tri], tpF[8][tri], clusterIndex, waveBase + tri,
                                    t_minX, t_minX + t_w - 1);
                     }
-                    __syncthreads();
+                    wave_lds_sync();
                 }
             }
             KSTAMP(3);
-            // A few bins per triangle: every lane appends its own records.  A slot in a bin costs an atomic with return on the
-            // bin's counter (~2 us round trip, and the triangles of a meshlet hit the same few bins), so the wave first counts
-            // its records per bin in an LDS window over the bins it touches, reserves each bin's run with ONE global atomic,
-            // and then hands out the slots from LDS.
-            const bool few = entries > 0 && entries <= COOP_ENTRIES && !(a.debugFlags & 2);
-            if (__any(few)) {
-                int wb0 = few ? band0 : 0x7FFFFFFF, wb1 = few ? band1 : -1, ws0 = few ? strip0 : 0x7FFFFFFF, ws1 = few ? strip1 : -1;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    wb0 = min(wb0, __shfl_xor(wb0, o)); wb1 = max(wb1, __shfl_xor(wb1, o));
-                    ws0 = min(ws0, __shfl_xor(ws0, o)); ws1 = max(ws1, __shfl_xor(ws1, o));
-                }
-                const int winW = ws1 - ws0 + 1, cells = (wb1 - wb0 + 1) * winW;
-                const bool windowed = cells <= BIN_WINDOW;      // wave-uniform
+            // the records of triangles with a few bins: slots handed out from the runs reserved above
+            if (anyFew) {
                 if (windowed) {
-                    for (int cI = (int)lane; cI < cells; cI += 64) binBase[cI] = 0u;
-                    __syncthreads();
-                    if (few) for (int band = band0; band <= band1; band++) if (owns_band(band)) for (int st = strip0; st <= strip1; st++) atomicAdd(&binBase[(band - wb0) * winW + (st - ws0)], 1u);
-                    __syncthreads();
-                    for (int cI = (int)lane; cI < cells; cI += 64) {
-                        const uint32_t nrec = binBase[cI];
-                        if (nrec != 0u) binBase[cI] = atomicAdd(&a.binCounts[vband(wb0 + cI / winW) * a.binsX + (uint32_t)(ws0 + cI % winW)], nrec);
-                    }
-                    __syncthreads();
+                    // the reserved runs have arrived (requested before the small boxes were walked)
+#pragma unroll
+                    for (int k = 0; k < BIN_WINDOW / 64; k++) { const int cI = (int)lane + 64 * k; if (cI < cells && resvCount[k] != 0u) binBase[cI] = resvBase[k]; }
+                    wave_lds_sync();
                 }
                 if (few) {
                     // step the row start band by band (the additions of the serial loop) and append one record per band and strip
@@ -505,9 +522,9 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
                         py += n;
                     }
                 }
-                if (windowed) __syncthreads();    // binBase is reused by the next batch
+                if (windowed) wave_lds_sync();    // binBase is reused by the next batch
             }
-            KSTAMP(4);
+            if (anyFew && !windowed) KSTAMP(6); else KSTAMP(4);      // (instrumented builds: passes whose bins do not fit the LDS window reserve slot by slot)
             // many bins: the whole wave emits the triangle.  lane L owns bands band0 + L, band0 + L + 64, ...: it steps the row
             // start down to each of them (the same additions the serial loop makes) and appends the band's record to every strip.
             uint64_t coop = __ballot(entries > COOP_ENTRIES && !(a.debugFlags & 2));
@@ -550,7 +567,7 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
             }
             KSTAMP(5);
         }
-        __syncthreads();   // LDS is reused by the next cluster
+        wave_lds_sync();   // LDS is reused by the next cluster
     }
 #ifdef BRMI_TILE_STAMPS
     if (lane < 8u && (a.debugFlags & 0x100)) { unsigned long long v = 0; for (int k = 0; k < 8; k++) if (lane == (uint32_t)k) v = kph[k]; atomicAdd(a.debugStamps + 16u + lane, v); }
