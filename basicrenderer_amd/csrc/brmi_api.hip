@@ -702,7 +702,10 @@ int brmi_execute_split(brmi_pass* p, brmi_stream stream, brmi_stream shadeStream
     p->fuseShadeIntoGBuffer = false; p->depthFinal = false;
     if (rc) return rc;
     if (!lightsDone && (rc = brmi_light_clustering(p, stream))) return rc;
-    if ((rc = brmi_shade(p, stream))) return rc;
+    p->shadeSharesChip = split;
+    rc = brmi_shade(p, stream);
+    p->shadeSharesChip = false;
+    if (rc) return rc;
     if (split) { BRMI_HIP(p, hipEventRecord(p->frameDone, static_cast<hipStream_t>(stream))); p->frameDoneRecorded = true; }
     return BRMI_OK;
 }

@@ -154,6 +154,7 @@ struct brmi_pass {
     bool sceneHasAlphaTest = false, sceneHasTextures = false, sceneHasParallax = false;   // some material is alpha tested / samples a texture (brmi_set_scene)
     bool sceneHasCoat = true, sceneHasFuzz = true;   // some OpenPBR material has a coat / fuzz layer (brmi_set_scene)
     std::vector<float> sliceStartHost; float sliceKey[3] = {0, 0, 0}; uint32_t sliceKeyN[2] = {0, 0};   // slice starts of the light-cluster grid and the inputs they were made from
+    bool shadeSharesChip = false;    // brmi_execute_split with two streams: the shading half runs beside another frame's geometry half
     bool fuseShadeOptIn = false;     // BRMI_FUSE_SHADE=1 at brmi_create
     bool fuseShadeIntoGBuffer = false, plainPixelsShaded = false;   // brmi_execute: k_gbuffer_shade shades the plain pixels as it writes the G-buffer
     bool lightGridDone = false;      // this frame's light clustering ran inside the culling pass's launches

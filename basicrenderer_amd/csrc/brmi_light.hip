@@ -33,11 +33,17 @@ __global__ void __launch_bounds__(256) k_lc_count(ClusterArgs a) { lc_count_wave
 __global__ void __launch_bounds__(256) k_lc_fill(ClusterArgs a) { lc_fill_block(a, blockIdx.x, threadIdx.x); }
 
 // =================================== K11 (device code: brmi_shade.h) ===========================
+// Waves per SIMD the plain variant is compiled for.  Alone on the chip the kernel wants four (128 VGPRs, 3 of them spilled: 218 -> 203 us); beside
+// another frame's geometry half it wants three (132 VGPRs): with 4 x 128 registers taken a retiring workgroup frees 128 per SIMD, k_raster's
+// 140-register waves find no room, and the frame in flight gets 10 % slower (profiles/r03_experiments.md).  brmi_execute_split picks.
 #ifndef BRMI_SHADE_WAVES
 #define BRMI_SHADE_WAVES 3
 #endif
-template <int MODE>
-__global__ void __launch_bounds__(256, MODE != 0 ? 1 : BRMI_SHADE_WAVES) k_shade(ShadeArgs a) {
+#ifndef BRMI_SHADE_WAVES_ALONE
+#define BRMI_SHADE_WAVES_ALONE 4
+#endif
+template <int MODE, int WAVES = BRMI_SHADE_WAVES>
+__global__ void __launch_bounds__(256, MODE != 0 ? 1 : WAVES) k_shade(ShadeArgs a) {
     const ShadeFrame k = make_shade_frame(a);
     __shared__ float sliceStart[64];
     __shared__ float unormT[256];
@@ -183,7 +189,8 @@ int launch_shade(brmi_pass* p, hipStream_t s) {
     // (Bistro 4K, two frames in flight: 0.436 -> 0.413 ms per frame; 16384: 0.425, 2048: 0.49)
     else {
         static const uint32_t pad = [] { const char* e = std::getenv("BRMI_SHADE_LDS_PAD"); return e ? (uint32_t)std::atoi(e) : 0u; }();   // (experiment: unused dynamic LDS caps the kernel's occupancy)
-        hipLaunchKernelGGL(k_shade<0>, dim3(8192), dim3(256), pad, s, a);
+        if (p->shadeSharesChip || BRMI_SHADE_WAVES_ALONE == BRMI_SHADE_WAVES) hipLaunchKernelGGL((k_shade<0, BRMI_SHADE_WAVES>), dim3(8192), dim3(256), pad, s, a);
+        else hipLaunchKernelGGL((k_shade<0, BRMI_SHADE_WAVES_ALONE>), dim3(8192), dim3(256), pad, s, a);
     }
     // deferred pixels by class: coat, fuzz, both -- only the variants some material of the scene can need
     if (p->sceneHasCoat) hipLaunchKernelGGL(k_shade<1>, dim3(512), dim3(256), 0, s, a);
