@@ -103,6 +103,9 @@ static void compute_sizes(brmi_pass* p) {
     w.instanceBitBase = take((uint64_t)std::max<size_t>(1, p->hostInstanceBitBase.size()) * 4);
     w.segPrefix = take((uint64_t)std::max<size_t>(1, p->hostSegPrefix.size()) * 4);
     w.meshLevelWidth = take((uint64_t)std::max<size_t>(1, p->hostMeshLevelWidth.size()) * 4);
+    w.flatNodes = take((uint64_t)std::max<size_t>(1, p->hostFlatNodes.size()) * sizeof(FlatNode));
+    w.flatLeaves = take((uint64_t)std::max<size_t>(1, p->hostFlatLeaves.size()) * sizeof(FlatLeaf));
+    w.instanceWalk = take((uint64_t)std::max<size_t>(1, p->hostInstanceWalk.size()) * sizeof(InstanceWalk));
     w.planes = take((uint64_t)2 * c.lightClusterSize[2] * 4);
     // phase-1 -> phase-2 hand-over (reference: clodStructs.hlsli:629-652); the replay bucket array doubles as the
     // phase-2 bucket array, so it has the full record capacity
@@ -416,6 +419,55 @@ int brmi_set_scene(brmi_pass* p, const brmi_scene_buffers* scene) {
         p->hostInstanceBitBase[i] = (uint32_t)bits; bits += meshBits[offs[i].clodMeshMetadataIndex];
         if (bits > 0xFFFFFFF0ull) return fail(p, BRMI_ERR_CAPACITY, "scene exceeds 2^32 (instance, meshlet) pairs");
     }
+    {   // flat traversal tables: the BVH of a mesh with at most 256 nodes, breadth-first, with what its leaves' groups and segments say folded in
+        std::vector<brmi_lod_group> groups; std::vector<brmi_per_mesh_instance> insts; std::vector<brmi_per_mesh> pms;
+        int rc2;
+        if ((rc2 = read_back(p, groups, sc.lodGroups, sc.lodGroupCount))) return rc2;
+        if ((rc2 = read_back(p, insts, sc.perMeshInstance, sc.perMeshInstanceCount))) return rc2;
+        if ((rc2 = read_back(p, pms, sc.perMesh, sc.perMeshCount))) return rc2;
+        p->hostFlatNodes.clear(); p->hostFlatLeaves.clear();
+        std::vector<uint32_t> flatBase(md.size(), 0), flatCount(md.size(), 0);
+        const bool flatOn = std::getenv("BRMI_FLAT_TRAVERSAL") ? std::atoi(std::getenv("BRMI_FLAT_TRAVERSAL")) != 0 : true;
+        std::vector<std::pair<uint32_t, uint32_t>> bfs;      // (node id, parent position)
+        for (size_t m = 0; flatOn && m < md.size(); m++) {
+            bfs.clear(); bfs.push_back({md[m].rootNode, 0u});
+            bool fits = true;
+            for (size_t k = 0; k < bfs.size() && fits; k++) {
+                const brmi_lod_node& nd = nodes[md[m].lodNodesBase + bfs[k].first];
+                if (nd.isLeaf != BRMI_NODE_INTERNAL) continue;
+                const uint32_t cc = std::min(nd.countMinusOne + 1u, BRMI_BVH_MAX_CHILDREN);
+                for (uint32_t c = 0; c < cc; c++) { bfs.push_back({nd.indexOrOffset + c, (uint32_t)k}); if (bfs.size() > 256) { fits = false; break; } }
+            }
+            if (!fits) continue;
+            flatBase[m] = (uint32_t)p->hostFlatNodes.size(); flatCount[m] = (uint32_t)bfs.size();
+            for (size_t k = 0; k < bfs.size(); k++) {
+                const brmi_lod_node& nd = nodes[md[m].lodNodesBase + bfs[k].first];
+                FlatNode f{}; FlatLeaf l{};
+                std::memcpy(f.cull, nd.cullCenterAndRadius, 16); std::memcpy(f.lod, nd.lodCenterAndRadius, 16); f.maxQuadricError = nd.maxQuadricError;
+                f.nodeId = bfs[k].first; f.info = bfs[k].second & 0xFFu;
+                if (nd.isLeaf == BRMI_NODE_INTERNAL) f.info |= 1u << 8;
+                else {
+                    const brmi_lod_group& g = groups[md[m].groupsBase + nd.ownerGroupId];
+                    std::memcpy(l.group, g.centerAndRadius, 16);
+                    if (nd.countMinusOne != 0u) { const brmi_lod_group& cg = groups[md[m].groupsBase + (nd.countMinusOne - 1u)]; std::memcpy(l.child, cg.centerAndRadius, 16); l.childParentError = cg.maxParentError; f.info |= 1u << 9; }
+                    const size_t si = (size_t)md[m].segmentsBase + nd.indexOrOffset;
+                    if (si >= segs.size()) return fail(p, BRMI_ERR_INVALID, "mesh %zu: leaf node %u names segment %u, which does not exist", m, bfs[k].first, nd.indexOrOffset);
+                    if (segs[si].meshletCount != 0u) f.info |= 1u << 10;
+                    if (segs[si].meshletCount > 0xFFFFu || segs[si].firstMeshletInPage > 0xFFFFu) { flatCount[m] = 0; break; }      // (the bucket record packs both in 16 bits; leave such a mesh to the level walk)
+                    f.ownerGroup = nd.ownerGroupId; f.segFirstCount = segs[si].firstMeshletInPage | (segs[si].meshletCount << 16);
+                    f.pageMapIndex = md[m].pageMapBase + segs[si].pageIndex; f.firstBitRel = p->hostSegPrefix[si];
+                }
+                p->hostFlatNodes.push_back(f); p->hostFlatLeaves.push_back(l);
+            }
+            if (flatCount[m] == 0) { p->hostFlatNodes.resize(flatBase[m]); p->hostFlatLeaves.resize(flatBase[m]); }
+        }
+        p->hostInstanceWalk.assign(offs.size(), InstanceWalk{0, 0, 0, 0});
+        for (size_t i = 0; i < offs.size() && i < insts.size(); i++) {
+            const uint32_t m = offs[i].clodMeshMetadataIndex;
+            const bool skinned = insts[i].perMeshBufferIndex < pms.size() && (pms[insts[i].perMeshBufferIndex].vertexFlags & BRMI_VERTEX_SKINNED) != 0;
+            p->hostInstanceWalk[i] = InstanceWalk{flatBase[m], flatCount[m], p->hostInstanceBitBase[i], skinned ? 1u : 0u};
+        }
+    }
     p->totalBits = bits;
     p->totalWords = (uint32_t)std::max<uint64_t>(1, (bits + 31) / 32);
     p->scanBlocks = (p->totalWords + 2047u) / 2048u;
@@ -461,6 +513,9 @@ int brmi_setup(brmi_pass* p, const brmi_resource_binding* b, uint32_t n, brmi_st
     if (!p->hostInstanceBitBase.empty()) BRMI_HIP(p, hipMemcpyAsync(p->wsPtr<uint32_t>(p->ws.instanceBitBase), p->hostInstanceBitBase.data(), p->hostInstanceBitBase.size() * 4, hipMemcpyHostToDevice, s));
     if (!p->hostSegPrefix.empty()) BRMI_HIP(p, hipMemcpyAsync(p->wsPtr<uint32_t>(p->ws.segPrefix), p->hostSegPrefix.data(), p->hostSegPrefix.size() * 4, hipMemcpyHostToDevice, s));
     if (!p->hostMeshLevelWidth.empty()) BRMI_HIP(p, hipMemcpyAsync(p->wsPtr<uint32_t>(p->ws.meshLevelWidth), p->hostMeshLevelWidth.data(), p->hostMeshLevelWidth.size() * 4, hipMemcpyHostToDevice, s));
+    if (!p->hostFlatNodes.empty()) BRMI_HIP(p, hipMemcpyAsync(p->wsPtr<FlatNode>(p->ws.flatNodes), p->hostFlatNodes.data(), p->hostFlatNodes.size() * sizeof(FlatNode), hipMemcpyHostToDevice, s));
+    if (!p->hostFlatLeaves.empty()) BRMI_HIP(p, hipMemcpyAsync(p->wsPtr<FlatLeaf>(p->ws.flatLeaves), p->hostFlatLeaves.data(), p->hostFlatLeaves.size() * sizeof(FlatLeaf), hipMemcpyHostToDevice, s));
+    if (!p->hostInstanceWalk.empty()) BRMI_HIP(p, hipMemcpyAsync(p->wsPtr<InstanceWalk>(p->ws.instanceWalk), p->hostInstanceWalk.data(), p->hostInstanceWalk.size() * sizeof(InstanceWalk), hipMemcpyHostToDevice, s));
     { int rc = launch_expand_luts(p, s); if (rc) return rc; }
     BRMI_HIP(p, hipStreamSynchronize(s));   // host vectors may be reused
     if (p->cfg.collectPassStatistics && !p->eventsCreated) {

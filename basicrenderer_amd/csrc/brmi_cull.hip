@@ -42,6 +42,7 @@ struct CullArgs {
     // mixed traversal: meshes whose widest BVH level fits the LDS frontier are walked by k_cull_hierarchy (one wave per instance, one launch),
     // the few wider ones by the level-per-launch kernels (all lanes of the chip on one level); the latter skip instances narrower than this
     const uint32_t* meshLevelWidth; uint32_t levelKernelsWidthLo;
+    const FlatNode* flatNodes; const FlatLeaf* flatLeaves; const InstanceWalk* instanceWalk;     // flat traversal of small hierarchies (brmi_internal.h)
 };
 
 BRMI_DEV f3 to_view_space(f3 c, const m4& model, const m4& view) { return xyz(mul_vm(mul_point(c, model), view)); }
@@ -405,6 +406,130 @@ __global__ void __launch_bounds__(64) k_cull_hierarchy(CullArgs a, BucketRecord*
         if (REPLAY) { const NodeRecord rec = a.replayNodes[seed]; instIndex = rec.instanceIndex; startNode = rec.nodeIdPacked & 0x3FFFFFFFu; }
         else instIndex = sc.activeDraws[seed];
         const brmi_per_mesh_instance inst = sc.perMeshInstance[instIndex];
+        if (!REPLAY) {
+            // ---- a hierarchy of at most 64 nodes: all of it at once, one lane per node.  The level walk below is a chain of ~10 dependent
+            // memory round trips per instance (instance -> mesh metadata -> root -> occlusion -> children -> group / segment -> page map ->
+            // bucket slots) and the launch lasts as long as one such chain; here the nodes, the leaves' groups and segments (FlatNode /
+            // FlatLeaf, folded by brmi_set_scene) and the object arrive together, the depth chain and the page map together after them.
+            // Same tests, same arithmetic, same records; a node is reached iff every ancestor let its children through.
+            const InstanceWalk iw = a.instanceWalk[instIndex];
+            if (iw.flatCount != 0u) {
+                constexpr uint32_t FLAT_CHUNKS = 4;      // 64 nodes each (brmi_set_scene: hierarchies of up to 256 nodes)
+                const uint32_t chunks = (iw.flatCount + 63u) >> 6;
+                const brmi_per_object* obj = sc.perObject + inst.perObjectBufferIndex;
+                // (what the later phases need of a node; the spheres are used at once)
+                uint32_t nodeIdA[FLAT_CHUNKS] = {}, parentA[FLAT_CHUNKS] = {}, ownerGroupA[FLAT_CHUNKS] = {}, segFirstCountA[FLAT_CHUNKS] = {}, firstBitRelA[FLAT_CHUNKS] = {};
+                const m4 model = load_m4(&obj->model[0][0]);
+                const float scale = max_axis_scale(model);
+                const f3 instC{inst.boundingSphere[0], inst.boundingSphere[1], inst.boundingSphere[2]}; const float instR = inst.boundingSphere[3];
+                {   // K1 (PureComputeObjectCullCS)
+                    const f3 c = to_view_space(instC, model, view);
+                    const float r = instR * scale;
+                    const bool bad = isnan(c.x) || isnan(c.y) || isnan(c.z) || isinf(c.x) || isinf(c.y) || isinf(c.z) || isnan(r) || isinf(r);
+                    nTested++;
+                    if (bad || sphere_outside_frustum(c, r, cam->clippingPlanes)) continue;
+                    nVisible++;
+                }
+                const bool skinned = iw.skinned != 0u;
+                uint64_t preM[FLAT_CHUNKS] = {}, expandM[FLAT_CHUNKS] = {}, hiddenM[FLAT_CHUNKS] = {}, leafM[FLAT_CHUNKS] = {}, reached[FLAT_CHUNKS] = {};
+                uint32_t slabDescA[FLAT_CHUNKS] = {}, slabOffA[FLAT_CHUNKS] = {};
+#pragma unroll
+                for (uint32_t c = 0; c < FLAT_CHUNKS; c++) if (c < chunks) {
+                    const bool mine = c * 64u + lane < iw.flatCount;
+                    FlatNode fn{}; FlatLeaf fl{};
+                    if (mine) { fn = a.flatNodes[iw.flatBase + c * 64u + lane]; fl = a.flatLeaves[iw.flatBase + c * 64u + lane]; }
+                    nodeIdA[c] = fn.nodeId; parentA[c] = fn.info & 0xFFu; ownerGroupA[c] = fn.ownerGroup; segFirstCountA[c] = fn.segFirstCount; firstBitRelA[c] = fn.firstBitRel;
+                    const bool internal = (fn.info >> 8) & 1u;
+                    const f3 cullC = skinned ? instC : f3{fn.cull[0], fn.cull[1], fn.cull[2]};
+                    const float cullR = skinned ? instR : fn.cull[3];
+                    const f3 cVS = to_view_space(cullC, model, view);
+                    const float rW = cullR * scale;
+                    const bool inFrustum = mine && !sphere_outside_frustum(cVS, rW, cam->clippingPlanes);
+                    // internal node: children pass when its projected error is above the threshold and the depth chain does not hide it;
+                    // as a child it was let through on the same two conditions (frustum, error)
+                    bool pre = inFrustum, expand = false, hidden = false, leafOk = false;
+                    if (inFrustum && internal) {
+                        const f3 lc = xyz(mul_point(f3{fn.lod[0], fn.lod[1], fn.lod[2]}, model));
+                        const float e = projected_error(lc, fn.lod[3] * scale, fn.maxQuadricError, scale, camPos, zNear, ortho);
+                        pre = e >= threshold;
+                        if (pre) { hidden = a.occlusion && occlusion_test(a, cam, false, cullC, cullR, cVS, rW, obj); expand = !hidden; }
+                    } else if (inFrustum) {
+                        const f3 gc = xyz(mul_point(f3{fl.group[0], fl.group[1], fl.group[2]}, model));
+                        const float eod = projected_error(gc, fl.group[3] * scale, fn.maxQuadricError, scale, camPos, zNear, ortho);
+                        bool ok = eod >= threshold;
+                        if (ok && ((fn.info >> 9) & 1u)) {      // refined_child_suppresses
+                            const f3 cc = xyz(mul_point(f3{fl.child[0], fl.child[1], fl.child[2]}, model));
+                            const float ce = projected_error(cc, fl.child[3] * scale, fl.childParentError, scale, camPos, zNear, ortho);
+                            if (!(ce < threshold)) ok = false;
+                        }
+                        if (ok && ((fn.info >> 10) & 1u)) {
+                            const brmi_group_page_map_entry pe = sc.groupPageMap[fn.pageMapIndex];
+                            slabDescA[c] = pe.slabDescriptorIndex; slabOffA[c] = pe.slabByteOffset;
+                            leafOk = slabDescA[c] != 0u;
+                        }
+                    }
+                    preM[c] = __ballot(pre); expandM[c] = __ballot(expand); hiddenM[c] = __ballot(hidden); leafM[c] = __ballot(leafOk);
+                }
+                // reached: the root, or a node that passed as a child of a reached node that lets its children through
+                reached[0] = 1ull;
+                for (bool changed = true; changed; ) {
+                    changed = false;
+#pragma unroll
+                    for (uint32_t c = 0; c < FLAT_CHUNKS; c++) if (c < chunks) {
+                        const uint32_t parent = parentA[c], pc = parent >> 6, pb = parent & 63u;
+                        uint64_t through = 0;      // reached parents that let their children through, the parent's chunk
+#pragma unroll
+                        for (uint32_t q = 0; q < FLAT_CHUNKS; q++) if (q == pc) through = reached[q] & expandM[q];
+                        const bool r = (c == 0u && lane == 0u) || (c * 64u + lane < iw.flatCount && ((preM[c] >> lane) & 1ull) && ((through >> pb) & 1ull) && !(c == 0u && lane == 0u));
+                        const uint64_t next = __ballot(r);
+                        if (next != reached[c]) { reached[c] = next; changed = true; }
+                    }
+                }
+#pragma unroll
+                for (uint32_t c = 0; c < FLAT_CHUNKS; c++) if (c < chunks) {
+                    const bool here = (reached[c] >> lane) & 1ull;
+                    nNodes += here ? 1u : 0u;
+                    if (a.occlusion) {
+                        const bool replayIt = here && ((hiddenM[c] >> lane) & 1ull);
+                        const uint32_t slot = wave_append(&a.counters[CNT_REPLAY_NODES], replayIt);
+                        if (replayIt) {
+                            if (slot < a.recordCapacity) a.replayNodes[slot] = NodeRecord{instIndex, 0x80000000u | (1u << 30) | (nodeIdA[c] & 0x3FFFFFFFu)};
+                            else atomicAdd(&a.counters[CNT_DROPPED_RECORDS], 1u);
+                        }
+                    }
+                    // bucket records of `factor` meshlets per reached leaf that passed (computeCulling.hlsl:385-406)
+                    const bool emitLeaf = here && ((leafM[c] >> lane) & 1ull);
+                    const uint32_t segFirst = segFirstCountA[c] & 0xFFFFu, segCount = segFirstCountA[c] >> 16;
+                    const uint32_t nChunks = emitLeaf ? (segCount + a.factor - 1u) / a.factor : 0u;
+                    uint32_t incl = nChunks;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o); if (lane >= (uint32_t)o) incl += v; }
+                    const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+                    if (total != 0u) {
+                        if (staged + total > HIER_STAGE) flush();
+                        const bool viaStage = total <= HIER_STAGE;
+                        uint32_t baseSlot = staged + (incl - nChunks);
+                        if (!viaStage) {
+                            uint32_t g0 = 0;
+                            if (lane == 0) g0 = atomicAdd(&a.counters[a.bucketCounter], total);
+                            baseSlot = (uint32_t)__shfl((int)g0, 0) + (incl - nChunks);
+                        }
+                        for (uint32_t k = 0; k < nChunks; k++) {
+                            BucketRecord b;
+                            b.instanceIndex = instIndex; b.groupIdPacked = ownerGroupA[c] & 0x7FFFFFFFu;
+                            b.meshletIndexAndCount = (min(a.factor, segCount - k * a.factor) << 16) | ((segFirst + k * a.factor) & 0xFFFFu);
+                            b.pageSlabDescriptorIndex = slabDescA[c]; b.pageSlabByteOffset = slabOffA[c];
+                            b.firstBit = iw.bitBase + firstBitRelA[c] + k * a.factor; b.pad0 = 0; b.pad1 = 0;
+                            if (viaStage) stage[baseSlot + k] = b;
+                            else if (baseSlot + k < a.recordCapacity) buckets[baseSlot + k] = b;
+                            else atomicAdd(&a.counters[CNT_DROPPED_RECORDS], 1u);
+                        }
+                        if (viaStage) staged += total;
+                    }
+                }
+                continue;
+            }
+        }
         const uint32_t mdIndex = sc.clodOffsets[instIndex].clodMeshMetadataIndex;
         // this launch handles the meshes whose widest BVH level fits its LDS frontier class, and the top of wider ones
         const uint32_t width = meshLevelWidth[mdIndex];
@@ -921,6 +1046,7 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
     CullArgs a;
     a.sc = p->scene; a.counters = p->counters();
     a.instanceBitBase = p->wsPtr<uint32_t>(p->ws.instanceBitBase); a.segPrefix = p->wsPtr<uint32_t>(p->ws.segPrefix);
+    a.flatNodes = p->wsPtr<FlatNode>(p->ws.flatNodes); a.flatLeaves = p->wsPtr<FlatLeaf>(p->ws.flatLeaves); a.instanceWalk = p->wsPtr<InstanceWalk>(p->ws.instanceWalk);
     a.recordCapacity = p->cfg.maxTraversalRecords; a.visibleCapacity = p->cfg.maxVisibleClusters;
     uint32_t f = p->cfg.phase2ExpansionFactor; f = f < 1 ? 1 : (f > 64 ? 64 : f);
     { uint32_t n = 1; for (uint32_t c = 2; c <= 64; c <<= 1) if (c <= f) n = c; f = n; }

@@ -62,6 +62,22 @@ __device__ inline void seed_phase2(uint32_t* counters, uint32_t capacity, uint32
 }
 
 // internal records (ours; the reference's 12 B / 24 B records plus the rank bookkeeping)
+// A mesh whose whole BVH has at most 256 nodes (brmi_set_scene walks it) is evaluated flat by the traversal kernel: one lane per node, the
+// records below instead of the node -> group / segment chain (static topology: node, group and segment contents as brmi_set_scene read them;
+// what the host may rewrite between frames -- instances, objects, the page map -- is still read from its buffers).
+struct FlatNode {                                                                     // 64 B, breadth-first (a parent's position is below its children's)
+    float cull[4], lod[4]; float maxQuadricError;
+    uint32_t nodeId;            // relative to the mesh's lodNodesBase (replay records name nodes by it)
+    uint32_t info;              // parent position [0, 8) | internal << 8 | has a refined group << 9 | segment holds meshlets << 10
+    uint32_t ownerGroup;        // leaf: mesh-local group
+    uint32_t segFirstCount;     // leaf: firstMeshletInPage | meshletCount << 16
+    uint32_t pageMapIndex;      // leaf: absolute index of the segment's page-map entry
+    uint32_t firstBitRel;       // leaf: the segment's first bit relative to the instance's
+    uint32_t pad;
+};
+struct FlatLeaf { float group[4], child[4]; float childParentError, pad[3]; };      // 48 B: the leaf's group sphere, its refined group's sphere and error
+struct InstanceWalk { uint32_t flatBase, flatCount /* 0: the level walk */, bitBase, skinned; };                                    // 16 B per mesh instance
+static_assert(sizeof(FlatNode) == 64 && sizeof(FlatLeaf) == 48 && sizeof(InstanceWalk) == 16, "flat traversal records");
 struct NodeRecord { uint32_t instanceIndex, nodeIdPacked; };                       // 8 B (single view)
 struct BucketRecord {                                                                 // 32 B
     uint32_t instanceIndex, groupIdPacked, meshletIndexAndCount, pageSlabDescriptorIndex;
@@ -123,7 +139,7 @@ struct LayerUniform { unsigned long long coatWord, fuzzWord, coatFilledWord, fuz
 
 struct Workspace {     // byte offsets into BRMI_RES_WORKSPACE
     uint64_t counters, frontierA, frontierB, buckets, tempVisible, bitmask1, bitmask2, wordPrefix, blockSums,
-             instanceBitBase, segPrefix, meshLevelWidth, planes, replayNodes, replayBuckets, lightVS, lightMeta, clusterPages, clusterHits, pageTotal, lightHitMasks, binCounts, binRecords, binOverflow, binPlan, binItems, binScratch, clusterSetup, resolveVerts, resolveTris, matWords, shadeTables, lutF, frameConst, objConst, matConst, deferredPixels, usedClusters,
+             instanceBitBase, segPrefix, meshLevelWidth, flatNodes, flatLeaves, instanceWalk, planes, replayNodes, replayBuckets, lightVS, lightMeta, clusterPages, clusterHits, pageTotal, lightHitMasks, binCounts, binRecords, binOverflow, binPlan, binItems, binScratch, clusterSetup, resolveVerts, resolveTris, matWords, shadeTables, lutF, frameConst, objConst, matConst, deferredPixels, usedClusters,
              frameSnapshot, tileCounts, tileLists, tileOverflow, xverts, debugStamps, clusterUv, binAlpha, overflowAlpha, resolveUVs, resolveColors, alphaMats, shadeRows, shadeAvgs, ggxQuads, shadeLights, clusterList, listEntries, listRecords, layerUniform, frameClearBytes, total;
 };
 
@@ -192,6 +208,7 @@ struct brmi_pass {
     const brmi_pass* chainOwner(uint32_t phase) const { return (phase == 1 && history) ? history : this; }
     brmi::HzbDesc hzbDesc() const;
     std::vector<uint32_t> hostInstanceBitBase, hostSegPrefix;
+    std::vector<brmi::FlatNode> hostFlatNodes; std::vector<brmi::FlatLeaf> hostFlatLeaves; std::vector<brmi::InstanceWalk> hostInstanceWalk;   // flat traversal tables (brmi_set_scene)
     brmi::Workspace ws{};
     brmi_camera camHost{};
     brmi_per_frame pfHost{};
