@@ -916,7 +916,10 @@ __global__ void __launch_bounds__(256) k_scan_words(const uint32_t* bitmask, uin
 // workgroup that has survivors to place scans the popcounts itself into LDS (a few thousand L2-resident words), workgroup 0 publishes the
 // total.  One ~5 us launch less per culling phase.  Larger bitmasks take the three scan launches (a variant with one LDS prefix per group
 // of words up to 2^17 words was measured on the dense frame's 25 k words: 55 us per phase against 27).
-constexpr uint32_t LOCAL_RANK_WORDS = 8192;
+#ifndef BRMI_LOCAL_RANK_WORDS
+#define BRMI_LOCAL_RANK_WORDS 8192
+#endif
+constexpr uint32_t LOCAL_RANK_WORDS = BRMI_LOCAL_RANK_WORDS;
 struct LocalRank { uint32_t totalWords, outIndex, usedIndex; };
 template <bool LOCAL_RANK>
 __global__ void __launch_bounds__(256) k_scatter_visible(const TempVisible* temp, uint32_t* counters, uint32_t tempCountIndex, const uint32_t* bitmask,
