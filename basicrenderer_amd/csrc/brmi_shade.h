@@ -155,6 +155,9 @@ struct ShadeLightRecord { float r0[4], r1[4], r2[4], r3[4]; };   // the same rec
 #ifndef BRMI_SHADE_SCALAR_LIGHTS
 #define BRMI_SHADE_SCALAR_LIGHTS 1
 #endif
+#ifndef BRMI_SHADE_METAL_STASH
+#define BRMI_SHADE_METAL_STASH 1      // the stand-alone variant of k_shade<0> parks the metal lobe's inputs in LDS
+#endif
 
 struct ShadeArgs {
     ShadeTables tables;
@@ -297,8 +300,8 @@ BRMI_DEV PixelCtx make_pixel_ctx(const Luts& L, const Frag& f, const ShadeRows* 
 
 // `h` = normalize(L + V), NoH, LoH come from the caller (correctly rounded, contraction off: 1 - NoH^2 amplifies their error at low
 // roughness); everything in here holds the HDR tolerance and may fuse.
-template <int MODE>
-BRMI_DEV f3 light_contribution(const Luts& L, const Frag& f, const PixelCtx& c, f3 lightToFrag, float NoL, float NoH, float LoH, float VdotL, float D, f3 lightColorIntensity, float attenuation, float spotAtt) {
+template <int MODE, bool STASH>
+BRMI_DEV f3 light_contribution(const Luts& L, const Frag& f, const PixelCtx& c, const float* stash, f3 lightToFrag, float NoL, float NoH, float LoH, float VdotL, float D, f3 lightColorIntensity, float attenuation, float spotAtt) {
     BRMI_FP_FAST
     const BaseState& base = c.base;
     const float NoV = c.NoV;
@@ -326,11 +329,18 @@ BRMI_DEV f3 light_contribution(const Luts& L, const Frag& f, const PixelCtx& c, 
     // is skipped for it.  A non-finite D*V keeps the full expression (0 * inf is NaN, not 0).
     f3 metalSpec{0.0f, 0.0f, 0.0f};
     if (!(base.metalSpecularWeight == 0.0f && fabsf(DV) <= 3.4028234e38f)) {
-        const f3 Fm = base.metalSpecularF0 + (f3{c.f90Metal, c.f90Metal, c.f90Metal} - base.metalSpecularF0) * pw;
-        const float mLight = sample_folded_row(c.imRow, NoL);
-        const float mTab = qdiv(c.mView * mLight, c.mAvgClamped);
+        // STASH: the lobe's per-pixel inputs wait in the lane's LDS slots (shade_pixel parked them) -- ten registers that only metallic pixels
+        // read.  For the variant that has the chip to itself: beside another frame's k_raster_bins (35 KB of LDS per workgroup) the 9 KB per
+        // workgroup cost more residency than the registers buy (frame in flight 0.571 -> 0.623 ms).
+        const f3 mF0 = STASH ? f3{stash[0 * 256], stash[1 * 256], stash[2 * 256]} : base.metalSpecularF0;
+        const f3 mMs = STASH ? f3{stash[3 * 256], stash[4 * 256], stash[5 * 256]} : base.metalMultipleScatterScale;
+        const float f90Metal = STASH ? stash[6 * 256] : c.f90Metal, mView = STASH ? stash[7 * 256] : c.mView, mAvgClamped = STASH ? stash[8 * 256] : c.mAvgClamped;
+        const float* imRow = STASH ? c.odRow + 32 : c.imRow;                    // ShadeRows: od[32], im[32]
+        const f3 Fm = mF0 + (f3{f90Metal, f90Metal, f90Metal} - mF0) * pw;
+        const float mLight = sample_folded_row(imRow, NoL);
+        const float mTab = qdiv(mView * mLight, mAvgClamped);
         const float mScale = min2(mTab, qrcp(max2(NoL, 1.0e-4f))) * (1.0f / PI_F);
-        metalSpec = base.metalSpecularWeight * (DV * Fm + base.metalMultipleScatterScale * mScale);
+        metalSpec = base.metalSpecularWeight * (DV * Fm + mMs * mScale);
     }
     const f3 specular = dielSpec + metalSpec;
     f3 brdf;
@@ -381,10 +391,12 @@ BRMI_DEV ShadeLightLanes stage_lights(const ShadeArgs& a, uint32_t listBase, uin
     }
     return s;
 }
-template <int MODE>
+template <int MODE, bool STASH = false>
 BRMI_DEV uint32_t shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const float* sliceStart, const float* unorm8, const float4* camK, const RawPixel& raw, bool live, uint64_t tileBase, uint32_t within) {
     const Luts& L = k.L;
     const uint32_t gx = k.gx, gy = k.gy, gz = k.gz, nearSlices = k.nearSlices;
+    __shared__ float metalStash[STASH ? 9 : 1][STASH ? 256 : 1];                     // (blockDim.x == 256 in every kernel built from this)
+    const float* stash = &metalStash[0][STASH ? threadIdx.x : 0u];
     live = live && as_u32(raw.d) != BRMI_DEPTH_EMPTY_BITS;
     Frag f; PixelCtx ctx; f3 posWS, posVS;        // only read by lanes that stay `live` (no initialiser: nothing to materialise for the others)
     uint32_t opaqueZero = 0u;
@@ -493,6 +505,11 @@ BRMI_DEV uint32_t shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const flo
         f.diffuseColor = weightedBaseColor * (1.0f - metal);
         const uint32_t entry = opIndex * 256u + ((mr >> 8) & 0xFFu);
         ctx = make_pixel_ctx<MODE>(L, f, a.shadeRows + entry, a.shadeAvgs[entry], mc, a.ggxQuads, (mr >> 8) & 0xFFu, (mr >> 16) & 0xFFu);
+        if (STASH && f.metalSpecularWeight != 0.0f) {
+            metalStash[0][threadIdx.x] = ctx.base.metalSpecularF0.x; metalStash[1][threadIdx.x] = ctx.base.metalSpecularF0.y; metalStash[2][threadIdx.x] = ctx.base.metalSpecularF0.z;
+            metalStash[3][threadIdx.x] = ctx.base.metalMultipleScatterScale.x; metalStash[4][threadIdx.x] = ctx.base.metalMultipleScatterScale.y; metalStash[5][threadIdx.x] = ctx.base.metalMultipleScatterScale.z;
+            metalStash[6][threadIdx.x] = ctx.f90Metal; metalStash[7][threadIdx.x] = ctx.mView; metalStash[8][threadIdx.x] = ctx.mAvgClamped;
+        }
     }
     f3 lighting{0.0f, 0.0f, 0.0f};
     // Waterfall over the distinct clusters of the wave (an 8x8 tile usually sits in one).  The loop and the staging run with every lane
@@ -546,7 +563,7 @@ BRMI_DEV uint32_t shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const flo
             const float VdotL = dot3(f.viewWS, lightToFrag);
             const float D = d_ggx(ctx.base.specularAlpha, NoH);
             const f3 col{lr.r2[0], lr.r2[1], lr.r2[2]};
-            lighting = lighting + light_contribution<MODE>(L, f, ctx, lightToFrag, NoL, NoH, LoH, VdotL, D, col, att, spot);
+            lighting = lighting + light_contribution<MODE, STASH>(L, f, ctx, stash, lightToFrag, NoL, NoH, LoH, VdotL, D, col, att, spot);
         }
 #else
         for (uint32_t c0 = 0; c0 < listCount; c0 += 64u) {
@@ -587,7 +604,7 @@ BRMI_DEV uint32_t shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const flo
                 const float VdotL = dot3(f.viewWS, lightToFrag);
                 const float D = d_ggx(ctx.base.specularAlpha, NoH);
                 const f3 col{bcast(s.r2.x, q), bcast(s.r2.y, q), bcast(s.r2.z, q)};
-                lighting = lighting + light_contribution<MODE>(L, f, ctx, lightToFrag, NoL, NoH, LoH, VdotL, D, col, att, spot);
+                lighting = lighting + light_contribution<MODE, STASH>(L, f, ctx, stash, lightToFrag, NoL, NoH, LoH, VdotL, D, col, att, spot);
             }
         }
 #endif
