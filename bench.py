@@ -339,7 +339,7 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False)
         shaded = W * (band[1] - band[0]) * n            # pixels dispatched per step, all ranks
         ms_per_step = dt / args.steps * 1e3
         value = shaded / 1e6 / (dt / args.steps)
-        dom = max(stage_ms, key=lambda k: stage_ms[k])
+        dom = dom_stage if stage_ms.get(dom_stage, 0.0) > 0 else max(stage_ms, key=lambda k: stage_ms[k])      # the stage the events stayed around (two stages within noise of each other must not swap here)
         dom_s = stage_ms[dom] * 1e-3
         achieved = per_stage_bytes[dom] / dom_s / 1e9 if dom_s > 0 else 0.0
         frame_gbs = total_bytes / (dt / args.steps) / 1e9
