@@ -181,6 +181,7 @@ struct brmi_pass {
     uint64_t totalBits = 0; uint32_t totalWords = 0, scanBlocks = 0;
     uint32_t numLightClusters = 0, lightPagePool = 0;
     uint32_t binOverflowPerStripe = 1u << 14;       // 64 stripes x 16384 records x 64 B = 64 MB
+    uint32_t binMinSlice = 1024, binSharedSlice = 512, binGrid = 1024;   // k_raster_bins: records one workgroup walks alone / per slice of a larger bin, workgroups of the pool (BRMI_BIN_MIN_SLICE, BRMI_BIN_SHARED_SLICE, BRMI_BIN_GRID)
     uint32_t binScratchTiles = 2048, binItemCapacity = 0;   // k_raster_bins: scratch tiles for bins several workgroups share (BRMI_BIN_SCRATCH_TILES), work items
     uint32_t binsX = 0, binsY = 0, binCapacity = 8192;   // raster bins: 256 px x 16 rows, binCapacity records of 64 B each (BRMI_BIN_CAPACITY): 1 GB at 4K, walked in slices of 1024
     bool rasterTiles = false;     // BRMI_RASTER_MODE=tiles (opaque scenes): cluster-granular sort-middle (k_raster_tile_lists / k_raster_tiles) instead of the triangle bins -- bit-exact, a fifth of the HBM traffic, 20-40 % slower (profiles/r03_experiments.md)

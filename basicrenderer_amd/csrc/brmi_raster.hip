@@ -1359,10 +1359,8 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
     a.objConst = p->wsPtr<float>(p->ws.objConst);
     a.bigTriArea = p->bigTriArea; a.bigTriAreaAlpha = p->bigTriAreaAlpha; a.debugFlags = p->rasterDebug;
     a.bigTriAreaDense = p->bigTriAreaDense; a.denseClusterCount = p->denseClusterCount;
-    static const uint32_t minSlice = [] { const char* e = std::getenv("BRMI_BIN_MIN_SLICE"); return e ? (uint32_t)std::max(32, std::atoi(e)) : 1024u; }();
-    a.binMinSlice = minSlice;
-    static const uint32_t sharedSlice = [] { const char* e = std::getenv("BRMI_BIN_SHARED_SLICE"); return e ? (uint32_t)std::max(32, std::atoi(e)) : 512u; }();
-    a.binSharedSlice = std::min(sharedSlice, minSlice) & ~31u;        // a multiple of the 32 records a step walks: no slice of the plan is empty
+    a.binMinSlice = p->binMinSlice;
+    a.binSharedSlice = std::max(32u, std::min(p->binSharedSlice, p->binMinSlice) & ~31u);        // a multiple of the 32 records a step walks: no slice of the plan is empty
     a.binPlan = p->wsPtr<uint32_t>(p->ws.binPlan); a.binItems = p->wsPtr<uint32_t>(p->ws.binItems); a.binScratch = p->wsPtr<unsigned long long>(p->ws.binScratch);
     a.binScratchTiles = p->binScratchTiles; a.binItemCapacity = p->binItemCapacity;
     a.binAlpha = p->wsPtr<AlphaRecord>(p->ws.binAlpha); a.overflowAlpha = p->wsPtr<AlphaRecord>(p->ws.overflowAlpha);
@@ -1385,8 +1383,7 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
         return BRMI_OK;
     }
     // the pool of k_raster_bins: four 512-thread workgroups per CU is what the LDS holds; phase 2 rarely has an item at all
-    static const uint32_t binGrid = [] { const char* e = std::getenv("BRMI_BIN_GRID"); return e ? (uint32_t)std::max(1, std::atoi(e)) : 1024u; }();
-    const dim3 bgrid(phase == 2 ? std::min(binGrid, 256u) : binGrid);
+    const dim3 bgrid(phase == 2 ? std::min(p->binGrid, 256u) : p->binGrid);
     // phase 2 rarely has more than a handful of clusters: 2048 workgroups (the kernel strides; two waves per SIMD) start and retire a little
     // faster than 8192 that find nothing (-3 us per frame)
     static const uint32_t grid2 = [] { const char* e = std::getenv("BRMI_RASTER_GRID2"); return e ? (uint32_t)std::max(64, std::atoi(e)) : 2048u; }();

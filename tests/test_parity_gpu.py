@@ -1296,6 +1296,58 @@ def test_clusters_beyond_the_screen_vertex_cache_take_the_overflow_path(name, sc
     r.close()
 
 
+@pytest.mark.parametrize("min_slice,shared_slice,pool,scratch", [(32, 32, 1024, 2048),     # every bin above 32 records is cut into slices of 32: plans of thousands of items, folded tiles
+                                                                 (32, 32, 8, 2048),        # a pool of eight workgroups takes them all by ticket
+                                                                 (64, 32, 3, 5),           # five scratch tiles: the first shared bins fold, the others merge with atomics
+                                                                 (32, 32, 1024, 0),        # no scratch tiles at all
+                                                                 (96, 64, 300, 2048)])     # slices just long enough for the sorted walk
+@pytest.mark.parametrize("name", ["sponza_small", "bistro_small", "tiny_skinned", "sponza_alpha", "bistro_alpha_skinned"])
+def test_bin_plans_slices_and_folds_draw_the_same_keys(name, min_slice, shared_slice, pool, scratch, scenes, oracle_frames):
+    """k_raster_bins takes (bin, slice) items from the plan k_raster_overflow's last workgroup writes; a bin with more records than one
+    workgroup walks alone is cut into slices whose tiles the last slice folds (scratch tiles) or that merge key by key (no tile left).
+    Whatever the slice length, the pool size and the number of scratch tiles: the oracle's keys, over two frames (the plan's counters,
+    tickets and done-counts are reset by the launches themselves)."""
+    from basicrenderer_amd.renderer import VisibilityRenderer
+    with _Env(BRMI_BIN_MIN_SLICE=min_slice, BRMI_BIN_SHARED_SLICE=shared_slice, BRMI_BIN_GRID=pool, BRMI_BIN_SCRATCH_TILES=scratch):
+        r = VisibilityRenderer(scenes(name), stats=True)
+    o = oracle_frames(name)
+    for _ in range(2):
+        r.execute()
+        c = r.counters()
+        assert c.droppedRecords == 0 and c.droppedClusters == 0
+        assert np.array_equal(r.visibility(), o.vis)
+    r.close()
+
+
+@pytest.mark.parametrize("name", ["bistro_small", "sponza_ownlod", "bistro_ownlod_skinned", "tiny_lod", "bistro_skinned"])
+def test_flat_and_level_traversal_agree(name, scenes, oracle_frames):
+    """Hierarchies of up to 256 nodes are evaluated flat (one lane per node, records folded at brmi_set_scene); BRMI_FLAT_TRAVERSAL=0 walks
+    every hierarchy level by level.  Both give the oracle's cluster list and the same counters (instances, nodes, meshlets tested), with
+    occlusion culling over two frames too (the replay lists phase 2 works from are the walk's)."""
+    import orc
+    from basicrenderer_amd.renderer import VisibilityRenderer
+    o = oracle_frames(name)
+    seen = []
+    for flat in (1, 0):
+        with _Env(BRMI_FLAT_TRAVERSAL=flat):
+            r = VisibilityRenderer(scenes(name), stats=True)
+        r.execute()
+        c = r.counters()
+        assert np.array_equal(r.visible_clusters(), o.clusters[: o.count])
+        seen.append((c.instancesTested, c.instancesVisible, c.nodesVisited, c.meshletsTested, c.visibleClusters))
+        r.close()
+        with _Env(BRMI_FLAT_TRAVERSAL=flat):
+            r = VisibilityRenderer(scenes(name), stats=True, occlusion=True)
+        r.execute(); r.execute()
+        c = r.counters()
+        seen.append((c.nodesVisited, c.meshletsTested, c.visibleClusters, c.visibleClustersPhase2, c.replayNodes, c.replayMeshlets))
+        # (two phases list the clusters in another order than the oracle's single pass: compare what the keys name)
+        for got, want in zip(orc.canonical_ids(r.visibility(), r.visible_clusters()), orc.canonical_ids(o.vis, o.clusters[: o.count])):
+            assert np.array_equal(got, want)
+        r.close()
+    assert seen[0] == seen[2] and seen[1] == seen[3], seen
+
+
 @pytest.mark.parametrize("name", ["sponza_small", "bistro_small", "tiny_lod", "tiny_skinned"])
 def test_triangle_bins_and_cluster_tiles_draw_the_same_keys(name, scenes, oracle_frames):
     """BRMI_RASTER_MODE=tiles selects the cluster-granular tile rasteriser (opaque scenes; an experiment of round 3 that moves a fifth of the bytes
