@@ -43,6 +43,7 @@ struct CullArgs {
     // the few wider ones by the level-per-launch kernels (all lanes of the chip on one level); the latter skip instances narrower than this
     const uint32_t* meshLevelWidth; uint32_t levelKernelsWidthLo;
     const FlatNode* flatNodes; const FlatLeaf* flatLeaves; const InstanceWalk* instanceWalk;     // flat traversal of small hierarchies (brmi_internal.h)
+    unsigned long long* debugStamps;     // instrumented builds (-DBRMI_TILE_STAMPS)
 };
 
 BRMI_DEV f3 to_view_space(f3 c, const m4& model, const m4& view) { return xyz(mul_vm(mul_point(c, model), view)); }
@@ -413,6 +414,14 @@ __global__ void __launch_bounds__(64) k_cull_hierarchy(CullArgs a, BucketRecord*
             // FlatLeaf, folded by brmi_set_scene) and the object arrive together, the depth chain and the page map together after them.
             // Same tests, same arithmetic, same records; a node is reached iff every ancestor let its children through.
             const InstanceWalk iw = a.instanceWalk[instIndex];
+#ifdef BRMI_TILE_STAMPS
+            unsigned long long hph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hprev = __builtin_amdgcn_s_memtime();
+#define HSTAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); hph[k] += now_ - hprev; hprev = now_; } while (0)
+            { uint32_t probe_ = iw.flatCount + inst.perObjectBufferIndex; asm volatile("" :: "v"(probe_)); }
+            HSTAMP(0);
+#else
+#define HSTAMP(k) do { } while (0)
+#endif
             if (iw.flatCount != 0u) {
                 constexpr uint32_t FLAT_CHUNKS = 4;      // 64 nodes each (brmi_set_scene: hierarchies of up to 256 nodes)
                 const uint32_t chunks = (iw.flatCount + 63u) >> 6;
@@ -430,6 +439,7 @@ __global__ void __launch_bounds__(64) k_cull_hierarchy(CullArgs a, BucketRecord*
                     if (bad || sphere_outside_frustum(c, r, cam->clippingPlanes)) continue;
                     nVisible++;
                 }
+                HSTAMP(1);
                 const bool skinned = iw.skinned != 0u;
                 uint64_t preM[FLAT_CHUNKS] = {}, expandM[FLAT_CHUNKS] = {}, hiddenM[FLAT_CHUNKS] = {}, leafM[FLAT_CHUNKS] = {}, reached[FLAT_CHUNKS] = {};
                 uint32_t slabDescA[FLAT_CHUNKS] = {}, slabOffA[FLAT_CHUNKS] = {};
@@ -470,6 +480,7 @@ __global__ void __launch_bounds__(64) k_cull_hierarchy(CullArgs a, BucketRecord*
                     }
                     preM[c] = __ballot(pre); expandM[c] = __ballot(expand); hiddenM[c] = __ballot(hidden); leafM[c] = __ballot(leafOk);
                 }
+                HSTAMP(2);
                 // reached: the root, or a node that passed as a child of a reached node that lets its children through
                 reached[0] = 1ull;
                 for (bool changed = true; changed; ) {
@@ -485,48 +496,59 @@ __global__ void __launch_bounds__(64) k_cull_hierarchy(CullArgs a, BucketRecord*
                         if (next != reached[c]) { reached[c] = next; changed = true; }
                     }
                 }
+                // Two reservations per instance -- replay nodes, bucket records -- and every wave of the launch reaches them at about the same
+                // time: ~2,000 atomics with return on each counter are served at ~90 per microsecond, 19 us for the last wave, and one after
+                // the other they were most of this kernel.  Both are requested back to back (two queues drain side by side), and the
+                // records go straight to the bucket array (the LDS stage collects the level walk's records: one instance per wave has
+                // nothing to collect).
+                uint32_t nReplay = 0, nBuckets = 0;                 // wave totals
+                uint32_t replayRank[FLAT_CHUNKS] = {}, bucketRank[FLAT_CHUNKS] = {}, chunksOfLeaf[FLAT_CHUNKS] = {};
 #pragma unroll
                 for (uint32_t c = 0; c < FLAT_CHUNKS; c++) if (c < chunks) {
                     const bool here = (reached[c] >> lane) & 1ull;
                     nNodes += here ? 1u : 0u;
-                    if (a.occlusion) {
-                        const bool replayIt = here && ((hiddenM[c] >> lane) & 1ull);
-                        const uint32_t slot = wave_append(&a.counters[CNT_REPLAY_NODES], replayIt);
-                        if (replayIt) {
-                            if (slot < a.recordCapacity) a.replayNodes[slot] = NodeRecord{instIndex, 0x80000000u | (1u << 30) | (nodeIdA[c] & 0x3FFFFFFFu)};
-                            else atomicAdd(&a.counters[CNT_DROPPED_RECORDS], 1u);
-                        }
-                    }
-                    // bucket records of `factor` meshlets per reached leaf that passed (computeCulling.hlsl:385-406)
+                    const uint64_t rm = a.occlusion ? (reached[c] & hiddenM[c]) : 0ull;
+                    replayRank[c] = nReplay + (uint32_t)__popcll(rm & ((1ull << lane) - 1ull));
+                    nReplay += (uint32_t)__popcll(rm);
                     const bool emitLeaf = here && ((leafM[c] >> lane) & 1ull);
-                    const uint32_t segFirst = segFirstCountA[c] & 0xFFFFu, segCount = segFirstCountA[c] >> 16;
-                    const uint32_t nChunks = emitLeaf ? (segCount + a.factor - 1u) / a.factor : 0u;
-                    uint32_t incl = nChunks;
+                    const uint32_t segCount = segFirstCountA[c] >> 16;
+                    chunksOfLeaf[c] = emitLeaf ? (segCount + a.factor - 1u) / a.factor : 0u;
+                    uint32_t incl = chunksOfLeaf[c];
 #pragma unroll
                     for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o); if (lane >= (uint32_t)o) incl += v; }
-                    const uint32_t total = (uint32_t)__shfl((int)incl, 63);
-                    if (total != 0u) {
-                        if (staged + total > HIER_STAGE) flush();
-                        const bool viaStage = total <= HIER_STAGE;
-                        uint32_t baseSlot = staged + (incl - nChunks);
-                        if (!viaStage) {
-                            uint32_t g0 = 0;
-                            if (lane == 0) g0 = atomicAdd(&a.counters[a.bucketCounter], total);
-                            baseSlot = (uint32_t)__shfl((int)g0, 0) + (incl - nChunks);
-                        }
-                        for (uint32_t k = 0; k < nChunks; k++) {
-                            BucketRecord b;
-                            b.instanceIndex = instIndex; b.groupIdPacked = ownerGroupA[c] & 0x7FFFFFFFu;
-                            b.meshletIndexAndCount = (min(a.factor, segCount - k * a.factor) << 16) | ((segFirst + k * a.factor) & 0xFFFFu);
-                            b.pageSlabDescriptorIndex = slabDescA[c]; b.pageSlabByteOffset = slabOffA[c];
-                            b.firstBit = iw.bitBase + firstBitRelA[c] + k * a.factor; b.pad0 = 0; b.pad1 = 0;
-                            if (viaStage) stage[baseSlot + k] = b;
-                            else if (baseSlot + k < a.recordCapacity) buckets[baseSlot + k] = b;
-                            else atomicAdd(&a.counters[CNT_DROPPED_RECORDS], 1u);
-                        }
-                        if (viaStage) staged += total;
+                    bucketRank[c] = nBuckets + incl - chunksOfLeaf[c];
+                    nBuckets += (uint32_t)__shfl((int)incl, 63);
+                }
+                uint32_t replayBase = 0, bucketBase = 0;
+                if (lane == 0) {
+                    if (nReplay != 0u) replayBase = atomicAdd(&a.counters[CNT_REPLAY_NODES], nReplay);
+                    if (nBuckets != 0u) bucketBase = atomicAdd(&a.counters[a.bucketCounter], nBuckets);
+                }
+                replayBase = (uint32_t)__shfl((int)replayBase, 0); bucketBase = (uint32_t)__shfl((int)bucketBase, 0);
+#pragma unroll
+                for (uint32_t c = 0; c < FLAT_CHUNKS; c++) if (c < chunks) {
+                    if (a.occlusion && ((reached[c] & hiddenM[c]) >> lane) & 1ull) {
+                        const uint32_t slot = replayBase + replayRank[c];
+                        if (slot < a.recordCapacity) a.replayNodes[slot] = NodeRecord{instIndex, 0x80000000u | (1u << 30) | (nodeIdA[c] & 0x3FFFFFFFu)};
+                        else atomicAdd(&a.counters[CNT_DROPPED_RECORDS], 1u);
+                    }
+                    // bucket records of `factor` meshlets per reached leaf that passed (computeCulling.hlsl:385-406)
+                    const uint32_t segFirst = segFirstCountA[c] & 0xFFFFu, segCount = segFirstCountA[c] >> 16;
+                    for (uint32_t k = 0; k < chunksOfLeaf[c]; k++) {
+                        const uint32_t slot = bucketBase + bucketRank[c] + k;
+                        if (slot >= a.recordCapacity) { atomicAdd(&a.counters[CNT_DROPPED_RECORDS], 1u); continue; }
+                        BucketRecord b;
+                        b.instanceIndex = instIndex; b.groupIdPacked = ownerGroupA[c] & 0x7FFFFFFFu;
+                        b.meshletIndexAndCount = (min(a.factor, segCount - k * a.factor) << 16) | ((segFirst + k * a.factor) & 0xFFFFu);
+                        b.pageSlabDescriptorIndex = slabDescA[c]; b.pageSlabByteOffset = slabOffA[c];
+                        b.firstBit = iw.bitBase + firstBitRelA[c] + k * a.factor; b.pad0 = 0; b.pad1 = 0;
+                        buckets[slot] = b;
                     }
                 }
+                HSTAMP(3);
+#ifdef BRMI_TILE_STAMPS
+                if (lane < 8u) { unsigned long long v = 0; for (int k = 0; k < 8; k++) if (lane == (uint32_t)k) v = hph[k]; atomicAdd(a.debugStamps + 48u + lane, v); }
+#endif
                 continue;
             }
         }
@@ -1049,7 +1071,7 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
     CullArgs a;
     a.sc = p->scene; a.counters = p->counters();
     a.instanceBitBase = p->wsPtr<uint32_t>(p->ws.instanceBitBase); a.segPrefix = p->wsPtr<uint32_t>(p->ws.segPrefix);
-    a.flatNodes = p->wsPtr<FlatNode>(p->ws.flatNodes); a.flatLeaves = p->wsPtr<FlatLeaf>(p->ws.flatLeaves); a.instanceWalk = p->wsPtr<InstanceWalk>(p->ws.instanceWalk);
+    a.flatNodes = p->wsPtr<FlatNode>(p->ws.flatNodes); a.flatLeaves = p->wsPtr<FlatLeaf>(p->ws.flatLeaves); a.instanceWalk = p->wsPtr<InstanceWalk>(p->ws.instanceWalk); a.debugStamps = p->wsPtr<unsigned long long>(p->ws.debugStamps);
     a.recordCapacity = p->cfg.maxTraversalRecords; a.visibleCapacity = p->cfg.maxVisibleClusters;
     uint32_t f = p->cfg.phase2ExpansionFactor; f = f < 1 ? 1 : (f > 64 ? 64 : f);
     { uint32_t n = 1; for (uint32_t c = 2; c <= 64; c <<= 1) if (c <= f) n = c; f = n; }
