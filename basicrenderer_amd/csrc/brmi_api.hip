@@ -302,6 +302,7 @@ int brmi_set_scene(brmi_pass* p, const brmi_scene_buffers* scene) {
         }
         // texture slots: the alpha-test variants of the rasteriser and the texture-sampling variant of the G-buffer pass are only
         // launched for scenes that need them
+        if (sc.openpbrMaterialCount > 65536u) return fail(p, BRMI_ERR_CAPACITY, "brmi_set_scene: %u OpenPBR material records; the shading pass folds 66 KB of table rows per record and takes at most 65536", sc.openpbrMaterialCount);
         std::vector<brmi_material_info> mats;
         if ((rc = read_back(p, mats, sc.materials, sc.materialCount))) return rc;
         p->sceneHasAlphaTest = false; p->sceneHasTextures = layerTextures; p->sceneHasParallax = false;

@@ -81,12 +81,12 @@ typedef struct brmi_scene_buffers {
     const brmi_per_mesh_instance*          perMeshInstance;  uint32_t perMeshInstanceCount;
     const brmi_mesh_instance_clod_offsets* clodOffsets;
     const brmi_clod_mesh_metadata*         meshMetadata;     uint32_t meshMetadataCount;
-    const brmi_lod_node*                   lodNodes;         uint32_t lodNodeCount;
+    const brmi_lod_node*                   lodNodes;         uint32_t lodNodeCount;     /* nodes, groups and segments are topology: brmi_set_scene folds them into derived tables; call it again when they change */
     const brmi_lod_group*                  lodGroups;        uint32_t lodGroupCount;
     const brmi_lod_segment*                lodSegments;      uint32_t lodSegmentCount;
     const brmi_group_page_map_entry*       groupPageMap;     uint32_t groupPageMapCount;
     const brmi_material_info*              materials;        uint32_t materialCount;
-    const brmi_openpbr_material_info*      openpbrMaterials; uint32_t openpbrMaterialCount;
+    const brmi_openpbr_material_info*      openpbrMaterials; uint32_t openpbrMaterialCount;   /* at most 65536: the shading pass keeps 66 KB of folded table rows per record in the workspace (brmi_set_scene refuses more) */
     const brmi_light_info*                 lights;           uint32_t lightCount;
     const uint32_t*                        activeLightIndices;
     const brmi_camera*                     cameras;          uint32_t cameraCount;
