@@ -44,6 +44,7 @@ struct CullArgs {
     const uint32_t* meshLevelWidth; uint32_t levelKernelsWidthLo;
     const FlatNode* flatNodes; const FlatLeaf* flatLeaves; const InstanceWalk* instanceWalk;     // flat traversal of small hierarchies (brmi_internal.h)
     unsigned long long* debugStamps;     // instrumented builds (-DBRMI_TILE_STAMPS)
+    uint32_t packedFlat;                 // phase 1: the launch's first ceil(draws / 8) waves take eight draws each (hierarchies of <= 8 nodes)
 };
 
 BRMI_DEV f3 to_view_space(f3 c, const m4& model, const m4& view) { return xyz(mul_vm(mul_point(c, model), view)); }
@@ -143,6 +144,13 @@ BRMI_DEV bool occlusion_test(const CullArgs& a, const brmi_camera* cam, bool rep
                              const brmi_per_object* obj) {
     if (replay) return occlusion_culled(a.hzb, cam, cam->projection[0][0], cam->projection[1][1], currentVS, -currentVS.z, currentRadius);
     const m4 prevModel = load_m4(&obj->prevModel[0][0]);
+    const f3 pc = to_view_space(localCenter, prevModel, load_m4(&cam->prevView[0][0]));
+    return occlusion_culled(a.hzb, cam, cam->prevUnjitteredProjection[0][0], cam->prevUnjitteredProjection[1][1], pc, -pc.z, localRadius * max_axis_scale(prevModel));
+}
+
+// phase 1's test with the previous model matrix already in registers (the flat traversal requests it together with the current one: behind the
+// node tests it was a memory round trip of its own in front of the depth chain's)
+BRMI_DEV bool occlusion_test_prev(const CullArgs& a, const brmi_camera* cam, f3 localCenter, float localRadius, const m4& prevModel) {
     const f3 pc = to_view_space(localCenter, prevModel, load_m4(&cam->prevView[0][0]));
     return occlusion_culled(a.hzb, cam, cam->prevUnjitteredProjection[0][0], cam->prevUnjitteredProjection[1][1], pc, -pc.z, localRadius * max_axis_scale(prevModel));
 }
@@ -402,7 +410,113 @@ __global__ void __launch_bounds__(64) k_cull_hierarchy(CullArgs a, BucketRecord*
         __syncthreads();
         staged = 0u;
     };
-    for (uint32_t seed = blockIdx.x; seed < seeds; seed += walkBlocks) {
+    // ---- eight instances to a wave.  The typical hierarchy of these scenes has five nodes (median; 90 % have <= 9): a wave per instance leaves
+    // 59 lanes idle AND queues two atomics with return per instance on two counters that serve ~90 per microsecond (2,017 instances: 19 us
+    // for the last wave, the launch's length).  The first ceil(draws / 8) waves take eight consecutive draws each, eight lanes per draw --
+    // object matrices per lane --, evaluate those whose hierarchy has <= 8 nodes exactly as the one-instance path below does, and make ONE
+    // reservation per counter for all of them; the waves behind them take one draw each and skip what was handled here.
+    uint32_t firstSeed = blockIdx.x, seedStride = walkBlocks;
+    if (!REPLAY && a.packedFlat) {
+        const uint32_t packedWaves = (seeds + 7u) >> 3;
+        if (blockIdx.x < packedWaves) {
+            const uint32_t g8 = lane & ~7u, j = lane & 7u;
+            const uint32_t seed = blockIdx.x * 8u + (lane >> 3);
+            const bool haveSeed = seed < seeds;
+            const uint32_t instIndex = haveSeed ? sc.activeDraws[seed] : 0u;
+            brmi_per_mesh_instance inst{}; InstanceWalk iw{0u, 0u, 0u, 0u};
+            if (haveSeed) { inst = sc.perMeshInstance[instIndex]; iw = a.instanceWalk[instIndex]; }
+            const bool small = haveSeed && iw.flatCount >= 1u && iw.flatCount <= 8u;
+            const brmi_per_object* obj = sc.perObject + (small ? inst.perObjectBufferIndex : 0u);
+            const bool mine = small && j < iw.flatCount;
+            FlatNode fn{}; FlatLeaf fl{};
+            if (mine) { fn = a.flatNodes[iw.flatBase + j]; fl = a.flatLeaves[iw.flatBase + j]; }
+            m4 model = load_m4(&obj->model[0][0]);
+            m4 prevModel = model;
+            if (a.occlusion && mine && ((fn.info >> 8) & 1u)) prevModel = load_m4(&obj->prevModel[0][0]);       // (internal nodes: the occlusion test's matrix, requested now)
+            const float scale = max_axis_scale(model);
+            const f3 instC{inst.boundingSphere[0], inst.boundingSphere[1], inst.boundingSphere[2]}; const float instR = inst.boundingSphere[3];
+            bool instVisible = false;
+            {   // K1 (PureComputeObjectCullCS), by every lane of the draw's group alike
+                const f3 c = to_view_space(instC, model, view);
+                const float r = instR * scale;
+                const bool bad = isnan(c.x) || isnan(c.y) || isnan(c.z) || isinf(c.x) || isinf(c.y) || isinf(c.z) || isnan(r) || isinf(r);
+                instVisible = small && !bad && !sphere_outside_frustum(c, r, cam->clippingPlanes);
+            }
+            nTested += (uint32_t)__popcll(__ballot(small && j == 0u)); nVisible += (uint32_t)__popcll(__ballot(instVisible && j == 0u));
+            const bool skinned = iw.skinned != 0u;
+            const bool internal = (fn.info >> 8) & 1u;
+            const f3 cullC = skinned ? instC : f3{fn.cull[0], fn.cull[1], fn.cull[2]};
+            const float cullR = skinned ? instR : fn.cull[3];
+            const f3 cVS = to_view_space(cullC, model, view);
+            const float rW = cullR * scale;
+            const bool inFrustum = mine && instVisible && !sphere_outside_frustum(cVS, rW, cam->clippingPlanes);
+            bool pre = inFrustum, expand = false, hidden = false, leafOk = false;
+            uint32_t slabDesc = 0, slabOff = 0;
+            if (inFrustum && internal) {
+                const f3 lc = xyz(mul_point(f3{fn.lod[0], fn.lod[1], fn.lod[2]}, model));
+                const float e = projected_error(lc, fn.lod[3] * scale, fn.maxQuadricError, scale, camPos, zNear, ortho);
+                pre = e >= threshold;
+                if (pre) { hidden = a.occlusion && occlusion_test_prev(a, cam, cullC, cullR, prevModel); expand = !hidden; }
+            } else if (inFrustum) {
+                const f3 gc = xyz(mul_point(f3{fl.group[0], fl.group[1], fl.group[2]}, model));
+                const float eod = projected_error(gc, fl.group[3] * scale, fn.maxQuadricError, scale, camPos, zNear, ortho);
+                bool ok = eod >= threshold;
+                if (ok && ((fn.info >> 9) & 1u)) {      // refined_child_suppresses
+                    const f3 cc = xyz(mul_point(f3{fl.child[0], fl.child[1], fl.child[2]}, model));
+                    const float ce = projected_error(cc, fl.child[3] * scale, fl.childParentError, scale, camPos, zNear, ortho);
+                    if (!(ce < threshold)) ok = false;
+                }
+                if (ok && ((fn.info >> 10) & 1u)) {
+                    const brmi_group_page_map_entry pe = sc.groupPageMap[fn.pageMapIndex];
+                    slabDesc = pe.slabDescriptorIndex; slabOff = pe.slabByteOffset;
+                    leafOk = slabDesc != 0u;
+                }
+            }
+            const uint64_t expandM = __ballot(expand);
+            const uint32_t parentLane = g8 | (fn.info & 7u);
+            uint64_t reached = __ballot(mine && instVisible && j == 0u);
+            for (;;) {
+                const bool r = mine && instVisible && (j == 0u || (pre && ((reached >> parentLane) & 1ull) && ((expandM >> parentLane) & 1ull)));
+                const uint64_t next = __ballot(r);
+                if (next == reached) break;
+                reached = next;
+            }
+            const bool here = (reached >> lane) & 1ull;
+            nNodes += here ? 1u : 0u;
+            const bool replayIt = a.occlusion && here && hidden;
+            const uint64_t replayM = __ballot(replayIt);
+            const bool emitLeaf = here && leafOk;
+            const uint32_t segFirst = fn.segFirstCount & 0xFFFFu, segCount = fn.segFirstCount >> 16;
+            const uint32_t nChunks = emitLeaf ? (segCount + a.factor - 1u) / a.factor : 0u;
+            uint32_t incl = nChunks;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o); if (lane >= (uint32_t)o) incl += v; }
+            const uint32_t nBuckets = (uint32_t)__shfl((int)incl, 63), nReplay = (uint32_t)__popcll(replayM);
+            uint32_t replayBase = 0, bucketBase = 0;
+            if (lane == 0) {
+                if (nReplay != 0u) replayBase = atomicAdd(&a.counters[CNT_REPLAY_NODES], nReplay);
+                if (nBuckets != 0u) bucketBase = atomicAdd(&a.counters[a.bucketCounter], nBuckets);
+            }
+            replayBase = (uint32_t)__shfl((int)replayBase, 0); bucketBase = (uint32_t)__shfl((int)bucketBase, 0);
+            if (replayIt) {
+                const uint32_t slot = replayBase + (uint32_t)__popcll(replayM & ((1ull << lane) - 1ull));
+                if (slot < a.recordCapacity) a.replayNodes[slot] = NodeRecord{instIndex, 0x80000000u | (1u << 30) | (fn.nodeId & 0x3FFFFFFFu)};
+                else atomicAdd(&a.counters[CNT_DROPPED_RECORDS], 1u);
+            }
+            for (uint32_t k = 0; k < nChunks; k++) {
+                const uint32_t slot = bucketBase + (incl - nChunks) + k;
+                if (slot >= a.recordCapacity) { atomicAdd(&a.counters[CNT_DROPPED_RECORDS], 1u); continue; }
+                BucketRecord b;
+                b.instanceIndex = instIndex; b.groupIdPacked = fn.ownerGroup & 0x7FFFFFFFu;
+                b.meshletIndexAndCount = (min(a.factor, segCount - k * a.factor) << 16) | ((segFirst + k * a.factor) & 0xFFFFu);
+                b.pageSlabDescriptorIndex = slabDesc; b.pageSlabByteOffset = slabOff;
+                b.firstBit = iw.bitBase + fn.firstBitRel + k * a.factor; b.pad0 = 0; b.pad1 = 0;
+                buckets[slot] = b;
+            }
+            firstSeed = seeds;                                  // nothing else for this wave
+        } else { firstSeed = blockIdx.x - packedWaves; seedStride = walkBlocks - packedWaves; }
+    }
+    for (uint32_t seed = firstSeed; seed < seeds; seed += seedStride) {
         uint32_t instIndex, startNode;
         if (REPLAY) { const NodeRecord rec = a.replayNodes[seed]; instIndex = rec.instanceIndex; startNode = rec.nodeIdPacked & 0x3FFFFFFFu; }
         else instIndex = sc.activeDraws[seed];
@@ -414,6 +528,7 @@ __global__ void __launch_bounds__(64) k_cull_hierarchy(CullArgs a, BucketRecord*
             // FlatLeaf, folded by brmi_set_scene) and the object arrive together, the depth chain and the page map together after them.
             // Same tests, same arithmetic, same records; a node is reached iff every ancestor let its children through.
             const InstanceWalk iw = a.instanceWalk[instIndex];
+            if (a.packedFlat && iw.flatCount >= 1u && iw.flatCount <= 8u) continue;      // one of the eight draws of a packed wave
 #ifdef BRMI_TILE_STAMPS
             unsigned long long hph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hprev = __builtin_amdgcn_s_memtime();
 #define HSTAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); hph[k] += now_ - hprev; hprev = now_; } while (0)
@@ -429,6 +544,7 @@ __global__ void __launch_bounds__(64) k_cull_hierarchy(CullArgs a, BucketRecord*
                 // (what the later phases need of a node; the spheres are used at once)
                 uint32_t nodeIdA[FLAT_CHUNKS] = {}, parentA[FLAT_CHUNKS] = {}, ownerGroupA[FLAT_CHUNKS] = {}, segFirstCountA[FLAT_CHUNKS] = {}, firstBitRelA[FLAT_CHUNKS] = {};
                 const m4 model = load_m4(&obj->model[0][0]);
+                const m4 prevModel = a.occlusion ? load_m4(&obj->prevModel[0][0]) : model;      // (the occlusion test's matrix, requested with the current one)
                 const float scale = max_axis_scale(model);
                 const f3 instC{inst.boundingSphere[0], inst.boundingSphere[1], inst.boundingSphere[2]}; const float instR = inst.boundingSphere[3];
                 {   // K1 (PureComputeObjectCullCS)
@@ -462,7 +578,7 @@ __global__ void __launch_bounds__(64) k_cull_hierarchy(CullArgs a, BucketRecord*
                         const f3 lc = xyz(mul_point(f3{fn.lod[0], fn.lod[1], fn.lod[2]}, model));
                         const float e = projected_error(lc, fn.lod[3] * scale, fn.maxQuadricError, scale, camPos, zNear, ortho);
                         pre = e >= threshold;
-                        if (pre) { hidden = a.occlusion && occlusion_test(a, cam, false, cullC, cullR, cVS, rW, obj); expand = !hidden; }
+                        if (pre) { hidden = a.occlusion && occlusion_test_prev(a, cam, cullC, cullR, prevModel); expand = !hidden; }
                     } else if (inFrustum) {
                         const f3 gc = xyz(mul_point(f3{fl.group[0], fl.group[1], fl.group[2]}, model));
                         const float eod = projected_error(gc, fl.group[3] * scale, fn.maxQuadricError, scale, camPos, zNear, ortho);
@@ -1075,7 +1191,7 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
     a.recordCapacity = p->cfg.maxTraversalRecords; a.visibleCapacity = p->cfg.maxVisibleClusters;
     uint32_t f = p->cfg.phase2ExpansionFactor; f = f < 1 ? 1 : (f > 64 ? 64 : f);
     { uint32_t n = 1; for (uint32_t c = 2; c <= 64; c <<= 1) if (c <= f) n = c; f = n; }
-    a.factor = f; a.phase = phase;
+    a.factor = f; a.phase = phase; a.packedFlat = 0u;
     // the band test's two planes through the eye only bound a row band under a symmetric perspective projection: an orthographic or
     // off-centre camera keeps the frustum test alone (the rasteriser's row filter still confines the band; nothing is lost but the early cull)
     const bool symmetricPerspective = p->camHost.isOrtho == 0 && p->camHost.projection[2][0] == 0.0f && p->camHost.projection[2][1] == 0.0f &&
@@ -1109,7 +1225,9 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
     if (phase == 1) {
         if (!p->frameStateCleared) BRMI_HIP(p, hipMemsetAsync(p->counters(), 0, p->ws.frameClearBytes, s));      // counters + both survivor bitmasks
         p->frameStateCleared = false;
-        const dim3 hgrid(std::min(std::max(1u, p->scene.activeDrawCount), 16384u));
+        // (the first ceil(draws / 8) waves of the walk take eight draws each: hierarchies of <= 8 nodes, the flat tables of brmi_set_scene)
+        a.packedFlat = (hierarchy && !p->hostFlatNodes.empty() && p->packedFlat) ? 1u : 0u;
+        const dim3 hgrid(std::min(std::max(1u, p->scene.activeDrawCount), 16384u) + (a.packedFlat ? (p->scene.activeDrawCount + 7u) / 8u : 0u));
         if (hierarchy) {
             // ONE launch: the 6 KB-frontier variant when every mesh is narrow (<= 256 nodes per level), else the 24 KB variant for all meshes up
             // to 1024 (two launches, one per class, ran one after the other: San-Miguel-class cull 178 -> 140 us with one)

@@ -170,6 +170,7 @@ struct brmi_pass {
     bool sceneHasAlphaTest = false, sceneHasTextures = false, sceneHasParallax = false;   // some material is alpha tested / samples a texture (brmi_set_scene)
     bool sceneHasCoat = true, sceneHasFuzz = true;   // some OpenPBR material has a coat / fuzz layer (brmi_set_scene)
     std::vector<float> sliceStartHost; float sliceKey[3] = {0, 0, 0}; uint32_t sliceKeyN[2] = {0, 0};   // slice starts of the light-cluster grid and the inputs they were made from
+    bool packedFlat = true;          // BRMI_FLAT_PACKED=0: one draw per wave of the traversal
     bool shadeSharesChip = false;    // brmi_execute_split with two streams: the shading half runs beside another frame's geometry half
     bool fuseShadeOptIn = false;     // BRMI_FUSE_SHADE=1 at brmi_create
     bool fuseShadeIntoGBuffer = false, plainPixelsShaded = false;   // brmi_execute: k_gbuffer_shade shades the plain pixels as it writes the G-buffer
