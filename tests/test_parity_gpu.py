@@ -1321,22 +1321,22 @@ def test_bin_plans_slices_and_folds_draw_the_same_keys(name, min_slice, shared_s
 
 @pytest.mark.parametrize("name", ["bistro_small", "sponza_ownlod", "bistro_ownlod_skinned", "tiny_lod", "bistro_skinned"])
 def test_flat_and_level_traversal_agree(name, scenes, oracle_frames):
-    """Hierarchies of up to 256 nodes are evaluated flat (one lane per node, records folded at brmi_set_scene); BRMI_FLAT_TRAVERSAL=0 walks
-    every hierarchy level by level.  Both give the oracle's cluster list and the same counters (instances, nodes, meshlets tested), with
+    """Hierarchies of up to 256 nodes are evaluated flat (one lane per node, records folded at brmi_set_scene; eight draws to a wave when they
+    have <= 8 nodes); BRMI_FLAT_TRAVERSAL=0 walks every hierarchy level by level.  All three give the oracle's cluster list and the same counters (instances, nodes, meshlets tested), with
     occlusion culling over two frames too (the replay lists phase 2 works from are the walk's)."""
     import orc
     from basicrenderer_amd.renderer import VisibilityRenderer
     o = oracle_frames(name)
     seen = []
-    for flat in (1, 0):
-        with _Env(BRMI_FLAT_TRAVERSAL=flat):
+    for flat, packed in ((1, 1), (1, 0), (0, 0)):      # flat with eight draws to a wave (hierarchies of <= 8 nodes), flat with one draw per wave, the level walk
+        with _Env(BRMI_FLAT_TRAVERSAL=flat, BRMI_FLAT_PACKED=packed):
             r = VisibilityRenderer(scenes(name), stats=True)
         r.execute()
         c = r.counters()
         assert np.array_equal(r.visible_clusters(), o.clusters[: o.count])
         seen.append((c.instancesTested, c.instancesVisible, c.nodesVisited, c.meshletsTested, c.visibleClusters))
         r.close()
-        with _Env(BRMI_FLAT_TRAVERSAL=flat):
+        with _Env(BRMI_FLAT_TRAVERSAL=flat, BRMI_FLAT_PACKED=packed):
             r = VisibilityRenderer(scenes(name), stats=True, occlusion=True)
         r.execute(); r.execute()
         c = r.counters()
@@ -1345,7 +1345,7 @@ def test_flat_and_level_traversal_agree(name, scenes, oracle_frames):
         for got, want in zip(orc.canonical_ids(r.visibility(), r.visible_clusters()), orc.canonical_ids(o.vis, o.clusters[: o.count])):
             assert np.array_equal(got, want)
         r.close()
-    assert seen[0] == seen[2] and seen[1] == seen[3], seen
+    assert seen[0] == seen[2] == seen[4] and seen[1] == seen[3] == seen[5], seen
 
 
 @pytest.mark.parametrize("name", ["sponza_small", "bistro_small", "tiny_lod", "tiny_skinned"])
