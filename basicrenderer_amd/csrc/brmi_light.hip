@@ -39,6 +39,9 @@ __global__ void __launch_bounds__(256) k_lc_fill(ClusterArgs a) { lc_fill_block(
 #ifndef BRMI_SHADE_WAVES
 #define BRMI_SHADE_WAVES 3
 #endif
+#ifndef BRMI_SHADE_STASH_SHARED
+#define BRMI_SHADE_STASH_SHARED 0      // floats the in-flight variant parks (experiments: 6)
+#endif
 #ifndef BRMI_SHADE_WAVES_ALONE
 #define BRMI_SHADE_WAVES_ALONE 4
 #endif
@@ -73,7 +76,7 @@ __global__ void __launch_bounds__(256, MODE != 0 ? 1 : WAVES) k_shade(ShadeArgs 
             bool nok = false;
             const RawPixel nxt = fetch(nt, ntx, nty, nok);
             const uint64_t tileBase = (uint64_t)(firstTile + t) << 6;
-            const uint32_t cls = shade_pixel<0, BRMI_SHADE_METAL_STASH && WAVES == BRMI_SHADE_WAVES_ALONE && BRMI_SHADE_WAVES_ALONE != BRMI_SHADE_WAVES>(a, k, sliceStart, unormT, camK, cur, ok, tileBase, lane);
+            const uint32_t cls = shade_pixel<0, (BRMI_SHADE_METAL_STASH && WAVES == BRMI_SHADE_WAVES_ALONE && BRMI_SHADE_WAVES_ALONE != BRMI_SHADE_WAVES) ? 9 : BRMI_SHADE_STASH_SHARED>(a, k, sliceStart, unormT, camK, cur, ok, tileBase, lane);
             shade_defer(a, t, cls, lane);
             cur = nxt; ok = nok; t = nt; tx = ntx; ty = nty;
         }

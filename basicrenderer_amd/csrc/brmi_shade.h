@@ -300,7 +300,7 @@ BRMI_DEV PixelCtx make_pixel_ctx(const Luts& L, const Frag& f, const ShadeRows* 
 
 // `h` = normalize(L + V), NoH, LoH come from the caller (correctly rounded, contraction off: 1 - NoH^2 amplifies their error at low
 // roughness); everything in here holds the HDR tolerance and may fuse.
-template <int MODE, bool STASH>
+template <int MODE, int STASH>
 BRMI_DEV f3 light_contribution(const Luts& L, const Frag& f, const PixelCtx& c, const float* stash, f3 lightToFrag, float NoL, float NoH, float LoH, float VdotL, float D, f3 lightColorIntensity, float attenuation, float spotAtt) {
     BRMI_FP_FAST
     const BaseState& base = c.base;
@@ -334,7 +334,7 @@ BRMI_DEV f3 light_contribution(const Luts& L, const Frag& f, const PixelCtx& c, 
         // workgroup cost more residency than the registers buy (frame in flight 0.571 -> 0.623 ms).
         const f3 mF0 = STASH ? f3{stash[0 * 256], stash[1 * 256], stash[2 * 256]} : base.metalSpecularF0;
         const f3 mMs = STASH ? f3{stash[3 * 256], stash[4 * 256], stash[5 * 256]} : base.metalMultipleScatterScale;
-        const float f90Metal = STASH ? stash[6 * 256] : c.f90Metal, mView = STASH ? stash[7 * 256] : c.mView, mAvgClamped = STASH ? stash[8 * 256] : c.mAvgClamped;
+        const float f90Metal = STASH > 6 ? stash[6 * 256] : c.f90Metal, mView = STASH > 6 ? stash[7 * 256] : c.mView, mAvgClamped = STASH > 6 ? stash[8 * 256] : c.mAvgClamped;
         const float* imRow = STASH ? c.odRow + 32 : c.imRow;                    // ShadeRows: od[32], im[32]
         const f3 Fm = mF0 + (f3{f90Metal, f90Metal, f90Metal} - mF0) * pw;
         const float mLight = sample_folded_row(imRow, NoL);
@@ -391,11 +391,11 @@ BRMI_DEV ShadeLightLanes stage_lights(const ShadeArgs& a, uint32_t listBase, uin
     }
     return s;
 }
-template <int MODE, bool STASH = false>
+template <int MODE, int STASH = 0>      // STASH: floats of the metal lobe's inputs parked in LDS (0, 6 or 9)
 BRMI_DEV uint32_t shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const float* sliceStart, const float* unorm8, const float4* camK, const RawPixel& raw, bool live, uint64_t tileBase, uint32_t within) {
     const Luts& L = k.L;
     const uint32_t gx = k.gx, gy = k.gy, gz = k.gz, nearSlices = k.nearSlices;
-    __shared__ float metalStash[STASH ? 9 : 1][STASH ? 256 : 1];                     // (blockDim.x == 256 in every kernel built from this)
+    __shared__ float metalStash[STASH ? STASH : 1][STASH ? 256 : 1];                     // (blockDim.x == 256 in every kernel built from this)
     const float* stash = &metalStash[0][STASH ? threadIdx.x : 0u];
     live = live && as_u32(raw.d) != BRMI_DEPTH_EMPTY_BITS;
     Frag f; PixelCtx ctx; f3 posWS, posVS;        // only read by lanes that stay `live` (no initialiser: nothing to materialise for the others)
@@ -508,7 +508,7 @@ BRMI_DEV uint32_t shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const flo
         if (STASH && f.metalSpecularWeight != 0.0f) {
             metalStash[0][threadIdx.x] = ctx.base.metalSpecularF0.x; metalStash[1][threadIdx.x] = ctx.base.metalSpecularF0.y; metalStash[2][threadIdx.x] = ctx.base.metalSpecularF0.z;
             metalStash[3][threadIdx.x] = ctx.base.metalMultipleScatterScale.x; metalStash[4][threadIdx.x] = ctx.base.metalMultipleScatterScale.y; metalStash[5][threadIdx.x] = ctx.base.metalMultipleScatterScale.z;
-            metalStash[6][threadIdx.x] = ctx.f90Metal; metalStash[7][threadIdx.x] = ctx.mView; metalStash[8][threadIdx.x] = ctx.mAvgClamped;
+            if (STASH > 6) { metalStash[6 % (STASH ? STASH : 1)][threadIdx.x] = ctx.f90Metal; metalStash[7 % (STASH ? STASH : 1)][threadIdx.x] = ctx.mView; metalStash[8 % (STASH ? STASH : 1)][threadIdx.x] = ctx.mAvgClamped; }
         }
     }
     f3 lighting{0.0f, 0.0f, 0.0f};
