@@ -61,7 +61,7 @@ class VisibilityRenderer:
         self.lib.brmi_default_config(C.byref(cfg), self.W, self.H)
         if stripes is not None:
             cfg.stripeRows, cfg.stripeCount, cfg.stripeIndex, cfg.fullHeight = stripes[0], stripes[1], stripes[2], scene.height
-        est = max(4096, 2 * scene.stats["meshletsTotal"] * max(1, scene.stats["instances"]) // max(1, scene.stats["meshes"]))
+        est = max(4096, scene.stats.get("instancedMeshlets") or 2 * scene.stats["meshletsTotal"] * max(1, scene.stats["instances"]) // max(1, scene.stats["meshes"]))      # every (instance, meshlet) pair: nothing more can be visible
         cfg.maxVisibleClusters = int(max_clusters or min(1 << 24, max(1 << 16, est)))
         cfg.maxTraversalRecords = cfg.maxVisibleClusters
         cfg.enableOcclusionCulling = 1 if occlusion else 0

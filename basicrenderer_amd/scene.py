@@ -125,6 +125,20 @@ class Scene:
         st = capi.SceneStats()
         lib.brmi_scene_get_stats(self._h, C.byref(st))
         self.stats = {n: (list(getattr(st, n)) if n.startswith("scene") else getattr(st, n)) for n, _ in capi.SceneStats._fields_}
+        # every (instance, meshlet) pair of the scene, all LOD levels: the bound on what a frame can list as visible (a pass sized by it keeps
+        # its resolve arena complete: one G-buffer variant per frame instead of two launches, brmi_resolve.hip)
+        try:
+            md = self.arrays["meshMetadata"].view(np.uint32).reshape(-1, 10)
+            seg = self.arrays["lodSegments"].view(np.uint32).reshape(-1, 4)
+            offs = self.arrays["clodOffsets"].view(np.uint32)
+            order = np.argsort(md[:, 1], kind="stable")
+            ends = np.append(md[order, 1][1:], len(seg))
+            csum = np.concatenate([[0], np.cumsum(seg[:, 2].astype(np.int64))])
+            per_mesh = np.zeros(len(md), dtype=np.int64)
+            per_mesh[order] = csum[ends] - csum[md[order, 1]]
+            self.stats["instancedMeshlets"] = int(per_mesh[offs[: self.counts.get("clodOffsets", len(offs))]].sum())
+        except (KeyError, ValueError, IndexError):
+            self.stats["instancedMeshlets"] = 0
         lib.brmi_scene_destroy(self._h)
         self._h = None
         self._keep = []
