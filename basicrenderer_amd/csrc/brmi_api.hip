@@ -100,6 +100,7 @@ static void compute_sizes(brmi_pass* p) {
     w.tempVisible = take((uint64_t)c.maxVisibleClusters * sizeof(TempVisible));
     w.wordPrefix = take((uint64_t)p->totalWords * 4);
     w.blockSums = take((uint64_t)(p->scanBlocks + 1) * 4);
+    w.scanAgg = take(65 * 8);
     w.instanceBitBase = take((uint64_t)std::max<size_t>(1, p->hostInstanceBitBase.size()) * 4);
     w.segPrefix = take((uint64_t)std::max<size_t>(1, p->hostSegPrefix.size()) * 4);
     w.meshLevelWidth = take((uint64_t)std::max<size_t>(1, p->hostMeshLevelWidth.size()) * 4);
@@ -231,6 +232,7 @@ int brmi_create(const brmi_config* cfg, brmi_pass** out) {
     p->totalWords = 1; p->scanBlocks = 1;
     if (const char* e = std::getenv("BRMI_CULL_LEVEL_KERNELS")) p->forceLevelKernels = std::atoi(e) != 0;
     if (const char* e = std::getenv("BRMI_RASTER_GRID")) p->rasterGrid = (uint32_t)std::max(64, std::atoi(e));
+    if (const char* e = std::getenv("BRMI_SCAN_CHAINED")) p->scanChained = std::atoi(e) != 0;
     if (const char* e = std::getenv("BRMI_FLAT_PACKED")) p->packedFlat = std::atoi(e) != 0;
     if (const char* e = std::getenv("BRMI_BIN_MIN_SLICE")) p->binMinSlice = (uint32_t)std::max(32, std::atoi(e));
     if (const char* e = std::getenv("BRMI_BIN_SHARED_SLICE")) p->binSharedSlice = (uint32_t)std::max(32, std::atoi(e));

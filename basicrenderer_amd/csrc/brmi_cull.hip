@@ -1047,6 +1047,53 @@ __global__ void __launch_bounds__(256) k_scan_words(const uint32_t* bitmask, uin
     }
 }
 
+// The three kernels above as ONE launch for bitmasks of up to 64 blocks (131 k words: every benchmark frame has 6-10): a block counts its 2048
+// words, publishes the sum with the launch's epoch in one 64-bit agent-scope store, waits for the sums of the blocks before it (all <= 64
+// blocks are resident at once: 256 CUs), and scans its words from there; the last block writes the total.  Two launches less per culling
+// phase -- with another frame's shading pass filling the chip every small launch of the geometry stream waits 5-15 us for its slots.
+constexpr uint32_t SCAN_CHAIN_BLOCKS = 64;
+__global__ void __launch_bounds__(256) k_scan_chained(const uint32_t* bitmask, uint32_t totalWords, unsigned long long* agg, uint32_t epoch, uint32_t* wordPrefix,
+                                                     uint32_t* counters, uint32_t outIndex, uint32_t capacity, uint32_t usedIndex) {
+    __shared__ uint32_t waveTotals[4];
+    __shared__ uint32_t blockPrefix, ticket;
+    // the block's place in the chain is the order in which blocks START (a ticket), not blockIdx: a block only ever waits for blocks that are
+    // running already, whatever order the dispatcher picks (agg[64] is the ticket word; the last block puts it back to zero)
+    if (threadIdx.x == 0) ticket = (uint32_t)__hip_atomic_fetch_add(&agg[SCAN_CHAIN_BLOCKS], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const uint32_t block = ticket;
+    const uint32_t base = block * SCAN_BLOCK_WORDS + threadIdx.x * 8u;       // eight consecutive words per thread
+    uint32_t pc[8], sum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 8u; k++) { const uint32_t w = base + k; pc[k] = w < totalWords ? (uint32_t)__popc(bitmask[w]) : 0u; sum += pc[k]; }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o); if ((threadIdx.x & 63u) >= (uint32_t)o) incl += t; }
+    if ((threadIdx.x & 63u) == 63u) waveTotals[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t waveBase = 0, blockSum = 0;
+    for (uint32_t k = 0; k < 4u; k++) { if (k < (threadIdx.x >> 6)) waveBase += waveTotals[k]; blockSum += waveTotals[k]; }
+    if (threadIdx.x == 0) __hip_atomic_store(&agg[block], ((unsigned long long)epoch << 32) | blockSum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < 64u) {
+        uint32_t mine = 0;
+        if (threadIdx.x < block) {
+            unsigned long long v;
+            do { v = __hip_atomic_load(&agg[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((uint32_t)(v >> 32) != epoch);
+            mine = (uint32_t)v;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mine += (uint32_t)__shfl_xor((int)mine, o);
+        if (threadIdx.x == 0) blockPrefix = mine;
+    }
+    __syncthreads();
+    uint32_t run = blockPrefix + waveBase + incl - sum;
+#pragma unroll
+    for (uint32_t k = 0; k < 8u; k++) { const uint32_t w = base + k; if (w < totalWords) wordPrefix[w] = run; run += pc[k]; }
+    if (block == gridDim.x - 1u && threadIdx.x == 0) {
+        __hip_atomic_store(&agg[SCAN_CHAIN_BLOCKS], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // every ticket of this launch has been taken
+        counters[outIndex] = min(blockPrefix + blockSum, capacity - (usedIndex == 0xFFFFFFFFu ? 0u : min(counters[usedIndex], capacity)));
+    }
+}
+
 // Places every survivor at its rank.  Also accumulates the vertex / triangle totals of the clusters that will be
 // rasterised (statistics for the algorithmic-byte count), one atomic per wave: a per-cluster atomic on three
 // shared words would serialise the whole rasteriser (~90 same-address atomics per microsecond).
@@ -1276,9 +1323,15 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
     if (localRank) {
         // ranked inside the scatter kernel
     } else {
-        hipLaunchKernelGGL(k_scan_reduce, dim3(p->scanBlocks), dim3(256), 0, s, bitmask, p->totalWords, blockSums);
-        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, blockSums, p->scanBlocks, p->counters(), outIndex, p->cfg.maxVisibleClusters, usedIndex);
-        hipLaunchKernelGGL(k_scan_words, dim3(p->scanBlocks), dim3(256), 0, s, bitmask, p->totalWords, blockSums, wordPrefix);
+        if (p->scanBlocks <= SCAN_CHAIN_BLOCKS && p->scanChained) {
+            if (++p->scanEpoch == 0u) p->scanEpoch = 1u;
+            hipLaunchKernelGGL(k_scan_chained, dim3(p->scanBlocks), dim3(256), 0, s, bitmask, p->totalWords, p->wsPtr<unsigned long long>(p->ws.scanAgg), p->scanEpoch, wordPrefix,
+                               p->counters(), outIndex, p->cfg.maxVisibleClusters, usedIndex);
+        } else {
+            hipLaunchKernelGGL(k_scan_reduce, dim3(p->scanBlocks), dim3(256), 0, s, bitmask, p->totalWords, blockSums);
+            hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, blockSums, p->scanBlocks, p->counters(), outIndex, p->cfg.maxVisibleClusters, usedIndex);
+            hipLaunchKernelGGL(k_scan_words, dim3(p->scanBlocks), dim3(256), 0, s, bitmask, p->totalWords, blockSums, wordPrefix);
+        }
     }
     auto scatter = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(smallGrid), dim3(256), 0, s, temp, p->counters(), (uint32_t)(phase == 1 ? CNT_TEMP_VISIBLE : CNT_TEMP_VISIBLE2), bitmask, wordPrefix,

@@ -139,7 +139,7 @@ struct LayerUniform { unsigned long long coatWord, fuzzWord, coatFilledWord, fuz
 
 struct Workspace {     // byte offsets into BRMI_RES_WORKSPACE
     uint64_t counters, frontierA, frontierB, buckets, tempVisible, bitmask1, bitmask2, wordPrefix, blockSums,
-             instanceBitBase, segPrefix, meshLevelWidth, flatNodes, flatLeaves, instanceWalk, planes, replayNodes, replayBuckets, lightVS, lightMeta, clusterPages, clusterHits, pageTotal, lightHitMasks, binCounts, binRecords, binOverflow, binPlan, binItems, binScratch, clusterSetup, resolveVerts, resolveTris, matWords, shadeTables, lutF, frameConst, objConst, matConst, deferredPixels, usedClusters,
+             instanceBitBase, segPrefix, meshLevelWidth, scanAgg, flatNodes, flatLeaves, instanceWalk, planes, replayNodes, replayBuckets, lightVS, lightMeta, clusterPages, clusterHits, pageTotal, lightHitMasks, binCounts, binRecords, binOverflow, binPlan, binItems, binScratch, clusterSetup, resolveVerts, resolveTris, matWords, shadeTables, lutF, frameConst, objConst, matConst, deferredPixels, usedClusters,
              frameSnapshot, tileCounts, tileLists, tileOverflow, xverts, debugStamps, clusterUv, binAlpha, overflowAlpha, resolveUVs, resolveColors, alphaMats, shadeRows, shadeAvgs, ggxQuads, shadeLights, clusterList, listEntries, listRecords, layerUniform, frameClearBytes, total;
 };
 
@@ -170,6 +170,7 @@ struct brmi_pass {
     bool sceneHasAlphaTest = false, sceneHasTextures = false, sceneHasParallax = false;   // some material is alpha tested / samples a texture (brmi_set_scene)
     bool sceneHasCoat = true, sceneHasFuzz = true;   // some OpenPBR material has a coat / fuzz layer (brmi_set_scene)
     std::vector<float> sliceStartHost; float sliceKey[3] = {0, 0, 0}; uint32_t sliceKeyN[2] = {0, 0};   // slice starts of the light-cluster grid and the inputs they were made from
+    bool scanChained = true; uint32_t scanEpoch = 0;      // the survivor ranking as one launch (BRMI_SCAN_CHAINED=0: three)
     bool packedFlat = true;          // BRMI_FLAT_PACKED=0: one draw per wave of the traversal
     bool shadeSharesChip = false;    // brmi_execute_split with two streams: the shading half runs beside another frame's geometry half
     bool fuseShadeOptIn = false;     // BRMI_FUSE_SHADE=1 at brmi_create
