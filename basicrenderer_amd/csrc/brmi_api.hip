@@ -232,6 +232,7 @@ int brmi_create(const brmi_config* cfg, brmi_pass** out) {
     p->totalWords = 1; p->scanBlocks = 1;
     if (const char* e = std::getenv("BRMI_CULL_LEVEL_KERNELS")) p->forceLevelKernels = std::atoi(e) != 0;
     if (const char* e = std::getenv("BRMI_RASTER_GRID")) p->rasterGrid = (uint32_t)std::max(64, std::atoi(e));
+    if (const char* e = std::getenv("BRMI_SHADE_GRID_SHARED")) p->shadeGridShared = (uint32_t)std::min(65535, std::max(256, std::atoi(e)));
     if (const char* e = std::getenv("BRMI_SCAN_CHAINED")) p->scanChained = std::atoi(e) != 0;
     if (const char* e = std::getenv("BRMI_FLAT_PACKED")) p->packedFlat = std::atoi(e) != 0;
     if (const char* e = std::getenv("BRMI_BIN_MIN_SLICE")) p->binMinSlice = (uint32_t)std::max(32, std::atoi(e));

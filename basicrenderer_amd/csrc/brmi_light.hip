@@ -192,7 +192,7 @@ int launch_shade(brmi_pass* p, hipStream_t s) {
     // (Bistro 4K, two frames in flight: 0.436 -> 0.413 ms per frame; 16384: 0.425, 2048: 0.49)
     else {
         static const uint32_t pad = [] { const char* e = std::getenv("BRMI_SHADE_LDS_PAD"); return e ? (uint32_t)std::atoi(e) : 0u; }();   // (experiment: unused dynamic LDS caps the kernel's occupancy)
-        if (p->shadeSharesChip || BRMI_SHADE_WAVES_ALONE == BRMI_SHADE_WAVES) hipLaunchKernelGGL((k_shade<0, BRMI_SHADE_WAVES>), dim3(8192), dim3(256), pad, s, a);
+        if (p->shadeSharesChip || BRMI_SHADE_WAVES_ALONE == BRMI_SHADE_WAVES) hipLaunchKernelGGL((k_shade<0, BRMI_SHADE_WAVES>), dim3(p->shadeGridShared), dim3(256), pad, s, a);
         else hipLaunchKernelGGL((k_shade<0, BRMI_SHADE_WAVES_ALONE>), dim3(8192), dim3(256), pad, s, a);
     }
     // deferred pixels by class: coat, fuzz, both -- only the variants some material of the scene can need
