@@ -233,6 +233,7 @@ int brmi_create(const brmi_config* cfg, brmi_pass** out) {
     if (const char* e = std::getenv("BRMI_CULL_LEVEL_KERNELS")) p->forceLevelKernels = std::atoi(e) != 0;
     if (const char* e = std::getenv("BRMI_RASTER_GRID")) p->rasterGrid = (uint32_t)std::max(64, std::atoi(e));
     if (const char* e = std::getenv("BRMI_SHADE_GRID_SHARED")) p->shadeGridShared = (uint32_t)std::min(65535, std::max(256, std::atoi(e)));
+    if (const char* e = std::getenv("BRMI_GBUFFER_GRID_SHARED")) p->gbufferGridShared = (uint32_t)std::min(65535, std::max(256, std::atoi(e)));
     if (const char* e = std::getenv("BRMI_SCAN_CHAINED")) p->scanChained = std::atoi(e) != 0;
     if (const char* e = std::getenv("BRMI_FLAT_PACKED")) p->packedFlat = std::atoi(e) != 0;
     if (const char* e = std::getenv("BRMI_BIN_MIN_SLICE")) p->binMinSlice = (uint32_t)std::max(32, std::atoi(e));
@@ -761,7 +762,9 @@ int brmi_execute_split(brmi_pass* p, brmi_stream stream, brmi_stream shadeStream
     if (fuseEnv && !lightsDone) { if ((rc = brmi_light_clustering(p, stream))) return rc; lightsDone = true; }
     p->fuseShadeIntoGBuffer = fuseEnv; p->plainPixelsShaded = false;
     p->depthFinal = p->cfg.enableOcclusionCulling != 0;
+    p->shadeSharesChip = split;
     rc = brmi_gbuffer(p, stream);
+    p->shadeSharesChip = false;
     p->fuseShadeIntoGBuffer = false; p->depthFinal = false;
     if (rc) return rc;
     if (!lightsDone && (rc = brmi_light_clustering(p, stream))) return rc;

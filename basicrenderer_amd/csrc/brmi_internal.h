@@ -173,6 +173,7 @@ struct brmi_pass {
     bool scanChained = true; uint32_t scanEpoch = 0;      // the survivor ranking as one launch (BRMI_SCAN_CHAINED=0: three)
     bool packedFlat = true;          // BRMI_FLAT_PACKED=0: one draw per wave of the traversal
     uint32_t shadeGridShared = 10240; // workgroups of k_shade<0, 3> (BRMI_SHADE_GRID_SHARED): shorter-lived than the stand-alone 8192 so that the other frame's small geometry launches find slots sooner (Bistro-class period 6144 / 8192 / 10240 / 12288: 0.547 / 0.539 / 0.530 / 0.531 ms; Sponza-class, whose geometry half is short: 0.386 / 0.398 / 0.398 / 0.397)
+    uint32_t gbufferGridShared = 4096; // workgroups of the lean k_gbuffer in a split frame (BRMI_GBUFFER_GRID_SHARED)
     bool shadeSharesChip = false;    // brmi_execute_split with two streams: the shading half runs beside another frame's geometry half
     bool fuseShadeOptIn = false;     // BRMI_FUSE_SHADE=1 at brmi_create
     bool fuseShadeIntoGBuffer = false, plainPixelsShaded = false;   // brmi_execute: k_gbuffer_shade shades the plain pixels as it writes the G-buffer

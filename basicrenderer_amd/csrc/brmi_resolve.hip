@@ -649,7 +649,7 @@ int launch_gbuffer(brmi_pass* p, hipStream_t s) {
         a.variantSelect = lean ? 0u : 1u;
         // the texture-sampling variants' waves live long: twice the workgroups shorten the tail (Sponza 4K textured 486 -> 472 us, parallax 1001 -> 963);
         // the constant-factor variant is best at 4096
-        const uint32_t grid = (p->sceneHasTextures || p->sceneHasVertexColors) ? 8192u : 4096u;
+        const uint32_t grid = (p->sceneHasTextures || p->sceneHasVertexColors) ? 8192u : (p->shadeSharesChip ? p->gbufferGridShared : 4096u);
         hipLaunchKernelGGL(leanKernel, dim3(grid), dim3(256), 0, s, a);
         if (!lean) { a.variantSelect = 2u; hipLaunchKernelGGL(fallbackKernel, dim3(4096), dim3(256), 0, s, a); }
     };
