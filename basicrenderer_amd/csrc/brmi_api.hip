@@ -223,6 +223,7 @@ int brmi_create(const brmi_config* cfg, brmi_pass** out) {
     if (cfg->maxVisibleClusters == 0 || cfg->maxVisibleClusters > (1u << 26) || cfg->maxTraversalRecords == 0) return BRMI_ERR_INVALID;
     if (cfg->lightClusterSize[0] == 0 || cfg->lightClusterSize[1] == 0 || cfg->lightClusterSize[2] == 0) return BRMI_ERR_INVALID;
     if (cfg->lightClusterSize[2] > 62u) return BRMI_ERR_INVALID;
+    if ((uint64_t)((cfg->width + 255u) / 256u) * ((cfg->height + 15u) / 16u) > 65535ull) return BRMI_ERR_INVALID;      // the raster bins' work items name a bin in 16 bits (16384 x 16368 px still fits)
     if (cfg->stripeCount > 1u) {      // interleaved partition: whole chunks of 16-row bin bands, the same number on every GPU, no band on top
         if (cfg->stripeRows == 0u || cfg->stripeRows % 16u || cfg->stripeIndex >= cfg->stripeCount || cfg->bandY0 != 0u || (cfg->bandY1 != 0u && cfg->bandY1 != cfg->height)) return BRMI_ERR_INVALID;
         if (cfg->fullHeight == 0u || cfg->fullHeight % (cfg->stripeRows * cfg->stripeCount) || cfg->height != cfg->fullHeight / cfg->stripeCount) return BRMI_ERR_INVALID;
