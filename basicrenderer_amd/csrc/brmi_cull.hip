@@ -999,7 +999,7 @@ __global__ void __launch_bounds__(256) k_scan_reduce(const uint32_t* bitmask, ui
 }
 
 // single workgroup: exclusive scan of blockSums in place; total -> counters[outIndex] (clamped to capacity)
-__global__ void __launch_bounds__(1024) k_scan_blocks(uint32_t* blockSums, uint32_t nBlocks, uint32_t* counters, uint32_t outIndex, uint32_t capacity, uint32_t usedIndex) {
+__global__ void __launch_bounds__(1024) k_scan_blocks(uint32_t* blockSums, uint32_t nBlocks, uint32_t* counters, uint32_t outIndex, uint32_t capacity, uint32_t usedIndex, uint32_t* hostFeedback) {
     __shared__ uint32_t waveTotals[16];
     __shared__ uint32_t carry;
     if (threadIdx.x == 0) carry = 0;
@@ -1020,7 +1020,11 @@ __global__ void __launch_bounds__(1024) k_scan_blocks(uint32_t* blockSums, uint3
         if (threadIdx.x == 1023) carry = c + waveBase + incl;
         __syncthreads();
     }
-    if (threadIdx.x == 0) counters[outIndex] = min(carry, capacity - (usedIndex == 0xFFFFFFFFu ? 0u : min(counters[usedIndex], capacity)));
+    if (threadIdx.x == 0) {
+        const uint32_t placed = min(carry, capacity - (usedIndex == 0xFFFFFFFFu ? 0u : min(counters[usedIndex], capacity)));
+        counters[outIndex] = placed;
+        if (hostFeedback) __hip_atomic_store(hostFeedback, placed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // (phase 2: the host's hint for the next frames)
+    }
 }
 
 __global__ void __launch_bounds__(256) k_scan_words(const uint32_t* bitmask, uint32_t totalWords, const uint32_t* blockSums, uint32_t* wordPrefix) {
@@ -1053,7 +1057,7 @@ __global__ void __launch_bounds__(256) k_scan_words(const uint32_t* bitmask, uin
 // phase -- with another frame's shading pass filling the chip every small launch of the geometry stream waits 5-15 us for its slots.
 constexpr uint32_t SCAN_CHAIN_BLOCKS = 64;
 __global__ void __launch_bounds__(256) k_scan_chained(const uint32_t* bitmask, uint32_t totalWords, unsigned long long* agg, uint32_t epoch, uint32_t* wordPrefix,
-                                                     uint32_t* counters, uint32_t outIndex, uint32_t capacity, uint32_t usedIndex) {
+                                                     uint32_t* counters, uint32_t outIndex, uint32_t capacity, uint32_t usedIndex, uint32_t* hostFeedback) {
     __shared__ uint32_t waveTotals[4];
     __shared__ uint32_t blockPrefix, ticket;
     // the block's place in the chain is the order in which blocks START (a ticket), not blockIdx: a block only ever waits for blocks that are
@@ -1090,7 +1094,9 @@ __global__ void __launch_bounds__(256) k_scan_chained(const uint32_t* bitmask, u
     for (uint32_t k = 0; k < 8u; k++) { const uint32_t w = base + k; if (w < totalWords) wordPrefix[w] = run; run += pc[k]; }
     if (block == gridDim.x - 1u && threadIdx.x == 0) {
         __hip_atomic_store(&agg[SCAN_CHAIN_BLOCKS], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // every ticket of this launch has been taken
-        counters[outIndex] = min(blockPrefix + blockSum, capacity - (usedIndex == 0xFFFFFFFFu ? 0u : min(counters[usedIndex], capacity)));
+        const uint32_t placed = min(blockPrefix + blockSum, capacity - (usedIndex == 0xFFFFFFFFu ? 0u : min(counters[usedIndex], capacity)));
+        counters[outIndex] = placed;
+        if (hostFeedback) __hip_atomic_store(hostFeedback, placed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // (phase 2: the host's hint for the next frames)
     }
 }
 
@@ -1105,7 +1111,7 @@ __global__ void __launch_bounds__(256) k_scan_chained(const uint32_t* bitmask, u
 #define BRMI_LOCAL_RANK_WORDS 8192
 #endif
 constexpr uint32_t LOCAL_RANK_WORDS = BRMI_LOCAL_RANK_WORDS;
-struct LocalRank { uint32_t totalWords, outIndex, usedIndex; };
+struct LocalRank { uint32_t totalWords, outIndex, usedIndex; uint32_t* hostFeedback; };
 template <bool LOCAL_RANK>
 __global__ void __launch_bounds__(256) k_scatter_visible(const TempVisible* temp, uint32_t* counters, uint32_t tempCountIndex, const uint32_t* bitmask,
                                                         const uint32_t* wordPrefix, uint4* visible, uint32_t baseIndexCounter, uint32_t capacity, uint32_t visibleCapacity,
@@ -1131,7 +1137,11 @@ __global__ void __launch_bounds__(256) k_scatter_visible(const TempVisible* temp
         for (uint32_t w = 0; w < 4; w++) { if (w < (threadIdx.x >> 6)) waveBase += waveTotals[w]; all += waveTotals[w]; }
         uint32_t run = waveBase + incl - sum;
         for (uint32_t w = w0; w < w1; w++) { prefixLds[w] = run; run += __popc(bitmask[w]); }
-        if (blockIdx.x == 0u && threadIdx.x == 0u) counters[lr.outIndex] = min(all, capacity - (lr.usedIndex == 0xFFFFFFFFu ? 0u : min(counters[lr.usedIndex], capacity)));
+        if (blockIdx.x == 0u && threadIdx.x == 0u) {
+            const uint32_t placed = min(all, capacity - (lr.usedIndex == 0xFFFFFFFFu ? 0u : min(counters[lr.usedIndex], capacity)));
+            counters[lr.outIndex] = placed;
+            if (lr.hostFeedback) __hip_atomic_store(lr.hostFeedback, placed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         __syncthreads();
     }
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += gridDim.x * blockDim.x) {
@@ -1319,6 +1329,14 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
     const uint32_t outIndex = phase == 1 ? CNT_VISIBLE : CNT_VISIBLE2, usedIndex = phase == 1 ? 0xFFFFFFFFu : (uint32_t)CNT_VISIBLE;
     // every workgroup of the scatter scanning the bitmask itself pays off while the bitmask is small (BASELINE-class scenes: ~1-4 k words);
     // from 8 k words on the three scan launches are faster (dense frame, 25 k words: 27 us against 55 us per phase)
+    // phase 2: the ranking kernel also tells the host how many clusters it placed (launch_raster's hint for the frames that follow)
+    if (phase == 2 && !p->phase2FeedbackHost && p->phase2DirectMax != 0u) {
+        if (hipHostMalloc(reinterpret_cast<void**>(&p->phase2FeedbackHost), 64, hipHostMallocMapped) == hipSuccess) {
+            *p->phase2FeedbackHost = 0xFFFFFFFFu;           // unknown: the three launches
+            if (hipHostGetDevicePointer(reinterpret_cast<void**>(&p->phase2FeedbackDev), p->phase2FeedbackHost, 0) != hipSuccess) { (void)hipHostFree(p->phase2FeedbackHost); p->phase2FeedbackHost = nullptr; p->phase2FeedbackDev = nullptr; }
+        } else p->phase2FeedbackHost = nullptr;
+    }
+    uint32_t* feedback = phase == 2 ? p->phase2FeedbackDev : nullptr;
     const bool localRank = p->totalWords <= LOCAL_RANK_WORDS && !p->forceLevelKernels;
     if (localRank) {
         // ranked inside the scatter kernel
@@ -1326,17 +1344,17 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
         if (p->scanBlocks <= SCAN_CHAIN_BLOCKS && p->scanChained) {
             if (++p->scanEpoch == 0u) p->scanEpoch = 1u;
             hipLaunchKernelGGL(k_scan_chained, dim3(p->scanBlocks), dim3(256), 0, s, bitmask, p->totalWords, p->wsPtr<unsigned long long>(p->ws.scanAgg), p->scanEpoch, wordPrefix,
-                               p->counters(), outIndex, p->cfg.maxVisibleClusters, usedIndex);
+                               p->counters(), outIndex, p->cfg.maxVisibleClusters, usedIndex, feedback);
         } else {
             hipLaunchKernelGGL(k_scan_reduce, dim3(p->scanBlocks), dim3(256), 0, s, bitmask, p->totalWords, blockSums);
-            hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, blockSums, p->scanBlocks, p->counters(), outIndex, p->cfg.maxVisibleClusters, usedIndex);
+            hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, blockSums, p->scanBlocks, p->counters(), outIndex, p->cfg.maxVisibleClusters, usedIndex, feedback);
             hipLaunchKernelGGL(k_scan_words, dim3(p->scanBlocks), dim3(256), 0, s, bitmask, p->totalWords, blockSums, wordPrefix);
         }
     }
     auto scatter = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(smallGrid), dim3(256), 0, s, temp, p->counters(), (uint32_t)(phase == 1 ? CNT_TEMP_VISIBLE : CNT_TEMP_VISIBLE2), bitmask, wordPrefix,
                            static_cast<uint4*>(p->res[BRMI_RES_VISIBLE_CLUSTERS]), phase == 1 ? 0xFFFFFFFFu : (uint32_t)CNT_VISIBLE, p->cfg.maxVisibleClusters, p->cfg.maxVisibleClusters, p->scene, p->wsPtr<ClusterSetup>(p->ws.clusterSetup), p->resolveCapacity, p->wsPtr<uint8_t>(p->ws.usedClusters),
-                           (p->sceneHasTextures || p->sceneHasAlphaTest || p->sceneHasVertexColors) ? p->wsPtr<ClusterUv>(p->ws.clusterUv) : nullptr, LocalRank{p->totalWords, outIndex, usedIndex});
+                           (p->sceneHasTextures || p->sceneHasAlphaTest || p->sceneHasVertexColors) ? p->wsPtr<ClusterUv>(p->ws.clusterUv) : nullptr, LocalRank{p->totalWords, outIndex, usedIndex, feedback});
     };
     if (localRank) scatter(k_scatter_visible<true>); else scatter(k_scatter_visible<false>);
     BRMI_LAUNCH_CHECK(p, "compaction");

@@ -170,6 +170,11 @@ struct brmi_pass {
     bool sceneHasAlphaTest = false, sceneHasTextures = false, sceneHasParallax = false;   // some material is alpha tested / samples a texture (brmi_set_scene)
     bool sceneHasCoat = true, sceneHasFuzz = true;   // some OpenPBR material has a coat / fuzz layer (brmi_set_scene)
     std::vector<float> sliceStartHost; float sliceKey[3] = {0, 0, 0}; uint32_t sliceKeyN[2] = {0, 0};   // slice starts of the light-cluster grid and the inputs they were made from
+    // Phase 2 of a frame usually draws nothing or a few dozen clusters; then its triangles all take the row re-deal with global atomics (one
+    // launch instead of k_raster + plan + bins).  Which it is, the host learns from the frames before: the ranking kernel of phase 2 also stores
+    // the survivor count in a host-mapped word that launch_raster reads without waiting (any value is safe: both paths draw the same keys).
+    uint32_t* phase2FeedbackHost = nullptr; uint32_t* phase2FeedbackDev = nullptr;
+    uint32_t phase2DirectMax = 256;   // BRMI_PHASE2_DIRECT_MAX: direct rasterisation while the last known phase-2 count is at most this (0: always bins)
     bool scanChained = true; uint32_t scanEpoch = 0;      // the survivor ranking as one launch (BRMI_SCAN_CHAINED=0: three)
     bool packedFlat = true;          // BRMI_FLAT_PACKED=0: one draw per wave of the traversal
     uint32_t shadeGridShared = 10240; // workgroups of k_shade<0, 3> (BRMI_SHADE_GRID_SHARED): shorter-lived than the stand-alone 8192 so that the other frame's small geometry launches find slots sooner (Bistro-class period 6144 / 8192 / 10240 / 12288: 0.547 / 0.539 / 0.530 / 0.531 ms; Sponza-class, whose geometry half is short: 0.386 / 0.398 / 0.398 / 0.397)

@@ -1384,18 +1384,25 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
     }
     // the pool of k_raster_bins: four 512-thread workgroups per CU is what the LDS holds; phase 2 rarely has an item at all
     const dim3 bgrid(phase == 2 ? std::min(p->binGrid, 256u) : p->binGrid);
+    // Phase 2 draws what phase 1's stale depth chain hid: nothing with a still camera, tens of clusters with a slowly moving one, a thousand
+    // with a fast one.  While the last count the host has seen (a host-mapped word the phase-2 ranking kernel stores, read here without any
+    // wait: a frame or two old) is small, the triangles all take the row re-deal with global atomics -- no records, so no plan and no bins
+    // launch: one launch instead of three on a chain of small launches that each wait for slots while another frame shades.  Above the
+    // limit the three launches pay (1,000 clusters: raster2 0.068 against 0.121 ms).  Either way the same keys.
+    const bool direct2 = phase == 2 && p->phase2FeedbackHost && *reinterpret_cast<volatile uint32_t*>(p->phase2FeedbackHost) <= p->phase2DirectMax && p->phase2DirectMax != 0u;
+    if (direct2) a.bigTriArea = a.bigTriAreaAlpha = a.bigTriAreaDense = 0x3FFFFFFF;
     // phase 2 rarely has more than a handful of clusters: 2048 workgroups (the kernel strides; two waves per SIMD) start and retire a little
     // faster than 8192 that find nothing (-3 us per frame)
     static const uint32_t grid2 = [] { const char* e = std::getenv("BRMI_RASTER_GRID2"); return e ? (uint32_t)std::max(64, std::atoi(e)) : 2048u; }();
     const dim3 rgrid(phase == 2 ? std::min(p->rasterGrid, grid2) : p->rasterGrid);
     if (p->sceneHasAlphaTest) {
         hipLaunchKernelGGL(k_raster<true>, rgrid, dim3(64), 0, s, a);
-        hipLaunchKernelGGL(k_raster_overflow<true>, dim3(129), dim3(256), 0, s, a);
-        if (!(p->rasterDebug & 4)) hipLaunchKernelGGL(k_raster_bins<true>, bgrid, dim3(BRMI_BIN_THREADS), 0, s, a);
+        if (!direct2) hipLaunchKernelGGL(k_raster_overflow<true>, dim3(129), dim3(256), 0, s, a);
+        if (!direct2 && !(p->rasterDebug & 4)) hipLaunchKernelGGL(k_raster_bins<true>, bgrid, dim3(BRMI_BIN_THREADS), 0, s, a);
     } else {
         hipLaunchKernelGGL(k_raster<false>, rgrid, dim3(64), 0, s, a);
-        hipLaunchKernelGGL(k_raster_overflow<false>, dim3(129), dim3(256), 0, s, a);
-        if (!(p->rasterDebug & 4)) hipLaunchKernelGGL(k_raster_bins<false>, bgrid, dim3(BRMI_BIN_THREADS), 0, s, a);
+        if (!direct2) hipLaunchKernelGGL(k_raster_overflow<false>, dim3(129), dim3(256), 0, s, a);
+        if (!direct2 && !(p->rasterDebug & 4)) hipLaunchKernelGGL(k_raster_bins<false>, bgrid, dim3(BRMI_BIN_THREADS), 0, s, a);
     }
     BRMI_LAUNCH_CHECK(p, "k_raster");
     return BRMI_OK;

@@ -43,7 +43,7 @@ WORKLOADS = {"sponza": ("sponza", {}, 0),
 LIGHTS = {"sponza": 64, "bistro": 256, "bistro_r2": 256, "san_miguel": 256, "bistro_dense": 256}
 BASELINE_CONFIG = {"sponza": "configs[1]", "bistro": "configs[2]", "bistro_r2": "configs[2], the instanced-budget frame of rounds 1-2", "san_miguel": "configs[3]",
                    "bistro_dense": "configs[2], dense geometry"}
-PATH_STEP = 0.02        # --camera-path: position on the preset's camera path advances by this much per frame (one unit = 0.35 m sideways, 0.6 m ahead, 4 degrees)
+PATH_STEP = float(os.environ.get("BRMI_BENCH_PATH_STEP", "0.02"))        # --camera-path: position on the preset's camera path advances by this much per frame (one unit = 0.35 m sideways, 0.6 m ahead, 4 degrees)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md)
 VALU_PEAK_WAVE_INSTS = 1.2288e12   # wave64 VALU instructions per second: 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles (MI355X_MICROARCH.md, cycle constants)
 # ... and what tools/valu_issue_probe.hip measured on the box (profiles/r03_valu_issue_probe.txt): independent v_fma / v_mul / v_mov streams at 2-4 waves
