@@ -993,6 +993,35 @@ def test_occlusion_two_phase_cluster_lists_exact(name, occlusion_runs):
         assert replayed > 0, "the case does not exercise the replay path"
 
 
+@pytest.mark.parametrize("direct_max", [0, 1 << 30])
+@pytest.mark.parametrize("name", list(OCCLUSION_CASES))
+def test_phase_two_rasterises_the_same_keys_with_and_without_bins(name, direct_max, occlusion_runs):
+    """Phase 2 sends its triangles through the bins (plan + pool) or, while the last survivor count the host has seen is small, through
+    k_raster's direct walk alone (BRMI_PHASE2_DIRECT_MAX; 0 = always the bins, huge = direct as soon as a count has arrived).  The same three
+    frames as the fixture's run (which uses the default limit): identical keys and depth either way."""
+    from conftest import Scene
+    from basicrenderer_amd.renderer import VisibilityRenderer
+    frames = occlusion_runs(name)
+    preset, W, H, kw = OCCLUSION_CASES[name]
+    r = None
+    with _Env(BRMI_PHASE2_DIRECT_MAX=direct_max):
+        r = VisibilityRenderer(frames[0]["scene"], occlusion=True, stats=True)
+    drew = 0
+    for step, f in enumerate(frames):
+        if step:
+            r.set_camera_from(f["scene"], frame_index=step)
+        r.execute()
+        __import__("torch").cuda.synchronize()              # (the count of this frame's phase 2 has reached the host before the next frame chooses)
+        c = r.counters()
+        drew += c.visibleClustersPhase2
+        assert np.array_equal(r.visible_clusters(), f["clusters"]), f"frame {step}"
+        assert np.array_equal(r.visibility(), f["vis"]), f"frame {step}"
+        assert np.array_equal(r.depth().view(np.uint32), f["depth"].view(np.uint32)), f"frame {step}"
+    r.close()
+    if name != "tiny_odd":
+        assert drew > 0, "phase 2 drew nothing in this case"
+
+
 @pytest.mark.parametrize("name", list(OCCLUSION_CASES))
 def test_occlusion_hzb_chain_bit_exact(name, occlusion_runs):
     for f in occlusion_runs(name):
