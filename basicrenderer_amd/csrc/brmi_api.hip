@@ -119,7 +119,7 @@ static void compute_sizes(brmi_pass* p) {
     w.pageTotal = take(16);
     w.lightHitMasks = take((uint64_t)p->numLightClusters * ((std::max(1u, p->scene.lightCount) + 63u) / 64u) * 8);
     p->binsX = (c.width + 255) / 256; p->binsY = (c.height + 15) / 16;
-    w.binCounts = take((uint64_t)p->binsX * p->binsY * 4);
+    w.binCounts = take((uint64_t)p->binsX * p->binsY * 4 * BRMI_BIN_COUNT_STRIDE);
     w.binRecords = take((uint64_t)p->binsX * p->binsY * p->binCapacity * 64);
     w.binOverflow = take((uint64_t)CNT_STRIPE_COUNT * p->binOverflowPerStripe * 64);
     // the plan of a k_raster_bins launch: header, three words per bin, the (bin, slice) items; scratch tiles of 32 KB for the slices of bins

@@ -10,6 +10,9 @@
 #include "brmi.h"
 #include "brmi_device.h"
 
+#ifndef BRMI_BIN_COUNT_STRIDE
+#define BRMI_BIN_COUNT_STRIDE 32      // words between the record counters of two raster bins (brmi_raster.hip)
+#endif
 namespace brmi {
 
 // device-visible counters block (u32 words) at the head of the workspace

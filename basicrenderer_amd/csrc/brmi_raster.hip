@@ -46,6 +46,9 @@ static_assert(sizeof(AlphaRecord) == 48, "AlphaRecord layout");
 constexpr int BIN_W = 256, BIN_ROWS = 16;          // bin = 4096 keys = 32 KB of LDS
 constexpr int BIN_W_SHIFT = 8, BIN_ROWS_SHIFT = 4;
 constexpr uint32_t BIN_SLICE = 1024;               // records of a bin one workgroup of k_raster_bins walks
+// a bin's record counter has a 128 B line to itself: atomics on ONE cache line serialise at 50-90 per microsecond whatever their addresses, and
+// the bins of a screen band (15 neighbours in one line, the horizon's among them) take thousands of slot reservations per frame
+constexpr uint32_t BIN_COUNT_STRIDE = BRMI_BIN_COUNT_STRIDE;
 constexpr int BIN_WINDOW = 256;                     // bins a wave can count in LDS at once (cells of its bin bounding box)
 constexpr int COOP_ENTRIES = 64;                    // triangles with more bin entries than this are emitted by the whole wave
 
@@ -239,7 +242,7 @@ BRMI_DEV void bin_store(const RasterArgs& a, const float* unorm, const BinRecord
     else raster_record_global(a, r, NoAlpha{}, strip, 0u, 1u);
 }
 BRMI_DEV void bin_append(const RasterArgs& a, const float* unorm, const BinRecord& r, const AlphaRecord& ar, uint32_t strip, uint32_t band) {
-    bin_store(a, unorm, r, ar, strip, band, atomicAdd(&a.binCounts[band * a.binsX + strip], 1u));
+    bin_store(a, unorm, r, ar, strip, band, atomicAdd(&a.binCounts[(size_t)(band * a.binsX + strip) * BIN_COUNT_STRIDE], 1u));
 }
 
 // three waves per SIMD (<= 168 VGPRs; the unconstrained kernel takes 181 and runs two): Bistro raster 122 -> 115 us, San Miguel 192 -> 182 us;
@@ -443,7 +446,7 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
                     for (int k = 0; k < BIN_WINDOW / 64; k++) {
                         const int cI = (int)lane + 64 * k;
                         resvCount[k] = cI < cells ? binBase[cI] : 0u;
-                        if (resvCount[k] != 0u) resvBase[k] = atomicAdd(&a.binCounts[vband(wb0 + cI / winW) * a.binsX + (uint32_t)(ws0 + cI % winW)], resvCount[k]);
+                        if (resvCount[k] != 0u) resvBase[k] = atomicAdd(&a.binCounts[(size_t)(vband(wb0 + cI / winW) * a.binsX + (uint32_t)(ws0 + cI % winW)) * BIN_COUNT_STRIDE], resvCount[k]);
                     }
                 }
             }
@@ -559,7 +562,7 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
                     for (int st0 = c_strip0; st0 <= c_strip1; st0 += 8) {
                         uint32_t slots[8];
 #pragma unroll
-                        for (int k = 0; k < 8; k++) slots[k] = (st0 + k <= c_strip1) ? atomicAdd(&a.binCounts[vb * a.binsX + (uint32_t)(st0 + k)], 1u) : 0u;
+                        for (int k = 0; k < 8; k++) slots[k] = (st0 + k <= c_strip1) ? atomicAdd(&a.binCounts[(size_t)(vb * a.binsX + (uint32_t)(st0 + k)) * BIN_COUNT_STRIDE], 1u) : 0u;
 #pragma unroll
                         for (int k = 0; k < 8; k++) if (st0 + k <= c_strip1) bin_store(a, unormT, r, c_arec, (uint32_t)(st0 + k), vb, slots[k]);
                     }
@@ -895,13 +898,13 @@ BRMI_DEV void plan_bins(const RasterArgs& a) {
     for (uint32_t b0 = 0; b0 < nBins; b0 += 8u * blockDim.x) {
         uint32_t n[8];
 #pragma unroll
-        for (uint32_t k = 0; k < 8u; k++) { const uint32_t b = b0 + k * blockDim.x + threadIdx.x; n[k] = b < nBins ? min(a.binCounts[b], a.binCapacity) : 0u; }      // eight loads in flight
+        for (uint32_t k = 0; k < 8u; k++) { const uint32_t b = b0 + k * blockDim.x + threadIdx.x; n[k] = b < nBins ? min(a.binCounts[(size_t)b * BIN_COUNT_STRIDE], a.binCapacity) : 0u; }      // eight loads in flight
 #pragma unroll
         for (uint32_t k = 0; k < 8u; k++) {
             const uint32_t b = b0 + k * blockDim.x + threadIdx.x;
             if (b >= nBins) continue;
             const uint32_t sc = slices_of(n[k]);
-            a.binCounts[b] = 0u; binN[b] = n[k]; binDone[b] = 0u;
+            a.binCounts[(size_t)b * BIN_COUNT_STRIDE] = 0u; binN[b] = n[k]; binDone[b] = 0u;
             uint32_t slot = 0xFFFFFFFFu;
             if (sc > 1u) { const uint32_t base = atomicAdd(&tileRun, sc); if (base + sc <= a.binScratchTiles) slot = base; }      // (any order: a tile range per shared bin)
             binSlot[b] = slot;
