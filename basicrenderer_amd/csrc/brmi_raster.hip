@@ -1392,7 +1392,9 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
     // wait: a frame or two old) is small, the triangles all take the row re-deal with global atomics -- no records, so no plan and no bins
     // launch: one launch instead of three on a chain of small launches that each wait for slots while another frame shades.  Above the
     // limit the three launches pay (1,000 clusters: raster2 0.068 against 0.121 ms).  Either way the same keys.
-    const bool direct2 = phase == 2 && p->phase2FeedbackHost && *reinterpret_cast<volatile uint32_t*>(p->phase2FeedbackHost) <= p->phase2DirectMax && p->phase2DirectMax != 0u;
+    // (not in scenes with alpha-tested materials: a tested pixel costs three times as much through the global chain as in a bin, and the
+    // San-Miguel-class camera path got 9 % slower with 19 phase-2 clusters per frame)
+    const bool direct2 = phase == 2 && !p->sceneHasAlphaTest && p->phase2FeedbackHost && *reinterpret_cast<volatile uint32_t*>(p->phase2FeedbackHost) <= p->phase2DirectMax && p->phase2DirectMax != 0u;
     if (direct2) a.bigTriArea = a.bigTriAreaAlpha = a.bigTriAreaDense = 0x3FFFFFFF;
     // phase 2 rarely has more than a handful of clusters: 2048 workgroups (the kernel strides; two waves per SIMD) start and retire a little
     // faster than 8192 that find nothing (-3 us per frame)
