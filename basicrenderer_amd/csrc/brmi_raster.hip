@@ -14,9 +14,11 @@
 //   * Sort-middle for everything larger: 64-bit global atomics are element-serialised in L2 (~100 G/s on
 //     MI355X, measured), so a frame with 3x overdraw of large triangles spends its time there.  Larger
 //     triangles are cut into records of <= 16 rows and appended to screen bins (256 px x 16 rows).
-//     k_raster_bins gives every bin to one workgroup: it walks the records one lane per row with LDS
-//     atomic-min into a 32 KB tile of keys and merges the tile into the visibility buffer once, with plain
-//     coalesced 64 B loads / stores (the bin is exclusively owned; k_raster has finished).
+//     k_raster_bins is a pool of workgroups that take (bin, slice) items, longest first, from a plan the launch before wrote
+//     (k_raster_overflow's last workgroup); a slice's records are counting-sorted by rows and row length (4, 8 or 16 lanes per
+//     record), walked with LDS atomic-min into a 32 KB tile of keys, and the tile is merged into the visibility buffer once with
+//     plain coalesced 64 B loads / stores (a bin one workgroup walks is exclusively owned; the slices of a larger bin park their
+//     tiles and the last one folds them).  Phase 2 of a frame, while it draws little, skips the bins altogether.
 //   * Per-pixel arithmetic is untouched by the re-scheduling: a lane that enters a row in the middle
 //     (bin strip) steps the barycentrics pixel by pixel from the row start exactly as the serial loop does.
 //   * the visibility surface is stored in 8x8 tiles (512 B = 4 cache lines), column-major inside the tile, so
