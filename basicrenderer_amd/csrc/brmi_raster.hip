@@ -917,7 +917,7 @@ BRMI_DEV void plan_bins(const RasterArgs& a) {
     if (threadIdx.x == 0) { uint32_t run = 0; for (int c = 15; c >= 0; c--) { classBase[c] = run; run += classCount[c]; } a.binPlan[0] = run; a.binPlan[1] = 0u; a.binPlan[2] = tileRun; }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < nBins; b += blockDim.x) {
-        const uint32_t n = binN[b], sc = slices_of(n);
+        const uint32_t n = __hip_atomic_load(&binN[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), sc = slices_of(n);      // (this thread's own store of a moment ago)
         if (sc == 0u) continue;
         const uint32_t at = atomicAdd(&classBase[class_of(n, sc)], sc);
         for (uint32_t z = 0; z < sc; z++) if (at + z < a.binItemCapacity) a.binItems[at + z] = b | (z << 16) | ((sc - 1u) << 24);
@@ -929,10 +929,10 @@ BRMI_DEV void plan_bins(const RasterArgs& a) {
 // cleared with the frame's counters and, between the two raster phases, by k_seed_phase2.
 template <bool ALPHA>
 __global__ void __launch_bounds__(256) k_raster_overflow(RasterArgs a) {
-    if (blockIdx.x == gridDim.x - 1u) { plan_bins(a); return; }
+    if (blockIdx.x == 0u) { plan_bins(a); return; }       // (the first workgroup: it is what the next launch waits for, so it should not queue behind the walkers)
     // a wave = four records at a time, one lane per row
     const uint32_t lane = threadIdx.x & 63u, sub = lane >> 4, row = lane & 15u;
-    const uint32_t walker = blockIdx.x * 4u + (threadIdx.x >> 6), walkers = (gridDim.x - 1u) * 4u;
+    const uint32_t walker = (blockIdx.x - 1u) * 4u + (threadIdx.x >> 6), walkers = (gridDim.x - 1u) * 4u;
     __shared__ float unormT[ALPHA ? 256 : 1];
     if (ALPHA) { unormT[threadIdx.x] = (float)threadIdx.x / 255.0f; __syncthreads(); }
     // lane = stripe: all 64 queue lengths with one load; nearly every frame has none
