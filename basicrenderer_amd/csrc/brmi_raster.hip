@@ -892,17 +892,22 @@ BRMI_DEV void plan_bins(const RasterArgs& a) {
     __shared__ uint32_t classCount[16], classBase[16], tileRun;
     const uint32_t nBins = a.binsX * a.binsY;
     uint32_t* binN = a.binPlan + 16, * binSlot = binN + nBins, * binDone = binSlot + nBins;
+    // LDS hand-offs between the block's waves: the LDS operations have to be done, not the global stores (which only this thread reads
+    // again, if at all) -- __syncthreads() would wait for those too, a memory round trip per barrier on the next launch's critical path
+    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     if (threadIdx.x < 16u) classCount[threadIdx.x] = 0u;
     if (threadIdx.x == 0) tileRun = 0u;
-    __syncthreads();
+    lds_barrier();
     auto slices_of = [&](uint32_t n) { return n == 0u ? 0u : n <= a.binMinSlice ? 1u : min((n + a.binSharedSlice - 1u) / a.binSharedSlice, 256u); };
     auto class_of = [&](uint32_t n, uint32_t sc) { const uint32_t len = (n + sc - 1u) / sc; return 31u - (uint32_t)__clz(len); };      // log2 of the slice length (< 16: a slice holds < 65536 records)
-    for (uint32_t b0 = 0; b0 < nBins; b0 += 8u * blockDim.x) {
-        uint32_t n[8];
+    constexpr uint32_t K = 8;
+    const bool oneChunk = nBins <= K * blockDim.x;      // (every frame up to 8K: a thread keeps its bins' counts in registers between the passes)
+    uint32_t n[K];
+    for (uint32_t b0 = 0; b0 < nBins; b0 += K * blockDim.x) {
 #pragma unroll
-        for (uint32_t k = 0; k < 8u; k++) { const uint32_t b = b0 + k * blockDim.x + threadIdx.x; n[k] = b < nBins ? min(a.binCounts[(size_t)b * BIN_COUNT_STRIDE], a.binCapacity) : 0u; }      // eight loads in flight
+        for (uint32_t k = 0; k < K; k++) { const uint32_t b = b0 + k * blockDim.x + threadIdx.x; n[k] = b < nBins ? min(a.binCounts[(size_t)b * BIN_COUNT_STRIDE], a.binCapacity) : 0u; }      // eight loads in flight
 #pragma unroll
-        for (uint32_t k = 0; k < 8u; k++) {
+        for (uint32_t k = 0; k < K; k++) {
             const uint32_t b = b0 + k * blockDim.x + threadIdx.x;
             if (b >= nBins) continue;
             const uint32_t sc = slices_of(n[k]);
@@ -913,14 +918,19 @@ BRMI_DEV void plan_bins(const RasterArgs& a) {
             if (sc != 0u) atomicAdd(&classCount[class_of(n[k], sc)], sc);
         }
     }
-    __syncthreads();
+    lds_barrier();
     if (threadIdx.x == 0) { uint32_t run = 0; for (int c = 15; c >= 0; c--) { classBase[c] = run; run += classCount[c]; } a.binPlan[0] = run; a.binPlan[1] = 0u; a.binPlan[2] = tileRun; }
-    __syncthreads();
-    for (uint32_t b = threadIdx.x; b < nBins; b += blockDim.x) {
-        const uint32_t n = __hip_atomic_load(&binN[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), sc = slices_of(n);      // (this thread's own store of a moment ago)
-        if (sc == 0u) continue;
-        const uint32_t at = atomicAdd(&classBase[class_of(n, sc)], sc);
-        for (uint32_t z = 0; z < sc; z++) if (at + z < a.binItemCapacity) a.binItems[at + z] = b | (z << 16) | ((sc - 1u) << 24);
+    lds_barrier();
+    for (uint32_t b0 = 0; b0 < nBins; b0 += K * blockDim.x) {
+#pragma unroll
+        for (uint32_t k = 0; k < K; k++) {
+            const uint32_t b = b0 + k * blockDim.x + threadIdx.x;
+            if (b >= nBins) continue;
+            const uint32_t nb = oneChunk ? n[k] : binN[b], sc = slices_of(nb);
+            if (sc == 0u) continue;
+            const uint32_t at = atomicAdd(&classBase[class_of(nb, sc)], sc);
+            for (uint32_t z = 0; z < sc; z++) if (at + z < a.binItemCapacity) a.binItems[at + z] = b | (z << 16) | ((sc - 1u) << 24);
+        }
     }
 }
 
@@ -929,6 +939,15 @@ BRMI_DEV void plan_bins(const RasterArgs& a) {
 // cleared with the frame's counters and, between the two raster phases, by k_seed_phase2.
 template <bool ALPHA>
 __global__ void __launch_bounds__(256) k_raster_overflow(RasterArgs a) {
+#ifdef BRMI_TILE_STAMPS
+    if (blockIdx.x == 0u) {        // (instrumented builds: how long the plan takes, in 10 ns units; slots 40 / 41 of the stamp words)
+        const unsigned long long t0_ = __builtin_amdgcn_s_memrealtime();
+        plan_bins(a);
+        __syncthreads();
+        if (threadIdx.x == 0 && (a.debugFlags & 0x400)) { atomicAdd(a.debugStamps + 40u, __builtin_amdgcn_s_memrealtime() - t0_); atomicAdd(a.debugStamps + 41u, 1ull); }
+        return;
+    }
+#endif
     if (blockIdx.x == 0u) { plan_bins(a); return; }       // (the first workgroup: it is what the next launch waits for, so it should not queue behind the walkers)
     // a wave = four records at a time, one lane per row
     const uint32_t lane = threadIdx.x & 63u, sub = lane >> 4, row = lane & 15u;
