@@ -625,7 +625,7 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES
     // last folds the others' tiles into its own and merges once, plainly -- no per-key atomics (as atomic-min merges, eight keys of a 64 B line
     // from several slices at a time, slices shorter than 1024 records LOST: raster 0.22 -> 0.25 -> 0.29 ms at 512 / 256).
     // Why a list: a grid of (bins x slices) workgroups started in grid order; a slice of 1024 records that started 30 us into the launch ended
-    // it at 126 us while the balanced load was 56 us, and 14,000 of the 16,200 workgroups found nothing (scratch/bins_timeline.py).
+    // it at 126 us while the balanced load was 56 us, and 14,000 of the 16,200 workgroups found nothing (tools/bins_timeline.py).
     __shared__ uint32_t curItem, doneBefore;
     const uint32_t itemCount = min(a.binPlan[0], a.binItemCapacity), nBins = a.binsX * a.binsY;
     const uint32_t* binN = a.binPlan + 16, * binSlot = binN + nBins; uint32_t* binDone = a.binPlan + 16 + 2u * nBins;

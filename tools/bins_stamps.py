@@ -1,0 +1,27 @@
+import os, sys, ctypes as C
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+from basicrenderer_amd import Scene, capi
+from basicrenderer_amd.renderer import VisibilityRenderer
+import bench
+wl = sys.argv[1]
+preset, kw, feat = bench.WORKLOADS[wl]
+sc = Scene(preset, 3840, 2160, point_lights=256, material_features=feat, **kw)
+r = VisibilityRenderer(sc, occlusion=True, stats=True)
+frames = 4
+for _ in range(frames):
+    r.execute()
+torch.cuda.synchronize()
+buf = np.zeros(64, dtype=np.uint64)
+r.lib.brmi_debug_read_bin_records.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+assert r.lib.brmi_debug_read_bin_records(r._h, buf.ctypes.data, buf.nbytes | (1 << 63)) == 0
+ph = buf[32:40].astype(np.float64)
+names = ["tile clear + barrier", "record walk: opaque rows (+ listing alpha records)", "alpha task list (scan of segment counts)", "alpha tasks: texcoord, texel fetch, filter, LDS min", "barrier before the merge (waiting for the slowest wave)", "merge into the visibility buffer"]
+tot = ph.sum()
+print(wl, "k_raster_bins phase shares (wave-cycles of every wave) over", frames, "frames; total %.3f G" % (tot / 1e9))
+for n, v in zip(names, ph):
+    print("  %5.1f %%  %s" % (100 * v / tot, n))
+ph2 = buf[16:24].astype(np.float64); names2 = ["cluster fetch", "vertex stage", "triangle setup", "small boxes: global atomic-min (+ alpha test)", "bin records, few bins", "bin records, whole wave", "bin records, few bins, window too small (slot by slot)", "loop overhead"]
+print(wl, "k_raster phase shares; total %.3f G" % (ph2.sum() / 1e9))
+for n, v in zip(names2, ph2):
+    if n != "-": print("  %5.1f %%  %s" % (100 * v / ph2.sum(), n))

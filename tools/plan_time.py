@@ -1,0 +1,17 @@
+import os, sys, ctypes as C
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+from basicrenderer_amd import Scene
+from basicrenderer_amd.renderer import VisibilityRenderer
+import bench
+for wl in ("bistro", "bistro_dense", "sponza"):
+    preset, kw, feat = bench.WORKLOADS[wl]
+    sc = Scene(preset, 3840, 2160, point_lights=256, material_features=feat, **kw)
+    r = VisibilityRenderer(sc, occlusion=True, stats=True)
+    for _ in range(6): r.execute()
+    torch.cuda.synchronize()
+    buf = np.zeros(64, dtype=np.uint64)
+    r.lib.brmi_debug_read_bin_records.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    assert r.lib.brmi_debug_read_bin_records(r._h, buf.ctypes.data, buf.nbytes | (1 << 63)) == 0
+    print(wl, "plan_bins: %.2f us per launch over %d launches" % (buf[40] / max(1, buf[41]) / 100.0, buf[41]), "| thread 0: counts arrive %.2f, pass 1 %.2f, barrier + bases %.2f, pass 2 %.2f us" % tuple(buf[42 + i] / max(1, buf[41]) / 100.0 for i in range(4)))
+    r.close()
