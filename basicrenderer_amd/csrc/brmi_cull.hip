@@ -1330,12 +1330,7 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
     // every workgroup of the scatter scanning the bitmask itself pays off while the bitmask is small (BASELINE-class scenes: ~1-4 k words);
     // from 8 k words on the three scan launches are faster (dense frame, 25 k words: 27 us against 55 us per phase)
     // phase 2: the ranking kernel also tells the host how many clusters it placed (launch_raster's hint for the frames that follow)
-    if (phase == 2 && !p->phase2FeedbackHost && p->phase2DirectMax != 0u) {
-        if (hipHostMalloc(reinterpret_cast<void**>(&p->phase2FeedbackHost), 64, hipHostMallocMapped) == hipSuccess) {
-            *p->phase2FeedbackHost = 0xFFFFFFFFu;           // unknown: the three launches
-            if (hipHostGetDevicePointer(reinterpret_cast<void**>(&p->phase2FeedbackDev), p->phase2FeedbackHost, 0) != hipSuccess) { (void)hipHostFree(p->phase2FeedbackHost); p->phase2FeedbackHost = nullptr; p->phase2FeedbackDev = nullptr; }
-        } else p->phase2FeedbackHost = nullptr;
-    }
+    if (phase == 2 && p->phase2DirectMax != 0u) (void)p->ensureFeedback();
     uint32_t* feedback = phase == 2 ? p->phase2FeedbackDev : nullptr;
     const bool localRank = p->totalWords <= LOCAL_RANK_WORDS && !p->forceLevelKernels;
     if (localRank) {

@@ -176,7 +176,14 @@ struct brmi_pass {
     // Phase 2 of a frame usually draws nothing or a few dozen clusters; then its triangles all take the row re-deal with global atomics (one
     // launch instead of k_raster + plan + bins).  Which it is, the host learns from the frames before: the ranking kernel of phase 2 also stores
     // the survivor count in a host-mapped word that launch_raster reads without waiting (any value is safe: both paths draw the same keys).
-    uint32_t* phase2FeedbackHost = nullptr; uint32_t* phase2FeedbackDev = nullptr;
+    uint32_t* phase2FeedbackHost = nullptr; uint32_t* phase2FeedbackDev = nullptr;      // word 0: phase-2 survivors; word 1: the frame had more than half a triangle per pixel (k_mark_used_clusters has work)
+    bool ensureFeedback() {          // the 64 B host-mapped block, made at first use; false: none (the callers then take their always-safe paths)
+        if (phase2FeedbackHost) return true;
+        if (hipHostMalloc(reinterpret_cast<void**>(&phase2FeedbackHost), 64, hipHostMallocMapped) != hipSuccess) { phase2FeedbackHost = nullptr; return false; }
+        phase2FeedbackHost[0] = 0xFFFFFFFFu; phase2FeedbackHost[1] = 1u;           // unknown: the general paths
+        if (hipHostGetDevicePointer(reinterpret_cast<void**>(&phase2FeedbackDev), phase2FeedbackHost, 0) != hipSuccess) { (void)hipHostFree(phase2FeedbackHost); phase2FeedbackHost = nullptr; phase2FeedbackDev = nullptr; return false; }
+        return true;
+    }
     uint32_t phase2DirectMax = 256;   // BRMI_PHASE2_DIRECT_MAX: direct rasterisation while the last known phase-2 count is at most this (0: always bins)
     bool scanChained = true; uint32_t scanEpoch = 0;      // the survivor ranking as one launch (BRMI_SCAN_CHAINED=0: three)
     bool packedFlat = true;          // BRMI_FLAT_PACKED=0: one draw per wave of the traversal

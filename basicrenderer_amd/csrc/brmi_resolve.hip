@@ -32,6 +32,7 @@ struct GBufferArgs {
     const m4* frameConst; const float* objConst;
     const ClusterSetup* setup; ResolveVertex* verts; ResolveTriangle* tris; uint32_t vertCapacity, triCapacity;
     MaterialWords* matWords;
+    uint32_t* hostFeedback;        // host-mapped words (brmi_pass::ensureFeedback) or null
     const uint8_t* used;           // per visible cluster: owns a pixel (valid when counters[CNT_RESOLVE_MARKED])
     const ClusterUv* clusterUv; float2* uvs;      // textured scenes: where the UV sets of every visible cluster live, decoded texcoords of the arena's vertices
     uint32_t uvSets;                              // sets the materials of the scene address (1 unless one names a set > 0): uvs holds [set][vertCapacity]
@@ -81,6 +82,10 @@ __global__ void __launch_bounds__(64) k_resolve_setup(GBufferArgs a) {
     const uint32_t lane = threadIdx.x;
     const uint32_t clusterCount = min(a.counters[CNT_VISIBLE] + a.counters[CNT_VISIBLE2], a.clusterCapacity);
     const bool marked = a.counters[CNT_RESOLVE_MARKED] != 0u;
+    if (blockIdx.x == 0u && lane == 0u && a.hostFeedback) {      // tell the host whether frames like this one need the marking pass (its hint for the next frames)
+        const uint64_t tris = ((uint64_t)a.counters[CNT_SUM_TRIS_HI] << 32) | a.counters[CNT_SUM_TRIS_LO];
+        __hip_atomic_store(a.hostFeedback + 1, tris * 2ull > a.pixelCount ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     for (uint32_t c = blockIdx.x; c < clusterCount; c += gridDim.x) {
         if (marked && a.used[c] == 0) continue;      // no pixel shows this cluster
         const ClusterSetup cs = a.setup[c];
@@ -597,6 +602,7 @@ __global__ void __launch_bounds__(256, BRMI_FUSED_WAVES) k_gbuffer_shade(GBuffer
 
 static GBufferArgs gbuffer_args_of(brmi_pass* p) {
     GBufferArgs a;
+    a.hostFeedback = nullptr;
     a.sc = shading_scene_of(p);      // the frame's camera / per-frame record as the constants kernel saw them (FrameSnapshot)
     a.clusters = static_cast<const uint4*>(p->res[BRMI_RES_VISIBLE_CLUSTERS]); a.counters = p->counters();
     a.vis = static_cast<const unsigned long long*>(p->res[BRMI_RES_VISIBILITY]);
@@ -623,10 +629,13 @@ static GBufferArgs gbuffer_args_of(brmi_pass* p) {
 // needs the final cluster list and keys only), so that the shading half starts with the pixel pass.
 int launch_resolve_setup(brmi_pass* p, hipStream_t s) {
     if (int rc = ensure_frame_constants(p, s)) return rc;
-    const GBufferArgs a = gbuffer_args_of(p);
+    GBufferArgs a = gbuffer_args_of(p);
+    a.hostFeedback = p->ensureFeedback() ? p->phase2FeedbackDev : nullptr;
     // the marking pass only acts on frames with more than half a triangle per pixel; no cut through the scene's DAGs has more triangles than all
     // its meshlets together (totalBits: one survivor bit per meshlet of every instance), so most scenes can never be such a frame
-    if ((uint64_t)p->totalBits * BRMI_MESHLET_MAX_TRIS * 2ull > p->bandPixelCount)
+    // ... and whether recent frames were of that kind the host reads from a word k_resolve_setup stores (no wait; a stale "no" only means
+    // that this frame's setup covers every visible cluster, which is always correct)
+    if ((uint64_t)p->totalBits * BRMI_MESHLET_MAX_TRIS * 2ull > p->bandPixelCount && (!a.hostFeedback || reinterpret_cast<volatile uint32_t*>(p->phase2FeedbackHost)[1] != 0u))
         hipLaunchKernelGGL(k_mark_used_clusters, dim3(2048), dim3(256), 0, s, a, p->wsPtr<uint8_t>(p->ws.usedClusters), p->counters());
     hipLaunchKernelGGL(k_resolve_setup, dim3(8192), dim3(64), 0, s, a);
     BRMI_LAUNCH_CHECK(p, "k_resolve_setup");
