@@ -236,6 +236,7 @@ int brmi_create(const brmi_config* cfg, brmi_pass** out) {
     if (const char* e = std::getenv("BRMI_SHADE_GRID_SHARED")) p->shadeGridShared = (uint32_t)std::min(65535, std::max(256, std::atoi(e)));
     if (const char* e = std::getenv("BRMI_GBUFFER_GRID_SHARED")) p->gbufferGridShared = (uint32_t)std::min(65535, std::max(256, std::atoi(e)));
     if (const char* e = std::getenv("BRMI_PHASE2_DIRECT_MAX")) p->phase2DirectMax = (uint32_t)std::max(0, std::atoi(e));
+    if (const char* e = std::getenv("BRMI_CLEAR_RIDER_BLOCKS")) p->clearRiderBlocks = (uint32_t)std::min(65535, std::max(64, std::atoi(e)));
     if (const char* e = std::getenv("BRMI_SCAN_CHAINED")) p->scanChained = std::atoi(e) != 0;
     if (const char* e = std::getenv("BRMI_FLAT_PACKED")) p->packedFlat = std::atoi(e) != 0;
     if (const char* e = std::getenv("BRMI_BIN_MIN_SLICE")) p->binMinSlice = (uint32_t)std::max(32, std::atoi(e));

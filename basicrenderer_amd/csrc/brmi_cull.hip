@@ -1291,7 +1291,7 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
             const bool wide = p->maxLevelWidth > 256u;
             const uint32_t widthHi = spillMode ? widthAll : (wide ? HIER_CAP_MAX : 256u);
             if (p->clearVisibilityWithTraversal) {
-                SideJobs sj{reinterpret_cast<ulonglong2*>(static_cast<unsigned long long*>(p->res[BRMI_RES_VISIBILITY]) + p->bandFirstPixel), p->bandPixelCount >> 1, hgrid.x, 8192u, cluster_args_of(p)};
+                SideJobs sj{reinterpret_cast<ulonglong2*>(static_cast<unsigned long long*>(p->res[BRMI_RES_VISIBILITY]) + p->bandFirstPixel), p->bandPixelCount >> 1, hgrid.x, p->clearRiderBlocks, cluster_args_of(p)};
                 const dim3 grid(hgrid.x + sj.clearBlocks + p->numLightClusters);
                 if (wide) hipLaunchKernelGGL((k_cull_hierarchy<false, 1024, BRMI_HIER_STAGE_WIDE, true>), grid, dim3(64), 0, s, a, buckets, meshWidth, 0u, widthHi, spillAbove, fa, sj);
                 else hipLaunchKernelGGL((k_cull_hierarchy<false, 256, 128, true>), grid, dim3(64), 0, s, a, buckets, meshWidth, 0u, widthHi, spillAbove, fa, sj);

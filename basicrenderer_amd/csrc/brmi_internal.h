@@ -185,6 +185,7 @@ struct brmi_pass {
         return true;
     }
     uint32_t phase2DirectMax = 256;   // BRMI_PHASE2_DIRECT_MAX: direct rasterisation while the last known phase-2 count is at most this (0: always bins)
+    uint32_t clearRiderBlocks = 8192; // single-wave workgroups of the visibility clear that ride on the traversal launch (BRMI_CLEAR_RIDER_BLOCKS)
     bool scanChained = true; uint32_t scanEpoch = 0;      // the survivor ranking as one launch (BRMI_SCAN_CHAINED=0: three)
     bool packedFlat = true;          // BRMI_FLAT_PACKED=0: one draw per wave of the traversal
     uint32_t shadeGridShared = 10240; // workgroups of k_shade<0, 3> (BRMI_SHADE_GRID_SHARED): shorter-lived than the stand-alone 8192 so that the other frame's small geometry launches find slots sooner (Bistro-class period 6144 / 8192 / 10240 / 12288: 0.547 / 0.539 / 0.530 / 0.531 ms; Sponza-class, whose geometry half is short: 0.386 / 0.398 / 0.398 / 0.397)
