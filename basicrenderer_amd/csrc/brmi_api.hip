@@ -237,6 +237,7 @@ int brmi_create(const brmi_config* cfg, brmi_pass** out) {
     if (const char* e = std::getenv("BRMI_GBUFFER_GRID_SHARED")) p->gbufferGridShared = (uint32_t)std::min(65535, std::max(256, std::atoi(e)));
     if (const char* e = std::getenv("BRMI_PHASE2_DIRECT_MAX")) p->phase2DirectMax = (uint32_t)std::max(0, std::atoi(e));
     if (const char* e = std::getenv("BRMI_CLEAR_RIDER_BLOCKS")) p->clearRiderBlocks = (uint32_t)std::min(65535, std::max(64, std::atoi(e)));
+    if (const char* e = std::getenv("BRMI_FLAT_WIDE")) p->wideFlat = std::atoi(e) != 0;
     if (const char* e = std::getenv("BRMI_SCAN_CHAINED")) p->scanChained = std::atoi(e) != 0;
     if (const char* e = std::getenv("BRMI_FLAT_PACKED")) p->packedFlat = std::atoi(e) != 0;
     if (const char* e = std::getenv("BRMI_BIN_MIN_SLICE")) p->binMinSlice = (uint32_t)std::max(32, std::atoi(e));
@@ -432,7 +433,7 @@ int brmi_set_scene(brmi_pass* p, const brmi_scene_buffers* scene) {
         p->hostInstanceBitBase[i] = (uint32_t)bits; bits += meshBits[offs[i].clodMeshMetadataIndex];
         if (bits > 0xFFFFFFF0ull) return fail(p, BRMI_ERR_CAPACITY, "scene exceeds 2^32 (instance, meshlet) pairs");
     }
-    {   // flat traversal tables: the BVH of a mesh with at most 256 nodes, breadth-first, with what its leaves' groups and segments say folded in
+    {   // flat traversal tables: the BVH of a mesh with at most 8192 nodes, breadth-first, with what its leaves' groups and segments say folded in
         std::vector<brmi_lod_group> groups; std::vector<brmi_per_mesh_instance> insts; std::vector<brmi_per_mesh> pms;
         int rc2;
         if ((rc2 = read_back(p, groups, sc.lodGroups, sc.lodGroupCount))) return rc2;
@@ -449,7 +450,7 @@ int brmi_set_scene(brmi_pass* p, const brmi_scene_buffers* scene) {
                 const brmi_lod_node& nd = nodes[md[m].lodNodesBase + bfs[k].first];
                 if (nd.isLeaf != BRMI_NODE_INTERNAL) continue;
                 const uint32_t cc = std::min(nd.countMinusOne + 1u, BRMI_BVH_MAX_CHILDREN);
-                for (uint32_t c = 0; c < cc; c++) { bfs.push_back({nd.indexOrOffset + c, (uint32_t)k}); if (bfs.size() > 256) { fits = false; break; } }
+                for (uint32_t c = 0; c < cc; c++) { bfs.push_back({nd.indexOrOffset + c, (uint32_t)k}); if (bfs.size() > 8192) { fits = false; break; } }
             }
             if (!fits) continue;
             flatBase[m] = (uint32_t)p->hostFlatNodes.size(); flatCount[m] = (uint32_t)bfs.size();
@@ -457,15 +458,15 @@ int brmi_set_scene(brmi_pass* p, const brmi_scene_buffers* scene) {
                 const brmi_lod_node& nd = nodes[md[m].lodNodesBase + bfs[k].first];
                 FlatNode f{}; FlatLeaf l{};
                 std::memcpy(f.cull, nd.cullCenterAndRadius, 16); std::memcpy(f.lod, nd.lodCenterAndRadius, 16); f.maxQuadricError = nd.maxQuadricError;
-                f.nodeId = bfs[k].first; f.info = bfs[k].second & 0xFFu;
-                if (nd.isLeaf == BRMI_NODE_INTERNAL) f.info |= 1u << 8;
+                f.nodeId = bfs[k].first; f.info = bfs[k].second << 8;
+                if (nd.isLeaf == BRMI_NODE_INTERNAL) f.info |= 1u;
                 else {
                     const brmi_lod_group& g = groups[md[m].groupsBase + nd.ownerGroupId];
                     std::memcpy(l.group, g.centerAndRadius, 16);
-                    if (nd.countMinusOne != 0u) { const brmi_lod_group& cg = groups[md[m].groupsBase + (nd.countMinusOne - 1u)]; std::memcpy(l.child, cg.centerAndRadius, 16); l.childParentError = cg.maxParentError; f.info |= 1u << 9; }
+                    if (nd.countMinusOne != 0u) { const brmi_lod_group& cg = groups[md[m].groupsBase + (nd.countMinusOne - 1u)]; std::memcpy(l.child, cg.centerAndRadius, 16); l.childParentError = cg.maxParentError; f.info |= 1u << 1; }
                     const size_t si = (size_t)md[m].segmentsBase + nd.indexOrOffset;
                     if (si >= segs.size()) return fail(p, BRMI_ERR_INVALID, "mesh %zu: leaf node %u names segment %u, which does not exist", m, bfs[k].first, nd.indexOrOffset);
-                    if (segs[si].meshletCount != 0u) f.info |= 1u << 10;
+                    if (segs[si].meshletCount != 0u) f.info |= 1u << 2;
                     if (segs[si].meshletCount > 0xFFFFu || segs[si].firstMeshletInPage > 0xFFFFu) { flatCount[m] = 0; break; }      // (the bucket record packs both in 16 bits; leave such a mesh to the level walk)
                     f.ownerGroup = nd.ownerGroupId; f.segFirstCount = segs[si].firstMeshletInPage | (segs[si].meshletCount << 16);
                     f.pageMapIndex = md[m].pageMapBase + segs[si].pageIndex; f.firstBitRel = p->hostSegPrefix[si];
@@ -474,6 +475,8 @@ int brmi_set_scene(brmi_pass* p, const brmi_scene_buffers* scene) {
             }
             if (flatCount[m] == 0) { p->hostFlatNodes.resize(flatBase[m]); p->hostFlatLeaves.resize(flatBase[m]); }
         }
+        p->anyWideFlat = false; p->allMeshesFlat = flatOn;
+        for (size_t m = 0; m < md.size(); m++) { if (flatCount[m] > 256u) p->anyWideFlat = true; if (flatCount[m] == 0u) p->allMeshesFlat = false; }
         p->hostInstanceWalk.assign(offs.size(), InstanceWalk{0, 0, 0, 0});
         for (size_t i = 0; i < offs.size() && i < insts.size(); i++) {
             const uint32_t m = offs[i].clodMeshMetadataIndex;
@@ -709,6 +712,7 @@ int brmi_execute_split(brmi_pass* p, brmi_stream stream, brmi_stream shadeStream
     int rc;
     p->executesSinceTimes++;
     const bool split = shadeStream != stream;
+    p->splitFrame = split;
     p->resolveSetupDone = false; p->depthFinal = false;      // (a frame that failed half-way must not leave its shortcuts to the stage entry points)
     if ((rc = wait_for_frames_in_flight(p, stream))) return rc;
     // When the phase-1 traversal is the one-launch LDS walk and the frame constants are due anyway, the frame needs no clear launch: the
@@ -777,6 +781,7 @@ int brmi_execute_split(brmi_pass* p, brmi_stream stream, brmi_stream shadeStream
     p->shadeSharesChip = false;
     if (rc) return rc;
     if (split) { BRMI_HIP(p, hipEventRecord(p->frameDone, static_cast<hipStream_t>(stream))); p->frameDoneRecorded = true; }
+    p->splitFrame = false;          // (the stage entry points, called on their own, are not part of a split frame)
     return BRMI_OK;
 }
 

@@ -44,6 +44,7 @@ struct CullArgs {
     const uint32_t* meshLevelWidth; uint32_t levelKernelsWidthLo;
     const FlatNode* flatNodes; const FlatLeaf* flatLeaves; const InstanceWalk* instanceWalk;     // flat traversal of small hierarchies (brmi_internal.h)
     unsigned long long* debugStamps;     // instrumented builds (-DBRMI_TILE_STAMPS)
+    uint32_t wideFlat;                   // phase 1: hierarchies of 257 .. 8192 nodes are k_cull_flat_wide's (the walk skips them)
     uint32_t packedFlat;                 // phase 1: the launch's first ceil(draws / 8) waves take eight draws each (hierarchies of <= 8 nodes)
 };
 
@@ -432,7 +433,7 @@ __global__ void __launch_bounds__(64) k_cull_hierarchy(CullArgs a, BucketRecord*
             if (mine) { fn = a.flatNodes[iw.flatBase + j]; fl = a.flatLeaves[iw.flatBase + j]; }
             m4 model = load_m4(&obj->model[0][0]);
             m4 prevModel = model;
-            if (a.occlusion && mine && ((fn.info >> 8) & 1u)) prevModel = load_m4(&obj->prevModel[0][0]);       // (internal nodes: the occlusion test's matrix, requested now)
+            if (a.occlusion && mine && ((fn.info & 1u))) prevModel = load_m4(&obj->prevModel[0][0]);       // (internal nodes: the occlusion test's matrix, requested now)
             const float scale = max_axis_scale(model);
             const f3 instC{inst.boundingSphere[0], inst.boundingSphere[1], inst.boundingSphere[2]}; const float instR = inst.boundingSphere[3];
             bool instVisible = false;
@@ -444,7 +445,7 @@ __global__ void __launch_bounds__(64) k_cull_hierarchy(CullArgs a, BucketRecord*
             }
             nTested += (uint32_t)__popcll(__ballot(small && j == 0u)); nVisible += (uint32_t)__popcll(__ballot(instVisible && j == 0u));
             const bool skinned = iw.skinned != 0u;
-            const bool internal = (fn.info >> 8) & 1u;
+            const bool internal = (fn.info & 1u);
             const f3 cullC = skinned ? instC : f3{fn.cull[0], fn.cull[1], fn.cull[2]};
             const float cullR = skinned ? instR : fn.cull[3];
             const f3 cVS = to_view_space(cullC, model, view);
@@ -461,19 +462,19 @@ __global__ void __launch_bounds__(64) k_cull_hierarchy(CullArgs a, BucketRecord*
                 const f3 gc = xyz(mul_point(f3{fl.group[0], fl.group[1], fl.group[2]}, model));
                 const float eod = projected_error(gc, fl.group[3] * scale, fn.maxQuadricError, scale, camPos, zNear, ortho);
                 bool ok = eod >= threshold;
-                if (ok && ((fn.info >> 9) & 1u)) {      // refined_child_suppresses
+                if (ok && ((fn.info >> 1) & 1u)) {      // refined_child_suppresses
                     const f3 cc = xyz(mul_point(f3{fl.child[0], fl.child[1], fl.child[2]}, model));
                     const float ce = projected_error(cc, fl.child[3] * scale, fl.childParentError, scale, camPos, zNear, ortho);
                     if (!(ce < threshold)) ok = false;
                 }
-                if (ok && ((fn.info >> 10) & 1u)) {
+                if (ok && ((fn.info >> 2) & 1u)) {
                     const brmi_group_page_map_entry pe = sc.groupPageMap[fn.pageMapIndex];
                     slabDesc = pe.slabDescriptorIndex; slabOff = pe.slabByteOffset;
                     leafOk = slabDesc != 0u;
                 }
             }
             const uint64_t expandM = __ballot(expand);
-            const uint32_t parentLane = g8 | (fn.info & 7u);
+            const uint32_t parentLane = g8 | ((fn.info >> 8) & 7u);
             uint64_t reached = __ballot(mine && instVisible && j == 0u);
             for (;;) {
                 const bool r = mine && instVisible && (j == 0u || (pre && ((reached >> parentLane) & 1ull) && ((expandM >> parentLane) & 1ull)));
@@ -537,7 +538,8 @@ __global__ void __launch_bounds__(64) k_cull_hierarchy(CullArgs a, BucketRecord*
 #else
 #define HSTAMP(k) do { } while (0)
 #endif
-            if (iw.flatCount != 0u) {
+            if (iw.flatCount > 256u && a.wideFlat) continue;      // k_cull_flat_wide's
+            if (iw.flatCount != 0u && iw.flatCount <= 256u) {
                 constexpr uint32_t FLAT_CHUNKS = 4;      // 64 nodes each (brmi_set_scene: hierarchies of up to 256 nodes)
                 const uint32_t chunks = (iw.flatCount + 63u) >> 6;
                 const brmi_per_object* obj = sc.perObject + inst.perObjectBufferIndex;
@@ -564,8 +566,8 @@ __global__ void __launch_bounds__(64) k_cull_hierarchy(CullArgs a, BucketRecord*
                     const bool mine = c * 64u + lane < iw.flatCount;
                     FlatNode fn{}; FlatLeaf fl{};
                     if (mine) { fn = a.flatNodes[iw.flatBase + c * 64u + lane]; fl = a.flatLeaves[iw.flatBase + c * 64u + lane]; }
-                    nodeIdA[c] = fn.nodeId; parentA[c] = fn.info & 0xFFu; ownerGroupA[c] = fn.ownerGroup; segFirstCountA[c] = fn.segFirstCount; firstBitRelA[c] = fn.firstBitRel;
-                    const bool internal = (fn.info >> 8) & 1u;
+                    nodeIdA[c] = fn.nodeId; parentA[c] = fn.info >> 8; ownerGroupA[c] = fn.ownerGroup; segFirstCountA[c] = fn.segFirstCount; firstBitRelA[c] = fn.firstBitRel;
+                    const bool internal = (fn.info & 1u);
                     const f3 cullC = skinned ? instC : f3{fn.cull[0], fn.cull[1], fn.cull[2]};
                     const float cullR = skinned ? instR : fn.cull[3];
                     const f3 cVS = to_view_space(cullC, model, view);
@@ -583,12 +585,12 @@ __global__ void __launch_bounds__(64) k_cull_hierarchy(CullArgs a, BucketRecord*
                         const f3 gc = xyz(mul_point(f3{fl.group[0], fl.group[1], fl.group[2]}, model));
                         const float eod = projected_error(gc, fl.group[3] * scale, fn.maxQuadricError, scale, camPos, zNear, ortho);
                         bool ok = eod >= threshold;
-                        if (ok && ((fn.info >> 9) & 1u)) {      // refined_child_suppresses
+                        if (ok && ((fn.info >> 1) & 1u)) {      // refined_child_suppresses
                             const f3 cc = xyz(mul_point(f3{fl.child[0], fl.child[1], fl.child[2]}, model));
                             const float ce = projected_error(cc, fl.child[3] * scale, fl.childParentError, scale, camPos, zNear, ortho);
                             if (!(ce < threshold)) ok = false;
                         }
-                        if (ok && ((fn.info >> 10) & 1u)) {
+                        if (ok && ((fn.info >> 2) & 1u)) {
                             const brmi_group_page_map_entry pe = sc.groupPageMap[fn.pageMapIndex];
                             slabDescA[c] = pe.slabDescriptorIndex; slabOffA[c] = pe.slabByteOffset;
                             leafOk = slabDescA[c] != 0u;
@@ -853,6 +855,146 @@ __global__ void __launch_bounds__(64) k_cull_hierarchy(CullArgs a, BucketRecord*
     for (int o = 32; o > 0; o >>= 1) nNodes += (uint32_t)__shfl_xor((int)nNodes, o);
     if (lane == 0) {
         uint32_t* stripe = a.counters + CNT_STRIPES + (blockIdx.x & (CNT_STRIPE_COUNT - 1u)) * CNT_STRIPE_WORDS;
+        if (nTested) atomicAdd(&stripe[0], nTested);
+        if (nVisible) atomicAdd(&stripe[1], nVisible);
+        if (nNodes) atomicAdd(&stripe[2], nNodes);
+    }
+}
+
+// Flat evaluation of a hierarchy of 257 .. 8192 nodes (the dense workload's terrain-like meshes: 4,270 nodes, six levels): one 1024-thread
+// workgroup per draw, a node per thread and chunk of 1024, the per-node verdicts and parent links in LDS, "reached" propagated there, one pair of
+// reservations per draw.  The level walk spent a launch per level on such a mesh (k_traverse: ~10 us each, three per phase) behind a chain of
+// LDS-walk steps; here every node of the hierarchy is fetched in at most eight rounds whatever the depth.  Same tests, same records.
+constexpr uint32_t FLAT_WIDE_MAX = 8192;
+__global__ void __launch_bounds__(1024) k_cull_flat_wide(CullArgs a, BucketRecord* buckets) {
+    __shared__ uint8_t verdict[FLAT_WIDE_MAX];          // bit 0 passes as a child, 1 lets its children through, 2 hidden by the depth chain, 3 leaf that emits, 4 reached
+    __shared__ uint16_t parentOf[FLAT_WIDE_MAX], recordsOf[FLAT_WIDE_MAX];
+    __shared__ uint32_t waveSum[2][16], changed, bases[2];
+    const brmi_scene_buffers& sc = a.sc;
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const uint32_t viewId = sc.perFrame->mainCameraIndex;
+    const brmi_camera* cam = sc.cameras + viewId;
+    const brmi_culling_camera* lodCam = sc.cullingCameras + viewId;
+    const bool ortho = cam->isOrtho != 0;
+    const f3 camPos{lodCam->positionWorldSpace[0], lodCam->positionWorldSpace[1], lodCam->positionWorldSpace[2]};
+    const float zNear = lodCam->zNear, threshold = lodCam->errorOverDistanceThreshold;
+    const m4 view = load_m4(&cam->view[0][0]);
+    uint32_t nTested = 0, nVisible = 0, nNodes = 0;
+    for (uint32_t seed = blockIdx.x; seed < sc.activeDrawCount; seed += gridDim.x) {
+        const uint32_t instIndex = sc.activeDraws[seed];
+        const InstanceWalk iw = a.instanceWalk[instIndex];
+        if (iw.flatCount <= 256u || iw.flatCount > FLAT_WIDE_MAX) continue;          // (block-uniform) the walk's, or not flat at all
+        const brmi_per_mesh_instance inst = sc.perMeshInstance[instIndex];
+        const brmi_per_object* obj = sc.perObject + inst.perObjectBufferIndex;
+        const m4 model = load_m4(&obj->model[0][0]);
+        const m4 prevModel = a.occlusion ? load_m4(&obj->prevModel[0][0]) : model;
+        const float scale = max_axis_scale(model);
+        const f3 instC{inst.boundingSphere[0], inst.boundingSphere[1], inst.boundingSphere[2]}; const float instR = inst.boundingSphere[3];
+        {   // K1 (PureComputeObjectCullCS)
+            const f3 c = to_view_space(instC, model, view);
+            const float r = instR * scale;
+            const bool bad = isnan(c.x) || isnan(c.y) || isnan(c.z) || isinf(c.x) || isinf(c.y) || isinf(c.z) || isnan(r) || isinf(r);
+            if (t == 0) nTested++;
+            if (bad || sphere_outside_frustum(c, r, cam->clippingPlanes)) continue;
+            if (t == 0) nVisible++;
+        }
+        const bool skinned = iw.skinned != 0u;
+        __syncthreads();                                    // the previous draw's LDS state has been read
+        for (uint32_t node = t; node < iw.flatCount; node += 1024u) {
+            const FlatNode fn = a.flatNodes[iw.flatBase + node];
+            const bool internal = (fn.info & 1u);
+            const f3 cullC = skinned ? instC : f3{fn.cull[0], fn.cull[1], fn.cull[2]};
+            const float cullR = skinned ? instR : fn.cull[3];
+            const f3 cVS = to_view_space(cullC, model, view);
+            const float rW = cullR * scale;
+            const bool inFrustum = !sphere_outside_frustum(cVS, rW, cam->clippingPlanes);
+            bool pre = inFrustum, expand = false, hidden = false, leafOk = false;
+            uint32_t records = 0;
+            if (inFrustum && internal) {
+                const f3 lc = xyz(mul_point(f3{fn.lod[0], fn.lod[1], fn.lod[2]}, model));
+                const float e = projected_error(lc, fn.lod[3] * scale, fn.maxQuadricError, scale, camPos, zNear, ortho);
+                pre = e >= threshold;
+                if (pre) { hidden = a.occlusion && occlusion_test_prev(a, cam, cullC, cullR, prevModel); expand = !hidden; }
+            } else if (inFrustum) {
+                const FlatLeaf fl = a.flatLeaves[iw.flatBase + node];
+                const f3 gc = xyz(mul_point(f3{fl.group[0], fl.group[1], fl.group[2]}, model));
+                const float eod = projected_error(gc, fl.group[3] * scale, fn.maxQuadricError, scale, camPos, zNear, ortho);
+                bool ok = eod >= threshold;
+                if (ok && ((fn.info >> 1) & 1u)) {      // refined_child_suppresses
+                    const f3 cc = xyz(mul_point(f3{fl.child[0], fl.child[1], fl.child[2]}, model));
+                    const float ce = projected_error(cc, fl.child[3] * scale, fl.childParentError, scale, camPos, zNear, ortho);
+                    if (!(ce < threshold)) ok = false;
+                }
+                if (ok && ((fn.info >> 2) & 1u)) {
+                    leafOk = sc.groupPageMap[fn.pageMapIndex].slabDescriptorIndex != 0u;
+                    records = leafOk ? ((fn.segFirstCount >> 16) + a.factor - 1u) / a.factor : 0u;
+                }
+            }
+            verdict[node] = (uint8_t)((pre ? 1u : 0u) | (expand ? 2u : 0u) | (hidden ? 4u : 0u) | (leafOk ? 8u : 0u) | (node == 0u ? 16u : 0u));
+            parentOf[node] = (uint16_t)(fn.info >> 8); recordsOf[node] = (uint16_t)records;
+        }
+        // reached: the root, or a node that passed as a child of a reached node that lets its children through (parents lie below their
+        // children in the breadth-first order, so a sweep settles a level at least)
+        for (;;) {
+            __syncthreads();
+            if (t == 0) changed = 0u;
+            __syncthreads();
+            for (uint32_t node = t; node < iw.flatCount; node += 1024u) {
+                const uint32_t v = verdict[node];
+                if (!(v & 16u) && (v & 1u)) { const uint32_t pv = verdict[parentOf[node]]; if ((pv & 18u) == 18u) { verdict[node] = (uint8_t)(v | 16u); changed = 1u; } }
+            }
+            __syncthreads();
+            if (changed == 0u) break;
+        }
+        // per thread: its nodes' replay records and bucket records, then a block-wide exclusive scan of both
+        uint32_t myReplay = 0, myBuckets = 0;
+        for (uint32_t node = t; node < iw.flatCount; node += 1024u) {
+            const uint32_t v = verdict[node];
+            if (v & 16u) { nNodes++; if (a.occlusion && (v & 4u)) myReplay++; if (v & 8u) myBuckets += recordsOf[node]; }
+        }
+        uint32_t inclR = myReplay, inclB = myBuckets;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t r = (uint32_t)__shfl_up((int)inclR, o), b = (uint32_t)__shfl_up((int)inclB, o); if (lane >= (uint32_t)o) { inclR += r; inclB += b; } }
+        if (lane == 63u) { waveSum[0][wave] = inclR; waveSum[1][wave] = inclB; }
+        __syncthreads();
+        uint32_t baseR = 0, baseB = 0, totalR = 0, totalB = 0;
+        for (uint32_t w = 0; w < 16u; w++) { if (w < wave) { baseR += waveSum[0][w]; baseB += waveSum[1][w]; } totalR += waveSum[0][w]; totalB += waveSum[1][w]; }
+        if (t == 0) {
+            bases[0] = totalR ? atomicAdd(&a.counters[CNT_REPLAY_NODES], totalR) : 0u;
+            bases[1] = totalB ? atomicAdd(&a.counters[a.bucketCounter], totalB) : 0u;
+        }
+        __syncthreads();
+        uint32_t slotR = bases[0] + baseR + inclR - myReplay, slotB = bases[1] + baseB + inclB - myBuckets;
+        for (uint32_t node = t; node < iw.flatCount; node += 1024u) {
+            const uint32_t v = verdict[node];
+            if (!(v & 16u)) continue;
+            if (a.occlusion && (v & 4u)) {
+                const FlatNode fn = a.flatNodes[iw.flatBase + node];
+                if (slotR < a.recordCapacity) a.replayNodes[slotR] = NodeRecord{instIndex, 0x80000000u | (1u << 30) | (fn.nodeId & 0x3FFFFFFFu)};
+                else atomicAdd(&a.counters[CNT_DROPPED_RECORDS], 1u);
+                slotR++;
+            }
+            if (v & 8u) {
+                const FlatNode fn = a.flatNodes[iw.flatBase + node];
+                const brmi_group_page_map_entry pe = sc.groupPageMap[fn.pageMapIndex];
+                const uint32_t segFirst = fn.segFirstCount & 0xFFFFu, segCount = fn.segFirstCount >> 16;
+                for (uint32_t k = 0; k < recordsOf[node]; k++, slotB++) {
+                    if (slotB >= a.recordCapacity) { atomicAdd(&a.counters[CNT_DROPPED_RECORDS], 1u); continue; }
+                    BucketRecord b;
+                    b.instanceIndex = instIndex; b.groupIdPacked = fn.ownerGroup & 0x7FFFFFFFu;
+                    b.meshletIndexAndCount = (min(a.factor, segCount - k * a.factor) << 16) | ((segFirst + k * a.factor) & 0xFFFFu);
+                    b.pageSlabDescriptorIndex = pe.slabDescriptorIndex; b.pageSlabByteOffset = pe.slabByteOffset;
+                    b.firstBit = iw.bitBase + fn.firstBitRel + k * a.factor; b.pad0 = 0; b.pad1 = 0;
+                    buckets[slotB] = b;
+                }
+            }
+        }
+    }
+    // statistics: one atomic per wave and counter on a stripe of its own
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nNodes += (uint32_t)__shfl_xor((int)nNodes, o);
+    if (lane == 0) {
+        uint32_t* stripe = a.counters + CNT_STRIPES + ((blockIdx.x * 16u + wave) & (CNT_STRIPE_COUNT - 1u)) * CNT_STRIPE_WORDS;
         if (nTested) atomicAdd(&stripe[0], nTested);
         if (nVisible) atomicAdd(&stripe[1], nVisible);
         if (nNodes) atomicAdd(&stripe[2], nNodes);
@@ -1248,7 +1390,7 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
     a.recordCapacity = p->cfg.maxTraversalRecords; a.visibleCapacity = p->cfg.maxVisibleClusters;
     uint32_t f = p->cfg.phase2ExpansionFactor; f = f < 1 ? 1 : (f > 64 ? 64 : f);
     { uint32_t n = 1; for (uint32_t c = 2; c <= 64; c <<= 1) if (c <= f) n = c; f = n; }
-    a.factor = f; a.phase = phase; a.packedFlat = 0u;
+    a.factor = f; a.phase = phase; a.packedFlat = 0u; a.wideFlat = 0u;
     // the band test's two planes through the eye only bound a row band under a symmetric perspective projection: an orthographic or
     // off-centre camera keeps the frustum test alone (the rasteriser's row filter still confines the band; nothing is lost but the early cull)
     const bool symmetricPerspective = p->camHost.isOrtho == 0 && p->camHost.projection[2][0] == 0.0f && p->camHost.projection[2][1] == 0.0f &&
@@ -1284,6 +1426,9 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
         p->frameStateCleared = false;
         // (the first ceil(draws / 8) waves of the walk take eight draws each: hierarchies of <= 8 nodes, the flat tables of brmi_set_scene)
         a.packedFlat = (hierarchy && !p->hostFlatNodes.empty() && p->packedFlat) ? 1u : 0u;
+        // (not beside another frame's shading half: a 1024-thread workgroup with 40 KB of LDS waits long for a CU that can take it, and the
+        // dense frame in flight went 0.795 -> 0.91 ms; alone the same frame's cull stage goes 0.180 -> 0.142 ms)
+        a.wideFlat = (hierarchy && p->anyWideFlat && p->wideFlat && !p->splitFrame) ? 1u : 0u;
         const dim3 hgrid(std::min(std::max(1u, p->scene.activeDrawCount), 16384u) + (a.packedFlat ? (p->scene.activeDrawCount + 7u) / 8u : 0u));
         if (hierarchy) {
             // ONE launch: the 6 KB-frontier variant when every mesh is narrow (<= 256 nodes per level), else the 24 KB variant for all meshes up
@@ -1299,6 +1444,7 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
             } else if (wide) hipLaunchKernelGGL((k_cull_hierarchy<false, 1024, BRMI_HIER_STAGE_WIDE>), hgrid, dim3(64), 0, s, a, buckets, meshWidth, 0u, widthHi, spillAbove, fa, NoSide{});
             else hipLaunchKernelGGL((k_cull_hierarchy<false, 256, 128>), hgrid, dim3(64), 0, s, a, buckets, meshWidth, 0u, widthHi, spillAbove, fa, NoSide{});
         }
+        if (a.wideFlat) hipLaunchKernelGGL(k_cull_flat_wide, dim3(std::min(std::max(1u, p->scene.activeDrawCount), 4096u)), dim3(1024), 0, s, a, buckets);
         if (levelKernels && !spillMode) hipLaunchKernelGGL(k_cull_instances, dim3(grid_for(p->scene.activeDrawCount, 256, maxBlocks)), dim3(256), 0, s, a, fa);
         BRMI_LAUNCH_CHECK(p, "k_cull_instances");
     } else {
@@ -1312,7 +1458,9 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
     // frontier sizes are only known on the device: size the grids for the worst case that can matter
     const uint32_t travGrid = grid_for(std::min<uint64_t>(p->cfg.maxTraversalRecords, (uint64_t)p->scene.lodNodeCount * 4 + 4096), 256, maxBlocks);
     const uint32_t levelLaunches = spillMode ? std::min(p->maxLevels, std::max(1u, p->spillLevels)) : p->maxLevels;
-    for (uint32_t level = 0; level < levelLaunches && levelKernels; level++) {
+    // (phase 1 of a scene whose every hierarchy is evaluated flat leaves nothing for the level kernels)
+    const bool flatCoversPhase1 = phase == 1 && hierarchy && spillMode && p->allMeshesFlat && a.wideFlat != 0u && !p->forceLevelKernels;
+    for (uint32_t level = 0; level < levelLaunches && levelKernels && !flatCoversPhase1; level++) {
         // without the walk in front (forced level kernels) phase 2 reads level 0 from the replay buffer; then ping-pong like phase 1 (level 0 writes fb)
         const NodeRecord* in = level == 0 ? ((phase == 1 || spillMode) ? fa : a.replayNodes) : ((level & 1u) ? fb : fa);
         hipLaunchKernelGGL(k_traverse, dim3(travGrid), dim3(256), 0, s, a, level, in, (level & 1u) ? fa : fb, buckets);

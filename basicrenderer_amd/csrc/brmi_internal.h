@@ -65,13 +65,14 @@ __device__ inline void seed_phase2(uint32_t* counters, uint32_t capacity, uint32
 }
 
 // internal records (ours; the reference's 12 B / 24 B records plus the rank bookkeeping)
-// A mesh whose whole BVH has at most 256 nodes (brmi_set_scene walks it) is evaluated flat by the traversal kernel: one lane per node, the
+// A mesh whose whole BVH has at most 8192 nodes (brmi_set_scene walks it) is evaluated flat by the traversal kernels: one lane per node (a wave for
+// up to 256 nodes, eight draws to a wave up to 8, a 1024-thread workgroup beyond 256), the
 // records below instead of the node -> group / segment chain (static topology: node, group and segment contents as brmi_set_scene read them;
 // what the host may rewrite between frames -- instances, objects, the page map -- is still read from its buffers).
 struct FlatNode {                                                                     // 64 B, breadth-first (a parent's position is below its children's)
     float cull[4], lod[4]; float maxQuadricError;
     uint32_t nodeId;            // relative to the mesh's lodNodesBase (replay records name nodes by it)
-    uint32_t info;              // parent position [0, 8) | internal << 8 | has a refined group << 9 | segment holds meshlets << 10
+    uint32_t info;              // internal | has a refined group << 1 | segment holds meshlets << 2 | parent position << 8 (breadth-first: below the node's own)
     uint32_t ownerGroup;        // leaf: mesh-local group
     uint32_t segFirstCount;     // leaf: firstMeshletInPage | meshletCount << 16
     uint32_t pageMapIndex;      // leaf: absolute index of the segment's page-map entry
@@ -186,6 +187,9 @@ struct brmi_pass {
     }
     uint32_t phase2DirectMax = 256;   // BRMI_PHASE2_DIRECT_MAX: direct rasterisation while the last known phase-2 count is at most this (0: always bins)
     uint32_t clearRiderBlocks = 8192; // single-wave workgroups of the visibility clear that ride on the traversal launch (BRMI_CLEAR_RIDER_BLOCKS)
+    bool splitFrame = false;         // brmi_execute_split with two streams: this frame's launches share the chip with another frame's
+    bool wideFlat = true;            // BRMI_FLAT_WIDE=0: hierarchies of more than 256 nodes take the level walk
+    bool anyWideFlat = false, allMeshesFlat = false;      // brmi_set_scene: some mesh has 257 .. 8192 nodes / every mesh has flat tables
     bool scanChained = true; uint32_t scanEpoch = 0;      // the survivor ranking as one launch (BRMI_SCAN_CHAINED=0: three)
     bool packedFlat = true;          // BRMI_FLAT_PACKED=0: one draw per wave of the traversal
     uint32_t shadeGridShared = 10240; // workgroups of k_shade<0, 3> (BRMI_SHADE_GRID_SHARED): shorter-lived than the stand-alone 8192 so that the other frame's small geometry launches find slots sooner (Bistro-class period 6144 / 8192 / 10240 / 12288: 0.547 / 0.539 / 0.530 / 0.531 ms; Sponza-class, whose geometry half is short: 0.386 / 0.398 / 0.398 / 0.397)
