@@ -649,6 +649,11 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES
         itemIndex = curItem;
     }
     for (; itemIndex < itemCount; ) {
+    // the thread's index as the compiler cannot see through: what an item derives from it (tile addresses, scan predicates, merge items) is then
+    // recomputed per item with a few VALU instructions instead of being hoisted out of this loop into registers that the pixel loops need (the
+    // alpha variant spilled ten such loop invariants)
+    uint32_t tid = threadIdx.x;
+    if (ALPHA) asm volatile("" : "+v"(tid));
 #ifdef BRMI_TILE_STAMPS
     const unsigned long long wgStart = __builtin_amdgcn_s_memrealtime();      // 100 MHz, the same clock on every CU: a timeline of the launch's items
 #endif
@@ -661,8 +666,8 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES
     const bool shared = sliceCount > 1u;                // other workgroups walk records of this bin too
     const uint32_t first = slice * sliceSize;
     const uint32_t n = max(first, min(nAll, first + sliceSize));      // (the plan's slices are never empty: sliceSize <= binSharedSlice, a multiple of 32)
-    if (ALPHA && threadIdx.x == 0) alphaCount = 0u;
-    for (uint32_t i = threadIdx.x; i < BIN_W * BIN_ROWS; i += BRMI_BIN_THREADS) tile[i] = BRMI_VIS_EMPTY;
+    if (ALPHA && tid == 0) alphaCount = 0u;
+    for (uint32_t i = tid; i < BIN_W * BIN_ROWS; i += BRMI_BIN_THREADS) tile[i] = BRMI_VIS_EMPTY;
     __syncthreads();
     BSTAMP(0);
     const int x0 = (int)(strip << BIN_W_SHIFT), y0 = (int)(band << BIN_ROWS_SHIFT);
@@ -677,12 +682,12 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES
     const uint32_t m = n - first;
     const bool sorted = BRMI_BIN_SORT && !ALPHA && m >= BRMI_BIN_SORT_MIN && m <= BIN_ORDER_CAP;
     if (sorted) {
-        if (threadIdx.x < SORT_CLASSES) classCount[threadIdx.x] = 0u;
+        if (tid < SORT_CLASSES) classCount[tid] = 0u;
         __syncthreads();
         uint32_t key[BIN_ORDER_CAP / BRMI_BIN_THREADS], slot[BIN_ORDER_CAP / BRMI_BIN_THREADS];
 #pragma unroll
         for (uint32_t k = 0; k < BIN_ORDER_CAP / BRMI_BIN_THREADS; k++) {
-            const uint32_t i = threadIdx.x + k * BRMI_BIN_THREADS;
+            const uint32_t i = tid + k * BRMI_BIN_THREADS;
             key[k] = 0xFFFFFFFFu;
             if (i < m) {
                 const BinRecord* r = recs + first + i;
@@ -694,14 +699,14 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES
             }
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
+        if (tid == 0) {
             uint32_t run = 0;
             for (uint32_t c = 0; c < SORT_CLASSES; c++) { classBase[c] = run; run += classCount[c]; }
             classBase[SORT_CLASSES] = run;
         }
         __syncthreads();
 #pragma unroll
-        for (uint32_t k = 0; k < BIN_ORDER_CAP / BRMI_BIN_THREADS; k++) if (key[k] != 0xFFFFFFFFu) order[classBase[key[k]] + slot[k]] = (uint16_t)(threadIdx.x + k * BRMI_BIN_THREADS);
+        for (uint32_t k = 0; k < BIN_ORDER_CAP / BRMI_BIN_THREADS; k++) if (key[k] != 0xFFFFFFFFu) order[classBase[key[k]] + slot[k]] = (uint16_t)(tid + k * BRMI_BIN_THREADS);
         __syncthreads();
     }
     // the record of the NEXT step is requested before this step's rows are walked: the records come from HBM (the launch before wrote 86 MiB of
@@ -711,7 +716,7 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES
     // instead of 46: beside three k_shade waves per SIMD the kernel then finds no room, and the frame with two in flight got 18 % slower.)
     for (uint32_t rc = sorted ? 0u : 2u; rc < 3u; rc++) {
     const uint32_t sh = 2u + rc;                                          // 4, 8 or 16 lanes per record
-    const uint32_t sub = threadIdx.x >> sh, row = threadIdx.x & ((1u << sh) - 1u), per = BRMI_BIN_THREADS >> sh;
+    const uint32_t sub = tid >> sh, row = tid & ((1u << sh) - 1u), per = BRMI_BIN_THREADS >> sh;
     const uint32_t cs = sorted ? classBase[rc * WIDTH_CLASSES] : 0u, ce = sorted ? classBase[(rc + 1u) * WIDTH_CLASSES] : m;
     auto record_at = [&](uint32_t idx) { return first + (sorted ? (uint32_t)order[idx] : idx); };
     BinRecord pending{}; uint32_t riPending = 0;
@@ -730,20 +735,16 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES
         const uint32_t rows = (r.triAndFlags >> 16) & 0xFFu;
         bool deferred = false;
         if (ALPHA && r.pad1 != 0u) {      // alpha tested: listed for the task pass below
-            uint32_t slot = 0;
-            if (row == 0u) slot = atomicAdd(&alphaCount, 1u);
-            slot = (uint32_t)__shfl((int)slot, (int)(lane_id() & 48u));
-            deferred = slot < ALPHA_LIST;                 // ri - first < BIN_SLICE <= 65536: fits the 16-bit list entry
-            if (deferred && row == 0u) alphaList[slot] = (uint16_t)(ri - first);
+            // (every alpha record of the slice has a list entry: the plan's slices hold at most ALPHA_LIST records in alpha-tested scenes, launch_raster.  The
+            // row walk below is the opaque one only -- with the alpha test inlined here as a fallback the kernel spilled 61 registers, round 3.)
+            if (row == 0u) { const uint32_t slot = atomicAdd(&alphaCount, 1u); if (slot < ALPHA_LIST) alphaList[slot] = (uint16_t)(ri - first); }      // ri - first < 65536: fits the 16-bit entry
+            deferred = true;
         }
         if (row < rows && !deferred) {
             float sb0 = r.sb0, sb1 = r.sb1;
             for (uint32_t k = 0; k < row; k++) { sb0 += r.dy_b0; sb1 += r.dy_b1; }
             const int py = r.rowStart + (int)row;
-            if ((uint32_t)py >= a.bandY0 && (uint32_t)py < a.bandY1 && ALPHA && r.pad1 != 0u)
-                raster_row(sink, tex_alpha_of(a, unormT, a.binAlpha[(size_t)bin * a.binCapacity + ri]), py, r.minX, r.rectWidth, (r.triAndFlags & 0x100u) != 0, sb0, sb1, r.dx_b0, r.dx_b1, -(r.dx_b0 + r.dx_b1),
-                           r.d0, r.d1, r.d2, r.clusterIndex, r.triAndFlags & 0x7Fu, x0, x0 + BIN_W - 1);
-            else if ((uint32_t)py >= a.bandY0 && (uint32_t)py < a.bandY1)
+            if ((uint32_t)py >= a.bandY0 && (uint32_t)py < a.bandY1)
                 raster_row(sink, NoAlpha{}, py, r.minX, r.rectWidth, (r.triAndFlags & 0x100u) != 0, sb0, sb1, r.dx_b0, r.dx_b1, -(r.dx_b0 + r.dx_b1), r.d0, r.d1, r.d2, r.clusterIndex, r.triAndFlags & 0x7Fu,
                            x0, x0 + BIN_W - 1);
         }
@@ -762,6 +763,7 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES
         // the row start like every clipped walk, so the keys are those of the serial loop.
         __syncthreads();
         const uint32_t listed = min(alphaCount, ALPHA_LIST);
+        if (tid == 0 && alphaCount > ALPHA_LIST) atomicAdd(&a.counters[CNT_DROPPED_RECORDS], alphaCount - ALPHA_LIST);      // impossible by construction; counted anyway
         auto tasks_of = [&](const BinRecord& r) {
             const int bx0 = max(r.minX, x0), bx1 = min(r.minX + r.rectWidth - 1, x0 + BIN_W - 1);
             return bx1 < bx0 ? 0u : ((r.triAndFlags >> 16) & 0xFFu) * (uint32_t)(((bx1 - bx0) >> ALPHA_SEG_SHIFT) + 1);
@@ -770,23 +772,23 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES
         constexpr uint32_t PER = ALPHA_LIST / BRMI_BIN_THREADS;
         uint32_t mine[PER]; uint32_t sum = 0;
 #pragma unroll
-        for (uint32_t k = 0; k < PER; k++) { const uint32_t j = threadIdx.x * PER + k; mine[k] = j < listed ? tasks_of(recs[first + alphaList[j]]) : 0u; sum += mine[k]; }
-        scanPart[threadIdx.x] = sum;
+        for (uint32_t k = 0; k < PER; k++) { const uint32_t j = tid * PER + k; mine[k] = j < listed ? tasks_of(recs[first + alphaList[j]]) : 0u; sum += mine[k]; }
+        scanPart[tid] = sum;
         __syncthreads();
         for (uint32_t o = 1; o < BRMI_BIN_THREADS; o <<= 1) {
-            const uint32_t v = threadIdx.x >= o ? scanPart[threadIdx.x - o] : 0u;
+            const uint32_t v = tid >= o ? scanPart[tid - o] : 0u;
             __syncthreads();
-            scanPart[threadIdx.x] += v;
+            scanPart[tid] += v;
             __syncthreads();
         }
-        uint32_t run = scanPart[threadIdx.x] - sum;
+        uint32_t run = scanPart[tid] - sum;
 #pragma unroll
-        for (uint32_t k = 0; k < PER; k++) { const uint32_t j = threadIdx.x * PER + k; if (j <= listed) taskStart[j] = run; run += mine[k]; }
-        if (threadIdx.x == BRMI_BIN_THREADS - 1u && listed == ALPHA_LIST) taskStart[ALPHA_LIST] = run;      // j never reaches ALPHA_LIST in the loop above
+        for (uint32_t k = 0; k < PER; k++) { const uint32_t j = tid * PER + k; if (j <= listed) taskStart[j] = run; run += mine[k]; }
+        if (tid == BRMI_BIN_THREADS - 1u && listed == ALPHA_LIST) taskStart[ALPHA_LIST] = run;      // j never reaches ALPHA_LIST in the loop above
         __syncthreads();
         const uint32_t total = listed ? taskStart[listed] : 0u;
         BSTAMP(2);
-        for (uint32_t task = threadIdx.x; task < total; task += BRMI_BIN_THREADS) {
+        for (uint32_t task = tid; task < total; task += BRMI_BIN_THREADS) {
             uint32_t j = 0;
 #pragma unroll
             for (uint32_t step = ALPHA_LIST / 2; step > 0; step >>= 1) if (j + step <= listed && taskStart[j + step] <= task) j += step;
@@ -815,12 +817,17 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES
         else {
             // agent-scope stores / loads (write through / read around the XCD's L2: the folding workgroup may sit on another XCD)
             unsigned long long* mine = a.binScratch + ((size_t)slot + slice) * (BIN_W * BIN_ROWS);
-            for (uint32_t i = threadIdx.x; i < BIN_W * BIN_ROWS; i += BRMI_BIN_THREADS) __hip_atomic_store(&mine[i], tile[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (uint32_t i = tid; i < BIN_W * BIN_ROWS; i += BRMI_BIN_THREADS) __hip_atomic_store(&mine[i], tile[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // every wave's stores have left (vmcnt), the workgroup has met, then the counter: the order the hand-off needs.  (Agent-scope
             // release / acquire fences instead write back and invalidate the XCD's whole L2 per slice: raster 0.22 -> 0.45 ms.)
+            // This is the fence-free form MI355X_MICROARCH.md lists as measured on gfx950 ("Hand-offs measured with sc1 loads in place of the
+            // acquire", first row): EVERY store of the handed-off bytes is write-through (sc1), every storing wave drains vmcnt, ONE lane adds to an
+            // agent-scope counter behind the workgroup's barrier, the consumer is the workgroup whose add returned last, its other waves load
+            // behind a barrier that lane joins, and EVERY load of the bytes is an sc1 load to registers.  Not an architectural guarantee of the
+            // HIP memory model; tests/test_parity_gpu.py forces shared bins (BRMI_BIN_MIN_SLICE=64) on full frames against the oracle.
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (threadIdx.x == 0) doneBefore = __hip_atomic_fetch_add(&binDone[bin], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) doneBefore = __hip_atomic_fetch_add(&binDone[bin], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
             fold = doneBefore + 1u == sliceCount;          // else another slice folds and merges
             if (fold) {
@@ -828,24 +835,24 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES
             const unsigned long long* tiles = a.binScratch + (size_t)slot * (BIN_W * BIN_ROWS);
             unsigned long long best[BIN_W * BIN_ROWS / BRMI_BIN_THREADS];
 #pragma unroll
-            for (uint32_t k = 0; k < BIN_W * BIN_ROWS / BRMI_BIN_THREADS; k++) best[k] = tile[threadIdx.x + k * BRMI_BIN_THREADS];
+            for (uint32_t k = 0; k < BIN_W * BIN_ROWS / BRMI_BIN_THREADS; k++) best[k] = tile[tid + k * BRMI_BIN_THREADS];
             for (uint32_t z = 0; z < sliceCount; z++) {
                 if (z == slice) continue;
                 unsigned long long o[BIN_W * BIN_ROWS / BRMI_BIN_THREADS];
 #pragma unroll
-                for (uint32_t k = 0; k < BIN_W * BIN_ROWS / BRMI_BIN_THREADS; k++) o[k] = __hip_atomic_load(&tiles[(size_t)z * (BIN_W * BIN_ROWS) + threadIdx.x + k * BRMI_BIN_THREADS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (uint32_t k = 0; k < BIN_W * BIN_ROWS / BRMI_BIN_THREADS; k++) o[k] = __hip_atomic_load(&tiles[(size_t)z * (BIN_W * BIN_ROWS) + tid + k * BRMI_BIN_THREADS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
                 for (uint32_t k = 0; k < BIN_W * BIN_ROWS / BRMI_BIN_THREADS; k++) best[k] = o[k] < best[k] ? o[k] : best[k];
             }
 #pragma unroll
-            for (uint32_t k = 0; k < BIN_W * BIN_ROWS / BRMI_BIN_THREADS; k++) tile[threadIdx.x + k * BRMI_BIN_THREADS] = best[k];
-            if (threadIdx.x == 0) __hip_atomic_store(&binDone[bin], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (uint32_t k = 0; k < BIN_W * BIN_ROWS / BRMI_BIN_THREADS; k++) tile[tid + k * BRMI_BIN_THREADS] = best[k];
+            if (tid == 0) __hip_atomic_store(&binDone[bin], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
             }
         }
     }
     // merge: item = (column x, upper / lower 8 rows) = 8 keys = 64 B, contiguous in the tile and in the 8x8-tiled surface
-    for (uint32_t item2 = threadIdx.x; fold && item2 < BIN_W * 2; item2 += BRMI_BIN_THREADS) {
+    for (uint32_t item2 = tid; fold && item2 < BIN_W * 2; item2 += BRMI_BIN_THREADS) {
         const uint32_t half = item2 >> 8 /* BIN_W items per half */, xl = item2 & (BIN_W - 1);
         const ulonglong2* src = reinterpret_cast<const ulonglong2*>(&tile[xl * BIN_ROWS + half * 8u]);
         ulonglong2 k[4];
@@ -870,13 +877,13 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES
     }
     BSTAMP(5);
 #ifdef BRMI_TILE_STAMPS
-    if (threadIdx.x == 0 && (a.debugFlags & 0x400)) {       // timeline: one entry per work item
+    if (tid == 0 && (a.debugFlags & 0x400)) {       // timeline: one entry per work item
         unsigned long long* w = a.debugStamps + 64u + 4u * (size_t)itemIndex;
         w[0] = wgStart; w[1] = __builtin_amdgcn_s_memrealtime(); w[2] = (unsigned long long)(n - first) | ((unsigned long long)item << 32); w[3] = wWalk;
     }
 #endif
     __syncthreads();                                    // the merge has read the tile (and everyone has read curItem)
-    if (threadIdx.x == 0) curItem = staticItems + atomicAdd(&a.binPlan[1], 1u);
+    if (tid == 0) curItem = staticItems + atomicAdd(&a.binPlan[1], 1u);
     __syncthreads();
     itemIndex = curItem;
     }   // work items
@@ -899,7 +906,7 @@ BRMI_DEV void plan_bins(const RasterArgs& a) {
     if (threadIdx.x == 0) tileRun = 0u;
     lds_barrier();
     auto slices_of = [&](uint32_t n) { return n == 0u ? 0u : n <= a.binMinSlice ? 1u : min((n + a.binSharedSlice - 1u) / a.binSharedSlice, 256u); };
-    auto class_of = [&](uint32_t n, uint32_t sc) { const uint32_t len = (n + sc - 1u) / sc; return 31u - (uint32_t)__clz(len); };      // log2 of the slice length (< 16: a slice holds < 65536 records)
+    auto class_of = [&](uint32_t n, uint32_t sc) { const uint32_t len = (n + sc - 1u) / sc; return min(15u, 31u - (uint32_t)__clz(len)); };      // log2 of the slice length, 16 classes (a slice of exactly 65536 records -- BRMI_BIN_CAPACITY = BRMI_BIN_MIN_SLICE = 65536 -- shares the last)
     constexpr uint32_t K = 8;
     const bool oneChunk = nBins <= K * blockDim.x;      // (every frame up to 8K: a thread keeps its bins' counts in registers between the passes)
     uint32_t n[K];
@@ -913,7 +920,10 @@ BRMI_DEV void plan_bins(const RasterArgs& a) {
             const uint32_t sc = slices_of(n[k]);
             a.binCounts[(size_t)b * BIN_COUNT_STRIDE] = 0u; binN[b] = n[k]; binDone[b] = 0u;
             uint32_t slot = 0xFFFFFFFFu;
-            if (sc > 1u) { const uint32_t base = atomicAdd(&tileRun, sc); if (base + sc <= a.binScratchTiles) slot = base; }      // (any order: a tile range per shared bin)
+            if (sc > 1u) {      // (any order: a tile range per shared bin; reserved only when it fits, so one oversized bin does not push the bins behind it onto the atomic merge)
+                uint32_t cur = *(volatile uint32_t*)&tileRun;
+                while (cur + sc <= a.binScratchTiles) { const uint32_t prev = atomicCAS(&tileRun, cur, cur + sc); if (prev == cur) { slot = cur; break; } cur = prev; }
+            }
             binSlot[b] = slot;
             if (sc != 0u) atomicAdd(&classCount[class_of(n[k], sc)], sc);
         }
@@ -929,6 +939,8 @@ BRMI_DEV void plan_bins(const RasterArgs& a) {
             const uint32_t nb = oneChunk ? n[k] : binN[b], sc = slices_of(nb);
             if (sc == 0u) continue;
             const uint32_t at = atomicAdd(&classBase[class_of(nb, sc)], sc);
+            // (binItemCapacity is the worst case -- every bin cut into slices of 32 -- up to 2^22 items: only frames beyond 16K x 16K can run out, and say so)
+            if (at + sc > a.binItemCapacity) atomicAdd(&a.counters[CNT_DROPPED_RECORDS], nb);
             for (uint32_t z = 0; z < sc; z++) if (at + z < a.binItemCapacity) a.binItems[at + z] = b | (z << 16) | ((sc - 1u) << 24);
         }
     }
@@ -1383,8 +1395,9 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
     a.objConst = p->wsPtr<float>(p->ws.objConst);
     a.bigTriArea = p->bigTriArea; a.bigTriAreaAlpha = p->bigTriAreaAlpha; a.debugFlags = p->rasterDebug;
     a.bigTriAreaDense = p->bigTriAreaDense; a.denseClusterCount = p->denseClusterCount;
-    a.binMinSlice = p->binMinSlice;
-    a.binSharedSlice = std::max(32u, std::min(p->binSharedSlice, p->binMinSlice) & ~31u);        // a multiple of the 32 records a step walks: no slice of the plan is empty
+    // alpha-tested scenes: a slice's alpha records all go through the task list of k_raster_bins<true> (BRMI_ALPHA_LIST entries), so no slice is longer than that
+    a.binMinSlice = p->sceneHasAlphaTest ? std::min(p->binMinSlice, (uint32_t)BRMI_ALPHA_LIST) : p->binMinSlice;
+    a.binSharedSlice = std::max(32u, std::min(p->binSharedSlice, a.binMinSlice) & ~31u);        // a multiple of the 32 records a step walks: no slice of the plan is empty
     a.binPlan = p->wsPtr<uint32_t>(p->ws.binPlan); a.binItems = p->wsPtr<uint32_t>(p->ws.binItems); a.binScratch = p->wsPtr<unsigned long long>(p->ws.binScratch);
     a.binScratchTiles = p->binScratchTiles; a.binItemCapacity = p->binItemCapacity;
     a.binAlpha = p->wsPtr<AlphaRecord>(p->ws.binAlpha); a.overflowAlpha = p->wsPtr<AlphaRecord>(p->ws.overflowAlpha);

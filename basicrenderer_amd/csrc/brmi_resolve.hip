@@ -273,7 +273,10 @@ template <typename M> BRMI_DEV m4 load_m4_any(const M* p) {     // p: float in t
     return r;
 }
 
-constexpr int RESOLVE_WATERFALL = 4;     // distinct mesh instances per 8x8 tile handled with scalar loads before falling back
+#ifndef BRMI_RESOLVE_WATERFALL
+#define BRMI_RESOLVE_WATERFALL 4
+#endif
+constexpr int RESOLVE_WATERFALL = BRMI_RESOLVE_WATERFALL;     // distinct mesh instances per 8x8 tile handled with scalar loads before falling back
 
 // INLINE_TABLES: the arena may be too small for the frame, keep the per-pixel table path (it doubles the register count, so
 // the host only picks this variant when the arena cannot hold every cluster the configuration allows).
@@ -291,6 +294,9 @@ constexpr int RESOLVE_WATERFALL = 4;     // distinct mesh instances per 8x8 tile
 #endif
 #ifndef BRMI_GBP_WAVES
 #define BRMI_GBP_WAVES 2
+#endif
+#ifndef FRAME_EARLY
+#define FRAME_EARLY 1
 #endif
 #ifndef BRMI_GBM_WAVES
 #define BRMI_GBM_WAVES 3
@@ -335,14 +341,18 @@ BRMI_DEV void gbuffer_body(const GBufferArgs& a, const Epi& epi) {
     // storing everything (107 against 103 us; without the stores: 93)
     constexpr bool skipCoat = SLIM == 2, skipFuzz = SLIM == 2;
     // view-projection products are frame constants; every lane derives them the way the shader does
-    const m4 unjVP = uni_m4(a.frameConst[1]), prevVP = uni_m4(a.frameConst[2]);
+    // (the texture-sampling variants re-load the two products per tile through the scalar cache instead of keeping 32 SGPRs over the fetch loops:
+    // their scalar registers spill into vector registers, and those are what the variant is short of)
+    m4 unjVP_{}, prevVP_{};
+    if (!TEXTURED) { unjVP_ = uni_m4(a.frameConst[1]); prevVP_ = uni_m4(a.frameConst[2]); }
     const float winX = uni((float)pf->screenResX), winY = uni((float)pf->screenResY);
     const uint64_t end = (a.pixelCount + 63ull) & ~63ull, stride = (uint64_t)gridDim.x * blockDim.x;
     // software pipeline: the key and the cluster record of the next tile are requested while this one is resolved (the chain
     // key -> cluster -> triangle -> vertices is four dependent loads)
     auto pixel_of = [&](uint64_t j, uint32_t& px, uint32_t& py) {
         const uint64_t i = a.firstPixel + j;
-        const uint32_t tile = (uint32_t)(i >> 6), within = (uint32_t)(i & 63u);
+        // a wave is one 8x8 tile (firstPixel, the block size and the stride are multiples of 64): the tile's row and column come out of scalar arithmetic
+        const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(i >> 6)), within = (uint32_t)(i & 63u);
         px = (tile % a.tilesX) * 8u + (within >> 3); py = (tile / a.tilesX) * 8u + (within & 7u);
         return j < a.pixelCount && px < a.W && py < a.H && py >= a.bandY0 && py < a.bandY1;
     };
@@ -401,7 +411,7 @@ BRMI_DEV void gbuffer_body(const GBufferArgs& a, const Epi& epi) {
                 else o[k] = decode_uv_set(a.clusterUv[clusterIndex], set, local);
             }
         };
-        const float uvx = ((float)px + 0.5f) / winX, uvy = ((float)stripe_rrow(a.stripes, py) + 0.5f) / winY;      // the pixel's row in the FRAME
+        const float uvx = ((float)px + 0.5f) / winX, uvy = ((float)(stripe_rrow(a.stripes, (uint32_t)__builtin_amdgcn_readfirstlane((int)(py & ~7u))) + (py & 7u)) + 0.5f) / winY;      // the pixel's row in the FRAME (chunks are multiples of 16 rows: the tile's eight rows lie in one, so its first row is mapped in scalar arithmetic)
         const float ndcX = uvx * 2.0f - 1.0f, ndcY = (1.0f - uvy) * 2.0f - 1.0f;
         const f3 l = bary_lambda(r, ndcX, ndcY);
         const f3 posOS{dot3(f3{p[0].x, p[1].x, p[2].x}, l), dot3(f3{p[0].y, p[1].y, p[2].y}, l), dot3(f3{p[0].z, p[1].z, p[2].z}, l)};
@@ -415,10 +425,13 @@ BRMI_DEV void gbuffer_body(const GBufferArgs& a, const Epi& epi) {
             const m4 normalMatrix = load_m4_any(nm);
             const f3 worldNormal = normalize3(mul_v3m3(normalOS, normalMatrix));
             // ComputeClodMotionVector
+            const m4 unjVP = TEXTURED ? load_m4_any(&kconst(a.frameConst)[1].m[0][0]) : unjVP_, prevVP = TEXTURED ? load_m4_any(&kconst(a.frameConst)[2].m[0][0]) : prevVP_;
             const f4 clipCur = mul_point(worldPosition, unjVP);
             const f3 prevWorld = xyz(mul_point(posOS, load_m4_any(&obj->prevModel[0][0])));
             const f4 clipPrev = mul_point(prevWorld, prevVP);
             const float mvx = clipCur.x / clipCur.w - clipPrev.x / clipPrev.w, mvy = clipCur.y / clipCur.w - clipPrev.y / clipPrev.w;
+            // (stored here, not with the other planes: the word does not depend on the material, and its two inputs would stay live over the texture fetches)
+            __builtin_nontemporal_store((uint32_t)(f32_to_f16_bits(mvx) | (f32_to_f16_bits(mvy) << 16)), &a.motion[i]);
             uint32_t albedoW = mw->albedo, mrW = mw->metallicRoughness;
             unsigned long long emissiveW = mw->emissive, coatW = mw->coat, fuzzW = mw->fuzz;
             f3 normalWS = worldNormal;
@@ -469,6 +482,8 @@ BRMI_DEV void gbuffer_body(const GBufferArgs& a, const Epi& epi) {
                     // with parallax the frame is needed before the fetches; without, building it next to its only use keeps six registers free over them.
                     // BuildMaterialUvBindings: the frame follows the normal slot's UV set, else the height slot's
                     if (PARALLAX && (flags & (BRMI_MATERIAL_NORMAL_MAP | BRMI_MATERIAL_PARALLAX))) { use_set((flags & BRMI_MATERIAL_NORMAL_MAP) ? mat->normalUvSetIndex : mat->heightUvSetIndex); cotangent_frame(); }
+                    // single-set scenes: the frame before the fetches too -- six values live over them instead of the corner positions and the barycentric derivatives (15)
+                    if (!PARALLAX && FRAME_EARLY && (flags & BRMI_MATERIAL_NORMAL_MAP)) { use_set(mat->normalUvSetIndex); cotangent_frame(); }
                     if (PARALLAX && (flags & BRMI_MATERIAL_PARALLAX)) {       // PSO_PARALLAX (utilities.hlsli:1869-1897): every slot on the height map's UV set moves with it
                         const brmi_camera* cam = sc.cameras + sc.perFrame->mainCameraIndex;
                         const f3 camPos{cam->positionWorldSpace[0], cam->positionWorldSpace[1], cam->positionWorldSpace[2]};
@@ -476,22 +491,19 @@ BRMI_DEV void gbuffer_body(const GBufferArgs& a, const Epi& epi) {
                         parallaxUv = parallax_coords(tb, bind(mat->heightMapIndex, mat->heightSamplerIndex), Tn, Bn, worldNormal, uv, normalize3(camPos - worldPosition), mat->heightMapScale, dUVdx, dUVdy);
                         parallaxSet = curSet; uv = parallaxUv;
                     }
-                    // One loop over the texture slots (one copy of the sampler code).  Metallic, roughness and occlusion usually are
-                    // channels of ONE texture (glTF packing): a slot bound like the previous one reuses its fetch.
-                    f4 sBase{1.0f, 1.0f, 1.0f, 1.0f}, sMetal{}, sRough{}, sAo{}, sNormal{}, sEmis{};
-                    const f4 one4{1.0f, 1.0f, 1.0f, 1.0f};
-                    f4 sL0 = one4, sL1 = one4, sL2 = one4, sL3 = one4, sL4 = one4, sL5 = one4;     // coat colour / weight / roughness, fuzz colour / weight / roughness
+                    // One loop over the six material slots (one copy of the sampler code).  Metallic, roughness and occlusion usually are
+                    // channels of ONE texture (glTF packing): a slot bound like the previous one reuses its fetch.  A slot's sample is consumed
+                    // where it arrives -- a channel, a product with the factor -- so that 13 values instead of six float4 stay live over the
+                    // fetches (round 4: the kernel spilled 67 registers at four waves per SIMD and half of its HBM writes were scratch).
+                    f4 baseColor{mat->baseColorFactor[0], mat->baseColorFactor[1], mat->baseColorFactor[2], mat->baseColorFactor[3]};
+                    float metallic = mat->metallicFactor, roughness = mat->roughnessFactor, ao = 1.0f;
+                    f3 sNormal{}, sEmis{};
                     const auto* opRec = as_space_of(mat, sc.openpbrMaterials) + mat->openPBRMaterialDataIndex;
                     {
                         uint32_t prevTi = 0xFFFFFFFFu, prevSi = 0xFFFFFFFFu, prevSet = 0xFFFFFFFFu; f4 prevSample{};      // same (texture, sampler, UV set) as the previous slot: same fetch
 #pragma nounroll
-                        for (uint32_t slot = 0; slot < (layerTex ? 12u : 6u); slot++) {
+                        for (uint32_t slot = 0; slot < 6u; slot++) {
                             uint32_t bit, ti, si, set;
-                            if (slot >= 6u) {       // ApplyOpenPBRTextureSampling (utilities.hlsli:720-846): bound when both indices are valid
-                                ti = opRec->textureBindings[2u * (slot - 6u)]; si = opRec->textureBindings[2u * (slot - 6u) + 1u]; set = opRec->textureBindings[26u + (slot - 6u)];
-                                if (ti == 0xFFFFFFFFu || si == 0xFFFFFFFFu) continue;
-                                bit = 0u;
-                            } else
                             switch (slot) {
                                 case 0: bit = BRMI_MATERIAL_BASE_COLOR_TEXTURE; ti = mat->baseColorTextureIndex; si = mat->baseColorSamplerIndex; set = mat->baseColorUvSetIndex; break;
                                 case 1: bit = BRMI_MATERIAL_METALLIC_TEXTURE; ti = mat->metallicTextureIndex; si = mat->metallicSamplerIndex; set = mat->metallicUvSetIndex; break;
@@ -500,48 +512,62 @@ BRMI_DEV void gbuffer_body(const GBufferArgs& a, const Epi& epi) {
                                 case 4: bit = BRMI_MATERIAL_NORMAL_MAP; ti = mat->normalTextureIndex; si = mat->normalSamplerIndex; set = mat->normalUvSetIndex; break;
                                 default: bit = BRMI_MATERIAL_EMISSIVE_TEXTURE; ti = mat->emissiveTextureIndex; si = mat->emissiveSamplerIndex; set = mat->emissiveUvSetIndex; break;
                             }
-                            if (slot < 6u && !(flags & bit)) continue;
+                            if (!(flags & bit)) continue;
                             use_set(set);
                             f4 t = prevSample;
                             if (ti != prevTi || si != prevSi || (MULTI_UV && curSet != prevSet) || ti >= sc.textureCount || si >= sc.samplerCount) t = sample_grad(tb, bind(ti, si), uv, dUVdx, dUVdy);
                             prevTi = ti; prevSi = si; prevSet = curSet; prevSample = t;
-                            if (slot == 0u) sBase = t; else if (slot == 1u) sMetal = t; else if (slot == 2u) sRough = t; else if (slot == 3u) sAo = t; else if (slot == 4u) sNormal = t; else if (slot == 5u) sEmis = t;
-                            else if (slot == 6u) sL0 = t; else if (slot == 7u) sL1 = t; else if (slot == 8u) sL2 = t; else if (slot == 9u) sL3 = t; else if (slot == 10u) sL4 = t; else sL5 = t;
+                            if (slot == 0u) baseColor = f4{baseColor.x * t.x, baseColor.y * t.y, baseColor.z * t.z, baseColor.w * t.w};
+                            else if (slot == 1u) metallic = swizzle4(t, mat->metallicChannel) * mat->metallicFactor;
+                            else if (slot == 2u) roughness = swizzle4(t, mat->roughnessChannel) * mat->roughnessFactor;
+                            else if (slot == 3u) ao = swizzle4(t, mat->aoChannel);
+                            else if (slot == 4u) sNormal = f3{t.x, t.y, t.z};
+                            else sEmis = f3{swizzle4(t, mat->emissiveChannels[0]), swizzle4(t, mat->emissiveChannels[1]), swizzle4(t, mat->emissiveChannels[2])};
                         }
                     }
-                    f4 baseColor{mat->baseColorFactor[0], mat->baseColorFactor[1], mat->baseColorFactor[2], mat->baseColorFactor[3]};
-                    if (flags & BRMI_MATERIAL_BASE_COLOR_TEXTURE) baseColor = f4{baseColor.x * sBase.x, baseColor.y * sBase.y, baseColor.z * sBase.z, baseColor.w * sBase.w};
-                    float metallic = mat->metallicFactor, roughness = mat->roughnessFactor, ao = 1.0f;
-                    if (flags & BRMI_MATERIAL_METALLIC_TEXTURE) metallic = swizzle4(sMetal, mat->metallicChannel) * mat->metallicFactor;
-                    if (flags & BRMI_MATERIAL_ROUGHNESS_TEXTURE) roughness = swizzle4(sRough, mat->roughnessChannel) * mat->roughnessFactor;
-                    if (flags & BRMI_MATERIAL_AO_TEXTURE) ao = swizzle4(sAo, mat->aoChannel);
                     if (flags & BRMI_MATERIAL_NORMAL_MAP) {
-                        if (!PARALLAX) { use_set(mat->normalUvSetIndex); cotangent_frame(); }
-                        const f4 t = sNormal;
-                        f3 tn = normalize3(f3{t.x, t.y, t.z} * 2.0f - f3{1.0f, 1.0f, 1.0f});
+                        if (!PARALLAX && !FRAME_EARLY) { use_set(mat->normalUvSetIndex); cotangent_frame(); }
+                        f3 tn = normalize3(sNormal * 2.0f - f3{1.0f, 1.0f, 1.0f});
                         if (flags & BRMI_MATERIAL_NEGATE_NORMALS) tn = -tn;
                         if (flags & BRMI_MATERIAL_INVERT_NORMAL_GREEN) tn.y = -tn.y;
                         normalWS = normalize3(f3{(tn.x * Tn.x + tn.y * Bn.x) + tn.z * worldNormal.x, (tn.x * Tn.y + tn.y * Bn.y) + tn.z * worldNormal.y, (tn.x * Tn.z + tn.y * Bn.z) + tn.z * worldNormal.z});
                     }
-                    f3 emissiveIn{mat->emissiveFactor[0], mat->emissiveFactor[1], mat->emissiveFactor[2]};
                     if (flags & BRMI_MATERIAL_EMISSIVE_TEXTURE) {
-                        const f4 t = sEmis;
-                        emissiveIn = f3{swizzle4(t, mat->emissiveChannels[0]), swizzle4(t, mat->emissiveChannels[1]), swizzle4(t, mat->emissiveChannels[2])} * emissiveIn;
+                        const f3 emissiveIn = sEmis * f3{mat->emissiveFactor[0], mat->emissiveFactor[1], mat->emissiveFactor[2]};
                         // ResolveCanonicalOpenPBRSurface: an all-zero sampled emissive falls back to the OpenPBR record's
-                        const auto* op = as_space_of(mat, sc.openpbrMaterials) + mat->openPBRMaterialDataIndex;
-                        const f3 canonical = f3{op->emissionColor[0], op->emissionColor[1], op->emissionColor[2]} * op->emissionLuminance;
+                        const f3 canonical = f3{opRec->emissionColor[0], opRec->emissionColor[1], opRec->emissionColor[2]} * opRec->emissionLuminance;
                         const f3 e = dot3(emissiveIn, emissiveIn) > 0.0f ? emissiveIn : canonical;
                         emissiveW = pack_half4(e.x, e.y, e.z, 0.0f);
                     }
                     albedoW = pack_unorm4(baseColor.x * vertexColor.x, baseColor.y * vertexColor.y, baseColor.z * vertexColor.z, ao);
                     mrW = (pack_unorm4(metallic, roughness, 0.0f, 0.0f) & 0xFFFFu) | (mrW & 0xFFFF0000u);       // coat roughness / fuzz weight stay the material's
                     if (layerTex) {
-                        // surface.x = saturate(record.x) [ResolveCanonicalOpenPBRSurface]; x *= sample (1 when the slot is unbound); x = saturate(x)
+                        // ApplyOpenPBRTextureSampling (utilities.hlsli:720-846): the six coat / fuzz slots, bound when both indices are valid.  A loop of
+                        // its own behind the packing of the base words: its six samples are not live over the material slots' fetches.
+                        // surface.x = saturate(record.x) [ResolveCanonicalOpenPBRSurface]; x *= sample (1 when the slot is unbound); x = saturate(x) -- applied
+                        // where the sample arrives: ten values live over the fetches instead of six float4
                         auto tbw = [&](uint32_t w) { return opRec->textureBindings[w]; };
-                        const f3 cc = sat3(sat3(f3{opRec->coatColor[0], opRec->coatColor[1], opRec->coatColor[2]}) * f3{swizzle4(sL0, tbw(12)), swizzle4(sL0, tbw(13)), swizzle4(sL0, tbw(14))});
-                        const float cw = sat(sat(opRec->coatWeight) * swizzle4(sL1, tbw(16))), cr = sat(sat(opRec->coatRoughness) * swizzle4(sL2, tbw(17)));
-                        const f3 fc = sat3(sat3(f3{opRec->fuzzColor[0], opRec->fuzzColor[1], opRec->fuzzColor[2]}) * f3{swizzle4(sL3, tbw(19)), swizzle4(sL3, tbw(20)), swizzle4(sL3, tbw(21))});
-                        const float fw = sat(sat(opRec->fuzzWeight) * swizzle4(sL4, tbw(23))), fr = sat(sat(opRec->fuzzRoughness) * swizzle4(sL5, tbw(24)));
+                        const f3 coatColor = sat3(f3{opRec->coatColor[0], opRec->coatColor[1], opRec->coatColor[2]}), fuzzColor = sat3(f3{opRec->fuzzColor[0], opRec->fuzzColor[1], opRec->fuzzColor[2]});
+                        f3 cc = sat3(coatColor * f3{1.0f, 1.0f, 1.0f}), fc = sat3(fuzzColor * f3{1.0f, 1.0f, 1.0f});
+                        float cw = sat(sat(opRec->coatWeight) * 1.0f), cr = sat(sat(opRec->coatRoughness) * 1.0f), fw = sat(sat(opRec->fuzzWeight) * 1.0f), fr = sat(sat(opRec->fuzzRoughness) * 1.0f);
+                        {
+                            uint32_t prevTi = 0xFFFFFFFFu, prevSi = 0xFFFFFFFFu, prevSet = 0xFFFFFFFFu; f4 prevSample{};
+#pragma nounroll
+                            for (uint32_t slot = 0; slot < 6u; slot++) {
+                                const uint32_t ti = opRec->textureBindings[2u * slot], si = opRec->textureBindings[2u * slot + 1u], set = opRec->textureBindings[26u + slot];
+                                if (ti == 0xFFFFFFFFu || si == 0xFFFFFFFFu) continue;
+                                use_set(set);
+                                f4 t = prevSample;
+                                if (ti != prevTi || si != prevSi || (MULTI_UV && curSet != prevSet) || ti >= sc.textureCount || si >= sc.samplerCount) t = sample_grad(tb, bind(ti, si), uv, dUVdx, dUVdy);
+                                prevTi = ti; prevSi = si; prevSet = curSet; prevSample = t;
+                                if (slot == 0u) cc = sat3(coatColor * f3{swizzle4(t, tbw(12)), swizzle4(t, tbw(13)), swizzle4(t, tbw(14))});
+                                else if (slot == 1u) cw = sat(sat(opRec->coatWeight) * swizzle4(t, tbw(16)));
+                                else if (slot == 2u) cr = sat(sat(opRec->coatRoughness) * swizzle4(t, tbw(17)));
+                                else if (slot == 3u) fc = sat3(fuzzColor * f3{swizzle4(t, tbw(19)), swizzle4(t, tbw(20)), swizzle4(t, tbw(21))});
+                                else if (slot == 4u) fw = sat(sat(opRec->fuzzWeight) * swizzle4(t, tbw(23)));
+                                else fr = sat(sat(opRec->fuzzRoughness) * swizzle4(t, tbw(24)));
+                            }
+                        }
                         coatW = pack_half4(cc.x, cc.y, cc.z, cw);
                         fuzzW = pack_half4(fc.x, fc.y, fc.z, fr);
                         mrW = (mrW & 0xFFFFu) | (pack_unorm4(0.0f, 0.0f, cr, fw) & 0xFFFF0000u);
@@ -557,13 +583,12 @@ BRMI_DEV void gbuffer_body(const GBufferArgs& a, const Epi& epi) {
             __builtin_nontemporal_store(emissiveW, &a.emissive[i]);
             if (!skipFuzz) __builtin_nontemporal_store(fuzzW, &a.fuzz[i]);
             __builtin_nontemporal_store(mrW, &a.metallicRoughness[i]);
-            __builtin_nontemporal_store((uint32_t)(f32_to_f16_bits(mvx) | (f32_to_f16_bits(mvy) << 16)), &a.motion[i]);
             if (Epi::kWanted) { outN = make_float4(normalWS.x, normalWS.y, normalWS.z, mw->opIndexF); outAl = albedoW; outMr = mrW; outCoat = coatW; outEmis = emissiveW; }
         };
         // waterfall over the distinct mesh instances of the tile (usually one or two)
         uint64_t pending = __ballot(valid);
         for (int it = 0; pending != 0ull; it++) {
-            if (it == RESOLVE_WATERFALL) {      // a tile of many small instances: per-lane loads for the rest
+            if (RESOLVE_WATERFALL > 0 && it == RESOLVE_WATERFALL) {      // a tile of many small instances: per-lane loads for the rest
                 if ((pending >> lane_id()) & 1ull)
                     finish(sc.perObject + cs.perObjectIndex, sc.normalMatrices + (size_t)cs.normalMatrixIndex * 16u, a.matWords + cs.materialDataIndex, sc.materials + cs.materialDataIndex);
                 break;

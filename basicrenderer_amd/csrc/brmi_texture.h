@@ -189,57 +189,69 @@ BRMI_DEV f4 sample_grad(const TexelTables& tb, const TexBinding& tx, f2 uv, f2 d
 
 // SWAlphaTestFailed (CLOD_SW_RASTER_DYNAMIC_ALPHA_TEST).  Everything that depends on the material alone -- the two texture
 // bindings, SampleLevel(.., 0)'s level choice -- is resolved once per cluster / record, not per pixel.
-struct AlphaLevel { const uint32_t* base; int w, h; };
-struct AlphaTex { AlphaLevel l0, l1; float frac; uint32_t filter, addressU, addressV; bool used; };
-struct AlphaMaterial { AlphaTex baseColor, opacity; float alphaFactor, cutoff; };
-static_assert(sizeof(AlphaMaterial) <= 128, "the per-material table reserves 128 B per entry");
-BRMI_DEV AlphaTex alpha_tex_of(const TexBinding& tx, bool enabled) {
+// Packed (round 4): the record is per-lane state of the rasteriser's pixel loops -- 28 registers as {pointer, w, h} x 2 levels x 2 textures made
+// k_raster_bins<true> spill; 16 now.  A level is its first texel and (w - 1) | (h - 1) << 16; the second level (read only when the sampler blends
+// mips at level-of-detail 0, i.e. frac != 0) is an offset from the first, in texels; filter and address modes of both textures share one word.
+struct AlphaTex { const uint32_t* base; uint32_t wh0; int32_t off1; uint32_t wh1; float frac; };      // 24 B
+struct AlphaMaterial { AlphaTex baseColor, opacity; float alphaFactor, cutoff; uint32_t flags, pad; };    // 64 B
+constexpr uint32_t ALPHA_FLAG_USED = 1u, ALPHA_FLAG_POINT = 2u, ALPHA_FLAG_ADDR_U_SHIFT = 2u, ALPHA_FLAG_ADDR_V_SHIFT = 4u, ALPHA_FLAG_OPACITY_SHIFT = 8u;      // per texture: used | point filter | addressU (2 bits) | addressV (2 bits)
+static_assert(sizeof(AlphaMaterial) == 64, "one cache line; the per-material table reserves 128 B per entry");
+static_assert(BRMI_ADDRESS_WRAP < 4u && BRMI_ADDRESS_MIRROR < 4u && BRMI_ADDRESS_CLAMP < 4u, "two bits per address mode");
+BRMI_DEV AlphaTex alpha_tex_of(const TexBinding& tx, bool enabled, uint32_t& flags) {
     AlphaTex t{};
-    t.used = enabled && tx.bound;
-    if (!t.used) return t;
+    flags = 0u;
+    if (!(enabled && tx.bound)) return t;
     float lod = min2(max2(0.0f + tx.sm.mipLodBias, tx.sm.minLod), tx.sm.maxLod);
     lod = min2(max2(lod, 0.0f), (float)(tx.mipCount - 1u));
-    t.filter = lod <= 0.0f ? tx.sm.magFilter : tx.sm.minFilter; t.addressU = tx.sm.addressU; t.addressV = tx.sm.addressV;
+    const uint32_t filter = lod <= 0.0f ? tx.sm.magFilter : tx.sm.minFilter;
+    auto mode = [](uint32_t m) { return (m == BRMI_ADDRESS_CLAMP || m == BRMI_ADDRESS_MIRROR) ? m : BRMI_ADDRESS_WRAP; };      // address_texel: anything else wraps
+    flags = ALPHA_FLAG_USED | (filter == BRMI_FILTER_POINT ? ALPHA_FLAG_POINT : 0u) | (mode(tx.sm.addressU) << ALPHA_FLAG_ADDR_U_SHIFT) | (mode(tx.sm.addressV) << ALPHA_FLAG_ADDR_V_SHIFT);
     uint32_t a, b;
     if (tx.sm.mipFilter == BRMI_FILTER_POINT) { a = (uint32_t)floor_to_int(lod + 0.5f); if (a > tx.mipCount - 1u) a = tx.mipCount - 1u; b = a; t.frac = 0.0f; }
     else { a = (uint32_t)floor_to_int(lod); t.frac = lod - floorf(lod); b = a + 1u > tx.mipCount - 1u ? tx.mipCount - 1u : a + 1u; }
-    t.l0 = AlphaLevel{tx.texels + as_global(tx.mipOffset)[a], (int)(tx.width >> a ? tx.width >> a : 1u), (int)(tx.height >> a ? tx.height >> a : 1u)};
-    t.l1 = AlphaLevel{tx.texels + as_global(tx.mipOffset)[b], (int)(tx.width >> b ? tx.width >> b : 1u), (int)(tx.height >> b ? tx.height >> b : 1u)};
+    auto dims = [&](uint32_t l) { const uint32_t w = tx.width >> l ? tx.width >> l : 1u, h = tx.height >> l ? tx.height >> l : 1u; return ((w - 1u) & 0xFFFFu) | ((h - 1u) << 16); };      // sides up to 65536
+    const uint32_t oa = as_global(tx.mipOffset)[a], ob = as_global(tx.mipOffset)[b];
+    t.base = tx.texels + oa; t.wh0 = dims(a); t.off1 = (int32_t)(ob - oa); t.wh1 = dims(b);
     return t;
 }
 template <typename MatPtr, typename TexPtr, typename SampPtr>
 BRMI_DEV AlphaMaterial load_alpha_material(MatPtr m, TexPtr textures, uint32_t textureCount, SampPtr samplers, uint32_t samplerCount) {
-    AlphaMaterial r;
+    AlphaMaterial r{};
     const uint32_t flags = m->materialFlags;
     r.alphaFactor = m->baseColorFactor[3]; r.cutoff = m->alphaCutoff;
-    r.baseColor = alpha_tex_of(bind_texture(textures, textureCount, samplers, samplerCount, m->baseColorTextureIndex, m->baseColorSamplerIndex), (flags & BRMI_MATERIAL_BASE_COLOR_TEXTURE) != 0u);
-    r.opacity = alpha_tex_of(bind_texture(textures, textureCount, samplers, samplerCount, m->opacityTextureIndex, m->opacitySamplerIndex), (flags & BRMI_MATERIAL_OPACITY_TEXTURE) != 0u);
+    uint32_t fb = 0u, fo = 0u;
+    r.baseColor = alpha_tex_of(bind_texture(textures, textureCount, samplers, samplerCount, m->baseColorTextureIndex, m->baseColorSamplerIndex), (flags & BRMI_MATERIAL_BASE_COLOR_TEXTURE) != 0u, fb);
+    r.opacity = alpha_tex_of(bind_texture(textures, textureCount, samplers, samplerCount, m->opacityTextureIndex, m->opacitySamplerIndex), (flags & BRMI_MATERIAL_OPACITY_TEXTURE) != 0u, fo);
+    r.flags = fb | (fo << ALPHA_FLAG_OPACITY_SHIFT);
     // a slot whose flag is set but whose descriptor is out of range reads as opaque white: alpha *= 1
     return r;
 }
-BRMI_DEV float alpha_level(const float* unorm, const AlphaLevel& L, const AlphaTex& t, f2 uv) {
-    if (t.filter == BRMI_FILTER_POINT)
-        return unorm[as_global(L.base)[(size_t)address_texel(floor_to_int(uv.y * (float)L.h), L.h, t.addressV) * (size_t)L.w + (size_t)address_texel(floor_to_int(uv.x * (float)L.w), L.w, t.addressU)] >> 24];
-    const float fx = uv.x * (float)L.w - 0.5f, fy = uv.y * (float)L.h - 0.5f;
+// one level of one texture: `flags` are the texture's six bits
+BRMI_DEV float alpha_level(const float* unorm, const uint32_t* base, uint32_t wh, uint32_t flags, f2 uv) {
+    const int w = (int)(wh & 0xFFFFu) + 1, h = (int)(wh >> 16) + 1;
+    const uint32_t addressU = (flags >> ALPHA_FLAG_ADDR_U_SHIFT) & 3u, addressV = (flags >> ALPHA_FLAG_ADDR_V_SHIFT) & 3u;
+    GlobalTexels g = as_global(base);
+    if (flags & ALPHA_FLAG_POINT)
+        return unorm[g[(size_t)address_texel(floor_to_int(uv.y * (float)h), h, addressV) * (size_t)w + (size_t)address_texel(floor_to_int(uv.x * (float)w), w, addressU)] >> 24];
+    const float fx = uv.x * (float)w - 0.5f, fy = uv.y * (float)h - 0.5f;
     const float tx_ = fx - floorf(fx), ty_ = fy - floorf(fy);
     const int x0 = floor_to_int(fx), y0 = floor_to_int(fy);
-    const int xa = address_texel(x0, L.w, t.addressU), xb = address_texel(x0 == 0x7FFFFFFF ? x0 : x0 + 1, L.w, t.addressU);
-    const int ya = address_texel(y0, L.h, t.addressV), yb = address_texel(y0 == 0x7FFFFFFF ? y0 : y0 + 1, L.h, t.addressV);
-    GlobalTexels g = as_global(L.base);
-    const uint32_t c00 = g[(size_t)ya * (size_t)L.w + (size_t)xa], c10 = g[(size_t)ya * (size_t)L.w + (size_t)xb], c01 = g[(size_t)yb * (size_t)L.w + (size_t)xa], c11 = g[(size_t)yb * (size_t)L.w + (size_t)xb];
+    const int xa = address_texel(x0, w, addressU), xb = address_texel(x0 == 0x7FFFFFFF ? x0 : x0 + 1, w, addressU);
+    const int ya = address_texel(y0, h, addressV), yb = address_texel(y0 == 0x7FFFFFFF ? y0 : y0 + 1, h, addressV);
+    const uint32_t c00 = g[(size_t)ya * (size_t)w + (size_t)xa], c10 = g[(size_t)ya * (size_t)w + (size_t)xb], c01 = g[(size_t)yb * (size_t)w + (size_t)xa], c11 = g[(size_t)yb * (size_t)w + (size_t)xb];
     const float a00 = unorm[c00 >> 24], a10 = unorm[c10 >> 24], a01 = unorm[c01 >> 24], a11 = unorm[c11 >> 24];
     const float top = a00 + tx_ * (a10 - a00), bot = a01 + tx_ * (a11 - a01);
     return top + ty_ * (bot - top);
 }
-BRMI_DEV float alpha_sample(const float* unorm, const AlphaTex& t, f2 uv) {
-    const float a = alpha_level(unorm, t.l0, t, uv);
+BRMI_DEV float alpha_sample(const float* unorm, const AlphaTex& t, uint32_t flags, f2 uv) {
+    const float a = alpha_level(unorm, t.base, t.wh0, flags, uv);
     if (t.frac == 0.0f) return a;
-    return a + t.frac * (alpha_level(unorm, t.l1, t, uv) - a);
+    return a + t.frac * (alpha_level(unorm, t.base + t.off1, t.wh1, flags, uv) - a);
 }
 BRMI_DEV bool alpha_test_failed(const float* unorm, const AlphaMaterial& m, f2 uv) {
     float alpha = m.alphaFactor;
-    if (m.baseColor.used) alpha *= alpha_sample(unorm, m.baseColor, uv);
-    if (m.opacity.used) alpha *= alpha_sample(unorm, m.opacity, uv);
+    if (m.flags & ALPHA_FLAG_USED) alpha *= alpha_sample(unorm, m.baseColor, m.flags, uv);
+    if ((m.flags >> ALPHA_FLAG_OPACITY_SHIFT) & ALPHA_FLAG_USED) alpha *= alpha_sample(unorm, m.opacity, m.flags >> ALPHA_FLAG_OPACITY_SHIFT, uv);
     return alpha < m.cutoff;
 }
 // the texcoord of a pixel from the stepped barycentrics (softwareRaster.hlsl:526-531)
