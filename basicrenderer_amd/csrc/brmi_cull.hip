@@ -1054,7 +1054,7 @@ __global__ void __launch_bounds__(256) k_cull_clusters(CullArgs a, const BucketR
         bool survives = false, occluded = false, tested = false;
         uint4 packed = make_uint4(0, 0, 0, 0);
         uint32_t bit = 0;
-        BucketRecord again{};
+        uint4 againLo = make_uint4(0u, 0u, 0u, 0u); uint2 againHi = make_uint2(0u, 0u);      // the replay record of an occluded meshlet (as plain words: a BucketRecord object here left an unused 36 B stack slot in the kernel's descriptor)
         if (idx < totalLanes) {
             const uint32_t bi = (uint32_t)(idx / a.factor), m = (uint32_t)(idx % a.factor);
             const BucketRecord b = buckets[bi];
@@ -1092,8 +1092,8 @@ __global__ void __launch_bounds__(256) k_cull_clusters(CullArgs a, const BucketR
                         survives = false;
                         if (!replay) {
                             occluded = true;
-                            again = b; again.groupIdPacked = 0x80000000u | (b.groupIdPacked & 0x7FFFFFFFu);
-                            again.meshletIndexAndCount = (1u << 16) | (lm & 0xFFFFu); again.firstBit = b.firstBit + m;
+                            againLo = make_uint4(b.instanceIndex, 0x80000000u | (b.groupIdPacked & 0x7FFFFFFFu), (1u << 16) | (lm & 0xFFFFu), b.pageSlabDescriptorIndex);
+                            againHi = make_uint2(b.pageSlabByteOffset, b.firstBit + m);
                         }
                     }
                     if (survives) {
@@ -1110,7 +1110,7 @@ __global__ void __launch_bounds__(256) k_cull_clusters(CullArgs a, const BucketR
         if (a.occlusion && a.phase == 1u) {
             const uint32_t rs = wave_append(&a.counters[CNT_REPLAY_MESHLETS], occluded);
             if (occluded) {
-                if (rs < a.recordCapacity) a.replayBuckets[rs] = again;
+                if (rs < a.recordCapacity) { uint4* dst = reinterpret_cast<uint4*>(&a.replayBuckets[rs]); dst[0] = againLo; dst[1] = make_uint4(againHi.x, againHi.y, 0u, 0u); }
                 else atomicAdd(&a.counters[CNT_DROPPED_RECORDS], 1u);
             }
         }

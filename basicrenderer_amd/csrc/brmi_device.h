@@ -127,11 +127,13 @@ BRMI_DEV float max_axis_scale(const m4& m) {   // MaxAxisScale_RowVector
 }
 
 // float -> int with the saturating semantics of v_cvt_i32_f32, stated explicitly
+// (round 4: the instruction itself.  Written as three compares and a cast the compiler kept the compares and wrapped the conversion in two
+// exec-mask sections -- a dozen instructions and two branches for each of the rasteriser's six clip divisions per row and the sampler's four
+// coordinates per footprint.  NaN -> 0, values beyond the range saturate, everything else truncates toward zero: the oracle's to_int_sat.)
 BRMI_DEV int to_int_sat(float f) {
-    if (!(f == f)) return 0;
-    if (f >= 2147483648.0f) return 2147483647;
-    if (f <= -2147483648.0f) return (-2147483647 - 1);
-    return (int)f;
+    int r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(f));
+    return r;
 }
 
 // ---- packing ----------------------------------------------------------------------------------

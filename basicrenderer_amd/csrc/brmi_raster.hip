@@ -47,7 +47,6 @@ struct AlphaRecord { AlphaTri tri; uint32_t materialDataIndex, pad[2]; };     //
 static_assert(sizeof(AlphaRecord) == 48, "AlphaRecord layout");
 constexpr int BIN_W = 256, BIN_ROWS = 16;          // bin = 4096 keys = 32 KB of LDS
 constexpr int BIN_W_SHIFT = 8, BIN_ROWS_SHIFT = 4;
-constexpr uint32_t BIN_SLICE = 1024;               // records of a bin one workgroup of k_raster_bins walks
 // a bin's record counter has a 128 B line to itself: atomics on ONE cache line serialise at 50-90 per microsecond whatever their addresses, and
 // the bins of a screen band (15 neighbours in one line, the horizon's among them) take thousands of slot reservations per frame
 constexpr uint32_t BIN_COUNT_STRIDE = BRMI_BIN_COUNT_STRIDE;

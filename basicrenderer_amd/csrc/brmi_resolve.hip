@@ -298,6 +298,9 @@ constexpr int RESOLVE_WATERFALL = BRMI_RESOLVE_WATERFALL;     // distinct mesh i
 #ifndef FRAME_EARLY
 #define FRAME_EARLY 1
 #endif
+#ifndef BRMI_GBPM_WAVES
+#define BRMI_GBPM_WAVES 3
+#endif
 #ifndef BRMI_GBM_WAVES
 #define BRMI_GBM_WAVES 3
 #endif
@@ -347,28 +350,34 @@ BRMI_DEV void gbuffer_body(const GBufferArgs& a, const Epi& epi) {
     if (!TEXTURED) { unjVP_ = uni_m4(a.frameConst[1]); prevVP_ = uni_m4(a.frameConst[2]); }
     const float winX = uni((float)pf->screenResX), winY = uni((float)pf->screenResY);
     const uint64_t end = (a.pixelCount + 63ull) & ~63ull, stride = (uint64_t)gridDim.x * blockDim.x;
-    // software pipeline: the key and the cluster record of the next tile are requested while this one is resolved (the chain
-    // key -> cluster -> triangle -> vertices is four dependent loads)
-    auto pixel_of = [&](uint64_t j, uint32_t& px, uint32_t& py) {
-        const uint64_t i = a.firstPixel + j;
-        // a wave is one 8x8 tile (firstPixel, the block size and the stride are multiples of 64): the tile's row and column come out of scalar arithmetic
-        const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(i >> 6)), within = (uint32_t)(i & 63u);
-        px = (tile % a.tilesX) * 8u + (within >> 3); py = (tile / a.tilesX) * 8u + (within & 7u);
-        return j < a.pixelCount && px < a.W && py < a.H && py >= a.bandY0 && py < a.bandY1;
+    // A wave is one 8x8 tile (firstPixel, the block size and the stride are multiples of 64).  The tile index, its row and column and every
+    // plane's address of the tile are wave-uniform: kept in scalar registers (round 4; as per-lane 64-bit indices they were a dozen vector
+    // registers of loop state, which the texture-sampling variants do not have), the lane contributes its constant offset inside the tile.
+    const uint32_t lane0 = threadIdx.x & 63u;
+    const uint64_t waveFirst = (uint64_t)blockIdx.x * blockDim.x + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
+    auto in_band = [&](uint64_t jb, uint32_t lane, uint32_t& px, uint32_t& py) {       // jb: first pixel of the wave's tile, relative to firstPixel (scalar)
+        const uint32_t tile = (uint32_t)((a.firstPixel + jb) >> 6);
+        px = (tile % a.tilesX) * 8u + (lane >> 3); py = (tile / a.tilesX) * 8u + (lane & 7u);
+        return jb + lane < a.pixelCount && px < a.W && py < a.H && py >= a.bandY0 && py < a.bandY1;
     };
-    uint64_t j0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t npx = 0, npy = 0;
-    bool nvalid = j0 < end && pixel_of(j0, npx, npy);
-    unsigned long long nkey = nvalid ? __builtin_nontemporal_load(&a.vis[a.firstPixel + j0]) : BRMI_VIS_EMPTY;
-    for (uint64_t j = j0; j < end; j += stride) {
-        const uint64_t i = a.firstPixel + j;
-        const uint32_t px = npx, py = npy;
-        bool valid = nvalid;
-        const bool inBand = nvalid;
+    // software pipeline: the key of the next tile is requested while this one is resolved (the chain key -> cluster -> triangle -> vertices is
+    // four dependent loads)
+    uint32_t px = 0, py = 0;
+    bool nvalid = waveFirst < end && in_band(waveFirst, lane0, px, py);
+    unsigned long long nkey = nvalid ? __builtin_nontemporal_load(a.vis + a.firstPixel + waveFirst + lane0) : BRMI_VIS_EMPTY;
+    for (uint64_t jb = waveFirst; jb < end; jb += stride) {
+        const uint64_t ib = a.firstPixel + jb;             // scalar; the lane's pixel is ib + lane
+        // (the lane index behind an opaque copy: what derives from it -- row and column inside the tile, the byte offsets of the plane stores -- is
+        // then computed where it is used, a VALU instruction each, instead of being hoisted out of the tile loop into registers of their own)
+        uint32_t lane = lane0;
+        asm volatile("" : "+v"(lane));
+        const uint64_t i = ib + lane;
+        bool valid = in_band(jb, lane, px, py);
+        const bool inBand = valid;
         const unsigned long long key = nkey;
         float4 outN = make_float4(0.0f, 0.0f, 0.0f, 0.0f); uint32_t outAl = 0u, outMr = 0u; unsigned long long outCoat = 0ull, outEmis = 0ull;      // the pixel's words, for the epilogue
-        if (j + stride < end) { nvalid = pixel_of(j + stride, npx, npy); nkey = nvalid ? __builtin_nontemporal_load(&a.vis[a.firstPixel + j + stride]) : BRMI_VIS_EMPTY; }
-        if (SLIM == 0 && valid && a.depth) __builtin_nontemporal_store((key == BRMI_VIS_EMPTY) ? as_f32(BRMI_DEPTH_EMPTY_BITS) : as_f32(((uint32_t)(key >> BRMI_VIS_META_BITS)) << 1), &a.depth[i]);
+        if (jb + stride < end) { uint32_t qx, qy; nvalid = in_band(jb + stride, lane, qx, qy); nkey = nvalid ? __builtin_nontemporal_load(a.vis + a.firstPixel + jb + stride + lane) : BRMI_VIS_EMPTY; }
+        if (SLIM == 0 && valid && a.depth) __builtin_nontemporal_store((key == BRMI_VIS_EMPTY) ? as_f32(BRMI_DEPTH_EMPTY_BITS) : as_f32(((uint32_t)(key >> BRMI_VIS_META_BITS)) << 1), a.depth + ib + lane);
         const uint32_t triId = (uint32_t)(key & 0x7Full);
         const uint32_t clusterIndex = (uint32_t)((key >> BRMI_VIS_TRI_BITS) & 0x3FFFFFFull);
         valid = valid && key != BRMI_VIS_EMPTY && clusterIndex < clusterCount;
@@ -431,7 +440,7 @@ BRMI_DEV void gbuffer_body(const GBufferArgs& a, const Epi& epi) {
             const f4 clipPrev = mul_point(prevWorld, prevVP);
             const float mvx = clipCur.x / clipCur.w - clipPrev.x / clipPrev.w, mvy = clipCur.y / clipCur.w - clipPrev.y / clipPrev.w;
             // (stored here, not with the other planes: the word does not depend on the material, and its two inputs would stay live over the texture fetches)
-            __builtin_nontemporal_store((uint32_t)(f32_to_f16_bits(mvx) | (f32_to_f16_bits(mvy) << 16)), &a.motion[i]);
+            __builtin_nontemporal_store((uint32_t)(f32_to_f16_bits(mvx) | (f32_to_f16_bits(mvy) << 16)), a.motion + ib + lane);
             uint32_t albedoW = mw->albedo, mrW = mw->metallicRoughness;
             unsigned long long emissiveW = mw->emissive, coatW = mw->coat, fuzzW = mw->fuzz;
             f3 normalWS = worldNormal;
@@ -577,12 +586,14 @@ BRMI_DEV void gbuffer_body(const GBufferArgs& a, const Epi& epi) {
             // streaming stores: 52 B per pixel written once and read once by the shading pass; keeping them out of the caches
             // leaves L2 / the memory-side cache to the vertex tables, the keys and the shading pass's own reads (0.149 -> 0.123 ms,
             // and 0.339 -> 0.324 ms for k_shade)
-            { float4 nv = make_float4(normalWS.x, normalWS.y, normalWS.z, mw->opIndexF); __builtin_nontemporal_store(nv.x, &a.normals[i].x); __builtin_nontemporal_store(nv.y, &a.normals[i].y); __builtin_nontemporal_store(nv.z, &a.normals[i].z); __builtin_nontemporal_store(nv.w, &a.normals[i].w); }
-            __builtin_nontemporal_store(albedoW, &a.albedo[i]);
-            if (!skipCoat) __builtin_nontemporal_store(coatW, &a.coat[i]);
-            __builtin_nontemporal_store(emissiveW, &a.emissive[i]);
-            if (!skipFuzz) __builtin_nontemporal_store(fuzzW, &a.fuzz[i]);
-            __builtin_nontemporal_store(mrW, &a.metallicRoughness[i]);
+            uint32_t laneS = lane0;
+            asm volatile("" : "+v"(laneS));
+            { float4 nv = make_float4(normalWS.x, normalWS.y, normalWS.z, mw->opIndexF); __builtin_nontemporal_store(nv.x, &(a.normals + ib)[laneS].x); __builtin_nontemporal_store(nv.y, &(a.normals + ib)[laneS].y); __builtin_nontemporal_store(nv.z, &(a.normals + ib)[laneS].z); __builtin_nontemporal_store(nv.w, &(a.normals + ib)[laneS].w); }
+            __builtin_nontemporal_store(albedoW, a.albedo + ib + laneS);
+            if (!skipCoat) __builtin_nontemporal_store(coatW, a.coat + ib + laneS);
+            __builtin_nontemporal_store(emissiveW, a.emissive + ib + laneS);
+            if (!skipFuzz) __builtin_nontemporal_store(fuzzW, a.fuzz + ib + laneS);
+            __builtin_nontemporal_store(mrW, a.metallicRoughness + ib + laneS);
             if (Epi::kWanted) { outN = make_float4(normalWS.x, normalWS.y, normalWS.z, mw->opIndexF); outAl = albedoW; outMr = mrW; outCoat = coatW; outEmis = emissiveW; }
         };
         // waterfall over the distinct mesh instances of the tile (usually one or two)
@@ -606,7 +617,7 @@ BRMI_DEV void gbuffer_body(const GBufferArgs& a, const Epi& epi) {
     }
 }
 template <bool INLINE_TABLES, bool TEXTURED, bool PARALLAX = false, bool MULTI_UV = false, int SLIM = 0>
-__global__ void __launch_bounds__(256, INLINE_TABLES ? 1 : (MULTI_UV ? BRMI_GBM_WAVES : (PARALLAX ? BRMI_GBP_WAVES : (TEXTURED ? BRMI_GBT_WAVES : BRMI_GB_WAVES)))) k_gbuffer(GBufferArgs a) {
+__global__ void __launch_bounds__(256, INLINE_TABLES ? 1 : (MULTI_UV ? (PARALLAX ? BRMI_GBPM_WAVES : BRMI_GBM_WAVES) : (PARALLAX ? BRMI_GBP_WAVES : (TEXTURED ? BRMI_GBT_WAVES : BRMI_GB_WAVES)))) k_gbuffer(GBufferArgs a) {
     gbuffer_body<INLINE_TABLES, TEXTURED, PARALLAX, MULTI_UV, SLIM>(a, NoEpilogue{});
 }
 

@@ -83,10 +83,14 @@ BRMI_DEV void stage_texel_tables(float* lds512, const float* srgbToLinear, uint3
 
 // one texture slot as the sampler sees it: descriptor and sampler state, fetched once per material (scalar loads when the
 // material index is wave-uniform: pass the tables through kconst())
-struct TexBinding { const uint32_t* texels; const uint32_t* mipOffset; uint32_t width, height, mipCount; bool srgb, bound; brmi_sampler_desc sm; };
+struct TexBinding { const uint32_t* texels; const uint32_t* mipOffset; uint32_t width, height, mipCount; bool srgb, bound; brmi_sampler_desc sm;
+                    bool waveUniform; };      // the descriptors came through the constant address space (scalar loads): every field is the same in all lanes
+template <typename T> struct is_kconst_ptr { static constexpr bool value = false; };
+template <typename T> struct is_kconst_ptr<const __attribute__((address_space(4))) T*> { static constexpr bool value = true; };
 template <typename TexPtr, typename SampPtr>
 BRMI_DEV TexBinding bind_texture(TexPtr textures, uint32_t textureCount, SampPtr samplers, uint32_t samplerCount, uint32_t textureIndex, uint32_t samplerIndex) {
     TexBinding b{};
+    b.waveUniform = is_kconst_ptr<TexPtr>::value && is_kconst_ptr<SampPtr>::value;
     b.bound = textureIndex < textureCount && samplerIndex < samplerCount;
     if (!b.bound) return b;
     const auto* td = textures + textureIndex;
@@ -154,7 +158,58 @@ BRMI_DEV LevelSetup prepare_level(const TexBinding& tx, float lodIn) {
     s.off0 = as_global(tx.mipOffset)[s.l0]; s.off1 = as_global(tx.mipOffset)[s.l1];
     return s;
 }
+// ---- the common case without branches (round 4) ---------------------------------------------------------------------------------------
+// A wave-uniform binding (the G-buffer kernel's waterfall path: one material per step) of a texture with power-of-two sides, filtered
+// linearly.  fetch_footprint decides per coordinate -- address mode, power of two or modulo, saturation of x0 + 1 -- with branches the
+// compiler turns into exec-mask sections: ~600 VALU instructions and ~60 branches per trilinear sample, measured.  Here the address modes
+// become three per-axis constants of level 0, shifted down per level (the level is per lane), and a coordinate is
+//     c = clamp(i & mask, 0, hi);  index = min(c, fold - c)
+//   wrap:   mask = n - 1,  hi = n - 1,  fold = INT_MAX  (no fold)            i & (n - 1)
+//   clamp:  mask = ~0,     hi = n - 1,  fold = INT_MAX                       clamp(i, 0, n - 1)
+//   mirror: mask = 2n - 1, hi = 2n - 1, fold = 2n - 1                        t = i & (2n - 1); t < n ? t : 2n - 1 - t
+// -- the values address_texel returns, for every 32-bit i (two's complement `&` is the mathematical modulo of a power of two); shifting
+// the level-0 constants right by the level (arithmetically: ~0 stays ~0) gives the level's, also where a side has shrunk to one texel.
+// Texel indices fit 32 bits (sides <= 16384: the chain has < 2^29 texels), so addresses are a scalar base and a 32-bit byte offset.
+struct Pow2Axis { int mask0, hi0, fold0; };
+BRMI_DEV Pow2Axis pow2_axis(uint32_t n, uint32_t mode) {
+    const int nm1 = (int)n - 1, m2 = (int)(2u * n) - 1;
+    if (mode == BRMI_ADDRESS_MIRROR) return {m2, m2, m2};
+    if (mode == BRMI_ADDRESS_CLAMP) return {-1, nm1, 0x7FFFFFFF};
+    return {nm1, nm1, 0x7FFFFFFF};
+}
+BRMI_DEV bool pow2_fast_path(const TexBinding& tx) {
+    return tx.waveUniform && (tx.width & (tx.width - 1u)) == 0u && (tx.height & (tx.height - 1u)) == 0u && tx.width <= 16384u && tx.height <= 16384u && tx.width != 0u && tx.height != 0u &&
+           tx.sm.minFilter == BRMI_FILTER_LINEAR && tx.sm.magFilter == BRMI_FILTER_LINEAR;
+}
+BRMI_DEV int address_pow2(int i, int mask, int hi, int fold) { int c = i & mask; c = c < 0 ? 0 : c; c = c > hi ? hi : c; const int m = fold - c; return c < m ? c : m; }
+BRMI_DEV int inc_sat(int x) { return x == 0x7FFFFFFF ? x : x + 1; }
+BRMI_DEV Footprint fetch_footprint_pow2(const TexBinding& tx, const Pow2Axis& ax, const Pow2Axis& ay, uint32_t levelOffset, uint32_t level, f2 uv) {
+    const uint32_t ws = tx.width >> level, hs = tx.height >> level;
+    const uint32_t w = ws ? ws : 1u, h = hs ? hs : 1u;
+    const float fx = uv.x * (float)(int)w - 0.5f, fy = uv.y * (float)(int)h - 0.5f;
+    Footprint f;
+    f.tx = fx - floorf(fx); f.ty = fy - floorf(fy);
+    const int x0 = floor_to_int(fx), y0 = floor_to_int(fy);
+    const int mx = ax.mask0 >> level, hx = ax.hi0 >> level, ox = ax.fold0 >> level, my = ay.mask0 >> level, hy = ay.hi0 >> level, oy = ay.fold0 >> level;
+    const uint32_t xa = (uint32_t)address_pow2(x0, mx, hx, ox), xb = (uint32_t)address_pow2(inc_sat(x0), mx, hx, ox);
+    const uint32_t ya = (uint32_t)address_pow2(y0, my, hy, oy), yb = (uint32_t)address_pow2(inc_sat(y0), my, hy, oy);
+    // rows and columns are < 2^14: 24-bit multiplies (full rate; v_mul_lo_u32 is a quarter-rate instruction)
+    const uint32_t rowA = __umul24(ya, w) + levelOffset, rowB = __umul24(yb, w) + levelOffset;
+    const __attribute__((address_space(1))) char* base = (const __attribute__((address_space(1))) char*)tx.texels;
+    auto texel = [&](uint32_t index) { return *(GlobalTexels)(base + (uint32_t)(index << 2)); };      // scalar base + 32-bit offset
+    f.c00 = texel(rowA + xa); f.c10 = texel(rowA + xb); f.c01 = texel(rowB + xa); f.c11 = texel(rowB + xb);
+    return f;
+}
+BRMI_DEV f4 sample_prepared_pow2(const TexelTables& tb, const TexBinding& tx, const LevelSetup& s, f2 uv) {
+    const Pow2Axis ax = pow2_axis(tx.width, tx.sm.addressU), ay = pow2_axis(tx.height, tx.sm.addressV);      // scalar: a handful of SALU instructions per sample
+    const Footprint f0 = fetch_footprint_pow2(tx, ax, ay, s.off0, s.l0, uv);
+    if (!__any(s.frac != 0.0f)) return filter_footprint(tb, f0, tx.srgb);
+    const Footprint f1 = fetch_footprint_pow2(tx, ax, ay, s.off1, s.l1, uv);
+    const f4 a = filter_footprint(tb, f0, tx.srgb);
+    return s.frac == 0.0f ? a : lerp4(a, filter_footprint(tb, f1, tx.srgb), s.frac);
+}
 BRMI_DEV f4 sample_prepared(const TexelTables& tb, const TexBinding& tx, const LevelSetup& s, f2 uv) {
+    if (pow2_fast_path(tx)) return sample_prepared_pow2(tb, tx, s, uv);      // (a scalar branch; not compiled at all for per-lane bindings)
     const Footprint f0 = fetch_footprint(tx, s.off0, s.l0, uv, s.filter);
     if (!__any(s.frac != 0.0f)) return filter_footprint(tb, f0, tx.srgb);       // a + 0 * (b - a) for every lane
     const Footprint f1 = fetch_footprint(tx, s.off1, s.l1, uv, s.filter);
@@ -194,7 +249,7 @@ BRMI_DEV f4 sample_grad(const TexelTables& tb, const TexBinding& tx, f2 uv, f2 d
 // mips at level-of-detail 0, i.e. frac != 0) is an offset from the first, in texels; filter and address modes of both textures share one word.
 struct AlphaTex { const uint32_t* base; uint32_t wh0; int32_t off1; uint32_t wh1; float frac; };      // 24 B
 struct AlphaMaterial { AlphaTex baseColor, opacity; float alphaFactor, cutoff; uint32_t flags, pad; };    // 64 B
-constexpr uint32_t ALPHA_FLAG_USED = 1u, ALPHA_FLAG_POINT = 2u, ALPHA_FLAG_ADDR_U_SHIFT = 2u, ALPHA_FLAG_ADDR_V_SHIFT = 4u, ALPHA_FLAG_OPACITY_SHIFT = 8u;      // per texture: used | point filter | addressU (2 bits) | addressV (2 bits)
+constexpr uint32_t ALPHA_FLAG_USED = 1u, ALPHA_FLAG_POINT = 2u, ALPHA_FLAG_ADDR_U_SHIFT = 2u, ALPHA_FLAG_ADDR_V_SHIFT = 4u, ALPHA_FLAG_POW2 = 64u, ALPHA_FLAG_OPACITY_SHIFT = 8u;      // per texture: used | point filter | addressU (2 bits) | addressV (2 bits) | sides are powers of two <= 16384
 static_assert(sizeof(AlphaMaterial) == 64, "one cache line; the per-material table reserves 128 B per entry");
 static_assert(BRMI_ADDRESS_WRAP < 4u && BRMI_ADDRESS_MIRROR < 4u && BRMI_ADDRESS_CLAMP < 4u, "two bits per address mode");
 BRMI_DEV AlphaTex alpha_tex_of(const TexBinding& tx, bool enabled, uint32_t& flags) {
@@ -205,7 +260,8 @@ BRMI_DEV AlphaTex alpha_tex_of(const TexBinding& tx, bool enabled, uint32_t& fla
     lod = min2(max2(lod, 0.0f), (float)(tx.mipCount - 1u));
     const uint32_t filter = lod <= 0.0f ? tx.sm.magFilter : tx.sm.minFilter;
     auto mode = [](uint32_t m) { return (m == BRMI_ADDRESS_CLAMP || m == BRMI_ADDRESS_MIRROR) ? m : BRMI_ADDRESS_WRAP; };      // address_texel: anything else wraps
-    flags = ALPHA_FLAG_USED | (filter == BRMI_FILTER_POINT ? ALPHA_FLAG_POINT : 0u) | (mode(tx.sm.addressU) << ALPHA_FLAG_ADDR_U_SHIFT) | (mode(tx.sm.addressV) << ALPHA_FLAG_ADDR_V_SHIFT);
+    const bool pow2 = (tx.width & (tx.width - 1u)) == 0u && (tx.height & (tx.height - 1u)) == 0u && tx.width <= 16384u && tx.height <= 16384u && tx.width != 0u && tx.height != 0u;
+    flags = ALPHA_FLAG_USED | (pow2 ? ALPHA_FLAG_POW2 : 0u) | (filter == BRMI_FILTER_POINT ? ALPHA_FLAG_POINT : 0u) | (mode(tx.sm.addressU) << ALPHA_FLAG_ADDR_U_SHIFT) | (mode(tx.sm.addressV) << ALPHA_FLAG_ADDR_V_SHIFT);
     uint32_t a, b;
     if (tx.sm.mipFilter == BRMI_FILTER_POINT) { a = (uint32_t)floor_to_int(lod + 0.5f); if (a > tx.mipCount - 1u) a = tx.mipCount - 1u; b = a; t.frac = 0.0f; }
     else { a = (uint32_t)floor_to_int(lod); t.frac = lod - floorf(lod); b = a + 1u > tx.mipCount - 1u ? tx.mipCount - 1u : a + 1u; }
@@ -227,7 +283,36 @@ BRMI_DEV AlphaMaterial load_alpha_material(MatPtr m, TexPtr textures, uint32_t t
     return r;
 }
 // one level of one texture: `flags` are the texture's six bits
+// (measured at compile time, round 4: with this path beside the general one the rasteriser's alpha kernels need ~40 more registers and spill; off)
+#ifndef BRMI_ALPHA_POW2_PATH
+#define BRMI_ALPHA_POW2_PATH 0
+#endif
+// the bilinear footprint of a power-of-two level without a branch (the addressing of sample_prepared_pow2, its per-axis constants derived per lane:
+// the lanes of the rasteriser's pixel loops belong to different materials)
+BRMI_DEV float alpha_level_pow2(const float* unorm, const uint32_t* base, uint32_t wh, uint32_t flags, f2 uv) {
+    const int wm1 = (int)(wh & 0xFFFFu), hm1 = (int)(wh >> 16);
+    const uint32_t w = (uint32_t)wm1 + 1u;
+    const float fx = uv.x * (float)(wm1 + 1) - 0.5f, fy = uv.y * (float)(hm1 + 1) - 0.5f;
+    const float tx_ = fx - floorf(fx), ty_ = fy - floorf(fy);
+    const int x0 = floor_to_int(fx), y0 = floor_to_int(fy);
+    const uint32_t modeU = (flags >> ALPHA_FLAG_ADDR_U_SHIFT) & 3u, modeV = (flags >> ALPHA_FLAG_ADDR_V_SHIFT) & 3u;
+    const int m2x = 2 * wm1 + 1, m2y = 2 * hm1 + 1;
+    const int hx = modeU == BRMI_ADDRESS_MIRROR ? m2x : wm1, ox = modeU == BRMI_ADDRESS_MIRROR ? m2x : 0x7FFFFFFF, mx = modeU == BRMI_ADDRESS_CLAMP ? -1 : hx;
+    const int hy = modeV == BRMI_ADDRESS_MIRROR ? m2y : hm1, oy = modeV == BRMI_ADDRESS_MIRROR ? m2y : 0x7FFFFFFF, my = modeV == BRMI_ADDRESS_CLAMP ? -1 : hy;
+    const uint32_t xa = (uint32_t)address_pow2(x0, mx, hx, ox), xb = (uint32_t)address_pow2(inc_sat(x0), mx, hx, ox);
+    const uint32_t ya = (uint32_t)address_pow2(y0, my, hy, oy), yb = (uint32_t)address_pow2(inc_sat(y0), my, hy, oy);
+    const uint32_t rowA = __umul24(ya, w), rowB = __umul24(yb, w);
+    const __attribute__((address_space(1))) char* g = (const __attribute__((address_space(1))) char*)base;
+    auto texel = [&](uint32_t index) { return *(GlobalTexels)(g + (uint32_t)(index << 2)); };
+    const uint32_t c00 = texel(rowA + xa), c10 = texel(rowA + xb), c01 = texel(rowB + xa), c11 = texel(rowB + xb);
+    const float a00 = unorm[c00 >> 24], a10 = unorm[c10 >> 24], a01 = unorm[c01 >> 24], a11 = unorm[c11 >> 24];
+    const float top = a00 + tx_ * (a10 - a00), bot = a01 + tx_ * (a11 - a01);
+    return top + ty_ * (bot - top);
+}
 BRMI_DEV float alpha_level(const float* unorm, const uint32_t* base, uint32_t wh, uint32_t flags, f2 uv) {
+#if BRMI_ALPHA_POW2_PATH
+    if ((flags & (ALPHA_FLAG_POW2 | ALPHA_FLAG_POINT)) == ALPHA_FLAG_POW2) return alpha_level_pow2(unorm, base, wh, flags, uv);      // (per lane; the general path below is skipped when no lane needs it)
+#endif
     const int w = (int)(wh & 0xFFFFu) + 1, h = (int)(wh >> 16) + 1;
     const uint32_t addressU = (flags >> ALPHA_FLAG_ADDR_U_SHIFT) & 3u, addressV = (flags >> ALPHA_FLAG_ADDR_V_SHIFT) & 3u;
     GlobalTexels g = as_global(base);
