@@ -42,6 +42,15 @@ __global__ void __launch_bounds__(256) k_lc_fill(ClusterArgs a) { lc_fill_block(
 #ifndef BRMI_SHADE_STASH_SHARED
 #define BRMI_SHADE_STASH_SHARED 0      // floats the in-flight variant parks (experiments: 6)
 #endif
+#ifndef BRMI_SHADE_OPAQUE_LANE
+#define BRMI_SHADE_OPAQUE_LANE 1
+#endif
+#ifndef BRMI_SHADE_PREFETCH
+#define BRMI_SHADE_PREFETCH 1
+#endif
+#ifndef BRMI_SHADE_STASH_ALONE
+#define BRMI_SHADE_STASH_ALONE 9       // floats the stand-alone variant parks in LDS per pixel: 9 = the metal lobe's inputs, 17 = + emissive + the diffuse fit's coefficients
+#endif
 #ifndef BRMI_SHADE_WAVES_ALONE
 #define BRMI_SHADE_WAVES_ALONE 4
 #endif
@@ -62,11 +71,14 @@ __global__ void __launch_bounds__(256, MODE != 0 ? 1 : WAVES) k_shade(ShadeArgs 
         uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
         uint32_t tx = (firstTile + t) % a.tilesX, ty = (firstTile + t) / a.tilesX;
         const uint32_t stepX = wavesInGrid % a.tilesX, stepY = wavesInGrid / a.tilesX;
-        const uint32_t lx = lane >> 3, ly = lane & 7u;
+        // (the lane index behind an opaque copy per tile: its row / column inside the tile and the byte offsets of the plane loads are then a VALU
+        // instruction each where they are used, not loop invariants in registers of their own -- the trick that took the G-buffer kernel from 73 to 59 VGPRs)
         auto fetch = [&](uint32_t tt, uint32_t ttx, uint32_t tty, bool& ok) {
-            const uint32_t px = ttx * 8u + lx, py = tty * 8u + ly;
+            uint32_t ln = lane;
+            if (BRMI_SHADE_OPAQUE_LANE) asm volatile("" : "+v"(ln));
+            const uint32_t px = ttx * 8u + (ln >> 3), py = tty * 8u + (ln & 7u);
             ok = tt < tileCount && px < a.W && py < a.H && py >= a.bandY0 && py < a.bandY1;
-            return ok ? load_raw_pixel_plain(a, ((uint64_t)(firstTile + tt) << 6), lane, px, py) : empty_raw_pixel();
+            return ok ? load_raw_pixel_plain(a, ((uint64_t)(firstTile + tt) << 6), ln, px, py) : empty_raw_pixel();
         };
         bool ok = false;
         RawPixel cur = fetch(t, tx, ty, ok);
@@ -74,10 +86,14 @@ __global__ void __launch_bounds__(256, MODE != 0 ? 1 : WAVES) k_shade(ShadeArgs 
             uint32_t nt = t + wavesInGrid, ntx = tx + stepX, nty = ty + stepY;
             if (ntx >= a.tilesX) { ntx -= a.tilesX; nty++; }
             bool nok = false;
-            const RawPixel nxt = fetch(nt, ntx, nty, nok);
+            RawPixel nxt = empty_raw_pixel();
+            if (BRMI_SHADE_PREFETCH) nxt = fetch(nt, ntx, nty, nok);
             const uint64_t tileBase = (uint64_t)(firstTile + t) << 6;
-            const uint32_t cls = shade_pixel<0, (BRMI_SHADE_METAL_STASH && WAVES == BRMI_SHADE_WAVES_ALONE && BRMI_SHADE_WAVES_ALONE != BRMI_SHADE_WAVES) ? 9 : BRMI_SHADE_STASH_SHARED>(a, k, sliceStart, unormT, camK, cur, ok, tileBase, lane);
-            shade_defer(a, t, cls, lane);
+            uint32_t ls = lane;
+            if (BRMI_SHADE_OPAQUE_LANE) asm volatile("" : "+v"(ls));
+            const uint32_t cls = shade_pixel<0, (BRMI_SHADE_METAL_STASH && WAVES == BRMI_SHADE_WAVES_ALONE && BRMI_SHADE_WAVES_ALONE != BRMI_SHADE_WAVES) ? BRMI_SHADE_STASH_ALONE : BRMI_SHADE_STASH_SHARED>(a, k, sliceStart, unormT, camK, cur, ok, tileBase, ls);
+            shade_defer(a, t, cls, ls);
+            if (!BRMI_SHADE_PREFETCH) nxt = fetch(nt, ntx, nty, nok);      // (experiments: the next tile's words requested behind this tile's shading, ~14 registers less in it)
             cur = nxt; ok = nok; t = nt; tx = ntx; ty = nty;
         }
     } else {

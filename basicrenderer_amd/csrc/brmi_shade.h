@@ -315,7 +315,9 @@ BRMI_DEV f3 light_contribution(const Luts& L, const Frag& f, const PixelCtx& c, 
         const float sv = VdotL - muIn * muOut;
         const float sOverT = sv > 0.0f ? qdiv(sv, max2(max2(muIn, muOut), 1.0e-4f)) : sv;
         const f3 single = c.eonSinglePre * (1.0f + rough * sOverT);
-        const float EOut = fon_dir_albedo_folded(muOut, c.fonA, c.fonK0, c.fonK1, c.fonK2, c.fonK3);
+        // STASH > 9: the five coefficients of the diffuse albedo fit wait in LDS too (read once per light evaluation)
+        const float EOut = STASH > 9 ? fon_dir_albedo_folded(muOut, stash[12 * 256], stash[13 * 256], stash[14 * 256], stash[15 * 256], stash[16 * 256])
+                                     : fon_dir_albedo_folded(muOut, c.fonA, c.fonK0, c.fonK1, c.fonK2, c.fonK3);
         const float k = max2(1.0e-4f, 1.0f - EOut) * c.eonEInOverDen;
         diffuse = (single + c.eonMsPre * f3{k, k, k}) * diffuseEnergyComp;
     }
@@ -510,6 +512,11 @@ BRMI_DEV uint32_t shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const flo
             metalStash[3][threadIdx.x] = ctx.base.metalMultipleScatterScale.x; metalStash[4][threadIdx.x] = ctx.base.metalMultipleScatterScale.y; metalStash[5][threadIdx.x] = ctx.base.metalMultipleScatterScale.z;
             if (STASH > 6) { metalStash[6 % (STASH ? STASH : 1)][threadIdx.x] = ctx.f90Metal; metalStash[7 % (STASH ? STASH : 1)][threadIdx.x] = ctx.mView; metalStash[8 % (STASH ? STASH : 1)][threadIdx.x] = ctx.mAvgClamped; }
         }
+        if (STASH > 9) {      // the emissive term (read once, after the lights) and the diffuse fit's coefficients (once per light evaluation): eight registers
+            constexpr int S = STASH ? STASH : 1;
+            metalStash[9 % S][threadIdx.x] = f.emissive.x; metalStash[10 % S][threadIdx.x] = f.emissive.y; metalStash[11 % S][threadIdx.x] = f.emissive.z;
+            metalStash[12 % S][threadIdx.x] = ctx.fonA; metalStash[13 % S][threadIdx.x] = ctx.fonK0; metalStash[14 % S][threadIdx.x] = ctx.fonK1; metalStash[15 % S][threadIdx.x] = ctx.fonK2; metalStash[16 % S][threadIdx.x] = ctx.fonK3;
+        }
     }
     f3 lighting{0.0f, 0.0f, 0.0f};
     // Waterfall over the distinct clusters of the wave (an 8x8 tile usually sits in one).  The loop and the staging run with every lane
@@ -612,7 +619,7 @@ BRMI_DEV uint32_t shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const flo
     }
     if (live) {
         // EvaluateOpenPBREmissive
-        if (MODE == 0) lighting = lighting + f.emissive;
+        if (MODE == 0) lighting = lighting + (STASH > 9 ? f3{stash[9 * 256], stash[10 * 256], stash[11 * 256]} : f.emissive);
         else {
             const float fuzzBase = (MODE & 2) ? 1.0f - fuzz_incoming_reflected(L, f.fuzzWeight, f.fuzzRoughness, f.NdotV) : 1.0f;
             const f3 coatT = (MODE & 1) ? coat_scale_incoming(L, ctx.coat, f.NdotV) : f3{1.0f, 1.0f, 1.0f};

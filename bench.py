@@ -51,8 +51,9 @@ VALU_PEAK_WAVE_INSTS = 1.2288e12   # wave64 VALU instructions per second: 256 CU
 # medians one per 4.2 cycles, v_rcp / v_exp / v_sqrt one per 8.2 cycles (0.30 T/s)
 VALU_PEAK_MEASURED = 0.96e12
 # profiles/<tag>_traffic.json (tools/profile.sh), keyed by (workload, material feature bits): traffic of another configuration is not this one's
-PROFILE_TAG = {("sponza", 0): "r03_sponza4k", ("bistro", 0): "r03_bistro4k", ("bistro_r2", 0): "r02_bistro4k", ("san_miguel", 0): "r02_sanmiguel4k", ("bistro_dense", 0): "r03_bistro4k_dense",
-               ("san_miguel", 24): "r03_sanmiguel4k", ("sponza", 136): "r02_sponza4k_parallax"}
+PROFILE_TAG = {("sponza", 0): "r04_sponza4k", ("bistro", 0): "r04_bistro4k", ("bistro_r2", 0): "r02_bistro4k", ("san_miguel", 0): "r02_sanmiguel4k", ("bistro_dense", 0): "r04_bistro4k_dense",
+               ("san_miguel", 24): "r04_sanmiguel4k", ("sponza", 136): "r02_sponza4k_parallax"}
+PROFILE_FALLBACK = {"r04_sponza4k": "r03_sponza4k", "r04_bistro4k": "r03_bistro4k", "r04_bistro4k_dense": "r03_bistro4k_dense", "r04_sanmiguel4k": "r03_sanmiguel4k"}      # until the round's profiles are committed
 _STREAM_CACHE = {}
 DOMINANT_KERNEL = {"raster": "k_raster", "gbuffer": "k_gbuffer", "shade": "k_shade", "cull": "k_traverse+k_cull_clusters", "clear": "k_clear_vis",
                    "light_cluster": "k_light_clustering", "depth_copy": "k_depth_copy", "hzb": "k_hzb_head", "cull2": "k_traverse+k_cull_clusters", "raster2": "k_raster"}
@@ -69,6 +70,10 @@ def main():
                          "pixel-sized triangles: > 20 k visible clusters, > 150 k meshlets tested per 4K frame (SURVEY.md 8 a-3's regime)")
     ap.add_argument("--no-second", action="store_true", help="N = 1 only: do not add the configs[1] (Sponza) measurement as `configs1` to the line")
     ap.add_argument("--no-dense", action="store_true", help="N = 1 only: do not add the dense-geometry measurement (bistro_dense) as `dense` to the line")
+    ap.add_argument("--no-third", action="store_true", help="N = 1 only: do not add the configs[3] measurement (San-Miguel-class frame, 30 %% alpha-tested and texture-sampled materials, "
+                                                             "one GPU) as `configs3` to the line")
+    ap.add_argument("--camera-path-fast", type=float, default=0.1,
+                    help="N = 1 only: path units per frame of a second, faster camera-path leg (`path_fast`: hundreds of phase-2 clusters per frame); 0 skips it")
     ap.add_argument("--camera-path", type=int, default=200,
                     help="N = 1 only: after the static-camera region, K frames along the preset's camera path (a new camera every frame, so that phase 2 of the "
                          "occlusion chain has work) reported as `path`; 0 skips it")
@@ -105,6 +110,8 @@ def main():
                          "no process group; the composer, if forced, gathers this rank's share only).  The line says so and is not an N-GPU number")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scale", type=float, default=1.0, help="fraction of the frame height the CPU baseline renders")
+    ap.add_argument("--cpu-scale-1thread", type=float, default=0.25,
+                    help="fraction of the frame height the single-thread CPU baseline renders (BASELINE.md 4(a): 1 thread and all cores; culling covers the whole frame either way)")
     args = ap.parse_args()
     if args.gpus < 1:
         fail_line(args, "--gpus must be >= 1")
@@ -147,6 +154,11 @@ def main():
         second = measure(args, "sponza", world, rank, local_rank, cpu=False, path=False)
         if out is not None:
             out["configs1"] = {k: second[k] for k in ("value", "unit", "ms_per_step", "ms_per_step_minmax", "config", "roofline", "stage_ms") if k in second}
+    if world == 1 and not args.no_third and args.workload != "san_miguel":
+        # configs[3]'s frame as SURVEY.md 8(d) config 4 states it -- 30 % alpha-tested, texture-sampled materials -- on one GPU, under the same clock
+        third = measure(args, "san_miguel", world, rank, local_rank, cpu=False, path=False)
+        if out is not None:
+            out["configs3"] = {k: third[k] for k in ("value", "unit", "ms_per_step", "ms_per_step_minmax", "config", "roofline", "stage_ms", "serial_frame_ms") if k in third}
     if world == 1 and not args.no_dense and args.workload != "bistro_dense":
         # SURVEY.md 8 a-3 / a-5's regime (tens of thousands of visible clusters, pixel-sized triangles) under the same clock as the headline
         dense = measure(args, "bistro_dense", world, rank, local_rank, cpu=False, path=False)
@@ -320,6 +332,12 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False)
         regions.append(float(t.item()))
     dt = sorted(regions)[len(regions) // 2]
 
+    if composer is not None and hasattr(composer, "wait_status"):
+        # peer-write composition: a wait for a peer's flag that timed out latches a status and the frame is composed anyway -- such a run is not a measurement
+        try:
+            composer.wait_status()
+        except Exception as e:      # noqa: BLE001
+            fail_line(args, f"peer-write composer: {e}")
     stage_ms = r.stage_times()          # mean over the last timed steps (HIP events on the execute stream); dominant stage only
     in_flight_ms = None
     if fif >= 2:
@@ -331,9 +349,11 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False)
         stage_ms = {k: (stage_ms[k] if k == dom_stage else warm_ms[k]) for k in warm_ms}
     per_stage_bytes, total_bytes = r.algorithmic_bytes()
     c = r.counters()
-    path_out = None
+    path_out, path_fast_out = None, None
     if path and n == 1 and args.camera_path > 0 and args.occlusion:
-        path_out = camera_path(args, scene, passes, streams, shade_streams, r, dev)
+        path_out = camera_path(args, scene, passes, streams, shade_streams, r, dev, PATH_STEP)
+        if args.camera_path_fast > 0:
+            path_fast_out = camera_path(args, scene, passes, streams, shade_streams, r, dev, args.camera_path_fast)
     out = None
     if rank == 0 or emulated:
         shaded = W * (band[1] - band[0]) * n            # pixels dispatched per step, all ranks
@@ -348,22 +368,27 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False)
         # workload / kernel is committed.
         traffic, valu = None, None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", PROFILE_TAG.get((workload, features), "none") + "_traffic.json")))
+            tag = PROFILE_TAG.get((workload, features), "none")
+            if not os.path.exists(os.path.join(ROOT, "profiles", tag + "_traffic.json")):
+                tag = PROFILE_FALLBACK.get(tag, tag)
+            tj = json.load(open(os.path.join(ROOT, "profiles", tag + "_traffic.json")))
             # the stage's kernels; template instantiations ("k_shade<0>", "k_raster<true>") are matched by base name.  A one-kernel stage reports
             # the instantiation that takes the most time per launch; the raster stage is three kernels launched once per occlusion phase, and
             # its traffic is their sum over the frame's launches (the committed averages are per launch, over both phases' launches)
             stage_kernels = {"raster": ["k_raster", "k_raster_bins", "k_raster_overflow"]}.get(dom, [DOMINANT_KERNEL.get(dom, dom).split("<")[0]])
-            per_frame = 2 if (dom == "raster" and args.occlusion) else 1
             traffic_sum, wi, found = 0, 0, False
             for base in stage_kernels:
                 cands = [k for k in tj if k.split("<")[0] == base]
                 if n == 1 and cands:
                     rec = tj[max(cands, key=lambda k: tj[k].get("avg_us", 0.0))]
+                    # launches per frame of THIS kernel in the committed --kernel-trace --stats run (Calls / frames; tools/pmc_report.py): since phase 2
+                    # rasterises directly while it is small, k_raster runs twice per frame but k_raster_bins / k_raster_overflow once
+                    per_frame = rec.get("calls_per_frame") or (2 if (dom == "raster" and args.occlusion) else 1)
                     traffic_sum += rec["hbm_bytes_per_launch"] * per_frame
                     wi += rec.get("valu_wave_insts_per_launch", 0) * per_frame
                     found = True
             if found:
-                traffic = traffic_sum
+                traffic = int(traffic_sum)
                 if wi:
                     # the microarchitecture guide's issue peak: one wave64 VALU instruction per 2 cycles per SIMD, 1024 SIMDs, 2.4 GHz
                     valu = {"wave_insts": int(wi), "insts_per_px": round(wi * 64.0 / (W * (band[1] - band[0])), 1), "peak_wave_insts_per_s": VALU_PEAK_WAVE_INSTS,
@@ -405,15 +430,18 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False)
             out["serial_frame_ms"] = round(serial_ms, 4)      # one pass, one stream, frames back to back (what --frames-in-flight 1 times)
         if path_out is not None:
             out["path"] = path_out
+        if path_fast_out is not None:
+            out["path_fast"] = path_fast_out
         if cpu:
             out["cpu_baseline"] = cpu_baseline(scene, args.cpu_scale)
+            out["cpu_baseline_1thread"] = cpu_baseline(scene, args.cpu_scale_1thread, threads=1, budget_s=6.0, max_frames=2)
             out["configs0"] = cpu_forward_baseline()
     for p in passes:
         p.close()
     return out
 
 
-def camera_path(args, scene, passes, streams, shade_streams, r, dev):
+def camera_path(args, scene, passes, streams, shade_streams, r, dev, path_step):
     """K frames along the preset's camera path, a new camera every frame (what the reference's CameraManager does between frames): the previous
     frame's depth chain no longer matches, phase 1 rejects what it should not, and phase 2 of the occlusion chain (replay, cull, rasterise,
     second chain build) has work -- the static-camera region times it finding nothing.  Same arrangement as the timed region (frames in flight);
@@ -421,7 +449,7 @@ def camera_path(args, scene, passes, streams, shade_streams, r, dev):
     import numpy as np
     import torch
     K = args.camera_path
-    cams = [scene.camera_at(PATH_STEP * (k + 1), PATH_STEP * k) for k in range(K)]
+    cams = [scene.camera_at(path_step * (k + 1), path_step * k) for k in range(K)]
     cam_dev = [(torch.from_numpy(c).to(dev), torch.from_numpy(cc).to(dev)) for c, cc in cams]
     fif = len(passes)
 
@@ -462,7 +490,7 @@ def camera_path(args, scene, passes, streams, shade_streams, r, dev):
     torch.cuda.synchronize()
     px = scene.width * scene.height
     return {"frames": K, "ms_per_step": round(dt / K * 1e3, 4), "value": round(px / 1e6 / (dt / K), 2), "unit": "Mpixels/s",
-            "camera": f"{PATH_STEP} path units per frame ({0.35 * PATH_STEP:.4f} m sideways, {0.6 * PATH_STEP:.4f} m ahead, {0.07 * PATH_STEP * 57.2958:.3f} degrees of yaw)",
+            "camera": f"{path_step} path units per frame ({0.35 * path_step:.4f} m sideways, {0.6 * path_step:.4f} m ahead, {0.07 * path_step * 57.2958:.3f} degrees of yaw)",
             "visible_clusters_phase1_mean": round(float(np.mean(phase1)), 1), "visible_clusters_phase2_mean": round(float(np.mean(phase2)), 1),
             "replayed_records_mean": round(float(np.mean(replayed)), 1), "frames_in_flight": fif,
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items() if v > 0},
@@ -490,18 +518,18 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
-def cpu_baseline(scene, scale):
-    """The CPU oracle (port of the reference HLSL) on the same frame, all host cores, one frame."""
+def cpu_baseline(scene, scale, threads=None, budget_s=10.0, max_frames=16):
+    """The CPU oracle (port of the reference HLSL) on the same frame: all host cores, or `threads`; whole frames (or the stated share of the rows) for about `budget_s` seconds."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc
-    cores = orc.effective_cores()
+    cores = threads or orc.effective_cores()
     f = orc.OracleFrame(scene, threads=cores)
     H = scene.height
     rows = max(8, int(H * scale) // 8 * 8)
     band = (0, rows) if rows < H else (0, 0)
     # whole frames of the same workload until ~10 s of wall time have been spent (at least 2, at most 16 frames)
     times = []
-    while len(times) < 2 or (sum(times) < 10.0 and len(times) < 16):
+    while len(times) < min(2, max_frames) or (sum(times) < budget_s and len(times) < max_frames):
         if hasattr(f, "vis"):
             del f.vis
         t0 = time.perf_counter()
@@ -516,7 +544,7 @@ def cpu_baseline(scene, scale):
     px = scene.width * (rows if rows < H else H)
     return {"value": round(px / 1e6 / dt, 3), "unit": "Mpixels/s", "cores": cores, "kind": "port",
             "sample": f"{len(times)} frames ({sum(times):.1f} s), median {dt:.2f} s per frame of rows [0,{rows if rows < H else H}) of {scene.width}x{H} ({px} px); "
-                      f"cull, raster, G-buffer, light clustering, shade; OpenMP over clusters / scanlines"}
+                      f"cull, raster, G-buffer, light clustering, shade; " + ("one thread" if cores == 1 else "OpenMP over clusters / scanlines")}
 
 
 def cpu_forward_baseline():

@@ -366,6 +366,29 @@ using namespace orc;
 
 extern "C" {
 
+// calculateLightContributionPBR on caller-supplied surface / light values, one call per sample: the hook a test uses to hold the per-light term against
+// an independently written float64 restatement of the HLSL (tests/test_oracle_cpu.py).  in: 50 floats per sample -- normal, view, lightToFrag, albedo,
+// diffuseColor, dielectricSpecularF0, metalSpecularF0, metalAverageFresnel, coatColor, coatF0, fuzzColor (3 each), baseDiffuseRoughness, specularAlpha,
+// weightedSpecularIor, dielectricSpecularWeight, metalSpecularWeight, coatWeight, coatIor, coatDarkening, coatRoughness, fuzzWeight, fuzzRoughness,
+// lightColor (3), intensity, attenuation, spotAttenuation.
+int orc_light_contribution(const brmi_scene_buffers* scp, const float* in, uint64_t n, float* out) {
+    const brmi_scene_buffers& sc = *scp;
+    const Luts L{sc.lutOpaqueDielectricEnergyComplement, sc.lutOpaqueDielectricAvgEnergyComplement, sc.lutIdealMetalEnergyComplement, sc.lutIdealMetalAvgEnergyComplement, sc.lutFuzzLTC};
+    for (uint64_t i = 0; i < n; i++) {
+        const float* p = in + i * 50;
+        auto v3 = [&](int k) { return float3{p[k], p[k + 1], p[k + 2]}; };
+        Frag f{};
+        f.normalWS = v3(0); f.viewWS = v3(3); const float3 l = v3(6);
+        f.albedo = v3(9); f.diffuseColor = v3(12); f.dielectricSpecularF0 = v3(15); f.metalSpecularF0 = v3(18); f.metalAverageFresnel = v3(21);
+        f.coatColor = v3(24); f.coatF0 = v3(27); f.fuzzColor = v3(30);
+        f.baseDiffuseRoughness = p[33]; f.specularAlpha = p[34]; f.weightedSpecularIor = p[35]; f.dielectricSpecularWeight = p[36]; f.metalSpecularWeight = p[37];
+        f.coatWeight = p[38]; f.coatIor = p[39]; f.coatDarkening = p[40]; f.coatRoughness = p[41]; f.fuzzWeight = p[42]; f.fuzzRoughness = p[43];
+        const float3 r = lightContribution(L, f, l, v3(44), p[47], p[48], p[49]);
+        out[i * 3] = r.x; out[i * 3 + 1] = r.y; out[i * 3 + 2] = r.z;
+    }
+    return 0;
+}
+
 // ComputeClusterID's slice of a view depth (lighting.hlsli:166-196).  log() = the correctly rounded fp32 logarithm (through double on both
 // sides): a pixel whose depth sits within an ulp of a slice boundary must land in the same slice on CPU and GPU, and their float logf
 // differ in the last bit.  (tests/test_oracle_cpu.py holds it against an arbitrary-precision restatement.)

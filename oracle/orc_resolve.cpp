@@ -306,6 +306,20 @@ using namespace orc;
 
 extern "C" {
 
+// CalcFullBary + InterpolateWithDeriv on caller-supplied clip-space corners (test hook, tests/test_oracle_cpu.py).  in: 19 floats per sample -- three
+// float4 corners, the pixel's NDC (2), the window size (2), three corner values; out: 12 floats -- lambda, ddx, ddy, then value / d/dx / d/dy of the corner values.
+int orc_calc_full_bary(const float* in, uint64_t n, float* out) {
+    for (uint64_t i = 0; i < n; i++) {
+        const float* p = in + i * 19;
+        const Bary b = calcFullBary(float4{p[0], p[1], p[2], p[3]}, float4{p[4], p[5], p[6], p[7]}, float4{p[8], p[9], p[10], p[11]}, float2{p[12], p[13]}, float2{p[14], p[15]});
+        const float3 v = interpDeriv(b, p[16], p[17], p[18]);
+        float* o = out + i * 12;
+        o[0] = b.lambda.x; o[1] = b.lambda.y; o[2] = b.lambda.z; o[3] = b.ddx.x; o[4] = b.ddx.y; o[5] = b.ddx.z; o[6] = b.ddy.x; o[7] = b.ddy.y; o[8] = b.ddy.z;
+        o[9] = v.x; o[10] = v.y; o[11] = v.z;
+    }
+    return 0;
+}
+
 // parallaxCoords on its own, one call per sample (tests): frame rows T / B / N, texcoord, world-space view direction, gradients
 int orc_parallax_coords(const brmi_scene_buffers* sc, uint32_t heightMapIndex, uint32_t heightSamplerIndex, float heightmapScale, const float* T, const float* B, const float* N,
                         const float* uv, const float* viewDir, const float* dUVdx, const float* dUVdy, uint64_t n, float* out) {

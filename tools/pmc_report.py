@@ -30,6 +30,8 @@ sq, n = load(f"{d}/sq/sq_counter_collection.csv")
 fe, nf = load(f"{d}/fetch/fetch_counter_collection.csv")
 wr, nw = load(f"{d}/write/write_counter_collection.csv")
 st = {r["Name"].split("(")[0]: r for r in csv.DictReader(open(f"{d}/stats/stats_kernel_stats.csv"))}
+# frames of the stats run = launches of the kernel every frame starts with; a kernel's launches per frame follow from its own call count
+frames = max(1, int(next((r["Calls"] for k, r in st.items() if "k_frame_constants" in k), "1")))
 print(f"{'kernel':44s} {'avg_us':>8s} {'calls':>6s} {'waves':>7s} {'VALU/wave':>9s} {'valu%':>6s} {'wait%':>6s} {'stall%':>6s} {'fetchMiB(raw)':>13s} {'writeMiB':>9s}")
 traffic = {}
 for k in sorted(sq, key=lambda k: -float(st.get(k, {"TotalDurationNs": 0})["TotalDurationNs"])):
@@ -43,6 +45,8 @@ for k in sorted(sq, key=lambda k: -float(st.get(k, {"TotalDurationNs": 0})["Tota
           f"{100 * s['SQ_ACTIVE_INST_VALU'] / wc:6.1f} {100 * s['SQ_WAIT_ANY'] / wc:6.1f} {100 * s['SQ_WAIT_INST_ANY'] / wc:6.1f} {fetch_kib / 1024:13.2f} {write_kib / 1024:9.2f}")
     traffic[name] = {"avg_us": round(avg, 2), "fetch_size_kib_raw": round(fetch_kib, 1), "write_size_kib": round(write_kib, 1),
                      "hbm_bytes_per_launch": int(2 * fetch_kib * 1024 + write_kib * 1024),
-                     "valu_wave_insts_per_launch": int(s["SQ_INSTS_VALU"] / max(c, 1)), "waves_per_launch": int(s["SQ_WAVES"] / max(c, 1))}
+                     "valu_wave_insts_per_launch": int(s["SQ_INSTS_VALU"] / max(c, 1)), "waves_per_launch": int(s["SQ_WAVES"] / max(c, 1)),
+                     # launches per frame in the --kernel-trace --stats run (Calls / frames): per-frame figures are per-launch averages x this
+                     "calls": int(st[k]["Calls"]) if k in st else None, "calls_per_frame": round(int(st[k]["Calls"]) / frames, 3) if k in st else None}
 if traffic_out:
     json.dump(traffic, open(traffic_out, "w"), indent=1, sort_keys=True)
