@@ -131,13 +131,16 @@ static void compute_sizes(brmi_pass* p) {
     w.binItems = take((uint64_t)p->binItemCapacity * 4);
     w.binScratch = take((uint64_t)std::max(1u, p->binScratchTiles) * 4096 * 8);
     raster_tile_grid(c.width, c.height, &p->rtilesX, &p->rtilesY);
-    w.tileCounts = take((uint64_t)p->rtilesX * p->rtilesY * 4);
-    w.tileLists = take((uint64_t)p->rtilesX * p->rtilesY * p->tileCapacity * 16);
-    p->xvertClusters = (uint32_t)std::min<uint64_t>(c.maxVisibleClusters, 1ull << 21);
-    if (const char* e = std::getenv("BRMI_XVERT_CLUSTERS")) p->xvertClusters = (uint32_t)std::max(0, std::atoi(e));   // tests: clusters beyond the cache take the overflow path
+    // the opt-in tile rasteriser's buffers (BRMI_RASTER_MODE=tiles, known since brmi_create): only a pass that runs it reserves them -- the screen-vertex
+    // cache alone is 1.5 KB per visible cluster, up to 3.2 GB per pass, and brmi_setup clears the whole workspace
+    const bool tiles = p->rasterTiles;
+    w.tileCounts = take(tiles ? (uint64_t)p->rtilesX * p->rtilesY * 4 : 16);
+    w.tileLists = take(tiles ? (uint64_t)p->rtilesX * p->rtilesY * p->tileCapacity * 16 : 16);
+    p->xvertClusters = tiles ? (uint32_t)std::min<uint64_t>(c.maxVisibleClusters, 1ull << 21) : 0u;
+    if (const char* e = std::getenv("BRMI_XVERT_CLUSTERS")) if (tiles) p->xvertClusters = (uint32_t)std::max(0, std::atoi(e));   // tests: clusters beyond the cache take the overflow path
     w.xverts = take((uint64_t)std::max(1u, p->xvertClusters) * 3 * BRMI_MESHLET_MAX_VERTS * 4);
-    w.tileOverflow = take((uint64_t)p->tileOverflowCapacity * 8);
-    w.debugStamps = take(4096 + 1024 * 1024);      // instrumented builds (-DBRMI_TILE_STAMPS) park per-phase cycle sums here
+    w.tileOverflow = take(tiles ? (uint64_t)p->tileOverflowCapacity * 8 : 16);
+    w.debugStamps = take(4096 + 1024 * 1024);      // instrumented builds (-DBRMI_TILE_STAMPS, possibly of one translation unit only) park per-phase cycle sums here
     w.clusterSetup = take((uint64_t)c.maxVisibleClusters * sizeof(ClusterSetup));
     // resolve arena: full tables (72 B per vertex + triangle slot) for up to 2^20 clusters = 9.7 GB of the 288; a configuration
     // that allows more visible clusters keeps the per-pixel path for the clusters that do not fit
@@ -619,6 +622,7 @@ int brmi_update(brmi_pass* p, const brmi_frame_update* u, brmi_stream stream) {
 // What a frame's first launch has to wait for when frames are in flight (brmi_execute_split, and the stage entry points that start a frame:
 // a graph that schedules the stages itself after a split frame gets the same ordering).  No-ops when nothing was recorded.
 static int wait_for_frames_in_flight(brmi_pass* p, brmi_stream stream) {
+    if (p->frameWaitsIssued) return BRMI_OK;      // brmi_execute_split has issued them for this frame: the stage entry points it calls do not repeat them
     // this pass's previous frame may still be resolving / shading on the other stream: its visibility buffer and tables are about to be rewritten
     if (p->frameDoneRecorded) BRMI_HIP(p, hipStreamWaitEvent(static_cast<hipStream_t>(stream), p->frameDone, 0));
     p->frameDoneRecorded = false;
@@ -713,8 +717,12 @@ int brmi_execute_split(brmi_pass* p, brmi_stream stream, brmi_stream shadeStream
     p->executesSinceTimes++;
     const bool split = shadeStream != stream;
     p->splitFrame = split;
+    // whatever way this call returns, the frame's shortcuts do not outlive it: stand-alone stage calls behind a failed frame must not find `splitFrame`
+    // (which disables the wide flat traversal), `shadeSharesChip` or the issued-waits mark still set
+    struct FrameScope { brmi_pass* p; ~FrameScope() { p->splitFrame = false; p->shadeSharesChip = false; p->frameWaitsIssued = false; p->clearFrameStateWithConstants = false; p->fuseFrameClear = false; p->seedInHzbTail = false; } } frameScope{p};
     p->resolveSetupDone = false; p->depthFinal = false;      // (a frame that failed half-way must not leave its shortcuts to the stage entry points)
     if ((rc = wait_for_frames_in_flight(p, stream))) return rc;
+    p->frameWaitsIssued = true;
     // When the phase-1 traversal is the one-launch LDS walk and the frame constants are due anyway, the frame needs no clear launch: the
     // constants kernel zeroes the culling state and the walk's launch carries the visibility clear (brmi_cull.hip, SideClear).
     static const bool rideEnv = [] { const char* e = std::getenv("BRMI_CLEAR_RIDES"); return !e || std::atoi(e) != 0; }();

@@ -173,6 +173,15 @@ BRMI_DEV bool stripe_rejects(const StripeMap& m, const brmi_camera* cam, f3 cent
     return stripe_first_owned(m, (uint32_t)r0) > (uint32_t)r1;
 }
 
+// Frustum test of an instance's or a hierarchy node's sphere, and -- interleaved partition, round 4 -- the ownership test on top of it: a sphere whose
+// screen rows (two rows of slack) hold none of this GPU's rows is not descended.  The cluster cull drops exactly such meshlets anyway
+// (stripe_rejects on the meshlet's own sphere, inside the node's); before this every rank walked every node and tested every meshlet of the
+// N-times-taller frame, which is where the render-side 0.78 of profiles/r03_rank_balance.md came from.  Dropped, not replayed.
+BRMI_DEV bool sphere_culled(const StripeMap& stripes, const brmi_camera* cam, f3 c, float r) {
+    if (sphere_outside_frustum(c, r, cam->clippingPlanes)) return true;
+    return stripe_on(stripes) && stripe_rejects(stripes, cam, c, r);
+}
+
 // K1 -------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_cull_instances(CullArgs a, NodeRecord* frontier0) {
     const brmi_scene_buffers& sc = a.sc;
@@ -189,7 +198,7 @@ __global__ void __launch_bounds__(256) k_cull_instances(CullArgs a, NodeRecord* 
             const f3 c = to_view_space(f3{inst.boundingSphere[0], inst.boundingSphere[1], inst.boundingSphere[2]}, model, view);
             const float r = inst.boundingSphere[3] * max_axis_scale(model);
             const bool bad = isnan(c.x) || isnan(c.y) || isnan(c.z) || isinf(c.x) || isinf(c.y) || isinf(c.z) || isnan(r) || isinf(r);
-            visible = !bad && !sphere_outside_frustum(c, r, cam->clippingPlanes);
+            visible = !bad && !sphere_culled(a.stripes, cam, c, r);
             root = sc.meshMetadata[sc.clodOffsets[ii].clodMeshMetadataIndex].rootNode;
             atomicAdd(&a.counters[CNT_INSTANCES_TESTED], 1u);
             if (visible) atomicAdd(&a.counters[CNT_INSTANCES_VISIBLE], 1u);
@@ -246,7 +255,7 @@ __global__ void __launch_bounds__(256) k_traverse(CullArgs a, uint32_t level, co
             const float cullR = skinned ? instR : node.cullCenterAndRadius[3];
             const f3 cVS = to_view_space(cullC, model, view);
             const float rW = cullR * scale;
-            const bool culled = !replay && sphere_outside_frustum(cVS, rW, cam->clippingPlanes);
+            const bool culled = !replay && sphere_culled(a.stripes, cam, cVS, rW);
             if (!culled) {
                 if (node.isLeaf != BRMI_NODE_INTERNAL) {
                     const brmi_lod_group* g = sc.lodGroups + (md.groupsBase + node.ownerGroupId);
@@ -330,7 +339,7 @@ __global__ void __launch_bounds__(256) k_traverse(CullArgs a, uint32_t level, co
                     const f3 cc = skinned ? instC : f3{ch->cullCenterAndRadius[0], ch->cullCenterAndRadius[1], ch->cullCenterAndRadius[2]};
                     const float cr = skinned ? instR : ch->cullCenterAndRadius[3];
                     const f3 ccVS = to_view_space(cc, model, view);
-                    emit = replay || !sphere_outside_frustum(ccVS, cr * scale, cam->clippingPlanes);
+                    emit = replay || !sphere_culled(a.stripes, cam, ccVS, cr * scale);
                     if (emit && ch->isLeaf == BRMI_NODE_INTERNAL) {
                         const f3 wc = xyz(mul_point(f3{ch->lodCenterAndRadius[0], ch->lodCenterAndRadius[1], ch->lodCenterAndRadius[2]}, model));
                         const float e = projected_error(wc, ch->lodCenterAndRadius[3] * scale, ch->maxQuadricError, scale, camPos, zNear, ortho);
@@ -441,7 +450,7 @@ __global__ void __launch_bounds__(64) k_cull_hierarchy(CullArgs a, BucketRecord*
                 const f3 c = to_view_space(instC, model, view);
                 const float r = instR * scale;
                 const bool bad = isnan(c.x) || isnan(c.y) || isnan(c.z) || isinf(c.x) || isinf(c.y) || isinf(c.z) || isnan(r) || isinf(r);
-                instVisible = small && !bad && !sphere_outside_frustum(c, r, cam->clippingPlanes);
+                instVisible = small && !bad && !sphere_culled(a.stripes, cam, c, r);
             }
             nTested += (uint32_t)__popcll(__ballot(small && j == 0u)); nVisible += (uint32_t)__popcll(__ballot(instVisible && j == 0u));
             const bool skinned = iw.skinned != 0u;
@@ -450,7 +459,7 @@ __global__ void __launch_bounds__(64) k_cull_hierarchy(CullArgs a, BucketRecord*
             const float cullR = skinned ? instR : fn.cull[3];
             const f3 cVS = to_view_space(cullC, model, view);
             const float rW = cullR * scale;
-            const bool inFrustum = mine && instVisible && !sphere_outside_frustum(cVS, rW, cam->clippingPlanes);
+            const bool inFrustum = mine && instVisible && !sphere_culled(a.stripes, cam, cVS, rW);
             bool pre = inFrustum, expand = false, hidden = false, leafOk = false;
             uint32_t slabDesc = 0, slabOff = 0;
             if (inFrustum && internal) {
@@ -554,7 +563,7 @@ __global__ void __launch_bounds__(64) k_cull_hierarchy(CullArgs a, BucketRecord*
                     const float r = instR * scale;
                     const bool bad = isnan(c.x) || isnan(c.y) || isnan(c.z) || isinf(c.x) || isinf(c.y) || isinf(c.z) || isnan(r) || isinf(r);
                     nTested++;
-                    if (bad || sphere_outside_frustum(c, r, cam->clippingPlanes)) continue;
+                    if (bad || sphere_culled(a.stripes, cam, c, r)) continue;
                     nVisible++;
                 }
                 HSTAMP(1);
@@ -572,7 +581,7 @@ __global__ void __launch_bounds__(64) k_cull_hierarchy(CullArgs a, BucketRecord*
                     const float cullR = skinned ? instR : fn.cull[3];
                     const f3 cVS = to_view_space(cullC, model, view);
                     const float rW = cullR * scale;
-                    const bool inFrustum = mine && !sphere_outside_frustum(cVS, rW, cam->clippingPlanes);
+                    const bool inFrustum = mine && !sphere_culled(a.stripes, cam, cVS, rW);
                     // internal node: children pass when its projected error is above the threshold and the depth chain does not hide it;
                     // as a child it was let through on the same two conditions (frustum, error)
                     bool pre = inFrustum, expand = false, hidden = false, leafOk = false;
@@ -685,7 +694,7 @@ __global__ void __launch_bounds__(64) k_cull_hierarchy(CullArgs a, BucketRecord*
             const f3 c = to_view_space(instC, model, view);
             const float r = instR * scale;
             const bool bad = isnan(c.x) || isnan(c.y) || isnan(c.z) || isinf(c.x) || isinf(c.y) || isinf(c.z) || isnan(r) || isinf(r);
-            const bool visible = !bad && !sphere_outside_frustum(c, r, cam->clippingPlanes);
+            const bool visible = !bad && !sphere_culled(a.stripes, cam, c, r);
             nTested++;
             if (!visible) continue;
             nVisible++;
@@ -722,7 +731,7 @@ __global__ void __launch_bounds__(64) k_cull_hierarchy(CullArgs a, BucketRecord*
                     const float cullR = skinned ? instR : node.cullCenterAndRadius[3];
                     const f3 cVS = to_view_space(cullC, model, view);
                     const float rW = cullR * scale;
-                    const bool culled = !REPLAY && sphere_outside_frustum(cVS, rW, cam->clippingPlanes);
+                    const bool culled = !REPLAY && sphere_culled(a.stripes, cam, cVS, rW);
                     if (!culled) {
                         if (node.isLeaf != BRMI_NODE_INTERNAL) {
                             const brmi_lod_group* g = sc.lodGroups + (md.groupsBase + node.ownerGroupId);
@@ -826,7 +835,7 @@ __global__ void __launch_bounds__(64) k_cull_hierarchy(CullArgs a, BucketRecord*
                                 const f3 cc = skinned ? instC : f3{ch->cullCenterAndRadius[0], ch->cullCenterAndRadius[1], ch->cullCenterAndRadius[2]};
                                 const float cr = skinned ? instR : ch->cullCenterAndRadius[3];
                                 const f3 ccVS = to_view_space(cc, model, view);
-                                emit = REPLAY || !sphere_outside_frustum(ccVS, cr * scale, cam->clippingPlanes);
+                                emit = REPLAY || !sphere_culled(a.stripes, cam, ccVS, cr * scale);
                                 if (emit && ch->isLeaf == BRMI_NODE_INTERNAL) {
                                     const f3 wc = xyz(mul_point(f3{ch->lodCenterAndRadius[0], ch->lodCenterAndRadius[1], ch->lodCenterAndRadius[2]}, model));
                                     const float e = projected_error(wc, ch->lodCenterAndRadius[3] * scale, ch->maxQuadricError, scale, camPos, zNear, ortho);
@@ -895,7 +904,7 @@ __global__ void __launch_bounds__(1024) k_cull_flat_wide(CullArgs a, BucketRecor
             const float r = instR * scale;
             const bool bad = isnan(c.x) || isnan(c.y) || isnan(c.z) || isinf(c.x) || isinf(c.y) || isinf(c.z) || isnan(r) || isinf(r);
             if (t == 0) nTested++;
-            if (bad || sphere_outside_frustum(c, r, cam->clippingPlanes)) continue;
+            if (bad || sphere_culled(a.stripes, cam, c, r)) continue;
             if (t == 0) nVisible++;
         }
         const bool skinned = iw.skinned != 0u;
@@ -907,7 +916,7 @@ __global__ void __launch_bounds__(1024) k_cull_flat_wide(CullArgs a, BucketRecor
             const float cullR = skinned ? instR : fn.cull[3];
             const f3 cVS = to_view_space(cullC, model, view);
             const float rW = cullR * scale;
-            const bool inFrustum = !sphere_outside_frustum(cVS, rW, cam->clippingPlanes);
+            const bool inFrustum = !sphere_culled(a.stripes, cam, cVS, rW);
             bool pre = inFrustum, expand = false, hidden = false, leafOk = false;
             uint32_t records = 0;
             if (inFrustum && internal) {

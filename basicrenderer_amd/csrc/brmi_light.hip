@@ -42,25 +42,43 @@ __global__ void __launch_bounds__(256) k_lc_fill(ClusterArgs a) { lc_fill_block(
 #ifndef BRMI_SHADE_STASH_SHARED
 #define BRMI_SHADE_STASH_SHARED 0      // floats the in-flight variant parks (experiments: 6)
 #endif
-#ifndef BRMI_SHADE_OPAQUE_LANE
-#define BRMI_SHADE_OPAQUE_LANE 1
+// Round 4: the stand-alone variant (brmi_execute, the stage entry point) runs FIVE waves per SIMD: the lane index goes through an opaque copy per tile
+// (what derives from it is then recomputed where it is used instead of living in hoisted registers: 125 -> 110 VGPRs), and the next tile's G-buffer words
+// are requested behind this tile's shading instead of in front of it (-14 registers: 95 VGPRs, no scratch) -- the fifth wave hides more latency than
+// the prefetch did (serial shading 0.191 -> 0.174 ms Bistro-class, 0.182 -> 0.164 Sponza-class).  The variant that shares the chip with another frame's
+// geometry half keeps the round-3 form on purpose: at 117 VGPRs it fits four waves per SIMD, runs faster itself (0.41 -> 0.33 ms in flight) and
+// starves the geometry stream -- period 0.522 -> 0.585 ms Bistro-class (profiles/r04_experiments.md).
+#ifndef BRMI_SHADE_OPAQUE_LANE_SHARED
+#define BRMI_SHADE_OPAQUE_LANE_SHARED 0
 #endif
-#ifndef BRMI_SHADE_PREFETCH
-#define BRMI_SHADE_PREFETCH 1
+#ifndef BRMI_SHADE_PREFETCH_ALONE
+#define BRMI_SHADE_PREFETCH_ALONE 0
 #endif
 #ifndef BRMI_SHADE_STASH_ALONE
 #define BRMI_SHADE_STASH_ALONE 9       // floats the stand-alone variant parks in LDS per pixel: 9 = the metal lobe's inputs, 17 = + emissive + the diffuse fit's coefficients
 #endif
 #ifndef BRMI_SHADE_WAVES_ALONE
-#define BRMI_SHADE_WAVES_ALONE 4
+#define BRMI_SHADE_WAVES_ALONE 5
+#endif
+// BRMI_SHADE_SHARED_MAXWAVES (experiments): the variant that shares the chip is capped at this many waves per SIMD -- amdgpu_waves_per_eu's upper bound makes
+// the kernel descriptor claim enough registers that no more waves fit -- 0 = no cap; BRMI_SHADE_SHARED_LEAN: that variant in the stand-alone one's form
+// (opaque lane index, no prefetch: 95 VGPRs)
+#ifndef BRMI_SHADE_SHARED_MAXWAVES
+#define BRMI_SHADE_SHARED_MAXWAVES 0
+#endif
+#ifndef BRMI_SHADE_SHARED_LEAN
+#define BRMI_SHADE_SHARED_LEAN 0
 #endif
 template <int MODE, int WAVES = BRMI_SHADE_WAVES>
-__global__ void __launch_bounds__(256, MODE != 0 ? 1 : WAVES) k_shade(ShadeArgs a) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE != 0 ? 1 : WAVES, (MODE == 0 && WAVES == BRMI_SHADE_WAVES && BRMI_SHADE_SHARED_MAXWAVES != 0) ? BRMI_SHADE_SHARED_MAXWAVES : 8)))
+k_shade(ShadeArgs a) {
     const ShadeFrame k = make_shade_frame(a);
     __shared__ float sliceStart[64];
     __shared__ float unormT[256];
     __shared__ float4 camK[9];                            // rows of projectionInverse, rows of viewInverse, camera position
     shade_stage_lds(a, k, sliceStart, unormT, camK);
+    constexpr bool ALONE = WAVES == BRMI_SHADE_WAVES_ALONE && BRMI_SHADE_WAVES_ALONE != BRMI_SHADE_WAVES;
+    constexpr bool OPAQUE_LANE = ALONE || BRMI_SHADE_OPAQUE_LANE_SHARED || BRMI_SHADE_SHARED_LEAN, PREFETCH = (!ALONE && !BRMI_SHADE_SHARED_LEAN) || (ALONE && BRMI_SHADE_PREFETCH_ALONE);
     if (MODE == 0) {
         // One 8x8 tile per wave and iteration: the tile index is wave-uniform, so the base address of every plane is scalar arithmetic and a
         // lane only adds its own constant offset (no per-lane 64-bit address math, no integer division per pixel).  Software pipeline: the
@@ -75,7 +93,7 @@ __global__ void __launch_bounds__(256, MODE != 0 ? 1 : WAVES) k_shade(ShadeArgs 
         // instruction each where they are used, not loop invariants in registers of their own -- the trick that took the G-buffer kernel from 73 to 59 VGPRs)
         auto fetch = [&](uint32_t tt, uint32_t ttx, uint32_t tty, bool& ok) {
             uint32_t ln = lane;
-            if (BRMI_SHADE_OPAQUE_LANE) asm volatile("" : "+v"(ln));
+            if (OPAQUE_LANE) asm volatile("" : "+v"(ln));
             const uint32_t px = ttx * 8u + (ln >> 3), py = tty * 8u + (ln & 7u);
             ok = tt < tileCount && px < a.W && py < a.H && py >= a.bandY0 && py < a.bandY1;
             return ok ? load_raw_pixel_plain(a, ((uint64_t)(firstTile + tt) << 6), ln, px, py) : empty_raw_pixel();
@@ -87,13 +105,13 @@ __global__ void __launch_bounds__(256, MODE != 0 ? 1 : WAVES) k_shade(ShadeArgs 
             if (ntx >= a.tilesX) { ntx -= a.tilesX; nty++; }
             bool nok = false;
             RawPixel nxt = empty_raw_pixel();
-            if (BRMI_SHADE_PREFETCH) nxt = fetch(nt, ntx, nty, nok);
+            if (PREFETCH) nxt = fetch(nt, ntx, nty, nok);
             const uint64_t tileBase = (uint64_t)(firstTile + t) << 6;
             uint32_t ls = lane;
-            if (BRMI_SHADE_OPAQUE_LANE) asm volatile("" : "+v"(ls));
+            if (OPAQUE_LANE) asm volatile("" : "+v"(ls));
             const uint32_t cls = shade_pixel<0, (BRMI_SHADE_METAL_STASH && WAVES == BRMI_SHADE_WAVES_ALONE && BRMI_SHADE_WAVES_ALONE != BRMI_SHADE_WAVES) ? BRMI_SHADE_STASH_ALONE : BRMI_SHADE_STASH_SHARED>(a, k, sliceStart, unormT, camK, cur, ok, tileBase, ls);
             shade_defer(a, t, cls, ls);
-            if (!BRMI_SHADE_PREFETCH) nxt = fetch(nt, ntx, nty, nok);      // (experiments: the next tile's words requested behind this tile's shading, ~14 registers less in it)
+            if (!PREFETCH) nxt = fetch(nt, ntx, nty, nok);      // (experiments: the next tile's words requested behind this tile's shading, ~14 registers less in it)
             cur = nxt; ok = nok; t = nt; tx = ntx; ty = nty;
         }
     } else {

@@ -153,7 +153,15 @@ int brmi_compose_alloc_shared(brmi_composer* c) {
     if (c->output) return fail(c, -4, "brmi_compose_alloc_shared: buffers are bound already");
     void* out = nullptr; void* fl = nullptr;
     CHECK_HIP(c, hipMalloc(&out, c->outputBytes * c->cfg.depth));
-    CHECK_HIP(c, hipMalloc(&fl, sizeof(FlagBlock)));
+    // The flag words are written by OTHER GPUs (over hipIpc mappings) while a kernel on this GPU polls them: coarse-grained device memory is only
+    // guaranteed coherent across agents at kernel boundaries, so a polling wave could keep reading a stale line from this GPU's own L2 until the
+    // timeout.  Uncached (MTYPE_UC) device memory, as RCCL takes for its own flags: every access goes to memory.  The images stay ordinary
+    // device memory on purpose: they are read by kernels launched AFTER the wait kernel has seen the landed words (a kernel boundary), and
+    // uncached images would make every consumer read them at fabric speed.
+    if (hipExtMallocWithFlags(&fl, sizeof(FlagBlock), hipDeviceMallocUncached) != hipSuccess) {
+        (void)hipGetLastError();
+        CHECK_HIP(c, hipExtMallocWithFlags(&fl, sizeof(FlagBlock), hipDeviceMallocFinegrained));
+    }
     CHECK_HIP(c, hipMemset(fl, 0, sizeof(FlagBlock)));
     CHECK_HIP(c, hipDeviceSynchronize());
     c->output = static_cast<uint8_t*>(out); c->flags = static_cast<FlagBlock*>(fl); c->ownsShared = true;
