@@ -269,6 +269,7 @@ void brmi_destroy(brmi_pass* p) {
     for (brmi_pass* user : p->historyUsers) user->history = nullptr;
     if (p->chainReady) (void)hipEventDestroy(p->chainReady);
     if (p->geometryDone) (void)hipEventDestroy(p->geometryDone);
+    if (p->cullDone) (void)hipEventDestroy(p->cullDone);
     if (p->frameDone) (void)hipEventDestroy(p->frameDone);
     if (p->phase2FeedbackHost) (void)hipHostFree(p->phase2FeedbackHost);
     delete p;
@@ -741,6 +742,17 @@ int brmi_execute_split(brmi_pass* p, brmi_stream stream, brmi_stream shadeStream
     if (rc) return rc;
     if ((rc = brmi_cull(p, 1, stream))) return rc;
     }
+    // The per-cluster resolve tables need the cluster list, not the keys: for the phase-1 clusters they are made NOW, on the shading stream (idle until
+    // this frame's pixel pass), beside the rasteriser -- the geometry half is a chain of latency-bound launches and this one was 40 us at its end.
+    // (Not on frames of more triangles than pixels, whose setup skips clusters that own no pixel and so needs the final keys.)
+    static const bool earlyEnv = [] { const char* e = std::getenv("BRMI_EARLY_RESOLVE_SETUP"); return !e || std::atoi(e) != 0; }();
+    const bool earlySetup = split && earlyEnv && !resolve_setup_marks(p);
+    if (earlySetup) {
+        if (!p->cullDone) BRMI_HIP(p, hipEventCreateWithFlags(&p->cullDone, hipEventDisableTiming));
+        BRMI_HIP(p, hipEventRecord(p->cullDone, static_cast<hipStream_t>(stream)));
+        BRMI_HIP(p, hipStreamWaitEvent(static_cast<hipStream_t>(shadeStream), p->cullDone, 0));
+        if ((rc = launch_resolve_setup(p, static_cast<hipStream_t>(shadeStream), 1u))) return rc;
+    }
     if ((rc = brmi_raster(p, 1, stream))) return rc;
     if (p->cfg.enableOcclusionCulling) {
         // reference graph: LinearDepthCopyPass1 -> LinearDepthDownsamplePass1 -> HierarchicalCullingPass2 -> ...RasterizeClustersPass2
@@ -764,7 +776,7 @@ int brmi_execute_split(brmi_pass* p, brmi_stream stream, brmi_stream shadeStream
     // the Bistro-class 4K frame -- both are bound by VALU issue (the G-buffer kernel at six waves per SIMD as well), so not reading the
     // 48 B per pixel back buys 6 us of the frame.  Kept as a tested variant, not as the default: the two-kernel frame is what the profiles describe.
     if (split) {
-        if ((rc = launch_resolve_setup(p, static_cast<hipStream_t>(stream)))) return rc;
+        if ((rc = launch_resolve_setup(p, static_cast<hipStream_t>(stream), earlySetup ? 2u : 0u))) return rc;
         p->resolveSetupDone = true;
         if (!p->geometryDone) BRMI_HIP(p, hipEventCreateWithFlags(&p->geometryDone, hipEventDisableTiming));
         if (!p->frameDone) BRMI_HIP(p, hipEventCreateWithFlags(&p->frameDone, hipEventDisableTiming));

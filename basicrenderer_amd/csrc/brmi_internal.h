@@ -224,6 +224,7 @@ struct brmi_pass {
     hipEvent_t chainReady = nullptr; // recorded by brmi_execute after the frame's last chain build when another pass may be reading it
     bool chainRecorded = false;
     brmi_stream chainStream = nullptr;   // the stream chainReady was last recorded on
+    hipEvent_t cullDone = nullptr;      // brmi_execute_split: the phase-1 cluster list is final (the resolve tables of those clusters are made beside the rasteriser)
     hipEvent_t geometryDone = nullptr, frameDone = nullptr;   // brmi_execute_split: geometry half -> shading half, and the frame's end on the shading stream
     bool frameDoneRecorded = false;
     std::vector<brmi_pass*> historyUsers;   // passes whose `history` is this pass (unlinked when it is destroyed)
@@ -270,7 +271,8 @@ void raster_tile_grid(uint32_t width, uint32_t height, uint32_t* tilesX, uint32_
 int launch_depth_copy(brmi_pass* p, hipStream_t s);
 int launch_hzb(brmi_pass* p, hipStream_t s, bool fromVisibility, bool onlyIfPhase2Drew);
 int launch_gbuffer(brmi_pass* p, hipStream_t s);
-int launch_resolve_setup(brmi_pass* p, hipStream_t s);
+int launch_resolve_setup(brmi_pass* p, hipStream_t s, uint32_t part);
+bool resolve_setup_marks(brmi_pass* p);
 int launch_light_clustering(brmi_pass* p, hipStream_t s);
 int launch_expand_luts(brmi_pass* p, hipStream_t s);
 int launch_shade(brmi_pass* p, hipStream_t s);

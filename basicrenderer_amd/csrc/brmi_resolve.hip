@@ -37,6 +37,7 @@ struct GBufferArgs {
     const ClusterUv* clusterUv; float2* uvs;      // textured scenes: where the UV sets of every visible cluster live, decoded texcoords of the arena's vertices
     uint32_t uvSets;                              // sets the materials of the scene address (1 unless one names a set > 0): uvs holds [set][vertCapacity]
     uint32_t* colors;                             // scenes with vertex colours: the RGBA8 colour of the arena's vertices
+    uint32_t setupPart;            // k_resolve_setup: 0 = every visible cluster, 1 = the phase-1 clusters only (launched beside the rasteriser), 2 = the phase-2 clusters only
     uint32_t variantSelect;        // 0: run; 1: run only when no cluster spilled out of the arena; 2: only when one did (counters[CNT_RESOLVE_SPILL])
 };
 
@@ -80,13 +81,15 @@ __global__ void __launch_bounds__(256) k_mark_used_clusters(GBufferArgs a, uint8
 __global__ void __launch_bounds__(64) k_resolve_setup(GBufferArgs a) {
     __shared__ float cx[BRMI_MESHLET_MAX_VERTS], cy[BRMI_MESHLET_MAX_VERTS], cw[BRMI_MESHLET_MAX_VERTS];
     const uint32_t lane = threadIdx.x;
-    const uint32_t clusterCount = min(a.counters[CNT_VISIBLE] + a.counters[CNT_VISIBLE2], a.clusterCapacity);
-    const bool marked = a.counters[CNT_RESOLVE_MARKED] != 0u;
-    if (blockIdx.x == 0u && lane == 0u && a.hostFeedback) {      // tell the host whether frames like this one need the marking pass (its hint for the next frames)
+    // part 1 runs while the rasteriser and the phase-2 culling are still at work: it reads the phase-1 count only (final since the compaction) and never the marks
+    const uint32_t firstCluster = a.setupPart == 2u ? min(a.counters[CNT_VISIBLE], a.clusterCapacity) : 0u;
+    const uint32_t clusterCount = a.setupPart == 1u ? min(a.counters[CNT_VISIBLE], a.clusterCapacity) : min(a.counters[CNT_VISIBLE] + a.counters[CNT_VISIBLE2], a.clusterCapacity);
+    const bool marked = a.setupPart == 0u && a.counters[CNT_RESOLVE_MARKED] != 0u;
+    if (blockIdx.x == 0u && lane == 0u && a.hostFeedback && a.setupPart != 1u) {      // tell the host whether frames like this one need the marking pass (its hint for the next frames)
         const uint64_t tris = ((uint64_t)a.counters[CNT_SUM_TRIS_HI] << 32) | a.counters[CNT_SUM_TRIS_LO];
         __hip_atomic_store(a.hostFeedback + 1, tris * 2ull > a.pixelCount ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    for (uint32_t c = blockIdx.x; c < clusterCount; c += gridDim.x) {
+    for (uint32_t c = firstCluster + blockIdx.x; c < clusterCount; c += gridDim.x) {
         if (marked && a.used[c] == 0) continue;      // no pixel shows this cluster
         const ClusterSetup cs = a.setup[c];
         if (cs.vertBase == BRMI_ARENA_NONE) continue;          // arena full: the pixel pass walks this cluster's data itself
@@ -638,7 +641,7 @@ __global__ void __launch_bounds__(256, BRMI_FUSED_WAVES) k_gbuffer_shade(GBuffer
 
 static GBufferArgs gbuffer_args_of(brmi_pass* p) {
     GBufferArgs a;
-    a.hostFeedback = nullptr;
+    a.hostFeedback = nullptr; a.setupPart = 0u;
     a.sc = shading_scene_of(p);      // the frame's camera / per-frame record as the constants kernel saw them (FrameSnapshot)
     a.clusters = static_cast<const uint4*>(p->res[BRMI_RES_VISIBLE_CLUSTERS]); a.counters = p->counters();
     a.vis = static_cast<const unsigned long long*>(p->res[BRMI_RES_VISIBILITY]);
@@ -663,10 +666,20 @@ static GBufferArgs gbuffer_args_of(brmi_pass* p) {
 
 // The per-cluster tables of the pixel pass.  Part of brmi_gbuffer; brmi_execute_split runs it at the end of the geometry half instead (it
 // needs the final cluster list and keys only), so that the shading half starts with the pixel pass.
-int launch_resolve_setup(brmi_pass* p, hipStream_t s) {
+// whether frames like the recent ones want the marking pass (which needs the final keys: the setup then cannot start before the rasteriser is done)
+bool resolve_setup_marks(brmi_pass* p) {
+    return (uint64_t)p->totalBits * BRMI_MESHLET_MAX_TRIS * 2ull > p->bandPixelCount && (!p->ensureFeedback() || reinterpret_cast<volatile uint32_t*>(p->phase2FeedbackHost)[1] != 0u);
+}
+int launch_resolve_setup(brmi_pass* p, hipStream_t s, uint32_t part) {
     if (int rc = ensure_frame_constants(p, s)) return rc;
     GBufferArgs a = gbuffer_args_of(p);
     a.hostFeedback = p->ensureFeedback() ? p->phase2FeedbackDev : nullptr;
+    a.setupPart = part;
+    if (part != 0u) {      // (brmi_execute_split: phase-1 clusters beside the rasteriser on the shading stream, phase-2 clusters -- usually a handful -- at the end of the geometry half)
+        hipLaunchKernelGGL(k_resolve_setup, dim3(part == 1u ? 8192 : 512), dim3(64), 0, s, a);
+        BRMI_LAUNCH_CHECK(p, "k_resolve_setup");
+        return BRMI_OK;
+    }
     // the marking pass only acts on frames with more than half a triangle per pixel; no cut through the scene's DAGs has more triangles than all
     // its meshlets together (totalBits: one survivor bit per meshlet of every instance), so most scenes can never be such a frame
     // ... and whether recent frames were of that kind the host reads from a word k_resolve_setup stores (no wait; a stale "no" only means
@@ -681,7 +694,7 @@ int launch_resolve_setup(brmi_pass* p, hipStream_t s) {
 int launch_gbuffer(brmi_pass* p, hipStream_t s) {
     if (int rc = ensure_frame_constants(p, s)) return rc;
     if (p->resolveSetupDone) p->resolveSetupDone = false;
-    else if (int rc = launch_resolve_setup(p, s)) return rc;
+    else if (int rc = launch_resolve_setup(p, s, 0u)) return rc;
     GBufferArgs a = gbuffer_args_of(p);
     // inside brmi_execute with occlusion culling the depth map is final; with the layer planes holding the scene's one coat / fuzz word the
     // slim instantiations leave 20 B per pixel unwritten.  The fallback variant (arena overflow) writes everything: same values.
