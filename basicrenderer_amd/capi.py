@@ -134,7 +134,7 @@ class ComposeConfig(C.Structure):
 
 COMPOSE_EXPORTS = ["brmi_compose_unique_id", "brmi_compose_create", "brmi_compose_staging_bytes", "brmi_compose_output_bytes", "brmi_compose_bind",
                    "brmi_compose_submit", "brmi_compose_finish", "brmi_compose_destroy", "brmi_compose_last_error",
-                   "brmi_compose_alloc_shared", "brmi_compose_export", "brmi_compose_import", "brmi_compose_last_wait_status"]
+                   "brmi_compose_alloc_shared", "brmi_compose_export", "brmi_compose_import", "brmi_compose_last_wait_status", "brmi_compose_submit_rows"]
 COMPOSE_HANDLE_BYTES = 160
 _compose_lib = None
 
@@ -167,6 +167,7 @@ def compose_lib():
         lib.brmi_compose_export.argtypes = [vp, C.c_char_p]
         lib.brmi_compose_import.argtypes = [vp, C.c_char_p, u32]
         lib.brmi_compose_last_wait_status.argtypes = [vp]
+        lib.brmi_compose_submit_rows.argtypes = [vp, vp, u32, u32, vp]
         lib.brmi_compose_destroy.restype = None
         lib.brmi_compose_last_error.argtypes = [vp]
         lib.brmi_compose_last_error.restype = C.c_char_p
@@ -220,7 +221,7 @@ def scene_lib():
 BRMI_EXPORTS = ["brmi_abi_version", "brmi_default_config", "brmi_create", "brmi_declare", "brmi_set_scene", "brmi_setup",
                 "brmi_update", "brmi_execute", "brmi_execute_split", "brmi_destroy", "brmi_last_error", "brmi_clear_visibility", "brmi_cull",
                 "brmi_raster", "brmi_depth_copy", "brmi_build_hzb", "brmi_invalidate_hzb", "brmi_set_history_source", "brmi_gbuffer", "brmi_light_clustering",
-                "brmi_shade", "brmi_read_counters", "brmi_stage_times", "brmi_set_timed_stages", "brmi_algorithmic_bytes", "brmi_debug_arith", "brmi_debug_arith_in_range", "brmi_debug_read_bin_records"]
+                "brmi_shade", "brmi_set_shade_slabs", "brmi_read_counters", "brmi_stage_times", "brmi_set_timed_stages", "brmi_algorithmic_bytes", "brmi_debug_arith", "brmi_debug_arith_in_range", "brmi_debug_read_bin_records"]
 
 
 def brmi_lib():
@@ -253,6 +254,7 @@ def brmi_lib():
             getattr(lib, n).argtypes = [vp, vp]
         lib.brmi_invalidate_hzb.argtypes = [vp]
         lib.brmi_set_history_source.argtypes = [vp, vp]
+        lib.brmi_set_shade_slabs.argtypes = [vp, u32, vp, vp]
         lib.brmi_cull.argtypes = [vp, u32, vp]
         lib.brmi_raster.argtypes = [vp, u32, vp]
         lib.brmi_read_counters.argtypes = [vp, C.POINTER(Counters), vp]

@@ -250,6 +250,7 @@ class PeerBandComposer:
         self._check(self.lib.brmi_compose_import(self._h, b"".join(handles), world), "brmi_compose_import")
         ob = self.lib.brmi_compose_output_bytes(self._h)
         self.surface, self.depth, self.frames, self.dev, self._ob, self.transport = surface_u8, depth, 0, dev, ob, transport
+        self._band = tuple(band)
         self.out = [None] * depth
 
     def _check(self, rc, what):
@@ -263,6 +264,16 @@ class PeerBandComposer:
     def submit(self, surface_u8=None):
         slot = self._check(self.lib.brmi_compose_submit(self._h, (self.surface if surface_u8 is None else surface_u8).data_ptr(), self._stream()), "brmi_compose_submit")
         self.frames += 1
+        return slot
+
+    def submit_rows(self, row0, row1, surface_u8=None, stream_ptr=None):
+        """One slab of the frame: rows [row0, row1) of the band, whose shading is already enqueued on the current stream; the stores travel on the
+        composer's own stream while the current stream goes on shading (brmi_compose_submit_rows).  The slab that ends at the band's last row
+        closes the frame."""
+        slot = self._check(self.lib.brmi_compose_submit_rows(self._h, (self.surface if surface_u8 is None else surface_u8).data_ptr(), self.C.c_uint32(row0), self.C.c_uint32(row1),
+                                                               self._stream() if stream_ptr is None else self.C.c_void_p(stream_ptr)), "brmi_compose_submit_rows")
+        if row1 == self._band[1]:
+            self.frames += 1
         return slot
 
     def finish(self):

@@ -701,6 +701,11 @@ int brmi_light_clustering(brmi_pass* p, brmi_stream stream) {
     CHECK_READY(p); hipStream_t s = static_cast<hipStream_t>(stream);
     STAGE_BEGIN(p, BRMI_STAGE_LIGHT_CLUSTER, s); int rc = launch_light_clustering(p, s); STAGE_END(p, BRMI_STAGE_LIGHT_CLUSTER, s); return rc;
 }
+int brmi_set_shade_slabs(brmi_pass* p, uint32_t slabs, brmi_slab_fn fn, void* user) {
+    if (!p) return BRMI_ERR_INVALID;
+    p->shadeSlabs = (fn && slabs > 1u) ? slabs : 0u; p->shadeSlabFn = p->shadeSlabs ? fn : nullptr; p->shadeSlabUser = p->shadeSlabs ? user : nullptr;
+    return BRMI_OK;
+}
 int brmi_shade(brmi_pass* p, brmi_stream stream) {
     CHECK_READY(p); hipStream_t s = static_cast<hipStream_t>(stream);
     STAGE_BEGIN(p, BRMI_STAGE_SHADE, s); int rc = launch_shade(p, s); STAGE_END(p, BRMI_STAGE_SHADE, s); return rc;

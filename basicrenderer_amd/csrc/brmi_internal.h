@@ -188,6 +188,7 @@ struct brmi_pass {
     uint32_t phase2DirectMax = 256;   // BRMI_PHASE2_DIRECT_MAX: direct rasterisation while the last known phase-2 count is at most this (0: always bins)
     uint32_t clearRiderBlocks = 8192; // single-wave workgroups of the visibility clear that ride on the traversal launch (BRMI_CLEAR_RIDER_BLOCKS)
     bool splitFrame = false;         // brmi_execute_split with two streams: this frame's launches share the chip with another frame's
+    uint32_t shadeSlabs = 0; brmi_slab_fn shadeSlabFn = nullptr; void* shadeSlabUser = nullptr;      // brmi_set_shade_slabs
     bool frameWaitsIssued = false;   // brmi_execute_split has issued this frame's cross-stream waits (the stage entry points it calls skip theirs)
     bool wideFlat = true;            // BRMI_FLAT_WIDE=0: hierarchies of more than 256 nodes take the level walk
     bool anyWideFlat = false, allMeshesFlat = false;      // brmi_set_scene: some mesh has 257 .. 8192 nodes / every mesh has flat tables

@@ -215,9 +215,30 @@ ShadeArgs shade_args_of(brmi_pass* p) {
     return a;
 }
 
+static int launch_shade_range(brmi_pass* p, hipStream_t s, uint32_t row0, uint32_t row1, uint32_t share);
 int launch_shade(brmi_pass* p, hipStream_t s) {
     if (int rc = ensure_frame_constants(p, s)) return rc;
-    const ShadeArgs a = shade_args_of(p);
+    if (p->shadeSlabs > 1u && p->shadeSlabFn && !p->plainPixelsShaded) {
+        // brmi_set_shade_slabs: the band in slabs of whole 8-row tile rows, top to bottom; after each slab's launches the host hook (the composition of those rows)
+        const uint32_t y0 = p->bandY0, y1 = p->bandY1, tileRows = (y1 - y0 + 7u) / 8u, n = std::min(p->shadeSlabs, std::max(1u, tileRows));
+        for (uint32_t k = 0; k < n; k++) {
+            const uint32_t r0 = y0 + (uint32_t)((uint64_t)tileRows * k / n) * 8u, r1 = std::min(y1, y0 + (uint32_t)((uint64_t)tileRows * (k + 1u) / n) * 8u);
+            if (r1 <= r0) continue;
+            if (int rc = launch_shade_range(p, s, r0, r1, n)) return rc;
+            p->shadeSlabFn(p->shadeSlabUser, r0, r1, static_cast<brmi_stream>(s));
+        }
+        return BRMI_OK;
+    }
+    return launch_shade_range(p, s, p->bandY0, p->bandY1, 1u);
+}
+// the deferred shading of the band's rows [row0, row1) (row0 a multiple of 8 above the band's first row); share: the launch is one of that many
+static int launch_shade_range(brmi_pass* p, hipStream_t s, uint32_t row0, uint32_t row1, uint32_t share) {
+    ShadeArgs a = shade_args_of(p);
+    if (share > 1u) {
+        const uint64_t first = a.firstPixel + (uint64_t)((row0 - p->bandY0) / 8u) * p->tilesX * 64ull;
+        a.pixelCount = (uint64_t)((row1 - row0 + 7u) / 8u) * p->tilesX * 64ull; a.firstPixel = first;
+        a.bandY0 = row0; a.bandY1 = row1;
+    }
     p->shadeSerial++;
     // inside brmi_execute the plain pixels may have been shaded by the fused G-buffer kernel already (brmi_resolve.hip: k_gbuffer_shade)
     if (p->plainPixelsShaded) p->plainPixelsShaded = false;
@@ -226,8 +247,8 @@ int launch_shade(brmi_pass* p, hipStream_t s) {
     // (Bistro 4K, two frames in flight: 0.436 -> 0.413 ms per frame; 16384: 0.425, 2048: 0.49)
     else {
         static const uint32_t pad = [] { const char* e = std::getenv("BRMI_SHADE_LDS_PAD"); return e ? (uint32_t)std::atoi(e) : 0u; }();   // (experiment: unused dynamic LDS caps the kernel's occupancy)
-        if (p->shadeSharesChip || BRMI_SHADE_WAVES_ALONE == BRMI_SHADE_WAVES) hipLaunchKernelGGL((k_shade<0, BRMI_SHADE_WAVES>), dim3(p->shadeGridShared), dim3(256), pad, s, a);
-        else hipLaunchKernelGGL((k_shade<0, BRMI_SHADE_WAVES_ALONE>), dim3(8192), dim3(256), pad, s, a);
+        if (p->shadeSharesChip || BRMI_SHADE_WAVES_ALONE == BRMI_SHADE_WAVES) hipLaunchKernelGGL((k_shade<0, BRMI_SHADE_WAVES>), dim3(std::max(256u, p->shadeGridShared / share)), dim3(256), pad, s, a);
+        else hipLaunchKernelGGL((k_shade<0, BRMI_SHADE_WAVES_ALONE>), dim3(std::max(256u, 8192u / share)), dim3(256), pad, s, a);
     }
     // deferred pixels by class: coat, fuzz, both -- only the variants some material of the scene can need
     if (p->sceneHasCoat) hipLaunchKernelGGL(k_shade<1>, dim3(512), dim3(256), 0, s, a);

@@ -39,6 +39,9 @@ struct brmi_composer {
     uint8_t* staging = nullptr; uint8_t* output = nullptr;
     uint64_t bandOffset = 0, bandBytes = 0, stagingBytes = 0, outputBytes = 0, pixels = 0;
     uint64_t frames = 0;
+    uint32_t openRow = 0;                       // submit_rows: next row expected (0 = no frame open)
+    hipEvent_t slabReady = nullptr;             // submit_rows: the slab's shading is enqueued (render stream -> composer stream)
+    hipEvent_t ownStores = nullptr; bool ownStoresRecorded = false;      // submit_rows: the rank's own stores of the newest frame (composer stream -> finish)
     std::string err;
 };
 
@@ -259,10 +262,53 @@ int brmi_compose_submit(brmi_composer* c, const void* surface, brmi_compose_stre
     return (int)slot;
 }
 
+int brmi_compose_submit_rows(brmi_composer* c, const void* surface, uint32_t row0, uint32_t row1, brmi_compose_stream renderStream) {
+    if (!c || !surface) return -1;
+    if (!c->peerWrite) return fail(c, -4, "brmi_compose_submit_rows: peer-write composers only (the all-gather moves whole bands: brmi_compose_submit)");
+    if (!c->staging) return fail(c, -4, "brmi_compose_submit_rows: call brmi_compose_alloc_shared first");
+    if (!c->imported && c->cfg.nRanks > 1) return fail(c, -4, "brmi_compose_submit_rows: call brmi_compose_import first");
+    const uint32_t y0 = c->cfg.bandY0, y1 = c->cfg.bandY1;
+    const uint32_t expect = c->openRow ? c->openRow : y0;
+    if (row0 % 8u || row1 % 8u || row0 >= row1 || row0 != expect || row1 > y1)
+        return fail(c, -1, "brmi_compose_submit_rows: rows [%u, %u) -- slabs are multiples of 8, ascending from %u and inside the band [%u, %u)", row0, row1, expect, y0, y1);
+    hipStream_t rs = static_cast<hipStream_t>(renderStream), cs = c->collStream;
+    const uint32_t slot = (uint32_t)(c->frames % c->cfg.depth), frame = (uint32_t)(c->frames + 1u), n = c->cfg.nRanks;
+    const unsigned long long ticks = (unsigned long long)(c->cfg.waitTimeoutMs ? c->cfg.waitTimeoutMs : 2000u) * 100000ull;
+    if (!c->slabReady) CHECK_HIP(c, hipEventCreateWithFlags(&c->slabReady, hipEventDisableTiming));
+    if (!c->ownStores) CHECK_HIP(c, hipEventCreateWithFlags(&c->ownStores, hipEventDisableTiming));
+    // the slab's rows are shaded by what is already enqueued on the render stream: the composer's stream follows it, the render stream goes on
+    CHECK_HIP(c, hipEventRecord(c->slabReady, rs));
+    CHECK_HIP(c, hipStreamWaitEvent(cs, c->slabReady, 0));
+    if (row0 == y0) {      // the frame opens: peers learn that this rank is at `frame`; the slot it overwrites in THEIR images must be free
+        hipLaunchKernelGGL(k_signal_submitted, dim3(1), dim3(64), 0, cs, c->peers, n, c->cfg.rank, frame);
+        if (n > 1) hipLaunchKernelGGL(k_wait_flags, dim3(1), dim3(64), 0, cs, c->flags->submitted, n, c->cfg.rank, frame, &c->flags->status, ticks);
+    }
+    const uint64_t tilesX = (c->cfg.width + 7u) / 8u, rowBytes = tilesX * 64u * c->cfg.bytesPerPixel;      // one 8-row tile row of the surface
+    const uint64_t slabIn = (uint64_t)((row0 - y0) / 8u) * rowBytes, slabBytes = (uint64_t)((row1 - row0) / 8u) * rowBytes;
+    const uint8_t* src = static_cast<const uint8_t*>(surface) + c->bandOffset + slabIn;
+    const uint64_t slotOffset = (uint64_t)slot * c->outputBytes;
+    if (c->cfg.transport == BRMI_TRANSPORT_RGB16F) {
+        const uint64_t quads = slabBytes / c->cfg.bytesPerPixel / 4u, bandOut = (uint64_t)c->cfg.rank * c->stagingBytes + slabIn / c->cfg.bytesPerPixel * 6u;
+        hipLaunchKernelGGL(k_peer_write<true>, dim3((unsigned)std::min<uint64_t>(2048, (quads + 255) / 256)), dim3(256), 0, cs, reinterpret_cast<const uint4*>(src), c->peers, n, slotOffset, bandOut, quads);
+    } else {
+        const uint64_t vecs = slabBytes / 16u, bandOut = (uint64_t)c->cfg.rank * c->stagingBytes + slabIn;
+        hipLaunchKernelGGL(k_peer_write<false>, dim3((unsigned)std::min<uint64_t>(2048, (vecs + 255) / 256)), dim3(256), 0, cs, reinterpret_cast<const uint4*>(src), c->peers, n, slotOffset, bandOut, vecs);
+    }
+    if (row1 == y1) {      // the frame closes
+        hipLaunchKernelGGL(k_signal_landed, dim3(1), dim3(64), 0, cs, c->peers, n, c->cfg.rank, slot, frame);
+        CHECK_HIP(c, hipEventRecord(c->ownStores, cs)); c->ownStoresRecorded = true;
+        c->openRow = 0; c->frames++;
+    } else c->openRow = row1;
+    CHECK_HIP(c, hipGetLastError());
+    return (int)slot;
+}
+
 int brmi_compose_finish(brmi_composer* c, brmi_compose_stream stream, void** composed) {
     if (!c) return -1;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (c->peerWrite) {
+        if (c->openRow) return fail(c, -4, "brmi_compose_finish: a frame is open (brmi_compose_submit_rows up to row %u so far)", c->openRow);
+        if (c->ownStoresRecorded) CHECK_HIP(c, hipStreamWaitEvent(s, c->ownStores, 0));      // the rank's own slabs went through the composer's stream
         if (c->frames && c->cfg.nRanks > 1) {
             const uint32_t slot = (uint32_t)((c->frames - 1) % c->cfg.depth);
             const unsigned long long ticks = (unsigned long long)(c->cfg.waitTimeoutMs ? c->cfg.waitTimeoutMs : 2000u) * 100000ull;
@@ -283,6 +329,8 @@ void brmi_compose_destroy(brmi_composer* c) {
     if (c->collStream) (void)hipStreamSynchronize(c->collStream);
     for (hipEvent_t e : c->staged) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->done) if (e) (void)hipEventDestroy(e);
+    if (c->slabReady) (void)hipEventDestroy(c->slabReady);
+    if (c->ownStores) (void)hipEventDestroy(c->ownStores);
     for (void* p : c->opened) (void)hipIpcCloseMemHandle(p);
     if (c->ownsShared) { (void)hipDeviceSynchronize(); (void)hipFree(c->output); (void)hipFree(c->flags); }
     if (c->comm) (void)ncclCommDestroy(c->comm);

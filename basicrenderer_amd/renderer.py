@@ -204,6 +204,17 @@ class VisibilityRenderer:
     def invalidate_hzb(self):
         self._check(self.lib.brmi_invalidate_hzb(self._h), "brmi_invalidate_hzb")
 
+    def set_shade_slabs(self, slabs, callback=None):
+        """brmi_set_shade_slabs: the deferred shading in `slabs` row slabs; `callback(row0, row1, stream_ptr)` is called on the host after each slab's
+        launches (the hook for PeerBandComposer.submit_rows).  slabs <= 1 or no callback: one launch over the band."""
+        if callback is None or slabs <= 1:
+            self._slab_cb = None
+            self._check(self.lib.brmi_set_shade_slabs(self._h, capi.u32(0), None, None), "brmi_set_shade_slabs")
+            return
+        proto = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p)
+        self._slab_cb = proto(lambda user, r0, r1, stream: callback(int(r0), int(r1), stream))      # kept alive with the pass
+        self._check(self.lib.brmi_set_shade_slabs(self._h, capi.u32(slabs), C.cast(self._slab_cb, C.c_void_p), None), "brmi_set_shade_slabs")
+
     def set_history_source(self, other):
         """Frames in flight: phase 1 tests against the depth chain `other` built for the frame before (None unlinks)."""
         self._check(self.lib.brmi_set_history_source(self._h, other._h if other is not None else None), "brmi_set_history_source")

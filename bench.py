@@ -94,6 +94,9 @@ def main():
     ap.add_argument("--composer", default="native", choices=["native", "peer", "torch"],
                     help="who composes the bands: libbrmi_compose.so with one RCCL all-gather per frame (native; default), libbrmi_compose.so's peer-write path "
                          "(peer: hipIpc-mapped output buffers, every rank stores its band into every other rank's image, no collective), or torch.distributed")
+    ap.add_argument("--compose-slabs", type=int, default=0,
+                    help="--composer peer: the deferred shading runs in this many row slabs and every slab's rows are handed to the composer as soon as its launches "
+                         "are enqueued (brmi_set_shade_slabs + brmi_compose_submit_rows): the stores travel on the composer's stream while the next slab is shaded")
     ap.add_argument("--force-compose", action="store_true", help="run the RCCL band composition even with one rank (checks the collective path on a single GPU)")
     ap.add_argument("--frames-in-flight", type=int, default=2, choices=[1, 2, 3],
                     help="2 (default) or 3 (the reference's numFramesInFlight default, Renderer.h:110): that many passes with their own resources render the frames "
@@ -273,6 +276,10 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False)
         else:
             composer = compose.BandComposer(hdr, band, W, 8, transport=args.transport)
 
+    slabbed = bool(composer is not None and args.compose_slabs > 1 and hasattr(composer, "submit_rows"))
+    if slabbed:
+        for q in passes:
+            q.set_shade_slabs(args.compose_slabs, lambda r0, r1, stream, q=q: composer.submit_rows(r0, r1, q.hdr_tensor(), stream_ptr=stream))
     frame_no = [0]
 
     def step(serial=False):
@@ -281,7 +288,7 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False)
         with torch.cuda.stream(streams[k]):
             p.update()                  # the per-frame Update phase (camera / per-frame constants), as the reference's passes run it every frame
             p.execute(None if serial else shade_streams[k])
-        if composer:
+        if composer and not slabbed:
             with torch.cuda.stream(streams[k] if serial or shade_streams[k] is None else shade_streams[k]):
                 composer.submit(p.hdr_tensor())
         frame_no[0] += 1

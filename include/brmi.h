@@ -222,6 +222,13 @@ int brmi_set_history_source(brmi_pass* pass, brmi_pass* source);
 int brmi_gbuffer(brmi_pass* pass, brmi_stream stream);            /* MaterialHistogram..EvaluateMaterialGroups (K7,K8) */
 int brmi_light_clustering(brmi_pass* pass, brmi_stream stream);   /* ClusterGenerationPass + LightCullingPass (K9,K10) */
 int brmi_shade(brmi_pass* pass, brmi_stream stream);              /* DeferredShadingPass (K11) */
+/* Shading in row slabs (multi-GPU composition overlapped with the frame's own shading): with slabs > 1 the deferred-shading launches of
+ * brmi_shade / brmi_execute / brmi_execute_split cover the band in that many slabs of rows (multiples of 8 surface rows, top to bottom), and
+ * `fn(user, row0, row1, stream)` is called on the host right after a slab's launches have been enqueued on `stream` -- the place to hand the rows
+ * to brmi_compose_submit_rows (include/brmi_compose.h), whose stores then travel while the next slab is shaded.  Same pixels, same bytes as
+ * one launch over the band.  slabs <= 1 or fn == NULL: one launch, no call. */
+typedef void (*brmi_slab_fn)(void* user, uint32_t row0, uint32_t row1, brmi_stream stream);
+int brmi_set_shade_slabs(brmi_pass* pass, uint32_t slabs, brmi_slab_fn fn, void* user);
 
 /* ---- introspection ------------------------------------------------------------------------- */
 int brmi_read_counters(brmi_pass* pass, brmi_counters* out, brmi_stream stream);   /* synchronises */

@@ -74,6 +74,13 @@ int brmi_compose_import(brmi_composer* c, const uint8_t* handles, uint32_t count
 int brmi_compose_last_wait_status(brmi_composer* c);
 /* `surface`: base of the tiled surface (the whole frame's allocation).  Returns the buffer slot used (>= 0) or a negative status. */
 int brmi_compose_submit(brmi_composer* c, const void* surface, brmi_compose_stream renderStream);
+/* PEER_WRITE only -- the composition overlapped with the frame's own shading ("overlap gather of finished tiles with shading of later tiles via a
+ * second stream").  A frame is submitted as slabs of rows [row0, row1) of the rank's band (frame rows, multiples of 8, ascending, together covering
+ * [bandY0, bandY1)): call it after the launches that shade those rows have been enqueued on `renderStream` (brmi_shade_rows).  An event orders the
+ * slab's stores -- on the composer's own stream, into every rank's image -- behind them, so they travel while the render stream shades the next
+ * slab.  The first slab of a frame opens it (the "submitted" signal and the wait for the peers' slots), the last one closes it ("landed") and
+ * returns the slot; earlier slabs return the slot too.  brmi_compose_finish orders a consumer behind the rank's own stores as well. */
+int brmi_compose_submit_rows(brmi_composer* c, const void* surface, uint32_t row0, uint32_t row1, brmi_compose_stream renderStream);
 /* `stream` waits for every collective in flight; *composed = the output buffer of the newest frame (NULL before the first submit). */
 int brmi_compose_finish(brmi_composer* c, brmi_compose_stream stream, void** composed);
 void brmi_compose_destroy(brmi_composer* c);

@@ -1,5 +1,5 @@
-"""One rank of the two-process peer-write composition test (tests/test_parity_gpu.py).  Started as a fresh child process per rank (no exec
-after GPU initialisation): both ranks live on cuda:0, exchange their hipIpcMemHandles through files in a scratch directory and compose
+"""One rank of the multi-process peer-write composition tests (tests/test_parity_gpu.py).  Started as a fresh child process per rank (no exec
+after GPU initialisation): all ranks live on cuda:0, exchange their hipIpcMemHandles through files in a scratch directory and compose
 `frames` frames of a synthetic RGBA16F surface whose bytes depend on (rank, frame).  Writes the composed image of the last frame to
 <dir>/composed_<rank>.npy; the parent checks it against the bytes both ranks must have contributed."""
 import os
@@ -17,6 +17,7 @@ def surface_bytes(rank, frame, nbytes):
 
 def main():
     root, scratch, rank, world, transport, frames = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5], int(sys.argv[6])
+    slabs = int(sys.argv[7]) if len(sys.argv) > 7 else 0          # > 0: every frame goes through brmi_compose_submit_rows in this many slabs of rows
     sys.path.insert(0, root)
     import torch
     from basicrenderer_amd import compose
@@ -46,7 +47,13 @@ def main():
         surf.copy_(torch.from_numpy(surface_bytes(rank, f, nbytes)).to(dev))
         if rank == 1 and f == 1:
             time.sleep(0.3)      # one rank late: the other one's wait kernels really wait
-        comp.submit()
+        if slabs:
+            # the slabs of a frame one by one, as a renderer that shades its band in row slabs would hand them over (the stores travel on the composer's stream)
+            step = 32 // slabs
+            for k in range(slabs):
+                comp.submit_rows(band[0] + k * step, band[0] + (k + 1) * step)
+        else:
+            comp.submit()
         last = comp.finish()
         torch.cuda.synchronize()
     comp.wait_status()

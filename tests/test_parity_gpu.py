@@ -802,6 +802,57 @@ def test_peer_write_composer_with_two_processes_on_one_gpu(transport, tmp_path):
         assert np.array_equal(got, want), f"rank {r}: composed image differs"
 
 
+def test_shading_in_row_slabs_reproduces_the_frame_and_reports_the_rows(scenes):
+    """brmi_set_shade_slabs: the deferred shading of a frame with coat and fuzz materials (the layered variants run per slab too) in 1, 3 and 5 slabs of
+    rows -- the lit target is the same bytes, and the host hook sees every slab once, top to bottom, in multiples of 8 rows covering the frame."""
+    from basicrenderer_amd.renderer import VisibilityRenderer
+    from basicrenderer_amd import Scene
+    sc = Scene("tiny", 256, 200, point_lights=6, lod_levels=2, material_features=3)
+    r = VisibilityRenderer(sc, stats=True)
+    r.execute()
+    ref = r.hdr().copy()
+    for slabs in (3, 5):
+        seen = []
+        r.set_shade_slabs(slabs, lambda r0, r1, stream: seen.append((r0, r1)))
+        r.execute()
+        assert np.array_equal(r.hdr(), ref), slabs
+        assert len(seen) == slabs and seen[0][0] == 0 and seen[-1][1] == 200 and all(a[1] == b[0] for a, b in zip(seen, seen[1:])) and all(a % 8 == 0 for a, _ in seen), seen
+    r.set_shade_slabs(0)
+    r.execute()
+    assert np.array_equal(r.hdr(), ref)
+    r.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("transport,slabs", [("surface", 2), ("rgb16f", 4)])
+def test_peer_write_composer_with_four_processes_and_row_slabs(transport, slabs, tmp_path):
+    """brmi_compose_submit_rows (composition overlapped with the frame's own shading) with FOUR PROCESSES on one GPU: a fresh child per
+    rank (no exec after GPU initialisation), handles exchanged through files, three pipelined frames, every frame handed over in 2 or 4 slabs of rows
+    whose stores travel on the composer's own stream; rank 1 is late for one frame.  Every rank's composed image of the last frame must hold all four
+    ranks' bands of THAT frame, byte for byte."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import peer_compose_worker as w
+    world, frames = 4, 3
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "peer_compose_worker.py"), ROOT, str(tmp_path), str(r), str(world), transport, str(frames), str(slabs)],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    outs = [p.communicate(timeout=600)[0].decode(errors="replace") for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    W, rows = 256, 32 * world
+    nbytes = (W // 8) * (rows // 8) * 64 * 8
+    band_bytes = nbytes // world
+    want = []
+    for r in range(world):
+        b = w.surface_bytes(r, frames - 1, nbytes)[r * band_bytes:(r + 1) * band_bytes]
+        want.append(b.view(np.int16).reshape(-1, 4)[:, :3].copy() if transport == "rgb16f" else b)
+    want = np.concatenate(want)
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), f"composed_{r}.npy"))
+        assert np.array_equal(got, want), f"rank {r}: composed image differs"
+
+
 @pytest.mark.parametrize("transport", ["surface", "rgb16f"])
 def test_native_composer_gathers_the_band_bytes(transport, scenes):
     """libbrmi_compose.so (RCCL called from C++, include/brmi_compose.h) with one rank: three pipelined submits of a row band of the lit
