@@ -98,11 +98,12 @@ def main():
                     help="--composer peer: the deferred shading runs in this many row slabs and every slab's rows are handed to the composer as soon as its launches "
                          "are enqueued (brmi_set_shade_slabs + brmi_compose_submit_rows): the stores travel on the composer's stream while the next slab is shaded")
     ap.add_argument("--force-compose", action="store_true", help="run the RCCL band composition even with one rank (checks the collective path on a single GPU)")
-    ap.add_argument("--frames-in-flight", type=int, default=2, choices=[1, 2, 3],
-                    help="2 (default) or 3 (the reference's numFramesInFlight default, Renderer.h:110): that many passes with their own resources render the frames "
+    ap.add_argument("--frames-in-flight", type=int, default=3, choices=[1, 2, 3],
+                    help="3 (default: the reference's numFramesInFlight default, Renderer.h:110) or 2: that many passes with their own resources render the frames "
                          "in turn on a geometry stream and a shading stream (brmi_set_history_source + brmi_execute_split) -- frame k+1's culling and rasterisation, "
-                         "which are latency-bound and leave most of the chip idle, overlap frame k's G-buffer and shading; a third pass gains 3 %% on the Bistro-class "
-                         "frame and loses 7 %% on the Sponza-class one.  1: one pass, one stream, frames back to back.  "
+                         "which are latency-bound and leave most of the chip idle, overlap frame k's G-buffer and shading; with two passes a pass's geometry half waits for "
+                         "its own shading half of two frames ago, which the third pass removes (round 4: Bistro-class 0.535 -> 0.510 ms, Sponza-class 0.412 -> 0.387, "
+                         "the dense and San-Miguel-class frames unchanged).  1: one pass, one stream, frames back to back.  "
                          "Every frame does all of its work either way; "
                          "the roofline block is measured on serial frames (a kernel's duration while it shares the CUs with another frame is not its own)")
     ap.add_argument("--keep-uniform-layer-planes", type=int, default=0, choices=[0, 1],
