@@ -413,7 +413,17 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
             auto owns_band = [&](int band) { return !striped || stripe_owns(a.stripes, (uint32_t)band << BIN_ROWS_SHIFT); };
             auto vband = [&](int band) { return striped ? stripe_vrow(a.stripes, (uint32_t)band << BIN_ROWS_SHIFT) >> BIN_ROWS_SHIFT : (uint32_t)band; };
             const int nStrips = strip1 - strip0 + 1;
-            const int entries = (big && yLo <= yHi) ? (band1 - band0 + 1) * nStrips : 0;
+            // The bands this GPU owns of the box, as bin bands of its SURFACE (owned frame rows are consecutive surface rows, chunks are multiples of 16
+            // rows).  Round 4: the interleaved partition counted and windowed the box's FRAME bands -- eight times the bands a rank owns of them on
+            // the 8-GPU frame -- so most big triangles took the one-at-a-time whole-wave path or fell out of the LDS window (one global atomic per
+            // record): a rank's k_raster ran 147 us where the 4K frame's takes 36 (tools/rank_balance.py, kernel stats of an emulated rank).
+            int sband0 = band0, sband1 = band1;
+            if (striped && big && yLo <= yHi) {
+                const uint32_t fo = stripe_first_owned(a.stripes, (uint32_t)yLo), lo = stripe_last_owned(a.stripes, (uint32_t)yHi);
+                if (lo == 0xFFFFFFFFu || fo > lo || fo > (uint32_t)yHi) { sband0 = 0; sband1 = -1; }
+                else { sband0 = (int)(stripe_vrow(a.stripes, fo) >> BIN_ROWS_SHIFT); sband1 = (int)(stripe_vrow(a.stripes, lo) >> BIN_ROWS_SHIFT); }
+            }
+            const int entries = (big && yLo <= yHi) ? (sband1 - sband0 + 1) * nStrips : 0;
             const uint32_t flags = t | (useScanlineRanges ? 0x100u : 0u);
             // row start at the first row of this GPU's band: the serial loop's additions from the box top, made once per triangle with
             // all lanes stepping side by side (a lower band of a multi-GPU frame starts thousands of rows below the top of a large box)
@@ -429,8 +439,8 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
             int wb0 = 0, ws0 = 0, winW = 1, cells = 0; bool windowed = false;
             uint32_t resvCount[BIN_WINDOW / 64] = {}, resvBase[BIN_WINDOW / 64] = {};
             if (anyFew) {
-                int wb1 = few ? band1 : -1, ws1 = few ? strip1 : -1;
-                wb0 = few ? band0 : 0x7FFFFFFF; ws0 = few ? strip0 : 0x7FFFFFFF;
+                int wb1 = few ? sband1 : -1, ws1 = few ? strip1 : -1;      // (the window is over surface bin bands)
+                wb0 = few ? sband0 : 0x7FFFFFFF; ws0 = few ? strip0 : 0x7FFFFFFF;
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) {
                     wb0 = min(wb0, __shfl_xor(wb0, o)); wb1 = max(wb1, __shfl_xor(wb1, o));
@@ -441,13 +451,13 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
                 if (windowed) {
                     for (int cI = (int)lane; cI < cells; cI += 64) binBase[cI] = 0u;
                     wave_lds_sync();
-                    if (few) for (int band = band0; band <= band1; band++) if (owns_band(band)) for (int st = strip0; st <= strip1; st++) atomicAdd(&binBase[(band - wb0) * winW + (st - ws0)], 1u);
+                    if (few) for (int sb = sband0; sb <= sband1; sb++) for (int st = strip0; st <= strip1; st++) atomicAdd(&binBase[(sb - wb0) * winW + (st - ws0)], 1u);
                     wave_lds_sync();
 #pragma unroll
                     for (int k = 0; k < BIN_WINDOW / 64; k++) {
                         const int cI = (int)lane + 64 * k;
                         resvCount[k] = cI < cells ? binBase[cI] : 0u;
-                        if (resvCount[k] != 0u) resvBase[k] = atomicAdd(&a.binCounts[(size_t)(vband(wb0 + cI / winW) * a.binsX + (uint32_t)(ws0 + cI % winW)) * BIN_COUNT_STRIDE], resvCount[k]);
+                        if (resvCount[k] != 0u) resvBase[k] = atomicAdd(&a.binCounts[(size_t)((uint32_t)(wb0 + cI / winW) * a.binsX + (uint32_t)(ws0 + cI % winW)) * BIN_COUNT_STRIDE], resvCount[k]);
                     }
                 }
             }
@@ -518,9 +528,12 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
                         r.clusterIndex = clusterIndex; r.triAndFlags = flags | ((uint32_t)n << 16);
                         r.minX = minX; r.rectWidth = rectWidth; r.rowStart = striped ? (int)stripe_vrow(a.stripes, (uint32_t)py) : py;      // (an owned band's rows are consecutive surface rows)
                         r.sb0 = sb0; r.sb1 = sb1; r.dx_b0 = dx_b0; r.dx_b1 = dx_b1; r.dy_b0 = dy_b0; r.dy_b1 = dy_b1; r.d0 = d0; r.d1 = d1; r.d2 = d2; r.pad0 = 0; r.pad1 = alphaCluster ? 1u : 0u;
-                        if (owns_band(band)) for (int st = strip0; st <= strip1; st++) {
-                            if (windowed) bin_store(a, unormT, r, arec, (uint32_t)st, vband(band), atomicAdd(&binBase[(band - wb0) * winW + (st - ws0)], 1u));
-                            else bin_append(a, unormT, r, arec, (uint32_t)st, vband(band));
+                        if (owns_band(band)) {
+                            const uint32_t vb = vband(band);
+                            for (int st = strip0; st <= strip1; st++) {
+                                if (windowed) bin_store(a, unormT, r, arec, (uint32_t)st, vb, atomicAdd(&binBase[((int)vb - wb0) * winW + (st - ws0)], 1u));
+                                else bin_append(a, unormT, r, arec, (uint32_t)st, vb);
+                            }
                         }
                         for (int k = 0; k < n; k++) { sb0 += dy_b0; sb1 += dy_b1; }
                         py += n;
