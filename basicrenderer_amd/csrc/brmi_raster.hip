@@ -50,8 +50,10 @@ constexpr int BIN_W_SHIFT = 8, BIN_ROWS_SHIFT = 4;
 // a bin's record counter has a 128 B line to itself: atomics on ONE cache line serialise at 50-90 per microsecond whatever their addresses, and
 // the bins of a screen band (15 neighbours in one line, the horizon's among them) take thousands of slot reservations per frame
 constexpr uint32_t BIN_COUNT_STRIDE = BRMI_BIN_COUNT_STRIDE;
-constexpr int BIN_WINDOW = 256;                     // bins a wave can count in LDS at once (cells of its bin bounding box)
-constexpr int COOP_ENTRIES = 64;                    // triangles with more bin entries than this are emitted by the whole wave
+constexpr int BIN_WINDOW = 256;                     // bins a wave counts in LDS with its reservations held in registers (cells of its bin bounding box)
+constexpr int COOP_ENTRIES = 64;                    // triangles with more bin entries than this are emitted by the whole wave ...
+constexpr int COOP_ENTRIES_TABLE = 512;             // ... or than this, when the launch has the wide count table (RasterArgs::tableCells > BIN_WINDOW)
+constexpr uint32_t BIN_TABLE_MAX = 2048;            // cells of the wide table (dynamic LDS, 8 KB: every bin of a 4K frame or of a rank's 7680 x 1088 surface)
 
 struct RasterArgs {
     BinRecord* binRecords; uint32_t* binCounts; uint32_t binCapacity, binsX, binsY;
@@ -66,6 +68,7 @@ struct RasterArgs {
     uint32_t binMinSlice;    // most records one workgroup walks alone: a bin with more is cut into slices (BRMI_BIN_MIN_SLICE)
     uint32_t binSharedSlice; // records per slice of such a bin (BRMI_BIN_SHARED_SLICE)
     // the plan of a k_raster_bins launch (plan_bins): header {itemCount, ticket}, per bin {records, first scratch tile, slices done}, the work items
+    uint32_t tableCells;     // k_raster: words of dynamic LDS behind the launch (>= BIN_WINDOW): the LDS window a wave counts its records per bin in
     uint32_t* binPlan; uint32_t* binItems; unsigned long long* binScratch; uint32_t binScratchTiles, binItemCapacity;
     int debugFlags;          // experiments only (BRMI_RASTER_DEBUG): 1 = skip the direct walk, 2 = skip bin emission, 4 = skip the bin pass, 8 = direct walk without the atomic
     brmi_scene_buffers sc;
@@ -265,7 +268,7 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
     __shared__ float tpA[ALPHA ? 9 : 1][64];
     __shared__ float unormT[ALPHA ? 256 : 1];      // code / 255.0f
     if (ALPHA) { for (uint32_t i = threadIdx.x; i < 256u; i += 64u) unormT[i] = (float)i / 255.0f; __syncthreads(); }
-    __shared__ uint32_t binBase[BIN_WINDOW];
+    extern __shared__ uint32_t binBase[];          // a.tableCells words (launch_raster)
     __shared__ float tpF[9][64];
     __shared__ int tpI[4][64];
     __shared__ uint32_t rowOff[65];
@@ -434,9 +437,16 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
             // its records per bin in an LDS window over the bins it touches and reserves each bin's run with ONE global atomic -- requested
             // HERE, before the small boxes are walked, and used after them: the round trip was 44 % of this kernel's wave-cycles when the
             // wave sat through it (phase stamps, Bistro-class frame).
-            const bool few = entries > 0 && entries <= COOP_ENTRIES && !(a.debugFlags & 2);
+            // Round 4: views with large near triangles (a camera path through the street: raster 0.17 -> 0.43 ms, k_raster 36 -> 160 us per launch) put the union of a
+            // wave's bin boxes beyond the 256-cell window, and every record then took a global atomic with return of its own, one after the other in
+            // its lane.  With the wide table (up to 2048 cells: the whole 4K frame) such passes still count in LDS and reserve with one atomic per bin,
+            // a batch of four in flight per lane; and since a lane's slots then come from LDS, triangles of up to 512 bin entries stay with their lane
+            // instead of being emitted one at a time by the whole wave.
+            const int coopEntries = a.tableCells > (uint32_t)BIN_WINDOW ? COOP_ENTRIES_TABLE : COOP_ENTRIES;
+            const bool few = entries > 0 && entries <= coopEntries && !(a.debugFlags & 2);
+            bool fewW = few;      // (a pass whose bins fit no window falls back to the 64-entry rule below)
             const bool anyFew = __any(few);
-            int wb0 = 0, ws0 = 0, winW = 1, cells = 0; bool windowed = false;
+            int wb0 = 0, ws0 = 0, winW = 1, cells = 0; bool windowed = false, wideWindow = false;
             uint32_t resvCount[BIN_WINDOW / 64] = {}, resvBase[BIN_WINDOW / 64] = {};
             if (anyFew) {
                 int wb1 = few ? sband1 : -1, ws1 = few ? strip1 : -1;      // (the window is over surface bin bands)
@@ -447,12 +457,15 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
                     ws0 = min(ws0, __shfl_xor(ws0, o)); ws1 = max(ws1, __shfl_xor(ws1, o));
                 }
                 winW = ws1 - ws0 + 1; cells = (wb1 - wb0 + 1) * winW;
-                windowed = cells <= BIN_WINDOW;      // wave-uniform
+                windowed = cells <= (int)a.tableCells;      // wave-uniform
+                wideWindow = windowed && cells > BIN_WINDOW;
+                fewW = few && (windowed || entries <= COOP_ENTRIES);
                 if (windowed) {
                     for (int cI = (int)lane; cI < cells; cI += 64) binBase[cI] = 0u;
                     wave_lds_sync();
                     if (few) for (int sb = sband0; sb <= sband1; sb++) for (int st = strip0; st <= strip1; st++) atomicAdd(&binBase[(sb - wb0) * winW + (st - ws0)], 1u);
                     wave_lds_sync();
+                    if (!wideWindow)
 #pragma unroll
                     for (int k = 0; k < BIN_WINDOW / 64; k++) {
                         const int cI = (int)lane + 64 * k;
@@ -511,13 +524,25 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
             KSTAMP(3);
             // the records of triangles with a few bins: slots handed out from the runs reserved above
             if (anyFew) {
-                if (windowed) {
+                if (windowed && !wideWindow) {
                     // the reserved runs have arrived (requested before the small boxes were walked)
 #pragma unroll
                     for (int k = 0; k < BIN_WINDOW / 64; k++) { const int cI = (int)lane + 64 * k; if (cI < cells && resvCount[k] != 0u) binBase[cI] = resvBase[k]; }
                     wave_lds_sync();
+                } else if (wideWindow) {
+                    // the wide window: counts -> bases in place, four reservations in flight per lane and round
+                    for (int c0 = 0; c0 < cells; c0 += 256) {
+                        uint32_t cnt[4], base[4];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) { const int cI = c0 + (int)lane + 64 * k; cnt[k] = cI < cells ? binBase[cI] : 0u; }
+#pragma unroll
+                        for (int k = 0; k < 4; k++) { const int cI = c0 + (int)lane + 64 * k; base[k] = cnt[k] != 0u ? atomicAdd(&a.binCounts[(size_t)((uint32_t)(wb0 + cI / winW) * a.binsX + (uint32_t)(ws0 + cI % winW)) * BIN_COUNT_STRIDE], cnt[k]) : 0u; }
+#pragma unroll
+                        for (int k = 0; k < 4; k++) { const int cI = c0 + (int)lane + 64 * k; if (cnt[k] != 0u) binBase[cI] = base[k]; }
+                    }
+                    wave_lds_sync();
                 }
-                if (few) {
+                if (fewW) {
                     // step the row start band by band (the additions of the serial loop) and append one record per band and strip
                     float sb0 = band_b0, sb1 = band_b1;
                     int py = yLo;
@@ -544,7 +569,7 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
             if (anyFew && !windowed) KSTAMP(6); else KSTAMP(4);      // (instrumented builds: passes whose bins do not fit the LDS window reserve slot by slot)
             // many bins: the whole wave emits the triangle.  lane L owns bands band0 + L, band0 + L + 64, ...: it steps the row
             // start down to each of them (the same additions the serial loop makes) and appends the band's record to every strip.
-            uint64_t coop = __ballot(entries > COOP_ENTRIES && !(a.debugFlags & 2));
+            uint64_t coop = __ballot(entries > 0 && !fewW && !(a.debugFlags & 2));
             while (coop != 0ull) {
                 const int src = __ffsll((unsigned long long)coop) - 1;
                 coop &= coop - 1ull;
@@ -1413,6 +1438,9 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
     a.binSharedSlice = std::max(32u, std::min(p->binSharedSlice, a.binMinSlice) & ~31u);        // a multiple of the 32 records a step walks: no slice of the plan is empty
     a.binPlan = p->wsPtr<uint32_t>(p->ws.binPlan); a.binItems = p->wsPtr<uint32_t>(p->ws.binItems); a.binScratch = p->wsPtr<unsigned long long>(p->ws.binScratch);
     a.binScratchTiles = p->binScratchTiles; a.binItemCapacity = p->binItemCapacity;
+    // the LDS window k_raster counts its records per bin in: every bin of the surface when that is at most 2048 cells (8 KB), else 2048 (BRMI_BIN_TABLE: 256 = the round-3 window only)
+    static const uint32_t tableEnv = [] { const char* e = std::getenv("BRMI_BIN_TABLE"); return e ? (uint32_t)std::max(256, std::min(2048, std::atoi(e))) : BIN_TABLE_MAX; }();
+    a.tableCells = std::max<uint32_t>(BIN_WINDOW, std::min<uint32_t>(tableEnv, (p->binsX * p->binsY + 63u) & ~63u));
     a.binAlpha = p->wsPtr<AlphaRecord>(p->ws.binAlpha); a.overflowAlpha = p->wsPtr<AlphaRecord>(p->ws.overflowAlpha);
     a.clusterUv = p->wsPtr<ClusterUv>(p->ws.clusterUv);
     a.alphaMats = p->wsPtr<AlphaMaterial>(p->ws.alphaMats);
@@ -1448,11 +1476,11 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
     static const uint32_t grid2 = [] { const char* e = std::getenv("BRMI_RASTER_GRID2"); return e ? (uint32_t)std::max(64, std::atoi(e)) : 2048u; }();
     const dim3 rgrid(phase == 2 ? std::min(p->rasterGrid, grid2) : p->rasterGrid);
     if (p->sceneHasAlphaTest) {
-        hipLaunchKernelGGL(k_raster<true>, rgrid, dim3(64), 0, s, a);
+        hipLaunchKernelGGL(k_raster<true>, rgrid, dim3(64), a.tableCells * 4u, s, a);
         if (!direct2) hipLaunchKernelGGL(k_raster_overflow<true>, dim3(129), dim3(256), 0, s, a);
         if (!direct2 && !(p->rasterDebug & 4)) hipLaunchKernelGGL(k_raster_bins<true>, bgrid, dim3(BRMI_BIN_THREADS), 0, s, a);
     } else {
-        hipLaunchKernelGGL(k_raster<false>, rgrid, dim3(64), 0, s, a);
+        hipLaunchKernelGGL(k_raster<false>, rgrid, dim3(64), a.tableCells * 4u, s, a);
         if (!direct2) hipLaunchKernelGGL(k_raster_overflow<false>, dim3(129), dim3(256), 0, s, a);
         if (!direct2 && !(p->rasterDebug & 4)) hipLaunchKernelGGL(k_raster_bins<false>, bgrid, dim3(BRMI_BIN_THREADS), 0, s, a);
     }

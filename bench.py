@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--emulate-rank", type=int, default=None,
                     help="testing on ONE GPU: render rank R's share of the --gpus N frame alone (same partition, frame size and passes as the N-GPU run; "
                          "no process group; the composer, if forced, gathers this rank's share only).  The line says so and is not an N-GPU number")
+    ap.add_argument("--camera-at", type=float, default=None,
+                    help="experiments: the static camera of every measured leg sits at this position of the preset's camera path (path units; default: the preset's camera)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scale", type=float, default=1.0, help="fraction of the frame height the CPU baseline renders")
     ap.add_argument("--cpu-scale-1thread", type=float, default=0.25,
@@ -235,6 +237,11 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False)
                 _STREAM_CACHE[key] = ([torch.cuda.Stream(dev) for _ in range(fif)], [None] * fif)        # one stream per pass, whole frames
             streams, shade_streams = _STREAM_CACHE[key]
 
+    if args.camera_at is not None:
+        cam_at = scene.camera_at(args.camera_at)
+        for q in passes:
+            q.set_camera_device(torch.from_numpy(cam_at[0]).to(dev), torch.from_numpy(cam_at[1]).to(dev), cam_at[0])
+        torch.cuda.synchronize()
     hdr = r.hdr_tensor()
     # all-gather of frame k overlaps the rendering of frame k + 1; the colour channels travel (RGB16F, 6 B/px): the lit target's alpha is constant
     composer, composer_used = None, args.composer
