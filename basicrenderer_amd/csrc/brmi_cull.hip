@@ -381,6 +381,7 @@ template <bool REPLAY, uint32_t HIER_CAP, uint32_t HIER_STAGE, bool SIDE = false
 // of the level kernels.  The top levels of a wide hierarchy hold a handful of nodes each; as level launches they cost 12 us apiece.
 __global__ void __launch_bounds__(64) k_cull_hierarchy(CullArgs a, BucketRecord* buckets, const uint32_t* meshLevelWidth, uint32_t widthLo, uint32_t widthHi, uint32_t spillAbove, NodeRecord* spillOut,
                                                     typename std::conditional<SIDE, SideJobs, NoSide>::type sj) {
+    wave_prio<PRIO_CULL>();
     uint32_t walkBlocks = gridDim.x;
     if constexpr (SIDE) {
         walkBlocks = sj.walkBlocks;
@@ -1041,6 +1042,7 @@ BRMI_DEV float4 skinned_meshlet_bounds(const brmi_scene_buffers& sc, const brmi_
 struct LcRide { uint32_t mainBlocks; ClusterArgs lc; };
 template <bool SIDE>
 __global__ void __launch_bounds__(256) k_cull_clusters(CullArgs a, const BucketRecord* buckets, TempVisible* temp, uint32_t* bitmask, typename std::conditional<SIDE, LcRide, NoSide>::type ride) {
+    wave_prio<PRIO_CULL>();
     uint32_t mainBlocks = gridDim.x;
     if constexpr (SIDE) {
         mainBlocks = ride.mainBlocks;
@@ -1209,6 +1211,7 @@ __global__ void __launch_bounds__(256) k_scan_words(const uint32_t* bitmask, uin
 constexpr uint32_t SCAN_CHAIN_BLOCKS = 64;
 __global__ void __launch_bounds__(256) k_scan_chained(const uint32_t* bitmask, uint32_t totalWords, unsigned long long* agg, uint32_t epoch, uint32_t* wordPrefix,
                                                      uint32_t* counters, uint32_t outIndex, uint32_t capacity, uint32_t usedIndex, uint32_t* hostFeedback) {
+    wave_prio<PRIO_SCAN>();
     __shared__ uint32_t waveTotals[4];
     __shared__ uint32_t blockPrefix, ticket;
     // the block's place in the chain is the order in which blocks START (a ticket), not blockIdx: a block only ever waits for blocks that are
@@ -1267,6 +1270,7 @@ template <bool LOCAL_RANK>
 __global__ void __launch_bounds__(256) k_scatter_visible(const TempVisible* temp, uint32_t* counters, uint32_t tempCountIndex, const uint32_t* bitmask,
                                                         const uint32_t* wordPrefix, uint4* visible, uint32_t baseIndexCounter, uint32_t capacity, uint32_t visibleCapacity,
                                                         brmi_scene_buffers sc, ClusterSetup* setup, uint32_t resolveCapacity, uint8_t* used, ClusterUv* clusterUv, LocalRank lr) {
+    wave_prio<PRIO_SCAN>();
     const uint8_t* const* slabs = sc.slabs;
     const uint32_t n = min(counters[tempCountIndex], visibleCapacity);
     const uint32_t base = baseIndexCounter == 0xFFFFFFFFu ? 0u : counters[baseIndexCounter];

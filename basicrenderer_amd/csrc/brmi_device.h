@@ -136,6 +136,22 @@ BRMI_DEV int to_int_sat(float f) {
     return r;
 }
 
+// Issue priority of the geometry half's waves (s_setprio: which wave of a SIMD the arbiter picks first).  The geometry kernels are short chains of
+// dependent loads; when they share a SIMD with another frame's shading waves (hundreds of VALU instructions between loads) every instruction of
+// theirs that waits its turn lengthens the chain the NEXT frame waits for.  0 = off (the hardware default for every wave).
+#ifndef BRMI_GEOM_PRIO
+#define BRMI_GEOM_PRIO 0
+#endif
+#ifndef BRMI_PRIO_MASK
+#define BRMI_PRIO_MASK 0
+#endif
+enum : int { PRIO_CULL = 1, PRIO_SCAN = 2, PRIO_RASTER = 4, PRIO_BINS = 8, PRIO_HZB = 16, PRIO_SETUP = 32, PRIO_GBUFFER = 64, PRIO_SHADE = 128 };
+template <int WHICH> BRMI_DEV void wave_prio() {
+#if BRMI_GEOM_PRIO
+    if (BRMI_PRIO_MASK & WHICH) __builtin_amdgcn_s_setprio(BRMI_GEOM_PRIO);
+#endif
+}
+
 // ---- packing ----------------------------------------------------------------------------------
 BRMI_DEV uint32_t f32_to_f16_bits(float f) { return (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)f); }   // v_cvt_f16_f32, RTNE
 BRMI_DEV float f16_bits_to_f32(uint32_t h) { return (float)__builtin_bit_cast(_Float16, (unsigned short)h); }

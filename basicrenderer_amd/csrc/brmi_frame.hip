@@ -220,6 +220,7 @@ struct FrameJobs {
 };
 
 __global__ void __launch_bounds__(64) k_frame_constants(FrameJobs j) {
+    wave_prio<PRIO_SCAN>();
     const uint32_t b = blockIdx.x;
     if (b < j.firstBlock[1]) job_object_constants(j.sc, j.frameConst, j.objConst, j.snapshot, (b - j.firstBlock[0]) * 64u + threadIdx.x);
     else if (b < j.firstBlock[2]) job_material_words(j.sc, j.matWords, j.alphaMats, (b - j.firstBlock[1]) * 64u + threadIdx.x);

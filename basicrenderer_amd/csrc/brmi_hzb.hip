@@ -44,6 +44,7 @@ BRMI_DEV void hzb_tail_levels(const HzbDesc& h, uint32_t firstMip, uint32_t thre
 // a launch of its own.)
 template <bool FROM_VIS>
 __global__ void __launch_bounds__(256) k_hzb_head(HzbDesc h, const unsigned long long* vis, float* depthOut, const uint32_t* skipUnless, uint32_t blockRow0) {
+    wave_prio<PRIO_HZB>();
     if (skipUnless && *skipUnless == 0u) return;
     __shared__ float lvl[16 * 16];
     const uint32_t tx = threadIdx.x >> 4, ty = threadIdx.x & 15u;             // ty fastest: follows the column-major tile layout
@@ -108,6 +109,7 @@ __global__ void __launch_bounds__(256) k_hzb_head(HzbDesc h, const unsigned long
 
 // `seedCounters` (brmi_execute's phase-1 build only): the block also does k_seed_phase2's work for the culling pass that follows.
 __global__ void __launch_bounds__(1024) k_hzb_tail(HzbDesc h, uint32_t firstMip, const uint32_t* skipUnless, uint32_t* seedCounters, uint32_t seedCapacity) {
+    wave_prio<PRIO_HZB>();
     if (skipUnless && *skipUnless == 0u) return;
     if (seedCounters) seed_phase2(seedCounters, seedCapacity, threadIdx.x);
     hzb_tail_levels(h, firstMip, 1024u);

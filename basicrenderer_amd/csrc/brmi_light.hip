@@ -72,6 +72,7 @@ __global__ void __launch_bounds__(256) k_lc_fill(ClusterArgs a) { lc_fill_block(
 template <int MODE, int WAVES = BRMI_SHADE_WAVES>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE != 0 ? 1 : WAVES, (MODE == 0 && WAVES == BRMI_SHADE_WAVES && BRMI_SHADE_SHARED_MAXWAVES != 0) ? BRMI_SHADE_SHARED_MAXWAVES : 8)))
 k_shade(ShadeArgs a) {
+    wave_prio<PRIO_SHADE>();
     const ShadeFrame k = make_shade_frame(a);
     __shared__ float sliceStart[64];
     __shared__ float unormT[256];

@@ -207,6 +207,27 @@ BRMI_DEV void raster_row(const Sink& sink, const Alpha& alphaFails, int py, int 
     }
 }
 
+// The prologue of raster_row on its own: where a clipped walk of one scanline starts (barycentrics stepped to pixel `px` exactly as the serial
+// loop steps them), where it ends, and whether every pixel in between is covered (the analytic scanline range) or each one is tested.
+struct SegWalk { float b0, b1; int px, x1; bool all; };
+BRMI_DEV SegWalk seg_begin(int minX, int rectWidth, bool useScanlineRanges, float sb0, float sb1, float dx_b0, float dx_b1, float dx_b2, int clipX0, int clipX1) {
+    SegWalk w; w.all = useScanlineRanges; w.b0 = sb0; w.b1 = sb1;
+    int x0 = minX; w.x1 = min(minX + rectWidth - 1, clipX1);
+    if (useScanlineRanges) {
+        const float sb2 = 1.0f - sb0 - sb1;
+        int firstOff = 0, lastOff = rectWidth - 1; bool has = true;
+        clip_scanline(sb0, dx_b0, firstOff, lastOff, has);
+        clip_scanline(sb1, dx_b1, firstOff, lastOff, has);
+        clip_scanline(sb2, dx_b2, firstOff, lastOff, has);
+        if (!has) { w.px = 0; w.x1 = -1; return w; }
+        w.b0 = sb0 + (float)firstOff * dx_b0; w.b1 = sb1 + (float)firstOff * dx_b1;
+        x0 = minX + firstOff; w.x1 = min(minX + lastOff, clipX1);
+    }
+    if (x0 < clipX0) { step_barycentrics(w.b0, w.b1, dx_b0, dx_b1, clipX0 - x0); x0 = clipX0; }
+    w.px = x0;
+    return w;
+}
+
 // Stores one record at a reserved slot of a bin; when the bin is full its rows are rasterised here with global atomics (counted).
 template <typename Alpha>
 BRMI_DEV void raster_record_global(const RasterArgs& a, const BinRecord& r, const Alpha& alpha, uint32_t strip, uint32_t firstRow, uint32_t rowStep) {
@@ -261,6 +282,7 @@ BRMI_DEV void bin_append(const RasterArgs& a, const float* unorm, const BinRecor
 #endif
 template <bool ALPHA>
 __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RASTER_WAVES) k_raster(RasterArgs a) {
+    wave_prio<PRIO_RASTER>();
     // (one wave per workgroup: LDS hand-offs between its lanes need wave_lds_sync() only.  __syncthreads() also waits for every global store
     // and atomic the wave has in flight -- the record stores and the small boxes' atomic-mins: a memory round trip per hand-off.)
     __shared__ float sx[BRMI_MESHLET_MAX_VERTS], sy[BRMI_MESHLET_MAX_VERTS], sd[BRMI_MESHLET_MAX_VERTS];
@@ -642,6 +664,7 @@ constexpr uint32_t BIN_ORDER_CAP = 1024;       // longest slice the walk order i
 #endif
 template <bool ALPHA>
 __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES : 1) k_raster_bins(RasterArgs a) {
+    wave_prio<PRIO_BINS>();
     __shared__ unsigned long long tile[BIN_W * BIN_ROWS];
     __shared__ float unormT[ALPHA ? 256 : 1];
 #ifndef BRMI_ALPHA_SEG_SHIFT
@@ -651,8 +674,16 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES
     constexpr uint32_t ALPHA_LIST = BRMI_ALPHA_LIST;      // alpha-tested records a bin hands to the task pass (later ones take the row path)
     __shared__ uint16_t alphaList[ALPHA ? ALPHA_LIST : 1];
     __shared__ uint32_t taskStart[ALPHA ? ALPHA_LIST + 1 : 1];      // exclusive prefix of the listed records' task counts
-    __shared__ uint32_t scanPart[ALPHA ? BRMI_BIN_THREADS : 1];
+    __shared__ uint32_t scanPart[ALPHA ? BRMI_BIN_THREADS / 64 : 1];      // the waves' sums of the task scan
     __shared__ uint32_t alphaCount;
+#ifndef BRMI_ALPHA_COMPACT
+#define BRMI_ALPHA_COMPACT 1
+#endif
+    // pixels of alpha-tested records that are covered and can still win their key, waiting for the test: a ring per wave (see the task pass)
+    constexpr uint32_t AQ = 128, AQ_WAVES = (ALPHA && BRMI_ALPHA_COMPACT) ? BRMI_BIN_THREADS / 64 : 1, AQ_N = (ALPHA && BRMI_ALPHA_COMPACT) ? AQ : 1;
+    __shared__ unsigned long long qKey[AQ_WAVES][AQ_N];
+    __shared__ float qU[AQ_WAVES][AQ_N], qV[AQ_WAVES][AQ_N];
+    __shared__ uint32_t qMeta[AQ_WAVES][AQ_N];
     __shared__ uint16_t order[ALPHA ? 1 : BIN_ORDER_CAP];       // the slice's records in walk order (opaque scenes)
     __shared__ uint32_t classCount[18], classBase[19];
     // The launch is a pool of workgroups that take work items -- (bin, slice) pairs, longest first -- from the list plan_bins wrote (the launch
@@ -805,26 +836,99 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES
             const int bx0 = max(r.minX, x0), bx1 = min(r.minX + r.rectWidth - 1, x0 + BIN_W - 1);
             return bx1 < bx0 ? 0u : ((r.triAndFlags >> 16) & 0xFFu) * (uint32_t)(((bx1 - bx0) >> ALPHA_SEG_SHIFT) + 1);
         };
-        // exclusive scan of the task counts: 8 consecutive records per thread, then a scan of the 512 partial sums
+        // exclusive scan of the task counts: PER consecutive records per thread, the threads' sums scanned inside each wave by shuffles and
+        // across the eight waves through LDS (round 4: a Hillis-Steele scan over the workgroup in LDS, two barriers per step, was 13 % of this
+        // kernel's wave-cycles on the San-Miguel-class frame)
         constexpr uint32_t PER = ALPHA_LIST / BRMI_BIN_THREADS;
         uint32_t mine[PER]; uint32_t sum = 0;
 #pragma unroll
         for (uint32_t k = 0; k < PER; k++) { const uint32_t j = tid * PER + k; mine[k] = j < listed ? tasks_of(recs[first + alphaList[j]]) : 0u; sum += mine[k]; }
-        scanPart[tid] = sum;
+        const uint32_t laneQ = tid & 63u, waveQ = tid >> 6;
+        uint32_t incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o); if (laneQ >= (uint32_t)o) incl += v; }
+        if (laneQ == 63u) scanPart[waveQ] = incl;
         __syncthreads();
-        for (uint32_t o = 1; o < BRMI_BIN_THREADS; o <<= 1) {
-            const uint32_t v = tid >= o ? scanPart[tid - o] : 0u;
-            __syncthreads();
-            scanPart[tid] += v;
-            __syncthreads();
-        }
-        uint32_t run = scanPart[tid] - sum;
+        uint32_t run = incl - sum;
+        for (uint32_t w = 0; w < waveQ; w++) run += scanPart[w];
 #pragma unroll
         for (uint32_t k = 0; k < PER; k++) { const uint32_t j = tid * PER + k; if (j <= listed) taskStart[j] = run; run += mine[k]; }
         if (tid == BRMI_BIN_THREADS - 1u && listed == ALPHA_LIST) taskStart[ALPHA_LIST] = run;      // j never reaches ALPHA_LIST in the loop above
         __syncthreads();
         const uint32_t total = listed ? taskStart[listed] : 0u;
         BSTAMP(2);
+#if BRMI_ALPHA_COMPACT
+        // Round 4.  A segment's lane used to test its pixels where it found them: of the 64 lanes of a wave a third had a covered pixel whose key could
+        // still win at any one step, and the wave ran the sampler (texcoord -> texel addresses -> dependent fetches -> filter: the bulk of this pass,
+        // which was 53 % of the kernel's wave-cycles on the San-Miguel-class frame) for them alone, eight times per task.  Now the walk only FINDS
+        // such pixels -- coverage, key, a look at the tile -- and appends them (key, texcoord, tile cell, material) to a ring of its wave in LDS
+        // (ballot + prefix count: no atomics); whenever 64 are waiting the wave tests them with every lane busy.  The keys and the test are the same;
+        // only the order in which keys reach the tile's 64-bit min changes.
+        {
+            const uint32_t lane = tid & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+            uint32_t qHead = 0, qTail = 0;      // wave-uniform
+            auto drain = [&](uint32_t n) {
+                wave_lds_sync();
+                if (lane < n) {
+                    const uint32_t e = (qHead + lane) & (AQ - 1u);
+                    const unsigned long long key = qKey[wave][e];
+                    const uint32_t meta = qMeta[wave][e], cell = meta & 0xFFFu;
+                    if (key < *(volatile const unsigned long long*)&tile[cell]) {        // (another pixel may have taken the cell since)
+                        const AlphaMaterial m = a.alphaMats[meta >> 12];
+                        if (!alpha_test_failed(unormT, m, f2{qU[wave][e], qV[wave][e]})) atomicMin(&tile[cell], key);
+                    }
+                }
+                qHead += n;
+                wave_lds_sync();
+            };
+            for (uint32_t tb = 0; tb < total; tb += BRMI_BIN_THREADS) {
+                const uint32_t task = tb + tid;
+                bool on = task < total;
+                SegWalk w{0.0f, 0.0f, 0, -1, false};
+                float dx0 = 0, dx1 = 0, d0 = 0, d1 = 0, d2 = 0; int py = 0; uint32_t cluster = 0, tri = 0, mat = 0;
+                AlphaTri at{};
+                if (on) {
+                    uint32_t j = 0;
+#pragma unroll
+                    for (uint32_t step = ALPHA_LIST / 2; step > 0; step >>= 1) if (j + step <= listed && taskStart[j + step] <= task) j += step;
+                    const uint32_t ri = first + alphaList[j];
+                    const BinRecord r = recs[ri];
+                    const AlphaRecord ar = a.binAlpha[(size_t)bin * a.binCapacity + ri];
+                    const int bx0 = max(r.minX, x0), bx1 = min(r.minX + r.rectWidth - 1, x0 + BIN_W - 1);
+                    const uint32_t nseg = (uint32_t)(((bx1 - bx0) >> ALPHA_SEG_SHIFT) + 1), local = task - taskStart[j];
+                    const uint32_t trow = local / nseg, tseg = local - trow * nseg;
+                    const int sx0 = bx0 + (int)(tseg << ALPHA_SEG_SHIFT), sx1 = min(sx0 + (1 << ALPHA_SEG_SHIFT) - 1, bx1);
+                    float sb0 = r.sb0, sb1 = r.sb1;
+                    for (uint32_t k = 0; k < trow; k++) { sb0 += r.dy_b0; sb1 += r.dy_b1; }
+                    py = r.rowStart + (int)trow;
+                    on = (uint32_t)py >= a.bandY0 && (uint32_t)py < a.bandY1;
+                    if (on) w = seg_begin(r.minX, r.rectWidth, (r.triAndFlags & 0x100u) != 0, sb0, sb1, r.dx_b0, r.dx_b1, -(r.dx_b0 + r.dx_b1), sx0, sx1);
+                    dx0 = r.dx_b0; dx1 = r.dx_b1; d0 = r.d0; d1 = r.d1; d2 = r.d2; cluster = r.clusterIndex; tri = r.triAndFlags & 0x7Fu; mat = ar.materialDataIndex; at = ar.tri;
+                }
+#pragma nounroll
+                for (int k = 0; k < (1 << ALPHA_SEG_SHIFT); k++) {
+                    const bool act = on && w.px <= w.x1;
+                    if (!__any(act)) break;
+                    const float b2 = 1.0f - w.b0 - w.b1;
+                    const bool cov = w.all || (w.b0 >= 0.0f && w.b1 >= 0.0f && b2 >= 0.0f);
+                    const float depth = w.b0 * d0 + w.b1 * d1 + b2 * d2;
+                    const unsigned long long key = (unsigned long long)pack_vis_key(depth, cluster, tri);
+                    const uint32_t cell = (uint32_t)((w.px - x0) * BIN_ROWS + (py - y0)) & 0xFFFu;
+                    const bool want = act && cov && key < *(volatile const unsigned long long*)&tile[cell];
+                    const unsigned long long m = __ballot(want);
+                    if (want) {
+                        const uint32_t e = (qTail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) & (AQ - 1u);
+                        const f2 uv = pixel_texcoord(at, w.b0, w.b1, b2);
+                        qKey[wave][e] = key; qU[wave][e] = uv.x; qV[wave][e] = uv.y; qMeta[wave][e] = cell | (mat << 12);
+                    }
+                    qTail += (uint32_t)__popcll(m);
+                    if (act) { w.b0 += dx0; w.b1 += dx1; w.px++; }
+                    if (qTail - qHead >= 64u) drain(64u);
+                }
+            }
+            if (qTail != qHead) drain(qTail - qHead);
+        }
+#else
         for (uint32_t task = tid; task < total; task += BRMI_BIN_THREADS) {
             uint32_t j = 0;
 #pragma unroll
@@ -842,6 +946,7 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES
                 raster_row(sink, tex_alpha_of(a, unormT, a.binAlpha[(size_t)bin * a.binCapacity + ri]), py, r.minX, r.rectWidth, (r.triAndFlags & 0x100u) != 0, sb0, sb1, r.dx_b0, r.dx_b1, -(r.dx_b0 + r.dx_b1),
                            r.d0, r.d1, r.d2, r.clusterIndex, r.triAndFlags & 0x7Fu, sx0, sx1);
         }
+#endif
         BSTAMP(3);
     }
     __syncthreads();
@@ -989,6 +1094,7 @@ BRMI_DEV void plan_bins(const RasterArgs& a) {
 // cleared with the frame's counters and, between the two raster phases, by k_seed_phase2.
 template <bool ALPHA>
 __global__ void __launch_bounds__(256) k_raster_overflow(RasterArgs a) {
+    wave_prio<PRIO_BINS>();
 #ifdef BRMI_TILE_STAMPS
     if (blockIdx.x == 0u) {        // (instrumented builds: how long the plan takes, in 10 ns units; slots 40 / 41 of the stamp words)
         const unsigned long long t0_ = __builtin_amdgcn_s_memrealtime();

@@ -79,6 +79,7 @@ __global__ void __launch_bounds__(256) k_mark_used_clusters(GBufferArgs a, uint8
 // and the decoded vertex normals are evaluated once per triangle / vertex here with the shader's operation order; the pixel
 // pass then only evaluates the part that depends on the pixel.  (The reference shader recomputes all of it per pixel.)
 __global__ void __launch_bounds__(64) k_resolve_setup(GBufferArgs a) {
+    wave_prio<PRIO_SETUP>();
     __shared__ float cx[BRMI_MESHLET_MAX_VERTS], cy[BRMI_MESHLET_MAX_VERTS], cw[BRMI_MESHLET_MAX_VERTS];
     const uint32_t lane = threadIdx.x;
     // part 1 runs while the rasteriser and the phase-2 culling are still at work: it reads the phase-1 count only (final since the compaction) and never the marks
@@ -621,6 +622,7 @@ BRMI_DEV void gbuffer_body(const GBufferArgs& a, const Epi& epi) {
 }
 template <bool INLINE_TABLES, bool TEXTURED, bool PARALLAX = false, bool MULTI_UV = false, int SLIM = 0>
 __global__ void __launch_bounds__(256, INLINE_TABLES ? 1 : (MULTI_UV ? (PARALLAX ? BRMI_GBPM_WAVES : BRMI_GBM_WAVES) : (PARALLAX ? BRMI_GBP_WAVES : (TEXTURED ? BRMI_GBT_WAVES : BRMI_GB_WAVES)))) k_gbuffer(GBufferArgs a) {
+    wave_prio<PRIO_GBUFFER>();
     gbuffer_body<INLINE_TABLES, TEXTURED, PARALLAX, MULTI_UV, SLIM>(a, NoEpilogue{});
 }
 

@@ -98,7 +98,7 @@ def main():
                     help="--composer peer: the deferred shading runs in this many row slabs and every slab's rows are handed to the composer as soon as its launches "
                          "are enqueued (brmi_set_shade_slabs + brmi_compose_submit_rows): the stores travel on the composer's stream while the next slab is shaded")
     ap.add_argument("--force-compose", action="store_true", help="run the RCCL band composition even with one rank (checks the collective path on a single GPU)")
-    ap.add_argument("--frames-in-flight", type=int, default=3, choices=[1, 2, 3],
+    ap.add_argument("--frames-in-flight", type=int, default=3, choices=[1, 2, 3, 4, 5, 6],
                     help="3 (default: the reference's numFramesInFlight default, Renderer.h:110) or 2: that many passes with their own resources render the frames "
                          "in turn on a geometry stream and a shading stream (brmi_set_history_source + brmi_execute_split) -- frame k+1's culling and rasterisation, "
                          "which are latency-bound and leave most of the chip idle, overlap frame k's G-buffer and shading; with two passes a pass's geometry half waits for "
