@@ -668,14 +668,14 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES
     __shared__ unsigned long long tile[BIN_W * BIN_ROWS];
     __shared__ float unormT[ALPHA ? 256 : 1];
 #ifndef BRMI_ALPHA_SEG_SHIFT
-#define BRMI_ALPHA_SEG_SHIFT 3
+#define BRMI_ALPHA_SEG_SHIFT 4
 #endif
     constexpr int ALPHA_SEG_SHIFT = BRMI_ALPHA_SEG_SHIFT;     // pixels per task = 1 << shift
     constexpr uint32_t ALPHA_LIST = BRMI_ALPHA_LIST;      // alpha-tested records a bin hands to the task pass (later ones take the row path)
     __shared__ uint16_t alphaList[ALPHA ? ALPHA_LIST : 1];
     __shared__ uint32_t taskStart[ALPHA ? ALPHA_LIST + 1 : 1];      // exclusive prefix of the listed records' task counts
     __shared__ uint32_t scanPart[ALPHA ? BRMI_BIN_THREADS / 64 : 1];      // the waves' sums of the task scan
-    __shared__ uint32_t alphaCount;
+    __shared__ uint32_t alphaCount, taskNext;
 #ifndef BRMI_ALPHA_COMPACT
 #define BRMI_ALPHA_COMPACT 1
 #endif
@@ -734,7 +734,7 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES
     const bool shared = sliceCount > 1u;                // other workgroups walk records of this bin too
     const uint32_t first = slice * sliceSize;
     const uint32_t n = max(first, min(nAll, first + sliceSize));      // (the plan's slices are never empty: sliceSize <= binSharedSlice, a multiple of 32)
-    if (ALPHA && tid == 0) alphaCount = 0u;
+    if (ALPHA && tid == 0) { alphaCount = 0u; taskNext = 0u; }
     for (uint32_t i = tid; i < BIN_W * BIN_ROWS; i += BRMI_BIN_THREADS) tile[i] = BRMI_VIS_EMPTY;
     __syncthreads();
     BSTAMP(0);
@@ -880,9 +880,16 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES
                 }
                 qHead += n;
                 wave_lds_sync();
+                BSTAMP(6);      // (instrumented builds: the sampling of 64 waiting pixels)
             };
-            for (uint32_t tb = 0; tb < total; tb += BRMI_BIN_THREADS) {
-                const uint32_t task = tb + tid;
+            // (tasks are taken 64 at a time from a counter of the workgroup: segments cost anything from nothing to sixteen sampled pixels, and with a
+            // fixed deal the waves waited 14 % of the kernel's wave-cycles for the slowest one at the barrier behind this pass)
+            for (;;) {
+                uint32_t tb = 0;
+                if (lane == 0u) tb = atomicAdd(&taskNext, 64u);
+                tb = (uint32_t)__builtin_amdgcn_readfirstlane((int)tb);
+                if (tb >= total) break;
+                const uint32_t task = tb + lane;
                 bool on = task < total;
                 SegWalk w{0.0f, 0.0f, 0, -1, false};
                 float dx0 = 0, dx1 = 0, d0 = 0, d1 = 0, d2 = 0; int py = 0; uint32_t cluster = 0, tri = 0, mat = 0;
@@ -905,6 +912,8 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES
                     if (on) w = seg_begin(r.minX, r.rectWidth, (r.triAndFlags & 0x100u) != 0, sb0, sb1, r.dx_b0, r.dx_b1, -(r.dx_b0 + r.dx_b1), sx0, sx1);
                     dx0 = r.dx_b0; dx1 = r.dx_b1; d0 = r.d0; d1 = r.d1; d2 = r.d2; cluster = r.clusterIndex; tri = r.triAndFlags & 0x7Fu; mat = ar.materialDataIndex; at = ar.tri;
                 }
+                { uint32_t probe_ = cluster + mat; asm volatile("" :: "v"(probe_)); }
+                BSTAMP(7);      // (instrumented builds: a task's record has arrived and its segment is set up)
 #pragma nounroll
                 for (int k = 0; k < (1 << ALPHA_SEG_SHIFT); k++) {
                     const bool act = on && w.px <= w.x1;
@@ -923,8 +932,9 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES
                     }
                     qTail += (uint32_t)__popcll(m);
                     if (act) { w.b0 += dx0; w.b1 += dx1; w.px++; }
-                    if (qTail - qHead >= 64u) drain(64u);
+                    if (qTail - qHead >= 64u) { BSTAMP(3); drain(64u); }
                 }
+                BSTAMP(3);
             }
             if (qTail != qHead) drain(qTail - qHead);
         }

@@ -18,7 +18,7 @@ buf = np.zeros(64, dtype=np.uint64)
 r.lib.brmi_debug_read_bin_records.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
 assert r.lib.brmi_debug_read_bin_records(r._h, buf.ctypes.data, buf.nbytes | (1 << 63)) == 0
 ph = buf[32:40].astype(np.float64)
-names = ["tile clear + barrier", "record walk: opaque rows (+ listing alpha records)", "alpha task list (scan of segment counts)", "alpha tasks: texcoord, texel fetch, filter, LDS min", "barrier before the merge (waiting for the slowest wave)", "merge into the visibility buffer"]
+names = ["tile clear + barrier", "record walk: opaque rows (+ listing alpha records)", "alpha task list (scan of segment counts)", "alpha tasks: the walk (coverage, key, look at the tile, append)", "barrier before the merge (waiting for the slowest wave)", "merge into the visibility buffer", "alpha tasks: sampling 64 waiting pixels (texel fetch, filter, LDS min)", "alpha tasks: finding the record, loading it, segment setup"]
 tot = ph.sum()
 print(wl, "k_raster_bins phase shares (wave-cycles of every wave) over", frames, "frames; total %.3f G" % (tot / 1e9))
 for n, v in zip(names, ph):
