@@ -318,6 +318,30 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
 #else
 #define KSTAMP(k) do { } while (0)
 #endif
+    // Alpha-tested pixels of the small boxes (round 4, as in k_raster_bins<true>): the row walk only finds covered pixels and appends them (key,
+    // texcoord, pixel, material) to this ring; whenever 64 are waiting the wave looks at the visibility buffer and samples for all of them at once --
+    // every lane busy in the sampler instead of the few whose row has a covered pixel at that step.  The ring lives across batches and clusters; what
+    // is left is tested when the wave has no more clusters.
+    constexpr uint32_t RQ = 128, RQ_N = ALPHA ? RQ : 1;
+    __shared__ unsigned long long rqKey[RQ_N];
+    __shared__ float rqU[RQ_N], rqV[RQ_N];
+    __shared__ uint32_t rqPix[RQ_N], rqMat[RQ_N];
+    uint32_t rqHead = 0, rqTail = 0;      // wave-uniform
+    auto rq_drain = [&](uint32_t n) {
+        wave_lds_sync();
+        if (lane < n) {
+            const uint32_t e = (rqHead + lane) & (RQ - 1u);
+            const unsigned long long key = rqKey[e];
+            const int px = (int)(rqPix[e] & 0xFFFFu), py = (int)(rqPix[e] >> 16);
+            const AlphaMaterial m = a.alphaMats[rqMat[e]];
+            // the look is as slow as the texel fetches: both are requested together and the pixel costs one memory round trip, not two
+            const unsigned long long cur = gsink.peek(px, py);
+            const bool fails = alpha_test_failed(unormT, m, f2{rqU[e], rqV[e]});
+            if (key < cur && !fails) gsink(px, py, key);
+        }
+        rqHead += n;
+        wave_lds_sync();
+    };
     for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
         KSTAMP(7);
         const uint32_t c = item / split, sub = item % split;
@@ -521,6 +545,43 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
                         tpA[3][lane] = arec.tri.uv0.x; tpA[4][lane] = arec.tri.uv0.y; tpA[5][lane] = arec.tri.uv1.x; tpA[6][lane] = arec.tri.uv1.y; tpA[7][lane] = arec.tri.uv2.x; tpA[8][lane] = arec.tri.uv2.y;
                     }
                     wave_lds_sync();
+                    if (alphaCluster) {
+                        for (uint32_t tb = 0; tb < totalRows; tb += 64) {
+                            const uint32_t task = tb + lane;
+                            bool on = task < totalRows;
+                            uint32_t tri = 0;
+#pragma unroll
+                            for (uint32_t step = 32; step > 0; step >>= 1) if (on && rowOff[tri + step] <= task) tri += step;
+                            const int t_minX = tpI[0][tri], t_w = tpI[1][tri], t_minY = tpI[2][tri];
+                            const int py = on ? tpI[3][tri] + (int)(task - rowOff[tri]) : 0;
+                            const float t_dx0 = tpF[2][tri], t_dx1 = tpF[3][tri], t_dy0 = tpF[4][tri], t_dy1 = tpF[5][tri];
+                            float sb0 = tpF[0][tri], sb1 = tpF[1][tri];
+                            if (striped && !stripe_owns(a.stripes, (uint32_t)py)) on = false;      // another GPU's row
+                            if (on) for (int k = py - t_minY; k > 0; k--) { sb0 += t_dy0; sb1 += t_dy1; }      // the serial loop's row stepping
+                            const int spy = striped ? (int)stripe_vrow(a.stripes, (uint32_t)py) : py;      // the row of this GPU's surface
+                            SegWalk w{0.0f, 0.0f, 0, -1, useScanlineRanges};
+                            if (on) w = seg_begin(t_minX, t_w, useScanlineRanges, sb0, sb1, t_dx0, t_dx1, -(t_dx0 + t_dx1), t_minX, t_minX + t_w - 1);
+                            const AlphaTri at{tpA[0][tri], tpA[1][tri], tpA[2][tri], f2{tpA[3][tri], tpA[4][tri]}, f2{tpA[5][tri], tpA[6][tri]}, f2{tpA[7][tri], tpA[8][tri]}};
+                            const float t_d0 = tpF[6][tri], t_d1 = tpF[7][tri], t_d2 = tpF[8][tri];
+                            for (;;) {
+                                const bool act = on && w.px <= w.x1;
+                                if (!__any(act)) break;
+                                const float b2 = 1.0f - w.b0 - w.b1;
+                                const bool want = act && (w.all || (w.b0 >= 0.0f && w.b1 >= 0.0f && b2 >= 0.0f));
+                                const unsigned long long m = __ballot(want);
+                                if (want) {
+                                    const float depth = w.b0 * t_d0 + w.b1 * t_d1 + b2 * t_d2;
+                                    const uint32_t e = (rqTail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) & (RQ - 1u);
+                                    const f2 uv = pixel_texcoord(at, w.b0, w.b1, b2);
+                                    rqKey[e] = (unsigned long long)pack_vis_key(depth, clusterIndex, waveBase + tri); rqU[e] = uv.x; rqV[e] = uv.y;
+                                    rqPix[e] = (uint32_t)w.px | ((uint32_t)spy << 16); rqMat[e] = cs.materialDataIndex;
+                                }
+                                rqTail += (uint32_t)__popcll(m);
+                                if (act) { w.b0 += t_dx0; w.b1 += t_dx1; w.px++; }
+                                if (rqTail - rqHead >= 64u) rq_drain(64u);
+                            }
+                        }
+                    } else
                     for (uint32_t task = lane; task < totalRows; task += 64) {
                         uint32_t tri = 0;
 #pragma unroll
@@ -532,11 +593,6 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
                         if (striped && !stripe_owns(a.stripes, (uint32_t)py)) continue;      // another GPU's row
                         for (int k = py - t_minY; k > 0; k--) { sb0 += t_dy0; sb1 += t_dy1; }      // the serial loop's row stepping
                         const int spy = striped ? (int)stripe_vrow(a.stripes, (uint32_t)py) : py;      // the row of this GPU's surface
-                        if (alphaCluster) {
-                            const TexAlpha ta{unormT, amat, AlphaTri{tpA[0][tri], tpA[1][tri], tpA[2][tri], f2{tpA[3][tri], tpA[4][tri]}, f2{tpA[5][tri], tpA[6][tri]}, f2{tpA[7][tri], tpA[8][tri]}}};
-                            raster_row(gsink, ta, spy, t_minX, t_w, useScanlineRanges, sb0, sb1, t_dx0, t_dx1, -(t_dx0 + t_dx1), tpF[6][tri], tpF[7][tri], tpF[8][tri], clusterIndex, waveBase + tri,
-                                       t_minX, t_minX + t_w - 1);
-                        } else
                         raster_row(gsink, NoAlpha{}, spy, t_minX, t_w, useScanlineRanges, sb0, sb1, t_dx0, t_dx1, -(t_dx0 + t_dx1), tpF[6][tri], tpF[7][tri], tpF[8][tri], clusterIndex, waveBase + tri,
                                    t_minX, t_minX + t_w - 1);
                     }
@@ -633,6 +689,7 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
         }
         wave_lds_sync();   // LDS is reused by the next cluster
     }
+    if (ALPHA && rqTail != rqHead) rq_drain(rqTail - rqHead);
 #ifdef BRMI_TILE_STAMPS
     if (lane < 8u && (a.debugFlags & 0x100)) { unsigned long long v = 0; for (int k = 0; k < 8; k++) if (lane == (uint32_t)k) v = kph[k]; atomicAdd(a.debugStamps + 16u + lane, v); }
 #endif
