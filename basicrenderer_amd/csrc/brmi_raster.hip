@@ -729,10 +729,10 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES
 #endif
     constexpr int ALPHA_SEG_SHIFT = BRMI_ALPHA_SEG_SHIFT;     // pixels per task = 1 << shift
     constexpr uint32_t ALPHA_LIST = BRMI_ALPHA_LIST;      // alpha-tested records a bin hands to the task pass (later ones take the row path)
-    __shared__ uint16_t alphaList[ALPHA ? ALPHA_LIST : 1];
+    __shared__ uint16_t rowStart[ALPHA ? ALPHA_LIST + 1 : 1];       // exclusive prefix of the opaque records' row counts (<= 16 rows each: the total fits 16 bits)
     __shared__ uint32_t taskStart[ALPHA ? ALPHA_LIST + 1 : 1];      // exclusive prefix of the listed records' task counts
-    __shared__ uint32_t scanPart[ALPHA ? BRMI_BIN_THREADS / 64 : 1];      // the waves' sums of the task scan
-    __shared__ uint32_t alphaCount, taskNext;
+    __shared__ uint32_t scanPart[ALPHA ? 2 * BRMI_BIN_THREADS / 64 : 1];      // the waves' sums of the task scan
+    __shared__ uint32_t taskNext, rowNext;
 #ifndef BRMI_ALPHA_COMPACT
 #define BRMI_ALPHA_COMPACT 1
 #endif
@@ -791,7 +791,7 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES
     const bool shared = sliceCount > 1u;                // other workgroups walk records of this bin too
     const uint32_t first = slice * sliceSize;
     const uint32_t n = max(first, min(nAll, first + sliceSize));      // (the plan's slices are never empty: sliceSize <= binSharedSlice, a multiple of 32)
-    if (ALPHA && tid == 0) { alphaCount = 0u; taskNext = 0u; }
+    if (ALPHA && tid == 0) { taskNext = 0u; rowNext = 0u; }
     for (uint32_t i = tid; i < BIN_W * BIN_ROWS; i += BRMI_BIN_THREADS) tile[i] = BRMI_VIS_EMPTY;
     __syncthreads();
     BSTAMP(0);
@@ -839,6 +839,7 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES
     // wave-cycles (phase stamps).  (Lane = record with the rows re-dealt to the lanes -- an owner byte per row in LDS, the record's fields
     // fetched from the owning lane with ds_bpermute -- walks a dense frame's 3-6-row records 8 % faster on its own, but needs 78 VGPRs
     // instead of 46: beside three k_shade waves per SIMD the kernel then finds no room, and the frame with two in flight got 18 % slower.)
+    if (!ALPHA)
     for (uint32_t rc = sorted ? 0u : 2u; rc < 3u; rc++) {
     const uint32_t sh = 2u + rc;                                          // 4, 8 or 16 lanes per record
     const uint32_t sub = tid >> sh, row = tid & ((1u << sh) - 1u), per = BRMI_BIN_THREADS >> sh;
@@ -850,7 +851,7 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES
     wPrev = __builtin_amdgcn_s_memtime();
 #endif
     for (uint32_t base = cs; base < ce; base += per) {
-        const uint32_t idx = base + sub, ri = riPending;
+        const uint32_t idx = base + sub;
         const BinRecord r = pending;
 #ifdef BRMI_TILE_STAMPS
         { uint32_t probe_ = r.clusterIndex; asm volatile("" :: "v"(probe_)); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); wWait += now_ - wPrev; wPrev = now_; }     // the record has arrived
@@ -858,14 +859,7 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES
         if (idx + per < ce) { riPending = record_at(idx + per); pending = recs[riPending]; }
         if (idx >= ce) continue;
         const uint32_t rows = (r.triAndFlags >> 16) & 0xFFu;
-        bool deferred = false;
-        if (ALPHA && r.pad1 != 0u) {      // alpha tested: listed for the task pass below
-            // (every alpha record of the slice has a list entry: the plan's slices hold at most ALPHA_LIST records in alpha-tested scenes, launch_raster.  The
-            // row walk below is the opaque one only -- with the alpha test inlined here as a fallback the kernel spilled 61 registers, round 3.)
-            if (row == 0u) { const uint32_t slot = atomicAdd(&alphaCount, 1u); if (slot < ALPHA_LIST) alphaList[slot] = (uint16_t)(ri - first); }      // ri - first < 65536: fits the 16-bit entry
-            deferred = true;
-        }
-        if (row < rows && !deferred) {
+        if (row < rows) {
             float sb0 = r.sb0, sb1 = r.sb1;
             for (uint32_t k = 0; k < row; k++) { sb0 += r.dy_b0; sb1 += r.dy_b1; }
             const int py = r.rowStart + (int)row;
@@ -880,40 +874,70 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES
     }   // row classes
     BSTAMP(1);
     if (ALPHA) {
-        // Alpha-tested records after the opaque ones (more keys to reject untested).  A pixel of theirs costs a texcoord, a dependent
-        // texel fetch and the filter, and the records of a bin are anything from two floor triangles that span it to hundreds of
-        // 10-pixel slivers: with one lane per record row most lanes idle or walk long rows alone.  The rows are cut into 8-pixel
-        // segments and ALL segments of the bin's alpha records form one task list (prefix sum over the records' segment counts in
-        // LDS, a task finds its record by bisection) dealt round-robin to the 512 lanes; a segment's barycentrics are stepped from
-        // the row start like every clipped walk, so the keys are those of the serial loop.
-        __syncthreads();
-        const uint32_t listed = min(alphaCount, ALPHA_LIST);
-        if (tid == 0 && alphaCount > ALPHA_LIST) atomicAdd(&a.counters[CNT_DROPPED_RECORDS], alphaCount - ALPHA_LIST);      // impossible by construction; counted anyway
-        auto tasks_of = [&](const BinRecord& r) {
-            const int bx0 = max(r.minX, x0), bx1 = min(r.minX + r.rectWidth - 1, x0 + BIN_W - 1);
-            return bx1 < bx0 ? 0u : ((r.triAndFlags >> 16) & 0xFFu) * (uint32_t)(((bx1 - bx0) >> ALPHA_SEG_SHIFT) + 1);
-        };
-        // exclusive scan of the task counts: PER consecutive records per thread, the threads' sums scanned inside each wave by shuffles and
-        // across the eight waves through LDS (round 4: a Hillis-Steele scan over the workgroup in LDS, two barriers per step, was 13 % of this
-        // kernel's wave-cycles on the San-Miguel-class frame)
+        // Scenes with alpha-tested materials (round 4).  A slice holds at most ALPHA_LIST records here (the plan's slices; launch_raster), in arrival order:
+        // opaque and tested triangles mixed, two floor triangles that span the bin beside hundreds of 10-pixel slivers.  One look at every record's
+        // header gives two task lists -- the ROWS of the opaque records, and the 16-pixel SEGMENTS of the tested records' rows (a tested pixel
+        // costs a texcoord, dependent texel fetches and the filter) -- as exclusive prefix sums in LDS; a task finds its record by bisection and steps
+        // its barycentrics from the record's start like every clipped walk, so the keys are the serial loop's.  The waves take tasks 64 at a time
+        // from two counters, rows first (more keys in the tile for the tested pixels to lose against untested), segments after, with no barrier in
+        // between.  (Before: sixteen lanes per record whatever its rows, the tested records' lanes idle, a barrier, then the segments in a fixed
+        // deal: 19 % + 15 % + 10 % of the kernel's wave-cycles went to the record walk and the two waits, San-Miguel-class frame.)
+        const uint32_t listed = min(m, ALPHA_LIST);
+        if (tid == 0 && m > ALPHA_LIST) atomicAdd(&a.counters[CNT_DROPPED_RECORDS], m - ALPHA_LIST);      // impossible by construction; counted anyway
         constexpr uint32_t PER = ALPHA_LIST / BRMI_BIN_THREADS;
-        uint32_t mine[PER]; uint32_t sum = 0;
+        uint32_t mineA[PER], mineO[PER]; uint32_t sumA = 0, sumO = 0;
 #pragma unroll
-        for (uint32_t k = 0; k < PER; k++) { const uint32_t j = tid * PER + k; mine[k] = j < listed ? tasks_of(recs[first + alphaList[j]]) : 0u; sum += mine[k]; }
+        for (uint32_t k = 0; k < PER; k++) {
+            const uint32_t j = tid * PER + k;
+            mineA[k] = 0u; mineO[k] = 0u;
+            if (j < listed) {
+                const BinRecord* r = recs + first + j;
+                const uint32_t rows = (r->triAndFlags >> 16) & 0xFFu;
+                const int bx0 = max(r->minX, x0), bx1 = min(r->minX + r->rectWidth - 1, x0 + BIN_W - 1);
+                if (r->pad1 != 0u) mineA[k] = bx1 < bx0 ? 0u : rows * (uint32_t)(((bx1 - bx0) >> ALPHA_SEG_SHIFT) + 1);
+                else mineO[k] = bx1 < bx0 ? 0u : rows;
+            }
+            sumA += mineA[k]; sumO += mineO[k];
+        }
         const uint32_t laneQ = tid & 63u, waveQ = tid >> 6;
-        uint32_t incl = sum;
+        uint32_t inclA = sumA, inclO = sumO;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o); if (laneQ >= (uint32_t)o) incl += v; }
-        if (laneQ == 63u) scanPart[waveQ] = incl;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t va = (uint32_t)__shfl_up((int)inclA, o), vo = (uint32_t)__shfl_up((int)inclO, o);
+            if (laneQ >= (uint32_t)o) { inclA += va; inclO += vo; }
+        }
+        if (laneQ == 63u) { scanPart[waveQ] = inclA; scanPart[BRMI_BIN_THREADS / 64 + waveQ] = inclO; }
         __syncthreads();
-        uint32_t run = incl - sum;
-        for (uint32_t w = 0; w < waveQ; w++) run += scanPart[w];
+        uint32_t runA = inclA - sumA, runO = inclO - sumO;
+        for (uint32_t w = 0; w < waveQ; w++) { runA += scanPart[w]; runO += scanPart[BRMI_BIN_THREADS / 64 + w]; }
 #pragma unroll
-        for (uint32_t k = 0; k < PER; k++) { const uint32_t j = tid * PER + k; if (j <= listed) taskStart[j] = run; run += mine[k]; }
-        if (tid == BRMI_BIN_THREADS - 1u && listed == ALPHA_LIST) taskStart[ALPHA_LIST] = run;      // j never reaches ALPHA_LIST in the loop above
+        for (uint32_t k = 0; k < PER; k++) { const uint32_t j = tid * PER + k; if (j <= listed) { taskStart[j] = runA; rowStart[j] = (uint16_t)runO; } runA += mineA[k]; runO += mineO[k]; }
+        if (tid == BRMI_BIN_THREADS - 1u && listed == ALPHA_LIST) { taskStart[ALPHA_LIST] = runA; rowStart[ALPHA_LIST] = (uint16_t)runO; }      // j never reaches ALPHA_LIST in the loop above
         __syncthreads();
-        const uint32_t total = listed ? taskStart[listed] : 0u;
+        const uint32_t total = listed ? taskStart[listed] : 0u, totalRows = listed ? rowStart[listed] : 0u;
         BSTAMP(2);
+        // ---- rows of the opaque records
+        for (;;) {
+            uint32_t tb = 0;
+            if (laneQ == 0u) tb = atomicAdd(&rowNext, 64u);
+            tb = (uint32_t)__builtin_amdgcn_readfirstlane((int)tb);
+            if (tb >= totalRows) break;
+            const uint32_t task = tb + laneQ;
+            if (task < totalRows) {
+                uint32_t j = 0;
+#pragma unroll
+                for (uint32_t step = ALPHA_LIST / 2; step > 0; step >>= 1) if (j + step <= listed && rowStart[j + step] <= task) j += step;
+                const BinRecord r = recs[first + j];
+                const uint32_t row = task - rowStart[j];
+                float sb0 = r.sb0, sb1 = r.sb1;
+                for (uint32_t k = 0; k < row; k++) { sb0 += r.dy_b0; sb1 += r.dy_b1; }
+                const int py = r.rowStart + (int)row;
+                if ((uint32_t)py >= a.bandY0 && (uint32_t)py < a.bandY1)
+                    raster_row(sink, NoAlpha{}, py, r.minX, r.rectWidth, (r.triAndFlags & 0x100u) != 0, sb0, sb1, r.dx_b0, r.dx_b1, -(r.dx_b0 + r.dx_b1), r.d0, r.d1, r.d2, r.clusterIndex, r.triAndFlags & 0x7Fu,
+                               x0, x0 + BIN_W - 1);
+            }
+        }
+        BSTAMP(1);
 #if BRMI_ALPHA_COMPACT
         // Round 4.  A segment's lane used to test its pixels where it found them: of the 64 lanes of a wave a third had a covered pixel whose key could
         // still win at any one step, and the wave ran the sampler (texcoord -> texel addresses -> dependent fetches -> filter: the bulk of this pass,
@@ -955,7 +979,7 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES
                     uint32_t j = 0;
 #pragma unroll
                     for (uint32_t step = ALPHA_LIST / 2; step > 0; step >>= 1) if (j + step <= listed && taskStart[j + step] <= task) j += step;
-                    const uint32_t ri = first + alphaList[j];
+                    const uint32_t ri = first + j;
                     const BinRecord r = recs[ri];
                     const AlphaRecord ar = a.binAlpha[(size_t)bin * a.binCapacity + ri];
                     const int bx0 = max(r.minX, x0), bx1 = min(r.minX + r.rectWidth - 1, x0 + BIN_W - 1);
@@ -994,24 +1018,6 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES
                 BSTAMP(3);
             }
             if (qTail != qHead) drain(qTail - qHead);
-        }
-#else
-        for (uint32_t task = tid; task < total; task += BRMI_BIN_THREADS) {
-            uint32_t j = 0;
-#pragma unroll
-            for (uint32_t step = ALPHA_LIST / 2; step > 0; step >>= 1) if (j + step <= listed && taskStart[j + step] <= task) j += step;
-            const uint32_t ri = first + alphaList[j];
-            const BinRecord r = recs[ri];
-            const int bx0 = max(r.minX, x0), bx1 = min(r.minX + r.rectWidth - 1, x0 + BIN_W - 1);
-            const uint32_t nseg = (uint32_t)(((bx1 - bx0) >> ALPHA_SEG_SHIFT) + 1), local = task - taskStart[j];
-            const uint32_t trow = local / nseg, tseg = local - trow * nseg;
-            const int sx0 = bx0 + (int)(tseg << ALPHA_SEG_SHIFT), sx1 = min(sx0 + (1 << ALPHA_SEG_SHIFT) - 1, bx1);
-            float sb0 = r.sb0, sb1 = r.sb1;
-            for (uint32_t k = 0; k < trow; k++) { sb0 += r.dy_b0; sb1 += r.dy_b1; }
-            const int py = r.rowStart + (int)trow;
-            if ((uint32_t)py >= a.bandY0 && (uint32_t)py < a.bandY1)
-                raster_row(sink, tex_alpha_of(a, unormT, a.binAlpha[(size_t)bin * a.binCapacity + ri]), py, r.minX, r.rectWidth, (r.triAndFlags & 0x100u) != 0, sb0, sb1, r.dx_b0, r.dx_b1, -(r.dx_b0 + r.dx_b1),
-                           r.d0, r.d1, r.d2, r.clusterIndex, r.triAndFlags & 0x7Fu, sx0, sx1);
         }
 #endif
         BSTAMP(3);
