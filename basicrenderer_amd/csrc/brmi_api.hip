@@ -622,10 +622,13 @@ int brmi_update(brmi_pass* p, const brmi_frame_update* u, brmi_stream stream) {
 
 // What a frame's first launch has to wait for when frames are in flight (brmi_execute_split, and the stage entry points that start a frame:
 // a graph that schedules the stages itself after a split frame gets the same ordering).  No-ops when nothing was recorded.
+// flags of the events that order the two halves of split frames (experiments: BRMI_EVENT_FLAGS, e.g. 0x2 | 0x40000000 = no timing, device-scope release)
+static unsigned sync_event_flags() { static const unsigned f = [] { const char* e = std::getenv("BRMI_EVENT_FLAGS"); return e ? (unsigned)std::strtoul(e, nullptr, 0) : (unsigned)hipEventDisableTiming; }(); return f; }
+static int dbg_events() { static const int m = [] { const char* e = std::getenv("BRMI_DEBUG_EVENTS"); return e ? std::atoi(e) : 0; }(); return m; }      // (experiments only: events NOT issued)
 static int wait_for_frames_in_flight(brmi_pass* p, brmi_stream stream) {
     if (p->frameWaitsIssued) return BRMI_OK;      // brmi_execute_split has issued them for this frame: the stage entry points it calls do not repeat them
     // this pass's previous frame may still be resolving / shading on the other stream: its visibility buffer and tables are about to be rewritten
-    if (p->frameDoneRecorded) BRMI_HIP(p, hipStreamWaitEvent(static_cast<hipStream_t>(stream), p->frameDone, 0));
+    if (p->frameDoneRecorded && !(dbg_events() & 16)) BRMI_HIP(p, hipStreamWaitEvent(static_cast<hipStream_t>(stream), p->frameDone, 0));
     p->frameDoneRecorded = false;
     // frames in flight: this frame's phase 1 reads the chain the source pass built for the frame before, possibly on another stream
     // (recorded on this very stream -- the passes of a ring share their geometry stream --: stream order already says so, and every wait
@@ -734,7 +737,22 @@ int brmi_execute_split(brmi_pass* p, brmi_stream stream, brmi_stream shadeStream
     static const bool rideEnv = [] { const char* e = std::getenv("BRMI_CLEAR_RIDES"); return !e || std::atoi(e) != 0; }();
     const bool rides = rideEnv && p->constantsSerial != p->updateSerial && p->minLevelWidth <= 1024u /* the one-launch walk runs (brmi_cull.hip: HIER_CAP_MAX) */ && !p->forceLevelKernels && p->scene.activeDrawCount != 0u;
     p->lightGridDone = false;
-    if (rides) {
+    // A split frame (round 4): the riders move to where they fit -- the visibility clear onto k_cull_clusters' launch (brmi_cull.hip: ClearRide), the
+    // light clustering onto the shading stream, which is idle until this frame's pixel pass (below, behind the same event as the early resolve setup).
+    static const bool sideEnv = [] { const char* e = std::getenv("BRMI_SIDE_RIDERS"); return !e || std::atoi(e) != 0; }();
+    // where the per-cluster resolve tables of a split frame are made (BRMI_EARLY_RESOLVE_SETUP): 0 = at the end of the geometry stream, 1 = for the phase-1
+    // clusters on the shading stream beside the rasteriser (an event after the culling), 2 = on the shading stream in front of the pixel pass (no event)
+    static const int setupWhere = [] { const char* e = std::getenv("BRMI_EARLY_RESOLVE_SETUP"); return e ? std::atoi(e) : 1; }();
+    const bool earlySetup = split && setupWhere == 1 && !resolve_setup_marks(p);
+    const bool lateSetup = split && setupWhere == 2;
+    const bool sideRiders = rides && split && sideEnv && (p->bandPixelCount & 1ull) == 0ull;
+    if (sideRiders) {
+        p->clearFrameStateWithConstants = true; p->clearVisibilityWithClusterCull = true;
+        rc = brmi_cull(p, 1, stream);
+        p->clearFrameStateWithConstants = false;
+        if (rc == BRMI_OK && p->clearVisibilityWithClusterCull) { p->clearVisibilityWithClusterCull = false; return brmi::fail(p, BRMI_ERR_STATE, "brmi_execute: the cluster culling did not carry the visibility clear"); }
+        if (rc) { p->clearVisibilityWithClusterCull = false; return rc; }
+    } else if (rides) {
         p->clearFrameStateWithConstants = true; p->clearVisibilityWithTraversal = true;
         rc = brmi_cull(p, 1, stream);
         p->clearFrameStateWithConstants = false;
@@ -750,12 +768,13 @@ int brmi_execute_split(brmi_pass* p, brmi_stream stream, brmi_stream shadeStream
     // The per-cluster resolve tables need the cluster list, not the keys: for the phase-1 clusters they are made NOW, on the shading stream (idle until
     // this frame's pixel pass), beside the rasteriser -- the geometry half is a chain of latency-bound launches and this one was 40 us at its end.
     // (Not on frames of more triangles than pixels, whose setup skips clusters that own no pixel and so needs the final keys.)
-    static const bool earlyEnv = [] { const char* e = std::getenv("BRMI_EARLY_RESOLVE_SETUP"); return !e || std::atoi(e) != 0; }();
-    const bool earlySetup = split && earlyEnv && !resolve_setup_marks(p);
     if (earlySetup) {
-        if (!p->cullDone) BRMI_HIP(p, hipEventCreateWithFlags(&p->cullDone, hipEventDisableTiming));
+        if (!p->cullDone) BRMI_HIP(p, hipEventCreateWithFlags(&p->cullDone, sync_event_flags()));
+        if (!(dbg_events() & 1)) {
         BRMI_HIP(p, hipEventRecord(p->cullDone, static_cast<hipStream_t>(stream)));
         BRMI_HIP(p, hipStreamWaitEvent(static_cast<hipStream_t>(shadeStream), p->cullDone, 0));
+        }
+        if (sideRiders) { if ((rc = brmi::launch_light_clustering(p, static_cast<hipStream_t>(shadeStream)))) return rc; p->lightGridDone = true; }
         if ((rc = launch_resolve_setup(p, static_cast<hipStream_t>(shadeStream), 1u))) return rc;
     }
     if ((rc = brmi_raster(p, 1, stream))) return rc;
@@ -773,20 +792,24 @@ int brmi_execute_split(brmi_pass* p, brmi_stream stream, brmi_stream shadeStream
         // renders the next frame on another stream (brmi_set_history_source) can start while this frame is resolved and shaded.
         if ((rc = build_hzb_fused(p, static_cast<hipStream_t>(stream), true, true))) return rc;
         // recorded every frame (a pass may be linked to this one later, from another stream)
-        if (!p->chainReady) BRMI_HIP(p, hipEventCreateWithFlags(&p->chainReady, hipEventDisableTiming));
-        BRMI_HIP(p, hipEventRecord(p->chainReady, static_cast<hipStream_t>(stream))); p->chainRecorded = true; p->chainStream = stream;
+        if (!p->chainReady) BRMI_HIP(p, hipEventCreateWithFlags(&p->chainReady, sync_event_flags()));
+        if (!(dbg_events() & 2)) { BRMI_HIP(p, hipEventRecord(p->chainReady, static_cast<hipStream_t>(stream))); p->chainRecorded = true; p->chainStream = stream; }
     }
     // BRMI_FUSE_SHADE=1 (off by default): one pass over the pixels for G-buffer + shading where the G-buffer kernel is the lean one
     // (brmi_resolve.hip: k_gbuffer_shade); the light lists must exist by then.  Measured: 338 us against 103 + 236 us for the two kernels on
     // the Bistro-class 4K frame -- both are bound by VALU issue (the G-buffer kernel at six waves per SIMD as well), so not reading the
     // 48 B per pixel back buys 6 us of the frame.  Kept as a tested variant, not as the default: the two-kernel frame is what the profiles describe.
     if (split) {
-        if ((rc = launch_resolve_setup(p, static_cast<hipStream_t>(stream), earlySetup ? 2u : 0u))) return rc;
-        p->resolveSetupDone = true;
-        if (!p->geometryDone) BRMI_HIP(p, hipEventCreateWithFlags(&p->geometryDone, hipEventDisableTiming));
-        if (!p->frameDone) BRMI_HIP(p, hipEventCreateWithFlags(&p->frameDone, hipEventDisableTiming));
+        if (!lateSetup) {
+            if ((rc = launch_resolve_setup(p, static_cast<hipStream_t>(stream), earlySetup ? 2u : 0u))) return rc;
+            p->resolveSetupDone = true;
+        }
+        if (!p->geometryDone) BRMI_HIP(p, hipEventCreateWithFlags(&p->geometryDone, sync_event_flags()));
+        if (!p->frameDone) BRMI_HIP(p, hipEventCreateWithFlags(&p->frameDone, sync_event_flags()));
+        if (!(dbg_events() & 4)) {
         BRMI_HIP(p, hipEventRecord(p->geometryDone, static_cast<hipStream_t>(stream)));
         BRMI_HIP(p, hipStreamWaitEvent(static_cast<hipStream_t>(shadeStream), p->geometryDone, 0));
+        }
         stream = shadeStream;
     }
     const bool fuseEnv = p->fuseShadeOptIn;
@@ -796,16 +819,18 @@ int brmi_execute_split(brmi_pass* p, brmi_stream stream, brmi_stream shadeStream
     p->fuseShadeIntoGBuffer = fuseEnv; p->plainPixelsShaded = false;
     p->depthFinal = p->cfg.enableOcclusionCulling != 0;
     p->shadeSharesChip = split;
-    rc = brmi_gbuffer(p, stream);
+    // (experiments only: BRMI_DEBUG_SKIP bit 0 drops the shading launch, bit 1 the G-buffer launch of brmi_execute -- what the other half costs without them)
+    static const int skipDbg = [] { const char* e = std::getenv("BRMI_DEBUG_SKIP"); return e ? std::atoi(e) : 0; }();
+    rc = (skipDbg & 2) ? BRMI_OK : brmi_gbuffer(p, stream);
     p->shadeSharesChip = false;
     p->fuseShadeIntoGBuffer = false; p->depthFinal = false;
     if (rc) return rc;
     if (!lightsDone && (rc = brmi_light_clustering(p, stream))) return rc;
     p->shadeSharesChip = split;
-    rc = brmi_shade(p, stream);
+    rc = (skipDbg & 1) ? BRMI_OK : brmi_shade(p, stream);
     p->shadeSharesChip = false;
     if (rc) return rc;
-    if (split) { BRMI_HIP(p, hipEventRecord(p->frameDone, static_cast<hipStream_t>(stream))); p->frameDoneRecorded = true; }
+    if (split && !(dbg_events() & 8)) { BRMI_HIP(p, hipEventRecord(p->frameDone, static_cast<hipStream_t>(stream))); p->frameDoneRecorded = true; }
     p->splitFrame = false;          // (the stage entry points, called on their own, are not part of a split frame)
     return BRMI_OK;
 }

@@ -1040,13 +1040,28 @@ BRMI_DEV float4 skinned_meshlet_bounds(const brmi_scene_buffers& sc, const brmi_
 // K3: per-meshlet cull ---------------------------------------------------------------------------
 // SIDE: workgroups behind the first `mainBlocks` run the second half of the light clustering (page prefix + fill; four clusters each)
 struct LcRide { uint32_t mainBlocks; ClusterArgs lc; };
-template <bool SIDE>
-__global__ void __launch_bounds__(256) k_cull_clusters(CullArgs a, const BucketRecord* buckets, TempVisible* temp, uint32_t* bitmask, typename std::conditional<SIDE, LcRide, NoSide>::type ride) {
+// SIDE == 2 (split frames, round 4): the workgroups behind the first `mainBlocks` clear the visibility keys instead.  As riders of the traversal's
+// launch the clear's 8,192 and the light clustering's 3,456 single-wave workgroups inherit the walk's 150 VGPRs; beside another frame's shading waves
+// (3 x 136 of a SIMD's 512 registers taken) each of them waited for a shading wave to retire -- k_cull_hierarchy 38 us alone, 97 us in flight
+// (kernel trace), on the chain the next frame waits for.  This kernel's waves fit the gap (<= 104 registers), and the light clustering of a split
+// frame runs on the shading stream (brmi_execute_split).
+struct ClearRide { uint32_t mainBlocks; ulonglong2* vis2; uint64_t n2; uint32_t clearBlocks; };
+template <int SIDE>
+__global__ void __launch_bounds__(256) k_cull_clusters(CullArgs a, const BucketRecord* buckets, TempVisible* temp, uint32_t* bitmask,
+                                                       typename std::conditional<SIDE == 1, LcRide, typename std::conditional<SIDE == 2, ClearRide, NoSide>::type>::type ride) {
     wave_prio<PRIO_CULL>();
     uint32_t mainBlocks = gridDim.x;
-    if constexpr (SIDE) {
+    if constexpr (SIDE == 1) {
         mainBlocks = ride.mainBlocks;
         if (blockIdx.x >= ride.mainBlocks) { lc_fill_block(ride.lc, blockIdx.x - ride.mainBlocks, threadIdx.x); return; }
+    }
+    if constexpr (SIDE == 2) {
+        mainBlocks = ride.mainBlocks;
+        if (blockIdx.x >= ride.mainBlocks) {
+            const uint64_t stride = (uint64_t)ride.clearBlocks * 256u;
+            for (uint64_t i = (uint64_t)(blockIdx.x - ride.mainBlocks) * 256u + threadIdx.x; i < ride.n2; i += stride) ride.vis2[i] = make_ulonglong2(BRMI_VIS_EMPTY, BRMI_VIS_EMPTY);
+            return;
+        }
     }
     const brmi_scene_buffers& sc = a.sc;
     const uint32_t bucketCount = min(a.counters[a.bucketCounter], a.recordCapacity);
@@ -1482,9 +1497,14 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
     // grid-stride kernels that usually find little to do: a few hundred workgroups retire in ~3 us, a thousand in ~6
     const uint32_t smallGrid = phase == 1 ? 512u : 128u;
     if (lightGridRides) {
-        hipLaunchKernelGGL(k_cull_clusters<true>, dim3(smallGrid + (p->numLightClusters + 3u) / 4u), dim3(256), 0, s, a, buckets, temp, bitmask, LcRide{smallGrid, cluster_args_of(p)});
+        hipLaunchKernelGGL(k_cull_clusters<1>, dim3(smallGrid + (p->numLightClusters + 3u) / 4u), dim3(256), 0, s, a, buckets, temp, bitmask, LcRide{smallGrid, cluster_args_of(p)});
         p->lightGridDone = true;
-    } else hipLaunchKernelGGL(k_cull_clusters<false>, dim3(smallGrid), dim3(256), 0, s, a, buckets, temp, bitmask, NoSide{});
+    } else if (phase == 1 && p->clearVisibilityWithClusterCull) {
+        const uint32_t clearBlocks = 2048;
+        hipLaunchKernelGGL(k_cull_clusters<2>, dim3(smallGrid + clearBlocks), dim3(256), 0, s, a, buckets, temp, bitmask,
+                           ClearRide{smallGrid, reinterpret_cast<ulonglong2*>(static_cast<unsigned long long*>(p->res[BRMI_RES_VISIBILITY]) + p->bandFirstPixel), p->bandPixelCount >> 1, clearBlocks});
+        p->clearVisibilityWithClusterCull = false;
+    } else hipLaunchKernelGGL(k_cull_clusters<0>, dim3(smallGrid), dim3(256), 0, s, a, buckets, temp, bitmask, NoSide{});
     BRMI_LAUNCH_CHECK(p, "k_cull_clusters");
     // phase 2 appends behind the phase-1 clusters: its capacity is what phase 1 left
     const uint32_t outIndex = phase == 1 ? CNT_VISIBLE : CNT_VISIBLE2, usedIndex = phase == 1 ? 0xFFFFFFFFu : (uint32_t)CNT_VISIBLE;

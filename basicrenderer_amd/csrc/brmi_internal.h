@@ -200,6 +200,7 @@ struct brmi_pass {
     bool fuseShadeOptIn = false;     // BRMI_FUSE_SHADE=1 at brmi_create
     bool fuseShadeIntoGBuffer = false, plainPixelsShaded = false;   // brmi_execute: k_gbuffer_shade shades the plain pixels as it writes the G-buffer
     bool lightGridDone = false;      // this frame's light clustering ran inside the culling pass's launches
+    bool clearVisibilityWithClusterCull = false;      // brmi_execute_split on two streams: the clear rides on k_cull_clusters instead (brmi_cull.hip: ClearRide)
     bool clearFrameStateWithConstants = false, clearVisibilityWithTraversal = false;   // brmi_execute: no clear launch (brmi_frame.hip, brmi_cull.hip)
     bool seedInHzbTail = false, phase2Seeded = false;           // brmi_execute: the tail of the phase-1 depth-chain build also seeds phase 2 (k_seed_phase2's work)
     bool fuseFrameClear = false, frameStateCleared = false;   // brmi_execute: the visibility clear also clears the culling pass's frame state

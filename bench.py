@@ -326,7 +326,7 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False)
     # 20 steps are 9 ms) is one noisy sample, so it is repeated (--repeats; 5 when --steps < 200) and the MEDIAN region is reported, the
     # spread beside it (`ms_per_step_minmax`); `steps` stays the per-region count.
     repeats = args.repeats if args.repeats > 0 else (5 if args.steps < 200 else 1)
-    regions = []
+    regions, issue_s = [], []
     for _ in range(repeats):
         frame_no[0] = 0
         if multi:
@@ -335,6 +335,7 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False)
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
+        issue_s.append(time.perf_counter() - t0)      # the host has issued every launch of the region (the GPU is still at work)
         if composer:
             composer.finish()               # the last frames' collectives are inside the timed region
         torch.cuda.synchronize()
@@ -417,6 +418,7 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False)
             "metric": "shaded Mpixels/s @4K (vis-buffer+resolve)", "value": round(value, 2), "unit": "Mpixels/s",
             "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "repeats": repeats, "ms_per_step_minmax": [round(min(regions) / args.steps * 1e3, 4), round(max(regions) / args.steps * 1e3, 4)],
+            "host_issue_ms_per_step": round(sorted(issue_s)[len(issue_s) // 2] / args.steps * 1e3, 4),      # the host thread's time to issue a frame's launches (it runs ahead of the GPU when this is below ms_per_step)
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{workload}-class procedural frame, {W}x{H}, 1 directional + {lights} point lights, "
                                    f"{scene.stats['instancedTriangles']} instanced tris, {scene.stats['instances']} instances"

@@ -1435,7 +1435,7 @@ def test_barycentrics_and_their_derivatives_against_a_float64_restatement_of_cal
 def test_kernels_of_the_benchmarked_frames_use_no_scratch_memory():
     """configs[1-3] launch these kernels; none of them may spill to scratch (round 3's textured G-buffer and alpha-tested bins kernels wrote half of their
     HBM bytes as spills).  Read from the gfx950 code object inside the built libbrmi.so (tools/kernel_resources.py = llvm-readelf --notes).
-    k_cull_clusters<false> carries a 36 B frame object that no instruction touches (0 spilled VGPRs, no scratch_ instruction in its ISA): allowed as such."""
+    k_cull_clusters<0> carries a 36 B frame object that no instruction touches (0 spilled VGPRs, no scratch_ instruction in its ISA): allowed as such."""
     import subprocess
     import sys
     lib = os.path.join(ROOT, "basicrenderer_amd", "lib", "libbrmi.so")
@@ -1449,11 +1449,11 @@ def test_kernels_of_the_benchmarked_frames_use_no_scratch_memory():
             rows[m.group(1).strip().replace("void ", "").replace("brmi::", "")] = dict(vgpr=int(m.group(2)), vspill=int(m.group(5)), scratch=int(m.group(7)))
     assert len(rows) > 40, out[:500]
     launched = ["k_frame_constants", "k_cull_hierarchy<false, 256u, 128u, true>", "k_cull_hierarchy<false, 1024u, 128u, true>", "k_cull_hierarchy<true, 256u, 128u, false>",
-                "k_cull_hierarchy<true, 1024u, 128u, false>", "k_cull_flat_wide", "k_cull_clusters<true>", "k_scan_chained", "k_scatter_visible<false>", "k_scatter_visible<true>",
+                "k_cull_hierarchy<true, 1024u, 128u, false>", "k_cull_flat_wide", "k_cull_clusters<1>", "k_cull_clusters<2>", "k_cull_hierarchy<false, 256u, 128u, false>", "k_cull_hierarchy<false, 1024u, 128u, false>", "k_lc_count", "k_lc_fill", "k_scan_chained", "k_scatter_visible<false>", "k_scatter_visible<true>",
                 "k_raster<false>", "k_raster<true>", "k_raster_overflow<false>", "k_raster_overflow<true>", "k_raster_bins<false>", "k_raster_bins<true>", "k_hzb_head<true>", "k_hzb_tail",
                 "k_resolve_setup", "k_gbuffer<false, false, false, false, 1>", "k_gbuffer<false, true, false, false, 1>", "k_gbuffer<true, true, false, false, 0>",
                 "k_gbuffer<false, false, false, false, 0>", "k_gbuffer<false, true, false, false, 0>", "k_shade<0, 3>", "k_shade<0, 5>", "k_traverse"]
     for k in launched:
         assert k in rows, (k, sorted(rows)[:80])
         assert rows[k]["vspill"] == 0 and rows[k]["scratch"] == 0, (k, rows[k])
-    assert rows["k_cull_clusters<false>"]["vspill"] == 0
+    assert rows["k_cull_clusters<0>"]["vspill"] == 0
