@@ -295,7 +295,13 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
     __shared__ int tpI[4][64];
     __shared__ uint32_t rowOff[65];
     const brmi_scene_buffers& sc = a.sc;
-    const uint32_t lane = threadIdx.x;
+    const uint32_t lane0 = threadIdx.x;
+#ifndef BRMI_RASTER_OPAQUE_LANE
+#define BRMI_RASTER_OPAQUE_LANE 0
+#endif
+#if !BRMI_RASTER_OPAQUE_LANE
+    const uint32_t lane = lane0;
+#endif
     // wave-uniform by construction; said so to the compiler, which then fetches a cluster's records with scalar loads (one s_load per record
     // instead of a chain of vector loads with a wait after each: the fetch was 11-29 % of the kernel's wave-cycles, measured with phase stamps)
     const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.firstCounter == 0xFFFFFFFFu ? 0u : a.counters[a.firstCounter]));
@@ -329,8 +335,8 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
     uint32_t rqHead = 0, rqTail = 0;      // wave-uniform
     auto rq_drain = [&](uint32_t n) {
         wave_lds_sync();
-        if (lane < n) {
-            const uint32_t e = (rqHead + lane) & (RQ - 1u);
+        if (lane0 < n) {
+            const uint32_t e = (rqHead + lane0) & (RQ - 1u);
             const unsigned long long key = rqKey[e];
             const int px = (int)(rqPix[e] & 0xFFFFu), py = (int)(rqPix[e] >> 16);
             const AlphaMaterial m = a.alphaMats[rqMat[e]];
@@ -343,6 +349,9 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
         wave_lds_sync();
     };
     for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
+#if BRMI_RASTER_OPAQUE_LANE
+        uint32_t lane = lane0; asm volatile("" : "+v"(lane));      // (what a cluster derives from the lane index is recomputed per cluster, not hoisted into registers and SGPR spill lanes)
+#endif
         KSTAMP(7);
         const uint32_t c = item / split, sub = item % split;
         const uint32_t clusterIndex = first + c;
@@ -493,7 +502,7 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
             bool fewW = few;      // (a pass whose bins fit no window falls back to the 64-entry rule below)
             const bool anyFew = __any(few);
             int wb0 = 0, ws0 = 0, winW = 1, cells = 0; bool windowed = false, wideWindow = false;
-            uint32_t resvCount[BIN_WINDOW / 64] = {}, resvBase[BIN_WINDOW / 64] = {};
+            uint32_t resvBase[BIN_WINDOW / 64] = {};      // (the counts stay in the LDS window until the bases replace them: four registers less across the small boxes)
             if (anyFew) {
                 int wb1 = few ? sband1 : -1, ws1 = few ? strip1 : -1;      // (the window is over surface bin bands)
                 wb0 = few ? sband0 : 0x7FFFFFFF; ws0 = few ? strip0 : 0x7FFFFFFF;
@@ -515,8 +524,8 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
 #pragma unroll
                     for (int k = 0; k < BIN_WINDOW / 64; k++) {
                         const int cI = (int)lane + 64 * k;
-                        resvCount[k] = cI < cells ? binBase[cI] : 0u;
-                        if (resvCount[k] != 0u) resvBase[k] = atomicAdd(&a.binCounts[(size_t)((uint32_t)(wb0 + cI / winW) * a.binsX + (uint32_t)(ws0 + cI % winW)) * BIN_COUNT_STRIDE], resvCount[k]);
+                        const uint32_t cnt = cI < cells ? binBase[cI] : 0u;
+                        if (cnt != 0u) resvBase[k] = atomicAdd(&a.binCounts[(size_t)((uint32_t)(wb0 + cI / winW) * a.binsX + (uint32_t)(ws0 + cI % winW)) * BIN_COUNT_STRIDE], cnt);
                     }
                 }
             }
@@ -605,7 +614,7 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
                 if (windowed && !wideWindow) {
                     // the reserved runs have arrived (requested before the small boxes were walked)
 #pragma unroll
-                    for (int k = 0; k < BIN_WINDOW / 64; k++) { const int cI = (int)lane + 64 * k; if (cI < cells && resvCount[k] != 0u) binBase[cI] = resvBase[k]; }
+                    for (int k = 0; k < BIN_WINDOW / 64; k++) { const int cI = (int)lane + 64 * k; if (cI < cells && binBase[cI] != 0u) binBase[cI] = resvBase[k]; }
                     wave_lds_sync();
                 } else if (wideWindow) {
                     // the wide window: counts -> bases in place, four reservations in flight per lane and round
@@ -691,7 +700,7 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
     }
     if (ALPHA && rqTail != rqHead) rq_drain(rqTail - rqHead);
 #ifdef BRMI_TILE_STAMPS
-    if (lane < 8u && (a.debugFlags & 0x100)) { unsigned long long v = 0; for (int k = 0; k < 8; k++) if (lane == (uint32_t)k) v = kph[k]; atomicAdd(a.debugStamps + 16u + lane, v); }
+    if (lane0 < 8u && (a.debugFlags & 0x100)) { unsigned long long v = 0; for (int k = 0; k < 8; k++) if (lane0 == (uint32_t)k) v = kph[k]; atomicAdd(a.debugStamps + 16u + lane0, v); }
 #endif
 }
 
