@@ -52,7 +52,10 @@ constexpr int BIN_W_SHIFT = 8, BIN_ROWS_SHIFT = 4;
 constexpr uint32_t BIN_COUNT_STRIDE = BRMI_BIN_COUNT_STRIDE;
 constexpr int BIN_WINDOW = 256;                     // bins a wave counts in LDS with its reservations held in registers (cells of its bin bounding box)
 constexpr int COOP_ENTRIES = 64;                    // triangles with more bin entries than this are emitted by the whole wave ...
-constexpr int COOP_ENTRIES_TABLE = 512;             // ... or than this, when the launch has the wide count table (RasterArgs::tableCells > BIN_WINDOW)
+#ifndef BRMI_COOP_ENTRIES_TABLE
+#define BRMI_COOP_ENTRIES_TABLE 512
+#endif
+constexpr int COOP_ENTRIES_TABLE = BRMI_COOP_ENTRIES_TABLE;             // ... or than this, when the launch has the wide count table (RasterArgs::tableCells > BIN_WINDOW)
 constexpr uint32_t BIN_TABLE_MAX = 2048;            // cells of the wide table (dynamic LDS, 8 KB: every bin of a 4K frame or of a rank's 7680 x 1088 surface)
 
 struct RasterArgs {
@@ -280,6 +283,9 @@ BRMI_DEV void bin_append(const RasterArgs& a, const float* unorm, const BinRecor
 #ifndef BRMI_RASTER_ALPHA_WAVES
 #define BRMI_RASTER_ALPHA_WAVES 2
 #endif
+#ifndef BRMI_RASTER_SPLIT_FIRST
+#define BRMI_RASTER_SPLIT_FIRST 2u
+#endif
 template <bool ALPHA>
 __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RASTER_WAVES) k_raster(RasterArgs a) {
     wave_prio<PRIO_RASTER>();
@@ -315,7 +321,11 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
     // so the passes are independent), sets up all 64 triangles of it (the vote needs them) and emits only its share of them.  Keys are
     // order-free, so the result is the same.
     uint32_t split = 1u;
-    if (!(a.debugFlags & 0x40000000u)) { while (split < 8u && count * split * 2u <= gridDim.x) split *= 2u; }
+    // (round 4: the FIRST doubling is allowed up to twice the grid -- some waves then take two half-clusters --, the others up to the grid: a view of 6 - 8 k
+    // clusters with large near triangles, where a cluster is 20 k bin records from one wave, takes two waves per cluster: raster 0.345 -> 0.32 ms at position
+    // 20 of the bench's path; a Sponza-class frame of 1.5 k clusters keeps four per cluster, eight cost it 10 us.  A larger grid does the same for the
+    // rasteriser alone, but 8,192 more waves that find nothing each wait for a slot beside the other frame's shading waves.)
+    if (!(a.debugFlags & 0x40000000u)) { while (split < 8u && count * split * 2u <= (split == 1u ? BRMI_RASTER_SPLIT_FIRST * gridDim.x : gridDim.x)) split *= 2u; }
     const uint32_t parts = max(split >> 1, 1u), lanesPerPart = 64u / parts;      // shares of a pass
     const uint32_t items = count * split;
 #ifdef BRMI_TILE_STAMPS

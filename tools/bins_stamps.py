@@ -1,5 +1,5 @@
 # Phase shares of k_raster_bins' and k_raster's wave-cycles (instrumented build -DBRMI_TILE_STAMPS; BRMI_RASTER_DEBUG=512 for the bins'
-# phases, 256 for k_raster's):  BRMI_RASTER_DEBUG=768 BRMI_LIB_PATH=$PWD/scratch/variants/stamps/libbrmi.so python3 tools/bins_stamps.py <workload>
+# phases, 256 for k_raster's):  BRMI_RASTER_DEBUG=768 BRMI_LIB_PATH=$PWD/scratch/variants/stamps/libbrmi.so python3 tools/bins_stamps.py <workload> [camera position on the preset's path]
 import os, sys, ctypes as C
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
@@ -10,6 +10,10 @@ wl = sys.argv[1]
 preset, kw, feat = bench.WORKLOADS[wl]
 sc = Scene(preset, 3840, 2160, point_lights=256, material_features=feat, **kw)
 r = VisibilityRenderer(sc, occlusion=True, stats=True)
+if len(sys.argv) > 2:      # the preset's camera at a position of its path
+    cam_at = sc.camera_at(float(sys.argv[2]))
+    r.set_camera_device(torch.from_numpy(cam_at[0]).to('cuda'), torch.from_numpy(cam_at[1]).to('cuda'), cam_at[0])
+    torch.cuda.synchronize()
 frames = 4
 for _ in range(frames):
     r.execute()
