@@ -711,6 +711,11 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
     if (ALPHA && rqTail != rqHead) rq_drain(rqTail - rqHead);
 #ifdef BRMI_TILE_STAMPS
     if (lane0 < 8u && (a.debugFlags & 0x100)) { unsigned long long v = 0; for (int k = 0; k < 8; k++) if (lane0 == (uint32_t)k) v = kph[k]; atomicAdd(a.debugStamps + 16u + lane0, v); }
+    if (lane0 == 0u && (a.debugFlags & 0x100)) {      // the launch's longest wave: its cycles per phase (slots 40 .. 47), kept by a 64-bit max on its total (slot 48)
+        unsigned long long tot = 0; for (int k = 0; k < 8; k++) tot += kph[k];
+        const unsigned long long before = atomicMax(a.debugStamps + 48u, tot);
+        if (tot > before) for (int k = 0; k < 8; k++) a.debugStamps[40 + k] = kph[k];      // (racy between near-equal waves: a diagnostic)
+    }
 #endif
 }
 

@@ -31,3 +31,9 @@ ph2 = buf[16:24].astype(np.float64); names2 = ["cluster fetch", "vertex stage", 
 print(wl, "k_raster phase shares; total %.3f G" % (ph2.sum() / 1e9))
 for n, v in zip(names2, ph2):
     if n != "-": print("  %5.1f %%  %s" % (100 * v / ph2.sum(), n))
+
+lw = buf[40:48].astype(np.float64)
+if lw.sum() > 0:
+    print(wl, "k_raster: the longest wave of the four frames' launches, %.0f k cycles (~%.0f us at 2.3 GHz)" % (lw.sum() / 1e3, lw.sum() / 2300.0))
+    for n, v in zip(names2, lw):
+        print("  %5.1f %%  %s" % (100 * v / lw.sum(), n))
