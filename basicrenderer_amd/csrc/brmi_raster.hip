@@ -1647,6 +1647,8 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
     a.binAlpha = p->wsPtr<AlphaRecord>(p->ws.binAlpha); a.overflowAlpha = p->wsPtr<AlphaRecord>(p->ws.overflowAlpha);
     a.clusterUv = p->wsPtr<ClusterUv>(p->ws.clusterUv);
     a.alphaMats = p->wsPtr<AlphaMaterial>(p->ws.alphaMats);
+    // (k_raster_bins<true> packs the material index of a waiting pixel with its 12-bit tile cell into one word)
+    if (p->sceneHasAlphaTest && p->scene.materialCount > (1u << 20)) return fail(p, BRMI_ERR_INVALID, "brmi_raster: %u materials in a scene with alpha-tested ones (at most %u)", p->scene.materialCount, 1u << 20);
     if (p->sceneHasAlphaTest) if (int rc = ensure_frame_constants(p, s)) return rc;
     a.tileCounts = p->wsPtr<uint32_t>(p->ws.tileCounts); a.tileLists = p->wsPtr<TileEntry>(p->ws.tileLists); a.tileCapacity = p->tileCapacity;
     a.xverts = p->wsPtr<float>(p->ws.xverts); a.xvertClusters = p->xvertClusters; a.debugStamps = p->wsPtr<unsigned long long>(p->ws.debugStamps);
