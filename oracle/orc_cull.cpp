@@ -68,36 +68,41 @@ static uint32_t ceilLog2Clamped(float x, uint32_t maxMip) {
     return m < maxMip ? m : maxMip;
 }
 
-// sphere_screen_extents + OcclusionCullingPerspectiveTexture2D (explicit-parameter overload)
-static bool occlusionCulled(const HzbView& hzb, const brmi_camera& cam, const mat4& proj, float3 centerVS, float sphereDepth, float radius) {
-    const float viewW = (float)cam.depthResX, viewH = (float)cam.depthResY, mips = (float)cam.numDepthMips;
+// sphere_screen_extents + OcclusionCullingPerspectiveTexture2D (explicit-parameter overload): everything up to the four taps
+struct OccTaps { float L, B, R, T; uint32_t mip, x0, y0, x1, y1, mw, mh; };
+static OccTaps occlusionTaps(float viewW, float viewH, float mips, float sx, float sy, float p00, float p11, float3 centerVS, float radius) {
+    OccTaps o;
     float3 p = centerVS; p.y = -p.y;
     float rad2 = radius * radius, d = p.z * radius;
     float hv = std::sqrt(p.x * p.x + p.z * p.z - rad2);
     float ha = p.x * hv, hb = p.x * radius, hc = p.z * hv;
-    float L = (ha - d) * proj.m[0][0] / (hc + hb);
-    float R = (ha + d) * proj.m[0][0] / (hc - hb);
+    float L = (ha - d) * p00 / (hc + hb);
+    float R = (ha + d) * p00 / (hc - hb);
     float vv = std::sqrt(p.y * p.y + p.z * p.z - rad2);
     float va = p.y * vv, vb = p.y * radius, vc = p.z * vv;
-    float B = (va - d) * proj.m[1][1] / (vc + vb);
-    float T = (va + d) * proj.m[1][1] / (vc - vb);
+    float B = (va - d) * p11 / (vc + vb);
+    float T = (va + d) * p11 / (vc - vb);
     L = -L; R = -R;
+    o.L = L; o.B = B; o.R = R; o.T = T;
     // vUV = saturate(vLBRT.xwzy * (0.5,-0.5,0.5,-0.5) + 0.5)
     float u0 = saturate(L * 0.5f + 0.5f), v0 = saturate(T * -0.5f + 0.5f), u1 = saturate(R * 0.5f + 0.5f), v1 = saturate(B * -0.5f + 0.5f);
     float ax0 = u0 * viewW, ay0 = v0 * viewH, ax1 = u1 * viewW, ay1 = v1 * viewH;
     float ex = ax1 - ax0, ey = ay1 - ay0;
-    const uint32_t mip = ceilLog2Clamped(fmax2(ex, ey), (uint32_t)mips - 1u);
-    const float sx = cam.UVScaleToNextPowerOf2[0], sy = cam.UVScaleToNextPowerOf2[1];
+    o.mip = ceilLog2Clamped(fmax2(ex, ey), (uint32_t)mips - 1u);
     float pu0 = u0 * sx, pv0 = v0 * sy, pu1 = u1 * sx, pv1 = v1 * sy;
     const float ssx = fmax2(sx, 1e-6f), ssy = fmax2(sy, 1e-6f);
     uint32_t hzbW = (uint32_t)std::nearbyint(viewW / ssx), hzbH = (uint32_t)std::nearbyint(viewH / ssy);
     hzbW = hzbW < 1 ? 1 : hzbW; hzbH = hzbH < 1 ? 1 : hzbH;
-    uint32_t mw = hzbW >> mip, mh = hzbH >> mip; mw = mw < 1 ? 1 : mw; mh = mh < 1 ? 1 : mh;
+    uint32_t mw = hzbW >> o.mip, mh = hzbH >> o.mip; mw = mw < 1 ? 1 : mw; mh = mh < 1 ? 1 : mh;
     auto px = [&](float u, uint32_t res) { uint32_t v = (uint32_t)std::floor(u * (float)res); return v > res - 1 ? res - 1 : v; };
-    uint32_t x0 = px(pu0, mw), y0 = px(pv0, mh), x1 = px(pu1, mw), y1 = px(pv1, mh);
-    if (mip >= hzb.mipCount) return false;
-    const float* m = hzb.data + hzb.mipOffsets[mip];
-    float d0 = m[(uint64_t)y0 * mw + x0], d1 = m[(uint64_t)y0 * mw + x1], d2 = m[(uint64_t)y1 * mw + x1], d3 = m[(uint64_t)y1 * mw + x0];
+    o.x0 = px(pu0, mw); o.y0 = px(pv0, mh); o.x1 = px(pu1, mw); o.y1 = px(pv1, mh); o.mw = mw; o.mh = mh;
+    return o;
+}
+static bool occlusionCulled(const HzbView& hzb, const brmi_camera& cam, const mat4& proj, float3 centerVS, float sphereDepth, float radius) {
+    const OccTaps o = occlusionTaps((float)cam.depthResX, (float)cam.depthResY, (float)cam.numDepthMips, cam.UVScaleToNextPowerOf2[0], cam.UVScaleToNextPowerOf2[1], proj.m[0][0], proj.m[1][1], centerVS, radius);
+    if (o.mip >= hzb.mipCount) return false;
+    const float* m = hzb.data + hzb.mipOffsets[o.mip];
+    float d0 = m[(uint64_t)o.y0 * o.mw + o.x0], d1 = m[(uint64_t)o.y0 * o.mw + o.x1], d2 = m[(uint64_t)o.y1 * o.mw + o.x1], d3 = m[(uint64_t)o.y1 * o.mw + o.x0];
     float mx = fmax2(fmax2(d0, d1), fmax2(d2, d3));
     return mx < sphereDepth - radius;
 }
@@ -140,6 +145,22 @@ struct NodeRec { uint32_t inst, node; bool allowRefine, replay; };
 using namespace orc;
 
 extern "C" {
+// Pieces of the culling tests on their own, for tests that hold them against independent restatements (tests/test_oracle_cpu.py).
+// in: viewW, viewH, mips, uvScale.x, uvScale.y, proj[0][0], proj[1][1], centre (view space, 3), radius   out: L, B, R, T, mip, x0, y0, x1, y1, mipW, mipH
+void orc_occlusion_taps(const float* in, float* out, uint32_t n) {
+    for (uint32_t i = 0; i < n; i++, in += 11, out += 11) {
+        const OccTaps o = occlusionTaps(in[0], in[1], in[2], in[3], in[4], in[5], in[6], float3{in[7], in[8], in[9]}, in[10]);
+        out[0] = o.L; out[1] = o.B; out[2] = o.R; out[3] = o.T; out[4] = (float)o.mip; out[5] = (float)o.x0; out[6] = (float)o.y0; out[7] = (float)o.x1; out[8] = (float)o.y1; out[9] = (float)o.mw; out[10] = (float)o.mh;
+    }
+}
+// in: centre (3), radius, six planes (24)   out: 1 = outside
+void orc_sphere_outside_frustum(const float* in, uint32_t* out, uint32_t n) {
+    for (uint32_t i = 0; i < n; i++, in += 28) { float pl[6][4]; std::memcpy(pl, in + 4, sizeof(pl)); out[i] = sphereOutsideFrustum(float3{in[0], in[1], in[2]}, in[3], pl) ? 1u : 0u; }
+}
+// in: world centre (3), world radius, mesh-space error, scale, camera position (3), zNear, ortho (0 / 1)   out: error over distance
+void orc_projected_error(const float* in, float* out, uint32_t n) {
+    for (uint32_t i = 0; i < n; i++, in += 11) out[i] = projectedGeometricError(float3{in[0], in[1], in[2]}, in[3], in[4], in[5], float3{in[6], in[7], in[8]}, in[9], in[10] != 0.0f);
+}
 
 typedef struct orc_cull_params {
     uint32_t phase;                 // 1 or 2

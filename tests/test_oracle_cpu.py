@@ -1432,6 +1432,98 @@ def test_barycentrics_and_their_derivatives_against_a_float64_restatement_of_cal
     assert worstL < 5.0e-5 and worstD < 5.0e-5, (worstL, worstD)
 
 
+def test_culling_tests_against_float64_restatements_of_the_hlsl():
+    """The numerically delicate pieces of the culling chain on 20,000 random inputs each, the oracle's fp32 against float64 written from the shader text:
+    sphere_screen_extents + OcclusionCullingPerspectiveTexture2D up to the four taps (sphereScreenExtents.hlsli:14-31, occlusionCulling.hlsli:165-212),
+    SphereOutsideFrustumViewSpace (computeCulling.hlsl:103-190: reject iff dot(n, c) + d < -r for some plane) and ProjectedGeometricError
+    (workGraphCulling.hlsl:1522-1541).  Extents within 2e-5 of the [-1, 1] screen (measured 4e-6 for spheres at least 1.5 radii in front of the camera); the mip
+    and the tap coordinates are integers cut out of those by ceil / floor -- they must agree wherever the float64 value is not within 1e-3 of the cut, and
+    differ by at most one step where it is; the frustum verdicts agree wherever the float64 margin exceeds 1e-5 of the sphere's distance scale; the projected
+    error within 1e-6 relative."""
+    import orc
+    rng = np.random.default_rng(47)
+    n = 20000
+    # ---- occlusion taps
+    viewW, viewH = 3840.0, 2160.0
+    mips = 12.0
+    sx, sy = 3840.0 / 4096.0, 2160.0 / 4096.0                  # UVScaleToNextPowerOf2 of a 4K depth map in a 4096^2 chain
+    p00, p11 = 1.0 / (np.tan(0.5 * 1.0) * 16.0 / 9.0), 1.0 / np.tan(0.5 * 1.0)
+    z = -rng.uniform(0.5, 200.0, n)                          # view space looks down -z; the shader is handed the sphere as it stands (and flips y itself)
+    r = rng.uniform(0.01, 0.3, n) * (-z) / 1.5              # completely in front of the camera: |z| >= 1.5 r ... 150 r
+    cx = rng.uniform(-1.3, 1.3, n) * (-z) / p00
+    cy = rng.uniform(-1.3, 1.3, n) * (-z) / p11
+    inp = np.zeros((n, 11), dtype=np.float32)
+    inp[:, 0], inp[:, 1], inp[:, 2], inp[:, 3], inp[:, 4], inp[:, 5], inp[:, 6] = viewW, viewH, mips, sx, sy, p00, p11
+    inp[:, 7], inp[:, 8], inp[:, 9], inp[:, 10] = cx, cy, z, r
+    got = np.zeros((n, 11), dtype=np.float32)
+    orc.lib().orc_occlusion_taps(inp.ctypes.data_as(C.c_void_p), got.ctypes.data_as(C.c_void_p), C.c_uint32(n))
+    q = inp.astype(np.float64)
+    px_, py_, pz_, rad = q[:, 7], -q[:, 8], q[:, 9], q[:, 10]                    # viewSpaceCenter.y = -viewSpaceCenter.y
+    rad2, d = rad * rad, pz_ * rad
+    hv = np.sqrt(px_ * px_ + pz_ * pz_ - rad2); ha, hb, hc = px_ * hv, px_ * rad, pz_ * hv
+    left, right = (ha - d) * q[:, 5] / (hc + hb), (ha + d) * q[:, 5] / (hc - hb)
+    vv = np.sqrt(py_ * py_ + pz_ * pz_ - rad2); va, vb, vc = py_ * vv, py_ * rad, pz_ * vv
+    bottom, top = (va - d) * q[:, 6] / (vc + vb), (va + d) * q[:, 6] / (vc - vb)
+    left, right = -left, -right                                                 # vLBRT.x = -vLBRT.x; vLBRT.z = -vLBRT.z
+    want_ext = np.stack([left, bottom, right, top], axis=1)
+    err = np.abs(got[:, 0:4].astype(np.float64) - want_ext)
+    assert err.max() < 2.0e-5, (float(err.max()), int(err.argmax()))
+    sat = lambda v: np.clip(v, 0.0, 1.0)
+    uv = np.stack([sat(left * 0.5 + 0.5), sat(top * -0.5 + 0.5), sat(right * 0.5 + 0.5), sat(bottom * -0.5 + 0.5)], axis=1)      # vLBRT.xwzy * (0.5, -0.5, 0.5, -0.5) + 0.5
+    aabb = uv * np.array([viewW, viewH, viewW, viewH])
+    ext = np.maximum(aabb[:, 2] - aabb[:, 0], aabb[:, 3] - aabb[:, 1])
+    with np.errstate(divide="ignore"):
+        lg = np.where(ext > 0.0, np.log2(np.maximum(ext, 1e-300)), -np.inf)
+    mip64 = np.clip(np.ceil(lg), 0.0, mips - 1.0)
+    mip_got = got[:, 4].astype(np.float64)
+    with np.errstate(invalid="ignore"):
+        near_cut = np.abs(lg - np.round(lg)) < 1.0e-3
+    assert np.all((mip_got == mip64) | near_cut), int(np.sum((mip_got != mip64) & ~near_cut))
+    assert np.abs(mip_got - mip64).max() <= 1.0
+    # the taps, in the mip the oracle chose (the rare near-cut cases above may sit one mip apart: compare like with like)
+    hzbW, hzbH = max(1, int(round(viewW / max(sx, 1e-6)))), max(1, int(round(viewH / max(sy, 1e-6))))
+    mw = np.maximum(1, hzbW >> mip_got.astype(np.int64)); mh = np.maximum(1, hzbH >> mip_got.astype(np.int64))
+    assert np.array_equal(mw.astype(np.float32), got[:, 9]) and np.array_equal(mh.astype(np.float32), got[:, 10])
+    padded = uv * np.array([sx, sy, sx, sy])
+    pos = padded * np.stack([mw, mh, mw, mh], axis=1)
+    tap64 = np.minimum(np.floor(pos), np.stack([mw, mh, mw, mh], axis=1) - 1)
+    tap_got = got[:, 5:9].astype(np.float64)
+    near_int = np.abs(pos - np.round(pos)) < 1.0e-3
+    assert np.all((tap_got == tap64) | near_int), int(np.sum((tap_got != tap64) & ~near_int))
+    assert np.abs(tap_got - tap64).max() <= 1.0
+    assert np.mean(tap_got == tap64) > 0.999
+    # ---- frustum
+    c = rng.uniform(-50.0, 50.0, (n, 3)); rr = rng.uniform(0.01, 5.0, n)
+    nrm = rng.normal(size=(n, 6, 3)); nrm /= np.linalg.norm(nrm, axis=2, keepdims=True)
+    dd = rng.uniform(-20.0, 60.0, (n, 6))
+    fin = np.zeros((n, 28), dtype=np.float32)
+    fin[:, 0:3], fin[:, 3] = c, rr
+    fin[:, 4:28] = np.concatenate([nrm, dd[:, :, None]], axis=2).reshape(n, 24)
+    fout = np.zeros(n, dtype=np.uint32)
+    orc.lib().orc_sphere_outside_frustum(fin.ctypes.data_as(C.c_void_p), fout.ctypes.data_as(C.c_void_p), C.c_uint32(n))
+    f64 = fin.astype(np.float64)
+    dist = np.einsum("ijk,ik->ij", f64[:, 4:28].reshape(n, 6, 4)[:, :, 0:3], f64[:, 0:3]) + f64[:, 4:28].reshape(n, 6, 4)[:, :, 3]
+    margin = dist + f64[:, 3:4]                                                 # a plane rejects iff dist < -r
+    want_out = (margin < 0.0).any(axis=1)
+    sure = np.abs(margin).min(axis=1) > 1.0e-5 * (np.abs(f64[:, 0:3]).sum(axis=1) + 60.0)
+    assert np.array_equal(fout[sure].astype(bool), want_out[sure]) and sure.mean() > 0.99
+    assert 0.2 < want_out.mean() < 0.98                                          # both verdicts occur
+    # ---- projected error
+    pin = np.zeros((n, 11), dtype=np.float32)
+    pin[:, 0:3] = rng.uniform(-100.0, 100.0, (n, 3)); pin[:, 3] = rng.uniform(0.01, 30.0, n); pin[:, 4] = rng.uniform(1e-4, 2.0, n); pin[:, 5] = rng.uniform(0.1, 4.0, n)
+    pin[:, 6:9] = rng.uniform(-100.0, 100.0, (n, 3)); pin[:, 9] = 0.1; pin[:, 10] = (rng.uniform(size=n) < 0.1)
+    pout = np.zeros(n, dtype=np.float32)
+    orc.lib().orc_projected_error(pin.ctypes.data_as(C.c_void_p), pout.ctypes.data_as(C.c_void_p), C.c_uint32(n))
+    p64 = pin.astype(np.float64)
+    ws = p64[:, 4] * p64[:, 5]
+    den = np.maximum(np.linalg.norm(p64[:, 0:3] - p64[:, 6:9], axis=1) - p64[:, 3], p64[:, 9])
+    want_err = np.where(p64[:, 10] != 0.0, ws, ws / den)
+    rel = np.abs(pout.astype(np.float64) - want_err) / want_err
+    # (distance - radius cancels when the camera sits near the sphere's surface: bound the error there by the cancellation, elsewhere 1e-6)
+    cancel = np.linalg.norm(p64[:, 0:3] - p64[:, 6:9], axis=1) / den
+    assert np.all(rel < 1.0e-6 * np.maximum(1.0, cancel)), float((rel / np.maximum(1.0, cancel)).max())
+
+
 def test_kernels_of_the_benchmarked_frames_use_no_scratch_memory():
     """configs[1-3] launch these kernels; none of them may spill to scratch (round 3's textured G-buffer and alpha-tested bins kernels wrote half of their
     HBM bytes as spills).  Read from the gfx950 code object inside the built libbrmi.so (tools/kernel_resources.py = llvm-readelf --notes).
