@@ -1666,7 +1666,17 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
         return BRMI_OK;
     }
     // the pool of k_raster_bins: four 512-thread workgroups per CU is what the LDS holds; phase 2 rarely has an item at all
-    const dim3 bgrid(phase == 2 ? std::min(p->binGrid, 256u) : p->binGrid);
+    // Round 4: phase-2 launches are sized by what the host last saw phase 2 draw (the host-mapped word of the ranking kernel, read without a wait: a frame
+    // or two old; every kernel here strides its grid or takes items by ticket, so any size gives the same keys).  Beside another frame's shading half a
+    // wave that finds nothing still has to find a slot -- 200 VGPRs for k_raster<true>, 66 KB of LDS for a k_raster_bins<true> workgroup -- and the three
+    // phase-2 launches of a still camera cost the San-Miguel-class frame ~150 us of its geometry chain in flight (kernel stats: k_raster<true> 61 us,
+    // k_raster_overflow<true> 53, k_raster_bins<true> 150 per launch on average, phase 1 and 2 alike).
+    static const bool sizeByHint = [] { const char* e = std::getenv("BRMI_PHASE2_SIZED"); return !e || std::atoi(e) != 0; }();
+    uint32_t hint2 = 0xFFFFFFFFu;
+    if (phase == 2 && sizeByHint && p->phase2FeedbackHost) hint2 = *reinterpret_cast<volatile uint32_t*>(p->phase2FeedbackHost);
+    auto pow2_at_least = [](uint32_t v) { uint32_t r = 1; while (r < v && r < (1u << 30)) r <<= 1; return r; };
+    const bool sized2 = hint2 < 128u;
+    const dim3 bgrid(phase == 2 ? (sized2 ? std::max(16u, std::min(256u, pow2_at_least(hint2 * 2u))) : std::min(p->binGrid, 256u)) : p->binGrid);
     // Phase 2 draws what phase 1's stale depth chain hid: nothing with a still camera, tens of clusters with a slowly moving one, a thousand
     // with a fast one.  While the last count the host has seen (a host-mapped word the phase-2 ranking kernel stores, read here without any
     // wait: a frame or two old) is small, the triangles all take the row re-deal with global atomics -- no records, so no plan and no bins
@@ -1679,14 +1689,15 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
     // phase 2 rarely has more than a handful of clusters: 2048 workgroups (the kernel strides; two waves per SIMD) start and retire a little
     // faster than 8192 that find nothing (-3 us per frame)
     static const uint32_t grid2 = [] { const char* e = std::getenv("BRMI_RASTER_GRID2"); return e ? (uint32_t)std::max(64, std::atoi(e)) : 2048u; }();
-    const dim3 rgrid(phase == 2 ? std::min(p->rasterGrid, grid2) : p->rasterGrid);
+    const dim3 rgrid(phase == 2 ? std::min(p->rasterGrid, sized2 ? std::max(128u, std::min(grid2, pow2_at_least(hint2 * 16u))) : grid2) : p->rasterGrid);
+    const dim3 ogrid(phase == 2 && sized2 ? std::max(2u, std::min(129u, hint2 / 4u + 2u)) : 129u);      // (block 0 plans the bins launch; the others walk the overflow queues)
     if (p->sceneHasAlphaTest) {
         hipLaunchKernelGGL(k_raster<true>, rgrid, dim3(64), a.tableCells * 4u, s, a);
-        if (!direct2) hipLaunchKernelGGL(k_raster_overflow<true>, dim3(129), dim3(256), 0, s, a);
+        if (!direct2) hipLaunchKernelGGL(k_raster_overflow<true>, ogrid, dim3(256), 0, s, a);
         if (!direct2 && !(p->rasterDebug & 4)) hipLaunchKernelGGL(k_raster_bins<true>, bgrid, dim3(BRMI_BIN_THREADS), 0, s, a);
     } else {
         hipLaunchKernelGGL(k_raster<false>, rgrid, dim3(64), a.tableCells * 4u, s, a);
-        if (!direct2) hipLaunchKernelGGL(k_raster_overflow<false>, dim3(129), dim3(256), 0, s, a);
+        if (!direct2) hipLaunchKernelGGL(k_raster_overflow<false>, ogrid, dim3(256), 0, s, a);
         if (!direct2 && !(p->rasterDebug & 4)) hipLaunchKernelGGL(k_raster_bins<false>, bgrid, dim3(BRMI_BIN_THREADS), 0, s, a);
     }
     BRMI_LAUNCH_CHECK(p, "k_raster");
