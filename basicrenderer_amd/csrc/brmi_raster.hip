@@ -738,10 +738,10 @@ constexpr uint32_t BIN_ORDER_CAP = 1024;       // longest slice the walk order i
 // register file and the LDS allow.  BRMI_ALPHA_LIST sizes two LDS arrays; at 4096 entries the workgroup needs 43 KB and only three
 // fit a CU, at 2048 it needs 31 KB and four do (profiles/r02_experiments.md).
 #ifndef BRMI_BIN_ALPHA_WAVES
-#define BRMI_BIN_ALPHA_WAVES 4
+#define BRMI_BIN_ALPHA_WAVES 6
 #endif
 #ifndef BRMI_ALPHA_LIST
-#define BRMI_ALPHA_LIST 2048
+#define BRMI_ALPHA_LIST 1024      // (round 4: 2048 until the ring of waiting pixels made LDS the limit; BRMI_BIN_MIN_SLICE's default is 1024 anyway)
 #endif
 template <bool ALPHA>
 __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES : 1) k_raster_bins(RasterArgs a) {
@@ -761,7 +761,13 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES
 #define BRMI_ALPHA_COMPACT 1
 #endif
     // pixels of alpha-tested records that are covered and can still win their key, waiting for the test: a ring per wave (see the task pass)
-    constexpr uint32_t AQ = 128, AQ_WAVES = (ALPHA && BRMI_ALPHA_COMPACT) ? BRMI_BIN_THREADS / 64 : 1, AQ_N = (ALPHA && BRMI_ALPHA_COMPACT) ? AQ : 1;
+// (64 entries: with the 1024-record task lists the workgroup needs 50 KB of LDS and 80 VGPRs -- three workgroups per CU, six waves per SIMD, instead of two and four
+    // with 128 entries and 2048 records: San-Miguel-class raster stage 0.265 -> 0.245 ms, frame in flight 0.867 -> 0.838.  A step that would overflow the ring tests what
+    // waits first.)
+#ifndef BRMI_ALPHA_RING
+#define BRMI_ALPHA_RING 64
+#endif
+    constexpr uint32_t AQ = BRMI_ALPHA_RING, AQ_WAVES = (ALPHA && BRMI_ALPHA_COMPACT) ? BRMI_BIN_THREADS / 64 : 1, AQ_N = (ALPHA && BRMI_ALPHA_COMPACT) ? AQ : 1;
     __shared__ unsigned long long qKey[AQ_WAVES][AQ_N];
     __shared__ float qU[AQ_WAVES][AQ_N], qV[AQ_WAVES][AQ_N];
     __shared__ uint32_t qMeta[AQ_WAVES][AQ_N];
@@ -1030,6 +1036,7 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES
                     const uint32_t cell = (uint32_t)((w.px - x0) * BIN_ROWS + (py - y0)) & 0xFFFu;
                     const bool want = act && cov && key < *(volatile const unsigned long long*)&tile[cell];
                     const unsigned long long m = __ballot(want);
+                    if (AQ < 128u && qTail - qHead + (uint32_t)__popcll(m) > AQ) { BSTAMP(3); drain(qTail - qHead); }      // (a 64-entry ring: make room first)
                     if (want) {
                         const uint32_t e = (qTail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) & (AQ - 1u);
                         const f2 uv = pixel_texcoord(at, w.b0, w.b1, b2);
