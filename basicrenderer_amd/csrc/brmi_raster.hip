@@ -735,8 +735,9 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
 #endif
 constexpr uint32_t BIN_ORDER_CAP = 1024;       // longest slice the walk order is built for (longer ones: BRMI_BIN_CAPACITY above 8192) walk in arrival order
 // The alpha-tested variant is bound by the latency of its per-pixel texel fetches: it wants as many resident workgroups as the
-// register file and the LDS allow.  BRMI_ALPHA_LIST sizes two LDS arrays; at 4096 entries the workgroup needs 43 KB and only three
-// fit a CU, at 2048 it needs 31 KB and four do (profiles/r02_experiments.md).
+// register file and the LDS allow.  BRMI_ALPHA_LIST sizes two LDS arrays (the task lists' prefix sums, 6 B per record); with the 32 KB tile, the
+// rings of waiting pixels (BRMI_ALPHA_RING x 20 B per wave) and the unorm table a workgroup is 50 KB at 1024 records and 64-entry rings: three
+// workgroups per CU = six waves per SIMD at 80 VGPRs (round 4; 67 KB / two workgroups / four waves at 2048 records and 128 entries).
 #ifndef BRMI_BIN_ALPHA_WAVES
 #define BRMI_BIN_ALPHA_WAVES 6
 #endif
