@@ -243,6 +243,7 @@ int brmi_create(const brmi_config* cfg, brmi_pass** out) {
     if (const char* e = std::getenv("BRMI_FLAT_WIDE")) p->wideFlat = std::atoi(e) != 0;
     if (const char* e = std::getenv("BRMI_SCAN_CHAINED")) p->scanChained = std::atoi(e) != 0;
     if (const char* e = std::getenv("BRMI_FLAT_PACKED")) p->packedFlat = std::atoi(e) != 0;
+    if (const char* e = std::getenv("BRMI_FLAT_LEVELS_MIN_DRAWS")) p->flatLevelsMinDraws = (uint32_t)std::max(0, std::atoi(e));      // (tests: 1 = the level-synchronous flat traversal for every scene; a huge value = never)
     if (const char* e = std::getenv("BRMI_BIN_MIN_SLICE")) p->binMinSlice = (uint32_t)std::max(32, std::atoi(e));
     if (const char* e = std::getenv("BRMI_BIN_SHARED_SLICE")) p->binSharedSlice = (uint32_t)std::max(32, std::atoi(e));
     if (const char* e = std::getenv("BRMI_BIN_GRID")) p->binGrid = (uint32_t)std::min(65535, std::max(1, std::atoi(e)));
@@ -443,7 +444,7 @@ int brmi_set_scene(brmi_pass* p, const brmi_scene_buffers* scene) {
         if ((rc2 = read_back(p, groups, sc.lodGroups, sc.lodGroupCount))) return rc2;
         if ((rc2 = read_back(p, insts, sc.perMeshInstance, sc.perMeshInstanceCount))) return rc2;
         if ((rc2 = read_back(p, pms, sc.perMesh, sc.perMeshCount))) return rc2;
-        p->hostFlatNodes.clear(); p->hostFlatLeaves.clear();
+        p->hostFlatNodes.clear(); p->hostFlatLeaves.clear(); p->flatMaxDepth = 1;
         std::vector<uint32_t> flatBase(md.size(), 0), flatCount(md.size(), 0);
         const bool flatOn = std::getenv("BRMI_FLAT_TRAVERSAL") ? std::atoi(std::getenv("BRMI_FLAT_TRAVERSAL")) != 0 : true;
         std::vector<std::pair<uint32_t, uint32_t>> bfs;      // (node id, parent position)
@@ -458,9 +459,13 @@ int brmi_set_scene(brmi_pass* p, const brmi_scene_buffers* scene) {
             }
             if (!fits) continue;
             flatBase[m] = (uint32_t)p->hostFlatNodes.size(); flatCount[m] = (uint32_t)bfs.size();
+            // (breadth-first: the children of a node are pushed together, so they sit side by side; position of the first and depth of every node)
+            std::vector<uint32_t> firstChild(bfs.size(), 0u), childCount(bfs.size(), 0u), depthOf(bfs.size(), 1u);
+            for (size_t k = 1; k < bfs.size(); k++) { const uint32_t par = bfs[k].second; if (childCount[par]++ == 0u) firstChild[par] = (uint32_t)k; depthOf[k] = depthOf[par] + 1u; p->flatMaxDepth = std::max(p->flatMaxDepth, depthOf[k]); }
             for (size_t k = 0; k < bfs.size(); k++) {
                 const brmi_lod_node& nd = nodes[md[m].lodNodesBase + bfs[k].first];
                 FlatNode f{}; FlatLeaf l{};
+                f.children = firstChild[k] | (childCount[k] << 16);
                 std::memcpy(f.cull, nd.cullCenterAndRadius, 16); std::memcpy(f.lod, nd.lodCenterAndRadius, 16); f.maxQuadricError = nd.maxQuadricError;
                 f.nodeId = bfs[k].first; f.info = bfs[k].second << 8;
                 if (nd.isLeaf == BRMI_NODE_INTERNAL) f.info |= 1u;
@@ -854,7 +859,7 @@ int brmi_read_counters(brmi_pass* p, brmi_counters* out, brmi_stream stream) {
     for (uint32_t st = 0; st < CNT_STRIPE_COUNT; st++) out->meshletsTested += c[CNT_STRIPES + st * CNT_STRIPE_WORDS + STRIPE_MESHLETS_TESTED];
     out->visibleClusters = c[CNT_VISIBLE]; out->visibleClustersPhase2 = c[CNT_VISIBLE2];
     out->droppedRecords = c[CNT_DROPPED_RECORDS]; out->droppedClusters = c[CNT_DROPPED_CLUSTERS]; out->lightPagesUsed = c[CNT_LIGHT_PAGES];
-    out->reserved[0] = c[CNT_SUM_VERTS_LO]; out->reserved[1] = c[CNT_SUM_VERTS_HI]; out->reserved[2] = c[CNT_SUM_TRIS_LO]; out->reserved[3] = c[CNT_SUM_TRIS_HI];
+    out->reserved[0] = c[CNT_SUM_VERTS_LO]; out->reserved[1] = 0u; out->reserved[2] = c[CNT_SUM_VERTS_HI]; out->reserved[3] = 0u;      // (vertex sum | triangle sum << 32 in one word, brmi_internal.h)
     out->reserved[4] = c[CNT_RASTER_CLUSTERS]; out->reserved[5] = c[CNT_BIN_OVERFLOW] + overflowQueued;
     out->replayNodes = c[CNT_REPLAY_NODES]; out->replayMeshlets = c[CNT_REPLAY_MESHLETS];
     return BRMI_OK;

@@ -46,6 +46,7 @@ struct CullArgs {
     unsigned long long* debugStamps;     // instrumented builds (-DBRMI_TILE_STAMPS)
     uint32_t wideFlat;                   // phase 1: hierarchies of 257 .. 8192 nodes are k_cull_flat_wide's (the walk skips them)
     uint32_t packedFlat;                 // phase 1: the launch's first ceil(draws / 8) waves take eight draws each (hierarchies of <= 8 nodes)
+    uint32_t* feedback;                  // host-mapped words (brmi_pass::ensureFeedback) or null: word 2 = phase 1's bucket records (the host sizes the next frames' launches by it)
 };
 
 BRMI_DEV f3 to_view_space(f3 c, const m4& model, const m4& view) { return xyz(mul_vm(mul_point(c, model), view)); }
@@ -1011,6 +1012,161 @@ __global__ void __launch_bounds__(1024) k_cull_flat_wide(CullArgs a, BucketRecor
     }
 }
 
+// Level-synchronous flat traversal for scenes of MANY draws (Zorah-class: 100 k instances of two 600-node hierarchies, 83 k of them in the frustum,
+// seven nodes reached in each on average).  One wave per draw -- the LDS walk above, or the flat evaluation of every node -- keeps the chip busy with
+// chains of dependent loads: 83 k instances x ~25 us of chain over the ~3 k waves that fit is 0.7 ms (measured 0.7 - 1.0 ms, and its one
+// reservation per draw on one counter, served at ~90 per microsecond, costs as much again), and evaluating all 600 nodes of every instance is 3 ms.
+// Here a LANE is a task: level 0 takes a draw (K1, then the root), every later level a (instance, flat position) record of the frontier the level
+// before wrote; a node's children sit side by side in the breadth-first tables (FlatNode::children), so their pre-filter is eight independent
+// loads.  Appends are aggregated per workgroup (three atomics per 256 tasks).  Same tests, same arithmetic, same records as the walk; the order of
+// the bucket records differs, which the survivor ranking (a bit per (instance, segment, meshlet)) does not see.  flatMaxDepth launches.
+template <bool FIRST>
+__global__ void __launch_bounds__(256) k_cull_flat_level(CullArgs a, uint32_t level, const NodeRecord* in, NodeRecord* out, BucketRecord* buckets) {
+    wave_prio<PRIO_CULL>();
+    __shared__ uint32_t waveTot[3][4], bases[3];
+    const brmi_scene_buffers& sc = a.sc;
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const uint32_t viewId = sc.perFrame->mainCameraIndex;
+    const brmi_camera* cam = sc.cameras + viewId;
+    const brmi_culling_camera* lodCam = sc.cullingCameras + viewId;
+    const bool ortho = cam->isOrtho != 0;
+    const f3 camPos{lodCam->positionWorldSpace[0], lodCam->positionWorldSpace[1], lodCam->positionWorldSpace[2]};
+    const float zNear = lodCam->zNear, threshold = lodCam->errorOverDistanceThreshold;
+    const m4 view = load_m4(&cam->view[0][0]);
+    const uint32_t count = FIRST ? sc.activeDrawCount : min(a.counters[CNT_FRONTIER0 + level], a.recordCapacity);
+    uint32_t* nextCount = &a.counters[CNT_FRONTIER0 + level + 1u];
+    const uint32_t rounded = (count + 255u) & ~255u;        // workgroup-uniform trip count (barriers inside)
+    uint32_t nTested = 0, nVisible = 0, nNodes = 0;
+    for (uint32_t idx = blockIdx.x * 256u + t; idx < rounded; idx += gridDim.x * 256u) {
+        bool have = idx < count;
+        uint32_t instIndex = 0, pos = 0;
+        InstanceWalk iw{0u, 0u, 0u, 0u}; brmi_per_mesh_instance inst{};
+        if (have) {
+            if (FIRST) instIndex = sc.activeDraws[idx];
+            else { const NodeRecord rec = in[idx]; instIndex = rec.instanceIndex; pos = rec.nodeIdPacked; }
+            iw = a.instanceWalk[instIndex]; inst = sc.perMeshInstance[instIndex];
+            if (iw.flatCount == 0u) have = false;         // (launch_cull takes this path only when every mesh has flat tables)
+        }
+        bool hidden = false, leafOk = false;
+        uint32_t childMask = 0, firstChild = 0, nChunks = 0, slabDesc = 0, slabOff = 0;
+        FlatNode fn{};
+        if (have) {
+            const brmi_per_object* obj = sc.perObject + inst.perObjectBufferIndex;
+            const m4 model = load_m4(&obj->model[0][0]);
+            const float scale = max_axis_scale(model);
+            const f3 instC{inst.boundingSphere[0], inst.boundingSphere[1], inst.boundingSphere[2]}; const float instR = inst.boundingSphere[3];
+            if (FIRST) {   // K1 (PureComputeObjectCullCS)
+                const f3 c = to_view_space(instC, model, view);
+                const float r = instR * scale;
+                const bool bad = isnan(c.x) || isnan(c.y) || isnan(c.z) || isinf(c.x) || isinf(c.y) || isinf(c.z) || isnan(r) || isinf(r);
+                nTested++;
+                if (bad || sphere_culled(a.stripes, cam, c, r)) have = false; else nVisible++;
+            }
+            if (have) {
+                nNodes++;
+                fn = a.flatNodes[iw.flatBase + pos];
+                const bool skinned = iw.skinned != 0u;
+                const bool internal = (fn.info & 1u);
+                const f3 cullC = skinned ? instC : f3{fn.cull[0], fn.cull[1], fn.cull[2]};
+                const float cullR = skinned ? instR : fn.cull[3];
+                const f3 cVS = to_view_space(cullC, model, view);
+                const float rW = cullR * scale;
+                const bool inFrustum = !sphere_culled(a.stripes, cam, cVS, rW);
+                if (inFrustum && internal) {
+                    const f3 lc = xyz(mul_point(f3{fn.lod[0], fn.lod[1], fn.lod[2]}, model));
+                    const float e = projected_error(lc, fn.lod[3] * scale, fn.maxQuadricError, scale, camPos, zNear, ortho);
+                    if (e >= threshold) {
+                        hidden = a.occlusion && occlusion_test_prev(a, cam, cullC, cullR, load_m4(&obj->prevModel[0][0]));
+                        if (!hidden) {
+                            // the children that pass as children: in the frustum and, internal ones, above the error threshold (computeCulling.hlsl:477-530)
+                            firstChild = fn.children & 0xFFFFu;
+                            const uint32_t cc = min(fn.children >> 16, BRMI_BVH_MAX_CHILDREN);
+#pragma unroll
+                            for (uint32_t c = 0; c < BRMI_BVH_MAX_CHILDREN; c++) if (c < cc) {
+                                const FlatNode* ch = a.flatNodes + (iw.flatBase + firstChild + c);
+                                const float4 cs = *reinterpret_cast<const float4*>(ch->cull), ls = *reinterpret_cast<const float4*>(ch->lod);
+                                const float chErr = ch->maxQuadricError; const uint32_t chInfo = ch->info;
+                                const f3 ccVS = to_view_space(skinned ? instC : f3{cs.x, cs.y, cs.z}, model, view);
+                                bool pre = !sphere_culled(a.stripes, cam, ccVS, (skinned ? instR : cs.w) * scale);
+                                if (pre && (chInfo & 1u)) {
+                                    const f3 wc = xyz(mul_point(f3{ls.x, ls.y, ls.z}, model));
+                                    pre = projected_error(wc, ls.w * scale, chErr, scale, camPos, zNear, ortho) >= threshold;
+                                }
+                                childMask |= pre ? (1u << c) : 0u;
+                            }
+                        }
+                    }
+                } else if (inFrustum) {
+                    const FlatLeaf fl = a.flatLeaves[iw.flatBase + pos];
+                    const f3 gc = xyz(mul_point(f3{fl.group[0], fl.group[1], fl.group[2]}, model));
+                    const float eod = projected_error(gc, fl.group[3] * scale, fn.maxQuadricError, scale, camPos, zNear, ortho);
+                    bool ok = eod >= threshold;
+                    if (ok && ((fn.info >> 1) & 1u)) {      // refined_child_suppresses
+                        const f3 cc = xyz(mul_point(f3{fl.child[0], fl.child[1], fl.child[2]}, model));
+                        const float ce = projected_error(cc, fl.child[3] * scale, fl.childParentError, scale, camPos, zNear, ortho);
+                        if (!(ce < threshold)) ok = false;
+                    }
+                    if (ok && ((fn.info >> 2) & 1u)) {
+                        const brmi_group_page_map_entry pe = sc.groupPageMap[fn.pageMapIndex];
+                        slabDesc = pe.slabDescriptorIndex; slabOff = pe.slabByteOffset;
+                        leafOk = slabDesc != 0u;
+                        nChunks = leafOk ? ((fn.segFirstCount >> 16) + a.factor - 1u) / a.factor : 0u;
+                    }
+                }
+            }
+        }
+        // one reservation per workgroup and output: frontier records, bucket records, replay nodes
+        const uint32_t mine[3] = {(uint32_t)__popc(childMask), nChunks, hidden ? 1u : 0u};
+        uint32_t incl[3] = {mine[0], mine[1], mine[2]};
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+#pragma unroll
+            for (int q = 0; q < 3; q++) { const uint32_t v = (uint32_t)__shfl_up((int)incl[q], o); if (lane >= (uint32_t)o) incl[q] += v; }
+        }
+        __syncthreads();                                 // the previous round's bases have been read
+        if (lane == 63u) { waveTot[0][wave] = incl[0]; waveTot[1][wave] = incl[1]; waveTot[2][wave] = incl[2]; }
+        __syncthreads();
+        if (t < 3u) {
+            const uint32_t total = waveTot[t][0] + waveTot[t][1] + waveTot[t][2] + waveTot[t][3];
+            uint32_t* counter = t == 0u ? nextCount : (t == 1u ? &a.counters[a.bucketCounter] : &a.counters[CNT_REPLAY_NODES]);
+            bases[t] = total ? atomicAdd(counter, total) : 0u;
+        }
+        __syncthreads();
+        uint32_t slot[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++) { uint32_t wb = 0; for (uint32_t w = 0; w < 4u; w++) if (w < wave) wb += waveTot[q][w]; slot[q] = bases[q] + wb + incl[q] - mine[q]; }
+        for (uint32_t m = childMask; m != 0u; m &= m - 1u, slot[0]++) {
+            if (slot[0] < a.recordCapacity) out[slot[0]] = NodeRecord{instIndex, firstChild + (uint32_t)__ffs((int)m) - 1u};
+            else atomicAdd(&a.counters[CNT_DROPPED_RECORDS], 1u);
+        }
+        if (nChunks != 0u) {
+            const uint32_t segFirst = fn.segFirstCount & 0xFFFFu, segCount = fn.segFirstCount >> 16;
+            for (uint32_t k = 0; k < nChunks; k++, slot[1]++) {
+                if (slot[1] >= a.recordCapacity) { atomicAdd(&a.counters[CNT_DROPPED_RECORDS], 1u); continue; }
+                BucketRecord b;
+                b.instanceIndex = instIndex; b.groupIdPacked = fn.ownerGroup & 0x7FFFFFFFu;
+                b.meshletIndexAndCount = (min(a.factor, segCount - k * a.factor) << 16) | ((segFirst + k * a.factor) & 0xFFFFu);
+                b.pageSlabDescriptorIndex = slabDesc; b.pageSlabByteOffset = slabOff;
+                b.firstBit = iw.bitBase + fn.firstBitRel + k * a.factor; b.pad0 = 0; b.pad1 = 0;
+                buckets[slot[1]] = b;
+            }
+        }
+        if (hidden) {
+            if (slot[2] < a.recordCapacity) a.replayNodes[slot[2]] = NodeRecord{instIndex, 0x80000000u | (1u << 30) | (fn.nodeId & 0x3FFFFFFFu)};
+            else atomicAdd(&a.counters[CNT_DROPPED_RECORDS], 1u);
+        }
+    }
+    // statistics: one atomic per wave and counter on a stripe of its own
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { nNodes += (uint32_t)__shfl_xor((int)nNodes, o); nTested += (uint32_t)__shfl_xor((int)nTested, o); nVisible += (uint32_t)__shfl_xor((int)nVisible, o); }
+    if (lane == 0) {
+        uint32_t* stripe = a.counters + CNT_STRIPES + ((blockIdx.x * 4u + wave) & (CNT_STRIPE_COUNT - 1u)) * CNT_STRIPE_WORDS;
+        if (nTested) atomicAdd(&stripe[0], nTested);
+        if (nVisible) atomicAdd(&stripe[1], nVisible);
+        if (nNodes) atomicAdd(&stripe[2], nNodes);
+    }
+}
+
 // ComputeSkinnedMeshletBounds (workGraphCulling.hlsl:1405-1467): the meshlet sphere moved by every bone the meshlet lists,
 // merged pairwise into one enclosing sphere
 BRMI_DEV float4 skinned_meshlet_bounds(const brmi_scene_buffers& sc, const brmi_meshlet_descriptor* desc, const brmi_page_header* hdr, const uint8_t* page, uint32_t slot, float4 staticBounds) {
@@ -1065,6 +1221,7 @@ __global__ void __launch_bounds__(256) k_cull_clusters(CullArgs a, const BucketR
     }
     const brmi_scene_buffers& sc = a.sc;
     const uint32_t bucketCount = min(a.counters[a.bucketCounter], a.recordCapacity);
+    if (a.feedback && a.phase == 1u && blockIdx.x == 0u && threadIdx.x == 0u) __hip_atomic_store(a.feedback + 2, bucketCount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const uint32_t viewId = sc.perFrame->mainCameraIndex;
     const brmi_camera* cam = sc.cameras + viewId;
     const brmi_culling_camera* lodCam = sc.cullingCameras + viewId;
@@ -1075,7 +1232,10 @@ __global__ void __launch_bounds__(256) k_cull_clusters(CullArgs a, const BucketR
     uint32_t* tempCount = &a.counters[a.phase == 2 ? CNT_TEMP_VISIBLE2 : CNT_TEMP_VISIBLE];
     // one lane per (bucket, meshlet-in-bucket): `factor` lanes cooperate on a record
     const uint64_t totalLanes = (uint64_t)bucketCount * a.factor;
-    const uint64_t rounded = (totalLanes + 63ull) & ~63ull;
+    const uint64_t rounded = (totalLanes + 255ull) & ~255ull;      // workgroup-uniform trip count (barriers inside)
+    // (round 5: the survivors' and the occluded meshlets' slots are reserved once per workgroup -- a Zorah-class frame tests 850 k meshlets, and one
+    // atomic with return per wave and list, 11 k on two lines, was a third of the kernel)
+    __shared__ uint32_t waveSurv[4], waveOccl[4], blockSlots[2];
     for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < rounded; idx += (uint64_t)mainBlocks * blockDim.x) {
         bool survives = false, occluded = false, tested = false;
         uint4 packed = make_uint4(0, 0, 0, 0);
@@ -1133,14 +1293,24 @@ __global__ void __launch_bounds__(256) k_cull_clusters(CullArgs a, const BucketR
             const uint64_t tm = __ballot(tested);
             if (tm != 0ull && (threadIdx.x & 63u) == 0u) atomicAdd(&a.counters[CNT_STRIPES + (blockIdx.x & (CNT_STRIPE_COUNT - 1u)) * CNT_STRIPE_WORDS + STRIPE_MESHLETS_TESTED], (uint32_t)__popcll(tm));
         }
-        if (a.occlusion && a.phase == 1u) {
-            const uint32_t rs = wave_append(&a.counters[CNT_REPLAY_MESHLETS], occluded);
-            if (occluded) {
-                if (rs < a.recordCapacity) { uint4* dst = reinterpret_cast<uint4*>(&a.replayBuckets[rs]); dst[0] = againLo; dst[1] = make_uint4(againHi.x, againHi.y, 0u, 0u); }
-                else atomicAdd(&a.counters[CNT_DROPPED_RECORDS], 1u);
-            }
+        occluded = occluded && a.occlusion && a.phase == 1u;
+        const uint64_t survM = __ballot(survives), occlM = __ballot(occluded);
+        const uint32_t wv = threadIdx.x >> 6;
+        __syncthreads();                                  // the previous round's slots have been read
+        if ((threadIdx.x & 63u) == 0u) { waveSurv[wv] = (uint32_t)__popcll(survM); waveOccl[wv] = (uint32_t)__popcll(occlM); }
+        __syncthreads();
+        if (threadIdx.x < 2u) {
+            const uint32_t* ws = threadIdx.x == 0u ? waveSurv : waveOccl;
+            const uint32_t total = ws[0] + ws[1] + ws[2] + ws[3];
+            blockSlots[threadIdx.x] = total ? atomicAdd(threadIdx.x == 0u ? tempCount : &a.counters[CNT_REPLAY_MESHLETS], total) : 0u;
         }
-        const uint32_t slot = wave_append(tempCount, survives);
+        __syncthreads();
+        uint32_t slot = blockSlots[0] + lane_rank(survM), rs = blockSlots[1] + lane_rank(occlM);
+        for (uint32_t w = 0; w < wv; w++) { slot += waveSurv[w]; rs += waveOccl[w]; }
+        if (occluded) {      // (only set in phase 1 of a frame with occlusion culling)
+            if (rs < a.recordCapacity) { uint4* dst = reinterpret_cast<uint4*>(&a.replayBuckets[rs]); dst[0] = againLo; dst[1] = make_uint4(againHi.x, againHi.y, 0u, 0u); }
+            else atomicAdd(&a.counters[CNT_DROPPED_RECORDS], 1u);
+        }
         if (survives) {
             if (slot < a.visibleCapacity) {
                 TempVisible t; t.packed = packed; t.bit = bit; t.pad0 = t.pad1 = t.pad2 = 0;
@@ -1314,7 +1484,14 @@ __global__ void __launch_bounds__(256) k_scatter_visible(const TempVisible* temp
         }
         __syncthreads();
     }
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += gridDim.x * blockDim.x) {
+    // (statistics double as the reservation of the clusters' tables in the resolve arena.  Round 5: ONE atomic per workgroup -- vertices in the low,
+    // triangles in the high half of one 64-bit word -- instead of three per wave on one cache line: a Zorah-class frame places 490 k clusters, and
+    // 23 k same-line atomics at ~90 per microsecond were 250 us, the whole kernel.  The count of placed clusters is one thread's sum.)
+    __shared__ unsigned long long blockBase;
+    __shared__ uint32_t waveV[4], waveT[4];
+    if (blockIdx.x == 0u && threadIdx.x == 0u) { const uint32_t room = base < capacity ? capacity - base : 0u; atomicAdd(&counters[CNT_RASTER_CLUSTERS], min(n, room)); }
+    const uint32_t rounded256 = (n + 255u) & ~255u;      // workgroup-uniform trip count (barriers inside)
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded256; i += gridDim.x * blockDim.x) {
         uint32_t verts = 0, tris = 0, placed = 0, dst = 0;
         TempVisible t{};
         const uint8_t* slab = nullptr; uint32_t pageOff = 0;
@@ -1335,25 +1512,22 @@ __global__ void __launch_bounds__(256) k_scatter_visible(const TempVisible* temp
                 placed = 1;
             }
         }
-        // wave totals (statistics) double as the reservation of the cluster's tables in the resolve arena: the value the
-        // atomic returns is the wave's base, an exclusive scan over the lanes gives every cluster its offset
         uint32_t inclV = verts, inclT = tris;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t v = (uint32_t)__shfl_up((int)inclV, o), tt = (uint32_t)__shfl_up((int)inclT, o);
             if ((threadIdx.x & 63u) >= (uint32_t)o) { inclV += v; inclT += tt; }
         }
-        const uint32_t totV = (uint32_t)__shfl((int)inclV, 63), totT = (uint32_t)__shfl((int)inclT, 63);
-        const uint64_t anyPlaced = __ballot(placed != 0);
-        unsigned long long baseV = 0, baseT = 0;
-        if (anyPlaced != 0ull) {
-            if ((threadIdx.x & 63u) == 0) {
-                baseV = atomicAdd(reinterpret_cast<unsigned long long*>(&counters[CNT_SUM_VERTS_LO]), (unsigned long long)totV);
-                baseT = atomicAdd(reinterpret_cast<unsigned long long*>(&counters[CNT_SUM_TRIS_LO]), (unsigned long long)totT);
-                atomicAdd(&counters[CNT_RASTER_CLUSTERS], (uint32_t)__popcll(anyPlaced));
-            }
-            baseV = __shfl((unsigned long long)baseV, 0); baseT = __shfl((unsigned long long)baseT, 0);
+        __syncthreads();                                  // the previous round's base and wave sums have been read
+        if ((threadIdx.x & 63u) == 63u) { waveV[threadIdx.x >> 6] = inclV; waveT[threadIdx.x >> 6] = inclT; }
+        __syncthreads();
+        if (threadIdx.x == 0u) {
+            const unsigned long long totV = (unsigned long long)waveV[0] + waveV[1] + waveV[2] + waveV[3], totT = (unsigned long long)waveT[0] + waveT[1] + waveT[2] + waveT[3];
+            blockBase = (totV | totT) ? atomicAdd(reinterpret_cast<unsigned long long*>(&counters[CNT_SUM_VERTS_LO]), totV | (totT << 32)) : 0ull;
         }
+        __syncthreads();
+        unsigned long long baseV = (uint32_t)blockBase, baseT = blockBase >> 32;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) { baseV += waveV[w]; baseT += waveT[w]; }
         if (placed) {
             // resolve the cluster for the rasteriser and the G-buffer pass
             const uint32_t instanceIndex = vc_instance(t.packed);
@@ -1419,6 +1593,7 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
     uint32_t f = p->cfg.phase2ExpansionFactor; f = f < 1 ? 1 : (f > 64 ? 64 : f);
     { uint32_t n = 1; for (uint32_t c = 2; c <= 64; c <<= 1) if (c <= f) n = c; f = n; }
     a.factor = f; a.phase = phase; a.packedFlat = 0u; a.wideFlat = 0u;
+    a.feedback = p->ensureFeedback() ? p->phase2FeedbackDev : nullptr;
     // the band test's two planes through the eye only bound a row band under a symmetric perspective projection: an orthographic or
     // off-centre camera keeps the frustum test alone (the rasteriser's row filter still confines the band; nothing is lost but the early cull)
     const bool symmetricPerspective = p->camHost.isOrtho == 0 && p->camHost.projection[2][0] == 0.0f && p->camHost.projection[2][1] == 0.0f &&
@@ -1440,6 +1615,7 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
 
     const uint32_t maxBlocks = 1024;
     bool lightGridRides = false;      // this call's launches carry the light clustering (brmi_execute)
+    bool flatLevels = false;          // phase 1 ran the level-synchronous flat traversal: nothing is left for the walk or the level kernels
     // one launch of k_cull_hierarchy for the meshes that fit its LDS frontier, the level kernels for the rest (or for everything: tests)
     const bool hierarchy = p->minLevelWidth <= HIER_CAP_MAX && !p->forceLevelKernels;
     const bool levelKernels = p->maxLevelWidth > p->spillWidth || p->forceLevelKernels;
@@ -1457,8 +1633,23 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
         // (not beside another frame's shading half: a 1024-thread workgroup with 40 KB of LDS waits long for a CU that can take it, and the
         // dense frame in flight went 0.795 -> 0.91 ms; alone the same frame's cull stage goes 0.180 -> 0.142 ms)
         a.wideFlat = (hierarchy && p->anyWideFlat && p->wideFlat && !p->splitFrame) ? 1u : 0u;
+        // Scenes of very many draws (Zorah-class): the level-synchronous flat traversal, a lane per (instance, node) task, one launch per level of the
+        // deepest hierarchy (k_cull_flat_level).  Its launches carry no riders: the visibility clear moves onto k_cull_clusters (ClearRide) and the
+        // light clustering is launched by the frame where it finds none done.
+        flatLevels = hierarchy && p->allMeshesFlat && !p->forceLevelKernels && p->scene.activeDrawCount >= std::max(1u, p->flatLevelsMinDraws);
+        if (flatLevels) {
+            if (p->clearVisibilityWithTraversal && (p->bandPixelCount & 1ull) == 0ull) { p->clearVisibilityWithTraversal = false; p->clearVisibilityWithClusterCull = true; }
+            else if (p->clearVisibilityWithTraversal) flatLevels = false;      // (an odd pixel count: the riding clear of the walk handles it)
+        }
+        if (flatLevels) {
+            hipLaunchKernelGGL(k_cull_flat_level<true>, dim3(grid_for(p->scene.activeDrawCount, 256, 8192)), dim3(256), 0, s, a, 0u, (const NodeRecord*)nullptr, fb, buckets);
+            // (frontier sizes live on the device; every level strides a fixed grid and a workgroup that finds none of its tasks leaves after one load)
+            for (uint32_t level = 1; level < p->flatMaxDepth; level++)
+                hipLaunchKernelGGL(k_cull_flat_level<false>, dim3(2048), dim3(256), 0, s, a, level, (level & 1u) ? fb : fa, (level & 1u) ? fa : fb, buckets);
+            BRMI_LAUNCH_CHECK(p, "k_cull_flat_level");
+        }
         const dim3 hgrid(std::min(std::max(1u, p->scene.activeDrawCount), 16384u) + (a.packedFlat ? (p->scene.activeDrawCount + 7u) / 8u : 0u));
-        if (hierarchy) {
+        if (hierarchy && !flatLevels) {
             // ONE launch: the 6 KB-frontier variant when every mesh is narrow (<= 256 nodes per level), else the 24 KB variant for all meshes up
             // to 1024 (two launches, one per class, ran one after the other: San-Miguel-class cull 178 -> 140 us with one)
             const bool wide = p->maxLevelWidth > 256u;
@@ -1472,8 +1663,8 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
             } else if (wide) hipLaunchKernelGGL((k_cull_hierarchy<false, 1024, BRMI_HIER_STAGE_WIDE>), hgrid, dim3(64), 0, s, a, buckets, meshWidth, 0u, widthHi, spillAbove, fa, NoSide{});
             else hipLaunchKernelGGL((k_cull_hierarchy<false, 256, 128>), hgrid, dim3(64), 0, s, a, buckets, meshWidth, 0u, widthHi, spillAbove, fa, NoSide{});
         }
-        if (a.wideFlat) hipLaunchKernelGGL(k_cull_flat_wide, dim3(std::min(std::max(1u, p->scene.activeDrawCount), 4096u)), dim3(1024), 0, s, a, buckets);
-        if (levelKernels && !spillMode) hipLaunchKernelGGL(k_cull_instances, dim3(grid_for(p->scene.activeDrawCount, 256, maxBlocks)), dim3(256), 0, s, a, fa);
+        if (a.wideFlat && !flatLevels) hipLaunchKernelGGL(k_cull_flat_wide, dim3(std::min(std::max(1u, p->scene.activeDrawCount), 4096u)), dim3(1024), 0, s, a, buckets);
+        if (levelKernels && !spillMode && !flatLevels) hipLaunchKernelGGL(k_cull_instances, dim3(grid_for(p->scene.activeDrawCount, 256, maxBlocks)), dim3(256), 0, s, a, fa);
         BRMI_LAUNCH_CHECK(p, "k_cull_instances");
     } else {
         // brmi_execute seeds in the tail of the depth-chain build that precedes this call (one launch less)
@@ -1488,14 +1679,22 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
     const uint32_t levelLaunches = spillMode ? std::min(p->maxLevels, std::max(1u, p->spillLevels)) : p->maxLevels;
     // (phase 1 of a scene whose every hierarchy is evaluated flat leaves nothing for the level kernels)
     const bool flatCoversPhase1 = phase == 1 && hierarchy && spillMode && p->allMeshesFlat && a.wideFlat != 0u && !p->forceLevelKernels;
-    for (uint32_t level = 0; level < levelLaunches && levelKernels && !flatCoversPhase1; level++) {
+    for (uint32_t level = 0; level < levelLaunches && levelKernels && !flatCoversPhase1 && !flatLevels; level++) {
         // without the walk in front (forced level kernels) phase 2 reads level 0 from the replay buffer; then ping-pong like phase 1 (level 0 writes fb)
         const NodeRecord* in = level == 0 ? ((phase == 1 || spillMode) ? fa : a.replayNodes) : ((level & 1u) ? fb : fa);
         hipLaunchKernelGGL(k_traverse, dim3(travGrid), dim3(256), 0, s, a, level, in, (level & 1u) ? fa : fb, buckets);
         BRMI_LAUNCH_CHECK(p, "k_traverse");
     }
     // grid-stride kernels that usually find little to do: a few hundred workgroups retire in ~3 us, a thousand in ~6
-    const uint32_t smallGrid = phase == 1 ? 512u : 128u;
+    // Frames of hundreds of thousands of records (Zorah-class: 180 k bucket records, 490 k survivors) need more than that: a lane's chain of dependent loads
+    // (record -> page header -> descriptor -> instance -> object -> depth chain) three or four times over was most of both kernels.  The counts of the frames
+    // before (host-mapped words the kernels write; read without waiting, any value is safe: the kernels stride their grids) size the launches.
+    uint32_t smallGrid = phase == 1 ? 512u : 128u, scatterGrid = smallGrid;
+    if (phase == 1 && p->phase2FeedbackHost) {
+        const uint32_t lastBuckets = reinterpret_cast<volatile uint32_t*>(p->phase2FeedbackHost)[2], lastVisible = reinterpret_cast<volatile uint32_t*>(p->phase2FeedbackHost)[3];
+        smallGrid = std::max(smallGrid, grid_for((uint64_t)std::min(lastBuckets, p->cfg.maxTraversalRecords) * f, 256, 8192));
+        scatterGrid = std::max(scatterGrid, grid_for(std::min(lastVisible, p->cfg.maxVisibleClusters), 256, 8192));
+    }
     if (lightGridRides) {
         hipLaunchKernelGGL(k_cull_clusters<1>, dim3(smallGrid + (p->numLightClusters + 3u) / 4u), dim3(256), 0, s, a, buckets, temp, bitmask, LcRide{smallGrid, cluster_args_of(p)});
         p->lightGridDone = true;
@@ -1512,7 +1711,7 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
     // from 8 k words on the three scan launches are faster (dense frame, 25 k words: 27 us against 55 us per phase)
     // phase 2: the ranking kernel also tells the host how many clusters it placed (launch_raster's hint for the frames that follow)
     if (phase == 2 && p->phase2DirectMax != 0u) (void)p->ensureFeedback();
-    uint32_t* feedback = phase == 2 ? p->phase2FeedbackDev : nullptr;
+    uint32_t* feedback = phase == 2 ? p->phase2FeedbackDev : (p->phase2FeedbackDev ? p->phase2FeedbackDev + 3 : nullptr);      // (phase 1: word 3, the sizes of the next frames' launches)
     const bool localRank = p->totalWords <= LOCAL_RANK_WORDS && !p->forceLevelKernels;
     if (localRank) {
         // ranked inside the scatter kernel
@@ -1528,7 +1727,7 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
         }
     }
     auto scatter = [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, dim3(smallGrid), dim3(256), 0, s, temp, p->counters(), (uint32_t)(phase == 1 ? CNT_TEMP_VISIBLE : CNT_TEMP_VISIBLE2), bitmask, wordPrefix,
+        hipLaunchKernelGGL(kernel, dim3(scatterGrid), dim3(256), 0, s, temp, p->counters(), (uint32_t)(phase == 1 ? CNT_TEMP_VISIBLE : CNT_TEMP_VISIBLE2), bitmask, wordPrefix,
                            static_cast<uint4*>(p->res[BRMI_RES_VISIBLE_CLUSTERS]), phase == 1 ? 0xFFFFFFFFu : (uint32_t)CNT_VISIBLE, p->cfg.maxVisibleClusters, p->cfg.maxVisibleClusters, p->scene, p->wsPtr<ClusterSetup>(p->ws.clusterSetup), p->resolveCapacity, p->wsPtr<uint8_t>(p->ws.usedClusters),
                            (p->sceneHasTextures || p->sceneHasAlphaTest || p->sceneHasVertexColors) ? p->wsPtr<ClusterUv>(p->ws.clusterUv) : nullptr, LocalRank{p->totalWords, outIndex, usedIndex, feedback});
     };

@@ -26,8 +26,9 @@ enum CounterIndex : uint32_t {
     CNT_NODES_VISITED,
     CNT_MESHLETS_TESTED,
     CNT_LIGHT_PAGES,
-    CNT_SUM_VERTS_LO = 14, CNT_SUM_VERTS_HI,     // sum of vertex counts of rasterised clusters (u64)
-    CNT_SUM_TRIS_LO, CNT_SUM_TRIS_HI,
+    CNT_SUM_VERTS_LO = 14, CNT_SUM_VERTS_HI,     // ONE 64-bit word: sum of the vertex counts of the rasterised clusters (low half) | of their triangle counts (high half): one atomic
+                                                 // reserves both runs of the resolve arena (<= 30 M clusters x 128 fits 32 bits)
+    CNT_SUM_TRIS_LO, CNT_SUM_TRIS_HI,            // (unused since round 5)
     CNT_RASTER_CLUSTERS,
     CNT_BIN_OVERFLOW,         // raster records that found their screen bin full (rasterised in place with global atomics)
     CNT_DEFERRED_PIXELS_B,    // second deferred-pixel counter: shading calls alternate, each clears the other one for the next call
@@ -77,7 +78,7 @@ struct FlatNode {                                                               
     uint32_t segFirstCount;     // leaf: firstMeshletInPage | meshletCount << 16
     uint32_t pageMapIndex;      // leaf: absolute index of the segment's page-map entry
     uint32_t firstBitRel;       // leaf: the segment's first bit relative to the instance's
-    uint32_t pad;
+    uint32_t children;          // internal: position of the first child | child count << 16 (breadth-first: a node's children sit side by side)
 };
 struct FlatLeaf { float group[4], child[4]; float childParentError, pad[3]; };      // 48 B: the leaf's group sphere, its refined group's sphere and error
 struct InstanceWalk { uint32_t flatBase, flatCount /* 0: the level walk */, bitBase, skinned; };                                    // 16 B per mesh instance
@@ -182,6 +183,7 @@ struct brmi_pass {
         if (phase2FeedbackHost) return true;
         if (hipHostMalloc(reinterpret_cast<void**>(&phase2FeedbackHost), 64, hipHostMallocMapped) != hipSuccess) { phase2FeedbackHost = nullptr; return false; }
         phase2FeedbackHost[0] = 0xFFFFFFFFu; phase2FeedbackHost[1] = 1u;           // unknown: the general paths
+        for (int k = 2; k < 16; k++) phase2FeedbackHost[k] = 0u;                  // word 2: phase 1's bucket records, word 3: phase 1's visible clusters (launch sizes of the frames that follow)
         if (hipHostGetDevicePointer(reinterpret_cast<void**>(&phase2FeedbackDev), phase2FeedbackHost, 0) != hipSuccess) { (void)hipHostFree(phase2FeedbackHost); phase2FeedbackHost = nullptr; phase2FeedbackDev = nullptr; return false; }
         return true;
     }
@@ -192,6 +194,8 @@ struct brmi_pass {
     bool frameWaitsIssued = false;   // brmi_execute_split has issued this frame's cross-stream waits (the stage entry points it calls skip theirs)
     bool wideFlat = true;            // BRMI_FLAT_WIDE=0: hierarchies of more than 256 nodes take the level walk
     bool anyWideFlat = false, allMeshesFlat = false;      // brmi_set_scene: some mesh has 257 .. 8192 nodes / every mesh has flat tables
+    uint32_t flatMaxDepth = 1;       // levels of the deepest flat hierarchy (launches of the level-synchronous flat traversal, brmi_cull.hip: k_cull_flat_level)
+    uint32_t flatLevelsMinDraws = 16384;   // BRMI_FLAT_LEVELS_MIN_DRAWS: scenes with at least this many draws (all hierarchies flat) take the level-synchronous flat traversal in phase 1
     bool scanChained = true; uint32_t scanEpoch = 0;      // the survivor ranking as one launch (BRMI_SCAN_CHAINED=0: three)
     bool packedFlat = true;          // BRMI_FLAT_PACKED=0: one draw per wave of the traversal
     uint32_t shadeGridShared = 10240; // workgroups of k_shade<0, 3> (BRMI_SHADE_GRID_SHARED): shorter-lived than the stand-alone 8192 so that the other frame's small geometry launches find slots sooner (Bistro-class period 6144 / 8192 / 10240 / 12288: 0.547 / 0.539 / 0.530 / 0.531 ms; Sponza-class, whose geometry half is short: 0.386 / 0.398 / 0.398 / 0.397)

@@ -59,7 +59,7 @@ BRMI_DEV f3 oct_decode_normal(uint32_t packed) {
 // device from the counters) this pass marks the clusters that own at least one pixel, and the setup kernel skips the rest.
 __global__ void __launch_bounds__(256) k_mark_used_clusters(GBufferArgs a, uint8_t* used, uint32_t* counters) {
     const uint32_t clusterCount = min(a.counters[CNT_VISIBLE] + a.counters[CNT_VISIBLE2], a.clusterCapacity);
-    const uint64_t tris = ((uint64_t)a.counters[CNT_SUM_TRIS_HI] << 32) | a.counters[CNT_SUM_TRIS_LO];
+    const uint64_t tris = (uint64_t)a.counters[CNT_SUM_VERTS_HI];
     if (tris * 2ull <= a.pixelCount) return;                 // wave-uniform: few triangles per pixel, set up everything
     if (blockIdx.x == 0 && threadIdx.x == 0) counters[CNT_RESOLVE_MARKED] = 1u;
     const uint64_t end = (a.pixelCount + 63ull) & ~63ull;
@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(64) k_resolve_setup(GBufferArgs a) {
     const uint32_t clusterCount = a.setupPart == 1u ? min(a.counters[CNT_VISIBLE], a.clusterCapacity) : min(a.counters[CNT_VISIBLE] + a.counters[CNT_VISIBLE2], a.clusterCapacity);
     const bool marked = a.setupPart == 0u && a.counters[CNT_RESOLVE_MARKED] != 0u;
     if (blockIdx.x == 0u && lane == 0u && a.hostFeedback && a.setupPart != 1u) {      // tell the host whether frames like this one need the marking pass (its hint for the next frames)
-        const uint64_t tris = ((uint64_t)a.counters[CNT_SUM_TRIS_HI] << 32) | a.counters[CNT_SUM_TRIS_LO];
+        const uint64_t tris = (uint64_t)a.counters[CNT_SUM_VERTS_HI];
         __hip_atomic_store(a.hostFeedback + 1, tris * 2ull > a.pixelCount ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     for (uint32_t c = firstCluster + blockIdx.x; c < clusterCount; c += gridDim.x) {

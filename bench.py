@@ -39,10 +39,14 @@ WORKLOADS = {"sponza": ("sponza", {}, 0),
              "bistro": ("bistro", dict(unique_budget=True, lod_builder="own", relief_slope=1.5), 0),
              "bistro_r2": ("bistro", {}, 0),
              "san_miguel": ("san_miguel", {}, 24),
-             "bistro_dense": ("bistro", dict(size_scale=20.0, detail=96.0), 0)}
-LIGHTS = {"sponza": 64, "bistro": 256, "bistro_r2": 256, "san_miguel": 256, "bistro_dense": 256}
+             "bistro_dense": ("bistro", dict(size_scale=20.0, detail=96.0), 0),
+             # zorah       configs[4] on ONE GPU: 8K, 100 k instances of two 459 k-triangle meshes (39 G instanced triangles), 1 % of the instances skinned;
+             #             ~670 k visible clusters out of ~1 M meshlets tested -- the LOD-select / traversal regime the reference is built for (README.md:11)
+             "zorah": ("zorah", dict(skinned_fraction=0.01), 0)}
+LIGHTS = {"sponza": 64, "bistro": 256, "bistro_r2": 256, "san_miguel": 256, "bistro_dense": 256, "zorah": 64}
+FRAME_SIZE = {"zorah": (7680, 4320)}      # N = 1 frame of a workload that is not the 4K one
 BASELINE_CONFIG = {"sponza": "configs[1]", "bistro": "configs[2]", "bistro_r2": "configs[2], the instanced-budget frame of rounds 1-2", "san_miguel": "configs[3]",
-                   "bistro_dense": "configs[2], dense geometry"}
+                   "bistro_dense": "configs[2], dense geometry", "zorah": "configs[4] on one GPU"}
 PATH_STEP = float(os.environ.get("BRMI_BENCH_PATH_STEP", "0.02"))        # --camera-path: position on the preset's camera path advances by this much per frame (one unit = 0.35 m sideways, 0.6 m ahead, 4 degrees)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md)
 VALU_PEAK_WAVE_INSTS = 1.2288e12   # wave64 VALU instructions per second: 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles (MI355X_MICROARCH.md, cycle constants)
@@ -52,7 +56,7 @@ VALU_PEAK_WAVE_INSTS = 1.2288e12   # wave64 VALU instructions per second: 256 CU
 VALU_PEAK_MEASURED = 0.96e12
 # profiles/<tag>_traffic.json (tools/profile.sh), keyed by (workload, material feature bits): traffic of another configuration is not this one's
 PROFILE_TAG = {("sponza", 0): "r04_sponza4k", ("bistro", 0): "r04_bistro4k", ("bistro_r2", 0): "r02_bistro4k", ("san_miguel", 0): "r02_sanmiguel4k", ("bistro_dense", 0): "r04_bistro4k_dense",
-               ("san_miguel", 24): "r04_sanmiguel4k", ("sponza", 136): "r02_sponza4k_parallax"}
+               ("san_miguel", 24): "r04_sanmiguel4k", ("zorah", 0): "r05_zorah8k", ("sponza", 136): "r02_sponza4k_parallax"}
 PROFILE_FALLBACK = {"r04_sponza4k": "r03_sponza4k", "r04_bistro4k": "r03_bistro4k", "r04_bistro4k_dense": "r03_bistro4k_dense", "r04_sanmiguel4k": "r03_sanmiguel4k"}      # until the round's profiles are committed
 _STREAM_CACHE = {}
 DOMINANT_KERNEL = {"raster": "k_raster", "gbuffer": "k_gbuffer", "shade": "k_shade", "cull": "k_traverse+k_cull_clusters", "clear": "k_clear_vis",
@@ -72,6 +76,8 @@ def main():
     ap.add_argument("--no-dense", action="store_true", help="N = 1 only: do not add the dense-geometry measurement (bistro_dense) as `dense` to the line")
     ap.add_argument("--no-third", action="store_true", help="N = 1 only: do not add the configs[3] measurement (San-Miguel-class frame, 30 %% alpha-tested and texture-sampled materials, "
                                                              "one GPU) as `configs3` to the line")
+    ap.add_argument("--no-fourth", action="store_true", help="N = 1 only: do not add the configs[4] measurement (Zorah-class 8K frame: 100 k instances, 1 %% skinned, ~670 k visible "
+                                                              "clusters, one GPU) as `configs4` to the line")
     ap.add_argument("--camera-path-fast", type=float, default=0.1,
                     help="N = 1 only: path units per frame of a second, faster camera-path leg (`path_fast`: hundreds of phase-2 clusters per frame); 0 skips it")
     ap.add_argument("--camera-path", type=int, default=200,
@@ -170,6 +176,11 @@ def main():
         dense = measure(args, "bistro_dense", world, rank, local_rank, cpu=False, path=False)
         if out is not None:
             out["dense"] = {k: dense[k] for k in ("value", "unit", "ms_per_step", "ms_per_step_minmax", "config", "roofline", "stage_ms", "serial_frame_ms") if k in dense}
+    if world == 1 and not args.no_fourth and args.workload != "zorah":
+        # configs[4]'s frame on one GPU: 8K, 100 k instances, ~670 k visible clusters -- the LOD-select regime (rows a-2 / a-3 / a-10) under the same clock
+        fourth = measure(args, "zorah", world, rank, local_rank, cpu=False, path=False)
+        if out is not None:
+            out["configs4"] = {k: fourth[k] for k in ("value", "unit", "ms_per_step", "ms_per_step_minmax", "config", "roofline", "stage_ms", "serial_frame_ms") if k in fourth}
     result_line = json.dumps(out) if out is not None else None
     if world > 1 or args.force_compose:
         # RCCL writes a version banner to the C stdout buffer; pushed out here, on every rank, so that rank 0's JSON is the last line
@@ -199,6 +210,8 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False)
     multi = n > 1 and not emulated          # a process group exists
     striped = n > 1 and args.partition == "stripes"
     W, H = compose.frame_size(n, args.partition)
+    if n == 1 and workload in FRAME_SIZE:
+        W, H = FRAME_SIZE[workload]
     if striped:
         compose.stripe_frame_rows(rank, n, H, args.stripe_rows)      # (raises on a chunk height that does not fit)
         band = (0, H // n)                                             # the rank's compact surfaces hold its rows only: the composer takes all of them
@@ -415,7 +428,7 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False)
             pass
         hbm_frac = achieved / HBM_PEAK_GBS
         out = {
-            "metric": "shaded Mpixels/s @4K (vis-buffer+resolve)", "value": round(value, 2), "unit": "Mpixels/s",
+            "metric": "shaded Mpixels/s @4K (vis-buffer+resolve)" if (W, H) not in FRAME_SIZE.values() else f"shaded Mpixels/s @{W}x{H} (vis-buffer+resolve)", "value": round(value, 2), "unit": "Mpixels/s",
             "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "repeats": repeats, "ms_per_step_minmax": [round(min(regions) / args.steps * 1e3, 4), round(max(regions) / args.steps * 1e3, 4)],
             "host_issue_ms_per_step": round(sorted(issue_s)[len(issue_s) // 2] / args.steps * 1e3, 4),      # the host thread's time to issue a frame's launches (it runs ahead of the GPU when this is below ms_per_step)

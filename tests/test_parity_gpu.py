@@ -1408,15 +1408,17 @@ def test_flat_and_level_traversal_agree(name, scenes, oracle_frames):
     from basicrenderer_amd.renderer import VisibilityRenderer
     o = oracle_frames(name)
     seen = []
-    for flat, packed in ((1, 1), (1, 0), (0, 0)):      # flat with eight draws to a wave (hierarchies of <= 8 nodes), flat with one draw per wave, the level walk
-        with _Env(BRMI_FLAT_TRAVERSAL=flat, BRMI_FLAT_PACKED=packed):
+    # flat with eight draws to a wave (hierarchies of <= 8 nodes), flat with one draw per wave, the level walk, and -- round 5 -- the level-synchronous
+    # flat traversal scenes of >= 16 k draws take (k_cull_flat_level: a lane per (instance, node) task, one launch per level), forced for every scene
+    for flat, packed, levels in ((1, 1, 1 << 30), (1, 0, 1 << 30), (0, 0, 1 << 30), (1, 1, 1)):
+        with _Env(BRMI_FLAT_TRAVERSAL=flat, BRMI_FLAT_PACKED=packed, BRMI_FLAT_LEVELS_MIN_DRAWS=levels):
             r = VisibilityRenderer(scenes(name), stats=True)
         r.execute()
         c = r.counters()
         assert np.array_equal(r.visible_clusters(), o.clusters[: o.count])
         seen.append((c.instancesTested, c.instancesVisible, c.nodesVisited, c.meshletsTested, c.visibleClusters))
         r.close()
-        with _Env(BRMI_FLAT_TRAVERSAL=flat, BRMI_FLAT_PACKED=packed):
+        with _Env(BRMI_FLAT_TRAVERSAL=flat, BRMI_FLAT_PACKED=packed, BRMI_FLAT_LEVELS_MIN_DRAWS=levels):
             r = VisibilityRenderer(scenes(name), stats=True, occlusion=True)
         r.execute(); r.execute()
         c = r.counters()
@@ -1425,7 +1427,7 @@ def test_flat_and_level_traversal_agree(name, scenes, oracle_frames):
         for got, want in zip(orc.canonical_ids(r.visibility(), r.visible_clusters()), orc.canonical_ids(o.vis, o.clusters[: o.count])):
             assert np.array_equal(got, want)
         r.close()
-    assert seen[0] == seen[2] == seen[4] and seen[1] == seen[3] == seen[5], seen
+    assert seen[0] == seen[2] == seen[4] == seen[6] and seen[1] == seen[3] == seen[5] == seen[7], seen
 
 
 @pytest.mark.parametrize("name", ["sponza_small", "bistro_small", "tiny_lod", "tiny_skinned"])
