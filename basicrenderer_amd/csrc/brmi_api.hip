@@ -92,6 +92,7 @@ static void compute_sizes(brmi_pass* p) {
     w.counters = take((uint64_t)(CNT_WORDS + 64) * 4);
     w.bitmask1 = take((uint64_t)p->totalWords * 4);
     w.bitmask2 = take((uint64_t)p->totalWords * 4);
+    w.blockDirty = take((uint64_t)2 * (p->scanBlocks + 1));      // per phase and 2048-word block of the bitmask: some survivor set a bit there (the ranking skips the others)
     w.frameClearBytes = off - w.counters;
     w.usedClusters = take((uint64_t)c.maxVisibleClusters);     // one byte per visible cluster, zeroed by the compaction kernel
     w.frontierA = take((uint64_t)c.maxTraversalRecords * sizeof(NodeRecord));

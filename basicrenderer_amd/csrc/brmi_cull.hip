@@ -1203,7 +1203,7 @@ struct LcRide { uint32_t mainBlocks; ClusterArgs lc; };
 // frame runs on the shading stream (brmi_execute_split).
 struct ClearRide { uint32_t mainBlocks; ulonglong2* vis2; uint64_t n2; uint32_t clearBlocks; };
 template <int SIDE>
-__global__ void __launch_bounds__(256) k_cull_clusters(CullArgs a, const BucketRecord* buckets, TempVisible* temp, uint32_t* bitmask,
+__global__ void __launch_bounds__(256) k_cull_clusters(CullArgs a, const BucketRecord* buckets, TempVisible* temp, uint32_t* bitmask, uint8_t* blockDirty,
                                                        typename std::conditional<SIDE == 1, LcRide, typename std::conditional<SIDE == 2, ClearRide, NoSide>::type>::type ride) {
     wave_prio<PRIO_CULL>();
     uint32_t mainBlocks = gridDim.x;
@@ -1221,7 +1221,7 @@ __global__ void __launch_bounds__(256) k_cull_clusters(CullArgs a, const BucketR
     }
     const brmi_scene_buffers& sc = a.sc;
     const uint32_t bucketCount = min(a.counters[a.bucketCounter], a.recordCapacity);
-    if (a.feedback && a.phase == 1u && blockIdx.x == 0u && threadIdx.x == 0u) __hip_atomic_store(a.feedback + 2, bucketCount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (a.feedback && blockIdx.x == 0u && threadIdx.x == 0u) __hip_atomic_store(a.feedback + (a.phase == 1u ? 2 : 4), bucketCount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const uint32_t viewId = sc.perFrame->mainCameraIndex;
     const brmi_camera* cam = sc.cameras + viewId;
     const brmi_culling_camera* lodCam = sc.cullingCameras + viewId;
@@ -1316,6 +1316,7 @@ __global__ void __launch_bounds__(256) k_cull_clusters(CullArgs a, const BucketR
                 TempVisible t; t.packed = packed; t.bit = bit; t.pad0 = t.pad1 = t.pad2 = 0;
                 temp[slot] = t;
                 atomicOr(&bitmask[bit >> 5], 1u << (bit & 31u));
+                blockDirty[bit >> 16] = 1;        // (the bit's 2048-word block of the ranking; every writer stores 1)
             } else atomicAdd(&a.counters[CNT_DROPPED_CLUSTERS], 1u);
         }
     }
@@ -1324,8 +1325,11 @@ __global__ void __launch_bounds__(256) k_cull_clusters(CullArgs a, const BucketR
 // rank = exclusive popcount scan over the bitmask ----------------------------------------------
 constexpr uint32_t SCAN_BLOCK_WORDS = 2048;   // words per workgroup (256 threads x 8)
 
-__global__ void __launch_bounds__(256) k_scan_reduce(const uint32_t* bitmask, uint32_t totalWords, uint32_t* blockSums) {
+// blockDirty: a block no survivor set a bit in sums to zero unread and needs no word prefixes (nobody asks for the rank of a bit that is not set): phase 2
+// of a Zorah-class frame places a hundred clusters in a bitmask of 12.8 M words.
+__global__ void __launch_bounds__(256) k_scan_reduce(const uint32_t* bitmask, uint32_t totalWords, uint32_t* blockSums, const uint8_t* blockDirty) {
     __shared__ uint32_t partial[4];
+    if (blockDirty[blockIdx.x] == 0) { if (threadIdx.x == 0) blockSums[blockIdx.x] = 0u; return; }
     const uint32_t base = blockIdx.x * SCAN_BLOCK_WORDS;
     uint32_t s = 0;
     for (uint32_t i = threadIdx.x; i < SCAN_BLOCK_WORDS; i += 256) { const uint32_t w = base + i; if (w < totalWords) s += __popc(bitmask[w]); }
@@ -1365,9 +1369,10 @@ __global__ void __launch_bounds__(1024) k_scan_blocks(uint32_t* blockSums, uint3
     }
 }
 
-__global__ void __launch_bounds__(256) k_scan_words(const uint32_t* bitmask, uint32_t totalWords, const uint32_t* blockSums, uint32_t* wordPrefix) {
+__global__ void __launch_bounds__(256) k_scan_words(const uint32_t* bitmask, uint32_t totalWords, const uint32_t* blockSums, uint32_t* wordPrefix, const uint8_t* blockDirty) {
     __shared__ uint32_t waveTotals[4];
     __shared__ uint32_t carry;
+    if (blockDirty[blockIdx.x] == 0) return;
     if (threadIdx.x == 0) carry = blockSums[blockIdx.x];
     __syncthreads();
     const uint32_t base = blockIdx.x * SCAN_BLOCK_WORDS;
@@ -1611,6 +1616,7 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
     BucketRecord* buckets = phase == 1 ? p->wsPtr<BucketRecord>(p->ws.buckets) : a.replayBuckets;
     TempVisible* temp = p->wsPtr<TempVisible>(p->ws.tempVisible);
     uint32_t* bitmask = p->wsPtr<uint32_t>(phase == 1 ? p->ws.bitmask1 : p->ws.bitmask2);
+    uint8_t* blockDirty = p->wsPtr<uint8_t>(p->ws.blockDirty) + (phase == 1 ? 0u : p->scanBlocks + 1u);
     uint32_t* wordPrefix = p->wsPtr<uint32_t>(p->ws.wordPrefix); uint32_t* blockSums = p->wsPtr<uint32_t>(p->ws.blockSums);
 
     const uint32_t maxBlocks = 1024;
@@ -1690,20 +1696,21 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
     // (record -> page header -> descriptor -> instance -> object -> depth chain) three or four times over was most of both kernels.  The counts of the frames
     // before (host-mapped words the kernels write; read without waiting, any value is safe: the kernels stride their grids) size the launches.
     uint32_t smallGrid = phase == 1 ? 512u : 128u, scatterGrid = smallGrid;
-    if (phase == 1 && p->phase2FeedbackHost) {
-        const uint32_t lastBuckets = reinterpret_cast<volatile uint32_t*>(p->phase2FeedbackHost)[2], lastVisible = reinterpret_cast<volatile uint32_t*>(p->phase2FeedbackHost)[3];
-        smallGrid = std::max(smallGrid, grid_for((uint64_t)std::min(lastBuckets, p->cfg.maxTraversalRecords) * f, 256, 8192));
-        scatterGrid = std::max(scatterGrid, grid_for(std::min(lastVisible, p->cfg.maxVisibleClusters), 256, 8192));
+    if (p->phase2FeedbackHost) {
+        const uint32_t lastBuckets = reinterpret_cast<volatile uint32_t*>(p->phase2FeedbackHost)[phase == 1 ? 2 : 4];
+        const uint32_t lastVisible = reinterpret_cast<volatile uint32_t*>(p->phase2FeedbackHost)[phase == 1 ? 3 : 0];      // (0xFFFFFFFF = unknown is clamped below)
+        smallGrid = std::max(smallGrid, grid_for((uint64_t)std::min<uint32_t>(lastBuckets, p->cfg.maxTraversalRecords) * f, 256, 8192));
+        scatterGrid = std::max(scatterGrid, grid_for(std::min<uint32_t>(lastVisible, p->cfg.maxVisibleClusters), 256, 8192));
     }
     if (lightGridRides) {
-        hipLaunchKernelGGL(k_cull_clusters<1>, dim3(smallGrid + (p->numLightClusters + 3u) / 4u), dim3(256), 0, s, a, buckets, temp, bitmask, LcRide{smallGrid, cluster_args_of(p)});
+        hipLaunchKernelGGL(k_cull_clusters<1>, dim3(smallGrid + (p->numLightClusters + 3u) / 4u), dim3(256), 0, s, a, buckets, temp, bitmask, blockDirty, LcRide{smallGrid, cluster_args_of(p)});
         p->lightGridDone = true;
     } else if (phase == 1 && p->clearVisibilityWithClusterCull) {
         const uint32_t clearBlocks = 2048;
-        hipLaunchKernelGGL(k_cull_clusters<2>, dim3(smallGrid + clearBlocks), dim3(256), 0, s, a, buckets, temp, bitmask,
+        hipLaunchKernelGGL(k_cull_clusters<2>, dim3(smallGrid + clearBlocks), dim3(256), 0, s, a, buckets, temp, bitmask, blockDirty,
                            ClearRide{smallGrid, reinterpret_cast<ulonglong2*>(static_cast<unsigned long long*>(p->res[BRMI_RES_VISIBILITY]) + p->bandFirstPixel), p->bandPixelCount >> 1, clearBlocks});
         p->clearVisibilityWithClusterCull = false;
-    } else hipLaunchKernelGGL(k_cull_clusters<0>, dim3(smallGrid), dim3(256), 0, s, a, buckets, temp, bitmask, NoSide{});
+    } else hipLaunchKernelGGL(k_cull_clusters<0>, dim3(smallGrid), dim3(256), 0, s, a, buckets, temp, bitmask, blockDirty, NoSide{});
     BRMI_LAUNCH_CHECK(p, "k_cull_clusters");
     // phase 2 appends behind the phase-1 clusters: its capacity is what phase 1 left
     const uint32_t outIndex = phase == 1 ? CNT_VISIBLE : CNT_VISIBLE2, usedIndex = phase == 1 ? 0xFFFFFFFFu : (uint32_t)CNT_VISIBLE;
@@ -1721,9 +1728,9 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
             hipLaunchKernelGGL(k_scan_chained, dim3(p->scanBlocks), dim3(256), 0, s, bitmask, p->totalWords, p->wsPtr<unsigned long long>(p->ws.scanAgg), p->scanEpoch, wordPrefix,
                                p->counters(), outIndex, p->cfg.maxVisibleClusters, usedIndex, feedback);
         } else {
-            hipLaunchKernelGGL(k_scan_reduce, dim3(p->scanBlocks), dim3(256), 0, s, bitmask, p->totalWords, blockSums);
+            hipLaunchKernelGGL(k_scan_reduce, dim3(p->scanBlocks), dim3(256), 0, s, bitmask, p->totalWords, blockSums, blockDirty);
             hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, blockSums, p->scanBlocks, p->counters(), outIndex, p->cfg.maxVisibleClusters, usedIndex, feedback);
-            hipLaunchKernelGGL(k_scan_words, dim3(p->scanBlocks), dim3(256), 0, s, bitmask, p->totalWords, blockSums, wordPrefix);
+            hipLaunchKernelGGL(k_scan_words, dim3(p->scanBlocks), dim3(256), 0, s, bitmask, p->totalWords, blockSums, wordPrefix, blockDirty);
         }
     }
     auto scatter = [&](auto kernel) {

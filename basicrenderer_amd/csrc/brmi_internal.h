@@ -143,7 +143,7 @@ struct FrameSnapshot { brmi_per_frame perFrame; brmi_camera camera; };
 struct LayerUniform { unsigned long long coatWord, fuzzWord, coatFilledWord, fuzzFilledWord; uint32_t coatUniform, fuzzUniform, coatFilled, fuzzFilled; };
 
 struct Workspace {     // byte offsets into BRMI_RES_WORKSPACE
-    uint64_t counters, frontierA, frontierB, buckets, tempVisible, bitmask1, bitmask2, wordPrefix, blockSums,
+    uint64_t counters, frontierA, frontierB, buckets, tempVisible, bitmask1, bitmask2, blockDirty, wordPrefix, blockSums,
              instanceBitBase, segPrefix, meshLevelWidth, scanAgg, flatNodes, flatLeaves, instanceWalk, planes, replayNodes, replayBuckets, lightVS, lightMeta, clusterPages, clusterHits, pageTotal, lightHitMasks, binCounts, binRecords, binOverflow, binPlan, binItems, binScratch, clusterSetup, resolveVerts, resolveTris, matWords, shadeTables, lutF, frameConst, objConst, matConst, deferredPixels, usedClusters,
              frameSnapshot, tileCounts, tileLists, tileOverflow, xverts, debugStamps, clusterUv, binAlpha, overflowAlpha, resolveUVs, resolveColors, alphaMats, shadeRows, shadeAvgs, ggxQuads, shadeLights, clusterList, listEntries, listRecords, layerUniform, frameClearBytes, total;
 };
