@@ -159,7 +159,7 @@ static void compute_sizes(brmi_pass* p) {
     p->deferredStripeCapacity = (uint32_t)(((p->bandPixelCount / 4096 + CNT_STRIPE_COUNT) / CNT_STRIPE_COUNT) * 4096);   // 64-tile runs of a stripe x 4096 pixels
     w.deferredPixels = take((uint64_t)3 * CNT_STRIPE_COUNT * p->deferredStripeCapacity * 4);      // one set of striped lists per layered class
     w.lutF = take((uint64_t)(32768 + 1024 + 1024 + 32 + 256) * 4);
-    w.shadeRows = take((uint64_t)std::max(1u, p->scene.openpbrMaterialCount) * 256 * 256);    // (OpenPBR material, roughness code) -> folded energy-table rows of the shading pass
+    w.shadeRows = take((uint64_t)std::max(1u, p->scene.openpbrMaterialCount) * 256 * 512);    // (OpenPBR material, roughness code) -> folded energy-table rows of the shading pass
     w.shadeAvgs = take((uint64_t)std::max(1u, p->scene.openpbrMaterialCount) * 256 * 8);
     w.ggxQuads = take(256 * 48);                                                                  // roughness code -> the GGX albedo fit as quadratics in N.V
     w.shadeLights = take((uint64_t)std::max(1u, p->scene.lightCount) * 64);                     // the shading pass's 64 B record per active light

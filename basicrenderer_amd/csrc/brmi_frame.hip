@@ -157,7 +157,12 @@ BRMI_DEV MatConst material_constants_of(const brmi_openpbr_material_info* op) {
     m.weightedSpecularIor = (1.0f + sq) / max2(1.0f - sq, 1.0e-4f);
     m.dielF0Scalar = ior_to_f0(m.weightedSpecularIor);
     m.coatF0Scalar = ior_to_f0(op->coatIor);
-    m.coatIor = op->coatIor; m.coatDarkening = sat(op->coatDarkening); m.baseDiffuseRoughness = sat(op->baseDiffuseRoughness); m.pad = 0.0f;
+    m.coatIor = op->coatIor; m.coatDarkening = sat(op->coatDarkening); m.baseDiffuseRoughness = sat(op->baseDiffuseRoughness);
+    {   // the pixel's own expressions (brmi_shade.h, PopulateFragmentInfoFromOpenPBR + EvaluateOpenPBRBaseLayerDirect), evaluated once per material
+        const f3 F0 = satq3(f3{m.specR, m.specG, m.specB} * m.dielF0Scalar);
+        const float tmp = 50.0f * 0.33f;
+        m.dielF0[0] = F0.x; m.dielF0[1] = F0.y; m.dielF0[2] = F0.z; m.f90Diel = satq(dot3(F0, f3{tmp, tmp, tmp}));
+    }
     {   // OpenPBRDiffuseEON, the part that only depends on the material's diffuse roughness (IBL.hlsli:94-131)
         const float rough = m.baseDiffuseRoughness;
         const float A = qrcp(1.0f + fon_a() * rough);
@@ -168,7 +173,6 @@ BRMI_DEV MatConst material_constants_of(const brmi_openpbr_material_info* op) {
         m.eonAvgE = A * (1.0f + fon_b() * rough);
         m.eonOneMinusAvgE = 1.0f - m.eonAvgE;
         m.eonInvDen = qrcp(max2(1.0e-4f, 1.0f - m.eonAvgE));
-        m.pad2[0] = m.pad2[1] = m.pad2[2] = 0.0f;
     }
     return m;
 }

@@ -107,10 +107,11 @@ constexpr uint32_t BRMI_CS_ALPHA = 1u << 28, BRMI_CS_TEXTURED = 1u << 29, BRMI_C
 struct AxisEntry { float uv; uint32_t tile; };       // per column / row: (i + 0.5) / res and the light-cluster tile index
 struct ShadeTables { AxisEntry* x; AxisEntry* y; float* sliceStart; };
 struct MatConst {
-    float baseWeight, specularWeight, specR, specG, specB, weightedSpecularIor, dielF0Scalar, coatF0Scalar, coatIor, coatDarkening, baseDiffuseRoughness, pad;
+    float baseWeight, specularWeight, specR, specG, specB, weightedSpecularIor, dielF0Scalar, coatF0Scalar, coatIor, coatDarkening, baseDiffuseRoughness, f90Diel;
     // OpenPBRDiffuseEON with the material's diffuse roughness folded in (tolerance-level re-association, brmi_light.hip):
     // fon_dir_albedo(mu) = fonA + mc (fonK[0] + mc (fonK[1] + mc (fonK[2] + mc fonK[3]))), mc = 1 - mu
-    float fonA, fonK[4], eonSingleScale /* A / pi */, eonAvgE, eonOneMinusAvgE, eonInvDen /* 1 / max(1e-4, 1 - avgE) */, pad2[3];
+    float fonA, fonK[4], eonSingleScale /* A / pi */, eonAvgE, eonOneMinusAvgE, eonInvDen /* 1 / max(1e-4, 1 - avgE) */, dielF0[3];
+    // dielF0 = sat(specularColor * dielF0Scalar), f90Diel = sat(dot(dielF0, 50 * 0.33)): the dielectric lobe's Fresnel ends depend on the material alone (round 5)
 };
 static_assert(sizeof(MatConst) == 96, "six float4");
 constexpr uint32_t BRMI_ARENA_NONE = 0xFFFFFFFFu;

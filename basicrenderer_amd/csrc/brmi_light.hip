@@ -73,6 +73,13 @@ template <int MODE, int WAVES = BRMI_SHADE_WAVES>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE != 0 ? 1 : WAVES, (MODE == 0 && WAVES == BRMI_SHADE_WAVES && BRMI_SHADE_SHARED_MAXWAVES != 0) ? BRMI_SHADE_SHARED_MAXWAVES : 8)))
 k_shade(ShadeArgs a) {
     wave_prio<PRIO_SHADE>();
+#ifndef BRMI_SHADE_SHARED_RESERVE
+#define BRMI_SHADE_SHARED_RESERVE 1
+#endif
+    // The variant that shares the chip holds 136 registers per wave ON PURPOSE (round 5: the arithmetic needs 123): three of its waves then leave a SIMD
+    // 104 registers for the other frame's geometry waves, four waves of 128 leave none -- the shading half gets faster and the frame slower (DESIGN.md 4.6:
+    // period 0.522 -> 0.585 ms when tried with a leaner kernel in round 4; 0.510 -> 0.519 in round 5).
+    if (MODE == 0 && WAVES == BRMI_SHADE_WAVES && BRMI_SHADE_WAVES_ALONE != BRMI_SHADE_WAVES && BRMI_SHADE_SHARED_RESERVE) asm volatile("" ::: "v131");
     const ShadeFrame k = make_shade_frame(a);
     __shared__ float sliceStart[64];
     __shared__ float unormT[256];
@@ -87,22 +94,37 @@ k_shade(ShadeArgs a) {
         const uint32_t lane = threadIdx.x & 63u;
         const uint32_t wavesInGrid = gridDim.x * (blockDim.x >> 6);
         const uint32_t tileCount = (uint32_t)((a.pixelCount + 63ull) >> 6), firstTile = (uint32_t)(a.firstPixel >> 6);
-        uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+#ifndef BRMI_SHADE_TILE_RUNS
+#define BRMI_SHADE_TILE_RUNS 1
+#endif
+        // Round 5: a wave takes a RUN of neighbouring tiles (tiles per wave = ceil(tiles / waves) of them, left to right) instead of every
+        // `wavesInGrid`-th tile of the band.  A light cluster of the 12 x 12 grid is 40 tiles wide at 4K, so the tiles of a run sit in one cluster nearly
+        // always: the list head and the 64 B light records the first tile fetched through the scalar cache (16 KB) are still there for the others.  Strided,
+        // every CU met every cluster of the frame -- 0.9 MB of records in list order -- and each light evaluation began with a scalar load that went to L2
+        // (an ablation that let every tile read the head of one table: k_shade 0.170 -> 0.138 ms).
+        const uint32_t waveInGrid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+        // (the stand-alone variant only: 0.1665 -> 0.1635 ms; beside another frame's geometry half the strided order is 2 % better -- tiles of one
+        // workgroup then end at different times and slots come free more evenly: Bistro-class 0.504 against 0.514 ms per frame, Sponza-class 0.388 / 0.397)
+        constexpr bool RUNS = BRMI_SHADE_TILE_RUNS && ALONE;
+        const uint32_t run = RUNS ? (tileCount + wavesInGrid - 1u) / wavesInGrid : 1u;
+        uint32_t t = RUNS ? waveInGrid * run : waveInGrid;
+        const uint32_t tEnd = RUNS ? min(t + run, tileCount) : tileCount;
         uint32_t tx = (firstTile + t) % a.tilesX, ty = (firstTile + t) / a.tilesX;
-        const uint32_t stepX = wavesInGrid % a.tilesX, stepY = wavesInGrid / a.tilesX;
+        const uint32_t stepX = RUNS ? 1u : wavesInGrid % a.tilesX, stepY = RUNS ? 0u : wavesInGrid / a.tilesX;
+        const uint32_t stepT = RUNS ? 1u : wavesInGrid;
         // (the lane index behind an opaque copy per tile: its row / column inside the tile and the byte offsets of the plane loads are then a VALU
         // instruction each where they are used, not loop invariants in registers of their own -- the trick that took the G-buffer kernel from 73 to 59 VGPRs)
         auto fetch = [&](uint32_t tt, uint32_t ttx, uint32_t tty, bool& ok) {
             uint32_t ln = lane;
             if (OPAQUE_LANE) asm volatile("" : "+v"(ln));
             const uint32_t px = ttx * 8u + (ln >> 3), py = tty * 8u + (ln & 7u);
-            ok = tt < tileCount && px < a.W && py < a.H && py >= a.bandY0 && py < a.bandY1;
+            ok = tt < tEnd && px < a.W && py < a.H && py >= a.bandY0 && py < a.bandY1;
             return ok ? load_raw_pixel_plain(a, ((uint64_t)(firstTile + tt) << 6), ln, px, py) : empty_raw_pixel();
         };
         bool ok = false;
         RawPixel cur = fetch(t, tx, ty, ok);
-        while (t < tileCount) {
-            uint32_t nt = t + wavesInGrid, ntx = tx + stepX, nty = ty + stepY;
+        while (t < tEnd) {
+            uint32_t nt = t + stepT, ntx = tx + stepX, nty = ty + stepY;
             if (ntx >= a.tilesX) { ntx -= a.tilesX; nty++; }
             bool nok = false;
             RawPixel nxt = empty_raw_pixel();

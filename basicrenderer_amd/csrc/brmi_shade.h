@@ -21,12 +21,15 @@ struct Frag {
     float NdotV, roughness, baseDiffuseRoughness, specularAlpha, weightedSpecularIor, dielectricSpecularWeight, metalSpecularWeight, coatWeight, coatIor, coatDarkening, coatRoughness, fuzzWeight, fuzzRoughness;
 };
 
+// MakeOpenPBRBaseLayerState saturates its inputs; every one of them arrives saturated here (shade_pixel builds the Frag from UNORM codes, clamped
+// roughness and MatConst values that material_constants_of saturated; the IOR is >= 1 by its formula), and saturating twice is the identity -- round 5
+// dropped the second pass (17 instructions per pixel).
 BRMI_DEV BaseState make_base_state(const Frag& f) {
     BaseState s;
-    s.weightedBaseColor = satq3(f.albedo); s.diffuseColor = f.diffuseColor; s.baseDiffuseRoughness = satq(f.baseDiffuseRoughness);
-    s.specularAlpha = satq(f.specularAlpha); s.weightedSpecularIor = max2(f.weightedSpecularIor, 1.0f);
-    s.dielectricSpecularF0 = satq3(f.dielectricSpecularF0); s.dielectricSpecularWeight = satq(f.dielectricSpecularWeight);
-    s.metalAverageFresnel = satq3(f.metalAverageFresnel); s.metalSpecularF0 = satq3(f.metalSpecularF0); s.metalSpecularWeight = satq(f.metalSpecularWeight);
+    s.weightedBaseColor = f.albedo; s.diffuseColor = f.diffuseColor; s.baseDiffuseRoughness = f.baseDiffuseRoughness;
+    s.specularAlpha = f.specularAlpha; s.weightedSpecularIor = f.weightedSpecularIor;
+    s.dielectricSpecularF0 = f.dielectricSpecularF0; s.dielectricSpecularWeight = f.dielectricSpecularWeight;
+    s.metalAverageFresnel = f.metalAverageFresnel; s.metalSpecularF0 = f.metalSpecularF0; s.metalSpecularWeight = f.metalSpecularWeight;
     s.metalMultipleScatterScale = s.metalSpecularWeight * s.metalAverageFresnel * s.metalAverageFresnel;
     return s;
 }
@@ -248,11 +251,11 @@ struct PixelCtx {
     float NoV;
     CoatState coat; FuzzState fuzz;
     f3 coatIn, coatComp;
-    float cachedView, mView, mAvgClamped;
+    float cachedView, mView, invMAvg;
     f3 dielComp;
     float f90Diel, f90Metal;
     f3 eonSinglePre, eonMsPre; float eonEInOverDen, fonA, fonK0, fonK1, fonK2, fonK3;
-    const float* odRow; const float* imRow;     // folded rows of the pixel's (material, roughness code)
+    const float2* odRow; const float2* imRow;   // folded rows of the pixel's (material, roughness code): {value, step to the next} pairs
     OdPrep coatOd;              // GENERAL: rows of the coat's (ior, roughness)
 };
 
@@ -278,13 +281,13 @@ BRMI_DEV PixelCtx make_pixel_ctx(const Luts& L, const Frag& f, const ShadeRows* 
     if (MODE & 2) c.fuzz = make_fuzz_state(L, f);
     const BaseState& b = c.base;
     c.odRow = rows->od; c.imRow = rows->im;
-    const float viewComp = sample_folded_row(c.odRow, satq(c.NoV));
-    c.cachedView = max2(0.0f, qdiv(viewComp, max2(avg.avgComp, 1.0e-12f)));
+    const float viewComp = sample_folded_row(c.odRow, c.NoV);
+    c.cachedView = max2(0.0f, viewComp * avg.invAvgComp);
     c.mView = sample_folded_row(c.imRow, c.NoV);
-    c.mAvgClamped = avg.mAvgClamped;
-    c.dielComp = ggx_energy_compensation_q(quads[roughCode], c.NoV, b.dielectricSpecularF0);
+    c.invMAvg = avg.invMAvgClamped;
+    c.dielComp = ggx_energy_compensation_q(quads[roughCode], c.NoV, b.dielectricSpecularF0) * b.dielectricSpecularWeight;      // (the lobe's weight folded in: light_contribution)
     const float tmp = 50.0f * 0.33f;
-    c.f90Diel = satq(dot3(b.dielectricSpecularF0, f3{tmp, tmp, tmp}));
+    c.f90Diel = mc.f90Diel;
     c.f90Metal = satq(dot3(b.metalSpecularF0, f3{tmp, tmp, tmp}));
     {   // OpenPBRDiffuseEON, view-only factors; what only depends on the material's diffuse roughness comes from MatConst
         BRMI_FP_FAST
@@ -300,54 +303,56 @@ BRMI_DEV PixelCtx make_pixel_ctx(const Luts& L, const Frag& f, const ShadeRows* 
 
 // `h` = normalize(L + V), NoH, LoH come from the caller (correctly rounded, contraction off: 1 - NoH^2 amplifies their error at low
 // roughness); everything in here holds the HDR tolerance and may fuse.
+// a * s + b per component as fused multiply-adds.  The f3 operators of brmi_device.h are compiled without contraction (the direction vectors need
+// them that way), and a `clang fp contract(fast)` block does not reach into them: every `b + a * s` written with the operators inside the BRDF
+// algebra was a multiply and an add (round 5: ~25 instructions per light evaluation).
+BRMI_DEV f3 fma3(f3 a, float s, f3 b) { return f3{__builtin_fmaf(a.x, s, b.x), __builtin_fmaf(a.y, s, b.y), __builtin_fmaf(a.z, s, b.z)}; }
+BRMI_DEV f3 fma3v(f3 a, f3 s, f3 b) { return f3{__builtin_fmaf(a.x, s.x, b.x), __builtin_fmaf(a.y, s.y, b.y), __builtin_fmaf(a.z, s.z, b.z)}; }
 template <int MODE, int STASH>
-BRMI_DEV f3 light_contribution(const Luts& L, const Frag& f, const PixelCtx& c, const float* stash, f3 lightToFrag, float NoL, float NoH, float LoH, float VdotL, float D, f3 lightColorIntensity, float attenuation, float spotAtt) {
+BRMI_DEV f3 light_contribution(const Luts& L, const Frag& f, const PixelCtx& c, const float* stash, f3 lightToFrag, float NoL, float NoH, float LoH, float VdotL, float D, f3 lightColorIntensity, float attenuation, float spotAtt, f3 acc) {
     BRMI_FP_FAST
     const BaseState& base = c.base;
     const float NoV = c.NoV;
     // diffuse: EON x dielectric energy compensation
-    const float lightComp = sample_folded_row(c.odRow, satq(NoL));
+    const float lightComp = sample_folded_row(c.odRow, NoL);
     const float diffuseEnergyComp = max2(0.0f, c.cachedView * lightComp);
     f3 diffuse;
     {
         const float rough = base.baseDiffuseRoughness;
-        const float muIn = satq(NoV), muOut = satq(NoL);
+        const float muIn = NoV, muOut = NoL;                  // (both saturated by the caller)
         const float sv = VdotL - muIn * muOut;
         const float sOverT = sv > 0.0f ? qdiv(sv, max2(max2(muIn, muOut), 1.0e-4f)) : sv;
-        const f3 single = c.eonSinglePre * (1.0f + rough * sOverT);
+        const float singleScale = 1.0f + rough * sOverT;
         // STASH > 9: the five coefficients of the diffuse albedo fit wait in LDS too (read once per light evaluation)
         const float EOut = STASH > 9 ? fon_dir_albedo_folded(muOut, stash[12 * 256], stash[13 * 256], stash[14 * 256], stash[15 * 256], stash[16 * 256])
                                      : fon_dir_albedo_folded(muOut, c.fonA, c.fonK0, c.fonK1, c.fonK2, c.fonK3);
         const float k = max2(1.0e-4f, 1.0f - EOut) * c.eonEInOverDen;
-        diffuse = (single + c.eonMsPre * f3{k, k, k}) * diffuseEnergyComp;
+        diffuse = fma3(c.eonMsPre, k, c.eonSinglePre * singleScale) * diffuseEnergyComp;
     }
     // specular: one D*V for both lobes (same roughness), one Schlick power
     const float DV = D * v_smith_ggx(base.specularAlpha, NoV, NoL);
     const float pw = __builtin_amdgcn_exp2f(5.0f * __builtin_amdgcn_logf(1.0f - LoH));   // pow(1 - LoH, 5) = exp2(5 log2 x), as DXC lowers it
-    const f3 Fd = base.dielectricSpecularF0 + (f3{c.f90Diel, c.f90Diel, c.f90Diel} - base.dielectricSpecularF0) * pw;
-    const f3 dielSpec = base.dielectricSpecularWeight * (DV * Fd) * c.dielComp;
+    const f3 Fd = fma3(f3{c.f90Diel, c.f90Diel, c.f90Diel} - base.dielectricSpecularF0, pw, base.dielectricSpecularF0);
+    // diffuse + dielectric lobe in one go: c.dielComp carries the dielectric weight (make_pixel_ctx)
+    f3 brdf = fma3v(Fd * DV, c.dielComp, diffuse);
     // A dielectric pixel (metal weight 0) has metalSpec = 0 * (finite) = +-0, and dielSpec + (+-0) = dielSpec up to the sign of a zero
     // that the sums into `lighting` (which starts at +0) cannot carry: the metal lobe -- table fetch, Fresnel, multiple-scatter term --
     // is skipped for it.  A non-finite D*V keeps the full expression (0 * inf is NaN, not 0).
-    f3 metalSpec{0.0f, 0.0f, 0.0f};
     if (!(base.metalSpecularWeight == 0.0f && fabsf(DV) <= 3.4028234e38f)) {
         // STASH: the lobe's per-pixel inputs wait in the lane's LDS slots (shade_pixel parked them) -- ten registers that only metallic pixels
         // read.  For the variant that has the chip to itself: beside another frame's k_raster_bins (35 KB of LDS per workgroup) the 9 KB per
         // workgroup cost more residency than the registers buy (frame in flight 0.571 -> 0.623 ms).
         const f3 mF0 = STASH ? f3{stash[0 * 256], stash[1 * 256], stash[2 * 256]} : base.metalSpecularF0;
         const f3 mMs = STASH ? f3{stash[3 * 256], stash[4 * 256], stash[5 * 256]} : base.metalMultipleScatterScale;
-        const float f90Metal = STASH > 6 ? stash[6 * 256] : c.f90Metal, mView = STASH > 6 ? stash[7 * 256] : c.mView, mAvgClamped = STASH > 6 ? stash[8 * 256] : c.mAvgClamped;
-        const float* imRow = STASH ? c.odRow + 32 : c.imRow;                    // ShadeRows: od[32], im[32]
-        const f3 Fm = mF0 + (f3{f90Metal, f90Metal, f90Metal} - mF0) * pw;
+        const float f90Metal = STASH > 6 ? stash[6 * 256] : c.f90Metal, mView = STASH > 6 ? stash[7 * 256] : c.mView, invMAvg = STASH > 6 ? stash[8 * 256] : c.invMAvg;
+        const float2* imRow = STASH ? c.odRow + 32 : c.imRow;                    // ShadeRows: od[32], im[32]
+        const f3 Fm = fma3(f3{f90Metal, f90Metal, f90Metal} - mF0, pw, mF0);
         const float mLight = sample_folded_row(imRow, NoL);
-        const float mTab = qdiv(mView * mLight, mAvgClamped);
+        const float mTab = (mView * mLight) * invMAvg;
         const float mScale = min2(mTab, qrcp(max2(NoL, 1.0e-4f))) * (1.0f / PI_F);
-        metalSpec = base.metalSpecularWeight * (DV * Fm + mMs * mScale);
+        brdf = fma3(fma3(mMs, mScale, Fm * DV), base.metalSpecularWeight, brdf);
     }
-    const f3 specular = dielSpec + metalSpec;
-    f3 brdf;
-    if (MODE == 0) brdf = diffuse + specular;
-    else {
+    if (MODE != 0) {
         float fuzzScale = 1.0f;
         f3 fuzzFr{0.0f, 0.0f, 0.0f};
         if (MODE & 2) {
@@ -365,9 +370,9 @@ BRMI_DEV f3 light_contribution(const Luts& L, const Frag& f, const PixelCtx& c, 
             }
         }
         const f3 baseAtt = f3{fuzzScale, fuzzScale, fuzzScale} * baseScale;
-        brdf = (diffuse + specular) * baseAtt + coatFr * f3{fuzzScale, fuzzScale, fuzzScale} + fuzzFr;
+        brdf = brdf * baseAtt + coatFr * f3{fuzzScale, fuzzScale, fuzzScale} + fuzzFr;
     }
-    return brdf * lightColorIntensity * (attenuation * spotAtt * NoL);
+    return fma3v(brdf, lightColorIntensity * (attenuation * spotAtt * NoL), acc);      // the pixel's sum so far + this light
 }
 
 // One pixel per lane of DeferredCSMain (deferred.hlsl:11-106).  Every lane of the wave runs through here together -- `live` lanes
@@ -479,7 +484,7 @@ BRMI_DEV uint32_t shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const flo
         const float baseWeight = mc.baseWeight, specularWeight = mc.specularWeight;
         const f3 specularColor{mc.specR, mc.specG, mc.specB};
         const f3 weightedBaseColor = satq3(baseColor * baseWeight);
-        f.dielectricSpecularF0 = satq3(specularColor * mc.dielF0Scalar);
+        f.dielectricSpecularF0 = f3{mc.dielF0[0], mc.dielF0[1], mc.dielF0[2]};      // sat(specularColor * dielF0Scalar), per material (k_frame_constants)
         const float coatPR = clampf(coatR, BRMI_MIN_PERCEPTUAL_ROUGHNESS, 1.0f);
         f.dielectricSpecularWeight = satq(1.0f - metal);
         f.metalSpecularWeight = satq(metal * specularWeight);
@@ -510,7 +515,7 @@ BRMI_DEV uint32_t shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const flo
         if (STASH && f.metalSpecularWeight != 0.0f) {
             metalStash[0][threadIdx.x] = ctx.base.metalSpecularF0.x; metalStash[1][threadIdx.x] = ctx.base.metalSpecularF0.y; metalStash[2][threadIdx.x] = ctx.base.metalSpecularF0.z;
             metalStash[3][threadIdx.x] = ctx.base.metalMultipleScatterScale.x; metalStash[4][threadIdx.x] = ctx.base.metalMultipleScatterScale.y; metalStash[5][threadIdx.x] = ctx.base.metalMultipleScatterScale.z;
-            if (STASH > 6) { metalStash[6 % (STASH ? STASH : 1)][threadIdx.x] = ctx.f90Metal; metalStash[7 % (STASH ? STASH : 1)][threadIdx.x] = ctx.mView; metalStash[8 % (STASH ? STASH : 1)][threadIdx.x] = ctx.mAvgClamped; }
+            if (STASH > 6) { metalStash[6 % (STASH ? STASH : 1)][threadIdx.x] = ctx.f90Metal; metalStash[7 % (STASH ? STASH : 1)][threadIdx.x] = ctx.mView; metalStash[8 % (STASH ? STASH : 1)][threadIdx.x] = ctx.invMAvg; }
         }
         if (STASH > 9) {      // the emissive term (read once, after the lights) and the diffuse fit's coefficients (once per light evaluation): eight registers
             constexpr int S = STASH ? STASH : 1;
@@ -535,7 +540,11 @@ BRMI_DEV uint32_t shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const flo
 #if BRMI_SHADE_SCALAR_LIGHTS
         // The records of a cluster's lights lie in list order (k_lc_fill), so light q of the list is ONE wave-uniform 64 B record: a scalar
         // load brings it into SGPRs -- no staging registers (16 VGPRs) and no v_readlane per field.
+#ifdef BRMI_ABLATE_LIGHTREC
+        const float4* recBase = a.shadeLights;      // (experiment: every tile reads the head of ONE table -- scalar-cache hits; wrong image)
+#else
         const float4* recBase = a.clustered ? a.listRecords + (size_t)listBase * 4u : a.shadeLights;
+#endif
         if (mine) for (uint32_t q = 0; q < listCount; q++) {
             // one s_load_dwordx16 (as sixteen separate words the compiler fetched the record in four dependent pieces)
             typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -570,7 +579,7 @@ BRMI_DEV uint32_t shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const flo
             const float VdotL = dot3(f.viewWS, lightToFrag);
             const float D = d_ggx(ctx.base.specularAlpha, NoH);
             const f3 col{lr.r2[0], lr.r2[1], lr.r2[2]};
-            lighting = lighting + light_contribution<MODE, STASH>(L, f, ctx, stash, lightToFrag, NoL, NoH, LoH, VdotL, D, col, att, spot);
+            lighting = light_contribution<MODE, STASH>(L, f, ctx, stash, lightToFrag, NoL, NoH, LoH, VdotL, D, col, att, spot, lighting);
         }
 #else
         for (uint32_t c0 = 0; c0 < listCount; c0 += 64u) {
@@ -611,7 +620,7 @@ BRMI_DEV uint32_t shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const flo
                 const float VdotL = dot3(f.viewWS, lightToFrag);
                 const float D = d_ggx(ctx.base.specularAlpha, NoH);
                 const f3 col{bcast(s.r2.x, q), bcast(s.r2.y, q), bcast(s.r2.z, q)};
-                lighting = lighting + light_contribution<MODE, STASH>(L, f, ctx, stash, lightToFrag, NoL, NoH, LoH, VdotL, D, col, att, spot);
+                lighting = light_contribution<MODE, STASH>(L, f, ctx, stash, lightToFrag, NoL, NoH, LoH, VdotL, D, col, att, spot, lighting);
             }
         }
 #endif

@@ -82,8 +82,8 @@ BRMI_DEV f3 ggx_energy_compensation_q(const GgxQuad& g, float x, f3 Fss) {
 #pragma unroll
     for (int i = 0; i < 4; i++) r[i] = g.q0[i] + x * (g.q1[i] + x * g.q2[i]);
     const float A = clampf(qdiv(r[0], r[2]), 0.0f, 1.0f), B = clampf(qdiv(r[1], r[3]), 0.0f, 1.0f);
-    const float Ess = A + B;
-    return f3{1.0f, 1.0f, 1.0f} + Fss * ((1.0f - Ess) * qrcp(Ess));
+    const float Ess = A + B, k = (1.0f - Ess) * qrcp(Ess);
+    return f3{__builtin_fmaf(Fss.x, k, 1.0f), __builtin_fmaf(Fss.y, k, 1.0f), __builtin_fmaf(Fss.z, k, 1.0f)};
 }
 BRMI_DEV f3 ggx_energy_compensation(float NdotV, float alpha, f3 Fss) {
     BRMI_FP_FAST
@@ -224,30 +224,37 @@ BRMI_DEV float average_fresnel(float eta) {
 // sample_rows computes them; what changes is the order in which the (multilinear) interpolation is associated, i.e. fp32 rounding in
 // the last bits -- tolerance-level, like the hardware rcp in the BRDF algebra.  Built by k_frame_constants with the first frame after
 // brmi_setup.
-struct ShadeRows { float od[32]; float im[32]; };                    // 256 B per (material, code)
-struct ShadeAverages { float avgComp, mAvgClamped; };              // lut_od_avg / max(lut_im_avg, 1e-12) of the pair
-static_assert(sizeof(ShadeRows) == 256 && sizeof(ShadeAverages) == 8, "table layouts");
+// Round 5: a row entry is the PAIR {value, next value - value}: one 8 B fetch and one fused multiply-add per sample, and the column is the cosine's
+// index itself -- remap_index() followed by sample_rows()'s `u * 32 - 0.5` is the identity on [0, 31] up to one rounding of 2^-25, which moves the
+// sample by ~1e-7 of a table step (tolerance-level; the old form cost 25 VALU instructions per sample, this one 8).
+struct ShadeRows { float2 od[32]; float2 im[32]; };                  // 512 B per (material, code)
+struct ShadeAverages { float invAvgComp, invMAvgClamped; };        // 1 / max(lut_od_avg, 1e-12), 1 / max(lut_im_avg, 1e-12) of the pair (hardware reciprocal, as the pixel took it)
+static_assert(sizeof(ShadeRows) == 512 && sizeof(ShadeAverages) == 8, "table layouts");
 BRMI_DEV void build_shade_rows(const Luts& L, float ior, float alpha, ShadeRows& r, ShadeAverages& a) {
     const OdPrep od = prep_od_e(L, ior, alpha);
     const LutRows im = prep_im_e(L, alpha);
+    float odv[32], imv[32];
     for (uint32_t x = 0; x < 32u; x++) {
         const float v0 = lerpf(L.odE[od.s0.r0 + x], L.odE[od.s0.r1 + x], od.s0.fy), v1 = lerpf(L.odE[od.s1.r0 + x], L.odE[od.s1.r1 + x], od.s1.fy);
-        r.od[x] = extrapolate_ior(lerpf(v0, v1, od.st), ior);
-        r.im[x] = lerpf(L.odE[im.r0 + x], L.odE[im.r1 + x], im.fy);
+        odv[x] = extrapolate_ior(lerpf(v0, v1, od.st), ior);
+        imv[x] = lerpf(L.odE[im.r0 + x], L.odE[im.r1 + x], im.fy);
     }
-    a.avgComp = lut_od_avg(L, ior, alpha); a.mAvgClamped = max2(lut_im_avg(L, alpha), 1.0e-12f);
+    for (uint32_t x = 0; x < 32u; x++) {
+        const uint32_t x1 = x < 31u ? x + 1u : 31u;
+        r.od[x] = make_float2(odv[x], odv[x1] - odv[x]); r.im[x] = make_float2(imv[x], imv[x1] - imv[x]);
+    }
+    a.invAvgComp = qrcp(max2(lut_od_avg(L, ior, alpha), 1.0e-12f)); a.invMAvgClamped = qrcp(max2(lut_im_avg(L, alpha), 1.0e-12f));
 }
-// one sample of a folded row: column and weight as in sample_rows
-BRMI_DEV float sample_folded_row(const float* row, float cosT) {
+// one sample of a folded row at cos(theta) (any finite value: saturated here)
+BRMI_DEV float sample_folded_row(const float2* row, float cosT) {
+    BRMI_FP_FAST
 #ifdef BRMI_ABLATE_ROWS
     return cosT * 0.5f;      // (experiment: the table gathers gone; wrong image)
 #endif
-    const float u = remap_index(clamp_index(cos_to_index(cosT)));
-    const float x = u * 32.0f - 0.5f;
+    const float x = satq(cosT) * TBL_M1;
     const float x0f = floorf(x);
-    const float fx = x - x0f;
-    const uint32_t x0 = clamp_texel(x0f, 32), x1 = clamp_texel(x0f + 1.0f, 32);
-    return lerpf(row[x0], row[x1], fx);
+    const float2 p = row[(uint32_t)x0f];
+    return __builtin_fmaf(x - x0f, p.y, p.x);
 }
 
 }  // namespace brmi
