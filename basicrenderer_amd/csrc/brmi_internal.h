@@ -188,7 +188,9 @@ struct brmi_pass {
         if (hipHostGetDevicePointer(reinterpret_cast<void**>(&phase2FeedbackDev), phase2FeedbackHost, 0) != hipSuccess) { (void)hipHostFree(phase2FeedbackHost); phase2FeedbackHost = nullptr; phase2FeedbackDev = nullptr; return false; }
         return true;
     }
-    uint32_t phase2DirectMax = 256;   // BRMI_PHASE2_DIRECT_MAX: direct rasterisation while the last known phase-2 count is at most this (0: always bins)
+    uint32_t phase2DirectMax = 128;   // BRMI_PHASE2_DIRECT_MAX: direct rasterisation while the last known phase-2 count is at most this (0: always bins).  Round 5: 256 -> 128 -- a camera that
+                                      // moves fast leaves phase 2 two to four hundred clusters of large near triangles, which the row re-deal walks in few lanes: path_fast raster2 0.12 -> 0.065 ms
+                                      // (0.648 -> 0.625 ms per frame); the slow path (30 - 80 clusters) and the still camera keep the one-launch form (sweep: profiles/r05_experiments.md)
     uint32_t clearRiderBlocks = 8192; // single-wave workgroups of the visibility clear that ride on the traversal launch (BRMI_CLEAR_RIDER_BLOCKS)
     bool splitFrame = false;         // brmi_execute_split with two streams: this frame's launches share the chip with another frame's
     uint32_t shadeSlabs = 0; brmi_slab_fn shadeSlabFn = nullptr; void* shadeSlabUser = nullptr;      // brmi_set_shade_slabs
