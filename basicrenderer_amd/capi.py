@@ -134,7 +134,7 @@ class ComposeConfig(C.Structure):
 
 COMPOSE_EXPORTS = ["brmi_compose_unique_id", "brmi_compose_create", "brmi_compose_staging_bytes", "brmi_compose_output_bytes", "brmi_compose_bind",
                    "brmi_compose_submit", "brmi_compose_finish", "brmi_compose_destroy", "brmi_compose_last_error",
-                   "brmi_compose_alloc_shared", "brmi_compose_export", "brmi_compose_import", "brmi_compose_last_wait_status", "brmi_compose_submit_rows"]
+                   "brmi_compose_alloc_shared", "brmi_compose_export", "brmi_compose_import", "brmi_compose_last_wait_status", "brmi_compose_submit_rows", "brmi_compose_wait_source"]
 COMPOSE_HANDLE_BYTES = 160
 _compose_lib = None
 
@@ -168,6 +168,7 @@ def compose_lib():
         lib.brmi_compose_import.argtypes = [vp, C.c_char_p, u32]
         lib.brmi_compose_last_wait_status.argtypes = [vp]
         lib.brmi_compose_submit_rows.argtypes = [vp, vp, u32, u32, vp]
+        lib.brmi_compose_wait_source.argtypes = [vp, vp, vp]; lib.brmi_compose_wait_source.restype = C.c_int
         lib.brmi_compose_destroy.restype = None
         lib.brmi_compose_last_error.argtypes = [vp]
         lib.brmi_compose_last_error.restype = C.c_char_p

@@ -21,6 +21,19 @@ def frame_size(n_gpus, partition="bands"):
     return (7680, (STRIPE_BAND_ROWS if partition == "stripes" else BAND_ROWS) * n_gpus)
 
 
+def strong_frame(n_gpus):
+    """Strong scaling (BASELINE.json configs[3]: "4K, screen-tile partition across 2/4/8"): THE 4K frame split N ways by the interleaved partition.
+    Chunks are multiples of the 16-row raster bin and every rank owns the same number of them, so the frame is 3840 x 2176 -- 2160 rows padded
+    to the next multiple of 16 N for N = 2, 4, 8 (0.7 % more pixels, stated in the bench line) -- in chunks of 128 / N rows (64, 32, 16)."""
+    if n_gpus == 1:
+        return (3840, 2176), 0
+    height = -(-2160 // (16 * n_gpus)) * (16 * n_gpus)
+    for rows in (64, 48, 32, 16):
+        if height % (rows * n_gpus) == 0:
+            return (3840, height), rows
+    raise ValueError(f"no chunk height for {n_gpus} GPUs")
+
+
 def stripe_frame_rows(rank, n_gpus, height, rows=STRIPE_ROWS):
     """Rows of the frame a rank owns under the interleaved partition, in the order of its compact surfaces (include/brmi.h,
     brmi_config::stripe*): chunks of `rows` rows, `n_gpus` chunks to a group, one chunk per group and rank, the order inside a group
@@ -276,12 +289,26 @@ class PeerBandComposer:
             self.frames += 1
         return slot
 
+    def wait_source(self, surface_u8=None, stream_ptr=None):
+        """Before `surface` is written again (the pass's next frame): the stream (default: the current one) waits for the composer's reads of the rows
+        submit_rows handed over (brmi_compose_wait_source)."""
+        self._check(self.lib.brmi_compose_wait_source(self._h, (self.surface if surface_u8 is None else surface_u8).data_ptr(),
+                                                        self._stream() if stream_ptr is None else self.C.c_void_p(stream_ptr)), "brmi_compose_wait_source")
+
     def finish(self):
         ptr = self.C.c_void_p()
         self._check(self.lib.brmi_compose_finish(self._h, self._stream(), self.C.byref(ptr)), "brmi_compose_finish")
         if not self.frames:
             return None
         t = self.torch.as_tensor(_DevicePointer(ptr.value, self._ob), device=self.dev)
+        return t.view(self.torch.int16).view(-1, 3) if self.transport == "rgb16f" else t
+
+    def slot_image(self, slot):
+        """The composed image in buffer `slot` (0 .. depth - 1) as finish() shapes it: frame f lives in slot f % depth until frame f + depth is submitted."""
+        ptr = self.C.c_void_p()
+        self._check(self.lib.brmi_compose_finish(self._h, self._stream(), self.C.byref(ptr)), "brmi_compose_finish")
+        base = ptr.value - ((self.frames - 1) % self.depth) * self._ob
+        t = self.torch.as_tensor(_DevicePointer(base + slot * self._ob, self._ob), device=self.dev)
         return t.view(self.torch.int16).view(-1, 3) if self.transport == "rgb16f" else t
 
     def wait_status(self):

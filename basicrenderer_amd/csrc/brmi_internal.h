@@ -217,7 +217,9 @@ struct brmi_pass {
     uint32_t binOverflowPerStripe = 1u << 14;       // 64 stripes x 16384 records x 64 B = 64 MB
     uint32_t binMinSlice = 1024, binSharedSlice = 512, binGrid = 1024;   // k_raster_bins: records one workgroup walks alone / per slice of a larger bin, workgroups of the pool (BRMI_BIN_MIN_SLICE, BRMI_BIN_SHARED_SLICE, BRMI_BIN_GRID)
     uint32_t binScratchTiles = 2048, binItemCapacity = 0;   // k_raster_bins: scratch tiles for bins several workgroups share (BRMI_BIN_SCRATCH_TILES), work items
-    uint32_t binsX = 0, binsY = 0, binCapacity = 8192;   // raster bins: 256 px x 16 rows, binCapacity records of 64 B each (BRMI_BIN_CAPACITY): 1 GB at 4K, walked in slices of 1024
+    uint32_t binsX = 0, binsY = 0, binCapacity = 16384;  // raster bins: 256 px x 16 rows, binCapacity records of 64 B each (BRMI_BIN_CAPACITY): 2 GB at 4K, walked in slices of 1024.
+                                                         // Round 5: 8192 -> 16384 -- rank 0 of the 8-GPU San-Miguel-class frame owns a double chunk on the horizon whose bins take
+                                                         // > 8192 records of alpha-tested leaves; the overflow queues' global-atomic walk made it 1.67 ms against the others' 1.05 (1.18 now)
     bool rasterTiles = false;     // BRMI_RASTER_MODE=tiles (opaque scenes): cluster-granular sort-middle (k_raster_tile_lists / k_raster_tiles) instead of the triangle bins -- bit-exact, a fifth of the HBM traffic, 20-40 % slower (profiles/r03_experiments.md)
     uint32_t rtilesX = 0, rtilesY = 0, tileCapacity = 1024, tileOverflowCapacity = 1u << 20, tileMinSlice = 128;
     uint32_t xvertClusters = 0;   // clusters the screen-vertex cache holds (1.5 KB each): min(maxVisibleClusters, 2^21); BRMI_XVERT_CLUSTERS   // 64 x 64 px raster tiles, cluster indices per tile list (BRMI_TILE_CAPACITY)

@@ -42,6 +42,10 @@ struct brmi_composer {
     uint32_t openRow = 0;                       // submit_rows: next row expected (0 = no frame open)
     hipEvent_t slabReady = nullptr;             // submit_rows: the slab's shading is enqueued (render stream -> composer stream)
     hipEvent_t ownStores = nullptr; bool ownStoresRecorded = false;      // submit_rows: the rank's own stores of the newest frame (composer stream -> finish)
+    // submit_rows reads the caller's surface on the COMPOSER's stream: the newest of those reads per surface (a renderer with frames in flight hands over
+    // the surfaces of several passes in turn), for brmi_compose_wait_source -- what the stream that next writes the surface has to wait for
+    struct SourceRead { const void* surface; hipEvent_t read; };
+    std::vector<SourceRead> sourceReads;
     std::string err;
 };
 
@@ -99,12 +103,14 @@ __global__ void __launch_bounds__(256) k_peer_write(const uint4* src, PeerTable 
 // after k_peer_write has retired (a kernel boundary makes its stores visible system-wide): "my band of `frame` has landed in your slot"
 __global__ void k_signal_landed(PeerTable peers, uint32_t nRanks, uint32_t rank, uint32_t slot, uint32_t frame) {
     const uint32_t p = threadIdx.x;
-    if (p < nRanks) __hip_atomic_store(&peers.flags[p]->landed[slot][rank], frame, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // (relaxed: the band's stores were made by an EARLIER kernel of this stream, whose end wrote them through; a release here is a system-scope write-back of
+    // every XCD's L2 -- G-buffer planes and all -- per signal, which cost a one-GPU frame 0.45 ms with two signals per frame, round 5)
+    if (p < nRanks) __hip_atomic_store(&peers.flags[p]->landed[slot][rank], frame, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // at the head of a submit: "I am at frame `frame`: whatever you hold for me of frame - depth may be overwritten"
 __global__ void k_signal_submitted(PeerTable peers, uint32_t nRanks, uint32_t rank, uint32_t frame) {
     const uint32_t p = threadIdx.x;
-    if (p < nRanks) __hip_atomic_store(&peers.flags[p]->submitted[rank], frame, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (p < nRanks) __hip_atomic_store(&peers.flags[p]->submitted[rank], frame, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // (nothing to publish with it: it only says how far this rank has come)
 }
 
 }  // namespace
@@ -294,6 +300,16 @@ int brmi_compose_submit_rows(brmi_composer* c, const void* surface, uint32_t row
         const uint64_t vecs = slabBytes / 16u, bandOut = (uint64_t)c->cfg.rank * c->stagingBytes + slabIn;
         hipLaunchKernelGGL(k_peer_write<false>, dim3((unsigned)std::min<uint64_t>(2048, (vecs + 255) / 256)), dim3(256), 0, cs, reinterpret_cast<const uint4*>(src), c->peers, n, slotOffset, bandOut, vecs);
     }
+    {   // the composer's stream has read these rows of `surface` once this event has passed (brmi_compose_wait_source)
+        brmi_composer::SourceRead* sr = nullptr;
+        for (auto& e : c->sourceReads) if (e.surface == surface) sr = &e;
+        if (!sr) {
+            if (c->sourceReads.size() >= 16) return fail(c, -3, "brmi_compose_submit_rows: more than 16 different source surfaces");
+            hipEvent_t ev = nullptr; CHECK_HIP(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            c->sourceReads.push_back({surface, ev}); sr = &c->sourceReads.back();
+        }
+        CHECK_HIP(c, hipEventRecord(sr->read, cs));
+    }
     if (row1 == y1) {      // the frame closes
         hipLaunchKernelGGL(k_signal_landed, dim3(1), dim3(64), 0, cs, c->peers, n, c->cfg.rank, slot, frame);
         CHECK_HIP(c, hipEventRecord(c->ownStores, cs)); c->ownStoresRecorded = true;
@@ -301,6 +317,13 @@ int brmi_compose_submit_rows(brmi_composer* c, const void* surface, uint32_t row
     } else c->openRow = row1;
     CHECK_HIP(c, hipGetLastError());
     return (int)slot;
+}
+
+int brmi_compose_wait_source(brmi_composer* c, const void* surface, brmi_compose_stream stream) {
+    if (!c || !surface) return -1;
+    // (brmi_compose_submit reads the surface on the caller's own render stream: stream order covers it, nothing was recorded, nothing to wait for)
+    for (auto& e : c->sourceReads) if (e.surface == surface) CHECK_HIP(c, hipStreamWaitEvent(static_cast<hipStream_t>(stream), e.read, 0));
+    return 0;
 }
 
 int brmi_compose_finish(brmi_composer* c, brmi_compose_stream stream, void** composed) {
@@ -331,6 +354,7 @@ void brmi_compose_destroy(brmi_composer* c) {
     for (hipEvent_t e : c->done) if (e) (void)hipEventDestroy(e);
     if (c->slabReady) (void)hipEventDestroy(c->slabReady);
     if (c->ownStores) (void)hipEventDestroy(c->ownStores);
+    for (auto& e : c->sourceReads) if (e.read) (void)hipEventDestroy(e.read);
     for (void* p : c->opened) (void)hipIpcCloseMemHandle(p);
     if (c->ownsShared) { (void)hipDeviceSynchronize(); (void)hipFree(c->output); (void)hipFree(c->flags); }
     if (c->comm) (void)ncclCommDestroy(c->comm);

@@ -144,10 +144,16 @@ class VisibilityRenderer:
             self._check(self.lib.brmi_execute(self._h, self._s()), "brmi_execute")
         else:
             self._check(self.lib.brmi_execute_split(self._h, self._s(), C.c_void_p(shading_stream.cuda_stream)), "brmi_execute_split")
+        err, self._slab_error = getattr(self, "_slab_error", None), None
+        if err is not None:
+            raise BrmiError(f"the shade-slab hook raised during execute: {err!r}") from err
 
     def stage(self, name, *args):
         fn = getattr(self.lib, "brmi_" + name)
         self._check(fn(self._h, *[capi.u32(a) for a in args], self._s()), "brmi_" + name)
+        err, self._slab_error = getattr(self, "_slab_error", None), None
+        if err is not None:
+            raise BrmiError(f"the shade-slab hook raised during brmi_{name}: {err!r}") from err
 
     def counters(self):
         c = capi.Counters()
@@ -212,7 +218,17 @@ class VisibilityRenderer:
             self._check(self.lib.brmi_set_shade_slabs(self._h, capi.u32(0), None, None), "brmi_set_shade_slabs")
             return
         proto = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p)
-        self._slab_cb = proto(lambda user, r0, r1, stream: callback(int(r0), int(r1), stream))      # kept alive with the pass
+
+        def trampoline(user, r0, r1, stream):
+            # ctypes swallows an exception raised inside a callback (it only prints it): keep the first one and re-raise it when the call into the
+            # library that ran the hook has returned (execute), so that a failed hand-over of a slab does not leave a half-composed frame unnoticed
+            try:
+                callback(int(r0), int(r1), stream)
+            except BaseException as e:      # noqa: BLE001
+                if self._slab_error is None:
+                    self._slab_error = e
+        self._slab_error = None
+        self._slab_cb = proto(trampoline)      # kept alive with the pass
         self._check(self.lib.brmi_set_shade_slabs(self._h, capi.u32(slabs), C.cast(self._slab_cb, C.c_void_p), None), "brmi_set_shade_slabs")
 
     def set_history_source(self, other):

@@ -8,7 +8,9 @@ clear -> cull -> software raster -> G-buffer(+depth) -> light clustering -> Open
 N = 1 : BASELINE.json configs[2], "Bistro 4K, meshlet cull + vis-buffer raster, 256 point lights" (3840x2160) -- the frame the
         north star's one numeric target is stated on (>= 60 fps).  The same run then measures configs[1] ("Sponza 4K,
         visibility-buffer + clustered resolve, 1 dir + 64 point lights") and reports it as `configs1` inside the line.
-N > 1 : weak scaling by screen tile: the frame is 7680 x 1088 N (7680 x 1080 N with --partition bands), geometry replicated; every rank shades
+N > 1 : BASELINE.json configs[3] (San-Miguel-class scene, 30 % alpha-tested + texture-sampled materials), two legs in one line (`weak`, `strong`; multi_gpu_legs), each
+        with the one-GPU frame it is measured against, rendered inside the same job.  The top-level fields are the weak leg's:
+        weak scaling by screen tile: the frame is 7680 x 1088 N (7680 x 1080 N with --partition bands), geometry replicated; every rank shades
         one 4K frame's worth of pixels -- by default the chunks of 64 rows the interleaved partition deals it (brmi_config::stripe*: one chunk
         of every group of N, compact surfaces; the slowest of 8 ranks takes 0.78 ms per frame against 1.62 ms with contiguous bands, measured
         rank by rank on one GPU) -- and the HDR shares are composed so that every rank holds all of them (one RCCL all-gather per frame, or
@@ -68,8 +70,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="bistro", choices=list(WORKLOADS),
-                    help="bistro (default) = BASELINE.json configs[2], the north star's target frame; sponza = configs[1]; san_miguel = configs[3]; "
+    ap.add_argument("--workload", default=None, choices=list(WORKLOADS),
+                    help="default: bistro for N = 1 (BASELINE.json configs[2], the north star's target frame), san_miguel for N > 1 (configs[3]: \"San-Miguel 4K, screen-tile partition "
+                         "across 2/4/8\").  sponza = configs[1]; zorah = configs[4] on one GPU; "
                          "bistro_dense: the Bistro-class street with 20x the triangle budget and fractal relief, so that the 1 px LOD test keeps "
                          "pixel-sized triangles: > 20 k visible clusters, > 150 k meshlets tested per 4K frame (SURVEY.md 8 a-3's regime)")
     ap.add_argument("--no-second", action="store_true", help="N = 1 only: do not add the configs[1] (Sponza) measurement as `configs1` to the line")
@@ -124,15 +127,18 @@ def main():
     ap.add_argument("--cpu-scale", type=float, default=1.0, help="fraction of the frame height the CPU baseline renders")
     ap.add_argument("--cpu-scale-1thread", type=float, default=0.25,
                     help="fraction of the frame height the single-thread CPU baseline renders (BASELINE.md 4(a): 1 thread and all cores; culling covers the whole frame either way)")
+    ap.add_argument("--legs", default="weak,strong", help="N > 1: which legs to run (weak, strong, or both)")
     args = ap.parse_args()
     if args.gpus < 1:
         fail_line(args, "--gpus must be >= 1")
+    if args.workload is None:
+        args.workload = "bistro" if args.gpus == 1 else "san_miguel"
     if args.emulate_rank is not None:
         if not (0 <= args.emulate_rank < args.gpus):
             fail_line(args, f"--emulate-rank {args.emulate_rank} of --gpus {args.gpus}")
         import torch
         torch.cuda.set_device(0)
-        out = measure(args, args.workload, args.gpus, args.emulate_rank, 0, cpu=False, path=False, emulated=True)
+        out = multi_gpu_legs(args, args.gpus, args.emulate_rank, 0, emulated=True)
         out["emulated"] = f"rank {args.emulate_rank} of {args.gpus} alone on one GPU: value counts all {args.gpus} ranks' pixels over THIS rank's time; not an N-GPU measurement"
         print(json.dumps(out), flush=True)
         return
@@ -160,7 +166,10 @@ def main():
     assert world == args.gpus
     torch.cuda.set_device(local_rank)
 
-    out = measure(args, args.workload, world, rank, local_rank, cpu=(world == 1 and not args.no_cpu_baseline))
+    if world > 1:
+        out = multi_gpu_legs(args, world, rank, local_rank, emulated=False)
+    else:
+        out = measure(args, args.workload, world, rank, local_rank, cpu=(world == 1 and not args.no_cpu_baseline))
     if world == 1 and not args.no_second and args.workload != "sponza":
         # the metric string's own wording ("vis-buffer+resolve") is configs[1]: measured by the same run, reported beside the target frame
         second = measure(args, "sponza", world, rank, local_rank, cpu=False, path=False)
@@ -193,8 +202,46 @@ def main():
         print(result_line, flush=True)
 
 
-def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False):
-    """K timed steps of one workload on this rank's GPU (all ranks call it together); rank 0 returns the result object."""
+def multi_gpu_legs(args, n, rank, local_rank, emulated):
+    """--gpus N > 1 (BASELINE.json configs[3]).  Two legs under one clock, and the one-GPU frame each of them is measured against, made inside the same job:
+      weak    every rank shades one 4K frame's worth of pixels: the frame is 7680 x 1088 N, interleaved partition in chunks of --stripe-rows rows; the
+              reference is the scene's 3840 x 2160 frame on one GPU (rank 0's; every rank renders it, each on its own GPU)
+      strong  THE 4K frame (3840 x 2176: 2160 rows padded to a multiple of 16 N) split N ways in chunks of 128 / N rows; the reference is that frame on one GPU
+    efficiency_vs_n1 = (value_N / N) / value_1 with value = pixels dispatched per second by all ranks.  The top-level fields of the line are the weak leg's
+    (`scaling`: weak -- what the north star's 0.9 is stated on)."""
+    from basicrenderer_amd import compose
+    legs = [x for x in args.legs.split(",") if x in ("weak", "strong")] or ["weak"]
+    wl = args.workload
+    result = {}
+    for leg in legs:
+        if leg == "weak":
+            frame, rows = compose.frame_size(n, args.partition), args.stripe_rows
+            ref_frame = compose.frame_size(1)          # the N = 1 problem of weak scaling: the scene's 4K frame (8.29 Mpixel; a rank of the N-GPU frame shades 8.36 M)
+        else:
+            frame, rows = compose.strong_frame(n)
+            ref_frame = frame
+        got = measure(args, wl, n, rank, local_rank, cpu=False, path=False, emulated=emulated, frame=frame, stripe_rows=rows)
+        ref = measure(args, wl, 1, 0, local_rank, cpu=False, path=False, emulated=True, frame=ref_frame, solo=True)      # every rank, on its own GPU; rank 0's is reported
+        if got is not None:
+            keep = ("value", "unit", "ms_per_step", "ms_per_step_minmax", "rank_ms_per_step", "config", "stage_ms", "serial_frame_ms", "host_issue_ms_per_step")
+            entry = {k: got[k] for k in keep if k in got}
+            entry["n1_reference"] = {"value": ref["value"], "ms_per_step": ref["ms_per_step"], "frame": list(ref_frame), "pixels": ref_frame[0] * ref_frame[1]}
+            entry["efficiency_vs_n1"] = round(got["value"] / n / ref["value"], 4)
+            result[leg] = (got, entry)
+    if not result:
+        return None
+    first = "weak" if "weak" in result else legs[0]
+    out = result[first][0]
+    out["scaling"] = first
+    for leg, (_, entry) in result.items():
+        out[leg] = entry
+    return out
+
+
+def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False, frame=None, stripe_rows=None, solo=False):
+    """K timed steps of one workload on this rank's GPU (all ranks call it together); rank 0 returns the result object.
+    frame: (W, H) instead of the workload's default; stripe_rows: chunk height of the interleaved partition instead of --stripe-rows; solo: a one-GPU
+    measurement inside an N-GPU job (no process group is touched; every rank returns its own result)."""
     import torch
     import torch.distributed as dist
     from basicrenderer_amd import Scene, compose
@@ -207,15 +254,18 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False)
     if args.lod_builder is not None:
         scene_kw["lod_builder"] = args.lod_builder
     lod_builder = scene_kw.get("lod_builder", "quadtree")
-    multi = n > 1 and not emulated          # a process group exists
+    multi = n > 1 and not emulated and not solo         # a process group exists
     striped = n > 1 and args.partition == "stripes"
+    stripe_rows = stripe_rows or args.stripe_rows
     W, H = compose.frame_size(n, args.partition)
     if n == 1 and workload in FRAME_SIZE:
         W, H = FRAME_SIZE[workload]
+    if frame is not None:
+        W, H = frame
     if striped:
-        compose.stripe_frame_rows(rank, n, H, args.stripe_rows)      # (raises on a chunk height that does not fit)
+        compose.stripe_frame_rows(rank, n, H, stripe_rows)      # (raises on a chunk height that does not fit)
         band = (0, H // n)                                             # the rank's compact surfaces hold its rows only: the composer takes all of them
-        part = dict(stripes=(args.stripe_rows, n, rank))
+        part = dict(stripes=(stripe_rows, n, rank))
     else:
         band = compose.band_of(rank, n, H)
         part = dict(band=band)
@@ -258,7 +308,7 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False)
     hdr = r.hdr_tensor()
     # all-gather of frame k overlaps the rendering of frame k + 1; the colour channels travel (RGB16F, 6 B/px): the lit target's alpha is constant
     composer, composer_used = None, args.composer
-    if multi or args.force_compose:
+    if multi or (args.force_compose and not solo):
         composer_used = args.composer
         if args.composer in ("native", "peer"):
             # libbrmi_compose.so issues the composition itself.  Whether it can is decided WITHOUT a collective first -- load the library, make
@@ -308,6 +358,8 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False)
         p = passes[k]
         with torch.cuda.stream(streams[k]):
             p.update()                  # the per-frame Update phase (camera / per-frame constants), as the reference's passes run it every frame
+            if slabbed and not os.environ.get("BRMI_BENCH_SKIP_WAIT_SOURCE"):                 # the composer's stream may still be reading this pass's HDR rows of its previous frame: the stream that shades waits for those reads
+                composer.wait_source(p.hdr_tensor(), stream_ptr=(streams[k] if serial or shade_streams[k] is None else shade_streams[k]).cuda_stream)
             p.execute(None if serial else shade_streams[k])
         if composer and not slabbed:
             with torch.cuda.stream(streams[k] if serial or shade_streams[k] is None else shade_streams[k]):
@@ -339,7 +391,7 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False)
     # 20 steps are 9 ms) is one noisy sample, so it is repeated (--repeats; 5 when --steps < 200) and the MEDIAN region is reported, the
     # spread beside it (`ms_per_step_minmax`); `steps` stays the per-region count.
     repeats = args.repeats if args.repeats > 0 else (5 if args.steps < 200 else 1)
-    regions, issue_s = [], []
+    regions, issue_s, own = [], [], []
     for _ in range(repeats):
         frame_no[0] = 0
         if multi:
@@ -352,14 +404,23 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False)
         if composer:
             composer.finish()               # the last frames' collectives are inside the timed region
         torch.cuda.synchronize()
+        t_done = time.perf_counter()
         if multi:
             dist.barrier()
         dt = time.perf_counter() - t0
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        own.append(float(t_done - t0))
         if multi:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         regions.append(float(t.item()))
     dt = sorted(regions)[len(regions) // 2]
+    # every rank's own time to finish its frames (before the closing barrier), median region: how evenly the partition loads the ranks
+    rank_ms = [sorted(own)[len(own) // 2] / args.steps * 1e3]
+    if multi:
+        mine = torch.tensor(rank_ms, dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(n)]
+        dist.all_gather(every, mine)
+        rank_ms = [float(x.item()) for x in every]
 
     if composer is not None and hasattr(composer, "wait_status"):
         # peer-write composition: a wait for a peer's flag that timed out latches a status and the frame is composed anyway -- such a run is not a measurement
@@ -384,7 +445,7 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False)
         if args.camera_path_fast > 0:
             path_fast_out = camera_path(args, scene, passes, streams, shade_streams, r, dev, args.camera_path_fast)
     out = None
-    if rank == 0 or emulated:
+    if rank == 0 or emulated or solo:
         shaded = W * (band[1] - band[0]) * n            # pixels dispatched per step, all ranks
         ms_per_step = dt / args.steps * 1e3
         value = shaded / 1e6 / (dt / args.steps)
@@ -439,12 +500,12 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False)
                                    + (", LOD DAGs from the library's cluster-LOD builder" if lod_builder == "own" else "")
                                    + (f", relief slope {scene_kw['relief_slope']}" if scene_kw.get("relief_slope") else "")
                                    + (f", material features {features} (8 = texture-sampled, 16 = alpha-tested materials)" if features else "")
-                                   + ((f", interleaved partition: chunks of {args.stripe_rows} rows, one per group of {n} and rank, {band[1]} rows per rank in compact surfaces" if striped else f", {n} row bands of 1080 rows") + f" + composition of HDR on every rank ({args.transport}, pipelined one frame deep, {'libbrmi_compose.so: one RCCL all-gather per frame' if composer_used == 'native' else ('libbrmi_compose.so: peer writes over hipIpc-mapped images, no collective' if composer_used == 'peer' else ('torch.distributed' if composer_used == 'torch' else composer_used))})" if composer else ""),
+                                   + ((f", interleaved partition: chunks of {stripe_rows} rows, one per group of {n} and rank, {band[1]} rows per rank in compact surfaces" if striped else f", {n} row bands of {band[1] - band[0]} rows") + f" + composition of HDR on every rank ({args.transport}, pipelined one frame deep, {'libbrmi_compose.so: one RCCL all-gather per frame' if composer_used == 'native' else ('libbrmi_compose.so: peer writes over hipIpc-mapped images, no collective' if composer_used == 'peer' else ('torch.distributed' if composer_used == 'torch' else composer_used))})" if composer else ""),
                        "baseline_config": BASELINE_CONFIG[workload],
                        "fps": round(1e3 / ms_per_step, 1),
                        "pixels_per_gpu": W * (band[1] - band[0]), "visible_clusters_rank0": int(c.visibleClusters),
                        "occlusion_culling": bool(args.occlusion), "visible_clusters_phase2_rank0": int(c.visibleClustersPhase2),
-                       "meshlets_tested_rank0": int(c.meshletsTested), "partition": (f"interleaved chunks of {args.stripe_rows} rows x{n}" if striped else f"row bands x{n}") if n > 1 else "single GPU",
+                       "meshlets_tested_rank0": int(c.meshletsTested), "partition": (f"interleaved chunks of {stripe_rows} rows x{n}" if striped else f"row bands x{n}") if n > 1 else "single GPU",
                        "frames_in_flight": fif},
             "roofline": {"bound": "valu" if (valu and valu["frac"] > hbm_frac) else "hbm", "kernel": {"raster": "k_raster + k_raster_bins (+ k_raster_overflow), both occlusion phases"}.get(dom, DOMINANT_KERNEL.get(dom, dom)), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(hbm_frac, 5), "traffic": traffic, "valu": valu,
@@ -455,6 +516,9 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False)
                               f"serial frames of one pass (nothing else on the GPU): '{dom}' over {min(args.steps, 200)} frames after the timed region, the other stages over 10 frames "
                               f"before it; inside the timed region, sharing the CUs with the other pass's frame, '{dom}' took {in_flight_ms:.4f} ms per launch"),
         }
+        if n > 1:
+            out["rank_ms_per_step"] = {"max": round(max(rank_ms), 4), "min": round(min(rank_ms), 4), "ranks": len(rank_ms),
+                                       "note": "each rank's own time to finish the region's frames, composition included (emulated: this rank alone)"}
         if fif >= 2:
             out["roofline"]["launch_ms_in_flight"] = round(in_flight_ms, 4)
             out["serial_frame_ms"] = round(serial_ms, 4)      # one pass, one stream, frames back to back (what --frames-in-flight 1 times)

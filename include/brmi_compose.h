@@ -81,6 +81,12 @@ int brmi_compose_submit(brmi_composer* c, const void* surface, brmi_compose_stre
  * slab.  The first slab of a frame opens it (the "submitted" signal and the wait for the peers' slots), the last one closes it ("landed") and
  * returns the slot; earlier slabs return the slot too.  brmi_compose_finish orders a consumer behind the rank's own stores as well. */
 int brmi_compose_submit_rows(brmi_composer* c, const void* surface, uint32_t row0, uint32_t row1, brmi_compose_stream renderStream);
+/* brmi_compose_submit_rows reads `surface` on the COMPOSER's stream, behind the render stream, which does not wait for it.  Before anything writes
+ * that surface again (the pass's next frame: with N frames in flight, N frames later) the writing stream must be ordered behind those reads:
+ * this call makes `stream` wait for the newest brmi_compose_submit_rows read of `surface` (no-op for a surface that was never handed over in rows;
+ * brmi_compose_submit reads on the render stream itself and needs nothing).  Without it a lagging peer -- the frame opens with a wait for every
+ * peer's slot -- lets a later frame's shading overwrite rows that have not been copied yet: torn images, no error. */
+int brmi_compose_wait_source(brmi_composer* c, const void* surface, brmi_compose_stream stream);
 /* `stream` waits for every collective in flight; *composed = the output buffer of the newest frame (NULL before the first submit). */
 int brmi_compose_finish(brmi_composer* c, brmi_compose_stream stream, void** composed);
 void brmi_compose_destroy(brmi_composer* c);

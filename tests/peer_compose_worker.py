@@ -18,6 +18,7 @@ def surface_bytes(rank, frame, nbytes):
 def main():
     root, scratch, rank, world, transport, frames = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5], int(sys.argv[6])
     slabs = int(sys.argv[7]) if len(sys.argv) > 7 else 0          # > 0: every frame goes through brmi_compose_submit_rows in this many slabs of rows
+    pipelined = len(sys.argv) > 8 and sys.argv[8] == "pipelined"   # no host wait between frames: the surface is rewritten on the render stream behind brmi_compose_wait_source
     sys.path.insert(0, root)
     import torch
     from basicrenderer_amd import compose
@@ -43,6 +44,27 @@ def main():
 
     comp = compose.PeerBandComposer(surf, band, W, 8, depth=2, transport=transport, rank=rank, world=world, exchange=exchange, timeout_ms=20000)
     last = None
+    if pipelined:
+        # Frames in flight as a renderer has them: every frame's bytes are in HBM already, the "shading" of a frame is a device copy into THE surface on the
+        # render stream, the slabs go to the composer's stream, and nothing waits on the host.  One rank is late, so the others' composer streams sit in the
+        # wait for its slot while their render streams run on: only brmi_compose_wait_source keeps the next frame's shading off rows that are not copied yet.
+        staged = [torch.from_numpy(surface_bytes(rank, f, nbytes)).to(dev) for f in range(frames)]
+        torch.cuda.synchronize()
+        step = 32 // slabs
+        for f in range(frames):
+            if rank == 1 and f == 1:
+                time.sleep(0.5)
+            if not os.environ.get("BRMI_TEST_SKIP_WAIT_SOURCE"):
+                comp.wait_source()
+            surf.copy_(staged[f], non_blocking=True)
+            for k in range(slabs):
+                comp.submit_rows(band[0] + k * step, band[0] + (k + 1) * step)
+        last = comp.finish()
+        torch.cuda.synchronize()
+        comp.wait_status()
+        np.save(os.path.join(scratch, f"composed_{rank}.npy"), last.cpu().numpy())
+        np.save(os.path.join(scratch, f"composed_prev_{rank}.npy"), comp.slot_image((frames - 2) % 2).cpu().numpy())      # the frame before the last is still in the other slot
+        frames = 0
     for f in range(frames):
         surf.copy_(torch.from_numpy(surface_bytes(rank, f, nbytes)).to(dev))
         if rank == 1 and f == 1:
@@ -56,8 +78,9 @@ def main():
             comp.submit()
         last = comp.finish()
         torch.cuda.synchronize()
-    comp.wait_status()
-    np.save(os.path.join(scratch, f"composed_{rank}.npy"), last.cpu().numpy())
+    if not pipelined:
+        comp.wait_status()
+        np.save(os.path.join(scratch, f"composed_{rank}.npy"), last.cpu().numpy())
     # both ranks keep their buffers mapped until the other one is done reading
     open(os.path.join(scratch, f"done_{rank}"), "w").close()
     t0 = time.time()

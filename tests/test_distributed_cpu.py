@@ -106,7 +106,9 @@ def test_interleaved_partition_is_a_partition_of_the_rows():
     come in whole chunks, and the chunk a rank owns inside a group runs back and forth from group to group."""
     sys.path.insert(0, ROOT)
     from basicrenderer_amd import compose
-    for n, H, rows in ((8, 1088 * 8, 64), (4, 1088 * 4, 16), (2, 64, 16), (3, 288, 32)):
+    strong = [(n,) + (compose.strong_frame(n)[0][1], compose.strong_frame(n)[1]) for n in (2, 4, 8)]      # bench.py's strong leg: 3840 x 2176 in chunks of 64 / 32 / 16 rows
+    assert strong == [(2, 2176, 64), (4, 2176, 32), (8, 2176, 16)] and compose.strong_frame(1) == ((3840, 2176), 0)
+    for n, H, rows in [(8, 1088 * 8, 64), (4, 1088 * 4, 16), (2, 64, 16), (3, 288, 32)] + strong:
         seen = np.zeros(H, dtype=int)
         for r in range(n):
             fr = compose.stripe_frame_rows(r, n, H, rows)

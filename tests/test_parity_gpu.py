@@ -692,7 +692,9 @@ def test_full_size_band_split_against_the_oracle(preset, lights, n, kw):
 
 @pytest.mark.parametrize("preset,lights,n,rows,kw", [("bistro", 256, 4, 64, dict(unique_budget=True, lod_builder="own", relief_slope=1.5)),   # the bench's N = 4 frame, its default chunk height
                                                      ("bistro", 256, 8, 16, dict()),                                                          # the finest interleave, eight ranks
-                                                     ("san_miguel", 256, 2, 272, dict(material_features=24))])                                # alpha-tested clusters across chunk boundaries
+                                                     ("san_miguel", 256, 2, 272, dict(material_features=24)),                                 # alpha-tested clusters across chunk boundaries
+                                                     ("san_miguel", 256, 8, 64, dict(material_features=24)),                                  # round 5: bench.py --gpus 8's weak leg (configs[3]'s scene, 7680 x 8704)
+                                                     ("san_miguel", 256, 8, 0, dict(material_features=24))])                                  # ... and its strong leg: THE 4K frame (3840 x 2176) in chunks of 16 rows
 def test_full_size_interleaved_partition_against_the_oracle(preset, lights, n, rows, kw):
     """bench.py --gpus N's default partition at its real size on one GPU: the 7680 x (1088 N) frame, every rank's interleaved share (compact
     surfaces, occlusion culling on, two frames each) against the oracle's full frame: triangle identities, depth and lit bytes of the rows
@@ -702,6 +704,8 @@ def test_full_size_interleaved_partition_against_the_oracle(preset, lights, n, r
     from conftest import Scene
     from basicrenderer_amd.renderer import VisibilityRenderer
     W, H = compose.frame_size(n, "stripes")
+    if rows == 0:
+        (W, H), rows = compose.strong_frame(n)          # (rows = 0 selects the strong leg's frame and chunk height)
     sc = Scene(preset, W, H, point_lights=lights, **kw)
     o = orc.OracleFrame(sc).run()
     fa, fb, fd = orc.canonical_ids(o.vis, o.clusters[: o.count])
@@ -851,6 +855,39 @@ def test_peer_write_composer_with_four_processes_and_row_slabs(transport, slabs,
     for r in range(world):
         got = np.load(os.path.join(str(tmp_path), f"composed_{r}.npy"))
         assert np.array_equal(got, want), f"rank {r}: composed image differs"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("transport,slabs", [("surface", 2), ("rgb16f", 4)])
+def test_peer_write_composer_pipelined_frames_with_a_late_peer(transport, slabs, tmp_path):
+    """Round 5 (the advisor's round-4 finding): brmi_compose_submit_rows reads the source surface on the composer's stream, and nothing ordered the NEXT
+    write of that surface behind those reads.  Two processes, four frames, no host wait between frames: a frame's "shading" is a device copy into the one
+    surface on the render stream, rank 1 arrives half a second late for frame 1 -- so rank 0's composer stream sits in the wait for rank 1's slot while
+    its render stream runs ahead into frame 2.  brmi_compose_wait_source holds that frame's write back; without it (BRMI_TEST_SKIP_WAIT_SOURCE=1 in the
+    worker) rank 0's band of the frame before the last comes out with a later frame's bytes.  Both images still held at the end -- the last frame's and
+    the one before -- must be the two ranks' bands of THEIR frame, byte for byte."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import peer_compose_worker as w
+    world, frames = 2, 4
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "peer_compose_worker.py"), ROOT, str(tmp_path), str(r), str(world), transport, str(frames), str(slabs), "pipelined"],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    outs = [p.communicate(timeout=600)[0].decode(errors="replace") for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    W, rows = 256, 32 * world
+    nbytes = (W // 8) * (rows // 8) * 64 * 8
+    band_bytes = nbytes // world
+    for name, frame in (("composed", frames - 1), ("composed_prev", frames - 2)):
+        want = []
+        for r in range(world):
+            b = w.surface_bytes(r, frame, nbytes)[r * band_bytes:(r + 1) * band_bytes]
+            want.append(b.view(np.int16).reshape(-1, 4)[:, :3].copy() if transport == "rgb16f" else b)
+        want = np.concatenate(want)
+        for r in range(world):
+            got = np.load(os.path.join(str(tmp_path), f"{name}_{r}.npy"))
+            assert np.array_equal(got, want), f"rank {r}: image of frame {frame} differs"
 
 
 @pytest.mark.parametrize("transport", ["surface", "rgb16f"])

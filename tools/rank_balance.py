@@ -24,6 +24,9 @@ def main():
     ap.add_argument("--stripe-rows", type=int, default=0, help="> 0: the in-kernel interleaved partition (brmi_config::stripe*) with chunks of this many rows, one pass ring per rank, "
                                                                 "on a frame of 1088 rows per rank (1080 has no multiple of 16 among its divisors)")
     ap.add_argument("--workload", default="bistro")
+    ap.add_argument("--leg", default=None, choices=["weak", "strong"],
+                    help="round 5: one of bench.py --gpus N's two legs (multi_gpu_legs) with its frame and chunk height -- weak: 7680 x 1088 N in chunks of 64 rows; strong: the "
+                         "4K frame, 3840 x 2176, in chunks of 128 / N rows -- and the one-GPU frame it is measured against, timed in the same call (`n1_ms`)")
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--frames-in-flight", type=int, default=2)
     ap.add_argument("--only", type=int, nargs="*", help="ranks to measure (default: all)")
@@ -35,7 +38,13 @@ def main():
     dev = torch.device("cuda:0")
     n, K, fif = args.ranks, args.chunks, args.frames_in_flight
     W, H = compose.frame_size(n)
-    if args.stripe_rows:
+    ref_frame = None
+    if args.leg == "weak":
+        (W, H), args.stripe_rows, ref_frame = compose.frame_size(n, "stripes"), args.stripe_rows or 64, compose.frame_size(1)
+    elif args.leg == "strong":
+        (W, H), args.stripe_rows = compose.strong_frame(n)
+        ref_frame = (W, H)
+    elif args.stripe_rows:
         H = 1088 * n
     preset, kw, features = bench.WORKLOADS[args.workload]
     scene = Scene(preset, W, H, point_lights=bench.LIGHTS[args.workload], directional=True, material_features=features, **kw)
@@ -46,6 +55,26 @@ def main():
     geo = [torch.cuda.Stream(dev, priority=-1) for _ in range(K)]
     shade = [[torch.cuda.Stream(dev, priority=0) for _ in range(fif)] for _ in range(K)]
     out = {"ranks": n, "stripe_rows": args.stripe_rows, "chunks_per_rank": K, "rows_per_chunk": rows, "frame": [W, H], "workload": args.workload, "frames_in_flight": fif, "per_rank": []}
+    if args.leg:
+        out["leg"] = args.leg
+    if ref_frame is not None:
+        # the one-GPU frame the leg is measured against (bench.py: n1_reference), same arrangement, same call
+        ref_scene = scene if ref_frame == (W, H) else Scene(preset, ref_frame[0], ref_frame[1], point_lights=bench.LIGHTS[args.workload], directional=True, material_features=features, **kw)
+        ring = [VisibilityRenderer(ref_scene, device=dev, stats=(j == 0), occlusion=True) for j in range(fif)]
+        for j in range(fif):
+            ring[j].set_history_source(ring[(j - 1) % fif])
+        for i in range(10 + args.steps):
+            if i == 10:
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+            p = ring[i % fif]
+            with torch.cuda.stream(geo[0]):
+                p.update(); p.execute(shade[0][i % fif])
+        torch.cuda.synchronize()
+        out["n1_ms"], out["n1_frame"] = round((time.perf_counter() - t0) / args.steps * 1e3, 4), list(ref_frame)
+        for p in ring:
+            p.close()
+        del ring, ref_scene
+        torch.cuda.empty_cache()
     for r in (args.only if args.only else range(n)):
         rings = []
         for k in range(K):
@@ -83,6 +112,10 @@ def main():
     t = [x["ms_per_frame"] for x in out["per_rank"]]
     out["max_over_min"] = round(max(t) / min(t), 3)
     out["max_ms"], out["min_ms"], out["mean_ms"] = max(t), min(t), round(sum(t) / len(t), 4)
+    if "n1_ms" in out:
+        # render-side efficiency of the slowest rank: weak = one rank's share of pixels per second against the one-GPU frame's; strong = speed-up / N
+        px_rank, px_ref = W * H / n, out["n1_frame"][0] * out["n1_frame"][1]
+        out["render_side_efficiency"] = round((px_rank / max(t)) / (px_ref / out["n1_ms"]), 4) if args.leg == "weak" else round(out["n1_ms"] / max(t) / n, 4)
     print(json.dumps(out))
 
 
