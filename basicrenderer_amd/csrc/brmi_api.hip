@@ -65,7 +65,7 @@ static void compute_sizes(brmi_pass* p) {
     { const uint32_t t0 = p->bandY0 / 8, t1 = (p->bandY1 + 7) / 8; p->bandFirstPixel = (uint64_t)t0 * p->tilesX * 64; p->bandPixelCount = (uint64_t)(t1 - t0) * p->tilesX * 64; }
     p->numLightClusters = c.lightClusterSize[0] * c.lightClusterSize[1] * c.lightClusterSize[2];
     p->lightPagePool = p->numLightClusters * BRMI_LIGHT_PAGES_PER_CLUSTER;
-    if (const char* e = std::getenv("BRMI_LIGHT_PAGE_POOL")) p->lightPagePool = (uint32_t)std::max(1, std::atoi(e));   // tests: exhaust the page pool
+    if (const long v = tuning("light_page_pool", 0)) p->lightPagePool = (uint32_t)std::max(1l, v);   // tests: exhaust the page pool
     for (int i = 0; i < BRMI_RES_COUNT; i++) p->resNeed[i] = 0;
     for (int i = BRMI_RES_VISIBILITY; i <= BRMI_RES_HDR_COLOR; i++) p->resNeed[i] = p->paddedPixels * kResBpp[i];
     p->resNeed[BRMI_RES_VISIBLE_CLUSTERS] = (uint64_t)c.maxVisibleClusters * 16;
@@ -127,26 +127,16 @@ static void compute_sizes(brmi_pass* p) {
     // that several workgroups walk (2048 tiles = 64 MB: a 4K frame whose every bin is full would want 16 k; bins beyond merge with atomics)
     p->binItemCapacity = p->binsX * p->binsY * std::max(1u, (p->binCapacity + 31u) / 32u > 256u ? 256u : (p->binCapacity + 31u) / 32u);
     p->binItemCapacity = std::min<uint32_t>(p->binItemCapacity, 1u << 22);
-    if (const char* e = std::getenv("BRMI_BIN_SCRATCH_TILES")) p->binScratchTiles = (uint32_t)std::max(0, std::atoi(e));
+    p->binScratchTiles = (uint32_t)std::max(0l, tuning("bin_scratch_tiles", p->binScratchTiles));
     w.binPlan = take((uint64_t)(16 + 3 * p->binsX * p->binsY) * 4);
     w.binItems = take((uint64_t)p->binItemCapacity * 4);
     w.binScratch = take((uint64_t)std::max(1u, p->binScratchTiles) * 4096 * 8);
-    raster_tile_grid(c.width, c.height, &p->rtilesX, &p->rtilesY);
-    // the opt-in tile rasteriser's buffers (BRMI_RASTER_MODE=tiles, known since brmi_create): only a pass that runs it reserves them -- the screen-vertex
-    // cache alone is 1.5 KB per visible cluster, up to 3.2 GB per pass, and brmi_setup clears the whole workspace
-    const bool tiles = p->rasterTiles;
-    w.tileCounts = take(tiles ? (uint64_t)p->rtilesX * p->rtilesY * 4 : 16);
-    w.tileLists = take(tiles ? (uint64_t)p->rtilesX * p->rtilesY * p->tileCapacity * 16 : 16);
-    p->xvertClusters = tiles ? (uint32_t)std::min<uint64_t>(c.maxVisibleClusters, 1ull << 21) : 0u;
-    if (const char* e = std::getenv("BRMI_XVERT_CLUSTERS")) if (tiles) p->xvertClusters = (uint32_t)std::max(0, std::atoi(e));   // tests: clusters beyond the cache take the overflow path
-    w.xverts = take((uint64_t)std::max(1u, p->xvertClusters) * 3 * BRMI_MESHLET_MAX_VERTS * 4);
-    w.tileOverflow = take(tiles ? (uint64_t)p->tileOverflowCapacity * 8 : 16);
     w.debugStamps = take(4096 + 1024 * 1024);      // instrumented builds (-DBRMI_TILE_STAMPS, possibly of one translation unit only) park per-phase cycle sums here
     w.clusterSetup = take((uint64_t)c.maxVisibleClusters * sizeof(ClusterSetup));
     // resolve arena: full tables (72 B per vertex + triangle slot) for up to 2^20 clusters = 9.7 GB of the 288; a configuration
     // that allows more visible clusters keeps the per-pixel path for the clusters that do not fit
     p->resolveCapacity = (uint32_t)std::min<uint64_t>((uint64_t)c.maxVisibleClusters, 1ull << 20) * BRMI_MESHLET_MAX_TRIS;
-    if (const char* e = std::getenv("BRMI_RESOLVE_CAPACITY")) p->resolveCapacity = (uint32_t)std::max(1, std::atoi(e));   // tests: force the per-pixel fallback
+    if (const long v = tuning("resolve_capacity", 0)) p->resolveCapacity = (uint32_t)std::max(1l, v);   // tests: force the per-pixel fallback
     w.resolveVerts = take((uint64_t)p->resolveCapacity * sizeof(ResolveVertex));
     w.resolveTris = take((uint64_t)p->resolveCapacity * sizeof(ResolveTriangle));
     w.shadeTables = take(((uint64_t)2 * c.width + 2 * c.height + 64) * 4);
@@ -222,6 +212,33 @@ void brmi_default_config(brmi_config* cfg, uint32_t width, uint32_t height) {
     cfg->keepUniformLayerPlanes = 0;          // opt-in: every plane is written every frame unless the host says the planes are its to keep
 }
 
+}  // extern "C"
+namespace brmi {
+// BRMI_TUNING="key=value,key=value": looked up on every call (a test sets it around the creation of one pass; nothing here is on a frame's path)
+static bool tuning_lookup(const char* key, long* out) {
+    const char* e = std::getenv("BRMI_TUNING");
+    if (!e) return false;
+    const size_t n = std::strlen(key);
+    for (const char* q = e; *q; ) {
+        while (*q == ',' || *q == ' ') q++;
+        const char* end = std::strchr(q, ',');
+        const size_t len = end ? (size_t)(end - q) : std::strlen(q);
+        if (len > n && std::strncmp(q, key, n) == 0 && q[n] == '=') { *out = std::strtol(q + n + 1, nullptr, 0); return true; }
+        q += len;
+    }
+    return false;
+}
+long tuning(const char* key, long def) { long v; return tuning_lookup(key, &v) ? v : def; }
+long experiment(const char* key, long def) {
+#ifdef BRMI_EXPERIMENTS
+    long v; return tuning_lookup(key, &v) ? v : def;
+#else
+    (void)key; return def;
+#endif
+}
+}  // namespace brmi
+extern "C" {
+
 int brmi_create(const brmi_config* cfg, brmi_pass** out) {
     if (!cfg || !out || cfg->structSize != sizeof(brmi_config) || cfg->width == 0 || cfg->height == 0) return BRMI_ERR_INVALID;
     if (cfg->maxVisibleClusters == 0 || cfg->maxVisibleClusters > (1u << 26) || cfg->maxTraversalRecords == 0) return BRMI_ERR_INVALID;
@@ -235,30 +252,27 @@ int brmi_create(const brmi_config* cfg, brmi_pass** out) {
     brmi_pass* p = new brmi_pass();
     p->cfg = *cfg;
     p->totalWords = 1; p->scanBlocks = 1;
-    if (const char* e = std::getenv("BRMI_CULL_LEVEL_KERNELS")) p->forceLevelKernels = std::atoi(e) != 0;
-    if (const char* e = std::getenv("BRMI_RASTER_GRID")) p->rasterGrid = (uint32_t)std::max(64, std::atoi(e));
-    if (const char* e = std::getenv("BRMI_SHADE_GRID_SHARED")) p->shadeGridShared = (uint32_t)std::min(65535, std::max(256, std::atoi(e)));
-    if (const char* e = std::getenv("BRMI_GBUFFER_GRID_SHARED")) p->gbufferGridShared = (uint32_t)std::min(65535, std::max(256, std::atoi(e)));
-    if (const char* e = std::getenv("BRMI_PHASE2_DIRECT_MAX")) p->phase2DirectMax = (uint32_t)std::max(0, std::atoi(e));
-    if (const char* e = std::getenv("BRMI_CLEAR_RIDER_BLOCKS")) p->clearRiderBlocks = (uint32_t)std::min(65535, std::max(64, std::atoi(e)));
-    if (const char* e = std::getenv("BRMI_FLAT_WIDE")) p->wideFlat = std::atoi(e) != 0;
-    if (const char* e = std::getenv("BRMI_SCAN_CHAINED")) p->scanChained = std::atoi(e) != 0;
-    if (const char* e = std::getenv("BRMI_FLAT_PACKED")) p->packedFlat = std::atoi(e) != 0;
-    if (const char* e = std::getenv("BRMI_FLAT_LEVELS_MIN_DRAWS")) p->flatLevelsMinDraws = (uint32_t)std::max(0, std::atoi(e));      // (tests: 1 = the level-synchronous flat traversal for every scene; a huge value = never)
-    if (const char* e = std::getenv("BRMI_BIN_MIN_SLICE")) p->binMinSlice = (uint32_t)std::max(32, std::atoi(e));
-    if (const char* e = std::getenv("BRMI_BIN_SHARED_SLICE")) p->binSharedSlice = (uint32_t)std::max(32, std::atoi(e));
-    if (const char* e = std::getenv("BRMI_BIN_GRID")) p->binGrid = (uint32_t)std::min(65535, std::max(1, std::atoi(e)));
-    if (const char* e = std::getenv("BRMI_FUSE_SHADE")) p->fuseShadeOptIn = std::atoi(e) != 0;
-    if (const char* e = std::getenv("BRMI_SPILL_WIDTH")) p->spillWidth = (uint32_t)std::min(1024, std::max(128, std::atoi(e)));
-    if (const char* e = std::getenv("BRMI_RASTER_DEBUG")) p->rasterDebug = std::atoi(e);
-    if (const char* e = std::getenv("BRMI_BIN_OVERFLOW")) p->binOverflowPerStripe = (uint32_t)std::max(0, std::atoi(e));
-    if (const char* e = std::getenv("BRMI_BIN_CAPACITY")) p->binCapacity = (uint32_t)std::min(65536, std::max(1, std::atoi(e)));   // 16-bit record indices inside a bin slice's alpha list; 65536 x 64 B x bins is far beyond any frame
-    if (const char* e = std::getenv("BRMI_BIG_TRI_AREA")) p->bigTriArea = p->bigTriAreaAlpha = p->bigTriAreaDense = std::max(1, std::atoi(e));
-    if (const char* e = std::getenv("BRMI_TILE_CAPACITY")) p->tileCapacity = (uint32_t)std::max(1, std::atoi(e));
-    if (const char* e = std::getenv("BRMI_TILE_SLICE")) p->tileMinSlice = (uint32_t)std::max(1, std::atoi(e));
-    if (const char* e = std::getenv("BRMI_TILE_OVERFLOW")) p->tileOverflowCapacity = (uint32_t)std::max(1, std::atoi(e));
-    if (const char* e = std::getenv("BRMI_RASTER_MODE")) p->rasterTiles = std::string(e) == "tiles";
-    if (const char* e = std::getenv("BRMI_BIG_TRI_AREA_ALPHA")) p->bigTriAreaAlpha = std::max(1, std::atoi(e));
+    // sizes and switches a test (or a user) may set: BRMI_TUNING="key=value,..." 
+    p->forceLevelKernels = tuning("cull_level_kernels", 0) != 0;
+    p->packedFlat = tuning("flat_packed", 1) != 0;
+    p->flatLevelsMinDraws = (uint32_t)std::max(0l, tuning("flat_levels_min_draws", p->flatLevelsMinDraws));      // (tests: 1 = the level-synchronous flat traversal for every scene)
+    p->phase2DirectMax = (uint32_t)std::max(0l, tuning("phase2_direct_max", p->phase2DirectMax));
+    p->binMinSlice = (uint32_t)std::max(32l, tuning("bin_min_slice", p->binMinSlice));
+    p->binSharedSlice = (uint32_t)std::max(32l, tuning("bin_shared_slice", p->binSharedSlice));
+    p->binGrid = (uint32_t)std::min(65535l, std::max(1l, tuning("bin_grid", p->binGrid)));
+    p->binOverflowPerStripe = (uint32_t)std::max(0l, tuning("bin_overflow", p->binOverflowPerStripe));
+    p->binCapacity = (uint32_t)std::min(65536l, std::max(1l, tuning("bin_capacity", p->binCapacity)));   // 16-bit record indices inside a bin slice's alpha list; 65536 x 64 B x bins is far beyond any frame
+    if (const long v = tuning("big_tri_area", 0)) p->bigTriArea = p->bigTriAreaAlpha = p->bigTriAreaDense = (int)std::max(1l, v);
+    // A/B switches of the experiment logs: only in builds with -DBRMI_EXPERIMENTS
+    p->rasterGrid = (uint32_t)std::max(64l, experiment("raster_grid", p->rasterGrid));
+    p->shadeGridShared = (uint32_t)std::min(65535l, std::max(256l, experiment("shade_grid_shared", p->shadeGridShared)));
+    p->gbufferGridShared = (uint32_t)std::min(65535l, std::max(256l, experiment("gbuffer_grid_shared", p->gbufferGridShared)));
+    p->clearRiderBlocks = (uint32_t)std::min(65535l, std::max(64l, experiment("clear_rider_blocks", p->clearRiderBlocks)));
+    p->wideFlat = experiment("flat_wide", 1) != 0;
+    p->scanChained = experiment("scan_chained", 1) != 0;
+    p->spillWidth = (uint32_t)std::min(1024l, std::max(128l, experiment("spill_width", p->spillWidth)));
+    p->rasterDebug = (int)experiment("raster_debug", 0);
+    if (const long v = experiment("big_tri_area_alpha", 0)) p->bigTriAreaAlpha = (int)std::max(1l, v);
     compute_sizes(p);
     *out = p;
     return BRMI_OK;
@@ -447,7 +461,7 @@ int brmi_set_scene(brmi_pass* p, const brmi_scene_buffers* scene) {
         if ((rc2 = read_back(p, pms, sc.perMesh, sc.perMeshCount))) return rc2;
         p->hostFlatNodes.clear(); p->hostFlatLeaves.clear(); p->flatMaxDepth = 1;
         std::vector<uint32_t> flatBase(md.size(), 0), flatCount(md.size(), 0);
-        const bool flatOn = std::getenv("BRMI_FLAT_TRAVERSAL") ? std::atoi(std::getenv("BRMI_FLAT_TRAVERSAL")) != 0 : true;
+        const bool flatOn = tuning("flat_traversal", 1) != 0;
         std::vector<std::pair<uint32_t, uint32_t>> bfs;      // (node id, parent position)
         for (size_t m = 0; flatOn && m < md.size(); m++) {
             bfs.clear(); bfs.push_back({md[m].rootNode, 0u});
@@ -629,8 +643,8 @@ int brmi_update(brmi_pass* p, const brmi_frame_update* u, brmi_stream stream) {
 // What a frame's first launch has to wait for when frames are in flight (brmi_execute_split, and the stage entry points that start a frame:
 // a graph that schedules the stages itself after a split frame gets the same ordering).  No-ops when nothing was recorded.
 // flags of the events that order the two halves of split frames (experiments: BRMI_EVENT_FLAGS, e.g. 0x2 | 0x40000000 = no timing, device-scope release)
-static unsigned sync_event_flags() { static const unsigned f = [] { const char* e = std::getenv("BRMI_EVENT_FLAGS"); return e ? (unsigned)std::strtoul(e, nullptr, 0) : (unsigned)hipEventDisableTiming; }(); return f; }
-static int dbg_events() { static const int m = [] { const char* e = std::getenv("BRMI_DEBUG_EVENTS"); return e ? std::atoi(e) : 0; }(); return m; }      // (experiments only: events NOT issued)
+static unsigned sync_event_flags() { static const unsigned f = (unsigned)experiment("event_flags", (long)hipEventDisableTiming); return f; }
+static int dbg_events() { static const int m = (int)experiment("debug_events", 0); return m; }      // (builds with -DBRMI_EXPERIMENTS only: events NOT issued)
 static int wait_for_frames_in_flight(brmi_pass* p, brmi_stream stream) {
     if (p->frameWaitsIssued) return BRMI_OK;      // brmi_execute_split has issued them for this frame: the stage entry points it calls do not repeat them
     // this pass's previous frame may still be resolving / shading on the other stream: its visibility buffer and tables are about to be rewritten
@@ -740,15 +754,15 @@ int brmi_execute_split(brmi_pass* p, brmi_stream stream, brmi_stream shadeStream
     p->frameWaitsIssued = true;
     // When the phase-1 traversal is the one-launch LDS walk and the frame constants are due anyway, the frame needs no clear launch: the
     // constants kernel zeroes the culling state and the walk's launch carries the visibility clear (brmi_cull.hip, SideClear).
-    static const bool rideEnv = [] { const char* e = std::getenv("BRMI_CLEAR_RIDES"); return !e || std::atoi(e) != 0; }();
+    static const bool rideEnv = experiment("clear_rides", 1) != 0;
     const bool rides = rideEnv && p->constantsSerial != p->updateSerial && p->minLevelWidth <= 1024u /* the one-launch walk runs (brmi_cull.hip: HIER_CAP_MAX) */ && !p->forceLevelKernels && p->scene.activeDrawCount != 0u;
     p->lightGridDone = false;
     // A split frame (round 4): the riders move to where they fit -- the visibility clear onto k_cull_clusters' launch (brmi_cull.hip: ClearRide), the
     // light clustering onto the shading stream, which is idle until this frame's pixel pass (below, behind the same event as the early resolve setup).
-    static const bool sideEnv = [] { const char* e = std::getenv("BRMI_SIDE_RIDERS"); return !e || std::atoi(e) != 0; }();
+    static const bool sideEnv = experiment("side_riders", 1) != 0;
     // where the per-cluster resolve tables of a split frame are made (BRMI_EARLY_RESOLVE_SETUP): 0 = at the end of the geometry stream, 1 = for the phase-1
     // clusters on the shading stream beside the rasteriser (an event after the culling), 2 = on the shading stream in front of the pixel pass (no event)
-    static const int setupWhere = [] { const char* e = std::getenv("BRMI_EARLY_RESOLVE_SETUP"); return e ? std::atoi(e) : 1; }();
+    static const int setupWhere = (int)experiment("early_resolve_setup", 1);
     const bool earlySetup = split && setupWhere == 1 && !resolve_setup_marks(p);
     const bool lateSetup = split && setupWhere == 2;
     const bool sideRiders = rides && split && sideEnv && (p->bandPixelCount & 1ull) == 0ull;
@@ -801,10 +815,6 @@ int brmi_execute_split(brmi_pass* p, brmi_stream stream, brmi_stream shadeStream
         if (!p->chainReady) BRMI_HIP(p, hipEventCreateWithFlags(&p->chainReady, sync_event_flags()));
         if (!(dbg_events() & 2)) { BRMI_HIP(p, hipEventRecord(p->chainReady, static_cast<hipStream_t>(stream))); p->chainRecorded = true; p->chainStream = stream; }
     }
-    // BRMI_FUSE_SHADE=1 (off by default): one pass over the pixels for G-buffer + shading where the G-buffer kernel is the lean one
-    // (brmi_resolve.hip: k_gbuffer_shade); the light lists must exist by then.  Measured: 338 us against 103 + 236 us for the two kernels on
-    // the Bistro-class 4K frame -- both are bound by VALU issue (the G-buffer kernel at six waves per SIMD as well), so not reading the
-    // 48 B per pixel back buys 6 us of the frame.  Kept as a tested variant, not as the default: the two-kernel frame is what the profiles describe.
     if (split) {
         if (!lateSetup) {
             if ((rc = launch_resolve_setup(p, static_cast<hipStream_t>(stream), earlySetup ? 2u : 0u))) return rc;
@@ -818,18 +828,15 @@ int brmi_execute_split(brmi_pass* p, brmi_stream stream, brmi_stream shadeStream
         }
         stream = shadeStream;
     }
-    const bool fuseEnv = p->fuseShadeOptIn;
-    bool lightsDone = p->lightGridDone;      // the culling pass's launches carried the light clustering
+    const bool lightsDone = p->lightGridDone;      // the culling pass's launches carried the light clustering
     p->lightGridDone = false;
-    if (fuseEnv && !lightsDone) { if ((rc = brmi_light_clustering(p, stream))) return rc; lightsDone = true; }
-    p->fuseShadeIntoGBuffer = fuseEnv; p->plainPixelsShaded = false;
     p->depthFinal = p->cfg.enableOcclusionCulling != 0;
     p->shadeSharesChip = split;
-    // (experiments only: BRMI_DEBUG_SKIP bit 0 drops the shading launch, bit 1 the G-buffer launch of brmi_execute -- what the other half costs without them)
-    static const int skipDbg = [] { const char* e = std::getenv("BRMI_DEBUG_SKIP"); return e ? std::atoi(e) : 0; }();
+    // (builds with -DBRMI_EXPERIMENTS only: debug_skip bit 0 drops the shading launch, bit 1 the G-buffer launch of brmi_execute -- what the other half costs without them)
+    static const int skipDbg = (int)experiment("debug_skip", 0);
     rc = (skipDbg & 2) ? BRMI_OK : brmi_gbuffer(p, stream);
     p->shadeSharesChip = false;
-    p->fuseShadeIntoGBuffer = false; p->depthFinal = false;
+    p->depthFinal = false;
     if (rc) return rc;
     if (!lightsDone && (rc = brmi_light_clustering(p, stream))) return rc;
     p->shadeSharesChip = split;

@@ -146,7 +146,7 @@ struct LayerUniform { unsigned long long coatWord, fuzzWord, coatFilledWord, fuz
 struct Workspace {     // byte offsets into BRMI_RES_WORKSPACE
     uint64_t counters, frontierA, frontierB, buckets, tempVisible, bitmask1, bitmask2, blockDirty, wordPrefix, blockSums,
              instanceBitBase, segPrefix, meshLevelWidth, scanAgg, flatNodes, flatLeaves, instanceWalk, planes, replayNodes, replayBuckets, lightVS, lightMeta, clusterPages, clusterHits, pageTotal, lightHitMasks, binCounts, binRecords, binOverflow, binPlan, binItems, binScratch, clusterSetup, resolveVerts, resolveTris, matWords, shadeTables, lutF, frameConst, objConst, matConst, deferredPixels, usedClusters,
-             frameSnapshot, tileCounts, tileLists, tileOverflow, xverts, debugStamps, clusterUv, binAlpha, overflowAlpha, resolveUVs, resolveColors, alphaMats, shadeRows, shadeAvgs, ggxQuads, shadeLights, clusterList, listEntries, listRecords, layerUniform, frameClearBytes, total;
+             frameSnapshot, debugStamps, clusterUv, binAlpha, overflowAlpha, resolveUVs, resolveColors, alphaMats, shadeRows, shadeAvgs, ggxQuads, shadeLights, clusterList, listEntries, listRecords, layerUniform, frameClearBytes, total;
 };
 
 }  // namespace brmi
@@ -204,8 +204,6 @@ struct brmi_pass {
     uint32_t shadeGridShared = 10240; // workgroups of k_shade<0, 3> (BRMI_SHADE_GRID_SHARED): shorter-lived than the stand-alone 8192 so that the other frame's small geometry launches find slots sooner (Bistro-class period 6144 / 8192 / 10240 / 12288: 0.547 / 0.539 / 0.530 / 0.531 ms; Sponza-class, whose geometry half is short: 0.386 / 0.398 / 0.398 / 0.397)
     uint32_t gbufferGridShared = 4096; // workgroups of the lean k_gbuffer in a split frame (BRMI_GBUFFER_GRID_SHARED)
     bool shadeSharesChip = false;    // brmi_execute_split with two streams: the shading half runs beside another frame's geometry half
-    bool fuseShadeOptIn = false;     // BRMI_FUSE_SHADE=1 at brmi_create
-    bool fuseShadeIntoGBuffer = false, plainPixelsShaded = false;   // brmi_execute: k_gbuffer_shade shades the plain pixels as it writes the G-buffer
     bool lightGridDone = false;      // this frame's light clustering ran inside the culling pass's launches
     bool clearVisibilityWithClusterCull = false;      // brmi_execute_split on two streams: the clear rides on k_cull_clusters instead (brmi_cull.hip: ClearRide)
     bool clearFrameStateWithConstants = false, clearVisibilityWithTraversal = false;   // brmi_execute: no clear launch (brmi_frame.hip, brmi_cull.hip)
@@ -220,9 +218,6 @@ struct brmi_pass {
     uint32_t binsX = 0, binsY = 0, binCapacity = 16384;  // raster bins: 256 px x 16 rows, binCapacity records of 64 B each (BRMI_BIN_CAPACITY): 2 GB at 4K, walked in slices of 1024.
                                                          // Round 5: 8192 -> 16384 -- rank 0 of the 8-GPU San-Miguel-class frame owns a double chunk on the horizon whose bins take
                                                          // > 8192 records of alpha-tested leaves; the overflow queues' global-atomic walk made it 1.67 ms against the others' 1.05 (1.18 now)
-    bool rasterTiles = false;     // BRMI_RASTER_MODE=tiles (opaque scenes): cluster-granular sort-middle (k_raster_tile_lists / k_raster_tiles) instead of the triangle bins -- bit-exact, a fifth of the HBM traffic, 20-40 % slower (profiles/r03_experiments.md)
-    uint32_t rtilesX = 0, rtilesY = 0, tileCapacity = 1024, tileOverflowCapacity = 1u << 20, tileMinSlice = 128;
-    uint32_t xvertClusters = 0;   // clusters the screen-vertex cache holds (1.5 KB each): min(maxVisibleClusters, 2^21); BRMI_XVERT_CLUSTERS   // 64 x 64 px raster tiles, cluster indices per tile list (BRMI_TILE_CAPACITY)
     uint32_t deferredStripeCapacity = 0;   // entries per deferred-pixel stripe
     uint32_t resolveCapacity = 0;   // vertices (and triangles) the resolve arena holds
     uint32_t rasterGrid = 8192;  // single-wave workgroups of k_raster (BRMI_RASTER_GRID)
@@ -268,6 +263,11 @@ struct brmi_pass {
 namespace brmi {
 
 int fail(brmi_pass* p, int code, const char* fmt, ...);
+// ONE environment variable, BRMI_TUNING="key=value,key=value" (DESIGN.md 6b).  tuning(): the keys a user or a test may set (sizes that force the rare
+// paths); experiment(): keys that only exist in builds with -DBRMI_EXPERIMENTS (A/B switches of the measurements in profiles/*_experiments.md:
+// they can drop events or launches and give wrong images) -- a product build returns the default whatever the environment says.
+long tuning(const char* key, long def);
+long experiment(const char* key, long def);
 #define BRMI_HIP(p, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return brmi::fail((p), BRMI_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); } while (0)
 #define BRMI_LAUNCH_CHECK(p, what) do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return brmi::fail((p), BRMI_ERR_HIP, "launch %s: %s", (what), hipGetErrorString(e_)); } while (0)
 
@@ -278,7 +278,6 @@ ShadeTables shade_tables_of(const brmi_pass* p);
 int launch_clear(brmi_pass* p, hipStream_t s);
 int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s);
 int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s);
-void raster_tile_grid(uint32_t width, uint32_t height, uint32_t* tilesX, uint32_t* tilesY);      // tiles of the cluster-granular rasteriser (brmi_raster.hip)
 int launch_depth_copy(brmi_pass* p, hipStream_t s);
 int launch_hzb(brmi_pass* p, hipStream_t s, bool fromVisibility, bool onlyIfPhase2Drew);
 int launch_gbuffer(brmi_pass* p, hipStream_t s);

@@ -241,7 +241,7 @@ ShadeArgs shade_args_of(brmi_pass* p) {
 static int launch_shade_range(brmi_pass* p, hipStream_t s, uint32_t row0, uint32_t row1, uint32_t share);
 int launch_shade(brmi_pass* p, hipStream_t s) {
     if (int rc = ensure_frame_constants(p, s)) return rc;
-    if (p->shadeSlabs > 1u && p->shadeSlabFn && !p->plainPixelsShaded) {
+    if (p->shadeSlabs > 1u && p->shadeSlabFn) {
         // brmi_set_shade_slabs: the band in slabs of whole 8-row tile rows, top to bottom; after each slab's launches the host hook (the composition of those rows)
         const uint32_t y0 = p->bandY0, y1 = p->bandY1, tileRows = (y1 - y0 + 7u) / 8u, n = std::min(p->shadeSlabs, std::max(1u, tileRows));
         for (uint32_t k = 0; k < n; k++) {
@@ -263,13 +263,11 @@ static int launch_shade_range(brmi_pass* p, hipStream_t s, uint32_t row0, uint32
         a.bandY0 = row0; a.bandY1 = row1;
     }
     p->shadeSerial++;
-    // inside brmi_execute the plain pixels may have been shaded by the fused G-buffer kernel already (brmi_resolve.hip: k_gbuffer_shade)
-    if (p->plainPixelsShaded) p->plainPixelsShaded = false;
     // 8192 workgroups of four waves, four tiles per wave at 4K: against 4096 (eight tiles per wave) the kernel's tail is shorter (233 -> 226 us)
     // and, with another frame's geometry half in flight beside it, slots come free twice as often for that half's high-priority launches
     // (Bistro 4K, two frames in flight: 0.436 -> 0.413 ms per frame; 16384: 0.425, 2048: 0.49)
-    else {
-        static const uint32_t pad = [] { const char* e = std::getenv("BRMI_SHADE_LDS_PAD"); return e ? (uint32_t)std::atoi(e) : 0u; }();   // (experiment: unused dynamic LDS caps the kernel's occupancy)
+    {
+        static const uint32_t pad = (uint32_t)experiment("shade_lds_pad", 0);   // (builds with -DBRMI_EXPERIMENTS: unused dynamic LDS caps the kernel's occupancy)
         if (p->shadeSharesChip || BRMI_SHADE_WAVES_ALONE == BRMI_SHADE_WAVES) hipLaunchKernelGGL((k_shade<0, BRMI_SHADE_WAVES>), dim3(std::max(256u, p->shadeGridShared / share)), dim3(256), pad, s, a);
         else hipLaunchKernelGGL((k_shade<0, BRMI_SHADE_WAVES_ALONE>), dim3(std::max(256u, 8192u / share)), dim3(256), pad, s, a);
     }

@@ -82,11 +82,7 @@ struct RasterArgs {
     uint32_t visW, visH, tilesX, bandY0, bandY1;      // visW x visH: the FRAME (scissor clamp); bandY0 / bandY1: rows of the surface this GPU renders (records live in surface rows)
     uint32_t rowLo, rowHi;                            // frame rows k_raster looks at: the band, or the whole frame with the interleaved partition ...
     StripeMap stripes;                                // ... whose ownership test and frame row -> surface row mapping this is
-    // cluster-granular sort-middle (k_raster_tile_lists / k_raster_tiles): per 64 x 64 px screen tile a list of visible-cluster indices
-    uint32_t* tileCounts; struct TileEntry* tileLists; uint32_t tileCapacity, rtilesX, rtilesY, tileMinSlice;
     unsigned long long* debugStamps;                     // instrumented builds only
-    float* xverts; uint32_t xvertClusters;               // screen-vertex cache: 384 floats per visible cluster, for clusters [0, xvertClusters)
-    uint2* tileOverflow; uint32_t tileOverflowCapacity;      // (cluster, tile) pairs that found their list full
 };
 
 // `frameState` (may be null): the counters + survivor bitmasks block that the culling pass clears at the start of a frame; brmi_execute
@@ -1233,379 +1229,6 @@ __global__ void __launch_bounds__(256) k_raster_overflow(RasterArgs a) {
 }
 
 
-// ---- cluster-granular sort-middle: screen tiles own their pixels ----------------------------------------------------------------------
-// The paths above move TRIANGLES to where the pixels are: every triangle above a few pixels becomes one 64 B record per 256 x 16 px bin it
-// touches, written to HBM by k_raster and read back by k_raster_bins -- on a frame of pixel-sized triangles that is 1.4 M records (86 MiB
-// out, 57 MiB in: five times the stage's algorithmic bytes) plus a global atomic per pixel of everything that stays below the binning
-// threshold.  Here the unit that travels is a 16 B CLUSTER ENTRY:
-//   k_raster_tile_lists  one wave per visible cluster: vertices to screen space ONCE (softwareRaster.hlsl:339-387; skinning included) into the
-//                        screen-vertex cache (12 B per vertex, structure of arrays per cluster), bounding box of the vertices in front of the
-//                        eye plane (a triangle with a vertex at or behind it is dropped whole, softwareRaster.hlsl:446-451), one entry {cluster,
-//                        counts, index pointer} appended to the list of every 64 x 64 px tile the box touches (one atomic per tile, all of a
-//                        wave's tiles in flight together).
-//   k_raster_tiles       one 512-thread workgroup per tile (and slice of its list), the tile's 4096 keys in LDS.  Each of the eight waves takes
-//                        list entries in turn: the entries of a wave are read with one load up front, the screen vertices and index bytes of
-//                        entry i + 1 are requested before entry i is rasterised (an entry's inputs are two dependent hops away from its list
-//                        slot; measured 17 us per entry and wave without the pipeline).  Lane = triangle for the setup (two passes, the
-//                        reference's wave vote per pass, exactly as k_raster), the rows of the triangles that reach into the tile are re-dealt
-//                        to the lanes, ds_min_u64 per covered pixel.  The tile is merged into the visibility buffer once, 64 B pieces in
-//                        surface order.  A cluster is set up once per tile it touches (2-5 on the dense frames): ~200 instructions per wave
-//                        and pass, against a 64 B record per triangle and bin.
-// No per-pixel global atomic is left on this path, no triangle record exists, and what the stage moves is what it must: cluster records,
-// vertices (twice: object space in, screen space out and back), indices and the keys.  Per-pixel arithmetic is the serial loop's, as
-// everywhere in this file (row starts stepped from the box top, pixels stepped from the row start).
-#ifndef BRMI_RT_W_SHIFT
-#define BRMI_RT_W_SHIFT 8
-#endif
-#ifndef BRMI_RT_H_SHIFT
-#define BRMI_RT_H_SHIFT 4
-#endif
-// tile shape: 4096 keys (32 KB of LDS, 512 merge items of 64 B); wide and low because a row task that enters a triangle's row in the middle
-// steps the barycentrics from the row start -- the serial loop's additions, which cannot be skipped -- so a W px wide triangle costs
-// ~W^2 / (2 x tile width) additions per row: 64 x 64 px tiles spent 74 % of the kernel there (measured with per-phase stamps)
-constexpr int RT_W_SHIFT = BRMI_RT_W_SHIFT, RT_H_SHIFT = BRMI_RT_H_SHIFT, RT_W = 1 << RT_W_SHIFT, RT_H = 1 << RT_H_SHIFT;
-static_assert(RT_W * RT_H == 4096 && RT_H >= 8, "4096 keys per tile, whole 8-row groups");
-constexpr uint32_t RT_THREADS = 512, RT_WAVES = RT_THREADS / 64;
-constexpr uint32_t RT_MAX_SLICE = 64u * RT_WAVES;
-
-
-struct WaveStage {           // one wave's staging area
-    float sx[BRMI_MESHLET_MAX_VERTS], sy[BRMI_MESHLET_MAX_VERTS], sd[BRMI_MESHLET_MAX_VERTS];
-    float tpF[9][64]; int tpI[3][64]; uint32_t rowOff[65];
-#ifdef BRMI_TILE_STAMPS
-    unsigned long long phase[8];      // instrumented builds: cycles per phase of raster_entry (uniform values, every lane stores the same)
-#endif
-};
-
-struct ClusterView { float visWidth, visHeight, sMinXf, sMinYf; int scMinX, scMinY, scMaxX, scMaxY; };
-BRMI_DEV ClusterView cluster_view(const brmi_scene_buffers& sc, uint32_t viewId) {
-    const brmi_view_raster_info ri = sc.viewRasterInfo[viewId];
-    ClusterView v;
-    v.visWidth = (float)(ri.scissorMaxX - ri.scissorMinX); v.visHeight = (float)(ri.scissorMaxY - ri.scissorMinY);
-    v.sMinXf = (float)ri.scissorMinX; v.sMinYf = (float)ri.scissorMinY;
-    v.scMinX = (int)ri.scissorMinX; v.scMinY = (int)ri.scissorMinY; v.scMaxX = (int)ri.scissorMaxX; v.scMaxY = (int)ri.scissorMaxY;
-    return v;
-}
-// one vertex of a cluster in screen space (softwareRaster.hlsl:339-387)
-BRMI_DEV void screen_vertex(const brmi_scene_buffers& sc, const ClusterSetup& cs, const ClusterView& cv, const m4& mvp, const f4& modelViewZ, bool skinVerts, uint32_t skinSlot, uint32_t v,
-                            float& osx, float& osy, float& osd) {
-    const uint32_t posFormat = (cs.counts >> 16) & 0xFFu;
-    f3 lp{0.0f, 0.0f, 0.0f};
-    if (posFormat == BRMI_POSITION_FORMAT_FLOAT3) {
-        const float* pp = reinterpret_cast<const float*>(cs.posBase + v * 12u);
-        lp = f3{pp[0], pp[1], pp[2]};
-    }
-    if (skinVerts) {
-        uint32_t joints[8]; float weights[8];
-        load_skin_influences(cs.nrmBase + cs.jointDelta + v * 32u, (cs.counts & BRMI_CS_WEIGHTS) ? cs.nrmBase + cs.weightDelta + v * 32u : nullptr, joints, weights);
-        lp = xyz(mul_point(lp, build_skin_matrix(sc.skinningMatrices, skinSlot, joints, weights)));
-    }
-    const f4 lp4{lp.x, lp.y, lp.z, 1.0f};
-    const f4 clip = mul_vm(lp4, mvp);
-    const float viewZ = dot4(lp4, modelViewZ);
-    const float invW = 1.0f / clip.w;
-    const float ndcx = clip.x * invW, ndcy = clip.y * invW;
-    osx = (ndcx + 1.0f) * 0.5f * cv.visWidth + cv.sMinXf;
-    osy = (1.0f - ndcy) * 0.5f * cv.visHeight + cv.sMinYf;
-    osd = -viewZ;
-}
-
-// What a tile needs to start on a cluster: 16 B, written once per (cluster, tile).  The screen vertices are in the cache at cluster * 384 floats
-// (sx[128] | sy[128] | sd[128]).  viewScissor: index of the cluster's view (its scissor clamps the triangle boxes).
-struct TileEntry { uint32_t cluster, countsAndView; const uint8_t* triBase; };      // countsAndView: vertCount | triCount << 8 | reverseWinding << 16 | viewId << 17
-static_assert(sizeof(TileEntry) == 16, "one 16 B store per entry");
-constexpr uint32_t XV_STRIDE = 3u * BRMI_MESHLET_MAX_VERTS;
-
-__global__ void __launch_bounds__(256) k_raster_tile_lists(RasterArgs a) {
-    const brmi_scene_buffers& sc = a.sc;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t first = a.firstCounter == 0xFFFFFFFFu ? 0u : a.counters[a.firstCounter];
-    const uint32_t count = a.counters[a.countCounter];
-    for (uint32_t c = blockIdx.x * 4u + wave; c < count; c += gridDim.x * 4u) {
-        const uint32_t clusterIndex = first + c;
-        const ClusterSetup cs = a.setup[clusterIndex];
-        const uint32_t vertCount = cs.counts & 0xFFu, triCount = (cs.counts >> 8) & 0xFFu;
-        const ClusterView cv = cluster_view(sc, cs.viewId);
-        const float* oc = a.objConst + (size_t)cs.perObjectIndex * 36u;
-        const m4 mvp = load_m4(oc);
-        const f4 modelViewZ{oc[32], oc[33], oc[34], oc[35]};
-        const bool skinVerts = (cs.counts & (BRMI_CS_SKINNED | BRMI_CS_JOINTS)) == (BRMI_CS_SKINNED | BRMI_CS_JOINTS);
-        const uint32_t skinSlot = skinVerts ? sc.perMeshInstance[cs.instanceIndex].skinningInstanceSlot : 0xFFFFFFFFu;
-        const bool cached = clusterIndex < a.xvertClusters;
-        float* xv = a.xverts + (size_t)clusterIndex * XV_STRIDE;
-        // box of the vertices in front of the eye plane, with the triangle setup's own rounding (floor, saturating conversion): it contains the
-        // clamped box of every triangle that survives the setup
-        int minX = 0x7FFFFFFF, minY = 0x7FFFFFFF, maxX = -0x7FFFFFFF - 1, maxY = -0x7FFFFFFF - 1;
-        for (uint32_t v = lane; v < vertCount; v += 64u) {
-            float x, y, d;
-            screen_vertex(sc, cs, cv, mvp, modelViewZ, skinVerts, skinSlot, v, x, y, d);
-            if (cached) { xv[v] = x; xv[BRMI_MESHLET_MAX_VERTS + v] = y; xv[2u * BRMI_MESHLET_MAX_VERTS + v] = d; }
-            if (d > 0.0f) {
-                const int fx = to_int_sat(floorf(x)), fy = to_int_sat(floorf(y));
-                minX = min(minX, fx); maxX = max(maxX, fx); minY = min(minY, fy); maxY = max(maxY, fy);
-            }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            minX = min(minX, __shfl_xor(minX, o)); maxX = max(maxX, __shfl_xor(maxX, o));
-            minY = min(minY, __shfl_xor(minY, o)); maxY = max(maxY, __shfl_xor(maxY, o));
-        }
-        minX = max(max(minX, cv.scMinX), 0); minY = max(max(minY, cv.scMinY), (int)a.bandY0);
-        maxX = min(min(maxX, cv.scMaxX - 1), (int)a.visW - 1); maxY = min(min(maxY, cv.scMaxY - 1), min((int)a.visH, (int)a.bandY1) - 1);
-        if (minX > maxX || minY > maxY) continue;
-        const int tx0 = minX >> RT_W_SHIFT, tx1 = maxX >> RT_W_SHIFT, ty0 = minY >> RT_H_SHIFT, ty1 = maxY >> RT_H_SHIFT;
-        const int tw = tx1 - tx0 + 1, cells = tw * (ty1 - ty0 + 1);
-        TileEntry e; e.cluster = clusterIndex; e.countsAndView = vertCount | (triCount << 8) | (((cs.counts >> 24) & 1u) << 16) | (cs.viewId << 17); e.triBase = cs.triBase;
-        for (int i = (int)lane; i < cells; i += 64) {
-            const uint32_t tile = (uint32_t)(ty0 + i / tw) * a.rtilesX + (uint32_t)(tx0 + i % tw);
-            const uint32_t slot = cached ? atomicAdd(&a.tileCounts[tile], 1u) : 0xFFFFFFFFu;      // (a cluster beyond the vertex cache goes the overflow way)
-            if (slot < a.tileCapacity) a.tileLists[(size_t)tile * a.tileCapacity + slot] = e;
-            else {
-                const uint32_t q = atomicAdd(&a.counters[CNT_TILE_OVERFLOW], 1u);
-                if (q < a.tileOverflowCapacity) a.tileOverflow[q] = make_uint2(clusterIndex, tile);
-                else atomicAdd(&a.counters[CNT_DROPPED_CLUSTERS], 1u);      // (capacity is a million pairs; counted, never silent)
-            }
-        }
-    }
-}
-
-// an entry's inputs as a wave holds them in registers: two screen vertices and two triangles' index bytes per lane
-struct EntryInputs { float x0, y0, d0, x1, y1, d1; uint32_t ia0, ia1, ia2, ib0, ib1, ib2; };
-BRMI_DEV EntryInputs load_entry_inputs(const RasterArgs& a, const TileEntry& e, uint32_t lane) {
-    EntryInputs in{};
-    const uint32_t vertCount = e.countsAndView & 0xFFu, triCount = (e.countsAndView >> 8) & 0xFFu;
-    const float* xv = a.xverts + (size_t)e.cluster * XV_STRIDE;
-    if (lane < vertCount) { in.x0 = xv[lane]; in.y0 = xv[BRMI_MESHLET_MAX_VERTS + lane]; in.d0 = xv[2u * BRMI_MESHLET_MAX_VERTS + lane]; }
-    if (lane + 64u < vertCount) { in.x1 = xv[lane + 64u]; in.y1 = xv[BRMI_MESHLET_MAX_VERTS + lane + 64u]; in.d1 = xv[2u * BRMI_MESHLET_MAX_VERTS + lane + 64u]; }
-    if (lane < triCount) { in.ia0 = e.triBase[lane * 3u]; in.ia1 = e.triBase[lane * 3u + 1u]; in.ia2 = e.triBase[lane * 3u + 2u]; }
-    if (lane + 64u < triCount) { in.ib0 = e.triBase[(lane + 64u) * 3u]; in.ib1 = e.triBase[(lane + 64u) * 3u + 1u]; in.ib2 = e.triBase[(lane + 64u) * 3u + 2u]; }
-    return in;
-}
-
-// One cluster against one clip rectangle (a tile's pixels inside this GPU's band), by one wave, its screen vertices and index bytes in `in`:
-// sink = the tile in LDS, or the visibility buffer for the overflow pairs.  Triangle arithmetic is k_raster's, statement by statement.
-template <typename Sink>
-BRMI_DEV void raster_entry(const RasterArgs& a, const TileEntry& e, const EntryInputs& in, const ClusterView& cv, const Sink& sink, int cx0, int cy0, int cx1, int cy1, WaveStage& w, uint32_t lane) {
-    const uint32_t clusterIndex = e.cluster;
-    const uint32_t vertCount = e.countsAndView & 0xFFu, triCount = (e.countsAndView >> 8) & 0xFFu;
-    const bool reverseWinding = ((e.countsAndView >> 16) & 1u) != 0u;
-#ifdef BRMI_TILE_STAMPS
-#define PHASE_STAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); w.phase[k] += now_ - tprev_; tprev_ = now_; } while (0)
-    unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
-#else
-#define PHASE_STAMP(k) do { } while (0)
-#endif
-    wave_lds_sync();      // the previous entry's readers of the staging area are done
-    if (lane < vertCount) { w.sx[lane] = in.x0; w.sy[lane] = in.y0; w.sd[lane] = in.d0; }
-    if (lane + 64u < vertCount) { w.sx[lane + 64u] = in.x1; w.sy[lane + 64u] = in.y1; w.sd[lane + 64u] = in.d1; }
-    wave_lds_sync();
-    PHASE_STAMP(0);
-    for (uint32_t waveBase = 0; waveBase < triCount; waveBase += 64u) {
-        const uint32_t t = waveBase + lane;
-        bool active = t < triCount;
-        float d0 = 0, d1 = 0, d2 = 0, row_b0 = 0, row_b1 = 0, dx_b0 = 0, dx_b1 = 0, dy_b0 = 0, dy_b1 = 0;
-        int minX = 0, minY = 0, maxX = -1, maxY = -1;
-        if (active) {
-            uint32_t i0 = waveBase ? in.ib0 : in.ia0, i1 = waveBase ? in.ib1 : in.ia1, i2 = waveBase ? in.ib2 : in.ia2;
-            if (reverseWinding) { const uint32_t tmp = i1; i1 = i2; i2 = tmp; }
-            const float s0x = w.sx[i0], s0y = w.sy[i0], s1x = w.sx[i1], s1y = w.sy[i1], s2x = w.sx[i2], s2y = w.sy[i2];
-            d0 = w.sd[i0]; d1 = w.sd[i1]; d2 = w.sd[i2];
-            if (d0 <= 0.0f || d1 <= 0.0f || d2 <= 0.0f) active = false;
-            const float e01x = s1x - s0x, e01y = s1y - s0y, e02x = s2x - s0x, e02y = s2y - s0y;
-            const float twiceArea = e01x * e02y - e01y * e02x;
-            if (twiceArea >= 0.0f) active = false;
-            if (active) {
-                const float invTwiceArea = -1.0f / twiceArea;
-                const float bbMinX = min2(min2(s0x, s1x), s2x), bbMinY = min2(min2(s0y, s1y), s2y);
-                const float bbMaxX = max2(max2(s0x, s1x), s2x), bbMaxY = max2(max2(s0y, s1y), s2y);
-                minX = to_int_sat(floorf(bbMinX)); minY = to_int_sat(floorf(bbMinY));
-                maxX = to_int_sat(floorf(bbMaxX)); maxY = to_int_sat(floorf(bbMaxY));
-                minX = max(minX, cv.scMinX); minY = max(minY, cv.scMinY);
-                maxX = min(maxX, cv.scMaxX - 1); maxY = min(maxY, cv.scMaxY - 1);
-                minX = max(minX, 0); minY = max(minY, 0);
-                maxX = min(maxX, (int)a.visW - 1); maxY = min(maxY, (int)a.visH - 1);
-                if (minX > maxX || minY > maxY) active = false;
-                else {
-                    const float ox = (float)minX + 0.5f, oy = (float)minY + 0.5f;
-                    const float e12x = s2x - s1x, e12y = s2y - s1y, e20x = s0x - s2x, e20y = s0y - s2y;
-                    row_b0 = ((ox - s1x) * e12y - (oy - s1y) * e12x) * invTwiceArea;
-                    row_b1 = ((ox - s2x) * e20y - (oy - s2y) * e20x) * invTwiceArea;
-                    dx_b0 = e12y * invTwiceArea; dx_b1 = e20y * invTwiceArea;
-                    dy_b0 = -e12x * invTwiceArea; dy_b1 = -e20x * invTwiceArea;
-                }
-            }
-        }
-        const int rectWidth = maxX - minX + 1;
-        const bool useScanlineRanges = __any(active && rectWidth > 4);      // softwareRaster.hlsl:502: over the pass's surviving triangles, wherever they lie
-        // rows of the box inside the clip rectangle
-        const int yLo = max(minY, cy0), yHi = min(maxY, cy1);
-        const bool here = active && yLo <= yHi && minX <= cx1 && maxX >= cx0;
-        const uint32_t myRows = here ? (uint32_t)(yHi - yLo + 1) : 0u;
-        if (!__any(here)) { PHASE_STAMP(1); continue; }      // (wave-uniform) nothing of this pass reaches into the rectangle
-        // the serial loop's additions from the box top down to the first row inside the rectangle, once per triangle, all lanes side by side
-        float top_b0 = row_b0, top_b1 = row_b1;
-        if (here) for (int y = minY; y < yLo; y++) { top_b0 += dy_b0; top_b1 += dy_b1; }
-        PHASE_STAMP(2);
-        uint32_t incl = myRows;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o); if (lane >= (uint32_t)o) incl += v; }
-        const uint32_t totalRows = (uint32_t)__shfl((int)incl, 63);
-        PHASE_STAMP(1);
-        if (totalRows == 0u) continue;      // (wave-uniform)
-        wave_lds_sync();      // the previous pass's tasks have read the parked setups
-        w.rowOff[lane] = incl - myRows;
-        if (lane == 63u) w.rowOff[64] = totalRows;
-        w.tpF[0][lane] = top_b0; w.tpF[1][lane] = top_b1; w.tpF[2][lane] = dx_b0; w.tpF[3][lane] = dx_b1; w.tpF[4][lane] = dy_b0; w.tpF[5][lane] = dy_b1;
-        w.tpF[6][lane] = d0; w.tpF[7][lane] = d1; w.tpF[8][lane] = d2;
-        w.tpI[0][lane] = minX; w.tpI[1][lane] = rectWidth; w.tpI[2][lane] = yLo;
-        wave_lds_sync();
-        PHASE_STAMP(3);
-#ifdef BRMI_TILE_STAMPS
-        w.phase[6] += totalRows; w.phase[7] += 1ull;
-#endif
-        for (uint32_t task = lane; task < totalRows; task += 64u) {
-            uint32_t tri = 0;
-#pragma unroll
-            for (uint32_t step = 32; step > 0; step >>= 1) if (w.rowOff[tri + step] <= task) tri += step;
-            const int t_minX = w.tpI[0][tri], t_w = w.tpI[1][tri], t_yLo = w.tpI[2][tri];
-            const int py = t_yLo + (int)(task - w.rowOff[tri]);
-            const float t_dx0 = w.tpF[2][tri], t_dx1 = w.tpF[3][tri], t_dy0 = w.tpF[4][tri], t_dy1 = w.tpF[5][tri];
-            float sb0 = w.tpF[0][tri], sb1 = w.tpF[1][tri];
-            for (int k = py - t_yLo; k > 0; k--) { sb0 += t_dy0; sb1 += t_dy1; }      // the serial loop's row stepping
-            raster_row(sink, NoAlpha{}, py, t_minX, t_w, useScanlineRanges, sb0, sb1, t_dx0, t_dx1, -(t_dx0 + t_dx1), w.tpF[6][tri], w.tpF[7][tri], w.tpF[8][tri], clusterIndex, waveBase + tri,
-                       max(t_minX, cx0), min(t_minX + t_w - 1, cx1));
-        }
-        PHASE_STAMP(4);
-    }
-}
-
-struct TileSink {
-    static constexpr bool kPeekCheap = true;
-    unsigned long long* tile; int x0, y0;       // tile[(px - x0) * RT_H + (py - y0)]
-    BRMI_DEV void operator()(int px, int py, unsigned long long key) const { atomicMin(&tile[(px - x0) * RT_H + (py - y0)], key); }
-    BRMI_DEV unsigned long long peek(int px, int py) const { return *(volatile const unsigned long long*)&tile[(px - x0) * RT_H + (py - y0)]; }
-};
-
-BRMI_DEV TileEntry entry_of_lane(const uint4& mine, uint32_t i) {      // lane i's entry to every lane (wave-uniform result)
-    TileEntry e;
-    e.cluster = (uint32_t)__builtin_amdgcn_readlane((int)mine.x, (int)i); e.countsAndView = (uint32_t)__builtin_amdgcn_readlane((int)mine.y, (int)i);
-    const uint64_t lo = (uint32_t)__builtin_amdgcn_readlane((int)mine.z, (int)i), hi = (uint32_t)__builtin_amdgcn_readlane((int)mine.w, (int)i);
-    e.triBase = reinterpret_cast<const uint8_t*>(lo | (hi << 32));
-    return e;
-}
-
-__global__ void __launch_bounds__(RT_THREADS, 4) k_raster_tiles(RasterArgs a, uint32_t firstTileRow) {
-    __shared__ unsigned long long tile[RT_W * RT_H];
-    __shared__ WaveStage stage[RT_WAVES];
-    const uint32_t tx = blockIdx.x, ty = firstTileRow + blockIdx.y, t = ty * a.rtilesX + tx;
-    const uint32_t nAll = min(a.tileCounts[t], a.tileCapacity);
-#ifdef BRMI_TILE_STAMPS
-    const unsigned long long stamp0 = __builtin_amdgcn_s_memrealtime();
-    if (threadIdx.x == 0 && gridDim.z > 1) { uint32_t* st = reinterpret_cast<uint32_t*>(a.binRecords) + 64u + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8u; st[0] = t; st[1] = blockIdx.z; st[2] = nAll; st[3] = 0; st[4] = (uint32_t)stamp0; st[5] = (uint32_t)stamp0; st[6] = (uint32_t)(stamp0 >> 32); st[7] = 0; }
-#endif
-    // a long list is shared evenly by the launch's slices; a list that fits one slice keeps the plain read-modify-write merge (it owns its pixels)
-    const uint32_t sliceSize = min(RT_MAX_SLICE, max(a.tileMinSlice, (nAll + gridDim.z - 1u) / gridDim.z));
-    const bool shared = nAll > sliceSize;
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const int x0 = (int)(tx << RT_W_SHIFT), y0 = (int)(ty << RT_H_SHIFT);
-    const int cx1 = min(x0 + RT_W, (int)a.visW) - 1, cy0 = max(y0, (int)a.bandY0), cy1 = min(y0 + RT_H, min((int)a.visH, (int)a.bandY1)) - 1;
-    const TileSink sink{tile, x0, y0};
-    const uint4* list = reinterpret_cast<const uint4*>(a.tileLists + (size_t)t * a.tileCapacity);
-#ifdef BRMI_TILE_STAMPS
-    if (lane < 8u) stage[wave].phase[lane] = 0ull;
-#endif
-    // slice blockIdx.z, then every gridDim.z-th one (a list beyond gridDim.z * RT_MAX_SLICE entries takes several rounds)
-    for (uint32_t first = blockIdx.z * sliceSize; first < nAll; first += gridDim.z * sliceSize) {
-        const uint32_t last = min(nAll, first + sliceSize);
-        __syncthreads();                                    // the previous round's merge has read the tile
-        for (uint32_t i = threadIdx.x; i < RT_W * RT_H; i += RT_THREADS) tile[i] = BRMI_VIS_EMPTY;
-        __syncthreads();
-        // this wave's entries: first + wave, + 8, ...; lane i holds the i-th of them (one load), inputs one entry ahead of the rasteriser
-        const uint32_t mineCount = first + wave < last ? (last - first - wave + RT_WAVES - 1u) / RT_WAVES : 0u;
-        uint4 mine = make_uint4(0u, 0u, 0u, 0u);
-        if (lane < mineCount) mine = list[first + wave + lane * RT_WAVES];
-        if (mineCount != 0u) {
-            TileEntry e = entry_of_lane(mine, 0u);
-            EntryInputs in = load_entry_inputs(a, e, lane);
-            uint32_t viewId = e.countsAndView >> 17;
-            ClusterView cv = cluster_view(a.sc, viewId);
-            for (uint32_t i = 0; i < mineCount; i++) {
-                const TileEntry cur = e; const EntryInputs curIn = in;
-                if (i + 1u < mineCount) { e = entry_of_lane(mine, i + 1u); in = load_entry_inputs(a, e, lane); }
-                if ((cur.countsAndView >> 17) != viewId) { viewId = cur.countsAndView >> 17; cv = cluster_view(a.sc, viewId); }
-                raster_entry(a, cur, curIn, cv, sink, x0, cy0, cx1, cy1, stage[wave], lane);
-            }
-        }
-        __syncthreads();
-#ifdef BRMI_TILE_STAMPS
-        if (threadIdx.x == 0 && gridDim.z > 1) { uint32_t* st = reinterpret_cast<uint32_t*>(a.binRecords) + 64u + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8u; st[3] += last - first; st[5] = (uint32_t)__builtin_amdgcn_s_memrealtime(); }
-        if (lane < 8u && a.debugFlags && gridDim.z > 1) { atomicAdd(reinterpret_cast<unsigned long long*>(a.binRecords) + 4u + lane, stage[wave].phase[lane]); stage[wave].phase[lane] = 0ull; }
-#endif
-        // merge: item = (column x, eight rows) = 8 keys = 64 B, contiguous in the LDS tile and in the 8x8-tiled surface; a wave moves 4 KB
-        const uint32_t xl = threadIdx.x & (RT_W - 1), g = threadIdx.x >> RT_W_SHIFT;
-        const ulonglong2* src = reinterpret_cast<const ulonglong2*>(&tile[xl * RT_H + g * 8u]);
-        ulonglong2 k[4];
-        bool any = false;
-#pragma unroll
-        for (int q = 0; q < 4; q++) { k[q] = src[q]; any = any || k[q].x != BRMI_VIS_EMPTY || k[q].y != BRMI_VIS_EMPTY; }
-        if (!any) continue;      // untouched (this also covers columns / rows beyond the target size and outside the band)
-        const uint32_t px = (uint32_t)x0 + xl, py = (uint32_t)y0 + g * 8u;
-        ulonglong2* dst = reinterpret_cast<ulonglong2*>(&a.vis[(((py >> 3) * a.tilesX + (px >> 3)) << 6) | ((px & 7u) << 3)]);
-        if (shared) {
-            // other slices of this tile merge too: atomic-min, but only for the keys that beat what is there already (a look costs a coalesced
-            // load; an L2 atomic per key is what made many small slices slower than few large ones)
-            unsigned long long* d1 = reinterpret_cast<unsigned long long*>(dst);
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const unsigned long long gx = __builtin_nontemporal_load(&d1[2 * q]), gy = __builtin_nontemporal_load(&d1[2 * q + 1]);
-                if (k[q].x < gx) atomicMin(&d1[2 * q], k[q].x);
-                if (k[q].y < gy) atomicMin(&d1[2 * q + 1], k[q].y);
-            }
-            continue;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const ulonglong2 gk = dst[q];
-            const ulonglong2 m = make_ulonglong2(gk.x < k[q].x ? gk.x : k[q].x, gk.y < k[q].y ? gk.y : k[q].y);
-            if (m.x != gk.x || m.y != gk.y) dst[q] = m;
-        }
-    }
-}
-
-// (cluster, tile) pairs that found the tile's list full (or whose cluster lies beyond the screen-vertex cache): one wave per pair, vertices
-// transformed in place, global atomics, after the tiles' plain merges.  The same launch empties the lists for the next phase / frame.
-__global__ void __launch_bounds__(64) k_raster_tile_overflow(RasterArgs a) {
-    __shared__ WaveStage stage;
-    const uint32_t lane = threadIdx.x;
-    for (uint32_t i = blockIdx.x * 64u + lane; i < a.rtilesX * a.rtilesY; i += gridDim.x * 64u) a.tileCounts[i] = 0u;
-    const uint32_t n = min(a.counters[CNT_TILE_OVERFLOW], a.tileOverflowCapacity);
-    const GlobalSink gsink{a.vis, a.tilesX, 0};
-    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
-        const uint2 pr = a.tileOverflow[i];
-        const ClusterSetup cs = a.setup[pr.x];
-        const uint32_t vertCount = cs.counts & 0xFFu, triCount = (cs.counts >> 8) & 0xFFu;
-        const ClusterView cv = cluster_view(a.sc, cs.viewId);
-        const float* oc = a.objConst + (size_t)cs.perObjectIndex * 36u;
-        const m4 mvp = load_m4(oc);
-        const f4 modelViewZ{oc[32], oc[33], oc[34], oc[35]};
-        const bool skinVerts = (cs.counts & (BRMI_CS_SKINNED | BRMI_CS_JOINTS)) == (BRMI_CS_SKINNED | BRMI_CS_JOINTS);
-        const uint32_t skinSlot = skinVerts ? a.sc.perMeshInstance[cs.instanceIndex].skinningInstanceSlot : 0xFFFFFFFFu;
-        TileEntry e; e.cluster = pr.x; e.countsAndView = vertCount | (triCount << 8) | (((cs.counts >> 24) & 1u) << 16) | (cs.viewId << 17); e.triBase = cs.triBase;
-        EntryInputs in{};
-        if (lane < vertCount) screen_vertex(a.sc, cs, cv, mvp, modelViewZ, skinVerts, skinSlot, lane, in.x0, in.y0, in.d0);
-        if (lane + 64u < vertCount) screen_vertex(a.sc, cs, cv, mvp, modelViewZ, skinVerts, skinSlot, lane + 64u, in.x1, in.y1, in.d1);
-        if (lane < triCount) { in.ia0 = e.triBase[lane * 3u]; in.ia1 = e.triBase[lane * 3u + 1u]; in.ia2 = e.triBase[lane * 3u + 2u]; }
-        if (lane + 64u < triCount) { in.ib0 = e.triBase[(lane + 64u) * 3u]; in.ib1 = e.triBase[(lane + 64u) * 3u + 1u]; in.ib2 = e.triBase[(lane + 64u) * 3u + 2u]; }
-        const int x0 = (int)((pr.y % a.rtilesX) << RT_W_SHIFT), y0 = (int)((pr.y / a.rtilesX) << RT_H_SHIFT);
-        raster_entry(a, e, in, cv, gsink, x0, max(y0, (int)a.bandY0), min(x0 + RT_W, (int)a.visW) - 1, min(y0 + RT_H, min((int)a.visH, (int)a.bandY1)) - 1, stage, lane);
-    }
-}
-// the pair count is folded into the frame's overflow statistic and zeroed once every workgroup of the launch above has read it
-__global__ void k_raster_tile_overflow_reset(uint32_t* counters) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) { const uint32_t n = counters[CNT_TILE_OVERFLOW]; if (n) { atomicAdd(&counters[CNT_BIN_OVERFLOW], n); counters[CNT_TILE_OVERFLOW] = 0u; } }
-}
-
-// K6: linear depth from the visibility key (gbuffer.hlsl:114-161); one lane per pixel, tile order
 __global__ void __launch_bounds__(256) k_depth_copy(const unsigned long long* vis, float* depth, uint64_t n) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const unsigned long long k = vis[i];
@@ -1622,8 +1245,6 @@ int launch_clear(brmi_pass* p, hipStream_t s) {
     BRMI_LAUNCH_CHECK(p, "k_clear_vis");
     return BRMI_OK;
 }
-
-void raster_tile_grid(uint32_t width, uint32_t height, uint32_t* tilesX, uint32_t* tilesY) { *tilesX = (width + RT_W - 1) / RT_W; *tilesY = (height + RT_H - 1) / RT_H; }
 
 static bool stripe_count_on(const brmi_pass* p) { return p->stripes.count > 1u; }
 
@@ -1650,7 +1271,7 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
     a.binPlan = p->wsPtr<uint32_t>(p->ws.binPlan); a.binItems = p->wsPtr<uint32_t>(p->ws.binItems); a.binScratch = p->wsPtr<unsigned long long>(p->ws.binScratch);
     a.binScratchTiles = p->binScratchTiles; a.binItemCapacity = p->binItemCapacity;
     // the LDS window k_raster counts its records per bin in: every bin of the surface when that is at most 2048 cells (8 KB), else 2048 (BRMI_BIN_TABLE: 256 = the round-3 window only)
-    static const uint32_t tableEnv = [] { const char* e = std::getenv("BRMI_BIN_TABLE"); return e ? (uint32_t)std::max(256, std::min(2048, std::atoi(e))) : BIN_TABLE_MAX; }();
+    static const uint32_t tableEnv = (uint32_t)std::max(256l, std::min(2048l, experiment("bin_table", BIN_TABLE_MAX)));
     a.tableCells = std::max<uint32_t>(BIN_WINDOW, std::min<uint32_t>(tableEnv, (p->binsX * p->binsY + 63u) & ~63u));
     a.binAlpha = p->wsPtr<AlphaRecord>(p->ws.binAlpha); a.overflowAlpha = p->wsPtr<AlphaRecord>(p->ws.overflowAlpha);
     a.clusterUv = p->wsPtr<ClusterUv>(p->ws.clusterUv);
@@ -1658,28 +1279,14 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
     // (k_raster_bins<true> packs the material index of a waiting pixel with its 12-bit tile cell into one word)
     if (p->sceneHasAlphaTest && p->scene.materialCount > (1u << 20)) return fail(p, BRMI_ERR_INVALID, "brmi_raster: %u materials in a scene with alpha-tested ones (at most %u)", p->scene.materialCount, 1u << 20);
     if (p->sceneHasAlphaTest) if (int rc = ensure_frame_constants(p, s)) return rc;
-    a.tileCounts = p->wsPtr<uint32_t>(p->ws.tileCounts); a.tileLists = p->wsPtr<TileEntry>(p->ws.tileLists); a.tileCapacity = p->tileCapacity;
-    a.xverts = p->wsPtr<float>(p->ws.xverts); a.xvertClusters = p->xvertClusters; a.debugStamps = p->wsPtr<unsigned long long>(p->ws.debugStamps);
-    a.rtilesX = p->rtilesX; a.rtilesY = p->rtilesY; a.tileOverflow = p->wsPtr<uint2>(p->ws.tileOverflow); a.tileOverflowCapacity = p->tileOverflowCapacity;
-    if (p->rasterTiles && !p->sceneHasAlphaTest && !stripe_count_on(p)) {      // (the tile path knows bands only)
-        // cluster-granular sort-middle: lists, tiles (only the tile rows of this GPU's band), overflow pairs + list reset
-        const uint32_t row0 = p->bandY0 >> RT_H_SHIFT, row1 = (p->bandY1 - 1u) >> RT_H_SHIFT;
-        a.tileMinSlice = p->tileMinSlice;
-        const uint32_t zslices = phase == 2 ? 1u : std::min(8u, (p->tileCapacity + p->tileMinSlice - 1u) / p->tileMinSlice);
-        hipLaunchKernelGGL(k_raster_tile_lists, dim3(phase == 2 ? 512u : 2048u), dim3(256), 0, s, a);
-        hipLaunchKernelGGL(k_raster_tiles, dim3(p->rtilesX, row1 - row0 + 1u, zslices), dim3(RT_THREADS), 0, s, a, row0);
-        hipLaunchKernelGGL(k_raster_tile_overflow, dim3(256), dim3(64), 0, s, a);
-        hipLaunchKernelGGL(k_raster_tile_overflow_reset, dim3(1), dim3(64), 0, s, a.counters);
-        BRMI_LAUNCH_CHECK(p, "k_raster_tiles");
-        return BRMI_OK;
-    }
+    a.debugStamps = p->wsPtr<unsigned long long>(p->ws.debugStamps);
     // the pool of k_raster_bins: four 512-thread workgroups per CU is what the LDS holds; phase 2 rarely has an item at all
     // Round 4: phase-2 launches are sized by what the host last saw phase 2 draw (the host-mapped word of the ranking kernel, read without a wait: a frame
     // or two old; every kernel here strides its grid or takes items by ticket, so any size gives the same keys).  Beside another frame's shading half a
     // wave that finds nothing still has to find a slot -- 200 VGPRs for k_raster<true>, 66 KB of LDS for a k_raster_bins<true> workgroup -- and the three
     // phase-2 launches of a still camera cost the San-Miguel-class frame ~150 us of its geometry chain in flight (kernel stats: k_raster<true> 61 us,
     // k_raster_overflow<true> 53, k_raster_bins<true> 150 per launch on average, phase 1 and 2 alike).
-    static const bool sizeByHint = [] { const char* e = std::getenv("BRMI_PHASE2_SIZED"); return !e || std::atoi(e) != 0; }();
+    static const bool sizeByHint = experiment("phase2_sized", 1) != 0;
     uint32_t hint2 = 0xFFFFFFFFu;
     if (phase == 2 && sizeByHint && p->phase2FeedbackHost) hint2 = *reinterpret_cast<volatile uint32_t*>(p->phase2FeedbackHost);
     auto pow2_at_least = [](uint32_t v) { uint32_t r = 1; while (r < v && r < (1u << 30)) r <<= 1; return r; };
@@ -1696,7 +1303,7 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
     if (direct2) a.bigTriArea = a.bigTriAreaAlpha = a.bigTriAreaDense = 0x3FFFFFFF;
     // phase 2 rarely has more than a handful of clusters: 2048 workgroups (the kernel strides; two waves per SIMD) start and retire a little
     // faster than 8192 that find nothing (-3 us per frame)
-    static const uint32_t grid2 = [] { const char* e = std::getenv("BRMI_RASTER_GRID2"); return e ? (uint32_t)std::max(64, std::atoi(e)) : 2048u; }();
+    static const uint32_t grid2 = (uint32_t)std::max(64l, experiment("raster_grid2", 2048));
     const dim3 rgrid(phase == 2 ? std::min(p->rasterGrid, sized2 ? std::max(128u, std::min(grid2, pow2_at_least(hint2 * 16u))) : grid2) : p->rasterGrid);
     const dim3 ogrid(phase == 2 && sized2 ? std::max(2u, std::min(129u, hint2 / 4u + 2u)) : 129u);      // (block 0 plans the bins launch; the others walk the overflow queues)
     if (p->sceneHasAlphaTest) {

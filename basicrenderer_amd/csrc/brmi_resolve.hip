@@ -14,7 +14,6 @@
 //     or written by the wave is one contiguous 256 B..1 KB segment.
 #include "brmi_device.h"
 #include "brmi_internal.h"
-#include "brmi_shade.h"
 #include "brmi_texture.h"
 
 namespace brmi {
@@ -309,29 +308,10 @@ constexpr int RESOLVE_WATERFALL = BRMI_RESOLVE_WATERFALL;     // distinct mesh i
 #define BRMI_GBM_WAVES 3
 #endif
 // Epi: what happens to a pixel's G-buffer words besides being stored.  `pixel()` is called once per lane and tile, in converged control flow,
-// after the tile's waterfall: nothing for the plain kernels, the whole deferred shading of the pixel for the fused one (k_gbuffer_shade).
+// after the tile's waterfall: nothing for the plain kernels (round 5 removed the fused G-buffer + shading kernel, which lost on measurement twice).
 struct NoEpilogue {
     static constexpr bool kWanted = false;
     BRMI_DEV void pixel(bool, unsigned long long, bool, uint32_t, uint32_t, uint64_t, const float4&, uint32_t, uint32_t, unsigned long long, unsigned long long) const {}
-};
-// The deferred shading of the pixel, from the words the G-buffer pass has just stored (the 48 B per pixel the shading pass would read back):
-// the same RawPixel k_shade<0> loads -- packed normals, UNORM8 / half words, the depth of the key -- goes through the same shade_pixel<0>.
-struct ShadeEpilogue {
-    static constexpr bool kWanted = true;
-    const ShadeArgs& sh; const ShadeFrame& k; const float* sliceStart; const float* unormT; const float4* camK;
-    BRMI_DEV void pixel(bool inBand, unsigned long long key, bool produced, uint32_t px, uint32_t py, uint64_t i, const float4& ns, uint32_t al, uint32_t mr, unsigned long long coat, unsigned long long emissive) const {
-        const uint32_t lane = threadIdx.x & 63u;
-        const uint64_t tileBase = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(i >> 6))) << 6;       // the wave's tile (wave-uniform, < 2^32 tiles)
-        RawPixel raw = empty_raw_pixel();
-        if (inBand) {
-            raw.ax = sh.tables.x[px]; raw.ay = sh.tables.y[py];
-            raw.d = (key == BRMI_VIS_EMPTY) ? as_f32(BRMI_DEPTH_EMPTY_BITS) : as_f32(((uint32_t)(key >> BRMI_VIS_META_BITS)) << 1);
-            if (produced) { raw.ns = ns; raw.al = al; raw.mr = mr; raw.es = emissive; raw.cs = sh.sceneHasCoat ? (coat & 0xFFFF000000000000ull) : 0ull; raw.fs = 0ull; }
-            else if (key != BRMI_VIS_EMPTY) raw = load_raw_pixel_plain(sh, tileBase, lane, px, py);      // a key that names no live triangle: whatever the planes hold, as the separate pass would read
-        }
-        const uint32_t cls = shade_pixel<0>(sh, k, sliceStart, unormT, camK, raw, inBand, tileBase, lane);
-        shade_defer(sh, (uint32_t)(tileBase >> 6) - (uint32_t)(sh.firstPixel >> 6), cls, lane);
-    }
 };
 template <bool INLINE_TABLES, bool TEXTURED, bool PARALLAX, bool MULTI_UV, int SLIM, class Epi>
 BRMI_DEV void gbuffer_body(const GBufferArgs& a, const Epi& epi) {
@@ -626,21 +606,6 @@ __global__ void __launch_bounds__(256, INLINE_TABLES ? 1 : (MULTI_UV ? (PARALLAX
     gbuffer_body<INLINE_TABLES, TEXTURED, PARALLAX, MULTI_UV, SLIM>(a, NoEpilogue{});
 }
 
-// G-buffer + deferred shading of the plain pixels in one pass over the frame (brmi_execute, scenes of constant-factor materials whose visible
-// clusters all fit the resolve arena): the 52 B per pixel of G-buffer are still written -- they are outputs -- but never read back, and the
-// shading arithmetic runs in the shadow of the stores.  Layered (coat / fuzz) pixels are listed for k_shade<1|2|3> as k_shade<0> lists them.
-#ifndef BRMI_FUSED_WAVES
-#define BRMI_FUSED_WAVES 3
-#endif
-__global__ void __launch_bounds__(256, BRMI_FUSED_WAVES) k_gbuffer_shade(GBufferArgs a, ShadeArgs sh) {
-    const ShadeFrame k = make_shade_frame(sh);
-    __shared__ float sliceStart[64];
-    __shared__ float unormT[256];
-    __shared__ float4 camK[9];
-    shade_stage_lds(sh, k, sliceStart, unormT, camK);
-    gbuffer_body<false, false, false, false, 0>(a, ShadeEpilogue{sh, k, sliceStart, unormT, camK});
-}
-
 static GBufferArgs gbuffer_args_of(brmi_pass* p) {
     GBufferArgs a;
     a.hostFeedback = nullptr; a.setupPart = 0u;
@@ -713,13 +678,6 @@ int launch_gbuffer(brmi_pass* p, hipStream_t s) {
         hipLaunchKernelGGL(leanKernel, dim3(grid), dim3(256), 0, s, a);
         if (!lean) { a.variantSelect = 2u; hipLaunchKernelGGL(fallbackKernel, dim3(4096), dim3(256), 0, s, a); }
     };
-    if (p->fuseShadeIntoGBuffer && lean && !p->sceneHasTextures && !p->sceneHasVertexColors) {
-        a.variantSelect = 0u;
-        hipLaunchKernelGGL(k_gbuffer_shade, dim3(4096), dim3(256), 0, s, a, shade_args_of(p));
-        p->plainPixelsShaded = true;
-        BRMI_LAUNCH_CHECK(p, "k_gbuffer_shade");
-        return BRMI_OK;
-    }
     if (p->sceneHasTextures || p->sceneHasVertexColors) {
         const bool multiUv = p->sceneUvSets > 1;
         // (SLIM: 0 / 1 / 2 as decided above)

@@ -479,30 +479,6 @@ def test_gltf_file_renders_like_the_oracle(tmp_path):
     r.close()
 
 
-def test_fused_gbuffer_and_shading_kernel_matches_the_oracle(monkeypatch):
-    """BRMI_FUSE_SHADE=1: brmi_execute shades the plain pixels inside the G-buffer kernel (k_gbuffer_shade) from the words it has just stored;
-    layered pixels still go through the per-class lists.  Same G-buffer bytes, HDR within one fp16 ULP of the oracle -- and of the two-kernel frame."""
-    import orc
-    from conftest import Scene
-    from basicrenderer_amd.renderer import VisibilityRenderer
-    sc = Scene("sponza", 640, 360, point_lights=24, size_scale=0.1, lod_levels=2, material_features=3, seed=29)
-    o = orc.OracleFrame(sc).run()
-    covered = o.vis != np.uint64(0xFFFFFFFFFFFFFFFF)
-    frames = {}
-    for fuse in ("0", "1"):
-        monkeypatch.setenv("BRMI_FUSE_SHADE", fuse)
-        r = VisibilityRenderer(sc)
-        r.execute(); r.execute()
-        assert np.array_equal(r.visibility(), o.vis)
-        g = r.gbuffer()
-        assert np.array_equal(g["normals"][covered].view(np.uint32), o.normals[covered].view(np.uint32)) and np.array_equal(g["albedo"][covered], o.albedo[covered])
-        hdr = r.hdr().view(np.uint16).astype(np.int32)
-        assert np.abs(hdr - o.hdr.view(np.uint16).astype(np.int32)).max() <= 1
-        frames[fuse] = hdr
-        r.close()
-    assert np.array_equal(frames["0"], frames["1"])              # the same arithmetic on the same words
-
-
 def test_alpha_test_on_odd_sized_single_level_textures_matches_the_oracle():
     """Every texture re-declared 100 x 60 with one level (not a power of two: the general modulo of wrap / mirror addressing, partial edge
     footprints): the rasteriser's alpha test and the G-buffer's sampler stay exact against the oracle."""
@@ -722,27 +698,6 @@ def test_full_size_interleaved_partition_against_the_oracle(preset, lights, n, r
         gh = r.hdr().view(np.uint16).astype(np.int32).reshape(H // n, W, 4)
         assert np.abs(gh[covered] - oh[fr][covered]).max() <= 1, f"rank {rank}"
         r.close()
-
-
-@pytest.mark.parametrize("preset,lights,kw", [("bistro", 256, dict(unique_budget=True, lod_builder="own", relief_slope=1.5)), ("bistro", 256, dict(size_scale=20.0, detail=96.0)), ("sponza", 64, dict())])
-def test_full_size_tile_rasteriser_draws_the_oracles_keys(preset, lights, kw):
-    """BRMI_RASTER_MODE=tiles (the cluster-granular rasteriser, opt-in) on the 4K bench frames: cluster list, keys and depth are the oracle's."""
-    import orc
-    from conftest import Scene
-    from basicrenderer_amd.renderer import VisibilityRenderer
-    sc = Scene(preset, 3840, 2160, point_lights=lights, **kw)
-    with _Env(BRMI_RASTER_MODE="tiles"):
-        r = VisibilityRenderer(sc, stats=True)
-    r.execute()
-    o = orc.OracleFrame(sc)
-    o.cull(); o.raster(); o.depth_copy()
-    c = r.counters()
-    assert c.droppedRecords == 0 and c.droppedClusters == 0
-    assert np.array_equal(r.visible_clusters(), o.clusters[: o.count])
-    vis = r.visibility()
-    assert np.array_equal(vis, o.vis), f"{int((vis != o.vis).sum())} keys differ"
-    assert np.array_equal(r.depth().view(np.uint32), o.depth.view(np.uint32))
-    r.close()
 
 
 def test_frame_from_an_independently_written_clod_cache_matches_the_oracle():
@@ -1353,24 +1308,23 @@ def test_occlusion_static_camera_culls_hidden_clusters_at_4k():
 
 # ---- fallback paths that a normal frame does not reach ----------------------------------------------------------------
 class _Env:
-    """Tuning knobs are read by brmi_create: set them around the construction of a renderer."""
+    """Tuning knobs are read by brmi_create / brmi_set_scene: set them around the construction of a renderer.  The library reads ONE variable,
+    BRMI_TUNING="key=value,..." (DESIGN.md 6b); the keyword BRMI_BIN_MIN_SLICE=32 becomes the key bin_min_slice there."""
 
     def __init__(self, **kv):
-        self.kv, self.old = kv, {}
+        self.kv, self.old = kv, None
 
     def __enter__(self):
         import os
-        for k, v in self.kv.items():
-            self.old[k] = os.environ.get(k)
-            os.environ[k] = str(v)
+        self.old = os.environ.get("BRMI_TUNING")
+        os.environ["BRMI_TUNING"] = ",".join(f"{k[5:].lower() if k.startswith('BRMI_') else k.lower()}={v}" for k, v in self.kv.items())
 
     def __exit__(self, *exc):
         import os
-        for k, v in self.old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+        if self.old is None:
+            os.environ.pop("BRMI_TUNING", None)
+        else:
+            os.environ["BRMI_TUNING"] = self.old
 
 
 @pytest.mark.parametrize("name,queue", [("sponza_small", 16384), ("bistro_small", 16384), ("sponza_small", 2), ("sponza_small", 0)])
@@ -1382,33 +1336,6 @@ def test_full_raster_bins_fall_back_to_global_atomics(name, queue, scenes, oracl
         r = VisibilityRenderer(scenes(name), stats=True)
     r.execute()
     assert queue == 0 or r.counters().reserved[5] > 0, "the case does not overflow any bin"
-    assert np.array_equal(r.visibility(), oracle_frames(name).vis)
-    r.close()
-
-
-@pytest.mark.parametrize("name,capacity,pairs,slice_", [("sponza_small", 2, 1 << 20, 128), ("bistro_small", 1, 1 << 20, 128), ("sponza_small", 300, 1 << 20, 2), ("bistro_small", 300, 1 << 20, 3), ("tiny_lod", 1, 1 << 20, 128)])
-def test_full_tile_lists_fall_back_to_global_atomics(name, capacity, pairs, slice_, scenes, oracle_frames):
-    """The tile rasteriser (opaque scenes): a tile whose cluster list is full hands the (cluster, tile) pair to the overflow pass (one wave per
-    pair, global atomics clipped to the tile); a list longer than one slice is walked by several workgroups that merge with atomic-min.  Same
-    keys either way, overflow counted."""
-    from basicrenderer_amd.renderer import VisibilityRenderer
-    with _Env(BRMI_RASTER_MODE="tiles", BRMI_TILE_CAPACITY=capacity, BRMI_TILE_OVERFLOW=pairs, BRMI_TILE_SLICE=slice_):
-        r = VisibilityRenderer(scenes(name), stats=True)
-    r.execute()
-    assert capacity >= 300 or r.counters().reserved[5] > 0, "the case does not overflow any tile list"
-    assert np.array_equal(r.visibility(), oracle_frames(name).vis)
-    r.close()
-
-
-@pytest.mark.parametrize("name", ["sponza_small", "tiny_skinned"])
-def test_clusters_beyond_the_screen_vertex_cache_take_the_overflow_path(name, scenes, oracle_frames):
-    """The tile rasteriser keeps the screen-space vertices of the first BRMI_XVERT_CLUSTERS visible clusters; a cluster beyond that is
-    rasterised by the overflow pass, which transforms its vertices in place: same keys."""
-    from basicrenderer_amd.renderer import VisibilityRenderer
-    with _Env(BRMI_RASTER_MODE="tiles", BRMI_XVERT_CLUSTERS=7):
-        r = VisibilityRenderer(scenes(name), stats=True)
-    r.execute()
-    assert r.counters().reserved[5] > 0, "no cluster went the overflow way"
     assert np.array_equal(r.visibility(), oracle_frames(name).vis)
     r.close()
 
@@ -1465,19 +1392,6 @@ def test_flat_and_level_traversal_agree(name, scenes, oracle_frames):
             assert np.array_equal(got, want)
         r.close()
     assert seen[0] == seen[2] == seen[4] == seen[6] and seen[1] == seen[3] == seen[5] == seen[7], seen
-
-
-@pytest.mark.parametrize("name", ["sponza_small", "bistro_small", "tiny_lod", "tiny_skinned"])
-def test_triangle_bins_and_cluster_tiles_draw_the_same_keys(name, scenes, oracle_frames):
-    """BRMI_RASTER_MODE=tiles selects the cluster-granular tile rasteriser (opaque scenes; an experiment of round 3 that moves a fifth of the bytes
-    but is slower, so the triangle bins stay the default): both paths give the oracle's keys."""
-    from basicrenderer_amd.renderer import VisibilityRenderer
-    for mode in ("bins", "tiles"):
-        with _Env(BRMI_RASTER_MODE=mode):
-            r = VisibilityRenderer(scenes(name), stats=True)
-        r.execute()
-        assert np.array_equal(r.visibility(), oracle_frames(name).vis), mode
-        r.close()
 
 
 @pytest.mark.parametrize("area", [1, 1 << 30])

@@ -1,5 +1,5 @@
-# Phase shares of k_raster_bins' and k_raster's wave-cycles (instrumented build -DBRMI_TILE_STAMPS; BRMI_RASTER_DEBUG=512 for the bins'
-# phases, 256 for k_raster's):  BRMI_RASTER_DEBUG=768 BRMI_LIB_PATH=$PWD/scratch/variants/stamps/libbrmi.so python3 tools/bins_stamps.py <workload> [camera position on the preset's path]
+# Phase shares of k_raster_bins' and k_raster's wave-cycles (instrumented build -DBRMI_TILE_STAMPS -DBRMI_EXPERIMENTS; BRMI_TUNING=raster_debug=512 for the bins'
+# phases, 256 for k_raster's):  BRMI_TUNING=raster_debug=768 BRMI_LIB_PATH=$PWD/scratch/variants/stamps/libbrmi.so python3 tools/bins_stamps.py <workload> [camera position on the preset's path]
 import os, sys, ctypes as C
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch

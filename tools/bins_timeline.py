@@ -1,4 +1,4 @@
-# timeline of k_raster_bins' workgroups (instrumented build, BRMI_RASTER_DEBUG=1024): python3 tools/bins_timeline.py [workload]
+# timeline of k_raster_bins' workgroups (instrumented build, BRMI_TUNING=raster_debug=1024): python3 tools/bins_timeline.py [workload]
 import os, sys, ctypes as C
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch

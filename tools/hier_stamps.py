@@ -1,5 +1,5 @@
 # Phase stamps of the flat traversal (k_cull_hierarchy): wave-cycles per visible instance and phase.  Needs an instrumented build:
-#   tools/mkvar.sh stamps "-DBRMI_TILE_STAMPS" brmi_raster brmi_cull;  BRMI_LIB_PATH=$PWD/scratch/variants/stamps/libbrmi.so python3 tools/hier_stamps.py [workload]
+#   tools/mkvar.sh stamps "-DBRMI_TILE_STAMPS -DBRMI_EXPERIMENTS" brmi_raster brmi_cull;  BRMI_LIB_PATH=$PWD/scratch/variants/stamps/libbrmi.so python3 tools/hier_stamps.py [workload]
 import os, sys, ctypes as C
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch

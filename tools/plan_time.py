@@ -1,5 +1,5 @@
-# Duration of plan_bins (the planner workgroup of k_raster_overflow), instrumented build as above with BRMI_RASTER_DEBUG=1024:
-#   BRMI_RASTER_DEBUG=1024 BRMI_LIB_PATH=$PWD/scratch/variants/stamps/libbrmi.so python3 tools/plan_time.py
+# Duration of plan_bins (the planner workgroup of k_raster_overflow), instrumented build as above with BRMI_TUNING=raster_debug=1024:
+#   BRMI_TUNING=raster_debug=1024 BRMI_LIB_PATH=$PWD/scratch/variants/stamps/libbrmi.so python3 tools/plan_time.py
 import os, sys, ctypes as C
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch

@@ -1,5 +1,5 @@
-# Phase shares of k_raster's wave-cycles (instrumented build -DBRMI_TILE_STAMPS, BRMI_RASTER_DEBUG=256):
-#   BRMI_RASTER_DEBUG=256 BRMI_LIB_PATH=$PWD/scratch/variants/stamps/libbrmi.so python3 tools/raster_stamps.py <workload>
+# Phase shares of k_raster's wave-cycles (instrumented build -DBRMI_TILE_STAMPS -DBRMI_EXPERIMENTS, BRMI_TUNING=raster_debug=256):
+#   BRMI_TUNING=raster_debug=256 BRMI_LIB_PATH=$PWD/scratch/variants/stamps/libbrmi.so python3 tools/raster_stamps.py <workload>
 import os, sys, ctypes as C
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
