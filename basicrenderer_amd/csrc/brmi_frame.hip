@@ -134,10 +134,17 @@ BRMI_DEV void job_light_spheres(const brmi_scene_buffers& sc, float4* lightVS, u
     const f3 dir{l->dirWorldSpace[0], l->dirWorldSpace[1], l->dirWorldSpace[2]};
     if (l->type == BRMI_LIGHT_DIRECTIONAL) r[0] = make_float4(-dir.x, -dir.y, -dir.z, -1.0f);     // lightToFrag; a negative range marks the type
     else r[0] = make_float4(l->posWorldSpace[0], l->posWorldSpace[1], l->posWorldSpace[2], max2(l->maxRange, 0.0f));
-    // dist > maxRange certainly holds once dist^2 exceeds this bound (sqrt is monotone and correctly rounded; 1e-6 covers the products' rounding);
-    // a negative range rejects every pixel
-    const float mr = as_f32(as_u32(max2(l->maxRange, 0.0f)) + 1u);
-    r[1] = make_float4(l->attenuation[0], l->attenuation[1], l->attenuation[2], l->maxRange < 0.0f ? -1.0f : (mr * mr) * 1.000001f);
+    // dist > maxRange (lighting.hlsli:614-617, dist = the correctly rounded sqrt of the squared distance) as a test on the SQUARED distance: sqrt is monotone, so
+    // the pixels the light reaches are exactly those with d2 <= T, T = the largest float whose root is <= maxRange -- found here once per light (R * R is within
+    // an ulp or two of it).  Round 5: the pixel needs neither a conservative bound nor the exact root for the cut; a negative range rejects every pixel.
+    float T = -1.0f;
+    if (!(l->maxRange < 0.0f)) {
+        const float R = max2(l->maxRange, 0.0f);
+        T = R * R;
+        for (int i = 0; i < 4 && sqrtf(T) > R; i++) T = as_f32(as_u32(T) - 1u);
+        for (int i = 0; i < 4; i++) { const float n = as_f32(as_u32(T) + 1u); if (sqrtf(n) <= R) T = n; else break; }
+    }
+    r[1] = make_float4(l->attenuation[0], l->attenuation[1], l->attenuation[2], T);
     r[2] = make_float4(l->color[0] * l->color[3], l->color[1] * l->color[3], l->color[2] * l->color[3], l->innerConeAngle);
     const bool spotL = l->type == BRMI_LIGHT_SPOT;
     const f3 sd = spotL ? normalize3(dir) : f3{0.0f, 0.0f, 0.0f};

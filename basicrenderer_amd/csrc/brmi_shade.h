@@ -153,11 +153,7 @@ BRMI_DEV f3 diffuse_eon(f3 albedo, float rough, float NdotV, float NdotL, float 
 //   [0] point / spot: world position, maxRange       directional: lightToFrag (= -direction), -1
 //   [1] attenuation polynomial, conservative upper bound of maxRange^2
 //   [2] colour x intensity, cos(inner)        [3] spot: normalize(direction), cos(outer); any other light: 0, -2
-struct ShadeLightLanes { float4 r0, r1, r2, r3; };      // one light per lane
 struct ShadeLightRecord { float r0[4], r1[4], r2[4], r3[4]; };   // the same record as plain words (scalar loads)
-#ifndef BRMI_SHADE_SCALAR_LIGHTS
-#define BRMI_SHADE_SCALAR_LIGHTS 1
-#endif
 #ifndef BRMI_SHADE_METAL_STASH
 #define BRMI_SHADE_METAL_STASH 1      // the stand-alone variant of k_shade<0> parks the metal lobe's inputs in LDS
 #endif
@@ -308,6 +304,22 @@ BRMI_DEV PixelCtx make_pixel_ctx(const Luts& L, const Frag& f, const ShadeRows* 
 // algebra was a multiply and an add (round 5: ~25 instructions per light evaluation).
 BRMI_DEV f3 fma3(f3 a, float s, f3 b) { return f3{__builtin_fmaf(a.x, s, b.x), __builtin_fmaf(a.y, s, b.y), __builtin_fmaf(a.z, s, b.z)}; }
 BRMI_DEV f3 fma3v(f3 a, f3 s, f3 b) { return f3{__builtin_fmaf(a.x, s.x, b.x), __builtin_fmaf(a.y, s.y, b.y), __builtin_fmaf(a.z, s.z, b.z)}; }
+// ---- round 5: direction vectors within an ulp instead of correctly rounded, where the surface is rough enough not to notice.
+// N, V, L, H are kept correctly rounded because the GGX term amplifies their error: D ~ 1 / (1 - NoH^2 + (NoH a)^2)^2, so an error d of NoH moves D by
+// ~4 d / a^2.  With the hardware reciprocal square root and one Newton step (and fused dot products) d ~ 3e-7; at alpha >= 0.1 (perceptual roughness >= 0.32)
+// that is <= 1.2e-4 of D, a quarter of an fp16 ulp (4.9e-4 .. 9.8e-4) at the very peak of a highlight -- inside the north star's 1-ulp bar by construction, for
+// every term of the sum.  A tile takes this path when ALL its live pixels are that rough (wave-uniform branch); smoother tiles keep the exact forms.
+// What stays exact on both paths: N and V (the bent normal cancels to ~1e-4 where the stored normal faces away, and N.V, N.L scale terms that vanish with them),
+// and L wherever |N.L| < SHADE_FAST_MIN_NOL.  Fast: L elsewhere, H, and the dot products N.H, L.H, V.L -- two normalisations and three dot products per light evaluation.
+#ifndef BRMI_SHADE_FAST_DIRECTIONS
+#define BRMI_SHADE_FAST_DIRECTIONS 1
+#endif
+struct FastDirections { static constexpr bool value = true; };
+struct ExactDirections { static constexpr bool value = false; };
+constexpr float SHADE_FAST_ALPHA = 0.1f, SHADE_FAST_MIN_NOL = 4.0e-3f;
+BRMI_DEV float dot3f(f3 a, f3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
+BRMI_DEV float rsq_nr(float x) { const float r = __builtin_amdgcn_rsqf(x); return r * __builtin_fmaf((-0.5f * x) * r, r, 1.5f); }      // one Newton step on v_rsq_f32
+BRMI_DEV f3 normalize3_fast(f3 a) { return a * rsq_nr(dot3f(a, a)); }
 template <int MODE, int STASH>
 BRMI_DEV f3 light_contribution(const Luts& L, const Frag& f, const PixelCtx& c, const float* stash, f3 lightToFrag, float NoL, float NoH, float LoH, float VdotL, float D, f3 lightColorIntensity, float attenuation, float spotAtt, f3 acc) {
     BRMI_FP_FAST
@@ -386,18 +398,6 @@ BRMI_DEV f3 light_contribution(const Luts& L, const Frag& f, const PixelCtx& c, 
 // MODE = class of pixel this instantiation shades (0 plain, 1 coat, 2 fuzz, 3 both: a layer that is absent has factors of exactly
 // 1 / 0, so the plain variant needs half the registers -- the same idea as the reference's per-material-permutation pixel lists).
 // Returns, for a live lane whose class is not MODE, that class (MODE 0 defers such pixels); 0 otherwise.
-#ifndef BRMI_SHADE_EARLY_STAGE
-#define BRMI_SHADE_EARLY_STAGE 0
-#endif
-BRMI_DEV ShadeLightLanes stage_lights(const ShadeArgs& a, uint32_t listBase, uint32_t c0, uint32_t n) {
-    ShadeLightLanes s;               // lanes >= n are never broadcast from
-    if (lane_id() < n) {
-        // clustered: the records lie in list order (k_lc_fill copies them there); else the active-light list itself, in order
-        const float4* rec = a.clustered ? a.listRecords + (size_t)(listBase + c0 + lane_id()) * 4u : a.shadeLights + (size_t)(c0 + lane_id()) * 4u;
-        s.r0 = rec[0]; s.r1 = rec[1]; s.r2 = rec[2]; s.r3 = rec[3];
-    }
-    return s;
-}
 template <int MODE, int STASH = 0>      // STASH: floats of the metal lobe's inputs parked in LDS (0, 6 or 9)
 BRMI_DEV uint32_t shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const float* sliceStart, const float* unorm8, const float4* camK, const RawPixel& raw, bool live, uint64_t tileBase, uint32_t within) {
     const Luts& L = k.L;
@@ -449,20 +449,21 @@ BRMI_DEV uint32_t shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const flo
             } else ci = 0u;
         }
     }
-    // ---- the first cluster of the wave: its list and the records of its first 64 lights are requested now
     uint64_t pending = a.enablePunctual ? __ballot(live && ci != 0xFFFFFFFFu) : 0ull;
     uint32_t uci = 0u, listBase = 0u, listCount = 0u;
-    ShadeLightLanes s;
-    if (BRMI_SHADE_EARLY_STAGE && pending != 0ull) {
-        uci = (uint32_t)__builtin_amdgcn_readlane((int)ci, (int)((uint32_t)__ffsll((unsigned long long)pending) - 1u));
-        listCount = k.numLights;                                     // no clustering: the whole active list, in order
-        if (a.clustered) { const auto* cl = kconst(reinterpret_cast<const uint32_t*>(a.clusterList)) + 2u * (size_t)uci; listBase = cl[0]; listCount = cl[1]; }
-        s = stage_lights(a, listBase, 0u, min(64u, listCount));
+    // every live pixel of the tile at least SHADE_FAST_ALPHA rough (plain pixels only: a coat has a roughness of its own): the tile's direction vectors take the fast forms
+    bool fastTile = false;
+    if (MODE == 0 && BRMI_SHADE_FAST_DIRECTIONS) {
+        const float prq = clampf(unorm8[(mr >> 8) & 0xFFu], BRMI_MIN_PERCEPTUAL_ROUGHNESS, 1.0f);
+        fastTile = !__any(live && prq * prq < SHADE_FAST_ALPHA);
     }
     // ---- GetFragmentInfoScreenSpace + PopulateFragmentInfoFromOpenPBR + the light-independent part of the BRDF
     if (live) {
         const float4 cp = camK[8 + opaqueZero];
-        const f3 viewDir = normalize3_q(f3{cp.x, cp.y, cp.z} - posWS);
+        const f3 toEye = f3{cp.x, cp.y, cp.z} - posWS;
+        // (V stays correctly rounded on both paths: the bent normal below is nrm + k V, which cancels to a vector of length ~1e-4 where the stored normal points
+        // away from the eye, and an ulp of V is then a part in a thousand of N -- measured: 205 fp16 ulps on such pixels with a fast V)
+        const f3 viewDir = normalize3_q(toEye);
         f.posWS = posWS; f.viewWS = viewDir;
         const float4 ns = raw.ns;
         const f3 nrm{ns.x, ns.y, ns.z};
@@ -472,7 +473,7 @@ BRMI_DEV uint32_t shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const flo
         const float prc = clampf(pr, BRMI_MIN_PERCEPTUAL_ROUGHNESS, 1.0f);
         f.roughness = prc * prc;
         const float NdotVraw = dot3(nrm, viewDir);
-        f.normalWS = normalize3_q(nrm + max2(0.0f, -NdotVraw + BRMI_MIN_N_DOT_V) * viewDir);
+        f.normalWS = normalize3_q(nrm + max2(0.0f, -NdotVraw + BRMI_MIN_N_DOT_V) * viewDir);      // (N too: N.L and N.V carry its absolute error to terms that vanish with them)
         f.NdotV = max2(BRMI_MIN_N_DOT_V, NdotVraw);
         uint32_t opIndex = (uint32_t)(ns.w + 0.5f);
         if (opIndex >= a.openpbrMaterialCount) opIndex = 0;
@@ -527,17 +528,13 @@ BRMI_DEV uint32_t shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const flo
     // Waterfall over the distinct clusters of the wave (an 8x8 tile usually sits in one).  The loop and the staging run with every lane
     // of the wave; only the light loop proper is restricted to the lanes of the cluster.  The lane set comes from a ballot and `uci`
     // depends on the loop-carried mask, so neither can be replaced by the per-lane `ci`.
-    bool staged = BRMI_SHADE_EARLY_STAGE != 0;           // (uci, listBase, listCount, s) describe the first cluster's first chunk
     while (pending != 0ull) {
-        if (!staged) {
-            uci = (uint32_t)__builtin_amdgcn_readlane((int)ci, (int)((uint32_t)__ffsll((unsigned long long)pending) - 1u));
-            listBase = 0u; listCount = k.numLights;
-            if (a.clustered) { const auto* cl = kconst(reinterpret_cast<const uint32_t*>(a.clusterList)) + 2u * (size_t)uci; listBase = cl[0]; listCount = cl[1]; }
-        }
+        uci = (uint32_t)__builtin_amdgcn_readlane((int)ci, (int)((uint32_t)__ffsll((unsigned long long)pending) - 1u));
+        listBase = 0u; listCount = k.numLights;
+        if (a.clustered) { const auto* cl = kconst(reinterpret_cast<const uint32_t*>(a.clusterList)) + 2u * (size_t)uci; listBase = cl[0]; listCount = cl[1]; }
         const uint64_t same = __ballot(live && ci == uci);
         pending &= ~same;
         const bool mine = (same >> lane_id()) & 1ull;
-#if BRMI_SHADE_SCALAR_LIGHTS
         // The records of a cluster's lights lie in list order (k_lc_fill), so light q of the list is ONE wave-uniform 64 B record: a scalar
         // load brings it into SGPRs -- no staging registers (16 VGPRs) and no v_readlane per field.
 #ifdef BRMI_ABLATE_LIGHTREC
@@ -545,86 +542,54 @@ BRMI_DEV uint32_t shade_pixel(const ShadeArgs& a, const ShadeFrame& k, const flo
 #else
         const float4* recBase = a.clustered ? a.listRecords + (size_t)listBase * 4u : a.shadeLights;
 #endif
-        if (mine) for (uint32_t q = 0; q < listCount; q++) {
-            // one s_load_dwordx16 (as sixteen separate words the compiler fetched the record in four dependent pieces)
-            typedef float f32x16 __attribute__((ext_vector_type(16)));
-            const f32x16 w = *reinterpret_cast<const __attribute__((address_space(4))) f32x16*>(kconst(recBase + (size_t)q * 4u));
-            const ShadeLightRecord lr{{w[0], w[1], w[2], w[3]}, {w[4], w[5], w[6], w[7]}, {w[8], w[9], w[10], w[11]}, {w[12], w[13], w[14], w[15]}};
-            const f3 lp{lr.r0[0], lr.r0[1], lr.r0[2]};
-            const float maxRange = lr.r0[3];
-            f3 lightToFrag; float att = 1.0f, spot = 1.0f;
-            if (maxRange < 0.0f) lightToFrag = lp;           // directional
-            else {
-                const float range2Hi = lr.r1[3];
-                const f3 toL = lp - posWS;
-                const float d2 = dot3(toL, toL);
-                if (d2 > range2Hi || dot3(f.normalWS, toL) < -1.0e-5f * qsqrt(d2)) continue;
-                float dist;
-                lightToFrag = normalize3_len(toL, d2, dist);
-                if (dist > maxRange) continue;
-                att = qrcp((lr.r1[0] + lr.r1[1] * dist + lr.r1[2] * dist * dist) + 0.0001f);
-            }
-            const float NoL = satq(dot3(f.normalWS, lightToFrag));
-            if (NoL == 0.0f) continue;
-            const float outer = lr.r3[3];
-            if (outer > -1.5f) {                                    // spot light
-                const f3 sd{lr.r3[0], lr.r3[1], lr.r3[2]};
-                const float inner = lr.r2[3];
-                const float cc = dot3(sd, normalize3_q(-lightToFrag));
-                if (!(cc > outer)) continue;
-                if (cc < inner) { const float t = satq((cc - outer) / (inner - outer)); spot = t * t * (3.0f - 2.0f * t); }
-            }
-            const f3 h = normalize3_q(lightToFrag + f.viewWS);
-            const float NoH = satq(dot3(f.normalWS, h)), LoH = satq(dot3(lightToFrag, h));
-            const float VdotL = dot3(f.viewWS, lightToFrag);
-            const float D = d_ggx(ctx.base.specularAlpha, NoH);
-            const f3 col{lr.r2[0], lr.r2[1], lr.r2[2]};
-            lighting = light_contribution<MODE, STASH>(L, f, ctx, stash, lightToFrag, NoL, NoH, LoH, VdotL, D, col, att, spot, lighting);
-        }
-#else
-        for (uint32_t c0 = 0; c0 < listCount; c0 += 64u) {
-            const uint32_t n = min(64u, listCount - c0);
-            if (!staged) s = stage_lights(a, listBase, c0, n);
-            staged = false;
-            if (mine) for (uint32_t q = 0; q < n; q++) {
-                const f3 lp{bcast(s.r0.x, q), bcast(s.r0.y, q), bcast(s.r0.z, q)};
-                const float maxRange = bcast(s.r0.w, q);
+        // (two instantiations of the loop, chosen per tile: FAST = the direction vectors within an ulp, see SHADE_FAST_ALPHA)
+        auto light_loop = [&](auto fastTag) {
+            constexpr bool FAST = decltype(fastTag)::value;
+            for (uint32_t q = 0; q < listCount; q++) {
+                // one s_load_dwordx16 (as sixteen separate words the compiler fetched the record in four dependent pieces)
+                typedef float f32x16 __attribute__((ext_vector_type(16)));
+                const f32x16 w = *reinterpret_cast<const __attribute__((address_space(4))) f32x16*>(kconst(recBase + (size_t)q * 4u));
+                const ShadeLightRecord lr{{w[0], w[1], w[2], w[3]}, {w[4], w[5], w[6], w[7]}, {w[8], w[9], w[10], w[11]}, {w[12], w[13], w[14], w[15]}};
+                const f3 lp{lr.r0[0], lr.r0[1], lr.r0[2]};
                 f3 lightToFrag; float att = 1.0f, spot = 1.0f;
-                if (maxRange < 0.0f) lightToFrag = lp;           // directional
+                if (lr.r0[3] < 0.0f) lightToFrag = lp;           // directional
                 else {
-                    const float range2Hi = bcast(s.r1.w, q);
+                    // lighting.hlsli:614-617's `dist > maxRange` as d2 > T (k_frame_constants: the largest squared distance whose correctly rounded root is <= maxRange)
                     const f3 toL = lp - posWS;
                     const float d2 = dot3(toL, toL);
-                    // conservative rejects (exactly the lanes dropped here would be dropped below): beyond the range, or facing away
-                    // by more than any rounding of normalize() can undo
-                    if (d2 > range2Hi || dot3(f.normalWS, toL) < -1.0e-5f * qsqrt(d2)) continue;
+                    if (d2 > lr.r1[3]) continue;
                     float dist;
-                    lightToFrag = normalize3_len(toL, d2, dist);         // length(toL), normalize(toL) = toL * (1 / sqrt(dot))
-                    if (dist > maxRange) continue;                      // lighting.hlsli:614-617
-                    const float a0 = bcast(s.r1.x, q), a1 = bcast(s.r1.y, q), a2 = bcast(s.r1.z, q);
-                    att = qrcp((a0 + a1 * dist + a2 * dist * dist) + 0.0001f);
+                    if (FAST) {
+                        const float inv = rsq_nr(d2); lightToFrag = toL * inv; dist = d2 * inv;
+                        // a light at grazing incidence: the term is proportional to N.L, whose ABSOLUTE error (~1.5e-7 with L an ulp off) is then a large part of it --
+                        // 17 fp16 ulps on pixels that one such light alone leaves at 1e-4 (measured) -- so those lanes take the correctly rounded L after all
+                        if (fabsf(dot3(f.normalWS, lightToFrag)) < SHADE_FAST_MIN_NOL) lightToFrag = normalize3_len(toL, d2, dist);
+                    } else {
+                        if (dot3(f.normalWS, toL) < -1.0e-5f * qsqrt(d2)) continue;      // facing away by more than any rounding of normalize() can undo: dropped before the exact root
+                        lightToFrag = normalize3_len(toL, d2, dist);
+                    }
+                    att = qrcp((lr.r1[0] + lr.r1[1] * dist + lr.r1[2] * dist * dist) + 0.0001f);
                 }
-                // a light at or below the horizon contributes brdf * ... * 0 = +-0 (the BRDF is finite): adding it is the identity, so skip it
                 const float NoL = satq(dot3(f.normalWS, lightToFrag));
                 if (NoL == 0.0f) continue;
-                const float outer = bcast(s.r3.w, q);
+                const float outer = lr.r3[3];
                 if (outer > -1.5f) {                                    // spot light
-                    const f3 sd{bcast(s.r3.x, q), bcast(s.r3.y, q), bcast(s.r3.z, q)};
-                    const float inner = bcast(s.r2.w, q);
+                    const f3 sd{lr.r3[0], lr.r3[1], lr.r3[2]};
+                    const float inner = lr.r2[3];
                     const float cc = dot3(sd, normalize3_q(-lightToFrag));
-                    if (!(cc > outer)) continue;                        // spot = 0: contribution is +-0
+                    if (!(cc > outer)) continue;
                     if (cc < inner) { const float t = satq((cc - outer) / (inner - outer)); spot = t * t * (3.0f - 2.0f * t); }
                 }
-                const f3 h = normalize3_q(lightToFrag + f.viewWS);      // N, V, L, H stay correctly rounded
-                const float NoH = satq(dot3(f.normalWS, h)), LoH = satq(dot3(lightToFrag, h));
-                const float VdotL = dot3(f.viewWS, lightToFrag);
+                const f3 hv = lightToFrag + f.viewWS;
+                const f3 h = FAST ? normalize3_fast(hv) : normalize3_q(hv);
+                const float NoH = satq(FAST ? dot3f(f.normalWS, h) : dot3(f.normalWS, h)), LoH = satq(FAST ? dot3f(lightToFrag, h) : dot3(lightToFrag, h));
+                const float VdotL = FAST ? dot3f(f.viewWS, lightToFrag) : dot3(f.viewWS, lightToFrag);
                 const float D = d_ggx(ctx.base.specularAlpha, NoH);
-                const f3 col{bcast(s.r2.x, q), bcast(s.r2.y, q), bcast(s.r2.z, q)};
+                const f3 col{lr.r2[0], lr.r2[1], lr.r2[2]};
                 lighting = light_contribution<MODE, STASH>(L, f, ctx, stash, lightToFrag, NoL, NoH, LoH, VdotL, D, col, att, spot, lighting);
             }
-        }
-#endif
-        staged = false;
+        };
+        if (mine) { if (fastTile) light_loop(FastDirections{}); else light_loop(ExactDirections{}); }
     }
     if (live) {
         // EvaluateOpenPBREmissive
