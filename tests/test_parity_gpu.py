@@ -282,6 +282,7 @@ def test_band_split_composes_to_full_frame(case, scenes, gpu_frames):
     ("sponza", 640, 384, dict(point_lights=16, size_scale=0.25, material_features=24), 32, 2),
     ("bistro", 640, 384, dict(point_lights=32, size_scale=0.1), 64, 3),
     ("tiny", 256, 144, dict(point_lights=4, skinned_fraction=1.0, lod_levels=2), 16, 3),
+    ("bistro", 640, 384, dict(point_lights=16, size_scale=0.2, skinned_fraction=0.5, lod_builder="own", detail=4.0), 16, 8),      # skinned instances of multi-level DAGs from the library's builder, eight ranks
 ])
 def test_interleaved_stripes_compose_to_full_frame(preset, W, H, kw, rows, count):
     """The interleaved screen partition (brmi_config::stripe*; SURVEY.md 8e): GPU r owns the chunks of `rows` rows with index r (mod count) and
@@ -297,9 +298,17 @@ def test_interleaved_stripes_compose_to_full_frame(preset, W, H, kw, rows, count
     fa, fb, fd = orc.canonical_ids(full.visibility(), full.visible_clusters())
     fh, fdepth = full.hdr(), full.depth().view(np.uint32)
     covered = np.zeros(H, dtype=bool)
+    # (round 5, the advisor's finding) the ownership test also rejects instances and hierarchy nodes, which is only right if a node's sphere holds its
+    # meshlets' -- skinned bounds inside the instance's sphere included: a cluster a rank drops wrongly is never replayed.  Every row belongs to some rank, so
+    # the UNION of the ranks' cluster lists must be the single-GPU list exactly, and no rank may list a cluster the full frame does not have.
+    as_set = lambda cl: set(map(tuple, np.asarray(cl)[:, :3].tolist()))
+    full_set, union = as_set(full.visible_clusters()), set()
     for index in range(count):
         r = VisibilityRenderer(sc, stripes=(rows, count, index))
         r.execute()
+        mine = as_set(r.visible_clusters())
+        assert mine <= full_set, f"rank {index} lists {len(mine - full_set)} clusters the full frame does not have"
+        union |= mine
         fr = r.frame_rows()
         assert len(fr) == H // count and not covered[fr].any()
         covered[fr] = True
@@ -309,6 +318,7 @@ def test_interleaved_stripes_compose_to_full_frame(preset, W, H, kw, rows, count
         assert np.array_equal(r.depth().view(np.uint32), fdepth[fr]), f"rank {index}: depth differs"
         r.close()
     assert covered.all()
+    assert union == full_set, f"{len(full_set - union)} visible clusters of the full frame are in no rank's list"
     full.close()
 
 

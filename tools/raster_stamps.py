@@ -8,7 +8,8 @@ from basicrenderer_amd.renderer import VisibilityRenderer
 import bench
 wl = sys.argv[1]
 preset, kw, feat = bench.WORKLOADS[wl]
-sc = Scene(preset, 3840, 2160, point_lights=256, material_features=feat, **kw)
+W, H = bench.FRAME_SIZE.get(wl, (3840, 2160))
+sc = Scene(preset, W, H, point_lights=bench.LIGHTS[wl], material_features=feat, **kw)
 r = VisibilityRenderer(sc, occlusion=True, stats=True)
 frames = 4
 for _ in range(frames):
