@@ -539,8 +539,28 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
             // Small boxes: global atomics.  lane = triangle leaves most lanes idle (culled triangles, boxes of very different
             // size), so the rows of the batch's small triangles are re-dealt to the lanes: an exclusive scan of the row counts,
             // the setup of every triangle parked in LDS, then lane k takes rows k, k + 64, ... of the concatenated row list.
+#ifndef BRMI_RASTER_TINY
+#define BRMI_RASTER_TINY 4
+#endif
+#ifndef BRMI_RASTER_TINY_RANGES
+#define BRMI_RASTER_TINY_RANGES 0
+#endif
+            // Round 5: a pass whose small boxes are ALL at most BRMI_RASTER_TINY x BRMI_RASTER_TINY pixels (frames of sub-pixel triangles: the Zorah-class frame rasterises 48 M
+            // triangles for 33 M pixels) is walked lane = triangle -- no prefix scan, no parking of thirteen values per triangle in LDS, no bisection per row task: the re-deal
+            // exists to balance boxes of very different size, and these are all the same.  Same arithmetic per pixel (raster_row from the box's first row).
+            const bool smallHere = active && !big && !(a.debugFlags & 1) && yLo <= yHi;
+            const bool tinyPass = BRMI_RASTER_TINY > 0 && !striped && !alphaCluster && (BRMI_RASTER_TINY_RANGES || !useScanlineRanges) && !__any(smallHere && (maxY - minY + 1) > BRMI_RASTER_TINY);
+            if (tinyPass) {
+                if (smallHere) {
+                    float sb0 = row_b0, sb1 = row_b1;
+                    for (int y = minY; y <= maxY; y++) {
+                        if (y >= yLo && y <= yHi) raster_row(gsink, NoAlpha{}, y, minX, rectWidth, useScanlineRanges, sb0, sb1, dx_b0, dx_b1, -(dx_b0 + dx_b1), d0, d1, d2, clusterIndex, t, minX, minX + rectWidth - 1);
+                        sb0 += dy_b0; sb1 += dy_b1;
+                    }
+                }
+            } else
             {
-                const bool small = active && !big && !(a.debugFlags & 1) && yLo <= yHi;
+                const bool small = smallHere;
                 uint32_t myRows = small ? (uint32_t)(yHi - yLo + 1) : 0u;
                 // interleaved partition: a box inside one chunk (nearly all small boxes) is owned whole or dropped here; one that straddles a
                 // chunk boundary keeps its rows and the row tasks test each
