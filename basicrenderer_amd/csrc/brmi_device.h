@@ -230,6 +230,13 @@ BRMI_DEV float uni(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_
 BRMI_DEV m4 uni_m4(const m4& a) { m4 r; for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) r.m[i][j] = uni(a.m[i][j]); return r; }
 BRMI_DEV uint32_t lane_id() { return __lane_id(); }
 BRMI_DEV uint32_t lane_rank(uint64_t mask) { return __popcll(mask & ((1ull << lane_id()) - 1ull)); }
+// LDS visibility inside ONE wave (single-wave workgroups, or waves of one workgroup that run different amounts of work: no workgroup barrier between their
+// steps).  __syncthreads() would also wait for every global store and atomic the wave has in flight: a memory round trip per hand-off.
+BRMI_DEV void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 // ---- skinning (BR/shaders/Include/skinningCommon.hlsli:23-88) -------------------------------------------------------------
 // `skinningMatrices` holds bone * inverseBind per (slot, joint), 64 joints per slot; LoadBoneSkinMatrix is its transpose.
 BRMI_DEV m4 load_bone_skin_matrix(const float* skinningMatrices, uint32_t slot, uint32_t joint) {

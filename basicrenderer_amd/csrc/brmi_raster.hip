@@ -95,13 +95,6 @@ __global__ void __launch_bounds__(256) k_clear_vis(unsigned long long* vis, uint
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < frameState16; i += (uint64_t)gridDim.x * blockDim.x) frameState[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
-// LDS visibility inside ONE wave (waves of one workgroup that run different amounts of work: no workgroup barrier between their steps)
-BRMI_DEV void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 // ClipScanlineRange (softwareRaster.hlsl:262-288).  The shader divides -value / step for a rising edge and value / -step for a falling one; IEEE
 // division is sign-symmetric, so both are the same number: ONE correctly rounded division per edge whatever the lanes' signs (as two branches a
 // wave whose lanes disagree about the sign ran both: six divisions per row, half of what a binned row of average length costs).

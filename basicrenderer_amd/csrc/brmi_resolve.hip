@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(64) k_resolve_setup(GBufferArgs a) {
                 for (uint32_t set = 0; set < a.uvSets; set++) { const f2 uv = decode_uv_set(a.clusterUv[c], set, v); a.uvs[(size_t)set * a.vertCapacity + cs.vertBase + v] = make_float2(uv.x, uv.y); }
             if (a.colors && (cs.counts & BRMI_CS_COLOR)) a.colors[cs.vertBase + v] = reinterpret_cast<const uint32_t*>(a.clusterUv[c].color)[v];
         }
-        __syncthreads();
+        wave_lds_sync();      // (one wave per workgroup: the LDS hand-off must not wait for the arena stores in flight, round 5)
         for (uint32_t t = lane; t < triCount; t += 64) {
             const uint8_t* tb = cs.triBase + t * 3u;
             const uint32_t i0 = tb[0], i1 = tb[1], i2 = tb[2];
@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(64) k_resolve_setup(GBufferArgs a) {
             r.indices = i0 | (i1 << 8) | (i2 << 16);
             a.tris[cs.triBase32 + t] = r;
         }
-        __syncthreads();
+        wave_lds_sync();
     }
 }
 

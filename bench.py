@@ -140,6 +140,8 @@ def main():
         torch.cuda.set_device(0)
         out = multi_gpu_legs(args, args.gpus, args.emulate_rank, 0, emulated=True)
         out["emulated"] = f"rank {args.emulate_rank} of {args.gpus} alone on one GPU: value counts all {args.gpus} ranks' pixels over THIS rank's time; not an N-GPU measurement"
+        import ctypes
+        ctypes.CDLL(None).fflush(None)          # (RCCL's version banner sits in the C stdout buffer under --force-compose: the JSON stays the last line)
         print(json.dumps(out), flush=True)
         return
     world_env = os.environ.get("WORLD_SIZE")
@@ -530,6 +532,14 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False,
             out["cpu_baseline"] = cpu_baseline(scene, args.cpu_scale)
             out["cpu_baseline_1thread"] = cpu_baseline(scene, args.cpu_scale_1thread, threads=1, budget_s=6.0, max_frames=2)
             out["configs0"] = cpu_forward_baseline()
+    if composer is not None:
+        # the leg's composer goes before the next leg makes its own (the RCCL path: every rank destroys its communicator at the same point of the same sequence)
+        composer.finish()
+        torch.cuda.synchronize()
+        if hasattr(composer, "close"):
+            composer.close()
+        if multi:
+            dist.barrier()
     for p in passes:
         p.close()
     return out
