@@ -1642,7 +1642,11 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
         // Scenes of very many draws (Zorah-class): the level-synchronous flat traversal, a lane per (instance, node) task, one launch per level of the
         // deepest hierarchy (k_cull_flat_level).  Its launches carry no riders: the visibility clear moves onto k_cull_clusters (ClearRide) and the
         // light clustering is launched by the frame where it finds none done.
-        flatLevels = hierarchy && p->allMeshesFlat && !p->forceLevelKernels && p->scene.activeDrawCount >= std::max(1u, p->flatLevelsMinDraws);
+        // (also, from a quarter of that count on, in a SPLIT frame of a scene whose hierarchies need the 24 KB-frontier variant of the walk: its single-wave workgroups of 150 registers
+        // and 24 KB of LDS find few slots beside another frame's shading waves -- San-Miguel-class, 7,577 draws: 0.848 -> 0.823 ms in flight although the stage alone is 0.107 -> 0.119;
+        // the dense and Bistro-class frames, with fewer draws, lose either way)
+        const uint32_t draws = p->scene.activeDrawCount, minDraws = std::max(1u, p->flatLevelsMinDraws);
+        flatLevels = hierarchy && p->allMeshesFlat && !p->forceLevelKernels && (draws >= minDraws || (p->splitFrame && p->maxLevelWidth > 256u && draws >= std::max(1u, minDraws / 4u)));
         if (flatLevels) {
             if (p->clearVisibilityWithTraversal && (p->bandPixelCount & 1ull) == 0ull) { p->clearVisibilityWithTraversal = false; p->clearVisibilityWithClusterCull = true; }
             else if (p->clearVisibilityWithTraversal) flatLevels = false;      // (an odd pixel count: the riding clear of the walk handles it)

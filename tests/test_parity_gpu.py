@@ -605,22 +605,27 @@ def test_full_size_frames_against_the_oracle(preset, W, H, lights, kw):
 @pytest.mark.parametrize("preset,lights,kw,in_flight", [("sponza", 64, dict(), 1), ("bistro", 256, dict(), 1), ("san_miguel", 256, dict(material_features=24), 1),
                                                         ("bistro", 256, dict(size_scale=20.0, detail=96.0), 1),      # the dense workload: 2-phase occlusion over the mixed traversal
                                                         ("bistro", 256, dict(), 2),                                  # two passes render alternate frames
-                                                        ("bistro", 256, dict(unique_budget=True, lod_builder="own", relief_slope=1.5), 2)])   # the bench default of round 3, as the bench runs it
+                                                        ("bistro", 256, dict(unique_budget=True, lod_builder="own", relief_slope=1.5), 2),    # the bench default of round 3, as the bench runs it
+                                                        ("bistro", 256, dict(unique_budget=True, lod_builder="own", relief_slope=1.5), 3),    # round 5: ... with the ring of three passes bench.py has run since round 4 (four frames: the ring closes)
+                                                        ("san_miguel", 256, dict(material_features=24), 3)])                                  # configs[3]'s scene in the same arrangement
 def test_full_size_camera_path_with_occlusion_against_the_oracle(preset, lights, kw, in_flight):
     """Three 4K frames of the camera path with 2-phase occlusion culling on (the bench default), every frame against the oracle's
     2-phase frame: both phases' cluster lists, keys, depth, G-buffer exact, HDR within one fp16 ULP on covered pixels (pixels without
-    geometry are not written -- DeferredCSMain returns -- so they keep the previous frame's value).  in_flight = 2: the frames
-    alternate between two linked passes (brmi_set_history_source), each testing phase 1 against the other's depth chain."""
+    geometry are not written -- DeferredCSMain returns -- so they keep the previous frame's value).  in_flight = 2 / 3: the frames
+    go round a ring of linked passes (brmi_set_history_source), each testing phase 1 against the chain of the pass that rendered the frame before
+    (in_flight = 3: four frames, so that the ring closes)."""
     import orc
     from conftest import Scene
     from basicrenderer_amd.renderer import VisibilityRenderer
     hz, passes = None, []
-    for step in range(3):
+    for step in range(max(3, in_flight + 1)):
         sc = Scene(preset, 3840, 2160, point_lights=lights, camera_step=step, **kw)
         if len(passes) < in_flight:
             passes.append(VisibilityRenderer(sc, occlusion=True, stats=True))
-            if len(passes) == 2:
-                passes[0].set_history_source(passes[1]); passes[1].set_history_source(passes[0])
+            if len(passes) >= 2:      # a ring: every pass tests phase 1 against the chain of the pass that rendered the frame before
+                passes[-1].set_history_source(passes[-2])
+                if len(passes) == in_flight:
+                    passes[0].set_history_source(passes[-1])
             r = passes[-1]
         else:
             r = passes[step % in_flight]
