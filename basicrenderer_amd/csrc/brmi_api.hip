@@ -749,7 +749,7 @@ int brmi_execute_split(brmi_pass* p, brmi_stream stream, brmi_stream shadeStream
     // whatever way this call returns, the frame's shortcuts do not outlive it: stand-alone stage calls behind a failed frame must not find `splitFrame`
     // (which disables the wide flat traversal), `shadeSharesChip` or the issued-waits mark still set
     struct FrameScope { brmi_pass* p; ~FrameScope() { p->splitFrame = false; p->shadeSharesChip = false; p->frameWaitsIssued = false; p->clearFrameStateWithConstants = false; p->fuseFrameClear = false; p->seedInHzbTail = false; } } frameScope{p};
-    p->resolveSetupDone = false; p->depthFinal = false;      // (a frame that failed half-way must not leave its shortcuts to the stage entry points)
+    p->resolveSetupDone = false; p->depthFinal = false; p->marksFromChain = false;      // (a frame that failed half-way must not leave its shortcuts to the stage entry points)
     if ((rc = wait_for_frames_in_flight(p, stream))) return rc;
     p->frameWaitsIssued = true;
     // When the phase-1 traversal is the one-launch LDS walk and the frame constants are due anyway, the frame needs no clear launch: the

@@ -236,6 +236,7 @@ struct brmi_pass {
     std::vector<brmi_pass*> historyUsers;   // passes whose `history` is this pass (unlinked when it is destroyed)
     bool layerPlanesDirty = false;   // brmi_setup: the next constants launch is followed by k_fill_layer_planes
     bool layerPlanesUniform = false; // ... which found one coat and one fuzz word for the whole scene and filled both planes (read back once)
+    bool marksFromChain = false;     // brmi_execute: the first depth-chain build of this frame stored the "owns a pixel" marks of the phase-1 clusters (no k_mark_used_clusters launch)
     bool resolveSetupDone = false;   // brmi_execute_split: the per-cluster tables were made on the geometry stream
     bool depthFinal = false;         // brmi_execute: the depth map is final before the G-buffer kernel runs (it skips its depth store)
     const brmi_pass* chainOwner(uint32_t phase) const { return (phase == 1 && history) ? history : this; }

@@ -1206,8 +1206,9 @@ BRMI_DEV void plan_bins(const RasterArgs& a) {
 // Records that did not fit their bin: four per wave64, one lane per row, global 64-bit atomics.  Runs BEFORE k_raster_bins (whose plain
 // read-modify-write merges then see these keys like k_raster's own); its last workgroup writes that launch's plan.  The queue lengths are
 // cleared with the frame's counters and, between the two raster phases, by k_seed_phase2.
-template <bool ALPHA>
-__global__ void __launch_bounds__(256) k_raster_overflow(RasterArgs a) {
+// THREADS: 256, or 1024 for surfaces of more than 4096 bins (an 8K frame has 8,100: the plan is ONE workgroup's work and was 51 us of the Zorah-class frame's chain)
+template <bool ALPHA, uint32_t THREADS = 256>
+__global__ void __launch_bounds__(THREADS) k_raster_overflow(RasterArgs a) {
     wave_prio<PRIO_BINS>();
 #ifdef BRMI_TILE_STAMPS
     if (blockIdx.x == 0u) {        // (instrumented builds: how long the plan takes, in 10 ns units; slots 40 / 41 of the stamp words)
@@ -1221,9 +1222,9 @@ __global__ void __launch_bounds__(256) k_raster_overflow(RasterArgs a) {
     if (blockIdx.x == 0u) { plan_bins(a); return; }       // (the first workgroup: it is what the next launch waits for, so it should not queue behind the walkers)
     // a wave = four records at a time, one lane per row
     const uint32_t lane = threadIdx.x & 63u, sub = lane >> 4, row = lane & 15u;
-    const uint32_t walker = (blockIdx.x - 1u) * 4u + (threadIdx.x >> 6), walkers = (gridDim.x - 1u) * 4u;
+    const uint32_t walker = (blockIdx.x - 1u) * (THREADS / 64u) + (threadIdx.x >> 6), walkers = (gridDim.x - 1u) * (THREADS / 64u);
     __shared__ float unormT[ALPHA ? 256 : 1];
-    if (ALPHA) { unormT[threadIdx.x] = (float)threadIdx.x / 255.0f; __syncthreads(); }
+    if (ALPHA) { if (threadIdx.x < 256u) unormT[threadIdx.x] = (float)threadIdx.x / 255.0f; __syncthreads(); }
     // lane = stripe: all 64 queue lengths with one load; nearly every frame has none
     const uint32_t mine = min(a.counters[CNT_STRIPES + lane * CNT_STRIPE_WORDS + STRIPE_OVERFLOW], a.overflowPerStripe);
     uint64_t busy = __ballot(mine != 0u);
@@ -1325,7 +1326,10 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
         if (!direct2 && !(p->rasterDebug & 4)) hipLaunchKernelGGL(k_raster_bins<true>, bgrid, dim3(BRMI_BIN_THREADS), 0, s, a);
     } else {
         hipLaunchKernelGGL(k_raster<false>, rgrid, dim3(64), a.tableCells * 4u, s, a);
-        if (!direct2) hipLaunchKernelGGL(k_raster_overflow<false>, ogrid, dim3(256), 0, s, a);
+        if (!direct2) {
+            if (p->binsX * p->binsY > 4096u) hipLaunchKernelGGL((k_raster_overflow<false, 1024>), dim3((ogrid.x - 1u + 3u) / 4u + 1u), dim3(1024), 0, s, a);
+            else hipLaunchKernelGGL(k_raster_overflow<false>, ogrid, dim3(256), 0, s, a);
+        }
         if (!direct2 && !(p->rasterDebug & 4)) hipLaunchKernelGGL(k_raster_bins<false>, bgrid, dim3(BRMI_BIN_THREADS), 0, s, a);
     }
     BRMI_LAUNCH_CHECK(p, "k_raster");

@@ -37,6 +37,7 @@ struct GBufferArgs {
     uint32_t uvSets;                              // sets the materials of the scene address (1 unless one names a set > 0): uvs holds [set][vertCapacity]
     uint32_t* colors;                             // scenes with vertex colours: the RGBA8 colour of the arena's vertices
     uint32_t setupPart;            // k_resolve_setup: 0 = every visible cluster, 1 = the phase-1 clusters only (launched beside the rasteriser), 2 = the phase-2 clusters only
+    uint32_t marksCoverPhase1Only; // the marks come from the first depth-chain build (brmi_hzb.hip): phase 2's clusters are all set up
     uint32_t variantSelect;        // 0: run; 1: run only when no cluster spilled out of the arena; 2: only when one did (counters[CNT_RESOLVE_SPILL])
 };
 
@@ -90,7 +91,7 @@ __global__ void __launch_bounds__(64) k_resolve_setup(GBufferArgs a) {
         __hip_atomic_store(a.hostFeedback + 1, tris * 2ull > a.pixelCount ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     for (uint32_t c = firstCluster + blockIdx.x; c < clusterCount; c += gridDim.x) {
-        if (marked && a.used[c] == 0) continue;      // no pixel shows this cluster
+        if (marked && a.used[c] == 0 && !(a.marksCoverPhase1Only && c >= min(a.counters[CNT_VISIBLE], a.clusterCapacity))) continue;      // no pixel shows this cluster
         const ClusterSetup cs = a.setup[c];
         if (cs.vertBase == BRMI_ARENA_NONE) continue;          // arena full: the pixel pass walks this cluster's data itself
         const uint32_t vertCount = cs.counts & 0xFFu, triCount = (cs.counts >> 8) & 0xFFu, posFormat = (cs.counts >> 16) & 0xFFu;
@@ -608,7 +609,7 @@ __global__ void __launch_bounds__(256, INLINE_TABLES ? 1 : (MULTI_UV ? (PARALLAX
 
 static GBufferArgs gbuffer_args_of(brmi_pass* p) {
     GBufferArgs a;
-    a.hostFeedback = nullptr; a.setupPart = 0u;
+    a.hostFeedback = nullptr; a.setupPart = 0u; a.marksCoverPhase1Only = 0u;
     a.sc = shading_scene_of(p);      // the frame's camera / per-frame record as the constants kernel saw them (FrameSnapshot)
     a.clusters = static_cast<const uint4*>(p->res[BRMI_RES_VISIBLE_CLUSTERS]); a.counters = p->counters();
     a.vis = static_cast<const unsigned long long*>(p->res[BRMI_RES_VISIBILITY]);
@@ -651,8 +652,10 @@ int launch_resolve_setup(brmi_pass* p, hipStream_t s, uint32_t part) {
     // its meshlets together (totalBits: one survivor bit per meshlet of every instance), so most scenes can never be such a frame
     // ... and whether recent frames were of that kind the host reads from a word k_resolve_setup stores (no wait; a stale "no" only means
     // that this frame's setup covers every visible cluster, which is always correct)
-    if ((uint64_t)p->totalBits * BRMI_MESHLET_MAX_TRIS * 2ull > p->bandPixelCount && (!a.hostFeedback || reinterpret_cast<volatile uint32_t*>(p->phase2FeedbackHost)[1] != 0u))
+    a.marksCoverPhase1Only = p->marksFromChain ? 1u : 0u;
+    if (!p->marksFromChain && (uint64_t)p->totalBits * BRMI_MESHLET_MAX_TRIS * 2ull > p->bandPixelCount && (!a.hostFeedback || reinterpret_cast<volatile uint32_t*>(p->phase2FeedbackHost)[1] != 0u))
         hipLaunchKernelGGL(k_mark_used_clusters, dim3(2048), dim3(256), 0, s, a, p->wsPtr<uint8_t>(p->ws.usedClusters), p->counters());
+    p->marksFromChain = false;
     hipLaunchKernelGGL(k_resolve_setup, dim3(8192), dim3(64), 0, s, a);
     BRMI_LAUNCH_CHECK(p, "k_resolve_setup");
     return BRMI_OK;
