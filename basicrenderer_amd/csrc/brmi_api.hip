@@ -93,6 +93,8 @@ static void compute_sizes(brmi_pass* p) {
     w.bitmask1 = take((uint64_t)p->totalWords * 4);
     w.bitmask2 = take((uint64_t)p->totalWords * 4);
     w.blockDirty = take((uint64_t)2 * (p->scanBlocks + 1));      // per phase and 2048-word block of the bitmask: some survivor set a bit there (the ranking skips the others)
+    // phase 2's footprint for the second depth-chain build: a byte per 32 x 32 px block of the chain's head, from byte 4 (byte 0: "everything", stored by a triangle of more than 16 blocks)
+    w.chainDirty = take(4ull + (uint64_t)((c.width + 31u) / 32u) * ((c.height + 31u) / 32u));
     w.frameClearBytes = off - w.counters;
     w.usedClusters = take((uint64_t)c.maxVisibleClusters);     // one byte per visible cluster, zeroed by the compaction kernel
     w.frontierA = take((uint64_t)c.maxTraversalRecords * sizeof(NodeRecord));

@@ -45,11 +45,15 @@ BRMI_DEV void hzb_tail_levels(const HzbDesc& h, uint32_t firstMip, uint32_t thre
 // MarkUsed (round 5; FROM_VIS, brmi_execute's first build): frames with more than half a triangle per pixel have the G-buffer pass set up only the clusters that own a pixel.
 // The keys go through this kernel anyway, so it stores the "owns a pixel" bytes of the phase-1 clusters on the way (k_mark_used_clusters read the 8 B per pixel a second time:
 // 57 us of the Zorah-class 8K frame); phase 2's clusters, a handful, all count as used, and a phase-1 cluster that phase 2 covers completely keeps its stale mark (set up for nothing).
-struct MarkUsed { uint8_t* used; uint32_t* counters; uint64_t pixelCount; uint32_t clusterCapacity; };
+struct MarkUsed { uint8_t* used; uint32_t* counters; uint64_t pixelCount; uint32_t clusterCapacity;
+                  const uint8_t* chainDirty; uint32_t chainBlocksX; };      // second build: only the blocks phase 2's triangles may have touched (brmi_raster.hip), null = all
 template <bool FROM_VIS>
 __global__ void __launch_bounds__(256) k_hzb_head(HzbDesc h, const unsigned long long* vis, float* depthOut, const uint32_t* skipUnless, uint32_t blockRow0, MarkUsed mk) {
     wave_prio<PRIO_HZB>();
     if (skipUnless && *skipUnless == 0u) return;
+    if (mk.chainDirty && mk.chainDirty[0] == 0u) {      // (workgroup-uniform) phase 1's values of this block's texels of the depth map and of mips 1 - 5 still stand
+        if (blockIdx.x >= mk.chainBlocksX || mk.chainDirty[4u + (blockIdx.y + blockRow0) * mk.chainBlocksX + blockIdx.x] == 0u) return;
+    }
     bool marking = false; uint32_t markCount = 0u;
     if (FROM_VIS && mk.used) {
         marking = (uint64_t)mk.counters[CNT_SUM_VERTS_HI] * 2ull > mk.pixelCount;      // (wave-uniform: the triangles of phase 1's clusters, from the compaction)
@@ -144,7 +148,8 @@ int launch_hzb(brmi_pass* p, hipStream_t s, bool fromVisibility, bool onlyIfPhas
         const uint32_t row0 = h.rowLo / 32u, row1 = std::min((h.rowHi + 31u) / 32u, h.paddedH / 32u);
         const dim3 grid(h.paddedW / 32, std::max(1u, row1 - row0));
         // brmi_execute's first build (the keys of phase 1) also marks the clusters that own a pixel when the frame may be one of more triangles than pixels
-        MarkUsed mk{nullptr, p->counters(), p->bandPixelCount, p->cfg.maxVisibleClusters};
+        MarkUsed mk{nullptr, p->counters(), p->bandPixelCount, p->cfg.maxVisibleClusters, nullptr, (p->cfg.width + 31u) / 32u};
+        if (fromVisibility && onlyIfPhase2Drew && p->chainDirtyTracked) mk.chainDirty = p->wsPtr<uint8_t>(p->ws.chainDirty);
         if (fromVisibility && !onlyIfPhase2Drew && p->seedInHzbTail && resolve_setup_marks(p)) { mk.used = p->wsPtr<uint8_t>(p->ws.usedClusters); p->marksFromChain = true; }
         if (fromVisibility) hipLaunchKernelGGL(k_hzb_head<true>, grid, dim3(256), 0, s, h, static_cast<const unsigned long long*>(p->res[BRMI_RES_VISIBILITY]), static_cast<float*>(p->res[BRMI_RES_LINEAR_DEPTH]), skip, row0, mk);
         else hipLaunchKernelGGL(k_hzb_head<false>, grid, dim3(256), 0, s, h, (const unsigned long long*)nullptr, (float*)nullptr, skip, row0, mk);

@@ -144,7 +144,7 @@ struct FrameSnapshot { brmi_per_frame perFrame; brmi_camera camera; };
 struct LayerUniform { unsigned long long coatWord, fuzzWord, coatFilledWord, fuzzFilledWord; uint32_t coatUniform, fuzzUniform, coatFilled, fuzzFilled; };
 
 struct Workspace {     // byte offsets into BRMI_RES_WORKSPACE
-    uint64_t counters, frontierA, frontierB, buckets, tempVisible, bitmask1, bitmask2, blockDirty, wordPrefix, blockSums,
+    uint64_t counters, frontierA, frontierB, buckets, tempVisible, bitmask1, bitmask2, blockDirty, chainDirty, wordPrefix, blockSums,
              instanceBitBase, segPrefix, meshLevelWidth, scanAgg, flatNodes, flatLeaves, instanceWalk, planes, replayNodes, replayBuckets, lightVS, lightMeta, clusterPages, clusterHits, pageTotal, lightHitMasks, binCounts, binRecords, binOverflow, binPlan, binItems, binScratch, clusterSetup, resolveVerts, resolveTris, matWords, shadeTables, lutF, frameConst, objConst, matConst, deferredPixels, usedClusters,
              frameSnapshot, debugStamps, clusterUv, binAlpha, overflowAlpha, resolveUVs, resolveColors, alphaMats, shadeRows, shadeAvgs, ggxQuads, shadeLights, clusterList, listEntries, listRecords, layerUniform, frameClearBytes, total;
 };
@@ -236,6 +236,7 @@ struct brmi_pass {
     std::vector<brmi_pass*> historyUsers;   // passes whose `history` is this pass (unlinked when it is destroyed)
     bool layerPlanesDirty = false;   // brmi_setup: the next constants launch is followed by k_fill_layer_planes
     bool layerPlanesUniform = false; // ... which found one coat and one fuzz word for the whole scene and filled both planes (read back once)
+    bool chainDirtyTracked = false;  // this frame's phase-2 rasteriser recorded the blocks it may have touched (the second chain build skips the others)
     bool marksFromChain = false;     // brmi_execute: the first depth-chain build of this frame stored the "owns a pixel" marks of the phase-1 clusters (no k_mark_used_clusters launch)
     bool resolveSetupDone = false;   // brmi_execute_split: the per-cluster tables were made on the geometry stream
     bool depthFinal = false;         // brmi_execute: the depth map is final before the G-buffer kernel runs (it skips its depth store)

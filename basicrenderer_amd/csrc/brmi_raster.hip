@@ -49,6 +49,9 @@ constexpr int BIN_W = 256, BIN_ROWS = 16;          // bin = 4096 keys = 32 KB of
 constexpr int BIN_W_SHIFT = 8, BIN_ROWS_SHIFT = 4;
 // a bin's record counter has a 128 B line to itself: atomics on ONE cache line serialise at 50-90 per microsecond whatever their addresses, and
 // the bins of a screen band (15 neighbours in one line, the horizon's among them) take thousands of slot reservations per frame
+#ifndef BRMI_CHAIN_DIRTY_BLOCKS
+#define BRMI_CHAIN_DIRTY_BLOCKS 1      // phase 2 records the 32 x 32 px blocks it may touch; the second depth-chain build redoes only those
+#endif
 constexpr uint32_t BIN_COUNT_STRIDE = BRMI_BIN_COUNT_STRIDE;
 constexpr int BIN_WINDOW = 256;                     // bins a wave counts in LDS with its reservations held in registers (cells of its bin bounding box)
 constexpr int COOP_ENTRIES = 64;                    // triangles with more bin entries than this are emitted by the whole wave ...
@@ -77,6 +80,7 @@ struct RasterArgs {
     brmi_scene_buffers sc;
     const uint4* clusters; const ClusterSetup* setup;
     uint32_t* counters;
+    uint8_t* chainDirty; uint32_t chainBlocksX;       // phase 2 only (else null): a byte per 32 x 32 px block its triangles may touch (byte 0: all, blocks from byte 4), for the second depth-chain build
     uint32_t firstCounter, countCounter;   // counter indices: first cluster (0xFFFFFFFF = 0) and cluster count
     unsigned long long* vis;
     uint32_t visW, visH, tilesX, bandY0, bandY1;      // visW x visH: the FRAME (scissor clamp); bandY0 / bandY1: rows of the surface this GPU renders (records live in surface rows)
@@ -455,6 +459,16 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
                 }
             }
             const int rectWidth = maxX - minX + 1;
+            if (a.chainDirty && active) {
+                // round 5 (phase 2 only, wave-uniform): what phase 2 draws is small; the chain's second build then only redoes the 32 x 32 px blocks a phase-2 triangle's
+                // box touches.  A byte per block, plain stores of 1 like the used-cluster marks: no atomic (they serialise on a line), nothing to wait for.
+                const int cy0 = max(minY, (int)a.rowLo), cy1 = min(maxY, (int)a.rowHi - 1);
+                if (cy0 <= cy1) {
+                    const int bx0 = minX >> 5, bx1 = maxX >> 5, by0 = cy0 >> 5, by1 = cy1 >> 5;
+                    if ((bx1 - bx0 + 1) * (by1 - by0 + 1) > 16) a.chainDirty[0] = 1;
+                    else for (int by = by0; by <= by1; by++) for (int bx = bx0; bx <= bx1; bx++) a.chainDirty[4u + (uint32_t)by * a.chainBlocksX + (uint32_t)bx] = 1;
+                }
+            }
             const bool useScanlineRanges = __any(active && rectWidth > 4);
             if (parts > 1u && lane / lanesPerPart != part) active = false;      // another wave's share of the pass
             const int rows = maxY - minY + 1;
@@ -1269,6 +1283,9 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
     a.sc = p->scene; a.clusters = static_cast<const uint4*>(p->res[BRMI_RES_VISIBLE_CLUSTERS]); a.counters = p->counters();
     a.setup = p->wsPtr<ClusterSetup>(p->ws.clusterSetup);
     a.firstCounter = 0xFFFFFFFFu; a.countCounter = CNT_VISIBLE;
+    // (the interleaved partition's surface rows are not the frame rows the boxes are in: there the second build redoes everything)
+    a.chainDirty = (BRMI_CHAIN_DIRTY_BLOCKS && phase == 2 && p->stripes.count <= 1u) ? p->wsPtr<uint8_t>(p->ws.chainDirty) : nullptr; a.chainBlocksX = (p->cfg.width + 31u) / 32u;
+    p->chainDirtyTracked = a.chainDirty != nullptr;
     if (phase == 2) { a.firstCounter = CNT_VISIBLE; a.countCounter = CNT_VISIBLE2; }   // clusters [visible1, visible1 + visible2)
     a.vis = static_cast<unsigned long long*>(p->res[BRMI_RES_VISIBILITY]);
     a.visW = p->cfg.width; a.visH = p->frameHeight(); a.tilesX = p->tilesX; a.bandY0 = p->bandY0; a.bandY1 = p->bandY1;
