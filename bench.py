@@ -44,11 +44,15 @@ WORKLOADS = {"sponza": ("sponza", {}, 0),
              "bistro_dense": ("bistro", dict(size_scale=20.0, detail=96.0), 0),
              # zorah       configs[4] on ONE GPU: 8K, 100 k instances of two 459 k-triangle meshes (39 G instanced triangles), 1 % of the instances skinned;
              #             ~670 k visible clusters out of ~1 M meshlets tested -- the LOD-select / traversal regime the reference is built for (README.md:11)
-             "zorah": ("zorah", dict(skinned_fraction=0.01), 0)}
-LIGHTS = {"sponza": 64, "bistro": 256, "bistro_r2": 256, "san_miguel": 256, "bistro_dense": 256, "zorah": 64}
+             "zorah": ("zorah", dict(skinned_fraction=0.01), 0),
+             # bistro_skinned  the headline frame with 30 % of its instances skinned (compute skinning folded into cull bounds, the rasteriser's vertex stage
+             #             and the G-buffer pass's vertex fetch -- four joints per vertex): what the skinned paths cost under the driver's clock
+             "bistro_skinned": ("bistro", dict(unique_budget=True, lod_builder="own", relief_slope=1.5, skinned_fraction=0.3), 0)}
+LIGHTS = {"sponza": 64, "bistro": 256, "bistro_r2": 256, "san_miguel": 256, "bistro_dense": 256, "zorah": 64, "bistro_skinned": 256}
 FRAME_SIZE = {"zorah": (7680, 4320)}      # N = 1 frame of a workload that is not the 4K one
 BASELINE_CONFIG = {"sponza": "configs[1]", "bistro": "configs[2]", "bistro_r2": "configs[2], the instanced-budget frame of rounds 1-2", "san_miguel": "configs[3]",
-                   "bistro_dense": "configs[2], dense geometry", "zorah": "configs[4] on one GPU"}
+                   "bistro_dense": "configs[2], dense geometry", "zorah": "configs[4] on one GPU",
+                   "bistro_skinned": "configs[2], 30 % of the instances skinned"}
 PATH_STEP = float(os.environ.get("BRMI_BENCH_PATH_STEP", "0.02"))        # --camera-path: position on the preset's camera path advances by this much per frame (one unit = 0.35 m sideways, 0.6 m ahead, 4 degrees)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md)
 VALU_PEAK_WAVE_INSTS = 1.2288e12   # wave64 VALU instructions per second: 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles (MI355X_MICROARCH.md, cycle constants)
@@ -77,6 +81,7 @@ def main():
                          "pixel-sized triangles: > 20 k visible clusters, > 150 k meshlets tested per 4K frame (SURVEY.md 8 a-3's regime)")
     ap.add_argument("--no-second", action="store_true", help="N = 1 only: do not add the configs[1] (Sponza) measurement as `configs1` to the line")
     ap.add_argument("--no-dense", action="store_true", help="N = 1 only: do not add the dense-geometry measurement (bistro_dense) as `dense` to the line")
+    ap.add_argument("--no-skinned", action="store_true", help="N = 1 only: do not add the skinned leg (the headline frame with 30 %% of its instances skinned) as `skinned` to the line")
     ap.add_argument("--no-third", action="store_true", help="N = 1 only: do not add the configs[3] measurement (San-Miguel-class frame, 30 %% alpha-tested and texture-sampled materials, "
                                                              "one GPU) as `configs3` to the line")
     ap.add_argument("--no-fourth", action="store_true", help="N = 1 only: do not add the configs[4] measurement (Zorah-class 8K frame: 100 k instances, 1 %% skinned, ~670 k visible "
@@ -179,14 +184,19 @@ def main():
             out["configs1"] = {k: second[k] for k in ("value", "unit", "ms_per_step", "ms_per_step_minmax", "config", "roofline", "stage_ms") if k in second}
     if world == 1 and not args.no_third and args.workload != "san_miguel":
         # configs[3]'s frame as SURVEY.md 8(d) config 4 states it -- 30 % alpha-tested, texture-sampled materials -- on one GPU, under the same clock
-        third = measure(args, "san_miguel", world, rank, local_rank, cpu=False, path=False)
+        third = measure(args, "san_miguel", world, rank, local_rank, cpu=False, path="path")       # (its camera-path leg too: phase 2 of the alpha-tested scene)
         if out is not None:
-            out["configs3"] = {k: third[k] for k in ("value", "unit", "ms_per_step", "ms_per_step_minmax", "config", "roofline", "stage_ms", "serial_frame_ms") if k in third}
+            out["configs3"] = {k: third[k] for k in ("value", "unit", "ms_per_step", "ms_per_step_minmax", "config", "roofline", "stage_ms", "serial_frame_ms", "path") if k in third}
     if world == 1 and not args.no_dense and args.workload != "bistro_dense":
         # SURVEY.md 8 a-3 / a-5's regime (tens of thousands of visible clusters, pixel-sized triangles) under the same clock as the headline
         dense = measure(args, "bistro_dense", world, rank, local_rank, cpu=False, path=False)
         if out is not None:
             out["dense"] = {k: dense[k] for k in ("value", "unit", "ms_per_step", "ms_per_step_minmax", "config", "roofline", "stage_ms", "serial_frame_ms") if k in dense}
+    if world == 1 and not args.no_skinned and args.workload != "bistro_skinned":
+        # row a-10 under the same clock: the headline frame with 30 % of its instances skinned
+        sk = measure(args, "bistro_skinned", world, rank, local_rank, cpu=False, path=False)
+        if out is not None:
+            out["skinned"] = {k: sk[k] for k in ("value", "unit", "ms_per_step", "ms_per_step_minmax", "config", "stage_ms", "serial_frame_ms") if k in sk}
     if world == 1 and not args.no_fourth and args.workload != "zorah":
         # configs[4]'s frame on one GPU: 8K, 100 k instances, ~670 k visible clusters -- the LOD-select regime (rows a-2 / a-3 / a-10) under the same clock
         fourth = measure(args, "zorah", world, rank, local_rank, cpu=False, path=False)
@@ -444,7 +454,7 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False,
     path_out, path_fast_out = None, None
     if path and n == 1 and args.camera_path > 0 and args.occlusion:
         path_out = camera_path(args, scene, passes, streams, shade_streams, r, dev, PATH_STEP)
-        if args.camera_path_fast > 0:
+        if args.camera_path_fast > 0 and path != "path":
             path_fast_out = camera_path(args, scene, passes, streams, shade_streams, r, dev, args.camera_path_fast)
     out = None
     if rank == 0 or emulated or solo:

@@ -5,7 +5,7 @@ TAG=$1; SET=$2; shift 2
 cd /tmp && export TMPDIR=/tmp
 O=$ROOT/gpurun_out/$TAG; mkdir -p $O
 cd $ROOT
-timeout 300 rocprofv3 --pmc $SET --kernel-trace -d $O/m -o p --output-format csv -- python3 bench.py --no-cpu-baseline --no-second --no-dense --no-third --no-fourth --camera-path 0 --steps 5 --warmup 2 "$@" > $O/m.log 2>&1
+timeout 300 rocprofv3 --pmc $SET --kernel-trace -d $O/m -o p --output-format csv -- python3 bench.py --no-cpu-baseline --no-second --no-dense --no-third --no-fourth --no-skinned --camera-path 0 --steps 5 --warmup 2 "$@" > $O/m.log 2>&1
 python3 - $O <<'PY' | tee -a $O/pmc.txt
 import csv, sys, collections, glob
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); disp = collections.defaultdict(set)

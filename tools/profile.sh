@@ -15,12 +15,12 @@ cd /tmp && export TMPDIR=/tmp
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT $ROOT/profiles
 cd $ROOT
-timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats --output-format csv -- python3 bench.py "$@" --frames-in-flight 1 --no-cpu-baseline --steps 30 --warmup 5 --no-second --no-dense --no-third --no-fourth --camera-path 0 > $OUT/stats.log 2>&1
-timeout 400 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --kernel-trace -d $OUT/sq -o sq --output-format csv -- python3 bench.py "$@" --frames-in-flight 1 --no-cpu-baseline --no-second --no-dense --no-third --no-fourth --camera-path 0 --steps 5 --warmup 2 > $OUT/sq.log 2>&1
-timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o fetch --output-format csv -- python3 bench.py "$@" --frames-in-flight 1 --no-cpu-baseline --no-second --no-dense --no-third --no-fourth --camera-path 0 --steps 5 --warmup 2 > $OUT/fetch.log 2>&1
-timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o write --output-format csv -- python3 bench.py "$@" --frames-in-flight 1 --no-cpu-baseline --no-second --no-dense --no-third --no-fourth --camera-path 0 --steps 5 --warmup 2 > $OUT/write.log 2>&1
-timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/stats2 -o stats --output-format csv -- python3 bench.py "$@" --no-cpu-baseline --steps 60 --warmup 5 --no-second --no-dense --no-third --no-fourth --camera-path 0 > $OUT/stats2.log 2>&1
-python3 bench.py "$@" --no-cpu-baseline --no-second --no-dense --no-third --no-fourth > $OUT/bench.json 2> $OUT/bench.err
+timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats --output-format csv -- python3 bench.py "$@" --frames-in-flight 1 --no-cpu-baseline --steps 30 --warmup 5 --no-second --no-dense --no-third --no-fourth --no-skinned --camera-path 0 > $OUT/stats.log 2>&1
+timeout 400 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --kernel-trace -d $OUT/sq -o sq --output-format csv -- python3 bench.py "$@" --frames-in-flight 1 --no-cpu-baseline --no-second --no-dense --no-third --no-fourth --no-skinned --camera-path 0 --steps 5 --warmup 2 > $OUT/sq.log 2>&1
+timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o fetch --output-format csv -- python3 bench.py "$@" --frames-in-flight 1 --no-cpu-baseline --no-second --no-dense --no-third --no-fourth --no-skinned --camera-path 0 --steps 5 --warmup 2 > $OUT/fetch.log 2>&1
+timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o write --output-format csv -- python3 bench.py "$@" --frames-in-flight 1 --no-cpu-baseline --no-second --no-dense --no-third --no-fourth --no-skinned --camera-path 0 --steps 5 --warmup 2 > $OUT/write.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/stats2 -o stats --output-format csv -- python3 bench.py "$@" --no-cpu-baseline --steps 60 --warmup 5 --no-second --no-dense --no-third --no-fourth --no-skinned --camera-path 0 > $OUT/stats2.log 2>&1
+python3 bench.py "$@" --no-cpu-baseline --no-second --no-dense --no-third --no-fourth --no-skinned > $OUT/bench.json 2> $OUT/bench.err
 cp $OUT/stats2/stats_kernel_stats.csv $ROOT/profiles/${TAG}_inflight_kernel_stats.csv
 cp $OUT/stats/stats_kernel_stats.csv $ROOT/profiles/${TAG}_kernel_stats.csv
 cp $OUT/bench.json $ROOT/profiles/${TAG}_bench.json
