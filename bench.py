@@ -519,7 +519,7 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False,
                        "occlusion_culling": bool(args.occlusion), "visible_clusters_phase2_rank0": int(c.visibleClustersPhase2),
                        "meshlets_tested_rank0": int(c.meshletsTested), "partition": (f"interleaved chunks of {stripe_rows} rows x{n}" if striped else f"row bands x{n}") if n > 1 else "single GPU",
                        "frames_in_flight": fif},
-            "roofline": {"bound": "valu" if (valu and valu["frac"] > hbm_frac) else "hbm", "kernel": {"raster": "k_raster + k_raster_bins (+ k_raster_overflow), both occlusion phases"}.get(dom, DOMINANT_KERNEL.get(dom, dom)), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "nearer_ceiling": "valu" if (valu and valu["frac"] > hbm_frac) else "hbm", "kernel": {"raster": "k_raster + k_raster_bins (+ k_raster_overflow), both occlusion phases"}.get(dom, DOMINANT_KERNEL.get(dom, dom)), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(hbm_frac, 5), "traffic": traffic, "valu": valu,
                          "algorithmic_bytes_per_launch": int(per_stage_bytes[dom]), "launch_ms": round(stage_ms[dom], 4),
                          "whole_frame": {"algorithmic_bytes": int(total_bytes), "achieved_GBps": round(frame_gbs, 2), "frac": round(frame_gbs / HBM_PEAK_GBS, 5)}},
