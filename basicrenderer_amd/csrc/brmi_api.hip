@@ -96,7 +96,6 @@ static void compute_sizes(brmi_pass* p) {
     // phase 2's footprint for the second depth-chain build: a byte per 32 x 32 px block of the chain's head, from byte 4 (byte 0: "everything", stored by a triangle of more than 16 blocks)
     w.chainDirty = take(4ull + (uint64_t)((c.width + 31u) / 32u) * ((c.height + 31u) / 32u));
     w.frameClearBytes = off - w.counters;
-    w.usedClusters = take((uint64_t)c.maxVisibleClusters);     // one byte per visible cluster, zeroed by the compaction kernel
     w.frontierA = take((uint64_t)c.maxTraversalRecords * sizeof(NodeRecord));
     w.frontierB = take((uint64_t)c.maxTraversalRecords * sizeof(NodeRecord));
     w.buckets = take((uint64_t)c.maxTraversalRecords * sizeof(BucketRecord));
@@ -259,6 +258,7 @@ int brmi_create(const brmi_config* cfg, brmi_pass** out) {
     p->packedFlat = tuning("flat_packed", 1) != 0;
     p->flatLevelsMinDraws = (uint32_t)std::max(0l, tuning("flat_levels_min_draws", p->flatLevelsMinDraws));      // (tests: 1 = the level-synchronous flat traversal for every scene)
     p->phase2DirectMax = (uint32_t)std::max(0l, tuning("phase2_direct_max", p->phase2DirectMax));
+    p->resolveInlineMode = (int)tuning("resolve_inline", -1);
     p->binMinSlice = (uint32_t)std::max(32l, tuning("bin_min_slice", p->binMinSlice));
     p->binSharedSlice = (uint32_t)std::max(32l, tuning("bin_shared_slice", p->binSharedSlice));
     p->binGrid = (uint32_t)std::min(65535l, std::max(1l, tuning("bin_grid", p->binGrid)));
@@ -751,7 +751,7 @@ int brmi_execute_split(brmi_pass* p, brmi_stream stream, brmi_stream shadeStream
     // whatever way this call returns, the frame's shortcuts do not outlive it: stand-alone stage calls behind a failed frame must not find `splitFrame`
     // (which disables the wide flat traversal), `shadeSharesChip` or the issued-waits mark still set
     struct FrameScope { brmi_pass* p; ~FrameScope() { p->splitFrame = false; p->shadeSharesChip = false; p->frameWaitsIssued = false; p->clearFrameStateWithConstants = false; p->fuseFrameClear = false; p->seedInHzbTail = false; } } frameScope{p};
-    p->resolveSetupDone = false; p->depthFinal = false; p->marksFromChain = false;      // (a frame that failed half-way must not leave its shortcuts to the stage entry points)
+    p->resolveSetupDone = false; p->depthFinal = false;      // (a frame that failed half-way must not leave its shortcuts to the stage entry points)
     if ((rc = wait_for_frames_in_flight(p, stream))) return rc;
     p->frameWaitsIssued = true;
     // When the phase-1 traversal is the one-launch LDS walk and the frame constants are due anyway, the frame needs no clear launch: the
@@ -765,7 +765,7 @@ int brmi_execute_split(brmi_pass* p, brmi_stream stream, brmi_stream shadeStream
     // where the per-cluster resolve tables of a split frame are made (BRMI_EARLY_RESOLVE_SETUP): 0 = at the end of the geometry stream, 1 = for the phase-1
     // clusters on the shading stream beside the rasteriser (an event after the culling), 2 = on the shading stream in front of the pixel pass (no event)
     static const int setupWhere = (int)experiment("early_resolve_setup", 1);
-    const bool earlySetup = split && setupWhere == 1 && !resolve_setup_marks(p);
+    const bool earlySetup = split && setupWhere == 1;      // (a frame that resolves without tables launches nothing there: launch_resolve_setup)
     const bool lateSetup = split && setupWhere == 2;
     const bool sideRiders = rides && split && sideEnv && (p->bandPixelCount & 1ull) == 0ull;
     if (sideRiders) {

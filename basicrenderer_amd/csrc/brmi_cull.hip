@@ -1459,7 +1459,7 @@ struct LocalRank { uint32_t totalWords, outIndex, usedIndex; uint32_t* hostFeedb
 template <bool LOCAL_RANK>
 __global__ void __launch_bounds__(256) k_scatter_visible(const TempVisible* temp, uint32_t* counters, uint32_t tempCountIndex, const uint32_t* bitmask,
                                                         const uint32_t* wordPrefix, uint4* visible, uint32_t baseIndexCounter, uint32_t capacity, uint32_t visibleCapacity,
-                                                        brmi_scene_buffers sc, ClusterSetup* setup, uint32_t resolveCapacity, uint8_t* used, ClusterUv* clusterUv, LocalRank lr) {
+                                                        brmi_scene_buffers sc, ClusterSetup* setup, uint32_t resolveCapacity, ClusterUv* clusterUv, LocalRank lr) {
     wave_prio<PRIO_SCAN>();
     const uint8_t* const* slabs = sc.slabs;
     const uint32_t n = min(counters[tempCountIndex], visibleCapacity);
@@ -1494,7 +1494,7 @@ __global__ void __launch_bounds__(256) k_scatter_visible(const TempVisible* temp
     // 23 k same-line atomics at ~90 per microsecond were 250 us, the whole kernel.  The count of placed clusters is one thread's sum.)
     __shared__ unsigned long long blockBase;
     __shared__ uint32_t waveV[4], waveT[4];
-    if (blockIdx.x == 0u && threadIdx.x == 0u) { const uint32_t room = base < capacity ? capacity - base : 0u; atomicAdd(&counters[CNT_RASTER_CLUSTERS], min(n, room)); }
+    if (blockIdx.x == 0u && threadIdx.x == 0u) { const uint32_t room = base < capacity ? capacity - base : 0u; atomicAdd(&counters[CNT_RASTER_CLUSTERS], min(n, room)); if (resolveCapacity == 0u && n != 0u) atomicOr(&counters[CNT_RESOLVE_SPILL], 1u); }
     const uint32_t rounded256 = (n + 255u) & ~255u;      // workgroup-uniform trip count (barriers inside)
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded256; i += gridDim.x * blockDim.x) {
         uint32_t verts = 0, tris = 0, placed = 0, dst = 0;
@@ -1567,9 +1567,8 @@ __global__ void __launch_bounds__(256) k_scatter_visible(const TempVisible* temp
             const unsigned long long v0 = baseV + (inclV - verts), t0 = baseT + (inclT - tris);
             const bool fits = v0 + verts <= resolveCapacity && t0 + tris <= resolveCapacity;
             cs.vertBase = fits ? (uint32_t)v0 : BRMI_ARENA_NONE; cs.triBase32 = fits ? (uint32_t)t0 : BRMI_ARENA_NONE;
-            if (!fits) atomicOr(&counters[CNT_RESOLVE_SPILL], 1u);      // selects the G-buffer kernel variant (brmi_gbuffer)
+            if (!fits && resolveCapacity != 0u) atomicOr(&counters[CNT_RESOLVE_SPILL], 1u);      // selects the G-buffer kernel variant (brmi_gbuffer); (capacity 0 = a frame without tables: flagged once, below -- half a million atomics on one word were 70 us of the 8K frame)
             setup[dst] = cs;
-            used[dst] = 0;        // "owns a pixel" flag of the G-buffer pass
         }
     }
 }
@@ -1737,9 +1736,12 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
             hipLaunchKernelGGL(k_scan_words, dim3(p->scanBlocks), dim3(256), 0, s, bitmask, p->totalWords, blockSums, wordPrefix, blockDirty);
         }
     }
+    // (a frame whose G-buffer pass works without the per-cluster tables reserves nothing in the resolve arena: every cluster is marked "no tables")
+    if (phase == 1) p->inlineResolve = resolve_inline_frame(p);
+    const uint32_t arenaCapacity = p->inlineResolve ? 0u : p->resolveCapacity;
     auto scatter = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(scatterGrid), dim3(256), 0, s, temp, p->counters(), (uint32_t)(phase == 1 ? CNT_TEMP_VISIBLE : CNT_TEMP_VISIBLE2), bitmask, wordPrefix,
-                           static_cast<uint4*>(p->res[BRMI_RES_VISIBLE_CLUSTERS]), phase == 1 ? 0xFFFFFFFFu : (uint32_t)CNT_VISIBLE, p->cfg.maxVisibleClusters, p->cfg.maxVisibleClusters, p->scene, p->wsPtr<ClusterSetup>(p->ws.clusterSetup), p->resolveCapacity, p->wsPtr<uint8_t>(p->ws.usedClusters),
+                           static_cast<uint4*>(p->res[BRMI_RES_VISIBLE_CLUSTERS]), phase == 1 ? 0xFFFFFFFFu : (uint32_t)CNT_VISIBLE, p->cfg.maxVisibleClusters, p->cfg.maxVisibleClusters, p->scene, p->wsPtr<ClusterSetup>(p->ws.clusterSetup), arenaCapacity,
                            (p->sceneHasTextures || p->sceneHasAlphaTest || p->sceneHasVertexColors) ? p->wsPtr<ClusterUv>(p->ws.clusterUv) : nullptr, LocalRank{p->totalWords, outIndex, usedIndex, feedback});
     };
     if (localRank) scatter(k_scatter_visible<true>); else scatter(k_scatter_visible<false>);

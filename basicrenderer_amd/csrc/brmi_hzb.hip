@@ -42,23 +42,14 @@ BRMI_DEV void hzb_tail_levels(const HzbDesc& h, uint32_t firstMip, uint32_t thre
 // (FidelityFX SPD's single-pass scheme -- the last workgroup to finish builds the tail -- was tried: every workgroup needs a device-scope fence
 // before it takes its ticket, which on this part writes back the XCD's L2; 4,352 of them turned a 20 us kernel into 1.1 ms.  The tail stays
 // a launch of its own.)
-// MarkUsed (round 5; FROM_VIS, brmi_execute's first build): frames with more than half a triangle per pixel have the G-buffer pass set up only the clusters that own a pixel.
-// The keys go through this kernel anyway, so it stores the "owns a pixel" bytes of the phase-1 clusters on the way (k_mark_used_clusters read the 8 B per pixel a second time:
-// 57 us of the Zorah-class 8K frame); phase 2's clusters, a handful, all count as used, and a phase-1 cluster that phase 2 covers completely keeps its stale mark (set up for nothing).
-struct MarkUsed { uint8_t* used; uint32_t* counters; uint64_t pixelCount; uint32_t clusterCapacity;
-                  const uint8_t* chainDirty; uint32_t chainBlocksX; };      // second build: only the blocks phase 2's triangles may have touched (brmi_raster.hip), null = all
+// DirtyBlocks: the second build of a frame only redoes the blocks phase 2's triangles may have touched (brmi_raster.hip); null = all
+struct DirtyBlocks { const uint8_t* chainDirty; uint32_t chainBlocksX; };
 template <bool FROM_VIS>
-__global__ void __launch_bounds__(256) k_hzb_head(HzbDesc h, const unsigned long long* vis, float* depthOut, const uint32_t* skipUnless, uint32_t blockRow0, MarkUsed mk) {
+__global__ void __launch_bounds__(256) k_hzb_head(HzbDesc h, const unsigned long long* vis, float* depthOut, const uint32_t* skipUnless, uint32_t blockRow0, DirtyBlocks mk) {
     wave_prio<PRIO_HZB>();
     if (skipUnless && *skipUnless == 0u) return;
     if (mk.chainDirty && mk.chainDirty[0] == 0u) {      // (workgroup-uniform) phase 1's values of this block's texels of the depth map and of mips 1 - 5 still stand
         if (blockIdx.x >= mk.chainBlocksX || mk.chainDirty[4u + (blockIdx.y + blockRow0) * mk.chainBlocksX + blockIdx.x] == 0u) return;
-    }
-    bool marking = false; uint32_t markCount = 0u;
-    if (FROM_VIS && mk.used) {
-        marking = (uint64_t)mk.counters[CNT_SUM_VERTS_HI] * 2ull > mk.pixelCount;      // (wave-uniform: the triangles of phase 1's clusters, from the compaction)
-        markCount = min(mk.counters[CNT_VISIBLE], mk.clusterCapacity);
-        if (marking && blockIdx.x == 0u && blockIdx.y == 0u && threadIdx.x == 0u) mk.counters[CNT_RESOLVE_MARKED] = 1u;
     }
     __shared__ float lvl[16 * 16];
     const uint32_t tx = threadIdx.x >> 4, ty = threadIdx.x & 15u;             // ty fastest: follows the column-major tile layout
@@ -78,11 +69,6 @@ __global__ void __launch_bounds__(256) k_hzb_head(HzbDesc h, const unsigned long
                     const ulonglong2 k2 = *reinterpret_cast<const ulonglong2*>(vis + ti);
                     d[c][0] = key_depth(k2.x); d[c][1] = key_depth(k2.y);
                     *reinterpret_cast<float2*>(depthOut + ti) = make_float2(d[c][0], d[c][1]);
-                    if (marking) {      // one byte per cluster, plain stores of 1 (every writer stores the same); the second key only when it names another cluster
-                        const uint32_t c0 = (uint32_t)((k2.x >> BRMI_VIS_TRI_BITS) & 0x3FFFFFFull), c1 = (uint32_t)((k2.y >> BRMI_VIS_TRI_BITS) & 0x3FFFFFFull);
-                        if (k2.x != BRMI_VIS_EMPTY && c0 < markCount) mk.used[c0] = 1;
-                        if (k2.y != BRMI_VIS_EMPTY && c1 < markCount && (c1 != c0 || k2.x == BRMI_VIS_EMPTY)) mk.used[c1] = 1;
-                    }
                 } else {
                     for (uint32_t r = 0; r < 2; r++) {
                         const uint32_t y = y0 + r;
@@ -90,7 +76,6 @@ __global__ void __launch_bounds__(256) k_hzb_head(HzbDesc h, const unsigned long
                         const unsigned long long k1 = in ? vis[tiled_index(x, y, h.tilesX)] : BRMI_VIS_EMPTY;
                         d[c][r] = key_depth(k1);
                         if (in) depthOut[tiled_index(x, y, h.tilesX)] = d[c][r];
-                        if (marking && k1 != BRMI_VIS_EMPTY) { const uint32_t c1 = (uint32_t)((k1 >> BRMI_VIS_TRI_BITS) & 0x3FFFFFFull); if (c1 < markCount) mk.used[c1] = 1; }
                     }
                 }
             }
@@ -147,10 +132,8 @@ int launch_hzb(brmi_pass* p, hipStream_t s, bool fromVisibility, bool onlyIfPhas
         // texels of mips 1-5 outside the band's 32-row strips never change: brmi_setup filled the chain with "empty"
         const uint32_t row0 = h.rowLo / 32u, row1 = std::min((h.rowHi + 31u) / 32u, h.paddedH / 32u);
         const dim3 grid(h.paddedW / 32, std::max(1u, row1 - row0));
-        // brmi_execute's first build (the keys of phase 1) also marks the clusters that own a pixel when the frame may be one of more triangles than pixels
-        MarkUsed mk{nullptr, p->counters(), p->bandPixelCount, p->cfg.maxVisibleClusters, nullptr, (p->cfg.width + 31u) / 32u};
+        DirtyBlocks mk{nullptr, (p->cfg.width + 31u) / 32u};
         if (fromVisibility && onlyIfPhase2Drew && p->chainDirtyTracked) mk.chainDirty = p->wsPtr<uint8_t>(p->ws.chainDirty);
-        if (fromVisibility && !onlyIfPhase2Drew && p->seedInHzbTail && resolve_setup_marks(p)) { mk.used = p->wsPtr<uint8_t>(p->ws.usedClusters); p->marksFromChain = true; }
         if (fromVisibility) hipLaunchKernelGGL(k_hzb_head<true>, grid, dim3(256), 0, s, h, static_cast<const unsigned long long*>(p->res[BRMI_RES_VISIBILITY]), static_cast<float*>(p->res[BRMI_RES_LINEAR_DEPTH]), skip, row0, mk);
         else hipLaunchKernelGGL(k_hzb_head<false>, grid, dim3(256), 0, s, h, (const unsigned long long*)nullptr, (float*)nullptr, skip, row0, mk);
         first = 6;

@@ -34,7 +34,7 @@ enum CounterIndex : uint32_t {
     CNT_DEFERRED_PIXELS_B,    // second deferred-pixel counter: shading calls alternate, each clears the other one for the next call
     CNT_DEFERRED_PIXELS,      // pixels the specialised shading kernel left to the general one
     CNT_RESOLVE_SPILL,        // some visible cluster found the resolve arena full (its pixels decode their vertices in place)
-    CNT_RESOLVE_MARKED,       // the G-buffer pass marked the clusters that own a pixel (frames with more triangles than pixels)
+    CNT_RESERVED_37,          // (round 4's "clusters marked" flag; the slot keeps the enumeration's layout)
     CNT_DEFERRED_DROPPED,     // layered pixels that found their deferred-list stripe full (impossible by construction; counted anyway)
     CNT_TILE_OVERFLOW,        // (cluster, tile) pairs of the tile rasteriser that found the tile's list full (folded into CNT_BIN_OVERFLOW per phase)
     CNT_FRONTIER0 = 32,       // frontier sizes per BFS level: [CNT_FRONTIER0 + level]
@@ -145,7 +145,7 @@ struct LayerUniform { unsigned long long coatWord, fuzzWord, coatFilledWord, fuz
 
 struct Workspace {     // byte offsets into BRMI_RES_WORKSPACE
     uint64_t counters, frontierA, frontierB, buckets, tempVisible, bitmask1, bitmask2, blockDirty, chainDirty, wordPrefix, blockSums,
-             instanceBitBase, segPrefix, meshLevelWidth, scanAgg, flatNodes, flatLeaves, instanceWalk, planes, replayNodes, replayBuckets, lightVS, lightMeta, clusterPages, clusterHits, pageTotal, lightHitMasks, binCounts, binRecords, binOverflow, binPlan, binItems, binScratch, clusterSetup, resolveVerts, resolveTris, matWords, shadeTables, lutF, frameConst, objConst, matConst, deferredPixels, usedClusters,
+             instanceBitBase, segPrefix, meshLevelWidth, scanAgg, flatNodes, flatLeaves, instanceWalk, planes, replayNodes, replayBuckets, lightVS, lightMeta, clusterPages, clusterHits, pageTotal, lightHitMasks, binCounts, binRecords, binOverflow, binPlan, binItems, binScratch, clusterSetup, resolveVerts, resolveTris, matWords, shadeTables, lutF, frameConst, objConst, matConst, deferredPixels,
              frameSnapshot, debugStamps, clusterUv, binAlpha, overflowAlpha, resolveUVs, resolveColors, alphaMats, shadeRows, shadeAvgs, ggxQuads, shadeLights, clusterList, listEntries, listRecords, layerUniform, frameClearBytes, total;
 };
 
@@ -179,7 +179,7 @@ struct brmi_pass {
     // Phase 2 of a frame usually draws nothing or a few dozen clusters; then its triangles all take the row re-deal with global atomics (one
     // launch instead of k_raster + plan + bins).  Which it is, the host learns from the frames before: the ranking kernel of phase 2 also stores
     // the survivor count in a host-mapped word that launch_raster reads without waiting (any value is safe: both paths draw the same keys).
-    uint32_t* phase2FeedbackHost = nullptr; uint32_t* phase2FeedbackDev = nullptr;      // word 0: phase-2 survivors; word 1: the frame had more than half a triangle per pixel (k_mark_used_clusters has work)
+    uint32_t* phase2FeedbackHost = nullptr; uint32_t* phase2FeedbackDev = nullptr;      // word 0: phase-2 survivors; word 1: frames like the last ones should resolve without the per-cluster tables (resolve_inline_frame)
     bool ensureFeedback() {          // the 64 B host-mapped block, made at first use; false: none (the callers then take their always-safe paths)
         if (phase2FeedbackHost) return true;
         if (hipHostMalloc(reinterpret_cast<void**>(&phase2FeedbackHost), 64, hipHostMallocMapped) != hipSuccess) { phase2FeedbackHost = nullptr; return false; }
@@ -237,7 +237,9 @@ struct brmi_pass {
     bool layerPlanesDirty = false;   // brmi_setup: the next constants launch is followed by k_fill_layer_planes
     bool layerPlanesUniform = false; // ... which found one coat and one fuzz word for the whole scene and filled both planes (read back once)
     bool chainDirtyTracked = false;  // this frame's phase-2 rasteriser recorded the blocks it may have touched (the second chain build skips the others)
-    bool marksFromChain = false;     // brmi_execute: the first depth-chain build of this frame stored the "owns a pixel" marks of the phase-1 clusters (no k_mark_used_clusters launch)
+    int resolveInlineMode = -1;      // BRMI_TUNING=resolve_inline: -1 by the frame, 0 never, 1 always (tests run scenes both ways)
+    bool inlineResolve = false;      // this frame's G-buffer pass derives a pixel's triangle from the cluster's own data (no per-cluster tables, no setup launch): frames of more
+                                     // triangles than pixels, decided when the frame's culling starts (resolve_inline_frame)
     bool resolveSetupDone = false;   // brmi_execute_split: the per-cluster tables were made on the geometry stream
     bool depthFinal = false;         // brmi_execute: the depth map is final before the G-buffer kernel runs (it skips its depth store)
     const brmi_pass* chainOwner(uint32_t phase) const { return (phase == 1 && history) ? history : this; }
@@ -284,7 +286,8 @@ int launch_depth_copy(brmi_pass* p, hipStream_t s);
 int launch_hzb(brmi_pass* p, hipStream_t s, bool fromVisibility, bool onlyIfPhase2Drew);
 int launch_gbuffer(brmi_pass* p, hipStream_t s);
 int launch_resolve_setup(brmi_pass* p, hipStream_t s, uint32_t part);
-bool resolve_setup_marks(brmi_pass* p);
+uint32_t resolve_inline_ratio(const brmi_pass* p);
+bool resolve_inline_frame(brmi_pass* p);
 int launch_light_clustering(brmi_pass* p, hipStream_t s);
 int launch_expand_luts(brmi_pass* p, hipStream_t s);
 int launch_shade(brmi_pass* p, hipStream_t s);

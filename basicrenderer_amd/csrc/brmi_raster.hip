@@ -461,7 +461,7 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
             const int rectWidth = maxX - minX + 1;
             if (a.chainDirty && active) {
                 // round 5 (phase 2 only, wave-uniform): what phase 2 draws is small; the chain's second build then only redoes the 32 x 32 px blocks a phase-2 triangle's
-                // box touches.  A byte per block, plain stores of 1 like the used-cluster marks: no atomic (they serialise on a line), nothing to wait for.
+                // box touches.  A byte per block, plain stores of 1 (every writer stores the same): no atomic (they serialise on a line), nothing to wait for.
                 const int cy0 = max(minY, (int)a.rowLo), cy1 = min(maxY, (int)a.rowHi - 1);
                 if (cy0 <= cy1) {
                     const int bx0 = minX >> 5, bx1 = maxX >> 5, by0 = cy0 >> 5, by1 = cy1 >> 5;

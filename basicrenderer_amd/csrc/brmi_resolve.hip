@@ -32,12 +32,11 @@ struct GBufferArgs {
     const ClusterSetup* setup; ResolveVertex* verts; ResolveTriangle* tris; uint32_t vertCapacity, triCapacity;
     MaterialWords* matWords;
     uint32_t* hostFeedback;        // host-mapped words (brmi_pass::ensureFeedback) or null
-    const uint8_t* used;           // per visible cluster: owns a pixel (valid when counters[CNT_RESOLVE_MARKED])
     const ClusterUv* clusterUv; float2* uvs;      // textured scenes: where the UV sets of every visible cluster live, decoded texcoords of the arena's vertices
     uint32_t uvSets;                              // sets the materials of the scene address (1 unless one names a set > 0): uvs holds [set][vertCapacity]
     uint32_t* colors;                             // scenes with vertex colours: the RGBA8 colour of the arena's vertices
     uint32_t setupPart;            // k_resolve_setup: 0 = every visible cluster, 1 = the phase-1 clusters only (launched beside the rasteriser), 2 = the phase-2 clusters only
-    uint32_t marksCoverPhase1Only; // the marks come from the first depth-chain build (brmi_hzb.hip): phase 2's clusters are all set up
+    uint32_t inlineRatio;          // a frame with more than 1 / inlineRatio cluster triangles per pixel resolves without the tables (resolve_inline_frame): what the kernels tell the host
     uint32_t variantSelect;        // 0: run; 1: run only when no cluster spilled out of the arena; 2: only when one did (counters[CNT_RESOLVE_SPILL])
 };
 
@@ -54,26 +53,6 @@ BRMI_DEV f3 oct_decode_normal(uint32_t packed) {
     return normalize3(v);
 }
 
-// Scenes of pixel-sized triangles (Zorah-class) have far more triangles in their visible clusters than pixels on screen; setting
-// up every triangle of every visible cluster would cost more than it saves.  When the frame is of that kind (decided on the
-// device from the counters) this pass marks the clusters that own at least one pixel, and the setup kernel skips the rest.
-__global__ void __launch_bounds__(256) k_mark_used_clusters(GBufferArgs a, uint8_t* used, uint32_t* counters) {
-    const uint32_t clusterCount = min(a.counters[CNT_VISIBLE] + a.counters[CNT_VISIBLE2], a.clusterCapacity);
-    const uint64_t tris = (uint64_t)a.counters[CNT_SUM_VERTS_HI];
-    if (tris * 2ull <= a.pixelCount) return;                 // wave-uniform: few triangles per pixel, set up everything
-    if (blockIdx.x == 0 && threadIdx.x == 0) counters[CNT_RESOLVE_MARKED] = 1u;
-    const uint64_t end = (a.pixelCount + 63ull) & ~63ull;
-    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < end; j += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t i = a.firstPixel + j;
-        const unsigned long long key = j < a.pixelCount ? a.vis[i] : BRMI_VIS_EMPTY;
-        const uint32_t cid = (uint32_t)((key >> BRMI_VIS_TRI_BITS) & 0x3FFFFFFull);
-        // one byte per cluster, plain stores (every writer stores 1; the compaction kernel zeroed the flags): a bit mask would need
-        // atomics on words shared by 32 clusters.  One store per run of equal ids along the tile's column-major order.
-        const uint32_t prev = (uint32_t)__shfl_up((int)cid, 1);
-        if (key != BRMI_VIS_EMPTY && cid < clusterCount && (lane_id() == 0u || cid != prev)) used[cid] = 1;
-    }
-}
-
 // Per-cluster resolve tables, one wave64 per visible cluster.  Everything CalcFullBary (clodResolveCommon.hlsli:104-143)
 // derives from the triangle alone -- the three projected vertices, 1/w, the screen-space derivatives of the barycentrics --
 // and the decoded vertex normals are evaluated once per triangle / vertex here with the shader's operation order; the pixel
@@ -82,16 +61,14 @@ __global__ void __launch_bounds__(64) k_resolve_setup(GBufferArgs a) {
     wave_prio<PRIO_SETUP>();
     __shared__ float cx[BRMI_MESHLET_MAX_VERTS], cy[BRMI_MESHLET_MAX_VERTS], cw[BRMI_MESHLET_MAX_VERTS];
     const uint32_t lane = threadIdx.x;
-    // part 1 runs while the rasteriser and the phase-2 culling are still at work: it reads the phase-1 count only (final since the compaction) and never the marks
+    // part 1 runs while the rasteriser and the phase-2 culling are still at work: it reads the phase-1 count only (final since the compaction)
     const uint32_t firstCluster = a.setupPart == 2u ? min(a.counters[CNT_VISIBLE], a.clusterCapacity) : 0u;
     const uint32_t clusterCount = a.setupPart == 1u ? min(a.counters[CNT_VISIBLE], a.clusterCapacity) : min(a.counters[CNT_VISIBLE] + a.counters[CNT_VISIBLE2], a.clusterCapacity);
-    const bool marked = a.setupPart == 0u && a.counters[CNT_RESOLVE_MARKED] != 0u;
-    if (blockIdx.x == 0u && lane == 0u && a.hostFeedback && a.setupPart != 1u) {      // tell the host whether frames like this one need the marking pass (its hint for the next frames)
+    if (blockIdx.x == 0u && lane == 0u && a.hostFeedback && a.setupPart != 1u) {      // tell the host whether frames like this one should resolve without the tables (its hint for the next frames)
         const uint64_t tris = (uint64_t)a.counters[CNT_SUM_VERTS_HI];
-        __hip_atomic_store(a.hostFeedback + 1, tris * 2ull > a.pixelCount ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(a.hostFeedback + 1, tris * a.inlineRatio > a.pixelCount ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     for (uint32_t c = firstCluster + blockIdx.x; c < clusterCount; c += gridDim.x) {
-        if (marked && a.used[c] == 0 && !(a.marksCoverPhase1Only && c >= min(a.counters[CNT_VISIBLE], a.clusterCapacity))) continue;      // no pixel shows this cluster
         const ClusterSetup cs = a.setup[c];
         if (cs.vertBase == BRMI_ARENA_NONE) continue;          // arena full: the pixel pass walks this cluster's data itself
         const uint32_t vertCount = cs.counts & 0xFFu, triCount = (cs.counts >> 8) & 0xFFu, posFormat = (cs.counts >> 16) & 0xFFu;
@@ -318,6 +295,8 @@ template <bool INLINE_TABLES, bool TEXTURED, bool PARALLAX, bool MULTI_UV, int S
 BRMI_DEV void gbuffer_body(const GBufferArgs& a, const Epi& epi) {
     const brmi_scene_buffers& sc = a.sc;
     if (a.variantSelect != 0u && (a.counters[CNT_RESOLVE_SPILL] != 0u) != (a.variantSelect == 2u)) return;     // the other variant's frame
+    if (INLINE_TABLES && a.hostFeedback && blockIdx.x == 0u && threadIdx.x == 0u)      // a frame without the setup launch: this kernel tells the host whether frames like this one are still of that kind
+        __hip_atomic_store(a.hostFeedback + 1, (uint64_t)a.counters[CNT_SUM_VERTS_HI] * a.inlineRatio > a.pixelCount ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __shared__ float texelTables[TEXTURED ? 512 : 1];          // code -> float: unorm, sRGB decode
     if (TEXTURED) { stage_texel_tables(texelTables, sc.srgbToLinear, threadIdx.x, 256u); __syncthreads(); }
     TexelTables tb; tb.t = texelTables;
@@ -609,7 +588,7 @@ __global__ void __launch_bounds__(256, INLINE_TABLES ? 1 : (MULTI_UV ? (PARALLAX
 
 static GBufferArgs gbuffer_args_of(brmi_pass* p) {
     GBufferArgs a;
-    a.hostFeedback = nullptr; a.setupPart = 0u; a.marksCoverPhase1Only = 0u;
+    a.hostFeedback = nullptr; a.setupPart = 0u; a.inlineRatio = resolve_inline_ratio(p);
     a.sc = shading_scene_of(p);      // the frame's camera / per-frame record as the constants kernel saw them (FrameSnapshot)
     a.clusters = static_cast<const uint4*>(p->res[BRMI_RES_VISIBLE_CLUSTERS]); a.counters = p->counters();
     a.vis = static_cast<const unsigned long long*>(p->res[BRMI_RES_VISIBILITY]);
@@ -624,7 +603,6 @@ static GBufferArgs gbuffer_args_of(brmi_pass* p) {
     a.setup = p->wsPtr<ClusterSetup>(p->ws.clusterSetup); a.verts = p->wsPtr<ResolveVertex>(p->ws.resolveVerts); a.tris = p->wsPtr<ResolveTriangle>(p->ws.resolveTris);
     a.vertCapacity = p->resolveCapacity; a.triCapacity = p->resolveCapacity;
     a.matWords = p->wsPtr<MaterialWords>(p->ws.matWords);
-    a.used = p->wsPtr<uint8_t>(p->ws.usedClusters);
     a.clusterUv = p->sceneHasTextures ? p->wsPtr<ClusterUv>(p->ws.clusterUv) : nullptr;
     a.uvs = p->sceneHasTextures ? p->wsPtr<float2>(p->ws.resolveUVs) : nullptr; a.uvSets = p->sceneUvSets;
     a.colors = p->sceneHasVertexColors ? p->wsPtr<uint32_t>(p->ws.resolveColors) : nullptr;
@@ -635,11 +613,21 @@ static GBufferArgs gbuffer_args_of(brmi_pass* p) {
 // The per-cluster tables of the pixel pass.  Part of brmi_gbuffer; brmi_execute_split runs it at the end of the geometry half instead (it
 // needs the final cluster list and keys only), so that the shading half starts with the pixel pass.
 // whether frames like the recent ones want the marking pass (which needs the final keys: the setup then cannot start before the rasteriser is done)
-bool resolve_setup_marks(brmi_pass* p) {
-    return (uint64_t)p->totalBits * BRMI_MESHLET_MAX_TRIS * 2ull > p->bandPixelCount && (!p->ensureFeedback() || reinterpret_cast<volatile uint32_t*>(p->phase2FeedbackHost)[1] != 0u);
+// Frames of many triangles per pixel (Zorah-class: 48 M cluster triangles for 33 M pixels) resolve WITHOUT the per-cluster tables (round 5): a triangle's table entry is
+// read by one pixel or by none, so making it in a pass of its own -- 0.29 ms at the end of the 8K frame's geometry half, 830 MB written and read back -- costs more than
+// deriving it where the pixel needs it (the G-buffer kernel's INLINE_TABLES form, until then the fallback for a full arena): 8K frame in flight 2.96 -> 2.66 ms, the
+// dense 4K frame (0.34 triangles per pixel) 0.724 -> 0.684; Bistro- / Sponza- / San-Miguel-class frames (0.12 - 0.2) keep the tables (0.50 -> 0.55, 0.385 -> 0.464, 0.82 -> 1.00 without).
+// The ratio: a quarter of a triangle per pixel; half for scenes whose pixels fetch texcoords or vertex colours too (the in-place form decodes them per pixel).  No cut through the
+// scene's DAGs below the ratio can be such a frame, and whether recent frames were is a word the device stores for the host (no wait; a stale answer picks the other, equally
+// exact, form).  BRMI_TUNING=resolve_inline=0 / 1: never / always (tests run scenes both ways).  (Replaces round 4's marking pass, which only skipped whole clusters.)
+uint32_t resolve_inline_ratio(const brmi_pass* p) { return (p->sceneHasTextures || p->sceneHasVertexColors) ? 2u : 4u; }
+bool resolve_inline_frame(brmi_pass* p) {
+    if (p->resolveInlineMode >= 0) return p->resolveInlineMode != 0;
+    return (uint64_t)p->totalBits * BRMI_MESHLET_MAX_TRIS * resolve_inline_ratio(p) > p->bandPixelCount && p->ensureFeedback() && reinterpret_cast<volatile uint32_t*>(p->phase2FeedbackHost)[1] != 0u;
 }
 int launch_resolve_setup(brmi_pass* p, hipStream_t s, uint32_t part) {
     if (int rc = ensure_frame_constants(p, s)) return rc;
+    if (p->inlineResolve) return BRMI_OK;      // (the compaction marked every cluster "no tables")
     GBufferArgs a = gbuffer_args_of(p);
     a.hostFeedback = p->ensureFeedback() ? p->phase2FeedbackDev : nullptr;
     a.setupPart = part;
@@ -648,14 +636,6 @@ int launch_resolve_setup(brmi_pass* p, hipStream_t s, uint32_t part) {
         BRMI_LAUNCH_CHECK(p, "k_resolve_setup");
         return BRMI_OK;
     }
-    // the marking pass only acts on frames with more than half a triangle per pixel; no cut through the scene's DAGs has more triangles than all
-    // its meshlets together (totalBits: one survivor bit per meshlet of every instance), so most scenes can never be such a frame
-    // ... and whether recent frames were of that kind the host reads from a word k_resolve_setup stores (no wait; a stale "no" only means
-    // that this frame's setup covers every visible cluster, which is always correct)
-    a.marksCoverPhase1Only = p->marksFromChain ? 1u : 0u;
-    if (!p->marksFromChain && (uint64_t)p->totalBits * BRMI_MESHLET_MAX_TRIS * 2ull > p->bandPixelCount && (!a.hostFeedback || reinterpret_cast<volatile uint32_t*>(p->phase2FeedbackHost)[1] != 0u))
-        hipLaunchKernelGGL(k_mark_used_clusters, dim3(2048), dim3(256), 0, s, a, p->wsPtr<uint8_t>(p->ws.usedClusters), p->counters());
-    p->marksFromChain = false;
     hipLaunchKernelGGL(k_resolve_setup, dim3(8192), dim3(64), 0, s, a);
     BRMI_LAUNCH_CHECK(p, "k_resolve_setup");
     return BRMI_OK;
@@ -674,6 +654,11 @@ int launch_gbuffer(brmi_pass* p, hipStream_t s) {
     // known on the device: both variants are launched and each leaves at once when the frame is the other one's (a ~5 us empty
     // launch against the two-waves-per-SIMD fallback variant on frames that do not need it: San-Miguel-class 4K 1.04 -> 0.98 ms).
     auto launch = [&](auto leanKernel, auto fallbackKernel) {
+        if (p->inlineResolve) {      // every cluster without tables: the in-place form alone
+            a.variantSelect = 0u; a.hostFeedback = p->ensureFeedback() ? p->phase2FeedbackDev : nullptr;
+            hipLaunchKernelGGL(fallbackKernel, dim3(8192), dim3(256), 0, s, a);
+            return;
+        }
         a.variantSelect = lean ? 0u : 1u;
         // the texture-sampling variants' waves live long: twice the workgroups shorten the tail (Sponza 4K textured 486 -> 472 us, parallax 1001 -> 963);
         // the constant-factor variant is best at 4096
@@ -689,7 +674,9 @@ int launch_gbuffer(brmi_pass* p, hipStream_t s) {
         if (p->sceneHasParallax) { if (multiUv) BRMI_GB_LAUNCH(true, true, true); else BRMI_GB_LAUNCH(true, true, false); }      // its own variants: the ray march costs the others registers they would spill
         else if (multiUv) BRMI_GB_LAUNCH(true, false, true);
         else BRMI_GB_LAUNCH(true, false, false);
-    } else BRMI_GB_LAUNCH(false, false, false);
+    } else if (p->inlineResolve && slim == 2) launch(k_gbuffer<false, false, false, false, 2>, k_gbuffer<true, false, false, false, 2>);      // (the in-place form of scenes without textures has the slim instantiations too)
+    else if (p->inlineResolve && slim == 1) launch(k_gbuffer<false, false, false, false, 1>, k_gbuffer<true, false, false, false, 1>);
+    else BRMI_GB_LAUNCH(false, false, false);
 #undef BRMI_GB_LAUNCH
     BRMI_LAUNCH_CHECK(p, "k_gbuffer");
     return BRMI_OK;

@@ -1463,6 +1463,30 @@ def test_resolve_without_arena_space_matches(scenes, oracle_frames):
     r.close()
 
 
+@pytest.mark.parametrize("name", ["bistro_small", "sponza_vcolor_textured", "bistro_skinned", "sponza_alpha", "tiny_lod"])
+def test_resolve_in_place_for_every_cluster_matches(name, scenes, oracle_frames):
+    """Frames of more triangles than pixels resolve without the per-cluster tables (no setup launch, every cluster marked "no tables": DESIGN.md 4.4); forced here
+    for ordinary scenes: same G-buffer bytes, same HDR image as with the tables."""
+    from basicrenderer_amd.renderer import VisibilityRenderer
+    o = oracle_frames(name)
+    with _Env(BRMI_RESOLVE_INLINE=1):
+        r = VisibilityRenderer(scenes(name), stats=True)
+    for _ in range(2):
+        r.execute()
+    g = r.gbuffer()
+    covered = o.vis != np.uint64(0xFFFFFFFFFFFFFFFF)
+    assert np.array_equal(r.visibility(), o.vis)
+    assert np.array_equal(g["normals"][covered].view(np.uint32), o.normals[covered].view(np.uint32))
+    for k, ref in (("albedo", o.albedo), ("mr", o.mr), ("motion", o.motion), ("coat", o.coat), ("emissive", o.emissive), ("fuzz", o.fuzz)):
+        assert np.array_equal(g[k][covered], ref[covered]), k
+    with _Env(BRMI_RESOLVE_INLINE=0):
+        t = VisibilityRenderer(scenes(name), stats=True)
+    for _ in range(2):
+        t.execute()
+    assert np.array_equal(r.hdr(), t.hdr())
+    r.close(); t.close()
+
+
 @pytest.mark.parametrize("name", ["bistro_small", "tiny_lod"])
 def test_per_level_traversal_kernels_match(name, scenes, oracle_frames):
     """The per-level traversal / three-launch scan (used for very wide hierarchies) gives the same cluster list."""
