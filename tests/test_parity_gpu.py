@@ -1522,6 +1522,39 @@ SWEEP = [
 
 
 @pytest.mark.parametrize("case", range(len(SWEEP)))
+def test_seeded_sweep_resolved_in_place(case):
+    """The sweep's frames with the G-buffer pass's in-place form for every cluster (what frames of many triangles per pixel take): skinned, textured,
+    vertex-coloured, multi-UV, parallax and alpha-tested clusters decode and project their vertices per pixel -- all seven planes and the HDR image against the oracle."""
+    import orc
+    from conftest import Scene
+    from basicrenderer_amd.renderer import VisibilityRenderer
+    preset, W, H, skw, rkw = SWEEP[case]
+    sc = Scene(preset, W, H, **skw)
+    with _Env(BRMI_RESOLVE_INLINE=1):
+        r = VisibilityRenderer(sc, stats=True, **rkw)
+    o = orc.OracleFrame(sc)
+    if rkw.get("occlusion"):
+        hz = None
+        for _ in range(2):
+            r.execute()
+            hz = o.run_occlusion(hz)
+        o.gbuffer(); o.light_cluster(); o.shade()
+    else:
+        r.execute()
+        o.run()
+    assert np.array_equal(r.visibility(), o.vis)
+    covered = o.vis != np.uint64(0xFFFFFFFFFFFFFFFF)
+    g = r.gbuffer()
+    assert np.array_equal(g["normals"][covered].view(np.uint32), o.normals[covered].view(np.uint32))
+    for k, ref in (("albedo", o.albedo), ("mr", o.mr), ("motion", o.motion), ("coat", o.coat), ("emissive", o.emissive), ("fuzz", o.fuzz)):
+        assert np.array_equal(g[k][covered], ref[covered]), k
+    a = r.hdr().view(np.uint16).reshape(H, W, 4)[covered]
+    b = o.hdr.view(np.uint16).reshape(H, W, 4)[covered]
+    assert _half_ulp_distance(a, b).max() <= 1
+    r.close()
+
+
+@pytest.mark.parametrize("case", range(len(SWEEP)))
 def test_seeded_sweep_whole_frame(case):
     """Odd target sizes (not multiples of the 8x8 tile, the 16-row band or the 256-pixel strip), other seeds, every option
     mix: the whole frame against the oracle -- cluster list, keys, depth, normals exact, HDR within one fp16 ULP."""
