@@ -552,7 +552,7 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
 #ifndef BRMI_RASTER_TINY_RANGES
 #define BRMI_RASTER_TINY_RANGES 0
 #endif
-            // Round 5: a pass whose small boxes are ALL at most BRMI_RASTER_TINY x BRMI_RASTER_TINY pixels (frames of sub-pixel triangles: the Zorah-class frame rasterises 48 M
+            // Round 5: a pass whose small boxes are ALL at most BRMI_RASTER_TINY x BRMI_RASTER_TINY pixels (frames of sub-pixel triangles: the Zorah-class frame rasterises 62 M
             // triangles for 33 M pixels) is walked lane = triangle -- no prefix scan, no parking of thirteen values per triangle in LDS, no bisection per row task: the re-deal
             // exists to balance boxes of very different size, and these are all the same.  Same arithmetic per pixel (raster_row from the box's first row).
             const bool smallHere = active && !big && !(a.debugFlags & 1) && yLo <= yHi;

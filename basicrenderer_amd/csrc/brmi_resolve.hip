@@ -613,8 +613,8 @@ static GBufferArgs gbuffer_args_of(brmi_pass* p) {
 // The per-cluster tables of the pixel pass.  Part of brmi_gbuffer; brmi_execute_split runs it at the end of the geometry half instead (it
 // needs the final cluster list and keys only), so that the shading half starts with the pixel pass.
 // whether frames like the recent ones want the marking pass (which needs the final keys: the setup then cannot start before the rasteriser is done)
-// Frames of many triangles per pixel (Zorah-class: 48 M cluster triangles for 33 M pixels) resolve WITHOUT the per-cluster tables (round 5): a triangle's table entry is
-// read by one pixel or by none, so making it in a pass of its own -- 0.29 ms at the end of the 8K frame's geometry half, 830 MB written and read back -- costs more than
+// Frames of many triangles per pixel (Zorah-class: 62 M cluster triangles for 33 M pixels, 2.3 M of them owning a pixel) resolve WITHOUT the per-cluster tables (round 5): a triangle's table entry is
+// read by a few pixels or, mostly, by none, so making it in a pass of its own -- 0.29 ms at the end of the 8K frame's geometry half, 830 MB written and read back -- costs more than
 // deriving it where the pixel needs it (the G-buffer kernel's INLINE_TABLES form, until then the fallback for a full arena): 8K frame in flight 2.96 -> 2.66 ms, the
 // dense 4K frame (0.34 triangles per pixel) 0.724 -> 0.684; Bistro- / Sponza- / San-Miguel-class frames (0.12 - 0.2) keep the tables (0.50 -> 0.55, 0.385 -> 0.464, 0.82 -> 1.00 without).
 // The ratio: a quarter of a triangle per pixel; half for scenes whose pixels fetch texcoords or vertex colours too (the in-place form decodes them per pixel).  No cut through the
