@@ -183,7 +183,7 @@ struct brmi_pass {
     bool ensureFeedback() {          // the 64 B host-mapped block, made at first use; false: none (the callers then take their always-safe paths)
         if (phase2FeedbackHost) return true;
         if (hipHostMalloc(reinterpret_cast<void**>(&phase2FeedbackHost), 64, hipHostMallocMapped) != hipSuccess) { phase2FeedbackHost = nullptr; return false; }
-        phase2FeedbackHost[0] = 0xFFFFFFFFu; phase2FeedbackHost[1] = 1u;           // unknown: the general paths
+        phase2FeedbackHost[0] = 0xFFFFFFFFu; phase2FeedbackHost[1] = 0u;           // unknown: the general paths (word 1: the per-cluster resolve tables)
         for (int k = 2; k < 16; k++) phase2FeedbackHost[k] = 0u;                  // word 2: phase 1's bucket records, word 3: phase 1's visible clusters (launch sizes of the frames that follow)
         if (hipHostGetDevicePointer(reinterpret_cast<void**>(&phase2FeedbackDev), phase2FeedbackHost, 0) != hipSuccess) { (void)hipHostFree(phase2FeedbackHost); phase2FeedbackHost = nullptr; phase2FeedbackDev = nullptr; return false; }
         return true;
