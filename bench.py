@@ -480,7 +480,9 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False,
             stage_kernels = {"raster": ["k_raster", "k_raster_bins", "k_raster_overflow"]}.get(dom, [DOMINANT_KERNEL.get(dom, dom).split("<")[0]])
             traffic_sum, wi, found = 0, 0, False
             for base in stage_kernels:
-                cands = [k for k in tj if k.split("<")[0] == base]
+                # (instantiations the steady state launches: a variant the first frames of a run took -- the in-place G-buffer kernel while the pass had no depth chain to cull against --
+                # has a handful of calls in the trace and is not this frame's kernel)
+                cands = [k for k in tj if k.split("<")[0] == base and tj[k].get("calls_per_frame", 1.0) >= 0.5]
                 if n == 1 and cands:
                     rec = tj[max(cands, key=lambda k: tj[k].get("avg_us", 0.0))]
                     # launches per frame of THIS kernel in the committed --kernel-trace --stats run (Calls / frames; tools/pmc_report.py): since phase 2
@@ -572,9 +574,13 @@ def dominant_stage(workload, features, stage_ms):
         if not os.path.exists(path):
             path = os.path.join(ROOT, "profiles", PROFILE_FALLBACK.get(tag, tag) + "_kernel_stats.csv")
         best, best_ns = None, 0.0
-        for row in csv.DictReader(open(path)):
+        rows = list(csv.DictReader(open(path)))
+        frames = max([int(r["Calls"]) for r in rows if "k_frame_constants" in r["Name"]] or [1])
+        for row in rows:
             name = row["Name"].replace("void ", "").replace("brmi::", "")
             stage = next((st for prefix, st in KERNEL_STAGE if name.startswith(prefix)), None)
+            if int(row["Calls"]) * 2 < frames:
+                continue      # a variant only the first frames of the trace launched (no depth chain yet: more clusters, the in-place G-buffer kernel) is not the steady state's kernel
             if stage is not None and float(row["AverageNs"]) > best_ns and stage_ms.get(stage, 0.0) > 0.0:
                 best, best_ns = stage, float(row["AverageNs"])
         return best or longest
