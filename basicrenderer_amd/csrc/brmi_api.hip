@@ -146,7 +146,7 @@ static void compute_sizes(brmi_pass* p) {
     w.frameConst = take(3 * 64);
     w.frameSnapshot = take(sizeof(FrameSnapshot));
     w.matConst = take((uint64_t)std::max(1u, p->scene.openpbrMaterialCount) * sizeof(MatConst));
-    w.objConst = take((uint64_t)std::max(1u, p->scene.perObjectCount) * 36 * 4);
+    w.objConst = take((uint64_t)std::max(1u, p->scene.perObjectCount) * OBJ_CONST_FLOATS * 4);
     p->deferredStripeCapacity = (uint32_t)(((p->bandPixelCount / 4096 + CNT_STRIPE_COUNT) / CNT_STRIPE_COUNT) * 4096);   // 64-tile runs of a stripe x 4096 pixels
     w.deferredPixels = take((uint64_t)3 * CNT_STRIPE_COUNT * p->deferredStripeCapacity * 4);      // one set of striped lists per layered class
     w.lutF = take((uint64_t)(32768 + 1024 + 1024 + 32 + 256) * 4);
@@ -166,6 +166,13 @@ static void compute_sizes(brmi_pass* p) {
     w.binAlpha = take(p->sceneHasAlphaTest ? (uint64_t)p->binsX * p->binsY * p->binCapacity * 48 : 16);
     w.overflowAlpha = take(p->sceneHasAlphaTest ? (uint64_t)CNT_STRIPE_COUNT * p->binOverflowPerStripe * 48 : 16);
     w.alphaMats = take(p->sceneHasAlphaTest ? (uint64_t)std::max(1u, p->scene.materialCount) * 128 : 16);
+    // round 6, the draw list: per-meshlet boxes of the resident pages, the (slab, page) -> first box table, and the three lists of a frame
+    w.meshletBoxes = take((uint64_t)std::max(1u, p->totalBoxes) * sizeof(MeshletBox));
+    w.pageBoxBase = take((uint64_t)std::max<size_t>(1, p->hostPageBoxBase.size()) * 4);
+    w.pageRefs = take((uint64_t)std::max<size_t>(1, p->hostPageRefs.size()) * sizeof(PageRef));
+    w.drawList = take(p->holdEnabled ? (uint64_t)c.maxVisibleClusters * 4 : 16);
+    w.heldRecords = take(p->holdEnabled ? (uint64_t)c.maxVisibleClusters * sizeof(HeldRecord) : 16);
+    w.lateList = take(p->holdEnabled ? (uint64_t)c.maxVisibleClusters * 4 : 16);
     w.total = off;
     p->resNeed[BRMI_RES_WORKSPACE] = w.total;
 }
@@ -510,6 +517,34 @@ int brmi_set_scene(brmi_pass* p, const brmi_scene_buffers* scene) {
             p->hostInstanceWalk[i] = InstanceWalk{flatBase[m], flatCount[m], p->hostInstanceBitBase[i], skinned ? 1u : 0u};
         }
     }
+    {   // Round 6, the draw list: every resident page of the page map, and where its meshlets' boxes start in the side table (k_meshlet_boxes fills it in brmi_setup).
+        // A page's meshlet count is the first word of its header (the builder's contract; one small read-back per page, not per frame).
+        std::vector<brmi_group_page_map_entry> pmap;
+        if ((rc = read_back(p, pmap, sc.groupPageMap, sc.groupPageMapCount))) return rc;
+        std::vector<const uint8_t*> slabPtrs;
+        if ((rc = read_back(p, slabPtrs, reinterpret_cast<const uint8_t* const*>(sc.slabs), sc.slabCount))) return rc;
+        p->hostPageRefs.clear(); p->totalBoxes = 0;
+        p->hostPageBoxBase.assign((size_t)std::max(1u, sc.slabCount) * 1024u, 0xFFFFFFFFu);
+        const bool boxesOn = tuning("hold_clusters", 1) != 0 && p->cfg.enableOcclusionCulling && sc.slabCount <= 4096u;
+        for (size_t i = 0; boxesOn && i < pmap.size(); i++) {
+            const uint32_t slab = pmap[i].slabDescriptorIndex, page = pmap[i].slabByteOffset / BRMI_PAGE_SIZE;
+            if (slab == 0u || page >= 1024u || !slabPtrs[slab]) continue;      // not resident (or beyond the 10 page bits of the packed cluster: such a page is never named)
+            uint32_t& base = p->hostPageBoxBase[(size_t)slab * 1024u + page];
+            if (base != 0xFFFFFFFFu) continue;                                  // several groups share a page
+            uint32_t meshlets = 0;
+            BRMI_HIP(p, hipMemcpy(&meshlets, slabPtrs[slab] + pmap[i].slabByteOffset, 4, hipMemcpyDeviceToHost));
+            meshlets = std::min(meshlets, (BRMI_PAGE_SIZE - 64u) / 64u);
+            if ((uint64_t)p->totalBoxes + meshlets > 0x7FFFFFFFull) break;
+            base = p->totalBoxes;
+            p->hostPageRefs.push_back(PageRef{slab, pmap[i].slabByteOffset, base, meshlets});
+            p->totalBoxes += meshlets;
+        }
+        // (the contiguous band and the interleaved partition keep the whole list: their surfaces hold this GPU's rows only -- the re-test would have to map rows)
+        p->holdEnabled = boxesOn && p->totalBoxes != 0u && p->stripes.count <= 1u && p->bandY0 == 0u && p->bandY1 == p->cfg.height;
+        p->holdMinClusters = (uint32_t)std::max(0l, tuning("hold_min_clusters", p->holdMinClusters));
+        p->holdMaxTexels = (uint32_t)std::min(16l, std::max(1l, tuning("hold_max_texels", p->holdMaxTexels)));
+        p->retestMaxTexels = (uint32_t)std::min(16l, std::max(1l, tuning("retest_max_texels", p->retestMaxTexels)));
+    }
     p->totalBits = bits;
     p->totalWords = (uint32_t)std::max<uint64_t>(1, (bits + 31) / 32);
     p->scanBlocks = (p->totalWords + 2047u) / 2048u;
@@ -558,7 +593,10 @@ int brmi_setup(brmi_pass* p, const brmi_resource_binding* b, uint32_t n, brmi_st
     if (!p->hostFlatNodes.empty()) BRMI_HIP(p, hipMemcpyAsync(p->wsPtr<FlatNode>(p->ws.flatNodes), p->hostFlatNodes.data(), p->hostFlatNodes.size() * sizeof(FlatNode), hipMemcpyHostToDevice, s));
     if (!p->hostFlatLeaves.empty()) BRMI_HIP(p, hipMemcpyAsync(p->wsPtr<FlatLeaf>(p->ws.flatLeaves), p->hostFlatLeaves.data(), p->hostFlatLeaves.size() * sizeof(FlatLeaf), hipMemcpyHostToDevice, s));
     if (!p->hostInstanceWalk.empty()) BRMI_HIP(p, hipMemcpyAsync(p->wsPtr<InstanceWalk>(p->ws.instanceWalk), p->hostInstanceWalk.data(), p->hostInstanceWalk.size() * sizeof(InstanceWalk), hipMemcpyHostToDevice, s));
+    if (!p->hostPageBoxBase.empty()) BRMI_HIP(p, hipMemcpyAsync(p->wsPtr<uint32_t>(p->ws.pageBoxBase), p->hostPageBoxBase.data(), p->hostPageBoxBase.size() * 4, hipMemcpyHostToDevice, s));
+    if (!p->hostPageRefs.empty()) BRMI_HIP(p, hipMemcpyAsync(p->wsPtr<PageRef>(p->ws.pageRefs), p->hostPageRefs.data(), p->hostPageRefs.size() * sizeof(PageRef), hipMemcpyHostToDevice, s));
     { int rc = launch_expand_luts(p, s); if (rc) return rc; }
+    { int rc = launch_meshlet_boxes(p, s); if (rc) return rc; }
     BRMI_HIP(p, hipStreamSynchronize(s));   // host vectors may be reused
     if (p->cfg.collectPassStatistics && !p->eventsCreated) {
         for (int i = 0; i < BRMI_STAGE_COUNT; i++) for (uint32_t k = 0; k < brmi_pass::kEventRing; k++) { BRMI_HIP(p, hipEventCreate(&p->evStart[i][k])); BRMI_HIP(p, hipEventCreate(&p->evStop[i][k])); }
@@ -869,7 +907,8 @@ int brmi_read_counters(brmi_pass* p, brmi_counters* out, brmi_stream stream) {
     for (uint32_t st = 0; st < CNT_STRIPE_COUNT; st++) out->meshletsTested += c[CNT_STRIPES + st * CNT_STRIPE_WORDS + STRIPE_MESHLETS_TESTED];
     out->visibleClusters = c[CNT_VISIBLE]; out->visibleClustersPhase2 = c[CNT_VISIBLE2];
     out->droppedRecords = c[CNT_DROPPED_RECORDS]; out->droppedClusters = c[CNT_DROPPED_CLUSTERS]; out->lightPagesUsed = c[CNT_LIGHT_PAGES];
-    out->reserved[0] = c[CNT_SUM_VERTS_LO]; out->reserved[1] = 0u; out->reserved[2] = c[CNT_SUM_VERTS_HI]; out->reserved[3] = 0u;      // (vertex sum | triangle sum << 32 in one word, brmi_internal.h)
+    out->reserved[0] = c[CNT_SUM_VERTS_LO]; out->reserved[2] = c[CNT_SUM_VERTS_HI];      // (vertex sum | triangle sum << 32 in one word, brmi_internal.h)
+    out->reserved[1] = std::min(c[CNT_HELD1], p->cfg.maxVisibleClusters); out->reserved[3] = std::min(c[CNT_LATE1], p->cfg.maxVisibleClusters);      // round 6: the draw list (include/brmi.h)
     out->reserved[4] = c[CNT_RASTER_CLUSTERS]; out->reserved[5] = c[CNT_BIN_OVERFLOW] + overflowQueued;
     out->replayNodes = c[CNT_REPLAY_NODES]; out->replayMeshlets = c[CNT_REPLAY_MESHLETS];
     return BRMI_OK;
@@ -914,7 +953,12 @@ int brmi_algorithmic_bytes(brmi_pass* p, uint64_t* perStage, uint64_t* total) {
     BRMI_HIP(p, hipDeviceSynchronize());
     brmi_counters c; int rc = brmi_read_counters(p, &c, nullptr); if (rc) return rc;
     const uint64_t P = (uint64_t)p->cfg.width * (p->bandY1 - p->bandY0);
-    const uint64_t sumV = ((uint64_t)c.reserved[1] << 32) | c.reserved[0], sumT = ((uint64_t)c.reserved[3] << 32) | c.reserved[2], nClusters = c.reserved[4];
+    uint64_t sumV = c.reserved[0], sumT = c.reserved[2], nClusters = c.reserved[4];
+    if (c.reserved[1] != 0u) {      // a frame that held clusters back: what was rasterised is the draw list, the late list and phase 2 (the held clusters that stayed hidden moved no vertex or index byte)
+        uint32_t vt[2];
+        BRMI_HIP(p, hipMemcpy(vt, p->counters() + CNT_DRAWN_VT, 8, hipMemcpyDeviceToHost));
+        sumV = vt[0]; sumT = vt[1]; nClusters -= c.reserved[1] - c.reserved[3];
+    }
     for (int i = 0; i < BRMI_STAGE_COUNT; i++) perStage[i] = 0;
     perStage[BRMI_STAGE_CLEAR] = 8 * P;
     perStage[BRMI_STAGE_CULL] = 64ull * c.meshletsTested + 16ull * (c.visibleClusters + c.visibleClustersPhase2) + 64ull * c.nodesVisited;

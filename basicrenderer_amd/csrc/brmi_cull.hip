@@ -1456,10 +1456,19 @@ __global__ void __launch_bounds__(256) k_scan_chained(const uint32_t* bitmask, u
 #endif
 constexpr uint32_t LOCAL_RANK_WORDS = BRMI_LOCAL_RANK_WORDS;
 struct LocalRank { uint32_t totalWords, outIndex, usedIndex; uint32_t* hostFeedback; };
-template <bool LOCAL_RANK>
+// Round 6: the lists of a frame that holds clusters back (brmi_raster.hip).  drawList == nullptr: every cluster of the visible list is rasterised in list order, as before.
+struct DrawLists {
+    uint32_t* drawList; HeldRecord* held; uint32_t countAll;      // countAll: phase 2 of such a frame -- every placed cluster is drawn and counts
+    // the prediction's inputs (phase 1): the chain the reference's test just read, the per-meshlet boxes, the per-object constants, the chain's size
+    // (box_behind_chain, brmi_internal.h: the same question the re-test asks -- of the PREVIOUS frame's chain with the previous frame's matrices.  The reference's own
+    // test asks it of the meshlet's SPHERE with four texels of a coarser mip, and lets through twice the clusters that own a pixel: profiles/r06_experiments.md --
+    // a box's near corner is the surface's, a sphere's near point half a cluster in front of it.)
+    const MeshletBox* boxes; const uint32_t* pageBoxBase; const float* objConst; uint32_t maxTexels; BoxViewport vp; HzbDesc hzb;
+};
+template <bool LOCAL_RANK, bool HOLD>      // HOLD: phase 1 of a frame that holds clusters back (the prediction and the two lists; the plain instantiations keep their registers)
 __global__ void __launch_bounds__(256) k_scatter_visible(const TempVisible* temp, uint32_t* counters, uint32_t tempCountIndex, const uint32_t* bitmask,
                                                         const uint32_t* wordPrefix, uint4* visible, uint32_t baseIndexCounter, uint32_t capacity, uint32_t visibleCapacity,
-                                                        brmi_scene_buffers sc, ClusterSetup* setup, uint32_t resolveCapacity, ClusterUv* clusterUv, LocalRank lr) {
+                                                        brmi_scene_buffers sc, ClusterSetup* setup, uint32_t resolveCapacity, ClusterUv* clusterUv, LocalRank lr, DrawLists dl) {
     wave_prio<PRIO_SCAN>();
     const uint8_t* const* slabs = sc.slabs;
     const uint32_t n = min(counters[tempCountIndex], visibleCapacity);
@@ -1493,7 +1502,8 @@ __global__ void __launch_bounds__(256) k_scatter_visible(const TempVisible* temp
     // triangles in the high half of one 64-bit word -- instead of three per wave on one cache line: a Zorah-class frame places 490 k clusters, and
     // 23 k same-line atomics at ~90 per microsecond were 250 us, the whole kernel.  The count of placed clusters is one thread's sum.)
     __shared__ unsigned long long blockBase;
-    __shared__ uint32_t waveV[4], waveT[4];
+    __shared__ uint32_t waveV[4], waveT[4], waveD[4], waveH[4], blockDraw, blockHeld;
+    unsigned long long drawnVT = 0ull;      // this thread's share of the vertex | triangle << 32 sums of the clusters on the draw list
     if (blockIdx.x == 0u && threadIdx.x == 0u) { const uint32_t room = base < capacity ? capacity - base : 0u; atomicAdd(&counters[CNT_RASTER_CLUSTERS], min(n, room)); if (resolveCapacity == 0u && n != 0u) atomicOr(&counters[CNT_RESOLVE_SPILL], 1u); }
     const uint32_t rounded256 = (n + 255u) & ~255u;      // workgroup-uniform trip count (barriers inside)
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded256; i += gridDim.x * blockDim.x) {
@@ -1501,6 +1511,7 @@ __global__ void __launch_bounds__(256) k_scatter_visible(const TempVisible* temp
         TempVisible t{};
         const uint8_t* slab = nullptr; uint32_t pageOff = 0;
         const brmi_page_header* hdr = nullptr; const brmi_meshlet_descriptor* desc = nullptr;
+        uint32_t held = 0u, boxIndex = 0xFFFFFFFFu, perObject = 0u;
         if (i < n) {
             t = temp[i];
             const uint32_t w = t.bit >> 5, b = t.bit & 31u;
@@ -1515,6 +1526,18 @@ __global__ void __launch_bounds__(256) k_scatter_visible(const TempVisible* temp
                 verts = min((desc->bitsAndVertexCount >> 24) & 0xFFu, BRMI_MESHLET_MAX_VERTS);
                 tris = min(desc->triangleCountAndRefinedGroup & 0xFFFFu, BRMI_MESHLET_MAX_TRIS);
                 placed = 1;
+                if (HOLD) {
+                    // (round 6: the cluster is visible as far as the reference's tests go and has its place in the list; is it worth drawing FIRST?)
+                    const brmi_per_mesh_instance inst = sc.perMeshInstance[vc_instance(t.packed)];
+                    perObject = inst.perObjectBufferIndex;
+                    const uint32_t boxBase = dl.pageBoxBase[(size_t)vc_slab(t.packed) * 1024u + (pageOff >> 18)];
+                    if (boxBase != 0xFFFFFFFFu && (sc.perMesh[inst.perMeshBufferIndex].vertexFlags & BRMI_VERTEX_SKINNED) == 0u) {
+                        boxIndex = boxBase + vc_meshlet(t.packed);
+                        const MeshletBox bx = dl.boxes[boxIndex];
+                        const float* oc = dl.objConst + (size_t)perObject * OBJ_CONST_FLOATS;
+                        if (bx.valid && box_behind_chain(dl.hzb, bx, oc + 36, oc + 52, dl.vp, dl.maxTexels)) held = 1u;
+                    }
+                }
             }
         }
         uint32_t inclV = verts, inclT = tris;
@@ -1523,14 +1546,26 @@ __global__ void __launch_bounds__(256) k_scatter_visible(const TempVisible* temp
             const uint32_t v = (uint32_t)__shfl_up((int)inclV, o), tt = (uint32_t)__shfl_up((int)inclT, o);
             if ((threadIdx.x & 63u) >= (uint32_t)o) { inclV += v; inclT += tt; }
         }
+        // the draw list and the held records: slots per workgroup, like the arena's
+        const bool isHeld = HOLD && placed != 0u && held != 0u, isDraw = HOLD && placed != 0u && !isHeld;
+        const uint64_t drawM = __ballot(isDraw), heldM = __ballot(isHeld);
         __syncthreads();                                  // the previous round's base and wave sums have been read
-        if ((threadIdx.x & 63u) == 63u) { waveV[threadIdx.x >> 6] = inclV; waveT[threadIdx.x >> 6] = inclT; }
+        if ((threadIdx.x & 63u) == 63u) { waveV[threadIdx.x >> 6] = inclV; waveT[threadIdx.x >> 6] = inclT; waveD[threadIdx.x >> 6] = (uint32_t)__popcll(drawM); waveH[threadIdx.x >> 6] = (uint32_t)__popcll(heldM); }
         __syncthreads();
         if (threadIdx.x == 0u) {
             const unsigned long long totV = (unsigned long long)waveV[0] + waveV[1] + waveV[2] + waveV[3], totT = (unsigned long long)waveT[0] + waveT[1] + waveT[2] + waveT[3];
             blockBase = (totV | totT) ? atomicAdd(reinterpret_cast<unsigned long long*>(&counters[CNT_SUM_VERTS_LO]), totV | (totT << 32)) : 0ull;
         }
+        if (HOLD && threadIdx.x == 64u) { const uint32_t tot = waveD[0] + waveD[1] + waveD[2] + waveD[3]; blockDraw = tot ? atomicAdd(&counters[CNT_DRAW1], tot) : 0u; }
+        if (HOLD && threadIdx.x == 128u) { const uint32_t tot = waveH[0] + waveH[1] + waveH[2] + waveH[3]; blockHeld = tot ? atomicAdd(&counters[CNT_HELD1], tot) : 0u; }
         __syncthreads();
+        if (dl.countAll && placed) drawnVT += (unsigned long long)verts | ((unsigned long long)tris << 32);
+        if (isDraw || isHeld) {
+            uint32_t slot = (isDraw ? blockDraw : blockHeld) + lane_rank(isDraw ? drawM : heldM);
+            for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) slot += isDraw ? waveD[w] : waveH[w];
+            if (isDraw) { dl.drawList[slot] = dst; drawnVT += (unsigned long long)verts | ((unsigned long long)tris << 32); }
+            else dl.held[slot] = HeldRecord{dst, boxIndex, perObject, verts | (tris << 16)};
+        }
         unsigned long long baseV = (uint32_t)blockBase, baseT = blockBase >> 32;
         for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) { baseV += waveV[w]; baseT += waveT[w]; }
         if (placed) {
@@ -1571,6 +1606,11 @@ __global__ void __launch_bounds__(256) k_scatter_visible(const TempVisible* temp
             setup[dst] = cs;
         }
     }
+    if (HOLD || dl.countAll) {      // one atomic per wave and launch (the sums are statistics: brmi_algorithmic_bytes)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) drawnVT += (unsigned long long)__shfl_xor((long long)drawnVT, o);
+        if ((threadIdx.x & 63u) == 0u && drawnVT != 0ull) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[CNT_DRAWN_VT]), drawnVT);
+    }
 }
 
 static inline uint32_t grid_for(uint64_t items, uint32_t block, uint32_t maxBlocks) {
@@ -1598,6 +1638,7 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
     { uint32_t n = 1; for (uint32_t c = 2; c <= 64; c <<= 1) if (c <= f) n = c; f = n; }
     a.factor = f; a.phase = phase; a.packedFlat = 0u; a.wideFlat = 0u;
     a.feedback = p->ensureFeedback() ? p->phase2FeedbackDev : nullptr;
+
     // the band test's two planes through the eye only bound a row band under a symmetric perspective projection: an orthographic or
     // off-centre camera keeps the frustum test alone (the rasteriser's row filter still confines the band; nothing is lost but the early cull)
     const bool symmetricPerspective = p->camHost.isOrtho == 0 && p->camHost.projection[2][0] == 0.0f && p->camHost.projection[2][1] == 0.0f &&
@@ -1609,6 +1650,12 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
     a.occlusion = (p->cfg.enableOcclusionCulling && chain->hzbValid && p->camHost.isOrtho == 0) ? 1u : 0u;
     a.replayNodes = p->wsPtr<NodeRecord>(p->ws.replayNodes); a.replayBuckets = p->wsPtr<BucketRecord>(p->ws.replayBuckets);
     a.hzb = chain->hzbDesc();
+    if (phase == 1) {
+        // Round 6: this frame holds clusters back when the pass can (brmi_set_scene), the previous frame's chain is there to predict from, and the frames before had
+        // enough clusters for the two extra launches to pay (the count is a host-mapped word a frame or two old; either way the same image)
+        const uint32_t lastVisible = p->phase2FeedbackHost ? reinterpret_cast<volatile uint32_t*>(p->phase2FeedbackHost)[3] : 0u;
+        p->holdThisFrame = p->holdEnabled && a.occlusion != 0u && (p->holdMinClusters == 0u || (lastVisible != 0xFFFFFFFFu && lastVisible >= p->holdMinClusters));
+    }
     a.frontier0Counter = phase == 1 ? (uint32_t)CNT_FRONTIER0 : (uint32_t)CNT_REPLAY_NODES;
     a.bucketCounter = CNT_BUCKETS;   // phase 2: seeded with the replayed meshlets, the bucket array is the replay buffer itself
     NodeRecord* fa = p->wsPtr<NodeRecord>(p->ws.frontierA); NodeRecord* fb = p->wsPtr<NodeRecord>(p->ws.frontierB);
@@ -1742,10 +1789,51 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
     auto scatter = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(scatterGrid), dim3(256), 0, s, temp, p->counters(), (uint32_t)(phase == 1 ? CNT_TEMP_VISIBLE : CNT_TEMP_VISIBLE2), bitmask, wordPrefix,
                            static_cast<uint4*>(p->res[BRMI_RES_VISIBLE_CLUSTERS]), phase == 1 ? 0xFFFFFFFFu : (uint32_t)CNT_VISIBLE, p->cfg.maxVisibleClusters, p->cfg.maxVisibleClusters, p->scene, p->wsPtr<ClusterSetup>(p->ws.clusterSetup), arenaCapacity,
-                           (p->sceneHasTextures || p->sceneHasAlphaTest || p->sceneHasVertexColors) ? p->wsPtr<ClusterUv>(p->ws.clusterUv) : nullptr, LocalRank{p->totalWords, outIndex, usedIndex, feedback});
+                           (p->sceneHasTextures || p->sceneHasAlphaTest || p->sceneHasVertexColors) ? p->wsPtr<ClusterUv>(p->ws.clusterUv) : nullptr, LocalRank{p->totalWords, outIndex, usedIndex, feedback},
+                           (phase == 1 && p->holdThisFrame) ? DrawLists{p->wsPtr<uint32_t>(p->ws.drawList), p->wsPtr<HeldRecord>(p->ws.heldRecords), 0u, p->wsPtr<MeshletBox>(p->ws.meshletBoxes), p->wsPtr<uint32_t>(p->ws.pageBoxBase),
+                                                                      p->wsPtr<float>(p->ws.objConst), p->holdMaxTexels, BoxViewport{(float)p->cfg.width, (float)p->cfg.height, 0.0f, 0.0f, 0, 0, (int)p->cfg.width - 1, (int)p->cfg.height - 1}, a.hzb}
+                                                          : DrawLists{nullptr, nullptr, p->holdThisFrame ? 1u : 0u, nullptr, nullptr, nullptr, 0u, BoxViewport{}, HzbDesc{}});
     };
-    if (localRank) scatter(k_scatter_visible<true>); else scatter(k_scatter_visible<false>);
+    const bool holdLists = phase == 1 && p->holdThisFrame;
+    if (localRank) { if (holdLists) scatter(k_scatter_visible<true, true>); else scatter(k_scatter_visible<true, false>); }
+    else { if (holdLists) scatter(k_scatter_visible<false, true>); else scatter(k_scatter_visible<false, false>); }
     BRMI_LAUNCH_CHECK(p, "compaction");
+    return BRMI_OK;
+}
+
+
+// Round 6: the object-space box of every meshlet of every resident page (brmi_setup; MeshletBox in brmi_internal.h).  One workgroup per page, a wave per meshlet.
+__global__ void __launch_bounds__(256) k_meshlet_boxes(const uint8_t* const* slabs, const PageRef* pages, MeshletBox* boxes) {
+    const PageRef pr = pages[blockIdx.x];
+    const uint8_t* page = slabs[pr.slab] + pr.byteOffset;
+    const brmi_page_header* hdr = reinterpret_cast<const brmi_page_header*>(page);
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool float3 = (hdr->compressedPositionQuantExp & 0xFFu) == BRMI_POSITION_FORMAT_FLOAT3;
+    for (uint32_t m = threadIdx.x >> 6; m < pr.meshletCount; m += 4u) {
+        const brmi_meshlet_descriptor* desc = reinterpret_cast<const brmi_meshlet_descriptor*>(page + hdr->descriptorOffset + m * 64u);
+        const uint32_t verts = min((desc->bitsAndVertexCount >> 24) & 0xFFu, BRMI_MESHLET_MAX_VERTS);
+        f3 lo{3.0e38f, 3.0e38f, 3.0e38f}, hi{-3.0e38f, -3.0e38f, -3.0e38f};
+        bool finite = true;
+        if (float3) for (uint32_t v = lane; v < verts; v += 64u) {
+            const float* pp = reinterpret_cast<const float*>(page + hdr->positionBitstreamOffset + desc->positionBitOffset + v * 12u);
+            const f3 q{pp[0], pp[1], pp[2]};
+            finite = finite && fabsf(q.x) < 1.0e30f && fabsf(q.y) < 1.0e30f && fabsf(q.z) < 1.0e30f;      // (NaN fails the comparison)
+            lo = min3v(lo, q); hi = max3v(hi, q);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo.x = min2(lo.x, __shfl_xor(lo.x, o)); lo.y = min2(lo.y, __shfl_xor(lo.y, o)); lo.z = min2(lo.z, __shfl_xor(lo.z, o));
+            hi.x = max2(hi.x, __shfl_xor(hi.x, o)); hi.y = max2(hi.y, __shfl_xor(hi.y, o)); hi.z = max2(hi.z, __shfl_xor(hi.z, o));
+        }
+        finite = __all(finite);
+        if (lane == 0u) boxes[pr.boxBase + m] = MeshletBox{{lo.x, lo.y, lo.z}, (float3 && verts != 0u && finite) ? 1u : 0u, {hi.x, hi.y, hi.z}, 0u};
+    }
+}
+
+int launch_meshlet_boxes(brmi_pass* p, hipStream_t s) {
+    if (p->hostPageRefs.empty()) return BRMI_OK;
+    hipLaunchKernelGGL(k_meshlet_boxes, dim3((uint32_t)p->hostPageRefs.size()), dim3(256), 0, s, p->scene.slabs, p->wsPtr<PageRef>(p->ws.pageRefs), p->wsPtr<MeshletBox>(p->ws.meshletBoxes));
+    BRMI_LAUNCH_CHECK(p, "k_meshlet_boxes");
     return BRMI_OK;
 }
 

@@ -42,14 +42,21 @@ BRMI_DEV void job_object_constants(const brmi_scene_buffers& sc, m4* frameConst,
     }
     if (o >= sc.perObjectCount) return;
     const m4 model = load_m4(&sc.perObject[o].model[0][0]);
-    m4* dst = reinterpret_cast<m4*>(objConst + (size_t)o * 36u);
     const m4 mvp = mul_mm(model, load_m4(&cc->viewProjection[0][0]));
     const m4 otc = mul_mm(model, viewProj);
     const f4 mvz = mul_mcol(model, f4{cc->viewZ[0], cc->viewZ[1], cc->viewZ[2], cc->viewZ[3]});
-    float* d = objConst + (size_t)o * 36u;
+    float* d = objConst + (size_t)o * OBJ_CONST_FLOATS;
     for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { d[i * 4 + j] = mvp.m[i][j]; d[16 + i * 4 + j] = otc.m[i][j]; }
     d[32] = mvz.x; d[33] = mvz.y; d[34] = mvz.z; d[35] = mvz.w;
-    (void)dst;
+    // round 6: where the object was in the PREVIOUS frame's view (the draw list's prediction looks a cluster's box up in the previous frame's depth
+    // chain, as the reference's occlusion test does with the sphere: prevModel, prevView, prevUnjitteredProjection -- occlusionCulling.hlsli:165-212's caller).
+    // Only a prediction reads these: no arithmetic contract.
+    const m4 prevModel = load_m4(&sc.perObject[o].prevModel[0][0]);
+    const m4 prevView = load_m4(&cam->prevView[0][0]);
+    const m4 pmvp = mul_mm(prevModel, mul_mm(prevView, load_m4(&cam->prevUnjitteredProjection[0][0])));
+    const f4 pmvz = mul_mcol(prevModel, f4{prevView.m[0][2], prevView.m[1][2], prevView.m[2][2], prevView.m[3][2]});
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) d[36 + i * 4 + j] = pmvp.m[i][j];
+    d[52] = pmvz.x; d[53] = pmvz.y; d[54] = pmvz.z; d[55] = pmvz.w;
 }
 
 // The constant-factor material of SampleMaterialEvalFromUvCache (no texture permutations) only depends on the material

@@ -116,8 +116,8 @@ __global__ void __launch_bounds__(256) k_hzb_head(HzbDesc h, const unsigned long
 // `seedCounters` (brmi_execute's phase-1 build only): the block also does k_seed_phase2's work for the culling pass that follows.
 __global__ void __launch_bounds__(1024) k_hzb_tail(HzbDesc h, uint32_t firstMip, const uint32_t* skipUnless, uint32_t* seedCounters, uint32_t seedCapacity) {
     wave_prio<PRIO_HZB>();
+    if (seedCounters) seed_phase2(seedCounters, seedCapacity, threadIdx.x);      // (whatever the build does: the culling pass that follows starts from these)
     if (skipUnless && *skipUnless == 0u) return;
-    if (seedCounters) seed_phase2(seedCounters, seedCapacity, threadIdx.x);
     hzb_tail_levels(h, firstMip, 1024u);
 }
 
@@ -126,20 +126,25 @@ int launch_hzb(brmi_pass* p, hipStream_t s, bool fromVisibility, bool onlyIfPhas
     const bool head = h.paddedW >= 32 && h.paddedH >= 32;
     if (fromVisibility && !head) { int rc = launch_depth_copy(p, s); if (rc) return rc; fromVisibility = false; }   // tiny targets: unfused
     if (p->hzbMipCount < 2) return BRMI_OK;     // 1 x 1 target: mip 0 is all there is
-    const uint32_t* skip = onlyIfPhase2Drew ? p->counters() + CNT_VISIBLE2 : nullptr;
+    // Round 6: a frame whose phase-1 rasteriser stage built the chain itself (brmi_raster.hip: the re-test reads it) has the chain of everything but the late pass; the
+    // build from the visibility keys that follows that stage redoes the late pass's blocks only -- nothing at all when the late list stayed empty.  (A build from the
+    // depth map, brmi_build_hzb after brmi_depth_copy, redoes everything as always.)
+    const bool lateOnly = p->chainBuiltInRaster && fromVisibility && !onlyIfPhase2Drew;
+    p->chainBuiltInRaster = false;
+    const uint32_t* skip = onlyIfPhase2Drew ? p->counters() + CNT_VISIBLE2 : (lateOnly ? p->counters() + CNT_LATE1 : nullptr);
     uint32_t first = 1;
     if (head) {
         // texels of mips 1-5 outside the band's 32-row strips never change: brmi_setup filled the chain with "empty"
         const uint32_t row0 = h.rowLo / 32u, row1 = std::min((h.rowHi + 31u) / 32u, h.paddedH / 32u);
         const dim3 grid(h.paddedW / 32, std::max(1u, row1 - row0));
         DirtyBlocks mk{nullptr, (p->cfg.width + 31u) / 32u};
-        if (fromVisibility && onlyIfPhase2Drew && p->chainDirtyTracked) mk.chainDirty = p->wsPtr<uint8_t>(p->ws.chainDirty);
+        if (fromVisibility && (onlyIfPhase2Drew || lateOnly) && p->chainDirtyTracked) mk.chainDirty = p->wsPtr<uint8_t>(p->ws.chainDirty);
         if (fromVisibility) hipLaunchKernelGGL(k_hzb_head<true>, grid, dim3(256), 0, s, h, static_cast<const unsigned long long*>(p->res[BRMI_RES_VISIBILITY]), static_cast<float*>(p->res[BRMI_RES_LINEAR_DEPTH]), skip, row0, mk);
         else hipLaunchKernelGGL(k_hzb_head<false>, grid, dim3(256), 0, s, h, (const unsigned long long*)nullptr, (float*)nullptr, skip, row0, mk);
         first = 6;
     }
     if (first < h.mipCount) {
-        const bool seed = p->seedInHzbTail && !onlyIfPhase2Drew;
+        const bool seed = p->seedInHzbTail && !onlyIfPhase2Drew;      // (seeding happens whether or not the levels are rebuilt)
         hipLaunchKernelGGL(k_hzb_tail, dim3(1), dim3(1024), 0, s, h, first, skip, seed ? p->counters() : nullptr, p->cfg.maxTraversalRecords);
         if (seed) p->phase2Seeded = true;
     }

@@ -50,8 +50,14 @@ enum CounterIndex : uint32_t {
     CNT_TEMP_VISIBLE2 = CNT_BUCKETS + 64,   // survivors of phase 2
     CNT_REPLAY_NODES = CNT_BUCKETS + 96,
     CNT_REPLAY_MESHLETS = CNT_BUCKETS + 128,
-    CNT_WORDS = CNT_BUCKETS + 160
+    // round 6, the draw list (brmi_raster.hip): clusters of the phase-1 visible list the rasteriser takes first / holds back for the re-test / draws late
+    CNT_DRAW1 = CNT_BUCKETS + 160,          // entries of the draw list
+    CNT_HELD1 = CNT_BUCKETS + 192,          // held records
+    CNT_LATE1 = CNT_BUCKETS + 224,          // held clusters the re-test could not prove hidden (drawn by the late pass)
+    CNT_DRAWN_VT = CNT_BUCKETS + 256,       // ONE 64-bit word (even index): vertex | triangle << 32 sums of the clusters that ARE rasterised in phase 1 (draw list + late list)
+    CNT_WORDS = CNT_BUCKETS + 288
 };
+static_assert((CNT_DRAWN_VT & 1u) == 0u, "64-bit counter");
 
 // Phase 2 starts from the replay buffers: the replayed meshlets become the first bucket records, the replayed nodes the level-0 frontier;
 // per-level frontier counters start from zero; the raster overflow queues of phase 1 are counted and emptied.  Thread t of (at least) 128.
@@ -89,6 +95,13 @@ struct BucketRecord {                                                           
     uint32_t pageSlabByteOffset, firstBit, pad0, pad1;
 };
 struct TempVisible { uint4 packed; uint32_t bit, pad0, pad1, pad2; };                // 32 B
+// Round 6: what the library keeps per meshlet BESIDE the reference's descriptor (whose only bound is a sphere): the object-space box of its vertices, made once per
+// brmi_setup from the page contents (k_meshlet_boxes).  Not part of the data contract; indexed by pageBoxBase[slab * 1024 + page] + meshlet.
+struct MeshletBox { float lo[3]; uint32_t valid; float hi[3]; uint32_t pad; };       // 32 B
+struct PageRef { uint32_t slab, byteOffset, boxBase, meshletCount; };                 // one resident page (brmi_set_scene walks the page map)
+struct HeldRecord { uint32_t clusterIndex, boxIndex, perObjectIndex, vertsTris /* vertices | triangles << 16 */; };   // 16 B: a visible cluster the phase-1 rasteriser does not take until the re-test has looked at it
+static_assert(sizeof(MeshletBox) == 32 && sizeof(PageRef) == 16 && sizeof(HeldRecord) == 16, "draw-list records");
+constexpr uint32_t OBJ_CONST_FLOATS = 56;      // per object: MVP (16), objectToClip (16), modelViewZ (4), previous frame's MVP (16) and modelViewZ (4)
 
 // Everything the rasteriser and the G-buffer pass need to start on a visible cluster, resolved once by the compaction
 // kernel (one lane per cluster, all in flight): the per-cluster chain cluster -> slab -> page header -> meshlet descriptor
@@ -133,6 +146,68 @@ struct HzbDesc {
     uint32_t mipOffset[kMaxHzbMips];
 };
 
+// ---- Round 6: is everything a meshlet can draw behind the depth chain `hzb`?  (brmi_cull.hip: the draw list's prediction, against the previous frame's chain with the
+// previous frame's matrices; brmi_raster.hip: the re-test that decides, against the chain of the keys the draw list left, with the frame's own.)  CONSERVATIVE for the
+// keys the chain was built from: `true` means no triangle of the meshlet can win a pixel against them.
+//   * rectangle: floor(min - g) .. floor(max + g) of the eight box corners' pixel coordinates (a vertex lies inside the box, the projection of a box in front of the
+//     eye plane inside the hull of its corners; g = a quarter pixel plus 2^-20 of the largest clip-space term in pixels at the nearest corner covers the rounding of
+//     the rasteriser's evaluation and of this one, whatever the association), clamped like the rasteriser's boxes (scissor, surface);
+//   * depth: the nearest corner's -viewZ less 2^-17 of itself and 2^-18 of the largest term of the dot product (vertex depths are convex combinations of corner
+//     depths; a key's depth a convex combination of vertex depths, one mantissa bit dropped);
+//   * every texel of the rectangle at the finest mip (>= 1) where it is at most maxTexels x maxTexels texels; a texel is the FARTHEST key depth of its pixels ("empty"
+//     where one has no key), so "all texels nearer than the box" is "all keys nearer than any key of the meshlet";
+//   * a box that reaches the eye plane (or any NaN) says false; an empty rectangle (off screen) says true: nothing to draw.
+struct BoxViewport { float width, height, minX, minY; int x0, y0, x1, y1; };      // (ndc + 1) / 2 * width + minX as the rasteriser has it; the clamp in pixels
+__device__ __forceinline__ bool box_behind_chain(const HzbDesc& hzb, const MeshletBox& bx, const float* mvpRows /* 16 floats, object -> clip */, const float* mvzRow /* 4 floats, -viewZ = -dot */,
+                                                 const BoxViewport& vp, uint32_t maxTexels) {
+    // per-axis products: corner (i, j, k) = X[i] + Y[j] + Z[k] + row 3 in the columns x, y, w of the matrix, and in the depth's dot product
+    float X[2][4], Y[2][4], Z[2][4];
+    const int col[3] = {0, 1, 3};
+    float magC = 0.0f, mag = fabsf(mvzRow[3]);
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        const float px = s ? bx.hi[0] : bx.lo[0], py = s ? bx.hi[1] : bx.lo[1], pz = s ? bx.hi[2] : bx.lo[2];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            X[s][c] = px * mvpRows[0 + col[c]]; Y[s][c] = py * mvpRows[4 + col[c]]; Z[s][c] = pz * mvpRows[8 + col[c]] + mvpRows[12 + col[c]];
+            magC = fmaxf(magC, fmaxf(fmaxf(fabsf(X[s][c]), fabsf(Y[s][c])), fmaxf(fabsf(pz * mvpRows[8 + col[c]]), fabsf(mvpRows[12 + col[c]]))));
+        }
+        X[s][3] = px * mvzRow[0]; Y[s][3] = py * mvzRow[1]; Z[s][3] = pz * mvzRow[2] + mvzRow[3];
+        mag = fmaxf(mag, fmaxf(fmaxf(fabsf(X[s][3]), fabsf(Y[s][3])), fabsf(pz * mvzRow[2])));
+    }
+    float sx0 = 3.0e38f, sy0 = 3.0e38f, sx1 = -3.0e38f, sy1 = -3.0e38f, d = 3.0e38f, w = 3.0e38f;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int i = k & 1, j = (k >> 1) & 1, l = k >> 2;
+        const float cx = (X[i][0] + Y[j][0]) + Z[l][0], cy = (X[i][1] + Y[j][1]) + Z[l][1], cw = (X[i][2] + Y[j][2]) + Z[l][2];
+        const float inv = __builtin_amdgcn_rcpf(cw);      // (1 ulp: inside the guard)
+        const float sx = (cx * inv + 1.0f) * 0.5f * vp.width + vp.minX, sy = (1.0f - cy * inv) * 0.5f * vp.height + vp.minY;
+        sx0 = fminf(sx0, sx); sx1 = fmaxf(sx1, sx); sy0 = fminf(sy0, sy); sy1 = fmaxf(sy1, sy);
+        d = fminf(d, -((X[i][3] + Y[j][3]) + Z[l][3])); w = fminf(w, cw);
+    }
+    if (!(w > 1e-6f && d > 0.0f && fabsf(sx0) < 1.0e9f && fabsf(sx1) < 1.0e9f && fabsf(sy0) < 1.0e9f && fabsf(sy1) < 1.0e9f)) return false;
+    const float guard = 0.25f + magC * __builtin_amdgcn_rcpf(w) * 9.5367431640625e-7f * (vp.width + vp.height);
+    const int x0 = max((int)floorf(fmaxf(sx0 - guard, -1.0e9f)), vp.x0), y0 = max((int)floorf(fmaxf(sy0 - guard, -1.0e9f)), vp.y0);
+    const int x1 = min((int)floorf(fminf(sx1 + guard, 1.0e9f)), vp.x1), y1 = min((int)floorf(fminf(sy1 + guard, 1.0e9f)), vp.y1);
+    const float nearSafe = d - (d * 7.62939453125e-6f + mag * 3.814697265625e-6f);
+    if (!(nearSafe > 0.0f)) return false;
+    if (x0 > x1 || y0 > y1) return true;
+    uint32_t mip = 1u;
+    while (mip + 1u < hzb.mipCount && (((x1 >> mip) - (x0 >> mip) + 1) > (int)maxTexels || ((y1 >> mip) - (y0 >> mip) + 1) > (int)maxTexels)) mip++;
+    if (mip >= hzb.mipCount) return false;
+    const uint32_t mw = max(hzb.paddedW >> mip, 1u), mh = max(hzb.paddedH >> mip, 1u);
+    if (((x1 >> mip) - (x0 >> mip) + 1) > (int)maxTexels || ((y1 >> mip) - (y0 >> mip) + 1) > (int)maxTexels) return false;      // (not even the last mip: a chain shorter than the surface)
+    const float* m = hzb.mips + hzb.mipOffset[mip];
+    const int tx0 = x0 >> mip, tx1 = min(x1 >> mip, (int)mw - 1), ty1 = min(y1 >> mip, (int)mh - 1);
+    // a row of texels at a time (its loads side by side); a cluster that shows usually says so in its first row
+    for (int y = y0 >> mip; y <= ty1; y++) {
+        float farthest = 0.0f;
+        for (int x = tx0; x <= tx1; x++) farthest = fmaxf(farthest, m[(size_t)y * mw + (uint32_t)x]);
+        if (!(farthest < nearSafe)) return false;
+    }
+    return true;
+}
+
 // Scenes whose materials all pack to the same coat (fuzz) G-buffer word: the word and whether the plane currently holds it everywhere
 // (brmi_frame.hip: job_layer_uniform, k_fill_layer_planes; brmi_resolve.hip skips the plane's stores)
 // The frame's main camera and per-frame record as the constants kernel found them (brmi_frame.hip).  The resolve + shading half of a frame reads
@@ -146,7 +221,8 @@ struct LayerUniform { unsigned long long coatWord, fuzzWord, coatFilledWord, fuz
 struct Workspace {     // byte offsets into BRMI_RES_WORKSPACE
     uint64_t counters, frontierA, frontierB, buckets, tempVisible, bitmask1, bitmask2, blockDirty, chainDirty, wordPrefix, blockSums,
              instanceBitBase, segPrefix, meshLevelWidth, scanAgg, flatNodes, flatLeaves, instanceWalk, planes, replayNodes, replayBuckets, lightVS, lightMeta, clusterPages, clusterHits, pageTotal, lightHitMasks, binCounts, binRecords, binOverflow, binPlan, binItems, binScratch, clusterSetup, resolveVerts, resolveTris, matWords, shadeTables, lutF, frameConst, objConst, matConst, deferredPixels,
-             frameSnapshot, debugStamps, clusterUv, binAlpha, overflowAlpha, resolveUVs, resolveColors, alphaMats, shadeRows, shadeAvgs, ggxQuads, shadeLights, clusterList, listEntries, listRecords, layerUniform, frameClearBytes, total;
+             frameSnapshot, debugStamps, clusterUv, binAlpha, overflowAlpha, resolveUVs, resolveColors, alphaMats, shadeRows, shadeAvgs, ggxQuads, shadeLights, clusterList, listEntries, listRecords, layerUniform,
+             meshletBoxes, pageBoxBase, pageRefs, drawList, heldRecords, lateList, frameClearBytes, total;
 };
 
 }  // namespace brmi
@@ -171,6 +247,16 @@ struct brmi_pass {
     uint32_t minLevelWidth = 0;      // narrowest such width over the meshes
     std::vector<uint32_t> hostMeshLevelWidth;   // per mesh metadata entry
     uint32_t maxLevelWidth = 0;      // widest BVH level of any mesh (decides between the per-instance and the per-level traversal)
+    // Round 6, the draw list: per-meshlet boxes of the scene's resident pages and whether this pass holds clusters back (brmi_raster.hip)
+    std::vector<brmi::PageRef> hostPageRefs; std::vector<uint32_t> hostPageBoxBase; uint32_t totalBoxes = 0;
+    bool holdEnabled = false;        // the pass can hold clusters back: occlusion culling on, no band / interleaved partition, boxes available (BRMI_TUNING hold_clusters=0: off)
+    bool holdThisFrame = false;      // this frame's phase 1 made a draw list (launch_cull -> launch_raster)
+    uint32_t holdMinClusters = 16384; // hold only on frames whose last known visible-cluster count is at least this (BRMI_TUNING hold_min_clusters): below it the re-test, the late
+                                     // pass and the chain's second look cost what the rasteriser saves (Bistro-class, 10 k clusters: +25 us; profiles/r06_experiments.md)
+    uint32_t holdMaxTexels = 8;      // the prediction reads at most this many texels per axis of the previous chain (BRMI_TUNING hold_max_texels; Zorah-class: 4 / 6 / 8 hold 41.6 / 47.7 / 49.6 %
+                                     // of the list, serial frame 2.574 / 2.53 / 2.50 ms against 2.948 without; a prediction finer than the re-test sends the difference to the late pass: 2.75)
+    uint32_t retestMaxTexels = 8;    // ... and the re-test of this frame's
+    bool chainBuiltInRaster = false; // this frame's phase-1 rasteriser stage built the chain itself (before its re-test): the build that follows redoes the late pass's blocks only
     bool sceneHasVertexColors = false;                           // some mesh's pages carry vertex colours (perMesh.vertexFlags bit 0)
     uint32_t sceneUvSets = 1;      // UV sets the texture slots of the scene's materials name (brmi_set_scene)
     bool sceneHasAlphaTest = false, sceneHasTextures = false, sceneHasParallax = false;   // some material is alpha tested / samples a texture (brmi_set_scene)
@@ -290,6 +376,7 @@ uint32_t resolve_inline_ratio(const brmi_pass* p);
 bool resolve_inline_frame(brmi_pass* p);
 int launch_light_clustering(brmi_pass* p, hipStream_t s);
 int launch_expand_luts(brmi_pass* p, hipStream_t s);
+int launch_meshlet_boxes(brmi_pass* p, hipStream_t s);      // brmi_setup: the per-meshlet boxes of the draw list's tests, from the page contents
 int launch_shade(brmi_pass* p, hipStream_t s);
 
 }  // namespace brmi

@@ -82,6 +82,8 @@ struct RasterArgs {
     uint32_t* counters;
     uint8_t* chainDirty; uint32_t chainBlocksX;       // phase 2 only (else null): a byte per 32 x 32 px block its triangles may touch (byte 0: all, blocks from byte 4), for the second depth-chain build
     uint32_t firstCounter, countCounter;   // counter indices: first cluster (0xFFFFFFFF = 0) and cluster count
+    const uint32_t* drawList;              // round 6: null = clusters first .. first + count of the visible list; else the `count` cluster indices to rasterise (draw list, late list)
+    uint32_t* countFeedback;               // host-mapped word or null: the launch's cluster count, for the sizes of the frames that follow
     unsigned long long* vis;
     uint32_t visW, visH, tilesX, bandY0, bandY1;      // visW x visH: the FRAME (scissor clamp); bandY0 / bandY1: rows of the surface this GPU renders (records live in surface rows)
     uint32_t rowLo, rowHi;                            // frame rows k_raster looks at: the band, or the whole frame with the interleaved partition ...
@@ -305,6 +307,7 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
     // instead of a chain of vector loads with a wait after each: the fetch was 11-29 % of the kernel's wave-cycles, measured with phase stamps)
     const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.firstCounter == 0xFFFFFFFFu ? 0u : a.counters[a.firstCounter]));
     const uint32_t count = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.counters[a.countCounter]);
+    if (a.countFeedback && blockIdx.x == 0u && lane0 == 0u) __hip_atomic_store(a.countFeedback, count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const GlobalSink gsink{a.vis, a.tilesX, a.debugFlags};
     // static round-robin over clusters: a shared queue head saturates at ~90 dequeues/us (MI355X_MICROARCH.md, row
     // "dequeue"), which is slower than the work itself once big triangles are handed off
@@ -351,13 +354,17 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
         rqHead += n;
         wave_lds_sync();
     };
+    // (round 6: a frame that holds clusters back names the clusters to draw in a list -- written by an earlier launch, so through the scalar cache; the NEXT item's
+    // entry is requested while this one is walked: one SGPR, unlike the 16 of the whole record that cost more than they saved in round 5)
+    uint32_t listed = (a.drawList && blockIdx.x < items) ? kconst(a.drawList)[first + blockIdx.x / split] : 0u;
     for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
 #if BRMI_RASTER_OPAQUE_LANE
         uint32_t lane = lane0; asm volatile("" : "+v"(lane));      // (what a cluster derives from the lane index is recomputed per cluster, not hoisted into registers and SGPR spill lanes)
 #endif
         KSTAMP(7);
         const uint32_t c = item / split, sub = item % split;
-        const uint32_t clusterIndex = first + c;
+        const uint32_t clusterIndex = a.drawList ? (uint32_t)__builtin_amdgcn_readfirstlane((int)listed) : first + c;
+        if (a.drawList && item + gridDim.x < items) listed = kconst(a.drawList)[first + (item + gridDim.x) / split];
         const ClusterSetup cs = load_uniform(&a.setup[clusterIndex]);        // resolved by the compaction kernel: one hop instead of six
         const uint32_t vertCount = cs.counts & 0xFFu, triCount = (cs.counts >> 8) & 0xFFu, posFormat = (cs.counts >> 16) & 0xFFu;
         const uint32_t passLo = split > 1u ? (sub / parts) * 64u : 0u, passHi = split > 1u ? min(passLo + 64u, triCount) : triCount;
@@ -367,7 +374,7 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
         const brmi_view_raster_info ri = load_uniform(&sc.viewRasterInfo[cs.viewId]);
         const float visWidth = (float)(ri.scissorMaxX - ri.scissorMinX), visHeight = (float)(ri.scissorMaxY - ri.scissorMinY);
         const float sMinXf = (float)ri.scissorMinX, sMinYf = (float)ri.scissorMinY;
-        const auto oc = kconst(a.objConst + (size_t)cs.perObjectIndex * 36u);
+        const auto oc = kconst(a.objConst + (size_t)cs.perObjectIndex * OBJ_CONST_FLOATS);
         m4 mvp;
 #pragma unroll
         for (int i = 0; i < 4; i++)
@@ -1264,6 +1271,52 @@ __global__ void __launch_bounds__(256) k_depth_copy(const unsigned long long* vi
     }
 }
 
+// ---- Round 6: the draw list's RE-TEST -----------------------------------------------------------------------------------------------------
+// The reference rasterises every cluster of the visible list (SoftwareRasterizeClustersPass1, CLodExtension.cpp:1920-2088); four in five of them own no pixel of the
+// frame -- hidden behind nearer clusters the occlusion test's sphere-against-four-texels let through (profiles/r05_experiments.md, r06_experiments.md).  A cluster
+// that cannot win a pixel of the phase-1 depth image need not be drawn for the image to be the reference's: the 64-bit min only ever lowers a key.  So phase 1
+// draws the clusters its culling PREDICTED visible (the draw list), builds the depth chain from the keys that leaves, and then this kernel looks at every held
+// cluster once: the box of its vertices (MeshletBox) through the frame's own object-to-clip matrix -- the rasteriser's arithmetic for the corners -- gives a pixel
+// rectangle that contains every pixel any triangle of the cluster can touch and a depth no vertex is nearer than; when every texel of the chain over that
+// rectangle (a texel = the FARTHEST key depth of its pixels, "empty" where one has no key) is nearer, the cluster is skipped for good, else it goes to the late
+// list and the late pass draws it before anything reads the phase-1 depth.  The phase-1 keys are then exactly those of drawing everything: phase 2, the chain
+// (rebuilt where the late pass drew) and every later stage see the reference's frame -- the whole parity suite runs with this on.  The prediction may be anything;
+// THIS test is what has to be conservative: box_behind_chain (brmi_internal.h) states how.
+// A lane per held cluster: the shape of the cluster cull (eight corner transforms and up to maxTexels^2 independent 4 B loads per lane).
+struct RetestArgs {
+    const HeldRecord* held; const MeshletBox* boxes; const float* objConst; const brmi_view_raster_info* viewRasterInfo;
+    HzbDesc hzb; uint32_t visW, visH, capacity, maxTexels;
+    uint32_t* counters; uint32_t* lateList; uint32_t* heldFeedback;      // (host-mapped word or null: the held count, for the grids of the frames that follow)
+};
+__global__ void __launch_bounds__(256) k_retest_held(RetestArgs a) {
+    wave_prio<PRIO_RASTER>();
+    const uint32_t n = min(a.counters[CNT_HELD1], a.capacity);
+    if (a.heldFeedback && blockIdx.x == 0u && threadIdx.x == 0u) __hip_atomic_store(a.heldFeedback, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const brmi_view_raster_info ri = a.viewRasterInfo[0];      // (single view: ClusterSetup::viewId is the main camera's)
+    const BoxViewport vp{(float)(ri.scissorMaxX - ri.scissorMinX), (float)(ri.scissorMaxY - ri.scissorMinY), (float)ri.scissorMinX, (float)ri.scissorMinY,
+                         max((int)ri.scissorMinX, 0), max((int)ri.scissorMinY, 0), min((int)ri.scissorMaxX - 1, (int)a.visW - 1), min((int)ri.scissorMaxY - 1, (int)a.visH - 1)};
+    unsigned long long lateVT = 0ull;
+    const uint32_t rounded = (n + 63u) & ~63u;      // wave-uniform trip count (wave_append inside)
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < rounded; g += gridDim.x * blockDim.x) {
+        const bool on = g < n;
+        HeldRecord hr{0u, 0u, 0u, 0u};
+        bool late = false;
+        if (on) {
+            hr = a.held[g];
+            const MeshletBox bx = a.boxes[hr.boxIndex];
+            const float* oc = a.objConst + (size_t)hr.perObjectIndex * OBJ_CONST_FLOATS;
+            late = !box_behind_chain(a.hzb, bx, oc, oc + 32, vp, a.maxTexels);
+        }
+        // the late list: one atomic per wave
+        const bool append = on && late;
+        const uint32_t slot = wave_append(&a.counters[CNT_LATE1], append);
+        if (append) { a.lateList[slot] = hr.clusterIndex; lateVT += (unsigned long long)(hr.vertsTris & 0xFFFFu) | ((unsigned long long)(hr.vertsTris >> 16) << 32); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lateVT += (unsigned long long)__shfl_xor((long long)lateVT, o);
+    if ((threadIdx.x & 63u) == 0u && lateVT != 0ull) atomicAdd(reinterpret_cast<unsigned long long*>(&a.counters[CNT_DRAWN_VT]), lateVT);
+}
+
 int launch_clear(brmi_pass* p, hipStream_t s) {
     // inside brmi_execute the culling pass follows immediately: take its frame clear along (frameClearBytes is a multiple of 256)
     uint4* frameState = p->fuseFrameClear ? p->wsPtr<uint4>(p->ws.counters) : nullptr;
@@ -1283,6 +1336,11 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
     a.sc = p->scene; a.clusters = static_cast<const uint4*>(p->res[BRMI_RES_VISIBLE_CLUSTERS]); a.counters = p->counters();
     a.setup = p->wsPtr<ClusterSetup>(p->ws.clusterSetup);
     a.firstCounter = 0xFFFFFFFFu; a.countCounter = CNT_VISIBLE;
+    a.drawList = nullptr; a.countFeedback = nullptr;
+    // round 6: a frame whose culling held clusters back (launch_cull) rasterises its draw list here, re-tests the held clusters against the keys that leaves, and
+    // draws the ones it cannot prove hidden in a late pass -- all inside this stage, before anything reads the phase-1 depth (k_retest_held)
+    const bool hold = phase == 1 && p->holdThisFrame;
+    if (hold) { a.drawList = p->wsPtr<uint32_t>(p->ws.drawList); a.countCounter = CNT_DRAW1; }
     // (the interleaved partition's surface rows are not the frame rows the boxes are in: there the second build redoes everything)
     a.chainDirty = (BRMI_CHAIN_DIRTY_BLOCKS && phase == 2 && p->stripes.count <= 1u) ? p->wsPtr<uint8_t>(p->ws.chainDirty) : nullptr; a.chainBlocksX = (p->cfg.width + 31u) / 32u;
     p->chainDirtyTracked = a.chainDirty != nullptr;
@@ -1350,6 +1408,42 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
         if (!direct2 && !(p->rasterDebug & 4)) hipLaunchKernelGGL(k_raster_bins<false>, bgrid, dim3(BRMI_BIN_THREADS), 0, s, a);
     }
     BRMI_LAUNCH_CHECK(p, "k_raster");
+    if (hold) {
+        // the chain of the keys the draw list left (LinearDepthCopyPass1 + LinearDepthDownsamplePass1's work, done here; the frame's own build after this stage then only
+        // redoes the blocks the late pass touched: launch_hzb)
+        p->chainBuiltInRaster = false;
+        if (int rc = launch_hzb(p, s, true, false)) return rc;
+        volatile uint32_t* fb = p->phase2FeedbackHost;      // words 5 / 6: the late and the held count of the frames before (no wait; any value gives the same keys)
+        const uint32_t lastLate = fb ? fb[5] : 0u, lastHeld = fb ? fb[6] : 0xFFFFFFFFu;
+        RetestArgs r;
+        r.held = p->wsPtr<HeldRecord>(p->ws.heldRecords); r.boxes = p->wsPtr<MeshletBox>(p->ws.meshletBoxes); r.objConst = a.objConst; r.viewRasterInfo = p->scene.viewRasterInfo;
+        r.hzb = p->hzbDesc(); r.visW = a.visW; r.visH = a.visH; r.capacity = p->cfg.maxVisibleClusters; r.maxTexels = p->retestMaxTexels;
+        r.counters = p->counters(); r.lateList = p->wsPtr<uint32_t>(p->ws.lateList); r.heldFeedback = p->phase2FeedbackDev ? p->phase2FeedbackDev + 6 : nullptr;
+        const uint32_t tgrid = std::max(16u, std::min(4096u, pow2_at_least(std::min(lastHeld, p->cfg.maxVisibleClusters) / 256u + 1u)));
+        hipLaunchKernelGGL(k_retest_held, dim3(tgrid), dim3(256), 0, s, r);
+        RasterArgs l = a;
+        l.drawList = r.lateList; l.countCounter = CNT_LATE1; l.countFeedback = p->phase2FeedbackDev ? p->phase2FeedbackDev + 5 : nullptr;
+        // what the late pass draws changes the depth under it: it records the 32 x 32 px blocks its triangles may touch, like phase 2
+        l.chainDirty = BRMI_CHAIN_DIRTY_BLOCKS ? p->wsPtr<uint8_t>(p->ws.chainDirty) : nullptr; l.chainBlocksX = (p->cfg.width + 31u) / 32u;
+        p->chainDirtyTracked = l.chainDirty != nullptr; p->chainBuiltInRaster = true;
+        // few late clusters (a still or slowly moving camera: the prediction and the re-test ask the same question of nearly the same depth): every triangle through the
+        // row re-deal with global atomics, ONE launch, as the small phase 2; many: records, plan and bins once more
+        const bool directLate = lastLate <= (p->sceneHasAlphaTest ? 0u : p->phase2DirectMax);
+        if (directLate) l.bigTriArea = l.bigTriAreaAlpha = l.bigTriAreaDense = 0x3FFFFFFF;
+        const dim3 lgrid(std::min(p->rasterGrid, std::max(128u, pow2_at_least(std::min(lastLate, 1u << 20) * 16u))));
+        if (p->sceneHasAlphaTest) {
+            hipLaunchKernelGGL(k_raster<true>, lgrid, dim3(64), l.tableCells * 4u, s, l);
+            if (!directLate) { hipLaunchKernelGGL(k_raster_overflow<true>, dim3(129), dim3(256), 0, s, l); hipLaunchKernelGGL(k_raster_bins<true>, dim3(p->binGrid), dim3(BRMI_BIN_THREADS), 0, s, l); }
+        } else {
+            hipLaunchKernelGGL(k_raster<false>, lgrid, dim3(64), l.tableCells * 4u, s, l);
+            if (!directLate) {
+                if (p->binsX * p->binsY > 4096u) hipLaunchKernelGGL((k_raster_overflow<false, 1024>), dim3(33), dim3(1024), 0, s, l);
+                else hipLaunchKernelGGL(k_raster_overflow<false>, dim3(129), dim3(256), 0, s, l);
+                hipLaunchKernelGGL(k_raster_bins<false>, dim3(p->binGrid), dim3(BRMI_BIN_THREADS), 0, s, l);
+            }
+        }
+        BRMI_LAUNCH_CHECK(p, "late raster pass");
+    }
     return BRMI_OK;
 }
 

@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(64) k_resolve_setup(GBufferArgs a) {
         const ClusterSetup cs = a.setup[c];
         if (cs.vertBase == BRMI_ARENA_NONE) continue;          // arena full: the pixel pass walks this cluster's data itself
         const uint32_t vertCount = cs.counts & 0xFFu, triCount = (cs.counts >> 8) & 0xFFu, posFormat = (cs.counts >> 16) & 0xFFu;
-        const m4 objectToClip = load_m4(a.objConst + (size_t)cs.perObjectIndex * 36u + 16u);
+        const m4 objectToClip = load_m4(a.objConst + (size_t)cs.perObjectIndex * OBJ_CONST_FLOATS + 16u);
         const bool skinned = (cs.counts & BRMI_CS_SKINNED) != 0u;
         const uint32_t skinSlot = skinned ? a.sc.perMeshInstance[cs.instanceIndex].skinningInstanceSlot : 0xFFFFFFFFu;
         for (uint32_t v = lane; v < vertCount; v += 64) {
@@ -216,7 +216,7 @@ BRMI_DEV float swizzle4(f4 v, uint32_t idx) { return idx == 0u ? v.x : idx == 1u
 BRMI_DEV void resolve_tables_inline(const GBufferArgs& a, const ClusterSetup& cs, uint32_t triId, ResolveTriangle& r, f3 p[3], f3 n[3]) {
     const uint8_t* tb = cs.triBase + triId * 3u;
     const uint32_t ti[3] = {tb[0], tb[1], tb[2]};
-    const m4 objectToClip = load_m4(a.objConst + (size_t)cs.perObjectIndex * 36u + 16u);
+    const m4 objectToClip = load_m4(a.objConst + (size_t)cs.perObjectIndex * OBJ_CONST_FLOATS + 16u);
     const bool skinned = (cs.counts & BRMI_CS_SKINNED) != 0u;
     const uint32_t skinSlot = skinned ? a.sc.perMeshInstance[cs.instanceIndex].skinningInstanceSlot : 0xFFFFFFFFu;
     f4 clip[3];

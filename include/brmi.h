@@ -167,6 +167,11 @@ typedef struct brmi_counters {
     uint32_t droppedRecords, droppedClusters;
     uint32_t lightPagesUsed;
     uint32_t replayNodes, replayMeshlets;   /* occluded in phase 1, re-tested in phase 2 */
+    /* Statistics of the rasteriser (no counterpart in CLodTelemetry.h).  [0] / [2]: vertex / triangle count sums of the visible clusters, both phases (32 bits
+     * each since round 5: brmi_create refuses a cluster capacity whose sums could exceed them).  [4]: clusters handed to the rasteriser stage; [5]: raster records
+     * that found their screen bin full.  Round 6, the draw list: [1] = clusters of the phase-1 visible list the culling HELD BACK as probably
+     * hidden, [3] = how many of those the re-test could not prove hidden and the late pass drew; [1] - [3] clusters of the list were never rasterised, and the
+     * image is the one of rasterising all of them.  Both 0 on frames that draw the list in order (no previous depth chain, multi-GPU partitions, hold_clusters=0). */
     uint32_t reserved[6];
 } brmi_counters;
 

@@ -1083,6 +1083,61 @@ def test_phase_two_rasterises_the_same_keys_with_and_without_bins(name, direct_m
         assert drew > 0, "phase 2 drew nothing in this case"
 
 
+@pytest.mark.parametrize("texels,late_direct", [(8, 1 << 30), (2, 0), (1, 1 << 30)])
+@pytest.mark.parametrize("name", list(OCCLUSION_CASES))
+def test_draw_list_holds_clusters_back_without_changing_a_key(name, texels, late_direct, occlusion_runs):
+    """Round 6, the draw list (brmi_raster.hip: k_retest_held).  Phase 1 rasterises the clusters its culling predicted visible, re-tests the held ones against the
+    chain of the keys that leaves and draws the ones it cannot prove hidden in a late pass.  Forced on (hold_min_clusters=0: by default only frames of >= 16 k visible
+    clusters do it) on the three frames of the camera path, with the prediction at several texel budgets (1 x 1 texels predicts badly: many late clusters) and the late
+    pass through the direct walk or through the bins: the visible list, the keys, the depth map, the depth chain and the reference's counters are those of the plain
+    frames (which the tests above hold against the oracle), frame by frame; clusters WERE held, and some of them were never drawn."""
+    from basicrenderer_amd.renderer import VisibilityRenderer
+    frames = occlusion_runs(name)
+    with _Env(hold_min_clusters=0, hold_max_texels=texels, retest_max_texels=max(texels, 2), BRMI_PHASE2_DIRECT_MAX=late_direct):
+        r = VisibilityRenderer(frames[0]["scene"], occlusion=True, stats=True)
+    held = late = 0
+    for step, f in enumerate(frames):
+        if step:
+            r.set_camera_from(f["scene"], frame_index=step)
+        r.execute()
+        __import__("torch").cuda.synchronize()
+        c, ref = r.counters(), f["counters"]
+        assert (c.visibleClusters, c.visibleClustersPhase2, c.replayNodes, c.replayMeshlets, c.meshletsTested, c.nodesVisited) == \
+               (ref.visibleClusters, ref.visibleClustersPhase2, ref.replayNodes, ref.replayMeshlets, ref.meshletsTested, ref.nodesVisited), f"frame {step}"
+        assert (c.reserved[0], c.reserved[2], c.reserved[4]) == (ref.reserved[0], ref.reserved[2], ref.reserved[4]), f"frame {step}: the list's vertex / triangle sums"
+        assert c.reserved[3] <= c.reserved[1] <= c.visibleClusters
+        if step == 0:
+            assert c.reserved[1] == 0, "no previous chain: nothing to predict from"
+        held += c.reserved[1]; late += c.reserved[3]
+        assert np.array_equal(r.visible_clusters(), f["clusters"]), f"frame {step}"
+        assert np.array_equal(r.visibility(), f["vis"]), f"frame {step}: a held cluster that was not drawn owned a pixel (or a late one was drawn wrong)"
+        assert np.array_equal(r.depth().view(np.uint32), f["depth"].view(np.uint32)), f"frame {step}"
+        for mip, (a, b) in enumerate(zip(r.hzb_mips(), f["hzb"])):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"frame {step}: chain mip {mip + 1} (the late pass's blocks were not rebuilt?)"
+        a, b = r.hdr().view(np.uint16), f["hdr"].view(np.uint16)
+        drawn = f["vis"] != np.uint64(0xFFFFFFFFFFFFFFFF)
+        assert np.array_equal(a.reshape(drawn.shape + (4,))[drawn], b.reshape(drawn.shape + (4,))[drawn]), f"frame {step}: lit image"
+    r.close()
+    if name != "tiny_odd":
+        assert held > late, f"{held} clusters held, {late} of them drawn late: none was skipped"
+        if texels == 1:
+            assert late > 0, "the late pass never ran"
+
+
+def test_draw_list_is_off_where_it_cannot_be_exact_yet(scenes):
+    """The re-test reads the chain in FRAME rows; passes that render a band or the interleaved chunks of a frame into compact surfaces keep the whole list (so do
+    passes without occlusion culling, and any pass with hold_clusters=0)."""
+    from basicrenderer_amd.renderer import VisibilityRenderer
+    sc = scenes("bistro_small")
+    for kw, tun in ((dict(band=(0, sc.height // 2 // 8 * 8)), dict(hold_min_clusters=0)), (dict(), dict(hold_min_clusters=0, hold_clusters=0))):
+        with _Env(**tun):
+            r = VisibilityRenderer(sc, occlusion=True, **kw)
+        for _ in range(3):
+            r.execute()
+        assert r.counters().reserved[1] == 0
+        r.close()
+
+
 @pytest.mark.parametrize("name", list(OCCLUSION_CASES))
 def test_occlusion_hzb_chain_bit_exact(name, occlusion_runs):
     for f in occlusion_runs(name):
