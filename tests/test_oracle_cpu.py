@@ -1541,12 +1541,14 @@ def test_kernels_of_the_benchmarked_frames_use_no_scratch_memory():
             rows[m.group(1).strip().replace("void ", "").replace("brmi::", "")] = dict(vgpr=int(m.group(2)), vspill=int(m.group(5)), scratch=int(m.group(7)))
     assert len(rows) > 40, out[:500]
     launched = ["k_frame_constants", "k_cull_hierarchy<false, 256u, 128u, true>", "k_cull_hierarchy<false, 1024u, 128u, true>", "k_cull_hierarchy<true, 256u, 128u, false>",
-                "k_cull_hierarchy<true, 1024u, 128u, false>", "k_cull_flat_wide", "k_cull_clusters<1>", "k_cull_clusters<2>", "k_cull_hierarchy<false, 256u, 128u, false>", "k_cull_hierarchy<false, 1024u, 128u, false>", "k_lc_count", "k_lc_fill", "k_scan_chained", "k_scatter_visible<false>", "k_scatter_visible<true>",
+                "k_cull_hierarchy<true, 1024u, 128u, false>", "k_cull_flat_wide", "k_cull_clusters<1>", "k_cull_clusters<2>", "k_cull_hierarchy<false, 256u, 128u, false>", "k_cull_hierarchy<false, 1024u, 128u, false>", "k_lc_count", "k_lc_fill", "k_scan_chained", "k_scatter_visible<false, false>", "k_scatter_visible<true, false>",
                 "k_raster<false>", "k_raster<true>", "k_raster_overflow<false, 256u>", "k_raster_overflow<false, 1024u>", "k_raster_overflow<true, 256u>", "k_raster_bins<false>", "k_raster_bins<true>", "k_hzb_head<true>", "k_hzb_tail",
                 "k_resolve_setup", "k_gbuffer<false, false, false, false, 1>", "k_gbuffer<false, true, false, false, 1>", "k_gbuffer<true, true, false, false, 0>",
                 "k_gbuffer<false, false, false, false, 0>", "k_gbuffer<false, true, false, false, 0>", "k_shade<0, 3>", "k_shade<0, 5>", "k_traverse",
                 # the Zorah-class and the dense frame (configs[4], `dense`): the level-synchronous traversal, the three-launch ranking, the in-place G-buffer kernel
-                "k_cull_flat_level<false>", "k_cull_flat_level<true>", "k_scan_reduce", "k_scan_blocks", "k_scan_words", "k_gbuffer<true, false, false, false, 1>", "k_gbuffer<true, false, false, false, 0>"]
+                "k_cull_flat_level<false>", "k_cull_flat_level<true>", "k_scan_reduce", "k_scan_blocks", "k_scan_words", "k_gbuffer<true, false, false, false, 1>", "k_gbuffer<true, false, false, false, 0>",
+                # ... and their draw list (round 6): the compaction with the prediction, the re-test
+                "k_scatter_visible<false, true>", "k_scatter_visible<true, true>", "k_retest_held", "k_meshlet_boxes"]
     for k in launched:
         assert k in rows, (k, sorted(rows)[:80])
         assert rows[k]["vspill"] == 0 and rows[k]["scratch"] == 0, (k, rows[k])
