@@ -249,7 +249,9 @@ extern "C" {
 
 int brmi_create(const brmi_config* cfg, brmi_pass** out) {
     if (!cfg || !out || cfg->structSize != sizeof(brmi_config) || cfg->width == 0 || cfg->height == 0) return BRMI_ERR_INVALID;
-    if (cfg->maxVisibleClusters == 0 || cfg->maxVisibleClusters > (1u << 26) || cfg->maxTraversalRecords == 0) return BRMI_ERR_INVALID;
+    // (<= 2^25 - 1 clusters: the vertex and the triangle count sums of a frame's list share one 64-bit counter, 128 per cluster at most -- brmi_internal.h, CNT_SUM_VERTS_LO; the
+    // reference's 30,000,000, Renderer.cpp:2494, fits)
+    if (cfg->maxVisibleClusters == 0 || cfg->maxVisibleClusters > (1u << 25) - 1u || cfg->maxTraversalRecords == 0) return BRMI_ERR_INVALID;
     if (cfg->lightClusterSize[0] == 0 || cfg->lightClusterSize[1] == 0 || cfg->lightClusterSize[2] == 0) return BRMI_ERR_INVALID;
     if (cfg->lightClusterSize[2] > 62u) return BRMI_ERR_INVALID;
     if ((uint64_t)((cfg->width + 255u) / 256u) * ((cfg->height + 15u) / 16u) > 65535ull) return BRMI_ERR_INVALID;      // the raster bins' work items name a bin in 16 bits (16384 x 16368 px still fits)
@@ -485,7 +487,12 @@ int brmi_set_scene(brmi_pass* p, const brmi_scene_buffers* scene) {
             flatBase[m] = (uint32_t)p->hostFlatNodes.size(); flatCount[m] = (uint32_t)bfs.size();
             // (breadth-first: the children of a node are pushed together, so they sit side by side; position of the first and depth of every node)
             std::vector<uint32_t> firstChild(bfs.size(), 0u), childCount(bfs.size(), 0u), depthOf(bfs.size(), 1u);
-            for (size_t k = 1; k < bfs.size(); k++) { const uint32_t par = bfs[k].second; if (childCount[par]++ == 0u) firstChild[par] = (uint32_t)k; depthOf[k] = depthOf[par] + 1u; p->flatMaxDepth = std::max(p->flatMaxDepth, depthOf[k]); }
+            uint32_t meshDepth = 1u;
+            for (size_t k = 1; k < bfs.size(); k++) { const uint32_t par = bfs[k].second; if (childCount[par]++ == 0u) firstChild[par] = (uint32_t)k; depthOf[k] = depthOf[par] + 1u; meshDepth = std::max(meshDepth, depthOf[k]); }
+            // the level-synchronous traversal keeps a frontier size per level in counters[CNT_FRONTIER0 + level] (96 words up to the stripe statistics) and launches a kernel per
+            // level: a hierarchy deeper than that, or than the configured level bound, is left to the level walk
+            if (meshDepth > std::min<uint32_t>(std::max(1u, p->cfg.maxBvhLevels), CNT_STRIPES - CNT_FRONTIER0 - 1u)) { flatCount[m] = 0; continue; }
+            p->flatMaxDepth = std::max(p->flatMaxDepth, meshDepth);
             for (size_t k = 0; k < bfs.size(); k++) {
                 const brmi_lod_node& nd = nodes[md[m].lodNodesBase + bfs[k].first];
                 FlatNode f{}; FlatLeaf l{};
@@ -972,6 +979,15 @@ int brmi_algorithmic_bytes(brmi_pass* p, uint64_t* perStage, uint64_t* total) {
     perStage[BRMI_STAGE_GBUFFER] = (8 + 52 + 4) * P;
     perStage[BRMI_STAGE_SHADE] = (4 + 48 + 8) * P;
     *total = 0; for (int i = 0; i < BRMI_STAGE_COUNT; i++) *total += perStage[i];
+    return BRMI_OK;
+}
+
+int brmi_algorithmic_bytes_launched(brmi_pass* p, uint64_t* perStage, uint64_t* total) {
+    if (int rc = brmi_algorithmic_bytes(p, perStage, total)) return rc;
+    if (!p->sceneHasCoat && !p->sceneHasFuzz) {      // k_shade<0>: depth 4 + normals 16 + albedo 4 + metallic / roughness 4 + emissive 8 read, HDR 8 written; the coat and fuzz planes (8 + 8) stay unread
+        const uint64_t P = (uint64_t)p->cfg.width * (p->bandY1 - p->bandY0);
+        *total -= perStage[BRMI_STAGE_SHADE]; perStage[BRMI_STAGE_SHADE] = 44ull * P; *total += perStage[BRMI_STAGE_SHADE];
+    }
     return BRMI_OK;
 }
 

@@ -85,6 +85,15 @@ __global__ void k_wait_flags(const uint32_t* words, uint32_t n, uint32_t skip, u
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");      // system scope: the bands behind the flags
 }
+// A store that goes THROUGH this GPU's caches to the memory it addresses (system-scope relaxed atomic store: global_store ... sc0 sc1 on gfx950; 8 B at a time, the widest
+// an atomic store comes in).  The images are ordinary coarse-grained device memory of OTHER GPUs mapped over hipIpc: a plain store may sit dirty in this GPU's L2 past the
+// end of the kernel (HIP only promises agent scope between kernels of a stream), and the `landed` flag -- uncached memory, written by the NEXT kernel with a relaxed
+// store -- could then reach the peer before the band it announces.  With write-through stores the kernel boundary (every store of the kernel has been acknowledged by
+// the memory it went to before the next kernel starts) is all the release the flag needs; a system-scope release fence instead writes back every XCD's whole L2 --
+// G-buffer planes and all -- and cost a frame 0.45 ms in round 5.
+__device__ __forceinline__ void store_through(uint2* d, uint2 v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(d), (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 // the band into every rank's image (own copy included).  RGB = drop the alpha on the way: four pixels (32 B) in, 24 B out per thread and peer.
 template <bool RGB>
 __global__ void __launch_bounds__(256) k_peer_write(const uint4* src, PeerTable peers, uint32_t nRanks, uint64_t slotOffset, uint64_t bandOffsetOut, uint64_t units) {
@@ -93,18 +102,18 @@ __global__ void __launch_bounds__(256) k_peer_write(const uint4* src, PeerTable 
             const uint4 a = src[2 * i], b = src[2 * i + 1];
             const uint32_t r0g0 = a.x, b0 = a.y & 0xFFFFu, r1g1 = a.z, b1 = a.w & 0xFFFFu, r2g2 = b.x, b2 = b.y & 0xFFFFu, r3g3 = b.z, b3 = b.w & 0xFFFFu;
             const uint2 o0 = make_uint2(r0g0, b0 | (r1g1 << 16)), o1 = make_uint2((r1g1 >> 16) | (b1 << 16), r2g2), o2 = make_uint2(b2 | (r3g3 << 16), (r3g3 >> 16) | (b3 << 16));
-            for (uint32_t p = 0; p < nRanks; p++) { uint2* d = reinterpret_cast<uint2*>(peers.output[p] + slotOffset + bandOffsetOut) + 3 * i; d[0] = o0; d[1] = o1; d[2] = o2; }
+            for (uint32_t p = 0; p < nRanks; p++) { uint2* d = reinterpret_cast<uint2*>(peers.output[p] + slotOffset + bandOffsetOut) + 3 * i; store_through(d, o0); store_through(d + 1, o1); store_through(d + 2, o2); }
         } else {
             const uint4 v = src[i];
-            for (uint32_t p = 0; p < nRanks; p++) reinterpret_cast<uint4*>(peers.output[p] + slotOffset + bandOffsetOut)[i] = v;
+            for (uint32_t p = 0; p < nRanks; p++) { uint2* d = reinterpret_cast<uint2*>(peers.output[p] + slotOffset + bandOffsetOut) + 2 * i; store_through(d, make_uint2(v.x, v.y)); store_through(d + 1, make_uint2(v.z, v.w)); }
         }
     }
 }
-// after k_peer_write has retired (a kernel boundary makes its stores visible system-wide): "my band of `frame` has landed in your slot"
+// after k_peer_write has retired: "my band of `frame` has landed in your slot"
 __global__ void k_signal_landed(PeerTable peers, uint32_t nRanks, uint32_t rank, uint32_t slot, uint32_t frame) {
     const uint32_t p = threadIdx.x;
-    // (relaxed: the band's stores were made by an EARLIER kernel of this stream, whose end wrote them through; a release here is a system-scope write-back of
-    // every XCD's L2 -- G-buffer planes and all -- per signal, which cost a one-GPU frame 0.45 ms with two signals per frame, round 5)
+    // (relaxed: the band's stores were write-through stores of an EARLIER kernel of this stream -- store_through above --, acknowledged by the peers' memory before
+    // that kernel retired; nothing of the band is left in this GPU's caches for a release to publish)
     if (p < nRanks) __hip_atomic_store(&peers.flags[p]->landed[slot][rank], frame, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // at the head of a submit: "I am at frame `frame`: whatever you hold for me of frame - depth may be overwritten"

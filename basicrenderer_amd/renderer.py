@@ -176,6 +176,13 @@ class VisibilityRenderer:
         self._check(self.lib.brmi_algorithmic_bytes(self._h, per, C.byref(total)), "brmi_algorithmic_bytes")
         return dict(zip(capi.STAGE_NAMES, [int(x) for x in per])), int(total.value)
 
+    def algorithmic_bytes_launched(self):
+        """The same for the kernel variants the frame launched (brmi_algorithmic_bytes_launched)."""
+        per = (capi.u64 * len(capi.STAGE_NAMES))()
+        total = capi.u64()
+        self._check(self.lib.brmi_algorithmic_bytes_launched(self._h, per, C.byref(total)), "brmi_algorithmic_bytes_launched")
+        return dict(zip(capi.STAGE_NAMES, [int(x) for x in per])), int(total.value)
+
     # -- read-back (linear layout) ---------------------------------------------------------------
     def _img(self, rid, dtype, comps=1):
         self.torch.cuda.synchronize(self.device)

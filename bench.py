@@ -398,6 +398,7 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False,
     serial_frames(10)                     # untimed: per-stage profile of the steady state, all stages
     warm_ms = r.stage_times()
     dom_stage = dominant_stage(workload, features, warm_ms)
+    longest_stage = max(warm_ms, key=lambda k: warm_ms[k]) if warm_ms else dom_stage      # this run's stage timers (whole stages: the raster stage is three kernels, two phases)
     r.set_timed_stages([dom_stage])
     # The timed region: EXACTLY --steps frames between a barrier + synchronize on both sides, MAX over ranks.  A short region (the driver's
     # 20 steps are 9 ms) is one noisy sample, so it is repeated (--repeats; 5 when --steps < 200) and the MEDIAN region is reported, the
@@ -450,6 +451,7 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False,
     if warm_ms:
         stage_ms = {k: (stage_ms[k] if k == dom_stage else warm_ms[k]) for k in warm_ms}
     per_stage_bytes, total_bytes = r.algorithmic_bytes()
+    launched_bytes, _ = r.algorithmic_bytes_launched()
     c = r.counters()
     path_out, path_fast_out = None, None
     if path and n == 1 and args.camera_path > 0 and args.occlusion:
@@ -502,6 +504,11 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False,
         except (OSError, ValueError, KeyError):
             pass
         hbm_frac = achieved / HBM_PEAK_GBS
+        # what the counters say the kernel MOVED (committed profile) over this run's launch time, and the bytes the launched variant is obliged to move (44 B / px of
+        # k_shade<0> when no material has a coat or fuzz layer, against 8(d)'s 60): `frac` keeps 8(d)'s definition, these two are the honest utilisation beside it
+        frac_traffic = round(traffic / dom_s / 1e9 / HBM_PEAK_GBS, 5) if (traffic and dom_s > 0) else None
+        frac_launched = round(launched_bytes[dom] / dom_s / 1e9 / HBM_PEAK_GBS, 5) if dom_s > 0 else None
+        nearer = "valu" if (valu and valu["frac"] > max(hbm_frac, frac_traffic or 0.0)) else "hbm"
         out = {
             "metric": "shaded Mpixels/s @4K (vis-buffer+resolve)" if (W, H) not in FRAME_SIZE.values() else f"shaded Mpixels/s @{W}x{H} (vis-buffer+resolve)", "value": round(value, 2), "unit": "Mpixels/s",
             "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -521,9 +528,13 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False,
                        "occlusion_culling": bool(args.occlusion), "visible_clusters_phase2_rank0": int(c.visibleClustersPhase2),
                        "meshlets_tested_rank0": int(c.meshletsTested), "partition": (f"interleaved chunks of {stripe_rows} rows x{n}" if striped else f"row bands x{n}") if n > 1 else "single GPU",
                        "frames_in_flight": fif},
-            "roofline": {"bound": "hbm", "nearer_ceiling": "valu" if (valu and valu["frac"] > hbm_frac) else "hbm", "kernel": {"raster": "k_raster + k_raster_bins (+ k_raster_overflow), both occlusion phases"}.get(dom, DOMINANT_KERNEL.get(dom, dom)), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(hbm_frac, 5), "traffic": traffic, "valu": valu,
-                         "algorithmic_bytes_per_launch": int(per_stage_bytes[dom]), "launch_ms": round(stage_ms[dom], 4),
+            "roofline": {"bound": nearer, "bound_note": "the ceiling the kernel sits nearer to: VALU issue (roofline.valu.frac, SQ_INSTS_VALU of the committed profile) or HBM (frac / frac_traffic); "
+                                                        "achieved / peak / unit / frac are the HBM figures of SURVEY.md 8(d) either way",
+                         "kernel_stage": dom, "longest_stage_this_run": longest_stage, "kernel_stage_is_longest_stage": bool(dom == longest_stage),
+                         "kernel": {"raster": "k_raster + k_raster_bins (+ k_raster_overflow), both occlusion phases"}.get(dom, DOMINANT_KERNEL.get(dom, dom)), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(hbm_frac, 5), "traffic": traffic, "frac_traffic": frac_traffic, "valu": valu,
+                         "algorithmic_bytes_per_launch": int(per_stage_bytes[dom]), "algorithmic_bytes_launched_variant": int(launched_bytes[dom]), "frac_launched_variant": frac_launched,
+                         "launch_ms": round(stage_ms[dom], 4),
                          "whole_frame": {"algorithmic_bytes": int(total_bytes), "achieved_GBps": round(frame_gbs, 2), "frac": round(frame_gbs / HBM_PEAK_GBS, 5)}},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items() if v > 0},
             "stage_ms_note": (f"'{dom}' from HIP events inside the timed region; the other stages from 10 untimed frames before it" if fif == 1 else
@@ -548,6 +559,8 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False,
         # the leg's composer goes before the next leg makes its own (the RCCL path: every rank destroys its communicator at the same point of the same sequence)
         composer.finish()
         torch.cuda.synchronize()
+        if multi:
+            dist.barrier()      # every rank has finished its frames: nobody polls, writes or waits on a peer's image / flag block any more when the first rank frees its own
         if hasattr(composer, "close"):
             composer.close()
         if multi:

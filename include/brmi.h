@@ -43,7 +43,7 @@ typedef void* brmi_stream;     /* hipStream_t; NULL = the default stream */
 typedef struct brmi_config {
     uint32_t structSize;               /* sizeof(brmi_config), for forward compatibility */
     uint32_t width, height;            /* visibility / G-buffer / HDR target size */
-    uint32_t maxVisibleClusters;       /* CLodExtension maxClusters (Renderer.cpp:2494: 30,000,000) */
+    uint32_t maxVisibleClusters;       /* CLodExtension maxClusters (Renderer.cpp:2494: 30,000,000); at most 2^25 - 1 */
     uint32_t maxTraversalRecords;      /* frontier + bucket capacity (reference shares maxClusters) */
     uint32_t enableOcclusionCulling;   /* 2-phase HZB culling (Renderer.h:157 default true) */
     uint32_t enableClusteredLighting;  /* PSO_CLUSTERED_LIGHTING (default true) */
@@ -247,6 +247,10 @@ int brmi_set_timed_stages(brmi_pass* pass, uint32_t stageMask);
 /* algorithmic bytes of the last frame per SURVEY.md 8(d): 140*P + sum(144+12V+3T) + 64*M + 16*Mvis + 64*N.  A read-back call: waits for
  * the device (whatever stream the frame ran on) before it reads the frame's counters. */
 int brmi_algorithmic_bytes(brmi_pass* pass, uint64_t* perStage /* [BRMI_STAGE_COUNT] */, uint64_t* total);
+/* The same count for the kernel variants the frame actually LAUNCHED: where a scene lets a stage move less than SURVEY.md 8(d)'s figure, this says how much it is
+ * obliged to move -- today one case: no material of the scene has a coat or a fuzz layer, so the shading pass does not read those two G-buffer planes (44 instead of
+ * 60 B per pixel).  brmi_algorithmic_bytes stays 8(d)'s definition; a roofline fraction against THIS count is the honest one for the launched kernel. */
+int brmi_algorithmic_bytes_launched(brmi_pass* pass, uint64_t* perStage /* [BRMI_STAGE_COUNT] */, uint64_t* total);
 
 /* ---- diagnostics ---------------------------------------------------------------------------- */
 /* Evaluates the library's fp32 primitives on device data so a test can check the arithmetic contract

@@ -18,6 +18,14 @@ CASES = ["tiny", "tiny_lod", "tiny_coat_fuzz", "sponza_coat_fuzz", "sponza_small
          "tiny_textured", "sponza_textured", "tiny_alpha", "sponza_alpha", "bistro_alpha_skinned", "sponza_clod_alpha", "tiny_vcolor", "sponza_vcolor_textured", "sponza_layer_textures", "tiny_layer_textures_only", "tiny_parallax", "sponza_parallax_all"]
 
 
+def _report_hdr_difference(what, a, b):
+    """Full-size frames: the share of covered HDR channels that differ from the oracle's by their one allowed fp16 ULP (north_star: <= 1 ULP per channel).  Printed
+    (pytest -s / the captured output of a failure) and bounded: round 5 measured 0.009 - 0.025 % on every full-size frame, so one channel in a thousand is a regression."""
+    frac = float((a != b).mean()) if a.size else 0.0
+    print(f"[hdr] {what}: {100.0 * frac:.4f} % of {a.size} covered channels differ by 1 fp16 ULP")
+    assert frac < 1.0e-3, f"{what}: {100.0 * frac:.3f} % of the covered channels differ from the oracle (all by <= 1 ULP, but round 5 measured <= 0.025 %)"
+
+
 @pytest.fixture(scope="module")
 def gpu_frames(scenes):
     from basicrenderer_amd.renderer import VisibilityRenderer
@@ -602,6 +610,7 @@ def test_full_size_frames_against_the_oracle(preset, W, H, lights, kw):
             assert np.array_equal(g[k][covered], ref[covered]), (k, inline)
         a, b = r.hdr().view(np.uint16).astype(np.int32), o.hdr.view(np.uint16).astype(np.int32)
         assert np.abs(a - b).max() <= 1, inline
+        _report_hdr_difference(f"full size {preset} {W}x{H} resolve_inline={inline}", a.reshape(H, W, 4)[covered], b.reshape(H, W, 4)[covered])
         r.close()
 
 
@@ -649,6 +658,7 @@ def test_full_size_camera_path_with_occlusion_against_the_oracle(preset, lights,
             assert np.array_equal(g[k][covered], ref[covered]), f"frame {step}: {k}"
         a, b = r.hdr().view(np.uint16).astype(np.int32).reshape(2160, 3840, 4)[covered], o.hdr.view(np.uint16).astype(np.int32).reshape(2160, 3840, 4)[covered]
         assert np.abs(a - b).max() <= 1, f"frame {step}"
+        _report_hdr_difference(f"camera path {preset} in_flight={in_flight} frame {step}", a, b)
         if step > 0 and preset != "sponza":
             assert o.count2 > 0, "the path does not exercise phase 2"
     for r in passes:
