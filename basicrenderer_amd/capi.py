@@ -104,7 +104,7 @@ class Config(C.Structure):
                 ("maxTraversalRecords", u32), ("enableOcclusionCulling", u32), ("enableClusteredLighting", u32),
                 ("enablePunctualLights", u32), ("lightClusterSize", u32 * 3), ("phase2ExpansionFactor", u32),
                 ("collectPassStatistics", u32), ("maxBvhLevels", u32), ("bandY0", u32), ("bandY1", u32),
-                ("keepUniformLayerPlanes", u32), ("stripeRows", u32), ("stripeCount", u32), ("stripeIndex", u32), ("fullHeight", u32), ("reserved", u32 * 3)]
+                ("keepUniformLayerPlanes", u32), ("stripeRows", u32), ("stripeCount", u32), ("stripeIndex", u32), ("fullHeight", u32), ("dynamicBand", u32), ("reserved", u32 * 2)]
 
 
 class ResourceDesc(C.Structure):
@@ -129,12 +129,12 @@ class Counters(C.Structure):
 class ComposeConfig(C.Structure):
     """brmi_compose_config (include/brmi_compose.h)."""
     _fields_ = [("structSize", u32), ("width", u32), ("bandY0", u32), ("bandY1", u32), ("bytesPerPixel", u32), ("transport", u32), ("depth", u32),
-                ("rank", u32), ("nRanks", u32), ("device", C.c_int32), ("path", u32), ("waitTimeoutMs", u32), ("reserved", u32 * 4)]
+                ("rank", u32), ("nRanks", u32), ("device", C.c_int32), ("path", u32), ("waitTimeoutMs", u32), ("frameHeight", u32), ("reserved", u32 * 3)]
 
 
 COMPOSE_EXPORTS = ["brmi_compose_unique_id", "brmi_compose_create", "brmi_compose_staging_bytes", "brmi_compose_output_bytes", "brmi_compose_bind",
                    "brmi_compose_submit", "brmi_compose_finish", "brmi_compose_destroy", "brmi_compose_last_error",
-                   "brmi_compose_alloc_shared", "brmi_compose_export", "brmi_compose_import", "brmi_compose_last_wait_status", "brmi_compose_submit_rows", "brmi_compose_wait_source"]
+                   "brmi_compose_alloc_shared", "brmi_compose_export", "brmi_compose_import", "brmi_compose_last_wait_status", "brmi_compose_submit_rows", "brmi_compose_wait_source", "brmi_compose_set_bounds", "brmi_compose_balance_rows"]
 COMPOSE_HANDLE_BYTES = 160
 _compose_lib = None
 
@@ -219,7 +219,7 @@ def scene_lib():
     return _scene_lib
 
 
-BRMI_EXPORTS = ["brmi_abi_version", "brmi_default_config", "brmi_create", "brmi_declare", "brmi_set_scene", "brmi_setup",
+BRMI_EXPORTS = ["brmi_abi_version", "brmi_default_config", "brmi_create", "brmi_declare", "brmi_set_scene", "brmi_setup", "brmi_set_band",
                 "brmi_update", "brmi_execute", "brmi_execute_split", "brmi_destroy", "brmi_last_error", "brmi_clear_visibility", "brmi_cull",
                 "brmi_raster", "brmi_depth_copy", "brmi_build_hzb", "brmi_invalidate_hzb", "brmi_set_history_source", "brmi_gbuffer", "brmi_light_clustering",
                 "brmi_shade", "brmi_set_shade_slabs", "brmi_read_counters", "brmi_stage_times", "brmi_set_timed_stages", "brmi_algorithmic_bytes", "brmi_algorithmic_bytes_launched", "brmi_debug_arith", "brmi_debug_arith_in_range", "brmi_debug_read_bin_records"]

@@ -56,6 +56,40 @@ def band_of(rank, n_gpus, height):
     return (rank * rows, (rank + 1) * rows)
 
 
+def equal_bounds(n_gpus, height, align=16):
+    """Row bounds [0, b1, ..., height] of n contiguous bands of (nearly) equal height, multiples of `align`: where a balanced partition starts."""
+    b = [min(height, int(round(height * k / n_gpus / align)) * align) for k in range(n_gpus + 1)]
+    b[0], b[-1] = 0, height
+    return b
+
+
+class RowBalancer:
+    """Cost-balanced contiguous regions (brmi_compose_balance_rows, libbrmi_compose.so): keeps the running per-row cost estimate and the current bounds; `update(rank_ms)`
+    folds one measurement in and returns the new bounds.  Deterministic host arithmetic: every rank holds one and feeds it the same numbers."""
+
+    def __init__(self, n_ranks, height, align=16, damping=1.0, min_rows=32, bounds=None):
+        import numpy as np
+        if height % align:
+            raise ValueError(f"{height} rows are not a multiple of {align}")
+        self.n, self.height, self.align, self.damping, self.min_rows = n_ranks, height, align, damping, min_rows
+        self.bounds = list(bounds) if bounds is not None else equal_bounds(n_ranks, height, align)
+        self.row_cost = np.zeros(height // align, dtype=np.float32)
+
+    def update(self, rank_ms):
+        import ctypes as C
+        from . import capi
+        n = self.n
+        ms = (C.c_float * n)(*[float(x) for x in rank_ms])
+        bin_ = (C.c_uint32 * (n + 1))(*[int(x) for x in self.bounds])
+        out = (C.c_uint32 * (n + 1))()
+        rc = capi.compose_lib().brmi_compose_balance_rows(ms, bin_, n, int(self.height), int(self.align), C.c_float(self.damping), int(self.min_rows),
+                                                           self.row_cost.ctypes.data_as(C.POINTER(C.c_float)), out)
+        if rc != 0:
+            raise ValueError(f"brmi_compose_balance_rows failed ({rc}): times {list(rank_ms)}, bounds {self.bounds}, height {self.height}")
+        self.bounds = [int(x) for x in out]
+        return self.bounds
+
+
 def band_byte_range(band, width, bytes_per_pixel):
     """Byte range of a row band inside a tiled (8x8) surface."""
     tiles_x = (width + TILE - 1) // TILE
@@ -143,12 +177,38 @@ class BandComposer:
         return self.out[(self.frames - 1) % self.depth] if self.frames else None
 
 
+def compose_unequal_bands(surface_u8, bounds, width, bytes_per_pixel, out=None, group=None):
+    """Bands of unequal height (cost-balanced regions: `bounds` = [0, b1, ..., height], rank r owns rows [bounds[r], bounds[r + 1])) composed into THE FRAME: one
+    broadcast per rank with that rank's byte count, straight to the band's place -- what libbrmi_compose.so issues as one RCCL group (brmi_compose_set_bounds), here over
+    torch.distributed (gloo on CPU in the tests).  Returns the composed tiled surface (every rank holds all of it)."""
+    import torch
+    import torch.distributed as dist
+    n, rank = dist.get_world_size(group), dist.get_rank(group)
+    if len(bounds) != n + 1:
+        raise ValueError(f"{len(bounds)} bounds for {n} ranks")
+    total = band_byte_range((0, bounds[-1]), width, bytes_per_pixel)[1]
+    if out is None:
+        out = torch.empty(total, dtype=torch.uint8, device=surface_u8.device)
+    work = []
+    for r in range(n):
+        lo, hi = band_byte_range((bounds[r], bounds[r + 1]), width, bytes_per_pixel)
+        if hi == lo:
+            continue
+        if r == rank:
+            out[lo:hi].copy_(surface_u8[lo:hi])
+        work.append(dist.broadcast(out[lo:hi], src=dist.get_global_rank(group, r) if group is not None else r, group=group, async_op=True))
+    for w in work:
+        w.wait()
+    return out
+
+
 class NativeBandComposer:
     """BandComposer's pipeline behind the C ABI of libbrmi_compose.so (include/brmi_compose.h): the staging copy, the RCCL all-gather on
     the composer's own stream and the event ordering all live in C++; this class only owns the buffers (the library allocates nothing)
     and hands the ncclUniqueId from rank 0 to the others over torch.distributed.  `out[i]` / finish() as BandComposer."""
 
-    def __init__(self, surface_u8, band, width, bytes_per_pixel, depth=2, group=None, transport="surface", rank=None, world=None):
+    def __init__(self, surface_u8, band, width, bytes_per_pixel, depth=2, group=None, transport="surface", rank=None, world=None, frame_height=0):
+        """frame_height > 0: bands of unequal, moving height (set_bounds before a frame's submit); the composed image is then the whole frame in transport form."""
         import ctypes as C
         import torch
         import torch.distributed as dist
@@ -172,6 +232,7 @@ class NativeBandComposer:
         cfg.width, cfg.bandY0, cfg.bandY1, cfg.bytesPerPixel = width, band[0], band[1], bytes_per_pixel
         cfg.transport = {"surface": 0, "rgb16f": 1}[transport]
         cfg.depth, cfg.rank, cfg.nRanks, cfg.device = depth, rank, world, dev.index or 0
+        cfg.frameHeight = frame_height
         self._h = capi.vp()
         rc = self.lib.brmi_compose_create(C.byref(cfg), ident, C.byref(self._h))
         if rc != 0:
@@ -192,6 +253,11 @@ class NativeBandComposer:
 
     def _stream(self):
         return self.C.c_void_p(self.torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def set_bounds(self, bounds):
+        """The partition of the frames submitted from now on (brmi_compose_set_bounds; composers made with frame_height)."""
+        arr = (self.C.c_uint32 * len(bounds))(*[int(b) for b in bounds])
+        self._check(self.lib.brmi_compose_set_bounds(self._h, arr), "brmi_compose_set_bounds")
 
     def submit(self, surface_u8=None):
         slot = self._check(self.lib.brmi_compose_submit(self._h, (self.surface if surface_u8 is None else surface_u8).data_ptr(), self._stream()), "brmi_compose_submit")
@@ -230,7 +296,7 @@ class PeerBandComposer:
     default uses torch.distributed.all_gather_object; a test with two processes and no process group passes its own).
     `out[i]` / finish() as BandComposer; finish() makes the current stream wait for the peers' bands of the newest frame."""
 
-    def __init__(self, surface_u8, band, width, bytes_per_pixel, depth=2, group=None, transport="surface", rank=None, world=None, exchange=None, timeout_ms=2000):
+    def __init__(self, surface_u8, band, width, bytes_per_pixel, depth=2, group=None, transport="surface", rank=None, world=None, exchange=None, timeout_ms=2000, frame_height=0):
         import ctypes as C
         import torch
         from . import capi
@@ -245,6 +311,7 @@ class PeerBandComposer:
         cfg.transport = {"surface": 0, "rgb16f": 1}[transport]
         cfg.depth, cfg.rank, cfg.nRanks, cfg.device = depth, rank, world, dev.index or 0
         cfg.path, cfg.waitTimeoutMs = 1, timeout_ms
+        cfg.frameHeight = frame_height
         self._h = capi.vp()
         rc = self.lib.brmi_compose_create(C.byref(cfg), bytes(128), C.byref(self._h))
         if rc != 0:
@@ -263,7 +330,7 @@ class PeerBandComposer:
         self._check(self.lib.brmi_compose_import(self._h, b"".join(handles), world), "brmi_compose_import")
         ob = self.lib.brmi_compose_output_bytes(self._h)
         self.surface, self.depth, self.frames, self.dev, self._ob, self.transport = surface_u8, depth, 0, dev, ob, transport
-        self._band = tuple(band)
+        self._band, self._rank = tuple(band), rank
         self.out = [None] * depth
 
     def _check(self, rc, what):
@@ -278,6 +345,12 @@ class PeerBandComposer:
         slot = self._check(self.lib.brmi_compose_submit(self._h, (self.surface if surface_u8 is None else surface_u8).data_ptr(), self._stream()), "brmi_compose_submit")
         self.frames += 1
         return slot
+
+    def set_bounds(self, bounds):
+        """The partition of the frames submitted from now on (brmi_compose_set_bounds; composers made with frame_height): this rank's band moves with it."""
+        arr = (self.C.c_uint32 * len(bounds))(*[int(b) for b in bounds])
+        self._check(self.lib.brmi_compose_set_bounds(self._h, arr), "brmi_compose_set_bounds")
+        self._band = (int(bounds[self._rank]), int(bounds[self._rank + 1]))      # (submit_rows counts a frame when a slab ends at the band's last row)
 
     def submit_rows(self, row0, row1, surface_u8=None, stream_ptr=None):
         """One slab of the frame: rows [row0, row1) of the band, whose shading is already enqueued on the current stream; the stores travel on the

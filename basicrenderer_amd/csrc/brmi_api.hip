@@ -147,7 +147,8 @@ static void compute_sizes(brmi_pass* p) {
     w.frameSnapshot = take(sizeof(FrameSnapshot));
     w.matConst = take((uint64_t)std::max(1u, p->scene.openpbrMaterialCount) * sizeof(MatConst));
     w.objConst = take((uint64_t)std::max(1u, p->scene.perObjectCount) * OBJ_CONST_FLOATS * 4);
-    p->deferredStripeCapacity = (uint32_t)(((p->bandPixelCount / 4096 + CNT_STRIPE_COUNT) / CNT_STRIPE_COUNT) * 4096);   // 64-tile runs of a stripe x 4096 pixels
+    // (a band that may change from frame to frame: sized for the whole frame)
+    p->deferredStripeCapacity = (uint32_t)((((c.dynamicBand ? p->paddedPixels : p->bandPixelCount) / 4096 + CNT_STRIPE_COUNT) / CNT_STRIPE_COUNT) * 4096);   // 64-tile runs of a stripe x 4096 pixels
     w.deferredPixels = take((uint64_t)3 * CNT_STRIPE_COUNT * p->deferredStripeCapacity * 4);      // one set of striped lists per layered class
     w.lutF = take((uint64_t)(32768 + 1024 + 1024 + 32 + 256) * 4);
     w.shadeRows = take((uint64_t)std::max(1u, p->scene.openpbrMaterialCount) * 256 * 512);    // (OpenPBR material, roughness code) -> folded energy-table rows of the shading pass
@@ -258,7 +259,9 @@ int brmi_create(const brmi_config* cfg, brmi_pass** out) {
     if (cfg->stripeCount > 1u) {      // interleaved partition: whole chunks of 16-row bin bands, the same number on every GPU, no band on top
         if (cfg->stripeRows == 0u || cfg->stripeRows % 16u || cfg->stripeIndex >= cfg->stripeCount || cfg->bandY0 != 0u || (cfg->bandY1 != 0u && cfg->bandY1 != cfg->height)) return BRMI_ERR_INVALID;
         if (cfg->fullHeight == 0u || cfg->fullHeight % (cfg->stripeRows * cfg->stripeCount) || cfg->height != cfg->fullHeight / cfg->stripeCount) return BRMI_ERR_INVALID;
-    }      // the slice-start table (workspace and the shading pass's LDS copy) holds 64 entries: gz + 2
+        if (cfg->dynamicBand) return BRMI_ERR_INVALID;
+    }
+    if (cfg->dynamicBand && (cfg->bandY0 % 8u || (cfg->bandY1 % 8u && cfg->bandY1 < cfg->height))) return BRMI_ERR_INVALID;      // the slice-start table (workspace and the shading pass's LDS copy) holds 64 entries: gz + 2
     brmi_pass* p = new brmi_pass();
     p->cfg = *cfg;
     p->totalWords = 1; p->scanBlocks = 1;
@@ -546,8 +549,9 @@ int brmi_set_scene(brmi_pass* p, const brmi_scene_buffers* scene) {
             p->hostPageRefs.push_back(PageRef{slab, pmap[i].slabByteOffset, base, meshlets});
             p->totalBoxes += meshlets;
         }
-        // (the contiguous band and the interleaved partition keep the whole list: their surfaces hold this GPU's rows only -- the re-test would have to map rows)
-        p->holdEnabled = boxesOn && p->totalBoxes != 0u && p->stripes.count <= 1u && p->bandY0 == 0u && p->bandY1 == p->cfg.height;
+        // (the interleaved partition keeps the whole list: its compact surfaces hold this GPU's chunks only -- the re-test would have to map rows.  A contiguous band
+        // lives in frame rows: the tests clamp their rectangles to it, and the chain's texels beyond it read "empty")
+        p->holdEnabled = boxesOn && p->totalBoxes != 0u && p->stripes.count <= 1u;
         p->holdMinClusters = (uint32_t)std::max(0l, tuning("hold_min_clusters", p->holdMinClusters));
         p->holdMaxTexels = (uint32_t)std::min(16l, std::max(1l, tuning("hold_max_texels", p->holdMaxTexels)));
         p->retestMaxTexels = (uint32_t)std::min(16l, std::max(1l, tuning("retest_max_texels", p->retestMaxTexels)));
@@ -559,6 +563,18 @@ int brmi_set_scene(brmi_pass* p, const brmi_scene_buffers* scene) {
     compute_sizes(p);
     p->haveScene = true;
     p->updateSerial++;
+    return BRMI_OK;
+}
+
+int brmi_set_band(brmi_pass* p, uint32_t bandY0, uint32_t bandY1) {
+    if (!p) return BRMI_ERR_INVALID;
+    if (!p->cfg.dynamicBand) return fail(p, BRMI_ERR_STATE, "brmi_set_band: the pass was created without brmi_config::dynamicBand");
+    if (bandY1 > p->cfg.height) bandY1 = p->cfg.height;
+    if (bandY0 % 8u || (bandY1 % 8u && bandY1 != p->cfg.height) || bandY0 >= bandY1) return fail(p, BRMI_ERR_INVALID, "brmi_set_band: rows [%u, %u) -- multiples of 8 inside the frame's %u rows", bandY0, bandY1, p->cfg.height);
+    p->bandY0 = bandY0; p->bandY1 = bandY1;
+    const uint32_t t0 = bandY0 / 8u, t1 = (bandY1 + 7u) / 8u;
+    p->bandFirstPixel = (uint64_t)t0 * p->tilesX * 64; p->bandPixelCount = (uint64_t)(t1 - t0) * p->tilesX * 64;
+    p->updated = false;      // the band planes of the culling are made by brmi_update
     return BRMI_OK;
 }
 
@@ -754,7 +770,7 @@ int brmi_set_history_source(brmi_pass* p, brmi_pass* source) {
     if (source) {
         if (!p->setupDone || !source->setupDone) return brmi::fail(p, BRMI_ERR_STATE, "brmi_set_history_source: both passes need brmi_setup first");
         if (!p->cfg.enableOcclusionCulling || !source->cfg.enableOcclusionCulling) return brmi::fail(p, BRMI_ERR_STATE, "brmi_set_history_source: both passes need enableOcclusionCulling (there is no history otherwise)");
-        if (p->cfg.width != source->cfg.width || p->cfg.height != source->cfg.height || p->bandY0 != source->bandY0 || p->bandY1 != source->bandY1)
+        if (p->cfg.width != source->cfg.width || p->cfg.height != source->cfg.height || ((p->bandY0 != source->bandY0 || p->bandY1 != source->bandY1) && !(p->cfg.dynamicBand && source->cfg.dynamicBand)))
             return brmi::fail(p, BRMI_ERR_INVALID, "brmi_set_history_source: the passes differ in size or band (%ux%u rows %u-%u against %ux%u rows %u-%u)", p->cfg.width, p->cfg.height, p->bandY0, p->bandY1,
                               source->cfg.width, source->cfg.height, source->bandY0, source->bandY1);
     }

@@ -178,9 +178,12 @@ BRMI_DEV bool stripe_rejects(const StripeMap& m, const brmi_camera* cam, f3 cent
 // screen rows (two rows of slack) hold none of this GPU's rows is not descended.  The cluster cull drops exactly such meshlets anyway
 // (stripe_rejects on the meshlet's own sphere, inside the node's); before this every rank walked every node and tested every meshlet of the
 // N-times-taller frame, which is where the render-side 0.78 of profiles/r03_rank_balance.md came from.  Dropped, not replayed.
-BRMI_DEV bool sphere_culled(const StripeMap& stripes, const brmi_camera* cam, f3 c, float r) {
+// Round 6: the same for the contiguous band (brmi_config::bandY0 / bandY1, brmi_set_band) -- its two view-space planes through the eye, which the cluster cull already tested
+// per meshlet: every rank of the 8-GPU San-Miguel-class frame visited all 37,600 nodes and tested 40 k meshlets for bands that show 24 .. 27 k clusters.
+BRMI_DEV bool sphere_culled(const CullArgs& a, const brmi_camera* cam, f3 c, float r) {
     if (sphere_outside_frustum(c, r, cam->clippingPlanes)) return true;
-    return stripe_on(stripes) && stripe_rejects(stripes, cam, c, r);
+    if (a.bandActive && (dot3(f3{a.bandTop[0], a.bandTop[1], a.bandTop[2]}, c) < -r || dot3(f3{a.bandBottom[0], a.bandBottom[1], a.bandBottom[2]}, c) < -r)) return true;
+    return stripe_on(a.stripes) && stripe_rejects(a.stripes, cam, c, r);
 }
 
 // K1 -------------------------------------------------------------------------------------------
@@ -199,7 +202,7 @@ __global__ void __launch_bounds__(256) k_cull_instances(CullArgs a, NodeRecord* 
             const f3 c = to_view_space(f3{inst.boundingSphere[0], inst.boundingSphere[1], inst.boundingSphere[2]}, model, view);
             const float r = inst.boundingSphere[3] * max_axis_scale(model);
             const bool bad = isnan(c.x) || isnan(c.y) || isnan(c.z) || isinf(c.x) || isinf(c.y) || isinf(c.z) || isnan(r) || isinf(r);
-            visible = !bad && !sphere_culled(a.stripes, cam, c, r);
+            visible = !bad && !sphere_culled(a, cam, c, r);
             root = sc.meshMetadata[sc.clodOffsets[ii].clodMeshMetadataIndex].rootNode;
             atomicAdd(&a.counters[CNT_INSTANCES_TESTED], 1u);
             if (visible) atomicAdd(&a.counters[CNT_INSTANCES_VISIBLE], 1u);
@@ -256,7 +259,7 @@ __global__ void __launch_bounds__(256) k_traverse(CullArgs a, uint32_t level, co
             const float cullR = skinned ? instR : node.cullCenterAndRadius[3];
             const f3 cVS = to_view_space(cullC, model, view);
             const float rW = cullR * scale;
-            const bool culled = !replay && sphere_culled(a.stripes, cam, cVS, rW);
+            const bool culled = !replay && sphere_culled(a, cam, cVS, rW);
             if (!culled) {
                 if (node.isLeaf != BRMI_NODE_INTERNAL) {
                     const brmi_lod_group* g = sc.lodGroups + (md.groupsBase + node.ownerGroupId);
@@ -340,7 +343,7 @@ __global__ void __launch_bounds__(256) k_traverse(CullArgs a, uint32_t level, co
                     const f3 cc = skinned ? instC : f3{ch->cullCenterAndRadius[0], ch->cullCenterAndRadius[1], ch->cullCenterAndRadius[2]};
                     const float cr = skinned ? instR : ch->cullCenterAndRadius[3];
                     const f3 ccVS = to_view_space(cc, model, view);
-                    emit = replay || !sphere_culled(a.stripes, cam, ccVS, cr * scale);
+                    emit = replay || !sphere_culled(a, cam, ccVS, cr * scale);
                     if (emit && ch->isLeaf == BRMI_NODE_INTERNAL) {
                         const f3 wc = xyz(mul_point(f3{ch->lodCenterAndRadius[0], ch->lodCenterAndRadius[1], ch->lodCenterAndRadius[2]}, model));
                         const float e = projected_error(wc, ch->lodCenterAndRadius[3] * scale, ch->maxQuadricError, scale, camPos, zNear, ortho);
@@ -452,7 +455,7 @@ __global__ void __launch_bounds__(64) k_cull_hierarchy(CullArgs a, BucketRecord*
                 const f3 c = to_view_space(instC, model, view);
                 const float r = instR * scale;
                 const bool bad = isnan(c.x) || isnan(c.y) || isnan(c.z) || isinf(c.x) || isinf(c.y) || isinf(c.z) || isnan(r) || isinf(r);
-                instVisible = small && !bad && !sphere_culled(a.stripes, cam, c, r);
+                instVisible = small && !bad && !sphere_culled(a, cam, c, r);
             }
             nTested += (uint32_t)__popcll(__ballot(small && j == 0u)); nVisible += (uint32_t)__popcll(__ballot(instVisible && j == 0u));
             const bool skinned = iw.skinned != 0u;
@@ -461,7 +464,7 @@ __global__ void __launch_bounds__(64) k_cull_hierarchy(CullArgs a, BucketRecord*
             const float cullR = skinned ? instR : fn.cull[3];
             const f3 cVS = to_view_space(cullC, model, view);
             const float rW = cullR * scale;
-            const bool inFrustum = mine && instVisible && !sphere_culled(a.stripes, cam, cVS, rW);
+            const bool inFrustum = mine && instVisible && !sphere_culled(a, cam, cVS, rW);
             bool pre = inFrustum, expand = false, hidden = false, leafOk = false;
             uint32_t slabDesc = 0, slabOff = 0;
             if (inFrustum && internal) {
@@ -565,7 +568,7 @@ __global__ void __launch_bounds__(64) k_cull_hierarchy(CullArgs a, BucketRecord*
                     const float r = instR * scale;
                     const bool bad = isnan(c.x) || isnan(c.y) || isnan(c.z) || isinf(c.x) || isinf(c.y) || isinf(c.z) || isnan(r) || isinf(r);
                     nTested++;
-                    if (bad || sphere_culled(a.stripes, cam, c, r)) continue;
+                    if (bad || sphere_culled(a, cam, c, r)) continue;
                     nVisible++;
                 }
                 HSTAMP(1);
@@ -583,7 +586,7 @@ __global__ void __launch_bounds__(64) k_cull_hierarchy(CullArgs a, BucketRecord*
                     const float cullR = skinned ? instR : fn.cull[3];
                     const f3 cVS = to_view_space(cullC, model, view);
                     const float rW = cullR * scale;
-                    const bool inFrustum = mine && !sphere_culled(a.stripes, cam, cVS, rW);
+                    const bool inFrustum = mine && !sphere_culled(a, cam, cVS, rW);
                     // internal node: children pass when its projected error is above the threshold and the depth chain does not hide it;
                     // as a child it was let through on the same two conditions (frustum, error)
                     bool pre = inFrustum, expand = false, hidden = false, leafOk = false;
@@ -696,7 +699,7 @@ __global__ void __launch_bounds__(64) k_cull_hierarchy(CullArgs a, BucketRecord*
             const f3 c = to_view_space(instC, model, view);
             const float r = instR * scale;
             const bool bad = isnan(c.x) || isnan(c.y) || isnan(c.z) || isinf(c.x) || isinf(c.y) || isinf(c.z) || isnan(r) || isinf(r);
-            const bool visible = !bad && !sphere_culled(a.stripes, cam, c, r);
+            const bool visible = !bad && !sphere_culled(a, cam, c, r);
             nTested++;
             if (!visible) continue;
             nVisible++;
@@ -733,7 +736,7 @@ __global__ void __launch_bounds__(64) k_cull_hierarchy(CullArgs a, BucketRecord*
                     const float cullR = skinned ? instR : node.cullCenterAndRadius[3];
                     const f3 cVS = to_view_space(cullC, model, view);
                     const float rW = cullR * scale;
-                    const bool culled = !REPLAY && sphere_culled(a.stripes, cam, cVS, rW);
+                    const bool culled = !REPLAY && sphere_culled(a, cam, cVS, rW);
                     if (!culled) {
                         if (node.isLeaf != BRMI_NODE_INTERNAL) {
                             const brmi_lod_group* g = sc.lodGroups + (md.groupsBase + node.ownerGroupId);
@@ -837,7 +840,7 @@ __global__ void __launch_bounds__(64) k_cull_hierarchy(CullArgs a, BucketRecord*
                                 const f3 cc = skinned ? instC : f3{ch->cullCenterAndRadius[0], ch->cullCenterAndRadius[1], ch->cullCenterAndRadius[2]};
                                 const float cr = skinned ? instR : ch->cullCenterAndRadius[3];
                                 const f3 ccVS = to_view_space(cc, model, view);
-                                emit = REPLAY || !sphere_culled(a.stripes, cam, ccVS, cr * scale);
+                                emit = REPLAY || !sphere_culled(a, cam, ccVS, cr * scale);
                                 if (emit && ch->isLeaf == BRMI_NODE_INTERNAL) {
                                     const f3 wc = xyz(mul_point(f3{ch->lodCenterAndRadius[0], ch->lodCenterAndRadius[1], ch->lodCenterAndRadius[2]}, model));
                                     const float e = projected_error(wc, ch->lodCenterAndRadius[3] * scale, ch->maxQuadricError, scale, camPos, zNear, ortho);
@@ -906,7 +909,7 @@ __global__ void __launch_bounds__(1024) k_cull_flat_wide(CullArgs a, BucketRecor
             const float r = instR * scale;
             const bool bad = isnan(c.x) || isnan(c.y) || isnan(c.z) || isinf(c.x) || isinf(c.y) || isinf(c.z) || isnan(r) || isinf(r);
             if (t == 0) nTested++;
-            if (bad || sphere_culled(a.stripes, cam, c, r)) continue;
+            if (bad || sphere_culled(a, cam, c, r)) continue;
             if (t == 0) nVisible++;
         }
         const bool skinned = iw.skinned != 0u;
@@ -918,7 +921,7 @@ __global__ void __launch_bounds__(1024) k_cull_flat_wide(CullArgs a, BucketRecor
             const float cullR = skinned ? instR : fn.cull[3];
             const f3 cVS = to_view_space(cullC, model, view);
             const float rW = cullR * scale;
-            const bool inFrustum = !sphere_culled(a.stripes, cam, cVS, rW);
+            const bool inFrustum = !sphere_culled(a, cam, cVS, rW);
             bool pre = inFrustum, expand = false, hidden = false, leafOk = false;
             uint32_t records = 0;
             if (inFrustum && internal) {
@@ -1060,7 +1063,7 @@ __global__ void __launch_bounds__(256) k_cull_flat_level(CullArgs a, uint32_t le
                 const float r = instR * scale;
                 const bool bad = isnan(c.x) || isnan(c.y) || isnan(c.z) || isinf(c.x) || isinf(c.y) || isinf(c.z) || isnan(r) || isinf(r);
                 nTested++;
-                if (bad || sphere_culled(a.stripes, cam, c, r)) have = false; else nVisible++;
+                if (bad || sphere_culled(a, cam, c, r)) have = false; else nVisible++;
             }
             if (have) {
                 nNodes++;
@@ -1071,7 +1074,7 @@ __global__ void __launch_bounds__(256) k_cull_flat_level(CullArgs a, uint32_t le
                 const float cullR = skinned ? instR : fn.cull[3];
                 const f3 cVS = to_view_space(cullC, model, view);
                 const float rW = cullR * scale;
-                const bool inFrustum = !sphere_culled(a.stripes, cam, cVS, rW);
+                const bool inFrustum = !sphere_culled(a, cam, cVS, rW);
                 if (inFrustum && internal) {
                     const f3 lc = xyz(mul_point(f3{fn.lod[0], fn.lod[1], fn.lod[2]}, model));
                     const float e = projected_error(lc, fn.lod[3] * scale, fn.maxQuadricError, scale, camPos, zNear, ortho);
@@ -1087,7 +1090,7 @@ __global__ void __launch_bounds__(256) k_cull_flat_level(CullArgs a, uint32_t le
                                 const float4 cs = *reinterpret_cast<const float4*>(ch->cull), ls = *reinterpret_cast<const float4*>(ch->lod);
                                 const float chErr = ch->maxQuadricError; const uint32_t chInfo = ch->info;
                                 const f3 ccVS = to_view_space(skinned ? instC : f3{cs.x, cs.y, cs.z}, model, view);
-                                bool pre = !sphere_culled(a.stripes, cam, ccVS, (skinned ? instR : cs.w) * scale);
+                                bool pre = !sphere_culled(a, cam, ccVS, (skinned ? instR : cs.w) * scale);
                                 if (pre && (chInfo & 1u)) {
                                     const f3 wc = xyz(mul_point(f3{ls.x, ls.y, ls.z}, model));
                                     pre = projected_error(wc, ls.w * scale, chErr, scale, camPos, zNear, ortho) >= threshold;
@@ -1791,7 +1794,7 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
                            static_cast<uint4*>(p->res[BRMI_RES_VISIBLE_CLUSTERS]), phase == 1 ? 0xFFFFFFFFu : (uint32_t)CNT_VISIBLE, p->cfg.maxVisibleClusters, p->cfg.maxVisibleClusters, p->scene, p->wsPtr<ClusterSetup>(p->ws.clusterSetup), arenaCapacity,
                            (p->sceneHasTextures || p->sceneHasAlphaTest || p->sceneHasVertexColors) ? p->wsPtr<ClusterUv>(p->ws.clusterUv) : nullptr, LocalRank{p->totalWords, outIndex, usedIndex, feedback},
                            (phase == 1 && p->holdThisFrame) ? DrawLists{p->wsPtr<uint32_t>(p->ws.drawList), p->wsPtr<HeldRecord>(p->ws.heldRecords), 0u, p->wsPtr<MeshletBox>(p->ws.meshletBoxes), p->wsPtr<uint32_t>(p->ws.pageBoxBase),
-                                                                      p->wsPtr<float>(p->ws.objConst), p->holdMaxTexels, BoxViewport{(float)p->cfg.width, (float)p->cfg.height, 0.0f, 0.0f, 0, 0, (int)p->cfg.width - 1, (int)p->cfg.height - 1}, a.hzb}
+                                                                      p->wsPtr<float>(p->ws.objConst), p->holdMaxTexels, BoxViewport{(float)p->cfg.width, (float)p->cfg.height, 0.0f, 0.0f, 0, (int)p->bandY0, (int)p->cfg.width - 1, (int)p->bandY1 - 1}, a.hzb}
                                                           : DrawLists{nullptr, nullptr, p->holdThisFrame ? 1u : 0u, nullptr, nullptr, nullptr, 0u, BoxViewport{}, HzbDesc{}});
     };
     const bool holdLists = phase == 1 && p->holdThisFrame;

@@ -135,7 +135,14 @@ int launch_hzb(brmi_pass* p, hipStream_t s, bool fromVisibility, bool onlyIfPhas
     uint32_t first = 1;
     if (head) {
         // texels of mips 1-5 outside the band's 32-row strips never change: brmi_setup filled the chain with "empty"
-        const uint32_t row0 = h.rowLo / 32u, row1 = std::min((h.rowHi + 31u) / 32u, h.paddedH / 32u);
+        uint32_t row0 = h.rowLo / 32u, row1 = std::min((h.rowHi + 31u) / 32u, h.paddedH / 32u);
+        if (!onlyIfPhase2Drew && !lateOnly) {
+            // a full build; a band that moved since the last one (brmi_set_band): the strips it left are rebuilt too -- rows outside the band read "empty", so their texels
+            // stop occluding -- and from here on the chain holds this band's strips
+            const uint32_t b0 = row0, b1 = row1;
+            if (p->chainStripLo < p->chainStripHi) { row0 = std::min(row0, p->chainStripLo); row1 = std::max(row1, std::min(p->chainStripHi, h.paddedH / 32u)); }
+            p->chainStripLo = b0; p->chainStripHi = b1;
+        }
         const dim3 grid(h.paddedW / 32, std::max(1u, row1 - row0));
         DirtyBlocks mk{nullptr, (p->cfg.width + 31u) / 32u};
         if (fromVisibility && (onlyIfPhase2Drew || lateOnly) && p->chainDirtyTracked) mk.chainDirty = p->wsPtr<uint8_t>(p->ws.chainDirty);

@@ -256,6 +256,7 @@ struct brmi_pass {
     uint32_t holdMaxTexels = 8;      // the prediction reads at most this many texels per axis of the previous chain (BRMI_TUNING hold_max_texels; Zorah-class: 4 / 6 / 8 hold 41.6 / 47.7 / 49.6 %
                                      // of the list, serial frame 2.574 / 2.53 / 2.50 ms against 2.948 without; a prediction finer than the re-test sends the difference to the late pass: 2.75)
     uint32_t retestMaxTexels = 8;    // ... and the re-test of this frame's
+    uint32_t chainStripLo = 0xFFFFFFFFu, chainStripHi = 0u;   // 32-row strips of the chain that hold texels of a band (a band that moves: the next full build also resets the strips it left)
     bool chainBuiltInRaster = false; // this frame's phase-1 rasteriser stage built the chain itself (before its re-test): the build that follows redoes the late pass's blocks only
     bool sceneHasVertexColors = false;                           // some mesh's pages carry vertex colours (perMesh.vertexFlags bit 0)
     uint32_t sceneUvSets = 1;      // UV sets the texture slots of the scene's materials name (brmi_set_scene)

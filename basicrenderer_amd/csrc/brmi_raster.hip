@@ -1174,8 +1174,11 @@ __global__ void __launch_bounds__(BRMI_BIN_THREADS, ALPHA ? BRMI_BIN_ALPHA_WAVES
 // (bin, slice) items are counting-sorted by length, longest first -- the pool of workgroups then ends its launch with short items.
 BRMI_DEV void plan_bins(const RasterArgs& a) {
     __shared__ uint32_t classCount[16], classBase[16], tileRun;
-    const uint32_t nBins = a.binsX * a.binsY;
-    uint32_t* binN = a.binPlan + 16, * binSlot = binN + nBins, * binDone = binSlot + nBins;
+    const uint32_t nBinsAll = a.binsX * a.binsY;
+    uint32_t* binN = a.binPlan + 16, * binSlot = binN + nBinsAll, * binDone = binSlot + nBinsAll;
+    // (round 6: a GPU that renders a row band of the frame only ever fills the bins of the band's bin rows -- the 8-GPU weak frame has 16,320 bins, a rank's band 2,280)
+    const uint32_t firstBin = a.stripes.count > 1u ? 0u : min((a.rowLo >> BIN_ROWS_SHIFT) * a.binsX, nBinsAll);
+    const uint32_t nBins = a.stripes.count > 1u ? nBinsAll : min(((a.rowHi + BIN_ROWS - 1u) >> BIN_ROWS_SHIFT) * a.binsX, nBinsAll);
     // LDS hand-offs between the block's waves: the LDS operations have to be done, not the global stores (which only this thread reads
     // again, if at all) -- __syncthreads() would wait for those too, a memory round trip per barrier on the next launch's critical path
     auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
@@ -1185,9 +1188,9 @@ BRMI_DEV void plan_bins(const RasterArgs& a) {
     auto slices_of = [&](uint32_t n) { return n == 0u ? 0u : n <= a.binMinSlice ? 1u : min((n + a.binSharedSlice - 1u) / a.binSharedSlice, 256u); };
     auto class_of = [&](uint32_t n, uint32_t sc) { const uint32_t len = (n + sc - 1u) / sc; return min(15u, 31u - (uint32_t)__clz(len)); };      // log2 of the slice length, 16 classes (a slice of exactly 65536 records -- BRMI_BIN_CAPACITY = BRMI_BIN_MIN_SLICE = 65536 -- shares the last)
     constexpr uint32_t K = 8;
-    const bool oneChunk = nBins <= K * blockDim.x;      // (every frame up to 8K: a thread keeps its bins' counts in registers between the passes)
+    const bool oneChunk = nBins - firstBin <= K * blockDim.x;      // (every frame up to 8K: a thread keeps its bins' counts in registers between the passes)
     uint32_t n[K];
-    for (uint32_t b0 = 0; b0 < nBins; b0 += K * blockDim.x) {
+    for (uint32_t b0 = firstBin; b0 < nBins; b0 += K * blockDim.x) {
 #pragma unroll
         for (uint32_t k = 0; k < K; k++) { const uint32_t b = b0 + k * blockDim.x + threadIdx.x; n[k] = b < nBins ? min(a.binCounts[(size_t)b * BIN_COUNT_STRIDE], a.binCapacity) : 0u; }      // eight loads in flight
 #pragma unroll
@@ -1209,7 +1212,7 @@ BRMI_DEV void plan_bins(const RasterArgs& a) {
     lds_barrier();
     if (threadIdx.x == 0) { uint32_t run = 0; for (int c = 15; c >= 0; c--) { classBase[c] = run; run += classCount[c]; } a.binPlan[0] = run; a.binPlan[1] = 0u; a.binPlan[2] = tileRun; }
     lds_barrier();
-    for (uint32_t b0 = 0; b0 < nBins; b0 += K * blockDim.x) {
+    for (uint32_t b0 = firstBin; b0 < nBins; b0 += K * blockDim.x) {
 #pragma unroll
         for (uint32_t k = 0; k < K; k++) {
             const uint32_t b = b0 + k * blockDim.x + threadIdx.x;
@@ -1285,7 +1288,7 @@ __global__ void __launch_bounds__(256) k_depth_copy(const unsigned long long* vi
 // A lane per held cluster: the shape of the cluster cull (eight corner transforms and up to maxTexels^2 independent 4 B loads per lane).
 struct RetestArgs {
     const HeldRecord* held; const MeshletBox* boxes; const float* objConst; const brmi_view_raster_info* viewRasterInfo;
-    HzbDesc hzb; uint32_t visW, visH, capacity, maxTexels;
+    HzbDesc hzb; uint32_t visW, visH, capacity, maxTexels, bandY0, bandY1;      // bandY0 .. bandY1: the rows this GPU renders (the rectangle's clamp)
     uint32_t* counters; uint32_t* lateList; uint32_t* heldFeedback;      // (host-mapped word or null: the held count, for the grids of the frames that follow)
 };
 __global__ void __launch_bounds__(256) k_retest_held(RetestArgs a) {
@@ -1294,7 +1297,7 @@ __global__ void __launch_bounds__(256) k_retest_held(RetestArgs a) {
     if (a.heldFeedback && blockIdx.x == 0u && threadIdx.x == 0u) __hip_atomic_store(a.heldFeedback, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const brmi_view_raster_info ri = a.viewRasterInfo[0];      // (single view: ClusterSetup::viewId is the main camera's)
     const BoxViewport vp{(float)(ri.scissorMaxX - ri.scissorMinX), (float)(ri.scissorMaxY - ri.scissorMinY), (float)ri.scissorMinX, (float)ri.scissorMinY,
-                         max((int)ri.scissorMinX, 0), max((int)ri.scissorMinY, 0), min((int)ri.scissorMaxX - 1, (int)a.visW - 1), min((int)ri.scissorMaxY - 1, (int)a.visH - 1)};
+                         max((int)ri.scissorMinX, 0), max(max((int)ri.scissorMinY, 0), (int)a.bandY0), min((int)ri.scissorMaxX - 1, (int)a.visW - 1), min(min((int)ri.scissorMaxY - 1, (int)a.visH - 1), (int)a.bandY1 - 1)};
     unsigned long long lateVT = 0ull;
     const uint32_t rounded = (n + 63u) & ~63u;      // wave-uniform trip count (wave_append inside)
     for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < rounded; g += gridDim.x * blockDim.x) {
@@ -1417,7 +1420,7 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
         const uint32_t lastLate = fb ? fb[5] : 0u, lastHeld = fb ? fb[6] : 0xFFFFFFFFu;
         RetestArgs r;
         r.held = p->wsPtr<HeldRecord>(p->ws.heldRecords); r.boxes = p->wsPtr<MeshletBox>(p->ws.meshletBoxes); r.objConst = a.objConst; r.viewRasterInfo = p->scene.viewRasterInfo;
-        r.hzb = p->hzbDesc(); r.visW = a.visW; r.visH = a.visH; r.capacity = p->cfg.maxVisibleClusters; r.maxTexels = p->retestMaxTexels;
+        r.hzb = p->hzbDesc(); r.visW = a.visW; r.visH = a.visH; r.capacity = p->cfg.maxVisibleClusters; r.maxTexels = p->retestMaxTexels; r.bandY0 = p->bandY0; r.bandY1 = p->bandY1;
         r.counters = p->counters(); r.lateList = p->wsPtr<uint32_t>(p->ws.lateList); r.heldFeedback = p->phase2FeedbackDev ? p->phase2FeedbackDev + 6 : nullptr;
         const uint32_t tgrid = std::max(16u, std::min(4096u, pow2_at_least(std::min(lastHeld, p->cfg.maxVisibleClusters) / 256u + 1u)));
         hipLaunchKernelGGL(k_retest_held, dim3(tgrid), dim3(256), 0, s, r);

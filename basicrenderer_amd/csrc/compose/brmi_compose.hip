@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -38,6 +39,10 @@ struct brmi_composer {
     std::vector<bool> inFlight;
     uint8_t* staging = nullptr; uint8_t* output = nullptr;
     uint64_t bandOffset = 0, bandBytes = 0, stagingBytes = 0, outputBytes = 0, pixels = 0;
+    bool dynamic = false;                       // cfg.frameHeight > 0: bands of any height at their own rows of the composed frame (brmi_compose_set_bounds)
+    std::vector<uint32_t> bounds;               // [nRanks + 1] rows, this frame's partition
+    uint64_t rowBytes = 0, rowBytesOut = 0;     // one 8-row tile row of the surface / of the composed image (transport form)
+    uint64_t bandOut() const { return dynamic ? (uint64_t)(cfg.bandY0 / 8u) * rowBytesOut : (uint64_t)cfg.rank * stagingBytes; }      // where this rank's band starts in a composed image
     uint64_t frames = 0;
     uint32_t openRow = 0;                       // submit_rows: next row expected (0 = no frame open)
     hipEvent_t slabReady = nullptr;             // submit_rows: the slab's shading is enqueued (render stream -> composer stream)
@@ -137,7 +142,8 @@ int brmi_compose_unique_id(uint8_t id[BRMI_COMPOSE_ID_BYTES]) {
 int brmi_compose_create(const brmi_compose_config* cfg, const uint8_t id[BRMI_COMPOSE_ID_BYTES], brmi_composer** out) {
     if (!cfg || !id || !out || cfg->structSize != sizeof(brmi_compose_config)) return -1;
     if (cfg->nRanks == 0 || cfg->rank >= cfg->nRanks || cfg->depth == 0 || cfg->depth > 8 || cfg->width == 0 || cfg->bytesPerPixel == 0) return -1;
-    if (cfg->bandY0 % 8u || cfg->bandY1 % 8u || cfg->bandY1 <= cfg->bandY0) return -1;
+    if (cfg->bandY0 % 8u || cfg->bandY1 % 8u || (cfg->bandY1 <= cfg->bandY0 && !cfg->frameHeight) || cfg->bandY1 < cfg->bandY0) return -1;
+    if (cfg->frameHeight && (cfg->frameHeight % 8u || cfg->bandY1 > cfg->frameHeight)) return -1;
     if (cfg->transport > BRMI_TRANSPORT_RGB16F || (cfg->transport == BRMI_TRANSPORT_RGB16F && cfg->bytesPerPixel != 8)) return -1;
     if (cfg->path > BRMI_COMPOSE_PEER_WRITE || (cfg->path == BRMI_COMPOSE_PEER_WRITE && cfg->nRanks > kMaxRanks)) return -1;
     brmi_composer* c = new brmi_composer();
@@ -148,6 +154,12 @@ int brmi_compose_create(const brmi_compose_config* cfg, const uint8_t id[BRMI_CO
     c->pixels = c->bandBytes / cfg->bytesPerPixel;
     c->stagingBytes = cfg->transport == BRMI_TRANSPORT_RGB16F ? c->pixels * 6u : c->bandBytes;
     c->outputBytes = c->stagingBytes * cfg->nRanks;
+    c->rowBytes = rowBytes; c->rowBytesOut = cfg->transport == BRMI_TRANSPORT_RGB16F ? rowBytes / cfg->bytesPerPixel * 6u : rowBytes;
+    if (cfg->frameHeight) {      // bands of any height: a staging buffer for up to the whole frame, the composed image IS the frame
+        c->dynamic = true;
+        c->stagingBytes = c->outputBytes = (uint64_t)(cfg->frameHeight / 8u) * c->rowBytesOut;
+        c->bounds.assign(cfg->nRanks + 1u, 0u);      // until brmi_compose_set_bounds: only this rank's band is known
+    }
     *out = c;
     CHECK_HIP(c, hipSetDevice(cfg->device));
     if (!c->peerWrite) {
@@ -233,6 +245,69 @@ int brmi_compose_bind(brmi_composer* c, void* staging, uint64_t stagingBytes, vo
     return 0;
 }
 
+int brmi_compose_set_bounds(brmi_composer* c, const uint32_t* rowBounds) {
+    if (!c || !rowBounds) return -1;
+    if (!c->dynamic) return fail(c, -4, "brmi_compose_set_bounds: the composer was created without frameHeight (equal bands, fixed)");
+    if (c->openRow) return fail(c, -4, "brmi_compose_set_bounds: a frame is open (brmi_compose_submit_rows up to row %u so far)", c->openRow);
+    const uint32_t n = c->cfg.nRanks;
+    if (rowBounds[0] != 0u || rowBounds[n] != c->cfg.frameHeight) return fail(c, -1, "brmi_compose_set_bounds: the bounds run from %u to %u, the frame from 0 to %u", rowBounds[0], rowBounds[n], c->cfg.frameHeight);
+    for (uint32_t r = 0; r < n; r++) if (rowBounds[r] % 8u || rowBounds[r + 1] < rowBounds[r]) return fail(c, -1, "brmi_compose_set_bounds: bound %u = %u (ascending multiples of 8)", r, rowBounds[r]);
+    c->bounds.assign(rowBounds, rowBounds + n + 1u);
+    c->cfg.bandY0 = rowBounds[c->cfg.rank]; c->cfg.bandY1 = rowBounds[c->cfg.rank + 1u];
+    c->bandOffset = (uint64_t)(c->cfg.bandY0 / 8u) * c->rowBytes; c->bandBytes = (uint64_t)((c->cfg.bandY1 - c->cfg.bandY0) / 8u) * c->rowBytes;
+    c->pixels = c->bandBytes / c->cfg.bytesPerPixel;
+    return 0;
+}
+
+int brmi_compose_balance_rows(const float* rankMs, const uint32_t* boundsIn, uint32_t nRanks, uint32_t frameHeight, uint32_t align, float damping, uint32_t minRows, float* rowCost, uint32_t* boundsOut) {
+    if (!rankMs || !boundsIn || !boundsOut || !rowCost || nRanks == 0 || align == 0 || frameHeight % align || boundsIn[0] != 0u || boundsIn[nRanks] != frameHeight) return -1;
+    if (!(damping > 0.0f) || damping > 1.0f) damping = 1.0f;
+    minRows = std::max(minRows, align); minRows = (minRows + align - 1u) / align * align;
+    if ((uint64_t)minRows * nRanks > frameHeight) return -1;
+    const uint32_t blocks = frameHeight / align;
+    for (uint32_t r = 0; r < nRanks; r++) if (boundsIn[r + 1] < boundsIn[r] || boundsIn[r] % align || !(rankMs[r] >= 0.0f)) return -1;
+    // 1. the cost profile learns from this measurement: inside every band the profile is scaled so that it adds up to the band's measured time.  Frames measured under
+    //    OTHER bounds shaped the profile inside the band; this one fixes its sum (iterative proportional fitting: a few partitions locate a horizon that one cannot)
+    bool any = false;
+    for (uint32_t b = 0; b < blocks; b++) any = any || rowCost[b] > 0.0f;
+    if (!any) for (uint32_t b = 0; b < blocks; b++) rowCost[b] = 1.0f;
+    double maxMs = 0.0;
+    for (uint32_t r = 0; r < nRanks; r++) {
+        const uint32_t lo = boundsIn[r] / align, hi = boundsIn[r + 1] / align;
+        double sum = 0.0;
+        for (uint32_t b = lo; b < hi; b++) sum += rowCost[b];
+        if (hi > lo && sum > 0.0) { const float k = (float)(rankMs[r] / sum); for (uint32_t b = lo; b < hi; b++) rowCost[b] *= k; }
+        else if (hi > lo) for (uint32_t b = lo; b < hi; b++) rowCost[b] = rankMs[r] / (float)(hi - lo);
+        maxMs = std::max(maxMs, (double)rankMs[r]);
+    }
+    // 2. cut the profile into pieces of equal cost
+    std::vector<double> cum(blocks + 1u, 0.0);
+    for (uint32_t b = 0; b < blocks; b++) cum[b + 1u] = cum[b] + std::max(0.0f, rowCost[b]);
+    const double total = cum[blocks];
+    boundsOut[0] = 0u; boundsOut[nRanks] = frameHeight;
+    uint32_t j = 0;
+    for (uint32_t k = 1; k < nRanks; k++) {
+        double ideal = (double)frameHeight * k / nRanks;
+        if (total > 0.0) {
+            const double want = total * k / nRanks;
+            while (j + 1u < blocks && cum[j + 1u] < want) j++;
+            const double c = cum[j + 1u] - cum[j];
+            ideal = ((double)j + (c > 0.0 ? std::min(1.0, std::max(0.0, (want - cum[j]) / c)) : 0.0)) * align;
+        }
+        const double moved = boundsIn[k] + (double)damping * (ideal - boundsIn[k]);
+        boundsOut[k] = (uint32_t)(std::min((double)frameHeight, std::max(0.0, moved)) / align + 0.5) * align;
+    }
+    // every band at least minRows high: push forwards, then backwards
+    for (uint32_t k = 1; k <= nRanks; k++) if (boundsOut[k] < boundsOut[k - 1] + minRows) boundsOut[k] = boundsOut[k - 1] + minRows;
+    boundsOut[nRanks] = frameHeight;
+    for (uint32_t k = nRanks; k-- > 1; ) if (boundsOut[k] + minRows > boundsOut[k + 1]) boundsOut[k] = boundsOut[k + 1] - minRows;
+    // 3. hysteresis: a partition the profile does not expect to beat the measured one by 3 % is not worth the chain strips and the occlusion history a moved band loses
+    double maxPredicted = 0.0;
+    for (uint32_t r = 0; r < nRanks; r++) maxPredicted = std::max(maxPredicted, cum[boundsOut[r + 1] / align] - cum[boundsOut[r] / align]);
+    if (maxPredicted > 0.97 * maxMs) for (uint32_t k = 0; k <= nRanks; k++) boundsOut[k] = boundsIn[k];
+    return 0;
+}
+
 int brmi_compose_submit(brmi_composer* c, const void* surface, brmi_compose_stream renderStream) {
     if (!c || !surface) return -1;
     if (!c->staging) return fail(c, -4, "brmi_compose_submit: call brmi_compose_bind first");
@@ -247,8 +322,9 @@ int brmi_compose_submit(brmi_composer* c, const void* surface, brmi_compose_stre
         // there too, i.e. until the slot it is about to overwrite in THEIR images is free; 3. the band; 4. "landed"
         hipLaunchKernelGGL(k_signal_submitted, dim3(1), dim3(64), 0, rs, c->peers, n, c->cfg.rank, frame);
         if (n > 1) hipLaunchKernelGGL(k_wait_flags, dim3(1), dim3(64), 0, rs, c->flags->submitted, n, c->cfg.rank, frame, &c->flags->status, ticks);
-        const uint64_t slotOffset = (uint64_t)slot * c->outputBytes, bandOut = (uint64_t)c->cfg.rank * c->stagingBytes;
-        if (c->cfg.transport == BRMI_TRANSPORT_RGB16F) {
+        const uint64_t slotOffset = (uint64_t)slot * c->outputBytes, bandOut = c->bandOut();
+        if (c->pixels == 0) { /* (a rank that owns no row of this frame still signals) */ }
+        else if (c->cfg.transport == BRMI_TRANSPORT_RGB16F) {
             const uint64_t quads = c->pixels / 4u;
             hipLaunchKernelGGL(k_peer_write<true>, dim3((unsigned)std::min<uint64_t>(4096, (quads + 255) / 256)), dim3(256), 0, rs, reinterpret_cast<const uint4*>(band), c->peers, n, slotOffset, bandOut, quads);
         } else {
@@ -263,13 +339,27 @@ int brmi_compose_submit(brmi_composer* c, const void* surface, brmi_compose_stre
     uint8_t* st = c->staging + (uint64_t)slot * c->stagingBytes; uint8_t* dst = c->output + (uint64_t)slot * c->outputBytes;
     const uint8_t* band = static_cast<const uint8_t*>(surface) + c->bandOffset;
     if (c->inFlight[slot]) CHECK_HIP(c, hipStreamWaitEvent(rs, c->done[slot], 0));       // the slot's previous collective has read the staging buffer
-    if (c->cfg.transport == BRMI_TRANSPORT_RGB16F) {
+    if (c->pixels == 0) { /* (dynamic bands: this rank owns no row of the frame; it still takes part in the collective) */ }
+    else if (c->cfg.transport == BRMI_TRANSPORT_RGB16F) {
         const uint64_t quads = c->pixels / 4u;                                            // a band is whole 8x8 tiles
         hipLaunchKernelGGL(k_pack_rgb16f, dim3((unsigned)std::min<uint64_t>(4096, (quads + 255) / 256)), dim3(256), 0, rs, reinterpret_cast<const uint4*>(band), reinterpret_cast<uint2*>(st), quads);
         CHECK_HIP(c, hipGetLastError());
     } else CHECK_HIP(c, hipMemcpyAsync(st, band, c->bandBytes, hipMemcpyDeviceToDevice, rs));
     CHECK_HIP(c, hipEventRecord(c->staged[slot], rs));
     CHECK_HIP(c, hipStreamWaitEvent(c->collStream, c->staged[slot], 0));
+    if (c->dynamic) {
+        // bands of unequal height: one broadcast per rank, each with its own byte count, issued as ONE group (RCCL fuses a group into one launch; on the xGMI mesh every
+        // root's band leaves over its own links, as in the all-gather)
+        if (c->cfg.nRanks > 1 && c->bounds[c->cfg.nRanks] == 0u) return fail(c, -4, "brmi_compose_submit: call brmi_compose_set_bounds first (the composer was created with frameHeight)");
+        CHECK_NCCL(c, ncclGroupStart());
+        for (uint32_t r = 0; r < c->cfg.nRanks; r++) {
+            const uint32_t y0 = c->cfg.nRanks > 1 ? c->bounds[r] : c->cfg.bandY0, y1 = c->cfg.nRanks > 1 ? c->bounds[r + 1] : c->cfg.bandY1;
+            const uint64_t off = (uint64_t)(y0 / 8u) * c->rowBytesOut, count = (uint64_t)((y1 - y0) / 8u) * c->rowBytesOut;
+            if (count == 0) continue;
+            CHECK_NCCL(c, ncclBroadcast(r == c->cfg.rank ? (const void*)st : (const void*)(dst + off), dst + off, count, ncclUint8, (int)r, c->comm, c->collStream));
+        }
+        CHECK_NCCL(c, ncclGroupEnd());
+    } else
     CHECK_NCCL(c, ncclAllGather(st, dst, c->stagingBytes, ncclUint8, c->comm, c->collStream));
     CHECK_HIP(c, hipEventRecord(c->done[slot], c->collStream));
     c->inFlight[slot] = true;
@@ -303,10 +393,10 @@ int brmi_compose_submit_rows(brmi_composer* c, const void* surface, uint32_t row
     const uint8_t* src = static_cast<const uint8_t*>(surface) + c->bandOffset + slabIn;
     const uint64_t slotOffset = (uint64_t)slot * c->outputBytes;
     if (c->cfg.transport == BRMI_TRANSPORT_RGB16F) {
-        const uint64_t quads = slabBytes / c->cfg.bytesPerPixel / 4u, bandOut = (uint64_t)c->cfg.rank * c->stagingBytes + slabIn / c->cfg.bytesPerPixel * 6u;
+        const uint64_t quads = slabBytes / c->cfg.bytesPerPixel / 4u, bandOut = c->bandOut() + slabIn / c->cfg.bytesPerPixel * 6u;
         hipLaunchKernelGGL(k_peer_write<true>, dim3((unsigned)std::min<uint64_t>(2048, (quads + 255) / 256)), dim3(256), 0, cs, reinterpret_cast<const uint4*>(src), c->peers, n, slotOffset, bandOut, quads);
     } else {
-        const uint64_t vecs = slabBytes / 16u, bandOut = (uint64_t)c->cfg.rank * c->stagingBytes + slabIn;
+        const uint64_t vecs = slabBytes / 16u, bandOut = c->bandOut() + slabIn;
         hipLaunchKernelGGL(k_peer_write<false>, dim3((unsigned)std::min<uint64_t>(2048, (vecs + 255) / 256)), dim3(256), 0, cs, reinterpret_cast<const uint4*>(src), c->peers, n, slotOffset, bandOut, vecs);
     }
     {   // the composer's stream has read these rows of `surface` once this event has passed (brmi_compose_wait_source)

@@ -128,6 +128,11 @@ class VisibilityRenderer:
         self._check(self.lib.brmi_update(self._h, C.byref(upd), self._s()), "brmi_update")
         self._cam_bytes = cameras_host      # update() of a later frame repeats this camera
 
+    def set_band(self, y0, y1):
+        """Rows [y0, y1) this pass renders from its next frame on (brmi_set_band; passes created with dynamicBand=1).  update() before the frame, as always."""
+        self._check(self.lib.brmi_set_band(self._h, capi.u32(int(y0)), capi.u32(int(y1))), "brmi_set_band")
+        self.band = (int(y0), int(y1))
+
     def update(self, frame_index=0):
         if getattr(self, "_cam_bytes", None) is not None:
             upd = capi.FrameUpdate(self._cam_bytes.ctypes.data, self.scene.per_frame_host().ctypes.data, frame_index)

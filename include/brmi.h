@@ -65,7 +65,10 @@ typedef struct brmi_config {
      * frame, g = v / stripeRows.  Cameras, lights and perFrame.screenResY describe the FULL frame.  bandY0 / bandY1 stay 0.
      * 0 / 1: off (the contiguous band of bandY0 / bandY1, or the whole frame). */
     uint32_t stripeRows, stripeCount, stripeIndex, fullHeight;
-    uint32_t reserved[3];
+    /* Round 6: 1 = the band may change from frame to frame (brmi_set_band; cost-balanced contiguous regions): per-band workspace tables are sized for
+     * the whole frame.  bandY0 / bandY1 are then the first frame's band.  Not with the interleaved partition. */
+    uint32_t dynamicBand;
+    uint32_t reserved[2];
 } brmi_config;
 
 void brmi_default_config(brmi_config* cfg, uint32_t width, uint32_t height);
@@ -206,6 +209,13 @@ int         brmi_execute(brmi_pass* pass, brmi_stream stream);                  
 int         brmi_execute_split(brmi_pass* pass, brmi_stream geometryStream, brmi_stream shadingStream);
 void        brmi_destroy(brmi_pass* pass);                                               /* Cleanup */
 const char* brmi_last_error(const brmi_pass* pass);
+
+/* Rows [bandY0, bandY1) of the frame this GPU renders FROM THE NEXT FRAME ON (multiples of 8; passes created with brmi_config::dynamicBand): call it between frames,
+ * before the frame's brmi_update.  The screen-tile split of SURVEY.md 8(e) with regions whose boundaries follow the cost of the frames before, so that every GPU takes
+ * the same time: a cluster is set up by the one GPU whose band holds it (two at a boundary), and the band test of the instance / node / cluster culling drops the rest
+ * of the hierarchy.  Launches already enqueued keep the band they were issued with.  The depth chain's texels of rows that leave the band are reset to "empty" by the
+ * next chain build, so a stale depth never occludes anything in phase 2. */
+int brmi_set_band(brmi_pass* pass, uint32_t bandY0, uint32_t bandY1);
 
 /* ---- stage-level entry points: one per compute pass the reference's graph schedules ---------
  * (order of BR/src/Render/GraphExtensions/CLodExtension.cpp:1580-2088 and

@@ -50,7 +50,12 @@ typedef struct brmi_compose_config {
     int32_t  device;                        /* HIP device of this rank */
     uint32_t path;                          /* brmi_compose_path (0 = the all-gather) */
     uint32_t waitTimeoutMs;                 /* PEER_WRITE: a wait for a peer's flag gives up after this long and latches an error (0 = 2000 ms) */
-    uint32_t reserved[4];
+    /* Round 6, cost-balanced contiguous regions (brmi_set_band): frameHeight > 0 = the ranks' bands partition a frame of that many rows (a multiple of 8), need not be
+     * of one height and may move from frame to frame (brmi_compose_set_bounds).  The composed image is then THE FRAME in transport form, every band at its own rows;
+     * a staging buffer holds up to the whole frame.  bandY0 / bandY1 are the first frame's band.  ALLGATHER path: the bands travel as one group of ncclBroadcast
+     * calls, one per rank, each with that rank's byte count (an all-gather needs equal counts); PEER_WRITE path: stores at the band's place, as before. */
+    uint32_t frameHeight;
+    uint32_t reserved[3];
 } brmi_compose_config;
 
 typedef struct brmi_composer brmi_composer;
@@ -72,6 +77,16 @@ int brmi_compose_alloc_shared(brmi_composer* c);
 int brmi_compose_export(brmi_composer* c, uint8_t handle[BRMI_COMPOSE_HANDLE_BYTES]);
 int brmi_compose_import(brmi_composer* c, const uint8_t* handles, uint32_t count);
 int brmi_compose_last_wait_status(brmi_composer* c);
+/* Composers with frameHeight > 0: the partition of the frames submitted from now on -- rows [rowBounds[r], rowBounds[r + 1]) belong to rank r; nRanks + 1 ascending
+ * multiples of 8 from 0 to frameHeight, the same array on every rank (a rank may own no row at all).  Not while a frame is open (brmi_compose_submit_rows). */
+int brmi_compose_set_bounds(brmi_composer* c, const uint32_t* rowBounds);
+/* Where the boundaries should go.  `rowCost` (frameHeight / align floats, in / out, all zero before the first call) is the host's running estimate of how a frame's
+ * cost is spread over the rows: each call first scales it inside every band [boundsIn[r], boundsIn[r + 1]) so that the band adds up to the time `rankMs[r]` the rank
+ * just measured (the shape inside a band comes from frames measured under other bounds: a few partitions locate a horizon one cannot), then `boundsOut` cuts it into
+ * pieces of equal cost, moved `damping` (0 .. 1] of the way there from `boundsIn`, rounded to multiples of `align` rows (8, or 16 = the raster bin), every band at least
+ * `minRows` high; bounds the estimate does not expect to beat the measured ones by 3 % are left as they are.  Pure host arithmetic: every rank evaluates it on the same
+ * numbers (one small all-gather of the times per rebalance) and gets the same partition.  Returns 0, or -1 for bad arguments. */
+int brmi_compose_balance_rows(const float* rankMs, const uint32_t* boundsIn, uint32_t nRanks, uint32_t frameHeight, uint32_t align, float damping, uint32_t minRows, float* rowCost, uint32_t* boundsOut);
 /* `surface`: base of the tiled surface (the whole frame's allocation).  Returns the buffer slot used (>= 0) or a negative status. */
 int brmi_compose_submit(brmi_composer* c, const void* surface, brmi_compose_stream renderStream);
 /* PEER_WRITE only -- the composition overlapped with the frame's own shading ("overlap gather of finished tiles with shading of later tiles via a

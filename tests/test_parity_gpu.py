@@ -694,6 +694,88 @@ def test_full_size_band_split_against_the_oracle(preset, lights, n, kw):
         r.close()
 
 
+@pytest.mark.parametrize("preset,lights,n,kw", [("bistro", 256, 2, dict()),
+                                                ("san_miguel", 256, 8, dict(material_features=24))])         # bench.py --gpus 8's weak leg: configs[3]'s scene, 7680 x 8704
+def test_full_size_balanced_regions_against_the_oracle(preset, lights, n, kw):
+    """Round 6: cost-balanced contiguous regions (brmi_set_band).  ONE ring-less pass with brmi_config::dynamicBand renders the ranks' bands in turn -- unequal heights, as
+    the balancer leaves them around a horizon, then MOVED bounds (the second partition shifts every boundary, so bands grow into rows whose chain strips another
+    partition left behind) -- with occlusion culling and the draw list on; every band equals the oracle's full frame on its rows: triangle identities, depth, lit bytes.
+    (Scenes of test_full_size_band_split_against_the_oracle: the reference's occlusion test -- a sphere against four texels -- is not conservative on every scene, and a
+    band's chain is not the full frame's; on the bench's relief scene at this size both the one-GPU frame and the bands lose a few hundred pixels to it, differently.)"""
+    import orc
+    from basicrenderer_amd import compose
+    from conftest import Scene
+    from basicrenderer_amd.renderer import VisibilityRenderer
+    W, H = compose.frame_size(n, "stripes")
+    sc = Scene(preset, W, H, point_lights=lights, **kw)
+    o = orc.OracleFrame(sc).run()
+    fa, fb, fd = orc.canonical_ids(o.vis, o.clusters[: o.count])
+    oh = o.hdr.view(np.uint16).astype(np.int32).reshape(H, W, 4)
+    mid = H // 2 // 16 * 16
+    if n == 2:
+        partitions = [[0, mid + 304, H], [0, mid - 208, H]]
+    else:      # thin bands around the middle of the frame (where the San-Miguel-class view has its horizon), tall ones above and below
+        partitions = [[0, mid - 1200, mid - 400, mid - 144, mid - 48, mid + 64, mid + 320, mid + 1504, H], [0, mid - 1488, mid - 560, mid - 192, mid - 16, mid + 112, mid + 432, mid + 1200, H]]
+    with _Env(hold_min_clusters=0):
+        r = VisibilityRenderer(sc, band=(partitions[0][0], partitions[0][1]), occlusion=True, stats=True, dynamicBand=1)
+    held = 0
+    for bounds in partitions:
+        for rank in range(n):
+            y0, y1 = bounds[rank], bounds[rank + 1]
+            r.set_band(y0, y1)
+            for _ in range(2):
+                r.update(); r.execute()
+            c = r.counters()
+            held += c.reserved[1]
+            assert c.droppedRecords == 0 and c.droppedClusters == 0
+            a, b, d = orc.canonical_ids(r.visibility(), r.visible_clusters())
+            assert np.array_equal(a[y0:y1], fa[y0:y1]) and np.array_equal(b[y0:y1], fb[y0:y1]) and np.array_equal(d[y0:y1], fd[y0:y1]), f"bounds {bounds}, rank {rank}"
+            covered = (o.vis != np.uint64(0xFFFFFFFFFFFFFFFF))[y0:y1]
+            gh = r.hdr().view(np.uint16).astype(np.int32).reshape(H, W, 4)
+            assert np.abs(gh[y0:y1][covered] - oh[y0:y1][covered]).max() <= 1, f"bounds {bounds}, rank {rank}"
+    r.close()
+    assert held > 0, "the draw list never held a cluster back in a band"
+
+
+def test_rccl_composition_of_unequal_bands_with_two_ranks():
+    """The N > 1 path of libbrmi_compose.so's dynamic bands -- one RCCL group of ncclBroadcast calls, a byte count per rank -- needs two GPUs: skipped cleanly on the
+    one-GPU boxes of this pool, there for a node that has them (two processes, one GPU each, 127.0.0.1)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29613",
+                          os.path.join(ROOT, "tests", "rccl_unequal_bands_worker.py")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_native_composer_places_a_band_at_its_own_rows():
+    """World size 1 of the same path (what one GPU can run): a composer made with frame_height composes THE FRAME, the rank's band at its own rows -- whatever the band's
+    height -- through the grouped-broadcast branch of brmi_compose_submit; brmi_compose_set_bounds moves the band between frames."""
+    import torch
+    from basicrenderer_amd import compose
+    W, H = 256, 128
+    surface = torch.randint(0, 255, (H // 8 * (W // 8) * 64 * 8,), dtype=torch.uint8, device="cuda")
+    for transport in ("surface", "rgb16f"):
+        band = (16, 64)
+        c = compose.NativeBandComposer(surface, band, W, 8, depth=2, transport=transport, rank=0, world=1, frame_height=H)
+        c.submit(); got = c.finish()
+        torch.cuda.synchronize()
+        lo, hi = compose.band_byte_range(band, W, 8)
+        if transport == "surface":
+            assert got.numel() == surface.numel() and torch.equal(got[lo:hi], surface[lo:hi])
+        else:
+            assert got.shape == (H * W, 3) and torch.equal(got[lo // 8: hi // 8], compose.rgb_of(surface)[lo // 8: hi // 8])
+        c.set_bounds([0, H])      # the next frame's partition: one rank, the whole frame
+        c.submit(); got = c.finish()
+        torch.cuda.synchronize()
+        assert torch.equal(got, surface if transport == "surface" else compose.rgb_of(surface)), transport
+        with pytest.raises(RuntimeError):
+            c.set_bounds([0, H - 8])      # the bounds must cover the frame
+        c.close()
+
+
 @pytest.mark.parametrize("preset,lights,n,rows,kw", [("bistro", 256, 4, 64, dict(unique_budget=True, lod_builder="own", relief_slope=1.5)),   # the bench's N = 4 frame, its default chunk height
                                                      ("bistro", 256, 8, 16, dict()),                                                          # the finest interleave, eight ranks
                                                      ("san_miguel", 256, 2, 272, dict(material_features=24)),                                 # alpha-tested clusters across chunk boundaries

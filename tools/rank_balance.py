@@ -30,6 +30,10 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--frames-in-flight", type=int, default=2)
     ap.add_argument("--only", type=int, nargs="*", help="ranks to measure (default: all)")
+    ap.add_argument("--partition", default=None, choices=["balanced"],
+                    help="round 6: cost-balanced contiguous regions (brmi_set_band + brmi_compose_balance_rows) on the leg's frame -- ONE ring of passes with dynamicBand renders "
+                         "the ranks' bands in turn, the balancer moves the bounds after every round of measurements (--balance-rounds), the last round is the table")
+    ap.add_argument("--balance-rounds", type=int, default=6)
     args = ap.parse_args()
     import torch
     import bench
@@ -75,7 +79,36 @@ def main():
             p.close()
         del ring, ref_scene
         torch.cuda.empty_cache()
-    for r in (args.only if args.only else range(n)):
+    if args.partition == "balanced":
+        # one ring for every rank and round: the band moves (brmi_set_band), the surfaces are the frame's
+        ring = [VisibilityRenderer(scene, device=dev, stats=(j == 0), band=(0, H // n // 16 * 16), occlusion=True, dynamicBand=1) for j in range(fif)]
+        for j in range(fif):
+            ring[j].set_history_source(ring[(j - 1) % fif])
+        bal = compose.RowBalancer(n, H, align=16, min_rows=32)
+        out["partition"], out["rounds"] = "balanced", []
+        for rnd in range(args.balance_rounds):
+            bounds, per = list(bal.bounds), []
+            for r in range(n):
+                for p in ring:
+                    p.set_band(bounds[r], bounds[r + 1])
+                steps = args.steps if rnd == args.balance_rounds - 1 else max(20, args.steps // 3)
+                for i in range(10 + steps):
+                    if i == 10:
+                        torch.cuda.synchronize(); t0 = time.perf_counter()
+                    p = ring[i % fif]
+                    with torch.cuda.stream(geo[0]):
+                        p.update(); p.execute(shade[0][i % fif])
+                torch.cuda.synchronize()
+                c = ring[0].counters()
+                per.append({"rank": r, "rows": [bounds[r], bounds[r + 1]], "ms_per_frame": round((time.perf_counter() - t0) / steps * 1e3, 4), "visible_clusters": int(c.visibleClusters), "held": int(c.reserved[1])})
+            t = [x["ms_per_frame"] for x in per]
+            out["rounds"].append({"bounds": bounds, "ms": t, "max_over_min": round(max(t) / min(t), 3)})
+            out["per_rank"] = per
+            if rnd + 1 < args.balance_rounds:
+                bal.update(t)
+        for p in ring:
+            p.close()
+    for r in ([] if args.partition == "balanced" else (args.only if args.only else range(n))):
         rings = []
         for k in range(K):
             c = r + k * n
