@@ -143,7 +143,7 @@ static void compute_sizes(brmi_pass* p) {
     w.shadeTables = take(((uint64_t)2 * c.width + 2 * c.height + 64) * 4);
     w.matWords = take((uint64_t)std::max(1u, p->scene.materialCount) * sizeof(MaterialWords));
     w.layerUniform = take(sizeof(LayerUniform));
-    w.frameConst = take(3 * 64);
+    w.frameConst = take(4 * 64);      // three matrix products and (round 6) the band's two planes
     w.frameSnapshot = take(sizeof(FrameSnapshot));
     w.matConst = take((uint64_t)std::max(1u, p->scene.openpbrMaterialCount) * sizeof(MatConst));
     w.objConst = take((uint64_t)std::max(1u, p->scene.perObjectCount) * OBJ_CONST_FLOATS * 4);

@@ -38,6 +38,7 @@ struct CullArgs {
     HzbDesc hzb;
     // multi-GPU row band: two view-space planes through the eye bounding the band (1 = active)
     uint32_t bandActive; float bandTop[3], bandBottom[3];
+    const float4* bandPlanes;        // the same two planes in memory (frameConst[3]): what the instance / node tests read
     StripeMap stripes;      // interleaved partition: ownership test of the cluster cull
     // mixed traversal: meshes whose widest BVH level fits the LDS frontier are walked by k_cull_hierarchy (one wave per instance, one launch),
     // the few wider ones by the level-per-launch kernels (all lanes of the chip on one level); the latter skip instances narrower than this
@@ -182,7 +183,10 @@ BRMI_DEV bool stripe_rejects(const StripeMap& m, const brmi_camera* cam, f3 cent
 // per meshlet: every rank of the 8-GPU San-Miguel-class frame visited all 37,600 nodes and tested 40 k meshlets for bands that show 24 .. 27 k clusters.
 BRMI_DEV bool sphere_culled(const CullArgs& a, const brmi_camera* cam, f3 c, float r) {
     if (sphere_outside_frustum(c, r, cam->clippingPlanes)) return true;
-    if (a.bandActive && (dot3(f3{a.bandTop[0], a.bandTop[1], a.bandTop[2]}, c) < -r || dot3(f3{a.bandBottom[0], a.bandBottom[1], a.bandBottom[2]}, c) < -r)) return true;
+    if (a.bandActive) {      // (the planes from memory, like the camera's: brmi_frame.hip)
+        const float4 top = a.bandPlanes[0], bottom = a.bandPlanes[1];
+        if ((top.x * c.x + top.y * c.y) + top.z * c.z < -r || (bottom.x * c.x + bottom.y * c.y) + bottom.z * c.z < -r) return true;
+    }
     return stripe_on(a.stripes) && stripe_rejects(a.stripes, cam, c, r);
 }
 
@@ -1648,6 +1652,7 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
                                       p->camHost.projection[3][0] == 0.0f && p->camHost.projection[3][1] == 0.0f;
     a.bandActive = ((p->bandY0 != 0 || p->bandY1 != p->cfg.height) && symmetricPerspective) ? 1u : 0u;
     for (int k = 0; k < 3; k++) { a.bandTop[k] = p->bandPlaneTop[k]; a.bandBottom[k] = p->bandPlaneBottom[k]; }
+    a.bandPlanes = reinterpret_cast<const float4*>(p->wsPtr<m4>(p->ws.frameConst) + 3);
     a.stripes = p->stripes;
     const brmi_pass* chain = p->chainOwner(phase);      // frames in flight: phase 1 reads the chain of the pass that rendered the frame before
     a.occlusion = (p->cfg.enableOcclusionCulling && chain->hzbValid && p->camHost.isOrtho == 0) ? 1u : 0u;

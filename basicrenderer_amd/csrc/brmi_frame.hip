@@ -23,7 +23,7 @@ namespace brmi {
 //   frameConst[0] = mul(view, projection)           frameConst[1] = mul(view, unjitteredProjection)
 //   frameConst[2] = mul(prevView, prevUnjitteredProjection)
 //   objConst[o]   = { mul(model, cullCam.viewProjection), mul(model, frameConst[0]), mul(model, cullCam.viewZ) }
-BRMI_DEV void job_object_constants(const brmi_scene_buffers& sc, m4* frameConst, float* objConst, FrameSnapshot* snap, uint32_t o) {
+BRMI_DEV void job_object_constants(const brmi_scene_buffers& sc, m4* frameConst, float* objConst, FrameSnapshot* snap, const float* bandPlanes, uint32_t o) {
     const uint32_t viewId = sc.perFrame->mainCameraIndex;
     if (o < 64u) {      // the job's first workgroup: the camera and the per-frame record the shading half will read (FrameSnapshot)
         const uint32_t* pfSrc = reinterpret_cast<const uint32_t*>(sc.perFrame); uint32_t* pfDst = reinterpret_cast<uint32_t*>(&snap->perFrame);
@@ -39,6 +39,10 @@ BRMI_DEV void job_object_constants(const brmi_scene_buffers& sc, m4* frameConst,
         frameConst[0] = viewProj;
         frameConst[1] = mul_mm(viewM, load_m4(&cam->unjitteredProjection[0][0]));
         frameConst[2] = mul_mm(load_m4(&cam->prevView[0][0]), load_m4(&cam->prevUnjitteredProjection[0][0]));
+        // the band's two view-space planes (brmi_update) where the traversal kernels read them like the camera's clipping planes: as kernel arguments they cost
+        // those kernels seven scalar registers each held across the whole walk
+        float* bp = &frameConst[3].m[0][0];
+        for (int k = 0; k < 8; k++) bp[k] = bandPlanes[k];
     }
     if (o >= sc.perObjectCount) return;
     const m4 model = load_m4(&sc.perObject[o].model[0][0]);
@@ -232,6 +236,7 @@ struct FrameJobs {
     AlphaMaterial* alphaMats; LayerUniform* layer;
     const float* lutF; ShadeRows* shadeRows; ShadeAverages* shadeAvgs; GgxQuad* ggxQuads;
     uint32_t W, H; StripeMap stripes;
+    float bandPlanes[8];         // top plane xyz, 0, bottom plane xyz, 0 (brmi_update)
     float sliceStart[64];        // first view depth of every light-cluster slice (brmi_update), [0] = 0, [gz + 1] = +inf
     uint4* frameState; uint64_t frameState16;      // brmi_execute: the culling pass's counters + survivor bitmasks, zeroed here (job 7)
     uint32_t firstBlock[8];      // block ranges of the seven jobs
@@ -240,7 +245,7 @@ struct FrameJobs {
 __global__ void __launch_bounds__(64) k_frame_constants(FrameJobs j) {
     wave_prio<PRIO_SCAN>();
     const uint32_t b = blockIdx.x;
-    if (b < j.firstBlock[1]) job_object_constants(j.sc, j.frameConst, j.objConst, j.snapshot, (b - j.firstBlock[0]) * 64u + threadIdx.x);
+    if (b < j.firstBlock[1]) job_object_constants(j.sc, j.frameConst, j.objConst, j.snapshot, j.bandPlanes, (b - j.firstBlock[0]) * 64u + threadIdx.x);
     else if (b < j.firstBlock[2]) job_material_words(j.sc, j.matWords, j.alphaMats, (b - j.firstBlock[1]) * 64u + threadIdx.x);
     else if (b < j.firstBlock[3]) job_material_constants(j.sc, j.matConst, (b - j.firstBlock[2]) * 64u + threadIdx.x);
     else if (b < j.firstBlock[4]) job_shade_tables(j.sc, j.tables, j.W, j.H, j.stripes, j.sliceStart, (b - j.firstBlock[3]) * 64u + threadIdx.x);
@@ -274,6 +279,8 @@ int ensure_frame_constants(brmi_pass* p, hipStream_t s) {
     j.alphaMats = p->sceneHasAlphaTest ? p->wsPtr<AlphaMaterial>(p->ws.alphaMats) : nullptr;
     j.layer = p->wsPtr<LayerUniform>(p->ws.layerUniform);
     j.W = p->cfg.width; j.H = p->cfg.height; j.stripes = p->stripes;
+    for (int k = 0; k < 3; k++) { j.bandPlanes[k] = p->bandPlaneTop[k]; j.bandPlanes[4 + k] = p->bandPlaneBottom[k]; }
+    j.bandPlanes[3] = j.bandPlanes[7] = 0.0f;
     for (uint32_t k = 0; k < 64; k++) j.sliceStart[k] = k < p->sliceStartHost.size() ? p->sliceStartHost[k] : 0.0f;
     auto blocks = [](uint32_t n) { return (std::max(1u, n) + 63u) / 64u; };
     j.lutF = p->wsPtr<float>(p->ws.lutF); j.shadeRows = p->wsPtr<ShadeRows>(p->ws.shadeRows); j.shadeAvgs = p->wsPtr<ShadeAverages>(p->ws.shadeAvgs); j.ggxQuads = p->wsPtr<GgxQuad>(p->ws.ggxQuads);
