@@ -174,6 +174,8 @@ static void compute_sizes(brmi_pass* p) {
     w.drawList = take(p->holdEnabled ? (uint64_t)c.maxVisibleClusters * 4 : 16);
     w.heldRecords = take(p->holdEnabled ? (uint64_t)c.maxVisibleClusters * sizeof(HeldRecord) : 16);
     w.lateList = take(p->holdEnabled ? (uint64_t)c.maxVisibleClusters * 4 : 16);
+    w.wideQueue = take((uint64_t)std::max(1u, p->wideCapacity) * 96);      // WideTri (brmi_raster.hip)
+    w.wideAlpha = take(p->sceneHasAlphaTest ? (uint64_t)std::max(1u, p->wideCapacity) * 48 : 16);
     w.total = off;
     p->resNeed[BRMI_RES_WORKSPACE] = w.total;
 }
@@ -271,6 +273,9 @@ int brmi_create(const brmi_config* cfg, brmi_pass** out) {
     p->flatLevelsMinDraws = (uint32_t)std::max(0l, tuning("flat_levels_min_draws", p->flatLevelsMinDraws));      // (tests: 1 = the level-synchronous flat traversal for every scene)
     p->phase2DirectMax = (uint32_t)std::max(0l, tuning("phase2_direct_max", p->phase2DirectMax));
     p->resolveInlineMode = (int)tuning("resolve_inline", -1);
+    p->wideCapacity = (uint32_t)std::min(1l << 20, std::max(0l, tuning("wide_capacity", p->wideCapacity)));
+    p->wideMinTriangles = (uint32_t)std::max(0l, tuning("wide_min_triangles", p->wideMinTriangles));
+    p->wideEntries = (uint32_t)std::max(1l, tuning("wide_entries", p->wideEntries));
     p->binMinSlice = (uint32_t)std::max(32l, tuning("bin_min_slice", p->binMinSlice));
     p->binSharedSlice = (uint32_t)std::max(32l, tuning("bin_shared_slice", p->binSharedSlice));
     p->binGrid = (uint32_t)std::min(65535l, std::max(1l, tuning("bin_grid", p->binGrid)));
@@ -1004,6 +1009,17 @@ int brmi_algorithmic_bytes_launched(brmi_pass* p, uint64_t* perStage, uint64_t* 
         const uint64_t P = (uint64_t)p->cfg.width * (p->bandY1 - p->bandY0);
         *total -= perStage[BRMI_STAGE_SHADE]; perStage[BRMI_STAGE_SHADE] = 44ull * P; *total += perStage[BRMI_STAGE_SHADE];
     }
+    return BRMI_OK;
+}
+
+int brmi_debug_wide_triangles(brmi_pass* p, uint32_t out[3]) {
+    if (!p || !out || !p->setupDone) return BRMI_ERR_INVALID;
+    BRMI_HIP(p, hipDeviceSynchronize());
+    uint32_t c[3] = {0u, 0u, 0u};
+    BRMI_HIP(p, hipMemcpy(&c[0], p->counters() + CNT_WIDE1, 4, hipMemcpyDeviceToHost));
+    BRMI_HIP(p, hipMemcpy(&c[1], p->counters() + CNT_WIDE1B, 4, hipMemcpyDeviceToHost));
+    BRMI_HIP(p, hipMemcpy(&c[2], p->counters() + CNT_WIDE2, 4, hipMemcpyDeviceToHost));
+    out[0] = c[0]; out[1] = c[1]; out[2] = c[2];
     return BRMI_OK;
 }
 

@@ -55,7 +55,9 @@ enum CounterIndex : uint32_t {
     CNT_HELD1 = CNT_BUCKETS + 192,          // held records
     CNT_LATE1 = CNT_BUCKETS + 224,          // held clusters the re-test could not prove hidden (drawn by the late pass)
     CNT_DRAWN_VT = CNT_BUCKETS + 256,       // ONE 64-bit word (even index): vertex | triangle << 32 sums of the clusters that ARE rasterised in phase 1 (draw list + late list)
-    CNT_WORDS = CNT_BUCKETS + 288
+    // round 6: triangles whose records a workgroup emits (k_raster_wide): queue lengths of the phase-1 draw pass, the late pass and phase 2
+    CNT_WIDE1 = CNT_BUCKETS + 288, CNT_WIDE1B = CNT_BUCKETS + 320, CNT_WIDE2 = CNT_BUCKETS + 352,
+    CNT_WORDS = CNT_BUCKETS + 384
 };
 static_assert((CNT_DRAWN_VT & 1u) == 0u, "64-bit counter");
 
@@ -222,7 +224,7 @@ struct Workspace {     // byte offsets into BRMI_RES_WORKSPACE
     uint64_t counters, frontierA, frontierB, buckets, tempVisible, bitmask1, bitmask2, blockDirty, chainDirty, wordPrefix, blockSums,
              instanceBitBase, segPrefix, meshLevelWidth, scanAgg, flatNodes, flatLeaves, instanceWalk, planes, replayNodes, replayBuckets, lightVS, lightMeta, clusterPages, clusterHits, pageTotal, lightHitMasks, binCounts, binRecords, binOverflow, binPlan, binItems, binScratch, clusterSetup, resolveVerts, resolveTris, matWords, shadeTables, lutF, frameConst, objConst, matConst, deferredPixels,
              frameSnapshot, debugStamps, clusterUv, binAlpha, overflowAlpha, resolveUVs, resolveColors, alphaMats, shadeRows, shadeAvgs, ggxQuads, shadeLights, clusterList, listEntries, listRecords, layerUniform,
-             meshletBoxes, pageBoxBase, pageRefs, drawList, heldRecords, lateList, frameClearBytes, total;
+             meshletBoxes, pageBoxBase, pageRefs, drawList, heldRecords, lateList, wideQueue, wideAlpha, frameClearBytes, total;
 };
 
 }  // namespace brmi
@@ -257,6 +259,9 @@ struct brmi_pass {
                                      // of the list, serial frame 2.574 / 2.53 / 2.50 ms against 2.948 without; a prediction finer than the re-test sends the difference to the late pass: 2.75)
     uint32_t retestMaxTexels = 8;    // ... and the re-test of this frame's
     uint32_t chainStripLo = 0xFFFFFFFFu, chainStripHi = 0u;   // 32-row strips of the chain that hold texels of a band (a band that moves: the next full build also resets the strips it left)
+    uint32_t wideCapacity = 16384;   // triangles the wide queue holds (BRMI_TUNING wide_capacity; 0 = every triangle is emitted by its own wave); beyond it the wave emits them itself
+    uint32_t wideEntries = 128;      // ... and, while it is launched, triangles of more bin entries than this go to it (BRMI_TUNING wide_entries; without it a lane keeps up to 512)
+    uint32_t wideMinTriangles = 4;   // the wide pass is launched while the last frame the host has seen queued at least this many (BRMI_TUNING wide_min_triangles)
     bool chainBuiltInRaster = false; // this frame's phase-1 rasteriser stage built the chain itself (before its re-test): the build that follows redoes the late pass's blocks only
     bool sceneHasVertexColors = false;                           // some mesh's pages carry vertex colours (perMesh.vertexFlags bit 0)
     uint32_t sceneUvSets = 1;      // UV sets the texture slots of the scene's materials name (brmi_set_scene)

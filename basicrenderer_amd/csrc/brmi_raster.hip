@@ -61,7 +61,16 @@ constexpr int COOP_ENTRIES = 64;                    // triangles with more bin e
 constexpr int COOP_ENTRIES_TABLE = BRMI_COOP_ENTRIES_TABLE;             // ... or than this, when the launch has the wide count table (RasterArgs::tableCells > BIN_WINDOW)
 constexpr uint32_t BIN_TABLE_MAX = 2048;            // cells of the wide table (dynamic LDS, 8 KB: every bin of a 4K frame or of a rank's 7680 x 1088 surface)
 
+// Round 6: a triangle whose records are emitted by a workgroup of k_raster_wide instead of by the wave that set it up.  A triangle of a near surface reaches thousands of
+// bins (a ground plane in the 8-GPU weak frame: 80 bin bands x 30 strips); one wave emitting them one band per lane was 200 us of a rank's frame and what the moving
+// camera's phase 1 waited for.  `base` is the record of the triangle's first row INSIDE this GPU's rows (rowStart = that frame row, barycentrics
+// stepped to it by the serial loop's additions); rows, bands and strips say where it goes.
+struct WideTri { BinRecord base; int32_t yHi, band0, band1, strip0, strip1; uint32_t pad[3]; };      // 96 B
+static_assert(sizeof(WideTri) == 96, "WideTri layout");
 struct RasterArgs {
+    WideTri* wideQueue; AlphaRecord* wideAlpha; uint32_t wideCapacity, wideCounter;      // wideQueue null: every triangle is emitted by its own wave; wideCounter: CNT_WIDE* of this launch
+    uint32_t wideEntries;        // with the queue on: triangles of more bin entries than this are queued (the lane-by-lane emission keeps the smaller ones)
+    uint32_t* wideFeedback;      // host-mapped word or null: the plan stores the launch's count of such triangles there (the host launches the wide pass by it)
     BinRecord* binRecords; uint32_t* binCounts; uint32_t binCapacity, binsX, binsY;
     BinRecord* overflow; uint32_t overflowPerStripe;     // 64 striped queues of records whose bin was full (pad0 = strip)
     AlphaRecord* binAlpha; AlphaRecord* overflowAlpha;   // side arrays of binRecords / overflow (alpha-tested scenes only)
@@ -517,7 +526,8 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
             // its lane.  With the wide table (up to 2048 cells: the whole 4K frame) such passes still count in LDS and reserve with one atomic per bin,
             // a batch of four in flight per lane; and since a lane's slots then come from LDS, triangles of up to 512 bin entries stay with their lane
             // instead of being emitted one at a time by the whole wave.
-            const int coopEntries = a.tableCells > (uint32_t)BIN_WINDOW ? COOP_ENTRIES_TABLE : COOP_ENTRIES;
+            // (round 6: with the wide pass behind this launch the limit is that pass's -- its emission is a workgroup's, a lane's is one record after the other)
+            const int coopEntries = a.wideQueue ? (int)a.wideEntries : (a.tableCells > (uint32_t)BIN_WINDOW ? COOP_ENTRIES_TABLE : COOP_ENTRIES);
             const bool few = entries > 0 && entries <= coopEntries && !(a.debugFlags & 2);
             bool fewW = few;      // (a pass whose bins fit no window falls back to the 64-entry rule below)
             const bool anyFew = __any(few);
@@ -696,7 +706,28 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
             if (anyFew && !windowed) KSTAMP(6); else KSTAMP(4);      // (instrumented builds: passes whose bins do not fit the LDS window reserve slot by slot)
             // many bins: the whole wave emits the triangle.  lane L owns bands band0 + L, band0 + L + 64, ...: it steps the row
             // start down to each of them (the same additions the serial loop makes) and appends the band's record to every strip.
-            uint64_t coop = __ballot(entries > 0 && !fewW && !(a.debugFlags & 2));
+            const bool isCoop = entries > 0 && !fewW && !(a.debugFlags & 2);
+            uint64_t coop = __ballot(isCoop);
+            const bool wideCand = entries > (int)a.wideEntries && !(a.debugFlags & 2);      // (with the queue on these are exactly the triangles `few` left out)
+            const uint64_t candM = __ballot(wideCand);
+            if (candM != 0ull) {
+                // round 6: these go to the wide queue (one reservation per wave); what does not fit -- or all of them, when the host has not launched the wide pass for this
+                // frame -- is emitted right here as before.  The count is kept either way: it is what the host decides by.
+                uint32_t slot = 0u;
+                if (lane == (uint32_t)__ffsll((unsigned long long)candM) - 1u) slot = atomicAdd(&a.counters[a.wideCounter], (uint32_t)__popcll(candM));
+                slot = (uint32_t)__shfl((int)slot, __ffsll((unsigned long long)candM) - 1) + lane_rank(candM);
+                const bool queued = wideCand && a.wideQueue != nullptr && slot < a.wideCapacity;
+                if (queued) {
+                    WideTri w;
+                    w.base.clusterIndex = clusterIndex; w.base.triAndFlags = flags; w.base.minX = minX; w.base.rectWidth = rectWidth; w.base.rowStart = yLo;
+                    w.base.sb0 = band_b0; w.base.sb1 = band_b1; w.base.dx_b0 = dx_b0; w.base.dx_b1 = dx_b1; w.base.dy_b0 = dy_b0; w.base.dy_b1 = dy_b1; w.base.d0 = d0; w.base.d1 = d1; w.base.d2 = d2;
+                    w.base.pad0 = 0u; w.base.pad1 = alphaCluster ? 1u : 0u;
+                    w.yHi = yHi; w.band0 = band0; w.band1 = band1; w.strip0 = strip0; w.strip1 = strip1; w.pad[0] = w.pad[1] = w.pad[2] = 0u;
+                    a.wideQueue[slot] = w;
+                    if (alphaCluster) { AlphaRecord ar = arec; ar.materialDataIndex = cs.materialDataIndex; a.wideAlpha[slot] = ar; }
+                }
+                coop = __ballot(isCoop && !queued);
+            }
             while (coop != 0ull) {
                 const int src = __ffsll((unsigned long long)coop) - 1;
                 coop &= coop - 1ull;
@@ -747,6 +778,59 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
         if (tot > before) for (int k = 0; k < 8; k++) a.debugStamps[40 + k] = kph[k];      // (racy between near-equal waves: a diagnostic)
     }
 #endif
+}
+
+// The queued triangles (WideTri): a workgroup per triangle, its eight waves take the bin bands in turn -- each steps the row start down to its bands with the serial loop's
+// additions, exactly as the emitting wave of k_raster does (brmi_raster.hip: "many bins") -- and the lanes of a wave the strips of the band: one slot reservation and one
+// 64 B store per lane, four bands' reservations in flight.  Runs between k_raster and the plan (which reads the bins' final counts).
+template <bool ALPHA>
+__global__ void __launch_bounds__(512) k_raster_wide(RasterArgs a) {
+    wave_prio<PRIO_RASTER>();
+    __shared__ float unormT[ALPHA ? 256 : 1];
+    if (ALPHA) { if (threadIdx.x < 256u) unormT[threadIdx.x] = (float)threadIdx.x / 255.0f; __syncthreads(); }
+    const uint32_t n = min(a.counters[a.wideCounter], a.wideCapacity);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+    const bool striped = stripe_on(a.stripes);
+    for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
+        const WideTri w = load_uniform(&a.wideQueue[e]);
+        AlphaRecord arec{};
+        const bool alpha = ALPHA && w.base.pad1 != 0u;
+        if (alpha) arec = a.wideAlpha[e];
+        float sb0 = w.base.sb0, sb1 = w.base.sb1;
+        int py = w.base.rowStart;
+        // this wave's bands, four at a time: records first (the stepping), then the four bands' slot reservations side by side, then the stores
+        for (int bandBase = w.band0 + (int)wave; bandBase <= w.band1; bandBase += 4 * (int)waves) {
+            // (only what differs from band to band is kept per band; the record is put together at the store)
+            float bsb0[4], bsb1[4]; int brow[4]; uint32_t bflags[4], vb[4]; bool own[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int band = bandBase + k * (int)waves;
+                own[k] = band <= w.band1 && (!striped || stripe_owns(a.stripes, (uint32_t)band << BIN_ROWS_SHIFT));
+                vb[k] = 0u; bsb0[k] = 0.0f; bsb1[k] = 0.0f; brow[k] = 0; bflags[k] = 0u;
+                if (own[k]) {      // (a band this GPU does not own is skipped; the stepping catches up from the last band this wave emitted)
+                    const int start = max(band << BIN_ROWS_SHIFT, w.base.rowStart);
+                    for (; py < start; py++) { sb0 += w.base.dy_b0; sb1 += w.base.dy_b1; }
+                    const int rows = min(((band + 1) << BIN_ROWS_SHIFT), w.yHi + 1) - start;
+                    bflags[k] = w.base.triAndFlags | ((uint32_t)rows << 16);
+                    brow[k] = striped ? (int)stripe_vrow(a.stripes, (uint32_t)start) : start;
+                    bsb0[k] = sb0; bsb1[k] = sb1;
+                    vb[k] = striped ? stripe_vrow(a.stripes, (uint32_t)band << BIN_ROWS_SHIFT) >> BIN_ROWS_SHIFT : (uint32_t)band;
+                }
+            }
+            for (int st0 = w.strip0; st0 <= w.strip1; st0 += 64) {
+                const int st = st0 + (int)lane;
+                uint32_t slots[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) slots[k] = (own[k] && st <= w.strip1) ? atomicAdd(&a.binCounts[(size_t)(vb[k] * a.binsX + (uint32_t)st) * BIN_COUNT_STRIDE], 1u) : 0u;
+#pragma unroll
+                for (int k = 0; k < 4; k++) if (own[k] && st <= w.strip1) {
+                    BinRecord r = w.base;
+                    r.triAndFlags = bflags[k]; r.rowStart = brow[k]; r.sb0 = bsb0[k]; r.sb1 = bsb1[k];
+                    bin_store(a, unormT, r, arec, (uint32_t)st, vb[k], slots[k]);
+                }
+            }
+        }
+    }
 }
 
 // One workgroup per bin: the bin's records are walked one lane per row (16 records at a time) with LDS atomic-min into a tile
@@ -1243,7 +1327,10 @@ __global__ void __launch_bounds__(THREADS) k_raster_overflow(RasterArgs a) {
         return;
     }
 #endif
-    if (blockIdx.x == 0u) { plan_bins(a); return; }       // (the first workgroup: it is what the next launch waits for, so it should not queue behind the walkers)
+    if (blockIdx.x == 0u) {       // (the first workgroup: it is what the next launch waits for, so it should not queue behind the walkers)
+        if (a.wideFeedback && threadIdx.x == 0u) __hip_atomic_store(a.wideFeedback, a.counters[a.wideCounter], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        plan_bins(a); return;
+    }
     // a wave = four records at a time, one lane per row
     const uint32_t lane = threadIdx.x & 63u, sub = lane >> 4, row = lane & 15u;
     const uint32_t walker = (blockIdx.x - 1u) * (THREADS / 64u) + (threadIdx.x >> 6), walkers = (gridDim.x - 1u) * (THREADS / 64u);
@@ -1344,6 +1431,14 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
     // draws the ones it cannot prove hidden in a late pass -- all inside this stage, before anything reads the phase-1 depth (k_retest_held)
     const bool hold = phase == 1 && p->holdThisFrame;
     if (hold) { a.drawList = p->wsPtr<uint32_t>(p->ws.drawList); a.countCounter = CNT_DRAW1; }
+    // round 6: triangles that reach very many bins are queued for k_raster_wide -- launched while the frames before had such triangles (host-mapped word 7: phase 1's
+    // count, stored by the plan; a frame or two old, and either way the same records)
+    const uint32_t lastWide = p->phase2FeedbackHost ? reinterpret_cast<volatile uint32_t*>(p->phase2FeedbackHost)[7] : 0u;
+    const bool wideOn = p->wideCapacity != 0u && lastWide >= std::max(1u, p->wideMinTriangles);
+    a.wideQueue = wideOn ? p->wsPtr<WideTri>(p->ws.wideQueue) : nullptr; a.wideAlpha = p->wsPtr<AlphaRecord>(p->ws.wideAlpha); a.wideCapacity = p->wideCapacity;
+    a.wideCounter = phase == 2 ? (uint32_t)CNT_WIDE2 : (uint32_t)CNT_WIDE1; a.wideEntries = p->wideEntries;
+    a.wideFeedback = (phase == 1 && p->phase2FeedbackDev) ? p->phase2FeedbackDev + 7 : nullptr;
+    const dim3 wgrid(std::max(32u, std::min(1024u, lastWide)));
     // (the interleaved partition's surface rows are not the frame rows the boxes are in: there the second build redoes everything)
     a.chainDirty = (BRMI_CHAIN_DIRTY_BLOCKS && phase == 2 && p->stripes.count <= 1u) ? p->wsPtr<uint8_t>(p->ws.chainDirty) : nullptr; a.chainBlocksX = (p->cfg.width + 31u) / 32u;
     p->chainDirtyTracked = a.chainDirty != nullptr;
@@ -1400,10 +1495,12 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
     const dim3 ogrid(phase == 2 && sized2 ? std::max(2u, std::min(129u, hint2 / 4u + 2u)) : 129u);      // (block 0 plans the bins launch; the others walk the overflow queues)
     if (p->sceneHasAlphaTest) {
         hipLaunchKernelGGL(k_raster<true>, rgrid, dim3(64), a.tableCells * 4u, s, a);
+        if (!direct2 && wideOn) hipLaunchKernelGGL(k_raster_wide<true>, wgrid, dim3(512), 0, s, a);
         if (!direct2) hipLaunchKernelGGL(k_raster_overflow<true>, ogrid, dim3(256), 0, s, a);
         if (!direct2 && !(p->rasterDebug & 4)) hipLaunchKernelGGL(k_raster_bins<true>, bgrid, dim3(BRMI_BIN_THREADS), 0, s, a);
     } else {
         hipLaunchKernelGGL(k_raster<false>, rgrid, dim3(64), a.tableCells * 4u, s, a);
+        if (!direct2 && wideOn) hipLaunchKernelGGL(k_raster_wide<false>, wgrid, dim3(512), 0, s, a);
         if (!direct2) {
             if (p->binsX * p->binsY > 4096u) hipLaunchKernelGGL((k_raster_overflow<false, 1024>), dim3((ogrid.x - 1u + 3u) / 4u + 1u), dim3(1024), 0, s, a);
             else hipLaunchKernelGGL(k_raster_overflow<false>, ogrid, dim3(256), 0, s, a);
@@ -1426,6 +1523,7 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
         hipLaunchKernelGGL(k_retest_held, dim3(tgrid), dim3(256), 0, s, r);
         RasterArgs l = a;
         l.drawList = r.lateList; l.countCounter = CNT_LATE1; l.countFeedback = p->phase2FeedbackDev ? p->phase2FeedbackDev + 5 : nullptr;
+        l.wideCounter = CNT_WIDE1B; l.wideFeedback = nullptr;
         // what the late pass draws changes the depth under it: it records the 32 x 32 px blocks its triangles may touch, like phase 2
         l.chainDirty = BRMI_CHAIN_DIRTY_BLOCKS ? p->wsPtr<uint8_t>(p->ws.chainDirty) : nullptr; l.chainBlocksX = (p->cfg.width + 31u) / 32u;
         p->chainDirtyTracked = l.chainDirty != nullptr; p->chainBuiltInRaster = true;
@@ -1436,9 +1534,11 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
         const dim3 lgrid(std::min(p->rasterGrid, std::max(128u, pow2_at_least(std::min(lastLate, 1u << 20) * 16u))));
         if (p->sceneHasAlphaTest) {
             hipLaunchKernelGGL(k_raster<true>, lgrid, dim3(64), l.tableCells * 4u, s, l);
+            if (!directLate && wideOn) hipLaunchKernelGGL(k_raster_wide<true>, wgrid, dim3(512), 0, s, l);
             if (!directLate) { hipLaunchKernelGGL(k_raster_overflow<true>, dim3(129), dim3(256), 0, s, l); hipLaunchKernelGGL(k_raster_bins<true>, dim3(p->binGrid), dim3(BRMI_BIN_THREADS), 0, s, l); }
         } else {
             hipLaunchKernelGGL(k_raster<false>, lgrid, dim3(64), l.tableCells * 4u, s, l);
+            if (!directLate && wideOn) hipLaunchKernelGGL(k_raster_wide<false>, wgrid, dim3(512), 0, s, l);
             if (!directLate) {
                 if (p->binsX * p->binsY > 4096u) hipLaunchKernelGGL((k_raster_overflow<false, 1024>), dim3(33), dim3(1024), 0, s, l);
                 else hipLaunchKernelGGL(k_raster_overflow<false>, dim3(129), dim3(256), 0, s, l);

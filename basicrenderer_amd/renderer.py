@@ -181,6 +181,12 @@ class VisibilityRenderer:
         self._check(self.lib.brmi_algorithmic_bytes(self._h, per, C.byref(total)), "brmi_algorithmic_bytes")
         return dict(zip(capi.STAGE_NAMES, [int(x) for x in per])), int(total.value)
 
+    def wide_triangles(self):
+        """(phase-1 draw pass, late pass, phase 2) counts of the last frame's triangles queued for the workgroup-wide record emission (brmi_debug_wide_triangles)."""
+        out = (capi.u32 * 3)()
+        self._check(self.lib.brmi_debug_wide_triangles(self._h, out), "brmi_debug_wide_triangles")
+        return tuple(int(x) for x in out)
+
     def algorithmic_bytes_launched(self):
         """The same for the kernel variants the frame launched (brmi_algorithmic_bytes_launched)."""
         per = (capi.u64 * len(capi.STAGE_NAMES))()

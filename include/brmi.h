@@ -267,6 +267,11 @@ int brmi_algorithmic_bytes_launched(brmi_pass* pass, uint64_t* perStage /* [BRMI
  * (correctly rounded a/b and sqrt(a), round-to-nearest-even float->half) against IEEE on the host. */
 int brmi_debug_arith(const float* a, const float* b, float* outDiv, float* outSqrt, uint32_t* outHalfBits, uint32_t n, brmi_stream stream);
 
+/* Triangles of the last frame whose bin records were many enough (> 512 bins, or > 64 where a wave's bins fit no LDS window) to be queued for the workgroup-wide
+ * emission pass (k_raster_wide): phase 1's draw pass, its late pass, phase 2.  Counted whether or not the pass was launched (the host launches it while the frames
+ * before had such triangles).  Waits for the device. */
+int brmi_debug_wide_triangles(brmi_pass* pass, uint32_t out[3]);
+
 /* Experiments only: the first `bytes` of the raster bin-record region of the workspace (instrumented builds park per-workgroup time stamps there). */
 int brmi_debug_read_bin_records(brmi_pass* pass, void* dst, uint64_t bytes);
 

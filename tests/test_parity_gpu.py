@@ -1216,6 +1216,33 @@ def test_draw_list_holds_clusters_back_without_changing_a_key(name, texels, late
             assert late > 0, "the late pass never ran"
 
 
+@pytest.mark.parametrize("preset,kw,step", [("bistro", dict(), 20), ("san_miguel", dict(material_features=24), 0)])
+def test_triangles_of_very_many_bins_take_the_wide_pass_with_the_same_keys(preset, kw, step):
+    """Round 6: a triangle that reaches more bins than a wave's LDS window holds (a near floor at 4K: 15 strips x 135 bands) is queued and its records are emitted by a
+    workgroup of k_raster_wide, a wave per group of bin bands, instead of by the one wave that set it up.  4K views that have such triangles (the Bistro-class camera
+    path's position 20; the alpha-tested San-Miguel-class frame exercises the queue's alpha side array), three frames each: wide pass forced on from the second frame
+    (wide_min_triangles=1), never launched (wide_capacity=0), and a queue of TWO entries (the rest falls back to the emitting wave in the same launch) -- identical keys."""
+    import torch
+    from conftest import Scene
+    from basicrenderer_amd.renderer import VisibilityRenderer
+    sc = Scene(preset, 3840, 2160, point_lights=8, camera_step=step, **kw)
+    ref, queued = None, 0
+    for tun in (dict(wide_capacity=0), dict(wide_min_triangles=1, wide_entries=16), dict(wide_min_triangles=1, wide_entries=16, wide_capacity=2)):
+        with _Env(**tun):
+            r = VisibilityRenderer(sc, occlusion=True)
+        for _ in range(3):
+            r.update(); r.execute()
+            torch.cuda.synchronize()      # (the count has reached the host before the next frame chooses)
+        vis = r.visibility()
+        if ref is None:
+            ref = vis
+        else:
+            assert np.array_equal(vis, ref), tun
+        queued = max(queued, sum(r.wide_triangles()))
+        r.close()
+    assert queued > 0, "the view has no triangle that takes the wide pass"
+
+
 def test_draw_list_is_off_where_it_cannot_be_exact_yet(scenes):
     """The re-test reads the chain in FRAME rows; passes that render a band or the interleaved chunks of a frame into compact surfaces keep the whole list (so do
     passes without occlusion culling, and any pass with hold_clusters=0)."""
