@@ -98,10 +98,16 @@ def main():
                     help="own: mesh LOD DAGs from the library's cluster-LOD builder (irregular meshlets, ~384-cluster groups) instead of the generator's quadtree; default: the workload's (bistro: own)")
     ap.add_argument("--material-features", type=int, default=None,
                     help="default: the workload's (san_miguel: 24, else 0).  scene generator feature bits (brmi_scene.h): 1 coat, 2 fuzz, 4 mirrored instances, 8 texture-sampled materials, 16 alpha-tested materials, 32 vertex colours, 64 OpenPBR layer textures, 128 parallax; 0 = BASELINE.json's constant-factor configuration")
-    ap.add_argument("--partition", default="stripes", choices=["stripes", "bands"],
-                    help="N > 1: how the frame is split.  stripes (default): the interleaved partition of SURVEY.md 8(e) -- chunks of --stripe-rows rows, one "
-                         "chunk of every group of N per rank, compact surfaces (brmi_config::stripe*); measured at N = 8 on one GPU the slowest rank takes "
-                         "0.78 ms per frame against 1.62 ms with contiguous bands (profiles/r03_rank_balance.md).  bands: one contiguous band of 1080 rows per rank")
+    ap.add_argument("--partition", default="auto", choices=["auto", "stripes", "bands", "balanced"],
+                    help="N > 1: how the frame is split.  stripes: the interleaved partition of SURVEY.md 8(e) -- chunks of --stripe-rows rows, one "
+                         "chunk of every group of N per rank, compact surfaces (brmi_config::stripe*).  balanced (round 6): contiguous bands whose boundaries follow the ranks' "
+                         "measured frame times (brmi_set_band + brmi_compose_balance_rows; --balance-rounds rounds of --balance-frames frames before the timed region, then fixed): a "
+                         "cluster is set up by one rank and the band test drops the rest of the hierarchy.  bands: equal contiguous bands of 1080 rows.  auto (default): the weak leg "
+                         "takes balanced from 8 ranks on and stripes below, the strong leg stripes -- what the rank-by-rank emulation on one GPU measured as the better of the two "
+                         "(profiles/r06_rank_balance.md: weak N = 8 render-side 0.82 against 0.72, N = 4 0.84 against 0.91)")
+    ap.add_argument("--balance-rounds", type=int, default=5)
+    ap.add_argument("--balance-frames", type=int, default=24)
+    ap.add_argument("--bounds", default=None, help="--partition balanced with --emulate-rank: the row bounds to render with (comma separated, N + 1 values), e.g. the last round of tools/rank_balance.py")
     ap.add_argument("--stripe-rows", type=int, default=64, help="chunk height of the interleaved partition (a multiple of 16 that divides 1088: 16, 32, 64, 272, 544)")
     ap.add_argument("--transport", default="rgb16f", choices=["rgb16f", "surface"],
                     help="what the band composition gathers: the colour channels as RGB16F (default; the composed image has no alpha plane) or the RGBA16F surface bytes")
@@ -227,12 +233,14 @@ def multi_gpu_legs(args, n, rank, local_rank, emulated):
     result = {}
     for leg in legs:
         if leg == "weak":
-            frame, rows = compose.frame_size(n, args.partition), args.stripe_rows
+            part = args.partition if args.partition != "auto" else ("balanced" if n >= 8 else "stripes")
+            frame, rows = compose.frame_size(n, "bands" if part == "bands" else "stripes"), args.stripe_rows
             ref_frame = compose.frame_size(1)          # the N = 1 problem of weak scaling: the scene's 4K frame (8.29 Mpixel; a rank of the N-GPU frame shades 8.36 M)
         else:
+            part = args.partition if args.partition != "auto" else "stripes"
             frame, rows = compose.strong_frame(n)
             ref_frame = frame
-        got = measure(args, wl, n, rank, local_rank, cpu=False, path=False, emulated=emulated, frame=frame, stripe_rows=rows)
+        got = measure(args, wl, n, rank, local_rank, cpu=False, path=False, emulated=emulated, frame=frame, stripe_rows=rows, partition=part)
         ref = measure(args, wl, 1, 0, local_rank, cpu=False, path=False, emulated=True, frame=ref_frame, solo=True)      # every rank, on its own GPU; rank 0's is reported
         if got is not None:
             keep = ("value", "unit", "ms_per_step", "ms_per_step_minmax", "rank_ms_per_step", "config", "stage_ms", "serial_frame_ms", "host_issue_ms_per_step")
@@ -250,7 +258,7 @@ def multi_gpu_legs(args, n, rank, local_rank, emulated):
     return out
 
 
-def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False, frame=None, stripe_rows=None, solo=False):
+def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False, frame=None, stripe_rows=None, solo=False, partition=None):
     """K timed steps of one workload on this rank's GPU (all ranks call it together); rank 0 returns the result object.
     frame: (W, H) instead of the workload's default; stripe_rows: chunk height of the interleaved partition instead of --stripe-rows; solo: a one-GPU
     measurement inside an N-GPU job (no process group is touched; every rank returns its own result)."""
@@ -267,9 +275,11 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False,
         scene_kw["lod_builder"] = args.lod_builder
     lod_builder = scene_kw.get("lod_builder", "quadtree")
     multi = n > 1 and not emulated and not solo         # a process group exists
-    striped = n > 1 and args.partition == "stripes"
+    partition = partition or (args.partition if args.partition != "auto" else "stripes")
+    striped = n > 1 and partition == "stripes"
+    balanced = n > 1 and partition == "balanced"
     stripe_rows = stripe_rows or args.stripe_rows
-    W, H = compose.frame_size(n, args.partition)
+    W, H = compose.frame_size(n, "bands" if partition == "bands" else "stripes")
     if n == 1 and workload in FRAME_SIZE:
         W, H = FRAME_SIZE[workload]
     if frame is not None:
@@ -278,6 +288,11 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False,
         compose.stripe_frame_rows(rank, n, H, stripe_rows)      # (raises on a chunk height that does not fit)
         band = (0, H // n)                                             # the rank's compact surfaces hold its rows only: the composer takes all of them
         part = dict(stripes=(stripe_rows, n, rank))
+    elif balanced:
+        # cost-balanced contiguous regions: full-frame surfaces, a band that moves (brmi_set_band); the first frames render equal bands
+        balancer = compose.RowBalancer(n, H, align=16, min_rows=32, bounds=[int(x) for x in args.bounds.split(",")] if args.bounds else None)
+        band = (balancer.bounds[rank], balancer.bounds[rank + 1])
+        part = dict(band=band, dynamicBand=1)
     else:
         band = compose.band_of(rank, n, H)
         part = dict(band=band)
@@ -347,15 +362,22 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False,
             failed = agree(failed)
             if not failed:
                 try:
-                    composer = (compose.PeerBandComposer if args.composer == "peer" else compose.NativeBandComposer)(hdr, band, W, 8, transport=args.transport, **(dict(rank=0, world=1) if emulated else {}))
+                    composer = (compose.PeerBandComposer if args.composer == "peer" else compose.NativeBandComposer)(hdr, band, W, 8, transport=args.transport, **(dict(rank=0, world=1) if emulated else {}),
+                                                                                                                      **(dict(frame_height=H) if balanced else {}))
+                    if balanced and not emulated:
+                        composer.set_bounds(balancer.bounds)
                 except Exception as e:      # noqa: BLE001
                     failed, why = 1, f"{type(e).__name__}: {e}"
                 failed = agree(failed)
+            if failed and balanced:
+                fail_line(args, f"--partition balanced needs libbrmi_compose.so's composer (bands of unequal height): {why or 'it failed on another rank'}")
             if failed:
                 if composer is not None:
                     composer.close()
                 composer = compose.BandComposer(hdr, band, W, 8, transport=args.transport)
                 composer_used = "torch (" + args.composer + " composer failed" + (f": {why}" if why else " on another rank") + ")"
+        elif balanced:
+            fail_line(args, "--partition balanced composes bands of unequal height: --composer native or peer")
         else:
             composer = compose.BandComposer(hdr, band, W, 8, transport=args.transport)
 
@@ -364,6 +386,7 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False,
         for q in passes:
             q.set_shade_slabs(args.compose_slabs, lambda r0, r1, stream, q=q: composer.submit_rows(r0, r1, q.hdr_tensor(), stream_ptr=stream))
     frame_no = [0]
+    compose_on = [True]
 
     def step(serial=False):
         k = 0 if serial else frame_no[0] % len(passes)
@@ -373,7 +396,7 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False,
             if slabbed and not os.environ.get("BRMI_BENCH_SKIP_WAIT_SOURCE"):                 # the composer's stream may still be reading this pass's HDR rows of its previous frame: the stream that shades waits for those reads
                 composer.wait_source(p.hdr_tensor(), stream_ptr=(streams[k] if serial or shade_streams[k] is None else shade_streams[k]).cuda_stream)
             p.execute(None if serial else shade_streams[k])
-        if composer and not slabbed:
+        if composer and not slabbed and compose_on[0]:
             with torch.cuda.stream(streams[k] if serial or shade_streams[k] is None else shade_streams[k]):
                 composer.submit(p.hdr_tensor())
         frame_no[0] += 1
@@ -389,6 +412,42 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False,
 
     for _ in range(args.warmup):
         step()
+    balance_log = None
+    if balanced and not args.bounds:
+        # The partition finds its bounds before the clock starts: a round = --balance-frames frames of every rank's current band WITHOUT the composition (a rank's own
+        # time, not its wait for the others), the times all-gathered, brmi_compose_balance_rows on every rank (same numbers, same bounds), brmi_set_band on the ring's
+        # passes and brmi_compose_set_bounds.  Then the bounds stay (a renderer would repeat a round every second or so).
+        if slabbed:
+            fail_line(args, "--partition balanced with --compose-slabs: not supported (the slabs follow a fixed band)")
+        if composer:
+            composer.finish()
+        compose_on[0] = False
+        balance_log = []
+        for rnd in range(max(0, args.balance_rounds)):
+            torch.cuda.synchronize()
+            if multi:
+                dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.balance_frames):
+                step()
+            torch.cuda.synchronize()
+            mine = torch.tensor([(time.perf_counter() - t0) / args.balance_frames * 1e3], dtype=torch.float64, device=dev)
+            if multi:
+                every = [torch.zeros_like(mine) for _ in range(n)]
+                dist.all_gather(every, mine)
+                times = [float(x.item()) for x in every]
+            else:
+                times = [float(mine.item())] * n      # (one emulated rank cannot know the others' times: pass --bounds)
+            balance_log.append({"bounds": list(balancer.bounds), "ms": [round(x, 4) for x in times]})
+            balancer.update(times)
+            band = (balancer.bounds[rank], balancer.bounds[rank + 1])
+            for q in passes:
+                q.set_band(*band)
+            if composer and not emulated:
+                composer.set_bounds(balancer.bounds)
+        compose_on[0] = True
+        for _ in range(len(passes) + 2):      # the moved bands' first frames (no depth history in the rows a band gained)
+            step()
     # Ten untimed frames after the warm-up are timed stage by stage; the timed region keeps HIP events only around the dominant stage (an
     # event pair is a barrier on the stream, ten pairs per frame cost ~5 %), whose mean launch duration feeds `roofline`.
     if composer:
@@ -460,7 +519,7 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False,
             path_fast_out = camera_path(args, scene, passes, streams, shade_streams, r, dev, args.camera_path_fast)
     out = None
     if rank == 0 or emulated or solo:
-        shaded = W * (band[1] - band[0]) * n            # pixels dispatched per step, all ranks
+        shaded = W * H if balanced else W * (band[1] - band[0]) * n            # pixels dispatched per step, all ranks
         ms_per_step = dt / args.steps * 1e3
         value = shaded / 1e6 / (dt / args.steps)
         dom = dom_stage if stage_ms.get(dom_stage, 0.0) > 0 else max(stage_ms, key=lambda k: stage_ms[k])      # the stage the events stayed around (two stages within noise of each other must not swap here)
@@ -521,12 +580,12 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False,
                                    + (", LOD DAGs from the library's cluster-LOD builder" if lod_builder == "own" else "")
                                    + (f", relief slope {scene_kw['relief_slope']}" if scene_kw.get("relief_slope") else "")
                                    + (f", material features {features} (8 = texture-sampled, 16 = alpha-tested materials)" if features else "")
-                                   + ((f", interleaved partition: chunks of {stripe_rows} rows, one per group of {n} and rank, {band[1]} rows per rank in compact surfaces" if striped else f", {n} row bands of {band[1] - band[0]} rows") + f" + composition of HDR on every rank ({args.transport}, pipelined one frame deep, {'libbrmi_compose.so: one RCCL all-gather per frame' if composer_used == 'native' else ('libbrmi_compose.so: peer writes over hipIpc-mapped images, no collective' if composer_used == 'peer' else ('torch.distributed' if composer_used == 'torch' else composer_used))})" if composer else ""),
+                                   + ((f", interleaved partition: chunks of {stripe_rows} rows, one per group of {n} and rank, {band[1]} rows per rank in compact surfaces" if striped else (f", {n} cost-balanced contiguous bands (this rank: rows {band[0]} - {band[1]})" if balanced else f", {n} row bands of {band[1] - band[0]} rows")) + f" + composition of HDR on every rank ({args.transport}, pipelined one frame deep, {'libbrmi_compose.so: one RCCL all-gather per frame' if composer_used == 'native' else ('libbrmi_compose.so: peer writes over hipIpc-mapped images, no collective' if composer_used == 'peer' else ('torch.distributed' if composer_used == 'torch' else composer_used))})" if composer else ""),
                        "baseline_config": BASELINE_CONFIG[workload],
                        "fps": round(1e3 / ms_per_step, 1),
                        "pixels_per_gpu": W * (band[1] - band[0]), "visible_clusters_rank0": int(c.visibleClusters),
                        "occlusion_culling": bool(args.occlusion), "visible_clusters_phase2_rank0": int(c.visibleClustersPhase2),
-                       "meshlets_tested_rank0": int(c.meshletsTested), "partition": (f"interleaved chunks of {stripe_rows} rows x{n}" if striped else f"row bands x{n}") if n > 1 else "single GPU",
+                       "meshlets_tested_rank0": int(c.meshletsTested), "partition": (f"interleaved chunks of {stripe_rows} rows x{n}" if striped else (f"cost-balanced contiguous bands x{n}" if balanced else f"row bands x{n}")) if n > 1 else "single GPU",
                        "frames_in_flight": fif},
             "roofline": {"bound": nearer, "bound_note": "the ceiling the kernel sits nearer to: VALU issue (roofline.valu.frac, SQ_INSTS_VALU of the committed profile) or HBM (frac / frac_traffic); "
                                                         "achieved / peak / unit / frac are the HBM figures of SURVEY.md 8(d) either way",
@@ -541,6 +600,9 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False,
                               f"serial frames of one pass (nothing else on the GPU): '{dom}' over {min(args.steps, 200)} frames after the timed region, the other stages over 10 frames "
                               f"before it; inside the timed region, sharing the CUs with the other pass's frame, '{dom}' took {in_flight_ms:.4f} ms per launch"),
         }
+        if balance_log is not None:
+            out["balance_rounds"] = balance_log
+            out["bounds"] = list(balancer.bounds)
         if n > 1:
             out["rank_ms_per_step"] = {"max": round(max(rank_ms), 4), "min": round(min(rank_ms), 4), "ranks": len(rank_ms),
                                        "note": "each rank's own time to finish the region's frames, composition included (emulated: this rank alone)"}
