@@ -1662,7 +1662,9 @@ int launch_cull(brmi_pass* p, uint32_t phase, hipStream_t s) {
         // Round 6: this frame holds clusters back when the pass can (brmi_set_scene), the previous frame's chain is there to predict from, and the frames before had
         // enough clusters for the two extra launches to pay (the count is a host-mapped word a frame or two old; either way the same image)
         const uint32_t lastVisible = p->phase2FeedbackHost ? reinterpret_cast<volatile uint32_t*>(p->phase2FeedbackHost)[3] : 0u;
-        p->holdThisFrame = p->holdEnabled && a.occlusion != 0u && (p->holdMinClusters == 0u || (lastVisible != 0xFFFFFFFFu && lastVisible >= p->holdMinClusters));
+        const uint32_t lastPhase2 = p->phase2FeedbackHost ? reinterpret_cast<volatile uint32_t*>(p->phase2FeedbackHost)[0] : 0xFFFFFFFFu;
+        p->holdThisFrame = p->holdEnabled && a.occlusion != 0u && (p->holdMinClusters == 0u || (lastVisible != 0xFFFFFFFFu && lastVisible >= p->holdMinClusters) ||
+                                                                  (p->holdStillMax != 0u && lastPhase2 < p->holdStillMax));
     }
     a.frontier0Counter = phase == 1 ? (uint32_t)CNT_FRONTIER0 : (uint32_t)CNT_REPLAY_NODES;
     a.bucketCounter = CNT_BUCKETS;   // phase 2: seeded with the replayed meshlets, the bucket array is the replay buffer itself

@@ -255,6 +255,11 @@ struct brmi_pass {
     bool holdThisFrame = false;      // this frame's phase 1 made a draw list (launch_cull -> launch_raster)
     uint32_t holdMinClusters = 16384; // hold only on frames whose last known visible-cluster count is at least this (BRMI_TUNING hold_min_clusters): below it the re-test, the late
                                      // pass and the chain's second look cost what the rasteriser saves (Bistro-class, 10 k clusters: +25 us; profiles/r06_experiments.md)
+    uint32_t lateDirectMax = 128;    // the late pass walks every triangle directly (no records, plan, bins) while the last known late count is at most this (BRMI_TUNING late_direct_max;
+                                     // 1024: the fast camera path's raster stage 0.338 -> 0.466 ms -- late clusters are the ones a moving view uncovers, near and large)
+    uint32_t holdStillMax = 8;       // frames of fewer than holdMinClusters clusters hold clusters back all the same while phase 2 of the last frame the host has seen drew fewer clusters than
+                                     // this (a still camera: the prediction is then exact and the late pass empty -- Bistro-class 0.505 -> 0.4815 ms in flight, San-Miguel-class 0.824 -> 0.776,
+                                     // Sponza-class unchanged, the skinned leg + 2.7 %; with the camera moving the late pass costs more than the rasteriser saves: path 0.545 -> 0.594); 0: never
     uint32_t holdMaxTexels = 8;      // the prediction reads at most this many texels per axis of the previous chain (BRMI_TUNING hold_max_texels; Zorah-class: 4 / 6 / 8 hold 41.6 / 47.7 / 49.6 %
                                      // of the list, serial frame 2.574 / 2.53 / 2.50 ms against 2.948 without; a prediction finer than the re-test sends the difference to the late pass: 2.75)
     uint32_t retestMaxTexels = 8;    // ... and the re-test of this frame's

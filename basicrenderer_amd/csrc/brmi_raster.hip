@@ -1529,7 +1529,7 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
         p->chainDirtyTracked = l.chainDirty != nullptr; p->chainBuiltInRaster = true;
         // few late clusters (a still or slowly moving camera: the prediction and the re-test ask the same question of nearly the same depth): every triangle through the
         // row re-deal with global atomics, ONE launch, as the small phase 2; many: records, plan and bins once more
-        const bool directLate = lastLate <= (p->sceneHasAlphaTest ? 0u : p->phase2DirectMax);
+        const bool directLate = lastLate <= (p->sceneHasAlphaTest ? 0u : p->lateDirectMax);
         if (directLate) l.bigTriArea = l.bigTriAreaAlpha = l.bigTriAreaDense = 0x3FFFFFFF;
         const dim3 lgrid(std::min(p->rasterGrid, std::max(128u, pow2_at_least(std::min(lastLate, 1u << 20) * 16u))));
         if (p->sceneHasAlphaTest) {

@@ -1179,8 +1179,8 @@ def test_phase_two_rasterises_the_same_keys_with_and_without_bins(name, direct_m
 @pytest.mark.parametrize("name", list(OCCLUSION_CASES))
 def test_draw_list_holds_clusters_back_without_changing_a_key(name, texels, late_direct, occlusion_runs):
     """Round 6, the draw list (brmi_raster.hip: k_retest_held).  Phase 1 rasterises the clusters its culling predicted visible, re-tests the held ones against the
-    chain of the keys that leaves and draws the ones it cannot prove hidden in a late pass.  Forced on (hold_min_clusters=0: by default only frames of >= 16 k visible
-    clusters do it) on the three frames of the camera path, with the prediction at several texel budgets (1 x 1 texels predicts badly: many late clusters) and the late
+    chain of the keys that leaves and draws the ones it cannot prove hidden in a late pass.  Forced on (hold_min_clusters=0: by default frames of >= 16 k visible
+    clusters do it, and smaller ones while the camera stands still) on the three frames of the camera path, with the prediction at several texel budgets (1 x 1 texels predicts badly: many late clusters) and the late
     pass through the direct walk or through the bins: the visible list, the keys, the depth map, the depth chain and the reference's counters are those of the plain
     frames (which the tests above hold against the oracle), frame by frame; clusters WERE held, and some of them were never drawn."""
     from basicrenderer_amd.renderer import VisibilityRenderer
