@@ -61,9 +61,9 @@ VALU_PEAK_WAVE_INSTS = 1.2288e12   # wave64 VALU instructions per second: 256 CU
 # medians one per 4.2 cycles, v_rcp / v_exp / v_sqrt one per 8.2 cycles (0.30 T/s)
 VALU_PEAK_MEASURED = 0.96e12
 # profiles/<tag>_traffic.json (tools/profile.sh), keyed by (workload, material feature bits): traffic of another configuration is not this one's
-PROFILE_TAG = {("sponza", 0): "r05_sponza4k", ("bistro", 0): "r05_bistro4k", ("bistro_r2", 0): "r02_bistro4k", ("san_miguel", 0): "r02_sanmiguel4k", ("bistro_dense", 0): "r05_bistro4k_dense",
-               ("san_miguel", 24): "r05_sanmiguel4k", ("zorah", 0): "r05_zorah8k", ("sponza", 136): "r02_sponza4k_parallax"}
-PROFILE_FALLBACK = {"r05_sponza4k": "r04_sponza4k", "r05_bistro4k": "r04_bistro4k", "r05_bistro4k_dense": "r04_bistro4k_dense", "r05_sanmiguel4k": "r04_sanmiguel4k"}      # until the round's profiles are committed
+PROFILE_TAG = {("sponza", 0): "r06_sponza4k", ("bistro", 0): "r06_bistro4k", ("bistro_r2", 0): "r02_bistro4k", ("san_miguel", 0): "r02_sanmiguel4k", ("bistro_dense", 0): "r06_bistro4k_dense",
+               ("san_miguel", 24): "r06_sanmiguel4k", ("zorah", 0): "r06_zorah8k", ("sponza", 136): "r02_sponza4k_parallax"}
+PROFILE_FALLBACK = {"r06_sponza4k": "r05_sponza4k", "r06_bistro4k": "r05_bistro4k", "r06_bistro4k_dense": "r05_bistro4k_dense", "r06_sanmiguel4k": "r05_sanmiguel4k", "r06_zorah8k": "r05_zorah8k"}      # until the round's profiles are committed
 _STREAM_CACHE = {}
 DOMINANT_KERNEL = {"raster": "k_raster", "gbuffer": "k_gbuffer", "shade": "k_shade", "cull": "k_traverse+k_cull_clusters", "clear": "k_clear_vis",
                    "light_cluster": "k_light_clustering", "depth_copy": "k_depth_copy", "hzb": "k_hzb_head", "cull2": "k_traverse+k_cull_clusters", "raster2": "k_raster"}

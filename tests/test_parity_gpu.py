@@ -1243,12 +1243,13 @@ def test_triangles_of_very_many_bins_take_the_wide_pass_with_the_same_keys(prese
     assert queued > 0, "the view has no triangle that takes the wide pass"
 
 
-def test_draw_list_is_off_where_it_cannot_be_exact_yet(scenes):
-    """The re-test reads the chain in FRAME rows; passes that render a band or the interleaved chunks of a frame into compact surfaces keep the whole list (so do
-    passes without occlusion culling, and any pass with hold_clusters=0)."""
+def test_draw_list_is_off_where_it_cannot_be_exact_yet():
+    """The re-test reads the chain in FRAME rows; passes that render the interleaved chunks of a frame into compact surfaces keep the whole list (so does any pass with
+    hold_clusters=0).  A contiguous band lives in frame rows and holds clusters back (test_full_size_balanced_regions_against_the_oracle)."""
+    from conftest import Scene
     from basicrenderer_amd.renderer import VisibilityRenderer
-    sc = scenes("bistro_small")
-    for kw, tun in ((dict(band=(0, sc.height // 2 // 8 * 8)), dict(hold_min_clusters=0)), (dict(), dict(hold_min_clusters=0, hold_clusters=0))):
+    sc = Scene("bistro", 640, 384, point_lights=8, size_scale=0.3)
+    for kw, tun in ((dict(stripes=(16, 2, 1)), dict(hold_min_clusters=0)), (dict(), dict(hold_min_clusters=0, hold_clusters=0))):
         with _Env(**tun):
             r = VisibilityRenderer(sc, occlusion=True, **kw)
         for _ in range(3):
