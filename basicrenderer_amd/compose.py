@@ -74,11 +74,21 @@ class RowBalancer:
         self.n, self.height, self.align, self.damping, self.min_rows = n_ranks, height, align, damping, min_rows
         self.bounds = list(bounds) if bounds is not None else equal_bounds(n_ranks, height, align)
         self.row_cost = np.zeros(height // align, dtype=np.float32)
+        self.best = None      # (slowest rank's time, bounds) of the best partition measured so far
+
+    def settle(self):
+        """The best partition any update() measured (the estimate keeps moving boundaries by a bin row or two around the optimum; the slowest rank's time is what counts):
+        makes it the current one and returns it."""
+        if self.best is not None:
+            self.bounds = list(self.best[1])
+        return self.bounds
 
     def update(self, rank_ms):
         import ctypes as C
         from . import capi
         n = self.n
+        if self.best is None or max(rank_ms) < self.best[0]:
+            self.best = (max(rank_ms), list(self.bounds))
         ms = (C.c_float * n)(*[float(x) for x in rank_ms])
         bin_ = (C.c_uint32 * (n + 1))(*[int(x) for x in self.bounds])
         out = (C.c_uint32 * (n + 1))()

@@ -102,10 +102,9 @@ def main():
                     help="N > 1: how the frame is split.  stripes: the interleaved partition of SURVEY.md 8(e) -- chunks of --stripe-rows rows, one "
                          "chunk of every group of N per rank, compact surfaces (brmi_config::stripe*).  balanced (round 6): contiguous bands whose boundaries follow the ranks' "
                          "measured frame times (brmi_set_band + brmi_compose_balance_rows; --balance-rounds rounds of --balance-frames frames before the timed region, then fixed): a "
-                         "cluster is set up by one rank and the band test drops the rest of the hierarchy.  bands: equal contiguous bands of 1080 rows.  auto (default): the weak leg "
-                         "takes balanced from 8 ranks on and stripes below, the strong leg stripes -- what the rank-by-rank emulation on one GPU measured as the better of the two "
-                         "(profiles/r06_rank_balance.md: weak N = 8 render-side 0.82 against 0.72, N = 4 0.84 against 0.91)")
-    ap.add_argument("--balance-rounds", type=int, default=5)
+                         "cluster is set up by one rank and the band test drops the rest of the hierarchy.  bands: equal contiguous bands of 1080 rows.  auto (default): balanced -- "
+                         "what the rank-by-rank emulation on one GPU measured as the better of the two on both legs (profiles/r06_rank_balance.md)")
+    ap.add_argument("--balance-rounds", type=int, default=6)
     ap.add_argument("--balance-frames", type=int, default=24)
     ap.add_argument("--bounds", default=None, help="--partition balanced with --emulate-rank: the row bounds to render with (comma separated, N + 1 values), e.g. the last round of tools/rank_balance.py")
     ap.add_argument("--stripe-rows", type=int, default=64, help="chunk height of the interleaved partition (a multiple of 16 that divides 1088: 16, 32, 64, 272, 544)")
@@ -233,11 +232,11 @@ def multi_gpu_legs(args, n, rank, local_rank, emulated):
     result = {}
     for leg in legs:
         if leg == "weak":
-            part = args.partition if args.partition != "auto" else ("balanced" if n >= 8 else "stripes")
+            part = args.partition if args.partition != "auto" else "balanced"
             frame, rows = compose.frame_size(n, "bands" if part == "bands" else "stripes"), args.stripe_rows
             ref_frame = compose.frame_size(1)          # the N = 1 problem of weak scaling: the scene's 4K frame (8.29 Mpixel; a rank of the N-GPU frame shades 8.36 M)
         else:
-            part = args.partition if args.partition != "auto" else "stripes"
+            part = args.partition if args.partition != "auto" else "balanced"
             frame, rows = compose.strong_frame(n)
             ref_frame = frame
         got = measure(args, wl, n, rank, local_rank, cpu=False, path=False, emulated=emulated, frame=frame, stripe_rows=rows, partition=part)
@@ -440,6 +439,8 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False,
                 times = [float(mine.item())] * n      # (one emulated rank cannot know the others' times: pass --bounds)
             balance_log.append({"bounds": list(balancer.bounds), "ms": [round(x, 4) for x in times]})
             balancer.update(times)
+            if rnd + 1 == max(0, args.balance_rounds):
+                balancer.settle()      # the timed region runs the best partition measured
             band = (balancer.bounds[rank], balancer.bounds[rank + 1])
             for q in passes:
                 q.set_band(*band)

@@ -104,8 +104,10 @@ def main():
             t = [x["ms_per_frame"] for x in per]
             out["rounds"].append({"bounds": bounds, "ms": t, "max_over_min": round(max(t) / min(t), 3)})
             out["per_rank"] = per
-            if rnd + 1 < args.balance_rounds:
+            if rnd + 2 < args.balance_rounds:
                 bal.update(t)
+            elif rnd + 2 == args.balance_rounds:
+                bal.update(t); bal.settle()      # the last round measures the best partition found
         for p in ring:
             p.close()
     for r in ([] if args.partition == "balanced" else (args.only if args.only else range(n))):
