@@ -189,6 +189,9 @@ uint32_t    brmi_abi_version(void);
 int         brmi_create(const brmi_config* cfg, brmi_pass** out);
 int         brmi_declare(brmi_pass* pass, brmi_declare_cb cb, void* user);            /* DeclareResourceUsages */
 int         brmi_set_scene(brmi_pass* pass, const brmi_scene_buffers* scene);          /* provider resolution   */
+/* Setup also reads the resident pages once (round 6): the object-space box of every meshlet goes into a side table of the workspace (the draw list's tests, DESIGN.md 4.3c;
+ * brmi_set_scene walked the page map for the table's size).  A host that rewrites page CONTENTS afterwards (streaming) calls brmi_set_scene + brmi_setup again; with
+ * BRMI_TUNING=hold_clusters=0 the table is neither sized nor made. */
 int         brmi_setup(brmi_pass* pass, const brmi_resource_binding* b, uint32_t n, brmi_stream stream); /* Setup */
 int         brmi_update(brmi_pass* pass, const brmi_frame_update* upd, brmi_stream stream);               /* Update */
 int         brmi_execute(brmi_pass* pass, brmi_stream stream);                          /* Execute: whole chain */
