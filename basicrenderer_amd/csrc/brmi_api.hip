@@ -1014,6 +1014,24 @@ int brmi_algorithmic_bytes_launched(brmi_pass* p, uint64_t* perStage, uint64_t* 
     return BRMI_OK;
 }
 
+int brmi_debug_read_held(brmi_pass* p, uint32_t* held, uint32_t heldCapacity, uint32_t* heldCount, uint32_t* late, uint32_t lateCapacity, uint32_t* lateCount) {
+    if (!p || !heldCount || !lateCount || !p->setupDone) return BRMI_ERR_INVALID;
+    BRMI_HIP(p, hipDeviceSynchronize());
+    uint32_t nh = 0, nl = 0;
+    BRMI_HIP(p, hipMemcpy(&nh, p->counters() + CNT_HELD1, 4, hipMemcpyDeviceToHost));
+    BRMI_HIP(p, hipMemcpy(&nl, p->counters() + CNT_LATE1, 4, hipMemcpyDeviceToHost));
+    if (!p->holdEnabled) nh = nl = 0;
+    nh = std::min(nh, p->cfg.maxVisibleClusters); nl = std::min(nl, p->cfg.maxVisibleClusters);
+    *heldCount = nh; *lateCount = nl;
+    if (held && nh) {
+        std::vector<HeldRecord> rec(std::min(nh, heldCapacity));
+        if (!rec.empty()) BRMI_HIP(p, hipMemcpy(rec.data(), p->wsPtr<HeldRecord>(p->ws.heldRecords), rec.size() * sizeof(HeldRecord), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < rec.size(); i++) held[i] = rec[i].clusterIndex;
+    }
+    if (late && nl && lateCapacity) BRMI_HIP(p, hipMemcpy(late, p->wsPtr<uint32_t>(p->ws.lateList), (size_t)std::min(nl, lateCapacity) * 4, hipMemcpyDeviceToHost));
+    return BRMI_OK;
+}
+
 int brmi_debug_wide_triangles(brmi_pass* p, uint32_t out[3]) {
     if (!p || !out || !p->setupDone) return BRMI_ERR_INVALID;
     BRMI_HIP(p, hipDeviceSynchronize());

@@ -181,6 +181,14 @@ class VisibilityRenderer:
         self._check(self.lib.brmi_algorithmic_bytes(self._h, per, C.byref(total)), "brmi_algorithmic_bytes")
         return dict(zip(capi.STAGE_NAMES, [int(x) for x in per])), int(total.value)
 
+    def held_clusters(self):
+        """(held, late): indices into visible_clusters() of the last frame's phase-1 clusters the culling held back, and of those the late pass drew (brmi_debug_read_held)."""
+        nh, nl = capi.u32(), capi.u32()
+        self._check(self.lib.brmi_debug_read_held(self._h, None, 0, C.byref(nh), None, 0, C.byref(nl)), "brmi_debug_read_held")
+        held, late = np.zeros(max(1, nh.value), dtype=np.uint32), np.zeros(max(1, nl.value), dtype=np.uint32)
+        self._check(self.lib.brmi_debug_read_held(self._h, held.ctypes.data_as(C.POINTER(capi.u32)), len(held), C.byref(nh), late.ctypes.data_as(C.POINTER(capi.u32)), len(late), C.byref(nl)), "brmi_debug_read_held")
+        return held[: nh.value], late[: nl.value]
+
     def wide_triangles(self):
         """(phase-1 draw pass, late pass, phase 2) counts of the last frame's triangles queued for the workgroup-wide record emission (brmi_debug_wide_triangles)."""
         out = (capi.u32 * 3)()

@@ -275,6 +275,10 @@ int brmi_debug_arith(const float* a, const float* b, float* outDiv, float* outSq
  * before had such triangles).  Waits for the device. */
 int brmi_debug_wide_triangles(brmi_pass* pass, uint32_t out[3]);
 
+/* The last frame's draw-list decisions, for tests (waits for the device): indices into the visible-cluster buffer of the phase-1 clusters the culling held back
+ * (`held`, up to heldCapacity entries; *heldCount = how many there were) and of those the late pass drew (`late`).  held minus late was never rasterised. */
+int brmi_debug_read_held(brmi_pass* pass, uint32_t* held, uint32_t heldCapacity, uint32_t* heldCount, uint32_t* late, uint32_t lateCapacity, uint32_t* lateCount);
+
 /* Experiments only: the first `bytes` of the raster bin-record region of the workspace (instrumented builds park per-workgroup time stamps there). */
 int brmi_debug_read_bin_records(brmi_pass* pass, void* dst, uint64_t bytes);
 

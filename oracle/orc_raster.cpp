@@ -223,6 +223,13 @@ int orc_raster_vote(const brmi_scene_buffers* sc, const brmi_visible_cluster* cl
     return 0;
 }
 
+// clusters[indices[i]] for i < n, each under its OWN index of the list (the key's cluster index): what a pass that draws part of the visible list must not have needed
+int orc_raster_subset(const brmi_scene_buffers* sc, const brmi_visible_cluster* clusters, const uint32_t* indices, uint32_t n, uint64_t* vis, uint32_t W, uint32_t H, int threads) {
+#pragma omp parallel for schedule(dynamic, 16) num_threads(threads > 0 ? threads : 1)
+    for (int64_t i = 0; i < (int64_t)n; i++) rasterCluster(*sc, clusters[indices[i]], indices[i], vis, W, H, 0, H);
+    return 0;
+}
+
 int orc_clear_visibility(uint64_t* vis, uint64_t pixels) { for (uint64_t i = 0; i < pixels; i++) vis[i] = BRMI_VIS_EMPTY; return 0; }
 
 // PerViewPrimaryDepthCopyCS: linear depth (0x7F7FFFFF where empty)

@@ -129,6 +129,14 @@ class OracleFrame:
         lib().orc_raster(C.byref(self.sb), P(self.clusters), u32(first), u32(cnt), P(self.vis), u32(W), u32(H), u32(band[0]), u32(band[1]), C.c_int(self.threads))
         return self.vis
 
+    def raster_subset_onto(self, vis, clusters, indices):
+        """clusters[indices] rasterised ON TOP of `vis` (a copy is returned), each under its own index of the list: the keys a pass that left those clusters out would have missed."""
+        out = np.ascontiguousarray(vis).copy()
+        cl = np.ascontiguousarray(clusters, dtype=np.uint32)
+        idx = np.ascontiguousarray(indices, dtype=np.uint32)
+        lib().orc_raster_subset(C.byref(self.sb), P(cl), P(idx), u32(len(idx)), P(out), u32(self.W), u32(self.H), C.c_int(self.threads))
+        return out
+
     def raster_vote(self, vote_mode):
         """The visibility image with the rasteriser's wave vote (softwareRaster.hlsl:502) evaluated another way: 0 wave64 (= raster()), 1 over
         32-triangle groups (wave32 hardware), 2 always scanline ranges, 3 never.  Measurement only; self.vis is untouched."""

@@ -1216,6 +1216,53 @@ def test_draw_list_holds_clusters_back_without_changing_a_key(name, texels, late
             assert late > 0, "the late pass never ran"
 
 
+@pytest.mark.parametrize("preset,W,H,lights,kw", [("bistro", 3840, 2160, 16, dict(unique_budget=True, lod_builder="own", relief_slope=1.5)),      # the headline scene
+                                                  ("bistro", 3840, 2160, 16, dict(size_scale=20.0, detail=96.0)),                               # the dense workload
+                                                  ("san_miguel", 3840, 2160, 16, dict(material_features=24)),
+                                                  ("zorah", 7680, 4320, 8, dict(skinned_fraction=0.01))])                                     # configs[4]: half of 487 k clusters
+def test_clusters_the_draw_list_never_rasterised_could_not_have_won_a_pixel(preset, W, H, lights, kw):
+    """The verdict's test for the draw list, on the GPU's own decisions at full size: the clusters held back and never drawn (brmi_debug_read_held: held minus late) are
+    rasterised by the CHECKER on top of the frame's final keys, each under its own index of the visible list -- no key changes, i.e. none of them could have won a pixel.
+    Still camera (nothing late) and two frames of the camera path (late clusters: those were drawn, and are not in the set)."""
+    import torch
+    import orc
+    from conftest import Scene
+    from basicrenderer_amd.renderer import VisibilityRenderer
+    sc = Scene(preset, W, H, point_lights=lights, **kw)
+    with _Env(hold_min_clusters=0):
+        r = VisibilityRenderer(sc, occlusion=True, stats=True)
+    o = orc.OracleFrame(sc)
+    skipped_total = late_total = 0
+    try:
+        sc.camera_at(0.1)
+        moving = True
+    except RuntimeError:
+        moving = False      # (a preset without a camera path: the still frame only)
+    for step in range(5 if moving else 3):
+        if step >= 3:      # the camera moves: frames 3 and 4
+            cam, cull = sc.camera_at(0.1 * (step - 2), 0.1 * (step - 3))
+            r.set_camera_device(torch.from_numpy(cam).cuda(), torch.from_numpy(cull).cuda(), cam, frame_index=step)
+            sc.arrays["cameras"][:] = cam; sc.arrays["cullingCameras"][:] = cull      # (the checker projects with the camera the pass was given)
+            o = orc.OracleFrame(sc)
+        else:
+            r.update(step)
+        r.execute()
+        if step in (0, 1):
+            continue
+        held, late = r.held_clusters()
+        skipped = np.setdiff1d(held, late)
+        skipped_total += len(skipped); late_total += len(late)
+        vis = r.visibility()
+        again = o.raster_subset_onto(vis, r.visible_clusters(), skipped)
+        changed = int((again != vis).sum())
+        assert changed == 0, f"frame {step}: {changed} pixels would have been won by one of the {len(skipped)} clusters that were never rasterised"
+        c = r.counters()
+        assert (c.reserved[1], c.reserved[3]) == (len(held), len(late))
+    r.close()
+    assert skipped_total > 0, "no cluster was held back and skipped"
+    assert late_total > 0 or not moving, "the moving frames drew nothing late"
+
+
 @pytest.mark.parametrize("preset,kw,step", [("bistro", dict(), 20), ("san_miguel", dict(material_features=24), 0)])
 def test_triangles_of_very_many_bins_take_the_wide_pass_with_the_same_keys(preset, kw, step):
     """Round 6: a triangle that reaches more bins than a wave's LDS window holds (a near floor at 4K: 15 strips x 135 bands) is queued and its records are emitted by a
