@@ -15,10 +15,17 @@ def surface_bytes(rank, frame, nbytes):
     return rng.integers(0, 256, nbytes, dtype=np.uint8)
 
 
+def moving_bounds(frame, world, rows):
+    """Round 6: the partition of frame `frame` under cost-balanced bands -- unequal heights that move from frame to frame (multiples of 8, every band at least 8 rows)."""
+    b = [0] + [k * (rows // world) + 8 * ((frame + 2 * k) % 3 - 1) for k in range(1, world)] + [rows]
+    return b
+
+
 def main():
     root, scratch, rank, world, transport, frames = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5], int(sys.argv[6])
     slabs = int(sys.argv[7]) if len(sys.argv) > 7 else 0          # > 0: every frame goes through brmi_compose_submit_rows in this many slabs of rows
     pipelined = len(sys.argv) > 8 and sys.argv[8] == "pipelined"   # no host wait between frames: the surface is rewritten on the render stream behind brmi_compose_wait_source
+    balanced = len(sys.argv) > 8 and sys.argv[8] == "balanced"     # bands of unequal, moving height at their own rows of the composed frame (brmi_compose_set_bounds)
     sys.path.insert(0, root)
     import torch
     from basicrenderer_amd import compose
@@ -42,9 +49,27 @@ def main():
             out.append(open(path, "rb").read())
         return out
 
-    comp = compose.PeerBandComposer(surf, band, W, 8, depth=2, transport=transport, rank=rank, world=world, exchange=exchange, timeout_ms=20000)
+    comp = compose.PeerBandComposer(surf, band, W, 8, depth=2, transport=transport, rank=rank, world=world, exchange=exchange, timeout_ms=20000, frame_height=rows if balanced else 0)
     last = None
-    if pipelined:
+    if balanced:
+        for f in range(frames):
+            bounds = moving_bounds(f, world, rows)
+            comp.set_bounds(bounds)
+            surf.copy_(torch.from_numpy(surface_bytes(rank, f, nbytes)).to(dev))
+            if rank == 1 and f == 1:
+                time.sleep(0.3)
+            y0, y1 = bounds[rank], bounds[rank + 1]
+            if slabs and y1 - y0 >= 16:      # two slabs of rows on the composer's stream
+                mid = (y0 + (y1 - y0) // 2) // 8 * 8
+                comp.submit_rows(y0, mid); comp.submit_rows(mid, y1)
+            else:
+                comp.submit()
+            last = comp.finish()
+            torch.cuda.synchronize()
+        comp.wait_status()
+        np.save(os.path.join(scratch, f"composed_{rank}.npy"), last.cpu().numpy())
+        frames = 0
+    if pipelined and not balanced:
         # Frames in flight as a renderer has them: every frame's bytes are in HBM already, the "shading" of a frame is a device copy into THE surface on the
         # render stream, the slabs go to the composer's stream, and nothing waits on the host.  One rank is late, so the others' composer streams sit in the
         # wait for its slot while their render streams run on: only brmi_compose_wait_source keeps the next frame's shading off rows that are not copied yet.
@@ -78,7 +103,7 @@ def main():
             comp.submit()
         last = comp.finish()
         torch.cuda.synchronize()
-    if not pipelined:
+    if not pipelined and not balanced:
         comp.wait_status()
         np.save(os.path.join(scratch, f"composed_{rank}.npy"), last.cpu().numpy())
     # both ranks keep their buffers mapped until the other one is done reading

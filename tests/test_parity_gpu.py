@@ -871,6 +871,37 @@ def test_peer_write_composer_with_two_processes_on_one_gpu(transport, tmp_path):
         assert np.array_equal(got, want), f"rank {r}: composed image differs"
 
 
+@pytest.mark.parametrize("transport,world,slabs", [("surface", 2, 0), ("rgb16f", 4, 0), ("surface", 4, 2)])
+def test_peer_write_composer_with_unequal_moving_bands(transport, world, slabs, tmp_path):
+    """Round 6, cost-balanced bands through the peer-write path with 2 and 4 PROCESSES on one GPU: every frame has its own partition (brmi_compose_set_bounds: bands of
+    unequal height that move by 8 rows from frame to frame), every rank stores its band at the band's own rows of every rank's image; whole bands or two slabs of rows.
+    Every rank's composed image of the last frame is THE FRAME: each rank's rows of that frame's partition, byte for byte."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import peer_compose_worker as w
+    from basicrenderer_amd import compose
+    frames = 4
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "peer_compose_worker.py"), ROOT, str(tmp_path), str(r), str(world), transport, str(frames), str(slabs), "balanced"],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    outs = [p.communicate(timeout=300)[0].decode(errors="replace") for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    W, rows = 256, 32 * world
+    nbytes = (W // 8) * (rows // 8) * 64 * 8
+    bounds = w.moving_bounds(frames - 1, world, rows)
+    assert len(set(b1 - b0 for b0, b1 in zip(bounds, bounds[1:]))) > 1, "the last frame's bands are of one height"
+    want = np.zeros(nbytes, dtype=np.uint8)
+    for r in range(world):
+        lo, hi = compose.band_byte_range((bounds[r], bounds[r + 1]), W, 8)
+        want[lo:hi] = w.surface_bytes(r, frames - 1, nbytes)[lo:hi]
+    if transport == "rgb16f":
+        want = want.view(np.int16).reshape(-1, 4)[:, :3].copy()
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), f"composed_{r}.npy"))
+        assert got.shape == want.shape and np.array_equal(got, want), f"rank {r}: composed frame differs"
+
+
 def test_shading_in_row_slabs_reproduces_the_frame_and_reports_the_rows(scenes):
     """brmi_set_shade_slabs: the deferred shading of a frame with coat and fuzz materials (the layered variants run per slab too) in 1, 3 and 5 slabs of
     rows -- the lit target is the same bytes, and the host hook sees every slab once, top to bottom, in multiples of 8 rows covering the frame."""
