@@ -780,18 +780,23 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
 #endif
 }
 
-// The queued triangles (WideTri): a workgroup per triangle, its eight waves take the bin bands in turn -- each steps the row start down to its bands with the serial loop's
+// The queued triangles (WideTri): eight single-wave workgroups per triangle take its bin bands in turn -- each steps the row start down to its bands with the serial loop's
 // additions, exactly as the emitting wave of k_raster does (brmi_raster.hip: "many bins") -- and the lanes of a wave the strips of the band: one slot reservation and one
 // 64 B store per lane, four bands' reservations in flight.  Runs between k_raster and the plan (which reads the bins' final counts).
+// (Single-wave workgroups: the first form, a 512-thread workgroup per triangle, was as fast alone and cost the Zorah-class frame 0.2 ms IN FLIGHT -- eight waves that have to
+// start together on one CU wait for the other frame's shading waves to retire, on the stream the next frame waits for: 2.40 against 2.20 ms, profiles/r06_experiments.md.)
+constexpr uint32_t WIDE_SHARES = 8;
 template <bool ALPHA>
-__global__ void __launch_bounds__(512) k_raster_wide(RasterArgs a) {
+__global__ void __launch_bounds__(64) k_raster_wide(RasterArgs a) {
     wave_prio<PRIO_RASTER>();
     __shared__ float unormT[ALPHA ? 256 : 1];
-    if (ALPHA) { if (threadIdx.x < 256u) unormT[threadIdx.x] = (float)threadIdx.x / 255.0f; __syncthreads(); }
+    if (ALPHA) { for (uint32_t i = threadIdx.x; i < 256u; i += 64u) unormT[i] = (float)i / 255.0f; __syncthreads(); }
     const uint32_t n = min(a.counters[a.wideCounter], a.wideCapacity);
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+    const uint32_t lane = threadIdx.x;
+    constexpr uint32_t waves = WIDE_SHARES;
     const bool striped = stripe_on(a.stripes);
-    for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
+    for (uint32_t item = blockIdx.x; item < n * WIDE_SHARES; item += gridDim.x) {
+        const uint32_t e = item / WIDE_SHARES, wave = item % WIDE_SHARES;
         const WideTri w = load_uniform(&a.wideQueue[e]);
         AlphaRecord arec{};
         const bool alpha = ALPHA && w.base.pad1 != 0u;
@@ -1438,7 +1443,7 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
     a.wideQueue = wideOn ? p->wsPtr<WideTri>(p->ws.wideQueue) : nullptr; a.wideAlpha = p->wsPtr<AlphaRecord>(p->ws.wideAlpha); a.wideCapacity = p->wideCapacity;
     a.wideCounter = phase == 2 ? (uint32_t)CNT_WIDE2 : (uint32_t)CNT_WIDE1; a.wideEntries = p->wideEntries;
     a.wideFeedback = (phase == 1 && p->phase2FeedbackDev) ? p->phase2FeedbackDev + 7 : nullptr;
-    const dim3 wgrid(std::max(32u, std::min(1024u, lastWide)));
+    const dim3 wgrid(std::max(64u, std::min(8192u, lastWide * 8u)));      // eight single-wave workgroups per queued triangle (WIDE_SHARES)
     // (the interleaved partition's surface rows are not the frame rows the boxes are in: there the second build redoes everything)
     a.chainDirty = (BRMI_CHAIN_DIRTY_BLOCKS && phase == 2 && p->stripes.count <= 1u) ? p->wsPtr<uint8_t>(p->ws.chainDirty) : nullptr; a.chainBlocksX = (p->cfg.width + 31u) / 32u;
     p->chainDirtyTracked = a.chainDirty != nullptr;
@@ -1495,12 +1500,12 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
     const dim3 ogrid(phase == 2 && sized2 ? std::max(2u, std::min(129u, hint2 / 4u + 2u)) : 129u);      // (block 0 plans the bins launch; the others walk the overflow queues)
     if (p->sceneHasAlphaTest) {
         hipLaunchKernelGGL(k_raster<true>, rgrid, dim3(64), a.tableCells * 4u, s, a);
-        if (!direct2 && wideOn) hipLaunchKernelGGL(k_raster_wide<true>, wgrid, dim3(512), 0, s, a);
+        if (!direct2 && wideOn) hipLaunchKernelGGL(k_raster_wide<true>, wgrid, dim3(64), 0, s, a);
         if (!direct2) hipLaunchKernelGGL(k_raster_overflow<true>, ogrid, dim3(256), 0, s, a);
         if (!direct2 && !(p->rasterDebug & 4)) hipLaunchKernelGGL(k_raster_bins<true>, bgrid, dim3(BRMI_BIN_THREADS), 0, s, a);
     } else {
         hipLaunchKernelGGL(k_raster<false>, rgrid, dim3(64), a.tableCells * 4u, s, a);
-        if (!direct2 && wideOn) hipLaunchKernelGGL(k_raster_wide<false>, wgrid, dim3(512), 0, s, a);
+        if (!direct2 && wideOn) hipLaunchKernelGGL(k_raster_wide<false>, wgrid, dim3(64), 0, s, a);
         if (!direct2) {
             if (p->binsX * p->binsY > 4096u) hipLaunchKernelGGL((k_raster_overflow<false, 1024>), dim3((ogrid.x - 1u + 3u) / 4u + 1u), dim3(1024), 0, s, a);
             else hipLaunchKernelGGL(k_raster_overflow<false>, ogrid, dim3(256), 0, s, a);
@@ -1534,11 +1539,11 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
         const dim3 lgrid(std::min(p->rasterGrid, std::max(128u, pow2_at_least(std::min(lastLate, 1u << 20) * 16u))));
         if (p->sceneHasAlphaTest) {
             hipLaunchKernelGGL(k_raster<true>, lgrid, dim3(64), l.tableCells * 4u, s, l);
-            if (!directLate && wideOn) hipLaunchKernelGGL(k_raster_wide<true>, wgrid, dim3(512), 0, s, l);
+            if (!directLate && wideOn) hipLaunchKernelGGL(k_raster_wide<true>, wgrid, dim3(64), 0, s, l);
             if (!directLate) { hipLaunchKernelGGL(k_raster_overflow<true>, dim3(129), dim3(256), 0, s, l); hipLaunchKernelGGL(k_raster_bins<true>, dim3(p->binGrid), dim3(BRMI_BIN_THREADS), 0, s, l); }
         } else {
             hipLaunchKernelGGL(k_raster<false>, lgrid, dim3(64), l.tableCells * 4u, s, l);
-            if (!directLate && wideOn) hipLaunchKernelGGL(k_raster_wide<false>, wgrid, dim3(512), 0, s, l);
+            if (!directLate && wideOn) hipLaunchKernelGGL(k_raster_wide<false>, wgrid, dim3(64), 0, s, l);
             if (!directLate) {
                 if (p->binsX * p->binsY > 4096u) hipLaunchKernelGGL((k_raster_overflow<false, 1024>), dim3(33), dim3(1024), 0, s, l);
                 else hipLaunchKernelGGL(k_raster_overflow<false>, dim3(129), dim3(256), 0, s, l);
