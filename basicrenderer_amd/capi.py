@@ -222,7 +222,7 @@ def scene_lib():
 BRMI_EXPORTS = ["brmi_abi_version", "brmi_default_config", "brmi_create", "brmi_declare", "brmi_set_scene", "brmi_setup", "brmi_set_band",
                 "brmi_update", "brmi_execute", "brmi_execute_split", "brmi_destroy", "brmi_last_error", "brmi_clear_visibility", "brmi_cull",
                 "brmi_raster", "brmi_depth_copy", "brmi_build_hzb", "brmi_invalidate_hzb", "brmi_set_history_source", "brmi_gbuffer", "brmi_light_clustering",
-                "brmi_shade", "brmi_set_shade_slabs", "brmi_read_counters", "brmi_stage_times", "brmi_set_timed_stages", "brmi_algorithmic_bytes", "brmi_algorithmic_bytes_launched", "brmi_debug_arith", "brmi_debug_arith_in_range", "brmi_debug_read_bin_records", "brmi_debug_wide_triangles", "brmi_debug_read_held"]
+                "brmi_shade", "brmi_set_shade_slabs", "brmi_read_counters", "brmi_stage_times", "brmi_set_timed_stages", "brmi_algorithmic_bytes", "brmi_algorithmic_bytes_launched", "brmi_debug_arith", "brmi_debug_arith_in_range", "brmi_debug_read_bin_records", "brmi_debug_wide_triangles", "brmi_debug_lean_clusters", "brmi_debug_read_lean_queue", "brmi_debug_read_held"]
 
 
 def brmi_lib():

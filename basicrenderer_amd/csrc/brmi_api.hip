@@ -172,6 +172,9 @@ static void compute_sizes(brmi_pass* p) {
     w.pageBoxBase = take((uint64_t)std::max<size_t>(1, p->hostPageBoxBase.size()) * 4);
     w.pageRefs = take((uint64_t)std::max<size_t>(1, p->hostPageRefs.size()) * sizeof(PageRef));
     w.drawList = take(p->holdEnabled ? (uint64_t)c.maxVisibleClusters * 4 : 16);
+    w.generalList = take(p->leanMinClusters != 0u ? (uint64_t)c.maxVisibleClusters * 4 : 16);
+    w.bigQueue = take(p->leanMinClusters != 0u ? (uint64_t)p->leanQueue * 96 : 16);      // WideTri
+    w.bigRuns = take(p->leanMinClusters != 0u ? (uint64_t)p->leanQueue * 8 : 16);
     w.heldRecords = take(p->holdEnabled ? (uint64_t)c.maxVisibleClusters * sizeof(HeldRecord) : 16);
     w.lateList = take(p->holdEnabled ? (uint64_t)c.maxVisibleClusters * 4 : 16);
     w.wideQueue = take((uint64_t)std::max(1u, p->wideCapacity) * 96);      // WideTri (brmi_raster.hip)
@@ -275,6 +278,12 @@ int brmi_create(const brmi_config* cfg, brmi_pass** out) {
     p->resolveInlineMode = (int)tuning("resolve_inline", -1);
     p->wideCapacity = (uint32_t)std::min(1l << 20, std::max(0l, tuning("wide_capacity", p->wideCapacity)));
     p->wideMinTriangles = (uint32_t)std::max(0l, tuning("wide_min_triangles", p->wideMinTriangles));
+    p->leanMinClusters = (uint32_t)std::max(0l, tuning("lean_min_clusters", p->leanMinClusters));
+    p->leanMaxGeneralPct = (uint32_t)std::max(0l, std::min(100l, tuning("lean_max_general_pct", p->leanMaxGeneralPct)));
+    p->leanGrid = (uint32_t)std::max(64l, tuning("lean_grid", p->leanGrid));
+    p->leanQueue = (uint32_t)std::max(64l, std::min(1l << 24, tuning("lean_queue", p->leanQueue))) & ~63u;      // (64 stripes)
+    p->leanWideEntries = (uint32_t)std::max(1l, tuning("lean_wide_entries", p->leanWideEntries));
+    p->leanEmitGrid = (uint32_t)std::max(64l, std::min(65536l, tuning("lean_emit_grid", p->leanEmitGrid))) & ~63u;
     p->wideEntries = (uint32_t)std::max(1l, tuning("wide_entries", p->wideEntries));
     p->binMinSlice = (uint32_t)std::max(32l, tuning("bin_min_slice", p->binMinSlice));
     p->binSharedSlice = (uint32_t)std::max(32l, tuning("bin_shared_slice", p->binSharedSlice));
@@ -1040,6 +1049,29 @@ int brmi_debug_wide_triangles(brmi_pass* p, uint32_t out[3]) {
     BRMI_HIP(p, hipMemcpy(&c[1], p->counters() + CNT_WIDE1B, 4, hipMemcpyDeviceToHost));
     BRMI_HIP(p, hipMemcpy(&c[2], p->counters() + CNT_WIDE2, 4, hipMemcpyDeviceToHost));
     out[0] = c[0]; out[1] = c[1]; out[2] = c[2];
+    return BRMI_OK;
+}
+
+int brmi_debug_lean_clusters(brmi_pass* p, uint32_t out[4]) {
+    if (!p || !out || !p->setupDone) return BRMI_ERR_INVALID;
+    BRMI_HIP(p, hipDeviceSynchronize());
+    uint32_t c = 0u, heads[64 * 32];
+    BRMI_HIP(p, hipMemcpy(&c, p->counters() + CNT_GENERAL1, 4, hipMemcpyDeviceToHost));
+    BRMI_HIP(p, hipMemcpy(heads, p->counters() + CNT_BIG1, sizeof(heads), hipMemcpyDeviceToHost));
+    out[0] = p->leanLastLaunch ? 1u : 0u; out[1] = c; out[2] = out[3] = 0u;
+    for (uint32_t s = 0; s < 64u; s++) { out[2] += heads[s * 32u]; out[3] += heads[s * 32u + 1u]; }
+    return BRMI_OK;
+}
+
+int brmi_debug_read_lean_queue(brmi_pass* p, uint32_t stripe, uint32_t* runs, uint32_t maxRuns, void* entries, uint32_t maxEntries, uint32_t counts[2]) {
+    if (!p || !counts || !p->setupDone || stripe >= 64u || p->leanMinClusters == 0u) return BRMI_ERR_INVALID;
+    BRMI_HIP(p, hipDeviceSynchronize());
+    uint32_t head[2];
+    BRMI_HIP(p, hipMemcpy(head, p->counters() + CNT_BIG1 + stripe * 32u, 8, hipMemcpyDeviceToHost));
+    const uint32_t cap = p->leanQueue / 64u;
+    counts[0] = std::min(head[0], cap); counts[1] = std::min(head[1], cap);
+    if (runs) BRMI_HIP(p, hipMemcpy(runs, p->wsPtr<uint8_t>(p->ws.bigRuns) + (size_t)stripe * cap * 8u, (size_t)std::min(maxRuns, counts[1]) * 8u, hipMemcpyDeviceToHost));
+    if (entries) BRMI_HIP(p, hipMemcpy(entries, p->wsPtr<uint8_t>(p->ws.bigQueue) + (size_t)stripe * cap * 96u, (size_t)std::min(maxEntries, counts[0]) * 96u, hipMemcpyDeviceToHost));
     return BRMI_OK;
 }
 

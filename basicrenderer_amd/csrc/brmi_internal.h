@@ -57,7 +57,9 @@ enum CounterIndex : uint32_t {
     CNT_DRAWN_VT = CNT_BUCKETS + 256,       // ONE 64-bit word (even index): vertex | triangle << 32 sums of the clusters that ARE rasterised in phase 1 (draw list + late list)
     // round 6: triangles whose records a workgroup emits (k_raster_wide): queue lengths of the phase-1 draw pass, the late pass and phase 2
     CNT_WIDE1 = CNT_BUCKETS + 288, CNT_WIDE1B = CNT_BUCKETS + 320, CNT_WIDE2 = CNT_BUCKETS + 352,
-    CNT_WORDS = CNT_BUCKETS + 384
+    CNT_GENERAL1 = CNT_BUCKETS + 384,       // round 6: clusters the lean rasteriser left to the general launch behind it (k_raster<false, true>)
+    CNT_BIG1 = CNT_BUCKETS + 416,           // ... and its queue of triangles large enough for the bins (k_raster_emit): 64 stripes x 32 words, a 64-bit head (entries | runs << 32) in the first two
+    CNT_WORDS = CNT_BUCKETS + 416 + 64 * 32
 };
 static_assert((CNT_DRAWN_VT & 1u) == 0u, "64-bit counter");
 
@@ -231,7 +233,7 @@ struct Workspace {     // byte offsets into BRMI_RES_WORKSPACE
     uint64_t counters, frontierA, frontierB, buckets, tempVisible, bitmask1, bitmask2, blockDirty, chainDirty, wordPrefix, blockSums,
              instanceBitBase, segPrefix, meshLevelWidth, scanAgg, flatNodes, flatLeaves, instanceWalk, planes, replayNodes, replayBuckets, lightVS, lightMeta, clusterPages, clusterHits, pageTotal, lightHitMasks, binCounts, binRecords, binOverflow, binPlan, binItems, binScratch, clusterSetup, resolveVerts, resolveTris, matWords, shadeTables, lutF, frameConst, objConst, matConst, deferredPixels,
              frameSnapshot, debugStamps, clusterUv, binAlpha, overflowAlpha, resolveUVs, resolveColors, alphaMats, shadeRows, shadeAvgs, ggxQuads, shadeLights, clusterList, listEntries, listRecords, layerUniform,
-             meshletBoxes, pageBoxBase, pageRefs, drawList, heldRecords, lateList, wideQueue, wideAlpha, frameClearBytes, total;
+             meshletBoxes, pageBoxBase, pageRefs, drawList, heldRecords, lateList, wideQueue, wideAlpha, generalList, bigQueue, bigRuns, frameClearBytes, total;
 };
 
 }  // namespace brmi
@@ -273,6 +275,11 @@ struct brmi_pass {
     uint32_t chainStripLo = 0xFFFFFFFFu, chainStripHi = 0u;   // 32-row strips of the chain that hold texels of a band (a band that moves: the next full build also resets the strips it left)
     uint32_t wideCapacity = 16384;   // triangles the wide queue holds (BRMI_TUNING wide_capacity; 0 = every triangle is emitted by its own wave); beyond it the wave emits them itself
     uint32_t wideEntries = 128;      // ... and, while it is launched, triangles of more bin entries than this go to it (BRMI_TUNING wide_entries; without it a lane keeps up to 512)
+    // the lean rasteriser (brmi_raster.hip, k_raster<false, true>): phase 1's main launch of frames whose last such launch the host has seen had at least leanMinClusters
+    // clusters (0 = never), while at most leanMaxGeneralPct % of them come back for the general launch (else off for 64 frames).  BRMI_TUNING lean_min_clusters,
+    // lean_max_general_pct, lean_grid.
+    uint32_t leanMinClusters = 32768, leanMaxGeneralPct = 40, leanGrid = 24576, leanEmitGrid = 4096, leanWideEntries = 16, leanQueue = 1u << 20;      // leanQueue: entries of the binned-triangle queue (96 B each; lean_queue)
+    bool leanActive = false, leanLastLaunch = false; uint32_t leanRetryIn = 0;
     uint32_t wideMinTriangles = 4;   // the wide pass is launched while the last frame the host has seen queued at least this many (BRMI_TUNING wide_min_triangles)
     bool chainBuiltInRaster = false; // this frame's phase-1 rasteriser stage built the chain itself (before its re-test): the build that follows redoes the late pass's blocks only
     bool sceneHasVertexColors = false;                           // some mesh's pages carry vertex colours (perMesh.vertexFlags bit 0)

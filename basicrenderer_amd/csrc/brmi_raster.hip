@@ -93,6 +93,13 @@ struct RasterArgs {
     uint32_t firstCounter, countCounter;   // counter indices: first cluster (0xFFFFFFFF = 0) and cluster count
     const uint32_t* drawList;              // round 6: null = clusters first .. first + count of the visible list; else the `count` cluster indices to rasterise (draw list, late list)
     uint32_t* countFeedback;               // host-mapped word or null: the launch's cluster count, for the sizes of the frames that follow
+    // round 6, k_raster<false, true> (the lean form): clusters it leaves to the general kernel -- a binned triangle, skinned vertices -- are named here
+    uint32_t* generalList; uint32_t generalCounter; uint32_t* generalFeedback;
+    // ... and its triangles large enough for the bins are queued (WideTri) for k_raster_emit; a full queue sends the cluster to the general list instead
+    // The queue is 64 stripes (a wave appends to stripe blockIdx & 63: one head per 128 B line -- a single head serialises the launch's appends at ~100 per microsecond),
+    // each `bigCapacity` entries and as many runs: a run is what one wave appended of one pass, {first entry, count}, and k_raster_emit takes a run per wave and step, so
+    // the 64 triangles a wave emits are one cluster's, as in k_raster.  Head of stripe s: the 64-bit word at counters[bigCounter + 32 s], entries | runs << 32.
+    WideTri* bigQueue; uint2* bigRuns; uint32_t bigCapacity, bigCounter, emitWideEntries;
     unsigned long long* vis;
     uint32_t visW, visH, tilesX, bandY0, bandY1;      // visW x visH: the FRAME (scissor clamp); bandY0 / bandY1: rows of the surface this GPU renders (records live in surface rows)
     uint32_t rowLo, rowHi;                            // frame rows k_raster looks at: the band, or the whole frame with the interleaved partition ...
@@ -290,8 +297,18 @@ BRMI_DEV void bin_append(const RasterArgs& a, const float* unorm, const BinRecor
 #ifndef BRMI_RASTER_SPLIT_FIRST
 #define BRMI_RASTER_SPLIT_FIRST 2u
 #endif
-template <bool ALPHA>
-__global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RASTER_WAVES) k_raster(RasterArgs a) {
+// LEAN (round 6): the kernel for frames of very many clusters of small triangles (the Zorah-class frame: 284 k clusters in the draw list, 62 M triangles for 33 M pixels).
+// Such a launch is a queue of per-cluster round-trip chains (record -> vertices -> setup -> atomics), and what hides them is waves per SIMD: the general kernel holds
+// 132 registers for paths these clusters never take (bin windows, the cooperative emission, alpha, skinning, the interleaved partition) and runs three.  The lean
+// instantiation compiles those paths out and runs BRMI_RASTER_LEAN_WAVES; a cluster that needs one of them (a triangle large enough for the bins, skinned vertices)
+// is put on `generalList` and drawn whole by a general launch behind this one -- keys are order-free and idempotent, so what the lean wave had already written of
+// it is written again, nothing else.  Same arithmetic per vertex, triangle and pixel: the code below is the same code.
+#ifndef BRMI_RASTER_LEAN_WAVES
+#define BRMI_RASTER_LEAN_WAVES 6
+#endif
+template <bool ALPHA, bool LEAN = false>
+__global__ void __launch_bounds__(64, LEAN ? BRMI_RASTER_LEAN_WAVES : (ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RASTER_WAVES)) k_raster(RasterArgs a) {
+    static_assert(!(ALPHA && LEAN), "the lean form has no alpha test");
     wave_prio<PRIO_RASTER>();
     // (one wave per workgroup: LDS hand-offs between its lanes need wave_lds_sync() only.  __syncthreads() also waits for every global store
     // and atomic the wave has in flight -- the record stores and the small boxes' atomic-mins: a memory round trip per hand-off.)
@@ -330,7 +347,7 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
     // clusters with large near triangles, where a cluster is 20 k bin records from one wave, takes two waves per cluster: raster 0.345 -> 0.32 ms at position
     // 20 of the bench's path; a Sponza-class frame of 1.5 k clusters keeps four per cluster, eight cost it 10 us.  A larger grid does the same for the
     // rasteriser alone, but 8,192 more waves that find nothing each wait for a slot beside the other frame's shading waves.)
-    if (!(a.debugFlags & 0x40000000u)) { while (split < 8u && count * split * 2u <= (split == 1u ? BRMI_RASTER_SPLIT_FIRST * gridDim.x : gridDim.x)) split *= 2u; }
+    if (!LEAN && !(a.debugFlags & 0x40000000u)) { while (split < 8u && count * split * 2u <= (split == 1u ? BRMI_RASTER_SPLIT_FIRST * gridDim.x : gridDim.x)) split *= 2u; }
     const uint32_t parts = max(split >> 1, 1u), lanesPerPart = 64u / parts;      // shares of a pass
     const uint32_t items = count * split;
 #ifdef BRMI_TILE_STAMPS
@@ -375,6 +392,7 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
         const uint32_t clusterIndex = a.drawList ? (uint32_t)__builtin_amdgcn_readfirstlane((int)listed) : first + c;
         if (a.drawList && item + gridDim.x < items) listed = kconst(a.drawList)[first + (item + gridDim.x) / split];
         const ClusterSetup cs = load_uniform(&a.setup[clusterIndex]);        // resolved by the compaction kernel: one hop instead of six
+        bool toGeneral = LEAN && (cs.counts & BRMI_CS_SKINNED) != 0u;      // (wave-uniform)
         const uint32_t vertCount = cs.counts & 0xFFu, triCount = (cs.counts >> 8) & 0xFFu, posFormat = (cs.counts >> 16) & 0xFFu;
         const uint32_t passLo = split > 1u ? (sub / parts) * 64u : 0u, passHi = split > 1u ? min(passLo + 64u, triCount) : triCount;
         const uint32_t part = sub % parts;
@@ -401,7 +419,7 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
             if (passLo + k * 64u < passHi && t < triCount) { pi0[k] = triBase[t * 3u]; pi1[k] = triBase[t * 3u + 1u]; pi2[k] = triBase[t * 3u + 2u]; }
         }
         // compute skinning, folded into the vertex fetch (softwareRaster.hlsl:349-360)
-        const bool skinVerts = (cs.counts & (BRMI_CS_SKINNED | BRMI_CS_JOINTS)) == (BRMI_CS_SKINNED | BRMI_CS_JOINTS);
+        const bool skinVerts = !LEAN && (cs.counts & (BRMI_CS_SKINNED | BRMI_CS_JOINTS)) == (BRMI_CS_SKINNED | BRMI_CS_JOINTS);
         const uint32_t skinSlot = skinVerts ? sc.perMeshInstance[cs.instanceIndex].skinningInstanceSlot : 0xFFFFFFFFu;
         const bool alphaCluster = ALPHA && (cs.counts & BRMI_CS_ALPHA) != 0u;
         ClusterUv cu{nullptr, nullptr};
@@ -411,6 +429,7 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
         if (a.debugFlags & 0x100) { const float probe_ = mvp.m[0][0] + modelViewZ.x + visWidth; if (probe_ == 1234.5f) a.counters[CNT_DROPPED_CLUSTERS] = 1u; }   // (instrumented runs: the cluster's records have arrived)
         KSTAMP(0);
         // vertex stage -> LDS (softwareRaster.hlsl:339-387)
+        if (!toGeneral)
         for (uint32_t v = lane; v < vertCount; v += 64) {
             f3 lp{0.0f, 0.0f, 0.0f};
             if (posFormat == BRMI_POSITION_FORMAT_FLOAT3) {
@@ -436,7 +455,7 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
         KSTAMP(1);
 
         // triangle stage: lane = triangle (softwareRaster.hlsl:416-611)
-        for (uint32_t waveBase = passLo; waveBase < passHi; waveBase += 64) {
+        for (uint32_t waveBase = passLo; waveBase < passHi && !toGeneral; waveBase += 64) {
             const uint32_t t = waveBase + lane;
             bool active = t < triCount;
             float d0 = 0, d1 = 0, d2 = 0, row_b0 = 0, row_b1 = 0, dx_b0 = 0, dx_b1 = 0, dy_b0 = 0, dy_b1 = 0;
@@ -475,7 +494,7 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
                 }
             }
             const int rectWidth = maxX - minX + 1;
-            if (a.chainDirty && active) {
+            if (!LEAN && a.chainDirty && active) {
                 // round 5 (phase 2 only, wave-uniform): what phase 2 draws is small; the chain's second build then only redoes the 32 x 32 px blocks a phase-2 triangle's
                 // box touches.  A byte per block, plain stores of 1 (every writer stores the same): no atomic (they serialise on a line), nothing to wait for.
                 const int cy0 = max(minY, (int)a.rowLo), cy1 = min(maxY, (int)a.rowHi - 1);
@@ -490,13 +509,41 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
             const int rows = maxY - minY + 1;
             // frames of many small clusters bin from 32 px on (the row re-deal's global atomics are what their waves wait for: 34-35 % of the
             // kernel's wave-cycles, phase stamps); frames of few large clusters keep 64 (measured both ways, profiles/r03_experiments.md)
-            const bool big = active && rows * rectWidth > (alphaCluster ? a.bigTriAreaAlpha : (count >= a.denseClusterCount ? a.bigTriAreaDense : a.bigTriArea));
+            const bool bigHere = active && rows * rectWidth > (alphaCluster ? a.bigTriAreaAlpha : (count >= a.denseClusterCount ? a.bigTriAreaDense : a.bigTriArea));
+            const bool big = !LEAN && bigHere;
             // bins the box overlaps (rows clipped to this GPU's band)
             const int yLo = max(minY, (int)a.rowLo), yHi = min(maxY, (int)a.rowHi - 1);
+            if (LEAN) {
+                // the lean form sets a binned triangle up and hands it on: its records are emitted by k_raster_emit, from the queue (one slot reservation per wave and pass)
+                const bool queue = bigHere && yLo <= yHi;
+                const uint64_t qm = __ballot(queue);
+                if (qm != 0ull) {
+                    const int leader = __ffsll((unsigned long long)qm) - 1;
+                    const uint32_t stripe = blockIdx.x & 63u, nq = (uint32_t)__popcll(qm);
+                    unsigned long long head = 0ull;
+                    if ((int)lane == leader) head = atomicAdd(reinterpret_cast<unsigned long long*>(&a.counters[a.bigCounter + stripe * 32u]), (1ull << 32) | (unsigned long long)nq);
+                    const uint32_t first = (uint32_t)__shfl((int)(uint32_t)head, leader), run = (uint32_t)__shfl((int)(uint32_t)(head >> 32), leader);
+                    const bool fits = first + nq <= a.bigCapacity && run < a.bigCapacity;      // (wave-uniform)
+                    if ((int)lane == leader && run < a.bigCapacity) a.bigRuns[(size_t)stripe * a.bigCapacity + run] = fits ? uint2{first, nq} : uint2{0u, 0u};
+                    if (queue && fits) {
+                        const uint32_t slot = stripe * a.bigCapacity + first + lane_rank(qm);
+                        float qb0 = row_b0, qb1 = row_b1;
+                        for (int y = minY; y < yLo; y++) { qb0 += dy_b0; qb1 += dy_b1; }      // (the serial loop's additions down to this GPU's first row of the box)
+                        WideTri w;
+                        w.base.clusterIndex = clusterIndex; w.base.triAndFlags = t | (useScanlineRanges ? 0x100u : 0u); w.base.minX = minX; w.base.rectWidth = rectWidth; w.base.rowStart = yLo;
+                        w.base.sb0 = qb0; w.base.sb1 = qb1; w.base.dx_b0 = dx_b0; w.base.dx_b1 = dx_b1; w.base.dy_b0 = dy_b0; w.base.dy_b1 = dy_b1; w.base.d0 = d0; w.base.d1 = d1; w.base.d2 = d2;
+                        w.base.pad0 = 0u; w.base.pad1 = 0u;
+                        w.yHi = yHi; w.band0 = yLo >> BIN_ROWS_SHIFT; w.band1 = yHi >> BIN_ROWS_SHIFT; w.strip0 = minX >> BIN_W_SHIFT; w.strip1 = maxX >> BIN_W_SHIFT; w.pad[0] = w.pad[1] = w.pad[2] = 0u;
+                        a.bigQueue[slot] = w;
+                    }
+                    // (a full queue: the general launch draws the whole cluster; what is in the queue of it already is then drawn twice -- the same keys)
+                    if (!fits) toGeneral = true;
+                }
+            }
             const int band0 = yLo >> BIN_ROWS_SHIFT, band1 = yHi >> BIN_ROWS_SHIFT, strip0 = minX >> BIN_W_SHIFT, strip1 = maxX >> BIN_W_SHIFT;
             // interleaved partition: a 16-row bin band of the frame is owned whole or not at all (chunks are multiples of 16 rows); an owned
             // one is bin band `vband` of this GPU's surfaces
-            const bool striped = stripe_on(a.stripes);
+            const bool striped = !LEAN && stripe_on(a.stripes);
             auto owns_band = [&](int band) { return !striped || stripe_owns(a.stripes, (uint32_t)band << BIN_ROWS_SHIFT); };
             auto vband = [&](int band) { return striped ? stripe_vrow(a.stripes, (uint32_t)band << BIN_ROWS_SHIFT) >> BIN_ROWS_SHIFT : (uint32_t)band; };
             const int nStrips = strip1 - strip0 + 1;
@@ -572,7 +619,7 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
             // Round 5: a pass whose small boxes are ALL at most BRMI_RASTER_TINY x BRMI_RASTER_TINY pixels (frames of sub-pixel triangles: the Zorah-class frame rasterises 62 M
             // triangles for 33 M pixels) is walked lane = triangle -- no prefix scan, no parking of thirteen values per triangle in LDS, no bisection per row task: the re-deal
             // exists to balance boxes of very different size, and these are all the same.  Same arithmetic per pixel (raster_row from the box's first row).
-            const bool smallHere = active && !big && !(a.debugFlags & 1) && yLo <= yHi;
+            const bool smallHere = active && !bigHere && !(a.debugFlags & 1) && yLo <= yHi;
             const bool tinyPass = BRMI_RASTER_TINY > 0 && !striped && !alphaCluster && (BRMI_RASTER_TINY_RANGES || !useScanlineRanges) && !__any(smallHere && (maxY - minY + 1) > BRMI_RASTER_TINY);
             if (tinyPass) {
                 if (smallHere) {
@@ -767,6 +814,7 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
             }
             KSTAMP(5);
         }
+        if (LEAN && toGeneral && lane == 0u) a.generalList[atomicAdd(&a.counters[a.generalCounter], 1u)] = clusterIndex;
         wave_lds_sync();   // LDS is reused by the next cluster
     }
     if (ALPHA && rqTail != rqHead) rq_drain(rqTail - rqHead);
@@ -778,6 +826,127 @@ __global__ void __launch_bounds__(64, ALPHA ? BRMI_RASTER_ALPHA_WAVES : BRMI_RAS
         if (tot > before) for (int k = 0; k < 8; k++) a.debugStamps[40 + k] = kph[k];      // (racy between near-equal waves: a diagnostic)
     }
 #endif
+}
+
+// The lean rasteriser's binned triangles (RasterArgs::bigQueue), 64 queue entries per wave and step: the record emission of k_raster on its own -- per-bin counts in
+// the LDS window, one reservation per bin and wave, slots handed out from LDS; triangles of more entries than the window rule allows are emitted by the whole wave, or
+// go on to the wide queue.  Consecutive entries are triangles of one cluster (a wave of k_raster<false, true> appends a pass's triangles together), so a wave's bins
+// are as few as they were there.  Records, and so keys, as k_raster writes them.
+__global__ void __launch_bounds__(64) k_raster_emit(RasterArgs a) {
+    wave_prio<PRIO_RASTER>();
+    extern __shared__ uint32_t binBase[];          // a.tableCells words
+    const uint32_t lane = threadIdx.x;
+    const uint32_t stripe = blockIdx.x & 63u;
+    const uint32_t nRuns = min((uint32_t)__builtin_amdgcn_readfirstlane((int)a.counters[a.bigCounter + stripe * 32u + 1u]), a.bigCapacity);
+    const AlphaRecord noAlpha{};
+    for (uint32_t run = blockIdx.x >> 6; run < nRuns; run += gridDim.x >> 6) {
+        const uint2 rd = load_uniform(&a.bigRuns[(size_t)stripe * a.bigCapacity + run]);
+        const bool have = lane < rd.y;
+        WideTri w{};
+        if (have) w = a.bigQueue[(size_t)stripe * a.bigCapacity + rd.x + lane];
+        w.pad[0] = w.pad[1] = w.pad[2] = 0u;      // (what the writer stored there; said here so that the three words are not carried -- in scratch -- to the wide queue's store)
+        const int nStrips = w.strip1 - w.strip0 + 1;
+        int entries = have ? (w.band1 - w.band0 + 1) * nStrips : 0;
+#ifdef BRMI_EXPERIMENTS
+        if (a.debugFlags & 0x200) { if (w.base.sb0 == 1234.5f && w.yHi == -77) a.counters[CNT_DROPPED_CLUSTERS] = 1u; entries = 0; }      // (timing runs: the entries have arrived, nothing is emitted)
+#endif
+        // (the wide pass takes this kernel's triangles from 16 entries on, not 128: a lane's records are emitted one after the other and the launch lasts as long as its longest
+        // lane -- 144 us at 128, 73 at 16, 61 at 8 for the Zorah-class frame's 573 k queued triangles, k_raster_wide 22 us either way; profiles/r06_experiments.md)
+        const int coopEntries = a.wideQueue ? (int)a.emitWideEntries : (a.tableCells > (uint32_t)BIN_WINDOW ? COOP_ENTRIES_TABLE : COOP_ENTRIES);
+        const bool few = entries > 0 && entries <= coopEntries;
+        bool fewW = few;
+        int wb0 = 0, ws0 = 0, winW = 1, cells = 0; bool windowed = false;
+        if (__any(few)) {
+            int wb1 = few ? w.band1 : -1, ws1 = few ? w.strip1 : -1;
+            wb0 = few ? w.band0 : 0x7FFFFFFF; ws0 = few ? w.strip0 : 0x7FFFFFFF;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                wb0 = min(wb0, __shfl_xor(wb0, o)); wb1 = max(wb1, __shfl_xor(wb1, o));
+                ws0 = min(ws0, __shfl_xor(ws0, o)); ws1 = max(ws1, __shfl_xor(ws1, o));
+            }
+            winW = ws1 - ws0 + 1; cells = (wb1 - wb0 + 1) * winW;
+            windowed = cells <= (int)a.tableCells;      // wave-uniform
+            fewW = few && (windowed || entries <= COOP_ENTRIES);
+            if (windowed) {
+                for (int cI = (int)lane; cI < cells; cI += 64) binBase[cI] = 0u;
+                wave_lds_sync();
+                if (few) for (int sb = w.band0; sb <= w.band1; sb++) for (int st = w.strip0; st <= w.strip1; st++) atomicAdd(&binBase[(sb - wb0) * winW + (st - ws0)], 1u);
+                wave_lds_sync();
+                // counts -> bases in place, four reservations in flight per lane and round
+                for (int c0 = 0; c0 < cells; c0 += 256) {
+                    uint32_t cnt[4], rb[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { const int cI = c0 + (int)lane + 64 * k; cnt[k] = cI < cells ? binBase[cI] : 0u; }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { const int cI = c0 + (int)lane + 64 * k; rb[k] = cnt[k] != 0u ? atomicAdd(&a.binCounts[(size_t)((uint32_t)(wb0 + cI / winW) * a.binsX + (uint32_t)(ws0 + cI % winW)) * BIN_COUNT_STRIDE], cnt[k]) : 0u; }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { const int cI = c0 + (int)lane + 64 * k; if (cnt[k] != 0u) binBase[cI] = rb[k]; }
+                }
+                wave_lds_sync();
+            }
+#ifdef BRMI_EXPERIMENTS
+            if (a.debugFlags & 0x400) { if (windowed) wave_lds_sync(); continue; }      // (timing runs: counted and reserved, no record stored)
+#endif
+            if (fewW) {
+                // step the row start band by band (the additions of the serial loop) and append one record per band and strip
+                float sb0 = w.base.sb0, sb1 = w.base.sb1;
+                int py = w.base.rowStart;
+                while (py <= w.yHi) {
+                    const int band = py >> BIN_ROWS_SHIFT;
+                    const int rows = min(((band + 1) << BIN_ROWS_SHIFT), w.yHi + 1) - py;
+                    BinRecord r = w.base;
+                    r.triAndFlags = w.base.triAndFlags | ((uint32_t)rows << 16); r.rowStart = py; r.sb0 = sb0; r.sb1 = sb1;
+                    for (int st = w.strip0; st <= w.strip1; st++) {
+                        if (windowed) bin_store(a, nullptr, r, noAlpha, (uint32_t)st, (uint32_t)band, atomicAdd(&binBase[(band - wb0) * winW + (st - ws0)], 1u));
+                        else bin_append(a, nullptr, r, noAlpha, (uint32_t)st, (uint32_t)band);
+                    }
+                    for (int k = 0; k < rows; k++) { sb0 += w.base.dy_b0; sb1 += w.base.dy_b1; }
+                    py += rows;
+                }
+            }
+            if (windowed) wave_lds_sync();    // binBase is reused by the next step
+        }
+        // many bins: the wide queue takes the triangle, or the whole wave emits it (lane L owns bands band0 + L, band0 + L + 64, ...)
+        const bool isCoop = entries > 0 && !fewW;
+        uint64_t coop = __ballot(isCoop);
+        const bool wideCand = entries > (int)a.emitWideEntries;
+        const uint64_t candM = __ballot(wideCand);
+        if (candM != 0ull) {
+            const int leader = __ffsll((unsigned long long)candM) - 1;
+            uint32_t slot = 0u;
+            if ((int)lane == leader) slot = atomicAdd(&a.counters[a.wideCounter], (uint32_t)__popcll(candM));
+            slot = (uint32_t)__shfl((int)slot, leader) + lane_rank(candM);
+            const bool queued = wideCand && a.wideQueue != nullptr && slot < a.wideCapacity;
+            if (queued) a.wideQueue[slot] = w;
+            coop = __ballot(isCoop && !queued);
+        }
+        while (coop != 0ull) {
+            const int src = __ffsll((unsigned long long)coop) - 1;
+            coop &= coop - 1ull;
+            BinRecord r;
+            r.clusterIndex = (uint32_t)__shfl((int)w.base.clusterIndex, src); r.minX = __shfl(w.base.minX, src); r.rectWidth = __shfl(w.base.rectWidth, src);
+            r.dx_b0 = __shfl(w.base.dx_b0, src); r.dx_b1 = __shfl(w.base.dx_b1, src); r.dy_b0 = __shfl(w.base.dy_b0, src); r.dy_b1 = __shfl(w.base.dy_b1, src);
+            r.d0 = __shfl(w.base.d0, src); r.d1 = __shfl(w.base.d1, src); r.d2 = __shfl(w.base.d2, src); r.pad0 = 0u; r.pad1 = 0u;
+            const uint32_t c_flags = (uint32_t)__shfl((int)w.base.triAndFlags, src);
+            const int c_yLo = __shfl(w.base.rowStart, src), c_yHi = __shfl(w.yHi, src), c_band0 = __shfl(w.band0, src), c_band1 = __shfl(w.band1, src);
+            const int c_strip0 = __shfl(w.strip0, src), c_strip1 = __shfl(w.strip1, src);
+            float sb0 = __shfl(w.base.sb0, src), sb1 = __shfl(w.base.sb1, src);
+            int py = c_yLo;
+            for (int band = c_band0 + (int)lane; band <= c_band1; band += 64) {
+                const int start = max(band << BIN_ROWS_SHIFT, c_yLo);
+                for (; py < start; py++) { sb0 += r.dy_b0; sb1 += r.dy_b1; }
+                const int rows = min(((band + 1) << BIN_ROWS_SHIFT), c_yHi + 1) - start;
+                r.triAndFlags = c_flags | ((uint32_t)rows << 16); r.rowStart = start; r.sb0 = sb0; r.sb1 = sb1;
+                for (int st0 = c_strip0; st0 <= c_strip1; st0 += 8) {
+                    uint32_t slots[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) slots[k] = (st0 + k <= c_strip1) ? atomicAdd(&a.binCounts[(size_t)((uint32_t)band * a.binsX + (uint32_t)(st0 + k)) * BIN_COUNT_STRIDE], 1u) : 0u;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) if (st0 + k <= c_strip1) bin_store(a, nullptr, r, noAlpha, (uint32_t)(st0 + k), (uint32_t)band, slots[k]);
+                }
+            }
+        }
+    }
 }
 
 // The queued triangles (WideTri): eight single-wave workgroups per triangle take its bin bands in turn -- each steps the row start down to its bands with the serial loop's
@@ -1431,7 +1600,7 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
     a.sc = p->scene; a.clusters = static_cast<const uint4*>(p->res[BRMI_RES_VISIBLE_CLUSTERS]); a.counters = p->counters();
     a.setup = p->wsPtr<ClusterSetup>(p->ws.clusterSetup);
     a.firstCounter = 0xFFFFFFFFu; a.countCounter = CNT_VISIBLE;
-    a.drawList = nullptr; a.countFeedback = nullptr;
+    a.drawList = nullptr; a.countFeedback = nullptr; a.generalList = nullptr; a.generalCounter = CNT_GENERAL1; a.generalFeedback = nullptr; a.bigQueue = nullptr; a.bigRuns = nullptr; a.bigCapacity = 0u; a.bigCounter = CNT_BIG1; a.emitWideEntries = p->leanWideEntries;
     // round 6: a frame whose culling held clusters back (launch_cull) rasterises its draw list here, re-tests the held clusters against the keys that leaves, and
     // draws the ones it cannot prove hidden in a late pass -- all inside this stage, before anything reads the phase-1 depth (k_retest_held)
     const bool hold = phase == 1 && p->holdThisFrame;
@@ -1504,6 +1673,31 @@ int launch_raster(brmi_pass* p, uint32_t phase, hipStream_t s) {
         if (!direct2) hipLaunchKernelGGL(k_raster_overflow<true>, ogrid, dim3(256), 0, s, a);
         if (!direct2 && !(p->rasterDebug & 4)) hipLaunchKernelGGL(k_raster_bins<true>, bgrid, dim3(BRMI_BIN_THREADS), 0, s, a);
     } else {
+        // round 6: the lean form for frames of very many clusters (k_raster<false, true>), the general launch behind it for what it leaves.  Decided from what the host last
+        // saw of such launches (host-mapped words 8 / 9: the main launch's cluster count, the general launch's; a frame or two old -- either way the same keys).
+        volatile uint32_t* fb = p->phase2FeedbackHost;
+        bool lean = false;
+        if (phase == 1 && fb && p->leanMinClusters != 0u && p->stripes.count <= 1u) {
+            const uint32_t lastCount = fb[8], lastGeneral = fb[9];
+            if (p->leanActive) {
+                if (lastCount < p->leanMinClusters) p->leanActive = false;
+                else if ((uint64_t)lastGeneral * 100u > (uint64_t)lastCount * p->leanMaxGeneralPct) { p->leanActive = false; p->leanRetryIn = 64u; }
+            } else if (p->leanRetryIn != 0u) p->leanRetryIn--;
+            else if (lastCount >= p->leanMinClusters) { p->leanActive = true; fb[9] = 0u; }
+            lean = p->leanActive;
+            a.countFeedback = p->phase2FeedbackDev + 8;
+        }
+        if (phase == 1) p->leanLastLaunch = lean;
+        if (lean) {
+            a.generalList = p->wsPtr<uint32_t>(p->ws.generalList); a.generalCounter = CNT_GENERAL1; a.generalFeedback = p->phase2FeedbackDev + 9;
+            a.bigQueue = p->wsPtr<WideTri>(p->ws.bigQueue); a.bigRuns = p->wsPtr<uint2>(p->ws.bigRuns); a.bigCapacity = p->leanQueue / 64u; a.bigCounter = CNT_BIG1;
+            hipLaunchKernelGGL((k_raster<false, true>), dim3(p->leanGrid), dim3(64), 0, s, a);
+            hipLaunchKernelGGL(k_raster_emit, dim3(p->leanEmitGrid), dim3(64), a.tableCells * 4u, s, a);
+            RasterArgs g = a;
+            g.drawList = a.generalList; g.firstCounter = 0xFFFFFFFFu; g.countCounter = CNT_GENERAL1; g.countFeedback = p->phase2FeedbackDev + 9;
+            const dim3 ggrid(std::min(p->rasterGrid, std::max(128u, pow2_at_least(std::min((uint32_t)fb[9], 1u << 20) * 16u))));
+            hipLaunchKernelGGL(k_raster<false>, ggrid, dim3(64), g.tableCells * 4u, s, g);
+        } else
         hipLaunchKernelGGL(k_raster<false>, rgrid, dim3(64), a.tableCells * 4u, s, a);
         if (!direct2 && wideOn) hipLaunchKernelGGL(k_raster_wide<false>, wgrid, dim3(64), 0, s, a);
         if (!direct2) {

@@ -189,6 +189,13 @@ class VisibilityRenderer:
         self._check(self.lib.brmi_debug_read_held(self._h, held.ctypes.data_as(C.POINTER(capi.u32)), len(held), C.byref(nh), late.ctypes.data_as(C.POINTER(capi.u32)), len(late), C.byref(nl)), "brmi_debug_read_held")
         return held[: nh.value], late[: nl.value]
 
+    def lean_clusters(self):
+        """(1 if the last frame's phase-1 main launch was the lean rasteriser, clusters it left to the general launch, triangles queued for k_raster_emit, runs of
+        them) -- brmi_debug_lean_clusters."""
+        out = (capi.u32 * 4)()
+        self._check(self.lib.brmi_debug_lean_clusters(self._h, out), "brmi_debug_lean_clusters")
+        return tuple(int(v) for v in out)
+
     def wide_triangles(self):
         """(phase-1 draw pass, late pass, phase 2) counts of the last frame's triangles queued for the workgroup-wide record emission (brmi_debug_wide_triangles)."""
         out = (capi.u32 * 3)()

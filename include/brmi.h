@@ -274,6 +274,14 @@ int brmi_debug_arith(const float* a, const float* b, float* outDiv, float* outSq
  * emission pass (k_raster_wide): phase 1's draw pass, its late pass, phase 2.  Counted whether or not the pass was launched (the host launches it while the frames
  * before had such triangles).  Waits for the device. */
 int brmi_debug_wide_triangles(brmi_pass* pass, uint32_t out[3]);
+/* Round 6, the lean rasteriser: out[0] = 1 when the last frame's phase-1 main launch was the lean form of k_raster (frames of very many clusters;
+ * BRMI_TUNING lean_min_clusters), out[1] = how many of its clusters it left to the general launch behind it (skinned vertices, a full triangle queue), out[2] / out[3] =
+ * triangles it queued for k_raster_emit (large enough for the bins) and the runs they were queued in (one per wave and pass; requested, so beyond a full queue's
+ * capacity).  Waits for the device. */
+int brmi_debug_lean_clusters(brmi_pass* pass, uint32_t out[4]);
+/* One of the 64 stripes of that queue as the last frame left it: counts = {entries, runs} (clamped to the stripe's capacity); runs = {first entry, count} pairs,
+ * entries = 96 B records (brmi_raster.hip, WideTri: a 64 B bin record of the triangle's first row, then yHi, band0, band1, strip0, strip1).  Either buffer may be null. */
+int brmi_debug_read_lean_queue(brmi_pass* pass, uint32_t stripe, uint32_t* runs, uint32_t maxRuns, void* entries, uint32_t maxEntries, uint32_t counts[2]);
 
 /* The last frame's draw-list decisions, for tests (waits for the device): indices into the visible-cluster buffer of the phase-1 clusters the culling held back
  * (`held`, up to heldCapacity entries; *heldCount = how many there were) and of those the late pass drew (`late`).  held minus late was never rasterised. */

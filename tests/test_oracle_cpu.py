@@ -1542,7 +1542,7 @@ def test_kernels_of_the_benchmarked_frames_use_no_scratch_memory():
     assert len(rows) > 40, out[:500]
     launched = ["k_frame_constants", "k_cull_hierarchy<false, 256u, 128u, true>", "k_cull_hierarchy<false, 1024u, 128u, true>", "k_cull_hierarchy<true, 256u, 128u, false>",
                 "k_cull_hierarchy<true, 1024u, 128u, false>", "k_cull_flat_wide", "k_cull_clusters<1>", "k_cull_clusters<2>", "k_cull_hierarchy<false, 256u, 128u, false>", "k_cull_hierarchy<false, 1024u, 128u, false>", "k_lc_count", "k_lc_fill", "k_scan_chained", "k_scatter_visible<false, false>", "k_scatter_visible<true, false>",
-                "k_raster<false>", "k_raster<true>", "k_raster_overflow<false, 256u>", "k_raster_overflow<false, 1024u>", "k_raster_overflow<true, 256u>", "k_raster_bins<false>", "k_raster_bins<true>", "k_hzb_head<true>", "k_hzb_tail",
+                "k_raster<false, false>", "k_raster<false, true>", "k_raster<true, false>", "k_raster_overflow<false, 256u>", "k_raster_overflow<false, 1024u>", "k_raster_overflow<true, 256u>", "k_raster_bins<false>", "k_raster_bins<true>", "k_hzb_head<true>", "k_hzb_tail",
                 "k_resolve_setup", "k_gbuffer<false, false, false, false, 1>", "k_gbuffer<false, true, false, false, 1>", "k_gbuffer<true, true, false, false, 0>",
                 "k_gbuffer<false, false, false, false, 0>", "k_gbuffer<false, true, false, false, 0>", "k_shade<0, 3>", "k_shade<0, 5>", "k_traverse",
                 # the Zorah-class and the dense frame (configs[4], `dense`): the level-synchronous traversal, the three-launch ranking, the in-place G-buffer kernel

@@ -1321,6 +1321,41 @@ def test_triangles_of_very_many_bins_take_the_wide_pass_with_the_same_keys(prese
     assert queued > 0, "the view has no triangle that takes the wide pass"
 
 
+@pytest.mark.parametrize("preset,kw,size,step", [("bistro", dict(), (3840, 2160), 0), ("bistro", dict(), (3840, 2160), 20), ("bistro", dict(skinned_fraction=0.3), (1920, 1080), 0),
+                                                 ("bistro", dict(size_scale=20.0, detail=96.0), (1920, 1080), 0)])
+def test_lean_rasteriser_and_the_general_launch_behind_it_leave_the_same_keys(preset, kw, size, step):
+    """Round 6: frames of very many clusters run phase 1's main launch as the lean form of k_raster (no record emission, no skinning: six waves per SIMD instead of three).
+    Its triangles large enough for the bins go to a queue and k_raster_emit writes their records; a cluster with skinned vertices -- or one whose triangles found the
+    queue full -- goes to a list and a general launch behind draws it whole.  Forced on for small frames (lean_min_clusters=1, never backed off): the keys and lists are
+    those of the general kernel alone (lean_min_clusters=0); the same with a queue of 64 triangles (most clusters with a binned triangle then take the general launch)
+    without the draw list (hold_clusters=0: the launch walks the visible list in order), and with the wide pass taking the emission's triangles from three bin entries on (lean_wide_entries=2)."""
+    import torch
+    from conftest import Scene
+    from basicrenderer_amd.renderer import VisibilityRenderer
+    sc = Scene(preset, size[0], size[1], point_lights=8, camera_step=step, **kw)
+    ref = None
+    on_ = dict(lean_min_clusters=1, lean_max_general_pct=100)
+    for tun in (dict(lean_min_clusters=0), on_, dict(on_, lean_queue=64), dict(on_, hold_clusters=0), dict(on_, wide_min_triangles=1, wide_entries=16, lean_wide_entries=2)):
+        with _Env(**tun):
+            r = VisibilityRenderer(sc, occlusion=True)
+        for _ in range(4):
+            r.update(); r.execute()
+            torch.cuda.synchronize()      # (the launch's counts have reached the host before the next frame chooses)
+        vis, lists = r.visibility(), r.visible_clusters()
+        on, general, queued, runs = r.lean_clusters()
+        if ref is None:
+            ref = (vis, lists)
+            assert on == 0
+        else:
+            assert on == 1, tun
+            assert np.array_equal(vis, ref[0]), tun
+            assert np.array_equal(lists, ref[1]), tun
+            if "lean_queue" in tun: assert general > 0, "a queue of 64 triangles did not overflow"
+            elif "skinned_fraction" in kw: assert general > 0, "no skinned cluster was left to the general launch"
+            elif len(tun) == 2: assert general == 0, general
+        r.close()
+
+
 def test_draw_list_is_off_where_it_cannot_be_exact_yet():
     """The re-test reads the chain in FRAME rows; passes that render the interleaved chunks of a frame into compact surfaces keep the whole list (so does any pass with
     hold_clusters=0).  A contiguous band lives in frame rows and holds clusters back (test_full_size_balanced_regions_against_the_oracle)."""

@@ -3,5 +3,5 @@
 set -e
 NAME=$1; shift
 mkdir -p scratch/variants
-make -s hip EXTRA="$*" LIBDIR=scratch/variants/$NAME >/dev/null
+make -s -j8 hip EXTRA="$*" LIBDIR=scratch/variants/$NAME OBJDIR=build/variants/$NAME >/dev/null
 echo scratch/variants/$NAME/libbrmi.so
