@@ -138,6 +138,10 @@ def main():
     ap.add_argument("--cpu-scale-1thread", type=float, default=0.25,
                     help="fraction of the frame height the single-thread CPU baseline renders (BASELINE.md 4(a): 1 thread and all cores; culling covers the whole frame either way)")
     ap.add_argument("--legs", default="weak,strong", help="N > 1: which legs to run (weak, strong, or both)")
+    ap.add_argument("--shared-gpu", action="store_true",
+                    help="N > 1, checks only: all N ranks render on cuda:0 of a one-GPU box -- torch.distributed over gloo (CPU tensors), the peer-write composer between the "
+                         "processes (RCCL refuses two ranks on one device).  Runs the whole N-rank control flow of this file (balancing rounds, composition, the reductions, "
+                         "the line); its numbers are N processes sharing one GPU, not an N-GPU measurement, and the line says so")
     args = ap.parse_args()
     if args.gpus < 1:
         fail_line(args, "--gpus must be >= 1")
@@ -164,22 +168,31 @@ def main():
 
     import torch
     import torch.distributed as dist
-    if torch.cuda.device_count() < args.gpus:
+    if torch.cuda.device_count() < args.gpus and not args.shared_gpu:
         fail_line(args, f"--gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.shared_gpu:
+        local_rank = 0
+        if args.composer == "native":
+            args.composer = "peer"
     if world > 1 or args.force_compose:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        if args.shared_gpu:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
     assert world == args.gpus
     torch.cuda.set_device(local_rank)
 
     if world > 1:
         out = multi_gpu_legs(args, world, rank, local_rank, emulated=False)
+        if out is not None and args.shared_gpu:
+            out["shared_gpu"] = f"all {world} ranks rendered on ONE GPU (gloo + the peer-write composer between the processes): a check of the N-rank control flow, not an N-GPU measurement"
     else:
         out = measure(args, args.workload, world, rank, local_rank, cpu=(world == 1 and not args.no_cpu_baseline))
     if world == 1 and not args.no_second and args.workload != "sponza":
@@ -266,6 +279,7 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False,
     from basicrenderer_amd import Scene, compose
     from basicrenderer_amd.renderer import VisibilityRenderer
     dev = torch.device(f"cuda:{local_rank}")
+    cdev = torch.device("cpu") if args.shared_gpu else dev      # where the tensors of the process group's collectives live (gloo: host memory)
     lights = LIGHTS[workload]
     preset, scene_kw, default_features = WORKLOADS[workload]
     scene_kw = dict(scene_kw)
@@ -354,7 +368,7 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False,
 
             def agree(flag):
                 if multi:
-                    t = torch.tensor([flag], device=dev, dtype=torch.int32)
+                    t = torch.tensor([flag], device=cdev, dtype=torch.int32)
                     dist.all_reduce(t, op=dist.ReduceOp.MAX)
                     return int(t.item())
                 return flag
@@ -362,7 +376,8 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False,
             if not failed:
                 try:
                     composer = (compose.PeerBandComposer if args.composer == "peer" else compose.NativeBandComposer)(hdr, band, W, 8, transport=args.transport, **(dict(rank=0, world=1) if emulated else {}),
-                                                                                                                      **(dict(frame_height=H) if balanced else {}))
+                                                                                                                      **(dict(frame_height=H) if balanced else {}),
+                                                                                                                      **(dict(timeout_ms=int(os.environ.get("BRMI_BENCH_PEER_TIMEOUT_MS", "30000"))) if args.shared_gpu and args.composer == "peer" else {}))
                     if balanced and not emulated:
                         composer.set_bounds(balancer.bounds)
                 except Exception as e:      # noqa: BLE001
@@ -430,7 +445,7 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False,
             for _ in range(args.balance_frames):
                 step()
             torch.cuda.synchronize()
-            mine = torch.tensor([(time.perf_counter() - t0) / args.balance_frames * 1e3], dtype=torch.float64, device=dev)
+            mine = torch.tensor([(time.perf_counter() - t0) / args.balance_frames * 1e3], dtype=torch.float64, device=cdev)
             if multi:
                 every = [torch.zeros_like(mine) for _ in range(n)]
                 dist.all_gather(every, mine)
@@ -481,7 +496,7 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False,
         if multi:
             dist.barrier()
         dt = time.perf_counter() - t0
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         own.append(float(t_done - t0))
         if multi:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -490,7 +505,7 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False,
     # every rank's own time to finish its frames (before the closing barrier), median region: how evenly the partition loads the ranks
     rank_ms = [sorted(own)[len(own) // 2] / args.steps * 1e3]
     if multi:
-        mine = torch.tensor(rank_ms, dtype=torch.float64, device=dev)
+        mine = torch.tensor(rank_ms, dtype=torch.float64, device=cdev)
         every = [torch.zeros_like(mine) for _ in range(n)]
         dist.all_gather(every, mine)
         rank_ms = [float(x.item()) for x in every]
@@ -725,6 +740,8 @@ def fail_line(args, why):
     if int(os.environ.get("RANK", "0")) == 0:
         print(json.dumps({"metric": "shaded Mpixels/s @4K (vis-buffer+resolve)", "value": None, "unit": "Mpixels/s", "n_gpus": args.gpus,
                           "steps": args.steps, "warmup": args.warmup, "error": why}), flush=True)
+    else:
+        print(f"bench.py rank {os.environ.get('RANK')}: {why}", file=sys.stderr, flush=True)      # (rank 0 owns stdout's one line)
     sys.exit(2)
 
 

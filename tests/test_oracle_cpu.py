@@ -1548,7 +1548,9 @@ def test_kernels_of_the_benchmarked_frames_use_no_scratch_memory():
                 # the Zorah-class and the dense frame (configs[4], `dense`): the level-synchronous traversal, the three-launch ranking, the in-place G-buffer kernel
                 "k_cull_flat_level<false>", "k_cull_flat_level<true>", "k_scan_reduce", "k_scan_blocks", "k_scan_words", "k_gbuffer<true, false, false, false, 1>", "k_gbuffer<true, false, false, false, 0>",
                 # ... and their draw list (round 6): the compaction with the prediction, the re-test
-                "k_scatter_visible<false, true>", "k_scatter_visible<true, true>", "k_retest_held", "k_meshlet_boxes"]
+                "k_scatter_visible<false, true>", "k_scatter_visible<true, true>", "k_retest_held", "k_meshlet_boxes",
+                # ... the wide-triangle pass, and the lean rasteriser's record emission
+                "k_raster_wide<false>", "k_raster_wide<true>", "k_raster_emit"]
     for k in launched:
         assert k in rows, (k, sorted(rows)[:80])
         assert rows[k]["vspill"] == 0 and rows[k]["scratch"] == 0, (k, rows[k])
