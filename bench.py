@@ -145,6 +145,7 @@ def main():
     args = ap.parse_args()
     if args.gpus < 1:
         fail_line(args, "--gpus must be >= 1")
+    args.workload_given = args.workload is not None
     if args.workload is None:
         args.workload = "bistro" if args.gpus == 1 else "san_miguel"
     if args.emulate_rank is not None:
@@ -233,7 +234,7 @@ def main():
 
 
 def multi_gpu_legs(args, n, rank, local_rank, emulated):
-    """--gpus N > 1 (BASELINE.json configs[3]).  Two legs under one clock, and the one-GPU frame each of them is measured against, made inside the same job:
+    """--gpus N > 1.  Legs under one clock, and the one-GPU frame each of them is measured against, made inside the same job (which scenes: `plan` below):
       weak    every rank shades one 4K frame's worth of pixels: the frame is 7680 x 1088 N, interleaved partition in chunks of --stripe-rows rows; the
               reference is the scene's 3840 x 2160 frame on one GPU (rank 0's; every rank renders it, each on its own GPU)
       strong  THE 4K frame (3840 x 2176: 2160 rows padded to a multiple of 16 N) split N ways in chunks of 128 / N rows; the reference is that frame on one GPU
@@ -241,9 +242,12 @@ def multi_gpu_legs(args, n, rank, local_rank, emulated):
     (`scaling`: weak -- what the north star's 0.9 is stated on)."""
     from basicrenderer_amd import compose
     legs = [x for x in args.legs.split(",") if x in ("weak", "strong")] or ["weak"]
-    wl = args.workload
+    # Round 6: without --workload the line's own value is the HEADLINE scene's weak leg -- `bench.py --gpus 1` reports that scene (configs[2]), so value(N) / N / value(1) across
+    # the driver's runs compares one scene with itself -- and configs[3]'s scene (San-Miguel-class, what BASELINE.json names for the partition) runs both legs beside it, under
+    # `configs3_weak` / `configs3_strong`, each with its own one-GPU reference.  With --workload: that scene's legs, `weak` / `strong`, as before.
+    plan = [(leg, leg, args.workload) for leg in legs] if args.workload_given else [("weak", "weak", "bistro")] + [("configs3_" + leg, leg, "san_miguel") for leg in legs]
     result = {}
-    for leg in legs:
+    for key, leg, wl in plan:
         if leg == "weak":
             part = args.partition if args.partition != "auto" else "balanced"
             frame, rows = compose.frame_size(n, "bands" if part == "bands" else "stripes"), args.stripe_rows
@@ -259,14 +263,15 @@ def multi_gpu_legs(args, n, rank, local_rank, emulated):
             entry = {k: got[k] for k in keep if k in got}
             entry["n1_reference"] = {"value": ref["value"], "ms_per_step": ref["ms_per_step"], "frame": list(ref_frame), "pixels": ref_frame[0] * ref_frame[1]}
             entry["efficiency_vs_n1"] = round(got["value"] / n / ref["value"], 4)
-            result[leg] = (got, entry)
+            entry["leg"] = leg
+            result[key] = (got, entry)
     if not result:
         return None
-    first = "weak" if "weak" in result else legs[0]
+    first = plan[0][0]
     out = result[first][0]
-    out["scaling"] = first
-    for leg, (_, entry) in result.items():
-        out[leg] = entry
+    out["scaling"] = plan[0][1]
+    for key, (_, entry) in result.items():
+        out[key] = entry
     return out
 
 

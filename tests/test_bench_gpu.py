@@ -36,6 +36,7 @@ def test_bench_runs_its_two_rank_flow_on_one_gpu():
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["warmup"] == 3 and out["higher_is_better"] is True and out["scaling"] == "weak"
     assert out["metric"].startswith("shaded Mpixels/s") and out["unit"] == "Mpixels/s" and out["value"] > 0 and out["ms_per_step"] > 0
     assert "shared_gpu" in out
-    for leg in ("weak", "strong"):
+    assert out["config"]["baseline_config"].startswith("configs[2]")      # the line's own value: the headline scene, weak-scaled
+    for leg in ("weak", "configs3_weak", "configs3_strong"):
         assert out[leg]["rank_ms_per_step"]["ranks"] == 2 and out[leg]["value"] > 0 and out[leg]["n1_reference"]["value"] > 0 and 0 < out[leg]["efficiency_vs_n1"]
     assert out["config"]["partition"].startswith("cost-balanced contiguous bands")
