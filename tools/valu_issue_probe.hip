@@ -18,7 +18,7 @@
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
-enum Op { OP_FMA = 0, OP_RCP = 1, OP_MIX = 2, OP_CNDMASK = 3, OP_MOV = 4, OP_CNDMASK_SGPR = 5, OP_EXP = 6, OP_SQRT = 7, OP_MED3 = 8, OP_MUL = 9 };
+enum Op { OP_FMA = 0, OP_RCP = 1, OP_MIX = 2, OP_CNDMASK = 3, OP_MOV = 4, OP_CNDMASK_SGPR = 5, OP_EXP = 6, OP_SQRT = 7, OP_MED3 = 8, OP_MUL = 9, OP_PK_FMA = 10, OP_PK_MUL = 11, OP_PK_ADD = 12 };
 
 #define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 #define FMA(i) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(x), "v"(y));
@@ -30,12 +30,19 @@ enum Op { OP_FMA = 0, OP_RCP = 1, OP_MIX = 2, OP_CNDMASK = 3, OP_MOV = 4, OP_CND
 #define SQR(i) asm volatile("v_sqrt_f32 %0, %0" : "+v"(a[i]));
 #define MED(i) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(x), "v"(y));
 #define MUL(i) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(y));
+// round 6: the packed forms (two f32 operations per lane and instruction; operands are aligned register pairs).  Four independent accumulator pairs, eight instructions per REP8.
+#define PKF(i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p[(i) & 3]) : "v"(px), "v"(py));
+#define PKM(i) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[(i) & 3]) : "v"(py));
+#define PKA(i) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[(i) & 3]) : "v"(py));
 
 template <int OP>
 __global__ void __launch_bounds__(1024) k_probe(float* out, unsigned long long* stamps, int trips, float x, float y) {
     extern __shared__ float pad[];
     float a[8];
     for (int i = 0; i < 8; i++) a[i] = x + (float)(threadIdx.x + i);
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f p[4], px = {x, x}, py = {y, y};
+    for (int i = 0; i < 4; i++) p[i] = v2f{a[2 * i], a[2 * i + 1]};
     if (threadIdx.x == 9999) pad[0] = x;
     const unsigned long long mask = 0x5555555555555555ull ^ (unsigned long long)trips;      // an SGPR pair
     if (OP == OP_CNDMASK) asm volatile("v_cmp_gt_f32 vcc, %0, %1" : : "v"(a[0]), "v"(y) : "vcc");      // vcc written once, before the loop
@@ -53,11 +60,15 @@ __global__ void __launch_bounds__(1024) k_probe(float* out, unsigned long long* 
             else if (OP == OP_SQRT) { REP8(SQR) }
             else if (OP == OP_MED3) { REP8(MED) }
             else if (OP == OP_MUL) { REP8(MUL) }
+            else if (OP == OP_PK_FMA) { REP8(PKF) }
+            else if (OP == OP_PK_MUL) { REP8(PKM) }
+            else if (OP == OP_PK_ADD) { REP8(PKA) }
             else { FMA(0) FMA(1) FMA(2) RCP(3) FMA(4) FMA(5) FMA(6) RCP(7) }      // three full-rate instructions per transcendental
         }
     }
     const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     float s = 0; for (int i = 0; i < 8; i++) s += a[i];
+    for (int i = 0; i < 4; i++) s += p[i].x + p[i].y;
     if (s == 1234.5f) out[0] = s;
     if ((threadIdx.x & 63) == 0) {
         const size_t w = (size_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
@@ -106,6 +117,9 @@ int main() {
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_probe<OP_CNDMASK_SGPR>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_probe<OP_EXP>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_probe<OP_SQRT>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_probe<OP_PK_FMA>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_probe<OP_PK_MUL>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_probe<OP_PK_ADD>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
     const int trips = 4000;      // ~1 M instructions per wave: 1-4 ms per launch
     if (run<OP_FMA>("v_fma_f32", cus, trips, out, stamps)) return 1;
     if (run<OP_RCP>("v_rcp_f32", cus, trips, out, stamps)) return 1;
@@ -117,5 +131,8 @@ int main() {
     if (run<OP_CNDMASK_SGPR>("v_cndmask_b32 (sgpr)", cus, trips, out, stamps)) return 1;
     if (run<OP_EXP>("v_exp_f32", cus, trips, out, stamps)) return 1;
     if (run<OP_SQRT>("v_sqrt_f32", cus, trips, out, stamps)) return 1;
+    if (run<OP_PK_FMA>("v_pk_fma_f32", cus, trips, out, stamps)) return 1;
+    if (run<OP_PK_MUL>("v_pk_mul_f32", cus, trips, out, stamps)) return 1;
+    if (run<OP_PK_ADD>("v_pk_add_f32", cus, trips, out, stamps)) return 1;
     return 0;
 }
