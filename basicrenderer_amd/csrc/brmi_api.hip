@@ -569,6 +569,7 @@ int brmi_set_scene(brmi_pass* p, const brmi_scene_buffers* scene) {
         p->holdMinClusters = (uint32_t)std::max(0l, tuning("hold_min_clusters", p->holdMinClusters));
         p->lateDirectMax = (uint32_t)std::max(0l, tuning("late_direct_max", p->lateDirectMax));
         p->holdStillMax = (uint32_t)std::max(0l, tuning("hold_still_max", p->holdStillMax));
+        p->holdFloor = (uint32_t)std::max(0l, tuning("hold_floor", p->holdFloor));
         p->holdMaxTexels = (uint32_t)std::min(16l, std::max(1l, tuning("hold_max_texels", p->holdMaxTexels)));
         p->retestMaxTexels = (uint32_t)std::min(16l, std::max(1l, tuning("retest_max_texels", p->retestMaxTexels)));
     }

@@ -266,6 +266,7 @@ struct brmi_pass {
                                      // pass and the chain's second look cost what the rasteriser saves (Bistro-class, 10 k clusters: +25 us; profiles/r06_experiments.md)
     uint32_t lateDirectMax = 128;    // the late pass walks every triangle directly (no records, plan, bins) while the last known late count is at most this (BRMI_TUNING late_direct_max;
                                      // 1024: the fast camera path's raster stage 0.338 -> 0.466 ms -- late clusters are the ones a moving view uncovers, near and large)
+    uint32_t holdFloor = 512;        // ... and at least this many clusters were visible (hold_floor)
     uint32_t holdStillMax = 8;       // frames of fewer than holdMinClusters clusters hold clusters back all the same while phase 2 of the last frame the host has seen drew fewer clusters than
                                      // this (a still camera: the prediction is then exact and the late pass empty -- Bistro-class 0.505 -> 0.4815 ms in flight, San-Miguel-class 0.824 -> 0.776,
                                      // Sponza-class unchanged, the skinned leg + 2.7 %; with the camera moving the late pass costs more than the rasteriser saves: path 0.545 -> 0.594); 0: never

@@ -1335,13 +1335,16 @@ def test_lean_rasteriser_and_the_general_launch_behind_it_leave_the_same_keys(pr
     sc = Scene(preset, size[0], size[1], point_lights=8, camera_step=step, **kw)
     ref = None
     on_ = dict(lean_min_clusters=1, lean_max_general_pct=100)
+    # (the skinned case also as a rank's row band of the frame: the queued triangle's first row is the band's, its row start stepped down to it)
+    part = dict(band=(size[1] // 4 // 16 * 16, size[1] * 3 // 4 // 16 * 16)) if "skinned_fraction" in kw else {}
     for tun in (dict(lean_min_clusters=0), on_, dict(on_, lean_queue=64), dict(on_, hold_clusters=0), dict(on_, wide_min_triangles=1, wide_entries=16, lean_wide_entries=2)):
         with _Env(**tun):
-            r = VisibilityRenderer(sc, occlusion=True)
+            r = VisibilityRenderer(sc, occlusion=True, **part)
         for _ in range(4):
             r.update(); r.execute()
             torch.cuda.synchronize()      # (the launch's counts have reached the host before the next frame chooses)
         vis, lists = r.visibility(), r.visible_clusters()
+        if part: vis = vis[part["band"][0]:part["band"][1]]
         on, general, queued, runs = r.lean_clusters()
         if ref is None:
             ref = (vis, lists)
