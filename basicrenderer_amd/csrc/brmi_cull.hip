@@ -1027,11 +1027,8 @@ __global__ void __launch_bounds__(1024) k_cull_flat_wide(CullArgs a, BucketRecor
 // before wrote; a node's children sit side by side in the breadth-first tables (FlatNode::children), so their pre-filter is eight independent
 // loads.  Appends are aggregated per workgroup (three atomics per 256 tasks).  Same tests, same arithmetic, same records as the walk; the order of
 // the bucket records differs, which the survivor ranking (a bit per (instance, segment, meshlet)) does not see.  flatMaxDepth launches.
-#ifndef BRMI_FLAT_LEVEL_WAVES
-#define BRMI_FLAT_LEVEL_WAVES 1
-#endif
 template <bool FIRST>
-__global__ void __launch_bounds__(256, BRMI_FLAT_LEVEL_WAVES) k_cull_flat_level(CullArgs a, uint32_t level, const NodeRecord* in, NodeRecord* out, BucketRecord* buckets) {
+__global__ void __launch_bounds__(256) k_cull_flat_level(CullArgs a, uint32_t level, const NodeRecord* in, NodeRecord* out, BucketRecord* buckets) {
     wave_prio<PRIO_CULL>();
     __shared__ uint32_t waveTot[3][4], bases[3];
     const brmi_scene_buffers& sc = a.sc;
@@ -1212,11 +1209,8 @@ struct LcRide { uint32_t mainBlocks; ClusterArgs lc; };
 // (kernel trace), on the chain the next frame waits for.  This kernel's waves fit the gap (<= 104 registers), and the light clustering of a split
 // frame runs on the shading stream (brmi_execute_split).
 struct ClearRide { uint32_t mainBlocks; ulonglong2* vis2; uint64_t n2; uint32_t clearBlocks; };
-#ifndef BRMI_CULL_CLUSTERS_WAVES
-#define BRMI_CULL_CLUSTERS_WAVES 1
-#endif
 template <int SIDE>
-__global__ void __launch_bounds__(256, BRMI_CULL_CLUSTERS_WAVES) k_cull_clusters(CullArgs a, const BucketRecord* buckets, TempVisible* temp, uint32_t* bitmask, uint8_t* blockDirty,
+__global__ void __launch_bounds__(256) k_cull_clusters(CullArgs a, const BucketRecord* buckets, TempVisible* temp, uint32_t* bitmask, uint8_t* blockDirty,
                                                        typename std::conditional<SIDE == 1, LcRide, typename std::conditional<SIDE == 2, ClearRide, NoSide>::type>::type ride) {
     wave_prio<PRIO_CULL>();
     uint32_t mainBlocks = gridDim.x;
