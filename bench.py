@@ -559,7 +559,7 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False,
             # the stage's kernels; template instantiations ("k_shade<0>", "k_raster<true>") are matched by base name.  A one-kernel stage reports
             # the instantiation that takes the most time per launch; the raster stage is three kernels launched once per occlusion phase, and
             # its traffic is their sum over the frame's launches (the committed averages are per launch, over both phases' launches)
-            stage_kernels = {"raster": ["k_raster", "k_raster_bins", "k_raster_overflow"]}.get(dom, [DOMINANT_KERNEL.get(dom, dom).split("<")[0]])
+            stage_kernels = {"raster": ["k_raster", "k_raster_emit", "k_raster_wide", "k_raster_bins", "k_raster_overflow"]}.get(dom, [DOMINANT_KERNEL.get(dom, dom).split("<")[0]])
             traffic_sum, wi, found = 0, 0, False
             for base in stage_kernels:
                 # (instantiations the steady state launches: a variant the first frames of a run took -- the in-place G-buffer kernel while the pass had no depth chain to cull against --
@@ -611,7 +611,7 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False,
             "roofline": {"bound": nearer, "bound_note": "the ceiling the kernel sits nearer to: VALU issue (roofline.valu.frac, SQ_INSTS_VALU of the committed profile) or HBM (frac / frac_traffic); "
                                                         "achieved / peak / unit / frac are the HBM figures of SURVEY.md 8(d) either way",
                          "kernel_stage": dom, "longest_stage_this_run": longest_stage, "kernel_stage_is_longest_stage": bool(dom == longest_stage),
-                         "kernel": {"raster": "k_raster + k_raster_bins (+ k_raster_overflow), both occlusion phases"}.get(dom, DOMINANT_KERNEL.get(dom, dom)), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "kernel": {"raster": "k_raster (+ k_raster_emit, k_raster_wide) + k_raster_bins (+ k_raster_overflow), both occlusion phases"}.get(dom, DOMINANT_KERNEL.get(dom, dom)), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(hbm_frac, 5), "traffic": traffic, "frac_traffic": frac_traffic, "valu": valu,
                          "algorithmic_bytes_per_launch": int(per_stage_bytes[dom]), "algorithmic_bytes_launched_variant": int(launched_bytes[dom]), "frac_launched_variant": frac_launched,
                          "launch_ms": round(stage_ms[dom], 4),
