@@ -1346,13 +1346,23 @@ def test_lean_rasteriser_and_the_general_launch_behind_it_leave_the_same_keys(pr
         vis, lists = r.visibility(), r.visible_clusters()
         if part: vis = vis[part["band"][0]:part["band"][1]]
         on, general, queued, runs = r.lean_clusters()
+        moved = []
+        if step == 0 and not part and len(tun) <= 2:
+            # ... and along the camera path, a new camera every frame: last frame's queue entries, runs and general list are not this frame's
+            for k in range(1, 4):
+                cam, cull = sc.camera_at(0.1 * k, 0.1 * (k - 1))
+                r.set_camera_device(torch.from_numpy(cam).cuda(), torch.from_numpy(cull).cuda(), cam, frame_index=4 + k)
+                r.execute(); torch.cuda.synchronize()
+                moved.append((r.visibility(), r.visible_clusters()))
         if ref is None:
-            ref = (vis, lists)
+            ref = (vis, lists, moved)
             assert on == 0
         else:
             assert on == 1, tun
             assert np.array_equal(vis, ref[0]), tun
             assert np.array_equal(lists, ref[1]), tun
+            for k, (mv, ml) in enumerate(moved):
+                assert np.array_equal(mv, ref[2][k][0]) and np.array_equal(ml, ref[2][k][1]), (tun, "moving frame", k)
             if "lean_queue" in tun: assert general > 0, "a queue of 64 triangles did not overflow"
             elif "skinned_fraction" in kw: assert general > 0, "no skinned cluster was left to the general launch"
             elif len(tun) == 2: assert general == 0, general
