@@ -279,6 +279,7 @@ int brmi_create(const brmi_config* cfg, brmi_pass** out) {
     p->wideCapacity = (uint32_t)std::min(1l << 20, std::max(0l, tuning("wide_capacity", p->wideCapacity)));
     p->wideMinTriangles = (uint32_t)std::max(0l, tuning("wide_min_triangles", p->wideMinTriangles));
     p->leanMinClusters = (uint32_t)std::max(0l, tuning("lean_min_clusters", p->leanMinClusters));
+    if (p->leanMinClusters > cfg->maxVisibleClusters) p->leanMinClusters = 0u;      // a pass whose list cannot get that long never runs the lean rasteriser: no queue in its workspace (104 MB)
     p->leanMaxGeneralPct = (uint32_t)std::max(0l, std::min(100l, tuning("lean_max_general_pct", p->leanMaxGeneralPct)));
     p->leanGrid = (uint32_t)std::max(64l, tuning("lean_grid", p->leanGrid));
     p->leanQueue = (uint32_t)std::max(64l, std::min(1l << 24, tuning("lean_queue", p->leanQueue))) & ~63u;      // (64 stripes)
