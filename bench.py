@@ -177,7 +177,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.shared_gpu:
         local_rank = 0
-        if args.composer == "native":
+        if args.composer == "native" and not os.environ.get("BRMI_BENCH_KEEP_COMPOSER"):      # (kept: RCCL refuses the second rank of a device and the run shows its fall-back to peer writes)
             args.composer = "peer"
     if world > 1 or args.force_compose:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -353,6 +353,7 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False,
     hdr = r.hdr_tensor()
     # all-gather of frame k overlaps the rendering of frame k + 1; the colour channels travel (RGB16F, 6 B/px): the lit target's alpha is constant
     composer, composer_used = None, args.composer
+    balance_frozen = False
     if multi or (args.force_compose and not solo):
         composer_used = args.composer
         if args.composer in ("native", "peer"):
@@ -378,23 +379,34 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False,
                     return int(t.item())
                 return flag
             failed = agree(failed)
-            if not failed:
+            # (round 6: the RCCL composer has never run with more than one rank on this pool -- RCCL refuses two ranks on one device -- so a failure of it on the driver's
+            # 8-GPU node must not cost the run: the peer-write composer is tried next, and then torch.distributed's all-gather of EQUAL bands, the balancing rounds skipped)
+            kinds = [args.composer] + (["peer"] if args.composer == "native" and multi else [])
+            whys = [why] if why else []
+            for kind in ([] if failed else kinds):
+                failed = 0
                 try:
-                    composer = (compose.PeerBandComposer if args.composer == "peer" else compose.NativeBandComposer)(hdr, band, W, 8, transport=args.transport, **(dict(rank=0, world=1) if emulated else {}),
-                                                                                                                      **(dict(frame_height=H) if balanced else {}),
-                                                                                                                      **(dict(timeout_ms=int(os.environ.get("BRMI_BENCH_PEER_TIMEOUT_MS", "30000"))) if args.shared_gpu and args.composer == "peer" else {}))
+                    composer = (compose.PeerBandComposer if kind == "peer" else compose.NativeBandComposer)(hdr, band, W, 8, transport=args.transport, **(dict(rank=0, world=1) if emulated else {}),
+                                                                                                             **(dict(frame_height=H) if balanced else {}),
+                                                                                                             **(dict(timeout_ms=int(os.environ.get("BRMI_BENCH_PEER_TIMEOUT_MS", "30000"))) if args.shared_gpu and kind == "peer" else {}))
                     if balanced and not emulated:
                         composer.set_bounds(balancer.bounds)
                 except Exception as e:      # noqa: BLE001
-                    failed, why = 1, f"{type(e).__name__}: {e}"
+                    failed = 1; whys.append(f"{kind}: {type(e).__name__}: {e}")
                 failed = agree(failed)
-            if failed and balanced:
-                fail_line(args, f"--partition balanced needs libbrmi_compose.so's composer (bands of unequal height): {why or 'it failed on another rank'}")
-            if failed:
+                if not failed:
+                    composer_used = kind if kind == args.composer else f"{kind} ({args.composer} composer failed" + (f": {whys[-1]}" if whys else " on another rank") + ")"
+                    break
                 if composer is not None:
                     composer.close()
+                    composer = None
+            if failed:
+                why = "; ".join(whys) or "it failed on another rank"
+                print(f"bench.py rank {rank}: libbrmi_compose.so's composers failed ({why}); torch.distributed all-gather of equal bands instead", file=sys.stderr, flush=True)
+                if balanced:
+                    balance_frozen = True      # equal bands: the all-gather needs equal shares (the balancer's first bounds are the equal split)
                 composer = compose.BandComposer(hdr, band, W, 8, transport=args.transport)
-                composer_used = "torch (" + args.composer + " composer failed" + (f": {why}" if why else " on another rank") + ")"
+                composer_used = "torch (" + args.composer + " composer failed: " + why + ")"
         elif balanced:
             fail_line(args, "--partition balanced composes bands of unequal height: --composer native or peer")
         else:
@@ -432,7 +444,7 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False,
     for _ in range(args.warmup):
         step()
     balance_log = None
-    if balanced and not args.bounds:
+    if balanced and not args.bounds and not balance_frozen:
         # The partition finds its bounds before the clock starts: a round = --balance-frames frames of every rank's current band WITHOUT the composition (a rank's own
         # time, not its wait for the others), the times all-gathered, brmi_compose_balance_rows on every rank (same numbers, same bounds), brmi_set_band on the ring's
         # passes and brmi_compose_set_bounds.  Then the bounds stay (a renderer would repeat a round every second or so).
@@ -606,7 +618,7 @@ def measure(args, workload, n, rank, local_rank, cpu, path=True, emulated=False,
                        "fps": round(1e3 / ms_per_step, 1),
                        "pixels_per_gpu": W * (band[1] - band[0]), "visible_clusters_rank0": int(c.visibleClusters),
                        "occlusion_culling": bool(args.occlusion), "visible_clusters_phase2_rank0": int(c.visibleClustersPhase2),
-                       "meshlets_tested_rank0": int(c.meshletsTested), "partition": (f"interleaved chunks of {stripe_rows} rows x{n}" if striped else (f"cost-balanced contiguous bands x{n}" if balanced else f"row bands x{n}")) if n > 1 else "single GPU",
+                       "meshlets_tested_rank0": int(c.meshletsTested), "partition": (f"interleaved chunks of {stripe_rows} rows x{n}" if striped else ((f"cost-balanced contiguous bands x{n}" + (" (left at the equal split: composer fallback)" if balance_frozen else "")) if balanced else f"row bands x{n}")) if n > 1 else "single GPU",
                        "frames_in_flight": fif},
             "roofline": {"bound": nearer, "bound_note": "the ceiling the kernel sits nearer to: VALU issue (roofline.valu.frac, SQ_INSTS_VALU of the committed profile) or HBM (frac / frac_traffic); "
                                                         "achieved / peak / unit / frac are the HBM figures of SURVEY.md 8(d) either way",

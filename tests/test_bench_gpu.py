@@ -40,3 +40,27 @@ def test_bench_runs_its_two_rank_flow_on_one_gpu():
     for leg in ("weak", "configs3_weak", "configs3_strong"):
         assert out[leg]["rank_ms_per_step"]["ranks"] == 2 and out[leg]["value"] > 0 and out[leg]["n1_reference"]["value"] > 0 and 0 < out[leg]["efficiency_vs_n1"]
     assert out["config"]["partition"].startswith("cost-balanced contiguous bands")
+
+
+@pytest.mark.gpu
+def test_bench_falls_back_to_peer_writes_when_rccl_refuses():
+    """The RCCL composer of the N-GPU bench has never had more than one rank on this pool.  Should it fail on the driver's node, every rank must learn so together and the run
+    must go on: here RCCL does refuse (two ranks on ONE device: 'Duplicate GPU detected'), the ranks agree, the peer-write composer takes over, and the line says what happened."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BRMI_BENCH_PEER_TIMEOUT_MS="10000", BRMI_BENCH_KEEP_COMPOSER="1")
+    for attempt in range(3):
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.join(ROOT, "bench.py"), "--gpus", "2", "--shared-gpu", "--workload", "sponza", "--legs", "weak", "--steps", "3", "--warmup", "2", "--balance-rounds", "1", "--balance-frames", "4"]
+        done = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+        text = done.stdout.decode(errors="replace")
+        if done.returncode == 0 or "a wait for a peer's band" not in text:
+            break
+    assert done.returncode == 0, text[-4000:]
+    out = json.loads([ln for ln in text.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["value"] > 0
+    assert "native composer failed" in out["config"]["workload"] and "peer" in out["config"]["workload"], out["config"]["workload"]
