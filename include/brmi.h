@@ -270,9 +270,9 @@ int brmi_algorithmic_bytes_launched(brmi_pass* pass, uint64_t* perStage /* [BRMI
  * (correctly rounded a/b and sqrt(a), round-to-nearest-even float->half) against IEEE on the host. */
 int brmi_debug_arith(const float* a, const float* b, float* outDiv, float* outSqrt, uint32_t* outHalfBits, uint32_t n, brmi_stream stream);
 
-/* Triangles of the last frame whose bin records were many enough (> 512 bins, or > 64 where a wave's bins fit no LDS window) to be queued for the workgroup-wide
- * emission pass (k_raster_wide): phase 1's draw pass, its late pass, phase 2.  Counted whether or not the pass was launched (the host launches it while the frames
- * before had such triangles).  Waits for the device. */
+/* Triangles of the last frame whose bin records were many enough (more than BRMI_TUNING wide_entries = 128 bins; 16 for the triangles the lean rasteriser queues,
+ * lean_wide_entries) to be handed to the cooperative emission pass (k_raster_wide): phase 1's draw pass, its late pass, phase 2.  Counted whether or not the pass
+ * was launched (the host launches it while the frames before had such triangles).  Waits for the device. */
 int brmi_debug_wide_triangles(brmi_pass* pass, uint32_t out[3]);
 /* Round 6, the lean rasteriser: out[0] = 1 when the last frame's phase-1 main launch was the lean form of k_raster (frames of very many clusters;
  * BRMI_TUNING lean_min_clusters), out[1] = how many of its clusters it left to the general launch behind it (skinned vertices, a full triangle queue), out[2] / out[3] =
